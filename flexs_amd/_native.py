@@ -1,0 +1,397 @@
+"""ctypes binding of libflexs_amd.so (C ABI in include/flexs_amd.h).
+
+There is deliberately NO CPU fallback: if the shared library is missing, or no
+gfx950 device is visible when an engine is needed, this module raises.  PyTorch
+is imported first only so that its bundled HIP runtime (same soname,
+libamdhip64.so.7) is the single runtime in the process -- torch tensors and
+streams can then be handed to the `_dev` entry points by raw pointer.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libflexs_amd.so")
+
+FX_OK, FX_EINVAL, FX_ESHAPE, FX_EBADCHAR, FX_ENODEV = 0, -1, -2, -3, -4
+FX_EHIP, FX_ENOMEM, FX_EUNSUPPORTED, FX_ESTATE = -5, -6, -7, -8
+FX_CNN, FX_MLP, FX_GE = 0, 1, 2
+FX_LEVENSHTEIN, FX_HAMMING = 0, 1
+
+_u8p = C.POINTER(C.c_uint8)
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); the CPU test-suite checks that every one is exported
+SIGNATURES = {
+    "fx_version": (C.c_int, []),
+    "fx_status_name": (C.c_char_p, [C.c_int]),
+    "fx_device_count": (C.c_int, []),
+    "fx_engine_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "fx_engine_destroy": (C.c_int, [_vp]),
+    "fx_engine_set_stream": (C.c_int, [_vp, _vp]),
+    "fx_engine_sync": (C.c_int, [_vp]),
+    "fx_last_error": (C.c_char_p, [_vp]),
+    "fx_engine_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
+    "fx_engine_get_option": (C.c_int, [_vp, C.c_char_p, _i64p]),
+    "fx_timer_start": (C.c_int, [_vp]),
+    "fx_timer_stop": (C.c_int, [_vp, _f32p]),
+    "fx_model_create": (C.c_int, [_vp] + [C.c_int] * 6 + [C.POINTER(_vp)]),
+    "fx_model_destroy": (C.c_int, [_vp]),
+    "fx_model_num_params": (C.c_int64, [_vp]),
+    "fx_model_set_weights": (C.c_int, [_vp, _f32p, C.c_int64]),
+    "fx_model_get_weights": (C.c_int, [_vp, _f32p, C.c_int64]),
+    "fx_score": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _vp, C.c_int64, C.c_int, _u8p, _vp, _vp]),
+    "fx_score_dev": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _vp, C.c_int64, C.c_int, _u8p, _vp, _vp]),
+    "fx_encode_onehot": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _u8p, C.c_int, _vp]),
+    "fx_encode_onehot_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _u8p, C.c_int, _vp]),
+    "fx_ensemble_reduce": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp]),
+    "fx_ensemble_reduce_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp]),
+    "fx_argmax_decode": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, _vp, _vp]),
+    "fx_min_dist": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, _vp, C.c_int64, C.c_int, _vp, _vp]),
+    "fx_cache_create": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    "fx_cache_destroy": (C.c_int, [_vp]),
+    "fx_cache_size": (C.c_int64, [_vp]),
+    "fx_cache_append": (C.c_int, [_vp, _vp, C.c_int64]),
+    "fx_cache_min_dist": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, _vp, _vp]),
+    "fx_nam_combine": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, _vp]),
+    "fx_debug_packed_size": (C.c_int64, [C.c_int] * 6),
+    "fx_debug_pack_layout": (C.c_int, [C.c_int] * 6 + [_i64p]),
+    "fx_debug_pack_weights": (C.c_int, [C.c_int] * 6 + [_f32p, C.c_int64, _f32p, C.c_int64]),
+    "fx_debug_myers": (C.c_int, [_vp, C.c_int, _vp, C.c_int]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libflexs_amd.so (fails loudly if it was never built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built. "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'` (or `make -C flexs_amd/csrc`). "
+                "flexs_amd has no CPU fallback."
+            )
+        import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first -> one HIP runtime per process)
+
+        _lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(_lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    return _lib
+
+
+def status_name(code: int) -> str:
+    return lib().fx_status_name(code).decode()
+
+
+class FxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{status_name(code)}: {msg}")
+        self.code = code
+
+
+def _raise(code: int, eng_handle=None):
+    msg = lib().fx_last_error(eng_handle).decode() if eng_handle is not None else lib().fx_last_error(None).decode()
+    # Python-side exception types follow the reference: unknown character ->
+    # ValueError (str.index, sequence_utils.py:46); shape problems -> ValueError
+    # (Keras raises ValueError on incompatible input shapes).
+    if code in (FX_EBADCHAR, FX_ESHAPE):
+        raise ValueError(msg or status_name(code))
+    raise FxError(code, msg)
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def make_lut(alphabet: str) -> np.ndarray:
+    """byte -> alphabet index (first occurrence, like str.index); 0xFF = absent."""
+    lut = np.full(256, 0xFF, np.uint8)
+    for i in range(len(alphabet) - 1, -1, -1):
+        o = ord(alphabet[i])
+        if o > 255:
+            raise ValueError("alphabet characters must be single bytes")
+        lut[o] = i
+    return lut
+
+
+def sequences_to_bytes(sequences, L: Optional[int] = None) -> np.ndarray:
+    """list/tuple/ndarray of str -> contiguous (N, L) uint8 (latin-1 code points).
+
+    Raises ValueError for ragged batches (Keras raises on a shape mismatch) and
+    for characters that do not fit one byte (cannot be in any FLEXS alphabet)."""
+    if isinstance(sequences, np.ndarray) and sequences.dtype.kind == "S":
+        a = np.ascontiguousarray(sequences)
+        N = a.shape[0]
+        w = a.dtype.itemsize
+        out = a.view(np.uint8).reshape(N, w)
+        if N and (out == 0).any():
+            raise ValueError("ragged sequence batch")
+    elif isinstance(sequences, np.ndarray) and sequences.dtype.kind == "U":
+        a = np.ascontiguousarray(sequences)
+        N = a.shape[0]
+        w = a.dtype.itemsize // 4
+        cp = a.view(np.uint32).reshape(N, w)
+        if N and (cp == 0).any():
+            raise ValueError("ragged sequence batch")
+        if N and cp.max(initial=0) > 255:
+            raise ValueError("substring not found")
+        out = cp.astype(np.uint8)
+    else:
+        seqs = list(sequences)
+        N = len(seqs)
+        if N == 0:
+            return np.zeros((0, L or 0), np.uint8)
+        w = len(seqs[0])
+        joined = "".join(seqs)
+        if len(joined) != N * w or any(len(s) != w for s in seqs):
+            raise ValueError("ragged sequence batch: all sequences must have the same length")
+        try:
+            raw = joined.encode("latin-1")
+        except UnicodeEncodeError:
+            raise ValueError("substring not found") from None
+        out = np.frombuffer(raw, dtype=np.uint8).reshape(N, w)
+    if L is not None and out.shape[0] and out.shape[1] != L:
+        raise ValueError(f"sequence length {out.shape[1]} does not match the model's seq_len {L}")
+    return out
+
+
+class Engine:
+    """One GPU's scoring engine (stream, scratch, deferred-error word)."""
+
+    _instances: Dict[int, "Engine"] = {}
+
+    def __init__(self, device: int = 0):
+        self._lib = lib()
+        h = _vp()
+        rc = self._lib.fx_engine_create(device, C.byref(h))
+        if rc != FX_OK:
+            msg = self._lib.fx_last_error(None).decode()
+            raise RuntimeError(
+                f"flexs_amd: cannot create a scoring engine on HIP device {device} "
+                f"({status_name(rc)}: {msg}). An MI355X (gfx950) GPU is required; there is no CPU fallback."
+            )
+        self.handle = h
+        self.device = device
+
+    @classmethod
+    def get(cls, device: Optional[int] = None) -> "Engine":
+        if device is None:
+            device = int(os.environ.get("FLEXS_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            n = lib().fx_device_count()
+            if n > 0:
+                device %= n
+        if device not in cls._instances:
+            cls._instances[device] = Engine(device)
+        return cls._instances[device]
+
+    def check(self, rc: int):
+        if rc != FX_OK:
+            _raise(rc, self.handle)
+
+    # ---- options / sync / timing
+    def set_option(self, key: str, value: int):
+        self.check(self._lib.fx_engine_set_option(self.handle, key.encode(), int(value)))
+
+    def get_option(self, key: str) -> int:
+        v = C.c_int64()
+        self.check(self._lib.fx_engine_get_option(self.handle, key.encode(), C.byref(v)))
+        return v.value
+
+    def set_stream(self, hip_stream: Optional[int]):
+        self.check(self._lib.fx_engine_set_stream(self.handle, _vp(hip_stream) if hip_stream else None))
+
+    def sync(self):
+        self.check(self._lib.fx_engine_sync(self.handle))
+
+    def timer_start(self):
+        self.check(self._lib.fx_timer_start(self.handle))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        self.check(self._lib.fx_timer_stop(self.handle, C.byref(ms)))
+        return ms.value
+
+    # ---- scoring
+    def score(self, models: Sequence["NativeModel"], seq_bytes: np.ndarray, lut: np.ndarray,
+              want_matrix: bool = True, want_mean: bool = False):
+        N, L = seq_bytes.shape
+        M = len(models)
+        arr = (_vp * M)(*[m.handle for m in models])
+        out_nm = np.empty((N, M), np.float32) if want_matrix else None
+        out_mean = np.empty((N,), np.float32) if want_mean else None
+        seq_bytes = np.ascontiguousarray(seq_bytes)
+        self.check(self._lib.fx_score(self.handle, arr, M, _ptr(seq_bytes), N, L,
+                                      lut.ctypes.data_as(_u8p), _ptr(out_nm), _ptr(out_mean)))
+        return out_nm, out_mean
+
+    def score_dev(self, models: Sequence["NativeModel"], d_ascii: int, N: int, L: int, lut: np.ndarray,
+                  d_out_nm: Optional[int], d_out_mean: Optional[int]):
+        M = len(models)
+        arr = (_vp * M)(*[m.handle for m in models])
+        self.check(self._lib.fx_score_dev(self.handle, arr, M, _vp(d_ascii), N, L, lut.ctypes.data_as(_u8p),
+                                          _vp(d_out_nm) if d_out_nm else None,
+                                          _vp(d_out_mean) if d_out_mean else None))
+
+    def encode_onehot(self, seq_bytes: np.ndarray, lut: np.ndarray, A: int) -> np.ndarray:
+        N, L = seq_bytes.shape
+        out = np.empty((N, L, A), np.float32)
+        seq_bytes = np.ascontiguousarray(seq_bytes)
+        self.check(self._lib.fx_encode_onehot(self.handle, _ptr(seq_bytes), N, L, lut.ctypes.data_as(_u8p), A, _ptr(out)))
+        return out
+
+    def encode_onehot_dev(self, d_ascii: int, N: int, L: int, lut: np.ndarray, A: int, d_out: int):
+        self.check(self._lib.fx_encode_onehot_dev(self.handle, _vp(d_ascii), N, L, lut.ctypes.data_as(_u8p), A, _vp(d_out)))
+
+    def ensemble_mean(self, scores_nm: np.ndarray) -> np.ndarray:
+        s = np.ascontiguousarray(scores_nm, np.float32)
+        out = np.empty(s.shape[0], np.float32)
+        self.check(self._lib.fx_ensemble_reduce(self.handle, _ptr(s), s.shape[0], s.shape[1], None, _ptr(out), None))
+        return out
+
+    def ensemble_weighted_sum(self, scores_nm: np.ndarray, weights: np.ndarray) -> np.ndarray:
+        s = np.ascontiguousarray(scores_nm, np.float32)
+        w = np.ascontiguousarray(weights, np.float64)
+        out = np.empty(s.shape[0], np.float64)
+        self.check(self._lib.fx_ensemble_reduce(self.handle, _ptr(s), s.shape[0], s.shape[1], _ptr(w), None, _ptr(out)))
+        return out
+
+    def ensemble_reduce_dev(self, d_scores: int, N: int, M: int, d_out32: int):
+        self.check(self._lib.fx_ensemble_reduce_dev(self.handle, _vp(d_scores), N, M, None, _vp(d_out32), None))
+
+    def argmax_decode(self, one_hot: np.ndarray, alphabet: str) -> np.ndarray:
+        x = np.ascontiguousarray(one_hot, np.float64)
+        P, L, A = x.shape
+        if A > len(alphabet):
+            # np.argmax could pick an index with no character: mirror the IndexError
+            pass
+        al = np.frombuffer(alphabet.encode("latin-1"), np.uint8)
+        if A > al.shape[0]:
+            al = np.concatenate([al, np.zeros(A - al.shape[0], np.uint8)])
+        out = np.empty((P, L), np.uint8)
+        self.check(self._lib.fx_argmax_decode(self.handle, _ptr(x), P, L, A, _ptr(np.ascontiguousarray(al)), _ptr(out)))
+        return out
+
+    def min_dist(self, queries: np.ndarray, cache: np.ndarray, mode: int = FX_LEVENSHTEIN):
+        q = np.ascontiguousarray(queries, np.uint8)
+        c = np.ascontiguousarray(cache, np.uint8)
+        Q, L = q.shape
+        dist = np.empty(Q, np.int32)
+        arg = np.empty(Q, np.int64)
+        self.check(self._lib.fx_min_dist(self.handle, mode, _ptr(q), Q, _ptr(c), c.shape[0], L, _ptr(dist), _ptr(arg)))
+        return dist, arg
+
+    def nam_combine(self, signal, noise, d, alpha_tab) -> np.ndarray:
+        signal = np.ascontiguousarray(signal, np.float64)
+        noise = np.ascontiguousarray(noise, np.float64)
+        d = np.ascontiguousarray(d, np.int32)
+        tab = np.ascontiguousarray(alpha_tab, np.float64)
+        out = np.empty(signal.shape[0], np.float64)
+        self.check(self._lib.fx_nam_combine(self.handle, signal.shape[0], _ptr(signal), _ptr(noise), _ptr(d),
+                                            _ptr(tab), tab.shape[0], _ptr(out)))
+        return out
+
+
+class NativeModel:
+    """fx_model handle: shape + device-resident weights of one surrogate."""
+
+    def __init__(self, engine: Engine, kind: int, L: int, A: int, F: int, H: int, K: int):
+        self.engine = engine
+        h = _vp()
+        rc = engine._lib.fx_model_create(engine.handle, kind, L, A, F, H, K, C.byref(h))
+        if rc != FX_OK:
+            _raise(rc, engine.handle)
+        self.handle = h
+        self.kind, self.L, self.A, self.F, self.H, self.K = kind, L, A, F, H, K
+        self.num_params = engine._lib.fx_model_num_params(h)
+
+    def set_weights(self, arrays: List[np.ndarray]):
+        blob = np.concatenate([np.asarray(a, np.float32).ravel() for a in arrays])
+        self.engine.check(self.engine._lib.fx_model_set_weights(self.handle, blob.ctypes.data_as(_f32p), blob.shape[0]))
+
+    def get_blob(self) -> np.ndarray:
+        blob = np.empty(self.num_params, np.float32)
+        self.engine.check(self.engine._lib.fx_model_get_weights(self.handle, blob.ctypes.data_as(_f32p), blob.shape[0]))
+        return blob
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.engine._lib.fx_model_destroy(self.handle)
+                self.handle = None
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
+class NativeCache:
+    """Device-resident, append-only NoisyAbstractModel key store."""
+
+    def __init__(self, engine: Engine, L: int):
+        self.engine = engine
+        self.L = L
+        h = _vp()
+        engine.check(engine._lib.fx_cache_create(engine.handle, L, C.byref(h)))
+        self.handle = h
+
+    def __len__(self):
+        return int(self.engine._lib.fx_cache_size(self.handle))
+
+    def append(self, keys_u8: np.ndarray):
+        k = np.ascontiguousarray(keys_u8, np.uint8)
+        if k.shape[0]:
+            self.engine.check(self.engine._lib.fx_cache_append(self.handle, _ptr(k), k.shape[0]))
+
+    def min_dist(self, queries: np.ndarray, mode: int = FX_LEVENSHTEIN):
+        q = np.ascontiguousarray(queries, np.uint8)
+        Q = q.shape[0]
+        dist = np.empty(Q, np.int32)
+        arg = np.empty(Q, np.int64)
+        self.engine.check(self.engine._lib.fx_cache_min_dist(self.handle, mode, _ptr(q), Q, _ptr(dist), _ptr(arg)))
+        return dist, arg
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.engine._lib.fx_cache_destroy(self.handle)
+                self.handle = None
+        except Exception:  # noqa: BLE001
+            pass
+
+
+# ---- host-only test hooks (usable without a GPU) ---------------------------
+def debug_pack_weights(kind, L, A, F, H, K, arrays) -> np.ndarray:
+    blob = np.concatenate([np.asarray(a, np.float32).ravel() for a in arrays])
+    n = lib().fx_debug_packed_size(kind, L, A, F, H, K)
+    out = np.empty(n, np.float32)
+    rc = lib().fx_debug_pack_weights(kind, L, A, F, H, K, blob.ctypes.data_as(_f32p), blob.shape[0],
+                                     out.ctypes.data_as(_f32p), n)
+    if rc != FX_OK:
+        raise ValueError(status_name(rc))
+    return out
+
+
+def debug_pack_layout(kind, L, A, F, H, K) -> dict:
+    v = (C.c_int64 * 12)()
+    rc = lib().fx_debug_pack_layout(kind, L, A, F, H, K, v)
+    if rc != FX_OK:
+        raise ValueError(status_name(rc))
+    names = ["FT", "HT", "SG1", "off_first", "off_c2", "off_c3", "off_cb", "conv_floats", "off_d1", "off_d2",
+             "off_d3", "off_db"]
+    return dict(zip(names, list(v)))
+
+
+def debug_myers(a: bytes, b: bytes) -> int:
+    a = np.frombuffer(bytes(a), np.uint8)
+    b = np.frombuffer(bytes(b), np.uint8)
+    return lib().fx_debug_myers(_ptr(a) if len(a) else None, len(a), _ptr(b) if len(b) else None, len(b))

@@ -1,0 +1,102 @@
+"""`NoisyAbstractModel` -- same contract as
+flexs/baselines/models/noisy_abstract_model.py:9-101.
+
+f_hat(x) = alpha^d f(x) + (1 - alpha^d) eps, d = edit distance to the nearest
+cached sequence (first cache entry attaining it), eps ~ Exp(mean = f(neighbour)).
+
+The O(Q*C) neighbour search runs on the GPU (bit-parallel Levenshtein, K4
+fx_cache_min_dist) against a device-resident copy of the cache keys; the blend
+is the K5 kernel (fx_nam_combine).  Everything that touches the global NumPy RNG
+or the ground-truth landscape stays on the host in the reference's order, so
+results and RNG state are bit-identical to the reference for the same seed.
+"""
+import numpy as np
+
+import flexs_amd
+from flexs_amd import _native
+from flexs_amd.types import SEQUENCES_TYPE
+
+
+class NoisyAbstractModel(flexs_amd.Model):
+    def __init__(self, landscape: flexs_amd.Landscape, signal_strength: float = 0.9, distance: str = "levenshtein",
+                 device: int = None):
+        super().__init__(f"NAMb_ss{signal_strength}")                 # noisy_abstract_model.py:36
+        self.landscape = landscape
+        self.ss = signal_strength
+        self.cache = {}
+        if distance not in ("levenshtein", "hamming"):
+            raise ValueError("distance must be 'levenshtein' (reference behaviour) or 'hamming'")
+        self._mode = _native.FX_LEVENSHTEIN if distance == "levenshtein" else _native.FX_HAMMING
+        self._device = device
+        self._dev_cache = None            # NativeCache mirroring list(self.cache) in insertion order
+        self._dev_keys = []               # python-side mirror of what was appended
+
+    # ---------------------------------------------------------------- device cache sync
+    def _sync_device_cache(self, L: int):
+        keys = self.cache.keys()
+        n = len(self._dev_keys)
+        stale = self._dev_cache is None or self._dev_cache.L != L or n > len(keys)
+        if not stale and n:
+            # dict order is append-only unless the user deleted entries: spot-check the boundary
+            it = iter(keys)
+            first = next(it)
+            stale = first != self._dev_keys[0]
+        if stale:
+            self._dev_cache = _native.NativeCache(_native.Engine.get(self._device), L)
+            self._dev_keys = []
+            n = 0
+        if len(keys) > n:
+            import itertools
+
+            new = [str(k) for k in itertools.islice(keys, n, None)]
+            if any(len(k) != L for k in new):
+                raise ValueError("NoisyAbstractModel: cached sequences must all have the query length")
+            self._dev_cache.append(_native.sequences_to_bytes(new, L=L))
+            self._dev_keys.extend(new)
+
+    def _get_min_distance(self, sequence):
+        """noisy_abstract_model.py:42-60 for one query (kept for API parity)."""
+        if len(self.cache) == 0:
+            return 0, sequence
+        d, nb = self._min_distances([sequence])
+        return int(d[0]), nb[0]
+
+    def _min_distances(self, sequences):
+        L = len(sequences[0])
+        self._sync_device_cache(L)
+        dist, arg = self._dev_cache.min_dist(_native.sequences_to_bytes(sequences, L=L), self._mode)
+        return dist, [self._dev_keys[i] for i in arg]
+
+    # ---------------------------------------------------------------- flexs.Model API
+    def train(self, sequences: SEQUENCES_TYPE, labels: np.ndarray):
+        self.cache.update(zip(sequences, labels))                      # :62-67
+
+    def _fitness_function(self, sequences):
+        sequences = np.array(sequences)
+        fitnesses = np.empty(len(sequences))
+        cached = np.array([seq in self.cache for seq in sequences], dtype=bool)
+        fitnesses[cached] = np.array([self.cache[seq] for seq in sequences[cached]])
+
+        new_seqs = sequences[~cached]
+        if len(new_seqs):
+            if len(self.cache) == 0:                                   # :44-45
+                dist = np.zeros(len(new_seqs), np.int32)
+                neighbours = list(new_seqs)
+            else:
+                dist, neighbours = self._min_distances([str(s) for s in new_seqs])
+            signal = np.empty(len(new_seqs))
+            noise = np.empty(len(new_seqs))
+            for i, (seq, nb) in enumerate(zip(new_seqs, neighbours)):
+                # same call order as the reference loop (:86-91): two oracle queries, one RNG draw
+                signal[i] = self.landscape.get_fitness([seq]).item()
+                neighbor_fitness = self.landscape.get_fitness([nb]).item()
+                if neighbor_fitness >= 0:
+                    noise[i] = np.random.exponential(scale=neighbor_fitness)
+                else:
+                    noise[i] = np.random.choice(list(self.cache.values()))
+            max_d = int(dist.max()) if len(dist) else 0
+            alpha_tab = np.array([self.ss ** d for d in range(max_d + 1)], np.float64)   # :93, Python float pow
+            fitnesses[~cached] = _native.Engine.get(self._device).nam_combine(signal, noise, dist, alpha_tab)
+
+        self.cache.update(zip(sequences[~cached], fitnesses[~cached]))  # :99
+        return np.array(fitnesses)

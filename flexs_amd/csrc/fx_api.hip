@@ -1,0 +1,609 @@
+// C ABI of libflexs_amd.so (see include/flexs_amd.h for the contract and the
+// reference file:line each entry point replaces).
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "fx_common.h"
+#include "myers.h"
+
+// ------------------------------------------------------------------ helpers
+static thread_local std::string g_last_error_noengine;
+
+int fx_fail(fx_engine* e, int status, const std::string& msg) {
+    if (e) e->last_error = msg; else g_last_error_noengine = msg;
+    return status;
+}
+
+int fx_scratch(fx_engine* e, int slot, size_t bytes, void** out) {
+    if (bytes > e->scratch_bytes[slot]) {
+        if (e->d_scratch[slot]) {
+            FX_HIP(e, hipStreamSynchronize(e->stream));
+            FX_HIP(e, hipFree(e->d_scratch[slot]));
+            e->d_scratch[slot] = nullptr; e->scratch_bytes[slot] = 0;
+        }
+        size_t cap = std::max<size_t>(bytes + bytes / 4, 1 << 16);
+        if (hipMalloc(&e->d_scratch[slot], cap) != hipSuccess) {
+            (void)hipGetLastError();
+            return fx_fail(e, FX_ENOMEM, "hipMalloc of device scratch failed");
+        }
+        e->scratch_bytes[slot] = cap;
+    }
+    *out = e->d_scratch[slot];
+    return FX_OK;
+}
+
+int fx_pinned(fx_engine* e, int slot, size_t bytes, void** out) {
+    if (bytes > e->pinned_bytes[slot]) {
+        if (e->h_pinned[slot]) {
+            FX_HIP(e, hipStreamSynchronize(e->stream));
+            FX_HIP(e, hipHostFree(e->h_pinned[slot]));
+            e->h_pinned[slot] = nullptr; e->pinned_bytes[slot] = 0;
+        }
+        size_t cap = std::max<size_t>(bytes + bytes / 4, 1 << 16);
+        if (hipHostMalloc(&e->h_pinned[slot], cap, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return fx_fail(e, FX_ENOMEM, "hipHostMalloc of pinned staging failed");
+        }
+        e->pinned_bytes[slot] = cap;
+    }
+    *out = e->h_pinned[slot];
+    return FX_OK;
+}
+
+int fx_upload_lut(fx_engine* e, const uint8_t lut[256]) {
+    if (e->lut_valid && std::memcmp(lut, e->h_lut, 256) == 0) return FX_OK;
+    std::memcpy(e->h_lut, lut, 256);
+    // h_lut lives in the engine: safe source for an async copy
+    FX_HIP(e, hipMemcpyAsync(e->d_lut, e->h_lut, 256, hipMemcpyHostToDevice, e->stream));
+    // a later call with a different LUT must not overwrite h_lut while this copy is pending
+    FX_HIP(e, hipStreamSynchronize(e->stream));
+    e->lut_valid = true;
+    return FX_OK;
+}
+
+static int check_deferred(fx_engine* e) {
+    // caller has synchronised the stream
+    unsigned err = 0;
+    FX_HIP(e, hipMemcpy(&err, e->d_err, sizeof(err), hipMemcpyDeviceToHost));
+    if (err) {
+        FX_HIP(e, hipMemset(e->d_err, 0, sizeof(unsigned)));
+        if (err & FX_ERR_BADCHAR) return fx_fail(e, FX_EBADCHAR, "substring not found: character outside the alphabet");
+    }
+    return FX_OK;
+}
+
+extern "C" {
+
+// ------------------------------------------------------------------ library
+int fx_version(void) { return FX_VERSION; }
+
+const char* fx_status_name(int s) {
+    switch (s) {
+        case FX_OK: return "FX_OK";
+        case FX_EINVAL: return "FX_EINVAL";
+        case FX_ESHAPE: return "FX_ESHAPE";
+        case FX_EBADCHAR: return "FX_EBADCHAR";
+        case FX_ENODEV: return "FX_ENODEV";
+        case FX_EHIP: return "FX_EHIP";
+        case FX_ENOMEM: return "FX_ENOMEM";
+        case FX_EUNSUPPORTED: return "FX_EUNSUPPORTED";
+        case FX_ESTATE: return "FX_ESTATE";
+    }
+    return "FX_UNKNOWN";
+}
+
+int fx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+// ------------------------------------------------------------------- engine
+int fx_engine_create(int device, fx_engine** out) {
+    if (!out) return FX_EINVAL;
+    *out = nullptr;
+    int n = fx_device_count();
+    if (n <= 0 || device < 0 || device >= n) return fx_fail(nullptr, FX_ENODEV, "no such HIP device");
+    fx_engine* e = new (std::nothrow) fx_engine();
+    if (!e) return FX_ENOMEM;
+    e->device = device;
+#define FX_CREATE_HIP(call)                                                                   \
+    do { hipError_t _r = (call); if (_r != hipSuccess) {                                      \
+        fx_fail(nullptr, FX_EHIP, std::string(#call) + ": " + hipGetErrorString(_r)); delete e; return FX_EHIP; } } while (0)
+    FX_CREATE_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    FX_CREATE_HIP(hipGetDeviceProperties(&prop, device));
+    e->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    e->max_lds = (int)std::max<size_t>(prop.maxSharedMemoryPerMultiProcessor, 64 * 1024);
+    if (e->max_lds > 160 * 1024) e->max_lds = 160 * 1024;
+    FX_CREATE_HIP(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+    e->stream = e->own_stream;
+    FX_CREATE_HIP(hipEventCreate(&e->ev0));
+    FX_CREATE_HIP(hipEventCreate(&e->ev1));
+    FX_CREATE_HIP(hipMalloc(&e->d_err, sizeof(unsigned)));
+    FX_CREATE_HIP(hipMemset(e->d_err, 0, sizeof(unsigned)));
+    FX_CREATE_HIP(hipMalloc(&e->d_lut, 256));
+#undef FX_CREATE_HIP
+    *out = e;
+    return FX_OK;
+}
+
+int fx_engine_destroy(fx_engine* e) {
+    if (!e) return FX_OK;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    for (auto& p : e->d_scratch) if (p) (void)hipFree(p);
+    for (auto& p : e->h_pinned) if (p) (void)hipHostFree(p);
+    if (e->d_err) (void)hipFree(e->d_err);
+    if (e->d_lut) (void)hipFree(e->d_lut);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    delete e;
+    return FX_OK;
+}
+
+int fx_engine_set_stream(fx_engine* e, void* hip_stream) {
+    if (!e) return FX_EINVAL;
+    FX_HIP(e, hipStreamSynchronize(e->stream));
+    e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+    return FX_OK;
+}
+
+int fx_engine_sync(fx_engine* e) {
+    if (!e) return FX_EINVAL;
+    FX_HIP(e, hipSetDevice(e->device));
+    FX_HIP(e, hipStreamSynchronize(e->stream));
+    return check_deferred(e);
+}
+
+const char* fx_last_error(fx_engine* e) { return e ? e->last_error.c_str() : g_last_error_noengine.c_str(); }
+
+static int64_t* option_slot(fx_engine* e, const char* key) {
+    if (!e || !key) return nullptr;
+    if (!std::strcmp(key, "force_generic")) return &e->force_generic;
+    if (!std::strcmp(key, "cnn_variant")) return &e->cnn_variant;
+    if (!std::strcmp(key, "grid_blocks")) return &e->grid_blocks;
+    return nullptr;
+}
+int fx_engine_set_option(fx_engine* e, const char* key, int64_t value) {
+    int64_t* s = option_slot(e, key);
+    if (!s) return fx_fail(e, FX_EINVAL, std::string("unknown option ") + (key ? key : "(null)"));
+    *s = value;
+    return FX_OK;
+}
+int fx_engine_get_option(fx_engine* e, const char* key, int64_t* value) {
+    if (!value) return FX_EINVAL;
+    if (e && key && !std::strcmp(key, "num_cus")) { *value = e->num_cus; return FX_OK; }
+    int64_t* s = option_slot(e, key);
+    if (!s) return fx_fail(e, FX_EINVAL, std::string("unknown option ") + (key ? key : "(null)"));
+    *value = *s;
+    return FX_OK;
+}
+
+int fx_timer_start(fx_engine* e) {
+    if (!e) return FX_EINVAL;
+    FX_HIP(e, hipEventRecord(e->ev0, e->stream));
+    return FX_OK;
+}
+int fx_timer_stop(fx_engine* e, float* ms) {
+    if (!e || !ms) return FX_EINVAL;
+    FX_HIP(e, hipEventRecord(e->ev1, e->stream));
+    FX_HIP(e, hipEventSynchronize(e->ev1));
+    FX_HIP(e, hipEventElapsedTime(ms, e->ev0, e->ev1));
+    return FX_OK;
+}
+
+// -------------------------------------------------------------------- model
+int fx_model_create(fx_engine* e, int kind, int L, int A, int F, int H, int K, fx_model** out) {
+    if (!e || !out) return FX_EINVAL;
+    *out = nullptr;
+    if (kind < FX_CNN || kind > FX_GE) return fx_fail(e, FX_EINVAL, "unknown model kind");
+    if (L < 1 || A < 1 || H < 1 || A > 254) return fx_fail(e, FX_EINVAL, "bad model dimensions");
+    if (kind == FX_CNN) {
+        if (F < 1 || K < 1 || A < 2) return fx_fail(e, FX_EINVAL, "bad CNN dimensions");
+        // Keras 'valid' Conv1D raises at construction when seq_len < kernel_size (cnn.py:25-32)
+        if (L < K) return fx_fail(e, FX_ESHAPE, "Negative dimension size: seq_len < kernel_size for 'valid' Conv1D");
+    } else {
+        F = 0; K = 0;
+    }
+    fx_model* m = new (std::nothrow) fx_model();
+    if (!m) return FX_ENOMEM;
+    m->eng = e;
+    m->shape = FxShape{kind, L, A, F, H, K};
+    m->layout = fx_pack_layout(m->shape);
+    const int64_t np = fx_num_params(m->shape);
+    m->blob.assign((size_t)np, 0.f);
+    FX_HIP(e, hipSetDevice(e->device));
+    if (hipMalloc(&m->d_blob, sizeof(float) * (size_t)np) != hipSuccess ||
+        hipMalloc(&m->d_packed, sizeof(float) * (size_t)m->layout.total_floats) != hipSuccess) {
+        (void)hipGetLastError();
+        if (m->d_blob) (void)hipFree(m->d_blob);
+        delete m;
+        return fx_fail(e, FX_ENOMEM, "hipMalloc of model weights failed");
+    }
+    *out = m;
+    return FX_OK;
+}
+
+int fx_model_destroy(fx_model* m) {
+    if (!m) return FX_OK;
+    (void)hipSetDevice(m->eng->device);
+    (void)hipStreamSynchronize(m->eng->stream);
+    if (m->d_blob) (void)hipFree(m->d_blob);
+    if (m->d_packed) (void)hipFree(m->d_packed);
+    delete m;
+    return FX_OK;
+}
+
+int64_t fx_model_num_params(const fx_model* m) { return m ? (int64_t)m->blob.size() : FX_EINVAL; }
+
+int fx_model_set_weights(fx_model* m, const float* blob, int64_t n) {
+    if (!m || !blob) return FX_EINVAL;
+    fx_engine* e = m->eng;
+    if (n != (int64_t)m->blob.size()) return fx_fail(e, FX_ESHAPE, "weight blob has the wrong number of floats");
+    FX_HIP(e, hipSetDevice(e->device));
+    std::memcpy(m->blob.data(), blob, sizeof(float) * (size_t)n);
+    std::vector<float> packed((size_t)m->layout.total_floats);
+    fx_pack_weights(m->shape, m->blob.data(), packed.data());
+    // in-flight kernels may still read the old weights
+    FX_HIP(e, hipStreamSynchronize(e->stream));
+    FX_HIP(e, hipMemcpy(m->d_blob, m->blob.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
+    FX_HIP(e, hipMemcpy(m->d_packed, packed.data(), sizeof(float) * packed.size(), hipMemcpyHostToDevice));
+    m->has_weights = true;
+    return FX_OK;
+}
+
+int fx_model_get_weights(const fx_model* m, float* blob, int64_t n) {
+    if (!m || !blob) return FX_EINVAL;
+    if (n != (int64_t)m->blob.size()) return FX_ESHAPE;
+    std::memcpy(blob, m->blob.data(), sizeof(float) * (size_t)n);
+    return FX_OK;
+}
+
+// ------------------------------------------------------------------ scoring
+static int score_dispatch(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N, int L,
+                          float* d_NM) {
+    // group consecutive members into launches of <= FX_MAX_M homogeneous models
+    for (int m0 = 0; m0 < M;) {
+        int cnt = 1;
+        const FxShape& s0 = models[m0]->shape;
+        while (m0 + cnt < M && cnt < FX_MAX_M) {
+            const FxShape& s = models[m0 + cnt]->shape;
+            if (s.kind != s0.kind || s.F != s0.F || s.H != s0.H || s.K != s0.K) break;
+            ++cnt;
+        }
+        int rc = FX_EUNSUPPORTED;
+        if (!e->force_generic) {
+            if (s0.kind == FX_CNN) rc = fx_launch_score_cnn_mfma(e, models + m0, cnt, d_ascii, N, d_NM, M, m0);
+            else rc = fx_launch_score_dense_mfma(e, models + m0, cnt, d_ascii, N, d_NM, M, m0);
+        }
+        if (rc == FX_EUNSUPPORTED) rc = fx_launch_score_generic(e, models + m0, cnt, d_ascii, N, d_NM, M, m0);
+        if (rc) return rc;
+        m0 += cnt;
+    }
+    (void)L;
+    return FX_OK;
+}
+
+static int validate_models(fx_engine* e, fx_model* const* models, int M, int L, const uint8_t* lut) {
+    if (!e || !models || M < 1 || !lut) return FX_EINVAL;
+    for (int m = 0; m < M; ++m) {
+        if (!models[m]) return fx_fail(e, FX_EINVAL, "null model handle");
+        if (models[m]->eng != e) return fx_fail(e, FX_EINVAL, "model belongs to another engine");
+        if (!models[m]->has_weights) return fx_fail(e, FX_ESTATE, "model weights were never set");
+        if (models[m]->shape.L != L) return fx_fail(e, FX_ESHAPE, "sequence length does not match the model's seq_len");
+        if (models[m]->shape.A != models[0]->shape.A) return fx_fail(e, FX_ESHAPE, "ensemble members use different alphabets");
+    }
+    for (int c = 0; c < 256; ++c)
+        if (lut[c] != 0xFF && lut[c] >= models[0]->shape.A) return fx_fail(e, FX_EINVAL, "LUT entry >= alphabet size");
+    return FX_OK;
+}
+
+int fx_score_dev(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N, int L,
+                 const uint8_t lut[256], float* d_out_NM, float* d_out_mean) {
+    int rc = validate_models(e, models, M, L, lut);
+    if (rc) return rc;
+    if (N < 0) return fx_fail(e, FX_EINVAL, "negative batch size");
+    if (N == 0) return FX_OK;
+    if (!d_ascii || (!d_out_NM && !d_out_mean)) return fx_fail(e, FX_EINVAL, "null buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    rc = fx_upload_lut(e, lut);
+    if (rc) return rc;
+    float* d_NM = d_out_NM;
+    if (!d_NM) {
+        void* p = nullptr;
+        rc = fx_scratch(e, 1, sizeof(float) * (size_t)N * (size_t)M, &p);
+        if (rc) return rc;
+        d_NM = (float*)p;
+    }
+    rc = score_dispatch(e, models, M, d_ascii, N, L, d_NM);
+    if (rc) return rc;
+    if (d_out_mean) rc = fx_launch_ensemble_reduce(e, d_NM, N, M, nullptr, d_out_mean, nullptr);
+    return rc;
+}
+
+int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii, int64_t N, int L,
+             const uint8_t lut[256], float* out_NM, float* out_mean) {
+    int rc = validate_models(e, models, M, L, lut);
+    if (rc) return rc;
+    if (N < 0) return fx_fail(e, FX_EINVAL, "negative batch size");
+    if (N == 0) return FX_OK;
+    if (!ascii || (!out_NM && !out_mean)) return fx_fail(e, FX_EINVAL, "null buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    // characters outside the alphabet are detected on the device (deferred error word)
+    const size_t in_bytes = (size_t)N * (size_t)L;
+    const size_t nm_bytes = sizeof(float) * (size_t)N * (size_t)M, mean_bytes = sizeof(float) * (size_t)N;
+    void *d_in = nullptr, *h_in = nullptr, *h_out = nullptr;
+    if ((rc = fx_scratch(e, 0, in_bytes, &d_in))) return rc;
+    if ((rc = fx_pinned(e, 0, in_bytes, &h_in))) return rc;
+    if ((rc = fx_pinned(e, 1, nm_bytes + mean_bytes, &h_out))) return rc;
+    void* d_out = nullptr;
+    if ((rc = fx_scratch(e, 1, nm_bytes + mean_bytes, &d_out))) return rc;
+    float* d_NM = (float*)d_out;
+    float* d_mean = (float*)((char*)d_out + nm_bytes);
+    std::memcpy(h_in, ascii, in_bytes);
+    FX_HIP(e, hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, e->stream));
+    if ((rc = fx_upload_lut(e, lut))) return rc;
+    if ((rc = score_dispatch(e, models, M, (const uint8_t*)d_in, N, L, d_NM))) return rc;
+    if (out_mean) {
+        if ((rc = fx_launch_ensemble_reduce(e, d_NM, N, M, nullptr, d_mean, nullptr))) return rc;
+        FX_HIP(e, hipMemcpyAsync((char*)h_out + nm_bytes, d_mean, mean_bytes, hipMemcpyDeviceToHost, e->stream));
+    }
+    if (out_NM) FX_HIP(e, hipMemcpyAsync(h_out, d_NM, nm_bytes, hipMemcpyDeviceToHost, e->stream));
+    FX_HIP(e, hipStreamSynchronize(e->stream));
+    if ((rc = check_deferred(e))) return rc;
+    if (out_NM) std::memcpy(out_NM, h_out, nm_bytes);
+    if (out_mean) std::memcpy(out_mean, (char*)h_out + nm_bytes, mean_bytes);
+    return FX_OK;
+}
+
+int fx_encode_onehot_dev(fx_engine* e, const uint8_t* d_ascii, int64_t N, int L, const uint8_t lut[256], int A,
+                         float* d_one_hot) {
+    if (!e || !lut || N < 0 || L < 0 || A < 1) return FX_EINVAL;
+    if (N == 0 || L == 0) return FX_OK;
+    if (!d_ascii || !d_one_hot) return fx_fail(e, FX_EINVAL, "null buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    int rc = fx_upload_lut(e, lut);
+    if (rc) return rc;
+    return fx_launch_encode_onehot(e, d_ascii, N, L, A, d_one_hot);
+}
+
+int fx_encode_onehot(fx_engine* e, const uint8_t* ascii, int64_t N, int L, const uint8_t lut[256], int A,
+                     float* one_hot) {
+    if (!e || !lut || N < 0 || L < 0 || A < 1) return FX_EINVAL;
+    if (N == 0 || L == 0) return FX_OK;
+    if (!ascii || !one_hot) return fx_fail(e, FX_EINVAL, "null buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    const size_t in_bytes = (size_t)N * L, out_bytes = sizeof(float) * (size_t)N * L * A;
+    void *d_in = nullptr, *d_out = nullptr;
+    int rc;
+    if ((rc = fx_scratch(e, 0, in_bytes, &d_in))) return rc;
+    if ((rc = fx_scratch(e, 1, out_bytes, &d_out))) return rc;
+    FX_HIP(e, hipMemcpyAsync(d_in, ascii, in_bytes, hipMemcpyHostToDevice, e->stream));
+    if ((rc = fx_upload_lut(e, lut))) return rc;
+    if ((rc = fx_launch_encode_onehot(e, (const uint8_t*)d_in, N, L, A, (float*)d_out))) return rc;
+    FX_HIP(e, hipMemcpyAsync(one_hot, d_out, out_bytes, hipMemcpyDeviceToHost, e->stream));
+    FX_HIP(e, hipStreamSynchronize(e->stream));
+    return check_deferred(e);
+}
+
+int fx_ensemble_reduce_dev(fx_engine* e, const float* d_scores, int64_t N, int M, const double* weights,
+                           float* d_out32, double* d_out64) {
+    if (!e || N < 0 || M < 1) return FX_EINVAL;
+    if (N == 0) return FX_OK;
+    if (!d_scores || (weights ? !d_out64 : !d_out32)) return fx_fail(e, FX_EINVAL, "null buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    const double* d_w = nullptr;
+    if (weights) {
+        void* p = nullptr;
+        int rc = fx_scratch(e, 3, sizeof(double) * (size_t)M, &p);
+        if (rc) return rc;
+        FX_HIP(e, hipMemcpyAsync(p, weights, sizeof(double) * (size_t)M, hipMemcpyHostToDevice, e->stream));
+        FX_HIP(e, hipStreamSynchronize(e->stream));       // `weights` is caller memory
+        d_w = (const double*)p;
+    }
+    return fx_launch_ensemble_reduce(e, d_scores, N, M, d_w, d_out32, d_out64);
+}
+
+int fx_ensemble_reduce(fx_engine* e, const float* scores, int64_t N, int M, const double* weights, float* out32,
+                       double* out64) {
+    if (!e || N < 0 || M < 1) return FX_EINVAL;
+    if (N == 0) return FX_OK;
+    if (!scores || (weights ? !out64 : !out32)) return fx_fail(e, FX_EINVAL, "null buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    const size_t in_bytes = sizeof(float) * (size_t)N * M;
+    const size_t out_bytes = (weights ? sizeof(double) : sizeof(float)) * (size_t)N;
+    void *d_in = nullptr, *d_out = nullptr;
+    int rc;
+    if ((rc = fx_scratch(e, 0, in_bytes, &d_in))) return rc;
+    if ((rc = fx_scratch(e, 1, out_bytes, &d_out))) return rc;
+    FX_HIP(e, hipMemcpyAsync(d_in, scores, in_bytes, hipMemcpyHostToDevice, e->stream));
+    rc = fx_ensemble_reduce_dev(e, (const float*)d_in, N, M, weights, (float*)d_out, (double*)d_out);
+    if (rc) return rc;
+    FX_HIP(e, hipMemcpyAsync(weights ? (void*)out64 : (void*)out32, d_out, out_bytes, hipMemcpyDeviceToHost, e->stream));
+    FX_HIP(e, hipStreamSynchronize(e->stream));
+    return FX_OK;
+}
+
+int fx_argmax_decode(fx_engine* e, const double* one_hot, int64_t P, int L, int A, const uint8_t* alphabet,
+                     uint8_t* out_chars) {
+    if (!e || P < 0 || L < 0 || A < 1) return FX_EINVAL;
+    const int64_t rows = P * L;
+    if (rows == 0) return FX_OK;
+    if (!one_hot || !alphabet || !out_chars) return fx_fail(e, FX_EINVAL, "null buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    const size_t in_bytes = sizeof(double) * (size_t)rows * A;
+    void *d_in = nullptr, *d_out = nullptr, *d_al = nullptr;
+    int rc;
+    if ((rc = fx_scratch(e, 0, in_bytes, &d_in))) return rc;
+    if ((rc = fx_scratch(e, 1, (size_t)rows, &d_out))) return rc;
+    if ((rc = fx_scratch(e, 3, 256, &d_al))) return rc;
+    FX_HIP(e, hipMemcpyAsync(d_in, one_hot, in_bytes, hipMemcpyHostToDevice, e->stream));
+    FX_HIP(e, hipMemcpyAsync(d_al, alphabet, (size_t)A, hipMemcpyHostToDevice, e->stream));
+    if ((rc = fx_launch_argmax_decode(e, (const double*)d_in, rows, A, (const uint8_t*)d_al, (uint8_t*)d_out))) return rc;
+    FX_HIP(e, hipMemcpyAsync(out_chars, d_out, (size_t)rows, hipMemcpyDeviceToHost, e->stream));
+    FX_HIP(e, hipStreamSynchronize(e->stream));
+    return FX_OK;
+}
+
+// ----------------------------------------------------- NoisyAbstractModel
+static int min_dist_common(fx_engine* e, int mode, const uint8_t* queries, int64_t Q, const uint8_t* d_cache,
+                           int64_t C, int L, int32_t* dist, int64_t* argmin) {
+    if (mode != FX_LEVENSHTEIN && mode != FX_HAMMING) return fx_fail(e, FX_EINVAL, "unknown distance mode");
+    if (Q == 0) return FX_OK;
+    if (C == 0) {                                           // noisy_abstract_model.py:44-45
+        for (int64_t i = 0; i < Q; ++i) { dist[i] = 0; argmin[i] = -1; }
+        return FX_OK;
+    }
+    int rc;
+    for (int64_t q0 = 0; q0 < Q; q0 += 32768) {
+        const int64_t qn = std::min<int64_t>(32768, Q - q0);
+        void *d_q = nullptr, *d_res = nullptr;
+        if ((rc = fx_scratch(e, 0, (size_t)qn * L + 16, &d_q))) return rc;
+        if ((rc = fx_scratch(e, 1, (size_t)qn * 24, &d_res))) return rc;
+        unsigned long long* d_keys = (unsigned long long*)d_res;
+        int64_t* d_arg = (int64_t*)((char*)d_res + (size_t)qn * 8);
+        int32_t* d_dist = (int32_t*)((char*)d_res + (size_t)qn * 16);
+        FX_HIP(e, hipMemcpyAsync(d_q, queries + q0 * L, (size_t)qn * L, hipMemcpyHostToDevice, e->stream));
+        if ((rc = fx_launch_min_dist(e, mode, (const uint8_t*)d_q, qn, d_cache, C, L, d_keys))) return rc;
+        if ((rc = fx_launch_min_dist_finish(e, d_keys, qn, C, d_dist, d_arg))) return rc;
+        FX_HIP(e, hipMemcpyAsync(dist + q0, d_dist, (size_t)qn * 4, hipMemcpyDeviceToHost, e->stream));
+        FX_HIP(e, hipMemcpyAsync(argmin + q0, d_arg, (size_t)qn * 8, hipMemcpyDeviceToHost, e->stream));
+        FX_HIP(e, hipStreamSynchronize(e->stream));
+    }
+    return FX_OK;
+}
+
+int fx_min_dist(fx_engine* e, int mode, const uint8_t* queries, int64_t Q, const uint8_t* cache, int64_t C, int L,
+                int32_t* dist, int64_t* argmin) {
+    if (!e || Q < 0 || C < 0 || L < 0) return FX_EINVAL;
+    if (Q > 0 && (!queries || !dist || !argmin)) return fx_fail(e, FX_EINVAL, "null buffer");
+    if (C > 0 && !cache) return fx_fail(e, FX_EINVAL, "null cache buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    void* d_cache = nullptr;
+    if (C > 0 && Q > 0) {
+        int rc = fx_scratch(e, 2, (size_t)C * L + 16, &d_cache);
+        if (rc) return rc;
+        FX_HIP(e, hipMemcpyAsync(d_cache, cache, (size_t)C * L, hipMemcpyHostToDevice, e->stream));
+    }
+    return min_dist_common(e, mode, queries, Q, (const uint8_t*)d_cache, C, L, dist, argmin);
+}
+
+int fx_cache_create(fx_engine* e, int L, fx_cache** out) {
+    if (!e || !out || L < 0) return FX_EINVAL;
+    fx_cache* c = new (std::nothrow) fx_cache();
+    if (!c) return FX_ENOMEM;
+    c->eng = e; c->L = L;
+    *out = c;
+    return FX_OK;
+}
+
+int fx_cache_destroy(fx_cache* c) {
+    if (!c) return FX_OK;
+    (void)hipSetDevice(c->eng->device);
+    (void)hipStreamSynchronize(c->eng->stream);
+    if (c->d_keys) (void)hipFree(c->d_keys);
+    delete c;
+    return FX_OK;
+}
+
+int64_t fx_cache_size(const fx_cache* c) { return c ? c->size : FX_EINVAL; }
+
+int fx_cache_append(fx_cache* c, const uint8_t* keys, int64_t n) {
+    if (!c || n < 0) return FX_EINVAL;
+    if (n == 0) return FX_OK;
+    fx_engine* e = c->eng;
+    if (!keys) return fx_fail(e, FX_EINVAL, "null buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    const size_t rowb = (size_t)std::max(c->L, 1);
+    if (c->size + n > c->capacity) {
+        int64_t cap = std::max<int64_t>(c->capacity * 2, std::max<int64_t>(c->size + n, 4096));
+        uint8_t* nk = nullptr;
+        if (hipMalloc(&nk, (size_t)cap * rowb + 16) != hipSuccess) { (void)hipGetLastError(); return fx_fail(e, FX_ENOMEM, "cache grow failed"); }
+        FX_HIP(e, hipStreamSynchronize(e->stream));
+        if (c->size) FX_HIP(e, hipMemcpy(nk, c->d_keys, (size_t)c->size * rowb, hipMemcpyDeviceToDevice));
+        if (c->d_keys) FX_HIP(e, hipFree(c->d_keys));
+        c->d_keys = nk; c->capacity = cap;
+    }
+    FX_HIP(e, hipMemcpy(c->d_keys + (size_t)c->size * rowb, keys, (size_t)n * rowb, hipMemcpyHostToDevice));
+    c->size += n;
+    return FX_OK;
+}
+
+int fx_cache_min_dist(fx_cache* c, int mode, const uint8_t* queries, int64_t Q, int32_t* dist, int64_t* argmin) {
+    if (!c || Q < 0) return FX_EINVAL;
+    fx_engine* e = c->eng;
+    if (Q > 0 && (!queries || !dist || !argmin)) return fx_fail(e, FX_EINVAL, "null buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    return min_dist_common(e, mode, queries, Q, c->d_keys, c->size, c->L, dist, argmin);
+}
+
+int fx_nam_combine(fx_engine* e, int64_t Q, const double* signal, const double* noise, const int32_t* d,
+                   const double* alpha_tab, int n_tab, double* out) {
+    if (!e || Q < 0 || n_tab < 1) return FX_EINVAL;
+    if (Q == 0) return FX_OK;
+    if (!signal || !noise || !d || !alpha_tab || !out) return fx_fail(e, FX_EINVAL, "null buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    const size_t qb = (size_t)Q * 8;
+    void *d_in = nullptr, *d_out = nullptr;
+    int rc;
+    if ((rc = fx_scratch(e, 0, 2 * qb + (size_t)Q * 4 + (size_t)n_tab * 8 + 64, &d_in))) return rc;
+    if ((rc = fx_scratch(e, 1, qb, &d_out))) return rc;
+    char* base = (char*)d_in;
+    double* d_sig = (double*)base;
+    double* d_noi = (double*)(base + qb);
+    double* d_tab = (double*)(base + 2 * qb);
+    int32_t* d_d = (int32_t*)(base + 2 * qb + (size_t)n_tab * 8);
+    FX_HIP(e, hipMemcpyAsync(d_sig, signal, qb, hipMemcpyHostToDevice, e->stream));
+    FX_HIP(e, hipMemcpyAsync(d_noi, noise, qb, hipMemcpyHostToDevice, e->stream));
+    FX_HIP(e, hipMemcpyAsync(d_tab, alpha_tab, (size_t)n_tab * 8, hipMemcpyHostToDevice, e->stream));
+    FX_HIP(e, hipMemcpyAsync(d_d, d, (size_t)Q * 4, hipMemcpyHostToDevice, e->stream));
+    if ((rc = fx_launch_nam_combine(e, Q, d_sig, d_noi, d_d, d_tab, n_tab, (double*)d_out))) return rc;
+    FX_HIP(e, hipMemcpyAsync(out, d_out, qb, hipMemcpyDeviceToHost, e->stream));
+    FX_HIP(e, hipStreamSynchronize(e->stream));
+    return FX_OK;
+}
+
+// --------------------------------------------------------------- debug / test
+// Host-only helpers (no device needed) exported so the CPU test-suite can check
+// the weight packing and the bit-parallel distance without a GPU.
+int64_t fx_debug_packed_size(int kind, int L, int A, int F, int H, int K) {
+    return fx_pack_layout(FxShape{kind, L, A, F, H, K}).total_floats;
+}
+int fx_debug_pack_layout(int kind, int L, int A, int F, int H, int K, int64_t* out12) {
+    if (!out12) return FX_EINVAL;
+    const FxPackLayout p = fx_pack_layout(FxShape{kind, L, A, F, H, K});
+    const int64_t v[12] = {p.FT, p.HT, p.SG1, p.off_first, p.off_c2, p.off_c3, p.off_cb, p.conv_floats,
+                           p.off_d1, p.off_d2, p.off_d3, p.off_db};
+    std::memcpy(out12, v, sizeof(v));
+    return FX_OK;
+}
+int fx_debug_pack_weights(int kind, int L, int A, int F, int H, int K, const float* blob, int64_t n, float* packed,
+                          int64_t cap) {
+    const FxShape s{kind, L, A, F, H, K};
+    if (!blob || !packed || n != fx_num_params(s) || cap < fx_pack_layout(s).total_floats) return FX_EINVAL;
+    fx_pack_weights(s, blob, packed);
+    return FX_OK;
+}
+int fx_debug_myers(const uint8_t* a, int la, const uint8_t* b, int lb) {
+    // pattern = a, text = b; same code path as the device kernel (myers.h)
+    if (la > 256 || la < 0 || lb < 0) return -1;
+    static thread_local uint64_t peq[256 * 4];
+    std::memset(peq, 0, sizeof(peq));
+    for (int i = 0; i < la; ++i) peq[a[i] * 4 + (i >> 6)] |= 1ull << (i & 63);
+    auto pf = [&](int c, int w) { return peq[c * 4 + w]; };
+    auto tf = [&](int i) { return (int)b[i]; };
+    const int W = (la + 63) / 64;
+    switch (W) {
+        case 0:
+        case 1: return fx_myers_distance<1>(la, lb, pf, tf);
+        case 2: return fx_myers_distance<2>(la, lb, pf, tf);
+        case 3: return fx_myers_distance<3>(la, lb, pf, tf);
+        default: return fx_myers_distance<4>(la, lb, pf, tf);
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,122 @@
+// Internal declarations shared by the translation units of libflexs_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/flexs_amd.h"
+
+#define FX_MAX_M 16          // models fused per launch (larger ensembles are split)
+#define FX_ERR_BADCHAR 1u    // bit in the deferred device error word
+
+// ---------------------------------------------------------------- shapes
+struct FxShape {
+    int kind, L, A, F, H, K;
+    int K3() const { return A - 1; }
+    int L1() const { return L - K + 1; }
+};
+
+// Packed (MFMA fragment) layout of one model's weights; all offsets in floats.
+// A "block" is 64 lanes x 4 floats: block[lane][r] = W[kin(lane, r)][16*mo + (lane & 15)],
+// i.e. the A operand (weights^T, M = output channels) of four consecutive
+// v_mfma_f32_16x16x4_f32 k-steps, fetched with one ds_read_b128 per lane.
+//   dense-style blocks (conv2/conv3 taps, dense layers; input = a previous MFMA result tile mi):
+//       kin = 16*mi + 4*(lane >> 4) + r        (k-step r consumes accumulator register r)
+//   first-layer blocks (one-hot input; conv1 or MLP layer 1; step group sg):
+//       kin = 16*sg + 4*r + (lane >> 4)        (k-step s = 4*sg + r covers rows 4s .. 4s+3)
+struct FxPackLayout {
+    int FT, HT;                 // output tiles of 16: filters, hidden units
+    int SG1;                    // first-layer step groups = ceil(rows / 16)
+    int64_t off_first;          // SG1 x (FT|HT) blocks
+    int64_t off_c2, off_c3;     // K x FT x FT, K3 x FT x FT blocks           (CNN)
+    int64_t off_cb;             // b1[16FT] b2[16FT] b3[16FT]                 (CNN)
+    int64_t conv_floats;        // everything above (the part that must sit in LDS)
+    int64_t off_d1, off_d2, off_d3;  // dense blocks: CNN d1 FTxHT, d2 HTxHT; MLP d2, d3 HTxHT; GE d3 HTxHT
+    int64_t off_db;             // bias / vector area (layout per kind, see pack.cpp)
+    int64_t total_floats;
+};
+
+FxPackLayout fx_pack_layout(const FxShape& s);
+int64_t fx_num_params(const FxShape& s);
+// Keras get_weights() blob -> packed fragment layout (host only, no device needed).
+void fx_pack_weights(const FxShape& s, const float* blob, float* packed);
+
+// ---------------------------------------------------------------- handles
+struct fx_engine {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string last_error;
+    // deferred error word (device) + pinned host mirror
+    unsigned* d_err = nullptr;
+    unsigned* h_err = nullptr;
+    // cached device LUT
+    uint8_t* d_lut = nullptr;
+    uint8_t h_lut[256];
+    bool lut_valid = false;
+    // growable scratch
+    void* d_scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[4] = {0, 0, 0, 0};
+    void* h_pinned[2] = {nullptr, nullptr};
+    size_t pinned_bytes[2] = {0, 0};
+    // options
+    int64_t force_generic = 0;
+    int64_t cnn_variant = 0;    // 0 = auto
+    int64_t grid_blocks = 0;    // 0 = auto (one per CU)
+    int num_cus = 256;
+    int max_lds = 160 * 1024;
+};
+
+struct fx_model {
+    fx_engine* eng = nullptr;
+    FxShape shape{};
+    FxPackLayout layout{};
+    std::vector<float> blob;    // host copy, Keras order
+    float* d_blob = nullptr;    // device copy, Keras order (generic kernels)
+    float* d_packed = nullptr;  // device copy, fragment layout (MFMA kernels)
+    bool has_weights = false;
+};
+
+struct fx_cache {
+    fx_engine* eng = nullptr;
+    int L = 0;
+    int64_t size = 0, capacity = 0;
+    uint8_t* d_keys = nullptr;  // capacity x L bytes, row-major, insertion order
+};
+
+// ---------------------------------------------------------------- helpers
+int fx_fail(fx_engine* e, int status, const std::string& msg);
+#define FX_HIP(e, call)                                                                   \
+    do {                                                                                  \
+        hipError_t _err = (call);                                                         \
+        if (_err != hipSuccess)                                                           \
+            return fx_fail((e), FX_EHIP, std::string(#call) + ": " + hipGetErrorString(_err)); \
+    } while (0)
+
+int fx_scratch(fx_engine* e, int slot, size_t bytes, void** out);
+int fx_pinned(fx_engine* e, int slot, size_t bytes, void** out);
+int fx_upload_lut(fx_engine* e, const uint8_t lut[256]);
+
+// ---------------------------------------------------------------- kernel launchers
+// (defined in the .hip files; all enqueue on e->stream and return an fx_status)
+int fx_launch_score_generic(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii,
+                            int64_t N, float* d_out_NM, int Mtot, int m_off);
+// returns FX_EUNSUPPORTED if no MFMA instantiation matches (caller falls back to generic)
+int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii,
+                             int64_t N, float* d_out_NM, int Mtot, int m_off);
+int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii,
+                               int64_t N, float* d_out_NM, int Mtot, int m_off);
+int fx_launch_encode_onehot(fx_engine* e, const uint8_t* d_ascii, int64_t N, int L, int A, float* d_out);
+int fx_launch_ensemble_reduce(fx_engine* e, const float* d_scores, int64_t N, int M,
+                              const double* d_weights, float* d_out32, double* d_out64);
+int fx_launch_argmax_decode(fx_engine* e, const double* d_onehot, int64_t rows, int A,
+                            const uint8_t* d_alphabet, uint8_t* d_out);
+int fx_launch_nam_combine(fx_engine* e, int64_t Q, const double* d_signal, const double* d_noise,
+                          const int32_t* d_dist, const double* d_alpha, int n_tab, double* d_out);
+int fx_launch_min_dist(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, const uint8_t* d_cache,
+                       int64_t C, int L, unsigned long long* d_keys);
+int fx_launch_min_dist_finish(fx_engine* e, const unsigned long long* d_keys, int64_t Q, int64_t C,
+                              int32_t* d_dist, int64_t* d_arg);

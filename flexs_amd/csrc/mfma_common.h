@@ -1,0 +1,108 @@
+// Device helpers shared by the MFMA scoring kernels (gfx950 only).
+//
+// Formulation.  Every layer is computed TRANSPOSED:  Out^T[ch_out][seq] =
+// W^T[ch_out][ch_in] * In^T[ch_in][seq], with v_mfma_f32_16x16x4_f32:
+//   A operand (16 x 4)  = weights^T   lane l holds A[i = l & 15][k = l >> 4]
+//   B operand (4 x 16)  = activations lane l holds B[k = l >> 4][j = l & 15]   (j = sequence)
+//   C/D       (16 x 16)               lane l, reg r holds D[row = 4*(l >> 4) + r][col = l & 15]
+// so a lane always owns ONE sequence (l & 15) and the lane group g = l >> 4
+// owns channels 16*tile + 4*g + r.  Feeding accumulator register r of tile mi
+// straight back as the B operand of k-step (mi, r) of the next layer contracts
+// over channels {16*mi + 4*g + r : g = 0..3} -- the weights are pre-permuted on
+// the host to match (pack.cpp), so activations never leave registers between
+// layers: no LDS round trip, no transposes.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f4 relu4(f4 v) {
+    f4 r;
+    r.x = fmaxf(v.x, 0.f); r.y = fmaxf(v.y, 0.f); r.z = fmaxf(v.z, 0.f); r.w = fmaxf(v.w, 0.f);
+    return r;
+}
+__device__ __forceinline__ f4 max4(f4 a, f4 b) {
+    f4 r;
+    r.x = fmaxf(a.x, b.x); r.y = fmaxf(a.y, b.y); r.z = fmaxf(a.z, b.z); r.w = fmaxf(a.w, b.w);
+    return r;
+}
+__device__ __forceinline__ f4 splat4(float v) { f4 r = {v, v, v, v}; return r; }
+
+__device__ __forceinline__ float fx_nan_to_num(float v) {
+    // np.nan_to_num (keras_model.py:77)
+    if (v != v) return 0.f;
+    if (v > 3.4028234663852886e38f) return 3.4028234663852886e38f;
+    if (v < -3.4028234663852886e38f) return -3.4028234663852886e38f;
+    return v;
+}
+
+// acc[mo][nt] += W-blocks(mi, mo) applied to in[mi][nt], for all mi < TI, mo < TO.
+// wblk points at block (mi = 0, mo = 0); blocks are ordered mi-major, 64 f4 each.
+// Loop order (mi, r, mo, nt) keeps >= TO*NT independent MFMAs between two
+// accumulations into the same register quad (16x16x4 f32: 32-cycle issue,
+// 40-cycle dependent latency).
+template <int TI, int TO, int NT, typename WPtr>
+__device__ __forceinline__ void mma_layer(WPtr wblk, const f4 (&in)[TI][NT], f4 (&acc)[TO][NT], int lane) {
+#pragma unroll
+    for (int mi = 0; mi < TI; ++mi) {
+        f4 a[TO];
+#pragma unroll
+        for (int mo = 0; mo < TO; ++mo) a[mo] = wblk[(mi * TO + mo) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mo = 0; mo < TO; ++mo)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mo][nt] = mfma16(a[mo][r], in[mi][nt][r], acc[mo][nt]);
+    }
+}
+
+// acc[mo][nt] = bias[16*mo + 4*g .. +3] broadcast over the lane's sequence
+template <int TO, int NT, typename BPtr>
+__device__ __forceinline__ void init_bias(BPtr bias, f4 (&acc)[TO][NT], int g) {
+#pragma unroll
+    for (int mo = 0; mo < TO; ++mo) {
+        const f4 b = *reinterpret_cast<const f4*>(&bias[16 * mo + 4 * g]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mo][nt] = b;
+    }
+}
+
+template <int T, int NT>
+__device__ __forceinline__ void relu_tiles(f4 (&x)[T][NT]) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) x[t][nt] = relu4(x[t][nt]);
+}
+
+// final H -> 1 layer: out[seq] = b + sum_ch w[ch] * h[ch][seq].  Each lane sums its
+// 4*HT channels, the four lane groups are combined with two cross-lane adds.
+template <int HT, int NT, typename VPtr>
+__device__ __forceinline__ void final_dot(VPtr wv, float bout, const f4 (&h)[HT][NT], float (&out)[NT], int g) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) out[nt] = 0.f;
+#pragma unroll
+    for (int mo = 0; mo < HT; ++mo) {
+        const f4 w = *reinterpret_cast<const f4*>(&wv[16 * mo + 4 * g]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            out[nt] = fmaf(w.x, h[mo][nt].x, out[nt]);
+            out[nt] = fmaf(w.y, h[mo][nt].y, out[nt]);
+            out[nt] = fmaf(w.z, h[mo][nt].z, out[nt]);
+            out[nt] = fmaf(w.w, h[mo][nt].w, out[nt]);
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        out[nt] += __shfl_xor(out[nt], 16);
+        out[nt] += __shfl_xor(out[nt], 32);
+        out[nt] += bout;
+    }
+}

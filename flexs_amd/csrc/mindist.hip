@@ -1,0 +1,114 @@
+// K4 min_dist: NoisyAbstractModel._get_min_distance (noisy_abstract_model.py:42-60)
+// for Q queries against C cache keys (insertion order), integer-exact.
+//
+// grid = (cache chunks, queries).  A block builds the query's 256-entry match-mask
+// table in LDS once, every thread then runs the bit-parallel Levenshtein
+// (myers.h) -- or a byte-compare Hamming -- against its cache entries and the
+// block folds (remapped distance, cache index) with a 64-bit min:
+//     key = (d' << 32) | index,   d' = 0 if d == 1, 1 if d == 0, d otherwise
+// which is exactly the reference's loop: the FIRST entry at distance 1 wins
+// outright (early `return`, :53-54), otherwise the first strict minimum (:56-58).
+// Integer VALU bound; HBM traffic is the cache once per query row (L2-resident).
+#include "fx_common.h"
+#include "myers.h"
+
+namespace {
+
+constexpr int CHUNK = 1024;     // cache entries per block
+
+template <int W>
+__global__ void __launch_bounds__(256) k_min_dist(int mode, const uint8_t* __restrict__ q, const uint8_t* __restrict__ cache,
+                                                  int64_t C, int L, unsigned long long* __restrict__ keys) {
+    __shared__ uint64_t peq[256 * W];
+    __shared__ uint8_t qs[W * 64];
+    __shared__ unsigned long long wave_min[4];
+    const int tid = threadIdx.x;
+    const int64_t qi = blockIdx.y;
+    for (int i = tid; i < L; i += 256) qs[i] = q[qi * L + i];
+    __syncthreads();
+    {   // thread c builds the masks of byte value c
+        uint64_t mk[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) mk[w] = 0;
+        for (int i = 0; i < L; ++i)
+            if (qs[i] == tid) {
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                    if ((i >> 6) == w) mk[w] |= 1ull << (i & 63);
+            }
+#pragma unroll
+        for (int w = 0; w < W; ++w) peq[tid * W + w] = mk[w];
+    }
+    __syncthreads();
+
+    unsigned long long best = ~0ull;
+    const int64_t c0 = (int64_t)blockIdx.x * CHUNK;
+    for (int k = 0; k < CHUNK / 256; ++k) {
+        const int64_t c = c0 + k * 256 + tid;
+        if (c >= C) break;
+        const uint8_t* t = cache + c * L;
+        int d;
+        if (mode == FX_HAMMING) {
+            d = 0;
+            for (int i = 0; i < L; ++i) d += (t[i] != qs[i]);
+        } else {
+            d = fx_myers_distance<W>(
+                L, L, [&](int ch, int w) { return peq[ch * W + w]; }, [&](int i) { return (int)t[i]; });
+        }
+        const unsigned dp = d == 1 ? 0u : (d == 0 ? 1u : (unsigned)d);
+        const unsigned long long key = ((unsigned long long)dp << 32) | (unsigned long long)c;
+        best = key < best ? key : best;
+    }
+    // wave min, then block min, then one atomic
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long o = __shfl_xor(best, off);
+        best = o < best ? o : best;
+    }
+    if ((tid & 63) == 0) wave_min[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long b = wave_min[0];
+        for (int w = 1; w < 4; ++w) b = wave_min[w] < b ? wave_min[w] : b;
+        if (b != ~0ull) atomicMin(&keys[qi], b);
+    }
+}
+
+__global__ void k_min_dist_finish(const unsigned long long* __restrict__ keys, int64_t Q, int32_t* __restrict__ dist,
+                                  int64_t* __restrict__ arg) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Q) return;
+    const unsigned long long k = keys[i];
+    const unsigned dp = (unsigned)(k >> 32);
+    dist[i] = dp == 0u ? 1 : (dp == 1u ? 0 : (int32_t)dp);
+    arg[i] = (int64_t)(k & 0xffffffffull);
+}
+
+}  // namespace
+
+int fx_launch_min_dist(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, const uint8_t* d_cache, int64_t C,
+                       int L, unsigned long long* d_keys) {
+    if (Q == 0 || C == 0) return FX_OK;
+    if (L > 256) return fx_fail(e, FX_EUNSUPPORTED, "min_dist: sequence length > 256");
+    if (Q > 65535) return fx_fail(e, FX_EINVAL, "min_dist: more than 65535 queries per call (split the batch)");
+    FX_HIP(e, hipMemsetAsync(d_keys, 0xFF, sizeof(unsigned long long) * (size_t)Q, e->stream));
+    dim3 grid((unsigned)((C + CHUNK - 1) / CHUNK), (unsigned)Q), block(256);
+    const int W = (L + 63) / 64;
+    switch (W) {
+        case 0:
+        case 1: hipLaunchKernelGGL(k_min_dist<1>, grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
+        case 2: hipLaunchKernelGGL(k_min_dist<2>, grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
+        case 3: hipLaunchKernelGGL(k_min_dist<3>, grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
+        default: hipLaunchKernelGGL(k_min_dist<4>, grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
+    }
+    FX_HIP(e, hipGetLastError());
+    return FX_OK;
+}
+
+int fx_launch_min_dist_finish(fx_engine* e, const unsigned long long* d_keys, int64_t Q, int64_t C, int32_t* d_dist,
+                              int64_t* d_arg) {
+    (void)C;
+    if (Q == 0) return FX_OK;
+    hipLaunchKernelGGL(k_min_dist_finish, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, e->stream, d_keys, Q, d_dist, d_arg);
+    FX_HIP(e, hipGetLastError());
+    return FX_OK;
+}

@@ -1,0 +1,158 @@
+// HBM-bound helper kernels: stand-alone encode (K-enc), ensemble reduce (K3),
+// NoisyAbstractModel blend (K5), argmax decode (K6).
+#include "fx_common.h"
+
+namespace {
+
+// ---- string_to_one_hot over a batch (sequence_utils.py:32-47, keras_model.py:70-75).
+// One thread per (sequence, position): reads 1 byte, writes A floats (one
+// 16-byte store when A == 4).  Algorithmic bytes per sequence: L + 4*L*A.
+template <int AT>
+__global__ void k_encode_onehot(const uint8_t* __restrict__ ascii, const uint8_t* __restrict__ lut,
+                                int64_t rows, int A, float* __restrict__ out, unsigned* err) {
+    __shared__ uint8_t lut_s[256];
+    if (threadIdx.x < 64)
+        reinterpret_cast<uint32_t*>(lut_s)[threadIdx.x] = reinterpret_cast<const uint32_t*>(lut)[threadIdx.x];
+    __syncthreads();
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
+        int c = lut_s[ascii[i]];
+        if (c == 0xFF) { bad = true; c = -1; }
+        if (AT == 4) {
+            float4 v = make_float4(c == 0, c == 1, c == 2, c == 3);
+            reinterpret_cast<float4*>(out)[i] = v;
+        } else {
+            float* o = out + i * A;
+            for (int a = 0; a < A; ++a) o[a] = (a == c) ? 1.f : 0.f;
+        }
+    }
+    if (bad) atomicOr(err, FX_ERR_BADCHAR);
+}
+
+// ---- NumPy pairwise summation order of one contiguous row (ensemble.py:24:
+// np.mean(x, axis=1) on the stacked float32 matrix).  Restated from NumPy's
+// pairwise_sum; verified bit-exact against numpy 2.2 (tests/test_oracle.py).
+template <typename T, typename Load>
+__device__ T np_pairwise(Load ld, int64_t base, int n) {
+    if (n < 8) {
+        T r = T(0);
+        for (int i = 0; i < n; ++i) r += ld(base + i);
+        return r;
+    }
+    if (n <= 128) {
+        T r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = ld(base + k);
+        int i = 8;
+        for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r[k] += ld(base + i + k);
+        }
+        T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += ld(base + i);
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise<T>(ld, base, n2) + np_pairwise<T>(ld, base + n2, n - n2);
+}
+
+// mean over members, float32 (Ensemble default combine_with)
+__global__ void k_ensemble_mean(const float* __restrict__ s, int64_t N, int M, float* __restrict__ out) {
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        auto ld = [&](int64_t i) { return s[i]; };
+        float sum = np_pairwise<float>(ld, n * M, M);
+        out[n] = sum / (float)M;
+    }
+}
+
+// AdaptiveEnsemble: np.sum(weights * scores, axis=1) -- float64 product then
+// pairwise float64 sum (adaptive_ensemble.py:54,102)
+__global__ void k_ensemble_wsum(const float* __restrict__ s, int64_t N, int M, const double* __restrict__ w,
+                                double* __restrict__ out) {
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = n * M;
+        auto ld = [&](int64_t i) { return w[i - b] * (double)s[i]; };
+        out[n] = np_pairwise<double>(ld, b, M);
+    }
+}
+
+// ---- noisy_abstract_model.py:93-94:  alpha*signal + (1 - alpha)*noise, alpha = ss**d (host table)
+__global__ void k_nam_combine(int64_t Q, const double* __restrict__ signal, const double* __restrict__ noise,
+                              const int32_t* __restrict__ d, const double* __restrict__ alpha_tab, int n_tab,
+                              double* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < Q; i += (int64_t)gridDim.x * blockDim.x) {
+        int di = d[i];
+        di = di < 0 ? 0 : (di >= n_tab ? n_tab - 1 : di);
+        const double alpha = alpha_tab[di];
+        // same operation order as the Python expression: (alpha*signal) + ((1-alpha)*noise)
+        out[i] = __dadd_rn(__dmul_rn(alpha, signal[i]), __dmul_rn(1.0 - alpha, noise[i]));
+    }
+}
+
+// ---- one_hot_to_string (sequence_utils.py:65-66): per-row np.argmax, first max wins, NaN = max
+__global__ void k_argmax_decode(const double* __restrict__ x, int64_t rows, int A,
+                                const uint8_t* __restrict__ alphabet, uint8_t* __restrict__ out) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+        const double* row = x + r * A;
+        int best = 0;
+        double bv = row[0];
+        for (int a = 1; a < A; ++a) {
+            const double v = row[a];
+            if (v > bv || (v != v && bv == bv)) { best = a; bv = v; }
+        }
+        out[r] = alphabet[best];
+    }
+}
+
+inline unsigned grid_for(int64_t n, int block, int cus) {
+    int64_t g = (n + block - 1) / block;
+    int64_t cap = (int64_t)cus * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+int fx_launch_encode_onehot(fx_engine* e, const uint8_t* d_ascii, int64_t N, int L, int A, float* d_out) {
+    const int64_t rows = N * L;
+    if (rows == 0) return FX_OK;
+    dim3 grid(grid_for(rows, 256, e->num_cus)), block(256);
+    if (A == 4)
+        hipLaunchKernelGGL(k_encode_onehot<4>, grid, block, 0, e->stream, d_ascii, e->d_lut, rows, A, d_out, e->d_err);
+    else
+        hipLaunchKernelGGL(k_encode_onehot<0>, grid, block, 0, e->stream, d_ascii, e->d_lut, rows, A, d_out, e->d_err);
+    FX_HIP(e, hipGetLastError());
+    return FX_OK;
+}
+
+int fx_launch_ensemble_reduce(fx_engine* e, const float* d_scores, int64_t N, int M, const double* d_weights,
+                              float* d_out32, double* d_out64) {
+    if (N == 0) return FX_OK;
+    dim3 grid(grid_for(N, 256, e->num_cus)), block(256);
+    if (d_weights == nullptr)
+        hipLaunchKernelGGL(k_ensemble_mean, grid, block, 0, e->stream, d_scores, N, M, d_out32);
+    else
+        hipLaunchKernelGGL(k_ensemble_wsum, grid, block, 0, e->stream, d_scores, N, M, d_weights, d_out64);
+    FX_HIP(e, hipGetLastError());
+    return FX_OK;
+}
+
+int fx_launch_argmax_decode(fx_engine* e, const double* d_onehot, int64_t rows, int A, const uint8_t* d_alphabet,
+                            uint8_t* d_out) {
+    if (rows == 0) return FX_OK;
+    dim3 grid(grid_for(rows, 256, e->num_cus)), block(256);
+    hipLaunchKernelGGL(k_argmax_decode, grid, block, 0, e->stream, d_onehot, rows, A, d_alphabet, d_out);
+    FX_HIP(e, hipGetLastError());
+    return FX_OK;
+}
+
+int fx_launch_nam_combine(fx_engine* e, int64_t Q, const double* d_signal, const double* d_noise,
+                          const int32_t* d_dist, const double* d_alpha, int n_tab, double* d_out) {
+    if (Q == 0) return FX_OK;
+    dim3 grid(grid_for(Q, 256, e->num_cus)), block(256);
+    hipLaunchKernelGGL(k_nam_combine, grid, block, 0, e->stream, Q, d_signal, d_noise, d_dist, d_alpha, n_tab, d_out);
+    FX_HIP(e, hipGetLastError());
+    return FX_OK;
+}

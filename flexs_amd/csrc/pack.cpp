@@ -1,0 +1,174 @@
+// Host-side weight packing: Keras get_weights() order -> MFMA fragment layout.
+// Pure C++ (no device calls) so it is unit-testable on a machine without a GPU
+// through fx_debug_pack_weights().  Layout documented in fx_common.h / DESIGN.md.
+#include <cstring>
+
+#include "fx_common.h"
+
+static inline int64_t rup(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+int64_t fx_num_params(const FxShape& s) {
+    const int64_t L = s.L, A = s.A, F = s.F, H = s.H, K = s.K;
+    switch (s.kind) {
+        case FX_CNN:   // cnn.py:23-54
+            return K * A * F + F + K * F * F + F + (A - 1) * F * F + F + F * H + H + H * H + H + H + 1;
+        case FX_MLP:   // mlp.py:21-31
+            return L * A * H + H + H * H + H + H * H + H + H + 1;
+        case FX_GE:    // global_epistasis_model.py:26-36
+            return L * A + 1 + H + H + H * H + H + H + 1;
+    }
+    return -1;
+}
+
+FxPackLayout fx_pack_layout(const FxShape& s) {
+    FxPackLayout p{};
+    p.FT = (s.F + 15) / 16;
+    p.HT = (s.H + 15) / 16;
+    const int64_t BLK = 256;
+    int64_t off = 0;
+    if (s.kind == FX_CNN) {
+        p.SG1 = (s.K * s.A + 15) / 16;
+        p.off_first = off; off += (int64_t)p.SG1 * p.FT * BLK;
+        p.off_c2 = off;    off += (int64_t)s.K * p.FT * p.FT * BLK;
+        p.off_c3 = off;    off += (int64_t)s.K3() * p.FT * p.FT * BLK;
+        p.off_cb = off;    off += 3 * 16 * p.FT;
+        p.conv_floats = off = rup(off, 4);
+        p.off_d1 = off;    off += (int64_t)p.FT * p.HT * BLK;
+        p.off_d2 = off;    off += (int64_t)p.HT * p.HT * BLK;
+        p.off_d3 = off;
+        p.off_db = off;    off += 3 * 16 * p.HT + 4;          // bd1, bd2, w3, bout
+    } else if (s.kind == FX_MLP) {
+        p.SG1 = (s.L * s.A + 15) / 16;
+        p.off_first = off; off += (int64_t)p.SG1 * p.HT * BLK;
+        p.off_c2 = p.off_c3 = p.off_cb = off;
+        p.conv_floats = off;
+        p.off_d1 = off;
+        p.off_d2 = off;    off += (int64_t)p.HT * p.HT * BLK;
+        p.off_d3 = off;    off += (int64_t)p.HT * p.HT * BLK;
+        p.off_db = off;    off += 4 * 16 * p.HT + 4;          // b1, b2, b3, w4, bout
+    } else {                                                   // FX_GE
+        p.SG1 = 0;
+        p.off_first = off; off += rup((int64_t)s.L * s.A, 4); // w1 vector, plain
+        p.off_c2 = p.off_c3 = p.off_cb = off;
+        p.conv_floats = off;
+        p.off_d1 = p.off_d2 = off;
+        p.off_d3 = off;    off += (int64_t)p.HT * p.HT * BLK;
+        p.off_db = off;    off += 4 + 4 * 16 * p.HT + 4;      // b1[4], w2, b2, b3, w4, bout
+    }
+    p.total_floats = rup(off, 4);
+    return p;
+}
+
+namespace {
+// W is [rows][cols] row-major.  dense-style block: kin = 16*mi + 4*g + r.
+void pack_dense_block(const float* W, int rows, int cols, int mi, int mo, float* blk) {
+    for (int lane = 0; lane < 64; ++lane)
+        for (int r = 0; r < 4; ++r) {
+            int kin = 16 * mi + 4 * (lane >> 4) + r;
+            int o = 16 * mo + (lane & 15);
+            blk[lane * 4 + r] = (kin < rows && o < cols) ? W[(int64_t)kin * cols + o] : 0.f;
+        }
+}
+// first-layer block: kin = 16*sg + 4*r + g.
+void pack_first_block(const float* W, int rows, int cols, int sg, int mo, float* blk) {
+    for (int lane = 0; lane < 64; ++lane)
+        for (int r = 0; r < 4; ++r) {
+            int kin = 16 * sg + 4 * r + (lane >> 4);
+            int o = 16 * mo + (lane & 15);
+            blk[lane * 4 + r] = (kin < rows && o < cols) ? W[(int64_t)kin * cols + o] : 0.f;
+        }
+}
+void pack_vec(const float* v, int n, int padded, float* dst) {
+    for (int i = 0; i < padded; ++i) dst[i] = i < n ? v[i] : 0.f;
+}
+}  // namespace
+
+void fx_pack_weights(const FxShape& s, const float* blob, float* packed) {
+    const FxPackLayout p = fx_pack_layout(s);
+    std::memset(packed, 0, sizeof(float) * (size_t)p.total_floats);
+    const int A = s.A, F = s.F, H = s.H, K = s.K, L = s.L, FT = p.FT, HT = p.HT;
+    const float* w = blob;
+    if (s.kind == FX_CNN) {
+        const int K3 = s.K3();
+        const float* w1 = w;  w += (int64_t)K * A * F;
+        const float* b1 = w;  w += F;
+        const float* w2 = w;  w += (int64_t)K * F * F;
+        const float* b2 = w;  w += F;
+        const float* w3 = w;  w += (int64_t)K3 * F * F;
+        const float* b3 = w;  w += F;
+        const float* d1 = w;  w += (int64_t)F * H;
+        const float* c1 = w;  w += H;
+        const float* d2 = w;  w += (int64_t)H * H;
+        const float* c2 = w;  w += H;
+        const float* d3 = w;  w += H;
+        const float* c3 = w;
+        for (int sg = 0; sg < p.SG1; ++sg)
+            for (int mo = 0; mo < FT; ++mo)
+                pack_first_block(w1, K * A, F, sg, mo, packed + p.off_first + ((int64_t)sg * FT + mo) * 256);
+        for (int j = 0; j < K; ++j)
+            for (int mi = 0; mi < FT; ++mi)
+                for (int mo = 0; mo < FT; ++mo)
+                    pack_dense_block(w2 + (int64_t)j * F * F, F, F, mi, mo,
+                                     packed + p.off_c2 + (((int64_t)j * FT + mi) * FT + mo) * 256);
+        for (int j = 0; j < K3; ++j)
+            for (int mi = 0; mi < FT; ++mi)
+                for (int mo = 0; mo < FT; ++mo)
+                    pack_dense_block(w3 + (int64_t)j * F * F, F, F, mi, mo,
+                                     packed + p.off_c3 + (((int64_t)j * FT + mi) * FT + mo) * 256);
+        pack_vec(b1, F, 16 * FT, packed + p.off_cb);
+        pack_vec(b2, F, 16 * FT, packed + p.off_cb + 16 * FT);
+        pack_vec(b3, F, 16 * FT, packed + p.off_cb + 32 * FT);
+        for (int mi = 0; mi < FT; ++mi)
+            for (int mo = 0; mo < HT; ++mo)
+                pack_dense_block(d1, F, H, mi, mo, packed + p.off_d1 + ((int64_t)mi * HT + mo) * 256);
+        for (int mi = 0; mi < HT; ++mi)
+            for (int mo = 0; mo < HT; ++mo)
+                pack_dense_block(d2, H, H, mi, mo, packed + p.off_d2 + ((int64_t)mi * HT + mo) * 256);
+        pack_vec(c1, H, 16 * HT, packed + p.off_db);
+        pack_vec(c2, H, 16 * HT, packed + p.off_db + 16 * HT);
+        pack_vec(d3, H, 16 * HT, packed + p.off_db + 32 * HT);
+        packed[p.off_db + 48 * HT] = c3[0];
+    } else if (s.kind == FX_MLP) {
+        const float* d1 = w;  w += (int64_t)L * A * H;
+        const float* c1 = w;  w += H;
+        const float* d2 = w;  w += (int64_t)H * H;
+        const float* c2 = w;  w += H;
+        const float* d3 = w;  w += (int64_t)H * H;
+        const float* c3 = w;  w += H;
+        const float* d4 = w;  w += H;
+        const float* c4 = w;
+        for (int sg = 0; sg < p.SG1; ++sg)
+            for (int mo = 0; mo < HT; ++mo)
+                pack_first_block(d1, L * A, H, sg, mo, packed + p.off_first + ((int64_t)sg * HT + mo) * 256);
+        for (int mi = 0; mi < HT; ++mi)
+            for (int mo = 0; mo < HT; ++mo) {
+                pack_dense_block(d2, H, H, mi, mo, packed + p.off_d2 + ((int64_t)mi * HT + mo) * 256);
+                pack_dense_block(d3, H, H, mi, mo, packed + p.off_d3 + ((int64_t)mi * HT + mo) * 256);
+            }
+        pack_vec(c1, H, 16 * HT, packed + p.off_db);
+        pack_vec(c2, H, 16 * HT, packed + p.off_db + 16 * HT);
+        pack_vec(c3, H, 16 * HT, packed + p.off_db + 32 * HT);
+        pack_vec(d4, H, 16 * HT, packed + p.off_db + 48 * HT);
+        packed[p.off_db + 64 * HT] = c4[0];
+    } else {
+        const float* d1 = w;  w += (int64_t)L * A;
+        const float* c1 = w;  w += 1;
+        const float* d2 = w;  w += H;
+        const float* c2 = w;  w += H;
+        const float* d3 = w;  w += (int64_t)H * H;
+        const float* c3 = w;  w += H;
+        const float* d4 = w;  w += H;
+        const float* c4 = w;
+        pack_vec(d1, L * A, (int)rup((int64_t)L * A, 4), packed + p.off_first);
+        for (int mi = 0; mi < HT; ++mi)
+            for (int mo = 0; mo < HT; ++mo)
+                pack_dense_block(d3, H, H, mi, mo, packed + p.off_d3 + ((int64_t)mi * HT + mo) * 256);
+        float* db = packed + p.off_db;
+        db[0] = c1[0];
+        pack_vec(d2, H, 16 * HT, db + 4);
+        pack_vec(c2, H, 16 * HT, db + 4 + 16 * HT);
+        pack_vec(c3, H, 16 * HT, db + 4 + 32 * HT);
+        pack_vec(d4, H, 16 * HT, db + 4 + 48 * HT);
+        db[4 + 64 * HT] = c4[0];
+    }
+}

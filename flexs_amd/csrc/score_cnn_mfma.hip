@@ -1,0 +1,304 @@
+// K1 score_cnn: string -> one-hot -> Conv1D x3 -> GlobalMaxPool -> Dense x3, fused, on f32 MFMA.
+//
+// Replaces, per (sequence, ensemble member):  sequence_utils.py:32-47 (encode),
+// keras_model.py:69-79 (tensor + predict + nan_to_num), cnn.py:23-54 (layers).
+//
+// One wave owns NT tiles of 16 sequences and streams over sequence positions,
+// keeping sliding windows of the conv1 / conv2 outputs in registers (see
+// mfma_common.h for the transposed-MFMA formulation).  Weights of the member
+// being scored sit in LDS in fragment order (pack.cpp); work units are
+// (member, tile-group) pairs, flattened member-major and split evenly over the
+// grid, so a block reloads LDS at most once per member boundary it straddles.
+//
+// Algorithmic work per sequence per member: L + 4 bytes of HBM
+// traffic, 2 * MACs FLOP with MACs = L1*K*A*F + L1*K*F*F + L1*(A-1)*F*F + F*H + H*H + H.
+// The kernel is f32-MFMA-bound (157.3 TFLOP/s peak), not HBM-bound.
+#include "fx_common.h"
+#include "mfma_common.h"
+
+namespace {
+
+struct CnnArgs {
+    const uint8_t* ascii;       // N x L
+    const uint8_t* lut;         // 256
+    const float* w[FX_MAX_M];   // packed weights per member
+    float* out;                 // N x Mtot
+    unsigned* err;
+    int64_t N;
+    int64_t TG;                 // tile groups per member = ceil(N / (16*NT))
+    int M, Mtot, m_off;
+    int L;
+    // packed-layout offsets (floats)
+    int off_first, off_c2, off_c3, off_cb, conv_floats, off_d1, off_d2, off_db, total_floats;
+};
+
+template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
+    constexpr int K3 = A - 1;
+    constexpr int PL2 = (K - 1) / 2, PR2 = K - 1 - PL2;
+    constexpr int PL3 = (K3 - 1) / 2, PR3 = K3 - 1 - PL3;
+    constexpr int S1 = (K * A + 3) / 4;                 // conv1 k-steps
+    static_assert(A % 4 == 0, "one-hot k-steps must not straddle a tap");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int g = lane >> 4, sq = lane & 15;
+    const int L = p.L, L1 = L - K + 1;
+    const int lds_floats = DENSE_LDS ? p.total_floats : p.conv_floats;
+    uint8_t* lut_s = reinterpret_cast<uint8_t*>(smem + lds_floats);
+
+    for (int i = tid; i < 64; i += blockDim.x)
+        reinterpret_cast<uint32_t*>(lut_s)[i] = reinterpret_cast<const uint32_t*>(p.lut)[i];
+
+    const int64_t U = (int64_t)p.M * p.TG;
+    const int64_t u_lo = U * blockIdx.x / gridDim.x, u_hi = U * (blockIdx.x + 1) / gridDim.x;
+    if (u_lo >= u_hi) return;
+    const int m_first = (int)(u_lo / p.TG), m_last = (int)((u_hi - 1) / p.TG);
+    bool bad = false;
+
+    for (int m = m_first; m <= m_last; ++m) {
+        __syncthreads();                                 // previous member's readers are done
+        {
+            const f4* src = reinterpret_cast<const f4*>(p.w[m]);
+            f4* dst = reinterpret_cast<f4*>(smem);
+            for (int i = tid; i < lds_floats / 4; i += blockDim.x) dst[i] = src[i];
+        }
+        __syncthreads();
+        const f4* w_first = reinterpret_cast<const f4*>(smem + p.off_first);
+        const f4* w_c2 = reinterpret_cast<const f4*>(smem + p.off_c2);
+        const f4* w_c3 = reinterpret_cast<const f4*>(smem + p.off_c3);
+        const float* cb = smem + p.off_cb;
+        const float* dbase = DENSE_LDS ? smem : p.w[m];
+        const f4* w_d1 = reinterpret_cast<const f4*>(dbase + p.off_d1);
+        const f4* w_d2 = reinterpret_cast<const f4*>(dbase + p.off_d2);
+        const float* db = dbase + p.off_db;
+
+        const int64_t t_lo = (u_lo > (int64_t)m * p.TG ? u_lo : (int64_t)m * p.TG) - (int64_t)m * p.TG;
+        const int64_t t_hi = (u_hi < (int64_t)(m + 1) * p.TG ? u_hi : (int64_t)(m + 1) * p.TG) - (int64_t)m * p.TG;
+
+        for (int64_t tg = t_lo + wave; tg < t_hi; tg += nwaves) {
+            // ---- this lane's sequences
+            int64_t n[NT];
+            const uint8_t* row[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                n[nt] = (tg * NT + nt) * 16 + sq;
+                row[nt] = p.ascii + (n[nt] < p.N ? n[nt] : 0) * L;   // out-of-range lanes recompute seq 0
+            }
+            // code window: cw[j] = alphabet index at position s + j
+            int cw[K][NT];
+#pragma unroll
+            for (int j = 0; j < K - 1; ++j)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    int c = lut_s[row[nt][j]];
+                    bad |= (c == 0xFF);
+                    cw[j + 1][nt] = c;                    // shifted down at the top of step 0
+                }
+            f4 win1[K][FT][NT], win2[K3][FT][NT], gmax[FT][NT];
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+#pragma unroll
+                for (int t = 0; t < FT; ++t)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) win1[j][t][nt] = splat4(0.f);
+#pragma unroll
+            for (int j = 0; j < K3; ++j)
+#pragma unroll
+                for (int t = 0; t < FT; ++t)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) win2[j][t][nt] = splat4(0.f);
+#pragma unroll
+            for (int t = 0; t < FT; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) gmax[t][nt] = splat4(0.f);   // relu output >= 0
+
+            const int steps = L1 + PR2 + PR3;
+            for (int s = 0; s < steps; ++s) {
+                // weights in LDS are loop-invariant: without this barrier LICM hoists every
+                // ds_read out of the position loop and spills hundreds of VGPRs
+                asm volatile("" ::: "memory");
+                // ---- slide the windows
+#pragma unroll
+                for (int j = 0; j < K - 1; ++j)
+#pragma unroll
+                    for (int t = 0; t < FT; ++t)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) win1[j][t][nt] = win1[j + 1][t][nt];
+#pragma unroll
+                for (int j = 0; j < K3 - 1; ++j)
+#pragma unroll
+                    for (int t = 0; t < FT; ++t)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) win2[j][t][nt] = win2[j + 1][t][nt];
+#pragma unroll
+                for (int j = 0; j < K - 1; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) cw[j][nt] = cw[j + 1][nt];
+
+                // ---- conv1 (valid) at t1 = s: one-hot B operand built in registers
+                if (s < L1) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        int c = lut_s[row[nt][s + K - 1]];
+                        bad |= (c == 0xFF);
+                        cw[K - 1][nt] = c;
+                    }
+                    f4 o1[FT][NT];
+                    init_bias<FT, NT>(cb, o1, g);
+#pragma unroll
+                    for (int st = 0; st < S1; ++st) {
+                        constexpr int dummy = 0; (void)dummy;
+                        const int j = (4 * st) / A;          // tap (compile-time after unroll)
+                        const int a0 = (4 * st) % A;         // first alphabet index of the step
+                        const int sg = st >> 2, r = st & 3;
+                        float b[NT];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) b[nt] = (cw[j][nt] == a0 + g) ? 1.f : 0.f;
+#pragma unroll
+                        for (int mo = 0; mo < FT; ++mo) {
+                            const float a = reinterpret_cast<const float*>(&w_first[(sg * FT + mo) * 64 + lane])[r];
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) o1[mo][nt] = mfma16(a, b[nt], o1[mo][nt]);
+                        }
+                    }
+                    relu_tiles<FT, NT>(o1);
+#pragma unroll
+                    for (int t = 0; t < FT; ++t)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) win1[K - 1][t][nt] = o1[t][nt];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < FT; ++t)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) win1[K - 1][t][nt] = splat4(0.f);
+                }
+
+                // ---- conv2 (same) at t2 = s - PR2; win1[j] = out1[t2 + j - PL2]
+                const int t2 = s - PR2;
+                if (t2 >= 0 && t2 < L1) {
+                    f4 o2[FT][NT];
+                    init_bias<FT, NT>(cb + 16 * FT, o2, g);
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        const int pp = t2 + j - PL2;
+                        if (pp >= 0 && pp < L1)            // zero padding contributes nothing
+                            mma_layer<FT, FT, NT>(w_c2 + j * FT * FT * 64, win1[j], o2, lane);
+                    }
+                    relu_tiles<FT, NT>(o2);
+#pragma unroll
+                    for (int t = 0; t < FT; ++t)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) win2[K3 - 1][t][nt] = o2[t][nt];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < FT; ++t)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) win2[K3 - 1][t][nt] = splat4(0.f);
+                }
+
+                // ---- conv3 (same, kernel A-1) at t3 = t2 - PR3; win2[j] = out2[t3 + j - PL3]
+                //      (MaxPooling1D(1) between conv2 and conv3 is the identity, cnn.py:40)
+                const int t3 = t2 - PR3;
+                if (t3 >= 0 && t3 < L1) {
+                    f4 o3[FT][NT];
+                    init_bias<FT, NT>(cb + 32 * FT, o3, g);
+#pragma unroll
+                    for (int j = 0; j < K3; ++j) {
+                        const int pp = t3 + j - PL3;
+                        if (pp >= 0 && pp < L1)
+                            mma_layer<FT, FT, NT>(w_c3 + j * FT * FT * 64, win2[j], o3, lane);
+                    }
+                    // GlobalMaxPooling1D of relu(o3): gmax starts at 0
+#pragma unroll
+                    for (int t = 0; t < FT; ++t)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) gmax[t][nt] = max4(gmax[t][nt], o3[t][nt]);
+                }
+            }
+
+            // ---- dense head: F -> H relu -> H relu -> (dropout inactive) -> 1
+            asm volatile("" ::: "memory");
+            f4 h1[HT][NT], h2[HT][NT];
+            init_bias<HT, NT>(db, h1, g);
+            mma_layer<FT, HT, NT>(w_d1, gmax, h1, lane);
+            relu_tiles<HT, NT>(h1);
+            init_bias<HT, NT>(db + 16 * HT, h2, g);
+            mma_layer<HT, HT, NT>(w_d2, h1, h2, lane);
+            relu_tiles<HT, NT>(h2);
+            float y[NT];
+            final_dot<HT, NT>(db + 32 * HT, db[48 * HT], h2, y, g);
+            if (g == 0) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    if (n[nt] < p.N) p.out[n[nt] * p.Mtot + p.m_off + m] = fx_nan_to_num(y[nt]);
+            }
+        }
+    }
+    if (bad) atomicOr(p.err, FX_ERR_BADCHAR);
+}
+
+template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES>
+int launch_inst(fx_engine* e, const CnnArgs& a, size_t lds_bytes) {
+    constexpr int waves = WAVES;
+    auto kern = k_score_cnn_mfma<A, K, FT, HT, NT, DENSE_LDS, WAVES>;
+    static bool attr_set[64] = {};
+    if (!attr_set[e->device & 63]) {
+        FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[e->device & 63] = true;
+    }
+    int64_t U = (int64_t)a.M * a.TG;
+    int64_t blocks = e->grid_blocks > 0 ? e->grid_blocks : e->num_cus;
+    // keep every wave busy: at least one unit per wave
+    int64_t need = (U + waves - 1) / waves;
+    if (blocks > need) blocks = need;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(waves * 64), lds_bytes, e->stream, a);
+    FX_HIP(e, hipGetLastError());
+    return FX_OK;
+}
+
+}  // namespace
+
+int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii,
+                             int64_t N, float* d_out_NM, int Mtot, int m_off) {
+    if (N == 0) return FX_OK;
+    const FxShape& s = models[0]->shape;
+    const FxPackLayout& lay = models[0]->layout;
+    for (int m = 0; m < M; ++m) {
+        const FxShape& t = models[m]->shape;
+        if (t.kind != FX_CNN || t.L != s.L || t.A != s.A || t.F != s.F || t.H != s.H || t.K != s.K)
+            return FX_EUNSUPPORTED;                      // heterogeneous: caller scores them one by one
+    }
+    if (s.F != 32 || s.K != 5 || lay.HT != 7 || (s.A != 4 && s.A != 20)) return FX_EUNSUPPORTED;
+    if (M > FX_MAX_M) return FX_EINVAL;
+
+    CnnArgs a{};
+    a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
+    for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
+    a.N = N; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L;
+    a.off_first = (int)lay.off_first; a.off_c2 = (int)lay.off_c2; a.off_c3 = (int)lay.off_c3;
+    a.off_cb = (int)lay.off_cb; a.conv_floats = (int)lay.conv_floats; a.off_d1 = (int)lay.off_d1;
+    a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
+
+    // variant: 1 = NT1 x 8 waves, 2 = NT2 x 4 waves, 3 = NT2 x 8 waves (A = 4 only)
+    int variant = (int)e->cnn_variant;
+    const size_t full = (size_t)lay.total_floats * 4 + 256, conv_only = (size_t)lay.conv_floats * 4 + 256;
+    if (s.A == 4) {
+        if (full > (size_t)e->max_lds) return FX_EUNSUPPORTED;
+        if (variant == 0) variant = 1;
+        int nt = variant == 1 ? 1 : 2;
+        a.TG = (N + 16 * nt - 1) / (16 * nt);
+        switch (variant) {
+            case 1: return launch_inst<4, 5, 2, 7, 1, true, 8>(e, a, full);
+            case 2: return launch_inst<4, 5, 2, 7, 2, true, 4>(e, a, full);
+            case 3: return launch_inst<4, 5, 2, 7, 2, true, 8>(e, a, full);
+            default: return fx_fail(e, FX_EINVAL, "cnn_variant must be 0..3");
+        }
+    } else {
+        if (conv_only > (size_t)e->max_lds) return FX_EUNSUPPORTED;
+        a.TG = (N + 15) / 16;
+        return launch_inst<20, 5, 2, 7, 1, false, 4>(e, a, conv_only);   // 1 wave / SIMD: 512-VGPR budget for the 19-tap window
+    }
+}

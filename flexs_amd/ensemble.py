@@ -1,0 +1,77 @@
+"""`Ensemble` -- same contract as flexs/ensemble.py:10-59, with the member
+forwards and the reduction fused into one engine call when every member is a
+device surrogate."""
+import os
+from typing import Callable, List
+
+import numpy as np
+
+import flexs_amd
+from flexs_amd import _native
+from flexs_amd.types import SEQUENCES_TYPE
+
+
+def _default_combine(x):
+    return np.mean(x, axis=1)              # ensemble.py:24
+
+
+def _device_members(models):
+    """True if all members can be scored by one fused fx_score call."""
+    from flexs_amd.baselines.models.keras_model import KerasModel
+
+    if not models or not all(isinstance(m, KerasModel) for m in models):
+        return False
+    m0 = models[0]
+    return all(m.model.L == m0.model.L and m.alphabet == m0.alphabet and m._device == m0._device for m in models)
+
+
+if os.environ.get("FLEXS_AMD_BIND_FLEXS") == "1":
+    import flexs as _flexs
+
+    _EnsembleBase = _flexs.Ensemble
+else:
+    _EnsembleBase = flexs_amd.Model
+
+
+class Ensemble(_EnsembleBase):
+    """
+    Ensemble of models / landscapes.
+
+    Attributes:
+        models: members.
+        combine_with: (num_seqs, num_models) -> (num_seqs,) reduction; default mean.
+    """
+
+    def __init__(
+        self,
+        models: List[flexs_amd.Landscape],
+        combine_with: Callable[[np.ndarray], np.ndarray] = _default_combine,
+    ):
+        name = f"Ens({'|'.join(model.name for model in models)})"            # ensemble.py:36
+        flexs_amd.Model.__init__(self, name)
+        self.models = models
+        self.combine_with = combine_with
+
+    def train(self, sequences: SEQUENCES_TYPE, labels: np.ndarray):
+        for model in self.models:                                             # ensemble.py:42-52
+            model.train(sequences, labels)
+
+    def _fitness_function(self, sequences):
+        if _device_members(self.models):
+            # ensemble.py:55-57 calls member.get_fitness -> every member's cost grows by N
+            n = len(sequences)
+            for m in self.models:
+                m.cost += n
+            m0 = self.models[0]
+            seq_bytes = _native.sequences_to_bytes(sequences, L=m0.model.L)
+            if seq_bytes.shape[0] == 0:
+                scores = np.zeros((0, len(self.models)), np.float32)
+                return self.combine_with(scores)
+            natives = [m.native() for m in self.models]
+            fused_mean = self.combine_with is _default_combine
+            nm, mean = m0._engine().score(natives, seq_bytes, m0._lut, want_matrix=not fused_mean, want_mean=fused_mean)
+            return mean if fused_mean else self.combine_with(nm)
+        # heterogeneous / foreign members: the reference's host-side stacking
+        # (foreign flexs.Model objects can only be called from Python; combine_with is user code)
+        scores = np.stack([model.get_fitness(sequences) for model in self.models], axis=1)
+        return self.combine_with(scores)

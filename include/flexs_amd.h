@@ -1,0 +1,182 @@
+/*
+ * flexs_amd.h -- C ABI of libflexs_amd.so, the MI355X (gfx950) scoring engine
+ * behind the FLEXS `Model.get_fitness` hot path.
+ *
+ * The reference (samsinai/FLEXS v0.2.7) is pure Python and has no FFI of its
+ * own; the boundary below is what a ctypes binding inside the reference's
+ * `KerasModel._fitness_function` / `Ensemble._fitness_function` /
+ * `NoisyAbstractModel._fitness_function` would call.
+ * Each entry point cites the reference code (paths relative to the FLEXS
+ * repository root) it replaces.
+ *
+ * Conventions
+ *   - plain C types only; every function returns an fx_status (0 = FX_OK,
+ *     negative = error) unless stated; the process is never aborted.
+ *   - "host" entry points take host pointers, are synchronous, and own all
+ *     staging (results are valid on return).
+ *   - "_dev" entry points take DEVICE pointers (HBM-resident buffers, e.g.
+ *     torch tensor .data_ptr()), enqueue on the engine's stream and return
+ *     immediately; call fx_engine_sync() to wait and to collect deferred
+ *     errors (unknown alphabet character).
+ *   - the caller owns every buffer it passes; the engine owns device scratch,
+ *     its stream (unless one is lent with fx_engine_set_stream) and the packed
+ *     weights behind fx_model handles.
+ *   - an engine handle is not thread-safe: one per host thread / per GPU.
+ */
+#ifndef FLEXS_AMD_H
+#define FLEXS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FX_VERSION 100 /* 0.1.0 */
+
+typedef enum fx_status {
+    FX_OK = 0,
+    FX_EINVAL = -1,       /* bad argument (null pointer, negative size, ...)          */
+    FX_ESHAPE = -2,       /* shape mismatch: len(seq) != seq_len, L < kernel_size ... */
+    FX_EBADCHAR = -3,     /* character not in the alphabet (str.index ValueError,
+                             flexs/utils/sequence_utils.py:46)                        */
+    FX_ENODEV = -4,       /* no usable gfx950 device                                  */
+    FX_EHIP = -5,         /* HIP runtime error (text in fx_last_error)                */
+    FX_ENOMEM = -6,
+    FX_EUNSUPPORTED = -7, /* configuration outside what the kernels implement         */
+    FX_ESTATE = -8        /* e.g. weights never set                                   */
+} fx_status;
+
+typedef enum fx_model_kind {
+    FX_CNN = 0, /* flexs/baselines/models/cnn.py:23-54                    */
+    FX_MLP = 1, /* flexs/baselines/models/mlp.py:21-31                    */
+    FX_GE = 2   /* flexs/baselines/models/global_epistasis_model.py:26-36 */
+} fx_model_kind;
+
+typedef enum fx_dist_mode {
+    FX_LEVENSHTEIN = 0, /* editdistance.eval, noisy_abstract_model.py:51 (parity default) */
+    FX_HAMMING = 1      /* BASELINE.json north-star wording; upper bound of the above     */
+} fx_dist_mode;
+
+typedef struct fx_engine fx_engine; /* one GPU: stream, scratch, deferred-error word   */
+typedef struct fx_model fx_model;   /* one surrogate: shape + packed device weights    */
+typedef struct fx_cache fx_cache;   /* device-resident NoisyAbstractModel cache keys   */
+
+/* ------------------------------------------------------------------ library */
+int fx_version(void);
+const char *fx_status_name(int status);
+int fx_device_count(void); /* >= 0, or negative fx_status */
+
+/* ------------------------------------------------------------------- engine */
+int fx_engine_create(int device, fx_engine **out);
+int fx_engine_destroy(fx_engine *e);
+/* Lend an external hipStream_t (e.g. torch.cuda.current_stream().cuda_stream);
+ * NULL restores the engine's own stream. */
+int fx_engine_set_stream(fx_engine *e, void *hip_stream);
+/* Wait for the stream; returns FX_EBADCHAR if any _dev call since the last
+ * sync met a character outside its alphabet. */
+int fx_engine_sync(fx_engine *e);
+const char *fx_last_error(fx_engine *e);
+/* Tuning / test knobs: "force_generic" (0/1: use the plain VALU kernels
+ * instead of the MFMA ones), "cnn_variant", "grid_blocks".  Unknown key ->
+ * FX_EINVAL. */
+int fx_engine_set_option(fx_engine *e, const char *key, int64_t value);
+int fx_engine_get_option(fx_engine *e, const char *key, int64_t *value);
+/* hipEvent pair on the engine's stream: start..stop brackets whatever was
+ * enqueued in between; stop synchronises and returns elapsed milliseconds. */
+int fx_timer_start(fx_engine *e);
+int fx_timer_stop(fx_engine *e, float *elapsed_ms);
+
+/* -------------------------------------------------------------------- model */
+/* Replaces the tf.keras.Sequential built in cnn.py:23-54 / mlp.py:21-31 /
+ * global_epistasis_model.py:26-36.  L = seq_len, A = len(alphabet),
+ * F = num_filters (CNN only), H = hidden_size, K = kernel_size (CNN only).
+ * FX_ESHAPE if kind == FX_CNN and L < K (Keras 'valid' conv raises). */
+int fx_model_create(fx_engine *e, int kind, int L, int A, int F, int H, int K, fx_model **out);
+int fx_model_destroy(fx_model *m);
+int64_t fx_model_num_params(const fx_model *m);
+/* Weight blob = the arrays of keras `model.get_weights()` flattened (C order)
+ * and concatenated: CNN  conv1 kernel[K][A][F], bias[F], conv2 kernel[K][F][F],
+ * bias[F], conv3 kernel[A-1][F][F], bias[F], dense[F][H], bias[H], dense[H][H],
+ * bias[H], dense[H][1], bias[1];  MLP  dense[L*A][H], b, dense[H][H], b,
+ * dense[H][H], b, dense[H][1], b;  GE  dense[L*A][1], b[1], dense[1][H], b,
+ * dense[H][H], b, dense[H][1], b[1].  Called once per explorer round after
+ * `train` (flexs/explorer.py:157-160). */
+int fx_model_set_weights(fx_model *m, const float *blob, int64_t n);
+int fx_model_get_weights(const fx_model *m, float *blob, int64_t n);
+
+/* ------------------------------------------------------------------ scoring */
+/* KerasModel._fitness_function (keras_model.py:69-79) for M models that share
+ * (L, A) + Ensemble._fitness_function (ensemble.py:54-59) fused:
+ *   ascii  N x L bytes, row-major, one sequence per row (no terminators)
+ *   lut    256 entries: byte -> alphabet index, 0xFF = not in alphabet
+ *   out_NM nullable, N x M float32, column m = models[m] (np.stack(axis=1))
+ *   out_mean nullable, N float32 = np.mean(out_NM, axis=1) in NumPy's own
+ *          float32 summation order (bit-exact w.r.t. the stacked matrix)
+ * Scores are float32 with np.nan_to_num applied (keras_model.py:77). */
+int fx_score(fx_engine *e, fx_model *const *models, int M, const uint8_t *ascii, int64_t N, int L,
+             const uint8_t lut[256], float *out_NM, float *out_mean);
+int fx_score_dev(fx_engine *e, fx_model *const *models, int M, const uint8_t *d_ascii, int64_t N,
+                 int L, const uint8_t lut[256], float *d_out_NM, float *d_out_mean);
+
+/* string_to_one_hot over a batch (sequence_utils.py:32-47 + keras_model.py:70-75):
+ * N x L bytes -> N x L x A float32 0/1.  Stand-alone, HBM-bound. */
+int fx_encode_onehot(fx_engine *e, const uint8_t *ascii, int64_t N, int L, const uint8_t lut[256],
+                     int A, float *one_hot);
+int fx_encode_onehot_dev(fx_engine *e, const uint8_t *d_ascii, int64_t N, int L,
+                         const uint8_t lut[256], int A, float *d_one_hot);
+
+/* Ensemble / AdaptiveEnsemble combine (ensemble.py:24,59;
+ * adaptive_ensemble.py:54,102): scores N x M float32 ->
+ *   weights == NULL : np.mean(scores, axis=1)      (NumPy pairwise order)
+ *   weights != NULL : np.sum(weights * scores, axis=1) computed in float64
+ *                     (weights float64[M], out64 float64[N]); out32 unused. */
+int fx_ensemble_reduce(fx_engine *e, const float *scores_NM, int64_t N, int M,
+                       const double *weights, float *out32, double *out64);
+int fx_ensemble_reduce_dev(fx_engine *e, const float *d_scores_NM, int64_t N, int M,
+                           const double *weights, float *d_out32, double *d_out64);
+
+/* one_hot_to_string (sequence_utils.py:50-66; callers cmaes.py:61-67,
+ * environments/dyna_ppo.py:144-147): P x L x A float64 -> P x L bytes
+ * alphabet[argmax], first maximum wins (np.argmax rule, NaN = maximum). */
+int fx_argmax_decode(fx_engine *e, const double *one_hot, int64_t P, int L, int A,
+                     const uint8_t *alphabet, uint8_t *out_chars);
+
+/* ----------------------------------------------------- NoisyAbstractModel */
+/* NoisyAbstractModel._get_min_distance (noisy_abstract_model.py:42-60) for Q
+ * queries against C cache keys kept in insertion order: dist[i] = min edit
+ * distance, argmin[i] = FIRST cache index attaining it (the reference's
+ * early-exit-at-1 + strict-< loop).  C == 0 -> dist 0, argmin -1
+ * (noisy_abstract_model.py:44-45).  All sequences have length L. */
+int fx_min_dist(fx_engine *e, int mode, const uint8_t *queries, int64_t Q, const uint8_t *cache,
+                int64_t C, int L, int32_t *dist, int64_t *argmin);
+/* Device-resident, append-only cache (self.cache keys, noisy_abstract_model.py:40,67,99). */
+int fx_cache_create(fx_engine *e, int L, fx_cache **out);
+int fx_cache_destroy(fx_cache *c);
+int64_t fx_cache_size(const fx_cache *c);
+int fx_cache_append(fx_cache *c, const uint8_t *keys, int64_t n);
+int fx_cache_min_dist(fx_cache *c, int mode, const uint8_t *queries, int64_t Q, int32_t *dist,
+                      int64_t *argmin);
+/* noisy_abstract_model.py:88-94 for Q uncached queries:
+ *   out[i] = alpha_tab[d[i]] * signal[i] + (1 - alpha_tab[d[i]]) * noise[i]
+ * with alpha_tab[k] = ss ** k built on the host (Python float pow) and
+ * noise[i] = scale[i] * standard_exponential draw (host legacy NumPy RNG,
+ * bit-identical to np.random.exponential(scale)). float64 throughout. */
+int fx_nam_combine(fx_engine *e, int64_t Q, const double *signal, const double *noise,
+                   const int32_t *d, const double *alpha_tab, int n_tab, double *out);
+
+/* ------------------------------------------------------------ test hooks */
+/* Host-only (no GPU needed): expose the weight packing (Keras order -> MFMA
+ * fragment order) and the bit-parallel Levenshtein that the device kernels use,
+ * so the CPU test-suite can check them against the oracle. */
+int64_t fx_debug_packed_size(int kind, int L, int A, int F, int H, int K);
+int fx_debug_pack_layout(int kind, int L, int A, int F, int H, int K, int64_t *out12);
+int fx_debug_pack_weights(int kind, int L, int A, int F, int H, int K, const float *blob, int64_t n,
+                          float *packed, int64_t cap);
+int fx_debug_myers(const uint8_t *a, int la, const uint8_t *b, int lb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLEXS_AMD_H */
