@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: BASELINE.json configs[1] -- TF-binding L=8 (alphabet
+TGCA), 3-member CNN(32,100,k=5) Ensemble, batch = 1e5 sequences per virtual-screen
+call -- on N GPUs of one node (one process per GPU, weak scaling over sequences).
+
+A step = one `Ensemble.get_fitness`-equivalent pass over one 1e5-sequence batch
+that is already resident in HBM: the fused encode+CNN scoring kernel for all
+three members, the ensemble mean kernel and, for N > 1, ONE RCCL all-gather of the
+per-rank means (the north-star's exchange step).  Prints one JSON line on rank 0.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+L, ALPHABET, F, H, K, M, BATCH = 8, "TGCA", 32, 100, 5, 3, 100_000
+
+
+def cpu_baseline(seq_bytes, weight_sets, budget_s=10.0):
+    """Reference-style CPU path (oracle/torch_twin.py: per-character Python encode
+    loop + 256-row fp32 forward on all host cores + np.stack/np.mean), timed on a
+    bounded sample of the same workload.  Checker code: used ONLY here."""
+    import torch
+
+    from flexs_amd import synth
+    from oracle import torch_twin
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    sample = min(seq_bytes.shape[0], 50_000)
+    seqs = synth.bytes_to_strings(seq_bytes[:sample])
+    torch_twin.ensemble_fitness_cpu(seqs[:512], ALPHABET, "cnn", weight_sets)           # warm-up
+    done, t0 = 0, time.perf_counter()
+    while True:
+        torch_twin.ensemble_fitness_cpu(seqs, ALPHABET, "cnn", weight_sets)
+        done += sample
+        el = time.perf_counter() - t0
+        if el >= budget_s or done >= 4 * sample:
+            break
+    return {"value": done / el, "unit": "sequences/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{done} sequences ({done // sample} pass(es) over the first {sample} of the batch), "
+                      f"{el:.1f} s; Python per-character encode loop is single-threaded, forward uses all cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=0, help="cnn kernel variant (0 = auto)")
+    ap.add_argument("--batch", type=int, default=BATCH)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from flexs_amd import _native, synth
+    from flexs_amd.baselines.models.keras_model import Architecture
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    N = args.batch
+    eng = _native.Engine.get(local_rank)
+    if args.variant:
+        eng.set_option("cnn_variant", args.variant)
+    stream = torch.cuda.Stream()
+    lut = _native.make_lut(ALPHABET)
+    arch = Architecture("cnn", L, len(ALPHABET), H, num_filters=F, kernel_size=K)
+    weight_sets = [synth.synthetic_weights(arch.shapes(), 1000 + m) for m in range(M)]
+    models = []
+    for ws in weight_sets:
+        nm = _native.NativeModel(eng, _native.FX_CNN, L, len(ALPHABET), F, H, K)
+        nm.set_weights(ws)
+        models.append(nm)
+    seq_bytes = synth.random_sequence_bytes(N, L, ALPHABET, seed=rank)
+
+    with torch.cuda.stream(stream):
+        eng.set_stream(stream.cuda_stream)
+        d_ascii = torch.from_numpy(seq_bytes).cuda()
+        d_nm = torch.empty((N, M), dtype=torch.float32, device="cuda")
+        d_mean = torch.empty((N,), dtype=torch.float32, device="cuda")
+        d_all = torch.empty((world * N,), dtype=torch.float32, device="cuda") if world > 1 else None
+        ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+        ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+        def step(k=None):
+            if k is not None:
+                ev_a[k].record(stream)
+            eng.score_dev(models, d_ascii.data_ptr(), N, L, lut, d_nm.data_ptr(), None)      # K1 fused encode+CNN x3
+            if k is not None:
+                ev_b[k].record(stream)
+            eng.ensemble_reduce_dev(d_nm.data_ptr(), N, M, d_mean.data_ptr())               # K3 np.mean order
+            if world > 1:
+                dist.all_gather_into_tensor(d_all, d_mean)                                   # RCCL over xGMI
+
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(k)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        eng.sync()                                       # raises if any bad character was met
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_a, ev_b)]))
+        got_mean = d_mean.cpu().numpy()
+        got_nm = d_nm.cpu().numpy()
+        eng.set_stream(None)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        assert np.array_equal(np.mean(got_nm, axis=1), got_mean), "device mean is not np.mean bit-for-bit"
+        macs = synth.algorithmic_macs("cnn", L, len(ALPHABET), H, F, K)
+        flop_per_launch = 2.0 * macs * M * N
+        peak = 157.3
+        achieved = flop_per_launch / (kern_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "sequences scored/sec (virtual-screen batch)",
+            "value": world * N * args.steps / elapsed,
+            "unit": "sequences/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"TF-binding L={L} alphabet={ALPHABET}, {M}-member CNN(num_filters={F}, "
+                                   f"hidden_size={H}, kernel_size={K}) Ensemble, batch={N} virtual-screen per GPU "
+                                   "(BASELINE.json configs[1]); inputs resident in HBM; step = fused encode+CNN "
+                                   "scoring kernel + ensemble-mean kernel" + (" + one RCCL all-gather" if world > 1 else ""),
+                       "global_batch": world * N, "seq_len": L, "members": M,
+                       "parallelism": f"sequence-parallel x{world}" if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "kernel": "k_score_cnn_mfma", "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         "kernel_ms": kern_ms, "flop_per_launch": flop_per_launch,
+                         "algorithmic_bytes_per_launch": (L + 4 * M) * N,
+                         "note": "f32-input MFMA peak (157.3 TFLOP/s); algorithmic FLOP = 2*MACs, not discounted "
+                                 "for one-hot sparsity / zero padding"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(seq_bytes, weight_sets)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

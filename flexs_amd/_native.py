@@ -66,6 +66,7 @@ SIGNATURES = {
     "fx_debug_pack_layout": (C.c_int, [C.c_int] * 6 + [_i64p]),
     "fx_debug_pack_weights": (C.c_int, [C.c_int] * 6 + [_f32p, C.c_int64, _f32p, C.c_int64]),
     "fx_debug_myers": (C.c_int, [_vp, C.c_int, _vp, C.c_int]),
+    "fx_debug_mfma_probe": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None
@@ -291,6 +292,14 @@ class Engine:
         arg = np.empty(Q, np.int64)
         self.check(self._lib.fx_min_dist(self.handle, mode, _ptr(q), Q, _ptr(c), c.shape[0], L, _ptr(dist), _ptr(arg)))
         return dist, arg
+
+    def mfma_probe(self, a64, b64, c256) -> np.ndarray:
+        a = np.ascontiguousarray(a64, np.float32)
+        b = np.ascontiguousarray(b64, np.float32)
+        c = np.ascontiguousarray(c256, np.float32).reshape(64, 4)
+        d = np.empty((64, 4), np.float32)
+        self.check(self._lib.fx_debug_mfma_probe(self.handle, _ptr(a), _ptr(b), _ptr(c), _ptr(d)))
+        return d
 
     def nam_combine(self, signal, noise, d, alpha_tab) -> np.ndarray:
         signal = np.ascontiguousarray(signal, np.float64)

@@ -588,6 +588,21 @@ int fx_debug_pack_weights(int kind, int L, int A, int F, int H, int K, const flo
     fx_pack_weights(s, blob, packed);
     return FX_OK;
 }
+int fx_debug_mfma_probe(fx_engine* e, const float* a64, const float* b64, const float* c256, float* d256) {
+    if (!e || !a64 || !b64 || !c256 || !d256) return FX_EINVAL;
+    FX_HIP(e, hipSetDevice(e->device));
+    void* buf = nullptr;
+    int rc = fx_scratch(e, 0, sizeof(float) * (64 + 64 + 256 + 256), &buf);
+    if (rc) return rc;
+    float* d = (float*)buf;
+    FX_HIP(e, hipMemcpyAsync(d, a64, 256, hipMemcpyHostToDevice, e->stream));
+    FX_HIP(e, hipMemcpyAsync(d + 64, b64, 256, hipMemcpyHostToDevice, e->stream));
+    FX_HIP(e, hipMemcpyAsync(d + 128, c256, 1024, hipMemcpyHostToDevice, e->stream));
+    if ((rc = fx_launch_mfma_probe(e, d, d + 64, d + 128, d + 384))) return rc;
+    FX_HIP(e, hipMemcpyAsync(d256, d + 384, 1024, hipMemcpyDeviceToHost, e->stream));
+    FX_HIP(e, hipStreamSynchronize(e->stream));
+    return FX_OK;
+}
 int fx_debug_myers(const uint8_t* a, int la, const uint8_t* b, int lb) {
     // pattern = a, text = b; same code path as the device kernel (myers.h)
     if (la > 256 || la < 0 || lb < 0) return -1;

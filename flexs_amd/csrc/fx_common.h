@@ -109,6 +109,7 @@ int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const
                              int64_t N, float* d_out_NM, int Mtot, int m_off);
 int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii,
                                int64_t N, float* d_out_NM, int Mtot, int m_off);
+int fx_launch_mfma_probe(fx_engine* e, const float* d_a, const float* d_b, const float* d_c, float* d_d);
 int fx_launch_encode_onehot(fx_engine* e, const uint8_t* d_ascii, int64_t N, int L, int A, float* d_out);
 int fx_launch_ensemble_reduce(fx_engine* e, const float* d_scores, int64_t N, int M,
                               const double* d_weights, float* d_out32, double* d_out64);

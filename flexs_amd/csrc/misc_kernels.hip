@@ -1,6 +1,7 @@
 // HBM-bound helper kernels: stand-alone encode (K-enc), ensemble reduce (K3),
 // NoisyAbstractModel blend (K5), argmax decode (K6).
 #include "fx_common.h"
+#include "mfma_common.h"
 
 namespace {
 
@@ -105,6 +106,16 @@ __global__ void k_argmax_decode(const double* __restrict__ x, int64_t rows, int 
     }
 }
 
+// ---- test hook: ONE v_mfma_f32_16x16x4_f32 on caller-supplied per-lane operands, so the
+// operand / result lane layout the scoring kernels rely on is checked on the real hardware.
+__global__ void k_mfma_probe(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                             float* __restrict__ d) {
+    const int lane = threadIdx.x;
+    f4 acc = *reinterpret_cast<const f4*>(c + 4 * lane);
+    acc = mfma16(a[lane], b[lane], acc);
+    *reinterpret_cast<f4*>(d + 4 * lane) = acc;
+}
+
 inline unsigned grid_for(int64_t n, int block, int cus) {
     int64_t g = (n + block - 1) / block;
     int64_t cap = (int64_t)cus * 8;
@@ -114,6 +125,12 @@ inline unsigned grid_for(int64_t n, int block, int cus) {
 }
 
 }  // namespace
+
+int fx_launch_mfma_probe(fx_engine* e, const float* d_a, const float* d_b, const float* d_c, float* d_d) {
+    hipLaunchKernelGGL(k_mfma_probe, dim3(1), dim3(64), 0, e->stream, d_a, d_b, d_c, d_d);
+    FX_HIP(e, hipGetLastError());
+    return FX_OK;
+}
 
 int fx_launch_encode_onehot(fx_engine* e, const uint8_t* d_ascii, int64_t N, int L, int A, float* d_out) {
     const int64_t rows = N * L;

@@ -1,7 +1,207 @@
-// K2 score_mlp / score_ge on f32 MFMA -- placeholder until the kernels land:
-// returns FX_EUNSUPPORTED so fx_score falls back to the shape-agnostic kernels.
+// K2 score_mlp / score_ge: string -> one-hot -> Dense stack, fused, on f32 MFMA.
+//
+// Replaces keras_model.py:69-79 + mlp.py:21-31 / global_epistasis_model.py:26-36.
+// Same transposed-MFMA formulation and work split as score_cnn_mfma.hip (see
+// mfma_common.h): a wave owns NT tiles of 16 sequences, activations stay in
+// accumulator registers from layer to layer, the member's weights sit in LDS.
+//   MLP  layer 1 is a one-hot MFMA contraction over k = l*A + a (k-step = 4 rows),
+//        layers 2-3 are HxH MFMA, layer 4 a per-lane dot + 2 cross-lane adds.
+//   GE   layer 1 (L*A -> 1) is a per-lane gather-sum from an LDS table, layer 2
+//        (1 -> H) a VALU fma written directly in B-operand layout, layer 3 HxH
+//        MFMA, layer 4 the dot.
+// Algorithmic work per sequence per member: L + 4 bytes; 2*MACs FLOP with
+// MACs = L*A*H + 2*H*H + H (MLP) or L*A + H + H*H + H (GE).
 #include "fx_common.h"
+#include "mfma_common.h"
 
-int fx_launch_score_dense_mfma(fx_engine*, fx_model* const*, int, const uint8_t*, int64_t, float*, int, int) {
-    return FX_EUNSUPPORTED;
+namespace {
+
+struct DenseArgs {
+    const uint8_t* ascii;
+    const uint8_t* lut;
+    const float* w[FX_MAX_M];
+    float* out;
+    unsigned* err;
+    int64_t N, TG;
+    int M, Mtot, m_off;
+    int L, A;
+    int SG1, off_first, off_d2, off_d3, off_db, total_floats;
+};
+
+template <int KIND, int A, int HT, int NT, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int g = lane >> 4, sq = lane & 15;
+    const int L = p.L;
+    uint8_t* lut_s = reinterpret_cast<uint8_t*>(smem + p.total_floats);
+    for (int i = tid; i < 64; i += blockDim.x)
+        reinterpret_cast<uint32_t*>(lut_s)[i] = reinterpret_cast<const uint32_t*>(p.lut)[i];
+
+    const int64_t U = (int64_t)p.M * p.TG;
+    const int64_t u_lo = U * blockIdx.x / gridDim.x, u_hi = U * (blockIdx.x + 1) / gridDim.x;
+    if (u_lo >= u_hi) return;
+    const int m_first = (int)(u_lo / p.TG), m_last = (int)((u_hi - 1) / p.TG);
+    bool bad = false;
+
+    for (int m = m_first; m <= m_last; ++m) {
+        __syncthreads();
+        {
+            const f4* src = reinterpret_cast<const f4*>(p.w[m]);
+            f4* dst = reinterpret_cast<f4*>(smem);
+            for (int i = tid; i < p.total_floats / 4; i += blockDim.x) dst[i] = src[i];
+        }
+        __syncthreads();
+        const float* w_first = smem + p.off_first;
+        const f4* w_d2 = reinterpret_cast<const f4*>(smem + p.off_d2);
+        const f4* w_d3 = reinterpret_cast<const f4*>(smem + p.off_d3);
+        const float* db = smem + p.off_db;
+
+        const int64_t t_lo = (u_lo > (int64_t)m * p.TG ? u_lo : (int64_t)m * p.TG) - (int64_t)m * p.TG;
+        const int64_t t_hi = (u_hi < (int64_t)(m + 1) * p.TG ? u_hi : (int64_t)(m + 1) * p.TG) - (int64_t)m * p.TG;
+
+        for (int64_t tg = t_lo + wave; tg < t_hi; tg += nwaves) {
+            asm volatile("" ::: "memory");               // keep LDS weight reads inside the tile loop
+            int64_t n[NT];
+            const uint8_t* row[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                n[nt] = (tg * NT + nt) * 16 + sq;
+                row[nt] = p.ascii + (n[nt] < p.N ? n[nt] : 0) * L;
+            }
+            f4 h[HT][NT];
+            float y[NT];
+            if (KIND == FX_MLP) {
+                static_assert(KIND != FX_MLP || A % 4 == 0, "one-hot k-steps must not straddle a position");
+                // ---- layer 1: relu(b1 + onehot @ W1), contraction index k = l*A + a
+                init_bias<HT, NT>(db, h, g);
+                for (int sg = 0; sg < p.SG1; ++sg) {
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k0 = 16 * sg + 4 * r;            // first row of this k-step
+                        const int l = k0 / A, a0 = k0 % A;
+                        float b[NT];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            int c = 0xFE;
+                            if (l < L) {
+                                c = lut_s[row[nt][l]];
+                                bad |= (c == 0xFF);
+                            }
+                            b[nt] = (c == a0 + g) ? 1.f : 0.f;
+                        }
+#pragma unroll
+                        for (int mo = 0; mo < HT; ++mo) {
+                            const float a = w_first[((sg * HT + mo) * 64 + lane) * 4 + r];
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) h[mo][nt] = mfma16(a, b[nt], h[mo][nt]);
+                        }
+                    }
+                }
+                relu_tiles<HT, NT>(h);
+                // ---- layers 2, 3
+                f4 h2[HT][NT];
+                init_bias<HT, NT>(db + 16 * HT, h2, g);
+                mma_layer<HT, HT, NT>(w_d2, h, h2, lane);
+                relu_tiles<HT, NT>(h2);
+                asm volatile("" ::: "memory");
+                init_bias<HT, NT>(db + 32 * HT, h, g);
+                mma_layer<HT, HT, NT>(w_d3, h2, h, lane);
+                relu_tiles<HT, NT>(h);
+                final_dot<HT, NT>(db + 48 * HT, db[64 * HT], h, y, g);
+            } else {
+                // ---- GE layer 1: s = relu(b1 + sum_l w1[l*A + code_l])   (scalar per sequence)
+                float s[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) s[nt] = db[0];
+                for (int l = 0; l < L; ++l) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        int c = lut_s[row[nt][l]];
+                        if (c == 0xFF) { bad = true; c = 0; }
+                        s[nt] += w_first[l * p.A + c];
+                    }
+                }
+                // ---- layer 2: h[ch] = relu(b2[ch] + s * w2[ch]) directly in B-operand layout
+                f4 h2[HT][NT];
+#pragma unroll
+                for (int mo = 0; mo < HT; ++mo) {
+                    const f4 w2 = *reinterpret_cast<const f4*>(&db[4 + 16 * mo + 4 * g]);
+                    const f4 b2 = *reinterpret_cast<const f4*>(&db[4 + 16 * HT + 16 * mo + 4 * g]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float sv = fmaxf(s[nt], 0.f);
+                        f4 v;
+                        v.x = fmaxf(fmaf(sv, w2.x, b2.x), 0.f);
+                        v.y = fmaxf(fmaf(sv, w2.y, b2.y), 0.f);
+                        v.z = fmaxf(fmaf(sv, w2.z, b2.z), 0.f);
+                        v.w = fmaxf(fmaf(sv, w2.w, b2.w), 0.f);
+                        h2[mo][nt] = v;
+                    }
+                }
+                // ---- layer 3 (HxH MFMA), layer 4 (dot)
+                init_bias<HT, NT>(db + 4 + 32 * HT, h, g);
+                mma_layer<HT, HT, NT>(w_d3, h2, h, lane);
+                relu_tiles<HT, NT>(h);
+                final_dot<HT, NT>(db + 4 + 48 * HT, db[4 + 64 * HT], h, y, g);
+            }
+            if (g == 0) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    if (n[nt] < p.N) p.out[n[nt] * p.Mtot + p.m_off + m] = fx_nan_to_num(y[nt]);
+            }
+        }
+    }
+    if (bad) atomicOr(p.err, FX_ERR_BADCHAR);
+}
+
+template <int KIND, int A, int HT, int NT, int WAVES>
+int launch_inst(fx_engine* e, const DenseArgs& a, size_t lds_bytes) {
+    auto kern = k_score_dense_mfma<KIND, A, HT, NT, WAVES>;
+    static bool attr_set[64] = {};
+    if (!attr_set[e->device & 63]) {
+        FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[e->device & 63] = true;
+    }
+    const int64_t U = (int64_t)a.M * a.TG;
+    int64_t blocks = e->grid_blocks > 0 ? e->grid_blocks : e->num_cus;
+    const int64_t need = (U + WAVES - 1) / WAVES;
+    if (blocks > need) blocks = need;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), lds_bytes, e->stream, a);
+    FX_HIP(e, hipGetLastError());
+    return FX_OK;
+}
+
+}  // namespace
+
+int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N,
+                               float* d_out_NM, int Mtot, int m_off) {
+    if (N == 0) return FX_OK;
+    const FxShape& s = models[0]->shape;
+    const FxPackLayout& lay = models[0]->layout;
+    for (int m = 0; m < M; ++m) {
+        const FxShape& t = models[m]->shape;
+        if (t.kind != s.kind || t.L != s.L || t.A != s.A || t.H != s.H) return FX_EUNSUPPORTED;
+    }
+    if (s.kind != FX_MLP && s.kind != FX_GE) return FX_EUNSUPPORTED;
+    if (lay.HT != 7 || M > FX_MAX_M) return FX_EUNSUPPORTED;
+    const size_t lds = (size_t)lay.total_floats * 4 + 256;
+    if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
+    if (s.kind == FX_MLP && s.A != 4 && s.A != 20) return FX_EUNSUPPORTED;
+
+    DenseArgs a{};
+    a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
+    for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
+    a.N = N; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.A = s.A;
+    a.SG1 = lay.SG1; a.off_first = (int)lay.off_first; a.off_d2 = (int)lay.off_d2; a.off_d3 = (int)lay.off_d3;
+    a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
+    a.TG = (N + 15) / 16;
+    if (s.kind == FX_MLP) {
+        if (s.A == 4) return launch_inst<FX_MLP, 4, 7, 1, 8>(e, a, lds);
+        return launch_inst<FX_MLP, 20, 7, 1, 8>(e, a, lds);
+    }
+    return launch_inst<FX_GE, 4, 7, 1, 8>(e, a, lds);    // A is a runtime stride for GE (template arg unused)
 }

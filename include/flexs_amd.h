@@ -175,6 +175,9 @@ int fx_debug_pack_layout(int kind, int L, int A, int F, int H, int K, int64_t *o
 int fx_debug_pack_weights(int kind, int L, int A, int F, int H, int K, const float *blob, int64_t n,
                           float *packed, int64_t cap);
 int fx_debug_myers(const uint8_t *a, int la, const uint8_t *b, int lb);
+/* GPU: one v_mfma_f32_16x16x4_f32 on per-lane operands a[64], b[64], c[64][4] -> d[64][4]
+ * (checks the lane layout the kernels assume on the real hardware). */
+int fx_debug_mfma_probe(fx_engine *e, const float *a64, const float *b64, const float *c256, float *d256);
 
 #ifdef __cplusplus
 }

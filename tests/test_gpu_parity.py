@@ -1,0 +1,400 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the oracle, the
+committed golden fixtures, and size-independent properties at BASELINE sizes.
+
+Tolerance for fp32 fitness scores (BASELINE.json north_star: "within 1e-5
+relative"): |gpu - oracle_f64| <= 1e-5 * |oracle| + 1e-6  element-wise
+(np.allclose form; the absolute term covers scores that cancel to ~0).
+Integer / float64 paths (distances, ensemble mean, NAM blend, codecs) are
+bit-exact.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import flexs_amd
+from flexs_amd import _native, synth
+from flexs_amd.baselines import models as bm
+from flexs_amd.utils import sequence_utils as s_utils
+from oracle import c_oracle, ref_np
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-5, 1e-6
+
+
+def close(got, want):
+    return np.abs(got - want) <= ATOL + RTOL * np.abs(want)
+
+
+def assert_scores(got, want, what=""):
+    assert got.dtype == np.float32
+    bad = ~close(got.astype(np.float64), want)
+    assert not bad.any(), (f"{what}: {bad.sum()} / {bad.size} outside tolerance; max abs err "
+                           f"{np.abs(got - want).max():.3e}, worst at {np.argmax(np.abs(got - want))}")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = _native.Engine.get(0)
+    yield e
+    e.set_option("force_generic", 0)
+    e.set_option("cnn_variant", 0)
+
+
+def rand_seqs(n, L, alphabet, seed):
+    b = synth.random_sequence_bytes(n, L, alphabet, seed)
+    return b, synth.bytes_to_strings(b)
+
+
+def make_native(eng, kind, L, A, H, F=0, K=0, seed=1000):
+    shapes = {"cnn": ref_np.cnn_shapes(L, A, F, H, K) if kind == "cnn" else None,
+              "mlp": ref_np.mlp_shapes(L, A, H), "ge": ref_np.ge_shapes(L, A, H)}[kind]
+    w = ref_np.synth_weights(shapes, seed)
+    nm = _native.NativeModel(eng, {"cnn": 0, "mlp": 1, "ge": 2}[kind], L, A, F, H, K)
+    nm.set_weights(w)
+    return nm, w
+
+
+# ------------------------------------------------------------------ MFMA layout ground truth
+def test_mfma_operand_layout(eng):
+    """The lane layout of v_mfma_f32_16x16x4_f32 assumed by the kernels and by
+    tests/mfma_sim.py, checked on the hardware with asymmetric operands."""
+    import mfma_sim
+
+    rng = np.random.default_rng(0)
+    a = rng.integers(-4, 5, 64).astype(np.float32)
+    b = rng.integers(-4, 5, 64).astype(np.float32)
+    c = rng.integers(-4, 5, (64, 4)).astype(np.float32)
+    got = eng.mfma_probe(a, b, c)
+    want = mfma_sim.mfma16(a.astype(np.float64), b.astype(np.float64), c.astype(np.float64))
+    assert np.array_equal(got, want.astype(np.float32))
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+
+    g.smoke()
+
+
+# ------------------------------------------------------------------ CNN
+@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 33, 1000, 4099])
+def test_cnn_l8_variants_and_tails(eng, variant, n):
+    """BASELINE configs[0]/[1] shape: TF-binding L=8, alphabet TGCA, CNN(32,100,k5)."""
+    eng.set_option("force_generic", 0)
+    eng.set_option("cnn_variant", variant)
+    nm, w = make_native(eng, "cnn", 8, 4, 100, 32, 5)
+    b, seqs = rand_seqs(n, 8, "TGCA", seed=n)
+    got, _ = eng.score([nm], b, _native.make_lut("TGCA"))
+    want = ref_np.keras_fitness(seqs, "TGCA", "cnn", w, exact=True)
+    assert_scores(got[:, 0], want, f"cnn L8 variant {variant} n={n}")
+    eng.set_option("cnn_variant", 0)
+
+
+@pytest.mark.parametrize("L,A,alpha,n", [(8, 4, "TGCA", 3000), (5, 4, "TGCA", 500), (6, 4, "TGCA", 500),
+                                         (14, 4, "UGCA", 2000), (50, 4, "UGCA", 600), (100, 4, "UGCA", 300),
+                                         (20, 20, s_utils.AAS, 400), (66, 20, s_utils.AAS, 200),
+                                         (90, 20, s_utils.AAS, 150)])
+def test_cnn_mfma_vs_oracle(eng, L, A, alpha, n):
+    eng.set_option("force_generic", 0)
+    nm, w = make_native(eng, "cnn", L, A, 100, 32, 5, seed=7)
+    b, seqs = rand_seqs(n, L, alpha, seed=L)
+    got, _ = eng.score([nm], b, _native.make_lut(alpha))
+    want = ref_np.keras_fitness(seqs, alpha, "cnn", w, exact=True)
+    assert_scores(got[:, 0], want, f"cnn mfma L={L} A={A}")
+    # the shape-agnostic kernel must agree too (independent on-device implementation)
+    eng.set_option("force_generic", 1)
+    got_g, _ = eng.score([nm], b, _native.make_lut(alpha))
+    eng.set_option("force_generic", 0)
+    assert_scores(got_g[:, 0], want, f"cnn generic L={L} A={A}")
+
+
+@pytest.mark.parametrize("L", [237, 238])
+def test_cnn_gfp_length(eng, L):
+    """BASELINE configs[4] shape (GFP: 238 residues in the reference, 237 in BASELINE.json), reduced N."""
+    nm, w = make_native(eng, "cnn", L, 20, 100, 32, 5, seed=3)
+    b, seqs = rand_seqs(96, L, s_utils.AAS, seed=L)
+    got, _ = eng.score([nm], b, _native.make_lut(s_utils.AAS))
+    want = ref_np.keras_fitness(seqs, s_utils.AAS, "cnn", w, exact=True)
+    assert_scores(got[:, 0], want, f"cnn L={L}")
+
+
+@pytest.mark.parametrize("L,A,alpha,F,H,K", [(3, 4, "TGCA", 1, 1, 2), (9, 4, "TGCA", 8, 20, 4), (12, 2, "01", 16, 30, 3),
+                                             (10, 4, "TGCA", 32, 100, 3), (8, 4, "TGCA", 32, 200, 5),
+                                             (5, 4, "TGCA", 32, 100, 5), (7, 20, s_utils.AAS, 4, 130, 2)])
+def test_cnn_odd_shapes_generic(eng, L, A, alpha, F, H, K):
+    """Shapes outside the MFMA instantiations (incl. the reference's own smoke test
+    CNN(seq_len=3, num_filters=1, hidden_size=1, kernel_size=2) and even kernels)."""
+    nm, w = make_native(eng, "cnn", L, A, H, F, K, seed=5)
+    b, seqs = rand_seqs(257, L, alpha, seed=1)
+    got, _ = eng.score([nm], b, _native.make_lut(alpha))
+    want = ref_np.keras_fitness(seqs, alpha, "cnn", w, exact=True)
+    assert_scores(got[:, 0], want, f"cnn odd {L},{A},{F},{H},{K}")
+
+
+# ------------------------------------------------------------------ MLP / GE
+@pytest.mark.parametrize("kind", ["mlp", "ge"])
+@pytest.mark.parametrize("L,A,alpha,H,n", [(14, 4, "UGCA", 100, 3000), (8, 4, "TGCA", 100, 1000), (14, 4, "UGCA", 97, 300),
+                                           (90, 20, s_utils.AAS, 100, 1000), (237, 20, s_utils.AAS, 100, 200),
+                                           (14, 4, "UGCA", 200, 300), (3, 4, "TGCA", 1, 50), (10, 2, "01", 100, 100)])
+def test_mlp_ge_vs_oracle(eng, kind, L, A, alpha, H, n):
+    for force in (0, 1):
+        eng.set_option("force_generic", force)
+        nm, w = make_native(eng, kind, L, A, H, seed=11)
+        b, seqs = rand_seqs(n, L, alpha, seed=L + H)
+        got, _ = eng.score([nm], b, _native.make_lut(alpha))
+        want = ref_np.keras_fitness(seqs, alpha, kind, w, exact=True)
+        assert_scores(got[:, 0], want, f"{kind} L={L} A={A} H={H} generic={force}")
+    eng.set_option("force_generic", 0)
+
+
+# ------------------------------------------------------------------ ensembles
+@pytest.mark.parametrize("M", [1, 2, 3, 8, 11, 17])
+def test_ensemble_matrix_and_numpy_order_mean(eng, M):
+    L, alpha = 8, "TGCA"
+    natives, ws = zip(*[make_native(eng, "cnn", L, 4, 100, 32, 5, seed=1000 + m) for m in range(M)])
+    b, seqs = rand_seqs(2049, L, alpha, seed=M)
+    nm, mean = eng.score(list(natives), b, _native.make_lut(alpha), want_matrix=True, want_mean=True)
+    assert nm.shape == (2049, M)
+    for m in range(M):
+        assert_scores(nm[:, m], ref_np.keras_fitness(seqs, alpha, "cnn", ws[m], exact=True), f"member {m}")
+    assert np.array_equal(mean, np.mean(nm, axis=1)), "device mean must be np.mean bit-for-bit (ensemble.py:24)"
+    assert np.array_equal(eng.ensemble_mean(nm), np.mean(nm, axis=1))
+
+
+def test_reduce_kernel_golden(eng, golden_dir):
+    meta = json.load(open(os.path.join(golden_dir, "ensemble.json")))
+    arrs = np.load(os.path.join(golden_dir, "ensemble.npz"))
+    for ci, case in enumerate(meta["cases"]):
+        if case["dtype"] != "float32":
+            continue
+        assert np.array_equal(eng.ensemble_mean(arrs[f"in{ci}"]), arrs[f"out{ci}"]), case
+    got = eng.ensemble_weighted_sum(arrs["ada_in"], arrs["ada_w"])
+    assert got.dtype == np.float64 and np.array_equal(got, arrs["ada_out_w"])
+    assert np.array_equal(eng.ensemble_weighted_sum(arrs["ada_in"], np.ones(4) / 4), arrs["ada_out_default"])
+    rng = np.random.default_rng(0)
+    for M in (7, 8, 9, 16, 100, 129, 300):
+        x = (rng.standard_normal((513, M)) * rng.choice([1e-3, 1, 1e3], (513, M))).astype(np.float32)
+        assert np.array_equal(eng.ensemble_mean(x), np.mean(x, axis=1)), M
+        w = rng.random(M)
+        assert np.array_equal(eng.ensemble_weighted_sum(x, w), np.sum(w * x, axis=1)), M
+
+
+def test_python_api_drop_in(eng):
+    """flexs.Model surface: dtypes, cost accounting (ensemble.py:55-57 via landscape.py:44), names."""
+    L, alpha = 14, "UGCA"
+    b, seqs = rand_seqs(333, L, alpha, seed=2)
+    members = [bm.CNN(L, 32, 100, alpha, seed=0), bm.MLP(L, 100, alpha, seed=1), bm.GlobalEpistasisModel(L, 100, alpha, seed=2)]
+    for m, kind in zip(members, ("cnn", "mlp", "ge")):
+        out = m.get_fitness(seqs)
+        assert out.dtype == np.float32 and out.shape == (333,) and m.cost == 333
+        assert_scores(out, ref_np.keras_fitness(seqs, alpha, kind, m.model.get_weights(), exact=True), kind)
+        assert np.array_equal(m.get_fitness(np.array(seqs)), out)            # ndarray input
+        assert np.array_equal(m.get_fitness(tuple(seqs[:5])), out[:5])
+        assert m.get_fitness([]).shape == (0,)
+    ens = flexs_amd.Ensemble(members)
+    for m in members:
+        m.cost = 0
+    out = ens.get_fitness(seqs)
+    assert ens.cost == 333 and all(m.cost == 333 for m in members)
+    stack = np.stack([m.get_fitness(seqs) for m in members], axis=1)
+    assert np.array_equal(out, np.mean(stack, axis=1))
+    ident = flexs_amd.Ensemble(members, combine_with=lambda x: x).get_fitness(seqs)   # BO's usage (bo.py:55-56)
+    assert np.array_equal(ident, stack)
+    ada = bm.AdaptiveEnsemble(members)
+    assert np.array_equal(ada.get_fitness(seqs), np.sum(ada.weights * stack, axis=1))
+    # weights reload (once per explorer round): set_weights must reach the device
+    new_w = ref_np.synth_weights(ref_np.mlp_shapes(L, 4, 100), 99)
+    members[1].model.set_weights(new_w)
+    assert_scores(members[1].get_fitness(seqs), ref_np.keras_fitness(seqs, alpha, "mlp", new_w, exact=True), "reloaded")
+    # the reference's own smoke scenario (tests/test_models.py:55-77)
+    bm.CNN(seq_len=3, num_filters=1, hidden_size=1, kernel_size=2, alphabet=s_utils.DNAA).get_fitness(["ATC"])
+    bm.GlobalEpistasisModel(seq_len=3, hidden_size=1, alphabet=s_utils.DNAA).get_fitness(["ATC"])
+    bm.MLP(seq_len=3, hidden_size=1, alphabet=s_utils.DNAA).get_fitness(["ATC"])
+
+
+def test_errors(eng):
+    cnn = bm.CNN(8, 32, 100, "TGCA", seed=0)
+    with pytest.raises(ValueError):
+        cnn.get_fitness(["ATGCATGX"])                      # str.index ValueError (sequence_utils.py:46)
+    assert cnn.get_fitness(["ATGCATGC"]).shape == (1,)     # engine still usable afterwards
+    with pytest.raises(ValueError):
+        cnn.get_fitness(["ATGC"])                          # wrong length
+    with pytest.raises(ValueError):
+        cnn.get_fitness(["ATGCATGC", "ATG"])               # ragged
+    with pytest.raises(ValueError):
+        s_utils.string_to_one_hot("ATXG", s_utils.DNAA)
+    lowercase = bm.MLP(4, 8, "TGCA", seed=0)
+    with pytest.raises(ValueError):
+        lowercase.get_fitness(["atgc"])
+    # nan_to_num (keras_model.py:77)
+    w = lowercase.model.get_weights()
+    w[-1][:] = np.nan
+    lowercase.model.set_weights(w)
+    assert lowercase.get_fitness(["ATGC"]).tolist() == [0.0]
+    w[-1][:] = np.inf
+    lowercase.model.set_weights(w)
+    assert lowercase.get_fitness(["ATGC"]).tolist() == [float(np.finfo(np.float32).max)]
+
+
+# ------------------------------------------------------------------ codecs
+def test_encode_decode_golden(eng, golden_dir):
+    fx = json.load(open(os.path.join(golden_dir, "encode.json")))
+    for case in fx["cases"]:
+        alpha = fx["alphabets"][case["alphabet"]] if "alphabet" in case else case["alphabet_literal"]
+        got = s_utils.string_to_one_hot(case["sequence"], alpha)
+        assert got.dtype == np.float64 and np.array_equal(got, np.array(case["one_hot"], dtype=np.float64))
+    meta = json.load(open(os.path.join(golden_dir, "decode.json")))
+    arrs = np.load(os.path.join(golden_dir, "decode.npz"))
+    alphabets = {"AAS": s_utils.AAS, "RNAA": s_utils.RNAA, "DNAA": s_utils.DNAA}
+    for i, (an, want) in enumerate(zip(meta["alphabet"], meta["strings"])):
+        assert s_utils.one_hot_to_string(arrs[f"x{i}"], alphabets[an]) == want
+    rng = np.random.default_rng(0)
+    for L, A, alpha in ((8, 4, "TGCA"), (90, 20, s_utils.AAS), (7, 2, "01")):
+        b, seqs = rand_seqs(1001, L, alpha, seed=L)
+        oh = s_utils.strings_to_one_hot(seqs, alpha)
+        assert oh.dtype == np.float32 and np.array_equal(oh, ref_np.encode_batch(seqs, alpha).astype(np.float32))
+        assert s_utils.one_hots_to_strings(oh, alpha) == seqs                  # round trip
+        x = rng.standard_normal((40, L, A))
+        x[::3] = np.round(x[::3])
+        x[5, 2, 1] = np.nan
+        assert s_utils.one_hots_to_strings(x, alpha) == [ref_np.one_hot_to_string(r, alpha) for r in x]
+
+
+# ------------------------------------------------------------------ NoisyAbstractModel
+@pytest.mark.parametrize("L,nsym,C,Q", [(8, 4, 300, 200), (14, 4, 2500, 150), (66, 20, 700, 60), (90, 20, 1500, 40),
+                                        (238, 20, 300, 20), (64, 4, 200, 50), (65, 4, 200, 50), (1, 4, 10, 10)])
+def test_min_dist_vs_oracle(eng, L, nsym, C, Q):
+    rng = np.random.default_rng(L * 7 + C)
+    base = rng.integers(65, 65 + nsym, (1, L)).astype(np.uint8)
+    cache = np.repeat(base, C, 0)
+    mut = rng.random((C, L)) < 0.15
+    cache[mut] = rng.integers(65, 65 + nsym, mut.sum())
+    if L > 4:
+        rot = rng.random(C) < 0.3                    # shifted copies: Levenshtein < Hamming
+        cache[rot] = np.roll(cache[rot], 1, axis=1)
+    q = cache[rng.integers(0, C, Q)].copy()
+    qm = rng.random((Q, L)) < 0.1
+    q[qm] = rng.integers(65, 65 + nsym, qm.sum())
+    q[0] = cache[C // 2]                             # exact hit present
+    for mode in (0, 1):
+        d_want, a_want = c_oracle.min_dist(q, cache, mode)
+        d_got, a_got = eng.min_dist(q, cache, mode)
+        assert np.array_equal(d_got, d_want) and np.array_equal(a_got, a_want), (L, mode)
+        dc = _native.NativeCache(eng, L)
+        dc.append(cache[: C // 3]); dc.append(cache[C // 3:])
+        assert len(dc) == C
+        d2, a2 = dc.min_dist(q, mode)
+        assert np.array_equal(d2, d_want) and np.array_equal(a2, a_want)
+    d0, a0 = eng.min_dist(q, cache[:0])
+    assert (d0 == 0).all() and (a0 == -1).all()      # noisy_abstract_model.py:44-45
+
+
+def test_min_dist_known_answers(eng, golden_dir):
+    known = json.load(open(os.path.join(golden_dir, "edit_distance_known.json")))["known"]
+    for k in known:
+        q = np.frombuffer(k["seq"].encode(), np.uint8)[None]
+        c = np.frombuffer(k["wt"].encode(), np.uint8)[None]
+        d, a = eng.min_dist(q, c, 0)
+        assert d[0] == k["levenshtein_dp"] and a[0] == 0
+        assert eng.min_dist(q, c, 1)[0][0] == k["hamming"]
+
+
+def test_nam_traces_bit_exact(eng, golden_dir):
+    """NoisyAbstractModel through the product class == the reference's outputs for seeded
+    traces: float64 values, oracle-call counts, cache order and RNG state."""
+    traces = json.load(open(os.path.join(golden_dir, "nam_traces.json")))["traces"]
+
+    class Table(flexs_amd.Landscape):
+        def __init__(self, values):
+            super().__init__("Table")
+            self.values = values
+
+        def _fitness_function(self, seqs):
+            return np.array([self.values[str(s)] for s in seqs])
+
+    for tr in traces:
+        land = Table(tr["landscape_values"])
+        np.random.seed(tr["seed"])
+        nam = bm.NoisyAbstractModel(land, signal_strength=tr["ss"])
+        assert nam.name == tr["name"]
+        if tr["empty_first"]:
+            m0 = bm.NoisyAbstractModel(Table(tr["landscape_values"]), signal_strength=tr["ss"])
+            assert m0.get_fitness(tr["empty_first"]["query"]).tolist() == tr["empty_first"]["out"]
+            assert len(m0.cache) == 1
+            np.random.seed(tr["seed"])
+        nam.train(tr["train_sequences"], tr["train_labels"])
+        for b, batch in enumerate(tr["batches"]):
+            out = nam.get_fitness(batch)
+            assert out.dtype == np.float64
+            assert out.tolist() == tr["outputs"][b], (tr["L"], b)
+            assert land.cost == tr["landscape_cost"][b]
+            assert len(nam.cache) == tr["cache_len"][b] and nam.cost == tr["model_cost"][b]
+        assert list(nam.cache.keys()) == tr["cache_keys_in_order"]
+        assert float(np.random.random()) == tr["rng_next_random"]
+    # the reference's own scenario (tests/test_models.py:80-99)
+    class Const(flexs_amd.Landscape):
+        def _fitness_function(self, seqs):
+            return np.ones(len(seqs)) * 2
+
+    nam = bm.NoisyAbstractModel(Const("c"), signal_strength=1)
+    assert nam.get_fitness(["ATC"]) == [2]
+    nam = bm.NoisyAbstractModel(Const("c"), signal_strength=0)
+    f = nam.get_fitness(["ATC"])
+    assert len(nam.cache) == 1 and nam.get_fitness(["ATC"]) == f
+    assert nam.get_fitness(["ATG"]) != [2]
+
+
+def test_nam_combine_kernel(eng):
+    rng = np.random.default_rng(0)
+    Q = 5001
+    signal, noise = rng.random(Q), rng.exponential(1.0, Q)
+    d = rng.integers(0, 15, Q).astype(np.int32)
+    for ss in (0.0, 0.5, 0.9, 1.0):
+        tab = np.array([ss ** k for k in range(15)])
+        want = np.array([tab[k] * s + (1 - tab[k]) * n for k, s, n in zip(d, signal, noise)])
+        assert np.array_equal(eng.nam_combine(signal, noise, d, tab), want)
+
+
+# ------------------------------------------------------------------ BASELINE sizes: properties
+def test_baseline_config1_full_batch(eng):
+    """configs[1]: TF-binding L=8, 3-member CNN ensemble, batch = 1e5 on one GPU.
+    Full oracle comparison (the float64 NumPy oracle does 3e5 forwards in seconds) plus
+    size-independent properties: permutation equivariance, duplicates, chunk invariance."""
+    L, alpha, N, M = 8, "TGCA", 100_000, 3
+    natives, ws = zip(*[make_native(eng, "cnn", L, 4, 100, 32, 5, seed=1000 + m) for m in range(M)])
+    lut = _native.make_lut(alpha)
+    b, seqs = rand_seqs(N, L, alpha, seed=0)
+    nm, mean = eng.score(list(natives), b, lut, want_matrix=True, want_mean=True)
+    x = ref_np.encode_batch(seqs, alpha)
+    for m in range(M):
+        assert_scores(nm[:, m], ref_np.cnn_forward(x, ws[m]), f"full batch member {m}")
+    assert np.array_equal(mean, np.mean(nm, axis=1))
+    perm = np.random.default_rng(1).permutation(N)
+    nm_p, mean_p = eng.score(list(natives), b[perm], lut, want_matrix=True, want_mean=True)
+    assert np.array_equal(nm_p, nm[perm]) and np.array_equal(mean_p, mean[perm])      # row independence, bit-exact
+    nm_c = np.concatenate([eng.score(list(natives), b[i:i + 33_333], lut)[0] for i in range(0, N, 33_333)])
+    assert np.array_equal(nm_c, nm)                                                    # chunk invariance
+    # all 4^8 8-mers exist in TF-binding: identical sequences must score identically
+    _, inv = np.unique(b, axis=0, return_inverse=True)
+    order = np.argsort(inv, kind="stable")
+    same = inv[order][1:] == inv[order][:-1]
+    assert np.array_equal(mean[order][1:][same], mean[order][:-1][same])
+
+
+def test_baseline_config3_and_4_shapes(eng):
+    """configs[2] (RNA L=14: MLP + NoisyAbstractModel) and configs[3] (AAV L=90, A=20:
+    8-member GlobalEpistasis ensemble) at one-GPU batch sizes."""
+    b, seqs = rand_seqs(100_000, 14, "UGCA", seed=3)
+    nm, w = make_native(eng, "mlp", 14, 4, 100, seed=1)
+    got, _ = eng.score([nm], b, _native.make_lut("UGCA"))
+    assert_scores(got[:, 0], ref_np.keras_fitness(seqs, "UGCA", "mlp", w, exact=True), "C3 mlp")
+    b, seqs = rand_seqs(100_000, 90, s_utils.AAS, seed=4)
+    natives, ws = zip(*[make_native(eng, "ge", 90, 20, 100, seed=2000 + m) for m in range(8)])
+    nm8, mean = eng.score(list(natives), b, _native.make_lut(s_utils.AAS), want_matrix=True, want_mean=True)
+    codes = ref_np.encode_codes(seqs, s_utils.AAS)
+    for m in range(8):
+        assert_scores(nm8[:, m], c_oracle.forward("ge", codes, 20, ws[m]), f"C4 ge member {m}")
+    assert np.array_equal(mean, np.mean(nm8, axis=1))

@@ -1,0 +1,203 @@
+"""Host-side logic of the drop-in API (no GPU): names, cost accounting, input
+marshalling, error types, constructors -- the scenarios of the reference's own
+tests/test_models.py plus the golden Ensemble / AdaptiveEnsemble fixtures on the
+foreign-member (host stacking) path."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import flexs_amd
+from flexs_amd import _native
+from flexs_amd.baselines import models as bm
+from flexs_amd.utils import sequence_utils as s_utils
+
+rng = np.random.default_rng(0)
+
+
+class FakeModel(flexs_amd.Model):
+    def _fitness_function(self, sequences):
+        return rng.random(size=len(sequences))
+
+    def train(self, *args, **kwargs):
+        pass
+
+
+class FakeConstantModel(flexs_amd.Model):
+    def __init__(self, constant):
+        super().__init__(name="ConstantModel")
+        self.constant = constant
+
+    def _fitness_function(self, sequences):
+        return np.ones(len(sequences)) * self.constant
+
+    def train(self, *args, **kwargs):
+        pass
+
+
+class FixedModel(flexs_amd.Model):
+    def __init__(self, name, values):
+        super().__init__(name)
+        self.values = values
+        self.trained = 0
+
+    def _fitness_function(self, sequences):
+        return self.values[: len(sequences)]
+
+    def train(self, sequences, labels):
+        self.trained += 1
+
+
+def test_landscape_cost_accounting():
+    m = FakeConstantModel(3)
+    assert m.cost == 0 and m.name == "ConstantModel"
+    m.get_fitness(["A", "B"])
+    m.get_fitness(np.array(["A"]))
+    assert m.cost == 3
+    m.cost = 0                                     # explorers reset it (flexs/explorer.py:126)
+    assert m.cost == 0
+    lam = flexs_amd.LandscapeAsModel(m)
+    assert lam.name == "LandscapeAsModel=ConstantModel"
+    assert lam.get_fitness(["A"]).tolist() == [3.0] and lam.cost == 1 and m.cost == 0
+    with pytest.raises(TypeError):
+        flexs_amd.Landscape("abstract")            # abstract base, like the reference
+
+
+def test_adaptive_ensemble_reference_scenario():
+    """tests/test_models.py:36-52 of the reference."""
+    ens = bm.AdaptiveEnsemble([FakeConstantModel(1), FakeConstantModel(2)])
+    assert np.sum(ens.weights) == 1
+    assert ens.get_fitness(["ATC"]) == 1.5
+    assert ens.name == "AdaptiveEns(ConstantModel|ConstantModel)"
+    members = [FakeModel(name="FakeModel") for _ in range(2)]
+    ens = bm.AdaptiveEnsemble(members)
+    ens.train(["ATC"] * 15, list(range(15)))
+    assert np.any(ens.weights != np.ones(2) / 2)
+    assert np.isclose(np.sum(ens.weights), 1)
+
+
+def test_ensemble_golden_host_path(golden_dir):
+    meta = json.load(open(os.path.join(golden_dir, "ensemble.json")))
+    arrs = np.load(os.path.join(golden_dir, "ensemble.npz"))
+    seqs = meta["sequences"]
+    for ci, case in enumerate(meta["cases"]):
+        vals = arrs[f"in{ci}"]
+        members = [FixedModel(f"m{j}", np.ascontiguousarray(vals[:, j])) for j in range(case["M"])]
+        e = flexs_amd.Ensemble(members)
+        out = e.get_fitness(seqs)
+        assert e.name == case["name"]
+        assert out.dtype == np.dtype(case["out_dtype"]) and np.array_equal(out, arrs[f"out{ci}"])
+        e.get_fitness(seqs[:10])
+        ident = flexs_amd.Ensemble(members, combine_with=lambda x: x).get_fitness(seqs)
+        assert np.array_equal(ident, arrs[f"ident{ci}"])
+        e.train(seqs, np.zeros(len(seqs)))
+        assert e.cost == case["ens_cost"]
+        assert [m.cost for m in members] == case["member_costs"]
+        assert [m.trained for m in members] == case["member_trained"]
+    members = [FixedModel(f"a{j}", np.ascontiguousarray(arrs["ada_in"][:, j])) for j in range(4)]
+    ae = bm.AdaptiveEnsemble(members)
+    assert ae.name == meta["adaptive"]["name"]
+    assert np.array_equal(ae.get_fitness(seqs), arrs["ada_out_default"])
+    ae.weights = bm.adaptive_ensemble.r2_weights(arrs["ada_preds"], arrs["ada_labels"])
+    assert np.allclose(ae.weights, arrs["ada_w"], rtol=1e-12)
+    ae.weights = arrs["ada_w"]
+    assert np.array_equal(ae.get_fitness(seqs), arrs["ada_out_w"])
+    assert ae.cost == meta["adaptive"]["cost"] and [m.cost for m in members] == meta["adaptive"]["member_costs"]
+
+
+def test_model_names_and_shapes():
+    cnn = bm.CNN(8, 32, 100, "TGCA")
+    assert cnn.name == "CNN_hidden_size_100_num_filters_32"            # cnn.py:58-59
+    assert cnn.model.count_params() == 22429
+    assert bm.CNN(237, 32, 100, s_utils.AAS).model.count_params() == 41373
+    mlp = bm.MLP(14, 100, "UGCA")
+    assert mlp.name == "MLP_hidden_size_100" and mlp.model.count_params() == 26001
+    ge = bm.GlobalEpistasisModel(90, 100, s_utils.AAS)
+    assert ge.name == "MLP_hidden_size_100"                            # sic, global_epistasis_model.py:39-40
+    assert ge.model.count_params() == 12202
+    assert bm.CNN(8, 32, 100, "TGCA", name="x").name == "x"
+    assert cnn.batch_size == 256 and cnn.epochs == 20 and cnn.alphabet == "TGCA"
+    ens = flexs_amd.Ensemble([cnn, mlp])
+    assert ens.name == "Ens(CNN_hidden_size_100_num_filters_32|MLP_hidden_size_100)"
+    # Keras-like weight access
+    w = cnn.model.get_weights()
+    assert [a.shape for a in w][:4] == [(5, 4, 32), (32,), (5, 32, 32), (32,)]
+    assert all(np.all(a == 0) for a in w[1::2])                        # zero biases, glorot kernels
+    lim = np.sqrt(6.0 / (5 * 4 + 5 * 32))
+    assert np.abs(w[0]).max() <= lim and np.abs(w[0]).max() > 0.5 * lim
+    with pytest.raises(ValueError):
+        cnn.model.set_weights(w[:-1])
+    nam = bm.NoisyAbstractModel(FakeConstantModel(2), signal_strength=0.75)
+    assert nam.name == "NAMb_ss0.75" and nam.ss == 0.75 and nam.cache == {}
+
+
+def test_valid_conv_shorter_than_kernel_raises_at_construction():
+    with pytest.raises(ValueError):
+        bm.CNN(seq_len=3, num_filters=1, hidden_size=1, alphabet="TGCA")   # default kernel_size=5
+    bm.CNN(seq_len=3, num_filters=1, hidden_size=1, kernel_size=2, alphabet="TGCA")  # tests/test_models.py:56-62
+
+
+def test_sequences_to_bytes():
+    b = _native.sequences_to_bytes(["ACGT", "TTTT"])
+    assert b.dtype == np.uint8 and b.shape == (2, 4) and bytes(b[0]) == b"ACGT"
+    assert np.array_equal(_native.sequences_to_bytes(np.array(["ACGT", "TTTT"])), b)
+    assert np.array_equal(_native.sequences_to_bytes(np.array([b"ACGT", b"TTTT"])), b)
+    assert np.array_equal(_native.sequences_to_bytes(("ACGT", "TTTT")), b)
+    assert np.array_equal(_native.sequences_to_bytes([np.str_("ACGT"), np.str_("TTTT")]), b)
+    assert _native.sequences_to_bytes([], L=8).shape == (0, 8)
+    for ragged in (["ACGT", "TTT"], np.array(["ACGT", "TT"]), ["ACGTA", "TTT"]):
+        with pytest.raises(ValueError):
+            _native.sequences_to_bytes(ragged)
+    with pytest.raises(ValueError):
+        _native.sequences_to_bytes(["ACGT"], L=8)
+    with pytest.raises(ValueError):
+        _native.sequences_to_bytes(["ACሴT"])
+
+
+def test_lut_first_occurrence():
+    lut = _native.make_lut("TGCA")
+    assert [lut[ord(c)] for c in "TGCA"] == [0, 1, 2, 3] and lut[ord("X")] == 0xFF
+    assert _native.make_lut("ABAC")[ord("A")] == 0     # str.index semantics
+
+
+def test_sequence_utils_host_helpers():
+    assert s_utils.AAS == "ILVAGMFYWEDQNHCRKSTP" and s_utils.RNAA == "UGCA" and s_utils.DNAA == "TGCA" and s_utils.BA == "01"
+    muts = s_utils.generate_single_mutants("AT", "TGCA")
+    assert muts[0] == "AT" and len(muts) == 1 + 2 * 4 and muts[1] == "TT" and muts[4] == "AT" and muts[5] == "AT"
+    seqs = s_utils.generate_random_sequences(7, 5, "TGCA")
+    assert len(seqs) == 5 and all(len(s) == 7 and set(s) <= set("TGCA") for s in seqs)
+    assert s_utils.generate_random_mutant("ACGT", 0.0, "TGCA") == "ACGT"
+    m = s_utils.generate_random_mutant("ACGT" * 10, 1.0, "T")
+    assert m == "T" * 40
+    base = np.eye(4)[[0, 1, 2, 3]]
+    sample = np.zeros((4, 4)); sample[1, 3] = 1
+    out = s_utils.construct_mutant_from_sample(sample, base)
+    assert out[1].tolist() == [0, 0, 0, 1] and np.array_equal(out[[0, 2, 3]], base[[0, 2, 3]])
+    assert s_utils.string_to_one_hot("", "TGCA").shape == (0, 4)
+
+
+def test_training_reduces_loss_and_bumps_version():
+    """PyTorch replacement of model.fit (keras_model.py:49-67): statistical check only."""
+    import torch
+
+    torch.manual_seed(0)
+    r = np.random.default_rng(1)
+    alphabet, L = "TGCA", 8
+    seqs = ["".join(alphabet[i] for i in row) for row in r.integers(0, 4, (400, L))]
+    labels = np.array([s.count("A") / L for s in seqs])
+    from oracle import ref_np    # checker only
+
+    for model in (bm.MLP(L, 32, alphabet, seed=0), bm.GlobalEpistasisModel(L, 16, alphabet, seed=0),
+                  bm.CNN(L, 8, 16, alphabet, seed=0)):
+        kind = model.model.kind
+        before = np.mean((ref_np.keras_fitness(seqs, alphabet, kind, model.model.get_weights()) - labels) ** 2)
+        v0 = getattr(model.model, "_version", 0)
+        model.train(seqs, labels)
+        after = np.mean((ref_np.keras_fitness(seqs, alphabet, kind, model.model.get_weights()) - labels) ** 2)
+        assert after < 0.5 * before, (kind, before, after)
+        assert model.model._version == v0 + 1
+    with pytest.raises(ValueError):
+        bm.MLP(L, 8, alphabet).train(["ACGTXCGT"], [0.0])
+    with pytest.raises(ValueError):
+        bm.MLP(L, 8, alphabet).train(["ACG"], [0.0])

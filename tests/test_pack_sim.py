@@ -1,0 +1,101 @@
+"""CPU checks of the pieces of the HIP path that do not need a GPU:
+  * the host weight packing (Keras order -> MFMA fragment order) + the kernels'
+    dataflow, via the lane-level model in tests/mfma_sim.py, against the oracle;
+  * the bit-parallel Levenshtein (same header the device kernel compiles)."""
+import json
+import os
+
+import numpy as np
+import pytest
+from hypothesis import given, settings
+from hypothesis import strategies as st
+
+import mfma_sim
+from flexs_amd import _native
+from oracle import c_oracle, ref_np
+
+
+@pytest.mark.parametrize("L,A,alpha", [(8, 4, "TGCA"), (5, 4, "TGCA"), (14, 4, "UGCA"), (27, 20, ref_np.AAS)])
+def test_cnn_dataflow_matches_oracle(L, A, alpha):
+    K, F, H = 5, 32, 100
+    rng = np.random.default_rng(L)
+    w = ref_np.synth_weights(ref_np.cnn_shapes(L, A, F, H, K), 1000)
+    packed = _native.debug_pack_weights(_native.FX_CNN, L, A, F, H, K, w)
+    lay = _native.debug_pack_layout(_native.FX_CNN, L, A, F, H, K)
+    assert lay["FT"] == 2 and lay["HT"] == 7
+    codes = rng.integers(0, A, (16, L)).astype(np.uint8)
+    seqs = ["".join(alpha[c] for c in r) for r in codes]
+    got = mfma_sim.cnn_tile(packed, lay, codes, A, K, F, H)
+    want = ref_np.keras_fitness(seqs, alpha, "cnn", w, exact=True)
+    assert np.abs(got - want).max() < 1e-12
+
+
+@pytest.mark.parametrize("L,A,alpha,H", [(14, 4, "UGCA", 100), (8, 4, "TGCA", 100), (9, 20, ref_np.AAS, 100),
+                                         (14, 4, "UGCA", 97)])
+def test_mlp_ge_dataflow_matches_oracle(L, A, alpha, H):
+    rng = np.random.default_rng(7)
+    codes = rng.integers(0, A, (16, L)).astype(np.uint8)
+    seqs = ["".join(alpha[c] for c in r) for r in codes]
+    for kind, shapes, fn, k in (("mlp", ref_np.mlp_shapes(L, A, H), mfma_sim.mlp_tile, _native.FX_MLP),
+                                ("ge", ref_np.ge_shapes(L, A, H), mfma_sim.ge_tile, _native.FX_GE)):
+        w = ref_np.synth_weights(shapes, 5)
+        packed = _native.debug_pack_weights(k, L, A, 0, H, 0, w)
+        lay = _native.debug_pack_layout(k, L, A, 0, H, 0)
+        got = fn(packed, lay, codes, A, H)
+        want = ref_np.keras_fitness(seqs, alpha, kind, w, exact=True)
+        assert np.abs(got - want).max() < 1e-12, kind
+
+
+def test_packed_sizes():
+    # CNN(32,100,K5) on a 4-letter alphabet: 25 780 floats = 100.7 KiB -> fits the 160 KiB LDS
+    assert _native.lib().fx_debug_packed_size(_native.FX_CNN, 8, 4, 32, 100, 5) == 25780
+    lay = _native.debug_pack_layout(_native.FX_CNN, 237, 20, 32, 100, 5)
+    assert lay["conv_floats"] * 4 < 160 * 1024            # conv part alone fits for the protein alphabet
+    with pytest.raises(ValueError):
+        _native.debug_pack_weights(_native.FX_CNN, 8, 4, 32, 100, 5, [np.zeros(3, np.float32)])
+
+
+# ---------------------------------------------------------------- bit-parallel Levenshtein
+def test_myers_known_answers(golden_dir):
+    known = json.load(open(os.path.join(golden_dir, "edit_distance_known.json")))["known"]
+    for k in known:                                        # L = 66, 90, 238: 2- and 4-word cases
+        assert _native.debug_myers(k["seq"].encode(), k["wt"].encode()) == k["levenshtein_dp"]
+
+
+@settings(max_examples=300, deadline=None)
+@given(st.text(alphabet="ACGT", min_size=0, max_size=40), st.text(alphabet="ACGT", min_size=0, max_size=40))
+def test_myers_equals_dp_short(a, b):
+    assert _native.debug_myers(a.encode(), b.encode()) == c_oracle.levenshtein(a, b)
+
+
+@settings(max_examples=150, deadline=None)
+@given(st.integers(1, 256), st.integers(0, 300), st.integers(0, 2**31), st.integers(2, 20))
+def test_myers_equals_dp_multiword(la, lb, seed, nsym):
+    rng = np.random.default_rng(seed)
+    a = bytes(rng.integers(65, 65 + nsym, la).astype(np.uint8))
+    # make b a noisy copy of a half of the time so that distances are small and structured
+    if seed % 2 and la:
+        b = bytearray(a)
+        for _ in range(int(rng.integers(0, 8))):
+            i = int(rng.integers(0, max(len(b), 1)))
+            op = int(rng.integers(0, 3))
+            if op == 0 and b:
+                b[i % len(b)] = int(rng.integers(65, 65 + nsym))
+            elif op == 1 and b:
+                del b[i % len(b)]
+            else:
+                b.insert(i % (len(b) + 1), int(rng.integers(65, 65 + nsym)))
+        b = bytes(b)
+    else:
+        b = bytes(rng.integers(65, 65 + nsym, lb).astype(np.uint8))
+    assert _native.debug_myers(a, b) == c_oracle.levenshtein(a, b)
+
+
+def test_myers_boundaries():
+    for L in (1, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256):
+        a = bytes([65 + (i * 7) % 4 for i in range(L)])
+        b = bytes([65 + (i * 5 + 1) % 4 for i in range(L)])
+        assert _native.debug_myers(a, b) == c_oracle.levenshtein(a, b)
+        assert _native.debug_myers(a, a) == 0
+        assert _native.debug_myers(a, a[1:] + a[:1]) == c_oracle.levenshtein(a, a[1:] + a[:1])
+    assert _native.debug_myers(b"x" * 257, b"x") == -1    # > 256: unsupported pattern length
