@@ -1,0 +1,62 @@
+"""Timed reference-style CPU path for bench.py's `cpu_baseline` leg.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Run as a child process:
+
+    python -m oracle.cpu_baseline_cli --L 8 --alphabet TGCA --members 3 --sample 50000 --budget 12
+
+Regenerates the bench workload from its seeds (flexs_amd.synth), times
+`oracle.torch_twin.ensemble_fitness_cpu` -- per-character Python encode loop
+(sequence_utils.py:44-47), 256-row fp32 forward on the host cores
+(keras_model.py:78), np.stack / np.mean (ensemble.py:55-59) -- and prints one JSON
+object.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--L", type=int, default=8)
+    ap.add_argument("--alphabet", default="TGCA")
+    ap.add_argument("--filters", type=int, default=32)
+    ap.add_argument("--hidden", type=int, default=100)
+    ap.add_argument("--kernel", type=int, default=5)
+    ap.add_argument("--members", type=int, default=3)
+    ap.add_argument("--sample", type=int, default=50_000)
+    ap.add_argument("--budget", type=float, default=12.0)
+    ap.add_argument("--max-threads", type=int, default=64)
+    a = ap.parse_args()
+
+    import torch
+
+    from flexs_amd import synth
+    from oracle import ref_np, torch_twin
+
+    threads = max(1, min(os.cpu_count() or 1, a.max_threads))
+    torch.set_num_threads(threads)
+    shapes = ref_np.cnn_shapes(a.L, len(a.alphabet), a.filters, a.hidden, a.kernel)
+    weight_sets = [synth.synthetic_weights(shapes, 1000 + m) for m in range(a.members)]
+    seqs = synth.bytes_to_strings(synth.random_sequence_bytes(a.sample, a.L, a.alphabet, seed=0))
+    torch_twin.ensemble_fitness_cpu(seqs[:512], a.alphabet, "cnn", weight_sets)           # warm-up
+    done, t0 = 0, time.perf_counter()
+    while True:
+        torch_twin.ensemble_fitness_cpu(seqs, a.alphabet, "cnn", weight_sets)
+        done += a.sample
+        el = time.perf_counter() - t0
+        if el >= a.budget or done >= 40 * a.sample:
+            break
+    print(json.dumps({
+        "value": done / el, "unit": "sequences/s", "cores": threads, "kind": "port",
+        "sample": f"{done} sequences ({done // a.sample} pass(es) over the first {a.sample} of the batch) in "
+                  f"{el:.1f} s; reference-style path: per-character Python encode loop (single thread) + 256-row "
+                  f"fp32 forward on {threads} torch threads + np.stack/np.mean; host has {os.cpu_count()} logical cores",
+    }))
+
+
+if __name__ == "__main__":
+    main()
