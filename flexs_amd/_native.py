@@ -391,12 +391,12 @@ def debug_pack_weights(kind, L, A, F, H, K, arrays) -> np.ndarray:
 
 
 def debug_pack_layout(kind, L, A, F, H, K) -> dict:
-    v = (C.c_int64 * 12)()
+    v = (C.c_int64 * 16)()
     rc = lib().fx_debug_pack_layout(kind, L, A, F, H, K, v)
     if rc != FX_OK:
         raise ValueError(status_name(rc))
     names = ["FT", "HT", "SG1", "off_first", "off_c2", "off_c3", "off_cb", "conv_floats", "off_d1", "off_d2",
-             "off_d3", "off_db"]
+             "off_d3", "off_db", "RLH", "total_floats"]
     return dict(zip(names, list(v)))
 
 

@@ -573,12 +573,12 @@ int fx_nam_combine(fx_engine* e, int64_t Q, const double* signal, const double* 
 int64_t fx_debug_packed_size(int kind, int L, int A, int F, int H, int K) {
     return fx_pack_layout(FxShape{kind, L, A, F, H, K}).total_floats;
 }
-int fx_debug_pack_layout(int kind, int L, int A, int F, int H, int K, int64_t* out12) {
-    if (!out12) return FX_EINVAL;
+int fx_debug_pack_layout(int kind, int L, int A, int F, int H, int K, int64_t* out16) {
+    if (!out16) return FX_EINVAL;
     const FxPackLayout p = fx_pack_layout(FxShape{kind, L, A, F, H, K});
-    const int64_t v[12] = {p.FT, p.HT, p.SG1, p.off_first, p.off_c2, p.off_c3, p.off_cb, p.conv_floats,
-                           p.off_d1, p.off_d2, p.off_d3, p.off_db};
-    std::memcpy(out12, v, sizeof(v));
+    const int64_t v[16] = {p.FT, p.HT, p.SG1, p.off_first, p.off_c2, p.off_c3, p.off_cb, p.conv_floats,
+                           p.off_d1, p.off_d2, p.off_d3, p.off_db, p.RLH, p.total_floats, 0, 0};
+    std::memcpy(out16, v, sizeof(v));
     return FX_OK;
 }
 int fx_debug_pack_weights(int kind, int L, int A, int F, int H, int K, const float* blob, int64_t n, float* packed,

@@ -29,6 +29,7 @@ struct FxShape {
 struct FxPackLayout {
     int FT, HT;                 // output tiles of 16: filters, hidden units
     int SG1;                    // first-layer step groups = ceil(rows / 16)
+    int RLH;                    // k-steps that carry real channels in the LAST hidden tile (1..4), see fx_hidden_pos
     int64_t off_first;          // SG1 x (FT|HT) blocks
     int64_t off_c2, off_c3;     // K x FT x FT, K3 x FT x FT blocks           (CNN)
     int64_t off_cb;             // b1[16FT] b2[16FT] b3[16FT]                 (CNN)
@@ -39,6 +40,12 @@ struct FxPackLayout {
 };
 
 FxPackLayout fx_pack_layout(const FxShape& s);
+// Position of hidden unit h inside the zero-padded 16*HT layout.  Hidden units are
+// interchangeable, so the tail tile (H - 16*(HT-1) real units) is laid out k-step-major
+// (unit i -> lane group i % 4, register i / 4): its real channels then occupy only
+// ceil(tail / 4) of the 4 k-steps, and the layers that CONSUME the tile skip the rest
+// (H = 100: 25 instead of 28 k-steps per HxH layer).
+int fx_hidden_pos(int h, int H);
 int64_t fx_num_params(const FxShape& s);
 // Keras get_weights() blob -> packed fragment layout (host only, no device needed).
 void fx_pack_weights(const FxShape& s, const float* blob, float* packed);

@@ -47,19 +47,25 @@ __device__ __forceinline__ float fx_nan_to_num(float v) {
 // Loop order (mi, r, mo, nt) keeps >= TO*NT independent MFMAs between two
 // accumulations into the same register quad (16x16x4 f32: 32-cycle issue,
 // 40-cycle dependent latency).
+// rl_last (wave-uniform, 1..4): number of k-steps of the LAST input tile that carry real
+// channels (hidden-unit tail laid out k-step-major by the packer, fx_hidden_pos); the
+// remaining k-steps would multiply zeros and are skipped.
 template <int TI, int TO, int NT, typename WPtr>
-__device__ __forceinline__ void mma_layer(WPtr wblk, const f4 (&in)[TI][NT], f4 (&acc)[TO][NT], int lane) {
+__device__ __forceinline__ void mma_layer(WPtr wblk, const f4 (&in)[TI][NT], f4 (&acc)[TO][NT], int lane,
+                                          int rl_last = 4) {
 #pragma unroll
     for (int mi = 0; mi < TI; ++mi) {
         f4 a[TO];
 #pragma unroll
         for (int mo = 0; mo < TO; ++mo) a[mo] = wblk[(mi * TO + mo) * 64 + lane];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r) {
+            if (mi == TI - 1 && r >= rl_last) break;
 #pragma unroll
             for (int mo = 0; mo < TO; ++mo)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[mo][nt] = mfma16(a[mo][r], in[mi][nt][r], acc[mo][nt]);
+        }
     }
 }
 

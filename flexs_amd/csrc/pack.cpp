@@ -2,6 +2,7 @@
 // Pure C++ (no device calls) so it is unit-testable on a machine without a GPU
 // through fx_debug_pack_weights().  Layout documented in fx_common.h / DESIGN.md.
 #include <cstring>
+#include <vector>
 
 #include "fx_common.h"
 
@@ -20,10 +21,22 @@ int64_t fx_num_params(const FxShape& s) {
     return -1;
 }
 
+int fx_hidden_pos(int h, int H) {
+    const int HT = (H + 15) / 16, base = 16 * (HT - 1);
+    if (h < base) return h;
+    const int i = h - base;
+    return base + 4 * (i % 4) + i / 4;
+}
+
 FxPackLayout fx_pack_layout(const FxShape& s) {
     FxPackLayout p{};
     p.FT = (s.F + 15) / 16;
     p.HT = (s.H + 15) / 16;
+    {
+        const int tail = s.H - 16 * (p.HT - 1);
+        p.RLH = tail >= 4 ? (tail + 3) / 4 : 1;          // unit i sits in k-step i / 4
+        if (p.RLH > 4) p.RLH = 4;
+    }
     const int64_t BLK = 256;
     int64_t off = 0;
     if (s.kind == FX_CNN) {
@@ -60,26 +73,43 @@ FxPackLayout fx_pack_layout(const FxShape& s) {
 }
 
 namespace {
-// W is [rows][cols] row-major.  dense-style block: kin = 16*mi + 4*g + r.
-void pack_dense_block(const float* W, int rows, int cols, int mi, int mo, float* blk) {
+// Maps from a POSITION in the padded layout to the source index (or -1 = zero padding).
+struct PosMap {
+    std::vector<int> src;
+    static PosMap identity(int n, int padded) {
+        PosMap m; m.src.assign(padded, -1);
+        for (int i = 0; i < n; ++i) m.src[i] = i;
+        return m;
+    }
+    static PosMap hidden(int H) {
+        const int HT = (H + 15) / 16;
+        PosMap m; m.src.assign(16 * HT, -1);
+        for (int h = 0; h < H; ++h) m.src[fx_hidden_pos(h, H)] = h;
+        return m;
+    }
+    int operator()(int pos) const { return pos < (int)src.size() ? src[pos] : -1; }
+};
+
+// W is [rows][cols] row-major.  dense-style block: input position = 16*mi + 4*g + r.
+void pack_dense_block(const float* W, int cols, const PosMap& rmap, const PosMap& cmap, int mi, int mo, float* blk) {
     for (int lane = 0; lane < 64; ++lane)
         for (int r = 0; r < 4; ++r) {
-            int kin = 16 * mi + 4 * (lane >> 4) + r;
-            int o = 16 * mo + (lane & 15);
-            blk[lane * 4 + r] = (kin < rows && o < cols) ? W[(int64_t)kin * cols + o] : 0.f;
+            const int kin = rmap(16 * mi + 4 * (lane >> 4) + r);
+            const int o = cmap(16 * mo + (lane & 15));
+            blk[lane * 4 + r] = (kin >= 0 && o >= 0) ? W[(int64_t)kin * cols + o] : 0.f;
         }
 }
-// first-layer block: kin = 16*sg + 4*r + g.
-void pack_first_block(const float* W, int rows, int cols, int sg, int mo, float* blk) {
+// first-layer block: input row = 16*sg + 4*r + g.
+void pack_first_block(const float* W, int rows, int cols, const PosMap& cmap, int sg, int mo, float* blk) {
     for (int lane = 0; lane < 64; ++lane)
         for (int r = 0; r < 4; ++r) {
-            int kin = 16 * sg + 4 * r + (lane >> 4);
-            int o = 16 * mo + (lane & 15);
-            blk[lane * 4 + r] = (kin < rows && o < cols) ? W[(int64_t)kin * cols + o] : 0.f;
+            const int kin = 16 * sg + 4 * r + (lane >> 4);
+            const int o = cmap(16 * mo + (lane & 15));
+            blk[lane * 4 + r] = (kin < rows && o >= 0) ? W[(int64_t)kin * cols + o] : 0.f;
         }
 }
-void pack_vec(const float* v, int n, int padded, float* dst) {
-    for (int i = 0; i < padded; ++i) dst[i] = i < n ? v[i] : 0.f;
+void pack_vec(const float* v, const PosMap& map, int padded, float* dst) {
+    for (int i = 0; i < padded; ++i) dst[i] = map(i) >= 0 ? v[map(i)] : 0.f;
 }
 }  // namespace
 
@@ -87,6 +117,7 @@ void fx_pack_weights(const FxShape& s, const float* blob, float* packed) {
     const FxPackLayout p = fx_pack_layout(s);
     std::memset(packed, 0, sizeof(float) * (size_t)p.total_floats);
     const int A = s.A, F = s.F, H = s.H, K = s.K, L = s.L, FT = p.FT, HT = p.HT;
+    const PosMap hid = PosMap::hidden(H), fil = PosMap::identity(F, 16 * FT);
     const float* w = blob;
     if (s.kind == FX_CNN) {
         const int K3 = s.K3();
@@ -104,29 +135,29 @@ void fx_pack_weights(const FxShape& s, const float* blob, float* packed) {
         const float* c3 = w;
         for (int sg = 0; sg < p.SG1; ++sg)
             for (int mo = 0; mo < FT; ++mo)
-                pack_first_block(w1, K * A, F, sg, mo, packed + p.off_first + ((int64_t)sg * FT + mo) * 256);
+                pack_first_block(w1, K * A, F, fil, sg, mo, packed + p.off_first + ((int64_t)sg * FT + mo) * 256);
         for (int j = 0; j < K; ++j)
             for (int mi = 0; mi < FT; ++mi)
                 for (int mo = 0; mo < FT; ++mo)
-                    pack_dense_block(w2 + (int64_t)j * F * F, F, F, mi, mo,
+                    pack_dense_block(w2 + (int64_t)j * F * F, F, fil, fil, mi, mo,
                                      packed + p.off_c2 + (((int64_t)j * FT + mi) * FT + mo) * 256);
         for (int j = 0; j < K3; ++j)
             for (int mi = 0; mi < FT; ++mi)
                 for (int mo = 0; mo < FT; ++mo)
-                    pack_dense_block(w3 + (int64_t)j * F * F, F, F, mi, mo,
+                    pack_dense_block(w3 + (int64_t)j * F * F, F, fil, fil, mi, mo,
                                      packed + p.off_c3 + (((int64_t)j * FT + mi) * FT + mo) * 256);
-        pack_vec(b1, F, 16 * FT, packed + p.off_cb);
-        pack_vec(b2, F, 16 * FT, packed + p.off_cb + 16 * FT);
-        pack_vec(b3, F, 16 * FT, packed + p.off_cb + 32 * FT);
+        pack_vec(b1, fil, 16 * FT, packed + p.off_cb);
+        pack_vec(b2, fil, 16 * FT, packed + p.off_cb + 16 * FT);
+        pack_vec(b3, fil, 16 * FT, packed + p.off_cb + 32 * FT);
         for (int mi = 0; mi < FT; ++mi)
             for (int mo = 0; mo < HT; ++mo)
-                pack_dense_block(d1, F, H, mi, mo, packed + p.off_d1 + ((int64_t)mi * HT + mo) * 256);
+                pack_dense_block(d1, H, fil, hid, mi, mo, packed + p.off_d1 + ((int64_t)mi * HT + mo) * 256);
         for (int mi = 0; mi < HT; ++mi)
             for (int mo = 0; mo < HT; ++mo)
-                pack_dense_block(d2, H, H, mi, mo, packed + p.off_d2 + ((int64_t)mi * HT + mo) * 256);
-        pack_vec(c1, H, 16 * HT, packed + p.off_db);
-        pack_vec(c2, H, 16 * HT, packed + p.off_db + 16 * HT);
-        pack_vec(d3, H, 16 * HT, packed + p.off_db + 32 * HT);
+                pack_dense_block(d2, H, hid, hid, mi, mo, packed + p.off_d2 + ((int64_t)mi * HT + mo) * 256);
+        pack_vec(c1, hid, 16 * HT, packed + p.off_db);
+        pack_vec(c2, hid, 16 * HT, packed + p.off_db + 16 * HT);
+        pack_vec(d3, hid, 16 * HT, packed + p.off_db + 32 * HT);
         packed[p.off_db + 48 * HT] = c3[0];
     } else if (s.kind == FX_MLP) {
         const float* d1 = w;  w += (int64_t)L * A * H;
@@ -139,16 +170,16 @@ void fx_pack_weights(const FxShape& s, const float* blob, float* packed) {
         const float* c4 = w;
         for (int sg = 0; sg < p.SG1; ++sg)
             for (int mo = 0; mo < HT; ++mo)
-                pack_first_block(d1, L * A, H, sg, mo, packed + p.off_first + ((int64_t)sg * HT + mo) * 256);
+                pack_first_block(d1, L * A, H, hid, sg, mo, packed + p.off_first + ((int64_t)sg * HT + mo) * 256);
         for (int mi = 0; mi < HT; ++mi)
             for (int mo = 0; mo < HT; ++mo) {
-                pack_dense_block(d2, H, H, mi, mo, packed + p.off_d2 + ((int64_t)mi * HT + mo) * 256);
-                pack_dense_block(d3, H, H, mi, mo, packed + p.off_d3 + ((int64_t)mi * HT + mo) * 256);
+                pack_dense_block(d2, H, hid, hid, mi, mo, packed + p.off_d2 + ((int64_t)mi * HT + mo) * 256);
+                pack_dense_block(d3, H, hid, hid, mi, mo, packed + p.off_d3 + ((int64_t)mi * HT + mo) * 256);
             }
-        pack_vec(c1, H, 16 * HT, packed + p.off_db);
-        pack_vec(c2, H, 16 * HT, packed + p.off_db + 16 * HT);
-        pack_vec(c3, H, 16 * HT, packed + p.off_db + 32 * HT);
-        pack_vec(d4, H, 16 * HT, packed + p.off_db + 48 * HT);
+        pack_vec(c1, hid, 16 * HT, packed + p.off_db);
+        pack_vec(c2, hid, 16 * HT, packed + p.off_db + 16 * HT);
+        pack_vec(c3, hid, 16 * HT, packed + p.off_db + 32 * HT);
+        pack_vec(d4, hid, 16 * HT, packed + p.off_db + 48 * HT);
         packed[p.off_db + 64 * HT] = c4[0];
     } else {
         const float* d1 = w;  w += (int64_t)L * A;
@@ -159,16 +190,16 @@ void fx_pack_weights(const FxShape& s, const float* blob, float* packed) {
         const float* c3 = w;  w += H;
         const float* d4 = w;  w += H;
         const float* c4 = w;
-        pack_vec(d1, L * A, (int)rup((int64_t)L * A, 4), packed + p.off_first);
+        pack_vec(d1, PosMap::identity(L * A, (int)rup((int64_t)L * A, 4)), (int)rup((int64_t)L * A, 4), packed + p.off_first);
         for (int mi = 0; mi < HT; ++mi)
             for (int mo = 0; mo < HT; ++mo)
-                pack_dense_block(d3, H, H, mi, mo, packed + p.off_d3 + ((int64_t)mi * HT + mo) * 256);
+                pack_dense_block(d3, H, hid, hid, mi, mo, packed + p.off_d3 + ((int64_t)mi * HT + mo) * 256);
         float* db = packed + p.off_db;
         db[0] = c1[0];
-        pack_vec(d2, H, 16 * HT, db + 4);
-        pack_vec(c2, H, 16 * HT, db + 4 + 16 * HT);
-        pack_vec(c3, H, 16 * HT, db + 4 + 32 * HT);
-        pack_vec(d4, H, 16 * HT, db + 4 + 48 * HT);
+        pack_vec(d2, hid, 16 * HT, db + 4);
+        pack_vec(c2, hid, 16 * HT, db + 4 + 16 * HT);
+        pack_vec(c3, hid, 16 * HT, db + 4 + 32 * HT);
+        pack_vec(d4, hid, 16 * HT, db + 4 + 48 * HT);
         db[4 + 64 * HT] = c4[0];
     }
 }

@@ -28,6 +28,7 @@ struct CnnArgs {
     int64_t TG;                 // tile groups per member = ceil(N / (16*NT))
     int M, Mtot, m_off;
     int L;
+    int rlh;                    // k-steps carrying real channels in the last hidden tile
     // packed-layout offsets (floats)
     int off_first, off_c2, off_c3, off_cb, conv_floats, off_d1, off_d2, off_db, total_floats;
 };
@@ -41,11 +42,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
     static_assert(A % 4 == 0, "one-hot k-steps must not straddle a tap");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int g = lane >> 4, sq = lane & 15;
     const int L = p.L, L1 = L - K + 1;
     const int lds_floats = DENSE_LDS ? p.total_floats : p.conv_floats;
     uint8_t* lut_s = reinterpret_cast<uint8_t*>(smem + lds_floats);
+    int* next_tile = reinterpret_cast<int*>(smem + lds_floats + 64);   // work counter, after the 256-byte LUT
 
     for (int i = tid; i < 64; i += blockDim.x)
         reinterpret_cast<uint32_t*>(lut_s)[i] = reinterpret_cast<const uint32_t*>(p.lut)[i];
@@ -58,6 +60,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
 
     for (int m = m_first; m <= m_last; ++m) {
         __syncthreads();                                 // previous member's readers are done
+        if (tid == 0) *next_tile = 0;
         {
             const f4* src = reinterpret_cast<const f4*>(p.w[m]);
             f4* dst = reinterpret_cast<f4*>(smem);
@@ -76,7 +79,14 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
         const int64_t t_lo = (u_lo > (int64_t)m * p.TG ? u_lo : (int64_t)m * p.TG) - (int64_t)m * p.TG;
         const int64_t t_hi = (u_hi < (int64_t)(m + 1) * p.TG ? u_hi : (int64_t)(m + 1) * p.TG) - (int64_t)m * p.TG;
 
-        for (int64_t tg = t_lo + wave; tg < t_hi; tg += nwaves) {
+        // waves pull tiles from a block-local counter: a SIMD's two waves then finish within
+        // one tile of each other whatever the split of the block's range was
+        for (;;) {
+            int pulled = 0;
+            if (lane == 0) pulled = atomicAdd(next_tile, 1);
+            pulled = __builtin_amdgcn_readfirstlane(pulled);
+            const int64_t tg = t_lo + pulled;
+            if (tg >= t_hi) break;
             // ---- this lane's sequences
             int64_t n[NT];
             const uint8_t* row[NT];
@@ -224,7 +234,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
             mma_layer<FT, HT, NT>(w_d1, gmax, h1, lane);
             relu_tiles<HT, NT>(h1);
             init_bias<HT, NT>(db + 16 * HT, h2, g);
-            mma_layer<HT, HT, NT>(w_d2, h1, h2, lane);
+            mma_layer<HT, HT, NT>(w_d2, h1, h2, lane, p.rlh);
             relu_tiles<HT, NT>(h2);
             float y[NT];
             final_dot<HT, NT>(db + 32 * HT, db[48 * HT], h2, y, g);
@@ -277,24 +287,25 @@ int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const
     CnnArgs a{};
     a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
     for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
-    a.N = N; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L;
+    a.N = N; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.rlh = lay.RLH;
     a.off_first = (int)lay.off_first; a.off_c2 = (int)lay.off_c2; a.off_c3 = (int)lay.off_c3;
     a.off_cb = (int)lay.off_cb; a.conv_floats = (int)lay.conv_floats; a.off_d1 = (int)lay.off_d1;
     a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
 
-    // variant: 1 = NT1 x 8 waves, 2 = NT2 x 4 waves, 3 = NT2 x 8 waves (A = 4 only)
+    // variant: 1 = NT1 x 8 waves, 2 = NT2 x 4 waves, 3 = NT2 x 8 waves, 4 = NT1 x 16 waves (A = 4 only)
     int variant = (int)e->cnn_variant;
-    const size_t full = (size_t)lay.total_floats * 4 + 256, conv_only = (size_t)lay.conv_floats * 4 + 256;
+    const size_t full = (size_t)lay.total_floats * 4 + 256 + 16, conv_only = (size_t)lay.conv_floats * 4 + 256 + 16;
     if (s.A == 4) {
         if (full > (size_t)e->max_lds) return FX_EUNSUPPORTED;
         if (variant == 0) variant = 1;
-        int nt = variant == 1 ? 1 : 2;
+        int nt = (variant == 1 || variant == 4) ? 1 : 2;
         a.TG = (N + 16 * nt - 1) / (16 * nt);
         switch (variant) {
             case 1: return launch_inst<4, 5, 2, 7, 1, true, 8>(e, a, full);
             case 2: return launch_inst<4, 5, 2, 7, 2, true, 4>(e, a, full);
             case 3: return launch_inst<4, 5, 2, 7, 2, true, 8>(e, a, full);
-            default: return fx_fail(e, FX_EINVAL, "cnn_variant must be 0..3");
+            case 4: return launch_inst<4, 5, 2, 7, 1, true, 16>(e, a, full);
+            default: return fx_fail(e, FX_EINVAL, "cnn_variant must be 0..4");
         }
     } else {
         if (conv_only > (size_t)e->max_lds) return FX_EUNSUPPORTED;

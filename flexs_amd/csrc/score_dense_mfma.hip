@@ -24,17 +24,18 @@ struct DenseArgs {
     unsigned* err;
     int64_t N, TG;
     int M, Mtot, m_off;
-    int L, A;
+    int L, A, rlh;
     int SG1, off_first, off_d2, off_d3, off_db, total_floats;
 };
 
 template <int KIND, int A, int HT, int NT, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int g = lane >> 4, sq = lane & 15;
     const int L = p.L;
     uint8_t* lut_s = reinterpret_cast<uint8_t*>(smem + p.total_floats);
+    int* next_tile = reinterpret_cast<int*>(smem + p.total_floats + 64);   // work counter, after the 256-byte LUT
     for (int i = tid; i < 64; i += blockDim.x)
         reinterpret_cast<uint32_t*>(lut_s)[i] = reinterpret_cast<const uint32_t*>(p.lut)[i];
 
@@ -46,6 +47,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
 
     for (int m = m_first; m <= m_last; ++m) {
         __syncthreads();
+        if (tid == 0) *next_tile = 0;
         {
             const f4* src = reinterpret_cast<const f4*>(p.w[m]);
             f4* dst = reinterpret_cast<f4*>(smem);
@@ -60,7 +62,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
         const int64_t t_lo = (u_lo > (int64_t)m * p.TG ? u_lo : (int64_t)m * p.TG) - (int64_t)m * p.TG;
         const int64_t t_hi = (u_hi < (int64_t)(m + 1) * p.TG ? u_hi : (int64_t)(m + 1) * p.TG) - (int64_t)m * p.TG;
 
-        for (int64_t tg = t_lo + wave; tg < t_hi; tg += nwaves) {
+        for (;;) {                                       // waves pull tiles from a block-local counter
+            int pulled = 0;
+            if (lane == 0) pulled = atomicAdd(next_tile, 1);
+            pulled = __builtin_amdgcn_readfirstlane(pulled);
+            const int64_t tg = t_lo + pulled;
+            if (tg >= t_hi) break;
             asm volatile("" ::: "memory");               // keep LDS weight reads inside the tile loop
             int64_t n[NT];
             const uint8_t* row[NT];
@@ -103,11 +110,11 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                 // ---- layers 2, 3
                 f4 h2[HT][NT];
                 init_bias<HT, NT>(db + 16 * HT, h2, g);
-                mma_layer<HT, HT, NT>(w_d2, h, h2, lane);
+                mma_layer<HT, HT, NT>(w_d2, h, h2, lane, p.rlh);
                 relu_tiles<HT, NT>(h2);
                 asm volatile("" ::: "memory");
                 init_bias<HT, NT>(db + 32 * HT, h, g);
-                mma_layer<HT, HT, NT>(w_d3, h2, h, lane);
+                mma_layer<HT, HT, NT>(w_d3, h2, h, lane, p.rlh);
                 relu_tiles<HT, NT>(h);
                 final_dot<HT, NT>(db + 48 * HT, db[64 * HT], h, y, g);
             } else {
@@ -142,7 +149,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                 }
                 // ---- layer 3 (HxH MFMA), layer 4 (dot)
                 init_bias<HT, NT>(db + 4 + 32 * HT, h, g);
-                mma_layer<HT, HT, NT>(w_d3, h2, h, lane);
+                mma_layer<HT, HT, NT>(w_d3, h2, h, lane, p.rlh);
                 relu_tiles<HT, NT>(h);
                 final_dot<HT, NT>(db + 4 + 48 * HT, db[4 + 64 * HT], h, y, g);
             }
@@ -188,14 +195,14 @@ int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, con
     }
     if (s.kind != FX_MLP && s.kind != FX_GE) return FX_EUNSUPPORTED;
     if (lay.HT != 7 || M > FX_MAX_M) return FX_EUNSUPPORTED;
-    const size_t lds = (size_t)lay.total_floats * 4 + 256;
+    const size_t lds = (size_t)lay.total_floats * 4 + 256 + 16;
     if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
     if (s.kind == FX_MLP && s.A != 4 && s.A != 20) return FX_EUNSUPPORTED;
 
     DenseArgs a{};
     a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
     for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
-    a.N = N; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.A = s.A;
+    a.N = N; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.A = s.A; a.rlh = lay.RLH;
     a.SG1 = lay.SG1; a.off_first = (int)lay.off_first; a.off_d2 = (int)lay.off_d2; a.off_d3 = (int)lay.off_d3;
     a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
     a.TG = (N + 15) / 16;

@@ -171,7 +171,7 @@ int fx_nam_combine(fx_engine *e, int64_t Q, const double *signal, const double *
  * fragment order) and the bit-parallel Levenshtein that the device kernels use,
  * so the CPU test-suite can check them against the oracle. */
 int64_t fx_debug_packed_size(int kind, int L, int A, int F, int H, int K);
-int fx_debug_pack_layout(int kind, int L, int A, int F, int H, int K, int64_t *out12);
+int fx_debug_pack_layout(int kind, int L, int A, int F, int H, int K, int64_t *out16);
 int fx_debug_pack_weights(int kind, int L, int A, int F, int H, int K, const float *blob, int64_t n,
                           float *packed, int64_t cap);
 int fx_debug_myers(const uint8_t *a, int la, const uint8_t *b, int lb);

@@ -36,11 +36,13 @@ def blocks(packed, off, idx):
     return packed[off + idx * 256: off + (idx + 1) * 256].reshape(64, 4)
 
 
-def mma_layer(packed, off, TI, TO, inp, acc):
+def mma_layer(packed, off, TI, TO, inp, acc, rl_last=4):
     """inp: list TI of (64,4); acc: list TO of (64,4) -- mirrors mma_layer<> in mfma_common.h"""
     for mi in range(TI):
         a = [blocks(packed, off, mi * TO + mo) for mo in range(TO)]
         for r in range(4):
+            if mi == TI - 1 and r >= rl_last:
+                break
             for mo in range(TO):
                 acc[mo] = mfma16(a[mo][:, r], inp[mi][:, r], acc[mo])
     return acc
@@ -114,7 +116,7 @@ def cnn_tile(packed, lay, codes16, A, K, F, H):
     h1 = init_bias(packed, db, HT)
     h1 = [np.maximum(x, 0) for x in mma_layer(packed, lay["off_d1"], FT, HT, gmax, h1)]
     h2 = init_bias(packed, db + 16 * HT, HT)
-    h2 = [np.maximum(x, 0) for x in mma_layer(packed, lay["off_d2"], HT, HT, h1, h2)]
+    h2 = [np.maximum(x, 0) for x in mma_layer(packed, lay["off_d2"], HT, HT, h1, h2, lay["RLH"])]
     y = final_dot(packed, db + 32 * HT, packed[db + 48 * HT], h2, HT)
     return y[:16]                                        # lanes of group 0 hold the 16 sequences
 
@@ -139,9 +141,9 @@ def mlp_tile(packed, lay, codes16, A, H):
             h[mo] = mfma16(aw, b, h[mo])
     h = [np.maximum(x, 0) for x in h]
     h2 = init_bias(packed, db + 16 * HT, HT)
-    h2 = [np.maximum(x, 0) for x in mma_layer(packed, lay["off_d2"], HT, HT, h, h2)]
+    h2 = [np.maximum(x, 0) for x in mma_layer(packed, lay["off_d2"], HT, HT, h, h2, lay["RLH"])]
     h3 = init_bias(packed, db + 32 * HT, HT)
-    h3 = [np.maximum(x, 0) for x in mma_layer(packed, lay["off_d3"], HT, HT, h2, h3)]
+    h3 = [np.maximum(x, 0) for x in mma_layer(packed, lay["off_d3"], HT, HT, h2, h3, lay["RLH"])]
     y = final_dot(packed, db + 48 * HT, packed[db + 64 * HT], h3, HT)
     return y[:16]
 
@@ -161,6 +163,6 @@ def ge_tile(packed, lay, codes16, A, H):
     b2 = init_bias(packed, db + 4 + 16 * HT, HT)
     h = [np.maximum(b2[mo] + s[:, None] * w2[mo], 0) for mo in range(HT)]
     h2 = init_bias(packed, db + 4 + 32 * HT, HT)
-    h2 = [np.maximum(x, 0) for x in mma_layer(packed, lay["off_d3"], HT, HT, h, h2)]
+    h2 = [np.maximum(x, 0) for x in mma_layer(packed, lay["off_d3"], HT, HT, h, h2, lay["RLH"])]
     y = final_dot(packed, db + 4 + 48 * HT, packed[db + 4 + 64 * HT], h2, HT)
     return y[:16]

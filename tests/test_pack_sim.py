@@ -31,7 +31,7 @@ def test_cnn_dataflow_matches_oracle(L, A, alpha):
 
 
 @pytest.mark.parametrize("L,A,alpha,H", [(14, 4, "UGCA", 100), (8, 4, "TGCA", 100), (9, 20, ref_np.AAS, 100),
-                                         (14, 4, "UGCA", 97)])
+                                         (14, 4, "UGCA", 97), (14, 4, "UGCA", 104), (14, 4, "UGCA", 107), (14, 4, "UGCA", 112)])
 def test_mlp_ge_dataflow_matches_oracle(L, A, alpha, H):
     rng = np.random.default_rng(7)
     codes = rng.integers(0, A, (16, L)).astype(np.uint8)
