@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="cnn kernel variant (0 = auto)")
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise RCCL and run the all-gather even with one rank (exercises the N>1 code path)")
     args = ap.parse_args()
 
     import torch
@@ -69,8 +71,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     N = args.batch
@@ -93,7 +97,7 @@ def main():
         d_ascii = torch.from_numpy(seq_bytes).cuda()
         d_nm = torch.empty((N, M), dtype=torch.float32, device="cuda")
         d_mean = torch.empty((N,), dtype=torch.float32, device="cuda")
-        d_all = torch.empty((world * N,), dtype=torch.float32, device="cuda") if world > 1 else None
+        d_all = torch.empty((world * N,), dtype=torch.float32, device="cuda") if use_dist else None
         ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
         ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
@@ -104,20 +108,20 @@ def main():
             if k is not None:
                 ev_b[k].record(stream)
             eng.ensemble_reduce_dev(d_nm.data_ptr(), N, M, d_mean.data_ptr())               # K3 np.mean order
-            if world > 1:
+            if use_dist:
                 dist.all_gather_into_tensor(d_all, d_mean)                                   # RCCL over xGMI
 
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(args.steps):
             step(k)
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
@@ -125,9 +129,12 @@ def main():
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_a, ev_b)]))
         got_mean = d_mean.cpu().numpy()
         got_nm = d_nm.cpu().numpy()
+        if use_dist:
+            gathered = d_all.cpu().numpy()
+            assert np.array_equal(gathered[rank * N:(rank + 1) * N], got_mean), "all-gather lost this rank's shard"
         eng.set_stream(None)
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -153,7 +160,7 @@ def main():
             "config": {"workload": f"TF-binding L={L} alphabet={ALPHABET}, {M}-member CNN(num_filters={F}, "
                                    f"hidden_size={H}, kernel_size={K}) Ensemble, batch={N} virtual-screen per GPU "
                                    "(BASELINE.json configs[1]); inputs resident in HBM; step = fused encode+CNN "
-                                   "scoring kernel + ensemble-mean kernel" + (" + one RCCL all-gather" if world > 1 else ""),
+                                   "scoring kernel + ensemble-mean kernel" + (" + one RCCL all-gather" if use_dist else ""),
                        "global_batch": world * N, "seq_len": L, "members": M,
                        "parallelism": f"sequence-parallel x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": "k_score_cnn_mfma", "achieved": achieved, "peak": peak,
@@ -166,7 +173,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -166,6 +166,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "force_generic")) return &e->force_generic;
     if (!std::strcmp(key, "cnn_variant")) return &e->cnn_variant;
     if (!std::strcmp(key, "grid_blocks")) return &e->grid_blocks;
+    if (!std::strcmp(key, "cnn_conv1_mfma")) return &e->cnn_conv1_mfma;
     return nullptr;
 }
 int fx_engine_set_option(fx_engine* e, const char* key, int64_t value) {
@@ -577,7 +578,7 @@ int fx_debug_pack_layout(int kind, int L, int A, int F, int H, int K, int64_t* o
     if (!out16) return FX_EINVAL;
     const FxPackLayout p = fx_pack_layout(FxShape{kind, L, A, F, H, K});
     const int64_t v[16] = {p.FT, p.HT, p.SG1, p.off_first, p.off_c2, p.off_c3, p.off_cb, p.conv_floats,
-                           p.off_d1, p.off_d2, p.off_d3, p.off_db, p.RLH, p.total_floats, 0, 0};
+                           p.off_d1, p.off_d2, p.off_d3, p.off_db, p.RLH, p.total_floats, p.off_w1p, 0};
     std::memcpy(out16, v, sizeof(v));
     return FX_OK;
 }

@@ -33,6 +33,7 @@ struct FxPackLayout {
     int64_t off_first;          // SG1 x (FT|HT) blocks
     int64_t off_c2, off_c3;     // K x FT x FT, K3 x FT x FT blocks           (CNN)
     int64_t off_cb;             // b1[16FT] b2[16FT] b3[16FT]                 (CNN)
+    int64_t off_w1p;            // conv1 kernel, plain [K*A][16FT] rows (gather form of the one-hot conv)
     int64_t conv_floats;        // everything above (the part that must sit in LDS)
     int64_t off_d1, off_d2, off_d3;  // dense blocks: CNN d1 FTxHT, d2 HTxHT; MLP d2, d3 HTxHT; GE d3 HTxHT
     int64_t off_db;             // bias / vector area (layout per kind, see pack.cpp)
@@ -73,6 +74,7 @@ struct fx_engine {
     int64_t force_generic = 0;
     int64_t cnn_variant = 0;    // 0 = auto
     int64_t grid_blocks = 0;    // 0 = auto (one per CU)
+    int64_t cnn_conv1_mfma = 0; // 1 = one-hot conv1 on MFMA instead of the LDS gather (A/B knob)
     int num_cus = 256;
     int max_lds = 160 * 1024;
 };

@@ -30,10 +30,10 @@ struct CnnArgs {
     int L;
     int rlh;                    // k-steps carrying real channels in the last hidden tile
     // packed-layout offsets (floats)
-    int off_first, off_c2, off_c3, off_cb, conv_floats, off_d1, off_d2, off_db, total_floats;
+    int off_first, off_c2, off_c3, off_cb, off_w1p, conv_floats, off_d1, off_d2, off_db, total_floats;
 };
 
-template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES>
+template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1>
 __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
     constexpr int K3 = A - 1;
     constexpr int PL2 = (K - 1) / 2, PR2 = K - 1 - PL2;
@@ -71,6 +71,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
         const f4* w_c2 = reinterpret_cast<const f4*>(smem + p.off_c2);
         const f4* w_c3 = reinterpret_cast<const f4*>(smem + p.off_c3);
         const float* cb = smem + p.off_cb;
+        const float* w1p = smem + p.off_w1p;
         const float* dbase = DENSE_LDS ? smem : p.w[m];
         const f4* w_d1 = reinterpret_cast<const f4*>(dbase + p.off_d1);
         const f4* w_d2 = reinterpret_cast<const f4*>(dbase + p.off_d2);
@@ -102,7 +103,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     int c = lut_s[row[nt][j]];
-                    bad |= (c == 0xFF);
+                    if (c == 0xFF) { bad = true; c = 0; }
                     cw[j + 1][nt] = c;                    // shifted down at the top of step 0
                 }
             f4 win1[K][FT][NT], win2[K3][FT][NT], gmax[FT][NT];
@@ -151,25 +152,40 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         int c = lut_s[row[nt][s + K - 1]];
-                        bad |= (c == 0xFF);
+                        if (c == 0xFF) { bad = true; c = 0; }
                         cw[K - 1][nt] = c;
                     }
                     f4 o1[FT][NT];
                     init_bias<FT, NT>(cb, o1, g);
+                    if (G1) {
+                        // one-hot conv == sum of K kernel rows selected by the codes: LDS gather + VALU adds
+                        // (takes the 2*K*A*F "multiply by one-hot" FLOP per position off the MFMA pipe)
 #pragma unroll
-                    for (int st = 0; st < S1; ++st) {
-                        constexpr int dummy = 0; (void)dummy;
-                        const int j = (4 * st) / A;          // tap (compile-time after unroll)
-                        const int a0 = (4 * st) % A;         // first alphabet index of the step
-                        const int sg = st >> 2, r = st & 3;
-                        float b[NT];
+                        for (int j = 0; j < K; ++j)
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) b[nt] = (cw[j][nt] == a0 + g) ? 1.f : 0.f;
+                            for (int nt = 0; nt < NT; ++nt) {
+                                const float* rowp = w1p + (j * A + cw[j][nt]) * (16 * FT) + 4 * g;
 #pragma unroll
-                        for (int mo = 0; mo < FT; ++mo) {
-                            const float a = reinterpret_cast<const float*>(&w_first[(sg * FT + mo) * 64 + lane])[r];
+                                for (int mo = 0; mo < FT; ++mo) {
+                                    const f4 w = *reinterpret_cast<const f4*>(rowp + 16 * mo);
+                                    o1[mo][nt] += w;
+                                }
+                            }
+                    } else {
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) o1[mo][nt] = mfma16(a, b[nt], o1[mo][nt]);
+                        for (int st = 0; st < S1; ++st) {
+                            const int j = (4 * st) / A;          // tap (compile-time after unroll)
+                            const int a0 = (4 * st) % A;         // first alphabet index of the step
+                            const int sg = st >> 2, r = st & 3;
+                            float b[NT];
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) b[nt] = (cw[j][nt] == a0 + g) ? 1.f : 0.f;
+#pragma unroll
+                            for (int mo = 0; mo < FT; ++mo) {
+                                const float a = reinterpret_cast<const float*>(&w_first[(sg * FT + mo) * 64 + lane])[r];
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt) o1[mo][nt] = mfma16(a, b[nt], o1[mo][nt]);
+                            }
                         }
                     }
                     relu_tiles<FT, NT>(o1);
@@ -248,10 +264,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
     if (bad) atomicOr(p.err, FX_ERR_BADCHAR);
 }
 
-template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES>
-int launch_inst(fx_engine* e, const CnnArgs& a, size_t lds_bytes) {
+template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1>
+int launch_g(fx_engine* e, const CnnArgs& a, size_t lds_bytes) {
     constexpr int waves = WAVES;
-    auto kern = k_score_cnn_mfma<A, K, FT, HT, NT, DENSE_LDS, WAVES>;
+    auto kern = k_score_cnn_mfma<A, K, FT, HT, NT, DENSE_LDS, WAVES, G1>;
     static bool attr_set[64] = {};
     if (!attr_set[e->device & 63]) {
         FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -267,6 +283,12 @@ int launch_inst(fx_engine* e, const CnnArgs& a, size_t lds_bytes) {
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(waves * 64), lds_bytes, e->stream, a);
     FX_HIP(e, hipGetLastError());
     return FX_OK;
+}
+
+template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES>
+int launch_inst(fx_engine* e, const CnnArgs& a, size_t lds_bytes) {
+    return e->cnn_conv1_mfma ? launch_g<A, K, FT, HT, NT, DENSE_LDS, WAVES, false>(e, a, lds_bytes)
+                             : launch_g<A, K, FT, HT, NT, DENSE_LDS, WAVES, true>(e, a, lds_bytes);
 }
 
 }  // namespace
@@ -289,7 +311,7 @@ int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const
     for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
     a.N = N; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.rlh = lay.RLH;
     a.off_first = (int)lay.off_first; a.off_c2 = (int)lay.off_c2; a.off_c3 = (int)lay.off_c3;
-    a.off_cb = (int)lay.off_cb; a.conv_floats = (int)lay.conv_floats; a.off_d1 = (int)lay.off_d1;
+    a.off_cb = (int)lay.off_cb; a.off_w1p = (int)lay.off_w1p; a.conv_floats = (int)lay.conv_floats; a.off_d1 = (int)lay.off_d1;
     a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
 
     // variant: 1 = NT1 x 8 waves, 2 = NT2 x 4 waves, 3 = NT2 x 8 waves, 4 = NT1 x 16 waves (A = 4 only)

@@ -64,7 +64,7 @@ def final_dot(packed, off_w, bout, h, HT):
     return out + bout
 
 
-def cnn_tile(packed, lay, codes16, A, K, F, H):
+def cnn_tile(packed, lay, codes16, A, K, F, H, conv1_gather=True):
     """codes16: (16, L) alphabet indices of the tile's sequences -> (16,) scores."""
     packed = packed.astype(np.float64)
     L = codes16.shape[1]
@@ -86,13 +86,19 @@ def cnn_tile(packed, lay, codes16, A, K, F, H):
         win2 = win2[1:] + [None]
         if s < L1:
             o1 = init_bias(packed, lay["off_cb"], FT)
-            for st in range(S1):
-                j, a0 = (4 * st) // A, (4 * st) % A
-                sg, r = st >> 2, st & 3
-                b = (code[:, s + j] == a0 + G).astype(np.float64)
-                for mo in range(FT):
-                    a = blocks(packed, lay["off_first"], sg * FT + mo)[:, r]
-                    o1[mo] = mfma16(a, b, o1[mo])
+            if conv1_gather:
+                for j in range(K):
+                    rowp = lay["off_w1p"] + (j * A + code[:, s + j]) * (16 * FT) + 4 * G
+                    for mo in range(FT):
+                        o1[mo] = o1[mo] + np.stack([packed[rowp + 16 * mo + r] for r in range(4)], axis=1)
+            else:
+                for st in range(S1):
+                    j, a0 = (4 * st) // A, (4 * st) % A
+                    sg, r = st >> 2, st & 3
+                    b = (code[:, s + j] == a0 + G).astype(np.float64)
+                    for mo in range(FT):
+                        a = blocks(packed, lay["off_first"], sg * FT + mo)[:, r]
+                        o1[mo] = mfma16(a, b, o1[mo])
             win1[K - 1] = [np.maximum(x, 0) for x in o1]
         else:
             win1[K - 1] = zero(FT)

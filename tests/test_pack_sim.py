@@ -25,9 +25,10 @@ def test_cnn_dataflow_matches_oracle(L, A, alpha):
     assert lay["FT"] == 2 and lay["HT"] == 7
     codes = rng.integers(0, A, (16, L)).astype(np.uint8)
     seqs = ["".join(alpha[c] for c in r) for r in codes]
-    got = mfma_sim.cnn_tile(packed, lay, codes, A, K, F, H)
     want = ref_np.keras_fitness(seqs, alpha, "cnn", w, exact=True)
-    assert np.abs(got - want).max() < 1e-12
+    for gather in (True, False):
+        got = mfma_sim.cnn_tile(packed, lay, codes, A, K, F, H, conv1_gather=gather)
+        assert np.abs(got - want).max() < 1e-12
 
 
 @pytest.mark.parametrize("L,A,alpha,H", [(14, 4, "UGCA", 100), (8, 4, "TGCA", 100), (9, 20, ref_np.AAS, 100),
@@ -48,7 +49,7 @@ def test_mlp_ge_dataflow_matches_oracle(L, A, alpha, H):
 
 def test_packed_sizes():
     # CNN(32,100,K5) on a 4-letter alphabet: 25 780 floats = 100.7 KiB -> fits the 160 KiB LDS
-    assert _native.lib().fx_debug_packed_size(_native.FX_CNN, 8, 4, 32, 100, 5) == 25780
+    assert _native.lib().fx_debug_packed_size(_native.FX_CNN, 8, 4, 32, 100, 5) == 26420
     lay = _native.debug_pack_layout(_native.FX_CNN, 237, 20, 32, 100, 5)
     assert lay["conv_floats"] * 4 < 160 * 1024            # conv part alone fits for the protein alphabet
     with pytest.raises(ValueError):
