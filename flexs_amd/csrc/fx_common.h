@@ -75,6 +75,7 @@ struct fx_engine {
     int64_t cnn_variant = 0;    // 0 = auto
     int64_t grid_blocks = 0;    // 0 = auto (one per CU)
     int64_t cnn_conv1_mfma = 0; // 1 = one-hot conv1 on MFMA instead of the LDS gather (A/B knob)
+    int64_t mlp_l1_mfma = 0;    // 1 = one-hot MLP layer 1 on MFMA instead of the LDS gather (A/B knob)
     int num_cus = 256;
     int max_lds = 160 * 1024;
 };

@@ -16,15 +16,33 @@ __global__ void k_encode_onehot(const uint8_t* __restrict__ ascii, const uint8_t
         reinterpret_cast<uint32_t*>(lut_s)[threadIdx.x] = reinterpret_cast<const uint32_t*>(lut)[threadIdx.x];
     __syncthreads();
     bool bad = false;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
-        int c = lut_s[ascii[i]];
-        if (c == 0xFF) { bad = true; c = -1; }
-        if (AT == 4) {
-            float4 v = make_float4(c == 0, c == 1, c == 2, c == 3);
-            reinterpret_cast<float4*>(out)[i] = v;
-        } else {
-            float* o = out + i * A;
-            for (int a = 0; a < A; ++a) o[a] = (a == c) ? 1.f : 0.f;
+    if (AT == 4) {
+        // A == 4: one 16-byte store per position
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
+            int c = lut_s[ascii[i]];
+            if (c == 0xFF) { bad = true; c = -1; }
+            reinterpret_cast<float4*>(out)[i] = make_float4(c == 0, c == 1, c == 2, c == 3);
+        }
+    } else if (AT == 1) {
+        // A % 4 == 0: one thread per 16-byte quad of the output, consecutive lanes -> consecutive quads
+        const int q = A >> 2;
+        const int64_t quads = rows * q;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t pos = i / q;
+            const int a4 = (int)(i - pos * q);
+            int c = lut_s[ascii[pos]];
+            if (c == 0xFF) { bad = true; c = -1; }
+            const int k = c - 4 * a4;
+            reinterpret_cast<float4*>(out)[i] = make_float4(k == 0, k == 1, k == 2, k == 3);
+        }
+    } else {
+        const int64_t total = rows * A;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t pos = i / A;
+            const int a = (int)(i - pos * A);
+            const int c = lut_s[ascii[pos]];
+            if (c == 0xFF) bad = true;
+            out[i] = (a == c) ? 1.f : 0.f;
         }
     }
     if (bad) atomicOr(err, FX_ERR_BADCHAR);
@@ -58,12 +76,68 @@ __device__ T np_pairwise(Load ld, int64_t base, int n) {
     return np_pairwise<T>(ld, base, n2) + np_pairwise<T>(ld, base + n2, n - n2);
 }
 
+// NumPy order for a compile-time row length (registers only)
+template <int M>
+__device__ __forceinline__ float np_sum_row(const float (&x)[M]) {
+    if constexpr (M < 8) {
+        float r = 0.f;
+#pragma unroll
+        for (int i = 0; i < M; ++i) r += x[i];
+        return r;
+    } else {
+        float r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = x[k];
+        constexpr int full = M - (M % 8);
+#pragma unroll
+        for (int i = 8; i < full; i += 8)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r[k] += x[i + k];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+#pragma unroll
+        for (int i = full; i < M; ++i) res += x[i];
+        return res;
+    }
+}
+
+// M <= 16: each thread reduces 4 consecutive rows = 4*M contiguous floats = M 16-byte loads,
+// and writes one 16-byte result; HBM-bound (4*M + 4 bytes per sequence).
+template <int M>
+__global__ void k_ensemble_mean_small(const float* __restrict__ s, int64_t N, float* __restrict__ out) {
+    const int64_t groups = N >> 2;
+    for (int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gi < groups; gi += (int64_t)gridDim.x * blockDim.x) {
+        float v[4 * M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            const float4 q = reinterpret_cast<const float4*>(s)[gi * M + j];
+            v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+        }
+        float res[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float x[M];
+#pragma unroll
+            for (int m = 0; m < M; ++m) x[m] = v[i * M + m];
+            res[i] = __fdiv_rn(np_sum_row<M>(x), (float)M);
+        }
+        reinterpret_cast<float4*>(out)[gi] = make_float4(res[0], res[1], res[2], res[3]);
+    }
+    // tail rows (N % 4)
+    const int64_t t = (groups << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < N && (int64_t)blockIdx.x * blockDim.x + threadIdx.x < 4) {
+        float x[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) x[m] = s[t * M + m];
+        out[t] = __fdiv_rn(np_sum_row<M>(x), (float)M);
+    }
+}
+
 // mean over members, float32 (Ensemble default combine_with)
 __global__ void k_ensemble_mean(const float* __restrict__ s, int64_t N, int M, float* __restrict__ out) {
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
         auto ld = [&](int64_t i) { return s[i]; };
         float sum = np_pairwise<float>(ld, n * M, M);
-        out[n] = sum / (float)M;
+        out[n] = __fdiv_rn(sum, (float)M);
     }
 }
 
@@ -73,7 +147,7 @@ __global__ void k_ensemble_wsum(const float* __restrict__ s, int64_t N, int M, c
                                 double* __restrict__ out) {
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = n * M;
-        auto ld = [&](int64_t i) { return w[i - b] * (double)s[i]; };
+        auto ld = [&](int64_t i) { return __dmul_rn(w[i - b], (double)s[i]); };
         out[n] = np_pairwise<double>(ld, b, M);
     }
 }
@@ -136,10 +210,15 @@ int fx_launch_encode_onehot(fx_engine* e, const uint8_t* d_ascii, int64_t N, int
     const int64_t rows = N * L;
     if (rows == 0) return FX_OK;
     dim3 grid(grid_for(rows, 256, e->num_cus)), block(256);
-    if (A == 4)
+    if (A == 4) {
         hipLaunchKernelGGL(k_encode_onehot<4>, grid, block, 0, e->stream, d_ascii, e->d_lut, rows, A, d_out, e->d_err);
-    else
-        hipLaunchKernelGGL(k_encode_onehot<0>, grid, block, 0, e->stream, d_ascii, e->d_lut, rows, A, d_out, e->d_err);
+    } else if (A % 4 == 0) {
+        dim3 g2(grid_for(rows * (A / 4), 256, e->num_cus));
+        hipLaunchKernelGGL(k_encode_onehot<1>, g2, block, 0, e->stream, d_ascii, e->d_lut, rows, A, d_out, e->d_err);
+    } else {
+        dim3 g2(grid_for(rows * A, 256, e->num_cus));
+        hipLaunchKernelGGL(k_encode_onehot<0>, g2, block, 0, e->stream, d_ascii, e->d_lut, rows, A, d_out, e->d_err);
+    }
     FX_HIP(e, hipGetLastError());
     return FX_OK;
 }
@@ -148,9 +227,18 @@ int fx_launch_ensemble_reduce(fx_engine* e, const float* d_scores, int64_t N, in
                               float* d_out32, double* d_out64) {
     if (N == 0) return FX_OK;
     dim3 grid(grid_for(N, 256, e->num_cus)), block(256);
-    if (d_weights == nullptr)
-        hipLaunchKernelGGL(k_ensemble_mean, grid, block, 0, e->stream, d_scores, N, M, d_out32);
-    else
+    if (d_weights == nullptr) {
+        dim3 gs(grid_for((N + 3) / 4, 256, e->num_cus));
+        const bool aligned = ((reinterpret_cast<uintptr_t>(d_scores) | reinterpret_cast<uintptr_t>(d_out32)) & 15) == 0;
+        switch (aligned ? M : 0) {
+#define FX_MEAN_CASE(m) case m: hipLaunchKernelGGL(k_ensemble_mean_small<m>, gs, block, 0, e->stream, d_scores, N, d_out32); break;
+            FX_MEAN_CASE(1) FX_MEAN_CASE(2) FX_MEAN_CASE(3) FX_MEAN_CASE(4) FX_MEAN_CASE(5) FX_MEAN_CASE(6)
+            FX_MEAN_CASE(7) FX_MEAN_CASE(8) FX_MEAN_CASE(9) FX_MEAN_CASE(10) FX_MEAN_CASE(11) FX_MEAN_CASE(12)
+            FX_MEAN_CASE(13) FX_MEAN_CASE(14) FX_MEAN_CASE(15) FX_MEAN_CASE(16)
+#undef FX_MEAN_CASE
+            default: hipLaunchKernelGGL(k_ensemble_mean, grid, block, 0, e->stream, d_scores, N, M, d_out32);
+        }
+    } else
         hipLaunchKernelGGL(k_ensemble_wsum, grid, block, 0, e->stream, d_scores, N, M, d_weights, d_out64);
     FX_HIP(e, hipGetLastError());
     return FX_OK;

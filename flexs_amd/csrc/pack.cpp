@@ -55,6 +55,7 @@ FxPackLayout fx_pack_layout(const FxShape& s) {
         p.SG1 = (s.L * s.A + 15) / 16;
         p.off_first = off; off += (int64_t)p.SG1 * p.HT * BLK;
         p.off_c2 = p.off_c3 = p.off_cb = off;
+        p.off_w1p = off;   off += (int64_t)s.L * s.A * 16 * p.HT;   // layer-1 kernel, plain [L*A][16HT] rows (gather form)
         p.conv_floats = off;
         p.off_d1 = off;
         p.off_d2 = off;    off += (int64_t)p.HT * p.HT * BLK;
@@ -178,6 +179,7 @@ void fx_pack_weights(const FxShape& s, const float* blob, float* packed) {
                 pack_dense_block(d2, H, hid, hid, mi, mo, packed + p.off_d2 + ((int64_t)mi * HT + mo) * 256);
                 pack_dense_block(d3, H, hid, hid, mi, mo, packed + p.off_d3 + ((int64_t)mi * HT + mo) * 256);
             }
+        for (int k = 0; k < L * A; ++k) pack_vec(d1 + (int64_t)k * H, hid, 16 * HT, packed + p.off_w1p + (int64_t)k * 16 * HT);
         pack_vec(c1, hid, 16 * HT, packed + p.off_db);
         pack_vec(c2, hid, 16 * HT, packed + p.off_db + 16 * HT);
         pack_vec(c3, hid, 16 * HT, packed + p.off_db + 32 * HT);

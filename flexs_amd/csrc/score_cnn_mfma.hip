@@ -319,7 +319,7 @@ int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const
     const size_t full = (size_t)lay.total_floats * 4 + 256 + 16, conv_only = (size_t)lay.conv_floats * 4 + 256 + 16;
     if (s.A == 4) {
         if (full > (size_t)e->max_lds) return FX_EUNSUPPORTED;
-        if (variant == 0) variant = 1;
+        if (variant == 0) variant = 4;                   // 16 waves = 4 per SIMD measured best (profiles/r1_run2_*)
         int nt = (variant == 1 || variant == 4) ? 1 : 2;
         a.TG = (N + 16 * nt - 1) / (16 * nt);
         switch (variant) {

@@ -25,17 +25,18 @@ struct DenseArgs {
     int64_t N, TG;
     int M, Mtot, m_off;
     int L, A, rlh;
-    int SG1, off_first, off_d2, off_d3, off_db, total_floats;
+    int SG1, off_first, off_w1p, off_d2, off_d3, off_db, total_floats;
+    int lds_from, lds_floats;   // the LDS image is packed[lds_from .. lds_from + lds_floats)
 };
 
-template <int KIND, int A, int HT, int NT, int WAVES>
+template <int KIND, int A, int HT, int NT, int WAVES, bool G1, bool W1G>
 __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int g = lane >> 4, sq = lane & 15;
     const int L = p.L;
-    uint8_t* lut_s = reinterpret_cast<uint8_t*>(smem + p.total_floats);
-    int* next_tile = reinterpret_cast<int*>(smem + p.total_floats + 64);   // work counter, after the 256-byte LUT
+    uint8_t* lut_s = reinterpret_cast<uint8_t*>(smem + p.lds_floats);
+    int* next_tile = reinterpret_cast<int*>(smem + p.lds_floats + 64);   // work counter, after the 256-byte LUT
     for (int i = tid; i < 64; i += blockDim.x)
         reinterpret_cast<uint32_t*>(lut_s)[i] = reinterpret_cast<const uint32_t*>(p.lut)[i];
 
@@ -49,15 +50,17 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
         __syncthreads();
         if (tid == 0) *next_tile = 0;
         {
-            const f4* src = reinterpret_cast<const f4*>(p.w[m]);
+            const f4* src = reinterpret_cast<const f4*>(p.w[m] + p.lds_from);
             f4* dst = reinterpret_cast<f4*>(smem);
-            for (int i = tid; i < p.total_floats / 4; i += blockDim.x) dst[i] = src[i];
+            for (int i = tid; i < p.lds_floats / 4; i += blockDim.x) dst[i] = src[i];
         }
         __syncthreads();
-        const float* w_first = smem + p.off_first;
-        const f4* w_d2 = reinterpret_cast<const f4*>(smem + p.off_d2);
-        const f4* w_d3 = reinterpret_cast<const f4*>(smem + p.off_d3);
-        const float* db = smem + p.off_db;
+        // W1G: the (large) first-layer rows stay in global memory / L2, only the HxH blocks sit in LDS
+        const float* w_first = W1G ? p.w[m] + p.off_first : smem + (p.off_first - p.lds_from);
+        const float* w1p = W1G ? p.w[m] + p.off_w1p : smem + (p.off_w1p - p.lds_from);
+        const f4* w_d2 = reinterpret_cast<const f4*>(smem + (p.off_d2 - p.lds_from));
+        const f4* w_d3 = reinterpret_cast<const f4*>(smem + (p.off_d3 - p.lds_from));
+        const float* db = smem + (p.off_db - p.lds_from);
 
         const int64_t t_lo = (u_lo > (int64_t)m * p.TG ? u_lo : (int64_t)m * p.TG) - (int64_t)m * p.TG;
         const int64_t t_hi = (u_hi < (int64_t)(m + 1) * p.TG ? u_hi : (int64_t)(m + 1) * p.TG) - (int64_t)m * p.TG;
@@ -82,27 +85,42 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                 static_assert(KIND != FX_MLP || A % 4 == 0, "one-hot k-steps must not straddle a position");
                 // ---- layer 1: relu(b1 + onehot @ W1), contraction index k = l*A + a
                 init_bias<HT, NT>(db, h, g);
-                for (int sg = 0; sg < p.SG1; ++sg) {
-                    asm volatile("" ::: "memory");
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int k0 = 16 * sg + 4 * r;            // first row of this k-step
-                        const int l = k0 / A, a0 = k0 % A;
-                        float b[NT];
+                if (G1) {
+                    // one-hot layer == sum of L kernel rows selected by the codes: LDS gather + VALU adds
+                    for (int l = 0; l < L; ++l) {
+                        asm volatile("" ::: "memory");
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
-                            int c = 0xFE;
-                            if (l < L) {
-                                c = lut_s[row[nt][l]];
-                                bad |= (c == 0xFF);
-                            }
-                            b[nt] = (c == a0 + g) ? 1.f : 0.f;
+                            int c = lut_s[row[nt][l]];
+                            if (c == 0xFF) { bad = true; c = 0; }
+                            const float* rowp = w1p + (l * p.A + c) * (16 * HT) + 4 * g;
+#pragma unroll
+                            for (int mo = 0; mo < HT; ++mo) h[mo][nt] += *reinterpret_cast<const f4*>(rowp + 16 * mo);
                         }
+                    }
+                } else {
+                    for (int sg = 0; sg < p.SG1; ++sg) {
+                        asm volatile("" ::: "memory");
 #pragma unroll
-                        for (int mo = 0; mo < HT; ++mo) {
-                            const float a = w_first[((sg * HT + mo) * 64 + lane) * 4 + r];
+                        for (int r = 0; r < 4; ++r) {
+                            const int k0 = 16 * sg + 4 * r;            // first row of this k-step
+                            const int l = k0 / A, a0 = k0 % A;
+                            float b[NT];
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) h[mo][nt] = mfma16(a, b[nt], h[mo][nt]);
+                            for (int nt = 0; nt < NT; ++nt) {
+                                int c = 0xFE;
+                                if (l < L) {
+                                    c = lut_s[row[nt][l]];
+                                    bad |= (c == 0xFF);
+                                }
+                                b[nt] = (c == a0 + g) ? 1.f : 0.f;
+                            }
+#pragma unroll
+                            for (int mo = 0; mo < HT; ++mo) {
+                                const float a = w_first[((sg * HT + mo) * 64 + lane) * 4 + r];
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt) h[mo][nt] = mfma16(a, b[nt], h[mo][nt]);
+                            }
                         }
                     }
                 }
@@ -119,16 +137,23 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                 final_dot<HT, NT>(db + 48 * HT, db[64 * HT], h, y, g);
             } else {
                 // ---- GE layer 1: s = relu(b1 + sum_l w1[l*A + code_l])   (scalar per sequence)
+                // (the four lane groups of a sequence each take every 4th position, then two cross-lane adds)
                 float s[NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) s[nt] = db[0];
-                for (int l = 0; l < L; ++l) {
+                for (int nt = 0; nt < NT; ++nt) s[nt] = 0.f;
+                for (int l = g; l < L; l += 4) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         int c = lut_s[row[nt][l]];
                         if (c == 0xFF) { bad = true; c = 0; }
                         s[nt] += w_first[l * p.A + c];
                     }
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    s[nt] += __shfl_xor(s[nt], 16);
+                    s[nt] += __shfl_xor(s[nt], 32);
+                    s[nt] += db[0];
                 }
                 // ---- layer 2: h[ch] = relu(b2[ch] + s * w2[ch]) directly in B-operand layout
                 f4 h2[HT][NT];
@@ -163,9 +188,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
     if (bad) atomicOr(p.err, FX_ERR_BADCHAR);
 }
 
-template <int KIND, int A, int HT, int NT, int WAVES>
+template <int KIND, int A, int HT, int NT, int WAVES, bool G1, bool W1G = false>
 int launch_inst(fx_engine* e, const DenseArgs& a, size_t lds_bytes) {
-    auto kern = k_score_dense_mfma<KIND, A, HT, NT, WAVES>;
+    auto kern = k_score_dense_mfma<KIND, A, HT, NT, WAVES, G1, W1G>;
     static bool attr_set[64] = {};
     if (!attr_set[e->device & 63]) {
         FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -195,20 +220,33 @@ int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, con
     }
     if (s.kind != FX_MLP && s.kind != FX_GE) return FX_EUNSUPPORTED;
     if (lay.HT != 7 || M > FX_MAX_M) return FX_EUNSUPPORTED;
-    const size_t lds = (size_t)lay.total_floats * 4 + 256 + 16;
-    if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
-    if (s.kind == FX_MLP && s.A != 4 && s.A != 20) return FX_EUNSUPPORTED;
-
+    size_t lds = (size_t)lay.total_floats * 4 + 256 + 16;
+    bool w1_global = false;
+    if (lds > (size_t)e->max_lds) {
+        // MLP with a large L*A: keep only the HxH blocks + vectors in LDS, gather layer-1 rows from L2
+        if (s.kind != FX_MLP) return FX_EUNSUPPORTED;
+        lds = (size_t)(lay.total_floats - lay.off_d2) * 4 + 256 + 16;
+        if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
+        w1_global = true;
+    }
+    if (s.kind == FX_MLP && s.A % 4 != 0 && e->mlp_l1_mfma) return FX_EUNSUPPORTED;
     DenseArgs a{};
     a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
     for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
     a.N = N; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.A = s.A; a.rlh = lay.RLH;
-    a.SG1 = lay.SG1; a.off_first = (int)lay.off_first; a.off_d2 = (int)lay.off_d2; a.off_d3 = (int)lay.off_d3;
+    a.SG1 = lay.SG1; a.off_first = (int)lay.off_first; a.off_w1p = (int)lay.off_w1p; a.off_d2 = (int)lay.off_d2; a.off_d3 = (int)lay.off_d3;
     a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
     a.TG = (N + 15) / 16;
+    a.lds_from = w1_global ? (int)lay.off_d2 : 0;
+    a.lds_floats = (int)lay.total_floats - a.lds_from;
     if (s.kind == FX_MLP) {
-        if (s.A == 4) return launch_inst<FX_MLP, 4, 7, 1, 8>(e, a, lds);
-        return launch_inst<FX_MLP, 20, 7, 1, 8>(e, a, lds);
+        if (w1_global) return launch_inst<FX_MLP, 4, 7, 1, 16, true, true>(e, a, lds);   // gather form: A is a runtime stride
+        if (e->mlp_l1_mfma) {
+            if (s.A == 4) return launch_inst<FX_MLP, 4, 7, 1, 16, false>(e, a, lds);
+            if (s.A == 20) return launch_inst<FX_MLP, 20, 7, 1, 16, false>(e, a, lds);
+            return FX_EUNSUPPORTED;
+        }
+        return launch_inst<FX_MLP, 4, 7, 1, 16, true>(e, a, lds);
     }
-    return launch_inst<FX_GE, 4, 7, 1, 8>(e, a, lds);    // A is a runtime stride for GE (template arg unused)
+    return launch_inst<FX_GE, 4, 7, 1, 16, false>(e, a, lds);    // A is a runtime stride for GE (template arg unused)
 }

@@ -127,7 +127,7 @@ def cnn_tile(packed, lay, codes16, A, K, F, H, conv1_gather=True):
     return y[:16]                                        # lanes of group 0 hold the 16 sequences
 
 
-def mlp_tile(packed, lay, codes16, A, H):
+def mlp_tile(packed, lay, codes16, A, H, l1_gather=True):
     """MLP: one-hot first layer on MFMA (k index = l*A + a), two HxH layers, dot."""
     packed = packed.astype(np.float64)
     L = codes16.shape[1]
@@ -136,15 +136,21 @@ def mlp_tile(packed, lay, codes16, A, H):
     S1 = (L * A + 3) // 4
     db = lay["off_db"]
     h = init_bias(packed, db, HT)
-    for st in range(S1):
-        sg, r = st >> 2, st & 3
-        k = 4 * st + G                                   # flattened feature index of this lane group
-        l, a = k // A, k % A
-        valid = k < L * A
-        b = np.where(valid, (code[LANES, np.minimum(l, L - 1)] == a), False).astype(np.float64)
-        for mo in range(HT):
-            aw = blocks(packed, lay["off_first"], sg * HT + mo)[:, r]
-            h[mo] = mfma16(aw, b, h[mo])
+    if l1_gather:
+        for l in range(L):
+            rowp = lay["off_w1p"] + (l * A + code[:, l]) * (16 * HT) + 4 * G
+            for mo in range(HT):
+                h[mo] = h[mo] + np.stack([packed[rowp + 16 * mo + r] for r in range(4)], axis=1)
+    else:
+        for st in range(S1):
+            sg, r = st >> 2, st & 3
+            k = 4 * st + G                                   # flattened feature index of this lane group
+            l, a = k // A, k % A
+            valid = k < L * A
+            b = np.where(valid, (code[LANES, np.minimum(l, L - 1)] == a), False).astype(np.float64)
+            for mo in range(HT):
+                aw = blocks(packed, lay["off_first"], sg * HT + mo)[:, r]
+                h[mo] = mfma16(aw, b, h[mo])
     h = [np.maximum(x, 0) for x in h]
     h2 = init_bias(packed, db + 16 * HT, HT)
     h2 = [np.maximum(x, 0) for x in mma_layer(packed, lay["off_d2"], HT, HT, h, h2, lay["RLH"])]
@@ -161,10 +167,12 @@ def ge_tile(packed, lay, codes16, A, H):
     HT = lay["HT"]
     code = codes16[SQ].astype(np.int64)
     db = lay["off_db"]
-    s = np.full(64, packed[db])
-    for l in range(L):
-        s = s + packed[lay["off_first"] + l * A + code[:, l]]
-    s = np.maximum(s, 0)
+    s = np.zeros(64)
+    for l in range(L):                                   # lane group g takes positions l = g (mod 4)
+        s = s + np.where(l % 4 == G, packed[lay["off_first"] + l * A + code[:, l]], 0.0)
+    s = s + s[LANES ^ 16]
+    s = s + s[LANES ^ 32]
+    s = np.maximum(s + packed[db], 0)
     w2 = init_bias(packed, db + 4, HT)
     b2 = init_bias(packed, db + 4 + 16 * HT, HT)
     h = [np.maximum(b2[mo] + s[:, None] * w2[mo], 0) for mo in range(HT)]

@@ -41,6 +41,8 @@ def eng():
     yield e
     e.set_option("force_generic", 0)
     e.set_option("cnn_variant", 0)
+    e.set_option("cnn_conv1_mfma", 0)
+    e.set_option("mlp_l1_mfma", 0)
 
 
 def rand_seqs(n, L, alphabet, seed):
@@ -79,18 +81,22 @@ def test_smoke_entry():
 
 
 # ------------------------------------------------------------------ CNN
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("conv1_mfma", [0, 1])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 33, 1000, 4099])
-def test_cnn_l8_variants_and_tails(eng, variant, n):
-    """BASELINE configs[0]/[1] shape: TF-binding L=8, alphabet TGCA, CNN(32,100,k5)."""
+def test_cnn_l8_variants_and_tails(eng, variant, n, conv1_mfma):
+    """BASELINE configs[0]/[1] shape: TF-binding L=8, alphabet TGCA, CNN(32,100,k5);
+    every launch geometry (variant) x both forms of the one-hot conv1 (LDS gather / MFMA)."""
     eng.set_option("force_generic", 0)
     eng.set_option("cnn_variant", variant)
+    eng.set_option("cnn_conv1_mfma", conv1_mfma)
     nm, w = make_native(eng, "cnn", 8, 4, 100, 32, 5)
     b, seqs = rand_seqs(n, 8, "TGCA", seed=n)
     got, _ = eng.score([nm], b, _native.make_lut("TGCA"))
     want = ref_np.keras_fitness(seqs, "TGCA", "cnn", w, exact=True)
     assert_scores(got[:, 0], want, f"cnn L8 variant {variant} n={n}")
     eng.set_option("cnn_variant", 0)
+    eng.set_option("cnn_conv1_mfma", 0)
 
 
 @pytest.mark.parametrize("L,A,alpha,n", [(8, 4, "TGCA", 3000), (5, 4, "TGCA", 500), (6, 4, "TGCA", 500),
@@ -104,6 +110,10 @@ def test_cnn_mfma_vs_oracle(eng, L, A, alpha, n):
     got, _ = eng.score([nm], b, _native.make_lut(alpha))
     want = ref_np.keras_fitness(seqs, alpha, "cnn", w, exact=True)
     assert_scores(got[:, 0], want, f"cnn mfma L={L} A={A}")
+    eng.set_option("cnn_conv1_mfma", 1)                  # one-hot conv1 on the MFMA pipe instead of the LDS gather
+    got_m, _ = eng.score([nm], b, _native.make_lut(alpha))
+    eng.set_option("cnn_conv1_mfma", 0)
+    assert_scores(got_m[:, 0], want, f"cnn mfma(conv1 on mfma) L={L} A={A}")
     # the shape-agnostic kernel must agree too (independent on-device implementation)
     eng.set_option("force_generic", 1)
     got_g, _ = eng.score([nm], b, _native.make_lut(alpha))
@@ -138,16 +148,20 @@ def test_cnn_odd_shapes_generic(eng, L, A, alpha, F, H, K):
 @pytest.mark.parametrize("kind", ["mlp", "ge"])
 @pytest.mark.parametrize("L,A,alpha,H,n", [(14, 4, "UGCA", 100, 3000), (8, 4, "TGCA", 100, 1000), (14, 4, "UGCA", 97, 300),
                                            (90, 20, s_utils.AAS, 100, 1000), (237, 20, s_utils.AAS, 100, 200),
-                                           (14, 4, "UGCA", 200, 300), (3, 4, "TGCA", 1, 50), (10, 2, "01", 100, 100)])
+                                           (14, 4, "UGCA", 200, 300), (3, 4, "TGCA", 1, 50), (10, 2, "01", 100, 100),
+                                           (14, 4, "UGCA", 104, 200), (14, 4, "UGCA", 109, 200), (50, 4, "UGCA", 100, 500),
+                                           (11, 3, "ABC", 100, 300)])
 def test_mlp_ge_vs_oracle(eng, kind, L, A, alpha, H, n):
-    for force in (0, 1):
+    for force, l1 in ((0, 0), (0, 1), (1, 0)):
         eng.set_option("force_generic", force)
+        eng.set_option("mlp_l1_mfma", l1)
         nm, w = make_native(eng, kind, L, A, H, seed=11)
         b, seqs = rand_seqs(n, L, alpha, seed=L + H)
         got, _ = eng.score([nm], b, _native.make_lut(alpha))
         want = ref_np.keras_fitness(seqs, alpha, kind, w, exact=True)
-        assert_scores(got[:, 0], want, f"{kind} L={L} A={A} H={H} generic={force}")
+        assert_scores(got[:, 0], want, f"{kind} L={L} A={A} H={H} generic={force} l1_mfma={l1}")
     eng.set_option("force_generic", 0)
+    eng.set_option("mlp_l1_mfma", 0)
 
 
 # ------------------------------------------------------------------ ensembles

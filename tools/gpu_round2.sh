@@ -10,7 +10,7 @@ python -c "import __graft_entry__ as g; g.build(quiet=True); print('build ok')" 
 timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --timeout 600 > $OUT/pytest_gpu.log 2>&1
 echo "pytest exit: $?" >> $OUT/pytest_gpu.log
 
-for v in 1 2 3 4; do
+for v in 1 4; do
   timeout 200 python bench.py --steps 100 --warmup 10 --variant $v --no-cpu-baseline > $OUT/bench_v$v.log 2>&1
   echo "exit $?" >> $OUT/bench_v$v.log
 done
@@ -20,12 +20,15 @@ echo "exit $?" >> $OUT/bench.log
 rm -rf $OUT/prof $OUT/pmc*
 timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof -o r1 -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/rocprof.log 2>&1
 # PMC: one counter group per run, --pmc only (no trace domains)
-timeout 300 rocprofv3 --pmc FETCH_SIZE -f csv -d $OUT/pmc_fetch -o r1 -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE -f csv -d $OUT/pmc_write -o r1 -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
+
+
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -f csv -d $OUT/pmc_sq -o r1 -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1
-timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAVES -f csv -d $OUT/pmc_lds -o r1 -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/pmc_lds.log 2>&1
+
 find $OUT/prof $OUT/pmc_* -type f | head -40 > $OUT/files.log
 
 timeout 900 python tools/perf_survey.py > $OUT/perf_survey.log 2>&1
 echo "exit $?" >> $OUT/perf_survey.log
 tail -2 $OUT/pytest_gpu.log; tail -2 $OUT/bench.log | cut -c1-400
+# the N>1 code path (RCCL init + all-gather + max-over-ranks) on one rank
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 50 --warmup 5 --force-dist --no-cpu-baseline > $OUT/bench_dist1.log 2>&1
+echo "exit $?" >> $OUT/bench_dist1.log

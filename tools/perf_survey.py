@@ -38,7 +38,7 @@ def natives(kind, L, A, H, M, F=0, K=0):
     return out
 
 
-def time_score(kind, L, alpha, H, M, N, F=0, K=0, reps=20, generic=False, variant=0, label=None):
+def time_score(kind, L, alpha, H, M, N, F=0, K=0, reps=20, generic=False, variant=0, label=None, opts=None):
     A = len(alpha)
     ms_ = natives(kind, L, A, H, M, F, K)
     lut = _native.make_lut(alpha)
@@ -47,6 +47,8 @@ def time_score(kind, L, alpha, H, M, N, F=0, K=0, reps=20, generic=False, varian
     torch.cuda.synchronize()
     eng.set_option("force_generic", int(generic))
     eng.set_option("cnn_variant", variant)
+    for k_, v_ in (opts or {}).items():
+        eng.set_option(k_, v_)
     for _ in range(3):
         eng.score_dev(ms_, d_in.data_ptr(), N, L, lut, d_nm.data_ptr(), None)
     eng.sync()
@@ -56,6 +58,8 @@ def time_score(kind, L, alpha, H, M, N, F=0, K=0, reps=20, generic=False, varian
     ms = eng.timer_stop() / reps
     eng.set_option("force_generic", 0)
     eng.set_option("cnn_variant", 0)
+    for k_ in (opts or {}):
+        eng.set_option(k_, 0)
     macs = synth.algorithmic_macs(kind, L, A, H, F, K)
     tf = 2.0 * macs * M * N / (ms * 1e-3) / 1e12
     gbs = (L + 4 * M) * N / (ms * 1e-3) / 1e9
@@ -174,8 +178,10 @@ def nam():
 def main():
     which = sys.argv[1:] or ["score", "hbm", "e2e", "nam"]
     if "score" in which:
-        for v in (1, 2, 3):
-            time_score("cnn", 8, "TGCA", 100, 3, 100_000, 32, 5, variant=v, label=f"C2 cnn L=8 M=3 N=1e5 variant {v}")
+        for v in (1, 2, 3, 4):
+            time_score("cnn", 8, "TGCA", 100, 3, 100_000, 32, 5, variant=v, label=f"C2 cnn L=8 M=3 N=1e5 variant {v} conv1=gather")
+            time_score("cnn", 8, "TGCA", 100, 3, 100_000, 32, 5, variant=v, label=f"C2 cnn L=8 M=3 N=1e5 variant {v} conv1=mfma",
+                       opts={"cnn_conv1_mfma": 1})
         time_score("cnn", 8, "TGCA", 100, 1, 10_000, 32, 5, label="C1 cnn L=8 M=1 N=1e4")
         time_score("cnn", 8, "TGCA", 100, 1, 100_000, 32, 5)
         time_score("cnn", 8, "TGCA", 100, 3, 1_000_000, 32, 5, reps=5)
@@ -184,7 +190,10 @@ def main():
         time_score("cnn", 14, "UGCA", 100, 1, 100_000, 32, 5)
         time_score("cnn", 50, "UGCA", 100, 1, 100_000, 32, 5, reps=5)
         time_score("cnn", 100, "UGCA", 100, 1, 100_000, 32, 5, reps=3)
-        time_score("mlp", 14, "UGCA", 100, 1, 100_000, label="C3 mlp L=14 H=100 M=1 N=1e5")
+        time_score("mlp", 14, "UGCA", 100, 1, 100_000, label="C3 mlp L=14 H=100 M=1 N=1e5 l1=gather")
+        time_score("mlp", 14, "UGCA", 100, 1, 100_000, label="C3 mlp L=14 H=100 M=1 N=1e5 l1=mfma", opts={"mlp_l1_mfma": 1})
+        time_score("mlp", 90, AAS, 100, 1, 100_000, reps=5, label="mlp L=90 A=20 H=100 M=1 N=1e5 (layer-1 rows gathered from L2)")
+        time_score("cnn", 237, AAS, 100, 1, 16_384, 32, 5, reps=2, label="C5 cnn L=237 A=20 M=1 N=16384 conv1=mfma", opts={"cnn_conv1_mfma": 1})
         time_score("mlp", 14, "UGCA", 100, 1, 1_000_000, reps=5)
         time_score("mlp", 14, "UGCA", 100, 1, 100_000, reps=2, generic=True)
         time_score("ge", 90, AAS, 100, 8, 100_000, label="C4 ge L=90 A=20 H=100 M=8 N=1e5")
