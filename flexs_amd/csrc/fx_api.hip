@@ -64,11 +64,11 @@ int fx_upload_lut(fx_engine* e, const uint8_t lut[256]) {
 }
 
 static int check_deferred(fx_engine* e) {
-    // caller has synchronised the stream
-    unsigned err = 0;
-    FX_HIP(e, hipMemcpy(&err, e->d_err, sizeof(err), hipMemcpyDeviceToHost));
+    // caller has synchronised the stream; the error word lives in mapped pinned host memory,
+    // so reading it costs nothing (no extra hipMemcpy on the small-call latency path)
+    const unsigned err = *reinterpret_cast<volatile unsigned*>(e->h_err);
     if (err) {
-        FX_HIP(e, hipMemset(e->d_err, 0, sizeof(unsigned)));
+        *reinterpret_cast<volatile unsigned*>(e->h_err) = 0;
         if (err & FX_ERR_BADCHAR) return fx_fail(e, FX_EBADCHAR, "substring not found: character outside the alphabet");
     }
     return FX_OK;
@@ -122,8 +122,9 @@ int fx_engine_create(int device, fx_engine** out) {
     e->stream = e->own_stream;
     FX_CREATE_HIP(hipEventCreate(&e->ev0));
     FX_CREATE_HIP(hipEventCreate(&e->ev1));
-    FX_CREATE_HIP(hipMalloc(&e->d_err, sizeof(unsigned)));
-    FX_CREATE_HIP(hipMemset(e->d_err, 0, sizeof(unsigned)));
+    FX_CREATE_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_err), 64, hipHostMallocMapped));
+    *e->h_err = 0;
+    FX_CREATE_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->d_err), e->h_err, 0));
     FX_CREATE_HIP(hipMalloc(&e->d_lut, 256));
 #undef FX_CREATE_HIP
     *out = e;
@@ -136,7 +137,7 @@ int fx_engine_destroy(fx_engine* e) {
     (void)hipStreamSynchronize(e->stream);
     for (auto& p : e->d_scratch) if (p) (void)hipFree(p);
     for (auto& p : e->h_pinned) if (p) (void)hipHostFree(p);
-    if (e->d_err) (void)hipFree(e->d_err);
+    if (e->h_err) (void)hipHostFree(e->h_err);
     if (e->d_lut) (void)hipFree(e->d_lut);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);

@@ -110,6 +110,15 @@ int fx_scratch(fx_engine* e, int slot, size_t bytes, void** out);
 int fx_pinned(fx_engine* e, int slot, size_t bytes, void** out);
 int fx_upload_lut(fx_engine* e, const uint8_t lut[256]);
 
+// Deferred error word: mapped pinned HOST memory (read by the host right after the stream
+// sync, no copy).  Only one bit is defined, so raising it is an idempotent system-scope
+// store -- no PCIe atomics needed.
+#if defined(__HIPCC__)
+__device__ __forceinline__ void fx_raise(unsigned* err, unsigned bit) {
+    __hip_atomic_store(err, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
+
 // ---------------------------------------------------------------- kernel launchers
 // (defined in the .hip files; all enqueue on e->stream and return an fx_status)
 int fx_launch_score_generic(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii,

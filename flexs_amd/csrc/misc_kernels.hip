@@ -45,7 +45,7 @@ __global__ void k_encode_onehot(const uint8_t* __restrict__ ascii, const uint8_t
             out[i] = (a == c) ? 1.f : 0.f;
         }
     }
-    if (bad) atomicOr(err, FX_ERR_BADCHAR);
+    if (bad) fx_raise(err, FX_ERR_BADCHAR);
 }
 
 // ---- NumPy pairwise summation order of one contiguous row (ensemble.py:24:

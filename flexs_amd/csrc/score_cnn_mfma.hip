@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
             }
         }
     }
-    if (bad) atomicOr(p.err, FX_ERR_BADCHAR);
+    if (bad) fx_raise(p.err, FX_ERR_BADCHAR);
 }
 
 template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1>
@@ -319,7 +319,9 @@ int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const
     const size_t full = (size_t)lay.total_floats * 4 + 256 + 16, conv_only = (size_t)lay.conv_floats * 4 + 256 + 16;
     if (s.A == 4) {
         if (full > (size_t)e->max_lds) return FX_EUNSUPPORTED;
-        if (variant == 0) variant = 4;                   // 16 waves = 4 per SIMD measured best (profiles/r1_run2_*)
+        // auto: 16 waves (4 per SIMD) measured best once every CU has plenty of tiles
+        // (profiles/r1_run3_*); small batches spread over more, smaller workgroups instead
+        if (variant == 0) variant = ((N + 15) / 16) * M >= (int64_t)e->num_cus * 32 ? 4 : 1;
         int nt = (variant == 1 || variant == 4) ? 1 : 2;
         a.TG = (N + 16 * nt - 1) / (16 * nt);
         switch (variant) {

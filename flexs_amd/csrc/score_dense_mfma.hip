@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
             }
         }
     }
-    if (bad) atomicOr(p.err, FX_ERR_BADCHAR);
+    if (bad) fx_raise(p.err, FX_ERR_BADCHAR);
 }
 
 template <int KIND, int A, int HT, int NT, int WAVES, bool G1, bool W1G = false>

@@ -114,7 +114,7 @@ __global__ void k_score_generic_cnn(GenericArgs a) {
     dense_ws(g1, g2, T, H, d2, c2, H);
     float y = dot_ws(g2, T, H, d3, c3[0]);
     a.out[n * a.Mtot + a.m] = nan_to_num(y);
-    if (bad) atomicOr(a.err, FX_ERR_BADCHAR);
+    if (bad) fx_raise(a.err, FX_ERR_BADCHAR);
 }
 
 __global__ void k_score_generic_mlp(GenericArgs a) {
@@ -140,7 +140,7 @@ __global__ void k_score_generic_mlp(GenericArgs a) {
     dense_ws(g1, g0, T, H, d3, c3, H);
     float y = dot_ws(g0, T, H, d4, c4[0]);
     a.out[n * a.Mtot + a.m] = nan_to_num(y);
-    if (bad) atomicOr(a.err, FX_ERR_BADCHAR);
+    if (bad) fx_raise(a.err, FX_ERR_BADCHAR);
 }
 
 __global__ void k_score_generic_ge(GenericArgs a) {
@@ -162,7 +162,7 @@ __global__ void k_score_generic_ge(GenericArgs a) {
     dense_ws(g0, g1, T, H, d3, c3, H);
     float y = dot_ws(g1, T, H, d4, c4[0]);
     a.out[n * a.Mtot + a.m] = nan_to_num(y);
-    if (bad) atomicOr(a.err, FX_ERR_BADCHAR);
+    if (bad) fx_raise(a.err, FX_ERR_BADCHAR);
 }
 
 }  // namespace

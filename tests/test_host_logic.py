@@ -201,3 +201,23 @@ def test_training_reduces_loss_and_bumps_version():
         bm.MLP(L, 8, alphabet).train(["ACGTXCGT"], [0.0])
     with pytest.raises(ValueError):
         bm.MLP(L, 8, alphabet).train(["ACG"], [0.0])
+
+
+def test_dyna_ppo_ensemble_gating():
+    """dyna_ppo.py:118-130: members below the r^2 threshold are ignored; none passing -> best single."""
+    a, b, c = FakeConstantModel(1.0), FakeConstantModel(3.0), FakeConstantModel(8.0)
+    ens = bm.DynaPPOEnsemble(3, "TGCA", models=[a, b, c])
+    assert ens.name == "DynaPPOEnsemble" and list(ens.r_squared_vals) == [1, 1, 1]
+    assert ens.get_fitness(["ATC", "ATG"]).tolist() == [4.0, 4.0]
+    ens.r_squared_vals = [0.9, 0.1, 0.6]
+    assert ens.get_fitness(["ATC"]).tolist() == [4.5]
+    ens.r_squared_vals = [0.2, 0.4, 0.1]
+    assert ens.get_fitness(["ATC"]).tolist() == [3.0]
+    assert (a.cost, b.cost, c.cost) == (3, 3, 3) and ens.cost == 4
+    ens.train(["ATC"] * 5, [0.0] * 5)                      # < 10 sequences: no-op (dyna_ppo.py:94-95)
+    assert list(ens.r_squared_vals) == [0.2, 0.4, 0.1]
+    ens.train(["ATC"] * 12, list(range(12)))               # constant predictions -> r^2 = 0 for every member
+    assert list(ens.r_squared_vals) == [0, 0, 0]
+    default = bm.DynaPPOEnsemble(14, "UGCA")
+    assert [m.name for m in default.models] == ["MLP_hidden_size_100", "MLP_hidden_size_200",
+                                                "CNN_hidden_size_100_num_filters_32"]
