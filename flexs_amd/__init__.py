@@ -11,6 +11,6 @@ from flexs_amd import types  # noqa: F401
 from flexs_amd.landscape import Landscape  # noqa: F401
 from flexs_amd.model import LandscapeAsModel, Model  # noqa: F401
 from flexs_amd.ensemble import Ensemble  # noqa: F401  isort:skip
-from flexs_amd import baselines, utils  # noqa: F401  isort:skip
+from flexs_amd import baselines, landscapes, utils  # noqa: F401  isort:skip
 
 __version__ = "0.1.0"

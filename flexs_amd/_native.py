@@ -61,6 +61,10 @@ SIGNATURES = {
     "fx_cache_size": (C.c_int64, [_vp]),
     "fx_cache_append": (C.c_int, [_vp, _vp, C.c_int64]),
     "fx_cache_min_dist": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, _vp, _vp]),
+    "fx_cache_distances": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, _vp]),
+    "fx_table_create": (C.c_int, [_vp, _vp, C.c_int64, C.POINTER(_vp)]),
+    "fx_table_destroy": (C.c_int, [_vp]),
+    "fx_table_lookup": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _u8p, C.c_int, _vp]),
     "fx_nam_combine": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "fx_debug_packed_size": (C.c_int64, [C.c_int] * 6),
     "fx_debug_pack_layout": (C.c_int, [C.c_int] * 6 + [_i64p]),
@@ -369,10 +373,47 @@ class NativeCache:
         self.engine.check(self.engine._lib.fx_cache_min_dist(self.handle, mode, _ptr(q), Q, _ptr(dist), _ptr(arg)))
         return dist, arg
 
+    def distances(self, queries: np.ndarray, mode: int = FX_LEVENSHTEIN) -> np.ndarray:
+        """(Q, C) uint8 matrix of min(distance, 255) against every stored key."""
+        q = np.ascontiguousarray(queries, np.uint8)
+        out = np.empty((q.shape[0], len(self)), np.uint8)
+        if out.size:
+            self.engine.check(self.engine._lib.fx_cache_distances(self.handle, mode, _ptr(q), q.shape[0], _ptr(out)))
+        return out
+
     def __del__(self):
         try:
             if self.handle:
                 self.engine._lib.fx_cache_destroy(self.handle)
+                self.handle = None
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class NativeTable:
+    """Device-resident look-up landscape: fitness = table[packed k-mer]."""
+
+    def __init__(self, engine: Engine, table: np.ndarray, alphabet: str, bits: int):
+        self.engine = engine
+        self.bits = bits
+        self.lut = make_lut(alphabet)
+        t = np.ascontiguousarray(table, np.float64)
+        h = _vp()
+        engine.check(engine._lib.fx_table_create(engine.handle, _ptr(t), t.shape[0], C.byref(h)))
+        self.handle = h
+
+    def lookup(self, seq_bytes: np.ndarray) -> np.ndarray:
+        b = np.ascontiguousarray(seq_bytes, np.uint8)
+        out = np.empty(b.shape[0], np.float64)
+        if b.shape[0]:
+            self.engine.check(self.engine._lib.fx_table_lookup(self.handle, _ptr(b), b.shape[0], b.shape[1],
+                                                               self.lut.ctypes.data_as(_u8p), self.bits, _ptr(out)))
+        return out
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.engine._lib.fx_table_destroy(self.handle)
                 self.handle = None
         except Exception:  # noqa: BLE001
             pass

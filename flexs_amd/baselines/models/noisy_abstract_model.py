@@ -86,14 +86,29 @@ class NoisyAbstractModel(flexs_amd.Model):
                 dist, neighbours = self._min_distances([str(s) for s in new_seqs])
             signal = np.empty(len(new_seqs))
             noise = np.empty(len(new_seqs))
-            for i, (seq, nb) in enumerate(zip(new_seqs, neighbours)):
-                # same call order as the reference loop (:86-91): two oracle queries, one RNG draw
-                signal[i] = self.landscape.get_fitness([seq]).item()
-                neighbor_fitness = self.landscape.get_fitness([nb]).item()
-                if neighbor_fitness >= 0:
-                    noise[i] = np.random.exponential(scale=neighbor_fitness)
-                else:
-                    noise[i] = np.random.choice(list(self.cache.values()))
+            done = False
+            if getattr(self.landscape, "batch_safe", False):
+                # Deterministic table landscape (e.g. flexs_amd.landscapes.TFBinding): query it in two
+                # batches instead of 2*Q one-element calls.  Same values, same total landscape.cost
+                # (+2 per query, :86-87); the RNG stream is unchanged because
+                # np.random.exponential(scale=array) draws element by element in order.
+                sig = self.landscape.get_fitness([str(s) for s in new_seqs])
+                nbf = self.landscape.get_fitness([str(s) for s in neighbours])
+                if (nbf >= 0).all():
+                    signal[:] = sig
+                    noise[:] = np.random.exponential(scale=nbf)
+                    done = True
+                else:                      # negative neighbour fitness consumes the RNG differently (:90-91)
+                    self.landscape.cost -= 2 * len(new_seqs)
+            if not done:
+                for i, (seq, nb) in enumerate(zip(new_seqs, neighbours)):
+                    # same call order as the reference loop (:86-91): two oracle queries, one RNG draw
+                    signal[i] = self.landscape.get_fitness([seq]).item()
+                    neighbor_fitness = self.landscape.get_fitness([nb]).item()
+                    if neighbor_fitness >= 0:
+                        noise[i] = np.random.exponential(scale=neighbor_fitness)
+                    else:
+                        noise[i] = np.random.choice(list(self.cache.values()))
             max_d = int(dist.max()) if len(dist) else 0
             alpha_tab = np.array([self.ss ** d for d in range(max_d + 1)], np.float64)   # :93, Python float pow
             fitnesses[~cached] = _native.Engine.get(self._device).nam_combine(signal, noise, dist, alpha_tab)

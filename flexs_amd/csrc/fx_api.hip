@@ -544,6 +544,67 @@ int fx_cache_min_dist(fx_cache* c, int mode, const uint8_t* queries, int64_t Q, 
     return min_dist_common(e, mode, queries, Q, c->d_keys, c->size, c->L, dist, argmin);
 }
 
+int fx_cache_distances(fx_cache* c, int mode, const uint8_t* queries, int64_t Q, uint8_t* out) {
+    if (!c || Q < 0) return FX_EINVAL;
+    fx_engine* e = c->eng;
+    if (mode != FX_LEVENSHTEIN && mode != FX_HAMMING) return fx_fail(e, FX_EINVAL, "unknown distance mode");
+    if (Q == 0 || c->size == 0) return FX_OK;
+    if (!queries || !out) return fx_fail(e, FX_EINVAL, "null buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    int rc;
+    const int64_t qstep = std::max<int64_t>(1, std::min<int64_t>(32768, ((int64_t)1 << 28) / std::max<int64_t>(c->size, 1)));
+    for (int64_t q0 = 0; q0 < Q; q0 += qstep) {
+        const int64_t qn = std::min<int64_t>(qstep, Q - q0);
+        void *d_q = nullptr, *d_out = nullptr;
+        if ((rc = fx_scratch(e, 0, (size_t)qn * c->L + 16, &d_q))) return rc;
+        if ((rc = fx_scratch(e, 1, (size_t)qn * c->size, &d_out))) return rc;
+        FX_HIP(e, hipMemcpyAsync(d_q, queries + q0 * c->L, (size_t)qn * c->L, hipMemcpyHostToDevice, e->stream));
+        if ((rc = fx_launch_distances(e, mode, (const uint8_t*)d_q, qn, c->d_keys, c->size, c->L, (uint8_t*)d_out))) return rc;
+        FX_HIP(e, hipMemcpyAsync(out + q0 * c->size, d_out, (size_t)qn * c->size, hipMemcpyDeviceToHost, e->stream));
+        FX_HIP(e, hipStreamSynchronize(e->stream));
+    }
+    return FX_OK;
+}
+
+int fx_table_create(fx_engine* e, const double* table, int64_t len, fx_table** out) {
+    if (!e || !table || len < 1 || !out) return FX_EINVAL;
+    FX_HIP(e, hipSetDevice(e->device));
+    fx_table* t = new (std::nothrow) fx_table();
+    if (!t) return FX_ENOMEM;
+    t->eng = e; t->len = len;
+    if (hipMalloc(&t->d_table, sizeof(double) * (size_t)len) != hipSuccess) { (void)hipGetLastError(); delete t; return fx_fail(e, FX_ENOMEM, "table alloc failed"); }
+    FX_HIP(e, hipMemcpy(t->d_table, table, sizeof(double) * (size_t)len, hipMemcpyHostToDevice));
+    *out = t;
+    return FX_OK;
+}
+
+int fx_table_destroy(fx_table* t) {
+    if (!t) return FX_OK;
+    (void)hipSetDevice(t->eng->device);
+    (void)hipStreamSynchronize(t->eng->stream);
+    if (t->d_table) (void)hipFree(t->d_table);
+    delete t;
+    return FX_OK;
+}
+
+int fx_table_lookup(fx_table* t, const uint8_t* ascii, int64_t N, int L, const uint8_t lut[256], int bits, double* out) {
+    if (!t || N < 0 || L < 0 || !lut || bits < 1 || bits > 8 || (int64_t)bits * L > 40) return FX_EINVAL;
+    fx_engine* e = t->eng;
+    if (N == 0) return FX_OK;
+    if (!ascii || !out) return fx_fail(e, FX_EINVAL, "null buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    void *d_in = nullptr, *d_out = nullptr;
+    int rc;
+    if ((rc = fx_scratch(e, 0, (size_t)N * L + 16, &d_in))) return rc;
+    if ((rc = fx_scratch(e, 1, (size_t)N * 8, &d_out))) return rc;
+    FX_HIP(e, hipMemcpyAsync(d_in, ascii, (size_t)N * L, hipMemcpyHostToDevice, e->stream));
+    if ((rc = fx_upload_lut(e, lut))) return rc;
+    if ((rc = fx_launch_table_lookup(e, t->d_table, t->len, (const uint8_t*)d_in, N, L, bits, (double*)d_out))) return rc;
+    FX_HIP(e, hipMemcpyAsync(out, d_out, (size_t)N * 8, hipMemcpyDeviceToHost, e->stream));
+    FX_HIP(e, hipStreamSynchronize(e->stream));
+    return FX_OK;
+}
+
 int fx_nam_combine(fx_engine* e, int64_t Q, const double* signal, const double* noise, const int32_t* d,
                    const double* alpha_tab, int n_tab, double* out) {
     if (!e || Q < 0 || n_tab < 1) return FX_EINVAL;

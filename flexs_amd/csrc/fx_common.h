@@ -97,6 +97,12 @@ struct fx_cache {
     uint8_t* d_keys = nullptr;  // capacity x L bytes, row-major, insertion order
 };
 
+struct fx_table {
+    fx_engine* eng = nullptr;
+    int64_t len = 0;
+    double* d_table = nullptr;
+};
+
 // ---------------------------------------------------------------- helpers
 int fx_fail(fx_engine* e, int status, const std::string& msg);
 #define FX_HIP(e, call)                                                                   \
@@ -138,5 +144,9 @@ int fx_launch_nam_combine(fx_engine* e, int64_t Q, const double* d_signal, const
                           const int32_t* d_dist, const double* d_alpha, int n_tab, double* d_out);
 int fx_launch_min_dist(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, const uint8_t* d_cache,
                        int64_t C, int L, unsigned long long* d_keys);
+int fx_launch_distances(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, const uint8_t* d_cache, int64_t C,
+                        int L, uint8_t* d_out);
+int fx_launch_table_lookup(fx_engine* e, const double* d_table, int64_t len, const uint8_t* d_ascii, int64_t N,
+                           int L, int bits, double* d_out);
 int fx_launch_min_dist_finish(fx_engine* e, const unsigned long long* d_keys, int64_t Q, int64_t C,
                               int32_t* d_dist, int64_t* d_arg);

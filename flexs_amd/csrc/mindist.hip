@@ -73,6 +73,47 @@ __global__ void __launch_bounds__(256) k_min_dist(int mode, const uint8_t* __res
     }
 }
 
+// Dense Q x C distance matrix (uint8, clamped) -- same per-pair code as k_min_dist.
+template <int W>
+__global__ void __launch_bounds__(256) k_distances(int mode, const uint8_t* __restrict__ q, const uint8_t* __restrict__ cache,
+                                                   int64_t C, int L, uint8_t* __restrict__ out) {
+    __shared__ uint64_t peq[256 * W];
+    __shared__ uint8_t qs[W * 64];
+    const int tid = threadIdx.x;
+    const int64_t qi = blockIdx.y;
+    for (int i = tid; i < L; i += 256) qs[i] = q[qi * L + i];
+    __syncthreads();
+    {
+        uint64_t mk[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) mk[w] = 0;
+        for (int i = 0; i < L; ++i)
+            if (qs[i] == tid) {
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                    if ((i >> 6) == w) mk[w] |= 1ull << (i & 63);
+            }
+#pragma unroll
+        for (int w = 0; w < W; ++w) peq[tid * W + w] = mk[w];
+    }
+    __syncthreads();
+    const int64_t c0 = (int64_t)blockIdx.x * CHUNK;
+    for (int k = 0; k < CHUNK / 256; ++k) {
+        const int64_t c = c0 + k * 256 + tid;
+        if (c >= C) break;
+        const uint8_t* t = cache + c * L;
+        int d;
+        if (mode == FX_HAMMING) {
+            d = 0;
+            for (int i = 0; i < L; ++i) d += (t[i] != qs[i]);
+        } else {
+            d = fx_myers_distance<W>(
+                L, L, [&](int ch, int w) { return peq[ch * W + w]; }, [&](int i) { return (int)t[i]; });
+        }
+        out[qi * C + c] = (uint8_t)(d > 255 ? 255 : d);
+    }
+}
+
 __global__ void k_min_dist_finish(const unsigned long long* __restrict__ keys, int64_t Q, int32_t* __restrict__ dist,
                                   int64_t* __restrict__ arg) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -99,6 +140,23 @@ int fx_launch_min_dist(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, co
         case 2: hipLaunchKernelGGL(k_min_dist<2>, grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
         case 3: hipLaunchKernelGGL(k_min_dist<3>, grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
         default: hipLaunchKernelGGL(k_min_dist<4>, grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
+    }
+    FX_HIP(e, hipGetLastError());
+    return FX_OK;
+}
+
+int fx_launch_distances(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, const uint8_t* d_cache, int64_t C,
+                        int L, uint8_t* d_out) {
+    if (Q == 0 || C == 0) return FX_OK;
+    if (L > 256) return fx_fail(e, FX_EUNSUPPORTED, "distances: sequence length > 256");
+    if (Q > 65535) return fx_fail(e, FX_EINVAL, "distances: more than 65535 queries per call");
+    dim3 grid((unsigned)((C + CHUNK - 1) / CHUNK), (unsigned)Q), block(256);
+    switch ((L + 63) / 64) {
+        case 0:
+        case 1: hipLaunchKernelGGL(k_distances<1>, grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;
+        case 2: hipLaunchKernelGGL(k_distances<2>, grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;
+        case 3: hipLaunchKernelGGL(k_distances<3>, grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;
+        default: hipLaunchKernelGGL(k_distances<4>, grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;
     }
     FX_HIP(e, hipGetLastError());
     return FX_OK;

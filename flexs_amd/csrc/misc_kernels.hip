@@ -180,6 +180,21 @@ __global__ void k_argmax_decode(const double* __restrict__ x, int64_t rows, int 
     }
 }
 
+// ---- table landscape (tf_binding.py:43-44): fitness = table[packed k-mer]; unknown character -> NaN
+__global__ void k_table_lookup(const double* __restrict__ table, int64_t len, const uint8_t* __restrict__ ascii,
+                               const uint8_t* __restrict__ lut, int64_t N, int L, int bits, double* __restrict__ out) {
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        int64_t idx = 0;
+        bool ok = true;
+        for (int i = 0; i < L; ++i) {
+            const int c = lut[ascii[n * L + i]];
+            ok &= (c != 0xFF);
+            idx |= (int64_t)(c & ((1 << bits) - 1)) << (bits * i);
+        }
+        out[n] = (ok && idx < len) ? table[idx] : __longlong_as_double(0x7ff8000000000000ll);
+    }
+}
+
 // ---- test hook: ONE v_mfma_f32_16x16x4_f32 on caller-supplied per-lane operands, so the
 // operand / result lane layout the scoring kernels rely on is checked on the real hardware.
 __global__ void k_mfma_probe(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
@@ -199,6 +214,15 @@ inline unsigned grid_for(int64_t n, int block, int cus) {
 }
 
 }  // namespace
+
+int fx_launch_table_lookup(fx_engine* e, const double* d_table, int64_t len, const uint8_t* d_ascii, int64_t N,
+                           int L, int bits, double* d_out) {
+    if (N == 0) return FX_OK;
+    dim3 grid(grid_for(N, 256, e->num_cus)), block(256);
+    hipLaunchKernelGGL(k_table_lookup, grid, block, 0, e->stream, d_table, len, d_ascii, e->d_lut, N, L, bits, d_out);
+    FX_HIP(e, hipGetLastError());
+    return FX_OK;
+}
 
 int fx_launch_mfma_probe(fx_engine* e, const float* d_a, const float* d_b, const float* d_c, float* d_d) {
     hipLaunchKernelGGL(k_mfma_probe, dim3(1), dim3(64), 0, e->stream, d_a, d_b, d_c, d_d);

@@ -1,0 +1,50 @@
+"""Edit-distance services built on the K4 kernels.
+
+`SeenSequences` is the device-backed form of the `all_seqs` bookkeeping in the
+DyNA-PPO environments (flexs/baselines/explorers/environments/dyna_ppo.py:106-114,
+267-275): `density(seq)` = sum of fitness / distance over every observed sequence
+at edit distance 1..radius, accumulated in insertion order like the reference loop
+(so the float result is bit-identical)."""
+import numpy as np
+
+from flexs_amd import _native
+
+
+class SeenSequences:
+    def __init__(self, seq_len: int, distance: str = "levenshtein", device: int = None):
+        self._L = seq_len
+        self._mode = _native.FX_LEVENSHTEIN if distance == "levenshtein" else _native.FX_HAMMING
+        self._cache = _native.NativeCache(_native.Engine.get(device), seq_len)
+        self._index = {}          # sequence -> position (dict semantics: re-adding updates the fitness)
+        self._fitness = []
+
+    def __len__(self):
+        return len(self._fitness)
+
+    def __contains__(self, seq):
+        return seq in self._index
+
+    def __getitem__(self, seq):
+        return self._fitness[self._index[seq]]
+
+    def add(self, seq: str, fitness: float):
+        """`self.all_seqs[seq] = fitness`."""
+        if seq in self._index:
+            self._fitness[self._index[seq]] = fitness
+            return
+        self._index[seq] = len(self._fitness)
+        self._fitness.append(fitness)
+        self._cache.append(_native.sequences_to_bytes([seq], L=self._L))
+
+    def distances(self, seq: str) -> np.ndarray:
+        return self._cache.distances(_native.sequences_to_bytes([seq], L=self._L), self._mode)[0]
+
+    def density(self, seq: str, dist_radius: int = 2):
+        """dyna_ppo.py:106-114: `dens += all_seqs[s] / dist` for 0 < dist <= radius, in insertion order."""
+        dens = 0
+        if len(self._fitness) == 0:
+            return dens
+        d = self.distances(seq)
+        for i in np.flatnonzero((d != 0) & (d <= dist_radius)):
+            dens += self._fitness[i] / int(d[i])
+        return dens

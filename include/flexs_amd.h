@@ -62,6 +62,7 @@ typedef enum fx_dist_mode {
 typedef struct fx_engine fx_engine; /* one GPU: stream, scratch, deferred-error word   */
 typedef struct fx_model fx_model;   /* one surrogate: shape + packed device weights    */
 typedef struct fx_cache fx_cache;   /* device-resident NoisyAbstractModel cache keys   */
+typedef struct fx_table fx_table;   /* device-resident k-mer -> fitness table landscape */
 
 /* ------------------------------------------------------------------ library */
 int fx_version(void);
@@ -165,6 +166,23 @@ int fx_cache_min_dist(fx_cache *c, int mode, const uint8_t *queries, int64_t Q, 
  * bit-identical to np.random.exponential(scale)). float64 throughout. */
 int fx_nam_combine(fx_engine *e, int64_t Q, const double *signal, const double *noise,
                    const int32_t *d, const double *alpha_tab, int n_tab, double *out);
+
+/* Dense distance matrix of Q queries against the device-resident keys: out[q*C + c] =
+ * min(distance, 255) as uint8 (C = fx_cache_size).  Serves `sequence_density`
+ * (flexs/baselines/explorers/environments/dyna_ppo.py:106-114,267-275: sum of
+ * fitness/dist over all seen sequences with 0 < dist <= 2): the host filters by radius
+ * and accumulates in insertion order, so the float sum stays bit-identical. */
+int fx_cache_distances(fx_cache *c, int mode, const uint8_t *queries, int64_t Q, uint8_t *out_QxC);
+
+/* ------------------------------------------------------- table landscapes */
+/* Ground-truth look-up landscapes, e.g. TFBinding
+ * (flexs/landscapes/tf_binding.py:38-44: dict of all 4^8 8-mers -> normalised E-score).
+ * table[idx] with idx = sum_i code(seq[i]) << (bits*i); entries that do not exist hold NaN
+ * (the Python layer turns a NaN / unknown character into the reference's KeyError). */
+int fx_table_create(fx_engine *e, const double *table, int64_t len, fx_table **out);
+int fx_table_destroy(fx_table *t);
+int fx_table_lookup(fx_table *t, const uint8_t *ascii, int64_t N, int L, const uint8_t lut[256],
+                    int bits, double *out);
 
 /* ------------------------------------------------------------ test hooks */
 /* Host-only (no GPU needed): expose the weight packing (Keras order -> MFMA

@@ -412,3 +412,108 @@ def test_baseline_config3_and_4_shapes(eng):
     for m in range(8):
         assert_scores(nm8[:, m], c_oracle.forward("ge", codes, 20, ws[m]), f"C4 ge member {m}")
     assert np.array_equal(mean, np.mean(nm8, axis=1))
+
+
+# ------------------------------------------------------------------ "next" rows
+def _write_tf_file(path, rng, n_pairs=2000):
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    seen, rows = set(), []
+    while len(rows) < n_pairs:
+        s = "".join("ACGT"[i] for i in rng.integers(0, 4, 8))
+        rc = "".join(comp[c] for c in reversed(s))
+        if s in seen or rc in seen:
+            continue
+        seen.update((s, rc))
+        rows.append((s, rc, rng.uniform(-0.3, 0.5), rng.uniform(1e3, 1e5), rng.normal()))
+    with open(path, "w") as f:
+        f.write("8-mer\t8-mer\tE-score\tMedian\tZ-score\n")          # the reference files repeat the column name
+        for r in rows:
+            f.write("%s\t%s\t%.5f\t%.2f\t%.4f\n" % r)
+    return rows
+
+
+def test_tf_binding_device_table(eng, tmp_path):
+    from flexs_amd.landscapes import TFBinding
+
+    rng = np.random.default_rng(0)
+    rows = _write_tf_file(tmp_path / "X_8mers.txt", rng)
+    land = TFBinding(str(tmp_path / "X_8mers.txt"))
+    assert land.name == "TF_Binding" and land.cost == 0
+    e = np.array([float("%.5f" % r[2]) for r in rows])
+    norm = (e - e.min()) / (e.max() - e.min())                       # tf_binding.py:33-34
+    want = {}
+    want.update({r[0]: v for r, v in zip(rows, norm)})
+    want.update({r[1]: v for r, v in zip(rows, norm)})
+    keys = list(want)
+    got = land.get_fitness(keys)
+    assert got.dtype == np.float64 and land.cost == len(keys)
+    assert np.array_equal(got, np.array([want[k] for k in keys]))
+    assert np.array_equal(land.get_fitness(np.array(keys[:7])), got[:7])
+    missing = next(s for s in ("".join("ACGT"[(i >> (2 * k)) & 3] for k in range(8)) for i in range(65536)) if s not in want)
+    with pytest.raises(KeyError):
+        land.get_fitness([keys[0], missing])
+    with pytest.raises(KeyError):
+        land.get_fitness(["ACGTACGX"])
+    with pytest.raises(KeyError):
+        land.get_fitness(["ACG"])
+    reg = flexs_amd.landscapes.tf_binding.registry(str(tmp_path))
+    assert list(reg) == ["X"] and len(reg["X"]["starts"]) == 14 and reg["X"]["params"]["landscape_file"].endswith("X_8mers.txt")
+
+
+def test_nam_batched_landscape_path_is_identical(eng, tmp_path):
+    """A `batch_safe` table landscape is queried in two batches instead of 2*Q calls: values,
+    costs and RNG stream must not change (noisy_abstract_model.py:86-94)."""
+    from flexs_amd.landscapes import TFBinding
+
+    rng = np.random.default_rng(1)
+    rows = _write_tf_file(tmp_path / "Y_8mers.txt", rng, n_pairs=6000)
+    keys = [r[0] for r in rows] + [r[1] for r in rows]
+
+    class Plain(flexs_amd.Landscape):                 # same values, one-by-one path
+        def __init__(self, inner):
+            super().__init__("plain")
+            self.inner = inner
+
+        def _fitness_function(self, seqs):
+            return self.inner._fitness_function(seqs)
+
+    outs = []
+    for wrap in (False, True):
+        land = TFBinding(str(tmp_path / "Y_8mers.txt"))
+        target = Plain(land) if wrap else land
+        np.random.seed(5)
+        nam = bm.NoisyAbstractModel(target, 0.9)
+        nam.train(keys[:50], land._fitness_function(keys[:50]))
+        o = [nam.get_fitness(keys[50 + 200 * i: 250 + 200 * i]) for i in range(3)]
+        o.append(nam.get_fitness(keys[100:400]))
+        outs.append((np.concatenate(o), target.cost, float(np.random.random()), list(nam.cache)))
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1:] == outs[1][1:]
+
+
+def test_sequence_density(eng):
+    """dyna_ppo.py:106-114 through the distance-matrix kernel, bit-identical to the Python loop."""
+    from flexs_amd.utils.edit_distance import SeenSequences
+
+    rng = np.random.default_rng(2)
+    for L, alpha in ((14, "UGCA"), (70, s_utils.AAS)):
+        base = "".join(alpha[i] for i in rng.integers(0, len(alpha), L))
+        seen = SeenSequences(L)
+        ref = {}
+        for _ in range(400):
+            s = list(base)
+            for _ in range(int(rng.integers(0, 4))):
+                s[int(rng.integers(0, L))] = alpha[int(rng.integers(0, len(alpha)))]
+            if rng.random() < 0.3:
+                s = s[1:] + s[:1]
+            s, f = "".join(s), float(rng.random())
+            seen.add(s, f)
+            ref[s] = f
+        assert len(seen) == len(ref) and seen[base] == ref[base] if base in ref else True
+        for q in list(ref)[:25] + [base]:
+            dens = 0
+            for s in ref:
+                d = c_oracle.levenshtein(s, q)
+                if d != 0 and d <= 2:
+                    dens += ref[s] / d
+            assert seen.density(q) == dens
+    assert SeenSequences(5).density("ACGTA") == 0

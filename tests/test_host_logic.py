@@ -221,3 +221,19 @@ def test_dyna_ppo_ensemble_gating():
     default = bm.DynaPPOEnsemble(14, "UGCA")
     assert [m.name for m in default.models] == ["MLP_hidden_size_100", "MLP_hidden_size_200",
                                                 "CNN_hidden_size_100_num_filters_32"]
+
+
+def test_tf_binding_host_tables_match_reference(golden_dir):
+    """Host half of TFBinding (parse + normalise, tf_binding.py:31-41) against values captured from
+    the reference class; needs the reference's data file, so it only runs in the build container."""
+    path = "/root/reference/flexs/landscapes/data/tf_binding/SIX6_REF_R1_8mers.txt"
+    if not os.path.exists(path):
+        pytest.skip("reference data files are not available on this machine")
+    from flexs_amd.landscapes import TFBinding
+
+    fx = json.load(open(os.path.join(golden_dir, "tf_binding.json")))
+    land = TFBinding(path)
+    assert land.name == fx["name"] and len(land.sequences) == 65536
+    assert [land.sequences[s] for s in fx["sample_sequences"]] == fx["sample_values"]
+    assert land.sequences["ATTATGTT"] == fx["tutorial_known_answer"]["value"]
+    assert getattr(land, "batch_safe") is True
