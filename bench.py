@@ -95,31 +95,45 @@ def main():
     with torch.cuda.stream(stream):
         eng.set_stream(stream.cuda_stream)
         d_ascii = torch.from_numpy(seq_bytes).cuda()
-        d_nm = torch.empty((N, M), dtype=torch.float32, device="cuda")
-        d_mean = torch.empty((N,), dtype=torch.float32, device="cuda")
-        d_all = torch.empty((world * N,), dtype=torch.float32, device="cuda") if use_dist else None
+        # two buffer sets: the all-gather of step k runs on RCCL's stream while step k+1 computes
+        d_nm = [torch.empty((N, M), dtype=torch.float32, device="cuda") for _ in range(2)]
+        d_mean = [torch.empty((N,), dtype=torch.float32, device="cuda") for _ in range(2)]
+        d_all = [torch.empty((world * N,), dtype=torch.float32, device="cuda") for _ in range(2)] if use_dist else None
+        pending = [None, None]
         ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
         ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
-        def step(k=None):
+        def step(i, k=None):
+            b = i & 1
+            if pending[b] is not None:
+                pending[b].wait()                        # buffer set b is free again (stream-side wait, no host sync)
+                pending[b] = None
             if k is not None:
                 ev_a[k].record(stream)
-            eng.score_dev(models, d_ascii.data_ptr(), N, L, lut, d_nm.data_ptr(), None)      # K1 fused encode+CNN x3
+            eng.score_dev(models, d_ascii.data_ptr(), N, L, lut, d_nm[b].data_ptr(), None)   # K1 fused encode+CNN x3
             if k is not None:
                 ev_b[k].record(stream)
-            eng.ensemble_reduce_dev(d_nm.data_ptr(), N, M, d_mean.data_ptr())               # K3 np.mean order
+            eng.ensemble_reduce_dev(d_nm[b].data_ptr(), N, M, d_mean[b].data_ptr())          # K3 np.mean order
             if use_dist:
-                dist.all_gather_into_tensor(d_all, d_mean)                                   # RCCL over xGMI
+                pending[b] = dist.all_gather_into_tensor(d_all[b], d_mean[b], async_op=True)  # RCCL over xGMI
 
-        for _ in range(args.warmup):
-            step()
+        def drain():
+            for b in (0, 1):
+                if pending[b] is not None:
+                    pending[b].wait()
+                    pending[b] = None
+
+        for i in range(args.warmup):
+            step(i)
+        drain()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(args.steps):
-            step(k)
+            step(k, k)
+        drain()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -127,10 +141,11 @@ def main():
         elapsed = time.perf_counter() - t0
         eng.sync()                                       # raises if any bad character was met
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_a, ev_b)]))
-        got_mean = d_mean.cpu().numpy()
-        got_nm = d_nm.cpu().numpy()
+        last = (args.steps - 1) & 1
+        got_mean = d_mean[last].cpu().numpy()
+        got_nm = d_nm[last].cpu().numpy()
         if use_dist:
-            gathered = d_all.cpu().numpy()
+            gathered = d_all[last].cpu().numpy()
             assert np.array_equal(gathered[rank * N:(rank + 1) * N], got_mean), "all-gather lost this rank's shard"
         eng.set_stream(None)
 
@@ -160,7 +175,7 @@ def main():
             "config": {"workload": f"TF-binding L={L} alphabet={ALPHABET}, {M}-member CNN(num_filters={F}, "
                                    f"hidden_size={H}, kernel_size={K}) Ensemble, batch={N} virtual-screen per GPU "
                                    "(BASELINE.json configs[1]); inputs resident in HBM; step = fused encode+CNN "
-                                   "scoring kernel + ensemble-mean kernel" + (" + one RCCL all-gather" if use_dist else ""),
+                                   "scoring kernel + ensemble-mean kernel" + (" + one RCCL all-gather of the per-rank means (async, overlapped with the next step's compute)" if use_dist else ""),
                        "global_batch": world * N, "seq_len": L, "members": M,
                        "parallelism": f"sequence-parallel x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": "k_score_cnn_mfma", "achieved": achieved, "peak": peak,

@@ -160,7 +160,7 @@ def sequences_to_bytes(sequences, L: Optional[int] = None) -> np.ndarray:
             return np.zeros((0, L or 0), np.uint8)
         w = len(seqs[0])
         joined = "".join(seqs)
-        if len(joined) != N * w or any(len(s) != w for s in seqs):
+        if len(joined) != N * w or set(map(len, seqs)) != {w}:
             raise ValueError("ragged sequence batch: all sequences must have the same length")
         try:
             raw = joined.encode("latin-1")
