@@ -75,6 +75,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        # the exchanged messages are 4*N bytes per rank (0.4 MB): latency-bound.  Keep RCCL to a couple of
+        # channels so its (overlapped) kernel does not take CUs away from the MFMA-bound scoring kernel.
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "2")
+        os.environ.setdefault("NCCL_MIN_NCHANNELS", "1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     N = args.batch
