@@ -75,6 +75,7 @@ struct fx_engine {
     int64_t cnn_variant = 0;    // 0 = auto
     int64_t grid_blocks = 0;    // 0 = auto (one per CU)
     int64_t cnn_conv1_mfma = 0; // 1 = one-hot conv1 on MFMA instead of the LDS gather (A/B knob)
+    int64_t cnn_pair = 1;       // 1 = wide alphabets (A = 20) use the two-waves-per-tile kernel (score_cnn_pair.hip)
     int64_t mlp_l1_mfma = 0;    // 1 = one-hot MLP layer 1 on MFMA instead of the LDS gather (A/B knob)
     int num_cus = 256;
     int max_lds = 160 * 1024;
@@ -131,6 +132,8 @@ int fx_launch_score_generic(fx_engine* e, fx_model* const* models, int M, const 
                             int64_t N, float* d_out_NM, int Mtot, int m_off);
 // returns FX_EUNSUPPORTED if no MFMA instantiation matches (caller falls back to generic)
 int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii,
+                             int64_t N, float* d_out_NM, int Mtot, int m_off);
+int fx_launch_score_cnn_pair(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii,
                              int64_t N, float* d_out_NM, int Mtot, int m_off);
 int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii,
                                int64_t N, float* d_out_NM, int Mtot, int m_off);

@@ -332,6 +332,10 @@ int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const
             default: return fx_fail(e, FX_EINVAL, "cnn_variant must be 0..4");
         }
     } else {
+        if (e->cnn_pair) {
+            const int rc = fx_launch_score_cnn_pair(e, models, M, d_ascii, N, d_out_NM, Mtot, m_off);
+            if (rc != FX_EUNSUPPORTED) return rc;
+        }
         if (conv_only > (size_t)e->max_lds) return FX_EUNSUPPORTED;
         a.TG = (N + 15) / 16;
         return launch_inst<20, 5, 2, 7, 1, false, 4>(e, a, conv_only);   // 1 wave / SIMD: 512-VGPR budget for the 19-tap window

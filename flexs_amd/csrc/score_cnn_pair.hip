@@ -1,0 +1,252 @@
+// K1 (wide-alphabet form) score_cnn_pair: the fused CNN scorer for large conv3 kernels
+// (protein alphabets: conv3 has A-1 = 19 taps, cnn.py:41-47).
+//
+// With 19 taps the register-resident sliding window of score_cnn_mfma.hip needs ~380
+// registers -> one wave per SIMD.  Here TWO waves share a tile of 16 sequences and split the
+// 32 filters: wave `mo` owns output-channel tile `mo` of conv2 and conv3.
+//   conv1  one-hot conv as an LDS row gather (both waves, it is VALU/LDS only)
+//   conv2  gather form, own output tile; the two halves of out2[t] are swapped through a
+//          1 KiB LDS slot per wave (double-buffered by step parity, one barrier per step)
+//   conv3  SCATTER form: out2[t] is multiplied by every tap and accumulated into a window
+//          of A-1 partial output sums (own tile only: (A-1) x 4 registers); the oldest
+//          slot is complete after each step and folds into the running global max.
+//          Every tap hits a different accumulator -> no dependent-MFMA stalls.
+// ~170 registers per wave -> 2+ waves per SIMD.  MFMA work is identical to the single-wave
+// form (no recomputation); tiles are dealt round-robin so that all waves of a block take the
+// same number of barriers.  Dense head: wave 0 of the pair (negligible next to the convs).
+#include "fx_common.h"
+#include "mfma_common.h"
+
+namespace {
+
+struct PairArgs {
+    const uint8_t* ascii;
+    const uint8_t* lut;
+    const float* w[FX_MAX_M];
+    float* out;
+    unsigned* err;
+    int64_t N, TG;
+    int M, Mtot, m_off;
+    int L, rlh;
+    int off_c2, off_c3, off_cb, off_w1p, conv_floats, off_d1, off_d2, off_db;
+    int lds_from, lds_floats;   // LDS image = packed[lds_from .. lds_from + lds_floats): conv2, conv3, biases, conv1 rows
+};
+
+template <int A, int K, int HT, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
+    constexpr int FT = 2, K3 = A - 1, PAIRS = WAVES / 2;
+    constexpr int PL2 = (K - 1) / 2, PR2 = K - 1 - PL2;
+    constexpr int PL3 = (K3 - 1) / 2, PR3 = K3 - 1 - PL3;
+    constexpr int TAPG = 4;                               // conv3 taps whose weights are in flight together
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pair = wave >> 1, mo = wave & 1;
+    const int g = lane >> 4, sq = lane & 15;
+    const int L = p.L, L1 = L - K + 1;
+    f4* xbuf = reinterpret_cast<f4*>(smem + p.lds_floats);             // [3: parity 0, parity 1, pooled][PAIRS][2 tiles][64 lanes]
+    uint8_t* lut_s = reinterpret_cast<uint8_t*>(smem + p.lds_floats + 3 * PAIRS * 2 * 64 * 4);
+
+    for (int i = tid; i < 64; i += blockDim.x)
+        reinterpret_cast<uint32_t*>(lut_s)[i] = reinterpret_cast<const uint32_t*>(p.lut)[i];
+
+    const int64_t U = (int64_t)p.M * p.TG;
+    const int64_t u_lo = U * blockIdx.x / gridDim.x, u_hi = U * (blockIdx.x + 1) / gridDim.x;
+    if (u_lo >= u_hi) return;
+    const int m_first = (int)(u_lo / p.TG), m_last = (int)((u_hi - 1) / p.TG);
+    bool bad = false;
+
+    for (int m = m_first; m <= m_last; ++m) {
+        __syncthreads();
+        {
+            const f4* src = reinterpret_cast<const f4*>(p.w[m] + p.lds_from);
+            f4* dst = reinterpret_cast<f4*>(smem);
+            for (int i = tid; i < p.lds_floats / 4; i += blockDim.x) dst[i] = src[i];
+        }
+        __syncthreads();
+        const f4* w_c2 = reinterpret_cast<const f4*>(smem + (p.off_c2 - p.lds_from));
+        const f4* w_c3 = reinterpret_cast<const f4*>(smem + (p.off_c3 - p.lds_from));
+        const float* cb = smem + (p.off_cb - p.lds_from);
+        const float* w1p = smem + (p.off_w1p - p.lds_from);
+        const f4* w_d1 = reinterpret_cast<const f4*>(p.w[m] + p.off_d1);   // dense head streams from L2
+        const f4* w_d2 = reinterpret_cast<const f4*>(p.w[m] + p.off_d2);
+        const float* db = p.w[m] + p.off_db;
+
+        const int64_t t_lo = (u_lo > (int64_t)m * p.TG ? u_lo : (int64_t)m * p.TG) - (int64_t)m * p.TG;
+        const int64_t t_hi = (u_hi < (int64_t)(m + 1) * p.TG ? u_hi : (int64_t)(m + 1) * p.TG) - (int64_t)m * p.TG;
+        const int iters = (int)((t_hi - t_lo + PAIRS - 1) / PAIRS);
+
+        for (int it = 0; it < iters; ++it) {
+            const int64_t tg = t_lo + (int64_t)it * PAIRS + pair;
+            const bool live = tg < t_hi;                 // idle pairs run along (barriers) on sequence 0
+            const int64_t n = tg * 16 + sq;
+            const uint8_t* row = p.ascii + ((live && n < p.N) ? n : 0) * L;
+
+            int cw[K];
+#pragma unroll
+            for (int j = 0; j < K - 1; ++j) {
+                int c = lut_s[row[j]];
+                if (c == 0xFF) { bad |= live; c = 0; }
+                cw[j + 1] = c;
+            }
+            f4 win1[K][FT], accw[K3], gmax = splat4(0.f);
+            const f4 bias3 = *reinterpret_cast<const f4*>(&cb[32 * FT + 16 * mo + 4 * g]);
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+#pragma unroll
+                for (int t = 0; t < FT; ++t) win1[j][t] = splat4(0.f);
+#pragma unroll
+            for (int j = 0; j < K3; ++j) accw[j] = bias3;
+
+            const int steps = L1 + PR2 + PR3;
+            for (int s = 0; s < steps; ++s) {
+                asm volatile("" ::: "memory");           // keep the LDS weight reads inside the position loop
+#pragma unroll
+                for (int j = 0; j < K - 1; ++j) {
+                    cw[j] = cw[j + 1];
+#pragma unroll
+                    for (int t = 0; t < FT; ++t) win1[j][t] = win1[j + 1][t];
+                }
+                // ---- conv1 (valid) at t1 = s: gather of K kernel rows, both channel tiles
+                if (s < L1) {
+                    int c = lut_s[row[s + K - 1]];
+                    if (c == 0xFF) { bad |= live; c = 0; }
+                    cw[K - 1] = c;
+                    f4 o1[FT];
+#pragma unroll
+                    for (int t = 0; t < FT; ++t) o1[t] = *reinterpret_cast<const f4*>(&cb[16 * t + 4 * g]);
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        const float* rowp = w1p + (j * A + cw[j]) * (16 * FT) + 4 * g;
+#pragma unroll
+                        for (int t = 0; t < FT; ++t) o1[t] += *reinterpret_cast<const f4*>(rowp + 16 * t);
+                    }
+#pragma unroll
+                    for (int t = 0; t < FT; ++t) win1[K - 1][t] = relu4(o1[t]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < FT; ++t) win1[K - 1][t] = splat4(0.f);
+                }
+
+                // ---- conv2 (same) at t2 = s - PR2, own output tile; two partial chains (one per input tile)
+                const int t2 = s - PR2;
+                if (t2 >= 0 && t2 < L1) {
+                    f4 o2a = *reinterpret_cast<const f4*>(&cb[16 * FT + 16 * mo + 4 * g]);
+                    f4 o2b = splat4(0.f);
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        // out-of-range taps read the zeros the window holds there
+                        const f4 a0 = w_c2[((j * FT + 0) * FT + mo) * 64 + lane];
+                        const f4 a1 = w_c2[((j * FT + 1) * FT + mo) * 64 + lane];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            o2a = mfma16(a0[r], win1[j][0][r], o2a);
+                            o2b = mfma16(a1[r], win1[j][1][r], o2b);
+                        }
+                    }
+                    const f4 mine = relu4(o2a + o2b);
+                    // ---- swap halves with the partner wave (slot per parity: one barrier per step)
+                    f4* slot = xbuf + (((s & 1) * PAIRS + pair) * 2) * 64;
+                    slot[mo * 64 + lane] = mine;
+                    __syncthreads();
+                    const f4 theirs = slot[(1 - mo) * 64 + lane];
+                    f4 out2[FT];                          // (no runtime-indexed register arrays: they go to scratch)
+                    out2[0] = mo == 0 ? mine : theirs;
+                    out2[1] = mo == 0 ? theirs : mine;
+
+                    // ---- conv3 (same, A-1 taps), scatter form: tap j feeds output position t2 - j + PL3,
+                    //      which lives in window slot K3-1-j (slot i <-> position t2 - PR3 + i)
+#pragma unroll
+                    for (int j0 = 0; j0 < K3; j0 += TAPG) {
+                        // fence the weight reads of each tap group: without it the scheduler hoists all
+                        // 2*(A-1) blocks ahead of the MFMAs and spills ~100 registers
+                        asm volatile("" ::: "memory");
+                        f4 a[TAPG][FT];
+#pragma unroll
+                        for (int jj = 0; jj < TAPG; ++jj)
+#pragma unroll
+                            for (int mi = 0; mi < FT; ++mi)
+                                if (j0 + jj < K3) a[jj][mi] = w_c3[(((j0 + jj) * FT + mi) * FT + mo) * 64 + lane];
+#pragma unroll
+                        for (int mi = 0; mi < FT; ++mi)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                                for (int jj = 0; jj < TAPG; ++jj) {
+                                    const int j = j0 + jj;
+                                    // (slots whose position falls outside [0, L1) are simply never pooled:
+                                    //  no per-tap branch -> straight-line MFMA stream)
+                                    if (j < K3) accw[K3 - 1 - j] = mfma16(a[jj][mi][r], out2[mi][r], accw[K3 - 1 - j]);
+                                }
+                    }
+                }
+                // ---- slot 0 (position t2 - PR3) is complete: GlobalMaxPooling1D of relu(conv3), then slide
+                const int t3f = t2 - PR3;
+                if (t3f >= 0 && t3f < L1) gmax = max4(gmax, accw[0]);
+#pragma unroll
+                for (int j = 0; j < K3 - 1; ++j) accw[j] = accw[j + 1];
+                accw[K3 - 1] = bias3;
+            }
+
+            // ---- pooled features: swap halves once more, then wave 0 of the pair runs the dense head
+            f4* slot = xbuf + ((2 * PAIRS + pair) * 2) * 64;      // dedicated slot: no reuse hazard with the step slots
+            slot[mo * 64 + lane] = gmax;
+            __syncthreads();
+            if (mo == 0) {
+                f4 pooled[FT][1];
+                pooled[0][0] = gmax;
+                pooled[1][0] = slot[64 + lane];           // (rewritten only after the next tile's ~L barriers)
+                f4 h1[HT][1], h2[HT][1];
+                init_bias<HT, 1>(db, h1, g);
+                mma_layer<FT, HT, 1>(w_d1, pooled, h1, lane);
+                relu_tiles<HT, 1>(h1);
+                init_bias<HT, 1>(db + 16 * HT, h2, g);
+                mma_layer<HT, HT, 1>(w_d2, h1, h2, lane, p.rlh);
+                relu_tiles<HT, 1>(h2);
+                float y[1];
+                final_dot<HT, 1>(db + 32 * HT, db[48 * HT], h2, y, g);
+                if (g == 0 && live && n < p.N) p.out[n * p.Mtot + p.m_off + m] = fx_nan_to_num(y[0]);
+            }
+        }
+    }
+    if (bad) fx_raise(p.err, FX_ERR_BADCHAR);
+}
+
+template <int A, int K, int HT, int WAVES>
+int launch_pair(fx_engine* e, const PairArgs& a, size_t lds_bytes) {
+    auto kern = k_score_cnn_pair<A, K, HT, WAVES>;
+    static bool attr_set[64] = {};
+    if (!attr_set[e->device & 63]) {
+        FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[e->device & 63] = true;
+    }
+    const int64_t U = (int64_t)a.M * a.TG;
+    int64_t blocks = e->grid_blocks > 0 ? e->grid_blocks : e->num_cus;
+    const int64_t need = (U + WAVES / 2 - 1) / (WAVES / 2);
+    if (blocks > need) blocks = need;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), lds_bytes, e->stream, a);
+    FX_HIP(e, hipGetLastError());
+    return FX_OK;
+}
+
+}  // namespace
+
+int fx_launch_score_cnn_pair(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N,
+                             float* d_out_NM, int Mtot, int m_off) {
+    if (N == 0) return FX_OK;
+    const FxShape& s = models[0]->shape;
+    const FxPackLayout& lay = models[0]->layout;
+    if (s.F != 32 || s.K != 5 || lay.HT != 7 || s.A != 20 || M > FX_MAX_M) return FX_EUNSUPPORTED;
+    constexpr int WAVES = 8;
+    const size_t lds = (size_t)(lay.conv_floats - lay.off_c2) * 4 + (size_t)3 * (WAVES / 2) * 2 * 64 * 16 + 256 + 16;
+    if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
+    PairArgs a{};
+    a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
+    for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
+    a.N = N; a.TG = (N + 15) / 16; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.rlh = lay.RLH;
+    a.off_c2 = (int)lay.off_c2; a.off_c3 = (int)lay.off_c3; a.off_cb = (int)lay.off_cb; a.off_w1p = (int)lay.off_w1p;
+    a.conv_floats = (int)lay.conv_floats; a.lds_from = (int)lay.off_c2; a.lds_floats = (int)(lay.conv_floats - lay.off_c2); a.off_d1 = (int)lay.off_d1; a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db;
+    return launch_pair<20, 5, 7, WAVES>(e, a, lds);
+}

@@ -180,3 +180,71 @@ def ge_tile(packed, lay, codes16, A, H):
     h2 = [np.maximum(x, 0) for x in mma_layer(packed, lay["off_d3"], HT, HT, h, h2, lay["RLH"])]
     y = final_dot(packed, db + 4 + 48 * HT, packed[db + 4 + 64 * HT], h2, HT)
     return y[:16]
+
+
+def cnn_pair_tile(packed, lay, codes16, A, K, F, H):
+    """score_cnn_pair.hip: two waves per tile, wave `mo` owns output-channel tile `mo` of conv2 /
+    conv3; conv3 in scatter form with a window of A-1 partial sums; halves swapped through LDS."""
+    packed = packed.astype(np.float64)
+    L = codes16.shape[1]
+    L1 = L - K + 1
+    K3 = A - 1
+    FT, HT = lay["FT"], lay["HT"]
+    assert FT == 2
+    PL2 = (K - 1) // 2
+    PR2 = K - 1 - PL2
+    PL3 = (K3 - 1) // 2
+    PR3 = K3 - 1 - PL3
+    code = codes16[SQ].astype(np.int64)
+    cb = lay["off_cb"]
+
+    def bias_tile(off, mo):
+        return np.stack([packed[off + 16 * mo + 4 * G + r] for r in range(4)], axis=1)
+
+    # per-wave state (index = mo)
+    win1 = [[[np.zeros((64, 4)) for _ in range(FT)] for _ in range(K)] for _ in range(2)]
+    accw = [[bias_tile(cb + 32 * FT, mo) for _ in range(K3)] for mo in range(2)]
+    gmax = [np.zeros((64, 4)) for _ in range(2)]
+    for s in range(L1 + PR2 + PR3):
+        t2 = s - PR2
+        mine = [None, None]
+        for mo in range(2):
+            win1[mo] = win1[mo][1:] + [None]
+            if s < L1:
+                o1 = [bias_tile(cb, t) for t in range(FT)]
+                for j in range(K):
+                    rowp = lay["off_w1p"] + (j * A + code[:, s + j]) * (16 * FT) + 4 * G
+                    for t in range(FT):
+                        o1[t] = o1[t] + np.stack([packed[rowp + 16 * t + r] for r in range(4)], axis=1)
+                win1[mo][K - 1] = [np.maximum(x, 0) for x in o1]
+            else:
+                win1[mo][K - 1] = [np.zeros((64, 4)) for _ in range(FT)]
+            if 0 <= t2 < L1:
+                o2a = bias_tile(cb + 16 * FT, mo)
+                o2b = np.zeros((64, 4))
+                for j in range(K):
+                    a0 = blocks(packed, lay["off_c2"], (j * FT + 0) * FT + mo)
+                    a1 = blocks(packed, lay["off_c2"], (j * FT + 1) * FT + mo)
+                    for r in range(4):
+                        o2a = mfma16(a0[:, r], win1[mo][j][0][:, r], o2a)
+                        o2b = mfma16(a1[:, r], win1[mo][j][1][:, r], o2b)
+                mine[mo] = np.maximum(o2a + o2b, 0)
+        for mo in range(2):
+            if 0 <= t2 < L1:
+                out2 = [mine[0], mine[1]]                # after the LDS swap both waves hold both halves
+                for j in range(K3):
+                    for mi in range(FT):
+                        a = blocks(packed, lay["off_c3"], (j * FT + mi) * FT + mo)
+                        for r in range(4):
+                            accw[mo][K3 - 1 - j] = mfma16(a[:, r], out2[mi][:, r], accw[mo][K3 - 1 - j])
+            t3f = t2 - PR3
+            if 0 <= t3f < L1:
+                gmax[mo] = np.maximum(gmax[mo], accw[mo][0])
+            accw[mo] = accw[mo][1:] + [bias_tile(cb + 32 * FT, mo)]
+    db = lay["off_db"]
+    pooled = [gmax[0], gmax[1]]
+    h1 = init_bias(packed, db, HT)
+    h1 = [np.maximum(x, 0) for x in mma_layer(packed, lay["off_d1"], FT, HT, pooled, h1)]
+    h2 = init_bias(packed, db + 16 * HT, HT)
+    h2 = [np.maximum(x, 0) for x in mma_layer(packed, lay["off_d2"], HT, HT, h1, h2, lay["RLH"])]
+    return final_dot(packed, db + 32 * HT, packed[db + 48 * HT], h2, HT)[:16]

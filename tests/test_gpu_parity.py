@@ -43,6 +43,7 @@ def eng():
     e.set_option("cnn_variant", 0)
     e.set_option("cnn_conv1_mfma", 0)
     e.set_option("mlp_l1_mfma", 0)
+    e.set_option("cnn_pair", 1)
 
 
 def rand_seqs(n, L, alphabet, seed):
@@ -102,7 +103,7 @@ def test_cnn_l8_variants_and_tails(eng, variant, n, conv1_mfma):
 @pytest.mark.parametrize("L,A,alpha,n", [(8, 4, "TGCA", 3000), (5, 4, "TGCA", 500), (6, 4, "TGCA", 500),
                                          (14, 4, "UGCA", 2000), (50, 4, "UGCA", 600), (100, 4, "UGCA", 300),
                                          (20, 20, s_utils.AAS, 400), (66, 20, s_utils.AAS, 200),
-                                         (90, 20, s_utils.AAS, 150)])
+                                         (90, 20, s_utils.AAS, 150), (5, 20, s_utils.AAS, 1000), (23, 20, s_utils.AAS, 4097)])
 def test_cnn_mfma_vs_oracle(eng, L, A, alpha, n):
     eng.set_option("force_generic", 0)
     nm, w = make_native(eng, "cnn", L, A, 100, 32, 5, seed=7)
@@ -110,9 +111,16 @@ def test_cnn_mfma_vs_oracle(eng, L, A, alpha, n):
     got, _ = eng.score([nm], b, _native.make_lut(alpha))
     want = ref_np.keras_fitness(seqs, alpha, "cnn", w, exact=True)
     assert_scores(got[:, 0], want, f"cnn mfma L={L} A={A}")
+    if A == 20:                                          # single-wave-per-tile form of the wide-alphabet kernel
+        eng.set_option("cnn_pair", 0)
+        got_s, _ = eng.score([nm], b, _native.make_lut(alpha))
+        eng.set_option("cnn_pair", 1)
+        assert_scores(got_s[:, 0], want, f"cnn single-wave form L={L} A={A}")
     eng.set_option("cnn_conv1_mfma", 1)                  # one-hot conv1 on the MFMA pipe instead of the LDS gather
+    eng.set_option("cnn_pair", 0)
     got_m, _ = eng.score([nm], b, _native.make_lut(alpha))
     eng.set_option("cnn_conv1_mfma", 0)
+    eng.set_option("cnn_pair", 1)
     assert_scores(got_m[:, 0], want, f"cnn mfma(conv1 on mfma) L={L} A={A}")
     # the shape-agnostic kernel must agree too (independent on-device implementation)
     eng.set_option("force_generic", 1)

@@ -31,6 +31,20 @@ def test_cnn_dataflow_matches_oracle(L, A, alpha):
         assert np.abs(got - want).max() < 1e-12
 
 
+@pytest.mark.parametrize("L,A,alpha", [(27, 20, ref_np.AAS), (5, 20, ref_np.AAS), (12, 4, "TGCA"), (40, 20, ref_np.AAS)])
+def test_cnn_pair_dataflow_matches_oracle(L, A, alpha):
+    """Two-waves-per-tile form (score_cnn_pair.hip): scatter-form conv3 window + LDS swap of the halves."""
+    K, F, H = 5, 32, 100
+    rng = np.random.default_rng(L + A)
+    w = ref_np.synth_weights(ref_np.cnn_shapes(L, A, F, H, K), 77)
+    packed = _native.debug_pack_weights(_native.FX_CNN, L, A, F, H, K, w)
+    lay = _native.debug_pack_layout(_native.FX_CNN, L, A, F, H, K)
+    codes = rng.integers(0, A, (16, L)).astype(np.uint8)
+    seqs = ["".join(alpha[c] for c in r) for r in codes]
+    want = ref_np.keras_fitness(seqs, alpha, "cnn", w, exact=True)
+    assert np.abs(mfma_sim.cnn_pair_tile(packed, lay, codes, A, K, F, H) - want).max() < 1e-12
+
+
 @pytest.mark.parametrize("L,A,alpha,H", [(14, 4, "UGCA", 100), (8, 4, "TGCA", 100), (9, 20, ref_np.AAS, 100),
                                          (14, 4, "UGCA", 97), (14, 4, "UGCA", 104), (14, 4, "UGCA", 107), (14, 4, "UGCA", 112)])
 def test_mlp_ge_dataflow_matches_oracle(L, A, alpha, H):

@@ -59,7 +59,7 @@ def time_score(kind, L, alpha, H, M, N, F=0, K=0, reps=20, generic=False, varian
     eng.set_option("force_generic", 0)
     eng.set_option("cnn_variant", 0)
     for k_ in (opts or {}):
-        eng.set_option(k_, 0)
+        eng.set_option(k_, 1 if k_ == "cnn_pair" else 0)
     macs = synth.algorithmic_macs(kind, L, A, H, F, K)
     tf = 2.0 * macs * M * N / (ms * 1e-3) / 1e12
     gbs = (L + 4 * M) * N / (ms * 1e-3) / 1e9
@@ -193,7 +193,8 @@ def main():
         time_score("mlp", 14, "UGCA", 100, 1, 100_000, label="C3 mlp L=14 H=100 M=1 N=1e5 l1=gather")
         time_score("mlp", 14, "UGCA", 100, 1, 100_000, label="C3 mlp L=14 H=100 M=1 N=1e5 l1=mfma", opts={"mlp_l1_mfma": 1})
         time_score("mlp", 90, AAS, 100, 1, 100_000, reps=5, label="mlp L=90 A=20 H=100 M=1 N=1e5 (layer-1 rows gathered from L2)")
-        time_score("cnn", 237, AAS, 100, 1, 16_384, 32, 5, reps=2, label="C5 cnn L=237 A=20 M=1 N=16384 conv1=mfma", opts={"cnn_conv1_mfma": 1})
+        time_score("cnn", 237, AAS, 100, 1, 16_384, 32, 5, reps=2, label="C5 cnn L=237 A=20 M=1 N=16384 single-wave form", opts={"cnn_pair": 0})
+        time_score("cnn", 237, AAS, 100, 3, 65_536, 32, 5, reps=1, label="C5 cnn L=237 A=20 M=3 N=65536 (pair form)")
         time_score("mlp", 14, "UGCA", 100, 1, 1_000_000, reps=5)
         time_score("mlp", 14, "UGCA", 100, 1, 100_000, reps=2, generic=True)
         time_score("ge", 90, AAS, 100, 8, 100_000, label="C4 ge L=90 A=20 H=100 M=8 N=1e5")
