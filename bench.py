@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="cnn kernel variant (0 = auto)")
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--reserve-cus", type=int, default=4, help="CUs left free for RCCL when running distributed")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the all-gather even with one rank (exercises the N>1 code path)")
     args = ap.parse_args()
@@ -85,6 +86,10 @@ def main():
     eng = _native.Engine.get(local_rank)
     if args.variant:
         eng.set_option("cnn_variant", args.variant)
+    if use_dist and args.reserve_cus > 0:
+        # K1 is a persistent one-workgroup-per-CU kernel: leave a few CUs to RCCL's channel workgroups so the
+        # (asynchronous) all-gather of step k really runs next to step k+1 instead of queueing behind it
+        eng.set_option("grid_blocks", max(1, eng.get_option("num_cus") - args.reserve_cus))
     stream = torch.cuda.Stream()
     lut = _native.make_lut(ALPHABET)
     arch = Architecture("cnn", L, len(ALPHABET), H, num_filters=F, kernel_size=K)

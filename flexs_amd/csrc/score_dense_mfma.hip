@@ -220,12 +220,15 @@ int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, con
     }
     if (s.kind != FX_MLP && s.kind != FX_GE) return FX_EUNSUPPORTED;
     if (lay.HT != 7 || M > FX_MAX_M) return FX_EUNSUPPORTED;
-    size_t lds = (size_t)lay.total_floats * 4 + 256 + 16;
+    // LDS image = packed[lds_from ..): GE and the MFMA first-layer form need everything; the gather form of the
+    // MLP skips the (unused) first-layer MFMA blocks; a first layer too big for LDS stays in L2 altogether.
+    int64_t lds_from = (s.kind == FX_MLP && !e->mlp_l1_mfma) ? lay.off_w1p : 0;
+    size_t lds = (size_t)(lay.total_floats - lds_from) * 4 + 256 + 16;
     bool w1_global = false;
     if (lds > (size_t)e->max_lds) {
-        // MLP with a large L*A: keep only the HxH blocks + vectors in LDS, gather layer-1 rows from L2
         if (s.kind != FX_MLP) return FX_EUNSUPPORTED;
-        lds = (size_t)(lay.total_floats - lay.off_d2) * 4 + 256 + 16;
+        lds_from = lay.off_d2;
+        lds = (size_t)(lay.total_floats - lds_from) * 4 + 256 + 16;
         if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
         w1_global = true;
     }
@@ -237,7 +240,7 @@ int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, con
     a.SG1 = lay.SG1; a.off_first = (int)lay.off_first; a.off_w1p = (int)lay.off_w1p; a.off_d2 = (int)lay.off_d2; a.off_d3 = (int)lay.off_d3;
     a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
     a.TG = (N + 15) / 16;
-    a.lds_from = w1_global ? (int)lay.off_d2 : 0;
+    a.lds_from = (int)lds_from;
     a.lds_floats = (int)lay.total_floats - a.lds_from;
     if (s.kind == FX_MLP) {
         if (w1_global) return launch_inst<FX_MLP, 4, 7, 1, 16, true, true>(e, a, lds);   // gather form: A is a runtime stride
