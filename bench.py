@@ -53,7 +53,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="cnn kernel variant (0 = auto)")
     ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--reserve-cus", type=int, default=4, help="CUs left free for RCCL when running distributed")
+    ap.add_argument("--reserve-cus", type=int, default=0,
+                    help="CUs left free for RCCL when running distributed (measured: no benefit, profiles/r1_run6_rccl_overlap_probe.md)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the all-gather even with one rank (exercises the N>1 code path)")
     args = ap.parse_args()

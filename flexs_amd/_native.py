@@ -437,7 +437,7 @@ def debug_pack_layout(kind, L, A, F, H, K) -> dict:
     if rc != FX_OK:
         raise ValueError(status_name(rc))
     names = ["FT", "HT", "SG1", "off_first", "off_c2", "off_c3", "off_cb", "conv_floats", "off_d1", "off_d2",
-             "off_d3", "off_db", "RLH", "total_floats", "off_w1p"]
+             "off_d3", "off_db", "RLH", "total_floats", "off_w1p", "HTR"]
     return dict(zip(names, list(v)))
 
 

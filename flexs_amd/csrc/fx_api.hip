@@ -642,7 +642,7 @@ int fx_debug_pack_layout(int kind, int L, int A, int F, int H, int K, int64_t* o
     if (!out16) return FX_EINVAL;
     const FxPackLayout p = fx_pack_layout(FxShape{kind, L, A, F, H, K});
     const int64_t v[16] = {p.FT, p.HT, p.SG1, p.off_first, p.off_c2, p.off_c3, p.off_cb, p.conv_floats,
-                           p.off_d1, p.off_d2, p.off_d3, p.off_db, p.RLH, p.total_floats, p.off_w1p, 0};
+                           p.off_d1, p.off_d2, p.off_d3, p.off_db, p.RLH, p.total_floats, p.off_w1p, p.HTR};
     std::memcpy(out16, v, sizeof(v));
     return FX_OK;
 }

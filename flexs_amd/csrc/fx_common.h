@@ -27,7 +27,8 @@ struct FxShape {
 //   first-layer blocks (one-hot input; conv1 or MLP layer 1; step group sg):
 //       kin = 16*sg + 4*r + (lane >> 4)        (k-step s = 4*sg + r covers rows 4s .. 4s+3)
 struct FxPackLayout {
-    int FT, HT;                 // output tiles of 16: filters, hidden units
+    int FT, HT;                 // output tiles of 16: filters, hidden units (HT rounded up to an instantiated size)
+    int HTR;                    // hidden tiles that hold real units = ceil(H / 16) <= HT; the rest is zero padding
     int SG1;                    // first-layer step groups = ceil(rows / 16)
     int RLH;                    // k-steps that carry real channels in the LAST hidden tile (1..4), see fx_hidden_pos
     int64_t off_first;          // SG1 x (FT|HT) blocks

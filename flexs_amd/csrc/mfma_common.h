@@ -49,7 +49,8 @@ __device__ __forceinline__ float fx_nan_to_num(float v) {
 // 40-cycle dependent latency).
 // rl_last (wave-uniform, 1..4): number of k-steps of the LAST input tile that carry real
 // channels (hidden-unit tail laid out k-step-major by the packer, fx_hidden_pos); the
-// remaining k-steps would multiply zeros and are skipped.
+// remaining k-steps would multiply zeros and are skipped.  (Hidden sizes that were rounded up
+// to a larger instantiated tile count pass 4: their padding tiles are computed as zeros.)
 template <int TI, int TO, int NT, typename WPtr>
 __device__ __forceinline__ void mma_layer(WPtr wblk, const f4 (&in)[TI][NT], f4 (&acc)[TO][NT], int lane,
                                           int rl_last = 4) {

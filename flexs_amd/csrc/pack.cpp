@@ -31,9 +31,16 @@ int fx_hidden_pos(int h, int H) {
 FxPackLayout fx_pack_layout(const FxShape& s) {
     FxPackLayout p{};
     p.FT = (s.F + 15) / 16;
-    p.HT = (s.H + 15) / 16;
+    p.HTR = (s.H + 15) / 16;
+    p.HT = p.HTR;
     {
-        const int tail = s.H - 16 * (p.HT - 1);
+        // the MFMA kernels are instantiated for these tile counts; round up (extra tiles are zero padding
+        // that the kernels skip); beyond the largest one the layout stays exact and the generic kernels run
+        static const int sizes[] = {1, 2, 4, 7, 8, 13};
+        for (int v : sizes) if (v >= p.HTR) { p.HT = v; break; }
+    }
+    {
+        const int tail = s.H - 16 * (p.HTR - 1);
         p.RLH = tail >= 4 ? (tail + 3) / 4 : 1;          // unit i sits in k-step i / 4
         if (p.RLH > 4) p.RLH = 4;
     }

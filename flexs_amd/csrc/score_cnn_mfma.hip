@@ -28,7 +28,7 @@ struct CnnArgs {
     int64_t TG;                 // tile groups per member = ceil(N / (16*NT))
     int M, Mtot, m_off;
     int L;
-    int rlh;                    // k-steps carrying real channels in the last hidden tile
+    int rlh, htr;               // hidden tail: real k-steps of the last real tile, number of real hidden tiles
     // packed-layout offsets (floats)
     int off_first, off_c2, off_c3, off_cb, off_w1p, conv_floats, off_d1, off_d2, off_db, total_floats;
 };
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
         const float* dbase = DENSE_LDS ? smem : p.w[m];
         const f4* w_d1 = reinterpret_cast<const f4*>(dbase + p.off_d1);
         const f4* w_d2 = reinterpret_cast<const f4*>(dbase + p.off_d2);
-        const float* db = dbase + p.off_db;
+        const float* db = dbase + p.off_db;   // (not const-qualified pointers: laundered per tile below)
 
         const int64_t t_lo = (u_lo > (int64_t)m * p.TG ? u_lo : (int64_t)m * p.TG) - (int64_t)m * p.TG;
         const int64_t t_hi = (u_hi < (int64_t)(m + 1) * p.TG ? u_hi : (int64_t)(m + 1) * p.TG) - (int64_t)m * p.TG;
@@ -245,6 +245,11 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
 
             // ---- dense head: F -> H relu -> H relu -> (dropout inactive) -> 1
             asm volatile("" ::: "memory");
+            if (!DENSE_LDS) {
+                // weights streamed from L2: launder the base pointer per tile, otherwise LICM hoists the
+                // 64-bit address of every 1 KiB block out of the tile loop and spills them
+                asm volatile("" : "+v"(w_d1), "+v"(w_d2), "+v"(db));
+            }
             f4 h1[HT][NT], h2[HT][NT];
             init_bias<HT, NT>(db, h1, g);
             mma_layer<FT, HT, NT>(w_d1, gmax, h1, lane);
@@ -293,6 +298,39 @@ int launch_inst(fx_engine* e, const CnnArgs& a, size_t lds_bytes) {
 
 }  // namespace
 
+namespace {
+
+// A = 4 (DNA / RNA): NT1 tiles; 16 waves (4 per SIMD) once every CU has plenty of tiles, else 8.
+// Hidden sizes other than the canonical 7 tiles get the auto geometry only; HT >= 8 needs the
+// 256-register budget of 8-wave workgroups for the dense head.
+template <int HT_>
+int dispatch_a4(fx_engine* e, const CnnArgs& a0, int variant, bool big, size_t full, size_t conv_only) {
+    CnnArgs a = a0;
+    const bool dl = full <= (size_t)e->max_lds;          // whole member in LDS, else dense head streams from L2
+    const size_t lds = dl ? full : conv_only;
+    if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
+    if constexpr (HT_ == 7) {
+        if (dl && variant != 0) {
+            const int nt = (variant == 1 || variant == 4) ? 1 : 2;
+            a.TG = (a.N + 16 * nt - 1) / (16 * nt);
+            switch (variant) {
+                case 1: return launch_inst<4, 5, 2, 7, 1, true, 8>(e, a, lds);
+                case 2: return launch_inst<4, 5, 2, 7, 2, true, 4>(e, a, lds);
+                case 3: return launch_inst<4, 5, 2, 7, 2, true, 8>(e, a, lds);
+                case 4: return launch_inst<4, 5, 2, 7, 1, true, 16>(e, a, lds);
+                default: return fx_fail(e, FX_EINVAL, "cnn_variant must be 0..4");
+            }
+        }
+    }
+    a.TG = (a.N + 15) / 16;
+    if constexpr (HT_ <= 7) {
+        if (big) return dl ? launch_inst<4, 5, 2, HT_, 1, true, 16>(e, a, lds) : launch_inst<4, 5, 2, HT_, 1, false, 16>(e, a, lds);
+    }
+    return dl ? launch_inst<4, 5, 2, HT_, 1, true, 8>(e, a, lds) : launch_inst<4, 5, 2, HT_, 1, false, 8>(e, a, lds);
+}
+
+}  // namespace
+
 int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii,
                              int64_t N, float* d_out_NM, int Mtot, int m_off) {
     if (N == 0) return FX_OK;
@@ -303,41 +341,37 @@ int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const
         if (t.kind != FX_CNN || t.L != s.L || t.A != s.A || t.F != s.F || t.H != s.H || t.K != s.K)
             return FX_EUNSUPPORTED;                      // heterogeneous: caller scores them one by one
     }
-    if (s.F != 32 || s.K != 5 || lay.HT != 7 || (s.A != 4 && s.A != 20)) return FX_EUNSUPPORTED;
+    if (s.F != 32 || s.K != 5 || (s.A != 4 && s.A != 20)) return FX_EUNSUPPORTED;
     if (M > FX_MAX_M) return FX_EINVAL;
 
     CnnArgs a{};
     a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
     for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
-    a.N = N; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.rlh = lay.RLH;
+    a.N = N; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4; a.htr = lay.HTR;
     a.off_first = (int)lay.off_first; a.off_c2 = (int)lay.off_c2; a.off_c3 = (int)lay.off_c3;
     a.off_cb = (int)lay.off_cb; a.off_w1p = (int)lay.off_w1p; a.conv_floats = (int)lay.conv_floats; a.off_d1 = (int)lay.off_d1;
     a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
 
-    // variant: 1 = NT1 x 8 waves, 2 = NT2 x 4 waves, 3 = NT2 x 8 waves, 4 = NT1 x 16 waves (A = 4 only)
-    int variant = (int)e->cnn_variant;
     const size_t full = (size_t)lay.total_floats * 4 + 256 + 16, conv_only = (size_t)lay.conv_floats * 4 + 256 + 16;
     if (s.A == 4) {
-        if (full > (size_t)e->max_lds) return FX_EUNSUPPORTED;
-        // auto: 16 waves (4 per SIMD) measured best once every CU has plenty of tiles
-        // (profiles/r1_run3_*); small batches spread over more, smaller workgroups instead
-        if (variant == 0) variant = ((N + 15) / 16) * M >= (int64_t)e->num_cus * 32 ? 4 : 1;
-        int nt = (variant == 1 || variant == 4) ? 1 : 2;
-        a.TG = (N + 16 * nt - 1) / (16 * nt);
-        switch (variant) {
-            case 1: return launch_inst<4, 5, 2, 7, 1, true, 8>(e, a, full);
-            case 2: return launch_inst<4, 5, 2, 7, 2, true, 4>(e, a, full);
-            case 3: return launch_inst<4, 5, 2, 7, 2, true, 8>(e, a, full);
-            case 4: return launch_inst<4, 5, 2, 7, 1, true, 16>(e, a, full);
-            default: return fx_fail(e, FX_EINVAL, "cnn_variant must be 0..4");
+        const bool big = ((N + 15) / 16) * M >= (int64_t)e->num_cus * 32;
+        const int variant = (int)e->cnn_variant;
+        switch (lay.HT) {
+            case 1: return dispatch_a4<1>(e, a, variant, big, full, conv_only);
+            case 2: return dispatch_a4<2>(e, a, variant, big, full, conv_only);
+            case 4: return dispatch_a4<4>(e, a, variant, big, full, conv_only);
+            case 7: return dispatch_a4<7>(e, a, variant, big, full, conv_only);
+            case 8: return dispatch_a4<8>(e, a, variant, big, full, conv_only);
+            case 13: return dispatch_a4<13>(e, a, variant, big, full, conv_only);
+            default: return FX_EUNSUPPORTED;
         }
-    } else {
-        if (e->cnn_pair) {
-            const int rc = fx_launch_score_cnn_pair(e, models, M, d_ascii, N, d_out_NM, Mtot, m_off);
-            if (rc != FX_EUNSUPPORTED) return rc;
-        }
-        if (conv_only > (size_t)e->max_lds) return FX_EUNSUPPORTED;
-        a.TG = (N + 15) / 16;
-        return launch_inst<20, 5, 2, 7, 1, false, 4>(e, a, conv_only);   // 1 wave / SIMD: 512-VGPR budget for the 19-tap window
     }
+    // A = 20 (proteins): two-waves-per-tile kernel; the single-wave window form (HT = 7 only) is the A/B baseline
+    if (e->cnn_pair) {
+        const int rc = fx_launch_score_cnn_pair(e, models, M, d_ascii, N, d_out_NM, Mtot, m_off);
+        if (rc != FX_EUNSUPPORTED) return rc;
+    }
+    if (lay.HT != 7 || conv_only > (size_t)e->max_lds) return FX_EUNSUPPORTED;
+    a.TG = (N + 15) / 16;
+    return launch_inst<20, 5, 2, 7, 1, false, 4>(e, a, conv_only);   // 1 wave / SIMD: 512-VGPR budget for the 19-tap window
 }

@@ -27,7 +27,7 @@ struct PairArgs {
     unsigned* err;
     int64_t N, TG;
     int M, Mtot, m_off;
-    int L, rlh;
+    int L, rlh, htr;
     int off_c2, off_c3, off_cb, off_w1p, conv_floats, off_d1, off_d2, off_db;
     int lds_from, lds_floats;   // LDS image = packed[lds_from .. lds_from + lds_floats): conv2, conv3, biases, conv1 rows
 };
@@ -193,6 +193,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
             slot[mo * 64 + lane] = gmax;
             __syncthreads();
             if (mo == 0) {
+                asm volatile("" : "+v"(w_d1), "+v"(w_d2), "+v"(db));   // keep block addresses out of the tile loop's live set
                 f4 pooled[FT][1];
                 pooled[0][0] = gmax;
                 pooled[1][0] = slot[64 + lane];           // (rewritten only after the next tile's ~L barriers)
@@ -238,15 +239,23 @@ int fx_launch_score_cnn_pair(fx_engine* e, fx_model* const* models, int M, const
     if (N == 0) return FX_OK;
     const FxShape& s = models[0]->shape;
     const FxPackLayout& lay = models[0]->layout;
-    if (s.F != 32 || s.K != 5 || lay.HT != 7 || s.A != 20 || M > FX_MAX_M) return FX_EUNSUPPORTED;
+    if (s.F != 32 || s.K != 5 || s.A != 20 || M > FX_MAX_M) return FX_EUNSUPPORTED;
     constexpr int WAVES = 8;
     const size_t lds = (size_t)(lay.conv_floats - lay.off_c2) * 4 + (size_t)3 * (WAVES / 2) * 2 * 64 * 16 + 256 + 16;
     if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
     PairArgs a{};
     a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
     for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
-    a.N = N; a.TG = (N + 15) / 16; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.rlh = lay.RLH;
+    a.N = N; a.TG = (N + 15) / 16; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4; a.htr = lay.HTR;
     a.off_c2 = (int)lay.off_c2; a.off_c3 = (int)lay.off_c3; a.off_cb = (int)lay.off_cb; a.off_w1p = (int)lay.off_w1p;
     a.conv_floats = (int)lay.conv_floats; a.lds_from = (int)lay.off_c2; a.lds_floats = (int)(lay.conv_floats - lay.off_c2); a.off_d1 = (int)lay.off_d1; a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db;
-    return launch_pair<20, 5, 7, WAVES>(e, a, lds);
+    switch (lay.HT) {
+        case 1: return launch_pair<20, 5, 1, WAVES>(e, a, lds);
+        case 2: return launch_pair<20, 5, 2, WAVES>(e, a, lds);
+        case 4: return launch_pair<20, 5, 4, WAVES>(e, a, lds);
+        case 7: return launch_pair<20, 5, 7, WAVES>(e, a, lds);
+        case 8: return launch_pair<20, 5, 8, WAVES>(e, a, lds);
+        case 13: return launch_pair<20, 5, 13, WAVES>(e, a, lds);
+        default: return FX_EUNSUPPORTED;
+    }
 }

@@ -24,12 +24,12 @@ struct DenseArgs {
     unsigned* err;
     int64_t N, TG;
     int M, Mtot, m_off;
-    int L, A, rlh;
+    int L, A, rlh, htr;
     int SG1, off_first, off_w1p, off_d2, off_d3, off_db, total_floats;
     int lds_from, lds_floats;   // the LDS image is packed[lds_from .. lds_from + lds_floats)
 };
 
-template <int KIND, int A, int HT, int NT, int WAVES, bool G1, bool W1G>
+template <int KIND, int A, int HT, int NT, int WAVES, bool G1, bool W1G, bool DG>
 __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -58,9 +58,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
         // W1G: the (large) first-layer rows stay in global memory / L2, only the HxH blocks sit in LDS
         const float* w_first = W1G ? p.w[m] + p.off_first : smem + (p.off_first - p.lds_from);
         const float* w1p = W1G ? p.w[m] + p.off_w1p : smem + (p.off_w1p - p.lds_from);
-        const f4* w_d2 = reinterpret_cast<const f4*>(smem + (p.off_d2 - p.lds_from));
-        const f4* w_d3 = reinterpret_cast<const f4*>(smem + (p.off_d3 - p.lds_from));
-        const float* db = smem + (p.off_db - p.lds_from);
+        // DG: HxH blocks too large for LDS (H > 128) stream from L2; the LDS image then ends before them
+        const f4* w_d2 = reinterpret_cast<const f4*>(DG ? p.w[m] + p.off_d2 : smem + (p.off_d2 - p.lds_from));
+        const f4* w_d3 = reinterpret_cast<const f4*>(DG ? p.w[m] + p.off_d3 : smem + (p.off_d3 - p.lds_from));
+        const float* db = DG ? p.w[m] + p.off_db : smem + (p.off_db - p.lds_from);
 
         const int64_t t_lo = (u_lo > (int64_t)m * p.TG ? u_lo : (int64_t)m * p.TG) - (int64_t)m * p.TG;
         const int64_t t_hi = (u_hi < (int64_t)(m + 1) * p.TG ? u_hi : (int64_t)(m + 1) * p.TG) - (int64_t)m * p.TG;
@@ -72,6 +73,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
             const int64_t tg = t_lo + pulled;
             if (tg >= t_hi) break;
             asm volatile("" ::: "memory");               // keep LDS weight reads inside the tile loop
+            if (DG) asm volatile("" : "+v"(w_d2), "+v"(w_d3), "+v"(db));   // L2-streamed blocks: no hoisted addresses
             int64_t n[NT];
             const uint8_t* row[NT];
 #pragma unroll
@@ -188,9 +190,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
     if (bad) fx_raise(p.err, FX_ERR_BADCHAR);
 }
 
-template <int KIND, int A, int HT, int NT, int WAVES, bool G1, bool W1G = false>
+template <int KIND, int A, int HT, int NT, int WAVES, bool G1, bool W1G = false, bool DG = false>
 int launch_inst(fx_engine* e, const DenseArgs& a, size_t lds_bytes) {
-    auto kern = k_score_dense_mfma<KIND, A, HT, NT, WAVES, G1, W1G>;
+    auto kern = k_score_dense_mfma<KIND, A, HT, NT, WAVES, G1, W1G, DG>;
     static bool attr_set[64] = {};
     if (!attr_set[e->device & 63]) {
         FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -209,6 +211,43 @@ int launch_inst(fx_engine* e, const DenseArgs& a, size_t lds_bytes) {
 
 }  // namespace
 
+namespace {
+
+// HT <= 7: 16 waves (128-register budget); HT = 8: 8 waves; HT = 13 (H <= 208): 8 waves and the HxH blocks stream from L2.
+template <int HT_>
+int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, DenseArgs& a) {
+    constexpr int W = HT_ <= 7 ? 16 : 8;
+    constexpr bool DGc = HT_ > 8;
+    const int64_t tail = DGc ? lay.off_d2 : lay.total_floats;           // end of the LDS image
+    int64_t lds_from = (s.kind == FX_MLP && !e->mlp_l1_mfma) ? lay.off_w1p : 0;
+    size_t lds = (size_t)(tail - lds_from) * 4 + 256 + 16;
+    bool w1_global = false;
+    if (lds > (size_t)e->max_lds) {
+        // MLP with a large L*A: first-layer rows are gathered from L2 as well
+        if (s.kind != FX_MLP) return FX_EUNSUPPORTED;
+        lds_from = DGc ? tail : lay.off_d2;
+        lds = (size_t)(tail - lds_from) * 4 + 256 + 16;
+        if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
+        w1_global = true;
+    }
+    a.lds_from = (int)lds_from;
+    a.lds_floats = (int)(tail - lds_from);
+    if (s.kind == FX_MLP) {
+        if (w1_global) return launch_inst<FX_MLP, 4, HT_, 1, W, true, true, DGc>(e, a, lds);   // gather form: A is a runtime stride
+        if (e->mlp_l1_mfma) {
+            if constexpr (HT_ == 7) {
+                if (s.A == 4) return launch_inst<FX_MLP, 4, 7, 1, W, false, false, false>(e, a, lds);
+                if (s.A == 20) return launch_inst<FX_MLP, 20, 7, 1, W, false, false, false>(e, a, lds);
+            }
+            return FX_EUNSUPPORTED;
+        }
+        return launch_inst<FX_MLP, 4, HT_, 1, W, true, false, DGc>(e, a, lds);
+    }
+    return launch_inst<FX_GE, 4, HT_, 1, W, false, false, DGc>(e, a, lds);    // A is a runtime stride for GE
+}
+
+}  // namespace
+
 int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N,
                                float* d_out_NM, int Mtot, int m_off) {
     if (N == 0) return FX_OK;
@@ -218,38 +257,21 @@ int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, con
         const FxShape& t = models[m]->shape;
         if (t.kind != s.kind || t.L != s.L || t.A != s.A || t.H != s.H) return FX_EUNSUPPORTED;
     }
-    if (s.kind != FX_MLP && s.kind != FX_GE) return FX_EUNSUPPORTED;
-    if (lay.HT != 7 || M > FX_MAX_M) return FX_EUNSUPPORTED;
-    // LDS image = packed[lds_from ..): GE and the MFMA first-layer form need everything; the gather form of the
-    // MLP skips the (unused) first-layer MFMA blocks; a first layer too big for LDS stays in L2 altogether.
-    int64_t lds_from = (s.kind == FX_MLP && !e->mlp_l1_mfma) ? lay.off_w1p : 0;
-    size_t lds = (size_t)(lay.total_floats - lds_from) * 4 + 256 + 16;
-    bool w1_global = false;
-    if (lds > (size_t)e->max_lds) {
-        if (s.kind != FX_MLP) return FX_EUNSUPPORTED;
-        lds_from = lay.off_d2;
-        lds = (size_t)(lay.total_floats - lds_from) * 4 + 256 + 16;
-        if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
-        w1_global = true;
-    }
-    if (s.kind == FX_MLP && s.A % 4 != 0 && e->mlp_l1_mfma) return FX_EUNSUPPORTED;
+    if ((s.kind != FX_MLP && s.kind != FX_GE) || M > FX_MAX_M) return FX_EUNSUPPORTED;
     DenseArgs a{};
     a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
     for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
-    a.N = N; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.A = s.A; a.rlh = lay.RLH;
+    a.N = N; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.A = s.A; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4; a.htr = lay.HTR;
     a.SG1 = lay.SG1; a.off_first = (int)lay.off_first; a.off_w1p = (int)lay.off_w1p; a.off_d2 = (int)lay.off_d2; a.off_d3 = (int)lay.off_d3;
     a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
     a.TG = (N + 15) / 16;
-    a.lds_from = (int)lds_from;
-    a.lds_floats = (int)lay.total_floats - a.lds_from;
-    if (s.kind == FX_MLP) {
-        if (w1_global) return launch_inst<FX_MLP, 4, 7, 1, 16, true, true>(e, a, lds);   // gather form: A is a runtime stride
-        if (e->mlp_l1_mfma) {
-            if (s.A == 4) return launch_inst<FX_MLP, 4, 7, 1, 16, false>(e, a, lds);
-            if (s.A == 20) return launch_inst<FX_MLP, 20, 7, 1, 16, false>(e, a, lds);
-            return FX_EUNSUPPORTED;
-        }
-        return launch_inst<FX_MLP, 4, 7, 1, 16, true>(e, a, lds);
+    switch (lay.HT) {
+        case 1: return dispatch_dense<1>(e, s, lay, a);
+        case 2: return dispatch_dense<2>(e, s, lay, a);
+        case 4: return dispatch_dense<4>(e, s, lay, a);
+        case 7: return dispatch_dense<7>(e, s, lay, a);
+        case 8: return dispatch_dense<8>(e, s, lay, a);
+        case 13: return dispatch_dense<13>(e, s, lay, a);
+        default: return FX_EUNSUPPORTED;
     }
-    return launch_inst<FX_GE, 4, 7, 1, 16, false>(e, a, lds);    // A is a runtime stride for GE (template arg unused)
 }

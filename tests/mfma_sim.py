@@ -31,6 +31,11 @@ def mfma16(a, b, c):
     return out
 
 
+def rl_of(lay):
+    """k-steps of the last hidden tile the kernels run (4 when H was rounded up to a larger tile count)."""
+    return lay["RLH"] if lay["HTR"] == lay["HT"] else 4
+
+
 def blocks(packed, off, idx):
     """f4 block `idx` starting at float offset `off`: (64 lanes, 4)."""
     return packed[off + idx * 256: off + (idx + 1) * 256].reshape(64, 4)
@@ -122,7 +127,7 @@ def cnn_tile(packed, lay, codes16, A, K, F, H, conv1_gather=True):
     h1 = init_bias(packed, db, HT)
     h1 = [np.maximum(x, 0) for x in mma_layer(packed, lay["off_d1"], FT, HT, gmax, h1)]
     h2 = init_bias(packed, db + 16 * HT, HT)
-    h2 = [np.maximum(x, 0) for x in mma_layer(packed, lay["off_d2"], HT, HT, h1, h2, lay["RLH"])]
+    h2 = [np.maximum(x, 0) for x in mma_layer(packed, lay["off_d2"], HT, HT, h1, h2, rl_of(lay))]
     y = final_dot(packed, db + 32 * HT, packed[db + 48 * HT], h2, HT)
     return y[:16]                                        # lanes of group 0 hold the 16 sequences
 
@@ -153,9 +158,9 @@ def mlp_tile(packed, lay, codes16, A, H, l1_gather=True):
                 h[mo] = mfma16(aw, b, h[mo])
     h = [np.maximum(x, 0) for x in h]
     h2 = init_bias(packed, db + 16 * HT, HT)
-    h2 = [np.maximum(x, 0) for x in mma_layer(packed, lay["off_d2"], HT, HT, h, h2, lay["RLH"])]
+    h2 = [np.maximum(x, 0) for x in mma_layer(packed, lay["off_d2"], HT, HT, h, h2, rl_of(lay))]
     h3 = init_bias(packed, db + 32 * HT, HT)
-    h3 = [np.maximum(x, 0) for x in mma_layer(packed, lay["off_d3"], HT, HT, h2, h3, lay["RLH"])]
+    h3 = [np.maximum(x, 0) for x in mma_layer(packed, lay["off_d3"], HT, HT, h2, h3, rl_of(lay))]
     y = final_dot(packed, db + 48 * HT, packed[db + 64 * HT], h3, HT)
     return y[:16]
 
@@ -177,7 +182,7 @@ def ge_tile(packed, lay, codes16, A, H):
     b2 = init_bias(packed, db + 4 + 16 * HT, HT)
     h = [np.maximum(b2[mo] + s[:, None] * w2[mo], 0) for mo in range(HT)]
     h2 = init_bias(packed, db + 4 + 32 * HT, HT)
-    h2 = [np.maximum(x, 0) for x in mma_layer(packed, lay["off_d3"], HT, HT, h, h2, lay["RLH"])]
+    h2 = [np.maximum(x, 0) for x in mma_layer(packed, lay["off_d3"], HT, HT, h, h2, rl_of(lay))]
     y = final_dot(packed, db + 4 + 48 * HT, packed[db + 4 + 64 * HT], h2, HT)
     return y[:16]
 
@@ -246,5 +251,5 @@ def cnn_pair_tile(packed, lay, codes16, A, K, F, H):
     h1 = init_bias(packed, db, HT)
     h1 = [np.maximum(x, 0) for x in mma_layer(packed, lay["off_d1"], FT, HT, pooled, h1)]
     h2 = init_bias(packed, db + 16 * HT, HT)
-    h2 = [np.maximum(x, 0) for x in mma_layer(packed, lay["off_d2"], HT, HT, h1, h2, lay["RLH"])]
+    h2 = [np.maximum(x, 0) for x in mma_layer(packed, lay["off_d2"], HT, HT, h1, h2, rl_of(lay))]
     return final_dot(packed, db + 32 * HT, packed[db + 48 * HT], h2, HT)[:16]
