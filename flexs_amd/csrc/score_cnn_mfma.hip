@@ -33,7 +33,9 @@ struct CnnArgs {
     int off_first, off_c2, off_c3, off_cb, off_w1p, conv_floats, off_d1, off_d2, off_db, total_floats;
 };
 
-template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1>
+// L1S > 0: number of conv positions known at compile time (L1S = seq_len - K + 1): the position loop is fully
+// unrolled, so the sliding windows become register renames instead of v_mov chains and the padding tests fold.
+template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1, int L1S = 0>
 __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
     constexpr int K3 = A - 1;
     constexpr int PL2 = (K - 1) / 2, PR2 = K - 1 - PL2;
@@ -44,7 +46,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int g = lane >> 4, sq = lane & 15;
-    const int L = p.L, L1 = L - K + 1;
+    const int L = p.L, L1 = L1S > 0 ? L1S : L - K + 1;
     const int lds_floats = DENSE_LDS ? p.total_floats : p.conv_floats;
     uint8_t* lut_s = reinterpret_cast<uint8_t*>(smem + lds_floats);
     int* next_tile = reinterpret_cast<int*>(smem + lds_floats + 64);   // work counter, after the 256-byte LUT
@@ -125,6 +127,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                 for (int nt = 0; nt < NT; ++nt) gmax[t][nt] = splat4(0.f);   // relu output >= 0
 
             const int steps = L1 + PR2 + PR3;
+#pragma unroll L1S > 0 ? L1S + PR2 + PR3 : 1
             for (int s = 0; s < steps; ++s) {
                 // weights in LDS are loop-invariant: without this barrier LICM hoists every
                 // ds_read out of the position loop and spills hundreds of VGPRs
@@ -269,10 +272,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
     if (bad) fx_raise(p.err, FX_ERR_BADCHAR);
 }
 
-template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1>
+template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1, int L1S = 0>
 int launch_g(fx_engine* e, const CnnArgs& a, size_t lds_bytes) {
     constexpr int waves = WAVES;
-    auto kern = k_score_cnn_mfma<A, K, FT, HT, NT, DENSE_LDS, WAVES, G1>;
+    auto kern = k_score_cnn_mfma<A, K, FT, HT, NT, DENSE_LDS, WAVES, G1, L1S>;
     static bool attr_set[64] = {};
     if (!attr_set[e->device & 63]) {
         FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -318,7 +321,10 @@ int dispatch_a4(fx_engine* e, const CnnArgs& a0, int variant, bool big, size_t f
                 case 2: return launch_inst<4, 5, 2, 7, 2, true, 4>(e, a, lds);
                 case 3: return launch_inst<4, 5, 2, 7, 2, true, 8>(e, a, lds);
                 case 4: return launch_inst<4, 5, 2, 7, 1, true, 16>(e, a, lds);
-                default: return fx_fail(e, FX_EINVAL, "cnn_variant must be 0..4");
+                case 5:                                  // variant 4 with the position loop unrolled (TF-binding: L = 8)
+                    if (a.L != 8) return fx_fail(e, FX_EINVAL, "cnn_variant 5 is the seq_len = 8 specialisation");
+                    return launch_g<4, 5, 2, 7, 1, true, 16, true, 4>(e, a, lds);
+                default: return fx_fail(e, FX_EINVAL, "cnn_variant must be 0..5");
             }
         }
     }
