@@ -150,6 +150,14 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         eng.sync()                                       # raises if any bad character was met
+        # untimed completeness check: every score must have been written by the kernels (scores are
+        # nan_to_num'ed, so a NaN that survives a step is an element nobody wrote)
+        d_nm[0].fill_(float("nan"))
+        d_mean[0].fill_(float("nan"))
+        step(0)
+        drain()
+        torch.cuda.synchronize()
+        assert not bool(torch.isnan(d_nm[0]).any()) and not bool(torch.isnan(d_mean[0]).any()), "unwritten scores"
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_a, ev_b)]))
         last = (args.steps - 1) & 1
         got_mean = d_mean[last].cpu().numpy()

@@ -170,6 +170,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "cnn_conv1_mfma")) return &e->cnn_conv1_mfma;
     if (!std::strcmp(key, "mlp_l1_mfma")) return &e->mlp_l1_mfma;
     if (!std::strcmp(key, "cnn_pair")) return &e->cnn_pair;
+    if (!std::strcmp(key, "poison_outputs")) return &e->poison_outputs;
     return nullptr;
 }
 int fx_engine_set_option(fx_engine* e, const char* key, int64_t value) {
@@ -270,6 +271,8 @@ int fx_model_get_weights(const fx_model* m, float* blob, int64_t n) {
 // ------------------------------------------------------------------ scoring
 static int score_dispatch(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N, int L,
                           float* d_NM) {
+    if (e->poison_outputs)      // scores are nan_to_num'ed, so a NaN that survives is an element no kernel wrote
+        FX_HIP(e, hipMemsetAsync(d_NM, 0xFF, sizeof(float) * (size_t)N * (size_t)M, e->stream));
     // group consecutive members into launches of <= FX_MAX_M homogeneous models
     for (int m0 = 0; m0 < M;) {
         int cnt = 1;

@@ -314,7 +314,7 @@ int dispatch_a4(fx_engine* e, const CnnArgs& a0, int variant, bool big, size_t f
     if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
     if constexpr (HT_ == 7) {
         if (dl && variant != 0) {
-            const int nt = (variant == 1 || variant == 4) ? 1 : 2;
+            const int nt = (variant == 2 || variant == 3) ? 2 : 1;
             a.TG = (a.N + 16 * nt - 1) / (16 * nt);
             switch (variant) {
                 case 1: return launch_inst<4, 5, 2, 7, 1, true, 8>(e, a, lds);

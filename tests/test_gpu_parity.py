@@ -30,6 +30,7 @@ def close(got, want):
 
 def assert_scores(got, want, what=""):
     assert got.dtype == np.float32
+    assert not np.isnan(got).any(), f"{what}: {np.isnan(got).sum()} output elements were never written"
     bad = ~close(got.astype(np.float64), want)
     assert not bad.any(), (f"{what}: {bad.sum()} / {bad.size} outside tolerance; max abs err "
                            f"{np.abs(got - want).max():.3e}, worst at {np.argmax(np.abs(got - want))}")
@@ -38,7 +39,9 @@ def assert_scores(got, want, what=""):
 @pytest.fixture(scope="module")
 def eng():
     e = _native.Engine.get(0)
+    e.set_option("poison_outputs", 1)       # an output element that no kernel wrote shows up as NaN
     yield e
+    e.set_option("poison_outputs", 0)
     e.set_option("force_generic", 0)
     e.set_option("cnn_variant", 0)
     e.set_option("cnn_conv1_mfma", 0)
