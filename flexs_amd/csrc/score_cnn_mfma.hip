@@ -313,6 +313,7 @@ int dispatch_a4(fx_engine* e, const CnnArgs& a0, int variant, bool big, size_t f
     const size_t lds = dl ? full : conv_only;
     if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
     if constexpr (HT_ == 7) {
+        if (dl && variant == 0 && big && a.L == 8) variant = 5;      // TF-binding: unrolled position loop (+5 %, profiles/r1_run9)
         if (dl && variant != 0) {
             const int nt = (variant == 2 || variant == 3) ? 2 : 1;
             a.TG = (a.N + 16 * nt - 1) / (16 * nt);
