@@ -10,8 +10,10 @@ one exchange step -- an all-gather of float32 scores:
                      the stacked (N, M) matrix of ensemble.py:55-57 on every
                      rank; the reduction (np.mean order) then runs locally.
   sequence-parallel  every rank holds all members; rank r scores the contiguous
-                     shard [lo_r, hi_r) of the batch and reduces it locally;
-                     ONE all-gather of the padded (ceil(N/world),) means.
+                     shard [lo_r, hi_r) of the batch with every member; ONE
+                     all-gather of the padded (ceil(N/world), M) blocks (bench.py,
+                     which only needs the default mean, gathers the per-rank means
+                     instead: 4 bytes per sequence).
 
 Messages are <= a few MB, i.e. latency-bound on xGMI (7 point-to-point links per
 GPU), so a single collective per call is the design point -- no bucketing, no
