@@ -22,6 +22,8 @@ timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof -o r1 -- python
 # PMC: one counter group per run, --pmc only (no trace domains)
 
 
+timeout 300 rocprofv3 --pmc FETCH_SIZE -f csv -d $OUT/pmc_fetch -o r1 -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE -f csv -d $OUT/pmc_write -o r1 -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -f csv -d $OUT/pmc_sq -o r1 -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1
 
 find $OUT/prof $OUT/pmc_* -type f | head -40 > $OUT/files.log
