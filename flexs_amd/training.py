@@ -29,21 +29,28 @@ def _encode(sequences, alphabet, L, device):
     return F.one_hot(codes, len(alphabet)).to(torch.float32).to(device)       # (n, L, A)
 
 
-def _conv_same(h, w, b):
+def _conv(h, w, b, same):
+    """Keras Conv1D(strides=1) as K small GEMMs (channels-last, no MIOpen find step on a fresh box):
+    h (n, L, Cin), w (k, Cin, Cout) -> (n, Lout, Cout); 'same' pads (k-1)//2 left, the rest right."""
     k = w.shape[0]
-    pl = (k - 1) // 2
-    return F.conv1d(F.pad(h, (pl, k - 1 - pl)), w.permute(2, 1, 0), b)
+    if same:
+        pl = (k - 1) // 2
+        h = F.pad(h, (0, 0, pl, k - 1 - pl))
+    lout = h.shape[1] - k + 1
+    out = b.expand(h.shape[0], lout, w.shape[2])
+    for j in range(k):
+        out = out + h[:, j:j + lout, :] @ w[j]
+    return out
 
 
 def forward(kind, params, x, train=False):
     """Differentiable forward with parameters in Keras layout; x (n, L, A) -> (n,)."""
     if kind == "cnn":
         w1, b1, w2, b2, w3, b3, d1, c1, d2, c2, d3, c3 = params
-        h = x.permute(0, 2, 1)
-        h = F.relu(F.conv1d(h, w1.permute(2, 1, 0), b1))
-        h = F.relu(_conv_same(h, w2, b2))
-        h = F.relu(_conv_same(h, w3, b3))
-        h = h.amax(dim=2)
+        h = F.relu(_conv(x, w1, b1, same=False))
+        h = F.relu(_conv(h, w2, b2, same=True))
+        h = F.relu(_conv(h, w3, b3, same=True))      # MaxPooling1D(1) in between is the identity
+        h = h.amax(dim=1)
         h = F.relu(h @ d1 + c1)
         h = F.relu(h @ d2 + c2)
         h = F.dropout(h, 0.25, training=train)
