@@ -313,7 +313,10 @@ int dispatch_a4(fx_engine* e, const CnnArgs& a0, int variant, bool big, size_t f
     const size_t lds = dl ? full : conv_only;
     if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
     if constexpr (HT_ == 7) {
-        if (dl && variant == 0 && big && a.L == 8) variant = 5;      // TF-binding: unrolled position loop (+5 %, profiles/r1_run9)
+        // canonical short landscapes get a fully unrolled position loop (+5 % at L = 8, profiles/r1_run9):
+        // TF-binding (L = 8) and the RNA landscapes (L = 14)
+        if (dl && variant == 0 && big && a.L == 8) variant = 5;
+        if (dl && variant == 0 && big && a.L == 14) variant = 6;
         if (dl && variant != 0) {
             const int nt = (variant == 2 || variant == 3) ? 2 : 1;
             a.TG = (a.N + 16 * nt - 1) / (16 * nt);
@@ -325,7 +328,10 @@ int dispatch_a4(fx_engine* e, const CnnArgs& a0, int variant, bool big, size_t f
                 case 5:                                  // variant 4 with the position loop unrolled (TF-binding: L = 8)
                     if (a.L != 8) return fx_fail(e, FX_EINVAL, "cnn_variant 5 is the seq_len = 8 specialisation");
                     return launch_g<4, 5, 2, 7, 1, true, 16, true, 4>(e, a, lds);
-                default: return fx_fail(e, FX_EINVAL, "cnn_variant must be 0..5");
+                case 6:
+                    if (a.L != 14) return fx_fail(e, FX_EINVAL, "cnn_variant 6 is the seq_len = 14 specialisation");
+                    return launch_g<4, 5, 2, 7, 1, true, 16, true, 10>(e, a, lds);
+                default: return fx_fail(e, FX_EINVAL, "cnn_variant must be 0..6");
             }
         }
     }

@@ -103,6 +103,22 @@ def test_cnn_l8_variants_and_tails(eng, variant, n, conv1_mfma):
     eng.set_option("cnn_conv1_mfma", 0)
 
 
+@pytest.mark.parametrize("n", [1, 31, 5000, 70000])
+def test_cnn_l14_unrolled_specialisation(eng, n):
+    """RNA L=14: variant 6 (unrolled position loop) vs the oracle and vs the dynamic-loop kernel."""
+    nm, w = make_native(eng, "cnn", 14, 4, 100, 32, 5, seed=21)
+    b, seqs = rand_seqs(n, 14, "UGCA", seed=n)
+    lut = _native.make_lut("UGCA")
+    eng.set_option("cnn_variant", 6)
+    got6, _ = eng.score([nm], b, lut)
+    eng.set_option("cnn_variant", 4)
+    got4, _ = eng.score([nm], b, lut)
+    eng.set_option("cnn_variant", 0)
+    want = ref_np.keras_fitness(seqs, "UGCA", "cnn", w, exact=True)
+    assert_scores(got6[:, 0], want, f"cnn L14 variant 6 n={n}")
+    assert_scores(got4[:, 0], want, f"cnn L14 variant 4 n={n}")
+
+
 @pytest.mark.parametrize("L,A,alpha,n", [(8, 4, "TGCA", 3000), (5, 4, "TGCA", 500), (6, 4, "TGCA", 500),
                                          (14, 4, "UGCA", 2000), (50, 4, "UGCA", 600), (100, 4, "UGCA", 300),
                                          (20, 20, s_utils.AAS, 400), (66, 20, s_utils.AAS, 200),
