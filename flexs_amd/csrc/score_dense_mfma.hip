@@ -89,15 +89,24 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                 init_bias<HT, NT>(db, h, g);
                 if (G1) {
                     // one-hot layer == sum of L kernel rows selected by the codes: LDS gather + VALU adds
-                    for (int l = 0; l < L; ++l) {
+                    for (int l0 = 0; l0 < L; l0 += 4) {
                         asm volatile("" ::: "memory");
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
-                            int c = lut_s[row[nt][l]];
-                            if (c == 0xFF) { bad = true; c = 0; }
-                            const float* rowp = w1p + (l * p.A + c) * (16 * HT) + 4 * g;
+                            int raw[4];
 #pragma unroll
-                            for (int mo = 0; mo < HT; ++mo) h[mo][nt] += *reinterpret_cast<const f4*>(rowp + 16 * mo);
+                            for (int k = 0; k < 4; ++k) raw[k] = row[nt][l0 + k < L ? l0 + k : 0];   // independent loads
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const int l = l0 + k;
+                                if (l < L) {
+                                    int c = lut_s[raw[k]];
+                                    if (c == 0xFF) { bad = true; c = 0; }
+                                    const float* rowp = w1p + (l * p.A + c) * (16 * HT) + 4 * g;
+#pragma unroll
+                                    for (int mo = 0; mo < HT; ++mo) h[mo][nt] += *reinterpret_cast<const f4*>(rowp + 16 * mo);
+                                }
+                            }
                         }
                     }
                 } else {
@@ -143,12 +152,25 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                 float s[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) s[nt] = 0.f;
-                for (int l = g; l < L; l += 4) {
+                // eight positions per trip: the byte loads, LUT reads and table reads of a trip are independent,
+                // so their latencies overlap instead of chaining
+                for (int l0 = g; l0 < L; l0 += 32) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        int c = lut_s[row[nt][l]];
-                        if (c == 0xFF) { bad = true; c = 0; }
-                        s[nt] += w_first[l * p.A + c];
+                        int raw[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int l = l0 + 4 * k;
+                            raw[k] = row[nt][l < L ? l : 0];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int l = l0 + 4 * k;
+                            int c = lut_s[raw[k]];
+                            if (c == 0xFF) { bad |= (l < L); c = 0; }
+                            const float w = w_first[(l < L ? l : 0) * p.A + c];
+                            s[nt] += (l < L) ? w : 0.f;
+                        }
                     }
                 }
 #pragma unroll
