@@ -42,7 +42,7 @@ int fx_pinned(fx_engine* e, int slot, size_t bytes, void** out) {
             e->h_pinned[slot] = nullptr; e->pinned_bytes[slot] = 0;
         }
         size_t cap = std::max<size_t>(bytes + bytes / 4, 1 << 16);
-        if (hipHostMalloc(&e->h_pinned[slot], cap, hipHostMallocDefault) != hipSuccess) {
+        if (hipHostMalloc(&e->h_pinned[slot], cap, hipHostMallocMapped) != hipSuccess) {
             (void)hipGetLastError();
             return fx_fail(e, FX_ENOMEM, "hipHostMalloc of pinned staging failed");
         }
@@ -352,15 +352,29 @@ int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii,
     float* d_NM = (float*)d_out;
     float* d_mean = (float*)((char*)d_out + nm_bytes);
     std::memcpy(h_in, ascii, in_bytes);
-    FX_HIP(e, hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, e->stream));
     if ((rc = fx_upload_lut(e, lut))) return rc;
-    if ((rc = score_dispatch(e, models, M, (const uint8_t*)d_in, N, L, d_NM))) return rc;
-    if (out_mean) {
-        if ((rc = fx_launch_ensemble_reduce(e, d_NM, N, M, nullptr, d_mean, nullptr))) return rc;
-        FX_HIP(e, hipMemcpyAsync((char*)h_out + nm_bytes, d_mean, mean_bytes, hipMemcpyDeviceToHost, e->stream));
+    if (in_bytes + nm_bytes + mean_bytes <= (size_t)(256 << 10)) {
+        // Small call (what Adalead / CMA-ES / DynaPPO issue): zero-copy through the mapped pinned
+        // staging buffers -- the kernels read the sequences from, and write the scores to, host memory over
+        // PCIe; two memcpy enqueues and their latencies disappear from the call.
+        void *dm_in = nullptr, *dm_out = nullptr;
+        FX_HIP(e, hipHostGetDevicePointer(&dm_in, h_in, 0));
+        FX_HIP(e, hipHostGetDevicePointer(&dm_out, h_out, 0));
+        float* m_NM = (float*)dm_out;
+        float* m_mean = (float*)((char*)dm_out + nm_bytes);
+        if ((rc = score_dispatch(e, models, M, (const uint8_t*)dm_in, N, L, out_NM ? m_NM : d_NM))) return rc;
+        if (out_mean && (rc = fx_launch_ensemble_reduce(e, out_NM ? m_NM : d_NM, N, M, nullptr, m_mean, nullptr))) return rc;
+        FX_HIP(e, hipStreamSynchronize(e->stream));
+    } else {
+        FX_HIP(e, hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, e->stream));
+        if ((rc = score_dispatch(e, models, M, (const uint8_t*)d_in, N, L, d_NM))) return rc;
+        if (out_mean) {
+            if ((rc = fx_launch_ensemble_reduce(e, d_NM, N, M, nullptr, d_mean, nullptr))) return rc;
+            FX_HIP(e, hipMemcpyAsync((char*)h_out + nm_bytes, d_mean, mean_bytes, hipMemcpyDeviceToHost, e->stream));
+        }
+        if (out_NM) FX_HIP(e, hipMemcpyAsync(h_out, d_NM, nm_bytes, hipMemcpyDeviceToHost, e->stream));
+        FX_HIP(e, hipStreamSynchronize(e->stream));
     }
-    if (out_NM) FX_HIP(e, hipMemcpyAsync(h_out, d_NM, nm_bytes, hipMemcpyDeviceToHost, e->stream));
-    FX_HIP(e, hipStreamSynchronize(e->stream));
     if ((rc = check_deferred(e))) return rc;
     if (out_NM) std::memcpy(out_NM, h_out, nm_bytes);
     if (out_mean) std::memcpy(out_mean, (char*)h_out + nm_bytes, mean_bytes);

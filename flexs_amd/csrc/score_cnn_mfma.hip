@@ -98,7 +98,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                 n[nt] = (tg * NT + nt) * 16 + sq;
                 row[nt] = p.ascii + (n[nt] < p.N ? n[nt] : 0) * L;   // out-of-range lanes recompute seq 0
             }
-            // code window: cw[j] = alphabet index at position s + j
+            // Sliding windows.  RING: positions live in slot (position mod window), and the position loop is
+            // unrolled by a multiple of both window lengths, so every slot index is a compile-time constant and
+            // nothing is ever moved.  Otherwise (19-tap protein window, A/B baseline only) slots are shifted.
+            constexpr bool RING = (L1S > 0) || (K * K3 <= 16);
+            constexpr int UN = L1S > 0 ? (L1S + PR2 + PR3) : (RING ? K * K3 : 1);   // trips per unrolled block
+            // code window: alphabet index at positions s .. s+K-1
             int cw[K][NT];
 #pragma unroll
             for (int j = 0; j < K - 1; ++j)
@@ -106,7 +111,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                 for (int nt = 0; nt < NT; ++nt) {
                     int c = lut_s[row[nt][j]];
                     if (c == 0xFF) { bad = true; c = 0; }
-                    cw[j + 1][nt] = c;                    // shifted down at the top of step 0
+                    cw[RING ? j : j + 1][nt] = c;         // (shifting form: moved down at the top of step 0)
                 }
             f4 win1[K][FT][NT], win2[K3][FT][NT], gmax[FT][NT];
 #pragma unroll
@@ -127,36 +132,48 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                 for (int nt = 0; nt < NT; ++nt) gmax[t][nt] = splat4(0.f);   // relu output >= 0
 
             const int steps = L1 + PR2 + PR3;
-#pragma unroll L1S > 0 ? L1S + PR2 + PR3 : 1
-            for (int s = 0; s < steps; ++s) {
+            for (int s0 = 0; s0 < steps; s0 += UN) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int s = s0 + u;
+                if (L1S > 0 || s < steps) {
                 // weights in LDS are loop-invariant: without this barrier LICM hoists every
                 // ds_read out of the position loop and spills hundreds of VGPRs
                 asm volatile("" ::: "memory");
-                // ---- slide the windows
+                if (!RING) {
+                    // ---- slide the windows
 #pragma unroll
-                for (int j = 0; j < K - 1; ++j)
+                    for (int j = 0; j < K - 1; ++j)
 #pragma unroll
-                    for (int t = 0; t < FT; ++t)
+                        for (int t = 0; t < FT; ++t)
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) win1[j][t][nt] = win1[j + 1][t][nt];
+                            for (int nt = 0; nt < NT; ++nt) win1[j][t][nt] = win1[j + 1][t][nt];
 #pragma unroll
-                for (int j = 0; j < K3 - 1; ++j)
+                    for (int j = 0; j < K3 - 1; ++j)
 #pragma unroll
-                    for (int t = 0; t < FT; ++t)
+                        for (int t = 0; t < FT; ++t)
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) win2[j][t][nt] = win2[j + 1][t][nt];
+                            for (int nt = 0; nt < NT; ++nt) win2[j][t][nt] = win2[j + 1][t][nt];
 #pragma unroll
-                for (int j = 0; j < K - 1; ++j)
+                    for (int j = 0; j < K - 1; ++j)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) cw[j][nt] = cw[j + 1][nt];
+                        for (int nt = 0; nt < NT; ++nt) cw[j][nt] = cw[j + 1][nt];
+                }
+                // slot of: code[s + j]; out1[s] (newest); out1[s - (K-1) + j]; out2[t2] (newest); out2[t2 - (K3-1) + j]
+                // (s = u mod K and mod K3 because s0 is a multiple of both; all constants once unrolled)
+#define FX_CW(j) (RING ? (u + (j)) % K : (j))
+#define FX_W1NEW (RING ? u % K : K - 1)
+#define FX_W1(j) (RING ? (u + 1 + (j)) % K : (j))
+#define FX_W2NEW (RING ? (u + K3 * K - PR2) % K3 : K3 - 1)
+#define FX_W2(j) (RING ? (u + K3 * K - PR2 + 1 + (j)) % K3 : (j))
 
-                // ---- conv1 (valid) at t1 = s: one-hot B operand built in registers
+                // ---- conv1 (valid) at t1 = s
                 if (s < L1) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         int c = lut_s[row[nt][s + K - 1]];
                         if (c == 0xFF) { bad = true; c = 0; }
-                        cw[K - 1][nt] = c;
+                        cw[FX_CW(K - 1)][nt] = c;
                     }
                     f4 o1[FT][NT];
                     init_bias<FT, NT>(cb, o1, g);
@@ -167,7 +184,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                         for (int j = 0; j < K; ++j)
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt) {
-                                const float* rowp = w1p + (j * A + cw[j][nt]) * (16 * FT) + 4 * g;
+                                const float* rowp = w1p + (j * A + cw[FX_CW(j)][nt]) * (16 * FT) + 4 * g;
 #pragma unroll
                                 for (int mo = 0; mo < FT; ++mo) {
                                     const f4 w = *reinterpret_cast<const f4*>(rowp + 16 * mo);
@@ -182,7 +199,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                             const int sg = st >> 2, r = st & 3;
                             float b[NT];
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) b[nt] = (cw[j][nt] == a0 + g) ? 1.f : 0.f;
+                            for (int nt = 0; nt < NT; ++nt) b[nt] = (cw[FX_CW(j)][nt] == a0 + g) ? 1.f : 0.f;
 #pragma unroll
                             for (int mo = 0; mo < FT; ++mo) {
                                 const float a = reinterpret_cast<const float*>(&w_first[(sg * FT + mo) * 64 + lane])[r];
@@ -195,15 +212,15 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
 #pragma unroll
                     for (int t = 0; t < FT; ++t)
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) win1[K - 1][t][nt] = o1[t][nt];
+                        for (int nt = 0; nt < NT; ++nt) win1[FX_W1NEW][t][nt] = o1[t][nt];
                 } else {
 #pragma unroll
                     for (int t = 0; t < FT; ++t)
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) win1[K - 1][t][nt] = splat4(0.f);
+                        for (int nt = 0; nt < NT; ++nt) win1[FX_W1NEW][t][nt] = splat4(0.f);
                 }
 
-                // ---- conv2 (same) at t2 = s - PR2; win1[j] = out1[t2 + j - PL2]
+                // ---- conv2 (same) at t2 = s - PR2; tap j reads out1[t2 + j - PL2] = out1[s - (K-1) + j]
                 const int t2 = s - PR2;
                 if (t2 >= 0 && t2 < L1) {
                     f4 o2[FT][NT];
@@ -212,21 +229,21 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                     for (int j = 0; j < K; ++j) {
                         const int pp = t2 + j - PL2;
                         if (pp >= 0 && pp < L1)            // zero padding contributes nothing
-                            mma_layer<FT, FT, NT>(w_c2 + j * FT * FT * 64, win1[j], o2, lane);
+                            mma_layer<FT, FT, NT>(w_c2 + j * FT * FT * 64, win1[FX_W1(j)], o2, lane);
                     }
                     relu_tiles<FT, NT>(o2);
 #pragma unroll
                     for (int t = 0; t < FT; ++t)
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) win2[K3 - 1][t][nt] = o2[t][nt];
+                        for (int nt = 0; nt < NT; ++nt) win2[FX_W2NEW][t][nt] = o2[t][nt];
                 } else {
 #pragma unroll
                     for (int t = 0; t < FT; ++t)
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) win2[K3 - 1][t][nt] = splat4(0.f);
+                        for (int nt = 0; nt < NT; ++nt) win2[FX_W2NEW][t][nt] = splat4(0.f);
                 }
 
-                // ---- conv3 (same, kernel A-1) at t3 = t2 - PR3; win2[j] = out2[t3 + j - PL3]
+                // ---- conv3 (same, kernel A-1) at t3 = t2 - PR3; tap j reads out2[t3 + j - PL3] = out2[t2 - (K3-1) + j]
                 //      (MaxPooling1D(1) between conv2 and conv3 is the identity, cnn.py:40)
                 const int t3 = t2 - PR3;
                 if (t3 >= 0 && t3 < L1) {
@@ -236,7 +253,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                     for (int j = 0; j < K3; ++j) {
                         const int pp = t3 + j - PL3;
                         if (pp >= 0 && pp < L1)
-                            mma_layer<FT, FT, NT>(w_c3 + j * FT * FT * 64, win2[j], o3, lane);
+                            mma_layer<FT, FT, NT>(w_c3 + j * FT * FT * 64, win2[FX_W2(j)], o3, lane);
                     }
                     // GlobalMaxPooling1D of relu(o3): gmax starts at 0
 #pragma unroll
@@ -244,6 +261,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) gmax[t][nt] = max4(gmax[t][nt], o3[t][nt]);
                 }
+#undef FX_CW
+#undef FX_W1NEW
+#undef FX_W1
+#undef FX_W2NEW
+#undef FX_W2
+                }
+            }
             }
 
             // ---- dense head: F -> H relu -> H relu -> (dropout inactive) -> 1
