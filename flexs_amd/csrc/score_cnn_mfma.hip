@@ -308,8 +308,8 @@ int launch_g(fx_engine* e, const CnnArgs& a, size_t lds_bytes) {
     }
     int64_t U = (int64_t)a.M * a.TG;
     int64_t blocks = e->grid_blocks > 0 ? e->grid_blocks : e->num_cus;
-    // keep every wave busy: at least one unit per wave
-    int64_t need = (U + waves - 1) / waves;
+    // never more workgroups than work units
+    int64_t need = U;                                // small batches: one unit per workgroup (lowest latency)
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(waves * 64), lds_bytes, e->stream, a);

@@ -224,7 +224,7 @@ int launch_pair(fx_engine* e, const PairArgs& a, size_t lds_bytes) {
     }
     const int64_t U = (int64_t)a.M * a.TG;
     int64_t blocks = e->grid_blocks > 0 ? e->grid_blocks : e->num_cus;
-    const int64_t need = (U + WAVES / 2 - 1) / (WAVES / 2);
+    const int64_t need = U;                          // small batches: one tile per workgroup (lowest latency)
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), lds_bytes, e->stream, a);
