@@ -557,3 +557,27 @@ def test_sequence_density(eng):
                     dens += ref[s] / d
             assert seen.density(q) == dens
     assert SeenSequences(5).density("ACGTA") == 0
+
+
+# ------------------------------------------------------------------ randomised shapes (dispatch boundaries)
+def test_random_shapes_against_oracle(eng):
+    """60 random (kind, L, alphabet, F, H, K, N) draws straddling the MFMA / shape-agnostic dispatch
+    boundaries (alphabets of 2..21 letters, hidden sizes 1..230, odd filter counts, even kernels)."""
+    rng = np.random.default_rng(2026)
+    letters = "ACDEFGHIKLMNPQRSTVWYX"
+    for trial in range(60):
+        kind = ("cnn", "mlp", "ge")[trial % 3]
+        A = int(rng.choice([2, 3, 4, 4, 5, 20, 20, 21]))
+        alpha = letters[:A]
+        L = int(rng.integers(1, 41))
+        H = int(rng.choice([1, 7, 16, 33, 64, 100, 100, 128, 130, 200, 230]))
+        F = int(rng.choice([1, 8, 32, 32, 32])) if kind == "cnn" else 0
+        K = int(rng.integers(1, min(L, 6) + 1)) if kind == "cnn" else 0
+        if kind == "cnn" and rng.random() < 0.5 and L >= 5:
+            K = 5
+        n = int(rng.choice([1, 2, 15, 16, 17, 100, 333]))
+        nm, w = make_native(eng, kind, L, A, H, F, K, seed=trial)
+        b, seqs = rand_seqs(n, L, alpha, seed=trial)
+        got, _ = eng.score([nm], b, _native.make_lut(alpha))
+        want = ref_np.keras_fitness(seqs, alpha, kind, w, exact=True)
+        assert_scores(got[:, 0], want, f"trial {trial}: {kind} L={L} A={A} F={F} H={H} K={K} n={n}")
