@@ -51,7 +51,9 @@ __device__ __forceinline__ float fx_nan_to_num(float v) {
 // channels (hidden-unit tail laid out k-step-major by the packer, fx_hidden_pos); the
 // remaining k-steps would multiply zeros and are skipped.  (Hidden sizes that were rounded up
 // to a larger instantiated tile count pass 4: their padding tiles are computed as zeros.)
-template <int TI, int TO, int NT, typename WPtr>
+// PRIO: raise the wave's issue priority around each MFMA cluster (A/B knob; waves of a SIMD are at
+// different phases here, the regime in which s_setprio can pay).
+template <int TI, int TO, int NT, bool PRIO = false, typename WPtr>
 __device__ __forceinline__ void mma_layer(WPtr wblk, const f4 (&in)[TI][NT], f4 (&acc)[TO][NT], int lane,
                                           int rl_last = 4) {
 #pragma unroll
@@ -59,6 +61,7 @@ __device__ __forceinline__ void mma_layer(WPtr wblk, const f4 (&in)[TI][NT], f4 
         f4 a[TO];
 #pragma unroll
         for (int mo = 0; mo < TO; ++mo) a[mo] = wblk[(mi * TO + mo) * 64 + lane];
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (mi == TI - 1 && r >= rl_last) break;
@@ -67,6 +70,7 @@ __device__ __forceinline__ void mma_layer(WPtr wblk, const f4 (&in)[TI][NT], f4 
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[mo][nt] = mfma16(a[mo][r], in[mi][nt][r], acc[mo][nt]);
         }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
     }
 }
 

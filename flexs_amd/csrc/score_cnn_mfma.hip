@@ -35,7 +35,7 @@ struct CnnArgs {
 
 // L1S > 0: number of conv positions known at compile time (L1S = seq_len - K + 1): the position loop is fully
 // unrolled, so the sliding windows become register renames instead of v_mov chains and the padding tests fold.
-template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1, int L1S = 0>
+template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1, int L1S = 0, bool PRIO = false>
 __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
     constexpr int K3 = A - 1;
     constexpr int PL2 = (K - 1) / 2, PR2 = K - 1 - PL2;
@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                     for (int j = 0; j < K; ++j) {
                         const int pp = t2 + j - PL2;
                         if (pp >= 0 && pp < L1)            // zero padding contributes nothing
-                            mma_layer<FT, FT, NT>(w_c2 + j * FT * FT * 64, win1[FX_W1(j)], o2, lane);
+                            mma_layer<FT, FT, NT, PRIO>(w_c2 + j * FT * FT * 64, win1[FX_W1(j)], o2, lane);
                     }
                     relu_tiles<FT, NT>(o2);
 #pragma unroll
@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                     for (int j = 0; j < K3; ++j) {
                         const int pp = t3 + j - PL3;
                         if (pp >= 0 && pp < L1)
-                            mma_layer<FT, FT, NT>(w_c3 + j * FT * FT * 64, win2[FX_W2(j)], o3, lane);
+                            mma_layer<FT, FT, NT, PRIO>(w_c3 + j * FT * FT * 64, win2[FX_W2(j)], o3, lane);
                     }
                     // GlobalMaxPooling1D of relu(o3): gmax starts at 0
 #pragma unroll
@@ -279,10 +279,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
             }
             f4 h1[HT][NT], h2[HT][NT];
             init_bias<HT, NT>(db, h1, g);
-            mma_layer<FT, HT, NT>(w_d1, gmax, h1, lane);
+            mma_layer<FT, HT, NT, PRIO>(w_d1, gmax, h1, lane);
             relu_tiles<HT, NT>(h1);
             init_bias<HT, NT>(db + 16 * HT, h2, g);
-            mma_layer<HT, HT, NT>(w_d2, h1, h2, lane, p.rlh);
+            mma_layer<HT, HT, NT, PRIO>(w_d2, h1, h2, lane, p.rlh);
             relu_tiles<HT, NT>(h2);
             float y[NT];
             final_dot<HT, NT>(db + 32 * HT, db[48 * HT], h2, y, g);
@@ -296,10 +296,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
     if (bad) fx_raise(p.err, FX_ERR_BADCHAR);
 }
 
-template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1, int L1S = 0>
+template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1, int L1S = 0, bool PRIO = false>
 int launch_g(fx_engine* e, const CnnArgs& a, size_t lds_bytes) {
     constexpr int waves = WAVES;
-    auto kern = k_score_cnn_mfma<A, K, FT, HT, NT, DENSE_LDS, WAVES, G1, L1S>;
+    auto kern = k_score_cnn_mfma<A, K, FT, HT, NT, DENSE_LDS, WAVES, G1, L1S, PRIO>;
     static bool attr_set[64] = {};
     if (!attr_set[e->device & 63]) {
         FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -355,7 +355,10 @@ int dispatch_a4(fx_engine* e, const CnnArgs& a0, int variant, bool big, size_t f
                 case 6:
                     if (a.L != 14) return fx_fail(e, FX_EINVAL, "cnn_variant 6 is the seq_len = 14 specialisation");
                     return launch_g<4, 5, 2, 7, 1, true, 16, true, 10>(e, a, lds);
-                default: return fx_fail(e, FX_EINVAL, "cnn_variant must be 0..6");
+                case 7:                                  // variant 5 + s_setprio around the MFMA clusters (A/B knob)
+                    if (a.L != 8) return fx_fail(e, FX_EINVAL, "cnn_variant 7 is a seq_len = 8 specialisation");
+                    return launch_g<4, 5, 2, 7, 1, true, 16, true, 4, true>(e, a, lds);
+                default: return fx_fail(e, FX_EINVAL, "cnn_variant must be 0..7");
             }
         }
     }

@@ -3,9 +3,9 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out; mkdir -p $OUT
 python -c "import __graft_entry__ as g; g.build(quiet=True)" > $OUT/env.log 2>&1
-timeout 600 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --timeout 600 -k "cnn_l8 or smoke or baseline_config1" > $OUT/pytest_quick.log 2>&1
-for rep in 1 2; do
-for v in 4 5 1; do
+timeout 600 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --timeout 600 -k "cnn_l8 or smoke or baseline_config1 or random_shapes" > $OUT/pytest_quick.log 2>&1
+for rep in 1 2 3; do
+for v in 5 7; do
   timeout 200 python bench.py --steps 200 --warmup 20 --variant $v --no-cpu-baseline > $OUT/bench_q_v${v}_$rep.log 2>&1
 done; done
 tail -2 $OUT/pytest_quick.log
