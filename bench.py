@@ -45,6 +45,45 @@ def cpu_baseline(budget_s=12.0, hard_timeout_s=150.0):
                 "sample": f"cpu baseline failed: {type(e).__name__}: {str(e)[:200]}"}
 
 
+def make_report(world, N, steps, warmup, elapsed, host_issue_s, kern_ms, use_dist):
+    """The one JSON line of the bench contract (pure function: unit-tested on the CPU)."""
+    from flexs_amd import synth
+
+    macs = synth.algorithmic_macs("cnn", L, len(ALPHABET), H, F, K)
+    flop_per_launch = 2.0 * macs * M * N                 # SURVEY.md 8d: 2 x dense MACs x members x sequences
+    peak = 157.3                                         # f32-input MFMA, MI355X_MICROARCH.md
+    achieved = flop_per_launch / (kern_ms * 1e-3) / 1e12
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+    return {
+        "metric": "sequences scored/sec (virtual-screen batch)",
+        "value": world * N * steps / elapsed,
+        "unit": "sequences/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3,
+        "host_issue_ms_per_step": host_issue_s / steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"TF-binding L={L} alphabet={ALPHABET}, {M}-member CNN(num_filters={F}, "
+                               f"hidden_size={H}, kernel_size={K}) Ensemble, batch={N} virtual-screen per GPU "
+                               "(BASELINE.json configs[1]); inputs resident in HBM; step = fused encode+CNN "
+                               "scoring kernel + ensemble-mean kernel"
+                               + (" + one RCCL all-gather of the per-rank means (own stream, overlapped with the "
+                                  "next step's compute)" if use_dist else ""),
+                   "global_batch": world * N, "seq_len": L, "members": M,
+                   "parallelism": f"sequence-parallel x{world}" if world > 1 else "single GPU"},
+        "roofline": {"bound": "mfma", "kernel": "k_score_cnn_mfma", "achieved": achieved, "peak": peak,
+                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                     "kernel_ms": kern_ms, "flop_per_launch": flop_per_launch,
+                     "algorithmic_bytes_per_launch": (L + 4 * M) * N,
+                     "note": "f32-input MFMA peak (157.3 TFLOP/s); algorithmic FLOP = 2*MACs, not discounted "
+                             "for one-hot sparsity / zero padding; traffic = FETCH_SIZE x2 + WRITE_SIZE from the "
+                             "PMC passes under profiles/"},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,36 +221,7 @@ def main():
 
     if rank == 0:
         assert np.array_equal(np.mean(got_nm, axis=1), got_mean), "device mean is not np.mean bit-for-bit"
-        macs = synth.algorithmic_macs("cnn", L, len(ALPHABET), H, F, K)
-        flop_per_launch = 2.0 * macs * M * N
-        peak = 157.3
-        achieved = flop_per_launch / (kern_ms * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        out = {
-            "metric": "sequences scored/sec (virtual-screen batch)",
-            "value": world * N * args.steps / elapsed,
-            "unit": "sequences/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "host_issue_ms_per_step": host_issue_s / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"TF-binding L={L} alphabet={ALPHABET}, {M}-member CNN(num_filters={F}, "
-                                   f"hidden_size={H}, kernel_size={K}) Ensemble, batch={N} virtual-screen per GPU "
-                                   "(BASELINE.json configs[1]); inputs resident in HBM; step = fused encode+CNN "
-                                   "scoring kernel + ensemble-mean kernel" + (" + one RCCL all-gather of the per-rank means (async, overlapped with the next step's compute)" if use_dist else ""),
-                       "global_batch": world * N, "seq_len": L, "members": M,
-                       "parallelism": f"sequence-parallel x{world}" if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "kernel": "k_score_cnn_mfma", "achieved": achieved, "peak": peak,
-                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                         "kernel_ms": kern_ms, "flop_per_launch": flop_per_launch,
-                         "algorithmic_bytes_per_launch": (L + 4 * M) * N,
-                         "note": "f32-input MFMA peak (157.3 TFLOP/s); algorithmic FLOP = 2*MACs, not discounted "
-                                 "for one-hot sparsity / zero padding"},
-        }
+        out = make_report(world, N, args.steps, args.warmup, elapsed, host_issue_s, kern_ms, use_dist)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -237,3 +237,26 @@ def test_tf_binding_host_tables_match_reference(golden_dir):
     assert [land.sequences[s] for s in fx["sample_sequences"]] == fx["sample_values"]
     assert land.sequences["ATTATGTT"] == fx["tutorial_known_answer"]["value"]
     assert getattr(land, "batch_safe") is True
+
+
+def test_bench_report_contract():
+    """bench.py's JSON line: the keys and types the driver reads (no GPU needed for the assembly itself)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    r = bench.make_report(world=2, N=100_000, steps=200, warmup=20, elapsed=0.05, host_issue_s=0.004, kern_ms=0.2, use_dist=True)
+    json.loads(json.dumps(r))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in r, key
+    assert r["n_gpus"] == 2 and r["steps"] == 200 and r["warmup"] == 20 and r["vs_baseline"] is None
+    assert r["value"] == pytest.approx(2 * 100_000 * 200 / 0.05) and r["ms_per_step"] == pytest.approx(0.25)
+    assert r["higher_is_better"] is True and r["scaling"] == "weak" and r["dtype"] == "f32" and r["data"] == "synthetic"
+    assert "workload" in r["config"] and "model" not in r["config"]
+    rf = r["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3
+    assert rf["flop_per_launch"] == 2.0 * 48628 * 3 * 100_000            # SURVEY.md 8d: 97 256 FLOP per sequence-member
+    assert rf["achieved"] == pytest.approx(rf["flop_per_launch"] / 0.2e-3 / 1e12) and rf["frac"] == pytest.approx(rf["achieved"] / 157.3)
+    assert rf["algorithmic_bytes_per_launch"] == (8 + 12) * 100_000
