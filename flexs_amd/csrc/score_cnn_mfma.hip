@@ -35,7 +35,7 @@ struct CnnArgs {
 
 // L1S > 0: number of conv positions known at compile time (L1S = seq_len - K + 1): the position loop is fully
 // unrolled, so the sliding windows become register renames instead of v_mov chains and the padding tests fold.
-template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1, int L1S = 0, bool PRIO = false>
+template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1, int L1S = 0, bool PRIO = true>
 __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
     constexpr int K3 = A - 1;
     constexpr int PL2 = (K - 1) / 2, PR2 = K - 1 - PL2;
@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
     if (bad) fx_raise(p.err, FX_ERR_BADCHAR);
 }
 
-template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1, int L1S = 0, bool PRIO = false>
+template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1, int L1S = 0, bool PRIO = true>
 int launch_g(fx_engine* e, const CnnArgs& a, size_t lds_bytes) {
     constexpr int waves = WAVES;
     auto kern = k_score_cnn_mfma<A, K, FT, HT, NT, DENSE_LDS, WAVES, G1, L1S, PRIO>;
@@ -339,7 +339,7 @@ int dispatch_a4(fx_engine* e, const CnnArgs& a0, int variant, bool big, size_t f
     if constexpr (HT_ == 7) {
         // canonical short landscapes get a fully unrolled position loop (+5 % at L = 8, profiles/r1_run9):
         // TF-binding (L = 8) and the RNA landscapes (L = 14)
-        if (dl && variant == 0 && big && a.L == 8) variant = 5;
+        if (dl && variant == 0 && big && a.L == 8) variant = 7;
         if (dl && variant == 0 && big && a.L == 14) variant = 6;
         if (dl && variant != 0) {
             const int nt = (variant == 2 || variant == 3) ? 2 : 1;
@@ -351,11 +351,11 @@ int dispatch_a4(fx_engine* e, const CnnArgs& a0, int variant, bool big, size_t f
                 case 4: return launch_inst<4, 5, 2, 7, 1, true, 16>(e, a, lds);
                 case 5:                                  // variant 4 with the position loop unrolled (TF-binding: L = 8)
                     if (a.L != 8) return fx_fail(e, FX_EINVAL, "cnn_variant 5 is the seq_len = 8 specialisation");
-                    return launch_g<4, 5, 2, 7, 1, true, 16, true, 4>(e, a, lds);
+                    return launch_g<4, 5, 2, 7, 1, true, 16, true, 4, false>(e, a, lds);   // no s_setprio (A/B baseline)
                 case 6:
                     if (a.L != 14) return fx_fail(e, FX_EINVAL, "cnn_variant 6 is the seq_len = 14 specialisation");
                     return launch_g<4, 5, 2, 7, 1, true, 16, true, 10>(e, a, lds);
-                case 7:                                  // variant 5 + s_setprio around the MFMA clusters (A/B knob)
+                case 7:                                  // unrolled L = 8 specialisation with s_setprio (the default)
                     if (a.L != 8) return fx_fail(e, FX_EINVAL, "cnn_variant 7 is a seq_len = 8 specialisation");
                     return launch_g<4, 5, 2, 7, 1, true, 16, true, 4, true>(e, a, lds);
                 default: return fx_fail(e, FX_EINVAL, "cnn_variant must be 0..7");
