@@ -51,10 +51,10 @@ __device__ __forceinline__ float fx_nan_to_num(float v) {
 // channels (hidden-unit tail laid out k-step-major by the packer, fx_hidden_pos); the
 // remaining k-steps would multiply zeros and are skipped.  (Hidden sizes that were rounded up
 // to a larger instantiated tile count pass 4: their padding tiles are computed as zeros.)
-// PRIO: raise the wave's issue priority around each MFMA cluster.  The waves of a SIMD are at different
-// phases here (independent tiles), the regime in which s_setprio pays: +2 % on the bench kernel
-// (profiles/r1_run16_setprio_ab.md).  Variant 5 of the CNN kernel keeps PRIO = false as the A/B baseline.
-template <int TI, int TO, int NT, bool PRIO = true, typename WPtr>
+// PRIO: raise the wave's issue priority around each MFMA cluster.  Measured +2 % on the unrolled L = 8
+// kernel in an interleaved A/B (profiles/r1_run16_setprio_ab.md) but neutral-to-negative on the dynamic-loop,
+// MLP and GE kernels (profiles/r1_run17_*), so it is opt-in per instantiation.
+template <int TI, int TO, int NT, bool PRIO = false, typename WPtr>
 __device__ __forceinline__ void mma_layer(WPtr wblk, const f4 (&in)[TI][NT], f4 (&acc)[TO][NT], int lane,
                                           int rl_last = 4) {
 #pragma unroll

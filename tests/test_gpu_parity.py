@@ -86,7 +86,7 @@ def test_smoke_entry():
 
 # ------------------------------------------------------------------ CNN
 @pytest.mark.parametrize("conv1_mfma", [0, 1])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 7])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 7, 8, 9])
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 33, 1000, 4099])
 def test_cnn_l8_variants_and_tails(eng, variant, n, conv1_mfma):
     """BASELINE configs[0]/[1] shape: TF-binding L=8, alphabet TGCA, CNN(32,100,k5);
@@ -109,8 +109,11 @@ def test_cnn_l14_unrolled_specialisation(eng, n):
     nm, w = make_native(eng, "cnn", 14, 4, 100, 32, 5, seed=21)
     b, seqs = rand_seqs(n, 14, "UGCA", seed=n)
     lut = _native.make_lut("UGCA")
+    eng.set_option("cnn_variant", 10)
+    got10, _ = eng.score([nm], b, lut)
     eng.set_option("cnn_variant", 6)
     got6, _ = eng.score([nm], b, lut)
+    assert np.array_equal(got6, got10)                   # s_setprio changes scheduling only
     eng.set_option("cnn_variant", 4)
     got4, _ = eng.score([nm], b, lut)
     eng.set_option("cnn_variant", 0)
