@@ -35,7 +35,7 @@ struct CnnArgs {
 
 // L1S > 0: number of conv positions known at compile time (L1S = seq_len - K + 1): the position loop is fully
 // unrolled, so the sliding windows become register renames instead of v_mov chains and the padding tests fold.
-template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1, int L1S = 0, bool PRIO = false, int FS = 1>
+template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1, int L1S = 0, bool PRIO = false>
 __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
     constexpr int K3 = A - 1;
     constexpr int PL2 = (K - 1) / 2, PR2 = K - 1 - PL2;
@@ -139,9 +139,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                 if (L1S > 0 || s < steps) {
                 // weights in LDS are loop-invariant: without this barrier LICM hoists every
                 // ds_read out of the position loop and spills hundreds of VGPRs
-                // (FS > 1, unrolled specialisations only: fence every FS-th position -- lets the scheduler start
-                //  the next position's weight reads under this position's MFMAs)
-                if (FS == 1 || (u % FS) == 0) asm volatile("" ::: "memory");
+                // (fencing only every 2nd / 4th position of the unrolled kernels measured no gain: profiles/r1_run18)
+                asm volatile("" ::: "memory");
                 if (!RING) {
                     // ---- slide the windows
 #pragma unroll
@@ -298,10 +297,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
     if (bad) fx_raise(p.err, FX_ERR_BADCHAR);
 }
 
-template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1, int L1S = 0, bool PRIO = false, int FS = 1>
+template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1, int L1S = 0, bool PRIO = false>
 int launch_g(fx_engine* e, const CnnArgs& a, size_t lds_bytes) {
     constexpr int waves = WAVES;
-    auto kern = k_score_cnn_mfma<A, K, FT, HT, NT, DENSE_LDS, WAVES, G1, L1S, PRIO, FS>;
+    auto kern = k_score_cnn_mfma<A, K, FT, HT, NT, DENSE_LDS, WAVES, G1, L1S, PRIO>;
     static bool attr_set[64] = {};
     if (!attr_set[e->device & 63]) {
         FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -339,10 +338,11 @@ int dispatch_a4(fx_engine* e, const CnnArgs& a0, int variant, bool big, size_t f
     const size_t lds = dl ? full : conv_only;
     if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
     if constexpr (HT_ == 7) {
-        // canonical short landscapes get a fully unrolled position loop (+5 % at L = 8, profiles/r1_run9):
+        // canonical short landscapes get a fully unrolled position loop with s_setprio around the MFMA clusters
+        // (+5 % and +2-4 % resp., interleaved A/B: profiles/r1_run9, r1_run16, r1_run18):
         // TF-binding (L = 8) and the RNA landscapes (L = 14)
         if (dl && variant == 0 && big && a.L == 8) variant = 7;
-        if (dl && variant == 0 && big && a.L == 14) variant = 6;
+        if (dl && variant == 0 && big && a.L == 14) variant = 10;
         if (dl && variant != 0) {
             const int nt = (variant == 2 || variant == 3) ? 2 : 1;
             a.TG = (a.N + 16 * nt - 1) / (16 * nt);
@@ -363,12 +363,6 @@ int dispatch_a4(fx_engine* e, const CnnArgs& a0, int variant, bool big, size_t f
                 case 7:                                  // unrolled L = 8 specialisation with s_setprio (the default)
                     if (a.L != 8) return fx_fail(e, FX_EINVAL, "cnn_variant 7 is a seq_len = 8 specialisation");
                     return launch_g<4, 5, 2, 7, 1, true, 16, true, 4, true>(e, a, lds);
-                case 8:                                  // variant 7 with a weight-reload fence every 2nd position (A/B)
-                    if (a.L != 8) return fx_fail(e, FX_EINVAL, "cnn_variant 8 is a seq_len = 8 specialisation");
-                    return launch_g<4, 5, 2, 7, 1, true, 16, true, 4, true, 2>(e, a, lds);
-                case 9:                                  // ... every 4th position (A/B)
-                    if (a.L != 8) return fx_fail(e, FX_EINVAL, "cnn_variant 9 is a seq_len = 8 specialisation");
-                    return launch_g<4, 5, 2, 7, 1, true, 16, true, 4, true, 4>(e, a, lds);
                 default: return fx_fail(e, FX_EINVAL, "cnn_variant must be 0..10");
             }
         }
