@@ -23,9 +23,10 @@ __global__ void k_encode_onehot(const uint8_t* __restrict__ ascii, const uint8_t
             if (c == 0xFF) { bad = true; c = -1; }
             reinterpret_cast<float4*>(out)[i] = make_float4(c == 0, c == 1, c == 2, c == 3);
         }
-    } else if (AT == 1) {
+    } else if (AT == 1 || AT == 20) {
         // A % 4 == 0: one thread per 16-byte quad of the output, consecutive lanes -> consecutive quads
-        const int q = A >> 2;
+        // (AT == 20: protein alphabet, quads per position known at compile time -> no runtime division)
+        const int q = AT == 20 ? 5 : (A >> 2);
         const int64_t quads = rows * q;
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (int64_t)gridDim.x * blockDim.x) {
             const int64_t pos = i / q;
@@ -236,6 +237,9 @@ int fx_launch_encode_onehot(fx_engine* e, const uint8_t* d_ascii, int64_t N, int
     dim3 grid(grid_for(rows, 256, e->num_cus)), block(256);
     if (A == 4) {
         hipLaunchKernelGGL(k_encode_onehot<4>, grid, block, 0, e->stream, d_ascii, e->d_lut, rows, A, d_out, e->d_err);
+    } else if (A == 20) {
+        dim3 g2(grid_for(rows * 5, 256, e->num_cus));
+        hipLaunchKernelGGL(k_encode_onehot<20>, g2, block, 0, e->stream, d_ascii, e->d_lut, rows, A, d_out, e->d_err);
     } else if (A % 4 == 0) {
         dim3 g2(grid_for(rows * (A / 4), 256, e->num_cus));
         hipLaunchKernelGGL(k_encode_onehot<1>, g2, block, 0, e->stream, d_ascii, e->d_lut, rows, A, d_out, e->d_err);
