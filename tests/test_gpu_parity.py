@@ -584,3 +584,18 @@ def test_random_shapes_against_oracle(eng):
         got, _ = eng.score([nm], b, _native.make_lut(alpha))
         want = ref_np.keras_fitness(seqs, alpha, kind, w, exact=True)
         assert_scores(got[:, 0], want, f"trial {trial}: {kind} L={L} A={A} F={F} H={H} K={K} n={n}")
+
+
+@pytest.mark.parametrize("kind,L,A,alpha,M,n", [("cnn", 30, 20, s_utils.AAS, 3, 700), ("cnn", 66, 20, s_utils.AAS, 5, 130),
+                                                ("mlp", 90, 20, s_utils.AAS, 3, 900), ("mlp", 14, 4, "UGCA", 5, 4000),
+                                                ("ge", 30, 20, s_utils.AAS, 11, 1000), ("cnn", 14, 4, "UGCA", 4, 70001)])
+def test_multi_member_launches(eng, kind, L, A, alpha, M, n):
+    """Several members in one fused launch: workgroup ranges straddle member boundaries (weights are
+    reloaded in LDS mid-range) -- pair kernel, L2-gathered MLP, unrolled L=14 kernel included."""
+    F, K = (32, 5) if kind == "cnn" else (0, 0)
+    natives, ws = zip(*[make_native(eng, kind, L, A, 100, F, K, seed=300 + m) for m in range(M)])
+    b, seqs = rand_seqs(n, L, alpha, seed=M * 7 + L)
+    nm, mean = eng.score(list(natives), b, _native.make_lut(alpha), want_matrix=True, want_mean=True)
+    for m in range(M):
+        assert_scores(nm[:, m], ref_np.keras_fitness(seqs, alpha, kind, ws[m], exact=True), f"{kind} member {m}/{M}")
+    assert np.array_equal(mean, np.mean(nm, axis=1))
