@@ -169,7 +169,6 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "grid_blocks")) return &e->grid_blocks;
     if (!std::strcmp(key, "cnn_conv1_mfma")) return &e->cnn_conv1_mfma;
     if (!std::strcmp(key, "mlp_l1_mfma")) return &e->mlp_l1_mfma;
-    if (!std::strcmp(key, "dense_prefetch")) return &e->dense_prefetch;
     if (!std::strcmp(key, "cnn_pair")) return &e->cnn_pair;
     if (!std::strcmp(key, "poison_outputs")) return &e->poison_outputs;
     return nullptr;

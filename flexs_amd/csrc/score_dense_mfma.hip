@@ -24,7 +24,7 @@ struct DenseArgs {
     unsigned* err;
     int64_t N, TG;
     int M, Mtot, m_off;
-    int L, A, rlh, htr, prefetch;
+    int L, A, rlh, htr;
     int SG1, off_first, off_w1p, off_d2, off_d3, off_db, total_floats;
     int lds_from, lds_floats;   // the LDS image is packed[lds_from .. lds_from + lds_floats)
 };
@@ -66,29 +66,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
         const int64_t t_lo = (u_lo > (int64_t)m * p.TG ? u_lo : (int64_t)m * p.TG) - (int64_t)m * p.TG;
         const int64_t t_hi = (u_hi < (int64_t)(m + 1) * p.TG ? u_hi : (int64_t)(m + 1) * p.TG) - (int64_t)m * p.TG;
 
-        // Waves pull tiles from a block-local counter, ONE TILE AHEAD: while tile t is computed, the first
-        // bytes of tile t+1's sequences are already being fetched (a dense tile is only ~6-11 k MFMA cycles,
-        // comparable to one HBM miss, so an unprefetched first touch would stall every tile).
-        int pulled_next = 0;
-        if (lane == 0) pulled_next = atomicAdd(next_tile, 1);
-        pulled_next = __builtin_amdgcn_readfirstlane(pulled_next);
-        for (;;) {
-            const int pulled = pulled_next;
+        for (;;) {                                       // waves pull tiles from a block-local counter
+            int pulled = 0;
+            if (lane == 0) pulled = atomicAdd(next_tile, 1);
+            pulled = __builtin_amdgcn_readfirstlane(pulled);
             const int64_t tg = t_lo + pulled;
             if (tg >= t_hi) break;
-            if (lane == 0) pulled_next = atomicAdd(next_tile, 1);
-            pulled_next = __builtin_amdgcn_readfirstlane(pulled_next);
-            int warm = 0;
-            // Issued AFTER this tile's own byte loads (vector loads return in order: a prefetch in front of them
-            // would make them wait for its miss) and before the MFMA layers, which cover its latency.
-            auto prefetch_next = [&]() {
-                const int64_t nn = ((t_lo + pulled_next) * NT) * 16 + sq;
-                if (p.prefetch && t_lo + pulled_next < t_hi && nn < p.N) {
-                    const uint8_t* nrow = p.ascii + nn * L;
-                    warm = nrow[0] + nrow[L - 1];             // touches the (at most two for L <= 64) lines of the row
-                    if (L > 64) warm += nrow[L / 2];
-                }
-            };
             asm volatile("" ::: "memory");               // keep LDS weight reads inside the tile loop
             if (DG) asm volatile("" : "+v"(w_d2), "+v"(w_d3), "+v"(db));   // L2-streamed blocks: no hoisted addresses
             int64_t n[NT];
@@ -153,7 +136,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                     }
                 }
                 relu_tiles<HT, NT>(h);
-                prefetch_next();
                 // ---- layers 2, 3
                 f4 h2[HT][NT];
                 init_bias<HT, NT>(db + 16 * HT, h2, g);
@@ -197,7 +179,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                     s[nt] += __shfl_xor(s[nt], 32);
                     s[nt] += db[0];
                 }
-                prefetch_next();
                 // ---- layer 2: h[ch] = relu(b2[ch] + s * w2[ch]) directly in B-operand layout
                 f4 h2[HT][NT];
 #pragma unroll
@@ -226,7 +207,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                 for (int nt = 0; nt < NT; ++nt)
                     if (n[nt] < p.N) p.out[n[nt] * p.Mtot + p.m_off + m] = fx_nan_to_num(y[nt]);
             }
-            asm volatile("" :: "v"(warm));                // the prefetch loads must be issued, their value is irrelevant
         }
     }
     if (bad) fx_raise(p.err, FX_ERR_BADCHAR);
@@ -303,7 +283,7 @@ int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, con
     DenseArgs a{};
     a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
     for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
-    a.N = N; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.A = s.A; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4; a.htr = lay.HTR; a.prefetch = e->dense_prefetch ? 1 : 0;
+    a.N = N; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.A = s.A; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4; a.htr = lay.HTR;
     a.SG1 = lay.SG1; a.off_first = (int)lay.off_first; a.off_w1p = (int)lay.off_w1p; a.off_d2 = (int)lay.off_d2; a.off_d3 = (int)lay.off_d3;
     a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
     a.TG = (N + 15) / 16;
