@@ -36,7 +36,7 @@ FxPackLayout fx_pack_layout(const FxShape& s) {
     {
         // the MFMA kernels are instantiated for these tile counts; round up (extra tiles are zero padding
         // that the kernels skip); beyond the largest one the layout stays exact and the generic kernels run
-        static const int sizes[] = {1, 2, 4, 7, 8, 13};
+        static const int sizes[] = {1, 2, 4, 7, 8, 13, 16};
         for (int v : sizes) if (v >= p.HTR) { p.HT = v; break; }
     }
     {

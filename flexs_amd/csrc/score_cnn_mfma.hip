@@ -408,6 +408,7 @@ int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const
             case 7: return dispatch_a4<7>(e, a, variant, big, full, conv_only);
             case 8: return dispatch_a4<8>(e, a, variant, big, full, conv_only);
             case 13: return dispatch_a4<13>(e, a, variant, big, full, conv_only);
+            case 16: return dispatch_a4<16>(e, a, variant, big, full, conv_only);
             default: return FX_EUNSUPPORTED;
         }
     }

@@ -256,6 +256,7 @@ int fx_launch_score_cnn_pair(fx_engine* e, fx_model* const* models, int M, const
         case 7: return launch_pair<20, 5, 7, WAVES>(e, a, lds);
         case 8: return launch_pair<20, 5, 8, WAVES>(e, a, lds);
         case 13: return launch_pair<20, 5, 13, WAVES>(e, a, lds);
+        case 16: return launch_pair<20, 5, 16, WAVES>(e, a, lds);
         default: return FX_EUNSUPPORTED;
     }
 }

@@ -235,7 +235,7 @@ int launch_inst(fx_engine* e, const DenseArgs& a, size_t lds_bytes) {
 
 namespace {
 
-// HT <= 7: 16 waves (128-register budget); HT = 8: 8 waves; HT = 13 (H <= 208): 8 waves and the HxH blocks stream from L2.
+// HT <= 7: 16 waves (128-register budget); HT = 8: 8 waves; HT = 13 / 16 (H <= 256): 8 waves and the HxH blocks stream from L2.
 template <int HT_>
 int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, DenseArgs& a) {
     constexpr int W = HT_ <= 7 ? 16 : 8;
@@ -294,6 +294,7 @@ int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, con
         case 7: return dispatch_dense<7>(e, s, lay, a);
         case 8: return dispatch_dense<8>(e, s, lay, a);
         case 13: return dispatch_dense<13>(e, s, lay, a);
+        case 16: return dispatch_dense<16>(e, s, lay, a);
         default: return FX_EUNSUPPORTED;
     }
 }

@@ -152,10 +152,10 @@ def test_cnn_mfma_vs_oracle(eng, L, A, alpha, n):
 
 
 @pytest.mark.parametrize("kind", ["cnn", "mlp", "ge"])
-@pytest.mark.parametrize("H", [1, 16, 20, 50, 64, 113, 128, 200, 208, 209, 300])
+@pytest.mark.parametrize("H", [1, 16, 20, 50, 64, 113, 128, 200, 208, 209, 256, 257, 300])
 def test_hidden_sizes(eng, kind, H):
     """Hidden sizes are rounded up to an instantiated tile count (1, 2, 4, 7, 8, 13 x 16) on the MFMA
-    path (H <= 208; HxH blocks stream from L2 beyond 128); larger ones use the shape-agnostic kernels."""
+    path (H <= 256; HxH blocks stream from L2 beyond 128); larger ones use the shape-agnostic kernels."""
     for L, A, alpha in ((8, 4, "TGCA"), (12, 20, s_utils.AAS)):
         nm, w = make_native(eng, kind, L, A, H, 32 if kind == "cnn" else 0, 5 if kind == "cnn" else 0, seed=H)
         b, seqs = rand_seqs(700, L, alpha, seed=H + L)

@@ -17,14 +17,14 @@ from oracle import c_oracle, ref_np
 
 @pytest.mark.parametrize("L,A,alpha,H", [(8, 4, "TGCA", 100), (5, 4, "TGCA", 100), (14, 4, "UGCA", 100),
                                          (27, 20, ref_np.AAS, 100), (8, 4, "TGCA", 1), (8, 4, "TGCA", 50),
-                                         (8, 4, "TGCA", 128), (9, 4, "TGCA", 200)])
+                                         (8, 4, "TGCA", 128), (9, 4, "TGCA", 200), (9, 4, "TGCA", 250)])
 def test_cnn_dataflow_matches_oracle(L, A, alpha, H):
     K, F = 5, 32
     rng = np.random.default_rng(L)
     w = ref_np.synth_weights(ref_np.cnn_shapes(L, A, F, H, K), 1000)
     packed = _native.debug_pack_weights(_native.FX_CNN, L, A, F, H, K, w)
     lay = _native.debug_pack_layout(_native.FX_CNN, L, A, F, H, K)
-    assert lay["FT"] == 2 and lay["HTR"] == -(-H // 16) and lay["HT"] in (1, 2, 4, 7, 8, 13) and lay["HT"] >= lay["HTR"]
+    assert lay["FT"] == 2 and lay["HTR"] == -(-H // 16) and lay["HT"] in (1, 2, 4, 7, 8, 13, 16) and lay["HT"] >= lay["HTR"]
     codes = rng.integers(0, A, (16, L)).astype(np.uint8)
     seqs = ["".join(alpha[c] for c in r) for r in codes]
     want = ref_np.keras_fitness(seqs, alpha, "cnn", w, exact=True)
@@ -50,7 +50,7 @@ def test_cnn_pair_dataflow_matches_oracle(L, A, alpha):
 @pytest.mark.parametrize("L,A,alpha,H", [(14, 4, "UGCA", 100), (8, 4, "TGCA", 100), (9, 20, ref_np.AAS, 100),
                                          (14, 4, "UGCA", 97), (14, 4, "UGCA", 104), (14, 4, "UGCA", 107), (14, 4, "UGCA", 112),
                                          (14, 4, "UGCA", 7), (14, 4, "UGCA", 33), (14, 4, "UGCA", 64), (14, 4, "UGCA", 120),
-                                         (14, 4, "UGCA", 200), (14, 4, "UGCA", 208)])
+                                         (14, 4, "UGCA", 200), (14, 4, "UGCA", 208), (14, 4, "UGCA", 256)])
 def test_mlp_ge_dataflow_matches_oracle(L, A, alpha, H):
     rng = np.random.default_rng(7)
     codes = rng.integers(0, A, (16, L)).astype(np.uint8)

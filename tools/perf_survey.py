@@ -176,7 +176,7 @@ def nam():
 
 
 def main():
-    which = sys.argv[1:] or ["score", "hbm", "e2e", "nam"]
+    which = sys.argv[1:] or ["score", "sweep", "hbm", "e2e", "nam"]
     if "score" in which:
         for v in (1, 2, 3, 4):
             time_score("cnn", 8, "TGCA", 100, 3, 100_000, 32, 5, variant=v, label=f"C2 cnn L=8 M=3 N=1e5 variant {v} conv1=gather")
@@ -208,6 +208,9 @@ def main():
         time_score("cnn", 8, "TGCA", 200, 3, 100_000, 32, 5, label="cnn L=8 H=200 M=3 N=1e5 (dense head from L2)")
         time_score("cnn", 237, AAS, 100, 1, 16_384, 32, 5, reps=2, label="C5 cnn L=237 A=20 M=1 N=16384")
         time_score("cnn", 237, AAS, 100, 3, 16_384, 32, 5, reps=1, label="C5 cnn L=237 A=20 M=3 N=16384")
+    if "sweep" in which:
+        for N in (1_000, 10_000, 30_000, 100_000, 300_000, 1_000_000, 10_000_000):
+            time_score("cnn", 8, "TGCA", 100, 3, N, 32, 5, reps=(20 if N <= 1_000_000 else 3), label=f"sweep C2 cnn L=8 M=3 N={N}")
     if "hbm" in which:
         time_hbm_kernels()
     if "e2e" in which:
