@@ -1,5 +1,11 @@
-"""`AdaptiveEnsemble` -- same contract as flexs/baselines/models/adaptive_ensemble.py:29-102."""
-from typing import List
+"""`AdaptiveEnsemble`: an ensemble whose member weights are re-estimated at every `train`
+(contract of flexs/baselines/models/adaptive_ensemble.py:29-102).
+
+Scoring of device-backed members is one fused launch (all members, one pass over the batch)
+followed by the weighted-sum kernel, which reproduces `np.sum(weights * scores, axis=1)` bit
+for bit (float64 products, NumPy summation order).
+"""
+from typing import Callable, List, Union
 
 import numpy as np
 import scipy.stats
@@ -10,60 +16,61 @@ from flexs_amd import _native
 from flexs_amd.ensemble import _device_members
 from flexs_amd.types import SEQUENCES_TYPE
 
+MIN_SAMPLES_FOR_REWEIGHTING = 10          # adaptive_ensemble.py:82
+
 
 def r2_weights(model_preds: np.ndarray, labels: np.ndarray) -> np.ndarray:
-    """Normalised squared Pearson r per model (adaptive_ensemble.py:12-26)."""
-    r2s = np.array([scipy.stats.pearsonr(preds, labels)[0] ** 2 for preds in model_preds])
-    return r2s / r2s.sum()
+    """Squared Pearson correlation of each model's predictions (rows of `model_preds`) with
+    `labels`, normalised to sum to one (adaptive_ensemble.py:12-26)."""
+    squared = [scipy.stats.pearsonr(row, labels)[0] ** 2 for row in model_preds]
+    squared = np.array(squared)
+    return squared / squared.sum()
 
 
-def _weighted_sum(w, x):
-    return np.sum(w * x, axis=1)           # adaptive_ensemble.py:54
+def _weighted_sum(weights, scores):
+    return np.sum(weights * scores, axis=1)
 
 
 class AdaptiveEnsemble(flexs_amd.Model):
-    """Ensemble whose members are re-weighted (r^2 on a validation split) at every `train`."""
-
-    def __init__(
-        self,
-        models: List[flexs_amd.Model],
-        combine_with="sum",
-        adapt_weights_with="r2_weights",
-        adaptive_val_size: float = 0.2,
-    ):
-        name = f"AdaptiveEns({'|'.join(model.name for model in models)})"
-        super().__init__(name)
+    def __init__(self, models: List[flexs_amd.Model], combine_with: Union[str, Callable] = "sum",
+                 adapt_weights_with: Union[str, Callable] = "r2_weights", adaptive_val_size: float = 0.2):
+        """
+        Args:
+            models: members.
+            combine_with: `(weights, scores (N, M)) -> (N,)`; "sum" = weighted sum.
+            adapt_weights_with: `(predictions (M, n_val), labels (n_val,)) -> weights (M,)`;
+                "r2_weights" = normalised squared Pearson r.
+            adaptive_val_size: fraction of the training data held out to estimate the weights.
+        """
+        super().__init__("AdaptiveEns(" + "|".join(m.name for m in models) + ")")
         self.models = models
-        self.weights = np.ones(len(models)) / len(models)
-        if combine_with == "sum":
-            combine_with = _weighted_sum
-        self.combine_with = combine_with
-        if adapt_weights_with == "r2_weights":
-            adapt_weights_with = r2_weights
-        self.adapt_weights_with = adapt_weights_with
+        self.weights = np.full(len(models), 1.0 / len(models))
+        self.combine_with = _weighted_sum if combine_with == "sum" else combine_with
+        self.adapt_weights_with = r2_weights if adapt_weights_with == "r2_weights" else adapt_weights_with
         self.adaptive_val_size = adaptive_val_size
 
     def train(self, sequences: SEQUENCES_TYPE, labels: np.ndarray):
-        if len(sequences) < 10:                                     # adaptive_ensemble.py:82-85
-            for model in self.models:
-                model.train(sequences, labels)
+        """Train the members; with >= 10 samples hold out a validation split and re-weight."""
+        if len(sequences) < MIN_SAMPLES_FOR_REWEIGHTING:
+            for member in self.models:
+                member.train(sequences, labels)
             return
-        (train_X, test_X, train_y, test_y) = sklearn.model_selection.train_test_split(
-            np.array(sequences), np.array(labels), test_size=self.adaptive_val_size
-        )
-        for model in self.models:
-            model.train(train_X, train_y)
-        preds = np.stack([model.get_fitness(test_X) for model in self.models], axis=0)
-        self.weights = self.adapt_weights_with(preds, test_y)
+        fit_x, val_x, fit_y, val_y = sklearn.model_selection.train_test_split(
+            np.array(sequences), np.array(labels), test_size=self.adaptive_val_size)
+        for member in self.models:
+            member.train(fit_x, fit_y)
+        val_preds = np.stack([member.get_fitness(val_x) for member in self.models], axis=0)
+        self.weights = self.adapt_weights_with(val_preds, val_y)
 
     def _fitness_function(self, sequences: SEQUENCES_TYPE) -> np.ndarray:
-        if _device_members(self.models) and self.combine_with is _weighted_sum and len(sequences):
-            n = len(sequences)
-            for m in self.models:
-                m.cost += n                                          # members are scored through get_fitness (:98-100)
-            m0 = self.models[0]
-            seq_bytes = _native.sequences_to_bytes(sequences, L=m0.model.L)
-            nm, _ = m0._engine().score([m.native() for m in self.models], seq_bytes, m0._lut, want_matrix=True)
-            return m0._engine().ensemble_weighted_sum(nm, np.asarray(self.weights, np.float64))
-        scores = np.stack([model.get_fitness(sequences) for model in self.models], axis=1)
-        return self.combine_with(self.weights, scores)
+        fused = _device_members(self.models) and self.combine_with is _weighted_sum and len(sequences) > 0
+        if not fused:
+            stacked = np.stack([member.get_fitness(sequences) for member in self.models], axis=1)
+            return self.combine_with(self.weights, stacked)
+        for member in self.models:                      # each member is charged as by its own get_fitness (:98-100)
+            member.cost += len(sequences)
+        first = self.models[0]
+        engine = first._engine()
+        seq_bytes = _native.sequences_to_bytes(sequences, L=first.model.L)
+        scores, _ = engine.score([m.native() for m in self.models], seq_bytes, first._lut, want_matrix=True)
+        return engine.ensemble_weighted_sum(scores, np.asarray(self.weights, np.float64))

@@ -1,40 +1,39 @@
-"""`Landscape` base class -- same contract as flexs/landscape.py:9-45."""
+"""`Landscape`: the root of the plugin API (contract of flexs/landscape.py:9-45).
+
+A landscape maps sequences to fitness values and counts how many it has been asked about:
+`get_fitness` adds `len(sequences)` to `cost` and then defers to the subclass hook
+`_fitness_function`.  Explorers read and reset `cost` (flexs/explorer.py:126) and log `name`.
+"""
 import abc
 import os
 
-import numpy as np
+from flexs_amd.types import FITNESS_TYPE, SEQUENCES_TYPE
 
-from flexs_amd.types import SEQUENCES_TYPE
 
-_BaseLandscape = None
-if os.environ.get("FLEXS_AMD_BIND_FLEXS") == "1":      # become real flexs subclasses
-    import flexs as _flexs
+def _reference_class(attr):
+    """With FLEXS_AMD_BIND_FLEXS=1 the classes of this package ARE (subclasses of) the reference's,
+    so `isinstance(model, flexs.Ensemble)`-style checks in reference code hold."""
+    if os.environ.get("FLEXS_AMD_BIND_FLEXS") != "1":
+        return None
+    import flexs
 
-    _BaseLandscape = _flexs.Landscape
+    return getattr(flexs, attr)
 
-if _BaseLandscape is not None:
-    Landscape = _BaseLandscape
-else:
 
-    class Landscape(abc.ABC):
-        """
-        Base class for all landscapes and for `Model`.
+class _Landscape(abc.ABC):
+    def __init__(self, name: str):
+        self.name = name      # appears in the run-log metadata
+        self.cost = 0         # sequences scored so far
 
-        Attributes:
-            cost (int): Number of sequences whose fitness has been evaluated.
-            name (str): Human-readable name used when logging explorer runs.
-        """
+    @abc.abstractmethod
+    def _fitness_function(self, sequences: SEQUENCES_TYPE) -> FITNESS_TYPE:
+        """Subclass hook: score `sequences` (no bookkeeping here)."""
 
-        def __init__(self, name: str):
-            self.cost = 0
-            self.name = name
+    def get_fitness(self, sequences: SEQUENCES_TYPE) -> FITNESS_TYPE:
+        """Public entry point -- not meant to be overridden (flexs/landscape.py:33-35)."""
+        self.cost = self.cost + len(sequences)
+        return self._fitness_function(sequences)
 
-        @abc.abstractmethod
-        def _fitness_function(self, sequences: SEQUENCES_TYPE) -> np.ndarray:
-            pass
 
-        def get_fitness(self, sequences: SEQUENCES_TYPE) -> np.ndarray:
-            """Score sequences: `cost += len(sequences)` then `_fitness_function`
-            (flexs/landscape.py:29-45).  Not to be overridden."""
-            self.cost += len(sequences)
-            return self._fitness_function(sequences)
+Landscape = _reference_class("Landscape") or _Landscape
+Landscape.__doc__ = Landscape.__doc__ or "Base class of every landscape and model: `name`, `cost`, `get_fitness`."

@@ -1,36 +1,35 @@
-"""`Model` / `LandscapeAsModel` -- same contract as flexs/model.py:11-54."""
+"""`Model` (a landscape that can be trained) and `LandscapeAsModel` (a perfect model) --
+contract of flexs/model.py:11-54."""
 import abc
-import os
 from typing import Any, List
 
-import numpy as np
+from flexs_amd.landscape import Landscape, _reference_class
+from flexs_amd.types import FITNESS_TYPE, SEQUENCES_TYPE
 
-from flexs_amd.landscape import Landscape
-from flexs_amd.types import SEQUENCES_TYPE
 
-if os.environ.get("FLEXS_AMD_BIND_FLEXS") == "1":
-    import flexs as _flexs
+class _Model(Landscape, abc.ABC):
+    """Adds `train`, which the explorer calls once per round with everything measured so far
+    (flexs/explorer.py:157-160)."""
 
-    Model = _flexs.Model
-    LandscapeAsModel = _flexs.LandscapeAsModel
-else:
+    @abc.abstractmethod
+    def train(self, sequences: SEQUENCES_TYPE, labels: List[Any]):
+        """Update the model from measured (sequence, fitness) pairs."""
 
-    class Model(Landscape, abc.ABC):
-        """Landscape + `train` (flexs/model.py:11-27)."""
 
-        @abc.abstractmethod
-        def train(self, sequences: SEQUENCES_TYPE, labels: List[Any]):
-            pass
+class _LandscapeAsModel(_Model):
+    """The oracle itself behind the model interface (for experiments with a perfect surrogate)."""
 
-    class LandscapeAsModel(Model):
-        """Wrap a landscape as a perfect model (flexs/model.py:30-54)."""
+    def __init__(self, landscape: Landscape):
+        super().__init__(name="LandscapeAsModel=" + landscape.name)
+        self.landscape = landscape
 
-        def __init__(self, landscape: Landscape):
-            super().__init__(f"LandscapeAsModel={landscape.name}")
-            self.landscape = landscape
+    def train(self, sequences: SEQUENCES_TYPE, labels: List[Any]):
+        return None           # nothing to learn
 
-        def _fitness_function(self, sequences: SEQUENCES_TYPE) -> np.ndarray:
-            return self.landscape._fitness_function(sequences)
+    def _fitness_function(self, sequences: SEQUENCES_TYPE) -> FITNESS_TYPE:
+        # the wrapped landscape's cost is NOT charged (flexs/model.py:49-50 calls the private hook)
+        return self.landscape._fitness_function(sequences)
 
-        def train(self, sequences: SEQUENCES_TYPE, labels: List[Any]):
-            pass
+
+Model = _reference_class("Model") or _Model
+LandscapeAsModel = _reference_class("LandscapeAsModel") or _LandscapeAsModel
