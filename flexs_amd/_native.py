@@ -131,6 +131,25 @@ def make_lut(alphabet: str) -> np.ndarray:
     return lut
 
 
+def ragged_to_bytes(sequences, L: int) -> np.ndarray:
+    """Strings of any lengths <= L -> (N, L) uint8 rows, NUL-padded on the right: the row format of the
+    edit-distance entry points (fx_min_dist / fx_cache_*), which `editdistance.eval` semantics require to
+    take unequal lengths (noisy_abstract_model.py:51)."""
+    seqs = [str(s) for s in sequences]
+    out = np.zeros((len(seqs), L), np.uint8)
+    for i, s in enumerate(seqs):
+        if len(s) > L:
+            raise ValueError(f"sequence of length {len(s)} does not fit a row of {L} bytes")
+        try:
+            row = np.frombuffer(s.encode("latin-1"), np.uint8)
+        except UnicodeEncodeError:
+            raise ValueError("substring not found") from None
+        if (row == 0).any():
+            raise ValueError("NUL characters cannot be part of a sequence")
+        out[i, : len(s)] = row
+    return out
+
+
 def sequences_to_bytes(sequences, L: Optional[int] = None) -> np.ndarray:
     """list/tuple/ndarray of str -> contiguous (N, L) uint8 (latin-1 code points).
 

@@ -32,27 +32,35 @@ class NoisyAbstractModel(flexs_amd.Model):
         self._dev_keys = []               # python-side mirror of what was appended
 
     # ---------------------------------------------------------------- device cache sync
-    def _sync_device_cache(self, L: int):
+    @staticmethod
+    def _rows(seqs, L: int) -> np.ndarray:
+        """(n, L) byte rows; sequences shorter than the row are NUL-padded (ragged batches are legal for
+        `editdistance.eval`, noisy_abstract_model.py:51, even though explorers keep one length)."""
+        if all(len(s) == L for s in seqs):
+            return _native.sequences_to_bytes(seqs, L=L)
+        return _native.ragged_to_bytes(seqs, L)
+
+    def _sync_device_cache(self, min_row: int):
+        """Bring the device copy of `list(self.cache)` up to date; rows hold at least `min_row` bytes."""
+        import itertools
+
         keys = self.cache.keys()
         n = len(self._dev_keys)
-        stale = self._dev_cache is None or self._dev_cache.L != L or n > len(keys)
+        stale = self._dev_cache is None or n > len(keys)
         if not stale and n:
             # dict order is append-only unless the user deleted entries: spot-check the boundary
-            it = iter(keys)
-            first = next(it)
-            stale = first != self._dev_keys[0]
+            stale = next(iter(keys)) != self._dev_keys[0]
+        fresh = [str(k) for k in itertools.islice(keys, 0 if stale else n, None)]
+        need = max([min_row, 1] + [len(k) for k in fresh])
+        if not stale and need > self._dev_cache.L:          # a longer sequence than any before: wider rows
+            stale, fresh = True, [str(k) for k in keys]
         if stale:
-            self._dev_cache = _native.NativeCache(_native.Engine.get(self._device), L)
+            need = max([need] + [len(k) for k in fresh])
+            self._dev_cache = _native.NativeCache(_native.Engine.get(self._device), need)
             self._dev_keys = []
-            n = 0
-        if len(keys) > n:
-            import itertools
-
-            new = [str(k) for k in itertools.islice(keys, n, None)]
-            if any(len(k) != L for k in new):
-                raise ValueError("NoisyAbstractModel: cached sequences must all have the query length")
-            self._dev_cache.append(_native.sequences_to_bytes(new, L=L))
-            self._dev_keys.extend(new)
+        if fresh:
+            self._dev_cache.append(self._rows(fresh, self._dev_cache.L))
+            self._dev_keys.extend(fresh)
 
     def _get_min_distance(self, sequence):
         """noisy_abstract_model.py:42-60 for one query (kept for API parity)."""
@@ -62,9 +70,8 @@ class NoisyAbstractModel(flexs_amd.Model):
         return int(d[0]), nb[0]
 
     def _min_distances(self, sequences):
-        L = len(sequences[0])
-        self._sync_device_cache(L)
-        dist, arg = self._dev_cache.min_dist(_native.sequences_to_bytes(sequences, L=L), self._mode)
+        self._sync_device_cache(max(len(s) for s in sequences))
+        dist, arg = self._dev_cache.min_dist(self._rows(sequences, self._dev_cache.L), self._mode)
         return dist, [self._dev_keys[i] for i in arg]
 
     # ---------------------------------------------------------------- flexs.Model API

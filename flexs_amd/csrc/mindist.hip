@@ -8,6 +8,10 @@
 //     key = (d' << 32) | index,   d' = 0 if d == 1, 1 if d == 0, d otherwise
 // which is exactly the reference's loop: the FIRST entry at distance 1 wins
 // outright (early `return`, :53-54), otherwise the first strict minimum (:56-58).
+// Rows are L bytes; a sequence shorter than L is NUL-padded (editdistance.eval takes strings of any
+// two lengths, noisy_abstract_model.py:51): the pattern length is the query's first NUL, the text stops
+// at the cache row's first NUL.  Hamming compares the padded rows byte-wise (a pad against a letter
+// counts as a mismatch).
 // Integer VALU bound; HBM traffic is the cache once per query row (L2-resident).
 #include "fx_common.h"
 #include "myers.h"
@@ -26,16 +30,20 @@ __global__ void __launch_bounds__(256) k_min_dist(int mode, const uint8_t* __res
     const int64_t qi = blockIdx.y;
     for (int i = tid; i < L; i += 256) qs[i] = q[qi * L + i];
     __syncthreads();
+    int m = L;                                         // query length (every thread finds it itself)
     {   // thread c builds the masks of byte value c
         uint64_t mk[W];
 #pragma unroll
         for (int w = 0; w < W; ++w) mk[w] = 0;
-        for (int i = 0; i < L; ++i)
-            if (qs[i] == tid) {
+        for (int i = 0; i < L; ++i) {
+            const int ch = qs[i];
+            if (ch == 0) { m = i; break; }             // NUL-padded (ragged) query
+            if (ch == tid) {
 #pragma unroll
                 for (int w = 0; w < W; ++w)
                     if ((i >> 6) == w) mk[w] |= 1ull << (i & 63);
             }
+        }
 #pragma unroll
         for (int w = 0; w < W; ++w) peq[tid * W + w] = mk[w];
     }
@@ -52,8 +60,8 @@ __global__ void __launch_bounds__(256) k_min_dist(int mode, const uint8_t* __res
             d = 0;
             for (int i = 0; i < L; ++i) d += (t[i] != qs[i]);
         } else {
-            d = fx_myers_distance<W>(
-                L, L, [&](int ch, int w) { return peq[ch * W + w]; }, [&](int i) { return (int)t[i]; });
+            d = fx_myers_distance<W, true>(
+                m, L, [&](int ch, int w) { return peq[ch * W + w]; }, [&](int i) { return (int)t[i]; });
         }
         const unsigned dp = d == 1 ? 0u : (d == 0 ? 1u : (unsigned)d);
         const unsigned long long key = ((unsigned long long)dp << 32) | (unsigned long long)c;
@@ -83,16 +91,20 @@ __global__ void __launch_bounds__(256) k_distances(int mode, const uint8_t* __re
     const int64_t qi = blockIdx.y;
     for (int i = tid; i < L; i += 256) qs[i] = q[qi * L + i];
     __syncthreads();
+    int m = L;
     {
         uint64_t mk[W];
 #pragma unroll
         for (int w = 0; w < W; ++w) mk[w] = 0;
-        for (int i = 0; i < L; ++i)
-            if (qs[i] == tid) {
+        for (int i = 0; i < L; ++i) {
+            const int ch = qs[i];
+            if (ch == 0) { m = i; break; }             // NUL-padded (ragged) query
+            if (ch == tid) {
 #pragma unroll
                 for (int w = 0; w < W; ++w)
                     if ((i >> 6) == w) mk[w] |= 1ull << (i & 63);
             }
+        }
 #pragma unroll
         for (int w = 0; w < W; ++w) peq[tid * W + w] = mk[w];
     }
@@ -107,8 +119,8 @@ __global__ void __launch_bounds__(256) k_distances(int mode, const uint8_t* __re
             d = 0;
             for (int i = 0; i < L; ++i) d += (t[i] != qs[i]);
         } else {
-            d = fx_myers_distance<W>(
-                L, L, [&](int ch, int w) { return peq[ch * W + w]; }, [&](int i) { return (int)t[i]; });
+            d = fx_myers_distance<W, true>(
+                m, L, [&](int ch, int w) { return peq[ch * W + w]; }, [&](int i) { return (int)t[i]; });
         }
         out[qi * C + c] = (uint8_t)(d > 255 ? 255 : d);
     }

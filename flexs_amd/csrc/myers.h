@@ -35,9 +35,10 @@ FX_HD int fx_myers_block(uint64_t& Pv, uint64_t& Mv, uint64_t Eq, int hin, int t
 // Levenshtein(pattern, text) given the pattern's match masks.
 //   peq(c, w): 64-bit mask, bit i set iff pattern[64*w + i] == c
 //   text(i):   i-th text byte
-template <int W, typename PeqFn, typename TextFn>
+// NULTERM: the text occupies a row of n bytes and ends at its first NUL byte (ragged rows are
+// NUL-padded; no FLEXS alphabet contains NUL), so n is an upper bound of the text length.
+template <int W, bool NULTERM = false, typename PeqFn, typename TextFn>
 FX_HD int fx_myers_distance(int m, int n, PeqFn peq, TextFn text) {
-    if (m == 0) return n;
     uint64_t Pv[W], Mv[W];
     const int nw = (m + 63) >> 6;
 #pragma unroll
@@ -46,12 +47,13 @@ FX_HD int fx_myers_distance(int m, int n, PeqFn peq, TextFn text) {
     const int top_last = (m - 1) & 63;
     for (int i = 0; i < n; ++i) {
         const int c = text(i);
+        if (NULTERM && c == 0) break;
         int h = 1;                                   // D[0][j] - D[0][j-1] = +1 (global alignment)
 #pragma unroll
         for (int w = 0; w < W; ++w) {
             if (w < nw) h = fx_myers_block(Pv[w], Mv[w], peq(c, w), h, (w == nw - 1) ? top_last : 63);
         }
-        score += h;
+        score += h;                                  // m == 0: no block runs, h stays +1 -> score = |text|
     }
     return score;
 }

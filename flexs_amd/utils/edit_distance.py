@@ -12,6 +12,8 @@ from flexs_amd import _native
 
 class SeenSequences:
     def __init__(self, seq_len: int, distance: str = "levenshtein", device: int = None):
+        """`seq_len` = row width on the device = the longest sequence that can be stored or queried
+        (shorter ones are NUL-padded; `editdistance.eval` does not need equal lengths)."""
         self._L = seq_len
         self._mode = _native.FX_LEVENSHTEIN if distance == "levenshtein" else _native.FX_HAMMING
         self._cache = _native.NativeCache(_native.Engine.get(device), seq_len)
@@ -34,10 +36,10 @@ class SeenSequences:
             return
         self._index[seq] = len(self._fitness)
         self._fitness.append(fitness)
-        self._cache.append(_native.sequences_to_bytes([seq], L=self._L))
+        self._cache.append(_native.ragged_to_bytes([seq], self._L))
 
     def distances(self, seq: str) -> np.ndarray:
-        return self._cache.distances(_native.sequences_to_bytes([seq], L=self._L), self._mode)[0]
+        return self._cache.distances(_native.ragged_to_bytes([seq], self._L), self._mode)[0]
 
     def density(self, seq: str, dist_radius: int = 2):
         """dyna_ppo.py:106-114: `dens += all_seqs[s] / dist` for 0 < dist <= radius, in insertion order."""

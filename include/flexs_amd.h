@@ -149,7 +149,10 @@ int fx_argmax_decode(fx_engine *e, const double *one_hot, int64_t P, int L, int 
  * queries against C cache keys kept in insertion order: dist[i] = min edit
  * distance, argmin[i] = FIRST cache index attaining it (the reference's
  * early-exit-at-1 + strict-< loop).  C == 0 -> dist 0, argmin -1
- * (noisy_abstract_model.py:44-45).  All sequences have length L. */
+ * (noisy_abstract_model.py:44-45).  Rows are L bytes; a sequence shorter than L is
+ * NUL-padded on the right (`editdistance.eval` accepts two strings of any lengths,
+ * noisy_abstract_model.py:51; no FLEXS alphabet contains NUL).  FX_HAMMING compares the
+ * padded rows byte-wise.  L <= 256. */
 int fx_min_dist(fx_engine *e, int mode, const uint8_t *queries, int64_t Q, const uint8_t *cache,
                 int64_t C, int L, int32_t *dist, int64_t *argmin);
 /* Device-resident, append-only cache (self.cache keys, noisy_abstract_model.py:40,67,99). */

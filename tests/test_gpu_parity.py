@@ -349,6 +349,78 @@ def test_min_dist_vs_oracle(eng, L, nsym, C, Q):
     assert (d0 == 0).all() and (a0 == -1).all()      # noisy_abstract_model.py:44-45
 
 
+def _ragged_strings(rng, n, lo, hi, alpha, base=None):
+    out = []
+    for _ in range(n):
+        if base is not None and rng.random() < 0.7:               # indel / substitution variants of one parent
+            s = list(base)
+            for _ in range(int(rng.integers(0, 4))):
+                r, i = rng.random(), int(rng.integers(0, max(len(s), 1)))
+                if r < 0.4 and len(s) > lo:
+                    del s[i]
+                elif r < 0.8 and len(s) < hi:
+                    s.insert(i, alpha[int(rng.integers(0, len(alpha)))])
+                elif s:
+                    s[i] = alpha[int(rng.integers(0, len(alpha)))]
+            out.append("".join(s))
+        else:
+            out.append("".join(alpha[i] for i in rng.integers(0, len(alpha), int(rng.integers(lo, hi + 1)))))
+    return out
+
+
+@pytest.mark.parametrize("lo,hi,alpha,C,Q", [(0, 12, "TGCA", 400, 120), (50, 80, s_utils.AAS, 300, 40),
+                                             (120, 200, s_utils.AAS, 150, 20), (1, 256, "UGCA", 60, 12)])
+def test_min_dist_ragged_lengths(eng, lo, hi, alpha, C, Q):
+    """`editdistance.eval` takes two strings of any lengths (noisy_abstract_model.py:51): NUL-padded rows."""
+    rng = np.random.default_rng(lo * 31 + hi)
+    base = "".join(alpha[i] for i in rng.integers(0, len(alpha), (lo + hi) // 2))
+    keys = list(dict.fromkeys(_ragged_strings(rng, C, lo, hi, alpha, base)))
+    queries = _ragged_strings(rng, Q, lo, hi, alpha, base) + [keys[len(keys) // 2], keys[-1][:-1] if keys[-1] else "A"]
+    queries = [q for q in queries if len(q) <= hi]
+    want = [ref_np.min_distance(q, keys, c_oracle.levenshtein) for q in queries]
+    for row in (hi, min(256, hi + 7)):                               # row wider than the longest sequence too
+        cache = _native.NativeCache(eng, row)
+        cache.append(_native.ragged_to_bytes(keys[: len(keys) // 2], row))
+        cache.append(_native.ragged_to_bytes(keys[len(keys) // 2:], row))
+        d, a = cache.min_dist(_native.ragged_to_bytes(queries, row), 0)
+        assert [(int(x), keys[i]) for x, i in zip(d, a)] == want
+        full = cache.distances(_native.ragged_to_bytes(queries[:6], row), 0)
+        assert [[int(v) for v in r] for r in full] == [[min(c_oracle.levenshtein(q, k), 255) for k in keys] for q in queries[:6]]
+    d, a = eng.min_dist(_native.ragged_to_bytes(queries, hi), _native.ragged_to_bytes(keys, hi), 0)
+    assert [(int(x), keys[i]) for x, i in zip(d, a)] == want
+
+
+def test_nam_ragged_lengths_match_oracle(eng):
+    """NoisyAbstractModel over sequences of unequal lengths (insertions / deletions), including a query
+    longer than anything cached (forces wider device rows): same floats, cache order and RNG position
+    as the restated reference loop."""
+    rng = np.random.default_rng(11)
+    alpha = "UGCA"
+    base = "".join(alpha[i] for i in rng.integers(0, 4, 14))
+    pool = list(dict.fromkeys(_ragged_strings(rng, 500, 9, 18, alpha, base)))
+    table = {s: float(rng.random()) for s in pool + ["".join(alpha[i] for i in rng.integers(0, 4, 30))]}
+    long_one = list(table)[-1]
+
+    class Table(flexs_amd.Landscape):
+        def __init__(self):
+            super().__init__("table")
+
+        def _fitness_function(self, seqs):
+            return np.array([table[str(s)] for s in seqs])
+
+    outs = []
+    for cls in (bm.NoisyAbstractModel, ref_np.NoisyAbstractModelOracle):
+        land = Table()
+        np.random.seed(3)
+        nam = cls(land, 0.8)
+        nam.train(pool[:40], np.array([table[s] for s in pool[:40]]))
+        o = [nam.get_fitness(pool[40 + 60 * i: 100 + 60 * i]) for i in range(4)]
+        o.append(nam.get_fitness([long_one] + pool[300:330]))
+        o.append(nam.get_fitness(pool[20:120]))
+        outs.append((np.concatenate(o), land.cost, nam.cost, list(nam.cache), float(np.random.random())))
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1:] == outs[1][1:]
+
+
 def test_min_dist_known_answers(eng, golden_dir):
     known = json.load(open(os.path.join(golden_dir, "edit_distance_known.json")))["known"]
     for k in known:

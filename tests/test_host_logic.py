@@ -260,3 +260,15 @@ def test_bench_report_contract():
     assert rf["flop_per_launch"] == 2.0 * 48628 * 3 * 100_000            # 97 256 FLOP per sequence-member
     assert rf["achieved"] == pytest.approx(rf["flop_per_launch"] / 0.2e-3 / 1e12) and rf["frac"] == pytest.approx(rf["achieved"] / 157.3)
     assert rf["algorithmic_bytes_per_launch"] == (8 + 12) * 100_000
+
+
+def test_ragged_rows_for_edit_distance():
+    """Row format of the edit-distance entry points: NUL-padded, strict about length and byte range."""
+    from flexs_amd import _native
+
+    rows = _native.ragged_to_bytes(["ACG", "", "ACGTAC"], 6)
+    assert rows.dtype == np.uint8 and rows.tolist() == [[65, 67, 71, 0, 0, 0], [0] * 6, [65, 67, 71, 84, 65, 67]]
+    assert _native.ragged_to_bytes([], 4).shape == (0, 4)
+    for bad in (["ACGTACG"], ["A\x00C"], ["A\u0394"]):
+        with pytest.raises(ValueError):
+            _native.ragged_to_bytes(bad, 6)
