@@ -22,6 +22,13 @@ ring pipelining.
 `score_fn(member_indices, seq_bytes) -> (n, len(member_indices)) float32` is
 injected so the sharding / gather logic is testable on CPU with gloo; the
 default scores on this rank's GPU through the engine.
+
+The NoisyAbstractModel neighbour search shards over the CACHE instead
+(`ShardedCache`): global entry i lives on rank i % world, every rank runs K4
+over its entries for all Q queries and ONE all-gather of Q 8-byte keys
+`(remapped distance << 32 | global index)` followed by an element-wise min
+reproduces the reference's "first entry at distance 1, else first strict
+minimum" rule, because the global index encodes insertion order.
 """
 from __future__ import annotations
 
@@ -149,3 +156,79 @@ class DistributedEnsemble(flexs_amd.Model):
         if self.combine_with is _default_combine and self._score_fn == self._score_on_engine and n:
             return _native.Engine.get(getattr(self.models[0], "_device", None)).ensemble_mean(scores)   # K3 on this GPU
         return self.combine_with(scores)
+
+
+# ---------------------------------------------------------------------------
+# NoisyAbstractModel: cache-sharded neighbour search
+# ---------------------------------------------------------------------------
+_NO_ENTRY = np.iinfo(np.int64).max
+
+
+def _remap(dist_: np.ndarray) -> np.ndarray:
+    """Distance 1 sorts first, then 0, then 2, 3, ... (noisy_abstract_model.py:53-58: a distance-1
+    entry returns immediately, otherwise the first strict minimum wins)."""
+    d = dist_.astype(np.int64)
+    return np.where(d == 1, 0, np.where(d == 0, 1, d))
+
+
+class ShardedCache:
+    """Drop-in for `_native.NativeCache` whose rows are dealt round-robin to the ranks of `group`
+    (SPMD: every rank appends the same rows and asks the same queries)."""
+
+    def __init__(self, row_bytes: int, group=None, local_factory: Optional[Callable] = None, device: int = None):
+        self.L = row_bytes
+        self.group = group
+        self.rank, self.world = _world(group)
+        make = local_factory or (lambda L: _native.NativeCache(_native.Engine.get(device), L))
+        self._local = make(row_bytes)
+        self._size = 0                                   # global number of entries
+
+    def __len__(self):
+        return self._size
+
+    def append(self, keys_u8: np.ndarray):
+        k = np.ascontiguousarray(keys_u8, np.uint8)
+        first = (self.rank - self._size) % self.world    # first row of this block that belongs to this rank
+        self._local.append(k[first:: self.world])
+        self._size += k.shape[0]
+
+    def min_dist(self, queries: np.ndarray, mode: int = _native.FX_LEVENSHTEIN):
+        q = np.ascontiguousarray(queries, np.uint8)
+        Q = q.shape[0]
+        if self._size == 0:                              # noisy_abstract_model.py:44-45
+            return np.zeros(Q, np.int32), np.full(Q, -1, np.int64)
+        keys = np.full(Q, _NO_ENTRY, np.int64)
+        if len(self._local) and Q:
+            d, a = self._local.min_dist(q, mode)
+            keys = (_remap(d) << 32) | (a.astype(np.int64) * self.world + self.rank)
+        if self.world > 1 and Q:
+            dev = _gather_device(self.group)
+            send = torch.from_numpy(keys).to(dev)
+            recv = torch.empty((self.world, Q), dtype=torch.int64, device=dev)
+            if dev.type == "cuda":
+                dist.all_gather_into_tensor(recv.view(-1), send, group=self.group)
+            else:
+                dist.all_gather(list(recv.unbind(0)), send, group=self.group)
+            keys = recv.min(dim=0).values.cpu().numpy()
+        dp = keys >> 32
+        return np.where(dp == 0, 1, np.where(dp == 1, 0, dp)).astype(np.int32), keys & 0xFFFFFFFF
+
+
+def ShardedNoisyAbstractModel(landscape, signal_strength: float = 0.9, distance: str = "levenshtein", group=None,
+                              local_factory: Optional[Callable] = None, blend_fn: Optional[Callable] = None,
+                              device: int = None):
+    """`NoisyAbstractModel` whose O(Q*C) neighbour search is split over the ranks of `group`; values,
+    cache order, landscape cost and RNG stream are those of the single-GPU model on every rank.
+    `local_factory` / `blend_fn` replace the two device steps (gloo tests on CPU)."""
+    from flexs_amd.baselines.models.noisy_abstract_model import NoisyAbstractModel
+
+    class _Sharded(NoisyAbstractModel):
+        def _new_device_cache(self, row_bytes: int):
+            return ShardedCache(row_bytes, group=group, local_factory=local_factory, device=device)
+
+        def _blend(self, signal, noise, dist_, alpha_tab):
+            if blend_fn is not None:
+                return blend_fn(signal, noise, dist_, alpha_tab)
+            return super()._blend(signal, noise, dist_, alpha_tab)
+
+    return _Sharded(landscape, signal_strength, distance=distance, device=device)

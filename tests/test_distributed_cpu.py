@@ -47,6 +47,18 @@ def table_score(member_idx, seq_bytes):
         if member_idx else np.zeros((s.shape[0], 0), np.float32)
 
 
+def _collect(q, procs):
+    results = []
+    for _ in procs:
+        r = q.get(timeout=120)
+        assert len(r) > 2, f"rank {r[0]} failed: {r[1]}"
+        results.append(r)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    return sorted(results, key=lambda t: t[0])
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -71,6 +83,9 @@ def _worker(rank, world, port, mode, M, n, q):
         out = ens.get_fitness(seqs)
         mat = fd.DistributedEnsemble(members, mode=mode, score_fn=score_fn, combine_with=lambda x: x).get_fitness(seqs)
         q.put((rank, out, mat, called, ens.cost, [m.cost for m in members]))
+    except BaseException as exc:      # surface worker failures at once instead of after the queue timeout
+        q.put((rank, repr(exc)))
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -84,10 +99,7 @@ def test_world2_gloo(mode, M, n):
     procs = [ctx.Process(target=_worker, args=(r, world, port, mode, M, n, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
-    for p in procs:
-        p.join(30)
-        assert p.exitcode == 0
+    results = _collect(q, procs)
     rng = np.random.default_rng(0)
     seq_bytes = np.frombuffer(b"TGCA", np.uint8)[rng.integers(0, 4, (n, 8))]
     want_mat = table_score(list(range(M)), seq_bytes)
@@ -101,3 +113,132 @@ def test_world2_gloo(mode, M, n):
         else:
             lo, hi = fd.shard_range(n, rank, world)
             assert idx == list(range(M)) and rows == hi - lo
+
+
+# ---------------------------------------------------------------- cache-sharded neighbour search
+class OracleLocalCache:
+    """CPU stand-in for this rank's device key store (the C restatement of the K4 rule)."""
+
+    def __init__(self, L):
+        self.L = L
+        self.rows = np.zeros((0, L), np.uint8)
+
+    def __len__(self):
+        return self.rows.shape[0]
+
+    def append(self, rows):
+        self.rows = np.concatenate([self.rows, rows.reshape(-1, self.L)])
+
+    def min_dist(self, q, mode):
+        from oracle import c_oracle
+
+        return c_oracle.min_dist(q, self.rows, mode)
+
+
+def _nam_inputs():
+    rng = np.random.default_rng(4)
+    base = rng.integers(0, 4, 14)
+    pool = []
+    for _ in range(700):
+        s = base.copy()
+        m = rng.random(14) < 0.12
+        s[m] = rng.integers(0, 4, m.sum())
+        if rng.random() < 0.3:
+            s = np.roll(s, 1)
+        pool.append("".join("UGCA"[i] for i in s))
+    pool = list(dict.fromkeys(pool))
+    table = {s: float(rng.random()) for s in pool}
+    return pool, table
+
+
+class TableLandscape(flexs_amd.Landscape):
+    def __init__(self, table):
+        super().__init__("table")
+        self.table = table
+
+    def _fitness_function(self, seqs):
+        return np.array([self.table[str(s)] for s in seqs])
+
+
+def _blend_f64(signal, noise, d, alpha_tab):
+    a = alpha_tab[d]                                    # noisy_abstract_model.py:93-94 in float64
+    return a * signal + (1 - a) * noise
+
+
+def _nam_trace(nam, land, pool, table):
+    np.random.seed(9)
+    nam.train(pool[:33], np.array([table[s] for s in pool[:33]]))
+    outs = [nam.get_fitness(pool[33 + 57 * i: 90 + 57 * i]) for i in range(4)]
+    outs.append(nam.get_fitness(pool[10:140]))
+    return np.concatenate(outs), land.cost, nam.cost, list(nam.cache), float(np.random.random())
+
+
+def _cache_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(1)
+        keys = rng.integers(65, 69, (501, 9)).astype(np.uint8)
+        keys[100] = keys[7]                                         # duplicate: the earlier index must win
+        queries = keys[rng.integers(0, 501, 80)].copy()
+        mut = rng.random(queries.shape) < 0.15
+        queries[mut] = rng.integers(65, 69, mut.sum())
+        sc = fd.ShardedCache(9, local_factory=OracleLocalCache)
+        empty = sc.min_dist(queries)
+        got, sizes = [], []
+        for lo, hi in ((0, 1), (1, 2), (2, 9), (9, 300), (300, 501)):   # odd block sizes: round-robin must stay aligned
+            sc.append(keys[lo:hi])
+            got.append([sc.min_dist(queries, mode) for mode in (0, 1)])
+            sizes.append((len(sc), len(sc._local)))
+        pool, table = _nam_inputs()
+        land = TableLandscape(table)
+        nam = fd.ShardedNoisyAbstractModel(land, 0.85, local_factory=OracleLocalCache, blend_fn=_blend_f64)
+        q.put((rank, empty, got, sizes, _nam_trace(nam, land, pool, table)))
+    except BaseException as exc:
+        q.put((rank, repr(exc)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_sharded_cache_and_nam():
+    from oracle import c_oracle, ref_np
+
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cache_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = _collect(q, procs)
+    rng = np.random.default_rng(1)
+    keys = rng.integers(65, 69, (501, 9)).astype(np.uint8)
+    keys[100] = keys[7]
+    queries = keys[rng.integers(0, 501, 80)].copy()
+    mut = rng.random(queries.shape) < 0.15
+    queries[mut] = rng.integers(65, 69, mut.sum())
+    pool, table = _nam_inputs()
+    land = TableLandscape(table)
+    want_trace = _nam_trace(ref_np.NoisyAbstractModelOracle(land, 0.85), land, pool, table)
+    for rank, empty, got, sizes, trace in results:
+        assert (empty[0] == 0).all() and (empty[1] == -1).all()
+        for (lo, hi), per_mode, (n_global, n_local) in zip(((0, 1), (1, 2), (2, 9), (9, 300), (300, 501)), got, sizes):
+            assert n_global == hi and n_local == len(range(rank, hi, world))
+            for mode, (d, a) in enumerate(per_mode):
+                d_want, a_want = c_oracle.min_dist(queries, keys[:hi], mode)
+                assert np.array_equal(d, d_want) and np.array_equal(a, a_want), (rank, hi, mode)
+        assert np.array_equal(trace[0], want_trace[0]) and trace[1:] == want_trace[1:]
+
+
+def test_sharded_cache_single_process():
+    """No process group: world = 1, the sharded store degenerates to the local one."""
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(2)
+    keys = rng.integers(65, 69, (200, 7)).astype(np.uint8)
+    sc = fd.ShardedCache(7, local_factory=OracleLocalCache)
+    sc.append(keys[:50]); sc.append(keys[50:])
+    d, a = sc.min_dist(keys[::3])
+    d_want, a_want = c_oracle.min_dist(keys[::3], keys, 0)
+    assert np.array_equal(d, d_want) and np.array_equal(a, a_want)
