@@ -27,7 +27,7 @@ faulthandler.enable()
 L, ALPHABET, F, H, K, M, BATCH = 8, "TGCA", 32, 100, 5, 3, 100_000
 
 
-def cpu_baseline(budget_s=12.0, hard_timeout_s=150.0):
+def cpu_baseline(budget_s=12.0, hard_timeout_s=150.0, nam=False):
     """Reference-style CPU path (oracle/cpu_baseline_cli.py -> oracle/torch_twin.py),
     timed on a bounded sample of the same workload in a child process with a hard
     timeout, so that the bench line is always printed.  Checker code: used ONLY here."""
@@ -35,7 +35,7 @@ def cpu_baseline(budget_s=12.0, hard_timeout_s=150.0):
 
     cmd = [sys.executable, "-m", "oracle.cpu_baseline_cli", "--L", str(L), "--alphabet", ALPHABET,
            "--filters", str(F), "--hidden", str(H), "--kernel", str(K), "--members", str(M),
-           "--sample", "50000", "--budget", str(budget_s)]
+           "--sample", "50000", "--budget", str(budget_s)] + (["--nam"] if nam else [])
     try:
         r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=hard_timeout_s)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-nam", action="store_true",
+                    help="cpu_baseline additionally times the NoisyAbstractModel CPU path (adds ~20 s)")
     ap.add_argument("--variant", type=int, default=0, help="cnn kernel variant (0 = auto)")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--reserve-cus", type=int, default=0,
@@ -223,7 +225,7 @@ def main():
         assert np.array_equal(np.mean(got_nm, axis=1), got_mean), "device mean is not np.mean bit-for-bit"
         out = make_report(world, N, args.steps, args.warmup, elapsed, host_issue_s, kern_ms, use_dist)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(nam=args.cpu_nam)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -65,6 +65,7 @@ SIGNATURES = {
     "fx_table_create": (C.c_int, [_vp, _vp, C.c_int64, C.POINTER(_vp)]),
     "fx_table_destroy": (C.c_int, [_vp]),
     "fx_table_lookup": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _u8p, C.c_int, _vp]),
+    "fx_table_additive": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _u8p, C.c_int, _vp]),
     "fx_nam_combine": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "fx_debug_packed_size": (C.c_int64, [C.c_int] * 6),
     "fx_debug_pack_layout": (C.c_int, [C.c_int] * 6 + [_i64p]),
@@ -410,13 +411,15 @@ class NativeCache:
 
 
 class NativeTable:
-    """Device-resident look-up landscape: fitness = table[packed k-mer]."""
+    """Device-resident look-up landscape: fitness = table[packed k-mer] (`lookup`), or a
+    per-position sum over an (L, ncol) table (`additive_sum`)."""
 
-    def __init__(self, engine: Engine, table: np.ndarray, alphabet: str, bits: int):
+    def __init__(self, engine: Engine, table: np.ndarray, alphabet: str, bits: int = 0, lut: np.ndarray = None):
         self.engine = engine
         self.bits = bits
-        self.lut = make_lut(alphabet)
-        t = np.ascontiguousarray(table, np.float64)
+        self.lut = make_lut(alphabet) if lut is None else np.ascontiguousarray(lut, np.uint8)
+        self.shape = np.shape(table)
+        t = np.ascontiguousarray(table, np.float64).ravel()
         h = _vp()
         engine.check(engine._lib.fx_table_create(engine.handle, _ptr(t), t.shape[0], C.byref(h)))
         self.handle = h
@@ -427,6 +430,18 @@ class NativeTable:
         if b.shape[0]:
             self.engine.check(self.engine._lib.fx_table_lookup(self.handle, _ptr(b), b.shape[0], b.shape[1],
                                                                self.lut.ctypes.data_as(_u8p), self.bits, _ptr(out)))
+        return out
+
+    def additive_sum(self, seq_bytes: np.ndarray) -> np.ndarray:
+        """out[n] = sum_i table[i, lut[seq[n, i]]], float64, accumulated in position order."""
+        b = np.ascontiguousarray(seq_bytes, np.uint8)
+        L, ncol = self.shape
+        if b.ndim != 2 or (b.shape[0] and b.shape[1] != L):
+            raise ValueError(f"additive table expects rows of {L} bytes")
+        out = np.empty(b.shape[0], np.float64)
+        if b.shape[0]:
+            self.engine.check(self.engine._lib.fx_table_additive(self.handle, _ptr(b), b.shape[0], L,
+                                                                 self.lut.ctypes.data_as(_u8p), ncol, _ptr(out)))
         return out
 
     def __del__(self):

@@ -623,6 +623,27 @@ int fx_table_lookup(fx_table* t, const uint8_t* ascii, int64_t N, int L, const u
     return FX_OK;
 }
 
+int fx_table_additive(fx_table* t, const uint8_t* ascii, int64_t N, int L, const uint8_t lut[256], int ncol, double* out) {
+    if (!t || N < 0 || L < 1 || !lut || ncol < 1 || ncol > 256) return FX_EINVAL;
+    fx_engine* e = t->eng;
+    if ((int64_t)L * ncol != t->len) return fx_fail(e, FX_ESHAPE, "additive table must hold L x ncol entries");
+    for (int c = 0; c < 256; ++c)
+        if (lut[c] >= ncol) return fx_fail(e, FX_EINVAL, "additive table: lut entry outside [0, ncol)");
+    if (N == 0) return FX_OK;
+    if (!ascii || !out) return fx_fail(e, FX_EINVAL, "null buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    void *d_in = nullptr, *d_out = nullptr;
+    int rc;
+    if ((rc = fx_scratch(e, 0, (size_t)N * L + 16, &d_in))) return rc;
+    if ((rc = fx_scratch(e, 1, (size_t)N * 8, &d_out))) return rc;
+    FX_HIP(e, hipMemcpyAsync(d_in, ascii, (size_t)N * L, hipMemcpyHostToDevice, e->stream));
+    if ((rc = fx_upload_lut(e, lut))) return rc;
+    if ((rc = fx_launch_additive_sum(e, t->d_table, L, ncol, (const uint8_t*)d_in, N, (double*)d_out))) return rc;
+    FX_HIP(e, hipMemcpyAsync(out, d_out, (size_t)N * 8, hipMemcpyDeviceToHost, e->stream));
+    FX_HIP(e, hipStreamSynchronize(e->stream));
+    return FX_OK;
+}
+
 int fx_nam_combine(fx_engine* e, int64_t Q, const double* signal, const double* noise, const int32_t* d,
                    const double* alpha_tab, int n_tab, double* out) {
     if (!e || Q < 0 || n_tab < 1) return FX_EINVAL;

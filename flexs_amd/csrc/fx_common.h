@@ -151,6 +151,8 @@ int fx_launch_min_dist(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, co
                        int64_t C, int L, unsigned long long* d_keys);
 int fx_launch_distances(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, const uint8_t* d_cache, int64_t C,
                         int L, uint8_t* d_out);
+int fx_launch_additive_sum(fx_engine* e, const double* d_table, int L, int ncol, const uint8_t* d_ascii, int64_t N,
+                           double* d_out);
 int fx_launch_table_lookup(fx_engine* e, const double* d_table, int64_t len, const uint8_t* d_ascii, int64_t N,
                            int L, int bits, double* d_out);
 int fx_launch_min_dist_finish(fx_engine* e, const unsigned long long* d_keys, int64_t Q, int64_t C,

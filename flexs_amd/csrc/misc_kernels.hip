@@ -196,6 +196,36 @@ __global__ void k_table_lookup(const double* __restrict__ table, int64_t len, co
     }
 }
 
+// ---- additive landscape (additive_aav_packaging.py:101-107): out[n] = sum over positions, IN ORDER, of
+// table[i][column(seq[n][i])] in float64 (one rounding per add, like the Python `+=` loop); residues a
+// position has no entry for map to an all-zero column.  A workgroup stages S whole rows (S*L bytes, one
+// contiguous 16-byte-aligned span) into LDS with coalesced loads; thread t then walks row t.
+__global__ void __launch_bounds__(256) k_additive_sum(const double* __restrict__ table, int L, int ncol,
+                                                      const uint8_t* __restrict__ ascii, const uint8_t* __restrict__ lut,
+                                                      int64_t N, int S, double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t tile[];
+    __shared__ uint8_t slut[256];
+    const int tid = threadIdx.x;
+    slut[tid] = lut[tid];
+    for (int64_t s0 = (int64_t)blockIdx.x * S; s0 < N; s0 += (int64_t)gridDim.x * S) {
+        const int ns = (int)(N - s0 < S ? N - s0 : S);
+        const int64_t nbytes = (int64_t)ns * L;
+        const uint8_t* src = ascii + s0 * L;
+        __syncthreads();
+        const int64_t nvec = nbytes >> 4;
+        for (int64_t v = tid; v < nvec; v += 256)
+            reinterpret_cast<uint4*>(tile)[v] = reinterpret_cast<const uint4*>(src)[v];
+        for (int64_t b = (nvec << 4) + tid; b < nbytes; b += 256) tile[b] = src[b];
+        __syncthreads();
+        if (tid < ns) {
+            const uint8_t* row = tile + (size_t)tid * L;
+            double acc = 0.0;
+            for (int i = 0; i < L; ++i) acc = __dadd_rn(acc, table[(int64_t)i * ncol + slut[row[i]]]);
+            out[s0 + tid] = acc;
+        }
+    }
+}
+
 // ---- test hook: ONE v_mfma_f32_16x16x4_f32 on caller-supplied per-lane operands, so the
 // operand / result lane layout the scoring kernels rely on is checked on the real hardware.
 __global__ void k_mfma_probe(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
@@ -221,6 +251,19 @@ int fx_launch_table_lookup(fx_engine* e, const double* d_table, int64_t len, con
     if (N == 0) return FX_OK;
     dim3 grid(grid_for(N, 256, e->num_cus)), block(256);
     hipLaunchKernelGGL(k_table_lookup, grid, block, 0, e->stream, d_table, len, d_ascii, e->d_lut, N, L, bits, d_out);
+    FX_HIP(e, hipGetLastError());
+    return FX_OK;
+}
+
+int fx_launch_additive_sum(fx_engine* e, const double* d_table, int L, int ncol, const uint8_t* d_ascii, int64_t N,
+                           double* d_out) {
+    if (N == 0) return FX_OK;
+    if (L < 1 || L > 3072) return fx_fail(e, FX_EUNSUPPORTED, "additive landscape: sequence length must be 1..3072");
+    int S = (49152 / L) & ~15;                        // rows per tile: whole rows, 16-byte-aligned span, <= 48 KiB
+    if (S > 256) S = 256;
+    if (S < 16) S = 16;
+    dim3 grid(grid_for(N, S, e->num_cus)), block(256);
+    hipLaunchKernelGGL(k_additive_sum, grid, block, (size_t)S * L, e->stream, d_table, L, ncol, d_ascii, e->d_lut, N, S, d_out);
     FX_HIP(e, hipGetLastError());
     return FX_OK;
 }

@@ -186,6 +186,13 @@ int fx_table_create(fx_engine *e, const double *table, int64_t len, fx_table **o
 int fx_table_destroy(fx_table *t);
 int fx_table_lookup(fx_table *t, const uint8_t *ascii, int64_t N, int L, const uint8_t lut[256],
                     int bits, double *out);
+/* Additive landscapes, e.g. AdditiveAAVPackaging._get_raw_fitness
+ * (flexs/landscapes/additive_aav_packaging.py:101-107): the table holds L x ncol entries,
+ * out[n] = table[0][lut[s0]] + table[1][lut[s1]] + ... accumulated in position order in
+ * float64 (the Python `+=` loop's roundings).  lut maps a byte to its column; residues
+ * without an entry share an all-zero column.  L <= 3072. */
+int fx_table_additive(fx_table *t, const uint8_t *ascii, int64_t N, int L, const uint8_t lut[256],
+                      int ncol, double *out);
 
 /* ------------------------------------------------------------ test hooks */
 /* Host-only (no GPU needed): expose the weight packing (Keras order -> MFMA

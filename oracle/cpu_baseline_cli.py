@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--sample", type=int, default=50_000)
     ap.add_argument("--budget", type=float, default=12.0)
     ap.add_argument("--max-threads", type=int, default=64)
+    ap.add_argument("--vector-budget", type=float, default=4.0)
+    ap.add_argument("--nam", action="store_true", help="also time the NoisyAbstractModel CPU path (~10-20 s)")
     a = ap.parse_args()
 
     import torch
@@ -66,8 +68,52 @@ def main():
         el = time.perf_counter() - t0
         if el >= a.budget or done >= 40 * a.sample:
             break
+    # Second figure: the same arithmetic with the host-side overheads removed --
+    # NumPy look-up-table encode instead of the per-character loop and one full-batch forward per member
+    # on every core -- so the GPU / CPU ratio can be read against a vectorised CPU too.
+    vec = None
+    if a.vector_budget > 0:
+        vt = min(ncpu, a.max_threads)
+        torch.set_num_threads(vt)
+        torch_twin.ensemble_fitness_cpu(seqs[:4096], a.alphabet, "cnn", weight_sets, batch_size=a.sample, loop_encode=False)
+        vdone, v0 = 0, time.perf_counter()
+        while True:
+            torch_twin.ensemble_fitness_cpu(seqs, a.alphabet, "cnn", weight_sets, batch_size=a.sample, loop_encode=False)
+            vdone += a.sample
+            vel = time.perf_counter() - v0
+            if vel >= a.vector_budget or vdone >= 400 * a.sample:
+                break
+        vec = {"value": vdone / vel, "unit": "sequences/s", "cores": vt,
+               "sample": f"{vdone} sequences in {vel:.1f} s; NumPy LUT encode + one full-batch fp32 forward per member"}
+    # Third figure: NoisyAbstractModel on the CPU the way the reference runs it (noisy_abstract_model.py:50-58:
+    # a Python loop over the cache calling a C edit distance per pair, early exit at distance 1), on the
+    # CbAS call pattern tools/perf_survey.py times on the GPU (RNA L=14, cache 1000 -> 3000, 20 calls x 100).
+    nam = None
+    if a.nam:
+        import numpy as np
+
+        from oracle import c_oracle
+
+        class _Table:
+            cost = 0
+
+            def get_fitness(self, seqs_):
+                self.cost += len(seqs_)
+                return np.array([(hash(str(s_)) % 1000) / 1000.0 for s_ in seqs_])
+
+        np.random.seed(0)
+        model = ref_np.NoisyAbstractModelOracle(_Table(), 0.9, dist=c_oracle.levenshtein)
+        model.train(synth.bytes_to_strings(synth.random_sequence_bytes(1000, 14, "UGCA", 5)), np.random.random(1000))
+        n0, total = time.perf_counter(), 0
+        for call in range(20):
+            model.get_fitness(synth.bytes_to_strings(synth.random_sequence_bytes(100, 14, "UGCA", 100 + call)))
+            total += 100
+        nel = time.perf_counter() - n0
+        nam = {"value": total / nel, "unit": "sequences/s", "cores": 1,
+               "sample": f"{total} queries in {nel:.1f} s; Python loop over the cache + C Levenshtein per pair"}
     print(json.dumps({
-        "value": done / el, "unit": "sequences/s", "cores": threads, "kind": "port",
+        "nam": nam,
+        "value": done / el, "unit": "sequences/s", "cores": threads, "kind": "port", "vectorised": vec,
         "sample": f"{done} sequences ({done // a.sample} pass(es) over the first {a.sample} of the batch) in "
                   f"{el:.1f} s; reference-style path: per-character Python encode loop (single thread) + 256-row "
                   f"fp32 forward on {threads} torch threads (fastest of {candidates}) + np.stack/np.mean; host has "

@@ -325,3 +325,44 @@ class NoisyAbstractModelOracle:
         fitnesses[~cached] = new
         self.cache.update(zip(sequences[~cached], fitnesses[~cached]))
         return np.array(fitnesses)
+
+
+# --------------------------------------------------------------------------
+# additive landscape
+# --------------------------------------------------------------------------
+class AdditiveAAVOracle:
+    """flexs/landscapes/additive_aav_packaging.py:25-119 restated: `data` is the parsed single-substitution
+    file {position(str): {residue: {"log2_<phenotype>_v_wt": x, "log2_packaging_v_wt": y}}}.
+    Pinned by tests/golden/additive_aav.json (outputs of the reference class on a synthetic data file)."""
+
+    def __init__(self, data, phenotype="heart", minimum_fitness_multiplier=1, start=0, end=735, noise=0):
+        self.name = f"AdditiveAAVPackaging_phenotype={phenotype}"
+        self.cost = 0
+        self.key = f"log2_{phenotype}_v_wt"
+        self.mfm, self.start, self.end, self.noise = minimum_fitness_multiplier, start, end, noise
+        self.data = {int(p): v for p, v in data.items() if start <= int(p) < end}          # :66-76
+        seq, total = "", 0
+        for pos in self.data:                                                              # :80-99
+            top, top_aa = -10, "M"
+            for aa in self.data[pos]:
+                fit = self.data[pos][aa][self.key]
+                if fit > top and self.data[pos][aa]["log2_packaging_v_wt"] > -6:
+                    top, top_aa = fit, aa
+            seq += top_aa
+            total += top
+        self.top_seq, self.max_possible = seq, total
+
+    def raw(self, seq):
+        total = 0                                                                          # :101-107
+        for i, s in enumerate(seq):
+            if s in self.data[self.start + i]:
+                total += self.data[self.start + i][s][self.key]
+        return total + self.mfm * self.max_possible
+
+    def get_fitness(self, sequences):
+        self.cost += len(sequences)
+        out = []
+        for seq in sequences:                                                              # :109-119
+            normed = self.raw(seq) / (self.max_possible * (self.mfm + 1))
+            out.append(max(0, normed + np.random.normal(scale=self.noise)))
+        return np.array(out)

@@ -671,3 +671,75 @@ def test_multi_member_launches(eng, kind, L, A, alpha, M, n):
     for m in range(M):
         assert_scores(nm[:, m], ref_np.keras_fitness(seqs, alpha, kind, ws[m], exact=True), f"{kind} member {m}/{M}")
     assert np.array_equal(mean, np.mean(nm, axis=1))
+
+
+# ------------------------------------------------------------------ additive landscape (section 8f-4)
+def test_additive_aav_matches_reference_fixture(eng, golden_dir, tmp_path):
+    """`AdditiveAAVPackaging` through the device table == the outputs of the reference class
+    (tests/golden/additive_aav.json): bit-exact floats, cost, RNG position, KeyError past the window."""
+    from flexs_amd.landscapes import AdditiveAAVPackaging
+    from flexs_amd.landscapes.additive_aav_packaging import registry
+
+    g = json.load(open(os.path.join(golden_dir, "additive_aav.json")))
+    path = str(tmp_path / "AAV2_single_subs.json")
+    json.dump(g["single_subs"], open(path, "w"))
+    for case in g["cases"]:
+        land = AdditiveAAVPackaging(data_file=path, **case["params"])
+        assert land.name == case["name"] and land.top_seq == case["top_seq"] and land.wild_type == case["wild_type"]
+        assert float(land.max_possible) == case["max_possible"]
+        np.random.seed(case["seed"])
+        out1 = land.get_fitness(case["sequences"])
+        out2 = land.get_fitness(np.array(case["sequences"][:7]))
+        assert str(out1.dtype) == case["dtype"]
+        assert out1.tolist() == case["fitness"] and out2.tolist() == case["fitness_second_call"]
+        assert land.cost == case["cost"] and float(np.random.random()) == case["rng_next_random"]
+        assert land._get_raw_fitness(case["sequences"][3]) == ref_np.AdditiveAAVOracle(g["single_subs"], **case["params"]).raw(case["sequences"][3])
+    with pytest.raises(KeyError) as err:
+        AdditiveAAVPackaging(data_file=path, start=450, end=460).get_fitness(["A" * 11])
+    assert err.value.args[0] == g["too_long_keyerror"]
+    assert registry() == g["registry"]
+    assert AdditiveAAVPackaging(data_file=path, start=450, end=460).get_fitness([]).shape == (0,)
+
+
+@pytest.mark.parametrize("L,n", [(90, 3001), (735, 517), (1, 40), (300, 70)])
+def test_additive_sum_kernel_vs_python_loop(eng, L, n):
+    """fx_table_additive at the registry window (90), the whole capsid (735: several LDS tiles per block) and
+    edge sizes: the in-order float64 sum of the Python loop, bit for bit."""
+    rng = np.random.default_rng(L)
+    ncol = 21
+    table = np.round(rng.normal(0, 2, (L, ncol)), 4)
+    table[:, -1] = 0.0
+    table[rng.random((L, ncol)) < 0.2] = 0.0
+    lut = np.full(256, ncol - 1, np.uint8)
+    for col, aa in enumerate(s_utils.AAS):
+        lut[ord(aa)] = col
+    rows = np.frombuffer((s_utils.AAS + "XZ").encode(), np.uint8)[rng.integers(0, 22, (n, L))]
+    rows[1, L // 2:] = 0                                            # NUL-padded short row
+    got = _native.NativeTable(eng, table, "", lut=lut).additive_sum(rows)
+    want = np.empty(n)
+    for i in range(n):
+        acc = 0
+        for p in range(L):
+            acc += float(table[p, lut[rows[i, p]]])
+        want[i] = acc
+    assert np.array_equal(got, want)
+    with pytest.raises(ValueError):
+        _native.NativeTable(eng, table, "", lut=lut).additive_sum(rows[:, :-1] if L > 1 else np.zeros((2, 3), np.uint8))
+
+
+def test_sharded_cache_degenerates_to_local_on_one_gpu(eng):
+    """flexs_amd.distributed.ShardedCache without a process group (world = 1) over the real device store."""
+    from flexs_amd import distributed as fd
+
+    rng = np.random.default_rng(8)
+    keys = rng.integers(65, 69, (700, 14)).astype(np.uint8)
+    q = keys[rng.integers(0, 700, 90)].copy()
+    m = rng.random(q.shape) < 0.1
+    q[m] = rng.integers(65, 69, m.sum())
+    sc = fd.ShardedCache(14)
+    assert sc.min_dist(q)[1].tolist() == [-1] * 90
+    sc.append(keys[:123]); sc.append(keys[123:])
+    for mode in (0, 1):
+        d, a = sc.min_dist(q, mode)
+        d_want, a_want = c_oracle.min_dist(q, keys, mode)
+        assert np.array_equal(d, d_want) and np.array_equal(a, a_want)
