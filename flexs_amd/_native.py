@@ -55,6 +55,8 @@ SIGNATURES = {
     "fx_ensemble_reduce": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp]),
     "fx_ensemble_reduce_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp]),
     "fx_argmax_decode": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, _vp, _vp]),
+    "fx_decode_score": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _vp, C.c_int64, C.c_int, C.c_int, _vp, _u8p, _vp, _vp,
+                                  _vp]),
     "fx_min_dist": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, _vp, C.c_int64, C.c_int, _vp, _vp]),
     "fx_cache_create": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     "fx_cache_destroy": (C.c_int, [_vp]),
@@ -307,6 +309,23 @@ class Engine:
         out = np.empty((P, L), np.uint8)
         self.check(self._lib.fx_argmax_decode(self.handle, _ptr(x), P, L, A, _ptr(np.ascontiguousarray(al)), _ptr(out)))
         return out
+
+    def decode_score(self, models: Sequence["NativeModel"], one_hot: np.ndarray, alphabet: str, lut: np.ndarray,
+                     want_matrix: bool = True, want_mean: bool = False):
+        """(P, L, A) floats -> ((P, L) decoded bytes, (P, M) scores, (P,) mean) in one device round trip."""
+        x = np.ascontiguousarray(one_hot, np.float64)
+        P, L, A = x.shape
+        if A != len(alphabet):
+            raise ValueError(f"one-hot width {A} does not match the alphabet ({len(alphabet)} letters)")
+        M = len(models)
+        arr = (_vp * M)(*[m.handle for m in models])
+        al = np.frombuffer(alphabet.encode("latin-1"), np.uint8)
+        chars = np.empty((P, L), np.uint8)
+        out_nm = np.empty((P, M), np.float32) if want_matrix else None
+        out_mean = np.empty((P,), np.float32) if want_mean else None
+        self.check(self._lib.fx_decode_score(self.handle, arr, M, _ptr(x), P, L, A, _ptr(np.ascontiguousarray(al)),
+                                             lut.ctypes.data_as(_u8p), _ptr(chars), _ptr(out_nm), _ptr(out_mean)))
+        return chars, out_nm, out_mean
 
     def min_dist(self, queries: np.ndarray, cache: np.ndarray, mode: int = FX_LEVENSHTEIN):
         q = np.ascontiguousarray(queries, np.uint8)

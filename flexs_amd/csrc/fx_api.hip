@@ -470,6 +470,45 @@ int fx_argmax_decode(fx_engine* e, const double* one_hot, int64_t P, int L, int 
     return FX_OK;
 }
 
+// CMA-ES / DynaPPO population step (cmaes.py:61-67 + 83-93, environments/dyna_ppo.py:144-163): decode P
+// solutions to sequences (K6) and score them with the ensemble in ONE device round trip -- the decoded
+// characters never leave the GPU between the two steps.
+int fx_decode_score(fx_engine* e, fx_model* const* models, int M, const double* one_hot, int64_t P, int L, int A,
+                    const uint8_t* alphabet, const uint8_t lut[256], uint8_t* out_chars, float* out_NM,
+                    float* out_mean) {
+    int rc = validate_models(e, models, M, L, lut);
+    if (rc) return rc;
+    if (P < 0 || A < 1) return fx_fail(e, FX_EINVAL, "bad population shape");
+    if (models[0]->shape.A != A) return fx_fail(e, FX_ESHAPE, "alphabet size does not match the model's");
+    if (P == 0 || L == 0) return FX_OK;
+    if (!one_hot || !alphabet || !out_chars || (!out_NM && !out_mean)) return fx_fail(e, FX_EINVAL, "null buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    const int64_t rows = P * L;
+    const size_t in_bytes = sizeof(double) * (size_t)rows * A;
+    const size_t nm_bytes = sizeof(float) * (size_t)P * (size_t)M, mean_bytes = sizeof(float) * (size_t)P;
+    void *d_in = nullptr, *d_out = nullptr, *d_txt = nullptr;
+    if ((rc = fx_scratch(e, 0, in_bytes, &d_in))) return rc;
+    if ((rc = fx_scratch(e, 1, nm_bytes + mean_bytes, &d_out))) return rc;
+    if ((rc = fx_scratch(e, 3, 256 + (size_t)rows + 16, &d_txt))) return rc;
+    uint8_t* d_al = (uint8_t*)d_txt;
+    uint8_t* d_chars = d_al + 256;
+    float* d_NM = (float*)d_out;
+    float* d_mean = (float*)((char*)d_out + nm_bytes);
+    FX_HIP(e, hipMemcpyAsync(d_in, one_hot, in_bytes, hipMemcpyHostToDevice, e->stream));
+    FX_HIP(e, hipMemcpyAsync(d_al, alphabet, (size_t)A, hipMemcpyHostToDevice, e->stream));
+    if ((rc = fx_upload_lut(e, lut))) return rc;
+    if ((rc = fx_launch_argmax_decode(e, (const double*)d_in, rows, A, d_al, d_chars))) return rc;
+    if ((rc = score_dispatch(e, models, M, d_chars, P, L, d_NM))) return rc;
+    if (out_mean) {
+        if ((rc = fx_launch_ensemble_reduce(e, d_NM, P, M, nullptr, d_mean, nullptr))) return rc;
+        FX_HIP(e, hipMemcpyAsync(out_mean, d_mean, mean_bytes, hipMemcpyDeviceToHost, e->stream));
+    }
+    if (out_NM) FX_HIP(e, hipMemcpyAsync(out_NM, d_NM, nm_bytes, hipMemcpyDeviceToHost, e->stream));
+    FX_HIP(e, hipMemcpyAsync(out_chars, d_chars, (size_t)rows, hipMemcpyDeviceToHost, e->stream));
+    FX_HIP(e, hipStreamSynchronize(e->stream));
+    return check_deferred(e);
+}
+
 // ----------------------------------------------------- NoisyAbstractModel
 static int min_dist_common(fx_engine* e, int mode, const uint8_t* queries, int64_t Q, const uint8_t* d_cache,
                            int64_t C, int L, int32_t* dist, int64_t* argmin) {

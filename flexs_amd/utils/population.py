@@ -1,0 +1,89 @@
+"""Batched form of the explorers' decode-then-score inner step.
+
+CMA-ES (`flexs/baselines/explorers/cmaes.py:61-67, 83-93`) and the DyNA-PPO environments
+(`environments/dyna_ppo.py:144-163`) turn a float (L, A) array into a sequence by per-position argmax and ask
+the model for ONE sequence at a time -- 15-40 launch-latency-bound `get_fitness([seq])` calls per iteration.
+`PopulationEvaluator.evaluate` answers a whole population in one device round trip (`fx_decode_score`):
+decode, score with every member, reduce, copy back.  What the explorer observes is unchanged:
+
+* strings: `alphabet[argmax]` per position, first maximum wins -- the intermediate hard one-hot of
+  `_soln_to_string` has the same argmax;
+* values: a sequence found in one of the caller's `known` dicts (first dict wins, cmaes.py:86-89) gets that
+  value; every other one gets `model.get_fitness([seq]).item()`'s value;
+* `model.cost` (and each ensemble member's) grows by the number of sequences that were NOT known, exactly as
+  the one-by-one loop charges them.
+
+Models that are not device surrogates are called one sequence at a time like the reference does (their
+answers may depend on call order, e.g. NoisyAbstractModel's cache and RNG).
+"""
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+from flexs_amd import _native
+from flexs_amd.ensemble import Ensemble, _default_combine, _device_members
+
+
+def _fused_members(model):
+    from flexs_amd.baselines.models.keras_model import KerasModel
+
+    if isinstance(model, KerasModel):
+        return [model]
+    if isinstance(model, Ensemble) and model.combine_with is _default_combine and _device_members(model.models):
+        return list(model.models)
+    return None
+
+
+class PopulationEvaluator:
+    def __init__(self, model, alphabet: str, seq_len: int):
+        self.model = model
+        self.alphabet = alphabet
+        self.seq_len = seq_len
+        self._members = _fused_members(model)
+        if self._members is not None and (self._members[0].alphabet != alphabet or self._members[0].model.L != seq_len):
+            raise ValueError("PopulationEvaluator: alphabet / seq_len differ from the model's")
+
+    def _as_one_hot(self, solutions) -> np.ndarray:
+        x = np.asarray(solutions, np.float64)
+        return x.reshape((-1, self.seq_len, len(self.alphabet)))              # cmaes.py:62
+
+    def decode(self, solutions) -> List[str]:
+        """`[_soln_to_string(s) for s in solutions]` on the device."""
+        x = self._as_one_hot(solutions)
+        if x.shape[0] == 0:
+            return []
+        chars = _native.Engine.get(getattr(self.model, "_device", None)).argmax_decode(x, self.alphabet)
+        return [r.tobytes().decode("latin-1") for r in chars]
+
+    def evaluate(self, solutions, known: Sequence[Dict[str, float]] = ()) -> Tuple[List[str], np.ndarray]:
+        x = self._as_one_hot(solutions)
+        P = x.shape[0]
+        values = np.empty(P, np.float64)
+        if P == 0:
+            return [], values
+        if self._members is None:
+            seqs = self.decode(x)
+            for i, seq in enumerate(seqs):
+                hit = next((d for d in known if seq in d), None)
+                values[i] = hit[seq] if hit is not None else self.model.get_fitness([seq]).item()
+            return seqs, values
+        m0 = self._members[0]
+        natives = [m.native() for m in self._members]
+        single = len(natives) == 1 and self.model is m0
+        chars, nm, mean = m0._engine().decode_score(natives, x, self.alphabet, m0._lut, want_matrix=single,
+                                                    want_mean=not single)
+        scores = nm[:, 0] if single else mean
+        seqs = [r.tobytes().decode("latin-1") for r in chars]
+        fresh = 0
+        for i, seq in enumerate(seqs):
+            hit = next((d for d in known if seq in d), None)
+            if hit is not None:
+                values[i] = hit[seq]
+            else:
+                values[i] = float(scores[i])
+                fresh += 1
+        self.model.cost += fresh                                               # landscape.py:44, one per unseen call
+        if not single:
+            for m in self._members:
+                m.cost += fresh                                                # ensemble.py:55-57
+        return seqs, values

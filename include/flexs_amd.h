@@ -144,6 +144,17 @@ int fx_ensemble_reduce_dev(fx_engine *e, const float *d_scores_NM, int64_t N, in
 int fx_argmax_decode(fx_engine *e, const double *one_hot, int64_t P, int L, int A,
                      const uint8_t *alphabet, uint8_t *out_chars);
 
+/* Population step of the explorers that optimise in one-hot space: CMAES
+ * `_soln_to_string` + `objective_function` (flexs/baselines/explorers/cmaes.py:61-67, 83-93) and
+ * the DyNA-PPO environment step (environments/dyna_ppo.py:144-163) decode a float (L, A) array
+ * to a sequence and score it, one sequence per `get_fitness` call.  fx_decode_score does both
+ * for P solutions in one device round trip: out_chars[p] = alphabet[argmax] (fx_argmax_decode
+ * rule), scores as fx_score would return for those sequences.  A decoded character outside
+ * the model's alphabet -> FX_EBADCHAR. */
+int fx_decode_score(fx_engine *e, fx_model *const *models, int M, const double *one_hot, int64_t P,
+                    int L, int A, const uint8_t *alphabet, const uint8_t lut[256],
+                    uint8_t *out_chars, float *out_NM, float *out_mean);
+
 /* ----------------------------------------------------- NoisyAbstractModel */
 /* NoisyAbstractModel._get_min_distance (noisy_abstract_model.py:42-60) for Q
  * queries against C cache keys kept in insertion order: dist[i] = min edit

@@ -73,9 +73,16 @@ def main():
     # on every core -- so the GPU / CPU ratio can be read against a vectorised CPU too.
     vec = None
     if a.vector_budget > 0:
-        vt = min(ncpu, a.max_threads)
+        vbest, vt = None, 1
+        for t in candidates:                              # full-batch convolutions do not always scale with threads
+            torch.set_num_threads(t)
+            torch_twin.ensemble_fitness_cpu(seqs[:4096], a.alphabet, "cnn", weight_sets, batch_size=a.sample, loop_encode=False)
+            p0 = time.perf_counter()
+            torch_twin.ensemble_fitness_cpu(probe, a.alphabet, "cnn", weight_sets, batch_size=a.sample, loop_encode=False)
+            d = time.perf_counter() - p0
+            if vbest is None or d < vbest:
+                vbest, vt = d, t
         torch.set_num_threads(vt)
-        torch_twin.ensemble_fitness_cpu(seqs[:4096], a.alphabet, "cnn", weight_sets, batch_size=a.sample, loop_encode=False)
         vdone, v0 = 0, time.perf_counter()
         while True:
             torch_twin.ensemble_fitness_cpu(seqs, a.alphabet, "cnn", weight_sets, batch_size=a.sample, loop_encode=False)
@@ -84,7 +91,8 @@ def main():
             if vel >= a.vector_budget or vdone >= 400 * a.sample:
                 break
         vec = {"value": vdone / vel, "unit": "sequences/s", "cores": vt,
-               "sample": f"{vdone} sequences in {vel:.1f} s; NumPy LUT encode + one full-batch fp32 forward per member"}
+               "sample": f"{vdone} sequences in {vel:.1f} s; NumPy LUT encode + one full-batch fp32 forward per member on "
+                         f"{vt} torch threads (fastest of {candidates})"}
     # Third figure: NoisyAbstractModel on the CPU the way the reference runs it (noisy_abstract_model.py:50-58:
     # a Python loop over the cache calling a C edit distance per pair, early exit at distance 1), on the
     # CbAS call pattern tools/perf_survey.py times on the GPU (RNA L=14, cache 1000 -> 3000, 20 calls x 100).

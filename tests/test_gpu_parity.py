@@ -743,3 +743,50 @@ def test_sharded_cache_degenerates_to_local_on_one_gpu(eng):
         d, a = sc.min_dist(q, mode)
         d_want, a_want = c_oracle.min_dist(q, keys, mode)
         assert np.array_equal(d, d_want) and np.array_equal(a, a_want)
+
+
+# ------------------------------------------------------------------ population step (section 8f-2)
+@pytest.mark.parametrize("which", ["ensemble", "single", "host-stacked"])
+def test_population_evaluator_equals_one_by_one_loop(eng, which):
+    """cmaes.py:61-67 + 83-93 for a whole population at once == the reference's loop of
+    `get_fitness([seq]).item()` calls: strings, values (bit for bit), cost on the model and its members."""
+    from flexs_amd.utils.population import PopulationEvaluator
+
+    L, alpha, P = 8, "TGCA", 37
+    rng = np.random.default_rng(5)
+
+    def build():
+        members = [bm.CNN(L, 32, 100, alpha, seed=s) for s in range(3)]
+        if which == "single":
+            return members[0], [members[0]]
+        if which == "host-stacked":                      # custom reduction: not fused, answered one by one
+            return flexs_amd.Ensemble(members, combine_with=lambda x: np.median(x, axis=1)), members
+        return flexs_amd.Ensemble(members), members
+
+    model, members = build()
+    twin, twin_members = build()
+    x = rng.standard_normal((P, L * len(alpha)))
+    x[5] = x[2]                                          # duplicate solutions inside one population
+    x[9, :4] = 0.0                                       # a tie: first maximum wins
+    want_seqs = [ref_np.one_hot_to_string(r.reshape(L, len(alpha)), alpha) for r in x]
+    known_a = {want_seqs[0]: 123.0, want_seqs[7]: -1.5}
+    known_b = {want_seqs[0]: 999.0, want_seqs[11]: 0.25}
+    want_vals = []
+    for s in want_seqs:                                  # objective_function, cmaes.py:83-93
+        if s in known_a:
+            want_vals.append(known_a[s])
+        elif s in known_b:
+            want_vals.append(known_b[s])
+        else:
+            want_vals.append(twin.get_fitness([s]).item())
+    ev = PopulationEvaluator(model, alpha, L)
+    assert ev.decode(x) == want_seqs
+    seqs, vals = ev.evaluate(x, known=(known_a, known_b))
+    assert seqs == want_seqs and vals.dtype == np.float64 and vals.tolist() == want_vals
+    assert model.cost == twin.cost == P - 3
+    if which != "single":
+        assert [m.cost for m in members] == [m.cost for m in twin_members] == [P - 3] * 3
+    assert ev.evaluate(np.zeros((0, L * 4)))[0] == []
+    if which != "host-stacked":
+        with pytest.raises(ValueError):
+            PopulationEvaluator(model, "UGCA", L)

@@ -134,6 +134,37 @@ def end_to_end():
         print(rows[-1], flush=True)
 
 
+def population():
+    """CMA-ES iteration (cmaes.py:83-108): P solutions decoded and scored, one by one vs one fused round trip."""
+    from flexs_amd.utils.population import PopulationEvaluator
+    from flexs_amd.utils import sequence_utils as s_utils
+
+    rng = np.random.default_rng(0)
+    for L, alpha, P in ((8, "TGCA", 16), (8, "TGCA", 40), (237, s_utils.AAS, 40)):
+        members = [bm.CNN(L, 32, 100, alpha, seed=m) for m in range(3)]
+        ens = flexs_amd.Ensemble(members)
+        ev = PopulationEvaluator(ens, alpha, L)
+        x = rng.standard_normal((P, L * len(alpha)))
+        for _ in range(5):
+            ev.evaluate(x)
+        ts = []
+        for _ in range(100):
+            t0 = time.perf_counter(); ev.evaluate(x); ts.append(time.perf_counter() - t0)
+        fused = float(np.median(ts))
+        ts = []
+        for _ in range(10):
+            t0 = time.perf_counter()
+            for r in x:                                    # the reference loop: decode on the host, one call per solution
+                oh = np.zeros((L, len(alpha)))
+                oh[np.arange(L), np.argmax(r.reshape(L, len(alpha)), axis=1)] = 1
+                ens.get_fitness([s_utils.one_hot_to_string(oh, alpha)]).item()
+            ts.append(time.perf_counter() - t0)
+        loop = float(np.median(ts))
+        rows.append({"what": f"population step P={P} L={L} A={len(alpha)} Ensemble(3xCNN): fused decode+score vs {P} single calls",
+                     "fused_us": fused * 1e6, "one_by_one_us": loop * 1e6, "speedup": loop / fused})
+        print(rows[-1], flush=True)
+
+
 def nam():
     rng = np.random.default_rng(0)
     for (L, nsym, Q, C) in ((14, 4, 100, 100), (14, 4, 100, 1000), (14, 4, 100, 20000), (14, 4, 2000, 20000),
@@ -176,7 +207,7 @@ def nam():
 
 
 def main():
-    which = sys.argv[1:] or ["score", "sweep", "hbm", "e2e", "nam"]
+    which = sys.argv[1:] or ["score", "sweep", "hbm", "e2e", "nam", "population"]
     if "score" in which:
         for v in (1, 2, 3, 4):
             time_score("cnn", 8, "TGCA", 100, 3, 100_000, 32, 5, variant=v, label=f"C2 cnn L=8 M=3 N=1e5 variant {v} conv1=gather")
@@ -217,6 +248,8 @@ def main():
         end_to_end()
     if "nam" in which:
         nam()
+    if "population" in which:
+        population()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "perf_survey.json"), "w"), indent=1)
 
