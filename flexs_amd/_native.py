@@ -134,6 +134,12 @@ def make_lut(alphabet: str) -> np.ndarray:
     return lut
 
 
+try:                                   # CPython helper built next to libflexs_amd.so by csrc/Makefile
+    from flexs_amd import _strpack
+except ImportError:                    # host-side convenience only: the pure-Python path below does the same
+    _strpack = None
+
+
 def ragged_to_bytes(sequences, L: int) -> np.ndarray:
     """Strings of any lengths <= L -> (N, L) uint8 rows, NUL-padded on the right: the row format of the
     edit-distance entry points (fx_min_dist / fx_cache_*), which `editdistance.eval` semantics require to
@@ -176,19 +182,28 @@ def sequences_to_bytes(sequences, L: Optional[int] = None) -> np.ndarray:
             raise ValueError("substring not found")
         out = cp.astype(np.uint8)
     else:
-        seqs = list(sequences)
+        seqs = sequences if isinstance(sequences, (list, tuple)) else list(sequences)
         N = len(seqs)
         if N == 0:
             return np.zeros((0, L or 0), np.uint8)
         w = len(seqs[0])
-        joined = "".join(seqs)
-        if len(joined) != N * w or set(map(len, seqs)) != {w}:
+        if _strpack is not None:
+            out = np.empty((N, w), np.uint8)
+            status = _strpack.pack(seqs, w, out)          # one pass, memcpy per string (csrc/strpack.c)
+        else:                                             # same checks in pure Python (helper not built)
+            joined = "".join(seqs)
+            status = 1 if (len(joined) != N * w or set(map(len, seqs)) != {w}) else 0
+            if status == 0:
+                try:
+                    out = np.frombuffer(joined.encode("latin-1"), dtype=np.uint8).reshape(N, w)
+                except UnicodeEncodeError:
+                    status = 2
+        if status == 1:
             raise ValueError("ragged sequence batch: all sequences must have the same length")
-        try:
-            raw = joined.encode("latin-1")
-        except UnicodeEncodeError:
-            raise ValueError("substring not found") from None
-        out = np.frombuffer(raw, dtype=np.uint8).reshape(N, w)
+        if status == 2:
+            raise ValueError("substring not found")
+        if status == 3:
+            raise TypeError("sequences must be str")
     if L is not None and out.shape[0] and out.shape[1] != L:
         raise ValueError(f"sequence length {out.shape[1]} does not match the model's seq_len {L}")
     return out

@@ -20,11 +20,12 @@ namespace {
 
 constexpr int CHUNK = 1024;     // cache entries per block
 
-template <int W>
+template <int W, typename Word>
 __global__ void __launch_bounds__(256) k_min_dist(int mode, const uint8_t* __restrict__ q, const uint8_t* __restrict__ cache,
                                                   int64_t C, int L, unsigned long long* __restrict__ keys) {
-    __shared__ uint64_t peq[256 * W];
-    __shared__ uint8_t qs[W * 64];
+    constexpr int BITS = 8 * (int)sizeof(Word);
+    __shared__ Word peq[256 * W];
+    __shared__ uint8_t qs[W * BITS];
     __shared__ unsigned long long wave_min[4];
     const int tid = threadIdx.x;
     const int64_t qi = blockIdx.y;
@@ -32,7 +33,7 @@ __global__ void __launch_bounds__(256) k_min_dist(int mode, const uint8_t* __res
     __syncthreads();
     int m = L;                                         // query length (every thread finds it itself)
     {   // thread c builds the masks of byte value c
-        uint64_t mk[W];
+        Word mk[W];
 #pragma unroll
         for (int w = 0; w < W; ++w) mk[w] = 0;
         for (int i = 0; i < L; ++i) {
@@ -41,7 +42,7 @@ __global__ void __launch_bounds__(256) k_min_dist(int mode, const uint8_t* __res
             if (ch == tid) {
 #pragma unroll
                 for (int w = 0; w < W; ++w)
-                    if ((i >> 6) == w) mk[w] |= 1ull << (i & 63);
+                    if ((i / BITS) == w) mk[w] |= Word(1) << (i % BITS);
             }
         }
 #pragma unroll
@@ -60,7 +61,7 @@ __global__ void __launch_bounds__(256) k_min_dist(int mode, const uint8_t* __res
             d = 0;
             for (int i = 0; i < L; ++i) d += (t[i] != qs[i]);
         } else {
-            d = fx_myers_distance<W, true>(
+            d = fx_myers_distance<W, true, Word>(
                 m, L, [&](int ch, int w) { return peq[ch * W + w]; }, [&](int i) { return (int)t[i]; });
         }
         const unsigned dp = d == 1 ? 0u : (d == 0 ? 1u : (unsigned)d);
@@ -82,18 +83,19 @@ __global__ void __launch_bounds__(256) k_min_dist(int mode, const uint8_t* __res
 }
 
 // Dense Q x C distance matrix (uint8, clamped) -- same per-pair code as k_min_dist.
-template <int W>
+template <int W, typename Word>
 __global__ void __launch_bounds__(256) k_distances(int mode, const uint8_t* __restrict__ q, const uint8_t* __restrict__ cache,
                                                    int64_t C, int L, uint8_t* __restrict__ out) {
-    __shared__ uint64_t peq[256 * W];
-    __shared__ uint8_t qs[W * 64];
+    constexpr int BITS = 8 * (int)sizeof(Word);
+    __shared__ Word peq[256 * W];
+    __shared__ uint8_t qs[W * BITS];
     const int tid = threadIdx.x;
     const int64_t qi = blockIdx.y;
     for (int i = tid; i < L; i += 256) qs[i] = q[qi * L + i];
     __syncthreads();
     int m = L;
     {
-        uint64_t mk[W];
+        Word mk[W];
 #pragma unroll
         for (int w = 0; w < W; ++w) mk[w] = 0;
         for (int i = 0; i < L; ++i) {
@@ -102,7 +104,7 @@ __global__ void __launch_bounds__(256) k_distances(int mode, const uint8_t* __re
             if (ch == tid) {
 #pragma unroll
                 for (int w = 0; w < W; ++w)
-                    if ((i >> 6) == w) mk[w] |= 1ull << (i & 63);
+                    if ((i / BITS) == w) mk[w] |= Word(1) << (i % BITS);
             }
         }
 #pragma unroll
@@ -119,7 +121,7 @@ __global__ void __launch_bounds__(256) k_distances(int mode, const uint8_t* __re
             d = 0;
             for (int i = 0; i < L; ++i) d += (t[i] != qs[i]);
         } else {
-            d = fx_myers_distance<W, true>(
+            d = fx_myers_distance<W, true, Word>(
                 m, L, [&](int ch, int w) { return peq[ch * W + w]; }, [&](int i) { return (int)t[i]; });
         }
         out[qi * C + c] = (uint8_t)(d > 255 ? 255 : d);
@@ -145,13 +147,15 @@ int fx_launch_min_dist(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, co
     if (Q > 65535) return fx_fail(e, FX_EINVAL, "min_dist: more than 65535 queries per call (split the batch)");
     FX_HIP(e, hipMemsetAsync(d_keys, 0xFF, sizeof(unsigned long long) * (size_t)Q, e->stream));
     dim3 grid((unsigned)((C + CHUNK - 1) / CHUNK), (unsigned)Q), block(256);
-    const int W = (L + 63) / 64;
-    switch (W) {
-        case 0:
-        case 1: hipLaunchKernelGGL(k_min_dist<1>, grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
-        case 2: hipLaunchKernelGGL(k_min_dist<2>, grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
-        case 3: hipLaunchKernelGGL(k_min_dist<3>, grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
-        default: hipLaunchKernelGGL(k_min_dist<4>, grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
+    if (L <= 32) {          // one 32-bit word per column: half the integer work of the 64-bit form
+        hipLaunchKernelGGL((k_min_dist<1, uint32_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys);
+    } else {
+        switch ((L + 63) / 64) {
+            case 1: hipLaunchKernelGGL((k_min_dist<1, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
+            case 2: hipLaunchKernelGGL((k_min_dist<2, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
+            case 3: hipLaunchKernelGGL((k_min_dist<3, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
+            default: hipLaunchKernelGGL((k_min_dist<4, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
+        }
     }
     FX_HIP(e, hipGetLastError());
     return FX_OK;
@@ -163,12 +167,15 @@ int fx_launch_distances(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, c
     if (L > 256) return fx_fail(e, FX_EUNSUPPORTED, "distances: sequence length > 256");
     if (Q > 65535) return fx_fail(e, FX_EINVAL, "distances: more than 65535 queries per call");
     dim3 grid((unsigned)((C + CHUNK - 1) / CHUNK), (unsigned)Q), block(256);
-    switch ((L + 63) / 64) {
-        case 0:
-        case 1: hipLaunchKernelGGL(k_distances<1>, grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;
-        case 2: hipLaunchKernelGGL(k_distances<2>, grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;
-        case 3: hipLaunchKernelGGL(k_distances<3>, grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;
-        default: hipLaunchKernelGGL(k_distances<4>, grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;
+    if (L <= 32) {
+        hipLaunchKernelGGL((k_distances<1, uint32_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out);
+    } else {
+        switch ((L + 63) / 64) {
+            case 1: hipLaunchKernelGGL((k_distances<1, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;
+            case 2: hipLaunchKernelGGL((k_distances<2, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;
+            case 3: hipLaunchKernelGGL((k_distances<3, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;
+            default: hipLaunchKernelGGL((k_distances<4, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;
+        }
     }
     FX_HIP(e, hipGetLastError());
     return FX_OK;

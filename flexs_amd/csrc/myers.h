@@ -13,45 +13,48 @@
 #define FX_HD inline
 #endif
 
-// One column step for one 64-bit block.  hin / return value in {-1, 0, +1}.
-// top = bit index whose horizontal delta is reported (63, or (m-1) % 64 in the last block).
-FX_HD int fx_myers_block(uint64_t& Pv, uint64_t& Mv, uint64_t Eq, int hin, int top) {
-    const uint64_t hneg = hin < 0 ? 1ull : 0ull;
-    const uint64_t Xv = Eq | Mv;
+// One column step for one block of `8 * sizeof(Word)` pattern rows.  hin / return value in {-1, 0, +1}.
+// top = bit index whose horizontal delta is reported (the block's last bit, or (m-1) % bits in the last block).
+// Word = uint32_t halves the integer work for patterns of <= 32 symbols (the DNA / RNA landscapes).
+template <typename Word>
+FX_HD int fx_myers_block(Word& Pv, Word& Mv, Word Eq, int hin, int top) {
+    const Word hneg = hin < 0 ? Word(1) : Word(0);
+    const Word Xv = Eq | Mv;
     Eq |= hneg;
-    const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-    uint64_t Ph = Mv | ~(Xh | Pv);
-    uint64_t Mh = Pv & Xh;
-    const int hout = (int)((Ph >> top) & 1ull) - (int)((Mh >> top) & 1ull);
+    const Word Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+    Word Ph = Mv | ~(Xh | Pv);
+    Word Mh = Pv & Xh;
+    const int hout = (int)((Ph >> top) & Word(1)) - (int)((Mh >> top) & Word(1));
     Ph <<= 1;
     Mh <<= 1;
     Mh |= hneg;
-    Ph |= (uint64_t)((hin + 1) >> 1);
+    Ph |= (Word)((hin + 1) >> 1);
     Pv = Mh | ~(Xv | Ph);
     Mv = Ph & Xv;
     return hout;
 }
 
 // Levenshtein(pattern, text) given the pattern's match masks.
-//   peq(c, w): 64-bit mask, bit i set iff pattern[64*w + i] == c
+//   peq(c, w): Word mask, bit i set iff pattern[bits*w + i] == c
 //   text(i):   i-th text byte
 // NULTERM: the text occupies a row of n bytes and ends at its first NUL byte (ragged rows are
 // NUL-padded; no FLEXS alphabet contains NUL), so n is an upper bound of the text length.
-template <int W, bool NULTERM = false, typename PeqFn, typename TextFn>
+template <int W, bool NULTERM = false, typename Word = uint64_t, typename PeqFn, typename TextFn>
 FX_HD int fx_myers_distance(int m, int n, PeqFn peq, TextFn text) {
-    uint64_t Pv[W], Mv[W];
-    const int nw = (m + 63) >> 6;
+    constexpr int BITS = 8 * (int)sizeof(Word);
+    Word Pv[W], Mv[W];
+    const int nw = (m + BITS - 1) / BITS;
 #pragma unroll
-    for (int w = 0; w < W; ++w) { Pv[w] = ~0ull; Mv[w] = 0ull; }
+    for (int w = 0; w < W; ++w) { Pv[w] = ~Word(0); Mv[w] = Word(0); }
     int score = m;
-    const int top_last = (m - 1) & 63;
+    const int top_last = (m - 1) & (BITS - 1);
     for (int i = 0; i < n; ++i) {
         const int c = text(i);
         if (NULTERM && c == 0) break;
         int h = 1;                                   // D[0][j] - D[0][j-1] = +1 (global alignment)
 #pragma unroll
         for (int w = 0; w < W; ++w) {
-            if (w < nw) h = fx_myers_block(Pv[w], Mv[w], peq(c, w), h, (w == nw - 1) ? top_last : 63);
+            if (w < nw) h = fx_myers_block<Word>(Pv[w], Mv[w], (Word)peq(c, w), h, (w == nw - 1) ? top_last : BITS - 1);
         }
         score += h;                                  // m == 0: no block runs, h stays +1 -> score = |text|
     }

@@ -41,6 +41,20 @@ class SeenSequences:
     def distances(self, seq: str) -> np.ndarray:
         return self._cache.distances(_native.ragged_to_bytes([seq], self._L), self._mode)[0]
 
+    def densities(self, seqs, dist_radius: int = 2):
+        """`[self.density(s) for s in seqs]` with ONE distance-matrix launch for the whole batch."""
+        seqs = [str(s) for s in seqs]
+        if not seqs or len(self._fitness) == 0:
+            return [0 for _ in seqs]
+        d_all = self._cache.distances(_native.ragged_to_bytes(seqs, self._L), self._mode)
+        out = []
+        for d in d_all:
+            dens = 0
+            for i in np.flatnonzero((d != 0) & (d <= dist_radius)):
+                dens += self._fitness[i] / int(d[i])
+            out.append(dens)
+        return out
+
     def density(self, seq: str, dist_radius: int = 2):
         """dyna_ppo.py:106-114: `dens += all_seqs[s] / dist` for 0 < dist <= radius, in insertion order."""
         dens = 0

@@ -87,3 +87,18 @@ class PopulationEvaluator:
             for m in self._members:
                 m.cost += fresh                                                # ensemble.py:55-57
         return seqs, values
+
+
+def terminal_rewards(evaluator: PopulationEvaluator, seen, states: np.ndarray, lam: float):
+    """Terminal branch of the DyNA-PPO environment step (environments/dyna_ppo.py:144-163) for the whole
+    environment batch: decode `states[:, :, :-1]` (the last column is the mask token), score the sequences,
+    record them in `seen` (a `flexs_amd.utils.edit_distance.SeenSequences`, the environment's `all_seqs`) and
+    return `(sequences, fitnesses, rewards)` with reward = fitness - lam * sequence_density, the density being
+    taken after the whole batch was recorded, as in the reference."""
+    states = np.asarray(states, np.float64)
+    seqs, fitnesses = evaluator.evaluate(states[:, :, :-1])
+    for seq, f in zip(seqs, fitnesses):
+        seen.add(seq, f)
+    dens = seen.densities(seqs)
+    rewards = np.array([f - lam * d for f, d in zip(fitnesses, dens)])
+    return seqs, fitnesses, rewards

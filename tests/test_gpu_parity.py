@@ -790,3 +790,41 @@ def test_population_evaluator_equals_one_by_one_loop(eng, which):
     if which != "host-stacked":
         with pytest.raises(ValueError):
             PopulationEvaluator(model, "UGCA", L)
+
+
+def test_terminal_rewards_equal_environment_loop(eng):
+    """environments/dyna_ppo.py:106-114 + 144-163 for a whole environment batch: same sequences, fitnesses and
+    density-penalised rewards as the per-sequence Python loops (density counted after the batch is recorded)."""
+    from flexs_amd.utils.edit_distance import SeenSequences
+    from flexs_amd.utils.population import PopulationEvaluator, terminal_rewards
+
+    L, alpha, B, lam = 14, "UGCA", 24, 0.1
+    rng = np.random.default_rng(6)
+    model = flexs_amd.Ensemble([bm.MLP(L, 100, alpha, seed=s) for s in range(2)])
+    twin = flexs_amd.Ensemble([bm.MLP(L, 100, alpha, seed=s) for s in range(2)])
+    seen, all_seqs = SeenSequences(L), {}
+    ev = PopulationEvaluator(model, alpha, L)
+    base = rng.integers(0, 4, L)
+    for episode in range(3):
+        states = np.zeros((B, L, len(alpha) + 1))
+        for b in range(B):
+            codes = base.copy()
+            m = rng.random(L) < 0.1
+            codes[m] = rng.integers(0, 4, m.sum())
+            states[b, np.arange(L), codes] = 1
+        states[1] = states[0]                                         # duplicates inside one batch
+        seqs, fit, rew = terminal_rewards(ev, seen, states, lam)
+        want_seqs = [ref_np.one_hot_to_string(st[:, :-1], alpha) for st in states]
+        want_fit = twin.get_fitness(want_seqs)
+        all_seqs.update(zip(want_seqs, want_fit.astype(np.float64)))
+        want_rew = []
+        for s_, f in zip(want_seqs, want_fit.astype(np.float64)):
+            dens = 0
+            for k in all_seqs:
+                dist = c_oracle.levenshtein(k, s_)
+                if dist != 0 and dist <= 2:
+                    dens += all_seqs[k] / dist
+            want_rew.append(f - lam * dens)
+        assert seqs == want_seqs and fit.tolist() == want_fit.astype(np.float64).tolist()
+        assert rew.tolist() == want_rew
+        assert model.cost == twin.cost and len(seen) == len(all_seqs)
