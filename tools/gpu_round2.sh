@@ -18,7 +18,7 @@ timeout 400 python bench.py --steps 200 --warmup 20 > $OUT/bench.log 2>&1
 echo "exit $?" >> $OUT/bench.log
 
 rm -rf $OUT/prof $OUT/pmc*
-timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof -o r1 -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/rocprof.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof -o r1 -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/rocprof.log 2>&1
 # PMC: one counter group per run, --pmc only (no trace domains)
 
 
