@@ -529,6 +529,30 @@ def test_baseline_config3_and_4_shapes(eng):
     assert np.array_equal(mean, np.mean(nm8, axis=1))
 
 
+def test_baseline_config5_one_gpu_share(eng):
+    """configs[4]: GFP L=237, A=20, 3-member CNN ensemble; one GPU's share of the 5e5 virtual screen
+    (62 500 sequences, pair kernel).  Oracle on a 600-row sample (6.5 MMAC per sequence and member),
+    size-independent properties on the whole batch: row independence under permutation, chunk
+    invariance, equal rows -> equal scores, mean == NumPy's, all bit-exact."""
+    L, alpha, N, M = 237, s_utils.AAS, 62_500, 3
+    natives, ws = zip(*[make_native(eng, "cnn", L, 20, 100, 32, 5, seed=3000 + m) for m in range(M)])
+    lut = _native.make_lut(alpha)
+    b, _ = rand_seqs(N, L, alpha, seed=9)
+    b[1000:1200] = b[:200]                                              # planted duplicates
+    nm, mean = eng.score(list(natives), b, lut, want_matrix=True, want_mean=True)
+    assert np.isfinite(nm).all() and np.array_equal(mean, np.mean(nm, axis=1))
+    assert np.array_equal(nm[1000:1200], nm[:200])
+    sample = np.random.default_rng(2).choice(N, 600, replace=False)
+    codes = lut[b[sample]]
+    for m in range(M):
+        assert_scores(nm[sample, m], c_oracle.forward("cnn", codes, 20, ws[m]), f"C5 member {m}")
+    perm = np.random.default_rng(3).permutation(N)
+    nm_p, _ = eng.score(list(natives), b[perm], lut)
+    assert np.array_equal(nm_p, nm[perm])
+    nm_c = np.concatenate([eng.score(list(natives), b[i:i + 20_011], lut)[0] for i in range(0, N, 20_011)])
+    assert np.array_equal(nm_c, nm)
+
+
 # ------------------------------------------------------------------ "next" rows (SURVEY.md 8f-3 / 8f-4)
 def _write_tf_file(path, rng, n_pairs=2000):
     comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
