@@ -529,6 +529,29 @@ def test_baseline_config3_and_4_shapes(eng):
     assert np.array_equal(mean, np.mean(nm8, axis=1))
 
 
+def test_baseline_config4_ten_million(eng):
+    """configs[3] at its upper size (N in {1e5, 1e7}): 1e7 AAV-length sequences x 8
+    GlobalEpistasis members through the host entry point (0.9 GB in, 0.36 GB out).  Oracle on a sample,
+    chunk invariance against separately scored slices, equal rows -> equal scores."""
+    L, alpha, N, M = 90, s_utils.AAS, 10_000_000, 8
+    natives, ws = zip(*[make_native(eng, "ge", L, 20, 100, seed=2000 + m) for m in range(M)])
+    lut = _native.make_lut(alpha)
+    rng = np.random.default_rng(12)
+    b = np.frombuffer(alpha.encode(), np.uint8)[rng.integers(0, 20, (N, L), dtype=np.uint8)]
+    b[N - 1000:] = b[:1000]
+    nm, mean = eng.score(list(natives), b, lut, want_matrix=True, want_mean=True)
+    assert nm.shape == (N, M) and np.isfinite(nm).all()
+    assert np.array_equal(nm[N - 1000:], nm[:1000])
+    sample = rng.choice(N, 4000, replace=False)
+    codes = lut[b[sample]]
+    for m in range(M):
+        assert_scores(nm[sample, m], c_oracle.forward("ge", codes, 20, ws[m]), f"C4 1e7 member {m}")
+    assert np.array_equal(mean[sample], np.mean(nm[sample], axis=1))
+    for lo in (0, 3_333_333, N - 70_001):
+        part, _ = eng.score(list(natives), b[lo:lo + 70_001], lut)
+        assert np.array_equal(part, nm[lo:lo + 70_001])
+
+
 def test_baseline_config5_one_gpu_share(eng):
     """configs[4]: GFP L=237, A=20, 3-member CNN ensemble; one GPU's share of the 5e5 virtual screen
     (62 500 sequences, pair kernel).  Oracle on a 600-row sample (6.5 MMAC per sequence and member),
