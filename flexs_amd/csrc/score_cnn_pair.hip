@@ -14,6 +14,14 @@
 // ~170 registers per wave -> 2+ waves per SIMD.  MFMA work is identical to the single-wave
 // form (no recomputation); tiles are dealt round-robin so that all waves of a block take the
 // same number of barriers.  Dense head: wave 0 of the pair (negligible next to the convs).
+//
+// SEG form (small batches: CMA-ES / DyNA-PPO populations of 1-40 protein sequences): a tile's L1 positions
+// are cut into SB x PAIRS segments, one per wave pair of SB workgroups.  A pair streams its segment plus a
+// halo of PL3 + PL2 positions before and PR2 + PR3 after it and pools only its own positions, so every conv3
+// output sees exactly the MFMA sequence of the whole-sequence form (bit-identical results).  Segment maxima
+// meet in a zeroed global pool through atomicMax on the float bits (post-ReLU values are >= 0, where float
+// order == unsigned order); the last workgroup of a tile to arrive runs the dense head.  Latency of a
+// 237-residue call drops from one wave walking 244 steps to ~40 steps.
 #include "fx_common.h"
 #include "mfma_common.h"
 
@@ -30,9 +38,32 @@ struct PairArgs {
     int L, rlh, htr;
     int off_c2, off_c3, off_cb, off_w1p, conv_floats, off_d1, off_d2, off_db;
     int lds_from, lds_floats;   // LDS image = packed[lds_from .. lds_from + lds_floats): conv2, conv3, biases, conv1 rows
+    int SB;                     // SEG form: workgroups per (member, tile) unit
+    unsigned* pool;             // SEG form: [units][2 tiles][64 lanes][4] pooled maxima (float bits), zeroed per launch
+    unsigned* cnt;              // SEG form: [units] arrival counters, zeroed per launch
 };
 
-template <int A, int K, int HT, int WAVES>
+// Dense head of one tile (cnn.py:49-54): 32 pooled features -> H -> H -> 1, one wave.
+template <int HT>
+__device__ __forceinline__ float pair_dense_head(const f4* w_d1, const f4* w_d2, const float* db, f4 pool0, f4 pool1,
+                                                 int lane, int g, int rlh) {
+    asm volatile("" : "+v"(w_d1), "+v"(w_d2), "+v"(db));   // keep block addresses out of the tile loop's live set
+    f4 pooled[2][1];
+    pooled[0][0] = pool0;
+    pooled[1][0] = pool1;
+    f4 h1[HT][1], h2[HT][1];
+    init_bias<HT, 1>(db, h1, g);
+    mma_layer<2, HT, 1>(w_d1, pooled, h1, lane);
+    relu_tiles<HT, 1>(h1);
+    init_bias<HT, 1>(db + 16 * HT, h2, g);
+    mma_layer<HT, HT, 1>(w_d2, h1, h2, lane, rlh);
+    relu_tiles<HT, 1>(h2);
+    float y[1];
+    final_dot<HT, 1>(db + 32 * HT, db[48 * HT], h2, y, g);
+    return y[0];
+}
+
+template <int A, int K, int HT, int WAVES, bool SEG>
 __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
     constexpr int FT = 2, K3 = A - 1, PAIRS = WAVES / 2;
     constexpr int PL2 = (K - 1) / 2, PR2 = K - 1 - PL2;
@@ -51,7 +82,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
         reinterpret_cast<uint32_t*>(lut_s)[i] = reinterpret_cast<const uint32_t*>(p.lut)[i];
 
     const int64_t U = (int64_t)p.M * p.TG;
-    const int64_t u_lo = U * blockIdx.x / gridDim.x, u_hi = U * (blockIdx.x + 1) / gridDim.x;
+    const int sb = SEG ? (int)(blockIdx.x % p.SB) : 0;
+    const int64_t u_lo = SEG ? (int64_t)(blockIdx.x / p.SB) : U * blockIdx.x / gridDim.x;
+    const int64_t u_hi = SEG ? u_lo + 1 : U * (blockIdx.x + 1) / gridDim.x;
     if (u_lo >= u_hi) return;
     const int m_first = (int)(u_lo / p.TG), m_last = (int)((u_hi - 1) / p.TG);
     bool bad = false;
@@ -74,18 +107,31 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
 
         const int64_t t_lo = (u_lo > (int64_t)m * p.TG ? u_lo : (int64_t)m * p.TG) - (int64_t)m * p.TG;
         const int64_t t_hi = (u_hi < (int64_t)(m + 1) * p.TG ? u_hi : (int64_t)(m + 1) * p.TG) - (int64_t)m * p.TG;
-        const int iters = (int)((t_hi - t_lo + PAIRS - 1) / PAIRS);
+        const int iters = SEG ? 1 : (int)((t_hi - t_lo + PAIRS - 1) / PAIRS);
 
         for (int it = 0; it < iters; ++it) {
-            const int64_t tg = t_lo + (int64_t)it * PAIRS + pair;
+            const int64_t tg = SEG ? t_lo : t_lo + (int64_t)it * PAIRS + pair;   // SEG: all pairs share the tile
             const bool live = tg < t_hi;                 // idle pairs run along (barriers) on sequence 0
             const int64_t n = tg * 16 + sq;
             const uint8_t* row = p.ascii + ((live && n < p.N) ? n : 0) * L;
 
+            const int steps = L1 + PR2 + PR3;
+            // positions this pair pools, the step it starts at, and the (block-uniform) number of steps
+            int seg_lo = 0, seg_hi = L1, s0 = 0, s_end = steps, nsteps = steps;
+            if (SEG) {
+                const int S = p.SB * PAIRS, q = sb * PAIRS + pair;
+                seg_lo = (int)((int64_t)L1 * q / S);
+                seg_hi = (int)((int64_t)L1 * (q + 1) / S);
+                s0 = seg_lo - PL3 - PL2 > 0 ? seg_lo - PL3 - PL2 : 0;
+                s_end = seg_hi + PR2 + PR3 < steps ? seg_hi + PR2 + PR3 : steps;
+                nsteps = (L1 + S - 1) / S + PL3 + PL2 + PR2 + PR3;
+            }
+            const int c2_from = seg_lo - PL3 > 0 ? seg_lo - PL3 : 0;   // first conv2 position this pair needs
+
             int cw[K];
 #pragma unroll
             for (int j = 0; j < K - 1; ++j) {
-                int c = lut_s[row[j]];
+                int c = lut_s[row[s0 + j]];
                 if (c == 0xFF) { bad |= live; c = 0; }
                 cw[j + 1] = c;
             }
@@ -98,8 +144,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
 #pragma unroll
             for (int j = 0; j < K3; ++j) accw[j] = bias3;
 
-            const int steps = L1 + PR2 + PR3;
-            for (int s = 0; s < steps; ++s) {
+            for (int k = 0; k < nsteps; ++k) {
+                const int s = s0 + k;
+                const bool on = !SEG || s < s_end;       // SEG: pairs with a shorter range idle along (barriers)
                 asm volatile("" ::: "memory");           // keep the LDS weight reads inside the position loop
 #pragma unroll
                 for (int j = 0; j < K - 1; ++j) {
@@ -108,7 +155,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
                     for (int t = 0; t < FT; ++t) win1[j][t] = win1[j + 1][t];
                 }
                 // ---- conv1 (valid) at t1 = s: gather of K kernel rows, both channel tiles
-                if (s < L1) {
+                if (on && s < L1) {
                     int c = lut_s[row[s + K - 1]];
                     if (c == 0xFF) { bad |= live; c = 0; }
                     cw[K - 1] = c;
@@ -130,7 +177,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
 
                 // ---- conv2 (same) at t2 = s - PR2, own output tile; two partial chains (one per input tile)
                 const int t2 = s - PR2;
-                if (t2 >= 0 && t2 < L1) {
+                const bool c2 = on && t2 >= c2_from && t2 < L1;
+                f4 mine = splat4(0.f);
+                f4* slot = xbuf + (((k & 1) * PAIRS + pair) * 2) * 64;
+                if (c2) {
                     f4 o2a = *reinterpret_cast<const f4*>(&cb[16 * FT + 16 * mo + 4 * g]);
                     f4 o2b = splat4(0.f);
 #pragma unroll
@@ -144,11 +194,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
                             o2b = mfma16(a1[r], win1[j][1][r], o2b);
                         }
                     }
-                    const f4 mine = relu4(o2a + o2b);
+                    mine = relu4(o2a + o2b);
                     // ---- swap halves with the partner wave (slot per parity: one barrier per step)
-                    f4* slot = xbuf + (((s & 1) * PAIRS + pair) * 2) * 64;
                     slot[mo * 64 + lane] = mine;
-                    __syncthreads();
+                    if (!SEG) __syncthreads();            // whole-sequence form: c2 is block-uniform
+                }
+                if (SEG) __syncthreads();                 // segment form: ranges differ per pair -> barrier every step
+                if (c2) {
                     const f4 theirs = slot[(1 - mo) * 64 + lane];
                     f4 out2[FT];                          // (no runtime-indexed register arrays: they go to scratch)
                     out2[0] = mo == 0 ? mine : theirs;
@@ -182,31 +234,44 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
                 }
                 // ---- slot 0 (position t2 - PR3) is complete: GlobalMaxPooling1D of relu(conv3), then slide
                 const int t3f = t2 - PR3;
-                if (t3f >= 0 && t3f < L1) gmax = max4(gmax, accw[0]);
+                if (t3f >= seg_lo && t3f < seg_hi) gmax = max4(gmax, accw[0]);
 #pragma unroll
                 for (int j = 0; j < K3 - 1; ++j) accw[j] = accw[j + 1];
                 accw[K3 - 1] = bias3;
             }
 
-            // ---- pooled features: swap halves once more, then wave 0 of the pair runs the dense head
-            f4* slot = xbuf + ((2 * PAIRS + pair) * 2) * 64;      // dedicated slot: no reuse hazard with the step slots
-            slot[mo * 64 + lane] = gmax;
-            __syncthreads();
-            if (mo == 0) {
-                asm volatile("" : "+v"(w_d1), "+v"(w_d2), "+v"(db));   // keep block addresses out of the tile loop's live set
-                f4 pooled[FT][1];
-                pooled[0][0] = gmax;
-                pooled[1][0] = slot[64 + lane];           // (rewritten only after the next tile's ~L barriers)
-                f4 h1[HT][1], h2[HT][1];
-                init_bias<HT, 1>(db, h1, g);
-                mma_layer<FT, HT, 1>(w_d1, pooled, h1, lane);
-                relu_tiles<HT, 1>(h1);
-                init_bias<HT, 1>(db + 16 * HT, h2, g);
-                mma_layer<HT, HT, 1>(w_d2, h1, h2, lane, p.rlh);
-                relu_tiles<HT, 1>(h2);
-                float y[1];
-                final_dot<HT, 1>(db + 32 * HT, db[48 * HT], h2, y, g);
-                if (g == 0 && live && n < p.N) p.out[n * p.Mtot + p.m_off + m] = fx_nan_to_num(y[0]);
+            if (!SEG) {
+                // ---- pooled features: swap halves once more, then wave 0 of the pair runs the dense head
+                f4* pslot = xbuf + ((2 * PAIRS + pair) * 2) * 64;  // dedicated slot: no reuse hazard with the step slots
+                pslot[mo * 64 + lane] = gmax;
+                __syncthreads();
+                if (mo == 0) {                            // (pslot is rewritten only after the next tile's ~L barriers)
+                    const float y = pair_dense_head<HT>(w_d1, w_d2, db, gmax, pslot[64 + lane], lane, g, p.rlh);
+                    if (g == 0 && live && n < p.N) p.out[n * p.Mtot + p.m_off + m] = fx_nan_to_num(y);
+                }
+            } else {
+                // ---- segment maxima meet in the global pool; the last workgroup of the tile runs the head
+                const int64_t unit = (int64_t)m * p.TG + tg;
+                unsigned* pl = p.pool + ((unit * 2 + mo) * 64 + lane) * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicMax(&pl[r], __float_as_uint(gmax[r]));
+                __threadfence();
+                __syncthreads();
+                int* last = reinterpret_cast<int*>(xbuf);                 // step slots are idle now
+                if (tid == 0) *last = (atomicAdd(&p.cnt[unit], 1u) == (unsigned)p.SB - 1u) ? 1 : 0;
+                __syncthreads();
+                if (*last && wave == 0) {
+                    __threadfence();
+                    const unsigned* p0 = p.pool + ((unit * 2 + 0) * 64 + lane) * 4;
+                    f4 pool0, pool1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {                         // device-coherent reads
+                        pool0[r] = __uint_as_float(__hip_atomic_load(&p0[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        pool1[r] = __uint_as_float(__hip_atomic_load(&p0[256 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    }
+                    const float y = pair_dense_head<HT>(w_d1, w_d2, db, pool0, pool1, lane, g, p.rlh);
+                    if (g == 0 && n < p.N) p.out[n * p.Mtot + p.m_off + m] = fx_nan_to_num(y);
+                }
             }
         }
     }
@@ -214,20 +279,41 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
 }
 
 template <int A, int K, int HT, int WAVES>
-int launch_pair(fx_engine* e, const PairArgs& a, size_t lds_bytes) {
-    auto kern = k_score_cnn_pair<A, K, HT, WAVES>;
+int launch_pair(fx_engine* e, PairArgs a, size_t lds_bytes) {
+    auto whole = k_score_cnn_pair<A, K, HT, WAVES, false>;
+    auto seg = k_score_cnn_pair<A, K, HT, WAVES, true>;
     static bool attr_set[64] = {};
     if (!attr_set[e->device & 63]) {
-        FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(whole), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(seg), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[e->device & 63] = true;
     }
     const int64_t U = (int64_t)a.M * a.TG;
+    const int L1 = a.L - K + 1;
+    // Small batch (a CMA-ES / DyNA-PPO population, a single sequence): fewer units than half the CUs.  Cut every
+    // tile into segments of >= 12 positions over SB workgroups so that the call's latency is ~L1/S + halo steps.
+    int64_t sb = L1 / ((WAVES / 2) * 12);
+    if (sb > e->num_cus / U) sb = e->num_cus / U;
+    if (e->cnn_pair_seg == 0 || 2 * U > e->num_cus) sb = 0;
+    if (e->cnn_pair_seg > 0) sb = e->cnn_pair_seg;                       // test knob: force SB
+    if (sb >= 1) {
+        void* ws = nullptr;
+        const size_t pool_bytes = (size_t)U * 2 * 64 * 4 * sizeof(unsigned), cnt_bytes = (size_t)U * sizeof(unsigned);
+        int rc = fx_scratch(e, 2, pool_bytes + cnt_bytes, &ws);
+        if (rc) return rc;
+        FX_HIP(e, hipMemsetAsync(ws, 0, pool_bytes + cnt_bytes, e->stream));
+        a.SB = (int)sb;
+        a.pool = (unsigned*)ws;
+        a.cnt = (unsigned*)((char*)ws + pool_bytes);
+        hipLaunchKernelGGL(seg, dim3((unsigned)(U * sb)), dim3(WAVES * 64), lds_bytes, e->stream, a);
+        FX_HIP(e, hipGetLastError());
+        return FX_OK;
+    }
     int64_t blocks = e->grid_blocks > 0 ? e->grid_blocks : e->num_cus;
-    const int64_t need = U;                          // small batches: one tile per workgroup (lowest latency)
+    const int64_t need = U;                          // one tile per workgroup at most
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), lds_bytes, e->stream, a);
+    hipLaunchKernelGGL(whole, dim3((unsigned)blocks), dim3(WAVES * 64), lds_bytes, e->stream, a);
     FX_HIP(e, hipGetLastError());
     return FX_OK;
 }

@@ -174,6 +174,34 @@ def test_cnn_gfp_length(eng, L):
     assert_scores(got[:, 0], want, f"cnn L={L}")
 
 
+@pytest.mark.parametrize("L,n,M", [(237, 40, 3), (238, 1, 1), (90, 16, 2), (90, 33, 1), (31, 5, 1), (60, 100, 2)])
+def test_cnn_pair_segmented_small_batches(eng, L, n, M):
+    """Position-segmented form of the wide-alphabet CNN kernel (CMA-ES / DyNA-PPO sized calls): every forced
+    segmentation (SB workgroups per tile) and the automatic one give the whole-sequence form's scores bit for bit,
+    and those match the oracle."""
+    natives, ws = zip(*[make_native(eng, "cnn", L, 20, 100, 32, 5, seed=40 + m) for m in range(M)])
+    lut = _native.make_lut(s_utils.AAS)
+    b, seqs = rand_seqs(n, L, s_utils.AAS, seed=L + n)
+    try:
+        eng.set_option("cnn_pair_seg", 0)
+        whole, _ = eng.score(list(natives), b, lut)
+        k = min(n, 64)
+        for m in range(M):
+            assert_scores(whole[:k, m], ref_np.keras_fitness(seqs[:k], s_utils.AAS, "cnn", ws[m], exact=True), f"pair L={L}")
+        for sb in (1, 2, 3, 5, 8, -1):
+            eng.set_option("cnn_pair_seg", sb)
+            got, mean = eng.score(list(natives), b, lut, want_matrix=True, want_mean=True)
+            assert np.array_equal(got, whole), (L, n, M, sb)
+            assert np.array_equal(mean, np.mean(whole, axis=1))
+        eng.set_option("cnn_pair_seg", 7)
+        bad = b.copy()
+        bad[n // 2, L - 3] = ord("Z")                     # bad character inside some segment only
+        with pytest.raises(ValueError):
+            eng.score(list(natives), bad, lut)
+    finally:
+        eng.set_option("cnn_pair_seg", -1)
+
+
 @pytest.mark.parametrize("L,A,alpha,F,H,K", [(3, 4, "TGCA", 1, 1, 2), (9, 4, "TGCA", 8, 20, 4), (12, 2, "01", 16, 30, 3),
                                              (10, 4, "TGCA", 32, 100, 3), (8, 4, "TGCA", 32, 200, 5),
                                              (5, 4, "TGCA", 32, 100, 5), (7, 20, s_utils.AAS, 4, 130, 2)])

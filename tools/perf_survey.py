@@ -165,6 +165,27 @@ def population():
         print(rows[-1], flush=True)
 
 
+def protein_small_calls():
+    """Latency of small calls on the GFP-length CNN ensemble, whole-sequence vs position-segmented pair kernel."""
+    from flexs_amd.utils import sequence_utils as s_utils
+
+    L, alpha = 237, s_utils.AAS
+    ens = flexs_amd.Ensemble([bm.CNN(L, 32, 100, alpha, seed=m) for m in range(3)])
+    for N in (1, 4, 16, 40, 100, 400):
+        seqs = synth.bytes_to_strings(synth.random_sequence_bytes(N, L, alpha, 3))
+        for seg, name in ((0, "whole-sequence form"), (-1, "segmented form (auto)")):
+            eng.set_option("cnn_pair_seg", seg)
+            for _ in range(3):
+                ens.get_fitness(seqs)
+            ts = []
+            for _ in range(30):
+                t0 = time.perf_counter(); ens.get_fitness(seqs); ts.append(time.perf_counter() - t0)
+            rows.append({"what": f"small call Ensemble(3xCNN L=237 A=20).get_fitness N={N}, {name}",
+                         "median_us": float(np.median(ts)) * 1e6, "seq_per_s": N / float(np.median(ts))})
+            print(rows[-1], flush=True)
+    eng.set_option("cnn_pair_seg", -1)
+
+
 def nam():
     rng = np.random.default_rng(0)
     for (L, nsym, Q, C) in ((14, 4, 100, 100), (14, 4, 100, 1000), (14, 4, 100, 20000), (14, 4, 2000, 20000),
@@ -207,7 +228,7 @@ def nam():
 
 
 def main():
-    which = sys.argv[1:] or ["score", "sweep", "hbm", "e2e", "nam", "population"]
+    which = sys.argv[1:] or ["score", "sweep", "hbm", "e2e", "nam", "population", "protein"]
     if "score" in which:
         for v in (1, 2, 3, 4):
             time_score("cnn", 8, "TGCA", 100, 3, 100_000, 32, 5, variant=v, label=f"C2 cnn L=8 M=3 N=1e5 variant {v} conv1=gather")
@@ -250,6 +271,8 @@ def main():
         nam()
     if "population" in which:
         population()
+    if "protein" in which:
+        protein_small_calls()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "perf_survey.json"), "w"), indent=1)
 
