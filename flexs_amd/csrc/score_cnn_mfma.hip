@@ -35,8 +35,14 @@ struct CnnArgs {
 
 // L1S > 0: number of conv positions known at compile time (L1S = seq_len - K + 1): the position loop is fully
 // unrolled, so the sliding windows become register renames instead of v_mov chains and the padding tests fold.
-template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1, int L1S = 0, bool PRIO = false>
+// SEG: small batches (fewer tiles than CUs) -- the WAVES waves of a workgroup share ONE tile and split its conv
+// positions: wave q streams segment q plus a halo of PL3 + PL2 positions before and PR2 + PR3 after it, pools
+// only its own positions (every conv3 output sees the same MFMA sequence as in the whole-sequence walk, so the
+// result is bit-identical), the segment maxima meet in LDS and wave 0 runs the dense head.
+template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1, int L1S = 0, bool PRIO = false,
+          bool SEG = false>
 __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
+    static_assert(!SEG || (NT == 1 && L1S == 0 && K * (A - 1) <= 16), "SEG is the ring-window, one-tile form");
     constexpr int K3 = A - 1;
     constexpr int PL2 = (K - 1) / 2, PR2 = K - 1 - PL2;
     constexpr int PL3 = (K3 - 1) / 2, PR3 = K3 - 1 - PL3;
@@ -84,11 +90,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
 
         // waves pull tiles from a block-local counter: a SIMD's two waves then finish within
         // one tile of each other whatever the split of the block's range was
-        for (;;) {
+        for (int64_t seg_tile = t_lo;; ++seg_tile) {
             int pulled = 0;
-            if (lane == 0) pulled = atomicAdd(next_tile, 1);
-            pulled = __builtin_amdgcn_readfirstlane(pulled);
-            const int64_t tg = t_lo + pulled;
+            if (!SEG) {
+                if (lane == 0) pulled = atomicAdd(next_tile, 1);
+                pulled = __builtin_amdgcn_readfirstlane(pulled);
+            }
+            const int64_t tg = SEG ? seg_tile : t_lo + pulled;   // SEG: every wave of the workgroup walks the same tiles
             if (tg >= t_hi) break;
             // ---- this lane's sequences
             int64_t n[NT];
@@ -132,11 +140,32 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                 for (int nt = 0; nt < NT; ++nt) gmax[t][nt] = splat4(0.f);   // relu output >= 0
 
             const int steps = L1 + PR2 + PR3;
-            for (int s0 = 0; s0 < steps; s0 += UN) {
+            // SEG: positions this wave pools, and the steps it has to run for them
+            int seg_lo = 0, seg_hi = L1, s_begin = 0, s_stop = steps;
+            if (SEG) {
+                const int q = tid >> 6;
+                seg_lo = (int)((int64_t)L1 * q / WAVES);
+                seg_hi = (int)((int64_t)L1 * (q + 1) / WAVES);
+                s_begin = seg_lo - PL3 - PL2 > 0 ? seg_lo - PL3 - PL2 : 0;
+                s_stop = seg_hi + PR2 + PR3 < steps ? seg_hi + PR2 + PR3 : steps;
+                if (seg_lo >= seg_hi) s_stop = 0;                 // more waves than positions: nothing to do
+            }
+            const int s_first = SEG ? (s_begin / UN) * UN : 0;     // ring slots assume block starts at multiples of UN
+            if (SEG && s_first > 0) {
+                // the code window is positional: refill it for the block this wave starts in
+#pragma unroll
+                for (int j = 0; j < K - 1; ++j) {
+                    int c = lut_s[row[0][s_first + j]];
+                    if (c == 0xFF) { bad = true; c = 0; }
+                    cw[j][0] = c;
+                }
+            }
+            for (int s0 = s_first; s0 < s_stop; s0 += UN) {
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
                 const int s = s0 + u;
-                if (L1S > 0 || s < steps) {
+                const bool act = !SEG || s >= s_begin;             // SEG: steps before the halo only advance the code window
+                if (L1S > 0 || s < s_stop) {
                 // weights in LDS are loop-invariant: without this barrier LICM hoists every
                 // ds_read out of the position loop and spills hundreds of VGPRs
                 // (fencing only every 2nd / 4th position of the unrolled kernels measured no gain: profiles/r1_run18)
@@ -176,6 +205,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                         if (c == 0xFF) { bad = true; c = 0; }
                         cw[FX_CW(K - 1)][nt] = c;
                     }
+                }
+                if (s < L1 && act) {
                     f4 o1[FT][NT];
                     init_bias<FT, NT>(cb, o1, g);
                     if (G1) {
@@ -223,7 +254,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
 
                 // ---- conv2 (same) at t2 = s - PR2; tap j reads out1[t2 + j - PL2] = out1[s - (K-1) + j]
                 const int t2 = s - PR2;
-                if (t2 >= 0 && t2 < L1) {
+                if (t2 >= 0 && t2 < L1 && act) {
                     f4 o2[FT][NT];
                     init_bias<FT, NT>(cb + 16 * FT, o2, g);
 #pragma unroll
@@ -247,7 +278,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                 // ---- conv3 (same, kernel A-1) at t3 = t2 - PR3; tap j reads out2[t3 + j - PL3] = out2[t2 - (K3-1) + j]
                 //      (MaxPooling1D(1) between conv2 and conv3 is the identity, cnn.py:40)
                 const int t3 = t2 - PR3;
-                if (t3 >= 0 && t3 < L1) {
+                if (t3 >= seg_lo && t3 < seg_hi) {
                     f4 o3[FT][NT];
                     init_bias<FT, NT>(cb + 32 * FT, o3, g);
 #pragma unroll
@@ -271,6 +302,19 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
             }
             }
 
+            if (SEG) {
+                // ---- segment maxima -> LDS; wave 0 folds them and carries on with the dense head
+                f4* seg_slot = reinterpret_cast<f4*>(smem + lds_floats + 64 + 4);   // after the LUT and the work counter
+                __syncthreads();                                  // previous tile's readers are done
+#pragma unroll
+                for (int t = 0; t < FT; ++t) seg_slot[((tid >> 6) * FT + t) * 64 + lane] = gmax[t][0];
+                __syncthreads();
+                if (tid >= 64) continue;
+#pragma unroll
+                for (int w = 1; w < WAVES; ++w)
+#pragma unroll
+                    for (int t = 0; t < FT; ++t) gmax[t][0] = max4(gmax[t][0], seg_slot[(w * FT + t) * 64 + lane]);
+            }
             // ---- dense head: F -> H relu -> H relu -> (dropout inactive) -> 1
             asm volatile("" ::: "memory");
             if (!DENSE_LDS) {
@@ -297,10 +341,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
     if (bad) fx_raise(p.err, FX_ERR_BADCHAR);
 }
 
-template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1, int L1S = 0, bool PRIO = false>
+template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1, int L1S = 0, bool PRIO = false,
+          bool SEG = false>
 int launch_g(fx_engine* e, const CnnArgs& a, size_t lds_bytes) {
     constexpr int waves = WAVES;
-    auto kern = k_score_cnn_mfma<A, K, FT, HT, NT, DENSE_LDS, WAVES, G1, L1S, PRIO>;
+    auto kern = k_score_cnn_mfma<A, K, FT, HT, NT, DENSE_LDS, WAVES, G1, L1S, PRIO, SEG>;
+    if (SEG) lds_bytes += (size_t)WAVES * FT * 64 * 16;          // segment-maxima slots
     static bool attr_set[64] = {};
     if (!attr_set[e->device & 63]) {
         FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -368,6 +414,16 @@ int dispatch_a4(fx_engine* e, const CnnArgs& a0, int variant, bool big, size_t f
         }
     }
     a.TG = (a.N + 15) / 16;
+    {
+        // small batch of long sequences (an explorer's 1-100 sequence call on an RNA landscape): the 8 waves of a
+        // workgroup split one tile's positions instead of 7 of them idling
+        const int64_t U = (int64_t)a.M * a.TG;
+        const int L1 = a.L - 5 + 1;
+        const bool seg = e->cnn_seg != 0 && variant == 0 && !e->cnn_conv1_mfma && U <= e->num_cus &&
+                         (e->cnn_seg > 0 || L1 >= 24) && lds + 8 * 2 * 64 * 16 <= (size_t)e->max_lds;
+        if (seg) return dl ? launch_g<4, 5, 2, HT_, 1, true, 8, true, 0, false, true>(e, a, lds)
+                           : launch_g<4, 5, 2, HT_, 1, false, 8, true, 0, false, true>(e, a, lds);
+    }
     if constexpr (HT_ <= 7) {
         if (big) return dl ? launch_inst<4, 5, 2, HT_, 1, true, 16>(e, a, lds) : launch_inst<4, 5, 2, HT_, 1, false, 16>(e, a, lds);
     }

@@ -174,6 +174,34 @@ def test_cnn_gfp_length(eng, L):
     assert_scores(got[:, 0], want, f"cnn L={L}")
 
 
+@pytest.mark.parametrize("L,n,M,H", [(100, 20, 3, 100), (50, 1, 1, 100), (50, 100, 2, 100), (14, 7, 1, 100), (9, 3, 1, 100),
+                                      (28, 33, 2, 64), (100, 16, 1, 200), (61, 40, 1, 256), (8, 5, 3, 100), (5, 2, 1, 100)])
+def test_cnn_position_split_small_batches(eng, L, n, M, H):
+    """Small batches of the 4-letter CNN kernel: the waves of a workgroup split one tile's positions (cnn_seg).
+    Forced on, automatic and off must agree bit for bit, and match the oracle -- including sequences with fewer
+    conv positions than waves (L = 5, 8, 9)."""
+    natives, ws = zip(*[make_native(eng, "cnn", L, 4, H, 32, 5, seed=70 + m) for m in range(M)])
+    lut = _native.make_lut("UGCA")
+    b, seqs = rand_seqs(n, L, "UGCA", seed=L * 3 + n)
+    try:
+        eng.set_option("cnn_seg", 0)
+        whole, _ = eng.score(list(natives), b, lut)
+        for m in range(M):
+            assert_scores(whole[:, m], ref_np.keras_fitness(seqs, "UGCA", "cnn", ws[m], exact=True), f"L={L} H={H}")
+        for mode in (1, -1):
+            eng.set_option("cnn_seg", mode)
+            got, mean = eng.score(list(natives), b, lut, want_matrix=True, want_mean=True)
+            assert np.array_equal(got, whole), (L, n, M, H, mode)
+            assert np.array_equal(mean, np.mean(whole, axis=1))
+        eng.set_option("cnn_seg", 1)
+        bad = b.copy()
+        bad[n // 2, L - 1] = ord("Z")
+        with pytest.raises(ValueError):
+            eng.score(list(natives), bad, lut)
+    finally:
+        eng.set_option("cnn_seg", -1)
+
+
 @pytest.mark.parametrize("L,n,M", [(237, 40, 3), (238, 1, 1), (90, 16, 2), (90, 33, 1), (31, 5, 1), (60, 100, 2)])
 def test_cnn_pair_segmented_small_batches(eng, L, n, M):
     """Position-segmented form of the wide-alphabet CNN kernel (CMA-ES / DyNA-PPO sized calls): every forced

@@ -184,6 +184,21 @@ def protein_small_calls():
                          "median_us": float(np.median(ts)) * 1e6, "seq_per_s": N / float(np.median(ts))})
             print(rows[-1], flush=True)
     eng.set_option("cnn_pair_seg", -1)
+    for L in (50, 100):
+        ens = flexs_amd.Ensemble([bm.CNN(L, 32, 100, "UGCA", seed=m) for m in range(3)])
+        for N in (1, 20, 100):
+            seqs = synth.bytes_to_strings(synth.random_sequence_bytes(N, L, "UGCA", 3))
+            for seg, name in ((0, "one wave per tile"), (-1, "waves split the positions (auto)")):
+                eng.set_option("cnn_seg", seg)
+                for _ in range(5):
+                    ens.get_fitness(seqs)
+                ts = []
+                for _ in range(100):
+                    t0 = time.perf_counter(); ens.get_fitness(seqs); ts.append(time.perf_counter() - t0)
+                rows.append({"what": f"small call Ensemble(3xCNN L={L} A=4).get_fitness N={N}, {name}",
+                             "median_us": float(np.median(ts)) * 1e6, "seq_per_s": N / float(np.median(ts))})
+                print(rows[-1], flush=True)
+    eng.set_option("cnn_seg", -1)
 
 
 def nam():
