@@ -20,50 +20,62 @@ namespace {
 
 constexpr int CHUNK = 1024;     // cache entries per block
 
+// Block prologue shared by both kernels: stage query `qi` in LDS, let thread c build the match masks of byte
+// value c, and return the query length (its first NUL, every thread finds it itself).
+template <int W, typename Word>
+__device__ __forceinline__ int load_query(const uint8_t* __restrict__ q, int64_t qi, int L, uint8_t* qs, Word* peq) {
+    constexpr int BITS = 8 * (int)sizeof(Word);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < L; i += 256) qs[i] = q[qi * L + i];
+    __syncthreads();
+    int m = L;
+    Word mk[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) mk[w] = 0;
+    for (int i = 0; i < L; ++i) {
+        const int ch = qs[i];
+        if (ch == 0) { m = i; break; }                 // NUL-padded (ragged) query
+        if (ch == tid) {
+#pragma unroll
+            for (int w = 0; w < W; ++w)
+                if ((i / BITS) == w) mk[w] |= Word(1) << (i % BITS);
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < W; ++w) peq[tid * W + w] = mk[w];
+    __syncthreads();
+    return m;
+}
+
+// Distance of the staged query to one cache row.
+template <int W, typename Word>
+__device__ __forceinline__ int pair_distance(int mode, int m, int L, const uint8_t* qs, const Word* peq,
+                                             const uint8_t* __restrict__ t) {
+    if (mode == FX_HAMMING) {
+        int d = 0;
+        for (int i = 0; i < L; ++i) d += (t[i] != qs[i]);
+        return d;
+    }
+    return fx_myers_distance<W, true, Word>(
+        m, L, [&](int ch, int w) { return peq[ch * W + w]; }, [&](int i) { return (int)t[i]; });
+}
+
 template <int W, typename Word>
 __global__ void __launch_bounds__(256) k_min_dist(int mode, const uint8_t* __restrict__ q, const uint8_t* __restrict__ cache,
                                                   int64_t C, int L, unsigned long long* __restrict__ keys) {
-    constexpr int BITS = 8 * (int)sizeof(Word);
     __shared__ Word peq[256 * W];
-    __shared__ uint8_t qs[W * BITS];
+    __shared__ uint8_t qs[W * 8 * sizeof(Word)];
     __shared__ unsigned long long wave_min[4];
     const int tid = threadIdx.x;
     const int64_t qi = blockIdx.y;
-    for (int i = tid; i < L; i += 256) qs[i] = q[qi * L + i];
-    __syncthreads();
-    int m = L;                                         // query length (every thread finds it itself)
-    {   // thread c builds the masks of byte value c
-        Word mk[W];
-#pragma unroll
-        for (int w = 0; w < W; ++w) mk[w] = 0;
-        for (int i = 0; i < L; ++i) {
-            const int ch = qs[i];
-            if (ch == 0) { m = i; break; }             // NUL-padded (ragged) query
-            if (ch == tid) {
-#pragma unroll
-                for (int w = 0; w < W; ++w)
-                    if ((i / BITS) == w) mk[w] |= Word(1) << (i % BITS);
-            }
-        }
-#pragma unroll
-        for (int w = 0; w < W; ++w) peq[tid * W + w] = mk[w];
-    }
-    __syncthreads();
+    const int m = load_query<W, Word>(q, qi, L, qs, peq);
 
     unsigned long long best = ~0ull;
     const int64_t c0 = (int64_t)blockIdx.x * CHUNK;
     for (int k = 0; k < CHUNK / 256; ++k) {
         const int64_t c = c0 + k * 256 + tid;
         if (c >= C) break;
-        const uint8_t* t = cache + c * L;
-        int d;
-        if (mode == FX_HAMMING) {
-            d = 0;
-            for (int i = 0; i < L; ++i) d += (t[i] != qs[i]);
-        } else {
-            d = fx_myers_distance<W, true, Word>(
-                m, L, [&](int ch, int w) { return peq[ch * W + w]; }, [&](int i) { return (int)t[i]; });
-        }
+        const int d = pair_distance<W, Word>(mode, m, L, qs, peq, cache + c * L);
         const unsigned dp = d == 1 ? 0u : (d == 0 ? 1u : (unsigned)d);
         const unsigned long long key = ((unsigned long long)dp << 32) | (unsigned long long)c;
         best = key < best ? key : best;
@@ -86,44 +98,15 @@ __global__ void __launch_bounds__(256) k_min_dist(int mode, const uint8_t* __res
 template <int W, typename Word>
 __global__ void __launch_bounds__(256) k_distances(int mode, const uint8_t* __restrict__ q, const uint8_t* __restrict__ cache,
                                                    int64_t C, int L, uint8_t* __restrict__ out) {
-    constexpr int BITS = 8 * (int)sizeof(Word);
     __shared__ Word peq[256 * W];
-    __shared__ uint8_t qs[W * BITS];
-    const int tid = threadIdx.x;
+    __shared__ uint8_t qs[W * 8 * sizeof(Word)];
     const int64_t qi = blockIdx.y;
-    for (int i = tid; i < L; i += 256) qs[i] = q[qi * L + i];
-    __syncthreads();
-    int m = L;
-    {
-        Word mk[W];
-#pragma unroll
-        for (int w = 0; w < W; ++w) mk[w] = 0;
-        for (int i = 0; i < L; ++i) {
-            const int ch = qs[i];
-            if (ch == 0) { m = i; break; }             // NUL-padded (ragged) query
-            if (ch == tid) {
-#pragma unroll
-                for (int w = 0; w < W; ++w)
-                    if ((i / BITS) == w) mk[w] |= Word(1) << (i % BITS);
-            }
-        }
-#pragma unroll
-        for (int w = 0; w < W; ++w) peq[tid * W + w] = mk[w];
-    }
-    __syncthreads();
+    const int m = load_query<W, Word>(q, qi, L, qs, peq);
     const int64_t c0 = (int64_t)blockIdx.x * CHUNK;
     for (int k = 0; k < CHUNK / 256; ++k) {
-        const int64_t c = c0 + k * 256 + tid;
+        const int64_t c = c0 + k * 256 + threadIdx.x;
         if (c >= C) break;
-        const uint8_t* t = cache + c * L;
-        int d;
-        if (mode == FX_HAMMING) {
-            d = 0;
-            for (int i = 0; i < L; ++i) d += (t[i] != qs[i]);
-        } else {
-            d = fx_myers_distance<W, true, Word>(
-                m, L, [&](int ch, int w) { return peq[ch * W + w]; }, [&](int i) { return (int)t[i]; });
-        }
+        const int d = pair_distance<W, Word>(mode, m, L, qs, peq, cache + c * L);
         out[qi * C + c] = (uint8_t)(d > 255 ? 255 : d);
     }
 }

@@ -153,26 +153,51 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) s[nt] = 0.f;
                 // eight positions per trip: the byte loads, LUT reads and table reads of a trip are independent,
-                // so their latencies overlap instead of chaining
-                for (int l0 = g; l0 < L; l0 += 32) {
+                // so their latencies overlap instead of chaining.  VALU instructions cost matrix-pipe time on gfx950
+                // (DESIGN.md section 4), so the trips that lie entirely inside the sequence run without the `l < L`
+                // selects, and bad characters are detected once per tile from the OR of all codes (a code is < A <= 127
+                // or 0xFF) instead of a compare + select per position.
+                unsigned seen = 0;
+                const int nfull = L >= 32 ? (L - 32) / 32 + 1 : 0;       // trips with l0 + 28 < L for every lane group
+                const unsigned amax = (unsigned)p.A - 1u;
+                for (int t = 0; t < nfull; ++t) {
+                    const int l0 = g + 32 * t;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         int raw[8];
 #pragma unroll
+                        for (int k = 0; k < 8; ++k) raw[k] = row[nt][l0 + 4 * k];
+                        const float* tab = w_first + l0 * p.A;
+#pragma unroll
                         for (int k = 0; k < 8; ++k) {
+                            const unsigned c = lut_s[raw[k]];
+                            seen |= c;
+                            const unsigned ci = c < amax ? c : amax;   // keeps the read inside the table for a bad character
+                            s[nt] += tab[4 * k * p.A + ci];
+                        }
+                    }
+                }
+                for (int l0 = g + 32 * nfull; l0 < L; l0 += 16) {        // guarded remainder, four positions per trip
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        int raw[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
                             const int l = l0 + 4 * k;
                             raw[k] = row[nt][l < L ? l : 0];
                         }
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) {
+                        for (int k = 0; k < 4; ++k) {
                             const int l = l0 + 4 * k;
-                            int c = lut_s[raw[k]];
-                            if (c == 0xFF) { bad |= (l < L); c = 0; }
-                            const float w = w_first[(l < L ? l : 0) * p.A + c];
+                            unsigned c = lut_s[raw[k]];
+                            seen |= (l < L) ? c : 0u;
+                            const unsigned ci = c < amax ? c : amax;
+                            const float w = w_first[(l < L ? l : 0) * p.A + ci];
                             s[nt] += (l < L) ? w : 0.f;
                         }
                     }
                 }
+                bad |= seen >= 0x80u;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     s[nt] += __shfl_xor(s[nt], 16);
@@ -280,6 +305,7 @@ int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, con
         if (t.kind != s.kind || t.L != s.L || t.A != s.A || t.H != s.H) return FX_EUNSUPPORTED;
     }
     if ((s.kind != FX_MLP && s.kind != FX_GE) || M > FX_MAX_M) return FX_EUNSUPPORTED;
+    if (s.kind == FX_GE && s.A > 127) return FX_EUNSUPPORTED;     // the gather's bad-character test ORs the codes: needs code < 0x80
     DenseArgs a{};
     a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
     for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
