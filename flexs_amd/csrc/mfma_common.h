@@ -22,11 +22,30 @@ __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// ReLU on the float bit pattern: a negative float is a negative integer, a non-negative one orders like its bits,
+// so max_i32(bits, 0) is relu(x) in exactly one VALU instruction (fmaxf makes the compiler quieten some MFMA
+// results first: an extra v_max_f32 v, v, v per component).  -0.0 -> +0.0; a NaN stays NaN or becomes 0 depending
+// on its sign bit and ends as 0 through nan_to_num either way.
+__device__ __forceinline__ float relu1(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
 __device__ __forceinline__ f4 relu4(f4 v) {
     f4 r;
-    r.x = fmaxf(v.x, 0.f); r.y = fmaxf(v.y, 0.f); r.z = fmaxf(v.z, 0.f); r.w = fmaxf(v.w, 0.f);
+    r.x = relu1(v.x); r.y = relu1(v.y); r.z = relu1(v.z); r.w = relu1(v.w);
     return r;
 }
+// Running global max of relu(x): `pool` is >= +0 throughout, so comparing the float bit patterns as signed
+// integers gives max(pool, x) -- any negative x (sign bit set) loses, non-negative floats order like integers --
+// in ONE v_max_i32 per component.  fmaxf would cost a second VALU instruction per component to quieten the MFMA
+// result first (IEEE mode), and VALU instructions cost matrix-pipe time here.  A NaN
+// activation wins the comparison and ends as 0 through nan_to_num, which is what np.max + np.nan_to_num give.
+__device__ __forceinline__ f4 pool_max4(f4 pool, f4 x) {
+    f4 r;
+    r.x = __int_as_float(max(__float_as_int(pool.x), __float_as_int(x.x)));
+    r.y = __int_as_float(max(__float_as_int(pool.y), __float_as_int(x.y)));
+    r.z = __int_as_float(max(__float_as_int(pool.z), __float_as_int(x.z)));
+    r.w = __int_as_float(max(__float_as_int(pool.w), __float_as_int(x.w)));
+    return r;
+}
+
 __device__ __forceinline__ f4 max4(f4 a, f4 b) {
     f4 r;
     r.x = fmaxf(a.x, b.x); r.y = fmaxf(a.y, b.y); r.z = fmaxf(a.z, b.z); r.w = fmaxf(a.w, b.w);

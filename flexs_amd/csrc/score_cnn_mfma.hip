@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
 #pragma unroll
                     for (int t = 0; t < FT; ++t)
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) gmax[t][nt] = max4(gmax[t][nt], o3[t][nt]);
+                        for (int nt = 0; nt < NT; ++nt) gmax[t][nt] = pool_max4(gmax[t][nt], o3[t][nt]);
                 }
 #undef FX_CW
 #undef FX_W1NEW
@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
 #pragma unroll
                 for (int w = 1; w < WAVES; ++w)
 #pragma unroll
-                    for (int t = 0; t < FT; ++t) gmax[t][0] = max4(gmax[t][0], seg_slot[(w * FT + t) * 64 + lane]);
+                    for (int t = 0; t < FT; ++t) gmax[t][0] = pool_max4(gmax[t][0], seg_slot[(w * FT + t) * 64 + lane]);
             }
             // ---- dense head: F -> H relu -> H relu -> (dropout inactive) -> 1
             asm volatile("" ::: "memory");

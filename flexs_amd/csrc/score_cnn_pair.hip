@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
                 }
                 // ---- slot 0 (position t2 - PR3) is complete: GlobalMaxPooling1D of relu(conv3), then slide
                 const int t3f = t2 - PR3;
-                if (t3f >= seg_lo && t3f < seg_hi) gmax = max4(gmax, accw[0]);
+                if (t3f >= seg_lo && t3f < seg_hi) gmax = pool_max4(gmax, accw[0]);
 #pragma unroll
                 for (int j = 0; j < K3 - 1; ++j) accw[j] = accw[j + 1];
                 accw[K3 - 1] = bias3;

@@ -212,12 +212,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                     const f4 b2 = *reinterpret_cast<const f4*>(&db[4 + 16 * HT + 16 * mo + 4 * g]);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        const float sv = fmaxf(s[nt], 0.f);
+                        const float sv = relu1(s[nt]);
                         f4 v;
-                        v.x = fmaxf(fmaf(sv, w2.x, b2.x), 0.f);
-                        v.y = fmaxf(fmaf(sv, w2.y, b2.y), 0.f);
-                        v.z = fmaxf(fmaf(sv, w2.z, b2.z), 0.f);
-                        v.w = fmaxf(fmaf(sv, w2.w, b2.w), 0.f);
+                        v.x = relu1(fmaf(sv, w2.x, b2.x));
+                        v.y = relu1(fmaf(sv, w2.y, b2.y));
+                        v.z = relu1(fmaf(sv, w2.z, b2.z));
+                        v.w = relu1(fmaf(sv, w2.w, b2.w));
                         h2[mo][nt] = v;
                     }
                 }
