@@ -89,6 +89,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                 init_bias<HT, NT>(db, h, g);
                 if (G1) {
                     // one-hot layer == sum of L kernel rows selected by the codes: LDS gather + VALU adds
+                    unsigned seen1 = 0;
+                    const unsigned amax1 = (unsigned)p.A - 1u;
                     for (int l0 = 0; l0 < L; l0 += 4) {
                         asm volatile("" ::: "memory");
 #pragma unroll
@@ -100,15 +102,17 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                             for (int k = 0; k < 4; ++k) {
                                 const int l = l0 + k;
                                 if (l < L) {
-                                    int c = lut_s[raw[k]];
-                                    if (c == 0xFF) { bad = true; c = 0; }
-                                    const float* rowp = w1p + (l * p.A + c) * (16 * HT) + 4 * g;
+                                    const unsigned c = lut_s[raw[k]];
+                                    seen1 |= c;                       // a code is < A <= 127, or 0xFF: tested once per tile
+                                    const unsigned ci = c < amax1 ? c : amax1;
+                                    const float* rowp = w1p + (l * p.A + ci) * (16 * HT) + 4 * g;
 #pragma unroll
                                     for (int mo = 0; mo < HT; ++mo) h[mo][nt] += *reinterpret_cast<const f4*>(rowp + 16 * mo);
                                 }
                             }
                         }
                     }
+                    bad |= seen1 >= 0x80u;
                 } else {
                     for (int sg = 0; sg < p.SG1; ++sg) {
                         asm volatile("" ::: "memory");
@@ -305,7 +309,7 @@ int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, con
         if (t.kind != s.kind || t.L != s.L || t.A != s.A || t.H != s.H) return FX_EUNSUPPORTED;
     }
     if ((s.kind != FX_MLP && s.kind != FX_GE) || M > FX_MAX_M) return FX_EUNSUPPORTED;
-    if (s.kind == FX_GE && s.A > 127) return FX_EUNSUPPORTED;     // the gather's bad-character test ORs the codes: needs code < 0x80
+    if (s.A > 127) return FX_EUNSUPPORTED;                        // the gathers' bad-character test ORs the codes: needs code < 0x80
     DenseArgs a{};
     a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
     for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
