@@ -78,6 +78,7 @@ struct fx_engine {
     int64_t cnn_conv1_mfma = 0; // 1 = one-hot conv1 on MFMA instead of the LDS gather (A/B knob)
     int64_t poison_outputs = 0; // test knob: fill score buffers with NaN before launching, so an element no kernel wrote is caught
     int64_t cnn_pair = 1;       // 1 = wide alphabets (A = 20) use the two-waves-per-tile kernel (score_cnn_pair.hip)
+    int64_t cnn_big_units = 12; // work units per CU from which the A = 4 CNN path switches to 16-wave (unrolled) workgroups
     int64_t cnn_seg = -1;       // A = 4 CNN kernel, small batches: -1 = waves of a workgroup split one tile's positions when L1 >= 24, 0 = never, 1 = whenever the batch is small
     int64_t cnn_pair_seg = -1;  // pair kernel, small batches: -1 = segment a tile's positions automatically, 0 = never, n > 0 = force SB = n workgroups per tile
     int64_t mlp_l1_mfma = 0;    // 1 = one-hot MLP layer 1 on MFMA instead of the LDS gather (A/B knob)

@@ -455,7 +455,7 @@ int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const
 
     const size_t full = (size_t)lay.total_floats * 4 + 256 + 16, conv_only = (size_t)lay.conv_floats * 4 + 256 + 16;
     if (s.A == 4) {
-        const bool big = ((N + 15) / 16) * M >= (int64_t)e->num_cus * 32;
+        const bool big = ((N + 15) / 16) * M >= (int64_t)e->num_cus * e->cnn_big_units;   // units per CU from which 16-wave workgroups pay
         const int variant = (int)e->cnn_variant;
         switch (lay.HT) {
             case 1: return dispatch_a4<1>(e, a, variant, big, full, conv_only);
