@@ -94,8 +94,8 @@ def main():
                     help="cpu_baseline additionally times the NoisyAbstractModel CPU path (adds ~20 s)")
     ap.add_argument("--variant", type=int, default=0, help="cnn kernel variant (0 = auto)")
     ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--reserve-cus", type=int, default=0,
-                    help="CUs left free for RCCL when running distributed (measured: no benefit, profiles/r1_run6_rccl_overlap_probe.md)")
+    ap.add_argument("--reserve-cus", type=int, default=-1,
+                    help="CUs left free for RCCL when running distributed; -1 = 4 when WORLD_SIZE > 1, else 0")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the all-gather even with one rank (exercises the N>1 code path)")
     args = ap.parse_args()
@@ -128,10 +128,15 @@ def main():
     eng = _native.Engine.get(local_rank)
     if args.variant:
         eng.set_option("cnn_variant", args.variant)
-    if use_dist and args.reserve_cus > 0:
-        # K1 is a persistent one-workgroup-per-CU kernel: leave a few CUs to RCCL's channel workgroups so the
-        # (asynchronous) all-gather of step k really runs next to step k+1 instead of queueing behind it
-        eng.set_option("grid_blocks", max(1, eng.get_option("num_cus") - args.reserve_cus))
+    reserve = args.reserve_cus if args.reserve_cus >= 0 else (4 if world > 1 else 0)
+    if use_dist and reserve > 0:
+        # K1 is a persistent one-workgroup-per-CU kernel whose 16 waves x 128 VGPRs fill a CU's register file, so
+        # RCCL's channel workgroups cannot co-reside with it: with every CU taken, the all-gather of step k would
+        # start only when two K1 workgroups of step k+1 have been held back for it, stretching that launch by the
+        # collective's latency.  Leaving a few CUs free (1.6 % of K1's throughput) lets it run next to step k+1.
+        # (With one rank the collective is a copy, so this could not be measured on the 1-GPU boxes:
+        # profiles/r1_run6_rccl_overlap_probe.md.)
+        eng.set_option("grid_blocks", max(1, eng.get_option("num_cus") - reserve))
     stream = torch.cuda.Stream()
     lut = _native.make_lut(ALPHABET)
     arch = Architecture("cnn", L, len(ALPHABET), H, num_filters=F, kernel_size=K)
