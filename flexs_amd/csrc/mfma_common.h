@@ -51,6 +51,22 @@ __device__ __forceinline__ f4 max4(f4 a, f4 b) {
     r.x = fmaxf(a.x, b.x); r.y = fmaxf(a.y, b.y); r.z = fmaxf(a.z, b.z); r.w = fmaxf(a.w, b.w);
     return r;
 }
+// Workgroup copy of a member's packed weights into LDS.  Eight 16-byte loads are in flight per thread before the
+// first LDS store, so the ~100 KiB image costs a couple of L2 round trips instead of one per 16 bytes per thread
+// (which is what a plain copy loop compiles to, and what small calls and small batches then mostly wait for).
+__device__ __forceinline__ void fill_lds(f4* __restrict__ dst, const f4* __restrict__ src, int n4) {
+    const int bd = blockDim.x;
+    for (int i0 = threadIdx.x; i0 < n4; i0 += 8 * bd) {
+        f4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (i0 + k * bd < n4) v[k] = src[i0 + k * bd];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (i0 + k * bd < n4) dst[i0 + k * bd] = v[k];
+    }
+}
+
 __device__ __forceinline__ f4 splat4(float v) { f4 r = {v, v, v, v}; return r; }
 
 __device__ __forceinline__ float fx_nan_to_num(float v) {

@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
         {
             const f4* src = reinterpret_cast<const f4*>(p.w[m]);
             f4* dst = reinterpret_cast<f4*>(smem);
-            for (int i = tid; i < lds_floats / 4; i += blockDim.x) dst[i] = src[i];
+            fill_lds(dst, src, lds_floats / 4);
         }
         __syncthreads();
         const f4* w_first = reinterpret_cast<const f4*>(smem + p.off_first);

@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
         {
             const f4* src = reinterpret_cast<const f4*>(p.w[m] + p.lds_from);
             f4* dst = reinterpret_cast<f4*>(smem);
-            for (int i = tid; i < p.lds_floats / 4; i += blockDim.x) dst[i] = src[i];
+            fill_lds(dst, src, p.lds_floats / 4);
         }
         __syncthreads();
         const f4* w_c2 = reinterpret_cast<const f4*>(smem + (p.off_c2 - p.lds_from));
