@@ -931,3 +931,41 @@ def test_terminal_rewards_equal_environment_loop(eng):
         assert seqs == want_seqs and fit.tolist() == want_fit.astype(np.float64).tolist()
         assert rew.tolist() == want_rew
         assert model.cost == twin.cost and len(seen) == len(all_seqs)
+
+
+def test_distributed_classes_on_one_rank_rccl(eng):
+    """flexs_amd.distributed over a real one-rank RCCL group (backend "nccl"): the device all-gather, weight
+    broadcast and the default on-engine scorers -- what the gloo tests replace by stubs -- give the single-GPU
+    Ensemble / cache answers."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from flexs_amd import distributed as fd
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        L, alpha = 14, "UGCA"
+        members = [bm.CNN(L, 32, 100, alpha, seed=0), bm.CNN(L, 32, 100, alpha, seed=1), bm.CNN(L, 32, 100, alpha, seed=2)]
+        b, seqs = rand_seqs(257, L, alpha, seed=4)
+        want = flexs_amd.Ensemble(members).get_fitness(seqs)
+        stack = np.stack([m.get_fitness(seqs) for m in members], axis=1)
+        for mode in ("member", "sequence"):
+            ens = fd.DistributedEnsemble(members, mode=mode)
+            assert np.array_equal(ens.get_fitness(seqs), want)
+            assert np.array_equal(fd.DistributedEnsemble(members, mode=mode, combine_with=lambda x: x).get_fitness(seqs), stack)
+            ens.broadcast_weights(src=0)
+            assert np.array_equal(ens.get_fitness(seqs), want)
+        sc = fd.ShardedCache(L)
+        sc.append(b[:200])
+        d, a = sc.min_dist(b[150:])
+        d_want, a_want = c_oracle.min_dist(b[150:], b[:200], 0)
+        assert np.array_equal(d, d_want) and np.array_equal(a, a_want)
+    finally:
+        dist.destroy_process_group()
