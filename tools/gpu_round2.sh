@@ -32,5 +32,5 @@ timeout 900 python tools/perf_survey.py > $OUT/perf_survey.log 2>&1
 echo "exit $?" >> $OUT/perf_survey.log
 tail -2 $OUT/pytest_gpu.log; tail -2 $OUT/bench.log | cut -c1-400
 # the N>1 code path (RCCL init + all-gather + max-over-ranks) on one rank
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 50 --warmup 5 --force-dist --no-cpu-baseline > $OUT/bench_dist1.log 2>&1
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 50 --warmup 5 --force-dist --reserve-cus 4 --no-cpu-baseline > $OUT/bench_dist1.log 2>&1
 echo "exit $?" >> $OUT/bench_dist1.log
