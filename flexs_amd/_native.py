@@ -49,6 +49,7 @@ SIGNATURES = {
     "fx_model_set_weights": (C.c_int, [_vp, _f32p, C.c_int64]),
     "fx_model_get_weights": (C.c_int, [_vp, _f32p, C.c_int64]),
     "fx_score": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _vp, C.c_int64, C.c_int, _u8p, _vp, _vp]),
+    "fx_staging_input": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp)]),
     "fx_score_dev": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _vp, C.c_int64, C.c_int, _u8p, _vp, _vp]),
     "fx_encode_onehot": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _u8p, C.c_int, _vp]),
     "fx_encode_onehot_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _u8p, C.c_int, _vp]),
@@ -159,7 +160,7 @@ def ragged_to_bytes(sequences, L: int) -> np.ndarray:
     return out
 
 
-def sequences_to_bytes(sequences, L: Optional[int] = None) -> np.ndarray:
+def sequences_to_bytes(sequences, L: Optional[int] = None, staging: Optional["Engine"] = None) -> np.ndarray:
     """list/tuple/ndarray of str -> contiguous (N, L) uint8 (latin-1 code points).
 
     Raises ValueError for ragged batches (Keras raises on a shape mismatch) and
@@ -188,7 +189,8 @@ def sequences_to_bytes(sequences, L: Optional[int] = None) -> np.ndarray:
             return np.zeros((0, L or 0), np.uint8)
         w = len(seqs[0])
         if _strpack is not None:
-            out = np.empty((N, w), np.uint8)
+            # with `staging`, straight into the engine's pinned input area (big batches: saves one pass over the bytes)
+            out = staging.staging_rows(N, w) if (staging is not None and N * w >= (256 << 10)) else np.empty((N, w), np.uint8)
             status = _strpack.pack(seqs, w, out)          # one pass, memcpy per string (csrc/strpack.c)
         else:                                             # same checks in pure Python (helper not built)
             joined = "".join(seqs)
@@ -264,6 +266,14 @@ class Engine:
         ms = C.c_float()
         self.check(self._lib.fx_timer_stop(self.handle, C.byref(ms)))
         return ms.value
+
+    def staging_rows(self, n: int, width: int) -> np.ndarray:
+        """(n, width) uint8 view of the engine's pinned input staging area: marshal strings straight into it and
+        hand it to `score` -- the call then skips its pageable-to-pinned copy.  Valid until the next call."""
+        p = _vp()
+        self.check(self._lib.fx_staging_input(self.handle, n * width, C.byref(p)))
+        buf = (C.c_uint8 * max(n * width, 1)).from_address(p.value)
+        return np.frombuffer(buf, np.uint8, n * width).reshape(n, width)
 
     # ---- scoring
     def score(self, models: Sequence["NativeModel"], seq_bytes: np.ndarray, lut: np.ndarray,

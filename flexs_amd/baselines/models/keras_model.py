@@ -138,7 +138,7 @@ class KerasModel(flexs_amd.Model):
     def _fitness_function(self, sequences):
         """keras_model.py:69-79: encode -> float32 tensor -> predict -> squeeze ->
         nan_to_num, fused on the GPU.  Returns float32 (N,)."""
-        seq_bytes = _native.sequences_to_bytes(sequences, L=self.model.L)
+        seq_bytes = _native.sequences_to_bytes(sequences, L=self.model.L, staging=self._engine())
         if seq_bytes.shape[0] == 0:
             return np.zeros((0,), np.float32)
         nm, _ = self._engine().score([self.native()], seq_bytes, self._lut, want_matrix=True)

@@ -335,6 +335,12 @@ int fx_score_dev(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_
     return rc;
 }
 
+int fx_staging_input(fx_engine* e, int64_t bytes, void** host) {
+    if (!e || bytes < 0 || !host) return FX_EINVAL;
+    FX_HIP(e, hipSetDevice(e->device));
+    return fx_pinned(e, 0, (size_t)std::max<int64_t>(bytes, 1), host);
+}
+
 int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii, int64_t N, int L,
              const uint8_t lut[256], float* out_NM, float* out_mean) {
     int rc = validate_models(e, models, M, L, lut);
@@ -354,7 +360,7 @@ int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii,
     if ((rc = fx_scratch(e, 1, nm_bytes + mean_bytes, &d_out))) return rc;
     float* d_NM = (float*)d_out;
     float* d_mean = (float*)((char*)d_out + nm_bytes);
-    std::memcpy(h_in, ascii, in_bytes);
+    if (ascii != h_in) std::memcpy(h_in, ascii, in_bytes);   // (fx_staging_input callers marshalled straight into it)
     if ((rc = fx_upload_lut(e, lut))) return rc;
     if (in_bytes + nm_bytes + mean_bytes <= (size_t)(256 << 10)) {
         // Small call (what Adalead / CMA-ES / DynaPPO issue): zero-copy through the mapped pinned

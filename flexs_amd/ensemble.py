@@ -63,7 +63,7 @@ class Ensemble(_EnsembleBase):
             for m in self.models:
                 m.cost += n
             m0 = self.models[0]
-            seq_bytes = _native.sequences_to_bytes(sequences, L=m0.model.L)
+            seq_bytes = _native.sequences_to_bytes(sequences, L=m0.model.L, staging=m0._engine())
             if seq_bytes.shape[0] == 0:
                 scores = np.zeros((0, len(self.models)), np.float32)
                 return self.combine_with(scores)

@@ -108,6 +108,12 @@ int fx_model_set_weights(fx_model *m, const float *blob, int64_t n);
 int fx_model_get_weights(const fx_model *m, float *blob, int64_t n);
 
 /* ------------------------------------------------------------------ scoring */
+/* The engine's pinned, GPU-mapped input staging area, grown to at least `bytes`.  A caller that
+ * marshals its strings straight into it (instead of into pageable memory) and then passes the
+ * same pointer to fx_score saves that call's host-to-staging copy.  The pointer is valid until
+ * the next fx_staging_input / fx_score on this engine asks for more. */
+int fx_staging_input(fx_engine *e, int64_t bytes, void **host);
+
 /* KerasModel._fitness_function (keras_model.py:69-79) for M models that share
  * (L, A) + Ensemble._fitness_function (ensemble.py:54-59) fused:
  *   ascii  N x L bytes, row-major, one sequence per row (no terminators)

@@ -1,0 +1,11 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+python -c "import __graft_entry__ as g; g.build(quiet=True); print('build ok')" > gpurun_out/env.log 2>&1
+timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --timeout 600 -k "drop_in or errors or config1 or round_loop or reference_scenarios or population or smoke or ensemble" > gpurun_out/pytest_k.log 2>&1
+echo "pytest exit: $?" >> gpurun_out/pytest_k.log
+tail -5 gpurun_out/pytest_k.log
+timeout 300 python tools/perf_survey.py e2e > gpurun_out/perf_e2e.log 2>&1
+cp gpurun_out/perf_survey.json gpurun_out/perf_e2e.json
+grep "end-to-end\|marshalling" gpurun_out/perf_e2e.log | cut -c1-220
