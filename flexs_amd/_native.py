@@ -50,6 +50,9 @@ SIGNATURES = {
     "fx_model_get_weights": (C.c_int, [_vp, _f32p, C.c_int64]),
     "fx_score": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _vp, C.c_int64, C.c_int, _u8p, _vp, _vp]),
     "fx_staging_input": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp)]),
+    "fx_score_begin": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int64, C.c_int, _u8p, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "fx_score_submit": (C.c_int, [_vp, C.c_int64, C.c_int64]),
+    "fx_score_finish": (C.c_int, [_vp, _vp, _vp]),
     "fx_score_dev": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _vp, C.c_int64, C.c_int, _u8p, _vp, _vp]),
     "fx_encode_onehot": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _u8p, C.c_int, _vp]),
     "fx_encode_onehot_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _u8p, C.c_int, _vp]),
@@ -211,6 +214,14 @@ def sequences_to_bytes(sequences, L: Optional[int] = None, staging: Optional["En
     return out
 
 
+CHUNKED_MIN_ROWS = 32768        # list[str] batches from this size on are packed and scored in overlapping pieces
+
+
+def wants_chunked(sequences, L: int) -> bool:
+    return (_strpack is not None and isinstance(sequences, (list, tuple)) and len(sequences) >= CHUNKED_MIN_ROWS
+            and isinstance(sequences[0], str) and len(sequences[0]) == L)
+
+
 class Engine:
     """One GPU's scoring engine (stream, scratch, deferred-error word)."""
 
@@ -286,6 +297,42 @@ class Engine:
         seq_bytes = np.ascontiguousarray(seq_bytes)
         self.check(self._lib.fx_score(self.handle, arr, M, _ptr(seq_bytes), N, L,
                                       lut.ctypes.data_as(_u8p), _ptr(out_nm), _ptr(out_mean)))
+        return out_nm, out_mean
+
+    def score_strings(self, models: Sequence["NativeModel"], seqs, L: int, lut: np.ndarray,
+                      want_matrix: bool = True, want_mean: bool = False, chunks: int = 0):
+        """`score` for a big list / tuple of str: the strings are packed into the pinned staging area in `chunks`
+        pieces and each piece is submitted as soon as it is packed, so packing piece k+1 (host) overlaps the
+        transfer and scoring of piece k (GPU).  Same results and exceptions as sequences_to_bytes + score."""
+        N, M = len(seqs), len(models)
+        arr = (_vp * M)(*[m.handle for m in models])
+        p = _vp()
+        self.check(self._lib.fx_score_begin(self.handle, arr, M, N, L, lut.ctypes.data_as(_u8p), int(want_matrix),
+                                            int(want_mean), C.byref(p)))
+        staging = np.frombuffer((C.c_uint8 * (N * L)).from_address(p.value), np.uint8, N * L).reshape(N, L)
+        if chunks <= 0:
+            chunks = min(max(N // 65536, 2), 16)          # ~64k-row pieces (measured: profiles/r1_run45_chunked_strings.log)
+        step = -(-N // chunks)
+        step += -step % 256
+        status = 0
+        try:
+            for r0 in range(0, N, step):
+                rows = min(step, N - r0)
+                status = _strpack.pack(seqs, L, staging[r0:r0 + rows], r0, rows)
+                if status:
+                    break
+                self.check(self._lib.fx_score_submit(self.handle, r0, rows))
+        finally:
+            out_nm = np.empty((N, M), np.float32) if want_matrix else None
+            out_mean = np.empty((N,), np.float32) if want_mean else None
+            rc = self._lib.fx_score_finish(self.handle, _ptr(out_nm), _ptr(out_mean))
+        if status == 1:
+            raise ValueError("ragged sequence batch: all sequences must have the same length")
+        if status == 2:
+            raise ValueError("substring not found")
+        if status == 3:
+            raise TypeError("sequences must be str")
+        self.check(rc)
         return out_nm, out_mean
 
     def score_dev(self, models: Sequence["NativeModel"], d_ascii: int, N: int, L: int, lut: np.ndarray,

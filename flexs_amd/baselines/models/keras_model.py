@@ -138,6 +138,9 @@ class KerasModel(flexs_amd.Model):
     def _fitness_function(self, sequences):
         """keras_model.py:69-79: encode -> float32 tensor -> predict -> squeeze ->
         nan_to_num, fused on the GPU.  Returns float32 (N,)."""
+        if _native.wants_chunked(sequences, self.model.L):
+            nm, _ = self._engine().score_strings([self.native()], sequences, self.model.L, self._lut, want_matrix=True)
+            return nm[:, 0]
         seq_bytes = _native.sequences_to_bytes(sequences, L=self.model.L, staging=self._engine())
         if seq_bytes.shape[0] == 0:
             return np.zeros((0,), np.float32)

@@ -390,6 +390,73 @@ int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii,
     return FX_OK;
 }
 
+// ---- the same call in pieces: the caller fills the pinned staging area chunk by chunk and submits each chunk
+// as soon as it is ready, so that marshalling chunk k+1 on the host overlaps transfer + scoring of chunk k.
+int fx_score_begin(fx_engine* e, fx_model* const* models, int M, int64_t N, int L, const uint8_t lut[256],
+                   int want_nm, int want_mean, void** staging) {
+    int rc = validate_models(e, models, M, L, lut);
+    if (rc) return rc;
+    if (N < 1 || !staging || (!want_nm && !want_mean)) return fx_fail(e, FX_EINVAL, "fx_score_begin: bad arguments");
+    if (e->chunked.active) return fx_fail(e, FX_ESTATE, "fx_score_begin: a chunked call is already in flight");
+    FX_HIP(e, hipSetDevice(e->device));
+    const size_t in_bytes = (size_t)N * (size_t)L;
+    const size_t nm_bytes = sizeof(float) * (size_t)N * (size_t)M, mean_bytes = sizeof(float) * (size_t)N;
+    void *d_in = nullptr, *h_in = nullptr, *h_out = nullptr, *d_out = nullptr;
+    if ((rc = fx_scratch(e, 0, in_bytes + 16, &d_in))) return rc;
+    if ((rc = fx_pinned(e, 0, in_bytes, &h_in))) return rc;
+    if ((rc = fx_pinned(e, 1, nm_bytes + mean_bytes, &h_out))) return rc;
+    if ((rc = fx_scratch(e, 1, nm_bytes + mean_bytes, &d_out))) return rc;
+    if ((rc = fx_upload_lut(e, lut))) return rc;
+    auto& c = e->chunked;
+    c.models.assign(models, models + M);
+    c.N = N; c.L = L; c.want_nm = want_nm != 0; c.want_mean = want_mean != 0;
+    c.h_in = (uint8_t*)h_in; c.d_in = (uint8_t*)d_in;
+    c.d_nm = (float*)d_out; c.d_mean = (float*)((char*)d_out + nm_bytes);
+    c.h_out = (char*)h_out;
+    c.active = true;
+    *staging = h_in;
+    return FX_OK;
+}
+
+int fx_score_submit(fx_engine* e, int64_t row0, int64_t rows) {
+    if (!e) return FX_EINVAL;
+    auto& c = e->chunked;
+    if (!c.active) return fx_fail(e, FX_ESTATE, "fx_score_submit without fx_score_begin");
+    if (row0 < 0 || rows < 0 || row0 + rows > c.N) return fx_fail(e, FX_EINVAL, "fx_score_submit: rows out of range");
+    if (rows == 0) return FX_OK;
+    FX_HIP(e, hipSetDevice(e->device));
+    const int M = (int)c.models.size();
+    const size_t nm_bytes = sizeof(float) * (size_t)c.N * (size_t)M;
+    int rc;
+    FX_HIP(e, hipMemcpyAsync(c.d_in + row0 * c.L, c.h_in + row0 * c.L, (size_t)rows * c.L, hipMemcpyHostToDevice, e->stream));
+    float* nm = c.d_nm + row0 * M;
+    if ((rc = score_dispatch(e, c.models.data(), M, c.d_in + row0 * c.L, rows, c.L, nm))) return rc;
+    if (c.want_mean) {
+        if ((rc = fx_launch_ensemble_reduce(e, nm, rows, M, nullptr, c.d_mean + row0, nullptr))) return rc;
+        FX_HIP(e, hipMemcpyAsync(c.h_out + nm_bytes + sizeof(float) * row0, c.d_mean + row0, sizeof(float) * rows,
+                                 hipMemcpyDeviceToHost, e->stream));
+    }
+    if (c.want_nm)
+        FX_HIP(e, hipMemcpyAsync(c.h_out + sizeof(float) * row0 * M, nm, sizeof(float) * rows * M, hipMemcpyDeviceToHost, e->stream));
+    return FX_OK;
+}
+
+int fx_score_finish(fx_engine* e, float* out_NM, float* out_mean) {
+    if (!e) return FX_EINVAL;
+    auto& c = e->chunked;
+    if (!c.active) return fx_fail(e, FX_ESTATE, "fx_score_finish without fx_score_begin");
+    c.active = false;
+    FX_HIP(e, hipSetDevice(e->device));
+    FX_HIP(e, hipStreamSynchronize(e->stream));
+    int rc = check_deferred(e);
+    if (rc) return rc;
+    const int M = (int)c.models.size();
+    const size_t nm_bytes = sizeof(float) * (size_t)c.N * (size_t)M;
+    if (c.want_nm && out_NM) std::memcpy(out_NM, c.h_out, nm_bytes);
+    if (c.want_mean && out_mean) std::memcpy(out_mean, c.h_out + nm_bytes, sizeof(float) * (size_t)c.N);
+    return FX_OK;
+}
+
 int fx_encode_onehot_dev(fx_engine* e, const uint8_t* d_ascii, int64_t N, int L, const uint8_t lut[256], int A,
                          float* d_one_hot) {
     if (!e || !lut || N < 0 || L < 0 || A < 1) return FX_EINVAL;

@@ -84,6 +84,17 @@ struct fx_engine {
     int64_t mlp_l1_mfma = 0;    // 1 = one-hot MLP layer 1 on MFMA instead of the LDS gather (A/B knob)
     int num_cus = 256;
     int max_lds = 160 * 1024;
+    // chunked host call in flight (fx_score_begin / _submit / _finish)
+    struct {
+        bool active = false;
+        std::vector<fx_model*> models;
+        int64_t N = 0;
+        int L = 0;
+        bool want_nm = false, want_mean = false;
+        uint8_t* h_in = nullptr; uint8_t* d_in = nullptr;
+        float* d_nm = nullptr; float* d_mean = nullptr;
+        char* h_out = nullptr;
+    } chunked;
 };
 
 struct fx_model {

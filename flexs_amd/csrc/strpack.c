@@ -4,7 +4,7 @@
  * into the byte matrix the C ABI wants costs more than the GPU work: "".join + encode + the length checks
  * is ~1.1 ms in pure Python.  This walks the sequence once and memcpy's each string's 1-byte buffer.
  *
- *   pack(seqs, L, out) -> 0           rows written to `out` (writable buffer of >= N*L bytes)
+ *   pack(seqs, L, out[, start, count]) -> 0   rows of seqs[start : start + count] written to `out` (>= count*L bytes)
  *                          1           some item has a length != L                    (caller raises)
  *                          2           some character does not fit one byte           (caller raises)
  *                          3           some item is not a str                         (caller raises)
@@ -15,13 +15,15 @@
 
 static PyObject* pack(PyObject* self, PyObject* args) {
     PyObject* seqs;
-    Py_ssize_t L;
+    Py_ssize_t L, start = 0, count = -1;
     Py_buffer out;
-    if (!PyArg_ParseTuple(args, "Onw*", &seqs, &L, &out)) return NULL;
+    if (!PyArg_ParseTuple(args, "Onw*|nn", &seqs, &L, &out, &start, &count)) return NULL;
     PyObject* fast = PySequence_Fast(seqs, "expected a list or tuple of str");
     if (!fast) { PyBuffer_Release(&out); return NULL; }
-    const Py_ssize_t n = PySequence_Fast_GET_SIZE(fast);
-    PyObject** items = PySequence_Fast_ITEMS(fast);
+    const Py_ssize_t total = PySequence_Fast_GET_SIZE(fast);
+    if (start < 0 || start > total) start = total;
+    const Py_ssize_t n = (count < 0 || start + count > total) ? total - start : count;   /* items [start, start + n) */
+    PyObject** items = PySequence_Fast_ITEMS(fast) + start;
     long status = 0;
     if (n > 0 && (L < 0 || out.len < n * L)) {
         PyErr_SetString(PyExc_ValueError, "strpack.pack: output buffer too small");

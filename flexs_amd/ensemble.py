@@ -63,6 +63,11 @@ class Ensemble(_EnsembleBase):
             for m in self.models:
                 m.cost += n
             m0 = self.models[0]
+            if _native.wants_chunked(sequences, m0.model.L):
+                fused_mean = self.combine_with is _default_combine
+                nm, mean = m0._engine().score_strings([m.native() for m in self.models], sequences, m0.model.L, m0._lut,
+                                                      want_matrix=not fused_mean, want_mean=fused_mean)
+                return mean if fused_mean else self.combine_with(nm)
             seq_bytes = _native.sequences_to_bytes(sequences, L=m0.model.L, staging=m0._engine())
             if seq_bytes.shape[0] == 0:
                 scores = np.zeros((0, len(self.models)), np.float32)

@@ -108,6 +108,16 @@ int fx_model_set_weights(fx_model *m, const float *blob, int64_t n);
 int fx_model_get_weights(const fx_model *m, float *blob, int64_t n);
 
 /* ------------------------------------------------------------------ scoring */
+/* fx_score in pieces, for callers whose input has to be marshalled first (Python strings): fill the
+ * returned staging area (N x L bytes, pinned) chunk by chunk and submit each chunk of rows as soon as
+ * it is ready -- host marshalling of chunk k+1 then overlaps the transfer and scoring of chunk k.
+ * fx_score_finish waits, reports a bad character (FX_EBADCHAR) and copies the results out.  One such
+ * call per engine at a time; chunks should start at multiples of 16 rows. */
+int fx_score_begin(fx_engine *e, fx_model *const *models, int M, int64_t N, int L,
+                   const uint8_t lut[256], int want_nm, int want_mean, void **staging);
+int fx_score_submit(fx_engine *e, int64_t row0, int64_t rows);
+int fx_score_finish(fx_engine *e, float *out_NM, float *out_mean);
+
 /* The engine's pinned, GPU-mapped input staging area, grown to at least `bytes`.  A caller that
  * marshals its strings straight into it (instead of into pageable memory) and then passes the
  * same pointer to fx_score saves that call's host-to-staging copy.  The pointer is valid until

@@ -969,3 +969,29 @@ def test_distributed_classes_on_one_rank_rccl(eng):
         assert np.array_equal(d, d_want) and np.array_equal(a, a_want)
     finally:
         dist.destroy_process_group()
+
+
+def test_big_string_batches_are_scored_in_overlapping_pieces(eng):
+    """list[str] batches of >= 32768 sequences take the chunked host call (fx_score_begin / _submit / _finish):
+    same scores, cost accounting and exceptions as the one-piece call."""
+    L, alpha, N = 8, "TGCA", 70_001
+    members = [bm.CNN(L, 32, 100, alpha, seed=s) for s in range(3)]
+    ens = flexs_amd.Ensemble(members)
+    b, seqs = rand_seqs(N, L, alpha, seed=21)
+    assert _native.wants_chunked(seqs, L) and not _native.wants_chunked(seqs[:100], L)
+    want_nm, want_mean = eng.score([m.native() for m in members], b, members[0]._lut, want_matrix=True, want_mean=True)
+    assert np.array_equal(ens.get_fitness(seqs), want_mean)                      # chunked, fused mean
+    assert np.array_equal(ens.get_fitness(tuple(seqs)), want_mean)
+    assert np.array_equal(members[1].get_fitness(seqs), want_nm[:, 1])           # chunked, single model
+    assert np.array_equal(flexs_amd.Ensemble(members, combine_with=lambda x: x).get_fitness(seqs), want_nm)
+    assert ens.cost == 2 * N and members[0].cost == 3 * N and members[1].cost == 4 * N
+    for chunks in (1, 3, 7):
+        nm, mean = eng.score_strings([m.native() for m in members], seqs, L, members[0]._lut, True, True, chunks=chunks)
+        assert np.array_equal(nm, want_nm) and np.array_equal(mean, want_mean)
+    for pos, bad, exc in ((N - 5, "TGCAZGCA", ValueError), (N - 5, "TGCA", ValueError), (60_000, 7, TypeError),
+                          (3, "TGCATΔCA", ValueError)):
+        broken = list(seqs)
+        broken[pos] = bad
+        with pytest.raises(exc):
+            ens.get_fitness(broken)
+        assert np.array_equal(ens.get_fitness(seqs[:40_000]), want_mean[:40_000])   # the engine is usable afterwards
