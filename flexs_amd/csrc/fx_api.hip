@@ -172,6 +172,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "cnn_pair")) return &e->cnn_pair;
     if (!std::strcmp(key, "cnn_pair_seg")) return &e->cnn_pair_seg;
     if (!std::strcmp(key, "cnn_seg")) return &e->cnn_seg;
+    if (!std::strcmp(key, "dense_slab")) return &e->dense_slab;
     if (!std::strcmp(key, "cnn_big_units")) return &e->cnn_big_units;
     if (!std::strcmp(key, "poison_outputs")) return &e->poison_outputs;
     return nullptr;

@@ -81,6 +81,7 @@ struct fx_engine {
     int64_t cnn_big_units = 12; // work units per CU from which the A = 4 CNN path switches to 16-wave (unrolled) workgroups
     int64_t cnn_seg = -1;       // A = 4 CNN kernel, small batches: -1 = waves of a workgroup split one tile's positions when L1 >= 24, 0 = never, 1 = whenever the batch is small
     int64_t cnn_pair_seg = -1;  // pair kernel, small batches: -1 = segment a tile's positions automatically, 0 = never, n > 0 = force SB = n workgroups per tile
+    int64_t dense_slab = 1;     // MLP / GE with H > 128: HxH blocks staged through LDS slabs by the workgroup (0 = every wave streams them from L2)
     int64_t mlp_l1_mfma = 0;    // 1 = one-hot MLP layer 1 on MFMA instead of the LDS gather (A/B knob)
     int num_cus = 256;
     int max_lds = 160 * 1024;

@@ -110,6 +110,65 @@ __device__ __forceinline__ void mma_layer(WPtr wblk, const f4 (&in)[TI][NT], f4 
     }
 }
 
+// mma_layer for weight matrices that do not fit LDS (hidden sizes 129..256: TI*TO KiB per layer): instead of every
+// wave streaming all blocks from L2 for every tile (which makes the kernel L2-bandwidth-bound), the WORKGROUP
+// streams them once per round of WAVES tiles through a double-buffered LDS slab of KG input tiles (KG*TO KiB).
+// While the waves run the MFMAs of slab s out of one buffer, every thread has the 16-byte pieces of slab s+1 in
+// flight in registers and parks them in the other buffer afterwards: one barrier per slab.  All waves of the
+// workgroup must call this in lockstep (same number of times).
+template <int TI, int TO, int KG, int THREADS>
+__device__ __forceinline__ void mma_layer_slab(const f4* __restrict__ wglob, f4* slab, const f4 (&in)[TI][1],
+                                               f4 (&acc)[TO][1], int lane, int rl_last) {
+    constexpr int SLAB = KG * TO * 64;                         // f4 per (full) slab
+    constexpr int NS = (TI + KG - 1) / KG;
+    constexpr int PER = (SLAB + THREADS - 1) / THREADS;
+    const int tid = threadIdx.x;
+    f4 pre[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        if (tid + k * THREADS < SLAB) pre[k] = wglob[tid + k * THREADS];
+    __syncthreads();                                            // every wave is done with both buffers (previous layer)
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        if (tid + k * THREADS < SLAB) slab[tid + k * THREADS] = pre[k];
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) {
+        __syncthreads();                                        // slab sl is in LDS; buffer (sl+1)&1 is free
+        const int next_f4 = (sl + 1 < NS) ? ((TI - (sl + 1) * KG < KG ? TI - (sl + 1) * KG : KG) * TO * 64) : 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            if (tid + k * THREADS < next_f4) pre[k] = wglob[(sl + 1) * SLAB + tid + k * THREADS];
+        const f4* buf = slab + (sl & 1) * SLAB;
+#pragma unroll
+        for (int j = 0; j < KG; ++j) {
+            const int mi = sl * KG + j;
+            if (mi < TI) {
+                // four output tiles at a time: 16 registers of A fragments in flight instead of 4*TO (the wide layers
+                // already hold 2*TO accumulator quads), still >= 4 independent MFMAs between dependent ones
+                constexpr int MC = 4;
+#pragma unroll
+                for (int m0 = 0; m0 < TO; m0 += MC) {
+                    f4 a[MC];
+#pragma unroll
+                    for (int c = 0; c < MC; ++c)
+                        if (m0 + c < TO) a[c] = buf[(j * TO + m0 + c) * 64 + lane];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (mi == TI - 1 && r >= rl_last) break;
+#pragma unroll
+                        for (int c = 0; c < MC; ++c)
+                            if (m0 + c < TO) acc[m0 + c][0] = mfma16(a[c][r], in[mi][0][r], acc[m0 + c][0]);
+                    }
+                }
+            }
+        }
+        f4* nbuf = slab + ((sl + 1) & 1) * SLAB;
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            if (tid + k * THREADS < next_f4) nbuf[tid + k * THREADS] = pre[k];
+    }
+}
+
 // acc[mo][nt] = bias[16*mo + 4*g .. +3] broadcast over the lane's sequence
 template <int TO, int NT, typename BPtr>
 __device__ __forceinline__ void init_bias(BPtr bias, f4 (&acc)[TO][NT], int g) {

@@ -29,14 +29,19 @@ struct DenseArgs {
     int lds_from, lds_floats;   // the LDS image is packed[lds_from .. lds_from + lds_floats)
 };
 
-template <int KIND, int A, int HT, int NT, int WAVES, bool G1, bool W1G, bool DG>
+// SLAB (with DG): the HxH blocks are streamed through LDS once per round of WAVES tiles (mma_layer_slab) instead
+// of once per tile per wave; the waves of a workgroup then walk the tiles in lockstep.
+template <int KIND, int A, int HT, int NT, int WAVES, bool G1, bool W1G, bool DG, bool SLAB = false>
 __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
+    static_assert(!SLAB || (DG && NT == 1), "SLAB streams the L2-resident blocks of the one-tile form");
+    constexpr int KG = 2;                                       // input tiles per slab
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int g = lane >> 4, sq = lane & 15;
     const int L = p.L;
     uint8_t* lut_s = reinterpret_cast<uint8_t*>(smem + p.lds_floats);
     int* next_tile = reinterpret_cast<int*>(smem + p.lds_floats + 64);   // work counter, after the 256-byte LUT
+    f4* slab = reinterpret_cast<f4*>(smem + p.lds_floats + 64 + 4);      // SLAB: 2 x KG*HT KiB
     for (int i = tid; i < 64; i += blockDim.x)
         reinterpret_cast<uint32_t*>(lut_s)[i] = reinterpret_cast<const uint32_t*>(p.lut)[i];
 
@@ -66,12 +71,17 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
         const int64_t t_lo = (u_lo > (int64_t)m * p.TG ? u_lo : (int64_t)m * p.TG) - (int64_t)m * p.TG;
         const int64_t t_hi = (u_hi < (int64_t)(m + 1) * p.TG ? u_hi : (int64_t)(m + 1) * p.TG) - (int64_t)m * p.TG;
 
-        for (;;) {                                       // waves pull tiles from a block-local counter
+        for (int64_t round = 0;; ++round) {              // waves pull tiles from a block-local counter
             int pulled = 0;
-            if (lane == 0) pulled = atomicAdd(next_tile, 1);
-            pulled = __builtin_amdgcn_readfirstlane(pulled);
-            const int64_t tg = t_lo + pulled;
-            if (tg >= t_hi) break;
+            if (!SLAB) {
+                if (lane == 0) pulled = atomicAdd(next_tile, 1);
+                pulled = __builtin_amdgcn_readfirstlane(pulled);
+            }
+            // SLAB: lockstep rounds of WAVES tiles; waves without a tile in the last round run along on tile 0
+            const int64_t tg_want = SLAB ? t_lo + round * WAVES + (tid >> 6) : t_lo + pulled;
+            if (SLAB ? (t_lo + round * WAVES >= t_hi) : (tg_want >= t_hi)) break;
+            const bool live = !SLAB || tg_want < t_hi;
+            const int64_t tg = live ? tg_want : t_lo;
             asm volatile("" ::: "memory");               // keep LDS weight reads inside the tile loop
             if (DG) asm volatile("" : "+v"(w_d2), "+v"(w_d3), "+v"(db));   // L2-streamed blocks: no hoisted addresses
             int64_t n[NT];
@@ -143,11 +153,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                 // ---- layers 2, 3
                 f4 h2[HT][NT];
                 init_bias<HT, NT>(db + 16 * HT, h2, g);
-                mma_layer<HT, HT, NT>(w_d2, h, h2, lane, p.rlh);
+                if constexpr (SLAB) mma_layer_slab<HT, HT, KG, WAVES * 64>(w_d2, slab, h, h2, lane, p.rlh);
+                else mma_layer<HT, HT, NT>(w_d2, h, h2, lane, p.rlh);
                 relu_tiles<HT, NT>(h2);
                 asm volatile("" ::: "memory");
                 init_bias<HT, NT>(db + 32 * HT, h, g);
-                mma_layer<HT, HT, NT>(w_d3, h2, h, lane, p.rlh);
+                if constexpr (SLAB) mma_layer_slab<HT, HT, KG, WAVES * 64>(w_d3, slab, h2, h, lane, p.rlh);
+                else mma_layer<HT, HT, NT>(w_d3, h2, h, lane, p.rlh);
                 relu_tiles<HT, NT>(h);
                 final_dot<HT, NT>(db + 48 * HT, db[64 * HT], h, y, g);
             } else {
@@ -227,23 +239,25 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                 }
                 // ---- layer 3 (HxH MFMA), layer 4 (dot)
                 init_bias<HT, NT>(db + 4 + 32 * HT, h, g);
-                mma_layer<HT, HT, NT>(w_d3, h2, h, lane, p.rlh);
+                if constexpr (SLAB) mma_layer_slab<HT, HT, KG, WAVES * 64>(w_d3, slab, h2, h, lane, p.rlh);
+                else mma_layer<HT, HT, NT>(w_d3, h2, h, lane, p.rlh);
                 relu_tiles<HT, NT>(h);
                 final_dot<HT, NT>(db + 4 + 48 * HT, db[4 + 64 * HT], h, y, g);
             }
             if (g == 0) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    if (n[nt] < p.N) p.out[n[nt] * p.Mtot + p.m_off + m] = fx_nan_to_num(y[nt]);
+                    if (live && n[nt] < p.N) p.out[n[nt] * p.Mtot + p.m_off + m] = fx_nan_to_num(y[nt]);
             }
         }
     }
     if (bad) fx_raise(p.err, FX_ERR_BADCHAR);
 }
 
-template <int KIND, int A, int HT, int NT, int WAVES, bool G1, bool W1G = false, bool DG = false>
+template <int KIND, int A, int HT, int NT, int WAVES, bool G1, bool W1G = false, bool DG = false, bool SLAB = false>
 int launch_inst(fx_engine* e, const DenseArgs& a, size_t lds_bytes) {
-    auto kern = k_score_dense_mfma<KIND, A, HT, NT, WAVES, G1, W1G, DG>;
+    auto kern = k_score_dense_mfma<KIND, A, HT, NT, WAVES, G1, W1G, DG, SLAB>;
+    if (SLAB) lds_bytes += (size_t)2 * 2 * HT * 1024;           // two slabs of KG = 2 input tiles
     static bool attr_set[64] = {};
     if (!attr_set[e->device & 63]) {
         FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -283,6 +297,15 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
     }
     a.lds_from = (int)lds_from;
     a.lds_floats = (int)(tail - lds_from);
+    if constexpr (DGc) {
+        // hidden sizes 129..256: stream the HxH blocks through LDS slabs, one pass per round of 8 tiles (A/B: dense_slab = 0)
+        // (not when the first-layer rows stream from L2 as well: measured 3 % slower there, profiles/r1_run46)
+        const bool slab = e->dense_slab != 0 && !e->mlp_l1_mfma && !w1_global && lds + (size_t)4 * HT_ * 1024 <= (size_t)e->max_lds;
+        if (slab) {
+            if (s.kind == FX_MLP) return launch_inst<FX_MLP, 4, HT_, 1, W, true, false, true, true>(e, a, lds);
+            return launch_inst<FX_GE, 4, HT_, 1, W, false, false, true, true>(e, a, lds);
+        }
+    }
     if (s.kind == FX_MLP) {
         if (w1_global) return launch_inst<FX_MLP, 4, HT_, 1, W, true, true, DGc>(e, a, lds);   // gather form: A is a runtime stride
         if (e->mlp_l1_mfma) {
