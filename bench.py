@@ -152,7 +152,9 @@ def main():
         eng.set_stream(stream.cuda_stream)
         d_ascii = torch.from_numpy(seq_bytes).cuda()
         # two buffer sets: the all-gather of step k runs on RCCL's stream while step k+1 computes
-        d_nm = [torch.empty((N, M), dtype=torch.float32, device="cuda") for _ in range(2)]
+        # the M members' scores as member-major planes (the layout fx_score_dev uses when only the mean is wanted)
+        stride = (N + 63) // 64 * 64
+        d_nm = [torch.empty((M, stride), dtype=torch.float32, device="cuda") for _ in range(2)]
         d_mean = [torch.empty((N,), dtype=torch.float32, device="cuda") for _ in range(2)]
         d_all = [torch.empty((world * N,), dtype=torch.float32, device="cuda") for _ in range(2)] if use_dist else None
         pending = [None, None]
@@ -169,10 +171,10 @@ def main():
                 pending[b] = None
             if k is not None:
                 ev_a[k].record(stream)
-            eng.score_dev(models, d_ascii.data_ptr(), N, L, lut, d_nm[b].data_ptr(), None)   # K1 fused encode+CNN x3
+            eng.score_planes_dev(models, d_ascii.data_ptr(), N, L, lut, d_nm[b].data_ptr(), stride)   # K1 fused encode+CNN x3
             if k is not None:
                 ev_b[k].record(stream)
-            eng.ensemble_reduce_dev(d_nm[b].data_ptr(), N, M, d_mean[b].data_ptr())          # K3 np.mean order
+            eng.ensemble_mean_planes_dev(d_nm[b].data_ptr(), N, M, stride, d_mean[b].data_ptr())     # K3 np.mean order
             if use_dist:
                 comm.wait_stream(stream)
                 with torch.cuda.stream(comm):
@@ -211,11 +213,11 @@ def main():
         step(0)
         drain()
         torch.cuda.synchronize()
-        assert not bool(torch.isnan(d_nm[0]).any()) and not bool(torch.isnan(d_mean[0]).any()), "unwritten scores"
+        assert not bool(torch.isnan(d_nm[0][:, :N]).any()) and not bool(torch.isnan(d_mean[0]).any()), "unwritten scores"
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_a, ev_b)]))
         last = (args.steps - 1) & 1
         got_mean = d_mean[last].cpu().numpy()
-        got_nm = d_nm[last].cpu().numpy()
+        got_nm = d_nm[last][:, :N].t().contiguous().cpu().numpy()        # (N, M), i.e. np.stack(axis=1)
         if use_dist:
             gathered = d_all[last].cpu().numpy()
             assert np.array_equal(gathered[rank * N:(rank + 1) * N], got_mean), "all-gather lost this rank's shard"

@@ -49,6 +49,8 @@ SIGNATURES = {
     "fx_model_set_weights": (C.c_int, [_vp, _f32p, C.c_int64]),
     "fx_model_get_weights": (C.c_int, [_vp, _f32p, C.c_int64]),
     "fx_score": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _vp, C.c_int64, C.c_int, _u8p, _vp, _vp]),
+    "fx_score_planes_dev": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _vp, C.c_int64, C.c_int, _u8p, _vp, C.c_int64]),
+    "fx_ensemble_mean_planes_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64, _vp]),
     "fx_staging_input": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp)]),
     "fx_score_begin": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int64, C.c_int, _u8p, C.c_int, C.c_int, C.POINTER(_vp)]),
     "fx_score_submit": (C.c_int, [_vp, C.c_int64, C.c_int64]),
@@ -342,6 +344,16 @@ class Engine:
         self.check(self._lib.fx_score_dev(self.handle, arr, M, _vp(d_ascii), N, L, lut.ctypes.data_as(_u8p),
                                           _vp(d_out_nm) if d_out_nm else None,
                                           _vp(d_out_mean) if d_out_mean else None))
+
+    def score_planes_dev(self, models: Sequence["NativeModel"], d_ascii: int, N: int, L: int, lut: np.ndarray,
+                         d_planes: int, stride: int):
+        M = len(models)
+        arr = (_vp * M)(*[m.handle for m in models])
+        self.check(self._lib.fx_score_planes_dev(self.handle, arr, M, _vp(d_ascii), N, L, lut.ctypes.data_as(_u8p),
+                                                 _vp(d_planes), stride))
+
+    def ensemble_mean_planes_dev(self, d_planes: int, N: int, M: int, stride: int, d_out32: int):
+        self.check(self._lib.fx_ensemble_mean_planes_dev(self.handle, _vp(d_planes), N, M, stride, _vp(d_out32)))
 
     def encode_onehot(self, seq_bytes: np.ndarray, lut: np.ndarray, A: int) -> np.ndarray:
         N, L = seq_bytes.shape

@@ -273,10 +273,19 @@ int fx_model_get_weights(const fx_model* m, float* blob, int64_t n) {
 }
 
 // ------------------------------------------------------------------ scoring
+// Plane stride of the engine's member-major intermediate for N sequences (floats; 256-byte aligned planes).
+static inline int64_t planar_stride_for(int64_t N) { return (N + 63) & ~(int64_t)63; }
+
+// planar_stride == 0: d_NM is the row-major (N, M) matrix of the ABI; > 0: M member planes that far apart.
 static int score_dispatch(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N, int L,
-                          float* d_NM) {
+                          float* d_NM, int64_t planar_stride = 0) {
     if (e->poison_outputs)      // scores are nan_to_num'ed, so a NaN that survives is an element no kernel wrote
-        FX_HIP(e, hipMemsetAsync(d_NM, 0xFF, sizeof(float) * (size_t)N * (size_t)M, e->stream));
+        FX_HIP(e, hipMemsetAsync(d_NM, 0xFF, sizeof(float) * (planar_stride ? (size_t)planar_stride * (size_t)M : (size_t)N * (size_t)M), e->stream));
+    struct Layout {                                     // the launchers read the layout from the engine
+        fx_engine* e;
+        Layout(fx_engine* e_, int64_t s) : e(e_) { e->planar_stride = s; }
+        ~Layout() { e->planar_stride = 0; }
+    } layout(e, planar_stride);
     // group consecutive members into launches of <= FX_MAX_M homogeneous models
     for (int m0 = 0; m0 < M;) {
         int cnt = 1;
@@ -325,15 +334,43 @@ int fx_score_dev(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_
     if (rc) return rc;
     float* d_NM = d_out_NM;
     if (!d_NM) {
+        // only the mean is wanted: the intermediate is the engine's own, laid out member-major (contiguous stores)
+        const int64_t stride = M <= 16 ? planar_stride_for(N) : 0;
         void* p = nullptr;
-        rc = fx_scratch(e, 1, sizeof(float) * (size_t)N * (size_t)M, &p);
+        rc = fx_scratch(e, 1, sizeof(float) * (stride ? (size_t)stride * (size_t)M : (size_t)N * (size_t)M), &p);
         if (rc) return rc;
         d_NM = (float*)p;
+        if (stride) {
+            if ((rc = score_dispatch(e, models, M, d_ascii, N, L, d_NM, stride))) return rc;
+            return fx_launch_ensemble_mean_planar(e, d_NM, N, M, stride, d_out_mean);
+        }
     }
     rc = score_dispatch(e, models, M, d_ascii, N, L, d_NM);
     if (rc) return rc;
     if (d_out_mean) rc = fx_launch_ensemble_reduce(e, d_NM, N, M, nullptr, d_out_mean, nullptr);
     return rc;
+}
+
+// The two halves of the mean-only device path, for callers that keep the intermediate themselves (bench.py times
+// them separately): scores as M member-major planes `stride` floats apart, then np.mean over the planes.
+int fx_score_planes_dev(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N, int L,
+                        const uint8_t lut[256], float* d_planes, int64_t stride) {
+    int rc = validate_models(e, models, M, L, lut);
+    if (rc) return rc;
+    if (N < 0 || stride < N || (stride & 3)) return fx_fail(e, FX_EINVAL, "fx_score_planes_dev: stride must be >= N and a multiple of 4");
+    if (N == 0) return FX_OK;
+    if (!d_ascii || !d_planes || (reinterpret_cast<uintptr_t>(d_planes) & 15)) return fx_fail(e, FX_EINVAL, "null or unaligned buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    if ((rc = fx_upload_lut(e, lut))) return rc;
+    return score_dispatch(e, models, M, d_ascii, N, L, d_planes, stride);
+}
+
+int fx_ensemble_mean_planes_dev(fx_engine* e, const float* d_planes, int64_t N, int M, int64_t stride, float* d_out_mean) {
+    if (!e || N < 0 || M < 1 || M > 16 || stride < N || (stride & 3)) return FX_EINVAL;
+    if (N == 0) return FX_OK;
+    if (!d_planes || !d_out_mean || (reinterpret_cast<uintptr_t>(d_planes) & 15)) return fx_fail(e, FX_EINVAL, "null or unaligned buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    return fx_launch_ensemble_mean_planar(e, d_planes, N, M, stride, d_out_mean);
 }
 
 int fx_staging_input(fx_engine* e, int64_t bytes, void** host) {
@@ -357,10 +394,13 @@ int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii,
     if ((rc = fx_scratch(e, 0, in_bytes, &d_in))) return rc;
     if ((rc = fx_pinned(e, 0, in_bytes, &h_in))) return rc;
     if ((rc = fx_pinned(e, 1, nm_bytes + mean_bytes, &h_out))) return rc;
+    // mean only: member-major planes as the intermediate (see fx_score_dev)
+    const int64_t stride = (!out_NM && M <= 16) ? planar_stride_for(N) : 0;
+    const size_t inter_bytes = stride ? sizeof(float) * (size_t)stride * (size_t)M : nm_bytes;
     void* d_out = nullptr;
-    if ((rc = fx_scratch(e, 1, nm_bytes + mean_bytes, &d_out))) return rc;
+    if ((rc = fx_scratch(e, 1, inter_bytes + mean_bytes, &d_out))) return rc;
     float* d_NM = (float*)d_out;
-    float* d_mean = (float*)((char*)d_out + nm_bytes);
+    float* d_mean = (float*)((char*)d_out + inter_bytes);
     if (ascii != h_in) std::memcpy(h_in, ascii, in_bytes);   // (fx_staging_input callers marshalled straight into it)
     if ((rc = fx_upload_lut(e, lut))) return rc;
     if (in_bytes + nm_bytes + mean_bytes <= (size_t)(256 << 10)) {
@@ -372,14 +412,16 @@ int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii,
         FX_HIP(e, hipHostGetDevicePointer(&dm_out, h_out, 0));
         float* m_NM = (float*)dm_out;
         float* m_mean = (float*)((char*)dm_out + nm_bytes);
-        if ((rc = score_dispatch(e, models, M, (const uint8_t*)dm_in, N, L, out_NM ? m_NM : d_NM))) return rc;
-        if (out_mean && (rc = fx_launch_ensemble_reduce(e, out_NM ? m_NM : d_NM, N, M, nullptr, m_mean, nullptr))) return rc;
+        if ((rc = score_dispatch(e, models, M, (const uint8_t*)dm_in, N, L, out_NM ? m_NM : d_NM, stride))) return rc;
+        if (out_mean && (rc = stride ? fx_launch_ensemble_mean_planar(e, d_NM, N, M, stride, m_mean)
+                                     : fx_launch_ensemble_reduce(e, out_NM ? m_NM : d_NM, N, M, nullptr, m_mean, nullptr))) return rc;
         FX_HIP(e, hipStreamSynchronize(e->stream));
     } else {
         FX_HIP(e, hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, e->stream));
-        if ((rc = score_dispatch(e, models, M, (const uint8_t*)d_in, N, L, d_NM))) return rc;
+        if ((rc = score_dispatch(e, models, M, (const uint8_t*)d_in, N, L, d_NM, stride))) return rc;
         if (out_mean) {
-            if ((rc = fx_launch_ensemble_reduce(e, d_NM, N, M, nullptr, d_mean, nullptr))) return rc;
+            if ((rc = stride ? fx_launch_ensemble_mean_planar(e, d_NM, N, M, stride, d_mean)
+                             : fx_launch_ensemble_reduce(e, d_NM, N, M, nullptr, d_mean, nullptr))) return rc;
             FX_HIP(e, hipMemcpyAsync((char*)h_out + nm_bytes, d_mean, mean_bytes, hipMemcpyDeviceToHost, e->stream));
         }
         if (out_NM) FX_HIP(e, hipMemcpyAsync(h_out, d_NM, nm_bytes, hipMemcpyDeviceToHost, e->stream));

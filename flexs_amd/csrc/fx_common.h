@@ -85,6 +85,10 @@ struct fx_engine {
     int64_t mlp_l1_mfma = 0;    // 1 = one-hot MLP layer 1 on MFMA instead of the LDS gather (A/B knob)
     int num_cus = 256;
     int max_lds = 160 * 1024;
+    // layout of the score matrix the next launch writes: 0 = row-major (N, M) as the ABI hands it out (np.stack axis=1);
+    // > 0 = member-major planes `planar_stride` floats apart (the engine's own intermediate when only the mean is wanted:
+    // a unit's 16 scores are then one contiguous 64-byte store instead of 16 four-byte stores 4*M bytes apart)
+    int64_t planar_stride = 0;
     // chunked host call in flight (fx_score_begin / _submit / _finish)
     struct {
         bool active = false;
@@ -156,6 +160,7 @@ int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, con
                                int64_t N, float* d_out_NM, int Mtot, int m_off);
 int fx_launch_mfma_probe(fx_engine* e, const float* d_a, const float* d_b, const float* d_c, float* d_d);
 int fx_launch_encode_onehot(fx_engine* e, const uint8_t* d_ascii, int64_t N, int L, int A, float* d_out);
+int fx_launch_ensemble_mean_planar(fx_engine* e, const float* d_planes, int64_t N, int M, int64_t stride, float* d_out32);
 int fx_launch_ensemble_reduce(fx_engine* e, const float* d_scores, int64_t N, int M,
                               const double* d_weights, float* d_out32, double* d_out64);
 int fx_launch_argmax_decode(fx_engine* e, const double* d_onehot, int64_t rows, int A,

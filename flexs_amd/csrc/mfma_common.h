@@ -51,6 +51,16 @@ __device__ __forceinline__ f4 max4(f4 a, f4 b) {
     r.x = fmaxf(a.x, b.x); r.y = fmaxf(a.y, b.y); r.z = fmaxf(a.z, b.z); r.w = fmaxf(a.w, b.w);
     return r;
 }
+// XCD-aware work split.  Workgroup b is observed to run on XCD b % 8, and every XCD has its own L2: with the plain
+// "block b takes the b-th slice of the (member, tile) units" the 32 workgroups behind one L2 would be spread over
+// every ensemble member, and each of the 8 L2s would fetch every member's weights from HBM.  This bijection hands
+// XCD x a CONTIGUOUS range of slices instead, so the workgroups that share an L2 also share (mostly) one member's
+// weight image and neighbouring rows of the sequence batch.  Placement is a speed assumption only.
+__device__ __forceinline__ unsigned fx_xcd_block() {
+    const unsigned b = blockIdx.x, g = gridDim.x, per = g >> 3, rem = g & 7u, x = b & 7u;
+    return x * per + (x < rem ? x : rem) + (b >> 3);
+}
+
 // Workgroup copy of a member's packed weights into LDS.  Eight 16-byte loads are in flight per thread before the
 // first LDS store, so the ~100 KiB image costs a couple of L2 round trips instead of one per 16 bytes per thread
 // (which is what a plain copy loop compiles to, and what small calls and small batches then mostly wait for).

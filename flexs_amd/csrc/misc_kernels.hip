@@ -294,6 +294,49 @@ int fx_launch_encode_onehot(fx_engine* e, const uint8_t* d_ascii, int64_t N, int
     return FX_OK;
 }
 
+// Member-major planes (the engine's intermediate when only the mean is asked for): thread i reduces rows 4i..4i+3
+// with one 16-byte load per member plane and one 16-byte store -- same NumPy summation order.
+template <int M>
+__global__ void k_ensemble_mean_planar(const float* __restrict__ planes, int64_t N, int64_t stride, float* __restrict__ out,
+                                       bool out_aligned) {
+    const int64_t groups = (N + 3) >> 2;
+    for (int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gi < groups; gi += (int64_t)gridDim.x * blockDim.x) {
+        float4 q[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) q[m] = reinterpret_cast<const float4*>(planes + m * stride)[gi];
+        float res[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float x[M];
+#pragma unroll
+            for (int m = 0; m < M; ++m) x[m] = i == 0 ? q[m].x : (i == 1 ? q[m].y : (i == 2 ? q[m].z : q[m].w));
+            res[i] = __fdiv_rn(np_sum_row<M>(x), (float)M);
+        }
+        if (out_aligned && 4 * gi + 3 < N) reinterpret_cast<float4*>(out)[gi] = make_float4(res[0], res[1], res[2], res[3]);
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (4 * gi + i < N) out[4 * gi + i] = res[i];
+        }
+    }
+}
+
+int fx_launch_ensemble_mean_planar(fx_engine* e, const float* d_planes, int64_t N, int M, int64_t stride, float* d_out32) {
+    if (N == 0) return FX_OK;
+    dim3 gs(grid_for((N + 3) / 4, 256, e->num_cus)), block(256);
+    const bool aligned = (reinterpret_cast<uintptr_t>(d_out32) & 15) == 0;   // (the planes always are)
+    switch (M) {
+#define FX_PLANAR_CASE(m) case m: hipLaunchKernelGGL(k_ensemble_mean_planar<m>, gs, block, 0, e->stream, d_planes, N, stride, d_out32, aligned); break;
+        FX_PLANAR_CASE(1) FX_PLANAR_CASE(2) FX_PLANAR_CASE(3) FX_PLANAR_CASE(4) FX_PLANAR_CASE(5) FX_PLANAR_CASE(6)
+        FX_PLANAR_CASE(7) FX_PLANAR_CASE(8) FX_PLANAR_CASE(9) FX_PLANAR_CASE(10) FX_PLANAR_CASE(11) FX_PLANAR_CASE(12)
+        FX_PLANAR_CASE(13) FX_PLANAR_CASE(14) FX_PLANAR_CASE(15) FX_PLANAR_CASE(16)
+#undef FX_PLANAR_CASE
+        default: return fx_fail(e, FX_EUNSUPPORTED, "planar mean: more than 16 members");
+    }
+    FX_HIP(e, hipGetLastError());
+    return FX_OK;
+}
+
 int fx_launch_ensemble_reduce(fx_engine* e, const float* d_scores, int64_t N, int M, const double* d_weights,
                               float* d_out32, double* d_out64) {
     if (N == 0) return FX_OK;

@@ -27,6 +27,7 @@ struct CnnArgs {
     int64_t N;
     int64_t TG;                 // tile groups per member = ceil(N / (16*NT))
     int M, Mtot, m_off;
+    int64_t out_sn, out_sm;     // score of (sequence n, member column c) lives at out[n * out_sn + c * out_sm]
     int L;
     int rlh, htr;               // hidden tail: real k-steps of the last real tile, number of real hidden tiles
     // packed-layout offsets (floats)
@@ -61,7 +62,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
         reinterpret_cast<uint32_t*>(lut_s)[i] = reinterpret_cast<const uint32_t*>(p.lut)[i];
 
     const int64_t U = (int64_t)p.M * p.TG;
-    const int64_t u_lo = U * blockIdx.x / gridDim.x, u_hi = U * (blockIdx.x + 1) / gridDim.x;
+    const int64_t bid = fx_xcd_block();
+    const int64_t u_lo = U * bid / gridDim.x, u_hi = U * (bid + 1) / gridDim.x;
     if (u_lo >= u_hi) return;
     const int m_first = (int)(u_lo / p.TG), m_last = (int)((u_hi - 1) / p.TG);
     bool bad = false;
@@ -334,7 +336,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
             if (g == 0) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    if (n[nt] < p.N) p.out[n[nt] * p.Mtot + p.m_off + m] = fx_nan_to_num(y[nt]);
+                    if (n[nt] < p.N) p.out[n[nt] * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y[nt]);
             }
         }
     }
@@ -448,6 +450,7 @@ int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const
     CnnArgs a{};
     a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
     for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
+    a.out_sn = e->planar_stride ? 1 : Mtot; a.out_sm = e->planar_stride ? e->planar_stride : 1;
     a.N = N; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4; a.htr = lay.HTR;
     a.off_first = (int)lay.off_first; a.off_c2 = (int)lay.off_c2; a.off_c3 = (int)lay.off_c3;
     a.off_cb = (int)lay.off_cb; a.off_w1p = (int)lay.off_w1p; a.conv_floats = (int)lay.conv_floats; a.off_d1 = (int)lay.off_d1;

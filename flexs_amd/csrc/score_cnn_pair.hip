@@ -35,6 +35,7 @@ struct PairArgs {
     unsigned* err;
     int64_t N, TG;
     int M, Mtot, m_off;
+    int64_t out_sn, out_sm;     // out[n * out_sn + column * out_sm]
     int L, rlh, htr;
     int off_c2, off_c3, off_cb, off_w1p, conv_floats, off_d1, off_d2, off_db;
     int lds_from, lds_floats;   // LDS image = packed[lds_from .. lds_from + lds_floats): conv2, conv3, biases, conv1 rows
@@ -83,8 +84,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
 
     const int64_t U = (int64_t)p.M * p.TG;
     const int sb = SEG ? (int)(blockIdx.x % p.SB) : 0;
-    const int64_t u_lo = SEG ? (int64_t)(blockIdx.x / p.SB) : U * blockIdx.x / gridDim.x;
-    const int64_t u_hi = SEG ? u_lo + 1 : U * (blockIdx.x + 1) / gridDim.x;
+    const int64_t bid = fx_xcd_block();
+    const int64_t u_lo = SEG ? (int64_t)(blockIdx.x / p.SB) : U * bid / gridDim.x;
+    const int64_t u_hi = SEG ? u_lo + 1 : U * (bid + 1) / gridDim.x;
     if (u_lo >= u_hi) return;
     const int m_first = (int)(u_lo / p.TG), m_last = (int)((u_hi - 1) / p.TG);
     bool bad = false;
@@ -247,7 +249,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
                 __syncthreads();
                 if (mo == 0) {                            // (pslot is rewritten only after the next tile's ~L barriers)
                     const float y = pair_dense_head<HT>(w_d1, w_d2, db, gmax, pslot[64 + lane], lane, g, p.rlh);
-                    if (g == 0 && live && n < p.N) p.out[n * p.Mtot + p.m_off + m] = fx_nan_to_num(y);
+                    if (g == 0 && live && n < p.N) p.out[n * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y);
                 }
             } else {
                 // ---- segment maxima meet in the global pool; the last workgroup of the tile runs the head
@@ -270,7 +272,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
                         pool1[r] = __uint_as_float(__hip_atomic_load(&p0[256 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                     }
                     const float y = pair_dense_head<HT>(w_d1, w_d2, db, pool0, pool1, lane, g, p.rlh);
-                    if (g == 0 && n < p.N) p.out[n * p.Mtot + p.m_off + m] = fx_nan_to_num(y);
+                    if (g == 0 && n < p.N) p.out[n * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y);
                 }
             }
         }
@@ -332,6 +334,7 @@ int fx_launch_score_cnn_pair(fx_engine* e, fx_model* const* models, int M, const
     PairArgs a{};
     a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
     for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
+    a.out_sn = e->planar_stride ? 1 : Mtot; a.out_sm = e->planar_stride ? e->planar_stride : 1;
     a.N = N; a.TG = (N + 15) / 16; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4; a.htr = lay.HTR;
     a.off_c2 = (int)lay.off_c2; a.off_c3 = (int)lay.off_c3; a.off_cb = (int)lay.off_cb; a.off_w1p = (int)lay.off_w1p;
     a.conv_floats = (int)lay.conv_floats; a.lds_from = (int)lay.off_c2; a.lds_floats = (int)(lay.conv_floats - lay.off_c2); a.off_d1 = (int)lay.off_d1; a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db;

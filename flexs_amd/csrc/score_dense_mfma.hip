@@ -24,6 +24,7 @@ struct DenseArgs {
     unsigned* err;
     int64_t N, TG;
     int M, Mtot, m_off;
+    int64_t out_sn, out_sm;     // out[n * out_sn + column * out_sm]
     int L, A, rlh, htr;
     int SG1, off_first, off_w1p, off_d2, off_d3, off_db, total_floats;
     int lds_from, lds_floats;   // the LDS image is packed[lds_from .. lds_from + lds_floats)
@@ -46,7 +47,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
         reinterpret_cast<uint32_t*>(lut_s)[i] = reinterpret_cast<const uint32_t*>(p.lut)[i];
 
     const int64_t U = (int64_t)p.M * p.TG;
-    const int64_t u_lo = U * blockIdx.x / gridDim.x, u_hi = U * (blockIdx.x + 1) / gridDim.x;
+    const int64_t bid = fx_xcd_block();
+    const int64_t u_lo = U * bid / gridDim.x, u_hi = U * (bid + 1) / gridDim.x;
     if (u_lo >= u_hi) return;
     const int m_first = (int)(u_lo / p.TG), m_last = (int)((u_hi - 1) / p.TG);
     bool bad = false;
@@ -247,7 +249,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
             if (g == 0) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    if (live && n[nt] < p.N) p.out[n[nt] * p.Mtot + p.m_off + m] = fx_nan_to_num(y[nt]);
+                    if (live && n[nt] < p.N) p.out[n[nt] * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y[nt]);
             }
         }
     }
@@ -336,6 +338,7 @@ int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, con
     DenseArgs a{};
     a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
     for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
+    a.out_sn = e->planar_stride ? 1 : Mtot; a.out_sm = e->planar_stride ? e->planar_stride : 1;
     a.N = N; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.A = s.A; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4; a.htr = lay.HTR;
     a.SG1 = lay.SG1; a.off_first = (int)lay.off_first; a.off_w1p = (int)lay.off_w1p; a.off_d2 = (int)lay.off_d2; a.off_d3 = (int)lay.off_d3;
     a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;

@@ -33,6 +33,7 @@ struct GenericArgs {
     int T;                  // threads in this launch (workspace pitch)
     int L, A, F, H, K;
     int Mtot, m;
+    int64_t out_sn, out_sm; // out[n * out_sn + m * out_sm]
     int rows1;              // CNN: rows of the first workspace region = max(L1*F, H)
 };
 
@@ -113,7 +114,7 @@ __global__ void k_score_generic_cnn(GenericArgs a) {
     dense_ws(pooled, g1, T, F, d1, c1, H);
     dense_ws(g1, g2, T, H, d2, c2, H);
     float y = dot_ws(g2, T, H, d3, c3[0]);
-    a.out[n * a.Mtot + a.m] = nan_to_num(y);
+    a.out[n * a.out_sn + a.m * a.out_sm] = nan_to_num(y);
     if (bad) fx_raise(a.err, FX_ERR_BADCHAR);
 }
 
@@ -139,7 +140,7 @@ __global__ void k_score_generic_mlp(GenericArgs a) {
     dense_ws(g0, g1, T, H, d2, c2, H);
     dense_ws(g1, g0, T, H, d3, c3, H);
     float y = dot_ws(g0, T, H, d4, c4[0]);
-    a.out[n * a.Mtot + a.m] = nan_to_num(y);
+    a.out[n * a.out_sn + a.m * a.out_sm] = nan_to_num(y);
     if (bad) fx_raise(a.err, FX_ERR_BADCHAR);
 }
 
@@ -161,7 +162,7 @@ __global__ void k_score_generic_ge(GenericArgs a) {
     for (int o = 0; o < H; ++o) g0[(int64_t)o * T] = fmaxf(fmaf(s, d2[o], c2[o]), 0.f);
     dense_ws(g0, g1, T, H, d3, c3, H);
     float y = dot_ws(g1, T, H, d4, c4[0]);
-    a.out[n * a.Mtot + a.m] = nan_to_num(y);
+    a.out[n * a.out_sn + a.m * a.out_sm] = nan_to_num(y);
     if (bad) fx_raise(a.err, FX_ERR_BADCHAR);
 }
 
@@ -195,6 +196,7 @@ int fx_launch_score_generic(fx_engine* e, fx_model* const* models, int M, const 
             a.ascii = d_ascii; a.lut = e->d_lut; a.blob = models[m]->d_blob; a.ws = (float*)ws;
             a.out = d_out_NM; a.err = e->d_err; a.N = N; a.n0 = n0; a.T = (int)T;
             a.L = s.L; a.A = s.A; a.F = s.F; a.H = s.H; a.K = s.K; a.Mtot = Mtot; a.m = m_off + m;
+            a.out_sn = e->planar_stride ? 1 : Mtot; a.out_sm = e->planar_stride ? e->planar_stride : 1;
             a.rows1 = (int)rows1;
             dim3 grid((unsigned)((T + 255) / 256)), block(256);
             if (s.kind == FX_CNN) {

@@ -136,6 +136,16 @@ int fx_score(fx_engine *e, fx_model *const *models, int M, const uint8_t *ascii,
              const uint8_t lut[256], float *out_NM, float *out_mean);
 int fx_score_dev(fx_engine *e, fx_model *const *models, int M, const uint8_t *d_ascii, int64_t N,
                  int L, const uint8_t lut[256], float *d_out_NM, float *d_out_mean);
+/* The mean-only device path in two calls, with the intermediate in the caller's hands: the M members' scores as
+ * member-major PLANES (`d_planes[m * stride + n]`, stride >= N, a multiple of 4, base 16-byte aligned) -- a work
+ * unit's 16 scores are then one contiguous 64-byte store instead of 16 stores 4*M bytes apart as in the (N, M)
+ * matrix of ensemble.py:55-57 -- then np.mean over the planes (M <= 16, NumPy summation order).  fx_score_dev
+ * uses the same layout internally when it is asked for the mean only. */
+int fx_score_planes_dev(fx_engine *e, fx_model *const *models, int M, const uint8_t *d_ascii, int64_t N,
+                        int L, const uint8_t lut[256], float *d_planes, int64_t stride);
+int fx_ensemble_mean_planes_dev(fx_engine *e, const float *d_planes, int64_t N, int M, int64_t stride,
+                                float *d_out_mean);
+
 
 /* string_to_one_hot over a batch (sequence_utils.py:32-47 + keras_model.py:70-75):
  * N x L bytes -> N x L x A float32 0/1.  Stand-alone, HBM-bound. */

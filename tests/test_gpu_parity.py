@@ -995,3 +995,40 @@ def test_big_string_batches_are_scored_in_overlapping_pieces(eng):
         with pytest.raises(exc):
             ens.get_fitness(broken)
         assert np.array_equal(ens.get_fitness(seqs[:40_000]), want_mean[:40_000])   # the engine is usable afterwards
+
+
+@pytest.mark.parametrize("kind,L,alpha,M,n", [("cnn", 8, "TGCA", 3, 100_001), ("cnn", 8, "TGCA", 1, 5), ("mlp", 14, "UGCA", 8, 1003),
+                                              ("ge", 90, s_utils.AAS, 16, 257), ("cnn", 237, s_utils.AAS, 2, 40),
+                                              ("cnn", 9, "TGCA", 3, 77), ("mlp", 14, "UGCA", 17, 300)])
+def test_mean_only_path_uses_planes_and_matches_matrix_path(eng, kind, L, alpha, M, n):
+    """Asking for the mean only lets the engine keep the scores as member-major planes (contiguous stores);
+    the mean must equal np.mean over the (N, M) matrix of the other path bit for bit, for every kernel family
+    (MFMA, pair / segmented, shape-agnostic) and through the explicit two-call form."""
+    import torch
+
+    F, K = (32, 5) if kind == "cnn" else (0, 0)
+    if L == 9:
+        F, K = 8, 4                                             # shape-agnostic kernels
+    natives, _ = zip(*[make_native(eng, kind, L, len(alpha), 100 if L != 9 else 20, F, K, seed=300 + m) for m in range(M)])
+    lut = _native.make_lut(alpha)
+    b, _ = rand_seqs(n, L, alpha, seed=n)
+    nm, mean_a = eng.score(list(natives), b, lut, want_matrix=True, want_mean=True)      # row-major intermediate
+    _, mean_b = eng.score(list(natives), b, lut, want_matrix=False, want_mean=True)      # planes (M <= 16)
+    assert np.array_equal(mean_a, np.mean(nm, axis=1)) and np.array_equal(mean_b, mean_a)
+    d_in = torch.from_numpy(b).cuda()
+    d_mean = torch.full((n,), float("nan"), device="cuda")
+    eng.score_dev(list(natives), d_in.data_ptr(), n, L, lut, None, d_mean.data_ptr())
+    eng.sync()
+    assert np.array_equal(d_mean.cpu().numpy(), mean_a)
+    if M <= 16:
+        stride = (n + 63) // 64 * 64
+        planes = torch.full((M, stride), float("nan"), device="cuda")
+        d_mean.fill_(float("nan"))
+        eng.score_planes_dev(list(natives), d_in.data_ptr(), n, L, lut, planes.data_ptr(), stride)
+        eng.ensemble_mean_planes_dev(planes.data_ptr(), n, M, stride, d_mean.data_ptr())
+        eng.sync()
+        assert np.array_equal(planes[:, :n].t().cpu().numpy(), nm) and np.array_equal(d_mean.cpu().numpy(), mean_a)
+        off = torch.full((n + 1,), float("nan"), device="cuda")       # a destination that is not 16-byte aligned
+        eng.ensemble_mean_planes_dev(planes.data_ptr(), n, M, stride, off.data_ptr() + 4)
+        eng.sync()
+        assert np.array_equal(off[1:].cpu().numpy(), mean_a)
