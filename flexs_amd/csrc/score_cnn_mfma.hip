@@ -444,7 +444,10 @@ int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const
         if (t.kind != FX_CNN || t.L != s.L || t.A != s.A || t.F != s.F || t.H != s.H || t.K != s.K)
             return FX_EUNSUPPORTED;                      // heterogeneous: caller scores them one by one
     }
-    if (s.F != 32 || s.K != 5 || (s.A != 4 && s.A != 20)) return FX_EUNSUPPORTED;
+    // num_filters 17..32 (two channel tiles; missing channels are zero padding of the packed blocks); kernel_size 5
+    // everywhere, 3 and 7 for the canonical hidden width (97..112 units); everything else -> shape-agnostic kernels
+    if (lay.FT != 2 || (s.A != 4 && s.A != 20)) return FX_EUNSUPPORTED;
+    if (s.K != 5 && !((s.K == 3 || s.K == 7) && lay.HT == 7)) return FX_EUNSUPPORTED;
     if (M > FX_MAX_M) return FX_EINVAL;
 
     CnnArgs a{};
@@ -457,6 +460,20 @@ int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const
     a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
 
     const size_t full = (size_t)lay.total_floats * 4 + 256 + 16, conv_only = (size_t)lay.conv_floats * 4 + 256 + 16;
+    if (s.A == 4 && s.K != 5) {
+        // other kernel sizes: the generic-length kernels only (no unrolled specialisations, conv1 in gather form)
+        if (full > (size_t)e->max_lds || e->cnn_conv1_mfma) return FX_EUNSUPPORTED;
+        const bool big = ((N + 15) / 16) * M >= (int64_t)e->num_cus * e->cnn_big_units;
+        a.TG = (N + 15) / 16;
+        const int L1 = s.L - s.K + 1;
+        const bool seg = e->cnn_seg != 0 && (int64_t)M * a.TG <= e->num_cus && (e->cnn_seg > 0 || L1 >= 24) &&
+                         full + 8 * 2 * 64 * 16 <= (size_t)e->max_lds;
+        if (s.K == 3) {
+            if (seg) return launch_g<4, 3, 2, 7, 1, true, 8, true, 0, false, true>(e, a, full);
+            return big ? launch_g<4, 3, 2, 7, 1, true, 16, true>(e, a, full) : launch_g<4, 3, 2, 7, 1, true, 8, true>(e, a, full);
+        }
+        return launch_g<4, 7, 2, 7, 1, true, 8, true>(e, a, full);     // 7-tap window: shifting form, 256-register budget
+    }
     if (s.A == 4) {
         const bool big = ((N + 15) / 16) * M >= (int64_t)e->num_cus * e->cnn_big_units;   // units per CU from which 16-wave workgroups pay
         const int variant = (int)e->cnn_variant;
@@ -476,7 +493,7 @@ int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const
         const int rc = fx_launch_score_cnn_pair(e, models, M, d_ascii, N, d_out_NM, Mtot, m_off);
         if (rc != FX_EUNSUPPORTED) return rc;
     }
-    if (lay.HT != 7 || conv_only > (size_t)e->max_lds) return FX_EUNSUPPORTED;
+    if (lay.HT != 7 || s.K != 5 || conv_only > (size_t)e->max_lds) return FX_EUNSUPPORTED;
     a.TG = (N + 15) / 16;
     return launch_inst<20, 5, 2, 7, 1, false, 4>(e, a, conv_only);   // 1 wave / SIMD: 512-VGPR budget for the 19-tap window
 }

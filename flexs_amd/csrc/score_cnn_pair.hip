@@ -327,7 +327,8 @@ int fx_launch_score_cnn_pair(fx_engine* e, fx_model* const* models, int M, const
     if (N == 0) return FX_OK;
     const FxShape& s = models[0]->shape;
     const FxPackLayout& lay = models[0]->layout;
-    if (s.F != 32 || s.K != 5 || s.A != 20 || M > FX_MAX_M) return FX_EUNSUPPORTED;
+    if (lay.FT != 2 || s.A != 20 || M > FX_MAX_M) return FX_EUNSUPPORTED;
+    if (s.K != 5 && !((s.K == 3 || s.K == 7) && lay.HT == 7)) return FX_EUNSUPPORTED;
     constexpr int WAVES = 8;
     const size_t lds = (size_t)(lay.conv_floats - lay.off_c2) * 4 + (size_t)3 * (WAVES / 2) * 2 * 64 * 16 + 256 + 16;
     if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
@@ -338,6 +339,8 @@ int fx_launch_score_cnn_pair(fx_engine* e, fx_model* const* models, int M, const
     a.N = N; a.TG = (N + 15) / 16; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4; a.htr = lay.HTR;
     a.off_c2 = (int)lay.off_c2; a.off_c3 = (int)lay.off_c3; a.off_cb = (int)lay.off_cb; a.off_w1p = (int)lay.off_w1p;
     a.conv_floats = (int)lay.conv_floats; a.lds_from = (int)lay.off_c2; a.lds_floats = (int)(lay.conv_floats - lay.off_c2); a.off_d1 = (int)lay.off_d1; a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db;
+    if (s.K == 3) return launch_pair<20, 3, 7, WAVES>(e, a, lds);
+    if (s.K == 7) return launch_pair<20, 7, 7, WAVES>(e, a, lds);
     switch (lay.HT) {
         case 1: return launch_pair<20, 5, 1, WAVES>(e, a, lds);
         case 2: return launch_pair<20, 5, 2, WAVES>(e, a, lds);

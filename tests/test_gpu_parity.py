@@ -1032,3 +1032,27 @@ def test_mean_only_path_uses_planes_and_matches_matrix_path(eng, kind, L, alpha,
         eng.ensemble_mean_planes_dev(planes.data_ptr(), n, M, stride, off.data_ptr() + 4)
         eng.sync()
         assert np.array_equal(off[1:].cpu().numpy(), mean_a)
+
+
+@pytest.mark.parametrize("L,alpha,F,K,n,M", [(8, "TGCA", 32, 3, 3000, 3), (14, "UGCA", 32, 7, 3000, 2), (50, "UGCA", 24, 3, 40, 1),
+                                             (50, "UGCA", 17, 7, 40, 1), (8, "TGCA", 20, 5, 70_000, 3), (9, "TGCA", 32, 7, 100, 1),
+                                             (60, s_utils.AAS, 32, 3, 300, 2), (60, s_utils.AAS, 28, 7, 33, 1), (237, s_utils.AAS, 32, 3, 20, 1),
+                                             (7, "TGCA", 32, 7, 5, 1), (3, "TGCA", 32, 3, 5, 1)])
+def test_cnn_other_kernel_sizes_and_filter_counts_on_mfma(eng, L, alpha, F, K, n, M):
+    """kernel_size 3 / 7 and num_filters 17..32 run on the MFMA kernels too (zero-padded channel tile, generic
+    window code): scores vs the oracle, and vs the shape-agnostic kernels of the same launch."""
+    natives, ws = zip(*[make_native(eng, "cnn", L, len(alpha), 100, F, K, seed=500 + m) for m in range(M)])
+    lut = _native.make_lut(alpha)
+    b, seqs = rand_seqs(n, L, alpha, seed=L * K + F)
+    got, mean = eng.score(list(natives), b, lut, want_matrix=True, want_mean=True)
+    k = min(n, 200)
+    codes = lut[b[:k]]
+    for m in range(M):
+        assert_scores(got[:k, m], c_oracle.forward("cnn", codes, len(alpha), ws[m]), f"L={L} F={F} K={K}")
+    assert np.array_equal(mean, np.mean(got, axis=1))
+    try:
+        eng.set_option("force_generic", 1)
+        ref, _ = eng.score(list(natives), b, lut)
+    finally:
+        eng.set_option("force_generic", 0)
+    assert np.allclose(got, ref, rtol=2e-5, atol=2e-6)
