@@ -1037,10 +1037,12 @@ def test_mean_only_path_uses_planes_and_matches_matrix_path(eng, kind, L, alpha,
 @pytest.mark.parametrize("L,alpha,F,K,n,M", [(8, "TGCA", 32, 3, 3000, 3), (14, "UGCA", 32, 7, 3000, 2), (50, "UGCA", 24, 3, 40, 1),
                                              (50, "UGCA", 17, 7, 40, 1), (8, "TGCA", 20, 5, 70_000, 3), (9, "TGCA", 32, 7, 100, 1),
                                              (60, s_utils.AAS, 32, 3, 300, 2), (60, s_utils.AAS, 28, 7, 33, 1), (237, s_utils.AAS, 32, 3, 20, 1),
-                                             (7, "TGCA", 32, 7, 5, 1), (3, "TGCA", 32, 3, 5, 1)])
+                                             (7, "TGCA", 32, 7, 5, 1), (3, "TGCA", 32, 3, 5, 1),
+                                             (14, "UGCA", 16, 5, 3000, 3), (8, "TGCA", 8, 5, 70_000, 2), (50, "UGCA", 16, 5, 40, 1),
+                                             (60, s_utils.AAS, 16, 5, 100, 2), (8, "TGCA", 1, 5, 64, 1)])
 def test_cnn_other_kernel_sizes_and_filter_counts_on_mfma(eng, L, alpha, F, K, n, M):
-    """kernel_size 3 / 7 and num_filters 17..32 run on the MFMA kernels too (zero-padded channel tile, generic
-    window code): scores vs the oracle, and vs the shape-agnostic kernels of the same launch."""
+    """kernel_size 3 / 7 and num_filters 1..32 run on the MFMA kernels too (one or two channel tiles, zero-padded;
+    generic window code): scores vs the oracle, and vs the shape-agnostic kernels of the same launch."""
     natives, ws = zip(*[make_native(eng, "cnn", L, len(alpha), 100, F, K, seed=500 + m) for m in range(M)])
     lut = _native.make_lut(alpha)
     b, seqs = rand_seqs(n, L, alpha, seed=L * K + F)
