@@ -1058,3 +1058,59 @@ def test_cnn_other_kernel_sizes_and_filter_counts_on_mfma(eng, L, alpha, F, K, n
     finally:
         eng.set_option("force_generic", 0)
     assert np.allclose(got, ref, rtol=2e-5, atol=2e-6)
+
+
+def test_c_abi_misuse_is_reported_not_fatal(eng):
+    """Status codes of the C ABI on misuse: every call returns an fx_status (mapped to ValueError / FxError by the
+    Python layer), nothing aborts, and the engine keeps working afterwards."""
+    import ctypes as C
+
+    lib, h = eng._lib, eng.handle
+    lut = _native.make_lut("TGCA")
+    nm, w = make_native(eng, "cnn", 8, 4, 100, 32, 5, seed=1)
+    b, _ = rand_seqs(32, 8, "TGCA", seed=1)
+    good, _ = eng.score([nm], b, lut)
+    # weights never set
+    empty = _native.NativeModel(eng, _native.FX_CNN, 8, 4, 32, 100, 5)
+    with pytest.raises(_native.FxError) as err:
+        eng.score([empty], b, lut)
+    assert err.value.code == _native.FX_ESTATE
+    # wrong sequence length for the model -> ValueError (Keras shape error)
+    with pytest.raises(ValueError):
+        eng.score([nm], b[:, :7].copy(), lut)
+    # LUT that maps a byte beyond the alphabet
+    bad_lut = lut.copy(); bad_lut[ord("Z")] = 9
+    with pytest.raises(_native.FxError) as err:
+        eng.score([nm], b, bad_lut)
+    assert err.value.code == _native.FX_EINVAL
+    # members with different alphabets / a valid-conv that cannot exist / wrong weight count
+    with pytest.raises(ValueError):
+        eng.score([nm, make_native(eng, "cnn", 8, 20, 100, 32, 5, seed=2)[0]], b, lut)
+    with pytest.raises((ValueError, _native.FxError)):
+        _native.NativeModel(eng, _native.FX_CNN, 3, 4, 32, 100, 5)                     # L < kernel_size
+    with pytest.raises((ValueError, _native.FxError)):
+        nm.set_weights(w[:-1])
+    # raw calls: null buffers, negative sizes, unknown option, protocol errors
+    arr = (C.c_void_p * 1)(nm.handle)
+    assert lib.fx_score(h, arr, 1, None, 4, 8, lut.ctypes.data_as(_native._u8p), None, None) == _native.FX_EINVAL
+    assert lib.fx_score(h, arr, 1, None, -1, 8, lut.ctypes.data_as(_native._u8p), None, None) == _native.FX_EINVAL
+    assert lib.fx_score(h, arr, 0, None, 4, 8, lut.ctypes.data_as(_native._u8p), None, None) == _native.FX_EINVAL
+    assert lib.fx_engine_set_option(h, b"no_such_option", 1) != _native.FX_OK
+    assert lib.fx_score_submit(h, 0, 16) == _native.FX_ESTATE and lib.fx_score_finish(h, None, None) == _native.FX_ESTATE
+    assert b"fx_score_finish" in lib.fx_last_error(h)
+    assert lib.fx_min_dist(h, 0, None, 4, None, 4, 300, None, None) != _native.FX_OK      # L > 256 / null buffers
+    with pytest.raises(_native.FxError) as err:
+        eng.min_dist(np.zeros((2, 300), np.uint8) + 65, np.zeros((3, 300), np.uint8) + 65)
+    assert err.value.code == _native.FX_EUNSUPPORTED
+    with pytest.raises((ValueError, _native.FxError)):
+        _native.NativeTable(eng, np.zeros((4, 5)), "", lut=np.full(256, 7, np.uint8)).additive_sum(np.zeros((2, 4), np.uint8))
+    assert lib.fx_status_name(_native.FX_EBADCHAR) == b"FX_EBADCHAR" and lib.fx_version() >= 100
+    # ... and the engine still scores
+    again, _ = eng.score([nm], b, lut)
+    assert np.array_equal(again, good)
+    # non-finite weights inside the network: NaN / inf end as nan_to_num says (keras_model.py:77)
+    w2 = [x.copy() for x in w]
+    w2[2][0, 0, 0] = np.nan                                                            # a conv2 weight
+    nm.set_weights(w2)
+    out, _ = eng.score([nm], b, lut)
+    assert np.isfinite(out).all()
