@@ -126,7 +126,21 @@ def _raise(code: int, eng_handle=None):
 
 
 def _ptr(a: Optional[np.ndarray]):
-    return None if a is None else a.ctypes.data_as(_vp)
+    """Address of an array's buffer as a plain int (c_void_p parameters take ints; `ndarray.ctypes.data_as` costs
+    microseconds, which is a tenth of a small call)."""
+    return None if a is None else a.__array_interface__["data"][0]
+
+
+_LUT_BUFFERS: Dict[bytes, "C.Array"] = {}
+
+
+def _lut_ptr(lut: np.ndarray):
+    """Persistent ctypes copy of a 256-byte LUT (keyed by content), so the per-call pointer is a dict look-up."""
+    key = lut.tobytes()
+    buf = _LUT_BUFFERS.get(key)
+    if buf is None:
+        buf = _LUT_BUFFERS[key] = C.cast((C.c_uint8 * 256).from_buffer_copy(key), _u8p)
+    return buf
 
 
 def make_lut(alphabet: str) -> np.ndarray:
@@ -298,7 +312,7 @@ class Engine:
         out_mean = np.empty((N,), np.float32) if want_mean else None
         seq_bytes = np.ascontiguousarray(seq_bytes)
         self.check(self._lib.fx_score(self.handle, arr, M, _ptr(seq_bytes), N, L,
-                                      lut.ctypes.data_as(_u8p), _ptr(out_nm), _ptr(out_mean)))
+                                      _lut_ptr(lut), _ptr(out_nm), _ptr(out_mean)))
         return out_nm, out_mean
 
     def score_strings(self, models: Sequence["NativeModel"], seqs, L: int, lut: np.ndarray,
@@ -309,7 +323,7 @@ class Engine:
         N, M = len(seqs), len(models)
         arr = (_vp * M)(*[m.handle for m in models])
         p = _vp()
-        self.check(self._lib.fx_score_begin(self.handle, arr, M, N, L, lut.ctypes.data_as(_u8p), int(want_matrix),
+        self.check(self._lib.fx_score_begin(self.handle, arr, M, N, L, _lut_ptr(lut), int(want_matrix),
                                             int(want_mean), C.byref(p)))
         staging = np.frombuffer((C.c_uint8 * (N * L)).from_address(p.value), np.uint8, N * L).reshape(N, L)
         if chunks <= 0:
@@ -341,7 +355,7 @@ class Engine:
                   d_out_nm: Optional[int], d_out_mean: Optional[int]):
         M = len(models)
         arr = (_vp * M)(*[m.handle for m in models])
-        self.check(self._lib.fx_score_dev(self.handle, arr, M, _vp(d_ascii), N, L, lut.ctypes.data_as(_u8p),
+        self.check(self._lib.fx_score_dev(self.handle, arr, M, _vp(d_ascii), N, L, _lut_ptr(lut),
                                           _vp(d_out_nm) if d_out_nm else None,
                                           _vp(d_out_mean) if d_out_mean else None))
 
@@ -349,7 +363,7 @@ class Engine:
                          d_planes: int, stride: int):
         M = len(models)
         arr = (_vp * M)(*[m.handle for m in models])
-        self.check(self._lib.fx_score_planes_dev(self.handle, arr, M, _vp(d_ascii), N, L, lut.ctypes.data_as(_u8p),
+        self.check(self._lib.fx_score_planes_dev(self.handle, arr, M, _vp(d_ascii), N, L, _lut_ptr(lut),
                                                  _vp(d_planes), stride))
 
     def ensemble_mean_planes_dev(self, d_planes: int, N: int, M: int, stride: int, d_out32: int):
@@ -359,11 +373,11 @@ class Engine:
         N, L = seq_bytes.shape
         out = np.empty((N, L, A), np.float32)
         seq_bytes = np.ascontiguousarray(seq_bytes)
-        self.check(self._lib.fx_encode_onehot(self.handle, _ptr(seq_bytes), N, L, lut.ctypes.data_as(_u8p), A, _ptr(out)))
+        self.check(self._lib.fx_encode_onehot(self.handle, _ptr(seq_bytes), N, L, _lut_ptr(lut), A, _ptr(out)))
         return out
 
     def encode_onehot_dev(self, d_ascii: int, N: int, L: int, lut: np.ndarray, A: int, d_out: int):
-        self.check(self._lib.fx_encode_onehot_dev(self.handle, _vp(d_ascii), N, L, lut.ctypes.data_as(_u8p), A, _vp(d_out)))
+        self.check(self._lib.fx_encode_onehot_dev(self.handle, _vp(d_ascii), N, L, _lut_ptr(lut), A, _vp(d_out)))
 
     def ensemble_mean(self, scores_nm: np.ndarray) -> np.ndarray:
         s = np.ascontiguousarray(scores_nm, np.float32)
@@ -408,7 +422,7 @@ class Engine:
         out_nm = np.empty((P, M), np.float32) if want_matrix else None
         out_mean = np.empty((P,), np.float32) if want_mean else None
         self.check(self._lib.fx_decode_score(self.handle, arr, M, _ptr(x), P, L, A, _ptr(np.ascontiguousarray(al)),
-                                             lut.ctypes.data_as(_u8p), _ptr(chars), _ptr(out_nm), _ptr(out_mean)))
+                                             _lut_ptr(lut), _ptr(chars), _ptr(out_nm), _ptr(out_mean)))
         return chars, out_nm, out_mean
 
     def min_dist(self, queries: np.ndarray, cache: np.ndarray, mode: int = FX_LEVENSHTEIN):
@@ -532,7 +546,7 @@ class NativeTable:
         out = np.empty(b.shape[0], np.float64)
         if b.shape[0]:
             self.engine.check(self.engine._lib.fx_table_lookup(self.handle, _ptr(b), b.shape[0], b.shape[1],
-                                                               self.lut.ctypes.data_as(_u8p), self.bits, _ptr(out)))
+                                                               _lut_ptr(self.lut), self.bits, _ptr(out)))
         return out
 
     def additive_sum(self, seq_bytes: np.ndarray) -> np.ndarray:
@@ -544,7 +558,7 @@ class NativeTable:
         out = np.empty(b.shape[0], np.float64)
         if b.shape[0]:
             self.engine.check(self.engine._lib.fx_table_additive(self.handle, _ptr(b), b.shape[0], L,
-                                                                 self.lut.ctypes.data_as(_u8p), ncol, _ptr(out)))
+                                                                 _lut_ptr(self.lut), ncol, _ptr(out)))
         return out
 
     def __del__(self):
