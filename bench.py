@@ -115,7 +115,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
+    saved_stdout = None
     if use_dist:
+        # RCCL prints a five-line version banner on STDOUT when its first communicator comes up; the contract is one
+        # JSON line there, so file descriptor 1 points at stderr until the line is printed
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         # the exchanged messages are 4*N bytes per rank (0.4 MB): latency-bound.  Keep RCCL to a couple of
@@ -233,6 +239,9 @@ def main():
         out = make_report(world, N, args.steps, args.warmup, elapsed, host_issue_s, kern_ms, use_dist)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nam=args.cpu_nam)
+        if saved_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
