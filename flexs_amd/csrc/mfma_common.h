@@ -46,11 +46,6 @@ __device__ __forceinline__ f4 pool_max4(f4 pool, f4 x) {
     return r;
 }
 
-__device__ __forceinline__ f4 max4(f4 a, f4 b) {
-    f4 r;
-    r.x = fmaxf(a.x, b.x); r.y = fmaxf(a.y, b.y); r.z = fmaxf(a.z, b.z); r.w = fmaxf(a.w, b.w);
-    return r;
-}
 // XCD-aware work split.  Workgroup b is observed to run on XCD b % 8, and every XCD has its own L2: with the plain
 // "block b takes the b-th slice of the (member, tile) units" the 32 workgroups behind one L2 would be spread over
 // every ensemble member, and each of the 8 L2s would fetch every member's weights from HBM.  This bijection hands

@@ -29,7 +29,7 @@ struct CnnArgs {
     int M, Mtot, m_off;
     int64_t out_sn, out_sm;     // score of (sequence n, member column c) lives at out[n * out_sn + c * out_sm]
     int L;
-    int rlh, htr;               // hidden tail: real k-steps of the last real tile, number of real hidden tiles
+    int rlh;                    // hidden tail: real k-steps of the last real hidden tile
     // packed-layout offsets (floats)
     int off_first, off_c2, off_c3, off_cb, off_w1p, conv_floats, off_d1, off_d2, off_db, total_floats;
 };
@@ -454,7 +454,7 @@ int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const
     a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
     for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
     a.out_sn = e->planar_stride ? 1 : Mtot; a.out_sm = e->planar_stride ? e->planar_stride : 1;
-    a.N = N; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4; a.htr = lay.HTR;
+    a.N = N; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4;
     a.off_first = (int)lay.off_first; a.off_c2 = (int)lay.off_c2; a.off_c3 = (int)lay.off_c3;
     a.off_cb = (int)lay.off_cb; a.off_w1p = (int)lay.off_w1p; a.conv_floats = (int)lay.conv_floats; a.off_d1 = (int)lay.off_d1;
     a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;

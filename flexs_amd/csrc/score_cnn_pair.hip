@@ -36,7 +36,7 @@ struct PairArgs {
     int64_t N, TG;
     int M, Mtot, m_off;
     int64_t out_sn, out_sm;     // out[n * out_sn + column * out_sm]
-    int L, rlh, htr;
+    int L, rlh;
     int off_c2, off_c3, off_cb, off_w1p, conv_floats, off_d1, off_d2, off_db;
     int lds_from, lds_floats;   // LDS image = packed[lds_from .. lds_from + lds_floats): conv2, conv3, biases, conv1 rows
     int SB;                     // SEG form: workgroups per (member, tile) unit
@@ -336,7 +336,7 @@ int fx_launch_score_cnn_pair(fx_engine* e, fx_model* const* models, int M, const
     a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
     for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
     a.out_sn = e->planar_stride ? 1 : Mtot; a.out_sm = e->planar_stride ? e->planar_stride : 1;
-    a.N = N; a.TG = (N + 15) / 16; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4; a.htr = lay.HTR;
+    a.N = N; a.TG = (N + 15) / 16; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4;
     a.off_c2 = (int)lay.off_c2; a.off_c3 = (int)lay.off_c3; a.off_cb = (int)lay.off_cb; a.off_w1p = (int)lay.off_w1p;
     a.conv_floats = (int)lay.conv_floats; a.lds_from = (int)lay.off_c2; a.lds_floats = (int)(lay.conv_floats - lay.off_c2); a.off_d1 = (int)lay.off_d1; a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db;
     if (s.K == 3) return launch_pair<20, 3, 7, WAVES>(e, a, lds);

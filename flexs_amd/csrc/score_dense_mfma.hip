@@ -25,7 +25,7 @@ struct DenseArgs {
     int64_t N, TG;
     int M, Mtot, m_off;
     int64_t out_sn, out_sm;     // out[n * out_sn + column * out_sm]
-    int L, A, rlh, htr;
+    int L, A, rlh;
     int SG1, off_first, off_w1p, off_d2, off_d3, off_db, total_floats;
     int lds_from, lds_floats;   // the LDS image is packed[lds_from .. lds_from + lds_floats)
 };
@@ -339,7 +339,7 @@ int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, con
     a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
     for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
     a.out_sn = e->planar_stride ? 1 : Mtot; a.out_sm = e->planar_stride ? e->planar_stride : 1;
-    a.N = N; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.A = s.A; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4; a.htr = lay.HTR;
+    a.N = N; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.A = s.A; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4;
     a.SG1 = lay.SG1; a.off_first = (int)lay.off_first; a.off_w1p = (int)lay.off_w1p; a.off_d2 = (int)lay.off_d2; a.off_d3 = (int)lay.off_d3;
     a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
     a.TG = (N + 15) / 16;
