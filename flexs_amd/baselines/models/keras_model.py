@@ -106,6 +106,13 @@ class KerasModel(flexs_amd.Model):
         self._native_model = None
         self._native_version = None
 
+    # ------------------------------------------------------------------ copy / pickle: device handles stay behind
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_native_model"] = None          # the copy uploads its weights to its own fx_model on first use
+        state["_native_version"] = None
+        return state
+
     # ------------------------------------------------------------------ engine plumbing
     @property
     def seq_len(self) -> int:

@@ -31,6 +31,12 @@ class NoisyAbstractModel(flexs_amd.Model):
         self._dev_cache = None            # NativeCache mirroring list(self.cache) in insertion order
         self._dev_keys = []               # python-side mirror of what was appended
 
+    def __getstate__(self):
+        state = self.__dict__.copy()           # copy / pickle: the device key store is rebuilt from `cache` on first use
+        state["_dev_cache"] = None
+        state["_dev_keys"] = []
+        return state
+
     # ---------------------------------------------------------------- device cache sync
     @staticmethod
     def _rows(seqs, L: int) -> np.ndarray:

@@ -82,6 +82,11 @@ class AdditiveAAVPackaging(flexs_amd.Landscape):
         return "".join(letters), total
 
     # ---------------------------------------------------------------- device table
+    def __getstate__(self):
+        state = self.__dict__.copy()           # copy / pickle: the device table is rebuilt on first use
+        state["_table"] = None
+        return state
+
     def _native_table(self) -> "_native.NativeTable":
         if self._table is None:
             L = self.end - self.start

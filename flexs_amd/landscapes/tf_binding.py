@@ -36,6 +36,11 @@ class TFBinding(flexs_amd.Landscape):
         self._device = device
         self._table = None
 
+    def __getstate__(self):
+        state = self.__dict__.copy()           # copy / pickle: the device table is rebuilt on first use
+        state["_table"] = None
+        return state
+
     def _native_table(self):
         if self._table is None:
             L = self._L

@@ -1114,3 +1114,34 @@ def test_c_abi_misuse_is_reported_not_fatal(eng):
     nm.set_weights(w2)
     out, _ = eng.score([nm], b, lut)
     assert np.isfinite(out).all()
+
+
+def test_deepcopy_and_pickle_of_live_models(eng):
+    """Models that already own device handles can be deep-copied and pickled (an explorer wrapper might): the copy
+    re-creates its own handles lazily and scores identically; NoisyAbstractModel rebuilds its device key store."""
+    import copy
+    import pickle
+
+    L, alpha = 14, "UGCA"
+    _, seqs = rand_seqs(300, L, alpha, seed=77)
+    ens = flexs_amd.Ensemble([bm.CNN(L, 32, 100, alpha, seed=0), bm.MLP(L, 100, alpha, seed=1)])
+    want = ens.get_fitness(seqs)                                          # handles now exist
+    for clone in (copy.deepcopy(ens), pickle.loads(pickle.dumps(ens))):
+        assert clone.models[0]._native_model is None
+        assert np.array_equal(clone.get_fitness(seqs), want) and clone.cost == 600
+
+    class Table(flexs_amd.Landscape):
+        def __init__(self):
+            super().__init__("table")
+
+        def _fitness_function(self, s):
+            return np.array([(sum(map(ord, str(x))) % 97) / 97.0 for x in s])
+
+    nam = bm.NoisyAbstractModel(Table(), 0.8)
+    nam.train(seqs[:100], np.linspace(0, 1, 100))
+    np.random.seed(1)
+    nam.get_fitness(seqs[100:150])
+    twin = copy.deepcopy(nam)
+    np.random.seed(2); a = nam.get_fitness(seqs[150:220])
+    np.random.seed(2); b = twin.get_fitness(seqs[150:220])
+    assert np.array_equal(a, b) and list(nam.cache) == list(twin.cache)

@@ -294,3 +294,38 @@ def test_string_marshalling_helper_equals_pure_python(monkeypatch):
     for c, exc in bad:
         with pytest.raises(exc):
             _native.sequences_to_bytes(c)
+
+
+def test_models_copy_and_pickle_without_device_handles():
+    """copy.deepcopy / pickle of the host-side objects must not try to duplicate device handles: they are dropped
+    and rebuilt lazily by the copy."""
+    import copy
+    import pickle
+
+    from flexs_amd.baselines.models.noisy_abstract_model import NoisyAbstractModel
+
+    cnn = bm.CNN(8, 32, 100, "TGCA", seed=3)
+    cnn.cost = 7
+    cnn._native_model, cnn._native_version = object(), (1, 2)          # stand-ins for a live fx_model
+    state = cnn.__getstate__()
+    assert state["_native_model"] is None and state["_native_version"] is None and state["cost"] == 7
+    assert all(np.array_equal(a, b) for a, b in zip(state["model"].get_weights(), cnn.model.get_weights()))
+    cnn._native_model = None
+    twin = pickle.loads(pickle.dumps(cnn))
+    assert twin.name == cnn.name and twin.cost == 7 and twin._native_model is None
+    assert all(np.array_equal(a, b) for a, b in zip(twin.model.get_weights(), cnn.model.get_weights()))
+    ens = copy.deepcopy(flexs_amd.Ensemble([cnn, bm.MLP(8, 16, "TGCA", seed=1)]))
+    assert [m.name for m in ens.models] == [cnn.name, "MLP_hidden_size_16"]
+
+    class Flat(flexs_amd.Landscape):
+        def __init__(self):
+            super().__init__("flat")
+
+        def _fitness_function(self, seqs):
+            return np.zeros(len(seqs))
+
+    nam = NoisyAbstractModel(Flat(), 0.5)
+    nam.cache = {"ACGT": 1.0}
+    nam._dev_cache, nam._dev_keys = object(), ["ACGT"]
+    st = nam.__getstate__()
+    assert st["_dev_cache"] is None and st["_dev_keys"] == [] and st["cache"] == {"ACGT": 1.0}
