@@ -43,28 +43,53 @@ __device__ __forceinline__ int load_code(const GenericArgs& a, int64_t n, int l,
     return c;
 }
 
+// The two contraction helpers compute OB outputs per pass over the inputs: one workspace load (the lane's
+// activation) then feeds OB fused multiply-adds whose weights are wave-uniform (scalar loads of OB consecutive
+// floats), instead of one memory instruction per multiply-add.  Every output still accumulates its terms in the
+// same order (bias first, inputs ascending), so results do not depend on OB.
+constexpr int OB = 16;
+
 // conv over workspace rows.  in rows [Lin*Cin], out rows [Lout*Cout]
 __device__ void conv_ws(const float* in, float* out, int T, int Lin, int Cin, const float* __restrict__ w,
                         const float* __restrict__ b, int k, int Cout, int pl) {
     for (int t = 0; t < Lin; ++t)
-        for (int o = 0; o < Cout; ++o) {
-            float acc = b[o];
+        for (int o0 = 0; o0 < Cout; o0 += OB) {
+            float acc[OB];
+#pragma unroll
+            for (int u = 0; u < OB; ++u) acc[u] = o0 + u < Cout ? b[o0 + u] : 0.f;
             for (int j = 0; j < k; ++j) {
-                int p = t + j - pl;
+                const int p = t + j - pl;
                 if (p < 0 || p >= Lin) continue;
-                for (int c = 0; c < Cin; ++c)
-                    acc = fmaf(in[(int64_t)(p * Cin + c) * T], w[((int64_t)j * Cin + c) * Cout + o], acc);
+                for (int c = 0; c < Cin; ++c) {
+                    const float x = in[(int64_t)(p * Cin + c) * T];
+                    const float* wr = w + ((int64_t)j * Cin + c) * Cout + o0;
+#pragma unroll
+                    for (int u = 0; u < OB; ++u)
+                        if (o0 + u < Cout) acc[u] = fmaf(x, wr[u], acc[u]);
+                }
             }
-            out[(int64_t)(t * Cout + o) * T] = fmaxf(acc, 0.f);
+#pragma unroll
+            for (int u = 0; u < OB; ++u)
+                if (o0 + u < Cout) out[(int64_t)(t * Cout + o0 + u) * T] = fmaxf(acc[u], 0.f);
         }
 }
 
 __device__ void dense_ws(const float* in, float* out, int T, int nin, const float* __restrict__ w,
                          const float* __restrict__ b, int nout) {
-    for (int o = 0; o < nout; ++o) {
-        float acc = b[o];
-        for (int i = 0; i < nin; ++i) acc = fmaf(in[(int64_t)i * T], w[(int64_t)i * nout + o], acc);
-        out[(int64_t)o * T] = fmaxf(acc, 0.f);
+    for (int o0 = 0; o0 < nout; o0 += OB) {
+        float acc[OB];
+#pragma unroll
+        for (int u = 0; u < OB; ++u) acc[u] = o0 + u < nout ? b[o0 + u] : 0.f;
+        for (int i = 0; i < nin; ++i) {
+            const float x = in[(int64_t)i * T];
+            const float* wr = w + (int64_t)i * nout + o0;
+#pragma unroll
+            for (int u = 0; u < OB; ++u)
+                if (o0 + u < nout) acc[u] = fmaf(x, wr[u], acc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < OB; ++u)
+            if (o0 + u < nout) out[(int64_t)(o0 + u) * T] = fmaxf(acc[u], 0.f);
     }
 }
 
