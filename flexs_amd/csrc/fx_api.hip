@@ -297,7 +297,10 @@ static int score_dispatch(fx_engine* e, fx_model* const* models, int M, const ui
         }
         int rc = FX_EUNSUPPORTED;
         if (!e->force_generic) {
-            if (s0.kind == FX_CNN) rc = fx_launch_score_cnn_mfma(e, models + m0, cnt, d_ascii, N, d_NM, M, m0);
+            if (s0.kind == FX_CNN) {
+                rc = fx_launch_score_cnn_mfma(e, models + m0, cnt, d_ascii, N, d_NM, M, m0);
+                if (rc == FX_EUNSUPPORTED) rc = fx_launch_score_cnn_split(e, models + m0, cnt, d_ascii, N, d_NM, M, m0);
+            }
             else rc = fx_launch_score_dense_mfma(e, models + m0, cnt, d_ascii, N, d_NM, M, m0);
         }
         if (rc == FX_EUNSUPPORTED) rc = fx_launch_score_generic(e, models + m0, cnt, d_ascii, N, d_NM, M, m0);

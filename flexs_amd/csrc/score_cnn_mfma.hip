@@ -1,378 +1,5 @@
-// K1 score_cnn: string -> one-hot -> Conv1D x3 -> GlobalMaxPool -> Dense x3, fused, on f32 MFMA.
-//
-// Replaces, per (sequence, ensemble member):  sequence_utils.py:32-47 (encode),
-// keras_model.py:69-79 (tensor + predict + nan_to_num), cnn.py:23-54 (layers).
-//
-// One wave owns NT tiles of 16 sequences and streams over sequence positions,
-// keeping sliding windows of the conv1 / conv2 outputs in registers (see
-// mfma_common.h for the transposed-MFMA formulation).  Weights of the member
-// being scored sit in LDS in fragment order (pack.cpp); work units are
-// (member, tile-group) pairs, flattened member-major and split evenly over the
-// grid, so a block reloads LDS at most once per member boundary it straddles.
-//
-// Algorithmic work per sequence per member: L + 4 bytes of HBM
-// traffic, 2 * MACs FLOP with MACs = L1*K*A*F + L1*K*F*F + L1*(A-1)*F*F + F*H + H*H + H.
-// The kernel is f32-MFMA-bound (157.3 TFLOP/s peak), not HBM-bound.
-#include "fx_common.h"
-#include "mfma_common.h"
-
-namespace {
-
-struct CnnArgs {
-    const uint8_t* ascii;       // N x L
-    const uint8_t* lut;         // 256
-    const float* w[FX_MAX_M];   // packed weights per member
-    float* out;                 // N x Mtot
-    unsigned* err;
-    int64_t N;
-    int64_t TG;                 // tile groups per member = ceil(N / (16*NT))
-    int M, Mtot, m_off;
-    int64_t out_sn, out_sm;     // score of (sequence n, member column c) lives at out[n * out_sn + c * out_sm]
-    int L;
-    int rlh;                    // hidden tail: real k-steps of the last real hidden tile
-    // packed-layout offsets (floats)
-    int off_first, off_c2, off_c3, off_cb, off_w1p, conv_floats, off_d1, off_d2, off_db, total_floats;
-};
-
-// L1S > 0: number of conv positions known at compile time (L1S = seq_len - K + 1): the position loop is fully
-// unrolled, so the sliding windows become register renames instead of v_mov chains and the padding tests fold.
-// SEG: small batches (fewer tiles than CUs) -- the WAVES waves of a workgroup share ONE tile and split its conv
-// positions: wave q streams segment q plus a halo of PL3 + PL2 positions before and PR2 + PR3 after it, pools
-// only its own positions (every conv3 output sees the same MFMA sequence as in the whole-sequence walk, so the
-// result is bit-identical), the segment maxima meet in LDS and wave 0 runs the dense head.
-template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1, int L1S = 0, bool PRIO = false,
-          bool SEG = false>
-__global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
-    static_assert(!SEG || (NT == 1 && L1S == 0 && K * (A - 1) <= 16), "SEG is the ring-window, one-tile form");
-    constexpr int K3 = A - 1;
-    constexpr int PL2 = (K - 1) / 2, PR2 = K - 1 - PL2;
-    constexpr int PL3 = (K3 - 1) / 2, PR3 = K3 - 1 - PL3;
-    constexpr int S1 = (K * A + 3) / 4;                 // conv1 k-steps
-    static_assert(A % 4 == 0, "one-hot k-steps must not straddle a tap");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int g = lane >> 4, sq = lane & 15;
-    const int L = p.L, L1 = L1S > 0 ? L1S : L - K + 1;
-    const int lds_floats = DENSE_LDS ? p.total_floats : p.conv_floats;
-    uint8_t* lut_s = reinterpret_cast<uint8_t*>(smem + lds_floats);
-    int* next_tile = reinterpret_cast<int*>(smem + lds_floats + 64);   // work counter, after the 256-byte LUT
-
-    for (int i = tid; i < 64; i += blockDim.x)
-        reinterpret_cast<uint32_t*>(lut_s)[i] = reinterpret_cast<const uint32_t*>(p.lut)[i];
-
-    const int64_t U = (int64_t)p.M * p.TG;
-    const int64_t bid = fx_xcd_block();
-    const int64_t u_lo = U * bid / gridDim.x, u_hi = U * (bid + 1) / gridDim.x;
-    if (u_lo >= u_hi) return;
-    const int m_first = (int)(u_lo / p.TG), m_last = (int)((u_hi - 1) / p.TG);
-    bool bad = false;
-
-    for (int m = m_first; m <= m_last; ++m) {
-        __syncthreads();                                 // previous member's readers are done
-        if (tid == 0) *next_tile = 0;
-        {
-            const f4* src = reinterpret_cast<const f4*>(p.w[m]);
-            f4* dst = reinterpret_cast<f4*>(smem);
-            fill_lds(dst, src, lds_floats / 4);
-        }
-        __syncthreads();
-        const f4* w_first = reinterpret_cast<const f4*>(smem + p.off_first);
-        const f4* w_c2 = reinterpret_cast<const f4*>(smem + p.off_c2);
-        const f4* w_c3 = reinterpret_cast<const f4*>(smem + p.off_c3);
-        const float* cb = smem + p.off_cb;
-        const float* w1p = smem + p.off_w1p;
-        const float* dbase = DENSE_LDS ? smem : p.w[m];
-        const f4* w_d1 = reinterpret_cast<const f4*>(dbase + p.off_d1);
-        const f4* w_d2 = reinterpret_cast<const f4*>(dbase + p.off_d2);
-        const float* db = dbase + p.off_db;   // (not const-qualified pointers: laundered per tile below)
-
-        const int64_t t_lo = (u_lo > (int64_t)m * p.TG ? u_lo : (int64_t)m * p.TG) - (int64_t)m * p.TG;
-        const int64_t t_hi = (u_hi < (int64_t)(m + 1) * p.TG ? u_hi : (int64_t)(m + 1) * p.TG) - (int64_t)m * p.TG;
-
-        // waves pull tiles from a block-local counter: a SIMD's two waves then finish within
-        // one tile of each other whatever the split of the block's range was
-        for (int64_t seg_tile = t_lo;; ++seg_tile) {
-            int pulled = 0;
-            if (!SEG) {
-                if (lane == 0) pulled = atomicAdd(next_tile, 1);
-                pulled = __builtin_amdgcn_readfirstlane(pulled);
-            }
-            const int64_t tg = SEG ? seg_tile : t_lo + pulled;   // SEG: every wave of the workgroup walks the same tiles
-            if (tg >= t_hi) break;
-            // ---- this lane's sequences
-            int64_t n[NT];
-            const uint8_t* row[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                n[nt] = (tg * NT + nt) * 16 + sq;
-                row[nt] = p.ascii + (n[nt] < p.N ? n[nt] : 0) * L;   // out-of-range lanes recompute seq 0
-            }
-            // Sliding windows.  RING: positions live in slot (position mod window), and the position loop is
-            // unrolled by a multiple of both window lengths, so every slot index is a compile-time constant and
-            // nothing is ever moved.  Otherwise (19-tap protein window, A/B baseline only) slots are shifted.
-            constexpr bool RING = (L1S > 0) || (K * K3 <= 16);
-            constexpr int UN = L1S > 0 ? (L1S + PR2 + PR3) : (RING ? K * K3 : 1);   // trips per unrolled block
-            // code window: alphabet index at positions s .. s+K-1
-            int cw[K][NT];
-#pragma unroll
-            for (int j = 0; j < K - 1; ++j)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    int c = lut_s[row[nt][j]];
-                    if (c == 0xFF) { bad = true; c = 0; }
-                    cw[RING ? j : j + 1][nt] = c;         // (shifting form: moved down at the top of step 0)
-                }
-            f4 win1[K][FT][NT], win2[K3][FT][NT], gmax[FT][NT];
-#pragma unroll
-            for (int j = 0; j < K; ++j)
-#pragma unroll
-                for (int t = 0; t < FT; ++t)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) win1[j][t][nt] = splat4(0.f);
-#pragma unroll
-            for (int j = 0; j < K3; ++j)
-#pragma unroll
-                for (int t = 0; t < FT; ++t)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) win2[j][t][nt] = splat4(0.f);
-#pragma unroll
-            for (int t = 0; t < FT; ++t)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) gmax[t][nt] = splat4(0.f);   // relu output >= 0
-
-            const int steps = L1 + PR2 + PR3;
-            // SEG: positions this wave pools, and the steps it has to run for them
-            int seg_lo = 0, seg_hi = L1, s_begin = 0, s_stop = steps;
-            if (SEG) {
-                const int q = tid >> 6;
-                seg_lo = (int)((int64_t)L1 * q / WAVES);
-                seg_hi = (int)((int64_t)L1 * (q + 1) / WAVES);
-                s_begin = seg_lo - PL3 - PL2 > 0 ? seg_lo - PL3 - PL2 : 0;
-                s_stop = seg_hi + PR2 + PR3 < steps ? seg_hi + PR2 + PR3 : steps;
-                if (seg_lo >= seg_hi) s_stop = 0;                 // more waves than positions: nothing to do
-            }
-            const int s_first = SEG ? (s_begin / UN) * UN : 0;     // ring slots assume block starts at multiples of UN
-            if (SEG && s_first > 0) {
-                // the code window is positional: refill it for the block this wave starts in
-#pragma unroll
-                for (int j = 0; j < K - 1; ++j) {
-                    int c = lut_s[row[0][s_first + j]];
-                    if (c == 0xFF) { bad = true; c = 0; }
-                    cw[j][0] = c;
-                }
-            }
-            for (int s0 = s_first; s0 < s_stop; s0 += UN) {
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int s = s0 + u;
-                const bool act = !SEG || s >= s_begin;             // SEG: steps before the halo only advance the code window
-                if (L1S > 0 || s < s_stop) {
-                // weights in LDS are loop-invariant: without this barrier LICM hoists every
-                // ds_read out of the position loop and spills hundreds of VGPRs
-                // (fencing only every 2nd / 4th position of the unrolled kernels measured no gain: profiles/r1_run18)
-                asm volatile("" ::: "memory");
-                if (!RING) {
-                    // ---- slide the windows
-#pragma unroll
-                    for (int j = 0; j < K - 1; ++j)
-#pragma unroll
-                        for (int t = 0; t < FT; ++t)
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) win1[j][t][nt] = win1[j + 1][t][nt];
-#pragma unroll
-                    for (int j = 0; j < K3 - 1; ++j)
-#pragma unroll
-                        for (int t = 0; t < FT; ++t)
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) win2[j][t][nt] = win2[j + 1][t][nt];
-#pragma unroll
-                    for (int j = 0; j < K - 1; ++j)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) cw[j][nt] = cw[j + 1][nt];
-                }
-                // slot of: code[s + j]; out1[s] (newest); out1[s - (K-1) + j]; out2[t2] (newest); out2[t2 - (K3-1) + j]
-                // (s = u mod K and mod K3 because s0 is a multiple of both; all constants once unrolled)
-#define FX_CW(j) (RING ? (u + (j)) % K : (j))
-#define FX_W1NEW (RING ? u % K : K - 1)
-#define FX_W1(j) (RING ? (u + 1 + (j)) % K : (j))
-#define FX_W2NEW (RING ? (u + K3 * K - PR2) % K3 : K3 - 1)
-#define FX_W2(j) (RING ? (u + K3 * K - PR2 + 1 + (j)) % K3 : (j))
-
-                // ---- conv1 (valid) at t1 = s
-                if (s < L1) {
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        int c = lut_s[row[nt][s + K - 1]];
-                        if (c == 0xFF) { bad = true; c = 0; }
-                        cw[FX_CW(K - 1)][nt] = c;
-                    }
-                }
-                if (s < L1 && act) {
-                    f4 o1[FT][NT];
-                    init_bias<FT, NT>(cb, o1, g);
-                    if (G1) {
-                        // one-hot conv == sum of K kernel rows selected by the codes: LDS gather + VALU adds
-                        // (takes the 2*K*A*F "multiply by one-hot" FLOP per position off the MFMA pipe)
-#pragma unroll
-                        for (int j = 0; j < K; ++j)
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) {
-                                const float* rowp = w1p + (j * A + cw[FX_CW(j)][nt]) * (16 * FT) + 4 * g;
-#pragma unroll
-                                for (int mo = 0; mo < FT; ++mo) {
-                                    const f4 w = *reinterpret_cast<const f4*>(rowp + 16 * mo);
-                                    o1[mo][nt] += w;
-                                }
-                            }
-                    } else {
-#pragma unroll
-                        for (int st = 0; st < S1; ++st) {
-                            const int j = (4 * st) / A;          // tap (compile-time after unroll)
-                            const int a0 = (4 * st) % A;         // first alphabet index of the step
-                            const int sg = st >> 2, r = st & 3;
-                            float b[NT];
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) b[nt] = (cw[FX_CW(j)][nt] == a0 + g) ? 1.f : 0.f;
-#pragma unroll
-                            for (int mo = 0; mo < FT; ++mo) {
-                                const float a = reinterpret_cast<const float*>(&w_first[(sg * FT + mo) * 64 + lane])[r];
-#pragma unroll
-                                for (int nt = 0; nt < NT; ++nt) o1[mo][nt] = mfma16(a, b[nt], o1[mo][nt]);
-                            }
-                        }
-                    }
-                    relu_tiles<FT, NT>(o1);
-#pragma unroll
-                    for (int t = 0; t < FT; ++t)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) win1[FX_W1NEW][t][nt] = o1[t][nt];
-                } else {
-#pragma unroll
-                    for (int t = 0; t < FT; ++t)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) win1[FX_W1NEW][t][nt] = splat4(0.f);
-                }
-
-                // ---- conv2 (same) at t2 = s - PR2; tap j reads out1[t2 + j - PL2] = out1[s - (K-1) + j]
-                const int t2 = s - PR2;
-                if (t2 >= 0 && t2 < L1 && act) {
-                    f4 o2[FT][NT];
-                    init_bias<FT, NT>(cb + 16 * FT, o2, g);
-#pragma unroll
-                    for (int j = 0; j < K; ++j) {
-                        const int pp = t2 + j - PL2;
-                        if (pp >= 0 && pp < L1)            // zero padding contributes nothing
-                            mma_layer<FT, FT, NT, PRIO>(w_c2 + j * FT * FT * 64, win1[FX_W1(j)], o2, lane);
-                    }
-                    relu_tiles<FT, NT>(o2);
-#pragma unroll
-                    for (int t = 0; t < FT; ++t)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) win2[FX_W2NEW][t][nt] = o2[t][nt];
-                } else {
-#pragma unroll
-                    for (int t = 0; t < FT; ++t)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) win2[FX_W2NEW][t][nt] = splat4(0.f);
-                }
-
-                // ---- conv3 (same, kernel A-1) at t3 = t2 - PR3; tap j reads out2[t3 + j - PL3] = out2[t2 - (K3-1) + j]
-                //      (MaxPooling1D(1) between conv2 and conv3 is the identity, cnn.py:40)
-                const int t3 = t2 - PR3;
-                if (t3 >= seg_lo && t3 < seg_hi) {
-                    f4 o3[FT][NT];
-                    init_bias<FT, NT>(cb + 32 * FT, o3, g);
-#pragma unroll
-                    for (int j = 0; j < K3; ++j) {
-                        const int pp = t3 + j - PL3;
-                        if (pp >= 0 && pp < L1)
-                            mma_layer<FT, FT, NT, PRIO>(w_c3 + j * FT * FT * 64, win2[FX_W2(j)], o3, lane);
-                    }
-                    // GlobalMaxPooling1D of relu(o3): gmax starts at 0
-#pragma unroll
-                    for (int t = 0; t < FT; ++t)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) gmax[t][nt] = pool_max4(gmax[t][nt], o3[t][nt]);
-                }
-#undef FX_CW
-#undef FX_W1NEW
-#undef FX_W1
-#undef FX_W2NEW
-#undef FX_W2
-                }
-            }
-            }
-
-            if (SEG) {
-                // ---- segment maxima -> LDS; wave 0 folds them and carries on with the dense head
-                f4* seg_slot = reinterpret_cast<f4*>(smem + lds_floats + 64 + 4);   // after the LUT and the work counter
-                __syncthreads();                                  // previous tile's readers are done
-#pragma unroll
-                for (int t = 0; t < FT; ++t) seg_slot[((tid >> 6) * FT + t) * 64 + lane] = gmax[t][0];
-                __syncthreads();
-                if (tid >= 64) continue;
-#pragma unroll
-                for (int w = 1; w < WAVES; ++w)
-#pragma unroll
-                    for (int t = 0; t < FT; ++t) gmax[t][0] = pool_max4(gmax[t][0], seg_slot[(w * FT + t) * 64 + lane]);
-            }
-            // ---- dense head: F -> H relu -> H relu -> (dropout inactive) -> 1
-            asm volatile("" ::: "memory");
-            if (!DENSE_LDS) {
-                // weights streamed from L2: launder the base pointer per tile, otherwise LICM hoists the
-                // 64-bit address of every 1 KiB block out of the tile loop and spills them
-                asm volatile("" : "+v"(w_d1), "+v"(w_d2), "+v"(db));
-            }
-            f4 h1[HT][NT], h2[HT][NT];
-            init_bias<HT, NT>(db, h1, g);
-            mma_layer<FT, HT, NT, PRIO>(w_d1, gmax, h1, lane);
-            relu_tiles<HT, NT>(h1);
-            init_bias<HT, NT>(db + 16 * HT, h2, g);
-            mma_layer<HT, HT, NT, PRIO>(w_d2, h1, h2, lane, p.rlh);
-            relu_tiles<HT, NT>(h2);
-            float y[NT];
-            final_dot<HT, NT>(db + 32 * HT, db[48 * HT], h2, y, g);
-            if (g == 0) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    if (n[nt] < p.N) p.out[n[nt] * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y[nt]);
-            }
-        }
-    }
-    if (bad) fx_raise(p.err, FX_ERR_BADCHAR);
-}
-
-template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1, int L1S = 0, bool PRIO = false,
-          bool SEG = false>
-int launch_g(fx_engine* e, const CnnArgs& a, size_t lds_bytes) {
-    constexpr int waves = WAVES;
-    auto kern = k_score_cnn_mfma<A, K, FT, HT, NT, DENSE_LDS, WAVES, G1, L1S, PRIO, SEG>;
-    if (SEG) lds_bytes += (size_t)WAVES * FT * 64 * 16;          // segment-maxima slots
-    static bool attr_set[64] = {};
-    if (!attr_set[e->device & 63]) {
-        FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set[e->device & 63] = true;
-    }
-    int64_t U = (int64_t)a.M * a.TG;
-    int64_t blocks = e->grid_blocks > 0 ? e->grid_blocks : e->num_cus;
-    // never more workgroups than work units
-    int64_t need = U;                                // small batches: one unit per workgroup (lowest latency)
-    if (blocks > need) blocks = need;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(waves * 64), lds_bytes, e->stream, a);
-    FX_HIP(e, hipGetLastError());
-    return FX_OK;
-}
-
-template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES>
-int launch_inst(fx_engine* e, const CnnArgs& a, size_t lds_bytes) {
-    return e->cnn_conv1_mfma ? launch_g<A, K, FT, HT, NT, DENSE_LDS, WAVES, false>(e, a, lds_bytes)
-                             : launch_g<A, K, FT, HT, NT, DENSE_LDS, WAVES, true>(e, a, lds_bytes);
-}
-
-}  // namespace
+// Dispatch of the fused CNN scoring kernels (template in score_cnn_kernel.h).
+#include "score_cnn_kernel.h"
 
 namespace {
 

@@ -1,0 +1,165 @@
+// Two-kernel CNN path for the shapes without a fused instantiation (4-letter alphabets; kernel_size 2..7,
+// num_filters <= 32, any hidden width up to 256 -- cnn.py:10-21 leaves all of them to the caller).
+//
+// The fused kernel is a template over (alphabet, kernel size, channel tiles, hidden tiles, ...): covering every
+// combination multiplies instantiations.  Here the two halves meet in HBM instead: the conv part
+// (k_score_cnn_mfma<..., HEAD = false>, score_cnn_kernel.h) leaves each tile's max-pooled features -- 16 sequences x
+// 16*FT channels, already in the accumulator layout the next MFMA wants as its B operand -- in a scratch buffer
+// (64*FT bytes per sequence), and k_cnn_head runs Dense-relu-Dense-relu-Dense on them.  Instantiations are
+// |kernel sizes| x |channel tiles| conv kernels + |channel tiles| x |hidden tile counts| head kernels.
+#include "score_cnn_kernel.h"
+
+namespace {
+
+struct HeadArgs {
+    const f4* pool;             // [(member * TG + tile) * FT + t][64 lanes]
+    const float* w[FX_MAX_M];   // packed weights per member
+    float* out;
+    int64_t N, TG;
+    int M, m_off;
+    int64_t out_sn, out_sm;
+    int rlh;
+    int off_d1, off_d2, off_db, head_floats;   // the head's part of the packed image: [off_d1, off_d1 + head_floats)
+};
+
+// WLDS: the head's weights (FT*HT + HT*HT KiB) fit LDS; otherwise (13 / 16 hidden tiles) they stream from L2.
+template <int FT, int HT, bool WLDS, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_cnn_head(HeadArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, sq = lane & 15;
+    const int64_t U = (int64_t)p.M * p.TG;
+    const int64_t bid = fx_xcd_block();
+    const int64_t u_lo = U * bid / gridDim.x, u_hi = U * (bid + 1) / gridDim.x;
+    if (u_lo >= u_hi) return;
+    const int m_first = (int)(u_lo / p.TG), m_last = (int)((u_hi - 1) / p.TG);
+    for (int m = m_first; m <= m_last; ++m) {
+        __syncthreads();
+        if (WLDS) fill_lds(reinterpret_cast<f4*>(smem), reinterpret_cast<const f4*>(p.w[m] + p.off_d1), p.head_floats / 4);
+        __syncthreads();
+        const float* base = WLDS ? smem : p.w[m] + p.off_d1;
+        const f4* w_d1 = reinterpret_cast<const f4*>(base);
+        const f4* w_d2 = reinterpret_cast<const f4*>(base + (p.off_d2 - p.off_d1));
+        const float* db = base + (p.off_db - p.off_d1);
+        const int64_t t_lo = (u_lo > (int64_t)m * p.TG ? u_lo : (int64_t)m * p.TG) - (int64_t)m * p.TG;
+        const int64_t t_hi = (u_hi < (int64_t)(m + 1) * p.TG ? u_hi : (int64_t)(m + 1) * p.TG) - (int64_t)m * p.TG;
+        for (int64_t tile = t_lo + wave; tile < t_hi; tile += WAVES) {
+            asm volatile("" ::: "memory");               // keep the weight reads inside the tile loop
+            if (!WLDS) asm volatile("" : "+v"(w_d1), "+v"(w_d2), "+v"(db));
+            f4 pooled[FT][1];
+            const f4* src = p.pool + (((int64_t)m * p.TG + tile) * FT) * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < FT; ++t) pooled[t][0] = src[t * 64];
+            f4 h1[HT][1], h2[HT][1];
+            init_bias<HT, 1>(db, h1, g);
+            mma_layer<FT, HT, 1>(w_d1, pooled, h1, lane);
+            relu_tiles<HT, 1>(h1);
+            init_bias<HT, 1>(db + 16 * HT, h2, g);
+            mma_layer<HT, HT, 1>(w_d2, h1, h2, lane, p.rlh);
+            relu_tiles<HT, 1>(h2);
+            float y[1];
+            final_dot<HT, 1>(db + 32 * HT, db[48 * HT], h2, y, g);
+            const int64_t n = tile * 16 + sq;
+            if (g == 0 && n < p.N) p.out[n * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y[0]);
+        }
+    }
+}
+
+template <int FT, int HT>
+int launch_head(fx_engine* e, const HeadArgs& a) {
+    constexpr int WAVES = 8;
+    const size_t lds = (size_t)a.head_floats * 4 + 16;
+    const bool wlds = lds <= (size_t)e->max_lds && HT <= 8;
+    const int64_t U = (int64_t)a.M * a.TG;
+    int64_t blocks = e->grid_blocks > 0 ? e->grid_blocks : e->num_cus;
+    if (blocks > (U + WAVES - 1) / WAVES) blocks = (U + WAVES - 1) / WAVES;
+    if (blocks < 1) blocks = 1;
+    if (wlds) {
+        auto kern = k_cnn_head<FT, HT, true, WAVES>;
+        static bool attr_set[64] = {};
+        if (!attr_set[e->device & 63]) {
+            FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set[e->device & 63] = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), lds, e->stream, a);
+    } else {
+        hipLaunchKernelGGL((k_cnn_head<FT, HT, false, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), 16, e->stream, a);
+    }
+    FX_HIP(e, hipGetLastError());
+    return FX_OK;
+}
+
+template <int FT>
+int dispatch_head(fx_engine* e, const HeadArgs& a, int HT) {
+    switch (HT) {
+        case 1: return launch_head<FT, 1>(e, a);
+        case 2: return launch_head<FT, 2>(e, a);
+        case 4: return launch_head<FT, 4>(e, a);
+        case 7: return launch_head<FT, 7>(e, a);
+        case 8: return launch_head<FT, 8>(e, a);
+        case 13: return launch_head<FT, 13>(e, a);
+        case 16: return launch_head<FT, 16>(e, a);
+        default: return FX_EUNSUPPORTED;
+    }
+}
+
+template <int K, int FT>
+int launch_conv(fx_engine* e, const CnnArgs& a, size_t lds) {
+    // conv part only: one tile per wave, 8 waves, conv weights in LDS, first layer in gather form
+    return launch_g<4, K, FT, 1, 1, false, 8, true, 0, false, false, false>(e, a, lds);
+}
+
+template <int FT>
+int dispatch_conv(fx_engine* e, const CnnArgs& a, size_t lds, int K) {
+    switch (K) {
+        case 2: return launch_conv<2, FT>(e, a, lds);
+        case 3: return launch_conv<3, FT>(e, a, lds);
+        case 4: return launch_conv<4, FT>(e, a, lds);
+        case 5: return launch_conv<5, FT>(e, a, lds);
+        case 6: return launch_conv<6, FT>(e, a, lds);
+        case 7: return launch_conv<7, FT>(e, a, lds);
+        default: return FX_EUNSUPPORTED;
+    }
+}
+
+}  // namespace
+
+int fx_launch_score_cnn_split(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N,
+                              float* d_out_NM, int Mtot, int m_off) {
+    if (N == 0) return FX_OK;
+    const FxShape& s = models[0]->shape;
+    const FxPackLayout& lay = models[0]->layout;
+    for (int m = 0; m < M; ++m) {
+        const FxShape& t = models[m]->shape;
+        if (t.kind != FX_CNN || t.L != s.L || t.A != s.A || t.F != s.F || t.H != s.H || t.K != s.K) return FX_EUNSUPPORTED;
+    }
+    if (s.A != 4 || lay.FT < 1 || lay.FT > 2 || s.K < 2 || s.K > 7 || s.H > 256 || M > FX_MAX_M || e->cnn_conv1_mfma)
+        return FX_EUNSUPPORTED;
+    const size_t conv_lds = (size_t)lay.conv_floats * 4 + 256 + 16;
+    if (conv_lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
+    const int64_t TG = (N + 15) / 16;
+    void* pool = nullptr;
+    int rc = fx_scratch(e, 2, (size_t)M * (size_t)TG * lay.FT * 64 * sizeof(f4), &pool);
+    if (rc) return rc;
+
+    CnnArgs a{};
+    a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
+    for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
+    a.out_sn = e->planar_stride ? 1 : Mtot; a.out_sm = e->planar_stride ? e->planar_stride : 1;
+    a.N = N; a.TG = TG; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.rlh = 4;
+    a.off_first = (int)lay.off_first; a.off_c2 = (int)lay.off_c2; a.off_c3 = (int)lay.off_c3;
+    a.off_cb = (int)lay.off_cb; a.off_w1p = (int)lay.off_w1p; a.conv_floats = (int)lay.conv_floats; a.off_d1 = (int)lay.off_d1;
+    a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
+    a.pool_out = (f4*)pool;
+    rc = lay.FT == 1 ? dispatch_conv<1>(e, a, conv_lds, s.K) : dispatch_conv<2>(e, a, conv_lds, s.K);
+    if (rc) return rc;
+
+    HeadArgs h{};
+    h.pool = (const f4*)pool; h.out = d_out_NM; h.N = N; h.TG = TG; h.M = M; h.m_off = m_off;
+    for (int m = 0; m < M; ++m) h.w[m] = models[m]->d_packed;
+    h.out_sn = a.out_sn; h.out_sm = a.out_sm;
+    h.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4;
+    h.off_d1 = (int)lay.off_d1; h.off_d2 = (int)lay.off_d2; h.off_db = (int)lay.off_db;
+    h.head_floats = (int)(lay.total_floats - lay.off_d1);
+    return lay.FT == 1 ? dispatch_head<1>(e, h, lay.HT) : dispatch_head<2>(e, h, lay.HT);
+}

@@ -1145,3 +1145,31 @@ def test_deepcopy_and_pickle_of_live_models(eng):
     np.random.seed(2); a = nam.get_fitness(seqs[150:220])
     np.random.seed(2); b = twin.get_fitness(seqs[150:220])
     assert np.array_equal(a, b) and list(nam.cache) == list(twin.cache)
+
+
+@pytest.mark.parametrize("L,F,H,K,n,M", [(8, 32, 50, 3, 5000, 3), (14, 32, 128, 7, 3000, 2), (14, 32, 200, 3, 2000, 1), (20, 32, 256, 6, 500, 1),
+                                         (9, 8, 20, 4, 300, 2), (8, 16, 64, 5, 70_000, 2), (30, 24, 100, 2, 100, 1), (12, 32, 100, 6, 33, 1),
+                                         (50, 32, 30, 3, 17, 1), (6, 1, 1, 2, 5, 1), (3, 32, 100, 3, 4, 1), (100, 12, 257 - 1, 4, 64, 1)])
+def test_cnn_split_conv_and_head_path(eng, L, F, H, K, n, M):
+    """CNN shapes without a fused instantiation (kernel_size 2..7 x any hidden width <= 256 x num_filters <= 32, 4-letter
+    alphabets) run as conv kernel + head kernel on MFMA: scores vs the oracle and vs the shape-agnostic kernels, the
+    mean-only (planes) form, and a bad character."""
+    natives, ws = zip(*[make_native(eng, "cnn", L, 4, H, F, K, seed=900 + m) for m in range(M)])
+    lut = _native.make_lut("TGCA")
+    b, _ = rand_seqs(n, L, "TGCA", seed=L * 7 + K + H)
+    got, mean = eng.score(list(natives), b, lut, want_matrix=True, want_mean=True)
+    k = min(n, 300)
+    for m in range(M):
+        assert_scores(got[:k, m], c_oracle.forward("cnn", lut[b[:k]], 4, ws[m]), f"L={L} F={F} H={H} K={K}")
+    assert np.array_equal(mean, np.mean(got, axis=1))
+    _, mean_only = eng.score(list(natives), b, lut, want_matrix=False, want_mean=True)
+    assert np.array_equal(mean_only, mean)
+    try:
+        eng.set_option("force_generic", 1)
+        ref, _ = eng.score(list(natives), b, lut)
+    finally:
+        eng.set_option("force_generic", 0)
+    assert np.allclose(got, ref, rtol=2e-5, atol=2e-6)
+    bad = b.copy(); bad[n // 2, L // 2] = ord("N")
+    with pytest.raises(ValueError):
+        eng.score(list(natives), bad, lut)

@@ -276,6 +276,8 @@ def main():
         time_score("cnn", 14, "UGCA", 100, 3, 100_000, 32, 3, label="cnn L=14 kernel_size=3 M=3 N=1e5")
         time_score("cnn", 14, "UGCA", 100, 3, 100_000, 32, 7, label="cnn L=14 kernel_size=7 M=3 N=1e5")
         time_score("cnn", 14, "UGCA", 100, 3, 100_000, 24, 5, label="cnn L=14 num_filters=24 M=3 N=1e5")
+        time_score("cnn", 14, "UGCA", 50, 3, 100_000, 32, 3, label="cnn L=14 kernel_size=3 hidden=50 M=3 N=1e5 (conv + head kernels)")
+        time_score("cnn", 14, "UGCA", 200, 3, 100_000, 32, 4, label="cnn L=14 kernel_size=4 hidden=200 M=3 N=1e5 (conv + head kernels)")
         time_score("cnn", 237, AAS, 100, 1, 16_384, 32, 5, reps=2, label="C5 cnn L=237 A=20 M=1 N=16384")
         time_score("cnn", 237, AAS, 100, 3, 16_384, 32, 5, reps=1, label="C5 cnn L=237 A=20 M=3 N=16384")
     if "sweep" in which:
