@@ -154,6 +154,7 @@ int fx_launch_score_generic(fx_engine* e, fx_model* const* models, int M, const 
 // returns FX_EUNSUPPORTED if no MFMA instantiation matches (caller falls back to generic)
 int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii,
                              int64_t N, float* d_out_NM, int Mtot, int m_off);
+int fx_launch_cnn_pair_conv(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N, void* d_pool);
 int fx_launch_score_cnn_split(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii,
                               int64_t N, float* d_out_NM, int Mtot, int m_off);
 int fx_launch_score_cnn_pair(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii,

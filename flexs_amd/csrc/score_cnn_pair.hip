@@ -64,8 +64,11 @@ __device__ __forceinline__ float pair_dense_head(const f4* w_d1, const f4* w_d2,
     return y[0];
 }
 
-template <int A, int K, int HT, int WAVES, bool SEG>
+// HEAD = false (whole-sequence form only): the conv part only -- each wave leaves its half of the tile's pooled features
+// in `pool` ([unit][2 tiles][64 lanes] f4, the layout of score_cnn_split.hip) and k_cnn_head finishes the sequence.
+template <int A, int K, int HT, int WAVES, bool SEG, bool HEAD = true>
 __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
+    static_assert(HEAD || !SEG, "the conv-only form is the whole-sequence form");
     constexpr int FT = 2, K3 = A - 1, PAIRS = WAVES / 2;
     constexpr int PL2 = (K - 1) / 2, PR2 = K - 1 - PL2;
     constexpr int PL3 = (K3 - 1) / 2, PR3 = K3 - 1 - PL3;
@@ -242,7 +245,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
                 accw[K3 - 1] = bias3;
             }
 
-            if (!SEG) {
+            if constexpr (!HEAD) {
+                if (live) reinterpret_cast<f4*>(p.pool)[(((int64_t)m * p.TG + tg) * 2 + mo) * 64 + lane] = gmax;
+            } else if (!SEG) {
                 // ---- pooled features: swap halves once more, then wave 0 of the pair runs the dense head
                 f4* pslot = xbuf + ((2 * PAIRS + pair) * 2) * 64;  // dedicated slot: no reuse hazard with the step slots
                 pslot[mo * 64 + lane] = gmax;
@@ -320,7 +325,53 @@ int launch_pair(fx_engine* e, PairArgs a, size_t lds_bytes) {
     return FX_OK;
 }
 
+template <int K>
+int launch_pair_conv(fx_engine* e, const PairArgs& a, size_t lds_bytes) {
+    constexpr int WAVES = 8;
+    auto kern = k_score_cnn_pair<20, K, 1, WAVES, false, false>;
+    static bool attr_set[64] = {};
+    if (!attr_set[e->device & 63]) {
+        FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[e->device & 63] = true;
+    }
+    const int64_t U = (int64_t)a.M * a.TG;
+    int64_t blocks = e->grid_blocks > 0 ? e->grid_blocks : e->num_cus;
+    if (blocks > U) blocks = U;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), lds_bytes, e->stream, a);
+    FX_HIP(e, hipGetLastError());
+    return FX_OK;
+}
+
 }  // namespace
+
+// Conv part only of a 20-letter CNN (kernel_size 2..7, two channel tiles): pooled features to `d_pool`
+// ([member * TG + tile][2][64 lanes] f4); score_cnn_split.hip runs the head kernel on them.
+int fx_launch_cnn_pair_conv(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N, void* d_pool) {
+    const FxShape& s = models[0]->shape;
+    const FxPackLayout& lay = models[0]->layout;
+    if (lay.FT != 2 || s.A != 20 || M > FX_MAX_M || s.K < 2 || s.K > 7) return FX_EUNSUPPORTED;
+    constexpr int WAVES = 8;
+    const size_t lds = (size_t)(lay.conv_floats - lay.off_c2) * 4 + (size_t)3 * (WAVES / 2) * 2 * 64 * 16 + 256 + 16;
+    if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
+    PairArgs a{};
+    a.ascii = d_ascii; a.lut = e->d_lut; a.out = nullptr; a.err = e->d_err;
+    for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
+    a.N = N; a.TG = (N + 15) / 16; a.M = M; a.Mtot = M; a.m_off = 0; a.L = s.L; a.rlh = 4;
+    a.off_c2 = (int)lay.off_c2; a.off_c3 = (int)lay.off_c3; a.off_cb = (int)lay.off_cb; a.off_w1p = (int)lay.off_w1p;
+    a.conv_floats = (int)lay.conv_floats; a.lds_from = (int)lay.off_c2; a.lds_floats = (int)(lay.conv_floats - lay.off_c2);
+    a.off_d1 = (int)lay.off_d1; a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db;
+    a.pool = (unsigned*)d_pool;
+    switch (s.K) {
+        case 2: return launch_pair_conv<2>(e, a, lds);
+        case 3: return launch_pair_conv<3>(e, a, lds);
+        case 4: return launch_pair_conv<4>(e, a, lds);
+        case 5: return launch_pair_conv<5>(e, a, lds);
+        case 6: return launch_pair_conv<6>(e, a, lds);
+        case 7: return launch_pair_conv<7>(e, a, lds);
+        default: return FX_EUNSUPPORTED;
+    }
+}
 
 int fx_launch_score_cnn_pair(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N,
                              float* d_out_NM, int Mtot, int m_off) {

@@ -1,5 +1,6 @@
-// Two-kernel CNN path for the shapes without a fused instantiation (4-letter alphabets; kernel_size 2..7,
-// num_filters <= 32, any hidden width up to 256 -- cnn.py:10-21 leaves all of them to the caller).
+// Two-kernel CNN path for the shapes without a fused instantiation (kernel_size 2..7, any hidden width up to 256;
+// num_filters <= 32 for 4-letter alphabets, 17..32 for the protein alphabet -- cnn.py:10-21 leaves all of them to the
+// caller).
 //
 // The fused kernel is a template over (alphabet, kernel size, channel tiles, hidden tiles, ...): covering every
 // combination multiplies instantiations.  Here the two halves meet in HBM instead: the conv part
@@ -133,14 +134,27 @@ int fx_launch_score_cnn_split(fx_engine* e, fx_model* const* models, int M, cons
         const FxShape& t = models[m]->shape;
         if (t.kind != FX_CNN || t.L != s.L || t.A != s.A || t.F != s.F || t.H != s.H || t.K != s.K) return FX_EUNSUPPORTED;
     }
-    if (s.A != 4 || lay.FT < 1 || lay.FT > 2 || s.K < 2 || s.K > 7 || s.H > 256 || M > FX_MAX_M || e->cnn_conv1_mfma)
+    if ((s.A != 4 && s.A != 20) || lay.FT < 1 || lay.FT > 2 || s.K < 2 || s.K > 7 || s.H > 256 || M > FX_MAX_M ||
+        e->cnn_conv1_mfma || (s.A == 20 && (lay.FT != 2 || !e->cnn_pair)))
         return FX_EUNSUPPORTED;
     const size_t conv_lds = (size_t)lay.conv_floats * 4 + 256 + 16;
-    if (conv_lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
+    if (s.A == 4 && conv_lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
     const int64_t TG = (N + 15) / 16;
     void* pool = nullptr;
     int rc = fx_scratch(e, 2, (size_t)M * (size_t)TG * lay.FT * 64 * sizeof(f4), &pool);
     if (rc) return rc;
+    if (s.A == 20) {
+        // protein alphabet: the conv part is the two-waves-per-tile kernel (score_cnn_pair.hip), same pool layout
+        if ((rc = fx_launch_cnn_pair_conv(e, models, M, d_ascii, N, pool))) return rc;
+        HeadArgs hp{};
+        hp.pool = (const f4*)pool; hp.out = d_out_NM; hp.N = N; hp.TG = TG; hp.M = M; hp.m_off = m_off;
+        for (int m = 0; m < M; ++m) hp.w[m] = models[m]->d_packed;
+        hp.out_sn = e->planar_stride ? 1 : Mtot; hp.out_sm = e->planar_stride ? e->planar_stride : 1;
+        hp.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4;
+        hp.off_d1 = (int)lay.off_d1; hp.off_d2 = (int)lay.off_d2; hp.off_db = (int)lay.off_db;
+        hp.head_floats = (int)(lay.total_floats - lay.off_d1);
+        return dispatch_head<2>(e, hp, lay.HT);
+    }
 
     CnnArgs a{};
     a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;

@@ -1173,3 +1173,26 @@ def test_cnn_split_conv_and_head_path(eng, L, F, H, K, n, M):
     bad = b.copy(); bad[n // 2, L // 2] = ord("N")
     with pytest.raises(ValueError):
         eng.score(list(natives), bad, lut)
+
+
+@pytest.mark.parametrize("L,F,H,K,n,M", [(30, 32, 100, 3, 200, 2), (60, 32, 50, 7, 64, 1), (25, 24, 200, 4, 100, 1), (90, 32, 100, 6, 40, 3),
+                                         (237, 32, 64, 3, 17, 1), (8, 32, 256, 2, 33, 1)])
+def test_cnn_split_path_protein_alphabet(eng, L, F, H, K, n, M):
+    """The conv + head split with the two-waves-per-tile conv kernel (20-letter alphabet, kernel_size 2..7, any hidden
+    width): scores vs the oracle and vs the shape-agnostic kernels."""
+    natives, ws = zip(*[make_native(eng, "cnn", L, 20, H, F, K, seed=950 + m) for m in range(M)])
+    lut = _native.make_lut(s_utils.AAS)
+    b, _ = rand_seqs(n, L, s_utils.AAS, seed=L + K + H)
+    got, mean = eng.score(list(natives), b, lut, want_matrix=True, want_mean=True)
+    for m in range(M):
+        assert_scores(got[:, m], c_oracle.forward("cnn", lut[b], 20, ws[m]), f"protein L={L} F={F} H={H} K={K}")
+    assert np.array_equal(mean, np.mean(got, axis=1))
+    try:
+        eng.set_option("force_generic", 1)
+        ref, _ = eng.score(list(natives), b, lut)
+    finally:
+        eng.set_option("force_generic", 0)
+    assert np.allclose(got, ref, rtol=2e-5, atol=2e-6)
+    bad = b.copy(); bad[n // 2, L - 1] = ord("B")
+    with pytest.raises(ValueError):
+        eng.score(list(natives), bad, lut)
