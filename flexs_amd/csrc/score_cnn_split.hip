@@ -1,5 +1,5 @@
 // Two-kernel CNN path for the shapes without a fused instantiation (kernel_size 2..7, any hidden width up to 256;
-// num_filters <= 32 for 4-letter alphabets, 17..32 for the protein alphabet -- cnn.py:10-21 leaves all of them to the
+// num_filters <= 64 for 4-letter alphabets (kernel_size <= 5 beyond 32 filters), 17..32 for the protein alphabet -- cnn.py:10-21 leaves all of them to the
 // caller).
 //
 // The fused kernel is a template over (alphabet, kernel size, channel tiles, hidden tiles, ...): covering every
@@ -117,8 +117,22 @@ int dispatch_conv(fx_engine* e, const CnnArgs& a, size_t lds, int K) {
         case 3: return launch_conv<3, FT>(e, a, lds);
         case 4: return launch_conv<4, FT>(e, a, lds);
         case 5: return launch_conv<5, FT>(e, a, lds);
-        case 6: return launch_conv<6, FT>(e, a, lds);
-        case 7: return launch_conv<7, FT>(e, a, lds);
+        default: break;
+    }
+    if constexpr (FT <= 2) {                 // (3-4 channel tiles: the 6- and 7-tap windows do not fit the register file)
+        if (K == 6) return launch_conv<6, FT>(e, a, lds);
+        if (K == 7) return launch_conv<7, FT>(e, a, lds);
+    }
+    return FX_EUNSUPPORTED;
+}
+
+template <typename Args, typename Fn1, typename Fn2, typename Fn3, typename Fn4>
+int by_channel_tiles(int FT, Fn1 f1, Fn2 f2, Fn3 f3, Fn4 f4_) {
+    switch (FT) {
+        case 1: return f1();
+        case 2: return f2();
+        case 3: return f3();
+        case 4: return f4_();
         default: return FX_EUNSUPPORTED;
     }
 }
@@ -134,7 +148,7 @@ int fx_launch_score_cnn_split(fx_engine* e, fx_model* const* models, int M, cons
         const FxShape& t = models[m]->shape;
         if (t.kind != FX_CNN || t.L != s.L || t.A != s.A || t.F != s.F || t.H != s.H || t.K != s.K) return FX_EUNSUPPORTED;
     }
-    if ((s.A != 4 && s.A != 20) || lay.FT < 1 || lay.FT > 2 || s.K < 2 || s.K > 7 || s.H > 256 || M > FX_MAX_M ||
+    if ((s.A != 4 && s.A != 20) || lay.FT < 1 || lay.FT > 4 || s.K < 2 || s.K > 7 || s.H > 256 || M > FX_MAX_M ||
         e->cnn_conv1_mfma || (s.A == 20 && (lay.FT != 2 || !e->cnn_pair)))
         return FX_EUNSUPPORTED;
     const size_t conv_lds = (size_t)lay.conv_floats * 4 + 256 + 16;
@@ -165,7 +179,8 @@ int fx_launch_score_cnn_split(fx_engine* e, fx_model* const* models, int M, cons
     a.off_cb = (int)lay.off_cb; a.off_w1p = (int)lay.off_w1p; a.conv_floats = (int)lay.conv_floats; a.off_d1 = (int)lay.off_d1;
     a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
     a.pool_out = (f4*)pool;
-    rc = lay.FT == 1 ? dispatch_conv<1>(e, a, conv_lds, s.K) : dispatch_conv<2>(e, a, conv_lds, s.K);
+    rc = by_channel_tiles<CnnArgs>(lay.FT, [&] { return dispatch_conv<1>(e, a, conv_lds, s.K); }, [&] { return dispatch_conv<2>(e, a, conv_lds, s.K); },
+                                   [&] { return dispatch_conv<3>(e, a, conv_lds, s.K); }, [&] { return dispatch_conv<4>(e, a, conv_lds, s.K); });
     if (rc) return rc;
 
     HeadArgs h{};
@@ -175,5 +190,6 @@ int fx_launch_score_cnn_split(fx_engine* e, fx_model* const* models, int M, cons
     h.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4;
     h.off_d1 = (int)lay.off_d1; h.off_d2 = (int)lay.off_d2; h.off_db = (int)lay.off_db;
     h.head_floats = (int)(lay.total_floats - lay.off_d1);
-    return lay.FT == 1 ? dispatch_head<1>(e, h, lay.HT) : dispatch_head<2>(e, h, lay.HT);
+    return by_channel_tiles<HeadArgs>(lay.FT, [&] { return dispatch_head<1>(e, h, lay.HT); }, [&] { return dispatch_head<2>(e, h, lay.HT); },
+                                      [&] { return dispatch_head<3>(e, h, lay.HT); }, [&] { return dispatch_head<4>(e, h, lay.HT); });
 }

@@ -1149,7 +1149,9 @@ def test_deepcopy_and_pickle_of_live_models(eng):
 
 @pytest.mark.parametrize("L,F,H,K,n,M", [(8, 32, 50, 3, 5000, 3), (14, 32, 128, 7, 3000, 2), (14, 32, 200, 3, 2000, 1), (20, 32, 256, 6, 500, 1),
                                          (9, 8, 20, 4, 300, 2), (8, 16, 64, 5, 70_000, 2), (30, 24, 100, 2, 100, 1), (12, 32, 100, 6, 33, 1),
-                                         (50, 32, 30, 3, 17, 1), (6, 1, 1, 2, 5, 1), (3, 32, 100, 3, 4, 1), (100, 12, 257 - 1, 4, 64, 1)])
+                                         (50, 32, 30, 3, 17, 1), (6, 1, 1, 2, 5, 1), (3, 32, 100, 3, 4, 1), (100, 12, 257 - 1, 4, 64, 1),
+                                         (8, 64, 100, 5, 20_000, 3), (14, 48, 100, 3, 1000, 2), (14, 64, 200, 4, 300, 1), (30, 40, 64, 2, 65, 1),
+                                         (8, 64, 100, 7, 50, 1)])
 def test_cnn_split_conv_and_head_path(eng, L, F, H, K, n, M):
     """CNN shapes without a fused instantiation (kernel_size 2..7 x any hidden width <= 256 x num_filters <= 32, 4-letter
     alphabets) run as conv kernel + head kernel on MFMA: scores vs the oracle and vs the shape-agnostic kernels, the
