@@ -87,8 +87,10 @@ def make_report(world, N, steps, warmup, elapsed, host_issue_s, kern_ms, use_dis
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    # defaults: 100 + 1000 launches of ~0.19 ms -- long enough for the clocks to settle (the first ~50 launches of a
+    # cold process run ~10 % slower: profiles/r1_run22 trace), still a fraction of a second
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nam", action="store_true",
                     help="cpu_baseline additionally times the NoisyAbstractModel CPU path (adds ~20 s)")

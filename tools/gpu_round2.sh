@@ -14,11 +14,11 @@ for v in 1 4 5; do
   timeout 200 python bench.py --steps 100 --warmup 10 --variant $v --no-cpu-baseline > $OUT/bench_v$v.log 2>&1
   echo "exit $?" >> $OUT/bench_v$v.log
 done
-timeout 400 python bench.py --steps 200 --warmup 20 > $OUT/bench.log 2>&1
+timeout 400 python bench.py > $OUT/bench.log 2>&1
 echo "exit $?" >> $OUT/bench.log
 
 rm -rf $OUT/prof $OUT/pmc*
-timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof -o r1 -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/rocprof.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof -o r1 -- python bench.py --no-cpu-baseline > $OUT/rocprof.log 2>&1
 # PMC: one counter group per run, --pmc only (no trace domains)
 
 
@@ -32,5 +32,5 @@ timeout 900 python tools/perf_survey.py > $OUT/perf_survey.log 2>&1
 echo "exit $?" >> $OUT/perf_survey.log
 tail -2 $OUT/pytest_gpu.log; tail -2 $OUT/bench.log | cut -c1-400
 # the N>1 code path (RCCL init + all-gather + max-over-ranks) on one rank
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 50 --warmup 5 --force-dist --reserve-cus 4 --no-cpu-baseline > $OUT/bench_dist1.log 2>&1
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --force-dist --reserve-cus 4 --no-cpu-baseline > $OUT/bench_dist1.log 2>&1
 echo "exit $?" >> $OUT/bench_dist1.log
