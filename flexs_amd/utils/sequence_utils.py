@@ -75,14 +75,12 @@ def construct_mutant_from_sample(pwm_sample: np.ndarray, one_hot_base: np.ndarra
 
 
 def generate_single_mutants(wt: str, alphabet: str) -> List[str]:
-    """Wild type followed by every single substitution, position-major (sequence_utils.py:69-77;
-    like the reference, the running template keeps the LAST substitution of earlier positions)."""
+    """Wild type followed by every single substitution, position-major (sequence_utils.py:69-77): len(wt) *
+    len(alphabet) variants, the identity substitution included, every variant one edit away from `wt`."""
     sequences = [wt]
-    template = list(wt)
     for i in range(len(wt)):
-        for ch in alphabet:
-            template[i] = ch
-            sequences.append("".join(template))
+        head, tail = wt[:i], wt[i + 1:]
+        sequences.extend(head + ch + tail for ch in alphabet)
     return sequences
 
 

@@ -329,3 +329,24 @@ def test_models_copy_and_pickle_without_device_handles():
     nam._dev_cache, nam._dev_keys = object(), ["ACGT"]
     st = nam.__getstate__()
     assert st["_dev_cache"] is None and st["_dev_keys"] == [] and st["cache"] == {"ACGT": 1.0}
+
+
+def test_sequence_generators_match_reference(golden_dir):
+    """generate_single_mutants / generate_random_sequences / generate_random_mutant / construct_mutant_from_sample
+    against outputs of the reference's own functions under fixed `random` seeds (same values, same RNG position)."""
+    import random
+
+    g = json.load(open(os.path.join(golden_dir, "sequence_generators.json")))
+    for c in g["single_mutants"]:
+        assert s_utils.generate_single_mutants(c["wt"], c["alphabet"]) == c["out"]
+    for c in g["random_sequences"]:
+        random.seed(c["seed"])
+        assert s_utils.generate_random_sequences(c["length"], c["number"], c["alphabet"]) == c["out"]
+        assert random.random() == c["next_random"]
+    for c in g["random_mutant"]:
+        random.seed(c["seed"])
+        assert [s_utils.generate_random_mutant(c["sequence"], c["mu"], c["alphabet"]) for _ in range(4)] == c["out"]
+        assert random.random() == c["next_random"]
+    for c in g["construct_mutant"]:
+        out = s_utils.construct_mutant_from_sample(np.array(c["sample"]), np.array(c["base"]))
+        assert out.tolist() == c["out"] and str(out.dtype) == c["dtype"]
