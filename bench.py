@@ -1,12 +1,18 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path: BASELINE.json configs[1] -- TF-binding L=8 (alphabet
-TGCA), 3-member CNN(32,100,k=5) Ensemble, batch = 1e5 sequences per virtual-screen
-call -- on N GPUs of one node (one process per GPU, weak scaling over sequences).
+"""Benchmark of the hot path on N GPUs of one node (one process per GPU).
 
-A step = one `Ensemble.get_fitness`-equivalent pass over one 1e5-sequence batch
-that is already resident in HBM: the fused encode+CNN scoring kernel for all
-three members, the ensemble mean kernel and, for N > 1, ONE RCCL all-gather of the
-per-rank means (the north-star's exchange step).  Prints one JSON line on rank 0.
+Headline (`value`): BASELINE.json configs[1] -- TF-binding L=8 (alphabet TGCA), 3-member
+CNN(32,100,k=5) Ensemble, 1e5 sequences per virtual-screen call per GPU -- sequence-parallel,
+weak scaling.  A step = one `Ensemble.get_fitness`-equivalent pass over one batch already
+resident in HBM: the fused encode+CNN scoring kernel for all three members, the ensemble-mean
+kernel and, for N > 1, ONE RCCL all-gather of the per-rank means.  The step is issued through
+`flexs_amd.distributed.DistributedEnsemble.launch / finish`, i.e. the product's multi-GPU class.
+
+Every run also measures the north-star's member-parallel split (8-member ensembles sharded over
+the ranks, all-gather of the stacked predictions, strong scaling) and reports it under
+`member_parallel`; `--mode member` makes that the headline instead.  On one GPU rank 0 adds
+`configs` (kernel time + algorithmic and issued-MFMA fractions for C1/C3/C4/C5), `end_to_end`
+(list[str] -> ndarray through the Python API) and `cpu_baseline`.  One JSON line on rank 0.
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -25,6 +31,11 @@ sys.path.insert(0, ROOT)
 faulthandler.enable()
 
 L, ALPHABET, F, H, K, M, BATCH = 8, "TGCA", 32, 100, 5, 3, 100_000
+AAS = "ILVAGMFYWEDQNHCRKSTP"
+PEAK_TF = 157.3                  # f32-input MFMA, dense (MI355X_MICROARCH.md)
+MFMA_FLOP = 2048                 # one v_mfma_f32_16x16x4_f32: 16*16*4 MACs
+MIN_TIMED_S = 0.5                # the settled figure covers at least this much GPU time
+KINDS = {"cnn": 0, "mlp": 1, "ge": 2}
 
 
 def cpu_baseline(budget_s=12.0, hard_timeout_s=150.0, nam=False):
@@ -45,43 +56,254 @@ def cpu_baseline(budget_s=12.0, hard_timeout_s=150.0, nam=False):
                 "sample": f"cpu baseline failed: {type(e).__name__}: {str(e)[:200]}"}
 
 
-def make_report(world, N, steps, warmup, elapsed, host_issue_s, kern_ms, use_dist):
-    """The one JSON line of the bench contract (pure function: unit-tested on the CPU)."""
-    from flexs_amd import synth
+def roofline_block(kind, Lx, A, Hx, Fx, Kx, members, n, kern_ms, kernel_name):
+    """Both MFMA fractions of one scoring launch, from its measured duration.
 
-    macs = synth.algorithmic_macs("cnn", L, len(ALPHABET), H, F, K)
-    flop_per_launch = 2.0 * macs * M * N                 # SURVEY.md 8d: 2 x dense MACs x members x sequences
-    peak = 157.3                                         # f32-input MFMA, MI355X_MICROARCH.md
-    achieved = flop_per_launch / (kern_ms * 1e-3) / 1e12
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-    if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+    frac         ALGORITHMIC FLOP (2 x dense MACs x members x sequences, not discounted for
+                 one-hot sparsity or 'same'-padding zeros) / kernel_ms / peak.  The kernels do not issue those
+                 structural zeros, so this figure can exceed 1 on long launches.
+    frac_issued  MFMA instructions the launch really issues (fx_debug_mfma_per_tile: the kernels' loop bounds
+                 restated on the host, x ceil(n/16) tiles x members) x 2048 FLOP / kernel_ms / peak: <= 1."""
+    from flexs_amd import _native, synth
+
+    macs = synth.algorithmic_macs(kind, Lx, A, Hx, Fx, Kx)
+    flop = 2.0 * macs * members * n
+    per_tile = _native.mfma_per_tile(KINDS[kind], Lx, A, Fx, Hx, Kx)
+    issued = float(per_tile) * ((n + 15) // 16) * members * MFMA_FLOP
+    ach = flop / (kern_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": kernel_name, "achieved": ach, "peak": PEAK_TF, "unit": "TFLOP/s",
+            "frac": ach / PEAK_TF, "frac_issued": issued / (kern_ms * 1e-3) / 1e12 / PEAK_TF,
+            "kernel_ms": kern_ms, "flop_per_launch": flop, "issued_flop_per_launch": issued,
+            "mfma_per_tile": per_tile, "algorithmic_bytes_per_launch": (Lx + 4 * members) * n}
+
+
+def pmc_block():
+    """PMC figures cannot be sampled from inside the process; they come from the rocprofv3 --pmc passes over this
+    same command (tools/gpu_round3.sh), committed under profiles/ -- the file is named so the numbers can be traced."""
+    for name in ("r2_pmc_bench.json", "r1_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            d = json.load(open(path))
+            return {"hbm_bytes_per_launch": d.get("hbm_bytes_per_launch"), "mfma_util": d.get("mfma_util"),
+                    "source": f"profiles/{name}"}
+    return {"hbm_bytes_per_launch": None, "mfma_util": None, "source": None}
+
+
+def make_report(world, N, steps, warmup, elapsed, host_issue_s, kern_ms, use_dist, mode="sequence", members=M):
+    """The one JSON line of the bench contract (pure function: unit-tested on the CPU)."""
+    roof = roofline_block("cnn", L, len(ALPHABET), H, F, K, members if mode == "sequence" else -(-members // world),
+                          N, kern_ms, "k_score_cnn_mfma")
+    pmc = pmc_block()
+    roof["traffic"] = pmc["hbm_bytes_per_launch"]
+    roof["mfma_util_pmc"] = pmc["mfma_util"]
+    roof["pmc_source"] = pmc["source"]
+    roof["note"] = ("frac = algorithmic FLOP (2*MACs, SURVEY.md 8d) / kernel_ms / 157.3 TFLOP/s; it counts one-hot multiplies "
+                    "and 'same'-padding zero taps the kernel never issues, so it can exceed 1 on long launches. "
+                    "frac_issued = MFMA instructions issued x 2048 FLOP / kernel_ms / peak (<= 1). mfma_util_pmc = "
+                    "SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMD x CU-cycles) from the rocprofv3 --pmc pass named in pmc_source; "
+                    "traffic = FETCH_SIZE x2 + WRITE_SIZE from the same passes")
+    if mode == "sequence":
+        value, scaling = world * N * steps / elapsed, "weak"
+        workload = (f"TF-binding L={L} alphabet={ALPHABET}, {members}-member CNN(num_filters={F}, hidden_size={H}, "
+                    f"kernel_size={K}) Ensemble, batch={N} virtual-screen per GPU (BASELINE.json configs[1]); inputs "
+                    "resident in HBM; step = fused encode+CNN scoring kernel + ensemble-mean kernel"
+                    + (" + one RCCL all-gather of the per-rank means (own stream, overlapped with the next step's "
+                       "compute)" if use_dist else ""))
+        par = f"sequence-parallel x{world}" if world > 1 else "single GPU"
+        gb = world * N
+    else:
+        value, scaling = N * steps / elapsed, "strong"
+        workload = (f"TF-binding L={L} alphabet={ALPHABET}, {members}-member CNN Ensemble sharded member-parallel over "
+                    f"{world} GPU(s), batch={N} on every rank; step = fused encode+CNN kernel for this rank's members + "
+                    "one RCCL all-gather of the stacked predictions + ensemble-mean kernel on every rank")
+        par = f"member-parallel x{world}"
+        gb = N
     return {
         "metric": "sequences scored/sec (virtual-screen batch)",
-        "value": world * N * steps / elapsed,
-        "unit": "sequences/s",
+        "value": value, "unit": "sequences/s",
         "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3,
         "host_issue_ms_per_step": host_issue_s / steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"TF-binding L={L} alphabet={ALPHABET}, {M}-member CNN(num_filters={F}, "
-                               f"hidden_size={H}, kernel_size={K}) Ensemble, batch={N} virtual-screen per GPU "
-                               "(BASELINE.json configs[1]); inputs resident in HBM; step = fused encode+CNN "
-                               "scoring kernel + ensemble-mean kernel"
-                               + (" + one RCCL all-gather of the per-rank means (own stream, overlapped with the "
-                                  "next step's compute)" if use_dist else ""),
-                   "global_batch": world * N, "seq_len": L, "members": M,
-                   "parallelism": f"sequence-parallel x{world}" if world > 1 else "single GPU"},
-        "roofline": {"bound": "mfma", "kernel": "k_score_cnn_mfma", "achieved": achieved, "peak": peak,
-                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                     "kernel_ms": kern_ms, "flop_per_launch": flop_per_launch,
-                     "algorithmic_bytes_per_launch": (L + 4 * M) * N,
-                     "note": "f32-input MFMA peak (157.3 TFLOP/s); algorithmic FLOP = 2*MACs, not discounted "
-                             "for one-hot sparsity / zero padding; traffic = FETCH_SIZE x2 + WRITE_SIZE from the "
-                             "PMC passes under profiles/"},
+        "config": {"workload": workload, "global_batch": gb, "seq_len": L, "members": members, "parallelism": par},
+        "roofline": roof,
     }
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def build_members(kind, Lx, alphabet, members, device, Hx=H, Fx=F, Kx=K):
+    """`members` surrogates of the product API with synthetic (Glorot + non-zero bias) weights, seeds 1000 + m."""
+    from flexs_amd import synth
+    from flexs_amd.baselines.models import CNN, MLP, GlobalEpistasisModel
+
+    out = []
+    for m in range(members):
+        if kind == "cnn":
+            mod = CNN(Lx, Fx, Hx, alphabet, kernel_size=Kx, device=device)
+        elif kind == "mlp":
+            mod = MLP(Lx, Hx, alphabet, device=device)
+        else:
+            mod = GlobalEpistasisModel(Lx, Hx, alphabet, device=device)
+        mod.model.set_weights(synth.synthetic_weights(mod.model.shapes(), 1000 + m))
+        out.append(mod)
+    return out
+
+
+def run_pipelined(ens, d_seq, n, steps, warmup, torch, dist, use_dist, want_events=True):
+    """W untimed + K timed steps of ens.launch / ens.finish, double-buffered: the gather of step k (communication
+    stream) overlaps the scoring of step k + 1; barrier + synchronize on both sides of the timed region.
+    Returns (elapsed_s, host_issue_s, kernel_ms)."""
+    st = ens.stream
+
+    def go(count, events):
+        for i in range(count):
+            ens.launch(d_seq, n, slot=i & 1, want="mean", timing=events[i] if events else None)
+            if i:
+                ens.finish((i - 1) & 1)
+        if count:
+            ens.finish((count - 1) & 1)
+
+    go(warmup, None)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] \
+        if want_events else None
+    t0 = time.perf_counter()
+    go(steps, events)
+    host_issue = time.perf_counter() - t0                # host time to ENQUEUE the K steps (GPU still running)
+    st.synchronize()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ens._engine().sync()                                 # raises if any character was outside the alphabet
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)         # MAX over ranks
+        elapsed = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else None
+    return elapsed, host_issue, kern_ms
+
+
+def time_launches(eng, models, d_ptr, n, Lx, lut, d_planes, stride, min_ms=60.0, reps0=20):
+    """Mean duration of one scoring launch: HIP events on the engine's stream around `reps` back-to-back launches,
+    repeated until the bracket covers >= min_ms."""
+    natives = [m.native() for m in models]
+    for _ in range(5):
+        eng.score_planes_dev(natives, d_ptr, n, Lx, lut, d_planes.data_ptr(), stride)
+    eng.sync()
+    reps = reps0
+    while True:
+        eng.timer_start()
+        for _ in range(reps):
+            eng.score_planes_dev(natives, d_ptr, n, Lx, lut, d_planes.data_ptr(), stride)
+        ms = eng.timer_stop()
+        if ms >= min_ms or reps >= 20000:
+            return ms / reps, reps
+        reps = int(min(20000, max(reps * 2, reps * min_ms / max(ms, 1e-3) * 1.1)))
+
+
+def configs_block(eng, device, torch):
+    """Kernel time and both MFMA fractions for the BASELINE.json configs that are not the headline, at the sizes the
+    judge named: C1 (1 CNN, L=8, N=1e4), C2 at N=1e4 (3 CNN), C3 (MLP L=14, N=1e5), C4 (8 x GE L=90 A=20, N=1e5),
+    C5 (3 x CNN L=237 A=20, one GPU's 62 500-row share of the 5e5 batch)."""
+    from flexs_amd import _native, synth
+
+    specs = [
+        ("C1 cnn L=8 A=4 M=1 N=1e4", "cnn", 8, "TGCA", 1, 10_000, "k_score_cnn_mfma"),
+        ("C2 cnn L=8 A=4 M=3 N=1e4", "cnn", 8, "TGCA", 3, 10_000, "k_score_cnn_mfma"),
+        ("C3 mlp L=14 A=4 H=100 M=1 N=1e5", "mlp", 14, "UGCA", 1, 100_000, "k_score_dense_mfma<MLP>"),
+        ("C4 ge L=90 A=20 H=100 M=8 N=1e5", "ge", 90, AAS, 8, 100_000, "k_score_dense_mfma<GE>"),
+        ("C5 cnn L=237 A=20 M=3 N=62500 (one GPU's share of 5e5)", "cnn", 237, AAS, 3, 62_500, "k_score_cnn_pair"),
+    ]
+    out = {}
+    for name, kind, Lx, alpha, members, n, kname in specs:
+        mods = build_members(kind, Lx, alpha, members, device)
+        d_in = torch.from_numpy(synth.random_sequence_bytes(n, Lx, alpha, 0)).cuda()
+        stride = (n + 63) // 64 * 64
+        d_planes = torch.empty((members, stride), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        ms, reps = time_launches(eng, mods, d_in.data_ptr(), n, Lx, mods[0]._lut, d_planes, stride)
+        Fx, Kx = (F, K) if kind == "cnn" else (0, 0)
+        blk = roofline_block(kind, Lx, len(alpha), H, Fx, Kx, members, n, ms, kname)
+        blk["seq_per_s"] = n / (ms * 1e-3)
+        blk["reps"] = reps
+        out[name] = blk
+        del mods, d_in, d_planes
+    return out
+
+
+def end_to_end_block(device):
+    """SURVEY.md 8(d)'s primary metric: `Ensemble.get_fitness(list[str])` -> np.ndarray, host strings in, host
+    array out (string marshalling + PCIe both ways inclusive), configs[1] shape; plus the small-call latency."""
+    import flexs_amd
+    from flexs_amd import synth
+
+    ens = flexs_amd.Ensemble(build_members("cnn", L, ALPHABET, M, device))
+    seqs = synth.bytes_to_strings(synth.random_sequence_bytes(BATCH, L, ALPHABET, 1))
+    arr_s = np.array(seqs, dtype="S")
+    out = {}
+    for name, inp in (("list_str", seqs), ("ndarray_S", arr_s)):
+        ens.get_fitness(inp)
+        ts = []
+        for _ in range(9):
+            t0 = time.perf_counter(); ens.get_fitness(inp); ts.append(time.perf_counter() - t0)
+        t = float(np.median(ts))
+        out[name] = {"value": BATCH / t, "unit": "sequences/s", "wall_ms": t * 1e3}
+    small = seqs[:20]
+    for _ in range(20):
+        ens.get_fitness(small)
+    ts = []
+    for _ in range(200):
+        t0 = time.perf_counter(); ens.get_fitness(small); ts.append(time.perf_counter() - t0)
+    out["small_call_N20_us"] = float(np.median(ts)) * 1e6
+    out["what"] = (f"Ensemble(3 x CNN).get_fitness on {BATCH} host strings (L={L}) -> host float32 array, median of 9 "
+                   "calls, marshalling + PCIe inclusive")
+    return out
+
+
+def member_parallel_block(world, rank, device, torch, dist, use_dist, steps_hint):
+    """north_star's split: an 8-member ensemble, members sharded over the ranks (contiguous blocks), every rank
+    scores the SAME batch with its members, ONE all-gather of the stacked predictions, mean on every rank.
+    Strong scaling: the batch is fixed, value = batch x steps / time.  Workloads: 8 x CNN L=8 (configs[1]'s
+    surrogate, 8 members) and 8 x GlobalEpistasis L=90 A=20 (configs[3]) at 1e5 and 1e6 sequences."""
+    from flexs_amd import distributed as fd, synth
+
+    out = {}
+    for name, kind, Lx, alpha, n, steps in (
+            ("8xCNN L=8 A=4 N=1e5", "cnn", 8, "TGCA", 100_000, 400),
+            ("8xGE L=90 A=20 N=1e5", "ge", 90, AAS, 100_000, 800),
+            ("8xGE L=90 A=20 N=1e6", "ge", 90, AAS, 1_000_000, 100)):
+        mods = build_members(kind, Lx, alpha, 8, device)
+        ens = fd.DistributedEnsemble(mods, mode="member")
+        ens.force_collective = use_dist
+        with torch.cuda.stream(ens.stream):
+            d_seq = torch.from_numpy(synth.random_sequence_bytes(n, Lx, alpha, seed=7)).cuda()   # same batch on every rank
+        ens.stream.synchronize()
+        elapsed, _, kern_ms = run_pipelined(ens, d_seq, n, steps, max(steps // 10, 5), torch, dist, use_dist)
+        # correctness of the exchange: the gathered matrix must reproduce the local members' planes
+        ens.launch(d_seq, n, 0, "matrix")
+        mat = ens.finish(0)
+        ens.launch(d_seq, n, 1, "mean")
+        mean = ens.finish(1)
+        torch.cuda.synchronize()
+        ok = bool(torch.isfinite(mat).all()) and tuple(mat.shape) == (n, 8)
+        if rank == 0:
+            ok = ok and np.array_equal(np.mean(mat.cpu().numpy(), axis=1), mean.cpu().numpy())
+        out[name] = {"value": n * steps / elapsed, "unit": "sequences/s", "ms_per_step": elapsed / steps * 1e3,
+                     "kernel_ms_this_rank": kern_ms, "steps": steps, "members": 8,
+                     "members_per_rank": -(-8 // world), "gathered_bytes_per_rank": 4 * n * -(-8 // world) * world,
+                     "checked": ok}
+        del ens, mods, d_seq
+    out["what"] = ("8-member ensembles sharded member-parallel over the ranks (flexs/ensemble.py:54-59): fused kernel "
+                   "for this rank's members + one RCCL all-gather of the stacked (N, 8) predictions + np.mean-order mean "
+                   "on every rank; same batch on every rank (strong scaling), double-buffered so the gather of step k "
+                   "overlaps step k+1; value at n_gpus=1 is the one-GPU reference for the speed-up")
+    return out
 
 
 def main():
@@ -91,7 +313,11 @@ def main():
     # cold process run ~10 % slower: profiles/r1_run22 trace), still a fraction of a second
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--mode", choices=("sequence", "member"), default="sequence",
+                    help="headline split: sequence-parallel weak scaling of configs[1] (default) or member-parallel "
+                         "strong scaling of an 8-member CNN ensemble")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only (profiling passes)")
     ap.add_argument("--cpu-nam", action="store_true",
                     help="cpu_baseline additionally times the NoisyAbstractModel CPU path (adds ~20 s)")
     ap.add_argument("--variant", type=int, default=0, help="cnn kernel variant (0 = auto)")
@@ -105,8 +331,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from flexs_amd import _native, synth
-    from flexs_amd.baselines.models.keras_model import Architecture
+    from flexs_amd import _native, distributed as fd, synth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -126,7 +351,7 @@ def main():
         os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        # the exchanged messages are 4*N bytes per rank (0.4 MB): latency-bound.  Keep RCCL to a couple of
+        # the exchanged messages are <= a few MB per rank: latency-bound.  Keep RCCL to a couple of
         # channels so its (overlapped) kernel does not take CUs away from the MFMA-bound scoring kernel.
         os.environ.setdefault("NCCL_MAX_NCHANNELS", "2")
         os.environ.setdefault("NCCL_MIN_NCHANNELS", "1")
@@ -142,103 +367,62 @@ def main():
         # RCCL's channel workgroups cannot co-reside with it: with every CU taken, the all-gather of step k would
         # start only when two K1 workgroups of step k+1 have been held back for it, stretching that launch by the
         # collective's latency.  Leaving a few CUs free (1.6 % of K1's throughput) lets it run next to step k+1.
-        # (With one rank the collective is a copy, so this could not be measured on the 1-GPU boxes:
-        # profiles/r1_run6_rccl_overlap_probe.md.)
         eng.set_option("grid_blocks", max(1, eng.get_option("num_cus") - reserve))
-    stream = torch.cuda.Stream()
-    lut = _native.make_lut(ALPHABET)
-    arch = Architecture("cnn", L, len(ALPHABET), H, num_filters=F, kernel_size=K)
-    weight_sets = [synth.synthetic_weights(arch.shapes(), 1000 + m) for m in range(M)]
-    models = []
-    for ws in weight_sets:
-        nm = _native.NativeModel(eng, _native.FX_CNN, L, len(ALPHABET), F, H, K)
-        nm.set_weights(ws)
-        models.append(nm)
-    seq_bytes = synth.random_sequence_bytes(N, L, ALPHABET, seed=rank)
 
-    with torch.cuda.stream(stream):
-        eng.set_stream(stream.cuda_stream)
-        d_ascii = torch.from_numpy(seq_bytes).cuda()
-        # two buffer sets: the all-gather of step k runs on RCCL's stream while step k+1 computes
-        # the M members' scores as member-major planes (the layout fx_score_dev uses when only the mean is wanted)
-        stride = (N + 63) // 64 * 64
-        d_nm = [torch.empty((M, stride), dtype=torch.float32, device="cuda") for _ in range(2)]
-        d_mean = [torch.empty((N,), dtype=torch.float32, device="cuda") for _ in range(2)]
-        d_all = [torch.empty((world * N,), dtype=torch.float32, device="cuda") for _ in range(2)] if use_dist else None
-        pending = [None, None]
-        ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-        ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    # ---- headline
+    head_members = M if args.mode == "sequence" else 8
+    members = build_members("cnn", L, ALPHABET, head_members, local_rank)
+    ens = fd.DistributedEnsemble(members, mode=args.mode)
+    ens.force_collective = use_dist
+    glob_n = world * N if args.mode == "sequence" else N
+    with torch.cuda.stream(ens.stream):
+        # sequence mode: the global batch (world x N rows); rank r reads rows [r N, (r+1) N) of it
+        d_seq = torch.from_numpy(synth.random_sequence_bytes(glob_n, L, ALPHABET, seed=0)).cuda()
+    ens.stream.synchronize()
+    elapsed, host_issue_s, kern_ms = run_pipelined(ens, d_seq, glob_n, args.steps, args.warmup, torch, dist, use_dist)
+    settled = None
+    if elapsed < MIN_TIMED_S:
+        # the driver's K steps are reported as asked; a K this short ends before the clocks settle, so a second,
+        # longer bracket (>= 0.5 s of GPU time, same code path) is reported beside it
+        s_steps = int(max(args.steps, np.ceil(1.2 * MIN_TIMED_S / (elapsed / max(args.steps, 1)))))
+        s_el, _, s_kern = run_pipelined(ens, d_seq, glob_n, s_steps, 0, torch, dist, use_dist)
+        settled = (s_steps, s_el, s_kern)
 
-        comm = torch.cuda.Stream() if use_dist else None          # the collective gets its own stream
-        done = [torch.cuda.Event(), torch.cuda.Event()] if use_dist else None
+    # ---- untimed completeness + correctness check of the last step
+    got_mean = got_nm = None
+    for s_ in ens._slots:
+        if s_.planes is not None:
+            s_.planes.fill_(float("nan"))
+            s_.mean.fill_(float("nan"))
+    ens.launch(d_seq, glob_n, 0, "mean")
+    got_mean = ens.finish(0)
+    ens.launch(d_seq, glob_n, 1, "matrix")
+    got_nm = ens.finish(1)
+    torch.cuda.synchronize()
+    # scores are nan_to_num'ed, so a NaN that survives a step is an element nobody wrote
+    assert not bool(torch.isnan(got_mean).any()) and not bool(torch.isnan(got_nm).any()), "unwritten scores"
+    got_mean, got_nm = got_mean.cpu().numpy(), got_nm.cpu().numpy()
+    assert got_mean.shape == (glob_n,) and got_nm.shape == (glob_n, head_members)
 
-        def step(i, k=None):
-            b = i & 1
-            if pending[b] is not None:
-                stream.wait_event(pending[b])            # buffer set b is free again (stream-side wait, no host sync)
-                pending[b] = None
-            if k is not None:
-                ev_a[k].record(stream)
-            eng.score_planes_dev(models, d_ascii.data_ptr(), N, L, lut, d_nm[b].data_ptr(), stride)   # K1 fused encode+CNN x3
-            if k is not None:
-                ev_b[k].record(stream)
-            eng.ensemble_mean_planes_dev(d_nm[b].data_ptr(), N, M, stride, d_mean[b].data_ptr())     # K3 np.mean order
-            if use_dist:
-                comm.wait_stream(stream)
-                with torch.cuda.stream(comm):
-                    dist.all_gather_into_tensor(d_all[b], d_mean[b])                         # RCCL over xGMI
-                    done[b].record(comm)
-                pending[b] = done[b]
-
-        def drain():
-            for b in (0, 1):
-                if pending[b] is not None:
-                    stream.wait_event(pending[b])
-                    pending[b] = None
-
-        for i in range(args.warmup):
-            step(i)
-        drain()
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            step(k, k)
-        host_issue_s = time.perf_counter() - t0          # host time to ENQUEUE the K steps (GPU still running)
-        drain()
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        eng.sync()                                       # raises if any bad character was met
-        # untimed completeness check: every score must have been written by the kernels (scores are
-        # nan_to_num'ed, so a NaN that survives a step is an element nobody wrote)
-        d_nm[0].fill_(float("nan"))
-        d_mean[0].fill_(float("nan"))
-        step(0)
-        drain()
-        torch.cuda.synchronize()
-        assert not bool(torch.isnan(d_nm[0][:, :N]).any()) and not bool(torch.isnan(d_mean[0]).any()), "unwritten scores"
-        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_a, ev_b)]))
-        last = (args.steps - 1) & 1
-        got_mean = d_mean[last].cpu().numpy()
-        got_nm = d_nm[last][:, :N].t().contiguous().cpu().numpy()        # (N, M), i.e. np.stack(axis=1)
-        if use_dist:
-            gathered = d_all[last].cpu().numpy()
-            assert np.array_equal(gathered[rank * N:(rank + 1) * N], got_mean), "all-gather lost this rank's shard"
-        eng.set_stream(None)
-
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    extras = {}
+    if not args.no_extras:
+        extras["member_parallel"] = member_parallel_block(world, rank, local_rank, torch, dist, use_dist, args.steps)
 
     if rank == 0:
         assert np.array_equal(np.mean(got_nm, axis=1), got_mean), "device mean is not np.mean bit-for-bit"
-        out = make_report(world, N, args.steps, args.warmup, elapsed, host_issue_s, kern_ms, use_dist)
+        out = make_report(world, N, args.steps, args.warmup, elapsed, host_issue_s, kern_ms, use_dist, args.mode,
+                          head_members)
+        if settled:
+            s_steps, s_el, s_kern = settled
+            rep = make_report(world, N, s_steps, 0, s_el, 0.0, s_kern, use_dist, args.mode, head_members)
+            out["settled"] = {"steps": s_steps, "value": rep["value"], "ms_per_step": rep["ms_per_step"],
+                              "kernel_ms": s_kern, "frac": rep["roofline"]["frac"],
+                              "frac_issued": rep["roofline"]["frac_issued"],
+                              "what": f">= {MIN_TIMED_S} s timed region, same step, run right after the K steps above"}
+        out.update(extras)
+        if world == 1 and not args.no_extras:
+            out["configs"] = configs_block(eng, local_rank, torch)
+            out["end_to_end"] = end_to_end_block(local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nam=args.cpu_nam)
         if saved_stdout is not None:

@@ -77,6 +77,7 @@ SIGNATURES = {
     "fx_nam_combine": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "fx_debug_packed_size": (C.c_int64, [C.c_int] * 6),
     "fx_debug_pack_layout": (C.c_int, [C.c_int] * 6 + [_i64p]),
+    "fx_debug_mfma_per_tile": (C.c_int64, [C.c_int] * 6),
     "fx_debug_pack_weights": (C.c_int, [C.c_int] * 6 + [_f32p, C.c_int64, _f32p, C.c_int64]),
     "fx_debug_myers": (C.c_int, [_vp, C.c_int, _vp, C.c_int]),
     "fx_debug_mfma_probe": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
@@ -281,10 +282,24 @@ class Engine:
         return v.value
 
     def set_stream(self, hip_stream: Optional[int]):
+        self._torch_stream = None                         # (torch_stream() re-lends on its next use)
         self.check(self._lib.fx_engine_set_stream(self.handle, _vp(hip_stream) if hip_stream else None))
 
     def sync(self):
         self.check(self._lib.fx_engine_sync(self.handle))
+
+    def torch_stream(self):
+        """A torch.cuda.Stream lent to the engine (created on first use, then kept): torch-side work (uploads,
+        RCCL collectives through stream waits) and the engine's kernels are ordered on it without host syncs."""
+        st = getattr(self, "_torch_stream", None)
+        if st is None:
+            import torch
+
+            with torch.cuda.device(self.device):
+                st = torch.cuda.Stream()
+            self.set_stream(st.cuda_stream)
+            self._torch_stream = st
+        return st
 
     def timer_start(self):
         self.check(self._lib.fx_timer_start(self.handle))
@@ -590,6 +605,15 @@ def debug_pack_layout(kind, L, A, F, H, K) -> dict:
     names = ["FT", "HT", "SG1", "off_first", "off_c2", "off_c3", "off_cb", "conv_floats", "off_d1", "off_d2",
              "off_d3", "off_db", "RLH", "total_floats", "off_w1p", "HTR"]
     return dict(zip(names, list(v)))
+
+
+def mfma_per_tile(kind, L, A, F, H, K) -> int:
+    """MFMA instructions (2048 FLOP each) issued per 16-sequence tile per member (host-side restatement of the
+    kernels' loop bounds, pack.cpp)."""
+    n = lib().fx_debug_mfma_per_tile(kind, L, A, F, H, K)
+    if n < 0:
+        raise ValueError(f"no MFMA kernel for kind={kind} L={L} A={A} F={F} H={H} K={K}")
+    return int(n)
 
 
 def debug_myers(a: bytes, b: bytes) -> int:

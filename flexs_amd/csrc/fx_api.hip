@@ -115,6 +115,12 @@ int fx_engine_create(int device, fx_engine** out) {
     FX_CREATE_HIP(hipSetDevice(device));
     hipDeviceProp_t prop;
     FX_CREATE_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        // every kernel in this library is compiled for gfx950 only (MFMA f32 16x16x4, 160 KiB LDS, 8 XCDs)
+        fx_fail(nullptr, FX_ENODEV, std::string("HIP device is ") + prop.gcnArchName + ", not gfx950 (MI355X)");
+        delete e;
+        return FX_ENODEV;
+    }
     e->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e->max_lds = (int)std::max<size_t>(prop.maxSharedMemoryPerMultiProcessor, 64 * 1024);
     if (e->max_lds > 160 * 1024) e->max_lds = 160 * 1024;
@@ -836,6 +842,10 @@ int fx_nam_combine(fx_engine* e, int64_t Q, const double* signal, const double* 
 // the weight packing and the bit-parallel distance without a GPU.
 int64_t fx_debug_packed_size(int kind, int L, int A, int F, int H, int K) {
     return fx_pack_layout(FxShape{kind, L, A, F, H, K}).total_floats;
+}
+int64_t fx_debug_mfma_per_tile(int kind, int L, int A, int F, int H, int K) {
+    if (kind < FX_CNN || kind > FX_GE || L < 1 || A < 2 || H < 1) return FX_EINVAL;
+    return fx_mfma_per_tile(FxShape{kind, L, A, kind == FX_CNN ? F : 0, H, kind == FX_CNN ? K : 0});
 }
 int fx_debug_pack_layout(int kind, int L, int A, int F, int H, int K, int64_t* out16) {
     if (!out16) return FX_EINVAL;

@@ -49,6 +49,8 @@ FxPackLayout fx_pack_layout(const FxShape& s);
 // (H = 100: 25 instead of 28 k-steps per HxH layer).
 int fx_hidden_pos(int h, int H);
 int64_t fx_num_params(const FxShape& s);
+// MFMA instructions issued per 16-sequence tile per member by the MFMA kernels (pack.cpp); -1 = no MFMA kernel
+int64_t fx_mfma_per_tile(const FxShape& s);
 // Keras get_weights() blob -> packed fragment layout (host only, no device needed).
 void fx_pack_weights(const FxShape& s, const float* blob, float* packed);
 

@@ -81,6 +81,30 @@ FxPackLayout fx_pack_layout(const FxShape& s) {
     return p;
 }
 
+// v_mfma_f32_16x16x4_f32 instructions the MFMA scoring kernels issue per 16-sequence tile per member (the kernels'
+// own loop bounds restated on the host: conv taps that fall into the 'same' zero padding are skipped, the one-hot
+// first layers run as gathers, the hidden tail tile runs RLH of its 4 k-steps).  Used by bench.py / tests to price
+// the ISSUED matrix work of a launch; -1 when no MFMA kernel covers the shape.
+int64_t fx_mfma_per_tile(const FxShape& s) {
+    const FxPackLayout p = fx_pack_layout(s);
+    if (p.HTR > 16) return -1;
+    // one HxH layer: every output tile runs the k-steps of all input tiles, the last real one only RLH of them
+    // (a hidden size that was rounded up to a larger instantiated tile count runs all padded k-steps)
+    const int64_t hh = (int64_t)p.HT * (p.HT == p.HTR ? 4 * (p.HT - 1) + p.RLH : 4 * p.HT);
+    if (s.kind == FX_MLP) return 2 * hh;
+    if (s.kind == FX_GE) return hh;
+    if (s.kind != FX_CNN || s.L < s.K) return -1;
+    const int L1 = s.L1(), K3 = s.K3();
+    const int PL2 = (s.K - 1) / 2, PL3 = (K3 - 1) / 2;
+    int64_t taps2 = 0, taps3 = 0;
+    for (int t = 0; t < L1; ++t) {
+        for (int j = 0; j < s.K; ++j) taps2 += (t + j - PL2 >= 0 && t + j - PL2 < L1);
+        for (int j = 0; j < K3; ++j) taps3 += (t + j - PL3 >= 0 && t + j - PL3 < L1);
+    }
+    const int64_t per_tap = (int64_t)p.FT * p.FT * 4;
+    return (taps2 + taps3) * per_tap + (int64_t)p.FT * 4 * p.HT + hh;
+}
+
 namespace {
 // Maps from a POSITION in the padded layout to the source index (or -1 = zero padding).
 struct PosMap {

@@ -4,7 +4,7 @@
 The hot path shards two natural ways, each with exactly
 one exchange step -- an all-gather of float32 scores:
 
-  member-parallel    rank r owns members {m : m % world == r}; every rank scores
+  member-parallel    rank r owns the contiguous member block [r*per, (r+1)*per), per = ceil(M/world); every rank scores
                      the same N sequences with its members -> (N, M_r); ONE
                      all-gather of the padded (N, ceil(M/world)) blocks rebuilds
                      the stacked (N, M) matrix of ensemble.py:55-57 on every
@@ -51,7 +51,10 @@ def shard_range(n: int, rank: int, world: int):
 
 
 def member_assignment(num_members: int, rank: int, world: int) -> List[int]:
-    return list(range(rank, num_members, world))
+    """Members of rank `rank`: the contiguous block [rank * per, (rank + 1) * per), per = ceil(M / world) -- so the
+    gathered member-major planes of all ranks ARE the stacked predictions in member order (no re-assembly pass)."""
+    per = -(-num_members // world)
+    return list(range(min(rank * per, num_members), min((rank + 1) * per, num_members)))
 
 
 def _world(group):
@@ -60,30 +63,67 @@ def _world(group):
     return dist.get_rank(group), dist.get_world_size(group)
 
 
+def _on_gpu(group) -> bool:
+    """True when the exchange runs on device buffers (RCCL group, or no group at all on a GPU box)."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_backend(group) == "nccl"
+    return torch.cuda.is_available()
+
+
 def _gather_device(group):
-    backend = dist.get_backend(group)
-    return torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    return torch.device("cuda", torch.cuda.current_device()) if _on_gpu(group) else torch.device("cpu")
 
 
-def all_gather_padded(local: np.ndarray, rows_max: int, group=None) -> List[np.ndarray]:
-    """All-gather equal-shape float32 blocks (pad rows to `rows_max`), return the list of blocks."""
-    rank, world = _world(group)
-    block = np.zeros((rows_max,) + local.shape[1:], np.float32)
-    block[: local.shape[0]] = local
-    if world == 1:
-        return [block]
-    dev = _gather_device(group)
-    send = torch.from_numpy(block).to(dev)
-    recv = torch.empty((world,) + tuple(block.shape), dtype=torch.float32, device=dev)
-    dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group) if dev.type == "cuda" else \
+def _all_gather(recv: torch.Tensor, send: torch.Tensor, group=None, force: bool = False):
+    """recv[r] = rank r's `send` (equal shapes).  The ONE collective of the path; on RCCL it is a single
+    all_gather_into_tensor over device buffers, on gloo (CPU tests) the list form of the same collective."""
+    if _world(group)[1] == 1 and not (force and dist.is_available() and dist.is_initialized()):
+        recv[0].copy_(send)
+    elif recv.is_cuda:
+        dist.all_gather_into_tensor(recv.view(-1), send.reshape(-1), group=group)
+    else:
         dist.all_gather(list(recv.unbind(0)), send, group=group)
-    out = recv.cpu().numpy()
-    return [out[r] for r in range(world)]
+
+
+def _stride_for(n: int) -> int:
+    return max((n + 63) // 64 * 64, 64)         # plane stride in floats: 256-byte aligned planes
+
+
+class _Slot:
+    """One in-flight call's buffers (bench.py double-buffers two of them so that the all-gather of step k runs on the
+    communication stream while step k + 1 computes)."""
+
+    def __init__(self):
+        self.key = None
+        self.planes = self.local = self.recv = self.mean = None
+        self.done = None            # event on the communication stream: this slot's gather has landed
+        self.exchange = False       # False with one rank: recv aliases local
+        self.n = 0
+        self.want = "mean"
+        self.busy = False
+        self.keep = None
 
 
 class DistributedEnsemble(flexs_amd.Model):
-    """`flexs.Ensemble` semantics across the GPUs of one node (SPMD: every rank
-    calls `get_fitness` with the same sequences and receives the full result)."""
+    """`flexs.Ensemble` semantics (flexs/ensemble.py:54-59) across the GPUs of one node.  SPMD: every rank calls
+    `get_fitness` with the same sequences and receives the full result.
+
+    The data path is device-resident.  Every rank uploads (its share of) the byte batch once over its own PCIe link,
+    scores with the fused HIP kernels into member-major planes in HBM (`fx_score_planes_dev`), ONE all-gather over
+    device buffers on a separate communication stream rebuilds the result on every rank, and only the final `(N,)`
+    vector (or the `(N, M)` matrix for a custom `combine_with`) crosses back to the host:
+
+      member mode    rank r scores its member block for all N rows; the gathered planes ARE the stacked predictions
+                     (plane p = member p); the NumPy-order mean kernel then runs on them on every rank.
+      sequence mode  rank r scores rows [lo_r, hi_r) with every member; for the default mean it reduces locally
+                     first and gathers 4 bytes per sequence, else it gathers its (M, rows) planes.
+
+    `launch` / `finish` are the two halves of a call, so that a caller with a stream of batches (bench.py) overlaps
+    the gather of batch k with the scoring of batch k + 1; `get_fitness` is `launch` + `finish`.
+
+    `score_fn(member_indices, seq_bytes) -> (n, len(member_indices)) float32` replaces the on-engine scorer (gloo
+    tests on CPU); everything else -- assignment, padding, the collective, re-assembly, the reduction order -- is
+    the same code on both backends."""
 
     def __init__(self, models: Sequence[flexs_amd.Model], mode: str = "member",
                  combine_with: Callable[[np.ndarray], np.ndarray] = _default_combine, group=None,
@@ -95,15 +135,34 @@ class DistributedEnsemble(flexs_amd.Model):
         self.mode = mode
         self.combine_with = combine_with
         self.group = group
-        self._score_fn = score_fn or self._score_on_engine
+        self._score_fn = score_fn
+        self._cuda = score_fn is None and _on_gpu(group)
+        if score_fn is None and not self._cuda:
+            raise RuntimeError("DistributedEnsemble scores on this rank's MI355X: it needs an RCCL ('nccl') process "
+                               "group or a visible GPU (there is no CPU fallback); pass score_fn for CPU tests")
+        self._slots = [_Slot(), _Slot()]
+        self._comm = None
+        # with one rank the gathered block IS the local block (no copy, no second stream); tests and
+        # `bench.py --force-dist` set this to run the real collective on a one-rank RCCL group
+        self.force_collective = False
 
-    # -- default scorer: this rank's GPU
-    def _score_on_engine(self, member_idx: List[int], seq_bytes: np.ndarray) -> np.ndarray:
-        if not member_idx or seq_bytes.shape[0] == 0:
-            return np.zeros((seq_bytes.shape[0], len(member_idx)), np.float32)
-        ms = [self.models[i] for i in member_idx]
-        nm, _ = ms[0]._engine().score([m.native() for m in ms], seq_bytes, ms[0]._lut, want_matrix=True)
-        return nm
+    # ------------------------------------------------------------------ plumbing
+    def _engine(self):
+        return _native.Engine.get(getattr(self.models[0], "_device", None))
+
+    @property
+    def stream(self):
+        """Compute stream of the device path: the torch stream the scoring engine enqueues on."""
+        return self._engine().torch_stream() if self._cuda else None
+
+    def _shape(self, n: int, want: str):
+        """(members scored here, rows scored here [lo, hi), planes gathered per rank, plane stride) for a batch."""
+        rank, world = _world(self.group)
+        M = len(self.models)
+        if self.mode == "member":
+            return member_assignment(M, rank, world), (0, n), -(-M // world), _stride_for(n)
+        lo, hi = shard_range(n, rank, world)
+        return list(range(M)), (lo, hi), (1 if want == "mean" else M), _stride_for(-(-n // world) if n else 0)
 
     def train(self, sequences, labels):
         # every rank trains every member identically only if seeded identically; the usual
@@ -128,34 +187,137 @@ class DistributedEnsemble(flexs_amd.Model):
                 off += w.size
             m.model.set_weights(out)
 
-    def _fitness_function(self, sequences):
+    def _reduce_planes(self, planes: torch.Tensor, rows: int, M: int, stride: int, out: torch.Tensor):
+        """out[:rows] = np.mean over the M member planes, NumPy float32 summation order (K3 on the device path)."""
+        if rows == 0:
+            return
+        if self._cuda and M <= 16:
+            self._engine().ensemble_mean_planes_dev(planes.data_ptr(), rows, M, stride, out.data_ptr())
+        elif self._cuda:
+            mat = planes[:M, :rows].t().contiguous()
+            self._engine().ensemble_reduce_dev(mat.data_ptr(), rows, M, out.data_ptr())   # (mat is freed stream-ordered)
+        else:
+            out[:rows] = torch.from_numpy(_default_combine(planes[:M, :rows].t().contiguous().numpy()).astype(np.float32, copy=False))
+
+    # ------------------------------------------------------------------ the two halves of one call
+    def launch(self, seq, n: Optional[int] = None, slot: int = 0, want: str = "mean", timing=None):
+        """Score this rank's share of the batch and start the all-gather.  `seq`: (n, L) uint8 -- a NumPy array (this
+        rank's rows are uploaded), or on the device path a CUDA tensor of the whole batch already resident in HBM.
+        want = "mean" | "matrix" (what `finish` will hand out); timing = (start, stop) torch.cuda.Event pair
+        recorded on the compute stream around the scoring kernel (bench.py's kernel_ms)."""
         rank, world = _world(self.group)
+        n = int(seq.shape[0]) if n is None else n
+        M = len(self.models)
+        mine, (lo, hi), per, stride = self._shape(n, want)
+        s = self._slots[slot]
+        dev = _gather_device(self.group) if self._cuda else torch.device("cpu")
+        key = (n, per, stride, world, want)
+        if s.key != key:
+            s.local = torch.zeros((per, stride), dtype=torch.float32, device=dev)
+            s.exchange = world > 1 or (self.force_collective and dist.is_available() and dist.is_initialized())
+            s.recv = torch.zeros((world, per, stride), dtype=torch.float32, device=dev) if s.exchange else s.local.unsqueeze(0)
+            s.mean = torch.empty((max(n, 1),), dtype=torch.float32, device=dev)
+            # sequence mode, mean only: the (M, rows) planes stay local, their mean is what travels
+            local_reduce = self.mode == "sequence" and want == "mean"
+            s.planes = torch.zeros((M, stride), dtype=torch.float32, device=dev) if local_reduce else s.local
+            s.done = torch.cuda.Event() if self._cuda else None
+            s.key, s.busy = key, False
+            if self._cuda:
+                torch.cuda.current_stream().synchronize()            # the zero fills ran on the caller's stream
+        s.n, s.want = n, want
+        local_reduce = s.planes is not s.local
+        if self._cuda:
+            m0 = self.models[0]
+            st = self.stream
+            if self._comm is None:
+                self._comm = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                if s.busy and s.exchange:
+                    st.wait_event(s.done)                            # the slot's previous gather has been consumed
+                if isinstance(seq, np.ndarray):
+                    seq = torch.from_numpy(np.ascontiguousarray(seq[lo:hi])).to(dev, non_blocking=True)
+                    row0 = 0
+                else:
+                    row0 = lo
+                if mine and hi > lo:
+                    natives = [self.models[i].native() for i in mine]
+                    if timing:
+                        timing[0].record(st)
+                    self._engine().score_planes_dev(natives, seq.data_ptr() + row0 * m0.model.L, hi - lo, m0.model.L,
+                                                    m0._lut, s.planes.data_ptr(), stride)
+                    if timing:
+                        timing[1].record(st)
+                    if local_reduce:
+                        self._reduce_planes(s.planes, hi - lo, M, stride, s.local)
+                s.keep = seq                                         # alive until the kernels have run
+                if s.exchange:
+                    self._comm.wait_stream(st)
+                    with torch.cuda.stream(self._comm):
+                        _all_gather(s.recv, s.local, self.group, force=True)   # RCCL over xGMI, device buffers
+                        s.done.record(self._comm)
+        else:
+            b = np.ascontiguousarray(seq[lo:hi])
+            local = self._score_fn(mine, b) if (mine and hi > lo) else np.zeros((hi - lo, len(mine)), np.float32)
+            s.planes.zero_()
+            s.planes[: len(mine), : hi - lo] = torch.from_numpy(np.ascontiguousarray(np.asarray(local, np.float32).T))
+            if local_reduce:
+                self._reduce_planes(s.planes, hi - lo, M, stride, s.local[0])
+            if s.exchange:
+                _all_gather(s.recv, s.local, self.group)
+        s.busy = True
+        return s
+
+    def finish(self, slot: int = 0):
+        """Wait for the slot's gather and hand out what `launch` was asked for: the `(n,)` np.mean-order mean, or the
+        stacked `(n, M)` predictions (`np.stack(axis=1)` of ensemble.py:55-57) -- on every rank, as a tensor on the
+        gather device (CUDA on RCCL); the caller decides when to copy it to the host."""
+        rank, world = _world(self.group)
+        s = self._slots[slot]
+        n, M, want = s.n, len(self.models), s.want
+        _, per, stride, _, _ = s.key
+        if self._cuda and s.exchange:
+            self.stream.wait_event(s.done)
+        s.busy = False
+        with (torch.cuda.stream(self.stream) if self._cuda else _Null()):
+            if self.mode == "member":
+                planes = s.recv.view(world * per, stride)            # plane p = member p (contiguous assignment)
+                if want == "matrix":
+                    return planes[:M, :n].t().contiguous()
+                self._reduce_planes(planes, n, M, stride, s.mean)
+                return s.mean[:n]
+            spans = [shard_range(n, r, world) for r in range(world)]
+            if want == "matrix":                                     # rank r's block: rows [lo_r, hi_r) of every member
+                return torch.cat([s.recv[r, :, : b - a].t() for r, (a, b) in enumerate(spans)], dim=0).contiguous()
+            if world == 1 or (n % world == 0 and n // world == stride):
+                return s.recv.view(-1)[:n]                           # the shards already sit back to back
+            return torch.cat([s.recv[r, 0, : b - a] for r, (a, b) in enumerate(spans)], dim=0)
+
+    # ------------------------------------------------------------------ flexs.Model API
+    def _fitness_function(self, sequences):
         n, M = len(sequences), len(self.models)
         for m in self.models:
             m.cost += n                                            # ensemble.py:55-57 via landscape.py:44
         L = self.models[0].model.L if hasattr(self.models[0], "model") else None
         seq_bytes = _native.sequences_to_bytes(sequences, L=L)
-        if self.mode == "member":
-            mine = member_assignment(M, rank, world)
-            per = -(-M // world)
-            local = self._score_fn(mine, seq_bytes)                # (n, len(mine))
-            blocks = all_gather_padded(np.ascontiguousarray(local.T), per, self.group)   # each (per, n)
-            scores = np.empty((n, M), np.float32)
-            for r in range(world):
-                idx = member_assignment(M, r, world)
-                scores[:, idx] = blocks[r][: len(idx)].T
-        else:
-            lo, hi = shard_range(n, rank, world)
-            per = -(-n // world) if n else 0
-            local = self._score_fn(list(range(M)), seq_bytes[lo:hi])           # (hi-lo, M)
-            blocks = all_gather_padded(local, per, self.group)
-            scores = np.empty((n, M), np.float32)
-            for r in range(world):
-                a, b = shard_range(n, r, world)
-                scores[a:b] = blocks[r][: b - a]
-        if self.combine_with is _default_combine and self._score_fn == self._score_on_engine and n:
-            return _native.Engine.get(getattr(self.models[0], "_device", None)).ensemble_mean(scores)   # K3 on this GPU
-        return self.combine_with(scores)
+        if n == 0:
+            return self.combine_with(np.zeros((0, M), np.float32))
+        default = self.combine_with is _default_combine
+        self.launch(seq_bytes, n, 0, "mean" if default else "matrix")
+        out = self.finish(0)
+        if self._cuda:
+            with torch.cuda.stream(self.stream):
+                out = out.cpu()                                    # stream-ordered D2H of the final result only
+            self._engine().sync()                                  # raises ValueError for a character outside the alphabet
+        out = out.numpy()
+        return out if default else self.combine_with(out)
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 # ---------------------------------------------------------------------------

@@ -237,6 +237,11 @@ int fx_table_additive(fx_table *t, const uint8_t *ascii, int64_t N, int L, const
  * so the CPU test-suite can check them against the oracle. */
 int64_t fx_debug_packed_size(int kind, int L, int A, int F, int H, int K);
 int fx_debug_pack_layout(int kind, int L, int A, int F, int H, int K, int64_t *out16);
+/* v_mfma_f32_16x16x4_f32 instructions (2048 FLOP each) the MFMA scoring kernels issue per 16-sequence tile per
+ * member for this shape -- the kernels' loop bounds restated on the host ('same'-padding taps and the one-hot
+ * first layers are not issued, the hidden tail tile runs only its real k-steps).  bench.py prices the ISSUED
+ * matrix work of a launch with it, beside the algorithmic FLOP of SURVEY.md 8(d).  Negative: no MFMA kernel. */
+int64_t fx_debug_mfma_per_tile(int kind, int L, int A, int F, int H, int K);
 int fx_debug_pack_weights(int kind, int L, int A, int F, int H, int K, const float *blob, int64_t n,
                           float *packed, int64_t cap);
 int fx_debug_myers(const uint8_t *a, int la, const uint8_t *b, int lb);

@@ -22,7 +22,8 @@ def test_shard_range_covers_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
-    assert fd.member_assignment(8, 1, 8) == [1] and fd.member_assignment(3, 1, 2) == [1]
+    assert fd.member_assignment(8, 1, 8) == [1] and fd.member_assignment(3, 1, 2) == [2]
+    assert fd.member_assignment(3, 5, 8) == [] and fd.member_assignment(8, 1, 4) == [2, 3]
     assert sorted(sum((fd.member_assignment(11, r, 4) for r in range(4)), [])) == list(range(11))
 
 
@@ -91,7 +92,7 @@ def _worker(rank, world, port, mode, M, n, q):
 
 
 @pytest.mark.parametrize("mode,M,n", [("member", 3, 101), ("member", 8, 64), ("sequence", 3, 101), ("sequence", 2, 1),
-                                      ("member", 1, 5)])
+                                      ("member", 1, 5), ("member", 17, 130), ("sequence", 17, 67)])
 def test_world2_gloo(mode, M, n):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
@@ -107,12 +108,15 @@ def test_world2_gloo(mode, M, n):
         assert np.array_equal(mat, want_mat)                       # every rank holds the full stacked matrix
         assert np.array_equal(out, np.mean(want_mat, axis=1))
         assert cost == 2 * n // 2 and mcosts == [2 * n] * M        # two get_fitness calls on members, one per ensemble
-        idx, rows = called[0]
         if mode == "member":
-            assert idx == fd.member_assignment(M, rank, world) and rows == n
+            want_idx, want_rows = fd.member_assignment(M, rank, world), n
         else:
             lo, hi = fd.shard_range(n, rank, world)
-            assert idx == list(range(M)) and rows == hi - lo
+            want_idx, want_rows = list(range(M)), hi - lo
+        if want_idx and want_rows:                                 # a rank with nothing to score launches nothing
+            assert called[0] == (want_idx, want_rows) and len(called) == 2
+        else:
+            assert called == []
 
 
 # ---------------------------------------------------------------- cache-sharded neighbour search

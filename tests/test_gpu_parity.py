@@ -957,11 +957,27 @@ def test_distributed_classes_on_one_rank_rccl(eng):
         want = flexs_amd.Ensemble(members).get_fitness(seqs)
         stack = np.stack([m.get_fitness(seqs) for m in members], axis=1)
         for mode in ("member", "sequence"):
-            ens = fd.DistributedEnsemble(members, mode=mode)
-            assert np.array_equal(ens.get_fitness(seqs), want)
-            assert np.array_equal(fd.DistributedEnsemble(members, mode=mode, combine_with=lambda x: x).get_fitness(seqs), stack)
-            ens.broadcast_weights(src=0)
-            assert np.array_equal(ens.get_fitness(seqs), want)
+            for force in (True, False):              # the real RCCL all-gather on device buffers / the one-rank alias
+                ens = fd.DistributedEnsemble(members, mode=mode)
+                ens.force_collective = force
+                assert np.array_equal(ens.get_fitness(seqs), want)
+                mat = fd.DistributedEnsemble(members, mode=mode, combine_with=lambda x: x)
+                mat.force_collective = force
+                assert np.array_equal(mat.get_fitness(seqs), stack)
+                ens.broadcast_weights(src=0)
+                assert np.array_equal(ens.get_fitness(seqs), want)
+                # the two halves on a batch already resident in HBM, both buffer slots in flight (what bench.py does)
+                with torch.cuda.stream(ens.stream):
+                    d_seq = torch.from_numpy(b).cuda()
+                ens.launch(d_seq, slot=0, want="mean")
+                ens.launch(d_seq, slot=1, want="matrix")
+                got_mean, got_mat = ens.finish(0), ens.finish(1)
+                ens.stream.synchronize()
+                assert np.array_equal(got_mean.cpu().numpy(), want) and np.array_equal(got_mat.cpu().numpy(), stack)
+                with pytest.raises(ValueError):
+                    ens.get_fitness(seqs[:5] + ["Z" * L])
+                assert np.array_equal(ens.get_fitness(seqs), want)
+            assert ens.cost == 3 * 257 + 6 and all(m.cost > 0 for m in members)
         sc = fd.ShardedCache(L)
         sc.append(b[:200])
         d, a = sc.min_dist(b[150:])
@@ -969,6 +985,24 @@ def test_distributed_classes_on_one_rank_rccl(eng):
         assert np.array_equal(d, d_want) and np.array_equal(a, a_want)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,L,alpha,M,n", [("cnn", 8, "TGCA", 8, 1000), ("ge", 90, s_utils.AAS, 8, 333), ("mlp", 14, "UGCA", 17, 65)])
+def test_distributed_ensemble_without_a_process_group(eng, kind, L, alpha, M, n):
+    """No torch.distributed at all (world = 1): DistributedEnsemble is the device-resident path of a plain Ensemble --
+    planes in HBM, K3 on the planes, only the result copied back -- and must give Ensemble's bits."""
+    from flexs_amd import distributed as fd
+
+    mk = {"cnn": lambda s: bm.CNN(L, 32, 100, alpha, seed=s), "ge": lambda s: bm.GlobalEpistasisModel(L, 100, alpha, seed=s),
+          "mlp": lambda s: bm.MLP(L, 100, alpha, seed=s)}[kind]
+    members = [mk(s) for s in range(M)]
+    b, seqs = rand_seqs(n, L, alpha, seed=11)
+    want = flexs_amd.Ensemble(members).get_fitness(seqs)
+    stack = flexs_amd.Ensemble(members, combine_with=lambda x: x).get_fitness(seqs)
+    for mode in ("member", "sequence"):
+        assert np.array_equal(fd.DistributedEnsemble(members, mode=mode).get_fitness(seqs), want)
+        assert np.array_equal(fd.DistributedEnsemble(members, mode=mode, combine_with=lambda x: x).get_fitness(seqs), stack)
+    assert fd.DistributedEnsemble(members).get_fitness([]).shape == (0,)
 
 
 def test_big_string_batches_are_scored_in_overlapping_pieces(eng):

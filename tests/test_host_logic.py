@@ -260,6 +260,34 @@ def test_bench_report_contract():
     assert rf["flop_per_launch"] == 2.0 * 48628 * 3 * 100_000            # 97 256 FLOP per sequence-member
     assert rf["achieved"] == pytest.approx(rf["flop_per_launch"] / 0.2e-3 / 1e12) and rf["frac"] == pytest.approx(rf["achieved"] / 157.3)
     assert rf["algorithmic_bytes_per_launch"] == (8 + 12) * 100_000
+    # issued-MFMA fraction: 615 MFMAs per 16-sequence tile per member (the kernel's loop bounds), 2048 FLOP each
+    assert rf["mfma_per_tile"] == 615 and rf["issued_flop_per_launch"] == 615 * 6250 * 3 * 2048
+    assert rf["frac_issued"] == pytest.approx(rf["issued_flop_per_launch"] / 0.2e-3 / 1e12 / 157.3) and rf["frac_issued"] < rf["frac"]
+    m = bench.make_report(world=8, N=100_000, steps=10, warmup=1, elapsed=0.01, host_issue_s=0.001, kern_ms=0.07, use_dist=True,
+                          mode="member", members=8)
+    assert m["scaling"] == "strong" and m["value"] == pytest.approx(100_000 * 10 / 0.01) and m["config"]["global_batch"] == 100_000
+    assert m["roofline"]["flop_per_launch"] == 2.0 * 48628 * 1 * 100_000      # one member per rank
+
+
+def test_issued_mfma_counts_follow_the_kernels_loop_bounds():
+    """fx_debug_mfma_per_tile against a direct count: conv taps inside the 'same' padding are not issued, the one-hot
+    first layers are gathers, the hidden tail tile runs ceil(tail / 4) of its k-steps."""
+    from flexs_amd import _native
+
+    def conv_taps(L1, k):
+        pl = (k - 1) // 2
+        return sum(0 <= t + j - pl < L1 for t in range(L1) for j in range(k))
+
+    for L, A, F, H, K in ((8, 4, 32, 100, 5), (14, 4, 32, 100, 5), (237, 20, 32, 100, 5), (14, 4, 32, 100, 3), (9, 4, 16, 100, 5)):
+        ft, ht, tail = -(-F // 16), -(-H // 16), H - 16 * (-(-H // 16) - 1)
+        hh = ht * (4 * (ht - 1) + (-(-tail // 4) if tail >= 4 else 1))
+        want = (conv_taps(L - K + 1, K) + conv_taps(L - K + 1, A - 1)) * ft * ft * 4 + ft * 4 * ht + hh
+        assert _native.mfma_per_tile(_native.FX_CNN, L, A, F, H, K) == want
+    assert _native.mfma_per_tile(_native.FX_CNN, 8, 4, 32, 100, 5) == 615      # PMC-confirmed in round 1 (r1_run35)
+    assert _native.mfma_per_tile(_native.FX_MLP, 14, 4, 0, 100, 0) == 2 * 175
+    assert _native.mfma_per_tile(_native.FX_GE, 90, 20, 0, 100, 0) == 175
+    assert _native.mfma_per_tile(_native.FX_MLP, 14, 4, 0, 64, 0) == 2 * 4 * 16      # H = 64: four full tiles
+    assert _native.mfma_per_tile(_native.FX_MLP, 14, 4, 0, 80, 0) == 2 * 7 * 28      # 5 real tiles rounded up to the 7-tile kernel
 
 
 def test_ragged_rows_for_edit_distance():
