@@ -78,6 +78,8 @@ SIGNATURES = {
     "fx_debug_packed_size": (C.c_int64, [C.c_int] * 6),
     "fx_debug_pack_layout": (C.c_int, [C.c_int] * 6 + [_i64p]),
     "fx_debug_mfma_per_tile": (C.c_int64, [C.c_int] * 6),
+    "fx_debug_trace_read": (C.c_int, [_vp, _vp, C.c_int64]),
+    "fx_debug_time_score": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _vp, C.c_int64, C.c_int, _u8p, _vp, C.c_int64, C.c_int, _f32p]),
     "fx_debug_pack_weights": (C.c_int, [C.c_int] * 6 + [_f32p, C.c_int64, _f32p, C.c_int64]),
     "fx_debug_myers": (C.c_int, [_vp, C.c_int, _vp, C.c_int]),
     "fx_debug_mfma_probe": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
@@ -308,6 +310,22 @@ class Engine:
         ms = C.c_float()
         self.check(self._lib.fx_timer_stop(self.handle, C.byref(ms)))
         return ms.value
+
+    def time_score_planes(self, models, d_ascii: int, N: int, L: int, lut: np.ndarray, d_planes: int, stride: int,
+                          reps: int) -> float:
+        """Milliseconds for `reps` back-to-back scoring launches issued from C (one hipEvent pair around them)."""
+        M = len(models)
+        arr = (_vp * M)(*[m.handle for m in models])
+        ms = C.c_float()
+        self.check(self._lib.fx_debug_time_score(self.handle, arr, M, _vp(d_ascii), N, L, _lut_ptr(lut), _vp(d_planes),
+                                                 stride, reps, C.byref(ms)))
+        return ms.value
+
+    def trace_read(self) -> np.ndarray:
+        """(1024 workgroups, 16 waves, 8 slots) uint64 in-kernel timeline of the last traced launch (option "trace")."""
+        out = np.zeros((1024, 16, 8), np.uint64)
+        self.check(self._lib.fx_debug_trace_read(self.handle, _ptr(out), out.size))
+        return out
 
     def staging_rows(self, n: int, width: int) -> np.ndarray:
         """(n, width) uint8 view of the engine's pinned input staging area: marshal strings straight into it and

@@ -63,6 +63,20 @@ int fx_upload_lut(fx_engine* e, const uint8_t lut[256]) {
     return FX_OK;
 }
 
+int fx_trace_buffer(fx_engine* e, unsigned long long** out) {
+    *out = nullptr;
+    if (!e->trace) return FX_OK;
+    if (!e->d_trace) {
+        if (hipMalloc(reinterpret_cast<void**>(&e->d_trace), FX_TRACE_BYTES) != hipSuccess) {
+            (void)hipGetLastError();
+            return fx_fail(e, FX_ENOMEM, "hipMalloc of the trace buffer failed");
+        }
+    }
+    FX_HIP(e, hipMemsetAsync(e->d_trace, 0, FX_TRACE_BYTES, e->stream));
+    *out = e->d_trace;
+    return FX_OK;
+}
+
 static int check_deferred(fx_engine* e) {
     // caller has synchronised the stream; the error word lives in mapped pinned host memory,
     // so reading it costs nothing (no extra hipMemcpy on the small-call latency path)
@@ -145,6 +159,7 @@ int fx_engine_destroy(fx_engine* e) {
     for (auto& p : e->h_pinned) if (p) (void)hipHostFree(p);
     if (e->h_err) (void)hipHostFree(e->h_err);
     if (e->d_lut) (void)hipFree(e->d_lut);
+    if (e->d_trace) (void)hipFree(e->d_trace);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -181,6 +196,8 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "dense_slab")) return &e->dense_slab;
     if (!std::strcmp(key, "cnn_big_units")) return &e->cnn_big_units;
     if (!std::strcmp(key, "poison_outputs")) return &e->poison_outputs;
+    if (!std::strcmp(key, "trace")) return &e->trace;
+    if (!std::strcmp(key, "ge_bytetab")) return &e->ge_bytetab;
     return nullptr;
 }
 int fx_engine_set_option(fx_engine* e, const char* key, int64_t value) {
@@ -249,6 +266,7 @@ int fx_model_destroy(fx_model* m) {
     (void)hipStreamSynchronize(m->eng->stream);
     if (m->d_blob) (void)hipFree(m->d_blob);
     if (m->d_packed) (void)hipFree(m->d_packed);
+    if (m->d_bytetab) (void)hipFree(m->d_bytetab);
     delete m;
     return FX_OK;
 }
@@ -268,6 +286,7 @@ int fx_model_set_weights(fx_model* m, const float* blob, int64_t n) {
     FX_HIP(e, hipMemcpy(m->d_blob, m->blob.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
     FX_HIP(e, hipMemcpy(m->d_packed, packed.data(), sizeof(float) * packed.size(), hipMemcpyHostToDevice));
     m->has_weights = true;
+    m->bt_valid = false;
     return FX_OK;
 }
 
@@ -842,6 +861,28 @@ int fx_nam_combine(fx_engine* e, int64_t Q, const double* signal, const double* 
 // the weight packing and the bit-parallel distance without a GPU.
 int64_t fx_debug_packed_size(int kind, int L, int A, int F, int H, int K) {
     return fx_pack_layout(FxShape{kind, L, A, F, H, K}).total_floats;
+}
+int fx_debug_trace_read(fx_engine* e, uint64_t* out, int64_t cap_words) {
+    if (!e || !out || cap_words < 0) return FX_EINVAL;
+    if (!e->d_trace) return fx_fail(e, FX_ESTATE, "no trace was recorded (set the \"trace\" option before scoring)");
+    FX_HIP(e, hipSetDevice(e->device));
+    FX_HIP(e, hipStreamSynchronize(e->stream));
+    const size_t n = std::min<size_t>((size_t)cap_words * 8, FX_TRACE_BYTES);
+    FX_HIP(e, hipMemcpy(out, e->d_trace, n, hipMemcpyDeviceToHost));
+    return FX_OK;
+}
+int fx_debug_time_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N, int L,
+                        const uint8_t lut[256], float* d_planes, int64_t stride, int reps, float* total_ms) {
+    if (!e || !total_ms || reps < 1) return FX_EINVAL;
+    int rc = fx_score_planes_dev(e, models, M, d_ascii, N, L, lut, d_planes, stride);   // validates; warms the caches
+    if (rc) return rc;
+    FX_HIP(e, hipEventRecord(e->ev0, e->stream));
+    for (int i = 0; i < reps; ++i)
+        if ((rc = fx_score_planes_dev(e, models, M, d_ascii, N, L, lut, d_planes, stride))) return rc;
+    FX_HIP(e, hipEventRecord(e->ev1, e->stream));
+    FX_HIP(e, hipEventSynchronize(e->ev1));
+    FX_HIP(e, hipEventElapsedTime(total_ms, e->ev0, e->ev1));
+    return FX_OK;
 }
 int64_t fx_debug_mfma_per_tile(int kind, int L, int A, int F, int H, int K) {
     if (kind < FX_CNN || kind > FX_GE || L < 1 || A < 2 || H < 1) return FX_EINVAL;

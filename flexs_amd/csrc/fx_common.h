@@ -84,6 +84,9 @@ struct fx_engine {
     int64_t cnn_seg = -1;       // A = 4 CNN kernel, small batches: -1 = waves of a workgroup split one tile's positions when L1 >= 24, 0 = never, 1 = whenever the batch is small
     int64_t cnn_pair_seg = -1;  // pair kernel, small batches: -1 = segment a tile's positions automatically, 0 = never, n > 0 = force SB = n workgroups per tile
     int64_t dense_slab = 1;     // MLP / GE with H > 128: HxH blocks staged through LDS slabs by the workgroup (0 = every wave streams them from L2)
+    int64_t ge_bytetab = 1;     // 1 = GlobalEpistasis layer 1 gathers from the byte-indexed per-position table (0 = LUT + code-indexed table: A/B)
+    int64_t trace = 0;          // 1 = the MFMA scoring kernels stamp an in-kernel timeline into d_trace (fx_debug_trace_read)
+    unsigned long long* d_trace = nullptr;
     int64_t mlp_l1_mfma = 0;    // 1 = one-hot MLP layer 1 on MFMA instead of the LDS gather (A/B knob)
     int num_cus = 256;
     int max_lds = 160 * 1024;
@@ -112,6 +115,12 @@ struct fx_model {
     float* d_blob = nullptr;    // device copy, Keras order (generic kernels)
     float* d_packed = nullptr;  // device copy, fragment layout (MFMA kernels)
     bool has_weights = false;
+    // GlobalEpistasis first layer as a per-position table indexed by the RAW byte (score_dense_mfma.hip): Lpad x 256
+    // floats, tab[l][b] = w1[l * A + lut[b]] (0 for bytes outside the alphabet and for the padding rows l >= L);
+    // built on the device for the LUT of the call, rebuilt when the weights or the LUT change
+    float* d_bytetab = nullptr;
+    uint8_t bt_lut[256];
+    bool bt_valid = false;
 };
 
 struct fx_cache {
@@ -139,6 +148,9 @@ int fx_fail(fx_engine* e, int status, const std::string& msg);
 int fx_scratch(fx_engine* e, int slot, size_t bytes, void** out);
 int fx_pinned(fx_engine* e, int slot, size_t bytes, void** out);
 int fx_upload_lut(fx_engine* e, const uint8_t lut[256]);
+// device timeline buffer for the launch about to be enqueued (zeroed), or nullptr when the "trace" option is off
+#define FX_TRACE_BYTES ((size_t)1024 * 16 * 8 * 8)
+int fx_trace_buffer(fx_engine* e, unsigned long long** out);
 
 // Deferred error word: mapped pinned HOST memory (read by the host right after the stream
 // sync, no copy).  Only one bit is defined, so raising it is an idempotent system-scope

@@ -56,6 +56,28 @@ __device__ __forceinline__ unsigned fx_xcd_block() {
     return x * per + (x < rem ? x : rem) + (b >> 3);
 }
 
+// Work split of the persistent scoring kernels.  Units = (member, tile), member-major; every workgroup takes one
+// contiguous range.  Whenever the grid has at least M workgroups the range lies inside ONE member: member m owns
+// the workgroups [ceil(G m / M), ceil(G (m + 1) / M)) (contiguous, so with fx_xcd_block they share an L2) and its
+// tiles are cut evenly over them.  A range that straddled two members made that workgroup wait at the member
+// boundary for its slowest wave, refill LDS and start over -- one tile duration plus a fill, which with few tiles
+// per workgroup WAS the kernel's tail (profiles/r2_trace_probe: 3 members x 1e4 sequences, 38 us span of which 12
+// were two straddling workgroups; 194 -> ~180 us on the 3 x 1e5 bench launch).
+__device__ __forceinline__ void fx_unit_range(int64_t TG, int M, int64_t& u_lo, int64_t& u_hi) {
+    const int64_t G = gridDim.x, bid = fx_xcd_block();
+    if (M > 1 && G >= M) {
+        const int64_t m = bid * M / G;
+        const int64_t g_lo = (m * G + M - 1) / M, g_hi = ((m + 1) * G + M - 1) / M;
+        const int64_t nb = g_hi - g_lo, j = bid - g_lo;
+        u_lo = m * TG + TG * j / nb;
+        u_hi = m * TG + TG * (j + 1) / nb;
+    } else {
+        const int64_t U = (int64_t)M * TG;
+        u_lo = U * bid / G;
+        u_hi = U * (bid + 1) / G;
+    }
+}
+
 // Workgroup copy of a member's packed weights into LDS.  Eight 16-byte loads are in flight per thread before the
 // first LDS store, so the ~100 KiB image costs a couple of L2 round trips instead of one per 16 bytes per thread
 // (which is what a plain copy loop compiles to, and what small calls and small batches then mostly wait for).
@@ -70,6 +92,15 @@ __device__ __forceinline__ void fill_lds(f4* __restrict__ dst, const f4* __restr
         for (int k = 0; k < 8; ++k)
             if (i0 + k * bd < n4) dst[i0 + k * bd] = v[k];
     }
+}
+
+// In-kernel timeline (engine option "trace", debugging / profiling only): the first lane of every wave stamps the
+// constant-rate wall clock (100 MHz) into slot `slot` of its row; `t` is null in normal operation.
+#define FX_TRACE_SLOTS 8
+#define FX_TRACE_WAVES 16
+__device__ __forceinline__ void fx_stamp(unsigned long long* t, int slot, unsigned long long v = ~0ull) {
+    if (t && (threadIdx.x & 63) == 0)
+        t[((size_t)blockIdx.x * FX_TRACE_WAVES + (threadIdx.x >> 6)) * FX_TRACE_SLOTS + slot] = (v == ~0ull) ? wall_clock64() : v;
 }
 
 __device__ __forceinline__ f4 splat4(float v) { f4 r = {v, v, v, v}; return r; }

@@ -27,6 +27,7 @@ struct CnnArgs {
     const float* w[FX_MAX_M];   // packed weights per member
     float* out;                 // N x Mtot
     unsigned* err;
+    unsigned long long* trace;  // in-kernel timeline (null = off), see fx_stamp
     int64_t N;
     int64_t TG;                 // tile groups per member = ceil(N / (16*NT))
     int M, Mtot, m_off;
@@ -66,15 +67,16 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
     uint8_t* lut_s = reinterpret_cast<uint8_t*>(smem + lds_floats);
     int* next_tile = reinterpret_cast<int*>(smem + lds_floats + 64);   // work counter, after the 256-byte LUT
 
+    fx_stamp(p.trace, 0);
     for (int i = tid; i < 64; i += blockDim.x)
         reinterpret_cast<uint32_t*>(lut_s)[i] = reinterpret_cast<const uint32_t*>(p.lut)[i];
 
-    const int64_t U = (int64_t)p.M * p.TG;
-    const int64_t bid = fx_xcd_block();
-    const int64_t u_lo = U * bid / gridDim.x, u_hi = U * (bid + 1) / gridDim.x;
+    int64_t u_lo, u_hi;
+    fx_unit_range(p.TG, p.M, u_lo, u_hi);
     if (u_lo >= u_hi) return;
     const int m_first = (int)(u_lo / p.TG), m_last = (int)((u_hi - 1) / p.TG);
     bool bad = false;
+    unsigned tiles_done = 0;
 
     for (int m = m_first; m <= m_last; ++m) {
         __syncthreads();                                 // previous member's readers are done
@@ -85,6 +87,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
             fill_lds(dst, src, lds_floats / 4);
         }
         __syncthreads();
+        if (m == m_first) fx_stamp(p.trace, 1);
         const f4* w_first = reinterpret_cast<const f4*>(smem + p.off_first);
         const f4* w_c2 = reinterpret_cast<const f4*>(smem + p.off_c2);
         const f4* w_c3 = reinterpret_cast<const f4*>(smem + p.off_c3);
@@ -108,6 +111,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
             }
             const int64_t tg = SEG ? seg_tile : t_lo + pulled;   // SEG: every wave of the workgroup walks the same tiles
             if (tg >= t_hi) break;
+            if (tiles_done == 0) fx_stamp(p.trace, 2);
             // ---- this lane's sequences
             int64_t n[NT];
             const uint8_t* row[NT];
@@ -352,8 +356,14 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                 for (int nt = 0; nt < NT; ++nt)
                     if (n[nt] < p.N) p.out[n[nt] * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y[nt]);
             }
+            if (p.trace) {
+                if (tiles_done == 0) fx_stamp(p.trace, 3);
+                fx_stamp(p.trace, 4);
+                fx_stamp(p.trace, 5, ++tiles_done);
+            }
         }
     }
+    fx_stamp(p.trace, 6);
     if (bad) fx_raise(p.err, FX_ERR_BADCHAR);
 }
 

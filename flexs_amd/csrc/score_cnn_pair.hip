@@ -85,11 +85,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
     for (int i = tid; i < 64; i += blockDim.x)
         reinterpret_cast<uint32_t*>(lut_s)[i] = reinterpret_cast<const uint32_t*>(p.lut)[i];
 
-    const int64_t U = (int64_t)p.M * p.TG;
     const int sb = SEG ? (int)(blockIdx.x % p.SB) : 0;
-    const int64_t bid = fx_xcd_block();
-    const int64_t u_lo = SEG ? (int64_t)(blockIdx.x / p.SB) : U * bid / gridDim.x;
-    const int64_t u_hi = SEG ? u_lo + 1 : U * (bid + 1) / gridDim.x;
+    int64_t u_lo, u_hi;
+    if (SEG) { u_lo = (int64_t)(blockIdx.x / p.SB); u_hi = u_lo + 1; }
+    else fx_unit_range(p.TG, p.M, u_lo, u_hi);
     if (u_lo >= u_hi) return;
     const int m_first = (int)(u_lo / p.TG), m_last = (int)((u_hi - 1) / p.TG);
     bool bad = false;

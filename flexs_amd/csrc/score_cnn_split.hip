@@ -29,9 +29,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_cnn_head(HeadArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, sq = lane & 15;
-    const int64_t U = (int64_t)p.M * p.TG;
-    const int64_t bid = fx_xcd_block();
-    const int64_t u_lo = U * bid / gridDim.x, u_hi = U * (bid + 1) / gridDim.x;
+    int64_t u_lo, u_hi;
+    fx_unit_range(p.TG, p.M, u_lo, u_hi);
     if (u_lo >= u_hi) return;
     const int m_first = (int)(u_lo / p.TG), m_last = (int)((u_hi - 1) / p.TG);
     for (int m = m_first; m <= m_last; ++m) {

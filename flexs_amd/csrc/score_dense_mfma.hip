@@ -11,6 +11,8 @@
 //        MFMA, layer 4 the dot.
 // Algorithmic work per sequence per member: L + 4 bytes; 2*MACs FLOP with
 // MACs = L*A*H + 2*H*H + H (MLP) or L*A + H + H*H + H (GE).
+#include <cstring>
+
 #include "fx_common.h"
 #include "mfma_common.h"
 
@@ -22,53 +24,73 @@ struct DenseArgs {
     const float* w[FX_MAX_M];
     float* out;
     unsigned* err;
+    unsigned long long* trace;  // in-kernel timeline (null = off), see fx_stamp
     int64_t N, TG;
     int M, Mtot, m_off;
     int64_t out_sn, out_sm;     // out[n * out_sn + column * out_sm]
     int L, A, rlh;
     int SG1, off_first, off_w1p, off_d2, off_d3, off_db, total_floats;
     int lds_from, lds_floats;   // the LDS image is packed[lds_from .. lds_from + lds_floats)
+    // BT (GlobalEpistasis): first layer as a per-position table indexed by the raw byte, Lpad x 256 floats at LDS offset 0
+    const float* bt[FX_MAX_M];
+    int Lpad;                   // L rounded up to 32 positions (the padding rows are zeros)
+    int validate;               // BT: 1 = member 0 of this launch checks the characters (once per call, not once per member)
 };
+
+// GE first layer as a table indexed by the RAW byte: tab[l][b] = w1[l * A + lut[b]], 0 for bytes outside the alphabet and
+// for the padding rows l >= L.  Built once per (weights, LUT) by the launcher.
+__global__ void k_ge_bytetab(const float* __restrict__ w1, const uint8_t* __restrict__ lut, int L, int A, int Lpad,
+                             float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Lpad * 256) return;
+    const int l = idx >> 8, c = lut[idx & 255];
+    out[idx] = (l < L && c < A) ? w1[l * A + c] : 0.f;
+}
 
 // SLAB (with DG): the HxH blocks are streamed through LDS once per round of WAVES tiles (mma_layer_slab) instead
 // of once per tile per wave; the waves of a workgroup then walk the tiles in lockstep.
-template <int KIND, int A, int HT, int NT, int WAVES, bool G1, bool W1G, bool DG, bool SLAB = false>
+template <int KIND, int A, int HT, int NT, int WAVES, bool G1, bool W1G, bool DG, bool SLAB = false, bool BT = false>
 __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
     static_assert(!SLAB || (DG && NT == 1), "SLAB streams the L2-resident blocks of the one-tile form");
+    static_assert(!BT || (KIND == FX_GE && NT == 1 && !DG && !SLAB), "BT is the GlobalEpistasis byte-table form");
     constexpr int KG = 2;                                       // input tiles per slab
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int g = lane >> 4, sq = lane & 15;
     const int L = p.L;
-    uint8_t* lut_s = reinterpret_cast<uint8_t*>(smem + p.lds_floats);
-    int* next_tile = reinterpret_cast<int*>(smem + p.lds_floats + 64);   // work counter, after the 256-byte LUT
-    f4* slab = reinterpret_cast<f4*>(smem + p.lds_floats + 64 + 4);      // SLAB: 2 x KG*HT KiB
+    float* img = smem + (BT ? p.Lpad * 256 : 0);                         // weight image (after the byte table, if any)
+    uint8_t* lut_s = reinterpret_cast<uint8_t*>(img + p.lds_floats);
+    int* next_tile = reinterpret_cast<int*>(img + p.lds_floats + 64);   // work counter, after the 256-byte LUT
+    f4* slab = reinterpret_cast<f4*>(img + p.lds_floats + 64 + 4);      // SLAB: 2 x KG*HT KiB
+    fx_stamp(p.trace, 0);
     for (int i = tid; i < 64; i += blockDim.x)
         reinterpret_cast<uint32_t*>(lut_s)[i] = reinterpret_cast<const uint32_t*>(p.lut)[i];
 
-    const int64_t U = (int64_t)p.M * p.TG;
-    const int64_t bid = fx_xcd_block();
-    const int64_t u_lo = U * bid / gridDim.x, u_hi = U * (bid + 1) / gridDim.x;
+    int64_t u_lo, u_hi;
+    fx_unit_range(p.TG, p.M, u_lo, u_hi);
     if (u_lo >= u_hi) return;
     const int m_first = (int)(u_lo / p.TG), m_last = (int)((u_hi - 1) / p.TG);
     bool bad = false;
+    unsigned tiles_done = 0;
 
     for (int m = m_first; m <= m_last; ++m) {
         __syncthreads();
         if (tid == 0) *next_tile = 0;
         {
             const f4* src = reinterpret_cast<const f4*>(p.w[m] + p.lds_from);
-            f4* dst = reinterpret_cast<f4*>(smem);
+            f4* dst = reinterpret_cast<f4*>(img);
             fill_lds(dst, src, p.lds_floats / 4);
+            if (BT) fill_lds(reinterpret_cast<f4*>(smem), reinterpret_cast<const f4*>(p.bt[m]), p.Lpad * 64);
         }
         __syncthreads();
+        if (m == m_first) fx_stamp(p.trace, 1);
         // W1G: the (large) first-layer rows stay in global memory / L2, only the HxH blocks sit in LDS
-        const float* w_first = W1G ? p.w[m] + p.off_first : smem + (p.off_first - p.lds_from);
-        const float* w1p = W1G ? p.w[m] + p.off_w1p : smem + (p.off_w1p - p.lds_from);
+        const float* w_first = W1G ? p.w[m] + p.off_first : img + (p.off_first - p.lds_from);
+        const float* w1p = W1G ? p.w[m] + p.off_w1p : img + (p.off_w1p - p.lds_from);
         // DG: HxH blocks too large for LDS (H > 128) stream from L2; the LDS image then ends before them
-        const f4* w_d2 = reinterpret_cast<const f4*>(DG ? p.w[m] + p.off_d2 : smem + (p.off_d2 - p.lds_from));
-        const f4* w_d3 = reinterpret_cast<const f4*>(DG ? p.w[m] + p.off_d3 : smem + (p.off_d3 - p.lds_from));
-        const float* db = DG ? p.w[m] + p.off_db : smem + (p.off_db - p.lds_from);
+        const f4* w_d2 = reinterpret_cast<const f4*>(DG ? p.w[m] + p.off_d2 : img + (p.off_d2 - p.lds_from));
+        const f4* w_d3 = reinterpret_cast<const f4*>(DG ? p.w[m] + p.off_d3 : img + (p.off_d3 - p.lds_from));
+        const float* db = DG ? p.w[m] + p.off_db : img + (p.off_db - p.lds_from);
 
         const int64_t t_lo = (u_lo > (int64_t)m * p.TG ? u_lo : (int64_t)m * p.TG) - (int64_t)m * p.TG;
         const int64_t t_hi = (u_hi < (int64_t)(m + 1) * p.TG ? u_hi : (int64_t)(m + 1) * p.TG) - (int64_t)m * p.TG;
@@ -84,6 +106,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
             if (SLAB ? (t_lo + round * WAVES >= t_hi) : (tg_want >= t_hi)) break;
             const bool live = !SLAB || tg_want < t_hi;
             const int64_t tg = live ? tg_want : t_lo;
+            if (tiles_done == 0) fx_stamp(p.trace, 2);
             asm volatile("" ::: "memory");               // keep LDS weight reads inside the tile loop
             if (DG) asm volatile("" : "+v"(w_d2), "+v"(w_d3), "+v"(db));   // L2-streamed blocks: no hoisted addresses
             int64_t n[NT];
@@ -170,6 +193,37 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                 float s[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) s[nt] = 0.f;
+                if constexpr (BT) {
+                    // Byte-indexed table at LDS offset 0: a position costs one address op (byte * 4 + the lane group's row)
+                    // and one add -- no LUT hop, no clamp, no per-position selects; every trip covers 8 positions of the
+                    // lane group (l = g + 4k) through immediate offsets.  Rows l >= L of the table are zeros, so whole
+                    // trips run to Lpad; the bytes read there belong to the next sequences, which exist for every tile
+                    // but the last ones of the batch (those take the guarded loop).  VALU instructions cost matrix-pipe
+                    // time on gfx950: this is 2 per position instead of ~7.
+                    const uint8_t* rp = row[0] + g;
+                    const char* tb = reinterpret_cast<const char*>(smem) + g * 1024;
+                    const bool safe = (tg * 16 + 16) * (int64_t)L + 32 <= p.N * (int64_t)L;
+                    if (safe) {
+                        for (int t = 0; t < p.Lpad; t += 32) {
+                            int raw[8];
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) raw[k] = rp[t + 4 * k];
+#pragma unroll
+                            for (int k = 0; k < 8; ++k)
+                                s[0] += *reinterpret_cast<const float*>(tb + t * 1024 + k * 4096 + raw[k] * 4);
+                        }
+                    } else {
+                        for (int l = g; l < L; l += 4)
+                            s[0] += *reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + l * 1024 + rp[l - g] * 4);
+                    }
+                    if (p.validate && m == 0) {
+                        // characters outside the alphabet: checked by the first member's units only (every member of
+                        // the launch reads the same bytes)
+                        unsigned seen = 0;
+                        for (int l = g; l < L; l += 4) seen |= lut_s[rp[l - g]];
+                        bad |= seen >= 0x80u;
+                    }
+                } else {
                 // eight positions per trip: the byte loads, LUT reads and table reads of a trip are independent,
                 // so their latencies overlap instead of chaining.  VALU instructions cost matrix-pipe time on gfx950
                 // (DESIGN.md section 4), so the trips that lie entirely inside the sequence run without the `l < L`
@@ -216,6 +270,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                     }
                 }
                 bad |= seen >= 0x80u;
+                }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     s[nt] += __shfl_xor(s[nt], 16);
@@ -251,14 +306,20 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                 for (int nt = 0; nt < NT; ++nt)
                     if (live && n[nt] < p.N) p.out[n[nt] * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y[nt]);
             }
+            if (p.trace) {
+                if (tiles_done == 0) fx_stamp(p.trace, 3);
+                fx_stamp(p.trace, 4);
+                fx_stamp(p.trace, 5, ++tiles_done);
+            }
         }
     }
+    fx_stamp(p.trace, 6);
     if (bad) fx_raise(p.err, FX_ERR_BADCHAR);
 }
 
-template <int KIND, int A, int HT, int NT, int WAVES, bool G1, bool W1G = false, bool DG = false, bool SLAB = false>
+template <int KIND, int A, int HT, int NT, int WAVES, bool G1, bool W1G = false, bool DG = false, bool SLAB = false, bool BT = false>
 int launch_inst(fx_engine* e, const DenseArgs& a, size_t lds_bytes) {
-    auto kern = k_score_dense_mfma<KIND, A, HT, NT, WAVES, G1, W1G, DG, SLAB>;
+    auto kern = k_score_dense_mfma<KIND, A, HT, NT, WAVES, G1, W1G, DG, SLAB, BT>;
     if (SLAB) lds_bytes += (size_t)2 * 2 * HT * 1024;           // two slabs of KG = 2 input tiles
     static bool attr_set[64] = {};
     if (!attr_set[e->device & 63]) {
@@ -289,6 +350,15 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
     int64_t lds_from = (s.kind == FX_MLP && !e->mlp_l1_mfma) ? lay.off_w1p : 0;
     size_t lds = (size_t)(tail - lds_from) * 4 + 256 + 16;
     bool w1_global = false;
+    if constexpr (!DGc) {
+        if (s.kind == FX_GE && a.Lpad > 0) {
+            // byte-indexed first-layer table (a.bt[] prepared by the caller) + the HxH blocks and vectors
+            a.lds_from = (int)lay.off_d3;
+            a.lds_floats = (int)(lay.total_floats - lay.off_d3);
+            return launch_inst<FX_GE, 4, HT_, 1, W, false, false, false, false, true>(
+                e, a, (size_t)a.Lpad * 1024 + (size_t)a.lds_floats * 4 + 256 + 16);
+        }
+    }
     if (lds > (size_t)e->max_lds) {
         // MLP with a large L*A: first-layer rows are gathered from L2 as well
         if (s.kind != FX_MLP) return FX_EUNSUPPORTED;
@@ -337,12 +407,36 @@ int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, con
     if (s.A > 127) return FX_EUNSUPPORTED;                        // the gathers' bad-character test ORs the codes: needs code < 0x80
     DenseArgs a{};
     a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
+    if (int rc = fx_trace_buffer(e, &a.trace)) return rc;
     for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
     a.out_sn = e->planar_stride ? 1 : Mtot; a.out_sm = e->planar_stride ? e->planar_stride : 1;
     a.N = N; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.A = s.A; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4;
     a.SG1 = lay.SG1; a.off_first = (int)lay.off_first; a.off_w1p = (int)lay.off_w1p; a.off_d2 = (int)lay.off_d2; a.off_d3 = (int)lay.off_d3;
     a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
     a.TG = (N + 15) / 16;
+    if (s.kind == FX_GE && e->ge_bytetab && lay.HT <= 8) {
+        const int Lpad = (s.L + 31) / 32 * 32;
+        const size_t need = (size_t)Lpad * 1024 + (size_t)(lay.total_floats - lay.off_d3) * 4 + 256 + 16;
+        if (need <= (size_t)e->max_lds) {
+            for (int m = 0; m < M; ++m) {
+                fx_model* mod = models[m];
+                if (!mod->d_bytetab && hipMalloc(reinterpret_cast<void**>(&mod->d_bytetab), (size_t)Lpad * 1024) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return fx_fail(e, FX_ENOMEM, "hipMalloc of the first-layer byte table failed");
+                }
+                if (!mod->bt_valid || std::memcmp(mod->bt_lut, e->h_lut, 256) != 0) {
+                    hipLaunchKernelGGL(k_ge_bytetab, dim3((unsigned)Lpad), dim3(256), 0, e->stream, mod->d_packed + lay.off_first,
+                                       e->d_lut, s.L, s.A, Lpad, mod->d_bytetab);
+                    FX_HIP(e, hipGetLastError());
+                    std::memcpy(mod->bt_lut, e->h_lut, 256);
+                    mod->bt_valid = true;
+                }
+                a.bt[m] = mod->d_bytetab;
+            }
+            a.Lpad = Lpad;
+            a.validate = (m_off == 0);
+        }
+    }
     switch (lay.HT) {
         case 1: return dispatch_dense<1>(e, s, lay, a);
         case 2: return dispatch_dense<2>(e, s, lay, a);

@@ -80,7 +80,7 @@ int fx_engine_set_stream(fx_engine *e, void *hip_stream);
 int fx_engine_sync(fx_engine *e);
 const char *fx_last_error(fx_engine *e);
 /* Tuning / test knobs: "force_generic" (0/1: use the plain VALU kernels
- * instead of the MFMA ones), "cnn_variant", "cnn_conv1_mfma", "cnn_pair", "cnn_big_units" (work units per CU from which 16-wave workgroups are used, default 12), "cnn_seg" (-1 auto / 0 off / 1 on: waves of a workgroup split one tile's positions, small batches of the 4-letter CNN kernel), "cnn_pair_seg" (-1 auto / 0 off / n workgroups per tile: position-segmented small-batch form of the wide-alphabet CNN kernel), "mlp_l1_mfma", "dense_slab" (1 = MLP / GE hidden layers wider than 128 are staged through LDS slabs by the workgroup), "grid_blocks", "poison_outputs" (test aid: NaN-fill score buffers first).  Unknown key ->
+ * instead of the MFMA ones), "cnn_variant", "cnn_conv1_mfma", "cnn_pair", "cnn_big_units" (work units per CU from which 16-wave workgroups are used, default 12), "cnn_seg" (-1 auto / 0 off / 1 on: waves of a workgroup split one tile's positions, small batches of the 4-letter CNN kernel), "cnn_pair_seg" (-1 auto / 0 off / n workgroups per tile: position-segmented small-batch form of the wide-alphabet CNN kernel), "mlp_l1_mfma", "dense_slab" (1 = MLP / GE hidden layers wider than 128 are staged through LDS slabs by the workgroup), "grid_blocks", "poison_outputs" (test aid: NaN-fill score buffers first), "trace" (profiling aid, see fx_debug_trace_read), "ge_bytetab" (1 = GlobalEpistasis layer 1 gathers from a per-position table indexed by the raw byte, 0 = LUT + code-indexed table).  Unknown key ->
  * FX_EINVAL. */
 int fx_engine_set_option(fx_engine *e, const char *key, int64_t value);
 int fx_engine_get_option(fx_engine *e, const char *key, int64_t *value);
@@ -242,6 +242,16 @@ int fx_debug_pack_layout(int kind, int L, int A, int F, int H, int K, int64_t *o
  * first layers are not issued, the hidden tail tile runs only its real k-steps).  bench.py prices the ISSUED
  * matrix work of a launch with it, beside the algorithmic FLOP of SURVEY.md 8(d).  Negative: no MFMA kernel. */
 int64_t fx_debug_mfma_per_tile(int kind, int L, int A, int F, int H, int K);
+/* Profiling aid: `reps` back-to-back fx_score_planes_dev launches bracketed by one hipEvent pair on the engine's
+ * stream, issued from C (a Python caller cannot enqueue a < 25 us kernel fast enough to keep the GPU busy, which
+ * would be measured as kernel time).  *total_ms = elapsed time of all `reps` launches. */
+int fx_debug_time_score(fx_engine *e, fx_model *const *models, int M, const uint8_t *d_ascii, int64_t N, int L,
+                        const uint8_t lut[256], float *d_planes, int64_t stride, int reps, float *total_ms);
+/* Profiling aid.  With the engine option "trace" = 1 the MFMA scoring kernels stamp an in-kernel timeline of the LAST
+ * launch: row (workgroup b, wave w) = 8 uint64 words at [(b * 16 + w) * 8]: 0 kernel entry, 1 weights resident in
+ * LDS, 2 first tile begins, 3 first tile done, 4 last tile done, 5 tiles processed by the wave, 6 wave exit; times
+ * are ticks of the 100 MHz constant clock, 0 = never reached.  Copies min(cap_words, 1024*16*8) words. */
+int fx_debug_trace_read(fx_engine *e, uint64_t *out, int64_t cap_words);
 int fx_debug_pack_weights(int kind, int L, int A, int F, int H, int K, const float *blob, int64_t n,
                           float *packed, int64_t cap);
 int fx_debug_myers(const uint8_t *a, int la, const uint8_t *b, int lb);

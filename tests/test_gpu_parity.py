@@ -264,6 +264,47 @@ def test_mlp_ge_vs_oracle(eng, kind, L, A, alpha, H, n):
 
 
 # ------------------------------------------------------------------ ensembles
+@pytest.mark.parametrize("L,alpha,H,M,n", [(90, s_utils.AAS, 100, 8, 3001), (90, s_utils.AAS, 100, 1, 17), (8, "TGCA", 100, 3, 1000),
+                                           (33, s_utils.AAS, 50, 2, 100), (100, "UGCA", 128, 1, 257), (64, s_utils.AAS, 16, 5, 16)])
+def test_ge_byte_table_first_layer(eng, L, alpha, H, M, n):
+    """GlobalEpistasis layer 1 gathered from the per-position table indexed by the raw byte (LDS-resident, padding
+    rows of zeros, bytes of the following rows read on full trips) gives the bits of the LUT + code-indexed gather --
+    same summation order -- and the oracle's values; characters are validated by the first member's units only."""
+    A = len(alpha)
+    pairs = [make_native(eng, "ge", L, A, H, seed=1000 + m) for m in range(M)]
+    nms = [p[0] for p in pairs]
+    lut = _native.make_lut(alpha)
+    b, seqs = rand_seqs(n, L, alpha, seed=5)
+    got, _ = eng.score(nms, b, lut)
+    eng.set_option("ge_bytetab", 0)
+    try:
+        old, _ = eng.score(nms, b, lut)
+    finally:
+        eng.set_option("ge_bytetab", 1)
+    assert np.array_equal(got, old)
+    for m in (0, M - 1):
+        assert_scores(got[:, m], ref_np.keras_fitness(seqs, alpha, "ge", pairs[m][1], exact=True), f"ge byte table member {m}")
+    # a bad character anywhere (last row, last position; first row) is reported whichever member's units meet it
+    for r, c in ((n - 1, L - 1), (0, 0), (n // 2, L // 2)):
+        bb = b.copy()
+        bb[r, c] = ord("z")
+        with pytest.raises(ValueError):
+            eng.score(nms, bb, lut)
+    # ... and a NaN weight is NOT a bad character: np.nan_to_num semantics (keras_model.py:77)
+    w = [x.copy() for x in pairs[0][1]]
+    w[0][3, 0] = np.nan
+    nms[0].set_weights(w)
+    out, _ = eng.score(nms, b, lut)                                   # must not raise
+    clean = b[:, 0] != ord(alpha[3])                                   # rows that never touch the NaN weight
+    assert np.array_equal(out[clean], got[clean]) and not np.isnan(out).any()
+    # a different alphabet order for the same model rebuilds the table
+    alpha2 = alpha[::-1]
+    lut2 = _native.make_lut(alpha2)
+    nms[0].set_weights(pairs[0][1])
+    got2, _ = eng.score(nms[:1], b, lut2)
+    assert_scores(got2[:, 0], ref_np.keras_fitness(seqs, alpha2, "ge", pairs[0][1], exact=True), "reversed alphabet")
+
+
 @pytest.mark.parametrize("M", [1, 2, 3, 8, 11, 17])
 def test_ensemble_matrix_and_numpy_order_mean(eng, M):
     L, alpha = 8, "TGCA"

@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""In-kernel timeline of one scoring launch (engine option "trace", fx_debug_trace_read): where a launch's time goes --
+LDS fill, first-tile latency, per-tile time, tail.  GPU box only.  Prints one JSON object per case.
+
+    python tools/trace_probe.py            # the round-2 case list
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from flexs_amd import _native, synth  # noqa: E402
+from flexs_amd.baselines.models.keras_model import Architecture  # noqa: E402
+
+AAS = "ILVAGMFYWEDQNHCRKSTP"
+eng = _native.Engine.get(0)
+TICK_US = 0.01          # 100 MHz constant clock
+
+
+def natives(kind, L, A, H, M, F=0, K=0):
+    arch = Architecture(kind, L, A, H, num_filters=F, kernel_size=K)
+    out = []
+    for m in range(M):
+        nm = _native.NativeModel(eng, {"cnn": 0, "mlp": 1, "ge": 2}[kind], L, A, F, H, K)
+        nm.set_weights(synth.synthetic_weights(arch.shapes(), 1000 + m))
+        out.append(nm)
+    return out
+
+
+def pct(x, q):
+    return float(np.percentile(x, q)) if len(x) else None
+
+
+def trace_case(label, kind, L, alpha, M, N, H=100, F=0, K=0, opts=None):
+    ms_ = natives(kind, L, len(alpha), H, M, F, K)
+    lut = _native.make_lut(alpha)
+    d_in = torch.from_numpy(synth.random_sequence_bytes(N, L, alpha, 0)).cuda()
+    stride = (N + 63) // 64 * 64
+    d_pl = torch.empty((M, stride), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for k_, v_ in (opts or {}).items():
+        eng.set_option(k_, v_)
+    for _ in range(30):
+        eng.score_planes_dev(ms_, d_in.data_ptr(), N, L, lut, d_pl.data_ptr(), stride)
+    eng.sync()
+    eng.timer_start()
+    for _ in range(50):
+        eng.score_planes_dev(ms_, d_in.data_ptr(), N, L, lut, d_pl.data_ptr(), stride)
+    ev_us = eng.timer_stop() / 50 * 1e3
+    eng.set_option("trace", 1)
+    res = []
+    for _ in range(3):
+        eng.score_planes_dev(ms_, d_in.data_ptr(), N, L, lut, d_pl.data_ptr(), stride)
+        eng.sync()
+        t = eng.trace_read().astype(np.int64)
+        entered = t[:, :, 0] > 0
+        t0 = t[:, :, 0][entered].min()
+        worked = t[:, :, 5] > 0
+        end_all = (t[:, :, 6][t[:, :, 6] > 0] - t0) * TICK_US
+        fill = (t[:, :, 1] - t[:, :, 0])[t[:, :, 1] > 0] * TICK_US
+        first_start = (t[:, :, 2][worked] - t0) * TICK_US
+        first_dur = (t[:, :, 3] - t[:, :, 2])[worked] * TICK_US
+        tiles = t[:, :, 5][worked]
+        per_tile = ((t[:, :, 4] - t[:, :, 2])[worked] * TICK_US) / tiles
+        last_done = (t[:, :, 4][worked] - t0) * TICK_US
+        entry = (t[:, :, 0][entered] - t0) * TICK_US
+        res.append({
+            "span_us": float(end_all.max()), "blocks": int(entered.any(axis=1).sum()), "waves_entered": int(entered.sum()),
+            "waves_with_tiles": int(worked.sum()), "tiles_per_working_wave": [int(tiles.min()), float(tiles.mean()), int(tiles.max())],
+            "entry_us_p50_max": [pct(entry, 50), float(entry.max())],
+            "fill_us_p50_max": [pct(fill, 50), float(fill.max())],
+            "first_tile_start_us_p50_max": [pct(first_start, 50), float(first_start.max())],
+            "first_tile_dur_us_p10_p50_p90_max": [pct(first_dur, 10), pct(first_dur, 50), pct(first_dur, 90), float(first_dur.max())],
+            "per_tile_us_p10_p50_p90": [pct(per_tile, 10), pct(per_tile, 50), pct(per_tile, 90)],
+            "last_tile_done_us_p10_p50_p90_max": [pct(last_done, 10), pct(last_done, 50), pct(last_done, 90), float(last_done.max())],
+        })
+    eng.set_option("trace", 0)
+    for k_ in (opts or {}):
+        eng.set_option(k_, {"cnn_big_units": 12, "cnn_seg": -1}.get(k_, 0))
+    out = {"what": label, "event_us_per_launch": ev_us, "trace": res[-1], "span_us_3runs": [r["span_us"] for r in res]}
+    print(json.dumps(out), flush=True)
+    return out
+
+
+if __name__ == "__main__":
+    rows = []
+    for M, N in ((1, 4000), (1, 10_000), (1, 32_768), (3, 10_000), (3, 100_000)):
+        rows.append(trace_case(f"cnn L=8 M={M} N={N}", "cnn", 8, "TGCA", M, N, F=32, K=5))
+    rows.append(trace_case("cnn L=8 M=1 N=10000 big_units=1", "cnn", 8, "TGCA", 1, 10_000, F=32, K=5, opts={"cnn_big_units": 1}))
+    for M, N in ((8, 100_000), (1, 100_000)):
+        rows.append(trace_case(f"ge L=90 M={M} N={N}", "ge", 90, AAS, M, N))
+    rows.append(trace_case("mlp L=14 M=1 N=100000", "mlp", 14, "UGCA", 1, 100_000))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "trace_probe.json"), "w"), indent=1)
