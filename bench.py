@@ -189,19 +189,15 @@ def run_pipelined(ens, d_seq, n, steps, warmup, torch, dist, use_dist, want_even
     return elapsed, host_issue, kern_ms
 
 
-def time_launches(eng, models, d_ptr, n, Lx, lut, d_planes, stride, min_ms=60.0, reps0=20):
-    """Mean duration of one scoring launch: HIP events on the engine's stream around `reps` back-to-back launches,
-    repeated until the bracket covers >= min_ms."""
+def time_launches(eng, models, d_ptr, n, Lx, lut, d_planes, stride, min_ms=60.0, reps0=50):
+    """Mean duration of one scoring launch: one HIP event pair on the engine's stream around `reps` back-to-back
+    launches issued from C (fx_debug_time_score -- Python cannot enqueue a ~15 us kernel fast enough to keep the GPU
+    busy, and the idle gaps would be booked as kernel time), repeated until the bracket covers >= min_ms."""
     natives = [m.native() for m in models]
-    for _ in range(5):
-        eng.score_planes_dev(natives, d_ptr, n, Lx, lut, d_planes.data_ptr(), stride)
-    eng.sync()
+    eng.time_score_planes(natives, d_ptr, n, Lx, lut, d_planes.data_ptr(), stride, 20)      # warm-up
     reps = reps0
     while True:
-        eng.timer_start()
-        for _ in range(reps):
-            eng.score_planes_dev(natives, d_ptr, n, Lx, lut, d_planes.data_ptr(), stride)
-        ms = eng.timer_stop()
+        ms = eng.time_score_planes(natives, d_ptr, n, Lx, lut, d_planes.data_ptr(), stride, reps)
         if ms >= min_ms or reps >= 20000:
             return ms / reps, reps
         reps = int(min(20000, max(reps * 2, reps * min_ms / max(ms, 1e-3) * 1.1)))

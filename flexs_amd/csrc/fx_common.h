@@ -115,8 +115,8 @@ struct fx_model {
     float* d_blob = nullptr;    // device copy, Keras order (generic kernels)
     float* d_packed = nullptr;  // device copy, fragment layout (MFMA kernels)
     bool has_weights = false;
-    // GlobalEpistasis first layer as a per-position table indexed by the RAW byte (score_dense_mfma.hip): Lpad x 256
-    // floats, tab[l][b] = w1[l * A + lut[b]] (0 for bytes outside the alphabet and for the padding rows l >= L);
+    // GlobalEpistasis first layer as a per-position table indexed by the RAW byte (score_dense_mfma.hip): Lpad x 32
+    // floats, tab[l][b - base] = w1[l * A + lut[b]] (0 for bytes outside the alphabet and for the padding rows l >= L);
     // built on the device for the LUT of the call, rebuilt when the weights or the LUT change
     float* d_bytetab = nullptr;
     uint8_t bt_lut[256];

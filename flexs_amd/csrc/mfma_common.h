@@ -78,6 +78,34 @@ __device__ __forceinline__ void fx_unit_range(int64_t TG, int M, int64_t& u_lo, 
     }
 }
 
+// The SIMD this wave runs on (HW_REG_HW_ID bits 5:4).  The matrix pipe belongs to the SIMD, so a workgroup's tiles are
+// dealt to its four SIMDs in equal shares and only the waves OF a SIMD pull from that share (one LDS counter per SIMD):
+// with one shared counter the share of a SIMD was whatever its waves happened to grab -- on mid-size launches (1-2
+// tiles per wave) one SIMD of a CU ran 8 tiles while another ran 4, and the kernel ended with the slowest SIMD
+// (profiles/r2_trace_probe: MLP, 1e5 sequences: median wave done at 35 us, last at 46 us).
+__device__ __forceinline__ int fx_simd_id() { return (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4); }
+
+// Share of the tile range [t_lo, t_hi) that belongs to this wave's SIMD, proportional to the number of the workgroup's
+// waves each SIMD hosts (counted once at kernel start by fx_count_simd_waves: 4-4-4-4 for a 16-wave workgroup, but
+// nothing here depends on the placement -- a SIMD without waves simply gets no tiles).
+struct FxSimdShare { int before, mine, total; };
+__device__ __forceinline__ FxSimdShare fx_count_simd_waves(int* counters, int simd) {
+    // counters: 4 ints of LDS; every thread of the workgroup must call this (two barriers)
+    if (threadIdx.x < 4) counters[threadIdx.x] = 0;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) atomicAdd(&counters[simd], 1);
+    __syncthreads();
+    FxSimdShare r{0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int w = counters[i];
+        if (i < simd) r.before += w;
+        if (i == simd) r.mine = w;
+        r.total += w;
+    }
+    return r;
+}
+
 // Workgroup copy of a member's packed weights into LDS.  Eight 16-byte loads are in flight per thread before the
 // first LDS store, so the ~100 KiB image costs a couple of L2 round trips instead of one per 16 bytes per thread
 // (which is what a plain copy loop compiles to, and what small calls and small batches then mostly wait for).

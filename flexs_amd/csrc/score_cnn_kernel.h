@@ -68,6 +68,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
     int* next_tile = reinterpret_cast<int*>(smem + lds_floats + 64);   // work counter, after the 256-byte LUT
 
     fx_stamp(p.trace, 0);
+    const int simd = fx_simd_id();
+    fx_stamp(p.trace, 7, (unsigned long long)simd + 1);
     for (int i = tid; i < 64; i += blockDim.x)
         reinterpret_cast<uint32_t*>(lut_s)[i] = reinterpret_cast<const uint32_t*>(p.lut)[i];
 
@@ -77,10 +79,11 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
     const int m_first = (int)(u_lo / p.TG), m_last = (int)((u_hi - 1) / p.TG);
     bool bad = false;
     unsigned tiles_done = 0;
+    const FxSimdShare share = fx_count_simd_waves(next_tile, simd);
 
     for (int m = m_first; m <= m_last; ++m) {
         __syncthreads();                                 // previous member's readers are done
-        if (tid == 0) *next_tile = 0;
+        if (tid < 4) next_tile[tid] = 0;
         {
             const f4* src = reinterpret_cast<const f4*>(p.w[m]);
             f4* dst = reinterpret_cast<f4*>(smem);
@@ -100,16 +103,20 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
 
         const int64_t t_lo = (u_lo > (int64_t)m * p.TG ? u_lo : (int64_t)m * p.TG) - (int64_t)m * p.TG;
         const int64_t t_hi = (u_hi < (int64_t)(m + 1) * p.TG ? u_hi : (int64_t)(m + 1) * p.TG) - (int64_t)m * p.TG;
+        // the workgroup's tiles in shares per SIMD (proportional to the waves it hosts); the waves of a SIMD pull from
+        // their share's counter
+        const int64_t s_lo = t_lo + (t_hi - t_lo) * share.before / share.total;
+        const int64_t s_hi = t_lo + (t_hi - t_lo) * (share.before + share.mine) / share.total;
 
-        // waves pull tiles from a block-local counter: a SIMD's two waves then finish within
-        // one tile of each other whatever the split of the block's range was
         for (int64_t seg_tile = t_lo;; ++seg_tile) {
-            int pulled = 0;
+            int64_t tg = seg_tile;                               // SEG: every wave of the workgroup walks the same tiles
             if (!SEG) {
-                if (lane == 0) pulled = atomicAdd(next_tile, 1);
+                int pulled = 0;
+                if (lane == 0) pulled = atomicAdd(&next_tile[simd], 1);
                 pulled = __builtin_amdgcn_readfirstlane(pulled);
+                tg = s_lo + pulled;
+                if (tg >= s_hi) break;
             }
-            const int64_t tg = SEG ? seg_tile : t_lo + pulled;   // SEG: every wave of the workgroup walks the same tiles
             if (tg >= t_hi) break;
             if (tiles_done == 0) fx_stamp(p.trace, 2);
             // ---- this lane's sequences

@@ -31,19 +31,22 @@ struct DenseArgs {
     int L, A, rlh;
     int SG1, off_first, off_w1p, off_d2, off_d3, off_db, total_floats;
     int lds_from, lds_floats;   // the LDS image is packed[lds_from .. lds_from + lds_floats)
-    // BT (GlobalEpistasis): first layer as a per-position table indexed by the raw byte, Lpad x 256 floats at LDS offset 0
+    // BT (GlobalEpistasis): first layer as a per-position table indexed by (raw byte - bt_base), Lpad x 32 floats at LDS offset 0
     const float* bt[FX_MAX_M];
     int Lpad;                   // L rounded up to 32 positions (the padding rows are zeros)
-    int validate;               // BT: 1 = member 0 of this launch checks the characters (once per call, not once per member)
+    int bt_base;                // smallest byte of the alphabet; every letter lies in [bt_base, bt_base + 32)
+    int validate;               // BT: 1 = this launch checks the characters, each tile by ONE of its members (once per call, not once per member)
 };
 
-// GE first layer as a table indexed by the RAW byte: tab[l][b] = w1[l * A + lut[b]], 0 for bytes outside the alphabet and
-// for the padding rows l >= L.  Built once per (weights, LUT) by the launcher.
-__global__ void k_ge_bytetab(const float* __restrict__ w1, const uint8_t* __restrict__ lut, int L, int A, int Lpad,
+// GE first layer as a table indexed by the RAW byte: tab[l][b - base] = w1[l * A + lut[b]] for the 32 byte values from
+// `base` on (every FLEXS alphabet spans fewer than 32 code points), 0 for bytes outside the alphabet and for the padding
+// rows l >= L.  Built once per (weights, LUT) by the launcher.
+__global__ void k_ge_bytetab(const float* __restrict__ w1, const uint8_t* __restrict__ lut, int L, int A, int Lpad, int base,
                              float* __restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= Lpad * 256) return;
-    const int l = idx >> 8, c = lut[idx & 255];
+    if (idx >= Lpad * 32) return;
+    const int l = idx >> 5, b = base + (idx & 31);
+    const int c = b < 256 ? lut[b] : 0xFF;
     out[idx] = (l < L && c < A) ? w1[l * A + c] : 0.f;
 }
 
@@ -58,11 +61,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int g = lane >> 4, sq = lane & 15;
     const int L = p.L;
-    float* img = smem + (BT ? p.Lpad * 256 : 0);                         // weight image (after the byte table, if any)
+    float* img = smem + (BT ? p.Lpad * 32 : 0);                          // weight image (after the byte table, if any)
     uint8_t* lut_s = reinterpret_cast<uint8_t*>(img + p.lds_floats);
     int* next_tile = reinterpret_cast<int*>(img + p.lds_floats + 64);   // work counter, after the 256-byte LUT
     f4* slab = reinterpret_cast<f4*>(img + p.lds_floats + 64 + 4);      // SLAB: 2 x KG*HT KiB
     fx_stamp(p.trace, 0);
+    const int simd = fx_simd_id();
+    fx_stamp(p.trace, 7, (unsigned long long)simd + 1);
     for (int i = tid; i < 64; i += blockDim.x)
         reinterpret_cast<uint32_t*>(lut_s)[i] = reinterpret_cast<const uint32_t*>(p.lut)[i];
 
@@ -72,15 +77,16 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
     const int m_first = (int)(u_lo / p.TG), m_last = (int)((u_hi - 1) / p.TG);
     bool bad = false;
     unsigned tiles_done = 0;
+    const FxSimdShare share = fx_count_simd_waves(next_tile, simd);
 
     for (int m = m_first; m <= m_last; ++m) {
         __syncthreads();
-        if (tid == 0) *next_tile = 0;
+        if (tid < 4) next_tile[tid] = 0;
         {
             const f4* src = reinterpret_cast<const f4*>(p.w[m] + p.lds_from);
             f4* dst = reinterpret_cast<f4*>(img);
             fill_lds(dst, src, p.lds_floats / 4);
-            if (BT) fill_lds(reinterpret_cast<f4*>(smem), reinterpret_cast<const f4*>(p.bt[m]), p.Lpad * 64);
+            if (BT) fill_lds(reinterpret_cast<f4*>(smem), reinterpret_cast<const f4*>(p.bt[m]), p.Lpad * 8);
         }
         __syncthreads();
         if (m == m_first) fx_stamp(p.trace, 1);
@@ -95,15 +101,21 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
         const int64_t t_lo = (u_lo > (int64_t)m * p.TG ? u_lo : (int64_t)m * p.TG) - (int64_t)m * p.TG;
         const int64_t t_hi = (u_hi < (int64_t)(m + 1) * p.TG ? u_hi : (int64_t)(m + 1) * p.TG) - (int64_t)m * p.TG;
 
-        for (int64_t round = 0;; ++round) {              // waves pull tiles from a block-local counter
-            int pulled = 0;
-            if (!SLAB) {
-                if (lane == 0) pulled = atomicAdd(next_tile, 1);
-                pulled = __builtin_amdgcn_readfirstlane(pulled);
-            }
+        // the workgroup's tiles in shares per SIMD (proportional to the waves it hosts); the waves of a SIMD pull from
+        // their share's counter
+        const int64_t s_lo = t_lo + (t_hi - t_lo) * share.before / share.total;
+        const int64_t s_hi = t_lo + (t_hi - t_lo) * (share.before + share.mine) / share.total;
+        for (int64_t round = 0;; ++round) {
             // SLAB: lockstep rounds of WAVES tiles; waves without a tile in the last round run along on tile 0
-            const int64_t tg_want = SLAB ? t_lo + round * WAVES + (tid >> 6) : t_lo + pulled;
-            if (SLAB ? (t_lo + round * WAVES >= t_hi) : (tg_want >= t_hi)) break;
+            int64_t tg_want = t_lo + round * WAVES + (tid >> 6);
+            if (!SLAB) {
+                int pulled = 0;
+                if (lane == 0) pulled = atomicAdd(&next_tile[simd], 1);
+                pulled = __builtin_amdgcn_readfirstlane(pulled);
+                tg_want = s_lo + pulled;
+                if (tg_want >= s_hi) break;
+            }
+            if (SLAB && t_lo + round * WAVES >= t_hi) break;
             const bool live = !SLAB || tg_want < t_hi;
             const int64_t tg = live ? tg_want : t_lo;
             if (tiles_done == 0) fx_stamp(p.trace, 2);
@@ -194,15 +206,20 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) s[nt] = 0.f;
                 if constexpr (BT) {
-                    // Byte-indexed table at LDS offset 0: a position costs one address op (byte * 4 + the lane group's row)
-                    // and one add -- no LUT hop, no clamp, no per-position selects; every trip covers 8 positions of the
-                    // lane group (l = g + 4k) through immediate offsets.  Rows l >= L of the table are zeros, so whole
-                    // trips run to Lpad; the bytes read there belong to the next sequences, which exist for every tile
-                    // but the last ones of the batch (those take the guarded loop).  VALU instructions cost matrix-pipe
-                    // time on gfx950: this is 2 per position instead of ~7.
+                    // Byte-indexed table at LDS offset 0 (128 bytes per position, index = byte - bt_base folded into the
+                    // lane's table pointer): a position costs one address op and one add -- no LUT hop, no clamp, no
+                    // per-position selects; every trip covers 8 positions of the lane group (l = g + 4k) through
+                    // immediate offsets.  Rows l >= L of the table are zeros, so whole trips run to Lpad; the bytes
+                    // read there belong to the next sequences, which exist for every tile but the last ones of the
+                    // batch (those take the guarded loop).  VALU instructions cost matrix-pipe time on gfx950: this is
+                    // 2 per position instead of ~7.  Characters outside the alphabet are checked
+                    // through the LUT by ONE member's unit per tile (all members read the same bytes): a byte outside
+                    // [bt_base, bt_base + 32) reads a neighbouring row or nothing, and the call fails anyway.
                     const uint8_t* rp = row[0] + g;
-                    const char* tb = reinterpret_cast<const char*>(smem) + g * 1024;
+                    const char* tb = reinterpret_cast<const char*>(smem) + g * 128 - p.bt_base * 4;
                     const bool safe = (tg * 16 + 16) * (int64_t)L + 32 <= p.N * (int64_t)L;
+                    const bool check = p.validate && (int)(tg % p.M) == m;
+                    unsigned seen = 0;
                     if (safe) {
                         for (int t = 0; t < p.Lpad; t += 32) {
                             int raw[8];
@@ -210,19 +227,24 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                             for (int k = 0; k < 8; ++k) raw[k] = rp[t + 4 * k];
 #pragma unroll
                             for (int k = 0; k < 8; ++k)
-                                s[0] += *reinterpret_cast<const float*>(tb + t * 1024 + k * 4096 + raw[k] * 4);
+                                s[0] += *reinterpret_cast<const float*>(tb + t * 128 + k * 512 + raw[k] * 4);
+                            if (check) {
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) {
+                                    const unsigned c = lut_s[raw[k]];
+                                    seen |= (t + 4 * k + g < L) ? c : 0u;
+                                }
+                            }
                         }
                     } else {
-                        for (int l = g; l < L; l += 4)
-                            s[0] += *reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + l * 1024 + rp[l - g] * 4);
+                        for (int l = g; l < L; l += 4) {
+                            const int raw = rp[l - g];
+                            s[0] += *reinterpret_cast<const float*>(tb + (l - g) * 128 + raw * 4);
+                            seen |= lut_s[raw];
+                        }
+                        if (!check) seen = 0;
                     }
-                    if (p.validate && m == 0) {
-                        // characters outside the alphabet: checked by the first member's units only (every member of
-                        // the launch reads the same bytes)
-                        unsigned seen = 0;
-                        for (int l = g; l < L; l += 4) seen |= lut_s[rp[l - g]];
-                        bad |= seen >= 0x80u;
-                    }
+                    bad |= seen >= 0x80u;
                 } else {
                 // eight positions per trip: the byte loads, LUT reads and table reads of a trip are independent,
                 // so their latencies overlap instead of chaining.  VALU instructions cost matrix-pipe time on gfx950
@@ -356,7 +378,7 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
             a.lds_from = (int)lay.off_d3;
             a.lds_floats = (int)(lay.total_floats - lay.off_d3);
             return launch_inst<FX_GE, 4, HT_, 1, W, false, false, false, false, true>(
-                e, a, (size_t)a.Lpad * 1024 + (size_t)a.lds_floats * 4 + 256 + 16);
+                e, a, (size_t)a.Lpad * 128 + (size_t)a.lds_floats * 4 + 256 + 16);
         }
     }
     if (lds > (size_t)e->max_lds) {
@@ -415,18 +437,21 @@ int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, con
     a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
     a.TG = (N + 15) / 16;
     if (s.kind == FX_GE && e->ge_bytetab && lay.HT <= 8) {
+        int lo = 256, hi = -1;                            // the alphabet's byte range
+        for (int b = 0; b < 256; ++b)
+            if (e->h_lut[b] != 0xFF) { lo = b < lo ? b : lo; hi = b; }
         const int Lpad = (s.L + 31) / 32 * 32;
-        const size_t need = (size_t)Lpad * 1024 + (size_t)(lay.total_floats - lay.off_d3) * 4 + 256 + 16;
-        if (need <= (size_t)e->max_lds) {
+        const size_t need = (size_t)Lpad * 128 + (size_t)(lay.total_floats - lay.off_d3) * 4 + 256 + 16;
+        if (hi >= lo && hi - lo < 32 && need <= (size_t)e->max_lds) {
             for (int m = 0; m < M; ++m) {
                 fx_model* mod = models[m];
-                if (!mod->d_bytetab && hipMalloc(reinterpret_cast<void**>(&mod->d_bytetab), (size_t)Lpad * 1024) != hipSuccess) {
+                if (!mod->d_bytetab && hipMalloc(reinterpret_cast<void**>(&mod->d_bytetab), (size_t)Lpad * 128) != hipSuccess) {
                     (void)hipGetLastError();
                     return fx_fail(e, FX_ENOMEM, "hipMalloc of the first-layer byte table failed");
                 }
                 if (!mod->bt_valid || std::memcmp(mod->bt_lut, e->h_lut, 256) != 0) {
-                    hipLaunchKernelGGL(k_ge_bytetab, dim3((unsigned)Lpad), dim3(256), 0, e->stream, mod->d_packed + lay.off_first,
-                                       e->d_lut, s.L, s.A, Lpad, mod->d_bytetab);
+                    hipLaunchKernelGGL(k_ge_bytetab, dim3((unsigned)(Lpad * 32 + 255) / 256), dim3(256), 0, e->stream,
+                                       mod->d_packed + lay.off_first, e->d_lut, s.L, s.A, Lpad, lo, mod->d_bytetab);
                     FX_HIP(e, hipGetLastError());
                     std::memcpy(mod->bt_lut, e->h_lut, 256);
                     mod->bt_valid = true;
@@ -434,6 +459,7 @@ int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, con
                 a.bt[m] = mod->d_bytetab;
             }
             a.Lpad = Lpad;
+            a.bt_base = lo;
             a.validate = (m_off == 0);
         }
     }

@@ -48,10 +48,7 @@ def trace_case(label, kind, L, alpha, M, N, H=100, F=0, K=0, opts=None):
     for _ in range(30):
         eng.score_planes_dev(ms_, d_in.data_ptr(), N, L, lut, d_pl.data_ptr(), stride)
     eng.sync()
-    eng.timer_start()
-    for _ in range(50):
-        eng.score_planes_dev(ms_, d_in.data_ptr(), N, L, lut, d_pl.data_ptr(), stride)
-    ev_us = eng.timer_stop() / 50 * 1e3
+    ev_us = eng.time_score_planes(ms_, d_in.data_ptr(), N, L, lut, d_pl.data_ptr(), stride, 300) / 300 * 1e3
     eng.set_option("trace", 1)
     res = []
     for _ in range(3):
@@ -81,7 +78,7 @@ def trace_case(label, kind, L, alpha, M, N, H=100, F=0, K=0, opts=None):
         })
     eng.set_option("trace", 0)
     for k_ in (opts or {}):
-        eng.set_option(k_, {"cnn_big_units": 12, "cnn_seg": -1}.get(k_, 0))
+        eng.set_option(k_, {"cnn_big_units": 12, "cnn_seg": -1, "ge_bytetab": 1}.get(k_, 0))
     out = {"what": label, "event_us_per_launch": ev_us, "trace": res[-1], "span_us_3runs": [r["span_us"] for r in res]}
     print(json.dumps(out), flush=True)
     return out
@@ -94,6 +91,7 @@ if __name__ == "__main__":
     rows.append(trace_case("cnn L=8 M=1 N=10000 big_units=1", "cnn", 8, "TGCA", 1, 10_000, F=32, K=5, opts={"cnn_big_units": 1}))
     for M, N in ((8, 100_000), (1, 100_000)):
         rows.append(trace_case(f"ge L=90 M={M} N={N}", "ge", 90, AAS, M, N))
+        rows.append(trace_case(f"ge L=90 M={M} N={N} ge_bytetab=0", "ge", 90, AAS, M, N, opts={"ge_bytetab": 0}))
     rows.append(trace_case("mlp L=14 M=1 N=100000", "mlp", 14, "UGCA", 1, 100_000))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "trace_probe.json"), "w"), indent=1)
