@@ -322,8 +322,8 @@ class Engine:
         return ms.value
 
     def trace_read(self) -> np.ndarray:
-        """(1024 workgroups, 16 waves, 8 slots) uint64 in-kernel timeline of the last traced launch (option "trace")."""
-        out = np.zeros((1024, 16, 8), np.uint64)
+        """(1024 workgroups, 16 waves, 16 slots) uint64 in-kernel timeline of the last traced launch (option "trace")."""
+        out = np.zeros((1024, 16, 16), np.uint64)
         self.check(self._lib.fx_debug_trace_read(self.handle, _ptr(out), out.size))
         return out
 

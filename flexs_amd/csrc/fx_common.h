@@ -149,7 +149,7 @@ int fx_scratch(fx_engine* e, int slot, size_t bytes, void** out);
 int fx_pinned(fx_engine* e, int slot, size_t bytes, void** out);
 int fx_upload_lut(fx_engine* e, const uint8_t lut[256]);
 // device timeline buffer for the launch about to be enqueued (zeroed), or nullptr when the "trace" option is off
-#define FX_TRACE_BYTES ((size_t)1024 * 16 * 8 * 8)
+#define FX_TRACE_BYTES ((size_t)1024 * 16 * 16 * 8)
 int fx_trace_buffer(fx_engine* e, unsigned long long** out);
 
 // Deferred error word: mapped pinned HOST memory (read by the host right after the stream

@@ -86,15 +86,15 @@ __device__ __forceinline__ void fx_unit_range(int64_t TG, int M, int64_t& u_lo, 
 __device__ __forceinline__ int fx_simd_id() { return (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4); }
 
 // Share of the tile range [t_lo, t_hi) that belongs to this wave's SIMD, proportional to the number of the workgroup's
-// waves each SIMD hosts (counted once at kernel start by fx_count_simd_waves: 4-4-4-4 for a 16-wave workgroup, but
+// waves each SIMD hosts (counted once at kernel start, fx_count_simd_wave: 4-4-4-4 for a 16-wave workgroup, but
 // nothing here depends on the placement -- a SIMD without waves simply gets no tiles).
 struct FxSimdShare { int before, mine, total; };
-__device__ __forceinline__ FxSimdShare fx_count_simd_waves(int* counters, int simd) {
-    // counters: 4 ints of LDS; every thread of the workgroup must call this (two barriers)
-    if (threadIdx.x < 4) counters[threadIdx.x] = 0;
-    __syncthreads();
+// counters: 4 ints of LDS that were zeroed before the workgroup's last barrier; the caller puts one barrier between
+// fx_count_simd_wave (every wave) and fx_simd_share (two existing barriers of the kernels are used, none is added)
+__device__ __forceinline__ void fx_count_simd_wave(int* counters, int simd) {
     if ((threadIdx.x & 63) == 0) atomicAdd(&counters[simd], 1);
-    __syncthreads();
+}
+__device__ __forceinline__ FxSimdShare fx_simd_share(const int* counters, int simd) {
     FxSimdShare r{0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -124,7 +124,7 @@ __device__ __forceinline__ void fill_lds(f4* __restrict__ dst, const f4* __restr
 
 // In-kernel timeline (engine option "trace", debugging / profiling only): the first lane of every wave stamps the
 // constant-rate wall clock (100 MHz) into slot `slot` of its row; `t` is null in normal operation.
-#define FX_TRACE_SLOTS 8
+#define FX_TRACE_SLOTS 16
 #define FX_TRACE_WAVES 16
 __device__ __forceinline__ void fx_stamp(unsigned long long* t, int slot, unsigned long long v = ~0ull) {
     if (t && (threadIdx.x & 63) == 0)

@@ -65,13 +65,15 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
     const int L = p.L, L1 = L1S > 0 ? L1S : L - K + 1;
     const int lds_floats = DENSE_LDS ? p.total_floats : p.conv_floats;
     uint8_t* lut_s = reinterpret_cast<uint8_t*>(smem + lds_floats);
-    int* next_tile = reinterpret_cast<int*>(smem + lds_floats + 64);   // work counter, after the 256-byte LUT
+    int* next_tile = reinterpret_cast<int*>(smem + lds_floats + 64);   // 4 work counters (one per SIMD), after the 256-byte LUT
+    int* simd_waves = next_tile + 4;                                   // 4 wave counts (workgroup's waves per SIMD)
 
     fx_stamp(p.trace, 0);
     const int simd = fx_simd_id();
     fx_stamp(p.trace, 7, (unsigned long long)simd + 1);
     for (int i = tid; i < 64; i += blockDim.x)
         reinterpret_cast<uint32_t*>(lut_s)[i] = reinterpret_cast<const uint32_t*>(p.lut)[i];
+    if (tid < 4) simd_waves[tid] = 0;
 
     int64_t u_lo, u_hi;
     fx_unit_range(p.TG, p.M, u_lo, u_hi);
@@ -79,17 +81,19 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
     const int m_first = (int)(u_lo / p.TG), m_last = (int)((u_hi - 1) / p.TG);
     bool bad = false;
     unsigned tiles_done = 0;
-    const FxSimdShare share = fx_count_simd_waves(next_tile, simd);
+    FxSimdShare share{0, 1, 1};
 
     for (int m = m_first; m <= m_last; ++m) {
         __syncthreads();                                 // previous member's readers are done
         if (tid < 4) next_tile[tid] = 0;
+        if (m == m_first) fx_count_simd_wave(simd_waves, simd);      // (zeroed before the barrier above)
         {
             const f4* src = reinterpret_cast<const f4*>(p.w[m]);
             f4* dst = reinterpret_cast<f4*>(smem);
             fill_lds(dst, src, lds_floats / 4);
         }
         __syncthreads();
+        if (m == m_first) share = fx_simd_share(simd_waves, simd);
         if (m == m_first) fx_stamp(p.trace, 1);
         const f4* w_first = reinterpret_cast<const f4*>(smem + p.off_first);
         const f4* w_c2 = reinterpret_cast<const f4*>(smem + p.off_c2);
@@ -142,6 +146,14 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                     if (c == 0xFF) { bad = true; c = 0; }
                     cw[RING ? j : j + 1][nt] = c;         // (shifting form: moved down at the top of step 0)
                 }
+            // Look-ahead queue of raw sequence bytes (generic-length form): the byte a step consumes was requested PF
+            // steps earlier, so its L2 / HBM latency is off the step's critical path.  A lone wave (small batches:
+            // one tile per SIMD) otherwise pays one global round trip per position (profiles/r2_trace_probe: 8.4 us
+            // for the conv part of an L = 8 tile whose MFMAs take 5.5 us).  The unrolled forms (L1S > 0) run with
+            // four waves per SIMD, which hide it, and have no registers to spare.
+            constexpr int PF = (L1S > 0) ? 1 : (RING ? 3 : 2);
+            static_assert(L1S > 0 || !RING || UN % PF == 0, "ring slots of the byte queue must be compile-time constants");
+            int rq[PF][NT];
             f4 win1[K][FT][NT], win2[K3][FT][NT], gmax[FT][NT];
 #pragma unroll
             for (int j = 0; j < K; ++j)
@@ -180,6 +192,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                     if (c == 0xFF) { bad = true; c = 0; }
                     cw[j][0] = c;
                 }
+            }
+            if (L1S == 0) {
+#pragma unroll
+                for (int q = 0; q < PF; ++q)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        rq[q][nt] = (s_first + K - 1 + q < L) ? (int)row[nt][s_first + K - 1 + q] : 0;
             }
             for (int s0 = s_first; s0 < s_stop; s0 += UN) {
 #pragma unroll
@@ -222,7 +241,19 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                 if (s < L1) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        int c = lut_s[row[nt][s + K - 1]];
+                        int raw;
+                        if (L1S > 0) raw = row[nt][s + K - 1];
+                        else {
+                            // oldest entry of the look-ahead queue; its slot takes the byte PF positions further on
+                            const int slot = RING ? u % PF : 0;
+                            raw = rq[slot][nt];
+                            if (!RING) {
+#pragma unroll
+                                for (int q = 0; q + 1 < PF; ++q) rq[q][nt] = rq[q + 1][nt];
+                            }
+                            if (s + K - 1 + PF < L) rq[RING ? slot : PF - 1][nt] = row[nt][s + K - 1 + PF];
+                        }
+                        int c = lut_s[raw];
                         if (c == 0xFF) { bad = true; c = 0; }
                         cw[FX_CW(K - 1)][nt] = c;
                     }
@@ -325,7 +356,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
 
             if (SEG) {
                 // ---- segment maxima -> LDS; wave 0 folds them and carries on with the dense head
-                f4* seg_slot = reinterpret_cast<f4*>(smem + lds_floats + 64 + 4);   // after the LUT and the work counter
+                f4* seg_slot = reinterpret_cast<f4*>(smem + lds_floats + 64 + 8);   // after the LUT and the counters
                 __syncthreads();                                  // previous tile's readers are done
 #pragma unroll
                 for (int t = 0; t < FT; ++t) seg_slot[((tid >> 6) * FT + t) * 64 + lane] = gmax[t][0];
@@ -343,6 +374,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                 continue;
             }
             // ---- dense head: F -> H relu -> H relu -> (dropout inactive) -> 1
+            if (tiles_done == 0) fx_stamp(p.trace, 8);
             asm volatile("" ::: "memory");
             if (!DENSE_LDS) {
                 // weights streamed from L2: launder the base pointer per tile, otherwise LICM hoists the
@@ -353,6 +385,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
             init_bias<HT, NT>(db, h1, g);
             mma_layer<FT, HT, NT, PRIO>(w_d1, gmax, h1, lane);
             relu_tiles<HT, NT>(h1);
+            if (tiles_done == 0) fx_stamp(p.trace, 9);
             init_bias<HT, NT>(db + 16 * HT, h2, g);
             mma_layer<HT, HT, NT, PRIO>(w_d2, h1, h2, lane, p.rlh);
             relu_tiles<HT, NT>(h2);

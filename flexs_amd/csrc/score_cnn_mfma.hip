@@ -87,7 +87,7 @@ int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const
     a.off_cb = (int)lay.off_cb; a.off_w1p = (int)lay.off_w1p; a.conv_floats = (int)lay.conv_floats; a.off_d1 = (int)lay.off_d1;
     a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
 
-    const size_t full = (size_t)lay.total_floats * 4 + 256 + 16, conv_only = (size_t)lay.conv_floats * 4 + 256 + 16;
+    const size_t full = (size_t)lay.total_floats * 4 + 256 + 32, conv_only = (size_t)lay.conv_floats * 4 + 256 + 32;
     if (lay.FT == 1) {
         // num_filters <= 16: one channel tile (canonical hidden width and kernel size only)
         if (full > (size_t)e->max_lds || e->cnn_conv1_mfma) return FX_EUNSUPPORTED;

@@ -63,13 +63,15 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
     const int L = p.L;
     float* img = smem + (BT ? p.Lpad * 32 : 0);                          // weight image (after the byte table, if any)
     uint8_t* lut_s = reinterpret_cast<uint8_t*>(img + p.lds_floats);
-    int* next_tile = reinterpret_cast<int*>(img + p.lds_floats + 64);   // work counter, after the 256-byte LUT
-    f4* slab = reinterpret_cast<f4*>(img + p.lds_floats + 64 + 4);      // SLAB: 2 x KG*HT KiB
+    int* next_tile = reinterpret_cast<int*>(img + p.lds_floats + 64);   // 4 work counters (one per SIMD), after the 256-byte LUT
+    int* simd_waves = next_tile + 4;                                    // 4 wave counts (workgroup's waves per SIMD)
+    f4* slab = reinterpret_cast<f4*>(img + p.lds_floats + 64 + 8);      // SLAB: 2 x KG*HT KiB
     fx_stamp(p.trace, 0);
     const int simd = fx_simd_id();
     fx_stamp(p.trace, 7, (unsigned long long)simd + 1);
     for (int i = tid; i < 64; i += blockDim.x)
         reinterpret_cast<uint32_t*>(lut_s)[i] = reinterpret_cast<const uint32_t*>(p.lut)[i];
+    if (tid < 4) simd_waves[tid] = 0;
 
     int64_t u_lo, u_hi;
     fx_unit_range(p.TG, p.M, u_lo, u_hi);
@@ -77,11 +79,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
     const int m_first = (int)(u_lo / p.TG), m_last = (int)((u_hi - 1) / p.TG);
     bool bad = false;
     unsigned tiles_done = 0;
-    const FxSimdShare share = fx_count_simd_waves(next_tile, simd);
+    FxSimdShare share{0, 1, 1};
 
     for (int m = m_first; m <= m_last; ++m) {
         __syncthreads();
         if (tid < 4) next_tile[tid] = 0;
+        if (m == m_first) fx_count_simd_wave(simd_waves, simd);      // (zeroed before the barrier above)
         {
             const f4* src = reinterpret_cast<const f4*>(p.w[m] + p.lds_from);
             f4* dst = reinterpret_cast<f4*>(img);
@@ -89,6 +92,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
             if (BT) fill_lds(reinterpret_cast<f4*>(smem), reinterpret_cast<const f4*>(p.bt[m]), p.Lpad * 8);
         }
         __syncthreads();
+        if (m == m_first) share = fx_simd_share(simd_waves, simd);
         if (m == m_first) fx_stamp(p.trace, 1);
         // W1G: the (large) first-layer rows stay in global memory / L2, only the HxH blocks sit in LDS
         const float* w_first = W1G ? p.w[m] + p.off_first : img + (p.off_first - p.lds_from);
@@ -138,23 +142,31 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                     // one-hot layer == sum of L kernel rows selected by the codes: LDS gather + VALU adds
                     unsigned seen1 = 0;
                     const unsigned amax1 = (unsigned)p.A - 1u;
-                    for (int l0 = 0; l0 < L; l0 += 4) {
-                        asm volatile("" ::: "memory");
+                    // the sequence bytes of 16 positions are requested at once (one global round trip per chunk, not
+                    // one per four positions: a wave alone on its SIMD waits for every one of them)
+                    for (int c0 = 0; c0 < L; c0 += 16) {
+                        int raw[NT][16];
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            int raw[4];
+                        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) raw[k] = row[nt][l0 + k < L ? l0 + k : 0];   // independent loads
+                            for (int k = 0; k < 16; ++k) raw[nt][k] = row[nt][c0 + k < L ? c0 + k : 0];   // independent loads
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                const int l = l0 + k;
-                                if (l < L) {
-                                    const unsigned c = lut_s[raw[k]];
-                                    seen1 |= c;                       // a code is < A <= 127, or 0xFF: tested once per tile
-                                    const unsigned ci = c < amax1 ? c : amax1;
-                                    const float* rowp = w1p + (l * p.A + ci) * (16 * HT) + 4 * g;
+                        for (int l0 = 0; l0 < 16; l0 += 4) {
+                            if (c0 + l0 >= L) break;
+                            asm volatile("" ::: "memory");
 #pragma unroll
-                                    for (int mo = 0; mo < HT; ++mo) h[mo][nt] += *reinterpret_cast<const f4*>(rowp + 16 * mo);
+                            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    const int l = c0 + l0 + k;
+                                    if (l < L) {
+                                        const unsigned c = lut_s[raw[nt][l0 + k]];
+                                        seen1 |= c;                       // a code is < A <= 127, or 0xFF: tested once per tile
+                                        const unsigned ci = c < amax1 ? c : amax1;
+                                        const float* rowp = w1p + (l * p.A + ci) * (16 * HT) + 4 * g;
+#pragma unroll
+                                        for (int mo = 0; mo < HT; ++mo) h[mo][nt] += *reinterpret_cast<const f4*>(rowp + 16 * mo);
+                                    }
                                 }
                             }
                         }
@@ -187,12 +199,14 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                     }
                 }
                 relu_tiles<HT, NT>(h);
+                if (tiles_done == 0) fx_stamp(p.trace, 8);
                 // ---- layers 2, 3
                 f4 h2[HT][NT];
                 init_bias<HT, NT>(db + 16 * HT, h2, g);
                 if constexpr (SLAB) mma_layer_slab<HT, HT, KG, WAVES * 64>(w_d2, slab, h, h2, lane, p.rlh);
                 else mma_layer<HT, HT, NT>(w_d2, h, h2, lane, p.rlh);
                 relu_tiles<HT, NT>(h2);
+                if (tiles_done == 0) fx_stamp(p.trace, 9);
                 asm volatile("" ::: "memory");
                 init_bias<HT, NT>(db + 32 * HT, h, g);
                 if constexpr (SLAB) mma_layer_slab<HT, HT, KG, WAVES * 64>(w_d3, slab, h2, h, lane, p.rlh);
@@ -221,20 +235,30 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                     const bool check = p.validate && (int)(tg % p.M) == m;
                     unsigned seen = 0;
                     if (safe) {
-                        for (int t = 0; t < p.Lpad; t += 32) {
-                            int raw[8];
+                        // four trips (32 bytes per lane) requested at once: one global round trip per 128 positions
+                        for (int t0 = 0; t0 < p.Lpad; t0 += 128) {
+                            int raw[4][8];
 #pragma unroll
-                            for (int k = 0; k < 8; ++k) raw[k] = rp[t + 4 * k];
+                            for (int tt = 0; tt < 4; ++tt)
+                                if (t0 + 32 * tt < p.Lpad) {
 #pragma unroll
-                            for (int k = 0; k < 8; ++k)
-                                s[0] += *reinterpret_cast<const float*>(tb + t * 128 + k * 512 + raw[k] * 4);
-                            if (check) {
-#pragma unroll
-                                for (int k = 0; k < 8; ++k) {
-                                    const unsigned c = lut_s[raw[k]];
-                                    seen |= (t + 4 * k + g < L) ? c : 0u;
+                                    for (int k = 0; k < 8; ++k) raw[tt][k] = rp[t0 + 32 * tt + 4 * k];
                                 }
-                            }
+#pragma unroll
+                            for (int tt = 0; tt < 4; ++tt)
+                                if (t0 + 32 * tt < p.Lpad) {
+                                    const int t = t0 + 32 * tt;
+#pragma unroll
+                                    for (int k = 0; k < 8; ++k)
+                                        s[0] += *reinterpret_cast<const float*>(tb + t * 128 + k * 512 + raw[tt][k] * 4);
+                                    if (check) {
+#pragma unroll
+                                        for (int k = 0; k < 8; ++k) {
+                                            const unsigned c = lut_s[raw[tt][k]];
+                                            seen |= (t + 4 * k + g < L) ? c : 0u;
+                                        }
+                                    }
+                                }
                         }
                     } else {
                         for (int l = g; l < L; l += 4) {
@@ -316,6 +340,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                         h2[mo][nt] = v;
                     }
                 }
+                if (tiles_done == 0) fx_stamp(p.trace, 8);
                 // ---- layer 3 (HxH MFMA), layer 4 (dot)
                 init_bias<HT, NT>(db + 4 + 32 * HT, h, g);
                 if constexpr (SLAB) mma_layer_slab<HT, HT, KG, WAVES * 64>(w_d3, slab, h2, h, lane, p.rlh);
@@ -370,7 +395,7 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
     constexpr bool DGc = HT_ > 8;
     const int64_t tail = DGc ? lay.off_d2 : lay.total_floats;           // end of the LDS image
     int64_t lds_from = (s.kind == FX_MLP && !e->mlp_l1_mfma) ? lay.off_w1p : 0;
-    size_t lds = (size_t)(tail - lds_from) * 4 + 256 + 16;
+    size_t lds = (size_t)(tail - lds_from) * 4 + 256 + 32;
     bool w1_global = false;
     if constexpr (!DGc) {
         if (s.kind == FX_GE && a.Lpad > 0) {
@@ -378,14 +403,14 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
             a.lds_from = (int)lay.off_d3;
             a.lds_floats = (int)(lay.total_floats - lay.off_d3);
             return launch_inst<FX_GE, 4, HT_, 1, W, false, false, false, false, true>(
-                e, a, (size_t)a.Lpad * 128 + (size_t)a.lds_floats * 4 + 256 + 16);
+                e, a, (size_t)a.Lpad * 128 + (size_t)a.lds_floats * 4 + 256 + 32);
         }
     }
     if (lds > (size_t)e->max_lds) {
         // MLP with a large L*A: first-layer rows are gathered from L2 as well
         if (s.kind != FX_MLP) return FX_EUNSUPPORTED;
         lds_from = DGc ? tail : lay.off_d2;
-        lds = (size_t)(tail - lds_from) * 4 + 256 + 16;
+        lds = (size_t)(tail - lds_from) * 4 + 256 + 32;
         if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
         w1_global = true;
     }
@@ -441,7 +466,7 @@ int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, con
         for (int b = 0; b < 256; ++b)
             if (e->h_lut[b] != 0xFF) { lo = b < lo ? b : lo; hi = b; }
         const int Lpad = (s.L + 31) / 32 * 32;
-        const size_t need = (size_t)Lpad * 128 + (size_t)(lay.total_floats - lay.off_d3) * 4 + 256 + 16;
+        const size_t need = (size_t)Lpad * 128 + (size_t)(lay.total_floats - lay.off_d3) * 4 + 256 + 32;
         if (hi >= lo && hi - lo < 32 && need <= (size_t)e->max_lds) {
             for (int m = 0; m < M; ++m) {
                 fx_model* mod = models[m];

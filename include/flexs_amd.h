@@ -248,9 +248,10 @@ int64_t fx_debug_mfma_per_tile(int kind, int L, int A, int F, int H, int K);
 int fx_debug_time_score(fx_engine *e, fx_model *const *models, int M, const uint8_t *d_ascii, int64_t N, int L,
                         const uint8_t lut[256], float *d_planes, int64_t stride, int reps, float *total_ms);
 /* Profiling aid.  With the engine option "trace" = 1 the MFMA scoring kernels stamp an in-kernel timeline of the LAST
- * launch: row (workgroup b, wave w) = 8 uint64 words at [(b * 16 + w) * 8]: 0 kernel entry, 1 weights resident in
- * LDS, 2 first tile begins, 3 first tile done, 4 last tile done, 5 tiles processed by the wave, 6 wave exit; times
- * are ticks of the 100 MHz constant clock, 0 = never reached.  Copies min(cap_words, 1024*16*8) words. */
+ * launch: row (workgroup b, wave w) = 16 uint64 words at [(b * 16 + w) * 16]: 0 kernel entry, 1 weights resident in
+ * LDS, 2 first tile begins, 3 first tile done, 4 last tile done, 5 tiles processed by the wave, 6 wave exit, 7 SIMD
+ * id + 1, 8..10 phases of the first tile (first layer / conv part done, next layer done, ...); times are ticks of the
+ * 100 MHz constant clock, 0 = never reached.  Copies min(cap_words, 1024*16*16) words. */
 int fx_debug_trace_read(fx_engine *e, uint64_t *out, int64_t cap_words);
 int fx_debug_pack_weights(int kind, int L, int A, int F, int H, int K, const float *blob, int64_t n,
                           float *packed, int64_t cap);

@@ -66,6 +66,8 @@ def trace_case(label, kind, L, alpha, M, N, H=100, F=0, K=0, opts=None):
         per_tile = ((t[:, :, 4] - t[:, :, 2])[worked] * TICK_US) / tiles
         last_done = (t[:, :, 4][worked] - t0) * TICK_US
         entry = (t[:, :, 0][entered] - t0) * TICK_US
+        ph = [((t[:, :, k] - t[:, :, 2])[worked & (t[:, :, k] > 0)] * TICK_US) for k in (8, 9, 10)]
+        simd_counts = [int(((t[:, :, 7] == v + 1) & entered).sum()) for v in range(4)]
         res.append({
             "span_us": float(end_all.max()), "blocks": int(entered.any(axis=1).sum()), "waves_entered": int(entered.sum()),
             "waves_with_tiles": int(worked.sum()), "tiles_per_working_wave": [int(tiles.min()), float(tiles.mean()), int(tiles.max())],
@@ -75,6 +77,11 @@ def trace_case(label, kind, L, alpha, M, N, H=100, F=0, K=0, opts=None):
             "first_tile_dur_us_p10_p50_p90_max": [pct(first_dur, 10), pct(first_dur, 50), pct(first_dur, 90), float(first_dur.max())],
             "per_tile_us_p10_p50_p90": [pct(per_tile, 10), pct(per_tile, 50), pct(per_tile, 90)],
             "last_tile_done_us_p10_p50_p90_max": [pct(last_done, 10), pct(last_done, 50), pct(last_done, 90), float(last_done.max())],
+            "first_tile_phase_ends_us_p50": [pct(x, 50) for x in ph], "waves_per_simd": simd_counts,
+            "block0_waves_simd_tiles_firststart_firstend_lastend": [
+                [int(t[0, w, 7]) - 1, int(t[0, w, 5]), round(float((t[0, w, 2] - t0) * TICK_US), 2) if t[0, w, 2] else None,
+                 round(float((t[0, w, 3] - t0) * TICK_US), 2) if t[0, w, 3] else None,
+                 round(float((t[0, w, 4] - t0) * TICK_US), 2) if t[0, w, 4] else None] for w in range(16) if t[0, w, 0]],
         })
     eng.set_option("trace", 0)
     for k_ in (opts or {}):
