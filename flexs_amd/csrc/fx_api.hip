@@ -198,6 +198,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "poison_outputs")) return &e->poison_outputs;
     if (!std::strcmp(key, "trace")) return &e->trace;
     if (!std::strcmp(key, "ge_bytetab")) return &e->ge_bytetab;
+    if (!std::strcmp(key, "wave_prio")) return &e->wave_prio;
     return nullptr;
 }
 int fx_engine_set_option(fx_engine* e, const char* key, int64_t value) {

@@ -85,6 +85,19 @@ __device__ __forceinline__ void fx_unit_range(int64_t TG, int M, int64_t& u_lo, 
 // (profiles/r2_trace_probe: MLP, 1e5 sequences: median wave done at 35 us, last at 46 us).
 __device__ __forceinline__ int fx_simd_id() { return (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4); }
 
+// Distinct issue priorities for the waves that share a SIMD (by hardware wave slot), for the whole kernel: the waves of
+// a workgroup start their first tiles in the same cycle and would otherwise sit in the same phase together -- all in
+// the LDS-bound first layer with the matrix pipe idle, then all queueing for the pipe.  With static priorities the
+// first wave runs ahead and the phases of the four waves interleave from the first tile on (engine option "wave_prio").
+__device__ __forceinline__ void fx_stagger_priority() {
+    switch (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 3) {       // HW_REG_HW_ID.WAVE_ID (slot in the SIMD)
+        case 0: __builtin_amdgcn_s_setprio(3); break;
+        case 1: __builtin_amdgcn_s_setprio(2); break;
+        case 2: __builtin_amdgcn_s_setprio(1); break;
+        default: __builtin_amdgcn_s_setprio(0); break;
+    }
+}
+
 // Share of the tile range [t_lo, t_hi) that belongs to this wave's SIMD, proportional to the number of the workgroup's
 // waves each SIMD hosts (counted once at kernel start, fx_count_simd_wave: 4-4-4-4 for a 16-wave workgroup, but
 // nothing here depends on the placement -- a SIMD without waves simply gets no tiles).
@@ -103,6 +116,10 @@ __device__ __forceinline__ FxSimdShare fx_simd_share(const int* counters, int si
         if (i == simd) r.mine = w;
         r.total += w;
     }
+    // wave-uniform: keep the three counts (and the tile bounds derived from them) in scalar registers
+    r.before = __builtin_amdgcn_readfirstlane(r.before);
+    r.mine = __builtin_amdgcn_readfirstlane(r.mine);
+    r.total = __builtin_amdgcn_readfirstlane(r.total);
     return r;
 }
 

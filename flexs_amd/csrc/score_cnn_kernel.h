@@ -28,6 +28,7 @@ struct CnnArgs {
     float* out;                 // N x Mtot
     unsigned* err;
     unsigned long long* trace;  // in-kernel timeline (null = off), see fx_stamp
+    int wave_prio;              // 1 = fx_stagger_priority
     int64_t N;
     int64_t TG;                 // tile groups per member = ceil(N / (16*NT))
     int M, Mtot, m_off;
@@ -69,6 +70,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
     int* simd_waves = next_tile + 4;                                   // 4 wave counts (workgroup's waves per SIMD)
 
     fx_stamp(p.trace, 0);
+    if (p.wave_prio) fx_stagger_priority();
     const int simd = fx_simd_id();
     fx_stamp(p.trace, 7, (unsigned long long)simd + 1);
     for (int i = tid; i < 64; i += blockDim.x)

@@ -25,6 +25,7 @@ struct DenseArgs {
     float* out;
     unsigned* err;
     unsigned long long* trace;  // in-kernel timeline (null = off), see fx_stamp
+    int wave_prio;              // 1 = fx_stagger_priority
     int64_t N, TG;
     int M, Mtot, m_off;
     int64_t out_sn, out_sm;     // out[n * out_sn + column * out_sm]
@@ -67,6 +68,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
     int* simd_waves = next_tile + 4;                                    // 4 wave counts (workgroup's waves per SIMD)
     f4* slab = reinterpret_cast<f4*>(img + p.lds_floats + 64 + 8);      // SLAB: 2 x KG*HT KiB
     fx_stamp(p.trace, 0);
+    if (p.wave_prio) fx_stagger_priority();
     const int simd = fx_simd_id();
     fx_stamp(p.trace, 7, (unsigned long long)simd + 1);
     for (int i = tid; i < 64; i += blockDim.x)
@@ -142,31 +144,23 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                     // one-hot layer == sum of L kernel rows selected by the codes: LDS gather + VALU adds
                     unsigned seen1 = 0;
                     const unsigned amax1 = (unsigned)p.A - 1u;
-                    // the sequence bytes of 16 positions are requested at once (one global round trip per chunk, not
-                    // one per four positions: a wave alone on its SIMD waits for every one of them)
-                    for (int c0 = 0; c0 < L; c0 += 16) {
-                        int raw[NT][16];
+                    for (int l0 = 0; l0 < L; l0 += 4) {
+                        asm volatile("" ::: "memory");
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
+                        for (int nt = 0; nt < NT; ++nt) {
+                            int raw[4];
 #pragma unroll
-                            for (int k = 0; k < 16; ++k) raw[nt][k] = row[nt][c0 + k < L ? c0 + k : 0];   // independent loads
+                            for (int k = 0; k < 4; ++k) raw[k] = row[nt][l0 + k < L ? l0 + k : 0];   // independent loads
 #pragma unroll
-                        for (int l0 = 0; l0 < 16; l0 += 4) {
-                            if (c0 + l0 >= L) break;
-                            asm volatile("" ::: "memory");
+                            for (int k = 0; k < 4; ++k) {
+                                const int l = l0 + k;
+                                if (l < L) {
+                                    const unsigned c = lut_s[raw[k]];
+                                    seen1 |= c;                       // a code is < A <= 127, or 0xFF: tested once per tile
+                                    const unsigned ci = c < amax1 ? c : amax1;
+                                    const float* rowp = w1p + (l * p.A + ci) * (16 * HT) + 4 * g;
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) {
-                                    const int l = c0 + l0 + k;
-                                    if (l < L) {
-                                        const unsigned c = lut_s[raw[nt][l0 + k]];
-                                        seen1 |= c;                       // a code is < A <= 127, or 0xFF: tested once per tile
-                                        const unsigned ci = c < amax1 ? c : amax1;
-                                        const float* rowp = w1p + (l * p.A + ci) * (16 * HT) + 4 * g;
-#pragma unroll
-                                        for (int mo = 0; mo < HT; ++mo) h[mo][nt] += *reinterpret_cast<const f4*>(rowp + 16 * mo);
-                                    }
+                                    for (int mo = 0; mo < HT; ++mo) h[mo][nt] += *reinterpret_cast<const f4*>(rowp + 16 * mo);
                                 }
                             }
                         }
@@ -235,30 +229,21 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                     const bool check = p.validate && (int)(tg % p.M) == m;
                     unsigned seen = 0;
                     if (safe) {
-                        // four trips (32 bytes per lane) requested at once: one global round trip per 128 positions
-                        for (int t0 = 0; t0 < p.Lpad; t0 += 128) {
-                            int raw[4][8];
+                        // (one trip = 8 bytes per lane in flight; 32 in flight measured slower: registers spill)
+                        for (int t = 0; t < p.Lpad; t += 32) {
+                            int raw[8];
 #pragma unroll
-                            for (int tt = 0; tt < 4; ++tt)
-                                if (t0 + 32 * tt < p.Lpad) {
+                            for (int k = 0; k < 8; ++k) raw[k] = rp[t + 4 * k];
 #pragma unroll
-                                    for (int k = 0; k < 8; ++k) raw[tt][k] = rp[t0 + 32 * tt + 4 * k];
+                            for (int k = 0; k < 8; ++k)
+                                s[0] += *reinterpret_cast<const float*>(tb + t * 128 + k * 512 + raw[k] * 4);
+                            if (check) {
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) {
+                                    const unsigned c = lut_s[raw[k]];
+                                    seen |= (t + 4 * k + g < L) ? c : 0u;
                                 }
-#pragma unroll
-                            for (int tt = 0; tt < 4; ++tt)
-                                if (t0 + 32 * tt < p.Lpad) {
-                                    const int t = t0 + 32 * tt;
-#pragma unroll
-                                    for (int k = 0; k < 8; ++k)
-                                        s[0] += *reinterpret_cast<const float*>(tb + t * 128 + k * 512 + raw[tt][k] * 4);
-                                    if (check) {
-#pragma unroll
-                                        for (int k = 0; k < 8; ++k) {
-                                            const unsigned c = lut_s[raw[tt][k]];
-                                            seen |= (t + 4 * k + g < L) ? c : 0u;
-                                        }
-                                    }
-                                }
+                            }
                         }
                     } else {
                         for (int l = g; l < L; l += 4) {
@@ -455,6 +440,7 @@ int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, con
     DenseArgs a{};
     a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
     if (int rc = fx_trace_buffer(e, &a.trace)) return rc;
+    a.wave_prio = (int)e->wave_prio;
     for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
     a.out_sn = e->planar_stride ? 1 : Mtot; a.out_sm = e->planar_stride ? e->planar_stride : 1;
     a.N = N; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.A = s.A; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4;

@@ -100,5 +100,11 @@ if __name__ == "__main__":
         rows.append(trace_case(f"ge L=90 M={M} N={N}", "ge", 90, AAS, M, N))
         rows.append(trace_case(f"ge L=90 M={M} N={N} ge_bytetab=0", "ge", 90, AAS, M, N, opts={"ge_bytetab": 0}))
     rows.append(trace_case("mlp L=14 M=1 N=100000", "mlp", 14, "UGCA", 1, 100_000))
+    rows.append(trace_case("mlp L=14 M=1 N=100000 wave_prio=1", "mlp", 14, "UGCA", 1, 100_000, opts={"wave_prio": 1}))
+    rows.append(trace_case("ge L=90 M=8 N=100000 wave_prio=1", "ge", 90, AAS, 8, 100_000, opts={"wave_prio": 1}))
+    rows.append(trace_case("ge L=90 M=1 N=100000 wave_prio=1", "ge", 90, AAS, 1, 100_000, opts={"wave_prio": 1}))
+    rows.append(trace_case("cnn L=8 M=3 N=100000 wave_prio=1", "cnn", 8, "TGCA", 3, 100_000, F=32, K=5, opts={"wave_prio": 1}))
+    rows.append(trace_case("cnn L=8 M=1 N=32768 wave_prio=1", "cnn", 8, "TGCA", 1, 32_768, F=32, K=5, opts={"wave_prio": 1}))
+    rows.append(trace_case("cnn L=8 M=3 N=10000 wave_prio=1", "cnn", 8, "TGCA", 3, 10_000, F=32, K=5, opts={"wave_prio": 1}))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "trace_probe.json"), "w"), indent=1)
