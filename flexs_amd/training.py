@@ -3,21 +3,41 @@
 SURVEY.md section 8(f)-1: surrogate training is the step right before the hot
 path every explorer round, kept in host Python / PyTorch-ROCm.  It reproduces
 what `model.compile(loss="MSE", optimizer="adam")` + `model.fit(batch_size=256,
-epochs=20)` do (cnn.py:56, mlp.py:33, global_epistasis_model.py:37): Adam with
-Keras defaults (lr 1e-3, betas .9/.999, eps 1e-7), mean-squared error, a fresh
-shuffle per epoch, Dropout(0.25) before the CNN's last Dense (cnn.py:51).
-Parity with Keras is statistical, not bitwise (different RNG streams).
+epochs=20)` do (cnn.py:56, mlp.py:33, global_epistasis_model.py:37):
+
+* loss: mean over the mini-batch of (prediction - label)^2;
+* optimiser: Keras' Adam, in Keras' own formulation -- step size
+  lr * sqrt(1 - b2^t) / (1 - b1^t) and `m / (sqrt(v) + epsilon)` with epsilon =
+  1e-7 ("epsilon hat" of Kingma & Ba, not the epsilon of their Algorithm 1, which is
+  what torch.optim.Adam implements) -- with lr 1e-3, betas .9 / .999;
+* optimiser STATE (first / second moments and the step count t) lives on the
+  `Architecture` and carries over from one `train` call to the next, as the
+  compiled Keras model's optimiser does across the explorer's rounds
+  (flexs/explorer.py:157-160 calls `model.train` once per round on the same
+  compiled model);
+* a fresh shuffle per epoch, a final partial mini-batch, Dropout(0.25) before
+  the CNN's last Dense layer in training mode (cnn.py:51).
+
+Parity with Keras is per step (tests/test_training.py checks one mini-batch step
+of every architecture against a NumPy restatement, oracle/train_np.py), not
+bitwise over a whole fit: the shuffles and dropout masks come from other RNG
+streams.
 
 Runs on `cuda` when a GPU is visible, else on the CPU (training is not the
 scored hot path; the trained weights are then uploaded to the scoring engine).
 """
 from __future__ import annotations
 
+import math
+
 import numpy as np
 import torch
 import torch.nn.functional as F
 
 from flexs_amd import _native
+
+LR, BETA_1, BETA_2, EPSILON = 1e-3, 0.9, 0.999, 1e-7      # tf.keras.optimizers.Adam defaults
+DROPOUT = 0.25                                            # cnn.py:51
 
 
 def _encode(sequences, alphabet, L, device):
@@ -43,8 +63,9 @@ def _conv(h, w, b, same):
     return out
 
 
-def forward(kind, params, x, train=False):
-    """Differentiable forward with parameters in Keras layout; x (n, L, A) -> (n,)."""
+def forward(kind, params, x, train=False, dropout_mask=None):
+    """Differentiable forward with parameters in Keras layout; x (n, L, A) -> (n,).
+    dropout_mask (n, H) of 0/1 replaces the random Dropout mask (tests)."""
     if kind == "cnn":
         w1, b1, w2, b2, w3, b3, d1, c1, d2, c2, d3, c3 = params
         h = F.relu(_conv(x, w1, b1, same=False))
@@ -53,7 +74,10 @@ def forward(kind, params, x, train=False):
         h = h.amax(dim=1)
         h = F.relu(h @ d1 + c1)
         h = F.relu(h @ d2 + c2)
-        h = F.dropout(h, 0.25, training=train)
+        if dropout_mask is not None:
+            h = h * dropout_mask / (1.0 - DROPOUT)   # Keras scales the kept units by 1 / (1 - rate)
+        else:
+            h = F.dropout(h, DROPOUT, training=train)
         return (h @ d3 + c3)[:, 0]
     d1, c1, d2, c2, d3, c3, d4, c4 = params
     h = x.reshape(x.shape[0], -1)
@@ -61,6 +85,58 @@ def forward(kind, params, x, train=False):
     h = F.relu(h @ d2 + c2)
     h = F.relu(h @ d3 + c3)
     return (h @ d4 + c4)[:, 0]
+
+
+class KerasAdam:
+    """Adam as tf.keras applies it (see the module docstring); state = (t, m, v), exported to / restored
+    from NumPy so that it can live on the `Architecture` between `train` calls."""
+
+    def __init__(self, params, state=None, lr=LR, beta_1=BETA_1, beta_2=BETA_2, epsilon=EPSILON):
+        self.params = params
+        self.lr, self.b1, self.b2, self.eps = lr, beta_1, beta_2, epsilon
+        if state is not None and len(state["m"]) == len(params) and \
+                all(tuple(m.shape) == tuple(p.shape) for m, p in zip(state["m"], params)):
+            self.t = int(state["t"])
+            self.m = [torch.as_tensor(a, dtype=p.dtype, device=p.device).clone() for a, p in zip(state["m"], params)]
+            self.v = [torch.as_tensor(a, dtype=p.dtype, device=p.device).clone() for a, p in zip(state["v"], params)]
+        else:
+            self.t = 0
+            self.m = [torch.zeros_like(p) for p in params]
+            self.v = [torch.zeros_like(p) for p in params]
+
+    @torch.no_grad()
+    def step(self):
+        self.t += 1
+        lr_t = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        grads = [p.grad for p in self.params]
+        torch._foreach_mul_(self.m, self.b1)
+        torch._foreach_add_(self.m, grads, alpha=1.0 - self.b1)
+        torch._foreach_mul_(self.v, self.b2)
+        torch._foreach_addcmul_(self.v, grads, grads, value=1.0 - self.b2)
+        denom = torch._foreach_sqrt(self.v)
+        torch._foreach_add_(denom, self.eps)
+        torch._foreach_addcdiv_(self.params, self.m, denom, value=-lr_t)
+
+    def state(self):
+        return {"t": self.t, "m": [m.detach().cpu().numpy() for m in self.m],
+                "v": [v.detach().cpu().numpy() for v in self.v]}
+
+
+def train_step(arch, x, y, dropout_mask=None, device=None):
+    """ONE mini-batch step on `arch` (weights and optimiser state updated in place): x (n, L, A) one-hot float32,
+    y (n,) labels.  Returns the loss before the step.  This is the unit `fit` repeats; tests drive it directly."""
+    device = device or (torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu"))
+    params = [torch.tensor(w, device=device, requires_grad=True) for w in arch._weights]
+    opt = KerasAdam(params, getattr(arch, "_opt_state", None))
+    xt = torch.as_tensor(np.asarray(x, np.float32), device=device)
+    yt = torch.as_tensor(np.asarray(y, np.float32), device=device)
+    mask = None if dropout_mask is None else torch.as_tensor(np.asarray(dropout_mask, np.float32), device=device)
+    loss = F.mse_loss(forward(arch.kind, params, xt, train=True, dropout_mask=mask), yt)
+    loss.backward()
+    opt.step()
+    arch.set_weights([p.detach().cpu().numpy() for p in params])
+    arch._opt_state = opt.state()
+    return float(loss.detach())
 
 
 def fit(arch, sequences, labels, alphabet, batch_size=256, epochs=20, verbose=False, seed=None):
@@ -73,7 +149,7 @@ def fit(arch, sequences, labels, alphabet, batch_size=256, epochs=20, verbose=Fa
     x = _encode(sequences, alphabet, arch.L, device)
     y = torch.as_tensor(np.asarray(labels, dtype=np.float32), device=device)
     params = [torch.tensor(w, device=device, requires_grad=True) for w in arch._weights]
-    opt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.999), eps=1e-7)
+    opt = KerasAdam(params, getattr(arch, "_opt_state", None))       # moments and step count of the previous rounds
     gen = torch.Generator(device="cpu")
     if seed is not None:
         gen.manual_seed(seed)
@@ -82,7 +158,8 @@ def fit(arch, sequences, labels, alphabet, batch_size=256, epochs=20, verbose=Fa
         total = 0.0
         for i in range(0, n, batch_size):
             idx = perm[i:i + batch_size]
-            opt.zero_grad(set_to_none=True)
+            for p in params:
+                p.grad = None
             loss = F.mse_loss(forward(arch.kind, params, x[idx], train=True), y[idx])
             loss.backward()
             opt.step()
@@ -90,3 +167,4 @@ def fit(arch, sequences, labels, alphabet, batch_size=256, epochs=20, verbose=Fa
         if verbose:
             print(f"Epoch {epoch + 1}/{epochs} - loss: {total / n:.6f}")
     arch.set_weights([p.detach().cpu().numpy() for p in params])
+    arch._opt_state = opt.state()
