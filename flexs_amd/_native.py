@@ -187,23 +187,24 @@ def sequences_to_bytes(sequences, L: Optional[int] = None, staging: Optional["En
 
     Raises ValueError for ragged batches (Keras raises on a shape mismatch) and
     for characters that do not fit one byte (cannot be in any FLEXS alphabet)."""
-    if isinstance(sequences, np.ndarray) and sequences.dtype.kind == "S":
+    if isinstance(sequences, np.ndarray) and sequences.dtype.kind in "SU":
+        # fixed-width NumPy strings: the item size may be wider than the strings (dtype 'U10' holding 8-mers, a slice of
+        # a wider array): the common length is what counts, as for the reference's per-string loop
         a = np.ascontiguousarray(sequences)
         N = a.shape[0]
-        w = a.dtype.itemsize
-        out = a.view(np.uint8).reshape(N, w)
-        if N and (out == 0).any():
-            raise ValueError("ragged sequence batch")
-    elif isinstance(sequences, np.ndarray) and sequences.dtype.kind == "U":
-        a = np.ascontiguousarray(sequences)
-        N = a.shape[0]
-        w = a.dtype.itemsize // 4
-        cp = a.view(np.uint32).reshape(N, w)
-        if N and (cp == 0).any():
-            raise ValueError("ragged sequence batch")
-        if N and cp.max(initial=0) > 255:
-            raise ValueError("substring not found")
-        out = cp.astype(np.uint8)
+        if a.dtype.kind == "S":
+            cp = a.view(np.uint8).reshape(N, a.dtype.itemsize)
+        else:
+            cp = a.view(np.uint32).reshape(N, a.dtype.itemsize // 4)
+        if N:
+            used = cp != 0
+            w = int(used.any(axis=0).nonzero()[0].max(initial=-1)) + 1      # longest string
+            cp = cp[:, :w]
+            if not used[:, :w].all():
+                raise ValueError("ragged sequence batch")
+            if cp.dtype != np.uint8 and cp.max(initial=0) > 255:
+                raise ValueError("substring not found")
+        out = np.ascontiguousarray(cp.astype(np.uint8, copy=False))
     else:
         seqs = sequences if isinstance(sequences, (list, tuple)) else list(sequences)
         N = len(seqs)

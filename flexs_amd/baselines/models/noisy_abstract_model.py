@@ -17,24 +17,53 @@ from flexs_amd import _native
 from flexs_amd.types import SEQUENCES_TYPE
 
 
+class _CacheDict(dict):
+    """`NoisyAbstractModel.cache`: a plain dict for every caller, which additionally counts removals -- the
+    device-resident copy of the keys is append-only, so anything but an append (del / pop / popitem / clear) has to
+    trigger a rebuild, wherever in the insertion order it happened."""
+
+    removals = 0
+
+    def __delitem__(self, key):
+        super().__delitem__(key)
+        self.removals += 1
+
+    def pop(self, *args):
+        n = len(self)
+        out = super().pop(*args)
+        self.removals += n != len(self)
+        return out
+
+    def popitem(self):
+        out = super().popitem()
+        self.removals += 1
+        return out
+
+    def clear(self):
+        super().clear()
+        self.removals += 1
+
+
 class NoisyAbstractModel(flexs_amd.Model):
     def __init__(self, landscape: flexs_amd.Landscape, signal_strength: float = 0.9, distance: str = "levenshtein",
                  device: int = None):
         super().__init__(f"NAMb_ss{signal_strength}")                 # noisy_abstract_model.py:36
         self.landscape = landscape
         self.ss = signal_strength
-        self.cache = {}
+        self.cache = _CacheDict()
         if distance not in ("levenshtein", "hamming"):
             raise ValueError("distance must be 'levenshtein' (reference behaviour) or 'hamming'")
         self._mode = _native.FX_LEVENSHTEIN if distance == "levenshtein" else _native.FX_HAMMING
         self._device = device
         self._dev_cache = None            # NativeCache mirroring list(self.cache) in insertion order
         self._dev_keys = []               # python-side mirror of what was appended
+        self._dev_token = None            # (id of the dict, its removal count) the device copy was built for
 
     def __getstate__(self):
         state = self.__dict__.copy()           # copy / pickle: the device key store is rebuilt from `cache` on first use
         state["_dev_cache"] = None
         state["_dev_keys"] = []
+        state["_dev_token"] = None
         return state
 
     # ---------------------------------------------------------------- device cache sync
@@ -53,9 +82,15 @@ class NoisyAbstractModel(flexs_amd.Model):
         keys = self.cache.keys()
         n = len(self._dev_keys)
         stale = self._dev_cache is None or n > len(keys)
-        if not stale and n:
-            # dict order is append-only unless the user deleted entries: spot-check the boundary
-            stale = next(iter(keys)) != self._dev_keys[0]
+        if isinstance(self.cache, _CacheDict):
+            # removals anywhere in the order are counted by the dict itself
+            token = (id(self.cache), self.cache.removals)
+            stale = stale or token != self._dev_token
+        else:
+            # the user replaced `cache` by a dict of their own: compare the whole mirrored prefix
+            token = None
+            stale = stale or any(str(a) != b for a, b in zip(keys, self._dev_keys))
+        self._dev_token = token
         fresh = [str(k) for k in itertools.islice(keys, 0 if stale else n, None)]
         need = max([min_row, 1] + [len(k) for k in fresh])
         if not stale and need > self._dev_cache.L:          # a longer sequence than any before: wider rows

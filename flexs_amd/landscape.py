@@ -35,5 +35,5 @@ class _Landscape(abc.ABC):
         return self._fitness_function(sequences)
 
 
+_Landscape.__doc__ = "Base class of every landscape and model: `name`, `cost`, `get_fitness`."
 Landscape = _reference_class("Landscape") or _Landscape
-Landscape.__doc__ = Landscape.__doc__ or "Base class of every landscape and model: `name`, `cost`, `get_fitness`."
