@@ -921,25 +921,28 @@ int fx_debug_mfma_probe(fx_engine* e, const float* a64, const float* b64, const 
 }
 int fx_debug_myers(const uint8_t* a, int la, const uint8_t* b, int lb) {
     // pattern = a, text = b; same code path as the device kernel (myers.h)
-    if (la > 256 || la < 0 || lb < 0) return -1;
+    if (la > 768 || la < 0 || lb < 0) return -1;
     if (la <= 32) {                                   // the kernels' 32-bit single-word form (mindist.hip)
         uint32_t peq32[256] = {0};
         for (int i = 0; i < la; ++i) peq32[a[i]] |= 1u << i;
         return fx_myers_distance<1, false, uint32_t>(
             la, lb, [&](int c, int) { return peq32[c]; }, [&](int i) { return (int)b[i]; });
     }
-    static thread_local uint64_t peq[256 * 4];
+    static thread_local uint64_t peq[256 * 12];
     std::memset(peq, 0, sizeof(peq));
-    for (int i = 0; i < la; ++i) peq[a[i] * 4 + (i >> 6)] |= 1ull << (i & 63);
-    auto pf = [&](int c, int w) { return peq[c * 4 + w]; };
+    for (int i = 0; i < la; ++i) peq[a[i] * 12 + (i >> 6)] |= 1ull << (i & 63);
+    auto pf = [&](int c, int w) { return peq[c * 12 + w]; };
     auto tf = [&](int i) { return (int)b[i]; };
     const int W = (la + 63) / 64;
-    switch (W) {
+    switch (W) {                                      // the same instantiations the kernels use
         case 0:
         case 1: return fx_myers_distance<1>(la, lb, pf, tf);
         case 2: return fx_myers_distance<2>(la, lb, pf, tf);
         case 3: return fx_myers_distance<3>(la, lb, pf, tf);
-        default: return fx_myers_distance<4>(la, lb, pf, tf);
+        case 4: return fx_myers_distance<4>(la, lb, pf, tf);
+        case 5: case 6: return fx_myers_distance<6>(la, lb, pf, tf);
+        case 7: case 8: return fx_myers_distance<8>(la, lb, pf, tf);
+        default: return fx_myers_distance<12>(la, lb, pf, tf);
     }
 }
 

@@ -19,6 +19,7 @@
 namespace {
 
 constexpr int CHUNK = 1024;     // cache entries per block
+constexpr int FX_MINDIST_MAX_L = 768;   // 12 words of 64 pattern rows
 
 // Block prologue shared by both kernels: stage query `qi` in LDS, let thread c build the match masks of byte
 // value c, and return the query length (its first NUL, every thread finds it itself).
@@ -126,7 +127,7 @@ __global__ void k_min_dist_finish(const unsigned long long* __restrict__ keys, i
 int fx_launch_min_dist(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, const uint8_t* d_cache, int64_t C,
                        int L, unsigned long long* d_keys) {
     if (Q == 0 || C == 0) return FX_OK;
-    if (L > 256) return fx_fail(e, FX_EUNSUPPORTED, "min_dist: sequence length > 256");
+    if (L > FX_MINDIST_MAX_L) return fx_fail(e, FX_EUNSUPPORTED, "min_dist: sequence length > 768");
     if (Q > 65535) return fx_fail(e, FX_EINVAL, "min_dist: more than 65535 queries per call (split the batch)");
     FX_HIP(e, hipMemsetAsync(d_keys, 0xFF, sizeof(unsigned long long) * (size_t)Q, e->stream));
     dim3 grid((unsigned)((C + CHUNK - 1) / CHUNK), (unsigned)Q), block(256);
@@ -137,7 +138,10 @@ int fx_launch_min_dist(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, co
             case 1: hipLaunchKernelGGL((k_min_dist<1, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
             case 2: hipLaunchKernelGGL((k_min_dist<2, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
             case 3: hipLaunchKernelGGL((k_min_dist<3, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
-            default: hipLaunchKernelGGL((k_min_dist<4, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
+            case 4: hipLaunchKernelGGL((k_min_dist<4, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
+            case 5: case 6: hipLaunchKernelGGL((k_min_dist<6, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
+            case 7: case 8: hipLaunchKernelGGL((k_min_dist<8, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
+            default: hipLaunchKernelGGL((k_min_dist<12, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;   // L <= 768 (full-length AAV capsid: 735)
         }
     }
     FX_HIP(e, hipGetLastError());
@@ -147,7 +151,7 @@ int fx_launch_min_dist(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, co
 int fx_launch_distances(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, const uint8_t* d_cache, int64_t C,
                         int L, uint8_t* d_out) {
     if (Q == 0 || C == 0) return FX_OK;
-    if (L > 256) return fx_fail(e, FX_EUNSUPPORTED, "distances: sequence length > 256");
+    if (L > FX_MINDIST_MAX_L) return fx_fail(e, FX_EUNSUPPORTED, "distances: sequence length > 768");
     if (Q > 65535) return fx_fail(e, FX_EINVAL, "distances: more than 65535 queries per call");
     dim3 grid((unsigned)((C + CHUNK - 1) / CHUNK), (unsigned)Q), block(256);
     if (L <= 32) {
@@ -157,7 +161,10 @@ int fx_launch_distances(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, c
             case 1: hipLaunchKernelGGL((k_distances<1, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;
             case 2: hipLaunchKernelGGL((k_distances<2, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;
             case 3: hipLaunchKernelGGL((k_distances<3, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;
-            default: hipLaunchKernelGGL((k_distances<4, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;
+            case 4: hipLaunchKernelGGL((k_distances<4, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;
+            case 5: case 6: hipLaunchKernelGGL((k_distances<6, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;
+            case 7: case 8: hipLaunchKernelGGL((k_distances<8, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;
+            default: hipLaunchKernelGGL((k_distances<12, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;   // L <= 768 (full-length AAV capsid: 735)
         }
     }
     FX_HIP(e, hipGetLastError());

@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
     constexpr int PL2 = (K - 1) / 2, PR2 = K - 1 - PL2;
     constexpr int PL3 = (K3 - 1) / 2, PR3 = K3 - 1 - PL3;
     constexpr int S1 = (K * A + 3) / 4;                 // conv1 k-steps
-    static_assert(A % 4 == 0, "one-hot k-steps must not straddle a tap");
+    static_assert(G1 || A % 4 == 0, "MFMA form of the one-hot conv: k-steps must not straddle a tap");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
             // one tile per SIMD) otherwise pays one global round trip per position (profiles/r2_trace_probe: 8.4 us
             // for the conv part of an L = 8 tile whose MFMAs take 5.5 us).  The unrolled forms (L1S > 0) run with
             // four waves per SIMD, which hide it, and have no registers to spare.
-            constexpr int PF = (L1S > 0) ? 1 : (RING ? 3 : 2);
+            constexpr int PF = (L1S > 0) ? 1 : (!RING ? 2 : (UN % 3 == 0 ? 3 : (UN % 2 == 0 ? 2 : 1)));
             static_assert(L1S > 0 || !RING || UN % PF == 0, "ring slots of the byte queue must be compile-time constants");
             int rq[PF][NT];
             f4 win1[K][FT][NT], win2[K3][FT][NT], gmax[FT][NT];

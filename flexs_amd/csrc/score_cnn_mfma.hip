@@ -73,7 +73,7 @@ int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const
     }
     // num_filters 17..32 (two channel tiles; missing channels are zero padding of the packed blocks); kernel_size 5
     // everywhere, 3 and 7 for the canonical hidden width (97..112 units); everything else -> shape-agnostic kernels
-    if ((lay.FT != 2 && !(lay.FT == 1 && s.K == 5 && lay.HT == 7)) || (s.A != 4 && s.A != 20)) return FX_EUNSUPPORTED;
+    if ((lay.FT != 2 && !(lay.FT == 1 && s.K == 5 && lay.HT == 7)) || (s.A != 4 && s.A != 20 && s.A != 2)) return FX_EUNSUPPORTED;
     if (s.K != 5 && !((s.K == 3 || s.K == 7) && lay.HT == 7)) return FX_EUNSUPPORTED;
     if (M > FX_MAX_M) return FX_EINVAL;
 
@@ -89,6 +89,18 @@ int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const
     a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
 
     const size_t full = (size_t)lay.total_floats * 4 + 256 + 32, conv_only = (size_t)lay.conv_floats * 4 + 256 + 32;
+    if (s.A == 2) {
+        // binary alphabet (`BA = "01"`, sequence_utils.py:16): conv3 has ONE tap (kernel_size = len(alphabet) - 1);
+        // canonical filter / hidden / kernel sizes only, first conv in gather form
+        if (lay.FT != 2 || lay.HT != 7 || s.K != 5 || full > (size_t)e->max_lds || e->cnn_conv1_mfma) return FX_EUNSUPPORTED;
+        a.TG = (N + 15) / 16;
+        const bool big = a.TG * M >= (int64_t)e->num_cus * e->cnn_big_units;
+        const int L1 = s.L - s.K + 1;
+        const bool seg = e->cnn_seg != 0 && (int64_t)M * a.TG <= e->num_cus && (e->cnn_seg > 0 || L1 >= 24) &&
+                         full + 8 * 2 * 64 * 16 <= (size_t)e->max_lds;
+        if (seg) return launch_g<2, 5, 2, 7, 1, true, 8, true, 0, false, true>(e, a, full);
+        return big ? launch_g<2, 5, 2, 7, 1, true, 16, true>(e, a, full) : launch_g<2, 5, 2, 7, 1, true, 8, true>(e, a, full);
+    }
     if (lay.FT == 1) {
         // num_filters <= 16: one channel tile (canonical hidden width and kernel size only)
         if (full > (size_t)e->max_lds || e->cnn_conv1_mfma) return FX_EUNSUPPORTED;

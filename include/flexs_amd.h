@@ -189,7 +189,7 @@ int fx_decode_score(fx_engine *e, fx_model *const *models, int M, const double *
  * (noisy_abstract_model.py:44-45).  Rows are L bytes; a sequence shorter than L is
  * NUL-padded on the right (`editdistance.eval` accepts two strings of any lengths,
  * noisy_abstract_model.py:51; no FLEXS alphabet contains NUL).  FX_HAMMING compares the
- * padded rows byte-wise.  L <= 256. */
+ * padded rows byte-wise.  L <= 768 (up to 12 64-bit words per column; the full-length AAV capsid is 735). */
 int fx_min_dist(fx_engine *e, int mode, const uint8_t *queries, int64_t Q, const uint8_t *cache,
                 int64_t C, int L, int32_t *dist, int64_t *argmin);
 /* Device-resident, append-only cache (self.cache keys, noisy_abstract_model.py:40,67,99). */

@@ -418,7 +418,8 @@ def test_encode_decode_golden(eng, golden_dir):
 
 
 # ------------------------------------------------------------------ NoisyAbstractModel
-@pytest.mark.parametrize("L,nsym,C,Q", [(8, 4, 300, 200), (14, 4, 2500, 150), (66, 20, 700, 60), (90, 20, 1500, 40),
+@pytest.mark.parametrize("L,nsym,C,Q", [(8, 4, 300, 200), (14, 4, 2500, 150), (66, 20, 700, 60), (90, 20, 1500, 40), (300, 20, 300, 12),
+                                        (513, 20, 200, 8), (735, 20, 150, 6),
                                         (238, 20, 300, 20), (64, 4, 200, 50), (65, 4, 200, 50), (1, 4, 10, 10)])
 def test_min_dist_vs_oracle(eng, L, nsym, C, Q):
     rng = np.random.default_rng(L * 7 + C)
@@ -1220,6 +1221,27 @@ def test_deepcopy_and_pickle_of_live_models(eng):
     np.random.seed(2); a = nam.get_fitness(seqs[150:220])
     np.random.seed(2); b = twin.get_fitness(seqs[150:220])
     assert np.array_equal(a, b) and list(nam.cache) == list(twin.cache)
+
+
+@pytest.mark.parametrize("L,n,M", [(10, 3000, 2), (5, 100, 1), (64, 20, 3), (30, 70000, 1)])
+def test_cnn_binary_alphabet_on_mfma(eng, L, n, M):
+    """`BA = "01"` (sequence_utils.py:16): the canonical CNN on a 2-letter alphabet (conv3 has a single tap) runs on the
+    MFMA kernels -- bulk, small-batch and position-segmented forms -- and agrees with the oracle and the VALU kernels."""
+    pairs = [make_native(eng, "cnn", L, 2, 100, 32, 5, seed=60 + m) for m in range(M)]
+    b, seqs = rand_seqs(n, L, "01", seed=L)
+    lut = _native.make_lut("01")
+    got, _ = eng.score([p[0] for p in pairs], b, lut)
+    for m in range(M):
+        assert_scores(got[:, m], ref_np.keras_fitness(seqs, "01", "cnn", pairs[m][1], exact=True), f"BA cnn L={L} member {m}")
+    eng.set_option("force_generic", 1)
+    try:
+        gen, _ = eng.score([p[0] for p in pairs], b[:500], lut)
+    finally:
+        eng.set_option("force_generic", 0)
+    assert np.abs(gen - got[:500]).max() <= 2e-5 * np.abs(gen).max() + 2e-6
+    bb = b.copy(); bb[n // 2, L - 1] = ord("2")
+    with pytest.raises(ValueError):
+        eng.score([p[0] for p in pairs], bb, lut)
 
 
 @pytest.mark.parametrize("L,F,H,K,n,M", [(8, 32, 50, 3, 5000, 3), (14, 32, 128, 7, 3000, 2), (14, 32, 200, 3, 2000, 1), (20, 32, 256, 6, 500, 1),

@@ -112,10 +112,10 @@ def test_myers_equals_dp_multiword(la, lb, seed, nsym):
 
 
 def test_myers_boundaries():
-    for L in (1, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256):
+    for L in (1, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 320, 384, 385, 512, 513, 735, 768):
         a = bytes([65 + (i * 7) % 4 for i in range(L)])
         b = bytes([65 + (i * 5 + 1) % 4 for i in range(L)])
         assert _native.debug_myers(a, b) == c_oracle.levenshtein(a, b)
         assert _native.debug_myers(a, a) == 0
         assert _native.debug_myers(a, a[1:] + a[:1]) == c_oracle.levenshtein(a, a[1:] + a[:1])
-    assert _native.debug_myers(b"x" * 257, b"x") == -1    # > 256: unsupported pattern length
+    assert _native.debug_myers(b"x" * 769, b"x") == -1    # > 768 (12 words): unsupported pattern length
