@@ -148,6 +148,15 @@ __device__ __forceinline__ void fx_stamp(unsigned long long* t, int slot, unsign
         t[((size_t)blockIdx.x * FX_TRACE_WAVES + (threadIdx.x >> 6)) * FX_TRACE_SLOTS + slot] = (v == ~0ull) ? wall_clock64() : v;
 }
 
+// Phase stamps INSIDE a tile (slots 8..10 of the first tile) split the tile's code into scheduling regions -- the
+// layers no longer overlap, +7 % on the GlobalEpistasis kernel -- so they exist only in builds made with
+// -DFX_TRACE_PHASES (make CXXFLAGS+=-DFX_TRACE_PHASES); the stamps at tile boundaries are always there.
+#if defined(FX_TRACE_PHASES)
+#define FX_PHASE_STAMP(slot) do { if (tiles_done == 0) fx_stamp(p.trace, (slot)); } while (0)
+#else
+#define FX_PHASE_STAMP(slot) do { } while (0)
+#endif
+
 __device__ __forceinline__ f4 splat4(float v) { f4 r = {v, v, v, v}; return r; }
 
 __device__ __forceinline__ float fx_nan_to_num(float v) {

@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                 continue;
             }
             // ---- dense head: F -> H relu -> H relu -> (dropout inactive) -> 1
-            if (tiles_done == 0) fx_stamp(p.trace, 8);
+            FX_PHASE_STAMP(8);
             asm volatile("" ::: "memory");
             if (!DENSE_LDS) {
                 // weights streamed from L2: launder the base pointer per tile, otherwise LICM hoists the
@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
             init_bias<HT, NT>(db, h1, g);
             mma_layer<FT, HT, NT, PRIO>(w_d1, gmax, h1, lane);
             relu_tiles<HT, NT>(h1);
-            if (tiles_done == 0) fx_stamp(p.trace, 9);
+            FX_PHASE_STAMP(9);
             init_bias<HT, NT>(db + 16 * HT, h2, g);
             mma_layer<HT, HT, NT, PRIO>(w_d2, h1, h2, lane, p.rlh);
             relu_tiles<HT, NT>(h2);

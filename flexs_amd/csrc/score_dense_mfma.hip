@@ -193,14 +193,14 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                     }
                 }
                 relu_tiles<HT, NT>(h);
-                if (tiles_done == 0) fx_stamp(p.trace, 8);
+                FX_PHASE_STAMP(8);
                 // ---- layers 2, 3
                 f4 h2[HT][NT];
                 init_bias<HT, NT>(db + 16 * HT, h2, g);
                 if constexpr (SLAB) mma_layer_slab<HT, HT, KG, WAVES * 64>(w_d2, slab, h, h2, lane, p.rlh);
                 else mma_layer<HT, HT, NT>(w_d2, h, h2, lane, p.rlh);
                 relu_tiles<HT, NT>(h2);
-                if (tiles_done == 0) fx_stamp(p.trace, 9);
+                FX_PHASE_STAMP(9);
                 asm volatile("" ::: "memory");
                 init_bias<HT, NT>(db + 32 * HT, h, g);
                 if constexpr (SLAB) mma_layer_slab<HT, HT, KG, WAVES * 64>(w_d3, slab, h2, h, lane, p.rlh);
@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                         h2[mo][nt] = v;
                     }
                 }
-                if (tiles_done == 0) fx_stamp(p.trace, 8);
+                FX_PHASE_STAMP(8);
                 // ---- layer 3 (HxH MFMA), layer 4 (dot)
                 init_bias<HT, NT>(db + 4 + 32 * HT, h, g);
                 if constexpr (SLAB) mma_layer_slab<HT, HT, KG, WAVES * 64>(w_d3, slab, h2, h, lane, p.rlh);

@@ -144,7 +144,7 @@ def test_tf_binding_run_logs_through_the_device_table(golden_dir, tmp_path):
         seqs = [s.decode() for s in fx[f"{tf}__sequences"]]
         vals = fx[f"{tf}__true_scores"]
         total += int(fx[f"{tf}__n_logged"])
-        lines = ["8-mer\t8-mer.1\tE-score\tMedian\tZ-score"] + [f"{s}\t{s.translate(comp)[::-1]}\t{v!r}\t0\t0" for s, v in zip(seqs, vals)]
+        lines = ["8-mer\t8-mer.1\tE-score\tMedian\tZ-score"] + [f"{s}\t{s.translate(comp)[::-1]}\t{float(v)!r}\t0\t0" for s, v in zip(seqs, vals)]
         path = tmp_path / f"{tf}_8mers.txt"
         path.write_text("\n".join(lines) + "\n")
         land = flexs_amd.landscapes.TFBinding(str(path))

@@ -1174,9 +1174,9 @@ def test_c_abi_misuse_is_reported_not_fatal(eng):
     assert lib.fx_engine_set_option(h, b"no_such_option", 1) != _native.FX_OK
     assert lib.fx_score_submit(h, 0, 16) == _native.FX_ESTATE and lib.fx_score_finish(h, None, None) == _native.FX_ESTATE
     assert b"fx_score_finish" in lib.fx_last_error(h)
-    assert lib.fx_min_dist(h, 0, None, 4, None, 4, 300, None, None) != _native.FX_OK      # L > 256 / null buffers
+    assert lib.fx_min_dist(h, 0, None, 4, None, 4, 800, None, None) != _native.FX_OK      # L > 768 / null buffers
     with pytest.raises(_native.FxError) as err:
-        eng.min_dist(np.zeros((2, 300), np.uint8) + 65, np.zeros((3, 300), np.uint8) + 65)
+        eng.min_dist(np.zeros((2, 800), np.uint8) + 65, np.zeros((3, 800), np.uint8) + 65)
     assert err.value.code == _native.FX_EUNSUPPORTED
     with pytest.raises((ValueError, _native.FxError)):
         _native.NativeTable(eng, np.zeros((4, 5)), "", lut=np.full(256, 7, np.uint8)).additive_sum(np.zeros((2, 4), np.uint8))

@@ -16,5 +16,6 @@ for l in open("gpurun_out/trace_probe.log"):
         print(d["what"], "| ev %.1f us span %.1f | fill %.2f | first tile %.1f | per tile p50 %.1f | done p10/p50/p90/max %s" % (
             d["event_us_per_launch"], t["span_us"], t["fill_us_p50_max"][0], t["first_tile_dur_us_p10_p50_p90_max"][1],
             t["per_tile_us_p10_p50_p90"][1], [round(x, 1) for x in t["last_tile_done_us_p10_p50_p90_max"]]), "| phases", t["first_tile_phase_ends_us_p50"], "simd", t["waves_per_simd"])
-        if "mlp" in d["what"] or "N=10000" in d["what"]: print("   block0:", t["block0_waves_simd_tiles_firststart_firstend_lastend"])
+        if "mlp" in d["what"]:
+            for b in t["slowest_blocks"]: print("   ", b)
 PY

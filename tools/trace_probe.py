@@ -36,6 +36,21 @@ def pct(x, q):
     return float(np.percentile(x, q)) if len(x) else None
 
 
+def slowest_blocks(t, t0, k=4):
+    """For the k workgroups that finish last (and the one that finishes first): tiles and finish time per SIMD."""
+    done = np.where(t[:, :, 4] > 0, (t[:, :, 4] - t0) * TICK_US, 0.0)
+    order = np.argsort(done.max(axis=1))
+    order = [b for b in order if done[b].max() > 0]
+    out = []
+    for b in [order[0]] + order[-k:]:
+        per = []
+        for sd in range(4):
+            w = np.flatnonzero(t[b, :, 7] == sd + 1)
+            per.append({"tiles": [int(x) for x in t[b, w, 5]], "done": [round(float(x), 1) for x in done[b, w]]})
+        out.append({"block": int(b), "tiles": int(t[b, :, 5].sum()), "simd": per})
+    return out
+
+
 def trace_case(label, kind, L, alpha, M, N, H=100, F=0, K=0, opts=None):
     ms_ = natives(kind, L, len(alpha), H, M, F, K)
     lut = _native.make_lut(alpha)
@@ -78,6 +93,7 @@ def trace_case(label, kind, L, alpha, M, N, H=100, F=0, K=0, opts=None):
             "per_tile_us_p10_p50_p90": [pct(per_tile, 10), pct(per_tile, 50), pct(per_tile, 90)],
             "last_tile_done_us_p10_p50_p90_max": [pct(last_done, 10), pct(last_done, 50), pct(last_done, 90), float(last_done.max())],
             "first_tile_phase_ends_us_p50": [pct(x, 50) for x in ph], "waves_per_simd": simd_counts,
+            "slowest_blocks": slowest_blocks(t, t0),
             "block0_waves_simd_tiles_firststart_firstend_lastend": [
                 [int(t[0, w, 7]) - 1, int(t[0, w, 5]), round(float((t[0, w, 2] - t0) * TICK_US), 2) if t[0, w, 2] else None,
                  round(float((t[0, w, 3] - t0) * TICK_US), 2) if t[0, w, 3] else None,
