@@ -190,6 +190,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "grid_blocks")) return &e->grid_blocks;
     if (!std::strcmp(key, "cnn_conv1_mfma")) return &e->cnn_conv1_mfma;
     if (!std::strcmp(key, "mlp_l1_mfma")) return &e->mlp_l1_mfma;
+    if (!std::strcmp(key, "mlp_pair")) return &e->mlp_pair;
     if (!std::strcmp(key, "cnn_pair")) return &e->cnn_pair;
     if (!std::strcmp(key, "cnn_pair_seg")) return &e->cnn_pair_seg;
     if (!std::strcmp(key, "cnn_seg")) return &e->cnn_seg;
@@ -251,7 +252,7 @@ int fx_model_create(fx_engine* e, int kind, int L, int A, int F, int H, int K, f
     m->blob.assign((size_t)np, 0.f);
     FX_HIP(e, hipSetDevice(e->device));
     if (hipMalloc(&m->d_blob, sizeof(float) * (size_t)np) != hipSuccess ||
-        hipMalloc(&m->d_packed, sizeof(float) * (size_t)m->layout.total_floats) != hipSuccess) {
+        hipMalloc(&m->d_packed, sizeof(float) * (size_t)m->layout.alloc_floats) != hipSuccess) {
         (void)hipGetLastError();
         if (m->d_blob) (void)hipFree(m->d_blob);
         delete m;
@@ -280,7 +281,7 @@ int fx_model_set_weights(fx_model* m, const float* blob, int64_t n) {
     if (n != (int64_t)m->blob.size()) return fx_fail(e, FX_ESHAPE, "weight blob has the wrong number of floats");
     FX_HIP(e, hipSetDevice(e->device));
     std::memcpy(m->blob.data(), blob, sizeof(float) * (size_t)n);
-    std::vector<float> packed((size_t)m->layout.total_floats);
+    std::vector<float> packed((size_t)m->layout.alloc_floats);
     fx_pack_weights(m->shape, m->blob.data(), packed.data());
     // in-flight kernels may still read the old weights
     FX_HIP(e, hipStreamSynchronize(e->stream));
@@ -861,7 +862,7 @@ int fx_nam_combine(fx_engine* e, int64_t Q, const double* signal, const double* 
 // Host-only helpers (no device needed) exported so the CPU test-suite can check
 // the weight packing and the bit-parallel distance without a GPU.
 int64_t fx_debug_packed_size(int kind, int L, int A, int F, int H, int K) {
-    return fx_pack_layout(FxShape{kind, L, A, F, H, K}).total_floats;
+    return fx_pack_layout(FxShape{kind, L, A, F, H, K}).alloc_floats;
 }
 int fx_debug_trace_read(fx_engine* e, uint64_t* out, int64_t cap_words) {
     if (!e || !out || cap_words < 0) return FX_EINVAL;
@@ -900,7 +901,7 @@ int fx_debug_pack_layout(int kind, int L, int A, int F, int H, int K, int64_t* o
 int fx_debug_pack_weights(int kind, int L, int A, int F, int H, int K, const float* blob, int64_t n, float* packed,
                           int64_t cap) {
     const FxShape s{kind, L, A, F, H, K};
-    if (!blob || !packed || n != fx_num_params(s) || cap < fx_pack_layout(s).total_floats) return FX_EINVAL;
+    if (!blob || !packed || n != fx_num_params(s) || cap < fx_pack_layout(s).alloc_floats) return FX_EINVAL;
     fx_pack_weights(s, blob, packed);
     return FX_OK;
 }

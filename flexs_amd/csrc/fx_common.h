@@ -38,7 +38,11 @@ struct FxPackLayout {
     int64_t conv_floats;        // everything above (the part that must sit in LDS)
     int64_t off_d1, off_d2, off_d3;  // dense blocks: CNN d1 FTxHT, d2 HTxHT; MLP d2, d3 HTxHT; GE d3 HTxHT
     int64_t off_db;             // bias / vector area (layout per kind, see pack.cpp)
-    int64_t total_floats;
+    int64_t total_floats;       // end of the vector area = end of what the kernels may stage in LDS as one image
+    // MLP on a 4-letter alphabet: first-layer rows summed for PAIRS of positions, [(L/2)*16 + (L%2)*4][16HT] floats after
+    // the image (row (pi*16 + 4*c0 + c1) = row(2pi, c0) + row(2pi+1, c1)); -1 = none
+    int64_t off_w1pair, pair_floats;
+    int64_t alloc_floats;       // size of the packed buffer (total_floats + pair table)
 };
 
 FxPackLayout fx_pack_layout(const FxShape& s);
@@ -88,6 +92,7 @@ struct fx_engine {
     int64_t wave_prio = 1;      // 1 = static, distinct issue priorities for the waves of a SIMD (fx_stagger_priority); 0 = A/B baseline
     int64_t trace = 0;          // 1 = the MFMA scoring kernels stamp an in-kernel timeline into d_trace (fx_debug_trace_read)
     unsigned long long* d_trace = nullptr;
+    int64_t mlp_pair = 1;       // 1 = MLP layer 1 on a 4-letter alphabet gathers one pre-summed row per PAIR of positions (0 = one row per position: A/B)
     int64_t mlp_l1_mfma = 0;    // 1 = one-hot MLP layer 1 on MFMA instead of the LDS gather (A/B knob)
     int num_cus = 256;
     int max_lds = 160 * 1024;

@@ -78,6 +78,13 @@ FxPackLayout fx_pack_layout(const FxShape& s) {
         p.off_db = off;    off += 4 + 4 * 16 * p.HT + 4;      // b1[4], w2, b2, b3, w4, bout
     }
     p.total_floats = rup(off, 4);
+    p.off_w1pair = -1;
+    p.pair_floats = 0;
+    if (s.kind == FX_MLP && s.A == 4) {
+        p.off_w1pair = p.total_floats;
+        p.pair_floats = ((int64_t)(s.L / 2) * 16 + (s.L % 2) * 4) * 16 * p.HT;
+    }
+    p.alloc_floats = p.total_floats + p.pair_floats;
     return p;
 }
 
@@ -148,7 +155,7 @@ void pack_vec(const float* v, const PosMap& map, int padded, float* dst) {
 
 void fx_pack_weights(const FxShape& s, const float* blob, float* packed) {
     const FxPackLayout p = fx_pack_layout(s);
-    std::memset(packed, 0, sizeof(float) * (size_t)p.total_floats);
+    std::memset(packed, 0, sizeof(float) * (size_t)p.alloc_floats);
     const int A = s.A, F = s.F, H = s.H, K = s.K, L = s.L, FT = p.FT, HT = p.HT;
     const PosMap hid = PosMap::hidden(H), fil = PosMap::identity(F, 16 * FT);
     const float* w = blob;
@@ -216,6 +223,22 @@ void fx_pack_weights(const FxShape& s, const float* blob, float* packed) {
         pack_vec(c3, hid, 16 * HT, packed + p.off_db + 32 * HT);
         pack_vec(d4, hid, 16 * HT, packed + p.off_db + 48 * HT);
         packed[p.off_db + 64 * HT] = c4[0];
+        if (p.off_w1pair >= 0) {
+            // one row per pair of positions and pair of letters: the float32 sum of the two single-position rows
+            const int64_t R = 16 * HT;
+            const float* rows = packed + p.off_w1p;
+            float* dst = packed + p.off_w1pair;
+            for (int pi = 0; pi < L / 2; ++pi)
+                for (int c0 = 0; c0 < 4; ++c0)
+                    for (int c1 = 0; c1 < 4; ++c1)
+                        for (int64_t k = 0; k < R; ++k)
+                            dst[((int64_t)pi * 16 + 4 * c0 + c1) * R + k] =
+                                rows[((int64_t)(2 * pi) * 4 + c0) * R + k] + rows[((int64_t)(2 * pi + 1) * 4 + c1) * R + k];
+            if (L % 2)
+                for (int c0 = 0; c0 < 4; ++c0)
+                    for (int64_t k = 0; k < R; ++k)
+                        dst[((int64_t)(L / 2) * 16 + c0) * R + k] = rows[((int64_t)(L - 1) * 4 + c0) * R + k];
+        }
     } else {
         const float* d1 = w;  w += (int64_t)L * A;
         const float* c1 = w;  w += 1;

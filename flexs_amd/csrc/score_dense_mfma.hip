@@ -32,6 +32,7 @@ struct DenseArgs {
     int L, A, rlh;
     int SG1, off_first, off_w1p, off_d2, off_d3, off_db, total_floats;
     int lds_from, lds_floats;   // the LDS image is packed[lds_from .. lds_from + lds_floats)
+    int off_w1pair, pair_floats; // PAIR (MLP, 4 letters): pre-summed first-layer rows per pair of positions, staged after the image
     // BT (GlobalEpistasis): first layer as a per-position table indexed by (raw byte - bt_base), Lpad x 32 floats at LDS offset 0
     const float* bt[FX_MAX_M];
     int Lpad;                   // L rounded up to 32 positions (the padding rows are zeros)
@@ -53,8 +54,9 @@ __global__ void k_ge_bytetab(const float* __restrict__ w1, const uint8_t* __rest
 
 // SLAB (with DG): the HxH blocks are streamed through LDS once per round of WAVES tiles (mma_layer_slab) instead
 // of once per tile per wave; the waves of a workgroup then walk the tiles in lockstep.
-template <int KIND, int A, int HT, int NT, int WAVES, bool G1, bool W1G, bool DG, bool SLAB = false, bool BT = false>
+template <int KIND, int A, int HT, int NT, int WAVES, bool G1, bool W1G, bool DG, bool SLAB = false, bool BT = false, bool PAIR = false>
 __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
+    static_assert(!PAIR || (KIND == FX_MLP && G1 && !W1G && !DG && NT == 1), "PAIR is the MLP gather form on a 4-letter alphabet");
     static_assert(!SLAB || (DG && NT == 1), "SLAB streams the L2-resident blocks of the one-tile form");
     static_assert(!BT || (KIND == FX_GE && NT == 1 && !DG && !SLAB), "BT is the GlobalEpistasis byte-table form");
     constexpr int KG = 2;                                       // input tiles per slab
@@ -63,10 +65,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
     const int g = lane >> 4, sq = lane & 15;
     const int L = p.L;
     float* img = smem + (BT ? p.Lpad * 32 : 0);                          // weight image (after the byte table, if any)
-    uint8_t* lut_s = reinterpret_cast<uint8_t*>(img + p.lds_floats);
-    int* next_tile = reinterpret_cast<int*>(img + p.lds_floats + 64);   // 4 work counters (one per SIMD), after the 256-byte LUT
+    float* wpair = img + p.lds_floats;                                   // PAIR: pair rows right after the image
+    float* aux = wpair + (PAIR ? p.pair_floats : 0);
+    uint8_t* lut_s = reinterpret_cast<uint8_t*>(aux);
+    int* next_tile = reinterpret_cast<int*>(aux + 64);                  // 4 work counters (one per SIMD), after the 256-byte LUT
     int* simd_waves = next_tile + 4;                                    // 4 wave counts (workgroup's waves per SIMD)
-    f4* slab = reinterpret_cast<f4*>(img + p.lds_floats + 64 + 8);      // SLAB: 2 x KG*HT KiB
+    f4* slab = reinterpret_cast<f4*>(aux + 64 + 8);                     // SLAB: 2 x KG*HT KiB
     fx_stamp(p.trace, 0);
     if (p.wave_prio) fx_stagger_priority();
     const int simd = fx_simd_id();
@@ -92,6 +96,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
             f4* dst = reinterpret_cast<f4*>(img);
             fill_lds(dst, src, p.lds_floats / 4);
             if (BT) fill_lds(reinterpret_cast<f4*>(smem), reinterpret_cast<const f4*>(p.bt[m]), p.Lpad * 8);
+            if (PAIR) fill_lds(reinterpret_cast<f4*>(wpair), reinterpret_cast<const f4*>(p.w[m] + p.off_w1pair), p.pair_floats / 4);
         }
         __syncthreads();
         if (m == m_first) share = fx_simd_share(simd_waves, simd);
@@ -140,7 +145,38 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                 static_assert(KIND != FX_MLP || A % 4 == 0, "one-hot k-steps must not straddle a position");
                 // ---- layer 1: relu(b1 + onehot @ W1), contraction index k = l*A + a
                 init_bias<HT, NT>(db, h, g);
-                if (G1) {
+                if constexpr (PAIR) {
+                    // 4-letter alphabet: one pre-summed row per PAIR of positions (16 letter pairs), i.e. half the LDS
+                    // traffic, half the adds and half the address arithmetic of the row-per-position gather below --
+                    // the first layer is what a tile waits for while the matrix pipe idles (profiles/r2_trace_probe)
+                    unsigned seen1 = 0;
+                    const int np2 = L >> 1;
+                    for (int p0 = 0; p0 < np2; p0 += 2) {
+                        asm volatile("" ::: "memory");
+                        int raw[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) raw[k] = row[0][2 * p0 + k < L ? 2 * p0 + k : 0];     // independent loads
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            if (p0 + k < np2) {
+                                const unsigned c0 = lut_s[raw[2 * k]], c1 = lut_s[raw[2 * k + 1]];
+                                seen1 |= c0 | c1;                  // a code is < 4, or 0xFF: tested once per tile
+                                const unsigned idx = ((c0 & 3u) << 2) | (c1 & 3u);
+                                const float* rowp = wpair + ((p0 + k) * 16 + idx) * (16 * HT) + 4 * g;
+#pragma unroll
+                                for (int mo = 0; mo < HT; ++mo) h[mo][0] += *reinterpret_cast<const f4*>(rowp + 16 * mo);
+                            }
+                        }
+                    }
+                    if (L & 1) {
+                        const unsigned c0 = lut_s[row[0][L - 1]];
+                        seen1 |= c0;
+                        const float* rowp = wpair + (np2 * 16 + (c0 & 3u)) * (16 * HT) + 4 * g;
+#pragma unroll
+                        for (int mo = 0; mo < HT; ++mo) h[mo][0] += *reinterpret_cast<const f4*>(rowp + 16 * mo);
+                    }
+                    bad |= seen1 >= 0x80u;
+                } else if (G1) {
                     // one-hot layer == sum of L kernel rows selected by the codes: LDS gather + VALU adds
                     unsigned seen1 = 0;
                     const unsigned amax1 = (unsigned)p.A - 1u;
@@ -349,9 +385,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
     if (bad) fx_raise(p.err, FX_ERR_BADCHAR);
 }
 
-template <int KIND, int A, int HT, int NT, int WAVES, bool G1, bool W1G = false, bool DG = false, bool SLAB = false, bool BT = false>
+template <int KIND, int A, int HT, int NT, int WAVES, bool G1, bool W1G = false, bool DG = false, bool SLAB = false, bool BT = false,
+          bool PAIR = false>
 int launch_inst(fx_engine* e, const DenseArgs& a, size_t lds_bytes) {
-    auto kern = k_score_dense_mfma<KIND, A, HT, NT, WAVES, G1, W1G, DG, SLAB, BT>;
+    auto kern = k_score_dense_mfma<KIND, A, HT, NT, WAVES, G1, W1G, DG, SLAB, BT, PAIR>;
     if (SLAB) lds_bytes += (size_t)2 * 2 * HT * 1024;           // two slabs of KG = 2 input tiles
     static bool attr_set[64] = {};
     if (!attr_set[e->device & 63]) {
@@ -418,6 +455,20 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
                 if (s.A == 20) return launch_inst<FX_MLP, 20, 7, 1, W, false, false, false>(e, a, lds);
             }
             return FX_EUNSUPPORTED;
+        }
+        if constexpr (!DGc) {
+            if (e->mlp_pair && lay.off_w1pair >= 0) {
+                // image = HxH blocks + vectors (the plain first-layer rows stay in global memory), then the pair rows
+                const int64_t img_floats = lay.total_floats - lay.off_d2;
+                const size_t need = (size_t)(img_floats + lay.pair_floats) * 4 + 256 + 32;
+                if (need <= (size_t)e->max_lds) {
+                    a.lds_from = (int)lay.off_d2;
+                    a.lds_floats = (int)img_floats;
+                    a.off_w1pair = (int)lay.off_w1pair;
+                    a.pair_floats = (int)lay.pair_floats;
+                    return launch_inst<FX_MLP, 4, HT_, 1, W, true, false, false, false, false, true>(e, a, need);
+                }
+            }
         }
         return launch_inst<FX_MLP, 4, HT_, 1, W, true, false, DGc>(e, a, lds);
     }

@@ -305,6 +305,31 @@ def test_ge_byte_table_first_layer(eng, L, alpha, H, M, n):
     assert_scores(got2[:, 0], ref_np.keras_fitness(seqs, alpha2, "ge", pairs[0][1], exact=True), "reversed alphabet")
 
 
+@pytest.mark.parametrize("L,H,M,n", [(14, 100, 1, 5000), (9, 100, 3, 333), (8, 64, 2, 100), (2, 100, 1, 40), (50, 100, 1, 1000)])
+def test_mlp_pair_rows_first_layer(eng, L, H, M, n):
+    """MLP layer 1 on a 4-letter alphabet from the pre-summed pair rows: within tolerance of the oracle and of the
+    row-per-position gather (one extra float32 rounding per pair), odd lengths, bad characters in either half of a pair."""
+    pairs = [make_native(eng, "mlp", L, 4, H, seed=70 + m) for m in range(M)]
+    nms = [p[0] for p in pairs]
+    lut = _native.make_lut("UGCA")
+    b, seqs = rand_seqs(n, L, "UGCA", seed=L)
+    got, _ = eng.score(nms, b, lut)
+    eng.set_option("mlp_pair", 0)
+    try:
+        single, _ = eng.score(nms, b, lut)
+    finally:
+        eng.set_option("mlp_pair", 1)
+    for m in range(M):
+        want = ref_np.keras_fitness(seqs, "UGCA", "mlp", pairs[m][1], exact=True)
+        assert_scores(got[:, m], want, f"mlp pair rows L={L} member {m}")
+        assert_scores(single[:, m], want, f"mlp single rows L={L} member {m}")
+    for col in {0, 1, L - 1}:
+        bb = b.copy()
+        bb[n - 1, col] = ord("T")                     # not in "UGCA"
+        with pytest.raises(ValueError):
+            eng.score(nms, bb, lut)
+
+
 @pytest.mark.parametrize("M", [1, 2, 3, 8, 11, 17])
 def test_ensemble_matrix_and_numpy_order_mean(eng, M):
     L, alpha = 8, "TGCA"

@@ -119,3 +119,27 @@ def test_myers_boundaries():
         assert _native.debug_myers(a, a) == 0
         assert _native.debug_myers(a, a[1:] + a[:1]) == c_oracle.levenshtein(a, a[1:] + a[:1])
     assert _native.debug_myers(b"x" * 769, b"x") == -1    # > 768 (12 words): unsupported pattern length
+
+
+def test_mlp_pair_rows_are_sums_of_the_single_position_rows():
+    """MLP on a 4-letter alphabet: the packed image carries, after the vectors, one row per (pair of positions, pair of
+    letters) = float32 sum of the two single-position rows (pack.cpp); an odd last position keeps its four rows."""
+    from oracle import ref_np
+
+    for L, H in ((14, 100), (7, 33), (2, 16)):
+        w = ref_np.synth_weights(ref_np.mlp_shapes(L, 4, H), 5)
+        lay = _native.debug_pack_layout(_native.FX_MLP, L, 4, 0, H, 0)
+        packed = _native.debug_pack_weights(_native.FX_MLP, L, 4, 0, H, 0, w)
+        R = 16 * lay["HT"]
+        rows = packed[lay["off_w1p"]: lay["off_w1p"] + L * 4 * R].reshape(L * 4, R)
+        n_pair_rows = (L // 2) * 16 + (L % 2) * 4
+        assert packed.shape[0] == lay["total_floats"] + n_pair_rows * R
+        pair = packed[lay["total_floats"]:].reshape(n_pair_rows, R)
+        for pi in range(L // 2):
+            for c0 in range(4):
+                for c1 in range(4):
+                    assert np.array_equal(pair[pi * 16 + 4 * c0 + c1], rows[(2 * pi) * 4 + c0] + rows[(2 * pi + 1) * 4 + c1])
+        if L % 2:
+            assert np.array_equal(pair[(L // 2) * 16:], rows[(L - 1) * 4:])
+    # other alphabets have no pair table
+    assert _native.lib().fx_debug_packed_size(_native.FX_MLP, 14, 20, 0, 100, 0) == _native.debug_pack_layout(_native.FX_MLP, 14, 20, 0, 100, 0)["total_floats"]
