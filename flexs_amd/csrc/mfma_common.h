@@ -98,6 +98,26 @@ __device__ __forceinline__ void fx_stagger_priority() {
     }
 }
 
+// The 16 x L sequence bytes of a tile are contiguous in memory: one wave copies them into its own LDS scratch with 16-byte
+// loads (ONE vector-memory instruction for L <= 64 instead of one byte-load instruction per position and lane group),
+// and the lanes then pick their bytes with ds_read_u8.  At kernel start every wave of the machine asks for its first
+// tile at once; with byte loads that was tens of thousands of requests and a ~2 us round trip per dependent step of a
+// first layer (profiles/r2_trace_probe: 8 us before the first MFMA of an MLP tile).  `src` may be unaligned (a row
+// offset into the caller's buffer): gfx950 runs compute with unaligned access enabled; the scratch is 16-byte aligned.
+typedef const __attribute__((address_space(3))) uint8_t* fx_lds_u8p;
+struct __attribute__((packed, aligned(1))) FxBytes16 { uint32_t w[4]; };
+__device__ __forceinline__ void fx_stage_tile(const uint8_t* __restrict__ src, int bytes, uint8_t* dst_lds, int lane) {
+    for (int off = lane * 16; off < bytes; off += 64 * 16) {
+        if (off + 16 <= bytes) {
+            const FxBytes16 v = *reinterpret_cast<const FxBytes16*>(src + off);
+            uint32_t* d = reinterpret_cast<uint32_t*>(dst_lds + off);
+            d[0] = v.w[0]; d[1] = v.w[1]; d[2] = v.w[2]; d[3] = v.w[3];
+        } else {
+            for (int b = off; b < bytes; ++b) dst_lds[b] = src[b];
+        }
+    }
+}
+
 // Share of the tile range [t_lo, t_hi) that belongs to this wave's SIMD, proportional to the number of the workgroup's
 // waves each SIMD hosts (counted once at kernel start, fx_count_simd_wave: 4-4-4-4 for a 16-wave workgroup, but
 // nothing here depends on the placement -- a SIMD without waves simply gets no tiles).

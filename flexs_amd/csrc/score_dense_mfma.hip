@@ -33,6 +33,7 @@ struct DenseArgs {
     int SG1, off_first, off_w1p, off_d2, off_d3, off_db, total_floats;
     int lds_from, lds_floats;   // the LDS image is packed[lds_from .. lds_from + lds_floats)
     int off_w1pair, pair_floats; // PAIR (MLP, 4 letters): pre-summed first-layer rows per pair of positions, staged after the image
+    int stage_stride;           // > 0: bytes of LDS scratch per wave for the tile's sequence bytes (fx_stage_tile); 0 = read them from global memory
     // BT (GlobalEpistasis): first layer as a per-position table indexed by (raw byte - bt_base), Lpad x 32 floats at LDS offset 0
     const float* bt[FX_MAX_M];
     int Lpad;                   // L rounded up to 32 positions (the padding rows are zeros)
@@ -71,6 +72,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
     int* next_tile = reinterpret_cast<int*>(aux + 64);                  // 4 work counters (one per SIMD), after the 256-byte LUT
     int* simd_waves = next_tile + 4;                                    // 4 wave counts (workgroup's waves per SIMD)
     f4* slab = reinterpret_cast<f4*>(aux + 64 + 8);                     // SLAB: 2 x KG*HT KiB
+    uint8_t* stw = reinterpret_cast<uint8_t*>(aux + 64 + 8) + (tid >> 6) * p.stage_stride;   // this wave's sequence-byte scratch (never with SLAB)
     fx_stamp(p.trace, 0);
     if (p.wave_prio) fx_stagger_priority();
     const int simd = fx_simd_id();
@@ -86,6 +88,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
     bool bad = false;
     unsigned tiles_done = 0;
     FxSimdShare share{0, 1, 1};
+    if (BT && p.stage_stride && lane < 32) stw[16 * L + lane] = (uint8_t)p.bt_base;   // what the padded trips of the last row read
 
     for (int m = m_first; m <= m_last; ++m) {
         __syncthreads();
@@ -139,6 +142,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                 n[nt] = (tg * NT + nt) * 16 + sq;
                 row[nt] = p.ascii + (n[nt] < p.N ? n[nt] : 0) * L;
             }
+            // the tile's bytes through this wave's LDS scratch (PAIR / BT first layers); lanes past the batch use row 0
+            const int64_t tile_rows = p.N - tg * 16 < 16 ? p.N - tg * 16 : 16;
+            if (p.stage_stride && (PAIR || BT)) fx_stage_tile(p.ascii + tg * 16 * L, (int)tile_rows * L, stw, lane);
+            const uint8_t* srow = stw + (n[0] < p.N ? sq : 0) * L;
             f4 h[HT][NT];
             float y[NT];
             if (KIND == FX_MLP) {
@@ -151,30 +158,34 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                     // the first layer is what a tile waits for while the matrix pipe idles (profiles/r2_trace_probe)
                     unsigned seen1 = 0;
                     const int np2 = L >> 1;
-                    for (int p0 = 0; p0 < np2; p0 += 2) {
-                        asm volatile("" ::: "memory");
-                        int raw[4];
+                    auto pair_layer = [&](auto rb) {
+                        for (int p0 = 0; p0 < np2; p0 += 2) {
+                            asm volatile("" ::: "memory");
+                            int raw[4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) raw[k] = row[0][2 * p0 + k < L ? 2 * p0 + k : 0];     // independent loads
+                            for (int k = 0; k < 4; ++k) raw[k] = rb[2 * p0 + k < L ? 2 * p0 + k : 0];     // independent loads
 #pragma unroll
-                        for (int k = 0; k < 2; ++k) {
-                            if (p0 + k < np2) {
-                                const unsigned c0 = lut_s[raw[2 * k]], c1 = lut_s[raw[2 * k + 1]];
-                                seen1 |= c0 | c1;                  // a code is < 4, or 0xFF: tested once per tile
-                                const unsigned idx = ((c0 & 3u) << 2) | (c1 & 3u);
-                                const float* rowp = wpair + ((p0 + k) * 16 + idx) * (16 * HT) + 4 * g;
+                            for (int k = 0; k < 2; ++k) {
+                                if (p0 + k < np2) {
+                                    const unsigned c0 = lut_s[raw[2 * k]], c1 = lut_s[raw[2 * k + 1]];
+                                    seen1 |= c0 | c1;                  // a code is < 4, or 0xFF: tested once per tile
+                                    const unsigned idx = ((c0 & 3u) << 2) | (c1 & 3u);
+                                    const float* rowp = wpair + ((p0 + k) * 16 + idx) * (16 * HT) + 4 * g;
 #pragma unroll
-                                for (int mo = 0; mo < HT; ++mo) h[mo][0] += *reinterpret_cast<const f4*>(rowp + 16 * mo);
+                                    for (int mo = 0; mo < HT; ++mo) h[mo][0] += *reinterpret_cast<const f4*>(rowp + 16 * mo);
+                                }
                             }
                         }
-                    }
-                    if (L & 1) {
-                        const unsigned c0 = lut_s[row[0][L - 1]];
-                        seen1 |= c0;
-                        const float* rowp = wpair + (np2 * 16 + (c0 & 3u)) * (16 * HT) + 4 * g;
+                        if (L & 1) {
+                            const unsigned c0 = lut_s[rb[L - 1]];
+                            seen1 |= c0;
+                            const float* rowp = wpair + (np2 * 16 + (c0 & 3u)) * (16 * HT) + 4 * g;
 #pragma unroll
-                        for (int mo = 0; mo < HT; ++mo) h[mo][0] += *reinterpret_cast<const f4*>(rowp + 16 * mo);
-                    }
+                            for (int mo = 0; mo < HT; ++mo) h[mo][0] += *reinterpret_cast<const f4*>(rowp + 16 * mo);
+                        }
+                    };
+                    if (p.stage_stride) pair_layer((fx_lds_u8p)srow);
+                    else pair_layer(row[0]);
                     bad |= seen1 >= 0x80u;
                 } else if (G1) {
                     // one-hot layer == sum of L kernel rows selected by the codes: LDS gather + VALU adds
@@ -259,36 +270,41 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                     // 2 per position instead of ~7.  Characters outside the alphabet are checked
                     // through the LUT by ONE member's unit per tile (all members read the same bytes): a byte outside
                     // [bt_base, bt_base + 32) reads a neighbouring row or nothing, and the call fails anyway.
-                    const uint8_t* rp = row[0] + g;
                     const char* tb = reinterpret_cast<const char*>(smem) + g * 128 - p.bt_base * 4;
-                    const bool safe = (tg * 16 + 16) * (int64_t)L + 32 <= p.N * (int64_t)L;
+                    // padded trips read past the row: into the following rows of the batch (global memory) or of the
+                    // staged tile (+ 32 filler bytes behind its last row), which exist for every full tile
+                    const bool safe = p.stage_stride ? tile_rows == 16 : (tg * 16 + 16) * (int64_t)L + 32 <= p.N * (int64_t)L;
                     const bool check = p.validate && (int)(tg % p.M) == m;
                     unsigned seen = 0;
-                    if (safe) {
-                        // (one trip = 8 bytes per lane in flight; 32 in flight measured slower: registers spill)
-                        for (int t = 0; t < p.Lpad; t += 32) {
-                            int raw[8];
+                    auto table_layer = [&](auto rp) {
+                        if (safe) {
+                            // (one trip = 8 bytes per lane in flight; 32 in flight measured slower: registers spill)
+                            for (int t = 0; t < p.Lpad; t += 32) {
+                                int raw[8];
 #pragma unroll
-                            for (int k = 0; k < 8; ++k) raw[k] = rp[t + 4 * k];
+                                for (int k = 0; k < 8; ++k) raw[k] = rp[t + 4 * k];
 #pragma unroll
-                            for (int k = 0; k < 8; ++k)
-                                s[0] += *reinterpret_cast<const float*>(tb + t * 128 + k * 512 + raw[k] * 4);
-                            if (check) {
+                                for (int k = 0; k < 8; ++k)
+                                    s[0] += *reinterpret_cast<const float*>(tb + t * 128 + k * 512 + raw[k] * 4);
+                                if (check) {
 #pragma unroll
-                                for (int k = 0; k < 8; ++k) {
-                                    const unsigned c = lut_s[raw[k]];
-                                    seen |= (t + 4 * k + g < L) ? c : 0u;
+                                    for (int k = 0; k < 8; ++k) {
+                                        const unsigned c = lut_s[raw[k]];
+                                        seen |= (t + 4 * k + g < L) ? c : 0u;
+                                    }
                                 }
                             }
+                        } else {
+                            for (int l = g; l < L; l += 4) {
+                                const int raw = rp[l - g];
+                                s[0] += *reinterpret_cast<const float*>(tb + (l - g) * 128 + raw * 4);
+                                seen |= lut_s[raw];
+                            }
+                            if (!check) seen = 0;
                         }
-                    } else {
-                        for (int l = g; l < L; l += 4) {
-                            const int raw = rp[l - g];
-                            s[0] += *reinterpret_cast<const float*>(tb + (l - g) * 128 + raw * 4);
-                            seen |= lut_s[raw];
-                        }
-                        if (!check) seen = 0;
-                    }
+                    };
+                    if (p.stage_stride) table_layer((fx_lds_u8p)(srow + g));
+                    else table_layer(row[0] + g);
                     bad |= seen >= 0x80u;
                 } else {
                 // eight positions per trip: the byte loads, LUT reads and table reads of a trip are independent,
@@ -424,8 +440,10 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
             // byte-indexed first-layer table (a.bt[] prepared by the caller) + the HxH blocks and vectors
             a.lds_from = (int)lay.off_d3;
             a.lds_floats = (int)(lay.total_floats - lay.off_d3);
-            return launch_inst<FX_GE, 4, HT_, 1, W, false, false, false, false, true>(
-                e, a, (size_t)a.Lpad * 128 + (size_t)a.lds_floats * 4 + 256 + 32);
+            size_t need = (size_t)a.Lpad * 128 + (size_t)a.lds_floats * 4 + 256 + 32;
+            const size_t stride = ((size_t)16 * s.L + 32 + 15) / 16 * 16;            // tile bytes + filler for the padded trips
+            if (e->stage_bytes && need + W * stride <= (size_t)e->max_lds) { a.stage_stride = (int)stride; need += W * stride; }
+            return launch_inst<FX_GE, 4, HT_, 1, W, false, false, false, false, true>(e, a, need);
         }
     }
     if (lds > (size_t)e->max_lds) {
@@ -460,8 +478,10 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
             if (e->mlp_pair && lay.off_w1pair >= 0) {
                 // image = HxH blocks + vectors (the plain first-layer rows stay in global memory), then the pair rows
                 const int64_t img_floats = lay.total_floats - lay.off_d2;
-                const size_t need = (size_t)(img_floats + lay.pair_floats) * 4 + 256 + 32;
+                size_t need = (size_t)(img_floats + lay.pair_floats) * 4 + 256 + 32;
                 if (need <= (size_t)e->max_lds) {
+                    const size_t stride = ((size_t)16 * s.L + 15) / 16 * 16;
+                    if (e->stage_bytes && need + W * stride <= (size_t)e->max_lds) { a.stage_stride = (int)stride; need += W * stride; }
                     a.lds_from = (int)lay.off_d2;
                     a.lds_floats = (int)img_floats;
                     a.off_w1pair = (int)lay.off_w1pair;

@@ -330,6 +330,33 @@ def test_mlp_pair_rows_first_layer(eng, L, H, M, n):
             eng.score(nms, bb, lut)
 
 
+@pytest.mark.parametrize("kind,L,alpha", [("mlp", 14, "UGCA"), ("ge", 90, s_utils.AAS), ("mlp", 9, "TGCA"), ("ge", 33, s_utils.AAS), ("cnn", 8, "TGCA")])
+def test_tile_bytes_staged_through_lds_equal_byte_loads_at_any_alignment(eng, kind, L, alpha):
+    """The MLP / GE kernels copy a tile's 16 x L bytes into LDS with 16-byte loads: same bits as the byte-load form
+    (`stage_bytes` = 0), for a device buffer that starts at any byte offset (a row offset into a caller's batch),
+    batches that end inside a tile, and one-sequence batches."""
+    import torch
+
+    F, K = (32, 5) if kind == "cnn" else (0, 0)
+    nm, w = make_native(eng, kind, L, len(alpha), 100, F, K, seed=3)
+    lut = _native.make_lut(alpha)
+    for n, off in ((1000, 0), (1000, 3), (37, 1), (16, 5), (1, 7), (4097, 13)):
+        b, seqs = rand_seqs(n, L, alpha, seed=n + off)
+        buf = torch.zeros(n * L + 64, dtype=torch.uint8, device="cuda")
+        buf[off:off + n * L] = torch.from_numpy(b.reshape(-1)).cuda()
+        outs = []
+        for stage in (1, 0):
+            eng.set_option("stage_bytes", stage)
+            out = torch.full((n, 1), float("nan"), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            eng.score_dev([nm], buf.data_ptr() + off, n, L, lut, out.data_ptr(), None)
+            eng.sync()
+            outs.append(out.cpu().numpy()[:, 0])
+        eng.set_option("stage_bytes", 1)
+        assert np.array_equal(outs[0], outs[1]), (kind, n, off)
+        assert_scores(outs[0], ref_np.keras_fitness(seqs, alpha, kind, w, exact=True), f"{kind} staged n={n} off={off}")
+
+
 @pytest.mark.parametrize("M", [1, 2, 3, 8, 11, 17])
 def test_ensemble_matrix_and_numpy_order_mean(eng, M):
     L, alpha = 8, "TGCA"

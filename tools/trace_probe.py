@@ -101,7 +101,7 @@ def trace_case(label, kind, L, alpha, M, N, H=100, F=0, K=0, opts=None):
         })
     eng.set_option("trace", 0)
     for k_ in (opts or {}):
-        eng.set_option(k_, {"cnn_big_units": 12, "cnn_seg": -1, "ge_bytetab": 1, "mlp_pair": 1, "wave_prio": 1}.get(k_, 0))
+        eng.set_option(k_, {"cnn_big_units": 12, "cnn_seg": -1, "ge_bytetab": 1, "mlp_pair": 1, "wave_prio": 1, "stage_bytes": 1}.get(k_, 0))
     out = {"what": label, "event_us_per_launch": ev_us, "trace": res[-1], "span_us_3runs": [r["span_us"] for r in res]}
     print(json.dumps(out), flush=True)
     return out
@@ -117,6 +117,9 @@ if __name__ == "__main__":
         rows.append(trace_case(f"ge L=90 M={M} N={N} ge_bytetab=0", "ge", 90, AAS, M, N, opts={"ge_bytetab": 0}))
     rows.append(trace_case("mlp L=14 M=1 N=100000", "mlp", 14, "UGCA", 1, 100_000))
     rows.append(trace_case("mlp L=14 M=1 N=100000 mlp_pair=0", "mlp", 14, "UGCA", 1, 100_000, opts={"mlp_pair": 0}))
+    rows.append(trace_case("mlp L=14 M=1 N=100000 stage_bytes=0", "mlp", 14, "UGCA", 1, 100_000, opts={"stage_bytes": 0}))
+    rows.append(trace_case("ge L=90 M=8 N=100000 stage_bytes=0", "ge", 90, AAS, 8, 100_000, opts={"stage_bytes": 0}))
+    rows.append(trace_case("ge L=90 M=1 N=100000 stage_bytes=0", "ge", 90, AAS, 1, 100_000, opts={"stage_bytes": 0}))
     rows.append(trace_case("ge L=90 M=8 N=100000 wave_prio=1", "ge", 90, AAS, 8, 100_000, opts={"wave_prio": 1}))
     rows.append(trace_case("ge L=90 M=1 N=100000 wave_prio=1", "ge", 90, AAS, 1, 100_000, opts={"wave_prio": 1}))
     rows.append(trace_case("cnn L=8 M=3 N=100000 wave_prio=1", "cnn", 8, "TGCA", 3, 100_000, F=32, K=5, opts={"wave_prio": 1}))
