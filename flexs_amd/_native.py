@@ -15,7 +15,8 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libflexs_amd.so")
+# FLEXS_AMD_LIB: another build of the same library (profiling builds, e.g. `make trace` = -DFX_TRACE_PHASES)
+LIB_PATH = os.environ.get("FLEXS_AMD_LIB") or os.path.join(_HERE, "libflexs_amd.so")
 
 FX_OK, FX_EINVAL, FX_ESHAPE, FX_EBADCHAR, FX_ENODEV = 0, -1, -2, -3, -4
 FX_EHIP, FX_ENOMEM, FX_EUNSUPPORTED, FX_ESTATE = -5, -6, -7, -8

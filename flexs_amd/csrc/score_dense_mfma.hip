@@ -253,6 +253,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                 if constexpr (SLAB) mma_layer_slab<HT, HT, KG, WAVES * 64>(w_d3, slab, h2, h, lane, p.rlh);
                 else mma_layer<HT, HT, NT>(w_d3, h2, h, lane, p.rlh);
                 relu_tiles<HT, NT>(h);
+                FX_PHASE_STAMP(10);
                 final_dot<HT, NT>(db + 48 * HT, db[64 * HT], h, y, g);
             } else {
                 // ---- GE layer 1: s = relu(b1 + sum_l w1[l*A + code_l])   (scalar per sequence)

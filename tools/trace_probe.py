@@ -109,6 +109,16 @@ def trace_case(label, kind, L, alpha, M, N, H=100, F=0, K=0, opts=None):
 
 if __name__ == "__main__":
     rows = []
+    if os.environ.get("FLEXS_AMD_LIB"):
+        # phase build: only the cases whose first-tile phases are in question
+        for M, N in ((1, 100_000), (1, 4_000)):
+            rows.append(trace_case(f"[phases] mlp L=14 M={M} N={N}", "mlp", 14, "UGCA", M, N))
+        rows.append(trace_case("[phases] ge L=90 M=1 N=100000", "ge", 90, AAS, 1, 100_000))
+        rows.append(trace_case("[phases] ge L=90 M=8 N=100000", "ge", 90, AAS, 8, 100_000))
+        rows.append(trace_case("[phases] ge L=90 M=1 N=4000", "ge", 90, AAS, 1, 4_000))
+        rows.append(trace_case("[phases] cnn L=8 M=1 N=10000", "cnn", 8, "TGCA", 1, 10_000, F=32, K=5))
+        json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "trace_probe_phases.json"), "w"), indent=1)
+        sys.exit(0)
     for M, N in ((1, 4000), (1, 10_000), (1, 32_768), (3, 10_000), (3, 100_000)):
         rows.append(trace_case(f"cnn L=8 M={M} N={N}", "cnn", 8, "TGCA", M, N, F=32, K=5))
     rows.append(trace_case("cnn L=8 M=1 N=10000 big_units=1", "cnn", 8, "TGCA", 1, 10_000, F=32, K=5, opts={"cnn_big_units": 1}))
