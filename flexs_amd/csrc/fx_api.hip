@@ -201,6 +201,8 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "trace")) return &e->trace;
     if (!std::strcmp(key, "ge_bytetab")) return &e->ge_bytetab;
     if (!std::strcmp(key, "wave_prio")) return &e->wave_prio;
+    if (!std::strcmp(key, "dense_waves")) return &e->dense_waves;
+    if (!std::strcmp(key, "dense_few_waves_below")) return &e->dense_few_waves_below;
     return nullptr;
 }
 int fx_engine_set_option(fx_engine* e, const char* key, int64_t value) {

@@ -432,6 +432,12 @@ template <int HT_>
 int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, DenseArgs& a) {
     constexpr int W = HT_ <= 7 ? 16 : 8;
     constexpr bool DGc = HT_ > 8;
+    // Mid-size launches (a handful of tiles per SIMD): two waves per SIMD instead of four.  With four, a SIMD's 5-7
+    // tiles go 2-2-1-1 to its waves: the first round runs four first layers at once on one LDS / VALU (7 us before the
+    // first MFMA), the second round has two waves left; with two waves the tiles go 3-3 and one wave's first layer
+    // overlaps the other's MFMA layers (profiles/r2_trace_probe).  Long launches keep four (best steady state).
+    const int64_t tiles_per_simd = (int64_t)a.M * a.TG / ((int64_t)e->num_cus * 4);
+    const bool few_waves = e->dense_waves == 8 || (e->dense_waves == 0 && tiles_per_simd < e->dense_few_waves_below);
     const int64_t tail = DGc ? lay.off_d2 : lay.total_floats;           // end of the LDS image
     int64_t lds_from = (s.kind == FX_MLP && !e->mlp_l1_mfma) ? lay.off_w1p : 0;
     size_t lds = (size_t)(tail - lds_from) * 4 + 256 + 32;
@@ -444,6 +450,9 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
             size_t need = (size_t)a.Lpad * 128 + (size_t)a.lds_floats * 4 + 256 + 32;
             const size_t stride = ((size_t)16 * s.L + 32 + 15) / 16 * 16;            // tile bytes + filler for the padded trips
             if (e->stage_bytes && need + W * stride <= (size_t)e->max_lds) { a.stage_stride = (int)stride; need += W * stride; }
+            if constexpr (HT_ == 7) {
+                if (few_waves) return launch_inst<FX_GE, 4, HT_, 1, 8, false, false, false, false, true>(e, a, need);
+            }
             return launch_inst<FX_GE, 4, HT_, 1, W, false, false, false, false, true>(e, a, need);
         }
     }
@@ -487,6 +496,9 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
                     a.lds_floats = (int)img_floats;
                     a.off_w1pair = (int)lay.off_w1pair;
                     a.pair_floats = (int)lay.pair_floats;
+                    if constexpr (HT_ == 7) {
+                        if (few_waves) return launch_inst<FX_MLP, 4, HT_, 1, 8, true, false, false, false, false, true>(e, a, need);
+                    }
                     return launch_inst<FX_MLP, 4, HT_, 1, W, true, false, false, false, false, true>(e, a, need);
                 }
             }

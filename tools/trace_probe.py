@@ -102,6 +102,8 @@ def trace_case(label, kind, L, alpha, M, N, H=100, F=0, K=0, opts=None):
     eng.set_option("trace", 0)
     for k_ in (opts or {}):
         eng.set_option(k_, {"cnn_big_units": 12, "cnn_seg": -1, "ge_bytetab": 1, "mlp_pair": 1, "wave_prio": 1, "stage_bytes": 1}.get(k_, 0))
+    for k_ in (opts or {}):
+        eng.set_option(k_, {"cnn_big_units": 12, "cnn_seg": -1, "ge_bytetab": 1, "mlp_pair": 1, "wave_prio": 1, "stage_bytes": 1, "dense_waves": 0}.get(k_, 0))
     out = {"what": label, "event_us_per_launch": ev_us, "trace": res[-1], "span_us_3runs": [r["span_us"] for r in res]}
     print(json.dumps(out), flush=True)
     return out
@@ -127,6 +129,11 @@ if __name__ == "__main__":
         rows.append(trace_case(f"ge L=90 M={M} N={N} ge_bytetab=0", "ge", 90, AAS, M, N, opts={"ge_bytetab": 0}))
     rows.append(trace_case("mlp L=14 M=1 N=100000", "mlp", 14, "UGCA", 1, 100_000))
     rows.append(trace_case("mlp L=14 M=1 N=100000 mlp_pair=0", "mlp", 14, "UGCA", 1, 100_000, opts={"mlp_pair": 0}))
+    for dw in (8, 16):
+        for N in (50_000, 100_000, 200_000, 400_000, 1_000_000):
+            rows.append(trace_case(f"mlp L=14 M=1 N={N} dense_waves={dw}", "mlp", 14, "UGCA", 1, N, opts={"dense_waves": dw}))
+        for M, N in ((1, 100_000), (1, 400_000), (8, 100_000)):
+            rows.append(trace_case(f"ge L=90 M={M} N={N} dense_waves={dw}", "ge", 90, AAS, M, N, opts={"dense_waves": dw}))
     rows.append(trace_case("mlp L=14 M=1 N=100000 stage_bytes=0", "mlp", 14, "UGCA", 1, 100_000, opts={"stage_bytes": 0}))
     rows.append(trace_case("ge L=90 M=8 N=100000 stage_bytes=0", "ge", 90, AAS, 8, 100_000, opts={"stage_bytes": 0}))
     rows.append(trace_case("ge L=90 M=1 N=100000 stage_bytes=0", "ge", 90, AAS, 1, 100_000, opts={"stage_bytes": 0}))
