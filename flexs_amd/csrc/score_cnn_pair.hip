@@ -64,11 +64,11 @@ __device__ __forceinline__ float pair_dense_head(const f4* w_d1, const f4* w_d2,
     return y[0];
 }
 
-// HEAD = false (whole-sequence form only): the conv part only -- each wave leaves its half of the tile's pooled features
-// in `pool` ([unit][2 tiles][64 lanes] f4, the layout of score_cnn_split.hip) and k_cnn_head finishes the sequence.
+// HEAD = false: the conv part only -- each wave leaves its half of the tile's pooled features in `pool`
+// ([unit][2 tiles][64 lanes] f4, the layout of score_cnn_split.hip; with SEG the segments meet there through atomicMax on
+// the float bits of a zeroed pool) and k_cnn_head finishes the sequence.
 template <int A, int K, int HT, int WAVES, bool SEG, bool HEAD = true>
 __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
-    static_assert(HEAD || !SEG, "the conv-only form is the whole-sequence form");
     constexpr int FT = 2, K3 = A - 1, PAIRS = WAVES / 2;
     constexpr int PL2 = (K - 1) / 2, PR2 = K - 1 - PL2;
     constexpr int PL3 = (K3 - 1) / 2, PR3 = K3 - 1 - PL3;
@@ -244,8 +244,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
                 accw[K3 - 1] = bias3;
             }
 
-            if constexpr (!HEAD) {
+            if constexpr (!HEAD && !SEG) {
                 if (live) reinterpret_cast<f4*>(p.pool)[(((int64_t)m * p.TG + tg) * 2 + mo) * 64 + lane] = gmax;
+            } else if constexpr (!HEAD && SEG) {
+                unsigned* pl = p.pool + ((((int64_t)m * p.TG + tg) * 2 + mo) * 64 + lane) * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicMax(&pl[r], __float_as_uint(gmax[r]));
             } else if (!SEG) {
                 // ---- pooled features: swap halves once more, then wave 0 of the pair runs the dense head
                 f4* pslot = xbuf + ((2 * PAIRS + pair) * 2) * 64;  // dedicated slot: no reuse hazard with the step slots
@@ -325,15 +329,30 @@ int launch_pair(fx_engine* e, PairArgs a, size_t lds_bytes) {
 }
 
 template <int K>
-int launch_pair_conv(fx_engine* e, const PairArgs& a, size_t lds_bytes) {
+int launch_pair_conv(fx_engine* e, PairArgs a, size_t lds_bytes) {
     constexpr int WAVES = 8;
     auto kern = k_score_cnn_pair<20, K, 1, WAVES, false, false>;
+    auto seg = k_score_cnn_pair<20, K, 1, WAVES, true, false>;
     static bool attr_set[64] = {};
     if (!attr_set[e->device & 63]) {
         FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(seg), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[e->device & 63] = true;
     }
     const int64_t U = (int64_t)a.M * a.TG;
+    // small batch: position-segmented over SB workgroups per tile, as launch_pair does for the fused form
+    const int L1 = a.L - K + 1;
+    int64_t sb = L1 / ((WAVES / 2) * 12);
+    if (sb > e->num_cus / U) sb = e->num_cus / U;
+    if (e->cnn_pair_seg == 0 || 2 * U > e->num_cus) sb = 0;
+    if (e->cnn_pair_seg > 0) sb = e->cnn_pair_seg;
+    if (sb >= 1) {
+        FX_HIP(e, hipMemsetAsync(a.pool, 0, (size_t)U * 2 * 64 * 4 * sizeof(unsigned), e->stream));   // maxima of relu outputs: >= +0
+        a.SB = (int)sb;
+        hipLaunchKernelGGL(seg, dim3((unsigned)(U * sb)), dim3(WAVES * 64), lds_bytes, e->stream, a);
+        FX_HIP(e, hipGetLastError());
+        return FX_OK;
+    }
     int64_t blocks = e->grid_blocks > 0 ? e->grid_blocks : e->num_cus;
     if (blocks > U) blocks = U;
     if (blocks < 1) blocks = 1;

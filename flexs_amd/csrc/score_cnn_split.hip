@@ -106,6 +106,14 @@ int dispatch_head(fx_engine* e, const HeadArgs& a, int HT) {
 template <int K, int FT>
 int launch_conv(fx_engine* e, const CnnArgs& a, size_t lds) {
     // conv part only: one tile per wave, 8 waves, conv weights in LDS, first layer in gather form
+    if constexpr (K * 3 <= 16) {
+        // small batch of long sequences (an explorer's 1-100 sequence call): the 8 waves of a workgroup split one
+        // tile's positions, as in the fused kernel (score_cnn_mfma.hip) -- bit-identical to the one-wave walk
+        const int L1 = a.L - K + 1;
+        const bool seg = e->cnn_seg != 0 && (int64_t)a.M * a.TG <= e->num_cus && (e->cnn_seg > 0 || L1 >= 24) &&
+                         lds + (size_t)8 * FT * 64 * 16 <= (size_t)e->max_lds;
+        if (seg) return launch_g<4, K, FT, 1, 1, false, 8, true, 0, false, true, false>(e, a, lds);
+    }
     return launch_g<4, K, FT, 1, 1, false, 8, true, 0, false, false, false>(e, a, lds);
 }
 

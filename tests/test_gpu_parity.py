@@ -1326,6 +1326,42 @@ def test_cnn_split_conv_and_head_path(eng, L, F, H, K, n, M):
         eng.score(list(natives), bad, lut)
 
 
+@pytest.mark.parametrize("A,alpha,L,F,H,K,n,M", [(4, "UGCA", 100, 32, 50, 3, 20, 3), (4, "UGCA", 50, 48, 200, 4, 1, 1), (4, "TGCA", 64, 16, 128, 2, 100, 2),
+                                                 (4, "UGCA", 40, 32, 64, 5, 33, 1), (20, s_utils.AAS, 237, 32, 50, 3, 40, 3),
+                                                 (20, s_utils.AAS, 90, 24, 200, 4, 1, 1), (20, s_utils.AAS, 120, 32, 128, 6, 16, 2)])
+def test_cnn_split_path_position_segmented_small_batches(eng, A, alpha, L, F, H, K, n, M):
+    """Small batches of long sequences on the conv + head path (non-canonical CNN shapes): the conv kernel cuts a
+    tile's positions over the waves of a workgroup (4-letter alphabets) or over several workgroups (protein alphabet,
+    segment maxima meeting in a zeroed pool through atomicMax on the float bits) -- same bits as the whole-sequence
+    walk, and the oracle's values."""
+    natives, ws = zip(*[make_native(eng, "cnn", L, A, H, F, K, seed=40 + m) for m in range(M)])
+    lut = _native.make_lut(alpha)
+    b, seqs = rand_seqs(n, L, alpha, seed=L + K)
+    got, mean = eng.score(list(natives), b, lut, want_matrix=True, want_mean=True)
+    eng.set_option("cnn_seg", 0)
+    eng.set_option("cnn_pair_seg", 0)
+    try:
+        whole, _ = eng.score(list(natives), b, lut)
+    finally:
+        eng.set_option("cnn_seg", -1)
+        eng.set_option("cnn_pair_seg", -1)
+    assert np.array_equal(got, whole)
+    for m in range(M):
+        assert_scores(got[:, m], ref_np.keras_fitness(seqs, alpha, "cnn", ws[m], exact=True), f"segmented split A={A} L={L} K={K} H={H}")
+    assert np.array_equal(mean, np.mean(got, axis=1))
+    if A == 20:
+        for sb in (1, 2, 3):                        # forced workgroups per tile
+            eng.set_option("cnn_pair_seg", sb)
+            try:
+                forced, _ = eng.score(list(natives), b, lut)
+            finally:
+                eng.set_option("cnn_pair_seg", -1)
+            assert np.array_equal(forced, whole), sb
+    bad = b.copy(); bad[n - 1, L - 1] = ord("!")
+    with pytest.raises(ValueError):
+        eng.score(list(natives), bad, lut)
+
+
 @pytest.mark.parametrize("L,F,H,K,n,M", [(30, 32, 100, 3, 200, 2), (60, 32, 50, 7, 64, 1), (25, 24, 200, 4, 100, 1), (90, 32, 100, 6, 40, 3),
                                          (237, 32, 64, 3, 17, 1), (8, 32, 256, 2, 33, 1)])
 def test_cnn_split_path_protein_alphabet(eng, L, F, H, K, n, M):
