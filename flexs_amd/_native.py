@@ -198,11 +198,14 @@ def sequences_to_bytes(sequences, L: Optional[int] = None, staging: Optional["En
         else:
             cp = a.view(np.uint32).reshape(N, a.dtype.itemsize // 4)
         if N:
-            used = cp != 0
-            w = int(used.any(axis=0).nonzero()[0].max(initial=-1)) + 1      # longest string
-            cp = cp[:, :w]
-            if not used[:, :w].all():
-                raise ValueError("ragged sequence batch")
+            if cp.shape[1] and cp.min() != 0:                              # the usual case: the item size IS the length
+                pass
+            else:
+                used = cp != 0
+                w = int(used.any(axis=0).nonzero()[0].max(initial=-1)) + 1  # longest string
+                cp = cp[:, :w]
+                if not used[:, :w].all():
+                    raise ValueError("ragged sequence batch")
             if cp.dtype != np.uint8 and cp.max(initial=0) > 255:
                 raise ValueError("substring not found")
         out = np.ascontiguousarray(cp.astype(np.uint8, copy=False))

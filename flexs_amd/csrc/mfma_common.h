@@ -65,14 +65,19 @@ __device__ __forceinline__ unsigned fx_xcd_block() {
 // were two straddling workgroups; 194 -> ~180 us on the 3 x 1e5 bench launch).
 __device__ __forceinline__ void fx_unit_range(int64_t TG, int M, int64_t& u_lo, int64_t& u_hi) {
     const int64_t G = gridDim.x, bid = fx_xcd_block();
-    if (M > 1 && G >= M) {
+    const int64_t U = (int64_t)M * TG;
+    // ... unless cutting at the member boundaries makes the largest share bigger: with coarse units (the two-waves-per-
+    // tile protein kernel: a tile is a ~1.4 ms serial walk, 12 tiles per workgroup) one more tile on the workgroups of a
+    // member with fewer workgroups outweighs a boundary crossing (3 x 1024 tiles on 256 workgroups: 12 each, or 13 on 85)
+    const int64_t nb_min = M > 0 ? G / M : 0;
+    const bool by_member = M > 1 && nb_min >= 1 && (TG + nb_min - 1) / nb_min <= (U + G - 1) / G;
+    if (by_member) {
         const int64_t m = bid * M / G;
         const int64_t g_lo = (m * G + M - 1) / M, g_hi = ((m + 1) * G + M - 1) / M;
         const int64_t nb = g_hi - g_lo, j = bid - g_lo;
         u_lo = m * TG + TG * j / nb;
         u_hi = m * TG + TG * (j + 1) / nb;
     } else {
-        const int64_t U = (int64_t)M * TG;
         u_lo = U * bid / G;
         u_hi = U * (bid + 1) / G;
     }

@@ -43,19 +43,16 @@ def time_score(kind, L, alpha, H, M, N, F=0, K=0, reps=20, generic=False, varian
     ms_ = natives(kind, L, A, H, M, F, K)
     lut = _native.make_lut(alpha)
     d_in = torch.from_numpy(synth.random_sequence_bytes(N, L, alpha, 0)).cuda()
-    d_nm = torch.empty((N, M), dtype=torch.float32, device="cuda")
+    stride = (N + 63) // 64 * 64
+    d_pl = torch.empty((M, stride), dtype=torch.float32, device="cuda")      # member-major planes (the engine's own layout)
     torch.cuda.synchronize()
     eng.set_option("force_generic", int(generic))
     eng.set_option("cnn_variant", variant)
     for k_, v_ in (opts or {}).items():
         eng.set_option(k_, v_)
-    for _ in range(3):
-        eng.score_dev(ms_, d_in.data_ptr(), N, L, lut, d_nm.data_ptr(), None)
-    eng.sync()
-    eng.timer_start()
-    for _ in range(reps):
-        eng.score_dev(ms_, d_in.data_ptr(), N, L, lut, d_nm.data_ptr(), None)
-    ms = eng.timer_stop() / reps
+    # launches issued from C (fx_debug_time_score): a Python loop cannot keep the GPU busy with < 25 us kernels
+    eng.time_score_planes(ms_, d_in.data_ptr(), N, L, lut, d_pl.data_ptr(), stride, 3)
+    ms = eng.time_score_planes(ms_, d_in.data_ptr(), N, L, lut, d_pl.data_ptr(), stride, reps) / reps
     eng.set_option("force_generic", 0)
     eng.set_option("cnn_variant", 0)
     for k_ in (opts or {}):
