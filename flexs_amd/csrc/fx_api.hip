@@ -66,6 +66,9 @@ int fx_upload_lut(fx_engine* e, const uint8_t lut[256]) {
 int fx_trace_buffer(fx_engine* e, unsigned long long** out) {
     *out = nullptr;
     if (!e->trace) return FX_OK;
+#if !defined(FX_TRACE)
+    return fx_fail(e, FX_EUNSUPPORTED, "this build has no in-kernel timeline: use the `make trace` build (FLEXS_AMD_LIB=.../libflexs_amd_trace.so)");
+#endif
     if (!e->d_trace) {
         if (hipMalloc(reinterpret_cast<void**>(&e->d_trace), FX_TRACE_BYTES) != hipSuccess) {
             (void)hipGetLastError();

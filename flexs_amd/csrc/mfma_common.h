@@ -151,16 +151,38 @@ __device__ __forceinline__ FxSimdShare fx_simd_share(const int* counters, int si
 // Workgroup copy of a member's packed weights into LDS.  Eight 16-byte loads are in flight per thread before the
 // first LDS store, so the ~100 KiB image costs a couple of L2 round trips instead of one per 16 bytes per thread
 // (which is what a plain copy loop compiles to, and what small calls and small batches then mostly wait for).
+template <int DEPTH = 8>
 __device__ __forceinline__ void fill_lds(f4* __restrict__ dst, const f4* __restrict__ src, int n4) {
     const int bd = blockDim.x;
-    for (int i0 = threadIdx.x; i0 < n4; i0 += 8 * bd) {
-        f4 v[8];
+    for (int i0 = threadIdx.x; i0 < n4; i0 += DEPTH * bd) {
+        f4 v[DEPTH];
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
+        for (int k = 0; k < DEPTH; ++k)
             if (i0 + k * bd < n4) v[k] = src[i0 + k * bd];
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
+        for (int k = 0; k < DEPTH; ++k)
             if (i0 + k * bd < n4) dst[i0 + k * bd] = v[k];
+    }
+}
+
+// Two segments in one pass (the dense kernels stage a first-layer table next to the weight image): all the loads of
+// both are in flight before the first LDS store, up to 12 per thread, so that the fill is ONE memory round trip instead
+// of one per segment (4.0 us for 63 KiB in two passes, profiles/r2_trace_probe).
+__device__ __forceinline__ void fill_lds2(f4* __restrict__ dst1, const f4* __restrict__ src1, int n1,
+                                          f4* __restrict__ dst2, const f4* __restrict__ src2, int n2) {
+    const int bd = blockDim.x, n = n1 + n2;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 12 * bd) {
+        f4 v[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const int i = i0 + k * bd;
+            if (i < n) v[k] = i < n1 ? src1[i] : src2[i - n1];
+        }
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const int i = i0 + k * bd;
+            if (i < n) { if (i < n1) dst1[i] = v[k]; else dst2[i - n1] = v[k]; }
+        }
     }
 }
 
@@ -168,15 +190,24 @@ __device__ __forceinline__ void fill_lds(f4* __restrict__ dst, const f4* __restr
 // constant-rate wall clock (100 MHz) into slot `slot` of its row; `t` is null in normal operation.
 #define FX_TRACE_SLOTS 16
 #define FX_TRACE_WAVES 16
+#if defined(FX_TRACE)
 __device__ __forceinline__ void fx_stamp(unsigned long long* t, int slot, unsigned long long v = ~0ull) {
     if (t && (threadIdx.x & 63) == 0)
         t[((size_t)blockIdx.x * FX_TRACE_WAVES + (threadIdx.x >> 6)) * FX_TRACE_SLOTS + slot] = (v == ~0ull) ? wall_clock64() : v;
 }
+// end of a tile: first-tile end (3), last-tile end (4), tiles processed (5)
+#define FX_TILE_DONE() do { if (p.trace) { if (tiles_done == 0) fx_stamp(p.trace, 3); fx_stamp(p.trace, 4); fx_stamp(p.trace, 5, ++tiles_done); } } while (0)
+#else
+// production build: the timeline costs registers in kernels that have none to spare (the 16-wave forms sit at their
+// 128-VGPR budget), so the stamps exist only in `make trace` builds (-DFX_TRACE, libflexs_amd_trace.so)
+__device__ __forceinline__ void fx_stamp(unsigned long long*, int, unsigned long long = 0) {}
+#define FX_TILE_DONE() do { } while (0)
+#endif
 
 // Phase stamps INSIDE a tile (slots 8..10 of the first tile) split the tile's code into scheduling regions -- the
 // layers no longer overlap, +7 % on the GlobalEpistasis kernel -- so they exist only in builds made with
-// -DFX_TRACE_PHASES (make CXXFLAGS+=-DFX_TRACE_PHASES); the stamps at tile boundaries are always there.
-#if defined(FX_TRACE_PHASES)
+// -DFX_TRACE_PHASES as well (make trace-phases).
+#if defined(FX_TRACE) && defined(FX_TRACE_PHASES)
 #define FX_PHASE_STAMP(slot) do { if (tiles_done == 0) fx_stamp(p.trace, (slot)); } while (0)
 #else
 #define FX_PHASE_STAMP(slot) do { } while (0)

@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
     if (u_lo >= u_hi) return;
     const int m_first = (int)(u_lo / p.TG), m_last = (int)((u_hi - 1) / p.TG);
     bool bad = false;
-    unsigned tiles_done = 0;
+    [[maybe_unused]] unsigned tiles_done = 0;
     FxSimdShare share{0, 1, 1};
 
     for (int m = m_first; m <= m_last; ++m) {
@@ -92,7 +92,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
         {
             const f4* src = reinterpret_cast<const f4*>(p.w[m]);
             f4* dst = reinterpret_cast<f4*>(smem);
-            fill_lds(dst, src, lds_floats / 4);
+            // a member's ~103 KiB in ONE round trip: 13 x 16 bytes in flight per thread for 8-wave workgroups, 8 for 16
+            fill_lds<(WAVES <= 8 ? 14 : 8)>(dst, src, lds_floats / 4);
         }
         __syncthreads();
         if (m == m_first) share = fx_simd_share(simd_waves, simd);
@@ -153,8 +154,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
             // one tile per SIMD) otherwise pays one global round trip per position (profiles/r2_trace_probe: 8.4 us
             // for the conv part of an L = 8 tile whose MFMAs take 5.5 us).  The unrolled forms (L1S > 0) run with
             // four waves per SIMD, which hide it, and have no registers to spare.
-            constexpr int PF = (L1S > 0) ? 1 : (!RING ? 2 : (UN % 3 == 0 ? 3 : (UN % 2 == 0 ? 2 : 1)));
-            static_assert(L1S > 0 || !RING || UN % PF == 0, "ring slots of the byte queue must be compile-time constants");
+            constexpr bool AHEAD = (L1S == 0) && (WAVES <= 8);     // (16-wave forms: four waves per SIMD hide it, no registers to spare)
+            constexpr int PF = !AHEAD ? 1 : (!RING ? 2 : (UN % 3 == 0 ? 3 : (UN % 2 == 0 ? 2 : 1)));
+            static_assert(!AHEAD || !RING || UN % PF == 0, "ring slots of the byte queue must be compile-time constants");
             int rq[PF][NT];
             f4 win1[K][FT][NT], win2[K3][FT][NT], gmax[FT][NT];
 #pragma unroll
@@ -195,7 +197,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                     cw[j][0] = c;
                 }
             }
-            if (L1S == 0) {
+            if (AHEAD) {
 #pragma unroll
                 for (int q = 0; q < PF; ++q)
 #pragma unroll
@@ -244,7 +246,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         int raw;
-                        if (L1S > 0) raw = row[nt][s + K - 1];
+                        if (!AHEAD) raw = row[nt][s + K - 1];
                         else {
                             // oldest entry of the look-ahead queue; its slot takes the byte PF positions further on
                             const int slot = RING ? u % PF : 0;
@@ -398,11 +400,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                 for (int nt = 0; nt < NT; ++nt)
                     if (n[nt] < p.N) p.out[n[nt] * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y[nt]);
             }
-            if (p.trace) {
-                if (tiles_done == 0) fx_stamp(p.trace, 3);
-                fx_stamp(p.trace, 4);
-                fx_stamp(p.trace, 5, ++tiles_done);
-            }
+            FX_TILE_DONE();
         }
     }
     fx_stamp(p.trace, 6);

@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
     if (u_lo >= u_hi) return;
     const int m_first = (int)(u_lo / p.TG), m_last = (int)((u_hi - 1) / p.TG);
     bool bad = false;
-    unsigned tiles_done = 0;
+    [[maybe_unused]] unsigned tiles_done = 0;
     FxSimdShare share{0, 1, 1};
     if (BT && p.stage_stride && lane < 32) stw[16 * L + lane] = (uint8_t)p.bt_base;   // what the padded trips of the last row read
 
@@ -97,9 +97,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
         {
             const f4* src = reinterpret_cast<const f4*>(p.w[m] + p.lds_from);
             f4* dst = reinterpret_cast<f4*>(img);
-            fill_lds(dst, src, p.lds_floats / 4);
-            if (BT) fill_lds(reinterpret_cast<f4*>(smem), reinterpret_cast<const f4*>(p.bt[m]), p.Lpad * 8);
-            if (PAIR) fill_lds(reinterpret_cast<f4*>(wpair), reinterpret_cast<const f4*>(p.w[m] + p.off_w1pair), p.pair_floats / 4);
+            if (BT) fill_lds2(dst, src, p.lds_floats / 4, reinterpret_cast<f4*>(smem), reinterpret_cast<const f4*>(p.bt[m]), p.Lpad * 8);
+            else if (PAIR) fill_lds2(dst, src, p.lds_floats / 4, reinterpret_cast<f4*>(wpair),
+                                     reinterpret_cast<const f4*>(p.w[m] + p.off_w1pair), p.pair_floats / 4);
+            else fill_lds(dst, src, p.lds_floats / 4);
         }
         __syncthreads();
         if (m == m_first) share = fx_simd_share(simd_waves, simd);
@@ -391,11 +392,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                 for (int nt = 0; nt < NT; ++nt)
                     if (live && n[nt] < p.N) p.out[n[nt] * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y[nt]);
             }
-            if (p.trace) {
-                if (tiles_done == 0) fx_stamp(p.trace, 3);
-                fx_stamp(p.trace, 4);
-                fx_stamp(p.trace, 5, ++tiles_done);
-            }
+            FX_TILE_DONE();
         }
     }
     fx_stamp(p.trace, 6);

@@ -7,7 +7,7 @@ python -c "import __graft_entry__ as g; g.build(quiet=True); print('build ok')" 
 timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --timeout 600 > $OUT/pytest_gpu.log 2>&1
 echo "pytest exit: $?" >> $OUT/pytest_gpu.log
 tail -15 $OUT/pytest_gpu.log
-timeout 400 python tools/trace_probe.py > $OUT/trace_probe.log 2>&1; echo "exit $?" >> $OUT/trace_probe.log
+FLEXS_AMD_LIB=$PWD/flexs_amd/libflexs_amd_trace.so timeout 400 python tools/trace_probe.py > $OUT/trace_probe.log 2>&1; echo "exit $?" >> $OUT/trace_probe.log
 python - <<'PY'
 import json
 for l in open("gpurun_out/trace_probe.log"):

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build(quiet=True); print('build ok')" > $OUT/env.log 2>&1
 timeout 600 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --timeout 600 -x -k "${1:-cnn_l8 or smoke or mlp_ge or hidden or position_split or ge_byte or multi_member}" > $OUT/pytest_quick.log 2>&1
 tail -4 $OUT/pytest_quick.log
-timeout 400 python tools/trace_probe.py > $OUT/trace_probe.log 2>&1; echo "exit $?" >> $OUT/trace_probe.log
+FLEXS_AMD_LIB=$PWD/flexs_amd/libflexs_amd_trace.so timeout 400 python tools/trace_probe.py > $OUT/trace_probe.log 2>&1; echo "exit $?" >> $OUT/trace_probe.log
 tail -3 $OUT/trace_probe.log | cut -c1-300
 python - <<'PY'
 import json

@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out; mkdir -p $OUT
 export TMPDIR=/tmp
-FLEXS_AMD_LIB=$PWD/flexs_amd/libflexs_amd_trace.so timeout 300 python tools/trace_probe.py > $OUT/trace_phases.log 2>&1; echo "exit $?" >> $OUT/trace_phases.log
+FLEXS_AMD_LIB=$PWD/flexs_amd/libflexs_amd_trace_phases.so FX_PHASES=1 timeout 300 python tools/trace_probe.py > $OUT/trace_phases.log 2>&1; echo "exit $?" >> $OUT/trace_phases.log
 python - <<'PY'
 import json
 for l in open("gpurun_out/trace_phases.log"):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""In-kernel timeline of one scoring launch (engine option "trace", fx_debug_trace_read): where a launch's time goes --
+"""In-kernel timeline of one scoring launch (`make trace` build + engine option "trace", fx_debug_trace_read): where a launch's time goes --
 LDS fill, first-tile latency, per-tile time, tail.  GPU box only.  Prints one JSON object per case.
 
     python tools/trace_probe.py            # the round-2 case list
@@ -111,8 +111,10 @@ def trace_case(label, kind, L, alpha, M, N, H=100, F=0, K=0, opts=None):
 
 if __name__ == "__main__":
     rows = []
-    if os.environ.get("FLEXS_AMD_LIB"):
-        # phase build: only the cases whose first-tile phases are in question
+    if not os.environ.get("FLEXS_AMD_LIB"):
+        raise SystemExit("the timeline needs the trace build: make -C flexs_amd/csrc trace; FLEXS_AMD_LIB=$PWD/flexs_amd/libflexs_amd_trace.so")
+    if os.environ.get("FX_PHASES"):
+        # phase build (make trace-phases): only the cases whose first-tile phases are in question
         for M, N in ((1, 100_000), (1, 4_000)):
             rows.append(trace_case(f"[phases] mlp L=14 M={M} N={N}", "mlp", 14, "UGCA", M, N))
         rows.append(trace_case("[phases] ge L=90 M=1 N=100000", "ge", 90, AAS, 1, 100_000))
