@@ -165,27 +165,6 @@ __device__ __forceinline__ void fill_lds(f4* __restrict__ dst, const f4* __restr
     }
 }
 
-// Two segments in one pass (the dense kernels stage a first-layer table next to the weight image): all the loads of
-// both are in flight before the first LDS store, up to 12 per thread, so that the fill is ONE memory round trip instead
-// of one per segment (4.0 us for 63 KiB in two passes, profiles/r2_trace_probe).
-__device__ __forceinline__ void fill_lds2(f4* __restrict__ dst1, const f4* __restrict__ src1, int n1,
-                                          f4* __restrict__ dst2, const f4* __restrict__ src2, int n2) {
-    const int bd = blockDim.x, n = n1 + n2;
-    for (int i0 = threadIdx.x; i0 < n; i0 += 12 * bd) {
-        f4 v[12];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) {
-            const int i = i0 + k * bd;
-            if (i < n) v[k] = i < n1 ? src1[i] : src2[i - n1];
-        }
-#pragma unroll
-        for (int k = 0; k < 12; ++k) {
-            const int i = i0 + k * bd;
-            if (i < n) { if (i < n1) dst1[i] = v[k]; else dst2[i - n1] = v[k]; }
-        }
-    }
-}
-
 // In-kernel timeline (engine option "trace", debugging / profiling only): the first lane of every wave stamps the
 // constant-rate wall clock (100 MHz) into slot `slot` of its row; `t` is null in normal operation.
 #define FX_TRACE_SLOTS 16

@@ -97,10 +97,11 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
         {
             const f4* src = reinterpret_cast<const f4*>(p.w[m] + p.lds_from);
             f4* dst = reinterpret_cast<f4*>(img);
-            if (BT) fill_lds2(dst, src, p.lds_floats / 4, reinterpret_cast<f4*>(smem), reinterpret_cast<const f4*>(p.bt[m]), p.Lpad * 8);
-            else if (PAIR) fill_lds2(dst, src, p.lds_floats / 4, reinterpret_cast<f4*>(wpair),
-                                     reinterpret_cast<const f4*>(p.w[m] + p.off_w1pair), p.pair_floats / 4);
-            else fill_lds(dst, src, p.lds_floats / 4);
+            // (both segments in one pass with 12 loads in flight per thread measured slower: the fill is bound by the
+            // request rate of 256 workgroups asking at once, not by round trips -- profiles/r2 trace)
+            fill_lds(dst, src, p.lds_floats / 4);
+            if (BT) fill_lds(reinterpret_cast<f4*>(smem), reinterpret_cast<const f4*>(p.bt[m]), p.Lpad * 8);
+            if (PAIR) fill_lds(reinterpret_cast<f4*>(wpair), reinterpret_cast<const f4*>(p.w[m] + p.off_w1pair), p.pair_floats / 4);
         }
         __syncthreads();
         if (m == m_first) share = fx_simd_share(simd_waves, simd);
