@@ -17,6 +17,9 @@ int dispatch_a4(fx_engine* e, const CnnArgs& a0, int variant, bool big, size_t f
         // (+5 % and +2-4 % resp., interleaved A/B: profiles/r1_run9, r1_run16, r1_run18):
         // TF-binding (L = 8) and the RNA landscapes (L = 14)
         if (dl && variant == 0 && big && a.L == 8) variant = 7;
+        // ... and in 8-wave workgroups for small and mid-size launches (one or two waves per SIMD: the unrolled walk is
+        // 5 % shorter per tile than the ring loop, profiles/r2_trace_probe)
+        if (dl && variant == 0 && !big && a.L == 8) variant = 11;
         if (dl && variant == 0 && big && a.L == 14) variant = 10;
         if (dl && variant != 0) {
             const int nt = (variant == 2 || variant == 3) ? 2 : 1;
@@ -38,7 +41,10 @@ int dispatch_a4(fx_engine* e, const CnnArgs& a0, int variant, bool big, size_t f
                 case 7:                                  // unrolled L = 8 specialisation with s_setprio (the default)
                     if (a.L != 8) return fx_fail(e, FX_EINVAL, "cnn_variant 7 is a seq_len = 8 specialisation");
                     return launch_g<4, 5, 2, 7, 1, true, 16, true, 4, true>(e, a, lds);
-                default: return fx_fail(e, FX_EINVAL, "cnn_variant must be 0..10");
+                case 11:                                 // unrolled L = 8 form in 8-wave workgroups (256-register budget): small launches
+                    if (a.L != 8) return fx_fail(e, FX_EINVAL, "cnn_variant 11 is a seq_len = 8 specialisation");
+                    return launch_g<4, 5, 2, 7, 1, true, 8, true, 4, true>(e, a, lds);
+                default: return fx_fail(e, FX_EINVAL, "cnn_variant must be 0..11");
             }
         }
     }

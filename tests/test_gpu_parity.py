@@ -86,7 +86,7 @@ def test_smoke_entry():
 
 # ------------------------------------------------------------------ CNN
 @pytest.mark.parametrize("conv1_mfma", [0, 1])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 7])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 7, 11])
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 33, 1000, 4099])
 def test_cnn_l8_variants_and_tails(eng, variant, n, conv1_mfma):
     """BASELINE configs[0]/[1] shape: TF-binding L=8, alphabet TGCA, CNN(32,100,k5);

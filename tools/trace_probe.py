@@ -126,6 +126,9 @@ if __name__ == "__main__":
     for M, N in ((1, 4000), (1, 10_000), (1, 32_768), (3, 10_000), (3, 100_000)):
         rows.append(trace_case(f"cnn L=8 M={M} N={N}", "cnn", 8, "TGCA", M, N, F=32, K=5))
     rows.append(trace_case("cnn L=8 M=1 N=10000 big_units=1", "cnn", 8, "TGCA", 1, 10_000, F=32, K=5, opts={"cnn_big_units": 1}))
+    rows.append(trace_case("cnn L=8 M=1 N=10000 variant=11", "cnn", 8, "TGCA", 1, 10_000, F=32, K=5, opts={"cnn_variant": 11}))
+    rows.append(trace_case("cnn L=8 M=3 N=10000 variant=11", "cnn", 8, "TGCA", 3, 10_000, F=32, K=5, opts={"cnn_variant": 11}))
+    rows.append(trace_case("cnn L=8 M=1 N=32768 variant=11", "cnn", 8, "TGCA", 1, 32_768, F=32, K=5, opts={"cnn_variant": 11}))
     for M, N in ((8, 100_000), (1, 100_000)):
         rows.append(trace_case(f"ge L=90 M={M} N={N}", "ge", 90, AAS, M, N))
         rows.append(trace_case(f"ge L=90 M={M} N={N} ge_bytetab=0", "ge", 90, AAS, M, N, opts={"ge_bytetab": 0}))
