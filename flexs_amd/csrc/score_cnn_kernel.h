@@ -29,6 +29,7 @@ struct CnnArgs {
     unsigned* err;
     unsigned long long* trace;  // in-kernel timeline (null = off), see fx_stamp
     int wave_prio;              // 1 = fx_stagger_priority
+    int stage_fill;             // 1 = small launches load the conv part first, idle waves bring the head's weights
     int64_t N;
     int64_t TG;                 // tile groups per member = ceil(N / (16*NT))
     int M, Mtot, m_off;
@@ -68,6 +69,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
     uint8_t* lut_s = reinterpret_cast<uint8_t*>(smem + lds_floats);
     int* next_tile = reinterpret_cast<int*>(smem + lds_floats + 64);   // 4 work counters (one per SIMD), after the 256-byte LUT
     int* simd_waves = next_tile + 4;                                   // 4 wave counts (workgroup's waves per SIMD)
+    int* stage_ctl = simd_waves + 4;                                   // staged fill: [0] next chunk, [1] chunks in LDS
 
     fx_stamp(p.trace, 0);
     if (p.wave_prio) fx_stagger_priority();
@@ -87,12 +89,22 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
 
     for (int m = m_first; m <= m_last; ++m) {
         __syncthreads();                                 // previous member's readers are done
+        const int64_t t_lo = (u_lo > (int64_t)m * p.TG ? u_lo : (int64_t)m * p.TG) - (int64_t)m * p.TG;
+        const int64_t t_hi = (u_hi < (int64_t)(m + 1) * p.TG ? u_hi : (int64_t)(m + 1) * p.TG) - (int64_t)m * p.TG;
+        // Staged fill (small launches: fewer tiles than waves).  Only the conv part (~35 of ~103 KiB) is loaded before
+        // the first tile starts; the waves that get no tile bring the dense head's weights meanwhile, chunk by chunk
+        // from an LDS counter, and the tile waves wait for the chunk count before their head -- an LDS flag instead of
+        // a barrier, because the waves are in different places.  The LDS fill is a fifth of a small launch.
+        constexpr bool CAN_STAGE = DENSE_LDS && HEAD && !SEG && WAVES <= 8;   // (the 16-wave forms run long launches and have no registers to spare)
+        const bool staged = CAN_STAGE && p.stage_fill && (t_hi - t_lo) < WAVES;
+        const int dense_f4 = (lds_floats - p.conv_floats) / 4, n_chunks = (dense_f4 + 511) / 512;
         if (tid < 4) next_tile[tid] = 0;
+        if (tid < 2) stage_ctl[tid] = 0;
         if (m == m_first) fx_count_simd_wave(simd_waves, simd);      // (zeroed before the barrier above)
         {
             const f4* src = reinterpret_cast<const f4*>(p.w[m]);
             f4* dst = reinterpret_cast<f4*>(smem);
-            fill_lds(dst, src, lds_floats / 4);      // (14 loads in flight per thread instead of 8: 3.4 us instead of 3.0, r2 trace)
+            fill_lds(dst, src, (staged ? p.conv_floats : lds_floats) / 4);   // (14 loads in flight per thread instead of 8: 3.4 us instead of 3.0, r2 trace)
         }
         __syncthreads();
         if (m == m_first) share = fx_simd_share(simd_waves, simd);
@@ -106,9 +118,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
         const f4* w_d1 = reinterpret_cast<const f4*>(dbase + p.off_d1);
         const f4* w_d2 = reinterpret_cast<const f4*>(dbase + p.off_d2);
         const float* db = dbase + p.off_db;   // (not const-qualified pointers: laundered per tile below)
+        bool got_tile = false, head_ready = !staged;
 
-        const int64_t t_lo = (u_lo > (int64_t)m * p.TG ? u_lo : (int64_t)m * p.TG) - (int64_t)m * p.TG;
-        const int64_t t_hi = (u_hi < (int64_t)(m + 1) * p.TG ? u_hi : (int64_t)(m + 1) * p.TG) - (int64_t)m * p.TG;
         // the workgroup's tiles in shares per SIMD (proportional to the waves it hosts); the waves of a SIMD pull from
         // their share's counter
         const int64_t s_lo = t_lo + (t_hi - t_lo) * share.before / share.total;
@@ -124,6 +135,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                 if (tg >= s_hi) break;
             }
             if (tg >= t_hi) break;
+            got_tile = true;
             if (tiles_done == 0) fx_stamp(p.trace, 2);
             // ---- this lane's sequences
             int64_t n[NT];
@@ -359,7 +371,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
 
             if (SEG) {
                 // ---- segment maxima -> LDS; wave 0 folds them and carries on with the dense head
-                f4* seg_slot = reinterpret_cast<f4*>(smem + lds_floats + 64 + 8);   // after the LUT and the counters
+                f4* seg_slot = reinterpret_cast<f4*>(smem + lds_floats + 64 + 12);  // after the LUT and the counters
                 __syncthreads();                                  // previous tile's readers are done
 #pragma unroll
                 for (int t = 0; t < FT; ++t) seg_slot[((tid >> 6) * FT + t) * 64 + lane] = gmax[t][0];
@@ -378,6 +390,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
             }
             // ---- dense head: F -> H relu -> H relu -> (dropout inactive) -> 1
             FX_PHASE_STAMP(8);
+            if (CAN_STAGE && !head_ready) {
+                // staged fill: the head's weights are brought by the idle waves; wait for their chunk count
+                while (__hip_atomic_load(&stage_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < n_chunks)
+                    __builtin_amdgcn_s_sleep(1);
+                __threadfence_block();
+                head_ready = true;
+            }
             asm volatile("" ::: "memory");
             if (!DENSE_LDS) {
                 // weights streamed from L2: launder the base pointer per tile, otherwise LICM hoists the
@@ -400,6 +419,32 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                     if (n[nt] < p.N) p.out[n[nt] * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y[nt]);
             }
             FX_TILE_DONE();
+        }
+        if (CAN_STAGE && staged && !got_tile) {
+            // this wave has no tile: bring the dense head's weights, 8 KiB per chunk
+            const f4* src = reinterpret_cast<const f4*>(p.w[m]) + p.conv_floats / 4;
+            f4* dst = reinterpret_cast<f4*>(smem) + p.conv_floats / 4;
+            int mine = 0;
+            for (;;) {
+                int c = 0;
+                if (lane == 0) c = atomicAdd(&stage_ctl[0], 1);
+                c = __builtin_amdgcn_readfirstlane(c);
+                if (c >= n_chunks) break;
+                f4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = c * 512 + k * 64 + lane;
+                    if (i < dense_f4) v[k] = src[i];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = c * 512 + k * 64 + lane;
+                    if (i < dense_f4) dst[i] = v[k];
+                }
+                ++mine;
+            }
+            __threadfence_block();                        // this wave's LDS stores have landed
+            if (lane == 0 && mine) atomicAdd(&stage_ctl[1], mine);
         }
     }
     fx_stamp(p.trace, 6);

@@ -87,6 +87,7 @@ int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const
     a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
     if (int rc = fx_trace_buffer(e, &a.trace)) return rc;
     a.wave_prio = (int)e->wave_prio;
+    a.stage_fill = (int)e->stage_fill;
     for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
     a.out_sn = e->planar_stride ? 1 : Mtot; a.out_sm = e->planar_stride ? e->planar_stride : 1;
     a.N = N; a.M = M; a.Mtot = Mtot; a.m_off = m_off; a.L = s.L; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4;
@@ -94,7 +95,7 @@ int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const
     a.off_cb = (int)lay.off_cb; a.off_w1p = (int)lay.off_w1p; a.conv_floats = (int)lay.conv_floats; a.off_d1 = (int)lay.off_d1;
     a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
 
-    const size_t full = (size_t)lay.total_floats * 4 + 256 + 32, conv_only = (size_t)lay.conv_floats * 4 + 256 + 32;
+    const size_t full = (size_t)lay.total_floats * 4 + 256 + 48, conv_only = (size_t)lay.conv_floats * 4 + 256 + 48;
     if (s.A == 2) {
         // binary alphabet (`BA = "01"`, sequence_utils.py:16): conv3 has ONE tap (kernel_size = len(alphabet) - 1);
         // canonical filter / hidden / kernel sizes only, first conv in gather form

@@ -158,7 +158,7 @@ int fx_launch_score_cnn_split(fx_engine* e, fx_model* const* models, int M, cons
     if ((s.A != 4 && s.A != 20) || lay.FT < 1 || lay.FT > 4 || s.K < 2 || s.K > 7 || s.H > 256 || M > FX_MAX_M ||
         e->cnn_conv1_mfma || (s.A == 20 && (lay.FT != 2 || !e->cnn_pair)))
         return FX_EUNSUPPORTED;
-    const size_t conv_lds = (size_t)lay.conv_floats * 4 + 256 + 32;
+    const size_t conv_lds = (size_t)lay.conv_floats * 4 + 256 + 48;
     if (s.A == 4 && conv_lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
     const int64_t TG = (N + 15) / 16;
     void* pool = nullptr;
