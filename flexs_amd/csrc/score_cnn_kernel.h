@@ -91,12 +91,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
         __syncthreads();                                 // previous member's readers are done
         const int64_t t_lo = (u_lo > (int64_t)m * p.TG ? u_lo : (int64_t)m * p.TG) - (int64_t)m * p.TG;
         const int64_t t_hi = (u_hi < (int64_t)(m + 1) * p.TG ? u_hi : (int64_t)(m + 1) * p.TG) - (int64_t)m * p.TG;
-        // Staged fill (small launches: fewer tiles than waves).  Only the conv part (~35 of ~103 KiB) is loaded before
+        // Staged fill (small launches: at most half as many tiles as waves).  Only the conv part (~35 of ~103 KiB) is loaded before
         // the first tile starts; the waves that get no tile bring the dense head's weights meanwhile, chunk by chunk
         // from an LDS counter, and the tile waves wait for the chunk count before their head -- an LDS flag instead of
         // a barrier, because the waves are in different places.  The LDS fill is a fifth of a small launch.
         constexpr bool CAN_STAGE = DENSE_LDS && HEAD && !SEG && WAVES <= 8;   // (the 16-wave forms run long launches and have no registers to spare)
-        const bool staged = CAN_STAGE && p.stage_fill && (t_hi - t_lo) < WAVES;
+        const bool staged = CAN_STAGE && p.stage_fill && 2 * (t_hi - t_lo) <= WAVES;   // at least half the waves are idle
         const int dense_f4 = (lds_floats - p.conv_floats) / 4, n_chunks = (dense_f4 + 511) / 512;
         if (tid < 4) next_tile[tid] = 0;
         if (tid < 2) stage_ctl[tid] = 0;

@@ -82,6 +82,10 @@ int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const
     if ((lay.FT != 2 && !(lay.FT == 1 && s.K == 5 && lay.HT == 7)) || (s.A != 4 && s.A != 20 && s.A != 2)) return FX_EUNSUPPORTED;
     if (s.K != 5 && !((s.K == 3 || s.K == 7) && lay.HT == 7)) return FX_EUNSUPPORTED;
     if (M > FX_MAX_M) return FX_EINVAL;
+    {
+        const int rc = fx_launch_score_cnn_quad(e, models, M, d_ascii, N, d_out_NM, Mtot, m_off);
+        if (rc != FX_EUNSUPPORTED) return rc;
+    }
 
     CnnArgs a{};
     a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;

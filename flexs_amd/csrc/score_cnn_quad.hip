@@ -1,0 +1,253 @@
+// K1, small launches: one tile of 16 sequences shared by FOUR waves (one per SIMD of the CU).
+//
+// With at most three tiles per workgroup (10^4 sequences on one member: 625 tiles for 256 CUs, configs[0]; every
+// explorer-size call) the one-wave-per-tile kernel runs a LONE wave per SIMD: ~75 % of the pipe for that wave, three of
+// the CU's four matrix pipes idle (profiles/r2_trace_probe: 12 us per tile whose MFMAs are 8 us of one pipe).  Here a
+// wave quad walks the network layer by layer and exchanges activations through LDS:
+//     wave q (= conv position q; TF-binding: seq_len 8, kernel 5 -> 4 positions)
+//     A  conv1 at position q (row gather)                       -> X[q]            barrier
+//     B  conv2 at position q from X[q-2 .. q+2]                  -> Y[q]            barrier
+//     C  conv3 at position q from Y[q-1 .. q+1], relu            -> X[q]            barrier
+//     D  global max over the 4 positions; dense 1, output tiles {q, q+4}  -> Y      barrier
+//     E  dense 2, output tiles {q, q+4} from all 7 tiles of Y    -> X               barrier
+//     F  wave 0: final dot over all 7 tiles of X, nan_to_num, store
+// Every output element sees exactly the MFMA / add sequence of the one-wave kernel (k-order (tap, input tile, k-step),
+// padding taps skipped, hidden tail k-steps skipped), the exchanges are copies: results are BIT-IDENTICAL to
+// k_score_cnn_mfma (tested), so a sequence scores the same in a call of 20 and in a batch of 10^5.
+// Three quads per workgroup (X / Y: 2 x 8 KiB per quad next to the member's ~103 KiB of weights); X and Y swap roles
+// every round so that wave 0's phase F never races the next round's phase A.
+#include "fx_common.h"
+#include "mfma_common.h"
+
+namespace {
+
+constexpr int QUADS = 3, QWAVES = 4 * QUADS;
+
+struct QuadArgs {
+    const uint8_t* ascii;
+    const uint8_t* lut;
+    const float* w[FX_MAX_M];
+    float* out;
+    unsigned* err;
+    unsigned long long* trace;  // in-kernel timeline of trace builds (null = off), see fx_stamp
+    int64_t N, TG;
+    int M, m_off;
+    int64_t out_sn, out_sm;
+    int rlh;
+    int off_c2, off_c3, off_cb, off_w1p, off_d1, off_d2, off_db, total_floats;
+};
+
+template <int HT>
+__global__ void __launch_bounds__(QWAVES * 64) k_score_cnn_quad(QuadArgs p) {
+    constexpr int A = 4, K = 5, K3 = 3, FT = 2, L = 8, L1 = 4, PL2 = 2, PL3 = 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int quad = wave >> 2, q = wave & 3;
+    const int g = lane >> 4, sq = lane & 15;
+    uint8_t* lut_s = reinterpret_cast<uint8_t*>(smem + p.total_floats);
+    f4* xq = reinterpret_cast<f4*>(smem + p.total_floats + 64) + quad * 1024;       // this quad's two 8 KiB buffers
+    fx_stamp(p.trace, 0);
+    fx_stamp(p.trace, 7, (unsigned long long)fx_simd_id() + 1);
+    [[maybe_unused]] unsigned tiles_done = 0;
+    for (int i = tid; i < 64; i += blockDim.x)
+        reinterpret_cast<uint32_t*>(lut_s)[i] = reinterpret_cast<const uint32_t*>(p.lut)[i];
+
+    int64_t u_lo, u_hi;
+    fx_unit_range(p.TG, p.M, u_lo, u_hi);
+    if (u_lo >= u_hi) return;
+    const int m_first = (int)(u_lo / p.TG), m_last = (int)((u_hi - 1) / p.TG);
+    bool bad = false;
+    int parity = 0;
+
+    for (int m = m_first; m <= m_last; ++m) {
+        __syncthreads();
+        fill_lds(reinterpret_cast<f4*>(smem), reinterpret_cast<const f4*>(p.w[m]), p.total_floats / 4);
+        __syncthreads();
+        if (m == m_first) fx_stamp(p.trace, 1);
+        const f4* w_c2 = reinterpret_cast<const f4*>(smem + p.off_c2);
+        const f4* w_c3 = reinterpret_cast<const f4*>(smem + p.off_c3);
+        const float* cb = smem + p.off_cb;
+        const float* w1p = smem + p.off_w1p;
+        const f4* w_d1 = reinterpret_cast<const f4*>(smem + p.off_d1);
+        const f4* w_d2 = reinterpret_cast<const f4*>(smem + p.off_d2);
+        const float* db = smem + p.off_db;
+        const int64_t t_lo = (u_lo > (int64_t)m * p.TG ? u_lo : (int64_t)m * p.TG) - (int64_t)m * p.TG;
+        const int64_t t_hi = (u_hi < (int64_t)(m + 1) * p.TG ? u_hi : (int64_t)(m + 1) * p.TG) - (int64_t)m * p.TG;
+        const int rounds = (int)((t_hi - t_lo + QUADS - 1) / QUADS);
+
+        for (int rd = 0; rd < rounds; ++rd, parity ^= 1) {
+            const int64_t tg = t_lo + (int64_t)rd * QUADS + quad;
+            const bool live = tg < t_hi;                             // idle quads run along for the barriers
+            const int64_t n = tg * 16 + sq;
+            const uint8_t* row = p.ascii + ((live && n < p.N) ? n : 0) * L;
+            f4* X = xq + (parity ? 512 : 0);
+            f4* Y = xq + (parity ? 0 : 512);
+            asm volatile("" ::: "memory");                           // keep the LDS weight reads inside the round
+            if (live && tiles_done == 0) fx_stamp(p.trace, 2);
+
+            // ---- A: conv1 (valid) at position q: bias + the K kernel rows selected by the codes, relu
+            f4 o1[FT][1];
+            if (live) {
+                int c[K];
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    c[j] = lut_s[row[q + j]];
+                    if (c[j] == 0xFF) { bad = true; c[j] = 0; }
+                }
+                init_bias<FT, 1>(cb, o1, g);
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const float* rowp = w1p + (j * A + c[j]) * (16 * FT) + 4 * g;
+#pragma unroll
+                    for (int t = 0; t < FT; ++t) o1[t][0] += *reinterpret_cast<const f4*>(rowp + 16 * t);
+                }
+                relu_tiles<FT, 1>(o1);
+#pragma unroll
+                for (int t = 0; t < FT; ++t) X[(q * FT + t) * 64 + lane] = o1[t][0];
+            }
+            __syncthreads();
+
+            // ---- B: conv2 (same) at position q; tap j reads out1[q + j - PL2], padding taps contribute nothing
+            f4 o2[FT][1];
+            if (live) {
+                init_bias<FT, 1>(cb + 16 * FT, o2, g);
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const int pp = q + j - PL2;
+                    if (pp >= 0 && pp < L1) {
+                        f4 in[FT][1];
+#pragma unroll
+                        for (int t = 0; t < FT; ++t) in[t][0] = X[(pp * FT + t) * 64 + lane];
+                        mma_layer<FT, FT, 1>(w_c2 + j * FT * FT * 64, in, o2, lane);
+                    }
+                }
+                relu_tiles<FT, 1>(o2);
+#pragma unroll
+                for (int t = 0; t < FT; ++t) Y[(q * FT + t) * 64 + lane] = o2[t][0];
+            }
+            __syncthreads();
+
+            // ---- C: conv3 (same, 3 taps) at position q from out2[q + j - PL3]; relu through the pooled max with 0
+            f4 o3[FT][1];
+            if (live) {
+                init_bias<FT, 1>(cb + 32 * FT, o3, g);
+#pragma unroll
+                for (int j = 0; j < K3; ++j) {
+                    const int pp = q + j - PL3;
+                    if (pp >= 0 && pp < L1) {
+                        f4 in[FT][1];
+#pragma unroll
+                        for (int t = 0; t < FT; ++t) in[t][0] = Y[(pp * FT + t) * 64 + lane];
+                        mma_layer<FT, FT, 1>(w_c3 + j * FT * FT * 64, in, o3, lane);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < FT; ++t) {
+                    o3[t][0] = pool_max4(splat4(0.f), o3[t][0]);
+                    X[(q * FT + t) * 64 + lane] = o3[t][0];
+                }
+            }
+            __syncthreads();
+
+            // ---- D: GlobalMaxPooling1D over the four positions; dense 1 for this wave's output tiles {q, q + 4}
+            if (live) {
+                f4 gmax[FT][1];
+#pragma unroll
+                for (int t = 0; t < FT; ++t) {
+                    gmax[t][0] = splat4(0.f);
+#pragma unroll
+                    for (int pp = 0; pp < L1; ++pp) gmax[t][0] = pool_max4(gmax[t][0], X[(pp * FT + t) * 64 + lane]);
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int mo = q + 4 * k;
+                    if (mo < HT) {
+                        f4 acc = *reinterpret_cast<const f4*>(&db[16 * mo + 4 * g]);
+#pragma unroll
+                        for (int mi = 0; mi < FT; ++mi) {
+                            const f4 a = w_d1[(mi * HT + mo) * 64 + lane];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc = mfma16(a[r], gmax[mi][0][r], acc);
+                        }
+                        Y[mo * 64 + lane] = relu4(acc);
+                    }
+                }
+            }
+            __syncthreads();
+
+            // ---- E: dense 2 for the output tiles {q, q + 4} from all HT tiles of dense 1
+            if (live) {
+                f4 h1[HT];
+#pragma unroll
+                for (int mi = 0; mi < HT; ++mi) h1[mi] = Y[mi * 64 + lane];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int mo = q + 4 * k;
+                    if (mo < HT) {
+                        f4 acc = *reinterpret_cast<const f4*>(&db[16 * HT + 16 * mo + 4 * g]);
+#pragma unroll
+                        for (int mi = 0; mi < HT; ++mi) {
+                            const f4 a = w_d2[(mi * HT + mo) * 64 + lane];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                if (mi == HT - 1 && r >= p.rlh) break;
+                                acc = mfma16(a[r], h1[mi][r], acc);
+                            }
+                        }
+                        X[mo * 64 + lane] = relu4(acc);
+                    }
+                }
+            }
+            __syncthreads();
+
+            // ---- F: Dense(1) on wave 0 of the quad
+            if (live && q == 0) {
+                f4 h2[HT][1];
+#pragma unroll
+                for (int mi = 0; mi < HT; ++mi) h2[mi][0] = X[mi * 64 + lane];
+                float y[1];
+                final_dot<HT, 1>(db + 32 * HT, db[48 * HT], h2, y, g);
+                if (g == 0 && n < p.N) p.out[n * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y[0]);
+            }
+            if (live) FX_TILE_DONE();
+        }
+    }
+    fx_stamp(p.trace, 6);
+    if (bad) fx_raise(p.err, FX_ERR_BADCHAR);
+}
+
+}  // namespace
+
+// FX_EUNSUPPORTED when the quad form does not apply (the caller carries on with the one-wave-per-tile kernels).
+int fx_launch_score_cnn_quad(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N,
+                             float* d_out_NM, int Mtot, int m_off) {
+    const FxShape& s = models[0]->shape;
+    const FxPackLayout& lay = models[0]->layout;
+    if (!e->cnn_quad || s.A != 4 || s.K != 5 || s.L != 8 || lay.FT != 2 || lay.HT != 7 || lay.HTR != 7 || e->cnn_conv1_mfma ||
+        e->cnn_variant || M > FX_MAX_M)
+        return FX_EUNSUPPORTED;
+    const int64_t TG = (N + 15) / 16, U = (int64_t)M * TG;
+    int64_t blocks = e->grid_blocks > 0 ? e->grid_blocks : e->num_cus;
+    if (blocks > U) blocks = U;
+    if (e->cnn_quad < 2 && U > (int64_t)QUADS * blocks) return FX_EUNSUPPORTED;       // more than one round per workgroup: not worth it
+    const size_t lds = (size_t)lay.total_floats * 4 + 256 + (size_t)QUADS * 16384;
+    if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
+    QuadArgs a{};
+    a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
+    if (int rc = fx_trace_buffer(e, &a.trace)) return rc;
+    for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
+    a.N = N; a.TG = TG; a.M = M; a.m_off = m_off;
+    a.out_sn = e->planar_stride ? 1 : Mtot; a.out_sm = e->planar_stride ? e->planar_stride : 1;
+    a.rlh = lay.RLH;
+    a.off_c2 = (int)lay.off_c2; a.off_c3 = (int)lay.off_c3; a.off_cb = (int)lay.off_cb; a.off_w1p = (int)lay.off_w1p;
+    a.off_d1 = (int)lay.off_d1; a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
+    auto kern = k_score_cnn_quad<7>;
+    static bool attr_set[64] = {};
+    if (!attr_set[e->device & 63]) {
+        FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[e->device & 63] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(QWAVES * 64), lds, e->stream, a);
+    FX_HIP(e, hipGetLastError());
+    return FX_OK;
+}

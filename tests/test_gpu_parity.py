@@ -1275,6 +1275,46 @@ def test_deepcopy_and_pickle_of_live_models(eng):
     assert np.array_equal(a, b) and list(nam.cache) == list(twin.cache)
 
 
+@pytest.mark.parametrize("n,M", [(1, 1), (16, 1), (17, 3), (100, 3), (1000, 1), (4000, 3), (10_000, 1), (12_289, 1), (2001, 8)])
+def test_cnn_quad_form_is_bit_identical_to_the_one_wave_kernel(eng, n, M):
+    """Small launches of the canonical TF-binding CNN (seq_len 8): a tile shared by four waves, activations exchanged
+    through LDS layer by layer (score_cnn_quad.hip).  Every output element sees the one-wave kernel's MFMA sequence, so
+    the scores are the SAME BITS (a sequence must score alike in a call of 20 and in a batch of 1e5), at any size when
+    forced, and a character outside the alphabet is reported from whichever wave reads it."""
+    pairs = [make_native(eng, "cnn", 8, 4, 100, 32, 5, seed=80 + m) for m in range(M)]
+    nms = [p[0] for p in pairs]
+    lut = _native.make_lut("TGCA")
+    b, seqs = rand_seqs(n, 8, "TGCA", seed=n)
+    outs = {}
+    for mode in (0, 1, 2):
+        eng.set_option("cnn_quad", mode)
+        try:
+            outs[mode], mean = eng.score(nms, b, lut, want_matrix=True, want_mean=True)
+            assert np.array_equal(mean, np.mean(outs[mode], axis=1))
+        finally:
+            eng.set_option("cnn_quad", 1)
+    assert np.array_equal(outs[1], outs[0]) and np.array_equal(outs[2], outs[0])
+    assert_scores(outs[2][:, M - 1], ref_np.keras_fitness(seqs, "TGCA", "cnn", pairs[M - 1][1], exact=True), f"quad n={n} M={M}")
+    eng.set_option("cnn_quad", 2)
+    try:
+        for col in (0, 3, 7):
+            bb = b.copy()
+            bb[n - 1, col] = ord("U")
+            with pytest.raises(ValueError):
+                eng.score(nms, bb, lut)
+    finally:
+        eng.set_option("cnn_quad", 1)
+    # hidden sizes whose last tile holds 1 .. 16 units (k-step tail), through the Python API
+    for H in (97, 100, 104, 112):
+        model = bm.CNN(8, 32, H, "TGCA", seed=H)
+        got = model.get_fitness(seqs[:50])
+        eng.set_option("cnn_quad", 0)
+        try:
+            assert np.array_equal(model.get_fitness(seqs[:50]), got)
+        finally:
+            eng.set_option("cnn_quad", 1)
+
+
 @pytest.mark.parametrize("L,n,M", [(10, 3000, 2), (5, 100, 1), (64, 20, 3), (30, 70000, 1)])
 def test_cnn_binary_alphabet_on_mfma(eng, L, n, M):
     """`BA = "01"` (sequence_utils.py:16): the canonical CNN on a 2-letter alphabet (conv3 has a single tap) runs on the

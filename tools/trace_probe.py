@@ -103,7 +103,7 @@ def trace_case(label, kind, L, alpha, M, N, H=100, F=0, K=0, opts=None):
     for k_ in (opts or {}):
         eng.set_option(k_, {"cnn_big_units": 12, "cnn_seg": -1, "ge_bytetab": 1, "mlp_pair": 1, "wave_prio": 1, "stage_bytes": 1}.get(k_, 0))
     for k_ in (opts or {}):
-        eng.set_option(k_, {"cnn_big_units": 12, "cnn_seg": -1, "ge_bytetab": 1, "mlp_pair": 1, "wave_prio": 1, "stage_bytes": 1, "dense_waves": 0, "stage_fill": 1}.get(k_, 0))
+        eng.set_option(k_, {"cnn_big_units": 12, "cnn_seg": -1, "ge_bytetab": 1, "mlp_pair": 1, "wave_prio": 1, "stage_bytes": 1, "dense_waves": 0, "stage_fill": 1, "cnn_quad": 1}.get(k_, 0))
     out = {"what": label, "event_us_per_launch": ev_us, "trace": res[-1], "span_us_3runs": [r["span_us"] for r in res]}
     print(json.dumps(out), flush=True)
     return out
@@ -126,6 +126,10 @@ if __name__ == "__main__":
     for M, N in ((1, 4000), (1, 10_000), (1, 32_768), (3, 10_000), (3, 100_000)):
         rows.append(trace_case(f"cnn L=8 M={M} N={N}", "cnn", 8, "TGCA", M, N, F=32, K=5))
     rows.append(trace_case("cnn L=8 M=1 N=10000 big_units=1", "cnn", 8, "TGCA", 1, 10_000, F=32, K=5, opts={"cnn_big_units": 1}))
+    rows.append(trace_case("cnn L=8 M=1 N=10000 cnn_quad=0", "cnn", 8, "TGCA", 1, 10_000, F=32, K=5, opts={"cnn_quad": 0}))
+    rows.append(trace_case("cnn L=8 M=1 N=4000 cnn_quad=0", "cnn", 8, "TGCA", 1, 4_000, F=32, K=5, opts={"cnn_quad": 0}))
+    rows.append(trace_case("cnn L=8 M=3 N=10000 cnn_quad=2", "cnn", 8, "TGCA", 3, 10_000, F=32, K=5, opts={"cnn_quad": 2}))
+    rows.append(trace_case("cnn L=8 M=1 N=32768 cnn_quad=2", "cnn", 8, "TGCA", 1, 32_768, F=32, K=5, opts={"cnn_quad": 2}))
     rows.append(trace_case("cnn L=8 M=1 N=10000 stage_fill=0", "cnn", 8, "TGCA", 1, 10_000, F=32, K=5, opts={"stage_fill": 0}))
     rows.append(trace_case("cnn L=8 M=1 N=4000 stage_fill=0", "cnn", 8, "TGCA", 1, 4_000, F=32, K=5, opts={"stage_fill": 0}))
     rows.append(trace_case("cnn L=8 M=3 N=10000 stage_fill=0", "cnn", 8, "TGCA", 3, 10_000, F=32, K=5, opts={"stage_fill": 0}))
