@@ -26,6 +26,8 @@ struct FxShape {
 //       kin = 16*mi + 4*(lane >> 4) + r        (k-step r consumes accumulator register r)
 //   first-layer blocks (one-hot input; conv1 or MLP layer 1; step group sg):
 //       kin = 16*sg + 4*r + (lane >> 4)        (k-step s = 4*sg + r covers rows 4s .. 4s+3)
+#define FX_PAIR_PAD 4          // floats between the MLP's pair rows (LDS bank spread, pack.cpp)
+
 struct FxPackLayout {
     int FT, HT;                 // output tiles of 16: filters, hidden units (HT rounded up to an instantiated size)
     int HTR;                    // hidden tiles that hold real units = ceil(H / 16) <= HT; the rest is zero padding
@@ -41,7 +43,7 @@ struct FxPackLayout {
     int64_t total_floats;       // end of the vector area = end of what the kernels may stage in LDS as one image
     // MLP on a 4-letter alphabet: first-layer rows summed for PAIRS of positions, [(L/2)*16 + (L%2)*4][16HT] floats after
     // the image (row (pi*16 + 4*c0 + c1) = row(2pi, c0) + row(2pi+1, c1)); -1 = none
-    int64_t off_w1pair, pair_floats;
+    int64_t off_w1pair, pair_floats;   // MLP, 4 letters: pre-summed rows per pair of positions, FX_PAIR_PAD floats of padding per row
     int64_t alloc_floats;       // size of the packed buffer (total_floats + pair table)
 };
 
@@ -95,6 +97,7 @@ struct fx_engine {
     int64_t trace = 0;          // 1 = the MFMA scoring kernels stamp an in-kernel timeline into d_trace (fx_debug_trace_read)
     unsigned long long* d_trace = nullptr;
     int64_t cnn_quad = 1;       // 1 = small launches of the canonical L = 8 CNN share a tile among four waves (score_cnn_quad.hip); 2 = whatever the size (test knob); 0 = off
+    int64_t dma_fill = 1;       // 1 = weight images go global -> LDS directly (global_load_lds), all in flight at kernel start, the first layers start when THEIR part has landed (0 = through registers, whole image before the first tile: A/B)
     int64_t stage_fill = 1;     // 1 = CNN launches with fewer tiles than waves per workgroup load the conv part first and let the idle waves bring the head's weights (0 = whole image before the first tile: A/B)
     int64_t stage_bytes = 1;    // 1 = MLP (pair rows) / GE (byte table) tiles copy their 16 x L sequence bytes into per-wave LDS scratch with 16-byte loads (0 = byte loads from global memory: A/B)
     int64_t mlp_pair = 1;       // 1 = MLP layer 1 on a 4-letter alphabet gathers one pre-summed row per PAIR of positions (0 = one row per position: A/B)

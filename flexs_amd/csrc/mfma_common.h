@@ -165,6 +165,60 @@ __device__ __forceinline__ void fill_lds(f4* __restrict__ dst, const f4* __restr
     }
 }
 
+// ---- direct global -> LDS copies (gfx950: global_load_lds_dword / _dwordx4) ---------------------------------------
+// The data never passes through VGPRs, so a wave can put its whole share of a member's weight image in flight at
+// kernel start and begin computing as soon as the FIRST part (what the first layers read) has landed, while the rest
+// is still on its way: a small launch otherwise waits ~3-5 us for ~100-150 KiB before its first instruction of work
+// (profiles/r2_trace_probe).  Written as inline assembly on purpose: the compiler's own tracking of such loads puts an
+// `s_waitcnt vmcnt(0)` in front of the next LDS read that might alias, i.e. waits for everything.  Ordering is by the
+// wave's vector-memory counter: loads return in order, so `fx_wait_vm(n)` (at most n still in flight) after issuing
+// part 1 and then n loads of part 2 guarantees part 1 -- loads the compiler issues in between only make the wait
+// stricter, never weaker.  Each wave waits for ITS loads; a workgroup barrier then publishes the part to all waves.
+// LDS address of lane i = M0 + i * (4 | 16): M0 is saved and restored around the instruction.
+__device__ __forceinline__ unsigned fx_lds_addr(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+__device__ __forceinline__ void fx_dma16(const void* g_lane, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g_lane), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ void fx_dma4(const void* g_lane, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g_lane), "s"(lds_base) : "memory");
+}
+// at most n (wave-uniform) vector-memory loads of this wave still in flight
+__device__ __forceinline__ void fx_wait_vm(int n) {
+    switch (n) {
+#define FX_VM_CASE(i) case i: asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); break;
+        FX_VM_CASE(1) FX_VM_CASE(2) FX_VM_CASE(3) FX_VM_CASE(4) FX_VM_CASE(5) FX_VM_CASE(6) FX_VM_CASE(7) FX_VM_CASE(8)
+        FX_VM_CASE(9) FX_VM_CASE(10) FX_VM_CASE(11) FX_VM_CASE(12) FX_VM_CASE(13) FX_VM_CASE(14) FX_VM_CASE(15) FX_VM_CASE(16)
+        FX_VM_CASE(17) FX_VM_CASE(18) FX_VM_CASE(19) FX_VM_CASE(20) FX_VM_CASE(21) FX_VM_CASE(22) FX_VM_CASE(23) FX_VM_CASE(24)
+#undef FX_VM_CASE
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+// Workgroup copy of n4 16-byte words (1 KiB chunks dealt round-robin to the `waves` waves); returns the number of
+// loads THIS wave issued (wave-uniform).  dst must be 16-byte aligned LDS, src 16-byte aligned global memory.
+__device__ __forceinline__ int fx_dma_fill(float* dst_lds, const float* __restrict__ src, int n4, int waves) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned base = __builtin_amdgcn_readfirstlane(fx_lds_addr(dst_lds));
+    int issued = 0;
+    for (int c = wave * 64; c < n4; c += waves * 64) {
+        if (c + lane < n4) fx_dma16(reinterpret_cast<const f4*>(src) + c + lane, base + (unsigned)c * 16u);
+        ++issued;
+    }
+    return issued;
+}
+
+// The 256-byte character LUT, global -> LDS without a round trip of its own: as a plain copy it is a load the workgroup
+// waits for BEFORE it asks for its weights, one more dependent ~1 us step at the start of every launch.  The caller
+// runs fx_wait_vm(0) (or waits for any younger load) before the barrier that publishes the weights.
+__device__ __forceinline__ void fx_lut_dma(uint8_t* lut_s, const uint8_t* __restrict__ lut) {
+    if (threadIdx.x < 64) fx_dma4(lut + threadIdx.x * 4, __builtin_amdgcn_readfirstlane(fx_lds_addr(lut_s)));
+}
+
 // In-kernel timeline (engine option "trace", debugging / profiling only): the first lane of every wave stamps the
 // constant-rate wall clock (100 MHz) into slot `slot` of its row; `t` is null in normal operation.
 #define FX_TRACE_SLOTS 16

@@ -82,7 +82,9 @@ FxPackLayout fx_pack_layout(const FxShape& s) {
     p.pair_floats = 0;
     if (s.kind == FX_MLP && s.A == 4) {
         p.off_w1pair = p.total_floats;
-        p.pair_floats = ((int64_t)(s.L / 2) * 16 + (s.L % 2) * 4) * 16 * p.HT;
+        // rows are FX_PAIR_PAD floats apart more than their length: 16 lanes gather 16 different rows at once, and with a
+        // stride of 16 HT floats (112: 48 mod 64 banks) rows r and r + 4 start on the same LDS bank
+        p.pair_floats = ((int64_t)(s.L / 2) * 16 + (s.L % 2) * 4) * (16 * p.HT + FX_PAIR_PAD);
     }
     p.alloc_floats = p.total_floats + p.pair_floats;
     return p;
@@ -225,19 +227,19 @@ void fx_pack_weights(const FxShape& s, const float* blob, float* packed) {
         packed[p.off_db + 64 * HT] = c4[0];
         if (p.off_w1pair >= 0) {
             // one row per pair of positions and pair of letters: the float32 sum of the two single-position rows
-            const int64_t R = 16 * HT;
+            const int64_t R = 16 * HT, RP = R + FX_PAIR_PAD;        // (the pad floats stay 0)
             const float* rows = packed + p.off_w1p;
             float* dst = packed + p.off_w1pair;
             for (int pi = 0; pi < L / 2; ++pi)
                 for (int c0 = 0; c0 < 4; ++c0)
                     for (int c1 = 0; c1 < 4; ++c1)
                         for (int64_t k = 0; k < R; ++k)
-                            dst[((int64_t)pi * 16 + 4 * c0 + c1) * R + k] =
+                            dst[((int64_t)pi * 16 + 4 * c0 + c1) * RP + k] =
                                 rows[((int64_t)(2 * pi) * 4 + c0) * R + k] + rows[((int64_t)(2 * pi + 1) * 4 + c1) * R + k];
             if (L % 2)
                 for (int c0 = 0; c0 < 4; ++c0)
                     for (int64_t k = 0; k < R; ++k)
-                        dst[((int64_t)(L / 2) * 16 + c0) * R + k] = rows[((int64_t)(L - 1) * 4 + c0) * R + k];
+                        dst[((int64_t)(L / 2) * 16 + c0) * RP + k] = rows[((int64_t)(L - 1) * 4 + c0) * R + k];
         }
     } else {
         const float* d1 = w;  w += (int64_t)L * A;

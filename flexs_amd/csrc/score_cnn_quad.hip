@@ -34,6 +34,7 @@ struct QuadArgs {
     int M, m_off;
     int64_t out_sn, out_sm;
     int rlh;
+    int dma;                    // 1 = weights (and the first round's bytes) go global -> LDS directly, head part lands during the convolutions
     int off_c2, off_c3, off_cb, off_w1p, off_d1, off_d2, off_db, total_floats;
 };
 
@@ -46,11 +47,11 @@ __global__ void __launch_bounds__(QWAVES * 64) k_score_cnn_quad(QuadArgs p) {
     const int g = lane >> 4, sq = lane & 15;
     uint8_t* lut_s = reinterpret_cast<uint8_t*>(smem + p.total_floats);
     f4* xq = reinterpret_cast<f4*>(smem + p.total_floats + 64) + quad * 1024;       // this quad's two 8 KiB buffers
+    uint8_t* bytes_s = reinterpret_cast<uint8_t*>(smem + p.total_floats + 64 + QUADS * 4096) + quad * (16 * L);   // dma: the first round's 16 x L bytes
     fx_stamp(p.trace, 0);
     fx_stamp(p.trace, 7, (unsigned long long)fx_simd_id() + 1);
     [[maybe_unused]] unsigned tiles_done = 0;
-    for (int i = tid; i < 64; i += blockDim.x)
-        reinterpret_cast<uint32_t*>(lut_s)[i] = reinterpret_cast<const uint32_t*>(p.lut)[i];
+    fx_lut_dma(lut_s, p.lut);                            // in flight together with the first member's weights
 
     int64_t u_lo, u_hi;
     fx_unit_range(p.TG, p.M, u_lo, u_hi);
@@ -58,10 +59,27 @@ __global__ void __launch_bounds__(QWAVES * 64) k_score_cnn_quad(QuadArgs p) {
     const int m_first = (int)(u_lo / p.TG), m_last = (int)((u_hi - 1) / p.TG);
     bool bad = false;
     int parity = 0;
+    // dma: the very first round reads its bytes from LDS (a compiler-tracked byte load from global memory would be waited
+    // for with vmcnt(0), i.e. together with the whole image); needs the 4-byte alignment of the dword copy
+    const bool lds_bytes = p.dma && (reinterpret_cast<uintptr_t>(p.ascii) & 3) == 0;
 
     for (int m = m_first; m <= m_last; ++m) {
         __syncthreads();
-        fill_lds(reinterpret_cast<f4*>(smem), reinterpret_cast<const f4*>(p.w[m]), p.total_floats / 4);
+        if (p.dma) {
+            if (lds_bytes && m == m_first && q == 0) {
+                const int64_t tg0 = u_lo - (int64_t)m * p.TG + quad;
+                const int64_t rows = p.N - tg0 * 16 < 16 ? p.N - tg0 * 16 : 16;
+                if (u_lo + quad < u_hi && tg0 < p.TG && lane < rows * (L / 4))
+                    fx_dma4(p.ascii + tg0 * 16 * L + lane * 4, __builtin_amdgcn_readfirstlane(fx_lds_addr(bytes_s)));
+            }
+            // conv part (+ conv1 rows, conv biases), then the head: both in flight, only the first is waited for here
+            fx_dma_fill(smem, p.w[m], p.off_d1 / 4, QWAVES);
+            const int head_loads = fx_dma_fill(smem + p.off_d1, p.w[m] + p.off_d1, (p.total_floats - p.off_d1) / 4, QWAVES);
+            fx_wait_vm(head_loads);
+        } else {
+            fill_lds(reinterpret_cast<f4*>(smem), reinterpret_cast<const f4*>(p.w[m]), p.total_floats / 4);
+            fx_wait_vm(0);
+        }
         __syncthreads();
         if (m == m_first) fx_stamp(p.trace, 1);
         const f4* w_c2 = reinterpret_cast<const f4*>(smem + p.off_c2);
@@ -89,11 +107,15 @@ __global__ void __launch_bounds__(QWAVES * 64) k_score_cnn_quad(QuadArgs p) {
             f4 o1[FT][1];
             if (live) {
                 int c[K];
+                auto codes = [&](auto rp) {
 #pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    c[j] = lut_s[row[q + j]];
-                    if (c[j] == 0xFF) { bad = true; c[j] = 0; }
-                }
+                    for (int j = 0; j < K; ++j) {
+                        c[j] = lut_s[rp[q + j]];
+                        if (c[j] == 0xFF) { bad = true; c[j] = 0; }
+                    }
+                };
+                if (lds_bytes && m == m_first && rd == 0) codes((fx_lds_u8p)(bytes_s + (n < p.N ? sq : 0) * L));
+                else codes(row);
                 init_bias<FT, 1>(cb, o1, g);
 #pragma unroll
                 for (int j = 0; j < K; ++j) {
@@ -147,6 +169,7 @@ __global__ void __launch_bounds__(QWAVES * 64) k_score_cnn_quad(QuadArgs p) {
                     X[(q * FT + t) * 64 + lane] = o3[t][0];
                 }
             }
+            if (p.dma && rd == 0) fx_wait_vm(0);                     // this wave's share of the head's weights has landed
             __syncthreads();
 
             // ---- D: GlobalMaxPooling1D over the four positions; dense 1 for this wave's output tiles {q, q + 4}
@@ -230,7 +253,7 @@ int fx_launch_score_cnn_quad(fx_engine* e, fx_model* const* models, int M, const
     int64_t blocks = e->grid_blocks > 0 ? e->grid_blocks : e->num_cus;
     if (blocks > U) blocks = U;
     if (e->cnn_quad < 2 && U > (int64_t)QUADS * blocks) return FX_EUNSUPPORTED;       // more than one round per workgroup: not worth it
-    const size_t lds = (size_t)lay.total_floats * 4 + 256 + (size_t)QUADS * 16384;
+    const size_t lds = (size_t)lay.total_floats * 4 + 256 + (size_t)QUADS * 16384 + (size_t)QUADS * 16 * s.L;
     if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
     QuadArgs a{};
     a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
@@ -239,6 +262,7 @@ int fx_launch_score_cnn_quad(fx_engine* e, fx_model* const* models, int M, const
     a.N = N; a.TG = TG; a.M = M; a.m_off = m_off;
     a.out_sn = e->planar_stride ? 1 : Mtot; a.out_sm = e->planar_stride ? e->planar_stride : 1;
     a.rlh = lay.RLH;
+    a.dma = e->dma_fill && lay.off_d1 % 4 == 0 && lay.total_floats % 4 == 0;
     a.off_c2 = (int)lay.off_c2; a.off_c3 = (int)lay.off_c3; a.off_cb = (int)lay.off_cb; a.off_w1p = (int)lay.off_w1p;
     a.off_d1 = (int)lay.off_d1; a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
     auto kern = k_score_cnn_quad<7>;

@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                                     const unsigned c0 = lut_s[raw[2 * k]], c1 = lut_s[raw[2 * k + 1]];
                                     seen1 |= c0 | c1;                  // a code is < 4, or 0xFF: tested once per tile
                                     const unsigned idx = ((c0 & 3u) << 2) | (c1 & 3u);
-                                    const float* rowp = wpair + ((p0 + k) * 16 + idx) * (16 * HT) + 4 * g;
+                                    const float* rowp = wpair + ((p0 + k) * 16 + idx) * (16 * HT + FX_PAIR_PAD) + 4 * g;
 #pragma unroll
                                     for (int mo = 0; mo < HT; ++mo) h[mo][0] += *reinterpret_cast<const f4*>(rowp + 16 * mo);
                                 }
@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                         if (L & 1) {
                             const unsigned c0 = lut_s[rb[L - 1]];
                             seen1 |= c0;
-                            const float* rowp = wpair + (np2 * 16 + (c0 & 3u)) * (16 * HT) + 4 * g;
+                            const float* rowp = wpair + (np2 * 16 + (c0 & 3u)) * (16 * HT + FX_PAIR_PAD) + 4 * g;
 #pragma unroll
                             for (int mo = 0; mo < HT; ++mo) h[mo][0] += *reinterpret_cast<const f4*>(rowp + 16 * mo);
                         }

@@ -1294,6 +1294,27 @@ def test_cnn_quad_form_is_bit_identical_to_the_one_wave_kernel(eng, n, M):
         finally:
             eng.set_option("cnn_quad", 1)
     assert np.array_equal(outs[1], outs[0]) and np.array_equal(outs[2], outs[0])
+    # the weights through registers instead of the direct global -> LDS copies (the head then lands before the first
+    # tile instead of during its convolutions): same bits; and a byte buffer that is not 4-byte aligned (the first
+    # round then reads its bytes from global memory like the later ones)
+    eng.set_option("dma_fill", 0)
+    try:
+        for mode in (1, 2):
+            eng.set_option("cnn_quad", mode)
+            assert np.array_equal(eng.score(nms, b, lut, want_matrix=True)[0], outs[0])
+    finally:
+        eng.set_option("dma_fill", 1)
+        eng.set_option("cnn_quad", 1)
+    import torch
+    dev = torch.zeros(n * 8 + 8, dtype=torch.uint8, device="cuda")
+    for shift in (1, 4):
+        dev[shift:shift + n * 8] = torch.from_numpy(b.reshape(-1)).cuda()
+        stride = (n + 3) // 4 * 4
+        planes = torch.full((M, stride), float("nan"), device="cuda")
+        torch.cuda.synchronize()
+        eng.score_planes_dev(nms, dev.data_ptr() + shift, n, 8, lut, planes.data_ptr(), stride)
+        eng.sync()
+        assert np.array_equal(planes[:, :n].cpu().numpy().T, outs[0]), shift
     assert_scores(outs[2][:, M - 1], ref_np.keras_fitness(seqs, "TGCA", "cnn", pairs[M - 1][1], exact=True), f"quad n={n} M={M}")
     eng.set_option("cnn_quad", 2)
     try:

@@ -123,7 +123,8 @@ def test_myers_boundaries():
 
 def test_mlp_pair_rows_are_sums_of_the_single_position_rows():
     """MLP on a 4-letter alphabet: the packed image carries, after the vectors, one row per (pair of positions, pair of
-    letters) = float32 sum of the two single-position rows (pack.cpp); an odd last position keeps its four rows."""
+    letters) = float32 sum of the two single-position rows (pack.cpp); an odd last position keeps its four rows.  Rows
+    are 4 zero floats apart (LDS bank spread of the 16-row gather)."""
     from oracle import ref_np
 
     for L, H in ((14, 100), (7, 33), (2, 16)):
@@ -133,8 +134,10 @@ def test_mlp_pair_rows_are_sums_of_the_single_position_rows():
         R = 16 * lay["HT"]
         rows = packed[lay["off_w1p"]: lay["off_w1p"] + L * 4 * R].reshape(L * 4, R)
         n_pair_rows = (L // 2) * 16 + (L % 2) * 4
-        assert packed.shape[0] == lay["total_floats"] + n_pair_rows * R
-        pair = packed[lay["total_floats"]:].reshape(n_pair_rows, R)
+        assert packed.shape[0] == lay["total_floats"] + n_pair_rows * (R + 4)
+        padded = packed[lay["total_floats"]:].reshape(n_pair_rows, R + 4)
+        pair = padded[:, :R]
+        assert not padded[:, R:].any()
         for pi in range(L // 2):
             for c0 in range(4):
                 for c1 in range(4):

@@ -103,7 +103,7 @@ def trace_case(label, kind, L, alpha, M, N, H=100, F=0, K=0, opts=None):
     for k_ in (opts or {}):
         eng.set_option(k_, {"cnn_big_units": 12, "cnn_seg": -1, "ge_bytetab": 1, "mlp_pair": 1, "wave_prio": 1, "stage_bytes": 1}.get(k_, 0))
     for k_ in (opts or {}):
-        eng.set_option(k_, {"cnn_big_units": 12, "cnn_seg": -1, "ge_bytetab": 1, "mlp_pair": 1, "wave_prio": 1, "stage_bytes": 1, "dense_waves": 0, "stage_fill": 1, "cnn_quad": 1}.get(k_, 0))
+        eng.set_option(k_, {"cnn_big_units": 12, "cnn_seg": -1, "ge_bytetab": 1, "mlp_pair": 1, "wave_prio": 1, "stage_bytes": 1, "dense_waves": 0, "stage_fill": 1, "cnn_quad": 1, "dma_fill": 1}.get(k_, 0))
     out = {"what": label, "event_us_per_launch": ev_us, "trace": res[-1], "span_us_3runs": [r["span_us"] for r in res]}
     print(json.dumps(out), flush=True)
     return out
@@ -122,6 +122,17 @@ if __name__ == "__main__":
         rows.append(trace_case("[phases] ge L=90 M=1 N=4000", "ge", 90, AAS, 1, 4_000))
         rows.append(trace_case("[phases] cnn L=8 M=1 N=10000", "cnn", 8, "TGCA", 1, 10_000, F=32, K=5))
         json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "trace_probe_phases.json"), "w"), indent=1)
+        sys.exit(0)
+    if os.environ.get("FX_SET") == "dma":
+        # direct global -> LDS weight copies (engine option dma_fill) against the copies through registers
+        for kind, L, alpha, M, N, kw in (("cnn", 8, "TGCA", 1, 4_000, dict(F=32, K=5)), ("cnn", 8, "TGCA", 1, 10_000, dict(F=32, K=5)),
+                                         ("cnn", 8, "TGCA", 3, 10_000, dict(F=32, K=5)), ("cnn", 8, "TGCA", 1, 32_768, dict(F=32, K=5)),
+                                         ("cnn", 14, "UGCA", 1, 10_000, dict(F=32, K=5)),
+                                         ("mlp", 14, "UGCA", 1, 100_000, {}), ("mlp", 14, "UGCA", 1, 20_000, {}),
+                                         ("ge", 90, AAS, 1, 100_000, {}), ("ge", 90, AAS, 8, 100_000, {})):
+            for dma in (1, 0):
+                rows.append(trace_case(f"{kind} L={L} M={M} N={N} dma_fill={dma}", kind, L, alpha, M, N, opts={"dma_fill": dma}, **kw))
+        json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "trace_probe_dma.json"), "w"), indent=1)
         sys.exit(0)
     for M, N in ((1, 4000), (1, 10_000), (1, 32_768), (3, 10_000), (3, 100_000)):
         rows.append(trace_case(f"cnn L=8 M={M} N={N}", "cnn", 8, "TGCA", M, N, F=32, K=5))
