@@ -1444,3 +1444,50 @@ def test_cnn_split_path_protein_alphabet(eng, L, F, H, K, n, M):
     bad = b.copy(); bad[n // 2, L - 1] = ord("B")
     with pytest.raises(ValueError):
         eng.score(list(natives), bad, lut)
+
+
+def _random_case(seed):
+    """One seeded draw of (architecture, shape, members, batch size) from everything the constructors of cnn.py:10-21,
+    mlp.py:10-19 and global_epistasis_model.py:15-24 accept -- canonical and odd sizes alike, so that every kernel
+    family (fused / conv + head / pair / segmented / quad / dense / slab / shape-agnostic) is hit by some draw."""
+    rng = np.random.default_rng(9000 + seed)
+    kind = ("cnn", "cnn", "mlp", "ge")[int(rng.integers(0, 4))]
+    alpha = ("TGCA", "UGCA", s_utils.AAS, "01", "ACGTN")[int(rng.choice(5, p=[.3, .25, .25, .1, .1]))]
+    A = len(alpha)
+    K = int(rng.integers(2, 8)) if rng.random() < 0.5 else 5
+    F = int(rng.choice([8, 16, 24, 32, 32, 32, 48, 64]))
+    H = int(rng.choice([7, 16, 50, 64, 100, 100, 100, 112, 128, 130, 200]))
+    lmax = 40 if A == 20 else 70
+    L = 8 if rng.random() < 0.25 else int(rng.integers(max(K, 3), lmax + 1))
+    M = int(rng.integers(1, 5))
+    n = int(rng.choice([1, 2, 15, 16, 17, 33, 100, 257, 1000, 3001]))
+    if kind != "cnn":
+        F = K = 0
+    return kind, alpha, A, L, H, F, K, M, n
+
+
+@pytest.mark.parametrize("seed", range(64))
+def test_random_shapes_against_the_oracle_and_batch_invariance(eng, seed):
+    """Seeded sweep over architectures, alphabets, shapes, member counts and batch sizes.  (1) every member's scores match
+    the float64 oracle within the stated tolerance; (2) the device mean is np.mean of the matrix, bit for bit;
+    (3) BATCH INVARIANCE: a sequence's score does not depend on the call it arrives in -- a prefix scored on its own
+    (which may select another kernel form: quad, position-segmented, fewer waves) gives the same bits, as the
+    reference's explorers assume when they cache and compare model scores across calls of different sizes."""
+    kind, alpha, A, L, H, F, K, M, n = _random_case(seed)
+    what = f"seed {seed}: {kind} alphabet {alpha!r} L={L} H={H} F={F} K={K} M={M} n={n}"
+    natives, ws = zip(*[make_native(eng, kind, L, A, H, F, K, seed=500 + 7 * seed + m) for m in range(M)])
+    lut = _native.make_lut(alpha)
+    b, seqs = rand_seqs(n, L, alpha, seed=seed)
+    got, mean = eng.score(list(natives), b, lut, want_matrix=True, want_mean=True)
+    for m in range(M):
+        assert_scores(got[:, m], ref_np.keras_fitness(seqs, alpha, kind, ws[m], exact=True), what + f" member {m}")
+    assert np.array_equal(mean, np.mean(got, axis=1)), what
+    rng = np.random.default_rng(seed)
+    for k in sorted({1, min(n, 20), int(rng.integers(1, n + 1))}):
+        part, _ = eng.score(list(natives), b[:k], lut)
+        assert np.array_equal(part, got[:k]), what + f": prefix of {k} scored differently"
+    # a character outside the alphabet anywhere in the batch fails the call (sequence_utils.py:46)
+    bad = b.copy()
+    bad[int(rng.integers(0, n)), int(rng.integers(0, L))] = ord("#")
+    with pytest.raises(ValueError):
+        eng.score(list(natives), bad, lut)
