@@ -25,10 +25,24 @@ streams.
 
 Runs on `cuda` when a GPU is visible, else on the CPU (training is not the
 scored hot path; the trained weights are then uploaded to the scoring engine).
+
+On the GPU one mini-batch step is ~150 tiny kernels (the networks have 12-40 thousand
+parameters and a batch is 256 rows): launched one by one from Python a step costs
+2.4 ms for the canonical CNN, 0.19 s per `train` call of an explorer round -- the
+GPU idles between launches.  `fit` therefore captures ONE step (gather of the
+mini-batch, forward, loss, backward, Adam with the step count on the device) in a
+hipGraph (`torch.cuda.CUDAGraph`) and replays it: the mini-batch indices and row
+weights are copied into the graph's static buffers before each replay, a final
+partial mini-batch is padded with zero-weight rows (the loss is the mean over the
+valid rows, as Keras' smaller last batch gives).  Same arithmetic as the eager
+step (`_adam_update` is shared; tests hold the two to each other), FLEXS_AMD_TRAIN_GRAPH=0
+switches the capture off.
 """
 from __future__ import annotations
 
 import math
+import os
+import weakref
 
 import numpy as np
 import torch
@@ -50,17 +64,16 @@ def _encode(sequences, alphabet, L, device):
 
 
 def _conv(h, w, b, same):
-    """Keras Conv1D(strides=1) as K small GEMMs (channels-last, no MIOpen find step on a fresh box):
+    """Keras Conv1D(strides=1), channels-last, as ONE GEMM on the unfolded input (no MIOpen find step on a fresh box, and
+    a handful of kernels per layer instead of a slice + GEMM + add per tap: the step is launch-bound, see `fit`):
     h (n, L, Cin), w (k, Cin, Cout) -> (n, Lout, Cout); 'same' pads (k-1)//2 left, the rest right."""
-    k = w.shape[0]
+    k, cin, cout = w.shape
     if same:
         pl = (k - 1) // 2
         h = F.pad(h, (0, 0, pl, k - 1 - pl))
-    lout = h.shape[1] - k + 1
-    out = b.expand(h.shape[0], lout, w.shape[2])
-    for j in range(k):
-        out = out + h[:, j:j + lout, :] @ w[j]
-    return out
+    n, lout = h.shape[0], h.shape[1] - k + 1
+    cols = h.unfold(1, k, 1).permute(0, 1, 3, 2).reshape(n * lout, k * cin)      # row (n, t): x[n, t + j, c] at (j, c)
+    return torch.addmm(b, cols, w.reshape(k * cin, cout)).view(n, lout, cout)
 
 
 def forward(kind, params, x, train=False, dropout_mask=None):
@@ -87,6 +100,20 @@ def forward(kind, params, x, train=False, dropout_mask=None):
     return (h @ d4 + c4)[:, 0]
 
 
+def _adam_update(params, grads, m, v, lr_t, b1=BETA_1, b2=BETA_2, eps=EPSILON):
+    """m, v, params <- one Keras-Adam update; lr_t = lr sqrt(1 - b2^t) / (1 - b1^t) as a Python float (eager step) or
+    a 0-dim float32 device tensor (captured step: the step count lives on the device)."""
+    torch._foreach_mul_(m, b1)
+    torch._foreach_add_(m, grads, alpha=1.0 - b1)
+    torch._foreach_mul_(v, b2)
+    torch._foreach_addcmul_(v, grads, grads, value=1.0 - b2)
+    denom = torch._foreach_sqrt(v)
+    torch._foreach_add_(denom, eps)
+    upd = torch._foreach_div(m, denom)
+    torch._foreach_mul_(upd, lr_t)
+    torch._foreach_sub_(params, upd)
+
+
 class KerasAdam:
     """Adam as tf.keras applies it (see the module docstring); state = (t, m, v), exported to / restored
     from NumPy so that it can live on the `Architecture` between `train` calls."""
@@ -108,14 +135,7 @@ class KerasAdam:
     def step(self):
         self.t += 1
         lr_t = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
-        grads = [p.grad for p in self.params]
-        torch._foreach_mul_(self.m, self.b1)
-        torch._foreach_add_(self.m, grads, alpha=1.0 - self.b1)
-        torch._foreach_mul_(self.v, self.b2)
-        torch._foreach_addcmul_(self.v, grads, grads, value=1.0 - self.b2)
-        denom = torch._foreach_sqrt(self.v)
-        torch._foreach_add_(denom, self.eps)
-        torch._foreach_addcdiv_(self.params, self.m, denom, value=-lr_t)
+        _adam_update(self.params, [p.grad for p in self.params], self.m, self.v, lr_t, self.b1, self.b2, self.eps)
 
     def state(self):
         return {"t": self.t, "m": [m.detach().cpu().numpy() for m in self.m],
@@ -139,6 +159,79 @@ def train_step(arch, x, y, dropout_mask=None, device=None):
     return float(loss.detach())
 
 
+class _GraphTrainer:
+    """One captured mini-batch step of one `Architecture` (see the module docstring).  Everything the graph touches has a
+    fixed address: parameters, Adam moments, step count, the data set (capacity rows), the batch's row indices and
+    row weights."""
+
+    def __init__(self, arch, device, batch_size, capacity):
+        self.kind, self.B, self.cap, self.device = arch.kind, int(batch_size), int(capacity), device
+        self.shapes = [tuple(s) for s in arch.shapes()]
+        self.params = [torch.zeros(s, dtype=torch.float32, device=device, requires_grad=True) for s in self.shapes]
+        self.m = [torch.zeros(s, dtype=torch.float32, device=device) for s in self.shapes]
+        self.v = [torch.zeros(s, dtype=torch.float32, device=device) for s in self.shapes]
+        self.t = torch.zeros((), dtype=torch.float64, device=device)
+        self.x_all = torch.zeros((self.cap, arch.L, arch.A), dtype=torch.float32, device=device)
+        self.y_all = torch.zeros((self.cap,), dtype=torch.float32, device=device)
+        self.idx = torch.zeros((self.B,), dtype=torch.int64, device=device)
+        self.wts = torch.ones((self.B,), dtype=torch.float32, device=device)
+        self.sq_err = torch.zeros((), dtype=torch.float32, device=device)      # sum of squared errors since last reset
+        # warm-up on a side stream (allocator, rocBLAS handles), then capture; neither may leave a trace in the state
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self._step()
+        torch.cuda.current_stream(device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._step()
+
+    def matches(self, arch, batch_size, n):
+        return self.kind == arch.kind and self.B == int(batch_size) and n <= self.cap and \
+            self.shapes == [tuple(s) for s in arch.shapes()] and tuple(self.x_all.shape[1:]) == (arch.L, arch.A)
+
+    def _step(self):
+        for p in self.params:
+            p.grad = None
+        xb = self.x_all.index_select(0, self.idx)
+        yb = self.y_all.index_select(0, self.idx)
+        se = (forward(self.kind, self.params, xb, train=True) - yb) ** 2 * self.wts
+        loss = se.sum() / self.wts.sum()                 # mean over the valid rows of the mini-batch
+        loss.backward()
+        with torch.no_grad():
+            self.sq_err += se.sum()
+            self.t += 1
+            lr_t = (LR * torch.sqrt(1.0 - BETA_2 ** self.t) / (1.0 - BETA_1 ** self.t)).to(torch.float32)
+            _adam_update(self.params, [p.grad for p in self.params], self.m, self.v, lr_t)
+
+    @torch.no_grad()
+    def load(self, weights, state):
+        for p, w in zip(self.params, weights):
+            p.copy_(torch.from_numpy(np.ascontiguousarray(w, np.float32)))
+        ok = state is not None and len(state["m"]) == len(self.shapes) and \
+            all(tuple(a.shape) == s for a, s in zip(state["m"], self.shapes))
+        self.t.fill_(float(state["t"]) if ok else 0.0)
+        for dst, key in ((self.m, "m"), (self.v, "v")):
+            for d, i in zip(dst, range(len(self.shapes))):
+                if ok:
+                    d.copy_(torch.from_numpy(np.ascontiguousarray(state[key][i], np.float32)))
+                else:
+                    d.zero_()
+        self.sq_err.zero_()
+
+    def state(self):
+        return {"t": int(round(float(self.t.item()))), "m": [a.detach().cpu().numpy() for a in self.m],
+                "v": [a.detach().cpu().numpy() for a in self.v]}
+
+
+_TRAINERS = weakref.WeakKeyDictionary()          # Architecture -> _GraphTrainer (device state stays out of pickles / copies)
+
+
+def _use_graph(device):
+    return device.type == "cuda" and os.environ.get("FLEXS_AMD_TRAIN_GRAPH", "1") != "0"
+
+
 def fit(arch, sequences, labels, alphabet, batch_size=256, epochs=20, verbose=False, seed=None):
     if arch.loss not in ("MSE", "mse", "mean_squared_error"):
         raise ValueError(f"unsupported loss {arch.loss!r} (the reference only ever uses 'MSE')")
@@ -148,11 +241,13 @@ def fit(arch, sequences, labels, alphabet, batch_size=256, epochs=20, verbose=Fa
     device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
     x = _encode(sequences, alphabet, arch.L, device)
     y = torch.as_tensor(np.asarray(labels, dtype=np.float32), device=device)
-    params = [torch.tensor(w, device=device, requires_grad=True) for w in arch._weights]
-    opt = KerasAdam(params, getattr(arch, "_opt_state", None))       # moments and step count of the previous rounds
     gen = torch.Generator(device="cpu")
     if seed is not None:
         gen.manual_seed(seed)
+    if _use_graph(device):
+        return _fit_graphed(arch, x, y, n, int(batch_size), epochs, verbose, gen, device)
+    params = [torch.tensor(w, device=device, requires_grad=True) for w in arch._weights]
+    opt = KerasAdam(params, getattr(arch, "_opt_state", None))       # moments and step count of the previous rounds
     for epoch in range(epochs):
         perm = torch.randperm(n, generator=gen).to(device)
         total = 0.0
@@ -168,3 +263,32 @@ def fit(arch, sequences, labels, alphabet, batch_size=256, epochs=20, verbose=Fa
             print(f"Epoch {epoch + 1}/{epochs} - loss: {total / n:.6f}")
     arch.set_weights([p.detach().cpu().numpy() for p in params])
     arch._opt_state = opt.state()
+
+
+def _fit_graphed(arch, x, y, n, B, epochs, verbose, gen, device):
+    tr = _TRAINERS.get(arch)
+    if tr is None or not tr.matches(arch, B, n):
+        cap = 1024
+        while cap < n:
+            cap *= 2
+        tr = _TRAINERS[arch] = _GraphTrainer(arch, device, B, cap)
+    tr.load(arch._weights, getattr(arch, "_opt_state", None))
+    with torch.no_grad():
+        tr.x_all[:n].copy_(x)
+        tr.y_all[:n].copy_(y)
+        steps = (n + B - 1) // B
+        wts = torch.ones((steps * B,), dtype=torch.float32, device=device)
+        wts[n:] = 0.0                                    # padding rows of the last mini-batch (they gather row 0)
+        for epoch in range(epochs):
+            perm = torch.zeros((steps * B,), dtype=torch.int64)
+            perm[:n] = torch.randperm(n, generator=gen)
+            perm = perm.to(device)
+            for i in range(0, steps * B, B):
+                tr.idx.copy_(perm[i:i + B])
+                tr.wts.copy_(wts[i:i + B])
+                tr.graph.replay()
+            if verbose:
+                print(f"Epoch {epoch + 1}/{epochs} - loss: {float(tr.sq_err.item()) / n:.6f}")
+                tr.sq_err.zero_()
+    arch.set_weights([p.detach().cpu().numpy() for p in tr.params])
+    arch._opt_state = tr.state()

@@ -146,3 +146,63 @@ def test_one_step_on_the_gpu_equals_keras_restatement(kind):
     got = model.get_fitness(seqs)
     want = ref_np.keras_fitness(seqs, "UGCA", kind, arch.get_weights(), exact=True)
     assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max() + 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["mlp", "ge", "cnn"])
+def test_captured_step_equals_the_eager_step(kind, monkeypatch):
+    """`fit` on the GPU replays ONE captured mini-batch step (hipGraph) instead of launching its ~150 kernels from Python.
+    Same shuffles (seeded), same arithmetic: weights and optimiser state after several epochs -- with a partial last
+    mini-batch (zero-weight padding rows in the captured step), over two `train` calls (state carried on the device
+    buffers' reload) and after the data set outgrew the captured capacity (re-capture) -- equal the eager path's to
+    float32 rounding.  Dropout is switched off for the comparison (its masks come from different RNG offsets)."""
+    import time
+
+    import torch
+
+    monkeypatch.setattr(training, "DROPOUT", 0.0)
+    L, alphabet = 9, "UGCA"
+    results = {}
+    for graph in ("1", "0"):
+        monkeypatch.setenv("FLEXS_AMD_TRAIN_GRAPH", graph)
+        model = _model(kind, L, alphabet, 3)
+        arch = model.model
+        for rnd, n in enumerate((300, 700, 1100)):            # 256 + 44 rows; ...; beyond the first capture's 1024 rows
+            seqs, _, y = _batch(kind, L, alphabet, n, 50 + rnd)
+            training.fit(arch, seqs, y, alphabet, batch_size=256, epochs=3, seed=rnd)
+        assert arch._opt_state["t"] == 3 * (2 + 3 + 5)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        training.fit(arch, seqs, y, alphabet, batch_size=256, epochs=3, seed=9)
+        torch.cuda.synchronize()
+        results[graph] = (arch.get_weights(), arch._opt_state, time.perf_counter() - t0)
+    (wg, sg, tg), (we, se, te) = results["1"], results["0"]
+    assert sg["t"] == se["t"]
+    for a, b in zip(wg, we):
+        assert np.abs(a - b).max() <= 2e-6 + 1e-5 * np.abs(b).max(), (kind, np.abs(a - b).max())
+    for a, b in zip(sg["m"], se["m"]):
+        assert np.allclose(a, b, rtol=1e-3, atol=1e-7)
+    for a, b in zip(sg["v"], se["v"]):
+        assert np.allclose(a, b, rtol=2e-3, atol=1e-10)
+    print(f"{kind}: 15 steps captured {tg * 1e3:.1f} ms, eager {te * 1e3:.1f} ms")
+
+
+@pytest.mark.gpu
+def test_captured_training_learns_and_feeds_the_engine():
+    """The product path end to end on the GPU: CNN.train (captured steps, dropout on) lowers the loss on a learnable
+    target, the new weights reach the scoring engine, and a deep copy of the model trains on without the original's
+    device state."""
+    rng = np.random.default_rng(0)
+    alphabet, L = "TGCA", 8
+    seqs = ["".join(alphabet[i] for i in row) for row in rng.integers(0, 4, (600, L))]
+    y = np.array([s.count("G") / L + 0.5 * (s[0] == "T") for s in seqs], np.float32)
+    model = bm.CNN(L, 32, 100, alphabet, seed=4)
+    before = float(np.mean((model.get_fitness(seqs) - y) ** 2))
+    model.train(seqs, y)
+    after = float(np.mean((model.get_fitness(seqs) - y) ** 2))
+    assert after < 0.25 * before, (before, after)
+    assert model.model._opt_state["t"] == 20 * 3
+    twin = copy.deepcopy(model)
+    twin.train(seqs, y)
+    assert twin.model._opt_state["t"] == 120 and model.model._opt_state["t"] == 60
+    assert float(np.mean((twin.get_fitness(seqs) - y) ** 2)) < after * 1.5
