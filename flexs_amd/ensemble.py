@@ -53,6 +53,15 @@ class Ensemble(_EnsembleBase):
         self.combine_with = combine_with
 
     def train(self, sequences: SEQUENCES_TYPE, labels: np.ndarray):
+        from flexs_amd.baselines.models.keras_model import KerasModel
+
+        if len(self.models) > 1 and all(isinstance(m, KerasModel) and type(m).train is KerasModel.train for m in self.models):
+            # the same loop, the members' training steps interleaved on the GPU (flexs_amd/training.py fit_many)
+            from flexs_amd import training
+
+            training.fit_many([m.model for m in self.models], sequences, labels, [m.alphabet for m in self.models],
+                              [m.batch_size for m in self.models], [m.epochs for m in self.models])
+            return
         for model in self.models:                                             # ensemble.py:42-52
             model.train(sequences, labels)
 

@@ -265,30 +265,107 @@ def fit(arch, sequences, labels, alphabet, batch_size=256, epochs=20, verbose=Fa
     arch._opt_state = opt.state()
 
 
+class _GraphedFit:
+    """One `fit` on the captured step, cut into the pieces `fit_many` interleaves: begin (weights, optimiser state and
+    data into the static buffers), start_epoch (a fresh shuffle), step (one replay), end (weights back)."""
+
+    def __init__(self, arch, x, y, n, B, epochs, verbose, gen, device, stream=None):
+        self.arch, self.n, self.B, self.epochs, self.verbose, self.gen, self.device = arch, n, B, epochs, verbose, gen, device
+        self.stream = stream
+        tr = _TRAINERS.get(arch)
+        if tr is None or not tr.matches(arch, B, n):
+            cap = 1024
+            while cap < n:
+                cap *= 2
+            tr = _TRAINERS[arch] = _GraphTrainer(arch, device, B, cap)
+        self.tr = tr
+        self.steps = (n + B - 1) // B
+        with torch.no_grad():
+            tr.load(arch._weights, getattr(arch, "_opt_state", None))
+            tr.x_all[:n].copy_(x)
+            tr.y_all[:n].copy_(y)
+            self.wts = torch.ones((self.steps * B,), dtype=torch.float32, device=device)
+            self.wts[n:] = 0.0                           # padding rows of the last mini-batch (they gather row 0)
+        self.perm = None
+        self.epoch = 0
+
+    def start_epoch(self):
+        perm = torch.zeros((self.steps * self.B,), dtype=torch.int64)
+        perm[:self.n] = torch.randperm(self.n, generator=self.gen)
+        self.perm = perm.to(self.device, non_blocking=True)
+
+    @torch.no_grad()
+    def step(self, i):
+        lo = i * self.B
+        self.tr.idx.copy_(self.perm[lo:lo + self.B])
+        self.tr.wts.copy_(self.wts[lo:lo + self.B])
+        self.tr.graph.replay()
+
+    def end_epoch(self):
+        self.epoch += 1
+        if self.verbose:
+            print(f"Epoch {self.epoch}/{self.epochs} - loss: {float(self.tr.sq_err.item()) / self.n:.6f}")
+            self.tr.sq_err.zero_()
+
+    def end(self):
+        self.arch.set_weights([p.detach().cpu().numpy() for p in self.tr.params])
+        self.arch._opt_state = self.tr.state()
+
+
 def _fit_graphed(arch, x, y, n, B, epochs, verbose, gen, device):
-    tr = _TRAINERS.get(arch)
-    if tr is None or not tr.matches(arch, B, n):
-        cap = 1024
-        while cap < n:
-            cap *= 2
-        tr = _TRAINERS[arch] = _GraphTrainer(arch, device, B, cap)
-    tr.load(arch._weights, getattr(arch, "_opt_state", None))
-    with torch.no_grad():
-        tr.x_all[:n].copy_(x)
-        tr.y_all[:n].copy_(y)
-        steps = (n + B - 1) // B
-        wts = torch.ones((steps * B,), dtype=torch.float32, device=device)
-        wts[n:] = 0.0                                    # padding rows of the last mini-batch (they gather row 0)
-        for epoch in range(epochs):
-            perm = torch.zeros((steps * B,), dtype=torch.int64)
-            perm[:n] = torch.randperm(n, generator=gen)
-            perm = perm.to(device)
-            for i in range(0, steps * B, B):
-                tr.idx.copy_(perm[i:i + B])
-                tr.wts.copy_(wts[i:i + B])
-                tr.graph.replay()
-            if verbose:
-                print(f"Epoch {epoch + 1}/{epochs} - loss: {float(tr.sq_err.item()) / n:.6f}")
-                tr.sq_err.zero_()
-    arch.set_weights([p.detach().cpu().numpy() for p in tr.params])
-    arch._opt_state = tr.state()
+    job = _GraphedFit(arch, x, y, n, B, epochs, verbose, gen, device)
+    for _ in range(epochs):
+        job.start_epoch()
+        for i in range(job.steps):
+            job.step(i)
+        job.end_epoch()
+    job.end()
+
+
+def fit_many(archs, sequences, labels, alphabets, batch_sizes, epochs, verbose=False, seeds=None):
+    """`for model in models: model.train(sequences, labels)` (flexs/ensemble.py:42-52) for members that are all device
+    surrogates: the members' captured steps are replayed on one HIP stream per member, step by step in turn, so that
+    the GPU works on all members at once -- a captured step is a serial chain of ~100 tiny kernels that leaves the
+    machine empty, and three chains side by side take about as long as one.  Every member keeps its own shuffles,
+    dropout masks and optimiser state exactly as in the one-by-one loop; only the wall time changes."""
+    n = len(sequences)
+    device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+    if n == 0:
+        return
+    if len(archs) < 2 or not _use_graph(device):
+        for k, (arch, alphabet, bs, ep) in enumerate(zip(archs, alphabets, batch_sizes, epochs)):
+            fit(arch, sequences, labels, alphabet, batch_size=bs, epochs=ep, verbose=verbose, seed=seeds[k] if seeds else None)
+        return
+    for arch in archs:
+        if arch.loss not in ("MSE", "mse", "mean_squared_error"):
+            raise ValueError(f"unsupported loss {arch.loss!r} (the reference only ever uses 'MSE')")
+    y = torch.as_tensor(np.asarray(labels, dtype=np.float32), device=device)
+    cur = torch.cuda.current_stream(device)
+    jobs, encoded = [], {}
+    for k, (arch, alphabet, bs, ep) in enumerate(zip(archs, alphabets, batch_sizes, epochs)):
+        key = (alphabet, arch.L)
+        if key not in encoded:
+            encoded[key] = _encode(sequences, alphabet, arch.L, device)
+        gen = torch.Generator(device="cpu")
+        if seeds:
+            gen.manual_seed(seeds[k])
+        jobs.append(_GraphedFit(arch, encoded[key], y, n, int(bs), ep, verbose, gen, device, stream=torch.cuda.Stream(device=device)))
+    for job in jobs:
+        job.stream.wait_stream(cur)                      # the static buffers were filled on the current stream
+    for epoch in range(max(j.epochs for j in jobs)):
+        live = [j for j in jobs if epoch < j.epochs]
+        for job in live:
+            with torch.cuda.stream(job.stream):
+                job.start_epoch()
+        for i in range(max(j.steps for j in live)):
+            for job in live:
+                if i < job.steps:
+                    with torch.cuda.stream(job.stream):
+                        job.step(i)
+        for job in live:
+            with torch.cuda.stream(job.stream):
+                job.end_epoch()
+    for job in jobs:
+        cur.wait_stream(job.stream)
+    for job in jobs:
+        job.end()
