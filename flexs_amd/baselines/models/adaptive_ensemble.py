@@ -13,7 +13,7 @@ import sklearn.model_selection
 
 import flexs_amd
 from flexs_amd import _native
-from flexs_amd.ensemble import _device_members
+from flexs_amd.ensemble import _device_members, train_members
 from flexs_amd.types import SEQUENCES_TYPE
 
 MIN_SAMPLES_FOR_REWEIGHTING = 10          # adaptive_ensemble.py:82
@@ -52,13 +52,11 @@ class AdaptiveEnsemble(flexs_amd.Model):
     def train(self, sequences: SEQUENCES_TYPE, labels: np.ndarray):
         """Train the members; with >= 10 samples hold out a validation split and re-weight."""
         if len(sequences) < MIN_SAMPLES_FOR_REWEIGHTING:
-            for member in self.models:
-                member.train(sequences, labels)
+            train_members(self.models, sequences, labels)
             return
         fit_x, val_x, fit_y, val_y = sklearn.model_selection.train_test_split(
             np.array(sequences), np.array(labels), test_size=self.adaptive_val_size)
-        for member in self.models:
-            member.train(fit_x, fit_y)
+        train_members(self.models, fit_x, fit_y)
         val_preds = np.stack([member.get_fitness(val_x) for member in self.models], axis=0)
         self.weights = self.adapt_weights_with(val_preds, val_y)
 

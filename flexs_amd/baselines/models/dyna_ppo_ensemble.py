@@ -16,7 +16,7 @@ import sklearn.model_selection
 
 import flexs_amd
 from flexs_amd import _native
-from flexs_amd.ensemble import _device_members
+from flexs_amd.ensemble import _device_members, train_members
 
 
 class DynaPPOEnsemble(flexs_amd.Model):
@@ -42,8 +42,7 @@ class DynaPPOEnsemble(flexs_amd.Model):
         (train_X, test_X, train_y, test_y) = sklearn.model_selection.train_test_split(
             np.array(sequences), np.array(labels), test_size=0.25
         )
-        for model in self.models:
-            model.train(train_X, train_y)
+        train_members(self.models, train_X, train_y)
         self.r_squared_vals = []
         for model in self.models:
             y_preds = model.get_fitness(test_X)

@@ -33,6 +33,22 @@ else:
     _EnsembleBase = flexs_amd.Model
 
 
+def train_members(models, sequences, labels):
+    """`for model in models: model.train(sequences, labels)` (flexs/ensemble.py:42-52, adaptive_ensemble.py:84-92,
+    dyna_ppo.py:104-107).  When every member is a device surrogate with the stock `train`, the same loop with the members'
+    training steps interleaved on the GPU (flexs_amd/training.py fit_many); any other member list is trained one by one."""
+    from flexs_amd.baselines.models.keras_model import KerasModel
+
+    if len(models) > 1 and all(isinstance(m, KerasModel) and type(m).train is KerasModel.train for m in models):
+        from flexs_amd import training
+
+        training.fit_many([m.model for m in models], sequences, labels, [m.alphabet for m in models],
+                          [m.batch_size for m in models], [m.epochs for m in models])
+        return
+    for model in models:
+        model.train(sequences, labels)
+
+
 class Ensemble(_EnsembleBase):
     """
     Ensemble of models / landscapes.
@@ -53,17 +69,7 @@ class Ensemble(_EnsembleBase):
         self.combine_with = combine_with
 
     def train(self, sequences: SEQUENCES_TYPE, labels: np.ndarray):
-        from flexs_amd.baselines.models.keras_model import KerasModel
-
-        if len(self.models) > 1 and all(isinstance(m, KerasModel) and type(m).train is KerasModel.train for m in self.models):
-            # the same loop, the members' training steps interleaved on the GPU (flexs_amd/training.py fit_many)
-            from flexs_amd import training
-
-            training.fit_many([m.model for m in self.models], sequences, labels, [m.alphabet for m in self.models],
-                              [m.batch_size for m in self.models], [m.epochs for m in self.models])
-            return
-        for model in self.models:                                             # ensemble.py:42-52
-            model.train(sequences, labels)
+        train_members(self.models, sequences, labels)                         # ensemble.py:42-52
 
     def _fitness_function(self, sequences):
         if _device_members(self.models):
