@@ -262,6 +262,39 @@ def end_to_end_block(device):
     return out
 
 
+def explorer_round_block(device, torch):
+    """SURVEY.md 8(f)-1/-2, the callers on either side of the path: one explorer round on configs[0]'s surrogate family --
+    `Ensemble.train` of the 3-CNN ensemble on 1000 measured sequences (Adam / MSE / 20 epochs / batch 256, captured
+    steps, members side by side), then one Adalead round (query budget 2000: several hundred model calls of 1-20
+    sequences).  Wall times, second call of each (graphs captured, engine warm)."""
+    import random
+
+    import flexs_amd
+    from flexs_amd import synth
+    from flexs_amd.utils import rollouts
+
+    ens = flexs_amd.Ensemble(build_members("cnn", L, ALPHABET, M, device))
+    n = 1000
+    seqs = synth.bytes_to_strings(synth.random_sequence_bytes(n, L, ALPHABET, 3))
+    y = np.random.default_rng(0).random(n)
+    out = {}
+    ens.train(seqs, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); ens.train(seqs, y); torch.cuda.synchronize()
+    out["train_3xCNN_n1000_ms"] = (time.perf_counter() - t0) * 1e3
+    out["train_steps_per_member"] = 20 * ((n + 255) // 256)
+    for i in range(2):
+        random.seed(1)
+        c0 = ens.cost
+        t0 = time.perf_counter()
+        rollouts.adalead_round(ens, seqs, y, sequences_batch_size=100, model_queries_per_batch=2000, alphabet=ALPHABET)
+        out["adalead_round_ms"] = (time.perf_counter() - t0) * 1e3
+        out["adalead_model_queries"] = int(ens.cost - c0)
+    out["what"] = ("one explorer round, 3 x CNN(32,100) L=8: Ensemble.train on 1000 measured sequences (PyTorch-ROCm, one captured "
+                   "hipGraph step per member, members interleaved) + flexs_amd.utils.rollouts.adalead_round (budget 2000 queries)")
+    return out
+
+
 def member_parallel_block(world, rank, device, torch, dist, use_dist, steps_hint):
     """north_star's split: an 8-member ensemble, members sharded over the ranks (contiguous blocks), every rank
     scores the SAME batch with its members, ONE all-gather of the stacked predictions, mean on every rank.
@@ -419,6 +452,7 @@ def main():
         if world == 1 and not args.no_extras:
             out["configs"] = configs_block(eng, local_rank, torch)
             out["end_to_end"] = end_to_end_block(local_rank)
+            out["explorer_round"] = explorer_round_block(local_rank, torch)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nam=args.cpu_nam)
         if saved_stdout is not None:
