@@ -16,6 +16,9 @@
 // k_score_cnn_mfma (tested), so a sequence scores the same in a call of 20 and in a batch of 10^5.
 // Three quads per workgroup (X / Y: 2 x 8 KiB per quad next to the member's ~103 KiB of weights); X and Y swap roles
 // every round so that wave 0's phase F never races the next round's phase A.
+// Start-up: the LUT, the first round's 16 x 8 sequence bytes and the whole weight image are requested at once by direct
+// global -> LDS copies (mfma_common.h fx_dma_fill); phase A starts when the conv part (~35 KiB) has landed, the dense
+// head's ~68 KiB arrive during the convolutions and are waited for before phase D (engine option dma_fill).
 #include "fx_common.h"
 #include "mfma_common.h"
 

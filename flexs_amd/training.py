@@ -166,6 +166,7 @@ class _GraphTrainer:
 
     def __init__(self, arch, device, batch_size, capacity):
         self.kind, self.B, self.cap, self.device = arch.kind, int(batch_size), int(capacity), device
+        self.device_index = torch.cuda.current_device()
         self.shapes = [tuple(s) for s in arch.shapes()]
         self.params = [torch.zeros(s, dtype=torch.float32, device=device, requires_grad=True) for s in self.shapes]
         self.m = [torch.zeros(s, dtype=torch.float32, device=device) for s in self.shapes]
@@ -189,7 +190,7 @@ class _GraphTrainer:
 
     def matches(self, arch, batch_size, n):
         return self.kind == arch.kind and self.B == int(batch_size) and n <= self.cap and \
-            self.shapes == [tuple(s) for s in arch.shapes()] and tuple(self.x_all.shape[1:]) == (arch.L, arch.A)
+            self.device_index == torch.cuda.current_device() and self.shapes == [tuple(s) for s in arch.shapes()] and tuple(self.x_all.shape[1:]) == (arch.L, arch.A)
 
     def _step(self):
         for p in self.params:
