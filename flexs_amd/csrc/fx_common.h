@@ -88,6 +88,7 @@ struct fx_engine {
     int64_t cnn_pair = 1;       // 1 = wide alphabets (A = 20) use the two-waves-per-tile kernel (score_cnn_pair.hip)
     int64_t cnn_big_units = 12; // work units per CU from which the A = 4 CNN path switches to 16-wave (unrolled) workgroups
     int64_t cnn_seg = -1;       // A = 4 CNN kernel, small batches: -1 = waves of a workgroup split one tile's positions when L1 >= 24, 0 = never, 1 = whenever the batch is small
+    int64_t cnn_pair_seg4 = 1;  // 1 = the segmented protein form may use 4-wave workgroups (one wave per SIMD) when twice as many still fit in one wave of the grid
     int64_t cnn_pair_seg = -1;  // pair kernel, small batches: -1 = segment a tile's positions automatically, 0 = never, n > 0 = force SB = n workgroups per tile
     int64_t dense_slab = 1;     // MLP / GE with H > 128: HxH blocks staged through LDS slabs by the workgroup (0 = every wave streams them from L2)
     int64_t ge_bytetab = 1;     // 1 = GlobalEpistasis layer 1 gathers from the byte-indexed per-position table (0 = LUT + code-indexed table: A/B)

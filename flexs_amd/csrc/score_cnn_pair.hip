@@ -44,6 +44,14 @@ struct PairArgs {
     unsigned* cnt;              // SEG form: [units] arrival counters, zeroed per launch
 };
 
+// workgroups per (member, tile) unit of the position-segmented small-batch form (see launch_pair)
+inline int64_t fx_pair_seg_count(int L1, int pairs, int64_t U, int64_t num_cus) {
+    int64_t sb = L1 / (pairs * 2);
+    if (sb > 128 / pairs) sb = 128 / pairs;
+    if (sb > num_cus / U) sb = num_cus / U;
+    return sb;
+}
+
 // Dense head of one tile (cnn.py:49-54): 32 pooled features -> H -> H -> 1, one wave.
 template <int HT>
 __device__ __forceinline__ float pair_dense_head(const f4* w_d1, const f4* w_d2, const float* db, f4 pool0, f4 pool1,
@@ -124,8 +132,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
             int seg_lo = 0, seg_hi = L1, s0 = 0, s_end = steps, nsteps = steps;
             if (SEG) {
                 const int S = p.SB * PAIRS, q = sb * PAIRS + pair;
-                seg_lo = (int)((int64_t)L1 * q / S);
-                seg_hi = (int)((int64_t)L1 * (q + 1) / S);
+                seg_lo = __builtin_amdgcn_readfirstlane((int)((int64_t)L1 * q / S));       // (wave-uniform: scalar tap tests below)
+                seg_hi = __builtin_amdgcn_readfirstlane((int)((int64_t)L1 * (q + 1) / S));
                 s0 = seg_lo - PL3 - PL2 > 0 ? seg_lo - PL3 - PL2 : 0;
                 s_end = seg_hi + PR2 + PR3 < steps ? seg_hi + PR2 + PR3 : steps;
                 nsteps = (L1 + S - 1) / S + PL3 + PL2 + PR2 + PR3;
@@ -212,6 +220,27 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
 
                     // ---- conv3 (same, A-1 taps), scatter form: tap j feeds output position t2 - j + PL3,
                     //      which lives in window slot K3-1-j (slot i <-> position t2 - PR3 + i)
+                    if constexpr (SEG) {
+                        // Segment form: only the taps that land on this pair's OWN positions are issued -- a halo step
+                        // feeds at most (segment length) of the A-1 window slots that will ever be pooled; the other
+                        // slots may hold anything.  Every own output still receives all its taps, in the same order:
+                        // same bits as the whole-sequence walk.  (A segment of 2-4 positions has 22 halo steps at
+                        // A = 20: conv3 drops from 152 to 16-32 MFMAs per wave per step.)
+                        const int j_lo = t2 + PL3 - seg_hi + 1, j_hi = t2 + PL3 - seg_lo;
+#pragma unroll
+                        for (int j = 0; j < K3; ++j) {
+                            if (j >= j_lo && j <= j_hi) {
+                                asm volatile("" ::: "memory");
+                                f4 a[FT];
+#pragma unroll
+                                for (int mi = 0; mi < FT; ++mi) a[mi] = w_c3[((j * FT + mi) * FT + mo) * 64 + lane];
+#pragma unroll
+                                for (int mi = 0; mi < FT; ++mi)
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) accw[K3 - 1 - j] = mfma16(a[mi][r], out2[mi][r], accw[K3 - 1 - j]);
+                            }
+                        }
+                    } else
 #pragma unroll
                     for (int j0 = 0; j0 < K3; j0 += TAPG) {
                         // fence the weight reads of each tap group: without it the scheduler hoists all
@@ -301,9 +330,11 @@ int launch_pair(fx_engine* e, PairArgs a, size_t lds_bytes) {
     const int64_t U = (int64_t)a.M * a.TG;
     const int L1 = a.L - K + 1;
     // Small batch (a CMA-ES / DyNA-PPO population, a single sequence): fewer units than half the CUs.  Cut every
-    // tile into segments of >= 12 positions over SB workgroups so that the call's latency is ~L1/S + halo steps.
-    int64_t sb = L1 / ((WAVES / 2) * 12);
-    if (sb > e->num_cus / U) sb = e->num_cus / U;
+    // tile into segments over SB workgroups so that the call's latency is ~L1/S + halo steps.  The halo (PL3 + PL2 +
+    // PR2 + PR3 = 22 positions at A = 20) is recomputed by every segment, but the machine is otherwise empty: as many
+    // workgroups per tile as fit in ONE wave of the grid (U x SB <= CUs), down to segments of two positions
+    // (tools/runs/r2_pair_seg_sweep.py: a 1-16 sequence call at L = 237 250 -> 181 us, at L = 90 269 -> 169 us).
+    int64_t sb = fx_pair_seg_count(L1, WAVES / 2, U, e->num_cus);
     if (e->cnn_pair_seg == 0 || 2 * U > e->num_cus) sb = 0;
     if (e->cnn_pair_seg > 0) sb = e->cnn_pair_seg;                       // test knob: force SB
     if (sb >= 1) {
@@ -312,9 +343,27 @@ int launch_pair(fx_engine* e, PairArgs a, size_t lds_bytes) {
         int rc = fx_scratch(e, 2, pool_bytes + cnt_bytes, &ws);
         if (rc) return rc;
         FX_HIP(e, hipMemsetAsync(ws, 0, pool_bytes + cnt_bytes, e->stream));
-        a.SB = (int)sb;
         a.pool = (unsigned*)ws;
         a.cnt = (unsigned*)((char*)ws + pool_bytes);
+        if constexpr (A == 20 && K == 5 && HT == 7 && WAVES == 8) {
+            // Same number of segments from twice the workgroups of half the size, when they still fit in one wave of the
+            // grid: ONE wave per SIMD instead of two.  A step of a wave is 192 MFMAs = 2.6 us of its SIMD's pipe, two
+            // waves on a SIMD take turns, and a call of a few sequences is a chain of ~25 such steps.
+            const int64_t sb4 = fx_pair_seg_count(L1, 2, U, e->num_cus);
+            if (e->cnn_pair_seg < 0 && e->cnn_pair_seg4 && sb4 * 2 >= sb * 4) {
+                auto seg4 = k_score_cnn_pair<A, K, HT, 4, true>;
+                static bool attr4[64] = {};
+                if (!attr4[e->device & 63]) {
+                    FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(seg4), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    attr4[e->device & 63] = true;
+                }
+                a.SB = (int)sb4;
+                hipLaunchKernelGGL(seg4, dim3((unsigned)(U * sb4)), dim3(4 * 64), lds_bytes, e->stream, a);
+                FX_HIP(e, hipGetLastError());
+                return FX_OK;
+            }
+        }
+        a.SB = (int)sb;
         hipLaunchKernelGGL(seg, dim3((unsigned)(U * sb)), dim3(WAVES * 64), lds_bytes, e->stream, a);
         FX_HIP(e, hipGetLastError());
         return FX_OK;
@@ -342,8 +391,7 @@ int launch_pair_conv(fx_engine* e, PairArgs a, size_t lds_bytes) {
     const int64_t U = (int64_t)a.M * a.TG;
     // small batch: position-segmented over SB workgroups per tile, as launch_pair does for the fused form
     const int L1 = a.L - K + 1;
-    int64_t sb = L1 / ((WAVES / 2) * 12);
-    if (sb > e->num_cus / U) sb = e->num_cus / U;
+    int64_t sb = fx_pair_seg_count(L1, WAVES / 2, U, e->num_cus);
     if (e->cnn_pair_seg == 0 || 2 * U > e->num_cus) sb = 0;
     if (e->cnn_pair_seg > 0) sb = e->cnn_pair_seg;
     if (sb >= 1) {
