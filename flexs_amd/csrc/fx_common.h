@@ -97,7 +97,7 @@ struct fx_engine {
     int64_t wave_prio = 1;      // 1 = static, distinct issue priorities for the waves of a SIMD (fx_stagger_priority); 0 = A/B baseline
     int64_t trace = 0;          // 1 = the MFMA scoring kernels stamp an in-kernel timeline into d_trace (fx_debug_trace_read)
     unsigned long long* d_trace = nullptr;
-    int64_t cnn_quad = 1;       // 1 = small launches of the canonical L = 8 CNN share a tile among four waves (score_cnn_quad.hip); 2 = whatever the size (test knob); 0 = off
+    int64_t cnn_quad = 1;       // 1 = small launches of the canonical 4-letter CNN with L <= 16 share a tile among four waves (score_cnn_quad.hip); 2 = whatever the size (test knob); 0 = off
     int64_t dma_fill = 1;       // 1 = weight images go global -> LDS directly (global_load_lds), all in flight at kernel start, the first layers start when THEIR part has landed (0 = through registers, whole image before the first tile: A/B)
     int64_t stage_fill = 1;     // 1 = CNN launches with fewer tiles than waves per workgroup load the conv part first and let the idle waves bring the head's weights (0 = whole image before the first tile: A/B)
     int64_t stage_bytes = 1;    // 1 = MLP (pair rows) / GE (byte table) tiles copy their 16 x L sequence bytes into per-wave LDS scratch with 16-byte loads (0 = byte loads from global memory: A/B)
@@ -186,7 +186,7 @@ int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const
 int fx_launch_cnn_pair_conv(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N, void* d_pool);
 int fx_launch_score_cnn_split(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii,
                               int64_t N, float* d_out_NM, int Mtot, int m_off);
-// small launches of the canonical TF-binding CNN: one tile shared by a wave quad (score_cnn_quad.hip)
+// small launches of the canonical 4-letter CNN, L <= 16 (TF-binding, RNA 14): one tile shared by a wave quad (score_cnn_quad.hip)
 int fx_launch_score_cnn_quad(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N,
                              float* d_out_NM, int Mtot, int m_off);
 int fx_launch_score_cnn_pair(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii,

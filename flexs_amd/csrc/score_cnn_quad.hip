@@ -4,18 +4,20 @@
 // explorer-size call) the one-wave-per-tile kernel runs a LONE wave per SIMD: ~75 % of the pipe for that wave, three of
 // the CU's four matrix pipes idle (profiles/r2_trace_probe: 12 us per tile whose MFMAs are 8 us of one pipe).  Here a
 // wave quad walks the network layer by layer and exchanges activations through LDS:
-//     wave q (= conv position q; TF-binding: seq_len 8, kernel 5 -> 4 positions)
-//     A  conv1 at position q (row gather)                       -> X[q]            barrier
-//     B  conv2 at position q from X[q-2 .. q+2]                  -> Y[q]            barrier
-//     C  conv3 at position q from Y[q-1 .. q+1], relu            -> X[q]            barrier
-//     D  global max over the 4 positions; dense 1, output tiles {q, q+4}  -> Y      barrier
+//     wave q takes the conv positions q, q + 4, q + 8, ... (TF-binding: seq_len 8, kernel 5 -> 4 positions, one each;
+//     RNA: seq_len 14 -> 10 positions, 3-3-2-2; up to 12 positions = seq_len 16)
+//     A  conv1 at its positions (row gather)                    -> X[pos]          barrier
+//     B  conv2 at its positions from X[pos-2 .. pos+2]           -> Y[pos]          barrier
+//     C  conv3 at its positions from Y[pos-1 .. pos+1], relu     -> X[pos]          barrier
+//     D  global max over all positions; dense 1, output tiles {q, q+4}    -> Y      barrier
 //     E  dense 2, output tiles {q, q+4} from all 7 tiles of Y    -> X               barrier
 //     F  wave 0: final dot over all 7 tiles of X, nan_to_num, store
 // Every output element sees exactly the MFMA / add sequence of the one-wave kernel (k-order (tap, input tile, k-step),
 // padding taps skipped, hidden tail k-steps skipped), the exchanges are copies: results are BIT-IDENTICAL to
 // k_score_cnn_mfma (tested), so a sequence scores the same in a call of 20 and in a batch of 10^5.
-// Three quads per workgroup (X / Y: 2 x 8 KiB per quad next to the member's ~103 KiB of weights); X and Y swap roles
-// every round so that wave 0's phase F never races the next round's phase A.
+// Three quads per workgroup at 4 positions (X / Y: 2 x 8 KiB per quad next to the member's ~103 KiB of weights), one quad
+// (X / Y: 2 x 24 KiB) at up to 12; X and Y swap roles every round so that wave 0's phase F never races the next round's
+// phase A.
 // Start-up: the LUT, the first round's 16 x 8 sequence bytes and the whole weight image are requested at once by direct
 // global -> LDS copies (mfma_common.h fx_dma_fill); phase A starts when the conv part (~35 KiB) has landed, the dense
 // head's ~68 KiB arrive during the convolutions and are waited for before phase D (engine option dma_fill).
@@ -24,7 +26,6 @@
 
 namespace {
 
-constexpr int QUADS = 3, QWAVES = 4 * QUADS;
 
 struct QuadArgs {
     const uint8_t* ascii;
@@ -36,21 +37,24 @@ struct QuadArgs {
     int64_t N, TG;
     int M, m_off;
     int64_t out_sn, out_sm;
-    int rlh;
+    int L, rlh;
     int dma;                    // 1 = weights (and the first round's bytes) go global -> LDS directly, head part lands during the convolutions
     int off_c2, off_c3, off_cb, off_w1p, off_d1, off_d2, off_db, total_floats;
 };
 
-template <int HT>
-__global__ void __launch_bounds__(QWAVES * 64) k_score_cnn_quad(QuadArgs p) {
-    constexpr int A = 4, K = 5, K3 = 3, FT = 2, L = 8, L1 = 4, PL2 = 2, PL3 = 1;
+// QUADS quads per workgroup; XT = 16-channel tiles per exchange buffer (>= FT x positions and >= HT)
+template <int HT, int QUADS, int XT>
+__global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
+    constexpr int A = 4, K = 5, K3 = 3, FT = 2, PL2 = 2, PL3 = 1, QWAVES = 4 * QUADS;
+    static_assert(XT >= HT + 1, "the dense layers exchange HT tiles through the same buffers");
+    const int L = p.L, L1 = L - K + 1;                   // (L1 * FT <= XT: checked by the launcher)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int quad = wave >> 2, q = wave & 3;
     const int g = lane >> 4, sq = lane & 15;
     uint8_t* lut_s = reinterpret_cast<uint8_t*>(smem + p.total_floats);
-    f4* xq = reinterpret_cast<f4*>(smem + p.total_floats + 64) + quad * 1024;       // this quad's two 8 KiB buffers
-    uint8_t* bytes_s = reinterpret_cast<uint8_t*>(smem + p.total_floats + 64 + QUADS * 4096) + quad * (16 * L);   // dma: the first round's 16 x L bytes
+    f4* xq = reinterpret_cast<f4*>(smem + p.total_floats + 64) + quad * (2 * XT * 64);   // this quad's two XT KiB buffers
+    uint8_t* bytes_s = reinterpret_cast<uint8_t*>(smem + p.total_floats + 64 + QUADS * 2 * XT * 256) + quad * 256;   // dma: the first round's 16 x L bytes (L <= 16)
     fx_stamp(p.trace, 0);
     fx_stamp(p.trace, 7, (unsigned long long)fx_simd_id() + 1);
     [[maybe_unused]] unsigned tiles_done = 0;
@@ -72,7 +76,9 @@ __global__ void __launch_bounds__(QWAVES * 64) k_score_cnn_quad(QuadArgs p) {
             if (lds_bytes && m == m_first && q == 0) {
                 const int64_t tg0 = u_lo - (int64_t)m * p.TG + quad;
                 const int64_t rows = p.N - tg0 * 16 < 16 ? p.N - tg0 * 16 : 16;
-                if (u_lo + quad < u_hi && tg0 < p.TG && lane < rows * (L / 4))
+                // (16 L bytes per tile: a multiple of 4; the last dword of a short tile may reach <= 3 bytes past the batch,
+                //  inside the same aligned dword -- never into another page)
+                if (u_lo + quad < u_hi && tg0 < p.TG && lane * 4 < rows * L)
                     fx_dma4(p.ascii + tg0 * 16 * L + lane * 4, __builtin_amdgcn_readfirstlane(fx_lds_addr(bytes_s)));
             }
             // conv part (+ conv1 rows, conv biases), then the head: both in flight, only the first is waited for here
@@ -101,87 +107,94 @@ __global__ void __launch_bounds__(QWAVES * 64) k_score_cnn_quad(QuadArgs p) {
             const bool live = tg < t_hi;                             // idle quads run along for the barriers
             const int64_t n = tg * 16 + sq;
             const uint8_t* row = p.ascii + ((live && n < p.N) ? n : 0) * L;
-            f4* X = xq + (parity ? 512 : 0);
-            f4* Y = xq + (parity ? 0 : 512);
+            f4* X = xq + (parity ? XT * 64 : 0);
+            f4* Y = xq + (parity ? 0 : XT * 64);
             asm volatile("" ::: "memory");                           // keep the LDS weight reads inside the round
             if (live && tiles_done == 0) fx_stamp(p.trace, 2);
 
-            // ---- A: conv1 (valid) at position q: bias + the K kernel rows selected by the codes, relu
-            f4 o1[FT][1];
+            // ---- A: conv1 (valid) at this wave's positions: bias + the K kernel rows selected by the codes, relu
             if (live) {
-                int c[K];
-                auto codes = [&](auto rp) {
+                for (int pos = q; pos < L1; pos += 4) {
+                    f4 o1[FT][1];
+                    int c[K];
+                    auto codes = [&](auto rp) {
+#pragma unroll
+                        for (int j = 0; j < K; ++j) {
+                            c[j] = lut_s[rp[pos + j]];
+                            if (c[j] == 0xFF) { bad = true; c[j] = 0; }
+                        }
+                    };
+                    if (lds_bytes && m == m_first && rd == 0) codes((fx_lds_u8p)(bytes_s + (n < p.N ? sq : 0) * L));
+                    else codes(row);
+                    init_bias<FT, 1>(cb, o1, g);
 #pragma unroll
                     for (int j = 0; j < K; ++j) {
-                        c[j] = lut_s[rp[q + j]];
-                        if (c[j] == 0xFF) { bad = true; c[j] = 0; }
+                        const float* rowp = w1p + (j * A + c[j]) * (16 * FT) + 4 * g;
+#pragma unroll
+                        for (int t = 0; t < FT; ++t) o1[t][0] += *reinterpret_cast<const f4*>(rowp + 16 * t);
                     }
-                };
-                if (lds_bytes && m == m_first && rd == 0) codes((fx_lds_u8p)(bytes_s + (n < p.N ? sq : 0) * L));
-                else codes(row);
-                init_bias<FT, 1>(cb, o1, g);
+                    relu_tiles<FT, 1>(o1);
 #pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const float* rowp = w1p + (j * A + c[j]) * (16 * FT) + 4 * g;
-#pragma unroll
-                    for (int t = 0; t < FT; ++t) o1[t][0] += *reinterpret_cast<const f4*>(rowp + 16 * t);
+                    for (int t = 0; t < FT; ++t) X[(pos * FT + t) * 64 + lane] = o1[t][0];
                 }
-                relu_tiles<FT, 1>(o1);
-#pragma unroll
-                for (int t = 0; t < FT; ++t) X[(q * FT + t) * 64 + lane] = o1[t][0];
             }
             __syncthreads();
 
-            // ---- B: conv2 (same) at position q; tap j reads out1[q + j - PL2], padding taps contribute nothing
-            f4 o2[FT][1];
+            // ---- B: conv2 (same) at this wave's positions; tap j reads out1[pos + j - PL2], padding taps contribute nothing
             if (live) {
-                init_bias<FT, 1>(cb + 16 * FT, o2, g);
+                for (int pos = q; pos < L1; pos += 4) {
+                    asm volatile("" ::: "memory");
+                    f4 o2[FT][1];
+                    init_bias<FT, 1>(cb + 16 * FT, o2, g);
 #pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const int pp = q + j - PL2;
-                    if (pp >= 0 && pp < L1) {
-                        f4 in[FT][1];
+                    for (int j = 0; j < K; ++j) {
+                        const int pp = pos + j - PL2;
+                        if (pp >= 0 && pp < L1) {
+                            f4 in[FT][1];
 #pragma unroll
-                        for (int t = 0; t < FT; ++t) in[t][0] = X[(pp * FT + t) * 64 + lane];
-                        mma_layer<FT, FT, 1>(w_c2 + j * FT * FT * 64, in, o2, lane);
+                            for (int t = 0; t < FT; ++t) in[t][0] = X[(pp * FT + t) * 64 + lane];
+                            mma_layer<FT, FT, 1>(w_c2 + j * FT * FT * 64, in, o2, lane);
+                        }
                     }
-                }
-                relu_tiles<FT, 1>(o2);
+                    relu_tiles<FT, 1>(o2);
 #pragma unroll
-                for (int t = 0; t < FT; ++t) Y[(q * FT + t) * 64 + lane] = o2[t][0];
+                    for (int t = 0; t < FT; ++t) Y[(pos * FT + t) * 64 + lane] = o2[t][0];
+                }
             }
             __syncthreads();
 
-            // ---- C: conv3 (same, 3 taps) at position q from out2[q + j - PL3]; relu through the pooled max with 0
-            f4 o3[FT][1];
+            // ---- C: conv3 (same, 3 taps) at this wave's positions from out2[pos + j - PL3]; relu through the pooled max with 0
             if (live) {
-                init_bias<FT, 1>(cb + 32 * FT, o3, g);
+                for (int pos = q; pos < L1; pos += 4) {
+                    asm volatile("" ::: "memory");
+                    f4 o3[FT][1];
+                    init_bias<FT, 1>(cb + 32 * FT, o3, g);
 #pragma unroll
-                for (int j = 0; j < K3; ++j) {
-                    const int pp = q + j - PL3;
-                    if (pp >= 0 && pp < L1) {
-                        f4 in[FT][1];
+                    for (int j = 0; j < K3; ++j) {
+                        const int pp = pos + j - PL3;
+                        if (pp >= 0 && pp < L1) {
+                            f4 in[FT][1];
 #pragma unroll
-                        for (int t = 0; t < FT; ++t) in[t][0] = Y[(pp * FT + t) * 64 + lane];
-                        mma_layer<FT, FT, 1>(w_c3 + j * FT * FT * 64, in, o3, lane);
+                            for (int t = 0; t < FT; ++t) in[t][0] = Y[(pp * FT + t) * 64 + lane];
+                            mma_layer<FT, FT, 1>(w_c3 + j * FT * FT * 64, in, o3, lane);
+                        }
                     }
-                }
 #pragma unroll
-                for (int t = 0; t < FT; ++t) {
-                    o3[t][0] = pool_max4(splat4(0.f), o3[t][0]);
-                    X[(q * FT + t) * 64 + lane] = o3[t][0];
+                    for (int t = 0; t < FT; ++t) {
+                        o3[t][0] = pool_max4(splat4(0.f), o3[t][0]);
+                        X[(pos * FT + t) * 64 + lane] = o3[t][0];
+                    }
                 }
             }
             if (p.dma && rd == 0) fx_wait_vm(0);                     // this wave's share of the head's weights has landed
             __syncthreads();
 
-            // ---- D: GlobalMaxPooling1D over the four positions; dense 1 for this wave's output tiles {q, q + 4}
+            // ---- D: GlobalMaxPooling1D over all positions; dense 1 for this wave's output tiles {q, q + 4}
             if (live) {
                 f4 gmax[FT][1];
 #pragma unroll
                 for (int t = 0; t < FT; ++t) {
                     gmax[t][0] = splat4(0.f);
-#pragma unroll
                     for (int pp = 0; pp < L1; ++pp) gmax[t][0] = pool_max4(gmax[t][0], X[(pp * FT + t) * 64 + lane]);
                 }
 #pragma unroll
@@ -244,37 +257,50 @@ __global__ void __launch_bounds__(QWAVES * 64) k_score_cnn_quad(QuadArgs p) {
 
 }  // namespace
 
+namespace {
+
+template <int QUADS, int XT>
+int launch_quad(fx_engine* e, QuadArgs a, int64_t U, int max_rounds) {
+    int64_t blocks = e->grid_blocks > 0 ? e->grid_blocks : e->num_cus;
+    if (blocks > U) blocks = U;
+    if (e->cnn_quad < 2 && U > (int64_t)max_rounds * QUADS * blocks) return FX_EUNSUPPORTED;   // long launches: one wave per tile
+    const size_t lds = (size_t)a.total_floats * 4 + 256 + (size_t)QUADS * 2 * XT * 1024 + (size_t)QUADS * 256;
+    if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
+    auto kern = k_score_cnn_quad<7, QUADS, XT>;
+    static bool attr_set[64] = {};
+    if (!attr_set[e->device & 63]) {
+        FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[e->device & 63] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(QUADS * 256), lds, e->stream, a);
+    FX_HIP(e, hipGetLastError());
+    return FX_OK;
+}
+
+}  // namespace
+
 // FX_EUNSUPPORTED when the quad form does not apply (the caller carries on with the one-wave-per-tile kernels).
 int fx_launch_score_cnn_quad(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N,
                              float* d_out_NM, int Mtot, int m_off) {
     const FxShape& s = models[0]->shape;
     const FxPackLayout& lay = models[0]->layout;
-    if (!e->cnn_quad || s.A != 4 || s.K != 5 || s.L != 8 || lay.FT != 2 || lay.HT != 7 || lay.HTR != 7 || e->cnn_conv1_mfma ||
-        e->cnn_variant || M > FX_MAX_M)
+    const int L1 = s.L - s.K + 1;
+    if (!e->cnn_quad || s.A != 4 || s.K != 5 || L1 < 1 || L1 > 12 || lay.FT != 2 || lay.HT != 7 || lay.HTR != 7 ||
+        e->cnn_conv1_mfma || e->cnn_variant || M > FX_MAX_M)
         return FX_EUNSUPPORTED;
     const int64_t TG = (N + 15) / 16, U = (int64_t)M * TG;
-    int64_t blocks = e->grid_blocks > 0 ? e->grid_blocks : e->num_cus;
-    if (blocks > U) blocks = U;
-    if (e->cnn_quad < 2 && U > (int64_t)QUADS * blocks) return FX_EUNSUPPORTED;       // more than one round per workgroup: not worth it
-    const size_t lds = (size_t)lay.total_floats * 4 + 256 + (size_t)QUADS * 16384 + (size_t)QUADS * 16 * s.L;
-    if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
     QuadArgs a{};
     a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
     if (int rc = fx_trace_buffer(e, &a.trace)) return rc;
     for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
     a.N = N; a.TG = TG; a.M = M; a.m_off = m_off;
     a.out_sn = e->planar_stride ? 1 : Mtot; a.out_sm = e->planar_stride ? e->planar_stride : 1;
-    a.rlh = lay.RLH;
+    a.L = s.L; a.rlh = lay.RLH;
     a.dma = e->dma_fill && lay.off_d1 % 4 == 0 && lay.total_floats % 4 == 0;
     a.off_c2 = (int)lay.off_c2; a.off_c3 = (int)lay.off_c3; a.off_cb = (int)lay.off_cb; a.off_w1p = (int)lay.off_w1p;
     a.off_d1 = (int)lay.off_d1; a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
-    auto kern = k_score_cnn_quad<7>;
-    static bool attr_set[64] = {};
-    if (!attr_set[e->device & 63]) {
-        FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set[e->device & 63] = true;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(QWAVES * 64), lds, e->stream, a);
-    FX_HIP(e, hipGetLastError());
-    return FX_OK;
+    // up to 4 conv positions (seq_len <= 8): three quads per workgroup, one round; up to 12 (seq_len <= 16): one quad
+    // with 2 x 24 KiB of exchange buffers, up to two rounds (a round is ~9 us against ~30 us for a lone wave's tile)
+    if (L1 <= 4) return launch_quad<3, 8>(e, a, U, 1);
+    return launch_quad<1, 24>(e, a, U, 2);
 }

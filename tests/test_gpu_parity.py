@@ -1275,16 +1275,18 @@ def test_deepcopy_and_pickle_of_live_models(eng):
     assert np.array_equal(a, b) and list(nam.cache) == list(twin.cache)
 
 
-@pytest.mark.parametrize("n,M", [(1, 1), (16, 1), (17, 3), (100, 3), (1000, 1), (4000, 3), (10_000, 1), (12_289, 1), (2001, 8)])
-def test_cnn_quad_form_is_bit_identical_to_the_one_wave_kernel(eng, n, M):
-    """Small launches of the canonical TF-binding CNN (seq_len 8): a tile shared by four waves, activations exchanged
-    through LDS layer by layer (score_cnn_quad.hip).  Every output element sees the one-wave kernel's MFMA sequence, so
+@pytest.mark.parametrize("L,n,M", [(8, 1, 1), (8, 16, 1), (8, 17, 3), (8, 100, 3), (8, 1000, 1), (8, 4000, 3), (8, 10_000, 1), (8, 12_289, 1), (8, 2001, 8),
+                                    (14, 1, 1), (14, 20, 3), (14, 1000, 3), (14, 4100, 1), (14, 8200, 1), (16, 33, 2), (5, 50, 1), (6, 700, 3), (11, 257, 2),
+                                    (13, 2001, 8)])
+def test_cnn_quad_form_is_bit_identical_to_the_one_wave_kernel(eng, L, n, M):
+    """Small launches of the canonical 4-letter CNN at seq_len <= 16 (TF-binding 8, RNA 14): a tile shared by four waves,
+    each taking every fourth conv position, activations exchanged through LDS layer by layer (score_cnn_quad.hip).  Every output element sees the one-wave kernel's MFMA sequence, so
     the scores are the SAME BITS (a sequence must score alike in a call of 20 and in a batch of 1e5), at any size when
     forced, and a character outside the alphabet is reported from whichever wave reads it."""
-    pairs = [make_native(eng, "cnn", 8, 4, 100, 32, 5, seed=80 + m) for m in range(M)]
+    pairs = [make_native(eng, "cnn", L, 4, 100, 32, 5, seed=80 + m) for m in range(M)]
     nms = [p[0] for p in pairs]
     lut = _native.make_lut("TGCA")
-    b, seqs = rand_seqs(n, 8, "TGCA", seed=n)
+    b, seqs = rand_seqs(n, L, "TGCA", seed=n)
     outs = {}
     for mode in (0, 1, 2):
         eng.set_option("cnn_quad", mode)
@@ -1306,19 +1308,19 @@ def test_cnn_quad_form_is_bit_identical_to_the_one_wave_kernel(eng, n, M):
         eng.set_option("dma_fill", 1)
         eng.set_option("cnn_quad", 1)
     import torch
-    dev = torch.zeros(n * 8 + 8, dtype=torch.uint8, device="cuda")
+    dev = torch.zeros(n * L + 8, dtype=torch.uint8, device="cuda")
     for shift in (1, 4):
-        dev[shift:shift + n * 8] = torch.from_numpy(b.reshape(-1)).cuda()
+        dev[shift:shift + n * L] = torch.from_numpy(b.reshape(-1)).cuda()
         stride = (n + 3) // 4 * 4
         planes = torch.full((M, stride), float("nan"), device="cuda")
         torch.cuda.synchronize()
-        eng.score_planes_dev(nms, dev.data_ptr() + shift, n, 8, lut, planes.data_ptr(), stride)
+        eng.score_planes_dev(nms, dev.data_ptr() + shift, n, L, lut, planes.data_ptr(), stride)
         eng.sync()
         assert np.array_equal(planes[:, :n].cpu().numpy().T, outs[0]), shift
-    assert_scores(outs[2][:, M - 1], ref_np.keras_fitness(seqs, "TGCA", "cnn", pairs[M - 1][1], exact=True), f"quad n={n} M={M}")
+    assert_scores(outs[2][:, M - 1], ref_np.keras_fitness(seqs, "TGCA", "cnn", pairs[M - 1][1], exact=True), f"quad L={L} n={n} M={M}")
     eng.set_option("cnn_quad", 2)
     try:
-        for col in (0, 3, 7):
+        for col in (0, L // 2, L - 1):
             bb = b.copy()
             bb[n - 1, col] = ord("U")
             with pytest.raises(ValueError):
@@ -1327,7 +1329,7 @@ def test_cnn_quad_form_is_bit_identical_to_the_one_wave_kernel(eng, n, M):
         eng.set_option("cnn_quad", 1)
     # hidden sizes whose last tile holds 1 .. 16 units (k-step tail), through the Python API
     for H in (97, 100, 104, 112):
-        model = bm.CNN(8, 32, H, "TGCA", seed=H)
+        model = bm.CNN(L, 32, H, "TGCA", seed=H)
         got = model.get_fitness(seqs[:50])
         eng.set_option("cnn_quad", 0)
         try:
