@@ -34,6 +34,25 @@ int fx_scratch(fx_engine* e, int slot, size_t bytes, void** out) {
     return FX_OK;
 }
 
+int fx_zero_pool(fx_engine* e, size_t bytes, void** out) {
+    if (bytes > e->zero_pool_bytes) {
+        if (e->d_zero_pool) {
+            FX_HIP(e, hipStreamSynchronize(e->stream));
+            FX_HIP(e, hipFree(e->d_zero_pool));
+            e->d_zero_pool = nullptr; e->zero_pool_bytes = 0;
+        }
+        const size_t cap = std::max<size_t>(bytes + bytes / 4, 1 << 16);
+        if (hipMalloc(&e->d_zero_pool, cap) != hipSuccess) {
+            (void)hipGetLastError();
+            return fx_fail(e, FX_ENOMEM, "hipMalloc of the zero pool failed");
+        }
+        e->zero_pool_bytes = cap;
+        FX_HIP(e, hipMemsetAsync(e->d_zero_pool, 0, cap, e->stream));
+    }
+    *out = e->d_zero_pool;
+    return FX_OK;
+}
+
 int fx_pinned(fx_engine* e, int slot, size_t bytes, void** out) {
     if (bytes > e->pinned_bytes[slot]) {
         if (e->h_pinned[slot]) {
@@ -159,6 +178,7 @@ int fx_engine_destroy(fx_engine* e) {
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     for (auto& p : e->d_scratch) if (p) (void)hipFree(p);
+    if (e->d_zero_pool) (void)hipFree(e->d_zero_pool);
     for (auto& p : e->h_pinned) if (p) (void)hipHostFree(p);
     if (e->h_err) (void)hipHostFree(e->h_err);
     if (e->d_lut) (void)hipFree(e->d_lut);
@@ -198,6 +218,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "stage_fill")) return &e->stage_fill;
     if (!std::strcmp(key, "dma_fill")) return &e->dma_fill;
     if (!std::strcmp(key, "cnn_pair_seg4")) return &e->cnn_pair_seg4;
+    if (!std::strcmp(key, "cnn_seg_multi")) return &e->cnn_seg_multi;
     if (!std::strcmp(key, "cnn_quad")) return &e->cnn_quad;
     if (!std::strcmp(key, "cnn_pair")) return &e->cnn_pair;
     if (!std::strcmp(key, "cnn_pair_seg")) return &e->cnn_pair_seg;

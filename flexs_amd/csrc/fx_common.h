@@ -77,6 +77,8 @@ struct fx_engine {
     // growable scratch
     void* d_scratch[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[4] = {0, 0, 0, 0};
+    void* d_zero_pool = nullptr;  // fx_zero_pool: all-zero between launches (the kernels that use it clean up after themselves)
+    size_t zero_pool_bytes = 0;
     void* h_pinned[2] = {nullptr, nullptr};
     size_t pinned_bytes[2] = {0, 0};
     // options
@@ -88,6 +90,7 @@ struct fx_engine {
     int64_t cnn_pair = 1;       // 1 = wide alphabets (A = 20) use the two-waves-per-tile kernel (score_cnn_pair.hip)
     int64_t cnn_big_units = 12; // work units per CU from which the A = 4 CNN path switches to 16-wave (unrolled) workgroups
     int64_t cnn_seg = -1;       // A = 4 CNN kernel, small batches: -1 = waves of a workgroup split one tile's positions when L1 >= 24, 0 = never, 1 = whenever the batch is small
+    int64_t cnn_seg_multi = 1;  // 1 = the position-segmented 4-letter form may spread a tile over several (4- or 8-wave) workgroups
     int64_t cnn_pair_seg4 = 1;  // 1 = the segmented protein form may use 4-wave workgroups (one wave per SIMD) when twice as many still fit in one wave of the grid
     int64_t cnn_pair_seg = -1;  // pair kernel, small batches: -1 = segment a tile's positions automatically, 0 = never, n > 0 = force SB = n workgroups per tile
     int64_t dense_slab = 1;     // MLP / GE with H > 128: HxH blocks staged through LDS slabs by the workgroup (0 = every wave streams them from L2)
@@ -162,6 +165,9 @@ int fx_fail(fx_engine* e, int status, const std::string& msg);
 
 int fx_scratch(fx_engine* e, int slot, size_t bytes, void** out);
 int fx_pinned(fx_engine* e, int slot, size_t bytes, void** out);
+// Device memory that is all zeros whenever no kernel is running: meeting points of the multi-workgroup small-batch forms
+// (maxima through atomicMax, arrival tickets).  Zeroed when (re)allocated; the last workgroup to use an entry resets it.
+int fx_zero_pool(fx_engine* e, size_t bytes, void** out);
 int fx_upload_lut(fx_engine* e, const uint8_t lut[256]);
 // device timeline buffer for the launch about to be enqueued (zeroed), or nullptr when the "trace" option is off
 #define FX_TRACE_BYTES ((size_t)1024 * 16 * 16 * 8)

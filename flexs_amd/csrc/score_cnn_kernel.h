@@ -37,6 +37,12 @@ struct CnnArgs {
     f4* pool_out;               // HEAD = false: pooled conv features, [(member * TG + tile) * FT + t][64 lanes]
     int L;
     int rlh;                    // hidden tail: real k-steps of the last real hidden tile
+    // SEG with seg_sb > 1: a tile's positions are cut over seg_sb workgroups (grid = units x seg_sb); their maxima meet in
+    // seg_pool ([unit][FT][64 lanes][4], float bits; fx_zero_pool: all zeros between launches, the last workgroup to arrive
+    // (seg_cnt ticket) reads the maxima, resets the entries and runs the head
+    int seg_sb;
+    unsigned* seg_pool;
+    unsigned* seg_cnt;
     // packed-layout offsets (floats)
     int off_first, off_c2, off_c3, off_cb, off_w1p, conv_floats, off_d1, off_d2, off_db, total_floats;
 };
@@ -80,7 +86,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
     if (tid < 4) simd_waves[tid] = 0;
 
     int64_t u_lo, u_hi;
-    fx_unit_range(p.TG, p.M, u_lo, u_hi);
+    const int seg_sb = (SEG && HEAD && p.seg_sb > 1) ? p.seg_sb : 1;   // workgroups per tile (multi-workgroup segment form)
+    const int seg_w = SEG ? (int)(blockIdx.x % (unsigned)seg_sb) : 0;
+    if (SEG && seg_sb > 1) { u_lo = blockIdx.x / (unsigned)seg_sb; u_hi = u_lo + 1; }
+    else fx_unit_range(p.TG, p.M, u_lo, u_hi);
     if (u_lo >= u_hi) return;
     const int m_first = (int)(u_lo / p.TG), m_last = (int)((u_hi - 1) / p.TG);
     bool bad = false;
@@ -191,9 +200,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
             // SEG: positions this wave pools, and the steps it has to run for them
             int seg_lo = 0, seg_hi = L1, s_begin = 0, s_stop = steps;
             if (SEG) {
-                const int q = tid >> 6;
-                seg_lo = (int)((int64_t)L1 * q / WAVES);
-                seg_hi = (int)((int64_t)L1 * (q + 1) / WAVES);
+                const int q = seg_w * WAVES + (tid >> 6), S = seg_sb * WAVES;
+                seg_lo = (int)((int64_t)L1 * q / S);
+                seg_hi = (int)((int64_t)L1 * (q + 1) / S);
                 s_begin = seg_lo - PL3 - PL2 > 0 ? seg_lo - PL3 - PL2 : 0;
                 s_stop = seg_hi + PR2 + PR3 < steps ? seg_hi + PR2 + PR3 : steps;
                 if (seg_lo >= seg_hi) s_stop = 0;                 // more waves than positions: nothing to do
@@ -381,6 +390,32 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                 for (int w = 1; w < WAVES; ++w)
 #pragma unroll
                     for (int t = 0; t < FT; ++t) gmax[t][0] = pool_max4(gmax[t][0], seg_slot[(w * FT + t) * 64 + lane]);
+                if constexpr (HEAD) {
+                    if (seg_sb > 1) {
+                        // ---- the workgroups of this tile meet in a zeroed global pool: atomicMax on the float bits (relu
+                        //      outputs are >= +0, where float order == unsigned order); the last to arrive runs the head
+                        const int64_t unit = (int64_t)m * p.TG + tg;
+                        unsigned* pl = p.seg_pool + (unit * FT * 64 + lane) * 4;
+#pragma unroll
+                        for (int t = 0; t < FT; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) atomicMax(&pl[t * 256 + r], __float_as_uint(gmax[t][0][r]));
+                        __threadfence();
+                        unsigned ticket = 0;
+                        if (lane == 0) ticket = atomicAdd(&p.seg_cnt[unit], 1u);
+                        ticket = __builtin_amdgcn_readfirstlane(ticket);
+                        if (ticket != (unsigned)seg_sb - 1u) continue;
+                        __threadfence();
+#pragma unroll
+                        for (int t = 0; t < FT; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {            // device-coherent reads; the entry goes back to zero
+                                gmax[t][0][r] = __uint_as_float(__hip_atomic_load(&pl[t * 256 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                                __hip_atomic_store(&pl[t * 256 + r], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        if (lane == 0) __hip_atomic_store(&p.seg_cnt[unit], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
             }
             if constexpr (!HEAD) {
                 f4* dst = p.pool_out + (((int64_t)m * p.TG + tg) * FT) * 64 + lane;
@@ -469,6 +504,7 @@ int launch_g(fx_engine* e, const CnnArgs& a, size_t lds_bytes) {
     int64_t need = U;                                // small batches: one unit per workgroup (lowest latency)
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
+    if (SEG && HEAD && a.seg_sb > 1) blocks = U * a.seg_sb;       // multi-workgroup segment form: exactly units x seg_sb
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(waves * 64), lds_bytes, e->stream, a);
     FX_HIP(e, hipGetLastError());
     return FX_OK;

@@ -56,8 +56,36 @@ int dispatch_a4(fx_engine* e, const CnnArgs& a0, int variant, bool big, size_t f
         const int L1 = a.L - 5 + 1;
         const bool seg = e->cnn_seg != 0 && variant == 0 && !e->cnn_conv1_mfma && U <= e->num_cus &&
                          (e->cnn_seg > 0 || L1 >= 24) && lds + 8 * 2 * 64 * 16 <= (size_t)e->max_lds;
-        if (seg) return dl ? launch_g<4, 5, 2, HT_, 1, true, 8, true, 0, false, true>(e, a, lds)
-                           : launch_g<4, 5, 2, HT_, 1, false, 8, true, 0, false, true>(e, a, lds);
+        if (seg) {
+            // Long sequences: cut the positions over several workgroups as well (halo: 3 positions per side).  As many
+            // segments (>= 2 positions) as one wave of the grid holds, from 4-wave workgroups -- one wave per SIMD -- when
+            // that gives as many as 8-wave ones would (score_cnn_pair.hip has the measurements behind both rules).
+            a.seg_sb = 1;
+            int waves = 8;
+            if constexpr (HT_ == 7) {
+                if (dl && e->cnn_seg < 0 && e->cnn_seg_multi) {
+                    auto count = [&](int w) {
+                        int64_t sb = L1 / (w * 2);
+                        if (sb > 64 / w) sb = 64 / w;
+                        if (sb > e->num_cus / U) sb = e->num_cus / U;
+                        return sb < 1 ? (int64_t)1 : sb;
+                    };
+                    const int64_t sb8 = count(8), sb4 = count(4);
+                    if (sb4 * 4 >= sb8 * 8) { waves = 4; a.seg_sb = (int)sb4; }
+                    else a.seg_sb = (int)sb8;
+                    if (a.seg_sb > 1) {
+                        void* ws = nullptr;
+                        const size_t pool_bytes = (size_t)U * 2 * 64 * 4 * sizeof(unsigned), cnt_bytes = (size_t)U * sizeof(unsigned);
+                        if (int rc = fx_zero_pool(e, pool_bytes + cnt_bytes, &ws)) return rc;
+                        a.seg_pool = (unsigned*)ws;
+                        a.seg_cnt = (unsigned*)((char*)ws + pool_bytes);
+                    }
+                    if (waves == 4) return launch_g<4, 5, 2, 7, 1, true, 4, true, 0, false, true>(e, a, lds);
+                }
+            }
+            return dl ? launch_g<4, 5, 2, HT_, 1, true, 8, true, 0, false, true>(e, a, lds)
+                      : launch_g<4, 5, 2, HT_, 1, false, 8, true, 0, false, true>(e, a, lds);
+        }
     }
     if constexpr (HT_ <= 7) {
         if (big) return dl ? launch_inst<4, 5, 2, HT_, 1, true, 16>(e, a, lds) : launch_inst<4, 5, 2, HT_, 1, false, 16>(e, a, lds);

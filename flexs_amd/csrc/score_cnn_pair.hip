@@ -40,8 +40,8 @@ struct PairArgs {
     int off_c2, off_c3, off_cb, off_w1p, conv_floats, off_d1, off_d2, off_db;
     int lds_from, lds_floats;   // LDS image = packed[lds_from .. lds_from + lds_floats): conv2, conv3, biases, conv1 rows
     int SB;                     // SEG form: workgroups per (member, tile) unit
-    unsigned* pool;             // SEG form: [units][2 tiles][64 lanes][4] pooled maxima (float bits), zeroed per launch
-    unsigned* cnt;              // SEG form: [units] arrival counters, zeroed per launch
+    unsigned* pool;             // SEG form: [units][2 tiles][64 lanes][4] pooled maxima (float bits); zero between launches (fx_zero_pool with the head, memset without)
+    unsigned* cnt;              // SEG form: [units] arrival counters, likewise
 };
 
 // workgroups per (member, tile) unit of the position-segmented small-batch form (see launch_pair)
@@ -304,10 +304,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
                     const unsigned* p0 = p.pool + ((unit * 2 + 0) * 64 + lane) * 4;
                     f4 pool0, pool1;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {                         // device-coherent reads
+                    for (int r = 0; r < 4; ++r) {                         // device-coherent reads; the entries go back to zero
                         pool0[r] = __uint_as_float(__hip_atomic_load(&p0[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                         pool1[r] = __uint_as_float(__hip_atomic_load(&p0[256 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        __hip_atomic_store(const_cast<unsigned*>(&p0[r]), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(const_cast<unsigned*>(&p0[256 + r]), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
+                    if (lane == 0) __hip_atomic_store(&p.cnt[unit], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const float y = pair_dense_head<HT>(w_d1, w_d2, db, pool0, pool1, lane, g, p.rlh);
                     if (g == 0 && n < p.N) p.out[n * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y);
                 }
@@ -340,9 +343,8 @@ int launch_pair(fx_engine* e, PairArgs a, size_t lds_bytes) {
     if (sb >= 1) {
         void* ws = nullptr;
         const size_t pool_bytes = (size_t)U * 2 * 64 * 4 * sizeof(unsigned), cnt_bytes = (size_t)U * sizeof(unsigned);
-        int rc = fx_scratch(e, 2, pool_bytes + cnt_bytes, &ws);
+        int rc = fx_zero_pool(e, pool_bytes + cnt_bytes, &ws);   // all zeros between launches: the head workgroup resets what it read
         if (rc) return rc;
-        FX_HIP(e, hipMemsetAsync(ws, 0, pool_bytes + cnt_bytes, e->stream));
         a.pool = (unsigned*)ws;
         a.cnt = (unsigned*)((char*)ws + pool_bytes);
         if constexpr (A == 20 && K == 5 && HT == 7 && WAVES == 8) {
