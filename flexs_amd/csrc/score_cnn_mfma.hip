@@ -54,8 +54,11 @@ int dispatch_a4(fx_engine* e, const CnnArgs& a0, int variant, bool big, size_t f
         // workgroup split one tile's positions instead of 7 of them idling
         const int64_t U = (int64_t)a.M * a.TG;
         const int L1 = a.L - 5 + 1;
+        // (one 8-wave workgroup per tile pays from 24 positions; spread over several 4-wave workgroups, from 13 -- shorter
+        //  sequences take the quad form)
+        const bool multi = HT_ == 7 && dl && e->cnn_seg < 0 && e->cnn_seg_multi && 2 * U <= e->num_cus;
         const bool seg = e->cnn_seg != 0 && variant == 0 && !e->cnn_conv1_mfma && U <= e->num_cus &&
-                         (e->cnn_seg > 0 || L1 >= 24) && lds + 8 * 2 * 64 * 16 <= (size_t)e->max_lds;
+                         (e->cnn_seg > 0 || L1 >= (multi ? 13 : 24)) && lds + 8 * 2 * 64 * 16 <= (size_t)e->max_lds;
         if (seg) {
             // Long sequences: cut the positions over several workgroups as well (halo: 3 positions per side).  As many
             // segments (>= 2 positions) as one wave of the grid holds, from 4-wave workgroups -- one wave per SIMD -- when
