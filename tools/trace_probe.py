@@ -84,7 +84,9 @@ def trace_case(label, kind, L, alpha, M, N, H=100, F=0, K=0, opts=None):
         ph = [((t[:, :, k] - t[:, :, 2])[worked & (t[:, :, k] > 0)] * TICK_US) for k in (8, 9, 10)]
         simd_counts = [int(((t[:, :, 7] == v + 1) & entered).sum()) for v in range(4)]
         res.append({
-            "span_us": float(end_all.max()), "blocks": int(entered.any(axis=1).sum()), "waves_entered": int(entered.sum()),
+            "span_us": float(end_all.max()), "exit_us_p10_p50_p90_max": [pct(end_all, 10), pct(end_all, 50), pct(end_all, 90), float(end_all.max())],
+            "tile_start_all_us_p50_max": [pct((t[:, :, 2][t[:, :, 2] > 0] - t0) * TICK_US, 50), float(((t[:, :, 2][t[:, :, 2] > 0] - t0) * TICK_US).max())],
+            "blocks": int(entered.any(axis=1).sum()), "waves_entered": int(entered.sum()),
             "waves_with_tiles": int(worked.sum()), "tiles_per_working_wave": [int(tiles.min()), float(tiles.mean()), int(tiles.max())],
             "entry_us_p50_max": [pct(entry, 50), float(entry.max())],
             "fill_us_p50_max": [pct(fill, 50), float(fill.max())],
@@ -103,7 +105,7 @@ def trace_case(label, kind, L, alpha, M, N, H=100, F=0, K=0, opts=None):
     for k_ in (opts or {}):
         eng.set_option(k_, {"cnn_big_units": 12, "cnn_seg": -1, "ge_bytetab": 1, "mlp_pair": 1, "wave_prio": 1, "stage_bytes": 1}.get(k_, 0))
     for k_ in (opts or {}):
-        eng.set_option(k_, {"cnn_big_units": 12, "cnn_seg": -1, "ge_bytetab": 1, "mlp_pair": 1, "wave_prio": 1, "stage_bytes": 1, "dense_waves": 0, "stage_fill": 1, "cnn_quad": 1, "dma_fill": 1}.get(k_, 0))
+        eng.set_option(k_, {"cnn_big_units": 12, "cnn_seg": -1, "ge_bytetab": 1, "mlp_pair": 1, "wave_prio": 1, "stage_bytes": 1, "dense_waves": 0, "stage_fill": 1, "cnn_quad": 1, "dma_fill": 1, "cnn_seg_multi": 1, "cnn_pair_seg4": 1}.get(k_, 0))
     out = {"what": label, "event_us_per_launch": ev_us, "trace": res[-1], "span_us_3runs": [r["span_us"] for r in res]}
     print(json.dumps(out), flush=True)
     return out
@@ -122,6 +124,14 @@ if __name__ == "__main__":
         rows.append(trace_case("[phases] ge L=90 M=1 N=4000", "ge", 90, AAS, 1, 4_000))
         rows.append(trace_case("[phases] cnn L=8 M=1 N=10000", "cnn", 8, "TGCA", 1, 10_000, F=32, K=5))
         json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "trace_probe_phases.json"), "w"), indent=1)
+        sys.exit(0)
+    if os.environ.get("FX_SET") == "seg":
+        # small launches of long sequences: position-segmented forms
+        for kind, L, alpha, M, N, kw in (("cnn", 100, "UGCA", 3, 20, dict(F=32, K=5)), ("cnn", 50, "UGCA", 3, 20, dict(F=32, K=5)),
+                                         ("cnn", 14, "UGCA", 3, 20, dict(F=32, K=5)), ("cnn", 237, AAS, 3, 16, dict(F=32, K=5))):
+            for multi in (1, 0):
+                rows.append(trace_case(f"{kind} L={L} M={M} N={N} cnn_seg_multi={multi}", kind, L, alpha, M, N, opts={"cnn_seg_multi": multi}, **kw))
+        json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "trace_probe_seg.json"), "w"), indent=1)
         sys.exit(0)
     if os.environ.get("FX_SET") == "dma":
         # direct global -> LDS weight copies (engine option dma_fill) against the copies through registers
