@@ -141,6 +141,7 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
                 }
             }
             __syncthreads();
+            if (live) FX_PHASE_STAMP(8);
 
             // ---- B: conv2 (same) at this wave's positions; tap j reads out1[pos + j - PL2], padding taps contribute nothing
             if (live) {
@@ -190,6 +191,7 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
             }
             if (p.dma && rd == 0) fx_wait_vm(0);                     // this wave's share of the head's weights has landed
             __syncthreads();
+            if (live) FX_PHASE_STAMP(9);
 
             // ---- D: GlobalMaxPooling1D over all positions; dense 1 for this wave's output tiles {q, q + 4}
             if (live) {
@@ -240,6 +242,7 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
                 }
             }
             __syncthreads();
+            if (live) FX_PHASE_STAMP(10);
 
             // ---- F: Dense(1) on wave 0 of the quad
             if (live && q == 0) {

@@ -123,6 +123,9 @@ if __name__ == "__main__":
         rows.append(trace_case("[phases] ge L=90 M=8 N=100000", "ge", 90, AAS, 8, 100_000))
         rows.append(trace_case("[phases] ge L=90 M=1 N=4000", "ge", 90, AAS, 1, 4_000))
         rows.append(trace_case("[phases] cnn L=8 M=1 N=10000", "cnn", 8, "TGCA", 1, 10_000, F=32, K=5))
+        rows.append(trace_case("[phases] cnn L=8 M=1 N=4000", "cnn", 8, "TGCA", 1, 4_000, F=32, K=5))
+        rows.append(trace_case("[phases] cnn L=8 M=3 N=20", "cnn", 8, "TGCA", 3, 20, F=32, K=5))
+        rows.append(trace_case("[phases] cnn L=14 M=3 N=20", "cnn", 14, "UGCA", 3, 20, F=32, K=5))
         json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "trace_probe_phases.json"), "w"), indent=1)
         sys.exit(0)
     if os.environ.get("FX_SET") == "seg":
