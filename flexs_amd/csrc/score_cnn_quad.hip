@@ -44,9 +44,10 @@ struct QuadArgs {
 
 // QUADS quads per workgroup; XT = 16-channel tiles per exchange buffer (>= FT x positions and >= HT); L1C > 0: the number
 // of conv positions is a compile-time constant (seq_len 8: one position per wave, the position loops fold away)
-template <int HT, int QUADS, int XT, int L1C>
+template <int HT, int QUADS, int XT, int L1C, int K = 5>
 __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
-    constexpr int A = 4, K = 5, K3 = 3, FT = 2, PL2 = 2, PL3 = 1, QWAVES = 4 * QUADS;
+    constexpr int A = 4, K3 = 3, FT = 2, PL2 = (K - 1) / 2, PL3 = 1, QWAVES = 4 * QUADS;
+    static_assert(K % 2 == 1, "'same' padding of conv2: (K - 1) / 2 on either side");
     static_assert(XT >= HT + 1, "the dense layers exchange HT tiles through the same buffers");
     const int L1 = L1C > 0 ? L1C : p.L - K + 1;           // (L1 * FT <= XT: checked by the launcher)
     const int L = L1 + K - 1;
@@ -264,14 +265,14 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
 
 namespace {
 
-template <int QUADS, int XT, int L1C>
+template <int QUADS, int XT, int L1C, int K = 5>
 int launch_quad(fx_engine* e, QuadArgs a, int64_t U, int max_rounds) {
     int64_t blocks = e->grid_blocks > 0 ? e->grid_blocks : e->num_cus;
     if (blocks > U) blocks = U;
     if (e->cnn_quad < 2 && U > (int64_t)max_rounds * QUADS * blocks) return FX_EUNSUPPORTED;   // long launches: one wave per tile
     const size_t lds = (size_t)a.total_floats * 4 + 256 + (size_t)QUADS * 2 * XT * 1024 + (size_t)QUADS * 256;
     if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
-    auto kern = k_score_cnn_quad<7, QUADS, XT, L1C>;
+    auto kern = k_score_cnn_quad<7, QUADS, XT, L1C, K>;
     static bool attr_set[64] = {};
     if (!attr_set[e->device & 63]) {
         FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -290,7 +291,7 @@ int fx_launch_score_cnn_quad(fx_engine* e, fx_model* const* models, int M, const
     const FxShape& s = models[0]->shape;
     const FxPackLayout& lay = models[0]->layout;
     const int L1 = s.L - s.K + 1;
-    if (!e->cnn_quad || s.A != 4 || s.K != 5 || L1 < 1 || L1 > 12 || lay.FT != 2 || lay.HT != 7 || lay.HTR != 7 ||
+    if (!e->cnn_quad || s.A != 4 || (s.K != 5 && s.K != 3 && s.K != 7) || L1 < 1 || L1 > 12 || lay.FT != 2 || lay.HT != 7 || lay.HTR != 7 ||
         e->cnn_conv1_mfma || e->cnn_variant || M > FX_MAX_M)
         return FX_EUNSUPPORTED;
     const int64_t TG = (N + 15) / 16, U = (int64_t)M * TG;
@@ -306,6 +307,9 @@ int fx_launch_score_cnn_quad(fx_engine* e, fx_model* const* models, int M, const
     a.off_d1 = (int)lay.off_d1; a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
     // up to 4 conv positions (seq_len <= 8): three quads per workgroup, one round; up to 12 (seq_len <= 16): one quad
     // with 2 x 24 KiB of exchange buffers, up to two rounds (a round is ~9 us against ~30 us for a lone wave's tile)
+    // (kernel sizes 3 and 7, the other two fused instantiations of the one-wave kernel: one quad, any position count)
+    if (s.K == 3) return launch_quad<1, 24, 0, 3>(e, a, U, 2);
+    if (s.K == 7) return launch_quad<1, 20, 0, 7>(e, a, U, 2);     // (seq_len <= 16: at most 10 positions; its image is 8 KiB larger)
     if (L1 == 4) return launch_quad<3, 8, 4>(e, a, U, 1);
     if (L1 < 4) return launch_quad<3, 8, 0>(e, a, U, 1);
     return launch_quad<1, 24, 0>(e, a, U, 2);

@@ -1278,12 +1278,13 @@ def test_deepcopy_and_pickle_of_live_models(eng):
 @pytest.mark.parametrize("L,n,M", [(8, 1, 1), (8, 16, 1), (8, 17, 3), (8, 100, 3), (8, 1000, 1), (8, 4000, 3), (8, 10_000, 1), (8, 12_289, 1), (8, 2001, 8),
                                     (14, 1, 1), (14, 20, 3), (14, 1000, 3), (14, 4100, 1), (14, 8200, 1), (16, 33, 2), (5, 50, 1), (6, 700, 3), (11, 257, 2),
                                     (13, 2001, 8)])
-def test_cnn_quad_form_is_bit_identical_to_the_one_wave_kernel(eng, L, n, M):
+@pytest.mark.parametrize("K", [5])
+def test_cnn_quad_form_is_bit_identical_to_the_one_wave_kernel(eng, L, n, M, K):
     """Small launches of the canonical 4-letter CNN at seq_len <= 16 (TF-binding 8, RNA 14): a tile shared by four waves,
     each taking every fourth conv position, activations exchanged through LDS layer by layer (score_cnn_quad.hip).  Every output element sees the one-wave kernel's MFMA sequence, so
     the scores are the SAME BITS (a sequence must score alike in a call of 20 and in a batch of 1e5), at any size when
     forced, and a character outside the alphabet is reported from whichever wave reads it."""
-    pairs = [make_native(eng, "cnn", L, 4, 100, 32, 5, seed=80 + m) for m in range(M)]
+    pairs = [make_native(eng, "cnn", L, 4, 100, 32, K, seed=80 + m) for m in range(M)]
     nms = [p[0] for p in pairs]
     lut = _native.make_lut("TGCA")
     b, seqs = rand_seqs(n, L, "TGCA", seed=n)
@@ -1329,13 +1330,36 @@ def test_cnn_quad_form_is_bit_identical_to_the_one_wave_kernel(eng, L, n, M):
         eng.set_option("cnn_quad", 1)
     # hidden sizes whose last tile holds 1 .. 16 units (k-step tail), through the Python API
     for H in (97, 100, 104, 112):
-        model = bm.CNN(L, 32, H, "TGCA", seed=H)
+        model = bm.CNN(L, 32, H, "TGCA", kernel_size=K, seed=H)
         got = model.get_fitness(seqs[:50])
         eng.set_option("cnn_quad", 0)
         try:
             assert np.array_equal(model.get_fitness(seqs[:50]), got)
         finally:
             eng.set_option("cnn_quad", 1)
+
+
+@pytest.mark.parametrize("L,n,M,K", [(8, 20, 3, 3), (14, 100, 3, 3), (14, 20, 1, 7), (16, 1000, 2, 7), (7, 17, 1, 7), (9, 4000, 1, 3), (14, 8000, 1, 3)])
+def test_cnn_quad_form_other_kernel_sizes(eng, L, n, M, K):
+    """The quad form for kernel sizes 3 and 7 (the other fused instantiations of the one-wave kernel): same bits, oracle."""
+    pairs = [make_native(eng, "cnn", L, 4, 100, 32, K, seed=90 + m) for m in range(M)]
+    nms = [p[0] for p in pairs]
+    lut = _native.make_lut("UGCA")
+    b, seqs = rand_seqs(n, L, "UGCA", seed=n + K)
+    outs = {}
+    for mode in (0, 1, 2):
+        eng.set_option("cnn_quad", mode)
+        try:
+            outs[mode], _ = eng.score(nms, b, lut, want_matrix=True)
+        finally:
+            eng.set_option("cnn_quad", 1)
+    assert np.array_equal(outs[1], outs[0]) and np.array_equal(outs[2], outs[0])
+    for m in range(M):
+        assert_scores(outs[2][:, m], ref_np.keras_fitness(seqs, "UGCA", "cnn", pairs[m][1], exact=True), f"quad K={K} L={L} n={n}")
+    bb = b.copy()
+    bb[n // 2, L - 1] = ord("T")
+    with pytest.raises(ValueError):
+        eng.score(nms, bb, lut)
 
 
 @pytest.mark.parametrize("L,n,M", [(10, 3000, 2), (5, 100, 1), (64, 20, 3), (30, 70000, 1)])
