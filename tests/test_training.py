@@ -244,3 +244,38 @@ def test_ensemble_members_train_side_by_side():
     w0, w1 = ens.models[0].model.get_weights(), ens.models[1].model.get_weights()
     assert not np.array_equal(w0[0], w1[0])
     assert np.array_equal(ens.get_fitness(seqs8[:50]), np.mean(np.stack([m.get_fitness(seqs8[:50]) for m in ens.models], axis=1), axis=1))
+
+
+def test_ensemble_train_reaches_every_member_on_any_backend():
+    """`Ensemble.train` / `AdaptiveEnsemble.train` go through ensemble.train_members: stock device surrogates are handed to
+    training.fit_many (on a machine without a GPU that is the one-by-one loop), any other member list -- a member with
+    its own `train`, a foreign model -- keeps the reference's loop (ensemble.py:42-52)."""
+    import flexs_amd
+    from flexs_amd.baselines.models.adaptive_ensemble import AdaptiveEnsemble
+
+    seqs, _, y = _batch("mlp", 8, "TGCA", 40, 3)
+    ens = flexs_amd.Ensemble([bm.MLP(8, 16, "TGCA", seed=i, epochs=2, batch_size=16) for i in range(3)])
+    ens.train(seqs, y)
+    assert [m.model._opt_state["t"] for m in ens.models] == [2 * 3] * 3
+
+    class Recorder(flexs_amd.Model):
+        def __init__(self):
+            super().__init__("rec")
+            self.calls = []
+
+        def train(self, sequences, labels):
+            self.calls.append(len(sequences))
+
+        def _fitness_function(self, sequences):
+            return np.zeros(len(sequences))
+
+    class OwnTrain(bm.MLP):
+        def train(self, sequences, labels, verbose=False):
+            self.seen = len(sequences)
+
+    rec, own, stock = Recorder(), OwnTrain(8, 16, "TGCA", seed=5), bm.MLP(8, 16, "TGCA", seed=6, epochs=1)
+    flexs_amd.Ensemble([rec, own, stock]).train(seqs, y)
+    assert rec.calls == [40] and own.seen == 40 and stock.model._opt_state["t"] == 1
+    ada = AdaptiveEnsemble([bm.MLP(8, 16, "TGCA", seed=7, epochs=1), bm.MLP(8, 16, "TGCA", seed=8, epochs=1)])
+    ada.train(seqs[:8], y[:8])                               # < 10 samples: no hold-out scoring (adaptive_ensemble.py:84-88)
+    assert all(m.model._opt_state["t"] == 1 for m in ada.models)
