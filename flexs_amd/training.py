@@ -226,6 +226,21 @@ class _GraphTrainer:
                 "v": [a.detach().cpu().numpy() for a in self.v]}
 
 
+class _CaptureFailed(RuntimeError):
+    pass
+
+
+_warned = set()
+
+
+def _warn_once(msg):
+    if msg not in _warned:
+        _warned.add(msg)
+        import warnings
+
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
 _TRAINERS = weakref.WeakKeyDictionary()          # Architecture -> _GraphTrainer (device state stays out of pickles / copies)
 
 
@@ -246,7 +261,10 @@ def fit(arch, sequences, labels, alphabet, batch_size=256, epochs=20, verbose=Fa
     if seed is not None:
         gen.manual_seed(seed)
     if _use_graph(device):
-        return _fit_graphed(arch, x, y, n, int(batch_size), epochs, verbose, gen, device)
+        try:
+            return _fit_graphed(arch, x, y, n, int(batch_size), epochs, verbose, gen, device)
+        except _CaptureFailed as ex:                     # (a driver / PyTorch build that cannot capture this step)
+            _warn_once(f"flexs_amd.training: hipGraph capture of the training step failed ({ex.__cause__!r}); training eagerly")
     params = [torch.tensor(w, device=device, requires_grad=True) for w in arch._weights]
     opt = KerasAdam(params, getattr(arch, "_opt_state", None))       # moments and step count of the previous rounds
     for epoch in range(epochs):
@@ -278,7 +296,11 @@ class _GraphedFit:
             cap = 1024
             while cap < n:
                 cap *= 2
-            tr = _TRAINERS[arch] = _GraphTrainer(arch, device, B, cap)
+            try:
+                tr = _GraphTrainer(arch, device, B, cap)
+            except Exception as ex:                      # noqa: BLE001 -- whatever the capture raised; the caller trains eagerly
+                raise _CaptureFailed(str(ex)) from ex
+            _TRAINERS[arch] = tr
         self.tr = tr
         self.steps = (n + B - 1) // B
         with torch.no_grad():
@@ -333,10 +355,13 @@ def fit_many(archs, sequences, labels, alphabets, batch_sizes, epochs, verbose=F
     device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
     if n == 0:
         return
-    if len(archs) < 2 or not _use_graph(device):
+    def one_by_one():
         for k, (arch, alphabet, bs, ep) in enumerate(zip(archs, alphabets, batch_sizes, epochs)):
             fit(arch, sequences, labels, alphabet, batch_size=bs, epochs=ep, verbose=verbose, seed=seeds[k] if seeds else None)
-        return
+
+    # (the same Architecture listed twice is trained twice in a row by the reference's loop: not interleavable)
+    if len(archs) < 2 or not _use_graph(device) or len({id(a) for a in archs}) < len(archs):
+        return one_by_one()
     for arch in archs:
         if arch.loss not in ("MSE", "mse", "mean_squared_error"):
             raise ValueError(f"unsupported loss {arch.loss!r} (the reference only ever uses 'MSE')")
@@ -350,7 +375,10 @@ def fit_many(archs, sequences, labels, alphabets, batch_sizes, epochs, verbose=F
         gen = torch.Generator(device="cpu")
         if seeds:
             gen.manual_seed(seeds[k])
-        jobs.append(_GraphedFit(arch, encoded[key], y, n, int(bs), ep, verbose, gen, device, stream=torch.cuda.Stream(device=device)))
+        try:
+            jobs.append(_GraphedFit(arch, encoded[key], y, n, int(bs), ep, verbose, gen, device, stream=torch.cuda.Stream(device=device)))
+        except _CaptureFailed:
+            return one_by_one()                          # (nothing has been trained yet: `fit` warns and trains eagerly)
     for job in jobs:
         job.stream.wait_stream(cur)                      # the static buffers were filled on the current stream
     for epoch in range(max(j.epochs for j in jobs)):
