@@ -265,14 +265,14 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
 
 namespace {
 
-template <int QUADS, int XT, int L1C, int K = 5>
+template <int QUADS, int XT, int L1C, int K = 5, int HT = 7>
 int launch_quad(fx_engine* e, QuadArgs a, int64_t U, int max_rounds) {
     int64_t blocks = e->grid_blocks > 0 ? e->grid_blocks : e->num_cus;
     if (blocks > U) blocks = U;
     if (e->cnn_quad < 2 && U > (int64_t)max_rounds * QUADS * blocks) return FX_EUNSUPPORTED;   // long launches: one wave per tile
     const size_t lds = (size_t)a.total_floats * 4 + 256 + (size_t)QUADS * 2 * XT * 1024 + (size_t)QUADS * 256;
     if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
-    auto kern = k_score_cnn_quad<7, QUADS, XT, L1C, K>;
+    auto kern = k_score_cnn_quad<HT, QUADS, XT, L1C, K>;
     static bool attr_set[64] = {};
     if (!attr_set[e->device & 63]) {
         FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -291,7 +291,9 @@ int fx_launch_score_cnn_quad(fx_engine* e, fx_model* const* models, int M, const
     const FxShape& s = models[0]->shape;
     const FxPackLayout& lay = models[0]->layout;
     const int L1 = s.L - s.K + 1;
-    if (!e->cnn_quad || s.A != 4 || (s.K != 5 && s.K != 3 && s.K != 7) || L1 < 1 || L1 > 12 || lay.FT != 2 || lay.HT != 7 || lay.HTR != 7 ||
+    // hidden layer: 7 tiles (97-112 units) for every kernel size; 1 / 2 / 4 tiles (<= 64 units) for kernel size 5
+    const bool ht_ok = lay.HT == 7 || (s.K == 5 && (lay.HT == 1 || lay.HT == 2 || lay.HT == 4));
+    if (!e->cnn_quad || s.A != 4 || (s.K != 5 && s.K != 3 && s.K != 7) || L1 < 1 || L1 > 12 || lay.FT != 2 || !ht_ok ||
         e->cnn_conv1_mfma || e->cnn_variant || M > FX_MAX_M)
         return FX_EUNSUPPORTED;
     const int64_t TG = (N + 15) / 16, U = (int64_t)M * TG;
@@ -301,7 +303,7 @@ int fx_launch_score_cnn_quad(fx_engine* e, fx_model* const* models, int M, const
     for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
     a.N = N; a.TG = TG; a.M = M; a.m_off = m_off;
     a.out_sn = e->planar_stride ? 1 : Mtot; a.out_sm = e->planar_stride ? e->planar_stride : 1;
-    a.L = s.L; a.rlh = lay.RLH;
+    a.L = s.L; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4;
     a.dma = e->dma_fill && lay.off_d1 % 4 == 0 && lay.total_floats % 4 == 0;
     a.off_c2 = (int)lay.off_c2; a.off_c3 = (int)lay.off_c3; a.off_cb = (int)lay.off_cb; a.off_w1p = (int)lay.off_w1p;
     a.off_d1 = (int)lay.off_d1; a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
@@ -310,6 +312,12 @@ int fx_launch_score_cnn_quad(fx_engine* e, fx_model* const* models, int M, const
     // (kernel sizes 3 and 7, the other two fused instantiations of the one-wave kernel: one quad, any position count)
     if (s.K == 3) return launch_quad<1, 24, 0, 3>(e, a, U, 2);
     if (s.K == 7) return launch_quad<1, 20, 0, 7>(e, a, U, 2);     // (seq_len <= 16: at most 10 positions; its image is 8 KiB larger)
+    switch (lay.HT) {
+        case 1: return L1 <= 4 ? launch_quad<3, 8, 0, 5, 1>(e, a, U, 1) : launch_quad<1, 24, 0, 5, 1>(e, a, U, 2);
+        case 2: return L1 <= 4 ? launch_quad<3, 8, 0, 5, 2>(e, a, U, 1) : launch_quad<1, 24, 0, 5, 2>(e, a, U, 2);
+        case 4: return L1 <= 4 ? launch_quad<3, 8, 0, 5, 4>(e, a, U, 1) : launch_quad<1, 24, 0, 5, 4>(e, a, U, 2);
+        default: break;
+    }
     if (L1 == 4) return launch_quad<3, 8, 4>(e, a, U, 1);
     if (L1 < 4) return launch_quad<3, 8, 0>(e, a, U, 1);
     return launch_quad<1, 24, 0>(e, a, U, 2);

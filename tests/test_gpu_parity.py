@@ -1362,6 +1362,27 @@ def test_cnn_quad_form_other_kernel_sizes(eng, L, n, M, K):
         eng.score(nms, bb, lut)
 
 
+@pytest.mark.parametrize("L,n,M,H", [(8, 20, 3, 10), (8, 700, 1, 16), (14, 100, 3, 30), (14, 20, 1, 50), (16, 1000, 2, 64), (8, 4000, 1, 64), (14, 33, 2, 70),
+                                     (8, 100, 3, 90), (14, 5000, 1, 32), (7, 17, 1, 96)])
+def test_cnn_quad_form_other_hidden_sizes(eng, L, n, M, H):
+    """The quad form for hidden layers of 1 / 2 / 4 tiles (<= 64 units) and for 65-96 units padded to 7 tiles: same bits as
+    the one-wave kernel, oracle."""
+    pairs = [make_native(eng, "cnn", L, 4, H, 32, 5, seed=95 + m) for m in range(M)]
+    nms = [p[0] for p in pairs]
+    lut = _native.make_lut("UGCA")
+    b, seqs = rand_seqs(n, L, "UGCA", seed=n + H)
+    outs = {}
+    for mode in (0, 1, 2):
+        eng.set_option("cnn_quad", mode)
+        try:
+            outs[mode], _ = eng.score(nms, b, lut, want_matrix=True)
+        finally:
+            eng.set_option("cnn_quad", 1)
+    assert np.array_equal(outs[1], outs[0]) and np.array_equal(outs[2], outs[0])
+    for m in range(M):
+        assert_scores(outs[2][:, m], ref_np.keras_fitness(seqs, "UGCA", "cnn", pairs[m][1], exact=True), f"quad H={H} L={L} n={n}")
+
+
 @pytest.mark.parametrize("L,n,M", [(10, 3000, 2), (5, 100, 1), (64, 20, 3), (30, 70000, 1)])
 def test_cnn_binary_alphabet_on_mfma(eng, L, n, M):
     """`BA = "01"` (sequence_utils.py:16): the canonical CNN on a 2-letter alphabet (conv3 has a single tap) runs on the
