@@ -47,7 +47,7 @@ int fx_zero_pool(fx_engine* e, size_t bytes, void** out) {
             return fx_fail(e, FX_ENOMEM, "hipMalloc of the zero pool failed");
         }
         e->zero_pool_bytes = cap;
-        FX_HIP(e, hipMemsetAsync(e->d_zero_pool, 0, cap, e->stream));
+        FX_HIP(e, hipMemset(e->d_zero_pool, 0, cap));     // synchronous: valid whatever stream the next launch uses
     }
     *out = e->d_zero_pool;
     return FX_OK;
