@@ -219,6 +219,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "dma_fill")) return &e->dma_fill;
     if (!std::strcmp(key, "cnn_pair_seg4")) return &e->cnn_pair_seg4;
     if (!std::strcmp(key, "cnn_seg_multi")) return &e->cnn_seg_multi;
+    if (!std::strcmp(key, "dense_small")) return &e->dense_small;
     if (!std::strcmp(key, "cnn_quad")) return &e->cnn_quad;
     if (!std::strcmp(key, "cnn_pair")) return &e->cnn_pair;
     if (!std::strcmp(key, "cnn_pair_seg")) return &e->cnn_pair_seg;

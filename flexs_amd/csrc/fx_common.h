@@ -90,6 +90,7 @@ struct fx_engine {
     int64_t cnn_pair = 1;       // 1 = wide alphabets (A = 20) use the two-waves-per-tile kernel (score_cnn_pair.hip)
     int64_t cnn_big_units = 12; // work units per CU from which the A = 4 CNN path switches to 16-wave (unrolled) workgroups
     int64_t cnn_seg = -1;       // A = 4 CNN kernel, small batches: -1 = waves of a workgroup split one tile's positions when L1 >= 24, 0 = never, 1 = whenever the batch is small
+    int64_t dense_small = 1;    // 1 = explorer-size MLP launches (one tile per workgroup, at most one workgroup per CU) deal a tile's output tiles to 8 waves (score_dense_small.hip); 2 = at any size (test knob); 0 = off
     int64_t cnn_seg_multi = 1;  // 1 = the position-segmented 4-letter form may spread a tile over several (4- or 8-wave) workgroups
     int64_t cnn_pair_seg4 = 1;  // 1 = the segmented protein form may use 4-wave workgroups (one wave per SIMD) when twice as many still fit in one wave of the grid
     int64_t cnn_pair_seg = -1;  // pair kernel, small batches: -1 = segment a tile's positions automatically, 0 = never, n > 0 = force SB = n workgroups per tile
@@ -197,6 +198,10 @@ int fx_launch_score_cnn_quad(fx_engine* e, fx_model* const* models, int M, const
                              float* d_out_NM, int Mtot, int m_off);
 int fx_launch_score_cnn_pair(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii,
                              int64_t N, float* d_out_NM, int Mtot, int m_off);
+// small launches of the MLP: a tile's output tiles dealt to the waves of a workgroup (score_dense_small.hip)
+int fx_launch_score_mlp_small(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N,
+                              float* d_out_NM, int Mtot, int m_off);
+int fx_mlp_first_layer_form(fx_engine* e, const FxShape& s, const FxPackLayout& lay);
 int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii,
                                int64_t N, float* d_out_NM, int Mtot, int m_off);
 int fx_launch_mfma_probe(fx_engine* e, const float* d_a, const float* d_b, const float* d_c, float* d_d);

@@ -508,6 +508,15 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
 
 }  // namespace
 
+// Which terms the persistent kernel's MLP first layer adds (the small-launch kernel must add the same ones):
+// 0 = one kernel row per position, 1 = one pre-summed row per PAIR of positions (the PAIR form), 2 = MFMA form (A/B option).
+int fx_mlp_first_layer_form(fx_engine* e, const FxShape& s, const FxPackLayout& lay) {
+    if (e->mlp_l1_mfma) return 2;
+    if (lay.HT > 8 || !e->mlp_pair || lay.off_w1pair < 0) return 0;
+    const size_t need = (size_t)(lay.total_floats - lay.off_d2 + lay.pair_floats) * 4 + 256 + 32;
+    return need <= (size_t)e->max_lds ? 1 : 0;
+}
+
 int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N,
                                float* d_out_NM, int Mtot, int m_off) {
     if (N == 0) return FX_OK;
@@ -519,6 +528,10 @@ int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, con
     }
     if ((s.kind != FX_MLP && s.kind != FX_GE) || M > FX_MAX_M) return FX_EUNSUPPORTED;
     if (s.A > 127) return FX_EUNSUPPORTED;                        // the gathers' bad-character test ORs the codes: needs code < 0x80
+    {
+        const int rc = fx_launch_score_mlp_small(e, models, M, d_ascii, N, d_out_NM, Mtot, m_off);
+        if (rc != FX_EUNSUPPORTED) return rc;
+    }
     DenseArgs a{};
     a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
     if (int rc = fx_trace_buffer(e, &a.trace)) return rc;

@@ -1,0 +1,216 @@
+// K2, small launches of the MLP: ONE tile of 16 sequences per workgroup, its OUTPUT tiles dealt to the 8 waves.
+//
+// An explorer-size call (1-100 sequences; DyNA-PPO's environment steps score 1-10 at a time with an ensemble that holds
+// an MLP(200), flexs/baselines/explorers/dyna_ppo.py:53-55) is one tile per member.  The persistent kernel
+// (score_dense_mfma.hip) then spends ~5 us copying a 150 KiB weight image into LDS for a single tile, or -- hidden sizes
+// above 128, whose HxH blocks do not fit -- streams 2 x 169 KiB through LDS slabs behind barriers (51 us), and the first
+// layer of a long sequence is a serial chain of row gathers (87 us at seq_len 100).  Here nothing is staged: wave w owns
+// output tiles {w, w + 8} of every layer and reads exactly the weights of those tiles from global memory (L2) into
+// registers -- an eighth of every matrix per wave, all loads of a layer in flight at once -- and the layers' outputs meet in
+// 2 x HT KiB of LDS.  Every output element sees the arithmetic of the persistent kernel (first layer: bias + the same
+// rows -- pre-summed pair rows where that kernel uses them -- in position order; hidden layers: (input tile, k-step)
+// order with the same tail skip; the same final dot), so the scores are the SAME BITS (tested).
+#include "fx_common.h"
+#include "mfma_common.h"
+
+namespace {
+
+constexpr int SW = 8;                                     // waves per workgroup
+
+struct SmallArgs {
+    const uint8_t* ascii;
+    const uint8_t* lut;
+    const float* w[FX_MAX_M];
+    float* out;
+    unsigned* err;
+    int64_t N, TG;
+    int M, m_off;
+    int64_t out_sn, out_sm;
+    int L, A, rlh;
+    int pair;                    // 1 = first layer from the pre-summed pair rows (4-letter alphabets), as the PAIR form of the persistent kernel
+    int off_w1p, off_w1pair, off_d2, off_d3, off_db;
+};
+
+template <int HT>
+__global__ void __launch_bounds__(SW * 64) k_score_mlp_small(SmallArgs p) {
+    constexpr int OT = (HT + SW - 1) / SW;                // output tiles per wave (1 or 2)
+    constexpr int PF = 8;                                 // first-layer rows in flight per output tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, sq = lane & 15;
+    const int L = p.L;
+    f4* hx = reinterpret_cast<f4*>(smem);                 // [2][HT][64]: layer outputs, double-buffered
+    uint8_t* lut_s = reinterpret_cast<uint8_t*>(smem + 2 * HT * 256);
+    uint8_t* bytes_s = lut_s + 256;                       // the tile's 16 x L bytes
+
+    const int64_t unit = blockIdx.x;
+    const int m = (int)(unit / p.TG);
+    const int64_t tg = unit - (int64_t)m * p.TG;
+    const int64_t rows = p.N - tg * 16 < 16 ? p.N - tg * 16 : 16;
+    const int64_t n = tg * 16 + sq;
+    for (int i = tid; i < 64; i += SW * 64) reinterpret_cast<uint32_t*>(lut_s)[i] = reinterpret_cast<const uint32_t*>(p.lut)[i];
+    for (int i = tid; i < (int)rows * L; i += SW * 64) bytes_s[i] = p.ascii[tg * 16 * L + i];
+    __syncthreads();
+    const uint8_t* row = bytes_s + (n < p.N ? sq : 0) * L;    // lanes past the batch recompute the tile's first sequence
+    const float* W = p.w[m];
+    const float* db = W + p.off_db;
+    bool bad = false;
+
+    // ---- layer 1: relu(b1 + sum of the kernel rows selected by the codes), this wave's output tiles only
+    f4 h[OT];
+#pragma unroll
+    for (int t = 0; t < OT; ++t) {
+        const int mo = wave + SW * t;
+        h[t] = mo < HT ? *reinterpret_cast<const f4*>(&db[16 * mo + 4 * g]) : splat4(0.f);
+    }
+    unsigned seen = 0;
+    if (p.pair) {
+        const float* wp = W + p.off_w1pair + 4 * g;
+        constexpr int RS = 16 * HT + FX_PAIR_PAD;
+        const int np2 = L >> 1, nterm = np2 + (L & 1);        // pair rows, then the odd last position's own row
+        for (int t0 = 0; t0 < nterm; t0 += PF) {
+            f4 r[PF][OT];
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const int pi = t0 + k;
+                if (pi < nterm) {
+                    int rowi;
+                    if (pi < np2) {
+                        const unsigned c0 = lut_s[row[2 * pi]], c1 = lut_s[row[2 * pi + 1]];
+                        seen |= c0 | c1;
+                        rowi = pi * 16 + (int)(((c0 & 3u) << 2) | (c1 & 3u));
+                    } else {
+                        const unsigned c0 = lut_s[row[L - 1]];
+                        seen |= c0;
+                        rowi = np2 * 16 + (int)(c0 & 3u);
+                    }
+#pragma unroll
+                    for (int t = 0; t < OT; ++t) {
+                        const int mo = wave + SW * t;
+                        if (mo < HT) r[k][t] = *reinterpret_cast<const f4*>(wp + (int64_t)rowi * RS + 16 * mo);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < PF; ++k)
+                if (t0 + k < nterm)
+#pragma unroll
+                    for (int t = 0; t < OT; ++t) h[t] += r[k][t];
+        }
+    } else {
+        const float* w1 = W + p.off_w1p + 4 * g;
+        const unsigned amax = (unsigned)p.A - 1u;
+        for (int l0 = 0; l0 < L; l0 += PF) {
+            f4 r[PF][OT];
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const int l = l0 + k;
+                if (l < L) {
+                    const unsigned c = lut_s[row[l]];
+                    seen |= c;
+                    const unsigned ci = c < amax ? c : amax;   // keeps the read inside the table for a bad character
+#pragma unroll
+                    for (int t = 0; t < OT; ++t) {
+                        const int mo = wave + SW * t;
+                        if (mo < HT) r[k][t] = *reinterpret_cast<const f4*>(w1 + ((int64_t)l * p.A + ci) * (16 * HT) + 16 * mo);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < PF; ++k)
+                if (l0 + k < L)
+#pragma unroll
+                    for (int t = 0; t < OT; ++t) h[t] += r[k][t];
+        }
+    }
+    bad |= seen >= 0x80u;
+#pragma unroll
+    for (int t = 0; t < OT; ++t) {
+        const int mo = wave + SW * t;
+        if (mo < HT) hx[mo * 64 + lane] = relu4(h[t]);
+    }
+    __syncthreads();
+
+    // ---- layers 2, 3: this wave's output tiles from all HT input tiles; A fragments straight from global memory
+    auto hidden = [&](const f4* wblk, const float* bias, const f4* src, f4* dst) {
+        f4 in[HT];
+#pragma unroll
+        for (int mi = 0; mi < HT; ++mi) in[mi] = src[mi * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < OT; ++t) {
+            const int mo = wave + SW * t;
+            if (mo < HT) {
+                f4 a[HT];
+#pragma unroll
+                for (int mi = 0; mi < HT; ++mi) a[mi] = wblk[(mi * HT + mo) * 64 + lane];
+                f4 acc = *reinterpret_cast<const f4*>(&bias[16 * mo + 4 * g]);
+#pragma unroll
+                for (int mi = 0; mi < HT; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (mi == HT - 1 && r >= p.rlh) break;
+                        acc = mfma16(a[mi][r], in[mi][r], acc);
+                    }
+                dst[mo * 64 + lane] = relu4(acc);
+            }
+        }
+    };
+    hidden(reinterpret_cast<const f4*>(W + p.off_d2), db + 16 * HT, hx, hx + HT * 64);
+    __syncthreads();
+    hidden(reinterpret_cast<const f4*>(W + p.off_d3), db + 32 * HT, hx + HT * 64, hx);
+    __syncthreads();
+
+    // ---- Dense(1): wave 0
+    if (wave == 0) {
+        f4 h3[HT][1];
+#pragma unroll
+        for (int mi = 0; mi < HT; ++mi) h3[mi][0] = hx[mi * 64 + lane];
+        float y[1];
+        final_dot<HT, 1>(db + 48 * HT, db[64 * HT], h3, y, g);
+        if (g == 0 && n < p.N) p.out[n * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y[0]);
+    }
+    if (bad) fx_raise(p.err, FX_ERR_BADCHAR);
+}
+
+template <int HT>
+int launch_small(fx_engine* e, const SmallArgs& a, int64_t U) {
+    auto kern = k_score_mlp_small<HT>;
+    const size_t lds = (size_t)2 * HT * 1024 + 256 + (size_t)16 * a.L;
+    if (lds > 64 * 1024) return FX_EUNSUPPORTED;
+    hipLaunchKernelGGL(kern, dim3((unsigned)U), dim3(SW * 64), lds, e->stream, a);
+    FX_HIP(e, hipGetLastError());
+    return FX_OK;
+}
+
+}  // namespace
+
+// FX_EUNSUPPORTED when the small-launch form does not apply (the caller carries on with the persistent kernel).
+int fx_launch_score_mlp_small(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N,
+                              float* d_out_NM, int Mtot, int m_off) {
+    const FxShape& s = models[0]->shape;
+    const FxPackLayout& lay = models[0]->layout;
+    if (!e->dense_small || s.kind != FX_MLP || M > FX_MAX_M || s.A > 127) return FX_EUNSUPPORTED;
+    const int64_t TG = (N + 15) / 16, U = (int64_t)M * TG;
+    // One workgroup per CU is ~8-9 us for the canonical shapes against ~14 us of the persistent kernel (LDS fill + a lone tile).
+    // Where that kernel's lone tile is a latency chain -- hidden layers streamed through LDS slabs (H > 128), a first
+    // layer gathered row by row from L2 (long sequences / wide alphabets) -- this form wins up to ~4 workgroups per CU
+    // (tools/runs/r2_mlp_small_crossover.py); beyond that its per-tile re-read of the weights from L2 loses.
+    const int64_t per_cu = (lay.HT > 8 || (int64_t)s.L * s.A >= 160) ? 4 : 1;
+    if (e->dense_small < 2 && U > per_cu * e->num_cus) return FX_EUNSUPPORTED;
+    const int form = fx_mlp_first_layer_form(e, s, lay);
+    if (form > 1) return FX_EUNSUPPORTED;
+    SmallArgs a{};
+    a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
+    for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
+    a.N = N; a.TG = TG; a.M = M; a.m_off = m_off;
+    a.out_sn = e->planar_stride ? 1 : Mtot; a.out_sm = e->planar_stride ? e->planar_stride : 1;
+    a.L = s.L; a.A = s.A; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4;
+    a.pair = form;
+    a.off_w1p = (int)lay.off_w1p; a.off_w1pair = (int)lay.off_w1pair; a.off_d2 = (int)lay.off_d2; a.off_d3 = (int)lay.off_d3;
+    a.off_db = (int)lay.off_db;
+    switch (lay.HT) {
+        case 7: return launch_small<7>(e, a, U);
+        case 13: return launch_small<13>(e, a, U);
+        default: return FX_EUNSUPPORTED;
+    }
+}

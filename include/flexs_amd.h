@@ -80,7 +80,7 @@ int fx_engine_set_stream(fx_engine *e, void *hip_stream);
 int fx_engine_sync(fx_engine *e);
 const char *fx_last_error(fx_engine *e);
 /* Tuning / test knobs: "force_generic" (0/1: use the plain VALU kernels
- * instead of the MFMA ones), "cnn_variant", "cnn_conv1_mfma", "cnn_pair", "cnn_big_units" (work units per CU from which 16-wave workgroups are used, default 12), "cnn_seg" (-1 auto / 0 off / 1 on: waves of a workgroup split one tile's positions, small batches of the 4-letter CNN kernel), "cnn_pair_seg" (-1 auto / 0 off / n workgroups per tile: position-segmented small-batch form of the wide-alphabet CNN kernel), "mlp_l1_mfma", "dense_slab" (1 = MLP / GE hidden layers wider than 128 are staged through LDS slabs by the workgroup), "grid_blocks", "poison_outputs" (test aid: NaN-fill score buffers first), "trace" (profiling aid, see fx_debug_trace_read), "cnn_quad" (1 = small launches of the 4-letter CNN (32 filters; kernel size 5 with <= 112 hidden units, 3 / 7 with 65-112) with seq_len <= 16 share each tile among four waves, 2 = at any size, 0 = off), "stage_fill" (1 = small CNN launches load the conv weights first and let idle waves bring the head's weights, 0 = whole image first), "cnn_seg_multi" (1 = the position-segmented 4-letter form may spread a tile over several workgroups, 0 = one workgroup per tile), "cnn_pair_seg4" (1 = the segmented wide-alphabet form may use 4-wave workgroups, 0 = 8-wave only), "dma_fill" (1 = weight images are copied global -> LDS directly, asynchronously, and the first layers start when their part has landed, 0 = through registers, whole image first), "stage_bytes" (1 = the MLP / GlobalEpistasis kernels copy a tile's sequence bytes into LDS with 16-byte loads, 0 = byte loads from global memory), "mlp_pair" (1 = MLP layer 1 on a 4-letter alphabet gathers one pre-summed row per pair of positions, 0 = one row per position), "dense_waves" (MLP / GE: 0 = auto, 8 / 16 = waves per workgroup) and "dense_few_waves_below" (auto: tiles per SIMD below which 8 waves are used, default 0 = never), "wave_prio" (1 = the waves that share a SIMD run at distinct, static issue priorities: A/B knob), "ge_bytetab" (1 = GlobalEpistasis layer 1 gathers from a per-position table indexed by the raw byte, 0 = LUT + code-indexed table).  Unknown key ->
+ * instead of the MFMA ones), "cnn_variant", "cnn_conv1_mfma", "cnn_pair", "cnn_big_units" (work units per CU from which 16-wave workgroups are used, default 12), "cnn_seg" (-1 auto / 0 off / 1 on: waves of a workgroup split one tile's positions, small batches of the 4-letter CNN kernel), "cnn_pair_seg" (-1 auto / 0 off / n workgroups per tile: position-segmented small-batch form of the wide-alphabet CNN kernel), "mlp_l1_mfma", "dense_slab" (1 = MLP / GE hidden layers wider than 128 are staged through LDS slabs by the workgroup), "grid_blocks", "poison_outputs" (test aid: NaN-fill score buffers first), "trace" (profiling aid, see fx_debug_trace_read), "cnn_quad" (1 = small launches of the 4-letter CNN (32 filters; kernel size 5 with <= 112 hidden units, 3 / 7 with 65-112) with seq_len <= 16 share each tile among four waves, 2 = at any size, 0 = off), "stage_fill" (1 = small CNN launches load the conv weights first and let idle waves bring the head's weights, 0 = whole image first), "dense_small" (1 = explorer-size MLP launches deal a tile's output tiles to the 8 waves of a workgroup and read the weights straight from L2, 2 = at any size, 0 = off), "cnn_seg_multi" (1 = the position-segmented 4-letter form may spread a tile over several workgroups, 0 = one workgroup per tile), "cnn_pair_seg4" (1 = the segmented wide-alphabet form may use 4-wave workgroups, 0 = 8-wave only), "dma_fill" (1 = weight images are copied global -> LDS directly, asynchronously, and the first layers start when their part has landed, 0 = through registers, whole image first), "stage_bytes" (1 = the MLP / GlobalEpistasis kernels copy a tile's sequence bytes into LDS with 16-byte loads, 0 = byte loads from global memory), "mlp_pair" (1 = MLP layer 1 on a 4-letter alphabet gathers one pre-summed row per pair of positions, 0 = one row per position), "dense_waves" (MLP / GE: 0 = auto, 8 / 16 = waves per workgroup) and "dense_few_waves_below" (auto: tiles per SIMD below which 8 waves are used, default 0 = never), "wave_prio" (1 = the waves that share a SIMD run at distinct, static issue priorities: A/B knob), "ge_bytetab" (1 = GlobalEpistasis layer 1 gathers from a per-position table indexed by the raw byte, 0 = LUT + code-indexed table).  Unknown key ->
  * FX_EINVAL. */
 int fx_engine_set_option(fx_engine *e, const char *key, int64_t value);
 int fx_engine_get_option(fx_engine *e, const char *key, int64_t *value);

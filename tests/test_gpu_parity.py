@@ -1538,3 +1538,49 @@ def test_random_shapes_against_the_oracle_and_batch_invariance(eng, seed):
     bad[int(rng.integers(0, n)), int(rng.integers(0, L))] = ord("#")
     with pytest.raises(ValueError):
         eng.score(list(natives), bad, lut)
+
+
+@pytest.mark.parametrize("L,alpha,H,n,M", [(14, "UGCA", 100, 20, 3), (14, "UGCA", 100, 1, 1), (8, "TGCA", 100, 100, 3), (15, "UGCA", 100, 33, 2), (50, "UGCA", 100, 17, 1),
+                                           (100, "UGCA", 100, 400, 3), (14, "UGCA", 200, 20, 3), (50, "UGCA", 200, 100, 1), (30, s_utils.AAS, 100, 40, 2),
+                                           (90, s_utils.AAS, 100, 20, 3), (237, s_utils.AAS, 100, 16, 1), (90, s_utils.AAS, 200, 7, 2), (14, "UGCA", 97, 50, 1),
+                                           (14, "UGCA", 112, 1000, 2), (9, "ACGTN", 100, 64, 1)])
+def test_mlp_small_launch_form_is_bit_identical_to_the_persistent_kernel(eng, L, alpha, H, n, M):
+    """Explorer-size MLP launches: one tile per workgroup, its output tiles dealt to 8 waves, weights read straight from L2
+    (score_dense_small.hip).  Same terms in the same order as the persistent kernel -- the pre-summed pair rows where that
+    kernel uses them (4-letter alphabets whose table fits LDS), plain rows otherwise, the slab-streamed wide hidden
+    layers -- so the SAME BITS, at any size when forced; oracle; a bad character anywhere fails the call."""
+    A = len(alpha)
+    pairs = [make_native(eng, "mlp", L, A, H, seed=60 + m) for m in range(M)]
+    nms = [p[0] for p in pairs]
+    lut = _native.make_lut(alpha)
+    b, seqs = rand_seqs(n, L, alpha, seed=n + L)
+    outs = {}
+    for mode in (0, 1, 2):
+        eng.set_option("dense_small", mode)
+        try:
+            outs[mode], mean = eng.score(nms, b, lut, want_matrix=True, want_mean=True)
+            assert np.array_equal(mean, np.mean(outs[mode], axis=1))
+        finally:
+            eng.set_option("dense_small", 1)
+    assert np.array_equal(outs[1], outs[0]) and np.array_equal(outs[2], outs[0])
+    for m in range(M):
+        assert_scores(outs[2][:, m], ref_np.keras_fitness(seqs, alpha, "mlp", pairs[m][1], exact=True), f"mlp small L={L} H={H} n={n}")
+    for form in (("mlp_pair", 0),):                           # the plain-row first layer on both sides
+        eng.set_option(*form)
+        try:
+            eng.set_option("dense_small", 0)
+            ref0, _ = eng.score(nms, b, lut, want_matrix=True)
+            eng.set_option("dense_small", 2)
+            got0, _ = eng.score(nms, b, lut, want_matrix=True)
+            assert np.array_equal(ref0, got0)
+        finally:
+            eng.set_option("mlp_pair", 1)
+            eng.set_option("dense_small", 1)
+    eng.set_option("dense_small", 2)
+    try:
+        bb = b.copy()
+        bb[n - 1, L - 1] = ord("#")
+        with pytest.raises(ValueError):
+            eng.score(nms, bb, lut)
+    finally:
+        eng.set_option("dense_small", 1)
