@@ -1,4 +1,5 @@
-// K2, small launches of the MLP: ONE tile of 16 sequences per workgroup, its OUTPUT tiles dealt to the 8 waves.
+// K2, small launches of the MLP / GlobalEpistasis model: ONE tile of 16 sequences per workgroup, its OUTPUT tiles dealt
+// to the 8 waves.
 //
 // An explorer-size call (1-100 sequences; DyNA-PPO's environment steps score 1-10 at a time with an ensemble that holds
 // an MLP(200), flexs/baselines/explorers/dyna_ppo.py:53-55) is one tile per member.  The persistent kernel
@@ -9,7 +10,9 @@
 // registers -- an eighth of every matrix per wave, all loads of a layer in flight at once -- and the layers' outputs meet in
 // 2 x HT KiB of LDS.  Every output element sees the arithmetic of the persistent kernel (first layer: bias + the same
 // rows -- pre-summed pair rows where that kernel uses them -- in position order; hidden layers: (input tile, k-step)
-// order with the same tail skip; the same final dot), so the scores are the SAME BITS (tested).
+// order with the same tail skip; the same final dot), so the scores are the SAME BITS (tested).  GlobalEpistasis: every
+// wave sums the scalar first layer itself (lane group g takes positions g, g + 4, ... in order, two cross-lane adds --
+// the persistent kernel's order), then owns its output tiles of the 1 -> H layer and of the H x H layer.
 #include "fx_common.h"
 #include "mfma_common.h"
 
@@ -28,11 +31,11 @@ struct SmallArgs {
     int64_t out_sn, out_sm;
     int L, A, rlh;
     int pair;                    // 1 = first layer from the pre-summed pair rows (4-letter alphabets), as the PAIR form of the persistent kernel
-    int off_w1p, off_w1pair, off_d2, off_d3, off_db;
+    int off_w1p, off_w1pair, off_d2, off_d3, off_db, off_first;
 };
 
-template <int HT>
-__global__ void __launch_bounds__(SW * 64) k_score_mlp_small(SmallArgs p) {
+template <int KIND, int HT>
+__global__ void __launch_bounds__(SW * 64) k_score_dense_small(SmallArgs p) {
     constexpr int OT = (HT + SW - 1) / SW;                // output tiles per wave (1 or 2)
     constexpr int PF = 8;                                 // first-layer rows in flight per output tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -56,6 +59,49 @@ __global__ void __launch_bounds__(SW * 64) k_score_mlp_small(SmallArgs p) {
     const float* db = W + p.off_db;
     bool bad = false;
 
+    if constexpr (KIND == FX_GE) {
+        // ---- GE layer 1: s = relu(b1 + sum_l w1[l * A + code_l]), a scalar per sequence; layer 2: relu(b2 + s * w2) for this
+        //      wave's output tiles, directly in B-operand layout
+        const float* w1 = W + p.off_first;
+        const unsigned amax = (unsigned)p.A - 1u;
+        float sacc = 0.f;
+        unsigned seen = 0;
+        for (int l0 = g; l0 < L; l0 += 4 * PF) {
+            float r[PF];
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const int l = l0 + 4 * k;
+                if (l < L) {
+                    const unsigned c = lut_s[row[l]];
+                    seen |= c;
+                    r[k] = w1[l * p.A + (int)(c < amax ? c : amax)];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < PF; ++k)
+                if (l0 + 4 * k < L) sacc += r[k];
+        }
+        bad |= seen >= 0x80u;
+        sacc += __shfl_xor(sacc, 16);
+        sacc += __shfl_xor(sacc, 32);
+        sacc += db[0];
+        const float sv = relu1(sacc);
+#pragma unroll
+        for (int t = 0; t < OT; ++t) {
+            const int mo = wave + SW * t;
+            if (mo < HT) {
+                const f4 w2 = *reinterpret_cast<const f4*>(&db[4 + 16 * mo + 4 * g]);
+                const f4 b2 = *reinterpret_cast<const f4*>(&db[4 + 16 * HT + 16 * mo + 4 * g]);
+                f4 v;
+                v.x = relu1(fmaf(sv, w2.x, b2.x));
+                v.y = relu1(fmaf(sv, w2.y, b2.y));
+                v.z = relu1(fmaf(sv, w2.z, b2.z));
+                v.w = relu1(fmaf(sv, w2.w, b2.w));
+                hx[mo * 64 + lane] = v;
+            }
+        }
+        __syncthreads();
+    } else {
     // ---- layer 1: relu(b1 + sum of the kernel rows selected by the codes), this wave's output tiles only
     f4 h[OT];
 #pragma unroll
@@ -131,6 +177,8 @@ __global__ void __launch_bounds__(SW * 64) k_score_mlp_small(SmallArgs p) {
     }
     __syncthreads();
 
+    }
+
     // ---- layers 2, 3: this wave's output tiles from all HT input tiles; A fragments straight from global memory
     auto hidden = [&](const f4* wblk, const float* bias, const f4* src, f4* dst) {
         f4 in[HT];
@@ -155,26 +203,33 @@ __global__ void __launch_bounds__(SW * 64) k_score_mlp_small(SmallArgs p) {
             }
         }
     };
-    hidden(reinterpret_cast<const f4*>(W + p.off_d2), db + 16 * HT, hx, hx + HT * 64);
-    __syncthreads();
-    hidden(reinterpret_cast<const f4*>(W + p.off_d3), db + 32 * HT, hx + HT * 64, hx);
+    const f4* last = hx;                                 // where the last hidden layer's output ends up
+    if constexpr (KIND == FX_GE) {
+        hidden(reinterpret_cast<const f4*>(W + p.off_d3), db + 4 + 32 * HT, hx, hx + HT * 64);
+        last = hx + HT * 64;
+    } else {
+        hidden(reinterpret_cast<const f4*>(W + p.off_d2), db + 16 * HT, hx, hx + HT * 64);
+        __syncthreads();
+        hidden(reinterpret_cast<const f4*>(W + p.off_d3), db + 32 * HT, hx + HT * 64, hx);
+    }
     __syncthreads();
 
     // ---- Dense(1): wave 0
     if (wave == 0) {
         f4 h3[HT][1];
 #pragma unroll
-        for (int mi = 0; mi < HT; ++mi) h3[mi][0] = hx[mi * 64 + lane];
+        for (int mi = 0; mi < HT; ++mi) h3[mi][0] = last[mi * 64 + lane];
         float y[1];
-        final_dot<HT, 1>(db + 48 * HT, db[64 * HT], h3, y, g);
+        if constexpr (KIND == FX_GE) final_dot<HT, 1>(db + 4 + 48 * HT, db[4 + 64 * HT], h3, y, g);
+        else final_dot<HT, 1>(db + 48 * HT, db[64 * HT], h3, y, g);
         if (g == 0 && n < p.N) p.out[n * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y[0]);
     }
     if (bad) fx_raise(p.err, FX_ERR_BADCHAR);
 }
 
-template <int HT>
+template <int KIND, int HT>
 int launch_small(fx_engine* e, const SmallArgs& a, int64_t U) {
-    auto kern = k_score_mlp_small<HT>;
+    auto kern = k_score_dense_small<KIND, HT>;
     const size_t lds = (size_t)2 * HT * 1024 + 256 + (size_t)16 * a.L;
     if (lds > 64 * 1024) return FX_EUNSUPPORTED;
     hipLaunchKernelGGL(kern, dim3((unsigned)U), dim3(SW * 64), lds, e->stream, a);
@@ -189,15 +244,15 @@ int fx_launch_score_mlp_small(fx_engine* e, fx_model* const* models, int M, cons
                               float* d_out_NM, int Mtot, int m_off) {
     const FxShape& s = models[0]->shape;
     const FxPackLayout& lay = models[0]->layout;
-    if (!e->dense_small || s.kind != FX_MLP || M > FX_MAX_M || s.A > 127) return FX_EUNSUPPORTED;
+    if (!e->dense_small || (s.kind != FX_MLP && s.kind != FX_GE) || M > FX_MAX_M || s.A > 127) return FX_EUNSUPPORTED;
     const int64_t TG = (N + 15) / 16, U = (int64_t)M * TG;
     // One workgroup per CU is ~8-9 us for the canonical shapes against ~14 us of the persistent kernel (LDS fill + a lone tile).
     // Where that kernel's lone tile is a latency chain -- hidden layers streamed through LDS slabs (H > 128), a first
     // layer gathered row by row from L2 (long sequences / wide alphabets) -- this form wins up to ~4 workgroups per CU
     // (tools/runs/r2_mlp_small_crossover.py); beyond that its per-tile re-read of the weights from L2 loses.
-    const int64_t per_cu = (lay.HT > 8 || (int64_t)s.L * s.A >= 160) ? 4 : 1;
+    const int64_t per_cu = (lay.HT > 8 || (s.kind == FX_MLP && (int64_t)s.L * s.A >= 160)) ? 4 : 1;
     if (e->dense_small < 2 && U > per_cu * e->num_cus) return FX_EUNSUPPORTED;
-    const int form = fx_mlp_first_layer_form(e, s, lay);
+    const int form = s.kind == FX_MLP ? fx_mlp_first_layer_form(e, s, lay) : 0;
     if (form > 1) return FX_EUNSUPPORTED;
     SmallArgs a{};
     a.ascii = d_ascii; a.lut = e->d_lut; a.out = d_out_NM; a.err = e->d_err;
@@ -207,10 +262,17 @@ int fx_launch_score_mlp_small(fx_engine* e, fx_model* const* models, int M, cons
     a.L = s.L; a.A = s.A; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4;
     a.pair = form;
     a.off_w1p = (int)lay.off_w1p; a.off_w1pair = (int)lay.off_w1pair; a.off_d2 = (int)lay.off_d2; a.off_d3 = (int)lay.off_d3;
-    a.off_db = (int)lay.off_db;
+    a.off_db = (int)lay.off_db; a.off_first = (int)lay.off_first;
+    if (s.kind == FX_GE) {
+        switch (lay.HT) {
+            case 7: return launch_small<FX_GE, 7>(e, a, U);
+            case 13: return launch_small<FX_GE, 13>(e, a, U);
+            default: return FX_EUNSUPPORTED;
+        }
+    }
     switch (lay.HT) {
-        case 7: return launch_small<7>(e, a, U);
-        case 13: return launch_small<13>(e, a, U);
+        case 7: return launch_small<FX_MLP, 7>(e, a, U);
+        case 13: return launch_small<FX_MLP, 13>(e, a, U);
         default: return FX_EUNSUPPORTED;
     }
 }

@@ -1544,13 +1544,14 @@ def test_random_shapes_against_the_oracle_and_batch_invariance(eng, seed):
                                            (100, "UGCA", 100, 400, 3), (14, "UGCA", 200, 20, 3), (50, "UGCA", 200, 100, 1), (30, s_utils.AAS, 100, 40, 2),
                                            (90, s_utils.AAS, 100, 20, 3), (237, s_utils.AAS, 100, 16, 1), (90, s_utils.AAS, 200, 7, 2), (14, "UGCA", 97, 50, 1),
                                            (14, "UGCA", 112, 1000, 2), (9, "ACGTN", 100, 64, 1)])
-def test_mlp_small_launch_form_is_bit_identical_to_the_persistent_kernel(eng, L, alpha, H, n, M):
+@pytest.mark.parametrize("kind", ["mlp", "ge"])
+def test_mlp_small_launch_form_is_bit_identical_to_the_persistent_kernel(eng, kind, L, alpha, H, n, M):
     """Explorer-size MLP launches: one tile per workgroup, its output tiles dealt to 8 waves, weights read straight from L2
     (score_dense_small.hip).  Same terms in the same order as the persistent kernel -- the pre-summed pair rows where that
     kernel uses them (4-letter alphabets whose table fits LDS), plain rows otherwise, the slab-streamed wide hidden
     layers -- so the SAME BITS, at any size when forced; oracle; a bad character anywhere fails the call."""
     A = len(alpha)
-    pairs = [make_native(eng, "mlp", L, A, H, seed=60 + m) for m in range(M)]
+    pairs = [make_native(eng, kind, L, A, H, seed=60 + m) for m in range(M)]
     nms = [p[0] for p in pairs]
     lut = _native.make_lut(alpha)
     b, seqs = rand_seqs(n, L, alpha, seed=n + L)
@@ -1564,17 +1565,17 @@ def test_mlp_small_launch_form_is_bit_identical_to_the_persistent_kernel(eng, L,
             eng.set_option("dense_small", 1)
     assert np.array_equal(outs[1], outs[0]) and np.array_equal(outs[2], outs[0])
     for m in range(M):
-        assert_scores(outs[2][:, m], ref_np.keras_fitness(seqs, alpha, "mlp", pairs[m][1], exact=True), f"mlp small L={L} H={H} n={n}")
-    for form in (("mlp_pair", 0),):                           # the plain-row first layer on both sides
+        assert_scores(outs[2][:, m], ref_np.keras_fitness(seqs, alpha, kind, pairs[m][1], exact=True), f"{kind} small L={L} H={H} n={n}")
+    for form in (("mlp_pair", 0), ("ge_bytetab", 0)):         # the plain-row / LUT-indexed first layers on both sides
         eng.set_option(*form)
         try:
             eng.set_option("dense_small", 0)
             ref0, _ = eng.score(nms, b, lut, want_matrix=True)
             eng.set_option("dense_small", 2)
             got0, _ = eng.score(nms, b, lut, want_matrix=True)
-            assert np.array_equal(ref0, got0)
+            assert np.array_equal(ref0, got0) and np.array_equal(ref0, outs[0]) or form[0] == "mlp_pair"
         finally:
-            eng.set_option("mlp_pair", 1)
+            eng.set_option(form[0], 1)
             eng.set_option("dense_small", 1)
     eng.set_option("dense_small", 2)
     try:
