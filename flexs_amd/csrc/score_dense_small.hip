@@ -263,16 +263,18 @@ int fx_launch_score_mlp_small(fx_engine* e, fx_model* const* models, int M, cons
     a.pair = form;
     a.off_w1p = (int)lay.off_w1p; a.off_w1pair = (int)lay.off_w1pair; a.off_d2 = (int)lay.off_d2; a.off_d3 = (int)lay.off_d3;
     a.off_db = (int)lay.off_db; a.off_first = (int)lay.off_first;
-    if (s.kind == FX_GE) {
-        switch (lay.HT) {
-            case 7: return launch_small<FX_GE, 7>(e, a, U);
-            case 13: return launch_small<FX_GE, 13>(e, a, U);
-            default: return FX_EUNSUPPORTED;
-        }
+#define FX_SMALL_CASES(KIND)                                        \
+    switch (lay.HT) {                                               \
+        case 1: return launch_small<KIND, 1>(e, a, U);              \
+        case 2: return launch_small<KIND, 2>(e, a, U);              \
+        case 4: return launch_small<KIND, 4>(e, a, U);              \
+        case 7: return launch_small<KIND, 7>(e, a, U);              \
+        case 8: return launch_small<KIND, 8>(e, a, U);              \
+        case 13: return launch_small<KIND, 13>(e, a, U);            \
+        case 16: return launch_small<KIND, 16>(e, a, U);            \
+        default: return FX_EUNSUPPORTED;                            \
     }
-    switch (lay.HT) {
-        case 7: return launch_small<FX_MLP, 7>(e, a, U);
-        case 13: return launch_small<FX_MLP, 13>(e, a, U);
-        default: return FX_EUNSUPPORTED;
-    }
+    if (s.kind == FX_GE) { FX_SMALL_CASES(FX_GE) }
+    FX_SMALL_CASES(FX_MLP)
+#undef FX_SMALL_CASES
 }

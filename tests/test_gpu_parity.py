@@ -1543,7 +1543,9 @@ def test_random_shapes_against_the_oracle_and_batch_invariance(eng, seed):
 @pytest.mark.parametrize("L,alpha,H,n,M", [(14, "UGCA", 100, 20, 3), (14, "UGCA", 100, 1, 1), (8, "TGCA", 100, 100, 3), (15, "UGCA", 100, 33, 2), (50, "UGCA", 100, 17, 1),
                                            (100, "UGCA", 100, 400, 3), (14, "UGCA", 200, 20, 3), (50, "UGCA", 200, 100, 1), (30, s_utils.AAS, 100, 40, 2),
                                            (90, s_utils.AAS, 100, 20, 3), (237, s_utils.AAS, 100, 16, 1), (90, s_utils.AAS, 200, 7, 2), (14, "UGCA", 97, 50, 1),
-                                           (14, "UGCA", 112, 1000, 2), (9, "ACGTN", 100, 64, 1)])
+                                           (14, "UGCA", 112, 1000, 2), (9, "ACGTN", 100, 64, 1), (14, "UGCA", 10, 20, 2), (14, "UGCA", 16, 300, 1),
+                                           (20, "UGCA", 30, 17, 3), (14, "UGCA", 50, 100, 1), (33, s_utils.AAS, 64, 20, 2), (14, "UGCA", 128, 40, 1),
+                                           (14, "UGCA", 130, 20, 2), (40, "UGCA", 256, 33, 1)])
 @pytest.mark.parametrize("kind", ["mlp", "ge"])
 def test_mlp_small_launch_form_is_bit_identical_to_the_persistent_kernel(eng, kind, L, alpha, H, n, M):
     """Explorer-size MLP launches: one tile per workgroup, its output tiles dealt to 8 waves, weights read straight from L2
