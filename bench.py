@@ -326,13 +326,97 @@ def member_parallel_block(world, rank, device, torch, dist, use_dist, steps_hint
         out[name] = {"value": n * steps / elapsed, "unit": "sequences/s", "ms_per_step": elapsed / steps * 1e3,
                      "kernel_ms_this_rank": kern_ms, "steps": steps, "members": 8,
                      "members_per_rank": -(-8 // world), "gathered_bytes_per_rank": 4 * n * -(-8 // world) * world,
+                     "one_gpu_reference": ONE_GPU_REF[name],
+                     "speedup_vs_1gpu": n * steps / elapsed / ONE_GPU_REF[name],
                      "checked": ok}
         del ens, mods, d_seq
     out["what"] = ("8-member ensembles sharded member-parallel over the ranks (flexs/ensemble.py:54-59): fused kernel "
                    "for this rank's members + one RCCL all-gather of the stacked (N, 8) predictions + np.mean-order mean "
                    "on every rank; same batch on every rank (strong scaling), double-buffered so the gather of step k "
-                   "overlaps step k+1; value at n_gpus=1 is the one-GPU reference for the speed-up")
+                   "overlaps step k+1; speedup_vs_1gpu = value / one_gpu_reference, the latter recorded from this same "
+                   "block at n_gpus=1 (profiles/r2_run4_bench.json); ideal = 8 / members_per_rank")
     return out
+
+# ---------------------------------------------------------------------------------------------------------------
+# One-GPU references of the member-parallel workloads (profiles/r2_run4_bench*.json, `member_parallel` at n_gpus = 1):
+# what `speedup_vs_1gpu` is computed against when the same command runs on N > 1 GPUs.
+ONE_GPU_REF = {"8xCNN L=8 A=4 N=1e5": 2.14e8, "8xGE L=90 A=20 N=1e5": 6.25e8, "8xGE L=90 A=20 N=1e6": 7.01e8}
+
+
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n_ranks, argv):
+    """`python bench.py --gpus N` without a launcher: start N local ranks (one per GPU) through
+    torch.distributed.run on 127.0.0.1 and hand their exit status back.  Rank 0 of the children prints the ONE JSON
+    line on the inherited stdout.  The torchrun form of the contract keeps working: a process that already carries
+    RANK / WORLD_SIZE never comes here."""
+    import subprocess
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_selftest(rank, world):
+    """`--cpu-selftest`: the launch path of the bench (self-spawn, rendezvous, double-buffered launch / finish through
+    DistributedEnsemble in both modes, MAX-over-ranks timing, one JSON line on rank 0) on the gloo backend with an
+    injected table scorer -- what the CPU suite can check of `--gpus N` without N GPUs.  Not a measurement."""
+    import torch
+    import torch.distributed as dist
+
+    import flexs_amd
+    from flexs_amd import distributed as fd, synth
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class _Member(flexs_amd.Model):
+        def train(self, *a):
+            pass
+
+        def _fitness_function(self, sequences):
+            raise AssertionError("scored through score_fn")
+
+    def score_fn(idx, b):
+        s = b.astype(np.float64).sum(axis=1)
+        return np.stack([np.sin(s * (m + 1) * 1e-2) for m in idx], axis=1).astype(np.float32) if idx \
+            else np.zeros((b.shape[0], 0), np.float32)
+
+    n, out = 1000, {}
+    seq = synth.random_sequence_bytes(n, L, ALPHABET, seed=0)
+    want = score_fn(list(range(8)), seq)
+    for mode in ("member", "sequence"):
+        ens = fd.DistributedEnsemble([_Member(f"m{i}") for i in range(8)], mode=mode, score_fn=score_fn)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(4):
+            ens.launch(seq, n, slot=i & 1, want="mean")
+            if i:
+                ens.finish((i - 1) & 1)
+        mean = ens.finish(1).numpy().copy()
+        ens.launch(seq, n, 0, "matrix")
+        mat = ens.finish(0).numpy()
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out[mode] = {"ok": bool(np.array_equal(mat, want) and np.array_equal(mean, np.mean(want, axis=1))),
+                     "max_over_ranks_s": float(t.item())}
+    ranks = dist.get_world_size()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "cpu-selftest of the launch path (gloo, injected scorer) -- not a measurement",
+                          "value": None, "n_gpus": 0, "ranks": ranks, "backend": "gloo", "selftest": out}), flush=True)
+    return 0 if all(v["ok"] for v in out.values()) else 1
 
 
 def main():
@@ -355,7 +439,14 @@ def main():
                     help="CUs left free for RCCL when running distributed; -1 = 4 when WORLD_SIZE > 1, else 0")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the all-gather even with one rank (exercises the N>1 code path)")
+    ap.add_argument("--cpu-selftest", action="store_true",
+                    help="run the launch path (self-spawn, rendezvous, launch/finish, one JSON line) on gloo with an "
+                         "injected scorer; no GPU needed, not a measurement")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # no launcher: become one.  N ranks, one per GPU, over RCCL; rank 0 prints the line.
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -366,9 +457,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
+    if args.cpu_selftest:
+        raise SystemExit(cpu_selftest(rank, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
+    if torch.cuda.device_count() < world or local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py --gpus {world}: {world} devices needed, {torch.cuda.device_count()} visible "
+                         f"(rank {rank}); one process per GPU, no oversubscription")
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     saved_stdout = None
@@ -448,6 +544,7 @@ def main():
                               "kernel_ms": s_kern, "frac": rep["roofline"]["frac"],
                               "frac_issued": rep["roofline"]["frac_issued"],
                               "what": f">= {MIN_TIMED_S} s timed region, same step, run right after the K steps above"}
+        out["rccl_ranks"] = dist.get_world_size() if use_dist else 0     # ranks RCCL reports (0: no communicator)
         out.update(extras)
         if world == 1 and not args.no_extras:
             out["configs"] = configs_block(eng, local_rank, torch)

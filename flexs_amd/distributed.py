@@ -136,10 +136,12 @@ class DistributedEnsemble(flexs_amd.Model):
         self.combine_with = combine_with
         self.group = group
         self._score_fn = score_fn
-        self._cuda = score_fn is None and _on_gpu(group)
+        self._cuda = score_fn is None and torch.cuda.is_available()
         if score_fn is None and not self._cuda:
-            raise RuntimeError("DistributedEnsemble scores on this rank's MI355X: it needs an RCCL ('nccl') process "
-                               "group or a visible GPU (there is no CPU fallback); pass score_fn for CPU tests")
+            raise RuntimeError("DistributedEnsemble scores on this rank's MI355X: no GPU is visible (there is no CPU "
+                               "fallback); pass score_fn for CPU tests")
+        # a non-RCCL group (gloo) with on-GPU scoring: the planes are staged through host tensors for the collective
+        self._host_exchange = self._cuda and not _on_gpu(group)
         self._slots = [_Slot(), _Slot()]
         self._comm = None
         # with one rank the gathered block IS the local block (no copy, no second stream); tests and
@@ -164,28 +166,82 @@ class DistributedEnsemble(flexs_amd.Model):
         lo, hi = shard_range(n, rank, world)
         return list(range(M)), (lo, hi), (1 if want == "mean" else M), _stride_for(-(-n // world) if n else 0)
 
-    def train(self, sequences, labels):
-        # every rank trains every member identically only if seeded identically; the usual
-        # pattern is: train on rank 0, broadcast weights (see broadcast_weights)
-        for m in self.models:
-            m.train(sequences, labels)
+    # ------------------------------------------------------------------ training (flexs/ensemble.py:42-52)
+    def _device_surrogates(self) -> bool:
+        from flexs_amd.baselines.models.keras_model import KerasModel
 
-    def broadcast_weights(self, src: int = 0):
-        """Ship rank `src`'s member weights to every rank (after a round's `train`)."""
+        return all(isinstance(m, KerasModel) and type(m).train is KerasModel.train for m in self.models)
+
+    def train(self, sequences, labels, seed: Optional[int] = None):
+        """`for model in self.models: model.train(sequences, labels)` (ensemble.py:42-52, called once per explorer round,
+        explorer.py:157-160), sharded like the scoring: in member mode rank r trains ONLY its member block
+        (`member_assignment`: ceil(M / world) members per rank, interleaved on the GPU by `training.fit_many`), then ONE
+        all-gather of the ranks' concatenated weight blobs puts every member's new weights on every rank
+        (`gather_weights`).  Member k trains with `seed + k` wherever it is trained, so the result equals the
+        single-process `Ensemble.train(..., seed=seed)` bit for bit; without a seed every member draws fresh shuffles /
+        dropout masks, as Keras does.  The optimiser state of a member stays with the rank that owns it (the assignment
+        is static).  Sequence mode (every rank scores with every member) and foreign members train everywhere."""
+        from flexs_amd.ensemble import train_members
+
+        rank, world = _world(self.group)
+        seeds = None if seed is None else [seed + k for k in range(len(self.models))]
+        if self.mode == "member" and world > 1 and self._device_surrogates():
+            mine = member_assignment(len(self.models), rank, world)
+            train_members([self.models[i] for i in mine], sequences, labels,
+                          None if seeds is None else [seeds[i] for i in mine])
+            self.gather_weights()
+        else:
+            train_members(self.models, sequences, labels, seeds)
+
+    def _blob_len(self) -> int:
+        return max(m.model.count_params() for m in self.models)
+
+    def _pack_weights(self, members: List[int], per: int, width: int) -> torch.Tensor:
+        """(per, width) float32: row j = member members[j]'s weight arrays back to back (Keras order), zero padded."""
+        host = np.zeros((per, width), np.float32)
+        for j, i in enumerate(members):
+            flat = np.concatenate([w.ravel() for w in self.models[i].model._weights])
+            host[j, : flat.size] = flat
+        return torch.from_numpy(host)
+
+    def _unpack_weights(self, row: np.ndarray, i: int):
+        arch, out, off = self.models[i].model, [], 0
+        for shp in arch.shapes():
+            size = int(np.prod(shp))
+            out.append(row[off: off + size].reshape(shp))
+            off += size
+        arch.set_weights(out)
+
+    def gather_weights(self):
+        """After a member-sharded `train`: ONE all-gather of every rank's `(ceil(M / world), P)` weight block (P = the
+        largest member's parameter count) over the gather device (device buffers on RCCL), then `set_weights` for the
+        members this rank does not own.  8 x 22 429 floats = 0.7 MB for the canonical CNN ensemble."""
         rank, world = _world(self.group)
         if world == 1:
             return
-        dev = _gather_device(self.group)
-        for m in self.models:
-            ws = m.model.get_weights()
-            flat = torch.from_numpy(np.concatenate([w.ravel() for w in ws])).to(dev)
-            dist.broadcast(flat, src=src, group=self.group)
-            flat = flat.cpu().numpy()
-            out, off = [], 0
-            for w in ws:
-                out.append(flat[off: off + w.size].reshape(w.shape))
-                off += w.size
-            m.model.set_weights(out)
+        M, dev = len(self.models), _gather_device(self.group)
+        per, width = -(-M // world), self._blob_len()
+        send = self._pack_weights(member_assignment(M, rank, world), per, width).to(dev)
+        recv = torch.empty((world, per, width), dtype=torch.float32, device=dev)
+        _all_gather(recv, send, self.group)
+        rows = recv.cpu().numpy().reshape(world * per, width)
+        mine = set(member_assignment(M, rank, world))
+        for i in range(M):
+            if i not in mine:                                      # contiguous assignment: row i IS member i
+                self._unpack_weights(rows[i], i)
+
+    def broadcast_weights(self, src: int = 0):
+        """Ship rank `src`'s member weights to every rank: ONE broadcast of all members' weights in one flat buffer."""
+        rank, world = _world(self.group)
+        if world == 1:
+            return
+        M, dev = len(self.models), _gather_device(self.group)
+        flat = self._pack_weights(list(range(M)), M, self._blob_len()).to(dev)
+        dist.broadcast(flat, src=src, group=self.group)
+        if rank != src:
+            rows = flat.cpu().numpy()
+            for i in range(M):
+                self._unpack_weights(rows[i], i)
 
     def _reduce_planes(self, planes: torch.Tensor, rows: int, M: int, stride: int, out: torch.Tensor):
         """out[:rows] = np.mean over the M member planes, NumPy float32 summation order (K3 on the device path)."""
@@ -210,7 +266,7 @@ class DistributedEnsemble(flexs_amd.Model):
         M = len(self.models)
         mine, (lo, hi), per, stride = self._shape(n, want)
         s = self._slots[slot]
-        dev = _gather_device(self.group) if self._cuda else torch.device("cpu")
+        dev = torch.device("cuda", torch.cuda.current_device()) if self._cuda else torch.device("cpu")
         key = (n, per, stride, world, want)
         if s.key != key:
             s.local = torch.zeros((per, stride), dtype=torch.float32, device=dev)
@@ -232,7 +288,7 @@ class DistributedEnsemble(flexs_amd.Model):
             if self._comm is None:
                 self._comm = torch.cuda.Stream()
             with torch.cuda.stream(st):
-                if s.busy and s.exchange:
+                if s.busy and s.exchange and not self._host_exchange:
                     st.wait_event(s.done)                            # the slot's previous gather has been consumed
                 if isinstance(seq, np.ndarray):
                     seq = torch.from_numpy(np.ascontiguousarray(seq[lo:hi])).to(dev, non_blocking=True)
@@ -250,7 +306,12 @@ class DistributedEnsemble(flexs_amd.Model):
                     if local_reduce:
                         self._reduce_planes(s.planes, hi - lo, M, stride, s.local)
                 s.keep = seq                                         # alive until the kernels have run
-                if s.exchange:
+                if s.exchange and self._host_exchange:
+                    host = s.local.cpu()                             # (stream-ordered, synchronous D2H)
+                    got = torch.empty((world,) + tuple(host.shape), dtype=torch.float32)
+                    _all_gather(got, host, self.group, force=True)   # gloo: the list form on host tensors
+                    s.recv.copy_(got)
+                elif s.exchange:
                     self._comm.wait_stream(st)
                     with torch.cuda.stream(self._comm):
                         _all_gather(s.recv, s.local, self.group, force=True)   # RCCL over xGMI, device buffers
@@ -275,7 +336,7 @@ class DistributedEnsemble(flexs_amd.Model):
         s = self._slots[slot]
         n, M, want = s.n, len(self.models), s.want
         _, per, stride, _, _ = s.key
-        if self._cuda and s.exchange:
+        if self._cuda and s.exchange and not self._host_exchange:
             self.stream.wait_event(s.done)
         s.busy = False
         with (torch.cuda.stream(self.stream) if self._cuda else _Null()):

@@ -33,20 +33,26 @@ else:
     _EnsembleBase = flexs_amd.Model
 
 
-def train_members(models, sequences, labels):
+def train_members(models, sequences, labels, seeds=None):
     """`for model in models: model.train(sequences, labels)` (flexs/ensemble.py:42-52, adaptive_ensemble.py:84-92,
     dyna_ppo.py:104-107).  When every member is a device surrogate with the stock `train`, the same loop with the members'
-    training steps interleaved on the GPU (flexs_amd/training.py fit_many); any other member list is trained one by one."""
+    training steps interleaved on the GPU (flexs_amd/training.py fit_many); any other member list is trained one by one.
+    `seeds` (one per member, device surrogates only) fixes each member's shuffles and dropout masks: a member then ends
+    up with the same weights whichever process trains it and whatever it is trained next to (member-sharded training)."""
     from flexs_amd.baselines.models.keras_model import KerasModel
 
-    if len(models) > 1 and all(isinstance(m, KerasModel) and type(m).train is KerasModel.train for m in models):
+    stock = [isinstance(m, KerasModel) and type(m).train is KerasModel.train for m in models]
+    if len(models) > 1 and all(stock):
         from flexs_amd import training
 
         training.fit_many([m.model for m in models], sequences, labels, [m.alphabet for m in models],
-                          [m.batch_size for m in models], [m.epochs for m in models])
+                          [m.batch_size for m in models], [m.epochs for m in models], seeds=seeds)
         return
-    for model in models:
-        model.train(sequences, labels)
+    for k, model in enumerate(models):
+        if seeds is not None and stock[k]:
+            model.train(sequences, labels, seed=seeds[k])
+        else:
+            model.train(sequences, labels)
 
 
 class Ensemble(_EnsembleBase):
@@ -68,8 +74,10 @@ class Ensemble(_EnsembleBase):
         self.models = models
         self.combine_with = combine_with
 
-    def train(self, sequences: SEQUENCES_TYPE, labels: np.ndarray):
-        train_members(self.models, sequences, labels)                         # ensemble.py:42-52
+    def train(self, sequences: SEQUENCES_TYPE, labels: np.ndarray, seed: int = None):
+        """ensemble.py:42-52.  `seed` (optional, not in the reference): member k trains with seed + k."""
+        seeds = None if seed is None else [seed + k for k in range(len(self.models))]
+        train_members(self.models, sequences, labels, seeds)
 
     def _fitness_function(self, sequences):
         if _device_members(self.models):

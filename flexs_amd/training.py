@@ -37,6 +37,14 @@ partial mini-batch is padded with zero-weight rows (the loss is the mean over th
 valid rows, as Keras' smaller last batch gives).  Same arithmetic as the eager
 step (`_adam_update` is shared; tests hold the two to each other), FLEXS_AMD_TRAIN_GRAPH=0
 switches the capture off.
+
+Dropout masks never come from torch's default generator: every `fit` owns a generator on
+the training device (seeded from the fit's own shuffle generator) and draws one (batch, H)
+Bernoulli mask per step from it -- OUTSIDE the captured graph, into a static buffer the graph
+reads.  A captured `F.dropout` would read the Philox offset that `graph.replay()` refills per
+generator, and the members of an `Ensemble` replay on separate streams: one member's dropout
+kernel could then see the offset written for another (round-2 advisor finding).  With explicit
+masks the interleaved and the one-by-one training of CNN members are the same arithmetic.
 """
 from __future__ import annotations
 
@@ -54,13 +62,37 @@ LR, BETA_1, BETA_2, EPSILON = 1e-3, 0.9, 0.999, 1e-7      # tf.keras.optimizers.
 DROPOUT = 0.25                                            # cnn.py:51
 
 
-def _encode(sequences, alphabet, L, device):
+def _codes(sequences, alphabet, L, device):
+    """(n, L) uint8 alphabet indices on `device` (ValueError for a character outside the alphabet, as
+    `alphabet.index` raises in sequence_utils.py:46)."""
     seq_bytes = _native.sequences_to_bytes(sequences, L=L)
-    lut = torch.from_numpy(_native.make_lut(alphabet).astype(np.int64))
-    codes = lut[torch.from_numpy(seq_bytes.astype(np.int64))]
+    codes = _native.make_lut(alphabet)[seq_bytes]
     if (codes == 255).any():
         raise ValueError("substring not found")
-    return F.one_hot(codes, len(alphabet)).to(torch.float32).to(device)       # (n, L, A)
+    return torch.from_numpy(np.ascontiguousarray(codes, np.uint8)).to(device)
+
+
+def _one_hot(codes, A):
+    """(..., L) uint8 -> (..., L, A) float32 one-hot; a compare against arange (no host sync, capturable)."""
+    return (codes.unsqueeze(-1) == torch.arange(A, dtype=torch.uint8, device=codes.device)).to(torch.float32)
+
+
+def _encode(sequences, alphabet, L, device):
+    return _one_hot(_codes(sequences, alphabet, L, device), len(alphabet))     # (n, L, A)
+
+
+def _mask_generator(gen, device):
+    """Generator on `device` for one fit's dropout masks, seeded by ONE draw from the fit's shuffle generator (so a seeded
+    fit is reproducible end to end, and the captured and the eager path consume `gen` alike)."""
+    seed = int(torch.randint(0, 2 ** 62, (1,), generator=gen).item())
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    return g
+
+
+def _draw_mask(out, gen):
+    """out (B, H) <- 0/1 keep mask, P(keep) = 1 - DROPOUT, from `gen` on the current stream."""
+    return out.bernoulli_(1.0 - DROPOUT, generator=gen)
 
 
 def _conv(h, w, b, same):
@@ -172,11 +204,16 @@ class _GraphTrainer:
         self.m = [torch.zeros(s, dtype=torch.float32, device=device) for s in self.shapes]
         self.v = [torch.zeros(s, dtype=torch.float32, device=device) for s in self.shapes]
         self.t = torch.zeros((), dtype=torch.float64, device=device)
-        self.x_all = torch.zeros((self.cap, arch.L, arch.A), dtype=torch.float32, device=device)
+        # the data set as alphabet indices (1 byte per position; the float32 one-hot rows of a 16k-row protein data set
+        # would be 310 MB per member, held for the Architecture's lifetime): one-hot is rebuilt per mini-batch in the graph
+        self.A = arch.A
+        self.x_all = torch.zeros((self.cap, arch.L), dtype=torch.uint8, device=device)
         self.y_all = torch.zeros((self.cap,), dtype=torch.float32, device=device)
         self.idx = torch.zeros((self.B,), dtype=torch.int64, device=device)
         self.wts = torch.ones((self.B,), dtype=torch.float32, device=device)
         self.sq_err = torch.zeros((), dtype=torch.float32, device=device)      # sum of squared errors since last reset
+        # CNN: this step's dropout keep mask, drawn by the caller before each replay (never inside the graph)
+        self.mask = torch.ones((self.B, arch.H), dtype=torch.float32, device=device) if arch.kind == "cnn" else None
         # warm-up on a side stream (allocator, rocBLAS handles), then capture; neither may leave a trace in the state
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream(device))
@@ -190,14 +227,14 @@ class _GraphTrainer:
 
     def matches(self, arch, batch_size, n):
         return self.kind == arch.kind and self.B == int(batch_size) and n <= self.cap and \
-            self.device_index == torch.cuda.current_device() and self.shapes == [tuple(s) for s in arch.shapes()] and tuple(self.x_all.shape[1:]) == (arch.L, arch.A)
+            self.device_index == torch.cuda.current_device() and self.shapes == [tuple(s) for s in arch.shapes()] and tuple(self.x_all.shape[1:]) == (arch.L,) and self.A == arch.A
 
     def _step(self):
         for p in self.params:
             p.grad = None
-        xb = self.x_all.index_select(0, self.idx)
+        xb = _one_hot(self.x_all.index_select(0, self.idx), self.A)
         yb = self.y_all.index_select(0, self.idx)
-        se = (forward(self.kind, self.params, xb, train=True) - yb) ** 2 * self.wts
+        se = (forward(self.kind, self.params, xb, train=True, dropout_mask=self.mask) - yb) ** 2 * self.wts
         loss = se.sum() / self.wts.sum()                 # mean over the valid rows of the mini-batch
         loss.backward()
         with torch.no_grad():
@@ -255,18 +292,21 @@ def fit(arch, sequences, labels, alphabet, batch_size=256, epochs=20, verbose=Fa
     if n == 0:
         return
     device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
-    x = _encode(sequences, alphabet, arch.L, device)
+    codes = _codes(sequences, alphabet, arch.L, device)
     y = torch.as_tensor(np.asarray(labels, dtype=np.float32), device=device)
     gen = torch.Generator(device="cpu")
     if seed is not None:
         gen.manual_seed(seed)
     if _use_graph(device):
         try:
-            return _fit_graphed(arch, x, y, n, int(batch_size), epochs, verbose, gen, device)
+            return _fit_graphed(arch, codes, y, n, int(batch_size), epochs, verbose, gen, device)
         except _CaptureFailed as ex:                     # (a driver / PyTorch build that cannot capture this step)
             _warn_once(f"flexs_amd.training: hipGraph capture of the training step failed ({ex.__cause__!r}); training eagerly")
+    x = _one_hot(codes, arch.A)
     params = [torch.tensor(w, device=device, requires_grad=True) for w in arch._weights]
     opt = KerasAdam(params, getattr(arch, "_opt_state", None))       # moments and step count of the previous rounds
+    mask_gen = _mask_generator(gen, device)
+    mask_buf = torch.ones((int(batch_size), arch.H), dtype=torch.float32, device=device) if arch.kind == "cnn" else None
     for epoch in range(epochs):
         perm = torch.randperm(n, generator=gen).to(device)
         total = 0.0
@@ -274,7 +314,9 @@ def fit(arch, sequences, labels, alphabet, batch_size=256, epochs=20, verbose=Fa
             idx = perm[i:i + batch_size]
             for p in params:
                 p.grad = None
-            loss = F.mse_loss(forward(arch.kind, params, x[idx], train=True), y[idx])
+            # a whole (batch, H) mask per step, as the captured step draws it; a partial last batch uses its first rows
+            mask = _draw_mask(mask_buf, mask_gen)[:idx.shape[0]] if mask_buf is not None else None
+            loss = F.mse_loss(forward(arch.kind, params, x[idx], train=True, dropout_mask=mask), y[idx])
             loss.backward()
             opt.step()
             total += float(loss.detach()) * idx.shape[0]
@@ -302,6 +344,7 @@ class _GraphedFit:
                 raise _CaptureFailed(str(ex)) from ex
             _TRAINERS[arch] = tr
         self.tr = tr
+        self.mask_gen = _mask_generator(gen, device)
         self.steps = (n + B - 1) // B
         with torch.no_grad():
             tr.load(arch._weights, getattr(arch, "_opt_state", None))
@@ -322,6 +365,8 @@ class _GraphedFit:
         lo = i * self.B
         self.tr.idx.copy_(self.perm[lo:lo + self.B])
         self.tr.wts.copy_(self.wts[lo:lo + self.B])
+        if self.tr.mask is not None:
+            _draw_mask(self.tr.mask, self.mask_gen)          # this job's generator, this job's stream
         self.tr.graph.replay()
 
     def end_epoch(self):
@@ -371,7 +416,7 @@ def fit_many(archs, sequences, labels, alphabets, batch_sizes, epochs, verbose=F
     for k, (arch, alphabet, bs, ep) in enumerate(zip(archs, alphabets, batch_sizes, epochs)):
         key = (alphabet, arch.L)
         if key not in encoded:
-            encoded[key] = _encode(sequences, alphabet, arch.L, device)
+            encoded[key] = _codes(sequences, alphabet, arch.L, device)
         gen = torch.Generator(device="cpu")
         if seeds:
             gen.manual_seed(seeds[k])

@@ -1,0 +1,198 @@
+"""`flexs_amd.distributed` over a REAL multi-rank RCCL group: one process per GPU, `torch.distributed` backend "nccl".
+
+The world-size-2 cases need two visible devices and skip below that (the `gpurun` box has one GPU; the driver's 8-GPU
+node has eight); the world-size-1 cases run the very same worker over a one-rank RCCL group, so every line of the worker
+is exercised on any GPU box.  What is held: member- and sequence-parallel `DistributedEnsemble` (mean and stacked
+matrix, both buffer slots in flight, bad-character propagation), member-sharded `train` + the weight all-gather, and
+the cache-sharded `NoisyAbstractModel` give the SINGLE-GPU bits on every rank (flexs/ensemble.py:42-59,
+noisy_abstract_model.py:42-101)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _devices():
+    from flexs_amd import _native
+
+    return _native.lib().fx_device_count()
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+
+    import flexs_amd
+    from flexs_amd import distributed as fd, synth
+    from flexs_amd.baselines import models as bm
+    from flexs_amd.utils import sequence_utils as s_utils
+
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    report = {}
+    try:
+        # ---- scoring: every mode against the single-GPU Ensemble on this rank's own device
+        for tag, mk, L, alpha, M, n in (
+                ("3xCNN L=8", lambda s: bm.CNN(8, 32, 100, "TGCA", seed=s, device=rank), 8, "TGCA", 3, 1001),
+                ("8xGE L=90", lambda s: bm.GlobalEpistasisModel(90, 100, s_utils.AAS, seed=s, device=rank), 90, s_utils.AAS, 8, 333),
+                ("5xMLP L=14", lambda s: bm.MLP(14, 100, "UGCA", seed=s, device=rank), 14, "UGCA", 5, 65)):
+            members = [mk(s) for s in range(M)]
+            b = synth.random_sequence_bytes(n, L, alpha, 11)
+            seqs = synth.bytes_to_strings(b)
+            want = flexs_amd.Ensemble(members).get_fitness(seqs)
+            stack = flexs_amd.Ensemble(members, combine_with=lambda x: x).get_fitness(seqs)
+            for mode in ("member", "sequence"):
+                ens = fd.DistributedEnsemble(members, mode=mode)
+                ens.force_collective = True                      # the real RCCL call even with one rank
+                assert np.array_equal(ens.get_fitness(seqs), want), (tag, mode, "mean")
+                mat = fd.DistributedEnsemble(members, mode=mode, combine_with=lambda x: x)
+                mat.force_collective = True
+                assert np.array_equal(mat.get_fitness(seqs), stack), (tag, mode, "matrix")
+                with torch.cuda.stream(ens.stream):
+                    d_seq = torch.from_numpy(b).cuda()
+                ens.launch(d_seq, slot=0, want="mean")            # both buffer slots in flight (what bench.py does)
+                ens.launch(d_seq, slot=1, want="matrix")
+                got_mean, got_mat = ens.finish(0), ens.finish(1)
+                ens.stream.synchronize()
+                assert np.array_equal(got_mean.cpu().numpy(), want) and np.array_equal(got_mat.cpu().numpy(), stack), (tag, mode)
+                try:
+                    ens.get_fitness(seqs[:5] + ["Z" * L])         # every rank sees the bad character (SPMD: same input)
+                    raise AssertionError("bad character accepted")
+                except ValueError:
+                    pass
+                assert np.array_equal(ens.get_fitness(seqs), want), (tag, mode, "after the error")
+            report[tag] = True
+
+        # ---- member-sharded training: rank r trains its block, one all-gather of the weight blobs; same seeds ->
+        # the weights of the single-process Ensemble.train on every rank
+        L, alpha, n = 8, "TGCA", 300
+        seqs = synth.bytes_to_strings(synth.random_sequence_bytes(n, L, alpha, 5))
+        y = np.random.default_rng(1).random(n)
+        for tag, mk in (("mlp", lambda s: bm.MLP(L, 24, alpha, seed=s, epochs=2, device=rank)),
+                        ("cnn", lambda s: bm.CNN(L, 8, 16, alpha, kernel_size=3, seed=s, epochs=2, device=rank))):
+            single = flexs_amd.Ensemble([mk(s) for s in range(3)])
+            single.train(seqs, y, seed=40)
+            sharded = fd.DistributedEnsemble([mk(s) for s in range(3)], mode="member")
+            sharded.train(seqs, y, seed=40)
+            for a, c in zip(single.models, sharded.models):
+                for wa, wc in zip(a.model.get_weights(), c.model.get_weights()):
+                    assert np.array_equal(wa, wc), ("sharded train", tag)
+            owned = fd.member_assignment(3, rank, world)
+            for i, m in enumerate(sharded.models):
+                trained_here = getattr(m.model, "_opt_state", None) is not None
+                assert trained_here == (i in owned), ("who trained what", tag, i, owned)
+            assert np.array_equal(sharded.get_fitness(seqs), single.get_fitness(seqs))
+            sharded.broadcast_weights(src=world - 1)
+            assert np.array_equal(sharded.get_fitness(seqs), single.get_fitness(seqs))
+            report["train " + tag] = True
+
+        # ---- cache-sharded NoisyAbstractModel: values, cache order, landscape cost, RNG position of the one-GPU model
+        rng = np.random.default_rng(4)
+        pool = list(dict.fromkeys(synth.bytes_to_strings(synth.random_sequence_bytes(900, 14, "UGCA", 2))))
+        table = {s: float(rng.random()) for s in pool}
+
+        class Table(flexs_amd.Landscape):
+            def __init__(self):
+                super().__init__("table")
+
+            def _fitness_function(self, ss):
+                return np.array([table[str(s)] for s in ss])
+
+        def trace(nam, land):
+            np.random.seed(9)
+            nam.train(pool[:33], np.array([table[s] for s in pool[:33]]))
+            outs = [nam.get_fitness(pool[33 + 57 * i: 90 + 57 * i]) for i in range(4)]
+            outs.append(nam.get_fitness(pool[10:340]))
+            return np.concatenate(outs), land.cost, nam.cost, list(nam.cache), float(np.random.random())
+
+        l1, l2 = Table(), Table()
+        want_t = trace(bm.NoisyAbstractModel(l1, 0.85, device=rank), l1)
+        got_t = trace(fd.ShardedNoisyAbstractModel(l2, 0.85, device=rank), l2)
+        assert np.array_equal(got_t[0], want_t[0]) and got_t[1:] == want_t[1:]
+        report["nam"] = True
+        q.put((rank, "ok", report))
+    except BaseException as exc:      # noqa: BLE001 -- surface worker failures at once instead of after the queue timeout
+        import traceback
+
+        q.put((rank, "fail", traceback.format_exc()[-3000:] + repr(exc)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_world(world):
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = []
+    for _ in procs:
+        r = q.get(timeout=600)
+        assert r[1] == "ok", f"rank {r[0]} failed:\n{r[2]}"
+        results.append(r)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in results) == list(range(world))
+    for _, _, report in results:
+        assert set(report) == {"3xCNN L=8", "8xGE L=90", "5xMLP L=14", "train mlp", "train cnn", "nam"}
+
+
+def test_one_rank_rccl_group_gives_single_gpu_bits():
+    _run_world(1)
+
+
+@pytest.mark.skipif(_devices() < 2, reason="needs two visible GPUs (one process per GPU)")
+def test_two_rank_rccl_group_gives_single_gpu_bits():
+    _run_world(2)
+
+
+@pytest.mark.skipif(_devices() < 4, reason="needs four visible GPUs")
+def test_four_rank_rccl_group_gives_single_gpu_bits():
+    _run_world(4)                     # 3 members on 4 ranks: one rank owns no member; 8 members: two per rank
+
+
+def test_bench_starts_its_own_ranks_and_names_missing_devices():
+    """`python bench.py --gpus N` with no launcher spawns N ranks by itself.  With fewer than N devices the
+    ranks say so AFTER having been spawned; with N devices the single JSON line comes from rank 0."""
+    n = _devices() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
+                        "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode != 0
+    assert f"{n} devices needed, {n - 1} visible" in r.stderr, r.stderr[-2000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.skipif(_devices() < 2, reason="needs two visible GPUs")
+def test_bench_two_gpus_prints_one_line():
+    import json
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert all(v["checked"] for k, v in d["member_parallel"].items() if k != "what")
+    assert all(v["members_per_rank"] == 4 and v["speedup_vs_1gpu"] > 0 for k, v in d["member_parallel"].items() if k != "what")
