@@ -38,7 +38,7 @@ MIN_TIMED_S = 0.5                # the settled figure covers at least this much 
 KINDS = {"cnn": 0, "mlp": 1, "ge": 2}
 
 
-def cpu_baseline(budget_s=12.0, hard_timeout_s=150.0, nam=False):
+def cpu_baseline(budget_s=12.0, hard_timeout_s=150.0, nam=False, nam_budget_s=3.0):
     """Reference-style CPU path (oracle/cpu_baseline_cli.py -> oracle/torch_twin.py),
     timed on a bounded sample of the same workload in a child process with a hard
     timeout, so that the bench line is always printed.  Checker code: used ONLY here."""
@@ -46,7 +46,7 @@ def cpu_baseline(budget_s=12.0, hard_timeout_s=150.0, nam=False):
 
     cmd = [sys.executable, "-m", "oracle.cpu_baseline_cli", "--L", str(L), "--alphabet", ALPHABET,
            "--filters", str(F), "--hidden", str(H), "--kernel", str(K), "--members", str(M),
-           "--sample", "50000", "--budget", str(budget_s)] + (["--nam"] if nam else [])
+           "--sample", "50000", "--budget", str(budget_s), "--nam-budget", str(nam_budget_s)] + (["--nam"] if nam else [])
     try:
         r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=hard_timeout_s)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
@@ -233,32 +233,144 @@ def configs_block(eng, device, torch):
     return out
 
 
-def end_to_end_block(device):
-    """SURVEY.md 8(d)'s primary metric: `Ensemble.get_fitness(list[str])` -> np.ndarray, host strings in, host
-    array out (string marshalling + PCIe both ways inclusive), configs[1] shape; plus the small-call latency."""
-    import flexs_amd
-    from flexs_amd import synth
+VALU_LANE_OPS = 256 * 4 * 16 * 2.4e9        # 256 CUs x 4 SIMDs x 16 lanes per cycle x 2.4 GHz = 3.93e13 lane-ops/s
+K4_LANE_OPS_PER_CHAR = 24.5                 # issued VALU lane-ops per (pair, text character), L <= 32: PMC, profiles/r2_run1_pmc_targets.md
 
-    ens = flexs_amd.Ensemble(build_members("cnn", L, ALPHABET, M, device))
-    seqs = synth.bytes_to_strings(synth.random_sequence_bytes(BATCH, L, ALPHABET, 1))
-    arr_s = np.array(seqs, dtype="S")
-    out = {}
-    for name, inp in (("list_str", seqs), ("ndarray_S", arr_s)):
-        ens.get_fitness(inp)
+
+def nam_block(eng, device):
+    """configs[2]'s other half: NoisyAbstractModel (noisy_abstract_model.py:42-101) on RNA L=14.
+    K4 (bit-parallel Levenshtein + first-arg-min) kernel time for Q=2000 uncached queries against C in {1e2, 1e3, 2e4}
+    cached sequences, launches issued from C (fx_debug_time_min_dist): pair evaluations/s and the fraction of the
+    integer-VALU issue rate (the roofline that binds K4: cache rows are L2-resident, HBM traffic ~ 0);
+    and `NoisyAbstractModel.get_fitness` end to end on the CbAS call pattern (20 calls x 100 sequences, cache 1000 -> 3000)
+    for a plain landscape (2 oracle calls + 1 RNG draw per query from a Python loop, as the reference) and a
+    `batch_safe` one (two batched oracle calls)."""
+    import flexs_amd
+    from flexs_amd import _native, synth
+    from flexs_amd.baselines.models import NoisyAbstractModel
+
+    Lx, alpha, Q = 14, "UGCA", 2000
+    out = {"k4": {}}
+    q = synth.random_sequence_bytes(Q, Lx, alpha, 77)
+    for C_ in (100, 1000, 20000):
+        cache = _native.NativeCache(eng, Lx)
+        cache.append(synth.random_sequence_bytes(C_, Lx, alpha, 78))
+        reps = 20
+        while True:
+            ms = cache.time_min_dist(q, _native.FX_LEVENSHTEIN, reps)
+            if ms >= 40.0 or reps >= 20000:
+                break
+            reps = int(min(20000, max(reps * 2, reps * 40.0 / max(ms, 1e-3) * 1.1)))
+        t = ms / reps * 1e-3
+        pairs = Q * C_
+        lane_ops = K4_LANE_OPS_PER_CHAR * Lx * pairs
+        out["k4"][f"L=14 Q=2000 C={C_}"] = {
+            "kernel_ms": t * 1e3, "pair_evals_per_s": pairs / t, "queries_per_s": Q / t,
+            "roofline": {"bound": "valu-int", "achieved": lane_ops / t / 1e12, "peak": VALU_LANE_OPS / 1e12,
+                         "unit": "T lane-ops/s", "frac": lane_ops / t / VALU_LANE_OPS,
+                         "lane_ops_per_pair_char": K4_LANE_OPS_PER_CHAR, "traffic": None},
+            "workgroups": -(-C_ // 1024) * Q, "reps": reps}
+        del cache
+    out["k4"]["note"] = ("frac = 24.5 issued VALU lane-ops per (pair, text character) [PMC, profiles/r2_run1_pmc_targets.md] x L x "
+                         "pairs / kernel time / (256 CU x 4 SIMD x 16 lanes x 2.4 GHz); one workgroup = one query x <= 1024 "
+                         "cache rows, so C = 100 runs 100 of 256 lanes per workgroup")
+
+    class _Synth(flexs_amd.Landscape):
+        """Deterministic table-like oracle: fitness = hash of the bytes in [0, 1) (ViennaRNA is absent)."""
+
+        def __init__(self, batch_safe):
+            super().__init__("synth")
+            self.batch_safe = batch_safe
+            self._w = (np.arange(1, Lx + 1, dtype=np.int64) * 2654435761) % 1000003
+
+        def _fitness_function(self, seqs):
+            b = _native.sequences_to_bytes([str(s_) for s_ in seqs], L=Lx).astype(np.int64)
+            return ((b * self._w).sum(axis=1) % 1000) / 1000.0
+
+    for name, safe in (("plain_landscape", False), ("batch_safe_landscape", True)):
         ts = []
-        for _ in range(9):
-            t0 = time.perf_counter(); ens.get_fitness(inp); ts.append(time.perf_counter() - t0)
+        for rep in range(2):                                   # second pass: engine and caches warm
+            np.random.seed(0)
+            model = NoisyAbstractModel(_Synth(safe), 0.9, device=device)
+            model.train(synth.bytes_to_strings(synth.random_sequence_bytes(1000, Lx, alpha, 5)), np.random.random(1000))
+            batches = [synth.bytes_to_strings(synth.random_sequence_bytes(100, Lx, alpha, 100 + c)) for c in range(20)]
+            t0 = time.perf_counter()
+            for bch in batches:
+                model.get_fitness(bch)
+            ts.append(time.perf_counter() - t0)
+        out[name] = {"value": 2000 / ts[-1], "unit": "sequences/s", "wall_ms": ts[-1] * 1e3, "cache_after": len(model.cache),
+                     "oracle_calls": int(model.landscape.cost)}
+    out["what"] = ("NoisyAbstractModel(ss=0.9).get_fitness, RNA L=14, CbAS pattern: 20 calls x 100 sequences, cache 1000 -> ~3000. "
+                   "Host-bound by construction: per call one K4 launch (~20 us) + K5, but the 2 oracle calls and the RNG draw "
+                   "per uncached query stay in a Python loop in the reference's order (plain landscape); a batch_safe landscape "
+                   "gets two batched oracle calls instead")
+    return out
+
+
+def end_to_end_block(device, configs=None):
+    """SURVEY.md 8(d)'s primary metric: `get_fitness(list[str])` -> np.ndarray, host strings in, host array out (string
+    marshalling + PCIe both ways inclusive), for configs[1] and -- marshalling cost grows with L -- for C3 (MLP L=14), C4
+    (8 x GE L=90) and C5 (3 x CNN L=237, one GPU's 62 500-row share); plus the small-call latency.  Each row carries its
+    split: `pack_ms` = the string marshalling alone (csrc/strpack.c into the pinned staging area, worker threads as the
+    call uses them; `pack_1thread_ms` beside it), `kernel_ms` = the scoring launch from `configs`, and what is left of
+    the wall time is PCIe + synchronisation + Python (pieces overlap in the chunked call, so the parts can exceed the whole)."""
+    import flexs_amd
+    from flexs_amd import _native, synth
+
+    strpack = _native._strpack
+    out = {}
+
+    def pack_ms(seqs, Lx, threads):
+        buf = np.empty((len(seqs), Lx), np.uint8)
+        prev = strpack.set_threads(threads)
+        ts = []
+        for _ in range(7):
+            t0 = time.perf_counter(); strpack.pack(seqs, Lx, buf); ts.append(time.perf_counter() - t0)
+        strpack.set_threads(prev)
+        return float(np.median(ts)) * 1e3
+
+    rows = (("C2 3xCNN L=8", "cnn", L, ALPHABET, M, BATCH, "C2 full (headline kernel)"),
+            ("C3 MLP L=14", "mlp", 14, "UGCA", 1, 100_000, "C3 mlp L=14 A=4 H=100 M=1 N=1e5"),
+            ("C4 8xGE L=90", "ge", 90, AAS, 8, 100_000, "C4 ge L=90 A=20 H=100 M=8 N=1e5"),
+            ("C5 3xCNN L=237", "cnn", 237, AAS, 3, 62_500, "C5 cnn L=237 A=20 M=3 N=62500 (one GPU's share of 5e5)"))
+    for name, kind, Lx, alpha, members, n, cfg_key in rows:
+        mods = build_members(kind, Lx, alpha, members, device)
+        model = flexs_amd.Ensemble(mods) if members > 1 else mods[0]
+        seqs = synth.bytes_to_strings(synth.random_sequence_bytes(n, Lx, alpha, 1))
+        model.get_fitness(seqs)
+        ts = []
+        for _ in range(5 if Lx > 100 else 9):
+            t0 = time.perf_counter(); model.get_fitness(seqs); ts.append(time.perf_counter() - t0)
         t = float(np.median(ts))
-        out[name] = {"value": BATCH / t, "unit": "sequences/s", "wall_ms": t * 1e3}
-    small = seqs[:20]
-    for _ in range(20):
-        ens.get_fitness(small)
-    ts = []
-    for _ in range(200):
-        t0 = time.perf_counter(); ens.get_fitness(small); ts.append(time.perf_counter() - t0)
-    out["small_call_N20_us"] = float(np.median(ts)) * 1e6
-    out["what"] = (f"Ensemble(3 x CNN).get_fitness on {BATCH} host strings (L={L}) -> host float32 array, median of 9 "
-                   "calls, marshalling + PCIe inclusive")
+        row = {"value": n / t, "unit": "sequences/s", "wall_ms": t * 1e3, "n": n}
+        if strpack is not None:
+            row["pack_ms"] = pack_ms(seqs, Lx, 0)
+            row["pack_1thread_ms"] = pack_ms(seqs, Lx, 1)
+        kern = (configs or {}).get(cfg_key, {}).get("kernel_ms")
+        if kern:
+            row["kernel_ms"] = kern
+            row["frac_of_kernel_rate"] = (n / t) / (n / (kern * 1e-3))
+        row["h2d_bytes"], row["d2h_bytes"] = n * Lx, 4 * n
+        out[name + " list_str"] = row
+        if name.startswith("C2"):
+            arr_s = np.array(seqs, dtype="S")
+            model.get_fitness(arr_s)
+            ts = []
+            for _ in range(9):
+                t0 = time.perf_counter(); model.get_fitness(arr_s); ts.append(time.perf_counter() - t0)
+            t = float(np.median(ts))
+            out["C2 3xCNN L=8 ndarray_S"] = {"value": n / t, "unit": "sequences/s", "wall_ms": t * 1e3}
+            small = seqs[:20]
+            for _ in range(20):
+                model.get_fitness(small)
+            ts = []
+            for _ in range(200):
+                t0 = time.perf_counter(); model.get_fitness(small); ts.append(time.perf_counter() - t0)
+            out["small_call_N20_us"] = float(np.median(ts)) * 1e6
+        del model, mods, seqs
+    out["list_str"] = out["C2 3xCNN L=8 list_str"]          # (round-2 key, kept)
+    out["what"] = ("get_fitness on host strings -> host float32 array, median wall time, marshalling + PCIe inclusive; "
+                   "pack_ms = strpack.pack alone (auto threads) / pack_1thread_ms single-threaded; kernel_ms from `configs`")
     return out
 
 
@@ -432,7 +544,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only (profiling passes)")
     ap.add_argument("--cpu-nam", action="store_true",
-                    help="cpu_baseline additionally times the NoisyAbstractModel CPU path (adds ~20 s)")
+                    help="cpu_baseline runs the NoisyAbstractModel CPU leg to its full 20 calls (~20 s) instead of ~3 s")
     ap.add_argument("--variant", type=int, default=0, help="cnn kernel variant (0 = auto)")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--reserve-cus", type=int, default=-1,
@@ -548,7 +660,9 @@ def main():
         out.update(extras)
         if world == 1 and not args.no_extras:
             out["configs"] = configs_block(eng, local_rank, torch)
-            out["end_to_end"] = end_to_end_block(local_rank)
+            out["configs"]["C3 nam L=14 A=4 (NoisyAbstractModel half of configs[2])"] = nam_block(eng, local_rank)
+            out["configs"]["C2 full (headline kernel)"] = {"kernel_ms": (settled[2] if settled else kern_ms)}
+            out["end_to_end"] = end_to_end_block(local_rank, out["configs"])
             out["explorer_round"] = explorer_round_block(local_rank, torch)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nam=args.cpu_nam)

@@ -81,6 +81,7 @@ SIGNATURES = {
     "fx_debug_mfma_per_tile": (C.c_int64, [C.c_int] * 6),
     "fx_debug_trace_read": (C.c_int, [_vp, _vp, C.c_int64]),
     "fx_debug_time_score": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _vp, C.c_int64, C.c_int, _u8p, _vp, C.c_int64, C.c_int, _f32p]),
+    "fx_debug_time_min_dist": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, C.c_int, _f32p]),
     "fx_debug_pack_weights": (C.c_int, [C.c_int] * 6 + [_f32p, C.c_int64, _f32p, C.c_int64]),
     "fx_debug_myers": (C.c_int, [_vp, C.c_int, _vp, C.c_int]),
     "fx_debug_mfma_probe": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
@@ -162,6 +163,8 @@ try:                                   # CPython helper built next to libflexs_a
     from flexs_amd import _strpack
 except ImportError:                    # host-side convenience only: the pure-Python path below does the same
     _strpack = None
+if _strpack is not None and os.environ.get("FLEXS_AMD_PACK_THREADS"):
+    _strpack.set_threads(int(os.environ["FLEXS_AMD_PACK_THREADS"]))     # 0 = auto (min(8, cores / 2)), 1 = single-threaded
 
 
 def ragged_to_bytes(sequences, L: int) -> np.ndarray:
@@ -547,6 +550,13 @@ class NativeCache:
         arg = np.empty(Q, np.int64)
         self.engine.check(self.engine._lib.fx_cache_min_dist(self.handle, mode, _ptr(q), Q, _ptr(dist), _ptr(arg)))
         return dist, arg
+
+    def time_min_dist(self, queries: np.ndarray, mode: int = FX_LEVENSHTEIN, reps: int = 10) -> float:
+        """Total milliseconds of `reps` back-to-back neighbour-search launches (fx_debug_time_min_dist, issued from C)."""
+        q = np.ascontiguousarray(queries, np.uint8)
+        ms = C.c_float(0.0)
+        self.engine.check(self.engine._lib.fx_debug_time_min_dist(self.handle, mode, _ptr(q), q.shape[0], reps, C.byref(ms)))
+        return float(ms.value)
 
     def distances(self, queries: np.ndarray, mode: int = FX_LEVENSHTEIN) -> np.ndarray:
         """(Q, C) uint8 matrix of min(distance, 255) against every stored key."""

@@ -47,7 +47,10 @@ int fx_zero_pool(fx_engine* e, size_t bytes, void** out) {
             return fx_fail(e, FX_ENOMEM, "hipMalloc of the zero pool failed");
         }
         e->zero_pool_bytes = cap;
-        FX_HIP(e, hipMemset(e->d_zero_pool, 0, cap));     // synchronous: valid whatever stream the next launch uses
+        // ordered explicitly: the memset rides the stream the segment launches use AND is waited for, so the zeros are
+        // there whatever stream (e->stream may be a lent torch stream) the next launch runs on
+        FX_HIP(e, hipMemsetAsync(e->d_zero_pool, 0, cap, e->stream));
+        FX_HIP(e, hipStreamSynchronize(e->stream));
     }
     *out = e->d_zero_pool;
     return FX_OK;
@@ -913,6 +916,27 @@ int fx_debug_time_score(fx_engine* e, fx_model* const* models, int M, const uint
     FX_HIP(e, hipEventRecord(e->ev0, e->stream));
     for (int i = 0; i < reps; ++i)
         if ((rc = fx_score_planes_dev(e, models, M, d_ascii, N, L, lut, d_planes, stride))) return rc;
+    FX_HIP(e, hipEventRecord(e->ev1, e->stream));
+    FX_HIP(e, hipEventSynchronize(e->ev1));
+    FX_HIP(e, hipEventElapsedTime(total_ms, e->ev0, e->ev1));
+    return FX_OK;
+}
+int fx_debug_time_min_dist(fx_cache* c, int mode, const uint8_t* queries, int64_t Q, int reps, float* total_ms) {
+    if (!c || !queries || !total_ms || reps < 1 || Q < 1 || Q > 32768) return FX_EINVAL;
+    fx_engine* e = c->eng;
+    if (mode != FX_LEVENSHTEIN && mode != FX_HAMMING) return fx_fail(e, FX_EINVAL, "unknown distance mode");
+    if (c->size == 0) return fx_fail(e, FX_EINVAL, "empty cache");
+    FX_HIP(e, hipSetDevice(e->device));
+    void *d_q = nullptr, *d_res = nullptr;
+    int rc;
+    if ((rc = fx_scratch(e, 0, (size_t)Q * c->L + 16, &d_q))) return rc;
+    if ((rc = fx_scratch(e, 1, (size_t)Q * 24, &d_res))) return rc;
+    FX_HIP(e, hipMemcpyAsync(d_q, queries, (size_t)Q * c->L, hipMemcpyHostToDevice, e->stream));
+    unsigned long long* d_keys = (unsigned long long*)d_res;
+    if ((rc = fx_launch_min_dist(e, mode, (const uint8_t*)d_q, Q, c->d_keys, c->size, c->L, d_keys))) return rc;   // warm
+    FX_HIP(e, hipEventRecord(e->ev0, e->stream));
+    for (int i = 0; i < reps; ++i)          // key reset + K4, what one neighbour search enqueues (the finish kernel is O(Q))
+        if ((rc = fx_launch_min_dist(e, mode, (const uint8_t*)d_q, Q, c->d_keys, c->size, c->L, d_keys))) return rc;
     FX_HIP(e, hipEventRecord(e->ev1, e->stream));
     FX_HIP(e, hipEventSynchronize(e->ev1));
     FX_HIP(e, hipEventElapsedTime(total_ms, e->ev0, e->ev1));

@@ -78,34 +78,35 @@ def adalead_round(model, measured_sequences: Sequence[str], measured_scores: Seq
     fuse = _stateless(model) if fuse is None else bool(fuse)
 
     sequences: Dict[str, float] = {}
-    spent = 0                                                               # model.cost - previous_model_cost
-    cost0 = model.cost
-    while spent < model_queries_per_batch:
+    cost0 = model.cost                                                      # previous_model_cost (adalead.py:113)
+
+    def spent():
+        # the budget is whatever the MODEL says it was charged (adalead.py:114,124,146 read model.cost), not a local
+        # count of the sequences handed over: a model that de-duplicates or charges differently stays in step
+        return model.cost - cost0
+
+    while spent() < model_queries_per_batch:
         for _ in range(rho):
             parents = recombine_population(parents, recomb_rate)
         for i in range(0, len(parents), eval_batch_size):
             roots = parents[i:i + eval_batch_size]
             nodes = list(enumerate(roots))
             root_fitnesses = None
-            if fuse and len(nodes) > 0 and spent + len(roots) + eval_batch_size < model_queries_per_batch:
+            if fuse and len(nodes) > 0 and spent() + len(roots) + eval_batch_size < model_queries_per_batch:
                 # first level generated before the roots are scored: roots + children in one call
                 child_idxs, children = _children(nodes, mu, alphabet, seen_before, sequences)
                 both = model.get_fitness(list(roots) + children)
                 root_fitnesses, fitnesses = both[:len(roots)], both[len(roots):]
-                spent += len(roots) + len(children)
                 sequences.update(zip(children, fitnesses))
                 nodes = [(idx, child) for idx, child, f in zip(child_idxs, children, fitnesses) if f >= root_fitnesses[idx]]
             else:
                 root_fitnesses = model.get_fitness(roots)
-                spent += len(roots)
-            while len(nodes) > 0 and spent + eval_batch_size < model_queries_per_batch:
+            while len(nodes) > 0 and spent() + eval_batch_size < model_queries_per_batch:
                 child_idxs, children = _children(nodes, mu, alphabet, seen_before, sequences)
                 fitnesses = model.get_fitness(children)
-                spent += len(children)
                 sequences.update(zip(children, fitnesses))
                 # a branch ends when the child scores below the root of its tree (adalead.py:153-162)
                 nodes = [(idx, child) for idx, child, f in zip(child_idxs, children, fitnesses) if f >= root_fitnesses[idx]]
-    assert model.cost - cost0 == spent
     if len(sequences) == 0:
         raise ValueError("No sequences generated. If `model_queries_per_batch` is small, try making `eval_batch_size` smaller")
     new_seqs = np.array(list(sequences.keys()))

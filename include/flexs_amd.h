@@ -247,6 +247,10 @@ int64_t fx_debug_mfma_per_tile(int kind, int L, int A, int F, int H, int K);
  * would be measured as kernel time).  *total_ms = elapsed time of all `reps` launches. */
 int fx_debug_time_score(fx_engine *e, fx_model *const *models, int M, const uint8_t *d_ascii, int64_t N, int L,
                         const uint8_t lut[256], float *d_planes, int64_t stride, int reps, float *total_ms);
+/* Profiling aid: `reps` back-to-back neighbour searches (key reset + K4 min-distance kernel) of Q host queries against
+ * the device-resident cache, one hipEvent pair on the engine's stream; queries are uploaded once, outside the bracket.
+ * *total_ms = elapsed time of all `reps` launches.  1 <= Q <= 32768, cache not empty. */
+int fx_debug_time_min_dist(fx_cache *c, int mode, const uint8_t *queries, int64_t Q, int reps, float *total_ms);
 /* Profiling aid.  With the engine option "trace" = 1 the MFMA scoring kernels stamp an in-kernel timeline of the LAST
  * launch: row (workgroup b, wave w) = 16 uint64 words at [(b * 16 + w) * 16]: 0 kernel entry, 1 weights resident in
  * LDS, 2 first tile begins, 3 first tile done, 4 last tile done, 5 tiles processed by the wave, 6 wave exit, 7 SIMD

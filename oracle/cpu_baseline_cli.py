@@ -31,7 +31,10 @@ def main():
     ap.add_argument("--budget", type=float, default=12.0)
     ap.add_argument("--max-threads", type=int, default=64)
     ap.add_argument("--vector-budget", type=float, default=4.0)
-    ap.add_argument("--nam", action="store_true", help="also time the NoisyAbstractModel CPU path (~10-20 s)")
+    ap.add_argument("--nam-budget", type=float, default=3.0,
+                    help="seconds of the NoisyAbstractModel CPU leg (CbAS call pattern, stops after the call that crosses "
+                         "the budget; 0 = skip)")
+    ap.add_argument("--nam", action="store_true", help="run the NoisyAbstractModel leg to its full 20 calls (~20 s)")
     a = ap.parse_args()
 
     import torch
@@ -97,7 +100,7 @@ def main():
     # a Python loop over the cache calling a C edit distance per pair, early exit at distance 1), on the
     # CbAS call pattern tools/perf_survey.py times on the GPU (RNA L=14, cache 1000 -> 3000, 20 calls x 100).
     nam = None
-    if a.nam:
+    if a.nam or a.nam_budget > 0:
         import numpy as np
 
         from oracle import c_oracle
@@ -116,16 +119,23 @@ def main():
         for call in range(20):
             model.get_fitness(synth.bytes_to_strings(synth.random_sequence_bytes(100, 14, "UGCA", 100 + call)))
             total += 100
+            if not a.nam and time.perf_counter() - n0 >= a.nam_budget:
+                break
         nel = time.perf_counter() - n0
         nam = {"value": total / nel, "unit": "sequences/s", "cores": 1,
-               "sample": f"{total} queries in {nel:.1f} s; Python loop over the cache + C Levenshtein per pair"}
+               "sample": f"{total} queries ({total // 100} CbAS-style calls of 100, RNA L=14, cache 1000 -> {len(model.cache)}) in "
+                         f"{nel:.1f} s; the reference's loop (noisy_abstract_model.py:50-58): Python over the cache, one C "
+                         "Levenshtein call per pair, early exit at distance 1, 2 oracle calls + 1 RNG draw per query"}
     print(json.dumps({
         "nam": nam,
         "value": done / el, "unit": "sequences/s", "cores": threads, "kind": "port", "vectorised": vec,
         "sample": f"{done} sequences ({done // a.sample} pass(es) over the first {a.sample} of the batch) in "
                   f"{el:.1f} s; reference-style path: per-character Python encode loop (single thread) + 256-row "
                   f"fp32 forward on {threads} torch threads (fastest of {candidates}) + np.stack/np.mean; host has "
-                  f"{os.cpu_count()} logical cores",
+                  f"{os.cpu_count()} logical cores.  NOT a tuned CPU path: the reference predicts in 256-row batches "
+                  f"(keras_model.py:78), i.e. {-(-a.sample // 256)} forwards of 256 x {a.L * len(a.alphabet)} inputs per member per pass, "
+                  "each too small to occupy more than one core (more threads were slower); `vectorised` is the same "
+                  "arithmetic as one full-batch forward on all useful cores",
     }))
 
 

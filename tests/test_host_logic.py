@@ -378,3 +378,36 @@ def test_sequence_generators_match_reference(golden_dir):
     for c in g["construct_mutant"]:
         out = s_utils.construct_mutant_from_sample(np.array(c["sample"]), np.array(c["base"]))
         assert out.tolist() == c["out"] and str(out.dtype) == c["dtype"]
+
+
+def test_string_packing_with_worker_threads():
+    """csrc/strpack.c packs big batches with a persistent pool of worker threads (GIL released; the workers only read
+    immutable str objects): same bytes as one thread at every thread count, sub-ranges included, and the FIRST bad item
+    in row order decides the status -- whichever share it falls in."""
+    from flexs_amd import synth
+
+    sp = _native._strpack
+    assert sp is not None
+    L, N = 24, 40_000                                    # 960 kB: above the threshold for the pool
+    b = synth.random_sequence_bytes(N, L, "ILVAGMFYWEDQNHCRKSTP", 3)
+    seqs = synth.bytes_to_strings(b)
+    prev = sp.set_threads(1)
+    try:
+        for threads in (1, 2, 3, 5, 8, 16, 0):
+            sp.set_threads(threads)
+            out = np.zeros((N, L), np.uint8)
+            assert sp.pack(seqs, L, out) == 0 and np.array_equal(out, b)
+            part = np.zeros((30_001, L), np.uint8)
+            assert sp.pack(seqs, L, part, 7_777, 30_001) == 0 and np.array_equal(part, b[7_777:37_778])
+        sp.set_threads(4)
+        out = np.zeros((N, L), np.uint8)
+        for where, bad, status in ((35_000, "A" * (L - 1), 1), (21_000, "A" * (L - 1) + "Δ", 2), (9_000, 7, 3)):
+            seqs[where] = bad                            # later shares fail first in time, earlier rows win
+            assert sp.pack(seqs, L, out) == status
+        seqs[5] = "x" * (L + 1)
+        assert sp.pack(seqs, L, out) == 1
+        # wide (UCS-2) strings that still fit one byte per character go through the per-character path in the workers too
+        wide = [("Δ" + "A" * L)[1:] for _ in range(N)]
+        assert sp.pack(wide, L, out) == 0 and (out == ord("A")).all()
+    finally:
+        sp.set_threads(prev)
