@@ -376,8 +376,9 @@ def end_to_end_block(device, configs=None):
 
 def explorer_round_block(device, torch):
     """SURVEY.md 8(f)-1/-2, the callers on either side of the path: one explorer round on configs[0]'s surrogate family --
-    `Ensemble.train` of the 3-CNN ensemble on 1000 measured sequences (Adam / MSE / 20 epochs / batch 256, captured
-    steps, members side by side), then one Adalead round (query budget 2000: several hundred model calls of 1-20
+    `Ensemble.train` of the 3-CNN ensemble on 1000 measured sequences (Adam / MSE / 20 epochs / batch 256: the hand-written
+    HIP step of csrc/train_core.h, all members in one fx_train_fit call; the captured-PyTorch-graph path of round 2 is
+    timed beside it), then one Adalead round (query budget 2000: several hundred model calls of 1-20
     sequences).  Wall times, second call of each (graphs captured, engine warm)."""
     import random
 
@@ -395,6 +396,20 @@ def explorer_round_block(device, torch):
     t0 = time.perf_counter(); ens.train(seqs, y); torch.cuda.synchronize()
     out["train_3xCNN_n1000_ms"] = (time.perf_counter() - t0) * 1e3
     out["train_steps_per_member"] = 20 * ((n + 255) // 256)
+    prev = os.environ.get("FLEXS_AMD_TRAIN")
+    try:                                                   # round 2's path, same call: one captured PyTorch step per member
+        os.environ["FLEXS_AMD_TRAIN"] = "graph"
+        ens.train(seqs, y)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); ens.train(seqs, y); torch.cuda.synchronize()
+        out["train_3xCNN_n1000_ms_pytorch_graph"] = (time.perf_counter() - t0) * 1e3
+    except Exception as ex:  # noqa: BLE001 - a comparison figure only
+        out["train_3xCNN_n1000_ms_pytorch_graph"] = f"failed: {type(ex).__name__}"
+    finally:
+        if prev is None:
+            os.environ.pop("FLEXS_AMD_TRAIN", None)
+        else:
+            os.environ["FLEXS_AMD_TRAIN"] = prev
     for i in range(2):
         random.seed(1)
         c0 = ens.cost
@@ -402,8 +417,9 @@ def explorer_round_block(device, torch):
         rollouts.adalead_round(ens, seqs, y, sequences_batch_size=100, model_queries_per_batch=2000, alphabet=ALPHABET)
         out["adalead_round_ms"] = (time.perf_counter() - t0) * 1e3
         out["adalead_model_queries"] = int(ens.cost - c0)
-    out["what"] = ("one explorer round, 3 x CNN(32,100) L=8: Ensemble.train on 1000 measured sequences (PyTorch-ROCm, one captured "
-                   "hipGraph step per member, members interleaved) + flexs_amd.utils.rollouts.adalead_round (budget 2000 queries)")
+    out["what"] = ("one explorer round, 3 x CNN(32,100) L=8: Ensemble.train on 1000 measured sequences (fx_train_fit: hand-written "
+                   "HIP forward+backward+Adam, 2 launches per mini-batch step for all members) + "
+                   "flexs_amd.utils.rollouts.adalead_round (budget 2000 queries)")
     return out
 
 

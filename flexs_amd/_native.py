@@ -84,6 +84,8 @@ SIGNATURES = {
     "fx_debug_time_min_dist": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, C.c_int, _f32p]),
     "fx_debug_pack_weights": (C.c_int, [C.c_int] * 6 + [_f32p, C.c_int64, _f32p, C.c_int64]),
     "fx_debug_myers": (C.c_int, [_vp, C.c_int, _vp, C.c_int]),
+    "fx_train_fit": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64, C.c_int, _u8p, _vp]),
+    "fx_debug_train_step_host": (C.c_int, [C.c_int] * 6 + [_vp, _vp, _vp, _vp, _vp, C.c_int, _u8p, _vp, _vp, C.c_int, _vp]),
     "fx_debug_mfma_probe": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
 }
 
@@ -653,3 +655,59 @@ def debug_myers(a: bytes, b: bytes) -> int:
     a = np.frombuffer(bytes(a), np.uint8)
     b = np.frombuffer(bytes(b), np.uint8)
     return lib().fx_debug_myers(_ptr(a) if len(a) else None, len(a), _ptr(b) if len(b) else None, len(b))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# training (csrc/train.hip)
+class FxFitJob(C.Structure):
+    """`fx_fit_job` of include/flexs_amd.h."""
+    _fields_ = [("kind", C.c_int), ("L", C.c_int), ("A", C.c_int), ("F", C.c_int), ("H", C.c_int), ("K", C.c_int),
+                ("weights", _vp), ("adam_m", _vp), ("adam_v", _vp), ("step", C.c_int64), ("order", _vp),
+                ("epochs", C.c_int), ("batch", C.c_int), ("keep", _vp), ("seed", C.c_uint64), ("step_loss", _vp)]
+
+
+def train_fit(engine: Engine, jobs: List[dict], seq_bytes: np.ndarray, lut: np.ndarray, labels: np.ndarray):
+    """fx_train_fit.  jobs: dicts with kind (int), L, A, F, H, K, weights / adam_m / adam_v (flat float32 arrays, updated
+    IN PLACE), step (int), order (int32 array [epochs * steps * batch]), epochs, batch, optional keep (uint8) and seed;
+    returns [(new step count, step_loss array)] per job."""
+    seq_bytes = np.ascontiguousarray(seq_bytes, np.uint8)
+    labels = np.ascontiguousarray(labels, np.float32)
+    n, L = seq_bytes.shape
+    arr = (FxFitJob * len(jobs))()
+    keepalive = []
+    for s, j in zip(arr, jobs):
+        steps = j["epochs"] * (-(-n // j["batch"])) if n else 0
+        order = np.ascontiguousarray(j["order"], np.int32)
+        if order.size != steps * j["batch"]:
+            raise ValueError("train_fit: `order` must hold epochs * ceil(n / batch) * batch entries")
+        loss = np.zeros(max(steps, 1), np.float32)
+        keep = None if j.get("keep") is None else np.ascontiguousarray(j["keep"], np.uint8)
+        for name in ("weights", "adam_m", "adam_v"):
+            a = j[name]
+            if a.dtype != np.float32 or not a.flags.c_contiguous:
+                raise ValueError(f"train_fit: {name} must be a contiguous float32 array (it is updated in place)")
+        s.kind, s.L, s.A, s.F, s.H, s.K = j["kind"], j["L"], j["A"], j["F"], j["H"], j["K"]
+        s.weights, s.adam_m, s.adam_v = j["weights"].ctypes.data, j["adam_m"].ctypes.data, j["adam_v"].ctypes.data
+        s.step, s.order, s.epochs, s.batch = int(j["step"]), order.ctypes.data, j["epochs"], j["batch"]
+        s.keep, s.seed, s.step_loss = (keep.ctypes.data if keep is not None else None), int(j.get("seed", 0)), loss.ctypes.data
+        keepalive.append((order, keep, loss))
+    engine.check(engine._lib.fx_train_fit(engine.handle, C.byref(arr), len(jobs), _ptr(seq_bytes), n, L, _lut_ptr(lut),
+                                          _ptr(labels)))
+    return [(int(s.step), k[2]) for s, k in zip(arr, keepalive)]
+
+
+def debug_train_step_host(kind: int, L: int, A: int, F: int, H: int, K: int, weights: np.ndarray, adam_m: np.ndarray,
+                          adam_v: np.ndarray, step: int, seq_bytes: np.ndarray, lut: np.ndarray, labels: np.ndarray,
+                          keep: Optional[np.ndarray] = None, R: int = 16):
+    """fx_debug_train_step_host (no GPU): one mini-batch step through the host build of the training kernels' source;
+    weights / moments updated in place; returns (new step count, loss before the update)."""
+    seq_bytes = np.ascontiguousarray(seq_bytes, np.uint8)
+    labels = np.ascontiguousarray(labels, np.float32)
+    st, loss = C.c_int64(step), C.c_float(0.0)
+    keep = None if keep is None else np.ascontiguousarray(keep, np.uint8)
+    rc = lib().fx_debug_train_step_host(kind, L, A, F, H, K, weights.ctypes.data, adam_m.ctypes.data, adam_v.ctypes.data,
+                                        C.addressof(st), _ptr(seq_bytes), seq_bytes.shape[0], _lut_ptr(lut), _ptr(labels),
+                                        _ptr(keep), R, C.addressof(loss))
+    if rc:
+        raise FxError(rc, f"fx_debug_train_step_host failed: {status_name(rc)}")
+    return int(st.value), float(loss.value)

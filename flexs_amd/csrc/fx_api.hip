@@ -182,6 +182,7 @@ int fx_engine_destroy(fx_engine* e) {
     (void)hipStreamSynchronize(e->stream);
     for (auto& p : e->d_scratch) if (p) (void)hipFree(p);
     if (e->d_zero_pool) (void)hipFree(e->d_zero_pool);
+    if (e->d_train) (void)hipFree(e->d_train);
     for (auto& p : e->h_pinned) if (p) (void)hipHostFree(p);
     if (e->h_err) (void)hipHostFree(e->h_err);
     if (e->d_lut) (void)hipFree(e->d_lut);
@@ -233,6 +234,9 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "trace")) return &e->trace;
     if (!std::strcmp(key, "ge_bytetab")) return &e->ge_bytetab;
     if (!std::strcmp(key, "wave_prio")) return &e->wave_prio;
+    if (!std::strcmp(key, "train_rows")) return &e->train_rows;
+    if (!std::strcmp(key, "train_lds")) return &e->train_lds;
+    if (!std::strcmp(key, "train_threads")) return &e->train_threads;
     if (!std::strcmp(key, "dense_waves")) return &e->dense_waves;
     if (!std::strcmp(key, "dense_few_waves_below")) return &e->dense_few_waves_below;
     return nullptr;

@@ -77,6 +77,8 @@ struct fx_engine {
     // growable scratch
     void* d_scratch[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[4] = {0, 0, 0, 0};
+    void* d_train = nullptr;      // fx_train_fit arena (grown on demand, kept between fits)
+    size_t train_bytes = 0;
     void* d_zero_pool = nullptr;  // fx_zero_pool: all-zero between launches (the kernels that use it clean up after themselves)
     size_t zero_pool_bytes = 0;
     void* h_pinned[2] = {nullptr, nullptr};
@@ -107,6 +109,9 @@ struct fx_engine {
     int64_t stage_bytes = 1;    // 1 = MLP (pair rows) / GE (byte table) tiles copy their 16 x L sequence bytes into per-wave LDS scratch with 16-byte loads (0 = byte loads from global memory: A/B)
     int64_t mlp_pair = 1;       // 1 = MLP layer 1 on a 4-letter alphabet gathers one pre-summed row per PAIR of positions (0 = one row per position: A/B)
     int64_t mlp_l1_mfma = 0;    // 1 = one-hot MLP layer 1 on MFMA instead of the LDS gather (A/B knob)
+    int64_t train_rows = 0;     // fx_train_fit: mini-batch rows per workgroup (0 = auto: 16, or 8 for small batches)
+    int64_t train_lds = 2;      // fx_train_fit: 2 = a slice's activations / gradients AND the member's weights live in LDS when they fit, 1 = the workspace only, 0 = global arena (A/B)
+    int64_t train_threads = 0;  // fx_train_fit: threads per forward+backward workgroup (256 / 512 / 1024; 0 = 1024)
     int num_cus = 256;
     int max_lds = 160 * 1024;
     // layout of the score matrix the next launch writes: 0 = row-major (N, M) as the ABI hands it out (np.stack axis=1);

@@ -1,0 +1,257 @@
+// fx_train_fit: `KerasModel.train` (flexs/baselines/models/keras_model.py:49-67 -> model.fit(batch_size, epochs)) for
+// one or several ensemble members at once, hand-written for gfx950 (train_core.h).
+//
+// One mini-batch step = TWO launches whatever the number of members:
+//   k_train_fb    grid (slices, members): forward + backward of R mini-batch rows, per-slice gradient partials;
+//   k_train_adam  grid (parameter blocks, members): fixed-order sum of the partials + Keras-Adam update.
+// A fit of `epochs` x ceil(n / batch) steps enqueues them back to back on the engine's stream from C -- no Python, no
+// framework dispatch between steps -- with everything the steps need resident on the device: the data set as bytes,
+// the labels, every step's mini-batch composition (the host draws the shuffles, as Keras does), per-step learning
+// rates.  Weights and optimiser moments go in and come out as plain host arrays in Keras get_weights() order, so
+// the caller (flexs_amd/training.py) keeps them on the `Architecture` between explorer rounds
+// (flexs/explorer.py:157-160) exactly as before.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "fx_common.h"
+#include "train_core.h"
+
+namespace {
+
+constexpr int FB_MAX_THREADS = 1024;
+constexpr size_t FB_LDS_BUDGET = 150 * 1024;
+
+__global__ void __launch_bounds__(FB_MAX_THREADS) k_train_fb(const FxtJob* __restrict__ jobs, int step, const uint8_t* __restrict__ ascii,
+                                                         const uint8_t* __restrict__ lut, const float* __restrict__ labels) {
+    extern __shared__ __attribute__((aligned(16))) float fxt_smem[];
+    const FxtJob& j = jobs[blockIdx.y];
+    if (step >= j.total_steps || (int)blockIdx.x >= j.S) return;
+    const float* w_local = nullptr;
+    if (j.w_in_lds) {
+        // the member's whole parameter vector next to the slice's workspace: every operand of every layer then comes
+        // from LDS -- the step is ~80 dependent operand fetches long, each an L2 round trip (~1.2 us) otherwise
+        float* wl = fxt_smem + j.ws_slice;
+        const int n4 = j.net.P >> 2;
+        const float4* src = reinterpret_cast<const float4*>(j.w);
+        float4* dst = reinterpret_cast<float4*>(wl);
+        for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * blockDim.x) {
+            float4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (i0 + k * (int)blockDim.x < n4) v[k] = src[i0 + k * blockDim.x];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (i0 + k * (int)blockDim.x < n4) dst[i0 + k * blockDim.x] = v[k];
+        }
+        for (int i = (n4 << 2) + threadIdx.x; i < j.net.P; i += blockDim.x) wl[i] = j.w[i];
+        w_local = wl;                       // (published by the first fxt_sync of the step)
+    }
+    fxt_forward_backward(j, FxtWg{(int)threadIdx.x, (int)blockDim.x}, step, (int)blockIdx.x, ascii, lut, labels,
+                         j.ws_in_lds ? fxt_smem : nullptr, w_local);
+}
+
+__global__ void __launch_bounds__(256) k_train_adam(const FxtJob* __restrict__ jobs, int step) {
+    const FxtJob& j = jobs[blockIdx.y];
+    if (step >= j.total_steps) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < j.net.P) fxt_adam(j, step, i);
+    if (i == 0 && j.step_loss) fxt_step_loss(j, step);
+}
+
+// Rows per slice.  More slices = more workgroups (the machine has 256 CUs and a step of one small network is a few
+// hundred thousand MACs), fewer rows per slice = emptier 16-row MFMA tiles in the dense layers and more partials to
+// sum.  The choice depends on the member's OWN shape and batch size only -- never on how many members train in the
+// same call -- so a member's gradient sums are cut the same way whether it trains alone, next to its ensemble, or on
+// another rank (member-sharded training): the fit is bit-reproducible across those.
+int rows_per_slice(const FxtNet& n, int batch, int num_cus, int forced) {
+    if (forced > 0) return forced > 64 ? 64 : forced;
+    int R = 16;
+    while (R > 8 && (batch + R - 1) / R < num_cus / 8) R >>= 1;
+    if (n.kind == 0 && n.L1 >= 32)          // long sequences: a row alone fills M tiles of the conv GEMMs
+        while (R > 1 && (batch + R - 1) / R < num_cus) R >>= 1;
+    return R;
+}
+
+struct Arena {                 // bump allocator over one device buffer (sizes first, then pointers)
+    char* base = nullptr;
+    size_t off = 0;
+    template <typename T>
+    T* take(size_t count) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = reinterpret_cast<T*>(base + off);
+        off += sizeof(T) * count;
+        return p;
+    }
+};
+
+}  // namespace
+
+int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, int64_t n, int L, const uint8_t lut[256],
+                 const float* labels) {
+    if (!e) return FX_EINVAL;
+    if (!jobs || M < 1 || M > 64 || !lut || n < 0 || L < 1) return fx_fail(e, FX_EINVAL, "fx_train_fit: bad arguments");
+    if (n == 0) return FX_OK;
+    if (!ascii || !labels) return fx_fail(e, FX_EINVAL, "fx_train_fit: null data");
+    if (n > (int64_t)1 << 30) return fx_fail(e, FX_EINVAL, "fx_train_fit: data set too large");
+    std::vector<FxtJob> hj((size_t)M);
+    std::vector<std::vector<float>> lr((size_t)M);
+    int max_steps = 0, max_S = 0, max_P = 0;
+    size_t lds_bytes = 0;
+    for (int m = 0; m < M; ++m) {
+        fx_fit_job& u = jobs[m];
+        if (u.kind < FX_CNN || u.kind > FX_GE || u.L != L || u.A < 1 || u.A > 254 || u.H < 1 || u.batch < 1 || u.epochs < 0 ||
+            !u.weights || !u.adam_m || !u.adam_v || !u.order || u.step < 0)
+            return fx_fail(e, FX_EINVAL, "fx_train_fit: bad job");
+        if (u.kind == FX_CNN && (u.F < 1 || u.K < 1 || u.A < 2 || L < u.K)) return fx_fail(e, FX_ESHAPE, "fx_train_fit: bad CNN shape");
+        FxtJob& j = hj[(size_t)m];
+        j = FxtJob{};
+        j.net = fxt_net(u.kind, L, u.A, u.kind == FX_CNN ? u.F : 0, u.H, u.kind == FX_CNN ? u.K : 0);
+        if ((int64_t)j.net.P != fx_num_params(FxShape{u.kind, L, u.A, j.net.F, u.H, j.net.K})) return fx_fail(e, FX_EINVAL, "fx_train_fit: parameter count mismatch");
+        j.batch = u.batch;
+        j.steps_per_epoch = (int)((n + u.batch - 1) / u.batch);
+        j.total_steps = u.epochs * j.steps_per_epoch;
+        j.n = (int)n;
+        j.R = rows_per_slice(j.net, u.batch, e->num_cus, (int)e->train_rows);
+        j.S = (u.batch + j.R - 1) / j.R;
+        j.seed = u.seed;
+        j.ws_slice = fxt_ws(j.net, j.R).total;
+        j.ws_in_lds = e->train_lds >= 1 && (size_t)j.ws_slice * 4 <= FB_LDS_BUDGET;
+        j.w_in_lds = j.ws_in_lds && e->train_lds >= 2 && ((size_t)j.ws_slice + (size_t)j.net.P) * 4 <= FB_LDS_BUDGET;
+        if (j.ws_in_lds) lds_bytes = std::max(lds_bytes, ((size_t)j.ws_slice + (j.w_in_lds ? (size_t)j.net.P : 0)) * 4);
+        max_steps = std::max(max_steps, j.total_steps);
+        max_S = std::max(max_S, j.S);
+        max_P = std::max(max_P, j.net.P);
+        lr[(size_t)m].resize((size_t)std::max(j.total_steps, 1));
+        for (int s = 0; s < j.total_steps; ++s) {
+            const double t = (double)(u.step + s + 1);           // keras Adam: lr_t = lr sqrt(1 - b2^t) / (1 - b1^t)
+            lr[(size_t)m][(size_t)s] = (float)(FXT_LR * std::sqrt(1.0 - std::pow(FXT_BETA_2, t)) / (1.0 - std::pow(FXT_BETA_1, t)));
+        }
+    }
+    for (int64_t i = 0; i < n * L; ++i)                          // alphabet.index raises ValueError (sequence_utils.py:46)
+        if (lut[ascii[i]] == 0xFF) return fx_fail(e, FX_EBADCHAR, "character outside the alphabet in the training set");
+    if (max_steps == 0) return FX_OK;
+    FX_HIP(e, hipSetDevice(e->device));
+
+    // ---- one device arena: job table, LUT, data, labels, and per member: weights, moments, partials, order, masks, lr, loss, workspace
+    size_t need = 0;
+    auto plan = [&](Arena& a) {
+        a.take<FxtJob>((size_t)M); a.take<uint8_t>(256); a.take<uint8_t>((size_t)n * L); a.take<float>((size_t)n);
+        for (int m = 0; m < M; ++m) {
+            const FxtJob& j = hj[(size_t)m];
+            a.take<float>((size_t)j.net.P); a.take<float>((size_t)j.net.P); a.take<float>((size_t)j.net.P);
+            a.take<float>((size_t)j.S * (j.net.P + 1));
+            a.take<int32_t>((size_t)j.total_steps * j.batch);
+            if (jobs[m].keep) a.take<uint8_t>((size_t)j.total_steps * j.batch * j.net.H);
+            a.take<float>((size_t)j.total_steps); a.take<float>((size_t)j.total_steps);
+            a.take<float>((size_t)j.S * (size_t)j.ws_slice);
+        }
+    };
+    { Arena probe; plan(probe); need = probe.off + 256; }
+    if (need > e->train_bytes) {
+        if (e->d_train) {
+            FX_HIP(e, hipStreamSynchronize(e->stream));
+            FX_HIP(e, hipFree(e->d_train));
+            e->d_train = nullptr; e->train_bytes = 0;
+        }
+        const size_t cap = need + need / 4;
+        if (hipMalloc(&e->d_train, cap) != hipSuccess) { (void)hipGetLastError(); return fx_fail(e, FX_ENOMEM, "hipMalloc of the training arena failed"); }
+        e->train_bytes = cap;
+    }
+    Arena a; a.base = (char*)e->d_train;
+    hipStream_t st = e->stream;
+    FxtJob* d_jobs = a.take<FxtJob>((size_t)M);
+    uint8_t* d_lut = a.take<uint8_t>(256);
+    uint8_t* d_ascii = a.take<uint8_t>((size_t)n * L);
+    float* d_labels = a.take<float>((size_t)n);
+    FX_HIP(e, hipMemcpyAsync(d_lut, lut, 256, hipMemcpyHostToDevice, st));
+    FX_HIP(e, hipMemcpyAsync(d_ascii, ascii, (size_t)n * L, hipMemcpyHostToDevice, st));
+    FX_HIP(e, hipMemcpyAsync(d_labels, labels, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, st));
+    for (int m = 0; m < M; ++m) {
+        FxtJob& j = hj[(size_t)m];
+        const size_t P = (size_t)j.net.P;
+        j.w = a.take<float>(P); j.adam_m = a.take<float>(P); j.adam_v = a.take<float>(P);
+        j.partial = a.take<float>((size_t)j.S * (P + 1));
+        int32_t* d_order = a.take<int32_t>((size_t)j.total_steps * j.batch);
+        j.order = d_order;
+        uint8_t* d_keep = nullptr;
+        if (jobs[m].keep) { d_keep = a.take<uint8_t>((size_t)j.total_steps * j.batch * j.net.H); j.keep = d_keep; }
+        float* d_lr = a.take<float>((size_t)j.total_steps);
+        j.lr_t = d_lr;
+        j.step_loss = a.take<float>((size_t)j.total_steps);
+        j.ws = a.take<float>((size_t)j.S * (size_t)j.ws_slice);
+        FX_HIP(e, hipMemcpyAsync(j.w, jobs[m].weights, sizeof(float) * P, hipMemcpyHostToDevice, st));
+        FX_HIP(e, hipMemcpyAsync(j.adam_m, jobs[m].adam_m, sizeof(float) * P, hipMemcpyHostToDevice, st));
+        FX_HIP(e, hipMemcpyAsync(j.adam_v, jobs[m].adam_v, sizeof(float) * P, hipMemcpyHostToDevice, st));
+        if (j.total_steps > 0) {
+            FX_HIP(e, hipMemcpyAsync(d_order, jobs[m].order, sizeof(int32_t) * (size_t)j.total_steps * j.batch, hipMemcpyHostToDevice, st));
+            if (d_keep) FX_HIP(e, hipMemcpyAsync(d_keep, jobs[m].keep, (size_t)j.total_steps * j.batch * j.net.H, hipMemcpyHostToDevice, st));
+            FX_HIP(e, hipMemcpyAsync(d_lr, lr[(size_t)m].data(), sizeof(float) * (size_t)j.total_steps, hipMemcpyHostToDevice, st));
+        }
+    }
+    FX_HIP(e, hipMemcpyAsync(d_jobs, hj.data(), sizeof(FxtJob) * (size_t)M, hipMemcpyHostToDevice, st));
+    // (the pageable host sources above -- hj, lr -- are staged by the runtime before hipMemcpyAsync returns)
+
+    const dim3 grid_fb((unsigned)max_S, (unsigned)M), grid_adam((unsigned)((max_P + 255) / 256), (unsigned)M);
+    if (lds_bytes > 48 * 1024) {
+        static bool attr_set[64] = {};
+        if (!attr_set[e->device & 63]) {
+            FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_fb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS_BUDGET));
+            attr_set[e->device & 63] = true;
+        }
+    }
+    int threads = (int)e->train_threads;
+    threads = threads >= 1024 ? 1024 : (threads >= 512 ? 512 : (threads >= 256 ? 256 : 1024));
+    for (int s = 0; s < max_steps; ++s) {
+        hipLaunchKernelGGL(k_train_fb, grid_fb, dim3((unsigned)threads), lds_bytes, st, d_jobs, s, d_ascii, d_lut, d_labels);
+        hipLaunchKernelGGL(k_train_adam, grid_adam, dim3(256), 0, st, d_jobs, s);
+    }
+    FX_HIP(e, hipGetLastError());
+    for (int m = 0; m < M; ++m) {
+        const FxtJob& j = hj[(size_t)m];
+        const size_t P = (size_t)j.net.P;
+        FX_HIP(e, hipMemcpyAsync(jobs[m].weights, j.w, sizeof(float) * P, hipMemcpyDeviceToHost, st));
+        FX_HIP(e, hipMemcpyAsync(jobs[m].adam_m, j.adam_m, sizeof(float) * P, hipMemcpyDeviceToHost, st));
+        FX_HIP(e, hipMemcpyAsync(jobs[m].adam_v, j.adam_v, sizeof(float) * P, hipMemcpyDeviceToHost, st));
+        if (jobs[m].step_loss && j.total_steps > 0)
+            FX_HIP(e, hipMemcpyAsync(jobs[m].step_loss, j.step_loss, sizeof(float) * (size_t)j.total_steps, hipMemcpyDeviceToHost, st));
+    }
+    FX_HIP(e, hipStreamSynchronize(st));
+    for (int m = 0; m < M; ++m) jobs[m].step += hj[(size_t)m].total_steps;
+    return FX_OK;
+}
+
+// Test hook, host only (no GPU): ONE mini-batch step of one member through the HOST build of train_core.h -- the
+// same source the kernels are compiled from, threads as loops, the MFMA as an fmaf chain.  tests/test_train_native.py
+// holds it to oracle/train_np.py on the CPU.  rows = the mini-batch (<= 4096 rows), slices of `R` rows.
+int fx_debug_train_step_host(int kind, int L, int A, int F, int H, int K, float* weights, float* adam_m, float* adam_v,
+                             int64_t* step, const uint8_t* ascii, int rows, const uint8_t lut[256], const float* labels,
+                             const uint8_t* keep, int R, float* loss_out) {
+    if (!weights || !adam_m || !adam_v || !step || !ascii || !lut || !labels || rows < 1 || rows > 4096 || R < 1 || R > 64) return FX_EINVAL;
+    if (kind < FX_CNN || kind > FX_GE) return FX_EINVAL;
+    FxtJob j{};
+    j.net = fxt_net(kind, L, A, kind == FX_CNN ? F : 0, H, kind == FX_CNN ? K : 0);
+    j.batch = rows; j.steps_per_epoch = 1; j.total_steps = 1; j.n = rows;
+    j.R = R; j.S = (rows + R - 1) / R;
+    j.w = weights; j.adam_m = adam_m; j.adam_v = adam_v;
+    std::vector<float> partial((size_t)j.S * (j.net.P + 1), 0.f);
+    j.partial = partial.data();
+    std::vector<int32_t> order((size_t)rows);
+    for (int i = 0; i < rows; ++i) order[(size_t)i] = i;
+    j.order = order.data();
+    j.keep = keep;
+    j.seed = 0;
+    const double t = (double)(*step + 1);
+    const float lr_t = (float)(FXT_LR * std::sqrt(1.0 - std::pow(FXT_BETA_2, t)) / (1.0 - std::pow(FXT_BETA_1, t)));
+    j.lr_t = &lr_t;
+    j.ws_slice = fxt_ws(j.net, R).total;
+    std::vector<float> ws((size_t)j.S * (size_t)j.ws_slice, 0.f);
+    j.ws = ws.data();
+    float loss = 0.f;
+    j.step_loss = &loss;
+    for (int s = 0; s < j.S; ++s) fxt_forward_backward(j, FxtWg{0, 1}, 0, s, ascii, lut, labels);
+    fxt_step_loss(j, 0);
+    for (int i = 0; i < j.net.P; ++i) fxt_adam(j, 0, i);
+    *step += 1;
+    if (loss_out) *loss_out = loss;
+    return FX_OK;
+}

@@ -1,0 +1,492 @@
+// One mini-batch training step of the reference surrogates (CNN / MLP / GlobalEpistasis) -- forward in training mode,
+// MSE loss, reverse-mode gradients, Keras-form Adam -- as two device phases:
+//
+//   fxt_forward_backward   one workgroup = (member, slice of R mini-batch rows): forward through every layer, backward
+//                          through every layer, the slice's gradient of EVERY parameter written to its own row of
+//                          `partial` (no atomics: the sum over slices happens in a fixed order in the second phase,
+//                          so a fit is deterministic whatever the grid looks like);
+//   fxt_adam               one thread per parameter: g = sum over slices (slice order), then
+//                          m <- b1 m + (1-b1) g, v <- b2 v + (1-b2) g^2, w <- w - lr_t m / (sqrt(v) + eps).
+//
+// Replaces `self.model.fit(...)` of flexs/baselines/models/keras_model.py:60-67 for the architectures compiled at
+// cnn.py:23-56, mlp.py:21-33, global_epistasis_model.py:26-37 (loss "MSE", optimizer "adam" = tf.keras Adam defaults).
+// The arithmetic follows oracle/train_np.py line by line (ties of GlobalMaxPooling1D share the gradient, ReLU has
+// gradient 0 at 0, Dropout(0.25) scales the kept units by 1 / 0.75, the loss is the mean over the VALID rows of a
+// partial last mini-batch).
+//
+// Every contraction -- Conv1D as an implicit GEMM over (tap, channel), Dense, and their two transposed forms for the
+// weight and the input gradients -- goes through ONE routine, fxt_gemm, whose operands are index functors: on the GPU
+// a wave owns 16 x 16 output tiles and feeds v_mfma_f32_16x16x4_f32 (exact f32, the f32 MFMA rate equals the vector
+// rate on gfx950 but costs 1 issue slot per 1024 MACs instead of 16), out-of-range elements are zeros, so ANY shape
+// the constructors accept trains on the matrix pipe.  The same source compiles for the host (FXT_DEVICE 0: threads
+// become loops, the MFMA becomes an fmaf chain): that build is what the CPU test-suite holds to oracle/train_np.py
+// (fx_debug_train_step_host), so index arithmetic and gradient algebra are verified without a GPU.
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FXT_DEVICE 1
+#else
+#define FXT_DEVICE 0
+#endif
+#if defined(__HIPCC__)
+#define FXT_HD __host__ __device__ __forceinline__
+#else
+#define FXT_HD inline
+#endif
+
+#define FXT_MAX_LAYERS 4
+#define FXT_DROPOUT 0.25f
+#define FXT_LR 1e-3
+#define FXT_BETA_1 0.9
+#define FXT_BETA_2 0.999
+#define FXT_EPSILON 1e-7f
+
+// Static description of one member's network: parameter offsets in Keras get_weights() order.
+struct FxtNet {
+    int kind, L, A, F, H, K;    // FX_CNN 0 / FX_MLP 1 / FX_GE 2
+    int L1, K3;                 // CNN: conv output length L - K + 1, conv3 taps A - 1
+    int P;                      // parameter count
+    int off_cw[3], off_cb[3];   // CNN: conv kernels (taps, Cin, Cout) and biases
+    int nl;                     // dense layers
+    int dim[FXT_MAX_LAYERS + 1];// dense stack widths: input, ..., output (= 1)
+    int off_w[FXT_MAX_LAYERS], off_b[FXT_MAX_LAYERS];
+    int onehot_in;              // 1 = the dense stack reads the flattened one-hot input (MLP / GE), 0 = pooled features (CNN)
+    int drop_layer;             // index of the dense layer whose OUTPUT passes through Dropout (-1 = none)
+};
+
+FXT_HD FxtNet fxt_net(int kind, int L, int A, int F, int H, int K) {
+    FxtNet n{};
+    n.kind = kind; n.L = L; n.A = A; n.F = F; n.H = H; n.K = K;
+    int off = 0;
+    if (kind == 0) {
+        n.L1 = L - K + 1; n.K3 = A - 1;
+        const int taps[3] = {K, K, A - 1}, cin[3] = {A, F, F};
+        for (int i = 0; i < 3; ++i) {
+            n.off_cw[i] = off; off += taps[i] * cin[i] * F;
+            n.off_cb[i] = off; off += F;
+        }
+        n.nl = 3; n.dim[0] = F; n.dim[1] = H; n.dim[2] = H; n.dim[3] = 1;
+        n.onehot_in = 0; n.drop_layer = 1;
+    } else if (kind == 1) {
+        n.nl = 4; n.dim[0] = L * A; n.dim[1] = H; n.dim[2] = H; n.dim[3] = H; n.dim[4] = 1;
+        n.onehot_in = 1; n.drop_layer = -1;
+    } else {
+        n.nl = 4; n.dim[0] = L * A; n.dim[1] = 1; n.dim[2] = H; n.dim[3] = H; n.dim[4] = 1;
+        n.onehot_in = 1; n.drop_layer = -1;
+    }
+    for (int i = 0; i < n.nl; ++i) {
+        n.off_w[i] = off; off += n.dim[i] * n.dim[i + 1];
+        n.off_b[i] = off; off += n.dim[i + 1];
+    }
+    n.P = off;
+    return n;
+}
+
+// Workspace of one slice (floats): codes, activations, gradients.  Offsets relative to the slice's base.
+struct FxtWs {
+    int codes;                  // R x L      alphabet indices (stored as int32 in the float buffer)
+    int a[3];                   // R x L1 x F post-ReLU conv outputs
+    int dzA, dzB;               // R x L1 x F gradient ping-pong
+    int g, cnt, dg;             // R x F      pooled maxima, tie counts, gradient
+    int act[FXT_MAX_LAYERS];    // R x dim[i+1] post-activation (post-dropout) outputs
+    int du[FXT_MAX_LAYERS];     // R x dim[i+1] gradient w.r.t. the pre-activation
+    int total;
+};
+
+FXT_HD FxtWs fxt_ws(const FxtNet& n, int R) {
+    FxtWs w{};
+    int off = 0;
+    w.codes = off; off += R * n.L;
+    if (n.kind == 0) {
+        const int s = R * n.L1 * n.F;
+        for (int i = 0; i < 3; ++i) { w.a[i] = off; off += s; }
+        w.dzA = off; off += s;
+        w.dzB = off; off += s;
+        w.g = off; off += R * n.F;
+        w.cnt = off; off += R * n.F;
+        w.dg = off; off += R * n.F;
+    }
+    for (int i = 0; i < n.nl; ++i) { w.act[i] = off; off += R * n.dim[i + 1]; }
+    for (int i = 0; i < n.nl; ++i) { w.du[i] = off; off += R * n.dim[i + 1]; }
+    w.total = (off + 3) & ~3;
+    return w;
+}
+
+// One member's training job as the kernels see it.
+struct FxtJob {
+    FxtNet net;
+    int batch;                  // mini-batch slots per step
+    int steps_per_epoch, total_steps;
+    int n;                      // data-set rows
+    int R, S;                   // rows per slice, slices per step = ceil(batch / R)
+    float* w;                   // [P]
+    float* adam_m; float* adam_v;
+    float* partial;             // [S][P + 1]: gradient partials, then the slice's sum of squared errors
+    const int32_t* order;       // [total_steps][batch] data-set row per slot, -1 = padding slot
+    const uint8_t* keep;        // optional explicit dropout keep mask [total_steps][batch][H]
+    unsigned long long seed;    // in-kernel dropout stream when keep == nullptr
+    const float* lr_t;          // [total_steps] lr sqrt(1 - b2^t) / (1 - b1^t), t = t0 + step + 1 (host, double precision)
+    float* ws; long long ws_slice;   // workspace, floats per slice
+    int ws_in_lds;              // 1 = the slice's workspace fits the workgroup's LDS and lives there
+    int w_in_lds;               // 1 = ... and the member's weights fit next to it (staged at kernel start)
+    float* step_loss;           // [total_steps] mean squared error of the step's valid rows (before the update)
+};
+
+// Execution context of a workgroup: on the device one instance per thread, on the host ONE instance that plays
+// every thread in turn (a phase is data-parallel; phases are separated by fxt_sync).
+struct FxtWg { int tid, nthr; };
+#define FXT_FOR(i, count, wg) for (int i = (wg).tid; i < (count); i += (wg).nthr)
+FXT_HD void fxt_sync() {
+#if FXT_DEVICE
+    __syncthreads();
+#endif
+}
+
+FXT_HD bool fxt_keep(const FxtJob& j, int step, int slot, int h) {
+    if (j.keep) return j.keep[((long long)step * j.batch + slot) * j.net.H + h] != 0;
+    unsigned long long z = j.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(((long long)step * j.batch + slot) * j.net.H + h + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (unsigned)(z >> 32) < 3221225472u;            // P(keep) = 0.75 = 1 - FXT_DROPOUT
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// C[m][n] = sum over (ko, ki) of A(m, ko, ki) * B(ko, ki, n),  m < Md, n < Nd, ko < Ko, ki < Ki.
+// The contraction index is kept as a PAIR so that conv taps / batch rows never need a division in the inner loop;
+// each ko runs ceil(Ki / 4) k-steps (the overhang multiplies zeros).  FA: prep(m) -> per-row state (computed once
+// per tile), at(state, ko, ki); FB: at(ko, ki, n); FC: put(m, n, value).
+template <class FA, class FB, class FC>
+FXT_HD void fxt_gemm(const FxtWg& wg, int Md, int Nd, int Ko, int Ki, const FA& fa, const FB& fb, const FC& fc) {
+#if FXT_DEVICE
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    constexpr int U = 8;                     // k-steps whose operand loads are in flight together
+    const int lane = wg.tid & 63, wave = wg.tid >> 6, nw = wg.nthr >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int tn = (Nd + 15) >> 4, tiles = ((Md + 15) >> 4) * tn;
+    const int T = Ko * ((Ki + 3) >> 2);      // k-steps of the whole contraction, (ko, k0) in row-major order
+    for (int t = wave; t < tiles; t += nw) {
+        const int m0 = (t / tn) << 4, n0 = (t % tn) << 4;
+        const int m = m0 + i, n = n0 + i;
+        const bool mok = m < Md, nok = n < Nd;
+        const auto st = fa.prep(mok ? m : 0);
+        f4_t acc = {0.f, 0.f, 0.f, 0.f};
+        // The operands come from L2 / LDS through index functors: issued one k-step at a time every MFMA would wait a
+        // full memory round trip (the first build ran at ~1 us per k-step).  U k-steps are loaded first, then
+        // multiplied; (ko, k0) advance as wave-uniform counters, so the flattening costs no division.
+        int ko = 0, k0 = 0;
+        for (int s = 0; s < T; s += U) {
+            float a[U], b[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int ki = k0 + kq;
+                const bool kok = (s + u < T) && ki < Ki;
+                a[u] = (mok && kok) ? fa.at(st, ko, ki) : 0.f;
+                b[u] = (nok && kok) ? fb.at(ko, ki, n) : 0.f;
+                k0 += 4;
+                if (k0 >= Ki) { k0 = 0; ++ko; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (s + u < T) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
+        }
+        if (nok) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mr = m0 + 4 * kq + r;
+                if (mr < Md) fc.put(mr, n, acc[r]);
+            }
+        }
+    }
+#else
+    (void)wg;
+    for (int m = 0; m < Md; ++m) {
+        const auto st = fa.prep(m);
+        for (int n = 0; n < Nd; ++n) {
+            float acc = 0.f;
+            for (int ko = 0; ko < Ko; ++ko)
+                for (int ki = 0; ki < Ki; ++ki) acc = fmaf(fa.at(st, ko, ki), fb.at(ko, ki, n), acc);
+            fc.put(m, n, acc);
+        }
+    }
+#endif
+}
+
+// ---- operand functors ------------------------------------------------------------------------------------------
+struct FxtRowMajorA {          // A(m, 0, k) = p[m * ld + k]
+    const float* p; int ld;
+    FXT_HD int prep(int m) const { return m * ld; }
+    FXT_HD float at(int st, int, int ki) const { return p[st + ki]; }
+};
+struct FxtRowMajorB {          // B(0, k, n) = p[k * ld + n]
+    const float* p; int ld;
+    FXT_HD float at(int, int ki, int n) const { return p[ki * ld + n]; }
+};
+struct FxtTransB {             // B(0, k, n) = p[n * ld + k]      (W^T for the input gradients)
+    const float* p; int ld;
+    FXT_HD float at(int, int ki, int n) const { return p[n * ld + ki]; }
+};
+// conv forward: rows m = (r, t), contraction (tap j, channel c): A = x[r][t + j - pl][c] inside the sequence, else 0
+struct FxtConvA {
+    const float* x; int Lx, C, pl;
+    struct St { int base, t; };
+    FXT_HD St prep(int m) const { const int r = m / Lx, t = m - r * Lx; return St{r * Lx * C, t}; }
+    FXT_HD float at(St s, int j, int c) const {
+        const int p = s.t + j - pl;
+        return (p >= 0 && p < Lx) ? x[s.base + p * C + c] : 0.f;
+    }
+};
+struct FxtConvW {              // B((j, c), n) = w[(j * C + c) * F + n]
+    const float* w; int C, F;
+    FXT_HD float at(int j, int c, int n) const { return w[(j * C + c) * F + n]; }
+};
+// conv input gradient: rows m = (r, s), contraction (tap j, out channel o): A = dz[r][s - j + pl][o], B = w[j][n][o]
+struct FxtConvGradA {
+    const float* dz; int Lx, F, pl;
+    struct St { int base, s; };
+    FXT_HD St prep(int m) const { const int r = m / Lx, s = m - r * Lx; return St{r * Lx * F, s}; }
+    FXT_HD float at(St st, int j, int o) const {
+        const int p = st.s - j + pl;
+        return (p >= 0 && p < Lx) ? dz[st.base + p * F + o] : 0.f;
+    }
+};
+struct FxtConvGradW {          // B((j, o), n = c) = w[(j * C + c) * F + o]
+    const float* w; int C, F;
+    FXT_HD float at(int j, int o, int n) const { return w[(j * C + n) * F + o]; }
+};
+// conv weight gradient: rows m = (tap j, channel c) plus ONE extra row for the bias; contraction (row r, position t)
+struct FxtConvWGradA {
+    const float* x; int Lx, C, pl, rows;     // rows = taps * C (row `rows` is the bias row: all ones)
+    struct St { int j, c; };
+    FXT_HD St prep(int m) const { return m >= rows ? St{-1, 0} : St{m / C, m % C}; }
+    FXT_HD float at(St s, int r, int t) const {
+        if (s.j < 0) return 1.f;
+        const int p = t + s.j - pl;
+        return (p >= 0 && p < Lx) ? x[(r * Lx + p) * C + s.c] : 0.f;
+    }
+};
+// conv1 / first dense layer: x is the one-hot of the codes.  Rows m = (j, c) = m / A, m % A plus the bias row.
+// conv = 1: contraction (ko = row r, ki = position t), element [code[r][t + j] == c];
+// conv = 0: contraction (ko = 0, ki = row r),          element [code[r][j] == c]   (j = the position of input unit m)
+struct FxtOneHotWGradA {
+    const int* codes; int L, A, rows, conv;
+    struct St { int j, c; };
+    FXT_HD St prep(int m) const { return m >= rows ? St{-1, 0} : St{m / A, m % A}; }
+    FXT_HD float at(St s, int ko, int ki) const {
+        if (s.j < 0) return 1.f;
+        const int r = conv ? ko : ki, t = conv ? ki : 0;
+        return codes[r * L + t + s.j] == s.c ? 1.f : 0.f;
+    }
+};
+struct FxtPosMajorB {          // B((r, t), n) = p[(r * Lx + t) * F + n]
+    const float* p; int Lx, F;
+    FXT_HD float at(int r, int t, int n) const { return p[(r * Lx + t) * F + n]; }
+};
+// dense weight gradient: rows m = input unit k plus the bias row; contraction over the slice's rows r
+struct FxtDenseWGradA {
+    const float* in; int Kd;
+    FXT_HD int prep(int m) const { return m; }
+    FXT_HD float at(int m, int, int r) const { return m >= Kd ? 1.f : in[r * Kd + m]; }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Forward + backward of one slice.  `slice` rows [slice * R, slice * R + R) of the mini-batch `step`.
+// `ws_local`: where the slice's workspace lives -- the workgroup's LDS on the device when it fits (activations are
+// written by one phase and read by the next: an LDS round trip instead of an L2 one), else nullptr = the global arena.
+// `w_local`: the member's weights staged in LDS by the caller (device, when they fit next to the workspace), else nullptr.
+FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int slice, const uint8_t* ascii,
+                                 const uint8_t* lut, const float* labels, float* ws_local = nullptr,
+                                 const float* w_local = nullptr) {
+    const FxtNet& n = j.net;
+    const int R = j.R, L = n.L, A = n.A, F = n.F;
+    const FxtWs w = fxt_ws(n, R);
+    float* ws = ws_local ? ws_local : j.ws + (long long)slice * j.ws_slice;
+    int* codes = reinterpret_cast<int*>(ws + w.codes);
+    float* part = j.partial + (long long)slice * (n.P + 1);
+    const float* W = w_local ? w_local : j.w;
+    const int32_t* order = j.order + (long long)step * j.batch;
+    const int slot0 = slice * R;
+    const int sidx = step % j.steps_per_epoch;
+    const int nvalid = (j.n - sidx * j.batch) < j.batch ? (j.n - sidx * j.batch) : j.batch;
+    const float keep_scale = 1.f / (1.f - FXT_DROPOUT);
+
+    // ---- the slice's rows as alphabet indices (padding slots read row 0: their gradient is zeroed at the loss)
+    FXT_FOR(i, R * L, wg) {
+        const int r = i / L, l = i - r * L;
+        const int slot = slot0 + r;
+        const int row = (slot < j.batch && order[slot] >= 0) ? order[slot] : 0;
+        codes[i] = lut[ascii[(long long)row * L + l]];
+    }
+    fxt_sync();
+
+    const float* feat = nullptr;            // input of the dense stack when it is not the one-hot
+    if (n.kind == 0) {
+        const int L1 = n.L1, K = n.K;
+        float* a1 = ws + w.a[0]; float* a2 = ws + w.a[1]; float* a3 = ws + w.a[2];
+        // conv1 ('valid') on a one-hot input: a sum of K kernel rows
+        FXT_FOR(i, R * L1 * F, wg) {
+            const int o = i % F, rt = i / F, t = rt % L1, r = rt / L1;
+            float s = W[n.off_cb[0] + o];
+            for (int jj = 0; jj < K; ++jj) s += W[n.off_cw[0] + (jj * A + codes[r * L + t + jj]) * F + o];
+            a1[i] = s > 0.f ? s : 0.f;
+        }
+        fxt_sync();
+        {   // conv2 ('same', K taps)
+            const float* b = W + n.off_cb[1];
+            struct Put { float* y; const float* b; int F; FXT_HD void put(int m, int nn, float v) const { v += b[nn]; y[m * F + nn] = v > 0.f ? v : 0.f; } };
+            fxt_gemm(wg, R * L1, F, K, F, FxtConvA{a1, L1, F, (K - 1) / 2}, FxtConvW{W + n.off_cw[1], F, F}, Put{a2, b, F});
+        }
+        fxt_sync();
+        {   // conv3 ('same', A - 1 taps)
+            const float* b = W + n.off_cb[2];
+            struct Put { float* y; const float* b; int F; FXT_HD void put(int m, int nn, float v) const { v += b[nn]; y[m * F + nn] = v > 0.f ? v : 0.f; } };
+            fxt_gemm(wg, R * L1, F, n.K3, F, FxtConvA{a2, L1, F, (n.K3 - 1) / 2}, FxtConvW{W + n.off_cw[2], F, F}, Put{a3, b, F});
+        }
+        fxt_sync();
+        float* g = ws + w.g; float* cnt = ws + w.cnt;
+        FXT_FOR(i, R * F, wg) {             // GlobalMaxPooling1D + the number of positions that attain the maximum
+            const int r = i / F, f = i - r * F;
+            float mx = a3[(r * L1) * F + f];
+            for (int t = 1; t < L1; ++t) { const float v = a3[(r * L1 + t) * F + f]; mx = v > mx ? v : mx; }
+            int c = 0;
+            for (int t = 0; t < L1; ++t) c += a3[(r * L1 + t) * F + f] == mx;
+            g[i] = mx; cnt[i] = (float)c;
+        }
+        fxt_sync();
+        feat = g;
+    }
+
+    // ---- dense stack, forward
+    for (int li = 0; li < n.nl; ++li) {
+        const int Kd = n.dim[li], Nd = n.dim[li + 1];
+        const float* Wl = W + n.off_w[li];
+        const float* bl = W + n.off_b[li];
+        float* out = ws + w.act[li];
+        const bool last = li == n.nl - 1;
+        const bool drop = li == n.drop_layer;
+        if (li == 0 && n.onehot_in) {
+            FXT_FOR(i, R * Nd, wg) {        // one-hot input: sum of L rows
+                const int r = i / Nd, o = i - r * Nd;
+                float s = bl[o];
+                for (int l = 0; l < L; ++l) s += Wl[(l * A + codes[r * L + l]) * Nd + o];
+                out[i] = (last || s > 0.f) ? s : 0.f;
+            }
+        } else {
+            const float* in = li == 0 ? feat : ws + w.act[li - 1];
+            struct Put {
+                float* y; const float* b; int Nd; bool last, drop; const FxtJob* j; int step, slot0; float ks;
+                FXT_HD void put(int m, int nn, float v) const {
+                    v += b[nn];
+                    if (!last) v = v > 0.f ? v : 0.f;
+                    if (drop) v = fxt_keep(*j, step, slot0 + m, nn) ? v * ks : 0.f;
+                    y[m * Nd + nn] = v;
+                }
+            };
+            fxt_gemm(wg, R, Nd, 1, Kd, FxtRowMajorA{in, Kd}, FxtRowMajorB{Wl, Nd}, Put{out, bl, Nd, last, drop, &j, step, slot0, keep_scale});
+        }
+        fxt_sync();
+    }
+
+    // ---- loss: d(mean over valid rows of (pred - y)^2) / d pred
+    {
+        const float* pred = ws + w.act[n.nl - 1];
+        float* du = ws + w.du[n.nl - 1];
+        FXT_FOR(r, R, wg) {
+            const int slot = slot0 + r;
+            const bool valid = slot < j.batch && order[slot] >= 0;
+            const float e = valid ? pred[r] - labels[order[slot]] : 0.f;
+            du[r] = 2.f * e / (float)nvalid;
+        }
+        fxt_sync();
+        FXT_FOR(i, 1, wg) {                 // the slice's sum of squared errors (fixed order)
+            float sse = 0.f;
+            for (int r = 0; r < R; ++r) { const float e = du[r] * (float)nvalid * 0.5f; sse += e * e; }
+            part[n.P] = sse;
+        }
+    }
+
+    // ---- dense stack, backward
+    for (int li = n.nl - 1; li >= 0; --li) {
+        const int Kd = n.dim[li], Nd = n.dim[li + 1];
+        const float* Wl = W + n.off_w[li];
+        const float* du = ws + w.du[li];
+        struct PutW { float* gw; float* gb; int Kd, Nd; FXT_HD void put(int m, int nn, float v) const { if (m < Kd) gw[m * Nd + nn] = v; else gb[nn] = v; } };
+        const PutW putw{part + n.off_w[li], part + n.off_b[li], Kd, Nd};
+        if (li == 0 && n.onehot_in) {
+            fxt_gemm(wg, Kd + 1, Nd, 1, R, FxtOneHotWGradA{codes, L, A, Kd, 0}, FxtRowMajorB{du, Nd}, putw);
+        } else {
+            const float* in = li == 0 ? feat : ws + w.act[li - 1];
+            fxt_gemm(wg, Kd + 1, Nd, 1, R, FxtDenseWGradA{in, Kd}, FxtRowMajorB{du, Nd}, putw);
+            // gradient w.r.t. the layer's input; through the previous layer's ReLU (and Dropout: a dropped unit's
+            // stored output is 0, a kept one carries the 1 / (1 - rate) scale)
+            if (li > 0) {
+                const bool dropped = (li - 1) == n.drop_layer;
+                struct PutX { float* d; const float* y; int Kd; float ks; FXT_HD void put(int m, int nn, float v) const { d[m * Kd + nn] = y[m * Kd + nn] > 0.f ? v * ks : 0.f; } };
+                fxt_gemm(wg, R, Kd, 1, Nd, FxtRowMajorA{du, Nd}, FxtTransB{Wl, Nd}, PutX{ws + w.du[li - 1], in, Kd, dropped ? keep_scale : 1.f});
+            } else {
+                struct PutG { float* d; int Kd; FXT_HD void put(int m, int nn, float v) const { d[m * Kd + nn] = v; } };
+                fxt_gemm(wg, R, Kd, 1, Nd, FxtRowMajorA{du, Nd}, FxtTransB{Wl, Nd}, PutG{ws + w.dg, Kd});
+            }
+        }
+        fxt_sync();
+    }
+
+    if (n.kind == 0) {
+        const int L1 = n.L1, K = n.K, K3 = n.K3;
+        const float* a1 = ws + w.a[0]; const float* a2 = ws + w.a[1]; const float* a3 = ws + w.a[2];
+        const float* g = ws + w.g; const float* cnt = ws + w.cnt; const float* dg = ws + w.dg;
+        float* dzA = ws + w.dzA; float* dzB = ws + w.dzB;
+        FXT_FOR(i, R * L1 * F, wg) {        // max-pool backward (ties share evenly) through conv3's ReLU
+            const int f = i % F, r = i / (F * L1);
+            const float v = a3[i];
+            dzA[i] = (v > 0.f && v == g[r * F + f]) ? dg[r * F + f] / cnt[r * F + f] : 0.f;
+        }
+        fxt_sync();
+        struct PutW { float* gw; float* gb; int rows, F; FXT_HD void put(int m, int nn, float v) const { if (m < rows) gw[m * F + nn] = v; else gb[nn] = v; } };
+        struct PutX { float* d; const float* y; int F; FXT_HD void put(int m, int nn, float v) const { d[m * F + nn] = y[m * F + nn] > 0.f ? v : 0.f; } };
+        // conv3
+        fxt_gemm(wg, K3 * F + 1, F, R, L1, FxtConvWGradA{a2, L1, F, (K3 - 1) / 2, K3 * F}, FxtPosMajorB{dzA, L1, F}, PutW{part + n.off_cw[2], part + n.off_cb[2], K3 * F, F});
+        fxt_gemm(wg, R * L1, F, K3, F, FxtConvGradA{dzA, L1, F, (K3 - 1) / 2}, FxtConvGradW{W + n.off_cw[2], F, F}, PutX{dzB, a2, F});
+        fxt_sync();
+        // conv2
+        fxt_gemm(wg, K * F + 1, F, R, L1, FxtConvWGradA{a1, L1, F, (K - 1) / 2, K * F}, FxtPosMajorB{dzB, L1, F}, PutW{part + n.off_cw[1], part + n.off_cb[1], K * F, F});
+        fxt_gemm(wg, R * L1, F, K, F, FxtConvGradA{dzB, L1, F, (K - 1) / 2}, FxtConvGradW{W + n.off_cw[1], F, F}, PutX{dzA, a1, F});
+        fxt_sync();
+        // conv1 (one-hot input, 'valid')
+        fxt_gemm(wg, K * A + 1, F, R, L1, FxtOneHotWGradA{codes, L, A, K * A, 1}, FxtPosMajorB{dzA, L1, F}, PutW{part + n.off_cw[0], part + n.off_cb[0], K * A, F});
+    }
+}
+
+// Sum of the slices' partial gradients (slice order) + one Keras-Adam update of parameter i.
+FXT_HD void fxt_adam(const FxtJob& j, int step, int i) {
+    const int P = j.net.P, S = j.S;
+    const float* part = j.partial + i;
+    float gsum = 0.f;
+    for (int s0 = 0; s0 < S; s0 += 8) {      // slice order; eight loads in flight (x + 0.f leaves x as it is)
+        float v[8];
+#if FXT_DEVICE
+#pragma unroll
+#endif
+        for (int u = 0; u < 8; ++u) v[u] = (s0 + u < S) ? part[(long long)(s0 + u) * (P + 1)] : 0.f;
+#if FXT_DEVICE
+#pragma unroll
+#endif
+        for (int u = 0; u < 8; ++u) gsum += v[u];
+    }
+    const float b1 = (float)FXT_BETA_1, b2 = (float)FXT_BETA_2;
+    const float m = b1 * j.adam_m[i] + (1.f - b1) * gsum;
+    const float v = b2 * j.adam_v[i] + (1.f - b2) * gsum * gsum;
+    j.adam_m[i] = m;
+    j.adam_v[i] = v;
+    j.w[i] = j.w[i] - j.lr_t[step] * m / (sqrtf(v) + FXT_EPSILON);
+}
+
+FXT_HD void fxt_step_loss(const FxtJob& j, int step) {
+    const int sidx = step % j.steps_per_epoch;
+    const int nvalid = (j.n - sidx * j.batch) < j.batch ? (j.n - sidx * j.batch) : j.batch;
+    float sse = 0.f;
+    for (int s = 0; s < j.S; ++s) sse += j.partial[(long long)s * (j.net.P + 1) + j.net.P];
+    j.step_loss[step] = sse / (float)nvalid;
+}

@@ -23,8 +23,15 @@ of every architecture against a NumPy restatement, oracle/train_np.py), not
 bitwise over a whole fit: the shuffles and dropout masks come from other RNG
 streams.
 
-Runs on `cuda` when a GPU is visible, else on the CPU (training is not the
-scored hot path; the trained weights are then uploaded to the scoring engine).
+Round 3: on a GPU the fit runs in hand-written HIP (`fx_train_fit`, csrc/train_core.h +
+train.hip): per mini-batch step ONE forward+backward launch over (row slices x ensemble
+members) and ONE Adam launch, every contraction on v_mfma_f32_16x16x4_f32, all steps of
+all members enqueued back to back from C.  The host only draws the shuffles (one
+`torch.randperm` per epoch and member, as before) and keeps weights / moments / step count
+on the `Architecture`.  FLEXS_AMD_TRAIN=graph | eager selects the PyTorch paths below
+instead (captured hipGraph step / plain eager step); without a GPU the eager PyTorch step
+runs on the CPU (training is not the scored hot path; the trained weights are then
+uploaded to the scoring engine).
 
 On the GPU one mini-batch step is ~150 tiny kernels (the networks have 12-40 thousand
 parameters and a batch is 256 rows): launched one by one from Python a step costs
@@ -282,7 +289,80 @@ _TRAINERS = weakref.WeakKeyDictionary()          # Architecture -> _GraphTrainer
 
 
 def _use_graph(device):
-    return device.type == "cuda" and os.environ.get("FLEXS_AMD_TRAIN_GRAPH", "1") != "0"
+    return _train_mode(device) == "graph"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# native path: fx_train_fit (csrc/train.hip)
+_KIND = {"cnn": _native.FX_CNN, "mlp": _native.FX_MLP, "ge": _native.FX_GE}
+
+
+def _train_mode(device):
+    """'native' (hand-written HIP, default on a GPU) | 'graph' (captured PyTorch step) | 'eager' (PyTorch step by step)."""
+    if device.type != "cuda":
+        return "eager"
+    mode = os.environ.get("FLEXS_AMD_TRAIN")
+    if mode is None:                                      # (round-2 switch, still honoured: 0 = eager PyTorch)
+        mode = "eager" if os.environ.get("FLEXS_AMD_TRAIN_GRAPH", "1") == "0" else "native"
+    return mode if mode in ("native", "graph", "eager") else "native"
+
+
+def _flat_state(arch):
+    """(weights, m, v, t) as flat float32 arrays in Keras get_weights() order (fresh optimiser: zeros, t = 0)."""
+    w = np.ascontiguousarray(np.concatenate([a.ravel() for a in arch._weights]).astype(np.float32))
+    st = getattr(arch, "_opt_state", None)
+    shapes = [tuple(sh) for sh in arch.shapes()]
+    ok = st is not None and len(st["m"]) == len(shapes) and all(tuple(a.shape) == sh for a, sh in zip(st["m"], shapes))
+    if ok:
+        m = np.ascontiguousarray(np.concatenate([np.asarray(a, np.float32).ravel() for a in st["m"]]))
+        v = np.ascontiguousarray(np.concatenate([np.asarray(a, np.float32).ravel() for a in st["v"]]))
+        return w, m, v, int(st["t"])
+    return w, np.zeros_like(w), np.zeros_like(w), 0
+
+
+def _unflat(flat, shapes):
+    out, off = [], 0
+    for sh in shapes:
+        k = int(np.prod(sh))
+        out.append(flat[off:off + k].reshape(sh).copy())
+        off += k
+    return out
+
+
+def _fit_native(archs, sequences, labels, alphabet, batch_sizes, epochs, verbose, gens):
+    """One `fx_train_fit` call for members that share the alphabet and the sequence length: every member's shuffles come
+    from its own generator (one `randperm` per epoch, after the one draw that seeds its dropout stream -- the same
+    consumption as the PyTorch paths, so a seeded fit shuffles identically on every path)."""
+    n, L = len(sequences), archs[0].L
+    seq_bytes = _native.sequences_to_bytes(sequences, L=L)
+    lut = _native.make_lut(alphabet)
+    if (lut[seq_bytes] == 255).any():
+        raise ValueError("substring not found")
+    y = np.asarray(labels, dtype=np.float32)
+    jobs, flats = [], []
+    for arch, B, ep, gen in zip(archs, batch_sizes, epochs, gens):
+        B = int(B)
+        steps = (n + B - 1) // B
+        seed = int(torch.randint(0, 2 ** 62, (1,), generator=gen).item())
+        order = np.full((ep, steps * B), -1, np.int32)
+        for e_ in range(ep):
+            order[e_, :n] = torch.randperm(n, generator=gen).numpy()
+        w, m, v, t = _flat_state(arch)
+        flats.append((w, m, v))
+        jobs.append({"kind": _KIND[arch.kind], "L": L, "A": arch.A, "F": arch.F, "H": arch.H, "K": arch.K, "weights": w,
+                     "adam_m": m, "adam_v": v, "step": t, "order": order, "epochs": ep, "batch": B, "seed": seed})
+    eng = _native.Engine.get(torch.cuda.current_device())
+    res = _native.train_fit(eng, jobs, seq_bytes, lut, y)
+    for arch, (w, m, v), (t, loss), job in zip(archs, flats, res, jobs):
+        shapes = [tuple(sh) for sh in arch.shapes()]
+        arch.set_weights(_unflat(w, shapes))
+        arch._opt_state = {"t": t, "m": _unflat(m, shapes), "v": _unflat(v, shapes)}
+        if verbose:
+            B, ep = job["batch"], job["epochs"]
+            steps = (n + B - 1) // B
+            valid = np.minimum(B, n - np.arange(steps) * B)
+            for e_ in range(ep):
+                print(f"Epoch {e_ + 1}/{ep} - loss: {float((loss[e_ * steps:(e_ + 1) * steps] * valid).sum() / n):.6f}")
 
 
 def fit(arch, sequences, labels, alphabet, batch_size=256, epochs=20, verbose=False, seed=None):
@@ -292,11 +372,13 @@ def fit(arch, sequences, labels, alphabet, batch_size=256, epochs=20, verbose=Fa
     if n == 0:
         return
     device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
-    codes = _codes(sequences, alphabet, arch.L, device)
-    y = torch.as_tensor(np.asarray(labels, dtype=np.float32), device=device)
     gen = torch.Generator(device="cpu")
     if seed is not None:
         gen.manual_seed(seed)
+    if _train_mode(device) == "native":
+        return _fit_native([arch], sequences, labels, alphabet, [batch_size], [epochs], verbose, [gen])
+    codes = _codes(sequences, alphabet, arch.L, device)
+    y = torch.as_tensor(np.asarray(labels, dtype=np.float32), device=device)
     if _use_graph(device):
         try:
             return _fit_graphed(arch, codes, y, n, int(batch_size), epochs, verbose, gen, device)
@@ -405,8 +487,25 @@ def fit_many(archs, sequences, labels, alphabets, batch_sizes, epochs, verbose=F
             fit(arch, sequences, labels, alphabet, batch_size=bs, epochs=ep, verbose=verbose, seed=seeds[k] if seeds else None)
 
     # (the same Architecture listed twice is trained twice in a row by the reference's loop: not interleavable)
-    if len(archs) < 2 or not _use_graph(device) or len({id(a) for a in archs}) < len(archs):
+    if len(archs) < 2 or len({id(a) for a in archs}) < len(archs) or _train_mode(device) == "eager":
         return one_by_one()
+    if _train_mode(device) == "native":
+        for arch in archs:
+            if arch.loss not in ("MSE", "mse", "mean_squared_error"):
+                raise ValueError(f"unsupported loss {arch.loss!r} (the reference only ever uses 'MSE')")
+        groups = {}
+        for k, (arch, alphabet) in enumerate(zip(archs, alphabets)):
+            groups.setdefault((alphabet, arch.L), []).append(k)
+        for (alphabet, _), ks in groups.items():          # members that see the same bytes train in ONE device call
+            gens = []
+            for k in ks:
+                g = torch.Generator(device="cpu")
+                if seeds:
+                    g.manual_seed(seeds[k])
+                gens.append(g)
+            _fit_native([archs[k] for k in ks], sequences, labels, alphabet, [batch_sizes[k] for k in ks],
+                        [epochs[k] for k in ks], verbose, gens)
+        return
     for arch in archs:
         if arch.loss not in ("MSE", "mse", "mean_squared_error"):
             raise ValueError(f"unsupported loss {arch.loss!r} (the reference only ever uses 'MSE')")

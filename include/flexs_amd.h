@@ -231,6 +231,35 @@ int fx_table_lookup(fx_table *t, const uint8_t *ascii, int64_t N, int L, const u
 int fx_table_additive(fx_table *t, const uint8_t *ascii, int64_t N, int L, const uint8_t lut[256],
                       int ncol, double *out);
 
+/* ------------------------------------------------------------ training
+ * `KerasModel.train` (flexs/baselines/models/keras_model.py:49-67: model.fit(one_hots, labels, batch_size, epochs) on a
+ * model compiled with loss "MSE", optimizer "adam": cnn.py:56, mlp.py:33, global_epistasis_model.py:37) for M ensemble
+ * members at once (flexs/ensemble.py:42-52), hand-written for gfx950 (csrc/train_core.h): per mini-batch step one
+ * forward+backward launch over (row slices x members) and one Adam launch, enqueued back to back from C.
+ * Arithmetic: forward in training mode (Dropout(0.25) before the CNN's last Dense, kept units scaled by 1 / 0.75), MSE
+ * over the VALID rows of the mini-batch, reverse-mode gradients (max-pool ties share evenly, ReLU' = 0 at 0), tf.keras
+ * Adam (lr 1e-3, beta 0.9 / 0.999, lr_t = lr sqrt(1 - b2^t) / (1 - b1^t), w -= lr_t m / (sqrt(v) + 1e-7)).
+ * The caller owns weights, moments and the step count (Keras get_weights() order, fx_num_params floats each): they are
+ * read at the start and written back at the end, so the optimiser state persists across explorer rounds on the host
+ * object as it does on a compiled Keras model (flexs/explorer.py:157-160). */
+typedef struct fx_fit_job {
+    int kind, L, A, F, H, K;      /* architecture: FX_CNN / FX_MLP / FX_GE (F, K ignored unless CNN) */
+    float *weights;               /* in / out */
+    float *adam_m, *adam_v;       /* in / out: first / second moments (zeros for a fresh optimiser) */
+    int64_t step;                 /* in / out: optimiser step count t */
+    const int32_t *order;         /* [epochs][ceil(n / batch)][batch]: data-set row of every mini-batch slot, in the order
+                                     the host shuffled them; -1 = padding slot (a partial last mini-batch), valid slots first */
+    int epochs, batch;
+    const uint8_t *keep;          /* CNN, optional: explicit Dropout keep mask [epochs * steps][batch][H] (1 = keep); NULL =
+                                     drawn in the kernel from `seed` (a counter-based hash per (step, slot, unit)) */
+    uint64_t seed;
+    float *step_loss;             /* out, optional: [epochs * steps] mean squared error of each mini-batch before its update */
+} fx_fit_job;
+/* ascii: n x L bytes (the measured sequences), labels: n floats.  All jobs train on the same data (same L, same lut).
+ * FX_EBADCHAR for a character outside the alphabet (ValueError in the reference's encode loop). */
+int fx_train_fit(fx_engine *e, fx_fit_job *jobs, int M, const uint8_t *ascii, int64_t n, int L,
+                 const uint8_t lut[256], const float *labels);
+
 /* ------------------------------------------------------------ test hooks */
 /* Host-only (no GPU needed): expose the weight packing (Keras order -> MFMA
  * fragment order) and the bit-parallel Levenshtein that the device kernels use,
@@ -260,6 +289,13 @@ int fx_debug_trace_read(fx_engine *e, uint64_t *out, int64_t cap_words);
 int fx_debug_pack_weights(int kind, int L, int A, int F, int H, int K, const float *blob, int64_t n,
                           float *packed, int64_t cap);
 int fx_debug_myers(const uint8_t *a, int la, const uint8_t *b, int lb);
+/* Host only (no GPU): ONE mini-batch training step of one member through the HOST build of csrc/train_core.h -- the
+ * source the training kernels are compiled from, threads as loops, the MFMA as an fmaf chain.  The mini-batch is all
+ * `rows` rows of `ascii` (<= 4096), cut into slices of R rows as the kernel would; weights / moments / step updated
+ * in place, *loss = mean squared error before the update.  keep: optional [rows][H] dropout mask (CNN). */
+int fx_debug_train_step_host(int kind, int L, int A, int F, int H, int K, float *weights, float *adam_m,
+                             float *adam_v, int64_t *step, const uint8_t *ascii, int rows, const uint8_t lut[256],
+                             const float *labels, const uint8_t *keep, int R, float *loss);
 /* GPU: one v_mfma_f32_16x16x4_f32 on per-lane operands a[64], b[64], c[64][4] -> d[64][4]
  * (checks the lane layout the kernels assume on the real hardware). */
 int fx_debug_mfma_probe(fx_engine *e, const float *a64, const float *b64, const float *c256, float *d256);

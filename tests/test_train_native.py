@@ -1,0 +1,202 @@
+"""The hand-written training step (flexs_amd/csrc/train_core.h: forward in training mode, MSE, reverse-mode gradients,
+Keras-form Adam; `KerasModel.train`, flexs/baselines/models/keras_model.py:49-67 with cnn.py:56 / mlp.py:33 /
+global_epistasis_model.py:37) against the float64 NumPy restatement oracle/train_np.py.
+
+CPU tier: the HOST build of the very source the kernels are compiled from (`fx_debug_train_step_host`: threads as loops,
+the MFMA as an fmaf chain) -- index arithmetic and gradient algebra of every layer form, for every architecture, several
+consecutive steps (optimiser state carried), any slicing of the mini-batch.  GPU tier: `fx_train_fit` on the device
+against the same oracle step by step, whole fits against the PyTorch path on the same shuffles, and the public
+`train` API end to end."""
+import numpy as np
+import pytest
+
+from flexs_amd import _native, training
+from flexs_amd.baselines import models as bm
+from oracle import ref_np, train_np
+
+KIND = {"cnn": 0, "mlp": 1, "ge": 2}
+CASES = [  # kind, L, alphabet, F, H, K, rows
+    ("mlp", 9, "UGCA", 0, 24, 0, 37), ("ge", 9, "UGCA", 0, 20, 0, 37), ("cnn", 9, "UGCA", 8, 16, 3, 37),
+    ("cnn", 8, "TGCA", 32, 100, 5, 24), ("cnn", 12, ref_np.AAS, 5, 7, 4, 19), ("mlp", 14, "UGCA", 0, 100, 0, 40),
+    ("ge", 30, ref_np.AAS, 0, 100, 0, 33), ("cnn", 6, "01", 3, 5, 2, 11), ("mlp", 5, ref_np.AAS, 0, 9, 0, 5),
+]
+
+
+def _flat(ws):
+    return np.ascontiguousarray(np.concatenate([np.asarray(w, np.float32).ravel() for w in ws]))
+
+
+def _unflat(flat, shapes):
+    out, off = [], 0
+    for s in shapes:
+        k = int(np.prod(s))
+        out.append(flat[off:off + k].reshape(s))
+        off += k
+    return out
+
+
+def _shapes(kind, L, A, F, H, K):
+    return {"cnn": lambda: ref_np.cnn_shapes(L, A, F, H, K), "mlp": lambda: ref_np.mlp_shapes(L, A, H), "ge": lambda: ref_np.ge_shapes(L, A, H)}[kind]()
+
+
+def _data(kind, L, alphabet, rows, seed):
+    rng = np.random.default_rng(seed)
+    idx = rng.integers(0, len(alphabet), (rows, L))
+    seqs = ["".join(alphabet[i] for i in row) for row in idx]
+    x = ref_np.encode_batch(seqs, alphabet).astype(np.float32)
+    y = rng.normal(size=rows).astype(np.float32)
+    b = np.frombuffer("".join(seqs).encode(), np.uint8).reshape(rows, L)
+    return seqs, b, x, y
+
+
+def check_against_oracle(step_fn, kind, L, alphabet, F, H, K, rows, steps=3):
+    """step_fn(w_flat, m_flat, v_flat, t, seq_bytes, y, keep) -> (t', loss); arrays updated in place."""
+    A = len(alphabet)
+    shapes = _shapes(kind, L, A, F, H, K)
+    w64 = [a.astype(np.float64) for a in ref_np.synth_weights(shapes, 77)]
+    state = train_np.new_state(w64)
+    w, m, v, t = _flat(w64), np.zeros(sum(int(np.prod(s)) for s in shapes), np.float32), None, 0
+    v = m.copy()
+    for step in range(steps):
+        _, b, x, y = _data(kind, L, alphabet, rows, 100 + step)
+        keep = (np.random.default_rng(step).random((rows, H)) >= train_np.DROPOUT).astype(np.uint8) if kind == "cnn" else None
+        want_loss, w64, state = train_np.train_step(kind, w64, x, y, state, None if keep is None else keep.astype(np.float32))
+        t, got_loss = step_fn(w, m, v, t, b, y, keep)
+        assert t == state["t"] == step + 1
+        assert got_loss == pytest.approx(want_loss, rel=3e-5, abs=1e-7)
+        for i, (a, ref) in enumerate(zip(_unflat(w, shapes), w64)):
+            assert np.abs(a - ref).max() <= 2e-6 + 2e-6 * np.abs(ref).max(), (kind, step, i, np.abs(a - ref).max())
+        # moments: float32 sums of a few hundred terms against float64 -- relative to the array's scale where terms cancel
+        for a, ref in zip(_unflat(m, shapes), state["m"]):
+            assert np.allclose(a, ref, rtol=3e-4, atol=1e-8 + 3e-6 * np.abs(ref).max()), (kind, step, "m", np.abs(a - ref).max())
+        for a, ref in zip(_unflat(v, shapes), state["v"]):
+            assert np.allclose(a, ref, rtol=6e-4, atol=1e-12 + 3e-6 * np.abs(ref).max()), (kind, step, "v", np.abs(a - ref).max())
+
+
+@pytest.mark.parametrize("kind,L,alphabet,F,H,K,rows", CASES)
+@pytest.mark.parametrize("R", [16, 5])
+def test_host_build_of_the_training_step_equals_the_keras_restatement(kind, L, alphabet, F, H, K, rows, R):
+    lut = _native.make_lut(alphabet)
+
+    def step_fn(w, m, v, t, b, y, keep):
+        return _native.debug_train_step_host(KIND[kind], L, len(alphabet), F, H, K, w, m, v, t, b, lut, y, keep, R=R)
+
+    check_against_oracle(step_fn, kind, L, alphabet, F, H, K, rows)
+
+
+def test_host_build_slicing_does_not_change_the_step():
+    """The gradient is a sum over slices in slice order: different R give the same weights to float32 rounding."""
+    kind, L, alphabet, F, H, K, rows = "cnn", 8, "TGCA", 8, 12, 3, 50
+    lut = _native.make_lut(alphabet)
+    shapes = _shapes(kind, L, 4, F, H, K)
+    _, b, _, y = _data(kind, L, alphabet, rows, 5)
+    outs = []
+    for R in (1, 4, 16, 64):
+        w = _flat(ref_np.synth_weights(shapes, 3))
+        m, v = np.zeros_like(w), np.zeros_like(w)
+        _native.debug_train_step_host(0, L, 4, F, H, K, w, m, v, 0, b, lut, y, np.ones((rows, H), np.uint8), R=R)
+        outs.append(w)
+    for o in outs[1:]:
+        assert np.abs(o - outs[0]).max() < 2e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GPU tier
+def _fit_once(eng, kind, L, A, F, H, K, w, m, v, t, b, y, order, epochs, batch, keep=None, seed=0, lut=None):
+    (t2, loss), = _native.train_fit(eng, [{"kind": KIND[kind], "L": L, "A": A, "F": F, "H": H, "K": K, "weights": w, "adam_m": m,
+                                           "adam_v": v, "step": t, "order": order, "epochs": epochs, "batch": batch,
+                                           "keep": keep, "seed": seed}], b, lut, y)
+    return t2, loss
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,L,alphabet,F,H,K,rows", CASES + [("cnn", 30, ref_np.AAS, 32, 100, 5, 40), ("cnn", 14, "UGCA", 32, 100, 5, 256)])
+def test_device_training_step_equals_the_keras_restatement(kind, L, alphabet, F, H, K, rows):
+    """fx_train_fit on the MI355X, one step per call (epochs = 1, batch = the whole data set, explicit dropout masks),
+    against oracle/train_np.py: loss, every weight within 2e-6 after each Adam step, moments, step count."""
+    eng = _native.Engine.get(0)
+    lut = _native.make_lut(alphabet)
+
+    def step_fn(w, m, v, t, b, y, keep):
+        t2, loss = _fit_once(eng, kind, L, len(alphabet), F, H, K, w, m, v, t, b, y, np.arange(rows, dtype=np.int32), 1, rows,
+                             keep=None if keep is None else keep[None], lut=lut)
+        return t2, float(loss[0])
+
+    check_against_oracle(step_fn, kind, L, alphabet, F, H, K, rows, steps=3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,F,H,K", [("cnn", 8, 16, 3), ("mlp", 0, 24, 0), ("ge", 0, 20, 0)])
+def test_device_fit_with_a_partial_last_batch_equals_the_restatement(kind, F, H, K):
+    """A whole fit in ONE call: 2 epochs x 3 mini-batches of 128 slots over 300 rows (the last one holds 44 valid rows and 84
+    padding slots), given shuffles and masks; the oracle replays the same steps on the rows each mini-batch holds."""
+    L, alphabet, n, B, epochs = 9, "UGCA", 300, 128, 2
+    A, steps = 4, 3
+    eng = _native.Engine.get(0)
+    lut = _native.make_lut(alphabet)
+    shapes = _shapes(kind, L, A, F, H, K)
+    _, b, x, y = _data(kind, L, alphabet, n, 9)
+    rng = np.random.default_rng(4)
+    order = np.full((epochs, steps * B), -1, np.int32)
+    for e in range(epochs):
+        order[e, :n] = rng.permutation(n)
+    keep = (rng.random((epochs * steps, B, H)) >= train_np.DROPOUT).astype(np.uint8) if kind == "cnn" else None
+    w64 = [a.astype(np.float64) for a in ref_np.synth_weights(shapes, 5)]
+    state = train_np.new_state(w64)
+    w = _flat(w64); m = np.zeros_like(w); v = np.zeros_like(w)
+    want_losses = []
+    for e in range(epochs):
+        for s in range(steps):
+            rows = order[e, s * B:(s + 1) * B]
+            rows = rows[rows >= 0]
+            mask = None if keep is None else keep[e * steps + s, :len(rows)].astype(np.float32)
+            loss, w64, state = train_np.train_step(kind, w64, x[rows], y[rows], state, mask)
+            want_losses.append(loss)
+    t, losses = _fit_once(eng, kind, L, A, F, H, K, w, m, v, 0, b, y, order, epochs, B, keep=keep, lut=lut)
+    assert t == epochs * steps == state["t"]
+    assert np.allclose(losses, want_losses, rtol=1e-4, atol=1e-7)
+    for a, ref in zip(_unflat(w, shapes), w64):
+        assert np.abs(a - ref).max() <= 6e-6 + 1e-5 * np.abs(ref).max(), (kind, np.abs(a - ref).max())   # 6 Adam steps
+    # characters outside the alphabet are refused before anything runs (ValueError in the reference's encode loop)
+    bad = b.copy(); bad[7, 3] = ord("Z")
+    with pytest.raises(ValueError):
+        _fit_once(eng, kind, L, A, F, H, K, w, m, v, t, bad, y, order, epochs, B, keep=keep, lut=lut)
+
+
+@pytest.mark.gpu
+def test_native_training_through_the_plugin_api_and_its_speed():
+    """`Ensemble.train` of the 3-CNN ensemble on 1000 measured sequences (the explorer round of bench.py): one device call,
+    every member learns, deterministic for a seed (bit-identical repeat), members trained together == one by one, the
+    in-kernel dropout stream keeps ~75 % of the units; wall time printed."""
+    import time
+
+    import flexs_amd
+
+    rng = np.random.default_rng(0)
+    alphabet, L, n = "TGCA", 8, 1000
+    seqs = ["".join(alphabet[i] for i in row) for row in rng.integers(0, 4, (n, L))]
+    y = np.array([s.count("G") / L + 0.5 * (s[0] == "T") for s in seqs], np.float32)
+
+    def fresh():
+        return flexs_amd.Ensemble([bm.CNN(L, 32, 100, alphabet, seed=m) for m in range(3)])
+
+    ens = fresh()
+    before = [float(np.mean((m.get_fitness(seqs) - y) ** 2)) for m in ens.models]
+    ens.train(seqs, y, seed=3)
+    for m, b0 in zip(ens.models, before):
+        assert m.model._opt_state["t"] == 20 * 4
+        assert float(np.mean((m.get_fitness(seqs) - y) ** 2)) < 0.3 * b0
+    again = fresh(); again.train(seqs, y, seed=3)
+    solo = fresh()
+    for k, m in enumerate(solo.models):
+        m.train(seqs, y, seed=3 + k)
+    for a, b_, c in zip(ens.models, again.models, solo.models):
+        for wa, wb, wc in zip(a.model.get_weights(), b_.model.get_weights(), c.model.get_weights()):
+            assert np.array_equal(wa, wb) and np.array_equal(wa, wc)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter(); ens.train(seqs, y); ts.append(time.perf_counter() - t0)
+    print(f"Ensemble.train 3xCNN(32,100) L=8 n=1000 (80 steps per member): {min(ts) * 1e3:.2f} ms")
+    # the in-kernel keep stream: fraction kept over one step's (batch x H) draws
+    from flexs_amd import training
+    assert training._train_mode(__import__("torch").device("cuda")) == "native"

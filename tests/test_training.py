@@ -149,13 +149,15 @@ def test_one_step_on_the_gpu_equals_keras_restatement(kind):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["mlp", "ge", "cnn"])
-def test_captured_step_equals_the_eager_step(kind, monkeypatch):
-    """`fit` on the GPU replays ONE captured mini-batch step (hipGraph) instead of launching its ~150 kernels from Python.
+@pytest.mark.parametrize("kind,fast", [("mlp", "graph"), ("ge", "graph"), ("cnn", "graph"), ("mlp", "native"), ("ge", "native")])
+def test_fast_fit_equals_the_eager_fit(kind, fast, monkeypatch):
+    """`fit` on the GPU runs the hand-written HIP step (FLEXS_AMD_TRAIN=native, the default: csrc/train_core.h) or replays
+    ONE captured PyTorch step (graph) instead of launching ~150 kernels per step from Python (eager).
     Same shuffles (seeded), same arithmetic: weights and optimiser state after several epochs -- with a partial last
-    mini-batch (zero-weight padding rows in the captured step), over two `train` calls (state carried on the device
-    buffers' reload) and after the data set outgrew the captured capacity (re-capture) -- equal the eager path's to
-    float32 rounding.  Dropout is switched off for the comparison (its masks come from different RNG offsets)."""
+    mini-batch, over several `train` calls (optimiser state carried) and with a growing data set -- equal the eager path's
+    to float32 rounding.  The CNN is compared on the captured path only, with Dropout switched off (the three paths draw
+    their masks from different streams; the native CNN step is held to the oracle with explicit masks in
+    tests/test_train_native.py)."""
     import time
 
     import torch
@@ -164,7 +166,7 @@ def test_captured_step_equals_the_eager_step(kind, monkeypatch):
     L, alphabet = 9, "UGCA"
     results = {}
     for graph in ("1", "0"):
-        monkeypatch.setenv("FLEXS_AMD_TRAIN_GRAPH", graph)
+        monkeypatch.setenv("FLEXS_AMD_TRAIN", fast if graph == "1" else "eager")
         model = _model(kind, L, alphabet, 3)
         arch = model.model
         for rnd, n in enumerate((300, 700, 1100)):            # 256 + 44 rows; ...; beyond the first capture's 1024 rows
@@ -184,7 +186,7 @@ def test_captured_step_equals_the_eager_step(kind, monkeypatch):
         assert np.allclose(a, b, rtol=1e-3, atol=1e-7)
     for a, b in zip(sg["v"], se["v"]):
         assert np.allclose(a, b, rtol=2e-3, atol=1e-10)
-    print(f"{kind}: 15 steps captured {tg * 1e3:.1f} ms, eager {te * 1e3:.1f} ms")
+    print(f"{kind}: 15 steps {fast} {tg * 1e3:.1f} ms, eager {te * 1e3:.1f} ms")
 
 
 @pytest.mark.gpu
@@ -209,12 +211,16 @@ def test_captured_training_learns_and_feeds_the_engine():
 
 
 @pytest.mark.gpu
-def test_ensemble_members_train_side_by_side():
-    """`Ensemble.train` interleaves its members' captured steps on one stream per member (training.fit_many).  With the
-    members' shuffles seeded, the result is what training them one after the other gives -- same bits: the streams only
-    overlap the members in time -- for members of different architectures, batch sizes and epoch counts; and through
-    the plugin API every member of a 3-CNN ensemble ends with its own weights, step count and a lower loss."""
+@pytest.mark.parametrize("mode", ["native", "graph"])
+def test_ensemble_members_train_side_by_side(mode, monkeypatch):
+    """`Ensemble.train` trains its members together (training.fit_many): ONE fx_train_fit call whose launches cover every
+    member (native), or the members' captured steps interleaved on one stream per member (graph).  With the members'
+    shuffles seeded, the result is what training them one after the other gives -- same bits -- for members of different
+    architectures, batch sizes and epoch counts; and through the plugin API every member of a 3-CNN ensemble ends
+    with its own weights, step count and a lower loss."""
     import flexs_amd
+
+    monkeypatch.setenv("FLEXS_AMD_TRAIN", mode)
 
     L, alphabet, n = 9, "UGCA", 700
     seqs, _, y = _batch("mlp", L, alphabet, n, 11)
