@@ -234,6 +234,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "trace")) return &e->trace;
     if (!std::strcmp(key, "ge_bytetab")) return &e->ge_bytetab;
     if (!std::strcmp(key, "wave_prio")) return &e->wave_prio;
+    if (!std::strcmp(key, "dense_pipe")) return &e->dense_pipe;
     if (!std::strcmp(key, "train_rows")) return &e->train_rows;
     if (!std::strcmp(key, "train_lds")) return &e->train_lds;
     if (!std::strcmp(key, "train_threads")) return &e->train_threads;

@@ -109,6 +109,7 @@ struct fx_engine {
     int64_t stage_bytes = 1;    // 1 = MLP (pair rows) / GE (byte table) tiles copy their 16 x L sequence bytes into per-wave LDS scratch with 16-byte loads (0 = byte loads from global memory: A/B)
     int64_t mlp_pair = 1;       // 1 = MLP layer 1 on a 4-letter alphabet gathers one pre-summed row per PAIR of positions (0 = one row per position: A/B)
     int64_t mlp_l1_mfma = 0;    // 1 = one-hot MLP layer 1 on MFMA instead of the LDS gather (A/B knob)
+    int64_t dense_pipe = 0;     // MLP (pair rows) / GE (byte table): 1 / 2 = the software-pipelined form (tile t + 1's first layer inside tile t's MFMA layers, 8 waves, two-part direct LDS fill; 2 = A operands double-buffered by hand).  Bit-identical but measured 11-13 % SLOWER than the 16-wave form at every size (profiles/r3_dense_pipe_ab.log): off; kept as the A/B
     int64_t train_rows = 0;     // fx_train_fit: mini-batch rows per workgroup (0 = auto: 16, or 8 for small batches)
     int64_t train_lds = 2;      // fx_train_fit: 2 = a slice's activations / gradients AND the member's weights live in LDS when they fit, 1 = the workspace only, 0 = global arena (A/B)
     int64_t train_threads = 0;  // fx_train_fit: threads per forward+backward workgroup (256 / 512 / 1024; 0 = 1024)

@@ -1587,3 +1587,46 @@ def test_mlp_small_launch_form_is_bit_identical_to_the_persistent_kernel(eng, ki
             eng.score(nms, bb, lut)
     finally:
         eng.set_option("dense_small", 1)
+
+
+@pytest.mark.parametrize("kind,L,alpha,H,M,n", [
+    ("mlp", 14, "UGCA", 100, 1, 100_000), ("mlp", 14, "UGCA", 100, 3, 20_000), ("mlp", 8, "TGCA", 100, 1, 5_000),
+    ("mlp", 9, "UGCA", 100, 2, 4_099), ("mlp", 16, "UGCA", 100, 1, 70_001), ("mlp", 17, "UGCA", 100, 1, 9_000),
+    ("mlp", 14, "UGCA", 128, 2, 9_001), ("mlp", 14, "UGCA", 112, 1, 6_000), ("mlp", 4, "TGCA", 100, 1, 4_500),
+    ("ge", 90, s_utils.AAS, 100, 8, 100_000), ("ge", 90, s_utils.AAS, 100, 1, 100_003), ("ge", 14, "UGCA", 100, 1, 20_000),
+    ("ge", 8, "TGCA", 100, 3, 10_000), ("ge", 64, s_utils.AAS, 100, 2, 8_191), ("ge", 100, "UGCA", 100, 1, 6_007),
+    ("ge", 128, s_utils.AAS, 128, 1, 5_000), ("ge", 33, s_utils.AAS, 128, 2, 7_000), ("ge", 96, "UGCA", 112, 1, 4_200),
+])
+def test_software_pipelined_dense_form_gives_the_same_bits(eng, kind, L, alpha, H, M, n):
+    """Round 3: the MLP (pair rows) / GlobalEpistasis (byte table) launches run tile t + 1's first layer inside tile t's
+    MFMA layers (`dense_pipe` = 1: 8 waves, two-part direct LDS fill).  Every output element sees the arithmetic of the
+    round-2 form (`dense_pipe` = 0), so the scores are the SAME BITS -- ragged last tiles, members, any alignment -- and
+    both agree with the oracle; a character outside the alphabet is reported from the pipelined first layer too."""
+    A = len(alpha)
+    natives, ws = zip(*[make_native(eng, kind, L, A, H, seed=700 + m) for m in range(M)])
+    lut = _native.make_lut(alpha)
+    b, seqs = rand_seqs(n, L, alpha, seed=L + H + M)
+    eng.set_option("dense_small", 0)                      # the persistent kernels at every size
+    try:
+        outs = {}
+        for pipe in (2, 1, 0):                            # 2 / 1: the pipelined form with / without hand-placed operand prefetch
+            eng.set_option("dense_pipe", pipe)
+            outs[pipe], _ = eng.score(list(natives), b, lut)
+            for cut in (1, 16, 17, 4097):                 # batch invariance: prefixes, ragged or not
+                if cut < n:
+                    part, _ = eng.score(list(natives), b[:cut], lut)
+                    assert np.array_equal(part, outs[pipe][:cut]), (pipe, cut)
+        assert np.array_equal(outs[1], outs[0]) and np.array_equal(outs[2], outs[0])
+        k = min(n, 400)
+        for m in range(M):
+            assert_scores(outs[1][:k, m], c_oracle.forward(kind, lut[b[:k]], A, ws[m]), f"{kind} L={L} H={H} member {m}")
+        eng.set_option("dense_pipe", 1)                   # (the form is optional: measured slower, see DESIGN.md section 8)
+        for where in (0, n // 2 + 5, n - 1):              # first tile of a wave, a pipelined tile, the ragged tail
+            bad = b.copy(); bad[where, L - 1] = ord("!")
+            with pytest.raises(ValueError):
+                eng.score(list(natives), bad, lut)
+        again, _ = eng.score(list(natives), b, lut)
+        assert np.array_equal(again, outs[1])
+    finally:
+        eng.set_option("dense_pipe", 0)
+        eng.set_option("dense_small", 1)
