@@ -50,6 +50,7 @@ SIGNATURES = {
     "fx_model_set_weights": (C.c_int, [_vp, _f32p, C.c_int64]),
     "fx_model_get_weights": (C.c_int, [_vp, _f32p, C.c_int64]),
     "fx_score": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _vp, C.c_int64, C.c_int, _u8p, _vp, _vp]),
+    "fx_plan_host_call": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "fx_score_planes_dev": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _vp, C.c_int64, C.c_int, _u8p, _vp, C.c_int64]),
     "fx_ensemble_mean_planes_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64, _vp]),
     "fx_staging_input": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp)]),
@@ -243,7 +244,8 @@ def sequences_to_bytes(sequences, L: Optional[int] = None, staging: Optional["En
     return out
 
 
-CHUNKED_MIN_ROWS = 32768        # list[str] batches from this size on are packed and scored in overlapping pieces
+CHUNKED_MIN_ROWS = int(os.environ.get("FLEXS_AMD_CHUNKED_MIN_ROWS", 32768))   # list[str] batches from this size on are packed and scored in overlapping pieces
+CHUNK_BYTES = int(os.environ.get("FLEXS_AMD_CHUNK_BYTES", 0))   # target bytes per piece (0 = auto, see score_strings)
 
 
 def wants_chunked(sequences, L: int) -> bool:
@@ -365,12 +367,22 @@ class Engine:
         transfer and scoring of piece k (GPU).  Same results and exceptions as sequences_to_bytes + score."""
         N, M = len(seqs), len(models)
         arr = (_vp * M)(*[m.handle for m in models])
+        if chunks <= 0:
+            if CHUNK_BYTES > 0:
+                chunks = min(max(N * L // CHUNK_BYTES, 1), 16)
+            else:
+                # the engine's plan: pieces of ~2 MB when its kernels read the staging area directly (zero-copy),
+                # 4 MB pieces for big uploads, ONE piece otherwise (profiles/r3_e2e_ab.log)
+                zc, pieces = C.c_int(0), C.c_int(1)
+                self.check(self._lib.fx_plan_host_call(self.handle, arr, M, N, L, C.byref(zc), C.byref(pieces)))
+                chunks = pieces.value
+        if chunks <= 1:
+            seq_bytes = sequences_to_bytes(seqs, L=L, staging=self)        # packed (several threads) straight into the pinned area
+            return self.score(models, seq_bytes, lut, want_matrix=want_matrix, want_mean=want_mean)
         p = _vp()
         self.check(self._lib.fx_score_begin(self.handle, arr, M, N, L, _lut_ptr(lut), int(want_matrix),
                                             int(want_mean), C.byref(p)))
         staging = np.frombuffer((C.c_uint8 * (N * L)).from_address(p.value), np.uint8, N * L).reshape(N, L)
-        if chunks <= 0:
-            chunks = min(max(N // 65536, 2), 16)          # ~64k-row pieces (measured: profiles/r1_run45_chunked_strings.log)
         step = -(-N // chunks)
         step += -step % 256
         status = 0

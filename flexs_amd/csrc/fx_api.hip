@@ -165,6 +165,12 @@ int fx_engine_create(int device, fx_engine** out) {
     if (e->max_lds > 160 * 1024) e->max_lds = 160 * 1024;
     FX_CREATE_HIP(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
     e->stream = e->own_stream;
+    FX_CREATE_HIP(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < fx_engine::MAX_PIECES; ++i) {
+        FX_CREATE_HIP(hipEventCreateWithFlags(&e->ev_in[i], hipEventDisableTiming));
+        FX_CREATE_HIP(hipEventCreateWithFlags(&e->ev_done[i], hipEventDisableTiming));
+        FX_CREATE_HIP(hipEventCreateWithFlags(&e->ev_out[i], hipEventDisableTiming));
+    }
     FX_CREATE_HIP(hipEventCreate(&e->ev0));
     FX_CREATE_HIP(hipEventCreate(&e->ev1));
     FX_CREATE_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_err), 64, hipHostMallocMapped));
@@ -187,6 +193,12 @@ int fx_engine_destroy(fx_engine* e) {
     if (e->h_err) (void)hipHostFree(e->h_err);
     if (e->d_lut) (void)hipFree(e->d_lut);
     if (e->d_trace) (void)hipFree(e->d_trace);
+    for (int i = 0; i < fx_engine::MAX_PIECES; ++i) {
+        if (e->ev_in[i]) (void)hipEventDestroy(e->ev_in[i]);
+        if (e->ev_done[i]) (void)hipEventDestroy(e->ev_done[i]);
+        if (e->ev_out[i]) (void)hipEventDestroy(e->ev_out[i]);
+    }
+    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -235,6 +247,9 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "ge_bytetab")) return &e->ge_bytetab;
     if (!std::strcmp(key, "wave_prio")) return &e->wave_prio;
     if (!std::strcmp(key, "dense_pipe")) return &e->dense_pipe;
+    if (!std::strcmp(key, "chunk_overlap")) return &e->chunk_overlap;
+    if (!std::strcmp(key, "zero_copy_bytes")) return &e->zero_copy_bytes;
+    if (!std::strcmp(key, "zero_copy_mode")) return &e->zero_copy_mode;
     if (!std::strcmp(key, "train_rows")) return &e->train_rows;
     if (!std::strcmp(key, "train_lds")) return &e->train_lds;
     if (!std::strcmp(key, "train_threads")) return &e->train_threads;
@@ -449,6 +464,53 @@ int fx_staging_input(fx_engine* e, int64_t bytes, void** host) {
     return fx_pinned(e, 0, (size_t)std::max<int64_t>(bytes, 1), host);
 }
 
+// How a host call (host bytes in, host scores out) should move its data.
+//   zero-copy  the kernels read the sequences from the mapped pinned staging area over PCIe and write the scores to
+//              pinned memory: no copy enqueues, no dependent copy -> kernel -> copy chain.  Every MEMBER's units read the
+//              bytes again (host memory is not cached in L2), so the traffic is M x N x L bytes: worth it when that
+//              hides behind the kernels (3 x CNN L = 8: 24 bytes per sequence against 0.3 MFLOP), ruinous when it does
+//              not (8 x GlobalEpistasis L = 90: 72 MB for a 0.15 ms launch; measured 1.43 ms vs 0.44 ms).
+//   pieces     > 1: pack + submit in pieces so that the host's string marshalling overlaps the GPU's work.
+// Model: t_kernel from the MFMA instructions the launch issues (fx_mfma_per_tile) at 75 % of the pipe; PCIe at 45 GB/s
+// for in-kernel reads, 35 GB/s + 25 us of enqueue / dependency latency for the copy path (profiles/r3_e2e_ab.log).
+static void plan_host_call(const fx_engine* e, fx_model* const* models, int M, int64_t N, int L, bool* zero_copy, int* pieces) {
+    const double bytes = (double)N * (double)L;
+    double t_k = 0.0;
+    bool mfma = true;
+    for (int m = 0; m < M; ++m) {
+        const int64_t per_tile = fx_mfma_per_tile(models[m]->shape);
+        if (per_tile < 0) { mfma = false; break; }
+        t_k += (double)per_tile * (double)((N + 15) / 16) * 32.0 / ((double)e->num_cus * 4.0 * 2.4e9) / 0.75;
+    }
+    const double t_zc = std::max(t_k, (double)M * bytes / 45e9);
+    const double t_copy = bytes / 35e9 + t_k + 25e-6;
+    bool zc = mfma && t_zc < t_copy;
+    if (e->zero_copy_mode == 0) zc = false;
+    if (e->zero_copy_mode == 1) zc = true;
+    // Pieces only pay when the host's marshalling (~20 GB/s with the packing threads + ~1 ns per string) is a visible
+    // share of the call AND every piece still fills the machine for a while (a piece shorter than ~0.25 ms of kernel
+    // time loses more to its start-up and tail than the overlap wins: 7 pieces of a 17.6 ms protein batch cost 3 ms).
+    const double t_pack = bytes / 20e9 + (double)N * 1e-9;
+    int p = 1;
+    if (t_pack > 0.15 * t_k || !mfma) {
+        p = zc ? (int)(bytes / (2 << 20) + 0.5)                           // ~2 MB of sequence bytes per piece
+               : (bytes >= (double)(16 << 20) ? (int)(bytes / (4 << 20)) : 1);   // big uploads: 4 MB pieces
+        const int cap = mfma ? (int)(t_k / 250e-6) : 16;
+        if (p > cap) p = cap;
+    }
+    *zero_copy = zc;
+    *pieces = p < 1 ? 1 : (p > 16 ? 16 : p);
+}
+
+int fx_plan_host_call(fx_engine* e, fx_model* const* models, int M, int64_t N, int L, int* zero_copy, int* pieces) {
+    if (!e || !models || M < 1 || N < 0 || L < 1 || !zero_copy || !pieces) return FX_EINVAL;
+    for (int m = 0; m < M; ++m) if (!models[m]) return FX_EINVAL;
+    bool zc = false;
+    plan_host_call(e, models, M, N, L, &zc, pieces);
+    *zero_copy = zc ? 1 : 0;
+    return FX_OK;
+}
+
 int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii, int64_t N, int L,
              const uint8_t lut[256], float* out_NM, float* out_mean) {
     int rc = validate_models(e, models, M, L, lut);
@@ -473,7 +535,10 @@ int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii,
     float* d_mean = (float*)((char*)d_out + inter_bytes);
     if (ascii != h_in) std::memcpy(h_in, ascii, in_bytes);   // (fx_staging_input callers marshalled straight into it)
     if ((rc = fx_upload_lut(e, lut))) return rc;
-    if (in_bytes + nm_bytes + mean_bytes <= (size_t)(256 << 10)) {
+    bool plan_zc = false;
+    int plan_pieces = 1;
+    plan_host_call(e, models, M, N, L, &plan_zc, &plan_pieces);
+    if (in_bytes + nm_bytes + mean_bytes <= (size_t)e->zero_copy_bytes || plan_zc) {
         // Small call (what Adalead / CMA-ES / DynaPPO issue): zero-copy through the mapped pinned
         // staging buffers -- the kernels read the sequences from, and write the scores to, host memory over
         // PCIe; two memcpy enqueues and their latencies disappear from the call.
@@ -526,6 +591,8 @@ int fx_score_begin(fx_engine* e, fx_model* const* models, int M, int64_t N, int 
     c.h_in = (uint8_t*)h_in; c.d_in = (uint8_t*)d_in;
     c.d_nm = (float*)d_out; c.d_mean = (float*)((char*)d_out + nm_bytes);
     c.h_out = (char*)h_out;
+    c.pieces = 0;
+    { int unused = 1; plan_host_call(e, models, M, N, L, &c.zero_copy, &unused); }
     c.active = true;
     *staging = h_in;
     return FX_OK;
@@ -541,16 +608,50 @@ int fx_score_submit(fx_engine* e, int64_t row0, int64_t rows) {
     const int M = (int)c.models.size();
     const size_t nm_bytes = sizeof(float) * (size_t)c.N * (size_t)M;
     int rc;
-    FX_HIP(e, hipMemcpyAsync(c.d_in + row0 * c.L, c.h_in + row0 * c.L, (size_t)rows * c.L, hipMemcpyHostToDevice, e->stream));
+    // transfers on the copy stream, kernels on the compute stream, one event triple per piece: the upload of piece k + 1
+    // (packed by the host while piece k runs) and the download of piece k - 1 overlap piece k's kernels
+    if (c.pieces >= fx_engine::MAX_PIECES) return fx_fail(e, FX_EINVAL, "fx_score_submit: more than 32 pieces in one call");
+    if (c.zero_copy) {
+        // no copy enqueues at all: the piece's kernels read its bytes from the pinned staging area over PCIe (L bytes
+        // per sequence against ~1e5 FLOP: the reads hide behind the MFMA work) and the results land in pinned memory
+        void *dm_in = nullptr, *dm_out = nullptr;
+        FX_HIP(e, hipHostGetDevicePointer(&dm_in, c.h_in, 0));
+        FX_HIP(e, hipHostGetDevicePointer(&dm_out, c.h_out, 0));
+        float* m_nm = (float*)dm_out + row0 * M;
+        float* m_mean = (float*)((char*)dm_out + nm_bytes) + row0;
+        float* nm = c.want_nm ? m_nm : c.d_nm + row0 * M;
+        if ((rc = score_dispatch(e, c.models.data(), M, (const uint8_t*)dm_in + row0 * c.L, rows, c.L, nm))) return rc;
+        if (c.want_mean && (rc = fx_launch_ensemble_reduce(e, nm, rows, M, nullptr, m_mean, nullptr))) return rc;
+        const int k = c.pieces;
+        FX_HIP(e, hipEventRecord(e->ev_out[k], e->stream));
+        c.row0[k] = row0; c.rows[k] = rows;
+        ++c.pieces;
+        return FX_OK;
+    }
+    const bool two = e->chunk_overlap != 0;
+    hipStream_t cs = two ? e->copy_stream : e->stream;
+    const int k = c.pieces;
+    FX_HIP(e, hipMemcpyAsync(c.d_in + row0 * c.L, c.h_in + row0 * c.L, (size_t)rows * c.L, hipMemcpyHostToDevice, cs));
+    if (two) {
+        FX_HIP(e, hipEventRecord(e->ev_in[k], cs));
+        FX_HIP(e, hipStreamWaitEvent(e->stream, e->ev_in[k], 0));
+    }
     float* nm = c.d_nm + row0 * M;
     if ((rc = score_dispatch(e, c.models.data(), M, c.d_in + row0 * c.L, rows, c.L, nm))) return rc;
-    if (c.want_mean) {
+    if (c.want_mean)
         if ((rc = fx_launch_ensemble_reduce(e, nm, rows, M, nullptr, c.d_mean + row0, nullptr))) return rc;
-        FX_HIP(e, hipMemcpyAsync(c.h_out + nm_bytes + sizeof(float) * row0, c.d_mean + row0, sizeof(float) * rows,
-                                 hipMemcpyDeviceToHost, e->stream));
+    if (two) {
+        FX_HIP(e, hipEventRecord(e->ev_done[k], e->stream));
+        FX_HIP(e, hipStreamWaitEvent(cs, e->ev_done[k], 0));
     }
+    if (c.want_mean)
+        FX_HIP(e, hipMemcpyAsync(c.h_out + nm_bytes + sizeof(float) * row0, c.d_mean + row0, sizeof(float) * rows,
+                                 hipMemcpyDeviceToHost, cs));
     if (c.want_nm)
-        FX_HIP(e, hipMemcpyAsync(c.h_out + sizeof(float) * row0 * M, nm, sizeof(float) * rows * M, hipMemcpyDeviceToHost, e->stream));
+        FX_HIP(e, hipMemcpyAsync(c.h_out + sizeof(float) * row0 * M, nm, sizeof(float) * rows * M, hipMemcpyDeviceToHost, cs));
+    FX_HIP(e, hipEventRecord(e->ev_out[k], cs));
+    c.row0[k] = row0; c.rows[k] = rows;
+    ++c.pieces;
     return FX_OK;
 }
 
@@ -560,14 +661,20 @@ int fx_score_finish(fx_engine* e, float* out_NM, float* out_mean) {
     if (!c.active) return fx_fail(e, FX_ESTATE, "fx_score_finish without fx_score_begin");
     c.active = false;
     FX_HIP(e, hipSetDevice(e->device));
-    FX_HIP(e, hipStreamSynchronize(e->stream));
-    int rc = check_deferred(e);
-    if (rc) return rc;
     const int M = (int)c.models.size();
     const size_t nm_bytes = sizeof(float) * (size_t)c.N * (size_t)M;
-    if (c.want_nm && out_NM) std::memcpy(out_NM, c.h_out, nm_bytes);
-    if (c.want_mean && out_mean) std::memcpy(out_mean, c.h_out + nm_bytes, sizeof(float) * (size_t)c.N);
-    return FX_OK;
+    // piece by piece: the host copies piece k out of the pinned area while the GPU still works on the later ones
+    // (a character outside the alphabet in ANY piece fails the call: the results are only trusted after the last check)
+    for (int k = 0; k < c.pieces; ++k) {
+        FX_HIP(e, hipEventSynchronize(e->ev_out[k]));
+        if (c.want_nm && out_NM)
+            std::memcpy(out_NM + c.row0[k] * M, c.h_out + sizeof(float) * c.row0[k] * M, sizeof(float) * (size_t)c.rows[k] * M);
+        if (c.want_mean && out_mean)
+            std::memcpy(out_mean + c.row0[k], c.h_out + nm_bytes + sizeof(float) * c.row0[k], sizeof(float) * (size_t)c.rows[k]);
+    }
+    FX_HIP(e, hipStreamSynchronize(e->copy_stream));
+    FX_HIP(e, hipStreamSynchronize(e->stream));
+    return check_deferred(e);
 }
 
 int fx_encode_onehot_dev(fx_engine* e, const uint8_t* d_ascii, int64_t N, int L, const uint8_t lut[256], int A,

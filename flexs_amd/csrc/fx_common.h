@@ -66,6 +66,11 @@ struct fx_engine {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // chunked host call (fx_score_begin / _submit / _finish): transfers ride a second stream, so that the upload of piece
+    // k + 1 and the download of piece k - 1 overlap the kernels of piece k; one event triple per piece
+    hipStream_t copy_stream = nullptr;
+    static constexpr int MAX_PIECES = 32;
+    hipEvent_t ev_in[MAX_PIECES] = {}, ev_done[MAX_PIECES] = {}, ev_out[MAX_PIECES] = {};
     std::string last_error;
     // deferred error word (device) + pinned host mirror
     unsigned* d_err = nullptr;
@@ -129,7 +134,13 @@ struct fx_engine {
         uint8_t* h_in = nullptr; uint8_t* d_in = nullptr;
         float* d_nm = nullptr; float* d_mean = nullptr;
         char* h_out = nullptr;
+        int pieces = 0;                                  // submitted so far
+        bool zero_copy = false;                          // the pieces' kernels read the pinned staging area directly
+        int64_t row0[32] = {}, rows[32] = {};
     } chunked;
+    int64_t chunk_overlap = 0;  // 1 = the chunked host call puts transfers and kernels on two streams (measured SLOWER than one stream: the cross-stream event waits cost more than the overlap buys, profiles/r3_e2e_ab.log; kept as the A/B)
+    int64_t zero_copy_bytes = 256 << 10;   // host calls whose input + output are at most this many bytes run zero-copy: the kernels read the sequences from / write the scores to mapped pinned host memory
+    int64_t zero_copy_mode = -1;           // host calls beyond zero_copy_bytes: -1 = zero-copy when the plan (fx_plan_host_call) says the PCIe reads hide behind the kernels, 0 = always copy, 1 = always zero-copy (A/B)
 };
 
 struct fx_model {

@@ -113,6 +113,11 @@ int fx_model_get_weights(const fx_model *m, float *blob, int64_t n);
  * it is ready -- host marshalling of chunk k+1 then overlaps the transfer and scoring of chunk k.
  * fx_score_finish waits, reports a bad character (FX_EBADCHAR) and copies the results out.  One such
  * call per engine at a time; chunks should start at multiples of 16 rows. */
+/* How the engine would move the data of a host call of N sequences: *zero_copy = 1 when the kernels will read the
+ * sequences from / write the scores to mapped pinned memory directly (no copies; chosen when M x N x L bytes of PCIe
+ * reads hide behind the kernels), *pieces = how many pieces a caller that marshals its input (Python strings) should
+ * submit (1 = a plain fx_score on the staging area). */
+int fx_plan_host_call(fx_engine *e, fx_model *const *models, int M, int64_t N, int L, int *zero_copy, int *pieces);
 int fx_score_begin(fx_engine *e, fx_model *const *models, int M, int64_t N, int L,
                    const uint8_t lut[256], int want_nm, int want_mean, void **staging);
 int fx_score_submit(fx_engine *e, int64_t row0, int64_t rows);
