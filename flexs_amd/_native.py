@@ -85,6 +85,7 @@ SIGNATURES = {
     "fx_debug_time_min_dist": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, C.c_int, _f32p]),
     "fx_debug_pack_weights": (C.c_int, [C.c_int] * 6 + [_f32p, C.c_int64, _f32p, C.c_int64]),
     "fx_debug_myers": (C.c_int, [_vp, C.c_int, _vp, C.c_int]),
+    "fx_debug_myers_strips": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int]),
     "fx_train_fit": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64, C.c_int, _u8p, _vp]),
     "fx_debug_train_step_host": (C.c_int, [C.c_int] * 6 + [_vp, _vp, _vp, _vp, _vp, C.c_int, _u8p, _vp, _vp, C.c_int, _vp]),
     "fx_debug_mfma_probe": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
@@ -661,6 +662,12 @@ def mfma_per_tile(kind, L, A, F, H, K) -> int:
     if n < 0:
         raise ValueError(f"no MFMA kernel for kind={kind} L={L} A={A} F={F} H={H} K={K}")
     return int(n)
+
+
+def debug_myers_strips(a: bytes, b: bytes, words_per_strip: int = 12) -> int:
+    a = np.frombuffer(a, np.uint8)
+    b = np.frombuffer(b, np.uint8)
+    return lib().fx_debug_myers_strips(_ptr(a) if len(a) else None, len(a), _ptr(b) if len(b) else None, len(b), words_per_strip)
 
 
 def debug_myers(a: bytes, b: bytes) -> int:

@@ -8,6 +8,24 @@
 #include "fx_common.h"
 #include "myers.h"
 
+// strips of `lw_rows` = 64 x LW pattern rows, as k_min_dist_long runs them for patterns beyond 768 symbols (LW = 12 there;
+// the test hook also takes LW = 1 so that short strings cross many strip boundaries)
+template <int LW>
+static int myers_strips_host(const uint8_t* a, int la, const uint8_t* b, int lb) {
+    std::vector<signed char> h((size_t)std::max(lb, 1), 0);
+    const int nstrips = la > 0 ? (la + 64 * LW - 1) / (64 * LW) : 1;
+    int part = 0;
+    for (int s = 0; s < nstrips; ++s) {
+        const int r0 = s * 64 * LW, rows = std::min(la - r0, 64 * LW);
+        std::vector<uint64_t> peq((size_t)256 * LW, 0);
+        for (int i = 0; i < rows; ++i) peq[(size_t)a[r0 + i] * LW + (i >> 6)] |= 1ull << (i & 63);
+        part = fx_myers_strip<LW>(rows > 0 ? rows : 0, lb, [&](int c, int w) { return peq[(size_t)c * LW + w]; },
+                                  [&](int i) { return (int)b[i]; }, h.data(), h.data(), 1, s == 0, s == nstrips - 1);
+    }
+    return la + part;
+}
+
+
 // ------------------------------------------------------------------ helpers
 static thread_local std::string g_last_error_noengine;
 
@@ -1088,9 +1106,17 @@ int fx_debug_mfma_probe(fx_engine* e, const float* a64, const float* b64, const 
     FX_HIP(e, hipStreamSynchronize(e->stream));
     return FX_OK;
 }
+int fx_debug_myers_strips(const uint8_t* a, int la, const uint8_t* b, int lb, int words_per_strip) {
+    if (la < 0 || lb < 0 || (la > 0 && !a) || (lb > 0 && !b)) return -1;
+    for (int i = 0; i < lb; ++i) if (b[i] == 0) return -1;       // (the strip routine stops at a NUL: not part of any alphabet)
+    if (words_per_strip == 1) return myers_strips_host<1>(a, la, b, lb);
+    if (words_per_strip == 12) return myers_strips_host<12>(a, la, b, lb);
+    return -1;
+}
 int fx_debug_myers(const uint8_t* a, int la, const uint8_t* b, int lb) {
     // pattern = a, text = b; same code path as the device kernel (myers.h)
-    if (la > 768 || la < 0 || lb < 0) return -1;
+    if (la < 0 || lb < 0) return -1;
+    if (la > 768) return myers_strips_host<12>(a, la, b, lb);   // what k_min_dist_long runs
     if (la <= 32) {                                   // the kernels' 32-bit single-word form (mindist.hip)
         uint32_t peq32[256] = {0};
         for (int i = 0; i < la; ++i) peq32[a[i]] |= 1u << i;

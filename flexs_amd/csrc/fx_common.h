@@ -80,8 +80,8 @@ struct fx_engine {
     uint8_t h_lut[256];
     bool lut_valid = false;
     // growable scratch
-    void* d_scratch[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_bytes[4] = {0, 0, 0, 0};
+    void* d_scratch[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[5] = {0, 0, 0, 0, 0};
     void* d_train = nullptr;      // fx_train_fit arena (grown on demand, kept between fits)
     size_t train_bytes = 0;
     void* d_zero_pool = nullptr;  // fx_zero_pool: all-zero between launches (the kernels that use it clean up after themselves)

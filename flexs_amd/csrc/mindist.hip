@@ -112,6 +112,92 @@ __global__ void __launch_bounds__(256) k_distances(int mode, const uint8_t* __re
     }
 }
 
+// ---- patterns longer than 768 symbols: the bit-parallel recurrence in STRIPS of 12 words -------------------------
+// `editdistance.eval` (noisy_abstract_model.py:51) takes strings of any length.  A strip is 768 rows of the DP matrix
+// (what fits a thread's registers); strip s is run over all text columns with the pattern rows [768 s, 768 s + 768):
+// its top boundary is the bottom boundary of strip s - 1 -- one horizontal delta in {-1, 0, +1} per column, kept in a
+// per-thread column of a global scratch array ([column][thread]: coalesced) -- its left boundary the usual +1 vertical
+// deltas, and the distance is m plus the bottom deltas of the LAST strip.  The workgroup shares the query, so the
+// strip loop and the rebuild of the match-mask table are workgroup-uniform.  Same per-block arithmetic as myers.h.
+constexpr int LW = 12;                                      // words per strip (myers.h fx_myers_strip)
+
+// MATRIX = false: fold (remapped distance, index) into keys[q]; true: dense uint8 distances
+template <bool MATRIX>
+__global__ void __launch_bounds__(256) k_min_dist_long(int mode, const uint8_t* __restrict__ q, int64_t q0, const uint8_t* __restrict__ cache,
+                                                       int64_t C, int L, unsigned long long* __restrict__ keys, uint8_t* __restrict__ out,
+                                                       int8_t* __restrict__ hbuf) {
+    __shared__ uint64_t peq[256 * LW];
+    __shared__ unsigned long long wave_min[4];
+    __shared__ int m_s;
+    const int tid = threadIdx.x;
+    const int64_t qi = q0 + blockIdx.y;
+    const uint8_t* qrow = q + qi * L;
+    if (tid == 0) {
+        int m = L;
+        for (int i = 0; i < L; ++i) if (qrow[i] == 0) { m = i; break; }
+        m_s = m;
+    }
+    __syncthreads();
+    const int m = m_s;
+    const size_t hstride = (size_t)gridDim.x * gridDim.y * 256;
+    int8_t* hcol = hbuf + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid;
+    const int nstrips = m > 0 ? (m + 64 * LW - 1) / (64 * LW) : 1;
+    unsigned long long best = ~0ull;
+    const int64_t c0 = (int64_t)blockIdx.x * CHUNK;
+    for (int k = 0; k < CHUNK / 256; ++k) {
+        const int64_t c = c0 + k * 256 + tid;
+        const bool live = c < C;                            // (every thread walks the strips: the table rebuild is a barrier)
+        const uint8_t* t = cache + (live ? c : 0) * L;
+        int d = 0;
+        if (mode == FX_HAMMING) {
+            if (live) for (int i = 0; i < L; ++i) d += (t[i] != qrow[i]);
+        } else {
+            for (int s = 0; s < nstrips; ++s) {
+                const int r0 = s * 64 * LW, rows = (m - r0) < 64 * LW ? (m - r0) : 64 * LW;
+                __syncthreads();                            // everybody is done with the previous table
+                uint64_t mk[LW];
+#pragma unroll
+                for (int w = 0; w < LW; ++w) mk[w] = 0;
+                for (int i = 0; i < rows; ++i)
+                    if (qrow[r0 + i] == tid) {
+#pragma unroll
+                        for (int w = 0; w < LW; ++w)
+                            if ((i >> 6) == w) mk[w] |= 1ull << (i & 63);
+                    }
+#pragma unroll
+                for (int w = 0; w < LW; ++w) peq[tid * LW + w] = mk[w];
+                __syncthreads();
+                if (live) {
+                    const int part = fx_myers_strip<LW>(rows > 0 ? rows : 0, L, [&](int ch, int w) { return peq[ch * LW + w]; },
+                                                        [&](int i) { return (int)t[i]; }, (const signed char*)hcol, (signed char*)hcol,
+                                                        hstride, s == 0, s == nstrips - 1);
+                    if (s == nstrips - 1) d = m + part;
+                }
+            }
+        }
+        if (!live) continue;
+        if (MATRIX) {
+            out[(qi - q0) * C + c] = (uint8_t)(d > 255 ? 255 : d);
+        } else {
+            const unsigned dp = d == 1 ? 0u : (d == 0 ? 1u : (unsigned)d);
+            const unsigned long long key = ((unsigned long long)dp << 32) | (unsigned long long)c;
+            best = key < best ? key : best;
+        }
+    }
+    if (MATRIX) return;
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long o = __shfl_xor(best, off);
+        best = o < best ? o : best;
+    }
+    if ((tid & 63) == 0) wave_min[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long b = wave_min[0];
+        for (int w = 1; w < 4; ++w) b = wave_min[w] < b ? wave_min[w] : b;
+        if (b != ~0ull) atomicMin(&keys[qi], b);
+    }
+}
+
 __global__ void k_min_dist_finish(const unsigned long long* __restrict__ keys, int64_t Q, int32_t* __restrict__ dist,
                                   int64_t* __restrict__ arg) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -122,14 +208,33 @@ __global__ void k_min_dist_finish(const unsigned long long* __restrict__ keys, i
     arg[i] = (int64_t)(k & 0xffffffffull);
 }
 
+// Long rows: queries in batches sized so that the boundary scratch ([column][thread] int8) stays below 256 MiB.
+template <bool MATRIX>
+int launch_long(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, const uint8_t* d_cache, int64_t C, int L,
+                unsigned long long* d_keys, uint8_t* d_out) {
+    const int64_t chunks = (C + CHUNK - 1) / CHUNK;
+    const int64_t per_query = chunks * 256 * (int64_t)L;
+    int64_t qb = ((int64_t)256 << 20) / per_query;
+    qb = qb < 1 ? 1 : (qb > Q ? Q : qb);
+    void* hbuf = nullptr;
+    if (int rc = fx_scratch(e, 4, (size_t)(per_query * qb), &hbuf)) return rc;
+    for (int64_t q0 = 0; q0 < Q; q0 += qb) {
+        const int64_t qn = Q - q0 < qb ? Q - q0 : qb;
+        hipLaunchKernelGGL(k_min_dist_long<MATRIX>, dim3((unsigned)chunks, (unsigned)qn), dim3(256), 0, e->stream, mode, d_q, q0, d_cache, C, L,
+                           d_keys, MATRIX ? d_out + q0 * C : nullptr, (int8_t*)hbuf);
+    }
+    FX_HIP(e, hipGetLastError());
+    return FX_OK;
+}
+
 }  // namespace
 
 int fx_launch_min_dist(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, const uint8_t* d_cache, int64_t C,
                        int L, unsigned long long* d_keys) {
     if (Q == 0 || C == 0) return FX_OK;
-    if (L > FX_MINDIST_MAX_L) return fx_fail(e, FX_EUNSUPPORTED, "min_dist: sequence length > 768");
     if (Q > 65535) return fx_fail(e, FX_EINVAL, "min_dist: more than 65535 queries per call (split the batch)");
     FX_HIP(e, hipMemsetAsync(d_keys, 0xFF, sizeof(unsigned long long) * (size_t)Q, e->stream));
+    if (L > FX_MINDIST_MAX_L) return launch_long<false>(e, mode, d_q, Q, d_cache, C, L, d_keys, nullptr);
     dim3 grid((unsigned)((C + CHUNK - 1) / CHUNK), (unsigned)Q), block(256);
     if (L <= 32) {          // one 32-bit word per column: half the integer work of the 64-bit form
         hipLaunchKernelGGL((k_min_dist<1, uint32_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys);
@@ -151,8 +256,8 @@ int fx_launch_min_dist(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, co
 int fx_launch_distances(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, const uint8_t* d_cache, int64_t C,
                         int L, uint8_t* d_out) {
     if (Q == 0 || C == 0) return FX_OK;
-    if (L > FX_MINDIST_MAX_L) return fx_fail(e, FX_EUNSUPPORTED, "distances: sequence length > 768");
     if (Q > 65535) return fx_fail(e, FX_EINVAL, "distances: more than 65535 queries per call");
+    if (L > FX_MINDIST_MAX_L) return launch_long<true>(e, mode, d_q, Q, d_cache, C, L, nullptr, d_out);
     dim3 grid((unsigned)((C + CHUNK - 1) / CHUNK), (unsigned)Q), block(256);
     if (L <= 32) {
         hipLaunchKernelGGL((k_distances<1, uint32_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out);

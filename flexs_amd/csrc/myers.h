@@ -60,3 +60,30 @@ FX_HD int fx_myers_distance(int m, int n, PeqFn peq, TextFn text) {
     }
     return score;
 }
+
+// ---- patterns longer than one register block set: the recurrence in STRIPS -------------------------------------------
+// Strip s = pattern rows [64 LW s, 64 LW (s + 1)) run over all text columns.  Its top boundary is the bottom boundary
+// of strip s - 1 -- one horizontal delta in {-1, 0, +1} per column, read from `hin` and overwritten in place through
+// `hout` (element i at [i * stride]) -- its left boundary the usual +1 vertical deltas (D[i][0] = i).  The last strip
+// returns the sum of its bottom deltas: distance = m + that sum.  `rows` = pattern rows in this strip (0 for an empty
+// pattern: every column then contributes +1, i.e. the distance is the text length).
+template <int LW, typename PeqFn, typename TextFn>
+FX_HD int fx_myers_strip(int rows, int n, PeqFn peq, TextFn text, const signed char* hin, signed char* hout, size_t stride,
+                         bool first, bool last) {
+    uint64_t Pv[LW], Mv[LW];
+    const int nw = (rows + 63) / 64;
+#pragma unroll
+    for (int w = 0; w < LW; ++w) { Pv[w] = ~uint64_t(0); Mv[w] = uint64_t(0); }
+    const int top_last = (rows - 1) & 63;
+    int sum = 0;
+    for (int i = 0; i < n; ++i) {
+        const int c = text(i);
+        if (c == 0) break;                                  // NUL-padded (ragged) row
+        int h = first ? 1 : (int)hin[(size_t)i * stride];
+#pragma unroll
+        for (int w = 0; w < LW; ++w)
+            if (w < nw) h = fx_myers_block<uint64_t>(Pv[w], Mv[w], (uint64_t)peq(c, w), h, (w == nw - 1) ? top_last : 63);
+        if (last) sum += h; else hout[(size_t)i * stride] = (signed char)h;
+    }
+    return sum;
+}

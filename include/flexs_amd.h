@@ -79,9 +79,40 @@ int fx_engine_set_stream(fx_engine *e, void *hip_stream);
  * sync met a character outside its alphabet. */
 int fx_engine_sync(fx_engine *e);
 const char *fx_last_error(fx_engine *e);
-/* Tuning / test knobs: "force_generic" (0/1: use the plain VALU kernels
- * instead of the MFMA ones), "cnn_variant", "cnn_conv1_mfma", "cnn_pair", "cnn_big_units" (work units per CU from which 16-wave workgroups are used, default 12), "cnn_seg" (-1 auto / 0 off / 1 on: waves of a workgroup split one tile's positions, small batches of the 4-letter CNN kernel), "cnn_pair_seg" (-1 auto / 0 off / n workgroups per tile: position-segmented small-batch form of the wide-alphabet CNN kernel), "mlp_l1_mfma", "dense_slab" (1 = MLP / GE hidden layers wider than 128 are staged through LDS slabs by the workgroup), "grid_blocks", "poison_outputs" (test aid: NaN-fill score buffers first), "trace" (profiling aid, see fx_debug_trace_read), "cnn_quad" (1 = small launches of the 4-letter CNN (32 filters; kernel size 5 with <= 112 hidden units, 3 / 7 with 65-112) with seq_len <= 16 share each tile among four waves, 2 = at any size, 0 = off), "stage_fill" (1 = small CNN launches load the conv weights first and let idle waves bring the head's weights, 0 = whole image first), "dense_small" (1 = explorer-size MLP launches deal a tile's output tiles to the 8 waves of a workgroup and read the weights straight from L2, 2 = at any size, 0 = off), "cnn_seg_multi" (1 = the position-segmented 4-letter form may spread a tile over several workgroups, 0 = one workgroup per tile), "cnn_pair_seg4" (1 = the segmented wide-alphabet form may use 4-wave workgroups, 0 = 8-wave only), "dma_fill" (1 = weight images are copied global -> LDS directly, asynchronously, and the first layers start when their part has landed, 0 = through registers, whole image first), "stage_bytes" (1 = the MLP / GlobalEpistasis kernels copy a tile's sequence bytes into LDS with 16-byte loads, 0 = byte loads from global memory), "mlp_pair" (1 = MLP layer 1 on a 4-letter alphabet gathers one pre-summed row per pair of positions, 0 = one row per position), "dense_waves" (MLP / GE: 0 = auto, 8 / 16 = waves per workgroup) and "dense_few_waves_below" (auto: tiles per SIMD below which 8 waves are used, default 0 = never), "wave_prio" (1 = the waves that share a SIMD run at distinct, static issue priorities: A/B knob), "ge_bytetab" (1 = GlobalEpistasis layer 1 gathers from a per-position table indexed by the raw byte, 0 = LUT + code-indexed table).  Unknown key ->
- * FX_EINVAL. */
+/* Engine options (string key -> int64).  Unknown key -> FX_EINVAL.  The defaults are what the measurements under
+ * profiles/ selected; an integrator normally sets none of them.
+ *
+ *   key               default  meaning
+ *   ----------------  -------  ----------------------------------------------------------------------------------
+ *   grid_blocks       0        workgroups of the persistent scoring kernels; 0 = one per CU.  Multi-GPU callers leave
+ *                              a few CUs to RCCL's channel kernels (bench.py: num_cus - 4).
+ *   num_cus           (read)   compute units of the device (get only).
+ *   force_generic     0        1 = score with the shape-agnostic VALU kernels instead of the MFMA ones: an independent
+ *                              on-device cross-check (~80x slower), used by the tests.
+ *   poison_outputs    0        1 = NaN-fill score buffers before every launch, so that an element no kernel wrote is
+ *                              caught (test aid).
+ *   trace             0        1 = the MFMA scoring kernels stamp an in-kernel timeline (fx_debug_trace_read; needs the
+ *                              `make trace` build).
+ *   zero_copy_bytes   262144   host calls whose input + output fit in this many bytes read / write mapped pinned
+ *                              host memory directly (explorer-size calls: no copy enqueues).
+ *   zero_copy_mode    -1       larger host calls: -1 = decide per call (fx_plan_host_call), 0 = always copy,
+ *                              1 = always zero-copy.
+ *   train_rows        0        fx_train_fit: mini-batch rows per forward+backward workgroup; 0 = automatic (depends on
+ *                              the member's own shape and batch size only: a fit is bit-reproducible whatever it is
+ *                              trained next to).
+ *   train_threads     0        fx_train_fit: threads per forward+backward workgroup (256 / 512 / 1024); 0 = 1024.
+ *   train_lds         2        fx_train_fit: 2 = activations, gradients and weights of a slice live in LDS when they
+ *                              fit, 1 = activations and gradients only, 0 = global memory.
+ *
+ * Kernel-form selectors -- every one chooses between forms that give the SAME BITS (tested), so they are speed knobs
+ * only; the defaults are the measured winners and the losers stay selectable as the A/B baseline of the profiles:
+ *   cnn_variant, cnn_big_units, cnn_pair, cnn_seg, cnn_seg_multi, cnn_pair_seg, cnn_pair_seg4, cnn_quad   (CNN launch forms)
+ *   dense_small, dense_slab, dense_waves, dense_few_waves_below, dense_pipe, mlp_pair, ge_bytetab          (MLP / GE forms)
+ *   stage_bytes, stage_fill, dma_fill, wave_prio                                                             (staging / scheduling)
+ *   cnn_conv1_mfma, mlp_l1_mfma     (one-hot first layers on MFMA instead of the LDS gather: NOT bit-identical, within
+ *                                    the 1e-5 budget; the slower A/B baseline)
+ *   chunk_overlap                   (chunked host call on two streams: measured slower, off)
+ * What each does, its values and the measurement that decided it: flexs_amd/csrc/OPTIONS.md. */
 int fx_engine_set_option(fx_engine *e, const char *key, int64_t value);
 int fx_engine_get_option(fx_engine *e, const char *key, int64_t *value);
 /* hipEvent pair on the engine's stream: start..stop brackets whatever was
@@ -294,6 +325,9 @@ int fx_debug_trace_read(fx_engine *e, uint64_t *out, int64_t cap_words);
 int fx_debug_pack_weights(int kind, int L, int A, int F, int H, int K, const float *blob, int64_t n,
                           float *packed, int64_t cap);
 int fx_debug_myers(const uint8_t *a, int la, const uint8_t *b, int lb);
+/* The strip form of the same recurrence (patterns beyond 768 symbols on the device: csrc/myers.h fx_myers_strip), with
+ * strips of 64 x words_per_strip pattern rows (12 = the device's; 1 = test aid, many strip boundaries on short strings). */
+int fx_debug_myers_strips(const uint8_t *a, int la, const uint8_t *b, int lb, int words_per_strip);
 /* Host only (no GPU): ONE mini-batch training step of one member through the HOST build of csrc/train_core.h -- the
  * source the training kernels are compiled from, threads as loops, the MFMA as an fmaf chain.  The mini-batch is all
  * `rows` rows of `ascii` (<= 4096), cut into slices of R rows as the kernel would; weights / moments / step updated

@@ -118,7 +118,44 @@ def test_myers_boundaries():
         assert _native.debug_myers(a, b) == c_oracle.levenshtein(a, b)
         assert _native.debug_myers(a, a) == 0
         assert _native.debug_myers(a, a[1:] + a[:1]) == c_oracle.levenshtein(a, a[1:] + a[:1])
-    assert _native.debug_myers(b"x" * 769, b"x") == -1    # > 768 (12 words): unsupported pattern length
+    # beyond 768 symbols (12 words) the device runs the recurrence in strips of 768 pattern rows; so does the hook
+    assert _native.debug_myers(b"x" * 769, b"x") == 768
+
+
+def test_myers_in_strips_for_patterns_of_any_length():
+    """`editdistance.eval` (noisy_abstract_model.py:51) has no length limit: beyond 768 symbols the kernels run the
+    bit-parallel recurrence in strips whose boundary is one horizontal delta per text column (csrc/myers.h
+    fx_myers_strip).  Property test against the DP oracle: 64-row strips (many boundaries on short strings, every
+    strip-boundary / word-boundary alignment) and the device's 768-row strips on long ones."""
+    rng = np.random.default_rng(5)
+    for trial in range(300):
+        nsym = int(rng.choice([2, 4, 20]))
+        la, lb = int(rng.integers(0, 300)), int(rng.integers(0, 300))
+        a = bytes(rng.integers(65, 65 + nsym, la).astype(np.uint8))
+        if trial % 2 and la:
+            b = bytearray(a)
+            for _ in range(int(rng.integers(0, 10))):
+                i = int(rng.integers(0, max(len(b), 1)))
+                op = int(rng.integers(0, 3))
+                if op == 0 and b:
+                    b[i % len(b)] = int(rng.integers(65, 65 + nsym))
+                elif op == 1 and b:
+                    del b[i % len(b)]
+                else:
+                    b.insert(i % (len(b) + 1), int(rng.integers(65, 65 + nsym)))
+            b = bytes(b)
+        else:
+            b = bytes(rng.integers(65, 65 + nsym, lb).astype(np.uint8))
+        want = c_oracle.levenshtein(a, b)
+        assert _native.debug_myers_strips(a, b, 1) == want, (trial, la, len(b))
+        assert _native.debug_myers_strips(a, b, 12) == want
+    for la in (63, 64, 65, 128, 129, 767, 768, 769, 1000, 1536, 1537, 2400):
+        a = bytes([65 + (i * 7) % 4 for i in range(la)])
+        b = bytes([65 + (i * 5 + 1) % 4 for i in range(la + 3)])
+        for x, y in ((a, b), (b, a), (a, a), (a, a[5:] + a[:5]), (a, b""), (b"", a)):
+            want = c_oracle.levenshtein(x, y)
+            assert _native.debug_myers_strips(x, y, 1) == want and _native.debug_myers_strips(x, y, 12) == want
+            assert _native.debug_myers(x, y) == want
 
 
 def test_mlp_pair_rows_are_sums_of_the_single_position_rows():
