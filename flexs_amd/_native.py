@@ -86,6 +86,7 @@ SIGNATURES = {
     "fx_debug_pack_weights": (C.c_int, [C.c_int] * 6 + [_f32p, C.c_int64, _f32p, C.c_int64]),
     "fx_debug_myers": (C.c_int, [_vp, C.c_int, _vp, C.c_int]),
     "fx_debug_myers_strips": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int]),
+    "fx_debug_train_trace": (C.c_int, [_vp, _vp]),
     "fx_train_fit": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64, C.c_int, _u8p, _vp]),
     "fx_debug_train_step_host": (C.c_int, [C.c_int] * 6 + [_vp, _vp, _vp, _vp, _vp, C.c_int, _u8p, _vp, _vp, C.c_int, _vp]),
     "fx_debug_mfma_probe": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),

@@ -207,6 +207,7 @@ int fx_engine_destroy(fx_engine* e) {
     for (auto& p : e->d_scratch) if (p) (void)hipFree(p);
     if (e->d_zero_pool) (void)hipFree(e->d_zero_pool);
     if (e->d_train) (void)hipFree(e->d_train);
+    if (e->d_train_dbg) (void)hipFree(e->d_train_dbg);
     for (auto& p : e->h_pinned) if (p) (void)hipHostFree(p);
     if (e->h_err) (void)hipHostFree(e->h_err);
     if (e->d_lut) (void)hipFree(e->d_lut);
@@ -271,6 +272,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "train_rows")) return &e->train_rows;
     if (!std::strcmp(key, "train_lds")) return &e->train_lds;
     if (!std::strcmp(key, "train_threads")) return &e->train_threads;
+    if (!std::strcmp(key, "train_trace")) return &e->train_trace;
     if (!std::strcmp(key, "dense_waves")) return &e->dense_waves;
     if (!std::strcmp(key, "dense_few_waves_below")) return &e->dense_few_waves_below;
     return nullptr;
@@ -1049,6 +1051,13 @@ int fx_debug_time_score(fx_engine* e, fx_model* const* models, int M, const uint
     FX_HIP(e, hipEventRecord(e->ev1, e->stream));
     FX_HIP(e, hipEventSynchronize(e->ev1));
     FX_HIP(e, hipEventElapsedTime(total_ms, e->ev0, e->ev1));
+    return FX_OK;
+}
+int fx_debug_train_trace(fx_engine* e, uint64_t* out64) {
+    if (!e || !out64) return FX_EINVAL;
+    if (!e->d_train_dbg) return fx_fail(e, FX_ESTATE, "no training trace: set the option train_trace and run fx_train_fit");
+    FX_HIP(e, hipSetDevice(e->device));
+    FX_HIP(e, hipMemcpy(out64, e->d_train_dbg, 64 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return FX_OK;
 }
 int fx_debug_time_min_dist(fx_cache* c, int mode, const uint8_t* queries, int64_t Q, int reps, float* total_ms) {

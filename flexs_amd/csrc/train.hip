@@ -28,26 +28,35 @@ __global__ void __launch_bounds__(FB_MAX_THREADS) k_train_fb(const FxtJob* __res
     extern __shared__ __attribute__((aligned(16))) float fxt_smem[];
     const FxtJob& j = jobs[blockIdx.y];
     if (step >= j.total_steps || (int)blockIdx.x >= j.S) return;
-    const float* w_local = nullptr;
+    typedef FxtMem<3>::F lds_f;             // (plain pointers in the host pass of this file, address-space-qualified on the device)
+    typedef FxtMem<3>::CF lds_cf;
+    typedef FxtMem<1>::F glb_f;
+    typedef FxtMem<1>::CF glb_cf;
+    const FxtWg wg{(int)threadIdx.x, (int)blockDim.x};
+    const int slice = (int)blockIdx.x;
     if (j.w_in_lds) {
         // the member's whole parameter vector next to the slice's workspace: every operand of every layer then comes
-        // from LDS -- the step is ~80 dependent operand fetches long, each an L2 round trip (~1.2 us) otherwise
+        // from LDS through ds_read (see train_core.h "address spaces")
         float* wl = fxt_smem + j.ws_slice;
+        typedef float v4f __attribute__((ext_vector_type(4)));
         const int n4 = j.net.P >> 2;
-        const float4* src = reinterpret_cast<const float4*>(j.w);
-        float4* dst = reinterpret_cast<float4*>(wl);
-        for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * blockDim.x) {
-            float4 v[4];
+        const v4f* src = reinterpret_cast<const v4f*>(j.w);
+        v4f* dst = reinterpret_cast<v4f*>(wl);
+        for (int i0 = threadIdx.x; i0 < n4; i0 += 12 * blockDim.x) {      // 12 x 16 bytes in flight per thread: ~2 round trips for 100 KiB
+            v4f v[12];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) if (i0 + k * (int)blockDim.x < n4) v[k] = src[i0 + k * blockDim.x];
+            for (int k = 0; k < 12; ++k) { const int i = i0 + k * (int)blockDim.x; v[k] = src[i < n4 ? i : n4 - 1]; }   // (clamped: the loads stay unconditional, in registers)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) if (i0 + k * (int)blockDim.x < n4) dst[i0 + k * blockDim.x] = v[k];
+            for (int k = 0; k < 12; ++k) { const int i = i0 + k * (int)blockDim.x; if (i < n4) dst[i] = v[k]; }
         }
         for (int i = (n4 << 2) + threadIdx.x; i < j.net.P; i += blockDim.x) wl[i] = j.w[i];
-        w_local = wl;                       // (published by the first fxt_sync of the step)
+        // (published by the first fxt_sync of the step)
+        fxt_forward_backward<3, 3>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl);
+    } else if (j.ws_in_lds) {
+        fxt_forward_backward<3, 1>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (glb_cf)j.w);
+    } else {
+        fxt_forward_backward<1, 1>(j, wg, step, slice, ascii, lut, labels, (glb_f)(j.ws + (long long)slice * j.ws_slice), (glb_cf)j.w);
     }
-    fxt_forward_backward(j, FxtWg{(int)threadIdx.x, (int)blockDim.x}, step, (int)blockIdx.x, ascii, lut, labels,
-                         j.ws_in_lds ? fxt_smem : nullptr, w_local);
 }
 
 __global__ void __launch_bounds__(256) k_train_adam(const FxtJob* __restrict__ jobs, int step) {
@@ -188,6 +197,14 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
             FX_HIP(e, hipMemcpyAsync(d_lr, lr[(size_t)m].data(), sizeof(float) * (size_t)j.total_steps, hipMemcpyHostToDevice, st));
         }
     }
+    if (e->train_trace) {
+        if (!e->d_train_dbg && hipMalloc(reinterpret_cast<void**>(&e->d_train_dbg), 64 * sizeof(unsigned long long)) != hipSuccess) {
+            (void)hipGetLastError();
+            return fx_fail(e, FX_ENOMEM, "hipMalloc of the training trace failed");
+        }
+        FX_HIP(e, hipMemsetAsync(e->d_train_dbg, 0, 64 * sizeof(unsigned long long), st));
+        hj[0].dbg = e->d_train_dbg;
+    }
     FX_HIP(e, hipMemcpyAsync(d_jobs, hj.data(), sizeof(FxtJob) * (size_t)M, hipMemcpyHostToDevice, st));
     // (the pageable host sources above -- hj, lr -- are staged by the runtime before hipMemcpyAsync returns)
 
@@ -248,7 +265,7 @@ int fx_debug_train_step_host(int kind, int L, int A, int F, int H, int K, float*
     j.ws = ws.data();
     float loss = 0.f;
     j.step_loss = &loss;
-    for (int s = 0; s < j.S; ++s) fxt_forward_backward(j, FxtWg{0, 1}, 0, s, ascii, lut, labels);
+    for (int s = 0; s < j.S; ++s) fxt_forward_backward<0, 0>(j, FxtWg{0, 1}, 0, s, ascii, lut, labels, j.ws + (long long)s * j.ws_slice, (const float*)j.w);
     fxt_step_loss(j, 0);
     for (int i = 0; i < j.net.P; ++i) fxt_adam(j, 0, i);
     *step += 1;

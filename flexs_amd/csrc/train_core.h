@@ -87,6 +87,7 @@ FXT_HD FxtNet fxt_net(int kind, int L, int A, int F, int H, int K) {
 // Workspace of one slice (floats): codes, activations, gradients.  Offsets relative to the slice's base.
 struct FxtWs {
     int codes;                  // R x L      alphabet indices (stored as int32 in the float buffer)
+    int ylab, yvalid;           // R          the rows' labels and validity (1.0 / 0.0), fetched together with the codes
     int a[3];                   // R x L1 x F post-ReLU conv outputs
     int dzA, dzB;               // R x L1 x F gradient ping-pong
     int g, cnt, dg;             // R x F      pooled maxima, tie counts, gradient
@@ -99,6 +100,8 @@ FXT_HD FxtWs fxt_ws(const FxtNet& n, int R) {
     FxtWs w{};
     int off = 0;
     w.codes = off; off += R * n.L;
+    w.ylab = off; off += R;
+    w.yvalid = off; off += R;
     if (n.kind == 0) {
         const int s = R * n.L1 * n.F;
         for (int i = 0; i < 3; ++i) { w.a[i] = off; off += s; }
@@ -108,8 +111,15 @@ FXT_HD FxtWs fxt_ws(const FxtNet& n, int R) {
         w.cnt = off; off += R * n.F;
         w.dg = off; off += R * n.F;
     }
-    for (int i = 0; i < n.nl; ++i) { w.act[i] = off; off += R * n.dim[i + 1]; }
-    for (int i = 0; i < n.nl; ++i) { w.du[i] = off; off += R * n.dim[i + 1]; }
+    // (fixed trip counts: with run-time bounds the offset table is indexed dynamically and lives in scratch memory)
+#if FXT_DEVICE
+#pragma unroll
+#endif
+    for (int i = 0; i < FXT_MAX_LAYERS; ++i) { w.act[i] = off; if (i < n.nl) off += R * n.dim[i + 1]; }
+#if FXT_DEVICE
+#pragma unroll
+#endif
+    for (int i = 0; i < FXT_MAX_LAYERS; ++i) { w.du[i] = off; if (i < n.nl) off += R * n.dim[i + 1]; }
     w.total = (off + 3) & ~3;
     return w;
 }
@@ -132,7 +142,16 @@ struct FxtJob {
     int ws_in_lds;              // 1 = the slice's workspace fits the workgroup's LDS and lives there
     int w_in_lds;               // 1 = ... and the member's weights fit next to it (staged at kernel start)
     float* step_loss;           // [total_steps] mean squared error of the step's valid rows (before the update)
+    unsigned long long* dbg;    // profiling aid (engine option "train_trace"): phase timestamps of workgroup (0, 0), else nullptr
 };
+
+// q = x / d for 0 <= x < 2^16, 1 <= d < 2^16 without a hardware divide (an integer division is ~40 instructions on
+// the GPU and the GEMM tiles decompose their row index once each): q = (x * ceil(2^32 / d)) >> 32, exact in that range.
+struct FxtDiv { unsigned d, magic; };
+FXT_HD FxtDiv fxt_div(int d) { return FxtDiv{(unsigned)d, d > 1 ? (unsigned)(0xFFFFFFFFull / (unsigned)d + 1ull) : 0u}; }
+FXT_HD int fxt_quot(int x, FxtDiv dv) {
+    return dv.d > 1 ? (int)(((unsigned long long)(unsigned)x * dv.magic) >> 32) : x;
+}
 
 // Execution context of a workgroup: on the device one instance per thread, on the host ONE instance that plays
 // every thread in turn (a phase is data-parallel; phases are separated by fxt_sync).
@@ -143,6 +162,12 @@ FXT_HD void fxt_sync() {
     __syncthreads();
 #endif
 }
+// phase stamp k of workgroup (0, 0): the 100 MHz wall clock after the phase's barrier
+#if FXT_DEVICE
+#define FXT_STAMP(k) do { if (j.dbg && wg.tid == 0 && slice == 0) j.dbg[(k)] = wall_clock64(); } while (0)
+#else
+#define FXT_STAMP(k) do { } while (0)
+#endif
 
 FXT_HD bool fxt_keep(const FxtJob& j, int step, int slot, int h) {
     if (j.keep) return j.keep[((long long)step * j.batch + slot) * j.net.H + h] != 0;
@@ -156,8 +181,8 @@ FXT_HD bool fxt_keep(const FxtJob& j, int step, int slot, int h) {
 // ---------------------------------------------------------------------------------------------------------------
 // C[m][n] = sum over (ko, ki) of A(m, ko, ki) * B(ko, ki, n),  m < Md, n < Nd, ko < Ko, ki < Ki.
 // The contraction index is kept as a PAIR so that conv taps / batch rows never need a division in the inner loop;
-// each ko runs ceil(Ki / 4) k-steps (the overhang multiplies zeros).  FA: prep(m) -> per-row state (computed once
-// per tile), at(state, ko, ki); FB: at(ko, ki, n); FC: put(m, n, value).
+// each ko runs ceil(Ki / 4) k-steps (the overhang multiplies zeros).  FA: prep(m, kq) -> per-lane state (once per
+// tile), at(state, ko, k0) = A(m, ko, k0 + kq); FB: prep(n, kq), at(state, ko, k0) = B(ko, k0 + kq, n); FC: put(m, n, value).
 template <class FA, class FB, class FC>
 FXT_HD void fxt_gemm(const FxtWg& wg, int Md, int Nd, int Ko, int Ki, const FA& fa, const FB& fb, const FC& fc) {
 #if FXT_DEVICE
@@ -171,7 +196,8 @@ FXT_HD void fxt_gemm(const FxtWg& wg, int Md, int Nd, int Ko, int Ki, const FA& 
         const int m0 = (t / tn) << 4, n0 = (t % tn) << 4;
         const int m = m0 + i, n = n0 + i;
         const bool mok = m < Md, nok = n < Nd;
-        const auto st = fa.prep(mok ? m : 0);
+        const auto sa = fa.prep(mok ? m : 0, kq);
+        const auto sb = fb.prep(nok ? n : 0, kq);
         f4_t acc = {0.f, 0.f, 0.f, 0.f};
         // The operands come from L2 / LDS through index functors: issued one k-step at a time every MFMA would wait a
         // full memory round trip (the first build ran at ~1 us per k-step).  U k-steps are loaded first, then
@@ -181,10 +207,14 @@ FXT_HD void fxt_gemm(const FxtWg& wg, int Md, int Nd, int Ko, int Ki, const FA& 
             float a[U], b[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int ki = k0 + kq;
-                const bool kok = (s + u < T) && ki < Ki;
-                a[u] = (mok && kok) ? fa.at(st, ko, ki) : 0.f;
-                b[u] = (nok && kok) ? fb.at(ko, ki, n) : 0.f;
+                // (a k-step past the end re-reads the first one -- always in range -- and is multiplied by zero: a select
+                // instead of a branch around every load; the functors' own range checks clamp the same way)
+                const bool live = s + u < T;
+                const bool kok = live && k0 + kq < Ki;
+                const float av = fa.at(sa, live ? ko : 0, live ? k0 : 0);
+                const float bv = fb.at(sb, live ? ko : 0, live ? k0 : 0);
+                a[u] = (mok && kok) ? av : 0.f;
+                b[u] = (nok && kok) ? bv : 0.f;
                 k0 += 4;
                 if (k0 >= Ki) { k0 = 0; ++ko; }
             }
@@ -202,115 +232,170 @@ FXT_HD void fxt_gemm(const FxtWg& wg, int Md, int Nd, int Ko, int Ki, const FA& 
     }
 #else
     (void)wg;
-    for (int m = 0; m < Md; ++m) {
-        const auto st = fa.prep(m);
+    for (int m = 0; m < Md; ++m)
         for (int n = 0; n < Nd; ++n) {
             float acc = 0.f;
             for (int ko = 0; ko < Ko; ++ko)
-                for (int ki = 0; ki < Ki; ++ki) acc = fmaf(fa.at(st, ko, ki), fb.at(ko, ki, n), acc);
+                for (int ki = 0; ki < Ki; ++ki)          // element ki belongs to lane group kq = ki % 4 of k-step k0 = ki - kq
+                    acc = fmaf(fa.at(fa.prep(m, ki & 3), ko, ki & ~3), fb.at(fb.prep(n, ki & 3), ko, ki & ~3), acc);
             fc.put(m, n, acc);
         }
-    }
 #endif
 }
 
+// ---- address spaces ---------------------------------------------------------------------------------------------
+// A pointer whose address space the compiler does not know is read with flat_load, and a FLAT access that resolves to
+// LDS is several times slower than ds_read (phase timeline, profiles/r3_train_trace.log: ~1.1 us per group of eight
+// k-steps with every operand in LDS).  The step is therefore compiled per placement -- workspace in LDS (3) or global
+// memory (1), weights in LDS or global memory -- with address-space-qualified pointer types; the host build has one.
+#if FXT_DEVICE
+template <int AS> struct FxtMem {
+    typedef __attribute__((address_space(AS))) float* F;
+    typedef const __attribute__((address_space(AS))) float* CF;
+    typedef __attribute__((address_space(AS))) int* I;
+    typedef const __attribute__((address_space(AS))) int* CI;
+};
+template <> struct FxtMem<0> { typedef float* F; typedef const float* CF; typedef int* I; typedef const int* CI; };   // (flat / host)
+#else
+template <int AS> struct FxtMem { typedef float* F; typedef const float* CF; typedef int* I; typedef const int* CI; };
+#endif
+
 // ---- operand functors ------------------------------------------------------------------------------------------
-struct FxtRowMajorA {          // A(m, 0, k) = p[m * ld + k]
-    const float* p; int ld;
-    FXT_HD int prep(int m) const { return m * ld; }
-    FXT_HD float at(int st, int, int ki) const { return p[st + ki]; }
+// A k-step covers contraction indices ki = k0 + kq, kq = lane >> 4 in 0..3, k0 wave-uniform.  Every functor splits its
+// address into a per-lane part (`prep`, once per tile: row / column decomposition, the kq term) and a wave-uniform part
+// built from (ko, k0) in `at` -- scalar arithmetic on the GPU -- so that an operand fetch costs one or two vector
+// instructions.  (The first build recomputed the whole index per element: ~12 VALU instructions per operand, and with
+// four waves per SIMD the address arithmetic, not the memory, set the step time.)
+template <class P>
+struct FxtRowMajorA {          // A(m, 0, ki) = p[m * ld + ki]
+    P p; int ld;
+    FXT_HD int prep(int m, int kq) const { return m * ld + kq; }
+    FXT_HD float at(int st, int, int k0) const { return p[st + k0]; }
 };
-struct FxtRowMajorB {          // B(0, k, n) = p[k * ld + n]
-    const float* p; int ld;
-    FXT_HD float at(int, int ki, int n) const { return p[ki * ld + n]; }
+template <class P>
+struct FxtRowMajorB {          // B(0, ki, n) = p[ki * ld + n]
+    P p; int ld;
+    FXT_HD int prep(int n, int kq) const { return kq * ld + n; }
+    FXT_HD float at(int st, int, int k0) const { return p[st + k0 * ld]; }
 };
-struct FxtTransB {             // B(0, k, n) = p[n * ld + k]      (W^T for the input gradients)
-    const float* p; int ld;
-    FXT_HD float at(int, int ki, int n) const { return p[n * ld + ki]; }
+template <class P>
+struct FxtTransB {             // B(0, ki, n) = p[n * ld + ki]      (W^T for the input gradients)
+    P p; int ld;
+    FXT_HD int prep(int n, int kq) const { return n * ld + kq; }
+    FXT_HD float at(int st, int, int k0) const { return p[st + k0]; }
 };
 // conv forward: rows m = (r, t), contraction (tap j, channel c): A = x[r][t + j - pl][c] inside the sequence, else 0
+template <class P>
 struct FxtConvA {
-    const float* x; int Lx, C, pl;
-    struct St { int base, t; };
-    FXT_HD St prep(int m) const { const int r = m / Lx, t = m - r * Lx; return St{r * Lx * C, t}; }
-    FXT_HD float at(St s, int j, int c) const {
-        const int p = s.t + j - pl;
-        return (p >= 0 && p < Lx) ? x[s.base + p * C + c] : 0.f;
+    P x; int Lx, C, pl; FxtDiv dL;
+    struct St { int base, tp; };
+    FXT_HD St prep(int m, int kq) const { const int r = fxt_quot(m, dL), t = m - r * Lx; return St{(m - pl) * C + kq, t - pl}; }
+    FXT_HD float at(St s, int j, int k0) const {
+        const int p = s.tp + j;
+        const bool ok = p >= 0 && p < Lx;
+        const float v = x[ok ? s.base + j * C + k0 : 0];             // (clamped index + select: no branch around the load)
+        return ok ? v : 0.f;
     }
 };
+template <class P>
 struct FxtConvW {              // B((j, c), n) = w[(j * C + c) * F + n]
-    const float* w; int C, F;
-    FXT_HD float at(int j, int c, int n) const { return w[(j * C + c) * F + n]; }
+    P w; int C, F;
+    FXT_HD int prep(int n, int kq) const { return kq * F + n; }
+    FXT_HD float at(int st, int j, int k0) const { return w[st + (j * C + k0) * F]; }
 };
 // conv input gradient: rows m = (r, s), contraction (tap j, out channel o): A = dz[r][s - j + pl][o], B = w[j][n][o]
+template <class P>
 struct FxtConvGradA {
-    const float* dz; int Lx, F, pl;
-    struct St { int base, s; };
-    FXT_HD St prep(int m) const { const int r = m / Lx, s = m - r * Lx; return St{r * Lx * F, s}; }
-    FXT_HD float at(St st, int j, int o) const {
-        const int p = st.s - j + pl;
-        return (p >= 0 && p < Lx) ? dz[st.base + p * F + o] : 0.f;
+    P dz; int Lx, F, pl; FxtDiv dL;
+    struct St { int base, sp; };
+    FXT_HD St prep(int m, int kq) const { const int r = fxt_quot(m, dL), s = m - r * Lx; return St{(m + pl) * F + kq, s + pl}; }
+    FXT_HD float at(St st, int j, int k0) const {
+        const int p = st.sp - j;
+        const bool ok = p >= 0 && p < Lx;
+        const float v = dz[ok ? st.base - j * F + k0 : 0];
+        return ok ? v : 0.f;
     }
 };
+template <class P>
 struct FxtConvGradW {          // B((j, o), n = c) = w[(j * C + c) * F + o]
-    const float* w; int C, F;
-    FXT_HD float at(int j, int o, int n) const { return w[(j * C + n) * F + o]; }
+    P w; int C, F;
+    FXT_HD int prep(int n, int kq) const { return n * F + kq; }
+    FXT_HD float at(int st, int j, int k0) const { return w[st + j * C * F + k0]; }
 };
 // conv weight gradient: rows m = (tap j, channel c) plus ONE extra row for the bias; contraction (row r, position t)
+template <class P>
 struct FxtConvWGradA {
-    const float* x; int Lx, C, pl, rows;     // rows = taps * C (row `rows` is the bias row: all ones)
-    struct St { int j, c; };
-    FXT_HD St prep(int m) const { return m >= rows ? St{-1, 0} : St{m / C, m % C}; }
-    FXT_HD float at(St s, int r, int t) const {
-        if (s.j < 0) return 1.f;
-        const int p = t + s.j - pl;
-        return (p >= 0 && p < Lx) ? x[(r * Lx + p) * C + s.c] : 0.f;
+    P x; int Lx, C, pl, rows; FxtDiv dC;     // rows = taps * C (row `rows` is the bias row: all ones)
+    struct St { int off, tp; };              // off < 0: bias row
+    FXT_HD St prep(int m, int kq) const {
+        if (m >= rows) return St{-1, 0};
+        const int j = fxt_quot(m, dC), c = m - j * C;
+        return St{(j - pl + kq) * C + c + (1 << 30), j - pl + kq};      // (+2^30: keeps `off` non-negative for taps left of the sequence)
+    }
+    FXT_HD float at(St s, int r, int k0) const {
+        const int p = s.tp + k0;
+        const bool ok = s.off >= 0 && p >= 0 && p < Lx;
+        const float v = x[ok ? s.off - (1 << 30) + (r * Lx + k0) * C : 0];
+        return s.off < 0 ? 1.f : (ok ? v : 0.f);
     }
 };
 // conv1 / first dense layer: x is the one-hot of the codes.  Rows m = (j, c) = m / A, m % A plus the bias row.
 // conv = 1: contraction (ko = row r, ki = position t), element [code[r][t + j] == c];
 // conv = 0: contraction (ko = 0, ki = row r),          element [code[r][j] == c]   (j = the position of input unit m)
+template <class P>
 struct FxtOneHotWGradA {
-    const int* codes; int L, A, rows, conv;
-    struct St { int j, c; };
-    FXT_HD St prep(int m) const { return m >= rows ? St{-1, 0} : St{m / A, m % A}; }
-    FXT_HD float at(St s, int ko, int ki) const {
-        if (s.j < 0) return 1.f;
-        const int r = conv ? ko : ki, t = conv ? ki : 0;
-        return codes[r * L + t + s.j] == s.c ? 1.f : 0.f;
+    P codes; int L, A, rows, conv; FxtDiv dA;
+    struct St { int off, c; };               // off < 0: bias row
+    FXT_HD St prep(int m, int kq) const {
+        if (m >= rows) return St{-1, 0};
+        const int j = fxt_quot(m, dA), c = m - j * A;
+        return St{conv ? j + kq : kq * L + j, c};
+    }
+    FXT_HD float at(St s, int ko, int k0) const {
+        const int code = codes[s.off < 0 ? 0 : s.off + (conv ? ko * L + k0 : k0 * L)];
+        return (s.off < 0 || code == s.c) ? 1.f : 0.f;
     }
 };
+template <class P>
 struct FxtPosMajorB {          // B((r, t), n) = p[(r * Lx + t) * F + n]
-    const float* p; int Lx, F;
-    FXT_HD float at(int r, int t, int n) const { return p[(r * Lx + t) * F + n]; }
+    P p; int Lx, F;
+    FXT_HD int prep(int n, int kq) const { return kq * F + n; }
+    FXT_HD float at(int st, int r, int k0) const { return p[st + (r * Lx + k0) * F]; }
 };
 // dense weight gradient: rows m = input unit k plus the bias row; contraction over the slice's rows r
+template <class P>
 struct FxtDenseWGradA {
-    const float* in; int Kd;
-    FXT_HD int prep(int m) const { return m; }
-    FXT_HD float at(int m, int, int r) const { return m >= Kd ? 1.f : in[r * Kd + m]; }
+    P in; int Kd;
+    FXT_HD int prep(int m, int kq) const { return m >= Kd ? -1 : kq * Kd + m; }
+    FXT_HD float at(int st, int, int k0) const { const float v = in[st < 0 ? 0 : st + k0 * Kd]; return st < 0 ? 1.f : v; }
 };
 
 // ---------------------------------------------------------------------------------------------------------------
 // Forward + backward of one slice.  `slice` rows [slice * R, slice * R + R) of the mini-batch `step`.
-// `ws_local`: where the slice's workspace lives -- the workgroup's LDS on the device when it fits (activations are
-// written by one phase and read by the next: an LDS round trip instead of an L2 one), else nullptr = the global arena.
-// `w_local`: the member's weights staged in LDS by the caller (device, when they fit next to the workspace), else nullptr.
+// `ws`: the slice's workspace -- the workgroup's LDS on the device when it fits (activations are written by one phase
+// and read by the next: an LDS round trip instead of an L2 one; WSAS = 3), else its row of the global arena (WSAS = 1).
+// `W`: the member's weights, staged in LDS by the caller when they fit next to the workspace (WAS = 3), else j.w.
+template <int WSAS, int WAS>
 FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int slice, const uint8_t* ascii,
-                                 const uint8_t* lut, const float* labels, float* ws_local = nullptr,
-                                 const float* w_local = nullptr) {
+                                 const uint8_t* lut, const float* labels, typename FxtMem<WSAS>::F ws,
+                                 typename FxtMem<WAS>::CF W) {
+    typedef typename FxtMem<WSAS>::F WsF;
+    typedef typename FxtMem<WSAS>::CF WsCF;
+    typedef typename FxtMem<WSAS>::I WsI;
+    typedef typename FxtMem<WSAS>::CI WsCI;
+    typedef typename FxtMem<WAS>::CF WCF;
     const FxtNet& n = j.net;
     const int R = j.R, L = n.L, A = n.A, F = n.F;
     const FxtWs w = fxt_ws(n, R);
-    float* ws = ws_local ? ws_local : j.ws + (long long)slice * j.ws_slice;
-    int* codes = reinterpret_cast<int*>(ws + w.codes);
+    WsI codes = (WsI)(ws + w.codes);
     float* part = j.partial + (long long)slice * (n.P + 1);
-    const float* W = w_local ? w_local : j.w;
     const int32_t* order = j.order + (long long)step * j.batch;
     const int slot0 = slice * R;
     const int sidx = step % j.steps_per_epoch;
     const int nvalid = (j.n - sidx * j.batch) < j.batch ? (j.n - sidx * j.batch) : j.batch;
+    FXT_STAMP(0);
     const float keep_scale = 1.f / (1.f - FXT_DROPOUT);
+    const FxtDiv dL1 = fxt_div(n.kind == 0 ? n.L1 : 1), dF = fxt_div(n.kind == 0 ? F : 1), dA = fxt_div(A);
 
     // ---- the slice's rows as alphabet indices (padding slots read row 0: their gradient is zeroed at the loss)
     FXT_FOR(i, R * L, wg) {
@@ -319,12 +404,18 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         const int row = (slot < j.batch && order[slot] >= 0) ? order[slot] : 0;
         codes[i] = lut[ascii[(long long)row * L + l]];
     }
-    fxt_sync();
+    FXT_FOR(r, R, wg) {                     // (the label fetch is a dependent global load too: issued here, used after the forward)
+        const int slot = slot0 + r;
+        const bool valid = slot < j.batch && order[slot] >= 0;
+        ws[w.ylab + r] = labels[valid ? order[slot] : 0];
+        ws[w.yvalid + r] = valid ? 1.f : 0.f;
+    }
+    fxt_sync(); FXT_STAMP(1);
 
-    const float* feat = nullptr;            // input of the dense stack when it is not the one-hot
+    WsCF feat = nullptr;            // input of the dense stack when it is not the one-hot
     if (n.kind == 0) {
         const int L1 = n.L1, K = n.K;
-        float* a1 = ws + w.a[0]; float* a2 = ws + w.a[1]; float* a3 = ws + w.a[2];
+        WsF a1 = ws + w.a[0]; WsF a2 = ws + w.a[1]; WsF a3 = ws + w.a[2];
         // conv1 ('valid') on a one-hot input: a sum of K kernel rows
         FXT_FOR(i, R * L1 * F, wg) {
             const int o = i % F, rt = i / F, t = rt % L1, r = rt / L1;
@@ -332,20 +423,20 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
             for (int jj = 0; jj < K; ++jj) s += W[n.off_cw[0] + (jj * A + codes[r * L + t + jj]) * F + o];
             a1[i] = s > 0.f ? s : 0.f;
         }
-        fxt_sync();
+        fxt_sync(); FXT_STAMP(2);
         {   // conv2 ('same', K taps)
-            const float* b = W + n.off_cb[1];
-            struct Put { float* y; const float* b; int F; FXT_HD void put(int m, int nn, float v) const { v += b[nn]; y[m * F + nn] = v > 0.f ? v : 0.f; } };
-            fxt_gemm(wg, R * L1, F, K, F, FxtConvA{a1, L1, F, (K - 1) / 2}, FxtConvW{W + n.off_cw[1], F, F}, Put{a2, b, F});
+            WCF b = W + n.off_cb[1];
+            struct Put { WsF y; WCF b; int F; FXT_HD void put(int m, int nn, float v) const { v += b[nn]; y[m * F + nn] = v > 0.f ? v : 0.f; } };
+            fxt_gemm(wg, R * L1, F, K, F, FxtConvA<WsCF>{a1, L1, F, (K - 1) / 2, dL1}, FxtConvW<WCF>{W + n.off_cw[1], F, F}, Put{a2, b, F});
         }
-        fxt_sync();
+        fxt_sync(); FXT_STAMP(3);
         {   // conv3 ('same', A - 1 taps)
-            const float* b = W + n.off_cb[2];
-            struct Put { float* y; const float* b; int F; FXT_HD void put(int m, int nn, float v) const { v += b[nn]; y[m * F + nn] = v > 0.f ? v : 0.f; } };
-            fxt_gemm(wg, R * L1, F, n.K3, F, FxtConvA{a2, L1, F, (n.K3 - 1) / 2}, FxtConvW{W + n.off_cw[2], F, F}, Put{a3, b, F});
+            WCF b = W + n.off_cb[2];
+            struct Put { WsF y; WCF b; int F; FXT_HD void put(int m, int nn, float v) const { v += b[nn]; y[m * F + nn] = v > 0.f ? v : 0.f; } };
+            fxt_gemm(wg, R * L1, F, n.K3, F, FxtConvA<WsCF>{a2, L1, F, (n.K3 - 1) / 2, dL1}, FxtConvW<WCF>{W + n.off_cw[2], F, F}, Put{a3, b, F});
         }
-        fxt_sync();
-        float* g = ws + w.g; float* cnt = ws + w.cnt;
+        fxt_sync(); FXT_STAMP(4);
+        WsF g = ws + w.g; WsF cnt = ws + w.cnt;
         FXT_FOR(i, R * F, wg) {             // GlobalMaxPooling1D + the number of positions that attain the maximum
             const int r = i / F, f = i - r * F;
             float mx = a3[(r * L1) * F + f];
@@ -354,16 +445,22 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
             for (int t = 0; t < L1; ++t) c += a3[(r * L1 + t) * F + f] == mx;
             g[i] = mx; cnt[i] = (float)c;
         }
-        fxt_sync();
+        fxt_sync(); FXT_STAMP(5);
         feat = g;
     }
 
-    // ---- dense stack, forward
-    for (int li = 0; li < n.nl; ++li) {
+    // ---- dense stack, forward  (unrolled over the at most four layers: with a compile-time layer index the workspace
+    // offsets are registers -- indexed at run time the little offset table lived in scratch memory, a global round trip
+    // per access in the middle of the step)
+#if FXT_DEVICE
+#pragma unroll
+#endif
+    for (int li = 0; li < FXT_MAX_LAYERS; ++li) {
+        if (li >= n.nl) break;
         const int Kd = n.dim[li], Nd = n.dim[li + 1];
-        const float* Wl = W + n.off_w[li];
-        const float* bl = W + n.off_b[li];
-        float* out = ws + w.act[li];
+        WCF Wl = W + n.off_w[li];
+        WCF bl = W + n.off_b[li];
+        WsF out = ws + w.act[li];
         const bool last = li == n.nl - 1;
         const bool drop = li == n.drop_layer;
         if (li == 0 && n.onehot_in) {
@@ -374,9 +471,9 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
                 out[i] = (last || s > 0.f) ? s : 0.f;
             }
         } else {
-            const float* in = li == 0 ? feat : ws + w.act[li - 1];
+            WsCF in = li == 0 ? feat : ws + w.act[li - 1];
             struct Put {
-                float* y; const float* b; int Nd; bool last, drop; const FxtJob* j; int step, slot0; float ks;
+                WsF y; WCF b; int Nd; bool last, drop; const FxtJob* j; int step, slot0; float ks;
                 FXT_HD void put(int m, int nn, float v) const {
                     v += b[nn];
                     if (!last) v = v > 0.f ? v : 0.f;
@@ -384,22 +481,23 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
                     y[m * Nd + nn] = v;
                 }
             };
-            fxt_gemm(wg, R, Nd, 1, Kd, FxtRowMajorA{in, Kd}, FxtRowMajorB{Wl, Nd}, Put{out, bl, Nd, last, drop, &j, step, slot0, keep_scale});
+            fxt_gemm(wg, R, Nd, 1, Kd, FxtRowMajorA<WsCF>{in, Kd}, FxtRowMajorB<WCF>{Wl, Nd}, Put{out, bl, Nd, last, drop, &j, step, slot0, keep_scale});
         }
-        fxt_sync();
+        fxt_sync(); FXT_STAMP(20 + li);
     }
 
     // ---- loss: d(mean over valid rows of (pred - y)^2) / d pred
     {
-        const float* pred = ws + w.act[n.nl - 1];
-        float* du = ws + w.du[n.nl - 1];
+        // (selects, not w.act[n.nl - 1]: a run-time index would put the offset table into scratch memory)
+        const int last_act = n.nl == 4 ? w.act[3] : (n.nl == 3 ? w.act[2] : (n.nl == 2 ? w.act[1] : w.act[0]));
+        const int last_du = n.nl == 4 ? w.du[3] : (n.nl == 3 ? w.du[2] : (n.nl == 2 ? w.du[1] : w.du[0]));
+        WsCF pred = ws + last_act;
+        WsF du = ws + last_du;
         FXT_FOR(r, R, wg) {
-            const int slot = slot0 + r;
-            const bool valid = slot < j.batch && order[slot] >= 0;
-            const float e = valid ? pred[r] - labels[order[slot]] : 0.f;
+            const float e = ws[w.yvalid + r] != 0.f ? pred[r] - ws[w.ylab + r] : 0.f;
             du[r] = 2.f * e / (float)nvalid;
         }
-        fxt_sync();
+        fxt_sync(); FXT_STAMP(7);
         FXT_FOR(i, 1, wg) {                 // the slice's sum of squared errors (fixed order)
             float sse = 0.f;
             for (int r = 0; r < R; ++r) { const float e = du[r] * (float)nvalid * 0.5f; sse += e * e; }
@@ -408,55 +506,61 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
     }
 
     // ---- dense stack, backward
-    for (int li = n.nl - 1; li >= 0; --li) {
+#if FXT_DEVICE
+#pragma unroll
+#endif
+    for (int lq = 0; lq < FXT_MAX_LAYERS; ++lq) {
+        const int li = FXT_MAX_LAYERS - 1 - lq;
+        if (li >= n.nl) continue;
         const int Kd = n.dim[li], Nd = n.dim[li + 1];
-        const float* Wl = W + n.off_w[li];
-        const float* du = ws + w.du[li];
+        WCF Wl = W + n.off_w[li];
+        WsCF du = ws + w.du[li];
         struct PutW { float* gw; float* gb; int Kd, Nd; FXT_HD void put(int m, int nn, float v) const { if (m < Kd) gw[m * Nd + nn] = v; else gb[nn] = v; } };
         const PutW putw{part + n.off_w[li], part + n.off_b[li], Kd, Nd};
         if (li == 0 && n.onehot_in) {
-            fxt_gemm(wg, Kd + 1, Nd, 1, R, FxtOneHotWGradA{codes, L, A, Kd, 0}, FxtRowMajorB{du, Nd}, putw);
+            fxt_gemm(wg, Kd + 1, Nd, 1, R, FxtOneHotWGradA<WsCI>{codes, L, A, Kd, 0, dA}, FxtRowMajorB<WsCF>{du, Nd}, putw);
         } else {
-            const float* in = li == 0 ? feat : ws + w.act[li - 1];
-            fxt_gemm(wg, Kd + 1, Nd, 1, R, FxtDenseWGradA{in, Kd}, FxtRowMajorB{du, Nd}, putw);
+            WsCF in = li == 0 ? feat : ws + w.act[li - 1];
+            fxt_gemm(wg, Kd + 1, Nd, 1, R, FxtDenseWGradA<WsCF>{in, Kd}, FxtRowMajorB<WsCF>{du, Nd}, putw);
             // gradient w.r.t. the layer's input; through the previous layer's ReLU (and Dropout: a dropped unit's
             // stored output is 0, a kept one carries the 1 / (1 - rate) scale)
             if (li > 0) {
                 const bool dropped = (li - 1) == n.drop_layer;
-                struct PutX { float* d; const float* y; int Kd; float ks; FXT_HD void put(int m, int nn, float v) const { d[m * Kd + nn] = y[m * Kd + nn] > 0.f ? v * ks : 0.f; } };
-                fxt_gemm(wg, R, Kd, 1, Nd, FxtRowMajorA{du, Nd}, FxtTransB{Wl, Nd}, PutX{ws + w.du[li - 1], in, Kd, dropped ? keep_scale : 1.f});
+                struct PutX { WsF d; WsCF y; int Kd; float ks; FXT_HD void put(int m, int nn, float v) const { d[m * Kd + nn] = y[m * Kd + nn] > 0.f ? v * ks : 0.f; } };
+                fxt_gemm(wg, R, Kd, 1, Nd, FxtRowMajorA<WsCF>{du, Nd}, FxtTransB<WCF>{Wl, Nd}, PutX{ws + w.du[li - 1], in, Kd, dropped ? keep_scale : 1.f});
             } else {
-                struct PutG { float* d; int Kd; FXT_HD void put(int m, int nn, float v) const { d[m * Kd + nn] = v; } };
-                fxt_gemm(wg, R, Kd, 1, Nd, FxtRowMajorA{du, Nd}, FxtTransB{Wl, Nd}, PutG{ws + w.dg, Kd});
+                struct PutG { WsF d; int Kd; FXT_HD void put(int m, int nn, float v) const { d[m * Kd + nn] = v; } };
+                fxt_gemm(wg, R, Kd, 1, Nd, FxtRowMajorA<WsCF>{du, Nd}, FxtTransB<WCF>{Wl, Nd}, PutG{ws + w.dg, Kd});
             }
         }
-        fxt_sync();
+        fxt_sync(); FXT_STAMP(30 + li);
     }
 
     if (n.kind == 0) {
         const int L1 = n.L1, K = n.K, K3 = n.K3;
-        const float* a1 = ws + w.a[0]; const float* a2 = ws + w.a[1]; const float* a3 = ws + w.a[2];
-        const float* g = ws + w.g; const float* cnt = ws + w.cnt; const float* dg = ws + w.dg;
-        float* dzA = ws + w.dzA; float* dzB = ws + w.dzB;
+        WsCF a1 = ws + w.a[0]; WsCF a2 = ws + w.a[1]; WsCF a3 = ws + w.a[2];
+        WsCF g = ws + w.g; WsCF cnt = ws + w.cnt; WsCF dg = ws + w.dg;
+        WsF dzA = ws + w.dzA; WsF dzB = ws + w.dzB;
         FXT_FOR(i, R * L1 * F, wg) {        // max-pool backward (ties share evenly) through conv3's ReLU
             const int f = i % F, r = i / (F * L1);
             const float v = a3[i];
             dzA[i] = (v > 0.f && v == g[r * F + f]) ? dg[r * F + f] / cnt[r * F + f] : 0.f;
         }
-        fxt_sync();
+        fxt_sync(); FXT_STAMP(9);
         struct PutW { float* gw; float* gb; int rows, F; FXT_HD void put(int m, int nn, float v) const { if (m < rows) gw[m * F + nn] = v; else gb[nn] = v; } };
-        struct PutX { float* d; const float* y; int F; FXT_HD void put(int m, int nn, float v) const { d[m * F + nn] = y[m * F + nn] > 0.f ? v : 0.f; } };
+        struct PutX { WsF d; WsCF y; int F; FXT_HD void put(int m, int nn, float v) const { d[m * F + nn] = y[m * F + nn] > 0.f ? v : 0.f; } };
         // conv3
-        fxt_gemm(wg, K3 * F + 1, F, R, L1, FxtConvWGradA{a2, L1, F, (K3 - 1) / 2, K3 * F}, FxtPosMajorB{dzA, L1, F}, PutW{part + n.off_cw[2], part + n.off_cb[2], K3 * F, F});
-        fxt_gemm(wg, R * L1, F, K3, F, FxtConvGradA{dzA, L1, F, (K3 - 1) / 2}, FxtConvGradW{W + n.off_cw[2], F, F}, PutX{dzB, a2, F});
-        fxt_sync();
+        fxt_gemm(wg, K3 * F + 1, F, R, L1, FxtConvWGradA<WsCF>{a2, L1, F, (K3 - 1) / 2, K3 * F, dF}, FxtPosMajorB<WsCF>{dzA, L1, F}, PutW{part + n.off_cw[2], part + n.off_cb[2], K3 * F, F});
+        fxt_gemm(wg, R * L1, F, K3, F, FxtConvGradA<WsCF>{dzA, L1, F, (K3 - 1) / 2, dL1}, FxtConvGradW<WCF>{W + n.off_cw[2], F, F}, PutX{dzB, a2, F});
+        fxt_sync(); FXT_STAMP(10);
         // conv2
-        fxt_gemm(wg, K * F + 1, F, R, L1, FxtConvWGradA{a1, L1, F, (K - 1) / 2, K * F}, FxtPosMajorB{dzB, L1, F}, PutW{part + n.off_cw[1], part + n.off_cb[1], K * F, F});
-        fxt_gemm(wg, R * L1, F, K, F, FxtConvGradA{dzB, L1, F, (K - 1) / 2}, FxtConvGradW{W + n.off_cw[1], F, F}, PutX{dzA, a1, F});
-        fxt_sync();
+        fxt_gemm(wg, K * F + 1, F, R, L1, FxtConvWGradA<WsCF>{a1, L1, F, (K - 1) / 2, K * F, dF}, FxtPosMajorB<WsCF>{dzB, L1, F}, PutW{part + n.off_cw[1], part + n.off_cb[1], K * F, F});
+        fxt_gemm(wg, R * L1, F, K, F, FxtConvGradA<WsCF>{dzB, L1, F, (K - 1) / 2, dL1}, FxtConvGradW<WCF>{W + n.off_cw[1], F, F}, PutX{dzA, a1, F});
+        fxt_sync(); FXT_STAMP(11);
         // conv1 (one-hot input, 'valid')
-        fxt_gemm(wg, K * A + 1, F, R, L1, FxtOneHotWGradA{codes, L, A, K * A, 1}, FxtPosMajorB{dzA, L1, F}, PutW{part + n.off_cw[0], part + n.off_cb[0], K * A, F});
+        fxt_gemm(wg, K * A + 1, F, R, L1, FxtOneHotWGradA<WsCI>{codes, L, A, K * A, 1, dA}, FxtPosMajorB<WsCF>{dzA, L1, F}, PutW{part + n.off_cw[0], part + n.off_cb[0], K * A, F});
     }
+    FXT_STAMP(63);
 }
 
 // Sum of the slices' partial gradients (slice order) + one Keras-Adam update of parameter i.

@@ -312,6 +312,11 @@ int64_t fx_debug_mfma_per_tile(int kind, int L, int A, int F, int H, int K);
  * would be measured as kernel time).  *total_ms = elapsed time of all `reps` launches. */
 int fx_debug_time_score(fx_engine *e, fx_model *const *models, int M, const uint8_t *d_ascii, int64_t N, int L,
                         const uint8_t lut[256], float *d_planes, int64_t stride, int reps, float *total_ms);
+/* Profiling aid.  With the engine option "train_trace" = 1, fx_train_fit stamps the 100 MHz wall clock after every phase
+ * of the forward+backward kernel (workgroup 0 of member 0; the last step's stamps survive): out64[0] start, 1 codes,
+ * 2..5 conv1 / conv2 / conv3 / pool (CNN), 20 + i dense layer i forward, 7 loss, 30 + i dense layer i backward, 9..11
+ * pool / conv3 / conv2 backward (CNN), 63 end.  0 = not reached. */
+int fx_debug_train_trace(fx_engine *e, uint64_t *out64);
 /* Profiling aid: `reps` back-to-back neighbour searches (key reset + K4 min-distance kernel) of Q host queries against
  * the device-resident cache, one hipEvent pair on the engine's stream; queries are uploaded once, outside the bracket.
  * *total_ms = elapsed time of all `reps` launches.  1 <= Q <= 32768, cache not empty. */
