@@ -80,7 +80,7 @@ def roofline_block(kind, Lx, A, Hx, Fx, Kx, members, n, kern_ms, kernel_name):
 def pmc_block():
     """PMC figures cannot be sampled from inside the process; they come from the rocprofv3 --pmc passes over this
     same command (tools/gpu_round3.sh), committed under profiles/ -- the file is named so the numbers can be traced."""
-    for name in ("r2_pmc_bench.json", "r1_pmc_traffic.json"):
+    for name in ("r3_pmc_bench.json", "r2_pmc_bench.json", "r1_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             d = json.load(open(path))

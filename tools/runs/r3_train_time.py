@@ -25,4 +25,4 @@ run("CNN L=8", lambda: bm.CNN(8, 32, 100, "TGCA", seed=0), 8, "TGCA", 1000)
 run("MLP L=14", lambda: bm.MLP(14, 100, "UGCA", seed=0), 14, "UGCA", 1000)
 run("Ensemble 8xGE L=90", lambda: flexs_amd.Ensemble([bm.GlobalEpistasisModel(90, 100, s_utils.AAS, seed=m) for m in range(8)]), 90, s_utils.AAS, 1000, modes=("native", "graph"))
 run("CNN L=90 A=20", lambda: bm.CNN(90, 32, 100, s_utils.AAS, seed=0), 90, s_utils.AAS, 1000, modes=("native", "graph"))
-run("Ensemble 3xCNN L=237 A=20", lambda: flexs_amd.Ensemble([bm.CNN(237, 32, 100, s_utils.AAS, seed=m) for m in range(3)]), 237, s_utils.AAS, 500, modes=("native", "graph"))
+run("Ensemble 3xCNN L=237 A=20", lambda: flexs_amd.Ensemble([bm.CNN(237, 32, 100, s_utils.AAS, seed=m) for m in range(3)]), 237, s_utils.AAS, 500, modes=("native",))
