@@ -200,3 +200,34 @@ def test_native_training_through_the_plugin_api_and_its_speed():
     # the in-kernel keep stream: fraction kept over one step's (batch x H) draws
     from flexs_amd import training
     assert training._train_mode(__import__("torch").device("cuda")) == "native"
+
+
+@pytest.mark.gpu
+def test_device_training_step_on_a_seeded_sweep_of_random_shapes():
+    """24 random draws of (architecture, alphabet, sequence length, filters, hidden width, kernel size, batch rows): two
+    consecutive device steps of each against oracle/train_np.py -- whatever tile counts, k-step overhangs, padding taps and
+    slice sizes the draw produces (the training kernels are shape-agnostic: every contraction goes through one routine)."""
+    eng = _native.Engine.get(0)
+    rng = np.random.default_rng(2024)
+    for draw in range(24):
+        kind = ("cnn", "mlp", "ge")[draw % 3]
+        alphabet = ("UGCA", ref_np.AAS, "01", "TGCA")[int(rng.integers(0, 4))]
+        A = len(alphabet)
+        K = int(rng.integers(2, 8)) if kind == "cnn" else 0
+        L = int(rng.integers(max(K, 1), 41))
+        F = int(rng.integers(1, 41)) if kind == "cnn" else 0
+        H = int(rng.integers(1, 131))
+        rows = int(rng.integers(1, 97))
+        if kind == "cnn" and A < 2:
+            continue
+        lut = _native.make_lut(alphabet)
+
+        def step_fn(w, m, v, t, b, y, keep, kind=kind, L=L, A=A, F=F, H=H, K=K, rows=rows, lut=lut):
+            t2, loss = _fit_once(eng, kind, L, A, F, H, K, w, m, v, t, b, y, np.arange(rows, dtype=np.int32), 1, rows,
+                                 keep=None if keep is None else keep[None], lut=lut)
+            return t2, float(loss[0])
+
+        try:
+            check_against_oracle(step_fn, kind, L, alphabet, F, H, K, rows, steps=2)
+        except AssertionError as exc:
+            raise AssertionError(f"draw {draw}: {kind} L={L} A={A} F={F} H={H} K={K} rows={rows}: {exc}") from exc
