@@ -186,6 +186,11 @@ class DistributedEnsemble(flexs_amd.Model):
         rank, world = _world(self.group)
         seeds = None if seed is None else [seed + k for k in range(len(self.models))]
         if self.mode == "member" and world > 1 and self._device_surrogates():
+            # every rank checks the whole training set first (ValueError of the reference's encode loop), so that a rank
+            # that owns no member fails WITH the others instead of waiting for them in the weight gather
+            for m in {(mm.alphabet, mm.model.L): mm for mm in self.models}.values():
+                if len(sequences) and (m._lut[_native.sequences_to_bytes(sequences, L=m.model.L)] == 255).any():
+                    raise ValueError("substring not found")
             mine = member_assignment(len(self.models), rank, world)
             train_members([self.models[i] for i in mine], sequences, labels,
                           None if seeds is None else [seeds[i] for i in mine])
@@ -368,7 +373,21 @@ class DistributedEnsemble(flexs_amd.Model):
         if self._cuda:
             with torch.cuda.stream(self.stream):
                 out = out.cpu()                                    # stream-ordered D2H of the final result only
-            self._engine().sync()                                  # raises ValueError for a character outside the alphabet
+            err = None
+            try:
+                self._engine().sync()                              # raises ValueError for a character outside the alphabet
+            except ValueError as ex:
+                err = ex
+            rank, world = _world(self.group)
+            if world > 1:
+                # SPMD: a character outside the alphabet fails the call on EVERY rank (sequence_utils.py:46 raises for the
+                # whole batch), also on the ranks whose row shard / member block never met it: agree on the flag
+                flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device=_gather_device(self.group))
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+                if int(flag.item()) and err is None:
+                    err = ValueError("substring not found")
+            if err is not None:
+                raise err
         out = out.numpy()
         return out if default else self.combine_with(out)
 

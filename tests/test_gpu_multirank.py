@@ -31,7 +31,10 @@ def _devices():
     return _native.lib().fx_device_count()
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="nccl", share_device=False):
+    """backend "nccl": one GPU per rank (RCCL).  backend "gloo" with share_device: every rank scores on GPU 0 and the
+    collective runs on host tensors -- the multi-rank logic of the product classes (shard offsets, padded planes, re-assembly,
+    sharded training, sharded cache) on real device buffers when only one GPU is there."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -43,15 +46,20 @@ def _worker(rank, world, port, q):
     from flexs_amd.baselines import models as bm
     from flexs_amd.utils import sequence_utils as s_utils
 
-    torch.cuda.set_device(rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    dev = 0 if share_device else rank
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    lrank = rank                         # logical rank (member / row / cache shard owner); `dev` = the GPU this process uses
     report = {}
     try:
         # ---- scoring: every mode against the single-GPU Ensemble on this rank's own device
         for tag, mk, L, alpha, M, n in (
-                ("3xCNN L=8", lambda s: bm.CNN(8, 32, 100, "TGCA", seed=s, device=rank), 8, "TGCA", 3, 1001),
-                ("8xGE L=90", lambda s: bm.GlobalEpistasisModel(90, 100, s_utils.AAS, seed=s, device=rank), 90, s_utils.AAS, 8, 333),
-                ("5xMLP L=14", lambda s: bm.MLP(14, 100, "UGCA", seed=s, device=rank), 14, "UGCA", 5, 65)):
+                ("3xCNN L=8", lambda s: bm.CNN(8, 32, 100, "TGCA", seed=s, device=dev), 8, "TGCA", 3, 1001),
+                ("8xGE L=90", lambda s: bm.GlobalEpistasisModel(90, 100, s_utils.AAS, seed=s, device=dev), 90, s_utils.AAS, 8, 333),
+                ("5xMLP L=14", lambda s: bm.MLP(14, 100, "UGCA", seed=s, device=dev), 14, "UGCA", 5, 65)):
             members = [mk(s) for s in range(M)]
             b = synth.random_sequence_bytes(n, L, alpha, 11)
             seqs = synth.bytes_to_strings(b)
@@ -84,8 +92,8 @@ def _worker(rank, world, port, q):
         L, alpha, n = 8, "TGCA", 300
         seqs = synth.bytes_to_strings(synth.random_sequence_bytes(n, L, alpha, 5))
         y = np.random.default_rng(1).random(n)
-        for tag, mk in (("mlp", lambda s: bm.MLP(L, 24, alpha, seed=s, epochs=2, device=rank)),
-                        ("cnn", lambda s: bm.CNN(L, 8, 16, alpha, kernel_size=3, seed=s, epochs=2, device=rank))):
+        for tag, mk in (("mlp", lambda s: bm.MLP(L, 24, alpha, seed=s, epochs=2, device=dev)),
+                        ("cnn", lambda s: bm.CNN(L, 8, 16, alpha, kernel_size=3, seed=s, epochs=2, device=dev))):
             single = flexs_amd.Ensemble([mk(s) for s in range(3)])
             single.train(seqs, y, seed=40)
             sharded = fd.DistributedEnsemble([mk(s) for s in range(3)], mode="member")
@@ -93,7 +101,7 @@ def _worker(rank, world, port, q):
             for a, c in zip(single.models, sharded.models):
                 for wa, wc in zip(a.model.get_weights(), c.model.get_weights()):
                     assert np.array_equal(wa, wc), ("sharded train", tag)
-            owned = fd.member_assignment(3, rank, world)
+            owned = fd.member_assignment(3, lrank, world)
             for i, m in enumerate(sharded.models):
                 trained_here = getattr(m.model, "_opt_state", None) is not None
                 assert trained_here == (i in owned), ("who trained what", tag, i, owned)
@@ -122,27 +130,27 @@ def _worker(rank, world, port, q):
             return np.concatenate(outs), land.cost, nam.cost, list(nam.cache), float(np.random.random())
 
         l1, l2 = Table(), Table()
-        want_t = trace(bm.NoisyAbstractModel(l1, 0.85, device=rank), l1)
-        got_t = trace(fd.ShardedNoisyAbstractModel(l2, 0.85, device=rank), l2)
+        want_t = trace(bm.NoisyAbstractModel(l1, 0.85, device=dev), l1)
+        got_t = trace(fd.ShardedNoisyAbstractModel(l2, 0.85, device=dev), l2)
         assert np.array_equal(got_t[0], want_t[0]) and got_t[1:] == want_t[1:]
         report["nam"] = True
-        q.put((rank, "ok", report))
+        q.put((lrank, "ok", report))
     except BaseException as exc:      # noqa: BLE001 -- surface worker failures at once instead of after the queue timeout
         import traceback
 
-        q.put((rank, "fail", traceback.format_exc()[-3000:] + repr(exc)))
+        q.put((lrank, "fail", traceback.format_exc()[-3000:] + repr(exc)))
         raise
     finally:
         dist.destroy_process_group()
 
 
-def _run_world(world):
+def _run_world(world, backend="nccl", share_device=False):
     import torch.multiprocessing as mp
 
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend, share_device)) for r in range(world)]
     for p in procs:
         p.start()
     results = []
@@ -160,6 +168,15 @@ def _run_world(world):
 
 def test_one_rank_rccl_group_gives_single_gpu_bits():
     _run_world(1)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_sharing_one_gpu_over_gloo_give_single_gpu_bits(world):
+    """Two / three ranks on ONE GPU (each process scores on device 0, collectives on gloo with the planes staged through host
+    tensors): everything of the N > 1 path except RCCL itself runs on real device buffers -- member blocks and row shards of
+    rank r > 0, padded plane exchange, re-assembly, sharded training + weight gather, cache sharding -- against the
+    single-GPU bits.  (3 ranks: 3 members -> one each, 8 -> 3 / 3 / 2, row shards of unequal length.)"""
+    _run_world(world, backend="gloo", share_device=True)
 
 
 @pytest.mark.skipif(_devices() < 2, reason="needs two visible GPUs (one process per GPU)")
