@@ -182,7 +182,7 @@ def run_pipelined(ens, d_seq, n, steps, warmup, torch, dist, use_dist, want_even
     elapsed = time.perf_counter() - t0
     ens._engine().sync()                                 # raises if any character was outside the alphabet
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)         # MAX over ranks
         elapsed = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else None
@@ -567,6 +567,10 @@ def main():
                     help="CUs left free for RCCL when running distributed; -1 = 4 when WORLD_SIZE > 1, else 0")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the all-gather even with one rank (exercises the N>1 code path)")
+    ap.add_argument("--debug-share-device", action="store_true",
+                    help="debugging aid for boxes with ONE GPU: all ranks score on device 0 and the collectives run on gloo "
+                         "(planes staged through host tensors) -- exercises the N > 1 control flow of this script and of "
+                         "DistributedEnsemble on real device buffers; not a measurement (the line is tagged)")
     ap.add_argument("--cpu-selftest", action="store_true",
                     help="run the launch path (self-spawn, rendezvous, launch/finish, one JSON line) on gloo with an "
                          "injected scorer; no GPU needed, not a measurement")
@@ -590,7 +594,9 @@ def main():
         raise SystemExit(cpu_selftest(rank, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
-    if torch.cuda.device_count() < world or local_rank >= torch.cuda.device_count():
+    if args.debug_share_device:
+        local_rank = 0
+    elif torch.cuda.device_count() < world or local_rank >= torch.cuda.device_count():
         raise SystemExit(f"bench.py --gpus {world}: {world} devices needed, {torch.cuda.device_count()} visible "
                          f"(rank {rank}); one process per GPU, no oversubscription")
     torch.cuda.set_device(local_rank)
@@ -608,7 +614,10 @@ def main():
         # channels so its (overlapped) kernel does not take CUs away from the MFMA-bound scoring kernel.
         os.environ.setdefault("NCCL_MAX_NCHANNELS", "2")
         os.environ.setdefault("NCCL_MIN_NCHANNELS", "1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.debug_share_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     N = args.batch
     eng = _native.Engine.get(local_rank)
@@ -673,6 +682,8 @@ def main():
                               "frac_issued": rep["roofline"]["frac_issued"],
                               "what": f">= {MIN_TIMED_S} s timed region, same step, run right after the K steps above"}
         out["rccl_ranks"] = dist.get_world_size() if use_dist else 0     # ranks RCCL reports (0: no communicator)
+        if args.debug_share_device:
+            out["debug_share_device"] = "all ranks on device 0, collectives on gloo through host tensors: NOT a measurement"
         out.update(extras)
         if world == 1 and not args.no_extras:
             out["configs"] = configs_block(eng, local_rank, torch)

@@ -200,6 +200,24 @@ def test_bench_starts_its_own_ranks_and_names_missing_devices():
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
+def test_bench_control_flow_with_two_ranks_on_one_gpu():
+    """`bench.py --gpus 2 --debug-share-device`: the N > 1 control flow of the bench (self-spawn, sequence-parallel headline over
+    a 2 x 1e5 global batch, settled bracket, member-parallel block, MAX over ranks, ONE line from rank 0) with both ranks on
+    device 0 and gloo collectives -- everything but RCCL, on a one-GPU box.  Not a measurement (the line says so)."""
+    import json
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--debug-share-device", "--steps", "6",
+                        "--warmup", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "debug_share_device" in d
+    assert d["config"]["global_batch"] == 200_000 and d["roofline"]["frac"] > 0
+    mp_ = {k: v for k, v in d["member_parallel"].items() if k != "what"}
+    assert all(v["checked"] and v["members_per_rank"] == 4 for v in mp_.values())
+
+
 @pytest.mark.skipif(_devices() < 2, reason="needs two visible GPUs")
 def test_bench_two_gpus_prints_one_line():
     import json
