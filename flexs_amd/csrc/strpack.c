@@ -67,6 +67,8 @@ static int g_workers = 0;              /* threads created so far */
 static int g_active = 0;               /* workers taking part in the current job */
 static int g_pending = 0;              /* shares of the current job not finished yet */
 static int g_threads_cfg = 0;          /* 0 = auto */
+static int g_busy = 0;                 /* a job owns the pool (a second caller -- another Python thread: the GIL is released
+                                          while a job runs -- packs its batch on its own thread instead of waiting) */
 
 static void* worker_main(void* arg) {
     const int id = (int)(intptr_t)arg;
@@ -92,7 +94,7 @@ static void after_fork_child(void) {
     pthread_mutex_init(&g_mu, NULL);
     pthread_cond_init(&g_go, NULL);
     pthread_cond_init(&g_done, NULL);
-    g_workers = 0; g_active = 0; g_pending = 0;
+    g_workers = 0; g_active = 0; g_pending = 0; g_busy = 0;
 }
 
 static int want_threads(Py_ssize_t bytes) {
@@ -113,6 +115,11 @@ static int want_threads(Py_ssize_t bytes) {
 static int pack_parallel(PyObject** items, unsigned char* dst, Py_ssize_t n, Py_ssize_t L, int threads) {
     const int helpers = threads - 1;
     pthread_mutex_lock(&g_mu);
+    if (g_busy) {
+        pthread_mutex_unlock(&g_mu);
+        return pack_range(items, dst, n, L, 0);
+    }
+    g_busy = 1;
     while (g_workers < helpers) {                                       /* grow the pool on demand */
         pthread_t th;
         pthread_attr_t at;
@@ -146,6 +153,7 @@ static int pack_parallel(PyObject** items, unsigned char* dst, Py_ssize_t n, Py_
     pthread_mutex_lock(&g_mu);
     while (g_pending > 0) pthread_cond_wait(&g_done, &g_mu);
     g_active = 0;
+    g_busy = 0;
     for (int w = 0; w < used && status == 0; ++w) status = g_share[w].status;   /* first failing share in row order */
     pthread_mutex_unlock(&g_mu);
     return status;

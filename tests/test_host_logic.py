@@ -411,3 +411,36 @@ def test_string_packing_with_worker_threads():
         assert sp.pack(wide, L, out) == 0 and (out == ord("A")).all()
     finally:
         sp.set_threads(prev)
+
+
+def test_string_packing_from_two_python_threads_at_once():
+    """The packing pool releases the GIL while it runs, so a second Python thread can enter `pack` meanwhile: it must not
+    disturb the job in flight (it packs on its own thread) and both results must be right."""
+    import threading
+
+    from flexs_amd import synth
+
+    sp = _native._strpack
+    prev = sp.set_threads(4)
+    try:
+        L, N = 32, 60_000
+        jobs = []
+        for seed in (1, 2, 3, 4):
+            b = synth.random_sequence_bytes(N, L, "UGCA", seed)
+            jobs.append((b, synth.bytes_to_strings(b), np.zeros((N, L), np.uint8)))
+        errors = []
+
+        def run(b, seqs, out):
+            for _ in range(6):
+                out[:] = 0
+                if sp.pack(seqs, L, out) != 0 or not np.array_equal(out, b):
+                    errors.append("mismatch")
+
+        threads = [threading.Thread(target=run, args=j) for j in jobs]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors
+    finally:
+        sp.set_threads(prev)
