@@ -43,6 +43,7 @@ SIGNATURES = {
     "fx_engine_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
     "fx_engine_get_option": (C.c_int, [_vp, C.c_char_p, _i64p]),
     "fx_timer_start": (C.c_int, [_vp]),
+    "fx_engine_counters": (C.c_int, [_vp, _i64p, C.c_int]),
     "fx_timer_stop": (C.c_int, [_vp, _f32p]),
     "fx_model_create": (C.c_int, [_vp] + [C.c_int] * 6 + [C.POINTER(_vp)]),
     "fx_model_destroy": (C.c_int, [_vp]),
@@ -316,6 +317,15 @@ class Engine:
             self.set_stream(st.cuda_stream)
             self._torch_stream = st
         return st
+
+    COUNTER_NAMES = ("host_calls", "device_calls", "sequences", "forwards", "bytes_h2d", "bytes_d2h", "zero_copy_calls",
+                     "pair_evals", "train_steps")
+
+    def counters(self, reset: bool = False) -> dict:
+        """Engine-side counters (fx_engine_counters): what went through this engine since creation / the last reset."""
+        out = (C.c_int64 * 9)()
+        self.check(self._lib.fx_engine_counters(self.handle, out, int(reset)))
+        return dict(zip(self.COUNTER_NAMES, [int(v) for v in out]))
 
     def timer_start(self):
         self.check(self._lib.fx_timer_start(self.handle))

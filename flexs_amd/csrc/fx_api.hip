@@ -292,6 +292,15 @@ int fx_engine_get_option(fx_engine* e, const char* key, int64_t* value) {
     return FX_OK;
 }
 
+int fx_engine_counters(fx_engine* e, int64_t* out9, int reset) {
+    if (!e || !out9) return FX_EINVAL;
+    const fx_engine::Counters& c = e->counters;
+    const int64_t v[9] = {c.host_calls, c.device_calls, c.sequences, c.forwards, c.bytes_h2d, c.bytes_d2h, c.zero_copy_calls,
+                          c.pair_evals, c.train_steps};
+    std::memcpy(out9, v, sizeof(v));
+    if (reset) e->counters = fx_engine::Counters{};
+    return FX_OK;
+}
 int fx_timer_start(fx_engine* e) {
     if (!e) return FX_EINVAL;
     FX_HIP(e, hipEventRecord(e->ev0, e->stream));
@@ -435,6 +444,7 @@ int fx_score_dev(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_
     if (N == 0) return FX_OK;
     if (!d_ascii || (!d_out_NM && !d_out_mean)) return fx_fail(e, FX_EINVAL, "null buffer");
     FX_HIP(e, hipSetDevice(e->device));
+    e->counters.device_calls += 1; e->counters.sequences += N; e->counters.forwards += N * M;
     rc = fx_upload_lut(e, lut);
     if (rc) return rc;
     float* d_NM = d_out_NM;
@@ -467,6 +477,7 @@ int fx_score_planes_dev(fx_engine* e, fx_model* const* models, int M, const uint
     if (!d_ascii || !d_planes || (reinterpret_cast<uintptr_t>(d_planes) & 15)) return fx_fail(e, FX_EINVAL, "null or unaligned buffer");
     FX_HIP(e, hipSetDevice(e->device));
     if ((rc = fx_upload_lut(e, lut))) return rc;
+    e->counters.device_calls += 1; e->counters.sequences += N; e->counters.forwards += N * M;
     return score_dispatch(e, models, M, d_ascii, N, L, d_planes, stride);
 }
 
@@ -558,7 +569,9 @@ int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii,
     bool plan_zc = false;
     int plan_pieces = 1;
     plan_host_call(e, models, M, N, L, &plan_zc, &plan_pieces);
+    e->counters.host_calls += 1; e->counters.sequences += N; e->counters.forwards += N * M;
     if (in_bytes + nm_bytes + mean_bytes <= (size_t)e->zero_copy_bytes || plan_zc) {
+        e->counters.zero_copy_calls += 1;
         // Small call (what Adalead / CMA-ES / DynaPPO issue): zero-copy through the mapped pinned
         // staging buffers -- the kernels read the sequences from, and write the scores to, host memory over
         // PCIe; two memcpy enqueues and their latencies disappear from the call.
@@ -572,6 +585,8 @@ int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii,
                                      : fx_launch_ensemble_reduce(e, out_NM ? m_NM : d_NM, N, M, nullptr, m_mean, nullptr))) return rc;
         FX_HIP(e, hipStreamSynchronize(e->stream));
     } else {
+        e->counters.bytes_h2d += (int64_t)in_bytes;
+        e->counters.bytes_d2h += (int64_t)((out_mean ? mean_bytes : 0) + (out_NM ? nm_bytes : 0));
         FX_HIP(e, hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, e->stream));
         if ((rc = score_dispatch(e, models, M, (const uint8_t*)d_in, N, L, d_NM, stride))) return rc;
         if (out_mean) {
@@ -631,6 +646,12 @@ int fx_score_submit(fx_engine* e, int64_t row0, int64_t rows) {
     // transfers on the copy stream, kernels on the compute stream, one event triple per piece: the upload of piece k + 1
     // (packed by the host while piece k runs) and the download of piece k - 1 overlap piece k's kernels
     if (c.pieces >= fx_engine::MAX_PIECES) return fx_fail(e, FX_EINVAL, "fx_score_submit: more than 32 pieces in one call");
+    if (c.pieces == 0) { e->counters.host_calls += 1; e->counters.zero_copy_calls += c.zero_copy ? 1 : 0; }
+    e->counters.sequences += rows; e->counters.forwards += rows * M;
+    if (!c.zero_copy) {
+        e->counters.bytes_h2d += rows * c.L;
+        e->counters.bytes_d2h += (int64_t)sizeof(float) * rows * ((c.want_mean ? 1 : 0) + (c.want_nm ? M : 0));
+    }
     if (c.zero_copy) {
         // no copy enqueues at all: the piece's kernels read its bytes from the pinned staging area over PCIe (L bytes
         // per sequence against ~1e5 FLOP: the reads hide behind the MFMA work) and the results land in pinned memory
@@ -834,6 +855,7 @@ static int min_dist_common(fx_engine* e, int mode, const uint8_t* queries, int64
         for (int64_t i = 0; i < Q; ++i) { dist[i] = 0; argmin[i] = -1; }
         return FX_OK;
     }
+    e->counters.pair_evals += Q * C;
     int rc;
     for (int64_t q0 = 0; q0 < Q; q0 += 32768) {
         const int64_t qn = std::min<int64_t>(32768, Q - q0);

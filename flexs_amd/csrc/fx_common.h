@@ -72,6 +72,17 @@ struct fx_engine {
     static constexpr int MAX_PIECES = 32;
     hipEvent_t ev_in[MAX_PIECES] = {}, ev_done[MAX_PIECES] = {}, ev_out[MAX_PIECES] = {};
     std::string last_error;
+    // engine-side counters (fx_engine_counters): what went through this engine since creation / the last reset
+    struct Counters {
+        int64_t host_calls = 0;        // fx_score / fx_score_finish / fx_decode_score calls (host buffers in, host scores out)
+        int64_t device_calls = 0;      // fx_score_dev / fx_score_planes_dev launches (device buffers)
+        int64_t sequences = 0;         // sequences scored (x members = forwards)
+        int64_t forwards = 0;          // sequences x members
+        int64_t bytes_h2d = 0, bytes_d2h = 0;   // copy-path bytes of the host calls
+        int64_t zero_copy_calls = 0;   // host calls whose kernels read / wrote pinned host memory directly
+        int64_t pair_evals = 0;        // (query, cache entry) distance evaluations
+        int64_t train_steps = 0;       // mini-batch steps x members run by fx_train_fit
+    } counters;
     // deferred error word (device) + pinned host mirror
     unsigned* d_err = nullptr;
     unsigned* h_err = nullptr;

@@ -233,7 +233,10 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
             FX_HIP(e, hipMemcpyAsync(jobs[m].step_loss, j.step_loss, sizeof(float) * (size_t)j.total_steps, hipMemcpyDeviceToHost, st));
     }
     FX_HIP(e, hipStreamSynchronize(st));
-    for (int m = 0; m < M; ++m) jobs[m].step += hj[(size_t)m].total_steps;
+    for (int m = 0; m < M; ++m) {
+        jobs[m].step += hj[(size_t)m].total_steps;
+        e->counters.train_steps += hj[(size_t)m].total_steps;
+    }
     return FX_OK;
 }
 

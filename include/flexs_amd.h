@@ -115,6 +115,11 @@ const char *fx_last_error(fx_engine *e);
  * What each does, its values and the measurement that decided it: flexs_amd/csrc/OPTIONS.md. */
 int fx_engine_set_option(fx_engine *e, const char *key, int64_t value);
 int fx_engine_get_option(fx_engine *e, const char *key, int64_t *value);
+/* Engine-side counters since creation (or the last reset): out9 = { host scoring calls, device-buffer scoring launches,
+ * sequences scored, forwards (sequences x members), bytes copied host -> device, bytes copied device -> host (copy path
+ * only), host calls served zero-copy, (query, cache entry) distance evaluations, training steps x members }.
+ * reset != 0 zeroes them after reading. */
+int fx_engine_counters(fx_engine *e, int64_t *out9, int reset);
 /* hipEvent pair on the engine's stream: start..stop brackets whatever was
  * enqueued in between; stop synchronises and returns elapsed milliseconds. */
 int fx_timer_start(fx_engine *e);

@@ -1682,3 +1682,34 @@ def test_software_pipelined_dense_form_gives_the_same_bits(eng, kind, L, alpha, 
     finally:
         eng.set_option("dense_pipe", 0)
         eng.set_option("dense_small", 1)
+
+
+def test_engine_counters(eng):
+    """fx_engine_counters: the engine's own account of what went through it (SURVEY.md section 5 aux: counters) -- host
+    calls, zero-copy vs copy path bytes, forwards, distance evaluations, training steps."""
+    from flexs_amd import training
+
+    eng.counters(reset=True)
+    L, alpha = 8, "TGCA"
+    members = [bm.CNN(L, 32, 100, alpha, seed=s) for s in range(3)]
+    ens = flexs_amd.Ensemble(members)
+    b, seqs = rand_seqs(20, L, alpha, seed=1)
+    ens.get_fitness(seqs)                                         # explorer-size call: zero-copy
+    c = eng.counters()
+    assert c["host_calls"] == 1 and c["zero_copy_calls"] == 1 and c["sequences"] == 20 and c["forwards"] == 60 and c["bytes_h2d"] == 0
+    eng.set_option("zero_copy_mode", 0)                           # force the copy path for a big batch
+    try:
+        b2, _ = rand_seqs(50_000, L, alpha, seed=2)
+        eng.score([m.native() for m in members], b2, members[0]._lut, want_matrix=True)
+    finally:
+        eng.set_option("zero_copy_mode", -1)
+    c = eng.counters()
+    assert c["host_calls"] == 2 and c["zero_copy_calls"] == 1 and c["bytes_h2d"] == 50_000 * L and c["bytes_d2h"] == 4 * 3 * 50_000
+    assert c["sequences"] == 50_020 and c["forwards"] == 3 * 50_020
+    eng.min_dist(b2[:7], b2[:1000])
+    assert eng.counters()["pair_evals"] == 7000
+    y = np.random.default_rng(0).random(20)
+    if training._train_mode(__import__("torch").device("cuda")) == "native":
+        ens.train(seqs, y)
+        assert eng.counters()["train_steps"] == 3 * 20            # 20 epochs x 1 mini-batch x 3 members
+    assert eng.counters(reset=True)["host_calls"] == 2 and eng.counters()["host_calls"] == 0
