@@ -170,6 +170,7 @@ FXT_HD void fxt_sync() {
 #endif
 
 FXT_HD bool fxt_keep(const FxtJob& j, int step, int slot, int h) {
+    if (slot >= j.batch) return true;                    // a slot past the mini-batch (the last slice's overhang): no mask entry, no gradient
     if (j.keep) return j.keep[((long long)step * j.batch + slot) * j.net.H + h] != 0;
     unsigned long long z = j.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(((long long)step * j.batch + slot) * j.net.H + h + 1);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;

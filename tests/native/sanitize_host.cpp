@@ -1,0 +1,100 @@
+// ASAN / UBSAN exercise of the host-compilable sources the device kernels are built from (test infrastructure):
+//   csrc/train_core.h  one training step of every architecture at odd shapes (index functors, workspace layout,
+//                      magic-number division, the fixed-order Adam reduction), threads as loops;
+//   csrc/myers.h       the bit-parallel Levenshtein in its register form and in strips, against a plain DP.
+// Built and run by tests/test_sanitizers.py with  g++ -fsanitize=address,undefined -fno-sanitize-recover=all.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../flexs_amd/csrc/myers.h"
+#include "../../flexs_amd/csrc/train_core.h"
+
+static unsigned long long rng_state = 88172645463325252ull;
+static unsigned rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (unsigned)(rng_state >> 11); }
+
+static int dp(const std::vector<unsigned char>& a, const std::vector<unsigned char>& b) {
+    std::vector<int> prev(b.size() + 1), cur(b.size() + 1);
+    for (size_t j = 0; j <= b.size(); ++j) prev[j] = (int)j;
+    for (size_t i = 1; i <= a.size(); ++i) {
+        cur[0] = (int)i;
+        for (size_t j = 1; j <= b.size(); ++j) {
+            const int sub = prev[j - 1] + (a[i - 1] != b[j - 1]);
+            cur[j] = std::min(std::min(prev[j] + 1, cur[j - 1] + 1), sub);
+        }
+        std::swap(prev, cur);
+    }
+    return prev[b.size()];
+}
+
+template <int LW>
+static int strips(const std::vector<unsigned char>& a, const std::vector<unsigned char>& b) {
+    std::vector<signed char> h(b.size() + 1, 0);
+    const int la = (int)a.size(), lb = (int)b.size();
+    const int ns = la > 0 ? (la + 64 * LW - 1) / (64 * LW) : 1;
+    int part = 0;
+    for (int s = 0; s < ns; ++s) {
+        const int r0 = s * 64 * LW, rows = std::min(la - r0, 64 * LW);
+        std::vector<uint64_t> peq((size_t)256 * LW, 0);
+        for (int i = 0; i < rows; ++i) peq[(size_t)a[r0 + i] * LW + (i >> 6)] |= 1ull << (i & 63);
+        part = fx_myers_strip<LW>(rows > 0 ? rows : 0, lb, [&](int c, int w) { return peq[(size_t)c * LW + w]; },
+                                  [&](int i) { return (int)b[i]; }, h.data(), h.data(), 1, s == 0, s == ns - 1);
+    }
+    return la + part;
+}
+
+static int train_case(int kind, int L, int A, int F, int H, int K, int rows, int R) {
+    FxtJob j{};
+    j.net = fxt_net(kind, L, A, kind == 0 ? F : 0, H, kind == 0 ? K : 0);
+    j.batch = rows; j.steps_per_epoch = 1; j.total_steps = 1; j.n = rows; j.R = R; j.S = (rows + R - 1) / R;
+    // exact-size heap buffers: any index past an array is an ASAN report
+    std::vector<float> w((size_t)j.net.P), m((size_t)j.net.P, 0.f), v((size_t)j.net.P, 0.f), partial((size_t)j.S * (j.net.P + 1), 0.f);
+    for (auto& x : w) x = ((int)(rnd() % 2001) - 1000) * 1e-4f;
+    std::vector<int32_t> order((size_t)rows);
+    for (int i = 0; i < rows; ++i) order[(size_t)i] = (rnd() % 7 == 0) ? -1 : (int)(rnd() % rows);      // some padding slots
+    std::vector<uint8_t> ascii((size_t)rows * L), lut(256, 0xFF), keep((size_t)rows * H);
+    for (int a = 0; a < A; ++a) lut[65 + a] = (uint8_t)a;
+    for (auto& c : ascii) c = (uint8_t)(65 + rnd() % A);
+    for (auto& k : keep) k = rnd() % 4 != 0;
+    std::vector<float> labels((size_t)rows);
+    for (auto& y : labels) y = (rnd() % 1000) * 1e-3f;
+    const float lr = 1e-3f;
+    float loss = 0.f;
+    j.w = w.data(); j.adam_m = m.data(); j.adam_v = v.data(); j.partial = partial.data(); j.order = order.data();
+    j.keep = kind == 0 ? keep.data() : nullptr; j.lr_t = &lr; j.step_loss = &loss;
+    j.ws_slice = fxt_ws(j.net, R).total;
+    std::vector<float> ws((size_t)j.S * (size_t)j.ws_slice, 0.f);
+    j.ws = ws.data();
+    for (int s = 0; s < j.S; ++s)
+        fxt_forward_backward<0, 0>(j, FxtWg{0, 1}, 0, s, ascii.data(), lut.data(), labels.data(), j.ws + (long long)s * j.ws_slice, (const float*)j.w);
+    fxt_step_loss(j, 0);
+    for (int i = 0; i < j.net.P; ++i) fxt_adam(j, 0, i);
+    for (float x : w) if (!(x == x)) { std::printf("NaN weight: kind %d L %d\n", kind, L); return 1; }
+    return 0;
+}
+
+int main() {
+    int bad = 0;
+    const int shapes[][8] = {  // kind, L, A, F, H, K, rows, R
+        {0, 8, 4, 32, 100, 5, 40, 8}, {0, 9, 4, 8, 16, 3, 37, 5}, {0, 12, 20, 5, 7, 4, 19, 16}, {0, 6, 2, 3, 5, 2, 11, 1}, {0, 7, 4, 1, 1, 7, 3, 4},
+        {1, 14, 4, 0, 100, 0, 48, 16}, {1, 5, 20, 0, 9, 0, 5, 3}, {1, 1, 2, 0, 1, 0, 1, 1}, {2, 30, 20, 0, 100, 0, 33, 8}, {2, 9, 4, 0, 20, 0, 37, 64}};
+    for (const auto& s : shapes) bad += train_case(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7]);
+    for (int trial = 0; trial < 215; ++trial) {
+        const int nsym = (trial % 3 == 0) ? 2 : ((trial % 3 == 1) ? 4 : 20);
+        std::vector<unsigned char> a(rnd() % (trial < 200 ? 200 : 1700)), b(rnd() % (trial < 200 ? 200 : 900));
+        for (auto& c : a) c = (unsigned char)(65 + rnd() % nsym);
+        for (auto& c : b) c = (unsigned char)(65 + rnd() % nsym);
+        const int want = dp(a, b);
+        if (strips<1>(a, b) != want || strips<12>(a, b) != want) { std::printf("strip mismatch at trial %d\n", trial); ++bad; }
+        if (a.size() <= 768) {
+            std::vector<uint64_t> peq(256 * 12, 0);
+            for (size_t i = 0; i < a.size(); ++i) peq[a[i] * 12 + (i >> 6)] |= 1ull << (i & 63);
+            const int got = fx_myers_distance<12>((int)a.size(), (int)b.size(), [&](int c, int w) { return peq[c * 12 + w]; },
+                                                  [&](int i) { return (int)b[i]; });
+            if (got != want) { std::printf("register form mismatch at trial %d\n", trial); ++bad; }
+        }
+    }
+    std::printf(bad ? "FAILED %d\n" : "sanitize_host: ok\n", bad);
+    return bad != 0;
+}

@@ -1,0 +1,79 @@
+"""ASAN / UBSAN builds of the host-compilable native sources (SURVEY.md section 5 aux: sanitizer build).
+
+* `tests/native/sanitize_host.cpp`: csrc/train_core.h (the training kernels' source, threads as loops) and csrc/myers.h
+  (register and strip forms of the bit-parallel Levenshtein) under  g++ -fsanitize=address,undefined  with exact-size heap
+  buffers: an index past any array, a signed overflow or an invalid shift in the kernels' index arithmetic aborts the run.
+* `csrc/strpack.c` (the CPython packing helper and its thread pool) rebuilt with the sanitizers and driven from a Python
+  child process that preloads the sanitizer runtimes: bytes, error statuses, sub-ranges, several threads."""
+import os
+import subprocess
+import sys
+import sysconfig
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SAN = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g", "-O1"]
+
+
+def _runtime(name):
+    path = subprocess.run(["gcc", f"-print-file-name={name}"], capture_output=True, text=True).stdout.strip()
+    return path if os.path.isabs(path) and os.path.exists(path) else None
+
+
+def test_kernel_sources_under_asan_and_ubsan(tmp_path):
+    exe = tmp_path / "sanitize_host"
+    r = subprocess.run(["g++", "-std=c++17", *SAN, os.path.join(ROOT, "tests", "native", "sanitize_host.cpp"), "-o", str(exe)],
+                       capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr and "unsupported" in r.stderr:
+        pytest.skip("sanitizers not available to this g++")
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert r.returncode == 0 and "sanitize_host: ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_string_packing_helper_under_asan_and_ubsan(tmp_path):
+    asan, ubsan = _runtime("libasan.so"), _runtime("libubsan.so")
+    if not asan or not ubsan:
+        pytest.skip("sanitizer runtimes not installed")
+    so = tmp_path / ("_strpack" + sysconfig.get_config_var("EXT_SUFFIX"))
+    r = subprocess.run(["gcc", *SAN, "-fPIC", "-shared", "-pthread", "-I", sysconfig.get_paths()["include"],
+                        os.path.join(ROOT, "flexs_amd", "csrc", "strpack.c"), "-o", str(so)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    child = r'''
+import sys, threading
+sys.path.insert(0, sys.argv[1])
+import _strpack as sp
+L, N = 24, 30000
+seqs = ["".join(chr(65 + (i * 7 + j * 3) % 20) for j in range(L)) for i in range(N)]
+want = "".join(seqs).encode()
+for threads in (1, 2, 5, 8):
+    sp.set_threads(threads)
+    out = bytearray(N * L)
+    assert sp.pack(seqs, L, out) == 0 and bytes(out) == want
+    part = bytearray(1001 * L)
+    assert sp.pack(seqs, L, part, 777, 1001) == 0 and bytes(part) == want[777 * L:1778 * L]
+sp.set_threads(4)
+out = bytearray(N * L)
+for where, bad, status in ((25000, "A" * (L - 1), 1), (9000, "A" * (L - 1) + "Δ", 2), (300, 7, 3)):
+    broken = list(seqs); broken[where] = bad
+    assert sp.pack(broken, L, out) == status
+try:
+    sp.pack(seqs, L, bytearray(10))
+    raise SystemExit("short buffer accepted")
+except ValueError:
+    pass
+errs = []
+def run():
+    o = bytearray(N * L)
+    for _ in range(4):
+        if sp.pack(seqs, L, o) != 0 or bytes(o) != want: errs.append(1)
+ts = [threading.Thread(target=run) for _ in range(3)]
+[t.start() for t in ts]; [t.join() for t in ts]
+assert not errs
+print("strpack sanitized: ok")
+'''
+    env = dict(os.environ, LD_PRELOAD=f"{asan}:{ubsan}", ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", PYTHONMALLOC="malloc")
+    r = subprocess.run([sys.executable, "-c", child, str(tmp_path)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "strpack sanitized: ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
