@@ -201,27 +201,76 @@ FXT_HD void fxt_gemm(const FxtWg& wg, int Md, int Nd, int Ko, int Ki, const FA& 
         const auto sb = fb.prep(nok ? n : 0, kq);
         f4_t acc = {0.f, 0.f, 0.f, 0.f};
         // The operands come from L2 / LDS through index functors: issued one k-step at a time every MFMA would wait a
-        // full memory round trip (the first build ran at ~1 us per k-step).  U k-steps are loaded first, then
-        // multiplied; (ko, k0) advance as wave-uniform counters, so the flattening costs no division.
-        int ko = 0, k0 = 0;
-        for (int s = 0; s < T; s += U) {
-            float a[U], b[U];
+        // full memory round trip (the first build ran at ~1 us per k-step).  U k-steps are loaded first, then multiplied.
+        // Rows past Md / columns past Nd need no masking: row i of A only reaches row i of the product, column j of B only
+        // column j, and those are never stored (their lanes read row / column 0).  Only the contraction index must be
+        // exact: a k-step past Ki has to contribute zero.
+        if (Ki >= 4 * U) {
+            // long inner index (conv taps x channels, dense layers): whole groups of U k-steps inside one `ko` need no
+            // range logic at all -- (ko, k0) are wave-uniform, the U fetches differ by constant offsets; the functors'
+            // own checks (conv positions) depend on ko only
+            for (int ko = 0; ko < Ko; ++ko) {
+                int k0 = 0;
+                for (; k0 + 4 * U <= Ki; k0 += 4 * U) {
+                    float a[U], b[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                // (a k-step past the end re-reads the first one -- always in range -- and is multiplied by zero: a select
-                // instead of a branch around every load; the functors' own range checks clamp the same way)
-                const bool live = s + u < T;
-                const bool kok = live && k0 + kq < Ki;
-                const float av = fa.at(sa, live ? ko : 0, live ? k0 : 0);
-                const float bv = fb.at(sb, live ? ko : 0, live ? k0 : 0);
-                a[u] = (mok && kok) ? av : 0.f;
-                b[u] = (nok && kok) ? bv : 0.f;
-                k0 += 4;
-                if (k0 >= Ki) { k0 = 0; ++ko; }
+                    for (int u = 0; u < U; ++u) { a[u] = fa.at(sa, ko, k0 + 4 * u); b[u] = fb.at(sb, ko, k0 + 4 * u); }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
+                }
+                if (k0 < Ki) {                               // the row's last, partial group
+                    float a[U], b[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int kk = k0 + 4 * u;
+                        const bool live = kk < Ki;           // wave-uniform
+                        const bool kok = kk + kq < Ki;
+                        const float av = fa.at(sa, ko, live ? kk : 0), bv = fb.at(sb, ko, live ? kk : 0);
+                        a[u] = kok ? av : 0.f;
+                        b[u] = kok ? bv : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        if (k0 + 4 * u < Ki) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
+                }
             }
+        } else if (Ki <= 4) {
+            // one k-step per `ko` (conv weight gradients of short sequences: the four positions of a row): k-step = ko
+            for (int s = 0; s < Ko; s += U) {
+                float a[U], b[U];
+                const bool kin = kq < Ki;
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (s + u < T) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
+                for (int u = 0; u < U; ++u) {
+                    const bool live = s + u < Ko;            // wave-uniform
+                    const float av = fa.at(sa, live ? s + u : 0, 0), bv = fb.at(sb, live ? s + u : 0, 0);
+                    a[u] = (live && kin) ? av : 0.f;
+                    b[u] = (live && kin) ? bv : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (s + u < Ko) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
+            }
+        } else {
+            // short inner index (weight gradients: positions of a row, rows of a slice): the (ko, k0) pairs are walked as
+            // one flat sequence of k-steps, wave-uniform counters instead of a division
+            int ko = 0, k0 = 0;
+            for (int s = 0; s < T; s += U) {
+                float a[U], b[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool live = s + u < T;
+                    const bool kok = live && k0 + kq < Ki;
+                    const float av = fa.at(sa, live ? ko : 0, live ? k0 : 0);
+                    const float bv = fb.at(sb, live ? ko : 0, live ? k0 : 0);
+                    a[u] = kok ? av : 0.f;
+                    b[u] = kok ? bv : 0.f;
+                    k0 += 4;
+                    if (k0 >= Ki) { k0 = 0; ++ko; }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (s + u < T) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
+            }
         }
         if (nok) {
 #pragma unroll
@@ -519,6 +568,8 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         struct PutW { float* gw; float* gb; int Kd, Nd; FXT_HD void put(int m, int nn, float v) const { if (m < Kd) gw[m * Nd + nn] = v; else gb[nn] = v; } };
         const PutW putw{part + n.off_w[li], part + n.off_b[li], Kd, Nd};
         if (li == 0 && n.onehot_in) {
+            // (one thread per output element -- 8 FMAs each, no per-tile bookkeeping -- was measured SLOWER than the 49
+            // two-k-step MFMA tiles here: 7.4 vs 6.1 us for the 100 x 100 layer, profiles/r3_train_trace.log)
             fxt_gemm(wg, Kd + 1, Nd, 1, R, FxtOneHotWGradA<WsCI>{codes, L, A, Kd, 0, dA}, FxtRowMajorB<WsCF>{du, Nd}, putw);
         } else {
             WsCF in = li == 0 ? feat : ws + w.act[li - 1];

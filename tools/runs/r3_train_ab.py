@@ -23,7 +23,7 @@ def run(tag, make, L, alpha, n, configs):
         print(f"{tag} n={n} rows={rows} lds={lds} threads={thr}: {min(ts) * 1e3:.2f} ms", flush=True)
     eng.set_option("train_rows", 0); eng.set_option("train_lds", 2); eng.set_option("train_threads", 0)
 
-cfg = [(0, 2, 0), (8, 2, 256), (8, 2, 512), (8, 2, 1024), (16, 2, 1024), (4, 2, 1024), (8, 1, 1024), (8, 0, 1024)]
+cfg = [(0, 2, 0), (8, 2, 1024), (16, 2, 1024), (4, 2, 1024), (8, 2, 512), (16, 2, 512)]
 run("Ensemble 3xCNN L=8", lambda: flexs_amd.Ensemble([bm.CNN(8, 32, 100, "TGCA", seed=m) for m in range(3)]), 8, "TGCA", 1000, cfg)
 run("CNN L=8", lambda: bm.CNN(8, 32, 100, "TGCA", seed=0), 8, "TGCA", 1000, cfg)
 run("MLP L=14", lambda: bm.MLP(14, 100, "UGCA", seed=0), 14, "UGCA", 1000, cfg)
