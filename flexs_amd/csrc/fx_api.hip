@@ -266,6 +266,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "ge_bytetab")) return &e->ge_bytetab;
     if (!std::strcmp(key, "wave_prio")) return &e->wave_prio;
     if (!std::strcmp(key, "dense_pipe")) return &e->dense_pipe;
+    if (!std::strcmp(key, "fuse_mean")) return &e->fuse_mean;
     if (!std::strcmp(key, "chunk_overlap")) return &e->chunk_overlap;
     if (!std::strcmp(key, "zero_copy_bytes")) return &e->zero_copy_bytes;
     if (!std::strcmp(key, "zero_copy_mode")) return &e->zero_copy_mode;
@@ -422,6 +423,18 @@ static int score_dispatch(fx_engine* e, fx_model* const* models, int M, const ui
     return FX_OK;
 }
 
+// score into member-major planes, then the NumPy-order mean -- in the scoring kernel itself where a launcher offers it
+static int score_then_mean(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N, int L,
+                           float* d_planes, int64_t stride, float* mean_dst) {
+    e->fuse_mean_out = (e->fuse_mean && stride && M > 1 && M <= 16) ? mean_dst : nullptr;
+    e->fused_mean_done = false;
+    const int rc = score_dispatch(e, models, M, d_ascii, N, L, d_planes, stride);
+    e->fuse_mean_out = nullptr;
+    if (rc) return rc;
+    if (e->fused_mean_done) return FX_OK;
+    return fx_launch_ensemble_mean_planar(e, d_planes, N, M, stride, mean_dst);
+}
+
 static int validate_models(fx_engine* e, fx_model* const* models, int M, int L, const uint8_t* lut) {
     if (!e || !models || M < 1 || !lut) return FX_EINVAL;
     for (int m = 0; m < M; ++m) {
@@ -455,10 +468,7 @@ int fx_score_dev(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_
         rc = fx_scratch(e, 1, sizeof(float) * (stride ? (size_t)stride * (size_t)M : (size_t)N * (size_t)M), &p);
         if (rc) return rc;
         d_NM = (float*)p;
-        if (stride) {
-            if ((rc = score_dispatch(e, models, M, d_ascii, N, L, d_NM, stride))) return rc;
-            return fx_launch_ensemble_mean_planar(e, d_NM, N, M, stride, d_out_mean);
-        }
+        if (stride) return score_then_mean(e, models, M, d_ascii, N, L, d_NM, stride, d_out_mean);
     }
     rc = score_dispatch(e, models, M, d_ascii, N, L, d_NM);
     if (rc) return rc;
@@ -580,18 +590,22 @@ int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii,
         FX_HIP(e, hipHostGetDevicePointer(&dm_out, h_out, 0));
         float* m_NM = (float*)dm_out;
         float* m_mean = (float*)((char*)dm_out + nm_bytes);
-        if ((rc = score_dispatch(e, models, M, (const uint8_t*)dm_in, N, L, out_NM ? m_NM : d_NM, stride))) return rc;
-        if (out_mean && (rc = stride ? fx_launch_ensemble_mean_planar(e, d_NM, N, M, stride, m_mean)
-                                     : fx_launch_ensemble_reduce(e, out_NM ? m_NM : d_NM, N, M, nullptr, m_mean, nullptr))) return rc;
+        if (stride) {
+            if ((rc = score_then_mean(e, models, M, (const uint8_t*)dm_in, N, L, d_NM, stride, m_mean))) return rc;
+        } else {
+            if ((rc = score_dispatch(e, models, M, (const uint8_t*)dm_in, N, L, out_NM ? m_NM : d_NM, stride))) return rc;
+            if (out_mean && (rc = fx_launch_ensemble_reduce(e, out_NM ? m_NM : d_NM, N, M, nullptr, m_mean, nullptr))) return rc;
+        }
         FX_HIP(e, hipStreamSynchronize(e->stream));
     } else {
         e->counters.bytes_h2d += (int64_t)in_bytes;
         e->counters.bytes_d2h += (int64_t)((out_mean ? mean_bytes : 0) + (out_NM ? nm_bytes : 0));
         FX_HIP(e, hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, e->stream));
-        if ((rc = score_dispatch(e, models, M, (const uint8_t*)d_in, N, L, d_NM, stride))) return rc;
+        if (stride) rc = score_then_mean(e, models, M, (const uint8_t*)d_in, N, L, d_NM, stride, d_mean);
+        else rc = score_dispatch(e, models, M, (const uint8_t*)d_in, N, L, d_NM, stride);
+        if (rc) return rc;
         if (out_mean) {
-            if ((rc = stride ? fx_launch_ensemble_mean_planar(e, d_NM, N, M, stride, d_mean)
-                             : fx_launch_ensemble_reduce(e, d_NM, N, M, nullptr, d_mean, nullptr))) return rc;
+            if (!stride && (rc = fx_launch_ensemble_reduce(e, d_NM, N, M, nullptr, d_mean, nullptr))) return rc;
             FX_HIP(e, hipMemcpyAsync((char*)h_out + nm_bytes, d_mean, mean_bytes, hipMemcpyDeviceToHost, e->stream));
         }
         if (out_NM) FX_HIP(e, hipMemcpyAsync(h_out, d_NM, nm_bytes, hipMemcpyDeviceToHost, e->stream));

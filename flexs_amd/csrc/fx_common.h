@@ -137,6 +137,11 @@ struct fx_engine {
     // > 0 = member-major planes `planar_stride` floats apart (the engine's own intermediate when only the mean is wanted:
     // a unit's 16 scores are then one contiguous 64-byte store instead of 16 four-byte stores 4*M bytes apart)
     int64_t planar_stride = 0;
+    // fused ensemble mean: set by the host / device entry points around score_dispatch when only the mean is wanted; a launcher
+    // that averages in-kernel (small launches of the canonical CNN: score_cnn_quad.hip) sets fused_mean_done
+    float* fuse_mean_out = nullptr;
+    bool fused_mean_done = false;
+    int64_t fuse_mean = 0;      // 1 = explorer-size CNN ensemble calls average in the scoring kernel (last member to finish a tile, tickets + device-scope fences) instead of launching the mean kernel.  Bit-identical, but the two fences cost what the 3 us launch saves: 32.1 vs 32.2 us per call (profiles/r3_fused_mean_ab.log): off, kept as the A/B
     // chunked host call in flight (fx_score_begin / _submit / _finish)
     struct {
         bool active = false;

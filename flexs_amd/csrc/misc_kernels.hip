@@ -77,29 +77,7 @@ __device__ T np_pairwise(Load ld, int64_t base, int n) {
     return np_pairwise<T>(ld, base, n2) + np_pairwise<T>(ld, base + n2, n - n2);
 }
 
-// NumPy order for a compile-time row length (registers only)
-template <int M>
-__device__ __forceinline__ float np_sum_row(const float (&x)[M]) {
-    if constexpr (M < 8) {
-        float r = 0.f;
-#pragma unroll
-        for (int i = 0; i < M; ++i) r += x[i];
-        return r;
-    } else {
-        float r[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) r[k] = x[k];
-        constexpr int full = M - (M % 8);
-#pragma unroll
-        for (int i = 8; i < full; i += 8)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) r[k] += x[i + k];
-        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-#pragma unroll
-        for (int i = full; i < M; ++i) res += x[i];
-        return res;
-    }
-}
+#include "np_sum.h"
 
 // M <= 16: each thread reduces 4 consecutive rows = 4*M contiguous floats = M 16-byte loads,
 // and writes one 16-byte result; HBM-bound (4*M + 4 bytes per sequence).

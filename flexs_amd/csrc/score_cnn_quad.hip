@@ -23,6 +23,7 @@
 // head's ~68 KiB arrive during the convolutions and are waited for before phase D (engine option dma_fill).
 #include "fx_common.h"
 #include "mfma_common.h"
+#include "np_sum.h"
 
 namespace {
 
@@ -39,6 +40,9 @@ struct QuadArgs {
     int64_t out_sn, out_sm;
     int L, rlh;
     int dma;                    // 1 = weights (and the first round's bytes) go global -> LDS directly, head part lands during the convolutions
+    // fused ensemble mean (explorer-size calls): the member whose workgroup finishes a tile LAST averages the tile's 16 sequences
+    float* mean_out;            // null = off
+    unsigned* tickets;          // one per tile, zero between launches (fx_zero_pool; the last arrival resets its entry)
     int off_c2, off_c3, off_cb, off_w1p, off_d1, off_d2, off_db, total_floats;
 };
 
@@ -253,6 +257,29 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
                 float y[1];
                 final_dot<HT, 1>(db + 32 * HT, db[48 * HT], h2, y, g);
                 if (g == 0 && n < p.N) p.out[n * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y[0]);
+                if (p.mean_out) {
+                    // np.mean over the members (ensemble.py:24) without a second launch: publish this member's 16 scores
+                    // device-wide, take the tile's ticket; the M-th arrival reads all members' scores back (past its own
+                    // L2: other members' workgroups may sit on other XCDs) and averages in NumPy's order.  Once per tile
+                    // and member, on launches of a few tiles -- the cross-XCD round trips that made this ruinous per work
+                    // unit of a 1e5-sequence launch cost a fraction of a microsecond here and save
+                    // the ~4 us mean launch of every explorer-size call.
+                    __threadfence();
+                    unsigned t = 0;
+                    if (lane == 0) t = __hip_atomic_fetch_add(&p.tickets[tg], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                    t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+                    if (t == (unsigned)p.M - 1u) {
+                        __threadfence();
+                        if (g == 0 && n < p.N) {
+                            float x[16];
+#pragma unroll
+                            for (int mm = 0; mm < 16; ++mm)
+                                x[mm] = mm < p.M ? __hip_atomic_load(p.out + n * p.out_sn + mm * p.out_sm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+                            p.mean_out[n] = np_mean_row16(x, p.M);
+                        }
+                        if (lane == 0) __hip_atomic_store(&p.tickets[tg], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
             }
             if (live) FX_TILE_DONE();
         }
@@ -305,6 +332,14 @@ int fx_launch_score_cnn_quad(fx_engine* e, fx_model* const* models, int M, const
     a.out_sn = e->planar_stride ? 1 : Mtot; a.out_sm = e->planar_stride ? e->planar_stride : 1;
     a.L = s.L; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4;
     a.dma = e->dma_fill && lay.off_d1 % 4 == 0 && lay.total_floats % 4 == 0;
+    const bool fuse = e->fuse_mean_out && e->planar_stride && m_off == 0 && M == Mtot && M <= 16 && TG <= 4096;
+    if (fuse) {
+        void* tk = nullptr;
+        if (int rc = fx_zero_pool(e, sizeof(unsigned) * (size_t)TG, &tk)) return rc;
+        a.mean_out = e->fuse_mean_out;
+        a.tickets = (unsigned*)tk;
+    }
+    const int rc_q = [&]() -> int {
     a.off_c2 = (int)lay.off_c2; a.off_c3 = (int)lay.off_c3; a.off_cb = (int)lay.off_cb; a.off_w1p = (int)lay.off_w1p;
     a.off_d1 = (int)lay.off_d1; a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
     // up to 4 conv positions (seq_len <= 8): three quads per workgroup, one round; up to 12 (seq_len <= 16): one quad
@@ -321,4 +356,7 @@ int fx_launch_score_cnn_quad(fx_engine* e, fx_model* const* models, int M, const
     if (L1 == 4) return launch_quad<3, 8, 4>(e, a, U, 1);
     if (L1 < 4) return launch_quad<3, 8, 0>(e, a, U, 1);
     return launch_quad<1, 24, 0>(e, a, U, 2);
+    }();
+    if (rc_q == FX_OK && fuse) e->fused_mean_done = true;
+    return rc_q;
 }

@@ -1713,3 +1713,34 @@ def test_engine_counters(eng):
         ens.train(seqs, y)
         assert eng.counters()["train_steps"] == 3 * 20            # 20 epochs x 1 mini-batch x 3 members
     assert eng.counters(reset=True)["host_calls"] == 2 and eng.counters()["host_calls"] == 0
+
+
+@pytest.mark.parametrize("L,alpha,M", [(8, "TGCA", 3), (8, "TGCA", 2), (14, "UGCA", 3), (8, "TGCA", 8), (14, "UGCA", 16), (8, "TGCA", 7)])
+def test_small_launch_fused_ensemble_mean(eng, L, alpha, M):
+    """Optional form (`fuse_mean` = 1; measured no faster than the separate 3 us launch, so off by default): explorer-size
+    calls of a CNN ensemble average in the scoring kernel itself (the member whose workgroup
+    finishes a tile last reads all members' scores back and averages in NumPy's order) instead of launching the mean kernel:
+    the same bits as the separate launch and as np.mean of the stacked matrix, for every batch size the small-launch form
+    serves, repeated calls (the tickets clean up after themselves), and a bad character still raises."""
+    members = [bm.CNN(L, 32, 100, alpha, seed=s) for s in range(M)]
+    ens = flexs_amd.Ensemble(members)
+    stack = flexs_amd.Ensemble(members, combine_with=lambda x: x)
+    for n in (1, 5, 16, 17, 20, 33, 48, 100, 400, 2001):
+        b, seqs = rand_seqs(n, L, alpha, seed=n)
+        want = np.mean(stack.get_fitness(seqs), axis=1)
+        for fuse in (1, 0, 1):
+            eng.set_option("fuse_mean", fuse)
+            try:
+                got = ens.get_fitness(seqs)
+                natives = [m.native() for m in members]
+                _, dev_mean = eng.score(natives, b, members[0]._lut, want_matrix=False, want_mean=True)
+            finally:
+                eng.set_option("fuse_mean", 0)
+            assert np.array_equal(got, want) and np.array_equal(dev_mean, want), (n, fuse)
+    eng.set_option("fuse_mean", 1)
+    try:
+        with pytest.raises(ValueError):
+            ens.get_fitness(seqs[:7] + ["Z" * L])
+        assert np.array_equal(ens.get_fitness(seqs[:20]), want[:20])
+    finally:
+        eng.set_option("fuse_mean", 0)
