@@ -7,6 +7,9 @@
 
 #include "fx_common.h"
 #include "myers.h"
+#include "np_sum.h"
+#include <atomic>
+#include <chrono>
 
 // strips of `lw_rows` = 64 x LW pattern rows, as k_min_dist_long runs them for patterns beyond 768 symbols (LW = 12 there;
 // the test hook also takes LW = 1 so that short strings cross many strip boundaries)
@@ -179,6 +182,7 @@ int fx_engine_create(int device, fx_engine** out) {
         return FX_ENODEV;
     }
     e->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    e->large_bar = prop.isLargeBar != 0;
     e->max_lds = (int)std::max<size_t>(prop.maxSharedMemoryPerMultiProcessor, 64 * 1024);
     if (e->max_lds > 160 * 1024) e->max_lds = 160 * 1024;
     FX_CREATE_HIP(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
@@ -203,6 +207,15 @@ int fx_engine_create(int device, fx_engine** out) {
 int fx_engine_destroy(fx_engine* e) {
     if (!e) return FX_OK;
     (void)hipSetDevice(e->device);
+    if (e->server.h_out) {
+        e->server.running = true;                          // (whatever the bookkeeping says: tell them)
+        fx_server_stop(e);
+        (void)hipStreamSynchronize(e->server.stream);
+        (void)hipStreamDestroy(e->server.stream);
+        (void)hipHostFree((void*)e->server.h_out);
+        (void)hipFree(e->server.in);
+        e->server.h_out = nullptr;
+    }
     (void)hipStreamSynchronize(e->stream);
     for (auto& p : e->d_scratch) if (p) (void)hipFree(p);
     if (e->d_zero_pool) (void)hipFree(e->d_zero_pool);
@@ -267,6 +280,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "wave_prio")) return &e->wave_prio;
     if (!std::strcmp(key, "dense_pipe")) return &e->dense_pipe;
     if (!std::strcmp(key, "fuse_mean")) return &e->fuse_mean;
+    if (!std::strcmp(key, "serve_small")) return &e->serve_small;
     if (!std::strcmp(key, "chunk_overlap")) return &e->chunk_overlap;
     if (!std::strcmp(key, "zero_copy_bytes")) return &e->zero_copy_bytes;
     if (!std::strcmp(key, "zero_copy_mode")) return &e->zero_copy_mode;
@@ -287,6 +301,11 @@ int fx_engine_set_option(fx_engine* e, const char* key, int64_t value) {
 int fx_engine_get_option(fx_engine* e, const char* key, int64_t* value) {
     if (!value) return FX_EINVAL;
     if (e && key && !std::strcmp(key, "num_cus")) { *value = e->num_cus; return FX_OK; }
+    // read-only: the resident form's bookkeeping (requests answered, generations started, requests that fell back to a launch)
+    if (e && key && !std::strcmp(key, "server_calls")) { *value = e->server.served; return FX_OK; }
+    if (e && key && !std::strcmp(key, "server_starts")) { *value = e->server.started; return FX_OK; }
+    if (e && key && !std::strcmp(key, "server_fallbacks")) { *value = e->server.fallbacks; return FX_OK; }
+    if (e && key && !std::strcmp(key, "server_resident")) { *value = e->server.running ? 1 : 0; return FX_OK; }
     int64_t* s = option_slot(e, key);
     if (!s) return fx_fail(e, FX_EINVAL, std::string("unknown option ") + (key ? key : "(null)"));
     *value = *s;
@@ -368,7 +387,13 @@ int fx_model_set_weights(fx_model* m, const float* blob, int64_t n) {
     std::memcpy(m->blob.data(), blob, sizeof(float) * (size_t)n);
     std::vector<float> packed((size_t)m->layout.alloc_floats);
     fx_pack_weights(m->shape, m->blob.data(), packed.data());
-    // in-flight kernels may still read the old weights
+    // in-flight kernels may still read the old weights (a resident generation holds them in LDS: it is told to leave,
+    // and the version makes the next call start a new one)
+    m->version += 1;
+    if (e->server.running) {
+        fx_server_stop(e);
+        FX_HIP(e, hipStreamSynchronize(e->server.stream));
+    }
     FX_HIP(e, hipStreamSynchronize(e->stream));
     FX_HIP(e, hipMemcpy(m->d_blob, m->blob.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
     FX_HIP(e, hipMemcpy(m->d_packed, packed.data(), sizeof(float) * packed.size(), hipMemcpyHostToDevice));
@@ -389,8 +414,10 @@ int fx_model_get_weights(const fx_model* m, float* blob, int64_t n) {
 static inline int64_t planar_stride_for(int64_t N) { return (N + 63) & ~(int64_t)63; }
 
 // planar_stride == 0: d_NM is the row-major (N, M) matrix of the ABI; > 0: M member planes that far apart.
+static void server_stop(fx_engine* e);
 static int score_dispatch(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N, int L,
                           float* d_NM, int64_t planar_stride = 0) {
+    if (e->server.running && (int64_t)M * ((N + 15) / 16) >= e->num_cus) server_stop(e);   // a launch that fills the chip wants every CU
     if (e->poison_outputs)      // scores are nan_to_num'ed, so a NaN that survives is an element no kernel wrote
         FX_HIP(e, hipMemsetAsync(d_NM, 0xFF, sizeof(float) * (planar_stride ? (size_t)planar_stride * (size_t)M : (size_t)N * (size_t)M), e->stream));
     struct Layout {                                     // the launchers read the layout from the engine
@@ -552,6 +579,113 @@ int fx_plan_host_call(fx_engine* e, fx_model* const* models, int M, int64_t N, i
     return FX_OK;
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Resident small-call form: the host side of the mailboxes (score_cnn_quad.hip, SERVER; FxMailIn / FxMailOut).
+static void server_stop(fx_engine* e) { fx_server_stop(e); }
+
+static int server_start(fx_engine* e, fx_model* const* models, int M, int L, const uint8_t lut[256]) {
+    auto& sv = e->server;
+    if (!e->large_bar) return FX_EUNSUPPORTED;             // the host must be able to store into device memory
+    if (!sv.h_out) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, sizeof(FxMailOut), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return FX_ENOMEM; }
+        sv.h_out = new (p) FxMailOut();
+        FX_HIP(e, hipHostGetDevicePointer(reinterpret_cast<void**>(&sv.d_out), sv.h_out, 0));
+        FX_HIP(e, hipExtMallocWithFlags(reinterpret_cast<void**>(&sv.in), sizeof(FxMailIn), hipDeviceMallocFinegrained));
+        FX_HIP(e, hipStreamCreateWithFlags(&sv.stream, hipStreamNonBlocking));
+    }
+    FX_HIP(e, hipStreamSynchronize(sv.stream));            // a previous generation has left (it was told to, or timed out)
+    std::memset((void*)sv.h_out, 0, sizeof(FxMailOut));
+    FX_HIP(e, hipMemsetAsync(sv.in, 0, sizeof(FxMailIn), sv.stream));
+    FX_HIP(e, hipStreamSynchronize(sv.stream));
+    sv.seq = 0;
+    int rc = fx_upload_lut(e, lut);
+    if (rc) return rc;
+    FX_HIP(e, hipStreamSynchronize(e->stream));            // the LUT (and any weight upload) must have landed before the workgroups read them
+    int cap = 0;
+    // idle 2 ms, life 10 s: a host that stops asking (or dies) frees the CUs by itself
+    rc = fx_launch_score_cnn_quad_server(e, models, M, sv.stream, sv.in, sv.d_out, 200000ull, 1000000000ull, &cap);
+    if (rc) return rc;
+    sv.models.assign(models, models + M);
+    sv.versions.clear();
+    for (int m = 0; m < M; ++m) sv.versions.push_back(models[m]->version);
+    std::memcpy(sv.lut, lut, 256);
+    sv.L = L; sv.cap = cap;
+    sv.running = true; sv.fresh = true;
+    sv.t_start = std::chrono::steady_clock::now();
+    sv.started += 1;
+    return FX_OK;
+}
+
+// FX_OK: answered.  FX_EUNSUPPORTED: not this time (the caller launches as usual).  Anything else: the call's error.
+static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii, int64_t N, int L,
+                       const uint8_t lut[256], float* out_NM, float* out_mean) {
+    auto& sv = e->server;
+    if (!e->serve_small || e->trace || e->force_generic || N < 1 || N > FX_SERVE_CAP || L > 16 || M > FX_MAX_M) return FX_EUNSUPPORTED;
+    bool same = sv.running && (int)sv.models.size() == M && sv.L == L && std::memcmp(sv.lut, lut, 256) == 0;
+    for (int m = 0; same && m < M; ++m) same = sv.models[m] == models[m] && sv.versions[m] == models[m]->version;
+    if (sv.running && !same) server_stop(e);
+    if (sv.running) {
+        if (N > sv.cap) return FX_EUNSUPPORTED;
+        if (!sv.fresh)
+            for (int m = 0; m < M && sv.running; ++m)
+                for (int t = 0; t < sv.cap / 16; ++t)
+                    if (!sv.h_out->alive[m][t]) { server_stop(e); break; }       // leaving by themselves (idle / lifetime): all go
+        // (a generation is replaced well before its workgroups' own lifetime limit)
+        if (sv.running && std::chrono::duration<double>(std::chrono::steady_clock::now() - sv.t_start).count() > 4.0) server_stop(e);
+    }
+    if (!sv.running) {
+        // residency pays from the second call on: start when the same ensemble asks twice in a row
+        const bool again = (int)sv.pending.size() == M && std::equal(sv.pending.begin(), sv.pending.end(), models);
+        if (!again) { sv.pending.assign(models, models + M); sv.streak = 1; return FX_EUNSUPPORTED; }
+        if (++sv.streak < 2) return FX_EUNSUPPORTED;
+        const int rc = server_start(e, models, M, L, lut);
+        if (rc) { sv.pending.clear(); sv.streak = 0; return FX_EUNSUPPORTED; }
+        if (N > sv.cap) return FX_EUNSUPPORTED;
+    }
+    // request: bytes, fence, request word, fence (write-combining stores may pass each other otherwise)
+    std::memcpy(sv.in->bytes, ascii, (size_t)N * L);
+    fx_bar_fence();
+    const unsigned seq = (unsigned)(++sv.seq);             // (a generation lives 4 s: far from 2^31 requests)
+    sv.in->req = ((unsigned long long)seq << 16) | (unsigned long long)N;
+    fx_bar_fence();
+    const auto t0 = std::chrono::steady_clock::now();
+    const double limit = sv.fresh ? 0.2 : 0.002;           // (the first request also waits for launch + weight fill)
+    const FxMailOut* h = sv.h_out;
+    bool bad = false;
+    float x[FX_MAX_M];
+    for (int64_t n = 0; n < N; ++n) {
+        for (int m = 0; m < M; ++m) {
+            unsigned spins = 0;
+            unsigned long long a;
+            while ((((a = h->ans[m][n]) >> 32) & 0x7FFFFFFFull) != seq) {
+                if ((++spins & 1023u) == 0) {
+                    const bool gone = !sv.fresh && !h->alive[m][n >> 4];
+                    if (gone || std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+                        server_stop(e);                    // fall back to a launch; the next calls start a new generation
+                        sv.fallbacks += 1;
+                        return FX_EUNSUPPORTED;
+                    }
+                }
+            }
+            bad = bad || (a >> 63);
+            const unsigned bits = (unsigned)a;
+            std::memcpy(&x[m], &bits, 4);
+        }
+        if (out_NM) for (int m = 0; m < M; ++m) out_NM[n * M + m] = x[m];
+        if (out_mean) {
+            float x16[16];
+            for (int m = 0; m < 16; ++m) x16[m] = m < M ? x[m] : 0.f;
+            out_mean[n] = np_mean_row16(x16, M);           // NumPy's order, the same routine the mean kernels use
+        }
+    }
+    sv.fresh = false;
+    sv.served += 1;
+    e->counters.host_calls += 1; e->counters.zero_copy_calls += 1; e->counters.sequences += N; e->counters.forwards += N * M;
+    if (bad) return fx_fail(e, FX_EBADCHAR, "substring not found: character outside the alphabet");
+    return FX_OK;
+}
+
 int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii, int64_t N, int L,
              const uint8_t lut[256], float* out_NM, float* out_mean) {
     int rc = validate_models(e, models, M, L, lut);
@@ -560,6 +694,10 @@ int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii,
     if (N == 0) return FX_OK;
     if (!ascii || (!out_NM && !out_mean)) return fx_fail(e, FX_EINVAL, "null buffer");
     FX_HIP(e, hipSetDevice(e->device));
+    {
+        rc = server_call(e, models, M, ascii, N, L, lut, out_NM, out_mean);
+        if (rc != FX_EUNSUPPORTED) return rc;
+    }
     // characters outside the alphabet are detected on the device (deferred error word)
     const size_t in_bytes = (size_t)N * (size_t)L;
     const size_t nm_bytes = sizeof(float) * (size_t)N * (size_t)M, mean_bytes = sizeof(float) * (size_t)N;

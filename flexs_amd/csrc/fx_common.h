@@ -4,12 +4,15 @@
 
 #include <cstdint>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "../../include/flexs_amd.h"
 
 #define FX_MAX_M 16          // models fused per launch (larger ensembles are split)
 #define FX_ERR_BADCHAR 1u    // bit in the deferred device error word
+#define FX_SERVE_TILES 16     // ... in 16-sequence tiles, one resident workgroup per (member, tile slot)
+#define FX_SERVE_CAP 256      // sequences per request of the resident small-call form (score_cnn_quad.hip)
 
 // ---------------------------------------------------------------- shapes
 struct FxShape {
@@ -59,6 +62,25 @@ int64_t fx_num_params(const FxShape& s);
 int64_t fx_mfma_per_tile(const FxShape& s);
 // Keras get_weights() blob -> packed fragment layout (host only, no device needed).
 void fx_pack_weights(const FxShape& s, const float* blob, float* packed);
+
+// Mailboxes of the resident ("server") form (host and device share these declarations).  Neither direction reads over
+// PCIe: the request lives in DEVICE memory, the host stores into it through the BAR (write-combining on the host side:
+// sfence after the bytes and after the request word) and the resident workgroups poll it locally; the answers live in
+// pinned HOST memory, the workgroups store (score, tag) pairs + a system fence and the host spins on its own memory.
+// Measured (tools/probes/mailbox_probe2.hip): 2.7 us round trip for one workgroup, 6 us for 48, against 25 us for 48
+// workgroups polling a request word in host memory (their reads serialise on the PCIe link).
+struct FxMailIn {                                      // device memory (fine-grained); the host only ever WRITES it
+    alignas(64) unsigned long long req;                // (sequence number << 16) | number of sequences; written LAST by the host
+    alignas(64) unsigned stop;                         // host: 1 = leave now
+    alignas(64) unsigned char bytes[FX_SERVE_CAP * 16];   // the request's sequences, row-major, L <= 16 bytes each
+};
+struct FxMailOut {                                     // pinned host memory; the host only ever READS it (after zeroing it between generations)
+    alignas(64) volatile unsigned alive[FX_MAX_M][FX_SERVE_TILES];   // 1 while the workgroup of (member, tile slot) is resident
+    // one 8-byte store per (member, sequence): the score's bits and the request's sequence number (bit 31: the tile met a
+    // character outside the alphabet).  Every element validates itself: no flag, no ordering assumption between lines
+    alignas(64) volatile unsigned long long ans[FX_MAX_M][FX_SERVE_CAP];
+};
+
 
 // ---------------------------------------------------------------- handles
 struct fx_engine {
@@ -141,6 +163,26 @@ struct fx_engine {
     // that averages in-kernel (small launches of the canonical CNN: score_cnn_quad.hip) sets fused_mean_done
     float* fuse_mean_out = nullptr;
     bool fused_mean_done = false;
+    // resident small-call form (score_cnn_quad.hip, SERVER): one workgroup per ensemble member stays on the device between
+    // explorer-size calls and answers them through a mailbox in mapped host memory
+    struct Server {
+        FxMailIn* in = nullptr;                          // device memory; also the host's (write-only) view through the BAR
+        FxMailOut* h_out = nullptr;                      // pinned host memory, and the device's view of it
+        FxMailOut* d_out = nullptr;
+        hipStream_t stream = nullptr;
+        bool running = false, fresh = false;
+        std::chrono::steady_clock::time_point t_start;
+        unsigned long long seq = 0;
+        std::vector<fx_model*> models;
+        std::vector<uint64_t> versions;
+        uint8_t lut[256] = {};
+        int L = 0, cap = 0;
+        int streak = 0;                                  // consecutive eligible calls with the key below (started at 2)
+        std::vector<fx_model*> pending;
+        int64_t served = 0, started = 0, fallbacks = 0;
+    } server;
+    bool large_bar = false;     // the host can store into device memory (the resident form needs it)
+    int64_t serve_small = 1;    // 1 = explorer-size calls of canonical CNN ensembles are answered by resident workgroups (0 = a launch per call: A/B)
     int64_t fuse_mean = 0;      // 1 = explorer-size CNN ensemble calls average in the scoring kernel (last member to finish a tile, tickets + device-scope fences) instead of launching the mean kernel.  Bit-identical, but the two fences cost what the 3 us launch saves: 32.1 vs 32.2 us per call (profiles/r3_fused_mean_ab.log): off, kept as the A/B
     // chunked host call in flight (fx_score_begin / _submit / _finish)
     struct {
@@ -169,6 +211,7 @@ struct fx_model {
     float* d_blob = nullptr;    // device copy, Keras order (generic kernels)
     float* d_packed = nullptr;  // device copy, fragment layout (MFMA kernels)
     bool has_weights = false;
+    uint64_t version = 0;       // bumped by every fx_model_set_weights
     // GlobalEpistasis first layer as a per-position table indexed by the RAW byte (score_dense_mfma.hip): Lpad x 32
     // floats, tab[l][b - base] = w1[l * A + lut[b]] (0 for bytes outside the alphabet and for the padding rows l >= L);
     // built on the device for the LUT of the call, rebuilt when the weights or the LUT change
@@ -231,6 +274,24 @@ int fx_launch_score_cnn_split(fx_engine* e, fx_model* const* models, int M, cons
 // small launches of the canonical 4-letter CNN, L <= 16 (TF-binding, RNA 14): one tile shared by a wave quad (score_cnn_quad.hip)
 int fx_launch_score_cnn_quad(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N,
                              float* d_out_NM, int Mtot, int m_off);
+// the resident form: one workgroup per model on `stream`, answering `d_mail`; *cap = sequences per request it serves.
+// FX_EUNSUPPORTED when the shape has no resident instantiation.
+// tell a resident generation to leave (its workgroups poll the flag between requests); the next eligible calls start a new one
+// host stores into device memory go through the write-combining BAR mapping: push them out
+inline void fx_bar_fence() {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    __builtin_ia32_sfence();
+#endif
+}
+inline void fx_server_stop(fx_engine* e) {
+    auto& sv = e->server;
+    if (!sv.running) return;
+    sv.in->stop = 1;
+    fx_bar_fence();
+    sv.running = false;
+}
+int fx_launch_score_cnn_quad_server(fx_engine* e, fx_model* const* models, int M, hipStream_t stream, FxMailIn* d_in, FxMailOut* d_out,
+                                    unsigned long long idle_ticks, unsigned long long life_ticks, int* cap);
 int fx_launch_score_cnn_pair(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii,
                              int64_t N, float* d_out_NM, int Mtot, int m_off);
 // small launches of the MLP: a tile's output tiles dealt to the waves of a workgroup (score_dense_small.hip)

@@ -7,7 +7,7 @@
 
 // NumPy order for a compile-time row length (registers only)
 template <int M>
-__device__ __forceinline__ float np_sum_row(const float (&x)[M]) {
+__host__ __device__ __forceinline__ float np_sum_row(const float (&x)[M]) {
     if constexpr (M < 8) {
         float r = 0.f;
 #pragma unroll
@@ -29,10 +29,19 @@ __device__ __forceinline__ float np_sum_row(const float (&x)[M]) {
     }
 }
 
+// round-to-nearest division on both sides (the device build runs with fast-math off; __fdiv_rn documents the intent)
+__host__ __device__ __forceinline__ float fx_np_div(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fdiv_rn(a, b);
+#else
+    return a / b;
+#endif
+}
+
 // mean of the first M entries of x (1 <= M <= 16), NumPy order, division as np.mean does it (sum / M in float32)
-__device__ __forceinline__ float np_mean_row16(const float (&x)[16], int M) {
+__host__ __device__ __forceinline__ float np_mean_row16(const float (&x)[16], int M) {
     switch (M) {
-#define FX_NP_CASE(m) case m: { float y[m]; _Pragma("unroll") for (int i = 0; i < m; ++i) y[i] = x[i]; return __fdiv_rn(np_sum_row<m>(y), (float)m); }
+#define FX_NP_CASE(m) case m: { float y[m]; _Pragma("unroll") for (int i = 0; i < m; ++i) y[i] = x[i]; return fx_np_div(np_sum_row<m>(y), (float)m); }
         FX_NP_CASE(1) FX_NP_CASE(2) FX_NP_CASE(3) FX_NP_CASE(4) FX_NP_CASE(5) FX_NP_CASE(6) FX_NP_CASE(7) FX_NP_CASE(8)
         FX_NP_CASE(9) FX_NP_CASE(10) FX_NP_CASE(11) FX_NP_CASE(12) FX_NP_CASE(13) FX_NP_CASE(14) FX_NP_CASE(15) FX_NP_CASE(16)
 #undef FX_NP_CASE

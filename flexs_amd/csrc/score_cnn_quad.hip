@@ -43,12 +43,19 @@ struct QuadArgs {
     // fused ensemble mean (explorer-size calls): the member whose workgroup finishes a tile LAST averages the tile's 16 sequences
     float* mean_out;            // null = off
     unsigned* tickets;          // one per tile, zero between launches (fx_zero_pool; the last arrival resets its entry)
+    // resident form
+    int srv_tiles; FxMailIn* min; FxMailOut* mout;               // null = ordinary launch
+    unsigned long long idle_ticks, life_ticks;   // leave after this long without a request / in total (100 MHz ticks)
     int off_c2, off_c3, off_cb, off_w1p, off_d1, off_d2, off_db, total_floats;
 };
 
 // QUADS quads per workgroup; XT = 16-channel tiles per exchange buffer (>= FT x positions and >= HT); L1C > 0: the number
 // of conv positions is a compile-time constant (seq_len 8: one position per wave, the position loops fold away)
-template <int HT, int QUADS, int XT, int L1C, int K = 5>
+// SERVER: the resident form.  One workgroup per member loads its weights ONCE and then answers requests from the mailbox
+// until told to stop, idle for idle_ticks, or life_ticks old: an explorer-size call then costs a mailbox round trip
+// (~3.8 us, tools/probes/mailbox_probe.hip) plus the rounds themselves instead of a launch + a 3.5 us weight fill + a
+// second launch for the mean + a completion wait (~24 us).  Same round code, same bits.
+template <int HT, int QUADS, int XT, int L1C, int K = 5, bool SERVER = false>
 __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
     constexpr int A = 4, K3 = 3, FT = 2, PL2 = (K - 1) / 2, PL3 = 1, QWAVES = 4 * QUADS;
     static_assert(K % 2 == 1, "'same' padding of conv2: (K - 1) / 2 on either side");
@@ -68,25 +75,42 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
     fx_lut_dma(lut_s, p.lut);                            // in flight together with the first member's weights
 
     int64_t u_lo, u_hi;
-    fx_unit_range(p.TG, p.M, u_lo, u_hi);
-    if (u_lo >= u_hi) return;
-    const int m_first = (int)(u_lo / p.TG), m_last = (int)((u_hi - 1) / p.TG);
+    int64_t Ncur = p.N, TGcur = p.TG;                    // SERVER: the current request's batch
+    const uint8_t* ascii = SERVER ? p.min->bytes : p.ascii;
+    float* outp = p.out;
+    [[maybe_unused]] const int srv_m = SERVER ? (int)blockIdx.x / p.srv_tiles : 0;      // SERVER: workgroup = (member, tile slot)
+    [[maybe_unused]] const int srv_slot = SERVER ? (int)blockIdx.x % p.srv_tiles : 0;
+    if constexpr (SERVER) {
+        static_assert(!SERVER || QUADS == 1, "the resident form keeps one tile per workgroup");
+        u_lo = u_hi = 0;                                  // tiles come with the requests
+    } else {
+        fx_unit_range(p.TG, p.M, u_lo, u_hi);
+        if (u_lo >= u_hi) return;
+    }
+    const int m_first = SERVER ? srv_m : (int)(u_lo / p.TG), m_last = SERVER ? srv_m : (int)((u_hi - 1) / p.TG);
     bool bad = false;
     int parity = 0;
+    [[maybe_unused]] unsigned long long srv_last = 0, srv_start = 0, srv_seen = 0;
+    // SERVER: request word, exit flag and the request's sequences (one read over PCIe) behind the quads' byte rows
+    uint8_t* srv_area = reinterpret_cast<uint8_t*>(smem + p.total_floats + 64 + QUADS * 2 * XT * 256) + QUADS * 256;
+    unsigned long long& srv_req = *reinterpret_cast<unsigned long long*>(srv_area);
+    int& srv_exit = *reinterpret_cast<int*>(srv_area + 8);
+    volatile int& srv_bad = *reinterpret_cast<volatile int*>(srv_area + 12);
+    unsigned* srv_bytes = reinterpret_cast<unsigned*>(srv_area + 16);
     // dma: the very first round reads its bytes from LDS (a compiler-tracked byte load from global memory would be waited
     // for with vmcnt(0), i.e. together with the whole image); needs the 4-byte alignment of the dword copy
-    const bool lds_bytes = p.dma && (reinterpret_cast<uintptr_t>(p.ascii) & 3) == 0;
+    const bool lds_bytes = !SERVER && p.dma && (reinterpret_cast<uintptr_t>(p.ascii) & 3) == 0;
 
     for (int m = m_first; m <= m_last; ++m) {
         __syncthreads();
         if (p.dma) {
             if (lds_bytes && m == m_first && q == 0) {
                 const int64_t tg0 = u_lo - (int64_t)m * p.TG + quad;
-                const int64_t rows = p.N - tg0 * 16 < 16 ? p.N - tg0 * 16 : 16;
+                const int64_t rows = Ncur - tg0 * 16 < 16 ? Ncur - tg0 * 16 : 16;
                 // (16 L bytes per tile: a multiple of 4; the last dword of a short tile may reach <= 3 bytes past the batch,
                 //  inside the same aligned dword -- never into another page)
                 if (u_lo + quad < u_hi && tg0 < p.TG && lane * 4 < rows * L)
-                    fx_dma4(p.ascii + tg0 * 16 * L + lane * 4, __builtin_amdgcn_readfirstlane(fx_lds_addr(bytes_s)));
+                    fx_dma4(ascii + tg0 * 16 * L + lane * 4, __builtin_amdgcn_readfirstlane(fx_lds_addr(bytes_s)));
             }
             // conv part (+ conv1 rows, conv biases), then the head: both in flight, only the first is waited for here
             fx_dma_fill(smem, p.w[m], p.off_d1 / 4, QWAVES);
@@ -105,15 +129,54 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
         const f4* w_d1 = reinterpret_cast<const f4*>(smem + p.off_d1);
         const f4* w_d2 = reinterpret_cast<const f4*>(smem + p.off_d2);
         const float* db = smem + p.off_db;
-        const int64_t t_lo = (u_lo > (int64_t)m * p.TG ? u_lo : (int64_t)m * p.TG) - (int64_t)m * p.TG;
-        const int64_t t_hi = (u_hi < (int64_t)(m + 1) * p.TG ? u_hi : (int64_t)(m + 1) * p.TG) - (int64_t)m * p.TG;
+        int64_t t_lo = SERVER ? 0 : (u_lo > (int64_t)m * p.TG ? u_lo : (int64_t)m * p.TG) - (int64_t)m * p.TG;
+        int64_t t_hi = SERVER ? 0 : (u_hi < (int64_t)(m + 1) * p.TG ? u_hi : (int64_t)(m + 1) * p.TG) - (int64_t)m * p.TG;
+        if constexpr (SERVER) {
+            if (p.dma) fx_wait_vm(0);                                // the whole image before the first request
+            __syncthreads();
+            if (tid == 0) {
+                srv_start = srv_seen = wall_clock64();
+                __hip_atomic_store(const_cast<unsigned*>(&p.mout->alive[m][srv_slot]), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+      for (;;) {                                                     // (SERVER: one iteration per request)
+        if constexpr (SERVER) {
+            if (tid == 0) {
+                int ex = 0;
+                unsigned long long r;
+                for (;;) {
+                    r = __hip_atomic_load(&p.min->req, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (r != srv_last) break;
+                    const unsigned long long now = wall_clock64();
+                    if (__hip_atomic_load(&p.min->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) || now - srv_seen > p.idle_ticks ||
+                        now - srv_start > p.life_ticks) { ex = 1; break; }
+                }
+                srv_req = r; srv_exit = ex; srv_bad = 0;
+            }
+            __syncthreads();
+            if (srv_exit) break;
+            Ncur = (int64_t)(srv_req & 0xFFFFull);
+            TGcur = (Ncur + 15) >> 4;
+            t_lo = srv_slot; t_hi = srv_slot < TGcur ? srv_slot + 1 : srv_slot;
+            bad = false;
+            if (t_hi == t_lo) {                                      // a request with fewer tiles: nothing to answer from this slot
+                if (tid == 0) { srv_last = srv_req; srv_seen = wall_clock64(); }
+                __syncthreads();                                     // (everybody has read the request word)
+                continue;
+            }
+            // this tile's bytes: one dword per thread (past the caches: the host wrote them through the BAR), then everybody reads LDS
+            const int64_t srv_rows = Ncur - (int64_t)srv_slot * 16 < 16 ? Ncur - (int64_t)srv_slot * 16 : 16;
+            if ((int64_t)tid * 4 < srv_rows * L)
+                srv_bytes[tid] = __hip_atomic_load(reinterpret_cast<const unsigned*>(ascii + (int64_t)srv_slot * 16 * L) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __syncthreads();
+        }
         const int rounds = (int)((t_hi - t_lo + QUADS - 1) / QUADS);
 
         for (int rd = 0; rd < rounds; ++rd, parity ^= 1) {
             const int64_t tg = t_lo + (int64_t)rd * QUADS + quad;
             const bool live = tg < t_hi;                             // idle quads run along for the barriers
             const int64_t n = tg * 16 + sq;
-            const uint8_t* row = p.ascii + ((live && n < p.N) ? n : 0) * L;
+            const uint8_t* row = ascii + ((live && n < Ncur) ? n : 0) * L;
             f4* X = xq + (parity ? XT * 64 : 0);
             f4* Y = xq + (parity ? 0 : XT * 64);
             asm volatile("" ::: "memory");                           // keep the LDS weight reads inside the round
@@ -131,7 +194,8 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
                             if (c[j] == 0xFF) { bad = true; c[j] = 0; }
                         }
                     };
-                    if (lds_bytes && m == m_first && rd == 0) codes((fx_lds_u8p)(bytes_s + (n < p.N ? sq : 0) * L));
+                    if constexpr (SERVER) codes((fx_lds_u8p)(reinterpret_cast<uint8_t*>(srv_bytes) + ((live && n < Ncur) ? sq : 0) * L));
+                    else if (lds_bytes && m == m_first && rd == 0) codes((fx_lds_u8p)(bytes_s + (n < Ncur ? sq : 0) * L));
                     else codes(row);
                     init_bias<FT, 1>(cb, o1, g);
 #pragma unroll
@@ -145,6 +209,7 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
                     for (int t = 0; t < FT; ++t) X[(pos * FT + t) * 64 + lane] = o1[t][0];
                 }
             }
+            if constexpr (SERVER) { if (bad) srv_bad = 1; }          // (read by wave 0 when it answers, several barriers later)
             __syncthreads();
             if (live) FX_PHASE_STAMP(8);
 
@@ -256,8 +321,17 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
                 for (int mi = 0; mi < HT; ++mi) h2[mi][0] = X[mi * 64 + lane];
                 float y[1];
                 final_dot<HT, 1>(db + 32 * HT, db[48 * HT], h2, y, g);
-                if (g == 0 && n < p.N) p.out[n * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y[0]);
-                if (p.mean_out) {
+                if constexpr (SERVER) {
+                    // (score, tag) in one 8-byte store to host memory; the fence pushes the lines out of this XCD's L2
+                    const unsigned tag = (unsigned)(srv_req >> 16) | (srv_bad ? 0x80000000u : 0u);
+                    if (g == 0 && n < Ncur)
+                        __hip_atomic_store(const_cast<unsigned long long*>(&p.mout->ans[m][n]),
+                                           ((unsigned long long)tag << 32) | __float_as_uint(fx_nan_to_num(y[0])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __threadfence_system();
+                } else {
+                    if (g == 0 && n < Ncur) outp[n * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y[0]);
+                }
+                if (!SERVER && p.mean_out) {
                     // np.mean over the members (ensemble.py:24) without a second launch: publish this member's 16 scores
                     // device-wide, take the tile's ticket; the M-th arrival reads all members' scores back (past its own
                     // L2: other members' workgroups may sit on other XCDs) and averages in NumPy's order.  Once per tile
@@ -270,7 +344,7 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
                     t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
                     if (t == (unsigned)p.M - 1u) {
                         __threadfence();
-                        if (g == 0 && n < p.N) {
+                        if (g == 0 && n < Ncur) {
                             float x[16];
 #pragma unroll
                             for (int mm = 0; mm < 16; ++mm)
@@ -283,9 +357,19 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
             }
             if (live) FX_TILE_DONE();
         }
+        if constexpr (SERVER) {
+            if (tid == 0) { srv_last = srv_req; srv_seen = wall_clock64(); }
+            __syncthreads();
+        } else {
+            break;
+        }
+      }
+        if constexpr (SERVER) {
+            if (tid == 0) __hip_atomic_store(const_cast<unsigned*>(&p.mout->alive[m][srv_slot]), 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     fx_stamp(p.trace, 6);
-    if (bad) fx_raise(p.err, FX_ERR_BADCHAR);
+    if (!SERVER && bad) fx_raise(p.err, FX_ERR_BADCHAR);
 }
 
 }  // namespace
@@ -359,4 +443,58 @@ int fx_launch_score_cnn_quad(fx_engine* e, fx_model* const* models, int M, const
     }();
     if (rc_q == FX_OK && fuse) e->fused_mean_done = true;
     return rc_q;
+}
+
+
+// ---- the resident form ----------------------------------------------------------------------------------------------
+namespace {
+
+template <int QUADS, int XT, int L1C>
+int launch_server(fx_engine* e, QuadArgs a, int M, hipStream_t stream) {
+    const size_t lds = (size_t)a.total_floats * 4 + 256 + (size_t)QUADS * 2 * XT * 1024 + (size_t)QUADS * 256 + 16 + 256;
+    if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
+    auto kern = k_score_cnn_quad<7, QUADS, XT, L1C, 5, true>;
+    static bool attr_set[64] = {};
+    if (!attr_set[e->device & 63]) {
+        FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[e->device & 63] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(M * a.srv_tiles)), dim3(QUADS * 256), lds, stream, a);
+    FX_HIP(e, hipGetLastError());
+    return FX_OK;
+}
+
+}  // namespace
+
+// Canonical shapes only (what the explorers' surrogates are built with: kernel size 5, 32 filters, 97-112 hidden units,
+// 4-letter alphabet, seq_len <= 16).  One workgroup (one quad) per member and tile slot: a request of N sequences is
+// answered by M x ceil(N / 16) of them, each on its own CU; at most ~a third of the chip stays resident.
+int fx_launch_score_cnn_quad_server(fx_engine* e, fx_model* const* models, int M, hipStream_t stream, FxMailIn* d_in, FxMailOut* d_out,
+                                    unsigned long long idle_ticks, unsigned long long life_ticks, int* cap) {
+    const FxShape& s = models[0]->shape;
+    const FxPackLayout& lay = models[0]->layout;
+    const int L1 = s.L - s.K + 1;
+    if (s.kind != FX_CNN || s.A != 4 || s.K != 5 || L1 < 1 || L1 > 12 || lay.FT != 2 || lay.HT != 7 || M > FX_MAX_M || M < 1 ||
+        e->cnn_conv1_mfma || e->cnn_variant)
+        return FX_EUNSUPPORTED;
+    for (int m = 1; m < M; ++m) {
+        const FxShape& t = models[m]->shape;
+        if (t.kind != s.kind || t.L != s.L || t.A != s.A || t.F != s.F || t.H != s.H || t.K != s.K) return FX_EUNSUPPORTED;
+    }
+    QuadArgs a{};
+    a.lut = e->d_lut; a.err = e->d_err;
+    for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
+    a.M = M; a.L = s.L; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4;
+    a.dma = e->dma_fill && lay.off_d1 % 4 == 0 && lay.total_floats % 4 == 0;
+    a.off_c2 = (int)lay.off_c2; a.off_c3 = (int)lay.off_c3; a.off_cb = (int)lay.off_cb; a.off_w1p = (int)lay.off_w1p;
+    a.off_d1 = (int)lay.off_d1; a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
+    a.min = d_in; a.mout = d_out; a.idle_ticks = idle_ticks; a.life_ticks = life_ticks;
+    int tiles = e->num_cus / 3 / M;
+    if (tiles > FX_SERVE_TILES) tiles = FX_SERVE_TILES;
+    if (tiles < 1) return FX_EUNSUPPORTED;
+    a.srv_tiles = tiles;
+    *cap = 16 * tiles;
+    if (L1 == 4) return launch_server<1, 8, 4>(e, a, M, stream);
+    if (L1 < 4) return launch_server<1, 8, 0>(e, a, M, stream);
+    return launch_server<1, 24, 0>(e, a, M, stream);
 }

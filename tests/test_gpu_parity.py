@@ -1744,3 +1744,67 @@ def test_small_launch_fused_ensemble_mean(eng, L, alpha, M):
         assert np.array_equal(ens.get_fitness(seqs[:20]), want[:20])
     finally:
         eng.set_option("fuse_mean", 0)
+
+
+@pytest.mark.parametrize("L,alpha,M", [(8, "TGCA", 3), (14, "UGCA", 3), (8, "TGCA", 1), (7, "TGCA", 8), (14, "UGCA", 16), (6, "ACGT", 2)])
+def test_resident_small_call_form(eng, L, alpha, M):
+    """`serve_small` (default on): from the second explorer-size call of the same canonical CNN ensemble on, one workgroup per
+    member stays on the device with its weights in LDS and answers requests through a mailbox in mapped host memory -- no
+    launch, no weight fill, no second launch for the mean.  Same round code as the launched small form, so the same bits:
+    every batch size it serves, interleaved with sizes it does not (those launch as before), repeated calls, a bad
+    character (ValueError, and the next call is fine), new weights (a new generation), an idle exit and restart."""
+    import time as _t
+    members = [bm.CNN(L, 32, 100, alpha, seed=s) for s in range(M)]
+    ens = flexs_amd.Ensemble(members)
+    stack = flexs_amd.Ensemble(members, combine_with=lambda x: x)
+    sizes = (1, 5, 16, 17, 20, 31, 32, 33, 48, 95, 96, 97, 400)
+    data = {n: rand_seqs(n, L, alpha, seed=100 + n)[1] for n in sizes}
+    eng.set_option("serve_small", 0)
+    try:
+        want = {n: ens.get_fitness(data[n]) for n in sizes}
+        want_nm = {n: stack.get_fitness(data[n]) for n in sizes}
+    finally:
+        eng.set_option("serve_small", 1)
+    for n in sizes:
+        assert np.array_equal(want[n], np.mean(want_nm[n], axis=1))
+    served0 = eng.get_option("server_calls")
+    for rep in range(3):
+        for n in sizes:
+            assert np.array_equal(ens.get_fitness(data[n]), want[n]), (rep, n)
+            assert np.array_equal(stack.get_fitness(data[n]), want_nm[n]), (rep, n)
+    assert eng.get_option("server_calls") - served0 >= 2 * 2 * 5, "explorer-size calls did not go through the resident form"
+    assert eng.get_option("server_fallbacks") == 0
+    # a character outside the alphabet: the reference's ValueError, and the resident workgroups carry on
+    with pytest.raises(ValueError):
+        ens.get_fitness(data[20][:7] + ["Z" * L])
+    assert np.array_equal(ens.get_fitness(data[20]), want[20])
+    # new weights: the resident generation is replaced
+    w0 = members[0].model.get_weights()
+    members[0].model.set_weights([w * 0.5 for w in w0])
+    eng.set_option("serve_small", 0)
+    try:
+        want_half = ens.get_fitness(data[20])
+    finally:
+        eng.set_option("serve_small", 1)
+    starts = eng.get_option("server_starts")
+    for _ in range(4):
+        assert np.array_equal(ens.get_fitness(data[20]), want_half)
+    assert eng.get_option("server_starts") == starts + 1
+    assert not np.array_equal(want_half, want[20])
+    members[0].model.set_weights(w0)
+    # idle: the workgroups leave by themselves after 2 ms without a request; the next calls launch, then start a new generation
+    for _ in range(3):
+        ens.get_fitness(data[5])
+    assert eng.get_option("server_resident") == 1
+    _t.sleep(0.05)
+    starts = eng.get_option("server_starts")
+    for _ in range(4):
+        assert np.array_equal(ens.get_fitness(data[5]), want[5])
+    assert eng.get_option("server_starts") == starts + 1 and eng.get_option("server_fallbacks") == 0
+    # a big launch in between tells them to leave (it wants every CU) and is itself unaffected
+    b, big = rand_seqs(100000, L, alpha, seed=7)
+    big_want = ens.get_fitness(big)
+    for _ in range(3):
+        ens.get_fitness(data[20])
+    assert np.array_equal(ens.get_fitness(big), big_want)
+    assert np.array_equal(ens.get_fitness(data[20]), want[20])
