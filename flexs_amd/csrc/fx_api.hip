@@ -281,6 +281,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "dense_pipe")) return &e->dense_pipe;
     if (!std::strcmp(key, "fuse_mean")) return &e->fuse_mean;
     if (!std::strcmp(key, "serve_small")) return &e->serve_small;
+    if (!std::strcmp(key, "serve_idle_us")) return &e->serve_idle_us;
     if (!std::strcmp(key, "chunk_overlap")) return &e->chunk_overlap;
     if (!std::strcmp(key, "zero_copy_bytes")) return &e->zero_copy_bytes;
     if (!std::strcmp(key, "zero_copy_mode")) return &e->zero_copy_mode;
@@ -595,16 +596,15 @@ static int server_start(fx_engine* e, fx_model* const* models, int M, int L, con
         FX_HIP(e, hipStreamCreateWithFlags(&sv.stream, hipStreamNonBlocking));
     }
     FX_HIP(e, hipStreamSynchronize(sv.stream));            // a previous generation has left (it was told to, or timed out)
-    std::memset((void*)sv.h_out, 0, sizeof(FxMailOut));
-    FX_HIP(e, hipMemsetAsync(sv.in, 0, sizeof(FxMailIn), sv.stream));
-    FX_HIP(e, hipStreamSynchronize(sv.stream));
-    sv.seq = 0;
+    std::memset((void*)sv.h_out->alive, 0, sizeof(sv.h_out->alive));   // (answers carry sequence numbers that never repeat: no need to clear them)
+    sv.in->req = 0; sv.in->stop = 0;                       // (through the BAR, like every host access to it; posted before the launch's doorbell)
+    fx_bar_fence();
     int rc = fx_upload_lut(e, lut);
     if (rc) return rc;
     FX_HIP(e, hipStreamSynchronize(e->stream));            // the LUT (and any weight upload) must have landed before the workgroups read them
     int cap = 0;
-    // idle 2 ms, life 10 s: a host that stops asking (or dies) frees the CUs by itself
-    rc = fx_launch_score_cnn_quad_server(e, models, M, sv.stream, sv.in, sv.d_out, 200000ull, 1000000000ull, &cap);
+    // a host that stops asking (or dies) frees the CUs by itself: after 2 x serve_idle_us (100 MHz ticks), and 10 s whatever happens
+    rc = fx_launch_score_cnn_quad_server(e, models, M, sv.stream, sv.in, sv.d_out, (unsigned long long)e->serve_idle_us * 200ull, 1000000000ull, &cap);
     if (rc) return rc;
     sv.models.assign(models, models + M);
     sv.versions.clear();
@@ -627,6 +627,9 @@ static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8
     if (sv.running && !same) server_stop(e);
     if (sv.running) {
         if (N > sv.cap) return FX_EUNSUPPORTED;
+        // the workgroups leave 2 x serve_idle_us after their last request: do not post to a generation that may be on its way out
+        if (!sv.fresh && std::chrono::duration<double>(std::chrono::steady_clock::now() - sv.t_post).count() * 1e6 > (double)e->serve_idle_us)
+            server_stop(e);
         if (!sv.fresh)
             for (int m = 0; m < M && sv.running; ++m)
                 for (int t = 0; t < sv.cap / 16; ++t)
@@ -635,21 +638,26 @@ static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8
         if (sv.running && std::chrono::duration<double>(std::chrono::steady_clock::now() - sv.t_start).count() > 4.0) server_stop(e);
     }
     if (!sv.running) {
-        // residency pays from the second call on: start when the same ensemble asks twice in a row
-        const bool again = (int)sv.pending.size() == M && std::equal(sv.pending.begin(), sv.pending.end(), models);
-        if (!again) { sv.pending.assign(models, models + M); sv.streak = 1; return FX_EUNSUPPORTED; }
-        if (++sv.streak < 2) return FX_EUNSUPPORTED;
+        // residency pays when calls come densely: start when the same ensemble asks again within the idle window (a caller
+        // with milliseconds of host work between its calls would pay a start per call and is better served by launches)
+        const auto now = std::chrono::steady_clock::now();
+        const bool again = (int)sv.pending.size() == M && std::equal(sv.pending.begin(), sv.pending.end(), models) &&
+                           std::chrono::duration<double>(now - sv.t_pending).count() * 1e6 < (double)e->serve_idle_us;
+        sv.t_pending = now;
+        if (!again) { sv.pending.assign(models, models + M); return FX_EUNSUPPORTED; }
         const int rc = server_start(e, models, M, L, lut);
-        if (rc) { sv.pending.clear(); sv.streak = 0; return FX_EUNSUPPORTED; }
+        if (rc) { sv.pending.clear(); return FX_EUNSUPPORTED; }
         if (N > sv.cap) return FX_EUNSUPPORTED;
     }
     // request: bytes, fence, request word, fence (write-combining stores may pass each other otherwise)
     std::memcpy(sv.in->bytes, ascii, (size_t)N * L);
     fx_bar_fence();
-    const unsigned seq = (unsigned)(++sv.seq);             // (a generation lives 4 s: far from 2^31 requests)
+    if ((++sv.seq & 0x7FFFFFFFull) == 0) ++sv.seq;         // 31-bit tags, never 0; they run on across generations, so a slot's stale answer never matches
+    const unsigned seq = (unsigned)(sv.seq & 0x7FFFFFFFull);
     sv.in->req = ((unsigned long long)seq << 16) | (unsigned long long)N;
     fx_bar_fence();
     const auto t0 = std::chrono::steady_clock::now();
+    sv.t_post = t0;
     const double limit = sv.fresh ? 0.2 : 0.002;           // (the first request also waits for launch + weight fill)
     const FxMailOut* h = sv.h_out;
     bool bad = false;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdint>
 #include <string>
 #include <chrono>
@@ -74,6 +75,7 @@ struct FxMailIn {                                      // device memory (fine-gr
     alignas(64) unsigned stop;                         // host: 1 = leave now
     alignas(64) unsigned char bytes[FX_SERVE_CAP * 16];   // the request's sequences, row-major, L <= 16 bytes each
 };
+static_assert(offsetof(FxMailIn, stop) == 64 && offsetof(FxMailIn, bytes) == 128, "server_start clears the first 128 bytes");
 struct FxMailOut {                                     // pinned host memory; the host only ever READS it (after zeroing it between generations)
     alignas(64) volatile unsigned alive[FX_MAX_M][FX_SERVE_TILES];   // 1 while the workgroup of (member, tile slot) is resident
     // one 8-byte store per (member, sequence): the score's bits and the request's sequence number (bit 31: the tile met a
@@ -171,17 +173,18 @@ struct fx_engine {
         FxMailOut* d_out = nullptr;
         hipStream_t stream = nullptr;
         bool running = false, fresh = false;
-        std::chrono::steady_clock::time_point t_start;
+        std::chrono::steady_clock::time_point t_start, t_post;   // generation start, last request
         unsigned long long seq = 0;
         std::vector<fx_model*> models;
         std::vector<uint64_t> versions;
         uint8_t lut[256] = {};
         int L = 0, cap = 0;
-        int streak = 0;                                  // consecutive eligible calls with the key below (started at 2)
-        std::vector<fx_model*> pending;
+        std::vector<fx_model*> pending;                  // the last eligible call's ensemble, and when it came
+        std::chrono::steady_clock::time_point t_pending;
         int64_t served = 0, started = 0, fallbacks = 0;
     } server;
     bool large_bar = false;     // the host can store into device memory (the resident form needs it)
+    int64_t serve_idle_us = 500;   // calls of the same ensemble closer than this start / keep the resident workgroups; they leave after twice this long without a request (a device-wide synchronize waits that long for them at most)
     int64_t serve_small = 1;    // 1 = explorer-size calls of canonical CNN ensembles are answered by resident workgroups (0 = a launch per call: A/B)
     int64_t fuse_mean = 0;      // 1 = explorer-size CNN ensemble calls average in the scoring kernel (last member to finish a tile, tickets + device-scope fences) instead of launching the mean kernel.  Bit-identical, but the two fences cost what the 3 us launch saves: 32.1 vs 32.2 us per call (profiles/r3_fused_mean_ab.log): off, kept as the A/B
     // chunked host call in flight (fx_score_begin / _submit / _finish)

@@ -97,6 +97,17 @@ const char *fx_last_error(fx_engine *e);
  *                              host memory directly (explorer-size calls: no copy enqueues).
  *   zero_copy_mode    -1       larger host calls: -1 = decide per call (fx_plan_host_call), 0 = always copy,
  *                              1 = always zero-copy.
+ *   serve_small       1        1 = explorer-size fx_score calls (<= 256 sequences, seq_len <= 16) of a canonical 4-letter
+ *                              CNN ensemble are answered by workgroups that STAY on the device between calls (weights
+ *                              in LDS, request and answer through mailboxes; no launch): 28 -> 11 us per call, same
+ *                              bits.  They start when the same ensemble calls twice within serve_idle_us and occupy
+ *                              members x ceil(cap / 16) <= num_cus / 3 CUs while resident; new weights, training, a
+ *                              launch that fills the chip, or engine destruction tell them to leave.  Needs a large
+ *                              BAR (the host stores the request into device memory); 0 = a launch per call.
+ *   serve_idle_us     500      ... calls further apart than this are launched; the workgroups leave by themselves after
+ *                              twice this long without a request.  A device-wide synchronize (hipDeviceSynchronize)
+ *                              issued right after a small call waits for that.
+ *   server_calls, server_starts, server_fallbacks, server_resident   (read) bookkeeping of the resident form.
  *   train_rows        0        fx_train_fit: mini-batch rows per forward+backward workgroup; 0 = automatic (depends on
  *                              the member's own shape and batch size only: a fit is bit-reproducible whatever it is
  *                              trained next to).
