@@ -604,7 +604,9 @@ static int server_start(fx_engine* e, fx_model* const* models, int M, int L, con
     FX_HIP(e, hipStreamSynchronize(e->stream));            // the LUT (and any weight upload) must have landed before the workgroups read them
     int cap = 0;
     // a host that stops asking (or dies) frees the CUs by itself: after 2 x serve_idle_us (100 MHz ticks), and 10 s whatever happens
-    rc = fx_launch_score_cnn_quad_server(e, models, M, sv.stream, sv.in, sv.d_out, (unsigned long long)e->serve_idle_us * 200ull, 1000000000ull, &cap);
+    const unsigned long long idle = (unsigned long long)e->serve_idle_us * 200ull, life = 1000000000ull;
+    rc = fx_launch_score_cnn_quad_server(e, models, M, sv.stream, sv.in, sv.d_out, idle, life, &cap);
+    if (rc == FX_EUNSUPPORTED) rc = fx_launch_score_dense_small_server(e, models, M, sv.stream, sv.in, sv.d_out, idle, life, &cap);
     if (rc) return rc;
     sv.models.assign(models, models + M);
     sv.versions.clear();
@@ -621,7 +623,7 @@ static int server_start(fx_engine* e, fx_model* const* models, int M, int L, con
 static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii, int64_t N, int L,
                        const uint8_t lut[256], float* out_NM, float* out_mean) {
     auto& sv = e->server;
-    if (!e->serve_small || e->trace || e->force_generic || N < 1 || N > FX_SERVE_CAP || L > 16 || M > FX_MAX_M) return FX_EUNSUPPORTED;
+    if (!e->serve_small || e->trace || e->force_generic || N < 1 || N > FX_SERVE_CAP || N * L > FX_SERVE_BYTES || M > FX_MAX_M) return FX_EUNSUPPORTED;
     bool same = sv.running && (int)sv.models.size() == M && sv.L == L && std::memcmp(sv.lut, lut, 256) == 0;
     for (int m = 0; same && m < M; ++m) same = sv.models[m] == models[m] && sv.versions[m] == models[m]->version;
     if (sv.running && !same) server_stop(e);

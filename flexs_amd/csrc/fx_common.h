@@ -13,6 +13,7 @@
 #define FX_MAX_M 16          // models fused per launch (larger ensembles are split)
 #define FX_ERR_BADCHAR 1u    // bit in the deferred device error word
 #define FX_SERVE_TILES 16     // ... in 16-sequence tiles, one resident workgroup per (member, tile slot)
+#define FX_SERVE_BYTES 16384   // ... and N x seq_len bytes at most
 #define FX_SERVE_CAP 256      // sequences per request of the resident small-call form (score_cnn_quad.hip)
 
 // ---------------------------------------------------------------- shapes
@@ -73,7 +74,7 @@ void fx_pack_weights(const FxShape& s, const float* blob, float* packed);
 struct FxMailIn {                                      // device memory (fine-grained); the host only ever WRITES it
     alignas(64) unsigned long long req;                // (sequence number << 16) | number of sequences; written LAST by the host
     alignas(64) unsigned stop;                         // host: 1 = leave now
-    alignas(64) unsigned char bytes[FX_SERVE_CAP * 16];   // the request's sequences, row-major, L <= 16 bytes each
+    alignas(64) unsigned char bytes[FX_SERVE_BYTES];   // the request's sequences, row-major
 };
 static_assert(offsetof(FxMailIn, stop) == 64 && offsetof(FxMailIn, bytes) == 128, "server_start clears the first 128 bytes");
 struct FxMailOut {                                     // pinned host memory; the host only ever READS it (after zeroing it between generations)
@@ -295,6 +296,8 @@ inline void fx_server_stop(fx_engine* e) {
 }
 int fx_launch_score_cnn_quad_server(fx_engine* e, fx_model* const* models, int M, hipStream_t stream, FxMailIn* d_in, FxMailOut* d_out,
                                     unsigned long long idle_ticks, unsigned long long life_ticks, int* cap);
+int fx_launch_score_dense_small_server(fx_engine* e, fx_model* const* models, int M, hipStream_t stream, FxMailIn* d_in, FxMailOut* d_out,
+                                       unsigned long long idle_ticks, unsigned long long life_ticks, int* cap);
 int fx_launch_score_cnn_pair(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii,
                              int64_t N, float* d_out_NM, int Mtot, int m_off);
 // small launches of the MLP: a tile's output tiles dealt to the waves of a workgroup (score_dense_small.hip)

@@ -32,9 +32,12 @@ struct SmallArgs {
     int L, A, rlh;
     int pair;                    // 1 = first layer from the pre-summed pair rows (4-letter alphabets), as the PAIR form of the persistent kernel
     int off_w1p, off_w1pair, off_d2, off_d3, off_db, off_first;
+    // SERVER (the resident form, see score_cnn_quad.hip): workgroup = (member, tile slot), requests from the mailboxes
+    int srv_tiles; FxMailIn* min; FxMailOut* mout;
+    unsigned long long idle_ticks, life_ticks;
 };
 
-template <int KIND, int HT>
+template <int KIND, int HT, bool SERVER = false>
 __global__ void __launch_bounds__(SW * 64) k_score_dense_small(SmallArgs p) {
     constexpr int OT = (HT + SW - 1) / SW;                // output tiles per wave (1 or 2)
     constexpr int PF = 8;                                 // first-layer rows in flight per output tile
@@ -47,14 +50,58 @@ __global__ void __launch_bounds__(SW * 64) k_score_dense_small(SmallArgs p) {
     uint8_t* bytes_s = lut_s + 256;                       // the tile's 16 x L bytes
 
     const int64_t unit = blockIdx.x;
-    const int m = (int)(unit / p.TG);
-    const int64_t tg = unit - (int64_t)m * p.TG;
-    const int64_t rows = p.N - tg * 16 < 16 ? p.N - tg * 16 : 16;
-    const int64_t n = tg * 16 + sq;
+    const int m = SERVER ? (int)(unit / p.srv_tiles) : (int)(unit / p.TG);
+    const int64_t tg = SERVER ? unit % p.srv_tiles : unit - (int64_t)m * p.TG;
+    int64_t Ncur = p.N;                                  // SERVER: the current request's batch
+    // SERVER: request word, exit flag, bad-character flag behind the tile's bytes
+    uint8_t* srv_area = bytes_s + ((16 * L + 15) & ~15);
+    unsigned long long& srv_req = *reinterpret_cast<unsigned long long*>(srv_area);
+    int& srv_exit = *reinterpret_cast<int*>(srv_area + 8);
+    volatile int& srv_bad = *reinterpret_cast<volatile int*>(srv_area + 12);
+    [[maybe_unused]] unsigned long long srv_last = 0, srv_start = 0, srv_seen = 0;
     for (int i = tid; i < 64; i += SW * 64) reinterpret_cast<uint32_t*>(lut_s)[i] = reinterpret_cast<const uint32_t*>(p.lut)[i];
-    for (int i = tid; i < (int)rows * L; i += SW * 64) bytes_s[i] = p.ascii[tg * 16 * L + i];
+    if constexpr (SERVER) {
+        __syncthreads();
+        if (tid == 0) {
+            srv_start = srv_seen = wall_clock64();
+            __hip_atomic_store(const_cast<unsigned*>(&p.mout->alive[m][tg]), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+  for (;;) {                                               // (SERVER: one iteration per request)
+    if constexpr (SERVER) {
+        if (tid == 0) {
+            int ex = 0;
+            unsigned long long r;
+            for (;;) {
+                r = __hip_atomic_load(&p.min->req, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (r != srv_last) break;
+                const unsigned long long now = wall_clock64();
+                if (__hip_atomic_load(&p.min->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) || now - srv_seen > p.idle_ticks ||
+                    now - srv_start > p.life_ticks) { ex = 1; break; }
+            }
+            srv_req = r; srv_exit = ex; srv_bad = 0;
+        }
+        __syncthreads();
+        if (srv_exit) break;
+        Ncur = (int64_t)(srv_req & 0xFFFFull);
+        if (tg * 16 >= Ncur) {                               // a request with fewer tiles: nothing to answer from this slot
+            if (tid == 0) { srv_last = srv_req; srv_seen = wall_clock64(); }
+            __syncthreads();                                 // (everybody has read the request word)
+            continue;
+        }
+    }
+    const int64_t rows = Ncur - tg * 16 < 16 ? Ncur - tg * 16 : 16;
+    const int64_t n = tg * 16 + sq;
+    if constexpr (SERVER) {
+        // the tile's bytes, dword-wise and past the caches (the host wrote them through the BAR)
+        const unsigned* src = reinterpret_cast<const unsigned*>(p.min->bytes + tg * 16 * L);
+        for (int i = tid; i * 4 < (int)rows * L; i += SW * 64)
+            reinterpret_cast<unsigned*>(bytes_s)[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+        for (int i = tid; i < (int)rows * L; i += SW * 64) bytes_s[i] = p.ascii[tg * 16 * L + i];
+    }
     __syncthreads();
-    const uint8_t* row = bytes_s + (n < p.N ? sq : 0) * L;    // lanes past the batch recompute the tile's first sequence
+    const uint8_t* row = bytes_s + (n < Ncur ? sq : 0) * L;    // lanes past the batch recompute the tile's first sequence
     const float* W = p.w[m];
     const float* db = W + p.off_db;
     bool bad = false;
@@ -82,6 +129,7 @@ __global__ void __launch_bounds__(SW * 64) k_score_dense_small(SmallArgs p) {
                 if (l0 + 4 * k < L) sacc += r[k];
         }
         bad |= seen >= 0x80u;
+        if constexpr (SERVER) { if (bad) srv_bad = 1; }      // (read by wave 0 when it answers, barriers later)
         sacc += __shfl_xor(sacc, 16);
         sacc += __shfl_xor(sacc, 32);
         sacc += db[0];
@@ -170,6 +218,7 @@ __global__ void __launch_bounds__(SW * 64) k_score_dense_small(SmallArgs p) {
         }
     }
     bad |= seen >= 0x80u;
+    if constexpr (SERVER) { if (bad) srv_bad = 1; }
 #pragma unroll
     for (int t = 0; t < OT; ++t) {
         const int mo = wave + SW * t;
@@ -222,9 +271,28 @@ __global__ void __launch_bounds__(SW * 64) k_score_dense_small(SmallArgs p) {
         float y[1];
         if constexpr (KIND == FX_GE) final_dot<HT, 1>(db + 4 + 48 * HT, db[4 + 64 * HT], h3, y, g);
         else final_dot<HT, 1>(db + 48 * HT, db[64 * HT], h3, y, g);
-        if (g == 0 && n < p.N) p.out[n * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y[0]);
+        if constexpr (SERVER) {
+            // (score, tag) in one 8-byte store to host memory; the fence pushes the lines out of this XCD's L2
+            const unsigned tag = (unsigned)(srv_req >> 16) | (srv_bad ? 0x80000000u : 0u);
+            if (g == 0 && n < Ncur)
+                __hip_atomic_store(const_cast<unsigned long long*>(&p.mout->ans[m][n]),
+                                   ((unsigned long long)tag << 32) | __float_as_uint(fx_nan_to_num(y[0])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
+        } else {
+            if (g == 0 && n < Ncur) p.out[n * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y[0]);
+        }
     }
-    if (bad) fx_raise(p.err, FX_ERR_BADCHAR);
+    if constexpr (SERVER) {
+        if (tid == 0) { srv_last = srv_req; srv_seen = wall_clock64(); }
+        __syncthreads();                                     // (the exchange buffers and the request word are free again)
+    } else {
+        if (bad) fx_raise(p.err, FX_ERR_BADCHAR);
+        break;
+    }
+  }
+    if constexpr (SERVER) {
+        if (tid == 0) __hip_atomic_store(const_cast<unsigned*>(&p.mout->alive[m][tg]), 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 template <int KIND, int HT>
@@ -233,6 +301,16 @@ int launch_small(fx_engine* e, const SmallArgs& a, int64_t U) {
     const size_t lds = (size_t)2 * HT * 1024 + 256 + (size_t)16 * a.L;
     if (lds > 64 * 1024) return FX_EUNSUPPORTED;
     hipLaunchKernelGGL(kern, dim3((unsigned)U), dim3(SW * 64), lds, e->stream, a);
+    FX_HIP(e, hipGetLastError());
+    return FX_OK;
+}
+
+template <int KIND, int HT>
+int launch_small_server(fx_engine* e, const SmallArgs& a, int M, hipStream_t stream) {
+    auto kern = k_score_dense_small<KIND, HT, true>;
+    const size_t lds = (size_t)2 * HT * 1024 + 256 + (((size_t)16 * a.L + 15) & ~(size_t)15) + 16;
+    if (lds > 64 * 1024) return FX_EUNSUPPORTED;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(M * a.srv_tiles)), dim3(SW * 64), lds, stream, a);
     FX_HIP(e, hipGetLastError());
     return FX_OK;
 }
@@ -273,6 +351,50 @@ int fx_launch_score_mlp_small(fx_engine* e, fx_model* const* models, int M, cons
         case 13: return launch_small<KIND, 13>(e, a, U);            \
         case 16: return launch_small<KIND, 16>(e, a, U);            \
         default: return FX_EUNSUPPORTED;                            \
+    }
+    if (s.kind == FX_GE) { FX_SMALL_CASES(FX_GE) }
+    FX_SMALL_CASES(FX_MLP)
+#undef FX_SMALL_CASES
+}
+
+
+// The resident form (see fx_launch_score_cnn_quad_server): one workgroup per member and tile slot, weights read from L2 at
+// every request as the launched form does (nothing to fill), so a request costs the mailbox round trip + the tile.
+int fx_launch_score_dense_small_server(fx_engine* e, fx_model* const* models, int M, hipStream_t stream, FxMailIn* d_in, FxMailOut* d_out,
+                                       unsigned long long idle_ticks, unsigned long long life_ticks, int* cap) {
+    const FxShape& s = models[0]->shape;
+    const FxPackLayout& lay = models[0]->layout;
+    if (!e->dense_small || (s.kind != FX_MLP && s.kind != FX_GE) || M > FX_MAX_M || M < 1 || s.A > 127) return FX_EUNSUPPORTED;
+    for (int m = 1; m < M; ++m) {
+        const FxShape& t = models[m]->shape;
+        if (t.kind != s.kind || t.L != s.L || t.A != s.A || t.H != s.H) return FX_EUNSUPPORTED;
+    }
+    const int form = s.kind == FX_MLP ? fx_mlp_first_layer_form(e, s, lay) : 0;
+    if (form > 1) return FX_EUNSUPPORTED;
+    int tiles = e->num_cus / 3 / M;
+    if (tiles > FX_SERVE_TILES) tiles = FX_SERVE_TILES;
+    if (tiles > FX_SERVE_BYTES / (16 * s.L)) tiles = FX_SERVE_BYTES / (16 * s.L);
+    if (tiles < 1) return FX_EUNSUPPORTED;
+    SmallArgs a{};
+    a.lut = e->d_lut; a.err = e->d_err;
+    for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
+    a.M = M;
+    a.L = s.L; a.A = s.A; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4;
+    a.pair = form;
+    a.off_w1p = (int)lay.off_w1p; a.off_w1pair = (int)lay.off_w1pair; a.off_d2 = (int)lay.off_d2; a.off_d3 = (int)lay.off_d3;
+    a.off_db = (int)lay.off_db; a.off_first = (int)lay.off_first;
+    a.srv_tiles = tiles; a.min = d_in; a.mout = d_out; a.idle_ticks = idle_ticks; a.life_ticks = life_ticks;
+    *cap = 16 * tiles;
+#define FX_SMALL_CASES(KIND)                                               \
+    switch (lay.HT) {                                                      \
+        case 1: return launch_small_server<KIND, 1>(e, a, M, stream);      \
+        case 2: return launch_small_server<KIND, 2>(e, a, M, stream);      \
+        case 4: return launch_small_server<KIND, 4>(e, a, M, stream);      \
+        case 7: return launch_small_server<KIND, 7>(e, a, M, stream);      \
+        case 8: return launch_small_server<KIND, 8>(e, a, M, stream);      \
+        case 13: return launch_small_server<KIND, 13>(e, a, M, stream);    \
+        case 16: return launch_small_server<KIND, 16>(e, a, M, stream);    \
+        default: return FX_EUNSUPPORTED;                                   \
     }
     if (s.kind == FX_GE) { FX_SMALL_CASES(FX_GE) }
     FX_SMALL_CASES(FX_MLP)

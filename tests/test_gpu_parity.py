@@ -1808,3 +1808,46 @@ def test_resident_small_call_form(eng, L, alpha, M):
         ens.get_fitness(data[20])
     assert np.array_equal(ens.get_fitness(big), big_want)
     assert np.array_equal(ens.get_fitness(data[20]), want[20])
+
+
+@pytest.mark.parametrize("kind,L,alpha,H,M", [("mlp", 14, "UGCA", 100, 1), ("mlp", 8, "TGCA", 200, 3), ("ge", 14, "UGCA", 100, 2),
+                                             ("mlp", 90, s_utils.AAS, 100, 1), ("ge", 90, s_utils.AAS, 50, 8), ("mlp", 237, s_utils.AAS, 100, 2)])
+def test_resident_small_call_form_mlp_ge(eng, kind, L, alpha, H, M):
+    """The resident form of the explorer-size MLP / GlobalEpistasis kernel (`score_dense_small.hip`, SERVER): the same
+    per-tile code in a request loop, so the same bits as the launched calls, for every size the mailboxes hold (256
+    sequences, 16 KiB of sequence bytes), with a bad character and new weights in between."""
+    cls = bm.MLP if kind == "mlp" else bm.GlobalEpistasisModel
+    members = [cls(L, H, alpha, seed=s) for s in range(M)]
+    ens = flexs_amd.Ensemble(members) if M > 1 else members[0]
+    stack = flexs_amd.Ensemble(members, combine_with=lambda x: x)
+    sizes = (1, 5, 16, 17, 33, 64, 65, 100, 256, 300)
+    data = {n: rand_seqs(n, L, alpha, seed=200 + n)[1] for n in sizes}
+    eng.set_option("serve_small", 0)
+    try:
+        want = {n: ens.get_fitness(data[n]) for n in sizes}
+        want_nm = {n: stack.get_fitness(data[n]) for n in sizes}
+    finally:
+        eng.set_option("serve_small", 1)
+    served0 = eng.get_option("server_calls")
+    for rep in range(3):
+        for n in sizes:
+            assert np.array_equal(ens.get_fitness(data[n]), want[n]), (rep, n)
+            assert np.array_equal(stack.get_fitness(data[n]), want_nm[n]), (rep, n)
+    assert eng.get_option("server_calls") - served0 >= 10, "explorer-size calls did not go through the resident form"
+    assert eng.get_option("server_fallbacks") == 0
+    with pytest.raises(ValueError):
+        ens.get_fitness(data[5][:3] + ["!" * L])
+    assert np.array_equal(ens.get_fitness(data[5]), want[5])
+    w0 = members[0].model.get_weights()
+    members[0].model.set_weights([w * 0.5 for w in w0])
+    eng.set_option("serve_small", 0)
+    try:
+        want_half = ens.get_fitness(data[17])
+    finally:
+        eng.set_option("serve_small", 1)
+    for _ in range(4):
+        assert np.array_equal(ens.get_fitness(data[17]), want_half)
+    assert not np.array_equal(want_half, want[17])
+    members[0].model.set_weights(w0)
+    for _ in range(3):
+        assert np.array_equal(ens.get_fitness(data[17]), want[17])

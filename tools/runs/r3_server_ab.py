@@ -6,8 +6,11 @@ from flexs_amd import _native, synth
 from flexs_amd.baselines import models as bm
 from flexs_amd.utils import rollouts
 eng = _native.Engine.get()
-for L, alpha, M in ((8, "TGCA", 3), (14, "UGCA", 3), (8, "TGCA", 1)):
-    members = [bm.CNN(L, 32, 100, alpha, seed=m) for m in range(M)]
+AAS = "ILVAGMFYWEDQNHCRKSTP"
+for kind, L, alpha, M in (("cnn", 8, "TGCA", 3), ("cnn", 14, "UGCA", 3), ("cnn", 8, "TGCA", 1), ("mlp", 14, "UGCA", 1), ("mlp", 8, "TGCA", 3),
+                          ("ge", 14, "UGCA", 3), ("mlp", 90, AAS, 1)):
+    members = [bm.CNN(L, 32, 100, alpha, seed=m) if kind == "cnn" else bm.MLP(L, 100, alpha, seed=m) if kind == "mlp"
+               else bm.GlobalEpistasisModel(L, 100, alpha, seed=m) for m in range(M)]
     ens = flexs_amd.Ensemble(members) if M > 1 else members[0]
     natives = [m.native() for m in members]
     for n in (1, 20, 32, 96):
@@ -24,7 +27,7 @@ for L, alpha, M in ((8, "TGCA", 3), (14, "UGCA", 3), (8, "TGCA", 1)):
                 tr = []
                 for _ in range(3000):
                     t0 = time.perf_counter(); eng.score(natives, b, members[0]._lut, want_matrix=False, want_mean=True); tr.append(time.perf_counter() - t0)
-                print(f"{M}xCNN L={L} N={n} serve_small={serve} [{rep}]: get_fitness(list[str]) {np.median(ts) * 1e6:.1f} us"
+                print(f"{M}x{kind.upper()} L={L} N={n} serve_small={serve} [{rep}]: get_fitness(list[str]) {np.median(ts) * 1e6:.1f} us"
                       f"  (p90 {np.percentile(ts, 90) * 1e6:.1f}), raw fx_score {np.median(tr) * 1e6:.1f} us (p90 {np.percentile(tr, 90) * 1e6:.1f})", flush=True)
 eng.set_option("serve_small", 1)
 print("server calls / starts / fallbacks:", eng.get_option("server_calls"), eng.get_option("server_starts"), eng.get_option("server_fallbacks"))

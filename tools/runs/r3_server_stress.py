@@ -5,8 +5,11 @@ from flexs_amd import _native, synth
 from flexs_amd.baselines import models as bm
 eng = _native.Engine.get()
 rng = np.random.default_rng(0)
-for L, alpha, M in ((7, "TGCA", 8), (8, "TGCA", 3), (14, "UGCA", 16), (14, "UGCA", 3)):
-    members = [bm.CNN(L, 32, 100, alpha, seed=m) for m in range(M)]
+AAS = "ILVAGMFYWEDQNHCRKSTP"
+for kind, L, alpha, M in (("cnn", 7, "TGCA", 8), ("cnn", 8, "TGCA", 3), ("cnn", 14, "UGCA", 16), ("cnn", 14, "UGCA", 3), ("mlp", 14, "UGCA", 3),
+                          ("ge", 14, "UGCA", 8), ("mlp", 90, AAS, 2), ("ge", 90, AAS, 1)):
+    members = [bm.CNN(L, 32, 100, alpha, seed=m) if kind == "cnn" else bm.MLP(L, 100, alpha, seed=m) if kind == "mlp"
+               else bm.GlobalEpistasisModel(L, 100, alpha, seed=m) for m in range(M)]
     natives = [m.native() for m in members]
     lut = members[0]._lut
     pool = synth.random_sequence_bytes(4096, L, alpha, 5)
@@ -30,5 +33,5 @@ for L, alpha, M in ((7, "TGCA", 8), (8, "TGCA", 3), (14, "UGCA", 16), (14, "UGCA
                       f" equal to the previous answer in those slots: {stale}; previous n={prev[0] if prev else None}", flush=True)
         prev = (n, got)
         if it % 5000 == 4999 and rng.random() < 0.5: time.sleep(0.01)
-    print(f"{M}xCNN L={L}: {bad} wrong answers of 40000 in {time.time() - t0:.1f} s; server calls/starts/fallbacks",
+    print(f"{M}x{kind.upper()} L={L}: {bad} wrong answers of 40000 in {time.time() - t0:.1f} s; server calls/starts/fallbacks",
           eng.get_option("server_calls"), eng.get_option("server_starts"), eng.get_option("server_fallbacks"), flush=True)
