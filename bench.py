@@ -367,6 +367,19 @@ def end_to_end_block(device, configs=None):
             for _ in range(200):
                 t0 = time.perf_counter(); model.get_fitness(small); ts.append(time.perf_counter() - t0)
             out["small_call_N20_us"] = float(np.median(ts)) * 1e6
+            # the same call with a launch per call (serve_small = 0: the form of rounds 1-2) beside the resident form
+            eng = mods[0]._engine()
+            try:
+                eng.set_option("serve_small", 0)
+                for _ in range(20):
+                    model.get_fitness(small)
+                ts = []
+                for _ in range(200):
+                    t0 = time.perf_counter(); model.get_fitness(small); ts.append(time.perf_counter() - t0)
+                out["small_call_N20_us_launch_per_call"] = float(np.median(ts)) * 1e6
+            finally:
+                eng.set_option("serve_small", 1)
+            out["small_call_resident_requests"] = int(eng.get_option("server_calls"))
         del model, mods, seqs
     out["list_str"] = out["C2 3xCNN L=8 list_str"]          # (round-2 key, kept)
     out["what"] = ("get_fitness on host strings -> host float32 array, median wall time, marshalling + PCIe inclusive; "

@@ -210,8 +210,7 @@ int fx_engine_destroy(fx_engine* e) {
     if (e->server.h_out) {
         e->server.running = true;                          // (whatever the bookkeeping says: tell them)
         fx_server_stop(e);
-        (void)hipStreamSynchronize(e->server.stream);
-        (void)hipStreamDestroy(e->server.stream);
+        for (hipStream_t st : e->server.streams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
         (void)hipHostFree((void*)e->server.h_out);
         (void)hipFree(e->server.in);
         e->server.h_out = nullptr;
@@ -297,6 +296,7 @@ int fx_engine_set_option(fx_engine* e, const char* key, int64_t value) {
     int64_t* s = option_slot(e, key);
     if (!s) return fx_fail(e, FX_EINVAL, std::string("unknown option ") + (key ? key : "(null)"));
     *s = value;
+    e->server.refused.clear();                             // (what has a resident form depends on the form selectors)
     return FX_OK;
 }
 int fx_engine_get_option(fx_engine* e, const char* key, int64_t* value) {
@@ -306,6 +306,7 @@ int fx_engine_get_option(fx_engine* e, const char* key, int64_t* value) {
     if (e && key && !std::strcmp(key, "server_calls")) { *value = e->server.served; return FX_OK; }
     if (e && key && !std::strcmp(key, "server_starts")) { *value = e->server.started; return FX_OK; }
     if (e && key && !std::strcmp(key, "server_fallbacks")) { *value = e->server.fallbacks; return FX_OK; }
+    if (e && key && !std::strcmp(key, "server_last_fallback")) { *value = e->server.fb_info; return FX_OK; }   // reason (1 left, 2 timed out) | member | sequence | waited us
     if (e && key && !std::strcmp(key, "server_resident")) { *value = e->server.running ? 1 : 0; return FX_OK; }
     int64_t* s = option_slot(e, key);
     if (!s) return fx_fail(e, FX_EINVAL, std::string("unknown option ") + (key ? key : "(null)"));
@@ -370,6 +371,17 @@ int fx_model_create(fx_engine* e, int kind, int L, int A, int F, int H, int K, f
 int fx_model_destroy(fx_model* m) {
     if (!m) return FX_OK;
     (void)hipSetDevice(m->eng->device);
+    {
+        // resident workgroups may read this model's weights: tell them to leave, wait for them; forget what was remembered about it
+        auto& sv = m->eng->server;
+        if (std::find(sv.models.begin(), sv.models.end(), m) != sv.models.end()) {
+            fx_server_stop(m->eng);
+            for (int g = 0; g < sv.groups; ++g) (void)hipStreamSynchronize(sv.streams[g]);
+            sv.models.clear();
+        }
+        sv.pending.clear();
+        sv.refused.clear();
+    }
     (void)hipStreamSynchronize(m->eng->stream);
     if (m->d_blob) (void)hipFree(m->d_blob);
     if (m->d_packed) (void)hipFree(m->d_packed);
@@ -393,7 +405,7 @@ int fx_model_set_weights(fx_model* m, const float* blob, int64_t n) {
     m->version += 1;
     if (e->server.running) {
         fx_server_stop(e);
-        FX_HIP(e, hipStreamSynchronize(e->server.stream));
+        for (int g = 0; g < e->server.groups; ++g) FX_HIP(e, hipStreamSynchronize(e->server.streams[g]));
     }
     FX_HIP(e, hipStreamSynchronize(e->stream));
     FX_HIP(e, hipMemcpy(m->d_blob, m->blob.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
@@ -593,21 +605,60 @@ static int server_start(fx_engine* e, fx_model* const* models, int M, int L, con
         sv.h_out = new (p) FxMailOut();
         FX_HIP(e, hipHostGetDevicePointer(reinterpret_cast<void**>(&sv.d_out), sv.h_out, 0));
         FX_HIP(e, hipExtMallocWithFlags(reinterpret_cast<void**>(&sv.in), sizeof(FxMailIn), hipDeviceMallocFinegrained));
-        FX_HIP(e, hipStreamCreateWithFlags(&sv.stream, hipStreamNonBlocking));
     }
-    FX_HIP(e, hipStreamSynchronize(sv.stream));            // a previous generation has left (it was told to, or timed out)
+    for (int g = 0; g < sv.groups; ++g) FX_HIP(e, hipStreamSynchronize(sv.streams[g]));   // a previous generation has left (it was told to, or timed out)
     std::memset((void*)sv.h_out->alive, 0, sizeof(sv.h_out->alive));   // (answers carry sequence numbers that never repeat: no need to clear them)
     sv.in->req = 0; sv.in->stop = 0;                       // (through the BAR, like every host access to it; posted before the launch's doorbell)
     fx_bar_fence();
     int rc = fx_upload_lut(e, lut);
     if (rc) return rc;
     FX_HIP(e, hipStreamSynchronize(e->stream));            // the LUT (and any weight upload) must have landed before the workgroups read them
-    int cap = 0;
+    // one workgroup per (member, 16-sequence tile slot), a third of the chip at most
+    int tiles = e->num_cus / 3 / M;
+    if (tiles > FX_SERVE_TILES) tiles = FX_SERVE_TILES;
+    if (tiles > FX_SERVE_BYTES / (16 * L)) tiles = FX_SERVE_BYTES / (16 * L);
+    if (tiles < 1) return FX_EUNSUPPORTED;
+    const int cap = 16 * tiles;
     // a host that stops asking (or dies) frees the CUs by itself: after 2 x serve_idle_us (100 MHz ticks), and 10 s whatever happens
     const unsigned long long idle = (unsigned long long)e->serve_idle_us * 200ull, life = 1000000000ull;
-    rc = fx_launch_score_cnn_quad_server(e, models, M, sv.stream, sv.in, sv.d_out, idle, life, &cap);
-    if (rc == FX_EUNSUPPORTED) rc = fx_launch_score_dense_small_server(e, models, M, sv.stream, sv.in, sv.d_out, idle, life, &cap);
-    if (rc) return rc;
+    // consecutive like members form a group; every group is its own resident launch on its own stream (all read the same
+    // request and answer into their members' rows), so a mixed ensemble -- DyNA-PPO's GE + MLP + CNN -- is served too
+    auto group_len = [&](int m0) {
+        int cnt = 1;
+        const FxShape& s0 = models[m0]->shape;
+        while (m0 + cnt < M) {
+            const FxShape& s = models[m0 + cnt]->shape;
+            if (s.kind != s0.kind || s.F != s0.F || s.H != s0.H || s.K != s0.K) break;
+            ++cnt;
+        }
+        return cnt;
+    };
+    // streams first (creating one takes milliseconds the first time; a group already launched would idle out meanwhile)
+    int want_streams = 0;
+    for (int m0 = 0; m0 < M; m0 += group_len(m0)) ++want_streams;
+    while ((int)sv.streams.size() < want_streams) {
+        // highest priority: the runtime keeps separate hardware queues per priority level, so a resident launch does not
+        // sit in front of work that normal-priority streams (the engine's, PyTorch's) submit to a shared hardware queue
+        hipStream_t st = nullptr;
+        int prio_low = 0, prio_high = 0;
+        FX_HIP(e, hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+        FX_HIP(e, hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_high));
+        sv.streams.push_back(st);
+    }
+    sv.groups = 0;
+    for (int m0 = 0; m0 < M;) {
+        const int cnt = group_len(m0);
+        hipStream_t st = sv.streams[sv.groups];
+        sv.groups += 1;
+        rc = fx_launch_score_cnn_quad_server(e, models + m0, cnt, m0, tiles, st, sv.in, sv.d_out, idle, life);
+        if (rc == FX_EUNSUPPORTED) rc = fx_launch_score_dense_small_server(e, models + m0, cnt, m0, tiles, st, sv.in, sv.d_out, idle, life);
+        if (rc) {                                          // a member without a resident form: the groups already started leave again
+            sv.in->stop = 1;
+            fx_bar_fence();
+            return rc;
+        }
+        m0 += cnt;
+    }
     sv.models.assign(models, models + M);
     sv.versions.clear();
     for (int m = 0; m < M; ++m) sv.versions.push_back(models[m]->version);
@@ -627,6 +678,8 @@ static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8
     bool same = sv.running && (int)sv.models.size() == M && sv.L == L && std::memcmp(sv.lut, lut, 256) == 0;
     for (int m = 0; same && m < M; ++m) same = sv.models[m] == models[m] && sv.versions[m] == models[m]->version;
     if (sv.running && !same) server_stop(e);
+    if (!sv.running && (int)sv.refused.size() == M && sv.refused_L == L && std::equal(sv.refused.begin(), sv.refused.end(), models))
+        return FX_EUNSUPPORTED;                            // (an ensemble with a member that has no resident form: asked once)
     if (sv.running) {
         if (N > sv.cap) return FX_EUNSUPPORTED;
         // the workgroups leave 2 x serve_idle_us after their last request: do not post to a generation that may be on its way out
@@ -648,7 +701,11 @@ static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8
         sv.t_pending = now;
         if (!again) { sv.pending.assign(models, models + M); return FX_EUNSUPPORTED; }
         const int rc = server_start(e, models, M, L, lut);
-        if (rc) { sv.pending.clear(); return FX_EUNSUPPORTED; }
+        if (rc) {
+            sv.pending.clear();
+            if (rc == FX_EUNSUPPORTED) { sv.refused.assign(models, models + M); sv.refused_L = L; }
+            return FX_EUNSUPPORTED;
+        }
         if (N > sv.cap) return FX_EUNSUPPORTED;
     }
     // request: bytes, fence, request word, fence (write-combining stores may pass each other otherwise)
@@ -660,7 +717,9 @@ static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8
     fx_bar_fence();
     const auto t0 = std::chrono::steady_clock::now();
     sv.t_post = t0;
-    const double limit = sv.fresh ? 0.2 : 0.002;           // (the first request also waits for launch + weight fill)
+    // (the first request of a generation also waits for the launch and the weight fill -- and the very first one of the
+    //  process for the runtime to create the high-priority hardware queue and load the kernels: ~0.3 s, once)
+    const double limit = sv.fresh ? 3.0 : 0.002;
     const FxMailOut* h = sv.h_out;
     bool bad = false;
     float x[FX_MAX_M];
@@ -671,9 +730,11 @@ static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8
             while ((((a = h->ans[m][n]) >> 32) & 0x7FFFFFFFull) != seq) {
                 if ((++spins & 1023u) == 0) {
                     const bool gone = !sv.fresh && !h->alive[m][n >> 4];
-                    if (gone || std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+                    const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    if (gone || waited > limit) {
                         server_stop(e);                    // fall back to a launch; the next calls start a new generation
                         sv.fallbacks += 1;
+                        sv.fb_info = (gone ? 1000000000ll : 2000000000ll) + (int64_t)m * 10000000 + n * 10000 + (int64_t)std::min(waited * 1e6, 9999.0);
                         return FX_EUNSUPPORTED;
                     }
                 }

@@ -172,7 +172,8 @@ struct fx_engine {
         FxMailIn* in = nullptr;                          // device memory; also the host's (write-only) view through the BAR
         FxMailOut* h_out = nullptr;                      // pinned host memory, and the device's view of it
         FxMailOut* d_out = nullptr;
-        hipStream_t stream = nullptr;
+        std::vector<hipStream_t> streams;               // one per group of like members (each group is its own resident launch)
+        int groups = 0;
         bool running = false, fresh = false;
         std::chrono::steady_clock::time_point t_start, t_post;   // generation start, last request
         unsigned long long seq = 0;
@@ -180,9 +181,11 @@ struct fx_engine {
         std::vector<uint64_t> versions;
         uint8_t lut[256] = {};
         int L = 0, cap = 0;
+        std::vector<fx_model*> refused;                  // the last ensemble that has a member without a resident form
+        int refused_L = 0;
         std::vector<fx_model*> pending;                  // the last eligible call's ensemble, and when it came
         std::chrono::steady_clock::time_point t_pending;
-        int64_t served = 0, started = 0, fallbacks = 0;
+        int64_t served = 0, started = 0, fallbacks = 0, fb_info = 0;
     } server;
     bool large_bar = false;     // the host can store into device memory (the resident form needs it)
     int64_t serve_idle_us = 500;   // calls of the same ensemble closer than this start / keep the resident workgroups; they leave after twice this long without a request (a device-wide synchronize waits that long for them at most)
@@ -294,10 +297,10 @@ inline void fx_server_stop(fx_engine* e) {
     fx_bar_fence();
     sv.running = false;
 }
-int fx_launch_score_cnn_quad_server(fx_engine* e, fx_model* const* models, int M, hipStream_t stream, FxMailIn* d_in, FxMailOut* d_out,
-                                    unsigned long long idle_ticks, unsigned long long life_ticks, int* cap);
-int fx_launch_score_dense_small_server(fx_engine* e, fx_model* const* models, int M, hipStream_t stream, FxMailIn* d_in, FxMailOut* d_out,
-                                       unsigned long long idle_ticks, unsigned long long life_ticks, int* cap);
+int fx_launch_score_cnn_quad_server(fx_engine* e, fx_model* const* models, int M, int m_off, int tiles, hipStream_t stream,
+                                    FxMailIn* d_in, FxMailOut* d_out, unsigned long long idle_ticks, unsigned long long life_ticks);
+int fx_launch_score_dense_small_server(fx_engine* e, fx_model* const* models, int M, int m_off, int tiles, hipStream_t stream,
+                                       FxMailIn* d_in, FxMailOut* d_out, unsigned long long idle_ticks, unsigned long long life_ticks);
 int fx_launch_score_cnn_pair(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii,
                              int64_t N, float* d_out_NM, int Mtot, int m_off);
 // small launches of the MLP: a tile's output tiles dealt to the waves of a workgroup (score_dense_small.hip)

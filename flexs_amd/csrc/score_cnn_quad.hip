@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
             __syncthreads();
             if (tid == 0) {
                 srv_start = srv_seen = wall_clock64();
-                __hip_atomic_store(const_cast<unsigned*>(&p.mout->alive[m][srv_slot]), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(const_cast<unsigned*>(&p.mout->alive[p.m_off + m][srv_slot]), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
       for (;;) {                                                     // (SERVER: one iteration per request)
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
                     r = __hip_atomic_load(&p.min->req, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
                     if (r != srv_last) break;
                     const unsigned long long now = wall_clock64();
-                    if (__hip_atomic_load(&p.min->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) || now - srv_seen > p.idle_ticks ||
+                    if (__hip_atomic_load(&p.min->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) || now - srv_seen > (srv_last ? p.idle_ticks : 64 * p.idle_ticks) ||   /* (a generation waits longer for its first request) */
                         now - srv_start > p.life_ticks) { ex = 1; break; }
                 }
                 srv_req = r; srv_exit = ex; srv_bad = 0;
@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
                     // (score, tag) in one 8-byte store to host memory; the fence pushes the lines out of this XCD's L2
                     const unsigned tag = (unsigned)(srv_req >> 16) | (srv_bad ? 0x80000000u : 0u);
                     if (g == 0 && n < Ncur)
-                        __hip_atomic_store(const_cast<unsigned long long*>(&p.mout->ans[m][n]),
+                        __hip_atomic_store(const_cast<unsigned long long*>(&p.mout->ans[p.m_off + m][n]),
                                            ((unsigned long long)tag << 32) | __float_as_uint(fx_nan_to_num(y[0])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     __threadfence_system();
                 } else {
@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
         }
       }
         if constexpr (SERVER) {
-            if (tid == 0) __hip_atomic_store(const_cast<unsigned*>(&p.mout->alive[m][srv_slot]), 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (tid == 0) __hip_atomic_store(const_cast<unsigned*>(&p.mout->alive[p.m_off + m][srv_slot]), 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     fx_stamp(p.trace, 6);
@@ -469,8 +469,8 @@ int launch_server(fx_engine* e, QuadArgs a, int M, hipStream_t stream) {
 // Canonical shapes only (what the explorers' surrogates are built with: kernel size 5, 32 filters, 97-112 hidden units,
 // 4-letter alphabet, seq_len <= 16).  One workgroup (one quad) per member and tile slot: a request of N sequences is
 // answered by M x ceil(N / 16) of them, each on its own CU; at most ~a third of the chip stays resident.
-int fx_launch_score_cnn_quad_server(fx_engine* e, fx_model* const* models, int M, hipStream_t stream, FxMailIn* d_in, FxMailOut* d_out,
-                                    unsigned long long idle_ticks, unsigned long long life_ticks, int* cap) {
+int fx_launch_score_cnn_quad_server(fx_engine* e, fx_model* const* models, int M, int m_off, int tiles, hipStream_t stream,
+                                    FxMailIn* d_in, FxMailOut* d_out, unsigned long long idle_ticks, unsigned long long life_ticks) {
     const FxShape& s = models[0]->shape;
     const FxPackLayout& lay = models[0]->layout;
     const int L1 = s.L - s.K + 1;
@@ -489,11 +489,7 @@ int fx_launch_score_cnn_quad_server(fx_engine* e, fx_model* const* models, int M
     a.off_c2 = (int)lay.off_c2; a.off_c3 = (int)lay.off_c3; a.off_cb = (int)lay.off_cb; a.off_w1p = (int)lay.off_w1p;
     a.off_d1 = (int)lay.off_d1; a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
     a.min = d_in; a.mout = d_out; a.idle_ticks = idle_ticks; a.life_ticks = life_ticks;
-    int tiles = e->num_cus / 3 / M;
-    if (tiles > FX_SERVE_TILES) tiles = FX_SERVE_TILES;
-    if (tiles < 1) return FX_EUNSUPPORTED;
-    a.srv_tiles = tiles;
-    *cap = 16 * tiles;
+    a.srv_tiles = tiles; a.m_off = m_off;
     if (L1 == 4) return launch_server<1, 8, 4>(e, a, M, stream);
     if (L1 < 4) return launch_server<1, 8, 0>(e, a, M, stream);
     return launch_server<1, 24, 0>(e, a, M, stream);

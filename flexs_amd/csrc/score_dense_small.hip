@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(SW * 64) k_score_dense_small(SmallArgs p) {
         __syncthreads();
         if (tid == 0) {
             srv_start = srv_seen = wall_clock64();
-            __hip_atomic_store(const_cast<unsigned*>(&p.mout->alive[m][tg]), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(const_cast<unsigned*>(&p.mout->alive[p.m_off + m][tg]), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
   for (;;) {                                               // (SERVER: one iteration per request)
@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(SW * 64) k_score_dense_small(SmallArgs p) {
                 r = __hip_atomic_load(&p.min->req, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (r != srv_last) break;
                 const unsigned long long now = wall_clock64();
-                if (__hip_atomic_load(&p.min->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) || now - srv_seen > p.idle_ticks ||
+                if (__hip_atomic_load(&p.min->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) || now - srv_seen > (srv_last ? p.idle_ticks : 64 * p.idle_ticks) ||   /* (a generation waits longer for its first request) */
                     now - srv_start > p.life_ticks) { ex = 1; break; }
             }
             srv_req = r; srv_exit = ex; srv_bad = 0;
@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(SW * 64) k_score_dense_small(SmallArgs p) {
             // (score, tag) in one 8-byte store to host memory; the fence pushes the lines out of this XCD's L2
             const unsigned tag = (unsigned)(srv_req >> 16) | (srv_bad ? 0x80000000u : 0u);
             if (g == 0 && n < Ncur)
-                __hip_atomic_store(const_cast<unsigned long long*>(&p.mout->ans[m][n]),
+                __hip_atomic_store(const_cast<unsigned long long*>(&p.mout->ans[p.m_off + m][n]),
                                    ((unsigned long long)tag << 32) | __float_as_uint(fx_nan_to_num(y[0])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __threadfence_system();
         } else {
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(SW * 64) k_score_dense_small(SmallArgs p) {
     }
   }
     if constexpr (SERVER) {
-        if (tid == 0) __hip_atomic_store(const_cast<unsigned*>(&p.mout->alive[m][tg]), 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid == 0) __hip_atomic_store(const_cast<unsigned*>(&p.mout->alive[p.m_off + m][tg]), 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -360,8 +360,8 @@ int fx_launch_score_mlp_small(fx_engine* e, fx_model* const* models, int M, cons
 
 // The resident form (see fx_launch_score_cnn_quad_server): one workgroup per member and tile slot, weights read from L2 at
 // every request as the launched form does (nothing to fill), so a request costs the mailbox round trip + the tile.
-int fx_launch_score_dense_small_server(fx_engine* e, fx_model* const* models, int M, hipStream_t stream, FxMailIn* d_in, FxMailOut* d_out,
-                                       unsigned long long idle_ticks, unsigned long long life_ticks, int* cap) {
+int fx_launch_score_dense_small_server(fx_engine* e, fx_model* const* models, int M, int m_off, int tiles, hipStream_t stream,
+                                       FxMailIn* d_in, FxMailOut* d_out, unsigned long long idle_ticks, unsigned long long life_ticks) {
     const FxShape& s = models[0]->shape;
     const FxPackLayout& lay = models[0]->layout;
     if (!e->dense_small || (s.kind != FX_MLP && s.kind != FX_GE) || M > FX_MAX_M || M < 1 || s.A > 127) return FX_EUNSUPPORTED;
@@ -371,20 +371,15 @@ int fx_launch_score_dense_small_server(fx_engine* e, fx_model* const* models, in
     }
     const int form = s.kind == FX_MLP ? fx_mlp_first_layer_form(e, s, lay) : 0;
     if (form > 1) return FX_EUNSUPPORTED;
-    int tiles = e->num_cus / 3 / M;
-    if (tiles > FX_SERVE_TILES) tiles = FX_SERVE_TILES;
-    if (tiles > FX_SERVE_BYTES / (16 * s.L)) tiles = FX_SERVE_BYTES / (16 * s.L);
-    if (tiles < 1) return FX_EUNSUPPORTED;
     SmallArgs a{};
     a.lut = e->d_lut; a.err = e->d_err;
     for (int m = 0; m < M; ++m) a.w[m] = models[m]->d_packed;
-    a.M = M;
+    a.M = M; a.m_off = m_off;
     a.L = s.L; a.A = s.A; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4;
     a.pair = form;
     a.off_w1p = (int)lay.off_w1p; a.off_w1pair = (int)lay.off_w1pair; a.off_d2 = (int)lay.off_d2; a.off_d3 = (int)lay.off_d3;
     a.off_db = (int)lay.off_db; a.off_first = (int)lay.off_first;
     a.srv_tiles = tiles; a.min = d_in; a.mout = d_out; a.idle_ticks = idle_ticks; a.life_ticks = life_ticks;
-    *cap = 16 * tiles;
 #define FX_SMALL_CASES(KIND)                                               \
     switch (lay.HT) {                                                      \
         case 1: return launch_small_server<KIND, 1>(e, a, M, stream);      \

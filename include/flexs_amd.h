@@ -97,10 +97,11 @@ const char *fx_last_error(fx_engine *e);
  *                              host memory directly (explorer-size calls: no copy enqueues).
  *   zero_copy_mode    -1       larger host calls: -1 = decide per call (fx_plan_host_call), 0 = always copy,
  *                              1 = always zero-copy.
- *   serve_small       1        1 = explorer-size fx_score calls (<= 256 sequences, seq_len <= 16) of a canonical 4-letter
- *                              CNN ensemble are answered by workgroups that STAY on the device between calls (weights
- *                              in LDS, request and answer through mailboxes; no launch): 28 -> 11 us per call, same
- *                              bits.  They start when the same ensemble calls twice within serve_idle_us and occupy
+ *   serve_small       1        1 = explorer-size fx_score calls (<= 256 sequences, <= 16 KiB of sequence bytes) of
+ *                              canonical 4-letter CNNs (seq_len <= 16), MLPs and GlobalEpistasis models -- one model,
+ *                              an ensemble, or a mix -- are answered by workgroups that STAY on the device between
+ *                              calls (request and answer through mailboxes; no launch): 28 -> 11 us per call, same
+ *                              bits.  They start when the same model list calls twice within serve_idle_us and occupy
  *                              members x ceil(cap / 16) <= num_cus / 3 CUs while resident; new weights, training, a
  *                              launch that fills the chip, or engine destruction tell them to leave.  Needs a large
  *                              BAR (the host stores the request into device memory); 0 = a launch per call.

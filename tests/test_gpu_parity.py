@@ -1851,3 +1851,62 @@ def test_resident_small_call_form_mlp_ge(eng, kind, L, alpha, H, M):
     members[0].model.set_weights(w0)
     for _ in range(3):
         assert np.array_equal(ens.get_fitness(data[17]), want[17])
+
+
+def test_resident_small_call_form_mixed_ensemble(eng):
+    """DyNA-PPO's default ensemble (dyna_ppo.py:53-55: GlobalEpistasis(100) + MLP(200) + CNN(32, 100)) and other mixed
+    member lists: every group of like members is its own resident launch, all answer the same request.  Same bits as the
+    launched calls; an ensemble with a member that has no resident form (a CNN on a 20-letter alphabet) keeps launching."""
+    L, alpha = 14, "UGCA"
+    lists = {
+        "dyna_ppo": [bm.GlobalEpistasisModel(L, 100, alpha, seed=1), bm.MLP(L, 200, alpha, seed=2), bm.CNN(L, 32, 100, alpha, seed=3)],
+        "cnn_mlp_cnn_cnn": [bm.CNN(L, 32, 100, alpha, seed=4), bm.MLP(L, 100, alpha, seed=5), bm.CNN(L, 32, 100, alpha, seed=6),
+                            bm.CNN(L, 32, 100, alpha, seed=7)],
+        "two_mlp_sizes": [bm.MLP(L, 100, alpha, seed=8), bm.MLP(L, 50, alpha, seed=9), bm.MLP(L, 50, alpha, seed=10)],
+    }
+    sizes = (1, 7, 16, 20, 33, 100, 256)
+    data = {n: rand_seqs(n, L, alpha, seed=300 + n)[1] for n in sizes}
+    for name, members in lists.items():
+        ens = flexs_amd.Ensemble(members)
+        stack = flexs_amd.Ensemble(members, combine_with=lambda x: x)
+        eng.set_option("serve_small", 0)
+        try:
+            want = {n: ens.get_fitness(data[n]) for n in sizes}
+            want_nm = {n: stack.get_fitness(data[n]) for n in sizes}
+        finally:
+            eng.set_option("serve_small", 1)
+        served0 = eng.get_option("server_calls")
+        for rep in range(3):
+            for n in sizes:
+                assert np.array_equal(ens.get_fitness(data[n]), want[n]), (name, rep, n)
+                assert np.array_equal(stack.get_fitness(data[n]), want_nm[n]), (name, rep, n)
+        assert eng.get_option("server_calls") - served0 >= 30, name
+        assert eng.get_option("server_fallbacks") == 0
+        with pytest.raises(ValueError):
+            ens.get_fitness(data[7][:3] + ["!" * L])
+        assert np.array_equal(ens.get_fitness(data[7]), want[7])
+    ppo = bm.DynaPPOEnsemble(L, alpha)
+    ppo.r_squared_vals = np.array([0.9, 0.8, 0.7])
+    eng.set_option("serve_small", 0)
+    try:
+        want = ppo.get_fitness(data[7])
+    finally:
+        eng.set_option("serve_small", 1)
+    served0 = eng.get_option("server_calls")
+    for _ in range(5):
+        assert np.array_equal(ppo.get_fitness(data[7]), want)
+    assert eng.get_option("server_calls") - served0 >= 3
+    # a member without a resident form: refused once, launched from then on, same results
+    La = 12
+    mixed = [bm.MLP(La, 100, s_utils.AAS, seed=1), bm.CNN(La, 32, 100, s_utils.AAS, seed=2)]
+    ens = flexs_amd.Ensemble(mixed)
+    seqs = rand_seqs(20, La, s_utils.AAS, seed=5)[1]
+    eng.set_option("serve_small", 0)
+    try:
+        want = ens.get_fitness(seqs)
+    finally:
+        eng.set_option("serve_small", 1)
+    served0, starts0 = eng.get_option("server_calls"), eng.get_option("server_starts")
+    for _ in range(6):
+        assert np.array_equal(ens.get_fitness(seqs), want)
+    assert eng.get_option("server_calls") == served0 and eng.get_option("server_starts") == starts0
