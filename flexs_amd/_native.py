@@ -251,6 +251,41 @@ CHUNKED_MIN_ROWS = int(os.environ.get("FLEXS_AMD_CHUNKED_MIN_ROWS", 32768))   # 
 CHUNK_BYTES = int(os.environ.get("FLEXS_AMD_CHUNK_BYTES", 0))   # target bytes per piece (0 = auto, see score_strings)
 
 
+# ---- explorer-size calls: one C call packs the strings and runs fx_score (csrc/strpack.c score_small) -------------------
+SMALL_CALL_ROWS = 256            # what the engine's resident form answers (FX_SERVE_CAP)
+SMALL_CALL_BYTES = 16384
+_HAS_SCORE_SMALL = _strpack is not None and hasattr(_strpack, "score_small")
+
+
+def small_plan(engine: "Engine", models: Sequence["NativeModel"], L: int, lut: np.ndarray, want_mean: bool) -> Optional[bytes]:
+    """The argument block of `score_small` for one model list (struct SmallPlan in csrc/strpack.c); build once, reuse
+    while the fx_model handles stay the same objects.  None when the helper is not built or the list does not fit."""
+    import struct
+
+    M = len(models)
+    if not _HAS_SCORE_SMALL or not 1 <= M <= 16 or L < 1 or L > SMALL_CALL_BYTES:
+        return None
+    fn = C.cast(engine._lib.fx_score, C.c_void_p).value
+    handles = [int(m.handle.value if hasattr(m.handle, "value") else m.handle) for m in models] + [0] * (16 - M)
+    eh = engine.handle
+    return struct.pack("PPqqq16P256s", fn, int(eh.value if hasattr(eh, "value") else eh), M, L, 2 if want_mean else 1,
+                       *handles, np.ascontiguousarray(lut, np.uint8).tobytes())
+
+
+def score_small(engine: "Engine", plan: bytes, seqs, M: int, want_mean: bool) -> Optional[np.ndarray]:
+    """get_fitness of a short list / tuple of str in one C call.  Returns the (N,) mean or the (N, M) matrix, or None
+    when the call is not for this path (too big, not strings, ragged ...): the caller then takes the general path, which
+    raises what the reference raises."""
+    n = len(seqs)
+    out = np.empty(n if want_mean else (n, M), np.float32)
+    st = _strpack.score_small(plan, seqs, out)
+    if st == 0:
+        return out
+    if st == -1 or 1000 < st < 2000:
+        return None
+    _raise(-(st - 2000) if st > 2000 else st, engine.handle)
+
+
 def wants_chunked(sequences, L: int) -> bool:
     return (_strpack is not None and isinstance(sequences, (list, tuple)) and len(sequences) >= CHUNKED_MIN_ROWS
             and isinstance(sequences[0], str) and len(sequences[0]) == L)

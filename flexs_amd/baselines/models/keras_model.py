@@ -105,12 +105,14 @@ class KerasModel(flexs_amd.Model):
         self._lut = _native.make_lut(alphabet)
         self._native_model = None
         self._native_version = None
+        self._small = None
 
     # ------------------------------------------------------------------ copy / pickle: device handles stay behind
     def __getstate__(self):
         state = self.__dict__.copy()
         state["_native_model"] = None          # the copy uploads its weights to its own fx_model on first use
         state["_native_version"] = None
+        state["_small"] = None
         return state
 
     # ------------------------------------------------------------------ engine plumbing
@@ -146,6 +148,16 @@ class KerasModel(flexs_amd.Model):
     def _fitness_function(self, sequences):
         """keras_model.py:69-79: encode -> float32 tensor -> predict -> squeeze ->
         nan_to_num, fused on the GPU.  Returns float32 (N,)."""
+        if type(sequences) in (list, tuple) and 0 < len(sequences) <= _native.SMALL_CALL_ROWS and _native._HAS_SCORE_SMALL:
+            # explorer-size call: string packing + fx_score in one C call on a cached argument block
+            nat = self.native()
+            c = self._small
+            if c is None or c[0] is not nat:
+                c = self._small = (nat, _native.small_plan(self._engine(), [nat], self.model.L, self._lut, False) or b"")
+            if c[1]:
+                out = _native.score_small(self._engine(), c[1], sequences, 1, False)    # (N, 1)
+                if out is not None:
+                    return out.reshape(len(sequences))
         if _native.wants_chunked(sequences, self.model.L):
             nm, _ = self._engine().score_strings([self.native()], sequences, self.model.L, self._lut, want_matrix=True)
             return nm[:, 0]

@@ -190,6 +190,54 @@ static PyObject* pack(PyObject* self, PyObject* args) {
     return PyLong_FromLong(status);
 }
 
+/* ---- explorer-size calls: pack + fx_score in one C call ------------------------------------------------------------
+ * A 20-sequence get_fitness is ~11 us inside fx_score (resident form) and used to spend another ~5 us in Python glue
+ * around it (NumPy staging array, ctypes argument conversion).  score_small(plan, seqs, out) packs the strings into a
+ * stack buffer and calls fx_score through the function pointer the plan carries.  The plan is built once per model list
+ * by flexs_amd/_native.py (struct layout below); this module does not link against libflexs_amd.so. */
+typedef int (*fx_score_fn)(void* e, void* const* models, int M, const unsigned char* ascii, long long N, int L,
+                           const unsigned char* lut, float* out_NM, float* out_mean);
+typedef struct {
+    void* fn;                  /* fx_score */
+    void* engine;
+    long long M, L, want;      /* want: 1 = (N, M) matrix, 2 = mean */
+    void* models[16];
+    unsigned char lut[256];
+} SmallPlan;
+#define SMALL_MAX_BYTES 16384
+
+static PyObject* score_small(PyObject* self, PyObject* args) {
+    Py_buffer plan, out;
+    PyObject* seqs;
+    (void)self;
+    if (!PyArg_ParseTuple(args, "y*Ow*", &plan, &seqs, &out)) return NULL;
+    long status = -1;                                      /* -1: not for this path (the caller takes the general one) */
+    if (plan.len == (Py_ssize_t)sizeof(SmallPlan) && (PyList_Check(seqs) || PyTuple_Check(seqs))) {
+        const SmallPlan* p = (const SmallPlan*)plan.buf;
+        const Py_ssize_t n = PySequence_Fast_GET_SIZE(seqs);
+        const Py_ssize_t need = (p->want == 1 ? n * p->M : n) * (Py_ssize_t)sizeof(float);
+        if (n > 0 && n * p->L <= SMALL_MAX_BYTES && out.len >= need && p->M >= 1 && p->M <= 16) {
+            unsigned char buf[SMALL_MAX_BYTES];
+            const int st = pack_range(PySequence_Fast_ITEMS(seqs), buf, n, (Py_ssize_t)p->L, 1);
+            if (st) {
+                status = 1000 + st;                        /* 1001 ragged, 1002 non-latin-1, 1003 not a str */
+            } else {
+                int rc;
+                float* o = (float*)out.buf;
+                Py_BEGIN_ALLOW_THREADS
+                rc = ((fx_score_fn)p->fn)(p->engine, (void* const*)p->models, (int)p->M, buf, (long long)n, (int)p->L, p->lut,
+                                          p->want == 1 ? o : NULL, p->want == 1 ? NULL : o);
+                Py_END_ALLOW_THREADS
+                status = rc;                               /* 0 or an FX_E* code (negative codes are mapped by the caller) */
+                if (rc < 0) status = 2000 - rc;
+            }
+        }
+    }
+    PyBuffer_Release(&plan);
+    PyBuffer_Release(&out);
+    return PyLong_FromLong(status);
+}
+
 static PyObject* set_threads(PyObject* self, PyObject* args) {
     int n;
     if (!PyArg_ParseTuple(args, "i", &n)) return NULL;
@@ -202,6 +250,7 @@ static PyObject* set_threads(PyObject* self, PyObject* args) {
 
 static PyMethodDef methods[] = {
     {"pack", pack, METH_VARARGS, "pack(seqs, L, out[, start, count]) -> status (0 ok, 1 ragged, 2 non-latin-1 character, 3 not a str)"},
+    {"score_small", score_small, METH_VARARGS, "score_small(plan, seqs, out) -> 0 ok, -1 not applicable, 1001..1003 packing status, FX error code (2000 + |code| if negative)"},
     {"set_threads", set_threads, METH_VARARGS, "set_threads(n) -> previous setting; 0 = auto (min(8, cores / 2)), 1 = single-threaded"},
     {NULL, NULL, 0, NULL}};
 

@@ -79,7 +79,47 @@ class Ensemble(_EnsembleBase):
         seeds = None if seed is None else [seed + k for k in range(len(self.models))]
         train_members(self.models, sequences, labels, seeds)
 
+    _small = None                                          # explorer-size fast path: (members, fx_models, {want_mean: plan})
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop("_small", None)                           # device handles stay behind (as in KerasModel.__getstate__)
+        return state
+
+    def _score_small(self, sequences):
+        """Calls of up to 256 strings: string packing + fx_score in ONE C call (csrc/strpack.c score_small) on an
+        argument block cached per member list.  None = not for this path (the general one below decides and raises)."""
+        models = self.models
+        c = self._small
+        if c is None or len(c[0]) != len(models) or any(a is not b for a, b in zip(c[0], models)):
+            c = self._small = (list(models), None, {}) if not _device_members(models) else (list(models), [], {})
+        if c[1] is None:
+            return None
+        natives = [m.native() for m in models]              # (uploads a member's new weights)
+        if len(natives) != len(c[1]) or any(a is not b for a, b in zip(natives, c[1])):
+            c = self._small = (c[0], natives, {})
+        want_mean = self.combine_with is _default_combine
+        plan = c[2].get(want_mean)
+        m0 = models[0]
+        if plan is None:
+            plan = c[2][want_mean] = _native.small_plan(m0._engine(), natives, m0.model.L, m0._lut, want_mean) or b""
+        if not plan:
+            return None
+        n = len(sequences)
+        for m in models:                                    # ensemble.py:55-57: every member's cost grows by N
+            m.cost += n
+        out = _native.score_small(m0._engine(), plan, sequences, len(models), want_mean)
+        if out is None:
+            for m in models:
+                m.cost -= n
+            return None
+        return out if want_mean else self.combine_with(out)
+
     def _fitness_function(self, sequences):
+        if type(sequences) in (list, tuple) and 0 < len(sequences) <= _native.SMALL_CALL_ROWS and _native._HAS_SCORE_SMALL:
+            out = self._score_small(sequences)
+            if out is not None:
+                return out
         if _device_members(self.models):
             # ensemble.py:55-57 calls member.get_fitness -> every member's cost grows by N
             n = len(sequences)

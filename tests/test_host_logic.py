@@ -444,3 +444,45 @@ def test_string_packing_from_two_python_threads_at_once():
         assert not errors
     finally:
         sp.set_threads(prev)
+
+
+def test_score_small_packs_and_calls_through_the_plan():
+    """csrc/strpack.c score_small: the explorer-size fast path packs the strings and calls the function the plan carries
+    (fx_score in production; a ctypes callback here, so the argument passing is checked without a GPU)."""
+    import ctypes as C
+    import struct
+
+    from flexs_amd import _native
+
+    if not _native._HAS_SCORE_SMALL:
+        pytest.skip("strpack helper not built")
+    seen = []
+    FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_uint8), C.c_longlong, C.c_int,
+                     C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_float))
+
+    def fake_fx_score(e, models, M, ascii, N, L, lut, out_nm, out_mean):
+        seen.append((e, [models[i] for i in range(M)], N, L, bytes(ascii[:N * L]), bool(out_nm), bool(out_mean), bytes(lut[:256])))
+        o = out_nm if out_nm else out_mean
+        for i in range(N * (M if out_nm else 1)):
+            o[i] = i + 0.5
+        return -3 if N == 3 else 0
+
+    fn = FN(fake_fx_score)
+    lut = _native.make_lut("ACGT")
+    for want in (1, 2):
+        plan = struct.pack("PPqqq16P256s", C.cast(fn, C.c_void_p).value, 777, 2, 4, want, *([11, 22] + [0] * 14), lut.tobytes())
+        out = np.empty((2, 2) if want == 1 else (2,), np.float32)
+        assert _native._strpack.score_small(plan, ["ACGT", "TTTT"], out) == 0
+        assert seen[-1] == (777, [11, 22], 2, 4, b"ACGTTTTT", want == 1, want == 2, lut.tobytes())
+        assert np.array_equal(out.ravel(), np.arange(out.size) + 0.5)
+        assert _native._strpack.score_small(plan, ("ACGT", "TTTT"), out) == 0
+    assert _native._strpack.score_small(plan, ["ACGT", "TTT"], out) == 1001           # ragged
+    assert _native._strpack.score_small(plan, ["ACGT", "TTTሴ"], out) == 1002      # not latin-1
+    assert _native._strpack.score_small(plan, ["ACGT", 5], out) == 1003               # not a str
+    assert _native._strpack.score_small(plan, ["ACGT"] * 3, np.empty(3, np.float32)) == 2003   # the callee's FX_EBADCHAR
+    assert _native._strpack.score_small(plan, ["ACGT"] * 5000, np.empty(5000, np.float32)) == -1  # too big for this path
+    assert _native._strpack.score_small(plan, ["ACGT", "TTTT"], np.empty(1, np.float32)) == -1     # output too small
+    assert _native._strpack.score_small(b"xx", ["ACGT"], out) == -1
+    assert _native._strpack.score_small(plan, np.array(["ACGT"]), out) == -1          # not a list / tuple
+    n_calls = len(seen)
+    assert _native._strpack.score_small(plan, [], out) == -1 and len(seen) == n_calls
