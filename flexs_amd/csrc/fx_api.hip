@@ -9,6 +9,8 @@
 #include "myers.h"
 #include "np_sum.h"
 #include <atomic>
+#include <csetjmp>
+#include <csignal>
 #include <chrono>
 
 // strips of `lw_rows` = 64 x LW pattern rows, as k_min_dist_long runs them for patterns beyond 768 symbols (LW = 12 there;
@@ -208,11 +210,11 @@ int fx_engine_destroy(fx_engine* e) {
     if (!e) return FX_OK;
     (void)hipSetDevice(e->device);
     if (e->server.h_out) {
-        e->server.running = true;                          // (whatever the bookkeeping says: tell them)
+        e->server.running = e->server.in != nullptr;       // (whatever the bookkeeping says: tell them)
         fx_server_stop(e);
         for (hipStream_t st : e->server.streams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
         (void)hipHostFree((void*)e->server.h_out);
-        (void)hipFree(e->server.in);
+        if (e->server.in) (void)hipFree(e->server.in);
         e->server.h_out = nullptr;
     }
     (void)hipStreamSynchronize(e->stream);
@@ -596,15 +598,43 @@ int fx_plan_host_call(fx_engine* e, fx_model* const* models, int M, int64_t N, i
 // Resident small-call form: the host side of the mailboxes (score_cnn_quad.hip, SERVER; FxMailIn / FxMailOut).
 static void server_stop(fx_engine* e) { fx_server_stop(e); }
 
+// One guarded store into the request mailbox before it is ever used: the device reports a large BAR, but whether THIS
+// allocation is mapped for the host is the runtime's business; a fault here is caught instead of killing the process.
+static sigjmp_buf g_probe_jmp;
+static void probe_fault(int) { siglongjmp(g_probe_jmp, 1); }
+static bool host_can_store(volatile unsigned* p) {
+    struct sigaction sa{}, old_segv{}, old_bus{};
+    sa.sa_handler = probe_fault;
+    sigemptyset(&sa.sa_mask);
+    sigaction(SIGSEGV, &sa, &old_segv);
+    sigaction(SIGBUS, &sa, &old_bus);
+    bool ok = false;
+    if (sigsetjmp(g_probe_jmp, 1) == 0) {
+        *p = 0u;
+        fx_bar_fence();
+        ok = true;
+    }
+    sigaction(SIGSEGV, &old_segv, nullptr);
+    sigaction(SIGBUS, &old_bus, nullptr);
+    return ok;
+}
+
 static int server_start(fx_engine* e, fx_model* const* models, int M, int L, const uint8_t lut[256]) {
     auto& sv = e->server;
     if (!e->large_bar) return FX_EUNSUPPORTED;             // the host must be able to store into device memory
     if (!sv.h_out) {
         void* p = nullptr;
         if (hipHostMalloc(&p, sizeof(FxMailOut), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return FX_ENOMEM; }
+        FxMailOut* d = nullptr;
+        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&d), p, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(p); return FX_EHIP; }
         sv.h_out = new (p) FxMailOut();
-        FX_HIP(e, hipHostGetDevicePointer(reinterpret_cast<void**>(&sv.d_out), sv.h_out, 0));
-        FX_HIP(e, hipExtMallocWithFlags(reinterpret_cast<void**>(&sv.in), sizeof(FxMailIn), hipDeviceMallocFinegrained));
+        sv.d_out = d;
+    }
+    if (!sv.in) {
+        FxMailIn* q = nullptr;
+        if (hipExtMallocWithFlags(reinterpret_cast<void**>(&q), sizeof(FxMailIn), hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); return FX_ENOMEM; }
+        if (!host_can_store(&q->stop)) { (void)hipFree(q); e->large_bar = false; return FX_EUNSUPPORTED; }
+        sv.in = q;
     }
     for (int g = 0; g < sv.groups; ++g) FX_HIP(e, hipStreamSynchronize(sv.streams[g]));   // a previous generation has left (it was told to, or timed out)
     std::memset((void*)sv.h_out->alive, 0, sizeof(sv.h_out->alive));   // (answers carry sequence numbers that never repeat: no need to clear them)
@@ -703,7 +733,8 @@ static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8
         const int rc = server_start(e, models, M, L, lut);
         if (rc) {
             sv.pending.clear();
-            if (rc == FX_EUNSUPPORTED) { sv.refused.assign(models, models + M); sv.refused_L = L; }
+            sv.refused.assign(models, models + M); sv.refused_L = L;   // (no resident form, or the start failed: do not try again per call)
+            (void)hipGetLastError();
             return FX_EUNSUPPORTED;
         }
         if (N > sv.cap) return FX_EUNSUPPORTED;
