@@ -360,25 +360,27 @@ def end_to_end_block(device, configs=None):
                 t0 = time.perf_counter(); model.get_fitness(arr_s); ts.append(time.perf_counter() - t0)
             t = float(np.median(ts))
             out["C2 3xCNN L=8 ndarray_S"] = {"value": n / t, "unit": "sequences/s", "wall_ms": t * 1e3}
-            small = seqs[:20]
-            for _ in range(20):
-                model.get_fitness(small)
-            ts = []
-            for _ in range(200):
-                t0 = time.perf_counter(); model.get_fitness(small); ts.append(time.perf_counter() - t0)
-            out["small_call_N20_us"] = float(np.median(ts)) * 1e6
-            # the same call with a launch per call (serve_small = 0: the form of rounds 1-2) beside the resident form
+            # small-call latency at N in {1, 4, 20, 100, 2001}, host strings -> host scores, median of 200 calls;
+            # resident form (up to 256 sequences) beside a launch per call (serve_small = 0: the form of rounds 1-2)
             eng = mods[0]._engine()
-            try:
-                eng.set_option("serve_small", 0)
+
+            def call_us(batch):
                 for _ in range(20):
-                    model.get_fitness(small)
+                    model.get_fitness(batch)
                 ts = []
                 for _ in range(200):
-                    t0 = time.perf_counter(); model.get_fitness(small); ts.append(time.perf_counter() - t0)
-                out["small_call_N20_us_launch_per_call"] = float(np.median(ts)) * 1e6
+                    t0 = time.perf_counter(); model.get_fitness(batch); ts.append(time.perf_counter() - t0)
+                return float(np.median(ts)) * 1e6
+
+            sizes = (1, 4, 20, 100, 2001)
+            out["small_call_us"] = {str(k): call_us(seqs[:k]) for k in sizes}
+            try:
+                eng.set_option("serve_small", 0)
+                out["small_call_us_launch_per_call"] = {str(k): call_us(seqs[:k]) for k in sizes}
             finally:
                 eng.set_option("serve_small", 1)
+            out["small_call_N20_us"] = out["small_call_us"]["20"]          # (round-2 key, kept)
+            out["small_call_N20_us_launch_per_call"] = out["small_call_us_launch_per_call"]["20"]
             out["small_call_resident_requests"] = int(eng.get_option("server_calls"))
         del model, mods, seqs
     out["list_str"] = out["C2 3xCNN L=8 list_str"]          # (round-2 key, kept)
