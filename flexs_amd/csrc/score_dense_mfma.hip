@@ -15,6 +15,7 @@
 
 #include "fx_common.h"
 #include "mfma_common.h"
+#include "score_dense_tile.h"
 
 namespace {
 
@@ -39,6 +40,9 @@ struct DenseArgs {
     int Lpad;                   // L rounded up to 32 positions (the padding rows are zeros)
     int bt_base;                // smallest byte of the alphabet; every letter lies in [bt_base, bt_base + 32)
     int validate;               // BT: 1 = this launch checks the characters, each tile by ONE of its members (once per call, not once per member)
+    // the tiles of a workgroup that do not divide among its four SIMDs are walked by groups of 8 waves (score_dense_tile.h):
+    // 0 = off, else the number of groups that find room for their exchange buffers (PAIR: over the pair rows; BT: at coop_off)
+    int coop, coop_off;
 };
 
 // GE first layer as a table indexed by the RAW byte: tab[l][b - base] = w1[l * A + lut[b]] for the 32 byte values from
@@ -61,6 +65,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
     static_assert(!SLAB || (DG && NT == 1), "SLAB streams the L2-resident blocks of the one-tile form");
     static_assert(!BT || (KIND == FX_GE && NT == 1 && !DG && !SLAB), "BT is the GlobalEpistasis byte-table form");
     constexpr int KG = 2;                                       // input tiles per slab
+    // the last (tiles mod 4) tiles of a workgroup shared by wave groups instead of making one SIMD run an extra tile
+    constexpr bool COOP_OK = NT == 1 && !SLAB && !DG && !W1G && WAVES == 16 && (PAIR || BT);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int g = lane >> 4, sq = lane & 15;
@@ -117,10 +123,38 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
         const int64_t t_lo = (u_lo > (int64_t)m * p.TG ? u_lo : (int64_t)m * p.TG) - (int64_t)m * p.TG;
         const int64_t t_hi = (u_hi < (int64_t)(m + 1) * p.TG ? u_hi : (int64_t)(m + 1) * p.TG) - (int64_t)m * p.TG;
 
+        // 25 tiles on four SIMDs are 7 + 6 + 6 + 6: the SIMD with the odd tile sets the time of the workgroup (at 1e5
+        // sequences every tile is 1 / 6 of the launch).  The tiles that do not divide by four are left out of the shares and
+        // walked afterwards by groups of 8 waves, output tiles dealt to the waves (~1.5 us for two tiles at once instead of
+        // ~6 us for a lone wave's tile).  PAIR: the groups' exchange buffers lie over the pair rows, which the first layer
+        // of that one round still reads -- so all shared tiles must fit one round, else none is shared.
+        int ncoop = 0;
+        if constexpr (COOP_OK) {
+            const int64_t cnt = t_hi - t_lo;
+            // (only where the odd tile weighs: up to 8 tiles per SIMD.  The shared walk is a once-per-workgroup code path --
+            //  cold in the instruction cache, five barriers -- and costs ~4 us against ~6 us for a lone wave's tile: -5 % at
+            //  5 and -2..-4 % at 6 tiles per SIMD, nothing at 60, +1 % when a workgroup's range spans three members)
+            if (p.coop && cnt >= 4 && u_hi - u_lo <= 32) {
+                const int r = (int)(cnt & 3);
+                ncoop = (PAIR && r > p.coop) ? 0 : r;
+            }
+        }
+        const int64_t t_main = t_hi - ncoop;
+        // the bytes of the shared tile this wave's group will walk, requested now (a full tile of <= 1 KiB: 16 bytes per lane),
+        // so that the round after the main loop does not start with a trip to memory
+        [[maybe_unused]] FxBytes16 coop_pre{};
+        [[maybe_unused]] bool coop_pre_ok = false;
+        if constexpr (COOP_OK) {
+            const int grp0 = (tid >> 6) >> 3;
+            if (ncoop && p.stage_stride && 16 * L <= 1024 && grp0 < p.coop && grp0 < ncoop && (t_main + grp0 + 1) * 16 <= p.N) {
+                coop_pre_ok = true;
+                if (lane * 16 < 16 * L) coop_pre = *reinterpret_cast<const FxBytes16*>(p.ascii + (t_main + grp0) * 16 * L + lane * 16);
+            }
+        }
         // the workgroup's tiles in shares per SIMD (proportional to the waves it hosts); the waves of a SIMD pull from
         // their share's counter
-        const int64_t s_lo = t_lo + (t_hi - t_lo) * share.before / share.total;
-        const int64_t s_hi = t_lo + (t_hi - t_lo) * (share.before + share.mine) / share.total;
+        const int64_t s_lo = t_lo + (t_main - t_lo) * share.before / share.total;
+        const int64_t s_hi = t_lo + (t_main - t_lo) * (share.before + share.mine) / share.total;
         for (int64_t round = 0;; ++round) {
             // SLAB: lockstep rounds of WAVES tiles; waves without a tile in the last round run along on tile 0
             int64_t tg_want = t_lo + round * WAVES + (tid >> 6);
@@ -394,6 +428,32 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                     if (live && n[nt] < p.N) p.out[n[nt] * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y[nt]);
             }
             FX_TILE_DONE();
+        }
+        if constexpr (COOP_OK) {
+            if (ncoop) {
+                __syncthreads();                                     // every wave is through with its own tiles (and its byte scratch)
+                const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wv >> 3, w8 = wv & 7;
+                f4* hx = reinterpret_cast<f4*>(PAIR ? wpair : smem + p.coop_off) + grp * (2 * HT * 64);
+                for (int c0 = 0; c0 < ncoop; c0 += p.coop) {
+                    const int i = c0 + grp;
+                    const bool live = grp < p.coop && i < ncoop;
+                    const int64_t tg = t_main + (live ? i : 0);
+                    const int64_t nn = tg * 16 + sq;
+                    const int64_t tile_rows = p.N - tg * 16 < 16 ? p.N - tg * 16 : 16;
+                    if (c0 == 0 && coop_pre_ok) {
+                        if (lane * 16 < 16 * L) {
+                            uint32_t* d = reinterpret_cast<uint32_t*>(stw + lane * 16);
+                            d[0] = coop_pre.w[0]; d[1] = coop_pre.w[1]; d[2] = coop_pre.w[2]; d[3] = coop_pre.w[3];
+                        }
+                    } else if (p.stage_stride && live) fx_stage_tile(p.ascii + tg * 16 * L, (int)tile_rows * L, stw, lane);
+                    const uint8_t* crow = p.stage_stride ? stw + (nn < p.N ? sq : 0) * L : p.ascii + (nn < p.N ? nn : 0) * L;
+                    float yc = 0.f;
+                    fx_dense_tile8<KIND, HT, PAIR>(live, w8, lane, crow, L, p.A, p.rlh, PAIR ? 1 : 0, p.w[m] + p.off_first, nullptr,
+                                                   wpair, w_d2, w_d3, db, lut_s, hx, nullptr, bad, yc);
+                    if (live && w8 == 0 && g == 0 && nn < p.N) p.out[nn * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(yc);
+                    if (c0 + p.coop < ncoop) __syncthreads();        // the next round reuses the exchange buffers
+                }
+            }
         }
     }
     fx_stamp(p.trace, 6);
@@ -871,6 +931,17 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
             if constexpr (HT_ == 7) {
                 if (few_waves) return launch_inst<FX_GE, 4, HT_, 1, 8, false, false, false, false, true>(e, a, need);
             }
+            if constexpr (W == 16) {
+                // shared last tiles: exchange buffers behind everything else (2 x HT KiB per group of 8 waves)
+                need = (need + 15) / 16 * 16;
+                // (GlobalEpistasis: a lone wave's tile is cheap -- one H x H layer -- and the shared walk measured 5-7 % SLOWER
+                //  (profiles/r3_dense_coop_ab.log): only dense_coop = 2 selects it, for the A/B)
+                for (int groups = 2; groups >= 1 && e->dense_coop == 2 && !a.coop; --groups)
+                    if (need + (size_t)groups * 2 * HT_ * 1024 <= (size_t)e->max_lds) {
+                        a.coop = groups; a.coop_off = (int)(need / 4);
+                        need += (size_t)groups * 2 * HT_ * 1024;
+                    }
+            }
             return launch_inst<FX_GE, 4, HT_, 1, W, false, false, false, false, true>(e, a, need);
         }
     }
@@ -922,6 +993,9 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
                     if constexpr (HT_ == 7) {
                         if (few_waves) return launch_inst<FX_MLP, 4, HT_, 1, 8, true, false, false, false, false, true>(e, a, need);
                     }
+                    // shared last tiles: the groups' exchange buffers (2 x HT KiB each) lie over the pair rows
+                    if (W == 16 && e->dense_coop)
+                        a.coop = (size_t)lay.pair_floats * 4 >= (size_t)4 * HT_ * 1024 ? 2 : (size_t)lay.pair_floats * 4 >= (size_t)2 * HT_ * 1024 ? 1 : 0;
                     return launch_inst<FX_MLP, 4, HT_, 1, W, true, false, false, false, false, true>(e, a, need);
                 }
             }

@@ -15,6 +15,7 @@
 // the persistent kernel's order), then owns its output tiles of the 1 -> H layer and of the H x H layer.
 #include "fx_common.h"
 #include "mfma_common.h"
+#include "score_dense_tile.h"
 
 namespace {
 
@@ -39,8 +40,6 @@ struct SmallArgs {
 
 template <int KIND, int HT, bool SERVER = false>
 __global__ void __launch_bounds__(SW * 64) k_score_dense_small(SmallArgs p) {
-    constexpr int OT = (HT + SW - 1) / SW;                // output tiles per wave (1 or 2)
-    constexpr int PF = 8;                                 // first-layer rows in flight per output tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, sq = lane & 15;
@@ -103,174 +102,14 @@ __global__ void __launch_bounds__(SW * 64) k_score_dense_small(SmallArgs p) {
     __syncthreads();
     const uint8_t* row = bytes_s + (n < Ncur ? sq : 0) * L;    // lanes past the batch recompute the tile's first sequence
     const float* W = p.w[m];
-    const float* db = W + p.off_db;
     bool bad = false;
+    float y0 = 0.f;
+    fx_dense_tile8<KIND, HT, false>(true, wave, lane, row, L, p.A, p.rlh, p.pair, W + p.off_first, W + p.off_w1p, W + p.off_w1pair,
+                                    reinterpret_cast<const f4*>(W + p.off_d2), reinterpret_cast<const f4*>(W + p.off_d3), W + p.off_db,
+                                    lut_s, hx, SERVER ? &srv_bad : nullptr, bad, y0);
 
-    if constexpr (KIND == FX_GE) {
-        // ---- GE layer 1: s = relu(b1 + sum_l w1[l * A + code_l]), a scalar per sequence; layer 2: relu(b2 + s * w2) for this
-        //      wave's output tiles, directly in B-operand layout
-        const float* w1 = W + p.off_first;
-        const unsigned amax = (unsigned)p.A - 1u;
-        float sacc = 0.f;
-        unsigned seen = 0;
-        for (int l0 = g; l0 < L; l0 += 4 * PF) {
-            float r[PF];
-#pragma unroll
-            for (int k = 0; k < PF; ++k) {
-                const int l = l0 + 4 * k;
-                if (l < L) {
-                    const unsigned c = lut_s[row[l]];
-                    seen |= c;
-                    r[k] = w1[l * p.A + (int)(c < amax ? c : amax)];
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < PF; ++k)
-                if (l0 + 4 * k < L) sacc += r[k];
-        }
-        bad |= seen >= 0x80u;
-        if constexpr (SERVER) { if (bad) srv_bad = 1; }      // (read by wave 0 when it answers, barriers later)
-        sacc += __shfl_xor(sacc, 16);
-        sacc += __shfl_xor(sacc, 32);
-        sacc += db[0];
-        const float sv = relu1(sacc);
-#pragma unroll
-        for (int t = 0; t < OT; ++t) {
-            const int mo = wave + SW * t;
-            if (mo < HT) {
-                const f4 w2 = *reinterpret_cast<const f4*>(&db[4 + 16 * mo + 4 * g]);
-                const f4 b2 = *reinterpret_cast<const f4*>(&db[4 + 16 * HT + 16 * mo + 4 * g]);
-                f4 v;
-                v.x = relu1(fmaf(sv, w2.x, b2.x));
-                v.y = relu1(fmaf(sv, w2.y, b2.y));
-                v.z = relu1(fmaf(sv, w2.z, b2.z));
-                v.w = relu1(fmaf(sv, w2.w, b2.w));
-                hx[mo * 64 + lane] = v;
-            }
-        }
-        __syncthreads();
-    } else {
-    // ---- layer 1: relu(b1 + sum of the kernel rows selected by the codes), this wave's output tiles only
-    f4 h[OT];
-#pragma unroll
-    for (int t = 0; t < OT; ++t) {
-        const int mo = wave + SW * t;
-        h[t] = mo < HT ? *reinterpret_cast<const f4*>(&db[16 * mo + 4 * g]) : splat4(0.f);
-    }
-    unsigned seen = 0;
-    if (p.pair) {
-        const float* wp = W + p.off_w1pair + 4 * g;
-        constexpr int RS = 16 * HT + FX_PAIR_PAD;
-        const int np2 = L >> 1, nterm = np2 + (L & 1);        // pair rows, then the odd last position's own row
-        for (int t0 = 0; t0 < nterm; t0 += PF) {
-            f4 r[PF][OT];
-#pragma unroll
-            for (int k = 0; k < PF; ++k) {
-                const int pi = t0 + k;
-                if (pi < nterm) {
-                    int rowi;
-                    if (pi < np2) {
-                        const unsigned c0 = lut_s[row[2 * pi]], c1 = lut_s[row[2 * pi + 1]];
-                        seen |= c0 | c1;
-                        rowi = pi * 16 + (int)(((c0 & 3u) << 2) | (c1 & 3u));
-                    } else {
-                        const unsigned c0 = lut_s[row[L - 1]];
-                        seen |= c0;
-                        rowi = np2 * 16 + (int)(c0 & 3u);
-                    }
-#pragma unroll
-                    for (int t = 0; t < OT; ++t) {
-                        const int mo = wave + SW * t;
-                        if (mo < HT) r[k][t] = *reinterpret_cast<const f4*>(wp + (int64_t)rowi * RS + 16 * mo);
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < PF; ++k)
-                if (t0 + k < nterm)
-#pragma unroll
-                    for (int t = 0; t < OT; ++t) h[t] += r[k][t];
-        }
-    } else {
-        const float* w1 = W + p.off_w1p + 4 * g;
-        const unsigned amax = (unsigned)p.A - 1u;
-        for (int l0 = 0; l0 < L; l0 += PF) {
-            f4 r[PF][OT];
-#pragma unroll
-            for (int k = 0; k < PF; ++k) {
-                const int l = l0 + k;
-                if (l < L) {
-                    const unsigned c = lut_s[row[l]];
-                    seen |= c;
-                    const unsigned ci = c < amax ? c : amax;   // keeps the read inside the table for a bad character
-#pragma unroll
-                    for (int t = 0; t < OT; ++t) {
-                        const int mo = wave + SW * t;
-                        if (mo < HT) r[k][t] = *reinterpret_cast<const f4*>(w1 + ((int64_t)l * p.A + ci) * (16 * HT) + 16 * mo);
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < PF; ++k)
-                if (l0 + k < L)
-#pragma unroll
-                    for (int t = 0; t < OT; ++t) h[t] += r[k][t];
-        }
-    }
-    bad |= seen >= 0x80u;
-    if constexpr (SERVER) { if (bad) srv_bad = 1; }
-#pragma unroll
-    for (int t = 0; t < OT; ++t) {
-        const int mo = wave + SW * t;
-        if (mo < HT) hx[mo * 64 + lane] = relu4(h[t]);
-    }
-    __syncthreads();
-
-    }
-
-    // ---- layers 2, 3: this wave's output tiles from all HT input tiles; A fragments straight from global memory
-    auto hidden = [&](const f4* wblk, const float* bias, const f4* src, f4* dst) {
-        f4 in[HT];
-#pragma unroll
-        for (int mi = 0; mi < HT; ++mi) in[mi] = src[mi * 64 + lane];
-#pragma unroll
-        for (int t = 0; t < OT; ++t) {
-            const int mo = wave + SW * t;
-            if (mo < HT) {
-                f4 a[HT];
-#pragma unroll
-                for (int mi = 0; mi < HT; ++mi) a[mi] = wblk[(mi * HT + mo) * 64 + lane];
-                f4 acc = *reinterpret_cast<const f4*>(&bias[16 * mo + 4 * g]);
-#pragma unroll
-                for (int mi = 0; mi < HT; ++mi)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (mi == HT - 1 && r >= p.rlh) break;
-                        acc = mfma16(a[mi][r], in[mi][r], acc);
-                    }
-                dst[mo * 64 + lane] = relu4(acc);
-            }
-        }
-    };
-    const f4* last = hx;                                 // where the last hidden layer's output ends up
-    if constexpr (KIND == FX_GE) {
-        hidden(reinterpret_cast<const f4*>(W + p.off_d3), db + 4 + 32 * HT, hx, hx + HT * 64);
-        last = hx + HT * 64;
-    } else {
-        hidden(reinterpret_cast<const f4*>(W + p.off_d2), db + 16 * HT, hx, hx + HT * 64);
-        __syncthreads();
-        hidden(reinterpret_cast<const f4*>(W + p.off_d3), db + 32 * HT, hx + HT * 64, hx);
-    }
-    __syncthreads();
-
-    // ---- Dense(1): wave 0
     if (wave == 0) {
-        f4 h3[HT][1];
-#pragma unroll
-        for (int mi = 0; mi < HT; ++mi) h3[mi][0] = last[mi * 64 + lane];
-        float y[1];
-        if constexpr (KIND == FX_GE) final_dot<HT, 1>(db + 4 + 48 * HT, db[4 + 64 * HT], h3, y, g);
-        else final_dot<HT, 1>(db + 48 * HT, db[64 * HT], h3, y, g);
+        float y[1] = {y0};
         if constexpr (SERVER) {
             // (score, tag) in one 8-byte store to host memory; the fence pushes the lines out of this XCD's L2
             const unsigned tag = (unsigned)(srv_req >> 16) | (srv_bad ? 0x80000000u : 0u);

@@ -323,7 +323,7 @@ def _flat_state(arch):
 def _unflat(flat, shapes):
     out, off = [], 0
     for sh in shapes:
-        k = int(np.prod(sh))
+        k = math.prod(sh)                                 # (np.prod costs 7 us per call: 0.75 ms of a 3-member fit)
         out.append(flat[off:off + k].reshape(sh).copy())
         off += k
     return out

@@ -1910,3 +1910,47 @@ def test_resident_small_call_form_mixed_ensemble(eng):
     for _ in range(6):
         assert np.array_equal(ens.get_fitness(seqs), want)
     assert eng.get_option("server_calls") == served0 and eng.get_option("server_starts") == starts0
+
+
+@pytest.mark.parametrize("kind,L,alpha,H,M,n", [
+    ("mlp", 14, "UGCA", 100, 1, 100_000), ("mlp", 14, "UGCA", 100, 1, 100_016), ("mlp", 14, "UGCA", 100, 1, 104_096),
+    ("mlp", 14, "UGCA", 100, 1, 108_192), ("mlp", 14, "UGCA", 100, 3, 33_333), ("mlp", 8, "TGCA", 100, 2, 50_001),
+    ("mlp", 4, "TGCA", 100, 1, 30_000), ("mlp", 16, "UGCA", 64, 1, 70_001), ("mlp", 14, "UGCA", 112, 1, 41_000),
+    ("ge", 90, s_utils.AAS, 100, 1, 100_000), ("ge", 90, s_utils.AAS, 100, 1, 104_096), ("ge", 90, s_utils.AAS, 100, 1, 108_200),
+    ("ge", 90, s_utils.AAS, 100, 1, 112_300), ("ge", 90, s_utils.AAS, 100, 8, 100_000), ("ge", 14, "UGCA", 100, 3, 33_333),
+    ("ge", 8, "TGCA", 50, 1, 21_000), ("ge", 237, s_utils.AAS, 100, 2, 20_480),
+])
+def test_shared_last_tiles_of_the_dense_kernel_give_the_same_bits(eng, kind, L, alpha, H, M, n):
+    """Round 3: the persistent MLP / GlobalEpistasis kernel leaves the (tiles mod 4) last tiles of a workgroup out of its
+    per-SIMD shares and walks them with groups of 8 waves (`dense_coop`, score_dense_tile.h) instead of letting one SIMD
+    run an extra tile.  Same arithmetic per output element, so the SAME BITS as one wave per tile (`dense_coop` = 0) --
+    every remainder (the sizes put 1, 2 and 3 odd tiles into the workgroups), members, ragged batches -- both agree with
+    the oracle, and a bad character in a shared tile is still reported."""
+    A = len(alpha)
+    natives, ws = zip(*[make_native(eng, kind, L, A, H, seed=900 + m) for m in range(M)])
+    lut = _native.make_lut(alpha)
+    b, seqs = rand_seqs(n, L, alpha, seed=L + H + M + 1)
+    eng.set_option("dense_small", 0)
+    try:
+        outs = {}
+        for coop in (2, 1, 0):                             # 2: GlobalEpistasis too (measured slower there, so 1 = MLP only)
+            eng.set_option("dense_coop", coop)
+            outs[coop], _ = eng.score(list(natives), b, lut)
+        assert np.array_equal(outs[1], outs[0]) and np.array_equal(outs[2], outs[0])
+        eng.set_option("dense_coop", 2)
+        k = min(n, 300)
+        for m in range(M):
+            assert_scores(outs[1][:k, m], c_oracle.forward(kind, lut[b[:k]], A, ws[m]), f"{kind} L={L} H={H} member {m}")
+            assert_scores(outs[1][n - k:, m], c_oracle.forward(kind, lut[b[n - k:]], A, ws[m]), f"{kind} L={L} H={H} member {m} tail")
+        # a character outside the alphabet anywhere -- the shared tiles are the last ones of each workgroup's range
+        ncu = eng.get_option("num_cus")
+        tiles = (n + 15) // 16
+        for where in (n - 1, 16 * (tiles // ncu) - 1, n // 2):
+            bad = b.copy(); bad[min(max(where, 0), n - 1), L - 1] = ord("!")
+            with pytest.raises(ValueError):
+                eng.score(list(natives), bad, lut)
+        again, _ = eng.score(list(natives), b, lut)
+        assert np.array_equal(again, outs[1])
+    finally:
+        eng.set_option("dense_coop", 1)
+        eng.set_option("dense_small", 1)
