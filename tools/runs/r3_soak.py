@@ -26,7 +26,8 @@ def fail(tag, ex):
 
 
 # (1) scoring sweep
-for seed in range(400, 700):
+SEED0 = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+for seed in range(SEED0, SEED0 + 300):
     kind, alpha, A, L, H, F, K, M, n = T._random_case(seed)
     try:
         natives, ws = zip(*[T.make_native(eng, kind, L, A, H, F, K, seed=500 + 7 * seed + m) for m in range(M)])
@@ -41,7 +42,7 @@ for seed in range(400, 700):
 print(f"[{time.time() - t_start:.0f}s] scoring sweep done", flush=True)
 
 # (2) training sweep
-rng = np.random.default_rng(99)
+rng = np.random.default_rng(99 + SEED0)
 for draw in range(150):
     kind = ("cnn", "mlp", "ge")[draw % 3]
     alphabet = ("UGCA", ref_np.AAS, "01", "TGCA")[int(rng.integers(0, 4))]
@@ -115,4 +116,57 @@ try:
     assert final_loss < 0.01, final_loss
 except Exception as ex:                                       # noqa: BLE001
     fail("explorer-loop pattern", ex)
+print(f"[{time.time() - t_start:.0f}s] explorer-loop pattern done", flush=True)
+
+# (6) the resident small-call form under an explorer's life: several model lists taking turns, bursts of small calls of random
+#     size, new weights, training, big calls and pauses in between -- every answer against the launched form's
+pool = {
+    "3cnn8": [bm.CNN(8, 32, 100, "TGCA", seed=s) for s in range(3)],
+    "mlp14": [bm.MLP(14, 100, "UGCA", seed=7)],
+    "dyna": [bm.GlobalEpistasisModel(14, 100, "UGCA", seed=1), bm.MLP(14, 200, "UGCA", seed=2), bm.CNN(14, 32, 100, "UGCA", seed=3)],
+    "8ge90": [bm.GlobalEpistasisModel(90, 100, s_utils.AAS, seed=s) for s in range(8)],
+}
+data = {k: synth.random_sequence_bytes(3000, v[0].model.L, v[0].alphabet, 11) for k, v in pool.items()}
+want = {}
+
+
+def refresh(key):
+    eng.set_option("serve_small", 0)
+    nat = [m.native() for m in pool[key]]
+    want[key], _ = eng.score(nat, data[key], pool[key][0]._lut, want_matrix=True, want_mean=False)
+    eng.set_option("serve_small", 1)
+
+
+eng.set_option("poison_outputs", 0)
+for k in pool:
+    refresh(k)
+served0 = eng.get_option("server_calls")
+try:
+    for rnd in range(1500):
+        key = list(pool)[int(rng.integers(0, len(pool)))]
+        members_k = pool[key]
+        ens_k = flexs_amd.Ensemble(members_k, combine_with=lambda x: x)
+        for _ in range(int(rng.integers(1, 30))):
+            n = int(rng.integers(1, 257)); off = int(rng.integers(0, 3000 - n))
+            got = ens_k.get_fitness(synth.bytes_to_strings(data[key][off:off + n]))
+            if not np.array_equal(got, want[key][off:off + n]):
+                raise AssertionError(f"round {rnd} {key} n={n} off={off}: {int((got != want[key][off:off + n]).sum())} scores differ")
+        ev = rng.random()
+        if ev < 0.15:                                         # new weights for one member
+            m = members_k[int(rng.integers(0, len(members_k)))]
+            m.model.set_weights([w * np.float32(1.0 + 0.01 * rng.standard_normal()) for w in m.model.get_weights()])
+            refresh(key)
+        elif ev < 0.22 and key == "3cnn8":                    # a training round
+            flexs_amd.Ensemble(members_k).train(seqs[:300], y[:300], seed=rnd)
+            refresh(key)
+        elif ev < 0.30:                                       # a launch that fills the chip
+            got = ens_k.get_fitness(synth.bytes_to_strings(data[key]))
+            assert np.array_equal(got, want[key])
+        elif ev < 0.40:
+            time.sleep(float(rng.choice([0.0003, 0.0007, 0.003])))
+    assert eng.get_option("server_fallbacks") == 0, eng.get_option("server_last_fallback")
+except Exception as ex:                                       # noqa: BLE001
+    fail("resident small-call form", ex)
+print(f"[{time.time() - t_start:.0f}s] resident form: {eng.get_option('server_calls') - served0} requests answered by resident workgroups, "
+      f"{eng.get_option('server_starts')} generations, {eng.get_option('server_fallbacks')} fallbacks", flush=True)
 print(f"[{time.time() - t_start:.0f}s] soak done, failures: {fails}", flush=True)
