@@ -282,6 +282,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "dense_pipe")) return &e->dense_pipe;
     if (!std::strcmp(key, "fuse_mean")) return &e->fuse_mean;
     if (!std::strcmp(key, "dense_coop")) return &e->dense_coop;
+    if (!std::strcmp(key, "quad_rotate")) return &e->quad_rotate;
     if (!std::strcmp(key, "serve_small")) return &e->serve_small;
     if (!std::strcmp(key, "serve_idle_us")) return &e->serve_idle_us;
     if (!std::strcmp(key, "chunk_overlap")) return &e->chunk_overlap;

@@ -188,6 +188,7 @@ struct fx_engine {
         int64_t served = 0, started = 0, fallbacks = 0, fb_info = 0;
     } server;
     bool large_bar = false;     // the host can store into device memory (the resident form needs it)
+    int64_t quad_rotate = 1;    // quad CNN form: the waves' roles rotate from quad to quad (balances the MFMA load of a CU's SIMDs; 0 = same roles: A/B)
     int64_t dense_coop = 1;     // MLP / GE persistent kernel: a workgroup's tiles that do not divide among its four SIMDs are walked by groups of 8 waves (0 = one wave each: A/B)
     int64_t serve_idle_us = 500;   // calls of the same ensemble closer than this start / keep the resident workgroups; they leave after twice this long without a request (a device-wide synchronize waits that long for them at most)
     int64_t serve_small = 1;    // 1 = explorer-size calls of canonical CNN ensembles are answered by resident workgroups (0 = a launch per call: A/B)

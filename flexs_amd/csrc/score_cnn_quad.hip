@@ -44,7 +44,7 @@ struct QuadArgs {
     float* mean_out;            // null = off
     unsigned* tickets;          // one per tile, zero between launches (fx_zero_pool; the last arrival resets its entry)
     // resident form
-    int srv_tiles; FxMailIn* min; FxMailOut* mout;               // null = ordinary launch
+    int rotate; int srv_tiles; FxMailIn* min; FxMailOut* mout;               // null = ordinary launch
     unsigned long long idle_ticks, life_ticks;   // leave after this long without a request / in total (100 MHz ticks)
     int off_c2, off_c3, off_cb, off_w1p, off_d1, off_d2, off_db, total_floats;
 };
@@ -64,7 +64,10 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
     const int L = L1 + K - 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int quad = wave >> 2, q = wave & 3;
+    // the wave's role in its quad, rotated from quad to quad: the four roles issue 184 / 184 / 152 / 116 MFMAs per tile
+    // (edge positions have fewer taps, role 3 owns one dense output tile instead of two), and with three quads in lockstep
+    // on a CU the SIMD that hosts role 0 of every quad would carry 552 of them -- rotated, the busiest carries 520
+    const int quad = wave >> 2, q = ((wave & 3) + (p.rotate ? quad : 0)) & 3;
     const int g = lane >> 4, sq = lane & 15;
     uint8_t* lut_s = reinterpret_cast<uint8_t*>(smem + p.total_floats);
     f4* xq = reinterpret_cast<f4*>(smem + p.total_floats + 64) + quad * (2 * XT * 64);   // this quad's two XT KiB buffers
@@ -415,6 +418,7 @@ int fx_launch_score_cnn_quad(fx_engine* e, fx_model* const* models, int M, const
     a.N = N; a.TG = TG; a.M = M; a.m_off = m_off;
     a.out_sn = e->planar_stride ? 1 : Mtot; a.out_sm = e->planar_stride ? e->planar_stride : 1;
     a.L = s.L; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4;
+    a.rotate = (int)e->quad_rotate;
     a.dma = e->dma_fill && lay.off_d1 % 4 == 0 && lay.total_floats % 4 == 0;
     const bool fuse = e->fuse_mean_out && e->planar_stride && m_off == 0 && M == Mtot && M <= 16 && TG <= 4096;
     if (fuse) {

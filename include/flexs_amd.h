@@ -118,7 +118,7 @@ const char *fx_last_error(fx_engine *e);
  *
  * Kernel-form selectors -- every one chooses between forms that give the SAME BITS (tested), so they are speed knobs
  * only; the defaults are the measured winners and the losers stay selectable as the A/B baseline of the profiles:
- *   cnn_variant, cnn_big_units, cnn_pair, cnn_seg, cnn_seg_multi, cnn_pair_seg, cnn_pair_seg4, cnn_quad   (CNN launch forms)
+ *   cnn_variant, cnn_big_units, cnn_pair, cnn_seg, cnn_seg_multi, cnn_pair_seg, cnn_pair_seg4, cnn_quad, quad_rotate   (CNN launch forms)
  *   dense_small, dense_slab, dense_waves, dense_few_waves_below, dense_pipe, dense_coop, mlp_pair, ge_bytetab   (MLP / GE forms)
  *   stage_bytes, stage_fill, dma_fill, wave_prio                                                             (staging / scheduling)
  *   cnn_conv1_mfma, mlp_l1_mfma     (one-hot first layers on MFMA instead of the LDS gather: NOT bit-identical, within

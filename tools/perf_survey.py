@@ -57,7 +57,7 @@ def time_score(kind, L, alpha, H, M, N, F=0, K=0, reps=20, generic=False, varian
     eng.set_option("cnn_variant", 0)
     for k_ in (opts or {}):
         eng.set_option(k_, {"cnn_pair": 1, "cnn_big_units": 12, "cnn_seg": -1, "cnn_pair_seg": -1, "dense_slab": 1, "ge_bytetab": 1, "mlp_pair": 1,
-                               "wave_prio": 1, "stage_bytes": 1, "stage_fill": 1, "cnn_quad": 1, "dma_fill": 1, "cnn_seg_multi": 1, "cnn_pair_seg4": 1, "dense_small": 1}.get(k_, 0))
+                               "wave_prio": 1, "stage_bytes": 1, "stage_fill": 1, "cnn_quad": 1, "dma_fill": 1, "cnn_seg_multi": 1, "cnn_pair_seg4": 1, "dense_small": 1, "dense_coop": 1, "quad_rotate": 1, "serve_small": 1}.get(k_, 0))
     macs = synth.algorithmic_macs(kind, L, A, H, F, K)
     tf = 2.0 * macs * M * N / (ms * 1e-3) / 1e12
     gbs = (L + 4 * M) * N / (ms * 1e-3) / 1e9
