@@ -129,18 +129,28 @@ class NoisyAbstractModel(flexs_amd.Model):
         self.cache.update(zip(sequences, labels))                      # :62-67
 
     def _fitness_function(self, sequences):
-        sequences = np.array(sequences)
-        fitnesses = np.empty(len(sequences))
-        cached = np.array([seq in self.cache for seq in sequences], dtype=bool)
-        fitnesses[cached] = np.array([self.cache[seq] for seq in sequences[cached]])
-
-        new_seqs = sequences[~cached]
-        if len(new_seqs):
-            if len(self.cache) == 0:                                   # :44-45
-                dist = np.zeros(len(new_seqs), np.int32)
-                neighbours = list(new_seqs)
+        # noisy_abstract_model.py:69-101.  Same decisions in the same order as the reference (which is cached is decided
+        # for the whole batch before anything is added; a new sequence that occurs twice is computed twice and the second
+        # value stays in the cache), on plain Python strings instead of a NumPy string array: 100 membership tests on
+        # np.str_ scalars cost more than the distance kernel.
+        seqs = [s if type(s) is str else str(s) for s in sequences]
+        cache = self.cache
+        fitnesses = np.empty(len(seqs))
+        new_idx = []
+        for i, s in enumerate(seqs):
+            v = cache.get(s, cache)                                    # (the dict itself as the "absent" marker)
+            if v is cache:
+                new_idx.append(i)
             else:
-                dist, neighbours = self._min_distances([str(s) for s in new_seqs])
+                fitnesses[i] = v
+
+        if new_idx:
+            new_seqs = [seqs[i] for i in new_idx]
+            if len(cache) == 0:                                        # :44-45
+                dist = np.zeros(len(new_seqs), np.int32)
+                neighbours = new_seqs
+            else:
+                dist, neighbours = self._min_distances(new_seqs)
             signal = np.empty(len(new_seqs))
             noise = np.empty(len(new_seqs))
             done = False
@@ -149,8 +159,8 @@ class NoisyAbstractModel(flexs_amd.Model):
                 # batches instead of 2*Q one-element calls.  Same values, same total landscape.cost
                 # (+2 per query, :86-87); the RNG stream is unchanged because
                 # np.random.exponential(scale=array) draws element by element in order.
-                sig = self.landscape.get_fitness([str(s) for s in new_seqs])
-                nbf = self.landscape.get_fitness([str(s) for s in neighbours])
+                sig = self.landscape.get_fitness(new_seqs)
+                nbf = self.landscape.get_fitness(neighbours)
                 if (nbf >= 0).all():
                     signal[:] = sig
                     noise[:] = np.random.exponential(scale=nbf)
@@ -168,7 +178,7 @@ class NoisyAbstractModel(flexs_amd.Model):
                         noise[i] = np.random.choice(list(self.cache.values()))
             max_d = int(dist.max()) if len(dist) else 0
             alpha_tab = np.array([self.ss ** d for d in range(max_d + 1)], np.float64)   # :93, Python float pow
-            fitnesses[~cached] = self._blend(signal, noise, dist, alpha_tab)
-
-        self.cache.update(zip(sequences[~cached], fitnesses[~cached]))  # :99
-        return np.array(fitnesses)
+            new_fit = self._blend(signal, noise, dist, alpha_tab)
+            fitnesses[new_idx] = new_fit
+            cache.update(zip(new_seqs, new_fit))                       # :99
+        return fitnesses

@@ -97,6 +97,22 @@ int fx_pinned(fx_engine* e, int slot, size_t bytes, void** out) {
     return FX_OK;
 }
 
+// Explorer-size calls of the small kernels (distances, blend, table look-ups): inputs and outputs in the engine's mapped
+// pinned staging areas, read / written by the kernel directly -- one launch and one wait instead of 3-5 copy enqueues
+// around them (a hipMemcpyAsync of a few hundred bytes costs as much as the kernel).  The kernel's end makes its
+// stores to host memory visible; the host copies the result out after the stream wait.
+struct FxZeroCopy { char *h_in, *d_in, *h_out, *d_out; };
+static int fx_zero_copy_buffers(fx_engine* e, size_t in_bytes, size_t out_bytes, FxZeroCopy* z) {
+    void *hi = nullptr, *ho = nullptr, *di = nullptr, *dout = nullptr;
+    int rc;
+    if ((rc = fx_pinned(e, 0, in_bytes + 64, &hi))) return rc;
+    if ((rc = fx_pinned(e, 1, out_bytes + 64, &ho))) return rc;
+    FX_HIP(e, hipHostGetDevicePointer(&di, hi, 0));
+    FX_HIP(e, hipHostGetDevicePointer(&dout, ho, 0));
+    *z = FxZeroCopy{(char*)hi, (char*)di, (char*)ho, (char*)dout};
+    return FX_OK;
+}
+
 int fx_upload_lut(fx_engine* e, const uint8_t lut[256]) {
     if (e->lut_valid && std::memcmp(lut, e->h_lut, 256) == 0) return FX_OK;
     std::memcpy(e->h_lut, lut, 256);
@@ -1113,6 +1129,22 @@ static int min_dist_common(fx_engine* e, int mode, const uint8_t* queries, int64
     }
     e->counters.pair_evals += Q * C;
     int rc;
+    if ((size_t)Q * L + (size_t)Q * 12 <= (size_t)e->zero_copy_bytes) {
+        // explorer-size query batch: queries read from / results written to mapped pinned memory (the keys stay on the device)
+        FxZeroCopy z;
+        void* d_keys = nullptr;
+        if ((rc = fx_zero_copy_buffers(e, (size_t)Q * L + 16, (size_t)Q * 16, &z))) return rc;
+        if ((rc = fx_scratch(e, 1, (size_t)Q * 8, &d_keys))) return rc;
+        std::memcpy(z.h_in, queries, (size_t)Q * L);
+        int64_t* zd_arg = (int64_t*)z.d_out;
+        int32_t* zd_dist = (int32_t*)(z.d_out + (size_t)Q * 8);
+        if ((rc = fx_launch_min_dist(e, mode, (const uint8_t*)z.d_in, Q, d_cache, C, L, (unsigned long long*)d_keys))) return rc;
+        if ((rc = fx_launch_min_dist_finish(e, (unsigned long long*)d_keys, Q, C, zd_dist, zd_arg))) return rc;
+        FX_HIP(e, hipStreamSynchronize(e->stream));
+        std::memcpy(argmin, z.h_out, (size_t)Q * 8);
+        std::memcpy(dist, z.h_out + (size_t)Q * 8, (size_t)Q * 4);
+        return FX_OK;
+    }
     for (int64_t q0 = 0; q0 < Q; q0 += 32768) {
         const int64_t qn = std::min<int64_t>(32768, Q - q0);
         void *d_q = nullptr, *d_res = nullptr;
@@ -1246,6 +1278,16 @@ int fx_table_lookup(fx_table* t, const uint8_t* ascii, int64_t N, int L, const u
     FX_HIP(e, hipSetDevice(e->device));
     void *d_in = nullptr, *d_out = nullptr;
     int rc;
+    if ((size_t)N * L + (size_t)N * 8 <= (size_t)e->zero_copy_bytes) {
+        FxZeroCopy z;
+        if ((rc = fx_zero_copy_buffers(e, (size_t)N * L + 16, (size_t)N * 8, &z))) return rc;
+        std::memcpy(z.h_in, ascii, (size_t)N * L);
+        if ((rc = fx_upload_lut(e, lut))) return rc;
+        if ((rc = fx_launch_table_lookup(e, t->d_table, t->len, (const uint8_t*)z.d_in, N, L, bits, (double*)z.d_out))) return rc;
+        FX_HIP(e, hipStreamSynchronize(e->stream));
+        std::memcpy(out, z.h_out, (size_t)N * 8);
+        return FX_OK;
+    }
     if ((rc = fx_scratch(e, 0, (size_t)N * L + 16, &d_in))) return rc;
     if ((rc = fx_scratch(e, 1, (size_t)N * 8, &d_out))) return rc;
     FX_HIP(e, hipMemcpyAsync(d_in, ascii, (size_t)N * L, hipMemcpyHostToDevice, e->stream));
@@ -1267,6 +1309,16 @@ int fx_table_additive(fx_table* t, const uint8_t* ascii, int64_t N, int L, const
     FX_HIP(e, hipSetDevice(e->device));
     void *d_in = nullptr, *d_out = nullptr;
     int rc;
+    if ((size_t)N * L + (size_t)N * 8 <= (size_t)e->zero_copy_bytes) {
+        FxZeroCopy z;
+        if ((rc = fx_zero_copy_buffers(e, (size_t)N * L + 16, (size_t)N * 8, &z))) return rc;
+        std::memcpy(z.h_in, ascii, (size_t)N * L);
+        if ((rc = fx_upload_lut(e, lut))) return rc;
+        if ((rc = fx_launch_additive_sum(e, t->d_table, L, ncol, (const uint8_t*)z.d_in, N, (double*)z.d_out))) return rc;
+        FX_HIP(e, hipStreamSynchronize(e->stream));
+        std::memcpy(out, z.h_out, (size_t)N * 8);
+        return FX_OK;
+    }
     if ((rc = fx_scratch(e, 0, (size_t)N * L + 16, &d_in))) return rc;
     if ((rc = fx_scratch(e, 1, (size_t)N * 8, &d_out))) return rc;
     FX_HIP(e, hipMemcpyAsync(d_in, ascii, (size_t)N * L, hipMemcpyHostToDevice, e->stream));
@@ -1286,6 +1338,20 @@ int fx_nam_combine(fx_engine* e, int64_t Q, const double* signal, const double* 
     const size_t qb = (size_t)Q * 8;
     void *d_in = nullptr, *d_out = nullptr;
     int rc;
+    if (3 * qb + (size_t)Q * 4 + (size_t)n_tab * 8 <= (size_t)e->zero_copy_bytes) {
+        FxZeroCopy z;
+        if ((rc = fx_zero_copy_buffers(e, 2 * qb + (size_t)n_tab * 8 + (size_t)Q * 4, qb, &z))) return rc;
+        const size_t o_tab = 2 * qb, o_d = 2 * qb + (size_t)n_tab * 8;
+        std::memcpy(z.h_in, signal, qb);
+        std::memcpy(z.h_in + qb, noise, qb);
+        std::memcpy(z.h_in + o_tab, alpha_tab, (size_t)n_tab * 8);
+        std::memcpy(z.h_in + o_d, d, (size_t)Q * 4);
+        if ((rc = fx_launch_nam_combine(e, Q, (const double*)z.d_in, (const double*)(z.d_in + qb), (const int32_t*)(z.d_in + o_d),
+                                        (const double*)(z.d_in + o_tab), n_tab, (double*)z.d_out))) return rc;
+        FX_HIP(e, hipStreamSynchronize(e->stream));
+        std::memcpy(out, z.h_out, qb);
+        return FX_OK;
+    }
     if ((rc = fx_scratch(e, 0, 2 * qb + (size_t)Q * 4 + (size_t)n_tab * 8 + 64, &d_in))) return rc;
     if ((rc = fx_scratch(e, 1, qb, &d_out))) return rc;
     char* base = (char*)d_in;
