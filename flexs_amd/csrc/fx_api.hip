@@ -1096,6 +1096,26 @@ int fx_decode_score(fx_engine* e, fx_model* const* models, int M, const double* 
     const size_t in_bytes = sizeof(double) * (size_t)rows * A;
     const size_t nm_bytes = sizeof(float) * (size_t)P * (size_t)M, mean_bytes = sizeof(float) * (size_t)P;
     void *d_in = nullptr, *d_out = nullptr, *d_txt = nullptr;
+    if (in_bytes + 256 + nm_bytes + mean_bytes + (size_t)rows <= (size_t)e->zero_copy_bytes) {
+        // a CMA-ES / DyNA-PPO population (15-40 members): the three kernels read and write mapped pinned memory, one wait
+        FxZeroCopy z;
+        const size_t o_chars = (nm_bytes + mean_bytes + 15) / 16 * 16;
+        if ((rc = fx_zero_copy_buffers(e, in_bytes + 256, o_chars + (size_t)rows + 16, &z))) return rc;
+        std::memcpy(z.h_in, one_hot, in_bytes);
+        std::memcpy(z.h_in + in_bytes, alphabet, (size_t)A);
+        if ((rc = fx_upload_lut(e, lut))) return rc;
+        float* z_NM = (float*)z.d_out;
+        float* z_mean = (float*)(z.d_out + nm_bytes);
+        uint8_t* z_chars = (uint8_t*)(z.d_out + o_chars);
+        if ((rc = fx_launch_argmax_decode(e, (const double*)z.d_in, rows, A, (const uint8_t*)(z.d_in + in_bytes), z_chars))) return rc;
+        if ((rc = score_dispatch(e, models, M, z_chars, P, L, z_NM))) return rc;
+        if (out_mean && (rc = fx_launch_ensemble_reduce(e, z_NM, P, M, nullptr, z_mean, nullptr))) return rc;
+        FX_HIP(e, hipStreamSynchronize(e->stream));
+        if (out_mean) std::memcpy(out_mean, z.h_out + nm_bytes, mean_bytes);
+        if (out_NM) std::memcpy(out_NM, z.h_out, nm_bytes);
+        std::memcpy(out_chars, z.h_out + o_chars, (size_t)rows);
+        return check_deferred(e);
+    }
     if ((rc = fx_scratch(e, 0, in_bytes, &d_in))) return rc;
     if ((rc = fx_scratch(e, 1, nm_bytes + mean_bytes, &d_out))) return rc;
     if ((rc = fx_scratch(e, 3, 256 + (size_t)rows + 16, &d_txt))) return rc;

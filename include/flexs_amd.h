@@ -94,7 +94,8 @@ const char *fx_last_error(fx_engine *e);
  *   trace             0        1 = the MFMA scoring kernels stamp an in-kernel timeline (fx_debug_trace_read; needs the
  *                              `make trace` build).
  *   zero_copy_bytes   262144   host calls whose input + output fit in this many bytes read / write mapped pinned
- *                              host memory directly (explorer-size calls: no copy enqueues).
+ *                              host memory directly (explorer-size calls: no copy enqueues) -- fx_score, and since
+ *                              round 3 fx_decode_score, fx_min_dist / fx_cache_min_dist, fx_nam_combine, fx_table_*.
  *   zero_copy_mode    -1       larger host calls: -1 = decide per call (fx_plan_host_call), 0 = always copy,
  *                              1 = always zero-copy.
  *   serve_small       1        1 = explorer-size fx_score calls (<= 256 sequences, <= 16 KiB of sequence bytes) of
