@@ -1048,6 +1048,18 @@ int fx_ensemble_reduce(fx_engine* e, const float* scores, int64_t N, int M, cons
     const size_t out_bytes = (weights ? sizeof(double) : sizeof(float)) * (size_t)N;
     void *d_in = nullptr, *d_out = nullptr;
     int rc;
+    if (in_bytes + out_bytes <= (size_t)e->zero_copy_bytes) {
+        FxZeroCopy z;
+        const size_t o_w = (in_bytes + 15) / 16 * 16;
+        if ((rc = fx_zero_copy_buffers(e, o_w + sizeof(double) * (size_t)M, out_bytes, &z))) return rc;
+        std::memcpy(z.h_in, scores, in_bytes);
+        if (weights) std::memcpy(z.h_in + o_w, weights, sizeof(double) * (size_t)M);
+        if ((rc = fx_launch_ensemble_reduce(e, (const float*)z.d_in, N, M, weights ? (const double*)(z.d_in + o_w) : nullptr,
+                                            (float*)z.d_out, (double*)z.d_out))) return rc;
+        FX_HIP(e, hipStreamSynchronize(e->stream));
+        std::memcpy(weights ? (void*)out64 : (void*)out32, z.h_out, out_bytes);
+        return FX_OK;
+    }
     if ((rc = fx_scratch(e, 0, in_bytes, &d_in))) return rc;
     if ((rc = fx_scratch(e, 1, out_bytes, &d_out))) return rc;
     FX_HIP(e, hipMemcpyAsync(d_in, scores, in_bytes, hipMemcpyHostToDevice, e->stream));
