@@ -72,6 +72,7 @@ SIGNATURES = {
     "fx_cache_size": (C.c_int64, [_vp]),
     "fx_cache_append": (C.c_int, [_vp, _vp, C.c_int64]),
     "fx_cache_min_dist": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, _vp, _vp]),
+    "fx_cache_nam_query": (C.c_int, [_vp, _vp, C.c_int, _u8p, C.c_int, _vp, C.c_int64, _vp, C.c_int64, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "fx_cache_distances": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, _vp]),
     "fx_table_create": (C.c_int, [_vp, _vp, C.c_int64, C.POINTER(_vp)]),
     "fx_table_destroy": (C.c_int, [_vp]),
@@ -611,6 +612,25 @@ class NativeCache:
         arg = np.empty(Q, np.int64)
         self.engine.check(self.engine._lib.fx_cache_min_dist(self.handle, mode, _ptr(q), Q, _ptr(dist), _ptr(arg)))
         return dist, arg
+
+    def nam_query(self, table: "NativeTable", queries: np.ndarray, E: np.ndarray, alpha_tab: np.ndarray, mode: int = FX_LEVENSHTEIN,
+                  append: Optional[np.ndarray] = None):
+        """NoisyAbstractModel's batch on a table landscape in one device round trip (fx_cache_nam_query): returns
+        (fitness float64, distance int32, nearest-neighbour index int64, flags int32).  `append`: rows that join the
+        cache before the search (as `append`)."""
+        q = np.ascontiguousarray(queries, np.uint8)
+        Q = q.shape[0]
+        app = None if append is None or append.shape[0] == 0 else np.ascontiguousarray(append, np.uint8)
+        E = np.ascontiguousarray(E, np.float64)
+        tab = np.ascontiguousarray(alpha_tab, np.float64)
+        out = np.empty(Q, np.float64)
+        dist = np.empty(Q, np.int32)
+        arg = np.empty(Q, np.int64)
+        flags = np.empty(Q, np.int32)
+        self.engine.check(self.engine._lib.fx_cache_nam_query(self.handle, table.handle, table.bits, _lut_ptr(table.lut), mode,
+                                                              _ptr(app), 0 if app is None else app.shape[0], _ptr(q), Q,
+                                                              _ptr(E), _ptr(tab), tab.shape[0], _ptr(out), _ptr(dist), _ptr(arg), _ptr(flags)))
+        return out, dist, arg, flags
 
     def time_min_dist(self, queries: np.ndarray, mode: int = FX_LEVENSHTEIN, reps: int = 10) -> float:
         """Total milliseconds of `reps` back-to-back neighbour-search launches (fx_debug_time_min_dist, issued from C)."""

@@ -44,6 +44,22 @@ class _CacheDict(dict):
         self.removals += 1
 
 
+def _rng_checkpoint():
+    """Returns restore(): puts NumPy's global RNG back where it is now.  `np.random.get_state()` costs ~40 us (it builds a
+    tuple around a copy of the 624-word state) -- more than the device round trip it guards; for the stock MT19937 bit
+    generator the 2500 bytes of its state struct (key[624] + pos; the legacy Gaussian cache is not touched by exponential
+    draws) are copied directly instead."""
+    import ctypes
+
+    bg = np.random.mtrand._rand._bit_generator
+    if type(bg).__name__ == "MT19937":
+        addr, size = bg.ctypes.state_address, 624 * 4 + 4
+        saved = ctypes.string_at(addr, size)
+        return lambda: ctypes.memmove(addr, saved, size)
+    state = np.random.get_state()
+    return lambda: np.random.set_state(state)
+
+
 class NoisyAbstractModel(flexs_amd.Model):
     def __init__(self, landscape: flexs_amd.Landscape, signal_strength: float = 0.9, distance: str = "levenshtein",
                  device: int = None):
@@ -75,8 +91,10 @@ class NoisyAbstractModel(flexs_amd.Model):
             return _native.sequences_to_bytes(seqs, L=L)
         return _native.ragged_to_bytes(seqs, L)
 
-    def _sync_device_cache(self, min_row: int):
-        """Bring the device copy of `list(self.cache)` up to date; rows hold at least `min_row` bytes."""
+    def _sync_device_cache(self, min_row: int, defer: bool = False):
+        """Bring the device copy of `list(self.cache)` up to date; rows hold at least `min_row` bytes.  `defer`: the keys
+        added since the last call are not appended here but returned as rows for the caller's next device call to append
+        (fx_cache_nam_query takes them along); None when nothing is pending."""
         import itertools
 
         keys = self.cache.keys()
@@ -100,8 +118,12 @@ class NoisyAbstractModel(flexs_amd.Model):
             self._dev_cache = self._new_device_cache(need)
             self._dev_keys = []
         if fresh:
-            self._dev_cache.append(self._rows(fresh, self._dev_cache.L))
+            rows = self._rows(fresh, self._dev_cache.L)
             self._dev_keys.extend(fresh)
+            if defer and not stale:
+                return rows
+            self._dev_cache.append(rows)
+        return None
 
     def _new_device_cache(self, row_bytes: int):
         """Key store with `.L`, `.append(rows)` and `.min_dist(rows, mode)`; the multi-GPU model
@@ -123,6 +145,55 @@ class NoisyAbstractModel(flexs_amd.Model):
         self._sync_device_cache(max(len(s) for s in sequences))
         dist, arg = self._dev_cache.min_dist(self._rows(sequences, self._dev_cache.L), self._mode)
         return dist, [self._dev_keys[i] for i in arg]
+
+    def _alpha_tab(self, L: int) -> np.ndarray:
+        """ss ** d for d = 0..L (:93, Python float pow), kept while ss and L stay the same."""
+        c = getattr(self, "_alpha_cache", None)
+        if c is None or c[0] != (self.ss, L):
+            c = self._alpha_cache = ((self.ss, L), np.array([self.ss ** d for d in range(L + 1)], np.float64))
+        return c[1]
+
+    def _fused_table_batch(self, new_seqs):
+        """The uncached part of a batch in ONE device round trip (fx_cache_nam_query) when the landscape is a device table of
+        packed k-mers (flexs_amd.landscapes.TFBinding) on this model's engine: neighbour search, both look-ups and the blend
+        stay on the device; the RNG draws are made here, in query order, exactly as `np.random.exponential(scale=...)`
+        makes them.  None = not applicable, or a case whose draws the reference makes differently (a negative neighbour
+        value, a sequence missing from the table): the RNG state is put back and the general path below decides."""
+        table_of = getattr(self.landscape, "_native_table", None)
+        if table_of is None or not getattr(self.landscape, "batch_safe", False) or len(self.cache) == 0 or type(self) is not NoisyAbstractModel:
+            return None
+        L = getattr(self.landscape, "_L", None)
+        if L is None or any(len(s) != L for s in new_seqs):
+            return None
+        try:
+            table = table_of()
+        except Exception:  # noqa: BLE001 - the general path reports what is wrong with the landscape
+            return None
+        if not table.bits or table.engine is not _native.Engine.get(self._device):
+            return None
+        pending = self._sync_device_cache(L, defer=True)              # the previous batch's sequences ride along with this call
+        try:
+            if self._dev_cache.L != L:
+                raise ValueError("cache rows wider than the landscape's sequences")
+            rows = _native.sequences_to_bytes(new_seqs, L=L)
+        except ValueError:
+            if pending is not None:
+                self._dev_cache.append(pending)
+            return None
+        restore = _rng_checkpoint()
+        E = np.random.standard_exponential(len(new_seqs))              # scale * E[i] is np.random.exponential(scale)[i]
+        alpha_tab = self._alpha_tab(L)
+        try:
+            fit, dist, arg, flags = self._dev_cache.nam_query(table, rows, E, alpha_tab, self._mode, append=pending)
+        except BaseException:
+            self._dev_cache = None                                      # (whether the pending keys arrived is unknown: rebuild on next use)
+            restore()
+            raise
+        if flags.any():
+            restore()
+            return None
+        self.landscape.cost += 2 * len(new_seqs)                       # the two oracle queries per sequence (:86-87)
+        return fit
 
     # ---------------------------------------------------------------- flexs.Model API
     def train(self, sequences: SEQUENCES_TYPE, labels: np.ndarray):
@@ -146,6 +217,11 @@ class NoisyAbstractModel(flexs_amd.Model):
 
         if new_idx:
             new_seqs = [seqs[i] for i in new_idx]
+            new_fit = self._fused_table_batch(new_seqs)
+            if new_fit is not None:
+                fitnesses[new_idx] = new_fit
+                cache.update(zip(new_seqs, new_fit))                   # :99
+                return fitnesses
             if len(cache) == 0:                                        # :44-45
                 dist = np.zeros(len(new_seqs), np.int32)
                 neighbours = new_seqs

@@ -1259,6 +1259,81 @@ int fx_cache_min_dist(fx_cache* c, int mode, const uint8_t* queries, int64_t Q, 
     return min_dist_common(e, mode, queries, Q, c->d_keys, c->size, c->L, dist, argmin);
 }
 
+int fx_cache_nam_query(fx_cache* c, fx_table* t, int bits, const uint8_t lut[256], int mode, const uint8_t* append_keys,
+                       int64_t n_append, const uint8_t* queries, int64_t Q, const double* E, const double* alpha_tab, int n_tab,
+                       double* out, int32_t* dist, int64_t* argmin, int32_t* flags) {
+    if (!c || !t || Q < 0 || n_append < 0 || n_tab < 1 || !lut || bits < 1 || bits > 8) return FX_EINVAL;
+    if (n_append > 0 && !append_keys) return FX_EINVAL;
+    fx_engine* e = c->eng;
+    if (t->eng != e) return fx_fail(e, FX_EINVAL, "table and cache belong to different engines");
+    if ((int64_t)bits * c->L > 40) return fx_fail(e, FX_EINVAL, "sequence too long for a packed-k-mer table");
+    if (mode != FX_LEVENSHTEIN && mode != FX_HAMMING) return fx_fail(e, FX_EINVAL, "unknown distance mode");
+    if (Q == 0) return n_append ? fx_cache_append(c, append_keys, n_append) : FX_OK;
+    if (!queries || !E || !alpha_tab || !out || !dist || !argmin || !flags) return fx_fail(e, FX_EINVAL, "null buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    const int L = c->L;
+    // the keys cached since the last call (the previous batch's sequences) join the cache first: in the same submission when
+    // they fit the staging area and the cache has room, else by fx_cache_append (a synchronous copy)
+    const size_t app_bytes = (size_t)n_append * std::max(L, 1);
+    const bool app_inline = n_append > 0 && c->size + n_append <= c->capacity &&
+                            app_bytes + (size_t)Q * (L + 36) + (size_t)n_tab * 8 + 64 <= (size_t)e->zero_copy_bytes;
+    if (n_append > 0 && !app_inline) {
+        const int rc0 = fx_cache_append(c, append_keys, n_append);
+        if (rc0) return rc0;
+    }
+    // inputs: queries | E | alpha table; outputs: out | argmin | dist | flags -- mapped pinned memory when the batch is of
+    // explorer size, device scratch + copies otherwise; the neighbour keys never leave the device
+    const size_t o_E = ((size_t)Q * L + 15) / 16 * 16, o_tab = o_E + (size_t)Q * 8, o_app = o_tab + ((size_t)n_tab * 8 + 15) / 16 * 16,
+                 in_bytes = o_app + (app_inline ? app_bytes : 0);
+    const size_t o_arg = (size_t)Q * 8, o_dist = 2 * (size_t)Q * 8, o_flags = o_dist + (size_t)Q * 4, out_bytes = o_flags + (size_t)Q * 4;
+    int rc;
+    char *h_in = nullptr, *d_in = nullptr, *h_out = nullptr, *d_out = nullptr;
+    const bool zc = in_bytes + out_bytes <= (size_t)e->zero_copy_bytes;
+    FxZeroCopy z{};
+    if ((rc = fx_zero_copy_buffers(e, in_bytes, out_bytes, &z))) return rc;     // (staging for the copy path too)
+    h_in = z.h_in; h_out = z.h_out;
+    if (zc) { d_in = z.d_in; d_out = z.d_out; }
+    else {
+        void *p0 = nullptr, *p1 = nullptr;
+        if ((rc = fx_scratch(e, 0, in_bytes + 16, &p0))) return rc;
+        if ((rc = fx_scratch(e, 3, out_bytes + 16, &p1))) return rc;
+        d_in = (char*)p0; d_out = (char*)p1;
+    }
+    std::memcpy(h_in, queries, (size_t)Q * L);
+    std::memcpy(h_in + o_E, E, (size_t)Q * 8);
+    std::memcpy(h_in + o_tab, alpha_tab, (size_t)n_tab * 8);
+    if (app_inline) {
+        std::memcpy(h_in + o_app, append_keys, app_bytes);
+        FX_HIP(e, hipMemcpyAsync(c->d_keys + (size_t)c->size * std::max(L, 1), h_in + o_app, app_bytes, hipMemcpyHostToDevice, e->stream));
+        c->size += n_append;
+    }
+    const int64_t C_ = c->size;
+    if (!zc) FX_HIP(e, hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, e->stream));
+    if ((rc = fx_upload_lut(e, lut))) return rc;
+    int64_t* d_arg = (int64_t*)(d_out + o_arg);
+    int32_t* d_dist = (int32_t*)(d_out + o_dist);
+    if (C_ > 0) {
+        void* d_keys = nullptr;
+        if ((rc = fx_scratch(e, 1, (size_t)Q * 8, &d_keys))) return rc;
+        e->counters.pair_evals += Q * C_;
+        if ((rc = fx_launch_min_dist(e, mode, (const uint8_t*)d_in, Q, c->d_keys, C_, L, (unsigned long long*)d_keys))) return rc;
+        if ((rc = fx_launch_min_dist_finish(e, (unsigned long long*)d_keys, Q, C_, d_dist, d_arg))) return rc;
+    } else {
+        FX_HIP(e, hipMemsetAsync(d_dist, 0, (size_t)Q * 4, e->stream));            // noisy_abstract_model.py:44-45
+        FX_HIP(e, hipMemsetAsync(d_arg, 0xFF, (size_t)Q * 8, e->stream));          // -1: the query itself
+    }
+    if ((rc = fx_launch_nam_table_blend(e, Q, (const uint8_t*)d_in, c->d_keys, d_arg, d_dist, t->d_table, t->len, L, bits,
+                                        (const double*)(d_in + o_E), (const double*)(d_in + o_tab), n_tab, (double*)d_out,
+                                        (int32_t*)(d_out + o_flags)))) return rc;
+    if (!zc) FX_HIP(e, hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, e->stream));
+    FX_HIP(e, hipStreamSynchronize(e->stream));
+    std::memcpy(out, h_out, (size_t)Q * 8);
+    std::memcpy(argmin, h_out + o_arg, (size_t)Q * 8);
+    std::memcpy(dist, h_out + o_dist, (size_t)Q * 4);
+    std::memcpy(flags, h_out + o_flags, (size_t)Q * 4);
+    return FX_OK;
+}
+
 int fx_cache_distances(fx_cache* c, int mode, const uint8_t* queries, int64_t Q, uint8_t* out) {
     if (!c || Q < 0) return FX_EINVAL;
     fx_engine* e = c->eng;

@@ -326,6 +326,9 @@ int fx_launch_distances(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, c
                         int L, uint8_t* d_out);
 int fx_launch_additive_sum(fx_engine* e, const double* d_table, int L, int ncol, const uint8_t* d_ascii, int64_t N,
                            double* d_out);
+int fx_launch_nam_table_blend(fx_engine* e, int64_t Q, const uint8_t* d_queries, const uint8_t* d_keys, const int64_t* d_arg,
+                              const int32_t* d_dist, const double* d_table, int64_t len, int L, int bits, const double* d_E,
+                              const double* d_alpha, int n_tab, double* d_out, int32_t* d_flags);
 int fx_launch_table_lookup(fx_engine* e, const double* d_table, int64_t len, const uint8_t* d_ascii, int64_t N,
                            int L, int bits, double* d_out);
 int fx_launch_min_dist_finish(fx_engine* e, const unsigned long long* d_keys, int64_t Q, int64_t C,

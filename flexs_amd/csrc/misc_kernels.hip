@@ -224,6 +224,53 @@ inline unsigned grid_for(int64_t n, int block, int cus) {
 
 }  // namespace
 
+// ---- NoisyAbstractModel on a table landscape, everything behind the neighbour search in one kernel
+// (noisy_abstract_model.py:86-94): signal = table[query], scale = table[nearest cached neighbour], noise = scale x E (what
+// np.random.exponential(scale) returns for the standard-exponential draw E), out = alpha^d signal + (1 - alpha^d) noise --
+// the look-up of k_table_lookup and the operation order of k_nam_combine.  flags: 1 = query or neighbour not in the table,
+// 2 = negative neighbour value (the reference then draws from the cache instead: the caller redoes the batch).
+__global__ void k_nam_table_blend(int64_t Q, const uint8_t* __restrict__ queries, const uint8_t* __restrict__ keys,
+                                  const int64_t* __restrict__ arg, const int32_t* __restrict__ d,
+                                  const double* __restrict__ table, int64_t len, const uint8_t* __restrict__ lut, int L, int bits,
+                                  const double* __restrict__ E, const double* __restrict__ alpha_tab, int n_tab,
+                                  double* __restrict__ out, int32_t* __restrict__ flags) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < Q; i += (int64_t)gridDim.x * blockDim.x) {
+        auto look = [&](const uint8_t* row) {
+            int64_t idx = 0;
+            bool ok = true;
+            for (int k = 0; k < L; ++k) {
+                const int c = lut[row[k]];
+                ok &= (c != 0xFF);
+                idx |= (int64_t)(c & ((1 << bits) - 1)) << (bits * k);
+            }
+            return (ok && idx < len) ? table[idx] : __longlong_as_double(0x7ff8000000000000ll);
+        };
+        const int64_t j = arg[i];
+        const double sig = look(queries + i * L);
+        const double nbf = j >= 0 ? look(keys + j * L) : sig;          // (empty cache: the query is its own neighbour)
+        int f = 0;
+        if (sig != sig || nbf != nbf) f |= 1;
+        if (nbf < 0.0) f |= 2;
+        flags[i] = f;
+        int di = d[i];
+        di = di < 0 ? 0 : (di >= n_tab ? n_tab - 1 : di);
+        const double alpha = alpha_tab[di];
+        const double noise = __dmul_rn(nbf, E[i]);
+        out[i] = __dadd_rn(__dmul_rn(alpha, sig), __dmul_rn(1.0 - alpha, noise));
+    }
+}
+
+int fx_launch_nam_table_blend(fx_engine* e, int64_t Q, const uint8_t* d_queries, const uint8_t* d_keys, const int64_t* d_arg,
+                              const int32_t* d_dist, const double* d_table, int64_t len, int L, int bits, const double* d_E,
+                              const double* d_alpha, int n_tab, double* d_out, int32_t* d_flags) {
+    if (Q == 0) return FX_OK;
+    dim3 grid(grid_for(Q, 256, e->num_cus)), block(256);
+    hipLaunchKernelGGL(k_nam_table_blend, grid, block, 0, e->stream, Q, d_queries, d_keys, d_arg, d_dist, d_table, len, e->d_lut, L, bits,
+                       d_E, d_alpha, n_tab, d_out, d_flags);
+    FX_HIP(e, hipGetLastError());
+    return FX_OK;
+}
+
 int fx_launch_table_lookup(fx_engine* e, const double* d_table, int64_t len, const uint8_t* d_ascii, int64_t N,
                            int L, int bits, double* d_out) {
     if (N == 0) return FX_OK;

@@ -253,6 +253,19 @@ int64_t fx_cache_size(const fx_cache *c);
 int fx_cache_append(fx_cache *c, const uint8_t *keys, int64_t n);
 int fx_cache_min_dist(fx_cache *c, int mode, const uint8_t *queries, int64_t Q, int32_t *dist,
                       int64_t *argmin);
+/* NoisyAbstractModel's whole batch on a table landscape in ONE device round trip (noisy_abstract_model.py:69-94 with
+ * flexs/landscapes/tf_binding.py:43-44 as the landscape): nearest cached neighbour of every query (as fx_cache_min_dist;
+ * rows of fx_cache L bytes), the table's value of the query and of its neighbour (as fx_table_lookup with `bits`, `lut`),
+ * noise = neighbour value x E[q] (E: the caller's standard-exponential draws, query order -- what
+ * np.random.exponential(scale = neighbour value) returns), out[q] = alpha_tab[d] signal + (1 - alpha_tab[d]) noise
+ * (as fx_nam_combine).  flags[q]: bit 0 = query or neighbour missing from the table (KeyError in the reference),
+ * bit 1 = negative neighbour value (the reference then draws from the cache, :90-91) -- in either case the caller
+ * restores its RNG state and takes the general path.  An empty cache: distance 0, the query is its own neighbour.
+ * append_keys (n_append rows, may be 0): keys that join the cache before the search, as by fx_cache_append -- the
+ * sequences the previous batch cached -- in the same submission when they fit the staging area. */
+int fx_cache_nam_query(fx_cache *c, fx_table *t, int bits, const uint8_t lut[256], int mode, const uint8_t *append_keys,
+                       int64_t n_append, const uint8_t *queries, int64_t Q, const double *E, const double *alpha_tab,
+                       int n_tab, double *out, int32_t *dist, int64_t *argmin, int32_t *flags);
 /* noisy_abstract_model.py:88-94 for Q uncached queries:
  *   out[i] = alpha_tab[d[i]] * signal[i] + (1 - alpha_tab[d[i]]) * noise[i]
  * with alpha_tab[k] = ss ** k built on the host (Python float pow) and

@@ -1954,3 +1954,75 @@ def test_shared_last_tiles_of_the_dense_kernel_give_the_same_bits(eng, kind, L, 
     finally:
         eng.set_option("dense_coop", 1)
         eng.set_option("dense_small", 1)
+
+
+def test_nam_fused_table_batch_and_its_fallbacks(eng):
+    """`NoisyAbstractModel` over a device table landscape answers the uncached part of a batch in one device round trip
+    (fx_cache_nam_query: neighbour search + both look-ups + blend, RNG draws made on the host in query order).  Against
+    the same landscape behind a plain wrapper (the reference's one-by-one loop): same values, same cache order, same
+    landscape cost and the same position of NumPy's global RNG afterwards -- also when the fused call has to hand the
+    batch back (a negative neighbour value: the reference draws from the cache instead; a sequence the table does not
+    hold: KeyError)."""
+    L = 6
+    rng = np.random.default_rng(3)
+    vals = rng.uniform(0.0, 1.0, 4 ** L)
+    neg = rng.random(4 ** L) < 0.02
+    vals[neg] = -rng.uniform(0.1, 1.0, int(neg.sum()))              # a few negative fitnesses
+    missing_idx = int(np.flatnonzero(~neg)[7])
+    vals[missing_idx] = np.nan                                       # one k-mer the table does not hold
+    all_seqs = ["".join("ACGT"[(i >> (2 * k)) & 3] for k in range(L)) for i in range(4 ** L)]
+
+    class Table(flexs_amd.Landscape):
+        batch_safe = True
+
+        def __init__(self):
+            super().__init__("table")
+            self._L = L
+            self._t = None
+
+        def _native_table(self):
+            if self._t is None:
+                self._t = _native.NativeTable(_native.Engine.get(None), vals, "ACGT", bits=2)
+            return self._t
+
+        def _fitness_function(self, seqs):
+            out = self._native_table().lookup(_native.sequences_to_bytes([str(s) for s in seqs], L=L))
+            if np.isnan(out).any():
+                raise KeyError(str(seqs[int(np.flatnonzero(np.isnan(out))[0])]))
+            return out
+
+    class Plain(flexs_amd.Landscape):                                # same values, the one-by-one path
+        def __init__(self, inner):
+            super().__init__("plain")
+            self.inner = inner
+
+        def _fitness_function(self, seqs):
+            return self.inner._fitness_function(seqs)
+
+    order = rng.permutation(4 ** L)
+    order = order[order != missing_idx]
+    pos_first = [all_seqs[i] for i in order if vals[i] >= 0][:40]    # training set without negative values
+    pool = [all_seqs[i] for i in order]
+    outs = []
+    for wrap in (False, True):
+        land = Table()
+        target = Plain(land) if wrap else land
+        np.random.seed(11)
+        nam = bm.NoisyAbstractModel(target, 0.8)
+        nam.train(pos_first, land._fitness_function(pos_first))
+        res = []
+        for i in range(12):                                          # batches of 1-60 sequences, some with negative neighbours later on
+            n = (1, 3, 20, 60)[i % 4]
+            res.append(nam.get_fitness(pool[100 + 60 * i: 100 + 60 * i + n]))
+        res.append(nam.get_fitness(pool[90:200]))                    # mostly cached
+        res.append(nam.get_fitness(pool[1000:1030]))
+        outs.append((np.concatenate(res), target.cost, float(np.random.random()), list(nam.cache), list(nam.cache.values())))
+        # a sequence the table does not hold: the reference's KeyError, nothing cached (what the RNG has consumed by then
+        # differs between a batched and a one-by-one landscape by construction, so this comes last)
+        n_cached = len(nam.cache)
+        with pytest.raises(KeyError):
+            nam.get_fitness(pool[900:905] + [all_seqs[missing_idx]] + pool[905:910])
+        assert len(nam.cache) == n_cached
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert outs[0][1:] == outs[1][1:]
+    assert (np.array(outs[0][4]) < 0).any(), "the scenario never produced a negative cached fitness: the fallback was not exercised"

@@ -486,3 +486,33 @@ def test_score_small_packs_and_calls_through_the_plan():
     assert _native._strpack.score_small(plan, np.array(["ACGT"]), out) == -1          # not a list / tuple
     n_calls = len(seen)
     assert _native._strpack.score_small(plan, [], out) == -1 and len(seen) == n_calls
+
+
+def test_rng_checkpoint_puts_numpys_global_stream_back():
+    """noisy_abstract_model._rng_checkpoint (the fused NoisyAbstractModel batch draws before it knows whether the batch is
+    its to answer): after restore() the global legacy RNG is exactly where it was -- also across the 624-word refill --
+    and `np.random.exponential(scale=array)` is `scale * standard_exponential(size)` draw for draw."""
+    from flexs_amd.baselines.models.noisy_abstract_model import _rng_checkpoint
+
+    def same(a, b):
+        return all(np.array_equal(x, y) if isinstance(x, np.ndarray) else x == y for x, y in zip(a, b))
+
+    for seed, burn, draws in ((7, 1000, 37), (8, 310, 500), (9, 0, 1), (10, 623, 2)):
+        np.random.seed(seed)
+        np.random.random(burn)
+        np.random.standard_normal(1)                       # (leaves a cached Gaussian behind: must survive too)
+        before = np.random.get_state()
+        restore = _rng_checkpoint()
+        first = np.random.standard_exponential(draws)
+        restore()
+        assert same(before, np.random.get_state())
+        assert np.array_equal(np.random.standard_exponential(draws), first)
+    for seed in range(4):
+        scale = np.random.default_rng(seed).random(50) * 3
+        scale[3] = 0.0
+        np.random.seed(seed)
+        a = np.random.exponential(scale=scale)
+        pos_a = np.random.get_state()[2]
+        np.random.seed(seed)
+        b = scale * np.random.standard_exponential(50)
+        assert np.array_equal(a, b) and np.random.get_state()[2] == pos_a
