@@ -300,6 +300,38 @@ def nam_block(eng, device):
             ts.append(time.perf_counter() - t0)
         out[name] = {"value": 2000 / ts[-1], "unit": "sequences/s", "wall_ms": ts[-1] * 1e3, "cache_after": len(model.cache),
                      "oracle_calls": int(model.landscape.cost)}
+    # the same pattern over a DEVICE table landscape (TF-binding style: every 8-mer has a value; flexs_amd.landscapes.TFBinding
+    # keeps such a table on the GPU): the whole uncached batch is one device round trip (fx_cache_nam_query)
+    class _Table(flexs_amd.Landscape):
+        batch_safe = True
+
+        def __init__(self):
+            super().__init__("table")
+            self._L, self._t = 8, None
+            self._vals = np.random.default_rng(3).random(4 ** 8)
+
+        def _native_table(self):
+            if self._t is None:
+                self._t = _native.NativeTable(_native.Engine.get(device), self._vals, "ACGT", bits=2)
+            return self._t
+
+        def _fitness_function(self, seqs):
+            return self._native_table().lookup(_native.sequences_to_bytes([str(s_) for s_ in seqs], L=8))
+
+    ts = []
+    for rep in range(2):
+        np.random.seed(0)
+        model = NoisyAbstractModel(_Table(), 0.9, device=device)
+        model.train(synth.bytes_to_strings(synth.random_sequence_bytes(1000, 8, "ACGT", 5)), np.random.random(1000))
+        batches = [synth.bytes_to_strings(synth.random_sequence_bytes(100, 8, "ACGT", 100 + c)) for c in range(20)]
+        t0 = time.perf_counter()
+        for bch in batches:
+            model.get_fitness(bch)
+        ts.append(time.perf_counter() - t0)
+    out["device_table_landscape_L8"] = {"value": 2000 / ts[-1], "unit": "sequences/s", "wall_ms": ts[-1] * 1e3, "cache_after": len(model.cache),
+                                        "oracle_calls": int(model.landscape.cost),
+                                        "what": "TF-binding style table of all 8-mers on the device: neighbour search + both look-ups + blend "
+                                                "of a batch in one device round trip (fx_cache_nam_query), RNG draws on the host"}
     out["what"] = ("NoisyAbstractModel(ss=0.9).get_fitness, RNA L=14, CbAS pattern: 20 calls x 100 sequences, cache 1000 -> ~3000. "
                    "Host-bound by construction: per call one K4 launch (~20 us) + K5, but the 2 oracle calls and the RNG draw "
                    "per uncached query stay in a Python loop in the reference's order (plain landscape); a batch_safe landscape "
