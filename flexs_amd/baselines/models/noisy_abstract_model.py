@@ -163,7 +163,7 @@ class NoisyAbstractModel(flexs_amd.Model):
         if table_of is None or not getattr(self.landscape, "batch_safe", False) or len(self.cache) == 0 or type(self) is not NoisyAbstractModel:
             return None
         L = getattr(self.landscape, "_L", None)
-        if L is None or any(len(s) != L for s in new_seqs):
+        if L is None or len(new_seqs) > 32768 or any(len(s) != L for s in new_seqs):
             return None
         try:
             table = table_of()

@@ -1269,6 +1269,7 @@ int fx_cache_nam_query(fx_cache* c, fx_table* t, int bits, const uint8_t lut[256
     if ((int64_t)bits * c->L > 40) return fx_fail(e, FX_EINVAL, "sequence too long for a packed-k-mer table");
     if (mode != FX_LEVENSHTEIN && mode != FX_HAMMING) return fx_fail(e, FX_EINVAL, "unknown distance mode");
     if (Q == 0) return n_append ? fx_cache_append(c, append_keys, n_append) : FX_OK;
+    if (Q > 32768) return fx_fail(e, FX_EUNSUPPORTED, "fx_cache_nam_query: at most 32768 queries per call (fx_cache_min_dist batches larger sets)");
     if (!queries || !E || !alpha_tab || !out || !dist || !argmin || !flags) return fx_fail(e, FX_EINVAL, "null buffer");
     FX_HIP(e, hipSetDevice(e->device));
     const int L = c->L;

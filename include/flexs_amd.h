@@ -262,7 +262,7 @@ int fx_cache_min_dist(fx_cache *c, int mode, const uint8_t *queries, int64_t Q, 
  * bit 1 = negative neighbour value (the reference then draws from the cache, :90-91) -- in either case the caller
  * restores its RNG state and takes the general path.  An empty cache: distance 0, the query is its own neighbour.
  * append_keys (n_append rows, may be 0): keys that join the cache before the search, as by fx_cache_append -- the
- * sequences the previous batch cached -- in the same submission when they fit the staging area. */
+ * sequences the previous batch cached -- in the same submission when they fit the staging area.  Q <= 32768. */
 int fx_cache_nam_query(fx_cache *c, fx_table *t, int bits, const uint8_t lut[256], int mode, const uint8_t *append_keys,
                        int64_t n_append, const uint8_t *queries, int64_t Q, const double *E, const double *alpha_tab,
                        int n_tab, double *out, int32_t *dist, int64_t *argmin, int32_t *flags);
