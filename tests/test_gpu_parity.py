@@ -2016,6 +2016,13 @@ def test_nam_fused_table_batch_and_its_fallbacks(eng):
             res.append(nam.get_fitness(pool[100 + 60 * i: 100 + 60 * i + n]))
         res.append(nam.get_fitness(pool[90:200]))                    # mostly cached
         res.append(nam.get_fitness(pool[1000:1030]))
+        eng.set_option("zero_copy_bytes", 2048)                      # a batch beyond the mapped staging area: the copy path
+        try:
+            res.append(nam.get_fitness(pool[1030:2500]))
+            res.append(nam.get_fitness(pool[2500:2510]))              # (small again: but the pending keys no longer fit inline)
+        finally:
+            eng.set_option("zero_copy_bytes", 262144)
+        res.append(nam.get_fitness(pool[2510:3900]))
         outs.append((np.concatenate(res), target.cost, float(np.random.random()), list(nam.cache), list(nam.cache.values())))
         # a sequence the table does not hold: the reference's KeyError, nothing cached (what the RNG has consumed by then
         # differs between a batched and a one-by-one landscape by construction, so this comes last)
