@@ -768,7 +768,9 @@ static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8
     sv.t_post = t0;
     // (the first request of a generation also waits for the launch and the weight fill -- and the very first one of the
     //  process for the runtime to create the high-priority hardware queue and load the kernels: ~0.3 s, once)
-    const double limit = sv.fresh ? 3.0 : 0.002;
+    // (later requests: a resident workgroup answers within microseconds and one that left says so through its `alive` word;
+    //  the limit only catches a device that has stopped making progress -- or is time-sliced away to another process)
+    const double limit = sv.fresh ? 3.0 : 0.02;
     const FxMailOut* h = sv.h_out;
     bool bad = false;
     float x[FX_MAX_M];
@@ -780,6 +782,9 @@ static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8
                 if ((++spins & 1023u) == 0) {
                     const bool gone = !sv.fresh && !h->alive[m][n >> 4];
                     const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    // (this thread may have been off the core for milliseconds between the read above and this clock: look again
+                    //  before giving up on an answer that has arrived meanwhile)
+                    if ((gone || waited > limit) && (((a = h->ans[m][n]) >> 32) & 0x7FFFFFFFull) == seq) break;
                     if (gone || waited > limit) {
                         server_stop(e);                    // fall back to a launch; the next calls start a new generation
                         sv.fallbacks += 1;

