@@ -2049,3 +2049,70 @@ def test_nam_fused_table_batch_and_its_fallbacks(eng):
     assert np.array_equal(outs[0][0], outs[1][0])
     assert outs[0][1:] == outs[1][1:]
     assert (np.array(outs[0][4]) < 0).any(), "the scenario never produced a negative cached fitness: the fallback was not exercised"
+
+
+def test_small_call_fast_path_bookkeeping(eng):
+    """The Python side of explorer-size calls (one C call on an argument block cached per model list): the block follows the
+    member list when it is edited, copies and pickles carry no device handles, costs are charged as by the general path, every
+    input form the general path takes is taken, and errors are the general path's errors."""
+    import copy
+    import pickle
+
+    L, alpha = 8, "TGCA"
+    members = [bm.CNN(L, 32, 100, alpha, seed=s) for s in range(3)]
+    ens = flexs_amd.Ensemble(members)
+    seqs = rand_seqs(40, L, alpha, seed=1)[1]
+    eng.set_option("serve_small", 0)
+    try:
+        want3 = ens.get_fitness(seqs)
+        extra = bm.MLP(L, 100, alpha, seed=9)
+        want4 = flexs_amd.Ensemble(members + [extra]).get_fitness(seqs)
+        want_single = members[1].get_fitness(seqs)
+    finally:
+        eng.set_option("serve_small", 1)
+    for form in (seqs, tuple(seqs), [np.str_(s) for s in seqs], np.array(seqs), np.array(seqs, dtype="S")):
+        assert np.array_equal(ens.get_fitness(form), want3)
+        assert np.array_equal(members[1].get_fitness(form), want_single)
+    c0 = [m.cost for m in members]
+    e0 = ens.cost
+    ens.get_fitness(seqs[:7])
+    assert ens.cost == e0 + 7 and [m.cost for m in members] == [c + 7 for c in c0]
+    # the member list is edited in place: the cached block must not answer for the old list
+    ens.models.append(extra)
+    assert np.array_equal(ens.get_fitness(seqs), want4)
+    ens.models.pop()
+    assert np.array_equal(ens.get_fitness(seqs), want3)
+    # copies / pickles: no device handles travel, the copy scores with handles of its own
+    for clone in (copy.deepcopy(ens), pickle.loads(pickle.dumps(ens))):
+        assert np.array_equal(clone.get_fitness(seqs), want3)
+        assert np.array_equal(clone.models[1].get_fitness(seqs), want_single)
+    # errors: ragged batch, character outside the alphabet, not a string -- whatever the general path raises
+    with pytest.raises(ValueError):
+        ens.get_fitness(seqs[:3] + ["ACG"])
+    with pytest.raises(ValueError):
+        ens.get_fitness(seqs[:3] + ["ACGTACGZ"])
+    with pytest.raises(ValueError):
+        members[0].get_fitness(["ACGTACGZ"])
+    c1 = [m.cost for m in members]
+    assert np.array_equal(ens.get_fitness(seqs), want3) and [m.cost for m in members] == [c + 40 for c in c1]
+    assert ens.get_fitness([]).shape == (0,)
+
+
+def test_resident_form_at_the_mailbox_limits(eng):
+    """Requests at the edges of what the mailboxes hold: 256 sequences, exactly 16 KiB of sequence bytes (L = 64), one byte
+    more (launched), 257 sequences (launched) -- all with the launched form's bits."""
+    alpha = s_utils.AAS
+    # (capacity = 16 sequences x min(16, 16384 // (16 L)) tile slots: 256 at L = 64, 240 at L = 65, 128 at L = 128)
+    for L, sizes in ((64, (255, 256, 257)), (65, (239, 240, 241)), (128, (127, 128, 129))):
+        m = bm.MLP(L, 100, alpha, seed=L)
+        data = {n: rand_seqs(n, L, alpha, seed=n)[1] for n in sizes}
+        eng.set_option("serve_small", 0)
+        try:
+            want = {n: m.get_fitness(data[n]) for n in sizes}
+        finally:
+            eng.set_option("serve_small", 1)
+        served0 = eng.get_option("server_calls")
+        for rep in range(4):
+            for n in sizes:
+                assert np.array_equal(m.get_fitness(data[n]), want[n]), (L, n, rep)
+        assert eng.get_option("server_calls") > served0
