@@ -450,7 +450,9 @@ static inline int64_t planar_stride_for(int64_t N) { return (N + 63) & ~(int64_t
 static void server_stop(fx_engine* e);
 static int score_dispatch(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N, int L,
                           float* d_NM, int64_t planar_stride = 0) {
-    if (e->server.running && (int64_t)M * ((N + 15) / 16) >= e->num_cus) server_stop(e);   // a launch that fills the chip wants every CU
+    // a launch whose workgroups would not all find a CU beside the resident ones tells those to leave (they hold most of their
+    // CU's LDS: a persistent workgroup that has to wait for one of them would wait for their idle exit)
+    if (e->server.running && (int64_t)M * ((N + 15) / 16) + e->server.wgs > e->num_cus) server_stop(e);
     if (e->poison_outputs)      // scores are nan_to_num'ed, so a NaN that survives is an element no kernel wrote
         FX_HIP(e, hipMemsetAsync(d_NM, 0xFF, sizeof(float) * (planar_stride ? (size_t)planar_stride * (size_t)M : (size_t)N * (size_t)M), e->stream));
     struct Layout {                                     // the launchers read the layout from the engine
@@ -711,7 +713,7 @@ static int server_start(fx_engine* e, fx_model* const* models, int M, int L, con
     sv.versions.clear();
     for (int m = 0; m < M; ++m) sv.versions.push_back(models[m]->version);
     std::memcpy(sv.lut, lut, 256);
-    sv.L = L; sv.cap = cap;
+    sv.L = L; sv.cap = cap; sv.wgs = M * tiles;
     sv.running = true; sv.fresh = true;
     sv.t_start = std::chrono::steady_clock::now();
     sv.started += 1;

@@ -180,7 +180,7 @@ struct fx_engine {
         std::vector<fx_model*> models;
         std::vector<uint64_t> versions;
         uint8_t lut[256] = {};
-        int L = 0, cap = 0;
+        int L = 0, cap = 0, wgs = 0;                     // ... and the CUs the generation occupies (one workgroup each)
         std::vector<fx_model*> refused;                  // the last ensemble that has a member without a resident form
         int refused_L = 0;
         std::vector<fx_model*> pending;                  // the last eligible call's ensemble, and when it came
