@@ -51,10 +51,12 @@ struct QuadArgs {
 
 // QUADS quads per workgroup; XT = 16-channel tiles per exchange buffer (>= FT x positions and >= HT); L1C > 0: the number
 // of conv positions is a compile-time constant (seq_len 8: one position per wave, the position loops fold away)
-// SERVER: the resident form.  One workgroup per member loads its weights ONCE and then answers requests from the mailbox
-// until told to stop, idle for idle_ticks, or life_ticks old: an explorer-size call then costs a mailbox round trip
-// (~3.8 us, tools/probes/mailbox_probe.hip) plus the rounds themselves instead of a launch + a 3.5 us weight fill + a
-// second launch for the mean + a completion wait (~24 us).  Same round code, same bits.
+// SERVER: the resident form (QUADS = 1).  One workgroup per (member, 16-sequence tile slot) loads its member's weights ONCE
+// and then answers requests until told to stop, idle for idle_ticks, or life_ticks old: it polls the request word in
+// DEVICE memory (FxMailIn: the host stores it through the BAR), stages its tile's bytes, runs the round below and stores
+// (score, request tag) pairs + a system fence into pinned HOST memory (FxMailOut) -- an explorer-size call then costs a
+// mailbox round trip (~3 us for a handful of workgroups, tools/probes/mailbox_probe2.hip) plus one round instead of a
+// launch + a 3.5 us weight fill + a second launch for the mean + a completion wait (~27 us).  Same round code, same bits.
 template <int HT, int QUADS, int XT, int L1C, int K = 5, bool SERVER = false>
 __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
     constexpr int A = 4, K3 = 3, FT = 2, PL2 = (K - 1) / 2, PL3 = 1, QWAVES = 4 * QUADS;
