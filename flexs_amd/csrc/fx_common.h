@@ -166,8 +166,8 @@ struct fx_engine {
     // that averages in-kernel (small launches of the canonical CNN: score_cnn_quad.hip) sets fused_mean_done
     float* fuse_mean_out = nullptr;
     bool fused_mean_done = false;
-    // resident small-call form (score_cnn_quad.hip, SERVER): one workgroup per ensemble member stays on the device between
-    // explorer-size calls and answers them through a mailbox in mapped host memory
+    // resident small-call form (score_cnn_quad.hip / score_dense_small.hip, SERVER): one workgroup per (member, tile slot) stays
+    // on the device between explorer-size calls and answers them through the mailboxes above
     struct Server {
         FxMailIn* in = nullptr;                          // device memory; also the host's (write-only) view through the BAR
         FxMailOut* h_out = nullptr;                      // pinned host memory, and the device's view of it

@@ -1766,8 +1766,9 @@ def _until_resident(eng, call, tries=12):
 @pytest.mark.parametrize("L,alpha,M", [(8, "TGCA", 3), (14, "UGCA", 3), (8, "TGCA", 1), (7, "TGCA", 8), (14, "UGCA", 16), (6, "ACGT", 2)])
 def test_resident_small_call_form(eng, L, alpha, M):
     """`serve_small` (default on): from the second explorer-size call of the same canonical CNN ensemble on, one workgroup per
-    member stays on the device with its weights in LDS and answers requests through a mailbox in mapped host memory -- no
-    launch, no weight fill, no second launch for the mean.  Same round code as the launched small form, so the same bits:
+    member and tile slot stays on the device with its weights in LDS and answers requests through mailboxes (request in device
+    memory written through the BAR, tagged answers in pinned host memory) -- no launch, no weight fill, no second launch for
+    the mean.  Same round code as the launched small form, so the same bits:
     every batch size it serves, interleaved with sizes it does not (those launch as before), repeated calls, a bad
     character (ValueError, and the next call is fine), new weights (a new generation), an idle exit and restart."""
     import time as _t
