@@ -148,6 +148,9 @@ class KerasModel(flexs_amd.Model):
     def _fitness_function(self, sequences):
         """keras_model.py:69-79: encode -> float32 tensor -> predict -> squeeze ->
         nan_to_num, fused on the GPU.  Returns float32 (N,)."""
+        if (type(sequences) is np.ndarray and sequences.dtype.kind == "U" and sequences.ndim == 1
+                and 0 < sequences.shape[0] <= _native.SMALL_CALL_ROWS):
+            sequences = sequences.tolist()                      # (explorers also pass small NumPy string arrays: same fast path)
         if type(sequences) in (list, tuple) and 0 < len(sequences) <= _native.SMALL_CALL_ROWS and _native._HAS_SCORE_SMALL:
             # explorer-size call: string packing + fx_score in one C call on a cached argument block
             nat = self.native()

@@ -116,6 +116,9 @@ class Ensemble(_EnsembleBase):
         return out if want_mean else self.combine_with(out)
 
     def _fitness_function(self, sequences):
+        if (type(sequences) is np.ndarray and sequences.dtype.kind == "U" and sequences.ndim == 1
+                and 0 < sequences.shape[0] <= _native.SMALL_CALL_ROWS):
+            sequences = sequences.tolist()                      # (explorers also pass small NumPy string arrays: same fast path)
         if type(sequences) in (list, tuple) and 0 < len(sequences) <= _native.SMALL_CALL_ROWS and _native._HAS_SCORE_SMALL:
             out = self._score_small(sequences)
             if out is not None:
