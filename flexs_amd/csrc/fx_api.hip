@@ -1350,6 +1350,16 @@ int fx_cache_distances(fx_cache* c, int mode, const uint8_t* queries, int64_t Q,
     if (!queries || !out) return fx_fail(e, FX_EINVAL, "null buffer");
     FX_HIP(e, hipSetDevice(e->device));
     int rc;
+    if ((size_t)Q * c->L + (size_t)Q * c->size <= (size_t)e->zero_copy_bytes) {
+        // a DyNA-PPO environment step (one sequence against everything seen): query and distance row in mapped pinned memory
+        FxZeroCopy z;
+        if ((rc = fx_zero_copy_buffers(e, (size_t)Q * c->L + 16, (size_t)Q * c->size, &z))) return rc;
+        std::memcpy(z.h_in, queries, (size_t)Q * c->L);
+        if ((rc = fx_launch_distances(e, mode, (const uint8_t*)z.d_in, Q, c->d_keys, c->size, c->L, (uint8_t*)z.d_out))) return rc;
+        FX_HIP(e, hipStreamSynchronize(e->stream));
+        std::memcpy(out, z.h_out, (size_t)Q * c->size);
+        return FX_OK;
+    }
     const int64_t qstep = std::max<int64_t>(1, std::min<int64_t>(32768, ((int64_t)1 << 28) / std::max<int64_t>(c->size, 1)));
     for (int64_t q0 = 0; q0 < Q; q0 += qstep) {
         const int64_t qn = std::min<int64_t>(qstep, Q - q0);
