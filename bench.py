@@ -79,13 +79,23 @@ def roofline_block(kind, Lx, A, Hx, Fx, Kx, members, n, kern_ms, kernel_name):
 
 def pmc_block():
     """PMC figures cannot be sampled from inside the process; they come from the rocprofv3 --pmc passes over this
-    same command (tools/gpu_round3.sh), committed under profiles/ -- the file is named so the numbers can be traced."""
-    for name in ("r3_pmc_bench.json", "r2_pmc_bench.json", "r1_pmc_traffic.json"):
+    same command (tools/gpu_round4.sh), committed under profiles/ -- the file is named, with the commit it was taken at
+    (`commit` inside the file, else the last commit that touched it), so the numbers can be traced."""
+    for name in ("r4_pmc_bench.json", "r3_pmc_bench.json", "r2_pmc_bench.json", "r1_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             d = json.load(open(path))
+            commit = d.get("commit")
+            if not commit:
+                try:
+                    import subprocess
+
+                    commit = subprocess.run(["git", "log", "-1", "--format=%h", "--", path], cwd=ROOT, capture_output=True,
+                                            text=True, timeout=5).stdout.strip() or None
+                except Exception:  # noqa: BLE001 (no git on the GPU box: the snapshot has no .git)
+                    commit = None
             return {"hbm_bytes_per_launch": d.get("hbm_bytes_per_launch"), "mfma_util": d.get("mfma_util"),
-                    "source": f"profiles/{name}"}
+                    "source": f"profiles/{name}" + (f" @ {commit}" if commit else "")}
     return {"hbm_bytes_per_launch": None, "mfma_util": None, "source": None}
 
 
@@ -421,6 +431,47 @@ def end_to_end_block(device, configs=None):
     return out
 
 
+def explorer_patterns_block(device):
+    """SURVEY.md 8(d)'s explorer call patterns for configs[3] and configs[4] (the C2 pattern is `small_call_us`):
+      DyNA-PPO  `environments/dyna_ppo.py:144-163`: the environment step scores 4-10 sequences per call with the ensemble
+                -- here 8 x GlobalEpistasis(100), L = 90, protein alphabet, `Ensemble.get_fitness(list[str])`;
+      CMA-ES    `cmaes.py:61-67, 83-108`: P = 15 / 40 solutions are argmax-decoded and scored one population at a time
+                -- here `PopulationEvaluator.evaluate` (fx_decode_score) on 3 x CNN(32,100), L = 237, plus the plain
+                one-sequence call of the reference loop.
+    Host arrays / strings in, host values out; median of 200 calls after 20 warm-up calls."""
+    import flexs_amd
+    from flexs_amd import synth
+    from flexs_amd.utils.population import PopulationEvaluator
+
+    def med_us(fn, reps=200):
+        for _ in range(20):
+            fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)) * 1e6
+
+    out = {}
+    ens = flexs_amd.Ensemble(build_members("ge", 90, AAS, 8, device))
+    seqs = synth.bytes_to_strings(synth.random_sequence_bytes(16, 90, AAS, 11))
+    out["dynappo_8xGE_L90_us"] = {str(k): med_us(lambda k=k: ens.get_fitness(seqs[:k])) for k in (4, 10)}
+    del ens
+    ens = flexs_amd.Ensemble(build_members("cnn", 237, AAS, 3, device))
+    ev = PopulationEvaluator(ens, AAS, 237)
+    rng = np.random.default_rng(5)
+    cm = {}
+    for P in (15, 40):
+        x = rng.standard_normal((P, 237 * len(AAS)))
+        cm[f"P={P}"] = med_us(lambda x=x: ev.evaluate(x), reps=100)
+    one = synth.bytes_to_strings(synth.random_sequence_bytes(1, 237, AAS, 12))
+    cm["N=1 get_fitness"] = med_us(lambda: ens.get_fitness(one), reps=100)
+    out["cmaes_3xCNN_L237_us"] = cm
+    out["what"] = ("explorer-size calls of configs[3] / configs[4], host in -> host out, median us per call: DyNA-PPO pattern "
+                   "(8 x GE L=90, 4 / 10 sequences per Ensemble.get_fitness call) and CMA-ES pattern (3 x CNN L=237: decode + score "
+                   "of a population of 15 / 40 in one fx_decode_score round trip; one-sequence get_fitness beside it)")
+    return out
+
+
 def explorer_round_block(device, torch):
     """SURVEY.md 8(f)-1/-2, the callers on either side of the path: one explorer round on configs[0]'s surrogate family --
     `Ensemble.train` of the 3-CNN ensemble on 1000 measured sequences (Adam / MSE / 20 epochs / batch 256: the hand-written
@@ -470,19 +521,34 @@ def explorer_round_block(device, torch):
     return out
 
 
-def member_parallel_block(world, rank, device, torch, dist, use_dist, steps_hint):
+MEMBER_PARALLEL_WORKLOADS = (("8xCNN L=8 A=4 N=1e5", "cnn", 8, "TGCA", 100_000, 400),
+                             ("8xGE L=90 A=20 N=1e5", "ge", 90, AAS, 100_000, 800),
+                             ("8xGE L=90 A=20 N=1e6", "ge", 90, AAS, 1_000_000, 100))
+
+
+def member_parallel_block(world, rank, device, torch, dist, use_dist, steps_hint, solo_group=None):
     """north_star's split: an 8-member ensemble, members sharded over the ranks (contiguous blocks), every rank
     scores the SAME batch with its members, ONE all-gather of the stacked predictions, mean on every rank.
     Strong scaling: the batch is fixed, value = batch x steps / time.  Workloads: 8 x CNN L=8 (configs[1]'s
-    surrogate, 8 members) and 8 x GlobalEpistasis L=90 A=20 (configs[3]) at 1e5 and 1e6 sequences."""
+    surrogate, 8 members) and 8 x GlobalEpistasis L=90 A=20 (configs[3]) at 1e5 and 1e6 sequences.
+    `speedup_vs_1gpu` divides by a one-GPU measurement OF THIS RUN: with one rank the block itself is that reference;
+    with several, rank 0 first runs the same workload alone over a one-rank group (`solo_group`) while the others wait."""
     from flexs_amd import distributed as fd, synth
 
     out = {}
-    for name, kind, Lx, alpha, n, steps in (
-            ("8xCNN L=8 A=4 N=1e5", "cnn", 8, "TGCA", 100_000, 400),
-            ("8xGE L=90 A=20 N=1e5", "ge", 90, AAS, 100_000, 800),
-            ("8xGE L=90 A=20 N=1e6", "ge", 90, AAS, 1_000_000, 100)):
+    for name, kind, Lx, alpha, n, steps in MEMBER_PARALLEL_WORKLOADS:
         mods = build_members(kind, Lx, alpha, 8, device)
+        ref = None
+        if world > 1 and solo_group is not None:
+            if rank == 0:
+                solo = fd.DistributedEnsemble(mods, mode="member", group=solo_group)
+                with torch.cuda.stream(solo.stream):
+                    d_solo = torch.from_numpy(synth.random_sequence_bytes(n, Lx, alpha, seed=7)).cuda()
+                solo.stream.synchronize()
+                el, _, _ = run_pipelined(solo, d_solo, n, steps, max(steps // 10, 5), torch, dist, False, want_events=False)
+                ref = n * steps / el
+                del solo, d_solo
+            dist.barrier()
         ens = fd.DistributedEnsemble(mods, mode="member")
         ens.force_collective = use_dist
         with torch.cuda.stream(ens.stream):
@@ -498,24 +564,90 @@ def member_parallel_block(world, rank, device, torch, dist, use_dist, steps_hint
         ok = bool(torch.isfinite(mat).all()) and tuple(mat.shape) == (n, 8)
         if rank == 0:
             ok = ok and np.array_equal(np.mean(mat.cpu().numpy(), axis=1), mean.cpu().numpy())
-        out[name] = {"value": n * steps / elapsed, "unit": "sequences/s", "ms_per_step": elapsed / steps * 1e3,
+        value = n * steps / elapsed
+        if world == 1 and not use_dist:
+            ref, ref_src = value, "this block (n_gpus = 1, no collective)"
+        elif ref is not None:
+            ref_src = "same run: rank 0 alone over a one-rank group, before the sharded measurement"
+        else:
+            ref_src = None
+        out[name] = {"value": value, "unit": "sequences/s", "ms_per_step": elapsed / steps * 1e3,
                      "kernel_ms_this_rank": kern_ms, "steps": steps, "members": 8,
                      "members_per_rank": -(-8 // world), "gathered_bytes_per_rank": 4 * n * -(-8 // world) * world,
-                     "one_gpu_reference": ONE_GPU_REF[name],
-                     "speedup_vs_1gpu": n * steps / elapsed / ONE_GPU_REF[name],
+                     "one_gpu_reference": ref, "one_gpu_reference_source": ref_src,
+                     "speedup_vs_1gpu": (value / ref) if ref else None,
                      "checked": ok}
         del ens, mods, d_seq
     out["what"] = ("8-member ensembles sharded member-parallel over the ranks (flexs/ensemble.py:54-59): fused kernel "
                    "for this rank's members + one RCCL all-gather of the stacked (N, 8) predictions + np.mean-order mean "
                    "on every rank; same batch on every rank (strong scaling), double-buffered so the gather of step k "
-                   "overlaps step k+1; speedup_vs_1gpu = value / one_gpu_reference, the latter recorded from this same "
-                   "block at n_gpus=1 (profiles/r2_run4_bench.json); ideal = 8 / members_per_rank")
+                   "overlaps step k+1; speedup_vs_1gpu = value / one_gpu_reference, the latter measured in THIS run "
+                   "(one_gpu_reference_source); ideal = 8 / members_per_rank")
     return out
 
-# ---------------------------------------------------------------------------------------------------------------
-# One-GPU references of the member-parallel workloads (profiles/r2_run4_bench*.json, `member_parallel` at n_gpus = 1):
-# what `speedup_vs_1gpu` is computed against when the same command runs on N > 1 GPUs.
-ONE_GPU_REF = {"8xCNN L=8 A=4 N=1e5": 2.14e8, "8xGE L=90 A=20 N=1e5": 6.25e8, "8xGE L=90 A=20 N=1e6": 7.01e8}
+def _sig(x, digits=4):
+    return None if x is None else float(f"{float(x):.{digits}g}")
+
+
+def compact_record(out):
+    """The path, not just the headline, inside the two objects a downstream parser of the contract line keeps: `roofline`
+    gets `per_config` (kernel time and both MFMA fractions of every BASELINE.json config, K4's integer-VALU fractions),
+    `config` gets `path` (end-to-end rates, explorer-size latencies, the explorer round, the settled headline, member-parallel
+    speed-ups).  Same numbers as the verbose blocks (`configs`, `end_to_end`, `explorer_round`, `explorer_patterns`,
+    `member_parallel`, `settled`) they are copied from; pure function of `out` (unit-tested on the CPU)."""
+    roof, cfg = out["roofline"], out["config"]
+    per = {"C2 3xCNN L8 N1e5 (headline)": {"kernel_ms": _sig(roof.get("kernel_ms")), "frac": _sig(roof.get("frac")),
+                                          "frac_issued": _sig(roof.get("frac_issued"))}}
+    short = {"C1 cnn L=8 A=4 M=1 N=1e4": "C1 1xCNN L8 N1e4", "C2 cnn L=8 A=4 M=3 N=1e4": "C2 3xCNN L8 N1e4",
+             "C3 mlp L=14 A=4 H=100 M=1 N=1e5": "C3 MLP L14 N1e5", "C4 ge L=90 A=20 H=100 M=8 N=1e5": "C4 8xGE L90 N1e5",
+             "C5 cnn L=237 A=20 M=3 N=62500 (one GPU's share of 5e5)": "C5 3xCNN L237 N62500"}
+    confs = out.get("configs") or {}
+    for key, name in short.items():
+        b = confs.get(key)
+        if b:
+            per[name] = {"kernel_ms": _sig(b.get("kernel_ms")), "frac": _sig(b.get("frac")), "frac_issued": _sig(b.get("frac_issued"))}
+    nam = next((v for k, v in confs.items() if k.startswith("C3 nam")), None)
+    if nam:
+        per["K4 Levenshtein L14 Q2000 (int-VALU frac)"] = {k.split()[-1]: _sig(v["roofline"]["frac"])
+                                                           for k, v in nam.get("k4", {}).items() if isinstance(v, dict)}
+    for k in ("C1 resident", "C2@1e4 resident"):
+        if k in confs:
+            per[k] = confs[k]
+    if len(per) > 1:
+        roof["per_config"] = per
+    path = {}
+    st = out.get("settled")
+    if st:
+        path["settled"] = {"value": _sig(st["value"]), "kernel_ms": _sig(st["kernel_ms"]), "frac_issued": _sig(st["frac_issued"])}
+    e2e = out.get("end_to_end") or {}
+    rows = {k.replace(" list_str", ""): v for k, v in e2e.items() if k.endswith(" list_str") and isinstance(v, dict) and k != "list_str"}
+    if rows:
+        path["e2e_list_str"] = {k: {"seq_per_s": _sig(v.get("value")), "wall_ms": _sig(v.get("wall_ms")),
+                                    "frac_of_kernel_rate": _sig(v.get("frac_of_kernel_rate"))} for k, v in rows.items()}
+    for k in ("small_call_us", "small_call_us_launch_per_call"):
+        if k in e2e:
+            path[k + " (3xCNN L8)"] = {n: _sig(v, 3) for n, v in e2e[k].items()}
+    pat = out.get("explorer_patterns") or {}
+    for k in ("dynappo_8xGE_L90_us", "cmaes_3xCNN_L237_us"):
+        if k in pat:
+            path[k] = {n: _sig(v, 3) for n, v in pat[k].items()}
+    er = out.get("explorer_round") or {}
+    if er:
+        path["explorer_round_3xCNN_L8"] = {"train_n1000_ms": _sig(er.get("train_3xCNN_n1000_ms")),
+                                           "adalead_round_ms": _sig(er.get("adalead_round_ms")),
+                                           "adalead_model_queries": er.get("adalead_model_queries")}
+    if nam:
+        path["nam_cbas_seq_per_s"] = {k: _sig(nam[k]["value"]) for k in ("plain_landscape", "batch_safe_landscape", "device_table_landscape_L8")
+                                      if k in nam}
+    mp_ = out.get("member_parallel") or {}
+    mp_rows = {k: v for k, v in mp_.items() if isinstance(v, dict)}
+    if mp_rows:
+        path["member_parallel"] = {k: {"value": _sig(v["value"]), "one_gpu_reference": _sig(v.get("one_gpu_reference")),
+                                       "speedup_vs_1gpu": _sig(v.get("speedup_vs_1gpu")), "members_per_rank": v.get("members_per_rank")}
+                                   for k, v in mp_rows.items()}
+    if path:
+        cfg["path"] = path
+    return out
 
 
 def _free_port():
@@ -715,7 +847,9 @@ def main():
 
     extras = {}
     if not args.no_extras:
-        extras["member_parallel"] = member_parallel_block(world, rank, local_rank, torch, dist, use_dist, args.steps)
+        # (a one-rank group for the in-run one-GPU reference of the member-parallel speed-ups: created by every rank)
+        solo_group = dist.new_group(ranks=[0]) if (use_dist and world > 1) else None
+        extras["member_parallel"] = member_parallel_block(world, rank, local_rank, torch, dist, use_dist, args.steps, solo_group)
 
     if rank == 0:
         assert np.array_equal(np.mean(got_nm, axis=1), got_mean), "device mean is not np.mean bit-for-bit"
@@ -738,8 +872,10 @@ def main():
             out["configs"]["C2 full (headline kernel)"] = {"kernel_ms": (settled[2] if settled else kern_ms)}
             out["end_to_end"] = end_to_end_block(local_rank, out["configs"])
             out["explorer_round"] = explorer_round_block(local_rank, torch)
+            out["explorer_patterns"] = explorer_patterns_block(local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nam=args.cpu_nam)
+        compact_record(out)
         if saved_stdout is not None:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)

@@ -44,15 +44,53 @@ class _CacheDict(dict):
         self.removals += 1
 
 
+_MT_FAST = None          # None = not checked yet; True / False = the raw-state shortcut of _rng_checkpoint is valid here
+
+
+def _mt_state_layout_ok() -> bool:
+    """Self-check of the shortcut below, once per process: the 2500 bytes at `state_address` must BE NumPy's MT19937 state
+    as `np.random.get_state()` reports it (key[624] as uint32, then pos as int32), and writing them back must restore a
+    stream that has moved on.  A NumPy that lays the struct out differently fails this and gets the slow, documented path
+    -- never a silently corrupted random stream."""
+    import ctypes
+
+    try:
+        bg = np.random.mtrand._rand._bit_generator
+        if type(bg).__name__ != "MT19937":
+            return False
+        keep = np.random.get_state()                                  # the user's stream: put back at the end, whatever happens
+        try:
+            addr, size = bg.ctypes.state_address, 624 * 4 + 4
+            name, key, pos = keep[0], keep[1], keep[2]
+            raw = ctypes.string_at(addr, size)
+            if name != "MT19937" or raw[:2496] != np.ascontiguousarray(key, dtype=np.uint32).tobytes() \
+                    or int.from_bytes(raw[2496:2500], "little", signed=True) != int(pos):
+                return False
+            np.random.standard_exponential(700)                       # crosses a 624-word refill of the key
+            moved = np.random.get_state()
+            if np.array_equal(moved[1], key) and moved[2] == pos:
+                return False
+            ctypes.memmove(addr, raw, size)
+            back = np.random.get_state()
+            return bool(np.array_equal(back[1], key) and back[2] == pos)
+        finally:
+            np.random.set_state(keep)
+    except Exception:                                                 # noqa: BLE001 (any surprise = no shortcut)
+        return False
+
+
 def _rng_checkpoint():
     """Returns restore(): puts NumPy's global RNG back where it is now.  `np.random.get_state()` costs ~40 us (it builds a
     tuple around a copy of the 624-word state) -- more than the device round trip it guards; for the stock MT19937 bit
     generator the 2500 bytes of its state struct (key[624] + pos; the legacy Gaussian cache is not touched by exponential
-    draws) are copied directly instead."""
+    draws) are copied directly instead -- after `_mt_state_layout_ok` has confirmed, once, that those bytes are the state."""
     import ctypes
 
+    global _MT_FAST
+    if _MT_FAST is None:
+        _MT_FAST = _mt_state_layout_ok()
     bg = np.random.mtrand._rand._bit_generator
-    if type(bg).__name__ == "MT19937":
+    if _MT_FAST and type(bg).__name__ == "MT19937":
         addr, size = bg.ctypes.state_address, 624 * 4 + 4
         saved = ctypes.string_at(addr, size)
         return lambda: ctypes.memmove(addr, saved, size)

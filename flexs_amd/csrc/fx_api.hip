@@ -9,8 +9,7 @@
 #include "myers.h"
 #include "np_sum.h"
 #include <atomic>
-#include <csetjmp>
-#include <csignal>
+#include <mutex>
 #include <chrono>
 
 // strips of `lw_rows` = 64 x LW pattern rows, as k_min_dist_long runs them for patterns beyond 768 symbols (LW = 12 there;
@@ -618,25 +617,45 @@ int fx_plan_host_call(fx_engine* e, fx_model* const* models, int M, int64_t N, i
 // Resident small-call form: the host side of the mailboxes (score_cnn_quad.hip, SERVER; FxMailIn / FxMailOut).
 static void server_stop(fx_engine* e) { fx_server_stop(e); }
 
-// One guarded store into the request mailbox before it is ever used: the device reports a large BAR, but whether THIS
-// allocation is mapped for the host is the runtime's business; a fault here is caught instead of killing the process.
-static sigjmp_buf g_probe_jmp;
-static void probe_fault(int) { siglongjmp(g_probe_jmp, 1); }
-static bool host_can_store(volatile unsigned* p) {
-    struct sigaction sa{}, old_segv{}, old_bus{};
-    sa.sa_handler = probe_fault;
-    sigemptyset(&sa.sa_mask);
-    sigaction(SIGSEGV, &sa, &old_segv);
-    sigaction(SIGBUS, &sa, &old_bus);
+// Can the host store into this device allocation?  The device reports a large BAR, but whether THIS allocation is mapped
+// into the process is the runtime's business.  Decided from facts, without ever faulting (round 3 probed with a guarded store
+// under a temporary SIGSEGV handler: not thread-safe, and hostile to a host application that owns its signal handlers):
+//   1. the address range must be a readable + writable mapping of this process (/proc/self/maps);
+//   2. a magic word stored through that mapping must be what a device -> host copy of the same address returns.
+// Serialised by a mutex (engines on different threads), decided once per allocation.
+static std::mutex g_probe_mu;
+static bool host_range_is_writable(const void* p, size_t len) {
+    FILE* f = std::fopen("/proc/self/maps", "r");
+    if (!f) return false;
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(p), hi = lo + len;
+    uintptr_t covered = lo;                               // the range may span adjacent mappings (listed in address order)
+    char line[512];
     bool ok = false;
-    if (sigsetjmp(g_probe_jmp, 1) == 0) {
-        *p = 0u;
-        fx_bar_fence();
-        ok = true;
+    while (std::fgets(line, sizeof line, f)) {
+        unsigned long long a = 0, b = 0;
+        char perm[8] = {};
+        if (std::sscanf(line, "%llx-%llx %7s", &a, &b, perm) != 3) continue;
+        if (b <= covered) continue;
+        if (a > covered) break;                            // a hole before the range is covered
+        if (perm[0] != 'r' || perm[1] != 'w') break;
+        covered = (uintptr_t)b;
+        if (covered >= hi) { ok = true; break; }
     }
-    sigaction(SIGSEGV, &old_segv, nullptr);
-    sigaction(SIGBUS, &old_bus, nullptr);
+    std::fclose(f);
     return ok;
+}
+static bool host_can_store(FxMailIn* q) {
+    std::lock_guard<std::mutex> lock(g_probe_mu);
+    if (!host_range_is_writable(q, sizeof(FxMailIn))) return false;
+    volatile unsigned* p = &q->stop;
+    const unsigned magic = 0x5EB1A5EDu;
+    *p = magic;
+    fx_bar_fence();
+    unsigned back = 0;
+    if (hipMemcpy(&back, const_cast<const unsigned*>(p), sizeof back, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return false; }
+    *p = 0u;
+    fx_bar_fence();
+    return back == magic;
 }
 
 static int server_start(fx_engine* e, fx_model* const* models, int M, int L, const uint8_t lut[256]) {
@@ -653,7 +672,7 @@ static int server_start(fx_engine* e, fx_model* const* models, int M, int L, con
     if (!sv.in) {
         FxMailIn* q = nullptr;
         if (hipExtMallocWithFlags(reinterpret_cast<void**>(&q), sizeof(FxMailIn), hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); return FX_ENOMEM; }
-        if (!host_can_store(&q->stop)) { (void)hipFree(q); e->large_bar = false; return FX_EUNSUPPORTED; }
+        if (!host_can_store(q)) { (void)hipFree(q); e->large_bar = false; return FX_EUNSUPPORTED; }
         sv.in = q;
     }
     for (int g = 0; g < sv.groups; ++g) FX_HIP(e, hipStreamSynchronize(sv.streams[g]));   // a previous generation has left (it was told to, or timed out)
@@ -781,6 +800,7 @@ static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8
             unsigned spins = 0;
             unsigned long long a;
             while ((((a = h->ans[m][n]) >> 32) & 0x7FFFFFFFull) != seq) {
+                __builtin_ia32_pause();                     // (spin-wait hint: leaves the core's resources to a sibling hyperthread)
                 if ((++spins & 1023u) == 0) {
                     const bool gone = !sv.fresh && !h->alive[m][n >> 4];
                     const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

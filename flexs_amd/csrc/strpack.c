@@ -10,9 +10,12 @@
  *                          3           some item is not a str                         (caller raises)
  *   set_threads(n) -> previous value   worker threads for big batches (0 = auto: min(8, cores / 2))
  *
- * Round 3: big batches are packed by several threads.  A str object is immutable and the list keeps every item alive
- * for the duration of the call, so the workers only READ object headers and character buffers -- no reference counts,
- * no allocation, no Python API call -- and the GIL is released while they run.  One string is one cache miss on a
+ * Round 3: big batches are packed by several threads.  A str object is immutable, so the workers only READ object
+ * headers and character buffers -- no reference counts, no allocation, no Python API call.  The CALLING thread keeps the
+ * GIL for the whole call (round 4, advisor finding): with the GIL released another Python thread could append to /
+ * delete from the caller's list while the workers walk its item array (a reallocated ob_item or a freed str = use after
+ * free); holding it costs nothing -- the call lasts tens of microseconds and the caller packs a share itself -- and no
+ * Python code can run until it returns, so the list and its strings cannot change.  One string is one cache miss on a
  * scattered heap object (~1.6 ns per 8-mer single-threaded at N = 1e5, ~10 ns per 90-mer): the loop is latency-bound,
  * which is exactly what several threads hide.  The pool is persistent (mutex + condition variable; the calling thread
  * takes a share itself), workers are created on first use and never joined.
@@ -67,8 +70,8 @@ static int g_workers = 0;              /* threads created so far */
 static int g_active = 0;               /* workers taking part in the current job */
 static int g_pending = 0;              /* shares of the current job not finished yet */
 static int g_threads_cfg = 0;          /* 0 = auto */
-static int g_busy = 0;                 /* a job owns the pool (a second caller -- another Python thread: the GIL is released
-                                          while a job runs -- packs its batch on its own thread instead of waiting) */
+static int g_busy = 0;                 /* a job owns the pool (a second caller -- only possible from a sub-interpreter with its own
+                                          GIL -- packs its batch on its own thread instead of waiting) */
 
 static void* worker_main(void* arg) {
     const int id = (int)(intptr_t)arg;
@@ -111,7 +114,8 @@ static int want_threads(Py_ssize_t bytes) {
     return t < 1 ? 1 : t;
 }
 
-/* n items -> dst with `threads` threads (the caller is one of them).  Called WITHOUT the GIL. */
+/* n items -> dst with `threads` threads (the caller, which holds the GIL, is one of them; the helpers never touch the
+ * interpreter: have_gil = 0 makes pack_range hand a legacy str back instead of calling into Python). */
 static int pack_parallel(PyObject** items, unsigned char* dst, Py_ssize_t n, Py_ssize_t L, int threads) {
     const int helpers = threads - 1;
     pthread_mutex_lock(&g_mu);
@@ -178,11 +182,8 @@ static PyObject* pack(PyObject* self, PyObject* args) {
     }
     unsigned char* dst = (unsigned char*)out.buf;
     const int threads = n > 0 ? want_threads(n * L) : 1;
-    if (threads > 1) {
-        Py_BEGIN_ALLOW_THREADS
+    if (threads > 1)                                                    /* GIL held: nobody can mutate `seqs` meanwhile (see top) */
         status = pack_parallel(items, dst, n, L, threads);
-        Py_END_ALLOW_THREADS
-    }
     if (threads <= 1 || status == 4)                                    /* small batch, or a legacy str: under the GIL */
         status = pack_range(items, dst, n, L, 1);
     Py_DECREF(fast);

@@ -192,8 +192,21 @@ class DistributedEnsemble(flexs_amd.Model):
                 if len(sequences) and (m._lut[_native.sequences_to_bytes(sequences, L=m.model.L)] == 255).any():
                     raise ValueError("substring not found")
             mine = member_assignment(len(self.models), rank, world)
-            train_members([self.models[i] for i in mine], sequences, labels,
-                          None if seeds is None else [seeds[i] for i in mine])
+            # SPMD: whatever fails on the rank that owns a member (an unsupported loss, an out-of-memory arena, an exception
+            # of a member's own `train`) must fail the call on EVERY rank -- the others would otherwise wait for it forever
+            # in the weight gather below.  Agree on one flag first, as `get_fitness` does.
+            err = None
+            try:
+                train_members([self.models[i] for i in mine], sequences, labels,
+                              None if seeds is None else [seeds[i] for i in mine])
+            except Exception as ex:                                # noqa: BLE001 (re-raised below, on every rank)
+                err = ex
+            flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device=_gather_device(self.group))
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            if err is not None:
+                raise err
+            if int(flag.item()):
+                raise RuntimeError("DistributedEnsemble.train: training failed on another rank (see that rank's exception)")
             self.gather_weights()
         else:
             train_members(self.models, sequences, labels, seeds)

@@ -329,6 +329,9 @@ def _unflat(flat, shapes):
     return out
 
 
+_NATIVE_MAX_MEMBERS = 64          # members per fx_train_fit call (csrc/train.hip)
+
+
 def _fit_native(archs, sequences, labels, alphabet, batch_sizes, epochs, verbose, gens):
     """One `fx_train_fit` call for members that share the alphabet and the sequence length: every member's shuffles come
     from its own generator (one `randperm` per epoch, after the one draw that seeds its dropout stream -- the same
@@ -503,8 +506,12 @@ def fit_many(archs, sequences, labels, alphabets, batch_sizes, epochs, verbose=F
                 if seeds:
                     g.manual_seed(seeds[k])
                 gens.append(g)
-            _fit_native([archs[k] for k in ks], sequences, labels, alphabet, [batch_sizes[k] for k in ks],
-                        [epochs[k] for k in ks], verbose, gens)
+            # fx_train_fit takes at most _NATIVE_MAX_MEMBERS members per call (train.hip); seeds are per member, so cutting
+            # a large group into several calls changes nothing but the number of launches
+            for c0 in range(0, len(ks), _NATIVE_MAX_MEMBERS):
+                kc = ks[c0:c0 + _NATIVE_MAX_MEMBERS]
+                _fit_native([archs[k] for k in kc], sequences, labels, alphabet, [batch_sizes[k] for k in kc],
+                            [epochs[k] for k in kc], verbose, gens[c0:c0 + _NATIVE_MAX_MEMBERS])
         return
     for arch in archs:
         if arch.loss not in ("MSE", "mse", "mean_squared_error"):

@@ -516,3 +516,59 @@ def test_rng_checkpoint_puts_numpys_global_stream_back():
         np.random.seed(seed)
         b = scale * np.random.standard_exponential(50)
         assert np.array_equal(a, b) and np.random.get_state()[2] == pos_a
+
+
+def test_rng_checkpoint_self_check_and_both_paths():
+    """`_rng_checkpoint` (NoisyAbstractModel's fused query hands a batch back to the one-by-one path with NumPy's global
+    stream restored): the raw-state shortcut is only taken after `_mt_state_layout_ok` has confirmed that the bytes at
+    `state_address` ARE the MT19937 state; the check itself leaves the user's stream (Gaussian cache included) alone, and
+    the documented slow path gives the same restore."""
+    from flexs_amd.baselines.models import noisy_abstract_model as nm
+
+    np.random.seed(123)
+    np.random.standard_normal(3)                                    # leaves a cached Gaussian in the legacy state
+    before = np.random.get_state()
+    ok = nm._mt_state_layout_ok()
+    after = np.random.get_state()
+    assert ok is True                                               # (NumPy 2.2's layout; a False here only means "slow path")
+    assert np.array_equal(before[1], after[1]) and before[2:] == after[2:]
+    for fast in (True, False):
+        nm._MT_FAST = fast
+        np.random.seed(7)
+        restore = nm._rng_checkpoint()
+        a = np.random.exponential(size=700)
+        restore()
+        assert np.array_equal(a, np.random.exponential(size=700))
+    nm._MT_FAST = None
+
+
+def test_bench_compact_record_carries_every_config():
+    """Round-3 verdict: the driver's parse of the bench line keeps `config` and `roofline` and drops the other blocks.
+    `compact_record` copies the per-config kernel table and the path's end-to-end / explorer figures INTO those two
+    objects; checked here on a committed builder-run line of round 3 (same block shapes)."""
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(__file__))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    line = json.load(open(os.path.join(root, "profiles", "r3_run4_bench_driver.json")))
+    line["explorer_patterns"] = {"dynappo_8xGE_L90_us": {"4": 12.0, "10": 12.5}, "cmaes_3xCNN_L237_us": {"P=15": 80.0, "P=40": 90.0, "N=1 get_fitness": 40.0}}
+    out = bench.compact_record(line)
+    json.loads(json.dumps(out))
+    per = out["roofline"]["per_config"]
+    for name in ("C2 3xCNN L8 N1e5 (headline)", "C1 1xCNN L8 N1e4", "C2 3xCNN L8 N1e4", "C3 MLP L14 N1e5", "C4 8xGE L90 N1e5", "C5 3xCNN L237 N62500"):
+        assert set(per[name]) == {"kernel_ms", "frac", "frac_issued"} and 0 < per[name]["frac_issued"] <= 1.0, name
+    assert per["C1 1xCNN L8 N1e4"]["kernel_ms"] == pytest.approx(line["configs"]["C1 cnn L=8 A=4 M=1 N=1e4"]["kernel_ms"], rel=1e-3)
+    assert set(per["K4 Levenshtein L14 Q2000 (int-VALU frac)"]) == {"C=100", "C=1000", "C=20000"}
+    path = out["config"]["path"]
+    assert set(path["e2e_list_str"]) == {"C2 3xCNN L=8", "C3 MLP L=14", "C4 8xGE L=90", "C5 3xCNN L=237"}
+    assert path["e2e_list_str"]["C2 3xCNN L=8"]["seq_per_s"] == pytest.approx(line["end_to_end"]["C2 3xCNN L=8 list_str"]["value"], rel=1e-3)
+    assert set(path["small_call_us (3xCNN L8)"]) == {"1", "4", "20", "100", "2001"}
+    assert path["explorer_round_3xCNN_L8"]["train_n1000_ms"] == pytest.approx(line["explorer_round"]["train_3xCNN_n1000_ms"], rel=1e-3)
+    assert path["dynappo_8xGE_L90_us"] == {"4": 12.0, "10": 12.5} and path["cmaes_3xCNN_L237_us"]["P=40"] == 90.0
+    assert path["settled"]["value"] == pytest.approx(line["settled"]["value"], rel=1e-3)
+    assert set(path["member_parallel"]) == {"8xCNN L=8 A=4 N=1e5", "8xGE L=90 A=20 N=1e5", "8xGE L=90 A=20 N=1e6"}
+    assert set(path["nam_cbas_seq_per_s"]) == {"plain_landscape", "batch_safe_landscape", "device_table_landscape_L8"}
+    # the contract keys are untouched
+    assert out["metric"] == line["metric"] and "workload" in out["config"]
