@@ -12,9 +12,15 @@
 
 #define FX_MAX_M 16          // models fused per launch (larger ensembles are split)
 #define FX_ERR_BADCHAR 1u    // bit in the deferred device error word
-#define FX_SERVE_TILES 16     // ... in 16-sequence tiles, one resident workgroup per (member, tile slot)
-#define FX_SERVE_BYTES 16384   // ... and N x seq_len bytes at most
-#define FX_SERVE_CAP 256      // sequences per request of the resident small-call form (score_cnn_quad.hip)
+// The resident form (score_cnn_quad.hip / score_dense_small.hip, SERVER).  Round 3: <= 16 tile slots per member on a third
+// of the CUs, one tile per slot and request -> 256 sequences.  Round 4 (engine option serve_wide): a generation may take
+// most of the chip -- up to FX_SERVE_TILES slots per member -- and a slot walks the tiles slot, slot + T, slot + 2T, ... of a
+// request, so requests of up to FX_SERVE_CAP sequences / FX_SERVE_BYTES bytes (a Random-explorer round of 2001 8-mers,
+// CbAS batches, Adalead's root + first-children call) are answered without a launch, a weight fill or a second launch.
+#define FX_SERVE_TILES 256     // tile slots per member at most (one resident workgroup each)
+#define FX_SERVE_BYTES 65536   // N x seq_len bytes per request at most
+#define FX_SERVE_CAP 4096      // sequences per request at most
+#define FX_SERVE_FAST 16       // the first slots of every member poll without a pause (explorer-size calls); the others sleep between polls
 
 // ---------------------------------------------------------------- shapes
 struct FxShape {
@@ -181,6 +187,7 @@ struct fx_engine {
         std::vector<uint64_t> versions;
         uint8_t lut[256] = {};
         int L = 0, cap = 0, wgs = 0;                     // ... and the CUs the generation occupies (one workgroup each)
+        int tiles = 0;                                   // tile slots per member of the running generation
         std::vector<fx_model*> refused;                  // the last ensemble that has a member without a resident form
         int refused_L = 0;
         std::vector<fx_model*> pending;                  // the last eligible call's ensemble, and when it came
@@ -191,6 +198,9 @@ struct fx_engine {
     int64_t quad_rotate = 1;    // quad CNN form: the waves' roles rotate from quad to quad (balances the MFMA load of a CU's SIMDs; 0 = same roles: A/B)
     int64_t dense_coop = 1;     // MLP / GE persistent kernel: a workgroup's tiles that do not divide among its four SIMDs are walked by groups of 8 waves (0 = one wave each: A/B)
     int64_t serve_idle_us = 500;   // calls of the same ensemble closer than this start / keep the resident workgroups; they leave after twice this long without a request (a device-wide synchronize waits that long for them at most)
+    int64_t serve_wide = 1;     // 1 = a resident generation takes (num_cus - serve_reserve_cus) / M tile slots per member and serves requests of up to 4096 sequences, a slot walking several tiles (0 = round 3's geometry: a third of the CUs, <= 16 slots, <= 256 sequences: A/B)
+    int64_t serve_reserve_cus = 16;   // CUs a wide generation leaves without a resident workgroup (kernels of other streams -- RCCL, PyTorch -- find room there at once; small ones also fit beside a resident workgroup)
+    int64_t serve_poll_sleep = 4;     // s_sleep units (64 clocks each) between polls of the slots beyond FX_SERVE_FAST (0 = every slot spins)
     int64_t serve_small = 1;    // 1 = explorer-size calls of canonical CNN ensembles are answered by resident workgroups (0 = a launch per call: A/B)
     int64_t fuse_mean = 0;      // 1 = explorer-size CNN ensemble calls average in the scoring kernel (last member to finish a tile, tickets + device-scope fences) instead of launching the mean kernel.  Bit-identical, but the two fences cost what the 3 us launch saves: 32.1 vs 32.2 us per call (profiles/r3_fused_mean_ab.log): off, kept as the A/B
     // chunked host call in flight (fx_score_begin / _submit / _finish)
@@ -303,6 +313,26 @@ int fx_launch_score_cnn_quad_server(fx_engine* e, fx_model* const* models, int M
                                     FxMailIn* d_in, FxMailOut* d_out, unsigned long long idle_ticks, unsigned long long life_ticks);
 int fx_launch_score_dense_small_server(fx_engine* e, fx_model* const* models, int M, int m_off, int tiles, hipStream_t stream,
                                        FxMailIn* d_in, FxMailOut* d_out, unsigned long long idle_ticks, unsigned long long life_ticks);
+// The resident workgroups' wait for the next request (thread 0 of a workgroup): returns the new request word, or `last` with
+// *leave = 1 when told to stop, idle for too long or too old.  Slots >= FX_SERVE_FAST pause `sleep_n` x 64 clocks between polls:
+// hundreds of workgroups spinning on one line of device memory would delay the few that an explorer-size request needs.
+#if defined(__HIPCC__)
+__device__ __forceinline__ unsigned long long fx_server_wait(const FxMailIn* in, unsigned long long last, unsigned long long seen,
+                                                             unsigned long long start, unsigned long long idle_ticks,
+                                                             unsigned long long life_ticks, int slot, int sleep_n, int* leave) {
+    *leave = 0;
+    for (;;) {
+        const unsigned long long r = __hip_atomic_load(&in->req, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (r != last) return r;
+        const unsigned long long now = wall_clock64();
+        if (__hip_atomic_load(&in->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) ||
+            now - seen > (last ? idle_ticks : 64 * idle_ticks) ||       /* (a generation waits longer for its first request) */
+            now - start > life_ticks) { *leave = 1; return last; }
+        if (slot >= FX_SERVE_FAST)
+            for (int k = 0; k < sleep_n; ++k) __builtin_amdgcn_s_sleep(1);
+    }
+}
+#endif
 int fx_launch_score_cnn_pair(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii,
                              int64_t N, float* d_out_NM, int Mtot, int m_off);
 // small launches of the MLP: a tile's output tiles dealt to the waves of a workgroup (score_dense_small.hip)

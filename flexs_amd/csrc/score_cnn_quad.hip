@@ -44,7 +44,7 @@ struct QuadArgs {
     float* mean_out;            // null = off
     unsigned* tickets;          // one per tile, zero between launches (fx_zero_pool; the last arrival resets its entry)
     // resident form
-    int rotate; int srv_tiles; FxMailIn* min; FxMailOut* mout;               // null = ordinary launch
+    int rotate; int srv_tiles; int srv_sleep; FxMailIn* min; FxMailOut* mout;               // null = ordinary launch
     unsigned long long idle_ticks, life_ticks;   // leave after this long without a request / in total (100 MHz ticks)
     int off_c2, off_c3, off_cb, off_w1p, off_d1, off_d2, off_db, total_floats;
 };
@@ -145,43 +145,42 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
             }
         }
       for (;;) {                                                     // (SERVER: one iteration per request)
+        [[maybe_unused]] int srv_rounds = 0;
         if constexpr (SERVER) {
             if (tid == 0) {
                 int ex = 0;
-                unsigned long long r;
-                for (;;) {
-                    r = __hip_atomic_load(&p.min->req, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-                    if (r != srv_last) break;
-                    const unsigned long long now = wall_clock64();
-                    if (__hip_atomic_load(&p.min->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) || now - srv_seen > (srv_last ? p.idle_ticks : 64 * p.idle_ticks) ||   /* (a generation waits longer for its first request) */
-                        now - srv_start > p.life_ticks) { ex = 1; break; }
-                }
+                const unsigned long long r = fx_server_wait(p.min, srv_last, srv_seen, srv_start, p.idle_ticks, p.life_ticks, srv_slot, p.srv_sleep, &ex);
                 srv_req = r; srv_exit = ex; srv_bad = 0;
             }
             __syncthreads();
             if (srv_exit) break;
             Ncur = (int64_t)(srv_req & 0xFFFFull);
             TGcur = (Ncur + 15) >> 4;
-            t_lo = srv_slot; t_hi = srv_slot < TGcur ? srv_slot + 1 : srv_slot;
+            // this slot's tiles of the request: slot, slot + T, slot + 2 T, ... (T = tile slots per member), one round each
+            srv_rounds = srv_slot < TGcur ? (int)((TGcur - srv_slot + p.srv_tiles - 1) / p.srv_tiles) : 0;
+            t_lo = srv_slot; t_hi = srv_slot + srv_rounds;
             bad = false;
-            if (t_hi == t_lo) {                                      // a request with fewer tiles: nothing to answer from this slot
+            if (srv_rounds == 0) {                                   // a request with fewer tiles: nothing to answer from this slot
                 if (tid == 0) { srv_last = srv_req; srv_seen = wall_clock64(); }
                 __syncthreads();                                     // (everybody has read the request word)
                 continue;
             }
-            // this tile's bytes: one dword per thread (past the caches: the host wrote them through the BAR), then everybody reads LDS
-            const int64_t srv_rows = Ncur - (int64_t)srv_slot * 16 < 16 ? Ncur - (int64_t)srv_slot * 16 : 16;
-            if ((int64_t)tid * 4 < srv_rows * L)
-                srv_bytes[tid] = __hip_atomic_load(reinterpret_cast<const unsigned*>(ascii + (int64_t)srv_slot * 16 * L) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __syncthreads();
         }
-        const int rounds = (int)((t_hi - t_lo + QUADS - 1) / QUADS);
+        const int rounds = SERVER ? srv_rounds : (int)((t_hi - t_lo + QUADS - 1) / QUADS);
 
         for (int rd = 0; rd < rounds; ++rd, parity ^= 1) {
-            const int64_t tg = t_lo + (int64_t)rd * QUADS + quad;
-            const bool live = tg < t_hi;                             // idle quads run along for the barriers
+            const int64_t tg = SERVER ? t_lo + (int64_t)rd * p.srv_tiles : t_lo + (int64_t)rd * QUADS + quad;
+            const bool live = SERVER || tg < t_hi;                   // idle quads run along for the barriers
             const int64_t n = tg * 16 + sq;
             const uint8_t* row = ascii + ((live && n < Ncur) ? n : 0) * L;
+            if constexpr (SERVER) {
+                // this tile's bytes: one dword per thread (past the caches: the host wrote them through the BAR), then everybody
+                // reads LDS.  (The previous round's readers of srv_bytes -- its phase A -- are several barriers behind.)
+                const int64_t srv_rows = Ncur - tg * 16 < 16 ? Ncur - tg * 16 : 16;
+                if ((int64_t)tid * 4 < srv_rows * L)
+                    srv_bytes[tid] = __hip_atomic_load(reinterpret_cast<const unsigned*>(ascii + tg * 16 * L) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __syncthreads();
+            }
             f4* X = xq + (parity ? XT * 64 : 0);
             f4* Y = xq + (parity ? 0 : XT * 64);
             asm volatile("" ::: "memory");                           // keep the LDS weight reads inside the round
@@ -474,7 +473,8 @@ int launch_server(fx_engine* e, QuadArgs a, int M, hipStream_t stream) {
 
 // Canonical shapes only (what the explorers' surrogates are built with: kernel size 5, 32 filters, 97-112 hidden units,
 // 4-letter alphabet, seq_len <= 16).  One workgroup (one quad) per member and tile slot: a request of N sequences is
-// answered by M x ceil(N / 16) of them, each on its own CU; at most ~a third of the chip stays resident.
+// answered by M x min(ceil(N / 16), tiles) of them, each on its own CU, slot s walking the tiles s, s + tiles, ... (round 4:
+// a wide generation holds most of the chip and serves up to 4096 sequences per request; round 3's held a third of it).
 int fx_launch_score_cnn_quad_server(fx_engine* e, fx_model* const* models, int M, int m_off, int tiles, hipStream_t stream,
                                     FxMailIn* d_in, FxMailOut* d_out, unsigned long long idle_ticks, unsigned long long life_ticks) {
     const FxShape& s = models[0]->shape;
@@ -495,7 +495,7 @@ int fx_launch_score_cnn_quad_server(fx_engine* e, fx_model* const* models, int M
     a.off_c2 = (int)lay.off_c2; a.off_c3 = (int)lay.off_c3; a.off_cb = (int)lay.off_cb; a.off_w1p = (int)lay.off_w1p;
     a.off_d1 = (int)lay.off_d1; a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
     a.min = d_in; a.mout = d_out; a.idle_ticks = idle_ticks; a.life_ticks = life_ticks;
-    a.srv_tiles = tiles; a.m_off = m_off;
+    a.srv_tiles = tiles; a.m_off = m_off; a.srv_sleep = (int)e->serve_poll_sleep;
     if (L1 == 4) return launch_server<1, 8, 4>(e, a, M, stream);
     if (L1 < 4) return launch_server<1, 8, 0>(e, a, M, stream);
     return launch_server<1, 24, 0>(e, a, M, stream);

@@ -34,7 +34,7 @@ struct SmallArgs {
     int pair;                    // 1 = first layer from the pre-summed pair rows (4-letter alphabets), as the PAIR form of the persistent kernel
     int off_w1p, off_w1pair, off_d2, off_d3, off_db, off_first;
     // SERVER (the resident form, see score_cnn_quad.hip): workgroup = (member, tile slot), requests from the mailboxes
-    int srv_tiles; FxMailIn* min; FxMailOut* mout;
+    int srv_tiles; int srv_sleep; FxMailIn* min; FxMailOut* mout;
     unsigned long long idle_ticks, life_ticks;
 };
 
@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(SW * 64) k_score_dense_small(SmallArgs p) {
 
     const int64_t unit = blockIdx.x;
     const int m = SERVER ? (int)(unit / p.srv_tiles) : (int)(unit / p.TG);
-    const int64_t tg = SERVER ? unit % p.srv_tiles : unit - (int64_t)m * p.TG;
+    const int64_t tg0 = SERVER ? unit % p.srv_tiles : unit - (int64_t)m * p.TG;    // the (first) tile of this workgroup
     int64_t Ncur = p.N;                                  // SERVER: the current request's batch
     // SERVER: request word, exit flag, bad-character flag behind the tile's bytes
     uint8_t* srv_area = bytes_s + ((16 * L + 15) & ~15);
@@ -63,74 +63,71 @@ __global__ void __launch_bounds__(SW * 64) k_score_dense_small(SmallArgs p) {
         __syncthreads();
         if (tid == 0) {
             srv_start = srv_seen = wall_clock64();
-            __hip_atomic_store(const_cast<unsigned*>(&p.mout->alive[p.m_off + m][tg]), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(const_cast<unsigned*>(&p.mout->alive[p.m_off + m][tg0]), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
   for (;;) {                                               // (SERVER: one iteration per request)
     if constexpr (SERVER) {
         if (tid == 0) {
             int ex = 0;
-            unsigned long long r;
-            for (;;) {
-                r = __hip_atomic_load(&p.min->req, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (r != srv_last) break;
-                const unsigned long long now = wall_clock64();
-                if (__hip_atomic_load(&p.min->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) || now - srv_seen > (srv_last ? p.idle_ticks : 64 * p.idle_ticks) ||   /* (a generation waits longer for its first request) */
-                    now - srv_start > p.life_ticks) { ex = 1; break; }
-            }
+            const unsigned long long r = fx_server_wait(p.min, srv_last, srv_seen, srv_start, p.idle_ticks, p.life_ticks, (int)tg0, p.srv_sleep, &ex);
             srv_req = r; srv_exit = ex; srv_bad = 0;
         }
         __syncthreads();
         if (srv_exit) break;
         Ncur = (int64_t)(srv_req & 0xFFFFull);
-        if (tg * 16 >= Ncur) {                               // a request with fewer tiles: nothing to answer from this slot
+        if (tg0 * 16 >= Ncur) {                              // a request with fewer tiles: nothing to answer from this slot
             if (tid == 0) { srv_last = srv_req; srv_seen = wall_clock64(); }
             __syncthreads();                                 // (everybody has read the request word)
             continue;
         }
     }
-    const int64_t rows = Ncur - tg * 16 < 16 ? Ncur - tg * 16 : 16;
-    const int64_t n = tg * 16 + sq;
-    if constexpr (SERVER) {
-        // the tile's bytes, dword-wise and past the caches (the host wrote them through the BAR)
-        const unsigned* src = reinterpret_cast<const unsigned*>(p.min->bytes + tg * 16 * L);
-        for (int i = tid; i * 4 < (int)rows * L; i += SW * 64)
-            reinterpret_cast<unsigned*>(bytes_s)[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    } else {
-        for (int i = tid; i < (int)rows * L; i += SW * 64) bytes_s[i] = p.ascii[tg * 16 * L + i];
-    }
-    __syncthreads();
-    const uint8_t* row = bytes_s + (n < Ncur ? sq : 0) * L;    // lanes past the batch recompute the tile's first sequence
-    const float* W = p.w[m];
     bool bad = false;
-    float y0 = 0.f;
-    fx_dense_tile8<KIND, HT, false>(true, wave, lane, row, L, p.A, p.rlh, p.pair, W + p.off_first, W + p.off_w1p, W + p.off_w1pair,
-                                    reinterpret_cast<const f4*>(W + p.off_d2), reinterpret_cast<const f4*>(W + p.off_d3), W + p.off_db,
-                                    lut_s, hx, SERVER ? &srv_bad : nullptr, bad, y0);
-
-    if (wave == 0) {
-        float y[1] = {y0};
+    // SERVER: this slot's tiles of the request -- slot, slot + T, slot + 2 T, ... (T = tile slots per member); else the one tile
+    for (int64_t tg = tg0; tg == tg0 || (SERVER && tg * 16 < Ncur); tg += SERVER ? p.srv_tiles : 1) {
+        const int64_t rows = Ncur - tg * 16 < 16 ? Ncur - tg * 16 : 16;
+        const int64_t n = tg * 16 + sq;
         if constexpr (SERVER) {
-            // (score, tag) in one 8-byte store to host memory; the fence pushes the lines out of this XCD's L2
-            const unsigned tag = (unsigned)(srv_req >> 16) | (srv_bad ? 0x80000000u : 0u);
-            if (g == 0 && n < Ncur)
-                __hip_atomic_store(const_cast<unsigned long long*>(&p.mout->ans[p.m_off + m][n]),
-                                   ((unsigned long long)tag << 32) | __float_as_uint(fx_nan_to_num(y[0])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __threadfence_system();
+            // the tile's bytes, dword-wise and past the caches (the host wrote them through the BAR)
+            const unsigned* src = reinterpret_cast<const unsigned*>(p.min->bytes + tg * 16 * L);
+            for (int i = tid; i * 4 < (int)rows * L; i += SW * 64)
+                reinterpret_cast<unsigned*>(bytes_s)[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         } else {
-            if (g == 0 && n < Ncur) p.out[n * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y[0]);
+            for (int i = tid; i < (int)rows * L; i += SW * 64) bytes_s[i] = p.ascii[tg * 16 * L + i];
         }
+        __syncthreads();
+        const uint8_t* row = bytes_s + (n < Ncur ? sq : 0) * L;    // lanes past the batch recompute the tile's first sequence
+        const float* W = p.w[m];
+        float y0 = 0.f;
+        fx_dense_tile8<KIND, HT, false>(true, wave, lane, row, L, p.A, p.rlh, p.pair, W + p.off_first, W + p.off_w1p, W + p.off_w1pair,
+                                        reinterpret_cast<const f4*>(W + p.off_d2), reinterpret_cast<const f4*>(W + p.off_d3), W + p.off_db,
+                                        lut_s, hx, SERVER ? &srv_bad : nullptr, bad, y0);
+
+        if (wave == 0) {
+            float y[1] = {y0};
+            if constexpr (SERVER) {
+                // (score, tag) in one 8-byte store to host memory; the fence pushes the lines out of this XCD's L2
+                const unsigned tag = (unsigned)(srv_req >> 16) | (srv_bad ? 0x80000000u : 0u);
+                if (g == 0 && n < Ncur)
+                    __hip_atomic_store(const_cast<unsigned long long*>(&p.mout->ans[p.m_off + m][n]),
+                                       ((unsigned long long)tag << 32) | __float_as_uint(fx_nan_to_num(y[0])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __threadfence_system();
+            } else {
+                if (g == 0 && n < Ncur) p.out[n * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y[0]);
+            }
+        }
+        if constexpr (SERVER) __syncthreads();               // (the byte rows and the exchange buffers are free for the slot's next tile)
     }
     if constexpr (SERVER) {
         if (tid == 0) { srv_last = srv_req; srv_seen = wall_clock64(); }
-        __syncthreads();                                     // (the exchange buffers and the request word are free again)
+        __syncthreads();                                     // (the request word is free again)
     } else {
         if (bad) fx_raise(p.err, FX_ERR_BADCHAR);
         break;
     }
   }
     if constexpr (SERVER) {
-        if (tid == 0) __hip_atomic_store(const_cast<unsigned*>(&p.mout->alive[p.m_off + m][tg]), 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid == 0) __hip_atomic_store(const_cast<unsigned*>(&p.mout->alive[p.m_off + m][tg0]), 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -218,7 +215,7 @@ int fx_launch_score_dense_small_server(fx_engine* e, fx_model* const* models, in
     a.pair = form;
     a.off_w1p = (int)lay.off_w1p; a.off_w1pair = (int)lay.off_w1pair; a.off_d2 = (int)lay.off_d2; a.off_d3 = (int)lay.off_d3;
     a.off_db = (int)lay.off_db; a.off_first = (int)lay.off_first;
-    a.srv_tiles = tiles; a.min = d_in; a.mout = d_out; a.idle_ticks = idle_ticks; a.life_ticks = life_ticks;
+    a.srv_tiles = tiles; a.srv_sleep = (int)e->serve_poll_sleep; a.min = d_in; a.mout = d_out; a.idle_ticks = idle_ticks; a.life_ticks = life_ticks;
 #define FX_SMALL_CASES(KIND)                                               \
     switch (lay.HT) {                                                      \
         case 1: return launch_small_server<KIND, 1>(e, a, M, stream);      \

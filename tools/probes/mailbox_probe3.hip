@@ -1,0 +1,146 @@
+// Third mailbox probe (gfx950), for the WIDE resident form (round-3 verdict, Next #1): how does the request round trip
+// scale when (almost) every CU hosts a resident workgroup, only SOME of which have work in a request?
+//   G resident workgroups poll one request word in fine-grained device memory (host writes through the BAR);
+//   a request names T tiles of 16 sequences; workgroup b owns tiles b, b + G, ...: it reads its tile's 128 request bytes
+//   (system-scope loads), waits `work` wall-clock ticks (stands in for the tile's arithmetic) and stores 16 tagged 8-byte
+//   answers per tile into pinned host memory + one system fence;
+//   poll modes: 0 = every workgroup spins; s > 0 = workgroups >= FAST sleep s x 64 cycles between polls (FAST = 48 keep spinning).
+// Host: memcpy of the request bytes into the BAR window, sfence, request word, sfence; scan of all 16 T tags.
+// Also: BAR write bandwidth for 16 KiB .. 256 KiB, and the host's scan rate over answers that are already there.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <immintrin.h>
+
+#define CK(x) do { hipError_t rc_ = (x); if (rc_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(rc_)); fflush(stdout); exit(2); } } while (0)
+#define MAXB (256 << 10)
+#define MAXT 2048
+
+struct MailIn { alignas(64) unsigned long long req; alignas(64) unsigned stop; alignas(64) unsigned bytes_w[MAXB / 4]; };
+
+__global__ void __launch_bounds__(256) k_server(MailIn* in, volatile unsigned long long* ans, unsigned long long life_ticks, int fast, int sleep_n,
+                                                 unsigned long long work_ticks) {
+    __shared__ unsigned long long s_req;
+    __shared__ int s_exit;
+    __shared__ unsigned s_bytes[32];
+    unsigned long long last = 0;
+    const unsigned long long t_start = wall_clock64();
+    const int G = gridDim.x, b = blockIdx.x;
+    for (;;) {
+        if (threadIdx.x == 0) {
+            int ex = 0;
+            unsigned long long r;
+            for (;;) {
+                r = __hip_atomic_load(&in->req, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (r != last) break;
+                if (__hip_atomic_load(&in->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) || wall_clock64() - t_start > life_ticks) { ex = 1; break; }
+                if (sleep_n > 0 && b >= fast) for (int k = 0; k < sleep_n; ++k) __builtin_amdgcn_s_sleep(1);
+            }
+            s_req = r; s_exit = ex;
+        }
+        __syncthreads();
+        if (s_exit) break;
+        const unsigned long long r = s_req;
+        const int T = (int)(r & 0xFFFF);
+        const unsigned tag = (unsigned)(r >> 16);
+        for (int t = b; t < T; t += G) {
+            if (threadIdx.x < 32)
+                s_bytes[threadIdx.x] = __hip_atomic_load(in->bytes_w + (size_t)t * 32 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __syncthreads();
+            if (work_ticks) { const unsigned long long t0 = wall_clock64(); while (wall_clock64() - t0 < work_ticks) {} }
+            if (threadIdx.x < 16)
+                __hip_atomic_store(const_cast<unsigned long long*>(&ans[(size_t)t * 16 + threadIdx.x]),
+                                   ((unsigned long long)tag << 32) | (s_bytes[threadIdx.x] & 0xFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
+            __syncthreads();
+        }
+        last = r;
+        __syncthreads();
+    }
+}
+
+static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main() {
+    MailIn* in = nullptr;
+    CK(hipExtMallocWithFlags((void**)&in, sizeof(MailIn), hipDeviceMallocFinegrained));
+    unsigned long long* h_ans = nullptr; unsigned long long* d_ans = nullptr;
+    CK(hipHostMalloc((void**)&h_ans, (size_t)MAXT * 16 * 8, hipHostMallocMapped | hipHostMallocCoherent));
+    CK(hipHostGetDevicePointer((void**)&d_ans, h_ans, 0));
+    std::memset(h_ans, 0, (size_t)MAXT * 16 * 8);
+    std::vector<unsigned char> src(MAXB);
+    for (size_t i = 0; i < src.size(); ++i) src[i] = (unsigned char)(i * 7);
+    // ---- BAR write bandwidth
+    for (size_t bytes : {(size_t)1024, (size_t)16384, (size_t)65536, (size_t)262144}) {
+        std::vector<double> ts;
+        for (int it = 0; it < 200; ++it) {
+            const double a = now_us();
+            std::memcpy(in->bytes_w, src.data(), bytes);
+            _mm_sfence();
+            ts.push_back(now_us() - a);
+        }
+        std::sort(ts.begin(), ts.end());
+        printf("BAR write of %6zu bytes + sfence: median %.2f us (%.1f GB/s)\n", bytes, ts[100], bytes / ts[100] * 1e-3);
+    }
+    // ---- host scan rate over answers already in memory (what server_call's per-element loop costs without waiting)
+    for (int T : {16, 128, 384, 1875}) {
+        for (int i = 0; i < T * 16; ++i) h_ans[i] = (0x1234ull << 32) | (unsigned)i;
+        std::vector<double> ts;
+        volatile unsigned long long sink = 0;
+        for (int it = 0; it < 50; ++it) {
+            const double a = now_us();
+            unsigned long long s = 0;
+            for (int i = 0; i < T * 16; ++i) { unsigned long long v; while ((((v = ((volatile unsigned long long*)h_ans)[i]) >> 32) & 0x7FFFFFFFu) != 0x1234u) {} s += v; }
+            sink += s;
+            ts.push_back(now_us() - a);
+        }
+        std::sort(ts.begin(), ts.end());
+        printf("host scan of %5d tagged answers (warm): median %.2f us\n", T * 16, ts[25]);
+    }
+    hipStream_t s1; CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+    unsigned long long seq = 0;
+    printf("\n   G  fast sleep work_us    T  bytes   median_us  p90_us  p99_us\n");
+    struct Cfg { int G, fast, sleep_n; double work_us; };
+    const Cfg cfgs[] = {{48, 48, 0, 0}, {128, 48, 0, 0}, {240, 48, 0, 0}, {240, 48, 2, 0}, {240, 48, 8, 0}, {240, 48, 32, 0},
+                        {48, 48, 0, 4.5}, {240, 48, 0, 4.5}, {240, 48, 8, 4.5}};
+    for (const Cfg& c : cfgs) {
+        in->req = 0; in->stop = 0; _mm_sfence();
+        CK(hipDeviceSynchronize());
+        hipLaunchKernelGGL(k_server, dim3(c.G), dim3(256), 0, s1, in, d_ans, 400000000ull, c.fast, c.sleep_n, (unsigned long long)(c.work_us * 100));
+        CK(hipGetLastError());
+        for (int T : {3, 48, 384, 1875}) {
+            const size_t bytes = (size_t)T * 128;
+            std::vector<double> ts;
+            bool ok = true;
+            for (int it = 0; it < 1200 && ok; ++it) {
+                const double a = now_us();
+                std::memcpy(in->bytes_w, src.data(), bytes);
+                _mm_sfence();
+                seq = (seq + 1) & 0x7FFFFFFFull; if (!seq) seq = 1;
+                in->req = (seq << 16) | (unsigned)T;
+                _mm_sfence();
+                for (int i = 0; i < T * 16 && ok; ++i) {
+                    unsigned spins = 0;
+                    while (((((volatile unsigned long long*)h_ans)[i] >> 32) & 0x7FFFFFFFull) != seq) {
+                        _mm_pause();
+                        if ((++spins & 0xFFFu) == 0 && now_us() - a > 2e6) { ok = false; break; }
+                    }
+                }
+                const double bq = now_us();
+                if (it >= 100) ts.push_back(bq - a);
+            }
+            if (!ok) { printf("%4d %4d %4d %6.1f %5d %6zu   TIMED OUT\n", c.G, c.fast, c.sleep_n, c.work_us, T, bytes); break; }
+            std::sort(ts.begin(), ts.end());
+            printf("%4d %4d %4d %6.1f %5d %6zu   %8.2f %7.2f %7.2f\n", c.G, c.fast, c.sleep_n, c.work_us, T, bytes, ts[ts.size() / 2], ts[ts.size() * 9 / 10], ts[ts.size() * 99 / 100]);
+            fflush(stdout);
+        }
+        in->stop = 1; _mm_sfence();
+        CK(hipStreamSynchronize(s1));
+    }
+    return 0;
+}
