@@ -253,8 +253,8 @@ CHUNK_BYTES = int(os.environ.get("FLEXS_AMD_CHUNK_BYTES", 0))   # target bytes p
 
 
 # ---- explorer-size calls: one C call packs the strings and runs fx_score (csrc/strpack.c score_small) -------------------
-SMALL_CALL_ROWS = 256            # what the engine's resident form answers (FX_SERVE_CAP)
-SMALL_CALL_BYTES = 16384
+SMALL_CALL_ROWS = 4096           # what the engine's resident form answers (FX_SERVE_CAP; 256 until round 4)
+SMALL_CALL_BYTES = 65536         # (FX_SERVE_BYTES, and the stack buffer of csrc/strpack.c score_small)
 _HAS_SCORE_SMALL = _strpack is not None and hasattr(_strpack, "score_small")
 
 

@@ -299,6 +299,10 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "dense_coop")) return &e->dense_coop;
     if (!std::strcmp(key, "quad_rotate")) return &e->quad_rotate;
     if (!std::strcmp(key, "serve_small")) return &e->serve_small;
+    if (!std::strcmp(key, "serve_wide")) return &e->serve_wide;
+    if (!std::strcmp(key, "serve_reserve_cus")) return &e->serve_reserve_cus;
+    if (!std::strcmp(key, "serve_poll_sleep")) return &e->serve_poll_sleep;
+    if (!std::strcmp(key, "serve_fence")) return &e->serve_fence;
     if (!std::strcmp(key, "serve_idle_us")) return &e->serve_idle_us;
     if (!std::strcmp(key, "chunk_overlap")) return &e->chunk_overlap;
     if (!std::strcmp(key, "zero_copy_bytes")) return &e->zero_copy_bytes;
@@ -314,6 +318,8 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
 int fx_engine_set_option(fx_engine* e, const char* key, int64_t value) {
     int64_t* s = option_slot(e, key);
     if (!s) return fx_fail(e, FX_EINVAL, std::string("unknown option ") + (key ? key : "(null)"));
+    const bool geometry = s == &e->serve_wide || s == &e->serve_reserve_cus || s == &e->serve_poll_sleep || s == &e->serve_fence;
+    if (geometry && *s != value) fx_server_stop(e);        // (a running generation has the old geometry: the next calls start a new one)
     *s = value;
     e->server.refused.clear();                             // (what has a resident form depends on the form selectors)
     return FX_OK;
@@ -682,12 +688,25 @@ static int server_start(fx_engine* e, fx_model* const* models, int M, int L, con
     int rc = fx_upload_lut(e, lut);
     if (rc) return rc;
     FX_HIP(e, hipStreamSynchronize(e->stream));            // the LUT (and any weight upload) must have landed before the workgroups read them
-    // one workgroup per (member, 16-sequence tile slot), a third of the chip at most
-    int tiles = e->num_cus / 3 / M;
-    if (tiles > FX_SERVE_TILES) tiles = FX_SERVE_TILES;
-    if (tiles > FX_SERVE_BYTES / (16 * L)) tiles = FX_SERVE_BYTES / (16 * L);
-    if (tiles < 1) return FX_EUNSUPPORTED;
-    const int cap = 16 * tiles;
+    // one workgroup per (member, 16-sequence tile slot).  Wide generation (round 4): most of the chip -- slot s of a member
+    // walks the tiles s, s + tiles, s + 2 tiles, ... of a request, so the capacity is what the mailboxes hold, not the slot
+    // count; round 3's geometry (serve_wide = 0): a third of the chip, <= 16 slots, one tile per slot.
+    int tiles, cap;
+    if (e->serve_wide) {
+        int reserve = (int)e->serve_reserve_cus;
+        if (reserve < 0) reserve = 0;
+        if (reserve > e->num_cus - M) reserve = e->num_cus - M;
+        tiles = (e->num_cus - reserve) / M;
+        if (tiles > FX_SERVE_TILES) tiles = FX_SERVE_TILES;
+        if (tiles < 1) return FX_EUNSUPPORTED;
+        cap = FX_SERVE_BYTES / L < FX_SERVE_CAP ? FX_SERVE_BYTES / L : FX_SERVE_CAP;
+    } else {
+        tiles = e->num_cus / 3 / M;
+        if (tiles > 16) tiles = 16;
+        if (tiles > 16384 / (16 * L)) tiles = 16384 / (16 * L);
+        if (tiles < 1) return FX_EUNSUPPORTED;
+        cap = 16 * tiles;
+    }
     // a host that stops asking (or dies) frees the CUs by itself: after 2 x serve_idle_us (100 MHz ticks), and 10 s whatever happens
     const unsigned long long idle = (unsigned long long)e->serve_idle_us * 200ull, life = 1000000000ull;
     // consecutive like members form a group; every group is its own resident launch on its own stream (all read the same
@@ -732,7 +751,7 @@ static int server_start(fx_engine* e, fx_model* const* models, int M, int L, con
     sv.versions.clear();
     for (int m = 0; m < M; ++m) sv.versions.push_back(models[m]->version);
     std::memcpy(sv.lut, lut, 256);
-    sv.L = L; sv.cap = cap; sv.wgs = M * tiles;
+    sv.L = L; sv.cap = cap; sv.wgs = M * tiles; sv.tiles = tiles;
     sv.running = true; sv.fresh = true;
     sv.t_start = std::chrono::steady_clock::now();
     sv.started += 1;
@@ -754,10 +773,16 @@ static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8
         // the workgroups leave 2 x serve_idle_us after their last request: do not post to a generation that may be on its way out
         if (!sv.fresh && std::chrono::duration<double>(std::chrono::steady_clock::now() - sv.t_post).count() * 1e6 > (double)e->serve_idle_us)
             server_stop(e);
-        if (!sv.fresh)
-            for (int m = 0; m < M && sv.running; ++m)
-                for (int t = 0; t < sv.cap / 16; ++t)
-                    if (!sv.h_out->alive[m][t]) { server_stop(e); break; }       // leaving by themselves (idle / lifetime): all go
+        if (!sv.fresh) {
+            // leaving by themselves (idle / lifetime): all go.  Looked at for the slots this request needs -- those are the
+            // ones whose answers would be waited for -- and, cheaply, for one rotating slot beyond them
+            const int need = (int)std::min<int64_t>((N + 15) / 16, sv.tiles);
+            for (int m = 0; m < M && sv.running; ++m) {
+                for (int t = 0; t < need; ++t)
+                    if (!sv.h_out->alive[m][t]) { server_stop(e); break; }
+                if (sv.running && !sv.h_out->alive[m][(int)(sv.seq % (unsigned)sv.tiles)]) server_stop(e);
+            }
+        }
         // (a generation is replaced well before its workgroups' own lifetime limit)
         if (sv.running && std::chrono::duration<double>(std::chrono::steady_clock::now() - sv.t_start).count() > 4.0) server_stop(e);
     }
@@ -802,7 +827,7 @@ static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8
             while ((((a = h->ans[m][n]) >> 32) & 0x7FFFFFFFull) != seq) {
                 __builtin_ia32_pause();                     // (spin-wait hint: leaves the core's resources to a sibling hyperthread)
                 if ((++spins & 1023u) == 0) {
-                    const bool gone = !sv.fresh && !h->alive[m][n >> 4];
+                    const bool gone = !sv.fresh && !h->alive[m][(n >> 4) % sv.tiles];
                     const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                     // (this thread may have been off the core for milliseconds between the read above and this clock: look again
                     //  before giving up on an answer that has arrived meanwhile)

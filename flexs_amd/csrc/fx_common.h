@@ -200,6 +200,7 @@ struct fx_engine {
     int64_t serve_idle_us = 500;   // calls of the same ensemble closer than this start / keep the resident workgroups; they leave after twice this long without a request (a device-wide synchronize waits that long for them at most)
     int64_t serve_wide = 1;     // 1 = a resident generation takes (num_cus - serve_reserve_cus) / M tile slots per member and serves requests of up to 4096 sequences, a slot walking several tiles (0 = round 3's geometry: a third of the CUs, <= 16 slots, <= 256 sequences: A/B)
     int64_t serve_reserve_cus = 16;   // CUs a wide generation leaves without a resident workgroup (kernels of other streams -- RCCL, PyTorch -- find room there at once; small ones also fit beside a resident workgroup)
+    int64_t serve_fence = 0;    // 1 = a system fence after every tile's answers (round 3: ~0.5 us each, and the fences of one XCD serialise -- 24 us for the 378 tiles of a 2001-sequence request, profiles/r4_mailbox_probe3.log); 0 = none: the answers are system-scope stores, which write through by themselves (profiles/r4_mailbox_probe4.log)
     int64_t serve_poll_sleep = 4;     // s_sleep units (64 clocks each) between polls of the slots beyond FX_SERVE_FAST (0 = every slot spins)
     int64_t serve_small = 1;    // 1 = explorer-size calls of canonical CNN ensembles are answered by resident workgroups (0 = a launch per call: A/B)
     int64_t fuse_mean = 0;      // 1 = explorer-size CNN ensemble calls average in the scoring kernel (last member to finish a tile, tickets + device-scope fences) instead of launching the mean kernel.  Bit-identical, but the two fences cost what the 3 us launch saves: 32.1 vs 32.2 us per call (profiles/r3_fused_mean_ab.log): off, kept as the A/B
@@ -322,8 +323,11 @@ __device__ __forceinline__ unsigned long long fx_server_wait(const FxMailIn* in,
                                                              unsigned long long life_ticks, int slot, int sleep_n, int* leave) {
     *leave = 0;
     for (;;) {
-        const unsigned long long r = __hip_atomic_load(&in->req, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (r != last) return r;
+        // relaxed polls, ONE acquire fence when the word changes: an acquire load is an L2 invalidate per iteration, and
+        // 240 workgroups invalidating their L2s in a loop delayed everybody (tools/probes/mailbox_probe4.hip: request round
+        // trip of 3 workgroups beside 237 idle ones 6.8 us with acquire polls, 4.7 us with relaxed ones; 3.5 us alone)
+        const unsigned long long r = __hip_atomic_load(&in->req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (r != last) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return r; }
         const unsigned long long now = wall_clock64();
         if (__hip_atomic_load(&in->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) ||
             now - seen > (last ? idle_ticks : 64 * idle_ticks) ||       /* (a generation waits longer for its first request) */

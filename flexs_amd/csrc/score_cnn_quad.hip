@@ -44,7 +44,7 @@ struct QuadArgs {
     float* mean_out;            // null = off
     unsigned* tickets;          // one per tile, zero between launches (fx_zero_pool; the last arrival resets its entry)
     // resident form
-    int rotate; int srv_tiles; int srv_sleep; FxMailIn* min; FxMailOut* mout;               // null = ordinary launch
+    int rotate; int srv_tiles; int srv_sleep; int srv_fence; FxMailIn* min; FxMailOut* mout;               // null = ordinary launch
     unsigned long long idle_ticks, life_ticks;   // leave after this long without a request / in total (100 MHz ticks)
     int off_c2, off_c3, off_cb, off_w1p, off_d1, off_d2, off_db, total_floats;
 };
@@ -326,12 +326,13 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
                 float y[1];
                 final_dot<HT, 1>(db + 32 * HT, db[48 * HT], h2, y, g);
                 if constexpr (SERVER) {
-                    // (score, tag) in one 8-byte store to host memory; the fence pushes the lines out of this XCD's L2
+                    // (score, tag) in one 8-byte SYSTEM-scope store to host memory: written through every cache level by itself
+                    // (round 3 added a system fence per tile -- ~0.5 us each, serialised per XCD; off by default now, serve_fence)
                     const unsigned tag = (unsigned)(srv_req >> 16) | (srv_bad ? 0x80000000u : 0u);
                     if (g == 0 && n < Ncur)
                         __hip_atomic_store(const_cast<unsigned long long*>(&p.mout->ans[p.m_off + m][n]),
                                            ((unsigned long long)tag << 32) | __float_as_uint(fx_nan_to_num(y[0])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    __threadfence_system();
+                    if (p.srv_fence) __threadfence_system();
                 } else {
                     if (g == 0 && n < Ncur) outp[n * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y[0]);
                 }
@@ -495,7 +496,7 @@ int fx_launch_score_cnn_quad_server(fx_engine* e, fx_model* const* models, int M
     a.off_c2 = (int)lay.off_c2; a.off_c3 = (int)lay.off_c3; a.off_cb = (int)lay.off_cb; a.off_w1p = (int)lay.off_w1p;
     a.off_d1 = (int)lay.off_d1; a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
     a.min = d_in; a.mout = d_out; a.idle_ticks = idle_ticks; a.life_ticks = life_ticks;
-    a.srv_tiles = tiles; a.m_off = m_off; a.srv_sleep = (int)e->serve_poll_sleep;
+    a.srv_tiles = tiles; a.m_off = m_off; a.srv_sleep = (int)e->serve_poll_sleep; a.srv_fence = (int)e->serve_fence;
     if (L1 == 4) return launch_server<1, 8, 4>(e, a, M, stream);
     if (L1 < 4) return launch_server<1, 8, 0>(e, a, M, stream);
     return launch_server<1, 24, 0>(e, a, M, stream);

@@ -34,7 +34,7 @@ struct SmallArgs {
     int pair;                    // 1 = first layer from the pre-summed pair rows (4-letter alphabets), as the PAIR form of the persistent kernel
     int off_w1p, off_w1pair, off_d2, off_d3, off_db, off_first;
     // SERVER (the resident form, see score_cnn_quad.hip): workgroup = (member, tile slot), requests from the mailboxes
-    int srv_tiles; int srv_sleep; FxMailIn* min; FxMailOut* mout;
+    int srv_tiles; int srv_sleep; int srv_fence; FxMailIn* min; FxMailOut* mout;
     unsigned long long idle_ticks, life_ticks;
 };
 
@@ -106,12 +106,12 @@ __global__ void __launch_bounds__(SW * 64) k_score_dense_small(SmallArgs p) {
         if (wave == 0) {
             float y[1] = {y0};
             if constexpr (SERVER) {
-                // (score, tag) in one 8-byte store to host memory; the fence pushes the lines out of this XCD's L2
+                // (score, tag) in one 8-byte SYSTEM-scope store to host memory (written through by itself; serve_fence = 1 adds round 3's fence)
                 const unsigned tag = (unsigned)(srv_req >> 16) | (srv_bad ? 0x80000000u : 0u);
                 if (g == 0 && n < Ncur)
                     __hip_atomic_store(const_cast<unsigned long long*>(&p.mout->ans[p.m_off + m][n]),
                                        ((unsigned long long)tag << 32) | __float_as_uint(fx_nan_to_num(y[0])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __threadfence_system();
+                if (p.srv_fence) __threadfence_system();
             } else {
                 if (g == 0 && n < Ncur) p.out[n * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y[0]);
             }
@@ -215,7 +215,7 @@ int fx_launch_score_dense_small_server(fx_engine* e, fx_model* const* models, in
     a.pair = form;
     a.off_w1p = (int)lay.off_w1p; a.off_w1pair = (int)lay.off_w1pair; a.off_d2 = (int)lay.off_d2; a.off_d3 = (int)lay.off_d3;
     a.off_db = (int)lay.off_db; a.off_first = (int)lay.off_first;
-    a.srv_tiles = tiles; a.srv_sleep = (int)e->serve_poll_sleep; a.min = d_in; a.mout = d_out; a.idle_ticks = idle_ticks; a.life_ticks = life_ticks;
+    a.srv_tiles = tiles; a.srv_sleep = (int)e->serve_poll_sleep; a.srv_fence = (int)e->serve_fence; a.min = d_in; a.mout = d_out; a.idle_ticks = idle_ticks; a.life_ticks = life_ticks;
 #define FX_SMALL_CASES(KIND)                                               \
     switch (lay.HT) {                                                      \
         case 1: return launch_small_server<KIND, 1>(e, a, M, stream);      \

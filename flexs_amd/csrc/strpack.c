@@ -205,7 +205,7 @@ typedef struct {
     void* models[16];
     unsigned char lut[256];
 } SmallPlan;
-#define SMALL_MAX_BYTES 16384
+#define SMALL_MAX_BYTES 65536          /* = FX_SERVE_BYTES: what one request of the resident form holds */
 
 static PyObject* score_small(PyObject* self, PyObject* args) {
     Py_buffer plan, out;

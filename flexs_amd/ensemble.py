@@ -87,7 +87,7 @@ class Ensemble(_EnsembleBase):
         return state
 
     def _score_small(self, sequences):
-        """Calls of up to 256 strings: string packing + fx_score in ONE C call (csrc/strpack.c score_small) on an
+        """Calls of up to 4096 strings (SMALL_CALL_ROWS): string packing + fx_score in ONE C call (csrc/strpack.c score_small) on an
         argument block cached per member list.  None = not for this path (the general one below decides and raises)."""
         models = self.models
         c = self._small

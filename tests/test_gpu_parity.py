@@ -2167,6 +2167,80 @@ def test_resident_answers_against_the_oracle(eng):
         _few_fallbacks(eng, fb0, f"{kind} L={L}")
 
 
+@pytest.mark.parametrize("kind,L,alpha,H,M", [("cnn", 8, "TGCA", 100, 3), ("cnn", 8, "TGCA", 100, 1), ("cnn", 14, "UGCA", 100, 2),
+                                             ("mlp", 14, "UGCA", 100, 1), ("ge", 14, "UGCA", 100, 3), ("ge", 90, s_utils.AAS, 100, 8),
+                                             ("mlp", 90, s_utils.AAS, 100, 1), ("mix", 14, "UGCA", 100, 3)])
+def test_resident_wide_form(eng, kind, L, alpha, H, M):
+    """Round 4 (`serve_wide`, default on): a resident generation takes most of the chip and a tile slot walks the tiles
+    slot, slot + T, slot + 2 T, ... of a request, so calls of 257 ... 4096 sequences (64 KiB of sequence bytes) -- a Random
+    explorer round of 2001, CbAS batches, Adalead's roots + first children -- are answered without a launch, a weight fill
+    and a second launch for the mean.  Same round / tile code as the launched small forms, so the SAME BITS as the launched
+    call (which for these sizes runs the one-wave-per-tile kernels: the forms are bit-identical by construction), and
+    directly beside the float64 oracle; sizes the mailboxes do not hold launch as before; a character outside the alphabet
+    in a late tile of a late slot is the reference's ValueError; round 3's geometry (serve_wide = 0) still serves <= 256."""
+    if kind == "mix":
+        members = [bm.GlobalEpistasisModel(L, 100, alpha, seed=1), bm.MLP(L, 200, alpha, seed=2), bm.CNN(L, 32, 100, alpha, seed=3)]
+        kinds = ["ge", "mlp", "cnn"]
+    else:
+        mk = {"cnn": lambda s: bm.CNN(L, 32, H, alpha, seed=s), "mlp": lambda s: bm.MLP(L, H, alpha, seed=s),
+              "ge": lambda s: bm.GlobalEpistasisModel(L, H, alpha, seed=s)}[kind]
+        members = [mk(70 + s) for s in range(M)]
+        kinds = [kind] * M
+    ens = flexs_amd.Ensemble(members) if M > 1 else members[0]
+    stack = flexs_amd.Ensemble(members, combine_with=lambda x: x)
+    cap = min(4096, 65536 // L)
+    sizes = [257, 300, 1000, 2001, cap - 1, cap, cap + 1]
+    if cap < 2001:
+        sizes = [257, 300, cap // 2, cap - 1, cap, cap + 1]
+    data = {n: rand_seqs(n, L, alpha, seed=400 + n)[1] for n in sizes}
+    eng.set_option("serve_small", 0)
+    try:
+        want = {n: ens.get_fitness(data[n]) for n in sizes}
+        want_nm = {n: stack.get_fitness(data[n]) for n in sizes}
+    finally:
+        eng.set_option("serve_small", 1)
+    small = data[257][:20]
+    assert _until_resident(eng, lambda: ens.get_fitness(small))
+    fb0 = eng.get_option("server_fallbacks")
+    for rep in range(2):
+        for n in sizes:
+            ens.get_fitness(small)                                       # (a launch for cap + 1 told the generation to leave)
+            ens.get_fitness(small)
+            c0 = eng.get_option("server_calls") + eng.get_option("server_fallbacks")
+            got = ens.get_fitness(data[n])
+            got_nm = stack.get_fitness(data[n])
+            served = eng.get_option("server_calls") + eng.get_option("server_fallbacks") - c0
+            assert served == (2 if n <= cap else 0), (n, cap, served)
+            assert np.array_equal(got, want[n]), (kind, n, rep)
+            assert np.array_equal(got_nm, want_nm[n]), (kind, n, rep)
+    _few_fallbacks(eng, fb0, f"wide {kind} L={L}")
+    # beside the oracle, directly
+    n = sizes[3]
+    got_nm = stack.get_fitness(data[n])
+    for m, (mod, kd) in enumerate(zip(members, kinds)):
+        ref = ref_np.keras_fitness(data[n], alpha, kd, [np.asarray(w, np.float64) for w in mod.model.get_weights()], exact=True)
+        assert_scores(got_nm[:, m], ref, f"wide resident {kd} L={L} member {m} n={n}")
+    # a character outside the alphabet in the LAST tile (a late slot's second or third tile): ValueError, then business as usual
+    for _ in range(3):
+        ens.get_fitness(small)
+    bad = list(data[sizes[3]])
+    bad[-1] = bad[-1][:-1] + "!"
+    with pytest.raises(ValueError):
+        ens.get_fitness(bad)
+    assert np.array_equal(ens.get_fitness(data[sizes[3]]), want[sizes[3]])
+    # round 3's geometry: <= 256 sequences are served, 257 launch; same bits
+    eng.set_option("serve_wide", 0)
+    try:
+        assert _until_resident(eng, lambda: ens.get_fitness(small))
+        c0 = eng.get_option("server_calls") + eng.get_option("server_fallbacks")
+        assert np.array_equal(ens.get_fitness(data[257][:100]), want[257][:100])     # (a prefix on its own: same bits, batch invariance)
+        got = ens.get_fitness(data[257])
+        assert np.array_equal(got, want[257])
+        assert eng.get_option("server_calls") + eng.get_option("server_fallbacks") - c0 <= 1
+    finally:
+        eng.set_option("serve_wide", 1)
+
+
 def test_small_call_fast_path_bookkeeping(eng):
     """The Python side of explorer-size calls (one C call on an argument block cached per model list): the block follows the
     member list when it is edited, copies and pickles carry no device handles, costs are charged as by the general path, every

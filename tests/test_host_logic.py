@@ -480,7 +480,7 @@ def test_score_small_packs_and_calls_through_the_plan():
     assert _native._strpack.score_small(plan, ["ACGT", "TTTሴ"], out) == 1002      # not latin-1
     assert _native._strpack.score_small(plan, ["ACGT", 5], out) == 1003               # not a str
     assert _native._strpack.score_small(plan, ["ACGT"] * 3, np.empty(3, np.float32)) == 2003   # the callee's FX_EBADCHAR
-    assert _native._strpack.score_small(plan, ["ACGT"] * 5000, np.empty(5000, np.float32)) == -1  # too big for this path
+    assert _native._strpack.score_small(plan, ["ACGT"] * 16385, np.empty(16385, np.float32)) == -1  # more than 64 KiB of sequence bytes: too big for this path
     assert _native._strpack.score_small(plan, ["ACGT", "TTTT"], np.empty(1, np.float32)) == -1     # output too small
     assert _native._strpack.score_small(b"xx", ["ACGT"], out) == -1
     assert _native._strpack.score_small(plan, np.array(["ACGT"]), out) == -1          # not a list / tuple
