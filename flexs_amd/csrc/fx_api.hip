@@ -683,7 +683,7 @@ static int server_start(fx_engine* e, fx_model* const* models, int M, int L, con
     }
     for (int g = 0; g < sv.groups; ++g) FX_HIP(e, hipStreamSynchronize(sv.streams[g]));   // a previous generation has left (it was told to, or timed out)
     std::memset((void*)sv.h_out->alive, 0, sizeof(sv.h_out->alive));   // (answers carry sequence numbers that never repeat: no need to clear them)
-    sv.in->req = 0; sv.in->stop = 0;                       // (through the BAR, like every host access to it; posted before the launch's doorbell)
+    sv.in->req = 0; sv.in->req_wide = 0; sv.in->stop = 0;  // (through the BAR, like every host access to it; posted before the launch's doorbell)
     fx_bar_fence();
     int rc = fx_upload_lut(e, lut);
     if (rc) return rc;
@@ -700,12 +700,18 @@ static int server_start(fx_engine* e, fx_model* const* models, int M, int L, con
         if (tiles > FX_SERVE_TILES) tiles = FX_SERVE_TILES;
         if (tiles < 1) return FX_EUNSUPPORTED;
         cap = FX_SERVE_BYTES / L < FX_SERVE_CAP ? FX_SERVE_BYTES / L : FX_SERVE_CAP;
+        // the first slots of every member -- as many as round 3's whole generation had -- spin on `req`; the rest poll `req_wide`
+        sv.fast = e->num_cus / 3 / M;
+        if (sv.fast > FX_SERVE_FAST) sv.fast = FX_SERVE_FAST;
+        if (sv.fast < 1) sv.fast = 1;
+        if (sv.fast > tiles) sv.fast = tiles;
     } else {
         tiles = e->num_cus / 3 / M;
         if (tiles > 16) tiles = 16;
         if (tiles > 16384 / (16 * L)) tiles = 16384 / (16 * L);
         if (tiles < 1) return FX_EUNSUPPORTED;
         cap = 16 * tiles;
+        sv.fast = tiles;
     }
     // a host that stops asking (or dies) frees the CUs by itself: after 2 x serve_idle_us (100 MHz ticks), and 10 s whatever happens
     const unsigned long long idle = (unsigned long long)e->serve_idle_us * 200ull, life = 1000000000ull;
@@ -808,6 +814,8 @@ static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8
     fx_bar_fence();
     if ((++sv.seq & 0x7FFFFFFFull) == 0) ++sv.seq;         // 31-bit tags, never 0; they run on across generations, so a slot's stale answer never matches
     const unsigned seq = (unsigned)(sv.seq & 0x7FFFFFFFull);
+    // (the slots beyond the fast ones poll the copy: written first -- a slot that sees it early finds the bytes in place all the same)
+    if (sv.fast < sv.tiles) sv.in->req_wide = ((unsigned long long)seq << 16) | (unsigned long long)N;
     sv.in->req = ((unsigned long long)seq << 16) | (unsigned long long)N;
     fx_bar_fence();
     const auto t0 = std::chrono::steady_clock::now();
@@ -819,36 +827,64 @@ static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8
     const double limit = sv.fresh ? 3.0 : 0.02;
     const FxMailOut* h = sv.h_out;
     bool bad = false;
-    float x[FX_MAX_M];
-    for (int64_t n = 0; n < N; ++n) {
-        for (int m = 0; m < M; ++m) {
+    // Collected MEMBER BY MEMBER into planes: every answer line was just written by the device, i.e. is a cache miss for
+    // this core, and a (sequence, member) walk touches M streams at once with nothing requested ahead -- 32 ns per sequence
+    // for three members, more than the device needed for a 1000-sequence request (profiles/r4_server_wide_ab_first.log).
+    // One sequential stream at a time with the lines eight ahead requested early costs a few ns per answer; by the time
+    // member 0 is through, the other members' answers have usually all landed.
+    if (sv.planes.size() < (size_t)M * (size_t)N) sv.planes.resize((size_t)M * (size_t)N);
+    float* pl = sv.planes.data();
+    for (int m = 0; m < M; ++m) {
+        const volatile unsigned long long* am = h->ans[m];
+        float* pm = pl + (size_t)m * (size_t)N;
+        for (int64_t n = 0; n < N; ++n) {
+            if ((n & 7) == 0) __builtin_prefetch(const_cast<const unsigned long long*>(am) + n + 64, 0, 0);
             unsigned spins = 0;
             unsigned long long a;
-            while ((((a = h->ans[m][n]) >> 32) & 0x7FFFFFFFull) != seq) {
+            while ((((a = am[n]) >> 32) & 0x7FFFFFFFull) != seq) {
                 __builtin_ia32_pause();                     // (spin-wait hint: leaves the core's resources to a sibling hyperthread)
                 if ((++spins & 1023u) == 0) {
                     const bool gone = !sv.fresh && !h->alive[m][(n >> 4) % sv.tiles];
                     const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                     // (this thread may have been off the core for milliseconds between the read above and this clock: look again
                     //  before giving up on an answer that has arrived meanwhile)
-                    if ((gone || waited > limit) && (((a = h->ans[m][n]) >> 32) & 0x7FFFFFFFull) == seq) break;
+                    if ((gone || waited > limit) && (((a = am[n]) >> 32) & 0x7FFFFFFFull) == seq) break;
                     if (gone || waited > limit) {
                         server_stop(e);                    // fall back to a launch; the next calls start a new generation
                         sv.fallbacks += 1;
-                        sv.fb_info = (gone ? 1000000000ll : 2000000000ll) + (int64_t)m * 10000000 + n * 10000 + (int64_t)std::min(waited * 1e6, 9999.0);
+                        sv.fb_info = (gone ? 1000000000ll : 2000000000ll) + (int64_t)m * 10000000 + (n % 1000) * 10000 + (int64_t)std::min(waited * 1e6, 9999.0);
                         return FX_EUNSUPPORTED;
                     }
                 }
             }
             bad = bad || (a >> 63);
             const unsigned bits = (unsigned)a;
-            std::memcpy(&x[m], &bits, 4);
+            std::memcpy(&pm[n], &bits, 4);
         }
-        if (out_NM) for (int m = 0; m < M; ++m) out_NM[n * M + m] = x[m];
-        if (out_mean) {
-            float x16[16];
-            for (int m = 0; m < 16; ++m) x16[m] = m < M ? x[m] : 0.f;
-            out_mean[n] = np_mean_row16(x16, M);           // NumPy's order, the same routine the mean kernels use
+    }
+    if (out_NM) {
+        for (int m = 0; m < M; ++m) {
+            const float* pm = pl + (size_t)m * (size_t)N;
+            for (int64_t n = 0; n < N; ++n) out_NM[n * M + m] = pm[n];
+        }
+    }
+    if (out_mean) {
+        if (M < 8) {
+            // NumPy's order for fewer than eight members is the plain left-to-right sum from 0 (np_sum_row): plane by plane,
+            // which the compiler vectorises over the sequences
+            for (int64_t n = 0; n < N; ++n) out_mean[n] = 0.f;
+            for (int m = 0; m < M; ++m) {
+                const float* pm = pl + (size_t)m * (size_t)N;
+                for (int64_t n = 0; n < N; ++n) out_mean[n] += pm[n];
+            }
+            const float fm = (float)M;
+            for (int64_t n = 0; n < N; ++n) out_mean[n] = out_mean[n] / fm;
+        } else {
+            for (int64_t n = 0; n < N; ++n) {
+                float x16[16];
+                for (int m = 0; m < 16; ++m) x16[m] = m < M ? pl[(size_t)m * (size_t)N + n] : 0.f;
+                out_mean[n] = np_mean_row16(x16, M);       // NumPy's order, the same routine the mean kernels use
+            }
         }
     }
     sv.fresh = false;

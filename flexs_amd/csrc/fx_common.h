@@ -81,6 +81,11 @@ struct FxMailIn {                                      // device memory (fine-gr
     alignas(64) unsigned long long req;                // (sequence number << 16) | number of sequences; written LAST by the host
     alignas(64) unsigned stop;                         // host: 1 = leave now
     alignas(64) unsigned char bytes[FX_SERVE_BYTES];   // the request's sequences, row-major
+    // the same request word once more, for the tile slots beyond the first few of every member (wide generation): a word that
+    // hundreds of workgroups poll is a queue in front of ONE memory channel, and the few slots an explorer-size request needs
+    // would wait in it (12.5 vs 11.2 us per 20-sequence call with 240 pollers on `req`, profiles/r4_server_wide_ab_first.log).
+    // The many poll this copy -- far from `req`'s line, with a pause between polls; it is written just BEFORE `req`.
+    alignas(64) unsigned long long req_wide;
 };
 static_assert(offsetof(FxMailIn, stop) == 64 && offsetof(FxMailIn, bytes) == 128, "server_start clears the first 128 bytes");
 struct FxMailOut {                                     // pinned host memory; the host only ever READS it (after zeroing it between generations)
@@ -187,12 +192,13 @@ struct fx_engine {
         std::vector<uint64_t> versions;
         uint8_t lut[256] = {};
         int L = 0, cap = 0, wgs = 0;                     // ... and the CUs the generation occupies (one workgroup each)
-        int tiles = 0;                                   // tile slots per member of the running generation
+        int tiles = 0, fast = 0;                         // tile slots per member of the running generation, and how many of them poll `req` (the others: `req_wide`)
         std::vector<fx_model*> refused;                  // the last ensemble that has a member without a resident form
         int refused_L = 0;
         std::vector<fx_model*> pending;                  // the last eligible call's ensemble, and when it came
         std::chrono::steady_clock::time_point t_pending;
         int64_t served = 0, started = 0, fallbacks = 0, fb_info = 0;
+        std::vector<float> planes;                       // the answers of a request, member-major (host scratch)
     } server;
     bool large_bar = false;     // the host can store into device memory (the resident form needs it)
     int64_t quad_rotate = 1;    // quad CNN form: the waves' roles rotate from quad to quad (balances the MFMA load of a CU's SIMDs; 0 = same roles: A/B)
@@ -201,7 +207,7 @@ struct fx_engine {
     int64_t serve_wide = 1;     // 1 = a resident generation takes (num_cus - serve_reserve_cus) / M tile slots per member and serves requests of up to 4096 sequences, a slot walking several tiles (0 = round 3's geometry: a third of the CUs, <= 16 slots, <= 256 sequences: A/B)
     int64_t serve_reserve_cus = 16;   // CUs a wide generation leaves without a resident workgroup (kernels of other streams -- RCCL, PyTorch -- find room there at once; small ones also fit beside a resident workgroup)
     int64_t serve_fence = 0;    // 1 = a system fence after every tile's answers (round 3: ~0.5 us each, and the fences of one XCD serialise -- 24 us for the 378 tiles of a 2001-sequence request, profiles/r4_mailbox_probe3.log); 0 = none: the answers are system-scope stores, which write through by themselves (profiles/r4_mailbox_probe4.log)
-    int64_t serve_poll_sleep = 4;     // s_sleep units (64 clocks each) between polls of the slots beyond FX_SERVE_FAST (0 = every slot spins)
+    int64_t serve_poll_sleep = 8;     // s_sleep units (64 clocks each) between polls of the slots beyond FX_SERVE_FAST (0 = every slot spins)
     int64_t serve_small = 1;    // 1 = explorer-size calls of canonical CNN ensembles are answered by resident workgroups (0 = a launch per call: A/B)
     int64_t fuse_mean = 0;      // 1 = explorer-size CNN ensemble calls average in the scoring kernel (last member to finish a tile, tickets + device-scope fences) instead of launching the mean kernel.  Bit-identical, but the two fences cost what the 3 us launch saves: 32.1 vs 32.2 us per call (profiles/r3_fused_mean_ab.log): off, kept as the A/B
     // chunked host call in flight (fx_score_begin / _submit / _finish)
@@ -315,24 +321,25 @@ int fx_launch_score_cnn_quad_server(fx_engine* e, fx_model* const* models, int M
 int fx_launch_score_dense_small_server(fx_engine* e, fx_model* const* models, int M, int m_off, int tiles, hipStream_t stream,
                                        FxMailIn* d_in, FxMailOut* d_out, unsigned long long idle_ticks, unsigned long long life_ticks);
 // The resident workgroups' wait for the next request (thread 0 of a workgroup): returns the new request word, or `last` with
-// *leave = 1 when told to stop, idle for too long or too old.  Slots >= FX_SERVE_FAST pause `sleep_n` x 64 clocks between polls:
-// hundreds of workgroups spinning on one line of device memory would delay the few that an explorer-size request needs.
+// *leave = 1 when told to stop, idle for too long or too old.  `fast` slots spin on `req`; the others poll `req_wide` (the same
+// word, written first) with `sleep_n` x 64 clocks between polls, so that they do not queue in front of the fast slots' line.
 #if defined(__HIPCC__)
 __device__ __forceinline__ unsigned long long fx_server_wait(const FxMailIn* in, unsigned long long last, unsigned long long seen,
                                                              unsigned long long start, unsigned long long idle_ticks,
-                                                             unsigned long long life_ticks, int slot, int sleep_n, int* leave) {
+                                                             unsigned long long life_ticks, bool fast, int sleep_n, int* leave) {
     *leave = 0;
+    const unsigned long long* word = fast ? &in->req : &in->req_wide;
     for (;;) {
         // relaxed polls, ONE acquire fence when the word changes: an acquire load is an L2 invalidate per iteration, and
         // 240 workgroups invalidating their L2s in a loop delayed everybody (tools/probes/mailbox_probe4.hip: request round
         // trip of 3 workgroups beside 237 idle ones 6.8 us with acquire polls, 4.7 us with relaxed ones; 3.5 us alone)
-        const unsigned long long r = __hip_atomic_load(&in->req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long r = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (r != last) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return r; }
         const unsigned long long now = wall_clock64();
         if (__hip_atomic_load(&in->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) ||
             now - seen > (last ? idle_ticks : 64 * idle_ticks) ||       /* (a generation waits longer for its first request) */
             now - start > life_ticks) { *leave = 1; return last; }
-        if (slot >= FX_SERVE_FAST)
+        if (!fast)
             for (int k = 0; k < sleep_n; ++k) __builtin_amdgcn_s_sleep(1);
     }
 }

@@ -44,7 +44,7 @@ struct QuadArgs {
     float* mean_out;            // null = off
     unsigned* tickets;          // one per tile, zero between launches (fx_zero_pool; the last arrival resets its entry)
     // resident form
-    int rotate; int srv_tiles; int srv_sleep; int srv_fence; FxMailIn* min; FxMailOut* mout;               // null = ordinary launch
+    int rotate; int srv_tiles; int srv_fast; int srv_sleep; int srv_fence; FxMailIn* min; FxMailOut* mout;               // null = ordinary launch
     unsigned long long idle_ticks, life_ticks;   // leave after this long without a request / in total (100 MHz ticks)
     int off_c2, off_c3, off_cb, off_w1p, off_d1, off_d2, off_db, total_floats;
 };
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
         if constexpr (SERVER) {
             if (tid == 0) {
                 int ex = 0;
-                const unsigned long long r = fx_server_wait(p.min, srv_last, srv_seen, srv_start, p.idle_ticks, p.life_ticks, srv_slot, p.srv_sleep, &ex);
+                const unsigned long long r = fx_server_wait(p.min, srv_last, srv_seen, srv_start, p.idle_ticks, p.life_ticks, srv_slot < p.srv_fast, p.srv_sleep, &ex);
                 srv_req = r; srv_exit = ex; srv_bad = 0;
             }
             __syncthreads();
@@ -496,7 +496,7 @@ int fx_launch_score_cnn_quad_server(fx_engine* e, fx_model* const* models, int M
     a.off_c2 = (int)lay.off_c2; a.off_c3 = (int)lay.off_c3; a.off_cb = (int)lay.off_cb; a.off_w1p = (int)lay.off_w1p;
     a.off_d1 = (int)lay.off_d1; a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
     a.min = d_in; a.mout = d_out; a.idle_ticks = idle_ticks; a.life_ticks = life_ticks;
-    a.srv_tiles = tiles; a.m_off = m_off; a.srv_sleep = (int)e->serve_poll_sleep; a.srv_fence = (int)e->serve_fence;
+    a.srv_tiles = tiles; a.m_off = m_off; a.srv_fast = e->server.fast; a.srv_sleep = (int)e->serve_poll_sleep; a.srv_fence = (int)e->serve_fence;
     if (L1 == 4) return launch_server<1, 8, 4>(e, a, M, stream);
     if (L1 < 4) return launch_server<1, 8, 0>(e, a, M, stream);
     return launch_server<1, 24, 0>(e, a, M, stream);

@@ -34,7 +34,7 @@ struct SmallArgs {
     int pair;                    // 1 = first layer from the pre-summed pair rows (4-letter alphabets), as the PAIR form of the persistent kernel
     int off_w1p, off_w1pair, off_d2, off_d3, off_db, off_first;
     // SERVER (the resident form, see score_cnn_quad.hip): workgroup = (member, tile slot), requests from the mailboxes
-    int srv_tiles; int srv_sleep; int srv_fence; FxMailIn* min; FxMailOut* mout;
+    int srv_tiles; int srv_fast; int srv_sleep; int srv_fence; FxMailIn* min; FxMailOut* mout;
     unsigned long long idle_ticks, life_ticks;
 };
 
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(SW * 64) k_score_dense_small(SmallArgs p) {
     if constexpr (SERVER) {
         if (tid == 0) {
             int ex = 0;
-            const unsigned long long r = fx_server_wait(p.min, srv_last, srv_seen, srv_start, p.idle_ticks, p.life_ticks, (int)tg0, p.srv_sleep, &ex);
+            const unsigned long long r = fx_server_wait(p.min, srv_last, srv_seen, srv_start, p.idle_ticks, p.life_ticks, (int)tg0 < p.srv_fast, p.srv_sleep, &ex);
             srv_req = r; srv_exit = ex; srv_bad = 0;
         }
         __syncthreads();
@@ -215,7 +215,7 @@ int fx_launch_score_dense_small_server(fx_engine* e, fx_model* const* models, in
     a.pair = form;
     a.off_w1p = (int)lay.off_w1p; a.off_w1pair = (int)lay.off_w1pair; a.off_d2 = (int)lay.off_d2; a.off_d3 = (int)lay.off_d3;
     a.off_db = (int)lay.off_db; a.off_first = (int)lay.off_first;
-    a.srv_tiles = tiles; a.srv_sleep = (int)e->serve_poll_sleep; a.srv_fence = (int)e->serve_fence; a.min = d_in; a.mout = d_out; a.idle_ticks = idle_ticks; a.life_ticks = life_ticks;
+    a.srv_tiles = tiles; a.srv_fast = e->server.fast; a.srv_sleep = (int)e->serve_poll_sleep; a.srv_fence = (int)e->serve_fence; a.min = d_in; a.mout = d_out; a.idle_ticks = idle_ticks; a.life_ticks = life_ticks;
 #define FX_SMALL_CASES(KIND)                                               \
     switch (lay.HT) {                                                      \
         case 1: return launch_small_server<KIND, 1>(e, a, M, stream);      \
