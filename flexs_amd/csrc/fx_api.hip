@@ -311,6 +311,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "train_lds")) return &e->train_lds;
     if (!std::strcmp(key, "train_threads")) return &e->train_threads;
     if (!std::strcmp(key, "train_trace")) return &e->train_trace;
+    if (!std::strcmp(key, "train_persistent")) return &e->train_persistent;
     if (!std::strcmp(key, "dense_waves")) return &e->dense_waves;
     if (!std::strcmp(key, "dense_few_waves_below")) return &e->dense_few_waves_below;
     return nullptr;
@@ -333,6 +334,8 @@ int fx_engine_get_option(fx_engine* e, const char* key, int64_t* value) {
     if (e && key && !std::strcmp(key, "server_fallbacks")) { *value = e->server.fallbacks; return FX_OK; }
     if (e && key && !std::strcmp(key, "server_last_fallback")) { *value = e->server.fb_info; return FX_OK; }   // reason (1 left, 2 timed out) | member | sequence | waited us
     if (e && key && !std::strcmp(key, "server_resident")) { *value = e->server.running ? 1 : 0; return FX_OK; }
+    if (e && key && !std::strcmp(key, "server_wide")) { *value = (e->server.running && e->server.wide) ? 1 : 0; return FX_OK; }
+    if (e && key && !std::strcmp(key, "server_slots")) { *value = e->server.running ? e->server.tiles : 0; return FX_OK; }
     int64_t* s = option_slot(e, key);
     if (!s) return fx_fail(e, FX_EINVAL, std::string("unknown option ") + (key ? key : "(null)"));
     *value = *s;
@@ -691,8 +694,16 @@ static int server_start(fx_engine* e, fx_model* const* models, int M, int L, con
     // one workgroup per (member, 16-sequence tile slot).  Wide generation (round 4): most of the chip -- slot s of a member
     // walks the tiles s, s + tiles, s + 2 tiles, ... of a request, so the capacity is what the mailboxes hold, not the slot
     // count; round 3's geometry (serve_wide = 0): a third of the chip, <= 16 slots, one tile per slot.
+    // serve_wide = 1 (default): ADAPTIVE -- a generation is wide when the caller has recently asked for more than 256 sequences at
+    // a time (server_call keeps the time of the last such request), narrow otherwise: 240 resident workgroups cost every
+    // explorer-size call ~1.2 us (13.2 vs 12.0 us per 20-sequence call, profiles/r4_server_wide_ab.log) whatever they poll and
+    // however long they sleep, and the callers that only ever ask for 1-20 sequences (Adalead's roll-outs, CMA-ES, DyNA-PPO)
+    // should not pay it.  serve_wide = 2: always wide (A/B, tests); 0: round 3's geometry.
+    const bool want_wide = e->serve_wide == 2 ||
+        (e->serve_wide == 1 && sv.mid_recent > 0 &&
+         std::chrono::duration<double>(std::chrono::steady_clock::now() - sv.t_mid).count() < 0.25);
     int tiles, cap;
-    if (e->serve_wide) {
+    if (want_wide) {
         int reserve = (int)e->serve_reserve_cus;
         if (reserve < 0) reserve = 0;
         if (reserve > e->num_cus - M) reserve = e->num_cus - M;
@@ -747,7 +758,7 @@ static int server_start(fx_engine* e, fx_model* const* models, int M, int L, con
         rc = fx_launch_score_cnn_quad_server(e, models + m0, cnt, m0, tiles, st, sv.in, sv.d_out, idle, life);
         if (rc == FX_EUNSUPPORTED) rc = fx_launch_score_dense_small_server(e, models + m0, cnt, m0, tiles, st, sv.in, sv.d_out, idle, life);
         if (rc) {                                          // a member without a resident form: the groups already started leave again
-            sv.in->stop = 1;
+            sv.in->stop = 1; sv.in->req_wide = FX_SERVE_LEAVE; sv.in->req = FX_SERVE_LEAVE;
             fx_bar_fence();
             return rc;
         }
@@ -757,7 +768,8 @@ static int server_start(fx_engine* e, fx_model* const* models, int M, int L, con
     sv.versions.clear();
     for (int m = 0; m < M; ++m) sv.versions.push_back(models[m]->version);
     std::memcpy(sv.lut, lut, 256);
-    sv.L = L; sv.cap = cap; sv.wgs = M * tiles; sv.tiles = tiles;
+    sv.L = L; sv.cap = cap; sv.wgs = M * tiles; sv.tiles = tiles; sv.wide = want_wide;
+    sv.seen.assign((size_t)FX_MAX_M * FX_SERVE_TILES, 0);
     sv.running = true; sv.fresh = true;
     sv.t_start = std::chrono::steady_clock::now();
     sv.started += 1;
@@ -774,19 +786,39 @@ static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8
     if (sv.running && !same) server_stop(e);
     if (!sv.running && (int)sv.refused.size() == M && sv.refused_L == L && std::equal(sv.refused.begin(), sv.refused.end(), models))
         return FX_EUNSUPPORTED;                            // (an ensemble with a member that has no resident form: asked once)
+    if (N > 256) {
+        // adaptive geometry: remember when the caller last asked for more than a narrow generation holds; the second such
+        // request within 2 ms while a narrow generation runs replaces it by a wide one (this call is launched)
+        const auto now = std::chrono::steady_clock::now();
+        const bool dense = sv.mid_recent > 0 && std::chrono::duration<double>(now - sv.t_mid).count() < 2e-3;
+        sv.t_mid = now;
+        sv.mid_recent = 1;
+        if (e->serve_wide == 1 && sv.running && !sv.wide && dense) {
+            server_stop(e);
+            sv.pending.assign(models, models + M);         // (the next call of this ensemble within the window starts the wide generation)
+            sv.t_pending = now;
+            return FX_EUNSUPPORTED;
+        }
+    }
     if (sv.running) {
         if (N > sv.cap) return FX_EUNSUPPORTED;
         // the workgroups leave 2 x serve_idle_us after their last request: do not post to a generation that may be on its way out
         if (!sv.fresh && std::chrono::duration<double>(std::chrono::steady_clock::now() - sv.t_post).count() * 1e6 > (double)e->serve_idle_us)
             server_stop(e);
-        if (!sv.fresh) {
-            // leaving by themselves (idle / lifetime): all go.  Looked at for the slots this request needs -- those are the
-            // ones whose answers would be waited for -- and, cheaply, for one rotating slot beyond them
+        {
+            // leaving by themselves (idle / lifetime): all go.  A slot counts as gone when it HAS been seen alive and no longer
+            // is -- the workgroups of a fresh generation raise their `alive` words as they start, the late ones microseconds
+            // after the first request was answered.  Looked at for the slots this request needs and one rotating slot.
             const int need = (int)std::min<int64_t>((N + 15) / 16, sv.tiles);
+            auto left = [&](int m, int t) {
+                uint8_t& seen = sv.seen[(size_t)m * FX_SERVE_TILES + t];
+                if (sv.h_out->alive[m][t]) { seen = 1; return false; }
+                return seen != 0;
+            };
             for (int m = 0; m < M && sv.running; ++m) {
                 for (int t = 0; t < need; ++t)
-                    if (!sv.h_out->alive[m][t]) { server_stop(e); break; }
-                if (sv.running && !sv.h_out->alive[m][(int)(sv.seq % (unsigned)sv.tiles)]) server_stop(e);
+                    if (left(m, t)) { server_stop(e); break; }
+                if (sv.running && left(m, (int)(sv.seq % (unsigned)sv.tiles))) server_stop(e);
             }
         }
         // (a generation is replaced well before its workgroups' own lifetime limit)
@@ -824,7 +856,10 @@ static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8
     //  process for the runtime to create the high-priority hardware queue and load the kernels: ~0.3 s, once)
     // (later requests: a resident workgroup answers within microseconds and one that left says so through its `alive` word;
     //  the limit only catches a device that has stopped making progress -- or is time-sliced away to another process)
-    const double limit = sv.fresh ? 3.0 : 0.02;
+    double limit = sv.fresh ? 3.0 : 0.02;
+    for (int m = 0; m < M && limit < 1.0; ++m)
+        for (int64_t t = 0; t < std::min<int64_t>((N + 15) / 16, sv.tiles); ++t)
+            if (!sv.seen[(size_t)m * FX_SERVE_TILES + t]) { limit = 3.0; break; }   // (a slot that has never answered may still be starting)
     const FxMailOut* h = sv.h_out;
     bool bad = false;
     // Collected MEMBER BY MEMBER into planes: every answer line was just written by the device, i.e. is a cache miss for
@@ -844,7 +879,8 @@ static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8
             while ((((a = am[n]) >> 32) & 0x7FFFFFFFull) != seq) {
                 __builtin_ia32_pause();                     // (spin-wait hint: leaves the core's resources to a sibling hyperthread)
                 if ((++spins & 1023u) == 0) {
-                    const bool gone = !sv.fresh && !h->alive[m][(n >> 4) % sv.tiles];
+                    const int slot = (int)((n >> 4) % sv.tiles);
+                    const bool gone = sv.seen[(size_t)m * FX_SERVE_TILES + slot] && !h->alive[m][slot];
                     const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                     // (this thread may have been off the core for milliseconds between the read above and this clock: look again
                     //  before giving up on an answer that has arrived meanwhile)
@@ -860,6 +896,7 @@ static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8
             bad = bad || (a >> 63);
             const unsigned bits = (unsigned)a;
             std::memcpy(&pm[n], &bits, 4);
+            if ((n & 15) == 0) sv.seen[(size_t)m * FX_SERVE_TILES + (size_t)((n >> 4) % sv.tiles)] = 1;   // (it answered: it is there)
         }
     }
     if (out_NM) {

@@ -20,6 +20,7 @@
 #define FX_SERVE_TILES 256     // tile slots per member at most (one resident workgroup each)
 #define FX_SERVE_BYTES 65536   // N x seq_len bytes per request at most
 #define FX_SERVE_CAP 4096      // sequences per request at most
+#define FX_SERVE_LEAVE 0xFFFFull   // request word that tells the resident workgroups to leave (sequence number 0, N = 0xFFFF: neither occurs in a request)
 #define FX_SERVE_FAST 16       // the first slots of every member poll without a pause (explorer-size calls); the others sleep between polls
 
 // ---------------------------------------------------------------- shapes
@@ -164,6 +165,7 @@ struct fx_engine {
     int64_t dense_pipe = 0;     // MLP (pair rows) / GE (byte table): 1 / 2 = the software-pipelined form (tile t + 1's first layer inside tile t's MFMA layers, 8 waves, two-part direct LDS fill; 2 = A operands double-buffered by hand).  Bit-identical but measured 11-13 % SLOWER than the 16-wave form at every size (profiles/r3_dense_pipe_ab.log): off; kept as the A/B
     int64_t train_rows = 0;     // fx_train_fit: mini-batch rows per workgroup (0 = auto: 16, or 8 for small batches)
     int64_t train_lds = 2;      // fx_train_fit: 2 = a slice's activations / gradients AND the member's weights live in LDS when they fit, 1 = the workspace only, 0 = global arena (A/B)
+    int64_t train_persistent = 1;   // fx_train_fit: 1 = the whole fit is ONE launch when all (slices x members) workgroups are co-resident: step barriers in device memory, Adam by the same workgroups (0 = two launches per step: A/B, and what larger ensembles get)
     int64_t train_trace = 0;    // profiling aid: 1 = fx_train_fit stamps the phases of the LAST step of member 0, workgroup 0 (fx_debug_train_trace)
     unsigned long long* d_train_dbg = nullptr;
     int64_t train_threads = 0;  // fx_train_fit: threads per forward+backward workgroup (256 / 512 / 1024; 0 = 1024)
@@ -186,6 +188,9 @@ struct fx_engine {
         std::vector<hipStream_t> streams;               // one per group of like members (each group is its own resident launch)
         int groups = 0;
         bool running = false, fresh = false;
+        bool wide = false;                               // the running generation's geometry
+        std::chrono::steady_clock::time_point t_mid;    // the last request of more than 256 sequences (adaptive geometry)
+        int mid_recent = 0;
         std::chrono::steady_clock::time_point t_start, t_post;   // generation start, last request
         unsigned long long seq = 0;
         std::vector<fx_model*> models;
@@ -198,6 +203,7 @@ struct fx_engine {
         std::vector<fx_model*> pending;                  // the last eligible call's ensemble, and when it came
         std::chrono::steady_clock::time_point t_pending;
         int64_t served = 0, started = 0, fallbacks = 0, fb_info = 0;
+        std::vector<uint8_t> seen;                       // [member][slot]: this generation's workgroup has been seen alive
         std::vector<float> planes;                       // the answers of a request, member-major (host scratch)
     } server;
     bool large_bar = false;     // the host can store into device memory (the resident form needs it)
@@ -312,7 +318,11 @@ inline void fx_bar_fence() {
 inline void fx_server_stop(fx_engine* e) {
     auto& sv = e->server;
     if (!sv.running) return;
+    // "leave" is a request word of its own (one load per poll on the device side): a value no request can have -- sequence
+    // number 0 is never used -- in both copies of the word; `stop` (read once per request loop) says the same for good measure
     sv.in->stop = 1;
+    sv.in->req_wide = FX_SERVE_LEAVE;
+    sv.in->req = FX_SERVE_LEAVE;
     fx_bar_fence();
     sv.running = false;
 }
@@ -334,10 +344,10 @@ __device__ __forceinline__ unsigned long long fx_server_wait(const FxMailIn* in,
         // 240 workgroups invalidating their L2s in a loop delayed everybody (tools/probes/mailbox_probe4.hip: request round
         // trip of 3 workgroups beside 237 idle ones 6.8 us with acquire polls, 4.7 us with relaxed ones; 3.5 us alone)
         const unsigned long long r = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (r == FX_SERVE_LEAVE) { *leave = 1; return last; }            // (told to leave: the word itself says so -- ONE load per poll)
         if (r != last) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return r; }
         const unsigned long long now = wall_clock64();
-        if (__hip_atomic_load(&in->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) ||
-            now - seen > (last ? idle_ticks : 64 * idle_ticks) ||       /* (a generation waits longer for its first request) */
+        if (now - seen > (last ? idle_ticks : 64 * idle_ticks) ||       /* (a generation waits longer for its first request) */
             now - start > life_ticks) { *leave = 1; return last; }
         if (!fast)
             for (int k = 0; k < sleep_n; ++k) __builtin_amdgcn_s_sleep(1);

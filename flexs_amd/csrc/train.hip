@@ -67,6 +67,88 @@ __global__ void __launch_bounds__(256) k_train_adam(const FxtJob* __restrict__ j
     if (i == 0 && j.step_loss) fxt_step_loss(j, step);
 }
 
+// ---- the whole fit as ONE launch (round 4) ----------------------------------------------------------------------------------
+// k_train_fb + k_train_adam per mini-batch step are two dependent launches -- 160 for a fit of 1000 sequences -- and every
+// forward+backward workgroup re-stages its member's weights from L2 at its start.  Here the (slices x members) workgroups stay
+// for the whole fit: per step a workgroup runs its slice's forward + backward (the same fxt_forward_backward: same bits), the S
+// workgroups of a MEMBER meet at a barrier in device memory (members never wait for each other), each then sums the partials
+// of ITS share of the parameters in slice order and applies Keras' Adam to them (the same fxt_adam: same bits), a second
+// barrier, and the new weights are read back into LDS.  Cross-workgroup visibility: the partials / weights are plain stores,
+// published by an agent-scope release (L2 write-back) before the arrival and picked up behind an agent-scope acquire after
+// the barrier -- twice per step, not per work unit.  Needs all workgroups co-resident (checked by the host through the
+// occupancy API; the resident scoring generation is told to leave first); a barrier that is not passed within ~2 s raises
+// the abort word and everybody leaves (the host reports FX_ESTATE) instead of hanging the device.
+struct FxtBar { unsigned count[64]; unsigned abort; };
+
+__device__ __forceinline__ bool fxt_member_barrier(FxtBar* bar, int m, unsigned target, int tid) {
+    __shared__ int s_abort;
+    __syncthreads();                                       // every wave's stores have reached the L2 (vmcnt(0) before the barrier)
+    if (tid == 0) {
+        __threadfence();                                   // release: this XCD's L2 writes back
+        __hip_atomic_fetch_add(&bar->count[m], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = wall_clock64();
+        int ab = 0;
+        while (__hip_atomic_load(&bar->count[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (__hip_atomic_load(&bar->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ab = 1; break; }
+            if (wall_clock64() - t0 > 200000000ull) {      // 2 s at 100 MHz: somebody never arrived (not co-resident?)
+                __hip_atomic_store(&bar->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ab = 1;
+                break;
+            }
+        }
+        __threadfence();                                   // acquire: what the others published is read past this L2's stale lines
+        s_abort = ab;
+    }
+    __syncthreads();
+    return s_abort == 0;
+}
+
+__global__ void __launch_bounds__(FB_MAX_THREADS) k_train_fit(const FxtJob* __restrict__ jobs, const uint8_t* __restrict__ ascii,
+                                                          const uint8_t* __restrict__ lut, const float* __restrict__ labels, FxtBar* bar) {
+    extern __shared__ __attribute__((aligned(16))) float fxt_smem[];
+    const FxtJob& j = jobs[blockIdx.y];
+    if ((int)blockIdx.x >= j.S) return;                    // (a member with fewer slices than the grid is wide: not part of its barrier)
+    typedef FxtMem<3>::F lds_f;
+    typedef FxtMem<3>::CF lds_cf;
+    typedef FxtMem<1>::F glb_f;
+    typedef FxtMem<1>::CF glb_cf;
+    const FxtWg wg{(int)threadIdx.x, (int)blockDim.x};
+    const int slice = (int)blockIdx.x, m = (int)blockIdx.y;
+    const int P = j.net.P;
+    const int p_lo = (int)((long long)P * slice / j.S), p_hi = (int)((long long)P * (slice + 1) / j.S);
+    float* wl = fxt_smem + j.ws_slice;
+    auto stage_weights = [&]() {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const int n4 = P >> 2;
+        const v4f* src = reinterpret_cast<const v4f*>(j.w);
+        v4f* dst = reinterpret_cast<v4f*>(wl);
+        for (int i0 = threadIdx.x; i0 < n4; i0 += 12 * blockDim.x) {
+            v4f v[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) { const int i = i0 + k * (int)blockDim.x; v[k] = src[i < n4 ? i : n4 - 1]; }
+#pragma unroll
+            for (int k = 0; k < 12; ++k) { const int i = i0 + k * (int)blockDim.x; if (i < n4) dst[i] = v[k]; }
+        }
+        for (int i = (n4 << 2) + threadIdx.x; i < P; i += blockDim.x) wl[i] = j.w[i];
+    };
+    unsigned phase = 0;
+    for (int step = 0; step < j.total_steps; ++step) {
+        if (j.w_in_lds) {
+            stage_weights();                               // (published by the first fxt_sync of the step)
+            fxt_forward_backward<3, 3>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl);
+        } else if (j.ws_in_lds) {
+            fxt_forward_backward<3, 1>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (glb_cf)j.w);
+        } else {
+            fxt_forward_backward<1, 1>(j, wg, step, slice, ascii, lut, labels, (glb_f)(j.ws + (long long)slice * j.ws_slice), (glb_cf)j.w);
+        }
+        if (!fxt_member_barrier(bar, m, (unsigned)j.S * ++phase, (int)threadIdx.x)) return;
+        for (int i = p_lo + (int)threadIdx.x; i < p_hi; i += (int)blockDim.x) fxt_adam(j, step, i);
+        if (slice == 0 && threadIdx.x == 0 && j.step_loss) fxt_step_loss(j, step);
+        if (!fxt_member_barrier(bar, m, (unsigned)j.S * ++phase, (int)threadIdx.x)) return;
+    }
+}
+
 // Rows per slice.  More slices = more workgroups (the machine has 256 CUs and a step of one small network is a few
 // hundred thousand MACs), fewer rows per slice = emptier 16-row MFMA tiles in the dense layers and more partials to
 // sum.  The choice depends on the member's OWN shape and batch size only -- never on how many members train in the
@@ -145,7 +227,7 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
     // ---- one device arena: job table, LUT, data, labels, and per member: weights, moments, partials, order, masks, lr, loss, workspace
     size_t need = 0;
     auto plan = [&](Arena& a) {
-        a.take<FxtJob>((size_t)M); a.take<uint8_t>(256); a.take<uint8_t>((size_t)n * L); a.take<float>((size_t)n);
+        a.take<FxtJob>((size_t)M); a.take<FxtBar>(1); a.take<uint8_t>(256); a.take<uint8_t>((size_t)n * L); a.take<float>((size_t)n);
         for (int m = 0; m < M; ++m) {
             const FxtJob& j = hj[(size_t)m];
             a.take<float>((size_t)j.net.P); a.take<float>((size_t)j.net.P); a.take<float>((size_t)j.net.P);
@@ -170,6 +252,8 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
     Arena a; a.base = (char*)e->d_train;
     hipStream_t st = e->stream;
     FxtJob* d_jobs = a.take<FxtJob>((size_t)M);
+    FxtBar* d_bar = a.take<FxtBar>(1);
+    unsigned h_abort = 0;
     uint8_t* d_lut = a.take<uint8_t>(256);
     uint8_t* d_ascii = a.take<uint8_t>((size_t)n * L);
     float* d_labels = a.take<float>((size_t)n);
@@ -219,11 +303,36 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
     }
     int threads = (int)e->train_threads;
     threads = threads >= 1024 ? 1024 : (threads >= 512 ? 512 : (threads >= 256 ? 256 : 1024));
-    for (int s = 0; s < max_steps; ++s) {
-        hipLaunchKernelGGL(k_train_fb, grid_fb, dim3((unsigned)threads), lds_bytes, st, d_jobs, s, d_ascii, d_lut, d_labels);
-        hipLaunchKernelGGL(k_train_adam, grid_adam, dim3(256), 0, st, d_jobs, s);
+    // one launch for the whole fit when every workgroup finds a CU at once (the step barriers need them co-resident)
+    bool persistent = e->train_persistent != 0 && M <= 64 && !e->train_trace;
+    if (persistent) {
+        if (lds_bytes > 48 * 1024) {
+            static bool attr_fit[64] = {};
+            if (!attr_fit[e->device & 63]) {
+                FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_fit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS_BUDGET));
+                attr_fit[e->device & 63] = true;
+            }
+        }
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_train_fit), threads, lds_bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            per_cu = 0;
+        }
+        // (a margin of a few CUs: a kernel of another stream or process may hold one for a while)
+        persistent = per_cu >= 1 && (int64_t)max_S * M <= (int64_t)per_cu * (e->num_cus - 8);
     }
-    FX_HIP(e, hipGetLastError());
+    if (persistent) {
+        FX_HIP(e, hipMemsetAsync(d_bar, 0, sizeof(FxtBar), st));
+        hipLaunchKernelGGL(k_train_fit, grid_fb, dim3((unsigned)threads), lds_bytes, st, d_jobs, d_ascii, d_lut, d_labels, d_bar);
+        FX_HIP(e, hipGetLastError());
+        FX_HIP(e, hipMemcpyAsync(&h_abort, &d_bar->abort, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    } else {
+        for (int s = 0; s < max_steps; ++s) {
+            hipLaunchKernelGGL(k_train_fb, grid_fb, dim3((unsigned)threads), lds_bytes, st, d_jobs, s, d_ascii, d_lut, d_labels);
+            hipLaunchKernelGGL(k_train_adam, grid_adam, dim3(256), 0, st, d_jobs, s);
+        }
+        FX_HIP(e, hipGetLastError());
+    }
     for (int m = 0; m < M; ++m) {
         const FxtJob& j = hj[(size_t)m];
         const size_t P = (size_t)j.net.P;
@@ -234,6 +343,8 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
             FX_HIP(e, hipMemcpyAsync(jobs[m].step_loss, j.step_loss, sizeof(float) * (size_t)j.total_steps, hipMemcpyDeviceToHost, st));
     }
     FX_HIP(e, hipStreamSynchronize(st));
+    if (h_abort) return fx_fail(e, FX_ESTATE, "fx_train_fit: a step barrier of the one-launch fit was not passed within 2 s (workgroups not co-resident?); "
+                                              "set the engine option train_persistent = 0 for a launch per step");
     for (int m = 0; m < M; ++m) {
         jobs[m].step += hj[(size_t)m].total_steps;
         e->counters.train_steps += hj[(size_t)m].total_steps;

@@ -2200,7 +2200,9 @@ def test_resident_wide_form(eng, kind, L, alpha, H, M):
     finally:
         eng.set_option("serve_small", 1)
     small = data[257][:20]
+    eng.set_option("serve_wide", 2)                                      # (always wide: the default, 1, chooses by the caller's recent sizes)
     assert _until_resident(eng, lambda: ens.get_fitness(small))
+    assert eng.get_option("server_wide") == 1 and eng.get_option("server_slots") > 16
     fb0 = eng.get_option("server_fallbacks")
     for rep in range(2):
         for n in sizes:
@@ -2232,6 +2234,7 @@ def test_resident_wide_form(eng, kind, L, alpha, H, M):
     eng.set_option("serve_wide", 0)
     try:
         assert _until_resident(eng, lambda: ens.get_fitness(small))
+        assert eng.get_option("server_wide") == 0 and eng.get_option("server_slots") <= 16
         c0 = eng.get_option("server_calls") + eng.get_option("server_fallbacks")
         assert np.array_equal(ens.get_fitness(data[257][:100]), want[257][:100])     # (a prefix on its own: same bits, batch invariance)
         got = ens.get_fitness(data[257])
@@ -2239,6 +2242,19 @@ def test_resident_wide_form(eng, kind, L, alpha, H, M):
         assert eng.get_option("server_calls") + eng.get_option("server_fallbacks") - c0 <= 1
     finally:
         eng.set_option("serve_wide", 1)
+    # the default: ADAPTIVE.  A caller that only asks for a few sequences gets the narrow generation (every explorer-size call
+    # is ~1.2 us faster without 240 resident workgroups); two requests of more than 256 sequences within 2 ms replace it by a
+    # wide one; same bits either way
+    import time as _t
+    _t.sleep(0.3)                                                        # (forget the sizes asked above)
+    assert _until_resident(eng, lambda: ens.get_fitness(small))
+    assert eng.get_option("server_wide") == 0
+    for _ in range(2):
+        assert np.array_equal(ens.get_fitness(data[300]), want[300])     # launched (narrow generation), then the switch
+    for _ in range(4):
+        assert np.array_equal(ens.get_fitness(data[300]), want[300])
+    assert eng.get_option("server_wide") == 1, "dense mid-size requests did not bring the wide generation"
+    assert np.array_equal(ens.get_fitness(small), want[257][:20])
 
 
 def test_small_call_fast_path_bookkeeping(eng):

@@ -272,3 +272,64 @@ def test_device_training_step_on_a_seeded_sweep_of_random_shapes():
             check_against_oracle(step_fn, kind, L, alphabet, F, H, K, rows, steps=2)
         except AssertionError as exc:
             raise AssertionError(f"draw {draw}: {kind} L={L} A={A} F={F} H={H} K={K} rows={rows}: {exc}") from exc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,L,alphabet,F,H,K,n,B,M", [("cnn", 8, "TGCA", 32, 100, 5, 1000, 256, 3), ("mlp", 14, "UGCA", 0, 100, 0, 300, 128, 2),
+                                                        ("ge", 30, ref_np.AAS, 0, 100, 0, 300, 64, 8), ("cnn", 9, "UGCA", 8, 16, 3, 150, 256, 1),
+                                                        ("cnn", 30, ref_np.AAS, 32, 100, 5, 120, 64, 2)])
+def test_one_launch_fit_equals_the_launch_per_step_fit(kind, L, alphabet, F, H, K, n, B, M):
+    """Round 4: the whole fit as ONE launch (`train_persistent`, default on: the (slices x members) workgroups stay for all
+    steps, the workgroups of a member meet at two barriers in device memory per step, Adam is applied by the same
+    workgroups) against round 3's two launches per step -- the same fxt_forward_backward and fxt_adam, the same slice order
+    of the gradient sum: weights, both moments, step count and per-step losses are the SAME BITS, for several members with
+    different seeds in one call, a ragged last mini-batch and the in-kernel dropout stream."""
+    eng = _native.Engine.get(0)
+    A, epochs = len(alphabet), 3
+    lut = _native.make_lut(alphabet)
+    shapes = _shapes(kind, L, A, F, H, K)
+    _, b, _, y = _data(kind, L, alphabet, n, 21)
+    steps = (n + B - 1) // B
+    rng = np.random.default_rng(8)
+    results = []
+    for persistent in (1, 0):
+        eng.set_option("train_persistent", persistent)
+        try:
+            jobs = []
+            r2 = np.random.default_rng(8)
+            for mem in range(M):
+                order = np.full((epochs, steps * B), -1, np.int32)
+                for e in range(epochs):
+                    order[e, :n] = r2.permutation(n)
+                w = _flat(ref_np.synth_weights(shapes, 40 + mem))
+                jobs.append({"kind": KIND[kind], "L": L, "A": A, "F": F, "H": H, "K": K, "weights": w, "adam_m": np.zeros_like(w),
+                             "adam_v": np.zeros_like(w), "step": 0, "order": order, "epochs": epochs, "batch": B, "seed": 1234 + mem})
+            res = _native.train_fit(eng, jobs, b, lut, y)
+            results.append([(j["weights"].copy(), j["adam_m"].copy(), j["adam_v"].copy(), t, np.asarray(loss).copy()) for j, (t, loss) in zip(jobs, res)])
+        finally:
+            eng.set_option("train_persistent", 1)
+    del rng
+    for mem, (a, c) in enumerate(zip(*results)):
+        assert a[3] == c[3] == epochs * steps
+        for what, x, z in zip(("weights", "adam_m", "adam_v", "losses"), (a[0], a[1], a[2], a[4]), (c[0], c[1], c[2], c[4])):
+            assert np.array_equal(x, z), (kind, mem, what, float(np.abs(x - z).max()))
+        assert np.isfinite(a[0]).all() and not np.array_equal(a[0], _flat(ref_np.synth_weights(shapes, 40 + mem)))
+
+
+@pytest.mark.gpu
+def test_more_members_than_one_device_call_takes():
+    """`Ensemble.train` with 70 like members (round-3 advisor finding: fx_train_fit takes 64 per call and `fit_many` handed it the
+    whole group): the group is cut into calls of <= 64, seeds are per member, so every member's weights equal a fit on its own."""
+    import flexs_amd
+
+    rng = np.random.default_rng(1)
+    alphabet, L, n = "UGCA", 9, 90
+    seqs = ["".join(alphabet[i] for i in row) for row in rng.integers(0, 4, (n, L))]
+    y = rng.random(n).astype(np.float32)
+    ens = flexs_amd.Ensemble([bm.GlobalEpistasisModel(L, 12, alphabet, seed=m, epochs=2, batch_size=32) for m in range(70)])
+    ens.train(seqs, y, seed=5)
+    for k in (0, 63, 64, 69):
+        solo = bm.GlobalEpistasisModel(L, 12, alphabet, seed=k, epochs=2, batch_size=32)
+        solo.train(seqs, y, seed=5 + k)
+        for wa, wb in zip(ens.models[k].model.get_weights(), solo.model.get_weights()):
+            assert np.array_equal(wa, wb), k

@@ -11,7 +11,7 @@ from flexs_amd.baselines import models as bm
 from flexs_amd.utils import rollouts
 eng = _native.Engine.get()
 AAS = "ILVAGMFYWEDQNHCRKSTP"
-MODES = {"wide": dict(serve_small=1, serve_wide=1, serve_fence=0), "wide+f": dict(serve_small=1, serve_wide=1, serve_fence=1),
+MODES = {"wide": dict(serve_small=1, serve_wide=2, serve_fence=0), "adaptive": dict(serve_small=1, serve_wide=1, serve_fence=0),
          "r3": dict(serve_small=1, serve_wide=0, serve_fence=1), "launch": dict(serve_small=0, serve_wide=1, serve_fence=0)}
 
 
@@ -55,7 +55,7 @@ for name, make, L, alpha in fams:
 ens = flexs_amd.Ensemble([bm.CNN(8, 32, 100, "TGCA", seed=m) for m in range(3)])
 seqs = synth.bytes_to_strings(synth.random_sequence_bytes(1000, 8, "TGCA", 3))
 y = np.random.default_rng(0).random(1000)
-for mode in ("wide", "r3", "launch"):
+for mode in ("adaptive", "wide", "r3", "launch"):
     set_mode(mode)
     ts = []
     for i in range(5):
@@ -65,4 +65,4 @@ for mode in ("wide", "r3", "launch"):
         rollouts.adalead_round(ens, seqs, y, sequences_batch_size=100, model_queries_per_batch=2000, alphabet="TGCA")
         ts.append((time.perf_counter() - t0) * 1e3)
     print(f"Adalead round, {mode}: {np.median(ts[1:]):.2f} ms (runs {[round(t, 2) for t in ts]}), {ens.cost - c0} queries", flush=True)
-set_mode("wide")
+set_mode("adaptive")
