@@ -165,7 +165,7 @@ struct fx_engine {
     int64_t dense_pipe = 0;     // MLP (pair rows) / GE (byte table): 1 / 2 = the software-pipelined form (tile t + 1's first layer inside tile t's MFMA layers, 8 waves, two-part direct LDS fill; 2 = A operands double-buffered by hand).  Bit-identical but measured 11-13 % SLOWER than the 16-wave form at every size (profiles/r3_dense_pipe_ab.log): off; kept as the A/B
     int64_t train_rows = 0;     // fx_train_fit: mini-batch rows per workgroup (0 = auto: 16, or 8 for small batches)
     int64_t train_lds = 2;      // fx_train_fit: 2 = a slice's activations / gradients AND the member's weights live in LDS when they fit, 1 = the workspace only, 0 = global arena (A/B)
-    int64_t train_persistent = 1;   // fx_train_fit: 1 = the whole fit is ONE launch when all (slices x members) workgroups are co-resident: step barriers in device memory, Adam by the same workgroups (0 = two launches per step: A/B, and what larger ensembles get)
+    int64_t train_persistent = 0;   // fx_train_fit: 1 = the whole fit is ONE launch when all (slices x members) workgroups are co-resident: two member barriers in device memory per step, Adam by the same workgroups.  Bit-identical to the launch-per-step form and NOT faster: 5.90 vs 5.41 ms for 3 x CNN on 1000 sequences, equal elsewhere (profiles/r4_train_one_launch_ab.log) -- two agent-scope release/acquire barriers + the weight re-read cost what two launch boundaries cost.  Off; kept as the A/B
     int64_t train_trace = 0;    // profiling aid: 1 = fx_train_fit stamps the phases of the LAST step of member 0, workgroup 0 (fx_debug_train_trace)
     unsigned long long* d_train_dbg = nullptr;
     int64_t train_threads = 0;  // fx_train_fit: threads per forward+backward workgroup (256 / 512 / 1024; 0 = 1024)

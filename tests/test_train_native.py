@@ -279,7 +279,7 @@ def test_device_training_step_on_a_seeded_sweep_of_random_shapes():
                                                         ("ge", 30, ref_np.AAS, 0, 100, 0, 300, 64, 8), ("cnn", 9, "UGCA", 8, 16, 3, 150, 256, 1),
                                                         ("cnn", 30, ref_np.AAS, 32, 100, 5, 120, 64, 2)])
 def test_one_launch_fit_equals_the_launch_per_step_fit(kind, L, alphabet, F, H, K, n, B, M):
-    """Round 4: the whole fit as ONE launch (`train_persistent`, default on: the (slices x members) workgroups stay for all
+    """Round 4: the whole fit as ONE launch (`train_persistent`; measured no faster, so off by default: the (slices x members) workgroups stay for all
     steps, the workgroups of a member meet at two barriers in device memory per step, Adam is applied by the same
     workgroups) against round 3's two launches per step -- the same fxt_forward_backward and fxt_adam, the same slice order
     of the gradient sum: weights, both moments, step count and per-step losses are the SAME BITS, for several members with
@@ -307,7 +307,7 @@ def test_one_launch_fit_equals_the_launch_per_step_fit(kind, L, alphabet, F, H, 
             res = _native.train_fit(eng, jobs, b, lut, y)
             results.append([(j["weights"].copy(), j["adam_m"].copy(), j["adam_v"].copy(), t, np.asarray(loss).copy()) for j, (t, loss) in zip(jobs, res)])
         finally:
-            eng.set_option("train_persistent", 1)
+            eng.set_option("train_persistent", 0)
     del rng
     for mem, (a, c) in enumerate(zip(*results)):
         assert a[3] == c[3] == epochs * steps

@@ -46,6 +46,8 @@ for name, make, L, alpha in fams:
         row = []
         for mode in MODES:
             set_mode(mode)
+            if mode == "adaptive":
+                time.sleep(0.3)                                  # (the adaptive geometry remembers mid-size requests for 0.25 s)
             med, p99 = call_us(model, pool[:n], reps=300 if n <= 1000 else 150)
             row.append(f"{med:9.1f} ({p99:6.1f})")
         print(f"   {n:<6d}" + "".join(f"{r:>18s}" for r in row), flush=True)
@@ -57,6 +59,7 @@ seqs = synth.bytes_to_strings(synth.random_sequence_bytes(1000, 8, "TGCA", 3))
 y = np.random.default_rng(0).random(1000)
 for mode in ("adaptive", "wide", "r3", "launch"):
     set_mode(mode)
+    time.sleep(0.3)
     ts = []
     for i in range(5):
         random.seed(1)

@@ -22,7 +22,7 @@ def run(tag, make, L, alpha, n):
         for _ in range(5):
             t0 = time.perf_counter(); model.train(seqs, y); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
         out.append(min(ts) * 1e3)
-    eng.set_option("train_persistent", 1)
+    eng.set_option("train_persistent", 0)
     print(f"{tag} n={n}: one launch per fit {out[0]:.2f} ms, two launches per step {out[1]:.2f} ms", flush=True)
 
 run("Ensemble 3xCNN L=8", lambda: flexs_amd.Ensemble([bm.CNN(8, 32, 100, "TGCA", seed=m) for m in range(3)]), 8, "TGCA", 1000)
