@@ -316,9 +316,30 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "dense_few_waves_below")) return &e->dense_few_waves_below;
     return nullptr;
 }
+// Kernel forms that were measured and lost (csrc/OPTIONS.md, "negative results") are compiled into the A/B build only
+// (`make -C flexs_amd/csrc ab` -> libflexs_amd_ab.so, -DFX_AB; FLEXS_AMD_LIB selects it): the production library refuses
+// the option values that would select them instead of silently running something else.
+static bool ab_only_value(const fx_engine* e, const int64_t* s, int64_t value) {
+#if defined(FX_AB)
+    (void)e; (void)s; (void)value;
+    return false;
+#else
+    if (s == &e->dense_pipe || s == &e->fuse_mean || s == &e->chunk_overlap || s == &e->cnn_conv1_mfma || s == &e->mlp_l1_mfma ||
+        s == &e->dense_few_waves_below)
+        return value != 0;
+    if (s == &e->dense_waves) return value == 8;
+    if (s == &e->cnn_pair) return value == 0;
+    if (s == &e->cnn_variant) return value == 2 || value == 3 || value == 5 || value == 6;
+    return false;
+#endif
+}
+
 int fx_engine_set_option(fx_engine* e, const char* key, int64_t value) {
     int64_t* s = option_slot(e, key);
     if (!s) return fx_fail(e, FX_EINVAL, std::string("unknown option ") + (key ? key : "(null)"));
+    if (ab_only_value(e, s, value))
+        return fx_fail(e, FX_EUNSUPPORTED, std::string("option ") + key + " = " + std::to_string(value) + " selects a kernel form of the A/B build "
+                       "(measured slower, see csrc/OPTIONS.md): make -C flexs_amd/csrc ab, FLEXS_AMD_LIB=.../libflexs_amd_ab.so");
     const bool geometry = s == &e->serve_wide || s == &e->serve_reserve_cus || s == &e->serve_poll_sleep || s == &e->serve_fence;
     if (geometry && *s != value) fx_server_stop(e);        // (a running generation has the old geometry: the next calls start a new one)
     *s = value;
@@ -328,6 +349,11 @@ int fx_engine_set_option(fx_engine* e, const char* key, int64_t value) {
 int fx_engine_get_option(fx_engine* e, const char* key, int64_t* value) {
     if (!value) return FX_EINVAL;
     if (e && key && !std::strcmp(key, "num_cus")) { *value = e->num_cus; return FX_OK; }
+#if defined(FX_AB)
+    if (e && key && !std::strcmp(key, "ab_build")) { *value = 1; return FX_OK; }
+#else
+    if (e && key && !std::strcmp(key, "ab_build")) { *value = 0; return FX_OK; }
+#endif
     // read-only: the resident form's bookkeeping (requests answered, generations started, requests that fell back to a launch)
     if (e && key && !std::strcmp(key, "server_calls")) { *value = e->server.served; return FX_OK; }
     if (e && key && !std::strcmp(key, "server_starts")) { *value = e->server.started; return FX_OK; }
@@ -1066,7 +1092,11 @@ int fx_score_submit(fx_engine* e, int64_t row0, int64_t rows) {
         ++c.pieces;
         return FX_OK;
     }
+#if defined(FX_AB)
     const bool two = e->chunk_overlap != 0;
+#else
+    const bool two = false;                               // (the two-stream form measured slower: A/B build only)
+#endif
     hipStream_t cs = two ? e->copy_stream : e->stream;
     const int k = c.pieces;
     FX_HIP(e, hipMemcpyAsync(c.d_in + row0 * c.L, c.h_in + row0 * c.L, (size_t)rows * c.L, hipMemcpyHostToDevice, cs));

@@ -512,8 +512,10 @@ int launch_g(fx_engine* e, const CnnArgs& a, size_t lds_bytes) {
 
 template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES>
 int launch_inst(fx_engine* e, const CnnArgs& a, size_t lds_bytes) {
-    return e->cnn_conv1_mfma ? launch_g<A, K, FT, HT, NT, DENSE_LDS, WAVES, false>(e, a, lds_bytes)
-                             : launch_g<A, K, FT, HT, NT, DENSE_LDS, WAVES, true>(e, a, lds_bytes);
+#if defined(FX_AB)   // (the MFMA form of the one-hot conv1 -- 3-15 % slower than the LDS gather -- lives in the A/B build, `make ab`)
+    if (e->cnn_conv1_mfma) return launch_g<A, K, FT, HT, NT, DENSE_LDS, WAVES, false>(e, a, lds_bytes);
+#endif
+    return launch_g<A, K, FT, HT, NT, DENSE_LDS, WAVES, true>(e, a, lds_bytes);
 }
 
 }  // namespace

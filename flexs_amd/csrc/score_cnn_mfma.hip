@@ -26,15 +26,17 @@ int dispatch_a4(fx_engine* e, const CnnArgs& a0, int variant, bool big, size_t f
             a.TG = (a.N + 16 * nt - 1) / (16 * nt);
             switch (variant) {
                 case 1: return launch_inst<4, 5, 2, 7, 1, true, 8>(e, a, lds);
+#if defined(FX_AB)   // (two tiles per wave, and the unrolled forms without s_setprio: measured losers, A/B build only)
                 case 2: return launch_inst<4, 5, 2, 7, 2, true, 4>(e, a, lds);
                 case 3: return launch_inst<4, 5, 2, 7, 2, true, 8>(e, a, lds);
-                case 4: return launch_inst<4, 5, 2, 7, 1, true, 16>(e, a, lds);
                 case 5:                                  // variant 4 with the position loop unrolled (TF-binding: L = 8)
                     if (a.L != 8) return fx_fail(e, FX_EINVAL, "cnn_variant 5 is the seq_len = 8 specialisation");
                     return launch_g<4, 5, 2, 7, 1, true, 16, true, 4, false>(e, a, lds);   // no s_setprio (A/B baseline)
                 case 6:
                     if (a.L != 14) return fx_fail(e, FX_EINVAL, "cnn_variant 6 is the seq_len = 14 specialisation");
                     return launch_g<4, 5, 2, 7, 1, true, 16, true, 10>(e, a, lds);
+#endif
+                case 4: return launch_inst<4, 5, 2, 7, 1, true, 16>(e, a, lds);
                 case 10:                                 // variant 6 with s_setprio (A/B)
                     if (a.L != 14) return fx_fail(e, FX_EINVAL, "cnn_variant 10 is a seq_len = 14 specialisation");
                     return launch_g<4, 5, 2, 7, 1, true, 16, true, 10, true>(e, a, lds);
@@ -188,7 +190,11 @@ int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const
         const int rc = fx_launch_score_cnn_pair(e, models, M, d_ascii, N, d_out_NM, Mtot, m_off);
         if (rc != FX_EUNSUPPORTED) return rc;
     }
+#if defined(FX_AB)
     if (lay.HT != 7 || s.K != 5 || conv_only > (size_t)e->max_lds) return FX_EUNSUPPORTED;
     a.TG = (N + 15) / 16;
-    return launch_inst<20, 5, 2, 7, 1, false, 4>(e, a, conv_only);   // 1 wave / SIMD: 512-VGPR budget for the 19-tap window
+    return launch_inst<20, 5, 2, 7, 1, false, 4>(e, a, conv_only);   // 1 wave / SIMD: 512-VGPR budget for the 19-tap window (0.76 vs 0.92 of peak for the pair form)
+#else
+    return FX_EUNSUPPORTED;                              // (the one-wave window form of the protein CNN lives in the A/B build)
+#endif
 }

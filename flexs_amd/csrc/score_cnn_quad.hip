@@ -336,6 +336,7 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
                 } else {
                     if (g == 0 && n < Ncur) outp[n * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y[0]);
                 }
+#if defined(FX_AB)   // (the in-kernel mean of explorer-size launches: no faster than the 3 us mean launch, A/B build only)
                 if (!SERVER && p.mean_out) {
                     // np.mean over the members (ensemble.py:24) without a second launch: publish this member's 16 scores
                     // device-wide, take the tile's ticket; the M-th arrival reads all members' scores back (past its own
@@ -359,6 +360,7 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
                         if (lane == 0) __hip_atomic_store(&p.tickets[tg], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
+#endif
             }
             if (live) FX_TILE_DONE();
         }
@@ -422,7 +424,11 @@ int fx_launch_score_cnn_quad(fx_engine* e, fx_model* const* models, int M, const
     a.L = s.L; a.rlh = (lay.HTR == lay.HT) ? lay.RLH : 4;
     a.rotate = (int)e->quad_rotate;
     a.dma = e->dma_fill && lay.off_d1 % 4 == 0 && lay.total_floats % 4 == 0;
+#if defined(FX_AB)
     const bool fuse = e->fuse_mean_out && e->planar_stride && m_off == 0 && M == Mtot && M <= 16 && TG <= 4096;
+#else
+    const bool fuse = false;
+#endif
     if (fuse) {
         void* tk = nullptr;
         if (int rc = fx_zero_pool(e, sizeof(unsigned) * (size_t)TG, &tk)) return rc;

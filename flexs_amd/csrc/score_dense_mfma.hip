@@ -482,6 +482,7 @@ int launch_inst(fx_engine* e, const DenseArgs& a, size_t lds_bytes) {
 }
 
 
+#if defined(FX_AB)   // (measured 11-13 % slower than the 16-wave form: lives in the A/B build only, `make ab`)
 // ---------------------------------------------------------------------------------------------------------------
 // Software-pipelined form (round 3) of the two LDS-resident first-layer forms above: PAIR (MLP, 4-letter alphabet)
 // and BT (GlobalEpistasis byte table).
@@ -892,6 +893,8 @@ int launch_pipe(fx_engine* e, const DenseArgs& a, size_t lds_bytes) {
     return launch_pipe_var<KIND, HT, NLD, 0>(e, a, lds_bytes);
 }
 
+#endif  // FX_AB
+
 }  // namespace
 
 namespace {
@@ -906,7 +909,7 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
     // first MFMA), the second round has two waves left; with two waves the tiles go 3-3 and one wave's first layer
     // overlaps the other's MFMA layers (profiles/r2_trace_probe).  Long launches keep four (best steady state).
     const int64_t tiles_per_simd = (int64_t)a.M * a.TG / ((int64_t)e->num_cus * 4);
-    const bool few_waves = e->dense_waves == 8 || (e->dense_waves == 0 && tiles_per_simd < e->dense_few_waves_below);
+    [[maybe_unused]] const bool few_waves = e->dense_waves == 8 || (e->dense_waves == 0 && tiles_per_simd < e->dense_few_waves_below);
     const int64_t tail = DGc ? lay.off_d2 : lay.total_floats;           // end of the LDS image
     int64_t lds_from = (s.kind == FX_MLP && !e->mlp_l1_mfma) ? lay.off_w1p : 0;
     size_t lds = (size_t)(tail - lds_from) * 4 + 256 + 32;
@@ -918,6 +921,7 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
             a.lds_floats = (int)(lay.total_floats - lay.off_d3);
             size_t need = (size_t)a.Lpad * 128 + (size_t)a.lds_floats * 4 + 256 + 32;
             const size_t stride = ((size_t)16 * s.L + 32 + 15) / 16 * 16;            // tile bytes + filler for the padded trips
+#if defined(FX_AB)
             if constexpr (HT_ <= 8) {
                 // software-pipelined form: one 32-position table trip per block row of the H x H layer
                 const size_t pneed = (size_t)a.Lpad * 128 + (size_t)a.lds_floats * 4 + 256 + 32 + 8 * stride;
@@ -927,10 +931,13 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
                     return launch_pipe<FX_GE, HT_, 2>(e, a, pneed);
                 }
             }
+#endif
             if (e->stage_bytes && need + W * stride <= (size_t)e->max_lds) { a.stage_stride = (int)stride; need += W * stride; }
+#if defined(FX_AB)
             if constexpr (HT_ == 7) {
                 if (few_waves) return launch_inst<FX_GE, 4, HT_, 1, 8, false, false, false, false, true>(e, a, need);
             }
+#endif
             if constexpr (W == 16) {
                 // shared last tiles: exchange buffers behind everything else (2 x HT KiB per group of 8 waves)
                 need = (need + 15) / 16 * 16;
@@ -966,6 +973,7 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
     }
     if (s.kind == FX_MLP) {
         if (w1_global) return launch_inst<FX_MLP, 4, HT_, 1, W, true, true, DGc>(e, a, lds);   // gather form: A is a runtime stride
+#if defined(FX_AB)
         if (e->mlp_l1_mfma) {
             if constexpr (HT_ == 7) {
                 if (s.A == 4) return launch_inst<FX_MLP, 4, 7, 1, W, false, false, false>(e, a, lds);
@@ -973,6 +981,7 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
             }
             return FX_EUNSUPPORTED;
         }
+#endif
         if constexpr (!DGc) {
             if (e->mlp_pair && lay.off_w1pair >= 0) {
                 // image = HxH blocks + vectors (the plain first-layer rows stay in global memory), then the pair rows
@@ -984,15 +993,19 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
                     a.lds_floats = (int)img_floats;
                     a.off_w1pair = (int)lay.off_w1pair;
                     a.pair_floats = (int)lay.pair_floats;
+#if defined(FX_AB)
                     // software-pipelined form: one pair-row gather per block row of the two H x H layers
                     if (e->dense_pipe && s.L / 2 + (s.L & 1) + 2 + 3 <= 2 * HT_ && s.L <= 32 && need + 8 * stride <= (size_t)e->max_lds) {
                         a.stage_stride = (int)stride;
                         return launch_pipe<FX_MLP, HT_, 1>(e, a, need + 8 * stride);
                     }
+#endif
                     if (e->stage_bytes && need + W * stride <= (size_t)e->max_lds) { a.stage_stride = (int)stride; need += W * stride; }
+#if defined(FX_AB)
                     if constexpr (HT_ == 7) {
                         if (few_waves) return launch_inst<FX_MLP, 4, HT_, 1, 8, true, false, false, false, false, true>(e, a, need);
                     }
+#endif
                     // shared last tiles: the groups' exchange buffers (2 x HT KiB each) lie over the pair rows
                     if (W == 16 && e->dense_coop)
                         a.coop = (size_t)lay.pair_floats * 4 >= (size_t)4 * HT_ * 1024 ? 2 : (size_t)lay.pair_floats * 4 >= (size_t)2 * HT_ * 1024 ? 1 : 0;

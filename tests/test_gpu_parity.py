@@ -49,6 +49,19 @@ def eng():
     e.set_option("cnn_pair", 1)
 
 
+def ab_option(eng, key, value):
+    """Selects a kernel form that was measured and lost (csrc/OPTIONS.md): compiled into the A/B build only
+    (`make -C flexs_amd/csrc ab`, FLEXS_AMD_LIB=.../libflexs_amd_ab.so).  False = the production library refused it: the
+    caller skips that leg."""
+    try:
+        eng.set_option(key, value)
+        return True
+    except _native.FxError as ex:
+        if ex.code == _native.FX_EUNSUPPORTED:
+            return False
+        raise
+
+
 def rand_seqs(n, L, alphabet, seed):
     b = synth.random_sequence_bytes(n, L, alphabet, seed)
     return b, synth.bytes_to_strings(b)
@@ -92,8 +105,9 @@ def test_cnn_l8_variants_and_tails(eng, variant, n, conv1_mfma):
     """BASELINE configs[0]/[1] shape: TF-binding L=8, alphabet TGCA, CNN(32,100,k5);
     every launch geometry (variant) x both forms of the one-hot conv1 (LDS gather / MFMA)."""
     eng.set_option("force_generic", 0)
-    eng.set_option("cnn_variant", variant)
-    eng.set_option("cnn_conv1_mfma", conv1_mfma)
+    if not (ab_option(eng, "cnn_variant", variant) and ab_option(eng, "cnn_conv1_mfma", conv1_mfma)):
+        eng.set_option("cnn_variant", 0)
+        pytest.skip("a kernel form of the A/B build (make ab)")
     nm, w = make_native(eng, "cnn", 8, 4, 100, 32, 5)
     b, seqs = rand_seqs(n, 8, "TGCA", seed=n)
     got, _ = eng.score([nm], b, _native.make_lut("TGCA"))
@@ -111,9 +125,9 @@ def test_cnn_l14_unrolled_specialisation(eng, n):
     lut = _native.make_lut("UGCA")
     eng.set_option("cnn_variant", 10)
     got10, _ = eng.score([nm], b, lut)
-    eng.set_option("cnn_variant", 6)
-    got6, _ = eng.score([nm], b, lut)
-    assert np.array_equal(got6, got10)                   # s_setprio changes scheduling only
+    if ab_option(eng, "cnn_variant", 6):
+        got6, _ = eng.score([nm], b, lut)
+        assert np.array_equal(got6, got10)               # s_setprio changes scheduling only
     eng.set_option("cnn_variant", 4)
     got4, _ = eng.score([nm], b, lut)
     eng.set_option("cnn_variant", 0)
@@ -133,17 +147,16 @@ def test_cnn_mfma_vs_oracle(eng, L, A, alpha, n):
     got, _ = eng.score([nm], b, _native.make_lut(alpha))
     want = ref_np.keras_fitness(seqs, alpha, "cnn", w, exact=True)
     assert_scores(got[:, 0], want, f"cnn mfma L={L} A={A}")
-    if A == 20:                                          # single-wave-per-tile form of the wide-alphabet kernel
-        eng.set_option("cnn_pair", 0)
+    if A == 20 and ab_option(eng, "cnn_pair", 0):        # single-wave-per-tile form of the wide-alphabet kernel (A/B build)
         got_s, _ = eng.score([nm], b, _native.make_lut(alpha))
         eng.set_option("cnn_pair", 1)
         assert_scores(got_s[:, 0], want, f"cnn single-wave form L={L} A={A}")
-    eng.set_option("cnn_conv1_mfma", 1)                  # one-hot conv1 on the MFMA pipe instead of the LDS gather
-    eng.set_option("cnn_pair", 0)
-    got_m, _ = eng.score([nm], b, _native.make_lut(alpha))
-    eng.set_option("cnn_conv1_mfma", 0)
-    eng.set_option("cnn_pair", 1)
-    assert_scores(got_m[:, 0], want, f"cnn mfma(conv1 on mfma) L={L} A={A}")
+    if ab_option(eng, "cnn_conv1_mfma", 1):              # one-hot conv1 on the MFMA pipe instead of the LDS gather (A/B build)
+        eng.set_option("cnn_pair", 0)
+        got_m, _ = eng.score([nm], b, _native.make_lut(alpha))
+        eng.set_option("cnn_conv1_mfma", 0)
+        eng.set_option("cnn_pair", 1)
+        assert_scores(got_m[:, 0], want, f"cnn mfma(conv1 on mfma) L={L} A={A}")
     # the shape-agnostic kernel must agree too (independent on-device implementation)
     eng.set_option("force_generic", 1)
     got_g, _ = eng.score([nm], b, _native.make_lut(alpha))
@@ -253,7 +266,8 @@ def test_cnn_odd_shapes_generic(eng, L, A, alpha, F, H, K):
 def test_mlp_ge_vs_oracle(eng, kind, L, A, alpha, H, n):
     for force, l1 in ((0, 0), (0, 1), (1, 0)):
         eng.set_option("force_generic", force)
-        eng.set_option("mlp_l1_mfma", l1)
+        if not ab_option(eng, "mlp_l1_mfma", l1):
+            continue                                     # (the MFMA form of the one-hot first layer: A/B build)
         nm, w = make_native(eng, kind, L, A, H, seed=11)
         b, seqs = rand_seqs(n, L, alpha, seed=L + H)
         got, _ = eng.score([nm], b, _native.make_lut(alpha))
@@ -1654,6 +1668,9 @@ def test_software_pipelined_dense_form_gives_the_same_bits(eng, kind, L, alpha, 
     MFMA layers (`dense_pipe` = 1: 8 waves, two-part direct LDS fill).  Every output element sees the arithmetic of the
     round-2 form (`dense_pipe` = 0), so the scores are the SAME BITS -- ragged last tiles, members, any alignment -- and
     both agree with the oracle; a character outside the alphabet is reported from the pipelined first layer too."""
+    if not ab_option(eng, "dense_pipe", 1):
+        pytest.skip("the software-pipelined dense form (measured 11-13 % slower) lives in the A/B build: make ab")
+    eng.set_option("dense_pipe", 0)
     A = len(alpha)
     natives, ws = zip(*[make_native(eng, kind, L, A, H, seed=700 + m) for m in range(M)])
     lut = _native.make_lut(alpha)
@@ -1722,6 +1739,9 @@ def test_small_launch_fused_ensemble_mean(eng, L, alpha, M):
     finishes a tile last reads all members' scores back and averages in NumPy's order) instead of launching the mean kernel:
     the same bits as the separate launch and as np.mean of the stacked matrix, for every batch size the small-launch form
     serves, repeated calls (the tickets clean up after themselves), and a bad character still raises."""
+    if not ab_option(eng, "fuse_mean", 1):
+        pytest.skip("the in-kernel ensemble mean of explorer-size launches (no faster than the mean launch) lives in the A/B build: make ab")
+    eng.set_option("fuse_mean", 0)
     members = [bm.CNN(L, 32, 100, alpha, seed=s) for s in range(M)]
     ens = flexs_amd.Ensemble(members)
     stack = flexs_amd.Ensemble(members, combine_with=lambda x: x)
