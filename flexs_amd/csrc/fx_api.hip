@@ -146,6 +146,11 @@ static int check_deferred(fx_engine* e) {
     const unsigned err = *reinterpret_cast<volatile unsigned*>(e->h_err);
     if (err) {
         *reinterpret_cast<volatile unsigned*>(e->h_err) = 0;
+        if (err & FX_ERR_TIMEOUT) {
+            // (the barrier counter no longer matches what the host has added up: start over)
+            if (e->d_lp_bar) { (void)hipMemset(e->d_lp_bar, 0, 64); e->lp_bar_total = 0; }
+            return fx_fail(e, FX_ESTATE, "a device-side barrier of the layer-parallel CNN form timed out (workgroups not co-resident?): set the engine option cnn_lp = 0");
+        }
         if (err & FX_ERR_BADCHAR) return fx_fail(e, FX_EBADCHAR, "substring not found: character outside the alphabet");
     }
     return FX_OK;
@@ -241,6 +246,7 @@ int fx_engine_destroy(fx_engine* e) {
     if (e->h_err) (void)hipHostFree(e->h_err);
     if (e->d_lut) (void)hipFree(e->d_lut);
     if (e->d_trace) (void)hipFree(e->d_trace);
+    if (e->d_lp_bar) (void)hipFree(e->d_lp_bar);
     for (int i = 0; i < fx_engine::MAX_PIECES; ++i) {
         if (e->ev_in[i]) (void)hipEventDestroy(e->ev_in[i]);
         if (e->ev_done[i]) (void)hipEventDestroy(e->ev_done[i]);
@@ -285,6 +291,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "cnn_seg_multi")) return &e->cnn_seg_multi;
     if (!std::strcmp(key, "dense_small")) return &e->dense_small;
     if (!std::strcmp(key, "cnn_quad")) return &e->cnn_quad;
+    if (!std::strcmp(key, "cnn_lp")) return &e->cnn_lp;
     if (!std::strcmp(key, "cnn_pair")) return &e->cnn_pair;
     if (!std::strcmp(key, "cnn_pair_seg")) return &e->cnn_pair_seg;
     if (!std::strcmp(key, "cnn_seg")) return &e->cnn_seg;
@@ -340,8 +347,9 @@ int fx_engine_set_option(fx_engine* e, const char* key, int64_t value) {
     if (ab_only_value(e, s, value))
         return fx_fail(e, FX_EUNSUPPORTED, std::string("option ") + key + " = " + std::to_string(value) + " selects a kernel form of the A/B build "
                        "(measured slower, see csrc/OPTIONS.md): make -C flexs_amd/csrc ab, FLEXS_AMD_LIB=.../libflexs_amd_ab.so");
-    const bool geometry = s == &e->serve_wide || s == &e->serve_reserve_cus || s == &e->serve_poll_sleep || s == &e->serve_fence;
-    if (geometry && *s != value) fx_server_stop(e);        // (a running generation has the old geometry: the next calls start a new one)
+    // a running resident generation was started under the old options (its geometry, but also the kernel forms its
+    // workgroups run: pair rows or plain rows, ...): it leaves, the next calls start a new one under the new ones
+    if (*s != value) fx_server_stop(e);
     *s = value;
     e->server.refused.clear();                             // (what has a resident form depends on the form selectors)
     return FX_OK;

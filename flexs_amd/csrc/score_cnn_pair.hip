@@ -42,6 +42,11 @@ struct PairArgs {
     int SB;                     // SEG form: workgroups per (member, tile) unit
     unsigned* pool;             // SEG form: [units][2 tiles][64 lanes][4] pooled maxima (float bits); zero between launches (fx_zero_pool with the head, memset without)
     unsigned* cnt;              // SEG form: [units] arrival counters, likewise
+    // LP form (layer-parallel small batches, k_score_cnn_lp)
+    f4* lp_out2;                // [unit][position][2 tiles][64 lanes]: conv2 outputs, between the two phases
+    unsigned* lp_bar;           // grid barrier: a counter that only ever grows; this launch passes at lp_target
+    unsigned lp_target;
+    int lp_nb;                  // position blocks (workgroups) per (member, tile) unit
 };
 
 // workgroups per (member, tile) unit of the position-segmented small-batch form (see launch_pair)
@@ -320,6 +325,246 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
     if (bad) fx_raise(p.err, FX_ERR_BADCHAR);
 }
 
+// LP form (round 4): small protein batches LAYER BY LAYER across the chip instead of position segments with halos.
+//
+// A CMA-ES population / DyNA-PPO environment batch is 1-40 sequences of 90-237 residues: 1-3 tiles per member.  The SEG form
+// above cuts a tile's positions into segments of two and pays for it with the halo: conv3 reaches 9 + 9 positions and conv2
+// 2 + 2 around every output, so a pair walks 24 steps (barrier + LDS exchange + ~70 MFMAs of a lone wave each, ~2.5 us) for
+// its 2 positions -- 73 us for one 237-residue tile whose whole arithmetic is ~90 k MFMAs = 1.2 us of the machine
+// (profiles/r2_protein_small_calls.log).  Here nothing is recomputed:
+//   phase 1  workgroup (unit, block b) computes conv1 + conv2 for ITS positions (conv1, a row gather, also for the 2 + 2
+//            neighbours conv2 reaches) and leaves out2[position] in device memory (2 KiB per position and tile);
+//   barrier  all workgroups of the launch (a counter in device memory, agent-scope release / acquire: one per launch);
+//   phase 2  the same workgroup computes conv3 for its positions from out2[position - 9 .. position + 9] (L2 reads),
+//            pools them, and the blocks of a unit meet in the zeroed pool (atomicMax on the float bits, ticket) as the SEG
+//            form's workgroups do; the last one runs the dense head.
+// A wave owns one output-channel tile (mo) and up to PBW positions; per output element the MFMA sequence is the pair
+// kernel's: conv2 = bias + taps 0..K-1 x (k-steps 0..3) as two chains (input tiles 0 / 1) added at the end, conv3 = bias +
+// the conv2 outputs in position order (= tap order) x (input tile, k-step) -- out-of-range positions are skipped for conv3 and
+// read as zeros for conv2, exactly as there -- so the scores are the SAME BITS as k_score_cnn_pair's (tested).
+// Needs every workgroup co-resident (grid <= CUs, ~111 KiB of LDS each: the launcher checks); a barrier not passed within
+// 1 s raises FX_ERR_TIMEOUT instead of hanging the device.
+template <int A, int K, int HT>
+__global__ void __launch_bounds__(256) k_score_cnn_lp(PairArgs p) {
+    constexpr int FT = 2, K3 = A - 1, PBW = 8;
+    constexpr int PL2 = (K - 1) / 2, PR2 = K - 1 - PL2;
+    constexpr int PL3 = (K3 - 1) / 2, PR3 = K3 - 1 - PL3;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mo = wave & 1, half = wave >> 1;
+    const int g = lane >> 4, sq = lane & 15;
+    const int L = p.L, L1 = L - K + 1, NB = p.lp_nb;
+    uint8_t* lut_s = reinterpret_cast<uint8_t*>(smem + p.lds_floats);
+    int* flags = reinterpret_cast<int*>(lut_s + 256);
+    for (int i = tid; i < 64; i += blockDim.x)
+        reinterpret_cast<uint32_t*>(lut_s)[i] = reinterpret_cast<const uint32_t*>(p.lut)[i];
+    const int64_t unit = blockIdx.x / (unsigned)NB;
+    const int b = (int)(blockIdx.x % (unsigned)NB);
+    const int m = (int)(unit / p.TG);
+    const int64_t tg = unit - (int64_t)m * p.TG;
+    fill_lds(reinterpret_cast<f4*>(smem), reinterpret_cast<const f4*>(p.w[m] + p.lds_from), p.lds_floats / 4);
+    __syncthreads();
+    const f4* w_c2 = reinterpret_cast<const f4*>(smem + (p.off_c2 - p.lds_from));
+    const f4* w_c3 = reinterpret_cast<const f4*>(smem + (p.off_c3 - p.lds_from));
+    const float* cb = smem + (p.off_cb - p.lds_from);
+    const float* w1p = smem + (p.off_w1p - p.lds_from);
+    // this block's positions, cut in two for the wave pairs (half 0 / 1); a wave owns output tile `mo` of them
+    const int P0 = (int)((int64_t)L1 * b / NB), P1 = (int)((int64_t)L1 * (b + 1) / NB);
+    const int h0 = __builtin_amdgcn_readfirstlane(P0 + (P1 - P0) * half / 2), h1 = __builtin_amdgcn_readfirstlane(P0 + (P1 - P0) * (half + 1) / 2);
+    const int64_t n = tg * 16 + sq;
+    const bool live = n < p.N;
+    const uint8_t* row = p.ascii + (live ? n : 0) * L;
+    f4* o2g = p.lp_out2 + (unit * L1) * 2 * 64;            // [position][tile][lane]
+    bool bad = false;
+
+    // ---- phase 1: conv1 (valid, row gather) over [h0 - PL2, h1 + PR2), conv2 (same) at [h0, h1): the pair kernel's step loop
+    if (h1 > h0) {
+        const int s0 = h0 - PL2 > 0 ? h0 - PL2 : 0;
+        const int s_last = h1 - 1 + PR2;
+        int cw[K];
+#pragma unroll
+        for (int j = 0; j < K - 1; ++j) {
+            int c = lut_s[row[s0 + j]];
+            if (c == 0xFF) { bad |= live; c = 0; }
+            cw[j + 1] = c;
+        }
+        f4 win1[K][FT];
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+            for (int t = 0; t < FT; ++t) win1[j][t] = splat4(0.f);
+        for (int s = s0; s <= s_last; ++s) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < K - 1; ++j) {
+                cw[j] = cw[j + 1];
+#pragma unroll
+                for (int t = 0; t < FT; ++t) win1[j][t] = win1[j + 1][t];
+            }
+            if (s < L1) {
+                int c = lut_s[row[s + K - 1]];
+                if (c == 0xFF) { bad |= live; c = 0; }
+                cw[K - 1] = c;
+                f4 o1[FT];
+#pragma unroll
+                for (int t = 0; t < FT; ++t) o1[t] = *reinterpret_cast<const f4*>(&cb[16 * t + 4 * g]);
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const float* rowp = w1p + (j * A + cw[j]) * (16 * FT) + 4 * g;
+#pragma unroll
+                    for (int t = 0; t < FT; ++t) o1[t] += *reinterpret_cast<const f4*>(rowp + 16 * t);
+                }
+#pragma unroll
+                for (int t = 0; t < FT; ++t) win1[K - 1][t] = relu4(o1[t]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < FT; ++t) win1[K - 1][t] = splat4(0.f);
+            }
+            const int t2 = s - PR2;
+            if (t2 >= h0 && t2 < L1) {                       // (t2 < h1 by the loop bound)
+                f4 o2a = *reinterpret_cast<const f4*>(&cb[16 * FT + 16 * mo + 4 * g]);
+                f4 o2b = splat4(0.f);
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const f4 a0 = w_c2[((j * FT + 0) * FT + mo) * 64 + lane];
+                    const f4 a1 = w_c2[((j * FT + 1) * FT + mo) * 64 + lane];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        o2a = mfma16(a0[r], win1[j][0][r], o2a);
+                        o2b = mfma16(a1[r], win1[j][1][r], o2b);
+                    }
+                }
+                o2g[(t2 * 2 + mo) * 64 + lane] = relu4(o2a + o2b);
+            }
+        }
+    }
+
+    // ---- barrier over the whole launch: conv2 outputs published (release), counter, wait, acquire
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_fetch_add(p.lp_bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = wall_clock64();
+        int timed_out = 0;
+        while ((int)(__hip_atomic_load(p.lp_bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.lp_target) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > 100000000ull) { timed_out = 1; break; }    // 1 s at 100 MHz
+        }
+        flags[0] = timed_out;
+    }
+    __syncthreads();
+    if (flags[0]) {
+        if (tid == 0) fx_raise(p.err, FX_ERR_TIMEOUT);
+        return;
+    }
+    __threadfence();                                          // acquire: the other workgroups' out2 rows are read past stale lines
+
+    // ---- phase 2: conv3 (same, A - 1 taps) at the wave's positions from out2[position - PL3 .. position + PR3], pooled
+    f4 gmax = splat4(0.f);
+    if (h1 > h0) {
+        const f4 bias3 = *reinterpret_cast<const f4*>(&cb[32 * FT + 16 * mo + 4 * g]);
+        f4 acc[PBW];
+#pragma unroll
+        for (int i = 0; i < PBW; ++i) acc[i] = bias3;
+        const int t_lo = h0 - PL3 > 0 ? h0 - PL3 : 0, t_hi = h1 - 1 + PR3 < L1 - 1 ? h1 - 1 + PR3 : L1 - 1;
+        f4 x0 = o2g[(t_lo * 2 + 0) * 64 + lane], x1 = o2g[(t_lo * 2 + 1) * 64 + lane];
+        for (int t2 = t_lo; t2 <= t_hi; ++t2) {
+            const f4 c0 = x0, c1 = x1;
+            if (t2 < t_hi) { x0 = o2g[((t2 + 1) * 2 + 0) * 64 + lane]; x1 = o2g[((t2 + 1) * 2 + 1) * 64 + lane]; }   // next position in flight
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < PBW; ++i) {
+                const int j = t2 + PL3 - (h0 + i);          // tap of out2[t2] for output position h0 + i (wave-uniform)
+                if (h0 + i < h1 && j >= 0 && j < K3) {
+                    const f4 a0 = w_c3[((j * FT + 0) * FT + mo) * 64 + lane];
+                    const f4 a1 = w_c3[((j * FT + 1) * FT + mo) * 64 + lane];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i] = mfma16(a0[r], c0[r], acc[i]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i] = mfma16(a1[r], c1[r], acc[i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PBW; ++i)
+            if (h0 + i < h1) gmax = pool_max4(gmax, acc[i]);
+        unsigned* pl = p.pool + ((unit * 2 + mo) * 64 + lane) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicMax(&pl[r], __float_as_uint(gmax[r]));
+    }
+    // ---- the blocks of a unit meet in the zeroed pool; the last to arrive runs the dense head (as the SEG form)
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) flags[1] = (atomicAdd(&p.cnt[unit], 1u) == (unsigned)NB - 1u) ? 1 : 0;
+    __syncthreads();
+    if (flags[1] && wave == 0) {
+        __threadfence();
+        const unsigned* p0 = p.pool + ((unit * 2 + 0) * 64 + lane) * 4;
+        f4 pool0, pool1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                         // device-coherent reads; the entries go back to zero
+            pool0[r] = __uint_as_float(__hip_atomic_load(&p0[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            pool1[r] = __uint_as_float(__hip_atomic_load(&p0[256 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            __hip_atomic_store(const_cast<unsigned*>(&p0[r]), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(const_cast<unsigned*>(&p0[256 + r]), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) __hip_atomic_store(&p.cnt[unit], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const f4* w_d1 = reinterpret_cast<const f4*>(p.w[m] + p.off_d1);   // dense head streams from L2
+        const f4* w_d2 = reinterpret_cast<const f4*>(p.w[m] + p.off_d2);
+        const float* db = p.w[m] + p.off_db;
+        const float y = pair_dense_head<HT>(w_d1, w_d2, db, pool0, pool1, lane, g, p.rlh);
+        if (g == 0 && n < p.N) p.out[n * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y);
+    }
+    if (bad) fx_raise(p.err, FX_ERR_BADCHAR);
+}
+
+// Launches the LP form when it applies: FX_EUNSUPPORTED otherwise (the caller carries on with the SEG / whole-sequence forms).
+template <int A, int K, int HT>
+int launch_lp(fx_engine* e, PairArgs a, size_t lds_bytes) {
+    constexpr int PBW = 8;
+    const int64_t U = (int64_t)a.M * a.TG;
+    const int L1 = a.L - K + 1;
+    int64_t room = e->num_cus - 8;                         // every workgroup must find a CU at once (the barrier); a few stay free
+    const int64_t nb_min = (L1 + 2 * PBW - 1) / (2 * PBW);  // <= PBW positions per wave, two waves (halves) per block
+    if (!e->cnn_lp || L1 < 24 || U < 1 || U * nb_min > room) return FX_EUNSUPPORTED;
+    // resident scoring workgroups of another ensemble hold most of their CU's LDS: work beside them when there is room for
+    // a useful grid, else tell them to leave (they do within microseconds; the barrier simply waits for the CUs they free)
+    if (e->server.running) {
+        if (U * nb_min * 2 <= room - e->server.wgs) room -= e->server.wgs;
+        else fx_server_stop(e);
+    }
+    int64_t nb = room / U;
+    if (nb > L1 / 2) nb = L1 / 2;                          // >= 2 positions per block: one per half
+    if (nb < nb_min) return FX_EUNSUPPORTED;
+    auto kern = k_score_cnn_lp<A, K, HT>;
+    static bool attr_set[64] = {};
+    if (!attr_set[e->device & 63]) {
+        FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[e->device & 63] = true;
+    }
+    void* ws = nullptr;
+    const size_t pool_bytes = (size_t)U * 2 * 64 * 4 * sizeof(unsigned), cnt_bytes = (size_t)U * sizeof(unsigned);
+    if (int rc = fx_zero_pool(e, pool_bytes + cnt_bytes, &ws)) return rc;
+    a.pool = (unsigned*)ws;
+    a.cnt = (unsigned*)((char*)ws + pool_bytes);
+    void* o2 = nullptr;
+    if (int rc = fx_scratch(e, 2, (size_t)U * L1 * 2 * 64 * sizeof(f4), &o2)) return rc;
+    a.lp_out2 = (f4*)o2;
+    if (!e->d_lp_bar) {
+        if (hipMalloc(reinterpret_cast<void**>(&e->d_lp_bar), 64) != hipSuccess) { (void)hipGetLastError(); return fx_fail(e, FX_ENOMEM, "hipMalloc of the barrier counter failed"); }
+        FX_HIP(e, hipMemsetAsync(e->d_lp_bar, 0, 64, e->stream));
+        e->lp_bar_total = 0;
+    }
+    a.lp_bar = e->d_lp_bar;
+    a.lp_nb = (int)nb;
+    e->lp_bar_total += (unsigned)(U * nb);
+    a.lp_target = e->lp_bar_total;
+    e->lp_launched = true;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(U * nb)), dim3(256), lds_bytes, e->stream, a);
+    FX_HIP(e, hipGetLastError());
+    return FX_OK;
+}
+
 template <int A, int K, int HT, int WAVES>
 int launch_pair(fx_engine* e, PairArgs a, size_t lds_bytes) {
     auto whole = k_score_cnn_pair<A, K, HT, WAVES, false>;
@@ -341,6 +586,13 @@ int launch_pair(fx_engine* e, PairArgs a, size_t lds_bytes) {
     if (e->cnn_pair_seg == 0 || 2 * U > e->num_cus) sb = 0;
     if (e->cnn_pair_seg > 0) sb = e->cnn_pair_seg;                       // test knob: force SB
     if (sb >= 1) {
+        if constexpr (A == 20 && K == 5 && HT == 7 && WAVES == 8) {
+            // layer-parallel form first (no halo recomputation): canonical protein CNN, units x position blocks <= CUs
+            if (e->cnn_pair_seg < 0) {
+                const int rc_lp = launch_lp<A, K, HT>(e, a, lds_bytes);
+                if (rc_lp != FX_EUNSUPPORTED) return rc_lp;
+            }
+        }
         void* ws = nullptr;
         const size_t pool_bytes = (size_t)U * 2 * 64 * 4 * sizeof(unsigned), cnt_bytes = (size_t)U * sizeof(unsigned);
         int rc = fx_zero_pool(e, pool_bytes + cnt_bytes, &ws);   // all zeros between launches: the head workgroup resets what it read

@@ -125,14 +125,14 @@ def test_cnn_l14_unrolled_specialisation(eng, n):
     lut = _native.make_lut("UGCA")
     eng.set_option("cnn_variant", 10)
     got10, _ = eng.score([nm], b, lut)
-    if ab_option(eng, "cnn_variant", 6):
+    if ab_option(eng, "cnn_variant", 6):                 # (the unrolled form without s_setprio: A/B build)
         got6, _ = eng.score([nm], b, lut)
         assert np.array_equal(got6, got10)               # s_setprio changes scheduling only
     eng.set_option("cnn_variant", 4)
     got4, _ = eng.score([nm], b, lut)
     eng.set_option("cnn_variant", 0)
     want = ref_np.keras_fitness(seqs, "UGCA", "cnn", w, exact=True)
-    assert_scores(got6[:, 0], want, f"cnn L14 variant 6 n={n}")
+    assert_scores(got10[:, 0], want, f"cnn L14 variant 10 n={n}")
     assert_scores(got4[:, 0], want, f"cnn L14 variant 4 n={n}")
 
 
@@ -241,6 +241,49 @@ def test_cnn_pair_segmented_small_batches(eng, L, n, M):
             eng.score(list(natives), bad, lut)
     finally:
         eng.set_option("cnn_pair_seg", -1)
+
+
+@pytest.mark.parametrize("L,n,M", [(237, 40, 3), (237, 1, 1), (237, 15, 3), (238, 16, 1), (90, 10, 3), (90, 33, 2), (100, 80, 3), (28, 5, 1),
+                                   (237, 17, 8), (150, 48, 5)])
+def test_cnn_layer_parallel_small_batches(eng, L, n, M):
+    """Round 4: small batches of the canonical protein CNN (a CMA-ES population of 15-40, a DyNA-PPO environment batch, one
+    sequence) LAYER-PARALLEL over the chip (`cnn_lp`, default on: conv1 + conv2 per position block, conv2 outputs through
+    device memory, one grid barrier, conv3 + pool per position block, head by the last block of a tile) instead of position
+    segments that recompute a 22-position halo each.  Per output element the pair kernel's MFMA sequence, so the SAME BITS as
+    the whole-sequence walk and as the segmented form; beside the float64 oracle; repeated launches (the barrier counter only
+    ever grows), a bad character in some block only, and batches too large for one wave of the grid keep the old forms."""
+    natives, ws = zip(*[make_native(eng, "cnn", L, 20, 100, 32, 5, seed=80 + m) for m in range(M)])
+    lut = _native.make_lut(s_utils.AAS)
+    b, seqs = rand_seqs(n, L, s_utils.AAS, seed=3 * L + n)
+    try:
+        eng.set_option("cnn_pair_seg", 0)
+        whole, _ = eng.score(list(natives), b, lut)
+        eng.set_option("cnn_pair_seg", -1)
+        eng.set_option("cnn_lp", 0)
+        seg, _ = eng.score(list(natives), b, lut)
+        eng.set_option("cnn_lp", 1)
+        assert np.array_equal(seg, whole)
+        for rep in range(4):
+            got, mean = eng.score(list(natives), b, lut, want_matrix=True, want_mean=True)
+            assert np.array_equal(got, whole), (L, n, M, rep)
+            assert np.array_equal(mean, np.mean(whole, axis=1))
+        for cut in (1, 16, 17, n - 1):                                    # batch invariance across forms
+            if 0 < cut < n:
+                part, _ = eng.score(list(natives), b[:cut], lut)
+                assert np.array_equal(part, whole[:cut]), cut
+        k = min(n, 48)
+        for m in range(M):
+            assert_scores(whole[:k, m], ref_np.keras_fitness(seqs[:k], s_utils.AAS, "cnn", ws[m], exact=True), f"lp L={L} member {m}")
+        for where in ((0, 0), (n // 2, L // 2), (n - 1, L - 1)):          # a bad character that only one position block reads
+            bad = b.copy()
+            bad[where] = ord("Z")
+            with pytest.raises(ValueError):
+                eng.score(list(natives), bad, lut)
+        again, _ = eng.score(list(natives), b, lut)
+        assert np.array_equal(again, whole)
+    finally:
+        eng.set_option("cnn_pair_seg", -1)
+        eng.set_option("cnn_lp", 1)
 
 
 @pytest.mark.parametrize("L,A,alpha,F,H,K", [(3, 4, "TGCA", 1, 1, 2), (9, 4, "TGCA", 8, 20, 4), (12, 2, "01", 16, 30, 3),
