@@ -148,7 +148,8 @@ static int check_deferred(fx_engine* e) {
         *reinterpret_cast<volatile unsigned*>(e->h_err) = 0;
         if (err & FX_ERR_TIMEOUT) {
             // (the barrier counter no longer matches what the host has added up: start over)
-            if (e->d_lp_bar) { (void)hipMemset(e->d_lp_bar, 0, 64); e->lp_bar_total = 0; }
+            if (e->d_lp_bar) { (void)hipMemset(e->d_lp_bar, 0, FX_LP_BAR_BYTES); for (unsigned& t : e->lp_bar_total) t = 0; }
+            if (e->d_zero_pool) (void)hipMemset(e->d_zero_pool, 0, e->zero_pool_bytes);   // (partial maxima / tickets may be left behind)
             return fx_fail(e, FX_ESTATE, "a device-side barrier of the layer-parallel CNN form timed out (workgroups not co-resident?): set the engine option cnn_lp = 0");
         }
         if (err & FX_ERR_BADCHAR) return fx_fail(e, FX_EBADCHAR, "substring not found: character outside the alphabet");
@@ -292,6 +293,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "dense_small")) return &e->dense_small;
     if (!std::strcmp(key, "cnn_quad")) return &e->cnn_quad;
     if (!std::strcmp(key, "cnn_lp")) return &e->cnn_lp;
+    if (!std::strcmp(key, "cnn_lp_debug")) return &e->cnn_lp_debug;
     if (!std::strcmp(key, "cnn_pair")) return &e->cnn_pair;
     if (!std::strcmp(key, "cnn_pair_seg")) return &e->cnn_pair_seg;
     if (!std::strcmp(key, "cnn_seg")) return &e->cnn_seg;

@@ -12,6 +12,7 @@
 
 #define FX_MAX_M 16          // models fused per launch (larger ensembles are split)
 #define FX_ERR_BADCHAR 1u    // bit in the deferred device error word
+#define FX_LP_BAR_BYTES (17 * 128)   // barrier counters of the layer-parallel protein form: top + 16 groups, a 128-byte line each
 #define FX_ERR_TIMEOUT 2u    // a device-side barrier (layer-parallel protein form) was not passed in time
 // The resident form (score_cnn_quad.hip / score_dense_small.hip, SERVER).  Round 3: <= 16 tile slots per member on a third
 // of the CUs, one tile per slot and request -> 256 sequences.  Round 4 (engine option serve_wide): a generation may take
@@ -158,8 +159,9 @@ struct fx_engine {
     int64_t trace = 0;          // 1 = the MFMA scoring kernels stamp an in-kernel timeline into d_trace (fx_debug_trace_read)
     unsigned long long* d_trace = nullptr;
     int64_t cnn_lp = 1;         // 1 = small batches of the canonical protein CNN (A = 20, kernel size 5, 97-112 hidden units) run LAYER-PARALLEL over the chip (conv2 outputs through device memory, one grid barrier) instead of position segments with recomputed halos (score_cnn_pair.hip k_score_cnn_lp); 0 = the SEG form: A/B
+    int64_t cnn_lp_debug = 0;   // profiling aid: the layer-parallel kernel leaves after stage k (1 fill, 2 phase 1, 3 conv3 fill, 4 barrier, 5 phase 2, 6 pool); results are garbage
     unsigned* d_lp_bar = nullptr;   // ... its barrier counter (only ever grows; lp_bar_total = what it reads after the launches enqueued so far)
-    unsigned lp_bar_total = 0;
+    unsigned lp_bar_total[17] = {};   // [0] top, [1 + g] group g
     bool lp_launched = false;
     int64_t cnn_quad = 1;       // 1 = small launches of the canonical 4-letter CNN with L <= 16 share a tile among four waves (score_cnn_quad.hip); 2 = whatever the size (test knob); 0 = off
     int64_t dma_fill = 1;       // 1 = weight images go global -> LDS directly (global_load_lds), all in flight at kernel start, the first layers start when THEIR part has landed (0 = through registers, whole image before the first tile: A/B)

@@ -199,6 +199,33 @@ __device__ __forceinline__ void fx_wait_vm(int n) {
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 }
+// ---- 16-byte stores / loads that are coherent across the XCDs WITHOUT fences (agent scope: `sc1`) ------------------------
+// Each XCD has its own L2; data one workgroup hands to workgroups on other XCDs inside a launch normally needs an agent-scope
+// release (a write-back of the XCD's whole L2) and an acquire (an invalidate) around the hand-off -- ~0.5 us each, and the
+// fences of one XCD serialise (profiles/r4_mailbox_probe3.log): 243 workgroups x 2 fences were 21 us of a 64 us launch.
+// An sc1 store writes through to memory and an sc1 load misses the non-coherent levels, so the hand-off needs only the
+// counter that orders it.  Inline assembly: the compiler has no 128-bit atomics, and it does not count these operations --
+// the caller waits with fx_wait_vm(0) before it signals (stores) / the loads wait themselves.
+__device__ __forceinline__ void fx_store16_agent(f4* p, f4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+// eight loads in flight, one wait
+__device__ __forceinline__ void fx_load16x8_agent(const f4* p0, const f4* p1, const f4* p2, const f4* p3, const f4* p4, const f4* p5,
+                                                  const f4* p6, const f4* p7, f4 (&v)[8]) {
+    asm volatile("global_load_dwordx4 %0, %8, off sc1\n\t"
+                 "global_load_dwordx4 %1, %9, off sc1\n\t"
+                 "global_load_dwordx4 %2, %10, off sc1\n\t"
+                 "global_load_dwordx4 %3, %11, off sc1\n\t"
+                 "global_load_dwordx4 %4, %12, off sc1\n\t"
+                 "global_load_dwordx4 %5, %13, off sc1\n\t"
+                 "global_load_dwordx4 %6, %14, off sc1\n\t"
+                 "global_load_dwordx4 %7, %15, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7)
+                 : "memory");
+}
+
 // Workgroup copy of n4 16-byte words (1 KiB chunks dealt round-robin to the `waves` waves); returns the number of
 // loads THIS wave issued (wave-uniform).  dst must be 16-byte aligned LDS, src 16-byte aligned global memory.
 __device__ __forceinline__ int fx_dma_fill(float* dst_lds, const float* __restrict__ src, int n4, int waves) {

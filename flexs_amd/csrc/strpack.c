@@ -30,11 +30,48 @@
 #define PAR_MIN_BYTES (192 << 10)      /* below this one thread is faster than waking the pool */
 
 typedef struct {
-    PyObject** items;
+    PyObject** items;                  /* pack job: the strings; NULL = an argmax job */
     unsigned char* dst;
     Py_ssize_t n, L;
     int status;                        /* first failure in this share (0 = none) */
+    const double* x;                   /* argmax job: n rows of L = A doubles each -> dst[row] = alphabet[argmax] */
+    const unsigned char* alphabet;
 } Share;
+
+/* `one_hot_to_string` (flexs/utils/sequence_utils.py:50-66) for rows of A doubles: dst[r] = alphabet[np.argmax(x[r])].
+ * NumPy's rule: the FIRST maximum wins; a NaN is a maximum (the first NaN wins).  Branch-free pass (strict >, so the first
+ * maximum stays), rows that hold a NaN are redone with the exact scalar rule. */
+static Py_ssize_t argmax_exact(const double* x, Py_ssize_t A) {   /* numpy: if (!(v <= best)) { best = v; idx = i; if (isnan(best)) break; } */
+    double best = x[0];
+    Py_ssize_t idx = 0;
+    if (best == best)
+        for (Py_ssize_t i = 1; i < A; ++i)
+            if (!(x[i] <= best)) { best = x[i]; idx = i; if (best != best) break; }
+    return idx;
+}
+static void argmax_rows(const double* x, Py_ssize_t rows, Py_ssize_t A, const unsigned char* alphabet, unsigned char* dst) {
+    Py_ssize_t r = 0;
+    /* four rows at a time: the (best, index) recurrence of one row is a chain of ~4-cycle selects; four independent chains
+     * keep the core busy (A = 20: 250 -> ~60 us for a population of 40 x 237 rows on one thread) */
+    for (; r + 4 <= rows; r += 4, x += 4 * A) {
+        const double *x0 = x, *x1 = x + A, *x2 = x + 2 * A, *x3 = x + 3 * A;
+        double b0 = x0[0], b1 = x1[0], b2 = x2[0], b3 = x3[0];
+        Py_ssize_t i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+        int nan = (b0 != b0) | (b1 != b1) | (b2 != b2) | (b3 != b3);
+        for (Py_ssize_t i = 1; i < A; ++i) {
+            const double v0 = x0[i], v1 = x1[i], v2 = x2[i], v3 = x3[i];
+            const int g0 = v0 > b0, g1 = v1 > b1, g2 = v2 > b2, g3 = v3 > b3;
+            nan |= (v0 != v0) | (v1 != v1) | (v2 != v2) | (v3 != v3);
+            i0 = g0 ? i : i0; b0 = g0 ? v0 : b0;
+            i1 = g1 ? i : i1; b1 = g1 ? v1 : b1;
+            i2 = g2 ? i : i2; b2 = g2 ? v2 : b2;
+            i3 = g3 ? i : i3; b3 = g3 ? v3 : b3;
+        }
+        if (nan) { i0 = argmax_exact(x0, A); i1 = argmax_exact(x1, A); i2 = argmax_exact(x2, A); i3 = argmax_exact(x3, A); }
+        dst[r] = alphabet[i0]; dst[r + 1] = alphabet[i1]; dst[r + 2] = alphabet[i2]; dst[r + 3] = alphabet[i3];
+    }
+    for (; r < rows; ++r, x += A) dst[r] = alphabet[argmax_exact(x, A)];
+}
 
 /* Pack items[0 .. n) -> dst; returns 0 / 1 / 2 / 3, or 4 for a legacy (not "ready") str that needs the GIL. */
 static int pack_range(PyObject** items, unsigned char* dst, Py_ssize_t n, Py_ssize_t L, int have_gil) {
@@ -85,7 +122,8 @@ static void* worker_main(void* arg) {
         seen = g_epoch;
         Share* sh = &g_share[id];
         pthread_mutex_unlock(&g_mu);
-        sh->status = pack_range(sh->items, sh->dst, sh->n, sh->L, 0);
+        if (sh->items) sh->status = pack_range(sh->items, sh->dst, sh->n, sh->L, 0);
+        else { argmax_rows(sh->x, sh->n, sh->L, sh->alphabet, sh->dst); sh->status = 0; }
         pthread_mutex_lock(&g_mu);
         if (--g_pending == 0) pthread_cond_signal(&g_done);
     }
@@ -114,14 +152,30 @@ static int want_threads(Py_ssize_t bytes) {
     return t < 1 ? 1 : t;
 }
 
+static int run_share(const Share* sh, Py_ssize_t first, Py_ssize_t count) {
+    if (sh->items) return pack_range(sh->items + first, sh->dst + first * sh->L, count, sh->L, 0);
+    argmax_rows(sh->x + first * sh->L, count, sh->L, sh->alphabet, sh->dst + first);
+    return 0;
+}
+
 /* n items -> dst with `threads` threads (the caller, which holds the GIL, is one of them; the helpers never touch the
  * interpreter: have_gil = 0 makes pack_range hand a legacy str back instead of calling into Python). */
+static int job_parallel(const Share* job, Py_ssize_t n, int threads);
 static int pack_parallel(PyObject** items, unsigned char* dst, Py_ssize_t n, Py_ssize_t L, int threads) {
+    Share job;
+    memset(&job, 0, sizeof job);
+    job.items = items; job.dst = dst; job.L = L;
+    return job_parallel(&job, n, threads);
+}
+static int job_parallel(const Share* job, Py_ssize_t n, int threads) {
+    PyObject** items = job->items;
+    unsigned char* dst = job->dst;
+    const Py_ssize_t L = job->L;
     const int helpers = threads - 1;
     pthread_mutex_lock(&g_mu);
     if (g_busy) {
         pthread_mutex_unlock(&g_mu);
-        return pack_range(items, dst, n, L, 0);
+        return run_share(job, 0, n);
     }
     g_busy = 1;
     while (g_workers < helpers) {                                       /* grow the pool on demand */
@@ -139,10 +193,10 @@ static int pack_parallel(PyObject** items, unsigned char* dst, Py_ssize_t n, Py_
     Py_ssize_t at_row = per < n ? per : n;                              /* the caller takes rows [0, per) */
     for (int w = 0; w < used; ++w) {
         const Py_ssize_t cnt = (at_row + per <= n) ? per : (n - at_row);
-        g_share[w].items = items + at_row;
-        g_share[w].dst = dst + at_row * L;
+        g_share[w] = *job;
+        if (items) { g_share[w].items = items + at_row; g_share[w].dst = dst + at_row * L; }
+        else { g_share[w].x = job->x + at_row * L; g_share[w].dst = dst + at_row; }
         g_share[w].n = cnt;
-        g_share[w].L = L;
         g_share[w].status = 0;
         at_row += cnt;
     }
@@ -152,7 +206,7 @@ static int pack_parallel(PyObject** items, unsigned char* dst, Py_ssize_t n, Py_
     if (used) pthread_cond_broadcast(&g_go);
     pthread_mutex_unlock(&g_mu);
 
-    int status = pack_range(items, dst, per < n ? per : n, L, 0);
+    int status = run_share(job, 0, per < n ? per : n);
 
     pthread_mutex_lock(&g_mu);
     while (g_pending > 0) pthread_cond_wait(&g_done, &g_mu);
@@ -239,6 +293,29 @@ static PyObject* score_small(PyObject* self, PyObject* args) {
     return PyLong_FromLong(status);
 }
 
+/* decode_argmax(x, rows, A, alphabet, out) -> 0: out[r] = alphabet[np.argmax(x[r * A : (r + 1) * A])] for a C-contiguous float64
+ * buffer -- the explorers' `_soln_to_string` / `one_hot_to_string` for a whole population on the HOST.  A population of 40
+ * 237-residue solutions is 1.5 MB of doubles: moving them to the GPU for the argmax kernel costs ~100 us of staging copies,
+ * several times the scoring launch; here the rows are split over the packing threads (~10 us), and only rows x 1 byte go on. */
+static PyObject* decode_argmax(PyObject* self, PyObject* args) {
+    Py_buffer x, alpha, out;
+    Py_ssize_t rows, A;
+    (void)self;
+    if (!PyArg_ParseTuple(args, "y*nny*w*", &x, &rows, &A, &alpha, &out)) return NULL;
+    long status = 0;
+    if (rows < 0 || A < 1 || x.len < rows * A * (Py_ssize_t)sizeof(double) || alpha.len < A || out.len < rows) status = 1;
+    else if (rows > 0) {
+        Share job;
+        memset(&job, 0, sizeof job);
+        job.x = (const double*)x.buf; job.alphabet = (const unsigned char*)alpha.buf; job.dst = (unsigned char*)out.buf; job.L = A;
+        int threads = want_threads(rows * A * (Py_ssize_t)sizeof(double) / 4);      /* (~4 cycles per double: a thread per 24 KiB-equivalents) */
+        if (threads > 1) status = job_parallel(&job, rows, threads);
+        else argmax_rows(job.x, rows, A, job.alphabet, job.dst);
+    }
+    PyBuffer_Release(&x); PyBuffer_Release(&alpha); PyBuffer_Release(&out);
+    return PyLong_FromLong(status);
+}
+
 static PyObject* set_threads(PyObject* self, PyObject* args) {
     int n;
     if (!PyArg_ParseTuple(args, "i", &n)) return NULL;
@@ -252,6 +329,7 @@ static PyObject* set_threads(PyObject* self, PyObject* args) {
 static PyMethodDef methods[] = {
     {"pack", pack, METH_VARARGS, "pack(seqs, L, out[, start, count]) -> status (0 ok, 1 ragged, 2 non-latin-1 character, 3 not a str)"},
     {"score_small", score_small, METH_VARARGS, "score_small(plan, seqs, out) -> 0 ok, -1 not applicable, 1001..1003 packing status, FX error code (2000 + |code| if negative)"},
+    {"decode_argmax", decode_argmax, METH_VARARGS, "decode_argmax(x_float64, rows, A, alphabet_bytes, out_uint8) -> 0 ok, 1 bad arguments: out[r] = alphabet[argmax of row r] (NumPy's first-max / NaN rule)"},
     {"set_threads", set_threads, METH_VARARGS, "set_threads(n) -> previous setting; 0 = auto (min(8, cores / 2)), 1 = single-threaded"},
     {NULL, NULL, 0, NULL}};
 

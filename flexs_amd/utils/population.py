@@ -34,6 +34,26 @@ def _fused_members(model):
     return None
 
 
+# Where the argmax of `_soln_to_string` runs for host arrays.  True: on the host (csrc/strpack.c decode_argmax, the rows split
+# over the packing threads), and only P x L bytes go to the device -- a population of 40 237-residue solutions is 1.5 MB of
+# float64, and staging that for the K6 kernel costs more than the scoring launch.  False: fx_decode_score (K6 + scoring + mean
+# in one device round trip, the form of rounds 1-3; still what device-resident inputs use).  Same strings, same values.
+HOST_DECODE = True
+
+
+def _decode_host(x: np.ndarray, alphabet: str):
+    """(P, L, A) float64 -> (P, L) uint8 characters, or None when the C helper is not built."""
+    sp = _native._strpack
+    if sp is None or not hasattr(sp, "decode_argmax"):
+        return None
+    x = np.ascontiguousarray(x, np.float64)
+    P, L, A = x.shape
+    out = np.empty((P, L), np.uint8)
+    if sp.decode_argmax(x, P * L, A, alphabet.encode("latin-1"), out) != 0:
+        return None
+    return out
+
+
 class PopulationEvaluator:
     def __init__(self, model, alphabet: str, seq_len: int):
         self.model = model
@@ -52,7 +72,9 @@ class PopulationEvaluator:
         x = self._as_one_hot(solutions)
         if x.shape[0] == 0:
             return []
-        chars = _native.Engine.get(getattr(self.model, "_device", None)).argmax_decode(x, self.alphabet)
+        chars = _decode_host(x, self.alphabet) if HOST_DECODE else None
+        if chars is None:
+            chars = _native.Engine.get(getattr(self.model, "_device", None)).argmax_decode(x, self.alphabet)
         return [r.tobytes().decode("latin-1") for r in chars]
 
     def evaluate(self, solutions, known: Sequence[Dict[str, float]] = ()) -> Tuple[List[str], np.ndarray]:
@@ -70,8 +92,12 @@ class PopulationEvaluator:
         m0 = self._members[0]
         natives = [m.native() for m in self._members]
         single = len(natives) == 1 and self.model is m0
-        chars, nm, mean = m0._engine().decode_score(natives, x, self.alphabet, m0._lut, want_matrix=single,
-                                                    want_mean=not single)
+        chars = _decode_host(x, self.alphabet) if HOST_DECODE else None
+        if chars is not None:
+            nm, mean = m0._engine().score(natives, chars, m0._lut, want_matrix=single, want_mean=not single)
+        else:
+            chars, nm, mean = m0._engine().decode_score(natives, x, self.alphabet, m0._lut, want_matrix=single,
+                                                        want_mean=not single)
         scores = nm[:, 0] if single else mean
         seqs = [r.tobytes().decode("latin-1") for r in chars]
         fresh = 0

@@ -37,7 +37,13 @@ for L in (237, 90):
                 r[f"kernel N={n}"] = ms / 200 * 1e3
             for P in (15, 40):
                 x = rng.standard_normal((P, L * 20))
-                r[f"P={P} decode+score"] = med_us(lambda: ev.evaluate(x))
+                from flexs_amd.utils import population
+                for host in (True, False):
+                    population.HOST_DECODE = host
+                    r[f"P={P} decode+score" + (" (host argmax)" if host else " (device argmax)")] = med_us(lambda: ev.evaluate(x))
+                population.HOST_DECODE = True
+                xo = np.ascontiguousarray(x.reshape(P, L, 20)); out = np.empty((P, L), np.uint8)
+                r[f"P={P} host argmax alone"] = med_us(lambda: _native._strpack.decode_argmax(xo, P * L, 20, AAS.encode(), out))
             rows.append(r)
         eng.set_option("cnn_lp", 1)
         print(f"== {M} x CNN(32,100) L={L} A=20: us, layer-parallel / segmented", flush=True)
