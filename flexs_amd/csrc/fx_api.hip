@@ -321,6 +321,8 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "train_threads")) return &e->train_threads;
     if (!std::strcmp(key, "train_trace")) return &e->train_trace;
     if (!std::strcmp(key, "train_persistent")) return &e->train_persistent;
+    if (!std::strcmp(key, "train_canon")) return &e->train_canon;
+    if (!std::strcmp(key, "train_split")) return &e->train_split;
     if (!std::strcmp(key, "dense_waves")) return &e->dense_waves;
     if (!std::strcmp(key, "dense_few_waves_below")) return &e->dense_few_waves_below;
     return nullptr;
@@ -334,7 +336,7 @@ static bool ab_only_value(const fx_engine* e, const int64_t* s, int64_t value) {
     return false;
 #else
     if (s == &e->dense_pipe || s == &e->fuse_mean || s == &e->chunk_overlap || s == &e->cnn_conv1_mfma || s == &e->mlp_l1_mfma ||
-        s == &e->dense_few_waves_below)
+        s == &e->dense_few_waves_below || s == &e->train_split)
         return value != 0;
     if (s == &e->dense_waves) return value == 8;
     if (s == &e->cnn_pair) return value == 0;

@@ -51,9 +51,18 @@ __global__ void __launch_bounds__(FB_MAX_THREADS) k_train_fb(const FxtJob* __res
         }
         for (int i = (n4 << 2) + threadIdx.x; i < j.net.P; i += blockDim.x) wl[i] = j.w[i];
         // (published by the first fxt_sync of the step)
-        fxt_forward_backward<3, 3>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl);
+        const lds_f sp33 = j.split_off ? (lds_f)(fxt_smem + j.split_off) : (lds_f) nullptr;     // split-K scratch behind the weights
+        // canonical shapes: the same source with the dimensions as compile-time constants (train_core.h FxtDims)
+        switch (j.canon) {
+            case 1: fxt_forward_backward<3, 3, FxtDims<0, 4, 32, 100, 5, 8>>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33); break;
+            case 2: fxt_forward_backward<3, 3, FxtDims<1, 4, 0, 100, 0, 8>>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33); break;
+            case 3: fxt_forward_backward<3, 3, FxtDims<2, 20, 0, 100, 0, 8>>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33); break;
+            case 4: fxt_forward_backward<3, 3, FxtDims<0, 4, 32, 100, 5, 8, 8>>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33); break;    // TF-binding
+            case 5: fxt_forward_backward<3, 3, FxtDims<0, 4, 32, 100, 5, 8, 14>>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33); break;   // RNA L = 14
+            default: fxt_forward_backward<3, 3>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33);
+        }
     } else if (j.ws_in_lds) {
-        fxt_forward_backward<3, 1>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (glb_cf)j.w);
+        fxt_forward_backward<3, 1>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (glb_cf)j.w, j.split_off ? (lds_f)(fxt_smem + j.split_off) : (lds_f) nullptr);
     } else {
         fxt_forward_backward<1, 1>(j, wg, step, slice, ascii, lut, labels, (glb_f)(j.ws + (long long)slice * j.ws_slice), (glb_cf)j.w);
     }
@@ -136,9 +145,9 @@ __global__ void __launch_bounds__(FB_MAX_THREADS) k_train_fit(const FxtJob* __re
     for (int step = 0; step < j.total_steps; ++step) {
         if (j.w_in_lds) {
             stage_weights();                               // (published by the first fxt_sync of the step)
-            fxt_forward_backward<3, 3>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl);
+            fxt_forward_backward<3, 3>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, j.split_off ? (lds_f)(fxt_smem + j.split_off) : (lds_f) nullptr);
         } else if (j.ws_in_lds) {
-            fxt_forward_backward<3, 1>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (glb_cf)j.w);
+            fxt_forward_backward<3, 1>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (glb_cf)j.w, j.split_off ? (lds_f)(fxt_smem + j.split_off) : (lds_f) nullptr);
         } else {
             fxt_forward_backward<1, 1>(j, wg, step, slice, ascii, lut, labels, (glb_f)(j.ws + (long long)slice * j.ws_slice), (glb_cf)j.w);
         }
@@ -209,7 +218,21 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
         j.ws_slice = fxt_ws(j.net, j.R).total;
         j.ws_in_lds = e->train_lds >= 1 && (size_t)j.ws_slice * 4 <= FB_LDS_BUDGET;
         j.w_in_lds = j.ws_in_lds && e->train_lds >= 2 && ((size_t)j.ws_slice + (size_t)j.net.P) * 4 <= FB_LDS_BUDGET;
+        // split-K scratch (train_core.h fxt_gemm) behind the workspace (and the weights) when the LDS budget allows
+        j.split_off = 0;
+        if (j.ws_in_lds && e->train_split) {
+            const size_t used = (((size_t)j.ws_slice + (j.w_in_lds ? (size_t)j.net.P : 0)) + 3) & ~(size_t)3;
+            if ((used + FXT_SPLIT_FLOATS) * 4 <= FB_LDS_BUDGET) j.split_off = (int)used;
+        }
         if (j.ws_in_lds) lds_bytes = std::max(lds_bytes, ((size_t)j.ws_slice + (j.w_in_lds ? (size_t)j.net.P : 0)) * 4);
+        if (j.split_off) lds_bytes = std::max(lds_bytes, ((size_t)j.split_off + FXT_SPLIT_FLOATS) * 4);
+        // canonical shapes get the instantiation with compile-time dimensions (workspace + weights in LDS, 8 rows per slice)
+        j.canon = 0;
+        if (e->train_canon && j.w_in_lds && j.R == 8) {
+            if (u.kind == FX_CNN && u.A == 4 && u.F == 32 && u.H == 100 && u.K == 5) j.canon = L == 8 ? 4 : (L == 14 ? 5 : 1);
+            if (u.kind == FX_MLP && u.A == 4 && u.H == 100) j.canon = 2;
+            if (u.kind == FX_GE && u.A == 20 && u.H == 100) j.canon = 3;
+        }
         max_steps = std::max(max_steps, j.total_steps);
         max_S = std::max(max_S, j.S);
         max_P = std::max(max_P, j.net.P);

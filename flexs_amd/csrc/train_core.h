@@ -141,6 +141,8 @@ struct FxtJob {
     float* ws; long long ws_slice;   // workspace, floats per slice
     int ws_in_lds;              // 1 = the slice's workspace fits the workgroup's LDS and lives there
     int w_in_lds;               // 1 = ... and the member's weights fit next to it (staged at kernel start)
+    int split_off;              // > 0: offset (floats) of the split-K scratch in the workgroup's LDS, 0 = products are not cut along the contraction
+    int canon;                  // > 0: a canonical shape with its own compile-time instantiation (train.hip), 0 = the shape-agnostic code
     float* step_loss;           // [total_steps] mean squared error of the step's valid rows (before the update)
     unsigned long long* dbg;    // profiling aid (engine option "train_trace"): phase timestamps of workgroup (0, 0), else nullptr
 };
@@ -160,6 +162,23 @@ struct FxtWg { int tid, nthr; };
 FXT_HD void fxt_sync() {
 #if FXT_DEVICE
     __syncthreads();
+#endif
+}
+// Barrier between two phases of fxt_forward_backward.  When the slice's workspace lives in LDS (WSAS = 3) everything one phase
+// hands to the next is in LDS, and what a phase writes to GLOBAL memory -- its gradient partials -- is read by the next LAUNCH
+// only: the barrier then orders the LDS traffic alone (release / acquire fences restricted to the local address space), and the
+// partial stores of six backward phases drain behind the following phases instead of being waited for (~1 us of L2 round trip)
+// at each of them, which is what a full __syncthreads() -- a workgroup fence over every address space -- costs.
+template <int WSAS>
+FXT_HD void fxt_sync_ws() {
+#if FXT_DEVICE
+    if constexpr (WSAS == 3) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    } else {
+        __syncthreads();
+    }
 #endif
 }
 // phase stamp k of workgroup (0, 0): the 100 MHz wall clock after the phase's barrier
@@ -184,16 +203,69 @@ FXT_HD bool fxt_keep(const FxtJob& j, int step, int slot, int h) {
 // The contraction index is kept as a PAIR so that conv taps / batch rows never need a division in the inner loop;
 // each ko runs ceil(Ki / 4) k-steps (the overhang multiplies zeros).  FA: prep(m, kq) -> per-lane state (once per
 // tile), at(state, ko, k0) = A(m, ko, k0 + kq); FB: prep(n, kq), at(state, ko, k0) = B(ko, k0 + kq, n); FC: put(m, n, value).
-template <class FA, class FB, class FC>
-FXT_HD void fxt_gemm(const FxtWg& wg, int Md, int Nd, int Ko, int Ki, const FA& fa, const FB& fb, const FC& fc) {
+// `first_wave`: the wave that takes tile 0 (tiles go round-robin from there).  Two products of one phase -- the few long tiles of
+// an input gradient and the many short ones of a weight gradient -- are dealt as ONE sequence: the second call passes
+// fxt_tiles(first product) as its first_wave, so no wave gets a long tile on top of a full share of short ones.
+FXT_HD int fxt_tiles(int Md, int Nd) { return ((Md + 15) >> 4) * ((Nd + 15) >> 4); }
+// `split` (device, LDS scratch of FXT_SPLIT_FLOATS floats, or null): a product with FEW tiles and a LONG contraction -- conv2
+// forward: 4 tiles of 40 k-steps for 16 waves -- is cut along the contraction as well: the groups of eight k-steps of a tile are
+// dealt to up to four waves, the partial tiles meet in the scratch (one LDS-only barrier), and the first wave of a tile adds them
+// in split order and runs the epilogue.  How a product is cut depends on its shape and the workgroup size only
+// (fxt_split_ways), so every instantiation of this source -- shape-agnostic or canonical -- sums in the same order.
+// ALL waves of the workgroup must call fxt_gemm together when `split` is given (the barrier).
+#define FXT_SPLIT_FLOATS 4096
+FXT_HD int fxt_split_ways(int tiles, int Ko, int Ki, int nw) {
+    if (Ki < 32 || tiles * 2 > nw) return 1;
+    const int groups = Ko * ((Ki + 31) >> 5);
+    int ways = nw / tiles;
+    if (ways > 4) ways = 4;
+    if (ways > groups) ways = groups;
+    return ways < 1 ? 1 : ways;
+}
+// workgroup jobs of a product (tiles x the ways it is cut): what the NEXT product of the phase passes as its first_wave
+FXT_HD int fxt_jobs(int Md, int Nd, int Ko, int Ki, int nw, bool can_split) {
+    const int t = fxt_tiles(Md, Nd);
+#if defined(FX_AB)
+    return t * (can_split ? fxt_split_ways(t, Ko, Ki, nw) : 1);
+#else
+    (void)Ko; (void)Ki; (void)nw; (void)can_split;
+    return t;
+#endif
+}
+template <class FA, class FB, class FC, class SP = float*>
+FXT_HD void fxt_gemm(const FxtWg& wg, int Md, int Nd, int Ko, int Ki, const FA& fa, const FB& fb, const FC& fc, int first_wave = 0,
+                     SP split = nullptr) {
 #if FXT_DEVICE
     typedef float f4_t __attribute__((ext_vector_type(4)));
     constexpr int U = 8;                     // k-steps whose operand loads are in flight together
-    const int lane = wg.tid & 63, wave = wg.tid >> 6, nw = wg.nthr >> 6;
+    const int lane = wg.tid & 63, nw = wg.nthr >> 6;
+    const int wave = ((wg.tid >> 6) + nw - first_wave % nw) % nw;
     const int i = lane & 15, kq = lane >> 4;
     const int tn = (Nd + 15) >> 4, tiles = ((Md + 15) >> 4) * tn;
     const int T = Ko * ((Ki + 3) >> 2);      // k-steps of the whole contraction, (ko, k0) in row-major order
-    for (int t = wave; t < tiles; t += nw) {
+    // (measured: the cut LOSES -- 24.6 -> 33.1 us per forward+backward launch of the 3 x CNN step, every phase it touches
+    //  slower: the extra barrier and the partial tiles through LDS cost more than the idle waves were worth,
+    //  profiles/r4_train_split_ab.log -- so it is compiled into the A/B build only; elsewhere ways == 1 folds it all away)
+#if defined(FX_AB)
+    const int ways = split ? fxt_split_ways(tiles, Ko, Ki, nw) : 1;
+#else
+    constexpr int ways = 1;
+    (void)split;
+#endif
+    const int gpk = (Ki + 31) >> 5, groups = Ko * gpk;
+    auto epilogue = [&](int t, f4_t acc) {
+        const int m0 = (t / tn) << 4, n = ((t % tn) << 4) + i;
+        if (n < Nd) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mr = m0 + 4 * kq + r;
+                if (mr < Md) fc.put(mr, n, acc[r]);
+            }
+        }
+    };
+    for (int job = wave; job < tiles * ways; job += nw) {
+        const int t = ways > 1 ? job / ways : job, sp = ways > 1 ? job - t * ways : 0;
+        const int g_lo = groups * sp / ways, g_hi = groups * (sp + 1) / ways;      // this job's groups of eight k-steps (ways > 1)
         const int m0 = (t / tn) << 4, n0 = (t % tn) << 4;
         const int m = m0 + i, n = n0 + i;
         const bool mok = m < Md, nok = n < Nd;
@@ -212,13 +284,14 @@ FXT_HD void fxt_gemm(const FxtWg& wg, int Md, int Nd, int Ko, int Ki, const FA& 
             for (int ko = 0; ko < Ko; ++ko) {
                 int k0 = 0;
                 for (; k0 + 4 * U <= Ki; k0 += 4 * U) {
+                    if (ways > 1) { const int gi = ko * gpk + (k0 >> 5); if (gi < g_lo || gi >= g_hi) continue; }
                     float a[U], b[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) { a[u] = fa.at(sa, ko, k0 + 4 * u); b[u] = fb.at(sb, ko, k0 + 4 * u); }
 #pragma unroll
                     for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
                 }
-                if (k0 < Ki) {                               // the row's last, partial group
+                if (k0 < Ki && (ways == 1 || (ko * gpk + (k0 >> 5) >= g_lo && ko * gpk + (k0 >> 5) < g_hi))) {   // the row's last, partial group
                     float a[U], b[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
@@ -272,16 +345,29 @@ FXT_HD void fxt_gemm(const FxtWg& wg, int Md, int Nd, int Ko, int Ki, const FA& 
                     if (s + u < T) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
             }
         }
-        if (nok) {
+        if (ways > 1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int mr = m0 + 4 * kq + r;
-                if (mr < Md) fc.put(mr, n, acc[r]);
-            }
+            for (int r = 0; r < 4; ++r) split[(job * 64 + lane) * 4 + r] = acc[r];
+        } else {
+            epilogue(t, acc);
+        }
+    }
+    if (ways > 1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        for (int t = wave; t < tiles; t += nw) {
+            f4_t acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = split[((t * ways) * 64 + lane) * 4 + r];
+            for (int sp = 1; sp < ways; ++sp)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] += split[((t * ways + sp) * 64 + lane) * 4 + r];
+            epilogue(t, acc);
         }
     }
 #else
-    (void)wg;
+    (void)wg; (void)first_wave; (void)split;
     for (int m = 0; m < Md; ++m)
         for (int n = 0; n < Nd; ++n) {
             float acc = 0.f;
@@ -420,27 +506,42 @@ struct FxtDenseWGradA {
     FXT_HD float at(int st, int, int k0) const { const float v = in[st < 0 ? 0 : st + k0 * Kd]; return st < 0 ? 1.f : v; }
 };
 
+// Compile-time shape of a CANONICAL network (round 4).  The step is written for any shape the constructors accept: every
+// contraction chooses among three k-step walks at run time, masks its overhangs, and builds its addresses from run-time
+// dimensions -- 100 KiB of code per placement, executed once per launch, i.e. streamed through the 64 KiB instruction cache
+// every step, and ~30 non-MFMA instructions per MFMA (profiles/r3_train_pmc.md).  For the shapes the explorers' surrogates are
+// actually built with (CNN(32, 100, kernel 5) on 4 letters, MLP(100), GlobalEpistasis(100)) the same
+// source is instantiated with the dimensions as constants: dead walks and masks fold away, offsets become immediates.  Same
+// arithmetic in the same order: the SAME BITS as the generic instantiation (GPU test).
+struct FxtDimsAny { static constexpr bool fixed = false; static constexpr int kind = 0, A = 0, F = 0, H = 0, K = 0, R = 0, L = 0; };
+template <int KIND, int A_, int F_, int H_, int K_, int R_, int L_ = 0>     // L_ = 0: the sequence length stays a run-time value
+struct FxtDims { static constexpr bool fixed = true; static constexpr int kind = KIND, A = A_, F = F_, H = H_, K = K_, R = R_, L = L_; };
+
 // ---------------------------------------------------------------------------------------------------------------
 // Forward + backward of one slice.  `slice` rows [slice * R, slice * R + R) of the mini-batch `step`.
 // `ws`: the slice's workspace -- the workgroup's LDS on the device when it fits (activations are written by one phase
 // and read by the next: an LDS round trip instead of an L2 one; WSAS = 3), else its row of the global arena (WSAS = 1).
 // `W`: the member's weights, staged in LDS by the caller when they fit next to the workspace (WAS = 3), else j.w.
-template <int WSAS, int WAS>
+template <int WSAS, int WAS, class D = FxtDimsAny>
 FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int slice, const uint8_t* ascii,
                                  const uint8_t* lut, const float* labels, typename FxtMem<WSAS>::F ws,
-                                 typename FxtMem<WAS>::CF W) {
+                                 typename FxtMem<WAS>::CF W, typename FxtMem<WSAS>::F split = nullptr) {
     typedef typename FxtMem<WSAS>::F WsF;
     typedef typename FxtMem<WSAS>::CF WsCF;
     typedef typename FxtMem<WSAS>::I WsI;
     typedef typename FxtMem<WSAS>::CI WsCI;
     typedef typename FxtMem<WAS>::CF WCF;
-    const FxtNet& n = j.net;
-    const int R = j.R, L = n.L, A = n.A, F = n.F;
+    // (a canonical instantiation rebuilds the description from its constants -- only the sequence length is a run-time value --
+    //  so that everything derived from it below is a constant too)
+    const FxtNet n = D::fixed ? fxt_net(D::kind, D::L > 0 ? D::L : j.net.L, D::A, D::F, D::H, D::K) : j.net;
+    const int R = D::fixed ? D::R : j.R, L = n.L, A = n.A, F = n.F;
     const FxtWs w = fxt_ws(n, R);
     WsI codes = (WsI)(ws + w.codes);
     float* part = j.partial + (long long)slice * (n.P + 1);
     const int32_t* order = j.order + (long long)step * j.batch;
     const int slot0 = slice * R;
+    const int nwv = wg.nthr >> 6;
+    const bool can_split = split != nullptr;
     const int sidx = step % j.steps_per_epoch;
     const int nvalid = (j.n - sidx * j.batch) < j.batch ? (j.n - sidx * j.batch) : j.batch;
     FXT_STAMP(0);
@@ -460,7 +561,7 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         ws[w.ylab + r] = labels[valid ? order[slot] : 0];
         ws[w.yvalid + r] = valid ? 1.f : 0.f;
     }
-    fxt_sync(); FXT_STAMP(1);
+    fxt_sync_ws<WSAS>(); FXT_STAMP(1);
 
     WsCF feat = nullptr;            // input of the dense stack when it is not the one-hot
     if (n.kind == 0) {
@@ -473,19 +574,19 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
             for (int jj = 0; jj < K; ++jj) s += W[n.off_cw[0] + (jj * A + codes[r * L + t + jj]) * F + o];
             a1[i] = s > 0.f ? s : 0.f;
         }
-        fxt_sync(); FXT_STAMP(2);
+        fxt_sync_ws<WSAS>(); FXT_STAMP(2);
         {   // conv2 ('same', K taps)
             WCF b = W + n.off_cb[1];
             struct Put { WsF y; WCF b; int F; FXT_HD void put(int m, int nn, float v) const { v += b[nn]; y[m * F + nn] = v > 0.f ? v : 0.f; } };
-            fxt_gemm(wg, R * L1, F, K, F, FxtConvA<WsCF>{a1, L1, F, (K - 1) / 2, dL1}, FxtConvW<WCF>{W + n.off_cw[1], F, F}, Put{a2, b, F});
+            fxt_gemm(wg, R * L1, F, K, F, FxtConvA<WsCF>{a1, L1, F, (K - 1) / 2, dL1}, FxtConvW<WCF>{W + n.off_cw[1], F, F}, Put{a2, b, F}, 0, split);
         }
-        fxt_sync(); FXT_STAMP(3);
+        fxt_sync_ws<WSAS>(); FXT_STAMP(3);
         {   // conv3 ('same', A - 1 taps)
             WCF b = W + n.off_cb[2];
             struct Put { WsF y; WCF b; int F; FXT_HD void put(int m, int nn, float v) const { v += b[nn]; y[m * F + nn] = v > 0.f ? v : 0.f; } };
-            fxt_gemm(wg, R * L1, F, n.K3, F, FxtConvA<WsCF>{a2, L1, F, (n.K3 - 1) / 2, dL1}, FxtConvW<WCF>{W + n.off_cw[2], F, F}, Put{a3, b, F});
+            fxt_gemm(wg, R * L1, F, n.K3, F, FxtConvA<WsCF>{a2, L1, F, (n.K3 - 1) / 2, dL1}, FxtConvW<WCF>{W + n.off_cw[2], F, F}, Put{a3, b, F}, 0, split);
         }
-        fxt_sync(); FXT_STAMP(4);
+        fxt_sync_ws<WSAS>(); FXT_STAMP(4);
         WsF g = ws + w.g; WsF cnt = ws + w.cnt;
         FXT_FOR(i, R * F, wg) {             // GlobalMaxPooling1D + the number of positions that attain the maximum
             const int r = i / F, f = i - r * F;
@@ -495,7 +596,7 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
             for (int t = 0; t < L1; ++t) c += a3[(r * L1 + t) * F + f] == mx;
             g[i] = mx; cnt[i] = (float)c;
         }
-        fxt_sync(); FXT_STAMP(5);
+        fxt_sync_ws<WSAS>(); FXT_STAMP(5);
         feat = g;
     }
 
@@ -531,9 +632,9 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
                     y[m * Nd + nn] = v;
                 }
             };
-            fxt_gemm(wg, R, Nd, 1, Kd, FxtRowMajorA<WsCF>{in, Kd}, FxtRowMajorB<WCF>{Wl, Nd}, Put{out, bl, Nd, last, drop, &j, step, slot0, keep_scale});
+            fxt_gemm(wg, R, Nd, 1, Kd, FxtRowMajorA<WsCF>{in, Kd}, FxtRowMajorB<WCF>{Wl, Nd}, Put{out, bl, Nd, last, drop, &j, step, slot0, keep_scale}, 0, split);
         }
-        fxt_sync(); FXT_STAMP(20 + li);
+        fxt_sync_ws<WSAS>(); FXT_STAMP(20 + li);
     }
 
     // ---- loss: d(mean over valid rows of (pred - y)^2) / d pred
@@ -547,7 +648,7 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
             const float e = ws[w.yvalid + r] != 0.f ? pred[r] - ws[w.ylab + r] : 0.f;
             du[r] = 2.f * e / (float)nvalid;
         }
-        fxt_sync(); FXT_STAMP(7);
+        fxt_sync_ws<WSAS>(); FXT_STAMP(7);
         FXT_FOR(i, 1, wg) {                 // the slice's sum of squared errors (fixed order)
             float sse = 0.f;
             for (int r = 0; r < R; ++r) { const float e = du[r] * (float)nvalid * 0.5f; sse += e * e; }
@@ -573,19 +674,20 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
             fxt_gemm(wg, Kd + 1, Nd, 1, R, FxtOneHotWGradA<WsCI>{codes, L, A, Kd, 0, dA}, FxtRowMajorB<WsCF>{du, Nd}, putw);
         } else {
             WsCF in = li == 0 ? feat : ws + w.act[li - 1];
-            fxt_gemm(wg, Kd + 1, Nd, 1, R, FxtDenseWGradA<WsCF>{in, Kd}, FxtRowMajorB<WsCF>{du, Nd}, putw);
-            // gradient w.r.t. the layer's input; through the previous layer's ReLU (and Dropout: a dropped unit's
-            // stored output is 0, a kept one carries the 1 / (1 - rate) scale)
+            // gradient w.r.t. the layer's input FIRST (few tiles, Nd k-steps each); through the previous layer's ReLU (and
+            // Dropout: a dropped unit's stored output is 0, a kept one carries the 1 / (1 - rate) scale) ...
             if (li > 0) {
                 const bool dropped = (li - 1) == n.drop_layer;
                 struct PutX { WsF d; WsCF y; int Kd; float ks; FXT_HD void put(int m, int nn, float v) const { d[m * Kd + nn] = y[m * Kd + nn] > 0.f ? v * ks : 0.f; } };
-                fxt_gemm(wg, R, Kd, 1, Nd, FxtRowMajorA<WsCF>{du, Nd}, FxtTransB<WCF>{Wl, Nd}, PutX{ws + w.du[li - 1], in, Kd, dropped ? keep_scale : 1.f});
+                fxt_gemm(wg, R, Kd, 1, Nd, FxtRowMajorA<WsCF>{du, Nd}, FxtTransB<WCF>{Wl, Nd}, PutX{ws + w.du[li - 1], in, Kd, dropped ? keep_scale : 1.f}, 0, split);
             } else {
                 struct PutG { WsF d; int Kd; FXT_HD void put(int m, int nn, float v) const { d[m * Kd + nn] = v; } };
-                fxt_gemm(wg, R, Kd, 1, Nd, FxtRowMajorA<WsCF>{du, Nd}, FxtTransB<WCF>{Wl, Nd}, PutG{ws + w.dg, Kd});
+                fxt_gemm(wg, R, Kd, 1, Nd, FxtRowMajorA<WsCF>{du, Nd}, FxtTransB<WCF>{Wl, Nd}, PutG{ws + w.dg, Kd}, 0, split);
             }
+            // ... then the weight gradient (many tiles of R / 4 k-steps), dealt on from the wave behind the last long tile
+            fxt_gemm(wg, Kd + 1, Nd, 1, R, FxtDenseWGradA<WsCF>{in, Kd}, FxtRowMajorB<WsCF>{du, Nd}, putw, fxt_jobs(R, Kd, 1, Nd, nwv, can_split));
         }
-        fxt_sync(); FXT_STAMP(30 + li);
+        fxt_sync_ws<WSAS>(); FXT_STAMP(30 + li);
     }
 
     if (n.kind == 0) {
@@ -598,17 +700,17 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
             const float v = a3[i];
             dzA[i] = (v > 0.f && v == g[r * F + f]) ? dg[r * F + f] / cnt[r * F + f] : 0.f;
         }
-        fxt_sync(); FXT_STAMP(9);
+        fxt_sync_ws<WSAS>(); FXT_STAMP(9);
         struct PutW { float* gw; float* gb; int rows, F; FXT_HD void put(int m, int nn, float v) const { if (m < rows) gw[m * F + nn] = v; else gb[nn] = v; } };
         struct PutX { WsF d; WsCF y; int F; FXT_HD void put(int m, int nn, float v) const { d[m * F + nn] = y[m * F + nn] > 0.f ? v : 0.f; } };
-        // conv3
-        fxt_gemm(wg, K3 * F + 1, F, R, L1, FxtConvWGradA<WsCF>{a2, L1, F, (K3 - 1) / 2, K3 * F, dF}, FxtPosMajorB<WsCF>{dzA, L1, F}, PutW{part + n.off_cw[2], part + n.off_cb[2], K3 * F, F});
-        fxt_gemm(wg, R * L1, F, K3, F, FxtConvGradA<WsCF>{dzA, L1, F, (K3 - 1) / 2, dL1}, FxtConvGradW<WCF>{W + n.off_cw[2], F, F}, PutX{dzB, a2, F});
-        fxt_sync(); FXT_STAMP(10);
+        // conv3: input gradient (few tiles, K3 x F / 4 k-steps) first, the weight gradient dealt on behind it
+        fxt_gemm(wg, R * L1, F, K3, F, FxtConvGradA<WsCF>{dzA, L1, F, (K3 - 1) / 2, dL1}, FxtConvGradW<WCF>{W + n.off_cw[2], F, F}, PutX{dzB, a2, F}, 0, split);
+        fxt_gemm(wg, K3 * F + 1, F, R, L1, FxtConvWGradA<WsCF>{a2, L1, F, (K3 - 1) / 2, K3 * F, dF}, FxtPosMajorB<WsCF>{dzA, L1, F}, PutW{part + n.off_cw[2], part + n.off_cb[2], K3 * F, F}, fxt_jobs(R * L1, F, K3, F, nwv, can_split));
+        fxt_sync_ws<WSAS>(); FXT_STAMP(10);
         // conv2
-        fxt_gemm(wg, K * F + 1, F, R, L1, FxtConvWGradA<WsCF>{a1, L1, F, (K - 1) / 2, K * F, dF}, FxtPosMajorB<WsCF>{dzB, L1, F}, PutW{part + n.off_cw[1], part + n.off_cb[1], K * F, F});
-        fxt_gemm(wg, R * L1, F, K, F, FxtConvGradA<WsCF>{dzB, L1, F, (K - 1) / 2, dL1}, FxtConvGradW<WCF>{W + n.off_cw[1], F, F}, PutX{dzA, a1, F});
-        fxt_sync(); FXT_STAMP(11);
+        fxt_gemm(wg, R * L1, F, K, F, FxtConvGradA<WsCF>{dzB, L1, F, (K - 1) / 2, dL1}, FxtConvGradW<WCF>{W + n.off_cw[1], F, F}, PutX{dzA, a1, F}, 0, split);
+        fxt_gemm(wg, K * F + 1, F, R, L1, FxtConvWGradA<WsCF>{a1, L1, F, (K - 1) / 2, K * F, dF}, FxtPosMajorB<WsCF>{dzB, L1, F}, PutW{part + n.off_cw[1], part + n.off_cb[1], K * F, F}, fxt_jobs(R * L1, F, K, F, nwv, can_split));
+        fxt_sync_ws<WSAS>(); FXT_STAMP(11);
         // conv1 (one-hot input, 'valid')
         fxt_gemm(wg, K * A + 1, F, R, L1, FxtOneHotWGradA<WsCI>{codes, L, A, K * A, 1, dA}, FxtPosMajorB<WsCF>{dzA, L1, F}, PutW{part + n.off_cw[0], part + n.off_cb[0], K * A, F});
     }
@@ -620,16 +722,16 @@ FXT_HD void fxt_adam(const FxtJob& j, int step, int i) {
     const int P = j.net.P, S = j.S;
     const float* part = j.partial + i;
     float gsum = 0.f;
-    for (int s0 = 0; s0 < S; s0 += 8) {      // slice order; eight loads in flight (x + 0.f leaves x as it is)
-        float v[8];
+    for (int s0 = 0; s0 < S; s0 += 32) {     // slice order; 32 loads in flight -- one L2 round trip for the 32 slices of a 256-row batch -- (x + 0.f leaves x as it is)
+        float v[32];
 #if FXT_DEVICE
 #pragma unroll
 #endif
-        for (int u = 0; u < 8; ++u) v[u] = (s0 + u < S) ? part[(long long)(s0 + u) * (P + 1)] : 0.f;
+        for (int u = 0; u < 32; ++u) v[u] = (s0 + u < S) ? part[(long long)(s0 + u) * (P + 1)] : 0.f;
 #if FXT_DEVICE
 #pragma unroll
 #endif
-        for (int u = 0; u < 8; ++u) gsum += v[u];
+        for (int u = 0; u < 32; ++u) gsum += v[u];
     }
     const float b1 = (float)FXT_BETA_1, b2 = (float)FXT_BETA_2;
     const float m = b1 * j.adam_m[i] + (1.f - b1) * gsum;

@@ -333,3 +333,41 @@ def test_more_members_than_one_device_call_takes():
         solo.train(seqs, y, seed=5 + k)
         for wa, wb in zip(ens.models[k].model.get_weights(), solo.model.get_weights()):
             assert np.array_equal(wa, wb), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,L,alphabet,F,H,K,n,B,M", [("cnn", 8, "TGCA", 32, 100, 5, 1000, 256, 3), ("cnn", 14, "UGCA", 32, 100, 5, 300, 256, 1),
+                                                        ("mlp", 14, "UGCA", 0, 100, 0, 300, 256, 2), ("ge", 90, ref_np.AAS, 0, 100, 0, 300, 256, 8)])
+def test_canonical_shape_instantiations_equal_the_shape_agnostic_step(kind, L, alphabet, F, H, K, n, B, M):
+    """Round 4: the canonical surrogates (CNN(32, 100, kernel 5) on 4 letters, MLP(100), GlobalEpistasis(100) on 20 letters) train
+    through an instantiation of the SAME source with the dimensions as compile-time constants (`train_canon`, default on: dead
+    k-step walks and masks fold away, a quarter of the code) -- the arithmetic and its order are untouched, so weights, moments,
+    step count and losses are the SAME BITS as the shape-agnostic instantiation's, with the in-kernel dropout stream, several
+    members and a ragged last mini-batch."""
+    eng = _native.Engine.get(0)
+    A, epochs = len(alphabet), 2
+    lut = _native.make_lut(alphabet)
+    shapes = _shapes(kind, L, A, F, H, K)
+    _, b, _, y = _data(kind, L, alphabet, n, 31)
+    steps = (n + B - 1) // B
+    results = []
+    for canon in (1, 0):
+        eng.set_option("train_canon", canon)
+        try:
+            jobs = []
+            r2 = np.random.default_rng(9)
+            for mem in range(M):
+                order = np.full((epochs, steps * B), -1, np.int32)
+                for e in range(epochs):
+                    order[e, :n] = r2.permutation(n)
+                w = _flat(ref_np.synth_weights(shapes, 50 + mem))
+                jobs.append({"kind": KIND[kind], "L": L, "A": A, "F": F, "H": H, "K": K, "weights": w, "adam_m": np.zeros_like(w),
+                             "adam_v": np.zeros_like(w), "step": 0, "order": order, "epochs": epochs, "batch": B, "seed": 77 + mem})
+            res = _native.train_fit(eng, jobs, b, lut, y)
+            results.append([(j["weights"].copy(), j["adam_m"].copy(), j["adam_v"].copy(), t, np.asarray(loss).copy()) for j, (t, loss) in zip(jobs, res)])
+        finally:
+            eng.set_option("train_canon", 1)
+    for mem, (a, c) in enumerate(zip(*results)):
+        assert a[3] == c[3] == epochs * steps
+        for what, x, z in zip(("weights", "adam_m", "adam_v", "losses"), (a[0], a[1], a[2], a[4]), (c[0], c[1], c[2], c[4])):
+            assert np.array_equal(x, z), (kind, mem, what, float(np.abs(x - z).max()))
