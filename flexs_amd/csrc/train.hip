@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "fx_common.h"
+#include "mfma_common.h"
 #include "train_core.h"
 
 namespace {
@@ -91,14 +92,15 @@ struct FxtBar { unsigned count[64]; unsigned abort; };
 
 __device__ __forceinline__ bool fxt_member_barrier(FxtBar* bar, int m, unsigned target, int tid) {
     __shared__ int s_abort;
-    __syncthreads();                                       // every wave's stores have reached the L2 (vmcnt(0) before the barrier)
+    fx_wait_vm(0);                                         // this wave's write-through stores (partials / weights) have been performed
+    __syncthreads();
     if (tid == 0) {
-        __threadfence();                                   // release: this XCD's L2 writes back
+        // no fence: what the workgroups exchange is written through and read past the non-coherent cache levels (agent_io)
         __hip_atomic_fetch_add(&bar->count[m], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long t0 = wall_clock64();
         int ab = 0;
         while (__hip_atomic_load(&bar->count[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(1);
             if (__hip_atomic_load(&bar->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ab = 1; break; }
             if (wall_clock64() - t0 > 200000000ull) {      // 2 s at 100 MHz: somebody never arrived (not co-resident?)
                 __hip_atomic_store(&bar->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -106,7 +108,6 @@ __device__ __forceinline__ bool fxt_member_barrier(FxtBar* bar, int m, unsigned 
                 break;
             }
         }
-        __threadfence();                                   // acquire: what the others published is read past this L2's stale lines
         s_abort = ab;
     }
     __syncthreads();
@@ -128,24 +129,34 @@ __global__ void __launch_bounds__(FB_MAX_THREADS) k_train_fit(const FxtJob* __re
     const int p_lo = (int)((long long)P * slice / j.S), p_hi = (int)((long long)P * (slice + 1) / j.S);
     float* wl = fxt_smem + j.ws_slice;
     auto stage_weights = [&]() {
-        typedef float v4f __attribute__((ext_vector_type(4)));
+        // the member's weights, as the workgroups that own their shares wrote them through: read past the non-coherent levels,
+        // eight 16-byte loads in flight per thread
         const int n4 = P >> 2;
-        const v4f* src = reinterpret_cast<const v4f*>(j.w);
-        v4f* dst = reinterpret_cast<v4f*>(wl);
-        for (int i0 = threadIdx.x; i0 < n4; i0 += 12 * blockDim.x) {
-            v4f v[12];
+        const f4* src = reinterpret_cast<const f4*>(j.w);
+        f4* dst = reinterpret_cast<f4*>(wl);
+        const int bd = (int)blockDim.x;
+        for (int i0 = threadIdx.x; i0 < n4; i0 += 8 * bd) {
+            f4 v[8];
+            auto at = [&](int k) { const int i = i0 + k * bd; return src + (i < n4 ? i : n4 - 1); };
+            fx_load16x8_agent(at(0), at(1), at(2), at(3), at(4), at(5), at(6), at(7), v);
 #pragma unroll
-            for (int k = 0; k < 12; ++k) { const int i = i0 + k * (int)blockDim.x; v[k] = src[i < n4 ? i : n4 - 1]; }
-#pragma unroll
-            for (int k = 0; k < 12; ++k) { const int i = i0 + k * (int)blockDim.x; if (i < n4) dst[i] = v[k]; }
+            for (int k = 0; k < 8; ++k) { const int i = i0 + k * bd; if (i < n4) dst[i] = v[k]; }
         }
-        for (int i = (n4 << 2) + threadIdx.x; i < P; i += blockDim.x) wl[i] = j.w[i];
+        for (int i = (n4 << 2) + threadIdx.x; i < P; i += blockDim.x) wl[i] = __hip_atomic_load(&j.w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     unsigned phase = 0;
     for (int step = 0; step < j.total_steps; ++step) {
         if (j.w_in_lds) {
             stage_weights();                               // (published by the first fxt_sync of the step)
-            fxt_forward_backward<3, 3>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, j.split_off ? (lds_f)(fxt_smem + j.split_off) : (lds_f) nullptr);
+            const lds_f sp33 = j.split_off ? (lds_f)(fxt_smem + j.split_off) : (lds_f) nullptr;
+            switch (j.canon) {                             // (the instantiations of k_train_fb: same bits)
+                case 1: fxt_forward_backward<3, 3, FxtDims<0, 4, 32, 100, 5, 8>>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33); break;
+                case 2: fxt_forward_backward<3, 3, FxtDims<1, 4, 0, 100, 0, 8>>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33); break;
+                case 3: fxt_forward_backward<3, 3, FxtDims<2, 20, 0, 100, 0, 8>>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33); break;
+                case 4: fxt_forward_backward<3, 3, FxtDims<0, 4, 32, 100, 5, 8, 8>>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33); break;
+                case 5: fxt_forward_backward<3, 3, FxtDims<0, 4, 32, 100, 5, 8, 14>>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33); break;
+                default: fxt_forward_backward<3, 3>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33);
+            }
         } else if (j.ws_in_lds) {
             fxt_forward_backward<3, 1>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (glb_cf)j.w, j.split_off ? (lds_f)(fxt_smem + j.split_off) : (lds_f) nullptr);
         } else {
@@ -313,20 +324,9 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
         FX_HIP(e, hipMemsetAsync(e->d_train_dbg, 0, 64 * sizeof(unsigned long long), st));
         hj[0].dbg = e->d_train_dbg;
     }
-    FX_HIP(e, hipMemcpyAsync(d_jobs, hj.data(), sizeof(FxtJob) * (size_t)M, hipMemcpyHostToDevice, st));
-    // (the pageable host sources above -- hj, lr -- are staged by the runtime before hipMemcpyAsync returns)
-
-    const dim3 grid_fb((unsigned)max_S, (unsigned)M), grid_adam((unsigned)((max_P + 255) / 256), (unsigned)M);
-    if (lds_bytes > 48 * 1024) {
-        static bool attr_set[64] = {};
-        if (!attr_set[e->device & 63]) {
-            FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_fb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS_BUDGET));
-            attr_set[e->device & 63] = true;
-        }
-    }
+    // one launch for the whole fit when every workgroup finds a CU at once (the step barriers need them co-resident)
     int threads = (int)e->train_threads;
     threads = threads >= 1024 ? 1024 : (threads >= 512 ? 512 : (threads >= 256 ? 256 : 1024));
-    // one launch for the whole fit when every workgroup finds a CU at once (the step barriers need them co-resident)
     bool persistent = e->train_persistent != 0 && M <= 64 && !e->train_trace;
     if (persistent) {
         if (lds_bytes > 48 * 1024) {
@@ -343,6 +343,18 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
         }
         // (a margin of a few CUs: a kernel of another stream or process may hold one for a while)
         persistent = per_cu >= 1 && (int64_t)max_S * M <= (int64_t)per_cu * (e->num_cus - 8);
+    }
+    for (FxtJob& j : hj) j.agent_io = persistent ? 1 : 0;
+    FX_HIP(e, hipMemcpyAsync(d_jobs, hj.data(), sizeof(FxtJob) * (size_t)M, hipMemcpyHostToDevice, st));
+    // (the pageable host sources above -- hj, lr -- are staged by the runtime before hipMemcpyAsync returns)
+
+    const dim3 grid_fb((unsigned)max_S, (unsigned)M), grid_adam((unsigned)((max_P + 255) / 256), (unsigned)M);
+    if (lds_bytes > 48 * 1024) {
+        static bool attr_set[64] = {};
+        if (!attr_set[e->device & 63]) {
+            FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_fb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS_BUDGET));
+            attr_set[e->device & 63] = true;
+        }
     }
     if (persistent) {
         FX_HIP(e, hipMemsetAsync(d_bar, 0, sizeof(FxtBar), st));

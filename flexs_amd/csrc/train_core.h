@@ -141,11 +141,28 @@ struct FxtJob {
     float* ws; long long ws_slice;   // workspace, floats per slice
     int ws_in_lds;              // 1 = the slice's workspace fits the workgroup's LDS and lives there
     int w_in_lds;               // 1 = ... and the member's weights fit next to it (staged at kernel start)
+    int agent_io;               // 1 = gradient partials and updated weights are written through / read past the non-coherent cache levels (the one-launch fit: workgroups exchange them inside a launch)
     int split_off;              // > 0: offset (floats) of the split-K scratch in the workgroup's LDS, 0 = products are not cut along the contraction
     int canon;                  // > 0: a canonical shape with its own compile-time instantiation (train.hip), 0 = the shape-agnostic code
     float* step_loss;           // [total_steps] mean squared error of the step's valid rows (before the update)
     unsigned long long* dbg;    // profiling aid (engine option "train_trace"): phase timestamps of workgroup (0, 0), else nullptr
 };
+
+// Stores / loads that are coherent across the XCDs without fences (agent scope, `sc1`): what the one-launch fit hands from
+// workgroup to workgroup -- gradient partials, updated weights -- inside a launch (see mfma_common.h fx_store16_agent for the
+// why: a release / acquire pair is a write-back + invalidate of the XCD's whole L2, ~0.5 us, serialised per XCD).
+#if FXT_DEVICE
+__device__ __forceinline__ void fxt_store_agent(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void fxt_load8_agent(const float* p, long long stride, float (&v)[8]) {   // v[k] = p[k * stride], eight in flight
+    asm volatile("global_load_dword %0, %8, off sc1\n\tglobal_load_dword %1, %9, off sc1\n\tglobal_load_dword %2, %10, off sc1\n\t"
+                 "global_load_dword %3, %11, off sc1\n\tglobal_load_dword %4, %12, off sc1\n\tglobal_load_dword %5, %13, off sc1\n\t"
+                 "global_load_dword %6, %14, off sc1\n\tglobal_load_dword %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(p), "v"(p + stride), "v"(p + 2 * stride), "v"(p + 3 * stride), "v"(p + 4 * stride), "v"(p + 5 * stride),
+                   "v"(p + 6 * stride), "v"(p + 7 * stride)
+                 : "memory");
+}
+#endif
 
 // q = x / d for 0 <= x < 2^16, 1 <= d < 2^16 without a hardware divide (an integer division is ~40 instructions on
 // the GPU and the GEMM tiles decompose their row index once each): q = (x * ceil(2^32 / d)) >> 32, exact in that range.
@@ -652,6 +669,9 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         FXT_FOR(i, 1, wg) {                 // the slice's sum of squared errors (fixed order)
             float sse = 0.f;
             for (int r = 0; r < R; ++r) { const float e = du[r] * (float)nvalid * 0.5f; sse += e * e; }
+#if FXT_DEVICE
+            if (j.agent_io) fxt_store_agent(&part[n.P], sse); else
+#endif
             part[n.P] = sse;
         }
     }
@@ -666,8 +686,17 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         const int Kd = n.dim[li], Nd = n.dim[li + 1];
         WCF Wl = W + n.off_w[li];
         WsCF du = ws + w.du[li];
-        struct PutW { float* gw; float* gb; int Kd, Nd; FXT_HD void put(int m, int nn, float v) const { if (m < Kd) gw[m * Nd + nn] = v; else gb[nn] = v; } };
-        const PutW putw{part + n.off_w[li], part + n.off_b[li], Kd, Nd};
+        struct PutW {
+            float* gw; float* gb; int Kd, Nd; bool agent;
+            FXT_HD void put(int m, int nn, float v) const {
+                float* p = m < Kd ? gw + m * Nd + nn : gb + nn;
+#if FXT_DEVICE
+                if (agent) { fxt_store_agent(p, v); return; }
+#endif
+                *p = v;
+            }
+        };
+        const PutW putw{part + n.off_w[li], part + n.off_b[li], Kd, Nd, j.agent_io != 0};
         if (li == 0 && n.onehot_in) {
             // (one thread per output element -- 8 FMAs each, no per-tile bookkeeping -- was measured SLOWER than the 49
             // two-k-step MFMA tiles here: 7.4 vs 6.1 us for the 100 x 100 layer, profiles/r3_train_trace.log)
@@ -701,18 +730,28 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
             dzA[i] = (v > 0.f && v == g[r * F + f]) ? dg[r * F + f] / cnt[r * F + f] : 0.f;
         }
         fxt_sync_ws<WSAS>(); FXT_STAMP(9);
-        struct PutW { float* gw; float* gb; int rows, F; FXT_HD void put(int m, int nn, float v) const { if (m < rows) gw[m * F + nn] = v; else gb[nn] = v; } };
+        struct PutW {
+            float* gw; float* gb; int rows, F; bool agent;
+            FXT_HD void put(int m, int nn, float v) const {
+                float* p = m < rows ? gw + m * F + nn : gb + nn;
+#if FXT_DEVICE
+                if (agent) { fxt_store_agent(p, v); return; }
+#endif
+                *p = v;
+            }
+        };
+        const bool ag = j.agent_io != 0;
         struct PutX { WsF d; WsCF y; int F; FXT_HD void put(int m, int nn, float v) const { d[m * F + nn] = y[m * F + nn] > 0.f ? v : 0.f; } };
         // conv3: input gradient (few tiles, K3 x F / 4 k-steps) first, the weight gradient dealt on behind it
         fxt_gemm(wg, R * L1, F, K3, F, FxtConvGradA<WsCF>{dzA, L1, F, (K3 - 1) / 2, dL1}, FxtConvGradW<WCF>{W + n.off_cw[2], F, F}, PutX{dzB, a2, F}, 0, split);
-        fxt_gemm(wg, K3 * F + 1, F, R, L1, FxtConvWGradA<WsCF>{a2, L1, F, (K3 - 1) / 2, K3 * F, dF}, FxtPosMajorB<WsCF>{dzA, L1, F}, PutW{part + n.off_cw[2], part + n.off_cb[2], K3 * F, F}, fxt_jobs(R * L1, F, K3, F, nwv, can_split));
+        fxt_gemm(wg, K3 * F + 1, F, R, L1, FxtConvWGradA<WsCF>{a2, L1, F, (K3 - 1) / 2, K3 * F, dF}, FxtPosMajorB<WsCF>{dzA, L1, F}, PutW{part + n.off_cw[2], part + n.off_cb[2], K3 * F, F, ag}, fxt_jobs(R * L1, F, K3, F, nwv, can_split));
         fxt_sync_ws<WSAS>(); FXT_STAMP(10);
         // conv2
         fxt_gemm(wg, R * L1, F, K, F, FxtConvGradA<WsCF>{dzB, L1, F, (K - 1) / 2, dL1}, FxtConvGradW<WCF>{W + n.off_cw[1], F, F}, PutX{dzA, a1, F}, 0, split);
-        fxt_gemm(wg, K * F + 1, F, R, L1, FxtConvWGradA<WsCF>{a1, L1, F, (K - 1) / 2, K * F, dF}, FxtPosMajorB<WsCF>{dzB, L1, F}, PutW{part + n.off_cw[1], part + n.off_cb[1], K * F, F}, fxt_jobs(R * L1, F, K, F, nwv, can_split));
+        fxt_gemm(wg, K * F + 1, F, R, L1, FxtConvWGradA<WsCF>{a1, L1, F, (K - 1) / 2, K * F, dF}, FxtPosMajorB<WsCF>{dzB, L1, F}, PutW{part + n.off_cw[1], part + n.off_cb[1], K * F, F, ag}, fxt_jobs(R * L1, F, K, F, nwv, can_split));
         fxt_sync_ws<WSAS>(); FXT_STAMP(11);
         // conv1 (one-hot input, 'valid')
-        fxt_gemm(wg, K * A + 1, F, R, L1, FxtOneHotWGradA<WsCI>{codes, L, A, K * A, 1, dA}, FxtPosMajorB<WsCF>{dzA, L1, F}, PutW{part + n.off_cw[0], part + n.off_cb[0], K * A, F});
+        fxt_gemm(wg, K * A + 1, F, R, L1, FxtOneHotWGradA<WsCI>{codes, L, A, K * A, 1, dA}, FxtPosMajorB<WsCF>{dzA, L1, F}, PutW{part + n.off_cw[0], part + n.off_cb[0], K * A, F, ag});
     }
     FXT_STAMP(63);
 }
@@ -722,6 +761,31 @@ FXT_HD void fxt_adam(const FxtJob& j, int step, int i) {
     const int P = j.net.P, S = j.S;
     const float* part = j.partial + i;
     float gsum = 0.f;
+#if FXT_DEVICE
+    if (j.agent_io) {
+        // the one-launch fit: the partials were written through by the other workgroups of the member (fxt_store_agent) and are
+        // read past the non-coherent cache levels, eight at a time; the new weight is written through for the same reason.
+        // Same sum (slice order), same update: same bits.
+        for (int s0 = 0; s0 < S; s0 += 8) {
+            float v[8];
+            fxt_load8_agent(part + (long long)s0 * (P + 1), (s0 + 8 <= S) ? (long long)(P + 1) : 0ll, v);   // (a ragged tail re-reads its first slice: handled below)
+            if (s0 + 8 <= S) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) gsum += v[u];
+            } else {
+                for (int u = 0; s0 + u < S; ++u) gsum += __hip_atomic_load(part + (long long)(s0 + u) * (P + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        const float b1 = (float)FXT_BETA_1, b2 = (float)FXT_BETA_2;
+        const float m = b1 * j.adam_m[i] + (1.f - b1) * gsum;
+        const float v = b2 * j.adam_v[i] + (1.f - b2) * gsum * gsum;
+        j.adam_m[i] = m;
+        j.adam_v[i] = v;
+        const float w_old = __hip_atomic_load(&j.w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fxt_store_agent(&j.w[i], w_old - j.lr_t[step] * m / (sqrtf(v) + FXT_EPSILON));
+        return;
+    }
+#endif
     for (int s0 = 0; s0 < S; s0 += 32) {     // slice order; 32 loads in flight -- one L2 round trip for the 32 slices of a 256-row batch -- (x + 0.f leaves x as it is)
         float v[32];
 #if FXT_DEVICE
@@ -745,6 +809,11 @@ FXT_HD void fxt_step_loss(const FxtJob& j, int step) {
     const int sidx = step % j.steps_per_epoch;
     const int nvalid = (j.n - sidx * j.batch) < j.batch ? (j.n - sidx * j.batch) : j.batch;
     float sse = 0.f;
+#if FXT_DEVICE
+    if (j.agent_io) {
+        for (int s = 0; s < j.S; ++s) sse += __hip_atomic_load(&j.partial[(long long)s * (j.net.P + 1) + j.net.P], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else
+#endif
     for (int s = 0; s < j.S; ++s) sse += j.partial[(long long)s * (j.net.P + 1) + j.net.P];
     j.step_loss[step] = sse / (float)nvalid;
 }
