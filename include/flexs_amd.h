@@ -98,18 +98,41 @@ const char *fx_last_error(fx_engine *e);
  *                              round 3 fx_decode_score, fx_min_dist / fx_cache_min_dist, fx_nam_combine, fx_table_*.
  *   zero_copy_mode    -1       larger host calls: -1 = decide per call (fx_plan_host_call), 0 = always copy,
  *                              1 = always zero-copy.
- *   serve_small       1        1 = explorer-size fx_score calls (<= 256 sequences, <= 16 KiB of sequence bytes) of
- *                              canonical 4-letter CNNs (seq_len <= 16), MLPs and GlobalEpistasis models -- one model,
- *                              an ensemble, or a mix -- are answered by workgroups that STAY on the device between
- *                              calls (request and answer through mailboxes; no launch): 28 -> 11 us per call, same
- *                              bits.  They start when the same model list calls twice within serve_idle_us and occupy
- *                              members x ceil(cap / 16) <= num_cus / 3 CUs while resident; new weights, training, a
- *                              launch that fills the chip, or engine destruction tell them to leave.  Needs a large
- *                              BAR (the host stores the request into device memory); 0 = a launch per call.
+ *   serve_small       1        1 = explorer-size fx_score calls of canonical 4-letter CNNs (seq_len <= 16), MLPs and
+ *                              GlobalEpistasis models -- one model, an ensemble, or a mix -- are answered by workgroups
+ *                              that STAY on the device between calls (request and answer through mailboxes; no launch):
+ *                              28 -> 10 us per 20-sequence call, same bits.  They start when the same model list calls
+ *                              twice within serve_idle_us; new weights, training, ANY option change, a launch that fills
+ *                              the chip, or engine destruction tell them to leave.  Needs a large BAR (the host stores
+ *                              the request into device memory; verified once from /proc/self/maps + a read-back, never
+ *                              by faulting); 0 = a launch per call.
+ *   serve_wide        1        geometry of a resident generation.  1 = ADAPTIVE: narrow (<= 16 tile slots per member on a
+ *                              third of the CUs, <= 256 sequences per request: round 3's form) for callers that only ask
+ *                              for a few sequences; WIDE -- (num_cus - serve_reserve_cus) / members tile slots, a slot
+ *                              walking the tiles slot, slot + T, ... of a request: up to 4096 sequences / 64 KiB per
+ *                              request, 2001 8-mers in 26 us instead of 39 -- as soon as the caller asks for more than
+ *                              256 sequences twice within 2 ms (240 resident workgroups cost every explorer-size call
+ *                              ~1.2 us, hence not always).  2 = always wide, 0 = always narrow (A/B).
+ *   serve_reserve_cus 16       CUs a wide generation leaves without a resident workgroup.
+ *   serve_poll_sleep  8        s_sleep units between polls of the tile slots beyond the first few of a wide generation
+ *                              (they poll a copy of the request word on a line of its own).
+ *   serve_fence       0        1 = round 3's system fence after every tile's answers (A/B; the answers are system-scope
+ *                              stores, which write through by themselves).
  *   serve_idle_us     500      ... calls further apart than this are launched; the workgroups leave by themselves after
  *                              twice this long without a request.  A device-wide synchronize (hipDeviceSynchronize)
  *                              issued right after a small call waits for that.
- *   server_calls, server_starts, server_fallbacks, server_resident   (read) bookkeeping of the resident form.
+ *   server_calls, server_starts, server_fallbacks, server_resident, server_wide, server_slots   (read) bookkeeping of the
+ *                              resident form.
+ *   ab_build          (read)   1 = this library is the A/B build (`make -C flexs_amd/csrc ab`): the kernel forms that were
+ *                              measured and LOST are compiled in; the production library refuses the option values that
+ *                              select them (FX_EUNSUPPORTED).
+ *   cnn_lp            1        1 = small batches of the canonical protein CNN run layer-parallel over the chip (conv2
+ *                              outputs through device memory, one grid barrier) instead of position segments with
+ *                              recomputed halos: a 237-residue call 64 -> 24 us, same bits.  0 = the segmented form.
+ *   train_canon       1        fx_train_fit: canonical shapes run the step instantiated with compile-time dimensions
+ *                              (k_train_fb 47.8 -> 32.8 us, same bits); 0 = the shape-agnostic code for everything.
+ *   train_persistent  0        fx_train_fit: 1 = the whole fit as ONE launch (member barriers in device memory, Adam by the
+ *                              same workgroups; needs all workgroups co-resident).  Same bits, no faster: off.
  *   train_rows        0        fx_train_fit: mini-batch rows per forward+backward workgroup; 0 = automatic (depends on
  *                              the member's own shape and batch size only: a fit is bit-reproducible whatever it is
  *                              trained next to).
@@ -122,9 +145,9 @@ const char *fx_last_error(fx_engine *e);
  *   cnn_variant, cnn_big_units, cnn_pair, cnn_seg, cnn_seg_multi, cnn_pair_seg, cnn_pair_seg4, cnn_quad, quad_rotate   (CNN launch forms)
  *   dense_small, dense_slab, dense_waves, dense_few_waves_below, dense_pipe, dense_coop, mlp_pair, ge_bytetab   (MLP / GE forms)
  *   stage_bytes, stage_fill, dma_fill, wave_prio                                                             (staging / scheduling)
- *   cnn_conv1_mfma, mlp_l1_mfma     (one-hot first layers on MFMA instead of the LDS gather: NOT bit-identical, within
- *                                    the 1e-5 budget; the slower A/B baseline)
- *   chunk_overlap                   (chunked host call on two streams: measured slower, off)
+ * A/B build only (the production library answers FX_EUNSUPPORTED): cnn_conv1_mfma, mlp_l1_mfma (one-hot first layers on MFMA
+ * instead of the LDS gather), dense_pipe, fuse_mean, chunk_overlap, dense_waves = 8, dense_few_waves_below, cnn_pair = 0,
+ * cnn_variant 2 / 3 / 5 / 6, train_split -- each measured slower than the default.
  * What each does, its values and the measurement that decided it: flexs_amd/csrc/OPTIONS.md. */
 int fx_engine_set_option(fx_engine *e, const char *key, int64_t value);
 int fx_engine_get_option(fx_engine *e, const char *key, int64_t *value);

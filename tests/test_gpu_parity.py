@@ -2173,10 +2173,11 @@ def test_nam_fused_query_against_reference_traces_and_oracle(eng, golden_dir):
         # (a trace whose table holds negative values may hand batches back to the one-by-one path -- the reference then draws
         #  from the cache instead -- whenever a negative value becomes a neighbour; the others must stay on the fused path)
         assert counts[0] + counts[1] >= 8 and (tr["has_negative_values"] or counts[1] == 0), f"fused path not taken: {counts}"
-    # (2) the oracle on the same seed: TF-binding sized table (all 8-mers), CbAS pattern -- 20 calls x 100 sequences on a cache of 1000
+    # (2) the oracle on the same seed: TF-binding sized table (all 8-mers), CbAS pattern (calls of 60 sequences on a growing cache;
+    #     kept small: the oracle's neighbour search is a Python loop over the cache)
     L, alpha = 8, "TGCA"
     vals = np.random.default_rng(9).random(4 ** L)
-    pool = synth.bytes_to_strings(synth.random_sequence_bytes(3200, L, alpha, 41))
+    pool = synth.bytes_to_strings(synth.random_sequence_bytes(1200, L, alpha, 41))
     idx = lambda s: sum(alpha.index(c) << (2 * k) for k, c in enumerate(s))      # noqa: E731
 
     class HostTable(flexs_amd.Landscape):
@@ -2189,13 +2190,13 @@ def test_nam_fused_query_against_reference_traces_and_oracle(eng, golden_dir):
         np.random.seed(77)
         nam = bm.NoisyAbstractModel(land, 0.9) if fused else ref_np.NoisyAbstractModelOracle(land, 0.9)
         counts = _count_fused(nam) if fused else None
-        nam.train(pool[:1000], vals[[idx(s) for s in pool[:1000]]])
-        res = [nam.get_fitness(pool[1000 + 100 * c: 1100 + 100 * c]) for c in range(20)]
-        res.append(nam.get_fitness(pool[900:1300]))                 # cached
-        res.append(nam.get_fitness([pool[3100]]))                   # one query
+        nam.train(pool[:300], vals[[idx(s) for s in pool[:300]]])
+        res = [nam.get_fitness(pool[300 + 60 * c: 360 + 60 * c]) for c in range(10)]
+        res.append(nam.get_fitness(pool[250:500]))                  # cached
+        res.append(nam.get_fitness([pool[1100]]))                   # one query
         outs.append((np.concatenate(res), land.cost, nam.cost, list(nam.cache), float(np.random.random())))
         if fused:
-            assert counts[0] >= 21 and counts[1] == 0, counts
+            assert counts[0] >= 11 and counts[1] == 0, counts
     assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1:] == outs[1][1:]
 
 
