@@ -242,6 +242,7 @@ int fx_engine_destroy(fx_engine* e) {
     for (auto& p : e->d_scratch) if (p) (void)hipFree(p);
     if (e->d_zero_pool) (void)hipFree(e->d_zero_pool);
     if (e->d_train) (void)hipFree(e->d_train);
+    if (e->h_train) (void)hipHostFree(e->h_train);
     if (e->d_train_dbg) (void)hipFree(e->d_train_dbg);
     for (auto& p : e->h_pinned) if (p) (void)hipHostFree(p);
     if (e->h_err) (void)hipHostFree(e->h_err);

@@ -134,6 +134,8 @@ struct fx_engine {
     size_t scratch_bytes[5] = {0, 0, 0, 0, 0};
     void* d_train = nullptr;      // fx_train_fit arena (grown on demand, kept between fits)
     size_t train_bytes = 0;
+    void* h_train = nullptr;      // pinned host image of the arena's uploaded regions (train.hip)
+    size_t train_host_bytes = 0;
     void* d_zero_pool = nullptr;  // fx_zero_pool: all-zero between launches (the kernels that use it clean up after themselves)
     size_t zero_pool_bytes = 0;
     void* h_pinned[2] = {nullptr, nullptr};

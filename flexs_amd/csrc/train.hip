@@ -35,22 +35,24 @@ __global__ void __launch_bounds__(FB_MAX_THREADS) k_train_fb(const FxtJob* __res
     typedef FxtMem<1>::CF glb_cf;
     const FxtWg wg{(int)threadIdx.x, (int)blockDim.x};
     const int slice = (int)blockIdx.x;
+    FXT_STAMP(62);                          // kernel entry (before the weights are staged)
     if (j.w_in_lds) {
         // the member's whole parameter vector next to the slice's workspace: every operand of every layer then comes
         // from LDS through ds_read (see train_core.h "address spaces")
         float* wl = fxt_smem + j.ws_slice;
         typedef float v4f __attribute__((ext_vector_type(4)));
+        // (the image has padded conv-kernel rows -- train_core.h "Row strides": a 16-byte piece never straddles a row)
+        const FxtLay lay = fxt_lay(j.net, true);
         const int n4 = j.net.P >> 2;
         const v4f* src = reinterpret_cast<const v4f*>(j.w);
-        v4f* dst = reinterpret_cast<v4f*>(wl);
         for (int i0 = threadIdx.x; i0 < n4; i0 += 12 * blockDim.x) {      // 12 x 16 bytes in flight per thread: ~2 round trips for 100 KiB
             v4f v[12];
 #pragma unroll
             for (int k = 0; k < 12; ++k) { const int i = i0 + k * (int)blockDim.x; v[k] = src[i < n4 ? i : n4 - 1]; }   // (clamped: the loads stay unconditional, in registers)
 #pragma unroll
-            for (int k = 0; k < 12; ++k) { const int i = i0 + k * (int)blockDim.x; if (i < n4) dst[i] = v[k]; }
+            for (int k = 0; k < 12; ++k) { const int i = i0 + k * (int)blockDim.x; if (i < n4) *reinterpret_cast<v4f*>(wl + fxt_image_off(j.net, lay, 4 * i)) = v[k]; }
         }
-        for (int i = (n4 << 2) + threadIdx.x; i < j.net.P; i += blockDim.x) wl[i] = j.w[i];
+        for (int i = (n4 << 2) + threadIdx.x; i < j.net.P; i += blockDim.x) wl[fxt_image_off(j.net, lay, i)] = j.w[i];
         // (published by the first fxt_sync of the step)
         const lds_f sp33 = j.split_off ? (lds_f)(fxt_smem + j.split_off) : (lds_f) nullptr;     // split-K scratch behind the weights
         // canonical shapes: the same source with the dimensions as compile-time constants (train_core.h FxtDims)
@@ -133,16 +135,16 @@ __global__ void __launch_bounds__(FB_MAX_THREADS) k_train_fit(const FxtJob* __re
         // eight 16-byte loads in flight per thread
         const int n4 = P >> 2;
         const f4* src = reinterpret_cast<const f4*>(j.w);
-        f4* dst = reinterpret_cast<f4*>(wl);
+        const FxtLay lay = fxt_lay(j.net, true);           // (padded conv-kernel rows: train_core.h "Row strides")
         const int bd = (int)blockDim.x;
         for (int i0 = threadIdx.x; i0 < n4; i0 += 8 * bd) {
             f4 v[8];
             auto at = [&](int k) { const int i = i0 + k * bd; return src + (i < n4 ? i : n4 - 1); };
             fx_load16x8_agent(at(0), at(1), at(2), at(3), at(4), at(5), at(6), at(7), v);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { const int i = i0 + k * bd; if (i < n4) dst[i] = v[k]; }
+            for (int k = 0; k < 8; ++k) { const int i = i0 + k * bd; if (i < n4) *reinterpret_cast<f4*>(wl + fxt_image_off(j.net, lay, 4 * i)) = v[k]; }
         }
-        for (int i = (n4 << 2) + threadIdx.x; i < P; i += blockDim.x) wl[i] = __hip_atomic_load(&j.w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = (n4 << 2) + threadIdx.x; i < P; i += blockDim.x) wl[fxt_image_off(j.net, lay, i)] = __hip_atomic_load(&j.w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     unsigned phase = 0;
     for (int step = 0; step < j.total_steps; ++step) {
@@ -227,20 +229,27 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
         j.S = (u.batch + j.R - 1) / j.R;
         j.seed = u.seed;
         j.ws_slice = fxt_ws(j.net, j.R).total;
+        if (j.net.kind == 0 && (size_t)j.ws_slice * 4 > FB_LDS_BUDGET) {     // padded rows just too large for LDS: unpadded in LDS beats padded in global memory
+            FxtNet plain = j.net;
+            plain.ldx = plain.F;
+            const int total = fxt_ws(plain, j.R).total;
+            if ((size_t)total * 4 <= FB_LDS_BUDGET) { j.net = plain; j.ws_slice = total; }
+        }
         j.ws_in_lds = e->train_lds >= 1 && (size_t)j.ws_slice * 4 <= FB_LDS_BUDGET;
-        j.w_in_lds = j.ws_in_lds && e->train_lds >= 2 && ((size_t)j.ws_slice + (size_t)j.net.P) * 4 <= FB_LDS_BUDGET;
+        const size_t w_image = (size_t)fxt_lay(j.net, true).total;     // the weights' LDS image (padded conv-kernel rows)
+        j.w_in_lds = j.ws_in_lds && e->train_lds >= 2 && (j.net.F & 3) == 0 && ((size_t)j.ws_slice + w_image) * 4 <= FB_LDS_BUDGET;
         // split-K scratch (train_core.h fxt_gemm) behind the workspace (and the weights) when the LDS budget allows
         j.split_off = 0;
         if (j.ws_in_lds && e->train_split) {
-            const size_t used = (((size_t)j.ws_slice + (j.w_in_lds ? (size_t)j.net.P : 0)) + 3) & ~(size_t)3;
+            const size_t used = (((size_t)j.ws_slice + (j.w_in_lds ? w_image : 0)) + 3) & ~(size_t)3;
             if ((used + FXT_SPLIT_FLOATS) * 4 <= FB_LDS_BUDGET) j.split_off = (int)used;
         }
-        if (j.ws_in_lds) lds_bytes = std::max(lds_bytes, ((size_t)j.ws_slice + (j.w_in_lds ? (size_t)j.net.P : 0)) * 4);
+        if (j.ws_in_lds) lds_bytes = std::max(lds_bytes, ((size_t)j.ws_slice + (j.w_in_lds ? w_image : 0)) * 4);
         if (j.split_off) lds_bytes = std::max(lds_bytes, ((size_t)j.split_off + FXT_SPLIT_FLOATS) * 4);
         // canonical shapes get the instantiation with compile-time dimensions (workspace + weights in LDS, 8 rows per slice)
         j.canon = 0;
         if (e->train_canon && j.w_in_lds && j.R == 8) {
-            if (u.kind == FX_CNN && u.A == 4 && u.F == 32 && u.H == 100 && u.K == 5) j.canon = L == 8 ? 4 : (L == 14 ? 5 : 1);
+            if (u.kind == FX_CNN && u.A == 4 && u.F == 32 && u.H == 100 && u.K == 5 && j.net.ldx == fxt_ld_x(32)) j.canon = L == 8 ? 4 : (L == 14 ? 5 : 1);
             if (u.kind == FX_MLP && u.A == 4 && u.H == 100) j.canon = 2;
             if (u.kind == FX_GE && u.A == 20 && u.H == 100) j.canon = 3;
         }
@@ -258,17 +267,33 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
     if (max_steps == 0) return FX_OK;
     FX_HIP(e, hipSetDevice(e->device));
 
-    // ---- one device arena: job table, LUT, data, labels, and per member: weights, moments, partials, order, masks, lr, loss, workspace
-    size_t need = 0;
+    // ---- one device arena in three regions (round 4):
+    //   A  per member: weights, Adam moments, per-step losses          -- uploaded AND downloaded
+    //   B  job table, LUT, data, labels, per member: order, lr, masks   -- uploaded
+    //   C  step barrier, per member: gradient partials, workspace       -- device only
+    // A + B are filled in a pinned host image of the same layout and go up as ONE copy, A comes back as ONE copy: the 19 + 12
+    // pageable hipMemcpyAsync calls of a three-member fit (each staged by the runtime, the downloads each a host wait) were
+    // ~0.5 ms of a 4 ms Ensemble.train.
+    size_t need = 0, bytes_a = 0, bytes_ab = 0;
     auto plan = [&](Arena& a) {
-        a.take<FxtJob>((size_t)M); a.take<FxtBar>(1); a.take<uint8_t>(256); a.take<uint8_t>((size_t)n * L); a.take<float>((size_t)n);
         for (int m = 0; m < M; ++m) {
             const FxtJob& j = hj[(size_t)m];
             a.take<float>((size_t)j.net.P); a.take<float>((size_t)j.net.P); a.take<float>((size_t)j.net.P);
-            a.take<float>((size_t)j.S * (j.net.P + 1));
+            a.take<float>((size_t)j.total_steps);
+        }
+        a.take<char>(0); bytes_a = a.off;
+        a.take<FxtJob>((size_t)M); a.take<uint8_t>(256); a.take<uint8_t>((size_t)n * L); a.take<float>((size_t)n);
+        for (int m = 0; m < M; ++m) {
+            const FxtJob& j = hj[(size_t)m];
             a.take<int32_t>((size_t)j.total_steps * j.batch);
+            a.take<float>((size_t)j.total_steps);
             if (jobs[m].keep) a.take<uint8_t>((size_t)j.total_steps * j.batch * j.net.H);
-            a.take<float>((size_t)j.total_steps); a.take<float>((size_t)j.total_steps);
+        }
+        a.take<char>(0); bytes_ab = a.off;
+        a.take<FxtBar>(1);
+        for (int m = 0; m < M; ++m) {
+            const FxtJob& j = hj[(size_t)m];
+            a.take<float>((size_t)j.S * (j.net.P + 1));
             a.take<float>((size_t)j.S * (size_t)j.ws_slice);
         }
     };
@@ -283,38 +308,58 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
         if (hipMalloc(&e->d_train, cap) != hipSuccess) { (void)hipGetLastError(); return fx_fail(e, FX_ENOMEM, "hipMalloc of the training arena failed"); }
         e->train_bytes = cap;
     }
+    if (bytes_ab > e->train_host_bytes) {
+        if (e->h_train) {
+            FX_HIP(e, hipStreamSynchronize(e->stream));
+            FX_HIP(e, hipHostFree(e->h_train));
+            e->h_train = nullptr; e->train_host_bytes = 0;
+        }
+        const size_t cap = bytes_ab + bytes_ab / 4;
+        if (hipHostMalloc(&e->h_train, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return fx_fail(e, FX_ENOMEM, "hipHostMalloc of the training staging image failed"); }
+        e->train_host_bytes = cap;
+    }
     Arena a; a.base = (char*)e->d_train;
     hipStream_t st = e->stream;
-    FxtJob* d_jobs = a.take<FxtJob>((size_t)M);
-    FxtBar* d_bar = a.take<FxtBar>(1);
+    // the host image's address of a device address in A or B
+    auto image = [&](const void* d) { return (char*)e->h_train + ((const char*)d - (const char*)e->d_train); };
     unsigned h_abort = 0;
-    uint8_t* d_lut = a.take<uint8_t>(256);
-    uint8_t* d_ascii = a.take<uint8_t>((size_t)n * L);
-    float* d_labels = a.take<float>((size_t)n);
-    FX_HIP(e, hipMemcpyAsync(d_lut, lut, 256, hipMemcpyHostToDevice, st));
-    FX_HIP(e, hipMemcpyAsync(d_ascii, ascii, (size_t)n * L, hipMemcpyHostToDevice, st));
-    FX_HIP(e, hipMemcpyAsync(d_labels, labels, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, st));
-    for (int m = 0; m < M; ++m) {
+    for (int m = 0; m < M; ++m) {                                  // region A
         FxtJob& j = hj[(size_t)m];
         const size_t P = (size_t)j.net.P;
         j.w = a.take<float>(P); j.adam_m = a.take<float>(P); j.adam_v = a.take<float>(P);
-        j.partial = a.take<float>((size_t)j.S * (P + 1));
+        j.step_loss = a.take<float>((size_t)j.total_steps);
+        std::memcpy(image(j.w), jobs[m].weights, sizeof(float) * P);
+        std::memcpy(image(j.adam_m), jobs[m].adam_m, sizeof(float) * P);
+        std::memcpy(image(j.adam_v), jobs[m].adam_v, sizeof(float) * P);
+    }
+    a.take<char>(0);
+    FxtJob* d_jobs = a.take<FxtJob>((size_t)M);                    // region B
+    uint8_t* d_lut = a.take<uint8_t>(256);
+    uint8_t* d_ascii = a.take<uint8_t>((size_t)n * L);
+    float* d_labels = a.take<float>((size_t)n);
+    std::memcpy(image(d_lut), lut, 256);
+    std::memcpy(image(d_ascii), ascii, (size_t)n * L);
+    std::memcpy(image(d_labels), labels, sizeof(float) * (size_t)n);
+    for (int m = 0; m < M; ++m) {
+        FxtJob& j = hj[(size_t)m];
         int32_t* d_order = a.take<int32_t>((size_t)j.total_steps * j.batch);
         j.order = d_order;
-        uint8_t* d_keep = nullptr;
-        if (jobs[m].keep) { d_keep = a.take<uint8_t>((size_t)j.total_steps * j.batch * j.net.H); j.keep = d_keep; }
         float* d_lr = a.take<float>((size_t)j.total_steps);
         j.lr_t = d_lr;
-        j.step_loss = a.take<float>((size_t)j.total_steps);
-        j.ws = a.take<float>((size_t)j.S * (size_t)j.ws_slice);
-        FX_HIP(e, hipMemcpyAsync(j.w, jobs[m].weights, sizeof(float) * P, hipMemcpyHostToDevice, st));
-        FX_HIP(e, hipMemcpyAsync(j.adam_m, jobs[m].adam_m, sizeof(float) * P, hipMemcpyHostToDevice, st));
-        FX_HIP(e, hipMemcpyAsync(j.adam_v, jobs[m].adam_v, sizeof(float) * P, hipMemcpyHostToDevice, st));
-        if (j.total_steps > 0) {
-            FX_HIP(e, hipMemcpyAsync(d_order, jobs[m].order, sizeof(int32_t) * (size_t)j.total_steps * j.batch, hipMemcpyHostToDevice, st));
-            if (d_keep) FX_HIP(e, hipMemcpyAsync(d_keep, jobs[m].keep, (size_t)j.total_steps * j.batch * j.net.H, hipMemcpyHostToDevice, st));
-            FX_HIP(e, hipMemcpyAsync(d_lr, lr[(size_t)m].data(), sizeof(float) * (size_t)j.total_steps, hipMemcpyHostToDevice, st));
+        std::memcpy(image(d_order), jobs[m].order, sizeof(int32_t) * (size_t)j.total_steps * j.batch);
+        std::memcpy(image(d_lr), lr[(size_t)m].data(), sizeof(float) * (size_t)j.total_steps);
+        if (jobs[m].keep) {
+            uint8_t* d_keep = a.take<uint8_t>((size_t)j.total_steps * j.batch * j.net.H);
+            j.keep = d_keep;
+            std::memcpy(image(d_keep), jobs[m].keep, (size_t)j.total_steps * j.batch * j.net.H);
         }
+    }
+    a.take<char>(0);
+    FxtBar* d_bar = a.take<FxtBar>(1);                             // region C
+    for (int m = 0; m < M; ++m) {
+        FxtJob& j = hj[(size_t)m];
+        j.partial = a.take<float>((size_t)j.S * ((size_t)j.net.P + 1));
+        j.ws = a.take<float>((size_t)j.S * (size_t)j.ws_slice);
     }
     if (e->train_trace) {
         if (!e->d_train_dbg && hipMalloc(reinterpret_cast<void**>(&e->d_train_dbg), 64 * sizeof(unsigned long long)) != hipSuccess) {
@@ -345,8 +390,8 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
         persistent = per_cu >= 1 && (int64_t)max_S * M <= (int64_t)per_cu * (e->num_cus - 8);
     }
     for (FxtJob& j : hj) j.agent_io = persistent ? 1 : 0;
-    FX_HIP(e, hipMemcpyAsync(d_jobs, hj.data(), sizeof(FxtJob) * (size_t)M, hipMemcpyHostToDevice, st));
-    // (the pageable host sources above -- hj, lr -- are staged by the runtime before hipMemcpyAsync returns)
+    std::memcpy(image(d_jobs), hj.data(), sizeof(FxtJob) * (size_t)M);
+    FX_HIP(e, hipMemcpyAsync(e->d_train, e->h_train, bytes_ab, hipMemcpyHostToDevice, st));      // regions A + B, one copy
 
     const dim3 grid_fb((unsigned)max_S, (unsigned)M), grid_adam((unsigned)((max_P + 255) / 256), (unsigned)M);
     if (lds_bytes > 48 * 1024) {
@@ -368,19 +413,17 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
         }
         FX_HIP(e, hipGetLastError());
     }
-    for (int m = 0; m < M; ++m) {
-        const FxtJob& j = hj[(size_t)m];
-        const size_t P = (size_t)j.net.P;
-        FX_HIP(e, hipMemcpyAsync(jobs[m].weights, j.w, sizeof(float) * P, hipMemcpyDeviceToHost, st));
-        FX_HIP(e, hipMemcpyAsync(jobs[m].adam_m, j.adam_m, sizeof(float) * P, hipMemcpyDeviceToHost, st));
-        FX_HIP(e, hipMemcpyAsync(jobs[m].adam_v, j.adam_v, sizeof(float) * P, hipMemcpyDeviceToHost, st));
-        if (jobs[m].step_loss && j.total_steps > 0)
-            FX_HIP(e, hipMemcpyAsync(jobs[m].step_loss, j.step_loss, sizeof(float) * (size_t)j.total_steps, hipMemcpyDeviceToHost, st));
-    }
+    FX_HIP(e, hipMemcpyAsync(e->h_train, e->d_train, bytes_a, hipMemcpyDeviceToHost, st));         // region A, one copy
     FX_HIP(e, hipStreamSynchronize(st));
     if (h_abort) return fx_fail(e, FX_ESTATE, "fx_train_fit: a step barrier of the one-launch fit was not passed within 2 s (workgroups not co-resident?); "
                                               "set the engine option train_persistent = 0 for a launch per step");
     for (int m = 0; m < M; ++m) {
+        const FxtJob& j = hj[(size_t)m];
+        const size_t P = (size_t)j.net.P;
+        std::memcpy(jobs[m].weights, image(j.w), sizeof(float) * P);
+        std::memcpy(jobs[m].adam_m, image(j.adam_m), sizeof(float) * P);
+        std::memcpy(jobs[m].adam_v, image(j.adam_v), sizeof(float) * P);
+        if (jobs[m].step_loss && j.total_steps > 0) std::memcpy(jobs[m].step_loss, image(j.step_loss), sizeof(float) * (size_t)j.total_steps);
         jobs[m].step += hj[(size_t)m].total_steps;
         e->counters.train_steps += hj[(size_t)m].total_steps;
     }

@@ -47,6 +47,7 @@
 struct FxtNet {
     int kind, L, A, F, H, K;    // FX_CNN 0 / FX_MLP 1 / FX_GE 2
     int L1, K3;                 // CNN: conv output length L - K + 1, conv3 taps A - 1
+    int ldx;                    // CNN: row stride of the F-wide activation arrays of the workspace ("Row strides" below)
     int P;                      // parameter count
     int off_cw[3], off_cb[3];   // CNN: conv kernels (taps, Cin, Cout) and biases
     int nl;                     // dense layers
@@ -56,12 +57,24 @@ struct FxtNet {
     int drop_layer;             // index of the dense layer whose OUTPUT passes through Dropout (-1 = none)
 };
 
+// Row strides (round 4).  The MFMA operand fetches are ds_read_b32 -- 32 banks, lanes 0-31 one group (MI355X_MICROARCH.md
+// "LDS"): sixteen rows x two k-columns.  With a row stride of 32 floats the sixteen rows of an A operand -- conv activations
+// (F = 32 channels) -- or of a transposed-weight B operand sit on ONE bank: 16-way conflicts, 32 LDS cycles per fetch instead
+// of 2, times the waves sharing the CU's LDS; that, not the MFMAs, set the time of the conv phases.  Activation rows are
+// therefore F + 2 floats apart (stride / 2 odd: sixteen rows on sixteen distinct even banks, the second k-column on the odd
+// ones), and the conv kernels' rows in the LDS image of the weights F + 4 (16-byte rows for the staging copy; 2-way at most).
+// The pad columns are never read.  Global weights, gradients and Adam moments keep the Keras layout.  (A host that finds the
+// padded workspace just too large for LDS may set FxtNet::ldx back to F: the unpadded workspace in LDS beats the padded one
+// in global memory.)
+FXT_HD int fxt_ld_x(int F) { return (F & 3) == 0 ? F + 2 : F; }
+FXT_HD int fxt_ld_w(int F) { return (F & 7) == 0 ? F + 4 : F; }
+
 FXT_HD FxtNet fxt_net(int kind, int L, int A, int F, int H, int K) {
     FxtNet n{};
     n.kind = kind; n.L = L; n.A = A; n.F = F; n.H = H; n.K = K;
     int off = 0;
     if (kind == 0) {
-        n.L1 = L - K + 1; n.K3 = A - 1;
+        n.L1 = L - K + 1; n.K3 = A - 1; n.ldx = fxt_ld_x(F);
         const int taps[3] = {K, K, A - 1}, cin[3] = {A, F, F};
         for (int i = 0; i < 3; ++i) {
             n.off_cw[i] = off; off += taps[i] * cin[i] * F;
@@ -84,13 +97,59 @@ FXT_HD FxtNet fxt_net(int kind, int L, int A, int F, int H, int K) {
     return n;
 }
 
+// Where a member's parameters sit in the image the step reads them from: the Keras get_weights() order of FxtNet (global
+// memory: `padded` = false) or the LDS image with padded conv-kernel rows.
+struct FxtLay {
+    int cw[3], cb[3];
+    int w[FXT_MAX_LAYERS], b[FXT_MAX_LAYERS];
+    int ldw;                    // row stride of the conv kernels
+    int total;
+};
+FXT_HD FxtLay fxt_lay(const FxtNet& n, bool padded) {
+    FxtLay y{};
+    y.ldw = (padded && n.kind == 0) ? fxt_ld_w(n.F) : n.F;
+    int off = 0;
+    if (n.kind == 0) {
+        const int rows[3] = {n.K * n.A, n.K * n.F, n.K3 * n.F};
+        for (int i = 0; i < 3; ++i) {
+            y.cw[i] = off; off += rows[i] * y.ldw;
+            y.cb[i] = off; off += n.F;
+        }
+    }
+#if FXT_DEVICE
+#pragma unroll
+#endif
+    for (int i = 0; i < FXT_MAX_LAYERS; ++i) {
+        y.w[i] = off; if (i < n.nl) off += n.dim[i] * n.dim[i + 1];
+        y.b[i] = off; if (i < n.nl) off += n.dim[i + 1];
+    }
+    y.total = off;
+    return y;
+}
+// image offset of parameter `g` (Keras order).  Everything behind a conv kernel keeps its distance to that kernel's end.
+FXT_HD int fxt_image_off(const FxtNet& n, const FxtLay& y, int g) {
+    if (y.ldw == n.F || n.kind != 0) return g;
+#if FXT_DEVICE
+#pragma unroll
+#endif
+    for (int c = 2; c >= 0; --c) {
+        if (g >= n.off_cw[c]) {
+            const int d = g - n.off_cw[c], size = n.off_cb[c] - n.off_cw[c];
+            if (d < size) return y.cw[c] + d + (d / n.F) * (y.ldw - n.F);
+            return y.cb[c] + (d - size);
+        }
+    }
+    return g;
+}
+
 // Workspace of one slice (floats): codes, activations, gradients.  Offsets relative to the slice's base.
 struct FxtWs {
     int codes;                  // R x L      alphabet indices (stored as int32 in the float buffer)
     int ylab, yvalid;           // R          the rows' labels and validity (1.0 / 0.0), fetched together with the codes
-    int a[3];                   // R x L1 x F post-ReLU conv outputs
-    int dzA, dzB;               // R x L1 x F gradient ping-pong
-    int g, cnt, dg;             // R x F      pooled maxima, tie counts, gradient
+    int ldF;                    // row stride of the F-wide arrays (fxt_ld_x)
+    int a[3];                   // R x L1 x ldF post-ReLU conv outputs
+    int dzA, dzB;               // R x L1 x ldF gradient ping-pong
+    int g, cnt, dg;             // R x ldF     pooled maxima, tie counts, gradient
     int act[FXT_MAX_LAYERS];    // R x dim[i+1] post-activation (post-dropout) outputs
     int du[FXT_MAX_LAYERS];     // R x dim[i+1] gradient w.r.t. the pre-activation
     int total;
@@ -103,13 +162,14 @@ FXT_HD FxtWs fxt_ws(const FxtNet& n, int R) {
     w.ylab = off; off += R;
     w.yvalid = off; off += R;
     if (n.kind == 0) {
-        const int s = R * n.L1 * n.F;
+        w.ldF = n.ldx;
+        const int s = R * n.L1 * w.ldF;
         for (int i = 0; i < 3; ++i) { w.a[i] = off; off += s; }
         w.dzA = off; off += s;
         w.dzB = off; off += s;
-        w.g = off; off += R * n.F;
-        w.cnt = off; off += R * n.F;
-        w.dg = off; off += R * n.F;
+        w.g = off; off += R * w.ldF;
+        w.cnt = off; off += R * w.ldF;
+        w.dg = off; off += R * w.ldF;
     }
     // (fixed trip counts: with run-time bounds the offset table is indexed dynamically and lives in scratch memory)
 #if FXT_DEVICE
@@ -439,7 +499,7 @@ struct FxtTransB {             // B(0, ki, n) = p[n * ld + ki]      (W^T for the
 };
 // conv forward: rows m = (r, t), contraction (tap j, channel c): A = x[r][t + j - pl][c] inside the sequence, else 0
 template <class P>
-struct FxtConvA {
+struct FxtConvA {               // (C = x's row stride)
     P x; int Lx, C, pl; FxtDiv dL;
     struct St { int base, tp; };
     FXT_HD St prep(int m, int kq) const { const int r = fxt_quot(m, dL), t = m - r * Lx; return St{(m - pl) * C + kq, t - pl}; }
@@ -451,14 +511,14 @@ struct FxtConvA {
     }
 };
 template <class P>
-struct FxtConvW {              // B((j, c), n) = w[(j * C + c) * F + n]
+struct FxtConvW {              // B((j, c), n) = w[(j * C + c) * F + n]      (F = the kernel's row stride)
     P w; int C, F;
     FXT_HD int prep(int n, int kq) const { return kq * F + n; }
     FXT_HD float at(int st, int j, int k0) const { return w[st + (j * C + k0) * F]; }
 };
 // conv input gradient: rows m = (r, s), contraction (tap j, out channel o): A = dz[r][s - j + pl][o], B = w[j][n][o]
 template <class P>
-struct FxtConvGradA {
+struct FxtConvGradA {           // (F = dz's row stride)
     P dz; int Lx, F, pl; FxtDiv dL;
     struct St { int base, sp; };
     FXT_HD St prep(int m, int kq) const { const int r = fxt_quot(m, dL), s = m - r * Lx; return St{(m + pl) * F + kq, s + pl}; }
@@ -470,7 +530,7 @@ struct FxtConvGradA {
     }
 };
 template <class P>
-struct FxtConvGradW {          // B((j, o), n = c) = w[(j * C + c) * F + o]
+struct FxtConvGradW {          // B((j, o), n = c) = w[(j * C + c) * F + o]  (F = the kernel's row stride)
     P w; int C, F;
     FXT_HD int prep(int n, int kq) const { return n * F + kq; }
     FXT_HD float at(int st, int j, int k0) const { return w[st + j * C * F + k0]; }
@@ -478,17 +538,17 @@ struct FxtConvGradW {          // B((j, o), n = c) = w[(j * C + c) * F + o]
 // conv weight gradient: rows m = (tap j, channel c) plus ONE extra row for the bias; contraction (row r, position t)
 template <class P>
 struct FxtConvWGradA {
-    P x; int Lx, C, pl, rows; FxtDiv dC;     // rows = taps * C (row `rows` is the bias row: all ones)
+    P x; int Lx, C, ld, pl, rows; FxtDiv dC; // rows = taps * C (row `rows` is the bias row: all ones); ld = x's row stride
     struct St { int off, tp; };              // off < 0: bias row
     FXT_HD St prep(int m, int kq) const {
         if (m >= rows) return St{-1, 0};
         const int j = fxt_quot(m, dC), c = m - j * C;
-        return St{(j - pl + kq) * C + c + (1 << 30), j - pl + kq};      // (+2^30: keeps `off` non-negative for taps left of the sequence)
+        return St{(j - pl + kq) * ld + c + (1 << 30), j - pl + kq};     // (+2^30: keeps `off` non-negative for taps left of the sequence)
     }
     FXT_HD float at(St s, int r, int k0) const {
         const int p = s.tp + k0;
         const bool ok = s.off >= 0 && p >= 0 && p < Lx;
-        const float v = x[ok ? s.off - (1 << 30) + (r * Lx + k0) * C : 0];
+        const float v = x[ok ? s.off - (1 << 30) + (r * Lx + k0) * ld : 0];
         return s.off < 0 ? 1.f : (ok ? v : 0.f);
     }
 };
@@ -510,7 +570,7 @@ struct FxtOneHotWGradA {
     }
 };
 template <class P>
-struct FxtPosMajorB {          // B((r, t), n) = p[(r * Lx + t) * F + n]
+struct FxtPosMajorB {          // B((r, t), n) = p[(r * Lx + t) * F + n]     (F = p's row stride)
     P p; int Lx, F;
     FXT_HD int prep(int n, int kq) const { return kq * F + n; }
     FXT_HD float at(int st, int r, int k0) const { return p[st + (r * Lx + k0) * F]; }
@@ -518,9 +578,9 @@ struct FxtPosMajorB {          // B((r, t), n) = p[(r * Lx + t) * F + n]
 // dense weight gradient: rows m = input unit k plus the bias row; contraction over the slice's rows r
 template <class P>
 struct FxtDenseWGradA {
-    P in; int Kd;
-    FXT_HD int prep(int m, int kq) const { return m >= Kd ? -1 : kq * Kd + m; }
-    FXT_HD float at(int st, int, int k0) const { const float v = in[st < 0 ? 0 : st + k0 * Kd]; return st < 0 ? 1.f : v; }
+    P in; int Kd, ld;          // ld = in's row stride
+    FXT_HD int prep(int m, int kq) const { return m >= Kd ? -1 : kq * ld + m; }
+    FXT_HD float at(int st, int, int k0) const { const float v = in[st < 0 ? 0 : st + k0 * ld]; return st < 0 ? 1.f : v; }
 };
 
 // Compile-time shape of a CANONICAL network (round 4).  The step is written for any shape the constructors accept: every
@@ -553,6 +613,8 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
     const FxtNet n = D::fixed ? fxt_net(D::kind, D::L > 0 ? D::L : j.net.L, D::A, D::F, D::H, D::K) : j.net;
     const int R = D::fixed ? D::R : j.R, L = n.L, A = n.A, F = n.F;
     const FxtWs w = fxt_ws(n, R);
+    const FxtLay y = fxt_lay(n, WAS == 3);      // (the LDS image of the weights has padded conv-kernel rows)
+    const int ldF = w.ldF, ldw = y.ldw;
     WsI codes = (WsI)(ws + w.codes);
     float* part = j.partial + (long long)slice * (n.P + 1);
     const int32_t* order = j.order + (long long)step * j.batch;
@@ -587,31 +649,31 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         // conv1 ('valid') on a one-hot input: a sum of K kernel rows
         FXT_FOR(i, R * L1 * F, wg) {
             const int o = i % F, rt = i / F, t = rt % L1, r = rt / L1;
-            float s = W[n.off_cb[0] + o];
-            for (int jj = 0; jj < K; ++jj) s += W[n.off_cw[0] + (jj * A + codes[r * L + t + jj]) * F + o];
-            a1[i] = s > 0.f ? s : 0.f;
+            float s = W[y.cb[0] + o];
+            for (int jj = 0; jj < K; ++jj) s += W[y.cw[0] + (jj * A + codes[r * L + t + jj]) * ldw + o];
+            a1[rt * ldF + o] = s > 0.f ? s : 0.f;
         }
         fxt_sync_ws<WSAS>(); FXT_STAMP(2);
         {   // conv2 ('same', K taps)
-            WCF b = W + n.off_cb[1];
-            struct Put { WsF y; WCF b; int F; FXT_HD void put(int m, int nn, float v) const { v += b[nn]; y[m * F + nn] = v > 0.f ? v : 0.f; } };
-            fxt_gemm(wg, R * L1, F, K, F, FxtConvA<WsCF>{a1, L1, F, (K - 1) / 2, dL1}, FxtConvW<WCF>{W + n.off_cw[1], F, F}, Put{a2, b, F}, 0, split);
+            WCF b = W + y.cb[1];
+            struct Put { WsF y; WCF b; int ld; FXT_HD void put(int m, int nn, float v) const { v += b[nn]; y[m * ld + nn] = v > 0.f ? v : 0.f; } };
+            fxt_gemm(wg, R * L1, F, K, F, FxtConvA<WsCF>{a1, L1, ldF, (K - 1) / 2, dL1}, FxtConvW<WCF>{W + y.cw[1], F, ldw}, Put{a2, b, ldF}, 0, split);
         }
         fxt_sync_ws<WSAS>(); FXT_STAMP(3);
         {   // conv3 ('same', A - 1 taps)
-            WCF b = W + n.off_cb[2];
-            struct Put { WsF y; WCF b; int F; FXT_HD void put(int m, int nn, float v) const { v += b[nn]; y[m * F + nn] = v > 0.f ? v : 0.f; } };
-            fxt_gemm(wg, R * L1, F, n.K3, F, FxtConvA<WsCF>{a2, L1, F, (n.K3 - 1) / 2, dL1}, FxtConvW<WCF>{W + n.off_cw[2], F, F}, Put{a3, b, F}, 0, split);
+            WCF b = W + y.cb[2];
+            struct Put { WsF y; WCF b; int ld; FXT_HD void put(int m, int nn, float v) const { v += b[nn]; y[m * ld + nn] = v > 0.f ? v : 0.f; } };
+            fxt_gemm(wg, R * L1, F, n.K3, F, FxtConvA<WsCF>{a2, L1, ldF, (n.K3 - 1) / 2, dL1}, FxtConvW<WCF>{W + y.cw[2], F, ldw}, Put{a3, b, ldF}, 0, split);
         }
         fxt_sync_ws<WSAS>(); FXT_STAMP(4);
         WsF g = ws + w.g; WsF cnt = ws + w.cnt;
         FXT_FOR(i, R * F, wg) {             // GlobalMaxPooling1D + the number of positions that attain the maximum
             const int r = i / F, f = i - r * F;
-            float mx = a3[(r * L1) * F + f];
-            for (int t = 1; t < L1; ++t) { const float v = a3[(r * L1 + t) * F + f]; mx = v > mx ? v : mx; }
+            float mx = a3[(r * L1) * ldF + f];
+            for (int t = 1; t < L1; ++t) { const float v = a3[(r * L1 + t) * ldF + f]; mx = v > mx ? v : mx; }
             int c = 0;
-            for (int t = 0; t < L1; ++t) c += a3[(r * L1 + t) * F + f] == mx;
-            g[i] = mx; cnt[i] = (float)c;
+            for (int t = 0; t < L1; ++t) c += a3[(r * L1 + t) * ldF + f] == mx;
+            g[r * ldF + f] = mx; cnt[r * ldF + f] = (float)c;
         }
         fxt_sync_ws<WSAS>(); FXT_STAMP(5);
         feat = g;
@@ -626,9 +688,10 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
     for (int li = 0; li < FXT_MAX_LAYERS; ++li) {
         if (li >= n.nl) break;
         const int Kd = n.dim[li], Nd = n.dim[li + 1];
-        WCF Wl = W + n.off_w[li];
-        WCF bl = W + n.off_b[li];
+        WCF Wl = W + y.w[li];
+        WCF bl = W + y.b[li];
         WsF out = ws + w.act[li];
+        const int ld_in = (li == 0 && !n.onehot_in) ? ldF : Kd;     // row stride of the layer's input
         const bool last = li == n.nl - 1;
         const bool drop = li == n.drop_layer;
         if (li == 0 && n.onehot_in) {
@@ -649,7 +712,7 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
                     y[m * Nd + nn] = v;
                 }
             };
-            fxt_gemm(wg, R, Nd, 1, Kd, FxtRowMajorA<WsCF>{in, Kd}, FxtRowMajorB<WCF>{Wl, Nd}, Put{out, bl, Nd, last, drop, &j, step, slot0, keep_scale}, 0, split);
+            fxt_gemm(wg, R, Nd, 1, Kd, FxtRowMajorA<WsCF>{in, ld_in}, FxtRowMajorB<WCF>{Wl, Nd}, Put{out, bl, Nd, last, drop, &j, step, slot0, keep_scale}, 0, split);
         }
         fxt_sync_ws<WSAS>(); FXT_STAMP(20 + li);
     }
@@ -684,8 +747,9 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         const int li = FXT_MAX_LAYERS - 1 - lq;
         if (li >= n.nl) continue;
         const int Kd = n.dim[li], Nd = n.dim[li + 1];
-        WCF Wl = W + n.off_w[li];
+        WCF Wl = W + y.w[li];
         WsCF du = ws + w.du[li];
+        const int ld_in = (li == 0 && !n.onehot_in) ? ldF : Kd;     // row stride of the layer's input
         struct PutW {
             float* gw; float* gb; int Kd, Nd; bool agent;
             FXT_HD void put(int m, int nn, float v) const {
@@ -710,11 +774,11 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
                 struct PutX { WsF d; WsCF y; int Kd; float ks; FXT_HD void put(int m, int nn, float v) const { d[m * Kd + nn] = y[m * Kd + nn] > 0.f ? v * ks : 0.f; } };
                 fxt_gemm(wg, R, Kd, 1, Nd, FxtRowMajorA<WsCF>{du, Nd}, FxtTransB<WCF>{Wl, Nd}, PutX{ws + w.du[li - 1], in, Kd, dropped ? keep_scale : 1.f}, 0, split);
             } else {
-                struct PutG { WsF d; int Kd; FXT_HD void put(int m, int nn, float v) const { d[m * Kd + nn] = v; } };
-                fxt_gemm(wg, R, Kd, 1, Nd, FxtRowMajorA<WsCF>{du, Nd}, FxtTransB<WCF>{Wl, Nd}, PutG{ws + w.dg, Kd}, 0, split);
+                struct PutG { WsF d; int ld; FXT_HD void put(int m, int nn, float v) const { d[m * ld + nn] = v; } };
+                fxt_gemm(wg, R, Kd, 1, Nd, FxtRowMajorA<WsCF>{du, Nd}, FxtTransB<WCF>{Wl, Nd}, PutG{ws + w.dg, ld_in}, 0, split);
             }
             // ... then the weight gradient (many tiles of R / 4 k-steps), dealt on from the wave behind the last long tile
-            fxt_gemm(wg, Kd + 1, Nd, 1, R, FxtDenseWGradA<WsCF>{in, Kd}, FxtRowMajorB<WsCF>{du, Nd}, putw, fxt_jobs(R, Kd, 1, Nd, nwv, can_split));
+            fxt_gemm(wg, Kd + 1, Nd, 1, R, FxtDenseWGradA<WsCF>{in, Kd, ld_in}, FxtRowMajorB<WsCF>{du, Nd}, putw, fxt_jobs(R, Kd, 1, Nd, nwv, can_split));
         }
         fxt_sync_ws<WSAS>(); FXT_STAMP(30 + li);
     }
@@ -725,9 +789,9 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         WsCF g = ws + w.g; WsCF cnt = ws + w.cnt; WsCF dg = ws + w.dg;
         WsF dzA = ws + w.dzA; WsF dzB = ws + w.dzB;
         FXT_FOR(i, R * L1 * F, wg) {        // max-pool backward (ties share evenly) through conv3's ReLU
-            const int f = i % F, r = i / (F * L1);
-            const float v = a3[i];
-            dzA[i] = (v > 0.f && v == g[r * F + f]) ? dg[r * F + f] / cnt[r * F + f] : 0.f;
+            const int f = i % F, rt = i / F, r = rt / L1;
+            const float v = a3[rt * ldF + f];
+            dzA[rt * ldF + f] = (v > 0.f && v == g[r * ldF + f]) ? dg[r * ldF + f] / cnt[r * ldF + f] : 0.f;
         }
         fxt_sync_ws<WSAS>(); FXT_STAMP(9);
         struct PutW {
@@ -741,17 +805,17 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
             }
         };
         const bool ag = j.agent_io != 0;
-        struct PutX { WsF d; WsCF y; int F; FXT_HD void put(int m, int nn, float v) const { d[m * F + nn] = y[m * F + nn] > 0.f ? v : 0.f; } };
+        struct PutX { WsF d; WsCF y; int ld; FXT_HD void put(int m, int nn, float v) const { d[m * ld + nn] = y[m * ld + nn] > 0.f ? v : 0.f; } };
         // conv3: input gradient (few tiles, K3 x F / 4 k-steps) first, the weight gradient dealt on behind it
-        fxt_gemm(wg, R * L1, F, K3, F, FxtConvGradA<WsCF>{dzA, L1, F, (K3 - 1) / 2, dL1}, FxtConvGradW<WCF>{W + n.off_cw[2], F, F}, PutX{dzB, a2, F}, 0, split);
-        fxt_gemm(wg, K3 * F + 1, F, R, L1, FxtConvWGradA<WsCF>{a2, L1, F, (K3 - 1) / 2, K3 * F, dF}, FxtPosMajorB<WsCF>{dzA, L1, F}, PutW{part + n.off_cw[2], part + n.off_cb[2], K3 * F, F, ag}, fxt_jobs(R * L1, F, K3, F, nwv, can_split));
+        fxt_gemm(wg, R * L1, F, K3, F, FxtConvGradA<WsCF>{dzA, L1, ldF, (K3 - 1) / 2, dL1}, FxtConvGradW<WCF>{W + y.cw[2], F, ldw}, PutX{dzB, a2, ldF}, 0, split);
+        fxt_gemm(wg, K3 * F + 1, F, R, L1, FxtConvWGradA<WsCF>{a2, L1, F, ldF, (K3 - 1) / 2, K3 * F, dF}, FxtPosMajorB<WsCF>{dzA, L1, ldF}, PutW{part + n.off_cw[2], part + n.off_cb[2], K3 * F, F, ag}, fxt_jobs(R * L1, F, K3, F, nwv, can_split));
         fxt_sync_ws<WSAS>(); FXT_STAMP(10);
         // conv2
-        fxt_gemm(wg, R * L1, F, K, F, FxtConvGradA<WsCF>{dzB, L1, F, (K - 1) / 2, dL1}, FxtConvGradW<WCF>{W + n.off_cw[1], F, F}, PutX{dzA, a1, F}, 0, split);
-        fxt_gemm(wg, K * F + 1, F, R, L1, FxtConvWGradA<WsCF>{a1, L1, F, (K - 1) / 2, K * F, dF}, FxtPosMajorB<WsCF>{dzB, L1, F}, PutW{part + n.off_cw[1], part + n.off_cb[1], K * F, F, ag}, fxt_jobs(R * L1, F, K, F, nwv, can_split));
+        fxt_gemm(wg, R * L1, F, K, F, FxtConvGradA<WsCF>{dzB, L1, ldF, (K - 1) / 2, dL1}, FxtConvGradW<WCF>{W + y.cw[1], F, ldw}, PutX{dzA, a1, ldF}, 0, split);
+        fxt_gemm(wg, K * F + 1, F, R, L1, FxtConvWGradA<WsCF>{a1, L1, F, ldF, (K - 1) / 2, K * F, dF}, FxtPosMajorB<WsCF>{dzB, L1, ldF}, PutW{part + n.off_cw[1], part + n.off_cb[1], K * F, F, ag}, fxt_jobs(R * L1, F, K, F, nwv, can_split));
         fxt_sync_ws<WSAS>(); FXT_STAMP(11);
         // conv1 (one-hot input, 'valid')
-        fxt_gemm(wg, K * A + 1, F, R, L1, FxtOneHotWGradA<WsCI>{codes, L, A, K * A, 1, dA}, FxtPosMajorB<WsCF>{dzA, L1, F}, PutW{part + n.off_cw[0], part + n.off_cb[0], K * A, F, ag});
+        fxt_gemm(wg, K * A + 1, F, R, L1, FxtOneHotWGradA<WsCI>{codes, L, A, K * A, 1, dA}, FxtPosMajorB<WsCF>{dzA, L1, ldF}, PutW{part + n.off_cw[0], part + n.off_cb[0], K * A, F, ag});
     }
     FXT_STAMP(63);
 }

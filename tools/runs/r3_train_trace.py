@@ -18,6 +18,7 @@ for tag, mk, L, alpha in (("3xCNN L=8", lambda: flexs_amd.Ensemble([bm.CNN(8, 32
     out = np.zeros(64, np.uint64)
     eng.check(eng._lib.fx_debug_train_trace(eng.handle, out.ctypes.data))
     t0 = int(out[0])
+    if out[62]: print(f"   kernel entry -> weights staged: {(t0 - int(out[62])) / 100:.2f} us")
     names = {0: "start (after weight staging)", 1: "codes+labels", 2: "conv1", 3: "conv2", 4: "conv3", 5: "pool", 20: "dense0 fwd", 21: "dense1 fwd", 22: "dense2 fwd",
              23: "dense3 fwd", 7: "loss", 33: "dense3 bwd", 32: "dense2 bwd", 31: "dense1 bwd", 30: "dense0 bwd", 9: "pool bwd", 10: "conv3 bwd", 11: "conv2 bwd", 63: "end (conv1 wgrad)"}
     ev = sorted((int(out[k]), k) for k in names if out[k])
