@@ -55,6 +55,9 @@ SIGNATURES = {
     "fx_score_planes_dev": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _vp, C.c_int64, C.c_int, _u8p, _vp, C.c_int64]),
     "fx_ensemble_mean_planes_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64, _vp]),
     "fx_staging_input": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp)]),
+    "fx_score_stream_begin": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int64, C.c_int, _u8p, C.POINTER(_vp)]),
+    "fx_score_stream_rows": (C.c_int, [_vp, C.c_int64]),
+    "fx_score_stream_end": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "fx_score_begin": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int64, C.c_int, _u8p, C.c_int, C.c_int, C.POINTER(_vp)]),
     "fx_score_submit": (C.c_int, [_vp, C.c_int64, C.c_int64]),
     "fx_score_finish": (C.c_int, [_vp, _vp, _vp]),
@@ -255,6 +258,10 @@ CHUNK_BYTES = int(os.environ.get("FLEXS_AMD_CHUNK_BYTES", 0))   # target bytes p
 # ---- explorer-size calls: one C call packs the strings and runs fx_score (csrc/strpack.c score_small) -------------------
 SMALL_CALL_ROWS = 4096           # what the engine's resident form answers (FX_SERVE_CAP; 256 until round 4)
 SMALL_CALL_BYTES = 65536         # (FX_SERVE_BYTES, and the stack buffer of csrc/strpack.c score_small)
+# calls of at least STREAM_MIN_ROWS strings are STREAMED when a resident generation can take them: the request is posted first and
+# the strings are packed straight into its mailbox, STREAM_STEP_ROWS at a time (fx_score_stream_*, include/flexs_amd.h); 0 = never
+STREAM_MIN_ROWS = 384
+STREAM_STEP_ROWS = 256
 _HAS_SCORE_SMALL = _strpack is not None and hasattr(_strpack, "score_small")
 
 
@@ -269,8 +276,10 @@ def small_plan(engine: "Engine", models: Sequence["NativeModel"], L: int, lut: n
     fn = C.cast(engine._lib.fx_score, C.c_void_p).value
     handles = [int(m.handle.value if hasattr(m.handle, "value") else m.handle) for m in models] + [0] * (16 - M)
     eh = engine.handle
-    return struct.pack("PPqqq16P256s", fn, int(eh.value if hasattr(eh, "value") else eh), M, L, 2 if want_mean else 1,
-                       *handles, np.ascontiguousarray(lut, np.uint8).tobytes())
+    stream = [C.cast(getattr(engine._lib, name), C.c_void_p).value or 0
+              for name in ("fx_score_stream_begin", "fx_score_stream_rows", "fx_score_stream_end")]
+    return struct.pack("PPqqq16P256sPPPqq", fn, int(eh.value if hasattr(eh, "value") else eh), M, L, 2 if want_mean else 1,
+                       *handles, np.ascontiguousarray(lut, np.uint8).tobytes(), *stream, STREAM_MIN_ROWS, STREAM_STEP_ROWS)
 
 
 def score_small(engine: "Engine", plan: bytes, seqs, M: int, want_mean: bool) -> Optional[np.ndarray]:

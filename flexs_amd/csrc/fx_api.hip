@@ -313,6 +313,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "serve_reserve_cus")) return &e->serve_reserve_cus;
     if (!std::strcmp(key, "serve_poll_sleep")) return &e->serve_poll_sleep;
     if (!std::strcmp(key, "serve_fence")) return &e->serve_fence;
+    if (!std::strcmp(key, "serve_quads")) return &e->serve_quads;
     if (!std::strcmp(key, "serve_idle_us")) return &e->serve_idle_us;
     if (!std::strcmp(key, "chunk_overlap")) return &e->chunk_overlap;
     if (!std::strcmp(key, "zero_copy_bytes")) return &e->zero_copy_bytes;
@@ -341,6 +342,7 @@ static bool ab_only_value(const fx_engine* e, const int64_t* s, int64_t value) {
         return value != 0;
     if (s == &e->dense_waves) return value == 8;
     if (s == &e->cnn_pair) return value == 0;
+    if (s == &e->serve_quads) return value != 1;
     if (s == &e->cnn_variant) return value == 2 || value == 3 || value == 5 || value == 6;
     return false;
 #endif
@@ -374,6 +376,8 @@ int fx_engine_get_option(fx_engine* e, const char* key, int64_t* value) {
     if (e && key && !std::strcmp(key, "server_last_fallback")) { *value = e->server.fb_info; return FX_OK; }   // reason (1 left, 2 timed out) | member | sequence | waited us
     if (e && key && !std::strcmp(key, "server_resident")) { *value = e->server.running ? 1 : 0; return FX_OK; }
     if (e && key && !std::strcmp(key, "server_wide")) { *value = (e->server.running && e->server.wide) ? 1 : 0; return FX_OK; }
+    if (e && key && !std::strncmp(key, "server_prof_", 12) && key[12] >= '0' && key[12] <= '7' && !key[13]) { *value = e->server.prof_ns[key[12] - '0']; return FX_OK; }
+    if (e && key && !std::strcmp(key, "server_streamed")) { *value = e->server.streamed; return FX_OK; }
     if (e && key && !std::strcmp(key, "server_slots")) { *value = e->server.running ? e->server.tiles : 0; return FX_OK; }
     int64_t* s = option_slot(e, key);
     if (!s) return fx_fail(e, FX_EINVAL, std::string("unknown option ") + (key ? key : "(null)"));
@@ -706,6 +710,8 @@ static bool host_can_store(FxMailIn* q) {
     return back == magic;
 }
 
+extern "C" int64_t fx_collect_lines(const volatile unsigned long long* ans, float* scores, int64_t n0, int64_t N, unsigned seq, int64_t ahead, int* bad);   // host_collect.cc
+
 static int server_start(fx_engine* e, fx_model* const* models, int M, int L, const uint8_t lut[256]) {
     auto& sv = e->server;
     if (!e->large_bar) return FX_EUNSUPPORTED;             // the host must be able to store into device memory
@@ -794,7 +800,9 @@ static int server_start(fx_engine* e, fx_model* const* models, int M, int L, con
         const int cnt = group_len(m0);
         hipStream_t st = sv.streams[sv.groups];
         sv.groups += 1;
-        rc = fx_launch_score_cnn_quad_server(e, models + m0, cnt, m0, tiles, st, sv.in, sv.d_out, idle, life);
+        int quads = 1;
+        rc = fx_launch_score_cnn_quad_server(e, models + m0, cnt, m0, tiles, st, sv.in, sv.d_out, idle, life, want_wide ? (int)e->serve_quads : 1, &quads);
+        for (int m = m0; m < m0 + cnt; ++m) sv.quads[m] = rc == FX_OK ? quads : 1;
         if (rc == FX_EUNSUPPORTED) rc = fx_launch_score_dense_small_server(e, models + m0, cnt, m0, tiles, st, sv.in, sv.d_out, idle, life);
         if (rc) {                                          // a member without a resident form: the groups already started leave again
             sv.in->stop = 1; sv.in->req_wide = FX_SERVE_LEAVE; sv.in->req = FX_SERVE_LEAVE;
@@ -816,9 +824,16 @@ static int server_start(fx_engine* e, fx_model* const* models, int M, int L, con
 }
 
 // FX_OK: answered.  FX_EUNSUPPORTED: not this time (the caller launches as usual).  Anything else: the call's error.
-static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii, int64_t N, int L,
-                       const uint8_t lut[256], float* out_NM, float* out_mean) {
+static int64_t server_since(const fx_engine* e) {
+    return (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - e->server.t_entry).count();
+}
+
+// May this request go to the resident form?  FX_OK: a generation of exactly these members is running (started here if the
+// calls come densely enough) and holds N sequences.  FX_EUNSUPPORTED: not this time.
+static int server_admit(fx_engine* e, fx_model* const* models, int M, int64_t N, int L, const uint8_t lut[256]) {
     auto& sv = e->server;
+    sv.t_entry = std::chrono::steady_clock::now();
+    auto since = [&]() { return server_since(e); };
     if (!e->serve_small || e->trace || e->force_generic || N < 1 || N > FX_SERVE_CAP || N * L > FX_SERVE_BYTES || M > FX_MAX_M) return FX_EUNSUPPORTED;
     bool same = sv.running && (int)sv.models.size() == M && sv.L == L && std::memcmp(sv.lut, lut, 256) == 0;
     for (int m = 0; same && m < M; ++m) same = sv.models[m] == models[m] && sv.versions[m] == models[m]->version;
@@ -848,14 +863,14 @@ static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8
             // leaving by themselves (idle / lifetime): all go.  A slot counts as gone when it HAS been seen alive and no longer
             // is -- the workgroups of a fresh generation raise their `alive` words as they start, the late ones microseconds
             // after the first request was answered.  Looked at for the slots this request needs and one rotating slot.
-            const int need = (int)std::min<int64_t>((N + 15) / 16, sv.tiles);
+            auto need = [&](int) { return (int)std::min<int64_t>((N + 15) / 16, sv.tiles); };
             auto left = [&](int m, int t) {
                 uint8_t& seen = sv.seen[(size_t)m * FX_SERVE_TILES + t];
                 if (sv.h_out->alive[m][t]) { seen = 1; return false; }
                 return seen != 0;
             };
             for (int m = 0; m < M && sv.running; ++m) {
-                for (int t = 0; t < need; ++t)
+                for (int t = 0, nt = need(m); t < nt; ++t)
                     if (left(m, t)) { server_stop(e); break; }
                 if (sv.running && left(m, (int)(sv.seq % (unsigned)sv.tiles))) server_stop(e);
             }
@@ -880,17 +895,45 @@ static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8
         }
         if (N > sv.cap) return FX_EUNSUPPORTED;
     }
-    // request: bytes, fence, request word, fence (write-combining stores may pass each other otherwise)
-    std::memcpy(sv.in->bytes, ascii, (size_t)N * L);
-    fx_bar_fence();
+    sv.prof_ns[0] = since();
+    return FX_OK;
+}
+
+// Post a request to the running generation.  `ascii` given: bytes, fence, request word, fence (write-combining stores may pass
+// each other otherwise).  `ascii` null: a STREAMED request -- `ready` = no rows yet, then the request word with FX_SERVE_STREAM;
+// the caller packs rows into sv.in->bytes and reports them with server_rows_ready.
+static void server_post(fx_engine* e, const uint8_t* ascii, int64_t N, int L) {
+    auto& sv = e->server;
     if ((++sv.seq & 0x7FFFFFFFull) == 0) ++sv.seq;         // 31-bit tags, never 0; they run on across generations, so a slot's stale answer never matches
     const unsigned seq = (unsigned)(sv.seq & 0x7FFFFFFFull);
-    // (the slots beyond the fast ones poll the copy: written first -- a slot that sees it early finds the bytes in place all the same)
-    if (sv.fast < sv.tiles) sv.in->req_wide = ((unsigned long long)seq << 16) | (unsigned long long)N;
-    sv.in->req = ((unsigned long long)seq << 16) | (unsigned long long)N;
+    unsigned long long word = ((unsigned long long)seq << 16) | (unsigned long long)N;
+    if (ascii) std::memcpy(sv.in->bytes, ascii, (size_t)N * L);
+    else { sv.in->ready = (unsigned long long)seq << 16; word |= FX_SERVE_STREAM; }
     fx_bar_fence();
-    const auto t0 = std::chrono::steady_clock::now();
-    sv.t_post = t0;
+    // (the slots beyond the fast ones poll the copy: written first -- a slot that sees it early finds the bytes in place all the same)
+    if (sv.fast < sv.tiles) sv.in->req_wide = word;
+    sv.in->req = word;
+    fx_bar_fence();
+    sv.t_post = std::chrono::steady_clock::now();
+    sv.posted_N = N;
+    sv.prof_ns[1] = server_since(e);
+}
+
+static void server_rows_ready(fx_engine* e, int64_t rows) {
+    auto& sv = e->server;
+    fx_bar_fence();                                        // the rows' bytes before the word that announces them
+    sv.in->ready = ((sv.seq & 0x7FFFFFFFull) << 16) | (unsigned long long)rows;
+    fx_bar_fence();                                        // (and out of the write-combining buffer now)
+}
+
+// Collect the posted request's answers.  FX_OK / FX_EBADCHAR: answered.  FX_EUNSUPPORTED: the generation did not answer
+// (it was stopped here); the caller launches as usual.
+static int server_collect(fx_engine* e, int M, float* out_NM, float* out_mean) {
+    auto& sv = e->server;
+    auto since = [&]() { return server_since(e); };
+    const int64_t N = sv.posted_N;
+    const unsigned seq = (unsigned)(sv.seq & 0x7FFFFFFFull);
+    const auto t0 = sv.t_post;
     // (the first request of a generation also waits for the launch and the weight fill -- and the very first one of the
     //  process for the runtime to create the high-priority hardware queue and load the kernels: ~0.3 s, once)
     // (later requests: a resident workgroup answers within microseconds and one that left says so through its `alive` word;
@@ -911,8 +954,23 @@ static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8
     for (int m = 0; m < M; ++m) {
         const volatile unsigned long long* am = h->ans[m];
         float* pm = pl + (size_t)m * (size_t)N;
+        // (lines ahead: 8 while the device is still answering -- a line requested before the device writes it comes back stale
+        //  and is missed again -- and 32 for the later members, whose answers have mostly landed by the time their turn comes)
+        const int64_t ahead = m == 0 ? 64 : 256;
+        if (m > 0) for (int64_t n = 0; n < ahead && n < N; n += 8) __builtin_prefetch(const_cast<const unsigned long long*>(am) + n, 0, 0);
+        int vbad = 0;
         for (int64_t n = 0; n < N; ++n) {
-            if ((n & 7) == 0) __builtin_prefetch(const_cast<const unsigned long long*>(am) + n + 64, 0, 0);
+            if ((n & 7) == 0) {
+                // whole lines whose eight answers have all arrived: vector path (host_collect.cc); the loop below waits for the rest
+                const int64_t n2 = fx_collect_lines(am, pm, n, N, seq, ahead, &vbad);
+                if (n2 > n) {
+                    if (m == 0 && n == 0) sv.prof_ns[2] = since();
+                    for (int64_t t = n >> 4; t <= (n2 - 1) >> 4; ++t) sv.seen[(size_t)m * FX_SERVE_TILES + (size_t)(t % sv.tiles)] = 1;
+                    n = n2 - 1;
+                    continue;
+                }
+                __builtin_prefetch(const_cast<const unsigned long long*>(am) + n + ahead, 0, 0);
+            }
             unsigned spins = 0;
             unsigned long long a;
             while ((((a = am[n]) >> 32) & 0x7FFFFFFFull) != seq) {
@@ -932,12 +990,16 @@ static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8
                     }
                 }
             }
+            if (m == 0 && n == 0) sv.prof_ns[2] = since();
             bad = bad || (a >> 63);
             const unsigned bits = (unsigned)a;
             std::memcpy(&pm[n], &bits, 4);
             if ((n & 15) == 0) sv.seen[(size_t)m * FX_SERVE_TILES + (size_t)((n >> 4) % sv.tiles)] = 1;   // (it answered: it is there)
         }
+        bad = bad || vbad;
+        if (m < 3) sv.prof_ns[5 + m] = since();
     }
+    sv.prof_ns[3] = since();
     if (out_NM) {
         for (int m = 0; m < M; ++m) {
             const float* pm = pl + (size_t)m * (size_t)N;
@@ -963,11 +1025,67 @@ static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8
             }
         }
     }
+    sv.prof_ns[4] = since();
     sv.fresh = false;
     sv.served += 1;
     e->counters.host_calls += 1; e->counters.zero_copy_calls += 1; e->counters.sequences += N; e->counters.forwards += N * M;
     if (bad) return fx_fail(e, FX_EBADCHAR, "substring not found: character outside the alphabet");
     return FX_OK;
+}
+
+// FX_OK: answered.  FX_EUNSUPPORTED: not this time (the caller launches as usual).  Anything else: the call's error.
+static int server_call(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii, int64_t N, int L,
+                       const uint8_t lut[256], float* out_NM, float* out_mean) {
+    const int rc = server_admit(e, models, M, N, L, lut);
+    if (rc) return rc;
+    server_post(e, ascii, N, L);
+    return server_collect(e, M, out_NM, out_mean);
+}
+
+// ---- streamed calls (round 4): the request is posted first, the caller packs its strings straight into the mailbox ----------
+int fx_score_stream_begin(fx_engine* e, fx_model* const* models, int M, int64_t N, int L, const uint8_t lut[256], uint8_t** rows_out) {
+    if (!e) return FX_EINVAL;
+    if (!rows_out) return fx_fail(e, FX_EINVAL, "null buffer");
+    int rc = validate_models(e, models, M, L, lut);
+    if (rc) return rc;
+    if (N < 1) return FX_EUNSUPPORTED;
+    if (e->server.streaming) return fx_fail(e, FX_ESTATE, "fx_score_stream_begin: a streamed call is already open");
+    {
+        // only a call that a RUNNING generation of exactly these members can take is streamed; everything else -- starting a
+        // generation, the adaptive change of geometry -- is the packed call's business (server_call), whose bookkeeping a
+        // refused attempt here must not touch
+        const auto& sv = e->server;
+        bool same = sv.running && !sv.fresh && N <= sv.cap && (int)sv.models.size() == M && sv.L == L && std::memcmp(sv.lut, lut, 256) == 0;
+        for (int m = 0; same && m < M; ++m) same = sv.models[m] == models[m] && sv.versions[m] == models[m]->version;
+        if (!same) return FX_EUNSUPPORTED;
+    }
+    FX_HIP(e, hipSetDevice(e->device));
+    rc = server_admit(e, models, M, N, L, lut);
+    if (rc) return rc;
+    server_post(e, nullptr, N, L);
+    e->server.streaming = true;
+    e->server.stream_M = M;
+    *rows_out = e->server.in->bytes;
+    return FX_OK;
+}
+
+int fx_score_stream_rows(fx_engine* e, int64_t rows) {
+    if (!e) return FX_EINVAL;
+    if (!e->server.streaming || rows < 0 || rows > e->server.posted_N) return fx_fail(e, FX_ESTATE, "fx_score_stream_rows: no streamed call open, or more rows than announced");
+    server_rows_ready(e, rows);
+    return FX_OK;
+}
+
+int fx_score_stream_end(fx_engine* e, int ok, float* out_NM, float* out_mean) {
+    if (!e) return FX_EINVAL;
+    if (!e->server.streaming) return fx_fail(e, FX_ESTATE, "fx_score_stream_end: no streamed call open");
+    e->server.streaming = false;
+    if (!ok) { server_stop(e); return FX_OK; }             // the caller could not pack its rows: the workgroups abandon the request and leave
+    if (!out_NM && !out_mean) { server_stop(e); return fx_fail(e, FX_EINVAL, "null buffer"); }
+    server_rows_ready(e, e->server.posted_N);
+    const int rc = server_collect(e, e->server.stream_M, out_NM, out_mean);
+    if (rc == FX_OK) e->server.streamed += 1;
+    return rc;
 }
 
 int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii, int64_t N, int L,

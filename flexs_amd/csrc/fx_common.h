@@ -23,6 +23,7 @@
 #define FX_SERVE_BYTES 65536   // N x seq_len bytes per request at most
 #define FX_SERVE_CAP 4096      // sequences per request at most
 #define FX_SERVE_LEAVE 0xFFFFull   // request word that tells the resident workgroups to leave (sequence number 0, N = 0xFFFF: neither occurs in a request)
+#define FX_SERVE_STREAM 0x8000ull          // request word, bit 15 of the row count: the bytes follow the request (FxMailIn::ready)
 #define FX_SERVE_FAST 16       // the first slots of every member poll without a pause (explorer-size calls); the others sleep between polls
 
 // ---------------------------------------------------------------- shapes
@@ -89,6 +90,11 @@ struct FxMailIn {                                      // device memory (fine-gr
     // would wait in it (12.5 vs 11.2 us per 20-sequence call with 240 pollers on `req`, profiles/r4_server_wide_ab_first.log).
     // The many poll this copy -- far from `req`'s line, with a pause between polls; it is written just BEFORE `req`.
     alignas(64) unsigned long long req_wide;
+    // STREAMED requests (round 4; request word bit 15, FX_SERVE_STREAM): the request is posted BEFORE its bytes, and the host
+    // packs the caller's strings straight into `bytes`, raising `ready` = (sequence number << 16) | rows packed so far every few
+    // hundred rows -- a tile starts as soon as ITS rows are there, so the packing of a 2001-string call (4.6 us) runs beside the
+    // first tiles instead of in front of them.  A workgroup waits for its rows in fx_server_rows_ready.
+    alignas(64) unsigned long long ready;
 };
 static_assert(offsetof(FxMailIn, stop) == 64 && offsetof(FxMailIn, bytes) == 128, "server_start clears the first 128 bytes");
 struct FxMailOut {                                     // pinned host memory; the host only ever READS it (after zeroing it between generations)
@@ -214,6 +220,12 @@ struct fx_engine {
         std::vector<fx_model*> pending;                  // the last eligible call's ensemble, and when it came
         std::chrono::steady_clock::time_point t_pending;
         int64_t served = 0, started = 0, fallbacks = 0, fb_info = 0;
+        std::chrono::steady_clock::time_point t_entry{};  // entry of the call being served (prof_ns counts from here)
+        int64_t posted_N = 0;                            // the posted request's sequences
+        int64_t streamed = 0;                            // streamed calls answered
+        bool streaming = false; int stream_M = 0;        // a streamed call is open (fx_score_stream_begin .. _end)
+        int64_t prof_ns[8] = {};                         // the last served call: checks, request posted, first answer seen, all collected, outputs written (ns since entry)
+        int quads[FX_MAX_M] = {};                        // tiles a member's workgroup answers side by side (CNN, wide generation, seq_len <= 8: 3; else 1)
         std::vector<uint8_t> seen;                       // [member][slot]: this generation's workgroup has been seen alive
         std::vector<float> planes;                       // the answers of a request, member-major (host scratch)
     } server;
@@ -223,6 +235,7 @@ struct fx_engine {
     int64_t serve_idle_us = 500;   // calls of the same ensemble closer than this start / keep the resident workgroups; they leave after twice this long without a request (a device-wide synchronize waits that long for them at most)
     int64_t serve_wide = 1;     // 1 = a resident generation takes (num_cus - serve_reserve_cus) / M tile slots per member and serves requests of up to 4096 sequences, a slot walking several tiles (0 = round 3's geometry: a third of the CUs, <= 16 slots, <= 256 sequences: A/B)
     int64_t serve_reserve_cus = 16;   // CUs a wide generation leaves without a resident workgroup (kernels of other streams -- RCCL, PyTorch -- find room there at once; small ones also fit beside a resident workgroup)
+    int64_t serve_quads = 1;    // wide generation, CNN with seq_len <= 8: tiles per resident workgroup side by side (1 = one; 3 = like the launched form: A/B build only -- slower once requests are streamed, csrc/OPTIONS.md)
     int64_t serve_fence = 0;    // 1 = a system fence after every tile's answers (round 3: ~0.5 us each, and the fences of one XCD serialise -- 24 us for the 378 tiles of a 2001-sequence request, profiles/r4_mailbox_probe3.log); 0 = none: the answers are system-scope stores, which write through by themselves (profiles/r4_mailbox_probe4.log)
     int64_t serve_poll_sleep = 8;     // s_sleep units (64 clocks each) between polls of the slots beyond FX_SERVE_FAST (0 = every slot spins)
     int64_t serve_small = 1;    // 1 = explorer-size calls of canonical CNN ensembles are answered by resident workgroups (0 = a launch per call: A/B)
@@ -338,13 +351,29 @@ inline void fx_server_stop(fx_engine* e) {
     sv.running = false;
 }
 int fx_launch_score_cnn_quad_server(fx_engine* e, fx_model* const* models, int M, int m_off, int tiles, hipStream_t stream,
-                                    FxMailIn* d_in, FxMailOut* d_out, unsigned long long idle_ticks, unsigned long long life_ticks);
+                                    FxMailIn* d_in, FxMailOut* d_out, unsigned long long idle_ticks, unsigned long long life_ticks,
+                                    int want_quads, int* quads_out);
 int fx_launch_score_dense_small_server(fx_engine* e, fx_model* const* models, int M, int m_off, int tiles, hipStream_t stream,
                                        FxMailIn* d_in, FxMailOut* d_out, unsigned long long idle_ticks, unsigned long long life_ticks);
 // The resident workgroups' wait for the next request (thread 0 of a workgroup): returns the new request word, or `last` with
 // *leave = 1 when told to stop, idle for too long or too old.  `fast` slots spin on `req`; the others poll `req_wide` (the same
 // word, written first) with `sleep_n` x 64 clocks between polls, so that they do not queue in front of the fast slots' line.
 #if defined(__HIPCC__)
+// A streamed request's tile: wait until the host has packed `need` rows.  false = abandon the request (the host said LEAVE, or
+// nothing came for 2 s: the tile must NOT be answered -- the host falls back to a launch when an answer stays away).
+// Called by whole waves (every lane polls the same word: one request per wave and poll).
+__device__ __forceinline__ bool fx_server_rows_ready(const FxMailIn* in, unsigned long long req, long long need) {
+    if (!(req & FX_SERVE_STREAM)) return true;
+    const unsigned long long tag = req >> 16, t0 = wall_clock64();
+    for (unsigned spins = 0;; ++spins) {
+        const unsigned long long r = __hip_atomic_load(&in->ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((r >> 16) == tag && (long long)(r & 0xFFFFull) >= need) return true;
+        if ((spins & 63u) == 63u) {
+            if (__hip_atomic_load(&in->req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == FX_SERVE_LEAVE) return false;
+            if (wall_clock64() - t0 > 200000000ull) return false;
+        }
+    }
+}
 __device__ __forceinline__ unsigned long long fx_server_wait(const FxMailIn* in, unsigned long long last, unsigned long long seen,
                                                              unsigned long long start, unsigned long long idle_ticks,
                                                              unsigned long long life_ticks, bool fast, int sleep_n, int* leave) {

@@ -86,7 +86,6 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
     [[maybe_unused]] const int srv_m = SERVER ? (int)blockIdx.x / p.srv_tiles : 0;      // SERVER: workgroup = (member, tile slot)
     [[maybe_unused]] const int srv_slot = SERVER ? (int)blockIdx.x % p.srv_tiles : 0;
     if constexpr (SERVER) {
-        static_assert(!SERVER || QUADS == 1, "the resident form keeps one tile per workgroup");
         u_lo = u_hi = 0;                                  // tiles come with the requests
     } else {
         fx_unit_range(p.TG, p.M, u_lo, u_hi);
@@ -101,7 +100,8 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
     unsigned long long& srv_req = *reinterpret_cast<unsigned long long*>(srv_area);
     int& srv_exit = *reinterpret_cast<int*>(srv_area + 8);
     volatile int& srv_bad = *reinterpret_cast<volatile int*>(srv_area + 12);
-    unsigned* srv_bytes = reinterpret_cast<unsigned*>(srv_area + 16);
+    volatile int& srv_abandon = *reinterpret_cast<volatile int*>(srv_area + 16);        // a streamed request whose rows never came: not answered
+    unsigned* srv_bytes = reinterpret_cast<unsigned*>(srv_area + 32) + quad * 256;      // this quad's tile: 16 x L bytes (<= 1 KiB)
     // dma: the very first round reads its bytes from LDS (a compiler-tracked byte load from global memory would be waited
     // for with vmcnt(0), i.e. together with the whole image); needs the 4-byte alignment of the dword copy
     const bool lds_bytes = !SERVER && p.dma && (reinterpret_cast<uintptr_t>(p.ascii) & 3) == 0;
@@ -150,14 +150,16 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
             if (tid == 0) {
                 int ex = 0;
                 const unsigned long long r = fx_server_wait(p.min, srv_last, srv_seen, srv_start, p.idle_ticks, p.life_ticks, srv_slot < p.srv_fast, p.srv_sleep, &ex);
-                srv_req = r; srv_exit = ex; srv_bad = 0;
+                srv_req = r; srv_exit = ex; srv_bad = 0; srv_abandon = 0;
             }
             __syncthreads();
             if (srv_exit) break;
-            Ncur = (int64_t)(srv_req & 0xFFFFull);
+            Ncur = (int64_t)(srv_req & 0x7FFFull);
             TGcur = (Ncur + 15) >> 4;
-            // this slot's tiles of the request: slot, slot + T, slot + 2 T, ... (T = tile slots per member), one round each
-            srv_rounds = srv_slot < TGcur ? (int)((TGcur - srv_slot + p.srv_tiles - 1) / p.srv_tiles) : 0;
+            // this slot's tiles of the request: slot, slot + T, slot + 2 T, ... (T = slots per member) -- QUADS of them per round,
+            // one per quad: a request of up to T tiles keeps one quad per workgroup busy (a lone quad is the fastest round),
+            // a larger one fills the second and third quads before anybody needs a second round
+            srv_rounds = srv_slot < TGcur ? (int)((TGcur - srv_slot + (int64_t)p.srv_tiles * QUADS - 1) / ((int64_t)p.srv_tiles * QUADS)) : 0;
             t_lo = srv_slot; t_hi = srv_slot + srv_rounds;
             bad = false;
             if (srv_rounds == 0) {                                   // a request with fewer tiles: nothing to answer from this slot
@@ -169,16 +171,19 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
         const int rounds = SERVER ? srv_rounds : (int)((t_hi - t_lo + QUADS - 1) / QUADS);
 
         for (int rd = 0; rd < rounds; ++rd, parity ^= 1) {
-            const int64_t tg = SERVER ? t_lo + (int64_t)rd * p.srv_tiles : t_lo + (int64_t)rd * QUADS + quad;
-            const bool live = SERVER || tg < t_hi;                   // idle quads run along for the barriers
+            const int64_t tg = SERVER ? t_lo + ((int64_t)rd * QUADS + quad) * p.srv_tiles : t_lo + (int64_t)rd * QUADS + quad;
+            const bool live = SERVER ? tg < TGcur : tg < t_hi;       // idle quads run along for the barriers
             const int64_t n = tg * 16 + sq;
             const uint8_t* row = ascii + ((live && n < Ncur) ? n : 0) * L;
             if constexpr (SERVER) {
                 // this tile's bytes: one dword per thread (past the caches: the host wrote them through the BAR), then everybody
                 // reads LDS.  (The previous round's readers of srv_bytes -- its phase A -- are several barriers behind.)
                 const int64_t srv_rows = Ncur - tg * 16 < 16 ? Ncur - tg * 16 : 16;
-                if ((int64_t)tid * 4 < srv_rows * L)
-                    srv_bytes[tid] = __hip_atomic_load(reinterpret_cast<const unsigned*>(ascii + tg * 16 * L) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const int qt = tid & 255;
+                if (live && (int64_t)qt * 4 < srv_rows * L) {
+                    if (!fx_server_rows_ready(p.min, srv_req, tg * 16 + srv_rows)) srv_abandon = 1;      // (a streamed request: the host is still packing)
+                    srv_bytes[qt] = __hip_atomic_load(reinterpret_cast<const unsigned*>(ascii + tg * 16 * L) + qt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
                 __syncthreads();
             }
             f4* X = xq + (parity ? XT * 64 : 0);
@@ -329,7 +334,7 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
                     // (score, tag) in one 8-byte SYSTEM-scope store to host memory: written through every cache level by itself
                     // (round 3 added a system fence per tile -- ~0.5 us each, serialised per XCD; off by default now, serve_fence)
                     const unsigned tag = (unsigned)(srv_req >> 16) | (srv_bad ? 0x80000000u : 0u);
-                    if (g == 0 && n < Ncur)
+                    if (g == 0 && n < Ncur && !srv_abandon)
                         __hip_atomic_store(const_cast<unsigned long long*>(&p.mout->ans[p.m_off + m][n]),
                                            ((unsigned long long)tag << 32) | __float_as_uint(fx_nan_to_num(y[0])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     if (p.srv_fence) __threadfence_system();
@@ -463,7 +468,7 @@ namespace {
 
 template <int QUADS, int XT, int L1C>
 int launch_server(fx_engine* e, QuadArgs a, int M, hipStream_t stream) {
-    const size_t lds = (size_t)a.total_floats * 4 + 256 + (size_t)QUADS * 2 * XT * 1024 + (size_t)QUADS * 256 + 16 + 256;
+    const size_t lds = (size_t)a.total_floats * 4 + 256 + (size_t)QUADS * 2 * XT * 1024 + (size_t)QUADS * 256 + 32 + (size_t)QUADS * 1024;
     if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
     auto kern = k_score_cnn_quad<7, QUADS, XT, L1C, 5, true>;
     static bool attr_set[64] = {};
@@ -483,7 +488,8 @@ int launch_server(fx_engine* e, QuadArgs a, int M, hipStream_t stream) {
 // answered by M x min(ceil(N / 16), tiles) of them, each on its own CU, slot s walking the tiles s, s + tiles, ... (round 4:
 // a wide generation holds most of the chip and serves up to 4096 sequences per request; round 3's held a third of it).
 int fx_launch_score_cnn_quad_server(fx_engine* e, fx_model* const* models, int M, int m_off, int tiles, hipStream_t stream,
-                                    FxMailIn* d_in, FxMailOut* d_out, unsigned long long idle_ticks, unsigned long long life_ticks) {
+                                    FxMailIn* d_in, FxMailOut* d_out, unsigned long long idle_ticks, unsigned long long life_ticks,
+                                    int want_quads, int* quads_out) {
     const FxShape& s = models[0]->shape;
     const FxPackLayout& lay = models[0]->layout;
     const int L1 = s.L - s.K + 1;
@@ -503,6 +509,24 @@ int fx_launch_score_cnn_quad_server(fx_engine* e, fx_model* const* models, int M
     a.off_d1 = (int)lay.off_d1; a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
     a.min = d_in; a.mout = d_out; a.idle_ticks = idle_ticks; a.life_ticks = life_ticks;
     a.srv_tiles = tiles; a.m_off = m_off; a.srv_fast = e->server.fast; a.srv_sleep = (int)e->serve_poll_sleep; a.srv_fence = (int)e->serve_fence;
+    // want_quads = 3 (a wide generation, seq_len <= 8): up to three tiles per workgroup side by side, like the launched form.  The
+    // second and third quads only get tiles when a request has more tiles than the generation has workgroups: a round with one
+    // busy quad takes ~6 us, with two ~8.5 us (four waves per tile, ~200 fp32 MFMAs each: the quads share the CU's four MFMA
+    // pipes), against 12 us for two rounds -- 44.8 -> 41.2 us for a 4096-sequence call of the 3 x CNN ensemble, 27.5 -> 26.6 us for
+    // 2001 (profiles/r4_server_quads_ab.log).  Filling the quads of ONE workgroup first was measured too: +2.4 us for every
+    // 20-sequence call (same log, first table).
+    // Once requests are STREAMED (tiles start as their rows arrive, staggered anyway) the extra quads lose: 23.3 vs 25.4 us for
+    // 2001 sequences, 25.8 vs 30.6 us for 4096 of a single CNN.  A/B build only.
+    *quads_out = 1;
+#if defined(FX_AB)
+    if (want_quads >= 3 && L1 <= 4) {
+        a.rotate = (int)e->quad_rotate;
+        const int rc = L1 == 4 ? launch_server<3, 8, 4>(e, a, M, stream) : launch_server<3, 8, 0>(e, a, M, stream);
+        if (rc != FX_EUNSUPPORTED) { *quads_out = 3; return rc; }
+    }
+#else
+    (void)want_quads;
+#endif
     if (L1 == 4) return launch_server<1, 8, 4>(e, a, M, stream);
     if (L1 < 4) return launch_server<1, 8, 0>(e, a, M, stream);
     return launch_server<1, 24, 0>(e, a, M, stream);

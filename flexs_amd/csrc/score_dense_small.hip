@@ -57,6 +57,7 @@ __global__ void __launch_bounds__(SW * 64) k_score_dense_small(SmallArgs p) {
     unsigned long long& srv_req = *reinterpret_cast<unsigned long long*>(srv_area);
     int& srv_exit = *reinterpret_cast<int*>(srv_area + 8);
     volatile int& srv_bad = *reinterpret_cast<volatile int*>(srv_area + 12);
+    volatile int& srv_abandon = *reinterpret_cast<volatile int*>(srv_area + 16);     // a streamed request whose rows never came: not answered
     [[maybe_unused]] unsigned long long srv_last = 0, srv_start = 0, srv_seen = 0;
     for (int i = tid; i < 64; i += SW * 64) reinterpret_cast<uint32_t*>(lut_s)[i] = reinterpret_cast<const uint32_t*>(p.lut)[i];
     if constexpr (SERVER) {
@@ -71,11 +72,11 @@ __global__ void __launch_bounds__(SW * 64) k_score_dense_small(SmallArgs p) {
         if (tid == 0) {
             int ex = 0;
             const unsigned long long r = fx_server_wait(p.min, srv_last, srv_seen, srv_start, p.idle_ticks, p.life_ticks, (int)tg0 < p.srv_fast, p.srv_sleep, &ex);
-            srv_req = r; srv_exit = ex; srv_bad = 0;
+            srv_req = r; srv_exit = ex; srv_bad = 0; srv_abandon = 0;
         }
         __syncthreads();
         if (srv_exit) break;
-        Ncur = (int64_t)(srv_req & 0xFFFFull);
+        Ncur = (int64_t)(srv_req & 0x7FFFull);
         if (tg0 * 16 >= Ncur) {                              // a request with fewer tiles: nothing to answer from this slot
             if (tid == 0) { srv_last = srv_req; srv_seen = wall_clock64(); }
             __syncthreads();                                 // (everybody has read the request word)
@@ -90,6 +91,7 @@ __global__ void __launch_bounds__(SW * 64) k_score_dense_small(SmallArgs p) {
         if constexpr (SERVER) {
             // the tile's bytes, dword-wise and past the caches (the host wrote them through the BAR)
             const unsigned* src = reinterpret_cast<const unsigned*>(p.min->bytes + tg * 16 * L);
+            if (!fx_server_rows_ready(p.min, srv_req, tg * 16 + rows)) srv_abandon = 1;           // (a streamed request: the host is still packing)
             for (int i = tid; i * 4 < (int)rows * L; i += SW * 64)
                 reinterpret_cast<unsigned*>(bytes_s)[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         } else {
@@ -108,7 +110,7 @@ __global__ void __launch_bounds__(SW * 64) k_score_dense_small(SmallArgs p) {
             if constexpr (SERVER) {
                 // (score, tag) in one 8-byte SYSTEM-scope store to host memory (written through by itself; serve_fence = 1 adds round 3's fence)
                 const unsigned tag = (unsigned)(srv_req >> 16) | (srv_bad ? 0x80000000u : 0u);
-                if (g == 0 && n < Ncur)
+                if (g == 0 && n < Ncur && !srv_abandon)
                     __hip_atomic_store(const_cast<unsigned long long*>(&p.mout->ans[p.m_off + m][n]),
                                        ((unsigned long long)tag << 32) | __float_as_uint(fx_nan_to_num(y[0])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (p.srv_fence) __threadfence_system();
@@ -144,7 +146,7 @@ int launch_small(fx_engine* e, const SmallArgs& a, int64_t U) {
 template <int KIND, int HT>
 int launch_small_server(fx_engine* e, const SmallArgs& a, int M, hipStream_t stream) {
     auto kern = k_score_dense_small<KIND, HT, true>;
-    const size_t lds = (size_t)2 * HT * 1024 + 256 + (((size_t)16 * a.L + 15) & ~(size_t)15) + 16;
+    const size_t lds = (size_t)2 * HT * 1024 + 256 + (((size_t)16 * a.L + 15) & ~(size_t)15) + 32;
     if (lds > 64 * 1024) return FX_EUNSUPPORTED;
     hipLaunchKernelGGL(kern, dim3((unsigned)(M * a.srv_tiles)), dim3(SW * 64), lds, stream, a);
     FX_HIP(e, hipGetLastError());

@@ -252,12 +252,19 @@ static PyObject* pack(PyObject* self, PyObject* args) {
  * by flexs_amd/_native.py (struct layout below); this module does not link against libflexs_amd.so. */
 typedef int (*fx_score_fn)(void* e, void* const* models, int M, const unsigned char* ascii, long long N, int L,
                            const unsigned char* lut, float* out_NM, float* out_mean);
+typedef int (*fx_stream_begin_fn)(void* e, void* const* models, int M, long long N, int L, const unsigned char* lut, unsigned char** rows);
+typedef int (*fx_stream_rows_fn)(void* e, long long rows);
+typedef int (*fx_stream_end_fn)(void* e, int ok, float* out_NM, float* out_mean);
 typedef struct {
     void* fn;                  /* fx_score */
     void* engine;
     long long M, L, want;      /* want: 1 = (N, M) matrix, 2 = mean */
     void* models[16];
     unsigned char lut[256];
+    /* streamed calls (include/flexs_amd.h fx_score_stream_*): the strings are packed straight into the resident form's mailbox
+     * while its first tiles are already being answered.  stream_min: calls of at least that many strings (0 = never). */
+    void* stream_begin; void* stream_rows; void* stream_end;
+    long long stream_min, stream_step;
 } SmallPlan;
 #define SMALL_MAX_BYTES 65536          /* = FX_SERVE_BYTES: what one request of the resident form holds */
 
@@ -273,12 +280,42 @@ static PyObject* score_small(PyObject* self, PyObject* args) {
         const Py_ssize_t need = (p->want == 1 ? n * p->M : n) * (Py_ssize_t)sizeof(float);
         if (n > 0 && n * p->L <= SMALL_MAX_BYTES && out.len >= need && p->M >= 1 && p->M <= 16) {
             unsigned char buf[SMALL_MAX_BYTES];
-            const int st = pack_range(PySequence_Fast_ITEMS(seqs), buf, n, (Py_ssize_t)p->L, 1);
-            if (st) {
+            float* o = (float*)out.buf;
+            int streamed = 0;
+            if (p->stream_begin && p->stream_min > 0 && n >= p->stream_min && p->stream_step > 0) {
+                unsigned char* rows = NULL;
+                if (((fx_stream_begin_fn)p->stream_begin)(p->engine, (void* const*)p->models, (int)p->M, (long long)n, (int)p->L, p->lut, &rows) == 0) {
+                    /* the request is posted: pack in pieces, front to back, each piece reported as soon as it is in place */
+                    PyObject** items = PySequence_Fast_ITEMS(seqs);
+                    int st = 0;
+                    for (Py_ssize_t r0 = 0; r0 < n && !st; r0 += (Py_ssize_t)p->stream_step) {
+                        const Py_ssize_t cnt = n - r0 < (Py_ssize_t)p->stream_step ? n - r0 : (Py_ssize_t)p->stream_step;
+                        st = pack_range(items + r0, rows + r0 * p->L, cnt, (Py_ssize_t)p->L, 1);
+                        if (!st && r0 + cnt < n) ((fx_stream_rows_fn)p->stream_rows)(p->engine, (long long)(r0 + cnt));
+                    }
+                    if (st) {
+                        ((fx_stream_end_fn)p->stream_end)(p->engine, 0, NULL, NULL);
+                        status = 1000 + st;
+                        streamed = 1;
+                    } else {
+                        int rc;
+                        Py_BEGIN_ALLOW_THREADS
+                        rc = ((fx_stream_end_fn)p->stream_end)(p->engine, 1, p->want == 1 ? o : NULL, p->want == 1 ? NULL : o);
+                        Py_END_ALLOW_THREADS
+                        if (rc != -7 /* FX_EUNSUPPORTED: the generation went away -- pack into own memory and launch, below */) {
+                            status = rc < 0 ? 2000 - rc : rc;
+                            streamed = 1;
+                        }
+                    }
+                }
+            }
+            const int st = streamed ? 0 : pack_range(PySequence_Fast_ITEMS(seqs), buf, n, (Py_ssize_t)p->L, 1);
+            if (streamed) {
+                /* answered (or failed) above */
+            } else if (st) {
                 status = 1000 + st;                        /* 1001 ragged, 1002 non-latin-1, 1003 not a str */
             } else {
                 int rc;
-                float* o = (float*)out.buf;
                 Py_BEGIN_ALLOW_THREADS
                 rc = ((fx_score_fn)p->fn)(p->engine, (void* const*)p->models, (int)p->M, buf, (long long)n, (int)p->L, p->lut,
                                           p->want == 1 ? o : NULL, p->want == 1 ? NULL : o);

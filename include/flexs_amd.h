@@ -213,6 +213,20 @@ int fx_score(fx_engine *e, fx_model *const *models, int M, const uint8_t *ascii,
              const uint8_t lut[256], float *out_NM, float *out_mean);
 int fx_score_dev(fx_engine *e, fx_model *const *models, int M, const uint8_t *d_ascii, int64_t N,
                  int L, const uint8_t lut[256], float *d_out_NM, float *d_out_mean);
+/* fx_score for a caller that still has to PACK its rows (a Python list of str, keras_model.py:69-79's argument): streamed
+ * over the resident form (round 4).  _begin posts the request for N sequences and hands out the mailbox's byte area (device
+ * memory behind the BAR: write it front to back, never read it); the caller packs rows into it in order and reports progress
+ * with _rows (total rows packed so far, every few hundred rows -- a resident workgroup starts a 16-row tile as soon as those
+ * rows are reported); _end(ok = 1) reports the last rows, collects the answers and writes out_NM / out_mean as fx_score
+ * does.  The packing of a 2001-string call then runs beside the first tiles instead of in front of them.
+ *   _begin: FX_OK, or FX_EUNSUPPORTED when the resident form does not take this call now (no generation running for these
+ *           members, too many sequences, first request of a generation ...): pack into own memory and call fx_score.
+ *   _end:   ok = 0: the caller could not pack (not a str, ragged ...): the request is abandoned, FX_OK.
+ *           FX_EUNSUPPORTED: the generation went away before it answered: pack into own memory and call fx_score.
+ * Same results, bit for bit, as fx_score on the packed rows. */
+int fx_score_stream_begin(fx_engine *e, fx_model *const *models, int M, int64_t N, int L, const uint8_t lut[256], uint8_t **rows);
+int fx_score_stream_rows(fx_engine *e, int64_t rows_packed);
+int fx_score_stream_end(fx_engine *e, int ok, float *out_NM, float *out_mean);
 /* The mean-only device path in two calls, with the intermediate in the caller's hands: the M members' scores as
  * member-major PLANES (`d_planes[m * stride + n]`, stride >= N, a multiple of 4, base 16-byte aligned) -- a work
  * unit's 16 scores are then one contiguous 64-byte store instead of 16 stores 4*M bytes apart as in the (N, M)

@@ -1817,6 +1817,70 @@ def _few_fallbacks(eng, before, what=""):
     assert n <= 3, f"{n} requests fell back to a launch {what} (last: {eng.get_option('server_last_fallback')})"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,L,alpha,M", [("cnn", 8, "TGCA", 3), ("mlp", 14, "UGCA", 1), ("ge", 14, "UGCA", 3), ("mix", 14, "UGCA", 3)])
+def test_resident_streamed_calls(eng, kind, L, alpha, M):
+    """Round 4, streamed requests (fx_score_stream_*): get_fitness(list[str]) of at least _native.STREAM_MIN_ROWS strings posts its
+    request FIRST and packs the strings straight into the resident generation's mailbox, reporting every 256 rows -- a tile is
+    answered as soon as its rows are there.  Same bits as the packed request and as the launched call; shorter calls are not
+    streamed; a list that cannot be packed (not a str / ragged, found after the request went out) raises what the reference raises,
+    the generation is replaced, and the next calls are right; a character outside the alphabet is the ValueError of every path."""
+    from flexs_amd import _native
+    if kind == "mix":
+        members = [bm.GlobalEpistasisModel(L, 100, alpha, seed=1), bm.MLP(L, 200, alpha, seed=2), bm.CNN(L, 32, 100, alpha, seed=3)]
+    else:
+        mk = {"cnn": lambda s: bm.CNN(L, 32, 100, alpha, seed=s), "mlp": lambda s: bm.MLP(L, 100, alpha, seed=s),
+              "ge": lambda s: bm.GlobalEpistasisModel(L, 100, alpha, seed=s)}[kind]
+        members = [mk(30 + s) for s in range(M)]
+    ens = flexs_amd.Ensemble(members) if M > 1 else members[0]
+    lo, step = _native.STREAM_MIN_ROWS, _native.STREAM_STEP_ROWS
+    assert lo > 0 and step > 0
+    sizes = [lo - 1, lo, lo + 1, step * 2, step * 2 + 17, 1000, 2001, min(4096, 65536 // L)]
+    data = {n: rand_seqs(n, L, alpha, seed=900 + n)[1] for n in sizes}
+    eng.set_option("serve_small", 0)
+    try:
+        want = {n: ens.get_fitness(data[n]) for n in sizes}
+    finally:
+        eng.set_option("serve_small", 1)
+    eng.set_option("serve_wide", 2)
+    try:
+        small = data[sizes[0]][:20]
+        assert _until_resident(eng, lambda: ens.get_fitness(small))
+        fb0 = eng.get_option("server_fallbacks")
+        for rep in range(3):
+            for n in sizes:
+                ens.get_fitness(small)
+                s0, c0 = eng.get_option("server_streamed"), eng.get_option("server_calls") + eng.get_option("server_fallbacks")
+                got = ens.get_fitness(data[n])
+                assert np.array_equal(got, want[n]), (kind, n, rep)
+                assert eng.get_option("server_calls") + eng.get_option("server_fallbacks") - c0 == 1, (kind, n)
+                if eng.get_option("server_fallbacks") == fb0:
+                    assert eng.get_option("server_streamed") - s0 == (1 if n >= lo else 0), (kind, n, rep)
+        _few_fallbacks(eng, fb0, f"streamed {kind} L={L}")
+        # tuples stream too; NumPy arrays of str take the same path through tolist()
+        assert np.array_equal(ens.get_fitness(tuple(data[1000])), want[1000])
+        assert np.array_equal(ens.get_fitness(np.array(data[1000])), want[1000])
+        # found while packing, after the request went out: a non-str in the last piece, a ragged string in the second
+        for bad_list, exc in ((data[1000][:-1] + [7], TypeError), (data[1000][:300] + [data[1000][300][:-1]] + data[1000][301:], ValueError)):
+            for _ in range(3):
+                ens.get_fitness(small)
+            with pytest.raises(exc):
+                ens.get_fitness(bad_list)
+            assert np.array_equal(ens.get_fitness(data[1000]), want[1000])
+            assert _until_resident(eng, lambda: ens.get_fitness(small))
+            assert np.array_equal(ens.get_fitness(data[2001]), want[2001])
+        # a character outside the alphabet (found by the device, in the last tile)
+        for _ in range(3):
+            ens.get_fitness(small)
+        bad = list(data[2001])
+        bad[-1] = bad[-1][:-1] + "!"
+        with pytest.raises(ValueError):
+            ens.get_fitness(bad)
+        assert np.array_equal(ens.get_fitness(data[2001]), want[2001])
+    finally:
+        eng.set_option("serve_wide", 1)
+
+
 def _until_resident(eng, call, tries=12):
     """Keep calling until a resident generation serves the calls (starting one takes two calls within the idle window)."""
     for _ in range(tries):

@@ -470,7 +470,8 @@ def test_score_small_packs_and_calls_through_the_plan():
     fn = FN(fake_fx_score)
     lut = _native.make_lut("ACGT")
     for want in (1, 2):
-        plan = struct.pack("PPqqq16P256s", C.cast(fn, C.c_void_p).value, 777, 2, 4, want, *([11, 22] + [0] * 14), lut.tobytes())
+        plan = struct.pack("PPqqq16P256sPPPqq", C.cast(fn, C.c_void_p).value, 777, 2, 4, want, *([11, 22] + [0] * 14), lut.tobytes(),
+                           0, 0, 0, 0, 0)                              # (no streamed calls)
         out = np.empty((2, 2) if want == 1 else (2,), np.float32)
         assert _native._strpack.score_small(plan, ["ACGT", "TTTT"], out) == 0
         assert seen[-1] == (777, [11, 22], 2, 4, b"ACGTTTTT", want == 1, want == 2, lut.tobytes())
@@ -486,6 +487,85 @@ def test_score_small_packs_and_calls_through_the_plan():
     assert _native._strpack.score_small(plan, np.array(["ACGT"]), out) == -1          # not a list / tuple
     n_calls = len(seen)
     assert _native._strpack.score_small(plan, [], out) == -1 and len(seen) == n_calls
+
+
+def test_score_small_streams_through_the_plan():
+    """csrc/strpack.c score_small, streamed form (include/flexs_amd.h fx_score_stream_*): calls of at least stream_min strings
+    are packed piece by piece into the area _begin hands out, every piece but the last reported with _rows, the answers come
+    from _end; a refusal from _begin or an FX_EUNSUPPORTED from _end lands in the packed call; a string that cannot be packed
+    closes the stream with ok = 0.  Fake callbacks: the protocol is checked without a GPU."""
+    import ctypes as C
+    import struct
+
+    from flexs_amd import _native
+
+    if not _native._HAS_SCORE_SMALL:
+        pytest.skip("strpack helper not built")
+    log = []
+    area = (C.c_uint8 * 4096)()
+    behaviour = {"begin": 0, "end": 0}
+    SCORE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_uint8), C.c_longlong, C.c_int,
+                        C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_float))
+    BEGIN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_longlong, C.c_int, C.POINTER(C.c_uint8),
+                        C.POINTER(C.POINTER(C.c_uint8)))
+    ROWS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_longlong)
+    END = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float))
+
+    def fake_score(e, models, M, ascii, N, L, lut, out_nm, out_mean):
+        log.append(("score", N, bytes(ascii[:N * L])))
+        for i in range(N):
+            out_mean[i] = -1.0
+        return 0
+
+    def fake_begin(e, models, M, N, L, lut, rows):
+        log.append(("begin", e, M, N, L))
+        if behaviour["begin"]:
+            return behaviour["begin"]
+        rows[0] = C.cast(area, C.POINTER(C.c_uint8))
+        return 0
+
+    def fake_rows(e, n):
+        log.append(("rows", n, bytes(area[:n * 4])))
+        return 0
+
+    def fake_end(e, ok, out_nm, out_mean):
+        log.append(("end", ok))
+        if ok and not behaviour["end"]:
+            for i in range(10):
+                out_mean[i] = i + 0.25
+        return behaviour["end"] if ok else 0
+
+    fns = [SCORE(fake_score), BEGIN(fake_begin), ROWS(fake_rows), END(fake_end)]
+    ptr = [C.cast(f, C.c_void_p).value for f in fns]
+    lut = _native.make_lut("ACGT")
+    plan = struct.pack("PPqqq16P256sPPPqq", ptr[0], 777, 1, 4, 2, *([11] + [0] * 15), lut.tobytes(), ptr[1], ptr[2], ptr[3], 8, 4)
+    seqs = ["ACGT", "CCCC", "GGGG", "TTTT", "AAAA", "ACAC", "GTGT", "TGCA", "CATG", "GGCC"]
+    packed = "".join(seqs).encode()
+    out = np.zeros(10, np.float32)
+    assert _native._strpack.score_small(plan, seqs, out) == 0
+    assert log == [("begin", 777, 1, 10, 4), ("rows", 4, packed[:16]), ("rows", 8, packed[:32]), ("end", 1)]
+    assert bytes(area[:40]) == packed and np.array_equal(out, np.arange(10) + 0.25)
+    del log[:]
+    assert _native._strpack.score_small(plan, seqs[:7], out) == 0                   # fewer than stream_min strings: the packed call
+    assert log == [("score", 7, packed[:28])]
+    del log[:]
+    behaviour["begin"] = -7                                                          # FX_EUNSUPPORTED: no generation for this call
+    assert _native._strpack.score_small(plan, seqs, out) == 0
+    assert log == [("begin", 777, 1, 10, 4), ("score", 10, packed)] and (out == -1.0).all()
+    del log[:]
+    behaviour["begin"], behaviour["end"] = 0, -7                                     # the generation went away before it answered
+    assert _native._strpack.score_small(plan, seqs, out) == 0
+    assert [x[0] for x in log] == ["begin", "rows", "rows", "end", "score"] and log[-1] == ("score", 10, packed)
+    del log[:]
+    behaviour["end"] = -3                                                            # the callee's FX_EBADCHAR
+    assert _native._strpack.score_small(plan, seqs, out) == 2003 and log[-1] == ("end", 1)
+    del log[:]
+    behaviour["end"] = 0
+    assert _native._strpack.score_small(plan, seqs[:9] + ["GGC"], out) == 1001      # ragged, found in the last piece
+    assert log[-1] == ("end", 0) and not any(x[0] == "score" for x in log)
+    del log[:]
+    assert _native._strpack.score_small(plan, seqs[:2] + [5] + seqs[3:], out) == 1003
+    assert log == [("begin", 777, 1, 10, 4), ("end", 0)]                            # (found in the first piece: nothing was reported)
 
 
 def test_rng_checkpoint_puts_numpys_global_stream_back():
