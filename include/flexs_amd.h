@@ -118,11 +118,16 @@ const char *fx_last_error(fx_engine *e);
  *                              (they poll a copy of the request word on a line of its own).
  *   serve_fence       0        1 = round 3's system fence after every tile's answers (A/B; the answers are system-scope
  *                              stores, which write through by themselves).
+ *   serve_quads       1        wide generation, 4-letter CNN with seq_len <= 8: tiles a resident workgroup answers side by
+ *                              side.  3 (the launched form's three quads) is in the A/B build only: slower once requests
+ *                              are streamed (fx_score_stream_*).
  *   serve_idle_us     500      ... calls further apart than this are launched; the workgroups leave by themselves after
  *                              twice this long without a request.  A device-wide synchronize (hipDeviceSynchronize)
  *                              issued right after a small call waits for that.
- *   server_calls, server_starts, server_fallbacks, server_resident, server_wide, server_slots   (read) bookkeeping of the
- *                              resident form.
+ *   server_calls, server_starts, server_fallbacks, server_resident, server_wide, server_slots, server_streamed   (read)
+ *                              bookkeeping of the resident form; server_prof_0 .. _7 (read): the last served call's
+ *                              timeline, ns since it entered the library (admitted, posted, first answer, collected,
+ *                              outputs written, member planes 0 - 2 done).
  *   ab_build          (read)   1 = this library is the A/B build (`make -C flexs_amd/csrc ab`): the kernel forms that were
  *                              measured and LOST are compiled in; the production library refuses the option values that
  *                              select them (FX_EUNSUPPORTED).
@@ -130,7 +135,8 @@ const char *fx_last_error(fx_engine *e);
  *                              outputs through device memory, one grid barrier) instead of position segments with
  *                              recomputed halos: a 237-residue call 64 -> 24 us, same bits.  0 = the segmented form.
  *   train_canon       1        fx_train_fit: canonical shapes run the step instantiated with compile-time dimensions
- *                              (k_train_fb 47.8 -> 32.8 us, same bits); 0 = the shape-agnostic code for everything.
+ *                              (k_train_fb 47.8 -> 29.8 us with the padded LDS rows, same bits); 0 = the shape-agnostic
+ *                              code for everything.
  *   train_persistent  0        fx_train_fit: 1 = the whole fit as ONE launch (member barriers in device memory, Adam by the
  *                              same workgroups; needs all workgroups co-resident).  Same bits, no faster: off.
  *   train_rows        0        fx_train_fit: mini-batch rows per forward+backward workgroup; 0 = automatic (depends on
@@ -147,7 +153,7 @@ const char *fx_last_error(fx_engine *e);
  *   stage_bytes, stage_fill, dma_fill, wave_prio                                                             (staging / scheduling)
  * A/B build only (the production library answers FX_EUNSUPPORTED): cnn_conv1_mfma, mlp_l1_mfma (one-hot first layers on MFMA
  * instead of the LDS gather), dense_pipe, fuse_mean, chunk_overlap, dense_waves = 8, dense_few_waves_below, cnn_pair = 0,
- * cnn_variant 2 / 3 / 5 / 6, train_split -- each measured slower than the default.
+ * cnn_variant 2 / 3 / 5 / 6, train_split, serve_quads = 3 -- each measured slower than the default.
  * What each does, its values and the measurement that decided it: flexs_amd/csrc/OPTIONS.md. */
 int fx_engine_set_option(fx_engine *e, const char *key, int64_t value);
 int fx_engine_get_option(fx_engine *e, const char *key, int64_t *value);
