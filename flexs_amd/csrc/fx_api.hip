@@ -314,6 +314,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "serve_poll_sleep")) return &e->serve_poll_sleep;
     if (!std::strcmp(key, "serve_fence")) return &e->serve_fence;
     if (!std::strcmp(key, "serve_quads")) return &e->serve_quads;
+    if (!std::strcmp(key, "host_mean_below")) return &e->host_mean_below;
     if (!std::strcmp(key, "serve_idle_us")) return &e->serve_idle_us;
     if (!std::strcmp(key, "chunk_overlap")) return &e->chunk_overlap;
     if (!std::strcmp(key, "zero_copy_bytes")) return &e->zero_copy_bytes;
@@ -377,6 +378,7 @@ int fx_engine_get_option(fx_engine* e, const char* key, int64_t* value) {
     if (e && key && !std::strcmp(key, "server_resident")) { *value = e->server.running ? 1 : 0; return FX_OK; }
     if (e && key && !std::strcmp(key, "server_wide")) { *value = (e->server.running && e->server.wide) ? 1 : 0; return FX_OK; }
     if (e && key && !std::strncmp(key, "server_prof_", 12) && key[12] >= '0' && key[12] <= '7' && !key[13]) { *value = e->server.prof_ns[key[12] - '0']; return FX_OK; }
+    if (e && key && !std::strncmp(key, "call_prof_", 10) && key[10] >= '0' && key[10] <= '3' && !key[11]) { *value = e->call_prof_ns[key[10] - '0']; return FX_OK; }
     if (e && key && !std::strcmp(key, "server_streamed")) { *value = e->server.streamed; return FX_OK; }
     if (e && key && !std::strcmp(key, "server_slots")) { *value = e->server.running ? e->server.tiles : 0; return FX_OK; }
     int64_t* s = option_slot(e, key);
@@ -425,6 +427,7 @@ int fx_model_create(fx_engine* e, int kind, int L, int A, int F, int H, int K, f
     m->eng = e;
     m->shape = FxShape{kind, L, A, F, H, K};
     m->layout = fx_pack_layout(m->shape);
+    m->mfma_per_tile = fx_mfma_per_tile(m->shape);
     const int64_t np = fx_num_params(m->shape);
     m->blob.assign((size_t)np, 0.f);
     FX_HIP(e, hipSetDevice(e->device));
@@ -632,7 +635,7 @@ static void plan_host_call(const fx_engine* e, fx_model* const* models, int M, i
     double t_k = 0.0;
     bool mfma = true;
     for (int m = 0; m < M; ++m) {
-        const int64_t per_tile = fx_mfma_per_tile(models[m]->shape);
+        const int64_t per_tile = models[m]->mfma_per_tile;       // (3.7 us per call of a three-member 237-residue ensemble when recomputed here)
         if (per_tile < 0) { mfma = false; break; }
         t_k += (double)per_tile * (double)((N + 15) / 16) * 32.0 / ((double)e->num_cus * 4.0 * 2.4e9) / 0.75;
     }
@@ -824,6 +827,27 @@ static int server_start(fx_engine* e, fx_model* const* models, int M, int L, con
 }
 
 // FX_OK: answered.  FX_EUNSUPPORTED: not this time (the caller launches as usual).  Anything else: the call's error.
+// np.mean over the members (ensemble.py:24) of M member planes `stride` floats apart, on the host, M <= 16, in NumPy's order.
+static void host_mean_planes(const float* pl, int64_t stride, int64_t N, int M, float* out_mean) {
+    if (M < 8) {
+        // NumPy's order for fewer than eight members is the plain left-to-right sum from 0 (np_sum_row): plane by plane,
+        // which the compiler vectorises over the sequences
+        for (int64_t n = 0; n < N; ++n) out_mean[n] = 0.f;
+        for (int m = 0; m < M; ++m) {
+            const float* pm = pl + (size_t)m * (size_t)stride;
+            for (int64_t n = 0; n < N; ++n) out_mean[n] += pm[n];
+        }
+        const float fm = (float)M;
+        for (int64_t n = 0; n < N; ++n) out_mean[n] = out_mean[n] / fm;
+    } else {
+        for (int64_t n = 0; n < N; ++n) {
+            float x16[16];
+            for (int m = 0; m < 16; ++m) x16[m] = m < M ? pl[(size_t)m * (size_t)stride + n] : 0.f;
+            out_mean[n] = np_mean_row16(x16, M);           // NumPy's order, the same routine the mean kernels use
+        }
+    }
+}
+
 static int64_t server_since(const fx_engine* e) {
     return (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - e->server.t_entry).count();
 }
@@ -1006,25 +1030,7 @@ static int server_collect(fx_engine* e, int M, float* out_NM, float* out_mean) {
             for (int64_t n = 0; n < N; ++n) out_NM[n * M + m] = pm[n];
         }
     }
-    if (out_mean) {
-        if (M < 8) {
-            // NumPy's order for fewer than eight members is the plain left-to-right sum from 0 (np_sum_row): plane by plane,
-            // which the compiler vectorises over the sequences
-            for (int64_t n = 0; n < N; ++n) out_mean[n] = 0.f;
-            for (int m = 0; m < M; ++m) {
-                const float* pm = pl + (size_t)m * (size_t)N;
-                for (int64_t n = 0; n < N; ++n) out_mean[n] += pm[n];
-            }
-            const float fm = (float)M;
-            for (int64_t n = 0; n < N; ++n) out_mean[n] = out_mean[n] / fm;
-        } else {
-            for (int64_t n = 0; n < N; ++n) {
-                float x16[16];
-                for (int m = 0; m < 16; ++m) x16[m] = m < M ? pl[(size_t)m * (size_t)N + n] : 0.f;
-                out_mean[n] = np_mean_row16(x16, M);       // NumPy's order, the same routine the mean kernels use
-            }
-        }
-    }
+    if (out_mean) host_mean_planes(pl, N, N, M, out_mean);
     sv.prof_ns[4] = since();
     sv.fresh = false;
     sv.served += 1;
@@ -1106,10 +1112,14 @@ int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii,
     void *d_in = nullptr, *h_in = nullptr, *h_out = nullptr;
     if ((rc = fx_scratch(e, 0, in_bytes, &d_in))) return rc;
     if ((rc = fx_pinned(e, 0, in_bytes, &h_in))) return rc;
-    if ((rc = fx_pinned(e, 1, nm_bytes + mean_bytes, &h_out))) return rc;
     // mean only: member-major planes as the intermediate (see fx_score_dev)
     const int64_t stride = (!out_NM && M <= 16) ? planar_stride_for(N) : 0;
     const size_t inter_bytes = stride ? sizeof(float) * (size_t)stride * (size_t)M : nm_bytes;
+    // explorer-size mean-only calls that are LAUNCHED (the protein CNN, shapes without a resident form): the member planes go
+    // straight to pinned host memory and the mean is taken here -- M x N floats over PCIe instead of N, and no second launch
+    // (~6 us of a 50 us call)
+    const bool host_mean = stride && M > 1 && N <= e->host_mean_below;
+    if ((rc = fx_pinned(e, 1, std::max(nm_bytes, host_mean ? inter_bytes : (size_t)0) + mean_bytes, &h_out))) return rc;
     void* d_out = nullptr;
     if ((rc = fx_scratch(e, 1, inter_bytes + mean_bytes, &d_out))) return rc;
     float* d_NM = (float*)d_out;
@@ -1130,7 +1140,17 @@ int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii,
         FX_HIP(e, hipHostGetDevicePointer(&dm_out, h_out, 0));
         float* m_NM = (float*)dm_out;
         float* m_mean = (float*)((char*)dm_out + nm_bytes);
-        if (stride) {
+        if (host_mean) {
+            e->call_prof_ns[0] = server_since(e);
+            if ((rc = score_dispatch(e, models, M, (const uint8_t*)dm_in, N, L, m_NM, stride))) return rc;
+            e->call_prof_ns[1] = server_since(e);
+            FX_HIP(e, hipStreamSynchronize(e->stream));
+            e->call_prof_ns[2] = server_since(e);
+            if ((rc = check_deferred(e))) return rc;
+            host_mean_planes((const float*)h_out, stride, N, M, out_mean);
+            e->call_prof_ns[3] = server_since(e);
+            return FX_OK;
+        } else if (stride) {
             if ((rc = score_then_mean(e, models, M, (const uint8_t*)dm_in, N, L, d_NM, stride, m_mean))) return rc;
         } else {
             if ((rc = score_dispatch(e, models, M, (const uint8_t*)dm_in, N, L, out_NM ? m_NM : d_NM, stride))) return rc;

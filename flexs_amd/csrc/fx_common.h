@@ -235,6 +235,8 @@ struct fx_engine {
     int64_t serve_idle_us = 500;   // calls of the same ensemble closer than this start / keep the resident workgroups; they leave after twice this long without a request (a device-wide synchronize waits that long for them at most)
     int64_t serve_wide = 1;     // 1 = a resident generation takes (num_cus - serve_reserve_cus) / M tile slots per member and serves requests of up to 4096 sequences, a slot walking several tiles (0 = round 3's geometry: a third of the CUs, <= 16 slots, <= 256 sequences: A/B)
     int64_t serve_reserve_cus = 16;   // CUs a wide generation leaves without a resident workgroup (kernels of other streams -- RCCL, PyTorch -- find room there at once; small ones also fit beside a resident workgroup)
+    int64_t call_prof_ns[4] = {};    // the last launched small mean-only host call: ns since entry at "prepared", "launched", "synchronised", "mean taken"
+    int64_t host_mean_below = 256;   // launched mean-only host calls of at most this many sequences (zero-copy): member planes to pinned host memory, np.mean's order on the host, no mean launch (0 = the mean kernel: A/B)
     int64_t serve_quads = 1;    // wide generation, CNN with seq_len <= 8: tiles per resident workgroup side by side (1 = one; 3 = like the launched form: A/B build only -- slower once requests are streamed, csrc/OPTIONS.md)
     int64_t serve_fence = 0;    // 1 = a system fence after every tile's answers (round 3: ~0.5 us each, and the fences of one XCD serialise -- 24 us for the 378 tiles of a 2001-sequence request, profiles/r4_mailbox_probe3.log); 0 = none: the answers are system-scope stores, which write through by themselves (profiles/r4_mailbox_probe4.log)
     int64_t serve_poll_sleep = 8;     // s_sleep units (64 clocks each) between polls of the slots beyond FX_SERVE_FAST (0 = every slot spins)
@@ -263,6 +265,7 @@ struct fx_model {
     fx_engine* eng = nullptr;
     FxShape shape{};
     FxPackLayout layout{};
+    int64_t mfma_per_tile = -1; // fx_mfma_per_tile(shape), once (the host-call planner asks per call: a loop over the positions)
     std::vector<float> blob;    // host copy, Keras order
     float* d_blob = nullptr;    // device copy, Keras order (generic kernels)
     float* d_packed = nullptr;  // device copy, fragment layout (MFMA kernels)

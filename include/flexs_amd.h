@@ -118,6 +118,10 @@ const char *fx_last_error(fx_engine *e);
  *                              (they poll a copy of the request word on a line of its own).
  *   serve_fence       0        1 = round 3's system fence after every tile's answers (A/B; the answers are system-scope
  *                              stores, which write through by themselves).
+ *   host_mean_below   256      launched mean-only host calls of at most this many sequences (the protein CNN's explorer-size
+ *                              calls): member planes straight to pinned host memory, np.mean's order on the host, no mean
+ *                              launch; same bits.  0 = the mean kernel.  call_prof_0 .. _3 (read): that call's timeline, ns
+ *                              (prepared, launched, synchronised, mean taken).
  *   serve_quads       1        wide generation, 4-letter CNN with seq_len <= 8: tiles a resident workgroup answers side by
  *                              side.  3 (the launched form's three quads) is in the A/B build only: slower once requests
  *                              are streamed (fx_score_stream_*).

@@ -1818,6 +1818,39 @@ def _few_fallbacks(eng, before, what=""):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("L,M", [(90, 3), (237, 2), (33, 8), (40, 16)])
+def test_host_side_mean_of_small_launched_calls(eng, L, M):
+    """Launched mean-only host calls of at most `host_mean_below` sequences (the protein CNN's explorer-size calls): the member
+    planes are written straight to pinned host memory and np.mean over the members is taken on the host in NumPy's order -- the
+    SAME BITS as the mean kernel (host_mean_below = 0) and as np.mean over the stacked member scores; beside the oracle."""
+    members = [bm.CNN(L, 32, 100, s_utils.AAS, seed=200 + s) for s in range(M)]
+    ens = flexs_amd.Ensemble(members)
+    stack = flexs_amd.Ensemble(members, combine_with=lambda x: x)
+    try:
+        for n in (1, 5, 16, 40, 256, 257):
+            seqs = rand_seqs(n, L, s_utils.AAS, seed=77 + n)[1]
+            eng.set_option("host_mean_below", 0)
+            want = ens.get_fitness(seqs)
+            eng.set_option("host_mean_below", 256)
+            got = ens.get_fitness(seqs)
+            nm = stack.get_fitness(seqs)
+            assert np.array_equal(got, want), (L, M, n)
+            assert np.array_equal(got, np.mean(nm, axis=1)), (L, M, n)
+        seqs = rand_seqs(16, L, s_utils.AAS, seed=5)[1]
+        got_nm = stack.get_fitness(seqs)
+        for m in (0, M - 1):
+            ref = ref_np.keras_fitness(seqs, s_utils.AAS, "cnn", [np.asarray(w, np.float64) for w in members[m].model.get_weights()], exact=True)
+            assert_scores(got_nm[:, m], ref, f"host-mean call, member {m}, L={L}")
+        bad = list(seqs)
+        bad[3] = bad[3][:-1] + "!"
+        with pytest.raises(ValueError):
+            ens.get_fitness(bad)
+        assert np.array_equal(ens.get_fitness(seqs), np.mean(got_nm, axis=1))
+    finally:
+        eng.set_option("host_mean_below", 256)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind,L,alpha,M", [("cnn", 8, "TGCA", 3), ("mlp", 14, "UGCA", 1), ("ge", 14, "UGCA", 3), ("mix", 14, "UGCA", 3)])
 def test_resident_streamed_calls(eng, kind, L, alpha, M):
     """Round 4, streamed requests (fx_score_stream_*): get_fitness(list[str]) of at least _native.STREAM_MIN_ROWS strings posts its
