@@ -220,6 +220,9 @@ int fx_engine_create(int device, fx_engine** out) {
     FX_CREATE_HIP(hipEventCreate(&e->ev1));
     FX_CREATE_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_err), 64, hipHostMallocMapped));
     *e->h_err = 0;
+    FX_CREATE_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_done), 64, hipHostMallocMapped | hipHostMallocCoherent));
+    *e->h_done = 0;
+    FX_CREATE_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->d_done), e->h_done, 0));
     FX_CREATE_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->d_err), e->h_err, 0));
     FX_CREATE_HIP(hipMalloc(&e->d_lut, 256));
 #undef FX_CREATE_HIP
@@ -249,6 +252,7 @@ int fx_engine_destroy(fx_engine* e) {
     if (e->d_lut) (void)hipFree(e->d_lut);
     if (e->d_trace) (void)hipFree(e->d_trace);
     if (e->d_lp_bar) (void)hipFree(e->d_lp_bar);
+    if (e->h_done) (void)hipHostFree(e->h_done);
     for (int i = 0; i < fx_engine::MAX_PIECES; ++i) {
         if (e->ev_in[i]) (void)hipEventDestroy(e->ev_in[i]);
         if (e->ev_done[i]) (void)hipEventDestroy(e->ev_done[i]);
@@ -315,6 +319,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "serve_fence")) return &e->serve_fence;
     if (!std::strcmp(key, "serve_quads")) return &e->serve_quads;
     if (!std::strcmp(key, "host_mean_below")) return &e->host_mean_below;
+    if (!std::strcmp(key, "done_flag")) return &e->done_flag;
     if (!std::strcmp(key, "serve_idle_us")) return &e->serve_idle_us;
     if (!std::strcmp(key, "chunk_overlap")) return &e->chunk_overlap;
     if (!std::strcmp(key, "zero_copy_bytes")) return &e->zero_copy_bytes;
@@ -524,6 +529,7 @@ static int score_dispatch(fx_engine* e, fx_model* const* models, int M, const ui
             ++cnt;
         }
         int rc = FX_EUNSUPPORTED;
+        e->done_armed = false;                             // (only the LAST launch of a dispatch may offer the completion flag)
         if (!e->force_generic) {
             if (s0.kind == FX_CNN) {
                 rc = fx_launch_score_cnn_mfma(e, models + m0, cnt, d_ascii, N, d_NM, M, m0);
@@ -848,6 +854,28 @@ static void host_mean_planes(const float* pl, int64_t stride, int64_t N, int M, 
     }
 }
 
+// Wait for the results of the launches just enqueued on the engine's stream: the completion flag of the last launch where it
+// offers one (poll: the word is in pinned host memory), else -- or when the flag stays away for 2 s -- the stream itself.
+static int wait_for_results(fx_engine* e) {
+    if (e->done_armed && e->done_flag) {
+        const volatile unsigned* w = e->h_done;
+        const unsigned want = e->done_seq;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0; *w != want; ++spins) {
+            __builtin_ia32_pause();
+            if ((spins & 4095u) == 4095u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) {
+                FX_HIP(e, hipStreamSynchronize(e->stream));   // (a kernel that left through an error path never raises the flag)
+                break;
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    } else {
+        FX_HIP(e, hipStreamSynchronize(e->stream));
+    }
+    e->done_armed = false;
+    return FX_OK;
+}
+
 static int64_t server_since(const fx_engine* e) {
     return (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - e->server.t_entry).count();
 }
@@ -1144,7 +1172,7 @@ int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii,
             e->call_prof_ns[0] = server_since(e);
             if ((rc = score_dispatch(e, models, M, (const uint8_t*)dm_in, N, L, m_NM, stride))) return rc;
             e->call_prof_ns[1] = server_since(e);
-            FX_HIP(e, hipStreamSynchronize(e->stream));
+            if ((rc = wait_for_results(e))) return rc;
             e->call_prof_ns[2] = server_since(e);
             if ((rc = check_deferred(e))) return rc;
             host_mean_planes((const float*)h_out, stride, N, M, out_mean);
@@ -1152,11 +1180,15 @@ int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii,
             return FX_OK;
         } else if (stride) {
             if ((rc = score_then_mean(e, models, M, (const uint8_t*)dm_in, N, L, d_NM, stride, m_mean))) return rc;
+            e->done_armed = false;                         // (the mean kernel, or a fused mean, is the last writer)
         } else {
             if ((rc = score_dispatch(e, models, M, (const uint8_t*)dm_in, N, L, out_NM ? m_NM : d_NM, stride))) return rc;
-            if (out_mean && (rc = fx_launch_ensemble_reduce(e, out_NM ? m_NM : d_NM, N, M, nullptr, m_mean, nullptr))) return rc;
+            if (out_mean) {
+                if ((rc = fx_launch_ensemble_reduce(e, out_NM ? m_NM : d_NM, N, M, nullptr, m_mean, nullptr))) return rc;
+                e->done_armed = false;
+            }
         }
-        FX_HIP(e, hipStreamSynchronize(e->stream));
+        if ((rc = wait_for_results(e))) return rc;         // (the last launch's completion flag where it offers one, else the stream)
     } else {
         e->counters.bytes_h2d += (int64_t)in_bytes;
         e->counters.bytes_d2h += (int64_t)((out_mean ? mean_bytes : 0) + (out_NM ? nm_bytes : 0));

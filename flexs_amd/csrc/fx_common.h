@@ -12,7 +12,7 @@
 
 #define FX_MAX_M 16          // models fused per launch (larger ensembles are split)
 #define FX_ERR_BADCHAR 1u    // bit in the deferred device error word
-#define FX_LP_BAR_BYTES (17 * 128)   // barrier counters of the layer-parallel protein form: top + 16 groups, a 128-byte line each
+#define FX_LP_BAR_BYTES (18 * 128)   // barrier counters of the layer-parallel protein form: top + 16 groups, a 128-byte line each; line 17: units finished (completion flag)
 #define FX_ERR_TIMEOUT 2u    // a device-side barrier (layer-parallel protein form) was not passed in time
 // The resident form (score_cnn_quad.hip / score_dense_small.hip, SERVER).  Round 3: <= 16 tile slots per member on a third
 // of the CUs, one tile per slot and request -> 256 sequences.  Round 4 (engine option serve_wide): a generation may take
@@ -171,6 +171,14 @@ struct fx_engine {
     unsigned* d_lp_bar = nullptr;   // ... its barrier counter (only ever grows; lp_bar_total = what it reads after the launches enqueued so far)
     unsigned lp_bar_total[17] = {};   // [0] top, [1 + g] group g
     bool lp_launched = false;
+    // Completion flag (round 4): a kernel form that can tell when its LAST result has been written stores done_seq into a word
+    // of pinned host memory, and a small host call polls that word instead of hipStreamSynchronize -- launch-to-"the host
+    // knows" beyond the kernel's own time 11.1 -> 6.0 us (tools/probes/sync_latency_probe.hip).  done_armed: the last launch of
+    // the current dispatch does so (cleared before every launch group, set by the launcher).
+    unsigned* h_done = nullptr; unsigned* d_done = nullptr;
+    unsigned done_seq = 0;
+    bool done_armed = false;
+    int64_t done_flag = 1;           // option: 1 = poll the completion flag where a kernel offers one, 0 = always hipStreamSynchronize (A/B)
     int64_t cnn_quad = 1;       // 1 = small launches of the canonical 4-letter CNN with L <= 16 share a tile among four waves (score_cnn_quad.hip); 2 = whatever the size (test knob); 0 = off
     int64_t dma_fill = 1;       // 1 = weight images go global -> LDS directly (global_load_lds), all in flight at kernel start, the first layers start when THEIR part has landed (0 = through registers, whole image before the first tile: A/B)
     int64_t stage_fill = 1;     // 1 = CNN launches with fewer tiles than waves per workgroup load the conv part first and let the idle waves bring the head's weights (0 = whole image before the first tile: A/B)

@@ -46,6 +46,8 @@ struct PairArgs {
     f4* lp_out2;                // [unit][position][2 tiles][64 lanes]: conv2 outputs, between the two phases
     unsigned* lp_bar;           // grid barrier: counters that only ever grow, 128 bytes apart: [0] top, [1 + g] group g = block mod 16
     unsigned lp_target;         // this launch passes when the top counter reaches lp_target ...
+    unsigned* lp_done;          // completion flag in pinned host memory (or null): the unit that finishes LAST stores lp_done_seq there
+    unsigned lp_done_seq;
     unsigned lp_gtarget[16];    // ... and the LAST block of group g (the one that brings its counter to lp_gtarget[g]) arrives at the top
     int lp_nb;                  // position blocks (workgroups) per (member, tile) unit
     int lp_head_floats;         // dense head image: packed[off_d1 .. total_floats)
@@ -577,6 +579,9 @@ __global__ void __launch_bounds__(256) k_score_cnn_lp(PairArgs p) {
         }
     }
     if (p.lp_debug == 5) return;
+    // (a bad character is reported BEFORE the block takes its ticket, and performed system-wide: the host may read the error word
+    //  as soon as the last unit's completion flag is up)
+    if (bad) { fx_raise(p.err, FX_ERR_BADCHAR); __threadfence_system(); }
     // ---- the blocks of a unit meet in the zeroed pool; the last to arrive runs the dense head (as the SEG form)
     __syncthreads();                                          // (every wave's atomicMax has been performed: vmcnt(0); device-scope atomics need no fence)
     if (p.lp_debug == 6) return;
@@ -624,9 +629,21 @@ __global__ void __launch_bounds__(256) k_score_cnn_lp(PairArgs p) {
             float y[1];
             final_dot<HT, 1>(db + 32 * HT, db[48 * HT], h2v, y, g);
             if (g == 0 && n < p.N) p.out[n * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y[0]);
+            if (p.lp_done) {
+                // completion flag: this unit's scores performed system-wide (they may live in pinned host memory), then the count of
+                // finished units; the last one puts the counter back and raises the flag the host is polling
+                __threadfence_system();
+                if (lane == 0) {
+                    unsigned* done = p.lp_bar + 32 * 17;
+                    const unsigned t = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                    if (t + 1u == (unsigned)(p.M * p.TG)) {
+                        __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(p.lp_done, p.lp_done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+            }
         }
     }
-    if (bad) fx_raise(p.err, FX_ERR_BADCHAR);
 }
 
 // Launches the LP form when it applies: FX_EUNSUPPORTED otherwise (the caller carries on with the SEG / whole-sequence forms).
@@ -680,6 +697,12 @@ int launch_lp(fx_engine* e, PairArgs a, size_t lds_bytes) {
     a.lp_nb = (int)nb;
     a.lp_rows_a = rows_a;
     a.lp_debug = (int)e->cnn_lp_debug;
+    a.lp_done = nullptr;
+    if (e->done_flag && !a.lp_debug) {
+        if (++e->done_seq == 0) ++e->done_seq;
+        a.lp_done = e->d_done; a.lp_done_seq = e->done_seq;
+        e->done_armed = true;
+    }
     const int64_t G = U * nb;
     const bool arrives = !(a.lp_debug >= 1 && a.lp_debug <= 3);   // (profiling stages that leave before the barrier do not arrive at it)
     for (int gi = 0; gi < 16; ++gi) {

@@ -122,6 +122,9 @@ const char *fx_last_error(fx_engine *e);
  *                              calls): member planes straight to pinned host memory, np.mean's order on the host, no mean
  *                              launch; same bits.  0 = the mean kernel.  call_prof_0 .. _3 (read): that call's timeline, ns
  *                              (prepared, launched, synchronised, mean taken).
+ *   done_flag         1        1 = a launched small host call whose last kernel can tell when its last result is written (the
+ *                              layer-parallel protein CNN form) is waited for by polling a completion word in pinned host
+ *                              memory instead of hipStreamSynchronize: ~4 us of a 46 us call; 0 = always the stream.
  *   serve_quads       1        wide generation, 4-letter CNN with seq_len <= 8: tiles a resident workgroup answers side by
  *                              side.  3 (the launched form's three quads) is in the A/B build only: slower once requests
  *                              are streamed (fx_score_stream_*).

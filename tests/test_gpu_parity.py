@@ -1834,6 +1834,12 @@ def test_host_side_mean_of_small_launched_calls(eng, L, M):
             eng.set_option("host_mean_below", 256)
             got = ens.get_fitness(seqs)
             nm = stack.get_fitness(seqs)
+            # ... and whether the host polls the kernel's completion flag (default) or waits for the stream
+            eng.set_option("done_flag", 0)
+            assert np.array_equal(ens.get_fitness(seqs), got) and np.array_equal(stack.get_fitness(seqs), nm), (L, M, n)
+            eng.set_option("done_flag", 1)
+            for _ in range(3):                               # (back-to-back flagged calls: every one waits for ITS launch)
+                assert np.array_equal(ens.get_fitness(seqs), got), (L, M, n)
             assert np.array_equal(got, want), (L, M, n)
             assert np.array_equal(got, np.mean(nm, axis=1)), (L, M, n)
         seqs = rand_seqs(16, L, s_utils.AAS, seed=5)[1]
@@ -1848,6 +1854,7 @@ def test_host_side_mean_of_small_launched_calls(eng, L, M):
         assert np.array_equal(ens.get_fitness(seqs), np.mean(got_nm, axis=1))
     finally:
         eng.set_option("host_mean_below", 256)
+        eng.set_option("done_flag", 1)
 
 
 @pytest.mark.gpu
