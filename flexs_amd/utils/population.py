@@ -60,6 +60,7 @@ class PopulationEvaluator:
         self.alphabet = alphabet
         self.seq_len = seq_len
         self._members = _fused_members(model)
+        self._plan_key, self._plan, self._alpha = None, b"", b""
         if self._members is not None and (self._members[0].alphabet != alphabet or self._members[0].model.L != seq_len):
             raise ValueError("PopulationEvaluator: alphabet / seq_len differ from the model's")
 
@@ -92,6 +93,10 @@ class PopulationEvaluator:
         m0 = self._members[0]
         natives = [m.native() for m in self._members]
         single = len(natives) == 1 and self.model is m0
+        step = self._one_call(x, natives, single) if HOST_DECODE else None
+        if step is not None:
+            seqs, scores = step
+            return seqs, self._account(seqs, scores, known, values, single)
         chars = _decode_host(x, self.alphabet) if HOST_DECODE else None
         if chars is not None:
             nm, mean = m0._engine().score(natives, chars, m0._lut, want_matrix=single, want_mean=not single)
@@ -100,7 +105,39 @@ class PopulationEvaluator:
                                                         want_mean=not single)
         scores = nm[:, 0] if single else mean
         seqs = [r.tobytes().decode("latin-1") for r in chars]
+        return seqs, self._account(seqs, scores, known, values, single)
+
+    def _one_call(self, x: np.ndarray, natives, single: bool):
+        """argmax + scoring + the rows as str in ONE C call (csrc/strpack.c population_step) on an argument block cached per member
+        list; None when the helper is not built (the caller takes the step in pieces)."""
+        sp = _native._strpack
+        if sp is None or not hasattr(sp, "population_step"):
+            return None
+        key = (tuple(id(n) for n in natives), single)
+        if self._plan_key != key:
+            m0 = self._members[0]
+            self._plan = _native.small_plan(m0._engine(), natives, self.seq_len, m0._lut, want_mean=not single) or b""
+            self._plan_key = key
+            self._alpha = self.alphabet.encode("latin-1")
+        if not self._plan:
+            return None
+        x = np.ascontiguousarray(x, np.float64)
+        P, L, A = x.shape
+        chars = np.empty((P, L), np.uint8)
+        out = np.empty((P, 1) if single else (P,), np.float32)
+        st, seqs = sp.population_step(self._plan, x, P, A, self._alpha, chars, out)
+        if st == 1:
+            return None
+        if st:
+            _native._raise(-(st - 2000) if st > 2000 else st, self._members[0]._engine().handle)
+        return seqs, (out[:, 0] if single else out)
+
+    def _account(self, seqs, scores, known, values, single):
         fresh = 0
+        if not known:
+            values[:] = scores
+            fresh = len(seqs)
+            seqs = ()
         for i, seq in enumerate(seqs):
             hit = next((d for d in known if seq in d), None)
             if hit is not None:
@@ -112,7 +149,7 @@ class PopulationEvaluator:
         if not single:
             for m in self._members:
                 m.cost += fresh                                                # ensemble.py:55-57
-        return seqs, values
+        return values
 
 
 def terminal_rewards(evaluator: PopulationEvaluator, seen, states: np.ndarray, lam: float):

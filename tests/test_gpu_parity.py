@@ -1093,6 +1093,26 @@ def test_population_evaluator_equals_one_by_one_loop(eng, which):
     if which != "single":
         assert [m.cost for m in members] == [m.cost for m in twin_members] == [P - 3] * 3
     assert ev.evaluate(np.zeros((0, L * 4)))[0] == []
+    # no `known` dicts (DyNA-PPO's environment step): argmax + scoring + strings in one C call (strpack.population_step) == the step in
+    # pieces (host argmax, Engine.score, per-row str) == the device argmax form, values and cost
+    from flexs_amd.utils import population
+    c0 = model.cost
+    seqs1, vals1 = ev.evaluate(x)
+    assert seqs1 == want_seqs and model.cost == c0 + P
+    helper = _native._strpack.population_step if which != "host-stacked" and hasattr(_native._strpack, "population_step") else None
+    try:
+        if helper is not None:
+            del _native._strpack.population_step             # (the step in pieces)
+        seqs2, vals2 = ev.evaluate(x)
+        population.HOST_DECODE = False                       # (argmax on the device: fx_decode_score)
+        seqs3, vals3 = ev.evaluate(x)
+    finally:
+        population.HOST_DECODE = True
+        if helper is not None:
+            _native._strpack.population_step = helper
+    assert seqs2 == want_seqs and seqs3 == want_seqs
+    assert vals1.tolist() == vals2.tolist() == vals3.tolist()
+    assert vals1.tolist() == [twin.get_fitness([s_]).item() for s_ in want_seqs]
     if which != "host-stacked":
         with pytest.raises(ValueError):
             PopulationEvaluator(model, "UGCA", L)

@@ -568,6 +568,45 @@ def test_score_small_streams_through_the_plan():
     assert log == [("begin", 777, 1, 10, 4), ("end", 0)]                            # (found in the first piece: nothing was reported)
 
 
+@pytest.mark.parametrize("A", [2, 4, 7, 8, 9, 20, 23])
+def test_host_argmax_follows_numpys_rule(A):
+    """csrc/strpack.c decode_argmax (`one_hot_to_string`, flexs/utils/sequence_utils.py:50-66, for a population on the host): both
+    code paths -- four interleaved scalar rows (A < 8) and the 256-bit form -- pick what np.argmax picks: the FIRST maximum, a NaN
+    is a maximum (the first NaN wins), +0 / -0 are equal, infinities, constant rows; single-threaded and over the packing threads."""
+    from flexs_amd import _native
+
+    sp = _native._strpack
+    if sp is None or not hasattr(sp, "decode_argmax"):
+        pytest.skip("strpack helper not built")
+    alpha = bytes(range(65, 65 + A))
+    rng = np.random.default_rng(A)
+    x = rng.standard_normal((20000, A))
+    x[5] = 0.0
+    x[6, A - 1] = np.nan
+    x[7, :] = np.nan
+    x[8, 0] = -0.0; x[8, 1:] = -1.0
+    x[9] = x[9].max()
+    x[10, -1] = 1e300
+    x[11, A - 2] = np.inf; x[11, A - 1] = np.inf
+    x[12] = -np.inf
+    x[13, :] = -0.0; x[13, A // 2] = 0.0
+    x[14, 0] = np.nan; x[14, 1] = np.inf
+    x[100:200] = np.round(x[100:200])                    # many ties
+    x[200:300, 1::2] = np.nan                            # NaNs at odd positions: index 1 wins
+    want = np.frombuffer(alpha, np.uint8)[np.argmax(x, axis=1)]
+    for threads in (1, 0):
+        prev = sp.set_threads(threads)
+        try:
+            out = np.zeros(x.shape[0], np.uint8)
+            assert sp.decode_argmax(x, x.shape[0], A, alpha, out) == 0
+            assert np.array_equal(out, want), np.nonzero(out != want)[0][:10]
+            few = np.zeros(3, np.uint8)                  # fewer rows than one interleaved group
+            assert sp.decode_argmax(np.ascontiguousarray(x[5:8]), 3, A, alpha, few) == 0 and np.array_equal(few, want[5:8])
+        finally:
+            sp.set_threads(prev)
+    assert sp.decode_argmax(x, x.shape[0], A, alpha[:A - 1], out) == 1          # alphabet shorter than the rows: refused
+
+
 def test_rng_checkpoint_puts_numpys_global_stream_back():
     """noisy_abstract_model._rng_checkpoint (the fused NoisyAbstractModel batch draws before it knows whether the batch is
     its to answer): after restore() the global legacy RNG is exactly where it was -- also across the 624-word refill --
