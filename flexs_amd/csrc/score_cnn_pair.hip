@@ -585,18 +585,21 @@ __global__ void __launch_bounds__(256) k_score_cnn_lp(PairArgs p) {
     // ---- the blocks of a unit meet in the zeroed pool; the last to arrive runs the dense head (as the SEG form)
     __syncthreads();                                          // (every wave's atomicMax has been performed: vmcnt(0); device-scope atomics need no fence)
     if (p.lp_debug == 6) return;
-    if (tid == 0) flags[1] = (atomicAdd(&p.cnt[unit], 1u) == (unsigned)NB - 1u) ? 1 : 0;
+    // Every block brings the head's weights (dense blocks + vectors, ~54 KiB) into LDS -- the conv blocks are not needed any more --
+    // while its ticket makes the round trip to L2: the block that turns out to be the unit's last finds them in place instead of
+    // starting a 2.5 us fill after it knows (the others are finished anyway; their fills cost L2 reads nobody is waiting for).
+    unsigned ticket = 0;
+    if (tid == 0) ticket = atomicAdd(&p.cnt[unit], 1u);
+    const int head_floats = p.lp_head_floats;
+    fill_lds(reinterpret_cast<f4*>(smem), reinterpret_cast<const f4*>(p.w[m] + p.off_d1), head_floats / 4);
+    if (tid == 0) flags[1] = (ticket == (unsigned)NB - 1u) ? 1 : 0;
     __syncthreads();
     if (flags[1]) {
-        // the head's weights (dense blocks + vectors, ~54 KiB) into LDS by the whole workgroup -- the conv blocks are not needed
-        // any more -- instead of one wave streaming them from the L2 block row by block row (7 dependent round trips)
-        const int head_floats = p.lp_head_floats;
-        fill_lds(reinterpret_cast<f4*>(smem), reinterpret_cast<const f4*>(p.w[m] + p.off_d1), head_floats / 4);
-        __syncthreads();
         // fold the unit's LP_POOLS sub-pools (2 KiB each): thread t takes 16-byte word t mod 128 of eight of them -- all eight
         // loads in flight at once, past the non-coherent cache levels -- and puts the entries back to zero; the two halves meet
         // in LDS (non-negative floats order like their bits: integer max)
         f4* fold = reinterpret_cast<f4*>(smem + ((head_floats + 3) & ~3));      // [2 halves][128 words], behind the head's weights
+        f4* hx = fold + 256;                                                   // the head's exchange tiles: [HT] dense 1, [HT] dense 2
         {
             f4* base = reinterpret_cast<f4*>(p.pool) + (size_t)unit * LP_POOLS * 128 + (size_t)(tid >> 7) * 8 * 128 + (tid & 127);
             f4 v[8];
@@ -610,22 +613,60 @@ __global__ void __launch_bounds__(256) k_score_cnn_lp(PairArgs p) {
             fx_wait_vm(0);
         }
         __syncthreads();
+        if (tid == 0) __hip_atomic_store(&p.cnt[unit], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // The dense head over all four waves (round 4; one wave ran its 252 MFMAs alone before: 2.6 us of a 7 us head): wave w owns
+        // the output tiles {w, w + 4} of both layers, the tiles change hands through LDS -- the quad kernel's phases D / E / F.
+        // Per output tile the same operands in the same order as pair_dense_head: the same bits.
+        const f4* w_d1 = reinterpret_cast<const f4*>(smem);
+        const f4* w_d2 = reinterpret_cast<const f4*>(smem + (p.off_d2 - p.off_d1));
+        const float* db = smem + (p.off_db - p.off_d1);
+        {
+            f4 pooled[2];
+            pooled[0] = pool_max4(fold[lane], fold[128 + lane]);
+            pooled[1] = pool_max4(fold[64 + lane], fold[192 + lane]);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int to = wave + 4 * k;
+                if (to < HT) {
+                    f4 acc = *reinterpret_cast<const f4*>(&db[16 * to + 4 * g]);
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) {
+                        const f4 a = w_d1[(mi * HT + to) * 64 + lane];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc = mfma16(a[r], pooled[mi][r], acc);
+                    }
+                    hx[to * 64 + lane] = relu4(acc);
+                }
+            }
+        }
+        __syncthreads();
+        {
+            f4 h1v[HT];
+#pragma unroll
+            for (int mi = 0; mi < HT; ++mi) h1v[mi] = hx[mi * 64 + lane];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int to = wave + 4 * k;
+                if (to < HT) {
+                    f4 acc = *reinterpret_cast<const f4*>(&db[16 * HT + 16 * to + 4 * g]);
+#pragma unroll
+                    for (int mi = 0; mi < HT; ++mi) {
+                        const f4 a = w_d2[(mi * HT + to) * 64 + lane];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (mi == HT - 1 && r >= p.rlh) break;
+                            acc = mfma16(a[r], h1v[mi][r], acc);
+                        }
+                    }
+                    hx[(HT + to) * 64 + lane] = relu4(acc);
+                }
+            }
+        }
+        __syncthreads();
         if (wave == 0) {
-            f4 pooled[2][1];
-            pooled[0][0] = pool_max4(fold[lane], fold[128 + lane]);
-            pooled[1][0] = pool_max4(fold[64 + lane], fold[192 + lane]);
-            if (lane == 0) __hip_atomic_store(&p.cnt[unit], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // (pair_dense_head's arithmetic, operands from LDS)
-            const f4* w_d1 = reinterpret_cast<const f4*>(smem);
-            const f4* w_d2 = reinterpret_cast<const f4*>(smem + (p.off_d2 - p.off_d1));
-            const float* db = smem + (p.off_db - p.off_d1);
-            f4 h1v[HT][1], h2v[HT][1];
-            init_bias<HT, 1>(db, h1v, g);
-            mma_layer<2, HT, 1>(w_d1, pooled, h1v, lane);
-            relu_tiles<HT, 1>(h1v);
-            init_bias<HT, 1>(db + 16 * HT, h2v, g);
-            mma_layer<HT, HT, 1>(w_d2, h1v, h2v, lane, p.rlh);
-            relu_tiles<HT, 1>(h2v);
+            f4 h2v[HT][1];
+#pragma unroll
+            for (int mi = 0; mi < HT; ++mi) h2v[mi][0] = hx[(HT + mi) * 64 + lane];
             float y[1];
             final_dot<HT, 1>(db + 32 * HT, db[48 * HT], h2v, y, g);
             if (g == 0 && n < p.N) p.out[n * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y[0]);

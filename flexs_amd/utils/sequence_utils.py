@@ -91,10 +91,7 @@ def generate_random_sequences(length: int, number: int, alphabet: str) -> List[s
 
 def generate_random_mutant(sequence: str, mu: float, alphabet: str) -> str:
     """Each residue is redrawn with probability `mu` (sequence_utils.py:87-108)."""
-    mutant = []
-    for s in sequence:
-        if random.random() < mu:
-            mutant.append(random.choice(alphabet))
-        else:
-            mutant.append(s)
-    return "".join(mutant)
+    # (same draws in the same order as the reference's loop -- one random() per residue, one choice() per redrawn residue;
+    #  Adalead calls this a few thousand times per round, hence the local names and the comprehension)
+    rnd, choice = random.random, random.choice
+    return "".join([choice(alphabet) if rnd() < mu else s for s in sequence])

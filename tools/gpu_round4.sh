@@ -17,6 +17,7 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE -f csv -d $OUT/pmc_write -o r4 -- $P > $O
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE -f csv -d $OUT/pmc_sq -o r4 -- $P > $OUT/pmc_sq.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS -f csv -d $OUT/pmc_inst -o r4 -- $P > $OUT/pmc_inst.log 2>&1
 python tools/summarize_pmc.py $OUT/pmc_bench.json $OUT/pmc_bench.md fetch=$OUT/pmc_fetch write=$OUT/pmc_write sq=$OUT/pmc_sq inst=$OUT/pmc_inst > $OUT/pmc_bench_summary.log 2>&1
+# (back in the repo: python tools/flatten_pmc.py gpurun_out/r4f/pmc_bench.json profiles/r4_pmc_bench.json <commit>  -- the form bench.py reads)
 timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_lp -o lp -- python tools/runs/r4_lp_prof.py > $OUT/rocprof_lp.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_train -o tr -- python tools/runs/r3_train_prof.py > $OUT/rocprof_train.log 2>&1
 find $OUT -name "*counter_collection.csv" -size +2M -delete
