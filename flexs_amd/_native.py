@@ -55,6 +55,7 @@ SIGNATURES = {
     "fx_score_planes_dev": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _vp, C.c_int64, C.c_int, _u8p, _vp, C.c_int64]),
     "fx_ensemble_mean_planes_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64, _vp]),
     "fx_staging_input": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp)]),
+    "fx_train_orders": (C.c_int, [C.c_uint64, C.c_int64, C.c_int, _vp]),
     "fx_score_stream_begin": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int64, C.c_int, _u8p, C.POINTER(_vp)]),
     "fx_score_stream_rows": (C.c_int, [_vp, C.c_int64]),
     "fx_score_stream_end": (C.c_int, [_vp, C.c_int, _vp, _vp]),
@@ -758,6 +759,15 @@ class FxFitJob(C.Structure):
     _fields_ = [("kind", C.c_int), ("L", C.c_int), ("A", C.c_int), ("F", C.c_int), ("H", C.c_int), ("K", C.c_int),
                 ("weights", _vp), ("adam_m", _vp), ("adam_v", _vp), ("step", C.c_int64), ("order", _vp),
                 ("epochs", C.c_int), ("batch", C.c_int), ("keep", _vp), ("seed", C.c_uint64), ("step_loss", _vp)]
+
+
+def train_orders(seed: int, n: int, epochs: int) -> np.ndarray:
+    """fx_train_orders: (epochs, n) int32, one uniformly random permutation of 0 .. n - 1 per epoch, all from `seed` (host only)."""
+    out = np.empty((epochs, n), np.int32)
+    rc = lib().fx_train_orders(C.c_uint64(seed & (2 ** 64 - 1)), n, epochs, _ptr(out))
+    if rc:
+        raise ValueError(f"fx_train_orders failed ({rc})")
+    return out
 
 
 def train_fit(engine: Engine, jobs: List[dict], seq_bytes: np.ndarray, lut: np.ndarray, labels: np.ndarray):

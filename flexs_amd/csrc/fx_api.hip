@@ -384,6 +384,7 @@ int fx_engine_get_option(fx_engine* e, const char* key, int64_t* value) {
     if (e && key && !std::strcmp(key, "server_wide")) { *value = (e->server.running && e->server.wide) ? 1 : 0; return FX_OK; }
     if (e && key && !std::strncmp(key, "server_prof_", 12) && key[12] >= '0' && key[12] <= '7' && !key[13]) { *value = e->server.prof_ns[key[12] - '0']; return FX_OK; }
     if (e && key && !std::strncmp(key, "call_prof_", 10) && key[10] >= '0' && key[10] <= '3' && !key[11]) { *value = e->call_prof_ns[key[10] - '0']; return FX_OK; }
+    if (e && key && !std::strncmp(key, "train_prof_", 11) && key[11] >= '0' && key[11] <= '4' && !key[12]) { *value = e->train_prof_ns[key[11] - '0']; return FX_OK; }
     if (e && key && !std::strcmp(key, "server_streamed")) { *value = e->server.streamed; return FX_OK; }
     if (e && key && !std::strcmp(key, "server_slots")) { *value = e->server.running ? e->server.tiles : 0; return FX_OK; }
     int64_t* s = option_slot(e, key);

@@ -140,6 +140,7 @@ struct fx_engine {
     size_t scratch_bytes[5] = {0, 0, 0, 0, 0};
     void* d_train = nullptr;      // fx_train_fit arena (grown on demand, kept between fits)
     size_t train_bytes = 0;
+    int64_t train_prof_ns[5] = {};   // the last fx_train_fit: ns since entry at "image filled", "upload enqueued", "launches enqueued", "synchronised", "results copied out"
     void* h_train = nullptr;      // pinned host image of the arena's uploaded regions (train.hip)
     size_t train_host_bytes = 0;
     void* d_zero_pool = nullptr;  // fx_zero_pool: all-zero between launches (the kernels that use it clean up after themselves)

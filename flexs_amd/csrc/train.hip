@@ -203,6 +203,8 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
                  const float* labels) {
     if (!e) return FX_EINVAL;
     if (!jobs || M < 1 || M > 64 || !lut || n < 0 || L < 1) return fx_fail(e, FX_EINVAL, "fx_train_fit: bad arguments");
+    const auto t_entry = std::chrono::steady_clock::now();
+    auto since = [&]() { return (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_entry).count(); };
     if (n == 0) return FX_OK;
     if (!ascii || !labels) return fx_fail(e, FX_EINVAL, "fx_train_fit: null data");
     if (n > (int64_t)1 << 30) return fx_fail(e, FX_EINVAL, "fx_train_fit: data set too large");
@@ -391,7 +393,9 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
     }
     for (FxtJob& j : hj) j.agent_io = persistent ? 1 : 0;
     std::memcpy(image(d_jobs), hj.data(), sizeof(FxtJob) * (size_t)M);
+    e->train_prof_ns[0] = since();
     FX_HIP(e, hipMemcpyAsync(e->d_train, e->h_train, bytes_ab, hipMemcpyHostToDevice, st));      // regions A + B, one copy
+    e->train_prof_ns[1] = since();
 
     const dim3 grid_fb((unsigned)max_S, (unsigned)M), grid_adam((unsigned)((max_P + 255) / 256), (unsigned)M);
     if (lds_bytes > 48 * 1024) {
@@ -413,8 +417,10 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
         }
         FX_HIP(e, hipGetLastError());
     }
+    e->train_prof_ns[2] = since();
     FX_HIP(e, hipMemcpyAsync(e->h_train, e->d_train, bytes_a, hipMemcpyDeviceToHost, st));         // region A, one copy
     FX_HIP(e, hipStreamSynchronize(st));
+    e->train_prof_ns[3] = since();
     if (h_abort) return fx_fail(e, FX_ESTATE, "fx_train_fit: a step barrier of the one-launch fit was not passed within 2 s (workgroups not co-resident?); "
                                               "set the engine option train_persistent = 0 for a launch per step");
     for (int m = 0; m < M; ++m) {
@@ -426,6 +432,44 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
         if (jobs[m].step_loss && j.total_steps > 0) std::memcpy(jobs[m].step_loss, image(j.step_loss), sizeof(float) * (size_t)j.total_steps);
         jobs[m].step += hj[(size_t)m].total_steps;
         e->counters.train_steps += hj[(size_t)m].total_steps;
+    }
+    e->train_prof_ns[4] = since();
+    return FX_OK;
+}
+
+// Epoch shuffles of one fit: see include/flexs_amd.h.
+int fx_train_orders(uint64_t seed, int64_t n, int epochs, int32_t* out) {
+    if (n < 0 || n > ((int64_t)1 << 30) || epochs < 0 || (!out && n > 0 && epochs > 0)) return FX_EINVAL;
+    uint64_t s[4];
+    for (int i = 0; i < 4; ++i) {                          // splitmix64: four state words that are never all zero
+        uint64_t z = (seed += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        s[i] = z ^ (z >> 31);
+    }
+    auto rotl = [](uint64_t x, int k) { return (x << k) | (x >> (64 - k)); };
+    auto next = [&]() {                                    // xoshiro256**
+        const uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+        s[2] ^= t; s[3] = rotl(s[3], 45);
+        return r;
+    };
+    auto below = [&](uint64_t bound) {                     // uniform in [0, bound): multiply-high with rejection (Lemire)
+        unsigned __int128 m = (unsigned __int128)next() * bound;
+        uint64_t lo = (uint64_t)m;
+        if (lo < bound) {
+            const uint64_t floor = (0 - bound) % bound;
+            while (lo < floor) { m = (unsigned __int128)next() * bound; lo = (uint64_t)m; }
+        }
+        return (uint64_t)(m >> 64);
+    };
+    for (int e_ = 0; e_ < epochs; ++e_) {
+        int32_t* p = out + (int64_t)e_ * n;
+        for (int64_t i = 0; i < n; ++i) p[i] = (int32_t)i;
+        for (int64_t i = n - 1; i > 0; --i) {
+            const int64_t j = (int64_t)below((uint64_t)i + 1);
+            const int32_t t = p[i]; p[i] = p[j]; p[j] = t;
+        }
     }
     return FX_OK;
 }

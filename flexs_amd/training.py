@@ -27,7 +27,7 @@ Round 3: on a GPU the fit runs in hand-written HIP (`fx_train_fit`, csrc/train_c
 train.hip): per mini-batch step ONE forward+backward launch over (row slices x ensemble
 members) and ONE Adam launch, every contraction on v_mfma_f32_16x16x4_f32, all steps of
 all members enqueued back to back from C.  The host only draws the shuffles (one
-`torch.randperm` per epoch and member, as before) and keeps weights / moments / step count
+`fx_train_orders` call per member) and keeps weights / moments / step count
 on the `Architecture`.  FLEXS_AMD_TRAIN=graph | eager selects the PyTorch paths below
 instead (captured hipGraph step / plain eager step); without a GPU the eager PyTorch step
 runs on the CPU (training is not the scored hot path; the trained weights are then
@@ -95,6 +95,15 @@ def _mask_generator(gen, device):
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     return g
+
+
+def _epoch_orders(gen, n: int, epochs: int) -> np.ndarray:
+    """The fit's epoch shuffles, (epochs, n) int32: ONE draw from the fit's generator seeds them all (csrc/train.hip
+    fx_train_orders: 60 shuffles of 1000 rows in 0.12 ms; one `torch.randperm` per epoch and member was 0.5 ms of a 3.6 ms
+    Ensemble.train).  Every path -- native, captured graph, eager -- takes its orders from here, after the draw that seeds its
+    dropout stream, so a seeded fit shuffles identically on all of them."""
+    seed = int(torch.randint(0, 2 ** 62, (1,), generator=gen).item())
+    return _native.train_orders(seed, n, epochs)
 
 
 def _draw_mask(out, gen):
@@ -324,7 +333,7 @@ def _unflat(flat, shapes):
     out, off = [], 0
     for sh in shapes:
         k = math.prod(sh)                                 # (np.prod costs 7 us per call: 0.75 ms of a 3-member fit)
-        out.append(flat[off:off + k].reshape(sh).copy())
+        out.append(flat[off:off + k].reshape(sh))          # (views: the flat array is this fit's own and lives on in them)
         off += k
     return out
 
@@ -334,7 +343,7 @@ _NATIVE_MAX_MEMBERS = 64          # members per fx_train_fit call (csrc/train.hi
 
 def _fit_native(archs, sequences, labels, alphabet, batch_sizes, epochs, verbose, gens):
     """One `fx_train_fit` call for members that share the alphabet and the sequence length: every member's shuffles come
-    from its own generator (one `randperm` per epoch, after the one draw that seeds its dropout stream -- the same
+    from its own generator (`_epoch_orders`, after the one draw that seeds its dropout stream -- the same
     consumption as the PyTorch paths, so a seeded fit shuffles identically on every path)."""
     n, L = len(sequences), archs[0].L
     seq_bytes = _native.sequences_to_bytes(sequences, L=L)
@@ -348,8 +357,7 @@ def _fit_native(archs, sequences, labels, alphabet, batch_sizes, epochs, verbose
         steps = (n + B - 1) // B
         seed = int(torch.randint(0, 2 ** 62, (1,), generator=gen).item())
         order = np.full((ep, steps * B), -1, np.int32)
-        for e_ in range(ep):
-            order[e_, :n] = torch.randperm(n, generator=gen).numpy()
+        order[:, :n] = _epoch_orders(gen, n, ep)
         w, m, v, t = _flat_state(arch)
         flats.append((w, m, v))
         jobs.append({"kind": _KIND[arch.kind], "L": L, "A": arch.A, "F": arch.F, "H": arch.H, "K": arch.K, "weights": w,
@@ -391,9 +399,10 @@ def fit(arch, sequences, labels, alphabet, batch_size=256, epochs=20, verbose=Fa
     params = [torch.tensor(w, device=device, requires_grad=True) for w in arch._weights]
     opt = KerasAdam(params, getattr(arch, "_opt_state", None))       # moments and step count of the previous rounds
     mask_gen = _mask_generator(gen, device)
+    orders = _epoch_orders(gen, n, epochs)
     mask_buf = torch.ones((int(batch_size), arch.H), dtype=torch.float32, device=device) if arch.kind == "cnn" else None
     for epoch in range(epochs):
-        perm = torch.randperm(n, generator=gen).to(device)
+        perm = torch.from_numpy(orders[epoch].astype(np.int64)).to(device)
         total = 0.0
         for i in range(0, n, batch_size):
             idx = perm[i:i + batch_size]
@@ -430,6 +439,7 @@ class _GraphedFit:
             _TRAINERS[arch] = tr
         self.tr = tr
         self.mask_gen = _mask_generator(gen, device)
+        self.orders = _epoch_orders(gen, n, epochs)
         self.steps = (n + B - 1) // B
         with torch.no_grad():
             tr.load(arch._weights, getattr(arch, "_opt_state", None))
@@ -442,7 +452,7 @@ class _GraphedFit:
 
     def start_epoch(self):
         perm = torch.zeros((self.steps * self.B,), dtype=torch.int64)
-        perm[:self.n] = torch.randperm(self.n, generator=self.gen)
+        perm[:self.n] = torch.from_numpy(self.orders[self.epoch].astype(np.int64))
         self.perm = perm.to(self.device, non_blocking=True)
 
     @torch.no_grad()

@@ -376,6 +376,13 @@ typedef struct fx_fit_job {
  * FX_EBADCHAR for a character outside the alphabet (ValueError in the reference's encode loop). */
 int fx_train_fit(fx_engine *e, fx_fit_job *jobs, int M, const uint8_t *ascii, int64_t n, int L,
                  const uint8_t lut[256], const float *labels);
+/* The epoch shuffles of one fit (`model.fit(..., shuffle=True)`, keras_model.py:62-66 -- Keras draws them from its own
+ * generator; any uniform shuffle is the same training procedure): out[e * n .. (e + 1) * n) = a uniformly random permutation of
+ * 0 .. n - 1 for every epoch e, all derived from `seed` (Fisher-Yates over xoshiro256** seeded through splitmix64, unbiased
+ * bounded draws).  Host only, no engine: 60 shuffles of 1000 rows take 0.12 ms here against 0.5 ms of torch.randperm calls --
+ * a seventh of a three-member fit.  Every training path of the Python package (fx_train_fit, the captured-graph and the eager
+ * PyTorch steps) takes its orders from here, so a seeded fit shuffles identically on all of them. */
+int fx_train_orders(uint64_t seed, int64_t n, int epochs, int32_t *out);
 
 /* ------------------------------------------------------------ test hooks */
 /* Host-only (no GPU needed): expose the weight packing (Keras order -> MFMA

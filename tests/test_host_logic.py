@@ -607,6 +607,34 @@ def test_host_argmax_follows_numpys_rule(A):
     assert sp.decode_argmax(x, x.shape[0], A, alpha[:A - 1], out) == 1          # alphabet shorter than the rows: refused
 
 
+def test_epoch_orders_are_uniform_permutations():
+    """fx_train_orders (the fit's epoch shuffles): every row is a permutation of 0 .. n - 1, a function of the seed alone, different
+    from epoch to epoch and seed to seed; every position receives every row about equally often (a coarse chi-square over many
+    shuffles of a short range -- catches a biased bounded draw or an off-by-one in the Fisher-Yates bounds); edge sizes."""
+    from flexs_amd import _native
+
+    a = _native.train_orders(12345, 1000, 20)
+    assert a.shape == (20, 1000) and a.dtype == np.int32
+    assert all(np.array_equal(np.sort(r), np.arange(1000)) for r in a)
+    assert np.array_equal(a, _native.train_orders(12345, 1000, 20))
+    assert np.array_equal(a[:5], _native.train_orders(12345, 1000, 5))            # (epochs come in sequence from the one stream)
+    assert len({r.tobytes() for r in a}) == 20
+    assert not np.array_equal(a, _native.train_orders(12346, 1000, 20))
+    assert _native.train_orders(1, 0, 3).shape == (3, 0) and _native.train_orders(1, 5, 0).shape == (0, 5)
+    assert np.array_equal(_native.train_orders(7, 1, 4), np.zeros((4, 1), np.int32))
+    n, reps = 7, 70000
+    s = _native.train_orders(99, n, reps)
+    counts = np.zeros((n, n))
+    for pos in range(n):
+        counts[pos] = np.bincount(s[:, pos], minlength=n)
+    expected = reps / n
+    chi2 = ((counts - expected) ** 2 / expected).sum()                              # 36 degrees of freedom: mean 36, sd 8.5
+    assert chi2 < 36 + 6 * 8.5, chi2
+    pairs = np.bincount(s[:, 0] * n + s[:, 1], minlength=n * n).reshape(n, n)     # first two positions jointly: n (n - 1) cells
+    off = pairs[~np.eye(n, dtype=bool)]
+    assert pairs.trace() == 0 and ((off - reps / (n * (n - 1))) ** 2 / (reps / (n * (n - 1)))).sum() < 41 + 6 * 9.1
+
+
 def test_rng_checkpoint_puts_numpys_global_stream_back():
     """noisy_abstract_model._rng_checkpoint (the fused NoisyAbstractModel batch draws before it knows whether the batch is
     its to answer): after restore() the global legacy RNG is exactly where it was -- also across the 624-word refill --
