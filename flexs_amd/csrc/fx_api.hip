@@ -887,6 +887,10 @@ static int server_admit(fx_engine* e, fx_model* const* models, int M, int64_t N,
     auto& sv = e->server;
     sv.t_entry = std::chrono::steady_clock::now();
     auto since = [&]() { return server_since(e); };
+    if (sv.streaming) {                                    // a streamed call that was never closed (fx_score_stream_end): abandoned
+        sv.streaming = false;
+        server_stop(e);
+    }
     if (!e->serve_small || e->trace || e->force_generic || N < 1 || N > FX_SERVE_CAP || N * L > FX_SERVE_BYTES || M > FX_MAX_M) return FX_EUNSUPPORTED;
     bool same = sv.running && (int)sv.models.size() == M && sv.L == L && std::memcmp(sv.lut, lut, 256) == 0;
     for (int m = 0; same && m < M; ++m) same = sv.models[m] == models[m] && sv.versions[m] == models[m]->version;
