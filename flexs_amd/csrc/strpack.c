@@ -443,6 +443,85 @@ static PyObject* population_step(PyObject* self, PyObject* args) {
     return Py_BuildValue("(lN)", status, list);
 }
 
+/* adalead_children(nodes, mu, alphabet, seen_before, seen_now, random, getrandbits) -> (child_idxs, children) | None
+ * One tree level of Adalead's roll-outs (flexs/baselines/explorers/adalead.py:128-150, flexs_amd/utils/rollouts.py _children): a
+ * child per node -- the parent of child number k is nodes[k - 1], so the first child descends from the LAST node -- drawn again
+ * until it is in neither `seen_before` (a set) nor `seen_now` (a dict).  A child is generate_random_mutant(node, mu, alphabet)
+ * (sequence_utils.py:87-108): per residue one random(); below mu the residue becomes random.choice(alphabet), i.e.
+ * alphabet[_randbelow(len(alphabet))] with _randbelow(n) = getrandbits(n.bit_length()) redrawn until it is below n.
+ * EVERY draw goes through the two callables the caller passes (the `random` module's own bound methods): the module's stream is
+ * consumed exactly as the Python loop consumes it -- the explorer traces generated by the reference pin that.  The loop itself
+ * (41 % of a round: ~1.2 us per mutant in Python) is what moves to C.  None: an argument this path does not handle (the caller
+ * runs the Python loop). */
+static PyObject* adalead_children(PyObject* self, PyObject* args) {
+    PyObject *nodes, *alphabet, *seen_before, *seen_now, *rnd, *bits;
+    double mu;
+    (void)self;
+    if (!PyArg_ParseTuple(args, "OdOOOOO", &nodes, &mu, &alphabet, &seen_before, &seen_now, &rnd, &bits)) return NULL;
+    if (!PyList_CheckExact(nodes) || !PyUnicode_Check(alphabet) || !PyAnySet_CheckExact(seen_before) || !PyDict_CheckExact(seen_now) ||
+        PyUnicode_READY(alphabet) < 0 || PyUnicode_KIND(alphabet) != PyUnicode_1BYTE_KIND)
+        Py_RETURN_NONE;
+    const Py_ssize_t n_nodes = PyList_GET_SIZE(nodes), n_alpha = PyUnicode_GET_LENGTH(alphabet);
+    if (n_alpha < 1 || n_alpha > 255) Py_RETURN_NONE;
+    const unsigned char* alpha = PyUnicode_1BYTE_DATA(alphabet);
+    int k_bits = 0;
+    for (Py_ssize_t t = n_alpha; t; t >>= 1) ++k_bits;                 /* n.bit_length() */
+    for (Py_ssize_t i = 0; i < n_nodes; ++i) {
+        PyObject* nd = PyList_GET_ITEM(nodes, i);
+        if (!PyTuple_CheckExact(nd) || PyTuple_GET_SIZE(nd) != 2 || !PyUnicode_Check(PyTuple_GET_ITEM(nd, 1)) ||
+            PyUnicode_READY(PyTuple_GET_ITEM(nd, 1)) < 0 || PyUnicode_KIND(PyTuple_GET_ITEM(nd, 1)) != PyUnicode_1BYTE_KIND ||
+            PyUnicode_GET_LENGTH(PyTuple_GET_ITEM(nd, 1)) > 4096)
+            Py_RETURN_NONE;
+    }
+    PyObject* k_obj = PyLong_FromLong(k_bits);
+    PyObject* idxs = PyList_New(0);
+    PyObject* children = PyList_New(0);
+    if (!k_obj || !idxs || !children) goto fail;
+    unsigned char buf[4096];
+    while (PyList_GET_SIZE(children) < n_nodes) {
+        const Py_ssize_t have = PyList_GET_SIZE(children);
+        PyObject* nd = PyList_GET_ITEM(nodes, have == 0 ? n_nodes - 1 : have - 1);      /* nodes[len(children) - 1] */
+        PyObject* node = PyTuple_GET_ITEM(nd, 1);
+        const Py_ssize_t L = PyUnicode_GET_LENGTH(node);
+        const unsigned char* src = PyUnicode_1BYTE_DATA(node);
+        const double mu_eff = mu * 1 / (double)L;                        /* mu * 1 / len(node), evaluated as Python does */
+        for (Py_ssize_t j = 0; j < L; ++j) {
+            PyObject* r = PyObject_CallNoArgs(rnd);
+            if (!r) goto fail;
+            const double x = PyFloat_AsDouble(r);
+            Py_DECREF(r);
+            if (x == -1.0 && PyErr_Occurred()) goto fail;
+            if (x < mu_eff) {
+                long pick;
+                do {
+                    PyObject* b = PyObject_CallOneArg(bits, k_obj);
+                    if (!b) goto fail;
+                    pick = PyLong_AsLong(b);
+                    Py_DECREF(b);
+                    if (pick == -1 && PyErr_Occurred()) goto fail;
+                } while (pick >= n_alpha);
+                buf[j] = alpha[pick];
+            } else {
+                buf[j] = src[j];
+            }
+        }
+        PyObject* child = PyUnicode_DecodeLatin1((const char*)buf, L, NULL);
+        if (!child) goto fail;
+        int seen = PySet_Contains(seen_before, child);
+        if (seen == 0) seen = PyDict_Contains(seen_now, child);
+        if (seen < 0) { Py_DECREF(child); goto fail; }
+        if (seen == 0) {
+            if (PyList_Append(idxs, PyTuple_GET_ITEM(nd, 0)) < 0 || PyList_Append(children, child) < 0) { Py_DECREF(child); goto fail; }
+        }
+        Py_DECREF(child);
+    }
+    Py_DECREF(k_obj);
+    return Py_BuildValue("(NN)", idxs, children);
+fail:
+    Py_XDECREF(k_obj); Py_XDECREF(idxs); Py_XDECREF(children);
+    return NULL;
+}
+
 static PyObject* set_threads(PyObject* self, PyObject* args) {
     int n;
     if (!PyArg_ParseTuple(args, "i", &n)) return NULL;
@@ -458,6 +537,7 @@ static PyMethodDef methods[] = {
     {"score_small", score_small, METH_VARARGS, "score_small(plan, seqs, out) -> 0 ok, -1 not applicable, 1001..1003 packing status, FX error code (2000 + |code| if negative)"},
     {"decode_argmax", decode_argmax, METH_VARARGS, "decode_argmax(x_float64, rows, A, alphabet_bytes, out_uint8) -> 0 ok, 1 bad arguments: out[r] = alphabet[argmax of row r] (NumPy's first-max / NaN rule)"},
     {"population_step", population_step, METH_VARARGS, "population_step(plan, x_float64, rows, A, alphabet_bytes, chars_uint8, scores_float32) -> (status, list of str | None): argmax decode + fx_score through the plan + the rows as str"},
+    {"adalead_children", adalead_children, METH_VARARGS, "adalead_children(nodes, mu, alphabet, seen_before_set, seen_now_dict, random.random, random.getrandbits) -> (child_idxs, children) | None: one tree level of Adalead's roll-outs, every draw through the two callables"},
     {"set_threads", set_threads, METH_VARARGS, "set_threads(n) -> previous setting; 0 = auto (min(8, cores / 2)), 1 = single-threaded"},
     {NULL, NULL, 0, NULL}};
 

@@ -50,7 +50,7 @@ def recombine_population(gen: List[str], recomb_rate: float) -> List[str]:
     return ret
 
 
-def _children(nodes, mu, alphabet, seen_before, seen_now):
+def _children_py(nodes, mu, alphabet, seen_before, seen_now):
     """One tree level (adalead.py:128-150): a child per node, re-drawn until it is new.  The reference takes the
     parent of child number k from `nodes[k - 1]` (so the first child descends from the LAST node): kept."""
     child_idxs, children = [], []
@@ -61,6 +61,54 @@ def _children(nodes, mu, alphabet, seen_before, seen_now):
             child_idxs.append(idx)
             children.append(child)
     return child_idxs, children
+
+
+def _c_children_ok() -> bool:
+    """Is csrc/strpack.c adalead_children usable here?  It makes every draw through `random.random` / `random.getrandbits`, on the
+    assumption that `random.choice(seq)` is `seq[_randbelow(len(seq))]` with `_randbelow(n)` = `getrandbits(n.bit_length())` redrawn
+    until below n (CPython 3.8-3.13).  Checked once, on a private copy of nothing: the same seeded state through both loops must
+    give the same children AND leave the generator in the same state; the module's state is put back afterwards."""
+    from flexs_amd import _native
+
+    sp = _native._strpack
+    if sp is None or not hasattr(sp, "adalead_children"):
+        return False
+    saved = random.getstate()
+    try:
+        ok = True
+        for seed, alphabet, L in ((11, "TGCA", 8), (12, "ILVAGMFYWEDQNHCRKSTP", 30), (13, "ABC", 5), (14, "AB", 3)):
+            rnd = random.Random(seed)
+            nodes = [(i, "".join(rnd.choice(alphabet) for _ in range(L))) for i in range(7)]
+            before = {nodes[2][1]}
+            now = {nodes[4][1]: 0.5}
+            random.seed(seed)
+            want = _children_py(nodes, 3, alphabet, before, now)
+            state_want = random.getstate()
+            random.seed(seed)
+            got = sp.adalead_children(nodes, 3, alphabet, before, now, random.random, random.getrandbits)
+            ok = ok and got is not None and (list(got[0]), list(got[1])) == want and random.getstate() == state_want
+        return ok
+    except Exception:  # noqa: BLE001 -- whatever goes wrong, the Python loop is the answer
+        return False
+    finally:
+        random.setstate(saved)
+
+
+_C_CHILDREN = None
+
+
+def _children(nodes, mu, alphabet, seen_before, seen_now):
+    """`_children_py` in C when the helper is built and passes its self-check (same children, same `random` stream)."""
+    global _C_CHILDREN
+    if _C_CHILDREN is None:
+        _C_CHILDREN = _c_children_ok()
+    if _C_CHILDREN:
+        from flexs_amd import _native
+
+        out = _native._strpack.adalead_children(nodes, mu, alphabet, seen_before, seen_now, random.random, random.getrandbits)
+        if out is not None:
+            return out
+    return _children_py(nodes, mu, alphabet, seen_before, seen_now)
 
 
 def adalead_round(model, measured_sequences: Sequence[str], measured_scores: Sequence[float], *, sequences_batch_size: int,

@@ -607,6 +607,48 @@ def test_host_argmax_follows_numpys_rule(A):
     assert sp.decode_argmax(x, x.shape[0], A, alpha[:A - 1], out) == 1          # alphabet shorter than the rows: refused
 
 
+def test_adalead_children_in_c_consume_the_random_stream_like_the_python_loop():
+    """csrc/strpack.c adalead_children (one tree level of Adalead's roll-outs, adalead.py:128-150): the same children, parents and
+    -- after every call -- the same state of Python's `random` generator as the Python loop it replaces, for several alphabets
+    (power-of-two and not: `_randbelow`'s redraws), mutation rates, re-draws of children that were seen before; arguments it does
+    not handle are handed back (None)."""
+    import random
+
+    from flexs_amd import _native
+    from flexs_amd.utils import rollouts
+
+    sp = _native._strpack
+    if sp is None or not hasattr(sp, "adalead_children"):
+        pytest.skip("strpack helper not built")
+    assert rollouts._c_children_ok()
+    saved = random.getstate()
+    try:
+        for seed, alphabet, L, mu, n_nodes in ((1, "TGCA", 8, 1, 20), (2, "ILVAGMFYWEDQNHCRKSTP", 40, 2, 13), (3, "ABC", 4, 1, 9),
+                                               (4, "AB", 3, 1, 4), (5, "ACGTN", 12, 5, 1), (6, "UGCA", 14, 0.5, 30)):
+            rnd = random.Random(seed)
+            nodes = [(i, "".join(rnd.choice(alphabet) for _ in range(L))) for i in range(n_nodes)]
+            before = {s_ for _, s_ in nodes[::2]}
+            now = {s_: 0.0 for _, s_ in nodes[1::3]}
+            random.seed(seed)
+            want, states = [], []
+            for _ in range(5):                               # consecutive levels share the stream
+                want.append(rollouts._children_py(nodes, mu, alphabet, before, now))
+                states.append(random.getstate())
+            random.seed(seed)
+            for w, st in zip(want, states):
+                got = sp.adalead_children(nodes, mu, alphabet, before, now, random.random, random.getrandbits)
+                assert (list(got[0]), list(got[1])) == w and random.getstate() == st
+                assert all(c not in before and c not in now for c in got[1])
+        nodes = [(0, "ACGT")]
+        assert sp.adalead_children(tuple(nodes), 1, "ACGT", set(), {}, random.random, random.getrandbits) is None    # not a list
+        assert sp.adalead_children(nodes, 1, "ACGT", [], {}, random.random, random.getrandbits) is None              # not a set
+        assert sp.adalead_children([(0, "AC\u1234T")], 1, "ACGT", set(), {}, random.random, random.getrandbits) is None
+        with pytest.raises(ZeroDivisionError):
+            sp.adalead_children(nodes, 1, "ACGT", set(), {}, lambda: 1 / 0, random.getrandbits)                      # the callable's error comes through
+    finally:
+        random.setstate(saved)
+
+
 def test_epoch_orders_are_uniform_permutations():
     """fx_train_orders (the fit's epoch shuffles): every row is a permutation of 0 .. n - 1, a function of the seed alone, different
     from epoch to epoch and seed to seed; every position receives every row about equally often (a coarse chi-square over many
