@@ -403,7 +403,7 @@ def end_to_end_block(device, configs=None):
             t = float(np.median(ts))
             out["C2 3xCNN L=8 ndarray_S"] = {"value": n / t, "unit": "sequences/s", "wall_ms": t * 1e3}
             # small-call latency at N in {1, 4, 20, 100, 2001}, host strings -> host scores, median of 200 calls;
-            # resident form (up to 256 sequences) beside a launch per call (serve_small = 0: the form of rounds 1-2)
+            # resident form (narrow generation up to 256 sequences, wide up to 4096, streamed from 384) beside a launch per call (serve_small = 0: the form of rounds 1-2)
             eng = mods[0]._engine()
 
             def call_us(batch):

@@ -181,7 +181,8 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
                 const int64_t srv_rows = Ncur - tg * 16 < 16 ? Ncur - tg * 16 : 16;
                 const int qt = tid & 255;
                 if (live && (int64_t)qt * 4 < srv_rows * L) {
-                    if (!fx_server_rows_ready(p.min, srv_req, tg * 16 + srv_rows)) srv_abandon = 1;      // (a streamed request: the host is still packing)
+                    // (a streamed request: the host is still packing; one that was given up is not waited for again)
+                    if (!srv_abandon && !fx_server_rows_ready(p.min, srv_req, tg * 16 + srv_rows)) srv_abandon = 1;
                     srv_bytes[qt] = __hip_atomic_load(reinterpret_cast<const unsigned*>(ascii + tg * 16 * L) + qt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
                 __syncthreads();

@@ -91,7 +91,8 @@ __global__ void __launch_bounds__(SW * 64) k_score_dense_small(SmallArgs p) {
         if constexpr (SERVER) {
             // the tile's bytes, dword-wise and past the caches (the host wrote them through the BAR)
             const unsigned* src = reinterpret_cast<const unsigned*>(p.min->bytes + tg * 16 * L);
-            if (!fx_server_rows_ready(p.min, srv_req, tg * 16 + rows)) srv_abandon = 1;           // (a streamed request: the host is still packing)
+            // (a streamed request: the host is still packing; one that was given up is not waited for again)
+            if (!srv_abandon && !fx_server_rows_ready(p.min, srv_req, tg * 16 + rows)) srv_abandon = 1;
             for (int i = tid; i * 4 < (int)rows * L; i += SW * 64)
                 reinterpret_cast<unsigned*>(bytes_s)[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         } else {
