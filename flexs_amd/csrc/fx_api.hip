@@ -318,6 +318,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "serve_poll_sleep")) return &e->serve_poll_sleep;
     if (!std::strcmp(key, "serve_fence")) return &e->serve_fence;
     if (!std::strcmp(key, "serve_quads")) return &e->serve_quads;
+    if (!std::strcmp(key, "serve_tiny")) return &e->serve_tiny;
     if (!std::strcmp(key, "host_mean_below")) return &e->host_mean_below;
     if (!std::strcmp(key, "done_flag")) return &e->done_flag;
     if (!std::strcmp(key, "serve_idle_us")) return &e->serve_idle_us;
@@ -741,7 +742,7 @@ static int server_start(fx_engine* e, fx_model* const* models, int M, int L, con
     }
     for (int g = 0; g < sv.groups; ++g) FX_HIP(e, hipStreamSynchronize(sv.streams[g]));   // a previous generation has left (it was told to, or timed out)
     std::memset((void*)sv.h_out->alive, 0, sizeof(sv.h_out->alive));   // (answers carry sequence numbers that never repeat: no need to clear them)
-    sv.in->req = 0; sv.in->req_wide = 0; sv.in->stop = 0;  // (through the BAR, like every host access to it; posted before the launch's doorbell)
+    sv.in->req = 0; sv.in->req_tail = 0; sv.in->req_wide = 0; sv.in->ready = 0; sv.in->stop = 0;  // (through the BAR, like every host access to it; posted before the launch's doorbell)
     fx_bar_fence();
     int rc = fx_upload_lut(e, lut);
     if (rc) return rc;
@@ -964,8 +965,19 @@ static void server_post(fx_engine* e, const uint8_t* ascii, int64_t N, int L) {
     if ((++sv.seq & 0x7FFFFFFFull) == 0) ++sv.seq;         // 31-bit tags, never 0; they run on across generations, so a slot's stale answer never matches
     const unsigned seq = (unsigned)(sv.seq & 0x7FFFFFFFull);
     unsigned long long word = ((unsigned long long)seq << 16) | (unsigned long long)N;
-    if (ascii) std::memcpy(sv.in->bytes, ascii, (size_t)N * L);
-    else { sv.in->ready = (unsigned long long)seq << 16; word |= FX_SERVE_STREAM; }
+    if (ascii && e->serve_tiny && (size_t)N * L <= FX_SERVE_TINY_BYTES) {
+        // a tiny request: its bytes and a second copy of the word go into the request word's own line (FxMailIn::tiny); the slot
+        // of tile 0 reads the whole line per poll and needs no second read for the bytes
+        word |= FX_SERVE_TINY;
+        unsigned char pad[FX_SERVE_TINY_BYTES] = {};
+        std::memcpy(pad, ascii, (size_t)N * L);
+        std::memcpy(sv.in->tiny, pad, sizeof pad);         // (the whole 48 bytes: full write-combining lines, and no stale bytes behind the request's)
+        sv.in->req_tail = word;
+    } else if (ascii) {
+        std::memcpy(sv.in->bytes, ascii, (size_t)N * L);
+    } else {
+        sv.in->ready = (unsigned long long)seq << 16; word |= FX_SERVE_STREAM;
+    }
     fx_bar_fence();
     // (the slots beyond the fast ones poll the copy: written first -- a slot that sees it early finds the bytes in place all the same)
     if (sv.fast < sv.tiles) sv.in->req_wide = word;

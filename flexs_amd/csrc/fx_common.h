@@ -23,6 +23,8 @@
 #define FX_SERVE_BYTES 65536   // N x seq_len bytes per request at most
 #define FX_SERVE_CAP 4096      // sequences per request at most
 #define FX_SERVE_LEAVE 0xFFFFull   // request word that tells the resident workgroups to leave (sequence number 0, N = 0xFFFF: neither occurs in a request)
+#define FX_SERVE_TINY 0x4000ull            // request word, bit 14: the request's bytes (<= FX_SERVE_TINY_BYTES) ride in the request word's own 64-byte line (FxMailIn::tiny)
+#define FX_SERVE_TINY_BYTES 48
 #define FX_SERVE_STREAM 0x8000ull          // request word, bit 15 of the row count: the bytes follow the request (FxMailIn::ready)
 #define FX_SERVE_FAST 16       // the first slots of every member poll without a pause (explorer-size calls); the others sleep between polls
 
@@ -83,6 +85,12 @@ void fx_pack_weights(const FxShape& s, const float* blob, float* packed);
 // workgroups polling a request word in host memory (their reads serialise on the PCIe link).
 struct FxMailIn {                                      // device memory (fine-grained); the host only ever WRITES it
     alignas(64) unsigned long long req;                // (sequence number << 16) | number of sequences; written LAST by the host
+    // TINY requests (round 4; request word bit 14): a request of at most 48 sequence bytes -- one to six 8-mers, three 14-mers: 85 %
+    // of Adalead's calls -- carries them in the rest of the request word's line, with the word once more at the line's end.  The
+    // first slot of every member polls the whole line (sixteen lanes, one 64-byte read) and has the bytes in registers the
+    // moment it sees the request: the second dependent read of device memory (the byte area, ~0.8 us) is gone from the call.
+    unsigned char tiny[FX_SERVE_TINY_BYTES];
+    unsigned long long req_tail;                       // = req of the tiny request (a reader that finds req != req_tail reads again)
     alignas(64) unsigned stop;                         // host: 1 = leave now
     alignas(64) unsigned char bytes[FX_SERVE_BYTES];   // the request's sequences, row-major
     // the same request word once more, for the tile slots beyond the first few of every member (wide generation): a word that
@@ -97,6 +105,7 @@ struct FxMailIn {                                      // device memory (fine-gr
     alignas(64) unsigned long long ready;
 };
 static_assert(offsetof(FxMailIn, stop) == 64 && offsetof(FxMailIn, bytes) == 128, "server_start clears the first 128 bytes");
+static_assert(offsetof(FxMailIn, tiny) == 8 && offsetof(FxMailIn, req_tail) == 56, "the request line: word, 48 bytes, word");
 struct FxMailOut {                                     // pinned host memory; the host only ever READS it (after zeroing it between generations)
     alignas(64) volatile unsigned alive[FX_MAX_M][FX_SERVE_TILES];   // 1 while the workgroup of (member, tile slot) is resident
     // one 8-byte store per (member, sequence): the score's bits and the request's sequence number (bit 31: the tile met a
@@ -246,6 +255,7 @@ struct fx_engine {
     int64_t serve_reserve_cus = 16;   // CUs a wide generation leaves without a resident workgroup (kernels of other streams -- RCCL, PyTorch -- find room there at once; small ones also fit beside a resident workgroup)
     int64_t call_prof_ns[4] = {};    // the last launched small mean-only host call: ns since entry at "prepared", "launched", "synchronised", "mean taken"
     int64_t host_mean_below = 256;   // launched mean-only host calls of at most this many sequences (zero-copy): member planes to pinned host memory, np.mean's order on the host, no mean launch (0 = the mean kernel: A/B)
+    int64_t serve_tiny = 1;     // 1 = requests of <= 48 sequence bytes carry them in the request word's own line (0 = always the byte area: A/B)
     int64_t serve_quads = 1;    // wide generation, CNN with seq_len <= 8: tiles per resident workgroup side by side (1 = one; 3 = like the launched form: A/B build only -- slower once requests are streamed, csrc/OPTIONS.md)
     int64_t serve_fence = 0;    // 1 = a system fence after every tile's answers (round 3: ~0.5 us each, and the fences of one XCD serialise -- 24 us for the 378 tiles of a 2001-sequence request, profiles/r4_mailbox_probe3.log); 0 = none: the answers are system-scope stores, which write through by themselves (profiles/r4_mailbox_probe4.log)
     int64_t serve_poll_sleep = 8;     // s_sleep units (64 clocks each) between polls of the slots beyond FX_SERVE_FAST (0 = every slot spins)
@@ -384,6 +394,33 @@ __device__ __forceinline__ bool fx_server_rows_ready(const FxMailIn* in, unsigne
             if (__hip_atomic_load(&in->req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == FX_SERVE_LEAVE) return false;
             if (wall_clock64() - t0 > 200000000ull) return false;
         }
+    }
+}
+// The same wait by ALL lanes of a wave, for the slot that answers tile 0 (the only tile of a tiny request): every poll reads the
+// whole request line -- lane l dword l & 15, one 64-byte read -- and the lanes keep their dword in *payload: when the word that
+// comes back carries FX_SERVE_TINY, lanes 2 .. 13 hold the request's bytes.  A line whose two copies of the word differ (a read
+// that overtook half of the host's write) is read again.
+__device__ __forceinline__ unsigned long long fx_server_wait_line(const FxMailIn* in, unsigned long long last, unsigned long long seen,
+                                                                  unsigned long long start, unsigned long long idle_ticks,
+                                                                  unsigned long long life_ticks, int lane, int* leave, unsigned* payload) {
+    *leave = 0;
+    const unsigned* line = reinterpret_cast<const unsigned*>(in) + (lane & 15);
+    for (;;) {
+        const unsigned v = __hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long r = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)v, 0) |
+                                     ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)v, 1) << 32);
+        if (r == FX_SERVE_LEAVE) { *leave = 1; return last; }
+        if (r != last) {
+            const unsigned long long tail = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)v, 14) |
+                                            ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)v, 15) << 32);
+            if (!(r & FX_SERVE_TINY) || tail == r) {
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                *payload = v;
+                return r;
+            }
+        }
+        const unsigned long long now = wall_clock64();
+        if (now - seen > (last ? idle_ticks : 64 * idle_ticks) || now - start > life_ticks) { *leave = 1; return last; }
     }
 }
 __device__ __forceinline__ unsigned long long fx_server_wait(const FxMailIn* in, unsigned long long last, unsigned long long seen,

@@ -139,22 +139,29 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
         if constexpr (SERVER) {
             if (p.dma) fx_wait_vm(0);                                // the whole image before the first request
             __syncthreads();
-            if (tid == 0) {
-                srv_start = srv_seen = wall_clock64();
+            if (wave == 0) srv_start = srv_seen = wall_clock64();      // (every lane of wave 0 keeps the wait's clocks: fx_server_wait_line)
+            if (tid == 0)
                 __hip_atomic_store(const_cast<unsigned*>(&p.mout->alive[p.m_off + m][srv_slot]), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
         }
       for (;;) {                                                     // (SERVER: one iteration per request)
         [[maybe_unused]] int srv_rounds = 0;
         if constexpr (SERVER) {
-            if (tid == 0) {
+            if (wave == 0) {
                 int ex = 0;
-                const unsigned long long r = fx_server_wait(p.min, srv_last, srv_seen, srv_start, p.idle_ticks, p.life_ticks, srv_slot < p.srv_fast, p.srv_sleep, &ex);
-                srv_req = r; srv_exit = ex; srv_bad = 0; srv_abandon = 0;
+                unsigned long long r = 0;
+                if (srv_slot == 0) {
+                    // the slot of tile 0 polls the whole request line: a tiny request's bytes arrive with the word (FxMailIn::tiny)
+                    unsigned payload = 0;
+                    r = fx_server_wait_line(p.min, srv_last, srv_seen, srv_start, p.idle_ticks, p.life_ticks, lane, &ex, &payload);
+                    if (!ex && (r & FX_SERVE_TINY) && lane >= 2 && lane < 14) srv_bytes[lane - 2] = payload;
+                } else if (lane == 0) {
+                    r = fx_server_wait(p.min, srv_last, srv_seen, srv_start, p.idle_ticks, p.life_ticks, srv_slot < p.srv_fast, p.srv_sleep, &ex);
+                }
+                if (lane == 0) { srv_req = r; srv_exit = ex; srv_bad = 0; srv_abandon = 0; }
             }
             __syncthreads();
             if (srv_exit) break;
-            Ncur = (int64_t)(srv_req & 0x7FFFull);
+            Ncur = (int64_t)(srv_req & 0x3FFFull);
             TGcur = (Ncur + 15) >> 4;
             // this slot's tiles of the request: slot, slot + T, slot + 2 T, ... (T = slots per member) -- QUADS of them per round,
             // one per quad: a request of up to T tiles keeps one quad per workgroup busy (a lone quad is the fastest round),
@@ -163,7 +170,7 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
             t_lo = srv_slot; t_hi = srv_slot + srv_rounds;
             bad = false;
             if (srv_rounds == 0) {                                   // a request with fewer tiles: nothing to answer from this slot
-                if (tid == 0) { srv_last = srv_req; srv_seen = wall_clock64(); }
+                if (wave == 0) { srv_last = srv_req; srv_seen = wall_clock64(); }
                 __syncthreads();                                     // (everybody has read the request word)
                 continue;
             }
@@ -180,7 +187,7 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
                 // reads LDS.  (The previous round's readers of srv_bytes -- its phase A -- are several barriers behind.)
                 const int64_t srv_rows = Ncur - tg * 16 < 16 ? Ncur - tg * 16 : 16;
                 const int qt = tid & 255;
-                if (live && (int64_t)qt * 4 < srv_rows * L) {
+                if (live && (int64_t)qt * 4 < srv_rows * L && !(srv_req & FX_SERVE_TINY)) {          // (a tiny request's bytes came with the word)
                     // (a streamed request: the host is still packing; one that was given up is not waited for again)
                     if (!srv_abandon && !fx_server_rows_ready(p.min, srv_req, tg * 16 + srv_rows)) srv_abandon = 1;
                     srv_bytes[qt] = __hip_atomic_load(reinterpret_cast<const unsigned*>(ascii + tg * 16 * L) + qt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -371,7 +378,7 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
             if (live) FX_TILE_DONE();
         }
         if constexpr (SERVER) {
-            if (tid == 0) { srv_last = srv_req; srv_seen = wall_clock64(); }
+            if (wave == 0) { srv_last = srv_req; srv_seen = wall_clock64(); }
             __syncthreads();
         } else {
             break;

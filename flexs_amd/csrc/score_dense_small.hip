@@ -62,23 +62,30 @@ __global__ void __launch_bounds__(SW * 64) k_score_dense_small(SmallArgs p) {
     for (int i = tid; i < 64; i += SW * 64) reinterpret_cast<uint32_t*>(lut_s)[i] = reinterpret_cast<const uint32_t*>(p.lut)[i];
     if constexpr (SERVER) {
         __syncthreads();
-        if (tid == 0) {
-            srv_start = srv_seen = wall_clock64();
+        if (wave == 0) srv_start = srv_seen = wall_clock64();          // (every lane of wave 0 keeps the wait's clocks: fx_server_wait_line)
+        if (tid == 0)
             __hip_atomic_store(const_cast<unsigned*>(&p.mout->alive[p.m_off + m][tg0]), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
     }
   for (;;) {                                               // (SERVER: one iteration per request)
     if constexpr (SERVER) {
-        if (tid == 0) {
+        if (wave == 0) {
             int ex = 0;
-            const unsigned long long r = fx_server_wait(p.min, srv_last, srv_seen, srv_start, p.idle_ticks, p.life_ticks, (int)tg0 < p.srv_fast, p.srv_sleep, &ex);
-            srv_req = r; srv_exit = ex; srv_bad = 0; srv_abandon = 0;
+            unsigned long long r = 0;
+            if (tg0 == 0) {
+                // the slot of tile 0 polls the whole request line: a tiny request's bytes arrive with the word (FxMailIn::tiny)
+                unsigned payload = 0;
+                r = fx_server_wait_line(p.min, srv_last, srv_seen, srv_start, p.idle_ticks, p.life_ticks, lane, &ex, &payload);
+                if (!ex && (r & FX_SERVE_TINY) && lane >= 2 && lane < 14) reinterpret_cast<unsigned*>(bytes_s)[lane - 2] = payload;
+            } else if (lane == 0) {
+                r = fx_server_wait(p.min, srv_last, srv_seen, srv_start, p.idle_ticks, p.life_ticks, (int)tg0 < p.srv_fast, p.srv_sleep, &ex);
+            }
+            if (lane == 0) { srv_req = r; srv_exit = ex; srv_bad = 0; srv_abandon = 0; }
         }
         __syncthreads();
         if (srv_exit) break;
-        Ncur = (int64_t)(srv_req & 0x7FFFull);
+        Ncur = (int64_t)(srv_req & 0x3FFFull);
         if (tg0 * 16 >= Ncur) {                              // a request with fewer tiles: nothing to answer from this slot
-            if (tid == 0) { srv_last = srv_req; srv_seen = wall_clock64(); }
+            if (wave == 0) { srv_last = srv_req; srv_seen = wall_clock64(); }
             __syncthreads();                                 // (everybody has read the request word)
             continue;
         }
@@ -88,7 +95,9 @@ __global__ void __launch_bounds__(SW * 64) k_score_dense_small(SmallArgs p) {
     for (int64_t tg = tg0; tg == tg0 || (SERVER && tg * 16 < Ncur); tg += SERVER ? p.srv_tiles : 1) {
         const int64_t rows = Ncur - tg * 16 < 16 ? Ncur - tg * 16 : 16;
         const int64_t n = tg * 16 + sq;
-        if constexpr (SERVER) {
+        if (SERVER && (srv_req & FX_SERVE_TINY)) {
+            // (a tiny request: its bytes came with the request word, wave 0 has put them in place)
+        } else if constexpr (SERVER) {
             // the tile's bytes, dword-wise and past the caches (the host wrote them through the BAR)
             const unsigned* src = reinterpret_cast<const unsigned*>(p.min->bytes + tg * 16 * L);
             // (a streamed request: the host is still packing; one that was given up is not waited for again)
@@ -122,7 +131,7 @@ __global__ void __launch_bounds__(SW * 64) k_score_dense_small(SmallArgs p) {
         if constexpr (SERVER) __syncthreads();               // (the byte rows and the exchange buffers are free for the slot's next tile)
     }
     if constexpr (SERVER) {
-        if (tid == 0) { srv_last = srv_req; srv_seen = wall_clock64(); }
+        if (wave == 0) { srv_last = srv_req; srv_seen = wall_clock64(); }
         __syncthreads();                                     // (the request word is free again)
     } else {
         if (bad) fx_raise(p.err, FX_ERR_BADCHAR);

@@ -125,6 +125,9 @@ const char *fx_last_error(fx_engine *e);
  *   done_flag         1        1 = a launched small host call whose last kernel can tell when its last result is written (the
  *                              layer-parallel protein CNN form) is waited for by polling a completion word in pinned host
  *                              memory instead of hipStreamSynchronize: ~4 us of a 46 us call; 0 = always the stream.
+ *   serve_tiny        1        1 = a request of at most 48 sequence bytes (one to six 8-mers) carries them in the request word's
+ *                              own 64-byte line; the workgroup of tile 0 reads the whole line per poll and needs no second
+ *                              read of device memory for the bytes (~0.2 us of a 9.4 us call).  0 = always the byte area.
  *   serve_quads       1        wide generation, 4-letter CNN with seq_len <= 8: tiles a resident workgroup answers side by
  *                              side.  3 (the launched form's three quads) is in the A/B build only: slower once requests
  *                              are streamed (fx_score_stream_*).

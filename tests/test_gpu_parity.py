@@ -1838,6 +1838,56 @@ def _few_fallbacks(eng, before, what=""):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,L,alpha,M", [("cnn", 8, "TGCA", 3), ("cnn", 14, "UGCA", 2), ("mlp", 14, "UGCA", 1), ("ge", 24, "UGCA", 3), ("mix", 8, "TGCA", 3)])
+def test_resident_tiny_requests(eng, kind, L, alpha, M):
+    """Round 4: a request of at most 48 sequence bytes (one to six 8-mers: most of Adalead's calls) carries its bytes in the request
+    word's own 64-byte line (FxMailIn::tiny, request bit 14); the slot of tile 0 reads the whole line per poll.  Same bits as the
+    byte-area request (serve_tiny = 0), as the launched call and beside the oracle, at every size around the 48-byte limit,
+    alternating with larger requests (stale bytes of an earlier tiny request must not leak into a later one), with a character
+    outside the alphabet."""
+    if kind == "mix":
+        members = [bm.GlobalEpistasisModel(L, 100, alpha, seed=1), bm.MLP(L, 100, alpha, seed=2), bm.CNN(L, 32, 100, alpha, seed=3)]
+        kinds = ["ge", "mlp", "cnn"]
+    else:
+        mk = {"cnn": lambda s: bm.CNN(L, 32, 100, alpha, seed=s), "mlp": lambda s: bm.MLP(L, 100, alpha, seed=s),
+              "ge": lambda s: bm.GlobalEpistasisModel(L, 100, alpha, seed=s)}[kind]
+        members = [mk(50 + s) for s in range(M)]
+        kinds = [kind] * M
+    ens = flexs_amd.Ensemble(members) if M > 1 else members[0]
+    stack = flexs_amd.Ensemble(members, combine_with=lambda x: x)
+    limit = 48 // L
+    sizes = sorted({1, 2, max(limit - 1, 1), limit, limit + 1, limit + 2, 16, 17, 40})
+    data = {n: rand_seqs(n, L, alpha, seed=600 + n)[1] for n in sizes}
+    eng.set_option("serve_small", 0)
+    try:
+        want = {n: ens.get_fitness(data[n]) for n in sizes}
+    finally:
+        eng.set_option("serve_small", 1)
+    try:
+        for tiny in (1, 0, 1):
+            eng.set_option("serve_tiny", tiny)
+            assert _until_resident(eng, lambda: ens.get_fitness(data[1]))
+            fb0 = eng.get_option("server_fallbacks")
+            for rep in range(3):
+                for n in sizes + sizes[::-1]:
+                    assert np.array_equal(ens.get_fitness(data[n]), want[n]), (kind, L, n, tiny, rep)
+            _few_fallbacks(eng, fb0, f"tiny {kind} L={L}")
+        got_nm = stack.get_fitness(data[limit])
+        for m, (mod, kd) in enumerate(zip(members, kinds)):
+            ref = ref_np.keras_fitness(data[limit], alpha, kd, [np.asarray(w, np.float64) for w in mod.model.get_weights()], exact=True)
+            assert_scores(got_nm[:, m], ref, f"tiny request, {kd} L={L} member {m}")
+        for _ in range(3):
+            ens.get_fitness(data[1])
+        bad = list(data[limit])
+        bad[-1] = bad[-1][:-1] + "!"
+        with pytest.raises(ValueError):
+            ens.get_fitness(bad)
+        assert np.array_equal(ens.get_fitness(data[limit]), want[limit])
+    finally:
+        eng.set_option("serve_tiny", 1)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("L,M", [(90, 3), (237, 2), (33, 8), (40, 16)])
 def test_host_side_mean_of_small_launched_calls(eng, L, M):
     """Launched mean-only host calls of at most `host_mean_below` sequences (the protein CNN's explorer-size calls): the member
