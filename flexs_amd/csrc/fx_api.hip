@@ -241,6 +241,7 @@ int fx_engine_destroy(fx_engine* e) {
         if (e->server.in) (void)hipFree(e->server.in);
         e->server.h_out = nullptr;
     }
+    fx_lp_disarm(e);
     (void)hipStreamSynchronize(e->stream);
     for (auto& p : e->d_scratch) if (p) (void)hipFree(p);
     if (e->d_zero_pool) (void)hipFree(e->d_zero_pool);
@@ -253,6 +254,8 @@ int fx_engine_destroy(fx_engine* e) {
     if (e->d_trace) (void)hipFree(e->d_trace);
     if (e->d_lp_bar) (void)hipFree(e->d_lp_bar);
     if (e->h_done) (void)hipHostFree(e->h_done);
+    if (e->lp_mail) (void)hipFree(e->lp_mail);
+    if (e->h_lp_state) (void)hipHostFree(e->h_lp_state);
     for (int i = 0; i < fx_engine::MAX_PIECES; ++i) {
         if (e->ev_in[i]) (void)hipEventDestroy(e->ev_in[i]);
         if (e->ev_done[i]) (void)hipEventDestroy(e->ev_done[i]);
@@ -321,6 +324,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "serve_tiny")) return &e->serve_tiny;
     if (!std::strcmp(key, "host_mean_below")) return &e->host_mean_below;
     if (!std::strcmp(key, "done_flag")) return &e->done_flag;
+    if (!std::strcmp(key, "lp_prelaunch")) return &e->lp_prelaunch;
     if (!std::strcmp(key, "serve_idle_us")) return &e->serve_idle_us;
     if (!std::strcmp(key, "chunk_overlap")) return &e->chunk_overlap;
     if (!std::strcmp(key, "zero_copy_bytes")) return &e->zero_copy_bytes;
@@ -339,6 +343,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
 // Kernel forms that were measured and lost (csrc/OPTIONS.md, "negative results") are compiled into the A/B build only
 // (`make -C flexs_amd/csrc ab` -> libflexs_amd_ab.so, -DFX_AB; FLEXS_AMD_LIB selects it): the production library refuses
 // the option values that would select them instead of silently running something else.
+static void lp_disarm(fx_engine* e);
 static bool ab_only_value(const fx_engine* e, const int64_t* s, int64_t value) {
 #if defined(FX_AB)
     (void)e; (void)s; (void)value;
@@ -363,7 +368,7 @@ int fx_engine_set_option(fx_engine* e, const char* key, int64_t value) {
                        "(measured slower, see csrc/OPTIONS.md): make -C flexs_amd/csrc ab, FLEXS_AMD_LIB=.../libflexs_amd_ab.so");
     // a running resident generation was started under the old options (its geometry, but also the kernel forms its
     // workgroups run: pair rows or plain rows, ...): it leaves, the next calls start a new one under the new ones
-    if (*s != value) fx_server_stop(e);
+    if (*s != value) { fx_server_stop(e); lp_disarm(e); }
     *s = value;
     e->server.refused.clear();                             // (what has a resident form depends on the form selectors)
     return FX_OK;
@@ -386,6 +391,7 @@ int fx_engine_get_option(fx_engine* e, const char* key, int64_t* value) {
     if (e && key && !std::strncmp(key, "server_prof_", 12) && key[12] >= '0' && key[12] <= '7' && !key[13]) { *value = e->server.prof_ns[key[12] - '0']; return FX_OK; }
     if (e && key && !std::strncmp(key, "call_prof_", 10) && key[10] >= '0' && key[10] <= '3' && !key[11]) { *value = e->call_prof_ns[key[10] - '0']; return FX_OK; }
     if (e && key && !std::strncmp(key, "train_prof_", 11) && key[11] >= '0' && key[11] <= '4' && !key[12]) { *value = e->train_prof_ns[key[11] - '0']; return FX_OK; }
+    if (e && key && !std::strcmp(key, "lp_armed_served")) { *value = e->lp_armed_served; return FX_OK; }
     if (e && key && !std::strcmp(key, "server_streamed")) { *value = e->server.streamed; return FX_OK; }
     if (e && key && !std::strcmp(key, "server_slots")) { *value = e->server.running ? e->server.tiles : 0; return FX_OK; }
     int64_t* s = option_slot(e, key);
@@ -509,12 +515,18 @@ static inline int64_t planar_stride_for(int64_t N) { return (N + 63) & ~(int64_t
 
 // planar_stride == 0: d_NM is the row-major (N, M) matrix of the ABI; > 0: M member planes that far apart.
 static void server_stop(fx_engine* e);
+static void lp_disarm(fx_engine* e);
 static int score_dispatch(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N, int L,
                           float* d_NM, int64_t planar_stride = 0) {
+    if (!e->lp_arm_next) lp_disarm(e);                     // (a pre-launched instance of another call shape holds the CUs: it leaves)
+    e->lp_launches = 0;
+    e->dispatch_groups = 0;
     // a launch whose workgroups would not all find a CU beside the resident ones tells those to leave (they hold most of their
     // CU's LDS: a persistent workgroup that has to wait for one of them would wait for their idle exit)
     if (e->server.running && (int64_t)M * ((N + 15) / 16) + e->server.wgs > e->num_cus) server_stop(e);
-    if (e->poison_outputs)      // scores are nan_to_num'ed, so a NaN that survives is an element no kernel wrote
+    if (e->poison_outputs && !e->lp_arm_next)   // scores are nan_to_num'ed, so a NaN that survives is an element no kernel wrote
+        // (not for a pre-launched instance: the memset would run between the end of the instance being answered and the host
+        //  reading ITS results from the same pinned planes; lp_serve_armed poisons them on the host instead)
         FX_HIP(e, hipMemsetAsync(d_NM, 0xFF, sizeof(float) * (planar_stride ? (size_t)planar_stride * (size_t)M : (size_t)N * (size_t)M), e->stream));
     struct Layout {                                     // the launchers read the layout from the engine
         fx_engine* e;
@@ -531,6 +543,7 @@ static int score_dispatch(fx_engine* e, fx_model* const* models, int M, const ui
             ++cnt;
         }
         int rc = FX_EUNSUPPORTED;
+        e->dispatch_groups += 1;
         e->done_armed = false;                             // (only the LAST launch of a dispatch may offer the completion flag)
         if (!e->force_generic) {
             if (s0.kind == FX_CNN) {
@@ -856,12 +869,140 @@ static void host_mean_planes(const float* pl, int64_t stride, int64_t N, int M, 
     }
 }
 
+// ---- pre-launched instance of the layer-parallel protein form (fx_common.h LpArmed) -------------------------------------------
+static bool lp_mail_ensure(fx_engine* e) {
+    if (e->lp_mail) return true;
+    if (e->lp_mail_refused || !e->large_bar) return false;
+    e->lp_mail_refused = true;                             // (until proven otherwise: asked once)
+    FxLpMail* q = nullptr;
+    if (hipExtMallocWithFlags(reinterpret_cast<void**>(&q), sizeof(FxLpMail), hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); return false; }
+    {
+        // can the host store into it?  (as for the resident form's mailbox: a writable mapping of this process + a read-back)
+        std::lock_guard<std::mutex> lock(g_probe_mu);
+        bool ok = host_range_is_writable(q, sizeof(FxLpMail));
+        if (ok) {
+            volatile unsigned long long* p = &q->req[0].w;
+            *p = 0x5EB1A5ED5EB1A5EDull;
+            fx_bar_fence();
+            unsigned long long back = 0;
+            ok = hipMemcpy(&back, const_cast<const unsigned long long*>(p), sizeof back, hipMemcpyDeviceToHost) == hipSuccess && back == 0x5EB1A5ED5EB1A5EDull;
+            if (!ok) (void)hipGetLastError();
+        }
+        if (!ok) { (void)hipFree(q); return false; }
+    }
+    if (!e->h_lp_state) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&e->h_lp_state), 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipHostGetDevicePointer(reinterpret_cast<void**>(&e->d_lp_state), e->h_lp_state, 0) != hipSuccess) {
+            (void)hipGetLastError(); (void)hipFree(q); return false;
+        }
+        *e->h_lp_state = 0;
+    }
+    for (auto& w : q->req) w.w = 0;
+    fx_bar_fence();
+    e->lp_mail = q;
+    e->lp_mail_refused = false;
+    return true;
+}
+
+// Tell a pre-launched instance to leave (harmless when it has left by itself) and put the layer-parallel form's barrier counters
+// back: the host counted the instance's arrivals when it enqueued it.  Stream-ordered: the memset runs after the instance.
+static void lp_disarm(fx_engine* e) {
+    if (!e->lp_armed.on) return;
+    e->lp_armed.on = false;
+    for (auto& w : e->lp_mail->req) w.w = ((unsigned long long)e->lp_armed.seq << 16) | 0xFFFFull;
+    fx_bar_fence();
+    if (e->d_lp_bar) { (void)hipMemsetAsync(e->d_lp_bar, 0, FX_LP_BAR_BYTES, e->stream); for (unsigned& t : e->lp_bar_total) t = 0; }
+}
+
+}  // extern "C"
+void fx_lp_disarm(fx_engine* e) { lp_disarm(e); }
+extern "C" {
+
+// Enqueue the NEXT instance of the call that was just answered by the layer-parallel form: same members, same batch size, results
+// to the same pinned planes / matrix.  It fills its weights and waits for its request word.
+static void lp_arm(fx_engine* e, fx_model* const* models, int M, int64_t N, int L, const uint8_t lut[256], float* out_dev, int64_t stride, int mode) {
+    if (!e->lp_prelaunch || !e->done_flag || e->trace || !lp_mail_ensure(e)) return;
+    e->lp_arm_next = true;
+    const int rc = score_dispatch(e, models, M, e->lp_mail->bytes, N, L, out_dev, stride);
+    e->lp_arm_next = false;
+    e->done_armed = false;                                 // (nobody waits for this launch's flag until it has been asked)
+    if (rc != FX_OK || e->lp_launches != 1 || e->dispatch_groups != 1) {
+        // (not the layer-parallel form after all: whatever was enqueued scored the mailbox's old bytes into the scratch planes --
+        //  harmless, and stream-ordered before anything that reads them)
+        (void)hipGetLastError();
+        return;
+    }
+    auto& a = e->lp_armed;
+    a.on = true;
+    a.models.assign(models, models + M);
+    a.versions.clear();
+    for (int m = 0; m < M; ++m) a.versions.push_back(models[m]->version);
+    a.N = N; a.L = L; a.mode = mode; a.stride = stride;
+    std::memcpy(a.lut, lut, 256);
+    a.seq = e->done_seq;
+    a.t = std::chrono::steady_clock::now();
+}
+
+// Is the pre-launched instance the one this call can use?
+static bool lp_armed_matches(const fx_engine* e, fx_model* const* models, int M, int64_t N, int L, const uint8_t lut[256], int64_t stride, int mode) {
+    const auto& a = e->lp_armed;
+    if (!a.on || (int)a.models.size() != M || a.N != N || a.L != L || a.mode != mode || a.stride != stride || std::memcmp(a.lut, lut, 256) != 0) return false;
+    for (int m = 0; m < M; ++m) if (a.models[m] != models[m] || a.versions[m] != models[m]->version) return false;
+    // (the instance leaves serve_idle_us after it started waiting: one that is about to is not asked any more)
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - a.t).count() * 1e6 < 0.6 * (double)e->serve_idle_us;
+}
+
+// Answer the call with the pre-launched instance: its sequences and request word go into the mailbox, the NEXT instance is
+// enqueued while this one computes, then the completion flag.  false: the instance had left (the caller launches as usual).
+static bool lp_serve_armed(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii, int64_t N, int L, const uint8_t lut[256],
+                           float* out_dev, int64_t stride, int mode, void* out_host, size_t out_bytes) {
+    auto& a = e->lp_armed;
+    const unsigned seq = a.seq;
+    if (e->poison_outputs) std::memset(out_host, 0xFF, out_bytes);     // (the instance writes pinned HOST memory: poisoned here)
+    std::memcpy(e->lp_mail->bytes, ascii, (size_t)N * L);
+    fx_bar_fence();
+    const unsigned long long word = ((unsigned long long)seq << 16) | (unsigned long long)N;
+    for (auto& w : e->lp_mail->req) w.w = word;
+    fx_bar_fence();
+    a.on = false;                                          // (being served: not to be cancelled by the dispatch below)
+    // the barrier totals of the instance being served are part of what the next one builds on: enqueue it now, it starts when
+    // this one is through
+    const auto t0 = std::chrono::steady_clock::now();
+    const volatile unsigned* done = e->h_done;
+    const volatile unsigned* state = e->h_lp_state;
+    const unsigned gone = (seq << 1) | 1u;
+    bool armed_next = false;
+    for (unsigned spins = 0;; ++spins) {
+        if (*done == seq) break;
+        if (*state == gone) {                              // it left just before the request arrived
+            if (armed_next) lp_disarm(e);
+            else if (e->d_lp_bar) { (void)hipMemsetAsync(e->d_lp_bar, 0, FX_LP_BAR_BYTES, e->stream); for (unsigned& t : e->lp_bar_total) t = 0; }
+            return false;
+        }
+        if (!armed_next) {                                 // (after the first look: ~2.6 us of enqueue beside the instance's ~25 us of work)
+            lp_arm(e, models, M, N, L, lut, out_dev, stride, mode);
+            armed_next = true;
+            continue;
+        }
+        __builtin_ia32_pause();
+        if ((spins & 4095u) == 4095u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) {
+            lp_disarm(e);
+            (void)hipStreamSynchronize(e->stream);
+            if (*done == seq) break;
+            return false;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    e->lp_armed_served += 1;
+    return true;
+}
+
 // Wait for the results of the launches just enqueued on the engine's stream: the completion flag of the last launch where it
 // offers one (poll: the word is in pinned host memory), else -- or when the flag stays away for 2 s -- the stream itself.
-static int wait_for_results(fx_engine* e) {
-    if (e->done_armed && e->done_flag) {
+static int wait_for_results(fx_engine* e, unsigned want_seq = 0) {
+    if ((e->done_armed || want_seq) && e->done_flag) {
         const volatile unsigned* w = e->h_done;
-        const unsigned want = e->done_seq;
+        const unsigned want = want_seq ? want_seq : e->done_seq;
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned spins = 0; *w != want; ++spins) {
             __builtin_ia32_pause();
@@ -1187,9 +1328,17 @@ int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii,
         float* m_mean = (float*)((char*)dm_out + nm_bytes);
         if (host_mean) {
             e->call_prof_ns[0] = server_since(e);
-            if ((rc = score_dispatch(e, models, M, (const uint8_t*)dm_in, N, L, m_NM, stride))) return rc;
-            e->call_prof_ns[1] = server_since(e);
-            if ((rc = wait_for_results(e))) return rc;
+            // a pre-launched instance of exactly this call (the caller is back within the idle window): no launch, no weight fill
+            bool served = lp_armed_matches(e, models, M, N, L, lut, stride, 1) && lp_serve_armed(e, models, M, ascii, N, L, lut, m_NM, stride, 1, h_out, inter_bytes);
+            if (!served) {
+                if ((rc = score_dispatch(e, models, M, (const uint8_t*)dm_in, N, L, m_NM, stride))) return rc;
+                e->call_prof_ns[1] = server_since(e);
+                // answered by the layer-parallel form alone: its NEXT instance is enqueued now, beside this one's work
+                const bool lp = e->done_armed && e->lp_launches == 1 && e->dispatch_groups == 1;
+                const unsigned seq = lp ? e->done_seq : 0;
+                if (lp) lp_arm(e, models, M, N, L, lut, m_NM, stride, 1);
+                if ((rc = wait_for_results(e, seq))) return rc;
+            }
             e->call_prof_ns[2] = server_since(e);
             if ((rc = check_deferred(e))) return rc;
             host_mean_planes((const float*)h_out, stride, N, M, out_mean);
@@ -1199,13 +1348,28 @@ int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii,
             if ((rc = score_then_mean(e, models, M, (const uint8_t*)dm_in, N, L, d_NM, stride, m_mean))) return rc;
             e->done_armed = false;                         // (the mean kernel, or a fused mean, is the last writer)
         } else {
-            if ((rc = score_dispatch(e, models, M, (const uint8_t*)dm_in, N, L, out_NM ? m_NM : d_NM, stride))) return rc;
-            if (out_mean) {
-                if ((rc = fx_launch_ensemble_reduce(e, out_NM ? m_NM : d_NM, N, M, nullptr, m_mean, nullptr))) return rc;
-                e->done_armed = false;
+            const bool plain_matrix = out_NM && !out_mean && N <= e->host_mean_below;
+            const bool served = plain_matrix && lp_armed_matches(e, models, M, N, L, lut, 0, 2) && lp_serve_armed(e, models, M, ascii, N, L, lut, m_NM, 0, 2, h_out, nm_bytes);
+            unsigned seq = 0;
+            if (!served) {
+                if ((rc = score_dispatch(e, models, M, (const uint8_t*)dm_in, N, L, out_NM ? m_NM : d_NM, stride))) return rc;
+                if (out_mean) {
+                    if ((rc = fx_launch_ensemble_reduce(e, out_NM ? m_NM : d_NM, N, M, nullptr, m_mean, nullptr))) return rc;
+                    e->done_armed = false;
+                }
+                if (plain_matrix && e->done_armed && e->lp_launches == 1 && e->dispatch_groups == 1) {
+                    seq = e->done_seq;
+                    lp_arm(e, models, M, N, L, lut, m_NM, 0, 2);
+                }
             }
+            if (served) e->done_armed = false;
+            else if ((rc = wait_for_results(e, seq))) return rc;   // (the last launch's completion flag where it offers one, else the stream)
+            if ((rc = check_deferred(e))) return rc;
+            if (out_NM) std::memcpy(out_NM, h_out, nm_bytes);
+            if (out_mean) std::memcpy(out_mean, (char*)h_out + nm_bytes, mean_bytes);
+            return FX_OK;
         }
-        if ((rc = wait_for_results(e))) return rc;         // (the last launch's completion flag where it offers one, else the stream)
+        if ((rc = wait_for_results(e))) return rc;         // (the mean kernel was the last writer: the stream)
     } else {
         e->counters.bytes_h2d += (int64_t)in_bytes;
         e->counters.bytes_d2h += (int64_t)((out_mean ? mean_bytes : 0) + (out_NM ? nm_bytes : 0));

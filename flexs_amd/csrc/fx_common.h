@@ -106,6 +106,14 @@ struct FxMailIn {                                      // device memory (fine-gr
 };
 static_assert(offsetof(FxMailIn, stop) == 64 && offsetof(FxMailIn, bytes) == 128, "server_start clears the first 128 bytes");
 static_assert(offsetof(FxMailIn, tiny) == 8 && offsetof(FxMailIn, req_tail) == 56, "the request line: word, 48 bytes, word");
+// Mailbox of a PRE-LAUNCHED instance of the layer-parallel protein form (round 4; score_cnn_pair.hip, fx_api.hip "armed"): fine-grained
+// device memory the host stores into through the BAR.  The instance has its weights in LDS and waits for ITS request word --
+// sixteen copies, a line each: block b polls copy b & 15 -- then reads the request's sequences from `bytes`.
+// request word of instance s for N sequences: (s << 16) | N; (s << 16) | 0xFFFF tells instance s to leave (words of other instances are ignored)
+struct FxLpMail {
+    struct alignas(64) Word { unsigned long long w; } req[16];
+    alignas(64) unsigned char bytes[FX_SERVE_BYTES];
+};
 struct FxMailOut {                                     // pinned host memory; the host only ever READS it (after zeroing it between generations)
     alignas(64) volatile unsigned alive[FX_MAX_M][FX_SERVE_TILES];   // 1 while the workgroup of (member, tile slot) is resident
     // one 8-byte store per (member, sequence): the score's bits and the request's sequence number (bit 31: the tile met a
@@ -188,6 +196,27 @@ struct fx_engine {
     unsigned* h_done = nullptr; unsigned* d_done = nullptr;
     unsigned done_seq = 0;
     bool done_armed = false;
+    // Pre-launched instance of the layer-parallel form (fx_api.hip lp_arm / lp_try_armed): after an explorer-size call of a protein
+    // CNN ensemble was answered by k_score_cnn_lp, the NEXT instance is enqueued at once -- it fills its weights and waits for
+    // its request word in lp_mail -- so a caller that comes back with the same shape within serve_idle_us pays neither the launch
+    // latency nor the weight fill.
+    FxLpMail* lp_mail = nullptr;     // (host pointer = device pointer: large BAR)
+    bool lp_mail_refused = false;
+    unsigned* h_lp_state = nullptr; unsigned* d_lp_state = nullptr;   // pinned host word: (instance sequence << 1) | 1 = "left without a request"
+    struct LpArmed {
+        bool on = false;
+        std::vector<fx_model*> models; std::vector<uint64_t> versions;
+        int64_t N = 0; int L = 0; int mode = 0;          // mode: 1 = member planes (mean on the host), 2 = (N, M) matrix
+        int64_t stride = 0;
+        uint8_t lut[256];
+        unsigned seq = 0;                                // the instance's completion-flag value; its request word = (seq << 16) | N
+        std::chrono::steady_clock::time_point t{};
+    } lp_armed;
+    bool lp_arm_next = false;        // launch_lp: make this launch a pre-launched instance
+    int lp_launches = 0;             // launch_lp calls of the current dispatch
+    int dispatch_groups = 0;         // launch groups of the current dispatch
+    int64_t lp_prelaunch = 1;        // option: 1 = pre-launch the next instance after an explorer-size call of the layer-parallel form (0 = never: A/B)
+    int64_t lp_armed_served = 0;     // (read) calls answered by a pre-launched instance
     int64_t done_flag = 1;           // option: 1 = poll the completion flag where a kernel offers one, 0 = always hipStreamSynchronize (A/B)
     int64_t cnn_quad = 1;       // 1 = small launches of the canonical 4-letter CNN with L <= 16 share a tile among four waves (score_cnn_quad.hip); 2 = whatever the size (test knob); 0 = off
     int64_t dma_fill = 1;       // 1 = weight images go global -> LDS directly (global_load_lds), all in flight at kernel start, the first layers start when THEIR part has landed (0 = through registers, whole image before the first tile: A/B)
@@ -372,6 +401,7 @@ inline void fx_server_stop(fx_engine* e) {
     fx_bar_fence();
     sv.running = false;
 }
+void fx_lp_disarm(fx_engine* e);      // a pre-launched instance of the layer-parallel form leaves (fx_api.hip)
 int fx_launch_score_cnn_quad_server(fx_engine* e, fx_model* const* models, int M, int m_off, int tiles, hipStream_t stream,
                                     FxMailIn* d_in, FxMailOut* d_out, unsigned long long idle_ticks, unsigned long long life_ticks,
                                     int want_quads, int* quads_out);

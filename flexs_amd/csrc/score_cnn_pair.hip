@@ -46,6 +46,9 @@ struct PairArgs {
     f4* lp_out2;                // [unit][position][2 tiles][64 lanes]: conv2 outputs, between the two phases
     unsigned* lp_bar;           // grid barrier: counters that only ever grow, 128 bytes apart: [0] top, [1 + g] group g = block mod 16
     unsigned lp_target;         // this launch passes when the top counter reaches lp_target ...
+    const FxLpMail* lp_mail;    // a PRE-LAUNCHED instance (or null): weights first, then wait for lp_word in lp_mail->req, sequences from lp_mail->bytes
+    unsigned long long lp_word, lp_idle_ticks;
+    unsigned* lp_state;         // pinned host word: (lp_done_seq << 1) | 1 when the instance leaves without having been asked
     unsigned* lp_done;          // completion flag in pinned host memory (or null): the unit that finishes LAST stores lp_done_seq there
     unsigned lp_done_seq;
     unsigned lp_gtarget[16];    // ... and the LAST block of group g (the one that brings its counter to lp_gtarget[g]) arrives at the top
@@ -385,19 +388,43 @@ __global__ void __launch_bounds__(256) k_score_cnn_lp(PairArgs p) {
     const int s0 = h0 - PL2 > 0 ? h0 - PL2 : 0;
     // the sequence bytes of phase 1, all requested at once (a byte per step from global memory is a ~1.5 us round trip per step):
     // lane (sq, g) brings bytes 4g .. 4g+3 of its sequence's span [s0, s0 + 16)
-    {
+    auto read_rows = [&]() {
         uint8_t rb[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const int at = s0 + 4 * g + i; rb[i] = row[at < L ? at : L - 1]; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) rows_s[sq * 16 + 4 * g + i] = rb[i];
-    }
+    };
+    if (!p.lp_mail) read_rows();                             // (a pre-launched instance has no sequences yet)
     // Two-part LDS fill: what phase 1 reads (conv2 blocks; biases + conv1 rows behind conv3) now, conv3 (78 of the 111 KiB) after
     // phase 1 -- its loads are in flight while the block waits at the barrier anyway
     const int a_lo = 0, a_hi = p.off_c3 - p.lds_from, c_lo = p.off_cb - p.lds_from, c_hi = p.lds_floats;
     fill_lds(reinterpret_cast<f4*>(smem + a_lo), reinterpret_cast<const f4*>(p.w[m] + p.lds_from + a_lo), (a_hi - a_lo) / 4);
     fill_lds(reinterpret_cast<f4*>(smem + c_lo), reinterpret_cast<const f4*>(p.w[m] + p.lds_from + c_lo), (c_hi - c_lo) / 4);
     __syncthreads();
+    if (p.lp_mail) {
+        // PRE-LAUNCHED instance: the weights are in LDS; wait for this instance's request word (the host stores it through the BAR
+        // once the caller is back with its sequences), or leave: told to (another call shape, another kernel wants the CUs), or
+        // nobody came within the idle window.  Leaving touches neither the barrier counters nor the pools: the host puts the
+        // counters back when it finds the instance gone.
+        if (tid == 0) {
+            const unsigned long long* w = &p.lp_mail->req[blockIdx.x & 15u].w;
+            const unsigned long long t0 = wall_clock64();
+            int go = 0;
+            for (;;) {
+                const unsigned long long r = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (r == p.lp_word) { go = 1; break; }
+                if (r == (p.lp_word | 0xFFFFull) || wall_clock64() - t0 > p.lp_idle_ticks) break;      // (told to leave: ITS sequence number with 0xFFFF sequences)
+                __builtin_amdgcn_s_sleep(2);
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            flags[2] = go;
+            if (!go && blockIdx.x == 0) __hip_atomic_store(p.lp_state, (p.lp_done_seq << 1) | 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __syncthreads();
+        if (!flags[2]) return;
+        read_rows();                                         // (first touch of these lines by this launch: written by the host just now)
+    }
     if (p.lp_debug == 1) return;
     const f4* w_c2 = reinterpret_cast<const f4*>(smem + (p.off_c2 - p.lds_from));
     const f4* w_c3 = reinterpret_cast<const f4*>(smem + (p.off_c3 - p.lds_from));
@@ -739,11 +766,21 @@ int launch_lp(fx_engine* e, PairArgs a, size_t lds_bytes) {
     a.lp_rows_a = rows_a;
     a.lp_debug = (int)e->cnn_lp_debug;
     a.lp_done = nullptr;
+    a.lp_mail = nullptr;
     if (e->done_flag && !a.lp_debug) {
         if (++e->done_seq == 0) ++e->done_seq;
+        if (e->done_seq >= 0x7FFFFFFFu) e->done_seq = 1;   // (a pre-launched instance reports (sequence << 1) | 1)
         a.lp_done = e->d_done; a.lp_done_seq = e->done_seq;
         e->done_armed = true;
+        if (e->lp_arm_next && e->lp_mail && e->d_lp_state) {
+            a.lp_mail = e->lp_mail;
+            a.ascii = e->lp_mail->bytes;
+            a.lp_word = ((unsigned long long)e->done_seq << 16) | (unsigned long long)a.N;
+            a.lp_idle_ticks = (unsigned long long)e->serve_idle_us * 100ull;
+            a.lp_state = e->d_lp_state;
+        }
     }
+    e->lp_launches += 1;
     const int64_t G = U * nb;
     const bool arrives = !(a.lp_debug >= 1 && a.lp_debug <= 3);   // (profiling stages that leave before the barrier do not arrive at it)
     for (int gi = 0; gi < 16; ++gi) {

@@ -209,6 +209,7 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
     if (!ascii || !labels) return fx_fail(e, FX_EINVAL, "fx_train_fit: null data");
     if (n > (int64_t)1 << 30) return fx_fail(e, FX_EINVAL, "fx_train_fit: data set too large");
     fx_server_stop(e);                                     // the step kernels want every CU
+    fx_lp_disarm(e);
     std::vector<FxtJob> hj((size_t)M);
     std::vector<std::vector<float>> lr((size_t)M);
     int max_steps = 0, max_S = 0, max_P = 0;

@@ -122,6 +122,14 @@ const char *fx_last_error(fx_engine *e);
  *                              calls): member planes straight to pinned host memory, np.mean's order on the host, no mean
  *                              launch; same bits.  0 = the mean kernel.  call_prof_0 .. _3 (read): that call's timeline, ns
  *                              (prepared, launched, synchronised, mean taken).
+ *   lp_prelaunch      1        1 = after an explorer-size host call of a protein CNN ensemble was answered by the layer-parallel
+ *                              form, the NEXT instance of that call (same members, batch size, output form) is enqueued at
+ *                              once: it fills its weights and waits up to serve_idle_us for its request word in a mailbox
+ *                              the host stores into through the BAR -- a caller that is back within that window (CMA-ES,
+ *                              DyNA-PPO) pays neither launch latency nor weight fill: 37.8 -> 31.9 us per call.  The waiting
+ *                              instance holds most CUs; a call of another shape, training, any option change tell it to
+ *                              leave at once, work enqueued on the engine's stream by anything else waits for its idle exit
+ *                              (<= serve_idle_us).  0 = a launch per call.  lp_armed_served (read): calls answered so.
  *   done_flag         1        1 = a launched small host call whose last kernel can tell when its last result is written (the
  *                              layer-parallel protein CNN form) is waited for by polling a completion word in pinned host
  *                              memory instead of hipStreamSynchronize: ~4 us of a 46 us call; 0 = always the stream.

@@ -1888,6 +1888,67 @@ def test_resident_tiny_requests(eng, kind, L, alpha, M):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("L,M", [(90, 3), (237, 1), (60, 2)])
+def test_prelaunched_instance_of_the_layer_parallel_form(eng, L, M):
+    """Round 4 (`lp_prelaunch`, default on): after an explorer-size call of a protein CNN ensemble was answered by the layer-parallel
+    form, the NEXT instance of that call is enqueued at once; it fills its weights and waits for its request word in a mailbox the
+    host stores into through the BAR, so a caller that is back with the same batch shape within the idle window pays neither the
+    launch latency nor the weight fill.  Same bits as a launch per call and beside the oracle; an instance of another shape /
+    another ensemble / after new weights / after an idle gap steps aside (and the barrier counters it was counted into are put
+    back); a character outside the alphabet is the ValueError of every path; training in between."""
+    import time as _t
+    members = [bm.CNN(L, 32, 100, s_utils.AAS, seed=300 + s) for s in range(M)]
+    ens = flexs_amd.Ensemble(members) if M > 1 else members[0]
+    other = flexs_amd.Ensemble([bm.CNN(8, 32, 100, "TGCA", seed=s) for s in range(3)])
+    sizes = (1, 7, 16, 17, 40)
+    data = {n: rand_seqs(n, L, s_utils.AAS, seed=40 + n)[1] for n in sizes}
+    small = rand_seqs(20, 8, "TGCA", seed=3)[1]
+    eng.set_option("lp_prelaunch", 0)
+    try:
+        want = {n: ens.get_fitness(data[n]) for n in sizes}
+        want_small = other.get_fitness(small)
+        eng.set_option("lp_prelaunch", 1)
+        s0 = eng.get_option("lp_armed_served")
+        for n in sizes:                                      # the same call again and again: from the second on, a pre-launched instance
+            for rep in range(6):
+                assert np.array_equal(ens.get_fitness(data[n]), want[n]), (L, M, n, rep)
+        assert eng.get_option("lp_armed_served") - s0 >= 3 * len(sizes)
+        for it in range(300):                                # everything that makes an instance step aside, interleaved
+            n = sizes[it % 5] if it % 3 == 0 else 7
+            assert np.array_equal(ens.get_fitness(data[n]), want[n]), (L, M, n, it)
+            if it % 20 == 19:
+                assert np.array_equal(other.get_fitness(small), want_small)
+            if it % 70 == 69:
+                _t.sleep(0.003)                              # (longer than the idle window: the instance has left by itself)
+            if it % 90 == 89:
+                bad = list(data[7])
+                bad[-1] = bad[-1][:-1] + "!"
+                with pytest.raises(ValueError):
+                    ens.get_fitness(bad)
+        got = ens.get_fitness(data[16])
+        if M > 1:
+            stack = flexs_amd.Ensemble(members, combine_with=lambda x: x).get_fitness(data[16])
+            assert np.array_equal(got, np.mean(stack, axis=1))
+        else:
+            stack = got[:, None]
+        ref = ref_np.keras_fitness(data[16], s_utils.AAS, "cnn", [np.asarray(w, np.float64) for w in members[0].model.get_weights()], exact=True)
+        assert_scores(stack[:, 0], ref, f"pre-launched instance, L={L}")
+        # new weights: the waiting instance has the OLD ones in LDS and must not answer
+        for _ in range(3):
+            ens.get_fitness(data[7])
+        y = np.linspace(0.0, 1.0, 40)
+        ens.train(data[40], y)
+        eng.set_option("lp_prelaunch", 0)
+        fresh = ens.get_fitness(data[7])
+        eng.set_option("lp_prelaunch", 1)
+        assert not np.array_equal(fresh, want[7])
+        for rep in range(4):
+            assert np.array_equal(ens.get_fitness(data[7]), fresh)
+    finally:
+        eng.set_option("lp_prelaunch", 1)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("L,M", [(90, 3), (237, 2), (33, 8), (40, 16)])
 def test_host_side_mean_of_small_launched_calls(eng, L, M):
     """Launched mean-only host calls of at most `host_mean_below` sequences (the protein CNN's explorer-size calls): the member
