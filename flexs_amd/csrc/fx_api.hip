@@ -1288,6 +1288,13 @@ int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii,
     if (N == 0) return FX_OK;
     if (!ascii || (!out_NM && !out_mean)) return fx_fail(e, FX_EINVAL, "null buffer");
     FX_HIP(e, hipSetDevice(e->device));
+    if (e->lp_armed.on) {
+        // a pre-launched instance of ANOTHER call leaves now, before this call's buffer management can wait for it on the stream
+        const auto& pa = e->lp_armed;
+        bool same = (int)pa.models.size() == M && pa.N == N && pa.L == L;
+        for (int m = 0; same && m < M; ++m) same = pa.models[m] == models[m];
+        if (!same) lp_disarm(e);
+    }
     {
         rc = server_call(e, models, M, ascii, N, L, lut, out_NM, out_mean);
         if (rc != FX_EUNSUPPORTED) return rc;
