@@ -195,6 +195,7 @@ struct fx_engine {
     // the current dispatch does so (cleared before every launch group, set by the launcher).
     unsigned* h_done = nullptr; unsigned* d_done = nullptr;
     unsigned done_seq = 0;
+    unsigned done_value = 0;         // last value handed to hipStreamWriteValue32 (h_done[8]): launches without a kernel-side flag
     bool done_armed = false;
     // Pre-launched instance of the layer-parallel form (fx_api.hip lp_arm / lp_try_armed): after an explorer-size call of a protein
     // CNN ensemble was answered by k_score_cnn_lp, the NEXT instance is enqueued at once -- it fills its weights and waits for
