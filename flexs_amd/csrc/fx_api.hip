@@ -1038,6 +1038,13 @@ static int wait_for_results(fx_engine* e, unsigned want_seq = 0) {
     return FX_OK;
 }
 
+// The explorer-size (zero-copy) forms of the small entry points -- distances, neighbour search, table look-ups, the fused
+// NoisyAbstractModel query, the population step: everything they enqueued has finished when this returns.
+static int fx_wait_small(fx_engine* e) {
+    e->done_armed = false;
+    return wait_for_results(e);
+}
+
 static int64_t server_since(const fx_engine* e) {
     return (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - e->server.t_entry).count();
 }
@@ -1601,7 +1608,7 @@ int fx_ensemble_reduce(fx_engine* e, const float* scores, int64_t N, int M, cons
         if (weights) std::memcpy(z.h_in + o_w, weights, sizeof(double) * (size_t)M);
         if ((rc = fx_launch_ensemble_reduce(e, (const float*)z.d_in, N, M, weights ? (const double*)(z.d_in + o_w) : nullptr,
                                             (float*)z.d_out, (double*)z.d_out))) return rc;
-        FX_HIP(e, hipStreamSynchronize(e->stream));
+        if ((rc = fx_wait_small(e))) return rc;          // (a completion value polled in pinned memory: wait_for_results)
         std::memcpy(weights ? (void*)out64 : (void*)out32, z.h_out, out_bytes);
         return FX_OK;
     }
@@ -1667,7 +1674,7 @@ int fx_decode_score(fx_engine* e, fx_model* const* models, int M, const double* 
         if ((rc = fx_launch_argmax_decode(e, (const double*)z.d_in, rows, A, (const uint8_t*)(z.d_in + in_bytes), z_chars))) return rc;
         if ((rc = score_dispatch(e, models, M, z_chars, P, L, z_NM))) return rc;
         if (out_mean && (rc = fx_launch_ensemble_reduce(e, z_NM, P, M, nullptr, z_mean, nullptr))) return rc;
-        FX_HIP(e, hipStreamSynchronize(e->stream));
+        if ((rc = fx_wait_small(e))) return rc;          // (a completion value polled in pinned memory: wait_for_results)
         if (out_mean) std::memcpy(out_mean, z.h_out + nm_bytes, mean_bytes);
         if (out_NM) std::memcpy(out_NM, z.h_out, nm_bytes);
         std::memcpy(out_chars, z.h_out + o_chars, (size_t)rows);
@@ -1717,7 +1724,7 @@ static int min_dist_common(fx_engine* e, int mode, const uint8_t* queries, int64
         int32_t* zd_dist = (int32_t*)(z.d_out + (size_t)Q * 8);
         if ((rc = fx_launch_min_dist(e, mode, (const uint8_t*)z.d_in, Q, d_cache, C, L, (unsigned long long*)d_keys))) return rc;
         if ((rc = fx_launch_min_dist_finish(e, (unsigned long long*)d_keys, Q, C, zd_dist, zd_arg))) return rc;
-        FX_HIP(e, hipStreamSynchronize(e->stream));
+        if ((rc = fx_wait_small(e))) return rc;          // (a completion value polled in pinned memory: wait_for_results)
         std::memcpy(argmin, z.h_out, (size_t)Q * 8);
         std::memcpy(dist, z.h_out + (size_t)Q * 8, (size_t)Q * 4);
         return FX_OK;
@@ -1872,7 +1879,7 @@ int fx_cache_nam_query(fx_cache* c, fx_table* t, int bits, const uint8_t lut[256
                                         (const double*)(d_in + o_E), (const double*)(d_in + o_tab), n_tab, (double*)d_out,
                                         (int32_t*)(d_out + o_flags)))) return rc;
     if (!zc) FX_HIP(e, hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, e->stream));
-    FX_HIP(e, hipStreamSynchronize(e->stream));
+    if ((rc = fx_wait_small(e))) return rc;          // (a completion value polled in pinned memory: wait_for_results)
     std::memcpy(out, h_out, (size_t)Q * 8);
     std::memcpy(argmin, h_out + o_arg, (size_t)Q * 8);
     std::memcpy(dist, h_out + o_dist, (size_t)Q * 4);
@@ -1894,7 +1901,7 @@ int fx_cache_distances(fx_cache* c, int mode, const uint8_t* queries, int64_t Q,
         if ((rc = fx_zero_copy_buffers(e, (size_t)Q * c->L + 16, (size_t)Q * c->size, &z))) return rc;
         std::memcpy(z.h_in, queries, (size_t)Q * c->L);
         if ((rc = fx_launch_distances(e, mode, (const uint8_t*)z.d_in, Q, c->d_keys, c->size, c->L, (uint8_t*)z.d_out))) return rc;
-        FX_HIP(e, hipStreamSynchronize(e->stream));
+        if ((rc = fx_wait_small(e))) return rc;          // (a completion value polled in pinned memory: wait_for_results)
         std::memcpy(out, z.h_out, (size_t)Q * c->size);
         return FX_OK;
     }
@@ -1947,7 +1954,7 @@ int fx_table_lookup(fx_table* t, const uint8_t* ascii, int64_t N, int L, const u
         std::memcpy(z.h_in, ascii, (size_t)N * L);
         if ((rc = fx_upload_lut(e, lut))) return rc;
         if ((rc = fx_launch_table_lookup(e, t->d_table, t->len, (const uint8_t*)z.d_in, N, L, bits, (double*)z.d_out))) return rc;
-        FX_HIP(e, hipStreamSynchronize(e->stream));
+        if ((rc = fx_wait_small(e))) return rc;          // (a completion value polled in pinned memory: wait_for_results)
         std::memcpy(out, z.h_out, (size_t)N * 8);
         return FX_OK;
     }
@@ -1978,7 +1985,7 @@ int fx_table_additive(fx_table* t, const uint8_t* ascii, int64_t N, int L, const
         std::memcpy(z.h_in, ascii, (size_t)N * L);
         if ((rc = fx_upload_lut(e, lut))) return rc;
         if ((rc = fx_launch_additive_sum(e, t->d_table, L, ncol, (const uint8_t*)z.d_in, N, (double*)z.d_out))) return rc;
-        FX_HIP(e, hipStreamSynchronize(e->stream));
+        if ((rc = fx_wait_small(e))) return rc;          // (a completion value polled in pinned memory: wait_for_results)
         std::memcpy(out, z.h_out, (size_t)N * 8);
         return FX_OK;
     }
@@ -2011,7 +2018,7 @@ int fx_nam_combine(fx_engine* e, int64_t Q, const double* signal, const double* 
         std::memcpy(z.h_in + o_d, d, (size_t)Q * 4);
         if ((rc = fx_launch_nam_combine(e, Q, (const double*)z.d_in, (const double*)(z.d_in + qb), (const int32_t*)(z.d_in + o_d),
                                         (const double*)(z.d_in + o_tab), n_tab, (double*)z.d_out))) return rc;
-        FX_HIP(e, hipStreamSynchronize(e->stream));
+        if ((rc = fx_wait_small(e))) return rc;          // (a completion value polled in pinned memory: wait_for_results)
         std::memcpy(out, z.h_out, qb);
         return FX_OK;
     }
