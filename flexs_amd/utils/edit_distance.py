@@ -47,12 +47,14 @@ class SeenSequences:
         if not seqs or len(self._fitness) == 0:
             return [0 for _ in seqs]
         d_all = self._cache.distances(_native.ragged_to_bytes(seqs, self._L), self._mode)
-        out = []
-        for d in d_all:
-            dens = 0
-            for i in np.flatnonzero((d != 0) & (d <= dist_radius)):
-                dens += self._fitness[i] / int(d[i])
-            out.append(dens)
+        # the neighbours of ALL queries with three array operations (row-major: within a query in insertion order, as the
+        # reference's dict walk), then the same Python float sums in the same order -- per query that was three NumPy calls on a
+        # 1000-element row, 35 us of a 67 us call for ten queries
+        rows, cols = np.nonzero((d_all != 0) & (d_all <= dist_radius))
+        out = [0] * len(seqs)
+        fit = self._fitness
+        for r, i, dist in zip(rows.tolist(), cols.tolist(), d_all[rows, cols].tolist()):
+            out[r] += fit[i] / dist
         return out
 
     def density(self, seq: str, dist_radius: int = 2):

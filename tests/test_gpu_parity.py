@@ -931,7 +931,11 @@ def test_sequence_density(eng):
                 if d != 0 and d <= 2:
                     dens += ref[s] / d
             assert seen.density(q) == dens
-    assert SeenSequences(5).density("ACGTA") == 0
+        # the batch form (one distance launch, the neighbours of all queries found with three array operations): same sums
+        qs = list(ref)[:40] + [base, base[1:] + base[:1]]
+        assert seen.densities(qs) == [seen.density(q) for q in qs]
+        assert seen.densities([]) == []
+    assert SeenSequences(5).density("ACGTA") == 0 and SeenSequences(5).densities(["ACGTA", "AC"]) == [0, 0]
 
 
 # ------------------------------------------------------------------ randomised shapes (dispatch boundaries)
