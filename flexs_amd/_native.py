@@ -78,6 +78,7 @@ SIGNATURES = {
     "fx_cache_min_dist": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, _vp, _vp]),
     "fx_cache_nam_query": (C.c_int, [_vp, _vp, C.c_int, _u8p, C.c_int, _vp, C.c_int64, _vp, C.c_int64, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "fx_cache_distances": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, _vp]),
+    "fx_cache_density": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, C.c_int, _vp, _vp, _vp]),
     "fx_table_create": (C.c_int, [_vp, _vp, C.c_int64, C.POINTER(_vp)]),
     "fx_table_destroy": (C.c_int, [_vp]),
     "fx_table_lookup": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _u8p, C.c_int, _vp]),
@@ -654,6 +655,17 @@ class NativeCache:
         ms = C.c_float(0.0)
         self.engine.check(self.engine._lib.fx_debug_time_min_dist(self.handle, mode, _ptr(q), q.shape[0], reps, C.byref(ms)))
         return float(ms.value)
+
+    def density(self, queries: np.ndarray, fitness: np.ndarray, radius: int, mode: int = FX_LEVENSHTEIN):
+        """fx_cache_density: (float64 densities, int32 neighbour counts) of the queries against every stored key."""
+        q = np.ascontiguousarray(queries, np.uint8)
+        f = np.ascontiguousarray(fitness, np.float64)
+        if f.shape[0] < len(self):
+            raise ValueError("one fitness value per stored key")
+        dens = np.empty(q.shape[0], np.float64)
+        cnt = np.empty(q.shape[0], np.int32)
+        self.engine.check(self.engine._lib.fx_cache_density(self.handle, mode, _ptr(q), q.shape[0], int(radius), _ptr(f), _ptr(dens), _ptr(cnt)))
+        return dens, cnt
 
     def distances(self, queries: np.ndarray, mode: int = FX_LEVENSHTEIN) -> np.ndarray:
         """(Q, C) uint8 matrix of min(distance, 255) against every stored key."""

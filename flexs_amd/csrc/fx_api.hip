@@ -322,6 +322,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "serve_fence")) return &e->serve_fence;
     if (!std::strcmp(key, "serve_quads")) return &e->serve_quads;
     if (!std::strcmp(key, "serve_tiny")) return &e->serve_tiny;
+    if (!std::strcmp(key, "dist_stage")) return &e->dist_stage;
     if (!std::strcmp(key, "host_mean_below")) return &e->host_mean_below;
     if (!std::strcmp(key, "done_flag")) return &e->done_flag;
     if (!std::strcmp(key, "lp_prelaunch")) return &e->lp_prelaunch;
@@ -1915,6 +1916,40 @@ int fx_cache_distances(fx_cache* c, int mode, const uint8_t* queries, int64_t Q,
         if ((rc = fx_launch_distances(e, mode, (const uint8_t*)d_q, qn, c->d_keys, c->size, c->L, (uint8_t*)d_out))) return rc;
         FX_HIP(e, hipMemcpyAsync(out + q0 * c->size, d_out, (size_t)qn * c->size, hipMemcpyDeviceToHost, e->stream));
         FX_HIP(e, hipStreamSynchronize(e->stream));
+    }
+    return FX_OK;
+}
+
+int fx_cache_density(fx_cache* c, int mode, const uint8_t* queries, int64_t Q, int radius, const double* fitness, double* density,
+                     int32_t* neighbours) {
+    if (!c || Q < 0 || radius < 0) return FX_EINVAL;
+    fx_engine* e = c->eng;
+    if (mode != FX_LEVENSHTEIN && mode != FX_HAMMING) return fx_fail(e, FX_EINVAL, "unknown distance mode");
+    if (Q == 0) return FX_OK;
+    if (!queries || !density || !neighbours || (!fitness && c->size > 0)) return fx_fail(e, FX_EINVAL, "null buffer");
+    const int64_t C = c->size;
+    for (int64_t q = 0; q < Q; ++q) { density[q] = 0.0; neighbours[q] = 0; }
+    if (C == 0) return FX_OK;
+    // query blocks whose distance rows fit the pinned staging area; a row at a time on the host: a byte compare per key, the
+    // division and the sum only for the few neighbours -- same operations, same order as `for s in all_seqs: ... dens += f / dist`
+    const int64_t qstep = std::max<int64_t>(1, std::min<int64_t>(Q, (int64_t)(e->zero_copy_bytes > 0 ? e->zero_copy_bytes : (1 << 18)) / std::max<int64_t>(C + c->L, 1)));
+    std::vector<uint8_t> rows;
+    const int r = radius > 254 ? 254 : radius;
+    for (int64_t q0 = 0; q0 < Q; q0 += qstep) {
+        const int64_t qn = std::min<int64_t>(qstep, Q - q0);
+        rows.resize((size_t)qn * (size_t)C);
+        if (int rc = fx_cache_distances(c, mode, queries + q0 * c->L, qn, rows.data())) return rc;
+        for (int64_t q = 0; q < qn; ++q) {
+            const uint8_t* d = rows.data() + (size_t)q * (size_t)C;
+            double dens = 0.0;
+            int32_t cnt = 0;
+            for (int64_t i = 0; i < C; ++i) {
+                const unsigned di = d[i];
+                if ((unsigned)(di - 1u) < (unsigned)r) { dens += fitness[i] / (double)di; ++cnt; }    // 0 < dist <= radius
+            }
+            density[q0 + q] = dens;
+            neighbours[q0 + q] = cnt;
+        }
     }
     return FX_OK;
 }

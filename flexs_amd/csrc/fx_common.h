@@ -285,6 +285,7 @@ struct fx_engine {
     int64_t serve_reserve_cus = 16;   // CUs a wide generation leaves without a resident workgroup (kernels of other streams -- RCCL, PyTorch -- find room there at once; small ones also fit beside a resident workgroup)
     int64_t call_prof_ns[4] = {};    // the last launched small mean-only host call: ns since entry at "prepared", "launched", "synchronised", "mean taken"
     int64_t host_mean_below = 256;   // launched mean-only host calls of at most this many sequences (zero-copy): member planes to pinned host memory, np.mean's order on the host, no mean launch (0 = the mean kernel: A/B)
+    int64_t dist_stage = 1;     // edit-distance kernels, small launches: 1 = a block's 256 cache rows are copied to LDS and the recurrence reads them there (rows of <= 160 bytes), 0 = every thread reads its row from global memory (A/B)
     int64_t serve_tiny = 1;     // 1 = requests of <= 48 sequence bytes carry them in the request word's own line (0 = always the byte area: A/B)
     int64_t serve_quads = 1;    // wide generation, CNN with seq_len <= 8: tiles per resident workgroup side by side (1 = one; 3 = like the launched form: A/B build only -- slower once requests are streamed, csrc/OPTIONS.md)
     int64_t serve_fence = 0;    // 1 = a system fence after every tile's answers (round 3: ~0.5 us each, and the fences of one XCD serialise -- 24 us for the 378 tiles of a 2001-sequence request, profiles/r4_mailbox_probe3.log); 0 = none: the answers are system-scope stores, which write through by themselves (profiles/r4_mailbox_probe4.log)

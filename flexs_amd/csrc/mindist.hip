@@ -21,6 +21,13 @@ namespace {
 constexpr int CHUNK = 1024;     // cache entries per block
 constexpr int FX_MINDIST_MAX_L = 768;   // 12 words of 64 pattern rows
 
+// Cache rows per block = passes x 256.  A large launch walks CHUNK rows per block (the query's match masks are built once per
+// block); an explorer-size one -- a DyNA-PPO environment step: ten queries against the 3000 sequences seen so far -- had 30 blocks
+// on 256 CUs that way, each thread walking four pairs in turn: one pass per block gives it four times the blocks (distance matrix
+// of that step 139 -> 59 us).  (Staging the rows through LDS was measured too: the recurrence, not the row bytes, is what a
+// pair costs -- 120 -> 143 us -- not kept.)
+static inline int fx_dist_passes(int64_t C, int64_t Q) { return ((C + CHUNK - 1) / CHUNK) * Q < 512 ? 1 : CHUNK / 256; }
+
 // Block prologue shared by both kernels: stage query `qi` in LDS, let thread c build the match masks of byte
 // value c, and return the query length (its first NUL, every thread finds it itself).
 template <int W, typename Word>
@@ -48,6 +55,26 @@ __device__ __forceinline__ int load_query(const uint8_t* __restrict__ q, int64_t
     return m;
 }
 
+// Small launches (fx_dist_passes == 1): the block's 256 cache rows -- ONE contiguous, 16-byte aligned piece of the cache -- are
+// copied to LDS with 16-byte loads that are all in flight at once, and the recurrence reads its text bytes from LDS.  Read from
+// global memory, a thread's row costs one ~0.45 us round trip PER COLUMN (the byte is needed to pick the match mask; nothing of the
+// next column can start before it): 42 us for a 90-residue pair whose arithmetic is ~5 us.  A large launch hides that behind its
+// other waves (0.94 of the integer-VALU roofline at 2000 x 20 000, BASELINE's shape) and keeps reading global memory.
+constexpr int FX_STAGE_MAX_L = 160;      // 40 KiB of rows beside the match masks
+__device__ __forceinline__ void stage_rows(const uint8_t* __restrict__ cache, int64_t c_first, int64_t C, int L, uint8_t* ts) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const int64_t rows = C - c_first < 256 ? C - c_first : 256;
+    const int total = (int)rows * L, n16 = total >> 4;
+    const uint8_t* src = cache + c_first * L;               // (c_first is a multiple of 256: 16-byte aligned whatever L)
+    constexpr int MAXV = FX_STAGE_MAX_L / 16;               // 16-byte pieces per thread
+    u4 v[MAXV];
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) { const int i = (int)threadIdx.x + k * 256; if (i < n16) v[k] = reinterpret_cast<const u4*>(src)[i]; }
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) { const int i = (int)threadIdx.x + k * 256; if (i < n16) reinterpret_cast<u4*>(ts)[i] = v[k]; }
+    for (int i = (n16 << 4) + (int)threadIdx.x; i < total; i += 256) ts[i] = src[i];
+}
+
 // Distance of the staged query to one cache row.
 template <int W, typename Word>
 __device__ __forceinline__ int pair_distance(int mode, int m, int L, const uint8_t* qs, const Word* peq,
@@ -61,22 +88,24 @@ __device__ __forceinline__ int pair_distance(int mode, int m, int L, const uint8
         m, L, [&](int ch, int w) { return peq[ch * W + w]; }, [&](int i) { return (int)t[i]; });
 }
 
-template <int W, typename Word>
+template <int W, typename Word, bool STAGE>
 __global__ void __launch_bounds__(256) k_min_dist(int mode, const uint8_t* __restrict__ q, const uint8_t* __restrict__ cache,
-                                                  int64_t C, int L, unsigned long long* __restrict__ keys) {
+                                                  int64_t C, int L, unsigned long long* __restrict__ keys, int passes) {
     __shared__ Word peq[256 * W];
     __shared__ uint8_t qs[W * 8 * sizeof(Word)];
     __shared__ unsigned long long wave_min[4];
+    extern __shared__ __attribute__((aligned(16))) uint8_t fx_text_rows[];
     const int tid = threadIdx.x;
     const int64_t qi = blockIdx.y;
+    const int64_t c0 = (int64_t)blockIdx.x * passes * 256;    // `passes` x 256 cache rows per block (fx_dist_passes)
+    if (STAGE) stage_rows(cache, c0, C, L, fx_text_rows);     // (passes == 1; published by load_query's barriers)
     const int m = load_query<W, Word>(q, qi, L, qs, peq);
 
     unsigned long long best = ~0ull;
-    const int64_t c0 = (int64_t)blockIdx.x * CHUNK;
-    for (int k = 0; k < CHUNK / 256; ++k) {
+    for (int k = 0; k < passes; ++k) {
         const int64_t c = c0 + k * 256 + tid;
         if (c >= C) break;
-        const int d = pair_distance<W, Word>(mode, m, L, qs, peq, cache + c * L);
+        const int d = pair_distance<W, Word>(mode, m, L, qs, peq, STAGE ? (const uint8_t*)fx_text_rows + tid * L : cache + c * L);
         const unsigned dp = d == 1 ? 0u : (d == 0 ? 1u : (unsigned)d);
         const unsigned long long key = ((unsigned long long)dp << 32) | (unsigned long long)c;
         best = key < best ? key : best;
@@ -96,18 +125,20 @@ __global__ void __launch_bounds__(256) k_min_dist(int mode, const uint8_t* __res
 }
 
 // Dense Q x C distance matrix (uint8, clamped) -- same per-pair code as k_min_dist.
-template <int W, typename Word>
+template <int W, typename Word, bool STAGE>
 __global__ void __launch_bounds__(256) k_distances(int mode, const uint8_t* __restrict__ q, const uint8_t* __restrict__ cache,
-                                                   int64_t C, int L, uint8_t* __restrict__ out) {
+                                                   int64_t C, int L, uint8_t* __restrict__ out, int passes) {
     __shared__ Word peq[256 * W];
     __shared__ uint8_t qs[W * 8 * sizeof(Word)];
+    extern __shared__ __attribute__((aligned(16))) uint8_t fx_text_rows[];
     const int64_t qi = blockIdx.y;
+    const int64_t c0 = (int64_t)blockIdx.x * passes * 256;
+    if (STAGE) stage_rows(cache, c0, C, L, fx_text_rows);     // (passes == 1; published by load_query's barriers)
     const int m = load_query<W, Word>(q, qi, L, qs, peq);
-    const int64_t c0 = (int64_t)blockIdx.x * CHUNK;
-    for (int k = 0; k < CHUNK / 256; ++k) {
+    for (int k = 0; k < passes; ++k) {
         const int64_t c = c0 + k * 256 + threadIdx.x;
         if (c >= C) break;
-        const int d = pair_distance<W, Word>(mode, m, L, qs, peq, cache + c * L);
+        const int d = pair_distance<W, Word>(mode, m, L, qs, peq, STAGE ? (const uint8_t*)fx_text_rows + threadIdx.x * L : cache + c * L);
         out[qi * C + c] = (uint8_t)(d > 255 ? 255 : d);
     }
 }
@@ -235,18 +266,21 @@ int fx_launch_min_dist(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, co
     if (Q > 65535) return fx_fail(e, FX_EINVAL, "min_dist: more than 65535 queries per call (split the batch)");
     FX_HIP(e, hipMemsetAsync(d_keys, 0xFF, sizeof(unsigned long long) * (size_t)Q, e->stream));
     if (L > FX_MINDIST_MAX_L) return launch_long<false>(e, mode, d_q, Q, d_cache, C, L, d_keys, nullptr);
-    dim3 grid((unsigned)((C + CHUNK - 1) / CHUNK), (unsigned)Q), block(256);
+    const int passes = fx_dist_passes(C, Q);
+    const bool stage = passes == 1 && L <= FX_STAGE_MAX_L && e->dist_stage;      // small launch: the block's cache rows through LDS
+    const size_t lds = (size_t)256 * L + 16;
+    dim3 grid((unsigned)((C + (int64_t)passes * 256 - 1) / ((int64_t)passes * 256)), (unsigned)Q), block(256);
     if (L <= 32) {          // one 32-bit word per column: half the integer work of the 64-bit form
-        hipLaunchKernelGGL((k_min_dist<1, uint32_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys);
+        { if (stage) hipLaunchKernelGGL((k_min_dist<1, uint32_t, true>), grid, block, lds, e->stream, mode, d_q, d_cache, C, L, d_keys, passes); else hipLaunchKernelGGL((k_min_dist<1, uint32_t, false>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys, passes); }
     } else {
         switch ((L + 63) / 64) {
-            case 1: hipLaunchKernelGGL((k_min_dist<1, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
-            case 2: hipLaunchKernelGGL((k_min_dist<2, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
-            case 3: hipLaunchKernelGGL((k_min_dist<3, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
-            case 4: hipLaunchKernelGGL((k_min_dist<4, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
-            case 5: case 6: hipLaunchKernelGGL((k_min_dist<6, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
-            case 7: case 8: hipLaunchKernelGGL((k_min_dist<8, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;
-            default: hipLaunchKernelGGL((k_min_dist<12, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys); break;   // L <= 768 (full-length AAV capsid: 735)
+            case 1: { if (stage) hipLaunchKernelGGL((k_min_dist<1, uint64_t, true>), grid, block, lds, e->stream, mode, d_q, d_cache, C, L, d_keys, passes); else hipLaunchKernelGGL((k_min_dist<1, uint64_t, false>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys, passes); } break;
+            case 2: { if (stage) hipLaunchKernelGGL((k_min_dist<2, uint64_t, true>), grid, block, lds, e->stream, mode, d_q, d_cache, C, L, d_keys, passes); else hipLaunchKernelGGL((k_min_dist<2, uint64_t, false>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys, passes); } break;
+            case 3: { if (stage) hipLaunchKernelGGL((k_min_dist<3, uint64_t, true>), grid, block, lds, e->stream, mode, d_q, d_cache, C, L, d_keys, passes); else hipLaunchKernelGGL((k_min_dist<3, uint64_t, false>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys, passes); } break;
+            case 4: { if (stage) hipLaunchKernelGGL((k_min_dist<4, uint64_t, true>), grid, block, lds, e->stream, mode, d_q, d_cache, C, L, d_keys, passes); else hipLaunchKernelGGL((k_min_dist<4, uint64_t, false>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys, passes); } break;
+            case 5: case 6: { if (stage) hipLaunchKernelGGL((k_min_dist<6, uint64_t, true>), grid, block, lds, e->stream, mode, d_q, d_cache, C, L, d_keys, passes); else hipLaunchKernelGGL((k_min_dist<6, uint64_t, false>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys, passes); } break;
+            case 7: case 8: { if (stage) hipLaunchKernelGGL((k_min_dist<8, uint64_t, true>), grid, block, lds, e->stream, mode, d_q, d_cache, C, L, d_keys, passes); else hipLaunchKernelGGL((k_min_dist<8, uint64_t, false>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys, passes); } break;
+            default: { if (stage) hipLaunchKernelGGL((k_min_dist<12, uint64_t, true>), grid, block, lds, e->stream, mode, d_q, d_cache, C, L, d_keys, passes); else hipLaunchKernelGGL((k_min_dist<12, uint64_t, false>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_keys, passes); } break;   // L <= 768 (full-length AAV capsid: 735)
         }
     }
     FX_HIP(e, hipGetLastError());
@@ -258,18 +292,21 @@ int fx_launch_distances(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, c
     if (Q == 0 || C == 0) return FX_OK;
     if (Q > 65535) return fx_fail(e, FX_EINVAL, "distances: more than 65535 queries per call");
     if (L > FX_MINDIST_MAX_L) return launch_long<true>(e, mode, d_q, Q, d_cache, C, L, nullptr, d_out);
-    dim3 grid((unsigned)((C + CHUNK - 1) / CHUNK), (unsigned)Q), block(256);
+    const int passes = fx_dist_passes(C, Q);
+    const bool stage = passes == 1 && L <= FX_STAGE_MAX_L && e->dist_stage;      // small launch: the block's cache rows through LDS
+    const size_t lds = (size_t)256 * L + 16;
+    dim3 grid((unsigned)((C + (int64_t)passes * 256 - 1) / ((int64_t)passes * 256)), (unsigned)Q), block(256);
     if (L <= 32) {
-        hipLaunchKernelGGL((k_distances<1, uint32_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out);
+        { if (stage) hipLaunchKernelGGL((k_distances<1, uint32_t, true>), grid, block, lds, e->stream, mode, d_q, d_cache, C, L, d_out, passes); else hipLaunchKernelGGL((k_distances<1, uint32_t, false>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out, passes); }
     } else {
         switch ((L + 63) / 64) {
-            case 1: hipLaunchKernelGGL((k_distances<1, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;
-            case 2: hipLaunchKernelGGL((k_distances<2, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;
-            case 3: hipLaunchKernelGGL((k_distances<3, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;
-            case 4: hipLaunchKernelGGL((k_distances<4, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;
-            case 5: case 6: hipLaunchKernelGGL((k_distances<6, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;
-            case 7: case 8: hipLaunchKernelGGL((k_distances<8, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;
-            default: hipLaunchKernelGGL((k_distances<12, uint64_t>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); break;   // L <= 768 (full-length AAV capsid: 735)
+            case 1: { if (stage) hipLaunchKernelGGL((k_distances<1, uint64_t, true>), grid, block, lds, e->stream, mode, d_q, d_cache, C, L, d_out, passes); else hipLaunchKernelGGL((k_distances<1, uint64_t, false>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out, passes); } break;
+            case 2: { if (stage) hipLaunchKernelGGL((k_distances<2, uint64_t, true>), grid, block, lds, e->stream, mode, d_q, d_cache, C, L, d_out, passes); else hipLaunchKernelGGL((k_distances<2, uint64_t, false>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out, passes); } break;
+            case 3: { if (stage) hipLaunchKernelGGL((k_distances<3, uint64_t, true>), grid, block, lds, e->stream, mode, d_q, d_cache, C, L, d_out, passes); else hipLaunchKernelGGL((k_distances<3, uint64_t, false>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out, passes); } break;
+            case 4: { if (stage) hipLaunchKernelGGL((k_distances<4, uint64_t, true>), grid, block, lds, e->stream, mode, d_q, d_cache, C, L, d_out, passes); else hipLaunchKernelGGL((k_distances<4, uint64_t, false>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out, passes); } break;
+            case 5: case 6: { if (stage) hipLaunchKernelGGL((k_distances<6, uint64_t, true>), grid, block, lds, e->stream, mode, d_q, d_cache, C, L, d_out, passes); else hipLaunchKernelGGL((k_distances<6, uint64_t, false>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out, passes); } break;
+            case 7: case 8: { if (stage) hipLaunchKernelGGL((k_distances<8, uint64_t, true>), grid, block, lds, e->stream, mode, d_q, d_cache, C, L, d_out, passes); else hipLaunchKernelGGL((k_distances<8, uint64_t, false>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out, passes); } break;
+            default: { if (stage) hipLaunchKernelGGL((k_distances<12, uint64_t, true>), grid, block, lds, e->stream, mode, d_q, d_cache, C, L, d_out, passes); else hipLaunchKernelGGL((k_distances<12, uint64_t, false>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out, passes); } break;   // L <= 768 (full-length AAV capsid: 735)
         }
     }
     FX_HIP(e, hipGetLastError());

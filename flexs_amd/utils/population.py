@@ -160,8 +160,11 @@ def terminal_rewards(evaluator: PopulationEvaluator, seen, states: np.ndarray, l
     taken after the whole batch was recorded, as in the reference."""
     states = np.asarray(states, np.float64)
     seqs, fitnesses = evaluator.evaluate(states[:, :, :-1])
-    for seq, f in zip(seqs, fitnesses):
-        seen.add(seq, f)
+    if hasattr(seen, "add_many"):
+        seen.add_many(seqs, fitnesses)                       # (one upload of the new keys)
+    else:
+        for seq, f in zip(seqs, fitnesses):
+            seen.add(seq, f)
     dens = seen.densities(seqs)
     rewards = np.array([f - lam * d for f, d in zip(fitnesses, dens)])
     return seqs, fitnesses, rewards

@@ -136,6 +136,8 @@ const char *fx_last_error(fx_engine *e);
  *   serve_tiny        1        1 = a request of at most 48 sequence bytes (one to six 8-mers) carries them in the request word's
  *                              own 64-byte line; the workgroup of tile 0 reads the whole line per poll and needs no second
  *                              read of device memory for the bytes (~0.2 us of a 9.4 us call).  0 = always the byte area.
+ *   dist_stage        1        edit-distance kernels, small launches (fewer than 512 blocks' worth): 1 = a block copies its 256
+ *                              cache rows (<= 160 bytes each) to LDS and the recurrence reads them there; 0 = from global memory.
  *   serve_quads       1        wide generation, 4-letter CNN with seq_len <= 8: tiles a resident workgroup answers side by
  *                              side.  3 (the launched form's three quads) is in the A/B build only: slower once requests
  *                              are streamed (fx_score_stream_*).
@@ -341,6 +343,13 @@ int fx_nam_combine(fx_engine *e, int64_t Q, const double *signal, const double *
  * fitness/dist over all seen sequences with 0 < dist <= 2): the host filters by radius
  * and accumulates in insertion order, so the float sum stays bit-identical. */
 int fx_cache_distances(fx_cache *c, int mode, const uint8_t *queries, int64_t Q, uint8_t *out_QxC);
+/* `sequence_density` itself (dyna_ppo.py:106-114) for Q queries: density[q] = sum over the stored keys i, in insertion order, of
+ * fitness[i] / dist(q, i) for 0 < dist <= radius (float64, the Python loop's operations in the Python loop's order);
+ * neighbours[q] = how many keys took part (0: the reference's `dens` is still the int 0 it started as).  One distance launch
+ * into pinned memory, the radius filter and the sums on the host in C -- a ten-query environment step against 3000 seen
+ * sequences spent 37 us in NumPy on the 30 000-byte matrix.  fitness: one float64 per stored key. */
+int fx_cache_density(fx_cache *c, int mode, const uint8_t *queries, int64_t Q, int radius, const double *fitness,
+                     double *density, int32_t *neighbours);
 
 /* ------------------------------------------------------- table landscapes */
 /* Ground-truth look-up landscapes, e.g. TFBinding

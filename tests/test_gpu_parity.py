@@ -935,6 +935,14 @@ def test_sequence_density(eng):
         qs = list(ref)[:40] + [base, base[1:] + base[:1]]
         assert seen.densities(qs) == [seen.density(q) for q in qs]
         assert seen.densities([]) == []
+        assert [type(v) for v in seen.densities(qs)] == [type(seen.density(q)) for q in qs]      # (int 0 without neighbours, as the reference)
+        for radius in (0, 1, 3):
+            assert seen.densities(qs[:10], radius) == [seen.density(q, radius) for q in qs[:10]]
+        # float32 fitness values divide and add in float32 under NumPy's rules: the batch form follows (Python operations)
+        seen32 = SeenSequences(L)
+        for s_, f_ in list(ref.items())[:120]:
+            seen32.add(s_, np.float32(f_))
+        assert seen32.densities(qs[:10]) == [seen32.density(q) for q in qs[:10]]
     assert SeenSequences(5).density("ACGTA") == 0 and SeenSequences(5).densities(["ACGTA", "AC"]) == [0, 0]
 
 
