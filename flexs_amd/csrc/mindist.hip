@@ -24,8 +24,7 @@ constexpr int FX_MINDIST_MAX_L = 768;   // 12 words of 64 pattern rows
 // Cache rows per block = passes x 256.  A large launch walks CHUNK rows per block (the query's match masks are built once per
 // block); an explorer-size one -- a DyNA-PPO environment step: ten queries against the 3000 sequences seen so far -- had 30 blocks
 // on 256 CUs that way, each thread walking four pairs in turn: one pass per block gives it four times the blocks (distance matrix
-// of that step 139 -> 59 us).  (Staging the rows through LDS was measured too: the recurrence, not the row bytes, is what a
-// pair costs -- 120 -> 143 us -- not kept.)
+// of that step 139 -> 59 us).
 static inline int fx_dist_passes(int64_t C, int64_t Q) { return ((C + CHUNK - 1) / CHUNK) * Q < 512 ? 1 : CHUNK / 256; }
 
 // Block prologue shared by both kernels: stage query `qi` in LDS, let thread c build the match masks of byte
