@@ -323,6 +323,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "serve_quads")) return &e->serve_quads;
     if (!std::strcmp(key, "serve_tiny")) return &e->serve_tiny;
     if (!std::strcmp(key, "dist_stage")) return &e->dist_stage;
+    if (!std::strcmp(key, "dist_bounded")) return &e->dist_bounded;
     if (!std::strcmp(key, "host_mean_below")) return &e->host_mean_below;
     if (!std::strcmp(key, "done_flag")) return &e->done_flag;
     if (!std::strcmp(key, "lp_prelaunch")) return &e->lp_prelaunch;
@@ -1888,7 +1889,12 @@ int fx_cache_nam_query(fx_cache* c, fx_table* t, int bits, const uint8_t lut[256
     return FX_OK;
 }
 
+static int cache_distances(fx_cache* c, int mode, const uint8_t* queries, int64_t Q, uint8_t* out, int bound);
 int fx_cache_distances(fx_cache* c, int mode, const uint8_t* queries, int64_t Q, uint8_t* out) {
+    return cache_distances(c, mode, queries, Q, out, 0);
+}
+// bound > 0: out = min(distance, bound + 1) where the banded kernel applies (explorer-size calls), the exact matrix otherwise
+static int cache_distances(fx_cache* c, int mode, const uint8_t* queries, int64_t Q, uint8_t* out, int bound) {
     if (!c || Q < 0) return FX_EINVAL;
     fx_engine* e = c->eng;
     if (mode != FX_LEVENSHTEIN && mode != FX_HAMMING) return fx_fail(e, FX_EINVAL, "unknown distance mode");
@@ -1901,7 +1907,9 @@ int fx_cache_distances(fx_cache* c, int mode, const uint8_t* queries, int64_t Q,
         FxZeroCopy z;
         if ((rc = fx_zero_copy_buffers(e, (size_t)Q * c->L + 16, (size_t)Q * c->size, &z))) return rc;
         std::memcpy(z.h_in, queries, (size_t)Q * c->L);
-        if ((rc = fx_launch_distances(e, mode, (const uint8_t*)z.d_in, Q, c->d_keys, c->size, c->L, (uint8_t*)z.d_out))) return rc;
+        rc = bound > 0 ? fx_launch_distances_bounded(e, mode, (const uint8_t*)z.d_in, Q, c->d_keys, c->size, c->L, bound, (uint8_t*)z.d_out) : FX_EUNSUPPORTED;
+        if (rc == FX_EUNSUPPORTED) rc = fx_launch_distances(e, mode, (const uint8_t*)z.d_in, Q, c->d_keys, c->size, c->L, (uint8_t*)z.d_out);
+        if (rc) return rc;
         if ((rc = fx_wait_small(e))) return rc;          // (a completion value polled in pinned memory: wait_for_results)
         std::memcpy(out, z.h_out, (size_t)Q * c->size);
         return FX_OK;
@@ -1938,7 +1946,7 @@ int fx_cache_density(fx_cache* c, int mode, const uint8_t* queries, int64_t Q, i
     for (int64_t q0 = 0; q0 < Q; q0 += qstep) {
         const int64_t qn = std::min<int64_t>(qstep, Q - q0);
         rows.resize((size_t)qn * (size_t)C);
-        if (int rc = fx_cache_distances(c, mode, queries + q0 * c->L, qn, rows.data())) return rc;
+        if (int rc = cache_distances(c, mode, queries + q0 * c->L, qn, rows.data(), r)) return rc;
         for (int64_t q = 0; q < qn; ++q) {
             const uint8_t* d = rows.data() + (size_t)q * (size_t)C;
             double dens = 0.0;

@@ -285,6 +285,7 @@ struct fx_engine {
     int64_t serve_reserve_cus = 16;   // CUs a wide generation leaves without a resident workgroup (kernels of other streams -- RCCL, PyTorch -- find room there at once; small ones also fit beside a resident workgroup)
     int64_t call_prof_ns[4] = {};    // the last launched small mean-only host call: ns since entry at "prepared", "launched", "synchronised", "mean taken"
     int64_t host_mean_below = 256;   // launched mean-only host calls of at most this many sequences (zero-copy): member planes to pinned host memory, np.mean's order on the host, no mean launch (0 = the mean kernel: A/B)
+    int64_t dist_bounded = 1;   // fx_cache_density: 1 = distances up to the radius by the banded kernel (min(d, radius + 1), radius 1 .. 3), 0 = the exact distance matrix (A/B)
     int64_t dist_stage = 1;     // edit-distance kernels, small launches: 1 = a block's 256 cache rows are copied to LDS and the recurrence reads them there (rows of <= 160 bytes), 0 = every thread reads its row from global memory (A/B)
     int64_t serve_tiny = 1;     // 1 = requests of <= 48 sequence bytes carry them in the request word's own line (0 = always the byte area: A/B)
     int64_t serve_quads = 1;    // wide generation, CNN with seq_len <= 8: tiles per resident workgroup side by side (1 = one; 3 = like the launched form: A/B build only -- slower once requests are streamed, csrc/OPTIONS.md)
@@ -494,6 +495,8 @@ int fx_launch_nam_combine(fx_engine* e, int64_t Q, const double* d_signal, const
                           const int32_t* d_dist, const double* d_alpha, int n_tab, double* d_out);
 int fx_launch_min_dist(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, const uint8_t* d_cache,
                        int64_t C, int L, unsigned long long* d_keys);
+int fx_launch_distances_bounded(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, const uint8_t* d_cache, int64_t C, int L,
+                                int K, uint8_t* d_out);
 int fx_launch_distances(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, const uint8_t* d_cache, int64_t C,
                         int L, uint8_t* d_out);
 int fx_launch_additive_sum(fx_engine* e, const double* d_table, int L, int ncol, const uint8_t* d_ascii, int64_t N,

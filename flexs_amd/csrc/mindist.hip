@@ -142,6 +142,76 @@ __global__ void __launch_bounds__(256) k_distances(int mode, const uint8_t* __re
     }
 }
 
+// ---- distances up to a BOUND (round 4): min(distance, K + 1) -----------------------------------------------------------------
+// `sequence_density` (dyna_ppo.py:106-114) only asks which stored sequences are within 2 edits and how far exactly.  Ukkonen's band:
+// a distance <= K can only run through cells |i - j| <= K of the DP matrix, 2 K + 1 per text column, and once a whole band column
+// exceeds K the answer is "more" -- for unrelated sequences after a handful of columns, where the bit-parallel recurrence above
+// always walks all of them (38 us for a 90-residue pair on a lone wave).  One thread per pair, the band in registers.
+template <int K>
+__device__ __forceinline__ int bounded_distance(int mode, int m, int L, const uint8_t* qs, const uint8_t* t) {
+    constexpr int B = 2 * K + 1, INF = K + 1;
+    if (mode == FX_HAMMING) {
+        int d = 0;
+        for (int i = 0; i < L && d <= K; ++i) d += (t[i] != qs[i]);
+        return d > K ? INF : d;
+    }
+    int prev[B];
+#pragma unroll
+    for (int r = 0; r < B; ++r) { const int j = r - K; prev[r] = (j >= 0 && j <= m) ? (j < INF ? j : INF) : INF; }      // row 0: D[0][j] = j
+    int n = L;
+    for (int i = 1; i <= L; ++i) {
+        const int bc = t[i - 1];
+        if (bc == 0) { n = i - 1; break; }                    // NUL-padded (ragged) row
+        int cur[B];
+        int left = INF, best = INF;
+#pragma unroll
+        for (int r = 0; r < B; ++r) {
+            const int j = i + r - K;
+            int v = INF;
+            if (j == 0) v = i < INF ? i : INF;               // D[i][0] = i
+            else if (j > 0 && j <= m) {
+                const int diag = prev[r] + (qs[j - 1] != bc);
+                const int up = r + 1 < B ? prev[r + 1] + 1 : INF;
+                v = diag < up ? diag : up;
+                v = left + 1 < v ? left + 1 : v;
+                v = v < INF ? v : INF;
+            }
+            cur[r] = v; left = v;
+            best = v < best ? v : best;
+        }
+#pragma unroll
+        for (int r = 0; r < B; ++r) prev[r] = cur[r];
+        if (best > K) return INF;
+    }
+    const int rr = m - n + K;
+    int d = INF;
+#pragma unroll
+    for (int r = 0; r < B; ++r) if (r == rr) d = prev[r];
+    return d;
+}
+
+template <int K, bool STAGE>
+__global__ void __launch_bounds__(256) k_distances_bounded(int mode, const uint8_t* __restrict__ q, const uint8_t* __restrict__ cache,
+                                                           int64_t C, int L, uint8_t* __restrict__ out) {
+    __shared__ uint8_t qs[FX_MINDIST_MAX_L];
+    __shared__ int m_s;
+    extern __shared__ __attribute__((aligned(16))) uint8_t fx_text_rows[];
+    const int tid = threadIdx.x;
+    const int64_t qi = blockIdx.y, c0 = (int64_t)blockIdx.x * 256;
+    if (STAGE) stage_rows(cache, c0, C, L, fx_text_rows);
+    for (int i = tid; i < L; i += 256) qs[i] = q[qi * L + i];
+    __syncthreads();
+    if (tid == 0) {
+        int m = L;
+        for (int i = 0; i < L; ++i) if (qs[i] == 0) { m = i; break; }
+        m_s = m;
+    }
+    __syncthreads();
+    const int64_t c = c0 + tid;
+    if (c >= C) return;
+    out[qi * C + c] = (uint8_t)bounded_distance<K>(mode, m_s, L, qs, STAGE ? (const uint8_t*)fx_text_rows + tid * L : cache + c * L);
+}
+
 // ---- patterns longer than 768 symbols: the bit-parallel recurrence in STRIPS of 12 words -------------------------
 // `editdistance.eval` (noisy_abstract_model.py:51) takes strings of any length.  A strip is 768 rows of the DP matrix
 // (what fits a thread's registers); strip s is run over all text columns with the pattern rows [768 s, 768 s + 768):
@@ -308,6 +378,23 @@ int fx_launch_distances(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, c
             default: { if (stage) hipLaunchKernelGGL((k_distances<12, uint64_t, true>), grid, block, lds, e->stream, mode, d_q, d_cache, C, L, d_out, passes); else hipLaunchKernelGGL((k_distances<12, uint64_t, false>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out, passes); } break;   // L <= 768 (full-length AAV capsid: 735)
         }
     }
+    FX_HIP(e, hipGetLastError());
+    return FX_OK;
+}
+
+// min(distance, K + 1) for K = 1 .. 3 and rows of at most 768 bytes: FX_EUNSUPPORTED otherwise (the caller takes the exact matrix).
+int fx_launch_distances_bounded(fx_engine* e, int mode, const uint8_t* d_q, int64_t Q, const uint8_t* d_cache, int64_t C, int L,
+                                int K, uint8_t* d_out) {
+    if (Q == 0 || C == 0) return FX_OK;
+    if (K < 1 || K > 3 || L > FX_MINDIST_MAX_L || Q > 65535 || !e->dist_bounded) return FX_EUNSUPPORTED;
+    const bool stage = L <= FX_STAGE_MAX_L && e->dist_stage;
+    const size_t lds = stage ? (size_t)256 * L + 16 : 0;
+    dim3 grid((unsigned)((C + 255) / 256), (unsigned)Q), block(256);
+#define FX_BOUNDED(KK)                                                                                                                   \
+    { if (stage) hipLaunchKernelGGL((k_distances_bounded<KK, true>), grid, block, lds, e->stream, mode, d_q, d_cache, C, L, d_out);     \
+      else hipLaunchKernelGGL((k_distances_bounded<KK, false>), grid, block, 0, e->stream, mode, d_q, d_cache, C, L, d_out); }
+    if (K == 1) FX_BOUNDED(1) else if (K == 2) FX_BOUNDED(2) else FX_BOUNDED(3)
+#undef FX_BOUNDED
     FX_HIP(e, hipGetLastError());
     return FX_OK;
 }

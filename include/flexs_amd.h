@@ -136,6 +136,8 @@ const char *fx_last_error(fx_engine *e);
  *   serve_tiny        1        1 = a request of at most 48 sequence bytes (one to six 8-mers) carries them in the request word's
  *                              own 64-byte line; the workgroup of tile 0 reads the whole line per poll and needs no second
  *                              read of device memory for the bytes (~0.2 us of a 9.4 us call).  0 = always the byte area.
+ *   dist_bounded      1        fx_cache_density with radius 1 .. 3: 1 = distances up to the radius by a banded kernel that
+ *                              leaves a pair once it is known to be farther; 0 = the exact distance matrix.  Same densities.
  *   dist_stage        1        edit-distance kernels, small launches (fewer than 512 blocks' worth): 1 = a block copies its 256
  *                              cache rows (<= 160 bytes each) to LDS and the recurrence reads them there; 0 = from global memory.
  *   serve_quads       1        wide generation, 4-letter CNN with seq_len <= 8: tiles a resident workgroup answers side by

@@ -936,8 +936,17 @@ def test_sequence_density(eng):
         assert seen.densities(qs) == [seen.density(q) for q in qs]
         assert seen.densities([]) == []
         assert [type(v) for v in seen.densities(qs)] == [type(seen.density(q)) for q in qs]      # (int 0 without neighbours, as the reference)
-        for radius in (0, 1, 3):
-            assert seen.densities(qs[:10], radius) == [seen.density(q, radius) for q in qs[:10]]
+        for radius in (0, 1, 2, 3, 4):                    # (1 .. 3: the banded kernel, min(d, radius + 1); else the exact matrix)
+            want_r = [seen.density(q, radius) for q in qs]
+            assert seen.densities(qs, radius) == want_r, radius
+            eng.set_option("dist_bounded", 0)
+            try:
+                assert seen.densities(qs, radius) == want_r, radius
+            finally:
+                eng.set_option("dist_bounded", 1)
+        # ragged queries and keys (shorter than the row, insertions / deletions at either end) through the band
+        short = [q[:-1] for q in qs[:8]] + [q[1:] for q in qs[:8]] + [q[2:] for q in qs[:4]] + [qs[0][:3], ""]
+        assert seen.densities(short) == [seen.density(q) for q in short]
         # float32 fitness values divide and add in float32 under NumPy's rules: the batch form follows (Python operations)
         seen32 = SeenSequences(L)
         for s_, f_ in list(ref.items())[:120]:
