@@ -92,6 +92,7 @@ SIGNATURES = {
     "fx_debug_time_min_dist": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, C.c_int, _f32p]),
     "fx_debug_pack_weights": (C.c_int, [C.c_int] * 6 + [_f32p, C.c_int64, _f32p, C.c_int64]),
     "fx_debug_myers": (C.c_int, [_vp, C.c_int, _vp, C.c_int]),
+    "fx_debug_bounded_distance": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int]),
     "fx_debug_myers_strips": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int]),
     "fx_debug_train_trace": (C.c_int, [_vp, _vp]),
     "fx_train_fit": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64, C.c_int, _u8p, _vp]),
@@ -762,6 +763,12 @@ def debug_myers_strips(a: bytes, b: bytes, words_per_strip: int = 12) -> int:
     a = np.frombuffer(a, np.uint8)
     b = np.frombuffer(b, np.uint8)
     return lib().fx_debug_myers_strips(_ptr(a) if len(a) else None, len(a), _ptr(b) if len(b) else None, len(b), words_per_strip)
+
+
+def debug_bounded_distance(a: bytes, b: bytes, K: int, hamming: bool = False) -> int:
+    a = np.frombuffer(bytes(a), np.uint8)
+    b = np.frombuffer(bytes(b), np.uint8)
+    return lib().fx_debug_bounded_distance(_ptr(a) if len(a) else None, len(a), _ptr(b) if len(b) else None, len(b), K, int(hamming))
 
 
 def debug_myers(a: bytes, b: bytes) -> int:

@@ -2179,6 +2179,17 @@ int fx_debug_myers_strips(const uint8_t* a, int la, const uint8_t* b, int lb, in
     if (words_per_strip == 12) return myers_strips_host<12>(a, la, b, lb);
     return -1;
 }
+int fx_debug_bounded_distance(const uint8_t* a, int la, const uint8_t* b, int lb, int K, int hamming) {
+    // the band of k_distances_bounded (myers.h) on the host: pattern a against the text row b, both NUL-padded to a common width
+    if (la < 0 || lb < 0 || K < 1 || K > 3 || (la > 0 && !a) || (lb > 0 && !b)) return -1;
+    const int L = std::max(std::max(la, lb), 1);
+    std::vector<uint8_t> qa((size_t)L + 1, 0), tb((size_t)L + 1, 0);
+    if (la) std::memcpy(qa.data(), a, (size_t)la);
+    if (lb) std::memcpy(tb.data(), b, (size_t)lb);
+    if (K == 1) return fx_bounded_distance<1>(hamming != 0, la, L, qa.data(), tb.data());
+    if (K == 2) return fx_bounded_distance<2>(hamming != 0, la, L, qa.data(), tb.data());
+    return fx_bounded_distance<3>(hamming != 0, la, L, qa.data(), tb.data());
+}
 int fx_debug_myers(const uint8_t* a, int la, const uint8_t* b, int lb) {
     // pattern = a, text = b; same code path as the device kernel (myers.h)
     if (la < 0 || lb < 0) return -1;

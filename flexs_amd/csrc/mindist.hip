@@ -147,49 +147,7 @@ __global__ void __launch_bounds__(256) k_distances(int mode, const uint8_t* __re
 // a distance <= K can only run through cells |i - j| <= K of the DP matrix, 2 K + 1 per text column, and once a whole band column
 // exceeds K the answer is "more" -- for unrelated sequences after a handful of columns, where the bit-parallel recurrence above
 // always walks all of them (38 us for a 90-residue pair on a lone wave).  One thread per pair, the band in registers.
-template <int K>
-__device__ __forceinline__ int bounded_distance(int mode, int m, int L, const uint8_t* qs, const uint8_t* t) {
-    constexpr int B = 2 * K + 1, INF = K + 1;
-    if (mode == FX_HAMMING) {
-        int d = 0;
-        for (int i = 0; i < L && d <= K; ++i) d += (t[i] != qs[i]);
-        return d > K ? INF : d;
-    }
-    int prev[B];
-#pragma unroll
-    for (int r = 0; r < B; ++r) { const int j = r - K; prev[r] = (j >= 0 && j <= m) ? (j < INF ? j : INF) : INF; }      // row 0: D[0][j] = j
-    int n = L;
-    for (int i = 1; i <= L; ++i) {
-        const int bc = t[i - 1];
-        if (bc == 0) { n = i - 1; break; }                    // NUL-padded (ragged) row
-        int cur[B];
-        int left = INF, best = INF;
-#pragma unroll
-        for (int r = 0; r < B; ++r) {
-            const int j = i + r - K;
-            int v = INF;
-            if (j == 0) v = i < INF ? i : INF;               // D[i][0] = i
-            else if (j > 0 && j <= m) {
-                const int diag = prev[r] + (qs[j - 1] != bc);
-                const int up = r + 1 < B ? prev[r + 1] + 1 : INF;
-                v = diag < up ? diag : up;
-                v = left + 1 < v ? left + 1 : v;
-                v = v < INF ? v : INF;
-            }
-            cur[r] = v; left = v;
-            best = v < best ? v : best;
-        }
-#pragma unroll
-        for (int r = 0; r < B; ++r) prev[r] = cur[r];
-        if (best > K) return INF;
-    }
-    const int rr = m - n + K;
-    int d = INF;
-#pragma unroll
-    for (int r = 0; r < B; ++r) if (r == rr) d = prev[r];
-    return d;
-}
-
+// (the band itself: myers.h fx_bounded_distance, shared with the host test hook fx_debug_bounded_distance)
 template <int K, bool STAGE>
 __global__ void __launch_bounds__(256) k_distances_bounded(int mode, const uint8_t* __restrict__ q, const uint8_t* __restrict__ cache,
                                                            int64_t C, int L, uint8_t* __restrict__ out) {
@@ -209,7 +167,7 @@ __global__ void __launch_bounds__(256) k_distances_bounded(int mode, const uint8
     __syncthreads();
     const int64_t c = c0 + tid;
     if (c >= C) return;
-    out[qi * C + c] = (uint8_t)bounded_distance<K>(mode, m_s, L, qs, STAGE ? (const uint8_t*)fx_text_rows + tid * L : cache + c * L);
+    out[qi * C + c] = (uint8_t)fx_bounded_distance<K>(mode == FX_HAMMING, m_s, L, qs, STAGE ? (const uint8_t*)fx_text_rows + tid * L : cache + c * L);
 }
 
 // ---- patterns longer than 768 symbols: the bit-parallel recurrence in STRIPS of 12 words -------------------------

@@ -87,3 +87,56 @@ FX_HD int fx_myers_strip(int rows, int n, PeqFn peq, TextFn text, const signed c
     }
     return sum;
 }
+
+// min(distance, K + 1) of the pattern qs[0 .. m) and the text row t[0 .. L) (NUL-padded when shorter): Ukkonen's band, 2 K + 1 cells
+// per text column, left as soon as a whole band column exceeds K.  hamming: position-wise mismatches over the whole row instead.
+template <int K>
+FX_HD int fx_bounded_distance(bool hamming, int m, int L, const uint8_t* qs, const uint8_t* t) {
+    constexpr int B = 2 * K + 1, INF = K + 1;
+    if (hamming) {
+        int d = 0;
+        for (int i = 0; i < L && d <= K; ++i) d += (t[i] != qs[i]);
+        return d > K ? INF : d;
+    }
+    int prev[B];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int r = 0; r < B; ++r) { const int j = r - K; prev[r] = (j >= 0 && j <= m) ? (j < INF ? j : INF) : INF; }      // row 0: D[0][j] = j
+    int n = L;
+    for (int i = 1; i <= L; ++i) {
+        const int bc = t[i - 1];
+        if (bc == 0) { n = i - 1; break; }                    // NUL-padded (ragged) row
+        int cur[B];
+        int left = INF, best = INF;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int r = 0; r < B; ++r) {
+            const int j = i + r - K;
+            int v = INF;
+            if (j == 0) v = i < INF ? i : INF;               // D[i][0] = i
+            else if (j > 0 && j <= m) {
+                const int diag = prev[r] + (qs[j - 1] != bc);
+                const int up = r + 1 < B ? prev[r + 1] + 1 : INF;
+                v = diag < up ? diag : up;
+                v = left + 1 < v ? left + 1 : v;
+                v = v < INF ? v : INF;
+            }
+            cur[r] = v; left = v;
+            best = v < best ? v : best;
+        }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int r = 0; r < B; ++r) prev[r] = cur[r];
+        if (best > K) return INF;
+    }
+    const int rr = m - n + K;
+    int d = INF;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int r = 0; r < B; ++r) if (r == rr) d = prev[r];
+    return d;
+}

@@ -440,6 +440,9 @@ int fx_debug_trace_read(fx_engine *e, uint64_t *out, int64_t cap_words);
 int fx_debug_pack_weights(int kind, int L, int A, int F, int H, int K, const float *blob, int64_t n,
                           float *packed, int64_t cap);
 int fx_debug_myers(const uint8_t *a, int la, const uint8_t *b, int lb);
+/* Host only: the banded bounded-distance routine of fx_cache_density's kernel (csrc/myers.h fx_bounded_distance) --
+ * min(levenshtein(a, b), K + 1) for K = 1 .. 3 (hamming != 0: position-wise mismatches over rows NUL-padded to a common width). */
+int fx_debug_bounded_distance(const uint8_t *a, int la, const uint8_t *b, int lb, int K, int hamming);
 /* The strip form of the same recurrence (patterns beyond 768 symbols on the device: csrc/myers.h fx_myers_strip), with
  * strips of 64 x words_per_strip pattern rows (12 = the device's; 1 = test aid, many strip boundaries on short strings). */
 int fx_debug_myers_strips(const uint8_t *a, int la, const uint8_t *b, int lb, int words_per_strip);

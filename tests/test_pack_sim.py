@@ -111,6 +111,40 @@ def test_myers_equals_dp_multiword(la, lb, seed, nsym):
     assert _native.debug_myers(a, b) == c_oracle.levenshtein(a, b)
 
 
+def test_bounded_distance_band_against_the_dp_oracle():
+    """csrc/myers.h fx_bounded_distance (the banded kernel behind fx_cache_density: `sequence_density` only asks for distances up to
+    its radius), host build: min(levenshtein, K + 1) for K = 1 .. 3 on pairs that are 0 .. 5 edits apart (substitutions, insertions,
+    deletions anywhere, so also unequal lengths and NUL-padded rows), on unrelated pairs, on empty strings; Hamming likewise."""
+    rng = np.random.default_rng(11)
+    pairs = [(b"", b""), (b"A", b""), (b"", b"AC"), (b"ACGT", b"ACGT"), (b"ACGT", b"CGTA"), (b"AAAA", b"AAAAAAA"), (b"ACGTACGT", b"TGCATGCA")]
+    for _ in range(1500):
+        la = int(rng.integers(0, 60))
+        nsym = int(rng.integers(2, 21))
+        a = bytes(rng.integers(65, 65 + nsym, la).astype(np.uint8))
+        b = bytearray(a)
+        for _e in range(int(rng.integers(0, 6))):
+            op = int(rng.integers(0, 3))
+            if op == 0 and b:
+                b[int(rng.integers(0, len(b)))] = int(rng.integers(65, 65 + nsym))
+            elif op == 1 and b:
+                del b[int(rng.integers(0, len(b)))]
+            else:
+                b.insert(int(rng.integers(0, len(b) + 1)), int(rng.integers(65, 65 + nsym)))
+        pairs.append((a, bytes(b)))
+        if rng.random() < 0.2:
+            pairs.append((a, bytes(rng.integers(65, 65 + nsym, int(rng.integers(0, 60))).astype(np.uint8))))
+    for a, b in pairs:
+        d = c_oracle.levenshtein(a, b)
+        for K in (1, 2, 3):
+            assert _native.debug_bounded_distance(a, b, K) == min(d, K + 1), (a, b, K, d)
+            assert _native.debug_bounded_distance(b, a, K) == min(d, K + 1), (b, a, K, d)
+        if len(a) == len(b):
+            h = sum(x != y for x, y in zip(a, b))
+            for K in (1, 2, 3):
+                assert _native.debug_bounded_distance(a, b, K, hamming=True) == min(h, K + 1)
+    assert _native.debug_bounded_distance(b"AC", b"AC", 4) == -1 and _native.debug_bounded_distance(b"AC", b"AC", 0) == -1
+
+
 def test_myers_boundaries():
     for L in (1, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 320, 384, 385, 512, 513, 735, 768):
         a = bytes([65 + (i * 7) % 4 for i in range(L)])
