@@ -649,6 +649,127 @@ def test_adalead_children_in_c_consume_the_random_stream_like_the_python_loop():
         random.setstate(saved)
 
 
+def test_population_step_decodes_scores_and_names_in_one_call():
+    """csrc/strpack.c population_step (CMA-ES / DyNA-PPO decode-then-score, cmaes.py:61-67, 83-93): per-position argmax of the
+    (P, L, A) array by NumPy's rule, those rows handed to the function the plan carries (fx_score in production; a ctypes callback
+    here), the rows back as Python strings.  No GPU."""
+    import ctypes as C
+    import struct
+
+    from flexs_amd import _native
+
+    sp = _native._strpack
+    if sp is None or not hasattr(sp, "population_step"):
+        pytest.skip("strpack helper not built")
+    seen = []
+    FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_uint8), C.c_longlong, C.c_int,
+                     C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_float))
+
+    def fake_fx_score(e, models, M, ascii, N, L, lut, out_nm, out_mean):
+        seen.append((N, L, bytes(ascii[:N * L]), bool(out_nm), bool(out_mean)))
+        o = out_nm if out_nm else out_mean
+        for i in range(N * (M if out_nm else 1)):
+            o[i] = i + 0.25
+        return -3 if N == 3 else 0
+
+    fn = FN(fake_fx_score)
+    alpha, L, A = "ILVAGMFYWEDQNHCRKSTP", 11, 20
+    lut = _native.make_lut(alpha)
+    rng = np.random.default_rng(4)
+    for want, M in ((2, 3), (1, 1)):
+        plan = struct.pack("PPqqq16P256sPPPqq", C.cast(fn, C.c_void_p).value, 777, M, L, want, *([11] * M + [0] * (16 - M)), lut.tobytes(),
+                           0, 0, 0, 0, 0)
+        for P in (1, 5, 40):
+            x = rng.standard_normal((P, L, A))
+            x[0, 0, :] = 0.0                                             # a tie: the first letter wins
+            x[0, 1, 3] = np.nan                                          # a NaN is a maximum
+            codes = np.argmax(x, axis=2)
+            want_rows = ["".join(alpha[c] for c in row) for row in codes]
+            chars = np.zeros((P, L), np.uint8)
+            out = np.zeros((P, M) if want == 1 else (P,), np.float32)
+            st, names = sp.population_step(plan, x, P, A, alpha.encode(), chars, out)
+            assert st == 0 and names == want_rows
+            assert [r.tobytes().decode() for r in chars] == want_rows
+            assert seen[-1] == (P, L, "".join(want_rows).encode(), want == 1, want == 2)
+            assert np.array_equal(out.ravel(), np.arange(out.size) + 0.25)
+    x = rng.standard_normal((3, L, A))
+    st, names = sp.population_step(plan, x, 3, A, alpha.encode(), np.zeros((3, L), np.uint8), np.zeros((3, 1), np.float32))
+    assert st == 2003 and names is None                                   # the callee's FX_EBADCHAR comes through
+    st, names = sp.population_step(plan, x, 3, A, alpha[:5].encode(), np.zeros((3, L), np.uint8), np.zeros((3, 1), np.float32))
+    assert st == 1 and names is None                                      # alphabet shorter than the rows
+    st, names = sp.population_step(b"xx", x, 3, A, alpha.encode(), np.zeros((3, L), np.uint8), np.zeros((3, 1), np.float32))
+    assert st == 1 and names is None
+
+
+def test_answer_lines_are_collected_like_the_scalar_loop():
+    """csrc/host_collect.cc fx_collect_lines (the vector path of the resident form's answer collection): whole 64-byte lines whose
+    eight tags equal the request's are unpacked -- scores bit for bit, the bad-character bit reported --, the walk stops at the first
+    line with an answer still missing (stale tag, or a tag that differs only in its high bits) and at a tail shorter than a line;
+    an unaligned start is handed back to the scalar loop.  Synthetic answer memory: no GPU."""
+    import ctypes as C
+
+    from flexs_amd import _native
+
+    lib = _native.lib()
+    if not hasattr(lib, "fx_collect_lines"):
+        pytest.skip("library without the vector collection")
+    fn = lib.fx_collect_lines
+    fn.restype = C.c_int64
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_uint, C.c_int64, C.c_void_p]
+    rng = np.random.default_rng(3)
+    N, seq = 100, 0x1234567
+    raw = np.zeros(N + 64, np.uint64)                                  # (+ slack: the routine prefetches ahead)
+    base = raw.ctypes.data
+    off = (-base) % 64 // 8                                            # first 64-byte aligned element
+    ans = raw[off:off + N]
+    assert ans.ctypes.data % 64 == 0
+    scores = rng.standard_normal(N).astype(np.float32)
+    scores[5] = np.float32(-0.0); scores[6] = np.float32(3.4e38)
+    bits = scores.view(np.uint32).astype(np.uint64)
+
+    def fill(arrived, tag=seq, bad_at=()):
+        ans[:] = (np.uint64(tag - 1) << np.uint64(32)) | bits          # stale answers of the previous request
+        for i in range(arrived):
+            ans[i] = (np.uint64(tag) << np.uint64(32)) | bits[i] | (np.uint64(1 << 63) if i in bad_at else np.uint64(0))
+
+    def collect(n0, n_total):
+        out = np.full(N, np.float32(7.0))
+        bad = C.c_int(0)
+        stop = fn(ans.ctypes.data, out.ctypes.data, n0, n_total, seq, 64, C.byref(bad))
+        return stop, out, bad.value
+
+    have_avx2 = True
+    fill(N)
+    stop, out, bad = collect(0, N)
+    if stop == 0:
+        have_avx2 = False                                              # (a CPU without AVX2: everything goes to the scalar loop)
+    else:
+        assert stop == 96 and bad == 0                                 # twelve whole lines; the four-answer tail is the scalar loop's
+        assert np.array_equal(out[:96].view(np.uint32), scores[:96].view(np.uint32)) and (out[96:] == 7.0).all()
+    if have_avx2:
+        fill(43)
+        stop, out, bad = collect(0, N)                                  # line 5 (answers 40 .. 47) is not complete
+        assert stop == 40 and np.array_equal(out[:40].view(np.uint32), scores[:40].view(np.uint32)) and (out[40:] == 7.0).all()
+        stop, out, bad = collect(16, N)
+        assert stop == 40 and (out[:16] == 7.0).all() and np.array_equal(out[16:40].view(np.uint32), scores[16:40].view(np.uint32))
+        fill(N, bad_at=(9, 70))
+        stop, out, bad = collect(0, N)
+        assert stop == 96 and bad == 1 and np.array_equal(out[:96].view(np.uint32), scores[:96].view(np.uint32))
+        fill(N, bad_at=(99,))                                           # (in the tail: not this routine's to see)
+        assert collect(0, N)[2] == 0
+        fill(N)
+        ans[20] = (np.uint64(seq ^ 0x40000000) << np.uint64(32)) | bits[20]      # a tag that differs in a high bit only
+        assert collect(0, N)[0] == 16
+        fill(N)
+        assert collect(4, N)[0] == 4                                     # not a line start: the scalar loop's
+        stop, out, bad = collect(0, 7)
+        assert stop == 0                                                 # fewer than eight answers
+        # an unaligned answer array is never touched
+        shifted = raw[off + 1:off + 1 + 32]
+        bad_c = C.c_int(0)
+        assert fn(shifted.ctypes.data, out.ctypes.data, 0, 32, seq, 64, C.byref(bad_c)) == 0
+
+
 def test_epoch_orders_are_uniform_permutations():
     """fx_train_orders (the fit's epoch shuffles): every row is a permutation of 0 .. n - 1, a function of the seed alone, different
     from epoch to epoch and seed to seed; every position receives every row about equally often (a coarse chi-square over many
