@@ -649,6 +649,81 @@ def test_adalead_children_in_c_consume_the_random_stream_like_the_python_loop():
         random.setstate(saved)
 
 
+def test_seen_sequences_bookkeeping_without_a_gpu():
+    """flexs_amd.utils.edit_distance.SeenSequences (DyNA-PPO's `all_seqs` + `sequence_density`, environments/dyna_ppo.py:106-114) over
+    a stand-in for the device cache (distances by the C oracle): dict semantics of add / add_many (re-adding updates the fitness,
+    duplicates inside a batch, ONE key upload per batch), the float64 mirror of the fitness values the C density sums read, the
+    batch densities against the reference's per-sequence loop -- with float64 values (C sums) and with a float32 value among them
+    (Python operations, as NumPy's scalar rules make the reference compute)."""
+    from flexs_amd import _native
+    from flexs_amd.utils.edit_distance import SeenSequences
+    from oracle import c_oracle
+
+    class FakeCache:
+        def __init__(self, L):
+            self.L, self.keys, self.appends = L, [], 0
+        def __len__(self):
+            return len(self.keys)
+        def append(self, rows):
+            self.appends += 1
+            self.keys.extend(bytes(r).rstrip(b"\0") for r in np.asarray(rows))
+        def distances(self, q, mode=None):
+            q = [bytes(r).rstrip(b"\0") for r in np.asarray(q)]
+            return np.array([[min(c_oracle.levenshtein(a, k), 255) for k in self.keys] for a in q], np.uint8).reshape(len(q), len(self.keys))
+        def density(self, q, fitness, radius, mode=None):
+            d = self.distances(q)
+            dens, cnt = np.zeros(len(d)), np.zeros(len(d), np.int32)
+            for r, row in enumerate(d):
+                for i, di in enumerate(row):
+                    if 0 < di <= radius:
+                        dens[r] += fitness[i] / float(di); cnt[r] += 1
+            return dens, cnt
+
+    def reference_density(all_seqs, seq, radius=2):                       # dyna_ppo.py:106-114
+        dens = 0
+        for s_ in all_seqs:
+            dist = c_oracle.levenshtein(s_.encode(), seq.encode())
+            if dist != 0 and dist <= radius:
+                dens += all_seqs[s_] / dist
+        return dens
+
+    rng = np.random.default_rng(8)
+    for use_f32 in (False, True):
+        L = 12
+        seen = SeenSequences.__new__(SeenSequences)
+        seen._L, seen._mode, seen._cache = L, _native.FX_LEVENSHTEIN, FakeCache(L)
+        seen._index, seen._fitness = {}, []
+        seen._fit_arr, seen._fit_f64 = np.empty(4, np.float64), True      # (small: the mirror grows by doubling)
+        all_seqs = {}
+        base = "ACGTACGTACGT"
+        def mutant():
+            s_ = list(base)
+            for _ in range(int(rng.integers(0, 3))):
+                s_[int(rng.integers(0, L))] = "ACGT"[int(rng.integers(0, 4))]
+            return "".join(s_)[: int(rng.integers(L - 1, L + 1))]
+        for step in range(12):
+            batch = [mutant() for _ in range(7)] + ([base] if step % 3 == 0 else [])
+            batch[2] = batch[0]                                           # a duplicate inside the batch: the later fitness wins
+            fits = [float(v) for v in rng.random(len(batch))]
+            if use_f32 and step == 5:
+                fits[1] = np.float32(fits[1])
+            before = seen._cache.appends
+            seen.add_many(batch, fits)
+            assert seen._cache.appends - before <= 1                      # one upload (none when nothing was new)
+            for s_, f in zip(batch, fits):
+                all_seqs[s_] = f
+            assert len(seen) == len(all_seqs) == len(seen._cache)
+            assert all(seen[s_] == all_seqs[s_] for s_ in all_seqs)
+            qs = batch + [mutant() for _ in range(3)]
+            assert seen.densities(qs) == [reference_density(all_seqs, q) for q in qs], (use_f32, step)
+            assert seen.densities(qs, 1) == [reference_density(all_seqs, q, 1) for q in qs]
+        assert (seen._fit_array() is None) == use_f32
+        if not use_f32:
+            assert np.array_equal(seen._fit_array(), np.array(seen._fitness))
+        seen.add(base, 0.125)                                             # the single-sequence form updates in place too
+        assert seen[base] == 0.125 and len(seen) == len(all_seqs)
+
+
 def test_population_step_decodes_scores_and_names_in_one_call():
     """csrc/strpack.c population_step (CMA-ES / DyNA-PPO decode-then-score, cmaes.py:61-67, 83-93): per-position argmax of the
     (P, L, A) array by NumPy's rule, those rows handed to the function the plan carries (fx_score in production; a ctypes callback
