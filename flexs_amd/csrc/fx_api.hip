@@ -954,6 +954,14 @@ static bool lp_armed_matches(const fx_engine* e, fx_model* const* models, int M,
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - a.t).count() * 1e6 < 0.6 * (double)e->serve_idle_us;
 }
 
+// The instance that was asked did not answer (it had left): it never arrived at the barrier counters the host counted forward for
+// it, and a next instance that was enqueued behind it builds on those totals -- that one is told to leave, the counters go back to
+// zero (stream-ordered behind both), whether or not a next instance was armed.
+static void lp_unserved(fx_engine* e) {
+    if (e->lp_armed.on) { lp_disarm(e); return; }
+    if (e->d_lp_bar) { (void)hipMemsetAsync(e->d_lp_bar, 0, FX_LP_BAR_BYTES, e->stream); for (unsigned& t : e->lp_bar_total) t = 0; }
+}
+
 // Answer the call with the pre-launched instance: its sequences and request word go into the mailbox, the NEXT instance is
 // enqueued while this one computes, then the completion flag.  false: the instance had left (the caller launches as usual).
 static bool lp_serve_armed(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii, int64_t N, int L, const uint8_t lut[256],
@@ -977,8 +985,7 @@ static bool lp_serve_armed(fx_engine* e, fx_model* const* models, int M, const u
     for (unsigned spins = 0;; ++spins) {
         if (*done == seq) break;
         if (*state == gone) {                              // it left just before the request arrived
-            if (armed_next) lp_disarm(e);
-            else if (e->d_lp_bar) { (void)hipMemsetAsync(e->d_lp_bar, 0, FX_LP_BAR_BYTES, e->stream); for (unsigned& t : e->lp_bar_total) t = 0; }
+            lp_unserved(e);
             return false;
         }
         if (!armed_next) {                                 // (after the first look: ~2.6 us of enqueue beside the instance's ~25 us of work)
@@ -988,9 +995,9 @@ static bool lp_serve_armed(fx_engine* e, fx_model* const* models, int M, const u
         }
         __builtin_ia32_pause();
         if ((spins & 4095u) == 4095u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) {
-            lp_disarm(e);
             (void)hipStreamSynchronize(e->stream);
             if (*done == seq) break;
+            lp_unserved(e);
             return false;
         }
     }
