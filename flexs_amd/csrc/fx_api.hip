@@ -1141,7 +1141,7 @@ static void server_post(fx_engine* e, const uint8_t* ascii, int64_t N, int L) {
     if ((++sv.seq & 0x7FFFFFFFull) == 0) ++sv.seq;         // 31-bit tags, never 0; they run on across generations, so a slot's stale answer never matches
     const unsigned seq = (unsigned)(sv.seq & 0x7FFFFFFFull);
     unsigned long long word = ((unsigned long long)seq << 16) | (unsigned long long)N;
-    if (ascii && e->serve_tiny && (size_t)N * L <= FX_SERVE_TINY_BYTES) {
+    if (ascii && e->serve_tiny && N <= 16 && (size_t)N * L <= FX_SERVE_TINY_BYTES) {      // (one tile: only its workgroup reads the line)
         // a tiny request: its bytes and a second copy of the word go into the request word's own line (FxMailIn::tiny); the slot
         // of tile 0 reads the whole line per poll and needs no second read for the bytes
         word |= FX_SERVE_TINY;

@@ -75,7 +75,9 @@ __global__ void __launch_bounds__(SW * 64) k_score_dense_small(SmallArgs p) {
                 // the slot of tile 0 polls the whole request line: a tiny request's bytes arrive with the word (FxMailIn::tiny)
                 unsigned payload = 0;
                 r = fx_server_wait_line(p.min, srv_last, srv_seen, srv_start, p.idle_ticks, p.life_ticks, lane, &ex, &payload);
-                if (!ex && (r & FX_SERVE_TINY) && lane >= 2 && lane < 14) reinterpret_cast<unsigned*>(bytes_s)[lane - 2] = payload;
+                // (only the dwords that hold the request's N x L bytes -- N <= 16, one tile: the tile's byte rows are 16 x L bytes)
+                if (!ex && (r & FX_SERVE_TINY) && lane >= 2 && lane < 14 && (lane - 2) * 4 < (int)(r & 0x3FFFull) * L)
+                    reinterpret_cast<unsigned*>(bytes_s)[lane - 2] = payload;
             } else if (lane == 0) {
                 r = fx_server_wait(p.min, srv_last, srv_seen, srv_start, p.idle_ticks, p.life_ticks, (int)tg0 < p.srv_fast, p.srv_sleep, &ex);
             }
