@@ -8,6 +8,7 @@
 #include <cstring>
 #include <vector>
 
+#include <algorithm>
 #include "../../flexs_amd/csrc/myers.h"
 #include "../../flexs_amd/csrc/train_core.h"
 
@@ -93,6 +94,38 @@ int main() {
             const int got = fx_myers_distance<12>((int)a.size(), (int)b.size(), [&](int c, int w) { return peq[c * 12 + w]; },
                                                   [&](int i) { return (int)b[i]; });
             if (got != want) { std::printf("register form mismatch at trial %d\n", trial); ++bad; }
+        }
+    }
+    // csrc/myers.h fx_bounded_distance (the band of fx_cache_density's kernel): the pattern in an exact-size buffer of m bytes, the
+    // text row in an exact-size buffer of L bytes (NUL-padded when shorter), as the kernel sees them; near pairs and unrelated ones
+    for (int trial = 0; trial < 600; ++trial) {
+        const int nsym = (trial % 2) ? 4 : 20;
+        std::vector<unsigned char> a(rnd() % 40), b;
+        for (auto& c : a) c = (unsigned char)(65 + rnd() % nsym);
+        if (trial % 5 == 0) { b.resize(rnd() % 40); for (auto& c : b) c = (unsigned char)(65 + rnd() % nsym); }
+        else {
+            b = a;
+            for (int e_ = (int)(rnd() % 5); e_ > 0; --e_) {
+                const unsigned op = rnd() % 3;
+                if (op == 0 && !b.empty()) b[rnd() % b.size()] = (unsigned char)(65 + rnd() % nsym);
+                else if (op == 1 && !b.empty()) b.erase(b.begin() + (long)(rnd() % b.size()));
+                else b.insert(b.begin() + (long)(rnd() % (b.size() + 1)), (unsigned char)(65 + rnd() % nsym));
+            }
+        }
+        const int want = dp(a, b);
+        const int L = (int)std::max<size_t>(std::max(a.size(), b.size()), 1);
+        std::vector<unsigned char> qa((size_t)L, 0), tb((size_t)L, 0);              // rows exactly L bytes wide
+        std::copy(a.begin(), a.end(), qa.begin());
+        std::copy(b.begin(), b.end(), tb.begin());
+        const int m = (int)a.size();
+        const int g1 = fx_bounded_distance<1>(false, m, L, qa.data(), tb.data());
+        const int g2 = fx_bounded_distance<2>(false, m, L, qa.data(), tb.data());
+        const int g3 = fx_bounded_distance<3>(false, m, L, qa.data(), tb.data());
+        if (g1 != std::min(want, 2) || g2 != std::min(want, 3) || g3 != std::min(want, 4)) { std::printf("band mismatch at trial %d: dp %d, got %d %d %d\n", trial, want, g1, g2, g3); ++bad; }
+        if (a.size() == b.size()) {
+            int h = 0;
+            for (size_t i = 0; i < a.size(); ++i) h += a[i] != b[i];
+            if (fx_bounded_distance<2>(true, m, (int)a.size(), qa.data(), tb.data()) != std::min(h, 3)) { std::printf("hamming band mismatch at trial %d\n", trial); ++bad; }
         }
     }
     std::printf(bad ? "FAILED %d\n" : "sanitize_host: ok\n", bad);

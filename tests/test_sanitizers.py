@@ -72,6 +72,40 @@ def run():
 ts = [threading.Thread(target=run) for _ in range(3)]
 [t.start() for t in ts]; [t.join() for t in ts]
 assert not errs
+# the argmax decode (scalar rows and the 256-bit form) on exact-size buffers, over the thread pool and its hot window
+import array, random, struct
+for A in (3, 8, 20, 23):
+    rows = 5000
+    x = array.array("d", [random.random() for _ in range(rows * A)])
+    x[7 * A + 1] = float("nan")
+    alpha = bytes(range(65, 65 + A))
+    for threads in (1, 4):
+        sp.set_threads(threads)
+        out = bytearray(rows)
+        assert sp.decode_argmax(x, rows, A, alpha, out) == 0
+        for r in (0, 7, 4999):
+            row = x[r * A:(r + 1) * A]
+            want_i = next((i for i, v in enumerate(row) if v != v), max(range(A), key=lambda i: (row[i], -i)))
+            assert out[r] == alpha[want_i], (A, r)
+# one Adalead tree level: every draw through the callables, strings of exact size
+random.seed(5)
+nodes = [(i, "".join(random.choice("ACGT") for _ in range(9))) for i in range(12)]
+idxs, kids = sp.adalead_children(nodes, 2, "ACGT", {nodes[0][1]}, {nodes[1][1]: 1.0}, random.random, random.getrandbits)
+assert len(kids) == 12 and all(len(k) == 9 for k in kids) and len(idxs) == 12
+# population_step and score_small through a plan whose function is a ctypes callback
+import ctypes as C
+FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_uint8), C.c_longlong, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_float))
+def fake(e, models, M, ascii, Nq, Lq, lut, out_nm, out_mean):
+    for i in range(Nq): out_mean[i] = float(sum(ascii[i * Lq + j] for j in range(Lq)))
+    return 0
+fn = FN(fake)
+plan = struct.pack("PPqqq16P256sPPPqq", C.cast(fn, C.c_void_p).value, 1, 1, 6, 2, *([1] + [0] * 15), bytes(256), 0, 0, 0, 0, 0)
+xs = array.array("d", [random.random() for _ in range(9 * 6 * 4)])
+chars, scores = bytearray(9 * 6), array.array("f", [0.0] * 9)
+st, names = sp.population_step(plan, xs, 9, 4, b"ACGT", chars, scores)
+assert st == 0 and len(names) == 9 and all(scores[i] == float(sum(chars[i * 6:(i + 1) * 6])) for i in range(9))
+out = array.array("f", [0.0] * 3)
+assert sp.score_small(plan, ["ACGTAC", "TTTTTT", "GGGGGG"], out) == 0 and out[1] == 6.0 * ord("T")
 print("strpack sanitized: ok")
 '''
     env = dict(os.environ, LD_PRELOAD=f"{asan}:{ubsan}", ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", PYTHONMALLOC="malloc")
