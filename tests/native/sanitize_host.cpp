@@ -10,6 +10,8 @@
 
 #include <algorithm>
 #include "../../flexs_amd/csrc/myers.h"
+#include "../../flexs_amd/csrc/host_collect.cc"      // fx_collect_lines: the vector path of the resident form's answer collection
+#include <cstdlib>
 #include "../../flexs_amd/csrc/train_core.h"
 
 static unsigned long long rng_state = 88172645463325252ull;
@@ -127,6 +129,22 @@ int main() {
             for (size_t i = 0; i < a.size(); ++i) h += a[i] != b[i];
             if (fx_bounded_distance<2>(true, m, (int)a.size(), qa.data(), tb.data()) != std::min(h, 3)) { std::printf("hamming band mismatch at trial %d\n", trial); ++bad; }
         }
+    }
+    // fx_collect_lines on an answer array of exactly N words (64-byte aligned, as FxMailOut's rows are): whole lines only, never a
+    // word past the end whatever has arrived
+    for (int N : {1, 7, 8, 9, 16, 63, 64, 100, 4096}) {
+        unsigned long long* ans = static_cast<unsigned long long*>(std::aligned_alloc(64, ((size_t)N * 8 + 63) / 64 * 64));
+        std::vector<float> out((size_t)N, 7.f);
+        const unsigned seq = 0x2345678u;
+        for (int arrived : {0, N / 3, N - 1, N}) {
+            for (int i = 0; i < N; ++i) ans[i] = ((unsigned long long)(i < arrived ? seq : seq - 1) << 32) | (unsigned)i;
+            int flag = 0;
+            const int64_t stop = fx_collect_lines(ans, out.data(), 0, N, seq, 64, &flag);
+            const int64_t want_stop = (int64_t)(std::min(arrived, N) / 8) * 8;
+            if (stop != want_stop && stop != 0) { std::printf("collect_lines: N %d arrived %d stopped at %lld\n", N, arrived, (long long)stop); ++bad; }
+            for (int64_t i = 0; i < stop; ++i) { unsigned u; std::memcpy(&u, &out[(size_t)i], 4); if (u != (unsigned)i) { ++bad; break; } }
+        }
+        std::free(ans);
     }
     std::printf(bad ? "FAILED %d\n" : "sanitize_host: ok\n", bad);
     return bad != 0;

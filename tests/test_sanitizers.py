@@ -1,6 +1,6 @@
 """ASAN / UBSAN builds of the host-compilable native sources (SURVEY.md section 5 aux: sanitizer build).
 
-* `tests/native/sanitize_host.cpp`: csrc/train_core.h (the training kernels' source, threads as loops) and csrc/myers.h
+* `tests/native/sanitize_host.cpp`: csrc/train_core.h (the training kernels' source, threads as loops), csrc/host_collect.cc (answer collection) and csrc/myers.h
   (register and strip forms of the bit-parallel Levenshtein) under  g++ -fsanitize=address,undefined  with exact-size heap
   buffers: an index past any array, a signed overflow or an invalid shift in the kernels' index arithmetic aborts the run.
 * `csrc/strpack.c` (the CPython packing helper and its thread pool) rebuilt with the sanitizers and driven from a Python
