@@ -9,6 +9,7 @@
 #include <vector>
 
 #include <algorithm>
+#include <array>
 #include "../../flexs_amd/csrc/myers.h"
 #include "../../flexs_amd/csrc/host_collect.cc"      // fx_collect_lines: the vector path of the resident form's answer collection
 #include <cstdlib>
@@ -96,6 +97,41 @@ int main() {
             const int got = fx_myers_distance<12>((int)a.size(), (int)b.size(), [&](int c, int w) { return peq[c * 12 + w]; },
                                                   [&](int i) { return (int)b[i]; });
             if (got != want) { std::printf("register form mismatch at trial %d\n", trial); ++bad; }
+        }
+    }
+    // csrc/train_core.h fxt_lay / fxt_image_off: the LDS image of a member's weights (conv-kernel rows padded against bank conflicts)
+    // is filled by the kernels from the Keras-order vector through fxt_image_off -- here every parameter's image offset is rebuilt
+    // from the layout's own tables and compared, for filter counts that are powers of two (the shift) and that are not (the division)
+    for (const auto& sh : std::vector<std::array<int, 6>>{{0, 8, 4, 32, 100, 5}, {0, 14, 4, 24, 50, 5}, {0, 30, 20, 40, 64, 3}, {0, 9, 4, 8, 16, 3},
+                                                          {0, 12, 20, 5, 7, 4}, {0, 10, 4, 16, 33, 7}, {1, 14, 4, 0, 100, 0}, {2, 30, 20, 0, 100, 0}}) {
+        const FxtNet n = fxt_net(sh[0], sh[1], sh[2], sh[3], sh[4], sh[5]);
+        for (const bool padded : {false, true}) {
+            const FxtLay y = fxt_lay(n, padded);
+            std::vector<int> want((size_t)n.P, -1);
+            if (n.kind == 0) {
+                const int rows[3] = {n.K * n.A, n.K * n.F, n.K3 * n.F};
+                for (int c = 0; c < 3; ++c) {
+                    for (int r = 0; r < rows[c]; ++r)
+                        for (int x = 0; x < n.F; ++x) want[(size_t)n.off_cw[c] + (size_t)r * n.F + x] = y.cw[c] + r * y.ldw + x;
+                    for (int x = 0; x < n.F; ++x) want[(size_t)n.off_cb[c] + x] = y.cb[c] + x;
+                }
+            }
+            for (int i = 0; i < n.nl; ++i) {
+                for (int x = 0; x < n.dim[i] * n.dim[i + 1]; ++x) want[(size_t)n.off_w[i] + x] = y.w[i] + x;
+                for (int x = 0; x < n.dim[i + 1]; ++x) want[(size_t)n.off_b[i] + x] = y.b[i] + x;
+            }
+            std::vector<char> used((size_t)y.total, 0);
+            for (int g = 0; g < n.P; ++g) {
+                const int at = fxt_image_off(n, y, g);
+                if (want[(size_t)g] < 0 || at != want[(size_t)g] || at < 0 || at >= y.total || used[(size_t)at]) {
+                    std::printf("image offset: kind %d F %d padded %d parameter %d -> %d, want %d\n", n.kind, n.F, (int)padded, g, at, want[(size_t)g]);
+                    ++bad;
+                    break;
+                }
+                used[(size_t)at] = 1;
+            }
+            if (!padded && y.total != n.P) { std::printf("unpadded image is not the Keras vector\n"); ++bad; }
+            if (padded && n.kind == 0 && (n.F % 8) == 0 && y.ldw != n.F + 4) { std::printf("conv rows not padded\n"); ++bad; }
         }
     }
     // csrc/myers.h fx_bounded_distance (the band of fx_cache_density's kernel): the pattern in an exact-size buffer of m bytes, the
