@@ -48,9 +48,14 @@ static int strips(const std::vector<unsigned char>& a, const std::vector<unsigne
     return la + part;
 }
 
-static int train_case(int kind, int L, int A, int F, int H, int K, int rows, int R) {
+// One mini-batch step.  plain_rows: the workspace's activation rows unpadded (FxtNet::ldx = F -- what the host falls back to when the
+// padded workspace misses the LDS budget); out_w: the updated weights (the two layouts must give the same bits).
+static int train_case(int kind, int L, int A, int F, int H, int K, int rows, int R, bool plain_rows = false, std::vector<float>* out_w = nullptr,
+                      unsigned seed = 0) {
+    if (seed) rng_state = seed;
     FxtJob j{};
     j.net = fxt_net(kind, L, A, kind == 0 ? F : 0, H, kind == 0 ? K : 0);
+    if (plain_rows && kind == 0) j.net.ldx = j.net.F;
     j.batch = rows; j.steps_per_epoch = 1; j.total_steps = 1; j.n = rows; j.R = R; j.S = (rows + R - 1) / R;
     // exact-size heap buffers: any index past an array is an ASAN report
     std::vector<float> w((size_t)j.net.P), m((size_t)j.net.P, 0.f), v((size_t)j.net.P, 0.f), partial((size_t)j.S * (j.net.P + 1), 0.f);
@@ -75,6 +80,7 @@ static int train_case(int kind, int L, int A, int F, int H, int K, int rows, int
     fxt_step_loss(j, 0);
     for (int i = 0; i < j.net.P; ++i) fxt_adam(j, 0, i);
     for (float x : w) if (!(x == x)) { std::printf("NaN weight: kind %d L %d\n", kind, L); return 1; }
+    if (out_w) *out_w = w;
     return 0;
 }
 
@@ -84,6 +90,14 @@ int main() {
         {0, 8, 4, 32, 100, 5, 40, 8}, {0, 9, 4, 8, 16, 3, 37, 5}, {0, 12, 20, 5, 7, 4, 19, 16}, {0, 6, 2, 3, 5, 2, 11, 1}, {0, 7, 4, 1, 1, 7, 3, 4},
         {1, 14, 4, 0, 100, 0, 48, 16}, {1, 5, 20, 0, 9, 0, 5, 3}, {1, 1, 2, 0, 1, 0, 1, 1}, {2, 30, 20, 0, 100, 0, 33, 8}, {2, 9, 4, 0, 20, 0, 37, 64}};
     for (const auto& s : shapes) bad += train_case(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7]);
+    // padded and unpadded activation rows: the same step bit for bit (the padding only moves rows apart)
+    for (const auto& s : shapes) {
+        if (s[0] != 0) continue;
+        std::vector<float> wa, wb;
+        bad += train_case(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], false, &wa, 12345u);
+        bad += train_case(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], true, &wb, 12345u);
+        if (wa.size() != wb.size() || std::memcmp(wa.data(), wb.data(), wa.size() * sizeof(float)) != 0) { std::printf("padded / plain rows differ: L %d F %d\n", s[1], s[3]); ++bad; }
+    }
     for (int trial = 0; trial < 215; ++trial) {
         const int nsym = (trial % 3 == 0) ? 2 : ((trial % 3 == 1) ? 4 : 20);
         std::vector<unsigned char> a(rnd() % (trial < 200 ? 200 : 1700)), b(rnd() % (trial < 200 ? 200 : 900));
