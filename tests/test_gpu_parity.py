@@ -1909,6 +1909,35 @@ def test_resident_tiny_requests(eng, kind, L, alpha, M):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,L,M", [("mlp", 2, 1), ("ge", 1, 2), ("ge", 2, 3), ("mlp", 1, 2), ("mlp", 3, 1)])
+def test_resident_tiny_requests_of_very_short_sequences(eng, kind, L, M):
+    """Sequences of 1-3 symbols: 48 bytes are more than one tile's 16 sequences (such requests take the byte area: only tile 0's
+    workgroup reads the request line) and a tile's byte rows (16 x L bytes) are shorter than the 48-byte line (the workgroup writes
+    only the dwords that hold the request's N x L bytes).  Resident answers against the launched call's bits, serve_tiny on and off
+    (`tools/runs/r4_tiny_edge.py`, `profiles/r4_tiny_edge.log`)."""
+    alpha = "UGCA"
+    mk = {"mlp": lambda s: bm.MLP(L, 100, alpha, seed=s), "ge": lambda s: bm.GlobalEpistasisModel(L, 100, alpha, seed=s)}[kind]
+    members = [mk(70 + s) for s in range(M)]
+    ens = flexs_amd.Ensemble(members) if M > 1 else members[0]
+    sizes = [1, 2, 3, 15, 16, 17, 23, 24, 25, 40, 47, 48, 49]
+    data = {n: rand_seqs(n, L, alpha, seed=900 + n)[1] for n in sizes}
+    eng.set_option("serve_small", 0)
+    try:
+        want = {n: ens.get_fitness(data[n]) for n in sizes}
+    finally:
+        eng.set_option("serve_small", 1)
+    try:
+        for tiny in (1, 0, 1):
+            eng.set_option("serve_tiny", tiny)
+            assert _until_resident(eng, lambda: ens.get_fitness(data[1]))
+            for rep in range(3):
+                for n in sizes + sizes[::-1]:
+                    assert np.array_equal(ens.get_fitness(data[n]), want[n]), (kind, L, n, tiny, rep)
+    finally:
+        eng.set_option("serve_tiny", 1)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("L,M", [(90, 3), (237, 1), (60, 2)])
 def test_prelaunched_instance_of_the_layer_parallel_form(eng, L, M):
     """Round 4 (`lp_prelaunch`, default on): after an explorer-size call of a protein CNN ensemble was answered by the layer-parallel
