@@ -337,6 +337,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "train_trace")) return &e->train_trace;
     if (!std::strcmp(key, "train_persistent")) return &e->train_persistent;
     if (!std::strcmp(key, "train_canon")) return &e->train_canon;
+    if (!std::strcmp(key, "train_swizzle")) return &e->train_swizzle;
     if (!std::strcmp(key, "train_split")) return &e->train_split;
     if (!std::strcmp(key, "dense_waves")) return &e->dense_waves;
     if (!std::strcmp(key, "dense_few_waves_below")) return &e->dense_few_waves_below;

@@ -71,6 +71,18 @@ __global__ void __launch_bounds__(FB_MAX_THREADS) k_train_fb(const FxtJob* __res
     }
 }
 
+// The same step for fits whose members ALL store their position-major arrays with rotated rows (train_core.h "Rotated rows",
+// FxtJob::canon = -1: workspace in LDS, weights from L2).  A kernel of its own, sharing no instantiation with k_train_fb, so that
+// the kernel every other fit runs keeps its code instruction for instruction.
+__global__ void __launch_bounds__(FB_MAX_THREADS) k_train_fb_swz(const FxtJob* __restrict__ jobs, int step, const uint8_t* __restrict__ ascii,
+                                                             const uint8_t* __restrict__ lut, const float* __restrict__ labels) {
+    extern __shared__ __attribute__((aligned(16))) float fxt_smem[];
+    const FxtJob& j = jobs[blockIdx.y];
+    if (step >= j.total_steps || (int)blockIdx.x >= j.S) return;
+    const FxtWg wg{(int)threadIdx.x, (int)blockDim.x};
+    fxt_forward_backward<3, 1, FxtDimsAny, true>(j, wg, step, (int)blockIdx.x, ascii, lut, labels, (FxtMem<3>::F)fxt_smem, (FxtMem<1>::CF)j.w, (FxtMem<3>::F) nullptr);
+}
+
 __global__ void __launch_bounds__(256) k_train_adam(const FxtJob* __restrict__ jobs, int step) {
     const FxtJob& j = jobs[blockIdx.y];
     if (step >= j.total_steps) return;
@@ -213,6 +225,7 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
     std::vector<FxtJob> hj((size_t)M);
     std::vector<std::vector<float>> lr((size_t)M);
     int max_steps = 0, max_S = 0, max_P = 0;
+    int n_swz = 0;                                         // members eligible for rotated rows: used when ALL of the fit's members are
     size_t lds_bytes = 0;
     for (int m = 0; m < M; ++m) {
         fx_fit_job& u = jobs[m];
@@ -256,6 +269,9 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
             if (u.kind == FX_MLP && u.A == 4 && u.H == 100) j.canon = 2;
             if (u.kind == FX_GE && u.A == 20 && u.H == 100) j.canon = 3;
         }
+        // long protein CNNs (unpadded rows in LDS, weights from L2): rotated rows instead of 16-way conflicted ones (train_core.h)
+        if (e->train_swizzle && j.net.kind == 0 && j.net.ldx == j.net.F && j.ws_in_lds && !j.w_in_lds && j.net.F >= 32 && (j.net.F & (j.net.F - 1)) == 0)
+            n_swz += 1;
         max_steps = std::max(max_steps, j.total_steps);
         max_S = std::max(max_S, j.S);
         max_P = std::max(max_P, j.net.P);
@@ -375,7 +391,9 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
     // one launch for the whole fit when every workgroup finds a CU at once (the step barriers need them co-resident)
     int threads = (int)e->train_threads;
     threads = threads >= 1024 ? 1024 : (threads >= 512 ? 512 : (threads >= 256 ? 256 : 1024));
-    bool persistent = e->train_persistent != 0 && M <= 64 && !e->train_trace;
+    const bool any_swz = n_swz == M;
+    if (any_swz) for (FxtJob& j : hj) { j.canon = -1; j.split_off = 0; }
+    bool persistent = e->train_persistent != 0 && M <= 64 && !e->train_trace && !any_swz;     // (the one-launch fit has no rotated-row form)
     if (persistent) {
         if (lds_bytes > 48 * 1024) {
             static bool attr_fit[64] = {};
@@ -405,6 +423,11 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
             FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_fb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS_BUDGET));
             attr_set[e->device & 63] = true;
         }
+        static bool attr_swz[64] = {};
+        if (any_swz && !attr_swz[e->device & 63]) {
+            FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_fb_swz), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS_BUDGET));
+            attr_swz[e->device & 63] = true;
+        }
     }
     if (persistent) {
         FX_HIP(e, hipMemsetAsync(d_bar, 0, sizeof(FxtBar), st));
@@ -413,7 +436,8 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
         FX_HIP(e, hipMemcpyAsync(&h_abort, &d_bar->abort, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     } else {
         for (int s = 0; s < max_steps; ++s) {
-            hipLaunchKernelGGL(k_train_fb, grid_fb, dim3((unsigned)threads), lds_bytes, st, d_jobs, s, d_ascii, d_lut, d_labels);
+            if (any_swz) hipLaunchKernelGGL(k_train_fb_swz, grid_fb, dim3((unsigned)threads), lds_bytes, st, d_jobs, s, d_ascii, d_lut, d_labels);
+            else hipLaunchKernelGGL(k_train_fb, grid_fb, dim3((unsigned)threads), lds_bytes, st, d_jobs, s, d_ascii, d_lut, d_labels);
             hipLaunchKernelGGL(k_train_adam, grid_adam, dim3(256), 0, st, d_jobs, s);
         }
         FX_HIP(e, hipGetLastError());

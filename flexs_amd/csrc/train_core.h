@@ -68,6 +68,19 @@ struct FxtNet {
 // in global memory.)
 FXT_HD int fxt_ld_x(int F) { return (F & 3) == 0 ? F + 2 : F; }
 FXT_HD int fxt_ld_w(int F) { return (F & 7) == 0 ? F + 4 : F; }
+// Rotated rows (SWZ; prepared at the end of round 4 for the long protein CNNs, engine option `train_swizzle`, not yet measured).  A
+// sequence of 237 residues leaves no room for padded rows: five position-major arrays of 233 x 32 floats are 146 of the 150 KiB, so
+// those fits run with unpadded rows (ldx = F) -- every conv operand fetch 16-way conflicted again.  Instead of widening the rows,
+// channel c of position-row `row` is stored at column (c + 2 row) mod F (F a power of two >= 32, row stride = F): the sixteen rows
+// of an A-operand fetch sit on sixteen distinct even banks and the second k-column on the odd ones, exactly as with F + 2 padding,
+// in the same 32 floats.  Only the five position-major arrays (conv outputs and their gradients) are rotated; they are reached
+// through fxt_xi and the ...Swz operand functors below, and the unrotated code keeps its own functors (the kernels every other
+// fit runs are unchanged instruction for instruction).  Where a value is stored does not change the value: the same bits as the
+// unrotated layout (sanitizer driver, CPU).
+template <bool SWZ>
+FXT_HD int fxt_xi(int row, int c, int ld) { return row * ld + (SWZ ? ((c + 2 * row) & (ld - 1)) : c); }
+template <bool SWZ, class A, class B> struct FxtPick { typedef A T; };
+template <class A, class B> struct FxtPick<true, A, B> { typedef B T; };
 
 FXT_HD FxtNet fxt_net(int kind, int L, int A, int F, int H, int K) {
     FxtNet n{};
@@ -207,7 +220,7 @@ struct FxtJob {
     int w_in_lds;               // 1 = ... and the member's weights fit next to it (staged at kernel start)
     int agent_io;               // 1 = gradient partials and updated weights are written through / read past the non-coherent cache levels (the one-launch fit: workgroups exchange them inside a launch)
     int split_off;              // > 0: offset (floats) of the split-K scratch in the workgroup's LDS, 0 = products are not cut along the contraction
-    int canon;                  // > 0: a canonical shape with its own compile-time instantiation (train.hip), 0 = the shape-agnostic code
+    int canon;                  // > 0: a canonical shape with its own compile-time instantiation (train.hip), 0 = the shape-agnostic code, -1 = the shape-agnostic code over rotated rows (SWZ)
     float* step_loss;           // [total_steps] mean squared error of the step's valid rows (before the update)
     unsigned long long* dbg;    // profiling aid (engine option "train_trace"): phase timestamps of workgroup (0, 0), else nullptr
 };
@@ -587,6 +600,56 @@ struct FxtDenseWGradA {
     FXT_HD float at(int st, int, int k0) const { const float v = in[st < 0 ? 0 : st + k0 * ld]; return st < 0 ? 1.f : v; }
 };
 
+// ---- the same operands over ROTATED rows (fxt_xi<true>; the row stride equals the channel count, a power of two) ----
+template <class P>
+struct FxtConvASwz {            // element (row m - pl + j, channel k0 + kq)
+    P x; int Lx, C, pl; FxtDiv dL;
+    struct St { int base, tp, rot; };
+    FXT_HD St prep(int m, int kq) const { const int r = fxt_quot(m, dL), t = m - r * Lx; return St{(m - pl) * C, t - pl, kq + 2 * (m - pl)}; }
+    FXT_HD float at(St s, int j, int k0) const {
+        const int p = s.tp + j;
+        const bool ok = p >= 0 && p < Lx;
+        const float v = x[ok ? s.base + j * C + ((s.rot + 2 * j + k0) & (C - 1)) : 0];
+        return ok ? v : 0.f;
+    }
+};
+template <class P>
+struct FxtConvGradASwz {        // element (row m + pl - j, channel k0 + kq)
+    P dz; int Lx, F, pl; FxtDiv dL;
+    struct St { int base, sp, rot; };
+    FXT_HD St prep(int m, int kq) const { const int r = fxt_quot(m, dL), s = m - r * Lx; return St{(m + pl) * F, s + pl, kq + 2 * (m + pl)}; }
+    FXT_HD float at(St st, int j, int k0) const {
+        const int p = st.sp - j;
+        const bool ok = p >= 0 && p < Lx;
+        const float v = dz[ok ? st.base - j * F + ((st.rot - 2 * j + k0) & (F - 1)) : 0];
+        return ok ? v : 0.f;
+    }
+};
+template <class P>
+struct FxtConvWGradASwz {       // element (row r Lx + k0 + j - pl + kq, channel c)
+    P x; int Lx, C, ld, pl, rows; FxtDiv dC;
+    struct St { int off, tp, rot; };         // off < 0: bias row
+    FXT_HD St prep(int m, int kq) const {
+        if (m >= rows) return St{-1, 0, 0};
+        const int j = fxt_quot(m, dC), c = m - j * C;
+        return St{(j - pl + kq) * ld + (1 << 30), j - pl + kq, c + 2 * (j - pl + kq)};
+    }
+    FXT_HD float at(St s, int r, int k0) const {
+        const int p = s.tp + k0;
+        const bool ok = s.off >= 0 && p >= 0 && p < Lx;
+        const int ru = r * Lx + k0;
+        const float v = x[ok ? s.off - (1 << 30) + ru * ld + ((s.rot + 2 * ru) & (ld - 1)) : 0];
+        return s.off < 0 ? 1.f : (ok ? v : 0.f);
+    }
+};
+template <class P>
+struct FxtPosMajorBSwz {        // element (row r Lx + k0 + kq, channel n)
+    P p; int Lx, F;
+    struct St { int off, rot; };
+    FXT_HD St prep(int n, int kq) const { return St{kq * F, n + 2 * kq}; }
+    FXT_HD float at(St st, int r, int k0) const { const int ru = r * Lx + k0; return p[st.off + ru * F + ((st.rot + 2 * ru) & (F - 1))]; }
+};
+
 // Compile-time shape of a CANONICAL network (round 4).  The step is written for any shape the constructors accept: every
 // contraction chooses among three k-step walks at run time, masks its overhangs, and builds its addresses from run-time
 // dimensions -- 100 KiB of code per placement, executed once per launch, i.e. streamed through the 64 KiB instruction cache
@@ -603,7 +666,7 @@ struct FxtDims { static constexpr bool fixed = true; static constexpr int kind =
 // `ws`: the slice's workspace -- the workgroup's LDS on the device when it fits (activations are written by one phase
 // and read by the next: an LDS round trip instead of an L2 one; WSAS = 3), else its row of the global arena (WSAS = 1).
 // `W`: the member's weights, staged in LDS by the caller when they fit next to the workspace (WAS = 3), else j.w.
-template <int WSAS, int WAS, class D = FxtDimsAny>
+template <int WSAS, int WAS, class D = FxtDimsAny, bool SWZ = false>
 FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int slice, const uint8_t* ascii,
                                  const uint8_t* lut, const float* labels, typename FxtMem<WSAS>::F ws,
                                  typename FxtMem<WAS>::CF W, typename FxtMem<WSAS>::F split = nullptr) {
@@ -612,6 +675,10 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
     typedef typename FxtMem<WSAS>::I WsI;
     typedef typename FxtMem<WSAS>::CI WsCI;
     typedef typename FxtMem<WAS>::CF WCF;
+    typedef typename FxtPick<SWZ, FxtConvA<WsCF>, FxtConvASwz<WsCF>>::T ConvA;
+    typedef typename FxtPick<SWZ, FxtConvGradA<WsCF>, FxtConvGradASwz<WsCF>>::T ConvGradA;
+    typedef typename FxtPick<SWZ, FxtConvWGradA<WsCF>, FxtConvWGradASwz<WsCF>>::T ConvWGradA;
+    typedef typename FxtPick<SWZ, FxtPosMajorB<WsCF>, FxtPosMajorBSwz<WsCF>>::T PosMajorB;
     // (a canonical instantiation rebuilds the description from its constants -- only the sequence length is a run-time value --
     //  so that everything derived from it below is a constant too)
     const FxtNet n = D::fixed ? fxt_net(D::kind, D::L > 0 ? D::L : j.net.L, D::A, D::F, D::H, D::K) : j.net;
@@ -655,28 +722,28 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
             const int o = i % F, rt = i / F, t = rt % L1, r = rt / L1;
             float s = W[y.cb[0] + o];
             for (int jj = 0; jj < K; ++jj) s += W[y.cw[0] + (jj * A + codes[r * L + t + jj]) * ldw + o];
-            a1[rt * ldF + o] = s > 0.f ? s : 0.f;
+            a1[fxt_xi<SWZ>(rt, o, ldF)] = s > 0.f ? s : 0.f;
         }
         fxt_sync_ws<WSAS>(); FXT_STAMP(2);
         {   // conv2 ('same', K taps)
             WCF b = W + y.cb[1];
-            struct Put { WsF y; WCF b; int ld; FXT_HD void put(int m, int nn, float v) const { v += b[nn]; y[m * ld + nn] = v > 0.f ? v : 0.f; } };
-            fxt_gemm(wg, R * L1, F, K, F, FxtConvA<WsCF>{a1, L1, ldF, (K - 1) / 2, dL1}, FxtConvW<WCF>{W + y.cw[1], F, ldw}, Put{a2, b, ldF}, 0, split);
+            struct Put { WsF y; WCF b; int ld; FXT_HD void put(int m, int nn, float v) const { v += b[nn]; y[fxt_xi<SWZ>(m, nn, ld)] = v > 0.f ? v : 0.f; } };
+            fxt_gemm(wg, R * L1, F, K, F, ConvA{a1, L1, ldF, (K - 1) / 2, dL1}, FxtConvW<WCF>{W + y.cw[1], F, ldw}, Put{a2, b, ldF}, 0, split);
         }
         fxt_sync_ws<WSAS>(); FXT_STAMP(3);
         {   // conv3 ('same', A - 1 taps)
             WCF b = W + y.cb[2];
-            struct Put { WsF y; WCF b; int ld; FXT_HD void put(int m, int nn, float v) const { v += b[nn]; y[m * ld + nn] = v > 0.f ? v : 0.f; } };
-            fxt_gemm(wg, R * L1, F, n.K3, F, FxtConvA<WsCF>{a2, L1, ldF, (n.K3 - 1) / 2, dL1}, FxtConvW<WCF>{W + y.cw[2], F, ldw}, Put{a3, b, ldF}, 0, split);
+            struct Put { WsF y; WCF b; int ld; FXT_HD void put(int m, int nn, float v) const { v += b[nn]; y[fxt_xi<SWZ>(m, nn, ld)] = v > 0.f ? v : 0.f; } };
+            fxt_gemm(wg, R * L1, F, n.K3, F, ConvA{a2, L1, ldF, (n.K3 - 1) / 2, dL1}, FxtConvW<WCF>{W + y.cw[2], F, ldw}, Put{a3, b, ldF}, 0, split);
         }
         fxt_sync_ws<WSAS>(); FXT_STAMP(4);
         WsF g = ws + w.g; WsF cnt = ws + w.cnt;
         FXT_FOR(i, R * F, wg) {             // GlobalMaxPooling1D + the number of positions that attain the maximum
             const int r = i / F, f = i - r * F;
-            float mx = a3[(r * L1) * ldF + f];
-            for (int t = 1; t < L1; ++t) { const float v = a3[(r * L1 + t) * ldF + f]; mx = v > mx ? v : mx; }
+            float mx = a3[fxt_xi<SWZ>(r * L1, f, ldF)];
+            for (int t = 1; t < L1; ++t) { const float v = a3[fxt_xi<SWZ>(r * L1 + t, f, ldF)]; mx = v > mx ? v : mx; }
             int c = 0;
-            for (int t = 0; t < L1; ++t) c += a3[(r * L1 + t) * ldF + f] == mx;
+            for (int t = 0; t < L1; ++t) c += a3[fxt_xi<SWZ>(r * L1 + t, f, ldF)] == mx;
             g[r * ldF + f] = mx; cnt[r * ldF + f] = (float)c;
         }
         fxt_sync_ws<WSAS>(); FXT_STAMP(5);
@@ -794,8 +861,8 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         WsF dzA = ws + w.dzA; WsF dzB = ws + w.dzB;
         FXT_FOR(i, R * L1 * F, wg) {        // max-pool backward (ties share evenly) through conv3's ReLU
             const int f = i % F, rt = i / F, r = rt / L1;
-            const float v = a3[rt * ldF + f];
-            dzA[rt * ldF + f] = (v > 0.f && v == g[r * ldF + f]) ? dg[r * ldF + f] / cnt[r * ldF + f] : 0.f;
+            const float v = a3[fxt_xi<SWZ>(rt, f, ldF)];
+            dzA[fxt_xi<SWZ>(rt, f, ldF)] = (v > 0.f && v == g[r * ldF + f]) ? dg[r * ldF + f] / cnt[r * ldF + f] : 0.f;
         }
         fxt_sync_ws<WSAS>(); FXT_STAMP(9);
         struct PutW {
@@ -809,17 +876,17 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
             }
         };
         const bool ag = j.agent_io != 0;
-        struct PutX { WsF d; WsCF y; int ld; FXT_HD void put(int m, int nn, float v) const { d[m * ld + nn] = y[m * ld + nn] > 0.f ? v : 0.f; } };
+        struct PutX { WsF d; WsCF y; int ld; FXT_HD void put(int m, int nn, float v) const { d[fxt_xi<SWZ>(m, nn, ld)] = y[fxt_xi<SWZ>(m, nn, ld)] > 0.f ? v : 0.f; } };
         // conv3: input gradient (few tiles, K3 x F / 4 k-steps) first, the weight gradient dealt on behind it
-        fxt_gemm(wg, R * L1, F, K3, F, FxtConvGradA<WsCF>{dzA, L1, ldF, (K3 - 1) / 2, dL1}, FxtConvGradW<WCF>{W + y.cw[2], F, ldw}, PutX{dzB, a2, ldF}, 0, split);
-        fxt_gemm(wg, K3 * F + 1, F, R, L1, FxtConvWGradA<WsCF>{a2, L1, F, ldF, (K3 - 1) / 2, K3 * F, dF}, FxtPosMajorB<WsCF>{dzA, L1, ldF}, PutW{part + n.off_cw[2], part + n.off_cb[2], K3 * F, F, ag}, fxt_jobs(R * L1, F, K3, F, nwv, can_split));
+        fxt_gemm(wg, R * L1, F, K3, F, ConvGradA{dzA, L1, ldF, (K3 - 1) / 2, dL1}, FxtConvGradW<WCF>{W + y.cw[2], F, ldw}, PutX{dzB, a2, ldF}, 0, split);
+        fxt_gemm(wg, K3 * F + 1, F, R, L1, ConvWGradA{a2, L1, F, ldF, (K3 - 1) / 2, K3 * F, dF}, PosMajorB{dzA, L1, ldF}, PutW{part + n.off_cw[2], part + n.off_cb[2], K3 * F, F, ag}, fxt_jobs(R * L1, F, K3, F, nwv, can_split));
         fxt_sync_ws<WSAS>(); FXT_STAMP(10);
         // conv2
-        fxt_gemm(wg, R * L1, F, K, F, FxtConvGradA<WsCF>{dzB, L1, ldF, (K - 1) / 2, dL1}, FxtConvGradW<WCF>{W + y.cw[1], F, ldw}, PutX{dzA, a1, ldF}, 0, split);
-        fxt_gemm(wg, K * F + 1, F, R, L1, FxtConvWGradA<WsCF>{a1, L1, F, ldF, (K - 1) / 2, K * F, dF}, FxtPosMajorB<WsCF>{dzB, L1, ldF}, PutW{part + n.off_cw[1], part + n.off_cb[1], K * F, F, ag}, fxt_jobs(R * L1, F, K, F, nwv, can_split));
+        fxt_gemm(wg, R * L1, F, K, F, ConvGradA{dzB, L1, ldF, (K - 1) / 2, dL1}, FxtConvGradW<WCF>{W + y.cw[1], F, ldw}, PutX{dzA, a1, ldF}, 0, split);
+        fxt_gemm(wg, K * F + 1, F, R, L1, ConvWGradA{a1, L1, F, ldF, (K - 1) / 2, K * F, dF}, PosMajorB{dzB, L1, ldF}, PutW{part + n.off_cw[1], part + n.off_cb[1], K * F, F, ag}, fxt_jobs(R * L1, F, K, F, nwv, can_split));
         fxt_sync_ws<WSAS>(); FXT_STAMP(11);
         // conv1 (one-hot input, 'valid')
-        fxt_gemm(wg, K * A + 1, F, R, L1, FxtOneHotWGradA<WsCI>{codes, L, A, K * A, 1, dA}, FxtPosMajorB<WsCF>{dzA, L1, ldF}, PutW{part + n.off_cw[0], part + n.off_cb[0], K * A, F, ag});
+        fxt_gemm(wg, K * A + 1, F, R, L1, FxtOneHotWGradA<WsCI>{codes, L, A, K * A, 1, dA}, PosMajorB{dzA, L1, ldF}, PutW{part + n.off_cw[0], part + n.off_cb[0], K * A, F, ag});
     }
     FXT_STAMP(63);
 }

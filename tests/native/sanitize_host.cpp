@@ -50,8 +50,9 @@ static int strips(const std::vector<unsigned char>& a, const std::vector<unsigne
 
 // One mini-batch step.  plain_rows: the workspace's activation rows unpadded (FxtNet::ldx = F -- what the host falls back to when the
 // padded workspace misses the LDS budget); out_w: the updated weights (the two layouts must give the same bits).
+// rotated: plain rows stored rotated (train_core.h "Rotated rows", F a power of two) -- again the same bits.
 static int train_case(int kind, int L, int A, int F, int H, int K, int rows, int R, bool plain_rows = false, std::vector<float>* out_w = nullptr,
-                      unsigned seed = 0) {
+                      unsigned seed = 0, bool rotated = false) {
     if (seed) rng_state = seed;
     FxtJob j{};
     j.net = fxt_net(kind, L, A, kind == 0 ? F : 0, H, kind == 0 ? K : 0);
@@ -75,8 +76,10 @@ static int train_case(int kind, int L, int A, int F, int H, int K, int rows, int
     j.ws_slice = fxt_ws(j.net, R).total;
     std::vector<float> ws((size_t)j.S * (size_t)j.ws_slice, 0.f);
     j.ws = ws.data();
-    for (int s = 0; s < j.S; ++s)
-        fxt_forward_backward<0, 0>(j, FxtWg{0, 1}, 0, s, ascii.data(), lut.data(), labels.data(), j.ws + (long long)s * j.ws_slice, (const float*)j.w);
+    for (int s = 0; s < j.S; ++s) {
+        if (rotated) fxt_forward_backward<0, 0, FxtDimsAny, true>(j, FxtWg{0, 1}, 0, s, ascii.data(), lut.data(), labels.data(), j.ws + (long long)s * j.ws_slice, (const float*)j.w);
+        else fxt_forward_backward<0, 0>(j, FxtWg{0, 1}, 0, s, ascii.data(), lut.data(), labels.data(), j.ws + (long long)s * j.ws_slice, (const float*)j.w);
+    }
     fxt_step_loss(j, 0);
     for (int i = 0; i < j.net.P; ++i) fxt_adam(j, 0, i);
     for (float x : w) if (!(x == x)) { std::printf("NaN weight: kind %d L %d\n", kind, L); return 1; }
@@ -90,6 +93,15 @@ int main() {
         {0, 8, 4, 32, 100, 5, 40, 8}, {0, 9, 4, 8, 16, 3, 37, 5}, {0, 12, 20, 5, 7, 4, 19, 16}, {0, 6, 2, 3, 5, 2, 11, 1}, {0, 7, 4, 1, 1, 7, 3, 4},
         {1, 14, 4, 0, 100, 0, 48, 16}, {1, 5, 20, 0, 9, 0, 5, 3}, {1, 1, 2, 0, 1, 0, 1, 1}, {2, 30, 20, 0, 100, 0, 33, 8}, {2, 9, 4, 0, 20, 0, 37, 64}};
     for (const auto& s : shapes) bad += train_case(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7]);
+    {   // rotated rows on the shapes they are meant for: a 20-letter alphabet, ONE row per slice (long sequences), 32 / 64 / 16 filters
+        const int rot[][8] = {{0, 41, 20, 32, 100, 5, 5, 1}, {0, 23, 20, 64, 9, 4, 3, 1}, {0, 19, 20, 16, 12, 3, 9, 2}, {0, 37, 6, 32, 7, 6, 4, 3}};
+        for (const auto& s : rot) {
+            std::vector<float> wa, wc;
+            bad += train_case(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], true, &wa, 777u, false);
+            bad += train_case(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], true, &wc, 777u, true);
+            if (wa.size() != wc.size() || std::memcmp(wa.data(), wc.data(), wa.size() * sizeof(float)) != 0) { std::printf("rotated rows differ: L %d F %d\n", s[1], s[3]); ++bad; }
+        }
+    }
     // padded and unpadded activation rows: the same step bit for bit (the padding only moves rows apart)
     for (const auto& s : shapes) {
         if (s[0] != 0) continue;
@@ -97,6 +109,10 @@ int main() {
         bad += train_case(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], false, &wa, 12345u);
         bad += train_case(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], true, &wb, 12345u);
         if (wa.size() != wb.size() || std::memcmp(wa.data(), wb.data(), wa.size() * sizeof(float)) != 0) { std::printf("padded / plain rows differ: L %d F %d\n", s[1], s[3]); ++bad; }
+        if (s[3] & (s[3] - 1)) continue;                   // rotated rows: power-of-two filter counts
+        std::vector<float> wc;
+        bad += train_case(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], true, &wc, 12345u, true);
+        if (wa.size() != wc.size() || std::memcmp(wa.data(), wc.data(), wa.size() * sizeof(float)) != 0) { std::printf("rotated rows differ: L %d F %d\n", s[1], s[3]); ++bad; }
     }
     for (int trial = 0; trial < 215; ++trial) {
         const int nsym = (trial % 3 == 0) ? 2 : ((trial % 3 == 1) ? 4 : 20);
