@@ -311,7 +311,12 @@ def wants_chunked(sequences, L: int) -> bool:
 
 
 class Engine:
-    """One GPU's scoring engine (stream, scratch, deferred-error word)."""
+    """One GPU's scoring engine (stream, scratch, deferred-error word).
+
+    NOT thread-safe, as include/flexs_amd.h says of the handle: calls into one engine come from one thread at a time.  `Engine.get`
+    hands every thread of the process the SAME engine per device, and the GIL is released inside the library calls, so two Python
+    threads that score or train through it at the same moment must serialise themselves (one lock around their model calls) -- or,
+    the deployment model, live in one process per GPU (`distributed.py`)."""
 
     _instances: Dict[int, "Engine"] = {}
 
