@@ -506,8 +506,8 @@ static PyObject* adalead_children(PyObject* self, PyObject* args) {
         PyObject* nd = PyList_GET_ITEM(nodes, i);
         if (!PyTuple_CheckExact(nd) || PyTuple_GET_SIZE(nd) != 2 || !PyUnicode_Check(PyTuple_GET_ITEM(nd, 1)) ||
             PyUnicode_READY(PyTuple_GET_ITEM(nd, 1)) < 0 || PyUnicode_KIND(PyTuple_GET_ITEM(nd, 1)) != PyUnicode_1BYTE_KIND ||
-            PyUnicode_GET_LENGTH(PyTuple_GET_ITEM(nd, 1)) > 4096)
-            Py_RETURN_NONE;
+            PyUnicode_GET_LENGTH(PyTuple_GET_ITEM(nd, 1)) > 4096 || PyUnicode_GET_LENGTH(PyTuple_GET_ITEM(nd, 1)) < 1)
+            Py_RETURN_NONE;                                             /* (an empty node: the Python loop raises what the reference raises) */
     }
     PyObject* k_obj = PyLong_FromLong(k_bits);
     PyObject* idxs = PyList_New(0);
