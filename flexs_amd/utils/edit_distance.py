@@ -72,12 +72,19 @@ class SeenSequences:
         if new:
             self._cache.append(_native.ragged_to_bytes(new, self._L))
 
+    @staticmethod
+    def _check_radius(dist_radius):
+        # the device reports min(distance, 255) in one byte (fx_cache_distances): a radius past 254 cannot be told from "far"
+        if dist_radius > 254:
+            raise ValueError("sequence density: dist_radius must be at most 254 (distances are kept in one byte)")
+
     def distances(self, seq: str) -> np.ndarray:
         return self._cache.distances(_native.ragged_to_bytes([seq], self._L), self._mode)[0]
 
     def densities(self, seqs, dist_radius: int = 2):
         """`[self.density(s) for s in seqs]` with ONE distance-matrix launch for the whole batch."""
         seqs = [str(s) for s in seqs]
+        self._check_radius(dist_radius)
         if not seqs or len(self._fitness) == 0:
             return [0 for _ in seqs]
         # one distance launch, the radius filter and the sums in C (fx_cache_density: the Python loop's float operations in
@@ -99,6 +106,7 @@ class SeenSequences:
     def density(self, seq: str, dist_radius: int = 2):
         """dyna_ppo.py:106-114: `dens += all_seqs[s] / dist` for 0 < dist <= radius, in insertion order."""
         dens = 0
+        self._check_radius(dist_radius)
         if len(self._fitness) == 0:
             return dens
         d = self.distances(seq)

@@ -722,6 +722,10 @@ def test_seen_sequences_bookkeeping_without_a_gpu():
             assert np.array_equal(seen._fit_array(), np.array(seen._fitness))
         seen.add(base, 0.125)                                             # the single-sequence form updates in place too
         assert seen[base] == 0.125 and len(seen) == len(all_seqs)
+        for call in (lambda: seen.densities([base], 255), lambda: seen.density(base, 300)):
+            with pytest.raises(ValueError):                               # (distances come back as min(d, 255) in one byte)
+                call()
+        assert seen.densities([base], 254) == [reference_density(all_seqs | {base: 0.125}, base, 254)]
 
 
 def test_population_step_decodes_scores_and_names_in_one_call():
