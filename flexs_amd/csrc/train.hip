@@ -80,7 +80,10 @@ __global__ void __launch_bounds__(FB_MAX_THREADS) k_train_fb_swz(const FxtJob* _
     const FxtJob& j = jobs[blockIdx.y];
     if (step >= j.total_steps || (int)blockIdx.x >= j.S) return;
     const FxtWg wg{(int)threadIdx.x, (int)blockDim.x};
-    fxt_forward_backward<3, 1, FxtDimsAny, true>(j, wg, step, (int)blockIdx.x, ascii, lut, labels, (FxtMem<3>::F)fxt_smem, (FxtMem<1>::CF)j.w, (FxtMem<3>::F) nullptr);
+    if (j.canon == -2)       // + the gradient array over the last conv output, conv kernels staged through LDS (j.split_off taps at a time)
+        fxt_forward_backward<3, 1, FxtDimsAny, 2>(j, wg, step, (int)blockIdx.x, ascii, lut, labels, (FxtMem<3>::F)fxt_smem, (FxtMem<1>::CF)j.w, (FxtMem<3>::F) nullptr);
+    else
+        fxt_forward_backward<3, 1, FxtDimsAny, 1>(j, wg, step, (int)blockIdx.x, ascii, lut, labels, (FxtMem<3>::F)fxt_smem, (FxtMem<1>::CF)j.w, (FxtMem<3>::F) nullptr);
 }
 
 __global__ void __launch_bounds__(256) k_train_adam(const FxtJob* __restrict__ jobs, int step) {
@@ -225,7 +228,8 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
     std::vector<FxtJob> hj((size_t)M);
     std::vector<std::vector<float>> lr((size_t)M);
     int max_steps = 0, max_S = 0, max_P = 0;
-    int n_swz = 0;                                         // members eligible for rotated rows: used when ALL of the fit's members are
+    int n_swz = 0, n_stage = 0;                            // members eligible for rotated rows / staged conv kernels: used when ALL of the fit's members are
+    std::vector<int> stage_taps((size_t)M, 0);
     size_t lds_bytes = 0;
     for (int m = 0; m < M; ++m) {
         fx_fit_job& u = jobs[m];
@@ -270,8 +274,16 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
             if (u.kind == FX_GE && u.A == 20 && u.H == 100) j.canon = 3;
         }
         // long protein CNNs (unpadded rows in LDS, weights from L2): rotated rows instead of 16-way conflicted ones (train_core.h)
-        if (e->train_swizzle && j.net.kind == 0 && j.net.ldx == j.net.F && j.ws_in_lds && !j.w_in_lds && j.net.F >= 32 && (j.net.F & (j.net.F - 1)) == 0)
+        if (e->train_swizzle && j.net.kind == 0 && j.net.ldx == j.net.F && j.ws_in_lds && !j.w_in_lds && j.net.F >= 32 && (j.net.F & (j.net.F - 1)) == 0) {
             n_swz += 1;
+            // train_swizzle = 2: how many taps of a conv kernel fit behind the four-array workspace (train_core.h MODE 2)
+            const size_t ws2 = (size_t)fxt_ws(j.net, j.R, true).total, tap = (size_t)j.net.F * (size_t)fxt_ld_w(j.net.F);
+            const int kmax = std::max(j.net.K, j.net.K3);
+            int taps = ws2 * 4 < FB_LDS_BUDGET ? (int)std::min<size_t>((FB_LDS_BUDGET / 4 - ws2) / tap, (size_t)kmax) : 0;
+            if (!fxt_staged_ok(j.R * j.net.L1, j.net.F, j.net.F, j.net.F, FB_MAX_THREADS / 64)) taps = 0;
+            stage_taps[(size_t)m] = taps;
+            if (e->train_swizzle >= 2 && taps >= 1) n_stage += 1;
+        }
         max_steps = std::max(max_steps, j.total_steps);
         max_S = std::max(max_S, j.S);
         max_P = std::max(max_P, j.net.P);
@@ -279,6 +291,21 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
         for (int s = 0; s < j.total_steps; ++s) {
             const double t = (double)(u.step + s + 1);           // keras Adam: lr_t = lr sqrt(1 - b2^t) / (1 - b1^t)
             lr[(size_t)m][(size_t)s] = (float)(FXT_LR * std::sqrt(1.0 - std::pow(FXT_BETA_2, t)) / (1.0 - std::pow(FXT_BETA_1, t)));
+        }
+    }
+    int threads = (int)e->train_threads;
+    threads = threads >= 1024 ? 1024 : (threads >= 512 ? 512 : (threads >= 256 ? 256 : 1024));
+    const bool any_swz = n_swz == M;
+    const bool staged = any_swz && n_stage == M && threads == FB_MAX_THREADS;     // (fxt_staged_ok was asked for 16 waves)
+    if (any_swz) {
+        for (int m = 0; m < M; ++m) {
+            FxtJob& j = hj[(size_t)m];
+            j.canon = staged ? -2 : -1;
+            j.split_off = staged ? stage_taps[(size_t)m] : 0;
+            if (staged) {
+                j.ws_slice = fxt_ws(j.net, j.R, true).total + stage_taps[(size_t)m] * j.net.F * fxt_ld_w(j.net.F);
+                lds_bytes = std::max(lds_bytes, (size_t)j.ws_slice * 4);
+            }
         }
     }
     for (int64_t i = 0; i < n * L; ++i)                          // alphabet.index raises ValueError (sequence_utils.py:46)
@@ -389,10 +416,6 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
         hj[0].dbg = e->d_train_dbg;
     }
     // one launch for the whole fit when every workgroup finds a CU at once (the step barriers need them co-resident)
-    int threads = (int)e->train_threads;
-    threads = threads >= 1024 ? 1024 : (threads >= 512 ? 512 : (threads >= 256 ? 256 : 1024));
-    const bool any_swz = n_swz == M;
-    if (any_swz) for (FxtJob& j : hj) { j.canon = -1; j.split_off = 0; }
     bool persistent = e->train_persistent != 0 && M <= 64 && !e->train_trace && !any_swz;     // (the one-launch fit has no rotated-row form)
     if (persistent) {
         if (lds_bytes > 48 * 1024) {

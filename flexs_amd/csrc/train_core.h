@@ -81,6 +81,12 @@ template <bool SWZ>
 FXT_HD int fxt_xi(int row, int c, int ld) { return row * ld + (SWZ ? ((c + 2 * row) & (ld - 1)) : c); }
 template <bool SWZ, class A, class B> struct FxtPick { typedef A T; };
 template <class A, class B> struct FxtPick<true, A, B> { typedef B T; };
+// MODE of fxt_forward_backward: 0 = rows as they are (padded or not), 1 = rotated rows, 2 = rotated rows + the gradient array dzA
+// over a[2] (fxt_ws alias_dz) + the conv kernels of conv2 / conv3 STAGED through the LDS that frees, a group of taps at a time
+// (fxt_gemm_staged): with 165 KiB of weights in global memory every B operand of the protein CNNs' conv products is an L2 round
+// trip, eight in flight per wave; staged, a tap's 32 x 32 block is fetched once per workgroup and product instead of once per
+// output tile.  The taps are walked in the same order with the same accumulators: the same bits.  (Also prepared at the end of
+// round 4 and not yet measured: `train_swizzle` = 2.)
 
 FXT_HD FxtNet fxt_net(int kind, int L, int A, int F, int H, int K) {
     FxtNet n{};
@@ -172,7 +178,9 @@ struct FxtWs {
     int total;
 };
 
-FXT_HD FxtWs fxt_ws(const FxtNet& n, int R) {
+// alias_dz: the gradient array dzA lies OVER the last conv output a[2] (the max-pool backward turns one into the other element by
+// element, and nothing reads a[2] afterwards): four position-major arrays instead of five (MODE 2 below).
+FXT_HD FxtWs fxt_ws(const FxtNet& n, int R, bool alias_dz = false) {
     FxtWs w{};
     int off = 0;
     w.codes = off; off += R * n.L;
@@ -182,7 +190,8 @@ FXT_HD FxtWs fxt_ws(const FxtNet& n, int R) {
         w.ldF = n.ldx;
         const int s = R * n.L1 * w.ldF;
         for (int i = 0; i < 3; ++i) { w.a[i] = off; off += s; }
-        w.dzA = off; off += s;
+        if (alias_dz) w.dzA = w.a[2];
+        else { w.dzA = off; off += s; }
         w.dzB = off; off += s;
         w.g = off; off += R * w.ldF;
         w.cnt = off; off += R * w.ldF;
@@ -479,16 +488,108 @@ FXT_HD void fxt_gemm(const FxtWg& wg, int Md, int Nd, int Ko, int Ki, const FA& 
 // k-steps with every operand in LDS).  The step is therefore compiled per placement -- workspace in LDS (3) or global
 // memory (1), weights in LDS or global memory -- with address-space-qualified pointer types; the host build has one.
 #if FXT_DEVICE
+typedef float fxt_f4 __attribute__((ext_vector_type(4)));
 template <int AS> struct FxtMem {
     typedef __attribute__((address_space(AS))) float* F;
     typedef const __attribute__((address_space(AS))) float* CF;
     typedef __attribute__((address_space(AS))) int* I;
     typedef const __attribute__((address_space(AS))) int* CI;
+    typedef const __attribute__((address_space(AS))) fxt_f4* CF4;      // sixteen bytes at a time (fxt_gemm_staged)
 };
-template <> struct FxtMem<0> { typedef float* F; typedef const float* CF; typedef int* I; typedef const int* CI; };   // (flat / host)
+template <> struct FxtMem<0> { typedef float* F; typedef const float* CF; typedef int* I; typedef const int* CI; typedef const fxt_f4* CF4; };   // (flat / host)
 #else
 template <int AS> struct FxtMem { typedef float* F; typedef const float* CF; typedef int* I; typedef const int* CI; };
 #endif
+
+
+// fxt_gemm for a conv product whose B operand -- taps [0, Ko) of a conv kernel, `rows_per_tap` rows of F floats each in global
+// memory at `wsrc` -- is staged through `wbuf` (LDS on the device; rows `ldw` floats apart) in groups of G taps.  `fb` is the B functor
+// built OVER wbuf: it is handed the tap index relative to its group.  Ki is a multiple of 32 (whole groups of eight k-steps), a wave
+// owns at most FXT_STAGED_TPW tiles whose accumulators stay in registers across the groups (the caller checks both: fxt_staged_ok).
+// ALL threads of the workgroup call it together (two LDS barriers per group).
+#define FXT_STAGED_TPW 2
+FXT_HD bool fxt_staged_ok(int Md, int Nd, int Ki, int F, int nw) { return (Ki & 31) == 0 && (F & 3) == 0 && fxt_tiles(Md, Nd) <= nw * FXT_STAGED_TPW; }
+template <int WSAS, int WAS, class FA, class FB, class FC>
+FXT_HD void fxt_gemm_staged(const FxtWg& wg, int Md, int Nd, int Ko, int Ki, const FA& fa, const FB& fb, const FC& fc,
+                            typename FxtMem<WAS>::CF wsrc, typename FxtMem<WSAS>::F wbuf, int G, int rows_per_tap, int F, int ldw) {
+    if (G < 1) G = Ko;                                     // (never from the host's sizing; a group must advance)
+#if FXT_DEVICE
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    constexpr int U = 8, TPW = FXT_STAGED_TPW;
+    const int lane = wg.tid & 63, nw = wg.nthr >> 6, wave = wg.tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int tn = (Nd + 15) >> 4, tiles = ((Md + 15) >> 4) * tn;
+    f4_t acc[TPW];
+    decltype(fa.prep(0, 0)) sa[TPW];
+    decltype(fb.prep(0, 0)) sb[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int t = wave + q * nw;
+        const int m = ((t / tn) << 4) + i, n = ((t % tn) << 4) + i;
+        acc[q] = f4_t{0.f, 0.f, 0.f, 0.f};
+        sa[q] = fa.prep((t < tiles && m < Md) ? m : 0, kq);
+        sb[q] = fb.prep((t < tiles && n < Nd) ? n : 0, kq);
+    }
+    const int f4_per_row = F >> 2;
+    for (int g0 = 0; g0 < Ko; g0 += G) {
+        const int g1 = g0 + G < Ko ? g0 + G : Ko;
+        fxt_sync_ws<WSAS>();                               // everybody is through with the previous group's taps (or the previous phase)
+        const int pieces = (g1 - g0) * rows_per_tap * f4_per_row;
+        for (int p = wg.tid; p < pieces; p += wg.nthr) {
+            const int row = p / f4_per_row, c4 = p - row * f4_per_row;
+            const f4_t v = *(typename FxtMem<WAS>::CF4)(wsrc + ((g0 * rows_per_tap + row) * F + 4 * c4));
+            const int o = row * ldw + 4 * c4;               // (scalar stores: they keep wbuf's address space -- ds_write, not flat)
+            wbuf[o] = v[0]; wbuf[o + 1] = v[1]; wbuf[o + 2] = v[2]; wbuf[o + 3] = v[3];
+        }
+        fxt_sync_ws<WSAS>();
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+            if (wave + q * nw >= tiles) continue;          // (wave-uniform)
+            for (int ko = g0; ko < g1; ++ko) {
+                for (int k0 = 0; k0 < Ki; k0 += 4 * U) {
+                    float a[U], b[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) { a[u] = fa.at(sa[q], ko, k0 + 4 * u); b[u] = fb.at(sb[q], ko - g0, k0 + 4 * u); }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc[q], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int t = wave + q * nw;
+        if (t >= tiles) continue;
+        const int m0 = (t / tn) << 4, n = ((t % tn) << 4) + i;
+        if (n < Nd) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mr = m0 + 4 * kq + r;
+                if (mr < Md) fc.put(mr, n, acc[q][r]);
+            }
+        }
+    }
+#else
+    (void)wg;
+    float* accs = new float[(size_t)Md * Nd]();
+    for (int g0 = 0; g0 < Ko; g0 += G) {
+        const int g1 = g0 + G < Ko ? g0 + G : Ko;
+        for (int row = 0; row < (g1 - g0) * rows_per_tap; ++row)
+            for (int c = 0; c < F; ++c) wbuf[row * ldw + c] = wsrc[(g0 * rows_per_tap + row) * F + c];
+        for (int m = 0; m < Md; ++m)
+            for (int n = 0; n < Nd; ++n) {
+                float acc = accs[(size_t)m * Nd + n];
+                for (int ko = g0; ko < g1; ++ko)
+                    for (int ki = 0; ki < Ki; ++ki)
+                        acc = fmaf(fa.at(fa.prep(m, ki & 3), ko, ki & ~3), fb.at(fb.prep(n, ki & 3), ko - g0, ki & ~3), acc);
+                accs[(size_t)m * Nd + n] = acc;
+            }
+    }
+    for (int m = 0; m < Md; ++m)
+        for (int n = 0; n < Nd; ++n) fc.put(m, n, accs[(size_t)m * Nd + n]);
+    delete[] accs;
+#endif
+}
 
 // ---- operand functors ------------------------------------------------------------------------------------------
 // A k-step covers contraction indices ki = k0 + kq, kq = lane >> 4 in 0..3, k0 wave-uniform.  Every functor splits its
@@ -666,7 +767,7 @@ struct FxtDims { static constexpr bool fixed = true; static constexpr int kind =
 // `ws`: the slice's workspace -- the workgroup's LDS on the device when it fits (activations are written by one phase
 // and read by the next: an LDS round trip instead of an L2 one; WSAS = 3), else its row of the global arena (WSAS = 1).
 // `W`: the member's weights, staged in LDS by the caller when they fit next to the workspace (WAS = 3), else j.w.
-template <int WSAS, int WAS, class D = FxtDimsAny, bool SWZ = false>
+template <int WSAS, int WAS, class D = FxtDimsAny, int MODE = 0>
 FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int slice, const uint8_t* ascii,
                                  const uint8_t* lut, const float* labels, typename FxtMem<WSAS>::F ws,
                                  typename FxtMem<WAS>::CF W, typename FxtMem<WSAS>::F split = nullptr) {
@@ -675,6 +776,7 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
     typedef typename FxtMem<WSAS>::I WsI;
     typedef typename FxtMem<WSAS>::CI WsCI;
     typedef typename FxtMem<WAS>::CF WCF;
+    constexpr bool SWZ = MODE != 0;
     typedef typename FxtPick<SWZ, FxtConvA<WsCF>, FxtConvASwz<WsCF>>::T ConvA;
     typedef typename FxtPick<SWZ, FxtConvGradA<WsCF>, FxtConvGradASwz<WsCF>>::T ConvGradA;
     typedef typename FxtPick<SWZ, FxtConvWGradA<WsCF>, FxtConvWGradASwz<WsCF>>::T ConvWGradA;
@@ -683,7 +785,10 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
     //  so that everything derived from it below is a constant too)
     const FxtNet n = D::fixed ? fxt_net(D::kind, D::L > 0 ? D::L : j.net.L, D::A, D::F, D::H, D::K) : j.net;
     const int R = D::fixed ? D::R : j.R, L = n.L, A = n.A, F = n.F;
-    const FxtWs w = fxt_ws(n, R);
+    const FxtWs w = fxt_ws(n, R, MODE == 2);
+    // MODE 2: the conv kernels' staging buffer behind the workspace, j.split_off taps at a time (the host sized it)
+    [[maybe_unused]] WsF wbuf = ws + w.total;
+    [[maybe_unused]] const int stage_taps = j.split_off;
     const FxtLay y = fxt_lay(n, WAS == 3);      // (the LDS image of the weights has padded conv-kernel rows)
     const int ldF = w.ldF, ldw = y.ldw;
     WsI codes = (WsI)(ws + w.codes);
@@ -728,12 +833,20 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         {   // conv2 ('same', K taps)
             WCF b = W + y.cb[1];
             struct Put { WsF y; WCF b; int ld; FXT_HD void put(int m, int nn, float v) const { v += b[nn]; y[fxt_xi<SWZ>(m, nn, ld)] = v > 0.f ? v : 0.f; } };
+            if constexpr (MODE == 2)
+                fxt_gemm_staged<WSAS, WAS>(wg, R * L1, F, K, F, ConvA{a1, L1, ldF, (K - 1) / 2, dL1}, FxtConvW<WsCF>{wbuf, F, fxt_ld_w(F)}, Put{a2, b, ldF},
+                                      W + y.cw[1], wbuf, stage_taps, F, F, fxt_ld_w(F));
+            else
             fxt_gemm(wg, R * L1, F, K, F, ConvA{a1, L1, ldF, (K - 1) / 2, dL1}, FxtConvW<WCF>{W + y.cw[1], F, ldw}, Put{a2, b, ldF}, 0, split);
         }
         fxt_sync_ws<WSAS>(); FXT_STAMP(3);
         {   // conv3 ('same', A - 1 taps)
             WCF b = W + y.cb[2];
             struct Put { WsF y; WCF b; int ld; FXT_HD void put(int m, int nn, float v) const { v += b[nn]; y[fxt_xi<SWZ>(m, nn, ld)] = v > 0.f ? v : 0.f; } };
+            if constexpr (MODE == 2)
+                fxt_gemm_staged<WSAS, WAS>(wg, R * L1, F, n.K3, F, ConvA{a2, L1, ldF, (n.K3 - 1) / 2, dL1}, FxtConvW<WsCF>{wbuf, F, fxt_ld_w(F)}, Put{a3, b, ldF},
+                                      W + y.cw[2], wbuf, stage_taps, F, F, fxt_ld_w(F));
+            else
             fxt_gemm(wg, R * L1, F, n.K3, F, ConvA{a2, L1, ldF, (n.K3 - 1) / 2, dL1}, FxtConvW<WCF>{W + y.cw[2], F, ldw}, Put{a3, b, ldF}, 0, split);
         }
         fxt_sync_ws<WSAS>(); FXT_STAMP(4);
@@ -878,10 +991,18 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         const bool ag = j.agent_io != 0;
         struct PutX { WsF d; WsCF y; int ld; FXT_HD void put(int m, int nn, float v) const { d[fxt_xi<SWZ>(m, nn, ld)] = y[fxt_xi<SWZ>(m, nn, ld)] > 0.f ? v : 0.f; } };
         // conv3: input gradient (few tiles, K3 x F / 4 k-steps) first, the weight gradient dealt on behind it
+        if constexpr (MODE == 2)
+            fxt_gemm_staged<WSAS, WAS>(wg, R * L1, F, K3, F, ConvGradA{dzA, L1, ldF, (K3 - 1) / 2, dL1}, FxtConvGradW<WsCF>{wbuf, F, fxt_ld_w(F)}, PutX{dzB, a2, ldF},
+                                  W + y.cw[2], wbuf, stage_taps, F, F, fxt_ld_w(F));
+        else
         fxt_gemm(wg, R * L1, F, K3, F, ConvGradA{dzA, L1, ldF, (K3 - 1) / 2, dL1}, FxtConvGradW<WCF>{W + y.cw[2], F, ldw}, PutX{dzB, a2, ldF}, 0, split);
         fxt_gemm(wg, K3 * F + 1, F, R, L1, ConvWGradA{a2, L1, F, ldF, (K3 - 1) / 2, K3 * F, dF}, PosMajorB{dzA, L1, ldF}, PutW{part + n.off_cw[2], part + n.off_cb[2], K3 * F, F, ag}, fxt_jobs(R * L1, F, K3, F, nwv, can_split));
         fxt_sync_ws<WSAS>(); FXT_STAMP(10);
         // conv2
+        if constexpr (MODE == 2)
+            fxt_gemm_staged<WSAS, WAS>(wg, R * L1, F, K, F, ConvGradA{dzB, L1, ldF, (K - 1) / 2, dL1}, FxtConvGradW<WsCF>{wbuf, F, fxt_ld_w(F)}, PutX{dzA, a1, ldF},
+                                  W + y.cw[1], wbuf, stage_taps, F, F, fxt_ld_w(F));
+        else
         fxt_gemm(wg, R * L1, F, K, F, ConvGradA{dzB, L1, ldF, (K - 1) / 2, dL1}, FxtConvGradW<WCF>{W + y.cw[1], F, ldw}, PutX{dzA, a1, ldF}, 0, split);
         fxt_gemm(wg, K * F + 1, F, R, L1, ConvWGradA{a1, L1, F, ldF, (K - 1) / 2, K * F, dF}, PosMajorB{dzB, L1, ldF}, PutW{part + n.off_cw[1], part + n.off_cb[1], K * F, F, ag}, fxt_jobs(R * L1, F, K, F, nwv, can_split));
         fxt_sync_ws<WSAS>(); FXT_STAMP(11);

@@ -162,8 +162,10 @@ const char *fx_last_error(fx_engine *e);
  *   train_swizzle     0        fx_train_fit: 1 = CNN fits whose padded workspace misses the LDS budget while the unpadded one
  *                              fits (32 filters, kernel 5, one row per slice: 226 ... 239 positions -- GFP) store their
  *                              position-major arrays with ROTATED rows (csrc/train_core.h) instead of unpadded, 16-way
- *                              bank-conflicted ones.  Same bits (held on the CPU through the host build of the source);
- *                              prepared at the end of round 4 and not yet measured on the device: off.
+ *                              bank-conflicted ones; 2 = also the gradient array over the last conv output and the conv
+ *                              kernels staged through the LDS that frees, a group of taps at a time (no L2 round trip per
+ *                              B operand).  Same bits (held on the CPU through the host build of the source); prepared
+ *                              at the end of round 4 and not yet run on the device: off.
  *   train_persistent  0        fx_train_fit: 1 = the whole fit as ONE launch (member barriers in device memory, Adam by the
  *                              same workgroups; needs all workgroups co-resident).  Same bits, no faster: off.
  *   train_rows        0        fx_train_fit: mini-batch rows per forward+backward workgroup; 0 = automatic (depends on

@@ -51,8 +51,10 @@ static int strips(const std::vector<unsigned char>& a, const std::vector<unsigne
 // One mini-batch step.  plain_rows: the workspace's activation rows unpadded (FxtNet::ldx = F -- what the host falls back to when the
 // padded workspace misses the LDS budget); out_w: the updated weights (the two layouts must give the same bits).
 // rotated: plain rows stored rotated (train_core.h "Rotated rows", F a power of two) -- again the same bits.
+// stage_taps > 0 (with rotated): MODE 2 -- the gradient array over the last conv output and the conv kernels staged through a buffer
+// behind the workspace, that many taps at a time -- and again the same bits.
 static int train_case(int kind, int L, int A, int F, int H, int K, int rows, int R, bool plain_rows = false, std::vector<float>* out_w = nullptr,
-                      unsigned seed = 0, bool rotated = false) {
+                      unsigned seed = 0, bool rotated = false, int stage_taps = 0) {
     if (seed) rng_state = seed;
     FxtJob j{};
     j.net = fxt_net(kind, L, A, kind == 0 ? F : 0, H, kind == 0 ? K : 0);
@@ -74,10 +76,15 @@ static int train_case(int kind, int L, int A, int F, int H, int K, int rows, int
     j.w = w.data(); j.adam_m = m.data(); j.adam_v = v.data(); j.partial = partial.data(); j.order = order.data();
     j.keep = kind == 0 ? keep.data() : nullptr; j.lr_t = &lr; j.step_loss = &loss;
     j.ws_slice = fxt_ws(j.net, R).total;
+    if (stage_taps > 0) {
+        j.ws_slice = fxt_ws(j.net, R, true).total + stage_taps * j.net.F * fxt_ld_w(j.net.F);      // exact size: four arrays + the tap buffer
+        j.split_off = stage_taps;
+    }
     std::vector<float> ws((size_t)j.S * (size_t)j.ws_slice, 0.f);
     j.ws = ws.data();
     for (int s = 0; s < j.S; ++s) {
-        if (rotated) fxt_forward_backward<0, 0, FxtDimsAny, true>(j, FxtWg{0, 1}, 0, s, ascii.data(), lut.data(), labels.data(), j.ws + (long long)s * j.ws_slice, (const float*)j.w);
+        if (rotated && stage_taps > 0) fxt_forward_backward<0, 0, FxtDimsAny, 2>(j, FxtWg{0, 1}, 0, s, ascii.data(), lut.data(), labels.data(), j.ws + (long long)s * j.ws_slice, (const float*)j.w);
+        else if (rotated) fxt_forward_backward<0, 0, FxtDimsAny, 1>(j, FxtWg{0, 1}, 0, s, ascii.data(), lut.data(), labels.data(), j.ws + (long long)s * j.ws_slice, (const float*)j.w);
         else fxt_forward_backward<0, 0>(j, FxtWg{0, 1}, 0, s, ascii.data(), lut.data(), labels.data(), j.ws + (long long)s * j.ws_slice, (const float*)j.w);
     }
     fxt_step_loss(j, 0);
@@ -100,6 +107,12 @@ int main() {
             bad += train_case(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], true, &wa, 777u, false);
             bad += train_case(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], true, &wc, 777u, true);
             if (wa.size() != wc.size() || std::memcmp(wa.data(), wc.data(), wa.size() * sizeof(float)) != 0) { std::printf("rotated rows differ: L %d F %d\n", s[1], s[3]); ++bad; }
+            if (s[3] & 31) continue;                       // staged conv kernels: whole groups of eight k-steps per tap
+            for (int taps : {1, 2, 6, 64}) {               // (64: more than any kernel has -- one group)
+                std::vector<float> wd;
+                bad += train_case(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], true, &wd, 777u, true, taps);
+                if (wa.size() != wd.size() || std::memcmp(wa.data(), wd.data(), wa.size() * sizeof(float)) != 0) { std::printf("staged conv kernels differ: L %d F %d taps %d\n", s[1], s[3], taps); ++bad; }
+            }
         }
     }
     // padded and unpadded activation rows: the same step bit for bit (the padding only moves rows apart)

@@ -1,5 +1,7 @@
 """PREPARED at the end of round 4, to be run FIRST in round 5 (no GPU seconds were left to run it): rotated rows for the long protein
-CNNs' training step (engine option train_swizzle, csrc/train_core.h "Rotated rows").  Checks that a fit gives the SAME BITS with the
+CNNs' training step (engine option train_swizzle = 1, csrc/train_core.h "Rotated rows"), and = 2: on top of it the gradient array over the last conv output
+and the conv kernels of conv2 / conv3 staged through the LDS that frees, six taps at a time (fxt_gemm_staged; its DEVICE loop has only
+been compiled, never run -- the host build covers the index arithmetic and the staging layout, not the tile / barrier logic).  Checks that a fit gives the SAME BITS with the
 option on and off, then times `train` both ways.  Expected where it applies (padded workspace past the 150 KiB LDS budget but unpadded within it:
 CNN(32 filters, kernel 5) at one row per slice, L = 226 ... 239 -- GFP's 237 / 238 residues): the conv phases lose their 16-way LDS bank conflicts.  Shapes whose padded workspace fits are not touched by the
 option (same time expected: a control).  If it wins: flip the default in fx_common.h, add the bit-identity leg below to
@@ -20,7 +22,7 @@ def run(tag, make, L, alpha, n):
     seqs = synth.bytes_to_strings(synth.random_sequence_bytes(n, L, alpha, 3))
     y = np.random.default_rng(0).random(n)
     weights, times = [], []
-    for swz in (0, 1):
+    for swz in (0, 1, 2):
         eng.set_option("train_swizzle", swz)
         model = make()
         model.train(seqs, y); torch.cuda.synchronize()
@@ -31,11 +33,12 @@ def run(tag, make, L, alpha, n):
             t0 = time.perf_counter(); model.train(seqs, y); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
         times.append(min(ts) * 1e3)
     eng.set_option("train_swizzle", 0)
-    same = all(np.array_equal(a, b) for a, b in zip(weights[0], weights[1]))
-    finite = all(np.isfinite(a).all() for a in weights[1])
-    bad += (not same) or (not finite)
-    print(f"{tag} n={n}: unrotated {times[0]:.2f} ms, rotated rows {times[1]:.2f} ms; weights after the first fit "
-          f"{'IDENTICAL' if same else 'DIFFER'}{'' if finite else ' (not finite)'}", flush=True)
+    same = [all(np.array_equal(a, b) for a, b in zip(weights[0], weights[k])) for k in (1, 2)]
+    finite = all(np.isfinite(a).all() for k in (1, 2) for a in weights[k])
+    bad += (not all(same)) or (not finite)
+    print(f"{tag} n={n}: unrotated {times[0]:.2f} ms, rotated rows {times[1]:.2f} ms, + staged conv kernels {times[2]:.2f} ms; weights after "
+          f"the first fit: rotated {'IDENTICAL' if same[0] else 'DIFFER'}, staged {'IDENTICAL' if same[1] else 'DIFFER'}"
+          f"{'' if finite else ' (not finite)'}", flush=True)
 
 run("Ensemble 3xCNN L=237 A=20", lambda: flexs_amd.Ensemble([bm.CNN(237, 32, 100, s_utils.AAS, seed=m) for m in range(3)]), 237, s_utils.AAS, 500)
 run("CNN L=237 A=20", lambda: bm.CNN(237, 32, 100, s_utils.AAS, seed=0), 237, s_utils.AAS, 500)
