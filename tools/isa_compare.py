@@ -1,3 +1,8 @@
+"""Are the kernels of a translation unit unchanged, instruction for instruction, after an edit?  Compares two device assembly files
+(hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off --cuda-device-only -S file.hip -o file.s, once per source tree) function
+by function with local labels renumbered by order of appearance.  Used at the end of round 4 (no GPU time left) to add the
+rotated-row / staged training kernel beside k_train_fb / k_train_adam / k_train_fit without touching their measured code:
+    python tools/isa_compare.py /tmp/old/train.s /tmp/new/train.s"""
 import re,sys
 def funcs(path):
     out={}; cur=None; buf=[]
