@@ -7,6 +7,8 @@ the MFMA as an fmaf chain) -- index arithmetic and gradient algebra of every lay
 consecutive steps (optimiser state carried), any slicing of the mini-batch.  GPU tier: `fx_train_fit` on the device
 against the same oracle step by step, whole fits against the PyTorch path on the same shuffles, and the public
 `train` API end to end."""
+import os
+
 import numpy as np
 import pytest
 
@@ -371,3 +373,45 @@ def test_canonical_shape_instantiations_equal_the_shape_agnostic_step(kind, L, a
         assert a[3] == c[3] == epochs * steps
         for what, x, z in zip(("weights", "adam_m", "adam_v", "losses"), (a[0], a[1], a[2], a[4]), (c[0], c[1], c[2], c[4])):
             assert np.array_equal(x, z), (kind, mem, what, float(np.abs(x - z).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("FLEXS_AMD_PREPARED") != "1",
+                    reason="train_swizzle was written after round 4's GPU budget was spent: the device run of this test is round 5's first job "
+                           "(FLEXS_AMD_PREPARED=1); on the CPU the same source gives the same bits (tests/native/sanitize_host.cpp)")
+@pytest.mark.parametrize("L,n,B,M", [(237, 300, 256, 3), (238, 130, 128, 1), (230, 100, 64, 2)])
+def test_rotated_rows_and_staged_conv_kernels_equal_the_plain_step(L, n, B, M):
+    """Prepared at the end of round 4 (`train_swizzle`, default off): GFP-length CNN fits -- unpadded activation rows in LDS, every conv
+    operand fetch 16-way bank-conflicted -- with rotated rows (1) and, on top, the gradient array over the last conv output and the
+    conv kernels staged through LDS in tap groups (2).  Where a value is stored and which memory a weight is read from do not change
+    the arithmetic or its order: weights, moments, step count and losses are the SAME BITS as the plain step's, with the in-kernel
+    dropout stream, several members and a ragged last mini-batch."""
+    eng = _native.Engine.get(0)
+    kind, alphabet, F, H, K = "cnn", ref_np.AAS, 32, 100, 5
+    A, epochs = len(alphabet), 2
+    lut = _native.make_lut(alphabet)
+    shapes = _shapes(kind, L, A, F, H, K)
+    _, b, _, y = _data(kind, L, alphabet, n, 31)
+    steps = (n + B - 1) // B
+    results = []
+    for swz in (0, 1, 2):
+        eng.set_option("train_swizzle", swz)
+        try:
+            jobs = []
+            r2 = np.random.default_rng(9)
+            for mem in range(M):
+                order = np.full((epochs, steps * B), -1, np.int32)
+                for e in range(epochs):
+                    order[e, :n] = r2.permutation(n)
+                w = _flat(ref_np.synth_weights(shapes, 50 + mem))
+                jobs.append({"kind": KIND[kind], "L": L, "A": A, "F": F, "H": H, "K": K, "weights": w, "adam_m": np.zeros_like(w),
+                             "adam_v": np.zeros_like(w), "step": 0, "order": order, "epochs": epochs, "batch": B, "seed": 77 + mem})
+            res = _native.train_fit(eng, jobs, b, lut, y)
+            results.append([(j["weights"].copy(), j["adam_m"].copy(), j["adam_v"].copy(), t, np.asarray(loss).copy()) for j, (t, loss) in zip(jobs, res)])
+        finally:
+            eng.set_option("train_swizzle", 0)
+    for swz in (1, 2):
+        for mem, (a, c) in enumerate(zip(results[0], results[swz])):
+            assert a[3] == c[3] == epochs * steps
+            for what, x, z in zip(("weights", "adam_m", "adam_v", "losses"), (a[0], a[1], a[2], a[4]), (c[0], c[1], c[2], c[4])):
+                assert np.isfinite(z).all() and np.array_equal(x, z), (swz, L, mem, what, float(np.abs(x - z).max()))
