@@ -25,7 +25,12 @@
 #include <cmath>
 #include <cstdint>
 
-#if defined(__HIP_DEVICE_COMPILE__)
+// FXT_EMUL (tests/native/simt_train.cpp, host, clang++): the DEVICE branches of this file compiled for the CPU and run by one host
+// thread per GPU thread -- the MFMA as a rendezvous of a wave's 64 threads, barriers as pthread barriers, LDS as heap memory, plain
+// pointers -- so that what only exists on the device side (tile-to-wave dealing, unrolled k-step groups, accumulators kept across
+// staging barriers, the barriers themselves: ThreadSanitizer sees a missing one as a data race) is exercised without a GPU.  The
+// emulator supplies the few builtins as macros / functions before including this header.
+#if defined(__HIP_DEVICE_COMPILE__) || defined(FXT_EMUL)
 #define FXT_DEVICE 1
 #else
 #define FXT_DEVICE 0
@@ -237,7 +242,10 @@ struct FxtJob {
 // Stores / loads that are coherent across the XCDs without fences (agent scope, `sc1`): what the one-launch fit hands from
 // workgroup to workgroup -- gradient partials, updated weights -- inside a launch (see mfma_common.h fx_store16_agent for the
 // why: a release / acquire pair is a write-back + invalidate of the XCD's whole L2, ~0.5 us, serialised per XCD).
-#if FXT_DEVICE
+#if defined(FXT_EMUL)
+inline void fxt_store_agent(float* p, float v) { *p = v; }
+inline void fxt_load8_agent(const float* p, long long stride, float (&v)[8]) { for (int k = 0; k < 8; ++k) v[k] = p[k * stride]; }
+#elif FXT_DEVICE
 __device__ __forceinline__ void fxt_store_agent(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void fxt_load8_agent(const float* p, long long stride, float (&v)[8]) {   // v[k] = p[k * stride], eight in flight
     asm volatile("global_load_dword %0, %8, off sc1\n\tglobal_load_dword %1, %9, off sc1\n\tglobal_load_dword %2, %10, off sc1\n\t"
@@ -401,9 +409,15 @@ FXT_HD void fxt_gemm(const FxtWg& wg, int Md, int Nd, int Ko, int Ki, const FA& 
                         const int kk = k0 + 4 * u;
                         const bool live = kk < Ki;           // wave-uniform
                         const bool kok = kk + kq < Ki;
+#if defined(FXT_EMUL)     // (the emulator does not perform a load whose value is masked away: on the device it reads -- and drops -- a
+                          //  neighbouring array's element, which a race detector reports and an exact-size buffer cannot hold)
+                        a[u] = kok ? fa.at(sa, ko, kk) : 0.f;
+                        b[u] = kok ? fb.at(sb, ko, kk) : 0.f;
+#else
                         const float av = fa.at(sa, ko, live ? kk : 0), bv = fb.at(sb, ko, live ? kk : 0);
                         a[u] = kok ? av : 0.f;
                         b[u] = kok ? bv : 0.f;
+#endif
                     }
 #pragma unroll
                     for (int u = 0; u < U; ++u)
@@ -418,9 +432,14 @@ FXT_HD void fxt_gemm(const FxtWg& wg, int Md, int Nd, int Ko, int Ki, const FA& 
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const bool live = s + u < Ko;            // wave-uniform
+#if defined(FXT_EMUL)
+                    a[u] = (live && kin) ? fa.at(sa, s + u, 0) : 0.f;
+                    b[u] = (live && kin) ? fb.at(sb, s + u, 0) : 0.f;
+#else
                     const float av = fa.at(sa, live ? s + u : 0, 0), bv = fb.at(sb, live ? s + u : 0, 0);
                     a[u] = (live && kin) ? av : 0.f;
                     b[u] = (live && kin) ? bv : 0.f;
+#endif
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u)
@@ -436,10 +455,15 @@ FXT_HD void fxt_gemm(const FxtWg& wg, int Md, int Nd, int Ko, int Ki, const FA& 
                 for (int u = 0; u < U; ++u) {
                     const bool live = s + u < T;
                     const bool kok = live && k0 + kq < Ki;
+#if defined(FXT_EMUL)
+                    a[u] = kok ? fa.at(sa, ko, k0) : 0.f;
+                    b[u] = kok ? fb.at(sb, ko, k0) : 0.f;
+#else
                     const float av = fa.at(sa, live ? ko : 0, live ? k0 : 0);
                     const float bv = fb.at(sb, live ? ko : 0, live ? k0 : 0);
                     a[u] = kok ? av : 0.f;
                     b[u] = kok ? bv : 0.f;
+#endif
                     k0 += 4;
                     if (k0 >= Ki) { k0 = 0; ++ko; }
                 }
@@ -487,7 +511,10 @@ FXT_HD void fxt_gemm(const FxtWg& wg, int Md, int Nd, int Ko, int Ki, const FA& 
 // LDS is several times slower than ds_read (phase timeline, profiles/r3_train_trace.log: ~1.1 us per group of eight
 // k-steps with every operand in LDS).  The step is therefore compiled per placement -- workspace in LDS (3) or global
 // memory (1), weights in LDS or global memory -- with address-space-qualified pointer types; the host build has one.
-#if FXT_DEVICE
+#if defined(FXT_EMUL)
+typedef float fxt_f4 __attribute__((ext_vector_type(4), aligned(4)));   // (host memory of the emulator: no 16-byte promise)
+template <int AS> struct FxtMem { typedef float* F; typedef const float* CF; typedef int* I; typedef const int* CI; typedef const fxt_f4* CF4; };
+#elif FXT_DEVICE
 typedef float fxt_f4 __attribute__((ext_vector_type(4)));
 template <int AS> struct FxtMem {
     typedef __attribute__((address_space(AS))) float* F;

@@ -3,6 +3,8 @@
 * `tests/native/sanitize_host.cpp`: csrc/train_core.h (the training kernels' source, threads as loops), csrc/host_collect.cc (answer collection) and csrc/myers.h
   (register and strip forms of the bit-parallel Levenshtein) under  g++ -fsanitize=address,undefined  with exact-size heap
   buffers: an index past any array, a signed overflow or an invalid shift in the kernels' index arithmetic aborts the run.
+* `tests/native/simt_train.cpp`: the DEVICE branches of csrc/train_core.h under a SIMT emulator (a host thread per GPU thread) with
+  ThreadSanitizer and AddressSanitizer.
 * `csrc/strpack.c` (the CPython packing helper and its thread pool) rebuilt with the sanitizers and driven from a Python
   child process that preloads the sanitizer runtimes: bytes, error statuses, sub-ranges, several threads."""
 import os
@@ -31,6 +33,37 @@ def test_kernel_sources_under_asan_and_ubsan(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
     assert r.returncode == 0 and "sanitize_host: ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def _host_clang():
+    for cand in ("/opt/rocm/lib/llvm/bin/clang++", "/opt/rocm/llvm/bin/clang++"):
+        if os.path.exists(cand):
+            return cand
+    return None
+
+
+@pytest.mark.parametrize("sanitizer", ["thread", "address,undefined"])
+def test_device_branches_of_the_training_source_under_a_simt_emulator(tmp_path, sanitizer):
+    """tests/native/simt_train.cpp: the DEVICE branches of csrc/train_core.h (FXT_EMUL) run by one host thread per GPU thread -- the
+    MFMA as a rendezvous of a wave's 64 threads, barriers as pthread barriers, LDS as a heap array of exactly the bytes the host code
+    asks for.  Plain rows, rotated rows and the staged conv kernels (`train_swizzle` 1 / 2, written when no GPU time was left) must
+    give the gradient partials and weights of the HOST build of the same source BIT FOR BIT; under ThreadSanitizer a missing barrier
+    is a data race (checked by removing one), under AddressSanitizer an index past the workspace or the staging buffer a report."""
+    cxx = _host_clang()
+    if cxx is None:
+        pytest.skip("no host clang++ (the emulator needs ext_vector_type)")
+    exe = tmp_path / "simt_train"
+    src = [os.path.join(ROOT, "tests", "native", f) for f in ("simt_ref.cpp", "simt_train.cpp")]
+    r = subprocess.run([cxx, "-std=c++17", "-O1", "-g", "-pthread", f"-fsanitize={sanitizer}", "-fno-sanitize-recover=all", *src, "-o", str(exe)],
+                       capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr and ("unsupported" in r.stderr or "cannot find" in r.stderr):
+        pytest.skip("sanitizer runtime not available to this clang++")
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([str(exe), "quick"], capture_output=True, text=True, timeout=1500,
+                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1", ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1"))
+    if r.returncode != 0 and ("Resource temporarily unavailable" in r.stderr or "std::system_error" in r.stderr or "failed to create thread" in r.stderr):
+        pytest.skip("this environment does not let a process start a workgroup's worth of threads")
+    assert r.returncode == 0 and "simt_train: ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
 def test_string_packing_helper_under_asan_and_ubsan(tmp_path):

@@ -1,7 +1,7 @@
 """PREPARED at the end of round 4, to be run FIRST in round 5 (no GPU seconds were left to run it): rotated rows for the long protein
 CNNs' training step (engine option train_swizzle = 1, csrc/train_core.h "Rotated rows"), and = 2: on top of it the gradient array over the last conv output
-and the conv kernels of conv2 / conv3 staged through the LDS that frees, six taps at a time (fxt_gemm_staged; its DEVICE loop has only
-been compiled, never run -- the host build covers the index arithmetic and the staging layout, not the tile / barrier logic).  Checks that a fit gives the SAME BITS with the
+and the conv kernels of conv2 / conv3 staged through the LDS that frees, six taps at a time (fxt_gemm_staged; on the CPU its device
+branch runs under the SIMT emulator of tests/native/simt_train.cpp, bit-identical and race-free there -- never yet on a device).  Checks that a fit gives the SAME BITS with the
 option on and off, then times `train` both ways.  Expected where it applies (padded workspace past the 150 KiB LDS budget but unpadded within it:
 CNN(32 filters, kernel 5) at one row per slice, L = 226 ... 239 -- GFP's 237 / 238 residues): the conv phases lose their 16-way LDS bank conflicts.  Shapes whose padded workspace fits are not touched by the
 option (same time expected: a control).  If it wins: flip the default in fx_common.h, add the bit-identity leg below to
