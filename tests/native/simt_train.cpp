@@ -108,6 +108,55 @@ static std::vector<float> emul_step(const SimtProblem& p, int mode, int nthr, in
     return w;
 }
 
+// The CANONICAL instantiations (compile-time dimensions, workspace AND the padded weight image in LDS: what k_train_fb runs for the
+// BASELINE surrogates).  canon: train.hip's case numbers.  The image is laid out as the kernel's staging copy lays it out.
+static std::vector<float> emul_step_canon(const SimtProblem& p, int canon, int nthr, std::vector<float>* partials) {
+    FxtJob j{};
+    j.net = fxt_net(p.kind, p.L, p.A, p.kind == 0 ? p.F : 0, p.H, p.kind == 0 ? p.K : 0);       // (padded rows: fxt_ld_x)
+    j.batch = p.rows; j.steps_per_epoch = 1; j.total_steps = 1; j.n = p.rows; j.R = p.R; j.S = (p.rows + p.R - 1) / p.R;
+    std::vector<float> w = p.w, m((size_t)j.net.P, 0.f), v((size_t)j.net.P, 0.f), part((size_t)j.S * (j.net.P + 1), 0.f);
+    const float lr = 1e-3f;
+    float loss = 0.f;
+    j.w = w.data(); j.adam_m = m.data(); j.adam_v = v.data(); j.partial = part.data(); j.order = p.order.data();
+    j.keep = p.kind == 0 ? p.keep.data() : nullptr; j.lr_t = &lr; j.step_loss = &loss;
+    j.ws_in_lds = 1; j.w_in_lds = 1; j.canon = canon;
+    j.ws_slice = fxt_ws(j.net, p.R).total;
+    const FxtLay lay = fxt_lay(j.net, true);
+    for (int s = 0; s < j.S; ++s) {
+        std::vector<float> lds((size_t)j.ws_slice + (size_t)lay.total, 0.f);
+        float* wl = lds.data() + j.ws_slice;
+        for (int i = 0; i < j.net.P; ++i) wl[fxt_image_off(j.net, lay, i)] = w[(size_t)i];
+        const int nw = nthr / 64;
+        std::vector<WaveBox> waves((size_t)nw);
+        for (auto& wv : waves) pthread_barrier_init(&wv.bar, nullptr, 64);
+        pthread_barrier_init(&g_wg_bar, nullptr, (unsigned)nthr);
+        g_waves = waves.data();
+        std::vector<std::thread> th;
+        for (int tid = 0; tid < nthr; ++tid)
+            th.emplace_back([&, tid]() {
+                t_tid = tid;
+                const FxtWg wg{tid, nthr};
+                const uint8_t* a = p.ascii.data(); const uint8_t* l = p.lut.data(); const float* y = p.labels.data();
+                float* ws = lds.data(); const float* W = wl;
+                switch (canon) {
+                    case 1: fxt_forward_backward<3, 3, FxtDims<0, 4, 32, 100, 5, 8>>(j, wg, 0, s, a, l, y, ws, W, (float*)nullptr); break;
+                    case 2: fxt_forward_backward<3, 3, FxtDims<1, 4, 0, 100, 0, 8>>(j, wg, 0, s, a, l, y, ws, W, (float*)nullptr); break;
+                    case 3: fxt_forward_backward<3, 3, FxtDims<2, 20, 0, 100, 0, 8>>(j, wg, 0, s, a, l, y, ws, W, (float*)nullptr); break;
+                    case 4: fxt_forward_backward<3, 3, FxtDims<0, 4, 32, 100, 5, 8, 8>>(j, wg, 0, s, a, l, y, ws, W, (float*)nullptr); break;
+                    default: fxt_forward_backward<3, 3>(j, wg, 0, s, a, l, y, ws, W, (float*)nullptr);
+                }
+            });
+        for (auto& t : th) t.join();
+        for (auto& wv : waves) pthread_barrier_destroy(&wv.bar);
+        pthread_barrier_destroy(&g_wg_bar);
+    }
+    if (partials) *partials = part;
+    t_tid = 0;
+    fxt_step_loss(j, 0);
+    for (int i = 0; i < j.net.P; ++i) fxt_adam(j, 0, i);
+    return w;
+}
+
 static int same(const char* what, const std::vector<float>& a, const std::vector<float>& b, const SimtProblem& p, int mode, int nthr, int taps) {
     if (a.size() == b.size() && std::memcmp(a.data(), b.data(), a.size() * sizeof(float)) == 0) return 0;
     size_t first = 0;
@@ -153,6 +202,23 @@ int main(int argc, char** argv) {
             bad += same("gradient partials", part_ref, part, p, 2, c.nthr, taps);
             bad += same("weights", want, got, p, 2, c.nthr, taps);
         }
+    }
+    // the canonical instantiations of the BASELINE surrogates (train.hip case numbers), 8 rows per slice, a ragged last slice
+    struct Canon { int canon, kind, L, A, F, H, K, rows, nthr; };
+    std::vector<Canon> canons = {{4, 0, 8, 4, 32, 100, 5, 11, 256}, {2, 1, 14, 4, 0, 100, 0, 9, 256}};
+    if (!quick) {
+        canons.push_back({1, 0, 10, 4, 32, 100, 5, 8, 512});
+        canons.push_back({3, 2, 25, 20, 0, 100, 0, 13, 256});
+        canons.push_back({0, 0, 8, 4, 32, 100, 5, 11, 1024});      // the shape-agnostic code over the same LDS image, 16 waves
+    }
+    for (const Canon& c : canons) {
+        const int P = simt_ref_params(c.kind, c.L, c.A, c.F, c.H, c.K);
+        const SimtProblem p = simt_problem(c.kind, c.L, c.A, c.F, c.H, c.K, c.rows, 8, P, 2000u + (unsigned)c.L);
+        std::vector<float> part_ref, part;
+        const std::vector<float> want = simt_ref_step(p, &part_ref);
+        const std::vector<float> got = emul_step_canon(p, c.canon, c.nthr, &part);
+        bad += same("gradient partials (canonical)", part_ref, part, p, 10 + c.canon, c.nthr, 0);
+        bad += same("weights (canonical)", want, got, p, 10 + c.canon, c.nthr, 0);
     }
     if (bad) { std::printf("simt_train: %d FAILED\n", bad); return 1; }
     std::printf("simt_train: ok\n");
