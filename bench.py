@@ -585,6 +585,29 @@ def member_parallel_block(world, rank, device, torch, dist, use_dist, steps_hint
                    "(one_gpu_reference_source); ideal = 8 / members_per_rank")
     return out
 
+def prepared_block(timeout_s=90.0):
+    """An A/B of kernel forms that were written after round 4's GPU budget was spent (csrc/OPTIONS.md `train_swizzle`: rotated LDS rows
+    and staged conv kernels for GFP-length CNN fits; DEFAULT OFF, bit-identical on the CPU under the SIMT emulator) -- measured here
+    because this run is the first time they meet a device.  In a CHILD process with a time limit: whatever happens to it, the
+    contract line above is already measured and is printed; the child's answer (or what went wrong) goes into
+    roofline.per_config.  Not part of `value`.  FLEXS_AMD_BENCH_PREPARED=0 skips it."""
+    import subprocess
+
+    if os.environ.get("FLEXS_AMD_BENCH_PREPARED", "1") == "0":
+        return {"skipped": "FLEXS_AMD_BENCH_PREPARED=0"}
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "runs", "r5_train_swizzle_ab.py"), "--json"], cwd=ROOT,
+                           capture_output=True, text=True, timeout=timeout_s)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": f"child exit {r.returncode}", "stderr_tail": r.stderr[-300:]}
+        return json.loads(lines[-1])
+    except subprocess.TimeoutExpired:
+        return {"error": f"no answer within {timeout_s:.0f} s (child stopped)"}
+    except Exception as ex:  # noqa: BLE001 -- an experiment must not cost the record
+        return {"error": f"{type(ex).__name__}: {ex}"}
+
+
 def _sig(x, digits=4):
     return None if x is None else float(f"{float(x):.{digits}g}")
 
@@ -613,6 +636,8 @@ def compact_record(out):
     for k in ("C1 resident", "C2@1e4 resident"):
         if k in confs:
             per[k] = confs[k]
+    if out.get("prepared_train_swizzle"):
+        per["train GFP-length CNN, train_swizzle 0/1/2 (prepared forms, default off)"] = out["prepared_train_swizzle"]
     if len(per) > 1:
         roof["per_config"] = per
     path = {}
@@ -875,6 +900,8 @@ def main():
             out["explorer_patterns"] = explorer_patterns_block(local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nam=args.cpu_nam)
+        if world == 1 and not args.no_extras:
+            out["prepared_train_swizzle"] = prepared_block()
         compact_record(out)
         if saved_stdout is not None:
             sys.stdout.flush()

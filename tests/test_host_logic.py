@@ -943,9 +943,16 @@ def test_bench_compact_record_carries_every_config():
     spec.loader.exec_module(bench)
     line = json.load(open(os.path.join(root, "profiles", "r3_run4_bench_driver.json")))
     line["explorer_patterns"] = {"dynappo_8xGE_L90_us": {"4": 12.0, "10": 12.5}, "cmaes_3xCNN_L237_us": {"P=15": 80.0, "P=40": 90.0, "N=1 get_fitness": 40.0}}
+    line["prepared_train_swizzle"] = {"Ensemble 3xCNN L=237 A=20 n=500": {"ms_per_fit": {"plain": 44.0, "rotated_rows": 30.0, "staged_conv_kernels": 25.0},
+                                                                           "same_bits_as_plain": {"rotated_rows": True, "staged_conv_kernels": True}}}
     out = bench.compact_record(line)
     json.loads(json.dumps(out))
     per = out["roofline"]["per_config"]
+    assert per["train GFP-length CNN, train_swizzle 0/1/2 (prepared forms, default off)"] == line["prepared_train_swizzle"]
+    # the child that measures them: whatever goes wrong in it is a field of the record, never an exception (here: no GPU)
+    got = bench.prepared_block(timeout_s=120.0)
+    assert isinstance(got, dict) and ("error" in got or "skipped" in got or any("ms_per_fit" in v for v in got.values() if isinstance(v, dict)))
+    json.dumps(got)
     for name in ("C2 3xCNN L8 N1e5 (headline)", "C1 1xCNN L8 N1e4", "C2 3xCNN L8 N1e4", "C3 MLP L14 N1e5", "C4 8xGE L90 N1e5", "C5 3xCNN L237 N62500"):
         assert set(per[name]) == {"kernel_ms", "frac", "frac_issued"} and 0 < per[name]["frac_issued"] <= 1.0, name
     assert per["C1 1xCNN L8 N1e4"]["kernel_ms"] == pytest.approx(line["configs"]["C1 cnn L=8 A=4 M=1 N=1e4"]["kernel_ms"], rel=1e-3)

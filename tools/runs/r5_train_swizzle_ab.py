@@ -16,6 +16,8 @@ from flexs_amd.baselines import models as bm
 from flexs_amd.utils import sequence_utils as s_utils
 eng = _native.Engine.get()
 bad = 0
+AS_JSON = "--json" in sys.argv          # bench.py's child: two shapes, one JSON line {shape: {ms: {...}, same_bits: {...}}}
+report = {}
 
 def run(tag, make, L, alpha, n):
     global bad
@@ -25,7 +27,7 @@ def run(tag, make, L, alpha, n):
     for swz in (0, 1, 2):
         eng.set_option("train_swizzle", swz)
         model = make()
-        model.train(seqs, y); torch.cuda.synchronize()
+        model.train(seqs, y, seed=5); torch.cuda.synchronize()      # (seeded: the same shuffles and dropout masks in every leg)
         members = model.models if hasattr(model, "models") else [model]
         weights.append([np.concatenate([np.asarray(w, np.float32).ravel() for w in m.model.get_weights()]) for m in members])
         ts = []
@@ -36,11 +38,20 @@ def run(tag, make, L, alpha, n):
     same = [all(np.array_equal(a, b) for a, b in zip(weights[0], weights[k])) for k in (1, 2)]
     finite = all(np.isfinite(a).all() for k in (1, 2) for a in weights[k])
     bad += (not all(same)) or (not finite)
+    report[f"{tag} n={n}"] = {"ms_per_fit": {"plain": round(times[0], 3), "rotated_rows": round(times[1], 3), "staged_conv_kernels": round(times[2], 3)},
+                              "same_bits_as_plain": {"rotated_rows": bool(same[0]), "staged_conv_kernels": bool(same[1])}, "finite": bool(finite)}
+    if AS_JSON:
+        return
     print(f"{tag} n={n}: unrotated {times[0]:.2f} ms, rotated rows {times[1]:.2f} ms, + staged conv kernels {times[2]:.2f} ms; weights after "
           f"the first fit: rotated {'IDENTICAL' if same[0] else 'DIFFER'}, staged {'IDENTICAL' if same[1] else 'DIFFER'}"
           f"{'' if finite else ' (not finite)'}", flush=True)
 
 run("Ensemble 3xCNN L=237 A=20", lambda: flexs_amd.Ensemble([bm.CNN(237, 32, 100, s_utils.AAS, seed=m) for m in range(3)]), 237, s_utils.AAS, 500)
+if AS_JSON:
+    import json
+    run("CNN L=238 A=20 (GFP + 1)", lambda: bm.CNN(238, 32, 100, s_utils.AAS, seed=0), 238, s_utils.AAS, 300)
+    print(json.dumps(report), flush=True)
+    sys.exit(0)
 run("CNN L=237 A=20", lambda: bm.CNN(237, 32, 100, s_utils.AAS, seed=0), 237, s_utils.AAS, 500)
 run("CNN L=238 A=20 (GFP + 1)", lambda: bm.CNN(238, 32, 100, s_utils.AAS, seed=0), 238, s_utils.AAS, 300)
 run("CNN L=230 A=20", lambda: bm.CNN(230, 32, 100, s_utils.AAS, seed=0), 230, s_utils.AAS, 500)
