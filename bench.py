@@ -602,8 +602,16 @@ def prepared_block(timeout_s=90.0):
         if r.returncode != 0 or not lines:
             return {"error": f"child exit {r.returncode}", "stderr_tail": r.stderr[-300:]}
         return json.loads(lines[-1])
-    except subprocess.TimeoutExpired:
-        return {"error": f"no answer within {timeout_s:.0f} s (child stopped)"}
+    except subprocess.TimeoutExpired as ex:
+        got = {"error": f"not finished within {timeout_s:.0f} s (child stopped); what it had reported until then is kept"}
+        try:
+            text = ex.stdout.decode() if isinstance(ex.stdout, bytes) else (ex.stdout or "")
+            lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+            if lines:
+                got.update(json.loads(lines[-1]))
+        except Exception:  # noqa: BLE001
+            pass
+        return got
     except Exception as ex:  # noqa: BLE001 -- an experiment must not cost the record
         return {"error": f"{type(ex).__name__}: {ex}"}
 
