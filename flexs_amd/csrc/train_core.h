@@ -878,6 +878,45 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         }
         fxt_sync_ws<WSAS>(); FXT_STAMP(4);
         WsF g = ws + w.g; WsF cnt = ws + w.cnt;
+        bool pooled = false;
+        if constexpr (MODE != 0) {
+            // The long sequences these modes serve run ONE row per slice: a thread per (row, channel) leaves 32 of 1024 threads with two
+            // dependent walks over 233 positions (~20 us of a step).  Here every (row, channel) is shared by FXT_POOL_PARTS threads,
+            // position t to thread t mod PARTS; partial maxima and tie counts meet in the (still unused) gradient array dzB.  A maximum
+            // and an integer count do not depend on the order they are taken in; the one order-dependent case of the walk below -- a NaN
+            // in position 0 stays, a NaN elsewhere is skipped -- is kept: the same bits.
+            constexpr int PARTS = 32;
+            if (L1 >= 2 * PARTS) {
+                pooled = true;
+                WsF pmax = ws + w.dzB; WsF pcnt = pmax + R * F * PARTS;        // (2 R F PARTS <= R L1 F floats)
+                FXT_FOR(i, R * F * PARTS, wg) {
+                    const int part = i % PARTS, rf = i / PARTS, r = rf / F, f = rf - r * F;
+                    float mx = -INFINITY;
+                    for (int t = part; t < L1; t += PARTS) { const float v = a3[fxt_xi<SWZ>(r * L1 + t, f, ldF)]; mx = v > mx ? v : mx; }
+                    pmax[i] = mx;
+                }
+                fxt_sync_ws<WSAS>();
+                FXT_FOR(i, R * F * PARTS, wg) {
+                    const int part = i % PARTS, rf = i / PARTS, r = rf / F, f = rf - r * F;
+                    float mx = pmax[rf * PARTS];
+                    for (int q = 1; q < PARTS; ++q) { const float v = pmax[rf * PARTS + q]; mx = v > mx ? v : mx; }
+                    const float first = a3[fxt_xi<SWZ>(r * L1, f, ldF)];
+                    if (first != first) mx = first;
+                    int c = 0;
+                    for (int t = part; t < L1; t += PARTS) c += a3[fxt_xi<SWZ>(r * L1 + t, f, ldF)] == mx;
+                    pcnt[i] = (float)c;
+                    if (part == 0) g[r * ldF + f] = mx;
+                }
+                fxt_sync_ws<WSAS>();
+                FXT_FOR(i, R * F, wg) {
+                    const int r = i / F, f = i - r * F;
+                    float c = 0.f;
+                    for (int q = 0; q < PARTS; ++q) c += pcnt[i * PARTS + q];      // (small integers: exact in any order)
+                    cnt[r * ldF + f] = c;
+                }
+            }
+        }
+        if (!pooled)
         FXT_FOR(i, R * F, wg) {             // GlobalMaxPooling1D + the number of positions that attain the maximum
             const int r = i / F, f = i - r * F;
             float mx = a3[fxt_xi<SWZ>(r * L1, f, ldF)];

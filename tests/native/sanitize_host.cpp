@@ -101,7 +101,8 @@ int main() {
         {1, 14, 4, 0, 100, 0, 48, 16}, {1, 5, 20, 0, 9, 0, 5, 3}, {1, 1, 2, 0, 1, 0, 1, 1}, {2, 30, 20, 0, 100, 0, 33, 8}, {2, 9, 4, 0, 20, 0, 37, 64}};
     for (const auto& s : shapes) bad += train_case(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7]);
     {   // rotated rows on the shapes they are meant for: a 20-letter alphabet, ONE row per slice (long sequences), 32 / 64 / 16 filters
-        const int rot[][8] = {{0, 41, 20, 32, 100, 5, 5, 1}, {0, 23, 20, 64, 9, 4, 3, 1}, {0, 19, 20, 16, 12, 3, 9, 2}, {0, 37, 6, 32, 7, 6, 4, 3}};
+        const int rot[][8] = {{0, 41, 20, 32, 100, 5, 5, 1}, {0, 23, 20, 64, 9, 4, 3, 1}, {0, 19, 20, 16, 12, 3, 9, 2}, {0, 37, 6, 32, 7, 6, 4, 3},
+                              {0, 70, 4, 32, 16, 5, 2, 1}, {0, 69, 6, 64, 5, 6, 1, 1}};      // (>= 64 positions: the max-pool shared by 32 threads per channel)
         for (const auto& s : rot) {
             std::vector<float> wa, wc;
             bad += train_case(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], true, &wa, 777u, false);

@@ -176,6 +176,7 @@ int main(int argc, char** argv) {
         {0, 12, 4, 32, 100, 5, 10, 5, 256},      // several rows per slice, 4 letters (conv3 has 3 taps), a ragged last slice
         {1, 9, 4, 0, 20, 0, 19, 8, 128},         // MLP: dense layers only, one-hot weight gradient
         {2, 14, 20, 0, 24, 0, 7, 4, 64},         // GlobalEpistasis on one wave
+        {0, 68, 4, 32, 20, 5, 1, 1, 512},        // 64 positions: the rotated modes' max-pool shared by 32 threads per channel; 4 x 2 conv tiles on 8 waves
     };
     if (!quick) {
         cases.push_back({0, 70, 20, 32, 100, 5, 1, 1, 512});     // 5 x 2 conv tiles on 8 waves
