@@ -843,6 +843,15 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         ws[w.ylab + r] = labels[valid ? order[slot] : 0];
         ws[w.yvalid + r] = valid ? 1.f : 0.f;
     }
+    // MODE 2: conv1's kernel and bias (K A rows of F floats + F: contiguous in Keras order) into the staging buffer as well, under the
+    // same barrier -- conv1 is K gathered kernel rows per output, from L2 otherwise (~7 dependent round trips per thread at one row per slice)
+    [[maybe_unused]] bool conv1_staged = false;
+    if constexpr (MODE == 2) {
+        if (n.kind == 0 && (n.K * A + 1) * F <= stage_taps * F * fxt_ld_w(F)) {
+            conv1_staged = true;
+            FXT_FOR(i, (n.K * A + 1) * F, wg) wbuf[i] = W[y.cw[0] + i];
+        }
+    }
     fxt_sync_ws<WSAS>(); FXT_STAMP(1);
 
     WsCF feat = nullptr;            // input of the dense stack when it is not the one-hot
@@ -850,6 +859,17 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         const int L1 = n.L1, K = n.K;
         WsF a1 = ws + w.a[0]; WsF a2 = ws + w.a[1]; WsF a3 = ws + w.a[2];
         // conv1 ('valid') on a one-hot input: a sum of K kernel rows
+        if constexpr (MODE == 2) {
+            if (conv1_staged) {
+                FXT_FOR(i, R * L1 * F, wg) {
+                    const int o = i % F, rt = i / F, t = rt % L1, r = rt / L1;
+                    float s = wbuf[K * A * F + o];
+                    for (int jj = 0; jj < K; ++jj) s += wbuf[(jj * A + codes[r * L + t + jj]) * F + o];
+                    a1[fxt_xi<SWZ>(rt, o, ldF)] = s > 0.f ? s : 0.f;
+                }
+            }
+        }
+        if (MODE != 2 || !conv1_staged)
         FXT_FOR(i, R * L1 * F, wg) {
             const int o = i % F, rt = i / F, t = rt % L1, r = rt / L1;
             float s = W[y.cb[0] + o];
