@@ -86,6 +86,17 @@ __global__ void __launch_bounds__(FB_MAX_THREADS) k_train_fb_swz(const FxtJob* _
         fxt_forward_backward<3, 1, FxtDimsAny, 1>(j, wg, step, (int)blockIdx.x, ascii, lut, labels, (FxtMem<3>::F)fxt_smem, (FxtMem<1>::CF)j.w, (FxtMem<3>::F) nullptr);
 }
 
+// Round 5: the F = 32 protein CNNs (train_core.h "MODE 3": paired tiles over conflict-free rotated kernel rows, register-prefetched
+// staging, sliding-window weight gradient).  FxtJob::canon = -3; again a kernel of its own (its register budget is its own).
+__global__ void __launch_bounds__(FB_MAX_THREADS) k_train_fb_c32(const FxtJob* __restrict__ jobs, int step, const uint8_t* __restrict__ ascii,
+                                                             const uint8_t* __restrict__ lut, const float* __restrict__ labels) {
+    extern __shared__ __attribute__((aligned(16))) float fxt_smem[];
+    const FxtJob& j = jobs[blockIdx.y];
+    if (step >= j.total_steps || (int)blockIdx.x >= j.S) return;
+    const FxtWg wg{(int)threadIdx.x, (int)blockDim.x};
+    fxt_forward_backward<3, 1, FxtDimsAny, 3>(j, wg, step, (int)blockIdx.x, ascii, lut, labels, (FxtMem<3>::F)fxt_smem, (FxtMem<1>::CF)j.w, (FxtMem<3>::F) nullptr);
+}
+
 __global__ void __launch_bounds__(256) k_train_adam(const FxtJob* __restrict__ jobs, int step) {
     const FxtJob& j = jobs[blockIdx.y];
     if (step >= j.total_steps) return;
@@ -228,8 +239,9 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
     std::vector<FxtJob> hj((size_t)M);
     std::vector<std::vector<float>> lr((size_t)M);
     int max_steps = 0, max_S = 0, max_P = 0;
-    int n_swz = 0, n_stage = 0;                            // members eligible for rotated rows / staged conv kernels: used when ALL of the fit's members are
-    std::vector<int> stage_taps((size_t)M, 0);
+    int n_swz = 0, n_stage = 0, n_c32 = 0;                 // members eligible for rotated rows / staged conv kernels / the F = 32 form: used when ALL of the fit's members are
+    std::vector<int> stage_taps((size_t)M, 0), c32_taps((size_t)M, 0);
+    std::vector<FxtNet> c32_net((size_t)M);
     size_t lds_bytes = 0;
     for (int m = 0; m < M; ++m) {
         fx_fit_job& u = jobs[m];
@@ -284,6 +296,18 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
             stage_taps[(size_t)m] = taps;
             if (e->train_swizzle >= 2 && taps >= 1) n_stage += 1;
         }
+        // round 5, train_swizzle = 3: ANY CNN with 32 filters whose weights miss LDS (the 20-letter alphabets: 165 KiB) and whose
+        // slice has at most 16 M tiles (R L1 <= 256) -- four rotated position-major arrays + at least one 4 KiB tap of staging in LDS;
+        // reaches the sequences whose five-array layout misses the budget (L = 240 ... 260 at one row per slice) as well
+        if (e->train_swizzle >= 3 && e->train_lds >= 1 && j.net.kind == 0 && j.net.F == 32 && !j.w_in_lds && j.net.K <= 4 * FXT_WG32_MAXT && j.net.K3 <= 4 * FXT_WG32_MAXT &&
+            j.net.K3 >= 1 && fxt_conv32_ok(j.R * j.net.L1, j.net.F, FB_MAX_THREADS / 64)) {
+            FxtNet rot = j.net;
+            rot.ldx = rot.F;
+            const size_t ws3 = (size_t)fxt_ws(rot, j.R, true).total;
+            const int kmax = std::max(rot.K, rot.K3);
+            const int taps = ws3 * 4 + 4096 <= FB_LDS_BUDGET ? (int)std::min<size_t>(std::min<size_t>((FB_LDS_BUDGET / 4 - ws3) / 1024, (size_t)kmax), (size_t)8) : 0;
+            if (taps >= 1) { n_c32 += 1; c32_taps[(size_t)m] = taps; c32_net[(size_t)m] = rot; }
+        }
         max_steps = std::max(max_steps, j.total_steps);
         max_S = std::max(max_S, j.S);
         max_P = std::max(max_P, j.net.P);
@@ -295,9 +319,21 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
     }
     int threads = (int)e->train_threads;
     threads = threads >= 1024 ? 1024 : (threads >= 512 ? 512 : (threads >= 256 ? 256 : 1024));
-    const bool any_swz = n_swz == M;
-    const bool staged = any_swz && n_stage == M && threads == FB_MAX_THREADS;     // (fxt_staged_ok was asked for 16 waves)
-    if (any_swz) {
+    const bool c32 = n_c32 == M && threads == FB_MAX_THREADS;
+    const bool any_swz = c32 || n_swz == M;
+    const bool staged = !c32 && any_swz && n_stage == M && threads == FB_MAX_THREADS;     // (fxt_staged_ok was asked for 16 waves)
+    if (c32) {
+        lds_bytes = 0;                                         // (the layouts sized above are not the ones these members run)
+        for (int m = 0; m < M; ++m) {
+            FxtJob& j = hj[(size_t)m];
+            j.net = c32_net[(size_t)m];
+            j.canon = -3;
+            j.ws_in_lds = 1; j.w_in_lds = 0;
+            j.split_off = c32_taps[(size_t)m];
+            j.ws_slice = fxt_ws(j.net, j.R, true).total + c32_taps[(size_t)m] * 1024;
+            lds_bytes = std::max(lds_bytes, (size_t)j.ws_slice * 4);
+        }
+    } else if (any_swz) {
         for (int m = 0; m < M; ++m) {
             FxtJob& j = hj[(size_t)m];
             j.canon = staged ? -2 : -1;
@@ -449,6 +485,7 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
         static bool attr_swz[64] = {};
         if (any_swz && !attr_swz[e->device & 63]) {
             FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_fb_swz), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS_BUDGET));
+            FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_fb_c32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS_BUDGET));
             attr_swz[e->device & 63] = true;
         }
     }
@@ -459,7 +496,8 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
         FX_HIP(e, hipMemcpyAsync(&h_abort, &d_bar->abort, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     } else {
         for (int s = 0; s < max_steps; ++s) {
-            if (any_swz) hipLaunchKernelGGL(k_train_fb_swz, grid_fb, dim3((unsigned)threads), lds_bytes, st, d_jobs, s, d_ascii, d_lut, d_labels);
+            if (c32) hipLaunchKernelGGL(k_train_fb_c32, grid_fb, dim3((unsigned)threads), lds_bytes, st, d_jobs, s, d_ascii, d_lut, d_labels);
+            else if (any_swz) hipLaunchKernelGGL(k_train_fb_swz, grid_fb, dim3((unsigned)threads), lds_bytes, st, d_jobs, s, d_ascii, d_lut, d_labels);
             else hipLaunchKernelGGL(k_train_fb, grid_fb, dim3((unsigned)threads), lds_bytes, st, d_jobs, s, d_ascii, d_lut, d_labels);
             hipLaunchKernelGGL(k_train_adam, grid_adam, dim3(256), 0, st, d_jobs, s);
         }

@@ -86,7 +86,8 @@ template <bool SWZ>
 FXT_HD int fxt_xi(int row, int c, int ld) { return row * ld + (SWZ ? ((c + 2 * row) & (ld - 1)) : c); }
 template <bool SWZ, class A, class B> struct FxtPick { typedef A T; };
 template <class A, class B> struct FxtPick<true, A, B> { typedef B T; };
-// MODE of fxt_forward_backward: 0 = rows as they are (padded or not), 1 = rotated rows, 2 = rotated rows + the gradient array dzA
+// MODE of fxt_forward_backward: 3 = MODE 2 with the F = 32 conv products of "MODE 3" below (paired tiles over conflict-free rotated
+// kernel rows, register-prefetched staging, sliding-window weight gradient); 0 = rows as they are (padded or not), 1 = rotated rows, 2 = rotated rows + the gradient array dzA
 // over a[2] (fxt_ws alias_dz) + the conv kernels of conv2 / conv3 STAGED through the LDS that frees, a group of taps at a time
 // (fxt_gemm_staged): with 165 KiB of weights in global memory every B operand of the protein CNNs' conv products is an L2 round
 // trip, eight in flight per wave; staged, a tap's 32 x 32 block is fetched once per workgroup and product instead of once per
@@ -618,6 +619,208 @@ FXT_HD void fxt_gemm_staged(const FxtWg& wg, int Md, int Nd, int Ko, int Ki, con
 #endif
 }
 
+// ---- MODE 3 (round 5): the conv products of the long protein CNNs, F = 32 filters ---------------------------------------------
+// Measured in round 5's first session (profiles/r5_train_gfp_*): the staged form (MODE 2) runs conv3 forward at 0.36 and its
+// backward at 0.30 of the f32-MFMA rate -- one A and one B ds_read (the B one 2-way conflicted: rows F + 4 apart) and ~10 address
+// instructions per MFMA, the staging copy's L2 round trip exposed between two barriers per tap group, and the weight gradient
+// (78 tiles x 59 k-steps) fetching both operands per MFMA through the heaviest index functors.  Three changes, same bits:
+//   * fxt_conv32_staged: a wave owns a 16-row M tile and BOTH 16-column N tiles (F = 32): one A fetch feeds two MFMAs.  The tap
+//     group's kernels are kept in LDS with 32-float rows, rotated so that the fetch is conflict-free WITHOUT padding -- forward:
+//     element (c, n) at column (n + 16 c) mod 32, transposed read of the input gradient: element (c, o) at column (o + 2 c) mod 32
+//     (a product stages its own copy, so each picks its rotation) -- seven taps per group instead of six in the same bytes; the
+//     next group's rows are fetched from L2 into registers BEFORE the current group's MFMAs and stored behind them;
+//   * fxt_conv32_wgrad: dW[j][c][o] = sum_t x[t + j - pl][c] dz[t][o].  Taps j and j + 4 read the same x k-step blocks one k-step
+//     apart, so a wave owns taps {res, res + 4, ...} x 16 channels x 16 out channels (16 jobs = 4 residues x 2 x 2): per k-step ONE
+//     new x block and ONE dz block from LDS feed up to five MFMAs out of a register window.  The bias row rides on the residue-3
+//     waves (four taps of conv3's nineteen).
+// Every output element still sums the same products in the same order through the same instruction: the SAME BITS as fxt_gemm.
+template <class P>
+struct FxtConvW32 {            // forward B((j, c), n) from the staging buffer: element (j, c, n) at (j 32 + c) 32 + (n + 16 c) mod 32
+    P w;
+    FXT_HD int prep(int n, int kq) const { return kq * 32 + ((n + 16 * kq) & 31); }
+    FXT_HD float at(int st, int j, int k0) const { return w[st + (j * 32 + k0) * 32]; }     // (k0 is a multiple of 4: 16 k0 = 0 mod 32)
+};
+template <class P>
+struct FxtConvGradW32 {        // input-gradient B((j, o), n = c) = W[j][c][o]: element (j, c, o) at (j 32 + c) 32 + (o + 2 c) mod 32
+    P w;
+    struct St { int base, rot; };
+    FXT_HD St prep(int n, int kq) const { return St{n * 32, (kq + 2 * n) & 31}; }
+    FXT_HD float at(St s, int j, int k0) const { return w[s.base + j * 1024 + ((s.rot + k0) & 31)]; }
+};
+FXT_HD bool fxt_conv32_ok(int Md, int F, int nw) { return F == 32 && ((Md + 15) >> 4) <= nw; }
+// ROT: 0 = forward rotation (16 c), 1 = input-gradient rotation (2 c).  `G` taps per group (the host sized wbuf for G x 1024 floats).
+template <int WSAS, int WAS, int ROT, class FA, class FB, class FC>
+FXT_HD void fxt_conv32_staged(const FxtWg& wg, int Md, int Ko, const FA& fa, const FB& fb, const FC& fc,
+                              typename FxtMem<WAS>::CF wsrc, typename FxtMem<WSAS>::F wbuf, int G) {
+    if (G < 1) G = 1;
+    if (G > Ko) G = Ko;
+#if FXT_DEVICE
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    constexpr int U = 8, PF = 2;                           // PF 16-byte pieces per thread in flight: 8 taps at 1024 threads
+    {   const int gmax = PF * wg.nthr / 256;               // (a narrower workgroup -- the emulator's -- takes smaller groups)
+        if (G > gmax) G = gmax < 1 ? 1 : gmax; }
+    const int lane = wg.tid & 63, wave = wg.tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int tm = (Md + 15) >> 4;
+    const bool have = wave < tm;                           // (wave-uniform; fxt_conv32_ok: every M tile has its wave)
+    const int m = wave * 16 + i;
+    const auto sa = fa.prep((have && m < Md) ? m : 0, kq);
+    const auto sb0 = fb.prep(i, kq), sb1 = fb.prep(i + 16, kq);
+    f4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    f4_t pre[PF];
+    auto fetch = [&](int g0, int g1) {
+        const int pieces = (g1 - g0) * 256;
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int p = wg.tid + q * wg.nthr;
+            if (p < pieces) pre[q] = *(typename FxtMem<WAS>::CF4)(wsrc + ((g0 * 32 + (p >> 3)) * 32 + 4 * (p & 7)));
+        }
+    };
+    auto store = [&](int g0, int g1) {
+        const int pieces = (g1 - g0) * 256;
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int p = wg.tid + q * wg.nthr;
+            if (p < pieces) {
+                const int row = p >> 3, col = 4 * (p & 7), rot = ROT ? 2 * row : 16 * row;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wbuf[row * 32 + ((col + e + rot) & 31)] = pre[q][e];
+            }
+        }
+    };
+    fetch(0, G);
+    for (int g0 = 0; g0 < Ko; g0 += G) {
+        const int g1 = g0 + G < Ko ? g0 + G : Ko;
+        fxt_sync_ws<WSAS>();                               // everybody is through with the previous group's taps (or the previous phase)
+        store(g0, g1);
+        if (g1 < Ko) fetch(g1, g1 + G < Ko ? g1 + G : Ko); // in flight behind this group's MFMAs
+        fxt_sync_ws<WSAS>();
+        if (!have) continue;
+        for (int ko = g0; ko < g1; ++ko) {
+            float a[U], b0[U], b1[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { a[u] = fa.at(sa, ko, 4 * u); b0[u] = fb.at(sb0, ko - g0, 4 * u); b1[u] = fb.at(sb1, ko - g0, 4 * u); }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b0[u], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b1[u], acc1, 0, 0, 0);
+            }
+        }
+    }
+    if (have) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int mr = wave * 16 + 4 * kq + r;
+            if (mr < Md) { fc.put(mr, i, acc0[r]); fc.put(mr, i + 16, acc1[r]); }
+        }
+    }
+#else
+    (void)wg;
+    float* accs = new float[(size_t)Md * 32]();
+    for (int g0 = 0; g0 < Ko; g0 += G) {
+        const int g1 = g0 + G < Ko ? g0 + G : Ko;
+        for (int row = 0; row < (g1 - g0) * 32; ++row)
+            for (int c = 0; c < 32; ++c) wbuf[row * 32 + ((c + (ROT ? 2 * row : 16 * row)) & 31)] = wsrc[(g0 * 32 + row) * 32 + c];
+        for (int m = 0; m < Md; ++m)
+            for (int n = 0; n < 32; ++n) {
+                float acc = accs[(size_t)m * 32 + n];
+                for (int ko = g0; ko < g1; ++ko)
+                    for (int ki = 0; ki < 32; ++ki)
+                        acc = fmaf(fa.at(fa.prep(m, ki & 3), ko, ki & ~3), fb.at(fb.prep(n, ki & 3), ko - g0, ki & ~3), acc);
+                accs[(size_t)m * 32 + n] = acc;
+            }
+    }
+    for (int m = 0; m < Md; ++m)
+        for (int n = 0; n < 32; ++n) fc.put(m, n, accs[(size_t)m * 32 + n]);
+    delete[] accs;
+#endif
+}
+
+// Conv weight gradient of a 32 -> 32 channel layer over ROTATED rows (see above): x, dz position-major arrays of R x L1 rows,
+// fc.put(row (j 32 + c, or Kt 32 for the bias), column o, value).  Kt <= 20 taps.
+#define FXT_WG32_MAXT 5
+template <class P, class FC>
+FXT_HD void fxt_conv32_wgrad(const FxtWg& wg, int R, int L1, int Kt, int pl, P x, P dz, const FC& fc) {
+#if FXT_DEVICE
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    constexpr int MT = FXT_WG32_MAXT;
+    const int lane = wg.tid & 63, nw = wg.nthr >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int S = (L1 + 3) >> 2;                           // k-steps of a row
+    for (int job = wg.tid >> 6; job < 16; job += nw) {     // (sixteen waves: one job each)
+        const int res = job >> 2, ct = (job >> 1) & 1, ot = job & 1;
+        const int NT = Kt > res ? (Kt - res + 3) >> 2 : 0; // taps res, res + 4, ... of this job (wave-uniform)
+        const bool bias = res == 3 && ct == 0;
+        if (NT == 0 && !bias) continue;
+        const int c = ct * 16 + i, o = ot * 16 + i;
+        f4_t acc[MT], accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < MT; ++q) acc[q] = f4_t{0.f, 0.f, 0.f, 0.f};
+        for (int rho = 0; rho < R; ++rho) {
+            const int base = rho * L1;
+            // x block b: position 4 b + kq + res - pl of the row, channel c (zero outside the row)
+            auto X = [&](int b) {
+                const int pp = 4 * b + kq + res - pl;
+                const bool ok = pp >= 0 && pp < L1;
+#if defined(FXT_EMUL)
+                return ok ? x[fxt_xi<true>(base + pp, c, 32)] : 0.f;
+#else
+                const float v = x[ok ? fxt_xi<true>(base + pp, c, 32) : 0];
+                return ok ? v : 0.f;
+#endif
+            };
+            auto B = [&](int s) {
+                const int t = 4 * s + kq;
+                const bool ok = t < L1;
+#if defined(FXT_EMUL)
+                return ok ? dz[fxt_xi<true>(base + t, o, 32)] : 0.f;
+#else
+                const float v = dz[ok ? fxt_xi<true>(base + t, o, 32) : 0];
+                return ok ? v : 0.f;
+#endif
+            };
+            float win[MT];
+#pragma unroll
+            for (int q = 0; q < MT - 1; ++q) win[q] = X(q);
+            float xn = X(MT - 1), bn = B(0);
+            for (int s = 0; s < S; ++s) {
+                win[MT - 1] = xn;
+                const float b = bn;
+                if (s + 1 < S) { xn = X(s + MT); bn = B(s + 1); }        // the next k-step's two fetches behind this one's MFMAs
+                const bool tok = 4 * s + kq < L1;                        // (false only in a row's last, partial k-step: both operands zero there, as fxt_gemm masks them)
+#pragma unroll
+                for (int q = 0; q < MT; ++q)
+                    if (q < NT) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(tok ? win[q] : 0.f, b, acc[q], 0, 0, 0);
+                if (bias) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(tok ? 1.f : 0.f, b, accb, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < MT - 1; ++q) win[q] = win[q + 1];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < MT; ++q)
+            if (q < NT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) fc.put((res + 4 * q) * 32 + ct * 16 + 4 * kq + r, o, acc[q][r]);
+            }
+        if (bias && kq == 0) fc.put(Kt * 32, o, accb[0]);
+    }
+#else
+    (void)wg;
+    for (int mrow = 0; mrow <= Kt * 32; ++mrow)
+        for (int o = 0; o < 32; ++o) {
+            const int j = mrow >> 5, c = mrow & 31;
+            float acc = 0.f;
+            for (int rho = 0; rho < R; ++rho)
+                for (int t = 0; t < L1; ++t) {
+                    const int pp = t + j - pl;
+                    const float a = mrow == Kt * 32 ? 1.f : ((pp >= 0 && pp < L1) ? x[fxt_xi<true>(rho * L1 + pp, c, 32)] : 0.f);
+                    acc = fmaf(a, dz[fxt_xi<true>(rho * L1 + t, o, 32)], acc);
+                }
+            fc.put(mrow, o, acc);
+        }
+#endif
+}
+
 // ---- operand functors ------------------------------------------------------------------------------------------
 // A k-step covers contraction indices ki = k0 + kq, kq = lane >> 4 in 0..3, k0 wave-uniform.  Every functor splits its
 // address into a per-lane part (`prep`, once per tile: row / column decomposition, the kq term) and a wave-uniform part
@@ -812,10 +1015,12 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
     //  so that everything derived from it below is a constant too)
     const FxtNet n = D::fixed ? fxt_net(D::kind, D::L > 0 ? D::L : j.net.L, D::A, D::F, D::H, D::K) : j.net;
     const int R = D::fixed ? D::R : j.R, L = n.L, A = n.A, F = n.F;
-    const FxtWs w = fxt_ws(n, R, MODE == 2);
-    // MODE 2: the conv kernels' staging buffer behind the workspace, j.split_off taps at a time (the host sized it)
+    const FxtWs w = fxt_ws(n, R, MODE >= 2);
+    // MODE 2 / 3: the conv kernels' staging buffer behind the workspace, j.split_off taps at a time (the host sized it: a tap is
+    // F rows of fxt_ld_w(F) floats in MODE 2, 32 rotated rows of 32 floats in MODE 3)
     [[maybe_unused]] WsF wbuf = ws + w.total;
     [[maybe_unused]] const int stage_taps = j.split_off;
+    [[maybe_unused]] const int tap_floats = MODE == 3 ? F * F : F * fxt_ld_w(F);
     const FxtLay y = fxt_lay(n, WAS == 3);      // (the LDS image of the weights has padded conv-kernel rows)
     const int ldF = w.ldF, ldw = y.ldw;
     WsI codes = (WsI)(ws + w.codes);
@@ -846,8 +1051,8 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
     // MODE 2: conv1's kernel and bias (K A rows of F floats + F: contiguous in Keras order) into the staging buffer as well, under the
     // same barrier -- conv1 is K gathered kernel rows per output, from L2 otherwise (~7 dependent round trips per thread at one row per slice)
     [[maybe_unused]] bool conv1_staged = false;
-    if constexpr (MODE == 2) {
-        if (n.kind == 0 && (n.K * A + 1) * F <= stage_taps * F * fxt_ld_w(F)) {
+    if constexpr (MODE >= 2) {
+        if (n.kind == 0 && (n.K * A + 1) * F <= stage_taps * tap_floats) {
             conv1_staged = true;
             FXT_FOR(i, (n.K * A + 1) * F, wg) wbuf[i] = W[y.cw[0] + i];
         }
@@ -859,7 +1064,7 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         const int L1 = n.L1, K = n.K;
         WsF a1 = ws + w.a[0]; WsF a2 = ws + w.a[1]; WsF a3 = ws + w.a[2];
         // conv1 ('valid') on a one-hot input: a sum of K kernel rows
-        if constexpr (MODE == 2) {
+        if constexpr (MODE >= 2) {
             if (conv1_staged) {
                 FXT_FOR(i, R * L1 * F, wg) {
                     const int o = i % F, rt = i / F, t = rt % L1, r = rt / L1;
@@ -869,7 +1074,7 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
                 }
             }
         }
-        if (MODE != 2 || !conv1_staged)
+        if (MODE < 2 || !conv1_staged)
         FXT_FOR(i, R * L1 * F, wg) {
             const int o = i % F, rt = i / F, t = rt % L1, r = rt / L1;
             float s = W[y.cb[0] + o];
@@ -880,7 +1085,9 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         {   // conv2 ('same', K taps)
             WCF b = W + y.cb[1];
             struct Put { WsF y; WCF b; int ld; FXT_HD void put(int m, int nn, float v) const { v += b[nn]; y[fxt_xi<SWZ>(m, nn, ld)] = v > 0.f ? v : 0.f; } };
-            if constexpr (MODE == 2)
+            if constexpr (MODE == 3)
+                fxt_conv32_staged<WSAS, WAS, 0>(wg, R * L1, K, ConvA{a1, L1, ldF, (K - 1) / 2, dL1}, FxtConvW32<WsCF>{wbuf}, Put{a2, b, ldF}, W + y.cw[1], wbuf, stage_taps);
+            else if constexpr (MODE == 2)
                 fxt_gemm_staged<WSAS, WAS>(wg, R * L1, F, K, F, ConvA{a1, L1, ldF, (K - 1) / 2, dL1}, FxtConvW<WsCF>{wbuf, F, fxt_ld_w(F)}, Put{a2, b, ldF},
                                       W + y.cw[1], wbuf, stage_taps, F, F, fxt_ld_w(F));
             else
@@ -890,7 +1097,9 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         {   // conv3 ('same', A - 1 taps)
             WCF b = W + y.cb[2];
             struct Put { WsF y; WCF b; int ld; FXT_HD void put(int m, int nn, float v) const { v += b[nn]; y[fxt_xi<SWZ>(m, nn, ld)] = v > 0.f ? v : 0.f; } };
-            if constexpr (MODE == 2)
+            if constexpr (MODE == 3)
+                fxt_conv32_staged<WSAS, WAS, 0>(wg, R * L1, n.K3, ConvA{a2, L1, ldF, (n.K3 - 1) / 2, dL1}, FxtConvW32<WsCF>{wbuf}, Put{a3, b, ldF}, W + y.cw[2], wbuf, stage_taps);
+            else if constexpr (MODE == 2)
                 fxt_gemm_staged<WSAS, WAS>(wg, R * L1, F, n.K3, F, ConvA{a2, L1, ldF, (n.K3 - 1) / 2, dL1}, FxtConvW<WsCF>{wbuf, F, fxt_ld_w(F)}, Put{a3, b, ldF},
                                       W + y.cw[2], wbuf, stage_taps, F, F, fxt_ld_w(F));
             else
@@ -1077,19 +1286,29 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         const bool ag = j.agent_io != 0;
         struct PutX { WsF d; WsCF y; int ld; FXT_HD void put(int m, int nn, float v) const { d[fxt_xi<SWZ>(m, nn, ld)] = y[fxt_xi<SWZ>(m, nn, ld)] > 0.f ? v : 0.f; } };
         // conv3: input gradient (few tiles, K3 x F / 4 k-steps) first, the weight gradient dealt on behind it
-        if constexpr (MODE == 2)
+        if constexpr (MODE == 3)
+            fxt_conv32_staged<WSAS, WAS, 1>(wg, R * L1, K3, ConvGradA{dzA, L1, ldF, (K3 - 1) / 2, dL1}, FxtConvGradW32<WsCF>{wbuf}, PutX{dzB, a2, ldF}, W + y.cw[2], wbuf, stage_taps);
+        else if constexpr (MODE == 2)
             fxt_gemm_staged<WSAS, WAS>(wg, R * L1, F, K3, F, ConvGradA{dzA, L1, ldF, (K3 - 1) / 2, dL1}, FxtConvGradW<WsCF>{wbuf, F, fxt_ld_w(F)}, PutX{dzB, a2, ldF},
                                   W + y.cw[2], wbuf, stage_taps, F, F, fxt_ld_w(F));
         else
         fxt_gemm(wg, R * L1, F, K3, F, ConvGradA{dzA, L1, ldF, (K3 - 1) / 2, dL1}, FxtConvGradW<WCF>{W + y.cw[2], F, ldw}, PutX{dzB, a2, ldF}, 0, split);
+        if constexpr (MODE == 3)
+            fxt_conv32_wgrad(wg, R, L1, K3, (K3 - 1) / 2, a2, (WsCF)dzA, PutW{part + n.off_cw[2], part + n.off_cb[2], K3 * F, F, ag});
+        else
         fxt_gemm(wg, K3 * F + 1, F, R, L1, ConvWGradA{a2, L1, F, ldF, (K3 - 1) / 2, K3 * F, dF}, PosMajorB{dzA, L1, ldF}, PutW{part + n.off_cw[2], part + n.off_cb[2], K3 * F, F, ag}, fxt_jobs(R * L1, F, K3, F, nwv, can_split));
         fxt_sync_ws<WSAS>(); FXT_STAMP(10);
         // conv2
-        if constexpr (MODE == 2)
+        if constexpr (MODE == 3)
+            fxt_conv32_staged<WSAS, WAS, 1>(wg, R * L1, K, ConvGradA{dzB, L1, ldF, (K - 1) / 2, dL1}, FxtConvGradW32<WsCF>{wbuf}, PutX{dzA, a1, ldF}, W + y.cw[1], wbuf, stage_taps);
+        else if constexpr (MODE == 2)
             fxt_gemm_staged<WSAS, WAS>(wg, R * L1, F, K, F, ConvGradA{dzB, L1, ldF, (K - 1) / 2, dL1}, FxtConvGradW<WsCF>{wbuf, F, fxt_ld_w(F)}, PutX{dzA, a1, ldF},
                                   W + y.cw[1], wbuf, stage_taps, F, F, fxt_ld_w(F));
         else
         fxt_gemm(wg, R * L1, F, K, F, ConvGradA{dzB, L1, ldF, (K - 1) / 2, dL1}, FxtConvGradW<WCF>{W + y.cw[1], F, ldw}, PutX{dzA, a1, ldF}, 0, split);
+        if constexpr (MODE == 3)
+            fxt_conv32_wgrad(wg, R, L1, K, (K - 1) / 2, a1, (WsCF)dzB, PutW{part + n.off_cw[1], part + n.off_cb[1], K * F, F, ag});
+        else
         fxt_gemm(wg, K * F + 1, F, R, L1, ConvWGradA{a1, L1, F, ldF, (K - 1) / 2, K * F, dF}, PosMajorB{dzB, L1, ldF}, PutW{part + n.off_cw[1], part + n.off_cb[1], K * F, F, ag}, fxt_jobs(R * L1, F, K, F, nwv, can_split));
         fxt_sync_ws<WSAS>(); FXT_STAMP(11);
         // conv1 (one-hot input, 'valid')

@@ -127,6 +127,24 @@ def test_host_build_of_the_training_step_equals_the_keras_restatement(kind, L, a
     check_against_oracle(step_fn, kind, L, alphabet, F, H, K, rows)
 
 
+PROTEIN_CASES = [  # kind, L, alphabet, F, H, K, rows   (BASELINE configs[3] / configs[4] lengths: AAV 90, GFP 237 / 238, and their neighbours)
+    ("cnn", 90, ref_np.AAS, 32, 100, 5, 64), ("cnn", 230, ref_np.AAS, 32, 100, 5, 16), ("cnn", 237, ref_np.AAS, 32, 100, 5, 32),
+    ("cnn", 238, ref_np.AAS, 32, 100, 5, 16), ("cnn", 260, ref_np.AAS, 32, 100, 5, 16), ("cnn", 300, ref_np.AAS, 32, 100, 5, 16),
+]
+
+
+@pytest.mark.parametrize("kind,L,alphabet,F,H,K,rows", [PROTEIN_CASES[0], ("cnn", 237, ref_np.AAS, 32, 100, 5, 6)])
+def test_host_build_at_protein_lengths_equals_the_keras_restatement(kind, L, alphabet, F, H, K, rows):
+    """The host build at the lengths the reference retrains at on the protein landscapes (explorer.py:157-160 with the AAV / GFP
+    landscapes' seq_len; cnn.py:23-56 -> conv3 has 19 taps): one row per slice, as the device cuts those fits."""
+    lut = _native.make_lut(alphabet)
+
+    def step_fn(w, m, v, t, b, y, keep):
+        return _native.debug_train_step_host(KIND[kind], L, len(alphabet), F, H, K, w, m, v, t, b, lut, y, keep, R=1)
+
+    check_against_oracle(step_fn, kind, L, alphabet, F, H, K, rows, steps=2)
+
+
 def test_host_build_slicing_does_not_change_the_step():
     """The gradient is a sum over slices in slice order: different R give the same weights to float32 rounding."""
     kind, L, alphabet, F, H, K, rows = "cnn", 8, "TGCA", 8, 12, 3, 50
@@ -166,6 +184,31 @@ def test_device_training_step_equals_the_keras_restatement(kind, L, alphabet, F,
         return t2, float(loss[0])
 
     check_against_oracle(step_fn, kind, L, alphabet, F, H, K, rows, steps=3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("swizzle", [None, 0, 1, 2])
+@pytest.mark.parametrize("kind,L,alphabet,F,H,K,rows", PROTEIN_CASES)
+def test_device_training_step_at_protein_lengths_equals_the_keras_restatement(kind, L, alphabet, F, H, K, rows, swizzle):
+    """Round 5 (verdict item 1): the device step against oracle/train_np.py -- not only against the plain device step -- at the
+    lengths BASELINE configs[3] / configs[4] retrain at: CNN L = 90 / A = 20 (padded rows in LDS, weights from L2), L = 230 / 237 /
+    238 (one row per slice, unpadded or rotated rows in LDS, the staged conv kernels), L = 260 (past the five-array LDS layout) and
+    L = 300 (workspace in global memory), 16 - 64 rows; under the engine's default form (None) and every explicit `train_swizzle`."""
+    eng = _native.Engine.get(0)
+    lut = _native.make_lut(alphabet)
+    default = eng.get_option("train_swizzle")
+    if swizzle is not None:
+        eng.set_option("train_swizzle", swizzle)
+
+    def step_fn(w, m, v, t, b, y, keep):
+        t2, loss = _fit_once(eng, kind, L, len(alphabet), F, H, K, w, m, v, t, b, y, np.arange(rows, dtype=np.int32), 1, rows,
+                             keep=None if keep is None else keep[None], lut=lut)
+        return t2, float(loss[0])
+
+    try:
+        check_against_oracle(step_fn, kind, L, alphabet, F, H, K, rows, steps=2)
+    finally:
+        eng.set_option("train_swizzle", default)
 
 
 @pytest.mark.gpu
@@ -376,12 +419,9 @@ def test_canonical_shape_instantiations_equal_the_shape_agnostic_step(kind, L, a
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("FLEXS_AMD_PREPARED") != "1",
-                    reason="train_swizzle was written after round 4's GPU budget was spent: the device run of this test is round 5's first job "
-                           "(FLEXS_AMD_PREPARED=1); on the CPU the same source gives the same bits (tests/native/sanitize_host.cpp)")
 @pytest.mark.parametrize("L,n,B,M", [(237, 300, 256, 3), (238, 130, 128, 1), (230, 100, 64, 2)])
 def test_rotated_rows_and_staged_conv_kernels_equal_the_plain_step(L, n, B, M):
-    """Prepared at the end of round 4 (`train_swizzle`, default off): GFP-length CNN fits -- unpadded activation rows in LDS, every conv
+    """Written at the end of round 4, first run on the device in round 5 (`train_swizzle`): GFP-length CNN fits -- unpadded activation rows in LDS, every conv
     operand fetch 16-way bank-conflicted -- with rotated rows (1) and, on top, the gradient array over the last conv output and the
     conv kernels staged through LDS in tap groups (2).  Where a value is stored and which memory a weight is read from do not change
     the arithmetic or its order: weights, moments, step count and losses are the SAME BITS as the plain step's, with the in-kernel
@@ -394,6 +434,7 @@ def test_rotated_rows_and_staged_conv_kernels_equal_the_plain_step(L, n, B, M):
     _, b, _, y = _data(kind, L, alphabet, n, 31)
     steps = (n + B - 1) // B
     results = []
+    default = eng.get_option("train_swizzle")
     for swz in (0, 1, 2):
         eng.set_option("train_swizzle", swz)
         try:
@@ -409,7 +450,7 @@ def test_rotated_rows_and_staged_conv_kernels_equal_the_plain_step(L, n, B, M):
             res = _native.train_fit(eng, jobs, b, lut, y)
             results.append([(j["weights"].copy(), j["adam_m"].copy(), j["adam_v"].copy(), t, np.asarray(loss).copy()) for j, (t, loss) in zip(jobs, res)])
         finally:
-            eng.set_option("train_swizzle", 0)
+            eng.set_option("train_swizzle", default)
     for swz in (1, 2):
         for mem, (a, c) in enumerate(zip(results[0], results[swz])):
             assert a[3] == c[3] == epochs * steps
