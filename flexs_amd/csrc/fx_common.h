@@ -231,7 +231,7 @@ struct fx_engine {
     int64_t train_persistent = 0;   // fx_train_fit: 1 = the whole fit is ONE launch when all (slices x members) workgroups are co-resident: two member barriers in device memory per step, Adam by the same workgroups.  Bit-identical to the launch-per-step form and NOT faster: 5.90 vs 5.41 ms for 3 x CNN on 1000 sequences, equal elsewhere (profiles/r4_train_one_launch_ab.log) -- two agent-scope release/acquire barriers + the weight re-read cost what two launch boundaries cost.  Off; kept as the A/B
     int64_t train_split = 0;    // A/B build only: 1 = products with few tiles and a long contraction are cut along the contraction over up to four waves (partial tiles through 16 KiB of LDS, one more barrier).  Bit-identical between instantiations and SLOWER: 24.6 -> 33.1 us per forward+backward launch (profiles/r4_train_split_ab.log)
     int64_t train_canon = 1;    // fx_train_fit: 1 = canonical shapes (CNN(32,100,k5) on 4 letters, MLP(100) on 4 letters, GlobalEpistasis(100) on 20) run the instantiation with compile-time dimensions; 0 = the shape-agnostic code for everything (A/B; bit-identical)
-    int64_t train_swizzle = 2;  // fx_train_fit: (2 = + dzA over a[2] and conv kernels staged through LDS, train_core.h MODE 2) 1 = CNN fits whose padded workspace misses the LDS budget (long protein sequences) store their position-major arrays with rotated rows (train_core.h) instead of unpadded, 16-way conflicted ones; same bits (CPU); prepared at the end of round 4, not yet measured
+    int64_t train_swizzle = 3;  // fx_train_fit: (3 = any CNN with 32 filters whose weights miss LDS and whose slice has <= 16 M tiles: train_core.h MODE 3 -- paired tiles over rotated kernel rows, register-prefetched staging, sliding-window weight gradient; else as 2) (2 = + dzA over a[2] and conv kernels staged through LDS, train_core.h MODE 2) 1 = CNN fits whose padded workspace misses the LDS budget (long protein sequences) store their position-major arrays with rotated rows (train_core.h) instead of unpadded, 16-way conflicted ones; same bits (CPU); prepared at the end of round 4, not yet measured
     int64_t train_trace = 0;    // profiling aid: 1 = fx_train_fit stamps the phases of the LAST step of member 0, workgroup 0 (fx_debug_train_trace)
     unsigned long long* d_train_dbg = nullptr;
     int64_t train_threads = 0;  // fx_train_fit: threads per forward+backward workgroup (256 / 512 / 1024; 0 = 1024)

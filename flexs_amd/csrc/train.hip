@@ -94,7 +94,10 @@ __global__ void __launch_bounds__(FB_MAX_THREADS) k_train_fb_c32(const FxtJob* _
     const FxtJob& j = jobs[blockIdx.y];
     if (step >= j.total_steps || (int)blockIdx.x >= j.S) return;
     const FxtWg wg{(int)threadIdx.x, (int)blockDim.x};
-    fxt_forward_backward<3, 1, FxtDimsAny, 3>(j, wg, step, (int)blockIdx.x, ascii, lut, labels, (FxtMem<3>::F)fxt_smem, (FxtMem<1>::CF)j.w, (FxtMem<3>::F) nullptr);
+    if (j.canon == -4)       // the protein surrogate of the BASELINE configs -- CNN(32, 100, kernel 5) on 20 letters, one row per slice -- with its dimensions as constants (train_core.h FxtDims: same bits, a fraction of the code)
+        fxt_forward_backward<3, 1, FxtDims<0, 20, 32, 100, 5, 1>, 3>(j, wg, step, (int)blockIdx.x, ascii, lut, labels, (FxtMem<3>::F)fxt_smem, (FxtMem<1>::CF)j.w, (FxtMem<3>::F) nullptr);
+    else
+        fxt_forward_backward<3, 1, FxtDimsAny, 3>(j, wg, step, (int)blockIdx.x, ascii, lut, labels, (FxtMem<3>::F)fxt_smem, (FxtMem<1>::CF)j.w, (FxtMem<3>::F) nullptr);
 }
 
 __global__ void __launch_bounds__(256) k_train_adam(const FxtJob* __restrict__ jobs, int step) {
@@ -327,7 +330,7 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
         for (int m = 0; m < M; ++m) {
             FxtJob& j = hj[(size_t)m];
             j.net = c32_net[(size_t)m];
-            j.canon = -3;
+            j.canon = (e->train_canon && j.net.A == 20 && j.net.H == 100 && j.net.K == 5 && j.R == 1) ? -4 : -3;
             j.ws_in_lds = 1; j.w_in_lds = 0;
             j.split_off = c32_taps[(size_t)m];
             j.ws_slice = fxt_ws(j.net, j.R, true).total + c32_taps[(size_t)m] * 1024;

@@ -1013,7 +1013,9 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
     typedef typename FxtPick<SWZ, FxtPosMajorB<WsCF>, FxtPosMajorBSwz<WsCF>>::T PosMajorB;
     // (a canonical instantiation rebuilds the description from its constants -- only the sequence length is a run-time value --
     //  so that everything derived from it below is a constant too)
-    const FxtNet n = D::fixed ? fxt_net(D::kind, D::L > 0 ? D::L : j.net.L, D::A, D::F, D::H, D::K) : j.net;
+    FxtNet n_ = D::fixed ? fxt_net(D::kind, D::L > 0 ? D::L : j.net.L, D::A, D::F, D::H, D::K) : j.net;
+    if (D::fixed && SWZ) n_.ldx = n_.F;        // (rotated rows are F floats apart)
+    const FxtNet n = n_;
     const int R = D::fixed ? D::R : j.R, L = n.L, A = n.A, F = n.F;
     const FxtWs w = fxt_ws(n, R, MODE >= 2);
     // MODE 2 / 3: the conv kernels' staging buffer behind the workspace, j.split_off taps at a time (the host sized it: a tap is

@@ -54,7 +54,7 @@ static int strips(const std::vector<unsigned char>& a, const std::vector<unsigne
 // stage_taps > 0 (with rotated): MODE 2 -- the gradient array over the last conv output and the conv kernels staged through a buffer
 // behind the workspace, that many taps at a time -- and again the same bits.
 static int train_case(int kind, int L, int A, int F, int H, int K, int rows, int R, bool plain_rows = false, std::vector<float>* out_w = nullptr,
-                      unsigned seed = 0, bool rotated = false, int stage_taps = 0) {
+                      unsigned seed = 0, bool rotated = false, int stage_taps = 0, bool c32 = false) {
     if (seed) rng_state = seed;
     FxtJob j{};
     j.net = fxt_net(kind, L, A, kind == 0 ? F : 0, H, kind == 0 ? K : 0);
@@ -80,10 +80,12 @@ static int train_case(int kind, int L, int A, int F, int H, int K, int rows, int
         j.ws_slice = fxt_ws(j.net, R, true).total + stage_taps * j.net.F * fxt_ld_w(j.net.F);      // exact size: four arrays + the tap buffer
         j.split_off = stage_taps;
     }
+    if (c32) j.ws_slice = fxt_ws(j.net, R, true).total + stage_taps * 1024;      // MODE 3: a tap = 32 rotated rows of 32 floats
     std::vector<float> ws((size_t)j.S * (size_t)j.ws_slice, 0.f);
     j.ws = ws.data();
     for (int s = 0; s < j.S; ++s) {
-        if (rotated && stage_taps > 0) fxt_forward_backward<0, 0, FxtDimsAny, 2>(j, FxtWg{0, 1}, 0, s, ascii.data(), lut.data(), labels.data(), j.ws + (long long)s * j.ws_slice, (const float*)j.w);
+        if (c32) fxt_forward_backward<0, 0, FxtDimsAny, 3>(j, FxtWg{0, 1}, 0, s, ascii.data(), lut.data(), labels.data(), j.ws + (long long)s * j.ws_slice, (const float*)j.w);
+        else if (rotated && stage_taps > 0) fxt_forward_backward<0, 0, FxtDimsAny, 2>(j, FxtWg{0, 1}, 0, s, ascii.data(), lut.data(), labels.data(), j.ws + (long long)s * j.ws_slice, (const float*)j.w);
         else if (rotated) fxt_forward_backward<0, 0, FxtDimsAny, 1>(j, FxtWg{0, 1}, 0, s, ascii.data(), lut.data(), labels.data(), j.ws + (long long)s * j.ws_slice, (const float*)j.w);
         else fxt_forward_backward<0, 0>(j, FxtWg{0, 1}, 0, s, ascii.data(), lut.data(), labels.data(), j.ws + (long long)s * j.ws_slice, (const float*)j.w);
     }
@@ -113,6 +115,12 @@ int main() {
                 std::vector<float> wd;
                 bad += train_case(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], true, &wd, 777u, true, taps);
                 if (wa.size() != wd.size() || std::memcmp(wa.data(), wd.data(), wa.size() * sizeof(float)) != 0) { std::printf("staged conv kernels differ: L %d F %d taps %d\n", s[1], s[3], taps); ++bad; }
+            }
+            if (s[3] != 32) continue;                      // MODE 3 (round 5): the F = 32 form -- rotated kernel rows in the tap buffer, the weight gradient on its own loop
+            for (int taps : {1, 3, 8}) {
+                std::vector<float> we;
+                bad += train_case(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], true, &we, 777u, true, taps, true);
+                if (wa.size() != we.size() || std::memcmp(wa.data(), we.data(), wa.size() * sizeof(float)) != 0) { std::printf("F = 32 form differs: L %d taps %d\n", s[1], taps); ++bad; }
             }
         }
     }

@@ -71,7 +71,8 @@ static void run_slice(const FxtJob& j, int mode, int nthr, int slice, const Simt
             t_tid = tid;
             const FxtWg wg{tid, nthr};
             const uint8_t* a = p.ascii.data(); const uint8_t* l = p.lut.data(); const float* y = p.labels.data();
-            if (mode == 2) fxt_forward_backward<3, 1, FxtDimsAny, 2>(j, wg, 0, slice, a, l, y, lds, (const float*)j.w, (float*)nullptr);
+            if (mode == 3) fxt_forward_backward<3, 1, FxtDimsAny, 3>(j, wg, 0, slice, a, l, y, lds, (const float*)j.w, (float*)nullptr);
+            else if (mode == 2) fxt_forward_backward<3, 1, FxtDimsAny, 2>(j, wg, 0, slice, a, l, y, lds, (const float*)j.w, (float*)nullptr);
             else if (mode == 1) fxt_forward_backward<3, 1, FxtDimsAny, 1>(j, wg, 0, slice, a, l, y, lds, (const float*)j.w, (float*)nullptr);
             else fxt_forward_backward<3, 1, FxtDimsAny, 0>(j, wg, 0, slice, a, l, y, lds, (const float*)j.w, (float*)nullptr);
         });
@@ -95,6 +96,10 @@ static std::vector<float> emul_step(const SimtProblem& p, int mode, int nthr, in
     j.ws_slice = fxt_ws(j.net, p.R).total;
     if (mode == 2) {
         j.ws_slice = fxt_ws(j.net, p.R, true).total + stage_taps * j.net.F * fxt_ld_w(j.net.F);
+        j.split_off = stage_taps;
+    }
+    if (mode == 3) {                                       // (a tap = 32 rotated rows of 32 floats)
+        j.ws_slice = fxt_ws(j.net, p.R, true).total + stage_taps * 1024;
         j.split_off = stage_taps;
     }
     for (int s = 0; s < j.S; ++s) {
@@ -177,11 +182,14 @@ int main(int argc, char** argv) {
         {1, 9, 4, 0, 20, 0, 19, 8, 128},         // MLP: dense layers only, one-hot weight gradient
         {2, 14, 20, 0, 24, 0, 7, 4, 64},         // GlobalEpistasis on one wave
         {0, 68, 4, 32, 20, 5, 1, 1, 512},        // 64 positions: the rotated modes' max-pool shared by 32 threads per channel; 4 x 2 conv tiles on 8 waves
+        {0, 37, 20, 32, 12, 5, 1, 1, 1024},      // sixteen waves (the device's workgroup): the F = 32 form's weight gradient deals one job per wave; 19 taps of conv3
     };
     if (!quick) {
         cases.push_back({0, 70, 20, 32, 100, 5, 1, 1, 512});     // 5 x 2 conv tiles on 8 waves
         cases.push_back({0, 23, 20, 64, 9, 4, 2, 1, 512});       // 64 filters (two groups of eight k-steps per tap), even kernel
         cases.push_back({0, 9, 4, 8, 16, 3, 37, 16, 1024});      // the full 16 waves, 8 filters, 16 rows per slice
+        cases.push_back({0, 237, 20, 32, 100, 5, 1, 1, 1024});   // GFP: 233 positions = 15 M tiles on 16 waves, 59 k-steps (the last one partial) per weight-gradient row
+        cases.push_back({0, 26, 20, 32, 16, 7, 4, 2, 512});      // two rows per slice (the window restarts per row), kernel 7 (residue 3 holds one tap + the bias)
     }
     for (const Case& c : cases) {
         const int P = simt_ref_params(c.kind, c.L, c.A, c.F, c.H, c.K);
@@ -197,6 +205,14 @@ int main(int argc, char** argv) {
         bad += same("gradient partials", part_ref, part, p, 1, c.nthr, 0);
         bad += same("weights", want, got, p, 1, c.nthr, 0);
         const int L1 = c.L - c.K + 1;
+        if (c.F == 32 && fxt_conv32_ok(c.R * L1, c.F, c.nthr / 64)) {
+            for (int taps : {1, 3, 8}) {                       // the F = 32 form: paired tiles over rotated kernel rows, sliding-window weight gradient
+                if (quick && taps == 3) continue;
+                got = emul_step(p, 3, c.nthr, taps, &part);
+                bad += same("gradient partials", part_ref, part, p, 3, c.nthr, taps);
+                bad += same("weights", want, got, p, 3, c.nthr, taps);
+            }
+        }
         if ((c.F & 31) || !fxt_staged_ok(c.R * L1, c.F, c.F, c.F, c.nthr / 64)) continue;
         for (int taps : {1, 2, 6}) {                           // + staged conv kernels, `taps` taps per group
             if (quick && taps == 1) continue;

@@ -187,7 +187,7 @@ def test_device_training_step_equals_the_keras_restatement(kind, L, alphabet, F,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("swizzle", [None, 0, 1, 2])
+@pytest.mark.parametrize("swizzle", [None, 0, 1, 2, 3])
 @pytest.mark.parametrize("kind,L,alphabet,F,H,K,rows", PROTEIN_CASES)
 def test_device_training_step_at_protein_lengths_equals_the_keras_restatement(kind, L, alphabet, F, H, K, rows, swizzle):
     """Round 5 (verdict item 1): the device step against oracle/train_np.py -- not only against the plain device step -- at the
@@ -419,7 +419,7 @@ def test_canonical_shape_instantiations_equal_the_shape_agnostic_step(kind, L, a
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("L,n,B,M", [(237, 300, 256, 3), (238, 130, 128, 1), (230, 100, 64, 2)])
+@pytest.mark.parametrize("L,n,B,M", [(237, 300, 256, 3), (238, 130, 128, 1), (230, 100, 64, 2), (90, 200, 256, 2), (260, 40, 32, 1)])
 def test_rotated_rows_and_staged_conv_kernels_equal_the_plain_step(L, n, B, M):
     """Written at the end of round 4, first run on the device in round 5 (`train_swizzle`): GFP-length CNN fits -- unpadded activation rows in LDS, every conv
     operand fetch 16-way bank-conflicted -- with rotated rows (1) and, on top, the gradient array over the last conv output and the
@@ -435,7 +435,7 @@ def test_rotated_rows_and_staged_conv_kernels_equal_the_plain_step(L, n, B, M):
     steps = (n + B - 1) // B
     results = []
     default = eng.get_option("train_swizzle")
-    for swz in (0, 1, 2):
+    for swz in (0, 1, 2, 3):
         eng.set_option("train_swizzle", swz)
         try:
             jobs = []
@@ -451,7 +451,7 @@ def test_rotated_rows_and_staged_conv_kernels_equal_the_plain_step(L, n, B, M):
             results.append([(j["weights"].copy(), j["adam_m"].copy(), j["adam_v"].copy(), t, np.asarray(loss).copy()) for j, (t, loss) in zip(jobs, res)])
         finally:
             eng.set_option("train_swizzle", default)
-    for swz in (1, 2):
+    for swz in (1, 2, 3):
         for mem, (a, c) in enumerate(zip(results[0], results[swz])):
             assert a[3] == c[3] == epochs * steps
             for what, x, z in zip(("weights", "adam_m", "adam_v", "losses"), (a[0], a[1], a[2], a[4]), (c[0], c[1], c[2], c[4])):

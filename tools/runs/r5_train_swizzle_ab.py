@@ -39,7 +39,7 @@ def phase_us(model, seqs, y):
     res["whole step"] = round((prev - int(out[0])) / 100.0, 2)
     return res
 
-LEGS = ("plain", "rotated_rows", "staged_conv_kernels")
+LEGS = ("plain", "rotated_rows", "staged_conv_kernels", "f32_form")
 
 def run(tag, make, L, alpha, n, phases=False):
     """The three legs one after the other; a leg that fails is named in the report and the others still count.  In --json mode the
@@ -95,6 +95,8 @@ if AS_JSON:
 run("CNN L=237 A=20", lambda: bm.CNN(237, 32, 100, s_utils.AAS, seed=0), 237, s_utils.AAS, 500)
 run("CNN L=238 A=20 (GFP + 1)", lambda: bm.CNN(238, 32, 100, s_utils.AAS, seed=0), 238, s_utils.AAS, 300)
 run("CNN L=230 A=20", lambda: bm.CNN(230, 32, 100, s_utils.AAS, seed=0), 230, s_utils.AAS, 500)
+run("Ensemble 3xCNN L=90 A=20 (AAV length)", lambda: flexs_amd.Ensemble([bm.CNN(90, 32, 100, s_utils.AAS, seed=m) for m in range(3)]), 90, s_utils.AAS, 500, phases=True)
+run("CNN L=250 A=20 (past the five-array layout)", lambda: bm.CNN(250, 32, 100, s_utils.AAS, seed=0), 250, s_utils.AAS, 300)
 run("control: CNN L=200 A=20 (padded rows fit)", lambda: bm.CNN(200, 32, 100, s_utils.AAS, seed=0), 200, s_utils.AAS, 500)
 run("control: Ensemble 3xCNN L=8", lambda: flexs_amd.Ensemble([bm.CNN(8, 32, 100, "TGCA", seed=m) for m in range(3)]), 8, "TGCA", 1000)
 sys.exit(1 if bad else 0)
