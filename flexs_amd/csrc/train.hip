@@ -94,18 +94,49 @@ __global__ void __launch_bounds__(FB_MAX_THREADS) k_train_fb_c32(const FxtJob* _
     const FxtJob& j = jobs[blockIdx.y];
     if (step >= j.total_steps || (int)blockIdx.x >= j.S) return;
     const FxtWg wg{(int)threadIdx.x, (int)blockDim.x};
-    if (j.canon == -4)       // the protein surrogate of the BASELINE configs -- CNN(32, 100, kernel 5) on 20 letters, one row per slice -- with its dimensions as constants (train_core.h FxtDims: same bits, a fraction of the code)
-        fxt_forward_backward<3, 1, FxtDims<0, 20, 32, 100, 5, 1>, 3>(j, wg, step, (int)blockIdx.x, ascii, lut, labels, (FxtMem<3>::F)fxt_smem, (FxtMem<1>::CF)j.w, (FxtMem<3>::F) nullptr);
-    else
-        fxt_forward_backward<3, 1, FxtDimsAny, 3>(j, wg, step, (int)blockIdx.x, ascii, lut, labels, (FxtMem<3>::F)fxt_smem, (FxtMem<1>::CF)j.w, (FxtMem<3>::F) nullptr);
+    fxt_forward_backward<3, 1, FxtDimsAny, 3>(j, wg, step, (int)blockIdx.x, ascii, lut, labels, (FxtMem<3>::F)fxt_smem, (FxtMem<1>::CF)j.w, (FxtMem<3>::F) nullptr);
+}
+// ... and the protein surrogate of the BASELINE configs -- CNN(32, 100, kernel 5) on 20 letters, one row per slice -- with its dimensions
+// as constants (train_core.h FxtDims: same bits; 1/3 of the code -- the shape-agnostic body is 90 KiB, streamed through the 64 KiB
+// instruction cache by every workgroup: 643 -> 483 us per launch at L = 237).  FxtJob::canon = -4, when ALL members have this shape.
+__global__ void __launch_bounds__(FB_MAX_THREADS) k_train_fb_c32p(const FxtJob* __restrict__ jobs, int step, const uint8_t* __restrict__ ascii,
+                                                              const uint8_t* __restrict__ lut, const float* __restrict__ labels) {
+    extern __shared__ __attribute__((aligned(16))) float fxt_smem[];
+    const FxtJob& j = jobs[blockIdx.y];
+    if (step >= j.total_steps || (int)blockIdx.x >= j.S) return;
+    const FxtWg wg{(int)threadIdx.x, (int)blockDim.x};
+    fxt_forward_backward<3, 1, FxtDims<0, 20, 32, 100, 5, 1>, 3>(j, wg, step, (int)blockIdx.x, ascii, lut, labels, (FxtMem<3>::F)fxt_smem, (FxtMem<1>::CF)j.w, (FxtMem<3>::F) nullptr);
 }
 
 __global__ void __launch_bounds__(256) k_train_adam(const FxtJob* __restrict__ jobs, int step) {
     const FxtJob& j = jobs[blockIdx.y];
     if (step >= j.total_steps) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < j.net.P) fxt_adam(j, step, i);
-    if (i == 0 && j.step_loss) fxt_step_loss(j, step);
+    if (j.pstride && (j.pstride & 3) == 0) {                // aligned rows (fx_train_fit's arena): four parameters per thread, 16-byte loads
+        const int i4 = 4 * i;
+        if (i4 + 3 < j.net.P) fxt_adam4(j, step, i4);
+        else for (int k = i4; k < j.net.P && k < i4 + 4; ++k) fxt_adam(j, step, k);
+    } else if (i < j.net.P) {
+        fxt_adam(j, step, i);
+    }
+    if (blockIdx.x == 0 && j.step_loss) {
+        // the step's loss = the slices' squared-error sums added in slice order.  One thread walking S dependent-looking global
+        // loads was the kernel's critical path (256 slices at one row per slice: ~75 us whatever the rest of the grid did, round 5):
+        // the workgroup fetches them side by side into LDS, one thread adds them in the same order
+        __shared__ float sse_s[512];
+        const int sidx = step % j.steps_per_epoch;
+        const int nvalid = (j.n - sidx * j.batch) < j.batch ? (j.n - sidx * j.batch) : j.batch;
+        const long long ps = fxt_pstride(j);
+        float sse = 0.f;
+        for (int c0 = 0; c0 < j.S; c0 += 512) {
+            const int cn = j.S - c0 < 512 ? j.S - c0 : 512;
+            __syncthreads();
+            for (int k = threadIdx.x; k < cn; k += blockDim.x) sse_s[k] = j.partial[(long long)(c0 + k) * ps + j.net.P];
+            __syncthreads();
+            if (threadIdx.x == 0) for (int k = 0; k < cn; ++k) sse += sse_s[k];
+        }
+        if (threadIdx.x == 0) j.step_loss[step] = sse / (float)nvalid;
+    }
 }
 
 // ---- the whole fit as ONE launch (round 4) ----------------------------------------------------------------------------------
@@ -263,6 +294,7 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
         j.R = rows_per_slice(j.net, u.batch, e->num_cus, (int)e->train_rows);
         j.S = (u.batch + j.R - 1) / j.R;
         j.seed = u.seed;
+        j.pstride = (j.net.P + 1 + 31) & ~31;
         j.ws_slice = fxt_ws(j.net, j.R).total;
         if (j.net.kind == 0 && (size_t)j.ws_slice * 4 > FB_LDS_BUDGET) {     // padded rows just too large for LDS: unpadded in LDS beats padded in global memory
             FxtNet plain = j.net;
@@ -325,12 +357,14 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
     const bool c32 = n_c32 == M && threads == FB_MAX_THREADS;
     const bool any_swz = c32 || n_swz == M;
     const bool staged = !c32 && any_swz && n_stage == M && threads == FB_MAX_THREADS;     // (fxt_staged_ok was asked for 16 waves)
+    bool c32p = c32 && e->train_canon != 0;                // every member the canonical protein shape?
     if (c32) {
         lds_bytes = 0;                                         // (the layouts sized above are not the ones these members run)
+        for (int m = 0; m < M; ++m) c32p = c32p && c32_net[(size_t)m].A == 20 && c32_net[(size_t)m].H == 100 && c32_net[(size_t)m].K == 5 && hj[(size_t)m].R == 1;
         for (int m = 0; m < M; ++m) {
             FxtJob& j = hj[(size_t)m];
             j.net = c32_net[(size_t)m];
-            j.canon = (e->train_canon && j.net.A == 20 && j.net.H == 100 && j.net.K == 5 && j.R == 1) ? -4 : -3;
+            j.canon = c32p ? -4 : -3;
             j.ws_in_lds = 1; j.w_in_lds = 0;
             j.split_off = c32_taps[(size_t)m];
             j.ws_slice = fxt_ws(j.net, j.R, true).total + c32_taps[(size_t)m] * 1024;
@@ -378,7 +412,7 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
         a.take<FxtBar>(1);
         for (int m = 0; m < M; ++m) {
             const FxtJob& j = hj[(size_t)m];
-            a.take<float>((size_t)j.S * (j.net.P + 1));
+            a.take<float>((size_t)j.S * (size_t)j.pstride);
             a.take<float>((size_t)j.S * (size_t)j.ws_slice);
         }
     };
@@ -443,7 +477,7 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
     FxtBar* d_bar = a.take<FxtBar>(1);                             // region C
     for (int m = 0; m < M; ++m) {
         FxtJob& j = hj[(size_t)m];
-        j.partial = a.take<float>((size_t)j.S * ((size_t)j.net.P + 1));
+        j.partial = a.take<float>((size_t)j.S * (size_t)j.pstride);
         j.ws = a.take<float>((size_t)j.S * (size_t)j.ws_slice);
     }
     if (e->train_trace) {
@@ -478,7 +512,7 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
     FX_HIP(e, hipMemcpyAsync(e->d_train, e->h_train, bytes_ab, hipMemcpyHostToDevice, st));      // regions A + B, one copy
     e->train_prof_ns[1] = since();
 
-    const dim3 grid_fb((unsigned)max_S, (unsigned)M), grid_adam((unsigned)((max_P + 255) / 256), (unsigned)M);
+    const dim3 grid_fb((unsigned)max_S, (unsigned)M), grid_adam((unsigned)(((max_P + 3) / 4 + 63) / 64), (unsigned)M);      // four parameters per thread (fxt_adam4), one wave per workgroup: a GFP-length CNN's 10 344 quads spread over 162 workgroups per member
     if (lds_bytes > 48 * 1024) {
         static bool attr_set[64] = {};
         if (!attr_set[e->device & 63]) {
@@ -489,6 +523,7 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
         if (any_swz && !attr_swz[e->device & 63]) {
             FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_fb_swz), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS_BUDGET));
             FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_fb_c32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS_BUDGET));
+            FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_fb_c32p), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS_BUDGET));
             attr_swz[e->device & 63] = true;
         }
     }
@@ -499,10 +534,11 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
         FX_HIP(e, hipMemcpyAsync(&h_abort, &d_bar->abort, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     } else {
         for (int s = 0; s < max_steps; ++s) {
-            if (c32) hipLaunchKernelGGL(k_train_fb_c32, grid_fb, dim3((unsigned)threads), lds_bytes, st, d_jobs, s, d_ascii, d_lut, d_labels);
+            if (c32p) hipLaunchKernelGGL(k_train_fb_c32p, grid_fb, dim3((unsigned)threads), lds_bytes, st, d_jobs, s, d_ascii, d_lut, d_labels);
+            else if (c32) hipLaunchKernelGGL(k_train_fb_c32, grid_fb, dim3((unsigned)threads), lds_bytes, st, d_jobs, s, d_ascii, d_lut, d_labels);
             else if (any_swz) hipLaunchKernelGGL(k_train_fb_swz, grid_fb, dim3((unsigned)threads), lds_bytes, st, d_jobs, s, d_ascii, d_lut, d_labels);
             else hipLaunchKernelGGL(k_train_fb, grid_fb, dim3((unsigned)threads), lds_bytes, st, d_jobs, s, d_ascii, d_lut, d_labels);
-            hipLaunchKernelGGL(k_train_adam, grid_adam, dim3(256), 0, st, d_jobs, s);
+            hipLaunchKernelGGL(k_train_adam, grid_adam, dim3(64), 0, st, d_jobs, s);
         }
         FX_HIP(e, hipGetLastError());
     }

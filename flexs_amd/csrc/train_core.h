@@ -179,6 +179,7 @@ struct FxtWs {
     int a[3];                   // R x L1 x ldF post-ReLU conv outputs
     int dzA, dzB;               // R x L1 x ldF gradient ping-pong
     int g, cnt, dg;             // R x ldF     pooled maxima, tie counts, gradient
+    int zero;                   // (alias_dz layouts) ldF zeros: where MODE 3's operand fetches of positions outside a row are sent (no select on the value)
     int act[FXT_MAX_LAYERS];    // R x dim[i+1] post-activation (post-dropout) outputs
     int du[FXT_MAX_LAYERS];     // R x dim[i+1] gradient w.r.t. the pre-activation
     int total;
@@ -202,6 +203,7 @@ FXT_HD FxtWs fxt_ws(const FxtNet& n, int R, bool alias_dz = false) {
         w.g = off; off += R * w.ldF;
         w.cnt = off; off += R * w.ldF;
         w.dg = off; off += R * w.ldF;
+        w.zero = off; if (alias_dz) off += w.ldF;
     }
     // (fixed trip counts: with run-time bounds the offset table is indexed dynamically and lives in scratch memory)
 #if FXT_DEVICE
@@ -225,7 +227,8 @@ struct FxtJob {
     int R, S;                   // rows per slice, slices per step = ceil(batch / R)
     float* w;                   // [P]
     float* adam_m; float* adam_v;
-    float* partial;             // [S][P + 1]: gradient partials, then the slice's sum of squared errors
+    float* partial;             // [S][pstride]: gradient partials, then the slice's sum of squared errors at [P]
+    int pstride;                // floats between two slices' rows (0 = P + 1).  fx_train_fit rounds it up to 32 floats: rows of P + 1 = 41 374 floats start 120 bytes into a cache line, so every 64-byte run of gradient stores straddled two sectors and every 256-byte run the Adam kernel reads three lines
     const int32_t* order;       // [total_steps][batch] data-set row per slot, -1 = padding slot
     const uint8_t* keep;        // optional explicit dropout keep mask [total_steps][batch][H]
     unsigned long long seed;    // in-kernel dropout stream when keep == nullptr
@@ -259,6 +262,28 @@ __device__ __forceinline__ void fxt_load8_agent(const float* p, long long stride
 }
 #endif
 
+// nothing is scheduled across this point (device); the emulator and the host have no scheduler to restrain
+#if FXT_DEVICE && !defined(FXT_EMUL)
+#define FXT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define FXT_SCHED_FENCE() ((void)0)
+#endif
+// experiment knob (round 5): how a block of MFMAs is delimited.  FXT_VAR 0: nothing; 1: fences (the block's MFMAs contiguous, no address
+// arithmetic among them); 2: fences + raised wave priority inside the block
+#ifndef FXT_VAR
+#define FXT_VAR 0
+#endif
+#if FXT_DEVICE && !defined(FXT_EMUL) && FXT_VAR == 1
+#define FXT_MMA_BEGIN() __builtin_amdgcn_sched_barrier(0)
+#define FXT_MMA_END() __builtin_amdgcn_sched_barrier(0)
+#elif FXT_DEVICE && !defined(FXT_EMUL) && FXT_VAR == 2
+#define FXT_MMA_BEGIN() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1); } while (0)
+#define FXT_MMA_END() do { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define FXT_MMA_BEGIN() ((void)0)
+#define FXT_MMA_END() ((void)0)
+#endif
+
 // q = x / d for 0 <= x < 2^16, 1 <= d < 2^16 without a hardware divide (an integer division is ~40 instructions on
 // the GPU and the GEMM tiles decompose their row index once each): q = (x * ceil(2^32 / d)) >> 32, exact in that range.
 struct FxtDiv { unsigned d, magic; };
@@ -270,6 +295,16 @@ FXT_HD int fxt_quot(int x, FxtDiv dv) {
 // Execution context of a workgroup: on the device one instance per thread, on the host ONE instance that plays
 // every thread in turn (a phase is data-parallel; phases are separated by fxt_sync).
 struct FxtWg { int tid, nthr; };
+// The wave's index as a SCALAR: tid >> 6 is the same in all 64 lanes, but the compiler cannot know it -- a tile loop dealt by
+// `tid >> 6` runs under exec masking with vector address arithmetic, an `if (wave-owned job)` becomes a divergent branch around every
+// MFMA (round 5: the weight-gradient loop's MFMAs each sat behind a saveexec / branch pair).  readfirstlane hands it over in an SGPR.
+FXT_HD int fxt_wave(const FxtWg& wg) {
+#if FXT_DEVICE && !defined(FXT_EMUL)
+    return __builtin_amdgcn_readfirstlane(wg.tid >> 6);
+#else
+    return wg.tid >> 6;
+#endif
+}
 #define FXT_FOR(i, count, wg) for (int i = (wg).tid; i < (count); i += (wg).nthr)
 FXT_HD void fxt_sync() {
 #if FXT_DEVICE
@@ -300,6 +335,7 @@ FXT_HD void fxt_sync_ws() {
 #define FXT_STAMP(k) do { } while (0)
 #endif
 
+FXT_HD long long fxt_pstride(const FxtJob& j) { return j.pstride ? j.pstride : j.net.P + 1; }
 FXT_HD bool fxt_keep(const FxtJob& j, int step, int slot, int h) {
     if (slot >= j.batch) return true;                    // a slot past the mini-batch (the last slice's overhang): no mask entry, no gradient
     if (j.keep) return j.keep[((long long)step * j.batch + slot) * j.net.H + h] != 0;
@@ -648,38 +684,38 @@ struct FxtConvGradW32 {        // input-gradient B((j, o), n = c) = W[j][c][o]: 
     FXT_HD float at(St s, int j, int k0) const { return w[s.base + j * 1024 + ((s.rot + k0) & 31)]; }
 };
 FXT_HD bool fxt_conv32_ok(int Md, int F, int nw) { return F == 32 && ((Md + 15) >> 4) <= nw; }
-// ROT: 0 = forward rotation (16 c), 1 = input-gradient rotation (2 c).  `G` taps per group (the host sized wbuf for G x 1024 floats).
-template <int WSAS, int WAS, int ROT, class FA, class FB, class FC>
-FXT_HD void fxt_conv32_staged(const FxtWg& wg, int Md, int Ko, const FA& fa, const FB& fb, const FC& fc,
-                              typename FxtMem<WAS>::CF wsrc, typename FxtMem<WSAS>::F wbuf, int G) {
-    if (G < 1) G = 1;
-    if (G > Ko) G = Ko;
+// A tap group on its way from L2 to the staging buffer: PF 16-byte pieces per thread in registers.  Carried ACROSS products and phase
+// barriers -- conv2's group is fetched while conv1 runs, conv3's first group behind conv2's MFMAs, conv3's input-gradient group while
+// the max-pool backward runs, conv2's behind conv3's input gradient -- so that no product starts by waiting for L2, and (backward) no
+// weight fetch is issued behind a phase's gradient-partial stores: vmcnt retires in order, a load issued after 78 KiB of partial stores
+// waits for all of them (round 5: conv2's backward phase took 30 us for ~10 us of work in every form; this was why).
+#define FXT_TAP_PF 2
+template <int WAS>
+struct FxtTapRegs {
 #if FXT_DEVICE
-    typedef float f4_t __attribute__((ext_vector_type(4)));
-    constexpr int U = 8, PF = 2;                           // PF 16-byte pieces per thread in flight: 8 taps at 1024 threads
-    {   const int gmax = PF * wg.nthr / 256;               // (a narrower workgroup -- the emulator's -- takes smaller groups)
-        if (G > gmax) G = gmax < 1 ? 1 : gmax; }
-    const int lane = wg.tid & 63, wave = wg.tid >> 6;
-    const int i = lane & 15, kq = lane >> 4;
-    const int tm = (Md + 15) >> 4;
-    const bool have = wave < tm;                           // (wave-uniform; fxt_conv32_ok: every M tile has its wave)
-    const int m = wave * 16 + i;
-    const auto sa = fa.prep((have && m < Md) ? m : 0, kq);
-    const auto sb0 = fb.prep(i, kq), sb1 = fb.prep(i + 16, kq);
-    f4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    f4_t pre[PF];
-    auto fetch = [&](int g0, int g1) {
-        const int pieces = (g1 - g0) * 256;
+    fxt_f4 pre[FXT_TAP_PF];
+#endif
+    int taps;                                              // taps held (0 = nothing)
+    FXT_HD void fetch(const FxtWg& wg, typename FxtMem<WAS>::CF wsrc, int g0, int g1) {      // taps [g0, g1) of a 32 x 32-per-tap kernel
+        taps = g1 - g0;
+#if FXT_DEVICE
+        const int pieces = taps * 256;
 #pragma unroll
-        for (int q = 0; q < PF; ++q) {
+        for (int q = 0; q < FXT_TAP_PF; ++q) {
             const int p = wg.tid + q * wg.nthr;
             if (p < pieces) pre[q] = *(typename FxtMem<WAS>::CF4)(wsrc + ((g0 * 32 + (p >> 3)) * 32 + 4 * (p & 7)));
         }
-    };
-    auto store = [&](int g0, int g1) {
-        const int pieces = (g1 - g0) * 256;
+#else
+        (void)wg; (void)wsrc; (void)g0;
+#endif
+    }
+    // into the staging buffer, rows rotated for the product that reads them (ROT 0: forward, column + 16 row; 1: input gradient, + 2 row)
+    template <int ROT, class WB>
+    FXT_HD void store(const FxtWg& wg, WB wbuf) {
+#if FXT_DEVICE
+        const int pieces = taps * 256;
 #pragma unroll
-        for (int q = 0; q < PF; ++q) {
+        for (int q = 0; q < FXT_TAP_PF; ++q) {
             const int p = wg.tid + q * wg.nthr;
             if (p < pieces) {
                 const int row = p >> 3, col = 4 * (p & 7), rot = ROT ? 2 * row : 16 * row;
@@ -687,35 +723,96 @@ FXT_HD void fxt_conv32_staged(const FxtWg& wg, int Md, int Ko, const FA& fa, con
                 for (int e = 0; e < 4; ++e) wbuf[row * 32 + ((col + e + rot) & 31)] = pre[q][e];
             }
         }
+#else
+        (void)wg; (void)wbuf;
+#endif
+        taps = 0;
+    }
+};
+// taps per group: what the host sized the buffer for, and what FXT_TAP_PF pieces per thread carry
+FXT_HD int fxt_conv32_group(int stage_taps, int nthr) {
+    const int gmax = FXT_TAP_PF * nthr / 256;
+    int G = stage_taps < gmax ? stage_taps : gmax;
+    return G < 1 ? 1 : G;
+}
+// ROT: 0 = forward rotation (16 c), 1 = input-gradient rotation (2 c).  `G` = fxt_conv32_group taps per group.
+// tap: the register carrier.  pre_loaded: it holds taps [0, min(G, Ko)) already.  in_wbuf: those taps are in wbuf already (stored and
+// published by an earlier barrier).  next_src / next_Ko: the NEXT product's kernel -- its first group is fetched into `tap` behind this
+// product's last group of MFMAs and left there.
+struct FxtNoDbg { FXT_HD void operator()(int) const {} };
+template <int WSAS, int WAS, int ROT, class FA, class FB, class FC, class DBG = FxtNoDbg>
+FXT_HD void fxt_conv32_staged(const FxtWg& wg, int Md, int Ko, const FA& fa, const FB& fb, const FC& fc,
+                              typename FxtMem<WAS>::CF wsrc, typename FxtMem<WSAS>::F wbuf, int G, FxtTapRegs<WAS>& tap,
+                              bool pre_loaded = false, bool in_wbuf = false, typename FxtMem<WAS>::CF next_src = nullptr, int next_Ko = 0,
+                              const DBG& dbg = DBG()) {
+    if (G < 1) G = 1;
+#if FXT_DEVICE
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    constexpr int U = 8;
+    const int lane = wg.tid & 63, wave = fxt_wave(wg);
+    const int i = lane & 15, kq = lane >> 4;
+    const int tm = (Md + 15) >> 4;
+    const bool have = wave < tm;                           // (wave-uniform; fxt_conv32_ok: every M tile has its wave)
+    const int m = wave * 16 + i;
+    const auto sa = fa.prep((have && m < Md) ? m : 0, kq);
+    const auto sb0 = fb.prep(i, kq), sb1 = fb.prep(i + 16, kq);
+    f4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const auto e0 = fc.pre(i), e1 = fc.pre(i + 16);        // what the epilogue needs per column (a bias from global memory): fetched now, not in a dependent chain at the end
+    // half a tap's operands: four k-steps of A and of both B tiles.  Half-tap h + 1's are fetched BEFORE half-tap h's eight MFMAs (two
+    // register sets of twelve, the loop unrolled by two): an LDS round trip hides behind ~256 cycles of matrix work instead of
+    // preceding it.  (Whole taps in flight -- 2 x 24 registers -- spilled at the 128 registers sixteen waves leave a thread.)
+    constexpr int UH = U / 2;
+    struct Ops { float a[UH], b0[UH], b1[UH]; };
+    auto load = [&](Ops& o, int h, int g0) {               // half-tap h of the group: tap g0 + h / 2, k-steps 4 (h & 1) ...
+        const int ko = g0 + (h >> 1), kb = 16 * (h & 1);
+#pragma unroll
+        for (int u = 0; u < UH; ++u) { o.a[u] = fa.at(sa, ko, kb + 4 * u); o.b0[u] = fb.at(sb0, ko - g0, kb + 4 * u); o.b1[u] = fb.at(sb1, ko - g0, kb + 4 * u); }
     };
-    fetch(0, G);
+    auto mma = [&](const Ops& o) {
+#pragma unroll
+        for (int u = 0; u < UH; ++u) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[u], o.b0[u], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[u], o.b1[u], acc1, 0, 0, 0);
+        }
+    };
+    if (!pre_loaded && !in_wbuf) tap.fetch(wg, wsrc, 0, G < Ko ? G : Ko);
     for (int g0 = 0; g0 < Ko; g0 += G) {
         const int g1 = g0 + G < Ko ? g0 + G : Ko;
-        fxt_sync_ws<WSAS>();                               // everybody is through with the previous group's taps (or the previous phase)
-        store(g0, g1);
-        if (g1 < Ko) fetch(g1, g1 + G < Ko ? g1 + G : Ko); // in flight behind this group's MFMAs
-        fxt_sync_ws<WSAS>();
-        if (!have) continue;
-        for (int ko = g0; ko < g1; ++ko) {
-            float a[U], b0[U], b1[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) { a[u] = fa.at(sa, ko, 4 * u); b0[u] = fb.at(sb0, ko - g0, 4 * u); b1[u] = fb.at(sb1, ko - g0, 4 * u); }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b0[u], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b1[u], acc1, 0, 0, 0);
-            }
+        if (!(in_wbuf && g0 == 0)) {
+            fxt_sync_ws<WSAS>();                           // everybody is through with the previous group's taps (or the previous phase)
+            tap.template store<ROT>(wg, wbuf);
         }
+        if (g1 < Ko) tap.fetch(wg, wsrc, g1, g1 + G < Ko ? g1 + G : Ko);       // in flight behind this group's MFMAs
+        else if (next_src) tap.fetch(wg, next_src, 0, G < next_Ko ? G : next_Ko);
+        fxt_sync_ws<WSAS>();
+        dbg(2 * (g0 / G));                                 // (profiling aid: this wave's clock before / after a group's MFMAs)
+        if (!have) continue;
+        Ops x, y;
+        const int H = 2 * (g1 - g0);                       // (even)
+        load(x, 0, g0);
+        for (int h = 0; h < H; h += 2) {
+            load(y, h + 1, g0);
+            FXT_SCHED_FENCE();                             // (the fetches stay IN FRONT of the MFMAs they hide behind: left alone, the scheduler sinks each one to just before its use)
+            FXT_MMA_BEGIN();
+            mma(x);
+            FXT_MMA_END();
+            load(x, h + 2 < H ? h + 2 : h, g0);            // (past the group's end: the same half-tap again, unused -- a straight-line body lets the waits be counted exactly)
+            FXT_SCHED_FENCE();
+            FXT_MMA_BEGIN();
+            mma(y);
+            FXT_MMA_END();
+        }
+        dbg(2 * (g0 / G) + 1);
     }
     if (have) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int mr = wave * 16 + 4 * kq + r;
-            if (mr < Md) { fc.put(mr, i, acc0[r]); fc.put(mr, i + 16, acc1[r]); }
+            if (mr < Md) { fc.put(mr, i, acc0[r], e0); fc.put(mr, i + 16, acc1[r], e1); }
         }
     }
 #else
-    (void)wg;
+    (void)wg; (void)tap; (void)pre_loaded; (void)in_wbuf; (void)next_src; (void)next_Ko;     // (the host build stages every group itself: the same values)
     float* accs = new float[(size_t)Md * 32]();
     for (int g0 = 0; g0 < Ko; g0 += G) {
         const int g1 = g0 + G < Ko ? g0 + G : Ko;
@@ -731,71 +828,109 @@ FXT_HD void fxt_conv32_staged(const FxtWg& wg, int Md, int Ko, const FA& fa, con
             }
     }
     for (int m = 0; m < Md; ++m)
-        for (int n = 0; n < 32; ++n) fc.put(m, n, accs[(size_t)m * 32 + n]);
+        for (int n = 0; n < 32; ++n) fc.put(m, n, accs[(size_t)m * 32 + n], fc.pre(n));
     delete[] accs;
 #endif
 }
 
 // Conv weight gradient of a 32 -> 32 channel layer over ROTATED rows (see above): x, dz position-major arrays of R x L1 rows,
-// fc.put(row (j 32 + c, or Kt 32 for the bias), column o, value).  Kt <= 20 taps.
+// fc.put(row (j 32 + c, or Kt 32 for the bias), column o, value).  Kt <= 20 taps.  `mid`: called by every wave ONCE, after its (first)
+// job's loop and before any of its gradient stores (the caller commits a prefetched tap group there: a barrier inside).
+// KT > 0: the tap count as a compile-time constant (canonical instantiations): a job's taps are then a constant per residue, its
+// MFMAs unconditional, and the register window turns over by renaming inside blocks of five k-steps instead of by moves.
 #define FXT_WG32_MAXT 5
-template <class P, class FC>
-FXT_HD void fxt_conv32_wgrad(const FxtWg& wg, int R, int L1, int Kt, int pl, P x, P dz, const FC& fc) {
+struct FxtNoHook { FXT_HD void operator()() const {} };
 #if FXT_DEVICE
-    typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef float fxt_acc4 __attribute__((ext_vector_type(4)));
+// one job's loops: taps res, res + 4, ... (NT of them; NT < 0: a run-time count `ntr`), channel tile at c, out-channel tile at o
+template <int NT, bool BIAS, class P>
+FXT_HD void fxt_wg32_job(int R, int L1, int res, int pl, int c, int o, int kq, int ntr, bool biasr, P x, P dz, P zero,
+                         fxt_acc4 (&acc)[FXT_WG32_MAXT], fxt_acc4& accb) {
+    constexpr int MT = FXT_WG32_MAXT;
+    const int S = (L1 + 3) >> 2, Sfull = L1 >> 2;          // k-steps of a row; those whose four positions all lie inside it
+    for (int rho = 0; rho < R; ++rho) {
+        const int base = rho * L1;
+        // x block b: position 4 b + kq + res - pl of the row, channel c (zero outside the row).  Fetch and mask are separate steps:
+        // the mask is applied where the value is USED, one k-step later, so nothing waits on LDS between a fetch and the MFMAs of
+        // the k-step it is issued in.
+        auto Xok = [&](int b) { const int pp = 4 * b + kq + res - pl; return pp >= 0 && pp < L1; };
+        // (positions outside the row are read from `zero`, a row of zeros in LDS: no select behind the fetch)
+        auto Xraw = [&](int b, bool ok) {
+            const int pp = 4 * b + kq + res - pl;
+            return *(ok ? x + fxt_xi<true>(base + pp, c, 32) : zero);
+        };
+        auto Braw = [&](int s, bool ok) {
+            const int t = 4 * s + kq;
+            return *(ok ? dz + fxt_xi<true>(base + t, o, 32) : zero);
+        };
+        float win[MT];                                     // win[(s + q) % MT] = x block s + q inside the blocks of MT k-steps below
+#pragma unroll
+        for (int q = 0; q < MT - 1; ++q) win[q] = Xraw(q, Xok(q));
+        bool xok = Xok(MT - 1), bok = kq < L1;
+        float xr = Xraw(MT - 1, xok), br = Braw(0, bok);
+        int s = 0;
+        if constexpr (NT >= 0) {
+            for (; s + MT <= Sfull; s += MT) {             // MT whole k-steps: the window's slots are compile-time constants
+#pragma unroll
+                for (int u = 0; u < MT; ++u) {
+                    win[(u + MT - 1) % MT] = xr;
+                    const float b = br;
+                    {   const int sn = s + u + 1;          // the next k-step's two fetches, behind this one's MFMAs (masked past the row's end)
+                        xok = Xok(sn + MT - 1); bok = 4 * sn + kq < L1;
+                        xr = Xraw(sn + MT - 1, xok); br = Braw(sn, bok); }
+                    FXT_SCHED_FENCE();
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(win[(u + q) % MT], b, acc[q], 0, 0, 0);
+                    if constexpr (BIAS) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, b, accb, 0, 0, 0);
+                }
+            }
+        }
+        const int nt = NT >= 0 ? NT : ntr;
+        const bool bias = NT >= 0 ? BIAS : biasr;
+        for (; s < S; ++s) {                               // the rest of the row (run-time tap counts: all of it): the window moves by copies
+            win[MT - 1] = xr;
+            const float b = br;
+            const bool tok = bok;                          // 4 s + kq < L1: false only in a row's last, partial k-step -- both operands zero there, as fxt_gemm masks them
+            if (s + 1 < S) {
+                xok = Xok(s + MT); bok = 4 * (s + 1) + kq < L1;
+                xr = Xraw(s + MT, xok); br = Braw(s + 1, bok);
+            }
+#pragma unroll
+            for (int q = 0; q < MT; ++q)
+                if (q < nt) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(tok ? win[q] : 0.f, b, acc[q], 0, 0, 0);
+            if (bias) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(tok ? 1.f : 0.f, b, accb, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < MT - 1; ++q) win[q] = win[q + 1];
+        }
+    }
+}
+#endif
+template <int KT = 0, class P, class FC, class HOOK = FxtNoHook>
+FXT_HD void fxt_conv32_wgrad(const FxtWg& wg, int R, int L1, int Kt, int pl, P x, P dz, P zero, const FC& fc, const HOOK& mid = HOOK()) {
+#if FXT_DEVICE
     constexpr int MT = FXT_WG32_MAXT;
     const int lane = wg.tid & 63, nw = wg.nthr >> 6;
     const int i = lane & 15, kq = lane >> 4;
-    const int S = (L1 + 3) >> 2;                           // k-steps of a row
-    for (int job = wg.tid >> 6; job < 16; job += nw) {     // (sixteen waves: one job each)
+    bool hooked = false;
+    for (int job = fxt_wave(wg); job < 16; job += nw) {    // (sixteen waves: one job each)
         const int res = job >> 2, ct = (job >> 1) & 1, ot = job & 1;
         const int NT = Kt > res ? (Kt - res + 3) >> 2 : 0; // taps res, res + 4, ... of this job (wave-uniform)
         const bool bias = res == 3 && ct == 0;
-        if (NT == 0 && !bias) continue;
         const int c = ct * 16 + i, o = ot * 16 + i;
-        f4_t acc[MT], accb = {0.f, 0.f, 0.f, 0.f};
+        fxt_acc4 acc[MT], accb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < MT; ++q) acc[q] = f4_t{0.f, 0.f, 0.f, 0.f};
-        for (int rho = 0; rho < R; ++rho) {
-            const int base = rho * L1;
-            // x block b: position 4 b + kq + res - pl of the row, channel c (zero outside the row)
-            auto X = [&](int b) {
-                const int pp = 4 * b + kq + res - pl;
-                const bool ok = pp >= 0 && pp < L1;
-#if defined(FXT_EMUL)
-                return ok ? x[fxt_xi<true>(base + pp, c, 32)] : 0.f;
-#else
-                const float v = x[ok ? fxt_xi<true>(base + pp, c, 32) : 0];
-                return ok ? v : 0.f;
-#endif
-            };
-            auto B = [&](int s) {
-                const int t = 4 * s + kq;
-                const bool ok = t < L1;
-#if defined(FXT_EMUL)
-                return ok ? dz[fxt_xi<true>(base + t, o, 32)] : 0.f;
-#else
-                const float v = dz[ok ? fxt_xi<true>(base + t, o, 32) : 0];
-                return ok ? v : 0.f;
-#endif
-            };
-            float win[MT];
-#pragma unroll
-            for (int q = 0; q < MT - 1; ++q) win[q] = X(q);
-            float xn = X(MT - 1), bn = B(0);
-            for (int s = 0; s < S; ++s) {
-                win[MT - 1] = xn;
-                const float b = bn;
-                if (s + 1 < S) { xn = X(s + MT); bn = B(s + 1); }        // the next k-step's two fetches behind this one's MFMAs
-                const bool tok = 4 * s + kq < L1;                        // (false only in a row's last, partial k-step: both operands zero there, as fxt_gemm masks them)
-#pragma unroll
-                for (int q = 0; q < MT; ++q)
-                    if (q < NT) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(tok ? win[q] : 0.f, b, acc[q], 0, 0, 0);
-                if (bias) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(tok ? 1.f : 0.f, b, accb, 0, 0, 0);
-#pragma unroll
-                for (int q = 0; q < MT - 1; ++q) win[q] = win[q + 1];
-            }
+        for (int q = 0; q < MT; ++q) acc[q] = fxt_acc4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (KT > 0) {
+            constexpr int N0 = (KT + 3) >> 2, N1 = KT > 1 ? (KT + 2) >> 2 : 0, N2 = KT > 2 ? (KT + 1) >> 2 : 0, N3 = KT > 3 ? KT >> 2 : 0;
+            if (res == 0) fxt_wg32_job<N0, false>(R, L1, res, pl, c, o, kq, NT, bias, x, dz, zero, acc, accb);
+            else if (res == 1) fxt_wg32_job<N1, false>(R, L1, res, pl, c, o, kq, NT, bias, x, dz, zero, acc, accb);
+            else if (res == 2) fxt_wg32_job<N2, false>(R, L1, res, pl, c, o, kq, NT, bias, x, dz, zero, acc, accb);
+            else if (bias) fxt_wg32_job<N3, true>(R, L1, res, pl, c, o, kq, NT, bias, x, dz, zero, acc, accb);
+            else fxt_wg32_job<N3, false>(R, L1, res, pl, c, o, kq, NT, bias, x, dz, zero, acc, accb);
+        } else {
+            fxt_wg32_job<-1, false>(R, L1, res, pl, c, o, kq, NT, bias, x, dz, zero, acc, accb);
         }
+        if (!hooked) { mid(); hooked = true; }
 #pragma unroll
         for (int q = 0; q < MT; ++q)
             if (q < NT) {
@@ -804,8 +939,10 @@ FXT_HD void fxt_conv32_wgrad(const FxtWg& wg, int R, int L1, int Kt, int pl, P x
             }
         if (bias && kq == 0) fc.put(Kt * 32, o, accb[0]);
     }
+    if (!hooked) mid();                                    // (more than sixteen waves: the rest still meets the hook's barrier)
 #else
-    (void)wg;
+    (void)wg; (void)zero;
+    mid();
     for (int mrow = 0; mrow <= Kt * 32; ++mrow)
         for (int o = 0; o < 32; ++o) {
             const int j = mrow >> 5, c = mrow & 31;
@@ -981,6 +1118,32 @@ struct FxtPosMajorBSwz {        // element (row r Lx + k0 + kq, channel n)
     FXT_HD float at(St st, int r, int k0) const { const int ru = r * Lx + k0; return p[st.off + ru * F + ((st.rot + 2 * ru) & (F - 1))]; }
 };
 
+// MODE 3: the same two A operands with positions outside the row sent to a row of zeros in LDS (`zoff`: its index relative to the
+// array) instead of a select on the fetched value -- the fetch then has no consumer but its MFMA, so it can be issued a half-tap ahead
+// (a select right behind the fetch made the compiler wait for LDS there), and four instructions per half-tap go away.  0.0 either way.
+template <class P>
+struct FxtConvAZ {
+    P x; int Lx, C, pl, zoff; FxtDiv dL;
+    struct St { int base, tp, rot; };
+    FXT_HD St prep(int m, int kq) const { const int r = fxt_quot(m, dL), t = m - r * Lx; return St{(m - pl) * C, t - pl, kq + 2 * (m - pl)}; }
+    FXT_HD float at(St s, int j, int k0) const {
+        const int p = s.tp + j;
+        const bool ok = p >= 0 && p < Lx;
+        return x[ok ? s.base + j * C + ((s.rot + 2 * j + k0) & (C - 1)) : zoff];
+    }
+};
+template <class P>
+struct FxtConvGradAZ {
+    P dz; int Lx, F, pl, zoff; FxtDiv dL;
+    struct St { int base, sp, rot; };
+    FXT_HD St prep(int m, int kq) const { const int r = fxt_quot(m, dL), s = m - r * Lx; return St{(m + pl) * F, s + pl, kq + 2 * (m + pl)}; }
+    FXT_HD float at(St st, int j, int k0) const {
+        const int p = st.sp - j;
+        const bool ok = p >= 0 && p < Lx;
+        return dz[ok ? st.base - j * F + ((st.rot - 2 * j + k0) & (F - 1)) : zoff];
+    }
+};
+
 // Compile-time shape of a CANONICAL network (round 4).  The step is written for any shape the constructors accept: every
 // contraction chooses among three k-step walks at run time, masks its overhangs, and builds its addresses from run-time
 // dimensions -- 100 KiB of code per placement, executed once per launch, i.e. streamed through the 64 KiB instruction cache
@@ -1023,10 +1186,13 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
     [[maybe_unused]] WsF wbuf = ws + w.total;
     [[maybe_unused]] const int stage_taps = j.split_off;
     [[maybe_unused]] const int tap_floats = MODE == 3 ? F * F : F * fxt_ld_w(F);
+    [[maybe_unused]] FxtTapRegs<WAS> tap;                  // MODE 3: the tap group in flight (see FxtTapRegs)
+    tap.taps = 0;
+    [[maybe_unused]] const int G3 = fxt_conv32_group(stage_taps, wg.nthr);
     const FxtLay y = fxt_lay(n, WAS == 3);      // (the LDS image of the weights has padded conv-kernel rows)
     const int ldF = w.ldF, ldw = y.ldw;
     WsI codes = (WsI)(ws + w.codes);
-    float* part = j.partial + (long long)slice * (n.P + 1);
+    float* part = j.partial + (long long)slice * fxt_pstride(j);
     const int32_t* order = j.order + (long long)step * j.batch;
     const int slot0 = slice * R;
     const int nwv = wg.nthr >> 6;
@@ -1037,6 +1203,12 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
     const float keep_scale = 1.f / (1.f - FXT_DROPOUT);
     const FxtDiv dL1 = fxt_div(n.kind == 0 ? n.L1 : 1), dF = fxt_div(n.kind == 0 ? F : 1), dA = fxt_div(A);
 
+    if constexpr (MODE == 3) {
+        if (n.kind == 0) {
+            tap.fetch(wg, W + y.cw[1], 0, G3 < n.K ? G3 : n.K);      // conv2's first tap group: two phases ahead
+            FXT_FOR(i, w.ldF, wg) ws[w.zero + i] = 0.f;              // the row of zeros (FxtConvAZ)
+        }
+    }
     // ---- the slice's rows as alphabet indices (padding slots read row 0: their gradient is zeroed at the loss)
     FXT_FOR(i, R * L, wg) {
         const int r = i / L, l = i - r * L;
@@ -1087,8 +1259,10 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         {   // conv2 ('same', K taps)
             WCF b = W + y.cb[1];
             struct Put { WsF y; WCF b; int ld; FXT_HD void put(int m, int nn, float v) const { v += b[nn]; y[fxt_xi<SWZ>(m, nn, ld)] = v > 0.f ? v : 0.f; } };
+            struct Put3 { WsF y; WCF b; int ld; FXT_HD float pre(int nn) const { return b[nn]; }
+                          FXT_HD void put(int m, int nn, float v, float bias) const { v += bias; y[fxt_xi<SWZ>(m, nn, ld)] = v > 0.f ? v : 0.f; } };
             if constexpr (MODE == 3)
-                fxt_conv32_staged<WSAS, WAS, 0>(wg, R * L1, K, ConvA{a1, L1, ldF, (K - 1) / 2, dL1}, FxtConvW32<WsCF>{wbuf}, Put{a2, b, ldF}, W + y.cw[1], wbuf, stage_taps);
+                fxt_conv32_staged<WSAS, WAS, 0>(wg, R * L1, K, FxtConvAZ<WsCF>{a1, L1, ldF, (K - 1) / 2, w.zero - w.a[0], dL1}, FxtConvW32<WsCF>{wbuf}, Put3{a2, b, ldF}, W + y.cw[1], wbuf, G3, tap, true, false, W + y.cw[2], n.K3);
             else if constexpr (MODE == 2)
                 fxt_gemm_staged<WSAS, WAS>(wg, R * L1, F, K, F, ConvA{a1, L1, ldF, (K - 1) / 2, dL1}, FxtConvW<WsCF>{wbuf, F, fxt_ld_w(F)}, Put{a2, b, ldF},
                                       W + y.cw[1], wbuf, stage_taps, F, F, fxt_ld_w(F));
@@ -1099,8 +1273,19 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         {   // conv3 ('same', A - 1 taps)
             WCF b = W + y.cb[2];
             struct Put { WsF y; WCF b; int ld; FXT_HD void put(int m, int nn, float v) const { v += b[nn]; y[fxt_xi<SWZ>(m, nn, ld)] = v > 0.f ? v : 0.f; } };
+            struct Put3 { WsF y; WCF b; int ld; FXT_HD float pre(int nn) const { return b[nn]; }
+                          FXT_HD void put(int m, int nn, float v, float bias) const { v += bias; y[fxt_xi<SWZ>(m, nn, ld)] = v > 0.f ? v : 0.f; } };
             if constexpr (MODE == 3)
-                fxt_conv32_staged<WSAS, WAS, 0>(wg, R * L1, n.K3, ConvA{a2, L1, ldF, (n.K3 - 1) / 2, dL1}, FxtConvW32<WsCF>{wbuf}, Put{a3, b, ldF}, W + y.cw[2], wbuf, stage_taps);
+                fxt_conv32_staged<WSAS, WAS, 0>(wg, R * L1, n.K3, FxtConvAZ<WsCF>{a2, L1, ldF, (n.K3 - 1) / 2, w.zero - w.a[1], dL1}, FxtConvW32<WsCF>{wbuf}, Put3{a3, b, ldF}, W + y.cw[2], wbuf, G3, tap, true, false, (WCF) nullptr, 0,
+                                                [&](int k) {           // profiling aid (train_trace): group 0 of conv3's forward -- every wave's clock at the end of its MFMAs (44 + wave); wave 0's at the group's start (60) and at the next group's (61)
+#if FXT_DEVICE
+                                                    if (j.dbg && slice == 0 && (wg.tid & 63) == 0) {
+                                                        if (k == 1) j.dbg[44 + (wg.tid >> 6)] = wall_clock64();
+                                                        if (k == 0 && wg.tid == 0) j.dbg[60] = wall_clock64();
+                                                        if (k == 2 && wg.tid == 0) j.dbg[61] = wall_clock64();
+                                                    }
+#endif
+                                                    (void)k; });
             else if constexpr (MODE == 2)
                 fxt_gemm_staged<WSAS, WAS>(wg, R * L1, F, n.K3, F, ConvA{a2, L1, ldF, (n.K3 - 1) / 2, dL1}, FxtConvW<WsCF>{wbuf, F, fxt_ld_w(F)}, Put{a3, b, ldF},
                                       W + y.cw[2], wbuf, stage_taps, F, F, fxt_ld_w(F));
@@ -1269,6 +1454,7 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         WsCF a1 = ws + w.a[0]; WsCF a2 = ws + w.a[1]; WsCF a3 = ws + w.a[2];
         WsCF g = ws + w.g; WsCF cnt = ws + w.cnt; WsCF dg = ws + w.dg;
         WsF dzA = ws + w.dzA; WsF dzB = ws + w.dzB;
+        if constexpr (MODE == 3) tap.fetch(wg, W + y.cw[2], 0, G3 < K3 ? G3 : K3);     // conv3's first group for the input gradient, behind this phase
         FXT_FOR(i, R * L1 * F, wg) {        // max-pool backward (ties share evenly) through conv3's ReLU
             const int f = i % F, rt = i / F, r = rt / L1;
             const float v = a3[fxt_xi<SWZ>(rt, f, ldF)];
@@ -1287,29 +1473,40 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         };
         const bool ag = j.agent_io != 0;
         struct PutX { WsF d; WsCF y; int ld; FXT_HD void put(int m, int nn, float v) const { d[fxt_xi<SWZ>(m, nn, ld)] = y[fxt_xi<SWZ>(m, nn, ld)] > 0.f ? v : 0.f; } };
+        struct PutX3 { WsF d; WsCF y; int ld; FXT_HD int pre(int) const { return 0; }
+                       FXT_HD void put(int m, int nn, float v, int) const { d[fxt_xi<SWZ>(m, nn, ld)] = y[fxt_xi<SWZ>(m, nn, ld)] > 0.f ? v : 0.f; } };
         // conv3: input gradient (few tiles, K3 x F / 4 k-steps) first, the weight gradient dealt on behind it
         if constexpr (MODE == 3)
-            fxt_conv32_staged<WSAS, WAS, 1>(wg, R * L1, K3, ConvGradA{dzA, L1, ldF, (K3 - 1) / 2, dL1}, FxtConvGradW32<WsCF>{wbuf}, PutX{dzB, a2, ldF}, W + y.cw[2], wbuf, stage_taps);
+            fxt_conv32_staged<WSAS, WAS, 1>(wg, R * L1, K3, FxtConvGradAZ<WsCF>{dzA, L1, ldF, (K3 - 1) / 2, w.zero - w.dzA, dL1}, FxtConvGradW32<WsCF>{wbuf}, PutX3{dzB, a2, ldF}, W + y.cw[2], wbuf, G3, tap, true, false,
+                                            W + y.cw[1], K);          // (leaves conv2's first group in `tap`: fetched BEFORE this phase's partial stores)
         else if constexpr (MODE == 2)
             fxt_gemm_staged<WSAS, WAS>(wg, R * L1, F, K3, F, ConvGradA{dzA, L1, ldF, (K3 - 1) / 2, dL1}, FxtConvGradW<WsCF>{wbuf, F, fxt_ld_w(F)}, PutX{dzB, a2, ldF},
                                   W + y.cw[2], wbuf, stage_taps, F, F, fxt_ld_w(F));
         else
         fxt_gemm(wg, R * L1, F, K3, F, ConvGradA{dzA, L1, ldF, (K3 - 1) / 2, dL1}, FxtConvGradW<WCF>{W + y.cw[2], F, ldw}, PutX{dzB, a2, ldF}, 0, split);
         if constexpr (MODE == 3)
-            fxt_conv32_wgrad(wg, R, L1, K3, (K3 - 1) / 2, a2, (WsCF)dzA, PutW{part + n.off_cw[2], part + n.off_cb[2], K3 * F, F, ag});
+        {   FXT_STAMP(40);
+            // the hook: conv2's group goes into the staging buffer (every wave is through with conv3's last group behind the barrier)
+            // before this phase's 78 KiB of partial stores are issued; conv2's input gradient then starts without touching global memory
+            auto commit = [&]() { fxt_sync_ws<WSAS>(); tap.template store<1>(wg, wbuf); FXT_STAMP(41); };
+            fxt_conv32_wgrad<D::fixed ? D::A - 1 : 0>(wg, R, L1, K3, (K3 - 1) / 2, a2, (WsCF)dzA, (WsCF)(ws + w.zero), PutW{part + n.off_cw[2], part + n.off_cb[2], K3 * F, F, ag}, commit);
+        }
         else
         fxt_gemm(wg, K3 * F + 1, F, R, L1, ConvWGradA{a2, L1, F, ldF, (K3 - 1) / 2, K3 * F, dF}, PosMajorB{dzA, L1, ldF}, PutW{part + n.off_cw[2], part + n.off_cb[2], K3 * F, F, ag}, fxt_jobs(R * L1, F, K3, F, nwv, can_split));
         fxt_sync_ws<WSAS>(); FXT_STAMP(10);
         // conv2
         if constexpr (MODE == 3)
-            fxt_conv32_staged<WSAS, WAS, 1>(wg, R * L1, K, ConvGradA{dzB, L1, ldF, (K - 1) / 2, dL1}, FxtConvGradW32<WsCF>{wbuf}, PutX{dzA, a1, ldF}, W + y.cw[1], wbuf, stage_taps);
+            fxt_conv32_staged<WSAS, WAS, 1>(wg, R * L1, K, FxtConvGradAZ<WsCF>{dzB, L1, ldF, (K - 1) / 2, w.zero - w.dzB, dL1}, FxtConvGradW32<WsCF>{wbuf}, PutX3{dzA, a1, ldF}, W + y.cw[1], wbuf, G3, tap, false, true);
         else if constexpr (MODE == 2)
             fxt_gemm_staged<WSAS, WAS>(wg, R * L1, F, K, F, ConvGradA{dzB, L1, ldF, (K - 1) / 2, dL1}, FxtConvGradW<WsCF>{wbuf, F, fxt_ld_w(F)}, PutX{dzA, a1, ldF},
                                   W + y.cw[1], wbuf, stage_taps, F, F, fxt_ld_w(F));
         else
         fxt_gemm(wg, R * L1, F, K, F, ConvGradA{dzB, L1, ldF, (K - 1) / 2, dL1}, FxtConvGradW<WCF>{W + y.cw[1], F, ldw}, PutX{dzA, a1, ldF}, 0, split);
         if constexpr (MODE == 3)
-            fxt_conv32_wgrad(wg, R, L1, K, (K - 1) / 2, a1, (WsCF)dzB, PutW{part + n.off_cw[1], part + n.off_cb[1], K * F, F, ag});
+        {   FXT_STAMP(42);
+            fxt_conv32_wgrad<D::fixed ? D::K : 0>(wg, R, L1, K, (K - 1) / 2, a1, (WsCF)dzB, (WsCF)(ws + w.zero), PutW{part + n.off_cw[1], part + n.off_cb[1], K * F, F, ag});
+            FXT_STAMP(43);
+        }
         else
         fxt_gemm(wg, K * F + 1, F, R, L1, ConvWGradA{a1, L1, F, ldF, (K - 1) / 2, K * F, dF}, PosMajorB{dzB, L1, ldF}, PutW{part + n.off_cw[1], part + n.off_cb[1], K * F, F, ag}, fxt_jobs(R * L1, F, K, F, nwv, can_split));
         fxt_sync_ws<WSAS>(); FXT_STAMP(11);
@@ -1321,7 +1518,8 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
 
 // Sum of the slices' partial gradients (slice order) + one Keras-Adam update of parameter i.
 FXT_HD void fxt_adam(const FxtJob& j, int step, int i) {
-    const int P = j.net.P, S = j.S;
+    const int S = j.S;
+    const long long ps = fxt_pstride(j);
     const float* part = j.partial + i;
     float gsum = 0.f;
 #if FXT_DEVICE
@@ -1331,12 +1529,12 @@ FXT_HD void fxt_adam(const FxtJob& j, int step, int i) {
         // Same sum (slice order), same update: same bits.
         for (int s0 = 0; s0 < S; s0 += 8) {
             float v[8];
-            fxt_load8_agent(part + (long long)s0 * (P + 1), (s0 + 8 <= S) ? (long long)(P + 1) : 0ll, v);   // (a ragged tail re-reads its first slice: handled below)
+            fxt_load8_agent(part + (long long)s0 * ps, (s0 + 8 <= S) ? ps : 0ll, v);   // (a ragged tail re-reads its first slice: handled below)
             if (s0 + 8 <= S) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) gsum += v[u];
             } else {
-                for (int u = 0; s0 + u < S; ++u) gsum += __hip_atomic_load(part + (long long)(s0 + u) * (P + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int u = 0; s0 + u < S; ++u) gsum += __hip_atomic_load(part + (long long)(s0 + u) * ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         const float b1 = (float)FXT_BETA_1, b2 = (float)FXT_BETA_2;
@@ -1354,7 +1552,7 @@ FXT_HD void fxt_adam(const FxtJob& j, int step, int i) {
 #if FXT_DEVICE
 #pragma unroll
 #endif
-        for (int u = 0; u < 32; ++u) v[u] = (s0 + u < S) ? part[(long long)(s0 + u) * (P + 1)] : 0.f;
+        for (int u = 0; u < 32; ++u) v[u] = (s0 + u < S) ? part[(long long)(s0 + u) * ps] : 0.f;
 #if FXT_DEVICE
 #pragma unroll
 #endif
@@ -1368,15 +1566,47 @@ FXT_HD void fxt_adam(const FxtJob& j, int step, int i) {
     j.w[i] = j.w[i] - j.lr_t[step] * m / (sqrtf(v) + FXT_EPSILON);
 }
 
+// The same update for parameters i4 ... i4 + 3 at once (device; rows of the partial array 16-byte aligned: FxtJob::pstride a multiple
+// of four, i4 a multiple of four, i4 + 3 < P).  A dword load per lane is 256 bytes per wave instruction and the kernel was bound by
+// the rate of those instructions, not by memory (round 5: 127 MB of partials of a GFP-length step in 77 us = 1.7 TB/s whatever the
+// number of loads in flight); 16 bytes per lane quarters them.  Every parameter's additions in the same (slice) order: the same bits.
+#if defined(__HIPCC__)
+__device__ __forceinline__ void fxt_adam4(const FxtJob& j, int step, int i4) {
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    const int S = j.S;
+    const long long ps = fxt_pstride(j);
+    const float* part = j.partial + i4;
+    f4_t g = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < S; s0 += 24) {
+        f4_t v[24];
+#pragma unroll
+        for (int u = 0; u < 24; ++u) v[u] = (s0 + u < S) ? *reinterpret_cast<const f4_t*>(part + (long long)(s0 + u) * ps) : f4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 24; ++u) { g[0] += v[u][0]; g[1] += v[u][1]; g[2] += v[u][2]; g[3] += v[u][3]; }
+    }
+    const float b1 = (float)FXT_BETA_1, b2 = (float)FXT_BETA_2, lr = j.lr_t[step];
+    f4_t m = *reinterpret_cast<const f4_t*>(j.adam_m + i4), v = *reinterpret_cast<const f4_t*>(j.adam_v + i4), w = *reinterpret_cast<const f4_t*>(j.w + i4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        m[c] = b1 * m[c] + (1.f - b1) * g[c];
+        v[c] = b2 * v[c] + (1.f - b2) * g[c] * g[c];
+        w[c] = w[c] - lr * m[c] / (sqrtf(v[c]) + FXT_EPSILON);
+    }
+    *reinterpret_cast<f4_t*>(j.adam_m + i4) = m;
+    *reinterpret_cast<f4_t*>(j.adam_v + i4) = v;
+    *reinterpret_cast<f4_t*>(j.w + i4) = w;
+}
+#endif
+
 FXT_HD void fxt_step_loss(const FxtJob& j, int step) {
     const int sidx = step % j.steps_per_epoch;
     const int nvalid = (j.n - sidx * j.batch) < j.batch ? (j.n - sidx * j.batch) : j.batch;
     float sse = 0.f;
 #if FXT_DEVICE
     if (j.agent_io) {
-        for (int s = 0; s < j.S; ++s) sse += __hip_atomic_load(&j.partial[(long long)s * (j.net.P + 1) + j.net.P], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int s = 0; s < j.S; ++s) sse += __hip_atomic_load(&j.partial[(long long)s * fxt_pstride(j) + j.net.P], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else
 #endif
-    for (int s = 0; s < j.S; ++s) sse += j.partial[(long long)s * (j.net.P + 1) + j.net.P];
+    for (int s = 0; s < j.S; ++s) sse += j.partial[(long long)s * fxt_pstride(j) + j.net.P];
     j.step_loss[step] = sse / (float)nvalid;
 }

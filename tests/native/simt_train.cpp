@@ -71,7 +71,8 @@ static void run_slice(const FxtJob& j, int mode, int nthr, int slice, const Simt
             t_tid = tid;
             const FxtWg wg{tid, nthr};
             const uint8_t* a = p.ascii.data(); const uint8_t* l = p.lut.data(); const float* y = p.labels.data();
-            if (mode == 3) fxt_forward_backward<3, 1, FxtDimsAny, 3>(j, wg, 0, slice, a, l, y, lds, (const float*)j.w, (float*)nullptr);
+            if (mode == 4) fxt_forward_backward<3, 1, FxtDims<0, 20, 32, 100, 5, 1>, 3>(j, wg, 0, slice, a, l, y, lds, (const float*)j.w, (float*)nullptr);
+            else if (mode == 3) fxt_forward_backward<3, 1, FxtDimsAny, 3>(j, wg, 0, slice, a, l, y, lds, (const float*)j.w, (float*)nullptr);
             else if (mode == 2) fxt_forward_backward<3, 1, FxtDimsAny, 2>(j, wg, 0, slice, a, l, y, lds, (const float*)j.w, (float*)nullptr);
             else if (mode == 1) fxt_forward_backward<3, 1, FxtDimsAny, 1>(j, wg, 0, slice, a, l, y, lds, (const float*)j.w, (float*)nullptr);
             else fxt_forward_backward<3, 1, FxtDimsAny, 0>(j, wg, 0, slice, a, l, y, lds, (const float*)j.w, (float*)nullptr);
@@ -98,7 +99,7 @@ static std::vector<float> emul_step(const SimtProblem& p, int mode, int nthr, in
         j.ws_slice = fxt_ws(j.net, p.R, true).total + stage_taps * j.net.F * fxt_ld_w(j.net.F);
         j.split_off = stage_taps;
     }
-    if (mode == 3) {                                       // (a tap = 32 rotated rows of 32 floats)
+    if (mode >= 3) {                                       // (a tap = 32 rotated rows of 32 floats; mode 4 = the canonical protein instantiation of mode 3)
         j.ws_slice = fxt_ws(j.net, p.R, true).total + stage_taps * 1024;
         j.split_off = stage_taps;
     }
@@ -182,7 +183,7 @@ int main(int argc, char** argv) {
         {1, 9, 4, 0, 20, 0, 19, 8, 128},         // MLP: dense layers only, one-hot weight gradient
         {2, 14, 20, 0, 24, 0, 7, 4, 64},         // GlobalEpistasis on one wave
         {0, 68, 4, 32, 20, 5, 1, 1, 512},        // 64 positions: the rotated modes' max-pool shared by 32 threads per channel; 4 x 2 conv tiles on 8 waves
-        {0, 37, 20, 32, 12, 5, 1, 1, 1024},      // sixteen waves (the device's workgroup): the F = 32 form's weight gradient deals one job per wave; 19 taps of conv3
+        {0, 37, 20, 32, 100, 5, 1, 1, 1024},      // sixteen waves (the device's workgroup): the F = 32 form's weight gradient deals one job per wave; 19 taps of conv3
     };
     if (!quick) {
         cases.push_back({0, 70, 20, 32, 100, 5, 1, 1, 512});     // 5 x 2 conv tiles on 8 waves
@@ -211,6 +212,11 @@ int main(int argc, char** argv) {
                 got = emul_step(p, 3, c.nthr, taps, &part);
                 bad += same("gradient partials", part_ref, part, p, 3, c.nthr, taps);
                 bad += same("weights", want, got, p, 3, c.nthr, taps);
+                if (c.A == 20 && c.H == 100 && c.K == 5 && c.R == 1 && taps != 1) {      // k_train_fb_c32p's instantiation: compile-time tap counts, the window renamed in blocks of five k-steps
+                    got = emul_step(p, 4, c.nthr, taps, &part);
+                    bad += same("gradient partials", part_ref, part, p, 4, c.nthr, taps);
+                    bad += same("weights", want, got, p, 4, c.nthr, taps);
+                }
             }
         }
         if ((c.F & 31) || !fxt_staged_ok(c.R * L1, c.F, c.F, c.F, c.nthr / 64)) continue;
