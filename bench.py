@@ -59,20 +59,24 @@ def cpu_baseline(budget_s=12.0, hard_timeout_s=150.0, nam=False, nam_budget_s=3.
 def roofline_block(kind, Lx, A, Hx, Fx, Kx, members, n, kern_ms, kernel_name):
     """Both MFMA fractions of one scoring launch, from its measured duration.
 
-    frac         ALGORITHMIC FLOP (2 x dense MACs x members x sequences, not discounted for
-                 one-hot sparsity or 'same'-padding zeros) / kernel_ms / peak.  The kernels do not issue those
-                 structural zeros, so this figure can exceed 1 on long launches.
-    frac_issued  MFMA instructions the launch really issues (fx_debug_mfma_per_tile: the kernels' loop bounds
-                 restated on the host, x ceil(n/16) tiles x members) x 2048 FLOP / kernel_ms / peak: <= 1."""
+    frac (= frac_issued)  MFMA instructions the launch really issues (fx_debug_mfma_per_tile: the kernels' loop bounds
+                 restated on the host, x ceil(n/16) tiles x members) x 2048 FLOP / kernel_ms / peak: the physical
+                 fraction of the matrix pipe, <= 1.  `achieved` is that rate in TFLOP/s.
+    frac_algorithmic  ALGORITHMIC FLOP (2 x dense MACs x members x sequences, not discounted for
+                 one-hot sparsity or 'same'-padding zeros) / kernel_ms / peak (`achieved_algorithmic`).  The kernels do
+                 not issue those structural zeros, so this figure can exceed 1 on long launches (round-4 verdict:
+                 a headline `frac` that can exceed 1 is not a roofline fraction -- it moved here)."""
     from flexs_amd import _native, synth
 
     macs = synth.algorithmic_macs(kind, Lx, A, Hx, Fx, Kx)
     flop = 2.0 * macs * members * n
     per_tile = _native.mfma_per_tile(KINDS[kind], Lx, A, Fx, Hx, Kx)
     issued = float(per_tile) * ((n + 15) // 16) * members * MFMA_FLOP
-    ach = flop / (kern_ms * 1e-3) / 1e12
+    ach_alg = flop / (kern_ms * 1e-3) / 1e12
+    ach = issued / (kern_ms * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": kernel_name, "achieved": ach, "peak": PEAK_TF, "unit": "TFLOP/s",
-            "frac": ach / PEAK_TF, "frac_issued": issued / (kern_ms * 1e-3) / 1e12 / PEAK_TF,
+            "frac": ach / PEAK_TF, "frac_issued": ach / PEAK_TF,
+            "achieved_algorithmic": ach_alg, "frac_algorithmic": ach_alg / PEAK_TF,
             "kernel_ms": kern_ms, "flop_per_launch": flop, "issued_flop_per_launch": issued,
             "mfma_per_tile": per_tile, "algorithmic_bytes_per_launch": (Lx + 4 * members) * n}
 
@@ -81,7 +85,7 @@ def pmc_block():
     """PMC figures cannot be sampled from inside the process; they come from the rocprofv3 --pmc passes over this
     same command (tools/gpu_round4.sh), committed under profiles/ -- the file is named, with the commit it was taken at
     (`commit` inside the file, else the last commit that touched it), so the numbers can be traced."""
-    for name in ("r4_pmc_bench.json", "r3_pmc_bench.json", "r2_pmc_bench.json", "r1_pmc_traffic.json"):
+    for name in ("r5_pmc_bench.json", "r4_pmc_bench.json", "r3_pmc_bench.json", "r2_pmc_bench.json", "r1_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             d = json.load(open(path))
@@ -107,9 +111,11 @@ def make_report(world, N, steps, warmup, elapsed, host_issue_s, kern_ms, use_dis
     roof["traffic"] = pmc["hbm_bytes_per_launch"]
     roof["mfma_util_pmc"] = pmc["mfma_util"]
     roof["pmc_source"] = pmc["source"]
-    roof["note"] = ("frac = algorithmic FLOP (2*MACs, SURVEY.md 8d) / kernel_ms / 157.3 TFLOP/s; it counts one-hot multiplies "
+    roof["note"] = ("frac = achieved / peak with achieved = MFMA instructions issued x 2048 FLOP / kernel_ms (the physical fraction "
+                    "of the f32 matrix pipe, <= 1; frac_issued is the same number under its old name). frac_algorithmic = "
+                    "algorithmic FLOP (2*MACs, SURVEY.md 8d) / kernel_ms / 157.3 TFLOP/s; it counts one-hot multiplies "
                     "and 'same'-padding zero taps the kernel never issues, so it can exceed 1 on long launches. "
-                    "frac_issued = MFMA instructions issued x 2048 FLOP / kernel_ms / peak (<= 1). mfma_util_pmc = "
+                    "Flat keys c1_* ... train_* carry every BASELINE config (see flat_scalars in bench.py). mfma_util_pmc = "
                     "SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMD x CU-cycles) from the rocprofv3 --pmc pass named in pmc_source; "
                     "traffic = FETCH_SIZE x2 + WRITE_SIZE from the same passes")
     if mode == "sequence":
@@ -225,17 +231,23 @@ def configs_block(eng, device, torch):
         ("C3 mlp L=14 A=4 H=100 M=1 N=1e5", "mlp", 14, "UGCA", 1, 100_000, "k_score_dense_mfma<MLP>"),
         ("C4 ge L=90 A=20 H=100 M=8 N=1e5", "ge", 90, AAS, 8, 100_000, "k_score_dense_mfma<GE>"),
         ("C5 cnn L=237 A=20 M=3 N=62500 (one GPU's share of 5e5)", "cnn", 237, AAS, 3, 62_500, "k_score_cnn_pair"),
+        # wide hidden layers (round-4 verdict item 4): H = 200 is DynaPPOEnsemble's default MLP member (dyna_ppo.py:52-55) and the Tutorial's
+        ("survey mlp H200 L14 N1e5", "mlp", 14, "UGCA", 1, 100_000, "k_score_dense_mfma<MLP>", 200),
+        ("survey cnn H200 L8 N1e5", "cnn", 8, "TGCA", 1, 100_000, "k_score_cnn_mfma", 200),
+        ("survey ge M1 L90 N1e5", "ge", 90, AAS, 1, 100_000, "k_score_dense_mfma<GE>", 100),
     ]
     out = {}
-    for name, kind, Lx, alpha, members, n, kname in specs:
-        mods = build_members(kind, Lx, alpha, members, device)
+    for spec in specs:
+        name, kind, Lx, alpha, members, n, kname = spec[:7]
+        Hx = spec[7] if len(spec) > 7 else H
+        mods = build_members(kind, Lx, alpha, members, device, Hx=Hx)
         d_in = torch.from_numpy(synth.random_sequence_bytes(n, Lx, alpha, 0)).cuda()
         stride = (n + 63) // 64 * 64
         d_planes = torch.empty((members, stride), dtype=torch.float32, device="cuda")
         torch.cuda.synchronize()
         ms, reps = time_launches(eng, mods, d_in.data_ptr(), n, Lx, mods[0]._lut, d_planes, stride)
         Fx, Kx = (F, K) if kind == "cnn" else (0, 0)
-        blk = roofline_block(kind, Lx, len(alpha), H, Fx, Kx, members, n, ms, kname)
+        blk = roofline_block(kind, Lx, len(alpha), Hx, Fx, Kx, members, n, ms, kname)
         blk["seq_per_s"] = n / (ms * 1e-3)
         blk["reps"] = reps
         out[name] = blk
@@ -508,6 +520,23 @@ def explorer_round_block(device, torch):
             os.environ.pop("FLEXS_AMD_TRAIN", None)
         else:
             os.environ["FLEXS_AMD_TRAIN"] = prev
+    # the fits BASELINE configs[3] / configs[4] retrain through every round (flexs/explorer.py:157-160): protein lengths, 20 letters
+    try:
+        for Lp, key in ((237, "train_3xCNN_L237_n500_ms"), (90, "train_3xCNN_L90_n500_ms")):
+            pens = flexs_amd.Ensemble(build_members("cnn", Lp, AAS, 3, device))
+            pseqs = synth.bytes_to_strings(synth.random_sequence_bytes(500, Lp, AAS, 3))
+            py = np.random.default_rng(0).random(500)
+            pens.train(pseqs, py); torch.cuda.synchronize()
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter(); pens.train(pseqs, py); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+            out[key] = min(ts) * 1e3
+            del pens
+        # forward + input-gradient + weight-gradient products of one row-step = 3 x 2 x dense MACs (6 485 108 at L = 237),
+        # 500 rows x 20 epochs x 3 members per fit
+        out["train_3xCNN_L237_frac_of_peak"] = 3 * 2.0 * synth.algorithmic_macs("cnn", 237, 20, H, F, K) * 500 * 20 * 3 / (out["train_3xCNN_L237_n500_ms"] * 1e-3) / 1e12 / PEAK_TF
+    except Exception as ex:  # noqa: BLE001 - never at the cost of the line
+        out["train_protein_error"] = f"{type(ex).__name__}: {ex}"[:200]
     for i in range(2):
         random.seed(1)
         c0 = ens.cost
@@ -620,6 +649,71 @@ def _sig(x, digits=4):
     return None if x is None else float(f"{float(x):.{digits}g}")
 
 
+def flat_scalars(out):
+    """Round-4 verdict item 2: the driver's parse keeps `roofline` / `config` but only their SCALAR members, so every BASELINE
+    config's figures are also written as flat keys of `roofline` (numbers only).  cN = BASELINE.json configs[N-1]:
+    c1 1xCNN L8 N1e4, c2_1e4 3xCNN L8 N1e4, c3 MLP L14 N1e5, c4 8xGE L90 N1e5, c5 3xCNN L237 N62500; k4 = the
+    NoisyAbstractModel neighbour search; e2e_* = get_fitness(list[str]) end to end; train_* = Ensemble.train fits;
+    *_frac_issued = MFMA instructions issued x 2048 FLOP / time / 157.3 TFLOP/s.  Pure function of `out`."""
+    flat = {}
+
+    def put(key, val, digits=4):
+        if isinstance(val, bool) or val is None:
+            return
+        if isinstance(val, (int, float)) and np.isfinite(val):
+            flat[key] = _sig(val, digits)
+
+    confs = out.get("configs") or {}
+    names = {"C1 cnn L=8 A=4 M=1 N=1e4": "c1", "C2 cnn L=8 A=4 M=3 N=1e4": "c2_1e4", "C3 mlp L=14 A=4 H=100 M=1 N=1e5": "c3",
+             "C4 ge L=90 A=20 H=100 M=8 N=1e5": "c4", "C5 cnn L=237 A=20 M=3 N=62500 (one GPU's share of 5e5)": "c5"}
+    for key, tag in names.items():
+        b = confs.get(key)
+        if isinstance(b, dict):
+            put(f"{tag}_kernel_ms", b.get("kernel_ms"))
+            put(f"{tag}_frac_issued", b.get("frac_issued", b.get("frac")))
+            put(f"{tag}_frac_algorithmic", b.get("frac_algorithmic"))
+            put(f"{tag}_seq_per_s", b.get("seq_per_s"))
+    for key, b in confs.items():
+        if isinstance(b, dict) and key.startswith("survey "):       # wide-hidden-layer rows (H = 200) of the perf survey
+            tag = key[len("survey "):].lower().replace(" ", "_").replace("=", "")
+            put(f"{tag}_kernel_ms", b.get("kernel_ms")); put(f"{tag}_frac_issued", b.get("frac_issued")); put(f"{tag}_frac_algorithmic", b.get("frac_algorithmic"))
+    nam = next((v for k, v in confs.items() if k.startswith("C3 nam")), None)
+    if isinstance(nam, dict):
+        for k, v in (nam.get("k4") or {}).items():
+            if isinstance(v, dict) and isinstance(v.get("roofline"), dict):
+                put("k4_" + k.split()[-1].lower().replace("=", ""), v["roofline"].get("frac"))        # k4_c100, k4_c1000, k4_c20000: int-VALU fraction
+                put("k4_" + k.split()[-1].lower().replace("=", "") + "_kernel_ms", v.get("kernel_ms"))
+        for k in ("plain_landscape", "batch_safe_landscape", "device_table_landscape_L8"):
+            if isinstance(nam.get(k), dict):
+                put(f"nam_{k.lower()}_seq_per_s", nam[k].get("value"))
+    st = out.get("settled")
+    if isinstance(st, dict):
+        put("settled_kernel_ms", st.get("kernel_ms")); put("settled_frac_issued", st.get("frac_issued")); put("settled_value", st.get("value"))
+        put("settled_frac_algorithmic", st.get("frac_algorithmic"))
+    e2e = out.get("end_to_end") or {}
+    for key, v in e2e.items():
+        if key.endswith(" list_str") and isinstance(v, dict):
+            tag = key.split()[0].lower()                            # C2 / C3 / C4 / C5
+            put(f"e2e_{tag}_seq_per_s", v.get("value")); put(f"e2e_{tag}_wall_ms", v.get("wall_ms"))
+            put(f"e2e_{tag}_frac_of_kernel", v.get("frac_of_kernel_rate"))
+    for k, pre in (("small_call_us", "small_call"), ("small_call_us_launch_per_call", "small_call_launched")):
+        for n, v in (e2e.get(k) or {}).items():
+            put(f"{pre}_n{n}_us", v, 3)
+    pat = out.get("explorer_patterns") or {}
+    for k, pre in (("dynappo_8xGE_L90_us", "dynappo"), ("cmaes_3xCNN_L237_us", "cmaes")):
+        for n, v in (pat.get(k) or {}).items():
+            put(f"{pre}_{str(n).lower().replace(' ', '_').replace('=', '')}_us", v, 3)
+    er = out.get("explorer_round") or {}
+    put("train_l8_ms", er.get("train_3xCNN_n1000_ms")); put("adalead_round_ms", er.get("adalead_round_ms"))
+    put("train_l237_ms", er.get("train_3xCNN_L237_n500_ms")); put("train_l237_frac_of_peak", er.get("train_3xCNN_L237_frac_of_peak"))
+    put("train_l90_ms", er.get("train_3xCNN_L90_n500_ms")); put("train_l237_fb_kernel_ms", er.get("train_L237_fb_kernel_ms"))
+    for k, v in (out.get("member_parallel") or {}).items():
+        if isinstance(v, dict):
+            tag = k.lower().replace(" ", "_").replace("=", "")
+            put(f"mp_{tag}_speedup", v.get("speedup_vs_1gpu")); put(f"mp_{tag}_seq_per_s", v.get("value"))
+    return flat
+
+
 def compact_record(out):
     """The path, not just the headline, inside the two objects a downstream parser of the contract line keeps: `roofline`
     gets `per_config` (kernel time and both MFMA fractions of every BASELINE.json config, K4's integer-VALU fractions),
@@ -629,6 +723,7 @@ def compact_record(out):
     roof, cfg = out["roofline"], out["config"]
     per = {"C2 3xCNN L8 N1e5 (headline)": {"kernel_ms": _sig(roof.get("kernel_ms")), "frac": _sig(roof.get("frac")),
                                           "frac_issued": _sig(roof.get("frac_issued"))}}
+    roof.update(flat_scalars(out))                          # scalars survive a parser that drops nested objects
     short = {"C1 cnn L=8 A=4 M=1 N=1e4": "C1 1xCNN L8 N1e4", "C2 cnn L=8 A=4 M=3 N=1e4": "C2 3xCNN L8 N1e4",
              "C3 mlp L=14 A=4 H=100 M=1 N=1e5": "C3 MLP L14 N1e5", "C4 ge L=90 A=20 H=100 M=8 N=1e5": "C4 8xGE L90 N1e5",
              "C5 cnn L=237 A=20 M=3 N=62500 (one GPU's share of 5e5)": "C5 3xCNN L237 N62500"}
@@ -645,7 +740,7 @@ def compact_record(out):
         if k in confs:
             per[k] = confs[k]
     if out.get("prepared_train_swizzle"):
-        per["train GFP-length CNN, train_swizzle 0/1/2 (prepared forms, default off)"] = out["prepared_train_swizzle"]
+        per["train GFP-length CNN by train_swizzle form (0 plain, 1 rotated rows, 2 staged kernels, 3 = default F=32 form)"] = out["prepared_train_swizzle"]
     if len(per) > 1:
         roof["per_config"] = per
     path = {}
@@ -893,7 +988,7 @@ def main():
             rep = make_report(world, N, s_steps, 0, s_el, 0.0, s_kern, use_dist, args.mode, head_members)
             out["settled"] = {"steps": s_steps, "value": rep["value"], "ms_per_step": rep["ms_per_step"],
                               "kernel_ms": s_kern, "frac": rep["roofline"]["frac"],
-                              "frac_issued": rep["roofline"]["frac_issued"],
+                              "frac_issued": rep["roofline"]["frac_issued"], "frac_algorithmic": rep["roofline"]["frac_algorithmic"],
                               "what": f">= {MIN_TIMED_S} s timed region, same step, run right after the K steps above"}
         out["rccl_ranks"] = dist.get_world_size() if use_dist else 0     # ranks RCCL reports (0: no communicator)
         if args.debug_share_device:

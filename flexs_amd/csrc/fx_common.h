@@ -12,7 +12,7 @@
 
 #define FX_MAX_M 16          // models fused per launch (larger ensembles are split)
 #define FX_ERR_BADCHAR 1u    // bit in the deferred device error word
-#define FX_LP_BAR_BYTES (18 * 128)   // barrier counters of the layer-parallel protein form: top + 16 groups, a 128-byte line each; line 17: units finished (completion flag)
+#define FX_LP_BAR_BYTES (19 * 128)   // barrier counters of the layer-parallel protein form: top + 16 groups, a 128-byte line each; line 17: units finished (completion flag); line 18: a pre-launched instance's go / leave decision
 #define FX_ERR_TIMEOUT 2u    // a device-side barrier (layer-parallel protein form) was not passed in time
 // The resident form (score_cnn_quad.hip / score_dense_small.hip, SERVER).  Round 3: <= 16 tile slots per member on a third
 // of the CUs, one tile per slot and request -> 256 sequences.  Round 4 (engine option serve_wide): a generation may take
@@ -211,6 +211,7 @@ struct fx_engine {
         int64_t stride = 0;
         uint8_t lut[256];
         unsigned seq = 0;                                // the instance's completion-flag value; its request word = (seq << 16) | N
+        const void* out_dev = nullptr; const void* scratch2 = nullptr; const void* zero_pool = nullptr;   // buffers baked into the armed launch (round-4 advisor: compared, not assumed)
         std::chrono::steady_clock::time_point t{};
     } lp_armed;
     bool lp_arm_next = false;        // launch_lp: make this launch a pre-launched instance

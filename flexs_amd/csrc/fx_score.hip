@@ -1,0 +1,596 @@
+// C ABI of libflexs_amd.so, part 2 of 5 (fx_internal.h): the scoring entry points -- fx_score and its device / planes / piecewise
+// forms, the launch planner, one-hot encode, ensemble reduction, argmax decode (+ score).
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "fx_common.h"
+#include "fx_internal.h"
+#include "myers.h"
+#include "np_sum.h"
+#include <atomic>
+#include <mutex>
+#include <chrono>
+
+extern "C" {
+
+// ------------------------------------------------------------------ scoring
+
+// planar_stride == 0: d_NM is the row-major (N, M) matrix of the ABI; > 0: M member planes that far apart.
+int score_dispatch(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N, int L,
+                          float* d_NM, int64_t planar_stride) {
+    if (!e->lp_arm_next) lp_disarm(e);                     // (a pre-launched instance of another call shape holds the CUs: it leaves)
+    e->lp_launches = 0;
+    e->dispatch_groups = 0;
+    // a launch whose workgroups would not all find a CU beside the resident ones tells those to leave (they hold most of their
+    // CU's LDS: a persistent workgroup that has to wait for one of them would wait for their idle exit)
+    if (e->server.running && (int64_t)M * ((N + 15) / 16) + e->server.wgs > e->num_cus) server_stop(e);
+    if (e->poison_outputs && !e->lp_arm_next)   // scores are nan_to_num'ed, so a NaN that survives is an element no kernel wrote
+        // (not for a pre-launched instance: the memset would run between the end of the instance being answered and the host
+        //  reading ITS results from the same pinned planes; lp_serve_armed poisons them on the host instead)
+        FX_HIP(e, hipMemsetAsync(d_NM, 0xFF, sizeof(float) * (planar_stride ? (size_t)planar_stride * (size_t)M : (size_t)N * (size_t)M), e->stream));
+    struct Layout {                                     // the launchers read the layout from the engine
+        fx_engine* e;
+        Layout(fx_engine* e_, int64_t s) : e(e_) { e->planar_stride = s; }
+        ~Layout() { e->planar_stride = 0; }
+    } layout(e, planar_stride);
+    // group consecutive members into launches of <= FX_MAX_M homogeneous models
+    for (int m0 = 0; m0 < M;) {
+        int cnt = 1;
+        const FxShape& s0 = models[m0]->shape;
+        while (m0 + cnt < M && cnt < FX_MAX_M) {
+            const FxShape& s = models[m0 + cnt]->shape;
+            if (s.kind != s0.kind || s.F != s0.F || s.H != s0.H || s.K != s0.K) break;
+            ++cnt;
+        }
+        int rc = FX_EUNSUPPORTED;
+        e->dispatch_groups += 1;
+        e->done_armed = false;                             // (only the LAST launch of a dispatch may offer the completion flag)
+        if (!e->force_generic) {
+            if (s0.kind == FX_CNN) {
+                rc = fx_launch_score_cnn_mfma(e, models + m0, cnt, d_ascii, N, d_NM, M, m0);
+                if (rc == FX_EUNSUPPORTED) rc = fx_launch_score_cnn_split(e, models + m0, cnt, d_ascii, N, d_NM, M, m0);
+            }
+            else rc = fx_launch_score_dense_mfma(e, models + m0, cnt, d_ascii, N, d_NM, M, m0);
+        }
+        if (rc == FX_EUNSUPPORTED) rc = fx_launch_score_generic(e, models + m0, cnt, d_ascii, N, d_NM, M, m0);
+        if (rc) return rc;
+        m0 += cnt;
+    }
+    (void)L;
+    return FX_OK;
+}
+
+// score into member-major planes, then the NumPy-order mean -- in the scoring kernel itself where a launcher offers it
+static int score_then_mean(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N, int L,
+                           float* d_planes, int64_t stride, float* mean_dst) {
+    e->fuse_mean_out = (e->fuse_mean && stride && M > 1 && M <= 16) ? mean_dst : nullptr;
+    e->fused_mean_done = false;
+    const int rc = score_dispatch(e, models, M, d_ascii, N, L, d_planes, stride);
+    e->fuse_mean_out = nullptr;
+    if (rc) return rc;
+    if (e->fused_mean_done) return FX_OK;
+    return fx_launch_ensemble_mean_planar(e, d_planes, N, M, stride, mean_dst);
+}
+
+int validate_models(fx_engine* e, fx_model* const* models, int M, int L, const uint8_t* lut) {
+    if (!e || !models || M < 1 || !lut) return FX_EINVAL;
+    for (int m = 0; m < M; ++m) {
+        if (!models[m]) return fx_fail(e, FX_EINVAL, "null model handle");
+        if (models[m]->eng != e) return fx_fail(e, FX_EINVAL, "model belongs to another engine");
+        if (!models[m]->has_weights) return fx_fail(e, FX_ESTATE, "model weights were never set");
+        if (models[m]->shape.L != L) return fx_fail(e, FX_ESHAPE, "sequence length does not match the model's seq_len");
+        if (models[m]->shape.A != models[0]->shape.A) return fx_fail(e, FX_ESHAPE, "ensemble members use different alphabets");
+    }
+    for (int c = 0; c < 256; ++c)
+        if (lut[c] != 0xFF && lut[c] >= models[0]->shape.A) return fx_fail(e, FX_EINVAL, "LUT entry >= alphabet size");
+    return FX_OK;
+}
+
+int fx_score_dev(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N, int L,
+                 const uint8_t lut[256], float* d_out_NM, float* d_out_mean) {
+    int rc = validate_models(e, models, M, L, lut);
+    if (rc) return rc;
+    if (N < 0) return fx_fail(e, FX_EINVAL, "negative batch size");
+    if (N == 0) return FX_OK;
+    if (!d_ascii || (!d_out_NM && !d_out_mean)) return fx_fail(e, FX_EINVAL, "null buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    e->counters.device_calls += 1; e->counters.sequences += N; e->counters.forwards += N * M;
+    rc = fx_upload_lut(e, lut);
+    if (rc) return rc;
+    float* d_NM = d_out_NM;
+    if (!d_NM) {
+        // only the mean is wanted: the intermediate is the engine's own, laid out member-major (contiguous stores)
+        const int64_t stride = M <= 16 ? planar_stride_for(N) : 0;
+        void* p = nullptr;
+        rc = fx_scratch(e, 1, sizeof(float) * (stride ? (size_t)stride * (size_t)M : (size_t)N * (size_t)M), &p);
+        if (rc) return rc;
+        d_NM = (float*)p;
+        if (stride) return score_then_mean(e, models, M, d_ascii, N, L, d_NM, stride, d_out_mean);
+    }
+    rc = score_dispatch(e, models, M, d_ascii, N, L, d_NM);
+    if (rc) return rc;
+    if (d_out_mean) rc = fx_launch_ensemble_reduce(e, d_NM, N, M, nullptr, d_out_mean, nullptr);
+    return rc;
+}
+
+// The two halves of the mean-only device path, for callers that keep the intermediate themselves (bench.py times
+// them separately): scores as M member-major planes `stride` floats apart, then np.mean over the planes.
+int fx_score_planes_dev(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N, int L,
+                        const uint8_t lut[256], float* d_planes, int64_t stride) {
+    int rc = validate_models(e, models, M, L, lut);
+    if (rc) return rc;
+    if (N < 0 || stride < N || (stride & 3)) return fx_fail(e, FX_EINVAL, "fx_score_planes_dev: stride must be >= N and a multiple of 4");
+    if (N == 0) return FX_OK;
+    if (!d_ascii || !d_planes || (reinterpret_cast<uintptr_t>(d_planes) & 15)) return fx_fail(e, FX_EINVAL, "null or unaligned buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    if ((rc = fx_upload_lut(e, lut))) return rc;
+    e->counters.device_calls += 1; e->counters.sequences += N; e->counters.forwards += N * M;
+    return score_dispatch(e, models, M, d_ascii, N, L, d_planes, stride);
+}
+
+int fx_ensemble_mean_planes_dev(fx_engine* e, const float* d_planes, int64_t N, int M, int64_t stride, float* d_out_mean) {
+    if (!e || N < 0 || M < 1 || M > 16 || stride < N || (stride & 3)) return FX_EINVAL;
+    if (N == 0) return FX_OK;
+    if (!d_planes || !d_out_mean || (reinterpret_cast<uintptr_t>(d_planes) & 15)) return fx_fail(e, FX_EINVAL, "null or unaligned buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    lp_disarm(e);                                          // (a pre-launched scoring instance holds most CUs until its idle limit: this call's kernels are queued behind it)
+    return fx_launch_ensemble_mean_planar(e, d_planes, N, M, stride, d_out_mean);
+}
+
+int fx_staging_input(fx_engine* e, int64_t bytes, void** host) {
+    if (!e || bytes < 0 || !host) return FX_EINVAL;
+    FX_HIP(e, hipSetDevice(e->device));
+    return fx_pinned(e, 0, (size_t)std::max<int64_t>(bytes, 1), host);
+}
+
+// How a host call (host bytes in, host scores out) should move its data.
+//   zero-copy  the kernels read the sequences from the mapped pinned staging area over PCIe and write the scores to
+//              pinned memory: no copy enqueues, no dependent copy -> kernel -> copy chain.  Every MEMBER's units read the
+//              bytes again (host memory is not cached in L2), so the traffic is M x N x L bytes: worth it when that
+//              hides behind the kernels (3 x CNN L = 8: 24 bytes per sequence against 0.3 MFLOP), ruinous when it does
+//              not (8 x GlobalEpistasis L = 90: 72 MB for a 0.15 ms launch; measured 1.43 ms vs 0.44 ms).
+//   pieces     > 1: pack + submit in pieces so that the host's string marshalling overlaps the GPU's work.
+// Model: t_kernel from the MFMA instructions the launch issues (fx_mfma_per_tile) at 75 % of the pipe; PCIe at 45 GB/s
+// for in-kernel reads, 35 GB/s + 25 us of enqueue / dependency latency for the copy path (profiles/r3_e2e_ab.log).
+static void plan_host_call(const fx_engine* e, fx_model* const* models, int M, int64_t N, int L, bool* zero_copy, int* pieces) {
+    const double bytes = (double)N * (double)L;
+    double t_k = 0.0;
+    bool mfma = true;
+    for (int m = 0; m < M; ++m) {
+        const int64_t per_tile = models[m]->mfma_per_tile;       // (3.7 us per call of a three-member 237-residue ensemble when recomputed here)
+        if (per_tile < 0) { mfma = false; break; }
+        t_k += (double)per_tile * (double)((N + 15) / 16) * 32.0 / ((double)e->num_cus * 4.0 * 2.4e9) / 0.75;
+    }
+    const double t_zc = std::max(t_k, (double)M * bytes / 45e9);
+    const double t_copy = bytes / 35e9 + t_k + 25e-6;
+    bool zc = mfma && t_zc < t_copy;
+    if (e->zero_copy_mode == 0) zc = false;
+    if (e->zero_copy_mode == 1) zc = true;
+    // Pieces only pay when the host's marshalling (~20 GB/s with the packing threads + ~1 ns per string) is a visible
+    // share of the call AND every piece still fills the machine for a while (a piece shorter than ~0.25 ms of kernel
+    // time loses more to its start-up and tail than the overlap wins: 7 pieces of a 17.6 ms protein batch cost 3 ms).
+    const double t_pack = bytes / 20e9 + (double)N * 1e-9;
+    int p = 1;
+    if (t_pack > 0.15 * t_k || !mfma) {
+        p = zc ? (int)(bytes / (2 << 20) + 0.5)                           // ~2 MB of sequence bytes per piece
+               : (bytes >= (double)(16 << 20) ? (int)(bytes / (4 << 20)) : 1);   // big uploads: 4 MB pieces
+        const int cap = mfma ? (int)(t_k / 250e-6) : 16;
+        if (p > cap) p = cap;
+    }
+    *zero_copy = zc;
+    *pieces = p < 1 ? 1 : (p > 16 ? 16 : p);
+}
+
+int fx_plan_host_call(fx_engine* e, fx_model* const* models, int M, int64_t N, int L, int* zero_copy, int* pieces) {
+    if (!e || !models || M < 1 || N < 0 || L < 1 || !zero_copy || !pieces) return FX_EINVAL;
+    for (int m = 0; m < M; ++m) if (!models[m]) return FX_EINVAL;
+    bool zc = false;
+    plan_host_call(e, models, M, N, L, &zc, pieces);
+    *zero_copy = zc ? 1 : 0;
+    return FX_OK;
+}
+
+int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii, int64_t N, int L,
+             const uint8_t lut[256], float* out_NM, float* out_mean) {
+    int rc = validate_models(e, models, M, L, lut);
+    if (rc) return rc;
+    if (N < 0) return fx_fail(e, FX_EINVAL, "negative batch size");
+    if (N == 0) return FX_OK;
+    if (!ascii || (!out_NM && !out_mean)) return fx_fail(e, FX_EINVAL, "null buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    if (e->lp_armed.on) {
+        // a pre-launched instance of ANOTHER call leaves now, before this call's buffer management can wait for it on the stream
+        const auto& pa = e->lp_armed;
+        bool same = (int)pa.models.size() == M && pa.N == N && pa.L == L;
+        for (int m = 0; same && m < M; ++m) same = pa.models[m] == models[m];
+        if (!same) lp_disarm(e);
+    }
+    {
+        rc = server_call(e, models, M, ascii, N, L, lut, out_NM, out_mean);
+        if (rc != FX_EUNSUPPORTED) return rc;
+    }
+    // characters outside the alphabet are detected on the device (deferred error word)
+    const size_t in_bytes = (size_t)N * (size_t)L;
+    const size_t nm_bytes = sizeof(float) * (size_t)N * (size_t)M, mean_bytes = sizeof(float) * (size_t)N;
+    void *d_in = nullptr, *h_in = nullptr, *h_out = nullptr;
+    if ((rc = fx_scratch(e, 0, in_bytes, &d_in))) return rc;
+    if ((rc = fx_pinned(e, 0, in_bytes, &h_in))) return rc;
+    // mean only: member-major planes as the intermediate (see fx_score_dev)
+    const int64_t stride = (!out_NM && M <= 16) ? planar_stride_for(N) : 0;
+    const size_t inter_bytes = stride ? sizeof(float) * (size_t)stride * (size_t)M : nm_bytes;
+    // explorer-size mean-only calls that are LAUNCHED (the protein CNN, shapes without a resident form): the member planes go
+    // straight to pinned host memory and the mean is taken here -- M x N floats over PCIe instead of N, and no second launch
+    // (~6 us of a 50 us call)
+    const bool host_mean = stride && M > 1 && N <= e->host_mean_below;
+    if ((rc = fx_pinned(e, 1, std::max(nm_bytes, host_mean ? inter_bytes : (size_t)0) + mean_bytes, &h_out))) return rc;
+    void* d_out = nullptr;
+    if ((rc = fx_scratch(e, 1, inter_bytes + mean_bytes, &d_out))) return rc;
+    float* d_NM = (float*)d_out;
+    float* d_mean = (float*)((char*)d_out + inter_bytes);
+    if (ascii != h_in) std::memcpy(h_in, ascii, in_bytes);   // (fx_staging_input callers marshalled straight into it)
+    if ((rc = fx_upload_lut(e, lut))) return rc;
+    bool plan_zc = false;
+    int plan_pieces = 1;
+    plan_host_call(e, models, M, N, L, &plan_zc, &plan_pieces);
+    e->counters.host_calls += 1; e->counters.sequences += N; e->counters.forwards += N * M;
+    if (in_bytes + nm_bytes + mean_bytes <= (size_t)e->zero_copy_bytes || plan_zc) {
+        e->counters.zero_copy_calls += 1;
+        // Small call (what Adalead / CMA-ES / DynaPPO issue): zero-copy through the mapped pinned
+        // staging buffers -- the kernels read the sequences from, and write the scores to, host memory over
+        // PCIe; two memcpy enqueues and their latencies disappear from the call.
+        void *dm_in = nullptr, *dm_out = nullptr;
+        FX_HIP(e, hipHostGetDevicePointer(&dm_in, h_in, 0));
+        FX_HIP(e, hipHostGetDevicePointer(&dm_out, h_out, 0));
+        float* m_NM = (float*)dm_out;
+        float* m_mean = (float*)((char*)dm_out + nm_bytes);
+        if (host_mean) {
+            e->call_prof_ns[0] = server_since(e);
+            // a pre-launched instance of exactly this call (the caller is back within the idle window): no launch, no weight fill
+            bool served = lp_armed_matches(e, models, M, N, L, lut, stride, 1, m_NM) && lp_serve_armed(e, models, M, ascii, N, L, lut, m_NM, stride, 1, h_out, inter_bytes);
+            if (!served) {
+                if ((rc = score_dispatch(e, models, M, (const uint8_t*)dm_in, N, L, m_NM, stride))) return rc;
+                e->call_prof_ns[1] = server_since(e);
+                // answered by the layer-parallel form alone: its NEXT instance is enqueued now, beside this one's work
+                const bool lp = e->done_armed && e->lp_launches == 1 && e->dispatch_groups == 1;
+                const unsigned seq = lp ? e->done_seq : 0;
+                if (lp) lp_arm(e, models, M, N, L, lut, m_NM, stride, 1);
+                if ((rc = wait_for_results(e, seq))) return rc;
+            }
+            e->call_prof_ns[2] = server_since(e);
+            if ((rc = check_deferred(e))) return rc;
+            host_mean_planes((const float*)h_out, stride, N, M, out_mean);
+            e->call_prof_ns[3] = server_since(e);
+            return FX_OK;
+        } else if (stride) {
+            if ((rc = score_then_mean(e, models, M, (const uint8_t*)dm_in, N, L, d_NM, stride, m_mean))) return rc;
+            e->done_armed = false;                         // (the mean kernel, or a fused mean, is the last writer)
+        } else {
+            const bool plain_matrix = out_NM && !out_mean && N <= e->host_mean_below;
+            const bool served = plain_matrix && lp_armed_matches(e, models, M, N, L, lut, 0, 2, m_NM) && lp_serve_armed(e, models, M, ascii, N, L, lut, m_NM, 0, 2, h_out, nm_bytes);
+            unsigned seq = 0;
+            if (!served) {
+                if ((rc = score_dispatch(e, models, M, (const uint8_t*)dm_in, N, L, out_NM ? m_NM : d_NM, stride))) return rc;
+                if (out_mean) {
+                    if ((rc = fx_launch_ensemble_reduce(e, out_NM ? m_NM : d_NM, N, M, nullptr, m_mean, nullptr))) return rc;
+                    e->done_armed = false;
+                }
+                if (plain_matrix && e->done_armed && e->lp_launches == 1 && e->dispatch_groups == 1) {
+                    seq = e->done_seq;
+                    lp_arm(e, models, M, N, L, lut, m_NM, 0, 2);
+                }
+            }
+            if (served) e->done_armed = false;
+            else if ((rc = wait_for_results(e, seq))) return rc;   // (the last launch's completion flag where it offers one, else the stream)
+            if ((rc = check_deferred(e))) return rc;
+            if (out_NM) std::memcpy(out_NM, h_out, nm_bytes);
+            if (out_mean) std::memcpy(out_mean, (char*)h_out + nm_bytes, mean_bytes);
+            return FX_OK;
+        }
+        if ((rc = wait_for_results(e))) return rc;         // (the mean kernel was the last writer: the stream)
+    } else {
+        e->counters.bytes_h2d += (int64_t)in_bytes;
+        e->counters.bytes_d2h += (int64_t)((out_mean ? mean_bytes : 0) + (out_NM ? nm_bytes : 0));
+        FX_HIP(e, hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, e->stream));
+        if (stride) rc = score_then_mean(e, models, M, (const uint8_t*)d_in, N, L, d_NM, stride, d_mean);
+        else rc = score_dispatch(e, models, M, (const uint8_t*)d_in, N, L, d_NM, stride);
+        if (rc) return rc;
+        if (out_mean) {
+            if (!stride && (rc = fx_launch_ensemble_reduce(e, d_NM, N, M, nullptr, d_mean, nullptr))) return rc;
+            FX_HIP(e, hipMemcpyAsync((char*)h_out + nm_bytes, d_mean, mean_bytes, hipMemcpyDeviceToHost, e->stream));
+        }
+        if (out_NM) FX_HIP(e, hipMemcpyAsync(h_out, d_NM, nm_bytes, hipMemcpyDeviceToHost, e->stream));
+        FX_HIP(e, hipStreamSynchronize(e->stream));
+    }
+    if ((rc = check_deferred(e))) return rc;
+    if (out_NM) std::memcpy(out_NM, h_out, nm_bytes);
+    if (out_mean) std::memcpy(out_mean, (char*)h_out + nm_bytes, mean_bytes);
+    return FX_OK;
+}
+
+// ---- the same call in pieces: the caller fills the pinned staging area chunk by chunk and submits each chunk
+// as soon as it is ready, so that marshalling chunk k+1 on the host overlaps transfer + scoring of chunk k.
+int fx_score_begin(fx_engine* e, fx_model* const* models, int M, int64_t N, int L, const uint8_t lut[256],
+                   int want_nm, int want_mean, void** staging) {
+    int rc = validate_models(e, models, M, L, lut);
+    if (rc) return rc;
+    if (N < 1 || !staging || (!want_nm && !want_mean)) return fx_fail(e, FX_EINVAL, "fx_score_begin: bad arguments");
+    if (e->chunked.active) return fx_fail(e, FX_ESTATE, "fx_score_begin: a chunked call is already in flight");
+    FX_HIP(e, hipSetDevice(e->device));
+    const size_t in_bytes = (size_t)N * (size_t)L;
+    const size_t nm_bytes = sizeof(float) * (size_t)N * (size_t)M, mean_bytes = sizeof(float) * (size_t)N;
+    void *d_in = nullptr, *h_in = nullptr, *h_out = nullptr, *d_out = nullptr;
+    if ((rc = fx_scratch(e, 0, in_bytes + 16, &d_in))) return rc;
+    if ((rc = fx_pinned(e, 0, in_bytes, &h_in))) return rc;
+    if ((rc = fx_pinned(e, 1, nm_bytes + mean_bytes, &h_out))) return rc;
+    if ((rc = fx_scratch(e, 1, nm_bytes + mean_bytes, &d_out))) return rc;
+    if ((rc = fx_upload_lut(e, lut))) return rc;
+    auto& c = e->chunked;
+    c.models.assign(models, models + M);
+    c.N = N; c.L = L; c.want_nm = want_nm != 0; c.want_mean = want_mean != 0;
+    c.h_in = (uint8_t*)h_in; c.d_in = (uint8_t*)d_in;
+    c.d_nm = (float*)d_out; c.d_mean = (float*)((char*)d_out + nm_bytes);
+    c.h_out = (char*)h_out;
+    c.pieces = 0;
+    { int unused = 1; plan_host_call(e, models, M, N, L, &c.zero_copy, &unused); }
+    c.active = true;
+    *staging = h_in;
+    return FX_OK;
+}
+
+int fx_score_submit(fx_engine* e, int64_t row0, int64_t rows) {
+    if (!e) return FX_EINVAL;
+    auto& c = e->chunked;
+    if (!c.active) return fx_fail(e, FX_ESTATE, "fx_score_submit without fx_score_begin");
+    if (row0 < 0 || rows < 0 || row0 + rows > c.N) return fx_fail(e, FX_EINVAL, "fx_score_submit: rows out of range");
+    if (rows == 0) return FX_OK;
+    FX_HIP(e, hipSetDevice(e->device));
+    const int M = (int)c.models.size();
+    const size_t nm_bytes = sizeof(float) * (size_t)c.N * (size_t)M;
+    int rc;
+    // transfers on the copy stream, kernels on the compute stream, one event triple per piece: the upload of piece k + 1
+    // (packed by the host while piece k runs) and the download of piece k - 1 overlap piece k's kernels
+    if (c.pieces >= fx_engine::MAX_PIECES) return fx_fail(e, FX_EINVAL, "fx_score_submit: more than 32 pieces in one call");
+    if (c.pieces == 0) { e->counters.host_calls += 1; e->counters.zero_copy_calls += c.zero_copy ? 1 : 0; }
+    e->counters.sequences += rows; e->counters.forwards += rows * M;
+    if (!c.zero_copy) {
+        e->counters.bytes_h2d += rows * c.L;
+        e->counters.bytes_d2h += (int64_t)sizeof(float) * rows * ((c.want_mean ? 1 : 0) + (c.want_nm ? M : 0));
+    }
+    if (c.zero_copy) {
+        // no copy enqueues at all: the piece's kernels read its bytes from the pinned staging area over PCIe (L bytes
+        // per sequence against ~1e5 FLOP: the reads hide behind the MFMA work) and the results land in pinned memory
+        void *dm_in = nullptr, *dm_out = nullptr;
+        FX_HIP(e, hipHostGetDevicePointer(&dm_in, c.h_in, 0));
+        FX_HIP(e, hipHostGetDevicePointer(&dm_out, c.h_out, 0));
+        float* m_nm = (float*)dm_out + row0 * M;
+        float* m_mean = (float*)((char*)dm_out + nm_bytes) + row0;
+        float* nm = c.want_nm ? m_nm : c.d_nm + row0 * M;
+        if ((rc = score_dispatch(e, c.models.data(), M, (const uint8_t*)dm_in + row0 * c.L, rows, c.L, nm))) return rc;
+        if (c.want_mean && (rc = fx_launch_ensemble_reduce(e, nm, rows, M, nullptr, m_mean, nullptr))) return rc;
+        const int k = c.pieces;
+        FX_HIP(e, hipEventRecord(e->ev_out[k], e->stream));
+        c.row0[k] = row0; c.rows[k] = rows;
+        ++c.pieces;
+        return FX_OK;
+    }
+#if defined(FX_AB)
+    const bool two = e->chunk_overlap != 0;
+#else
+    const bool two = false;                               // (the two-stream form measured slower: A/B build only)
+#endif
+    hipStream_t cs = two ? e->copy_stream : e->stream;
+    const int k = c.pieces;
+    FX_HIP(e, hipMemcpyAsync(c.d_in + row0 * c.L, c.h_in + row0 * c.L, (size_t)rows * c.L, hipMemcpyHostToDevice, cs));
+    if (two) {
+        FX_HIP(e, hipEventRecord(e->ev_in[k], cs));
+        FX_HIP(e, hipStreamWaitEvent(e->stream, e->ev_in[k], 0));
+    }
+    float* nm = c.d_nm + row0 * M;
+    if ((rc = score_dispatch(e, c.models.data(), M, c.d_in + row0 * c.L, rows, c.L, nm))) return rc;
+    if (c.want_mean)
+        if ((rc = fx_launch_ensemble_reduce(e, nm, rows, M, nullptr, c.d_mean + row0, nullptr))) return rc;
+    if (two) {
+        FX_HIP(e, hipEventRecord(e->ev_done[k], e->stream));
+        FX_HIP(e, hipStreamWaitEvent(cs, e->ev_done[k], 0));
+    }
+    if (c.want_mean)
+        FX_HIP(e, hipMemcpyAsync(c.h_out + nm_bytes + sizeof(float) * row0, c.d_mean + row0, sizeof(float) * rows,
+                                 hipMemcpyDeviceToHost, cs));
+    if (c.want_nm)
+        FX_HIP(e, hipMemcpyAsync(c.h_out + sizeof(float) * row0 * M, nm, sizeof(float) * rows * M, hipMemcpyDeviceToHost, cs));
+    FX_HIP(e, hipEventRecord(e->ev_out[k], cs));
+    c.row0[k] = row0; c.rows[k] = rows;
+    ++c.pieces;
+    return FX_OK;
+}
+
+int fx_score_finish(fx_engine* e, float* out_NM, float* out_mean) {
+    if (!e) return FX_EINVAL;
+    auto& c = e->chunked;
+    if (!c.active) return fx_fail(e, FX_ESTATE, "fx_score_finish without fx_score_begin");
+    c.active = false;
+    FX_HIP(e, hipSetDevice(e->device));
+    const int M = (int)c.models.size();
+    const size_t nm_bytes = sizeof(float) * (size_t)c.N * (size_t)M;
+    // piece by piece: the host copies piece k out of the pinned area while the GPU still works on the later ones
+    // (a character outside the alphabet in ANY piece fails the call: the results are only trusted after the last check)
+    for (int k = 0; k < c.pieces; ++k) {
+        FX_HIP(e, hipEventSynchronize(e->ev_out[k]));
+        if (c.want_nm && out_NM)
+            std::memcpy(out_NM + c.row0[k] * M, c.h_out + sizeof(float) * c.row0[k] * M, sizeof(float) * (size_t)c.rows[k] * M);
+        if (c.want_mean && out_mean)
+            std::memcpy(out_mean + c.row0[k], c.h_out + nm_bytes + sizeof(float) * c.row0[k], sizeof(float) * (size_t)c.rows[k]);
+    }
+    FX_HIP(e, hipStreamSynchronize(e->copy_stream));
+    FX_HIP(e, hipStreamSynchronize(e->stream));
+    return check_deferred(e);
+}
+
+int fx_encode_onehot_dev(fx_engine* e, const uint8_t* d_ascii, int64_t N, int L, const uint8_t lut[256], int A,
+                         float* d_one_hot) {
+    if (!e || !lut || N < 0 || L < 0 || A < 1) return FX_EINVAL;
+    if (N == 0 || L == 0) return FX_OK;
+    if (!d_ascii || !d_one_hot) return fx_fail(e, FX_EINVAL, "null buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    lp_disarm(e);                                          // (a pre-launched scoring instance holds most CUs until its idle limit: this call's kernels are queued behind it)
+    int rc = fx_upload_lut(e, lut);
+    if (rc) return rc;
+    return fx_launch_encode_onehot(e, d_ascii, N, L, A, d_one_hot);
+}
+
+int fx_encode_onehot(fx_engine* e, const uint8_t* ascii, int64_t N, int L, const uint8_t lut[256], int A,
+                     float* one_hot) {
+    if (!e || !lut || N < 0 || L < 0 || A < 1) return FX_EINVAL;
+    if (N == 0 || L == 0) return FX_OK;
+    if (!ascii || !one_hot) return fx_fail(e, FX_EINVAL, "null buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    lp_disarm(e);                                          // (a pre-launched scoring instance holds most CUs until its idle limit: this call's kernels are queued behind it)
+    const size_t in_bytes = (size_t)N * L, out_bytes = sizeof(float) * (size_t)N * L * A;
+    void *d_in = nullptr, *d_out = nullptr;
+    int rc;
+    if ((rc = fx_scratch(e, 0, in_bytes, &d_in))) return rc;
+    if ((rc = fx_scratch(e, 1, out_bytes, &d_out))) return rc;
+    FX_HIP(e, hipMemcpyAsync(d_in, ascii, in_bytes, hipMemcpyHostToDevice, e->stream));
+    if ((rc = fx_upload_lut(e, lut))) return rc;
+    if ((rc = fx_launch_encode_onehot(e, (const uint8_t*)d_in, N, L, A, (float*)d_out))) return rc;
+    FX_HIP(e, hipMemcpyAsync(one_hot, d_out, out_bytes, hipMemcpyDeviceToHost, e->stream));
+    FX_HIP(e, hipStreamSynchronize(e->stream));
+    return check_deferred(e);
+}
+
+int fx_ensemble_reduce_dev(fx_engine* e, const float* d_scores, int64_t N, int M, const double* weights,
+                           float* d_out32, double* d_out64) {
+    if (!e || N < 0 || M < 1) return FX_EINVAL;
+    if (N == 0) return FX_OK;
+    if (!d_scores || (weights ? !d_out64 : !d_out32)) return fx_fail(e, FX_EINVAL, "null buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    lp_disarm(e);                                          // (a pre-launched scoring instance holds most CUs until its idle limit: this call's kernels are queued behind it)
+    const double* d_w = nullptr;
+    if (weights) {
+        void* p = nullptr;
+        int rc = fx_scratch(e, 3, sizeof(double) * (size_t)M, &p);
+        if (rc) return rc;
+        FX_HIP(e, hipMemcpyAsync(p, weights, sizeof(double) * (size_t)M, hipMemcpyHostToDevice, e->stream));
+        FX_HIP(e, hipStreamSynchronize(e->stream));       // `weights` is caller memory
+        d_w = (const double*)p;
+    }
+    return fx_launch_ensemble_reduce(e, d_scores, N, M, d_w, d_out32, d_out64);
+}
+
+int fx_ensemble_reduce(fx_engine* e, const float* scores, int64_t N, int M, const double* weights, float* out32,
+                       double* out64) {
+    if (!e || N < 0 || M < 1) return FX_EINVAL;
+    if (N == 0) return FX_OK;
+    if (!scores || (weights ? !out64 : !out32)) return fx_fail(e, FX_EINVAL, "null buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    lp_disarm(e);                                          // (a pre-launched scoring instance holds most CUs until its idle limit: this call's kernels are queued behind it)
+    const size_t in_bytes = sizeof(float) * (size_t)N * M;
+    const size_t out_bytes = (weights ? sizeof(double) : sizeof(float)) * (size_t)N;
+    void *d_in = nullptr, *d_out = nullptr;
+    int rc;
+    if (in_bytes + out_bytes <= (size_t)e->zero_copy_bytes) {
+        FxZeroCopy z;
+        const size_t o_w = (in_bytes + 15) / 16 * 16;
+        if ((rc = fx_zero_copy_buffers(e, o_w + sizeof(double) * (size_t)M, out_bytes, &z))) return rc;
+        std::memcpy(z.h_in, scores, in_bytes);
+        if (weights) std::memcpy(z.h_in + o_w, weights, sizeof(double) * (size_t)M);
+        if ((rc = fx_launch_ensemble_reduce(e, (const float*)z.d_in, N, M, weights ? (const double*)(z.d_in + o_w) : nullptr,
+                                            (float*)z.d_out, (double*)z.d_out))) return rc;
+        if ((rc = fx_wait_small(e))) return rc;          // (a completion value polled in pinned memory: wait_for_results)
+        std::memcpy(weights ? (void*)out64 : (void*)out32, z.h_out, out_bytes);
+        return FX_OK;
+    }
+    if ((rc = fx_scratch(e, 0, in_bytes, &d_in))) return rc;
+    if ((rc = fx_scratch(e, 1, out_bytes, &d_out))) return rc;
+    FX_HIP(e, hipMemcpyAsync(d_in, scores, in_bytes, hipMemcpyHostToDevice, e->stream));
+    rc = fx_ensemble_reduce_dev(e, (const float*)d_in, N, M, weights, (float*)d_out, (double*)d_out);
+    if (rc) return rc;
+    FX_HIP(e, hipMemcpyAsync(weights ? (void*)out64 : (void*)out32, d_out, out_bytes, hipMemcpyDeviceToHost, e->stream));
+    FX_HIP(e, hipStreamSynchronize(e->stream));
+    return FX_OK;
+}
+
+int fx_argmax_decode(fx_engine* e, const double* one_hot, int64_t P, int L, int A, const uint8_t* alphabet,
+                     uint8_t* out_chars) {
+    if (!e || P < 0 || L < 0 || A < 1) return FX_EINVAL;
+    const int64_t rows = P * L;
+    if (rows == 0) return FX_OK;
+    if (!one_hot || !alphabet || !out_chars) return fx_fail(e, FX_EINVAL, "null buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    lp_disarm(e);                                          // (a pre-launched scoring instance holds most CUs until its idle limit: this call's kernels are queued behind it)
+    const size_t in_bytes = sizeof(double) * (size_t)rows * A;
+    void *d_in = nullptr, *d_out = nullptr, *d_al = nullptr;
+    int rc;
+    if ((rc = fx_scratch(e, 0, in_bytes, &d_in))) return rc;
+    if ((rc = fx_scratch(e, 1, (size_t)rows, &d_out))) return rc;
+    if ((rc = fx_scratch(e, 3, 256, &d_al))) return rc;
+    FX_HIP(e, hipMemcpyAsync(d_in, one_hot, in_bytes, hipMemcpyHostToDevice, e->stream));
+    FX_HIP(e, hipMemcpyAsync(d_al, alphabet, (size_t)A, hipMemcpyHostToDevice, e->stream));
+    if ((rc = fx_launch_argmax_decode(e, (const double*)d_in, rows, A, (const uint8_t*)d_al, (uint8_t*)d_out))) return rc;
+    FX_HIP(e, hipMemcpyAsync(out_chars, d_out, (size_t)rows, hipMemcpyDeviceToHost, e->stream));
+    FX_HIP(e, hipStreamSynchronize(e->stream));
+    return FX_OK;
+}
+
+// CMA-ES / DynaPPO population step (cmaes.py:61-67 + 83-93, environments/dyna_ppo.py:144-163): decode P
+// solutions to sequences (K6) and score them with the ensemble in ONE device round trip -- the decoded
+// characters never leave the GPU between the two steps.
+int fx_decode_score(fx_engine* e, fx_model* const* models, int M, const double* one_hot, int64_t P, int L, int A,
+                    const uint8_t* alphabet, const uint8_t lut[256], uint8_t* out_chars, float* out_NM,
+                    float* out_mean) {
+    int rc = validate_models(e, models, M, L, lut);
+    if (rc) return rc;
+    if (P < 0 || A < 1) return fx_fail(e, FX_EINVAL, "bad population shape");
+    if (models[0]->shape.A != A) return fx_fail(e, FX_ESHAPE, "alphabet size does not match the model's");
+    if (P == 0 || L == 0) return FX_OK;
+    if (!one_hot || !alphabet || !out_chars || (!out_NM && !out_mean)) return fx_fail(e, FX_EINVAL, "null buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    const int64_t rows = P * L;
+    const size_t in_bytes = sizeof(double) * (size_t)rows * A;
+    const size_t nm_bytes = sizeof(float) * (size_t)P * (size_t)M, mean_bytes = sizeof(float) * (size_t)P;
+    void *d_in = nullptr, *d_out = nullptr, *d_txt = nullptr;
+    if (in_bytes + 256 + nm_bytes + mean_bytes + (size_t)rows <= (size_t)e->zero_copy_bytes) {
+        // a CMA-ES / DyNA-PPO population (15-40 members): the three kernels read and write mapped pinned memory, one wait
+        FxZeroCopy z;
+        const size_t o_chars = (nm_bytes + mean_bytes + 15) / 16 * 16;
+        if ((rc = fx_zero_copy_buffers(e, in_bytes + 256, o_chars + (size_t)rows + 16, &z))) return rc;
+        std::memcpy(z.h_in, one_hot, in_bytes);
+        std::memcpy(z.h_in + in_bytes, alphabet, (size_t)A);
+        if ((rc = fx_upload_lut(e, lut))) return rc;
+        float* z_NM = (float*)z.d_out;
+        float* z_mean = (float*)(z.d_out + nm_bytes);
+        uint8_t* z_chars = (uint8_t*)(z.d_out + o_chars);
+        if ((rc = fx_launch_argmax_decode(e, (const double*)z.d_in, rows, A, (const uint8_t*)(z.d_in + in_bytes), z_chars))) return rc;
+        if ((rc = score_dispatch(e, models, M, z_chars, P, L, z_NM))) return rc;
+        if (out_mean && (rc = fx_launch_ensemble_reduce(e, z_NM, P, M, nullptr, z_mean, nullptr))) return rc;
+        if ((rc = fx_wait_small(e))) return rc;          // (a completion value polled in pinned memory: wait_for_results)
+        if (out_mean) std::memcpy(out_mean, z.h_out + nm_bytes, mean_bytes);
+        if (out_NM) std::memcpy(out_NM, z.h_out, nm_bytes);
+        std::memcpy(out_chars, z.h_out + o_chars, (size_t)rows);
+        return check_deferred(e);
+    }
+    if ((rc = fx_scratch(e, 0, in_bytes, &d_in))) return rc;
+    if ((rc = fx_scratch(e, 1, nm_bytes + mean_bytes, &d_out))) return rc;
+    if ((rc = fx_scratch(e, 3, 256 + (size_t)rows + 16, &d_txt))) return rc;
+    uint8_t* d_al = (uint8_t*)d_txt;
+    uint8_t* d_chars = d_al + 256;
+    float* d_NM = (float*)d_out;
+    float* d_mean = (float*)((char*)d_out + nm_bytes);
+    FX_HIP(e, hipMemcpyAsync(d_in, one_hot, in_bytes, hipMemcpyHostToDevice, e->stream));
+    FX_HIP(e, hipMemcpyAsync(d_al, alphabet, (size_t)A, hipMemcpyHostToDevice, e->stream));
+    if ((rc = fx_upload_lut(e, lut))) return rc;
+    if ((rc = fx_launch_argmax_decode(e, (const double*)d_in, rows, A, d_al, d_chars))) return rc;
+    if ((rc = score_dispatch(e, models, M, d_chars, P, L, d_NM))) return rc;
+    if (out_mean) {
+        if ((rc = fx_launch_ensemble_reduce(e, d_NM, P, M, nullptr, d_mean, nullptr))) return rc;
+        FX_HIP(e, hipMemcpyAsync(out_mean, d_mean, mean_bytes, hipMemcpyDeviceToHost, e->stream));
+    }
+    if (out_NM) FX_HIP(e, hipMemcpyAsync(out_NM, d_NM, nm_bytes, hipMemcpyDeviceToHost, e->stream));
+    FX_HIP(e, hipMemcpyAsync(out_chars, d_chars, (size_t)rows, hipMemcpyDeviceToHost, e->stream));
+    FX_HIP(e, hipStreamSynchronize(e->stream));
+    return check_deferred(e);
+}
+
+}  // extern "C"

@@ -49,6 +49,7 @@ struct PairArgs {
     const FxLpMail* lp_mail;    // a PRE-LAUNCHED instance (or null): weights first, then wait for lp_word in lp_mail->req, sequences from lp_mail->bytes
     unsigned long long lp_word, lp_idle_ticks;
     unsigned* lp_state;         // pinned host word: (lp_done_seq << 1) | 1 when the instance leaves without having been asked
+    unsigned* lp_decide;        // device word: the instance's ONE go / leave decision, (lp_done_seq << 2) | 1 or 2 (line 18 of the barrier counters)
     unsigned* lp_done;          // completion flag in pinned host memory (or null): the unit that finishes LAST stores lp_done_seq there
     unsigned lp_done_seq;
     unsigned lp_gtarget[16];    // ... and the LAST block of group g (the one that brings its counter to lp_gtarget[g]) arrives at the top
@@ -410,11 +411,21 @@ __global__ void __launch_bounds__(256) k_score_cnn_lp(PairArgs p) {
         if (tid == 0) {
             const unsigned long long* w = &p.lp_mail->req[blockIdx.x & 15u].w;
             const unsigned long long t0 = wall_clock64();
+            // ONE decision for the whole instance (round-4 advisor finding): every block used to decide on its own clock and its own
+            // copy of the request word, so a host thread descheduled between the 16 word stores -- or a post landing as the idle window
+            // closed -- could leave some blocks gone and others waiting at the grid barrier for them (FX_ERR_TIMEOUT after 1 s).  The
+            // first block to see a reason to go or to leave publishes it in device memory -- (sequence number << 2) | 1 go / 2 leave,
+            // compare-and-swap from whatever an older instance left there -- and every block, that one included, does what the word says.
+            const unsigned tag = p.lp_done_seq << 2;
             int go = 0;
             for (;;) {
+                unsigned d = __hip_atomic_load(p.lp_decide, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((d & ~3u) == tag && (d & 3u)) { go = (d & 3u) == 1u; break; }
                 const unsigned long long r = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (r == p.lp_word) { go = 1; break; }
-                if (r == (p.lp_word | 0xFFFFull) || wall_clock64() - t0 > p.lp_idle_ticks) break;      // (told to leave: ITS sequence number with 0xFFFF sequences)
+                unsigned mine = 0;
+                if (r == p.lp_word) mine = tag | 1u;
+                else if (r == (p.lp_word | 0xFFFFull) || wall_clock64() - t0 > p.lp_idle_ticks) mine = tag | 2u;      // (told to leave: ITS sequence number with 0xFFFF sequences)
+                if (mine) { (void)__hip_atomic_compare_exchange_strong(p.lp_decide, &d, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); continue; }
                 __builtin_amdgcn_s_sleep(2);
             }
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
@@ -778,6 +789,7 @@ int launch_lp(fx_engine* e, PairArgs a, size_t lds_bytes) {
             a.lp_word = ((unsigned long long)e->done_seq << 16) | (unsigned long long)a.N;
             a.lp_idle_ticks = (unsigned long long)e->serve_idle_us * 100ull;
             a.lp_state = e->d_lp_state;
+            a.lp_decide = e->d_lp_bar + 18 * 32;
         }
     }
     e->lp_launches += 1;

@@ -2,7 +2,7 @@
 committed golden fixtures, and size-independent properties at BASELINE sizes.
 
 Tolerance for fp32 fitness scores (BASELINE.json north_star: "within 1e-5
-relative"): |gpu - oracle_f64| <= 1e-5 * |oracle| + 1e-6  element-wise
+relative"): |gpu - oracle_f64| <= 1e-5 * |oracle| + 2.5e-7  element-wise
 (np.allclose form; the absolute term covers scores that cancel to ~0).
 Integer / float64 paths (distances, ensemble mean, NAM blend, codecs) are
 bit-exact.
@@ -21,7 +21,11 @@ from oracle import c_oracle, ref_np
 
 pytestmark = pytest.mark.gpu
 
-RTOL, ATOL = 1e-5, 1e-6
+# Round 5 (verdict item 7): the absolute term is what the kernels were MEASURED to need -- the worst absolute error over every
+# family of this suite is 2.5e-7 (profiles/r1_run69_parity_error_stats.json, profiles/r5_parity_error_stats.json) -- not the 1e-6
+# of rounds 1-4 (6 x slack); the relative term is north_star's.
+RTOL, ATOL = 1e-5, 2.5e-7
+ERROR_STATS = {}          # what -> worst figures seen by assert_scores in this session (written out by the module fixture below)
 
 
 def close(got, want):
@@ -31,6 +35,14 @@ def close(got, want):
 def assert_scores(got, want, what=""):
     assert got.dtype == np.float32
     assert not np.isnan(got).any(), f"{what}: {np.isnan(got).sum()} output elements were never written"
+    g64, w64 = got.astype(np.float64), np.asarray(want, np.float64)
+    if g64.size:
+        err = np.abs(g64 - w64)
+        row = ERROR_STATS.setdefault(what or "(unnamed)", {"n": 0, "max_abs_err": 0.0, "max_err_over_tolerance": 0.0, "max_abs_ref": 0.0})
+        row["n"] += int(err.size)
+        row["max_abs_err"] = max(row["max_abs_err"], float(err.max()))
+        row["max_err_over_tolerance"] = max(row["max_err_over_tolerance"], float((err / (ATOL + RTOL * np.abs(w64))).max()))
+        row["max_abs_ref"] = max(row["max_abs_ref"], float(np.abs(w64).max()))
     bad = ~close(got.astype(np.float64), want)
     assert not bad.any(), (f"{what}: {bad.sum()} / {bad.size} outside tolerance; max abs err "
                            f"{np.abs(got - want).max():.3e}, worst at {np.argmax(np.abs(got - want))}")
@@ -41,6 +53,14 @@ def eng():
     e = _native.Engine.get(0)
     e.set_option("poison_outputs", 1)       # an output element that no kernel wrote shows up as NaN
     yield e
+    try:                                    # per-config worst errors of this run (gpurun merges gpurun_out/ back; copied to profiles/ by hand)
+        out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out_dir, exist_ok=True)
+        rows = [dict(what=k, atol=ATOL, rtol=RTOL, **v) for k, v in sorted(ERROR_STATS.items())]
+        with open(os.path.join(out_dir, "parity_error_stats.json"), "w") as fh:
+            json.dump(rows, fh, indent=1)
+    except OSError:
+        pass
     e.set_option("poison_outputs", 0)
     e.set_option("force_generic", 0)
     e.set_option("cnn_variant", 0)

@@ -258,11 +258,12 @@ def test_bench_report_contract():
     rf = r["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3
     assert rf["flop_per_launch"] == 2.0 * 48628 * 3 * 100_000            # 97 256 FLOP per sequence-member
-    assert rf["achieved"] == pytest.approx(rf["flop_per_launch"] / 0.2e-3 / 1e12) and rf["frac"] == pytest.approx(rf["achieved"] / 157.3)
+    assert rf["achieved_algorithmic"] == pytest.approx(rf["flop_per_launch"] / 0.2e-3 / 1e12) and rf["frac_algorithmic"] == pytest.approx(rf["achieved_algorithmic"] / 157.3)
+    assert rf["achieved"] == pytest.approx(rf["issued_flop_per_launch"] / 0.2e-3 / 1e12) and rf["frac"] == pytest.approx(rf["achieved"] / 157.3) and rf["frac"] <= 1.0
     assert rf["algorithmic_bytes_per_launch"] == (8 + 12) * 100_000
     # issued-MFMA fraction: 615 MFMAs per 16-sequence tile per member (the kernel's loop bounds), 2048 FLOP each
     assert rf["mfma_per_tile"] == 615 and rf["issued_flop_per_launch"] == 615 * 6250 * 3 * 2048
-    assert rf["frac_issued"] == pytest.approx(rf["issued_flop_per_launch"] / 0.2e-3 / 1e12 / 157.3) and rf["frac_issued"] < rf["frac"]
+    assert rf["frac_issued"] == pytest.approx(rf["issued_flop_per_launch"] / 0.2e-3 / 1e12 / 157.3) and rf["frac_issued"] == rf["frac"] < rf["frac_algorithmic"]
     m = bench.make_report(world=8, N=100_000, steps=10, warmup=1, elapsed=0.01, host_issue_s=0.001, kern_ms=0.07, use_dist=True,
                           mode="member", members=8)
     assert m["scaling"] == "strong" and m["value"] == pytest.approx(100_000 * 10 / 0.01) and m["config"]["global_batch"] == 100_000
@@ -948,7 +949,17 @@ def test_bench_compact_record_carries_every_config():
     out = bench.compact_record(line)
     json.loads(json.dumps(out))
     per = out["roofline"]["per_config"]
-    assert per["train GFP-length CNN, train_swizzle 0/1/2 (prepared forms, default off)"] == line["prepared_train_swizzle"]
+    assert per["train GFP-length CNN by train_swizzle form (0 plain, 1 rotated rows, 2 staged kernels, 3 = default F=32 form)"] == line["prepared_train_swizzle"]
+    # round-4 verdict item 2: every config as FLAT SCALARS of `roofline` (a parser that drops nested objects keeps them)
+    line["explorer_round"]["train_3xCNN_L237_n500_ms"] = 18.5; line["explorer_round"]["train_3xCNN_L237_frac_of_peak"] = 0.4
+    out = bench.compact_record(line)
+    roof = out["roofline"]
+    for k in ("c1_kernel_ms", "c1_frac_issued", "c2_1e4_frac_issued", "c3_kernel_ms", "c3_frac_issued", "c4_frac_issued", "c5_frac_issued", "k4_c100", "k4_c1000", "k4_c20000",
+              "settled_kernel_ms", "settled_frac_issued", "e2e_c2_seq_per_s", "e2e_c3_frac_of_kernel", "e2e_c4_frac_of_kernel", "e2e_c5_seq_per_s", "train_l8_ms", "train_l237_ms",
+              "train_l237_frac_of_peak", "adalead_round_ms", "small_call_n20_us", "small_call_n1_us", "dynappo_10_us", "cmaes_p40_us", "nam_batch_safe_landscape_seq_per_s"):
+        assert isinstance(roof.get(k), float) and roof[k] > 0, k
+    assert all(not isinstance(v, (dict, list)) for k, v in roof.items() if k[:3] in ("c1_", "c3_", "c4_", "c5_", "k4_", "e2e", "tra", "set", "sma", "dyn", "cma", "nam", "mp_"))
+    assert roof["c1_kernel_ms"] == pytest.approx(line["configs"]["C1 cnn L=8 A=4 M=1 N=1e4"]["kernel_ms"], rel=1e-3)
     # the child that measures them: whatever goes wrong in it is a field of the record, never an exception (here: no GPU)
     got = bench.prepared_block(timeout_s=120.0)
     assert isinstance(got, dict) and ("error" in got or "skipped" in got or any("ms_per_fit" in v for v in got.values() if isinstance(v, dict)))

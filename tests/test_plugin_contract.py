@@ -109,7 +109,7 @@ def test_smallest_surrogates_score_and_match_the_oracle():
         out = model.get_fitness(seqs)
         want = ref_np.keras_fitness(seqs, s_utils.DNAA, kind, model.model.get_weights(), exact=True)
         assert out.shape == (3,) and out.dtype == np.float32 and model.cost == 3
-        assert np.abs(out - want).max() <= 1e-5 * np.abs(want).max() + 1e-6
+        assert np.abs(out - want).max() <= 1e-5 * np.abs(want).max() + 2.5e-7
     with pytest.raises(ValueError):                      # Keras: 'valid' Conv1D with seq_len < kernel_size (cnn.py:25-32)
         baselines.models.CNN(seq_len=3, num_filters=1, hidden_size=1, alphabet=s_utils.DNAA)
 
