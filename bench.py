@@ -83,7 +83,7 @@ def roofline_block(kind, Lx, A, Hx, Fx, Kx, members, n, kern_ms, kernel_name):
 
 def pmc_block():
     """PMC figures cannot be sampled from inside the process; they come from the rocprofv3 --pmc passes over this
-    same command (tools/gpu_round4.sh), committed under profiles/ -- the file is named, with the commit it was taken at
+    same command (tools/archive/gpu_round4.sh), committed under profiles/ -- the file is named, with the commit it was taken at
     (`commit` inside the file, else the last commit that touched it), so the numbers can be traced."""
     for name in ("r5_pmc_bench.json", "r4_pmc_bench.json", "r3_pmc_bench.json", "r2_pmc_bench.json", "r1_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
@@ -256,7 +256,7 @@ def configs_block(eng, device, torch):
 
 
 VALU_LANE_OPS = 256 * 4 * 16 * 2.4e9        # 256 CUs x 4 SIMDs x 16 lanes per cycle x 2.4 GHz = 3.93e13 lane-ops/s
-K4_LANE_OPS_PER_CHAR = 24.5                 # issued VALU lane-ops per (pair, text character), L <= 32: PMC, profiles/r2_run1_pmc_targets.md
+K4_LANE_OPS_PER_CHAR = 24.5                 # issued VALU lane-ops per (pair, text character), L <= 32: PMC, profiles/archive/r2_run1_pmc_targets.md
 
 
 def nam_block(eng, device):
@@ -293,7 +293,7 @@ def nam_block(eng, device):
                          "lane_ops_per_pair_char": K4_LANE_OPS_PER_CHAR, "traffic": None},
             "workgroups": -(-C_ // 1024) * Q, "reps": reps}
         del cache
-    out["k4"]["note"] = ("frac = 24.5 issued VALU lane-ops per (pair, text character) [PMC, profiles/r2_run1_pmc_targets.md] x L x "
+    out["k4"]["note"] = ("frac = 24.5 issued VALU lane-ops per (pair, text character) [PMC, profiles/archive/r2_run1_pmc_targets.md] x L x "
                          "pairs / kernel time / (256 CU x 4 SIMD x 16 lanes x 2.4 GHz); one workgroup = one query x <= 1024 "
                          "cache rows, so C = 100 runs 100 of 256 lanes per workgroup")
 
@@ -686,6 +686,9 @@ def flat_scalars(out):
         for k in ("plain_landscape", "batch_safe_landscape", "device_table_landscape_L8"):
             if isinstance(nam.get(k), dict):
                 put(f"nam_{k.lower()}_seq_per_s", nam[k].get("value"))
+    cs = out.get("cold_start")
+    if isinstance(cs, dict):
+        put("cold_start_kernel_ms", cs.get("kernel_ms")); put("cold_start_frac_issued", cs.get("frac_issued")); put("cold_start_value", cs.get("value"))
     st = out.get("settled")
     if isinstance(st, dict):
         put("settled_kernel_ms", st.get("kernel_ms")); put("settled_frac_issued", st.get("frac_issued")); put("settled_value", st.get("value"))
@@ -858,7 +861,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: 100 + 1000 launches of ~0.19 ms -- long enough for the clocks to settle (the first ~50 launches of a
-    # cold process run ~10 % slower: profiles/r1_run22 trace), still a fraction of a second
+    # cold process run ~10 % slower: profiles/archive/r1_run22 trace), still a fraction of a second
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--mode", choices=("sequence", "member"), default="sequence",
@@ -981,8 +984,23 @@ def main():
 
     if rank == 0:
         assert np.array_equal(np.mean(got_nm, axis=1), got_mean), "device mean is not np.mean bit-for-bit"
+        cold = None
+        confs = None
+        if world == 1 and not args.no_extras:
+            # The per-config kernel measurements run HERE, between the first bracket and the contract's: a fresh process times its
+            # first K steps while the device is still ramping its clocks (20 steps = 4 ms of GPU time: 0.205 ms per launch against
+            # 0.185 settled, round-4 verdict weak #3), which says nothing about the kernel and is not how an explorer meets it -- its
+            # virtual screen follows a retrain.  The contract's W warm-ups + K timed steps are therefore measured (again, same code
+            # path, same barrier + synchronize bracket) after this GPU work; the first bracket is kept as `cold_start`.
+            confs = configs_block(eng, local_rank, torch)
+            cold = {"ms_per_step": elapsed / args.steps * 1e3, "kernel_ms": kern_ms, "value": world * N * args.steps / elapsed,
+                    "what": "the same W warm-ups + K timed steps as the first GPU work of the process (device clocks still ramping)"}
+            elapsed, host_issue_s, kern_ms = run_pipelined(ens, d_seq, glob_n, args.steps, args.warmup, torch, dist, use_dist)
         out = make_report(world, N, args.steps, args.warmup, elapsed, host_issue_s, kern_ms, use_dist, args.mode,
                           head_members)
+        if cold:
+            cold["frac_issued"] = out["roofline"]["frac_issued"] * out["roofline"]["kernel_ms"] / cold["kernel_ms"]
+            out["cold_start"] = cold
         if settled:
             s_steps, s_el, s_kern = settled
             rep = make_report(world, N, s_steps, 0, s_el, 0.0, s_kern, use_dist, args.mode, head_members)
@@ -995,7 +1013,7 @@ def main():
             out["debug_share_device"] = "all ranks on device 0, collectives on gloo through host tensors: NOT a measurement"
         out.update(extras)
         if world == 1 and not args.no_extras:
-            out["configs"] = configs_block(eng, local_rank, torch)
+            out["configs"] = confs
             out["configs"]["C3 nam L=14 A=4 (NoisyAbstractModel half of configs[2])"] = nam_block(eng, local_rank)
             out["configs"]["C2 full (headline kernel)"] = {"kernel_ms": (settled[2] if settled else kern_ms)}
             out["end_to_end"] = end_to_end_block(local_rank, out["configs"])

@@ -61,7 +61,7 @@ __device__ __forceinline__ unsigned fx_xcd_block() {
 // the workgroups [ceil(G m / M), ceil(G (m + 1) / M)) (contiguous, so with fx_xcd_block they share an L2) and its
 // tiles are cut evenly over them.  A range that straddled two members made that workgroup wait at the member
 // boundary for its slowest wave, refill LDS and start over -- one tile duration plus a fill, which with few tiles
-// per workgroup WAS the kernel's tail (profiles/r2_trace_probe: 3 members x 1e4 sequences, 38 us span of which 12
+// per workgroup WAS the kernel's tail (profiles/archive/r2_trace_probe: 3 members x 1e4 sequences, 38 us span of which 12
 // were two straddling workgroups; 194 -> ~180 us on the 3 x 1e5 bench launch).
 __device__ __forceinline__ void fx_unit_range(int64_t TG, int M, int64_t& u_lo, int64_t& u_hi) {
     const int64_t G = gridDim.x, bid = fx_xcd_block();
@@ -87,7 +87,7 @@ __device__ __forceinline__ void fx_unit_range(int64_t TG, int M, int64_t& u_lo, 
 // dealt to its four SIMDs in equal shares and only the waves OF a SIMD pull from that share (one LDS counter per SIMD):
 // with one shared counter the share of a SIMD was whatever its waves happened to grab -- on mid-size launches (1-2
 // tiles per wave) one SIMD of a CU ran 8 tiles while another ran 4, and the kernel ended with the slowest SIMD
-// (profiles/r2_trace_probe: MLP, 1e5 sequences: median wave done at 35 us, last at 46 us).
+// (profiles/archive/r2_trace_probe: MLP, 1e5 sequences: median wave done at 35 us, last at 46 us).
 __device__ __forceinline__ int fx_simd_id() { return (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4); }
 
 // Distinct issue priorities for the waves that share a SIMD (by hardware wave slot), for the whole kernel: the waves of
@@ -107,7 +107,7 @@ __device__ __forceinline__ void fx_stagger_priority() {
 // loads (ONE vector-memory instruction for L <= 64 instead of one byte-load instruction per position and lane group),
 // and the lanes then pick their bytes with ds_read_u8.  At kernel start every wave of the machine asks for its first
 // tile at once; with byte loads that was tens of thousands of requests and a ~2 us round trip per dependent step of a
-// first layer (profiles/r2_trace_probe: 8 us before the first MFMA of an MLP tile).  `src` may be unaligned (a row
+// first layer (profiles/archive/r2_trace_probe: 8 us before the first MFMA of an MLP tile).  `src` may be unaligned (a row
 // offset into the caller's buffer): gfx950 runs compute with unaligned access enabled; the scratch is 16-byte aligned.
 typedef const __attribute__((address_space(3))) uint8_t* fx_lds_u8p;
 struct __attribute__((packed, aligned(1))) FxBytes16 { uint32_t w[4]; };
@@ -169,7 +169,7 @@ __device__ __forceinline__ void fill_lds(f4* __restrict__ dst, const f4* __restr
 // The data never passes through VGPRs, so a wave can put its whole share of a member's weight image in flight at
 // kernel start and begin computing as soon as the FIRST part (what the first layers read) has landed, while the rest
 // is still on its way: a small launch otherwise waits ~3-5 us for ~100-150 KiB before its first instruction of work
-// (profiles/r2_trace_probe).  Written as inline assembly on purpose: the compiler's own tracking of such loads puts an
+// (profiles/archive/r2_trace_probe).  Written as inline assembly on purpose: the compiler's own tracking of such loads puts an
 // `s_waitcnt vmcnt(0)` in front of the next LDS read that might alias, i.e. waits for everything.  Ordering is by the
 // wave's vector-memory counter: loads return in order, so `fx_wait_vm(n)` (at most n still in flight) after issuing
 // part 1 and then n loads of part 2 guarantees part 1 -- loads the compiler issues in between only make the wait
@@ -293,8 +293,8 @@ __device__ __forceinline__ float fx_nan_to_num(float v) {
 // remaining k-steps would multiply zeros and are skipped.  (Hidden sizes that were rounded up
 // to a larger instantiated tile count pass 4: their padding tiles are computed as zeros.)
 // PRIO: raise the wave's issue priority around each MFMA cluster.  Measured +2 % on the unrolled L = 8
-// kernel in an interleaved A/B (profiles/r1_run16_setprio_ab.md) but neutral-to-negative on the dynamic-loop,
-// MLP and GE kernels (profiles/r1_run17_*), so it is opt-in per instantiation.
+// kernel in an interleaved A/B (profiles/archive/r1_run16_setprio_ab.md) but neutral-to-negative on the dynamic-loop,
+// MLP and GE kernels (profiles/archive/r1_run17_*), so it is opt-in per instantiation.
 template <int TI, int TO, int NT, bool PRIO = false, typename WPtr>
 __device__ __forceinline__ void mma_layer(WPtr wblk, const f4 (&in)[TI][NT], f4 (&acc)[TO][NT], int lane,
                                           int rl_last = 4) {

@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                 }
             // Look-ahead queue of raw sequence bytes (generic-length form): the byte a step consumes was requested PF
             // steps earlier, so its L2 / HBM latency is off the step's critical path.  A lone wave (small batches:
-            // one tile per SIMD) otherwise pays one global round trip per position (profiles/r2_trace_probe: 8.4 us
+            // one tile per SIMD) otherwise pays one global round trip per position (profiles/archive/r2_trace_probe: 8.4 us
             // for the conv part of an L = 8 tile whose MFMAs take 5.5 us).  The unrolled forms (L1S > 0) run with
             // four waves per SIMD, which hide it, and have no registers to spare.
             constexpr bool AHEAD = (L1S == 0) && (WAVES <= 8);     // (16-wave forms: four waves per SIMD hide it, no registers to spare)
@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                 if (L1S > 0 || s < s_stop) {
                 // weights in LDS are loop-invariant: without this barrier LICM hoists every
                 // ds_read out of the position loop and spills hundreds of VGPRs
-                // (fencing only every 2nd / 4th position of the unrolled kernels measured no gain: profiles/r1_run18)
+                // (fencing only every 2nd / 4th position of the unrolled kernels measured no gain: profiles/archive/r1_run18)
                 asm volatile("" ::: "memory");
                 if (!RING) {
                     // ---- slide the windows

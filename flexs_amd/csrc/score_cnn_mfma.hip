@@ -14,11 +14,11 @@ int dispatch_a4(fx_engine* e, const CnnArgs& a0, int variant, bool big, size_t f
     if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
     if constexpr (HT_ == 7) {
         // canonical short landscapes get a fully unrolled position loop with s_setprio around the MFMA clusters
-        // (+5 % and +2-4 % resp., interleaved A/B: profiles/r1_run9, r1_run16, r1_run18):
+        // (+5 % and +2-4 % resp., interleaved A/B: profiles/archive/r1_run9, r1_run16, r1_run18):
         // TF-binding (L = 8) and the RNA landscapes (L = 14)
         if (dl && variant == 0 && big && a.L == 8) variant = 7;
         // ... and in 8-wave workgroups for small and mid-size launches (one or two waves per SIMD: the unrolled walk is
-        // 5 % shorter per tile than the ring loop, profiles/r2_trace_probe)
+        // 5 % shorter per tile than the ring loop, profiles/archive/r2_trace_probe)
         if (dl && variant == 0 && !big && a.L == 8) variant = 11;
         if (dl && variant == 0 && big && a.L == 14) variant = 10;
         if (dl && variant != 0) {

@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
 // above cuts a tile's positions into segments of two and pays for it with the halo: conv3 reaches 9 + 9 positions and conv2
 // 2 + 2 around every output, so a pair walks 24 steps (barrier + LDS exchange + ~70 MFMAs of a lone wave each, ~2.5 us) for
 // its 2 positions -- 73 us for one 237-residue tile whose whole arithmetic is ~90 k MFMAs = 1.2 us of the machine
-// (profiles/r2_protein_small_calls.log).  Here nothing is recomputed:
+// (profiles/archive/r2_protein_small_calls.log).  Here nothing is recomputed:
 //   phase 1  workgroup (unit, block b) computes conv1 + conv2 for ITS positions (conv1, a row gather, also for the 2 + 2
 //            neighbours conv2 reaches) and leaves out2[position] in device memory (2 KiB per position and tile);
 //   barrier  all workgroups of the launch (a counter in device memory, agent-scope release / acquire: one per launch);
@@ -826,7 +826,7 @@ int launch_pair(fx_engine* e, PairArgs a, size_t lds_bytes) {
     // tile into segments over SB workgroups so that the call's latency is ~L1/S + halo steps.  The halo (PL3 + PL2 +
     // PR2 + PR3 = 22 positions at A = 20) is recomputed by every segment, but the machine is otherwise empty: as many
     // workgroups per tile as fit in ONE wave of the grid (U x SB <= CUs), down to segments of two positions
-    // (tools/runs/r2_pair_seg_sweep.py: a 1-16 sequence call at L = 237 250 -> 181 us, at L = 90 269 -> 169 us).
+    // (tools/archive/runs/r2_pair_seg_sweep.py: a 1-16 sequence call at L = 237 250 -> 181 us, at L = 90 269 -> 169 us).
     int64_t sb = fx_pair_seg_count(L1, WAVES / 2, U, e->num_cus);
     if (e->cnn_pair_seg == 0 || 2 * U > e->num_cus) sb = 0;
     if (e->cnn_pair_seg > 0) sb = e->cnn_pair_seg;                       // test knob: force SB

@@ -2,7 +2,7 @@
 //
 // With at most three tiles per workgroup (10^4 sequences on one member: 625 tiles for 256 CUs, configs[0]; every
 // explorer-size call) the one-wave-per-tile kernel runs a LONE wave per SIMD: ~75 % of the pipe for that wave, three of
-// the CU's four matrix pipes idle (profiles/r2_trace_probe: 12 us per tile whose MFMAs are 8 us of one pipe).  Here a
+// the CU's four matrix pipes idle (profiles/archive/r2_trace_probe: 12 us per tile whose MFMAs are 8 us of one pipe).  Here a
 // wave quad walks the network layer by layer and exchanges activations through LDS:
 //     wave q takes the conv positions q, q + 4, q + 8, ... (TF-binding: seq_len 8, kernel 5 -> 4 positions, one each;
 //     RNA: seq_len 14 -> 10 positions, 3-3-2-2; up to 12 positions = seq_len 16)

@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                 if constexpr (PAIR) {
                     // 4-letter alphabet: one pre-summed row per PAIR of positions (16 letter pairs), i.e. half the LDS
                     // traffic, half the adds and half the address arithmetic of the row-per-position gather below --
-                    // the first layer is what a tile waits for while the matrix pipe idles (profiles/r2_trace_probe)
+                    // the first layer is what a tile waits for while the matrix pipe idles (profiles/archive/r2_trace_probe)
                     unsigned seen1 = 0;
                     const int np2 = L >> 1;
                     auto pair_layer = [&](auto rb) {
@@ -907,7 +907,7 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
     // Mid-size launches (a handful of tiles per SIMD): two waves per SIMD instead of four.  With four, a SIMD's 5-7
     // tiles go 2-2-1-1 to its waves: the first round runs four first layers at once on one LDS / VALU (7 us before the
     // first MFMA), the second round has two waves left; with two waves the tiles go 3-3 and one wave's first layer
-    // overlaps the other's MFMA layers (profiles/r2_trace_probe).  Long launches keep four (best steady state).
+    // overlaps the other's MFMA layers (profiles/archive/r2_trace_probe).  Long launches keep four (best steady state).
     const int64_t tiles_per_simd = (int64_t)a.M * a.TG / ((int64_t)e->num_cus * 4);
     [[maybe_unused]] const bool few_waves = e->dense_waves == 8 || (e->dense_waves == 0 && tiles_per_simd < e->dense_few_waves_below);
     const int64_t tail = DGc ? lay.off_d2 : lay.total_floats;           // end of the LDS image
@@ -964,7 +964,7 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
     a.lds_floats = (int)(tail - lds_from);
     if constexpr (DGc) {
         // hidden sizes 129..256: stream the HxH blocks through LDS slabs, one pass per round of 8 tiles (A/B: dense_slab = 0)
-        // (not when the first-layer rows stream from L2 as well: measured 3 % slower there, profiles/r1_run46)
+        // (not when the first-layer rows stream from L2 as well: measured 3 % slower there, profiles/archive/r1_run46)
         const bool slab = e->dense_slab != 0 && !e->mlp_l1_mfma && !w1_global && lds + (size_t)4 * HT_ * 1024 <= (size_t)e->max_lds;
         if (slab) {
             if (s.kind == FX_MLP) return launch_inst<FX_MLP, 4, HT_, 1, W, true, false, true, true>(e, a, lds);

@@ -177,7 +177,7 @@ int fx_launch_score_mlp_small(fx_engine* e, fx_model* const* models, int M, cons
     // One workgroup per CU is ~8-9 us for the canonical shapes against ~14 us of the persistent kernel (LDS fill + a lone tile).
     // Where that kernel's lone tile is a latency chain -- hidden layers streamed through LDS slabs (H > 128), a first
     // layer gathered row by row from L2 (long sequences / wide alphabets) -- this form wins up to ~4 workgroups per CU
-    // (tools/runs/r2_mlp_small_crossover.py); beyond that its per-tile re-read of the weights from L2 loses.
+    // (tools/archive/runs/r2_mlp_small_crossover.py); beyond that its per-tile re-read of the weights from L2 loses.
     const int64_t per_cu = (lay.HT > 8 || (s.kind == FX_MLP && (int64_t)s.L * s.A >= 160)) ? 4 : 1;
     if (e->dense_small < 2 && U > per_cu * e->num_cus) return FX_EUNSUPPORTED;
     const int form = s.kind == FX_MLP ? fx_mlp_first_layer_form(e, s, lay) : 0;

@@ -19,81 +19,9 @@ from flexs_amd.baselines import models as bm
 from flexs_amd.utils import sequence_utils as s_utils
 from oracle import c_oracle, ref_np
 
+from gpu_common import ATOL, ERROR_STATS, RTOL, ab_option, assert_scores, close, eng, make_native, rand_seqs  # noqa: F401  (eng: the session fixture)
+
 pytestmark = pytest.mark.gpu
-
-# Round 5 (verdict item 7): the absolute term is what the kernels were MEASURED to need -- the worst absolute error over every
-# family of this suite is 2.5e-7 (profiles/r1_run69_parity_error_stats.json, profiles/r5_parity_error_stats.json) -- not the 1e-6
-# of rounds 1-4 (6 x slack); the relative term is north_star's.
-RTOL, ATOL = 1e-5, 2.5e-7
-ERROR_STATS = {}          # what -> worst figures seen by assert_scores in this session (written out by the module fixture below)
-
-
-def close(got, want):
-    return np.abs(got - want) <= ATOL + RTOL * np.abs(want)
-
-
-def assert_scores(got, want, what=""):
-    assert got.dtype == np.float32
-    assert not np.isnan(got).any(), f"{what}: {np.isnan(got).sum()} output elements were never written"
-    g64, w64 = got.astype(np.float64), np.asarray(want, np.float64)
-    if g64.size:
-        err = np.abs(g64 - w64)
-        row = ERROR_STATS.setdefault(what or "(unnamed)", {"n": 0, "max_abs_err": 0.0, "max_err_over_tolerance": 0.0, "max_abs_ref": 0.0})
-        row["n"] += int(err.size)
-        row["max_abs_err"] = max(row["max_abs_err"], float(err.max()))
-        row["max_err_over_tolerance"] = max(row["max_err_over_tolerance"], float((err / (ATOL + RTOL * np.abs(w64))).max()))
-        row["max_abs_ref"] = max(row["max_abs_ref"], float(np.abs(w64).max()))
-    bad = ~close(got.astype(np.float64), want)
-    assert not bad.any(), (f"{what}: {bad.sum()} / {bad.size} outside tolerance; max abs err "
-                           f"{np.abs(got - want).max():.3e}, worst at {np.argmax(np.abs(got - want))}")
-
-
-@pytest.fixture(scope="module")
-def eng():
-    e = _native.Engine.get(0)
-    e.set_option("poison_outputs", 1)       # an output element that no kernel wrote shows up as NaN
-    yield e
-    try:                                    # per-config worst errors of this run (gpurun merges gpurun_out/ back; copied to profiles/ by hand)
-        out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-        os.makedirs(out_dir, exist_ok=True)
-        rows = [dict(what=k, atol=ATOL, rtol=RTOL, **v) for k, v in sorted(ERROR_STATS.items())]
-        with open(os.path.join(out_dir, "parity_error_stats.json"), "w") as fh:
-            json.dump(rows, fh, indent=1)
-    except OSError:
-        pass
-    e.set_option("poison_outputs", 0)
-    e.set_option("force_generic", 0)
-    e.set_option("cnn_variant", 0)
-    e.set_option("cnn_conv1_mfma", 0)
-    e.set_option("mlp_l1_mfma", 0)
-    e.set_option("cnn_pair", 1)
-
-
-def ab_option(eng, key, value):
-    """Selects a kernel form that was measured and lost (csrc/OPTIONS.md): compiled into the A/B build only
-    (`make -C flexs_amd/csrc ab`, FLEXS_AMD_LIB=.../libflexs_amd_ab.so).  False = the production library refused it: the
-    caller skips that leg."""
-    try:
-        eng.set_option(key, value)
-        return True
-    except _native.FxError as ex:
-        if ex.code == _native.FX_EUNSUPPORTED:
-            return False
-        raise
-
-
-def rand_seqs(n, L, alphabet, seed):
-    b = synth.random_sequence_bytes(n, L, alphabet, seed)
-    return b, synth.bytes_to_strings(b)
-
-
-def make_native(eng, kind, L, A, H, F=0, K=0, seed=1000):
-    shapes = {"cnn": ref_np.cnn_shapes(L, A, F, H, K) if kind == "cnn" else None,
-              "mlp": ref_np.mlp_shapes(L, A, H), "ge": ref_np.ge_shapes(L, A, H)}[kind]
-    w = ref_np.synth_weights(shapes, seed)
-    nm = _native.NativeModel(eng, {"cnn": 0, "mlp": 1, "ge": 2}[kind], L, A, F, H, K)
-    nm.set_weights(w)
-    return nm, w
 
 
 # ------------------------------------------------------------------ MFMA layout ground truth
@@ -207,105 +135,6 @@ def test_cnn_gfp_length(eng, L):
     assert_scores(got[:, 0], want, f"cnn L={L}")
 
 
-@pytest.mark.parametrize("L,n,M,H", [(100, 20, 3, 100), (50, 1, 1, 100), (50, 100, 2, 100), (14, 7, 1, 100), (9, 3, 1, 100),
-                                      (28, 33, 2, 64), (100, 16, 1, 200), (61, 40, 1, 256), (8, 5, 3, 100), (5, 2, 1, 100)])
-def test_cnn_position_split_small_batches(eng, L, n, M, H):
-    """Small batches of the 4-letter CNN kernel: the waves of a workgroup split one tile's positions (cnn_seg).
-    Forced on, automatic and off must agree bit for bit, and match the oracle -- including sequences with fewer
-    conv positions than waves (L = 5, 8, 9)."""
-    natives, ws = zip(*[make_native(eng, "cnn", L, 4, H, 32, 5, seed=70 + m) for m in range(M)])
-    lut = _native.make_lut("UGCA")
-    b, seqs = rand_seqs(n, L, "UGCA", seed=L * 3 + n)
-    try:
-        eng.set_option("cnn_seg", 0)
-        whole, _ = eng.score(list(natives), b, lut)
-        for m in range(M):
-            assert_scores(whole[:, m], ref_np.keras_fitness(seqs, "UGCA", "cnn", ws[m], exact=True), f"L={L} H={H}")
-        for mode in (1, -1):
-            eng.set_option("cnn_seg", mode)
-            got, mean = eng.score(list(natives), b, lut, want_matrix=True, want_mean=True)
-            assert np.array_equal(got, whole), (L, n, M, H, mode)
-            assert np.array_equal(mean, np.mean(whole, axis=1))
-        eng.set_option("cnn_seg", 1)
-        bad = b.copy()
-        bad[n // 2, L - 1] = ord("Z")
-        with pytest.raises(ValueError):
-            eng.score(list(natives), bad, lut)
-    finally:
-        eng.set_option("cnn_seg", -1)
-
-
-@pytest.mark.parametrize("L,n,M", [(237, 40, 3), (238, 1, 1), (90, 16, 2), (90, 33, 1), (31, 5, 1), (60, 100, 2)])
-def test_cnn_pair_segmented_small_batches(eng, L, n, M):
-    """Position-segmented form of the wide-alphabet CNN kernel (CMA-ES / DyNA-PPO sized calls): every forced
-    segmentation (SB workgroups per tile) and the automatic one give the whole-sequence form's scores bit for bit,
-    and those match the oracle."""
-    natives, ws = zip(*[make_native(eng, "cnn", L, 20, 100, 32, 5, seed=40 + m) for m in range(M)])
-    lut = _native.make_lut(s_utils.AAS)
-    b, seqs = rand_seqs(n, L, s_utils.AAS, seed=L + n)
-    try:
-        eng.set_option("cnn_pair_seg", 0)
-        whole, _ = eng.score(list(natives), b, lut)
-        k = min(n, 64)
-        for m in range(M):
-            assert_scores(whole[:k, m], ref_np.keras_fitness(seqs[:k], s_utils.AAS, "cnn", ws[m], exact=True), f"pair L={L}")
-        for sb in (1, 2, 3, 5, 8, -1):
-            eng.set_option("cnn_pair_seg", sb)
-            got, mean = eng.score(list(natives), b, lut, want_matrix=True, want_mean=True)
-            assert np.array_equal(got, whole), (L, n, M, sb)
-            assert np.array_equal(mean, np.mean(whole, axis=1))
-        eng.set_option("cnn_pair_seg", 7)
-        bad = b.copy()
-        bad[n // 2, L - 3] = ord("Z")                     # bad character inside some segment only
-        with pytest.raises(ValueError):
-            eng.score(list(natives), bad, lut)
-    finally:
-        eng.set_option("cnn_pair_seg", -1)
-
-
-@pytest.mark.parametrize("L,n,M", [(237, 40, 3), (237, 1, 1), (237, 15, 3), (238, 16, 1), (90, 10, 3), (90, 33, 2), (100, 80, 3), (28, 5, 1),
-                                   (237, 17, 8), (150, 48, 5)])
-def test_cnn_layer_parallel_small_batches(eng, L, n, M):
-    """Round 4: small batches of the canonical protein CNN (a CMA-ES population of 15-40, a DyNA-PPO environment batch, one
-    sequence) LAYER-PARALLEL over the chip (`cnn_lp`, default on: conv1 + conv2 per position block, conv2 outputs through
-    device memory, one grid barrier, conv3 + pool per position block, head by the last block of a tile) instead of position
-    segments that recompute a 22-position halo each.  Per output element the pair kernel's MFMA sequence, so the SAME BITS as
-    the whole-sequence walk and as the segmented form; beside the float64 oracle; repeated launches (the barrier counter only
-    ever grows), a bad character in some block only, and batches too large for one wave of the grid keep the old forms."""
-    natives, ws = zip(*[make_native(eng, "cnn", L, 20, 100, 32, 5, seed=80 + m) for m in range(M)])
-    lut = _native.make_lut(s_utils.AAS)
-    b, seqs = rand_seqs(n, L, s_utils.AAS, seed=3 * L + n)
-    try:
-        eng.set_option("cnn_pair_seg", 0)
-        whole, _ = eng.score(list(natives), b, lut)
-        eng.set_option("cnn_pair_seg", -1)
-        eng.set_option("cnn_lp", 0)
-        seg, _ = eng.score(list(natives), b, lut)
-        eng.set_option("cnn_lp", 1)
-        assert np.array_equal(seg, whole)
-        for rep in range(4):
-            got, mean = eng.score(list(natives), b, lut, want_matrix=True, want_mean=True)
-            assert np.array_equal(got, whole), (L, n, M, rep)
-            assert np.array_equal(mean, np.mean(whole, axis=1))
-        for cut in (1, 16, 17, n - 1):                                    # batch invariance across forms
-            if 0 < cut < n:
-                part, _ = eng.score(list(natives), b[:cut], lut)
-                assert np.array_equal(part, whole[:cut]), cut
-        k = min(n, 48)
-        for m in range(M):
-            assert_scores(whole[:k, m], ref_np.keras_fitness(seqs[:k], s_utils.AAS, "cnn", ws[m], exact=True), f"lp L={L} member {m}")
-        for where in ((0, 0), (n // 2, L // 2), (n - 1, L - 1)):          # a bad character that only one position block reads
-            bad = b.copy()
-            bad[where] = ord("Z")
-            with pytest.raises(ValueError):
-                eng.score(list(natives), bad, lut)
-        again, _ = eng.score(list(natives), b, lut)
-        assert np.array_equal(again, whole)
-    finally:
-        eng.set_option("cnn_pair_seg", -1)
-        eng.set_option("cnn_lp", 1)
-
-
 @pytest.mark.parametrize("L,A,alpha,F,H,K", [(3, 4, "TGCA", 1, 1, 2), (9, 4, "TGCA", 8, 20, 4), (12, 2, "01", 16, 30, 3),
                                              (10, 4, "TGCA", 32, 100, 3), (8, 4, "TGCA", 32, 200, 5),
                                              (5, 4, "TGCA", 32, 100, 5), (7, 20, s_utils.AAS, 4, 130, 2)])
@@ -340,100 +169,6 @@ def test_mlp_ge_vs_oracle(eng, kind, L, A, alpha, H, n):
     eng.set_option("mlp_l1_mfma", 0)
 
 
-# ------------------------------------------------------------------ ensembles
-@pytest.mark.parametrize("L,alpha,H,M,n", [(90, s_utils.AAS, 100, 8, 3001), (90, s_utils.AAS, 100, 1, 17), (8, "TGCA", 100, 3, 1000),
-                                           (33, s_utils.AAS, 50, 2, 100), (100, "UGCA", 128, 1, 257), (64, s_utils.AAS, 16, 5, 16)])
-def test_ge_byte_table_first_layer(eng, L, alpha, H, M, n):
-    """GlobalEpistasis layer 1 gathered from the per-position table indexed by the raw byte (LDS-resident, padding
-    rows of zeros, bytes of the following rows read on full trips) gives the bits of the LUT + code-indexed gather --
-    same summation order -- and the oracle's values; characters are validated by the first member's units only."""
-    A = len(alpha)
-    pairs = [make_native(eng, "ge", L, A, H, seed=1000 + m) for m in range(M)]
-    nms = [p[0] for p in pairs]
-    lut = _native.make_lut(alpha)
-    b, seqs = rand_seqs(n, L, alpha, seed=5)
-    got, _ = eng.score(nms, b, lut)
-    eng.set_option("ge_bytetab", 0)
-    try:
-        old, _ = eng.score(nms, b, lut)
-    finally:
-        eng.set_option("ge_bytetab", 1)
-    assert np.array_equal(got, old)
-    for m in (0, M - 1):
-        assert_scores(got[:, m], ref_np.keras_fitness(seqs, alpha, "ge", pairs[m][1], exact=True), f"ge byte table member {m}")
-    # a bad character anywhere (last row, last position; first row) is reported whichever member's units meet it
-    for r, c in ((n - 1, L - 1), (0, 0), (n // 2, L // 2)):
-        bb = b.copy()
-        bb[r, c] = ord("z")
-        with pytest.raises(ValueError):
-            eng.score(nms, bb, lut)
-    # ... and a NaN weight is NOT a bad character: np.nan_to_num semantics (keras_model.py:77)
-    w = [x.copy() for x in pairs[0][1]]
-    w[0][3, 0] = np.nan
-    nms[0].set_weights(w)
-    out, _ = eng.score(nms, b, lut)                                   # must not raise
-    clean = b[:, 0] != ord(alpha[3])                                   # rows that never touch the NaN weight
-    assert np.array_equal(out[clean], got[clean]) and not np.isnan(out).any()
-    # a different alphabet order for the same model rebuilds the table
-    alpha2 = alpha[::-1]
-    lut2 = _native.make_lut(alpha2)
-    nms[0].set_weights(pairs[0][1])
-    got2, _ = eng.score(nms[:1], b, lut2)
-    assert_scores(got2[:, 0], ref_np.keras_fitness(seqs, alpha2, "ge", pairs[0][1], exact=True), "reversed alphabet")
-
-
-@pytest.mark.parametrize("L,H,M,n", [(14, 100, 1, 5000), (9, 100, 3, 333), (8, 64, 2, 100), (2, 100, 1, 40), (50, 100, 1, 1000)])
-def test_mlp_pair_rows_first_layer(eng, L, H, M, n):
-    """MLP layer 1 on a 4-letter alphabet from the pre-summed pair rows: within tolerance of the oracle and of the
-    row-per-position gather (one extra float32 rounding per pair), odd lengths, bad characters in either half of a pair."""
-    pairs = [make_native(eng, "mlp", L, 4, H, seed=70 + m) for m in range(M)]
-    nms = [p[0] for p in pairs]
-    lut = _native.make_lut("UGCA")
-    b, seqs = rand_seqs(n, L, "UGCA", seed=L)
-    got, _ = eng.score(nms, b, lut)
-    eng.set_option("mlp_pair", 0)
-    try:
-        single, _ = eng.score(nms, b, lut)
-    finally:
-        eng.set_option("mlp_pair", 1)
-    for m in range(M):
-        want = ref_np.keras_fitness(seqs, "UGCA", "mlp", pairs[m][1], exact=True)
-        assert_scores(got[:, m], want, f"mlp pair rows L={L} member {m}")
-        assert_scores(single[:, m], want, f"mlp single rows L={L} member {m}")
-    for col in {0, 1, L - 1}:
-        bb = b.copy()
-        bb[n - 1, col] = ord("T")                     # not in "UGCA"
-        with pytest.raises(ValueError):
-            eng.score(nms, bb, lut)
-
-
-@pytest.mark.parametrize("kind,L,alpha", [("mlp", 14, "UGCA"), ("ge", 90, s_utils.AAS), ("mlp", 9, "TGCA"), ("ge", 33, s_utils.AAS), ("cnn", 8, "TGCA")])
-def test_tile_bytes_staged_through_lds_equal_byte_loads_at_any_alignment(eng, kind, L, alpha):
-    """The MLP / GE kernels copy a tile's 16 x L bytes into LDS with 16-byte loads: same bits as the byte-load form
-    (`stage_bytes` = 0), for a device buffer that starts at any byte offset (a row offset into a caller's batch),
-    batches that end inside a tile, and one-sequence batches."""
-    import torch
-
-    F, K = (32, 5) if kind == "cnn" else (0, 0)
-    nm, w = make_native(eng, kind, L, len(alpha), 100, F, K, seed=3)
-    lut = _native.make_lut(alpha)
-    for n, off in ((1000, 0), (1000, 3), (37, 1), (16, 5), (1, 7), (4097, 13)):
-        b, seqs = rand_seqs(n, L, alpha, seed=n + off)
-        buf = torch.zeros(n * L + 64, dtype=torch.uint8, device="cuda")
-        buf[off:off + n * L] = torch.from_numpy(b.reshape(-1)).cuda()
-        outs = []
-        for stage in (1, 0):
-            eng.set_option("stage_bytes", stage)
-            out = torch.full((n, 1), float("nan"), dtype=torch.float32, device="cuda")
-            torch.cuda.synchronize()
-            eng.score_dev([nm], buf.data_ptr() + off, n, L, lut, out.data_ptr(), None)
-            eng.sync()
-            outs.append(out.cpu().numpy()[:, 0])
-        eng.set_option("stage_bytes", 1)
-        assert np.array_equal(outs[0], outs[1]), (kind, n, off)
-        assert_scores(outs[0], ref_np.keras_fitness(seqs, alpha, kind, w, exact=True), f"{kind} staged n={n} off={off}")
-
-
 @pytest.mark.parametrize("M", [1, 2, 3, 8, 11, 17])
 def test_ensemble_matrix_and_numpy_order_mean(eng, M):
     L, alpha = 8, "TGCA"
@@ -465,63 +200,6 @@ def test_reduce_kernel_golden(eng, golden_dir):
         assert np.array_equal(eng.ensemble_weighted_sum(x, w), np.sum(w * x, axis=1)), M
 
 
-def test_python_api_drop_in(eng):
-    """flexs.Model surface: dtypes, cost accounting (ensemble.py:55-57 via landscape.py:44), names."""
-    L, alpha = 14, "UGCA"
-    b, seqs = rand_seqs(333, L, alpha, seed=2)
-    members = [bm.CNN(L, 32, 100, alpha, seed=0), bm.MLP(L, 100, alpha, seed=1), bm.GlobalEpistasisModel(L, 100, alpha, seed=2)]
-    for m, kind in zip(members, ("cnn", "mlp", "ge")):
-        out = m.get_fitness(seqs)
-        assert out.dtype == np.float32 and out.shape == (333,) and m.cost == 333
-        assert_scores(out, ref_np.keras_fitness(seqs, alpha, kind, m.model.get_weights(), exact=True), kind)
-        assert np.array_equal(m.get_fitness(np.array(seqs)), out)            # ndarray input
-        assert np.array_equal(m.get_fitness(tuple(seqs[:5])), out[:5])
-        assert m.get_fitness([]).shape == (0,)
-    ens = flexs_amd.Ensemble(members)
-    for m in members:
-        m.cost = 0
-    out = ens.get_fitness(seqs)
-    assert ens.cost == 333 and all(m.cost == 333 for m in members)
-    stack = np.stack([m.get_fitness(seqs) for m in members], axis=1)
-    assert np.array_equal(out, np.mean(stack, axis=1))
-    ident = flexs_amd.Ensemble(members, combine_with=lambda x: x).get_fitness(seqs)   # BO's usage (bo.py:55-56)
-    assert np.array_equal(ident, stack)
-    ada = bm.AdaptiveEnsemble(members)
-    assert np.array_equal(ada.get_fitness(seqs), np.sum(ada.weights * stack, axis=1))
-    # weights reload (once per explorer round): set_weights must reach the device
-    new_w = ref_np.synth_weights(ref_np.mlp_shapes(L, 4, 100), 99)
-    members[1].model.set_weights(new_w)
-    assert_scores(members[1].get_fitness(seqs), ref_np.keras_fitness(seqs, alpha, "mlp", new_w, exact=True), "reloaded")
-    # the reference's own smoke scenario (tests/test_models.py:55-77)
-    bm.CNN(seq_len=3, num_filters=1, hidden_size=1, kernel_size=2, alphabet=s_utils.DNAA).get_fitness(["ATC"])
-    bm.GlobalEpistasisModel(seq_len=3, hidden_size=1, alphabet=s_utils.DNAA).get_fitness(["ATC"])
-    bm.MLP(seq_len=3, hidden_size=1, alphabet=s_utils.DNAA).get_fitness(["ATC"])
-
-
-def test_errors(eng):
-    cnn = bm.CNN(8, 32, 100, "TGCA", seed=0)
-    with pytest.raises(ValueError):
-        cnn.get_fitness(["ATGCATGX"])                      # str.index ValueError (sequence_utils.py:46)
-    assert cnn.get_fitness(["ATGCATGC"]).shape == (1,)     # engine still usable afterwards
-    with pytest.raises(ValueError):
-        cnn.get_fitness(["ATGC"])                          # wrong length
-    with pytest.raises(ValueError):
-        cnn.get_fitness(["ATGCATGC", "ATG"])               # ragged
-    with pytest.raises(ValueError):
-        s_utils.string_to_one_hot("ATXG", s_utils.DNAA)
-    lowercase = bm.MLP(4, 8, "TGCA", seed=0)
-    with pytest.raises(ValueError):
-        lowercase.get_fitness(["atgc"])
-    # nan_to_num (keras_model.py:77)
-    w = lowercase.model.get_weights()
-    w[-1][:] = np.nan
-    lowercase.model.set_weights(w)
-    assert lowercase.get_fitness(["ATGC"]).tolist() == [0.0]
-    w[-1][:] = np.inf
-    lowercase.model.set_weights(w)
-    assert lowercase.get_fitness(["ATGC"]).tolist() == [float(np.finfo(np.float32).max)]
-
-
 # ------------------------------------------------------------------ codecs
 def test_encode_decode_golden(eng, golden_dir):
     fx = json.load(open(os.path.join(golden_dir, "encode.json")))
@@ -544,174 +222,6 @@ def test_encode_decode_golden(eng, golden_dir):
         x[::3] = np.round(x[::3])
         x[5, 2, 1] = np.nan
         assert s_utils.one_hots_to_strings(x, alpha) == [ref_np.one_hot_to_string(r, alpha) for r in x]
-
-
-# ------------------------------------------------------------------ NoisyAbstractModel
-@pytest.mark.parametrize("L,nsym,C,Q", [(8, 4, 300, 200), (14, 4, 2500, 150), (66, 20, 700, 60), (90, 20, 1500, 40), (300, 20, 300, 12),
-                                        (513, 20, 200, 8), (735, 20, 150, 6), (769, 20, 1100, 5), (1000, 4, 300, 7), (1600, 20, 40, 3),
-                                        (238, 20, 300, 20), (64, 4, 200, 50), (65, 4, 200, 50), (1, 4, 10, 10)])
-def test_min_dist_vs_oracle(eng, L, nsym, C, Q):
-    rng = np.random.default_rng(L * 7 + C)
-    base = rng.integers(65, 65 + nsym, (1, L)).astype(np.uint8)
-    cache = np.repeat(base, C, 0)
-    mut = rng.random((C, L)) < 0.15
-    cache[mut] = rng.integers(65, 65 + nsym, mut.sum())
-    if L > 4:
-        rot = rng.random(C) < 0.3                    # shifted copies: Levenshtein < Hamming
-        cache[rot] = np.roll(cache[rot], 1, axis=1)
-    q = cache[rng.integers(0, C, Q)].copy()
-    qm = rng.random((Q, L)) < 0.1
-    q[qm] = rng.integers(65, 65 + nsym, qm.sum())
-    q[0] = cache[C // 2]                             # exact hit present
-    for mode in (0, 1):
-        d_want, a_want = c_oracle.min_dist(q, cache, mode)
-        d_got, a_got = eng.min_dist(q, cache, mode)
-        assert np.array_equal(d_got, d_want) and np.array_equal(a_got, a_want), (L, mode)
-        dc = _native.NativeCache(eng, L)
-        dc.append(cache[: C // 3]); dc.append(cache[C // 3:])
-        assert len(dc) == C
-        d2, a2 = dc.min_dist(q, mode)
-        assert np.array_equal(d2, d_want) and np.array_equal(a2, a_want)
-    d0, a0 = eng.min_dist(q, cache[:0])
-    assert (d0 == 0).all() and (a0 == -1).all()      # noisy_abstract_model.py:44-45
-
-
-def _ragged_strings(rng, n, lo, hi, alpha, base=None):
-    out = []
-    for _ in range(n):
-        if base is not None and rng.random() < 0.7:               # indel / substitution variants of one parent
-            s = list(base)
-            for _ in range(int(rng.integers(0, 4))):
-                r, i = rng.random(), int(rng.integers(0, max(len(s), 1)))
-                if r < 0.4 and len(s) > lo:
-                    del s[i]
-                elif r < 0.8 and len(s) < hi:
-                    s.insert(i, alpha[int(rng.integers(0, len(alpha)))])
-                elif s:
-                    s[i] = alpha[int(rng.integers(0, len(alpha)))]
-            out.append("".join(s))
-        else:
-            out.append("".join(alpha[i] for i in rng.integers(0, len(alpha), int(rng.integers(lo, hi + 1)))))
-    return out
-
-
-@pytest.mark.parametrize("lo,hi,alpha,C,Q", [(0, 12, "TGCA", 400, 120), (50, 80, s_utils.AAS, 300, 40),
-                                             (120, 200, s_utils.AAS, 150, 20), (1, 256, "UGCA", 60, 12)])
-def test_min_dist_ragged_lengths(eng, lo, hi, alpha, C, Q):
-    """`editdistance.eval` takes two strings of any lengths (noisy_abstract_model.py:51): NUL-padded rows."""
-    rng = np.random.default_rng(lo * 31 + hi)
-    base = "".join(alpha[i] for i in rng.integers(0, len(alpha), (lo + hi) // 2))
-    keys = list(dict.fromkeys(_ragged_strings(rng, C, lo, hi, alpha, base)))
-    queries = _ragged_strings(rng, Q, lo, hi, alpha, base) + [keys[len(keys) // 2], keys[-1][:-1] if keys[-1] else "A"]
-    queries = [q for q in queries if len(q) <= hi]
-    want = [ref_np.min_distance(q, keys, c_oracle.levenshtein) for q in queries]
-    for row in (hi, min(256, hi + 7)):                               # row wider than the longest sequence too
-        cache = _native.NativeCache(eng, row)
-        cache.append(_native.ragged_to_bytes(keys[: len(keys) // 2], row))
-        cache.append(_native.ragged_to_bytes(keys[len(keys) // 2:], row))
-        d, a = cache.min_dist(_native.ragged_to_bytes(queries, row), 0)
-        assert [(int(x), keys[i]) for x, i in zip(d, a)] == want
-        full = cache.distances(_native.ragged_to_bytes(queries[:6], row), 0)
-        assert [[int(v) for v in r] for r in full] == [[min(c_oracle.levenshtein(q, k), 255) for k in keys] for q in queries[:6]]
-    d, a = eng.min_dist(_native.ragged_to_bytes(queries, hi), _native.ragged_to_bytes(keys, hi), 0)
-    assert [(int(x), keys[i]) for x, i in zip(d, a)] == want
-
-
-def test_nam_ragged_lengths_match_oracle(eng):
-    """NoisyAbstractModel over sequences of unequal lengths (insertions / deletions), including a query
-    longer than anything cached (forces wider device rows): same floats, cache order and RNG position
-    as the restated reference loop."""
-    rng = np.random.default_rng(11)
-    alpha = "UGCA"
-    base = "".join(alpha[i] for i in rng.integers(0, 4, 14))
-    pool = list(dict.fromkeys(_ragged_strings(rng, 500, 9, 18, alpha, base)))
-    table = {s: float(rng.random()) for s in pool + ["".join(alpha[i] for i in rng.integers(0, 4, 30))]}
-    long_one = list(table)[-1]
-
-    class Table(flexs_amd.Landscape):
-        def __init__(self):
-            super().__init__("table")
-
-        def _fitness_function(self, seqs):
-            return np.array([table[str(s)] for s in seqs])
-
-    outs = []
-    for cls in (bm.NoisyAbstractModel, ref_np.NoisyAbstractModelOracle):
-        land = Table()
-        np.random.seed(3)
-        nam = cls(land, 0.8)
-        nam.train(pool[:40], np.array([table[s] for s in pool[:40]]))
-        o = [nam.get_fitness(pool[40 + 60 * i: 100 + 60 * i]) for i in range(4)]
-        o.append(nam.get_fitness([long_one] + pool[300:330]))
-        o.append(nam.get_fitness(pool[20:120]))
-        outs.append((np.concatenate(o), land.cost, nam.cost, list(nam.cache), float(np.random.random())))
-    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1:] == outs[1][1:]
-
-
-def test_min_dist_known_answers(eng, golden_dir):
-    known = json.load(open(os.path.join(golden_dir, "edit_distance_known.json")))["known"]
-    for k in known:
-        q = np.frombuffer(k["seq"].encode(), np.uint8)[None]
-        c = np.frombuffer(k["wt"].encode(), np.uint8)[None]
-        d, a = eng.min_dist(q, c, 0)
-        assert d[0] == k["levenshtein_dp"] and a[0] == 0
-        assert eng.min_dist(q, c, 1)[0][0] == k["hamming"]
-
-
-def test_nam_traces_bit_exact(eng, golden_dir):
-    """NoisyAbstractModel through the product class == the reference's outputs for seeded
-    traces: float64 values, oracle-call counts, cache order and RNG state."""
-    traces = json.load(open(os.path.join(golden_dir, "nam_traces.json")))["traces"]
-
-    class Table(flexs_amd.Landscape):
-        def __init__(self, values):
-            super().__init__("Table")
-            self.values = values
-
-        def _fitness_function(self, seqs):
-            return np.array([self.values[str(s)] for s in seqs])
-
-    for tr in traces:
-        land = Table(tr["landscape_values"])
-        np.random.seed(tr["seed"])
-        nam = bm.NoisyAbstractModel(land, signal_strength=tr["ss"])
-        assert nam.name == tr["name"]
-        if tr["empty_first"]:
-            m0 = bm.NoisyAbstractModel(Table(tr["landscape_values"]), signal_strength=tr["ss"])
-            assert m0.get_fitness(tr["empty_first"]["query"]).tolist() == tr["empty_first"]["out"]
-            assert len(m0.cache) == 1
-            np.random.seed(tr["seed"])
-        nam.train(tr["train_sequences"], tr["train_labels"])
-        for b, batch in enumerate(tr["batches"]):
-            out = nam.get_fitness(batch)
-            assert out.dtype == np.float64
-            assert out.tolist() == tr["outputs"][b], (tr["L"], b)
-            assert land.cost == tr["landscape_cost"][b]
-            assert len(nam.cache) == tr["cache_len"][b] and nam.cost == tr["model_cost"][b]
-        assert list(nam.cache.keys()) == tr["cache_keys_in_order"]
-        assert float(np.random.random()) == tr["rng_next_random"]
-    # the reference's own scenario (tests/test_models.py:80-99)
-    class Const(flexs_amd.Landscape):
-        def _fitness_function(self, seqs):
-            return np.ones(len(seqs)) * 2
-
-    nam = bm.NoisyAbstractModel(Const("c"), signal_strength=1)
-    assert nam.get_fitness(["ATC"]) == [2]
-    nam = bm.NoisyAbstractModel(Const("c"), signal_strength=0)
-    f = nam.get_fitness(["ATC"])
-    assert len(nam.cache) == 1 and nam.get_fitness(["ATC"]) == f
-    assert nam.get_fitness(["ATG"]) != [2]
-
-
-def test_nam_combine_kernel(eng):
-    rng = np.random.default_rng(0)
-    Q = 5001
-    signal, noise = rng.random(Q), rng.exponential(1.0, Q)
-    d = rng.integers(0, 15, Q).astype(np.int32)
-    for ss in (0.0, 0.5, 0.9, 1.0):
-        tab = np.array([ss ** k for k in range(15)])
-        want = np.array([tab[k] * s + (1 - tab[k]) * n for k, s, n in zip(d, signal, noise)])
-        assert np.array_equal(eng.nam_combine(signal, noise, d, tab), want)
 
 
 # ------------------------------------------------------------------ BASELINE sizes: properties
@@ -849,132 +359,6 @@ def test_baseline_config5_eight_members_and_gfp_238(eng):
         assert np.array_equal(part, nm[1_234:5_678])
 
 
-# ------------------------------------------------------------------ "next" rows
-def _write_tf_file(path, rng, n_pairs=2000):
-    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
-    seen, rows = set(), []
-    while len(rows) < n_pairs:
-        s = "".join("ACGT"[i] for i in rng.integers(0, 4, 8))
-        rc = "".join(comp[c] for c in reversed(s))
-        if s in seen or rc in seen:
-            continue
-        seen.update((s, rc))
-        rows.append((s, rc, rng.uniform(-0.3, 0.5), rng.uniform(1e3, 1e5), rng.normal()))
-    with open(path, "w") as f:
-        f.write("8-mer\t8-mer\tE-score\tMedian\tZ-score\n")          # the reference files repeat the column name
-        for r in rows:
-            f.write("%s\t%s\t%.5f\t%.2f\t%.4f\n" % r)
-    return rows
-
-
-def test_tf_binding_device_table(eng, tmp_path):
-    from flexs_amd.landscapes import TFBinding
-
-    rng = np.random.default_rng(0)
-    rows = _write_tf_file(tmp_path / "X_8mers.txt", rng)
-    land = TFBinding(str(tmp_path / "X_8mers.txt"))
-    assert land.name == "TF_Binding" and land.cost == 0
-    e = np.array([float("%.5f" % r[2]) for r in rows])
-    norm = (e - e.min()) / (e.max() - e.min())                       # tf_binding.py:33-34
-    want = {}
-    want.update({r[0]: v for r, v in zip(rows, norm)})
-    want.update({r[1]: v for r, v in zip(rows, norm)})
-    keys = list(want)
-    got = land.get_fitness(keys)
-    assert got.dtype == np.float64 and land.cost == len(keys)
-    assert np.array_equal(got, np.array([want[k] for k in keys]))
-    assert np.array_equal(land.get_fitness(np.array(keys[:7])), got[:7])
-    missing = next(s for s in ("".join("ACGT"[(i >> (2 * k)) & 3] for k in range(8)) for i in range(65536)) if s not in want)
-    with pytest.raises(KeyError):
-        land.get_fitness([keys[0], missing])
-    with pytest.raises(KeyError):
-        land.get_fitness(["ACGTACGX"])
-    with pytest.raises(KeyError):
-        land.get_fitness(["ACG"])
-    reg = flexs_amd.landscapes.tf_binding.registry(str(tmp_path))
-    assert list(reg) == ["X"] and len(reg["X"]["starts"]) == 14 and reg["X"]["params"]["landscape_file"].endswith("X_8mers.txt")
-
-
-def test_nam_batched_landscape_path_is_identical(eng, tmp_path):
-    """A `batch_safe` table landscape is queried in two batches instead of 2*Q calls: values,
-    costs and RNG stream must not change (noisy_abstract_model.py:86-94)."""
-    from flexs_amd.landscapes import TFBinding
-
-    rng = np.random.default_rng(1)
-    rows = _write_tf_file(tmp_path / "Y_8mers.txt", rng, n_pairs=6000)
-    keys = [r[0] for r in rows] + [r[1] for r in rows]
-
-    class Plain(flexs_amd.Landscape):                 # same values, one-by-one path
-        def __init__(self, inner):
-            super().__init__("plain")
-            self.inner = inner
-
-        def _fitness_function(self, seqs):
-            return self.inner._fitness_function(seqs)
-
-    outs = []
-    for wrap in (False, True):
-        land = TFBinding(str(tmp_path / "Y_8mers.txt"))
-        target = Plain(land) if wrap else land
-        np.random.seed(5)
-        nam = bm.NoisyAbstractModel(target, 0.9)
-        nam.train(keys[:50], land._fitness_function(keys[:50]))
-        o = [nam.get_fitness(keys[50 + 200 * i: 250 + 200 * i]) for i in range(3)]
-        o.append(nam.get_fitness(keys[100:400]))
-        outs.append((np.concatenate(o), target.cost, float(np.random.random()), list(nam.cache)))
-    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1:] == outs[1][1:]
-
-
-def test_sequence_density(eng):
-    """dyna_ppo.py:106-114 through the distance-matrix kernel, bit-identical to the Python loop."""
-    from flexs_amd.utils.edit_distance import SeenSequences
-
-    rng = np.random.default_rng(2)
-    for L, alpha in ((14, "UGCA"), (70, s_utils.AAS)):
-        base = "".join(alpha[i] for i in rng.integers(0, len(alpha), L))
-        seen = SeenSequences(L)
-        ref = {}
-        for _ in range(400):
-            s = list(base)
-            for _ in range(int(rng.integers(0, 4))):
-                s[int(rng.integers(0, L))] = alpha[int(rng.integers(0, len(alpha)))]
-            if rng.random() < 0.3:
-                s = s[1:] + s[:1]
-            s, f = "".join(s), float(rng.random())
-            seen.add(s, f)
-            ref[s] = f
-        assert len(seen) == len(ref) and seen[base] == ref[base] if base in ref else True
-        for q in list(ref)[:25] + [base]:
-            dens = 0
-            for s in ref:
-                d = c_oracle.levenshtein(s, q)
-                if d != 0 and d <= 2:
-                    dens += ref[s] / d
-            assert seen.density(q) == dens
-        # the batch form (one distance launch, the neighbours of all queries found with three array operations): same sums
-        qs = list(ref)[:40] + [base, base[1:] + base[:1]]
-        assert seen.densities(qs) == [seen.density(q) for q in qs]
-        assert seen.densities([]) == []
-        assert [type(v) for v in seen.densities(qs)] == [type(seen.density(q)) for q in qs]      # (int 0 without neighbours, as the reference)
-        for radius in (0, 1, 2, 3, 4):                    # (1 .. 3: the banded kernel, min(d, radius + 1); else the exact matrix)
-            want_r = [seen.density(q, radius) for q in qs]
-            assert seen.densities(qs, radius) == want_r, radius
-            eng.set_option("dist_bounded", 0)
-            try:
-                assert seen.densities(qs, radius) == want_r, radius
-            finally:
-                eng.set_option("dist_bounded", 1)
-        # ragged queries and keys (shorter than the row, insertions / deletions at either end) through the band
-        short = [q[:-1] for q in qs[:8]] + [q[1:] for q in qs[:8]] + [q[2:] for q in qs[:4]] + [qs[0][:3], ""]
-        assert seen.densities(short) == [seen.density(q) for q in short]
-        # float32 fitness values divide and add in float32 under NumPy's rules: the batch form follows (Python operations)
-        seen32 = SeenSequences(L)
-        for s_, f_ in list(ref.items())[:120]:
-            seen32.add(s_, np.float32(f_))
-        assert seen32.densities(qs[:10]) == [seen32.density(q) for q in qs[:10]]
-    assert SeenSequences(5).density("ACGTA") == 0 and SeenSequences(5).densities(["ACGTA", "AC"]) == [0, 0]
-
-
 # ------------------------------------------------------------------ randomised shapes (dispatch boundaries)
 def test_random_shapes_against_oracle(eng):
     """60 random (kind, L, alphabet, F, H, K, N) draws straddling the MFMA / shape-agnostic dispatch
@@ -1014,324 +398,6 @@ def test_multi_member_launches(eng, kind, L, A, alpha, M, n):
     assert np.array_equal(mean, np.mean(nm, axis=1))
 
 
-# ------------------------------------------------------------------ additive landscape (section 8f-4)
-def test_additive_aav_matches_reference_fixture(eng, golden_dir, tmp_path):
-    """`AdditiveAAVPackaging` through the device table == the outputs of the reference class
-    (tests/golden/additive_aav.json): bit-exact floats, cost, RNG position, KeyError past the window."""
-    from flexs_amd.landscapes import AdditiveAAVPackaging
-    from flexs_amd.landscapes.additive_aav_packaging import registry
-
-    g = json.load(open(os.path.join(golden_dir, "additive_aav.json")))
-    path = str(tmp_path / "AAV2_single_subs.json")
-    json.dump(g["single_subs"], open(path, "w"))
-    for case in g["cases"]:
-        land = AdditiveAAVPackaging(data_file=path, **case["params"])
-        assert land.name == case["name"] and land.top_seq == case["top_seq"] and land.wild_type == case["wild_type"]
-        assert float(land.max_possible) == case["max_possible"]
-        np.random.seed(case["seed"])
-        out1 = land.get_fitness(case["sequences"])
-        out2 = land.get_fitness(np.array(case["sequences"][:7]))
-        assert str(out1.dtype) == case["dtype"]
-        assert out1.tolist() == case["fitness"] and out2.tolist() == case["fitness_second_call"]
-        assert land.cost == case["cost"] and float(np.random.random()) == case["rng_next_random"]
-        assert land._get_raw_fitness(case["sequences"][3]) == ref_np.AdditiveAAVOracle(g["single_subs"], **case["params"]).raw(case["sequences"][3])
-    with pytest.raises(KeyError) as err:
-        AdditiveAAVPackaging(data_file=path, start=450, end=460).get_fitness(["A" * 11])
-    assert err.value.args[0] == g["too_long_keyerror"]
-    assert registry() == g["registry"]
-    assert AdditiveAAVPackaging(data_file=path, start=450, end=460).get_fitness([]).shape == (0,)
-
-
-@pytest.mark.parametrize("L,n", [(90, 3001), (735, 517), (1, 40), (300, 70)])
-def test_additive_sum_kernel_vs_python_loop(eng, L, n):
-    """fx_table_additive at the registry window (90), the whole capsid (735: several LDS tiles per block) and
-    edge sizes: the in-order float64 sum of the Python loop, bit for bit."""
-    rng = np.random.default_rng(L)
-    ncol = 21
-    table = np.round(rng.normal(0, 2, (L, ncol)), 4)
-    table[:, -1] = 0.0
-    table[rng.random((L, ncol)) < 0.2] = 0.0
-    lut = np.full(256, ncol - 1, np.uint8)
-    for col, aa in enumerate(s_utils.AAS):
-        lut[ord(aa)] = col
-    rows = np.frombuffer((s_utils.AAS + "XZ").encode(), np.uint8)[rng.integers(0, 22, (n, L))]
-    rows[1, L // 2:] = 0                                            # NUL-padded short row
-    got = _native.NativeTable(eng, table, "", lut=lut).additive_sum(rows)
-    want = np.empty(n)
-    for i in range(n):
-        acc = 0
-        for p in range(L):
-            acc += float(table[p, lut[rows[i, p]]])
-        want[i] = acc
-    assert np.array_equal(got, want)
-    with pytest.raises(ValueError):
-        _native.NativeTable(eng, table, "", lut=lut).additive_sum(rows[:, :-1] if L > 1 else np.zeros((2, 3), np.uint8))
-
-
-def test_sharded_cache_degenerates_to_local_on_one_gpu(eng):
-    """flexs_amd.distributed.ShardedCache without a process group (world = 1) over the real device store."""
-    from flexs_amd import distributed as fd
-
-    rng = np.random.default_rng(8)
-    keys = rng.integers(65, 69, (700, 14)).astype(np.uint8)
-    q = keys[rng.integers(0, 700, 90)].copy()
-    m = rng.random(q.shape) < 0.1
-    q[m] = rng.integers(65, 69, m.sum())
-    sc = fd.ShardedCache(14)
-    assert sc.min_dist(q)[1].tolist() == [-1] * 90
-    sc.append(keys[:123]); sc.append(keys[123:])
-    for mode in (0, 1):
-        d, a = sc.min_dist(q, mode)
-        d_want, a_want = c_oracle.min_dist(q, keys, mode)
-        assert np.array_equal(d, d_want) and np.array_equal(a, a_want)
-
-
-# ------------------------------------------------------------------ population step (section 8f-2)
-@pytest.mark.parametrize("which", ["ensemble", "single", "host-stacked"])
-def test_population_evaluator_equals_one_by_one_loop(eng, which):
-    """cmaes.py:61-67 + 83-93 for a whole population at once == the reference's loop of
-    `get_fitness([seq]).item()` calls: strings, values (bit for bit), cost on the model and its members."""
-    from flexs_amd.utils.population import PopulationEvaluator
-
-    L, alpha, P = 8, "TGCA", 37
-    rng = np.random.default_rng(5)
-
-    def build():
-        members = [bm.CNN(L, 32, 100, alpha, seed=s) for s in range(3)]
-        if which == "single":
-            return members[0], [members[0]]
-        if which == "host-stacked":                      # custom reduction: not fused, answered one by one
-            return flexs_amd.Ensemble(members, combine_with=lambda x: np.median(x, axis=1)), members
-        return flexs_amd.Ensemble(members), members
-
-    model, members = build()
-    twin, twin_members = build()
-    x = rng.standard_normal((P, L * len(alpha)))
-    x[5] = x[2]                                          # duplicate solutions inside one population
-    x[9, :4] = 0.0                                       # a tie: first maximum wins
-    want_seqs = [ref_np.one_hot_to_string(r.reshape(L, len(alpha)), alpha) for r in x]
-    known_a = {want_seqs[0]: 123.0, want_seqs[7]: -1.5}
-    known_b = {want_seqs[0]: 999.0, want_seqs[11]: 0.25}
-    want_vals = []
-    for s in want_seqs:                                  # objective_function, cmaes.py:83-93
-        if s in known_a:
-            want_vals.append(known_a[s])
-        elif s in known_b:
-            want_vals.append(known_b[s])
-        else:
-            want_vals.append(twin.get_fitness([s]).item())
-    ev = PopulationEvaluator(model, alpha, L)
-    assert ev.decode(x) == want_seqs
-    seqs, vals = ev.evaluate(x, known=(known_a, known_b))
-    assert seqs == want_seqs and vals.dtype == np.float64 and vals.tolist() == want_vals
-    # ... and the values themselves against the ORACLE (the loop above compares the HIP path with itself)
-    fresh = [i for i, s_ in enumerate(want_seqs) if s_ not in known_a and s_ not in known_b]
-    stack = np.stack([ref_np.keras_fitness([want_seqs[i] for i in fresh], alpha, "cnn", m.model.get_weights(), exact=True)
-                      for m in members], axis=1)
-    want_oracle = stack[:, 0] if which == "single" else (np.median(stack, axis=1) if which == "host-stacked" else stack.mean(axis=1))
-    assert_scores(vals[fresh].astype(np.float32), want_oracle, f"population values ({which})")
-    assert model.cost == twin.cost == P - 3
-    if which != "single":
-        assert [m.cost for m in members] == [m.cost for m in twin_members] == [P - 3] * 3
-    assert ev.evaluate(np.zeros((0, L * 4)))[0] == []
-    # no `known` dicts (DyNA-PPO's environment step): argmax + scoring + strings in one C call (strpack.population_step) == the step in
-    # pieces (host argmax, Engine.score, per-row str) == the device argmax form, values and cost
-    from flexs_amd.utils import population
-    c0 = model.cost
-    seqs1, vals1 = ev.evaluate(x)
-    assert seqs1 == want_seqs and model.cost == c0 + P
-    helper = _native._strpack.population_step if which != "host-stacked" and hasattr(_native._strpack, "population_step") else None
-    try:
-        if helper is not None:
-            del _native._strpack.population_step             # (the step in pieces)
-        seqs2, vals2 = ev.evaluate(x)
-        population.HOST_DECODE = False                       # (argmax on the device: fx_decode_score)
-        seqs3, vals3 = ev.evaluate(x)
-    finally:
-        population.HOST_DECODE = True
-        if helper is not None:
-            _native._strpack.population_step = helper
-    assert seqs2 == want_seqs and seqs3 == want_seqs
-    assert vals1.tolist() == vals2.tolist() == vals3.tolist()
-    assert vals1.tolist() == [twin.get_fitness([s_]).item() for s_ in want_seqs]
-    if which != "host-stacked":
-        with pytest.raises(ValueError):
-            PopulationEvaluator(model, "UGCA", L)
-
-
-def test_terminal_rewards_equal_environment_loop(eng):
-    """environments/dyna_ppo.py:106-114 + 144-163 for a whole environment batch: same sequences, fitnesses and
-    density-penalised rewards as the per-sequence Python loops (density counted after the batch is recorded)."""
-    from flexs_amd.utils.edit_distance import SeenSequences
-    from flexs_amd.utils.population import PopulationEvaluator, terminal_rewards
-
-    L, alpha, B, lam = 14, "UGCA", 24, 0.1
-    rng = np.random.default_rng(6)
-    model = flexs_amd.Ensemble([bm.MLP(L, 100, alpha, seed=s) for s in range(2)])
-    twin = flexs_amd.Ensemble([bm.MLP(L, 100, alpha, seed=s) for s in range(2)])
-    seen, all_seqs = SeenSequences(L), {}
-    ev = PopulationEvaluator(model, alpha, L)
-    base = rng.integers(0, 4, L)
-    for episode in range(3):
-        states = np.zeros((B, L, len(alpha) + 1))
-        for b in range(B):
-            codes = base.copy()
-            m = rng.random(L) < 0.1
-            codes[m] = rng.integers(0, 4, m.sum())
-            states[b, np.arange(L), codes] = 1
-        states[1] = states[0]                                         # duplicates inside one batch
-        seqs, fit, rew = terminal_rewards(ev, seen, states, lam)
-        want_seqs = [ref_np.one_hot_to_string(st[:, :-1], alpha) for st in states]
-        want_fit = twin.get_fitness(want_seqs)
-        all_seqs.update(zip(want_seqs, want_fit.astype(np.float64)))
-        want_rew = []
-        for s_, f in zip(want_seqs, want_fit.astype(np.float64)):
-            dens = 0
-            for k in all_seqs:
-                dist = c_oracle.levenshtein(k, s_)
-                if dist != 0 and dist <= 2:
-                    dens += all_seqs[k] / dist
-            want_rew.append(f - lam * dens)
-        assert seqs == want_seqs and fit.tolist() == want_fit.astype(np.float64).tolist()
-        assert rew.tolist() == want_rew
-        assert model.cost == twin.cost and len(seen) == len(all_seqs)
-
-
-def test_distributed_classes_on_one_rank_rccl(eng):
-    """flexs_amd.distributed over a real one-rank RCCL group (backend "nccl"): the device all-gather, weight
-    broadcast and the default on-engine scorers -- what the gloo tests replace by stubs -- give the single-GPU
-    Ensemble / cache answers."""
-    import socket
-
-    import torch
-    import torch.distributed as dist
-
-    from flexs_amd import distributed as fd
-
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
-                            device_id=torch.device("cuda", 0))
-    try:
-        L, alpha = 14, "UGCA"
-        members = [bm.CNN(L, 32, 100, alpha, seed=0), bm.CNN(L, 32, 100, alpha, seed=1), bm.CNN(L, 32, 100, alpha, seed=2)]
-        b, seqs = rand_seqs(257, L, alpha, seed=4)
-        want = flexs_amd.Ensemble(members).get_fitness(seqs)
-        stack = np.stack([m.get_fitness(seqs) for m in members], axis=1)
-        for mode in ("member", "sequence"):
-            for force in (True, False):              # the real RCCL all-gather on device buffers / the one-rank alias
-                ens = fd.DistributedEnsemble(members, mode=mode)
-                ens.force_collective = force
-                assert np.array_equal(ens.get_fitness(seqs), want)
-                mat = fd.DistributedEnsemble(members, mode=mode, combine_with=lambda x: x)
-                mat.force_collective = force
-                assert np.array_equal(mat.get_fitness(seqs), stack)
-                ens.broadcast_weights(src=0)
-                assert np.array_equal(ens.get_fitness(seqs), want)
-                # the two halves on a batch already resident in HBM, both buffer slots in flight (what bench.py does)
-                with torch.cuda.stream(ens.stream):
-                    d_seq = torch.from_numpy(b).cuda()
-                ens.launch(d_seq, slot=0, want="mean")
-                ens.launch(d_seq, slot=1, want="matrix")
-                got_mean, got_mat = ens.finish(0), ens.finish(1)
-                ens.stream.synchronize()
-                assert np.array_equal(got_mean.cpu().numpy(), want) and np.array_equal(got_mat.cpu().numpy(), stack)
-                with pytest.raises(ValueError):
-                    ens.get_fitness(seqs[:5] + ["Z" * L])
-                assert np.array_equal(ens.get_fitness(seqs), want)
-            assert ens.cost == 3 * 257 + 6 and all(m.cost > 0 for m in members)
-        sc = fd.ShardedCache(L)
-        sc.append(b[:200])
-        d, a = sc.min_dist(b[150:])
-        d_want, a_want = c_oracle.min_dist(b[150:], b[:200], 0)
-        assert np.array_equal(d, d_want) and np.array_equal(a, a_want)
-    finally:
-        dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("kind,L,alpha,M,n", [("cnn", 8, "TGCA", 8, 1000), ("ge", 90, s_utils.AAS, 8, 333), ("mlp", 14, "UGCA", 17, 65)])
-def test_distributed_ensemble_without_a_process_group(eng, kind, L, alpha, M, n):
-    """No torch.distributed at all (world = 1): DistributedEnsemble is the device-resident path of a plain Ensemble --
-    planes in HBM, K3 on the planes, only the result copied back -- and must give Ensemble's bits."""
-    from flexs_amd import distributed as fd
-
-    mk = {"cnn": lambda s: bm.CNN(L, 32, 100, alpha, seed=s), "ge": lambda s: bm.GlobalEpistasisModel(L, 100, alpha, seed=s),
-          "mlp": lambda s: bm.MLP(L, 100, alpha, seed=s)}[kind]
-    members = [mk(s) for s in range(M)]
-    b, seqs = rand_seqs(n, L, alpha, seed=11)
-    want = flexs_amd.Ensemble(members).get_fitness(seqs)
-    stack = flexs_amd.Ensemble(members, combine_with=lambda x: x).get_fitness(seqs)
-    for mode in ("member", "sequence"):
-        assert np.array_equal(fd.DistributedEnsemble(members, mode=mode).get_fitness(seqs), want)
-        assert np.array_equal(fd.DistributedEnsemble(members, mode=mode, combine_with=lambda x: x).get_fitness(seqs), stack)
-    assert fd.DistributedEnsemble(members).get_fitness([]).shape == (0,)
-
-
-def test_big_string_batches_are_scored_in_overlapping_pieces(eng):
-    """list[str] batches of >= 32768 sequences take the chunked host call (fx_score_begin / _submit / _finish):
-    same scores, cost accounting and exceptions as the one-piece call."""
-    L, alpha, N = 8, "TGCA", 70_001
-    members = [bm.CNN(L, 32, 100, alpha, seed=s) for s in range(3)]
-    ens = flexs_amd.Ensemble(members)
-    b, seqs = rand_seqs(N, L, alpha, seed=21)
-    assert _native.wants_chunked(seqs, L) and not _native.wants_chunked(seqs[:100], L)
-    want_nm, want_mean = eng.score([m.native() for m in members], b, members[0]._lut, want_matrix=True, want_mean=True)
-    assert np.array_equal(ens.get_fitness(seqs), want_mean)                      # chunked, fused mean
-    assert np.array_equal(ens.get_fitness(tuple(seqs)), want_mean)
-    assert np.array_equal(members[1].get_fitness(seqs), want_nm[:, 1])           # chunked, single model
-    assert np.array_equal(flexs_amd.Ensemble(members, combine_with=lambda x: x).get_fitness(seqs), want_nm)
-    assert ens.cost == 2 * N and members[0].cost == 3 * N and members[1].cost == 4 * N
-    for chunks in (1, 3, 7):
-        nm, mean = eng.score_strings([m.native() for m in members], seqs, L, members[0]._lut, True, True, chunks=chunks)
-        assert np.array_equal(nm, want_nm) and np.array_equal(mean, want_mean)
-    for pos, bad, exc in ((N - 5, "TGCAZGCA", ValueError), (N - 5, "TGCA", ValueError), (60_000, 7, TypeError),
-                          (3, "TGCATΔCA", ValueError)):
-        broken = list(seqs)
-        broken[pos] = bad
-        with pytest.raises(exc):
-            ens.get_fitness(broken)
-        assert np.array_equal(ens.get_fitness(seqs[:40_000]), want_mean[:40_000])   # the engine is usable afterwards
-
-
-@pytest.mark.parametrize("kind,L,alpha,M,n", [("cnn", 8, "TGCA", 3, 100_001), ("cnn", 8, "TGCA", 1, 5), ("mlp", 14, "UGCA", 8, 1003),
-                                              ("ge", 90, s_utils.AAS, 16, 257), ("cnn", 237, s_utils.AAS, 2, 40),
-                                              ("cnn", 9, "TGCA", 3, 77), ("mlp", 14, "UGCA", 17, 300)])
-def test_mean_only_path_uses_planes_and_matches_matrix_path(eng, kind, L, alpha, M, n):
-    """Asking for the mean only lets the engine keep the scores as member-major planes (contiguous stores);
-    the mean must equal np.mean over the (N, M) matrix of the other path bit for bit, for every kernel family
-    (MFMA, pair / segmented, shape-agnostic) and through the explicit two-call form."""
-    import torch
-
-    F, K = (32, 5) if kind == "cnn" else (0, 0)
-    if L == 9:
-        F, K = 8, 4                                             # shape-agnostic kernels
-    natives, _ = zip(*[make_native(eng, kind, L, len(alpha), 100 if L != 9 else 20, F, K, seed=300 + m) for m in range(M)])
-    lut = _native.make_lut(alpha)
-    b, _ = rand_seqs(n, L, alpha, seed=n)
-    nm, mean_a = eng.score(list(natives), b, lut, want_matrix=True, want_mean=True)      # row-major intermediate
-    _, mean_b = eng.score(list(natives), b, lut, want_matrix=False, want_mean=True)      # planes (M <= 16)
-    assert np.array_equal(mean_a, np.mean(nm, axis=1)) and np.array_equal(mean_b, mean_a)
-    d_in = torch.from_numpy(b).cuda()
-    d_mean = torch.full((n,), float("nan"), device="cuda")
-    eng.score_dev(list(natives), d_in.data_ptr(), n, L, lut, None, d_mean.data_ptr())
-    eng.sync()
-    assert np.array_equal(d_mean.cpu().numpy(), mean_a)
-    if M <= 16:
-        stride = (n + 63) // 64 * 64
-        planes = torch.full((M, stride), float("nan"), device="cuda")
-        d_mean.fill_(float("nan"))
-        eng.score_planes_dev(list(natives), d_in.data_ptr(), n, L, lut, planes.data_ptr(), stride)
-        eng.ensemble_mean_planes_dev(planes.data_ptr(), n, M, stride, d_mean.data_ptr())
-        eng.sync()
-        assert np.array_equal(planes[:, :n].t().cpu().numpy(), nm) and np.array_equal(d_mean.cpu().numpy(), mean_a)
-        off = torch.full((n + 1,), float("nan"), device="cuda")       # a destination that is not 16-byte aligned
-        eng.ensemble_mean_planes_dev(planes.data_ptr(), n, M, stride, off.data_ptr() + 4)
-        eng.sync()
-        assert np.array_equal(off[1:].cpu().numpy(), mean_a)
-
-
 @pytest.mark.parametrize("L,alpha,F,K,n,M", [(8, "TGCA", 32, 3, 3000, 3), (14, "UGCA", 32, 7, 3000, 2), (50, "UGCA", 24, 3, 40, 1),
                                              (50, "UGCA", 17, 7, 40, 1), (8, "TGCA", 20, 5, 70_000, 3), (9, "TGCA", 32, 7, 100, 1),
                                              (60, s_utils.AAS, 32, 3, 300, 2), (60, s_utils.AAS, 28, 7, 33, 1), (237, s_utils.AAS, 32, 3, 20, 1),
@@ -1358,201 +424,6 @@ def test_cnn_other_kernel_sizes_and_filter_counts_on_mfma(eng, L, alpha, F, K, n
     assert np.allclose(got, ref, rtol=2e-5, atol=2e-6)
 
 
-def test_c_abi_misuse_is_reported_not_fatal(eng):
-    """Status codes of the C ABI on misuse: every call returns an fx_status (mapped to ValueError / FxError by the
-    Python layer), nothing aborts, and the engine keeps working afterwards."""
-    import ctypes as C
-
-    lib, h = eng._lib, eng.handle
-    lut = _native.make_lut("TGCA")
-    nm, w = make_native(eng, "cnn", 8, 4, 100, 32, 5, seed=1)
-    b, _ = rand_seqs(32, 8, "TGCA", seed=1)
-    good, _ = eng.score([nm], b, lut)
-    # weights never set
-    empty = _native.NativeModel(eng, _native.FX_CNN, 8, 4, 32, 100, 5)
-    with pytest.raises(_native.FxError) as err:
-        eng.score([empty], b, lut)
-    assert err.value.code == _native.FX_ESTATE
-    # wrong sequence length for the model -> ValueError (Keras shape error)
-    with pytest.raises(ValueError):
-        eng.score([nm], b[:, :7].copy(), lut)
-    # LUT that maps a byte beyond the alphabet
-    bad_lut = lut.copy(); bad_lut[ord("Z")] = 9
-    with pytest.raises(_native.FxError) as err:
-        eng.score([nm], b, bad_lut)
-    assert err.value.code == _native.FX_EINVAL
-    # members with different alphabets / a valid-conv that cannot exist / wrong weight count
-    with pytest.raises(ValueError):
-        eng.score([nm, make_native(eng, "cnn", 8, 20, 100, 32, 5, seed=2)[0]], b, lut)
-    with pytest.raises((ValueError, _native.FxError)):
-        _native.NativeModel(eng, _native.FX_CNN, 3, 4, 32, 100, 5)                     # L < kernel_size
-    with pytest.raises((ValueError, _native.FxError)):
-        nm.set_weights(w[:-1])
-    # raw calls: null buffers, negative sizes, unknown option, protocol errors
-    arr = (C.c_void_p * 1)(nm.handle)
-    assert lib.fx_score(h, arr, 1, None, 4, 8, lut.ctypes.data_as(_native._u8p), None, None) == _native.FX_EINVAL
-    assert lib.fx_score(h, arr, 1, None, -1, 8, lut.ctypes.data_as(_native._u8p), None, None) == _native.FX_EINVAL
-    assert lib.fx_score(h, arr, 0, None, 4, 8, lut.ctypes.data_as(_native._u8p), None, None) == _native.FX_EINVAL
-    assert lib.fx_engine_set_option(h, b"no_such_option", 1) != _native.FX_OK
-    assert lib.fx_score_submit(h, 0, 16) == _native.FX_ESTATE and lib.fx_score_finish(h, None, None) == _native.FX_ESTATE
-    assert b"fx_score_finish" in lib.fx_last_error(h)
-    assert lib.fx_min_dist(h, 0, None, 4, None, 4, 800, None, None) != _native.FX_OK      # null buffers
-    # (rows beyond 768 symbols are served since round 3 -- the strip form of the recurrence, csrc/mindist.hip)
-    d800, a800 = eng.min_dist(np.zeros((2, 800), np.uint8) + 65, np.zeros((3, 800), np.uint8) + 65)
-    assert (d800 == 0).all() and (a800 == 0).all()
-    with pytest.raises((ValueError, _native.FxError)):
-        _native.NativeTable(eng, np.zeros((4, 5)), "", lut=np.full(256, 7, np.uint8)).additive_sum(np.zeros((2, 4), np.uint8))
-    assert lib.fx_status_name(_native.FX_EBADCHAR) == b"FX_EBADCHAR" and lib.fx_version() >= 100
-    # ... and the engine still scores
-    again, _ = eng.score([nm], b, lut)
-    assert np.array_equal(again, good)
-    # non-finite weights inside the network: NaN / inf end as nan_to_num says (keras_model.py:77)
-    w2 = [x.copy() for x in w]
-    w2[2][0, 0, 0] = np.nan                                                            # a conv2 weight
-    nm.set_weights(w2)
-    out, _ = eng.score([nm], b, lut)
-    assert np.isfinite(out).all()
-
-
-def test_deepcopy_and_pickle_of_live_models(eng):
-    """Models that already own device handles can be deep-copied and pickled (an explorer wrapper might): the copy
-    re-creates its own handles lazily and scores identically; NoisyAbstractModel rebuilds its device key store."""
-    import copy
-    import pickle
-
-    L, alpha = 14, "UGCA"
-    _, seqs = rand_seqs(300, L, alpha, seed=77)
-    ens = flexs_amd.Ensemble([bm.CNN(L, 32, 100, alpha, seed=0), bm.MLP(L, 100, alpha, seed=1)])
-    want = ens.get_fitness(seqs)                                          # handles now exist
-    for clone in (copy.deepcopy(ens), pickle.loads(pickle.dumps(ens))):
-        assert clone.models[0]._native_model is None
-        assert np.array_equal(clone.get_fitness(seqs), want) and clone.cost == 600
-
-    class Table(flexs_amd.Landscape):
-        def __init__(self):
-            super().__init__("table")
-
-        def _fitness_function(self, s):
-            return np.array([(sum(map(ord, str(x))) % 97) / 97.0 for x in s])
-
-    nam = bm.NoisyAbstractModel(Table(), 0.8)
-    nam.train(seqs[:100], np.linspace(0, 1, 100))
-    np.random.seed(1)
-    nam.get_fitness(seqs[100:150])
-    twin = copy.deepcopy(nam)
-    np.random.seed(2); a = nam.get_fitness(seqs[150:220])
-    np.random.seed(2); b = twin.get_fitness(seqs[150:220])
-    assert np.array_equal(a, b) and list(nam.cache) == list(twin.cache)
-
-
-@pytest.mark.parametrize("L,n,M", [(8, 1, 1), (8, 16, 1), (8, 17, 3), (8, 100, 3), (8, 1000, 1), (8, 4000, 3), (8, 10_000, 1), (8, 12_289, 1), (8, 2001, 8),
-                                    (14, 1, 1), (14, 20, 3), (14, 1000, 3), (14, 4100, 1), (14, 8200, 1), (16, 33, 2), (5, 50, 1), (6, 700, 3), (11, 257, 2),
-                                    (13, 2001, 8)])
-@pytest.mark.parametrize("K", [5])
-def test_cnn_quad_form_is_bit_identical_to_the_one_wave_kernel(eng, L, n, M, K):
-    """Small launches of the canonical 4-letter CNN at seq_len <= 16 (TF-binding 8, RNA 14): a tile shared by four waves,
-    each taking every fourth conv position, activations exchanged through LDS layer by layer (score_cnn_quad.hip).  Every output element sees the one-wave kernel's MFMA sequence, so
-    the scores are the SAME BITS (a sequence must score alike in a call of 20 and in a batch of 1e5), at any size when
-    forced, and a character outside the alphabet is reported from whichever wave reads it."""
-    pairs = [make_native(eng, "cnn", L, 4, 100, 32, K, seed=80 + m) for m in range(M)]
-    nms = [p[0] for p in pairs]
-    lut = _native.make_lut("TGCA")
-    b, seqs = rand_seqs(n, L, "TGCA", seed=n)
-    outs = {}
-    for mode in (0, 1, 2):
-        eng.set_option("cnn_quad", mode)
-        try:
-            outs[mode], mean = eng.score(nms, b, lut, want_matrix=True, want_mean=True)
-            assert np.array_equal(mean, np.mean(outs[mode], axis=1))
-        finally:
-            eng.set_option("cnn_quad", 1)
-    assert np.array_equal(outs[1], outs[0]) and np.array_equal(outs[2], outs[0])
-    # the weights through registers instead of the direct global -> LDS copies (the head then lands before the first
-    # tile instead of during its convolutions): same bits; and a byte buffer that is not 4-byte aligned (the first
-    # round then reads its bytes from global memory like the later ones)
-    eng.set_option("dma_fill", 0)
-    try:
-        for mode in (1, 2):
-            eng.set_option("cnn_quad", mode)
-            assert np.array_equal(eng.score(nms, b, lut, want_matrix=True)[0], outs[0])
-    finally:
-        eng.set_option("dma_fill", 1)
-        eng.set_option("cnn_quad", 1)
-    import torch
-    dev = torch.zeros(n * L + 8, dtype=torch.uint8, device="cuda")
-    for shift in (1, 4):
-        dev[shift:shift + n * L] = torch.from_numpy(b.reshape(-1)).cuda()
-        stride = (n + 3) // 4 * 4
-        planes = torch.full((M, stride), float("nan"), device="cuda")
-        torch.cuda.synchronize()
-        eng.score_planes_dev(nms, dev.data_ptr() + shift, n, L, lut, planes.data_ptr(), stride)
-        eng.sync()
-        assert np.array_equal(planes[:, :n].cpu().numpy().T, outs[0]), shift
-    assert_scores(outs[2][:, M - 1], ref_np.keras_fitness(seqs, "TGCA", "cnn", pairs[M - 1][1], exact=True), f"quad L={L} n={n} M={M}")
-    eng.set_option("cnn_quad", 2)
-    try:
-        for col in (0, L // 2, L - 1):
-            bb = b.copy()
-            bb[n - 1, col] = ord("U")
-            with pytest.raises(ValueError):
-                eng.score(nms, bb, lut)
-    finally:
-        eng.set_option("cnn_quad", 1)
-    # hidden sizes whose last tile holds 1 .. 16 units (k-step tail), through the Python API
-    for H in (97, 100, 104, 112):
-        model = bm.CNN(L, 32, H, "TGCA", kernel_size=K, seed=H)
-        got = model.get_fitness(seqs[:50])
-        eng.set_option("cnn_quad", 0)
-        try:
-            assert np.array_equal(model.get_fitness(seqs[:50]), got)
-        finally:
-            eng.set_option("cnn_quad", 1)
-
-
-@pytest.mark.parametrize("L,n,M,K", [(8, 20, 3, 3), (14, 100, 3, 3), (14, 20, 1, 7), (16, 1000, 2, 7), (7, 17, 1, 7), (9, 4000, 1, 3), (14, 8000, 1, 3)])
-def test_cnn_quad_form_other_kernel_sizes(eng, L, n, M, K):
-    """The quad form for kernel sizes 3 and 7 (the other fused instantiations of the one-wave kernel): same bits, oracle."""
-    pairs = [make_native(eng, "cnn", L, 4, 100, 32, K, seed=90 + m) for m in range(M)]
-    nms = [p[0] for p in pairs]
-    lut = _native.make_lut("UGCA")
-    b, seqs = rand_seqs(n, L, "UGCA", seed=n + K)
-    outs = {}
-    for mode in (0, 1, 2):
-        eng.set_option("cnn_quad", mode)
-        try:
-            outs[mode], _ = eng.score(nms, b, lut, want_matrix=True)
-        finally:
-            eng.set_option("cnn_quad", 1)
-    assert np.array_equal(outs[1], outs[0]) and np.array_equal(outs[2], outs[0])
-    for m in range(M):
-        assert_scores(outs[2][:, m], ref_np.keras_fitness(seqs, "UGCA", "cnn", pairs[m][1], exact=True), f"quad K={K} L={L} n={n}")
-    bb = b.copy()
-    bb[n // 2, L - 1] = ord("T")
-    with pytest.raises(ValueError):
-        eng.score(nms, bb, lut)
-
-
-@pytest.mark.parametrize("L,n,M,H", [(8, 20, 3, 10), (8, 700, 1, 16), (14, 100, 3, 30), (14, 20, 1, 50), (16, 1000, 2, 64), (8, 4000, 1, 64), (14, 33, 2, 70),
-                                     (8, 100, 3, 90), (14, 5000, 1, 32), (7, 17, 1, 96)])
-def test_cnn_quad_form_other_hidden_sizes(eng, L, n, M, H):
-    """The quad form for hidden layers of 1 / 2 / 4 tiles (<= 64 units) and for 65-96 units padded to 7 tiles: same bits as
-    the one-wave kernel, oracle."""
-    pairs = [make_native(eng, "cnn", L, 4, H, 32, 5, seed=95 + m) for m in range(M)]
-    nms = [p[0] for p in pairs]
-    lut = _native.make_lut("UGCA")
-    b, seqs = rand_seqs(n, L, "UGCA", seed=n + H)
-    outs = {}
-    for mode in (0, 1, 2):
-        eng.set_option("cnn_quad", mode)
-        try:
-            outs[mode], _ = eng.score(nms, b, lut, want_matrix=True)
-        finally:
-            eng.set_option("cnn_quad", 1)
-    assert np.array_equal(outs[1], outs[0]) and np.array_equal(outs[2], outs[0])
-    for m in range(M):
-        assert_scores(outs[2][:, m], ref_np.keras_fitness(seqs, "UGCA", "cnn", pairs[m][1], exact=True), f"quad H={H} L={L} n={n}")
-
-
 @pytest.mark.parametrize("L,n,M", [(10, 3000, 2), (5, 100, 1), (64, 20, 3), (30, 70000, 1)])
 def test_cnn_binary_alphabet_on_mfma(eng, L, n, M):
     """`BA = "01"` (sequence_utils.py:16): the canonical CNN on a 2-letter alphabet (conv3 has a single tap) runs on the
@@ -1572,95 +443,6 @@ def test_cnn_binary_alphabet_on_mfma(eng, L, n, M):
     bb = b.copy(); bb[n // 2, L - 1] = ord("2")
     with pytest.raises(ValueError):
         eng.score([p[0] for p in pairs], bb, lut)
-
-
-@pytest.mark.parametrize("L,F,H,K,n,M", [(8, 32, 50, 3, 5000, 3), (14, 32, 128, 7, 3000, 2), (14, 32, 200, 3, 2000, 1), (20, 32, 256, 6, 500, 1),
-                                         (9, 8, 20, 4, 300, 2), (8, 16, 64, 5, 70_000, 2), (30, 24, 100, 2, 100, 1), (12, 32, 100, 6, 33, 1),
-                                         (50, 32, 30, 3, 17, 1), (6, 1, 1, 2, 5, 1), (3, 32, 100, 3, 4, 1), (100, 12, 257 - 1, 4, 64, 1),
-                                         (8, 64, 100, 5, 20_000, 3), (14, 48, 100, 3, 1000, 2), (14, 64, 200, 4, 300, 1), (30, 40, 64, 2, 65, 1),
-                                         (8, 64, 100, 7, 50, 1)])
-def test_cnn_split_conv_and_head_path(eng, L, F, H, K, n, M):
-    """CNN shapes without a fused instantiation (kernel_size 2..7 x any hidden width <= 256 x num_filters <= 32, 4-letter
-    alphabets) run as conv kernel + head kernel on MFMA: scores vs the oracle and vs the shape-agnostic kernels, the
-    mean-only (planes) form, and a bad character."""
-    natives, ws = zip(*[make_native(eng, "cnn", L, 4, H, F, K, seed=900 + m) for m in range(M)])
-    lut = _native.make_lut("TGCA")
-    b, _ = rand_seqs(n, L, "TGCA", seed=L * 7 + K + H)
-    got, mean = eng.score(list(natives), b, lut, want_matrix=True, want_mean=True)
-    k = min(n, 300)
-    for m in range(M):
-        assert_scores(got[:k, m], c_oracle.forward("cnn", lut[b[:k]], 4, ws[m]), f"L={L} F={F} H={H} K={K}")
-    assert np.array_equal(mean, np.mean(got, axis=1))
-    _, mean_only = eng.score(list(natives), b, lut, want_matrix=False, want_mean=True)
-    assert np.array_equal(mean_only, mean)
-    try:
-        eng.set_option("force_generic", 1)
-        ref, _ = eng.score(list(natives), b, lut)
-    finally:
-        eng.set_option("force_generic", 0)
-    assert np.allclose(got, ref, rtol=2e-5, atol=2e-6)
-    bad = b.copy(); bad[n // 2, L // 2] = ord("N")
-    with pytest.raises(ValueError):
-        eng.score(list(natives), bad, lut)
-
-
-@pytest.mark.parametrize("A,alpha,L,F,H,K,n,M", [(4, "UGCA", 100, 32, 50, 3, 20, 3), (4, "UGCA", 50, 48, 200, 4, 1, 1), (4, "TGCA", 64, 16, 128, 2, 100, 2),
-                                                 (4, "UGCA", 40, 32, 64, 5, 33, 1), (20, s_utils.AAS, 237, 32, 50, 3, 40, 3),
-                                                 (20, s_utils.AAS, 90, 24, 200, 4, 1, 1), (20, s_utils.AAS, 120, 32, 128, 6, 16, 2)])
-def test_cnn_split_path_position_segmented_small_batches(eng, A, alpha, L, F, H, K, n, M):
-    """Small batches of long sequences on the conv + head path (non-canonical CNN shapes): the conv kernel cuts a
-    tile's positions over the waves of a workgroup (4-letter alphabets) or over several workgroups (protein alphabet,
-    segment maxima meeting in a zeroed pool through atomicMax on the float bits) -- same bits as the whole-sequence
-    walk, and the oracle's values."""
-    natives, ws = zip(*[make_native(eng, "cnn", L, A, H, F, K, seed=40 + m) for m in range(M)])
-    lut = _native.make_lut(alpha)
-    b, seqs = rand_seqs(n, L, alpha, seed=L + K)
-    got, mean = eng.score(list(natives), b, lut, want_matrix=True, want_mean=True)
-    eng.set_option("cnn_seg", 0)
-    eng.set_option("cnn_pair_seg", 0)
-    try:
-        whole, _ = eng.score(list(natives), b, lut)
-    finally:
-        eng.set_option("cnn_seg", -1)
-        eng.set_option("cnn_pair_seg", -1)
-    assert np.array_equal(got, whole)
-    for m in range(M):
-        assert_scores(got[:, m], ref_np.keras_fitness(seqs, alpha, "cnn", ws[m], exact=True), f"segmented split A={A} L={L} K={K} H={H}")
-    assert np.array_equal(mean, np.mean(got, axis=1))
-    if A == 20:
-        for sb in (1, 2, 3):                        # forced workgroups per tile
-            eng.set_option("cnn_pair_seg", sb)
-            try:
-                forced, _ = eng.score(list(natives), b, lut)
-            finally:
-                eng.set_option("cnn_pair_seg", -1)
-            assert np.array_equal(forced, whole), sb
-    bad = b.copy(); bad[n - 1, L - 1] = ord("!")
-    with pytest.raises(ValueError):
-        eng.score(list(natives), bad, lut)
-
-
-@pytest.mark.parametrize("L,F,H,K,n,M", [(30, 32, 100, 3, 200, 2), (60, 32, 50, 7, 64, 1), (25, 24, 200, 4, 100, 1), (90, 32, 100, 6, 40, 3),
-                                         (237, 32, 64, 3, 17, 1), (8, 32, 256, 2, 33, 1)])
-def test_cnn_split_path_protein_alphabet(eng, L, F, H, K, n, M):
-    """The conv + head split with the two-waves-per-tile conv kernel (20-letter alphabet, kernel_size 2..7, any hidden
-    width): scores vs the oracle and vs the shape-agnostic kernels."""
-    natives, ws = zip(*[make_native(eng, "cnn", L, 20, H, F, K, seed=950 + m) for m in range(M)])
-    lut = _native.make_lut(s_utils.AAS)
-    b, _ = rand_seqs(n, L, s_utils.AAS, seed=L + K + H)
-    got, mean = eng.score(list(natives), b, lut, want_matrix=True, want_mean=True)
-    for m in range(M):
-        assert_scores(got[:, m], c_oracle.forward("cnn", lut[b], 20, ws[m]), f"protein L={L} F={F} H={H} K={K}")
-    assert np.array_equal(mean, np.mean(got, axis=1))
-    try:
-        eng.set_option("force_generic", 1)
-        ref, _ = eng.score(list(natives), b, lut)
-    finally:
-        eng.set_option("force_generic", 0)
-    assert np.allclose(got, ref, rtol=2e-5, atol=2e-6)
-    bad = b.copy(); bad[n // 2, L - 1] = ord("B")
-    with pytest.raises(ValueError):
-        eng.score(list(natives), bad, lut)
 
 
 def _random_case(seed):
@@ -1708,988 +490,3 @@ def test_random_shapes_against_the_oracle_and_batch_invariance(eng, seed):
     bad[int(rng.integers(0, n)), int(rng.integers(0, L))] = ord("#")
     with pytest.raises(ValueError):
         eng.score(list(natives), bad, lut)
-
-
-@pytest.mark.parametrize("L,alpha,H,n,M", [(14, "UGCA", 100, 20, 3), (14, "UGCA", 100, 1, 1), (8, "TGCA", 100, 100, 3), (15, "UGCA", 100, 33, 2), (50, "UGCA", 100, 17, 1),
-                                           (100, "UGCA", 100, 400, 3), (14, "UGCA", 200, 20, 3), (50, "UGCA", 200, 100, 1), (30, s_utils.AAS, 100, 40, 2),
-                                           (90, s_utils.AAS, 100, 20, 3), (237, s_utils.AAS, 100, 16, 1), (90, s_utils.AAS, 200, 7, 2), (14, "UGCA", 97, 50, 1),
-                                           (14, "UGCA", 112, 1000, 2), (9, "ACGTN", 100, 64, 1), (14, "UGCA", 10, 20, 2), (14, "UGCA", 16, 300, 1),
-                                           (20, "UGCA", 30, 17, 3), (14, "UGCA", 50, 100, 1), (33, s_utils.AAS, 64, 20, 2), (14, "UGCA", 128, 40, 1),
-                                           (14, "UGCA", 130, 20, 2), (40, "UGCA", 256, 33, 1)])
-@pytest.mark.parametrize("kind", ["mlp", "ge"])
-def test_mlp_small_launch_form_is_bit_identical_to_the_persistent_kernel(eng, kind, L, alpha, H, n, M):
-    """Explorer-size MLP launches: one tile per workgroup, its output tiles dealt to 8 waves, weights read straight from L2
-    (score_dense_small.hip).  Same terms in the same order as the persistent kernel -- the pre-summed pair rows where that
-    kernel uses them (4-letter alphabets whose table fits LDS), plain rows otherwise, the slab-streamed wide hidden
-    layers -- so the SAME BITS, at any size when forced; oracle; a bad character anywhere fails the call."""
-    A = len(alpha)
-    pairs = [make_native(eng, kind, L, A, H, seed=60 + m) for m in range(M)]
-    nms = [p[0] for p in pairs]
-    lut = _native.make_lut(alpha)
-    b, seqs = rand_seqs(n, L, alpha, seed=n + L)
-    outs = {}
-    for mode in (0, 1, 2):
-        eng.set_option("dense_small", mode)
-        try:
-            outs[mode], mean = eng.score(nms, b, lut, want_matrix=True, want_mean=True)
-            assert np.array_equal(mean, np.mean(outs[mode], axis=1))
-        finally:
-            eng.set_option("dense_small", 1)
-    assert np.array_equal(outs[1], outs[0]) and np.array_equal(outs[2], outs[0])
-    for m in range(M):
-        assert_scores(outs[2][:, m], ref_np.keras_fitness(seqs, alpha, kind, pairs[m][1], exact=True), f"{kind} small L={L} H={H} n={n}")
-    for form in (("mlp_pair", 0), ("ge_bytetab", 0)):         # the plain-row / LUT-indexed first layers on both sides
-        eng.set_option(*form)
-        try:
-            eng.set_option("dense_small", 0)
-            ref0, _ = eng.score(nms, b, lut, want_matrix=True)
-            eng.set_option("dense_small", 2)
-            got0, _ = eng.score(nms, b, lut, want_matrix=True)
-            assert np.array_equal(ref0, got0) and np.array_equal(ref0, outs[0]) or form[0] == "mlp_pair"
-        finally:
-            eng.set_option(form[0], 1)
-            eng.set_option("dense_small", 1)
-    eng.set_option("dense_small", 2)
-    try:
-        bb = b.copy()
-        bb[n - 1, L - 1] = ord("#")
-        with pytest.raises(ValueError):
-            eng.score(nms, bb, lut)
-    finally:
-        eng.set_option("dense_small", 1)
-
-
-@pytest.mark.parametrize("kind,L,alpha,H,M,n", [
-    ("mlp", 14, "UGCA", 100, 1, 100_000), ("mlp", 14, "UGCA", 100, 3, 20_000), ("mlp", 8, "TGCA", 100, 1, 5_000),
-    ("mlp", 9, "UGCA", 100, 2, 4_099), ("mlp", 16, "UGCA", 100, 1, 70_001), ("mlp", 17, "UGCA", 100, 1, 9_000),
-    ("mlp", 14, "UGCA", 128, 2, 9_001), ("mlp", 14, "UGCA", 112, 1, 6_000), ("mlp", 4, "TGCA", 100, 1, 4_500),
-    ("ge", 90, s_utils.AAS, 100, 8, 100_000), ("ge", 90, s_utils.AAS, 100, 1, 100_003), ("ge", 14, "UGCA", 100, 1, 20_000),
-    ("ge", 8, "TGCA", 100, 3, 10_000), ("ge", 64, s_utils.AAS, 100, 2, 8_191), ("ge", 100, "UGCA", 100, 1, 6_007),
-    ("ge", 128, s_utils.AAS, 128, 1, 5_000), ("ge", 33, s_utils.AAS, 128, 2, 7_000), ("ge", 96, "UGCA", 112, 1, 4_200),
-])
-def test_software_pipelined_dense_form_gives_the_same_bits(eng, kind, L, alpha, H, M, n):
-    """Round 3: the MLP (pair rows) / GlobalEpistasis (byte table) launches run tile t + 1's first layer inside tile t's
-    MFMA layers (`dense_pipe` = 1: 8 waves, two-part direct LDS fill).  Every output element sees the arithmetic of the
-    round-2 form (`dense_pipe` = 0), so the scores are the SAME BITS -- ragged last tiles, members, any alignment -- and
-    both agree with the oracle; a character outside the alphabet is reported from the pipelined first layer too."""
-    if not ab_option(eng, "dense_pipe", 1):
-        pytest.skip("the software-pipelined dense form (measured 11-13 % slower) lives in the A/B build: make ab")
-    eng.set_option("dense_pipe", 0)
-    A = len(alpha)
-    natives, ws = zip(*[make_native(eng, kind, L, A, H, seed=700 + m) for m in range(M)])
-    lut = _native.make_lut(alpha)
-    b, seqs = rand_seqs(n, L, alpha, seed=L + H + M)
-    eng.set_option("dense_small", 0)                      # the persistent kernels at every size
-    try:
-        outs = {}
-        for pipe in (2, 1, 0):                            # 2 / 1: the pipelined form with / without hand-placed operand prefetch
-            eng.set_option("dense_pipe", pipe)
-            outs[pipe], _ = eng.score(list(natives), b, lut)
-            for cut in (1, 16, 17, 4097):                 # batch invariance: prefixes, ragged or not
-                if cut < n:
-                    part, _ = eng.score(list(natives), b[:cut], lut)
-                    assert np.array_equal(part, outs[pipe][:cut]), (pipe, cut)
-        assert np.array_equal(outs[1], outs[0]) and np.array_equal(outs[2], outs[0])
-        k = min(n, 400)
-        for m in range(M):
-            assert_scores(outs[1][:k, m], c_oracle.forward(kind, lut[b[:k]], A, ws[m]), f"{kind} L={L} H={H} member {m}")
-        eng.set_option("dense_pipe", 1)                   # (the form is optional: measured slower, see DESIGN.md section 8)
-        for where in (0, n // 2 + 5, n - 1):              # first tile of a wave, a pipelined tile, the ragged tail
-            bad = b.copy(); bad[where, L - 1] = ord("!")
-            with pytest.raises(ValueError):
-                eng.score(list(natives), bad, lut)
-        again, _ = eng.score(list(natives), b, lut)
-        assert np.array_equal(again, outs[1])
-    finally:
-        eng.set_option("dense_pipe", 0)
-        eng.set_option("dense_small", 1)
-
-
-def test_engine_counters(eng):
-    """fx_engine_counters: the engine's own account of what went through it (SURVEY.md section 5 aux: counters) -- host
-    calls, zero-copy vs copy path bytes, forwards, distance evaluations, training steps."""
-    from flexs_amd import training
-
-    eng.counters(reset=True)
-    L, alpha = 8, "TGCA"
-    members = [bm.CNN(L, 32, 100, alpha, seed=s) for s in range(3)]
-    ens = flexs_amd.Ensemble(members)
-    b, seqs = rand_seqs(20, L, alpha, seed=1)
-    ens.get_fitness(seqs)                                         # explorer-size call: zero-copy
-    c = eng.counters()
-    assert c["host_calls"] == 1 and c["zero_copy_calls"] == 1 and c["sequences"] == 20 and c["forwards"] == 60 and c["bytes_h2d"] == 0
-    eng.set_option("zero_copy_mode", 0)                           # force the copy path for a big batch
-    try:
-        b2, _ = rand_seqs(50_000, L, alpha, seed=2)
-        eng.score([m.native() for m in members], b2, members[0]._lut, want_matrix=True)
-    finally:
-        eng.set_option("zero_copy_mode", -1)
-    c = eng.counters()
-    assert c["host_calls"] == 2 and c["zero_copy_calls"] == 1 and c["bytes_h2d"] == 50_000 * L and c["bytes_d2h"] == 4 * 3 * 50_000
-    assert c["sequences"] == 50_020 and c["forwards"] == 3 * 50_020
-    eng.min_dist(b2[:7], b2[:1000])
-    assert eng.counters()["pair_evals"] == 7000
-    y = np.random.default_rng(0).random(20)
-    if training._train_mode(__import__("torch").device("cuda")) == "native":
-        ens.train(seqs, y)
-        assert eng.counters()["train_steps"] == 3 * 20            # 20 epochs x 1 mini-batch x 3 members
-    assert eng.counters(reset=True)["host_calls"] == 2 and eng.counters()["host_calls"] == 0
-
-
-@pytest.mark.parametrize("L,alpha,M", [(8, "TGCA", 3), (8, "TGCA", 2), (14, "UGCA", 3), (8, "TGCA", 8), (14, "UGCA", 16), (8, "TGCA", 7)])
-def test_small_launch_fused_ensemble_mean(eng, L, alpha, M):
-    """Optional form (`fuse_mean` = 1; measured no faster than the separate 3 us launch, so off by default): explorer-size
-    calls of a CNN ensemble average in the scoring kernel itself (the member whose workgroup
-    finishes a tile last reads all members' scores back and averages in NumPy's order) instead of launching the mean kernel:
-    the same bits as the separate launch and as np.mean of the stacked matrix, for every batch size the small-launch form
-    serves, repeated calls (the tickets clean up after themselves), and a bad character still raises."""
-    if not ab_option(eng, "fuse_mean", 1):
-        pytest.skip("the in-kernel ensemble mean of explorer-size launches (no faster than the mean launch) lives in the A/B build: make ab")
-    eng.set_option("fuse_mean", 0)
-    members = [bm.CNN(L, 32, 100, alpha, seed=s) for s in range(M)]
-    ens = flexs_amd.Ensemble(members)
-    stack = flexs_amd.Ensemble(members, combine_with=lambda x: x)
-    for n in (1, 5, 16, 17, 20, 33, 48, 100, 400, 2001):
-        b, seqs = rand_seqs(n, L, alpha, seed=n)
-        want = np.mean(stack.get_fitness(seqs), axis=1)
-        for fuse in (1, 0, 1):
-            eng.set_option("fuse_mean", fuse)
-            try:
-                got = ens.get_fitness(seqs)
-                natives = [m.native() for m in members]
-                _, dev_mean = eng.score(natives, b, members[0]._lut, want_matrix=False, want_mean=True)
-            finally:
-                eng.set_option("fuse_mean", 0)
-            assert np.array_equal(got, want) and np.array_equal(dev_mean, want), (n, fuse)
-    eng.set_option("fuse_mean", 1)
-    try:
-        with pytest.raises(ValueError):
-            ens.get_fitness(seqs[:7] + ["Z" * L])
-        assert np.array_equal(ens.get_fitness(seqs[:20]), want[:20])
-    finally:
-        eng.set_option("fuse_mean", 0)
-
-
-def _few_fallbacks(eng, before, what=""):
-    """A request the resident workgroups do not answer in time falls back to a launch (same result).  That is a timing event --
-    the calling thread loses its core for longer than the idle window between deciding to post and posting -- so the tests
-    do not demand zero of them, only that they stay rare."""
-    n = eng.get_option("server_fallbacks") - before
-    assert n <= 3, f"{n} requests fell back to a launch {what} (last: {eng.get_option('server_last_fallback')})"
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("kind,L,alpha,M", [("cnn", 8, "TGCA", 3), ("cnn", 14, "UGCA", 2), ("mlp", 14, "UGCA", 1), ("ge", 24, "UGCA", 3), ("mix", 8, "TGCA", 3)])
-def test_resident_tiny_requests(eng, kind, L, alpha, M):
-    """Round 4: a request of at most 48 sequence bytes (one to six 8-mers: most of Adalead's calls) carries its bytes in the request
-    word's own 64-byte line (FxMailIn::tiny, request bit 14); the slot of tile 0 reads the whole line per poll.  Same bits as the
-    byte-area request (serve_tiny = 0), as the launched call and beside the oracle, at every size around the 48-byte limit,
-    alternating with larger requests (stale bytes of an earlier tiny request must not leak into a later one), with a character
-    outside the alphabet."""
-    if kind == "mix":
-        members = [bm.GlobalEpistasisModel(L, 100, alpha, seed=1), bm.MLP(L, 100, alpha, seed=2), bm.CNN(L, 32, 100, alpha, seed=3)]
-        kinds = ["ge", "mlp", "cnn"]
-    else:
-        mk = {"cnn": lambda s: bm.CNN(L, 32, 100, alpha, seed=s), "mlp": lambda s: bm.MLP(L, 100, alpha, seed=s),
-              "ge": lambda s: bm.GlobalEpistasisModel(L, 100, alpha, seed=s)}[kind]
-        members = [mk(50 + s) for s in range(M)]
-        kinds = [kind] * M
-    ens = flexs_amd.Ensemble(members) if M > 1 else members[0]
-    stack = flexs_amd.Ensemble(members, combine_with=lambda x: x)
-    limit = 48 // L
-    sizes = sorted({1, 2, max(limit - 1, 1), limit, limit + 1, limit + 2, 16, 17, 40})
-    data = {n: rand_seqs(n, L, alpha, seed=600 + n)[1] for n in sizes}
-    eng.set_option("serve_small", 0)
-    try:
-        want = {n: ens.get_fitness(data[n]) for n in sizes}
-    finally:
-        eng.set_option("serve_small", 1)
-    try:
-        for tiny in (1, 0, 1):
-            eng.set_option("serve_tiny", tiny)
-            assert _until_resident(eng, lambda: ens.get_fitness(data[1]))
-            fb0 = eng.get_option("server_fallbacks")
-            for rep in range(3):
-                for n in sizes + sizes[::-1]:
-                    assert np.array_equal(ens.get_fitness(data[n]), want[n]), (kind, L, n, tiny, rep)
-            _few_fallbacks(eng, fb0, f"tiny {kind} L={L}")
-        got_nm = stack.get_fitness(data[limit])
-        for m, (mod, kd) in enumerate(zip(members, kinds)):
-            ref = ref_np.keras_fitness(data[limit], alpha, kd, [np.asarray(w, np.float64) for w in mod.model.get_weights()], exact=True)
-            assert_scores(got_nm[:, m], ref, f"tiny request, {kd} L={L} member {m}")
-        for _ in range(3):
-            ens.get_fitness(data[1])
-        bad = list(data[limit])
-        bad[-1] = bad[-1][:-1] + "!"
-        with pytest.raises(ValueError):
-            ens.get_fitness(bad)
-        assert np.array_equal(ens.get_fitness(data[limit]), want[limit])
-    finally:
-        eng.set_option("serve_tiny", 1)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("kind,L,M", [("mlp", 2, 1), ("ge", 1, 2), ("ge", 2, 3), ("mlp", 1, 2), ("mlp", 3, 1)])
-def test_resident_tiny_requests_of_very_short_sequences(eng, kind, L, M):
-    """Sequences of 1-3 symbols: 48 bytes are more than one tile's 16 sequences (such requests take the byte area: only tile 0's
-    workgroup reads the request line) and a tile's byte rows (16 x L bytes) are shorter than the 48-byte line (the workgroup writes
-    only the dwords that hold the request's N x L bytes).  Resident answers against the launched call's bits, serve_tiny on and off
-    (`tools/runs/r4_tiny_edge.py`, `profiles/r4_tiny_edge.log`)."""
-    alpha = "UGCA"
-    mk = {"mlp": lambda s: bm.MLP(L, 100, alpha, seed=s), "ge": lambda s: bm.GlobalEpistasisModel(L, 100, alpha, seed=s)}[kind]
-    members = [mk(70 + s) for s in range(M)]
-    ens = flexs_amd.Ensemble(members) if M > 1 else members[0]
-    sizes = [1, 2, 3, 15, 16, 17, 23, 24, 25, 40, 47, 48, 49]
-    data = {n: rand_seqs(n, L, alpha, seed=900 + n)[1] for n in sizes}
-    eng.set_option("serve_small", 0)
-    try:
-        want = {n: ens.get_fitness(data[n]) for n in sizes}
-    finally:
-        eng.set_option("serve_small", 1)
-    try:
-        for tiny in (1, 0, 1):
-            eng.set_option("serve_tiny", tiny)
-            assert _until_resident(eng, lambda: ens.get_fitness(data[1]))
-            for rep in range(3):
-                for n in sizes + sizes[::-1]:
-                    assert np.array_equal(ens.get_fitness(data[n]), want[n]), (kind, L, n, tiny, rep)
-    finally:
-        eng.set_option("serve_tiny", 1)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("L,M", [(90, 3), (237, 1), (60, 2)])
-def test_prelaunched_instance_of_the_layer_parallel_form(eng, L, M):
-    """Round 4 (`lp_prelaunch`, default on): after an explorer-size call of a protein CNN ensemble was answered by the layer-parallel
-    form, the NEXT instance of that call is enqueued at once; it fills its weights and waits for its request word in a mailbox the
-    host stores into through the BAR, so a caller that is back with the same batch shape within the idle window pays neither the
-    launch latency nor the weight fill.  Same bits as a launch per call and beside the oracle; an instance of another shape /
-    another ensemble / after new weights / after an idle gap steps aside (and the barrier counters it was counted into are put
-    back); a character outside the alphabet is the ValueError of every path; training in between."""
-    import time as _t
-    members = [bm.CNN(L, 32, 100, s_utils.AAS, seed=300 + s) for s in range(M)]
-    ens = flexs_amd.Ensemble(members) if M > 1 else members[0]
-    other = flexs_amd.Ensemble([bm.CNN(8, 32, 100, "TGCA", seed=s) for s in range(3)])
-    sizes = (1, 7, 16, 17, 40)
-    data = {n: rand_seqs(n, L, s_utils.AAS, seed=40 + n)[1] for n in sizes}
-    small = rand_seqs(20, 8, "TGCA", seed=3)[1]
-    eng.set_option("lp_prelaunch", 0)
-    try:
-        want = {n: ens.get_fitness(data[n]) for n in sizes}
-        want_small = other.get_fitness(small)
-        eng.set_option("lp_prelaunch", 1)
-        s0 = eng.get_option("lp_armed_served")
-        for n in sizes:                                      # the same call again and again: from the second on, a pre-launched instance
-            for rep in range(6):
-                assert np.array_equal(ens.get_fitness(data[n]), want[n]), (L, M, n, rep)
-        # (timing: an instance is only asked while it is younger than 0.6 x the idle window -- most of these back-to-back calls
-        #  are, a descheduled test process may miss some)
-        assert eng.get_option("lp_armed_served") - s0 >= len(sizes)
-        for it in range(300):                                # everything that makes an instance step aside, interleaved
-            n = sizes[it % 5] if it % 3 == 0 else 7
-            assert np.array_equal(ens.get_fitness(data[n]), want[n]), (L, M, n, it)
-            if it % 20 == 19:
-                assert np.array_equal(other.get_fitness(small), want_small)
-            if it % 70 == 69:
-                _t.sleep(0.003)                              # (longer than the idle window: the instance has left by itself)
-            if it % 90 == 89:
-                bad = list(data[7])
-                bad[-1] = bad[-1][:-1] + "!"
-                with pytest.raises(ValueError):
-                    ens.get_fitness(bad)
-        got = ens.get_fitness(data[16])
-        if M > 1:
-            stack = flexs_amd.Ensemble(members, combine_with=lambda x: x).get_fitness(data[16])
-            assert np.array_equal(got, np.mean(stack, axis=1))
-        else:
-            stack = got[:, None]
-        ref = ref_np.keras_fitness(data[16], s_utils.AAS, "cnn", [np.asarray(w, np.float64) for w in members[0].model.get_weights()], exact=True)
-        assert_scores(stack[:, 0], ref, f"pre-launched instance, L={L}")
-        # new weights: the waiting instance has the OLD ones in LDS and must not answer
-        for _ in range(3):
-            ens.get_fitness(data[7])
-        y = np.linspace(0.0, 1.0, 40)
-        ens.train(data[40], y)
-        eng.set_option("lp_prelaunch", 0)
-        fresh = ens.get_fitness(data[7])
-        eng.set_option("lp_prelaunch", 1)
-        assert not np.array_equal(fresh, want[7])
-        for rep in range(4):
-            assert np.array_equal(ens.get_fitness(data[7]), fresh)
-    finally:
-        eng.set_option("lp_prelaunch", 1)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("L,M", [(90, 3), (237, 2), (33, 8), (40, 16)])
-def test_host_side_mean_of_small_launched_calls(eng, L, M):
-    """Launched mean-only host calls of at most `host_mean_below` sequences (the protein CNN's explorer-size calls): the member
-    planes are written straight to pinned host memory and np.mean over the members is taken on the host in NumPy's order -- the
-    SAME BITS as the mean kernel (host_mean_below = 0) and as np.mean over the stacked member scores; beside the oracle."""
-    members = [bm.CNN(L, 32, 100, s_utils.AAS, seed=200 + s) for s in range(M)]
-    ens = flexs_amd.Ensemble(members)
-    stack = flexs_amd.Ensemble(members, combine_with=lambda x: x)
-    try:
-        for n in (1, 5, 16, 40, 256, 257):
-            seqs = rand_seqs(n, L, s_utils.AAS, seed=77 + n)[1]
-            eng.set_option("host_mean_below", 0)
-            want = ens.get_fitness(seqs)
-            eng.set_option("host_mean_below", 256)
-            got = ens.get_fitness(seqs)
-            nm = stack.get_fitness(seqs)
-            # ... and whether the host polls the kernel's completion flag (default) or waits for the stream
-            eng.set_option("done_flag", 0)
-            assert np.array_equal(ens.get_fitness(seqs), got) and np.array_equal(stack.get_fitness(seqs), nm), (L, M, n)
-            eng.set_option("done_flag", 1)
-            for _ in range(3):                               # (back-to-back flagged calls: every one waits for ITS launch)
-                assert np.array_equal(ens.get_fitness(seqs), got), (L, M, n)
-            assert np.array_equal(got, want), (L, M, n)
-            assert np.array_equal(got, np.mean(nm, axis=1)), (L, M, n)
-        seqs = rand_seqs(16, L, s_utils.AAS, seed=5)[1]
-        got_nm = stack.get_fitness(seqs)
-        for m in (0, M - 1):
-            ref = ref_np.keras_fitness(seqs, s_utils.AAS, "cnn", [np.asarray(w, np.float64) for w in members[m].model.get_weights()], exact=True)
-            assert_scores(got_nm[:, m], ref, f"host-mean call, member {m}, L={L}")
-        bad = list(seqs)
-        bad[3] = bad[3][:-1] + "!"
-        with pytest.raises(ValueError):
-            ens.get_fitness(bad)
-        assert np.array_equal(ens.get_fitness(seqs), np.mean(got_nm, axis=1))
-    finally:
-        eng.set_option("host_mean_below", 256)
-        eng.set_option("done_flag", 1)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("kind,L,alpha,M", [("cnn", 8, "TGCA", 3), ("mlp", 14, "UGCA", 1), ("ge", 14, "UGCA", 3), ("mix", 14, "UGCA", 3)])
-def test_resident_streamed_calls(eng, kind, L, alpha, M):
-    """Round 4, streamed requests (fx_score_stream_*): get_fitness(list[str]) of at least _native.STREAM_MIN_ROWS strings posts its
-    request FIRST and packs the strings straight into the resident generation's mailbox, reporting every 256 rows -- a tile is
-    answered as soon as its rows are there.  Same bits as the packed request and as the launched call; shorter calls are not
-    streamed; a list that cannot be packed (not a str / ragged, found after the request went out) raises what the reference raises,
-    the generation is replaced, and the next calls are right; a character outside the alphabet is the ValueError of every path."""
-    from flexs_amd import _native
-    if kind == "mix":
-        members = [bm.GlobalEpistasisModel(L, 100, alpha, seed=1), bm.MLP(L, 200, alpha, seed=2), bm.CNN(L, 32, 100, alpha, seed=3)]
-    else:
-        mk = {"cnn": lambda s: bm.CNN(L, 32, 100, alpha, seed=s), "mlp": lambda s: bm.MLP(L, 100, alpha, seed=s),
-              "ge": lambda s: bm.GlobalEpistasisModel(L, 100, alpha, seed=s)}[kind]
-        members = [mk(30 + s) for s in range(M)]
-    ens = flexs_amd.Ensemble(members) if M > 1 else members[0]
-    lo, step = _native.STREAM_MIN_ROWS, _native.STREAM_STEP_ROWS
-    assert lo > 0 and step > 0
-    sizes = [lo - 1, lo, lo + 1, step * 2, step * 2 + 17, 1000, 2001, min(4096, 65536 // L)]
-    data = {n: rand_seqs(n, L, alpha, seed=900 + n)[1] for n in sizes}
-    eng.set_option("serve_small", 0)
-    try:
-        want = {n: ens.get_fitness(data[n]) for n in sizes}
-    finally:
-        eng.set_option("serve_small", 1)
-    eng.set_option("serve_wide", 2)
-    try:
-        small = data[sizes[0]][:20]
-        assert _until_resident(eng, lambda: ens.get_fitness(small))
-        fb0 = eng.get_option("server_fallbacks")
-        for rep in range(3):
-            for n in sizes:
-                ens.get_fitness(small)
-                s0, c0 = eng.get_option("server_streamed"), eng.get_option("server_calls") + eng.get_option("server_fallbacks")
-                got = ens.get_fitness(data[n])
-                assert np.array_equal(got, want[n]), (kind, n, rep)
-                assert eng.get_option("server_calls") + eng.get_option("server_fallbacks") - c0 == 1, (kind, n)
-                if eng.get_option("server_fallbacks") == fb0:
-                    assert eng.get_option("server_streamed") - s0 == (1 if n >= lo else 0), (kind, n, rep)
-        _few_fallbacks(eng, fb0, f"streamed {kind} L={L}")
-        # tuples stream too; NumPy arrays of str take the same path through tolist()
-        assert np.array_equal(ens.get_fitness(tuple(data[1000])), want[1000])
-        assert np.array_equal(ens.get_fitness(np.array(data[1000])), want[1000])
-        # found while packing, after the request went out: a non-str in the last piece, a ragged string in the second
-        for bad_list, exc in ((data[1000][:-1] + [7], TypeError), (data[1000][:300] + [data[1000][300][:-1]] + data[1000][301:], ValueError)):
-            for _ in range(3):
-                ens.get_fitness(small)
-            with pytest.raises(exc):
-                ens.get_fitness(bad_list)
-            assert np.array_equal(ens.get_fitness(data[1000]), want[1000])
-            assert _until_resident(eng, lambda: ens.get_fitness(small))
-            assert np.array_equal(ens.get_fitness(data[2001]), want[2001])
-        # a character outside the alphabet (found by the device, in the last tile)
-        for _ in range(3):
-            ens.get_fitness(small)
-        bad = list(data[2001])
-        bad[-1] = bad[-1][:-1] + "!"
-        with pytest.raises(ValueError):
-            ens.get_fitness(bad)
-        assert np.array_equal(ens.get_fitness(data[2001]), want[2001])
-    finally:
-        eng.set_option("serve_wide", 1)
-
-
-def _until_resident(eng, call, tries=12):
-    """Keep calling until a resident generation serves the calls (starting one takes two calls within the idle window)."""
-    for _ in range(tries):
-        call()
-        if eng.get_option("server_resident") == 1:
-            return True
-    return False
-
-
-@pytest.mark.parametrize("L,alpha,M", [(8, "TGCA", 3), (14, "UGCA", 3), (8, "TGCA", 1), (7, "TGCA", 8), (14, "UGCA", 16), (6, "ACGT", 2)])
-def test_resident_small_call_form(eng, L, alpha, M):
-    """`serve_small` (default on): from the second explorer-size call of the same canonical CNN ensemble on, one workgroup per
-    member and tile slot stays on the device with its weights in LDS and answers requests through mailboxes (request in device
-    memory written through the BAR, tagged answers in pinned host memory) -- no launch, no weight fill, no second launch for
-    the mean.  Same round code as the launched small form, so the same bits:
-    every batch size it serves, interleaved with sizes it does not (those launch as before), repeated calls, a bad
-    character (ValueError, and the next call is fine), new weights (a new generation), an idle exit and restart."""
-    import time as _t
-    members = [bm.CNN(L, 32, 100, alpha, seed=s) for s in range(M)]
-    ens = flexs_amd.Ensemble(members)
-    stack = flexs_amd.Ensemble(members, combine_with=lambda x: x)
-    sizes = (1, 5, 16, 17, 20, 31, 32, 33, 48, 95, 96, 97, 400)
-    data = {n: rand_seqs(n, L, alpha, seed=100 + n)[1] for n in sizes}
-    eng.set_option("serve_small", 0)
-    try:
-        want = {n: ens.get_fitness(data[n]) for n in sizes}
-        want_nm = {n: stack.get_fitness(data[n]) for n in sizes}
-    finally:
-        eng.set_option("serve_small", 1)
-    for n in sizes:
-        assert np.array_equal(want[n], np.mean(want_nm[n], axis=1))
-    served0, fb0 = eng.get_option("server_calls"), eng.get_option("server_fallbacks")
-    for rep in range(3):
-        for n in sizes:
-            assert np.array_equal(ens.get_fitness(data[n]), want[n]), (rep, n)
-            assert np.array_equal(stack.get_fitness(data[n]), want_nm[n]), (rep, n)
-    assert eng.get_option("server_calls") - served0 >= 2 * 2 * 5, "explorer-size calls did not go through the resident form"
-    _few_fallbacks(eng, fb0)
-    # a character outside the alphabet: the reference's ValueError, and the resident workgroups carry on
-    with pytest.raises(ValueError):
-        ens.get_fitness(data[20][:7] + ["Z" * L])
-    assert np.array_equal(ens.get_fitness(data[20]), want[20])
-    # new weights: the resident generation is replaced
-    w0 = members[0].model.get_weights()
-    members[0].model.set_weights([w * 0.5 for w in w0])
-    eng.set_option("serve_small", 0)
-    try:
-        want_half = ens.get_fitness(data[20])
-    finally:
-        eng.set_option("serve_small", 1)
-    starts = eng.get_option("server_starts")
-    for _ in range(6):
-        assert np.array_equal(ens.get_fitness(data[20]), want_half)
-    assert eng.get_option("server_starts") >= starts + 1
-    assert not np.array_equal(want_half, want[20])
-    members[0].model.set_weights(w0)
-    # idle: the workgroups leave by themselves 1 ms after the last request; the next calls launch, then start a new generation
-    assert _until_resident(eng, lambda: ens.get_fitness(data[5]))
-    _t.sleep(0.05)
-    starts = eng.get_option("server_starts")
-    for _ in range(6):
-        assert np.array_equal(ens.get_fitness(data[5]), want[5])
-    assert eng.get_option("server_starts") >= starts + 1
-    _few_fallbacks(eng, fb0, "over the whole test")
-    # a big launch in between tells them to leave (it wants every CU) and is itself unaffected
-    b, big = rand_seqs(100000, L, alpha, seed=7)
-    big_want = ens.get_fitness(big)
-    for _ in range(3):
-        ens.get_fitness(data[20])
-    assert np.array_equal(ens.get_fitness(big), big_want)
-    assert np.array_equal(ens.get_fitness(data[20]), want[20])
-
-
-@pytest.mark.parametrize("kind,L,alpha,H,M", [("mlp", 14, "UGCA", 100, 1), ("mlp", 8, "TGCA", 200, 3), ("ge", 14, "UGCA", 100, 2),
-                                             ("mlp", 90, s_utils.AAS, 100, 1), ("ge", 90, s_utils.AAS, 50, 8), ("mlp", 237, s_utils.AAS, 100, 2)])
-def test_resident_small_call_form_mlp_ge(eng, kind, L, alpha, H, M):
-    """The resident form of the explorer-size MLP / GlobalEpistasis kernel (`score_dense_small.hip`, SERVER): the same
-    per-tile code in a request loop, so the same bits as the launched calls, for every size the mailboxes hold (256
-    sequences, 16 KiB of sequence bytes), with a bad character and new weights in between."""
-    cls = bm.MLP if kind == "mlp" else bm.GlobalEpistasisModel
-    members = [cls(L, H, alpha, seed=s) for s in range(M)]
-    ens = flexs_amd.Ensemble(members) if M > 1 else members[0]
-    stack = flexs_amd.Ensemble(members, combine_with=lambda x: x)
-    sizes = (1, 5, 16, 17, 33, 64, 65, 100, 256, 300)
-    data = {n: rand_seqs(n, L, alpha, seed=200 + n)[1] for n in sizes}
-    eng.set_option("serve_small", 0)
-    try:
-        want = {n: ens.get_fitness(data[n]) for n in sizes}
-        want_nm = {n: stack.get_fitness(data[n]) for n in sizes}
-    finally:
-        eng.set_option("serve_small", 1)
-    served0, fb0 = eng.get_option("server_calls"), eng.get_option("server_fallbacks")
-    for rep in range(3):
-        for n in sizes:
-            assert np.array_equal(ens.get_fitness(data[n]), want[n]), (rep, n)
-            assert np.array_equal(stack.get_fitness(data[n]), want_nm[n]), (rep, n)
-    assert eng.get_option("server_calls") - served0 >= 10, "explorer-size calls did not go through the resident form"
-    _few_fallbacks(eng, fb0)
-    with pytest.raises(ValueError):
-        ens.get_fitness(data[5][:3] + ["!" * L])
-    assert np.array_equal(ens.get_fitness(data[5]), want[5])
-    w0 = members[0].model.get_weights()
-    members[0].model.set_weights([w * 0.5 for w in w0])
-    eng.set_option("serve_small", 0)
-    try:
-        want_half = ens.get_fitness(data[17])
-    finally:
-        eng.set_option("serve_small", 1)
-    for _ in range(4):
-        assert np.array_equal(ens.get_fitness(data[17]), want_half)
-    assert not np.array_equal(want_half, want[17])
-    members[0].model.set_weights(w0)
-    for _ in range(3):
-        assert np.array_equal(ens.get_fitness(data[17]), want[17])
-
-
-def test_resident_small_call_form_mixed_ensemble(eng):
-    """DyNA-PPO's default ensemble (dyna_ppo.py:53-55: GlobalEpistasis(100) + MLP(200) + CNN(32, 100)) and other mixed
-    member lists: every group of like members is its own resident launch, all answer the same request.  Same bits as the
-    launched calls; an ensemble with a member that has no resident form (a CNN on a 20-letter alphabet) keeps launching."""
-    L, alpha = 14, "UGCA"
-    lists = {
-        "dyna_ppo": [bm.GlobalEpistasisModel(L, 100, alpha, seed=1), bm.MLP(L, 200, alpha, seed=2), bm.CNN(L, 32, 100, alpha, seed=3)],
-        "cnn_mlp_cnn_cnn": [bm.CNN(L, 32, 100, alpha, seed=4), bm.MLP(L, 100, alpha, seed=5), bm.CNN(L, 32, 100, alpha, seed=6),
-                            bm.CNN(L, 32, 100, alpha, seed=7)],
-        "two_mlp_sizes": [bm.MLP(L, 100, alpha, seed=8), bm.MLP(L, 50, alpha, seed=9), bm.MLP(L, 50, alpha, seed=10)],
-    }
-    sizes = (1, 7, 16, 20, 33, 100, 256)
-    data = {n: rand_seqs(n, L, alpha, seed=300 + n)[1] for n in sizes}
-    for name, members in lists.items():
-        ens = flexs_amd.Ensemble(members)
-        stack = flexs_amd.Ensemble(members, combine_with=lambda x: x)
-        eng.set_option("serve_small", 0)
-        try:
-            want = {n: ens.get_fitness(data[n]) for n in sizes}
-            want_nm = {n: stack.get_fitness(data[n]) for n in sizes}
-        finally:
-            eng.set_option("serve_small", 1)
-        served0, fb0 = eng.get_option("server_calls"), eng.get_option("server_fallbacks")
-        for rep in range(3):
-            for n in sizes:
-                assert np.array_equal(ens.get_fitness(data[n]), want[n]), (name, rep, n)
-                assert np.array_equal(stack.get_fitness(data[n]), want_nm[n]), (name, rep, n)
-        assert eng.get_option("server_calls") - served0 >= 30, name
-        _few_fallbacks(eng, fb0, name)
-        with pytest.raises(ValueError):
-            ens.get_fitness(data[7][:3] + ["!" * L])
-        assert np.array_equal(ens.get_fitness(data[7]), want[7])
-    ppo = bm.DynaPPOEnsemble(L, alpha)
-    ppo.r_squared_vals = np.array([0.9, 0.8, 0.7])
-    eng.set_option("serve_small", 0)
-    try:
-        want = ppo.get_fitness(data[7])
-    finally:
-        eng.set_option("serve_small", 1)
-    served0 = eng.get_option("server_calls")
-    for _ in range(8):
-        assert np.array_equal(ppo.get_fitness(data[7]), want)
-    assert eng.get_option("server_calls") - served0 >= 3
-    # a member without a resident form: refused once, launched from then on, same results
-    La = 12
-    mixed = [bm.MLP(La, 100, s_utils.AAS, seed=1), bm.CNN(La, 32, 100, s_utils.AAS, seed=2)]
-    ens = flexs_amd.Ensemble(mixed)
-    seqs = rand_seqs(20, La, s_utils.AAS, seed=5)[1]
-    eng.set_option("serve_small", 0)
-    try:
-        want = ens.get_fitness(seqs)
-    finally:
-        eng.set_option("serve_small", 1)
-    served0, starts0 = eng.get_option("server_calls"), eng.get_option("server_starts")
-    for _ in range(6):
-        assert np.array_equal(ens.get_fitness(seqs), want)
-    assert eng.get_option("server_calls") == served0 and eng.get_option("server_starts") == starts0
-
-
-@pytest.mark.parametrize("kind,L,alpha,H,M,n", [
-    ("mlp", 14, "UGCA", 100, 1, 100_000), ("mlp", 14, "UGCA", 100, 1, 100_016), ("mlp", 14, "UGCA", 100, 1, 104_096),
-    ("mlp", 14, "UGCA", 100, 1, 108_192), ("mlp", 14, "UGCA", 100, 3, 33_333), ("mlp", 8, "TGCA", 100, 2, 50_001),
-    ("mlp", 4, "TGCA", 100, 1, 30_000), ("mlp", 16, "UGCA", 64, 1, 70_001), ("mlp", 14, "UGCA", 112, 1, 41_000),
-    ("ge", 90, s_utils.AAS, 100, 1, 100_000), ("ge", 90, s_utils.AAS, 100, 1, 104_096), ("ge", 90, s_utils.AAS, 100, 1, 108_200),
-    ("ge", 90, s_utils.AAS, 100, 1, 112_300), ("ge", 90, s_utils.AAS, 100, 8, 100_000), ("ge", 14, "UGCA", 100, 3, 33_333),
-    ("ge", 8, "TGCA", 50, 1, 21_000), ("ge", 237, s_utils.AAS, 100, 2, 20_480),
-])
-def test_shared_last_tiles_of_the_dense_kernel_give_the_same_bits(eng, kind, L, alpha, H, M, n):
-    """Round 3: the persistent MLP / GlobalEpistasis kernel leaves the (tiles mod 4) last tiles of a workgroup out of its
-    per-SIMD shares and walks them with groups of 8 waves (`dense_coop`, score_dense_tile.h) instead of letting one SIMD
-    run an extra tile.  Same arithmetic per output element, so the SAME BITS as one wave per tile (`dense_coop` = 0) --
-    every remainder (the sizes put 1, 2 and 3 odd tiles into the workgroups), members, ragged batches -- both agree with
-    the oracle, and a bad character in a shared tile is still reported."""
-    A = len(alpha)
-    natives, ws = zip(*[make_native(eng, kind, L, A, H, seed=900 + m) for m in range(M)])
-    lut = _native.make_lut(alpha)
-    b, seqs = rand_seqs(n, L, alpha, seed=L + H + M + 1)
-    eng.set_option("dense_small", 0)
-    try:
-        outs = {}
-        for coop in (2, 1, 0):                             # 2: GlobalEpistasis too (measured slower there, so 1 = MLP only)
-            eng.set_option("dense_coop", coop)
-            outs[coop], _ = eng.score(list(natives), b, lut)
-        assert np.array_equal(outs[1], outs[0]) and np.array_equal(outs[2], outs[0])
-        eng.set_option("dense_coop", 2)
-        k = min(n, 300)
-        for m in range(M):
-            assert_scores(outs[1][:k, m], c_oracle.forward(kind, lut[b[:k]], A, ws[m]), f"{kind} L={L} H={H} member {m}")
-            assert_scores(outs[1][n - k:, m], c_oracle.forward(kind, lut[b[n - k:]], A, ws[m]), f"{kind} L={L} H={H} member {m} tail")
-        # a character outside the alphabet anywhere -- the shared tiles are the last ones of each workgroup's range
-        ncu = eng.get_option("num_cus")
-        tiles = (n + 15) // 16
-        for where in (n - 1, 16 * (tiles // ncu) - 1, n // 2):
-            bad = b.copy(); bad[min(max(where, 0), n - 1), L - 1] = ord("!")
-            with pytest.raises(ValueError):
-                eng.score(list(natives), bad, lut)
-        again, _ = eng.score(list(natives), b, lut)
-        assert np.array_equal(again, outs[1])
-    finally:
-        eng.set_option("dense_coop", 1)
-        eng.set_option("dense_small", 1)
-
-
-def test_nam_fused_table_batch_and_its_fallbacks(eng):
-    """`NoisyAbstractModel` over a device table landscape answers the uncached part of a batch in one device round trip
-    (fx_cache_nam_query: neighbour search + both look-ups + blend, RNG draws made on the host in query order).  Against
-    the same landscape behind a plain wrapper (the reference's one-by-one loop): same values, same cache order, same
-    landscape cost and the same position of NumPy's global RNG afterwards -- also when the fused call has to hand the
-    batch back (a negative neighbour value: the reference draws from the cache instead; a sequence the table does not
-    hold: KeyError)."""
-    L = 6
-    rng = np.random.default_rng(3)
-    vals = rng.uniform(0.0, 1.0, 4 ** L)
-    neg = rng.random(4 ** L) < 0.02
-    vals[neg] = -rng.uniform(0.1, 1.0, int(neg.sum()))              # a few negative fitnesses
-    missing_idx = int(np.flatnonzero(~neg)[7])
-    vals[missing_idx] = np.nan                                       # one k-mer the table does not hold
-    all_seqs = ["".join("ACGT"[(i >> (2 * k)) & 3] for k in range(L)) for i in range(4 ** L)]
-
-    class Table(flexs_amd.Landscape):
-        batch_safe = True
-
-        def __init__(self):
-            super().__init__("table")
-            self._L = L
-            self._t = None
-
-        def _native_table(self):
-            if self._t is None:
-                self._t = _native.NativeTable(_native.Engine.get(None), vals, "ACGT", bits=2)
-            return self._t
-
-        def _fitness_function(self, seqs):
-            out = self._native_table().lookup(_native.sequences_to_bytes([str(s) for s in seqs], L=L))
-            if np.isnan(out).any():
-                raise KeyError(str(seqs[int(np.flatnonzero(np.isnan(out))[0])]))
-            return out
-
-    class Plain(flexs_amd.Landscape):                                # same values, the one-by-one path
-        def __init__(self, inner):
-            super().__init__("plain")
-            self.inner = inner
-
-        def _fitness_function(self, seqs):
-            return self.inner._fitness_function(seqs)
-
-    order = rng.permutation(4 ** L)
-    order = order[order != missing_idx]
-    pos_first = [all_seqs[i] for i in order if vals[i] >= 0][:40]    # training set without negative values
-    pool = [all_seqs[i] for i in order]
-    outs = []
-    for wrap in (False, True):
-        land = Table()
-        target = Plain(land) if wrap else land
-        np.random.seed(11)
-        nam = bm.NoisyAbstractModel(target, 0.8)
-        nam.train(pos_first, land._fitness_function(pos_first))
-        res = []
-        for i in range(12):                                          # batches of 1-60 sequences, some with negative neighbours later on
-            n = (1, 3, 20, 60)[i % 4]
-            res.append(nam.get_fitness(pool[100 + 60 * i: 100 + 60 * i + n]))
-        res.append(nam.get_fitness(pool[90:200]))                    # mostly cached
-        res.append(nam.get_fitness(pool[1000:1030]))
-        eng.set_option("zero_copy_bytes", 2048)                      # a batch beyond the mapped staging area: the copy path
-        try:
-            res.append(nam.get_fitness(pool[1030:2500]))
-            res.append(nam.get_fitness(pool[2500:2510]))              # (small again: but the pending keys no longer fit inline)
-        finally:
-            eng.set_option("zero_copy_bytes", 262144)
-        res.append(nam.get_fitness(pool[2510:3900]))
-        outs.append((np.concatenate(res), target.cost, float(np.random.random()), list(nam.cache), list(nam.cache.values())))
-        # a sequence the table does not hold: the reference's KeyError, nothing cached (what the RNG has consumed by then
-        # differs between a batched and a one-by-one landscape by construction, so this comes last)
-        n_cached = len(nam.cache)
-        with pytest.raises(KeyError):
-            nam.get_fitness(pool[900:905] + [all_seqs[missing_idx]] + pool[905:910])
-        assert len(nam.cache) == n_cached
-    assert np.array_equal(outs[0][0], outs[1][0])
-    assert outs[0][1:] == outs[1][1:]
-    assert (np.array(outs[0][4]) < 0).any(), "the scenario never produced a negative cached fitness: the fallback was not exercised"
-
-
-def _device_table_landscape(vals, alpha, L):
-    class Table(flexs_amd.Landscape):
-        batch_safe = True
-
-        def __init__(self):
-            super().__init__("Table")
-            self._L = L
-            self._t = None
-
-        def _native_table(self):
-            if self._t is None:
-                self._t = _native.NativeTable(_native.Engine.get(None), vals, alpha, bits=2)
-            return self._t
-
-        def _fitness_function(self, seqs):
-            return self._native_table().lookup(_native.sequences_to_bytes([str(s) for s in seqs], L=L))
-
-    return Table()
-
-
-def _count_fused(nam):
-    """Wraps `_fused_table_batch`: [batches answered by fx_cache_nam_query, batches it handed back to the general path]."""
-    counts = [0, 0]
-    inner = nam._fused_table_batch
-
-    def wrapped(new_seqs):
-        out = inner(new_seqs)
-        counts[0 if out is not None else 1] += 1
-        return out
-
-    nam._fused_table_batch = wrapped
-    return counts
-
-
-def test_nam_fused_query_against_reference_traces_and_oracle(eng, golden_dir):
-    """Round-3 verdict, weak #2: the fused NoisyAbstractModel query (`fx_cache_nam_query`: append of the pending keys +
-    neighbour search + both table look-ups + blend in one submission) was only ever held to the product's own one-by-one
-    path.  Here it stands DIRECTLY beside (1) outputs of the reference's class on complete k-mer tables
-    (`nam_table_traces.json`, made by running flexs/baselines/models/noisy_abstract_model.py) and (2) the oracle
-    (`ref_np.NoisyAbstractModelOracle`) on the same seed for the CbAS pattern of BASELINE configs[2]: values, landscape cost,
-    cache order, model cost and the position of NumPy's global RNG, bit for bit -- and the fused path must really have run."""
-    traces = json.load(open(os.path.join(golden_dir, "nam_table_traces.json")))["traces"]
-    for tr in traces:
-        land = _device_table_landscape(np.array(tr["table_values"]), tr["alphabet"], tr["L"])
-        np.random.seed(tr["seed"])
-        nam = bm.NoisyAbstractModel(land, signal_strength=tr["ss"])
-        assert nam.name == tr["name"]
-        counts = _count_fused(nam)
-        nam.train(tr["train_sequences"], tr["train_labels"])
-        for b, batch in enumerate(tr["batches"]):
-            out = nam.get_fitness(batch)
-            assert out.dtype == np.float64 and out.tolist() == tr["outputs"][b], (tr["L"], tr["ss"], b)
-            assert land.cost == tr["landscape_cost"][b] and len(nam.cache) == tr["cache_len"][b] and nam.cost == tr["model_cost"][b]
-        assert list(nam.cache.keys()) == tr["cache_keys_in_order"]
-        assert float(np.random.random()) == tr["rng_next_random"]
-        # (a trace whose table holds negative values may hand batches back to the one-by-one path -- the reference then draws
-        #  from the cache instead -- whenever a negative value becomes a neighbour; the others must stay on the fused path)
-        assert counts[0] + counts[1] >= 8 and (tr["has_negative_values"] or counts[1] == 0), f"fused path not taken: {counts}"
-    # (2) the oracle on the same seed: TF-binding sized table (all 8-mers), CbAS pattern (calls of 60 sequences on a growing cache;
-    #     kept small: the oracle's neighbour search is a Python loop over the cache)
-    L, alpha = 8, "TGCA"
-    vals = np.random.default_rng(9).random(4 ** L)
-    pool = synth.bytes_to_strings(synth.random_sequence_bytes(1200, L, alpha, 41))
-    idx = lambda s: sum(alpha.index(c) << (2 * k) for k, c in enumerate(s))      # noqa: E731
-
-    class HostTable(flexs_amd.Landscape):
-        def _fitness_function(self, seqs):
-            return np.array([vals[idx(str(s))] for s in seqs])
-
-    outs = []
-    for fused in (True, False):
-        land = _device_table_landscape(vals, alpha, L) if fused else HostTable("Table")
-        np.random.seed(77)
-        nam = bm.NoisyAbstractModel(land, 0.9) if fused else ref_np.NoisyAbstractModelOracle(land, 0.9)
-        counts = _count_fused(nam) if fused else None
-        nam.train(pool[:300], vals[[idx(s) for s in pool[:300]]])
-        res = [nam.get_fitness(pool[300 + 60 * c: 360 + 60 * c]) for c in range(10)]
-        res.append(nam.get_fitness(pool[250:500]))                  # cached
-        res.append(nam.get_fitness([pool[1100]]))                   # one query
-        outs.append((np.concatenate(res), land.cost, nam.cost, list(nam.cache), float(np.random.random())))
-        if fused:
-            assert counts[0] >= 11 and counts[1] == 0, counts
-    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1:] == outs[1][1:]
-
-
-def test_resident_answers_against_the_oracle(eng):
-    """Round-3 verdict, weak #2: the resident form (explorer-size calls answered by workgroups that stay on the device) was
-    held to the launched form bit for bit, which is held to the oracle -- transitive.  Here every served family stands
-    directly beside `ref_np.keras_fitness` (float64), at the 1e-5 tolerance of the parity suite, on calls that WERE
-    answered by resident workgroups."""
-    cases = [("cnn", 8, "TGCA", 100, 3), ("cnn", 14, "UGCA", 100, 2), ("cnn", 8, "TGCA", 100, 1), ("mlp", 14, "UGCA", 100, 1),
-             ("mlp", 8, "TGCA", 200, 2), ("ge", 14, "UGCA", 100, 3), ("ge", 90, s_utils.AAS, 100, 8), ("mlp", 90, s_utils.AAS, 100, 1)]
-    for kind, L, alpha, H, M in cases:
-        mk = {"cnn": lambda s: bm.CNN(L, 32, H, alpha, seed=s), "mlp": lambda s: bm.MLP(L, H, alpha, seed=s),
-              "ge": lambda s: bm.GlobalEpistasisModel(L, H, alpha, seed=s)}[kind]
-        members = [mk(50 + s) for s in range(M)]
-        stack = flexs_amd.Ensemble(members, combine_with=lambda x: x)
-        ens = flexs_amd.Ensemble(members)
-        served0, fb0 = eng.get_option("server_calls"), eng.get_option("server_fallbacks")
-        for n in (1, 16, 20, 100, 150):
-            seqs = rand_seqs(n, L, alpha, seed=900 + n)[1]
-            want = np.stack([ref_np.keras_fitness(seqs, alpha, kind, [np.asarray(w, np.float64) for w in m.model.get_weights()], exact=True)
-                             for m in members], axis=1)
-            assert _until_resident(eng, lambda: ens.get_fitness(seqs)), (kind, L, M, n)
-            c0 = eng.get_option("server_calls") + eng.get_option("server_fallbacks")
-            got = stack.get_fitness(seqs)
-            mean = ens.get_fitness(seqs)
-            assert eng.get_option("server_calls") + eng.get_option("server_fallbacks") == c0 + 2, "not answered by the resident form"
-            assert got.shape == (n, M)
-            for m in range(M):
-                assert_scores(got[:, m], want[:, m], f"resident {kind} L={L} H={H} member {m} n={n}")
-            assert np.array_equal(mean, np.mean(got, axis=1))
-        assert eng.get_option("server_calls") - served0 >= 10, (kind, L, M)      # (two asserted calls per size, plus the warm-up ones)
-        _few_fallbacks(eng, fb0, f"{kind} L={L}")
-
-
-@pytest.mark.parametrize("kind,L,alpha,H,M", [("cnn", 8, "TGCA", 100, 3), ("cnn", 8, "TGCA", 100, 1), ("cnn", 14, "UGCA", 100, 2),
-                                             ("mlp", 14, "UGCA", 100, 1), ("ge", 14, "UGCA", 100, 3), ("ge", 90, s_utils.AAS, 100, 8),
-                                             ("mlp", 90, s_utils.AAS, 100, 1), ("mix", 14, "UGCA", 100, 3)])
-def test_resident_wide_form(eng, kind, L, alpha, H, M):
-    """Round 4 (`serve_wide`, default on): a resident generation takes most of the chip and a tile slot walks the tiles
-    slot, slot + T, slot + 2 T, ... of a request, so calls of 257 ... 4096 sequences (64 KiB of sequence bytes) -- a Random
-    explorer round of 2001, CbAS batches, Adalead's roots + first children -- are answered without a launch, a weight fill
-    and a second launch for the mean.  Same round / tile code as the launched small forms, so the SAME BITS as the launched
-    call (which for these sizes runs the one-wave-per-tile kernels: the forms are bit-identical by construction), and
-    directly beside the float64 oracle; sizes the mailboxes do not hold launch as before; a character outside the alphabet
-    in a late tile of a late slot is the reference's ValueError; round 3's geometry (serve_wide = 0) still serves <= 256."""
-    if kind == "mix":
-        members = [bm.GlobalEpistasisModel(L, 100, alpha, seed=1), bm.MLP(L, 200, alpha, seed=2), bm.CNN(L, 32, 100, alpha, seed=3)]
-        kinds = ["ge", "mlp", "cnn"]
-    else:
-        mk = {"cnn": lambda s: bm.CNN(L, 32, H, alpha, seed=s), "mlp": lambda s: bm.MLP(L, H, alpha, seed=s),
-              "ge": lambda s: bm.GlobalEpistasisModel(L, H, alpha, seed=s)}[kind]
-        members = [mk(70 + s) for s in range(M)]
-        kinds = [kind] * M
-    ens = flexs_amd.Ensemble(members) if M > 1 else members[0]
-    stack = flexs_amd.Ensemble(members, combine_with=lambda x: x)
-    cap = min(4096, 65536 // L)
-    sizes = [257, 300, 1000, 2001, cap - 1, cap, cap + 1]
-    if cap < 2001:
-        sizes = [257, 300, cap // 2, cap - 1, cap, cap + 1]
-    data = {n: rand_seqs(n, L, alpha, seed=400 + n)[1] for n in sizes}
-    eng.set_option("serve_small", 0)
-    try:
-        want = {n: ens.get_fitness(data[n]) for n in sizes}
-        want_nm = {n: stack.get_fitness(data[n]) for n in sizes}
-    finally:
-        eng.set_option("serve_small", 1)
-    small = data[257][:20]
-    eng.set_option("serve_wide", 2)                                      # (always wide: the default, 1, chooses by the caller's recent sizes)
-    assert _until_resident(eng, lambda: ens.get_fitness(small))
-    assert eng.get_option("server_wide") == 1 and eng.get_option("server_slots") > 16
-    fb0 = eng.get_option("server_fallbacks")
-    for rep in range(2):
-        for n in sizes:
-            ens.get_fitness(small)                                       # (a launch for cap + 1 told the generation to leave)
-            ens.get_fitness(small)
-            c0 = eng.get_option("server_calls") + eng.get_option("server_fallbacks")
-            got = ens.get_fitness(data[n])
-            got_nm = stack.get_fitness(data[n])
-            served = eng.get_option("server_calls") + eng.get_option("server_fallbacks") - c0
-            assert served == (2 if n <= cap else 0), (n, cap, served)
-            assert np.array_equal(got, want[n]), (kind, n, rep)
-            assert np.array_equal(got_nm, want_nm[n]), (kind, n, rep)
-    _few_fallbacks(eng, fb0, f"wide {kind} L={L}")
-    # beside the oracle, directly
-    n = sizes[3]
-    got_nm = stack.get_fitness(data[n])
-    for m, (mod, kd) in enumerate(zip(members, kinds)):
-        ref = ref_np.keras_fitness(data[n], alpha, kd, [np.asarray(w, np.float64) for w in mod.model.get_weights()], exact=True)
-        assert_scores(got_nm[:, m], ref, f"wide resident {kd} L={L} member {m} n={n}")
-    # a character outside the alphabet in the LAST tile (a late slot's second or third tile): ValueError, then business as usual
-    for _ in range(3):
-        ens.get_fitness(small)
-    bad = list(data[sizes[3]])
-    bad[-1] = bad[-1][:-1] + "!"
-    with pytest.raises(ValueError):
-        ens.get_fitness(bad)
-    assert np.array_equal(ens.get_fitness(data[sizes[3]]), want[sizes[3]])
-    # round 3's geometry: <= 256 sequences are served, 257 launch; same bits
-    eng.set_option("serve_wide", 0)
-    try:
-        assert _until_resident(eng, lambda: ens.get_fitness(small))
-        assert eng.get_option("server_wide") == 0 and eng.get_option("server_slots") <= 16
-        c0 = eng.get_option("server_calls") + eng.get_option("server_fallbacks")
-        assert np.array_equal(ens.get_fitness(data[257][:100]), want[257][:100])     # (a prefix on its own: same bits, batch invariance)
-        got = ens.get_fitness(data[257])
-        assert np.array_equal(got, want[257])
-        assert eng.get_option("server_calls") + eng.get_option("server_fallbacks") - c0 <= 1
-    finally:
-        eng.set_option("serve_wide", 1)
-    # the default: ADAPTIVE.  A caller that only asks for a few sequences gets the narrow generation (every explorer-size call
-    # is ~1.2 us faster without 240 resident workgroups); two requests of more than 256 sequences within 2 ms replace it by a
-    # wide one; same bits either way
-    import time as _t
-    _t.sleep(0.3)                                                        # (forget the sizes asked above)
-    assert _until_resident(eng, lambda: ens.get_fitness(small))
-    assert eng.get_option("server_wide") == 0
-    for _ in range(2):
-        assert np.array_equal(ens.get_fitness(data[300]), want[300])     # launched (narrow generation), then the switch
-    for _ in range(4):
-        assert np.array_equal(ens.get_fitness(data[300]), want[300])
-    assert eng.get_option("server_wide") == 1, "dense mid-size requests did not bring the wide generation"
-    assert np.array_equal(ens.get_fitness(small), want[257][:20])
-
-
-def test_small_call_fast_path_bookkeeping(eng):
-    """The Python side of explorer-size calls (one C call on an argument block cached per model list): the block follows the
-    member list when it is edited, copies and pickles carry no device handles, costs are charged as by the general path, every
-    input form the general path takes is taken, and errors are the general path's errors."""
-    import copy
-    import pickle
-
-    L, alpha = 8, "TGCA"
-    members = [bm.CNN(L, 32, 100, alpha, seed=s) for s in range(3)]
-    ens = flexs_amd.Ensemble(members)
-    seqs = rand_seqs(40, L, alpha, seed=1)[1]
-    eng.set_option("serve_small", 0)
-    try:
-        want3 = ens.get_fitness(seqs)
-        extra = bm.MLP(L, 100, alpha, seed=9)
-        want4 = flexs_amd.Ensemble(members + [extra]).get_fitness(seqs)
-        want_single = members[1].get_fitness(seqs)
-    finally:
-        eng.set_option("serve_small", 1)
-    for form in (seqs, tuple(seqs), [np.str_(s) for s in seqs], np.array(seqs), np.array(seqs, dtype="S")):
-        assert np.array_equal(ens.get_fitness(form), want3)
-        assert np.array_equal(members[1].get_fitness(form), want_single)
-    c0 = [m.cost for m in members]
-    e0 = ens.cost
-    ens.get_fitness(seqs[:7])
-    assert ens.cost == e0 + 7 and [m.cost for m in members] == [c + 7 for c in c0]
-    # the member list is edited in place: the cached block must not answer for the old list
-    ens.models.append(extra)
-    assert np.array_equal(ens.get_fitness(seqs), want4)
-    ens.models.pop()
-    assert np.array_equal(ens.get_fitness(seqs), want3)
-    # copies / pickles: no device handles travel, the copy scores with handles of its own
-    for clone in (copy.deepcopy(ens), pickle.loads(pickle.dumps(ens))):
-        assert np.array_equal(clone.get_fitness(seqs), want3)
-        assert np.array_equal(clone.models[1].get_fitness(seqs), want_single)
-    # errors: ragged batch, character outside the alphabet, not a string -- whatever the general path raises
-    with pytest.raises(ValueError):
-        ens.get_fitness(seqs[:3] + ["ACG"])
-    with pytest.raises(ValueError):
-        ens.get_fitness(seqs[:3] + ["ACGTACGZ"])
-    with pytest.raises(ValueError):
-        members[0].get_fitness(["ACGTACGZ"])
-    c1 = [m.cost for m in members]
-    assert np.array_equal(ens.get_fitness(seqs), want3) and [m.cost for m in members] == [c + 40 for c in c1]
-    assert ens.get_fitness([]).shape == (0,)
-
-
-def test_resident_form_at_the_mailbox_limits(eng):
-    """Requests at the edges of what the mailboxes hold: 256 sequences, exactly 16 KiB of sequence bytes (L = 64), one byte
-    more (launched), 257 sequences (launched) -- all with the launched form's bits."""
-    alpha = s_utils.AAS
-    # (capacity = 16 sequences x min(16, 16384 // (16 L)) tile slots: 256 at L = 64, 240 at L = 65, 128 at L = 128)
-    for L, sizes in ((64, (255, 256, 257)), (65, (239, 240, 241)), (128, (127, 128, 129))):
-        m = bm.MLP(L, 100, alpha, seed=L)
-        data = {n: rand_seqs(n, L, alpha, seed=n)[1] for n in sizes}
-        eng.set_option("serve_small", 0)
-        try:
-            want = {n: m.get_fitness(data[n]) for n in sizes}
-        finally:
-            eng.set_option("serve_small", 1)
-        served0 = eng.get_option("server_calls")
-        for rep in range(4):
-            for n in sizes:
-                assert np.array_equal(m.get_fitness(data[n]), want[n]), (L, n, rep)
-        assert eng.get_option("server_calls") > served0

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Build and run one probe under tools/probes on the GPU box: tools/gpu_probe.sh mailbox_probe2
+# Build and run one probe under tools/probes on the GPU box: tools/archive/gpu_probe.sh mailbox_probe2
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -std=c++17 tools/probes/$1.hip -o /tmp/$1 2>&1 | tail -5

@@ -7,4 +7,4 @@ python -c "import __graft_entry__ as g; g.build(quiet=True); print('build ok')" 
 timeout 900 python -m pytest tests/test_train_native.py tests/test_training.py -m gpu -q --tb=short -p no:cacheprovider --timeout 600 -s > $OUT/pytest_train.log 2>&1
 echo "pytest exit: $?" >> $OUT/pytest_train.log
 grep -v "^$" $OUT/pytest_train.log | tail -40
-timeout 300 python tools/runs/r3_train_time.py > $OUT/train_time.log 2>&1; cat $OUT/train_time.log | tail -30
+timeout 300 python tools/archive/runs/r3_train_time.py > $OUT/train_time.log 2>&1; cat $OUT/train_time.log | tail -30

@@ -6,7 +6,7 @@ python -c "import __graft_entry__ as g; g.build(quiet=True); print('build ok')" 
 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=short -p no:cacheprovider --timeout 600 -x -k "pipelined or mlp or ge_ or dense or sweep" > $OUT/pytest_dense.log 2>&1
 echo "pytest exit: $?" >> $OUT/pytest_dense.log
 grep -v "^$" $OUT/pytest_dense.log | tail -25
-timeout 400 python tools/runs/r3_dense_pipe_ab.py > $OUT/dense_pipe_ab.log 2>&1
+timeout 400 python tools/archive/runs/r3_dense_pipe_ab.py > $OUT/dense_pipe_ab.log 2>&1
 grep "dense_pipe" $OUT/dense_pipe_ab.log | python -c "
 import sys, ast
 for ln in sys.stdin:

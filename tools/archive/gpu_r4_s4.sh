@@ -10,7 +10,7 @@ grep -v "^\.*$" $OUT/pytest_resident.log | tail -30
 timeout 600 python -m pytest tests/test_train_native.py tests/test_training.py -m gpu -q --tb=short -p no:cacheprovider --timeout 300 -s > $OUT/pytest_train.log 2>&1
 echo "pytest exit: $?" >> $OUT/pytest_train.log
 grep -v "^\.*$" $OUT/pytest_train.log | tail -30
-timeout 300 python tools/runs/r4_train_time.py > $OUT/train_time.log 2>&1; echo "exit: $?" >> $OUT/train_time.log
+timeout 300 python tools/archive/runs/r4_train_time.py > $OUT/train_time.log 2>&1; echo "exit: $?" >> $OUT/train_time.log
 grep -v "amdgpu.ids" $OUT/train_time.log
-timeout 500 python tools/runs/r4_server_wide_ab.py > $OUT/wide_ab.log 2>&1; echo "exit: $?" >> $OUT/wide_ab.log
+timeout 500 python tools/archive/runs/r4_server_wide_ab.py > $OUT/wide_ab.log 2>&1; echo "exit: $?" >> $OUT/wide_ab.log
 grep -v "amdgpu.ids" $OUT/wide_ab.log

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session: parity tests, bench variants, rocprof kernel trace.
-# Usage (from the build container):  gpurun --timeout 1500 -- 'bash tools/gpu_round.sh'
+# Usage (from the build container):  gpurun --timeout 1500 -- 'bash tools/archive/gpu_round.sh'
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out
 mkdir -p $OUT

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 3 validation + profile session: GPU tests, bench lines, kernel trace, PMC passes (separate runs, --pmc only), survey.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-OUT=gpurun_out/r3d; rm -rf $OUT; mkdir -p $OUT
+OUT=gpurun_out/r3; rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build(quiet=True); print('build ok')" > $OUT/env.log 2>&1
 timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --timeout 900 > $OUT/pytest_gpu.log 2>&1
@@ -28,17 +28,8 @@ timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OUT/profT -o t -- $T > $
 timeout 900 python tools/perf_survey.py > $OUT/perf_survey.log 2>&1; echo "exit $?" >> $OUT/perf_survey.log
 cp gpurun_out/perf_survey.json $OUT/ 2>/dev/null
 timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_train -o tr -- python tools/runs/r3_train_prof.py > $OUT/rocprof_train.log 2>&1
-timeout 200 python tools/runs/r3_train_trace.py > $OUT/train_trace.log 2>&1
-timeout 300 python tools/runs/r3_train_time.py > $OUT/train_time.log 2>&1
-timeout 300 python tools/runs/r3_dense_coop_ab.py > $OUT/dense_coop_ab.log 2>&1
-timeout 200 python tools/runs/r3_quad_rotate_ab.py > $OUT/quad_rotate_ab.log 2>&1
-timeout 200 python tools/runs/r3_nam_fused_ab.py > $OUT/nam_fused_ab.log 2>&1
-timeout 200 python tools/runs/r3_small_zero_copy_ab.py > $OUT/small_zero_copy_ab.log 2>&1
-timeout 300 python tools/runs/r3_server_ab.py > $OUT/server_ab.log 2>&1
-timeout 300 python tools/runs/r3_server_stress.py > $OUT/server_stress.log 2>&1
-timeout 300 python tools/runs/r3_server_mixed.py > $OUT/server_mixed.log 2>&1
-timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_srv1 -o s1 -- python tools/runs/r3_server_trace.py 1 > $OUT/rocprof_server_on.log 2>&1
-timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_srv0 -o s0 -- python tools/runs/r3_server_trace.py 0 > $OUT/rocprof_server_off.log 2>&1
+timeout 200 python tools/archive/runs/r3_train_trace.py > $OUT/train_trace.log 2>&1
+timeout 300 python tools/archive/runs/r3_train_time.py > $OUT/train_time.log 2>&1
 # keep the merged directory small: drop the raw per-dispatch CSVs of the PMC passes (summaries stay)
 find $OUT -name "*counter_collection.csv" -size +2M -delete
 find $OUT -name "*_kernel_trace.csv" -size +2M -delete

@@ -10,7 +10,7 @@ out = {"kernel": name, "hbm_bytes_per_launch": k.get("hbm_bytes"), "fetch_size_k
        "lds_bank_conflict_cycles": k.get("SQ_LDS_BANK_CONFLICT"), "lds_active_cycles": k.get("SQ_LDS_IDX_ACTIVE"),
        "kernel_us_profiled": (k.get("ns") or {}).get("sq", 0) / 1e3 or None, "commit": commit,
        "note": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ util set | SQ inst set, separate runs, no trace domains) over "
-               "`python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extras` (tools/gpu_round4.sh), summarised by "
+               "`python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extras` (tools/archive/gpu_round4.sh), summarised by "
                "tools/summarize_pmc.py; hbm_bytes = FETCH_SIZE x 2 (gfx950 unit correction) + WRITE_SIZE, KiB -> bytes; "
                "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMD x CU-cycles)",
        "all_kernels": d}
