@@ -82,8 +82,17 @@ FXT_HD int fxt_ld_w(int F) { return (F & 7) == 0 ? F + 4 : F; }
 // through fxt_xi and the ...Swz operand functors below, and the unrotated code keeps its own functors (the kernels every other
 // fit runs are unchanged instruction for instruction).  Where a value is stored does not change the value: the same bits as the
 // unrotated layout (sanitizer driver, CPU).
-template <bool SWZ>
-FXT_HD int fxt_xi(int row, int c, int ld) { return row * ld + (SWZ ? ((c + 2 * row) & (ld - 1)) : c); }
+// LAY 0: rows as they are; 1 (true): rotated rows; 2: FRAGMENT rows (MODE 3, 32 channels, round 5) -- channel c = 16 h + 4 u + kq of a
+// row is stored at column 4 ((4 h + kq + (row & 6)) mod 8) + u: the four channels a lane feeds to the four k-steps of a half-tap (same
+// kq, u = 0 .. 3) are 16 contiguous bytes, so an A operand is ONE ds_read_b128 per half-tap instead of four ds_read_b32 -- a lone wave
+// gets a fifth of the LDS rate on 4-byte reads (MI355X_MICROARCH.md, LDS), and with the matrix pipe handed to the oldest wave the
+// conv products ran one wave per SIMD at a time, each waiting on its own reads (round 5, per-wave stamps) -- and the chunk rotation
+// by (row & 6) keeps the sixteen lanes of each ds_read_b128 lane group on sixteen distinct 16-byte bank groups for ANY starting row.
+template <int LAY>
+FXT_HD int fxt_xi(int row, int c, int ld) {
+    if (LAY == 2) return row * 32 + 4 * ((((c >> 4) << 2) + (c & 3) + (row & 6)) & 7) + ((c >> 2) & 3);
+    return row * ld + (LAY ? ((c + 2 * row) & (ld - 1)) : c);
+}
 template <bool SWZ, class A, class B> struct FxtPick { typedef A T; };
 template <class A, class B> struct FxtPick<true, A, B> { typedef B T; };
 // MODE of fxt_forward_backward: 3 = MODE 2 with the F = 32 conv products of "MODE 3" below (paired tiles over conflict-free rotated
@@ -195,6 +204,7 @@ FXT_HD FxtWs fxt_ws(const FxtNet& n, int R, bool alias_dz = false) {
     w.yvalid = off; off += R;
     if (n.kind == 0) {
         w.ldF = n.ldx;
+        if (alias_dz) off = (off + 3) & ~3;     // (16-byte aligned arrays: MODE 3 fetches operands with ds_read_b128)
         const int s = R * n.L1 * w.ldF;
         for (int i = 0; i < 3; ++i) { w.a[i] = off; off += s; }
         if (alias_dz) w.dzA = w.a[2];
@@ -550,7 +560,7 @@ FXT_HD void fxt_gemm(const FxtWg& wg, int Md, int Nd, int Ko, int Ki, const FA& 
 // memory (1), weights in LDS or global memory -- with address-space-qualified pointer types; the host build has one.
 #if defined(FXT_EMUL)
 typedef float fxt_f4 __attribute__((ext_vector_type(4), aligned(4)));   // (host memory of the emulator: no 16-byte promise)
-template <int AS> struct FxtMem { typedef float* F; typedef const float* CF; typedef int* I; typedef const int* CI; typedef const fxt_f4* CF4; };
+template <int AS> struct FxtMem { typedef float* F; typedef const float* CF; typedef int* I; typedef const int* CI; typedef const fxt_f4* CF4; typedef fxt_f4* F4; };
 #elif FXT_DEVICE
 typedef float fxt_f4 __attribute__((ext_vector_type(4)));
 template <int AS> struct FxtMem {
@@ -559,10 +569,11 @@ template <int AS> struct FxtMem {
     typedef __attribute__((address_space(AS))) int* I;
     typedef const __attribute__((address_space(AS))) int* CI;
     typedef const __attribute__((address_space(AS))) fxt_f4* CF4;      // sixteen bytes at a time (fxt_gemm_staged)
+    typedef __attribute__((address_space(AS))) fxt_f4* F4;
 };
-template <> struct FxtMem<0> { typedef float* F; typedef const float* CF; typedef int* I; typedef const int* CI; typedef const fxt_f4* CF4; };   // (flat / host)
+template <> struct FxtMem<0> { typedef float* F; typedef const float* CF; typedef int* I; typedef const int* CI; typedef const fxt_f4* CF4; typedef fxt_f4* F4; };   // (flat / host)
 #else
-template <int AS> struct FxtMem { typedef float* F; typedef const float* CF; typedef int* I; typedef const int* CI; };
+template <int AS> struct FxtMem { typedef float* F; typedef const float* CF; typedef int* I; typedef const int* CI; typedef const float* CF4; };   // (CF4: never dereferenced by the host build)
 #endif
 
 
@@ -670,19 +681,26 @@ FXT_HD void fxt_gemm_staged(const FxtWg& wg, int Md, int Nd, int Ko, int Ki, con
 //     new x block and ONE dz block from LDS feed up to five MFMAs out of a register window.  The bias row rides on the residue-3
 //     waves (four taps of conv3's nineteen).
 // Every output element still sums the same products in the same order through the same instruction: the SAME BITS as fxt_gemm.
-template <class P>
-struct FxtConvW32 {            // forward B((j, c), n) from the staging buffer: element (j, c, n) at (j 32 + c) 32 + (n + 16 c) mod 32
+// The tap group in the staging buffer, FRAGMENT order: a tap is 2 halves x 32 columns x 16 floats; the sixteen floats of (half h, column n)
+// are [kq'][u] with kq' = (kq + 2 ((n >> 3) & 1)) mod 4 (the swizzle keeps the sixteen lanes of a ds_read_b128 lane group on distinct
+// 16-byte bank groups) and hold the contraction elements 16 h + 4 u + kq: forward B((j, c), n) = W[j][c][n] with c the contraction,
+// input gradient B((j, o), c) = W[j][c][o] with o the contraction and c the column.  A lane's operand for a half-tap is one 16-byte read
+// at a per-lane offset plus a wave-uniform one.
+template <class P, class P4>
+struct FxtConvW4 {
     P w;
-    FXT_HD int prep(int n, int kq) const { return kq * 32 + ((n + 16 * kq) & 31); }
-    FXT_HD float at(int st, int j, int k0) const { return w[st + (j * 32 + k0) * 32]; }     // (k0 is a multiple of 4: 16 k0 = 0 mod 32)
+    FXT_HD int prep(int n, int kq) const { return n * 16 + 4 * ((kq + 2 * ((n >> 3) & 1)) & 3); }
+    FXT_HD float at(int st, int j, int k0) const { return w[st + (j * 2 + (k0 >> 4)) * 512 + ((k0 >> 2) & 3)]; }       // (scalar form: host build)
+    FXT_HD auto at4(int st, int j, int h) const { return *(P4)(w + st + (j * 2 + h) * 512); }
 };
-template <class P>
-struct FxtConvGradW32 {        // input-gradient B((j, o), n = c) = W[j][c][o]: element (j, c, o) at (j 32 + c) 32 + (o + 2 c) mod 32
-    P w;
-    struct St { int base, rot; };
-    FXT_HD St prep(int n, int kq) const { return St{n * 32, (kq + 2 * n) & 31}; }
-    FXT_HD float at(St s, int j, int k0) const { return w[s.base + j * 1024 + ((s.rot + k0) & 31)]; }
-};
+// where element (row = jrel 32 + c, column e) of a kernel's tap group goes.  ROT 0: forward (contraction = row's channel c, column n = e);
+// 1: input gradient (contraction = e, column = c)
+template <int ROT>
+FXT_HD int fxt_w4_off(int row, int e) {
+    const int jrel = row >> 5, c = row & 31;
+    const int k = ROT ? e : c, n = ROT ? c : e;              // contraction element, column
+    return ((jrel * 2 + (k >> 4)) * 32 + n) * 16 + 4 * (((k & 3) + 2 * ((n >> 3) & 1)) & 3) + ((k >> 2) & 3);
+}
 FXT_HD bool fxt_conv32_ok(int Md, int F, int nw) { return F == 32 && ((Md + 15) >> 4) <= nw; }
 // A tap group on its way from L2 to the staging buffer: PF 16-byte pieces per thread in registers.  Carried ACROSS products and phase
 // barriers -- conv2's group is fetched while conv1 runs, conv3's first group behind conv2's MFMAs, conv3's input-gradient group while
@@ -690,12 +708,18 @@ FXT_HD bool fxt_conv32_ok(int Md, int F, int nw) { return F == 32 && ((Md + 15) 
 // weight fetch is issued behind a phase's gradient-partial stores: vmcnt retires in order, a load issued after 78 KiB of partial stores
 // waits for all of them (round 5: conv2's backward phase took 30 us for ~10 us of work in every form; this was why).
 #define FXT_TAP_PF 2
+// A piece = the sixteen bytes one lane of the product will read as ONE operand: piece p of a group is (tap p >> 8, half (p >> 7) & 1,
+// column (p >> 2) & 31, lane group kq = p & 3) and holds the contraction elements 16 half + 4 u + kq, u = 0 .. 3 -- four dword loads
+// (64-byte runs across the lanes) and ONE ds_write_b128 into the fragment order of FxtConvW4, conflict-free.  (Fetched as 16-byte
+// row pieces and scattered by four ds_write_b32 the stores hit the banks 8-way: ~0.9 us per group between two barriers, round 5.)
 template <int WAS>
 struct FxtTapRegs {
 #if FXT_DEVICE
     fxt_f4 pre[FXT_TAP_PF];
 #endif
     int taps;                                              // taps held (0 = nothing)
+    // ROT 0: forward (contraction = the kernel's input channel, column = output channel); 1: input gradient (the other way round)
+    template <int ROT>
     FXT_HD void fetch(const FxtWg& wg, typename FxtMem<WAS>::CF wsrc, int g0, int g1) {      // taps [g0, g1) of a 32 x 32-per-tap kernel
         taps = g1 - g0;
 #if FXT_DEVICE
@@ -703,14 +727,18 @@ struct FxtTapRegs {
 #pragma unroll
         for (int q = 0; q < FXT_TAP_PF; ++q) {
             const int p = wg.tid + q * wg.nthr;
-            if (p < pieces) pre[q] = *(typename FxtMem<WAS>::CF4)(wsrc + ((g0 * 32 + (p >> 3)) * 32 + 4 * (p & 7)));
+            if (p < pieces) {
+                const int jr = p >> 8, half = (p >> 7) & 1, col = (p >> 2) & 31, kq = p & 3;
+                typename FxtMem<WAS>::CF src = wsrc + (g0 + jr) * 1024 + (ROT ? col * 32 + half * 16 + kq : (half * 16 + kq) * 32 + col);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pre[q][u] = src[(ROT ? 4 : 128) * u];
+            }
         }
 #else
         (void)wg; (void)wsrc; (void)g0;
 #endif
     }
-    // into the staging buffer, rows rotated for the product that reads them (ROT 0: forward, column + 16 row; 1: input gradient, + 2 row)
-    template <int ROT, class WB>
+    template <int WSAS, class WB>
     FXT_HD void store(const FxtWg& wg, WB wbuf) {
 #if FXT_DEVICE
         const int pieces = taps * 256;
@@ -718,9 +746,8 @@ struct FxtTapRegs {
         for (int q = 0; q < FXT_TAP_PF; ++q) {
             const int p = wg.tid + q * wg.nthr;
             if (p < pieces) {
-                const int row = p >> 3, col = 4 * (p & 7), rot = ROT ? 2 * row : 16 * row;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) wbuf[row * 32 + ((col + e + rot) & 31)] = pre[q][e];
+                const int blk = p >> 2, col = blk & 31, kq = p & 3;         // blk = (tap 2 + half) 32 + column
+                *(typename FxtMem<WSAS>::F4)(wbuf + blk * 16 + 4 * ((kq + 2 * ((col >> 3) & 1)) & 3)) = pre[q];
             }
         }
 #else
@@ -762,11 +789,10 @@ FXT_HD void fxt_conv32_staged(const FxtWg& wg, int Md, int Ko, const FA& fa, con
     // register sets of twelve, the loop unrolled by two): an LDS round trip hides behind ~256 cycles of matrix work instead of
     // preceding it.  (Whole taps in flight -- 2 x 24 registers -- spilled at the 128 registers sixteen waves leave a thread.)
     constexpr int UH = U / 2;
-    struct Ops { float a[UH], b0[UH], b1[UH]; };
+    struct Ops { f4_t a, b0, b1; };                        // (one 16-byte LDS read each: fxt_xi<2>, FxtConvW4)
     auto load = [&](Ops& o, int h, int g0) {               // half-tap h of the group: tap g0 + h / 2, k-steps 4 (h & 1) ...
-        const int ko = g0 + (h >> 1), kb = 16 * (h & 1);
-#pragma unroll
-        for (int u = 0; u < UH; ++u) { o.a[u] = fa.at(sa, ko, kb + 4 * u); o.b0[u] = fb.at(sb0, ko - g0, kb + 4 * u); o.b1[u] = fb.at(sb1, ko - g0, kb + 4 * u); }
+        const int ko = g0 + (h >> 1);
+        o.a = fa.at4(sa, ko, h & 1); o.b0 = fb.at4(sb0, ko - g0, h & 1); o.b1 = fb.at4(sb1, ko - g0, h & 1);
     };
     auto mma = [&](const Ops& o) {
 #pragma unroll
@@ -775,18 +801,26 @@ FXT_HD void fxt_conv32_staged(const FxtWg& wg, int Md, int Ko, const FA& fa, con
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[u], o.b1[u], acc1, 0, 0, 0);
         }
     };
-    if (!pre_loaded && !in_wbuf) tap.fetch(wg, wsrc, 0, G < Ko ? G : Ko);
+    if (!pre_loaded && !in_wbuf) tap.template fetch<ROT>(wg, wsrc, 0, G < Ko ? G : Ko);
     for (int g0 = 0; g0 < Ko; g0 += G) {
         const int g1 = g0 + G < Ko ? g0 + G : Ko;
         if (!(in_wbuf && g0 == 0)) {
             fxt_sync_ws<WSAS>();                           // everybody is through with the previous group's taps (or the previous phase)
-            tap.template store<ROT>(wg, wbuf);
+            tap.template store<WSAS>(wg, wbuf);
         }
-        if (g1 < Ko) tap.fetch(wg, wsrc, g1, g1 + G < Ko ? g1 + G : Ko);       // in flight behind this group's MFMAs
-        else if (next_src) tap.fetch(wg, next_src, 0, G < next_Ko ? G : next_Ko);
+        if (g1 < Ko) tap.template fetch<ROT>(wg, wsrc, g1, g1 + G < Ko ? g1 + G : Ko);       // in flight behind this group's MFMAs
+        else if (next_src) tap.template fetch<ROT>(wg, next_src, 0, G < next_Ko ? G : next_Ko);
         fxt_sync_ws<WSAS>();
         dbg(2 * (g0 / G));                                 // (profiling aid: this wave's clock before / after a group's MFMAs)
         if (!have) continue;
+#if FXT_DEVICE && !defined(FXT_EMUL) && FXT_VAR == 3
+        switch (wave >> 2) {                                // experiment: the four waves of a SIMD at distinct issue priorities
+            case 0: __builtin_amdgcn_s_setprio(3); break;
+            case 1: __builtin_amdgcn_s_setprio(2); break;
+            case 2: __builtin_amdgcn_s_setprio(1); break;
+            default: __builtin_amdgcn_s_setprio(0); break;
+        }
+#endif
         Ops x, y;
         const int H = 2 * (g1 - g0);                       // (even)
         load(x, 0, g0);
@@ -802,6 +836,9 @@ FXT_HD void fxt_conv32_staged(const FxtWg& wg, int Md, int Ko, const FA& fa, con
             mma(y);
             FXT_MMA_END();
         }
+#if FXT_DEVICE && !defined(FXT_EMUL) && FXT_VAR == 3
+        __builtin_amdgcn_s_setprio(0);
+#endif
         dbg(2 * (g0 / G) + 1);
     }
     if (have) {
@@ -817,7 +854,7 @@ FXT_HD void fxt_conv32_staged(const FxtWg& wg, int Md, int Ko, const FA& fa, con
     for (int g0 = 0; g0 < Ko; g0 += G) {
         const int g1 = g0 + G < Ko ? g0 + G : Ko;
         for (int row = 0; row < (g1 - g0) * 32; ++row)
-            for (int c = 0; c < 32; ++c) wbuf[row * 32 + ((c + (ROT ? 2 * row : 16 * row)) & 31)] = wsrc[(g0 * 32 + row) * 32 + c];
+            for (int c = 0; c < 32; ++c) wbuf[fxt_w4_off<ROT>(row, c)] = wsrc[(g0 * 32 + row) * 32 + c];
         for (int m = 0; m < Md; ++m)
             for (int n = 0; n < 32; ++n) {
                 float acc = accs[(size_t)m * 32 + n];
@@ -857,17 +894,20 @@ FXT_HD void fxt_wg32_job(int R, int L1, int res, int pl, int c, int o, int kq, i
         // (positions outside the row are read from `zero`, a row of zeros in LDS: no select behind the fetch)
         auto Xraw = [&](int b, bool ok) {
             const int pp = 4 * b + kq + res - pl;
-            return *(ok ? x + fxt_xi<true>(base + pp, c, 32) : zero);
+            return *(ok ? x + fxt_xi<2>(base + pp, c, 32) : zero);
         };
         auto Braw = [&](int s, bool ok) {
             const int t = 4 * s + kq;
-            return *(ok ? dz + fxt_xi<true>(base + t, o, 32) : zero);
+            return *(ok ? dz + fxt_xi<2>(base + t, o, 32) : zero);
         };
         float win[MT];                                     // win[(s + q) % MT] = x block s + q inside the blocks of MT k-steps below
 #pragma unroll
         for (int q = 0; q < MT - 1; ++q) win[q] = Xraw(q, Xok(q));
-        bool xok = Xok(MT - 1), bok = kq < L1;
-        float xr = Xraw(MT - 1, xok), br = Braw(0, bok);
+        // two k-steps of operands in flight: (xr, br) for the step about to run, (xr2, br2) for the one after -- one step ahead covers
+        // an LDS round trip only behind five MFMAs; conv2's jobs issue one or two per k-step (round 5: 345 cycles per k-step there)
+        bool bok = kq < L1, bok2 = 4 + kq < L1;
+        float xr = Xraw(MT - 1, Xok(MT - 1)), br = Braw(0, bok);
+        float xr2 = Xraw(MT, Xok(MT)), br2 = Braw(1, bok2);
         int s = 0;
         if constexpr (NT >= 0) {
             for (; s + MT <= Sfull; s += MT) {             // MT whole k-steps: the window's slots are compile-time constants
@@ -875,9 +915,10 @@ FXT_HD void fxt_wg32_job(int R, int L1, int res, int pl, int c, int o, int kq, i
                 for (int u = 0; u < MT; ++u) {
                     win[(u + MT - 1) % MT] = xr;
                     const float b = br;
-                    {   const int sn = s + u + 1;          // the next k-step's two fetches, behind this one's MFMAs (masked past the row's end)
-                        xok = Xok(sn + MT - 1); bok = 4 * sn + kq < L1;
-                        xr = Xraw(sn + MT - 1, xok); br = Braw(sn, bok); }
+                    xr = xr2; br = br2; bok = bok2;
+                    {   const int sn = s + u + 2;          // the fetches of the k-step after next (masked past the row's end)
+                        bok2 = 4 * sn + kq < L1;
+                        xr2 = Xraw(sn + MT - 1, Xok(sn + MT - 1)); br2 = Braw(sn, bok2); }
                     FXT_SCHED_FENCE();
 #pragma unroll
                     for (int q = 0; q < NT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(win[(u + q) % MT], b, acc[q], 0, 0, 0);
@@ -891,10 +932,9 @@ FXT_HD void fxt_wg32_job(int R, int L1, int res, int pl, int c, int o, int kq, i
             win[MT - 1] = xr;
             const float b = br;
             const bool tok = bok;                          // 4 s + kq < L1: false only in a row's last, partial k-step -- both operands zero there, as fxt_gemm masks them
-            if (s + 1 < S) {
-                xok = Xok(s + MT); bok = 4 * (s + 1) + kq < L1;
-                xr = Xraw(s + MT, xok); br = Braw(s + 1, bok);
-            }
+            xr = xr2; br = br2; bok = bok2;
+            bok2 = 4 * (s + 2) + kq < L1;
+            xr2 = Xraw(s + MT + 1, Xok(s + MT + 1)); br2 = Braw(s + 2, bok2);
 #pragma unroll
             for (int q = 0; q < MT; ++q)
                 if (q < nt) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(tok ? win[q] : 0.f, b, acc[q], 0, 0, 0);
@@ -950,8 +990,8 @@ FXT_HD void fxt_conv32_wgrad(const FxtWg& wg, int R, int L1, int Kt, int pl, P x
             for (int rho = 0; rho < R; ++rho)
                 for (int t = 0; t < L1; ++t) {
                     const int pp = t + j - pl;
-                    const float a = mrow == Kt * 32 ? 1.f : ((pp >= 0 && pp < L1) ? x[fxt_xi<true>(rho * L1 + pp, c, 32)] : 0.f);
-                    acc = fmaf(a, dz[fxt_xi<true>(rho * L1 + t, o, 32)], acc);
+                    const float a = mrow == Kt * 32 ? 1.f : ((pp >= 0 && pp < L1) ? x[fxt_xi<2>(rho * L1 + pp, c, 32)] : 0.f);
+                    acc = fmaf(a, dz[fxt_xi<2>(rho * L1 + t, o, 32)], acc);
                 }
             fc.put(mrow, o, acc);
         }
@@ -1118,30 +1158,46 @@ struct FxtPosMajorBSwz {        // element (row r Lx + k0 + kq, channel n)
     FXT_HD float at(St st, int r, int k0) const { const int ru = r * Lx + k0; return p[st.off + ru * F + ((st.rot + 2 * ru) & (F - 1))]; }
 };
 
-// MODE 3: the same two A operands with positions outside the row sent to a row of zeros in LDS (`zoff`: its index relative to the
+// MODE 3: the conv A operands over FRAGMENT rows (fxt_xi<2>), positions outside the row sent to a row of zeros in LDS (`zoff`: its index relative to the
 // array) instead of a select on the fetched value -- the fetch then has no consumer but its MFMA, so it can be issued a half-tap ahead
 // (a select right behind the fetch made the compiler wait for LDS there), and four instructions per half-tap go away.  0.0 either way.
-template <class P>
-struct FxtConvAZ {
-    P x; int Lx, C, pl, zoff; FxtDiv dL;
-    struct St { int base, tp, rot; };
-    FXT_HD St prep(int m, int kq) const { const int r = fxt_quot(m, dL), t = m - r * Lx; return St{(m - pl) * C, t - pl, kq + 2 * (m - pl)}; }
-    FXT_HD float at(St s, int j, int k0) const {
+template <class P, class P4>
+struct FxtConvAZ {              // conv forward over fragment rows: element (row m - pl + j, channel k0 + kq)
+    P x; int Lx, pl, zoff; FxtDiv dL;
+    struct St { int row, tp, kq; };
+    FXT_HD St prep(int m, int kq) const { const int r = fxt_quot(m, dL), t = m - r * Lx; return St{m - pl, t - pl, kq}; }
+    FXT_HD float at(St s, int j, int k0) const {             // (scalar form: host build)
         const int p = s.tp + j;
+        return (p >= 0 && p < Lx) ? x[fxt_xi<2>(s.row + j, k0 + s.kq, 32)] : 0.f;
+    }
+    FXT_HD auto at4(St s, int j, int h) const {              // channels 16 h + 4 u + kq, u = 0 .. 3: one 16-byte read
+        const int p = s.tp + j, row = s.row + j;
         const bool ok = p >= 0 && p < Lx;
-        return x[ok ? s.base + j * C + ((s.rot + 2 * j + k0) & (C - 1)) : zoff];
+        return *(P4)(x + (ok ? row * 32 + 4 * ((4 * h + s.kq + (row & 6)) & 7) : zoff));
     }
 };
-template <class P>
-struct FxtConvGradAZ {
-    P dz; int Lx, F, pl, zoff; FxtDiv dL;
-    struct St { int base, sp, rot; };
-    FXT_HD St prep(int m, int kq) const { const int r = fxt_quot(m, dL), s = m - r * Lx; return St{(m + pl) * F, s + pl, kq + 2 * (m + pl)}; }
+template <class P, class P4>
+struct FxtConvGradAZ {          // conv input gradient over fragment rows: element (row m + pl - j, channel k0 + kq)
+    P dz; int Lx, pl, zoff; FxtDiv dL;
+    struct St { int row, sp, kq; };
+    FXT_HD St prep(int m, int kq) const { const int r = fxt_quot(m, dL), s = m - r * Lx; return St{m + pl, s + pl, kq}; }
     FXT_HD float at(St st, int j, int k0) const {
         const int p = st.sp - j;
-        const bool ok = p >= 0 && p < Lx;
-        return dz[ok ? st.base - j * F + ((st.rot - 2 * j + k0) & (F - 1)) : zoff];
+        return (p >= 0 && p < Lx) ? dz[fxt_xi<2>(st.row - j, k0 + st.kq, 32)] : 0.f;
     }
+    FXT_HD auto at4(St st, int j, int h) const {
+        const int p = st.sp - j, row = st.row - j;
+        const bool ok = p >= 0 && p < Lx;
+        return *(P4)(dz + (ok ? row * 32 + 4 * ((4 * h + st.kq + (row & 6)) & 7) : zoff));
+    }
+};
+// B((r, t), n) over any layout (conv1's weight gradient reads the fragment rows through the shape-agnostic product)
+template <class P, int LAY>
+struct FxtPosMajorBL {
+    P p; int Lx, F;
+    struct St { int n, kq; };
+    FXT_HD St prep(int n, int kq) const { return St{n, kq}; }
+    FXT_HD float at(St st, int r, int k0) const { return p[fxt_xi<LAY>(r * Lx + k0 + st.kq, st.n, F)]; }
 };
 
 // Compile-time shape of a CANONICAL network (round 4).  The step is written for any shape the constructors accept: every
@@ -1170,6 +1226,8 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
     typedef typename FxtMem<WSAS>::CI WsCI;
     typedef typename FxtMem<WAS>::CF WCF;
     constexpr bool SWZ = MODE != 0;
+    constexpr int LAY = MODE == 3 ? 2 : (MODE != 0 ? 1 : 0);      // how the position-major arrays are indexed (fxt_xi)
+    typedef typename FxtMem<WSAS>::CF4 WsCF4;
     typedef typename FxtPick<SWZ, FxtConvA<WsCF>, FxtConvASwz<WsCF>>::T ConvA;
     typedef typename FxtPick<SWZ, FxtConvGradA<WsCF>, FxtConvGradASwz<WsCF>>::T ConvGradA;
     typedef typename FxtPick<SWZ, FxtConvWGradA<WsCF>, FxtConvWGradASwz<WsCF>>::T ConvWGradA;
@@ -1205,7 +1263,7 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
 
     if constexpr (MODE == 3) {
         if (n.kind == 0) {
-            tap.fetch(wg, W + y.cw[1], 0, G3 < n.K ? G3 : n.K);      // conv2's first tap group: two phases ahead
+            tap.template fetch<0>(wg, W + y.cw[1], 0, G3 < n.K ? G3 : n.K);      // conv2's first tap group: two phases ahead
             FXT_FOR(i, w.ldF, wg) ws[w.zero + i] = 0.f;              // the row of zeros (FxtConvAZ)
         }
     }
@@ -1244,7 +1302,7 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
                     const int o = i % F, rt = i / F, t = rt % L1, r = rt / L1;
                     float s = wbuf[K * A * F + o];
                     for (int jj = 0; jj < K; ++jj) s += wbuf[(jj * A + codes[r * L + t + jj]) * F + o];
-                    a1[fxt_xi<SWZ>(rt, o, ldF)] = s > 0.f ? s : 0.f;
+                    a1[fxt_xi<LAY>(rt, o, ldF)] = s > 0.f ? s : 0.f;
                 }
             }
         }
@@ -1253,16 +1311,16 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
             const int o = i % F, rt = i / F, t = rt % L1, r = rt / L1;
             float s = W[y.cb[0] + o];
             for (int jj = 0; jj < K; ++jj) s += W[y.cw[0] + (jj * A + codes[r * L + t + jj]) * ldw + o];
-            a1[fxt_xi<SWZ>(rt, o, ldF)] = s > 0.f ? s : 0.f;
+            a1[fxt_xi<LAY>(rt, o, ldF)] = s > 0.f ? s : 0.f;
         }
         fxt_sync_ws<WSAS>(); FXT_STAMP(2);
         {   // conv2 ('same', K taps)
             WCF b = W + y.cb[1];
-            struct Put { WsF y; WCF b; int ld; FXT_HD void put(int m, int nn, float v) const { v += b[nn]; y[fxt_xi<SWZ>(m, nn, ld)] = v > 0.f ? v : 0.f; } };
+            struct Put { WsF y; WCF b; int ld; FXT_HD void put(int m, int nn, float v) const { v += b[nn]; y[fxt_xi<LAY>(m, nn, ld)] = v > 0.f ? v : 0.f; } };
             struct Put3 { WsF y; WCF b; int ld; FXT_HD float pre(int nn) const { return b[nn]; }
-                          FXT_HD void put(int m, int nn, float v, float bias) const { v += bias; y[fxt_xi<SWZ>(m, nn, ld)] = v > 0.f ? v : 0.f; } };
+                          FXT_HD void put(int m, int nn, float v, float bias) const { v += bias; y[fxt_xi<LAY>(m, nn, ld)] = v > 0.f ? v : 0.f; } };
             if constexpr (MODE == 3)
-                fxt_conv32_staged<WSAS, WAS, 0>(wg, R * L1, K, FxtConvAZ<WsCF>{a1, L1, ldF, (K - 1) / 2, w.zero - w.a[0], dL1}, FxtConvW32<WsCF>{wbuf}, Put3{a2, b, ldF}, W + y.cw[1], wbuf, G3, tap, true, false, W + y.cw[2], n.K3);
+                fxt_conv32_staged<WSAS, WAS, 0>(wg, R * L1, K, FxtConvAZ<WsCF, WsCF4>{a1, L1, (K - 1) / 2, w.zero - w.a[0], dL1}, FxtConvW4<WsCF, WsCF4>{wbuf}, Put3{a2, b, ldF}, W + y.cw[1], wbuf, G3, tap, true, false, W + y.cw[2], n.K3);
             else if constexpr (MODE == 2)
                 fxt_gemm_staged<WSAS, WAS>(wg, R * L1, F, K, F, ConvA{a1, L1, ldF, (K - 1) / 2, dL1}, FxtConvW<WsCF>{wbuf, F, fxt_ld_w(F)}, Put{a2, b, ldF},
                                       W + y.cw[1], wbuf, stage_taps, F, F, fxt_ld_w(F));
@@ -1272,11 +1330,11 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         fxt_sync_ws<WSAS>(); FXT_STAMP(3);
         {   // conv3 ('same', A - 1 taps)
             WCF b = W + y.cb[2];
-            struct Put { WsF y; WCF b; int ld; FXT_HD void put(int m, int nn, float v) const { v += b[nn]; y[fxt_xi<SWZ>(m, nn, ld)] = v > 0.f ? v : 0.f; } };
+            struct Put { WsF y; WCF b; int ld; FXT_HD void put(int m, int nn, float v) const { v += b[nn]; y[fxt_xi<LAY>(m, nn, ld)] = v > 0.f ? v : 0.f; } };
             struct Put3 { WsF y; WCF b; int ld; FXT_HD float pre(int nn) const { return b[nn]; }
-                          FXT_HD void put(int m, int nn, float v, float bias) const { v += bias; y[fxt_xi<SWZ>(m, nn, ld)] = v > 0.f ? v : 0.f; } };
+                          FXT_HD void put(int m, int nn, float v, float bias) const { v += bias; y[fxt_xi<LAY>(m, nn, ld)] = v > 0.f ? v : 0.f; } };
             if constexpr (MODE == 3)
-                fxt_conv32_staged<WSAS, WAS, 0>(wg, R * L1, n.K3, FxtConvAZ<WsCF>{a2, L1, ldF, (n.K3 - 1) / 2, w.zero - w.a[1], dL1}, FxtConvW32<WsCF>{wbuf}, Put3{a3, b, ldF}, W + y.cw[2], wbuf, G3, tap, true, false, (WCF) nullptr, 0,
+                fxt_conv32_staged<WSAS, WAS, 0>(wg, R * L1, n.K3, FxtConvAZ<WsCF, WsCF4>{a2, L1, (n.K3 - 1) / 2, w.zero - w.a[1], dL1}, FxtConvW4<WsCF, WsCF4>{wbuf}, Put3{a3, b, ldF}, W + y.cw[2], wbuf, G3, tap, true, false, (WCF) nullptr, 0,
                                                 [&](int k) {           // profiling aid (train_trace): group 0 of conv3's forward -- every wave's clock at the end of its MFMAs (44 + wave); wave 0's at the group's start (60) and at the next group's (61)
 #if FXT_DEVICE
                                                     if (j.dbg && slice == 0 && (wg.tid & 63) == 0) {
@@ -1308,7 +1366,7 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
                 FXT_FOR(i, R * F * PARTS, wg) {
                     const int part = i % PARTS, rf = i / PARTS, r = rf / F, f = rf - r * F;
                     float mx = -INFINITY;
-                    for (int t = part; t < L1; t += PARTS) { const float v = a3[fxt_xi<SWZ>(r * L1 + t, f, ldF)]; mx = v > mx ? v : mx; }
+                    for (int t = part; t < L1; t += PARTS) { const float v = a3[fxt_xi<LAY>(r * L1 + t, f, ldF)]; mx = v > mx ? v : mx; }
                     pmax[i] = mx;
                 }
                 fxt_sync_ws<WSAS>();
@@ -1316,10 +1374,10 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
                     const int part = i % PARTS, rf = i / PARTS, r = rf / F, f = rf - r * F;
                     float mx = pmax[rf * PARTS];
                     for (int q = 1; q < PARTS; ++q) { const float v = pmax[rf * PARTS + q]; mx = v > mx ? v : mx; }
-                    const float first = a3[fxt_xi<SWZ>(r * L1, f, ldF)];
+                    const float first = a3[fxt_xi<LAY>(r * L1, f, ldF)];
                     if (first != first) mx = first;
                     int c = 0;
-                    for (int t = part; t < L1; t += PARTS) c += a3[fxt_xi<SWZ>(r * L1 + t, f, ldF)] == mx;
+                    for (int t = part; t < L1; t += PARTS) c += a3[fxt_xi<LAY>(r * L1 + t, f, ldF)] == mx;
                     pcnt[i] = (float)c;
                     if (part == 0) g[r * ldF + f] = mx;
                 }
@@ -1335,10 +1393,10 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         if (!pooled)
         FXT_FOR(i, R * F, wg) {             // GlobalMaxPooling1D + the number of positions that attain the maximum
             const int r = i / F, f = i - r * F;
-            float mx = a3[fxt_xi<SWZ>(r * L1, f, ldF)];
-            for (int t = 1; t < L1; ++t) { const float v = a3[fxt_xi<SWZ>(r * L1 + t, f, ldF)]; mx = v > mx ? v : mx; }
+            float mx = a3[fxt_xi<LAY>(r * L1, f, ldF)];
+            for (int t = 1; t < L1; ++t) { const float v = a3[fxt_xi<LAY>(r * L1 + t, f, ldF)]; mx = v > mx ? v : mx; }
             int c = 0;
-            for (int t = 0; t < L1; ++t) c += a3[fxt_xi<SWZ>(r * L1 + t, f, ldF)] == mx;
+            for (int t = 0; t < L1; ++t) c += a3[fxt_xi<LAY>(r * L1 + t, f, ldF)] == mx;
             g[r * ldF + f] = mx; cnt[r * ldF + f] = (float)c;
         }
         fxt_sync_ws<WSAS>(); FXT_STAMP(5);
@@ -1454,11 +1512,11 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         WsCF a1 = ws + w.a[0]; WsCF a2 = ws + w.a[1]; WsCF a3 = ws + w.a[2];
         WsCF g = ws + w.g; WsCF cnt = ws + w.cnt; WsCF dg = ws + w.dg;
         WsF dzA = ws + w.dzA; WsF dzB = ws + w.dzB;
-        if constexpr (MODE == 3) tap.fetch(wg, W + y.cw[2], 0, G3 < K3 ? G3 : K3);     // conv3's first group for the input gradient, behind this phase
+        if constexpr (MODE == 3) tap.template fetch<1>(wg, W + y.cw[2], 0, G3 < K3 ? G3 : K3);     // conv3's first group for the input gradient, behind this phase
         FXT_FOR(i, R * L1 * F, wg) {        // max-pool backward (ties share evenly) through conv3's ReLU
             const int f = i % F, rt = i / F, r = rt / L1;
-            const float v = a3[fxt_xi<SWZ>(rt, f, ldF)];
-            dzA[fxt_xi<SWZ>(rt, f, ldF)] = (v > 0.f && v == g[r * ldF + f]) ? dg[r * ldF + f] / cnt[r * ldF + f] : 0.f;
+            const float v = a3[fxt_xi<LAY>(rt, f, ldF)];
+            dzA[fxt_xi<LAY>(rt, f, ldF)] = (v > 0.f && v == g[r * ldF + f]) ? dg[r * ldF + f] / cnt[r * ldF + f] : 0.f;
         }
         fxt_sync_ws<WSAS>(); FXT_STAMP(9);
         struct PutW {
@@ -1472,12 +1530,12 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
             }
         };
         const bool ag = j.agent_io != 0;
-        struct PutX { WsF d; WsCF y; int ld; FXT_HD void put(int m, int nn, float v) const { d[fxt_xi<SWZ>(m, nn, ld)] = y[fxt_xi<SWZ>(m, nn, ld)] > 0.f ? v : 0.f; } };
+        struct PutX { WsF d; WsCF y; int ld; FXT_HD void put(int m, int nn, float v) const { d[fxt_xi<LAY>(m, nn, ld)] = y[fxt_xi<LAY>(m, nn, ld)] > 0.f ? v : 0.f; } };
         struct PutX3 { WsF d; WsCF y; int ld; FXT_HD int pre(int) const { return 0; }
-                       FXT_HD void put(int m, int nn, float v, int) const { d[fxt_xi<SWZ>(m, nn, ld)] = y[fxt_xi<SWZ>(m, nn, ld)] > 0.f ? v : 0.f; } };
+                       FXT_HD void put(int m, int nn, float v, int) const { d[fxt_xi<LAY>(m, nn, ld)] = y[fxt_xi<LAY>(m, nn, ld)] > 0.f ? v : 0.f; } };
         // conv3: input gradient (few tiles, K3 x F / 4 k-steps) first, the weight gradient dealt on behind it
         if constexpr (MODE == 3)
-            fxt_conv32_staged<WSAS, WAS, 1>(wg, R * L1, K3, FxtConvGradAZ<WsCF>{dzA, L1, ldF, (K3 - 1) / 2, w.zero - w.dzA, dL1}, FxtConvGradW32<WsCF>{wbuf}, PutX3{dzB, a2, ldF}, W + y.cw[2], wbuf, G3, tap, true, false,
+            fxt_conv32_staged<WSAS, WAS, 1>(wg, R * L1, K3, FxtConvGradAZ<WsCF, WsCF4>{dzA, L1, (K3 - 1) / 2, w.zero - w.dzA, dL1}, FxtConvW4<WsCF, WsCF4>{wbuf}, PutX3{dzB, a2, ldF}, W + y.cw[2], wbuf, G3, tap, true, false,
                                             W + y.cw[1], K);          // (leaves conv2's first group in `tap`: fetched BEFORE this phase's partial stores)
         else if constexpr (MODE == 2)
             fxt_gemm_staged<WSAS, WAS>(wg, R * L1, F, K3, F, ConvGradA{dzA, L1, ldF, (K3 - 1) / 2, dL1}, FxtConvGradW<WsCF>{wbuf, F, fxt_ld_w(F)}, PutX{dzB, a2, ldF},
@@ -1488,7 +1546,7 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         {   FXT_STAMP(40);
             // the hook: conv2's group goes into the staging buffer (every wave is through with conv3's last group behind the barrier)
             // before this phase's 78 KiB of partial stores are issued; conv2's input gradient then starts without touching global memory
-            auto commit = [&]() { fxt_sync_ws<WSAS>(); tap.template store<1>(wg, wbuf); FXT_STAMP(41); };
+            auto commit = [&]() { fxt_sync_ws<WSAS>(); tap.template store<WSAS>(wg, wbuf); FXT_STAMP(41); };
             fxt_conv32_wgrad<D::fixed ? D::A - 1 : 0>(wg, R, L1, K3, (K3 - 1) / 2, a2, (WsCF)dzA, (WsCF)(ws + w.zero), PutW{part + n.off_cw[2], part + n.off_cb[2], K3 * F, F, ag}, commit);
         }
         else
@@ -1496,7 +1554,7 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         fxt_sync_ws<WSAS>(); FXT_STAMP(10);
         // conv2
         if constexpr (MODE == 3)
-            fxt_conv32_staged<WSAS, WAS, 1>(wg, R * L1, K, FxtConvGradAZ<WsCF>{dzB, L1, ldF, (K - 1) / 2, w.zero - w.dzB, dL1}, FxtConvGradW32<WsCF>{wbuf}, PutX3{dzA, a1, ldF}, W + y.cw[1], wbuf, G3, tap, false, true);
+            fxt_conv32_staged<WSAS, WAS, 1>(wg, R * L1, K, FxtConvGradAZ<WsCF, WsCF4>{dzB, L1, (K - 1) / 2, w.zero - w.dzB, dL1}, FxtConvW4<WsCF, WsCF4>{wbuf}, PutX3{dzA, a1, ldF}, W + y.cw[1], wbuf, G3, tap, false, true);
         else if constexpr (MODE == 2)
             fxt_gemm_staged<WSAS, WAS>(wg, R * L1, F, K, F, ConvGradA{dzB, L1, ldF, (K - 1) / 2, dL1}, FxtConvGradW<WsCF>{wbuf, F, fxt_ld_w(F)}, PutX{dzA, a1, ldF},
                                   W + y.cw[1], wbuf, stage_taps, F, F, fxt_ld_w(F));
@@ -1511,6 +1569,9 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         fxt_gemm(wg, K * F + 1, F, R, L1, ConvWGradA{a1, L1, F, ldF, (K - 1) / 2, K * F, dF}, PosMajorB{dzB, L1, ldF}, PutW{part + n.off_cw[1], part + n.off_cb[1], K * F, F, ag}, fxt_jobs(R * L1, F, K, F, nwv, can_split));
         fxt_sync_ws<WSAS>(); FXT_STAMP(11);
         // conv1 (one-hot input, 'valid')
+        if constexpr (MODE == 3)
+            fxt_gemm(wg, K * A + 1, F, R, L1, FxtOneHotWGradA<WsCI>{codes, L, A, K * A, 1, dA}, FxtPosMajorBL<WsCF, 2>{dzA, L1, ldF}, PutW{part + n.off_cw[0], part + n.off_cb[0], K * A, F, ag});
+        else
         fxt_gemm(wg, K * A + 1, F, R, L1, FxtOneHotWGradA<WsCI>{codes, L, A, K * A, 1, dA}, PosMajorB{dzA, L1, ldF}, PutW{part + n.off_cw[0], part + n.off_cb[0], K * A, F, ag});
     }
     FXT_STAMP(63);
