@@ -278,22 +278,6 @@ __device__ __forceinline__ void fxt_load8_agent(const float* p, long long stride
 #else
 #define FXT_SCHED_FENCE() ((void)0)
 #endif
-// experiment knob (round 5): how a block of MFMAs is delimited.  FXT_VAR 0: nothing; 1: fences (the block's MFMAs contiguous, no address
-// arithmetic among them); 2: fences + raised wave priority inside the block
-#ifndef FXT_VAR
-#define FXT_VAR 0
-#endif
-#if FXT_DEVICE && !defined(FXT_EMUL) && FXT_VAR == 1
-#define FXT_MMA_BEGIN() __builtin_amdgcn_sched_barrier(0)
-#define FXT_MMA_END() __builtin_amdgcn_sched_barrier(0)
-#elif FXT_DEVICE && !defined(FXT_EMUL) && FXT_VAR == 2
-#define FXT_MMA_BEGIN() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1); } while (0)
-#define FXT_MMA_END() do { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define FXT_MMA_BEGIN() ((void)0)
-#define FXT_MMA_END() ((void)0)
-#endif
-
 // q = x / d for 0 <= x < 2^16, 1 <= d < 2^16 without a hardware divide (an integer division is ~40 instructions on
 // the GPU and the GEMM tiles decompose their row index once each): q = (x * ceil(2^32 / d)) >> 32, exact in that range.
 struct FxtDiv { unsigned d, magic; };
@@ -813,32 +797,17 @@ FXT_HD void fxt_conv32_staged(const FxtWg& wg, int Md, int Ko, const FA& fa, con
         fxt_sync_ws<WSAS>();
         dbg(2 * (g0 / G));                                 // (profiling aid: this wave's clock before / after a group's MFMAs)
         if (!have) continue;
-#if FXT_DEVICE && !defined(FXT_EMUL) && FXT_VAR == 3
-        switch (wave >> 2) {                                // experiment: the four waves of a SIMD at distinct issue priorities
-            case 0: __builtin_amdgcn_s_setprio(3); break;
-            case 1: __builtin_amdgcn_s_setprio(2); break;
-            case 2: __builtin_amdgcn_s_setprio(1); break;
-            default: __builtin_amdgcn_s_setprio(0); break;
-        }
-#endif
         Ops x, y;
         const int H = 2 * (g1 - g0);                       // (even)
         load(x, 0, g0);
         for (int h = 0; h < H; h += 2) {
             load(y, h + 1, g0);
             FXT_SCHED_FENCE();                             // (the fetches stay IN FRONT of the MFMAs they hide behind: left alone, the scheduler sinks each one to just before its use)
-            FXT_MMA_BEGIN();
             mma(x);
-            FXT_MMA_END();
             load(x, h + 2 < H ? h + 2 : h, g0);            // (past the group's end: the same half-tap again, unused -- a straight-line body lets the waits be counted exactly)
             FXT_SCHED_FENCE();
-            FXT_MMA_BEGIN();
             mma(y);
-            FXT_MMA_END();
         }
-#if FXT_DEVICE && !defined(FXT_EMUL) && FXT_VAR == 3
-        __builtin_amdgcn_s_setprio(0);
-#endif
         dbg(2 * (g0 / G) + 1);
     }
     if (have) {
