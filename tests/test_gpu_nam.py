@@ -20,7 +20,9 @@ pytestmark = pytest.mark.gpu
 # ------------------------------------------------------------------ NoisyAbstractModel
 @pytest.mark.parametrize("L,nsym,C,Q", [(8, 4, 300, 200), (14, 4, 2500, 150), (66, 20, 700, 60), (90, 20, 1500, 40), (300, 20, 300, 12),
                                         (513, 20, 200, 8), (735, 20, 150, 6), (769, 20, 1100, 5), (1000, 4, 300, 7), (1600, 20, 40, 3),
-                                        (238, 20, 300, 20), (64, 4, 200, 50), (65, 4, 200, 50), (1, 4, 10, 10)])
+                                        (238, 20, 300, 20), (64, 4, 200, 50), (65, 4, 200, 50), (1, 4, 10, 10),
+                                        # small caches, several queries per block (k_min_dist_small: C <= 128, L <= 32, Q >= 64)
+                                        (14, 4, 100, 2000), (8, 4, 17, 300), (32, 20, 128, 100), (14, 4, 1, 64), (31, 4, 127, 65), (5, 4, 16, 513)])
 def test_min_dist_vs_oracle(eng, L, nsym, C, Q):
     rng = np.random.default_rng(L * 7 + C)
     base = rng.integers(65, 65 + nsym, (1, L)).astype(np.uint8)
@@ -67,7 +69,8 @@ def _ragged_strings(rng, n, lo, hi, alpha, base=None):
 
 
 @pytest.mark.parametrize("lo,hi,alpha,C,Q", [(0, 12, "TGCA", 400, 120), (50, 80, s_utils.AAS, 300, 40),
-                                             (120, 200, s_utils.AAS, 150, 20), (1, 256, "UGCA", 60, 12)])
+                                             (120, 200, s_utils.AAS, 150, 20), (1, 256, "UGCA", 60, 12),
+                                             (0, 12, "TGCA", 90, 130), (3, 30, s_utils.AAS, 120, 70)])      # small caches: k_min_dist_small over NUL-padded rows
 def test_min_dist_ragged_lengths(eng, lo, hi, alpha, C, Q):
     """`editdistance.eval` takes two strings of any lengths (noisy_abstract_model.py:51): NUL-padded rows."""
     rng = np.random.default_rng(lo * 31 + hi)
