@@ -106,7 +106,7 @@ struct FxMailIn {                                      // device memory (fine-gr
 };
 static_assert(offsetof(FxMailIn, stop) == 64 && offsetof(FxMailIn, bytes) == 128, "server_start clears the first 128 bytes");
 static_assert(offsetof(FxMailIn, tiny) == 8 && offsetof(FxMailIn, req_tail) == 56, "the request line: word, 48 bytes, word");
-// Mailbox of a PRE-LAUNCHED instance of the layer-parallel protein form (round 4; score_cnn_pair.hip, fx_api.hip "armed"): fine-grained
+// Mailbox of a PRE-LAUNCHED instance of the layer-parallel protein form (round 4; score_cnn_pair.hip, fx_resident.hip "armed"): fine-grained
 // device memory the host stores into through the BAR.  The instance has its weights in LDS and waits for ITS request word --
 // sixteen copies, a line each: block b polls copy b & 15 -- then reads the request's sequences from `bytes`.
 // request word of instance s for N sequences: (s << 16) | N; (s << 16) | 0xFFFF tells instance s to leave (words of other instances are ignored)
@@ -197,7 +197,7 @@ struct fx_engine {
     unsigned done_seq = 0;
     unsigned done_value = 0;         // last value handed to hipStreamWriteValue32 (h_done[8]): launches without a kernel-side flag
     bool done_armed = false;
-    // Pre-launched instance of the layer-parallel form (fx_api.hip lp_arm / lp_try_armed): after an explorer-size call of a protein
+    // Pre-launched instance of the layer-parallel form (fx_resident.hip lp_arm / lp_serve_armed): after an explorer-size call of a protein
     // CNN ensemble was answered by k_score_cnn_lp, the NEXT instance is enqueued at once -- it fills its weights and waits for
     // its request word in lp_mail -- so a caller that comes back with the same shape within serve_idle_us pays neither the launch
     // latency nor the weight fill.
@@ -406,7 +406,7 @@ inline void fx_server_stop(fx_engine* e) {
     fx_bar_fence();
     sv.running = false;
 }
-void fx_lp_disarm(fx_engine* e);      // a pre-launched instance of the layer-parallel form leaves (fx_api.hip)
+void fx_lp_disarm(fx_engine* e);      // a pre-launched instance of the layer-parallel form leaves (fx_resident.hip)
 int fx_launch_score_cnn_quad_server(fx_engine* e, fx_model* const* models, int M, int m_off, int tiles, hipStream_t stream,
                                     FxMailIn* d_in, FxMailOut* d_out, unsigned long long idle_ticks, unsigned long long life_ticks,
                                     int want_quads, int* quads_out);

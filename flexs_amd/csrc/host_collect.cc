@@ -1,4 +1,4 @@
-// Host side of the resident form: the fast path of the answer collection (fx_api.hip server_call).  Plain C++, no GPU code --
+// Host side of the resident form: the fast path of the answer collection (fx_resident.hip server_call).  Plain C++, no GPU code --
 // kept out of the HIP translation units because it uses x86 vector intrinsics.
 //
 // An answer is one 8-byte word in pinned host memory, written by the device in one store: bits 0-31 the score (float32),
