@@ -198,30 +198,37 @@ int main(int argc, char** argv) {
         std::vector<float> part_ref, part;
         const std::vector<float> want = simt_ref_step(p, &part_ref);
         // the device branches as they are (plain rows): the emulator's own check -- fxt_gemm's device side has run on MI355X
-        std::vector<float> got = emul_step(p, 0, c.nthr, 0, &part);
-        bad += same("gradient partials", part_ref, part, p, 0, c.nthr, 0);
-        bad += same("weights", want, got, p, 0, c.nthr, 0);
+        std::vector<float> got;
+        const bool only_c32 = quick && c.nthr == 1024 && c.kind == 0 && c.F == 32;     // (sanitizer builds: the sixteen-wave case runs the default form only)
+        if (!only_c32) {
+            got = emul_step(p, 0, c.nthr, 0, &part);
+            bad += same("gradient partials", part_ref, part, p, 0, c.nthr, 0);
+            bad += same("weights", want, got, p, 0, c.nthr, 0);
+        }
         if (c.kind != 0 || (c.F & (c.F - 1))) continue;
-        got = emul_step(p, 1, c.nthr, 0, &part);               // rotated rows
-        bad += same("gradient partials", part_ref, part, p, 1, c.nthr, 0);
-        bad += same("weights", want, got, p, 1, c.nthr, 0);
+        if (!only_c32) {
+            got = emul_step(p, 1, c.nthr, 0, &part);           // rotated rows
+            bad += same("gradient partials", part_ref, part, p, 1, c.nthr, 0);
+            bad += same("weights", want, got, p, 1, c.nthr, 0);
+        }
         const int L1 = c.L - c.K + 1;
         if (c.F == 32 && fxt_conv32_ok(c.R * L1, c.F, c.nthr / 64)) {
-            for (int taps : {1, 3, 8}) {                       // the F = 32 form: paired tiles over rotated kernel rows, sliding-window weight gradient
-                if (quick && taps == 3) continue;
+            for (int taps : {1, 3, 8}) {                       // the F = 32 form: paired tiles over fragment rows, sliding-window weight gradient
+                if (quick && taps != 8) continue;              // (the sanitizer builds: one group size; every group size in the full run)
+                if (quick && c.nthr == 1024 && (c.A != 20 || c.H != 100)) continue;
                 got = emul_step(p, 3, c.nthr, taps, &part);
                 bad += same("gradient partials", part_ref, part, p, 3, c.nthr, taps);
                 bad += same("weights", want, got, p, 3, c.nthr, taps);
-                if (c.A == 20 && c.H == 100 && c.K == 5 && c.R == 1 && taps != 1) {      // k_train_fb_c32p's instantiation: compile-time tap counts, the window renamed in blocks of five k-steps
+                if (c.A == 20 && c.H == 100 && c.K == 5 && c.R == 1 && taps != 1 && !(quick && c.nthr == 1024)) {      // k_train_fb_c32p's instantiation: compile-time tap counts, the window renamed in blocks of five k-steps
                     got = emul_step(p, 4, c.nthr, taps, &part);
                     bad += same("gradient partials", part_ref, part, p, 4, c.nthr, taps);
                     bad += same("weights", want, got, p, 4, c.nthr, taps);
                 }
             }
         }
-        if ((c.F & 31) || !fxt_staged_ok(c.R * L1, c.F, c.F, c.F, c.nthr / 64)) continue;
+        if ((c.F & 31) || !fxt_staged_ok(c.R * L1, c.F, c.F, c.F, c.nthr / 64) || only_c32) continue;
         for (int taps : {1, 2, 6}) {                           // + staged conv kernels, `taps` taps per group
-            if (quick && taps == 1) continue;
+            if (quick && taps != 2) continue;
             got = emul_step(p, 2, c.nthr, taps, &part);
             bad += same("gradient partials", part_ref, part, p, 2, c.nthr, taps);
             bad += same("weights", want, got, p, 2, c.nthr, taps);
