@@ -159,13 +159,14 @@ const char *fx_last_error(fx_engine *e);
  *   train_canon       1        fx_train_fit: canonical shapes run the step instantiated with compile-time dimensions
  *                              (k_train_fb 47.8 -> 29.8 us with the padded LDS rows, same bits); 0 = the shape-agnostic
  *                              code for everything.
- *   train_swizzle     0        fx_train_fit: 1 = CNN fits whose padded workspace misses the LDS budget while the unpadded one
- *                              fits (32 filters, kernel 5, one row per slice: 226 ... 239 positions -- GFP) store their
- *                              position-major arrays with ROTATED rows (csrc/train_core.h) instead of unpadded, 16-way
- *                              bank-conflicted ones; 2 = also the gradient array over the last conv output and the conv
- *                              kernels staged through the LDS that frees, a group of taps at a time (no L2 round trip per
- *                              B operand).  Same bits (held on the CPU through the host build of the source); prepared
- *                              at the end of round 4 and not yet run on the device: off.
+ *   train_swizzle     3        fx_train_fit, CNNs whose weights do not fit LDS (the 20-letter alphabets).  3 = any CNN with 32
+ *                              filters and at most 16 M tiles per slice (one row per slice up to 260 residues) runs the F = 32
+ *                              form: fragment-order rows and staged kernels (every MFMA operand one ds_read_b128), paired
+ *                              output tiles, tap groups carried in registers across phases, sliding-window weight gradient,
+ *                              a canonical instantiation for CNN(32, 100, kernel 5) on 20 letters (3 x CNN at 237 residues on
+ *                              500 sequences: 43.9 -> 17.9 ms).  2 / 1 = round 4's forms for 226 ... 239 positions (staged
+ *                              conv kernels over rotated rows / rotated rows only: 31.6 / 42.1 ms), 0 = the plain step.  Same
+ *                              bits in every form (GPU tests), each held to the float64 restatement at 90 ... 300 residues.
  *   train_persistent  0        fx_train_fit: 1 = the whole fit as ONE launch (member barriers in device memory, Adam by the
  *                              same workgroups; needs all workgroups co-resident).  Same bits, no faster: off.
  *   train_rows        0        fx_train_fit: mini-batch rows per forward+backward workgroup; 0 = automatic (depends on
