@@ -112,12 +112,14 @@ class NoisyAbstractModel(flexs_amd.Model):
         self._dev_cache = None            # NativeCache mirroring list(self.cache) in insertion order
         self._dev_keys = []               # python-side mirror of what was appended
         self._dev_token = None            # (id of the dict, its removal count) the device copy was built for
+        self._pending = []                # keys THIS model put into `cache` since the last sync, in insertion order (see _note_new_keys)
 
     def __getstate__(self):
         state = self.__dict__.copy()           # copy / pickle: the device key store is rebuilt from `cache` on first use
         state["_dev_cache"] = None
         state["_dev_keys"] = []
         state["_dev_token"] = None
+        state["_pending"] = []
         return state
 
     # ---------------------------------------------------------------- device cache sync
@@ -147,7 +149,14 @@ class NoisyAbstractModel(flexs_amd.Model):
             token = None
             stale = stale or any(str(a) != b for a, b in zip(keys, self._dev_keys))
         self._dev_token = token
-        fresh = [str(k) for k in itertools.islice(keys, 0 if stale else n, None)]
+        pending, self._pending = getattr(self, "_pending", []), []
+        if not stale and token is not None and len(keys) == n + len(pending):
+            # every key beyond the mirrored prefix was put there by this model (train / _fitness_function note what they add, in
+            # order): no walk over the dict.  Skipping the first n keys of a dict is O(n) -- 12 us of a 49-us one-sequence call at
+            # 10 000 cached sequences, growing with the cache (round 5, tools/runs/r5_nam_py_profile.py)
+            fresh = pending
+        else:
+            fresh = [str(k) for k in itertools.islice(keys, 0 if stale else n, None)]
         need = max([min_row, 1] + [len(k) for k in fresh])
         if not stale and need > self._dev_cache.L:          # a longer sequence than any before: wider rows
             stale, fresh = True, [str(k) for k in keys]
@@ -234,7 +243,22 @@ class NoisyAbstractModel(flexs_amd.Model):
         return fit
 
     # ---------------------------------------------------------------- flexs.Model API
+    def _note_new_keys(self, keys):
+        """Call BEFORE `cache.update(zip(keys, ...))`: remembers, in order, the keys that update will append (first occurrences
+        of keys not yet cached).  A cache somebody else also writes to is noticed by its length and walked as before."""
+        cache = self.cache
+        if len(self._dev_keys) + len(self._pending) != len(cache):
+            self._pending = []                                         # (out of step already: the next sync walks the dict)
+            return
+        seen = set()
+        for k in keys:
+            k = k if type(k) is str else str(k)
+            if k not in cache and k not in seen:
+                seen.add(k)
+                self._pending.append(k)
+
     def train(self, sequences: SEQUENCES_TYPE, labels: np.ndarray):
+        self._note_new_keys(sequences)
         self.cache.update(zip(sequences, labels))                      # :62-67
 
     def _fitness_function(self, sequences):
@@ -258,6 +282,7 @@ class NoisyAbstractModel(flexs_amd.Model):
             new_fit = self._fused_table_batch(new_seqs)
             if new_fit is not None:
                 fitnesses[new_idx] = new_fit
+                self._note_new_keys(new_seqs)
                 cache.update(zip(new_seqs, new_fit))                   # :99
                 return fitnesses
             if len(cache) == 0:                                        # :44-45
@@ -294,5 +319,6 @@ class NoisyAbstractModel(flexs_amd.Model):
             alpha_tab = np.array([self.ss ** d for d in range(max_d + 1)], np.float64)   # :93, Python float pow
             new_fit = self._blend(signal, noise, dist, alpha_tab)
             fitnesses[new_idx] = new_fit
+            self._note_new_keys(new_seqs)
             cache.update(zip(new_seqs, new_fit))                       # :99
         return fitnesses

@@ -979,3 +979,59 @@ def test_bench_compact_record_carries_every_config():
     assert set(path["nam_cbas_seq_per_s"]) == {"plain_landscape", "batch_safe_landscape", "device_table_landscape_L8"}
     # the contract keys are untouched
     assert out["metric"] == line["metric"] and "workload" in out["config"]
+
+
+def test_nam_device_mirror_follows_the_cache_without_walking_it():
+    """`NoisyAbstractModel._sync_device_cache` (round 5): the keys the model itself adds are noted as they are added, so bringing the
+    device mirror up to date no longer skips the first n keys of the dict (O(cache) per call).  The mirror must still equal
+    `list(cache)` whatever happens to the dict: the model's own inserts (duplicates inside a batch, keys it already has), a key put in
+    by somebody else, deletions, a replaced dict, a pickle round trip."""
+    import pickle
+
+    from flexs_amd.baselines.models import noisy_abstract_model as nm
+
+    class FakeCache:                       # what _new_device_cache hands out: records the rows appended (no GPU here)
+        def __init__(self, L):
+            self.L, self.rows = L, []
+
+        def append(self, rows):
+            self.rows.extend(bytes(r).rstrip(b"\x00").decode() for r in rows)
+
+    class Land(flexs_amd.Landscape):
+        def __init__(self):
+            super().__init__("land")
+
+        def _fitness_function(self, seqs):
+            return np.array([len(s) / 10.0 for s in seqs])
+
+    class M(nm.NoisyAbstractModel):
+        def _new_device_cache(self, row_bytes):
+            return FakeCache(row_bytes)
+
+        def _rows(self, seqs, L):
+            return [s.encode().ljust(L, b"\x00") for s in seqs]
+
+    m = M(Land(), 0.9)
+
+    def synced():
+        m._sync_device_cache(1)
+        assert m._dev_keys == [str(k) for k in m.cache] == m._dev_cache.rows, (m._dev_keys, list(m.cache))
+
+    m.train(["AAA", "CCC", "AAA", "GGG"], np.array([1.0, 2.0, 3.0, 4.0]))
+    assert m._pending == ["AAA", "CCC", "GGG"]
+    synced()
+    m.train(np.array(["TTT", "CCC", "ACG"]), np.array([5.0, 6.0, 7.0]))      # np.str_ keys, one of them known
+    assert m._pending == ["TTT", "ACG"]
+    synced()
+    m._note_new_keys(["GGA", "GGA", "AAA"]); m.cache.update(zip(["GGA", "GGA", "AAA"], [1.0, 2.0, 3.0]))
+    assert m._pending == ["GGA"]
+    m.cache["CAT"] = 0.5                   # somebody else writes to the public dict: the note is out of step, the walk takes over
+    synced()
+    m._note_new_keys(["TAG"]); m.cache.update({"TAG": 0.1})
+    del m.cache["CCC"]                     # a removal anywhere: rebuild
+    synced()
+    m.cache = dict(m.cache); m.cache["NEW"] = 1.0      # a plain dict instead of the counting one
+    m._note_new_keys(["XYZ"]); m.cache["XYZ"] = 2.0
+    synced()
+    m2 = pickle.loads(pickle.dumps(m))
+    assert m2._pending == [] and m2._dev_keys == []
