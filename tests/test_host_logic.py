@@ -986,8 +986,6 @@ def test_nam_device_mirror_follows_the_cache_without_walking_it():
     device mirror up to date no longer skips the first n keys of the dict (O(cache) per call).  The mirror must still equal
     `list(cache)` whatever happens to the dict: the model's own inserts (duplicates inside a batch, keys it already has), a key put in
     by somebody else, deletions, a replaced dict, a pickle round trip."""
-    import pickle
-
     from flexs_amd.baselines.models import noisy_abstract_model as nm
 
     class FakeCache:                       # what _new_device_cache hands out: records the rows appended (no GPU here)
@@ -1033,5 +1031,6 @@ def test_nam_device_mirror_follows_the_cache_without_walking_it():
     m.cache = dict(m.cache); m.cache["NEW"] = 1.0      # a plain dict instead of the counting one
     m._note_new_keys(["XYZ"]); m.cache["XYZ"] = 2.0
     synced()
-    m2 = pickle.loads(pickle.dumps(m))
-    assert m2._pending == [] and m2._dev_keys == []
+    m._note_new_keys(["QQQ"]); m.cache["QQQ"] = 3.0
+    state = m.__getstate__()               # what copy / pickle carry: no device mirror, no pending note
+    assert state["_pending"] == [] and state["_dev_keys"] == [] and state["_dev_cache"] is None and "QQQ" in state["cache"]
