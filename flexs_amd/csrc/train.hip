@@ -62,6 +62,7 @@ __global__ void __launch_bounds__(FB_MAX_THREADS) k_train_fb(const FxtJob* __res
             case 3: fxt_forward_backward<3, 3, FxtDims<2, 20, 0, 100, 0, 8>>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33); break;
             case 4: fxt_forward_backward<3, 3, FxtDims<0, 4, 32, 100, 5, 8, 8>>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33); break;    // TF-binding
             case 5: fxt_forward_backward<3, 3, FxtDims<0, 4, 32, 100, 5, 8, 14>>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33); break;   // RNA L = 14
+            case 6: fxt_forward_backward<3, 3, FxtDims<0, 4, 32, 100, 5, 4, 14>>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33); break;   // RNA L = 14, four rows per slice (the weights fit beside them)
             default: fxt_forward_backward<3, 3>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33);
         }
     } else if (j.ws_in_lds) {
@@ -217,6 +218,7 @@ __global__ void __launch_bounds__(FB_MAX_THREADS) k_train_fit(const FxtJob* __re
                 case 3: fxt_forward_backward<3, 3, FxtDims<2, 20, 0, 100, 0, 8>>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33); break;
                 case 4: fxt_forward_backward<3, 3, FxtDims<0, 4, 32, 100, 5, 8, 8>>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33); break;
                 case 5: fxt_forward_backward<3, 3, FxtDims<0, 4, 32, 100, 5, 8, 14>>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33); break;
+                case 6: fxt_forward_backward<3, 3, FxtDims<0, 4, 32, 100, 5, 4, 14>>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33); break;
                 default: fxt_forward_backward<3, 3>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33);
             }
         } else if (j.ws_in_lds) {
@@ -292,6 +294,15 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
         j.total_steps = u.epochs * j.steps_per_epoch;
         j.n = (int)n;
         j.R = rows_per_slice(j.net, u.batch, e->num_cus, (int)e->train_rows);
+        // A CNN whose weights would fit LDS beside a SMALLER slice runs fewer rows per slice (round 5): CNN(32, 100, 5) on 4 letters at
+        // seq_len 14 -- the RNA landscapes -- needs 71 KiB of workspace at eight rows, 165 KiB with its 94 KiB weight image, and ran with
+        // every B operand an L2 round trip (66 us per step; 36 KiB at four rows: image and workspace resident).  From the member's own
+        // shape only, like R itself.
+        if (j.net.kind == 0 && !e->train_rows && e->train_lds >= 2 && (j.net.F & 3) == 0) {
+            const size_t img = (size_t)fxt_lay(j.net, true).total;
+            if (img * 4 + 8192 <= FB_LDS_BUDGET)
+                while (j.R > 2 && ((size_t)fxt_ws(j.net, j.R).total + img) * 4 > FB_LDS_BUDGET) j.R >>= 1;
+        }
         j.S = (u.batch + j.R - 1) / j.R;
         j.seed = u.seed;
         j.pstride = (j.net.P + 1 + 31) & ~31;
@@ -315,6 +326,7 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
         if (j.split_off) lds_bytes = std::max(lds_bytes, ((size_t)j.split_off + FXT_SPLIT_FLOATS) * 4);
         // canonical shapes get the instantiation with compile-time dimensions (workspace + weights in LDS, 8 rows per slice)
         j.canon = 0;
+        if (e->train_canon && j.w_in_lds && j.R == 4 && u.kind == FX_CNN && u.A == 4 && u.F == 32 && u.H == 100 && u.K == 5 && L == 14 && j.net.ldx == fxt_ld_x(32)) j.canon = 6;
         if (e->train_canon && j.w_in_lds && j.R == 8) {
             if (u.kind == FX_CNN && u.A == 4 && u.F == 32 && u.H == 100 && u.K == 5 && j.net.ldx == fxt_ld_x(32)) j.canon = L == 8 ? 4 : (L == 14 ? 5 : 1);
             if (u.kind == FX_MLP && u.A == 4 && u.H == 100) j.canon = 2;

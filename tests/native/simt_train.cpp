@@ -149,6 +149,7 @@ static std::vector<float> emul_step_canon(const SimtProblem& p, int canon, int n
                     case 2: fxt_forward_backward<3, 3, FxtDims<1, 4, 0, 100, 0, 8>>(j, wg, 0, s, a, l, y, ws, W, (float*)nullptr); break;
                     case 3: fxt_forward_backward<3, 3, FxtDims<2, 20, 0, 100, 0, 8>>(j, wg, 0, s, a, l, y, ws, W, (float*)nullptr); break;
                     case 4: fxt_forward_backward<3, 3, FxtDims<0, 4, 32, 100, 5, 8, 8>>(j, wg, 0, s, a, l, y, ws, W, (float*)nullptr); break;
+                    case 6: fxt_forward_backward<3, 3, FxtDims<0, 4, 32, 100, 5, 4, 14>>(j, wg, 0, s, a, l, y, ws, W, (float*)nullptr); break;
                     default: fxt_forward_backward<3, 3>(j, wg, 0, s, a, l, y, ws, W, (float*)nullptr);
                 }
             });
@@ -241,10 +242,11 @@ int main(int argc, char** argv) {
         canons.push_back({1, 0, 10, 4, 32, 100, 5, 8, 512});
         canons.push_back({3, 2, 25, 20, 0, 100, 0, 13, 256});
         canons.push_back({0, 0, 8, 4, 32, 100, 5, 11, 1024});      // the shape-agnostic code over the same LDS image, 16 waves
+        canons.push_back({6, 0, 14, 4, 32, 100, 5, 10, 512});      // RNA length, FOUR rows per slice (round 5: the weights fit beside them)
     }
     for (const Canon& c : canons) {
         const int P = simt_ref_params(c.kind, c.L, c.A, c.F, c.H, c.K);
-        const SimtProblem p = simt_problem(c.kind, c.L, c.A, c.F, c.H, c.K, c.rows, 8, P, 2000u + (unsigned)c.L);
+        const SimtProblem p = simt_problem(c.kind, c.L, c.A, c.F, c.H, c.K, c.rows, c.canon == 6 ? 4 : 8, P, 2000u + (unsigned)c.L);
         std::vector<float> part_ref, part;
         const std::vector<float> want = simt_ref_step(p, &part_ref);
         const std::vector<float> got = emul_step_canon(p, c.canon, c.nthr, &part);
