@@ -63,6 +63,7 @@ __global__ void __launch_bounds__(FB_MAX_THREADS) k_train_fb(const FxtJob* __res
             case 4: fxt_forward_backward<3, 3, FxtDims<0, 4, 32, 100, 5, 8, 8>>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33); break;    // TF-binding
             case 5: fxt_forward_backward<3, 3, FxtDims<0, 4, 32, 100, 5, 8, 14>>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33); break;   // RNA L = 14
             case 6: fxt_forward_backward<3, 3, FxtDims<0, 4, 32, 100, 5, 4, 14>>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33); break;   // RNA L = 14, four rows per slice (the weights fit beside them)
+            case 7: fxt_forward_backward<3, 3, FxtDims<0, 4, 32, 100, 5, 0>>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33); break;       // the 4-letter CNN at any length and rows per slice
             default: fxt_forward_backward<3, 3>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33);
         }
     } else if (j.ws_in_lds) {
@@ -106,7 +107,10 @@ __global__ void __launch_bounds__(FB_MAX_THREADS) k_train_fb_c32p(const FxtJob* 
     const FxtJob& j = jobs[blockIdx.y];
     if (step >= j.total_steps || (int)blockIdx.x >= j.S) return;
     const FxtWg wg{(int)threadIdx.x, (int)blockDim.x};
-    fxt_forward_backward<3, 1, FxtDims<0, 20, 32, 100, 5, 1>, 3>(j, wg, step, (int)blockIdx.x, ascii, lut, labels, (FxtMem<3>::F)fxt_smem, (FxtMem<1>::CF)j.w, (FxtMem<3>::F) nullptr);
+    if (j.R == 1)
+        fxt_forward_backward<3, 1, FxtDims<0, 20, 32, 100, 5, 1>, 3>(j, wg, step, (int)blockIdx.x, ascii, lut, labels, (FxtMem<3>::F)fxt_smem, (FxtMem<1>::CF)j.w, (FxtMem<3>::F) nullptr);
+    else     // short protein sequences (fewer than 36 residues: several rows per slice) -- the same constants, the rows a run-time value
+        fxt_forward_backward<3, 1, FxtDims<0, 20, 32, 100, 5, 0>, 3>(j, wg, step, (int)blockIdx.x, ascii, lut, labels, (FxtMem<3>::F)fxt_smem, (FxtMem<1>::CF)j.w, (FxtMem<3>::F) nullptr);
 }
 
 __global__ void __launch_bounds__(256) k_train_adam(const FxtJob* __restrict__ jobs, int step) {
@@ -219,6 +223,7 @@ __global__ void __launch_bounds__(FB_MAX_THREADS) k_train_fit(const FxtJob* __re
                 case 4: fxt_forward_backward<3, 3, FxtDims<0, 4, 32, 100, 5, 8, 8>>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33); break;
                 case 5: fxt_forward_backward<3, 3, FxtDims<0, 4, 32, 100, 5, 8, 14>>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33); break;
                 case 6: fxt_forward_backward<3, 3, FxtDims<0, 4, 32, 100, 5, 4, 14>>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33); break;
+                case 7: fxt_forward_backward<3, 3, FxtDims<0, 4, 32, 100, 5, 0>>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33); break;
                 default: fxt_forward_backward<3, 3>(j, wg, step, slice, ascii, lut, labels, (lds_f)fxt_smem, (lds_cf)wl, sp33);
             }
         } else if (j.ws_in_lds) {
@@ -327,6 +332,7 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
         // canonical shapes get the instantiation with compile-time dimensions (workspace + weights in LDS, 8 rows per slice)
         j.canon = 0;
         if (e->train_canon && j.w_in_lds && j.R == 4 && u.kind == FX_CNN && u.A == 4 && u.F == 32 && u.H == 100 && u.K == 5 && L == 14 && j.net.ldx == fxt_ld_x(32)) j.canon = 6;
+        if (e->train_canon && j.w_in_lds && j.R != 8 && j.canon == 0 && u.kind == FX_CNN && u.A == 4 && u.F == 32 && u.H == 100 && u.K == 5 && j.net.ldx == fxt_ld_x(32)) j.canon = 7;
         if (e->train_canon && j.w_in_lds && j.R == 8) {
             if (u.kind == FX_CNN && u.A == 4 && u.F == 32 && u.H == 100 && u.K == 5 && j.net.ldx == fxt_ld_x(32)) j.canon = L == 8 ? 4 : (L == 14 ? 5 : 1);
             if (u.kind == FX_MLP && u.A == 4 && u.H == 100) j.canon = 2;
@@ -372,7 +378,7 @@ int fx_train_fit(fx_engine* e, fx_fit_job* jobs, int M, const uint8_t* ascii, in
     bool c32p = c32 && e->train_canon != 0;                // every member the canonical protein shape?
     if (c32) {
         lds_bytes = 0;                                         // (the layouts sized above are not the ones these members run)
-        for (int m = 0; m < M; ++m) c32p = c32p && c32_net[(size_t)m].A == 20 && c32_net[(size_t)m].H == 100 && c32_net[(size_t)m].K == 5 && hj[(size_t)m].R == 1;
+        for (int m = 0; m < M; ++m) c32p = c32p && c32_net[(size_t)m].A == 20 && c32_net[(size_t)m].H == 100 && c32_net[(size_t)m].K == 5;
         for (int m = 0; m < M; ++m) {
             FxtJob& j = hj[(size_t)m];
             j.net = c32_net[(size_t)m];

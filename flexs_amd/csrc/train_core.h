@@ -1177,7 +1177,7 @@ struct FxtPosMajorBL {
 // source is instantiated with the dimensions as constants: dead walks and masks fold away, offsets become immediates.  Same
 // arithmetic in the same order: the SAME BITS as the generic instantiation (GPU test).
 struct FxtDimsAny { static constexpr bool fixed = false; static constexpr int kind = 0, A = 0, F = 0, H = 0, K = 0, R = 0, L = 0; };
-template <int KIND, int A_, int F_, int H_, int K_, int R_, int L_ = 0>     // L_ = 0: the sequence length stays a run-time value
+template <int KIND, int A_, int F_, int H_, int K_, int R_, int L_ = 0>     // L_ = 0 / R_ = 0: the sequence length / the rows per slice stay run-time values
 struct FxtDims { static constexpr bool fixed = true; static constexpr int kind = KIND, A = A_, F = F_, H = H_, K = K_, R = R_, L = L_; };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1206,7 +1206,7 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
     FxtNet n_ = D::fixed ? fxt_net(D::kind, D::L > 0 ? D::L : j.net.L, D::A, D::F, D::H, D::K) : j.net;
     if (D::fixed && SWZ) n_.ldx = n_.F;        // (rotated rows are F floats apart)
     const FxtNet n = n_;
-    const int R = D::fixed ? D::R : j.R, L = n.L, A = n.A, F = n.F;
+    const int R = (D::fixed && D::R > 0) ? D::R : j.R, L = n.L, A = n.A, F = n.F;      // (R_ = 0: the rows per slice stay a run-time value too)
     const FxtWs w = fxt_ws(n, R, MODE >= 2);
     // MODE 2 / 3: the conv kernels' staging buffer behind the workspace, j.split_off taps at a time (the host sized it: a tap is
     // F rows of fxt_ld_w(F) floats in MODE 2, 32 rotated rows of 32 floats in MODE 3)

@@ -382,7 +382,10 @@ def test_more_members_than_one_device_call_takes():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,L,alphabet,F,H,K,n,B,M", [("cnn", 8, "TGCA", 32, 100, 5, 1000, 256, 3), ("cnn", 14, "UGCA", 32, 100, 5, 300, 256, 1),
-                                                        ("mlp", 14, "UGCA", 0, 100, 0, 300, 256, 2), ("ge", 90, ref_np.AAS, 0, 100, 0, 300, 256, 8)])
+                                                        ("mlp", 14, "UGCA", 0, 100, 0, 300, 256, 2), ("ge", 90, ref_np.AAS, 0, 100, 0, 300, 256, 8),
+                                                        # round 5: run-time rows per slice (4-letter CNN at other lengths; short and long protein CNNs in the F = 32 form)
+                                                        ("cnn", 20, "UGCA", 32, 100, 5, 300, 256, 2), ("cnn", 50, "TGCA", 32, 100, 5, 200, 128, 1),
+                                                        ("cnn", 20, ref_np.AAS, 32, 100, 5, 300, 256, 2), ("cnn", 90, ref_np.AAS, 32, 100, 5, 200, 256, 1)])
 def test_canonical_shape_instantiations_equal_the_shape_agnostic_step(kind, L, alphabet, F, H, K, n, B, M):
     """Round 4: the canonical surrogates (CNN(32, 100, kernel 5) on 4 letters, MLP(100), GlobalEpistasis(100) on 20 letters) train
     through an instantiation of the SAME source with the dimensions as compile-time constants (`train_canon`, default on: dead
