@@ -143,6 +143,18 @@ def _raise(code: int, eng_handle=None):
     raise FxError(code, msg)
 
 
+def raise_small_status(st: int, eng_handle=None):
+    """Status words of the C fast paths in csrc/strpack.c (score_small, population_step): 0 done, -1 / 1 / 1001-1003 "not for this
+    path" (handled by the callers), 2000 + |FX_E*| a library error.  One place turns the last form back into the (negative) FX code
+    `_raise` maps to the reference's exception types; anything else is reported as it is instead of being passed on as if it were a
+    code (round-4 advisor finding)."""
+    if st > 2000:
+        _raise(-(st - 2000), eng_handle)
+    if st < 0:
+        _raise(st, eng_handle)
+    raise FxError(FX_EINVAL, f"unexpected status {st} from the C fast path")
+
+
 def _ptr(a: Optional[np.ndarray]):
     """Address of an array's buffer as a plain int (c_void_p parameters take ints; `ndarray.ctypes.data_as` costs
     microseconds, which is a tenth of a small call)."""

@@ -357,12 +357,24 @@ static PyObject* score_small(PyObject* self, PyObject* args) {
         const Py_ssize_t n = PySequence_Fast_GET_SIZE(seqs);
         const Py_ssize_t need = (p->want == 1 ? n * p->M : n) * (Py_ssize_t)sizeof(float);
         if (n > 0 && n * p->L <= SMALL_MAX_BYTES && out.len >= need && p->M >= 1 && p->M <= 16) {
-            unsigned char buf[SMALL_MAX_BYTES];
+            /* explorer-size calls pack into 4 KiB on the stack; the few that are larger (up to one mailbox request, 64 KiB) into a
+             * per-thread heap buffer -- a 64 KiB frame in every call overflowed threads with small stacks (round-4 advisor) */
+            unsigned char small[4096];
+            static __thread unsigned char* big = NULL;
+            unsigned char* buf = small;
+            if (n * p->L > (Py_ssize_t)sizeof(small)) {
+                if (!big) big = (unsigned char*)malloc(SMALL_MAX_BYTES);
+                buf = big;
+            }
             float* o = (float*)out.buf;
             int streamed = 0;
             if (p->stream_begin && p->stream_min > 0 && n >= p->stream_min && p->stream_step > 0) {
                 unsigned char* rows = NULL;
-                if (((fx_stream_begin_fn)p->stream_begin)(p->engine, (void* const*)p->models, (int)p->M, (long long)n, (int)p->L, p->lut, &rows) == 0) {
+                int rc_begin;
+                Py_BEGIN_ALLOW_THREADS                     /* (it may end / start a generation: a stream synchronise; round-4 advisor) */
+                rc_begin = ((fx_stream_begin_fn)p->stream_begin)(p->engine, (void* const*)p->models, (int)p->M, (long long)n, (int)p->L, p->lut, &rows);
+                Py_END_ALLOW_THREADS
+                if (rc_begin == 0) {
                     /* the request is posted: pack in pieces, front to back, each piece reported as soon as it is in place */
                     PyObject** items = PySequence_Fast_ITEMS(seqs);
                     int st = 0;
@@ -387,9 +399,11 @@ static PyObject* score_small(PyObject* self, PyObject* args) {
                     }
                 }
             }
-            const int st = streamed ? 0 : pack_range(PySequence_Fast_ITEMS(seqs), buf, n, (Py_ssize_t)p->L, 1);
+            const int st = (streamed || !buf) ? 0 : pack_range(PySequence_Fast_ITEMS(seqs), buf, n, (Py_ssize_t)p->L, 1);
             if (streamed) {
                 /* answered (or failed) above */
+            } else if (!buf) {
+                status = -1;                               /* (no memory for the packing buffer: the general path) */
             } else if (st) {
                 status = 1000 + st;                        /* 1001 ragged, 1002 non-latin-1, 1003 not a str */
             } else {

@@ -133,7 +133,7 @@ class Ensemble(_EnsembleBase):
             return None                                     # (not for this path: the general one raises what the reference raises)
         for m in models:
             m.cost += n                                     # (the reference charges the members before a member's predict raises)
-        _native._raise(-(st - 2000) if st > 2000 else st, c[3].handle)
+        _native.raise_small_status(st, c[3].handle)
 
     def _fitness_function(self, sequences):
         if (type(sequences) is np.ndarray and sequences.dtype.kind == "U" and sequences.ndim == 1

@@ -129,7 +129,7 @@ class PopulationEvaluator:
         if st == 1:
             return None
         if st:
-            _native._raise(-(st - 2000) if st > 2000 else st, self._members[0]._engine().handle)
+            _native.raise_small_status(st, self._members[0]._engine().handle)
         return seqs, (out[:, 0] if single else out)
 
     def _account(self, seqs, scores, known, values, single):
