@@ -59,6 +59,9 @@ SIGNATURES = {
     "fx_score_stream_begin": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int64, C.c_int, _u8p, C.POINTER(_vp)]),
     "fx_score_stream_rows": (C.c_int, [_vp, C.c_int64]),
     "fx_score_stream_end": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "fx_score_begin_staged": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int64, C.c_int, _u8p, C.c_int, C.c_int, C.c_int,
+                                        C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_uint), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "fx_score_abandon": (C.c_int, [_vp]),
     "fx_score_begin": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int64, C.c_int, _u8p, C.c_int, C.c_int, C.POINTER(_vp)]),
     "fx_score_submit": (C.c_int, [_vp, C.c_int64, C.c_int64]),
     "fx_score_finish": (C.c_int, [_vp, _vp, _vp]),
@@ -284,6 +287,7 @@ SMALL_CALL_BYTES = 65536         # (FX_SERVE_BYTES, and the stack buffer of csrc
 STREAM_MIN_ROWS = 384
 STREAM_STEP_ROWS = 256
 _HAS_SCORE_SMALL = _strpack is not None and hasattr(_strpack, "score_small")
+_HAS_PACK_STAGED = _strpack is not None and hasattr(_strpack, "pack_staged")
 
 
 def small_plan(engine: "Engine", models: Sequence["NativeModel"], L: int, lut: np.ndarray, want_mean: bool) -> Optional[bytes]:
@@ -315,6 +319,16 @@ def score_small(engine: "Engine", plan: bytes, seqs, M: int, want_mean: bool) ->
     if st == -1 or 1000 < st < 2000:
         return None
     _raise(-(st - 2000) if st > 2000 else st, engine.handle)
+
+
+def _raise_pack_status(status: int):
+    """What the reference raises for a batch `_strpack` could not pack (string_to_one_hot's np.array / str.index failures)."""
+    if status == 1:
+        raise ValueError("ragged sequence batch: all sequences must have the same length")
+    if status == 2:
+        raise ValueError("substring not found")
+    if status == 3:
+        raise TypeError("sequences must be str")
 
 
 def wants_chunked(sequences, L: int) -> bool:
@@ -450,6 +464,30 @@ class Engine:
         transfer and scoring of piece k (GPU).  Same results and exceptions as sequences_to_bytes + score."""
         N, M = len(seqs), len(models)
         arr = (_vp * M)(*[m.handle for m in models])
+        if chunks <= 0 and CHUNK_BYTES <= 0 and _HAS_PACK_STAGED:
+            # launched first, packed behind: where the engine's kernels can wait for their rows (fx_score_begin_staged) the launch
+            # latency and most of the kernel's run lie beside the packing instead of behind it
+            lanes = min(_strpack.lanes_for(N * L), 16)
+            p, w, base, stages, pitch = _vp(), _vp(), C.c_uint(0), C.c_int(0), C.c_int(0)
+            rc = self._lib.fx_score_begin_staged(self.handle, arr, M, N, L, _lut_ptr(lut), int(want_matrix), int(want_mean), lanes,
+                                                 C.byref(p), C.byref(w), C.byref(base), C.byref(stages), C.byref(pitch))
+            if rc == FX_OK:
+                status = 3
+                try:
+                    status = _strpack.pack_staged(seqs, L, p.value, stages.value, pitch.value, lanes, w.value, base.value)
+                finally:
+                    if status:
+                        self._lib.fx_score_abandon(self.handle)
+                    out_nm = np.empty((N, M), np.float32) if want_matrix else None
+                    out_mean = np.empty((N,), np.float32) if want_mean else None
+                    rc = self._lib.fx_score_finish(self.handle, _ptr(out_nm), _ptr(out_mean))
+                if status == 5:         # (legacy str objects need the GIL: the plain path)
+                    return self.score(models, sequences_to_bytes(seqs, L=L, staging=self), lut, want_matrix=want_matrix, want_mean=want_mean)
+                _raise_pack_status(status)
+                self.check(rc)
+                return out_nm, out_mean
+            if rc != FX_EUNSUPPORTED:
+                self.check(rc)
         if chunks <= 0:
             if CHUNK_BYTES > 0:
                 chunks = min(max(N * L // CHUNK_BYTES, 1), 16)
@@ -480,12 +518,7 @@ class Engine:
             out_nm = np.empty((N, M), np.float32) if want_matrix else None
             out_mean = np.empty((N,), np.float32) if want_mean else None
             rc = self._lib.fx_score_finish(self.handle, _ptr(out_nm), _ptr(out_mean))
-        if status == 1:
-            raise ValueError("ragged sequence batch: all sequences must have the same length")
-        if status == 2:
-            raise ValueError("substring not found")
-        if status == 3:
-            raise TypeError("sequences must be str")
+        _raise_pack_status(status)
         self.check(rc)
         return out_nm, out_mean
 

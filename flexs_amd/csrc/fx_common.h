@@ -14,6 +14,24 @@
 #define FX_ERR_BADCHAR 1u    // bit in the deferred device error word
 #define FX_LP_BAR_BYTES (19 * 128)   // barrier counters of the layer-parallel protein form: top + 16 groups, a 128-byte line each; line 17: units finished (completion flag); line 18: a pre-launched instance's go / leave decision
 #define FX_ERR_TIMEOUT 2u    // a device-side barrier (layer-parallel protein form) was not passed in time
+#define FX_ERR_STARVED 4u    // a launched-first host call (FxRowsReady) never saw some of its rows arrive: the host redoes the call the plain way
+
+// "Launch first, pack behind" (round 5): a big host call of list[str] launches its kernels BEFORE the strings are packed; the packing
+// threads fill the pinned staging area stage by stage -- stage j = the 16-row tiles t with t % Q == j -- and publish, per packing
+// lane, how many stages they have finished (word = base + stages done, device memory written through the BAR).  A wave that pulls
+// tile t waits until every lane has published stage t % Q.  The staging area of such a call is TILE-PITCHED: tile t's rows start at
+// t * pitch, a whole number of 128-byte lines, so no cache line holds rows of two tiles and a line fetched for one tile can never
+// carry a neighbour's rows from before they were packed -- which is what lets the wait do without a cache invalidate (an acquire
+// fence of agent or system scope after the poll cost the 1024 waves of a launch ~85 us, and reading the rows with system-scope
+// loads instead cost the MLP launch 50-120 us: profiles/r5_launch_first.log).
+// words == nullptr: the call's rows are all there, N x L contiguous (every other call).
+struct FxRowsReady {
+    const unsigned* words;      // one unsigned per lane, all in one 64-byte line (one request per poll)
+    unsigned base;              // this call's origin of the counts (stale values of earlier calls compare as "nothing yet")
+    int lanes;                  // 1 .. 16
+    int Q;                      // number of stages
+    int pitch;                  // bytes from one tile's rows to the next tile's
+};
 // The resident form (score_cnn_quad.hip / score_dense_small.hip, SERVER).  Round 3: <= 16 tile slots per member on a third
 // of the CUs, one tile per slot and request -> 256 sequences.  Round 4 (engine option serve_wide): a generation may take
 // most of the chip -- up to FX_SERVE_TILES slots per member -- and a slot walks the tiles slot, slot + T, slot + 2T, ... of a
@@ -295,6 +313,15 @@ struct fx_engine {
     int64_t serve_poll_sleep = 8;     // s_sleep units (64 clocks each) between polls of the slots beyond FX_SERVE_FAST (0 = every slot spins)
     int64_t serve_small = 1;    // 1 = explorer-size calls of canonical CNN ensembles are answered by resident workgroups (0 = a launch per call: A/B)
     int64_t fuse_mean = 0;      // 1 = explorer-size CNN ensemble calls average in the scoring kernel (last member to finish a tile, tickets + device-scope fences) instead of launching the mean kernel.  Bit-identical, but the two fences cost what the 3 us launch saves: 32.1 vs 32.2 us per call (profiles/r3_fused_mean_ab.log): off, kept as the A/B
+    // launched-first host call (fx_score_begin_staged): what the launchers that can wait for rows copy into their arguments, and
+    // whether the launch just enqueued did (a launcher that cannot returns FX_EUNSUPPORTED before it enqueues anything)
+    struct { bool on = false, used = false; FxRowsReady r = {nullptr, 0, 0, 0, 0}; } rows_req;
+    int64_t rows_min_share = 0;                          // (request) tiles in the shortest per-SIMD share of the launch
+    unsigned* rows_words = nullptr;                      // 16 lines of device memory the host stores into (large BAR), or null
+    bool rows_refused = false;
+    unsigned rows_base = 0;
+    int64_t launch_first_calls = 0, launch_first_redone = 0;   // (read) host calls launched before their strings were packed; of those, redone the plain way
+    int64_t launch_first = 1;   // 1 = big list[str] calls whose kernels can wait for rows are launched before the strings are packed (0 = pack, then launch: A/B)
     // chunked host call in flight (fx_score_begin / _submit / _finish)
     struct {
         bool active = false;
@@ -308,11 +335,28 @@ struct fx_engine {
         int pieces = 0;                                  // submitted so far
         bool zero_copy = false;                          // the pieces' kernels read the pinned staging area directly
         int64_t row0[32] = {}, rows[32] = {};
+        uint8_t lut[256] = {};      // staged: for a plain second attempt
+        unsigned* words = nullptr; unsigned base = 0; int lanes = 0, Q = 0, pitch = 0;
+        bool packed_ok = true;      // staged: the caller packed every row (fx_score_finish_staged says otherwise)
+        bool redo = false;          // staged: the launch did not wait for rows after all (never expected), or raised an error word: redo the plain way
+        bool staged = false;        // launched first: the kernels are already enqueued and wait for the rows (fx_score_begin_staged)
+        int64_t stride = 0;         // staged, mean only: the member planes' stride in d_nm
+        unsigned flag[32] = {};     // zero-copy pieces: the value the command processor writes to h_done[8] behind piece k (0 = an event was recorded instead)
     } chunked;
     int64_t chunk_overlap = 0;  // 1 = the chunked host call puts transfers and kernels on two streams (measured SLOWER than one stream: the cross-stream event waits cost more than the overlap buys, profiles/r3_e2e_ab.log; kept as the A/B)
     int64_t zero_copy_bytes = 256 << 10;   // host calls whose input + output are at most this many bytes run zero-copy: the kernels read the sequences from / write the scores to mapped pinned host memory
     int64_t zero_copy_mode = -1;           // host calls beyond zero_copy_bytes: -1 = zero-copy when the plan (fx_plan_host_call) says the PCIe reads hide behind the kernels, 0 = always copy, 1 = always zero-copy (A/B)
 };
+
+// The launcher's part of a launched-first call's plan: as many stages as the shortest per-SIMD share has tiles.  false = too few
+// to order (nothing launched).
+inline bool fx_rows_plan(fx_engine* e) {
+    int64_t Q = e->rows_min_share;
+    if (Q > 2048) Q = 2048;
+    if (Q < 2) return false;
+    e->rows_req.r.Q = (int)Q;
+    return true;
+}
 
 struct fx_model {
     fx_engine* eng = nullptr;
@@ -370,6 +414,27 @@ int fx_trace_buffer(fx_engine* e, unsigned long long** out);
 #if defined(__HIPCC__)
 __device__ __forceinline__ void fx_raise(unsigned* err, unsigned bit) {
     __hip_atomic_store(err, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// Wave-uniform: returns when the rows of stage `stage` are in the staging area.  `known` = stages this wave has already seen
+// published (the words are only read again for a later stage: once the host has finished packing, one poll settles the rest of the
+// kernel).  The acquire is system scope: the rows were written by the host and are read over PCIe right after.  A host that dies
+// mid-call must not hang the device: after 0.25 s the wave raises FX_ERR_STARVED and goes on (the host redoes the call).
+__device__ __forceinline__ void fx_rows_wait(const FxRowsReady& r, int stage, int& known, unsigned* err) {
+    if (stage < known) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        int have = 0x7FFFFFFF;
+        if (lane < r.lanes) have = (int)(__hip_atomic_load(r.words + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - r.base);
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) { const int other = __shfl_xor(have, o); have = other < have ? other : have; }   // (lanes 0 .. 15 hold every word)
+        have = __builtin_amdgcn_readfirstlane(have);
+        known = have < 0 ? 0 : (have > r.Q ? r.Q : have);        // (a value of an earlier call lies below this call's base)
+        if (stage < known) break;
+        if (wall_clock64() - t0 > 25000000ull) { if (lane == 0) fx_raise(err, FX_ERR_STARVED); known = r.Q; break; }
+        __builtin_amdgcn_s_sleep(64);                            // (~1.7 us: a thousand waiting waves must not flood the line the host stores into)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       // (the rows are read after the poll; no invalidate: see FxRowsReady)
 }
 #endif
 

@@ -25,6 +25,7 @@ FXI void host_mean_planes(const float* pl, int64_t stride, int64_t N, int M, flo
 FXI void lp_arm(fx_engine* e, fx_model* const* models, int M, int64_t N, int L, const uint8_t lut[256], float* out_dev, int64_t stride, int mode);      // fx_resident.hip
 FXI bool lp_armed_matches(const fx_engine* e, fx_model* const* models, int M, int64_t N, int L, const uint8_t lut[256], int64_t stride, int mode, const void* out_dev);      // fx_resident.hip
 FXI void lp_disarm(fx_engine* e);      // fx_resident.hip
+FXI unsigned* rows_words_ensure(fx_engine* e);      // fx_resident.hip: the line of device memory a launched-first call's packing lanes store into, or null
 FXI bool lp_serve_armed(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii, int64_t N, int L, const uint8_t lut[256], float* out_dev, int64_t stride, int mode, void* out_host, size_t out_bytes);      // fx_resident.hip
 FXI int server_call(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii, int64_t N, int L, const uint8_t lut[256], float* out_NM, float* out_mean);      // fx_resident.hip
 FXI int64_t server_since(const fx_engine* e);      // fx_resident.hip

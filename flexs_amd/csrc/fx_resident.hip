@@ -195,6 +195,33 @@ void host_mean_planes(const float* pl, int64_t stride, int64_t N, int M, float* 
     }
 }
 
+// ---- launched-first host calls (fx_common.h FxRowsReady): one line of device memory the host can store into ---------------------
+unsigned* rows_words_ensure(fx_engine* e) {
+    if (e->rows_words) return e->rows_words;
+    if (e->rows_refused || !e->large_bar) return nullptr;
+    e->rows_refused = true;                                // (asked once)
+    unsigned* q = nullptr;
+    if (hipExtMallocWithFlags(reinterpret_cast<void**>(&q), 256, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    {
+        std::lock_guard<std::mutex> lock(g_probe_mu);
+        bool ok = host_range_is_writable(q, 256);
+        if (ok) {
+            volatile unsigned* p = q;
+            *p = 0x5EB1A5EDu;
+            fx_bar_fence();
+            unsigned back = 0;
+            ok = hipMemcpy(&back, const_cast<const unsigned*>(p), sizeof back, hipMemcpyDeviceToHost) == hipSuccess && back == 0x5EB1A5EDu;
+            if (!ok) (void)hipGetLastError();
+        }
+        if (!ok) { (void)hipFree(q); return nullptr; }
+    }
+    for (int i = 0; i < 64; ++i) reinterpret_cast<volatile unsigned*>(q)[i] = 0u;
+    fx_bar_fence();
+    e->rows_words = q;
+    e->rows_refused = false;
+    return q;
+}
+
 // ---- pre-launched instance of the layer-parallel protein form (fx_common.h LpArmed) -------------------------------------------
 static bool lp_mail_ensure(fx_engine* e) {
     if (e->lp_mail) return true;

@@ -47,6 +47,12 @@ int score_dispatch(fx_engine* e, fx_model* const* models, int M, const uint8_t* 
         int rc = FX_EUNSUPPORTED;
         e->dispatch_groups += 1;
         e->done_armed = false;                             // (only the LAST launch of a dispatch may offer the completion flag)
+        if (e->rows_req.on) {
+            // launched-first host call: ONE launch of a kernel that waits for its rows, or nothing at all (the caller then packs first)
+            if (cnt != M || e->force_generic) return FX_EUNSUPPORTED;
+            if (s0.kind == FX_CNN) return fx_launch_score_cnn_mfma(e, models, M, d_ascii, N, d_NM, M, 0);
+            return fx_launch_score_dense_mfma(e, models, M, d_ascii, N, d_NM, M, 0);
+        }
         if (!e->force_generic) {
             if (s0.kind == FX_CNN) {
                 rc = fx_launch_score_cnn_mfma(e, models + m0, cnt, d_ascii, N, d_NM, M, m0);
@@ -270,8 +276,10 @@ int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii,
             const bool plain_matrix = out_NM && !out_mean && N <= e->host_mean_below;
             const bool served = plain_matrix && lp_armed_matches(e, models, M, N, L, lut, 0, 2, m_NM) && lp_serve_armed(e, models, M, ascii, N, L, lut, m_NM, 0, 2, h_out, nm_bytes);
             unsigned seq = 0;
+            e->call_prof_ns[0] = server_since(e);
             if (!served) {
                 if ((rc = score_dispatch(e, models, M, (const uint8_t*)dm_in, N, L, out_NM ? m_NM : d_NM, stride))) return rc;
+                e->call_prof_ns[1] = server_since(e);
                 if (out_mean) {
                     if ((rc = fx_launch_ensemble_reduce(e, out_NM ? m_NM : d_NM, N, M, nullptr, m_mean, nullptr))) return rc;
                     e->done_armed = false;
@@ -283,9 +291,11 @@ int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii,
             }
             if (served) e->done_armed = false;
             else if ((rc = wait_for_results(e, seq))) return rc;   // (the last launch's completion flag where it offers one, else the stream)
+            e->call_prof_ns[2] = server_since(e);
             if ((rc = check_deferred(e))) return rc;
             if (out_NM) std::memcpy(out_NM, h_out, nm_bytes);
             if (out_mean) std::memcpy(out_mean, (char*)h_out + nm_bytes, mean_bytes);
+            e->call_prof_ns[3] = server_since(e);
             return FX_OK;
         }
         if ((rc = wait_for_results(e))) return rc;         // (the mean kernel was the last writer: the stream)
@@ -339,6 +349,103 @@ int fx_score_begin(fx_engine* e, fx_model* const* models, int M, int64_t N, int 
     return FX_OK;
 }
 
+// "Launch first, pack behind" (round 5).  The call's kernels are enqueued HERE, before a single string has been packed: they read
+// the pinned staging area directly (the zero-copy plan) and every wave waits, tile by tile, for the packing lanes to publish the
+// stage its tile belongs to (FxRowsReady).  The caller then packs the stages in order -- `_strpack.pack_staged` -- storing
+// `base + stages done` into words[lane] after each, and calls fx_score_finish.  The launch latency, the weight fill and most of
+// the kernel's run now lie BESIDE the packing instead of behind it (profiles/r5_e2e_breakdown.log: 37 us of packing and 90 us of
+// launch + kernel + wait back to back for the 1e5-sequence MLP call).
+// The staging area of such a call is TILE-PITCHED: the 16 rows of tile t start at t * pitch, pitch = 16 L rounded up to whole
+// 128-byte lines, so that no cache line holds rows of two tiles -- see FxRowsReady.
+// FX_EUNSUPPORTED (nothing enqueued, no call in flight): the plan is not zero-copy, the shape's kernel cannot wait for rows, the
+// host cannot store into device memory, or there are too few tiles per SIMD to order -- the caller packs first, as before.
+static int staged_enqueue(fx_engine* e, bool* waits) {
+    auto& c = e->chunked;
+    const int M = (int)c.models.size();
+    const size_t nm_bytes = sizeof(float) * (size_t)c.N * (size_t)M;
+    void *dm_in = nullptr, *dm_out = nullptr;
+    FX_HIP(e, hipHostGetDevicePointer(&dm_in, c.h_in, 0));
+    FX_HIP(e, hipHostGetDevicePointer(&dm_out, c.h_out, 0));
+    float* m_NM = (float*)dm_out;
+    float* m_mean = (float*)((char*)dm_out + nm_bytes);
+    // stages: as many as the SHORTEST per-SIMD share of a workgroup has tiles, so that every share holds a tile of every stage
+    // (member m's tiles are cut over ~G / M workgroups, a workgroup's over its four SIMDs); the launcher has the last word
+    const int64_t TG = (c.N + 15) / 16, U = TG * M;
+    int64_t G = e->grid_blocks > 0 ? e->grid_blocks : e->num_cus;
+    if (G > U) G = U;
+    const int64_t nb = M > 1 ? (G + M - 1) / M : G;      // workgroups of one member, at most
+    e->rows_min_share = TG / (nb > 0 ? nb : 1) / 4;
+    e->rows_req.on = true; e->rows_req.used = false;
+    e->rows_req.r = FxRowsReady{c.words, c.base, c.lanes, 0, c.pitch};
+    int rc;
+    if (c.stride) rc = score_then_mean(e, c.models.data(), M, (const uint8_t*)dm_in, c.N, c.L, c.d_nm, c.stride, m_mean);
+    else {
+        rc = score_dispatch(e, c.models.data(), M, (const uint8_t*)dm_in, c.N, c.L, c.want_nm ? m_NM : c.d_nm, 0);
+        if (!rc && c.want_mean) rc = fx_launch_ensemble_reduce(e, c.want_nm ? m_NM : c.d_nm, c.N, M, nullptr, m_mean, nullptr);
+    }
+    *waits = e->rows_req.used;
+    e->rows_req.on = false;
+    c.Q = e->rows_req.r.Q;
+    e->done_armed = false;                                 // (finish waits on the stream: the mean kernel may be the last writer)
+    return rc;
+}
+
+int fx_score_begin_staged(fx_engine* e, fx_model* const* models, int M, int64_t N, int L, const uint8_t lut[256],
+                          int want_nm, int want_mean, int lanes, void** staging, void** words, unsigned* base, int* stages, int* tile_pitch) {
+    int rc = validate_models(e, models, M, L, lut);
+    if (rc) return rc;
+    if (N < 1 || !staging || !words || !base || !stages || !tile_pitch || (!want_nm && !want_mean) || lanes < 1 || lanes > 16)
+        return fx_fail(e, FX_EINVAL, "fx_score_begin_staged: bad arguments");
+    if (e->chunked.active) return fx_fail(e, FX_ESTATE, "fx_score_begin_staged: a chunked call is already in flight");
+    if (!e->launch_first) return FX_EUNSUPPORTED;
+    FX_HIP(e, hipSetDevice(e->device));
+    bool zc = false;
+    { int unused = 1; plan_host_call(e, models, M, N, L, &zc, &unused); }
+    if (!zc) return FX_EUNSUPPORTED;
+    unsigned* w = rows_words_ensure(e);
+    if (!w) return FX_EUNSUPPORTED;
+    const int64_t TG = (N + 15) / 16;
+    const int pitch = (16 * L + 127) / 128 * 128;
+    const size_t in_bytes = (size_t)TG * (size_t)pitch;
+    const size_t nm_bytes = sizeof(float) * (size_t)N * (size_t)M, mean_bytes = sizeof(float) * (size_t)N;
+    void *d_in = nullptr, *h_in = nullptr, *h_out = nullptr, *d_out = nullptr;
+    const int64_t stride = (!want_nm && M <= 16) ? planar_stride_for(N) : 0;
+    const size_t inter_bytes = stride ? sizeof(float) * (size_t)stride * (size_t)M : nm_bytes;
+    if ((rc = fx_scratch(e, 0, in_bytes + 16, &d_in))) return rc;
+    if ((rc = fx_pinned(e, 0, in_bytes, &h_in))) return rc;
+    if ((rc = fx_pinned(e, 1, nm_bytes + mean_bytes, &h_out))) return rc;
+    if ((rc = fx_scratch(e, 1, inter_bytes + mean_bytes, &d_out))) return rc;
+    if ((rc = fx_upload_lut(e, lut))) return rc;
+    auto& c = e->chunked;
+    c.models.assign(models, models + M);
+    c.N = N; c.L = L; c.want_nm = want_nm != 0; c.want_mean = want_mean != 0;
+    c.h_in = (uint8_t*)h_in; c.d_in = (uint8_t*)d_in;
+    c.d_nm = (float*)d_out; c.d_mean = nullptr;
+    c.h_out = (char*)h_out;
+    c.pieces = 0; c.zero_copy = true; c.stride = stride;
+    e->rows_base += 4096u;
+    c.words = w; c.base = e->rows_base; c.lanes = lanes; c.pitch = pitch; c.packed_ok = true;
+    bool waits = false;
+    rc = staged_enqueue(e, &waits);
+    if (rc && !waits) return rc;                           // (FX_EUNSUPPORTED: nothing was enqueued)
+    c.redo = rc != 0 || !waits;                            // (an enqueue failed half-way: let the queue drain, then try again)
+    c.staged = true;
+    c.active = true;
+    e->counters.host_calls += 1; e->counters.zero_copy_calls += 1; e->counters.sequences += N; e->counters.forwards += N * M;
+    e->launch_first_calls += 1;
+    *staging = h_in; *words = w; *base = c.base; *stages = c.Q; *tile_pitch = pitch;
+    return FX_OK;
+}
+
+// The caller of a launched-first call could not pack every row (a ragged batch, a non-str item): fx_score_finish then only waits for
+// the kernels and drops whatever they raised over the rows that never came.
+int fx_score_abandon(fx_engine* e) {
+    if (!e) return FX_EINVAL;
+    if (!e->chunked.active) return fx_fail(e, FX_ESTATE, "fx_score_abandon without a call in flight");
+    e->chunked.packed_ok = false;
+    return FX_OK;
+}
+
 int fx_score_submit(fx_engine* e, int64_t row0, int64_t rows) {
     if (!e) return FX_EINVAL;
     auto& c = e->chunked;
@@ -370,7 +477,16 @@ int fx_score_submit(fx_engine* e, int64_t row0, int64_t rows) {
         if ((rc = score_dispatch(e, c.models.data(), M, (const uint8_t*)dm_in + row0 * c.L, rows, c.L, nm))) return rc;
         if (c.want_mean && (rc = fx_launch_ensemble_reduce(e, nm, rows, M, nullptr, m_mean, nullptr))) return rc;
         const int k = c.pieces;
-        FX_HIP(e, hipEventRecord(e->ev_out[k], e->stream));
+        // "piece k is done": a word written by the command processor behind the piece's launches and polled in pinned host
+        // memory (as wait_for_results does) -- an event record + hipEventSynchronize cost ~30 us per piece, which was more
+        // than the overlap of packing with scoring bought (profiles/r5_e2e_breakdown.log)
+        c.flag[k] = 0;
+        if (e->done_flag && e->d_done) {
+            const unsigned v = ++e->done_value ? e->done_value : ++e->done_value;
+            if (hipStreamWriteValue32(e->stream, e->d_done + 8, v, 0) == hipSuccess) c.flag[k] = v;
+            else (void)hipGetLastError();
+        }
+        if (!c.flag[k]) FX_HIP(e, hipEventRecord(e->ev_out[k], e->stream));
         c.row0[k] = row0; c.rows[k] = rows;
         ++c.pieces;
         return FX_OK;
@@ -401,6 +517,7 @@ int fx_score_submit(fx_engine* e, int64_t row0, int64_t rows) {
     if (c.want_nm)
         FX_HIP(e, hipMemcpyAsync(c.h_out + sizeof(float) * row0 * M, nm, sizeof(float) * rows * M, hipMemcpyDeviceToHost, cs));
     FX_HIP(e, hipEventRecord(e->ev_out[k], cs));
+    c.flag[k] = 0;
     c.row0[k] = row0; c.rows[k] = rows;
     ++c.pieces;
     return FX_OK;
@@ -414,17 +531,61 @@ int fx_score_finish(fx_engine* e, float* out_NM, float* out_mean) {
     FX_HIP(e, hipSetDevice(e->device));
     const int M = (int)c.models.size();
     const size_t nm_bytes = sizeof(float) * (size_t)c.N * (size_t)M;
+    if (c.staged) {
+        c.staged = false;
+        // every stage counts as published now, whatever became of the packing (a caller that failed half-way must not leave the
+        // kernels waiting; they then run on whatever the staging area holds and the results are dropped by the caller)
+        for (int l = 0; l < c.lanes; ++l) reinterpret_cast<volatile unsigned*>(c.words)[l] = c.base + (unsigned)c.Q;
+        fx_bar_fence();
+        int rc = wait_for_results(e);
+        if (rc) return rc;
+        const unsigned err = *reinterpret_cast<volatile unsigned*>(e->h_err);
+        if ((err & FX_ERR_STARVED) || c.redo || (err && !c.packed_ok)) {
+            // rows that never came, a launch that did not wait, or an error word raised over rows the caller says it failed to pack:
+            // when the caller did pack everything, the same launch once more -- every stage is published, nothing waits -- gives
+            // the answer and the error the reference gives; when it did not, there is nothing to answer
+            *reinterpret_cast<volatile unsigned*>(e->h_err) = 0;
+            e->launch_first_redone += 1;
+            if (!c.packed_ok) return FX_OK;                // (the caller raises its own packing error)
+            bool waits = false;
+            if ((rc = staged_enqueue(e, &waits))) return rc == FX_EUNSUPPORTED ? fx_fail(e, FX_ESTATE, "launched-first call: the second attempt found no kernel") : rc;
+            if ((rc = wait_for_results(e))) return rc;
+        }
+        if ((rc = check_deferred(e))) return rc;
+        if (c.want_nm && out_NM) std::memcpy(out_NM, c.h_out, nm_bytes);
+        if (c.want_mean && out_mean) std::memcpy(out_mean, c.h_out + nm_bytes, sizeof(float) * (size_t)c.N);
+        return FX_OK;
+    }
     // piece by piece: the host copies piece k out of the pinned area while the GPU still works on the later ones
     // (a character outside the alphabet in ANY piece fails the call: the results are only trusted after the last check)
+    bool flags_only = c.pieces > 0;
     for (int k = 0; k < c.pieces; ++k) {
-        FX_HIP(e, hipEventSynchronize(e->ev_out[k]));
+        if (c.flag[k]) {
+            // (the stream is in order: the word only moves forward, piece k is done when it has reached piece k's value)
+            const volatile unsigned* w = e->h_done + 8;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spins = 0; (int)(*w - c.flag[k]) < 0; ++spins) {
+                __builtin_ia32_pause();
+                if ((spins & 4095u) == 4095u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) {
+                    FX_HIP(e, hipStreamSynchronize(e->stream));
+                    break;
+                }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        } else {
+            flags_only = false;
+            FX_HIP(e, hipEventSynchronize(e->ev_out[k]));
+        }
         if (c.want_nm && out_NM)
             std::memcpy(out_NM + c.row0[k] * M, c.h_out + sizeof(float) * c.row0[k] * M, sizeof(float) * (size_t)c.rows[k] * M);
         if (c.want_mean && out_mean)
             std::memcpy(out_mean + c.row0[k], c.h_out + nm_bytes + sizeof(float) * c.row0[k], sizeof(float) * (size_t)c.rows[k]);
     }
-    FX_HIP(e, hipStreamSynchronize(e->copy_stream));
-    FX_HIP(e, hipStreamSynchronize(e->stream));
+    if (!flags_only) {
+        FX_HIP(e, hipStreamSynchronize(e->copy_stream));
+        FX_HIP(e, hipStreamSynchronize(e->stream));
+    }
+    e->done_armed = false;
     return check_deferred(e);
 }
 

@@ -45,6 +45,7 @@ struct CnnArgs {
     unsigned* seg_cnt;
     // packed-layout offsets (floats)
     int off_first, off_c2, off_c3, off_cb, off_w1p, conv_floats, off_d1, off_d2, off_db, total_floats;
+    FxRowsReady ready;          // launched-first host call: the rows arrive while the kernel runs (words == nullptr: they are all there)
 };
 
 // L1S > 0: number of conv positions known at compile time (L1S = seq_len - K + 1): the position loop is fully
@@ -133,6 +134,14 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
         // their share's counter
         const int64_t s_lo = t_lo + (t_hi - t_lo) * share.before / share.total;
         const int64_t s_hi = t_lo + (t_hi - t_lo) * (share.before + share.mine) / share.total;
+        // launched-first call: the host packs the tiles of stage 0 first, then stage 1, ... (FxRowsReady): the share is walked from
+        // its first tile of stage 0 on (and around), so the stages it asks for come in the order they are packed
+        const bool rows_arrive = !SEG && NT == 1 && p.ready.words != nullptr;
+        int rows_rot = 0, rows_known = 0;
+        if (rows_arrive) {
+            const int64_t t0 = (s_lo + p.ready.Q - 1) / p.ready.Q * p.ready.Q;
+            if (t0 < s_hi) rows_rot = (int)(t0 - s_lo);
+        }
 
         for (int64_t seg_tile = t_lo;; ++seg_tile) {
             int64_t tg = seg_tile;                               // SEG: every wave of the workgroup walks the same tiles
@@ -142,6 +151,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                 pulled = __builtin_amdgcn_readfirstlane(pulled);
                 tg = s_lo + pulled;
                 if (tg >= s_hi) break;
+                if (rows_arrive) {
+                    const int len = (int)(s_hi - s_lo);
+                    int at = pulled + rows_rot;
+                    if (at >= len) at -= len;
+                    tg = s_lo + at;
+                    fx_rows_wait(p.ready, (int)(tg % p.ready.Q), rows_known, p.err);
+                }
             }
             if (tg >= t_hi) break;
             got_tile = true;
@@ -153,6 +169,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
             for (int nt = 0; nt < NT; ++nt) {
                 n[nt] = (tg * NT + nt) * 16 + sq;
                 row[nt] = p.ascii + (n[nt] < p.N ? n[nt] : 0) * L;   // out-of-range lanes recompute seq 0
+                if (rows_arrive) row[nt] = p.ascii + tg * p.ready.pitch + (n[nt] < p.N ? sq : 0) * L;   // (tile-pitched staging; a ragged last tile's spare lanes take its row 0)
             }
             // Sliding windows.  RING: positions live in slot (position mod window), and the position loop is
             // unrolled by a multiple of both window lengths, so every slot index is a compile-time constant and
@@ -488,7 +505,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
 
 template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1, int L1S = 0, bool PRIO = false,
           bool SEG = false, bool HEAD = true>
-int launch_g(fx_engine* e, const CnnArgs& a, size_t lds_bytes) {
+int launch_g(fx_engine* e, const CnnArgs& a_in, size_t lds_bytes) {
     constexpr int waves = WAVES;
     auto kern = k_score_cnn_mfma<A, K, FT, HT, NT, DENSE_LDS, WAVES, G1, L1S, PRIO, SEG, HEAD>;
     if (SEG) lds_bytes += (size_t)WAVES * FT * 64 * 16;          // segment-maxima slots
@@ -497,6 +514,14 @@ int launch_g(fx_engine* e, const CnnArgs& a, size_t lds_bytes) {
         FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[e->device & 63] = true;
+    }
+    CnnArgs a = a_in;
+    if (e->rows_req.on) {
+        // (a launched-first call: this kernel waits for its rows tile by tile -- the forms that share a tile among waves do not)
+        if (SEG || NT != 1 || !HEAD) return FX_EUNSUPPORTED;
+        if (!fx_rows_plan(e)) return FX_EUNSUPPORTED;
+        a.ready = e->rows_req.r;
+        e->rows_req.used = true;
     }
     int64_t U = (int64_t)a.M * a.TG;
     int64_t blocks = e->grid_blocks > 0 ? e->grid_blocks : e->num_cus;

@@ -59,7 +59,7 @@ int dispatch_a4(fx_engine* e, const CnnArgs& a0, int variant, bool big, size_t f
         // (one 8-wave workgroup per tile pays from 24 positions; spread over several 4-wave workgroups, from 13 -- shorter
         //  sequences take the quad form)
         const bool multi = HT_ == 7 && dl && e->cnn_seg < 0 && e->cnn_seg_multi && 2 * U <= e->num_cus;
-        const bool seg = e->cnn_seg != 0 && variant == 0 && !e->cnn_conv1_mfma && U <= e->num_cus &&
+        const bool seg = !e->rows_req.on && e->cnn_seg != 0 && variant == 0 && !e->cnn_conv1_mfma && U <= e->num_cus &&
                          (e->cnn_seg > 0 || L1 >= (multi ? 13 : 24)) && lds + 8 * 2 * 64 * 16 <= (size_t)e->max_lds;
         if (seg) {
             // Long sequences: cut the positions over several workgroups as well (halo: 3 positions per side).  As many
@@ -115,7 +115,9 @@ int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const
     if ((lay.FT != 2 && !(lay.FT == 1 && s.K == 5 && lay.HT == 7)) || (s.A != 4 && s.A != 20 && s.A != 2)) return FX_EUNSUPPORTED;
     if (s.K != 5 && !((s.K == 3 || s.K == 7) && lay.HT == 7)) return FX_EUNSUPPORTED;
     if (M > FX_MAX_M) return FX_EINVAL;
-    {
+    // a launched-first host call (rows arrive while the kernel runs): the whole-tile-per-wave forms of the 4-letter CNN only
+    if (e->rows_req.on && !(s.A == 4 && s.K == 5 && lay.FT == 2)) return FX_EUNSUPPORTED;
+    if (!e->rows_req.on) {
         const int rc = fx_launch_score_cnn_quad(e, models, M, d_ascii, N, d_out_NM, Mtot, m_off);
         if (rc != FX_EUNSUPPORTED) return rc;
     }

@@ -43,6 +43,7 @@ struct DenseArgs {
     // the tiles of a workgroup that do not divide among its four SIMDs are walked by groups of 8 waves (score_dense_tile.h):
     // 0 = off, else the number of groups that find room for their exchange buffers (PAIR: over the pair rows; BT: at coop_off)
     int coop, coop_off;
+    FxRowsReady ready;          // launched-first host call: the rows arrive while the kernel runs (words == nullptr: they are all there)
 };
 
 // GE first layer as a table indexed by the RAW byte: tab[l][b - base] = w1[l * A + lut[b]] for the 32 byte values from
@@ -134,7 +135,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
             // (only where the odd tile weighs: up to 8 tiles per SIMD.  The shared walk is a once-per-workgroup code path --
             //  cold in the instruction cache, five barriers -- and costs ~4 us against ~6 us for a lone wave's tile: -5 % at
             //  5 and -2..-4 % at 6 tiles per SIMD, nothing at 60, +1 % when a workgroup's range spans three members)
-            if (p.coop && cnt >= 4 && u_hi - u_lo <= 32) {
+            if (p.coop && cnt >= 4 && u_hi - u_lo <= 32 && !p.ready.words) {   // (rows that arrive during the run: no shared walk -- its bytes are asked for up front)
                 const int r = (int)(cnt & 3);
                 ncoop = (PAIR && r > p.coop) ? 0 : r;
             }
@@ -155,6 +156,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
         // their share's counter
         const int64_t s_lo = t_lo + (t_main - t_lo) * share.before / share.total;
         const int64_t s_hi = t_lo + (t_main - t_lo) * (share.before + share.mine) / share.total;
+        // launched-first call (as in score_cnn_kernel.h): the share is walked from its first block of stage 0 on, and around
+        const bool rows_arrive = !SLAB && NT == 1 && p.ready.words != nullptr;
+        int rows_rot = 0, rows_known = 0;
+        if (rows_arrive) {
+            const int64_t t0 = (s_lo + p.ready.Q - 1) / p.ready.Q * p.ready.Q;
+            if (t0 < s_hi) rows_rot = (int)(t0 - s_lo);
+        }
         for (int64_t round = 0;; ++round) {
             // SLAB: lockstep rounds of WAVES tiles; waves without a tile in the last round run along on tile 0
             int64_t tg_want = t_lo + round * WAVES + (tid >> 6);
@@ -164,6 +172,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                 pulled = __builtin_amdgcn_readfirstlane(pulled);
                 tg_want = s_lo + pulled;
                 if (tg_want >= s_hi) break;
+                if (rows_arrive) {
+                    const int len = (int)(s_hi - s_lo);
+                    int at = pulled + rows_rot;
+                    if (at >= len) at -= len;
+                    tg_want = s_lo + at;
+                    fx_rows_wait(p.ready, (int)(tg_want % p.ready.Q), rows_known, p.err);
+                }
             }
             if (SLAB && t_lo + round * WAVES >= t_hi) break;
             const bool live = !SLAB || tg_want < t_hi;
@@ -177,10 +192,11 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
             for (int nt = 0; nt < NT; ++nt) {
                 n[nt] = (tg * NT + nt) * 16 + sq;
                 row[nt] = p.ascii + (n[nt] < p.N ? n[nt] : 0) * L;
+                if (rows_arrive) row[nt] = p.ascii + tg * p.ready.pitch + (n[nt] < p.N ? sq : 0) * L;   // (tile-pitched staging)
             }
             // the tile's bytes through this wave's LDS scratch (PAIR / BT first layers); lanes past the batch use row 0
             const int64_t tile_rows = p.N - tg * 16 < 16 ? p.N - tg * 16 : 16;
-            if (p.stage_stride && (PAIR || BT)) fx_stage_tile(p.ascii + tg * 16 * L, (int)tile_rows * L, stw, lane);
+            if (p.stage_stride && (PAIR || BT)) fx_stage_tile(p.ascii + tg * (rows_arrive ? (int64_t)p.ready.pitch : (int64_t)16 * L), (int)tile_rows * L, stw, lane);
             const uint8_t* srow = stw + (n[0] < p.N ? sq : 0) * L;
             f4 h[HT][NT];
             float y[NT];
@@ -462,7 +478,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
 
 template <int KIND, int A, int HT, int NT, int WAVES, bool G1, bool W1G = false, bool DG = false, bool SLAB = false, bool BT = false,
           bool PAIR = false>
-int launch_inst(fx_engine* e, const DenseArgs& a, size_t lds_bytes) {
+int launch_inst(fx_engine* e, const DenseArgs& a_in, size_t lds_bytes) {
     auto kern = k_score_dense_mfma<KIND, A, HT, NT, WAVES, G1, W1G, DG, SLAB, BT, PAIR>;
     if (SLAB) lds_bytes += (size_t)2 * 2 * HT * 1024;           // two slabs of KG = 2 input tiles
     static bool attr_set[64] = {};
@@ -470,6 +486,14 @@ int launch_inst(fx_engine* e, const DenseArgs& a, size_t lds_bytes) {
         FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[e->device & 63] = true;
+    }
+    DenseArgs a = a_in;
+    if (e->rows_req.on) {
+        // (a launched-first call: this kernel waits for its rows tile by tile -- the lockstep slab form does not)
+        if (SLAB || NT != 1) return FX_EUNSUPPORTED;
+        if (!fx_rows_plan(e)) return FX_EUNSUPPORTED;
+        a.ready = e->rows_req.r;
+        e->rows_req.used = true;
     }
     const int64_t U = (int64_t)a.M * a.TG;
     int64_t blocks = e->grid_blocks > 0 ? e->grid_blocks : e->num_cus;
@@ -869,6 +893,7 @@ __global__ void __launch_bounds__(512) k_score_dense_pipe(DenseArgs p) {
 
 template <int KIND, int HT, int NLD, int VAR>
 int launch_pipe_var(fx_engine* e, const DenseArgs& a, size_t lds_bytes) {
+    if (e->rows_req.on) return FX_EUNSUPPORTED;             // (this form asks for the next tile's bytes a tile ahead: not for rows that arrive during the run)
     auto kern = k_score_dense_pipe<KIND, HT, NLD, VAR>;
     static bool attr_set[64] = {};
     if (!attr_set[e->device & 63]) {
@@ -925,7 +950,7 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
             if constexpr (HT_ <= 8) {
                 // software-pipelined form: one 32-position table trip per block row of the H x H layer
                 const size_t pneed = (size_t)a.Lpad * 128 + (size_t)a.lds_floats * 4 + 256 + 32 + 8 * stride;
-                if (e->dense_pipe && a.Lpad / 32 + 2 + 1 <= HT_ && s.L <= 128 && pneed <= (size_t)e->max_lds) {
+                if (e->dense_pipe && !e->rows_req.on && a.Lpad / 32 + 2 + 1 <= HT_ && s.L <= 128 && pneed <= (size_t)e->max_lds) {
                     a.stage_stride = (int)stride;
                     if (s.L <= 64) return launch_pipe<FX_GE, HT_, 1>(e, a, pneed);
                     return launch_pipe<FX_GE, HT_, 2>(e, a, pneed);
@@ -995,7 +1020,7 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
                     a.pair_floats = (int)lay.pair_floats;
 #if defined(FX_AB)
                     // software-pipelined form: one pair-row gather per block row of the two H x H layers
-                    if (e->dense_pipe && s.L / 2 + (s.L & 1) + 2 + 3 <= 2 * HT_ && s.L <= 32 && need + 8 * stride <= (size_t)e->max_lds) {
+                    if (e->dense_pipe && !e->rows_req.on && s.L / 2 + (s.L & 1) + 2 + 3 <= 2 * HT_ && s.L <= 32 && need + 8 * stride <= (size_t)e->max_lds) {
                         a.stage_stride = (int)stride;
                         return launch_pipe<FX_MLP, HT_, 1>(e, a, need + 8 * stride);
                     }
@@ -1040,7 +1065,7 @@ int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, con
     }
     if ((s.kind != FX_MLP && s.kind != FX_GE) || M > FX_MAX_M) return FX_EUNSUPPORTED;
     if (s.A > 127) return FX_EUNSUPPORTED;                        // the gathers' bad-character test ORs the codes: needs code < 0x80
-    {
+    if (!e->rows_req.on) {                                        // (a launched-first host call is big: the persistent forms only)
         const int rc = fx_launch_score_mlp_small(e, models, M, d_ascii, N, d_out_NM, Mtot, m_off);
         if (rc != FX_EUNSUPPORTED) return rc;
     }

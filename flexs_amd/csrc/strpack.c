@@ -23,6 +23,7 @@
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <pthread.h>
+#include <stdint.h>
 #include <string.h>
 #include <unistd.h>
 
@@ -36,6 +37,12 @@ typedef struct {
     int status;                        /* first failure in this share (0 = none) */
     const double* x;                   /* argmax job: n rows of L = A doubles each -> dst[row] = alphabet[argmax] */
     const unsigned char* alphabet;
+    /* staged pack job (Q > 0, pack_staged below): every thread sees ALL n items; thread `worker` of `workers` owns the lanes
+     * worker, worker + workers, ... of `lanes` */
+    int Q, lanes, worker, workers;
+    Py_ssize_t pitch;                  /* bytes from one tile's rows to the next tile's */
+    volatile unsigned* words;
+    unsigned base;
 } Share;
 
 /* `one_hot_to_string` (flexs/utils/sequence_utils.py:50-66) for rows of A doubles: dst[r] = alphabet[np.argmax(x[r])].
@@ -117,8 +124,17 @@ static void argmax_rows(const double* x, Py_ssize_t rows, Py_ssize_t A, const un
 
 /* Pack items[0 .. n) -> dst; returns 0 / 1 / 2 / 3, or 4 for a legacy (not "ready") str that needs the GIL. */
 static int pack_range(PyObject** items, unsigned char* dst, Py_ssize_t n, Py_ssize_t L, int have_gil) {
+    /* The str objects of a real batch lie scattered over the heap: object i + 8's header (and, for a short compact str, its characters,
+     * which follow the header) is asked for while object i is copied -- the list's pointer array itself is sequential. */
+    enum { AHEAD = 8 };
     for (Py_ssize_t i = 0; i < n; ++i, dst += L) {
         PyObject* s = items[i];
+        if (i + AHEAD < n) {
+            const char* nx = (const char*)items[i + AHEAD];
+            __builtin_prefetch(nx, 0, 1);
+            __builtin_prefetch(nx + 64, 0, 1);
+            if (L > 64) { __builtin_prefetch(nx + 128, 0, 1); if (L > 128) { __builtin_prefetch(nx + 192, 0, 1); __builtin_prefetch(nx + 256, 0, 1); } }
+        }
         if (!PyUnicode_Check(s)) return 3;
         if (!PyUnicode_IS_READY(s)) {
             if (!have_gil) return 4;
@@ -127,7 +143,15 @@ static int pack_range(PyObject** items, unsigned char* dst, Py_ssize_t n, Py_ssi
         if (PyUnicode_GET_LENGTH(s) != L) return 1;
         const int kind = PyUnicode_KIND(s);
         if (kind == PyUnicode_1BYTE_KIND) {
-            memcpy(dst, PyUnicode_1BYTE_DATA(s), (size_t)L);
+            const unsigned char* src = PyUnicode_1BYTE_DATA(s);
+            /* short rows (RNA / DNA landscapes: 8 .. 50 letters): two overlapping fixed-size moves instead of a call into memcpy */
+            if (L >= 8 && L <= 16) {
+                uint64_t a, b;
+                memcpy(&a, src, 8); memcpy(&b, src + L - 8, 8);
+                memcpy(dst, &a, 8); memcpy(dst + L - 8, &b, 8);
+            } else {
+                memcpy(dst, src, (size_t)L);
+            }
         } else {
             const void* data = PyUnicode_DATA(s);
             for (Py_ssize_t j = 0; j < L; ++j) {
@@ -138,6 +162,48 @@ static int pack_range(PyObject** items, unsigned char* dst, Py_ssize_t n, Py_ssi
         }
     }
     return 0;
+}
+
+/* Staged packing for a call whose kernels are already running (include/flexs_amd.h fx_score_begin_staged): the staging area is
+ * tile-pitched -- the 16 rows of tile t start at t * pitch -- and stage j = the tiles t with t % Q == j, in the order j = 0, 1, ...;
+ * lane l of `lanes` packs the l-th of `lanes` equal parts of a stage's tile list and then publishes base + j + 1 in words[l] --
+ * device memory behind the write-combining BAR mapping: a store fence in front (the rows are ordinary stores that must be visible
+ * first) and one behind (push the word out now).  Whatever happens, every lane ends at base + Q: the kernels must never be left
+ * waiting for a call that failed on the host. */
+static inline void publish(volatile unsigned* w, unsigned v) {
+#if defined(__x86_64__)
+    __builtin_ia32_sfence();
+    *w = v;
+    __builtin_ia32_sfence();
+#else
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    *w = v;
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+#endif
+}
+static int run_staged(const Share* sh) {
+    const Py_ssize_t N = sh->n, L = sh->L, pitch = sh->pitch, TG = (N + 15) / 16, Q = sh->Q;
+    PyObject** items = sh->items;
+    int status = 0;
+    for (Py_ssize_t j = 0; j < Q && !status; ++j) {
+        const Py_ssize_t nj = j < TG ? (TG - j + Q - 1) / Q : 0;          /* tiles j, j + Q, j + 2 Q, ... < TG */
+        for (int l = sh->worker; l < sh->lanes && !status; l += sh->workers) {
+            const Py_ssize_t i0 = nj * l / sh->lanes, i1 = nj * (l + 1) / sh->lanes;
+            for (Py_ssize_t i = i0; i < i1 && !status; ++i) {
+                const Py_ssize_t t = j + i * Q, r0 = t * 16;
+                const Py_ssize_t cnt = N - r0 < 16 ? N - r0 : 16;
+                if (i + 1 < i1) {                                           /* the next tile's objects lie Q tiles further on: ask for the first of them now */
+                    const Py_ssize_t nx = r0 + Q * 16;
+                    for (Py_ssize_t r = 0; r < 8 && nx + r < N; ++r) __builtin_prefetch((const char*)items[nx + r], 0, 1);
+                }
+                status = pack_range(items + r0, sh->dst + t * pitch, cnt, L, 0);
+            }
+        }
+        if (!status)
+            for (int l = sh->worker; l < sh->lanes; l += sh->workers) publish(sh->words + l, sh->base + (unsigned)j + 1u);
+    }
+    for (int l = sh->worker; l < sh->lanes; l += sh->workers) publish(sh->words + l, sh->base + (unsigned)Q);
+    return status;
 }
 
 /* ---- persistent pool ---- */
@@ -196,7 +262,8 @@ static void* worker_main(void* arg) {
         seen = g_epoch;
         Share* sh = &g_share[id];
         pthread_mutex_unlock(&g_mu);
-        if (sh->items) sh->status = pack_range(sh->items, sh->dst, sh->n, sh->L, 0);
+        if (sh->Q > 0) sh->status = run_staged(sh);
+        else if (sh->items) sh->status = pack_range(sh->items, sh->dst, sh->n, sh->L, 0);
         else { argmax_rows(sh->x, sh->n, sh->L, sh->alphabet, sh->dst); sh->status = 0; }
         pthread_mutex_lock(&g_mu);
         if (--g_pending == 0) pthread_cond_signal(&g_done);
@@ -227,6 +294,7 @@ static int want_threads(Py_ssize_t bytes) {
 }
 
 static int run_share(const Share* sh, Py_ssize_t first, Py_ssize_t count) {
+    if (sh->Q > 0) return run_staged(sh);                              /* (a staged job's threads all see the whole batch) */
     if (sh->items) return pack_range(sh->items + first, sh->dst + first * sh->L, count, sh->L, 0);
     argmax_rows(sh->x + first * sh->L, count, sh->L, sh->alphabet, sh->dst + first);
     return 0;
@@ -249,6 +317,7 @@ static int job_parallel(const Share* job, Py_ssize_t n, int threads) {
     pthread_mutex_lock(&g_mu);
     if (g_busy) {
         pthread_mutex_unlock(&g_mu);
+        if (job->Q > 0) { Share all = *job; all.worker = 0; all.workers = 1; return run_staged(&all); }
         return run_share(job, 0, n);
     }
     g_busy = 1;
@@ -268,6 +337,7 @@ static int job_parallel(const Share* job, Py_ssize_t n, int threads) {
     for (int w = 0; w < used; ++w) {
         const Py_ssize_t cnt = (at_row + per <= n) ? per : (n - at_row);
         g_share[w] = *job;
+        if (job->Q > 0) { g_share[w].worker = w + 1; g_share[w].workers = used + 1; g_share[w].status = 0; continue; }
         if (items) { g_share[w].items = items + at_row; g_share[w].dst = dst + at_row * L; }
         else { g_share[w].x = job->x + at_row * L; g_share[w].dst = dst + at_row; }
         g_share[w].n = cnt;
@@ -280,7 +350,9 @@ static int job_parallel(const Share* job, Py_ssize_t n, int threads) {
     if (used) pthread_cond_broadcast(&g_go);
     pthread_mutex_unlock(&g_mu);
 
-    int status = run_share(job, 0, per < n ? per : n);
+    int status;
+    if (job->Q > 0) { Share mine = *job; mine.worker = 0; mine.workers = used + 1; status = run_staged(&mine); }
+    else status = run_share(job, 0, per < n ? per : n);
 
     if (hot_enabled()) {                                                /* the helpers are about as far as the caller: look before sleeping */
         const unsigned long long t0 = hot_clock();
@@ -293,6 +365,40 @@ static int job_parallel(const Share* job, Py_ssize_t n, int threads) {
     for (int w = 0; w < used && status == 0; ++w) status = g_share[w].status;   /* first failing share in row order */
     pthread_mutex_unlock(&g_mu);
     return status;
+}
+
+/* pack_staged(seqs, L, staging_address, stages, tile_pitch, lanes, words_address, base) -> status as `pack` (5 = a legacy str object made
+ * the helpers give up: the caller abandons the call and takes the plain path).  lanes_for(bytes) -> how many packing threads a batch of that size gets. */
+static PyObject* pack_staged(PyObject* self, PyObject* args) {
+    PyObject* seqs;
+    Py_ssize_t L;
+    unsigned long long dst_addr, words_addr;
+    int Q, lanes, pitch;
+    unsigned int base;
+    if (!PyArg_ParseTuple(args, "OnKiiiKI", &seqs, &L, &dst_addr, &Q, &pitch, &lanes, &words_addr, &base)) return NULL;
+    PyObject* fast = PySequence_Fast(seqs, "expected a list or tuple of str");
+    if (!fast) return NULL;
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(fast);
+    if (L < 1 || Q < 1 || pitch < 16 * L || lanes < 1 || lanes > 16 || !dst_addr || !words_addr) {
+        Py_DECREF(fast);
+        PyErr_SetString(PyExc_ValueError, "strpack.pack_staged: bad arguments");
+        return NULL;
+    }
+    Share job;
+    memset(&job, 0, sizeof job);
+    job.items = PySequence_Fast_ITEMS(fast); job.dst = (unsigned char*)(uintptr_t)dst_addr; job.n = n; job.L = L;
+    job.Q = Q; job.pitch = pitch; job.lanes = lanes; job.words = (volatile unsigned*)(uintptr_t)words_addr; job.base = base;
+    int threads = want_threads(n * L);
+    if (threads > lanes) threads = lanes;
+    long status = threads > 1 ? job_parallel(&job, n, threads) : job_parallel(&job, n, 1);
+    if (status == 4) status = 5;
+    Py_DECREF(fast);
+    return PyLong_FromLong(status);
+}
+static PyObject* lanes_for(PyObject* self, PyObject* args) {
+    Py_ssize_t bytes;
+    if (!PyArg_ParseTuple(args, "n", &bytes)) return NULL;
+    return PyLong_FromLong(want_threads(bytes));
 }
 
 static PyObject* pack(PyObject* self, PyObject* args) {
@@ -584,6 +690,8 @@ static PyObject* set_threads(PyObject* self, PyObject* args) {
 
 static PyMethodDef methods[] = {
     {"pack", pack, METH_VARARGS, "pack(seqs, L, out[, start, count]) -> status (0 ok, 1 ragged, 2 non-latin-1 character, 3 not a str)"},
+    {"pack_staged", pack_staged, METH_VARARGS, "pack_staged(seqs, L, staging_address, stages, tile_pitch, lanes, words_address, base) -> status (as pack; 5 = legacy str objects: abandon, take the plain path)"},
+    {"lanes_for", lanes_for, METH_VARARGS, "lanes_for(bytes) -> packing threads a batch of that many bytes gets"},
     {"score_small", score_small, METH_VARARGS, "score_small(plan, seqs, out) -> 0 ok, -1 not applicable, 1001..1003 packing status, FX error code (2000 + |code| if negative)"},
     {"decode_argmax", decode_argmax, METH_VARARGS, "decode_argmax(x_float64, rows, A, alphabet_bytes, out_uint8) -> 0 ok, 1 bad arguments: out[r] = alphabet[argmax of row r] (NumPy's first-max / NaN rule)"},
     {"population_step", population_step, METH_VARARGS, "population_step(plan, x_float64, rows, A, alphabet_bytes, chars_uint8, scores_float32) -> (status, list of str | None): argmax decode + fx_score through the plan + the rows as str"},

@@ -230,6 +230,20 @@ int fx_score_begin(fx_engine *e, fx_model *const *models, int M, int64_t N, int 
                    const uint8_t lut[256], int want_nm, int want_mean, void **staging);
 int fx_score_submit(fx_engine *e, int64_t row0, int64_t rows);
 int fx_score_finish(fx_engine *e, float *out_NM, float *out_mean);
+/* The same call launched FIRST and packed behind (replaces nothing in the reference -- its `get_fitness` encodes, then
+ * predicts, keras_model.py:69-79; this is how the encoding of a big list of str hides behind the GPU's work): the kernels
+ * are enqueued by this function and read the staging area tile by tile as the caller fills it.  The staging area of such a
+ * call is TILE-PITCHED: the (up to) 16 rows of tile t, L bytes each, start at t * *tile_pitch (16 L rounded up to whole
+ * 128-byte lines).  The caller packs in STAGES -- stage j = the tiles t with t % *stages == j -- split over `lanes` packing
+ * threads (lane l takes the l-th of `lanes` equal parts of each stage's tile list), and after finishing its part of stage j
+ * lane l stores *base + j + 1 into words[l] (device memory mapped into the host: a store fence in front of the store and
+ * one behind it), then calls fx_score_finish as for the call in pieces -- after fx_score_abandon if it could not pack
+ * every row (finish then only waits for the kernels; the results are meaningless).  FX_EUNSUPPORTED = not for this call
+ * (nothing enqueued, no call in flight): use fx_score_begin or fx_score.  Engine option launch_first = 0 turns it off. */
+int fx_score_begin_staged(fx_engine *e, fx_model *const *models, int M, int64_t N, int L,
+                          const uint8_t lut[256], int want_nm, int want_mean, int lanes,
+                          void **staging, void **words, unsigned *base, int *stages, int *tile_pitch);
+int fx_score_abandon(fx_engine *e);
 
 /* The engine's pinned, GPU-mapped input staging area, grown to at least `bytes`.  A caller that
  * marshals its strings straight into it (instead of into pageable memory) and then passes the
