@@ -397,6 +397,26 @@ def end_to_end_block(device, configs=None):
             t0 = time.perf_counter(); model.get_fitness(seqs); ts.append(time.perf_counter() - t0)
         t = float(np.median(ts))
         row = {"value": n / t, "unit": "sequences/s", "wall_ms": t * 1e3, "n": n}
+        # launched first, packed behind (fx_score_begin_staged) where the plan and the kernel allow it: the A/B beside it
+        eng_ab = mods[0]._engine()
+        try:
+            c0 = eng_ab.get_option("launch_first_calls")
+            model.get_fitness(seqs)
+            row["launched_first"] = bool(eng_ab.get_option("launch_first_calls") - c0)
+            if row["launched_first"]:
+                eng_ab.set_option("launch_first", 0)
+                model.get_fitness(seqs)
+                ts = []
+                for _ in range(5 if Lx > 100 else 9):
+                    t0 = time.perf_counter(); model.get_fitness(seqs); ts.append(time.perf_counter() - t0)
+                row["wall_ms_packed_first"] = float(np.median(ts)) * 1e3
+        except Exception:                                   # (a library without the option: the row stays as it is)
+            pass
+        finally:
+            try:
+                eng_ab.set_option("launch_first", 1)
+            except Exception:
+                pass
         if strpack is not None:
             row["pack_ms"] = pack_ms(seqs, Lx, 0)
             row["pack_1thread_ms"] = pack_ms(seqs, Lx, 1)
@@ -699,6 +719,7 @@ def flat_scalars(out):
             tag = key.split()[0].lower()                            # C2 / C3 / C4 / C5
             put(f"e2e_{tag}_seq_per_s", v.get("value")); put(f"e2e_{tag}_wall_ms", v.get("wall_ms"))
             put(f"e2e_{tag}_frac_of_kernel", v.get("frac_of_kernel_rate"))
+            put(f"e2e_{tag}_wall_ms_packed_first", v.get("wall_ms_packed_first"))
     for k, pre in (("small_call_us", "small_call"), ("small_call_us_launch_per_call", "small_call_launched")):
         for n, v in (e2e.get(k) or {}).items():
             put(f"{pre}_n{n}_us", v, 3)

@@ -315,6 +315,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "zero_copy_bytes")) return &e->zero_copy_bytes;
     if (!std::strcmp(key, "zero_copy_mode")) return &e->zero_copy_mode;
     if (!std::strcmp(key, "launch_first")) return &e->launch_first;
+    if (!std::strcmp(key, "cnn_stage_host")) return &e->cnn_stage_host;
     if (!std::strcmp(key, "train_rows")) return &e->train_rows;
     if (!std::strcmp(key, "train_lds")) return &e->train_lds;
     if (!std::strcmp(key, "train_threads")) return &e->train_threads;

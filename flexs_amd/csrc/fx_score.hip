@@ -17,6 +17,13 @@ extern "C" {
 
 // ------------------------------------------------------------------ scoring
 
+// (for the launchers: the sequences of the launches enqueued while this lives are read from pinned host memory)
+struct HostBytes {
+    fx_engine* e;
+    explicit HostBytes(fx_engine* e_) : e(e_) { e->ascii_host = true; }
+    ~HostBytes() { e->ascii_host = false; }
+};
+
 // planar_stride == 0: d_NM is the row-major (N, M) matrix of the ABI; > 0: M member planes that far apart.
 int score_dispatch(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N, int L,
                           float* d_NM, int64_t planar_stride) {
@@ -251,6 +258,7 @@ int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii,
         FX_HIP(e, hipHostGetDevicePointer(&dm_out, h_out, 0));
         float* m_NM = (float*)dm_out;
         float* m_mean = (float*)((char*)dm_out + nm_bytes);
+        HostBytes host_bytes(e);
         if (host_mean) {
             e->call_prof_ns[0] = server_since(e);
             // a pre-launched instance of exactly this call (the caller is back within the idle window): no launch, no weight fill
@@ -377,6 +385,7 @@ static int staged_enqueue(fx_engine* e, bool* waits) {
     e->rows_min_share = TG / (nb > 0 ? nb : 1) / 4;
     e->rows_req.on = true; e->rows_req.used = false;
     e->rows_req.r = FxRowsReady{c.words, c.base, c.lanes, 0, c.pitch};
+    HostBytes host_bytes(e);
     int rc;
     if (c.stride) rc = score_then_mean(e, c.models.data(), M, (const uint8_t*)dm_in, c.N, c.L, c.d_nm, c.stride, m_mean);
     else {
@@ -474,6 +483,7 @@ int fx_score_submit(fx_engine* e, int64_t row0, int64_t rows) {
         float* m_nm = (float*)dm_out + row0 * M;
         float* m_mean = (float*)((char*)dm_out + nm_bytes) + row0;
         float* nm = c.want_nm ? m_nm : c.d_nm + row0 * M;
+        HostBytes host_bytes(e);
         if ((rc = score_dispatch(e, c.models.data(), M, (const uint8_t*)dm_in + row0 * c.L, rows, c.L, nm))) return rc;
         if (c.want_mean && (rc = fx_launch_ensemble_reduce(e, nm, rows, M, nullptr, m_mean, nullptr))) return rc;
         const int k = c.pieces;

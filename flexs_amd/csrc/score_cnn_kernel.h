@@ -45,6 +45,7 @@ struct CnnArgs {
     unsigned* seg_cnt;
     // packed-layout offsets (floats)
     int off_first, off_c2, off_c3, off_cb, off_w1p, conv_floats, off_d1, off_d2, off_db, total_floats;
+    int stw_stride;             // STG: bytes of LDS scratch per wave (16 L rounded up to 16)
     FxRowsReady ready;          // launched-first host call: the rows arrive while the kernel runs (words == nullptr: they are all there)
 };
 
@@ -58,8 +59,9 @@ struct CnnArgs {
 // (= B-operand) layout and a separate head kernel (score_cnn_split.hip) finishes the sequence.  Used for the CNN
 // shapes whose (kernel size, hidden width) pair has no fused instantiation.
 template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1, int L1S = 0, bool PRIO = false,
-          bool SEG = false, bool HEAD = true>
+          bool SEG = false, bool HEAD = true, bool STG = false>
 __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
+    static_assert(!STG || (!SEG && NT == 1), "STG copies ONE whole tile's bytes into the wave's LDS scratch");
     static_assert(HEAD || (NT == 1 && !DENSE_LDS), "the conv-only form is one tile per wave, conv weights in LDS");
     static_assert(!SEG || (NT == 1 && L1S == 0 && K * (A - 1) <= 16), "SEG is the ring-window, one-tile form");
     constexpr int K3 = A - 1;
@@ -77,6 +79,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
     int* next_tile = reinterpret_cast<int*>(smem + lds_floats + 64);   // 4 work counters (one per SIMD), after the 256-byte LUT
     int* simd_waves = next_tile + 4;                                   // 4 wave counts (workgroup's waves per SIMD)
     int* stage_ctl = simd_waves + 4;                                   // staged fill: [0] next chunk, [1] chunks in LDS
+    // STG (the sequences lie in HOST memory, read over PCIe -- the zero-copy host calls): the 16 x L bytes of a tile are brought into
+    // this wave's LDS scratch with ONE 16-byte load per lane and the position loop picks its bytes from there.  Reads of host memory
+    // are served by no cache: the byte load per position and lane group of the form below was a PCIe round trip each (~2 us), which
+    // four waves per SIMD hide in a long launch but not at 1-2 tiles per wave (profiles/r5_e2e_breakdown.log: 98 us against 62 us for
+    // the 1e5-sequence launch with the bytes in HBM).
+    [[maybe_unused]] uint8_t* stw = reinterpret_cast<uint8_t*>(smem + lds_floats + 64 + 12) + (tid >> 6) * p.stw_stride;
 
     fx_stamp(p.trace, 0);
     if (p.wave_prio) fx_stagger_priority();
@@ -171,6 +179,17 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                 row[nt] = p.ascii + (n[nt] < p.N ? n[nt] : 0) * L;   // out-of-range lanes recompute seq 0
                 if (rows_arrive) row[nt] = p.ascii + tg * p.ready.pitch + (n[nt] < p.N ? sq : 0) * L;   // (tile-pitched staging; a ragged last tile's spare lanes take its row 0)
             }
+            [[maybe_unused]] fx_lds_u8p srow = nullptr;
+            if constexpr (STG) {
+                const int64_t tile_rows = p.N - tg * 16 < 16 ? p.N - tg * 16 : 16;
+                fx_stage_tile(p.ascii + tg * (rows_arrive ? (int64_t)p.ready.pitch : (int64_t)16 * L), (int)tile_rows * L, stw, lane);
+                srow = (fx_lds_u8p)(stw + (n[0] < p.N ? sq : 0) * L);
+            }
+            // a byte of this lane's sequence
+            auto seq_byte = [&](int nt, int at) -> int {
+                if constexpr (STG) return (int)srow[at];
+                else return (int)row[nt][at];
+            };
             // Sliding windows.  RING: positions live in slot (position mod window), and the position loop is
             // unrolled by a multiple of both window lengths, so every slot index is a compile-time constant and
             // nothing is ever moved.  Otherwise (19-tap protein window, A/B baseline only) slots are shifted.
@@ -182,7 +201,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
             for (int j = 0; j < K - 1; ++j)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    int c = lut_s[row[nt][j]];
+                    int c = lut_s[seq_byte(nt, j)];
                     if (c == 0xFF) { bad = true; c = 0; }
                     cw[RING ? j : j + 1][nt] = c;         // (shifting form: moved down at the top of step 0)
                 }
@@ -239,7 +258,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                 for (int q = 0; q < PF; ++q)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        rq[q][nt] = (s_first + K - 1 + q < L) ? (int)row[nt][s_first + K - 1 + q] : 0;
+                        rq[q][nt] = (s_first + K - 1 + q < L) ? seq_byte(nt, s_first + K - 1 + q) : 0;
             }
             for (int s0 = s_first; s0 < s_stop; s0 += UN) {
 #pragma unroll
@@ -283,7 +302,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         int raw;
-                        if (!AHEAD) raw = row[nt][s + K - 1];
+                        if (!AHEAD) raw = seq_byte(nt, s + K - 1);
                         else {
                             // oldest entry of the look-ahead queue; its slot takes the byte PF positions further on
                             const int slot = RING ? u % PF : 0;
@@ -292,7 +311,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
 #pragma unroll
                                 for (int q = 0; q + 1 < PF; ++q) rq[q][nt] = rq[q + 1][nt];
                             }
-                            if (s + K - 1 + PF < L) rq[RING ? slot : PF - 1][nt] = row[nt][s + K - 1 + PF];
+                            if (s + K - 1 + PF < L) rq[RING ? slot : PF - 1][nt] = seq_byte(nt, s + K - 1 + PF);
                         }
                         int c = lut_s[raw];
                         if (c == 0xFF) { bad = true; c = 0; }
@@ -504,11 +523,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
 }
 
 template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1, int L1S = 0, bool PRIO = false,
-          bool SEG = false, bool HEAD = true>
+          bool SEG = false, bool HEAD = true, bool STG = false>
 int launch_g(fx_engine* e, const CnnArgs& a_in, size_t lds_bytes) {
     constexpr int waves = WAVES;
-    auto kern = k_score_cnn_mfma<A, K, FT, HT, NT, DENSE_LDS, WAVES, G1, L1S, PRIO, SEG, HEAD>;
+    auto kern = k_score_cnn_mfma<A, K, FT, HT, NT, DENSE_LDS, WAVES, G1, L1S, PRIO, SEG, HEAD, STG>;
     if (SEG) lds_bytes += (size_t)WAVES * FT * 64 * 16;          // segment-maxima slots
+    if (STG) lds_bytes += (size_t)WAVES * ((16 * (size_t)a_in.L + 15) / 16 * 16);   // a tile's bytes per wave
     static bool attr_set[64] = {};
     if (!attr_set[e->device & 63]) {
         FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -516,6 +536,7 @@ int launch_g(fx_engine* e, const CnnArgs& a_in, size_t lds_bytes) {
         attr_set[e->device & 63] = true;
     }
     CnnArgs a = a_in;
+    a.stw_stride = STG ? (int)((16 * (size_t)a.L + 15) / 16 * 16) : 0;
     if (e->rows_req.on) {
         // (a launched-first call: this kernel waits for its rows tile by tile -- the forms that share a tile among waves do not)
         if (SEG || NT != 1 || !HEAD) return FX_EUNSUPPORTED;

@@ -13,6 +13,21 @@ int dispatch_a4(fx_engine* e, const CnnArgs& a0, int variant, bool big, size_t f
     const size_t lds = dl ? full : conv_only;
     if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
     if constexpr (HT_ == 7) {
+        // the sequences lie in host memory (zero-copy host calls): the forms that copy a tile's bytes into LDS first (STG) -- same
+        // walk, same bits -- where the scratch fits beside the weights
+        if (e->ascii_host && e->cnn_stage_host && dl && (variant == 0 || variant == 7 || variant == 10 || variant == 11) &&
+            lds + 16 * ((16 * (size_t)a.L + 15) / 16 * 16) <= (size_t)e->max_lds) {
+            a.TG = (a.N + 15) / 16;
+            const int64_t U = (int64_t)a.M * a.TG;
+            const bool seg_size = e->cnn_seg != 0 && U <= e->num_cus;       // (explorer-size launches keep their own forms below)
+            if (!seg_size) {
+                if (big && a.L == 8) return launch_g<4, 5, 2, 7, 1, true, 16, true, 4, true, false, true, true>(e, a, lds);
+                if (big && a.L == 14) return launch_g<4, 5, 2, 7, 1, true, 16, true, 10, true, false, true, true>(e, a, lds);
+                if (big) return launch_g<4, 5, 2, 7, 1, true, 16, true, 0, false, false, true, true>(e, a, lds);
+                if (a.L == 8) return launch_g<4, 5, 2, 7, 1, true, 8, true, 4, true, false, true, true>(e, a, lds);
+                return launch_g<4, 5, 2, 7, 1, true, 8, true, 0, false, false, true, true>(e, a, lds);
+            }
+        }
         // canonical short landscapes get a fully unrolled position loop with s_setprio around the MFMA clusters
         // (+5 % and +2-4 % resp., interleaved A/B: profiles/archive/r1_run9, r1_run16, r1_run18):
         // TF-binding (L = 8) and the RNA landscapes (L = 14)

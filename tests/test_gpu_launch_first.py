@@ -1,0 +1,159 @@
+"""GPU tests of the launched-first host call (include/flexs_amd.h fx_score_begin_staged): a big list of str is scored by kernels that
+were enqueued BEFORE the strings were packed and wait, tile by tile, for the packing threads.  Same bits as the packed-first call,
+the reference's exceptions, a device that never hangs on a host that stops packing."""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+
+import flexs_amd
+from flexs_amd import _native, synth
+from flexs_amd.baselines import models as bm
+from flexs_amd.utils import sequence_utils as s_utils
+
+from gpu_common import eng, rand_seqs  # noqa: F401  (eng: the session fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(kind, L, alpha, M):
+    make = {"cnn": lambda s: bm.CNN(L, 32, 100, alpha, seed=s), "mlp": lambda s: bm.MLP(L, 100, alpha, seed=s),
+            "ge": lambda s: bm.GlobalEpistasisModel(L, 100, alpha, seed=s)}[kind]
+    members = [make(s) for s in range(M)]
+    return members[0] if M == 1 else flexs_amd.Ensemble(members)
+
+
+def _counts(eng):
+    return eng.get_option("launch_first_calls"), eng.get_option("launch_first_redone")
+
+
+@pytest.fixture
+def launch_first(eng):
+    yield eng
+    eng.set_option("launch_first", 1)
+
+
+# (kind, L, alphabet, members, strings, launched first?)  -- the last column is what the plan is expected to say on an MI355X:
+# zero-copy shapes with at least two tiles per SIMD launch first; the protein CNN's pair form and copy-planned calls do not
+CASES = [("cnn", 8, "TGCA", 1, 100_003, True), ("cnn", 8, "TGCA", 3, 70_001, True), ("cnn", 14, "UGCA", 1, 50_000, True),
+         ("cnn", 50, "UGCA", 3, 33_000, True), ("mlp", 14, "UGCA", 1, 100_000, True), ("mlp", 14, "UGCA", 3, 40_001, True),
+         ("ge", 14, "UGCA", 1, 100_000, None), ("mlp", 50, "UGCA", 1, 40_000, None), ("cnn", 90, s_utils.AAS, 1, 33_000, False),
+         ("cnn", 8, "TGCA", 1, 32_768, True), ("cnn", 8, "TGCA", 3, 250_000, True)]
+
+
+@pytest.mark.parametrize("kind,L,alpha,M,n,expect", CASES)
+def test_launched_first_call_gives_the_packed_first_bits(launch_first, kind, L, alpha, M, n, expect):
+    eng = launch_first
+    model = _model(kind, L, alpha, M)
+    _, seqs = rand_seqs(n, L, alpha, seed=n % 97)
+    eng.set_option("launch_first", 0)
+    c0 = _counts(eng)
+    want = np.asarray(model.get_fitness(seqs)).copy()
+    assert _counts(eng) == c0                                   # (the option is honoured)
+    eng.set_option("launch_first", 1)
+    got = np.asarray(model.get_fitness(seqs))
+    c1 = _counts(eng)
+    assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert c1[1] == c0[1]                                       # nothing had to be redone
+    if expect is not None:
+        assert (c1[0] - c0[0] == 1) == expect, "the plan changed: update CASES (or the planner)"
+    again = np.asarray(model.get_fitness(tuple(seqs)))           # tuples too; and the second call of a row finds warm buffers
+    assert np.array_equal(again.view(np.uint32), want.view(np.uint32))
+    if M > 1:                                                    # the matrix path (BO's combine_with = identity)
+        ident = flexs_amd.Ensemble(model.models, combine_with=lambda x: x)
+        eng.set_option("launch_first", 0)
+        want_nm = ident.get_fitness(seqs).copy()
+        eng.set_option("launch_first", 1)
+        assert np.array_equal(ident.get_fitness(seqs).view(np.uint32), want_nm.view(np.uint32))
+
+
+def test_launched_first_call_raises_what_the_reference_raises(launch_first):
+    eng = launch_first
+    L, alpha, n = 8, "TGCA", 70_001
+    ens = _model("cnn", L, alpha, 3)
+    _, seqs = rand_seqs(n, L, alpha, seed=5)
+    want = ens.get_fitness(seqs).copy()
+    c0 = _counts(eng)
+    assert c0[0] > 0
+    # first tile of stage 0, the middle, the ragged last tile; a character outside the alphabet, outside latin-1, a wrong length, a non-str
+    for pos, bad, exc in ((0, "TGCAZGCA", ValueError), (n // 2, "TGCAZGCA", ValueError), (n - 1, "TGCAZGCA", ValueError),
+                          (n - 5, "TGCA", ValueError), (17, "TGCATGCAT", ValueError), (60_000, 7, TypeError), (3, "TGCATΔCA", ValueError)):
+        broken = list(seqs)
+        broken[pos] = bad
+        with pytest.raises(exc):
+            ens.get_fitness(broken)
+        assert np.array_equal(ens.get_fitness(seqs), want)       # the engine is usable afterwards, and nothing of the failed call is left
+    assert _counts(eng)[0] - c0[0] == 14
+    assert ens.get_fitness([]).shape == (0,)
+
+
+def test_explorer_size_calls_around_a_launched_first_call(launch_first):
+    """The resident workgroups of explorer-size calls and a launched-first launch on the same engine: each leaves the other's answers alone."""
+    eng = launch_first
+    L, alpha = 8, "TGCA"
+    ens = _model("cnn", L, alpha, 3)
+    _, big = rand_seqs(60_000, L, alpha, seed=8)
+    _, small = rand_seqs(40, L, alpha, seed=9)
+    want_big, want_small = ens.get_fitness(big).copy(), ens.get_fitness(small).copy()
+    for _ in range(3):
+        for _ in range(5):
+            assert np.array_equal(ens.get_fitness(small), want_small)
+        assert np.array_equal(ens.get_fitness(big), want_big)
+    assert np.array_equal(ens.get_fitness(small), want_small)
+
+
+def test_a_host_that_stops_packing_does_not_hang_the_device(launch_first):
+    """The kernels of a launched-first call give up on rows that do not come within 0.25 s (FX_ERR_STARVED) instead of waiting for
+    ever; fx_score_finish then runs the launch once more over the rows the caller has packed since."""
+    eng = launch_first
+    if not _native._HAS_PACK_STAGED:
+        pytest.skip("no _strpack.pack_staged in this build")
+    L, alpha, n = 8, "TGCA", 50_000
+    model = _model("cnn", L, alpha, 1)
+    _, seqs = rand_seqs(n, L, alpha, seed=3)
+    want = model.get_fitness(seqs).copy()
+    lib, nm, lut = eng._lib, model.native(), model._lut
+    arr = (_native._vp * 1)(nm.handle)
+    p, w, base, stages, pitch = _native._vp(), _native._vp(), C.c_uint(0), C.c_int(0), C.c_int(0)
+    redone = _counts(eng)[1]
+    rc = lib.fx_score_begin_staged(eng.handle, arr, 1, n, L, _native._lut_ptr(lut), 1, 0, 4, C.byref(p), C.byref(w), C.byref(base),
+                                   C.byref(stages), C.byref(pitch))
+    assert rc == _native.FX_OK and stages.value >= 2 and pitch.value == 128
+    time.sleep(0.4)                                              # nobody packs: the waves time out
+    assert _native._strpack.pack_staged(seqs, L, p.value, stages.value, pitch.value, 4, w.value, base.value) == 0
+    out = np.empty((n, 1), np.float32)
+    eng.check(lib.fx_score_finish(eng.handle, _native._ptr(out), None))
+    assert np.array_equal(out[:, 0], want)
+    assert _counts(eng)[1] == redone + 1
+    # ... and a caller that gives up altogether: finish only waits
+    rc = lib.fx_score_begin_staged(eng.handle, arr, 1, n, L, _native._lut_ptr(lut), 1, 0, 4, C.byref(p), C.byref(w), C.byref(base),
+                                   C.byref(stages), C.byref(pitch))
+    assert rc == _native.FX_OK
+    eng.check(lib.fx_score_abandon(eng.handle))
+    eng.check(lib.fx_score_finish(eng.handle, _native._ptr(out), None))
+    assert np.array_equal(model.get_fitness(seqs), want)
+    # misuse: no call in flight
+    assert lib.fx_score_abandon(eng.handle) == _native.FX_ESTATE
+
+
+@pytest.mark.parametrize("L,alpha,M,n", [(8, "TGCA", 3, 70_001), (14, "UGCA", 1, 40_000), (8, "TGCA", 1, 6_000), (50, "UGCA", 3, 9_001), (23, "TGCA", 2, 33_000)])
+def test_host_resident_bytes_through_lds_give_the_same_bits(launch_first, L, alpha, M, n):
+    """Zero-copy host calls of the 4-letter CNN copy a tile's bytes into LDS with one wide load (engine option cnn_stage_host = 1)
+    instead of a byte load over PCIe per position: the same walk, the same bits, launched first or not."""
+    eng = launch_first
+    model = _model("cnn", L, alpha, M)
+    b, seqs = rand_seqs(n, L, alpha, seed=11)
+    got = {}
+    try:
+        for stage in (0, 1):
+            eng.set_option("cnn_stage_host", stage)
+            for first in (0, 1):
+                eng.set_option("launch_first", first)
+                got[stage, first] = np.asarray(model.get_fitness(seqs)).copy()
+            got[stage, "bytes"] = np.asarray(model.get_fitness(b)).copy()     # (packed bytes in: the plain host call)
+    finally:
+        eng.set_option("cnn_stage_host", 1)
+    want = got[0, 0].view(np.uint32)
+    for key, v in got.items():
+        assert np.array_equal(v.view(np.uint32), want), key

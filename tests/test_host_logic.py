@@ -1034,3 +1034,33 @@ def test_nam_device_mirror_follows_the_cache_without_walking_it():
     m._note_new_keys(["QQQ"]); m.cache["QQQ"] = 3.0
     state = m.__getstate__()               # what copy / pickle carry: no device mirror, no pending note
     assert state["_pending"] == [] and state["_dev_keys"] == [] and state["_dev_cache"] is None and "QQQ" in state["cache"]
+
+
+def test_staged_packing_fills_a_tile_pitched_area_and_publishes_every_lane():
+    """`_strpack.pack_staged` (the host half of a launched-first call, include/flexs_amd.h fx_score_begin_staged): the rows of tile t
+    land at t * pitch, every lane's word ends at base + stages whatever happens, the statuses are `pack`'s."""
+    from flexs_amd import _native, synth
+    sp = _native._strpack
+    if sp is None or not hasattr(sp, "pack_staged"):
+        pytest.skip("_strpack was not built")
+    for n, L, Q, lanes in ((100_000, 14, 7, 8), (1000, 8, 3, 4), (33, 5, 2, 1), (100_001, 8, 19, 8), (5000, 90, 4, 16), (70, 14, 3, 2),
+                           (40, 8, 9, 3)):                       # (more stages than tiles: the empty ones are published too)
+        ref = np.asarray(synth.random_sequence_bytes(n, L, "ACGT", 3)).reshape(n, L)
+        seqs = synth.bytes_to_strings(ref)
+        pitch, TG = (16 * L + 127) // 128 * 128, (n + 15) // 16
+        dst = np.full(TG * pitch, 0xEE, np.uint8)
+        words = np.zeros(16, np.uint32)
+        assert sp.pack_staged(seqs, L, dst.ctypes.data, Q, pitch, lanes, words.ctypes.data, 4096) == 0
+        tiles = dst.reshape(TG, pitch)
+        assert (tiles[:, :16 * L].reshape(TG * 16, L)[:n] == ref).all()
+        assert (tiles[:, 16 * L:] == 0xEE).all()                 # the padding of a tile is never written
+        assert (words[:lanes] == 4096 + Q).all() and (words[lanes:] == 0).all()
+        for pos, bad, status in ((n // 2, "A" * (L + 1), 1), (n - 1, "A" * (L - 1) + "\u0394", 2), (0, 7, 3)):
+            broken = list(seqs)
+            broken[pos] = bad
+            words[:] = 0
+            assert sp.pack_staged(broken, L, dst.ctypes.data, Q, pitch, lanes, words.ctypes.data, 8192) == status
+            assert (words[:lanes] == 8192 + Q).all()             # the kernels are never left waiting
+    assert sp.lanes_for(100) == 1 and 1 <= sp.lanes_for(1 << 24) <= 16
+    with pytest.raises(ValueError):
+        sp.pack_staged(["ACGT"], 4, 1, 2, 16, 1, 1, 0)           # pitch < 16 L

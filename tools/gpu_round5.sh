@@ -20,6 +20,10 @@ python tools/summarize_pmc.py $OUT/pmc_bench.json $OUT/pmc_bench.md fetch=$OUT/p
 # (back in the repo: python tools/flatten_pmc.py gpurun_out/r5f/pmc_bench.json profiles/r5_pmc_bench.json <commit>  -- the form bench.py reads)
 timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_lp -o lp -- python tools/runs/r4_lp_prof.py > $OUT/rocprof_lp.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_train -o tr -- python tools/runs/r3_train_prof.py > $OUT/rocprof_train.log 2>&1
+timeout 200 python tools/runs/r5_launch_first.py > $OUT/launch_first.log 2>&1
+timeout 100 python tools/runs/r5_launch_first_parts.py >> $OUT/launch_first.log 2>&1
+timeout 100 python tools/runs/r5_e2e_breakdown.py > $OUT/e2e_breakdown.log 2>&1
+timeout 100 python tools/runs/r5_stage_host_ab.py > $OUT/stage_host_ab.log 2>&1
 cp gpurun_out/parity_error_stats.json $OUT/ 2>/dev/null
 find $OUT -name "*counter_collection.csv" -size +2M -delete
 find $OUT -name "*_kernel_trace.csv" -size +1M -delete
