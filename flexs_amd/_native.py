@@ -275,7 +275,7 @@ def sequences_to_bytes(sequences, L: Optional[int] = None, staging: Optional["En
     return out
 
 
-CHUNKED_MIN_ROWS = int(os.environ.get("FLEXS_AMD_CHUNKED_MIN_ROWS", 32768))   # list[str] batches from this size on are packed and scored in overlapping pieces
+CHUNKED_MIN_ROWS = int(os.environ.get("FLEXS_AMD_CHUNKED_MIN_ROWS", 16384))   # list[str] batches from this size on are launched first and packed behind where the engine can (score_strings), else packed and scored in overlapping pieces where that pays (16384: where ensembles start to gain, profiles/r5_launch_first_mid.log)
 CHUNK_BYTES = int(os.environ.get("FLEXS_AMD_CHUNK_BYTES", 0))   # target bytes per piece (0 = auto, see score_strings)
 
 

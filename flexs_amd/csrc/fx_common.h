@@ -431,7 +431,7 @@ __device__ __forceinline__ void fx_rows_wait(const FxRowsReady& r, int stage, in
 #pragma unroll
         for (int o = 8; o >= 1; o >>= 1) { const int other = __shfl_xor(have, o); have = other < have ? other : have; }   // (lanes 0 .. 15 hold every word)
         have = __builtin_amdgcn_readfirstlane(have);
-        known = have < 0 ? 0 : (have > r.Q ? r.Q : have);        // (a value of an earlier call lies below this call's base)
+        known = (have < 0 || have > r.Q) ? 0 : have;             // (a value of an earlier call lies below this call's base; nothing of this call lies above base + Q)
         if (stage < known) break;
         if (wall_clock64() - t0 > 25000000ull) { if (lane == 0) fx_raise(err, FX_ERR_STARVED); known = r.Q; break; }
         __builtin_amdgcn_s_sleep(64);                            // (~1.7 us: a thousand waiting waves must not flood the line the host stores into)

@@ -9,6 +9,13 @@
  *                          2           some character does not fit one byte           (caller raises)
  *                          3           some item is not a str                         (caller raises)
  *   set_threads(n) -> previous value   worker threads for big batches (0 = auto: min(8, cores / 2))
+ *   pack_staged(seqs, L, staging, stages, tile_pitch, lanes, words, base) -> status as pack, 5 = take the plain path
+ *                                      round 5: the host half of a call whose kernels are ALREADY running (fx_score_begin_staged):
+ *                                      tiles packed stage by stage into a tile-pitched area, progress published through the BAR
+ *   lanes_for(bytes) -> threads such a batch gets
+ *
+ * Round 5: the next object's header (and a short str's characters, which follow it) is prefetched eight items ahead -- a real batch's
+ * strings lie scattered over the heap -- and rows of 8 .. 16 characters move as two overlapping 8-byte words instead of a memcpy call.
  *
  * Round 3: big batches are packed by several threads.  A str object is immutable, so the workers only READ object
  * headers and character buffers -- no reference counts, no allocation, no Python API call.  The CALLING thread keeps the

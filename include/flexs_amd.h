@@ -98,6 +98,9 @@ const char *fx_last_error(fx_engine *e);
  *                              round 3 fx_decode_score, fx_min_dist / fx_cache_min_dist, fx_nam_combine, fx_table_*.
  *   zero_copy_mode    -1       larger host calls: -1 = decide per call (fx_plan_host_call), 0 = always copy,
  *                              1 = always zero-copy.
+ *   launch_first      1        1 = fx_score_begin_staged is offered (big zero-copy calls of callers that marshal strings:
+ *                              kernels enqueued before the strings are packed); 0 = it answers FX_EUNSUPPORTED.  Needs a
+ *                              large BAR, as serve_small does.  Read-only companions: launch_first_calls, launch_first_redone.
  *   serve_small       1        1 = explorer-size fx_score calls of canonical 4-letter CNNs (seq_len <= 16), MLPs and
  *                              GlobalEpistasis models -- one model, an ensemble, or a mix -- are answered by workgroups
  *                              that STAY on the device between calls (request and answer through mailboxes; no launch):

@@ -258,7 +258,7 @@ def test_distributed_ensemble_without_a_process_group(eng, kind, L, alpha, M, n)
 
 
 def test_big_string_batches_are_scored_in_overlapping_pieces(eng):
-    """list[str] batches of >= 32768 sequences take the chunked host call (fx_score_begin / _submit / _finish):
+    """list[str] batches of >= 16384 sequences take the launched-first or the chunked host call (fx_score_begin / _submit / _finish):
     same scores, cost accounting and exceptions as the one-piece call."""
     L, alpha, N = 8, "TGCA", 70_001
     members = [bm.CNN(L, 32, 100, alpha, seed=s) for s in range(3)]

@@ -39,7 +39,8 @@ def launch_first(eng):
 CASES = [("cnn", 8, "TGCA", 1, 100_003, True), ("cnn", 8, "TGCA", 3, 70_001, True), ("cnn", 14, "UGCA", 1, 50_000, True),
          ("cnn", 50, "UGCA", 3, 33_000, True), ("mlp", 14, "UGCA", 1, 100_000, True), ("mlp", 14, "UGCA", 3, 40_001, True),
          ("ge", 14, "UGCA", 1, 100_000, None), ("mlp", 50, "UGCA", 1, 40_000, None), ("cnn", 90, s_utils.AAS, 1, 33_000, False),
-         ("cnn", 8, "TGCA", 1, 32_768, True), ("cnn", 8, "TGCA", 3, 250_000, True)]
+         ("cnn", 8, "TGCA", 1, 32_768, True), ("cnn", 8, "TGCA", 3, 250_000, True), ("mlp", 14, "UGCA", 3, 16_384, True),
+         ("cnn", 8, "TGCA", 1, 16_400, False)]
 
 
 @pytest.mark.parametrize("kind,L,alpha,M,n,expect", CASES)
@@ -151,7 +152,9 @@ def test_host_resident_bytes_through_lds_give_the_same_bits(launch_first, L, alp
             for first in (0, 1):
                 eng.set_option("launch_first", first)
                 got[stage, first] = np.asarray(model.get_fitness(seqs)).copy()
-            got[stage, "bytes"] = np.asarray(model.get_fitness(b)).copy()     # (packed bytes in: the plain host call)
+            members = model.models if M > 1 else [model]                      # (packed bytes in: the plain host call)
+            nm, mean = eng.score([m.native() for m in members], b, members[0]._lut, want_matrix=(M == 1), want_mean=(M > 1))
+            got[stage, "bytes"] = (nm[:, 0] if M == 1 else mean).copy()
     finally:
         eng.set_option("cnn_stage_host", 1)
     want = got[0, 0].view(np.uint32)

@@ -13,7 +13,8 @@ for tag, model, L, alpha, n in (("1xCNN L=8", bm.CNN(8, 32, 100, "TGCA", seed=0)
     model.get_fitness(seqs)
     nm = model.native(); lut = model._lut
     arr = (_native._vp * 1)(nm.handle)
-    dst = np.empty((n, L), np.uint8); words = np.zeros(16, np.uint32)
+    pitch = (16 * L + 127) // 128 * 128
+    dst = np.empty((n, L), np.uint8); dst_t = np.empty(((n + 15) // 16) * pitch, np.uint8); words = np.zeros(16, np.uint32)
     lanes = sp.lanes_for(n * L)
     def t(f, k=15):
         ts = []
@@ -23,7 +24,7 @@ for tag, model, L, alpha, n in (("1xCNN L=8", bm.CNN(8, 32, 100, "TGCA", seed=0)
     print(tag, "lanes", lanes)
     print("  plain pack into numpy: %.0f us" % t(lambda: sp.pack(seqs, L, dst, 0, n)))
     for Q in (1, 2, 6, 24):
-        print("  staged pack, %d stages, words in host memory: %.0f us" % (Q, t(lambda: sp.pack_staged(seqs, L, dst.ctypes.data, Q, 16, lanes, words.ctypes.data, 4096))))
+        print("  staged pack, %d stages, words in host memory: %.0f us" % (Q, t(lambda: sp.pack_staged(seqs, L, dst_t.ctypes.data, Q, pitch, lanes, words.ctypes.data, 4096))))
     rows = []
     for _ in range(15):
         p, w, base, stages, brows = _native._vp(), _native._vp(), C.c_uint(0), C.c_int(0), C.c_int(0)
@@ -42,5 +43,5 @@ for tag, model, L, alpha, n in (("1xCNN L=8", bm.CNN(8, 32, 100, "TGCA", seed=0)
     print("  launched first (%d stages): begin %.0f us, staged pack %.0f us, finish %.0f us" % (stages.value, r[0], r[1], r[2]))
     # the same staged packing into the pinned area with the words in device memory, no kernel running
     p2 = _native.sequences_to_bytes(seqs[:16], L=L, staging=eng)
-    print("  staged pack into the pinned area, words behind the BAR, GPU idle: %.0f us" % t(lambda: sp.pack_staged(seqs, L, p.value, stages.value, brows.value, lanes, w.value, base.value + 8192)))
+    print("  staged pack into the pinned area, words behind the BAR, GPU idle: %.0f us" % t(lambda: sp.pack_staged(seqs, L, p.value, stages.value, brows.value, lanes, w.value, base.value - 4096)))
     print("  plain pack into the pinned area: %.0f us" % t(lambda: _native.sequences_to_bytes(seqs, L=L, staging=eng)))
