@@ -410,6 +410,17 @@ def end_to_end_block(device, configs=None):
                 for _ in range(5 if Lx > 100 else 9):
                     t0 = time.perf_counter(); model.get_fitness(seqs); ts.append(time.perf_counter() - t0)
                 row["wall_ms_packed_first"] = float(np.median(ts)) * 1e3
+                # ... and with the results handed out in place (FLEXS_AMD_RESULTS_IN_PLACE = 1, opt-in: see flexs_amd/_native.py)
+                eng_ab.set_option("launch_first", 1)
+                prev_in_place, _native.RESULTS_IN_PLACE = _native.RESULTS_IN_PLACE, 1
+                try:
+                    model.get_fitness(seqs)
+                    ts = []
+                    for _ in range(5 if Lx > 100 else 9):
+                        t0 = time.perf_counter(); model.get_fitness(seqs); ts.append(time.perf_counter() - t0)
+                    row["wall_ms_results_in_place"] = float(np.median(ts)) * 1e3
+                finally:
+                    _native.RESULTS_IN_PLACE = prev_in_place
         except Exception:                                   # (a library without the option: the row stays as it is)
             pass
         finally:
@@ -720,6 +731,7 @@ def flat_scalars(out):
             put(f"e2e_{tag}_seq_per_s", v.get("value")); put(f"e2e_{tag}_wall_ms", v.get("wall_ms"))
             put(f"e2e_{tag}_frac_of_kernel", v.get("frac_of_kernel_rate"))
             put(f"e2e_{tag}_wall_ms_packed_first", v.get("wall_ms_packed_first"))
+            put(f"e2e_{tag}_wall_ms_results_in_place", v.get("wall_ms_results_in_place"))
     for k, pre in (("small_call_us", "small_call"), ("small_call_us_launch_per_call", "small_call_launched")):
         for n, v in (e2e.get(k) or {}).items():
             put(f"{pre}_n{n}_us", v, 3)

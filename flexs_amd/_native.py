@@ -60,8 +60,10 @@ SIGNATURES = {
     "fx_score_stream_rows": (C.c_int, [_vp, C.c_int64]),
     "fx_score_stream_end": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "fx_score_begin_staged": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int64, C.c_int, _u8p, C.c_int, C.c_int, C.c_int,
-                                        C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_uint), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+                                        C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_uint), C.POINTER(C.c_int), C.POINTER(C.c_int), _vp]),
     "fx_score_abandon": (C.c_int, [_vp]),
+    "fx_result_alloc": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp)]),
+    "fx_result_free": (C.c_int, [_vp, _vp]),
     "fx_score_begin": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int64, C.c_int, _u8p, C.c_int, C.c_int, C.POINTER(_vp)]),
     "fx_score_submit": (C.c_int, [_vp, C.c_int64, C.c_int64]),
     "fx_score_finish": (C.c_int, [_vp, _vp, _vp]),
@@ -321,6 +323,53 @@ def score_small(engine: "Engine", plan: bytes, seqs, M: int, want_mean: bool) ->
     _raise(-(st - 2000) if st > 2000 else st, engine.handle)
 
 
+# 1 = launched-first calls hand their results out IN PLACE: arrays over pinned buffers of a pool, no copy (~10 us of a 1e5-string call).
+# Opt-in: such an array is ordinary memory to NumPy, but pinned allocations are not inherited by a fork()ed child -- a child that reads
+# a result array it inherited (instead of receiving it pickled) would fault -- which a drop-in for `get_fitness` must not risk by default.
+RESULTS_IN_PLACE = int(os.environ.get("FLEXS_AMD_RESULTS_IN_PLACE", 0))
+
+
+class _ResultPool:
+    """Pinned, GPU-mapped result buffers (fx_result_alloc) for the calls whose kernels write the scores straight into the memory the
+    caller gets back: the array wraps the buffer and the buffer returns to the pool when the array's last view dies.  Bounded -- a
+    caller that keeps every result alive simply gets ordinary arrays (a copy) from the 17th outstanding buffer or the 257th MiB on;
+    buffers are never handed back to HIP before the process ends (an array may outlive the engine object)."""
+    MAX_OUT, MAX_BYTES = 16, 256 << 20
+
+    def __init__(self, engine: "Engine"):
+        self._engine = engine
+        self._free: Dict[int, list] = {}
+        self._out = 0
+        self._bytes = 0
+
+    def take(self, nbytes: int):
+        cap = 1 << max(int(nbytes - 1).bit_length(), 16)
+        free = self._free.get(cap)
+        if free:
+            addr = free.pop()
+        else:
+            if self._out >= self.MAX_OUT or self._bytes + cap > self.MAX_BYTES:
+                return None
+            p = _vp()
+            if self._engine._lib.fx_result_alloc(self._engine.handle, cap, C.byref(p)) != FX_OK:
+                return None
+            addr = p.value
+            self._bytes += cap
+        self._out += 1
+        return addr, cap
+
+    def give_back(self, addr: int, cap: int):
+        self._out -= 1
+        self._free.setdefault(cap, []).append(addr)
+
+    def wrap(self, addr: int, cap: int, parts):
+        """float32 arrays over one leased buffer: parts = [(byte offset, shape), ...]; the lease ends with the last of their views."""
+        import weakref
+        raw = (C.c_char * cap).from_address(addr)
+        weakref.finalize(raw, self.give_back, addr, cap)
+        return [np.frombuffer(raw, np.float32, int(np.prod(shape)), offset=off).reshape(shape) for off, shape in parts]
+
+
 def _raise_pack_status(status: int):
     """What the reference raises for a batch `_strpack` could not pack (string_to_one_hot's np.array / str.index failures)."""
     if status == 1:
@@ -373,6 +422,12 @@ class Engine:
     def check(self, rc: int):
         if rc != FX_OK:
             _raise(rc, self.handle)
+
+    def _results(self) -> "_ResultPool":
+        pool = self.__dict__.get("_result_pool")
+        if pool is None:
+            pool = self.__dict__["_result_pool"] = _ResultPool(self)
+        return pool
 
     # ---- options / sync / timing
     def set_option(self, key: str, value: int):
@@ -469,23 +524,42 @@ class Engine:
             # latency and most of the kernel's run lie beside the packing instead of behind it
             lanes = min(_strpack.lanes_for(N * L), 16)
             p, w, base, stages, pitch = _vp(), _vp(), C.c_uint(0), C.c_int(0), C.c_int(0)
+            nm_res = 4 * N * M if want_matrix else 0
+            lease = self._results().take(nm_res + (4 * N if want_mean else 0)) if RESULTS_IN_PLACE else None
             rc = self._lib.fx_score_begin_staged(self.handle, arr, M, N, L, _lut_ptr(lut), int(want_matrix), int(want_mean), lanes,
-                                                 C.byref(p), C.byref(w), C.byref(base), C.byref(stages), C.byref(pitch))
+                                                 C.byref(p), C.byref(w), C.byref(base), C.byref(stages), C.byref(pitch),
+                                                 _vp(lease[0]) if lease else None)
             if rc == FX_OK:
-                status = 3
+                status, handed_out = 3, False
                 try:
                     status = _strpack.pack_staged(seqs, L, p.value, stages.value, pitch.value, lanes, w.value, base.value)
                 finally:
                     if status:
                         self._lib.fx_score_abandon(self.handle)
-                    out_nm = np.empty((N, M), np.float32) if want_matrix else None
-                    out_mean = np.empty((N,), np.float32) if want_mean else None
-                    rc = self._lib.fx_score_finish(self.handle, _ptr(out_nm), _ptr(out_mean))
+                    try:
+                        if lease:
+                            out_nm = out_mean = None
+                            rc = self._lib.fx_score_finish(self.handle, None, None)
+                            if status == 0 and rc == FX_OK:
+                                parts = ([(0, (N, M))] if want_matrix else []) + ([(nm_res, (N,))] if want_mean else [])
+                                views = self._results().wrap(lease[0], lease[1], parts)
+                                handed_out = True
+                                out_nm = views[0] if want_matrix else None
+                                out_mean = views[-1] if want_mean else None
+                        else:
+                            out_nm = np.empty((N, M), np.float32) if want_matrix else None
+                            out_mean = np.empty((N,), np.float32) if want_mean else None
+                            rc = self._lib.fx_score_finish(self.handle, _ptr(out_nm), _ptr(out_mean))
+                    finally:
+                        if lease and not handed_out:
+                            self._results().give_back(*lease)
                 if status == 5:         # (legacy str objects need the GIL: the plain path)
                     return self.score(models, sequences_to_bytes(seqs, L=L, staging=self), lut, want_matrix=want_matrix, want_mean=want_mean)
                 _raise_pack_status(status)
                 self.check(rc)
                 return out_nm, out_mean
+            if lease:
+                self._results().give_back(*lease)
             if rc != FX_EUNSUPPORTED:
                 self.check(rc)
         if chunks <= 0:

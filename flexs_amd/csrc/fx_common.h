@@ -339,6 +339,7 @@ struct fx_engine {
         int64_t row0[32] = {}, rows[32] = {};
         uint8_t lut[256] = {};      // staged: for a plain second attempt
         unsigned* words = nullptr; unsigned base = 0; int lanes = 0, Q = 0, pitch = 0;
+        bool in_place = false;      // staged: the results area is the caller's (fx_result_alloc): finish copies nothing
         bool packed_ok = true;      // staged: the caller packed every row (fx_score_finish_staged says otherwise)
         bool redo = false;          // staged: the launch did not wait for rows after all (never expected), or raised an error word: redo the plain way
         bool staged = false;        // launched first: the kernels are already enqueued and wait for the rows (fx_score_begin_staged)

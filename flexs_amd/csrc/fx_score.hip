@@ -370,7 +370,7 @@ int fx_score_begin(fx_engine* e, fx_model* const* models, int M, int64_t N, int 
 static int staged_enqueue(fx_engine* e, bool* waits) {
     auto& c = e->chunked;
     const int M = (int)c.models.size();
-    const size_t nm_bytes = sizeof(float) * (size_t)c.N * (size_t)M;
+    const size_t nm_bytes = c.want_nm ? sizeof(float) * (size_t)c.N * (size_t)M : 0;   // (the results area: the matrix if wanted, then the mean)
     void *dm_in = nullptr, *dm_out = nullptr;
     FX_HIP(e, hipHostGetDevicePointer(&dm_in, c.h_in, 0));
     FX_HIP(e, hipHostGetDevicePointer(&dm_out, c.h_out, 0));
@@ -400,7 +400,8 @@ static int staged_enqueue(fx_engine* e, bool* waits) {
 }
 
 int fx_score_begin_staged(fx_engine* e, fx_model* const* models, int M, int64_t N, int L, const uint8_t lut[256],
-                          int want_nm, int want_mean, int lanes, void** staging, void** words, unsigned* base, int* stages, int* tile_pitch) {
+                          int want_nm, int want_mean, int lanes, void** staging, void** words, unsigned* base, int* stages, int* tile_pitch,
+                          void* results) {
     int rc = validate_models(e, models, M, L, lut);
     if (rc) return rc;
     if (N < 1 || !staging || !words || !base || !stages || !tile_pitch || (!want_nm && !want_mean) || lanes < 1 || lanes > 16)
@@ -420,9 +421,13 @@ int fx_score_begin_staged(fx_engine* e, fx_model* const* models, int M, int64_t 
     void *d_in = nullptr, *h_in = nullptr, *h_out = nullptr, *d_out = nullptr;
     const int64_t stride = (!want_nm && M <= 16) ? planar_stride_for(N) : 0;
     const size_t inter_bytes = stride ? sizeof(float) * (size_t)stride * (size_t)M : nm_bytes;
-    if ((rc = fx_scratch(e, 0, in_bytes + 16, &d_in))) return rc;
-    if ((rc = fx_pinned(e, 0, in_bytes, &h_in))) return rc;
-    if ((rc = fx_pinned(e, 1, nm_bytes + mean_bytes, &h_out))) return rc;
+    if ((rc = fx_pinned(e, 0, in_bytes, &h_in))) return rc;     // (no device copy of the input: the kernels read this)
+    if (results) {
+        // results in place: the kernels write into the caller's own pinned buffer (fx_result_alloc) and fx_score_finish copies nothing
+        void* probe = nullptr;
+        if (hipHostGetDevicePointer(&probe, results, 0) != hipSuccess) { (void)hipGetLastError(); return fx_fail(e, FX_EINVAL, "fx_score_begin_staged: results is not memory of fx_result_alloc"); }
+        h_out = results;
+    } else if ((rc = fx_pinned(e, 1, nm_bytes + mean_bytes, &h_out))) return rc;
     if ((rc = fx_scratch(e, 1, inter_bytes + mean_bytes, &d_out))) return rc;
     if ((rc = fx_upload_lut(e, lut))) return rc;
     auto& c = e->chunked;
@@ -433,7 +438,7 @@ int fx_score_begin_staged(fx_engine* e, fx_model* const* models, int M, int64_t 
     c.h_out = (char*)h_out;
     c.pieces = 0; c.zero_copy = true; c.stride = stride;
     e->rows_base += 4096u;
-    c.words = w; c.base = e->rows_base; c.lanes = lanes; c.pitch = pitch; c.packed_ok = true;
+    c.words = w; c.base = e->rows_base; c.lanes = lanes; c.pitch = pitch; c.packed_ok = true; c.in_place = results != nullptr;
     bool waits = false;
     rc = staged_enqueue(e, &waits);
     if (rc && !waits) return rc;                           // (FX_EUNSUPPORTED: nothing was enqueued)
@@ -443,6 +448,27 @@ int fx_score_begin_staged(fx_engine* e, fx_model* const* models, int M, int64_t 
     e->counters.host_calls += 1; e->counters.zero_copy_calls += 1; e->counters.sequences += N; e->counters.forwards += N * M;
     e->launch_first_calls += 1;
     *staging = h_in; *words = w; *base = c.base; *stages = c.Q; *tile_pitch = pitch;
+    return FX_OK;
+}
+
+// Pinned, GPU-mapped host memory for results that are handed out in place (fx_score_begin_staged's `results`): the caller owns it
+// -- typically a pool behind the arrays that wrap it -- and gives it back with fx_result_free when nothing refers to it any more.
+int fx_result_alloc(fx_engine* e, int64_t bytes, void** host) {
+    if (!e || bytes < 1 || !host) return FX_EINVAL;
+    FX_HIP(e, hipSetDevice(e->device));
+    void* p = nullptr;
+    if (hipHostMalloc(&p, (size_t)bytes, hipHostMallocMapped) != hipSuccess) {
+        (void)hipGetLastError();
+        return fx_fail(e, FX_ENOMEM, "hipHostMalloc of a result buffer failed");
+    }
+    *host = p;
+    return FX_OK;
+}
+int fx_result_free(fx_engine* e, void* host) {
+    if (!e || !host) return FX_EINVAL;
+    FX_HIP(e, hipSetDevice(e->device));
+    FX_HIP(e, hipStreamSynchronize(e->stream));           // (nothing in flight writes into it)
+    FX_HIP(e, hipHostFree(host));
     return FX_OK;
 }
 
@@ -562,8 +588,10 @@ int fx_score_finish(fx_engine* e, float* out_NM, float* out_mean) {
             if ((rc = wait_for_results(e))) return rc;
         }
         if ((rc = check_deferred(e))) return rc;
+        if (c.in_place) return FX_OK;                      // (the caller's buffer holds the matrix, then the mean)
+        const size_t nm_res = c.want_nm ? nm_bytes : 0;
         if (c.want_nm && out_NM) std::memcpy(out_NM, c.h_out, nm_bytes);
-        if (c.want_mean && out_mean) std::memcpy(out_mean, c.h_out + nm_bytes, sizeof(float) * (size_t)c.N);
+        if (c.want_mean && out_mean) std::memcpy(out_mean, c.h_out + nm_res, sizeof(float) * (size_t)c.N);
         return FX_OK;
     }
     // piece by piece: the host copies piece k out of the pinned area while the GPU still works on the later ones

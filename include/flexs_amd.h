@@ -245,8 +245,16 @@ int fx_score_finish(fx_engine *e, float *out_NM, float *out_mean);
  * (nothing enqueued, no call in flight): use fx_score_begin or fx_score.  Engine option launch_first = 0 turns it off. */
 int fx_score_begin_staged(fx_engine *e, fx_model *const *models, int M, int64_t N, int L,
                           const uint8_t lut[256], int want_nm, int want_mean, int lanes,
-                          void **staging, void **words, unsigned *base, int *stages, int *tile_pitch);
+                          void **staging, void **words, unsigned *base, int *stages, int *tile_pitch,
+                          void *results);
 int fx_score_abandon(fx_engine *e);
+/* `results` of fx_score_begin_staged (nullable): a buffer of fx_result_alloc of at least (want_nm ? 4 N M : 0) +
+ * (want_mean ? 4 N : 0) bytes that the kernels write the (N, M) matrix and then the mean INTO -- fx_score_finish then
+ * copies nothing (its out_NM / out_mean are ignored) and the caller wraps the buffer (NumPy: an array whose base owns the
+ * buffer and gives it back to a pool when the last view dies).  Pinned, GPU-mapped host memory; free with fx_result_free
+ * once nothing refers to it. */
+int fx_result_alloc(fx_engine *e, int64_t bytes, void **host);
+int fx_result_free(fx_engine *e, void *host);
 
 /* The engine's pinned, GPU-mapped input staging area, grown to at least `bytes`.  A caller that
  * marshals its strings straight into it (instead of into pageable memory) and then passes the

@@ -119,7 +119,7 @@ def test_a_host_that_stops_packing_does_not_hang_the_device(launch_first):
     p, w, base, stages, pitch = _native._vp(), _native._vp(), C.c_uint(0), C.c_int(0), C.c_int(0)
     redone = _counts(eng)[1]
     rc = lib.fx_score_begin_staged(eng.handle, arr, 1, n, L, _native._lut_ptr(lut), 1, 0, 4, C.byref(p), C.byref(w), C.byref(base),
-                                   C.byref(stages), C.byref(pitch))
+                                   C.byref(stages), C.byref(pitch), None)
     assert rc == _native.FX_OK and stages.value >= 2 and pitch.value == 128
     time.sleep(0.4)                                              # nobody packs: the waves time out
     assert _native._strpack.pack_staged(seqs, L, p.value, stages.value, pitch.value, 4, w.value, base.value) == 0
@@ -129,7 +129,7 @@ def test_a_host_that_stops_packing_does_not_hang_the_device(launch_first):
     assert _counts(eng)[1] == redone + 1
     # ... and a caller that gives up altogether: finish only waits
     rc = lib.fx_score_begin_staged(eng.handle, arr, 1, n, L, _native._lut_ptr(lut), 1, 0, 4, C.byref(p), C.byref(w), C.byref(base),
-                                   C.byref(stages), C.byref(pitch))
+                                   C.byref(stages), C.byref(pitch), None)
     assert rc == _native.FX_OK
     eng.check(lib.fx_score_abandon(eng.handle))
     eng.check(lib.fx_score_finish(eng.handle, _native._ptr(out), None))
@@ -160,3 +160,59 @@ def test_host_resident_bytes_through_lds_give_the_same_bits(launch_first, L, alp
     want = got[0, 0].view(np.uint32)
     for key, v in got.items():
         assert np.array_equal(v.view(np.uint32), want), key
+
+
+def test_results_in_place_are_ordinary_arrays_over_leased_pinned_buffers(launch_first, monkeypatch):
+    """FLEXS_AMD_RESULTS_IN_PLACE=1: a launched-first call's kernels write into a pinned buffer that the returned array wraps (no copy);
+    the buffer goes back to the pool with the array's last view, a caller that hoards results gets ordinary arrays, a failed call leaks
+    nothing."""
+    import gc
+    eng = launch_first
+    monkeypatch.setattr(_native, "RESULTS_IN_PLACE", 1)
+    L, alpha, n = 8, "TGCA", 70_001
+    ens = _model("cnn", L, alpha, 3)
+    _, seqs = rand_seqs(n, L, alpha, seed=13)
+    monkeypatch.setattr(_native, "RESULTS_IN_PLACE", 0)
+    want = ens.get_fitness(seqs).copy()
+    want_nm = flexs_amd.Ensemble(ens.models, combine_with=lambda x: x).get_fitness(seqs).copy()
+    monkeypatch.setattr(_native, "RESULTS_IN_PLACE", 1)
+    pool = eng._results()
+    out0 = pool._out
+    got = ens.get_fitness(seqs)
+    assert got.dtype == np.float32 and got.shape == (n,) and np.array_equal(got, want)
+    assert pool._out == out0 + 1 and not got.flags.owndata
+    view = got[10:20]
+    got += 1.0                                                   # writable, like any result array
+    assert np.array_equal(got, want + 1.0)
+    del got
+    gc.collect()
+    assert pool._out == out0 + 1                                 # the view keeps the lease
+    assert np.array_equal(view, want[10:20] + 1.0)
+    del view
+    gc.collect()
+    assert pool._out == out0
+    # matrix and mean of one call share a lease
+    nm, mean = eng.score_strings([m.native() for m in ens.models], seqs, L, ens.models[0]._lut, want_matrix=True, want_mean=True)
+    assert np.array_equal(nm, want_nm) and np.array_equal(mean, want) and pool._out == out0 + 1
+    del nm
+    gc.collect()
+    assert pool._out == out0 + 1 and np.array_equal(mean, want)
+    del mean
+    gc.collect()
+    assert pool._out == out0
+    # a hoarder: beyond the pool's bound the results are ordinary arrays
+    kept = [ens.get_fitness(seqs) for _ in range(_native._ResultPool.MAX_OUT + 3)]
+    assert all(np.array_equal(k, want) for k in kept)
+    assert pool._out == _native._ResultPool.MAX_OUT and sum(k.flags.owndata for k in kept) >= 3
+    del kept
+    gc.collect()
+    assert pool._out == out0
+    # a failed call gives its lease back
+    broken = list(seqs)
+    broken[n // 3] = "TGCAZGCA"
+    with pytest.raises(ValueError):
+        ens.get_fitness(broken)
+    broken[n // 3] = "TGC"
+    with pytest.raises(ValueError):
+        ens.get_fitness(broken)
+    assert pool._out == out0 and np.array_equal(ens.get_fitness(seqs), want)
