@@ -25,6 +25,17 @@
 // fence of agent or system scope after the poll cost the 1024 waves of a launch ~85 us, and reading the rows with system-scope
 // loads instead cost the MLP launch 50-120 us: profiles/r5_launch_first.log).
 // words == nullptr: the call's rows are all there, N x L contiguous (every other call).
+// Relay inside a launched-first launch of an ENSEMBLE whose members would each read the rows over PCIe again (M x the bytes: what made
+// zero-copy ruinous for 8 x GlobalEpistasis L = 90): member 0's workgroups read a tile from the host staging area, score it, and
+// pass its bytes on to device memory (`dst`, same tile pitch; device-scope stores, then flags[tile] = seq); the other members' waves
+// wait for the tile's flag and read it from there (device-scope loads).  The rows cross PCIe ONCE and the upload runs beside the
+// scoring instead of in front of it.  flags == nullptr: no relay.
+struct FxRelay {
+    uint8_t* dst;
+    unsigned* flags;            // one word per tile
+    unsigned seq;               // this call's value (never 0)
+};
+
 struct FxRowsReady {
     const unsigned* words;      // one unsigned per lane, all in one 64-byte line (one request per poll)
     unsigned base;              // this call's origin of the counts (stale values of earlier calls compare as "nothing yet")
@@ -315,7 +326,10 @@ struct fx_engine {
     int64_t fuse_mean = 0;      // 1 = explorer-size CNN ensemble calls average in the scoring kernel (last member to finish a tile, tickets + device-scope fences) instead of launching the mean kernel.  Bit-identical, but the two fences cost what the 3 us launch saves: 32.1 vs 32.2 us per call (profiles/r3_fused_mean_ab.log): off, kept as the A/B
     // launched-first host call (fx_score_begin_staged): what the launchers that can wait for rows copy into their arguments, and
     // whether the launch just enqueued did (a launcher that cannot returns FX_EUNSUPPORTED before it enqueues anything)
-    struct { bool on = false, used = false; FxRowsReady r = {nullptr, 0, 0, 0, 0}; } rows_req;
+    struct { bool on = false, used = false; FxRowsReady r = {nullptr, 0, 0, 0, 0}; FxRelay relay = {nullptr, nullptr, 0}; bool relay_used = false; } rows_req;
+    unsigned* relay_flags = nullptr; size_t relay_flag_words = 0; unsigned relay_seq = 0;
+    int64_t launch_relay = 1;   // 1 = launched-first calls of dense ensembles whose plan says "copy" relay the rows through member 0's workgroups (0 = such calls pack, upload, then launch: A/B)
+    int64_t launch_relay_calls = 0;
     int64_t rows_min_share = 0;                          // (request) tiles in the shortest per-SIMD share of the launch
     unsigned* rows_words = nullptr;                      // 16 lines of device memory the host stores into (large BAR), or null
     bool rows_refused = false;
@@ -339,6 +353,7 @@ struct fx_engine {
         int64_t row0[32] = {}, rows[32] = {};
         uint8_t lut[256] = {};      // staged: for a plain second attempt
         unsigned* words = nullptr; unsigned base = 0; int lanes = 0, Q = 0, pitch = 0;
+        bool relay = false;         // staged: member 0's workgroups pass the rows on through d_in (FxRelay)
         bool in_place = false;      // staged: the results area is the caller's (fx_result_alloc): finish copies nothing
         bool packed_ok = true;      // staged: the caller packed every row (fx_score_finish_staged says otherwise)
         bool redo = false;          // staged: the launch did not wait for rows after all (never expected), or raised an error word: redo the plain way
@@ -417,6 +432,20 @@ int fx_trace_buffer(fx_engine* e, unsigned long long** out);
 #if defined(__HIPCC__)
 __device__ __forceinline__ void fx_raise(unsigned* err, unsigned bit) {
     __hip_atomic_store(err, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// Relay reader: wave-uniform wait for flags[tile] == seq (device scope; the tile's bytes were stored before the flag, both past the
+// caches).  Gives up like fx_rows_wait.
+__device__ __forceinline__ void fx_relay_wait(const unsigned* flag, unsigned seq, unsigned* err) {
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        unsigned v = 0;
+        if ((threadIdx.x & 63) == 0) v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = __builtin_amdgcn_readfirstlane(v);
+        if (v == seq) break;
+        if (wall_clock64() - t0 > 25000000ull) { if ((threadIdx.x & 63) == 0) fx_raise(err, FX_ERR_STARVED); break; }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 // Wave-uniform: returns when the rows of stage `stage` are in the staging area.  `known` = stages this wave has already seen
 // published (the words are only read again for a later stage: once the host has finished packing, one poll settles the rest of the

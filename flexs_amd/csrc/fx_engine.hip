@@ -238,6 +238,7 @@ int fx_engine_destroy(fx_engine* e) {
     if (e->h_done) (void)hipHostFree(e->h_done);
     if (e->lp_mail) (void)hipFree(e->lp_mail);
     if (e->rows_words) (void)hipFree(e->rows_words);
+    if (e->relay_flags) (void)hipFree(e->relay_flags);
     if (e->h_lp_state) (void)hipHostFree(e->h_lp_state);
     for (int i = 0; i < fx_engine::MAX_PIECES; ++i) {
         if (e->ev_in[i]) (void)hipEventDestroy(e->ev_in[i]);
@@ -316,6 +317,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "zero_copy_mode")) return &e->zero_copy_mode;
     if (!std::strcmp(key, "launch_first")) return &e->launch_first;
     if (!std::strcmp(key, "cnn_stage_host")) return &e->cnn_stage_host;
+    if (!std::strcmp(key, "launch_relay")) return &e->launch_relay;
     if (!std::strcmp(key, "train_rows")) return &e->train_rows;
     if (!std::strcmp(key, "train_lds")) return &e->train_lds;
     if (!std::strcmp(key, "train_threads")) return &e->train_threads;
@@ -381,6 +383,7 @@ int fx_engine_get_option(fx_engine* e, const char* key, int64_t* value) {
     if (e && key && !std::strcmp(key, "lp_armed_served")) { *value = e->lp_armed_served; return FX_OK; }
     if (e && key && !std::strcmp(key, "launch_first_calls")) { *value = e->launch_first_calls; return FX_OK; }
     if (e && key && !std::strcmp(key, "launch_first_redone")) { *value = e->launch_first_redone; return FX_OK; }
+    if (e && key && !std::strcmp(key, "launch_relay_calls")) { *value = e->launch_relay_calls; return FX_OK; }
     if (e && key && !std::strcmp(key, "server_streamed")) { *value = e->server.streamed; return FX_OK; }
     if (e && key && !std::strcmp(key, "server_slots")) { *value = e->server.running ? e->server.tiles : 0; return FX_OK; }
     int64_t* s = option_slot(e, key);

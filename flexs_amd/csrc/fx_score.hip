@@ -383,8 +383,9 @@ static int staged_enqueue(fx_engine* e, bool* waits) {
     if (G > U) G = U;
     const int64_t nb = M > 1 ? (G + M - 1) / M : G;      // workgroups of one member, at most
     e->rows_min_share = TG / (nb > 0 ? nb : 1) / 4;
-    e->rows_req.on = true; e->rows_req.used = false;
+    e->rows_req.on = true; e->rows_req.used = false; e->rows_req.relay_used = false;
     e->rows_req.r = FxRowsReady{c.words, c.base, c.lanes, 0, c.pitch};
+    e->rows_req.relay = c.relay ? FxRelay{c.d_in, e->relay_flags, e->relay_seq} : FxRelay{nullptr, nullptr, 0};
     HostBytes host_bytes(e);
     int rc;
     if (c.stride) rc = score_then_mean(e, c.models.data(), M, (const uint8_t*)dm_in, c.N, c.L, c.d_nm, c.stride, m_mean);
@@ -394,6 +395,7 @@ static int staged_enqueue(fx_engine* e, bool* waits) {
     }
     *waits = e->rows_req.used;
     e->rows_req.on = false;
+    e->rows_req.relay = FxRelay{nullptr, nullptr, 0};
     c.Q = e->rows_req.r.Q;
     e->done_armed = false;                                 // (finish waits on the stream: the mean kernel may be the last writer)
     return rc;
@@ -411,14 +413,28 @@ int fx_score_begin_staged(fx_engine* e, fx_model* const* models, int M, int64_t 
     FX_HIP(e, hipSetDevice(e->device));
     bool zc = false;
     { int unused = 1; plan_host_call(e, models, M, N, L, &zc, &unused); }
-    if (!zc) return FX_EUNSUPPORTED;
+    // every member reading the rows over PCIe again does not hide behind the kernels (the "copy" plan): member 0's workgroups
+    // relay them through device memory (FxRelay) where the ensemble's kernel can, else the caller packs, uploads, launches
+    const bool relay = !zc;
+    if (relay && (!e->launch_relay || M < 2)) return FX_EUNSUPPORTED;
     unsigned* w = rows_words_ensure(e);
     if (!w) return FX_EUNSUPPORTED;
     const int64_t TG = (N + 15) / 16;
     const int pitch = (16 * L + 127) / 128 * 128;
     const size_t in_bytes = (size_t)TG * (size_t)pitch;
-    const size_t nm_bytes = sizeof(float) * (size_t)N * (size_t)M, mean_bytes = sizeof(float) * (size_t)N;
     void *d_in = nullptr, *h_in = nullptr, *h_out = nullptr, *d_out = nullptr;
+    if (relay) {
+        if ((size_t)TG > e->relay_flag_words) {
+            if (e->relay_flags) { FX_HIP(e, hipStreamSynchronize(e->stream)); (void)hipFree(e->relay_flags); e->relay_flags = nullptr; e->relay_flag_words = 0; }
+            const size_t words = (size_t)TG + (size_t)TG / 4 + 1024;
+            if (hipMalloc(reinterpret_cast<void**>(&e->relay_flags), words * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return FX_EUNSUPPORTED; }
+            FX_HIP(e, hipMemset(e->relay_flags, 0, words * sizeof(unsigned)));
+            e->relay_flag_words = words;
+        }
+        if (++e->relay_seq == 0) ++e->relay_seq;
+        if ((rc = fx_scratch(e, 0, in_bytes + 16, &d_in))) return rc;
+    }
+    const size_t nm_bytes = sizeof(float) * (size_t)N * (size_t)M, mean_bytes = sizeof(float) * (size_t)N;
     const int64_t stride = (!want_nm && M <= 16) ? planar_stride_for(N) : 0;
     const size_t inter_bytes = stride ? sizeof(float) * (size_t)stride * (size_t)M : nm_bytes;
     if ((rc = fx_pinned(e, 0, in_bytes, &h_in))) return rc;     // (no device copy of the input: the kernels read this)
@@ -439,6 +455,7 @@ int fx_score_begin_staged(fx_engine* e, fx_model* const* models, int M, int64_t 
     c.pieces = 0; c.zero_copy = true; c.stride = stride;
     e->rows_base += 4096u;
     c.words = w; c.base = e->rows_base; c.lanes = lanes; c.pitch = pitch; c.packed_ok = true; c.in_place = results != nullptr;
+    c.relay = relay;
     bool waits = false;
     rc = staged_enqueue(e, &waits);
     if (rc && !waits) return rc;                           // (FX_EUNSUPPORTED: nothing was enqueued)
@@ -447,6 +464,7 @@ int fx_score_begin_staged(fx_engine* e, fx_model* const* models, int M, int64_t 
     c.active = true;
     e->counters.host_calls += 1; e->counters.zero_copy_calls += 1; e->counters.sequences += N; e->counters.forwards += N * M;
     e->launch_first_calls += 1;
+    if (relay) e->launch_relay_calls += 1;
     *staging = h_in; *words = w; *base = c.base; *stages = c.Q; *tile_pitch = pitch;
     return FX_OK;
 }

@@ -123,6 +123,31 @@ __device__ __forceinline__ void fx_stage_tile(const uint8_t* __restrict__ src, i
     }
 }
 
+// Relay forms of fx_stage_tile (FxRelay): PASS = the tile's bytes also go to `relay` in device memory with device-scope stores (the
+// caller then waits for them -- fx_wait_vm(0) -- and raises the tile's flag); FROM = they come from there with device-scope loads.
+// A tile starts at a multiple of 128 bytes in both areas: the 8-byte accesses are aligned.
+__device__ __forceinline__ void fx_stage_tile_pass(const uint8_t* __restrict__ src, int bytes, uint8_t* dst_lds, int lane, uint8_t* relay) {
+    for (int off = lane * 16; off < bytes; off += 64 * 16) {
+        FxBytes16 v{};
+        if (off + 16 <= bytes) v = *reinterpret_cast<const FxBytes16*>(src + off);
+        else for (int b = off; b < bytes; ++b) reinterpret_cast<uint8_t*>(&v)[b - off] = src[b];
+        uint32_t* d = reinterpret_cast<uint32_t*>(dst_lds + off);
+        d[0] = v.w[0]; d[1] = v.w[1]; d[2] = v.w[2]; d[3] = v.w[3];               // (the scratch is a multiple of 16 bytes)
+        unsigned long long* r8 = reinterpret_cast<unsigned long long*>(relay + off);
+        __hip_atomic_store(r8, (unsigned long long)v.w[0] | ((unsigned long long)v.w[1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(r8 + 1, (unsigned long long)v.w[2] | ((unsigned long long)v.w[3] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void fx_stage_tile_from(const uint8_t* relay, int bytes, uint8_t* dst_lds, int lane) {
+    for (int off = lane * 16; off < bytes; off += 64 * 16) {
+        const unsigned long long* r8 = reinterpret_cast<const unsigned long long*>(relay + off);
+        const unsigned long long a = __hip_atomic_load(r8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long b = __hip_atomic_load(r8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t* d = reinterpret_cast<uint32_t*>(dst_lds + off);
+        d[0] = (uint32_t)a; d[1] = (uint32_t)(a >> 32); d[2] = (uint32_t)b; d[3] = (uint32_t)(b >> 32);
+    }
+}
+
 // Share of the tile range [t_lo, t_hi) that belongs to this wave's SIMD, proportional to the number of the workgroup's
 // waves each SIMD hosts (counted once at kernel start, fx_count_simd_wave: 4-4-4-4 for a 16-wave workgroup, but
 // nothing here depends on the placement -- a SIMD without waves simply gets no tiles).

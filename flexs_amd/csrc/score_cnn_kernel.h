@@ -539,7 +539,7 @@ int launch_g(fx_engine* e, const CnnArgs& a_in, size_t lds_bytes) {
     a.stw_stride = STG ? (int)((16 * (size_t)a.L + 15) / 16 * 16) : 0;
     if (e->rows_req.on) {
         // (a launched-first call: this kernel waits for its rows tile by tile -- the forms that share a tile among waves do not)
-        if (SEG || NT != 1 || !HEAD) return FX_EUNSUPPORTED;
+        if (SEG || NT != 1 || !HEAD || e->rows_req.relay.flags) return FX_EUNSUPPORTED;   // (no relay form of this kernel)
         if (!fx_rows_plan(e)) return FX_EUNSUPPORTED;
         a.ready = e->rows_req.r;
         e->rows_req.used = true;

@@ -44,6 +44,7 @@ struct DenseArgs {
     // 0 = off, else the number of groups that find room for their exchange buffers (PAIR: over the pair rows; BT: at coop_off)
     int coop, coop_off;
     FxRowsReady ready;          // launched-first host call: the rows arrive while the kernel runs (words == nullptr: they are all there)
+    FxRelay relay;              // ... and member 0's workgroups pass them on to the other members through device memory (flags == nullptr: no)
 };
 
 // GE first layer as a table indexed by the RAW byte: tab[l][b - base] = w1[l * A + lut[b]] for the 32 byte values from
@@ -177,7 +178,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                     int at = pulled + rows_rot;
                     if (at >= len) at -= len;
                     tg_want = s_lo + at;
-                    fx_rows_wait(p.ready, (int)(tg_want % p.ready.Q), rows_known, p.err);
+                    // (a relay's readers wait for member 0's workgroups, not for the host)
+                    if (!p.relay.flags || m + p.m_off == 0) fx_rows_wait(p.ready, (int)(tg_want % p.ready.Q), rows_known, p.err);
                 }
             }
             if (SLAB && t_lo + round * WAVES >= t_hi) break;
@@ -196,7 +198,19 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
             }
             // the tile's bytes through this wave's LDS scratch (PAIR / BT first layers); lanes past the batch use row 0
             const int64_t tile_rows = p.N - tg * 16 < 16 ? p.N - tg * 16 : 16;
-            if (p.stage_stride && (PAIR || BT)) fx_stage_tile(p.ascii + tg * (rows_arrive ? (int64_t)p.ready.pitch : (int64_t)16 * L), (int)tile_rows * L, stw, lane);
+            if (p.stage_stride && (PAIR || BT)) {
+                const int64_t at_byte = tg * (rows_arrive ? (int64_t)p.ready.pitch : (int64_t)16 * L);
+                if (rows_arrive && p.relay.flags) {
+                    if (m + p.m_off == 0) {
+                        fx_stage_tile_pass(p.ascii + at_byte, (int)tile_rows * L, stw, lane, p.relay.dst + at_byte);
+                        fx_wait_vm(0);                              // this wave's stores have been taken ...
+                        if (lane == 0) __hip_atomic_store(p.relay.flags + tg, p.relay.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... the tile is there
+                    } else {
+                        fx_relay_wait(p.relay.flags + tg, p.relay.seq, p.err);
+                        fx_stage_tile_from(p.relay.dst + at_byte, (int)tile_rows * L, stw, lane);
+                    }
+                } else fx_stage_tile(p.ascii + at_byte, (int)tile_rows * L, stw, lane);
+            }
             const uint8_t* srow = stw + (n[0] < p.N ? sq : 0) * L;
             f4 h[HT][NT];
             float y[NT];
@@ -491,8 +505,14 @@ int launch_inst(fx_engine* e, const DenseArgs& a_in, size_t lds_bytes) {
     if (e->rows_req.on) {
         // (a launched-first call: this kernel waits for its rows tile by tile -- the lockstep slab form does not)
         if (SLAB || NT != 1) return FX_EUNSUPPORTED;
+        if (e->rows_req.relay.flags) {
+            // the relay: the forms that copy a tile's bytes into LDS first, one launch for the whole ensemble
+            if (!((PAIR || BT) && a.stage_stride > 0) || a.M < 2 || a.m_off != 0 || a.M != a.Mtot) return FX_EUNSUPPORTED;
+        }
         if (!fx_rows_plan(e)) return FX_EUNSUPPORTED;
         a.ready = e->rows_req.r;
+        a.relay = e->rows_req.relay;
+        e->rows_req.relay_used = a.relay.flags != nullptr;
         e->rows_req.used = true;
     }
     const int64_t U = (int64_t)a.M * a.TG;

@@ -216,3 +216,39 @@ def test_results_in_place_are_ordinary_arrays_over_leased_pinned_buffers(launch_
     with pytest.raises(ValueError):
         ens.get_fitness(broken)
     assert pool._out == out0 and np.array_equal(ens.get_fitness(seqs), want)
+
+
+@pytest.mark.parametrize("kind,L,alpha,M,n", [("ge", 90, s_utils.AAS, 8, 100_000), ("ge", 90, s_utils.AAS, 3, 40_003), ("ge", 237, s_utils.AAS, 8, 20_000),
+                                              ("ge", 50, "UGCA", 5, 70_001)])
+def test_relay_through_member_zero_gives_the_same_bits(launch_first, kind, L, alpha, M, n):
+    """Ensembles whose members would each read the rows over PCIe again (the "copy" plan): in a launched-first call member 0's
+    workgroups pass every tile on through device memory and the other members read it there (FxRelay, engine option launch_relay).
+    Same bits as pack -> upload -> launch, call after call (the tiles travel between workgroups on different XCDs past the caches),
+    mean and matrix paths, and the reference's exceptions."""
+    eng = launch_first
+    ens = _model(kind, L, alpha, M)
+    ident = flexs_amd.Ensemble(ens.models, combine_with=lambda x: x)
+    _, seqs = rand_seqs(n, L, alpha, seed=n % 89)
+    try:
+        eng.set_option("launch_relay", 0)
+        want, want_nm = ens.get_fitness(seqs).copy(), ident.get_fitness(seqs).copy()
+        eng.set_option("launch_relay", 1)
+        c0 = eng.get_option("launch_relay_calls")
+        redone = eng.get_option("launch_first_redone")
+        for _ in range(6):
+            assert np.array_equal(ens.get_fitness(seqs).view(np.uint32), want.view(np.uint32))
+        assert np.array_equal(ident.get_fitness(seqs).view(np.uint32), want_nm.view(np.uint32))
+        relayed = eng.get_option("launch_relay_calls") - c0
+        assert relayed in (0, 7) and eng.get_option("launch_first_redone") == redone
+        if (kind, L, M) == ("ge", 90, 8):
+            assert relayed == 7, "BASELINE config C4's shape is expected to take the relay on an MI355X"
+        broken = list(seqs)
+        broken[n // 2] = seqs[0][:-1]
+        with pytest.raises(ValueError):
+            ens.get_fitness(broken)
+        broken[n // 2] = seqs[0][:-1] + "!"
+        with pytest.raises(ValueError):
+            ens.get_fitness(broken)
+        assert np.array_equal(ens.get_fitness(seqs), want)
+    finally:
+        eng.set_option("launch_relay", 1)
