@@ -205,6 +205,10 @@ int fx_plan_host_call(fx_engine* e, fx_model* const* models, int M, int64_t N, i
     return FX_OK;
 }
 
+static int relay_prepare(fx_engine* e, int64_t TG);
+static int staged_enqueue(fx_engine* e, bool* waits);
+static bool ascii_rows_relay_ok(const fx_engine* e) { return e->large_bar && !e->rows_refused; }
+
 int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii, int64_t N, int L,
              const uint8_t lut[256], float* out_NM, float* out_mean) {
     int rc = validate_models(e, models, M, L, lut);
@@ -308,6 +312,34 @@ int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii,
         }
         if ((rc = wait_for_results(e))) return rc;         // (the mean kernel was the last writer: the stream)
     } else {
+        if (e->launch_relay && M >= 2 && !e->chunked.active && ascii_rows_relay_ok(e)) {
+            // An ensemble whose members would each read the bytes over PCIe again: no upload in front of the launch -- member 0's
+            // workgroups read the staging area and pass every tile on through device memory (FxRelay), the transfer runs beside
+            // the scoring.  The launched-first machinery with every stage published: fx_score_finish does the rest.
+            unsigned* w = rows_words_ensure(e);
+            const int64_t TG = (N + 15) / 16;
+            void* d_relay = nullptr;
+            const size_t relay_bytes = (size_t)TG * (size_t)((16 * L + 127) / 128 * 128);
+            if (w && relay_prepare(e, TG) == FX_OK && fx_scratch(e, 5, relay_bytes + 16, &d_relay) == FX_OK) {
+                auto& c = e->chunked;
+                c.models.assign(models, models + M);
+                c.N = N; c.L = L; c.want_nm = out_NM != nullptr; c.want_mean = out_mean != nullptr;
+                c.h_in = (uint8_t*)h_in; c.d_in = (uint8_t*)d_relay;
+                c.d_nm = d_NM; c.d_mean = nullptr; c.h_out = (char*)h_out;
+                c.pieces = 0; c.zero_copy = true; c.stride = (!out_NM && M <= 16) ? stride : 0;
+                e->rows_base += 4096u;
+                c.words = w; c.base = e->rows_base; c.lanes = 1; c.pitch = 16 * L; c.packed_ok = true; c.in_place = false; c.relay = true;
+                bool waits = false;
+                rc = staged_enqueue(e, &waits);
+                if (waits) {
+                    c.redo = rc != 0;
+                    c.staged = true; c.active = true;
+                    e->launch_relay_calls += 1;
+                    return fx_score_finish(e, out_NM, out_mean);
+                }
+                if (rc != FX_EUNSUPPORTED) return rc;       // (else nothing was enqueued: the upload below)
+            }
+        }
         e->counters.bytes_h2d += (int64_t)in_bytes;
         e->counters.bytes_d2h += (int64_t)((out_mean ? mean_bytes : 0) + (out_NM ? nm_bytes : 0));
         FX_HIP(e, hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, e->stream));
@@ -367,6 +399,24 @@ int fx_score_begin(fx_engine* e, fx_model* const* models, int M, int64_t N, int 
 // 128-byte lines, so that no cache line holds rows of two tiles -- see FxRowsReady.
 // FX_EUNSUPPORTED (nothing enqueued, no call in flight): the plan is not zero-copy, the shape's kernel cannot wait for rows, the
 // host cannot store into device memory, or there are too few tiles per SIMD to order -- the caller packs first, as before.
+// a flag per tile (zero when allocated; a call's value never repeats) and the call's value
+static int relay_prepare(fx_engine* e, int64_t TG) {
+    if ((size_t)TG > e->relay_flag_words) {
+        if (e->relay_flags) { FX_HIP(e, hipStreamSynchronize(e->stream)); (void)hipFree(e->relay_flags); e->relay_flags = nullptr; e->relay_flag_words = 0; }
+        const size_t words = (size_t)TG + (size_t)TG / 4 + 1024;
+        if (hipMalloc(reinterpret_cast<void**>(&e->relay_flags), words * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return FX_EUNSUPPORTED; }
+        FX_HIP(e, hipMemset(e->relay_flags, 0, words * sizeof(unsigned)));
+        e->relay_flag_words = words;
+    }
+    if (++e->relay_seq == 0) {
+        // (the value wrapped: flags of 2^32 calls ago could match -- clear them)
+        FX_HIP(e, hipStreamSynchronize(e->stream));
+        FX_HIP(e, hipMemset(e->relay_flags, 0, e->relay_flag_words * sizeof(unsigned)));
+        ++e->relay_seq;
+    }
+    return FX_OK;
+}
+
 static int staged_enqueue(fx_engine* e, bool* waits) {
     auto& c = e->chunked;
     const int M = (int)c.models.size();
@@ -385,7 +435,7 @@ static int staged_enqueue(fx_engine* e, bool* waits) {
     e->rows_min_share = TG / (nb > 0 ? nb : 1) / 4;
     e->rows_req.on = true; e->rows_req.used = false; e->rows_req.relay_used = false;
     e->rows_req.r = FxRowsReady{c.words, c.base, c.lanes, 0, c.pitch};
-    e->rows_req.relay = c.relay ? FxRelay{c.d_in, e->relay_flags, e->relay_seq} : FxRelay{nullptr, nullptr, 0};
+    e->rows_req.relay = c.relay ? FxRelay{c.d_in, e->relay_flags, e->relay_seq, (16 * c.L + 127) / 128 * 128} : FxRelay{nullptr, nullptr, 0, 0};
     HostBytes host_bytes(e);
     int rc;
     if (c.stride) rc = score_then_mean(e, c.models.data(), M, (const uint8_t*)dm_in, c.N, c.L, c.d_nm, c.stride, m_mean);
@@ -395,7 +445,7 @@ static int staged_enqueue(fx_engine* e, bool* waits) {
     }
     *waits = e->rows_req.used;
     e->rows_req.on = false;
-    e->rows_req.relay = FxRelay{nullptr, nullptr, 0};
+    e->rows_req.relay = FxRelay{nullptr, nullptr, 0, 0};
     c.Q = e->rows_req.r.Q;
     e->done_armed = false;                                 // (finish waits on the stream: the mean kernel may be the last writer)
     return rc;
@@ -424,14 +474,7 @@ int fx_score_begin_staged(fx_engine* e, fx_model* const* models, int M, int64_t 
     const size_t in_bytes = (size_t)TG * (size_t)pitch;
     void *d_in = nullptr, *h_in = nullptr, *h_out = nullptr, *d_out = nullptr;
     if (relay) {
-        if ((size_t)TG > e->relay_flag_words) {
-            if (e->relay_flags) { FX_HIP(e, hipStreamSynchronize(e->stream)); (void)hipFree(e->relay_flags); e->relay_flags = nullptr; e->relay_flag_words = 0; }
-            const size_t words = (size_t)TG + (size_t)TG / 4 + 1024;
-            if (hipMalloc(reinterpret_cast<void**>(&e->relay_flags), words * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return FX_EUNSUPPORTED; }
-            FX_HIP(e, hipMemset(e->relay_flags, 0, words * sizeof(unsigned)));
-            e->relay_flag_words = words;
-        }
-        if (++e->relay_seq == 0) ++e->relay_seq;
+        if ((rc = relay_prepare(e, TG))) return rc;
         if ((rc = fx_scratch(e, 0, in_bytes + 16, &d_in))) return rc;
     }
     const size_t nm_bytes = sizeof(float) * (size_t)N * (size_t)M, mean_bytes = sizeof(float) * (size_t)N;

@@ -201,13 +201,14 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
             if (p.stage_stride && (PAIR || BT)) {
                 const int64_t at_byte = tg * (rows_arrive ? (int64_t)p.ready.pitch : (int64_t)16 * L);
                 if (rows_arrive && p.relay.flags) {
+                    const int64_t relay_byte = tg * (int64_t)p.relay.pitch;
                     if (m + p.m_off == 0) {
-                        fx_stage_tile_pass(p.ascii + at_byte, (int)tile_rows * L, stw, lane, p.relay.dst + at_byte);
+                        fx_stage_tile_pass(p.ascii + at_byte, (int)tile_rows * L, stw, lane, p.relay.dst + relay_byte);
                         fx_wait_vm(0);                              // this wave's stores have been taken ...
                         if (lane == 0) __hip_atomic_store(p.relay.flags + tg, p.relay.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... the tile is there
                     } else {
                         fx_relay_wait(p.relay.flags + tg, p.relay.seq, p.err);
-                        fx_stage_tile_from(p.relay.dst + at_byte, (int)tile_rows * L, stw, lane);
+                        fx_stage_tile_from(p.relay.dst + relay_byte, (int)tile_rows * L, stw, lane);
                     }
                 } else fx_stage_tile(p.ascii + at_byte, (int)tile_rows * L, stw, lane);
             }

@@ -242,6 +242,20 @@ def test_relay_through_member_zero_gives_the_same_bits(launch_first, kind, L, al
         assert relayed in (0, 7) and eng.get_option("launch_first_redone") == redone
         if (kind, L, M) == ("ge", 90, 8):
             assert relayed == 7, "BASELINE config C4's shape is expected to take the relay on an MI355X"
+        # the plain host call on packed bytes (an ndarray of bytes, a C caller): no upload in front of the launch, the same relay
+        b, _ = rand_seqs(n, L, alpha, seed=n % 89)
+        nat, lut = [m.native() for m in ens.models], ens.models[0]._lut
+        c1 = eng.get_option("launch_relay_calls")
+        for want_matrix in (False, True):
+            nm, mean = eng.score(nat, b, lut, want_matrix=want_matrix, want_mean=True)
+            assert np.array_equal(mean.view(np.uint32), want.view(np.uint32))
+            assert nm is None or np.array_equal(nm.view(np.uint32), want_nm.view(np.uint32))
+        assert eng.get_option("launch_relay_calls") - c1 in (0, 2) and (relayed == 0) == (eng.get_option("launch_relay_calls") == c1)
+        bad = np.array(b, copy=True)
+        bad[n - 3, L - 1] = ord("!")
+        with pytest.raises(ValueError):
+            eng.score(nat, bad, lut, want_matrix=False, want_mean=True)
+        assert np.array_equal(eng.score(nat, b, lut, want_matrix=False, want_mean=True)[1], want)
         broken = list(seqs)
         broken[n // 2] = seqs[0][:-1]
         with pytest.raises(ValueError):

@@ -33,6 +33,25 @@ for tag, make, M, L, alpha, n in cases:
         bad += int(not np.array_equal(got.view(np.uint32), want.view(np.uint32)))
     took = eng.get_option("launch_relay_calls") - c0
     t_on = med(lambda: ens.get_fitness(seqs))
+    # the plain host call on packed bytes (what an ndarray of bytes, or a C caller, gets): no upload in front of the launch
+    b = np.asarray(synth.random_sequence_bytes(n, L, alpha, n)).reshape(n, L)
+    nat = [m.native() for m in ens.models]
+    eng.set_option("launch_relay", 0)
+    want_b = eng.score(nat, b, ens.models[0]._lut, want_matrix=False, want_mean=True)[1].copy()
+    tb_off = med(lambda: eng.score(nat, b, ens.models[0]._lut, want_matrix=False, want_mean=True))
+    eng.set_option("launch_relay", 1)
+    cb = eng.get_option("launch_relay_calls")
+    for _ in range(10):
+        got_b = eng.score(nat, b, ens.models[0]._lut, want_matrix=False, want_mean=True)[1]
+        bad += int(not np.array_equal(got_b.view(np.uint32), want_b.view(np.uint32)))
+    nm_b = eng.score(nat, b, ens.models[0]._lut, want_matrix=True, want_mean=True)
+    eng.set_option("launch_relay", 0)
+    nm_w = eng.score(nat, b, ens.models[0]._lut, want_matrix=True, want_mean=True)
+    eng.set_option("launch_relay", 1)
+    bad += int(not (np.array_equal(nm_b[0], nm_w[0]) and np.array_equal(nm_b[1], nm_w[1])))
+    took_b = eng.get_option("launch_relay_calls") - cb
+    tb_on = med(lambda: eng.score(nat, b, ens.models[0]._lut, want_matrix=False, want_mean=True))
+    print(f"{tag} n={n}: fx_score on packed bytes: relayed {took_b} of 11 calls; {tb_off:.0f} us without, {tb_on:.0f} us with the relay", flush=True)
     print(f"{tag} n={n}: relayed {took} of 25 calls, redone {eng.get_option('launch_first_redone') - r0}, calls with other bits {bad}; "
           f"{t_off:.0f} us without, {t_on:.0f} us with the relay", flush=True)
     assert bad == 0
