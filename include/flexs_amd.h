@@ -101,6 +101,10 @@ const char *fx_last_error(fx_engine *e);
  *   launch_first      1        1 = fx_score_begin_staged is offered (big zero-copy calls of callers that marshal strings:
  *                              kernels enqueued before the strings are packed); 0 = it answers FX_EUNSUPPORTED.  Needs a
  *                              large BAR, as serve_small does.  Read-only companions: launch_first_calls, launch_first_redone.
+ *   launch_relay      1        1 = host calls of dense ensembles whose plan says "copy" (fx_plan_host_call) run without an
+ *                              upload in front of the launch: member 0's workgroups read the staging area and pass every tile
+ *                              on to the other members through device memory (fx_score, and fx_score_begin_staged, which then
+ *                              takes such calls too).  Read-only companion: launch_relay_calls.
  *   serve_small       1        1 = explorer-size fx_score calls of canonical 4-letter CNNs (seq_len <= 16), MLPs and
  *                              GlobalEpistasis models -- one model, an ensemble, or a mix -- are answered by workgroups
  *                              that STAY on the device between calls (request and answer through mailboxes; no launch):

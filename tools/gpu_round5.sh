@@ -24,6 +24,7 @@ timeout 200 python tools/runs/r5_launch_first.py > $OUT/launch_first.log 2>&1
 timeout 100 python tools/runs/r5_launch_first_parts.py >> $OUT/launch_first.log 2>&1
 timeout 100 python tools/runs/r5_e2e_breakdown.py > $OUT/e2e_breakdown.log 2>&1
 timeout 100 python tools/runs/r5_stage_host_ab.py > $OUT/stage_host_ab.log 2>&1
+timeout 200 python tools/runs/r5_relay.py > $OUT/relay.log 2>&1
 cp gpurun_out/parity_error_stats.json $OUT/ 2>/dev/null
 find $OUT -name "*counter_collection.csv" -size +2M -delete
 find $OUT -name "*_kernel_trace.csv" -size +1M -delete
