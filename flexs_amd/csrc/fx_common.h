@@ -35,6 +35,7 @@ struct FxRelay {
     unsigned* flags;            // one word per tile
     unsigned seq;               // this call's value (never 0)
     int pitch;                  // bytes from one tile to the next in dst: whole 128-byte lines (no line holds bytes of two tiles)
+    int spread;                 // 1 = workgroups take their unit ranges in plain block order: member 0's sit on all eight XCDs
 };
 
 struct FxRowsReady {
@@ -327,7 +328,8 @@ struct fx_engine {
     int64_t fuse_mean = 0;      // 1 = explorer-size CNN ensemble calls average in the scoring kernel (last member to finish a tile, tickets + device-scope fences) instead of launching the mean kernel.  Bit-identical, but the two fences cost what the 3 us launch saves: 32.1 vs 32.2 us per call (profiles/r3_fused_mean_ab.log): off, kept as the A/B
     // launched-first host call (fx_score_begin_staged): what the launchers that can wait for rows copy into their arguments, and
     // whether the launch just enqueued did (a launcher that cannot returns FX_EUNSUPPORTED before it enqueues anything)
-    struct { bool on = false, used = false; FxRowsReady r = {nullptr, 0, 0, 0, 0}; FxRelay relay = {nullptr, nullptr, 0, 0}; bool relay_used = false; } rows_req;
+    struct { bool on = false, used = false; FxRowsReady r = {nullptr, 0, 0, 0, 0}; FxRelay relay = {nullptr, nullptr, 0, 0, 0}; bool relay_used = false; } rows_req;
+    int64_t relay_spread = 0;   // 1 = relay launches take their unit ranges in plain block order: member 0's workgroups on all eight XCDs instead of one (no gain: A/B)
     unsigned* relay_flags = nullptr; size_t relay_flag_words = 0; unsigned relay_seq = 0;
     int64_t launch_relay = 1;   // 1 = launched-first calls of dense ensembles whose plan says "copy" relay the rows through member 0's workgroups (0 = such calls pack, upload, then launch: A/B)
     int64_t launch_relay_calls = 0;

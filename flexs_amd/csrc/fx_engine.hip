@@ -134,6 +134,7 @@ int check_deferred(fx_engine* e) {
             if (e->d_zero_pool) (void)hipMemset(e->d_zero_pool, 0, e->zero_pool_bytes);   // (partial maxima / tickets may be left behind)
             return fx_fail(e, FX_ESTATE, "a device-side barrier of the layer-parallel CNN form timed out (workgroups not co-resident?): set the engine option cnn_lp = 0");
         }
+        if (err & FX_ERR_STARVED) return fx_fail(e, FX_ESTATE, "rows of a launched-first call never reached the kernels (launch_first = 0 turns the form off)");
         if (err & FX_ERR_BADCHAR) return fx_fail(e, FX_EBADCHAR, "substring not found: character outside the alphabet");
     }
     return FX_OK;
@@ -318,6 +319,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "launch_first")) return &e->launch_first;
     if (!std::strcmp(key, "cnn_stage_host")) return &e->cnn_stage_host;
     if (!std::strcmp(key, "launch_relay")) return &e->launch_relay;
+    if (!std::strcmp(key, "relay_spread")) return &e->relay_spread;
     if (!std::strcmp(key, "train_rows")) return &e->train_rows;
     if (!std::strcmp(key, "train_lds")) return &e->train_lds;
     if (!std::strcmp(key, "train_threads")) return &e->train_threads;

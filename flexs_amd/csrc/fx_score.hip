@@ -435,7 +435,7 @@ static int staged_enqueue(fx_engine* e, bool* waits) {
     e->rows_min_share = TG / (nb > 0 ? nb : 1) / 4;
     e->rows_req.on = true; e->rows_req.used = false; e->rows_req.relay_used = false;
     e->rows_req.r = FxRowsReady{c.words, c.base, c.lanes, 0, c.pitch};
-    e->rows_req.relay = c.relay ? FxRelay{c.d_in, e->relay_flags, e->relay_seq, (16 * c.L + 127) / 128 * 128} : FxRelay{nullptr, nullptr, 0, 0};
+    e->rows_req.relay = c.relay ? FxRelay{c.d_in, e->relay_flags, e->relay_seq, (16 * c.L + 127) / 128 * 128, (int)e->relay_spread} : FxRelay{nullptr, nullptr, 0, 0, 0};
     HostBytes host_bytes(e);
     int rc;
     if (c.stride) rc = score_then_mean(e, c.models.data(), M, (const uint8_t*)dm_in, c.N, c.L, c.d_nm, c.stride, m_mean);
@@ -445,7 +445,7 @@ static int staged_enqueue(fx_engine* e, bool* waits) {
     }
     *waits = e->rows_req.used;
     e->rows_req.on = false;
-    e->rows_req.relay = FxRelay{nullptr, nullptr, 0, 0};
+    e->rows_req.relay = FxRelay{nullptr, nullptr, 0, 0, 0};
     c.Q = e->rows_req.r.Q;
     e->done_armed = false;                                 // (finish waits on the stream: the mean kernel may be the last writer)
     return rc;
@@ -637,16 +637,26 @@ int fx_score_finish(fx_engine* e, float* out_NM, float* out_mean) {
         int rc = wait_for_results(e);
         if (rc) return rc;
         const unsigned err = *reinterpret_cast<volatile unsigned*>(e->h_err);
-        if ((err & FX_ERR_STARVED) || c.redo || (err && !c.packed_ok)) {
-            // rows that never came, a launch that did not wait, or an error word raised over rows the caller says it failed to pack:
-            // when the caller did pack everything, the same launch once more -- every stage is published, nothing waits -- gives
-            // the answer and the error the reference gives; when it did not, there is nothing to answer
+        if (err || c.redo) {
+            // ANY error word (the bits overwrite each other: a "bad character" may stand for rows that never came and were scored as
+            // they lay), or a launch that did not wait.  When the caller did pack everything, the same launch once more -- every
+            // stage is published, nothing waits -- gives the answer and the error the reference gives; when it did not, there is
+            // nothing to answer
             *reinterpret_cast<volatile unsigned*>(e->h_err) = 0;
             e->launch_first_redone += 1;
             if (!c.packed_ok) return FX_OK;                // (the caller raises its own packing error)
             bool waits = false;
             if ((rc = staged_enqueue(e, &waits))) return rc == FX_EUNSUPPORTED ? fx_fail(e, FX_ESTATE, "launched-first call: the second attempt found no kernel") : rc;
             if ((rc = wait_for_results(e))) return rc;
+            if (c.relay && (*reinterpret_cast<volatile unsigned*>(e->h_err) & FX_ERR_STARVED)) {
+                // a relay's readers starved again although every row was there: member 0's workgroups did not get onto the device
+                // beside them (another process holding CUs).  Third attempt without the relay: every member reads the host rows
+                // itself -- slow, but no workgroup waits for another
+                *reinterpret_cast<volatile unsigned*>(e->h_err) = 0;
+                c.relay = false;
+                if ((rc = staged_enqueue(e, &waits))) return rc == FX_EUNSUPPORTED ? fx_fail(e, FX_ESTATE, "launched-first call: the third attempt found no kernel") : rc;
+                if ((rc = wait_for_results(e))) return rc;
+            }
         }
         if ((rc = check_deferred(e))) return rc;
         if (c.in_place) return FX_OK;                      // (the caller's buffer holds the matrix, then the mean)

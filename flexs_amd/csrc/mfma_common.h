@@ -63,8 +63,10 @@ __device__ __forceinline__ unsigned fx_xcd_block() {
 // boundary for its slowest wave, refill LDS and start over -- one tile duration plus a fill, which with few tiles
 // per workgroup WAS the kernel's tail (profiles/archive/r2_trace_probe: 3 members x 1e4 sequences, 38 us span of which 12
 // were two straddling workgroups; 194 -> ~180 us on the 3 x 1e5 bench launch).
-__device__ __forceinline__ void fx_unit_range(int64_t TG, int M, int64_t& u_lo, int64_t& u_hi) {
-    const int64_t G = gridDim.x, bid = fx_xcd_block();
+// spread = true (relay launches, FxRelay): plain block order instead -- member 0's workgroups, the only ones that pull rows over
+// PCIe, then sit on all eight XCDs instead of one.
+__device__ __forceinline__ void fx_unit_range(int64_t TG, int M, int64_t& u_lo, int64_t& u_hi, bool spread = false) {
+    const int64_t G = gridDim.x, bid = spread ? (int64_t)blockIdx.x : (int64_t)fx_xcd_block();
     const int64_t U = (int64_t)M * TG;
     // ... unless cutting at the member boundaries makes the largest share bigger: with coarse units (the two-waves-per-
     // tile protein kernel: a tile is a ~1.4 ms serial walk, 12 tiles per workgroup) one more tile on the workgroups of a

@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
     if (tid < 4) simd_waves[tid] = 0;
 
     int64_t u_lo, u_hi;
-    fx_unit_range(p.TG, p.M, u_lo, u_hi);
+    fx_unit_range(p.TG, p.M, u_lo, u_hi, p.relay.flags != nullptr && p.relay.spread);
     if (u_lo >= u_hi) return;
     const int m_first = (int)(u_lo / p.TG), m_last = (int)((u_hi - 1) / p.TG);
     bool bad = false;
