@@ -266,3 +266,56 @@ def test_relay_through_member_zero_gives_the_same_bits(launch_first, kind, L, al
         assert np.array_equal(ens.get_fitness(seqs), want)
     finally:
         eng.set_option("launch_relay", 1)
+
+
+_TWO_PROC = r"""
+import os, sys, time, hashlib
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import flexs_amd
+from flexs_amd import synth, _native
+from flexs_amd.baselines import models as bm
+from flexs_amd.utils import sequence_utils as s_utils
+ens = flexs_amd.Ensemble([bm.GlobalEpistasisModel(90, 100, s_utils.AAS, seed=s) for s in range(8)])
+cnn = flexs_amd.Ensemble([bm.CNN(8, 32, 100, "TGCA", seed=s) for s in range(3)])
+a = synth.bytes_to_strings(synth.random_sequence_bytes(60_000, 90, s_utils.AAS, 7))
+b = synth.bytes_to_strings(synth.random_sequence_bytes(70_001, 8, "TGCA", 8))
+ens.get_fitness(a[:100]); cnn.get_fitness(b[:100])
+open(sys.argv[2] + ".ready", "w").close()
+while not os.path.exists(sys.argv[3] + ".ready"):
+    time.sleep(0.001)
+h = hashlib.sha256()
+for _ in range(12):
+    h.update(ens.get_fitness(a).tobytes()); h.update(cnn.get_fitness(b).tobytes())
+eng = _native.Engine.get()
+print(h.hexdigest(), eng.get_option("launch_first_calls"), eng.get_option("launch_relay_calls"), eng.get_option("launch_first_redone"))
+"""
+
+
+def test_two_processes_on_one_gpu_with_launched_first_calls(launch_first, tmp_path):
+    """Two processes whose persistent launches wait on their own hosts (and, in a relay, on their own member-0 workgroups) share one
+    GPU: whichever launch the device runs first, both get the single-process bits -- a launch that starves because the other process
+    holds the CUs is run again (and a relay, if need be, without the relay)."""
+    import hashlib
+    import subprocess
+    import sys
+    eng = launch_first
+    ens = _model("ge", 90, s_utils.AAS, 8)
+    cnn = _model("cnn", 8, "TGCA", 3)
+    a = synth.bytes_to_strings(synth.random_sequence_bytes(60_000, 90, s_utils.AAS, 7))
+    b = synth.bytes_to_strings(synth.random_sequence_bytes(70_001, 8, "TGCA", 8))
+    h = hashlib.sha256()
+    wa, wb = ens.get_fitness(a), cnn.get_fitness(b)
+    for _ in range(12):
+        h.update(wa.tobytes()); h.update(wb.tobytes())
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    marks = [str(tmp_path / "p0"), str(tmp_path / "p1")]
+    procs = [subprocess.Popen([sys.executable, "-c", _TWO_PROC, root, marks[i], marks[1 - i]], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for i in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-2000:]
+        digest, first, relayed, redone = out.strip().split()[-4:]
+        assert digest == h.hexdigest(), (out, err[-500:])
+        assert int(first) >= 24 and int(relayed) >= 12
