@@ -60,7 +60,7 @@ SIGNATURES = {
     "fx_score_stream_rows": (C.c_int, [_vp, C.c_int64]),
     "fx_score_stream_end": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "fx_score_begin_staged": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int64, C.c_int, _u8p, C.c_int, C.c_int, C.c_int,
-                                        C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_uint), C.POINTER(C.c_int), C.POINTER(C.c_int), _vp]),
+                                        C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_uint), C.POINTER(C.c_int), C.POINTER(C.c_int), _vp, C.c_int64]),
     "fx_score_abandon": (C.c_int, [_vp]),
     "fx_result_alloc": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp)]),
     "fx_result_free": (C.c_int, [_vp, _vp]),
@@ -528,7 +528,7 @@ class Engine:
             lease = self._results().take(nm_res + (4 * N if want_mean else 0)) if RESULTS_IN_PLACE else None
             rc = self._lib.fx_score_begin_staged(self.handle, arr, M, N, L, _lut_ptr(lut), int(want_matrix), int(want_mean), lanes,
                                                  C.byref(p), C.byref(w), C.byref(base), C.byref(stages), C.byref(pitch),
-                                                 _vp(lease[0]) if lease else None)
+                                                 _vp(lease[0]) if lease else None, lease[1] if lease else 0)
             if rc == FX_OK:
                 status, handed_out = 3, False
                 try:

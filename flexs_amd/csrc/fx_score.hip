@@ -453,7 +453,7 @@ static int staged_enqueue(fx_engine* e, bool* waits) {
 
 int fx_score_begin_staged(fx_engine* e, fx_model* const* models, int M, int64_t N, int L, const uint8_t lut[256],
                           int want_nm, int want_mean, int lanes, void** staging, void** words, unsigned* base, int* stages, int* tile_pitch,
-                          void* results) {
+                          void* results, int64_t results_bytes) {
     int rc = validate_models(e, models, M, L, lut);
     if (rc) return rc;
     if (N < 1 || !staging || !words || !base || !stages || !tile_pitch || (!want_nm && !want_mean) || lanes < 1 || lanes > 16)
@@ -484,6 +484,8 @@ int fx_score_begin_staged(fx_engine* e, fx_model* const* models, int M, int64_t 
     if (results) {
         // results in place: the kernels write into the caller's own pinned buffer (fx_result_alloc) and fx_score_finish copies nothing
         void* probe = nullptr;
+        if (results_bytes < (int64_t)((want_nm ? nm_bytes : 0) + (want_mean ? mean_bytes : 0)))
+            return fx_fail(e, FX_EINVAL, "fx_score_begin_staged: results buffer too small");
         if (hipHostGetDevicePointer(&probe, results, 0) != hipSuccess) { (void)hipGetLastError(); return fx_fail(e, FX_EINVAL, "fx_score_begin_staged: results is not memory of fx_result_alloc"); }
         h_out = results;
     } else if ((rc = fx_pinned(e, 1, nm_bytes + mean_bytes, &h_out))) return rc;

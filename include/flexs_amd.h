@@ -250,10 +250,10 @@ int fx_score_finish(fx_engine *e, float *out_NM, float *out_mean);
 int fx_score_begin_staged(fx_engine *e, fx_model *const *models, int M, int64_t N, int L,
                           const uint8_t lut[256], int want_nm, int want_mean, int lanes,
                           void **staging, void **words, unsigned *base, int *stages, int *tile_pitch,
-                          void *results);
+                          void *results, int64_t results_bytes);
 int fx_score_abandon(fx_engine *e);
-/* `results` of fx_score_begin_staged (nullable): a buffer of fx_result_alloc of at least (want_nm ? 4 N M : 0) +
- * (want_mean ? 4 N : 0) bytes that the kernels write the (N, M) matrix and then the mean INTO -- fx_score_finish then
+/* `results` of fx_score_begin_staged (nullable; `results_bytes` its size): a buffer of fx_result_alloc of at least
+ * (want_nm ? 4 N M : 0) + (want_mean ? 4 N : 0) bytes that the kernels write the (N, M) matrix and then the mean INTO -- fx_score_finish then
  * copies nothing (its out_NM / out_mean are ignored) and the caller wraps the buffer (NumPy: an array whose base owns the
  * buffer and gives it back to a pool when the last view dies).  Pinned, GPU-mapped host memory; free with fx_result_free
  * once nothing refers to it. */

@@ -119,7 +119,7 @@ def test_a_host_that_stops_packing_does_not_hang_the_device(launch_first):
     p, w, base, stages, pitch = _native._vp(), _native._vp(), C.c_uint(0), C.c_int(0), C.c_int(0)
     redone = _counts(eng)[1]
     rc = lib.fx_score_begin_staged(eng.handle, arr, 1, n, L, _native._lut_ptr(lut), 1, 0, 4, C.byref(p), C.byref(w), C.byref(base),
-                                   C.byref(stages), C.byref(pitch), None)
+                                   C.byref(stages), C.byref(pitch), None, 0)
     assert rc == _native.FX_OK and stages.value >= 2 and pitch.value == 128
     time.sleep(0.4)                                              # nobody packs: the waves time out
     assert _native._strpack.pack_staged(seqs, L, p.value, stages.value, pitch.value, 4, w.value, base.value) == 0
@@ -129,7 +129,7 @@ def test_a_host_that_stops_packing_does_not_hang_the_device(launch_first):
     assert _counts(eng)[1] == redone + 1
     # ... and a caller that gives up altogether: finish only waits
     rc = lib.fx_score_begin_staged(eng.handle, arr, 1, n, L, _native._lut_ptr(lut), 1, 0, 4, C.byref(p), C.byref(w), C.byref(base),
-                                   C.byref(stages), C.byref(pitch), None)
+                                   C.byref(stages), C.byref(pitch), None, 0)
     assert rc == _native.FX_OK
     eng.check(lib.fx_score_abandon(eng.handle))
     eng.check(lib.fx_score_finish(eng.handle, _native._ptr(out), None))

@@ -21,7 +21,7 @@ for tag, model, L, alpha, n in (("1xCNN L=8", bm.CNN(8, 32, 100, "TGCA", seed=0)
     def call(mode):
         p, w, base, stages, brows = _native._vp(), _native._vp(), C.c_uint(0), C.c_int(0), C.c_int(0)
         t0 = time.perf_counter()
-        rc = lib.fx_score_begin_staged(eng.handle, arr, 1, n, L, _native._lut_ptr(lut), 1, 0, lanes, C.byref(p), C.byref(w), C.byref(base), C.byref(stages), C.byref(brows), None)
+        rc = lib.fx_score_begin_staged(eng.handle, arr, 1, n, L, _native._lut_ptr(lut), 1, 0, lanes, C.byref(p), C.byref(w), C.byref(base), C.byref(stages), C.byref(brows), None, 0)
         assert rc == 0, rc
         words = (C.c_uint * 16).from_address(w.value)
         Q = stages.value
