@@ -329,6 +329,7 @@ struct fx_engine {
     // launched-first host call (fx_score_begin_staged): what the launchers that can wait for rows copy into their arguments, and
     // whether the launch just enqueued did (a launcher that cannot returns FX_EUNSUPPORTED before it enqueues anything)
     struct { bool on = false, used = false; FxRowsReady r = {nullptr, 0, 0, 0, 0}; FxRelay relay = {nullptr, nullptr, 0, 0, 0}; bool relay_used = false; } rows_req;
+    int64_t staging_noncoherent = 0;   // (experiment) 1 = the input staging area is non-coherent host memory (cached in L2)
     int64_t relay_spread = 0;   // 1 = relay launches take their unit ranges in plain block order: member 0's workgroups on all eight XCDs instead of one (no gain: A/B)
     unsigned* relay_flags = nullptr; size_t relay_flag_words = 0; unsigned relay_seq = 0;
     int64_t launch_relay = 1;   // 1 = launched-first calls of dense ensembles whose plan says "copy" relay the rows through member 0's workgroups (0 = such calls pack, upload, then launch: A/B)

@@ -69,7 +69,10 @@ int fx_pinned(fx_engine* e, int slot, size_t bytes, void** out) {
             e->h_pinned[slot] = nullptr; e->pinned_bytes[slot] = 0;
         }
         size_t cap = std::max<size_t>(bytes + bytes / 4, 1 << 16);
-        if (hipHostMalloc(&e->h_pinned[slot], cap, hipHostMallocMapped) != hipSuccess) {
+        // (experiment, option staging_noncoherent: the INPUT staging area as non-coherent host memory -- cached in the GPU's L2, made
+        //  visible at kernel boundaries; rows that arrive during a launch are tile-pitched, so no line is read before it is written)
+        const unsigned flags = hipHostMallocMapped | ((slot == 0 && e->staging_noncoherent) ? hipHostMallocNonCoherent : 0u);
+        if (hipHostMalloc(&e->h_pinned[slot], cap, flags) != hipSuccess) {
             (void)hipGetLastError();
             return fx_fail(e, FX_ENOMEM, "hipHostMalloc of pinned staging failed");
         }
@@ -320,6 +323,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "cnn_stage_host")) return &e->cnn_stage_host;
     if (!std::strcmp(key, "launch_relay")) return &e->launch_relay;
     if (!std::strcmp(key, "relay_spread")) return &e->relay_spread;
+    if (!std::strcmp(key, "staging_noncoherent")) return &e->staging_noncoherent;
     if (!std::strcmp(key, "train_rows")) return &e->train_rows;
     if (!std::strcmp(key, "train_lds")) return &e->train_lds;
     if (!std::strcmp(key, "train_threads")) return &e->train_threads;
@@ -360,6 +364,12 @@ int fx_engine_set_option(fx_engine* e, const char* key, int64_t value) {
     // a running resident generation was started under the old options (its geometry, but also the kernel forms its
     // workgroups run: pair rows or plain rows, ...): it leaves, the next calls start a new one under the new ones
     if (*s != value) { fx_server_stop(e); lp_disarm(e); }
+    if (s == &e->staging_noncoherent && *s != value && e->h_pinned[0]) {
+        // (the staging area is reallocated with the other attribute on next use)
+        (void)hipStreamSynchronize(e->stream);
+        (void)hipHostFree(e->h_pinned[0]);
+        e->h_pinned[0] = nullptr; e->pinned_bytes[0] = 0;
+    }
     *s = value;
     e->server.refused.clear();                             // (what has a resident form depends on the form selectors)
     return FX_OK;
