@@ -396,6 +396,7 @@ int fx_engine_get_option(fx_engine* e, const char* key, int64_t* value) {
     if (e && key && !std::strcmp(key, "launch_first_calls")) { *value = e->launch_first_calls; return FX_OK; }
     if (e && key && !std::strcmp(key, "launch_first_redone")) { *value = e->launch_first_redone; return FX_OK; }
     if (e && key && !std::strcmp(key, "launch_relay_calls")) { *value = e->launch_relay_calls; return FX_OK; }
+    if (e && key && !std::strcmp(key, "large_bar")) { *value = (e->large_bar && !e->rows_refused) ? 1 : 0; return FX_OK; }   // (the host can store into device memory: resident forms, launched-first calls)
     if (e && key && !std::strcmp(key, "server_streamed")) { *value = e->server.streamed; return FX_OK; }
     if (e && key && !std::strcmp(key, "server_slots")) { *value = e->server.running ? e->server.tiles : 0; return FX_OK; }
     int64_t* s = option_slot(e, key);
