@@ -321,3 +321,26 @@ def test_two_processes_on_one_gpu_with_launched_first_calls(launch_first, tmp_pa
         digest, first, relayed, redone = out.strip().split()[-4:]
         assert digest == h.hexdigest(), (out, err[-500:])
         assert int(first) >= 24 and int(relayed) >= 12
+
+
+@pytest.mark.parametrize("kind,L,alpha,M", [("ge", 90, s_utils.AAS, 8), ("cnn", 8, "TGCA", 3), ("mlp", 14, "UGCA", 1)])
+def test_alternating_batches_leave_nothing_behind(launch_first, kind, L, alpha, M):
+    """Consecutive launched-first (and relay) calls on DIFFERENT batches of one shape, and of different sizes: bytes of the previous
+    call left in a cache, in the staging area, in the relay area or behind a tile flag would show as the other batch's scores."""
+    eng = launch_first
+    model = _model(kind, L, alpha, M)
+    batches = []
+    try:
+        eng.set_option("launch_first", 0)
+        eng.set_option("launch_relay", 0)
+        for k, n in enumerate((70_000, 70_000, 40_001, 90_000)):
+            _, seqs = rand_seqs(n, L, alpha, seed=500 + k)
+            batches.append((seqs, np.asarray(model.get_fitness(seqs)).copy()))
+        eng.set_option("launch_first", 1)
+        eng.set_option("launch_relay", 1)
+        for _ in range(5):
+            for seqs, want in batches:
+                assert np.array_equal(np.asarray(model.get_fitness(seqs)).view(np.uint32), want.view(np.uint32))
+    finally:
+        eng.set_option("launch_first", 1)
+        eng.set_option("launch_relay", 1)
