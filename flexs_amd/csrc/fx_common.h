@@ -329,6 +329,7 @@ struct fx_engine {
     // launched-first host call (fx_score_begin_staged): what the launchers that can wait for rows copy into their arguments, and
     // whether the launch just enqueued did (a launcher that cannot returns FX_EUNSUPPORTED before it enqueues anything)
     struct { bool on = false, used = false; FxRowsReady r = {nullptr, 0, 0, 0, 0}; FxRelay relay = {nullptr, nullptr, 0, 0, 0}; bool relay_used = false; } rows_req;
+    int64_t dense_prefetch = 1; // MLP / GE launches that read rows from host memory ask for the next tile's bytes a tile ahead: 1 = in a relay of >= 4 members (where it pays), 2 = always (A/B), 0 = never
     int64_t staging_noncoherent = 0;   // (experiment) 1 = the input staging area is non-coherent host memory (cached in L2)
     int64_t relay_spread = 0;   // 1 = relay launches take their unit ranges in plain block order: member 0's workgroups on all eight XCDs instead of one (no gain: A/B)
     unsigned* relay_flags = nullptr; size_t relay_flag_words = 0; unsigned relay_seq = 0;

@@ -324,6 +324,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "launch_relay")) return &e->launch_relay;
     if (!std::strcmp(key, "relay_spread")) return &e->relay_spread;
     if (!std::strcmp(key, "staging_noncoherent")) return &e->staging_noncoherent;
+    if (!std::strcmp(key, "dense_prefetch")) return &e->dense_prefetch;
     if (!std::strcmp(key, "train_rows")) return &e->train_rows;
     if (!std::strcmp(key, "train_lds")) return &e->train_lds;
     if (!std::strcmp(key, "train_threads")) return &e->train_threads;

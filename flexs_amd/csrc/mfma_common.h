@@ -130,14 +130,21 @@ __device__ __forceinline__ void fx_stage_tile(const uint8_t* __restrict__ src, i
 // A tile starts at a multiple of 128 bytes in both areas: the 8-byte accesses are aligned.
 __device__ __forceinline__ void fx_stage_tile_pass(const uint8_t* __restrict__ src, int bytes, uint8_t* dst_lds, int lane, uint8_t* relay) {
     for (int off = lane * 16; off < bytes; off += 64 * 16) {
-        FxBytes16 v{};
-        if (off + 16 <= bytes) v = *reinterpret_cast<const FxBytes16*>(src + off);
-        else for (int b = off; b < bytes; ++b) reinterpret_cast<uint8_t*>(&v)[b - off] = src[b];
-        uint32_t* d = reinterpret_cast<uint32_t*>(dst_lds + off);
-        d[0] = v.w[0]; d[1] = v.w[1]; d[2] = v.w[2]; d[3] = v.w[3];               // (the scratch is a multiple of 16 bytes)
-        unsigned long long* r8 = reinterpret_cast<unsigned long long*>(relay + off);
-        __hip_atomic_store(r8, (unsigned long long)v.w[0] | ((unsigned long long)v.w[1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(r8 + 1, (unsigned long long)v.w[2] | ((unsigned long long)v.w[3] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (off + 16 <= bytes) {
+            const FxBytes16 v = *reinterpret_cast<const FxBytes16*>(src + off);
+            uint32_t* d = reinterpret_cast<uint32_t*>(dst_lds + off);
+            d[0] = v.w[0]; d[1] = v.w[1]; d[2] = v.w[2]; d[3] = v.w[3];
+            unsigned long long* r8 = reinterpret_cast<unsigned long long*>(relay + off);
+            __hip_atomic_store(r8, (unsigned long long)v.w[0] | ((unsigned long long)v.w[1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(r8 + 1, (unsigned long long)v.w[2] | ((unsigned long long)v.w[3] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            // (the ragged last tile of a batch: byte by byte -- no register array indexed at run time)
+            for (int b = off; b < bytes; ++b) {
+                const uint8_t x = src[b];
+                dst_lds[b] = x;
+                __hip_atomic_store(relay + b, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 __device__ __forceinline__ void fx_stage_tile_from(const uint8_t* relay, int bytes, uint8_t* dst_lds, int lane) {
@@ -215,6 +222,28 @@ __device__ __forceinline__ void fx_dma4(const void* g_lane, unsigned lds_base) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g_lane), "s"(lds_base) : "memory");
 }
+// A FULL tile's bytes (a multiple of 16) global -> this wave's LDS scratch without registers and without waiting: the caller scores
+// another tile meanwhile and runs fx_wait_vm(0) before it reads the scratch.  For rows in HOST memory (zero-copy launches): the
+// PCIe round trip of a tile's bytes then lies beside the previous tile's work instead of in front of its own.
+__device__ __forceinline__ void fx_stage_tile_dma(const uint8_t* src, int bytes, uint8_t* dst_lds, int lane) {
+    const unsigned base = __builtin_amdgcn_readfirstlane(fx_lds_addr(dst_lds));
+    for (int c = 0; c * 1024 < bytes; ++c) {
+        const int off = c * 1024 + lane * 16;
+        if (off < bytes) fx_dma16(src + off, base + (unsigned)c * 1024u);
+    }
+}
+// Relay (FxRelay): a tile that sits in this wave's LDS scratch goes on to the relay area (device-scope stores; the caller waits --
+// fx_wait_vm(0) -- and raises the tile's flag).
+__device__ __forceinline__ void fx_relay_from_lds(const uint8_t* src_lds, int bytes, int lane, uint8_t* relay) {
+    for (int off = lane * 16; off < bytes; off += 64 * 16) {
+        const uint32_t* d = reinterpret_cast<const uint32_t*>(src_lds + off);
+        const unsigned long long a = (unsigned long long)d[0] | ((unsigned long long)d[1] << 32), b = (unsigned long long)d[2] | ((unsigned long long)d[3] << 32);
+        unsigned long long* r8 = reinterpret_cast<unsigned long long*>(relay + off);
+        __hip_atomic_store(r8, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(r8 + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // at most n (wave-uniform) vector-memory loads of this wave still in flight
 __device__ __forceinline__ void fx_wait_vm(int n) {
     switch (n) {

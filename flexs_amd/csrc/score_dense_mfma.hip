@@ -61,8 +61,12 @@ __global__ void k_ge_bytetab(const float* __restrict__ w1, const uint8_t* __rest
 
 // SLAB (with DG): the HxH blocks are streamed through LDS once per round of WAVES tiles (mma_layer_slab) instead
 // of once per tile per wave; the waves of a workgroup then walk the tiles in lockstep.
-template <int KIND, int A, int HT, int NT, int WAVES, bool G1, bool W1G, bool DG, bool SLAB = false, bool BT = false, bool PAIR = false>
+// PF (rows in HOST memory, the PAIR / BT forms that copy a tile's bytes into LDS): a wave claims its NEXT tile before it scores the
+// current one and asks for that tile's bytes straight into a second LDS scratch (fx_stage_tile_dma) -- the PCIe round trip, 3 us
+// idle and ~16 us with the link saturated, then lies beside a tile's work instead of in front of every tile of a latency-bound walk.
+template <int KIND, int A, int HT, int NT, int WAVES, bool G1, bool W1G, bool DG, bool SLAB = false, bool BT = false, bool PAIR = false, bool PF = false>
 __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
+    static_assert(!PF || ((PAIR || BT) && NT == 1 && !SLAB), "PF is a form of the staged-tile first layers");
     static_assert(!PAIR || (KIND == FX_MLP && G1 && !W1G && !DG && NT == 1), "PAIR is the MLP gather form on a 4-letter alphabet");
     static_assert(!SLAB || (DG && NT == 1), "SLAB streams the L2-resident blocks of the one-tile form");
     static_assert(!BT || (KIND == FX_GE && NT == 1 && !DG && !SLAB), "BT is the GlobalEpistasis byte-table form");
@@ -80,7 +84,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
     int* next_tile = reinterpret_cast<int*>(aux + 64);                  // 4 work counters (one per SIMD), after the 256-byte LUT
     int* simd_waves = next_tile + 4;                                    // 4 wave counts (workgroup's waves per SIMD)
     f4* slab = reinterpret_cast<f4*>(aux + 64 + 8);                     // SLAB: 2 x KG*HT KiB
-    uint8_t* stw = reinterpret_cast<uint8_t*>(aux + 64 + 8) + (tid >> 6) * p.stage_stride;   // this wave's sequence-byte scratch (never with SLAB)
+    uint8_t* stw = reinterpret_cast<uint8_t*>(aux + 64 + 8) + (tid >> 6) * p.stage_stride * (PF ? 2 : 1);   // this wave's sequence-byte scratch (never with SLAB)
+    [[maybe_unused]] uint8_t* stw_alt = stw + p.stage_stride;           // PF: the scratch the next tile's bytes arrive in
     fx_stamp(p.trace, 0);
     if (p.wave_prio) fx_stagger_priority();
     const int simd = fx_simd_id();
@@ -97,6 +102,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
     [[maybe_unused]] unsigned tiles_done = 0;
     FxSimdShare share{0, 1, 1};
     if (BT && p.stage_stride && lane < 32) stw[16 * L + lane] = (uint8_t)p.bt_base;   // what the padded trips of the last row read
+    if (PF && BT && p.stage_stride && lane < 32) stw_alt[16 * L + lane] = (uint8_t)p.bt_base;
 
     for (int m = m_first; m <= m_last; ++m) {
         __syncthreads();
@@ -164,23 +170,28 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
             const int64_t t0 = (s_lo + p.ready.Q - 1) / p.ready.Q * p.ready.Q;
             if (t0 < s_hi) rows_rot = (int)(t0 - s_lo);
         }
+        // the next tile of this wave's SIMD share (-1: none left)
+        auto pull_tile = [&]() -> int64_t {
+            int pulled = 0;
+            if (lane == 0) pulled = atomicAdd(&next_tile[simd], 1);
+            pulled = __builtin_amdgcn_readfirstlane(pulled);
+            if (s_lo + pulled >= s_hi) return -1;
+            if (!rows_arrive) return s_lo + pulled;
+            const int len = (int)(s_hi - s_lo);
+            int at = pulled + rows_rot;
+            if (at >= len) at -= len;
+            return s_lo + at;
+        };
+        [[maybe_unused]] int64_t pf_next = -2;              // PF: the tile claimed ahead (-2: none claimed, -1: the share is exhausted)
+        [[maybe_unused]] bool pf_issued = false;            // PF: ... and its bytes are on their way into stw_alt
         for (int64_t round = 0;; ++round) {
             // SLAB: lockstep rounds of WAVES tiles; waves without a tile in the last round run along on tile 0
             int64_t tg_want = t_lo + round * WAVES + (tid >> 6);
             if (!SLAB) {
-                int pulled = 0;
-                if (lane == 0) pulled = atomicAdd(&next_tile[simd], 1);
-                pulled = __builtin_amdgcn_readfirstlane(pulled);
-                tg_want = s_lo + pulled;
-                if (tg_want >= s_hi) break;
-                if (rows_arrive) {
-                    const int len = (int)(s_hi - s_lo);
-                    int at = pulled + rows_rot;
-                    if (at >= len) at -= len;
-                    tg_want = s_lo + at;
-                    // (a relay's readers wait for member 0's workgroups, not for the host)
-                    if (!p.relay.flags || m + p.m_off == 0) fx_rows_wait(p.ready, (int)(tg_want % p.ready.Q), rows_known, p.err);
-                }
+                tg_want = (PF && pf_next != -2) ? pf_next : pull_tile();
+                if (tg_want < 0) break;
+                // (a relay's readers wait for member 0's workgroups, not for the host)
+                if (rows_arrive && (!p.relay.flags || m + p.m_off == 0)) fx_rows_wait(p.ready, (int)(tg_want % p.ready.Q), rows_known, p.err);
             }
             if (SLAB && t_lo + round * WAVES >= t_hi) break;
             const bool live = !SLAB || tg_want < t_hi;
@@ -199,10 +210,29 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
             // the tile's bytes through this wave's LDS scratch (PAIR / BT first layers); lanes past the batch use row 0
             const int64_t tile_rows = p.N - tg * 16 < 16 ? p.N - tg * 16 : 16;
             if (p.stage_stride && (PAIR || BT)) {
-                const int64_t at_byte = tg * (rows_arrive ? (int64_t)p.ready.pitch : (int64_t)16 * L);
-                if (rows_arrive && p.relay.flags) {
+                const int64_t tile_pitch = rows_arrive ? (int64_t)p.ready.pitch : (int64_t)16 * L;
+                const int64_t at_byte = tg * tile_pitch;
+                const bool relayed = rows_arrive && p.relay.flags;
+                const bool copier = relayed && m + p.m_off == 0;
+                bool have_bytes = false;
+                if constexpr (PF) {
+                    if (pf_issued) {
+                        // this tile's bytes were asked for a tile ago: they are in the other scratch (once the loads have landed)
+                        uint8_t* t = stw; stw = stw_alt; stw_alt = t;
+                        fx_wait_vm(0);
+                        have_bytes = true;
+                    }
+                    pf_next = -2; pf_issued = false;
+                }
+                if (have_bytes) {
+                    if (copier) {
+                        fx_relay_from_lds(stw, (int)tile_rows * L, lane, p.relay.dst + tg * (int64_t)p.relay.pitch);
+                        fx_wait_vm(0);
+                        if (lane == 0) __hip_atomic_store(p.relay.flags + tg, p.relay.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                } else if (relayed) {
                     const int64_t relay_byte = tg * (int64_t)p.relay.pitch;
-                    if (m + p.m_off == 0) {
+                    if (copier) {
                         fx_stage_tile_pass(p.ascii + at_byte, (int)tile_rows * L, stw, lane, p.relay.dst + relay_byte);
                         fx_wait_vm(0);                              // this wave's stores have been taken ...
                         if (lane == 0) __hip_atomic_store(p.relay.flags + tg, p.relay.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... the tile is there
@@ -211,6 +241,17 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                         fx_stage_tile_from(p.relay.dst + relay_byte, (int)tile_rows * L, stw, lane);
                     }
                 } else fx_stage_tile(p.ascii + at_byte, (int)tile_rows * L, stw, lane);
+                if constexpr (PF) {
+                    // claim the next tile now and, if it is whole and its rows are known to be there, ask for its bytes (waves that
+                    // read the host staging area: all of them without a relay, member 0's with one)
+                    if (!relayed || copier) {
+                        pf_next = pull_tile();
+                        if (pf_next >= 0 && (pf_next + 1) * 16 <= p.N && (!rows_arrive || (int)(pf_next % p.ready.Q) < rows_known)) {
+                            fx_stage_tile_dma(p.ascii + pf_next * tile_pitch, 16 * L, stw_alt, lane);
+                            pf_issued = true;
+                        }
+                    }
+                }
             }
             const uint8_t* srow = stw + (n[0] < p.N ? sq : 0) * L;
             f4 h[HT][NT];
@@ -492,9 +533,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
 }
 
 template <int KIND, int A, int HT, int NT, int WAVES, bool G1, bool W1G = false, bool DG = false, bool SLAB = false, bool BT = false,
-          bool PAIR = false>
+          bool PAIR = false, bool PF = false>
 int launch_inst(fx_engine* e, const DenseArgs& a_in, size_t lds_bytes) {
-    auto kern = k_score_dense_mfma<KIND, A, HT, NT, WAVES, G1, W1G, DG, SLAB, BT, PAIR>;
+    auto kern = k_score_dense_mfma<KIND, A, HT, NT, WAVES, G1, W1G, DG, SLAB, BT, PAIR, PF>;
     if (SLAB) lds_bytes += (size_t)2 * 2 * HT * 1024;           // two slabs of KG = 2 input tiles
     static bool attr_set[64] = {};
     if (!attr_set[e->device & 63]) {
@@ -945,6 +986,12 @@ int launch_pipe(fx_engine* e, const DenseArgs& a, size_t lds_bytes) {
 
 namespace {
 
+// dense_prefetch: 1 = where it was measured to pay (a relay of at least four members), 2 = every launch that reads host rows (A/B), 0 = never
+static bool fx_dense_prefetch_pays(const fx_engine* e, int M) {
+    if (e->dense_prefetch == 2) return true;
+    return e->dense_prefetch == 1 && e->rows_req.on && e->rows_req.relay.flags != nullptr && M >= 4;
+}
+
 // HT <= 7: 16 waves (128-register budget); HT = 8: 8 waves; HT = 13 / 16 (H <= 256): 8 waves and the HxH blocks stream from L2.
 template <int HT_>
 int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, DenseArgs& a) {
@@ -994,6 +1041,14 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
                         a.coop = groups; a.coop_off = (int)(need / 4);
                         need += (size_t)groups * 2 * HT_ * 1024;
                     }
+            }
+            if constexpr (W == 16) {
+                // rows in host memory: the next tile's bytes are asked for a tile ahead (PF: a second scratch per wave)
+                // (where it pays: a relay, whose few copying waves see the link's full latency -- 8 x GE L=90: 285 -> 234 us per
+                //  launch; without a relay every wave reads for itself and claiming a tile ahead costs more than it hides: MLP L=14
+                //  93 -> 101 us, 3 x GE with a relay 175 -> 183: profiles/r5_dense_prefetch.log)
+                if (e->ascii_host && fx_dense_prefetch_pays(e, a.M) && a.stage_stride > 0 && !a.coop && need + (size_t)W * stride <= (size_t)e->max_lds)
+                    return launch_inst<FX_GE, 4, HT_, 1, W, false, false, false, false, true, false, true>(e, a, need + (size_t)W * stride);
             }
             return launch_inst<FX_GE, 4, HT_, 1, W, false, false, false, false, true>(e, a, need);
         }
@@ -1055,6 +1110,10 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
                     // shared last tiles: the groups' exchange buffers (2 x HT KiB each) lie over the pair rows
                     if (W == 16 && e->dense_coop)
                         a.coop = (size_t)lay.pair_floats * 4 >= (size_t)4 * HT_ * 1024 ? 2 : (size_t)lay.pair_floats * 4 >= (size_t)2 * HT_ * 1024 ? 1 : 0;
+                    if constexpr (W == 16) {
+                        if (e->ascii_host && fx_dense_prefetch_pays(e, a.M) && a.stage_stride > 0 && need + (size_t)W * stride <= (size_t)e->max_lds)
+                            return launch_inst<FX_MLP, 4, HT_, 1, W, true, false, false, false, false, true, true>(e, a, need + (size_t)W * stride);
+                    }
                     return launch_inst<FX_MLP, 4, HT_, 1, W, true, false, false, false, false, true>(e, a, need);
                 }
             }

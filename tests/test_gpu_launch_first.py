@@ -344,3 +344,29 @@ def test_alternating_batches_leave_nothing_behind(launch_first, kind, L, alpha, 
     finally:
         eng.set_option("launch_first", 1)
         eng.set_option("launch_relay", 1)
+
+
+@pytest.mark.parametrize("kind,L,alpha,M,n", [("ge", 90, s_utils.AAS, 8, 70_001), ("mlp", 14, "UGCA", 1, 60_000), ("mlp", 14, "UGCA", 3, 40_003),
+                                              ("ge", 90, s_utils.AAS, 3, 40_000), ("ge", 237, s_utils.AAS, 8, 20_000)])
+def test_next_tile_prefetch_gives_the_same_bits(launch_first, kind, L, alpha, M, n):
+    """MLP / GE launches that read their rows from host memory may claim a tile ahead and ask for its bytes straight into a second
+    LDS scratch (engine option dense_prefetch: 1 = in a relay of at least four members, 2 = always, 0 = never): the same bits from
+    strings and from packed bytes, with another batch in between."""
+    eng = launch_first
+    model = _model(kind, L, alpha, M)
+    members = model.models if M > 1 else [model]
+    b, seqs = rand_seqs(n, L, alpha, seed=31)
+    _, other = rand_seqs(n, L, alpha, seed=32)
+    got = {}
+    try:
+        for pf in (0, 1, 2):
+            eng.set_option("dense_prefetch", pf)
+            model.get_fitness(other)
+            got[pf, "str"] = np.asarray(model.get_fitness(seqs)).copy()
+            nm, mean = eng.score([m.native() for m in members], b, members[0]._lut, want_matrix=(M == 1), want_mean=(M > 1))
+            got[pf, "bytes"] = (nm[:, 0] if M == 1 else mean).copy()
+    finally:
+        eng.set_option("dense_prefetch", 1)
+    want = got[0, "str"].view(np.uint32)
+    for key, v in got.items():
+        assert np.array_equal(v.view(np.uint32), want), key
