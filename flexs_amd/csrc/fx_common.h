@@ -340,7 +340,7 @@ struct fx_engine {
     bool rows_refused = false;
     unsigned rows_base = 0;
     bool ascii_host = false;    // (request) the launch about to be enqueued reads its sequences from pinned HOST memory (zero-copy host calls)
-    int64_t cnn_stage_host = 1; // 1 = such launches of the canonical 4-letter CNN copy a tile's bytes into LDS with one wide load (0 = a byte load per position: A/B)
+    int64_t cnn_stage_host = 1; // 1 = such launches of the canonical 4-letter CNN copy a tile's bytes into LDS with one wide load (0 = a byte load per position: A/B; 2 = 1 + the next tile's bytes asked for a tile ahead: A/B, no gain)
     int64_t launch_first_calls = 0, launch_first_redone = 0;   // (read) host calls launched before their strings were packed; of those, redone the plain way
     int64_t launch_first = 1;   // 1 = big list[str] calls whose kernels can wait for rows are launched before the strings are packed (0 = pack, then launch: A/B)
     // chunked host call in flight (fx_score_begin / _submit / _finish)

@@ -46,6 +46,7 @@ struct CnnArgs {
     // packed-layout offsets (floats)
     int off_first, off_c2, off_c3, off_cb, off_w1p, conv_floats, off_d1, off_d2, off_db, total_floats;
     int stw_stride;             // STG: bytes of LDS scratch per wave (16 L rounded up to 16)
+    int stw_ahead;              // STG: 1 = two scratches per wave, the next tile's bytes are asked for a tile ahead (fx_stage_tile_dma)
     FxRowsReady ready;          // launched-first host call: the rows arrive while the kernel runs (words == nullptr: they are all there)
 };
 
@@ -84,7 +85,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
     // are served by no cache: the byte load per position and lane group of the form below was a PCIe round trip each (~2 us), which
     // four waves per SIMD hide in a long launch but not at 1-2 tiles per wave (profiles/r5_e2e_breakdown.log: 98 us against 62 us for
     // the 1e5-sequence launch with the bytes in HBM).
-    [[maybe_unused]] uint8_t* stw = reinterpret_cast<uint8_t*>(smem + lds_floats + 64 + 12) + (tid >> 6) * p.stw_stride;
+    [[maybe_unused]] uint8_t* stw = reinterpret_cast<uint8_t*>(smem + lds_floats + 64 + 12) + (tid >> 6) * p.stw_stride * (p.stw_ahead ? 2 : 1);
+    [[maybe_unused]] uint8_t* stw_alt = stw + p.stw_stride;
 
     fx_stamp(p.trace, 0);
     if (p.wave_prio) fx_stagger_priority();
@@ -151,21 +153,26 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
             if (t0 < s_hi) rows_rot = (int)(t0 - s_lo);
         }
 
+        // the next tile of this wave's SIMD share (-1: none left)
+        auto pull_tile = [&]() -> int64_t {
+            int pulled = 0;
+            if (lane == 0) pulled = atomicAdd(&next_tile[simd], 1);
+            pulled = __builtin_amdgcn_readfirstlane(pulled);
+            if (s_lo + pulled >= s_hi) return -1;
+            if (!rows_arrive) return s_lo + pulled;
+            const int len = (int)(s_hi - s_lo);
+            int at = pulled + rows_rot;
+            if (at >= len) at -= len;
+            return s_lo + at;
+        };
+        [[maybe_unused]] int64_t pf_next = -2;              // STG, stw_ahead: the tile claimed ahead (-2: none claimed, -1: the share is exhausted)
+        [[maybe_unused]] bool pf_issued = false;            // ... and its bytes are on their way into stw_alt
         for (int64_t seg_tile = t_lo;; ++seg_tile) {
             int64_t tg = seg_tile;                               // SEG: every wave of the workgroup walks the same tiles
             if (!SEG) {
-                int pulled = 0;
-                if (lane == 0) pulled = atomicAdd(&next_tile[simd], 1);
-                pulled = __builtin_amdgcn_readfirstlane(pulled);
-                tg = s_lo + pulled;
-                if (tg >= s_hi) break;
-                if (rows_arrive) {
-                    const int len = (int)(s_hi - s_lo);
-                    int at = pulled + rows_rot;
-                    if (at >= len) at -= len;
-                    tg = s_lo + at;
-                    fx_rows_wait(p.ready, (int)(tg % p.ready.Q), rows_known, p.err);
-                }
+                tg = (STG && pf_next != -2) ? pf_next : pull_tile();
+                if (tg < 0) break;
+                if (rows_arrive) fx_rows_wait(p.ready, (int)(tg % p.ready.Q), rows_known, p.err);
             }
             if (tg >= t_hi) break;
             got_tile = true;
@@ -182,7 +189,22 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
             [[maybe_unused]] fx_lds_u8p srow = nullptr;
             if constexpr (STG) {
                 const int64_t tile_rows = p.N - tg * 16 < 16 ? p.N - tg * 16 : 16;
-                fx_stage_tile(p.ascii + tg * (rows_arrive ? (int64_t)p.ready.pitch : (int64_t)16 * L), (int)tile_rows * L, stw, lane);
+                const int64_t tile_pitch = rows_arrive ? (int64_t)p.ready.pitch : (int64_t)16 * L;
+                if (pf_issued) {
+                    // asked for a tile ago: the bytes are in the other scratch once the loads have landed
+                    uint8_t* t = stw; stw = stw_alt; stw_alt = t;
+                    fx_wait_vm(0);
+                } else fx_stage_tile(p.ascii + tg * tile_pitch, (int)tile_rows * L, stw, lane);
+                pf_next = -2; pf_issued = false;
+                if (p.stw_ahead) {
+                    // claim the next tile now; if it is whole and its rows are known to be there, ask for its bytes: the PCIe round
+                    // trip then lies beside this tile's work instead of in front of the next one's
+                    pf_next = pull_tile();
+                    if (pf_next >= 0 && (pf_next + 1) * 16 <= p.N && (!rows_arrive || (int)(pf_next % p.ready.Q) < rows_known)) {
+                        fx_stage_tile_dma(p.ascii + pf_next * tile_pitch, 16 * L, stw_alt, lane);
+                        pf_issued = true;
+                    }
+                }
                 srow = (fx_lds_u8p)(stw + (n[0] < p.N ? sq : 0) * L);
             }
             // a byte of this lane's sequence
@@ -528,7 +550,8 @@ int launch_g(fx_engine* e, const CnnArgs& a_in, size_t lds_bytes) {
     constexpr int waves = WAVES;
     auto kern = k_score_cnn_mfma<A, K, FT, HT, NT, DENSE_LDS, WAVES, G1, L1S, PRIO, SEG, HEAD, STG>;
     if (SEG) lds_bytes += (size_t)WAVES * FT * 64 * 16;          // segment-maxima slots
-    if (STG) lds_bytes += (size_t)WAVES * ((16 * (size_t)a_in.L + 15) / 16 * 16);   // a tile's bytes per wave
+    const bool ahead = STG && e->cnn_stage_host >= 2 && lds_bytes + 2 * (size_t)WAVES * ((16 * (size_t)a_in.L + 15) / 16 * 16) <= (size_t)e->max_lds;
+    if (STG) lds_bytes += (size_t)WAVES * ((16 * (size_t)a_in.L + 15) / 16 * 16) * (ahead ? 2 : 1);   // a tile's bytes per wave (two scratches with the look-ahead)
     static bool attr_set[64] = {};
     if (!attr_set[e->device & 63]) {
         FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -537,6 +560,7 @@ int launch_g(fx_engine* e, const CnnArgs& a_in, size_t lds_bytes) {
     }
     CnnArgs a = a_in;
     a.stw_stride = STG ? (int)((16 * (size_t)a.L + 15) / 16 * 16) : 0;
+    a.stw_ahead = ahead ? 1 : 0;
     if (e->rows_req.on) {
         // (a launched-first call: this kernel waits for its rows tile by tile -- the forms that share a tile among waves do not)
         if (SEG || NT != 1 || !HEAD || e->rows_req.relay.flags) return FX_EUNSUPPORTED;   // (no relay form of this kernel)

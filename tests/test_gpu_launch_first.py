@@ -149,7 +149,7 @@ def test_host_resident_bytes_through_lds_give_the_same_bits(launch_first, L, alp
     b, seqs = rand_seqs(n, L, alpha, seed=11)
     got = {}
     try:
-        for stage in (0, 1):
+        for stage in (0, 1, 2):
             eng.set_option("cnn_stage_host", stage)
             for first in (0, 1):
                 eng.set_option("launch_first", first)
