@@ -7,12 +7,16 @@ weak scaling.  A step = one `Ensemble.get_fitness`-equivalent pass over one batc
 resident in HBM: the fused encode+CNN scoring kernel for all three members, the ensemble-mean
 kernel and, for N > 1, ONE RCCL all-gather of the per-rank means.  The step is issued through
 `flexs_amd.distributed.DistributedEnsemble.launch / finish`, i.e. the product's multi-GPU class.
+Beside it, at the top level of the same line: `e2e_value` = SURVEY.md 8(d)'s end-to-end metric,
+`Ensemble.get_fitness(list[str]) -> np.ndarray` (host strings in, host array out) on the same
+workload, and `e2e_frac_of_kernel`.
 
-Every run also measures the north-star's member-parallel split (8-member ensembles sharded over
-the ranks, all-gather of the stacked predictions, strong scaling) and reports it under
-`member_parallel`; `--mode member` makes that the headline instead.  On one GPU rank 0 adds
-`configs` (kernel time + algorithmic and issued-MFMA fractions for C1/C3/C4/C5), `end_to_end`
-(list[str] -> ndarray through the Python API) and `cpu_baseline`.  One JSON line on rank 0.
+stdout carries ONE JSON line of at most 4 KB (`contract_line`): the contract keys, `roofline`
+(headline kernel + one kernel_ms / issued-MFMA fraction per BASELINE config, scalars only) and
+`cpu_baseline`.  Everything else the run measures (tools/bench_blocks.py: per-config blocks, the
+NoisyAbstractModel half of configs[2], end-to-end splits, explorer patterns and round, the
+member-parallel split) is the FULL record: one JSON line on stderr and
+`gpurun_out/bench_full.json`.
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -30,12 +34,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 faulthandler.enable()
 
-L, ALPHABET, F, H, K, M, BATCH = 8, "TGCA", 32, 100, 5, 3, 100_000
-AAS = "ILVAGMFYWEDQNHCRKSTP"
-PEAK_TF = 157.3                  # f32-input MFMA, dense (MI355X_MICROARCH.md)
-MFMA_FLOP = 2048                 # one v_mfma_f32_16x16x4_f32: 16*16*4 MACs
-MIN_TIMED_S = 0.5                # the settled figure covers at least this much GPU time
-KINDS = {"cnn": 0, "mlp": 1, "ge": 2}
+from tools.bench_common import (AAS, ALPHABET, BATCH, F, H, K, KINDS, L, M, MFMA_FLOP, MIN_TIMED_S, PEAK_TF, _sig,  # noqa: E402,F401
+                                build_members, roofline_block, run_pipelined, time_launches)
+
+MAX_LINE_BYTES = 4096            # the driver's parser lost a 24.8 KB line in round 5 (parsed 14.9 KB in round 4)
 
 
 def cpu_baseline(budget_s=12.0, hard_timeout_s=150.0, nam=False, nam_budget_s=3.0):
@@ -54,31 +56,6 @@ def cpu_baseline(budget_s=12.0, hard_timeout_s=150.0, nam=False, nam_budget_s=3.
     except Exception as e:  # noqa: BLE001 - the GPU numbers must still be reported
         return {"value": None, "unit": "sequences/s", "cores": None, "kind": "port",
                 "sample": f"cpu baseline failed: {type(e).__name__}: {str(e)[:200]}"}
-
-
-def roofline_block(kind, Lx, A, Hx, Fx, Kx, members, n, kern_ms, kernel_name):
-    """Both MFMA fractions of one scoring launch, from its measured duration.
-
-    frac (= frac_issued)  MFMA instructions the launch really issues (fx_debug_mfma_per_tile: the kernels' loop bounds
-                 restated on the host, x ceil(n/16) tiles x members) x 2048 FLOP / kernel_ms / peak: the physical
-                 fraction of the matrix pipe, <= 1.  `achieved` is that rate in TFLOP/s.
-    frac_algorithmic  ALGORITHMIC FLOP (2 x dense MACs x members x sequences, not discounted for
-                 one-hot sparsity or 'same'-padding zeros) / kernel_ms / peak (`achieved_algorithmic`).  The kernels do
-                 not issue those structural zeros, so this figure can exceed 1 on long launches (round-4 verdict:
-                 a headline `frac` that can exceed 1 is not a roofline fraction -- it moved here)."""
-    from flexs_amd import _native, synth
-
-    macs = synth.algorithmic_macs(kind, Lx, A, Hx, Fx, Kx)
-    flop = 2.0 * macs * members * n
-    per_tile = _native.mfma_per_tile(KINDS[kind], Lx, A, Fx, Hx, Kx)
-    issued = float(per_tile) * ((n + 15) // 16) * members * MFMA_FLOP
-    ach_alg = flop / (kern_ms * 1e-3) / 1e12
-    ach = issued / (kern_ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": kernel_name, "achieved": ach, "peak": PEAK_TF, "unit": "TFLOP/s",
-            "frac": ach / PEAK_TF, "frac_issued": ach / PEAK_TF,
-            "achieved_algorithmic": ach_alg, "frac_algorithmic": ach_alg / PEAK_TF,
-            "kernel_ms": kern_ms, "flop_per_launch": flop, "issued_flop_per_launch": issued,
-            "mfma_per_tile": per_tile, "algorithmic_bytes_per_launch": (Lx + 4 * members) * n}
 
 
 def pmc_block():
@@ -115,7 +92,7 @@ def make_report(world, N, steps, warmup, elapsed, host_issue_s, kern_ms, use_dis
                     "of the f32 matrix pipe, <= 1; frac_issued is the same number under its old name). frac_algorithmic = "
                     "algorithmic FLOP (2*MACs, SURVEY.md 8d) / kernel_ms / 157.3 TFLOP/s; it counts one-hot multiplies "
                     "and 'same'-padding zero taps the kernel never issues, so it can exceed 1 on long launches. "
-                    "Flat keys c1_* ... train_* carry every BASELINE config (see flat_scalars in bench.py). mfma_util_pmc = "
+                    "The contract line carries c1_* ... train_* scalars for every BASELINE config (contract_scalars in bench.py). mfma_util_pmc = "
                     "SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMD x CU-cycles) from the rocprofv3 --pmc pass named in pmc_source; "
                     "traffic = FETCH_SIZE x2 + WRITE_SIZE from the same passes")
     if mode == "sequence":
@@ -147,545 +124,19 @@ def make_report(world, N, steps, warmup, elapsed, host_issue_s, kern_ms, use_dis
     }
 
 
+
 # ---------------------------------------------------------------------------------------------------------------
-def build_members(kind, Lx, alphabet, members, device, Hx=H, Fx=F, Kx=K):
-    """`members` surrogates of the product API with synthetic (Glorot + non-zero bias) weights, seeds 1000 + m."""
-    from flexs_amd import synth
-    from flexs_amd.baselines.models import CNN, MLP, GlobalEpistasisModel
-
-    out = []
-    for m in range(members):
-        if kind == "cnn":
-            mod = CNN(Lx, Fx, Hx, alphabet, kernel_size=Kx, device=device)
-        elif kind == "mlp":
-            mod = MLP(Lx, Hx, alphabet, device=device)
-        else:
-            mod = GlobalEpistasisModel(Lx, Hx, alphabet, device=device)
-        mod.model.set_weights(synth.synthetic_weights(mod.model.shapes(), 1000 + m))
-        out.append(mod)
-    return out
+# cN = BASELINE.json configs[N-1] at the sizes the per-config block measures; tag -> key of the full record's `configs`
+CONFIG_TAGS = {"c1": "C1 cnn L=8 A=4 M=1 N=1e4", "c2_1e4": "C2 cnn L=8 A=4 M=3 N=1e4", "c3": "C3 mlp L=14 A=4 H=100 M=1 N=1e5",
+               "c4": "C4 ge L=90 A=20 H=100 M=8 N=1e5", "c5": "C5 cnn L=237 A=20 M=3 N=62500 (one GPU's share of 5e5)",
+               "mlp_h200": "survey mlp H200 L14 N1e5", "cnn_h200": "survey cnn H200 L8 N1e5", "ge_m1": "survey ge M1 L90 N1e5"}
 
 
-def run_pipelined(ens, d_seq, n, steps, warmup, torch, dist, use_dist, want_events=True):
-    """W untimed + K timed steps of ens.launch / ens.finish, double-buffered: the gather of step k (communication
-    stream) overlaps the scoring of step k + 1; barrier + synchronize on both sides of the timed region.
-    Returns (elapsed_s, host_issue_s, kernel_ms)."""
-    st = ens.stream
-
-    def go(count, events):
-        for i in range(count):
-            ens.launch(d_seq, n, slot=i & 1, want="mean", timing=events[i] if events else None)
-            if i:
-                ens.finish((i - 1) & 1)
-        if count:
-            ens.finish((count - 1) & 1)
-
-    go(warmup, None)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] \
-        if want_events else None
-    t0 = time.perf_counter()
-    go(steps, events)
-    host_issue = time.perf_counter() - t0                # host time to ENQUEUE the K steps (GPU still running)
-    st.synchronize()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    ens._engine().sync()                                 # raises if any character was outside the alphabet
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)         # MAX over ranks
-        elapsed = float(t.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else None
-    return elapsed, host_issue, kern_ms
-
-
-def time_launches(eng, models, d_ptr, n, Lx, lut, d_planes, stride, min_ms=60.0, reps0=50):
-    """Mean duration of one scoring launch: one HIP event pair on the engine's stream around `reps` back-to-back
-    launches issued from C (fx_debug_time_score -- Python cannot enqueue a ~15 us kernel fast enough to keep the GPU
-    busy, and the idle gaps would be booked as kernel time), repeated until the bracket covers >= min_ms."""
-    natives = [m.native() for m in models]
-    eng.time_score_planes(natives, d_ptr, n, Lx, lut, d_planes.data_ptr(), stride, 20)      # warm-up
-    reps = reps0
-    while True:
-        ms = eng.time_score_planes(natives, d_ptr, n, Lx, lut, d_planes.data_ptr(), stride, reps)
-        if ms >= min_ms or reps >= 20000:
-            return ms / reps, reps
-        reps = int(min(20000, max(reps * 2, reps * min_ms / max(ms, 1e-3) * 1.1)))
-
-
-def configs_block(eng, device, torch):
-    """Kernel time and both MFMA fractions for the BASELINE.json configs that are not the headline, at the sizes the
-    judge named: C1 (1 CNN, L=8, N=1e4), C2 at N=1e4 (3 CNN), C3 (MLP L=14, N=1e5), C4 (8 x GE L=90 A=20, N=1e5),
-    C5 (3 x CNN L=237 A=20, one GPU's 62 500-row share of the 5e5 batch)."""
-    from flexs_amd import _native, synth
-
-    specs = [
-        ("C1 cnn L=8 A=4 M=1 N=1e4", "cnn", 8, "TGCA", 1, 10_000, "k_score_cnn_mfma"),
-        ("C2 cnn L=8 A=4 M=3 N=1e4", "cnn", 8, "TGCA", 3, 10_000, "k_score_cnn_mfma"),
-        ("C3 mlp L=14 A=4 H=100 M=1 N=1e5", "mlp", 14, "UGCA", 1, 100_000, "k_score_dense_mfma<MLP>"),
-        ("C4 ge L=90 A=20 H=100 M=8 N=1e5", "ge", 90, AAS, 8, 100_000, "k_score_dense_mfma<GE>"),
-        ("C5 cnn L=237 A=20 M=3 N=62500 (one GPU's share of 5e5)", "cnn", 237, AAS, 3, 62_500, "k_score_cnn_pair"),
-        # wide hidden layers (round-4 verdict item 4): H = 200 is DynaPPOEnsemble's default MLP member (dyna_ppo.py:52-55) and the Tutorial's
-        ("survey mlp H200 L14 N1e5", "mlp", 14, "UGCA", 1, 100_000, "k_score_dense_mfma<MLP>", 200),
-        ("survey cnn H200 L8 N1e5", "cnn", 8, "TGCA", 1, 100_000, "k_score_cnn_mfma", 200),
-        ("survey ge M1 L90 N1e5", "ge", 90, AAS, 1, 100_000, "k_score_dense_mfma<GE>", 100),
-    ]
-    out = {}
-    for spec in specs:
-        name, kind, Lx, alpha, members, n, kname = spec[:7]
-        Hx = spec[7] if len(spec) > 7 else H
-        mods = build_members(kind, Lx, alpha, members, device, Hx=Hx)
-        d_in = torch.from_numpy(synth.random_sequence_bytes(n, Lx, alpha, 0)).cuda()
-        stride = (n + 63) // 64 * 64
-        d_planes = torch.empty((members, stride), dtype=torch.float32, device="cuda")
-        torch.cuda.synchronize()
-        ms, reps = time_launches(eng, mods, d_in.data_ptr(), n, Lx, mods[0]._lut, d_planes, stride)
-        Fx, Kx = (F, K) if kind == "cnn" else (0, 0)
-        blk = roofline_block(kind, Lx, len(alpha), Hx, Fx, Kx, members, n, ms, kname)
-        blk["seq_per_s"] = n / (ms * 1e-3)
-        blk["reps"] = reps
-        out[name] = blk
-        del mods, d_in, d_planes
-    return out
-
-
-VALU_LANE_OPS = 256 * 4 * 16 * 2.4e9        # 256 CUs x 4 SIMDs x 16 lanes per cycle x 2.4 GHz = 3.93e13 lane-ops/s
-K4_LANE_OPS_PER_CHAR = 24.5                 # issued VALU lane-ops per (pair, text character), L <= 32: PMC, profiles/archive/r2_run1_pmc_targets.md
-
-
-def nam_block(eng, device):
-    """configs[2]'s other half: NoisyAbstractModel (noisy_abstract_model.py:42-101) on RNA L=14.
-    K4 (bit-parallel Levenshtein + first-arg-min) kernel time for Q=2000 uncached queries against C in {1e2, 1e3, 2e4}
-    cached sequences, launches issued from C (fx_debug_time_min_dist): pair evaluations/s and the fraction of the
-    integer-VALU issue rate (the roofline that binds K4: cache rows are L2-resident, HBM traffic ~ 0);
-    and `NoisyAbstractModel.get_fitness` end to end on the CbAS call pattern (20 calls x 100 sequences, cache 1000 -> 3000)
-    for a plain landscape (2 oracle calls + 1 RNG draw per query from a Python loop, as the reference) and a
-    `batch_safe` one (two batched oracle calls)."""
-    import flexs_amd
-    from flexs_amd import _native, synth
-    from flexs_amd.baselines.models import NoisyAbstractModel
-
-    Lx, alpha, Q = 14, "UGCA", 2000
-    out = {"k4": {}}
-    q = synth.random_sequence_bytes(Q, Lx, alpha, 77)
-    for C_ in (100, 1000, 20000):
-        cache = _native.NativeCache(eng, Lx)
-        cache.append(synth.random_sequence_bytes(C_, Lx, alpha, 78))
-        reps = 20
-        while True:
-            ms = cache.time_min_dist(q, _native.FX_LEVENSHTEIN, reps)
-            if ms >= 40.0 or reps >= 20000:
-                break
-            reps = int(min(20000, max(reps * 2, reps * 40.0 / max(ms, 1e-3) * 1.1)))
-        t = ms / reps * 1e-3
-        pairs = Q * C_
-        lane_ops = K4_LANE_OPS_PER_CHAR * Lx * pairs
-        out["k4"][f"L=14 Q=2000 C={C_}"] = {
-            "kernel_ms": t * 1e3, "pair_evals_per_s": pairs / t, "queries_per_s": Q / t,
-            "roofline": {"bound": "valu-int", "achieved": lane_ops / t / 1e12, "peak": VALU_LANE_OPS / 1e12,
-                         "unit": "T lane-ops/s", "frac": lane_ops / t / VALU_LANE_OPS,
-                         "lane_ops_per_pair_char": K4_LANE_OPS_PER_CHAR, "traffic": None},
-            "workgroups": -(-C_ // 1024) * Q, "reps": reps}
-        del cache
-    out["k4"]["note"] = ("frac = 24.5 issued VALU lane-ops per (pair, text character) [PMC, profiles/archive/r2_run1_pmc_targets.md] x L x "
-                         "pairs / kernel time / (256 CU x 4 SIMD x 16 lanes x 2.4 GHz); one workgroup = one query x <= 1024 "
-                         "cache rows, so C = 100 runs 100 of 256 lanes per workgroup")
-
-    class _Synth(flexs_amd.Landscape):
-        """Deterministic table-like oracle: fitness = hash of the bytes in [0, 1) (ViennaRNA is absent)."""
-
-        def __init__(self, batch_safe):
-            super().__init__("synth")
-            self.batch_safe = batch_safe
-            self._w = (np.arange(1, Lx + 1, dtype=np.int64) * 2654435761) % 1000003
-
-        def _fitness_function(self, seqs):
-            b = _native.sequences_to_bytes([str(s_) for s_ in seqs], L=Lx).astype(np.int64)
-            return ((b * self._w).sum(axis=1) % 1000) / 1000.0
-
-    for name, safe in (("plain_landscape", False), ("batch_safe_landscape", True)):
-        ts = []
-        for rep in range(2):                                   # second pass: engine and caches warm
-            np.random.seed(0)
-            model = NoisyAbstractModel(_Synth(safe), 0.9, device=device)
-            model.train(synth.bytes_to_strings(synth.random_sequence_bytes(1000, Lx, alpha, 5)), np.random.random(1000))
-            batches = [synth.bytes_to_strings(synth.random_sequence_bytes(100, Lx, alpha, 100 + c)) for c in range(20)]
-            t0 = time.perf_counter()
-            for bch in batches:
-                model.get_fitness(bch)
-            ts.append(time.perf_counter() - t0)
-        out[name] = {"value": 2000 / ts[-1], "unit": "sequences/s", "wall_ms": ts[-1] * 1e3, "cache_after": len(model.cache),
-                     "oracle_calls": int(model.landscape.cost)}
-    # the same pattern over a DEVICE table landscape (TF-binding style: every 8-mer has a value; flexs_amd.landscapes.TFBinding
-    # keeps such a table on the GPU): the whole uncached batch is one device round trip (fx_cache_nam_query)
-    class _Table(flexs_amd.Landscape):
-        batch_safe = True
-
-        def __init__(self):
-            super().__init__("table")
-            self._L, self._t = 8, None
-            self._vals = np.random.default_rng(3).random(4 ** 8)
-
-        def _native_table(self):
-            if self._t is None:
-                self._t = _native.NativeTable(_native.Engine.get(device), self._vals, "ACGT", bits=2)
-            return self._t
-
-        def _fitness_function(self, seqs):
-            return self._native_table().lookup(_native.sequences_to_bytes([str(s_) for s_ in seqs], L=8))
-
-    ts = []
-    for rep in range(2):
-        np.random.seed(0)
-        model = NoisyAbstractModel(_Table(), 0.9, device=device)
-        model.train(synth.bytes_to_strings(synth.random_sequence_bytes(1000, 8, "ACGT", 5)), np.random.random(1000))
-        batches = [synth.bytes_to_strings(synth.random_sequence_bytes(100, 8, "ACGT", 100 + c)) for c in range(20)]
-        t0 = time.perf_counter()
-        for bch in batches:
-            model.get_fitness(bch)
-        ts.append(time.perf_counter() - t0)
-    out["device_table_landscape_L8"] = {"value": 2000 / ts[-1], "unit": "sequences/s", "wall_ms": ts[-1] * 1e3, "cache_after": len(model.cache),
-                                        "oracle_calls": int(model.landscape.cost),
-                                        "what": "TF-binding style table of all 8-mers on the device: neighbour search + both look-ups + blend "
-                                                "of a batch in one device round trip (fx_cache_nam_query), RNG draws on the host"}
-    out["what"] = ("NoisyAbstractModel(ss=0.9).get_fitness, RNA L=14, CbAS pattern: 20 calls x 100 sequences, cache 1000 -> ~3000. "
-                   "Host-bound by construction: per call one K4 launch (~20 us) + K5, but the 2 oracle calls and the RNG draw "
-                   "per uncached query stay in a Python loop in the reference's order (plain landscape); a batch_safe landscape "
-                   "gets two batched oracle calls instead")
-    return out
-
-
-def end_to_end_block(device, configs=None):
-    """SURVEY.md 8(d)'s primary metric: `get_fitness(list[str])` -> np.ndarray, host strings in, host array out (string
-    marshalling + PCIe both ways inclusive), for configs[1] and -- marshalling cost grows with L -- for C3 (MLP L=14), C4
-    (8 x GE L=90) and C5 (3 x CNN L=237, one GPU's 62 500-row share); plus the small-call latency.  Each row carries its
-    split: `pack_ms` = the string marshalling alone (csrc/strpack.c into the pinned staging area, worker threads as the
-    call uses them; `pack_1thread_ms` beside it), `kernel_ms` = the scoring launch from `configs`, and what is left of
-    the wall time is PCIe + synchronisation + Python (pieces overlap in the chunked call, so the parts can exceed the whole)."""
-    import flexs_amd
-    from flexs_amd import _native, synth
-
-    strpack = _native._strpack
-    out = {}
-
-    def pack_ms(seqs, Lx, threads):
-        buf = np.empty((len(seqs), Lx), np.uint8)
-        prev = strpack.set_threads(threads)
-        ts = []
-        for _ in range(7):
-            t0 = time.perf_counter(); strpack.pack(seqs, Lx, buf); ts.append(time.perf_counter() - t0)
-        strpack.set_threads(prev)
-        return float(np.median(ts)) * 1e3
-
-    rows = (("C2 3xCNN L=8", "cnn", L, ALPHABET, M, BATCH, "C2 full (headline kernel)"),
-            ("C3 MLP L=14", "mlp", 14, "UGCA", 1, 100_000, "C3 mlp L=14 A=4 H=100 M=1 N=1e5"),
-            ("C4 8xGE L=90", "ge", 90, AAS, 8, 100_000, "C4 ge L=90 A=20 H=100 M=8 N=1e5"),
-            ("C5 3xCNN L=237", "cnn", 237, AAS, 3, 62_500, "C5 cnn L=237 A=20 M=3 N=62500 (one GPU's share of 5e5)"))
-    for name, kind, Lx, alpha, members, n, cfg_key in rows:
-        mods = build_members(kind, Lx, alpha, members, device)
-        model = flexs_amd.Ensemble(mods) if members > 1 else mods[0]
-        seqs = synth.bytes_to_strings(synth.random_sequence_bytes(n, Lx, alpha, 1))
-        model.get_fitness(seqs)
-        ts = []
-        for _ in range(5 if Lx > 100 else 9):
-            t0 = time.perf_counter(); model.get_fitness(seqs); ts.append(time.perf_counter() - t0)
-        t = float(np.median(ts))
-        row = {"value": n / t, "unit": "sequences/s", "wall_ms": t * 1e3, "n": n}
-        # launched first, packed behind (fx_score_begin_staged) where the plan and the kernel allow it: the A/B beside it
-        eng_ab = mods[0]._engine()
-        try:
-            c0 = eng_ab.get_option("launch_first_calls")
-            model.get_fitness(seqs)
-            row["launched_first"] = bool(eng_ab.get_option("launch_first_calls") - c0)
-            if row["launched_first"]:
-                eng_ab.set_option("launch_first", 0)
-                model.get_fitness(seqs)
-                ts = []
-                for _ in range(5 if Lx > 100 else 9):
-                    t0 = time.perf_counter(); model.get_fitness(seqs); ts.append(time.perf_counter() - t0)
-                row["wall_ms_packed_first"] = float(np.median(ts)) * 1e3
-                # ... and with the results handed out in place (FLEXS_AMD_RESULTS_IN_PLACE = 1, opt-in: see flexs_amd/_native.py)
-                eng_ab.set_option("launch_first", 1)
-                prev_in_place, _native.RESULTS_IN_PLACE = _native.RESULTS_IN_PLACE, 1
-                try:
-                    model.get_fitness(seqs)
-                    ts = []
-                    for _ in range(5 if Lx > 100 else 9):
-                        t0 = time.perf_counter(); model.get_fitness(seqs); ts.append(time.perf_counter() - t0)
-                    row["wall_ms_results_in_place"] = float(np.median(ts)) * 1e3
-                finally:
-                    _native.RESULTS_IN_PLACE = prev_in_place
-        except Exception:                                   # (a library without the option: the row stays as it is)
-            pass
-        finally:
-            try:
-                eng_ab.set_option("launch_first", 1)
-            except Exception:
-                pass
-        if strpack is not None:
-            row["pack_ms"] = pack_ms(seqs, Lx, 0)
-            row["pack_1thread_ms"] = pack_ms(seqs, Lx, 1)
-        kern = (configs or {}).get(cfg_key, {}).get("kernel_ms")
-        if kern:
-            row["kernel_ms"] = kern
-            row["frac_of_kernel_rate"] = (n / t) / (n / (kern * 1e-3))
-        row["h2d_bytes"], row["d2h_bytes"] = n * Lx, 4 * n
-        out[name + " list_str"] = row
-        if name.startswith("C2"):
-            arr_s = np.array(seqs, dtype="S")
-            model.get_fitness(arr_s)
-            ts = []
-            for _ in range(9):
-                t0 = time.perf_counter(); model.get_fitness(arr_s); ts.append(time.perf_counter() - t0)
-            t = float(np.median(ts))
-            out["C2 3xCNN L=8 ndarray_S"] = {"value": n / t, "unit": "sequences/s", "wall_ms": t * 1e3}
-            # SURVEY.md 8(d): small-call latency at N in {1, 4, 20, 100, 2001}, host strings -> host scores, median of 200 calls;
-            # resident form (narrow generation up to 256 sequences, wide up to 4096, streamed from 384) beside a launch per call (serve_small = 0: the form of rounds 1-2)
-            eng = mods[0]._engine()
-
-            def call_us(batch):
-                for _ in range(20):
-                    model.get_fitness(batch)
-                ts = []
-                for _ in range(200):
-                    t0 = time.perf_counter(); model.get_fitness(batch); ts.append(time.perf_counter() - t0)
-                return float(np.median(ts)) * 1e6
-
-            sizes = (1, 4, 20, 100, 2001)
-            out["small_call_us"] = {str(k): call_us(seqs[:k]) for k in sizes}
-            try:
-                eng.set_option("serve_small", 0)
-                out["small_call_us_launch_per_call"] = {str(k): call_us(seqs[:k]) for k in sizes}
-            finally:
-                eng.set_option("serve_small", 1)
-            out["small_call_N20_us"] = out["small_call_us"]["20"]          # (round-2 key, kept)
-            out["small_call_N20_us_launch_per_call"] = out["small_call_us_launch_per_call"]["20"]
-            out["small_call_resident_requests"] = int(eng.get_option("server_calls"))
-        del model, mods, seqs
-    out["list_str"] = out["C2 3xCNN L=8 list_str"]          # (round-2 key, kept)
-    out["what"] = ("get_fitness on host strings -> host float32 array, median wall time, marshalling + PCIe inclusive; "
-                   "pack_ms = strpack.pack alone (auto threads) / pack_1thread_ms single-threaded; kernel_ms from `configs`")
-    return out
-
-
-def explorer_patterns_block(device):
-    """SURVEY.md 8(d)'s explorer call patterns for configs[3] and configs[4] (the C2 pattern is `small_call_us`):
-      DyNA-PPO  `environments/dyna_ppo.py:144-163`: the environment step scores 4-10 sequences per call with the ensemble
-                -- here 8 x GlobalEpistasis(100), L = 90, protein alphabet, `Ensemble.get_fitness(list[str])`;
-      CMA-ES    `cmaes.py:61-67, 83-108`: P = 15 / 40 solutions are argmax-decoded and scored one population at a time
-                -- here `PopulationEvaluator.evaluate` (fx_decode_score) on 3 x CNN(32,100), L = 237, plus the plain
-                one-sequence call of the reference loop.
-    Host arrays / strings in, host values out; median of 200 calls after 20 warm-up calls."""
-    import flexs_amd
-    from flexs_amd import synth
-    from flexs_amd.utils.population import PopulationEvaluator
-
-    def med_us(fn, reps=200):
-        for _ in range(20):
-            fn()
-        ts = []
-        for _ in range(reps):
-            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
-        return float(np.median(ts)) * 1e6
-
-    out = {}
-    ens = flexs_amd.Ensemble(build_members("ge", 90, AAS, 8, device))
-    seqs = synth.bytes_to_strings(synth.random_sequence_bytes(16, 90, AAS, 11))
-    out["dynappo_8xGE_L90_us"] = {str(k): med_us(lambda k=k: ens.get_fitness(seqs[:k])) for k in (4, 10)}
-    del ens
-    ens = flexs_amd.Ensemble(build_members("cnn", 237, AAS, 3, device))
-    ev = PopulationEvaluator(ens, AAS, 237)
-    rng = np.random.default_rng(5)
-    cm = {}
-    for P in (15, 40):
-        x = rng.standard_normal((P, 237 * len(AAS)))
-        cm[f"P={P}"] = med_us(lambda x=x: ev.evaluate(x), reps=100)
-    one = synth.bytes_to_strings(synth.random_sequence_bytes(1, 237, AAS, 12))
-    cm["N=1 get_fitness"] = med_us(lambda: ens.get_fitness(one), reps=100)
-    out["cmaes_3xCNN_L237_us"] = cm
-    out["what"] = ("explorer-size calls of configs[3] / configs[4], host in -> host out, median us per call: DyNA-PPO pattern "
-                   "(8 x GE L=90, 4 / 10 sequences per Ensemble.get_fitness call) and CMA-ES pattern (3 x CNN L=237: decode + score "
-                   "of a population of 15 / 40 in one fx_decode_score round trip; one-sequence get_fitness beside it)")
-    return out
-
-
-def explorer_round_block(device, torch):
-    """SURVEY.md 8(f)-1/-2, the callers on either side of the path: one explorer round on configs[0]'s surrogate family --
-    `Ensemble.train` of the 3-CNN ensemble on 1000 measured sequences (Adam / MSE / 20 epochs / batch 256: the hand-written
-    HIP step of csrc/train_core.h, all members in one fx_train_fit call; the captured-PyTorch-graph path of round 2 is
-    timed beside it), then one Adalead round (query budget 2000: several hundred model calls of 1-20
-    sequences).  Wall times, second call of each (graphs captured, engine warm)."""
-    import random
-
-    import flexs_amd
-    from flexs_amd import synth
-    from flexs_amd.utils import rollouts
-
-    ens = flexs_amd.Ensemble(build_members("cnn", L, ALPHABET, M, device))
-    n = 1000
-    seqs = synth.bytes_to_strings(synth.random_sequence_bytes(n, L, ALPHABET, 3))
-    y = np.random.default_rng(0).random(n)
-    out = {}
-    ens.train(seqs, y)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter(); ens.train(seqs, y); torch.cuda.synchronize()
-    out["train_3xCNN_n1000_ms"] = (time.perf_counter() - t0) * 1e3
-    out["train_steps_per_member"] = 20 * ((n + 255) // 256)
-    prev = os.environ.get("FLEXS_AMD_TRAIN")
-    try:                                                   # round 2's path, same call: one captured PyTorch step per member
-        os.environ["FLEXS_AMD_TRAIN"] = "graph"
-        ens.train(seqs, y)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter(); ens.train(seqs, y); torch.cuda.synchronize()
-        out["train_3xCNN_n1000_ms_pytorch_graph"] = (time.perf_counter() - t0) * 1e3
-    except Exception as ex:  # noqa: BLE001 - a comparison figure only
-        out["train_3xCNN_n1000_ms_pytorch_graph"] = f"failed: {type(ex).__name__}"
-    finally:
-        if prev is None:
-            os.environ.pop("FLEXS_AMD_TRAIN", None)
-        else:
-            os.environ["FLEXS_AMD_TRAIN"] = prev
-    # the fits BASELINE configs[3] / configs[4] retrain through every round (flexs/explorer.py:157-160): protein lengths, 20 letters
-    try:
-        for Lp, key in ((237, "train_3xCNN_L237_n500_ms"), (90, "train_3xCNN_L90_n500_ms")):
-            pens = flexs_amd.Ensemble(build_members("cnn", Lp, AAS, 3, device))
-            pseqs = synth.bytes_to_strings(synth.random_sequence_bytes(500, Lp, AAS, 3))
-            py = np.random.default_rng(0).random(500)
-            pens.train(pseqs, py); torch.cuda.synchronize()
-            ts = []
-            for _ in range(3):
-                t0 = time.perf_counter(); pens.train(pseqs, py); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-            out[key] = min(ts) * 1e3
-            del pens
-        # forward + input-gradient + weight-gradient products of one row-step = 3 x 2 x dense MACs (SURVEY 8a: 6 485 108 at L = 237),
-        # 500 rows x 20 epochs x 3 members per fit
-        out["train_3xCNN_L237_frac_of_peak"] = 3 * 2.0 * synth.algorithmic_macs("cnn", 237, 20, H, F, K) * 500 * 20 * 3 / (out["train_3xCNN_L237_n500_ms"] * 1e-3) / 1e12 / PEAK_TF
-    except Exception as ex:  # noqa: BLE001 - never at the cost of the line
-        out["train_protein_error"] = f"{type(ex).__name__}: {ex}"[:200]
-    for i in range(2):
-        random.seed(1)
-        c0 = ens.cost
-        t0 = time.perf_counter()
-        rollouts.adalead_round(ens, seqs, y, sequences_batch_size=100, model_queries_per_batch=2000, alphabet=ALPHABET)
-        out["adalead_round_ms"] = (time.perf_counter() - t0) * 1e3
-        out["adalead_model_queries"] = int(ens.cost - c0)
-    out["what"] = ("one explorer round, 3 x CNN(32,100) L=8: Ensemble.train on 1000 measured sequences (fx_train_fit: hand-written "
-                   "HIP forward+backward+Adam, 2 launches per mini-batch step for all members) + "
-                   "flexs_amd.utils.rollouts.adalead_round (budget 2000 queries)")
-    return out
-
-
-MEMBER_PARALLEL_WORKLOADS = (("8xCNN L=8 A=4 N=1e5", "cnn", 8, "TGCA", 100_000, 400),
-                             ("8xGE L=90 A=20 N=1e5", "ge", 90, AAS, 100_000, 800),
-                             ("8xGE L=90 A=20 N=1e6", "ge", 90, AAS, 1_000_000, 100))
-
-
-def member_parallel_block(world, rank, device, torch, dist, use_dist, steps_hint, solo_group=None):
-    """north_star's split: an 8-member ensemble, members sharded over the ranks (contiguous blocks), every rank
-    scores the SAME batch with its members, ONE all-gather of the stacked predictions, mean on every rank.
-    Strong scaling: the batch is fixed, value = batch x steps / time.  Workloads: 8 x CNN L=8 (configs[1]'s
-    surrogate, 8 members) and 8 x GlobalEpistasis L=90 A=20 (configs[3]) at 1e5 and 1e6 sequences.
-    `speedup_vs_1gpu` divides by a one-GPU measurement OF THIS RUN: with one rank the block itself is that reference;
-    with several, rank 0 first runs the same workload alone over a one-rank group (`solo_group`) while the others wait."""
-    from flexs_amd import distributed as fd, synth
-
-    out = {}
-    for name, kind, Lx, alpha, n, steps in MEMBER_PARALLEL_WORKLOADS:
-        mods = build_members(kind, Lx, alpha, 8, device)
-        ref = None
-        if world > 1 and solo_group is not None:
-            if rank == 0:
-                solo = fd.DistributedEnsemble(mods, mode="member", group=solo_group)
-                with torch.cuda.stream(solo.stream):
-                    d_solo = torch.from_numpy(synth.random_sequence_bytes(n, Lx, alpha, seed=7)).cuda()
-                solo.stream.synchronize()
-                el, _, _ = run_pipelined(solo, d_solo, n, steps, max(steps // 10, 5), torch, dist, False, want_events=False)
-                ref = n * steps / el
-                del solo, d_solo
-            dist.barrier()
-        ens = fd.DistributedEnsemble(mods, mode="member")
-        ens.force_collective = use_dist
-        with torch.cuda.stream(ens.stream):
-            d_seq = torch.from_numpy(synth.random_sequence_bytes(n, Lx, alpha, seed=7)).cuda()   # same batch on every rank
-        ens.stream.synchronize()
-        elapsed, _, kern_ms = run_pipelined(ens, d_seq, n, steps, max(steps // 10, 5), torch, dist, use_dist)
-        # correctness of the exchange: the gathered matrix must reproduce the local members' planes
-        ens.launch(d_seq, n, 0, "matrix")
-        mat = ens.finish(0)
-        ens.launch(d_seq, n, 1, "mean")
-        mean = ens.finish(1)
-        torch.cuda.synchronize()
-        ok = bool(torch.isfinite(mat).all()) and tuple(mat.shape) == (n, 8)
-        if rank == 0:
-            ok = ok and np.array_equal(np.mean(mat.cpu().numpy(), axis=1), mean.cpu().numpy())
-        value = n * steps / elapsed
-        if world == 1 and not use_dist:
-            ref, ref_src = value, "this block (n_gpus = 1, no collective)"
-        elif ref is not None:
-            ref_src = "same run: rank 0 alone over a one-rank group, before the sharded measurement"
-        else:
-            ref_src = None
-        out[name] = {"value": value, "unit": "sequences/s", "ms_per_step": elapsed / steps * 1e3,
-                     "kernel_ms_this_rank": kern_ms, "steps": steps, "members": 8,
-                     "members_per_rank": -(-8 // world), "gathered_bytes_per_rank": 4 * n * -(-8 // world) * world,
-                     "one_gpu_reference": ref, "one_gpu_reference_source": ref_src,
-                     "speedup_vs_1gpu": (value / ref) if ref else None,
-                     "checked": ok}
-        del ens, mods, d_seq
-    out["what"] = ("8-member ensembles sharded member-parallel over the ranks (flexs/ensemble.py:54-59): fused kernel "
-                   "for this rank's members + one RCCL all-gather of the stacked (N, 8) predictions + np.mean-order mean "
-                   "on every rank; same batch on every rank (strong scaling), double-buffered so the gather of step k "
-                   "overlaps step k+1; speedup_vs_1gpu = value / one_gpu_reference, the latter measured in THIS run "
-                   "(one_gpu_reference_source); ideal = 8 / members_per_rank")
-    return out
-
-def prepared_block(timeout_s=90.0):
-    """An A/B of kernel forms that were written after round 4's GPU budget was spent (csrc/OPTIONS.md `train_swizzle`: rotated LDS rows
-    and staged conv kernels for GFP-length CNN fits; DEFAULT OFF, bit-identical on the CPU under the SIMT emulator) -- measured here
-    because this run is the first time they meet a device.  In a CHILD process with a time limit: whatever happens to it, the
-    contract line above is already measured and is printed; the child's answer (or what went wrong) goes into
-    roofline.per_config.  Not part of `value`.  FLEXS_AMD_BENCH_PREPARED=0 skips it."""
-    import subprocess
-
-    if os.environ.get("FLEXS_AMD_BENCH_PREPARED", "1") == "0":
-        return {"skipped": "FLEXS_AMD_BENCH_PREPARED=0"}
-    try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "runs", "r5_train_swizzle_ab.py"), "--json"], cwd=ROOT,
-                           capture_output=True, text=True, timeout=timeout_s)
-        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-        if r.returncode != 0 or not lines:
-            return {"error": f"child exit {r.returncode}", "stderr_tail": r.stderr[-300:]}
-        return json.loads(lines[-1])
-    except subprocess.TimeoutExpired as ex:
-        got = {"error": f"not finished within {timeout_s:.0f} s (child stopped); what it had reported until then is kept"}
-        try:
-            text = ex.stdout.decode() if isinstance(ex.stdout, bytes) else (ex.stdout or "")
-            lines = [ln for ln in text.splitlines() if ln.startswith("{")]
-            if lines:
-                got.update(json.loads(lines[-1]))
-        except Exception:  # noqa: BLE001
-            pass
-        return got
-    except Exception as ex:  # noqa: BLE001 -- an experiment must not cost the record
-        return {"error": f"{type(ex).__name__}: {ex}"}
-
-
-def _sig(x, digits=4):
-    return None if x is None else float(f"{float(x):.{digits}g}")
-
-
-def flat_scalars(out):
-    """Round-4 verdict item 2: the driver's parse keeps `roofline` / `config` but only their SCALAR members, so every BASELINE
-    config's figures are also written as flat keys of `roofline` (numbers only).  cN = BASELINE.json configs[N-1]:
-    c1 1xCNN L8 N1e4, c2_1e4 3xCNN L8 N1e4, c3 MLP L14 N1e5, c4 8xGE L90 N1e5, c5 3xCNN L237 N62500; k4 = the
-    NoisyAbstractModel neighbour search; e2e_* = get_fitness(list[str]) end to end; train_* = Ensemble.train fits;
-    *_frac_issued = MFMA instructions issued x 2048 FLOP / time / 157.3 TFLOP/s.  Pure function of `out`."""
+def contract_scalars(full):
+    """The bounded set of per-config scalars the contract line carries inside `roofline` (numbers only, 4 significant digits; keys in
+    the order they are dropped LAST -> FIRST if the line had to shrink).  cN_kernel_ms / cN_frac_issued: kernel time and MFMA
+    instructions issued x 2048 FLOP / time / 157.3 TFLOP/s; e2e_cN_frac_of_kernel: get_fitness(list[str]) rate / kernel rate;
+    k4_*: NoisyAbstractModel neighbour search, fraction of the integer-VALU issue rate.  Pure function of the full record."""
     flat = {}
 
     def put(key, val, digits=4):
@@ -694,124 +145,112 @@ def flat_scalars(out):
         if isinstance(val, (int, float)) and np.isfinite(val):
             flat[key] = _sig(val, digits)
 
-    confs = out.get("configs") or {}
-    names = {"C1 cnn L=8 A=4 M=1 N=1e4": "c1", "C2 cnn L=8 A=4 M=3 N=1e4": "c2_1e4", "C3 mlp L=14 A=4 H=100 M=1 N=1e5": "c3",
-             "C4 ge L=90 A=20 H=100 M=8 N=1e5": "c4", "C5 cnn L=237 A=20 M=3 N=62500 (one GPU's share of 5e5)": "c5"}
-    for key, tag in names.items():
+    confs = full.get("configs") or {}
+    for tag, key in CONFIG_TAGS.items():
         b = confs.get(key)
         if isinstance(b, dict):
             put(f"{tag}_kernel_ms", b.get("kernel_ms"))
             put(f"{tag}_frac_issued", b.get("frac_issued", b.get("frac")))
-            put(f"{tag}_frac_algorithmic", b.get("frac_algorithmic"))
-            put(f"{tag}_seq_per_s", b.get("seq_per_s"))
-    for key, b in confs.items():
-        if isinstance(b, dict) and key.startswith("survey "):       # wide-hidden-layer rows (H = 200) of the perf survey
-            tag = key[len("survey "):].lower().replace(" ", "_").replace("=", "")
-            put(f"{tag}_kernel_ms", b.get("kernel_ms")); put(f"{tag}_frac_issued", b.get("frac_issued")); put(f"{tag}_frac_algorithmic", b.get("frac_algorithmic"))
+    e2e = full.get("end_to_end") or {}
+    for key, v in e2e.items():
+        if key.endswith(" list_str") and key != "list_str" and isinstance(v, dict):
+            tag = key.split()[0].lower()                            # c2 / c3 / c4 / c5
+            put(f"e2e_{tag}_frac_of_kernel", v.get("frac_of_kernel_rate"))
+            put(f"e2e_{tag}_seq_per_s", v.get("value"))
+    er = full.get("explorer_round") or {}
+    put("train_l237_frac_of_peak", er.get("train_3xCNN_L237_frac_of_peak"))
+    put("train_l237_ms", er.get("train_3xCNN_L237_n500_ms"))
+    put("train_l8_ms", er.get("train_3xCNN_n1000_ms"))
+    put("adalead_round_ms", er.get("adalead_round_ms"))
     nam = next((v for k, v in confs.items() if k.startswith("C3 nam")), None)
     if isinstance(nam, dict):
         for k, v in (nam.get("k4") or {}).items():
             if isinstance(v, dict) and isinstance(v.get("roofline"), dict):
-                put("k4_" + k.split()[-1].lower().replace("=", ""), v["roofline"].get("frac"))        # k4_c100, k4_c1000, k4_c20000: int-VALU fraction
-                put("k4_" + k.split()[-1].lower().replace("=", "") + "_kernel_ms", v.get("kernel_ms"))
-        for k in ("plain_landscape", "batch_safe_landscape", "device_table_landscape_L8"):
+                put("k4_" + k.split()[-1].lower().replace("=", ""), v["roofline"].get("frac"))        # k4_c100, k4_c1000, k4_c20000
+        for k, short in (("plain_landscape", "nam_plain"), ("device_table_landscape_L8", "nam_table")):
             if isinstance(nam.get(k), dict):
-                put(f"nam_{k.lower()}_seq_per_s", nam[k].get("value"))
-    cs = out.get("cold_start")
-    if isinstance(cs, dict):
-        put("cold_start_kernel_ms", cs.get("kernel_ms")); put("cold_start_frac_issued", cs.get("frac_issued")); put("cold_start_value", cs.get("value"))
-    st = out.get("settled")
-    if isinstance(st, dict):
-        put("settled_kernel_ms", st.get("kernel_ms")); put("settled_frac_issued", st.get("frac_issued")); put("settled_value", st.get("value"))
-        put("settled_frac_algorithmic", st.get("frac_algorithmic"))
-    e2e = out.get("end_to_end") or {}
-    for key, v in e2e.items():
-        if key.endswith(" list_str") and isinstance(v, dict):
-            tag = key.split()[0].lower()                            # C2 / C3 / C4 / C5
-            put(f"e2e_{tag}_seq_per_s", v.get("value")); put(f"e2e_{tag}_wall_ms", v.get("wall_ms"))
-            put(f"e2e_{tag}_frac_of_kernel", v.get("frac_of_kernel_rate"))
-            put(f"e2e_{tag}_wall_ms_packed_first", v.get("wall_ms_packed_first"))
-            put(f"e2e_{tag}_wall_ms_results_in_place", v.get("wall_ms_results_in_place"))
-    for k, pre in (("small_call_us", "small_call"), ("small_call_us_launch_per_call", "small_call_launched")):
-        for n, v in (e2e.get(k) or {}).items():
-            put(f"{pre}_n{n}_us", v, 3)
-    pat = out.get("explorer_patterns") or {}
-    for k, pre in (("dynappo_8xGE_L90_us", "dynappo"), ("cmaes_3xCNN_L237_us", "cmaes")):
-        for n, v in (pat.get(k) or {}).items():
-            put(f"{pre}_{str(n).lower().replace(' ', '_').replace('=', '')}_us", v, 3)
-    er = out.get("explorer_round") or {}
-    put("train_l8_ms", er.get("train_3xCNN_n1000_ms")); put("adalead_round_ms", er.get("adalead_round_ms"))
-    put("train_l237_ms", er.get("train_3xCNN_L237_n500_ms")); put("train_l237_frac_of_peak", er.get("train_3xCNN_L237_frac_of_peak"))
-    put("train_l90_ms", er.get("train_3xCNN_L90_n500_ms")); put("train_l237_fb_kernel_ms", er.get("train_L237_fb_kernel_ms"))
-    for k, v in (out.get("member_parallel") or {}).items():
-        if isinstance(v, dict):
-            tag = k.lower().replace(" ", "_").replace("=", "")
-            put(f"mp_{tag}_speedup", v.get("speedup_vs_1gpu")); put(f"mp_{tag}_seq_per_s", v.get("value"))
+                put(f"{short}_seq_per_s", nam[k].get("value"))
+    for tag in ("settled", "cold_start"):
+        b = full.get(tag)
+        if isinstance(b, dict):
+            put(f"{tag}_kernel_ms", b.get("kernel_ms")); put(f"{tag}_frac_issued", b.get("frac_issued"))
+    for n, v in (e2e.get("small_call_us") or {}).items():
+        if n in ("1", "20", "2001"):
+            put(f"small_call_n{n}_us", v, 3)
+    pat = full.get("explorer_patterns") or {}
+    put("dynappo_n10_us", (pat.get("dynappo_8xGE_L90_us") or {}).get("10"), 3)
+    put("cmaes_p40_us", (pat.get("cmaes_3xCNN_L237_us") or {}).get("P=40"), 3)
+    for k, v in (full.get("member_parallel") or {}).items():
+        if isinstance(v, dict) and v.get("speedup_vs_1gpu") is not None and full.get("n_gpus", 1) > 1:
+            put("mp_" + k.split()[0].lower() + "_" + k.split()[-1].lower().replace("=", "") + "_speedup", v.get("speedup_vs_1gpu"))
     return flat
 
 
-def compact_record(out):
-    """The path, not just the headline, inside the two objects a downstream parser of the contract line keeps: `roofline`
-    gets `per_config` (kernel time and both MFMA fractions of every BASELINE.json config, K4's integer-VALU fractions),
-    `config` gets `path` (end-to-end rates, explorer-size latencies, the explorer round, the settled headline, member-parallel
-    speed-ups).  Same numbers as the verbose blocks (`configs`, `end_to_end`, `explorer_round`, `explorer_patterns`,
-    `member_parallel`, `settled`) they are copied from; pure function of `out` (unit-tested on the CPU)."""
-    roof, cfg = out["roofline"], out["config"]
-    per = {"C2 3xCNN L8 N1e5 (headline)": {"kernel_ms": _sig(roof.get("kernel_ms")), "frac": _sig(roof.get("frac")),
-                                          "frac_issued": _sig(roof.get("frac_issued"))}}
-    roof.update(flat_scalars(out))                          # scalars survive a parser that drops nested objects
-    short = {"C1 cnn L=8 A=4 M=1 N=1e4": "C1 1xCNN L8 N1e4", "C2 cnn L=8 A=4 M=3 N=1e4": "C2 3xCNN L8 N1e4",
-             "C3 mlp L=14 A=4 H=100 M=1 N=1e5": "C3 MLP L14 N1e5", "C4 ge L=90 A=20 H=100 M=8 N=1e5": "C4 8xGE L90 N1e5",
-             "C5 cnn L=237 A=20 M=3 N=62500 (one GPU's share of 5e5)": "C5 3xCNN L237 N62500"}
-    confs = out.get("configs") or {}
-    for key, name in short.items():
-        b = confs.get(key)
-        if b:
-            per[name] = {"kernel_ms": _sig(b.get("kernel_ms")), "frac": _sig(b.get("frac")), "frac_issued": _sig(b.get("frac_issued"))}
-    nam = next((v for k, v in confs.items() if k.startswith("C3 nam")), None)
-    if nam:
-        per["K4 Levenshtein L14 Q2000 (int-VALU frac)"] = {k.split()[-1]: _sig(v["roofline"]["frac"])
-                                                           for k, v in nam.get("k4", {}).items() if isinstance(v, dict)}
-    for k in ("C1 resident", "C2@1e4 resident"):
-        if k in confs:
-            per[k] = confs[k]
-    if out.get("prepared_train_swizzle"):
-        per["train GFP-length CNN by train_swizzle form (0 plain, 1 rotated rows, 2 staged kernels, 3 = default F=32 form)"] = out["prepared_train_swizzle"]
-    if len(per) > 1:
-        roof["per_config"] = per
-    path = {}
-    st = out.get("settled")
-    if st:
-        path["settled"] = {"value": _sig(st["value"]), "kernel_ms": _sig(st["kernel_ms"]), "frac_issued": _sig(st["frac_issued"])}
-    e2e = out.get("end_to_end") or {}
-    rows = {k.replace(" list_str", ""): v for k, v in e2e.items() if k.endswith(" list_str") and isinstance(v, dict) and k != "list_str"}
-    if rows:
-        path["e2e_list_str"] = {k: {"seq_per_s": _sig(v.get("value")), "wall_ms": _sig(v.get("wall_ms")),
-                                    "frac_of_kernel_rate": _sig(v.get("frac_of_kernel_rate"))} for k, v in rows.items()}
-    for k in ("small_call_us", "small_call_us_launch_per_call"):
-        if k in e2e:
-            path[k + " (3xCNN L8)"] = {n: _sig(v, 3) for n, v in e2e[k].items()}
-    pat = out.get("explorer_patterns") or {}
-    for k in ("dynappo_8xGE_L90_us", "cmaes_3xCNN_L237_us"):
-        if k in pat:
-            path[k] = {n: _sig(v, 3) for n, v in pat[k].items()}
-    er = out.get("explorer_round") or {}
-    if er:
-        path["explorer_round_3xCNN_L8"] = {"train_n1000_ms": _sig(er.get("train_3xCNN_n1000_ms")),
-                                           "adalead_round_ms": _sig(er.get("adalead_round_ms")),
-                                           "adalead_model_queries": er.get("adalead_model_queries")}
-    if nam:
-        path["nam_cbas_seq_per_s"] = {k: _sig(nam[k]["value"]) for k in ("plain_landscape", "batch_safe_landscape", "device_table_landscape_L8")
-                                      if k in nam}
-    mp_ = out.get("member_parallel") or {}
-    mp_rows = {k: v for k, v in mp_.items() if isinstance(v, dict)}
-    if mp_rows:
-        path["member_parallel"] = {k: {"value": _sig(v["value"]), "one_gpu_reference": _sig(v.get("one_gpu_reference")),
-                                       "speedup_vs_1gpu": _sig(v.get("speedup_vs_1gpu")), "members_per_rank": v.get("members_per_rank")}
-                                   for k, v in mp_rows.items()}
-    if path:
-        cfg["path"] = path
-    return out
+def contract_line(full, full_path=None):
+    """The ONE stdout line: the contract keys, `config`, `roofline` (dominant kernel + contract_scalars), `cpu_baseline`, the end-to-end
+    figure beside `value` -- and nothing nested deeper, no prose blocks.  Guaranteed <= MAX_LINE_BYTES: per-config scalars are dropped
+    from the end of contract_scalars' order if a future field pushed the line over (never the contract keys).  Returns (dict, text)."""
+    r = full["roofline"]
+    cfg = full["config"]
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "vs_baseline", "dtype", "data")}
+    for k in ("value", "ms_per_step"):
+        line[k] = _sig(line[k], 6)
+    c2 = (full.get("end_to_end") or {}).get("C2 3xCNN L=8 list_str")
+    if isinstance(c2, dict):
+        # SURVEY.md 8(d)'s metric proper: Ensemble.get_fitness(list[str]) -> ndarray, host strings in, host array out (same workload)
+        line["e2e_value"] = _sig(c2.get("value"), 6)
+        line["e2e_ms_per_call"] = _sig(c2.get("wall_ms"), 4)
+        line["e2e_frac_of_kernel"] = _sig(c2.get("frac_of_kernel_rate"), 4)
+    if r.get("kernel_ms"):
+        line["kernel_value"] = _sig(cfg["global_batch"] / full["n_gpus"] / (r["kernel_ms"] * 1e-3), 6)
+    line["config"] = {"workload": cfg["workload"], "global_batch": cfg["global_batch"], "seq_len": cfg["seq_len"],
+                      "members": cfg["members"], "parallelism": cfg["parallelism"]}
+    roof = {"bound": r["bound"], "kernel": r["kernel"], "achieved": _sig(r["achieved"]), "peak": r["peak"], "unit": r["unit"],
+            "frac": _sig(r["frac"]), "frac_algorithmic": _sig(r["frac_algorithmic"]), "kernel_ms": _sig(r["kernel_ms"]),
+            "traffic": (int(round(r["traffic"])) if r.get("traffic") else None), "algorithmic_bytes": r.get("algorithmic_bytes_per_launch"),
+            "mfma_util_pmc": _sig(r.get("mfma_util_pmc")), "pmc_source": r.get("pmc_source")}
+    line["roofline"] = roof
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        vec, nam = cb.get("vectorised") or {}, cb.get("nam") or {}
+        line["cpu_baseline"] = {"value": _sig(cb.get("value"), 6), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                                "sample": (cb.get("sample_short") or cb.get("sample") or "")[:200],
+                                "vectorised_value": _sig(vec.get("value"), 6), "vectorised_cores": vec.get("cores"),
+                                "nam_value": _sig(nam.get("value"), 4)}
+    for k in ("rccl_ranks", "debug_share_device"):
+        if k in full:
+            line[k] = full[k]
+    if full_path:
+        line["full_record"] = full_path
+    extra = list(contract_scalars(full).items())
+    while True:
+        line["roofline"] = dict(roof, **dict(extra))
+        text = json.dumps(line, separators=(",", ":"))
+        if len(text.encode()) <= MAX_LINE_BYTES or not extra:
+            break
+        extra.pop()
+    if len(text.encode()) > MAX_LINE_BYTES:                 # (cannot happen with the fields above; the contract keys are never cut)
+        line["config"]["workload"] = line["config"]["workload"][:300]
+        line.get("cpu_baseline", {}).pop("sample", None)
+        text = json.dumps(line, separators=(",", ":"))
+    return line, text
+
+
+def write_full_record(full, path="gpurun_out/bench_full.json"):
+    """The full record: one JSON line on stderr and `path` (default gpurun_out/bench_full.json, merged back from the GPU box; relative
+    paths are relative to the repository).  Returns where it went, for the contract line's `full_record`."""
+    text = json.dumps(full)
+    sys.stderr.write(text + "\n")
+    sys.stderr.flush()
+    try:
+        dst = path if os.path.isabs(path) else os.path.join(ROOT, path)
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        with open(dst, "w") as f:
+            f.write(text + "\n")
+        return f"{path} (+ stderr)"
+    except OSError:
+        return "stderr"
 
 
 def _free_port():
@@ -849,6 +288,9 @@ def cpu_selftest(rank, world):
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)                               # gloo announces its peers on STDOUT: the one line is all that may go there
+    os.dup2(2, 1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
 
     class _Member(flexs_amd.Model):
@@ -884,6 +326,8 @@ def cpu_selftest(rank, world):
                      "max_over_ranks_s": float(t.item())}
     ranks = dist.get_world_size()
     dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
     if rank == 0:
         print(json.dumps({"metric": "cpu-selftest of the launch path (gloo, injected scorer) -- not a measurement",
                           "value": None, "n_gpus": 0, "ranks": ranks, "backend": "gloo", "selftest": out}), flush=True)
@@ -902,6 +346,10 @@ def main():
                          "strong scaling of an 8-member CNN ensemble")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only (profiling passes)")
+    ap.add_argument("--full-record", default="gpurun_out/bench_full.json",
+                    help="where the full record (every verbose block) is written besides stderr")
+    ap.add_argument("--prepared", action="store_true",
+                    help="also time the four train_swizzle forms of the GFP-length fit in a child process (round 5's A/B; ~60 s)")
     ap.add_argument("--cpu-nam", action="store_true",
                     help="cpu_baseline runs the NoisyAbstractModel CPU leg to its full 20 calls (~20 s) instead of ~3 s")
     ap.add_argument("--variant", type=int, default=0, help="cnn kernel variant (0 = auto)")
@@ -927,6 +375,7 @@ def main():
     import torch.distributed as dist
 
     from flexs_amd import _native, distributed as fd, synth
+    from tools import bench_blocks as bb
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1013,7 +462,7 @@ def main():
     if not args.no_extras:
         # (a one-rank group for the in-run one-GPU reference of the member-parallel speed-ups: created by every rank)
         solo_group = dist.new_group(ranks=[0]) if (use_dist and world > 1) else None
-        extras["member_parallel"] = member_parallel_block(world, rank, local_rank, torch, dist, use_dist, args.steps, solo_group)
+        extras["member_parallel"] = bb.member_parallel_block(world, rank, local_rank, torch, dist, use_dist, args.steps, solo_group)
 
     if rank == 0:
         assert np.array_equal(np.mean(got_nm, axis=1), got_mean), "device mean is not np.mean bit-for-bit"
@@ -1025,7 +474,7 @@ def main():
             # 0.185 settled, round-4 verdict weak #3), which says nothing about the kernel and is not how an explorer meets it -- its
             # virtual screen follows a retrain.  The contract's W warm-ups + K timed steps are therefore measured (again, same code
             # path, same barrier + synchronize bracket) after this GPU work; the first bracket is kept as `cold_start`.
-            confs = configs_block(eng, local_rank, torch)
+            confs = bb.configs_block(eng, local_rank, torch)
             cold = {"ms_per_step": elapsed / args.steps * 1e3, "kernel_ms": kern_ms, "value": world * N * args.steps / elapsed,
                     "what": "the same W warm-ups + K timed steps as the first GPU work of the process (device clocks still ramping)"}
             elapsed, host_issue_s, kern_ms = run_pipelined(ens, d_seq, glob_n, args.steps, args.warmup, torch, dist, use_dist)
@@ -1045,22 +494,37 @@ def main():
         if args.debug_share_device:
             out["debug_share_device"] = "all ranks on device 0, collectives on gloo through host tensors: NOT a measurement"
         out.update(extras)
+
+        def guarded(key, fn):
+            """A verbose block must never cost the contract line: what goes wrong in one is a field of the full record."""
+            try:
+                return fn()
+            except Exception as ex:  # noqa: BLE001
+                out.setdefault("block_errors", {})[key] = f"{type(ex).__name__}: {ex}"[:300]
+                return None
+
         if world == 1 and not args.no_extras:
             out["configs"] = confs
-            out["configs"]["C3 nam L=14 A=4 (NoisyAbstractModel half of configs[2])"] = nam_block(eng, local_rank)
+            nam = guarded("nam", lambda: bb.nam_block(eng, local_rank))
+            if nam:
+                out["configs"]["C3 nam L=14 A=4 (NoisyAbstractModel half of configs[2])"] = nam
             out["configs"]["C2 full (headline kernel)"] = {"kernel_ms": (settled[2] if settled else kern_ms)}
-            out["end_to_end"] = end_to_end_block(local_rank, out["configs"])
-            out["explorer_round"] = explorer_round_block(local_rank, torch)
-            out["explorer_patterns"] = explorer_patterns_block(local_rank)
+            for key, fn in (("end_to_end", lambda: bb.end_to_end_block(local_rank, out["configs"])),
+                            ("explorer_round", lambda: bb.explorer_round_block(local_rank, torch)),
+                            ("explorer_patterns", lambda: bb.explorer_patterns_block(local_rank))):
+                got = guarded(key, fn)
+                if got is not None:
+                    out[key] = got
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nam=args.cpu_nam)
-        if world == 1 and not args.no_extras:
-            out["prepared_train_swizzle"] = prepared_block()
-        compact_record(out)
+        if world == 1 and args.prepared:
+            out["prepared_train_swizzle"] = bb.prepared_block()
         if saved_stdout is not None:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
-        print(json.dumps(out), flush=True)
+        full_path = write_full_record(out, args.full_record)
+        _, text = contract_line(out, full_path)
+        print(text, flush=True)
     if use_dist:
         dist.destroy_process_group()
 

@@ -39,6 +39,7 @@ SIGNATURES = {
     "fx_engine_destroy": (C.c_int, [_vp]),
     "fx_engine_set_stream": (C.c_int, [_vp, _vp]),
     "fx_engine_sync": (C.c_int, [_vp]),
+    "fx_engine_error_word_dev": (C.c_int, [_vp, _vp]),
     "fx_last_error": (C.c_char_p, [_vp]),
     "fx_engine_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
     "fx_engine_get_option": (C.c_int, [_vp, C.c_char_p, _i64p]),
@@ -323,14 +324,15 @@ def score_small(engine: "Engine", plan: bytes, seqs, M: int, want_mean: bool) ->
     _raise(-(st - 2000) if st > 2000 else st, engine.handle)
 
 
-# 1 = launched-first calls hand their results out IN PLACE: arrays over pinned buffers of a pool, no copy (~10 us of a 1e5-string call).
-# Opt-in: such an array is ordinary memory to NumPy, but pinned allocations are not inherited by a fork()ed child -- a child that reads
-# a result array it inherited (instead of receiving it pickled) would fault -- which a drop-in for `get_fitness` must not risk by default.
-RESULTS_IN_PLACE = int(os.environ.get("FLEXS_AMD_RESULTS_IN_PLACE", 0))
+# 1 (default since round 6) = launched-first calls hand their results out IN PLACE: arrays over registered host buffers of a pool, no copy
+# (~10-20 us of a 1e5-string call).  The buffers are ordinary anonymous memory registered with the device (fx_result_alloc: mmap +
+# hipHostRegister), so a fork()ed child inherits a result array copy-on-write like any NumPy array (round 5 used hipHostMalloc memory,
+# which a child does not inherit: that kept the form opt-in; tests/test_gpu_api.py forks and reads).  0 = always copy into np.empty.
+RESULTS_IN_PLACE = int(os.environ.get("FLEXS_AMD_RESULTS_IN_PLACE", 1))
 
 
 class _ResultPool:
-    """Pinned, GPU-mapped result buffers (fx_result_alloc) for the calls whose kernels write the scores straight into the memory the
+    """Registered (pinned, GPU-mapped) anonymous host buffers (fx_result_alloc) for the calls whose kernels write the scores straight into the memory the
     caller gets back: the array wraps the buffer and the buffer returns to the pool when the array's last view dies.  Bounded -- a
     caller that keeps every result alive simply gets ordinary arrays (a copy) from the 17th outstanding buffer or the 257th MiB on;
     buffers are never handed back to HIP before the process ends (an array may outlive the engine object)."""
@@ -444,6 +446,10 @@ class Engine:
 
     def sync(self):
         self.check(self._lib.fx_engine_sync(self.handle))
+
+    def error_word_dev(self, d_dst: int):
+        """Stream-ordered: the float at device address `d_dst` = this engine's deferred error bits (see flexs_amd.h)."""
+        self.check(self._lib.fx_engine_error_word_dev(self.handle, _vp(d_dst)))
 
     def torch_stream(self):
         """A torch.cuda.Stream lent to the engine (created on first use, then kept): torch-side work (uploads,

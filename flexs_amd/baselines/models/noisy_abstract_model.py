@@ -247,7 +247,8 @@ class NoisyAbstractModel(flexs_amd.Model):
         """Call BEFORE `cache.update(zip(keys, ...))`: remembers, in order, the keys that update will append (first occurrences
         of keys not yet cached).  A cache somebody else also writes to is noticed by its length and walked as before."""
         cache = self.cache
-        if len(self._dev_keys) + len(self._pending) != len(cache):
+        pending = getattr(self, "_pending", None)                      # (an instance restored from an older pickle has none)
+        if pending is None or len(getattr(self, "_dev_keys", ())) + len(pending) != len(cache):
             self._pending = []                                         # (out of step already: the next sync walks the dict)
             return
         seen = set()
@@ -255,9 +256,13 @@ class NoisyAbstractModel(flexs_amd.Model):
             k = k if type(k) is str else str(k)
             if k not in cache and k not in seen:
                 seen.add(k)
-                self._pending.append(k)
+                pending.append(k)
 
     def train(self, sequences: SEQUENCES_TYPE, labels: np.ndarray):
+        # the reference's `self.cache.update(zip(sequences, labels))` takes any iterable, also a one-shot one (generator, map, zip):
+        # materialise it once -- the note below must not be the pass that uses it up
+        if not isinstance(sequences, (list, tuple, np.ndarray)):
+            sequences = list(sequences)
         self._note_new_keys(sequences)
         self.cache.update(zip(sequences, labels))                      # :62-67
 

@@ -4,6 +4,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <map>
 #include <string>
 #include <chrono>
 #include <vector>
@@ -179,6 +180,7 @@ struct fx_engine {
     // deferred error word (device) + pinned host mirror
     unsigned* d_err = nullptr;
     unsigned* h_err = nullptr;
+    std::map<void*, size_t> result_bufs;   // fx_result_alloc: registered anonymous mappings (address -> length), freed by fx_result_free only
     // cached device LUT
     uint8_t* d_lut = nullptr;
     uint8_t h_lut[256];
@@ -330,7 +332,6 @@ struct fx_engine {
     // whether the launch just enqueued did (a launcher that cannot returns FX_EUNSUPPORTED before it enqueues anything)
     struct { bool on = false, used = false; FxRowsReady r = {nullptr, 0, 0, 0, 0}; FxRelay relay = {nullptr, nullptr, 0, 0, 0}; bool relay_used = false; } rows_req;
     int64_t dense_prefetch = 1; // MLP / GE launches that read rows from host memory ask for the next tile's bytes a tile ahead: 1 = in a relay of >= 4 members (where it pays), 2 = always (A/B), 0 = never
-    int64_t staging_noncoherent = 0;   // (experiment) 1 = the input staging area is non-coherent host memory (cached in L2)
     int64_t relay_spread = 0;   // 1 = relay launches take their unit ranges in plain block order: member 0's workgroups on all eight XCDs instead of one (no gain: A/B)
     unsigned* relay_flags = nullptr; size_t relay_flag_words = 0; unsigned relay_seq = 0;
     int64_t launch_relay = 1;   // 1 = launched-first calls of dense ensembles whose plan says "copy" relay the rows through member 0's workgroups (0 = such calls pack, upload, then launch: A/B)
@@ -431,12 +432,21 @@ int fx_upload_lut(fx_engine* e, const uint8_t lut[256]);
 #define FX_TRACE_BYTES ((size_t)1024 * 16 * 16 * 8)
 int fx_trace_buffer(fx_engine* e, unsigned long long** out);
 
-// Deferred error word: mapped pinned HOST memory (read by the host right after the stream
-// sync, no copy).  Only one bit is defined, so raising it is an idempotent system-scope
-// store -- no PCIe atomics needed.
+// Deferred error words: mapped pinned HOST memory (read by the host right after the stream sync, no copy).  One 32-bit word PER
+// error bit (word log2(bit) of the 64-byte line), so raising one is an idempotent system-scope store that cannot wipe another
+// kernel's different error -- no PCIe atomics needed.  The host reads them OR-ed (fx_err_read).
+#define FX_ERR_WORDS 3
+inline unsigned fx_err_read(const unsigned* h_err) {
+    unsigned v = 0;
+    for (int i = 0; i < FX_ERR_WORDS; ++i) v |= reinterpret_cast<const volatile unsigned*>(h_err)[i];
+    return v;
+}
+inline void fx_err_clear(unsigned* h_err) {
+    for (int i = 0; i < FX_ERR_WORDS; ++i) reinterpret_cast<volatile unsigned*>(h_err)[i] = 0;
+}
 #if defined(__HIPCC__)
 __device__ __forceinline__ void fx_raise(unsigned* err, unsigned bit) {
-    __hip_atomic_store(err, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(err + (31 - __clz(bit)), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // Relay reader: wave-uniform wait for flags[tile] == seq (device scope; the tile's bytes were stored before the flag, both past the
 // caches).  Gives up like fx_rows_wait.
@@ -454,7 +464,10 @@ __device__ __forceinline__ void fx_relay_wait(const unsigned* flag, unsigned seq
 }
 // Wave-uniform: returns when the rows of stage `stage` are in the staging area.  `known` = stages this wave has already seen
 // published (the words are only read again for a later stage: once the host has finished packing, one poll settles the rest of the
-// kernel).  The acquire is system scope: the rows were written by the host and are read over PCIe right after.  A host that dies
+// kernel).  The poll is a system-scope load; NO acquire fence or cache invalidate follows it (a workgroup-scope fence only keeps the
+// compiler from hoisting the row loads): the staging area is coherent host memory, which no device cache level holds, and it is
+// tile-pitched, so a line fetched for one tile never carries a neighbour's rows from before they were packed (FxRowsReady; an
+// agent- or system-scope acquire here costs a launch ~85 us, profiles/r5_launch_first.log).  A host that dies
 // mid-call must not hang the device: after 0.25 s the wave raises FX_ERR_STARVED and goes on (the host redoes the call).
 __device__ __forceinline__ void fx_rows_wait(const FxRowsReady& r, int stage, int& known, unsigned* err) {
     if (stage < known) return;

@@ -69,10 +69,10 @@ int fx_pinned(fx_engine* e, int slot, size_t bytes, void** out) {
             e->h_pinned[slot] = nullptr; e->pinned_bytes[slot] = 0;
         }
         size_t cap = std::max<size_t>(bytes + bytes / 4, 1 << 16);
-        // (experiment, option staging_noncoherent: the INPUT staging area as non-coherent host memory -- cached in the GPU's L2, made
-        //  visible at kernel boundaries; rows that arrive during a launch are tile-pitched, so no line is read before it is written)
-        const unsigned flags = hipHostMallocMapped | ((slot == 0 && e->staging_noncoherent) ? hipHostMallocNonCoherent : 0u);
-        if (hipHostMalloc(&e->h_pinned[slot], cap, flags) != hipSuccess) {
+        // COHERENT (uncached on the device) host memory: the launched-first forms read rows the host stores while the kernel runs and
+        // rely on no device cache level holding a line of the staging area (fx_rows_wait); a non-coherent area was measured in round 5,
+        // bought nothing (profiles/r5: 255 / 110 / 340 us either way) and is gone
+        if (hipHostMalloc(&e->h_pinned[slot], cap, hipHostMallocMapped) != hipSuccess) {
             (void)hipGetLastError();
             return fx_fail(e, FX_ENOMEM, "hipHostMalloc of pinned staging failed");
         }
@@ -125,12 +125,18 @@ int fx_trace_buffer(fx_engine* e, unsigned long long** out) {
     return FX_OK;
 }
 
+__global__ void k_error_word(const unsigned* err, float* dst) {
+    unsigned v = 0;
+    for (int i = 0; i < FX_ERR_WORDS; ++i) v |= __hip_atomic_load(err + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    *dst = (float)v;
+}
+
 int check_deferred(fx_engine* e) {
     // caller has synchronised the stream; the error word lives in mapped pinned host memory,
     // so reading it costs nothing (no extra hipMemcpy on the small-call latency path)
-    const unsigned err = *reinterpret_cast<volatile unsigned*>(e->h_err);
+    const unsigned err = fx_err_read(e->h_err);
     if (err) {
-        *reinterpret_cast<volatile unsigned*>(e->h_err) = 0;
+        fx_err_clear(e->h_err);
         if (err & FX_ERR_TIMEOUT) {
             // (the barrier counter no longer matches what the host has added up: start over)
             if (e->d_lp_bar) { (void)hipMemset(e->d_lp_bar, 0, FX_LP_BAR_BYTES); for (unsigned& t : e->lp_bar_total) t = 0; }
@@ -205,7 +211,7 @@ int fx_engine_create(int device, fx_engine** out) {
     FX_CREATE_HIP(hipEventCreate(&e->ev0));
     FX_CREATE_HIP(hipEventCreate(&e->ev1));
     FX_CREATE_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_err), 64, hipHostMallocMapped));
-    *e->h_err = 0;
+    fx_err_clear(e->h_err);
     FX_CREATE_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->h_done), 64, hipHostMallocMapped | hipHostMallocCoherent));
     *e->h_done = 0;
     FX_CREATE_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->d_done), e->h_done, 0));
@@ -271,6 +277,18 @@ int fx_engine_sync(fx_engine* e) {
     return check_deferred(e);
 }
 
+// The deferred error words of this engine, OR-ed, as ONE float at `d_dst` -- enqueued on the engine's stream, i.e. it reports every kernel
+// enqueued before it.  flexs_amd/distributed.py puts it into the padding of the block a rank sends into the all-gather, so that "a
+// character outside the alphabet on ANY rank" travels with the scores (one collective per call, no flag all-reduce, no host sync).
+// Exact: the word is < 8.  Does not clear the words: fx_engine_sync still reports them on this rank.
+int fx_engine_error_word_dev(fx_engine* e, float* d_dst) {
+    if (!e || !d_dst) return FX_EINVAL;
+    FX_HIP(e, hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_error_word, dim3(1), dim3(1), 0, e->stream, e->d_err, d_dst);
+    FX_HIP(e, hipGetLastError());
+    return FX_OK;
+}
+
 const char* fx_last_error(fx_engine* e) { return e ? e->last_error.c_str() : g_last_error_noengine.c_str(); }
 
 static int64_t* option_slot(fx_engine* e, const char* key) {
@@ -323,7 +341,6 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "cnn_stage_host")) return &e->cnn_stage_host;
     if (!std::strcmp(key, "launch_relay")) return &e->launch_relay;
     if (!std::strcmp(key, "relay_spread")) return &e->relay_spread;
-    if (!std::strcmp(key, "staging_noncoherent")) return &e->staging_noncoherent;
     if (!std::strcmp(key, "dense_prefetch")) return &e->dense_prefetch;
     if (!std::strcmp(key, "train_rows")) return &e->train_rows;
     if (!std::strcmp(key, "train_lds")) return &e->train_lds;
@@ -365,12 +382,6 @@ int fx_engine_set_option(fx_engine* e, const char* key, int64_t value) {
     // a running resident generation was started under the old options (its geometry, but also the kernel forms its
     // workgroups run: pair rows or plain rows, ...): it leaves, the next calls start a new one under the new ones
     if (*s != value) { fx_server_stop(e); lp_disarm(e); }
-    if (s == &e->staging_noncoherent && *s != value && e->h_pinned[0]) {
-        // (the staging area is reallocated with the other attribute on next use)
-        (void)hipStreamSynchronize(e->stream);
-        (void)hipHostFree(e->h_pinned[0]);
-        e->h_pinned[0] = nullptr; e->pinned_bytes[0] = 0;
-    }
     *s = value;
     e->server.refused.clear();                             // (what has a resident form depends on the form selectors)
     return FX_OK;

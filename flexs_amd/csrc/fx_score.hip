@@ -5,6 +5,8 @@
 #include <cstring>
 #include <new>
 
+#include <sys/mman.h>
+
 #include "fx_common.h"
 #include "fx_internal.h"
 #include "myers.h"
@@ -331,8 +333,10 @@ int fx_score(fx_engine* e, fx_model* const* models, int M, const uint8_t* ascii,
                 c.words = w; c.base = e->rows_base; c.lanes = 1; c.pitch = 16 * L; c.packed_ok = true; c.in_place = false; c.relay = true;
                 bool waits = false;
                 rc = staged_enqueue(e, &waits);
-                if (waits) {
-                    c.redo = rc != 0;
+                if (waits || rc == FX_OK) {
+                    // (rc == FX_OK without `waits`: a launcher enqueued a kernel that did not take the rows request -- none does today.
+                    // Its results are not the relay's: fx_score_finish redoes the launch, as fx_score_begin_staged has it do)
+                    c.redo = rc != 0 || !waits;
                     c.staged = true; c.active = true;
                     e->launch_relay_calls += 1;
                     return fx_score_finish(e, out_NM, out_mean);
@@ -514,24 +518,44 @@ int fx_score_begin_staged(fx_engine* e, fx_model* const* models, int M, int64_t 
     return FX_OK;
 }
 
-// Pinned, GPU-mapped host memory for results that are handed out in place (fx_score_begin_staged's `results`): the caller owns it
-// -- typically a pool behind the arrays that wrap it -- and gives it back with fx_result_free when nothing refers to it any more.
+// Host memory for results that are handed out in place (fx_score_begin_staged's `results`): the caller owns it -- typically a pool
+// behind the arrays that wrap it -- and gives it back with fx_result_free when nothing refers to it any more.
+// ORDINARY anonymous memory (mmap), then registered with the device (hipHostRegister: pinned + GPU-mapped, the kernels store into it
+// over PCIe as they do into hipHostMalloc memory).  Round 5 used hipHostMalloc, whose mapping a fork()ed child does NOT inherit: a child
+// that read a result array it inherited would fault, which kept the in-place form opt-in.  An anonymous mapping is inherited
+// (copy-on-write) like any NumPy array; the registration stays with the parent.
 int fx_result_alloc(fx_engine* e, int64_t bytes, void** host) {
     if (!e || bytes < 1 || !host) return FX_EINVAL;
     FX_HIP(e, hipSetDevice(e->device));
-    void* p = nullptr;
-    if (hipHostMalloc(&p, (size_t)bytes, hipHostMallocMapped) != hipSuccess) {
+    const size_t len = ((size_t)bytes + 4095) & ~(size_t)4095;
+    void* p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (p == MAP_FAILED) return fx_fail(e, FX_ENOMEM, "mmap of a result buffer failed");
+    std::memset(p, 0, len);                                // (touch every page before it is pinned)
+    void* dev = nullptr;
+    if (hipHostRegister(p, len, hipHostRegisterMapped) != hipSuccess || hipHostGetDevicePointer(&dev, p, 0) != hipSuccess) {
         (void)hipGetLastError();
-        return fx_fail(e, FX_ENOMEM, "hipHostMalloc of a result buffer failed");
+        (void)hipHostUnregister(p); (void)hipGetLastError();
+        munmap(p, len);
+        return fx_fail(e, FX_ENOMEM, "hipHostRegister of a result buffer failed");
     }
+    if (dev != p) {                                        // (the kernels are handed the host address: unified addressing is assumed)
+        (void)hipHostUnregister(p);
+        munmap(p, len);
+        return fx_fail(e, FX_EUNSUPPORTED, "registered host memory is not mapped at its host address on this device");
+    }
+    e->result_bufs[p] = len;
     *host = p;
     return FX_OK;
 }
 int fx_result_free(fx_engine* e, void* host) {
     if (!e || !host) return FX_EINVAL;
+    auto it = e->result_bufs.find(host);
+    if (it == e->result_bufs.end()) return fx_fail(e, FX_EINVAL, "fx_result_free: not a buffer of fx_result_alloc");
     FX_HIP(e, hipSetDevice(e->device));
     FX_HIP(e, hipStreamSynchronize(e->stream));           // (nothing in flight writes into it)
-    FX_HIP(e, hipHostFree(host));
+    FX_HIP(e, hipHostUnregister(host));
+    munmap(host, it->second);
+    e->result_bufs.erase(it);
     return FX_OK;
 }
 
@@ -638,23 +662,23 @@ int fx_score_finish(fx_engine* e, float* out_NM, float* out_mean) {
         fx_bar_fence();
         int rc = wait_for_results(e);
         if (rc) return rc;
-        const unsigned err = *reinterpret_cast<volatile unsigned*>(e->h_err);
+        const unsigned err = fx_err_read(e->h_err);
         if (err || c.redo) {
-            // ANY error word (the bits overwrite each other: a "bad character" may stand for rows that never came and were scored as
-            // they lay), or a launch that did not wait.  When the caller did pack everything, the same launch once more -- every
+            // ANY error (rows that never came were scored as they lay, so a "bad character" beside "starved" says nothing about the
+            // caller's strings), or a launch that did not wait.  When the caller did pack everything, the same launch once more -- every
             // stage is published, nothing waits -- gives the answer and the error the reference gives; when it did not, there is
             // nothing to answer
-            *reinterpret_cast<volatile unsigned*>(e->h_err) = 0;
+            fx_err_clear(e->h_err);
             e->launch_first_redone += 1;
             if (!c.packed_ok) return FX_OK;                // (the caller raises its own packing error)
             bool waits = false;
             if ((rc = staged_enqueue(e, &waits))) return rc == FX_EUNSUPPORTED ? fx_fail(e, FX_ESTATE, "launched-first call: the second attempt found no kernel") : rc;
             if ((rc = wait_for_results(e))) return rc;
-            if (c.relay && (*reinterpret_cast<volatile unsigned*>(e->h_err) & FX_ERR_STARVED)) {
+            if (c.relay && (fx_err_read(e->h_err) & FX_ERR_STARVED)) {
                 // a relay's readers starved again although every row was there: member 0's workgroups did not get onto the device
                 // beside them (another process holding CUs).  Third attempt without the relay: every member reads the host rows
                 // itself -- slow, but no workgroup waits for another
-                *reinterpret_cast<volatile unsigned*>(e->h_err) = 0;
+                fx_err_clear(e->h_err);
                 c.relay = false;
                 if ((rc = staged_enqueue(e, &waits))) return rc == FX_EUNSUPPORTED ? fx_fail(e, FX_ESTATE, "launched-first call: the third attempt found no kernel") : rc;
                 if ((rc = wait_for_results(e))) return rc;

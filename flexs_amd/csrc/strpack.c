@@ -459,6 +459,20 @@ typedef struct {
 } SmallPlan;
 #define SMALL_MAX_BYTES 65536          /* = FX_SERVE_BYTES: what one request of the resident form holds */
 
+/* per-thread 64 KiB packing buffer of score_small, freed when its thread ends (round-5 advisor: it leaked per exiting thread) */
+static pthread_key_t big_key;
+static pthread_once_t big_once = PTHREAD_ONCE_INIT;
+static void big_make_key(void) { (void)pthread_key_create(&big_key, free); }
+static unsigned char* big_buffer(void) {
+    (void)pthread_once(&big_once, big_make_key);
+    unsigned char* b = (unsigned char*)pthread_getspecific(big_key);
+    if (!b) {
+        b = (unsigned char*)malloc(SMALL_MAX_BYTES);
+        if (b && pthread_setspecific(big_key, b) != 0) { free(b); b = NULL; }
+    }
+    return b;
+}
+
 static PyObject* score_small(PyObject* self, PyObject* args) {
     Py_buffer plan, out;
     PyObject* seqs;
@@ -473,12 +487,9 @@ static PyObject* score_small(PyObject* self, PyObject* args) {
             /* explorer-size calls pack into 4 KiB on the stack; the few that are larger (up to one mailbox request, 64 KiB) into a
              * per-thread heap buffer -- a 64 KiB frame in every call overflowed threads with small stacks (round-4 advisor) */
             unsigned char small[4096];
-            static __thread unsigned char* big = NULL;
             unsigned char* buf = small;
-            if (n * p->L > (Py_ssize_t)sizeof(small)) {
-                if (!big) big = (unsigned char*)malloc(SMALL_MAX_BYTES);
-                buf = big;
-            }
+            if (n * p->L > (Py_ssize_t)sizeof(small)) buf = big_buffer();
+            int changed = 0;                               /* the caller's list was resized while the GIL was released (see below) */
             float* o = (float*)out.buf;
             int streamed = 0;
             if (p->stream_begin && p->stream_min > 0 && n >= p->stream_min && p->stream_step > 0) {
@@ -487,7 +498,13 @@ static PyObject* score_small(PyObject* self, PyObject* args) {
                 Py_BEGIN_ALLOW_THREADS                     /* (it may end / start a generation: a stream synchronise; round-4 advisor) */
                 rc_begin = ((fx_stream_begin_fn)p->stream_begin)(p->engine, (void* const*)p->models, (int)p->M, (long long)n, (int)p->L, p->lut, &rows);
                 Py_END_ALLOW_THREADS
-                if (rc_begin == 0) {
+                /* another Python thread ran meanwhile: a list it resized has a stale n (and perhaps moved items) -- give the request
+                 * back and leave this call to the general path, which takes its own snapshot (round-5 advisor) */
+                changed = PySequence_Fast_GET_SIZE(seqs) != n;
+                if (rc_begin == 0 && changed) {
+                    ((fx_stream_end_fn)p->stream_end)(p->engine, 0, NULL, NULL);
+                    streamed = 1;                          /* (status stays -1) */
+                } else if (rc_begin == 0) {
                     /* the request is posted: pack in pieces, front to back, each piece reported as soon as it is in place */
                     PyObject** items = PySequence_Fast_ITEMS(seqs);
                     int st = 0;
@@ -512,9 +529,10 @@ static PyObject* score_small(PyObject* self, PyObject* args) {
                     }
                 }
             }
+            if (!streamed && PySequence_Fast_GET_SIZE(seqs) != n) { changed = 1; streamed = 1; }   /* (stream_end released the GIL too) */
             const int st = (streamed || !buf) ? 0 : pack_range(PySequence_Fast_ITEMS(seqs), buf, n, (Py_ssize_t)p->L, 1);
             if (streamed) {
-                /* answered (or failed) above */
+                /* answered (or failed) above; `changed`: status is still -1, the general path */
             } else if (!buf) {
                 status = -1;                               /* (no memory for the packing buffer: the general path) */
             } else if (st) {

@@ -121,8 +121,10 @@ __global__ void __launch_bounds__(256) k_train_adam(const FxtJob* __restrict__ j
         const int i4 = 4 * i;
         if (i4 + 3 < j.net.P) fxt_adam4(j, step, i4);
         else for (int k = i4; k < j.net.P && k < i4 + 4; ++k) fxt_adam(j, step, k);
-    } else if (i < j.net.P) {
-        fxt_adam(j, step, i);
+    } else {
+        // unaligned rows (pstride 0 = P + 1 is legal in FxtJob; fx_train_fit never builds one): one parameter at a time, grid-stride --
+        // the grid is sized for four per thread
+        for (int k = i; k < j.net.P; k += (int)(gridDim.x * blockDim.x)) fxt_adam(j, step, k);
     }
     if (blockIdx.x == 0 && j.step_loss) {
         // the step's loss = the slices' squared-error sums added in slice order.  One thread walking S dependent-looking global

@@ -86,7 +86,12 @@ def _all_gather(recv: torch.Tensor, send: torch.Tensor, group=None, force: bool 
 
 
 def _stride_for(n: int) -> int:
-    return max((n + 63) // 64 * 64, 64)         # plane stride in floats: 256-byte aligned planes
+    """Plane stride in floats: 256-byte aligned planes plus one 64-float block of padding that no kernel writes.  Its last element
+    on plane 0 of a rank's block carries that rank's error word through the all-gather (`_FLAG`)."""
+    return (n + 63) // 64 * 64 + 64
+
+
+_FLAG = -1          # s.local[0, _FLAG]: this rank's deferred error bits as a float (0.0 = none); s.recv[r, 0, _FLAG]: rank r's
 
 
 class _Slot:
@@ -102,6 +107,7 @@ class _Slot:
         self.want = "mean"
         self.busy = False
         self.keep = None
+        self.err = None             # (injected scorer only) the ValueError this rank's scorer raised
 
 
 class DistributedEnsemble(flexs_amd.Model):
@@ -194,20 +200,14 @@ class DistributedEnsemble(flexs_amd.Model):
             mine = member_assignment(len(self.models), rank, world)
             # SPMD: whatever fails on the rank that owns a member (an unsupported loss, an out-of-memory arena, an exception
             # of a member's own `train`) must fail the call on EVERY rank -- the others would otherwise wait for it forever
-            # in the weight gather below.  Agree on one flag first, as `get_fitness` does.
+            # in the weight gather below.  The failing rank still joins the gather; its flag travels in the block it sends.
             err = None
             try:
                 train_members([self.models[i] for i in mine], sequences, labels,
                               None if seeds is None else [seeds[i] for i in mine])
             except Exception as ex:                                # noqa: BLE001 (re-raised below, on every rank)
                 err = ex
-            flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device=_gather_device(self.group))
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
-            if err is not None:
-                raise err
-            if int(flag.item()):
-                raise RuntimeError("DistributedEnsemble.train: training failed on another rank (see that rank's exception)")
-            self.gather_weights()
+            self.gather_weights(failed=err)                        # (raises on every rank if any rank failed)
         else:
             train_members(self.models, sequences, labels, seeds)
 
@@ -230,19 +230,30 @@ class DistributedEnsemble(flexs_amd.Model):
             off += size
         arch.set_weights(out)
 
-    def gather_weights(self):
-        """After a member-sharded `train`: ONE all-gather of every rank's `(ceil(M / world), P)` weight block (P = the
-        largest member's parameter count) over the gather device (device buffers on RCCL), then `set_weights` for the
-        members this rank does not own.  8 x 22 429 floats = 0.7 MB for the canonical CNN ensemble."""
+    def gather_weights(self, failed: Optional[BaseException] = None):
+        """After a member-sharded `train`: ONE all-gather of every rank's `(ceil(M / world), P + 1)` weight block (P = the
+        largest member's parameter count; the extra column of row 0 = 1.0 when this rank's training `failed`) over the gather
+        device (device buffers on RCCL), then `set_weights` for the members this rank does not own.  8 x 22 429 floats =
+        0.7 MB for the canonical CNN ensemble.  A failure on any rank raises on every rank -- the failing one its own
+        exception, the others a RuntimeError -- and leaves the members' weights as they were."""
         rank, world = _world(self.group)
         if world == 1:
+            if failed is not None:
+                raise failed
             return
         M, dev = len(self.models), _gather_device(self.group)
         per, width = -(-M // world), self._blob_len()
-        send = self._pack_weights(member_assignment(M, rank, world), per, width).to(dev)
-        recv = torch.empty((world, per, width), dtype=torch.float32, device=dev)
+        block = self._pack_weights(member_assignment(M, rank, world), per, width + 1)
+        block[0, width] = 0.0 if failed is None else 1.0
+        send = block.to(dev)
+        recv = torch.empty((world, per, width + 1), dtype=torch.float32, device=dev)
         _all_gather(recv, send, self.group)
-        rows = recv.cpu().numpy().reshape(world * per, width)
+        got = recv.cpu().numpy()
+        if failed is not None:
+            raise failed
+        if (got[:, 0, width] != 0).any():
+            raise RuntimeError("DistributedEnsemble.train: training failed on another rank (see that rank's exception)")
+        rows = got[:, :, :width].reshape(world * per, width)
         mine = set(member_assignment(M, rank, world))
         for i in range(M):
             if i not in mine:                                      # contiguous assignment: row i IS member i
@@ -323,6 +334,10 @@ class DistributedEnsemble(flexs_amd.Model):
                         timing[1].record(st)
                     if local_reduce:
                         self._reduce_planes(s.planes, hi - lo, M, stride, s.local)
+                if s.exchange:
+                    # the error word travels WITH the scores: a character outside the alphabet fails the call on every rank
+                    # (sequence_utils.py:46 raises for the whole batch) without a second collective or a host sync
+                    self._engine().error_word_dev(s.local.data_ptr() + 4 * (stride - 1))
                 s.keep = seq                                         # alive until the kernels have run
                 if s.exchange and self._host_exchange:
                     host = s.local.cpu()                             # (stream-ordered, synchronous D2H)
@@ -336,11 +351,16 @@ class DistributedEnsemble(flexs_amd.Model):
                         s.done.record(self._comm)
         else:
             b = np.ascontiguousarray(seq[lo:hi])
-            local = self._score_fn(mine, b) if (mine and hi > lo) else np.zeros((hi - lo, len(mine)), np.float32)
+            s.err = None
+            try:
+                local = self._score_fn(mine, b) if (mine and hi > lo) else np.zeros((hi - lo, len(mine)), np.float32)
+            except ValueError as ex:                                 # the injected scorer's "character outside the alphabet"
+                s.err, local = ex, np.zeros((hi - lo, len(mine)), np.float32)
             s.planes.zero_()
             s.planes[: len(mine), : hi - lo] = torch.from_numpy(np.ascontiguousarray(np.asarray(local, np.float32).T))
             if local_reduce:
                 self._reduce_planes(s.planes, hi - lo, M, stride, s.local[0])
+            s.local[0, _FLAG] = 0.0 if s.err is None else 1.0
             if s.exchange:
                 _all_gather(s.recv, s.local, self.group)
         s.busy = True
@@ -381,26 +401,31 @@ class DistributedEnsemble(flexs_amd.Model):
         if n == 0:
             return self.combine_with(np.zeros((0, M), np.float32))
         default = self.combine_with is _default_combine
-        self.launch(seq_bytes, n, 0, "mean" if default else "matrix")
+        s = self.launch(seq_bytes, n, 0, "mean" if default else "matrix")
         out = self.finish(0)
+        rank, world = _world(self.group)
+        err, flags = s.err, None
         if self._cuda:
             with torch.cuda.stream(self.stream):
-                out = out.cpu()                                    # stream-ordered D2H of the final result only
-            err = None
+                if s.exchange:
+                    # ONE stream-ordered D2H: the result with every rank's error word behind it (they came with the gather)
+                    shape = tuple(out.shape)
+                    both = torch.cat([out.reshape(-1), s.recv[:, 0, _FLAG]]).cpu()
+                    out, flags = both[: both.numel() - world].reshape(shape), both[both.numel() - world:]
+                else:
+                    out = out.cpu()                                # stream-ordered D2H of the final result only
             try:
                 self._engine().sync()                              # raises ValueError for a character outside the alphabet
             except ValueError as ex:
                 err = ex
-            rank, world = _world(self.group)
-            if world > 1:
-                # SPMD: a character outside the alphabet fails the call on EVERY rank (sequence_utils.py:46 raises for the
-                # whole batch), also on the ranks whose row shard / member block never met it: agree on the flag
-                flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device=_gather_device(self.group))
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
-                if int(flag.item()) and err is None:
-                    err = ValueError("substring not found")
-            if err is not None:
-                raise err
+        elif s.exchange:
+            flags = s.recv[:, 0, _FLAG]
+        # SPMD: a character outside the alphabet fails the call on EVERY rank (sequence_utils.py:46 raises for the whole batch),
+        # also on the ranks whose row shard / member block never met it
+        if err is None and flags is not None and bool((flags != 0).any()):
+            err = ValueError("substring not found")
+        if err is not None:
+            raise err
         out = out.numpy()
         return out if default else self.combine_with(out)
 

@@ -78,6 +78,11 @@ int fx_engine_set_stream(fx_engine *e, void *hip_stream);
 /* Wait for the stream; returns FX_EBADCHAR if any _dev call since the last
  * sync met a character outside its alphabet. */
 int fx_engine_sync(fx_engine *e);
+/* Stream-ordered: *d_dst (device memory) = the engine's deferred error bits (1 = character outside the alphabet) as a float,
+ * covering every _dev call enqueued before it; the bits stay set for fx_engine_sync.  Multi-GPU callers place it in the block
+ * they all-gather, so an error on any rank reaches every rank with the scores -- the path's ONE collective
+ * (flexs/ensemble.py:54-59 sharded). */
+int fx_engine_error_word_dev(fx_engine *e, float *d_dst);
 const char *fx_last_error(fx_engine *e);
 /* Engine options (string key -> int64).  Unknown key -> FX_EINVAL.  The defaults are what the measurements under
  * profiles/ selected; an integrator normally sets none of them.

@@ -129,6 +129,8 @@ def main():
     print(json.dumps({
         "nam": nam,
         "value": done / el, "unit": "sequences/s", "cores": threads, "kind": "port", "vectorised": vec,
+        "sample_short": f"{done} seqs of the configs[1] batch in {el:.1f} s: Python encode loop + 256-row fp32 torch-CPU forward x {a.members} + "
+                        f"np.mean, {threads} thread(s) (fastest of {candidates}); host {os.cpu_count()} cores",
         "sample": f"{done} sequences ({done // a.sample} pass(es) over the first {a.sample} of the batch) in "
                   f"{el:.1f} s; reference-style path: per-character Python encode loop (single thread) + 256-row "
                   f"fp32 forward on {threads} torch threads (fastest of {candidates}) + np.stack/np.mean; host has "

@@ -119,6 +119,84 @@ def test_world2_gloo(mode, M, n):
             assert called == []
 
 
+def _count_collectives():
+    """Wrap every torch.distributed collective the module could issue; returns the list the calls are recorded in."""
+    calls = []
+    for name in ("all_gather", "all_gather_into_tensor", "all_reduce", "broadcast", "barrier", "reduce", "gather", "all_to_all"):
+        orig = getattr(dist, name)
+
+        def counted(*a, _orig=orig, _name=name, **kw):
+            calls.append(_name)
+            return _orig(*a, **kw)
+
+        setattr(dist, name, counted)
+    return calls
+
+
+def _one_collective_worker(rank, world, port, mode, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(0)
+        n = 101
+        seqs = ["".join("TGCA"[i] for i in row) for row in rng.integers(0, 4, (n, 8))]
+        members = [Stub(m) for m in range(3)]
+        bad_on = {"rank": None}
+
+        def score_fn(idx, b):
+            if bad_on["rank"] == rank:                             # only THIS rank's shard / member block meets the bad character
+                raise ValueError("substring not found")
+            return table_score(idx, b)
+
+        ens = fd.DistributedEnsemble(members, mode=mode, score_fn=score_fn)
+        calls = _count_collectives()
+        out = ens.get_fitness(seqs)
+        per_call = list(calls)
+        del calls[:]
+        mat = fd.DistributedEnsemble(members, mode=mode, score_fn=score_fn, combine_with=lambda x: x).get_fitness(seqs)
+        per_matrix_call = list(calls)
+        del calls[:]
+        raised = []
+        for bad_rank in (0, 1):
+            bad_on["rank"] = bad_rank
+            try:
+                ens.get_fitness(seqs)
+                raised.append(None)
+            except ValueError as ex:
+                raised.append(str(ex))
+        bad_on["rank"] = None
+        after = ens.get_fitness(seqs)                              # the flag does not stick to the next call
+        q.put((rank, out, mat, per_call, per_matrix_call, raised, list(calls), after))
+    except BaseException as exc:
+        q.put((rank, repr(exc)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["member", "sequence"])
+def test_world2_get_fitness_is_one_collective_and_errors_reach_every_rank(mode):
+    """SURVEY.md 8(e) / flexs/ensemble.py:54-59 sharded: exactly ONE exchange step per call.  Round 5 agreed on "a character outside
+    the alphabet" with a second collective (all-reduce of a flag) and a blocking `.item()`; the flag now rides in the padding of the
+    gathered block.  Counted here on gloo: one all-gather per `get_fitness`, nothing else -- and a ValueError raised by ONE rank's
+    scorer still ends the call on EVERY rank (sequence_utils.py:46 raises for the whole batch), three collectives for three calls."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_one_collective_worker, args=(r, world, port, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = _collect(q, procs)
+    rng = np.random.default_rng(0)
+    want_mat = table_score([0, 1, 2], np.frombuffer(b"TGCA", np.uint8)[rng.integers(0, 4, (101, 8))])
+    for rank, out, mat, per_call, per_matrix_call, raised, err_calls, after in results:
+        assert per_call == ["all_gather"] and per_matrix_call == ["all_gather"]
+        assert np.array_equal(mat, want_mat) and np.array_equal(out, np.mean(want_mat, axis=1)) and np.array_equal(after, out)
+        assert raised == ["substring not found"] * 2                # whichever rank met it, both raise
+        assert err_calls == ["all_gather"] * 3
+
+
 # ---------------------------------------------------------------- cache-sharded neighbour search
 class OracleLocalCache:
     """CPU stand-in for this rank's device key store (the C restatement of the K4 rule)."""
@@ -323,11 +401,12 @@ def _train_fail_worker(rank, world, port, q):
         members = _make_trainables()
         members[2].model.loss = "huber"                              # member 2 lives on rank 1 only: fit raises ValueError THERE
         ens = fd.DistributedEnsemble(members, mode="member", score_fn=table_score)
+        calls = _count_collectives()
         try:
             ens.train(seqs, y, seed=11)
-            q.put((rank, "no exception", None))
+            q.put((rank, "no exception", None, calls))
         except Exception as exc:                                      # noqa: BLE001
-            q.put((rank, type(exc).__name__, str(exc)))
+            q.put((rank, type(exc).__name__, str(exc), calls))
     except BaseException as exc:
         q.put((rank, repr(exc)))
         raise
@@ -347,6 +426,7 @@ def test_world2_member_sharded_train_failure_reaches_every_rank():
     got = {r[0]: r[1:] for r in _collect(q, procs)}
     assert got[1][0] == "ValueError" and "unsupported loss" in got[1][1]
     assert got[0][0] == "RuntimeError" and "another rank" in got[0][1]
+    assert got[0][2] == ["all_gather"] and got[1][2] == ["all_gather"]      # the failure flag rode in the ONE weight gather
 
 
 def test_bench_spawns_its_own_ranks():

@@ -164,6 +164,45 @@ def test_host_resident_bytes_through_lds_give_the_same_bits(launch_first, L, alp
         assert np.array_equal(v.view(np.uint32), want), key
 
 
+def test_results_in_place_survive_a_fork(launch_first, monkeypatch):
+    """Round 6: results in place are the default.  The buffers are anonymous memory registered with the device (fx_result_alloc: mmap +
+    hipHostRegister), so a fork()ed child that reads a result array it inherited sees the parent's values (round 5's hipHostMalloc
+    buffers were not inherited by a child: it would have faulted) -- and the parent's buffer still takes the next call's scores."""
+    import os
+
+    assert _native.RESULTS_IN_PLACE == 1 or os.environ.get("FLEXS_AMD_RESULTS_IN_PLACE") == "0"
+    monkeypatch.setattr(_native, "RESULTS_IN_PLACE", 1)
+    L, alpha, n = 8, "TGCA", 50_000
+    ens = _model("cnn", L, alpha, 3)
+    _, seqs = rand_seqs(n, L, alpha, seed=21)
+    got = ens.get_fitness(seqs)
+    assert not got.flags.owndata                                  # over a leased buffer
+    want = got.copy()
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:                                                  # child: plain reads of inherited memory, no HIP call
+        try:
+            ok = bool(np.array_equal(got, want)) and float(got.sum()) == float(want.sum())
+            os.write(w, b"1" if ok else b"0")
+        finally:
+            os._exit(0)
+    os.close(w)
+    _, status = os.waitpid(pid, 0)
+    answer = os.read(r, 1)
+    os.close(r)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, f"child died: status {status}"
+    assert answer == b"1"
+    # the parent goes on: the same buffers take the next calls (the fork write-protected their pages for a moment)
+    again = ens.get_fitness(seqs)
+    assert np.array_equal(again, want) and np.array_equal(got, want)
+    del got, again
+    _, seqs2 = rand_seqs(n, L, alpha, seed=22)
+    monkeypatch.setattr(_native, "RESULTS_IN_PLACE", 0)
+    want2 = ens.get_fitness(seqs2)
+    monkeypatch.setattr(_native, "RESULTS_IN_PLACE", 1)
+    assert np.array_equal(ens.get_fitness(seqs2), want2)
+
+
 def test_results_in_place_are_ordinary_arrays_over_leased_pinned_buffers(launch_first, monkeypatch):
     """FLEXS_AMD_RESULTS_IN_PLACE=1: a launched-first call's kernels write into a pinned buffer that the returned array wraps (no copy);
     the buffer goes back to the pool with the array's last view, a caller that hoards results gets ordinary arrays, a failed call leaks

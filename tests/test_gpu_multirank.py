@@ -275,28 +275,39 @@ def test_bench_control_flow_with_two_ranks_on_one_gpu():
     device 0 and gloo collectives -- everything but RCCL, on a one-GPU box.  Not a measurement (the line says so)."""
     import json
 
+    import tempfile
+
+    full_path = os.path.join(tempfile.mkdtemp(), "bench_full.json")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--debug-share-device", "--steps", "6",
-                        "--warmup", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--warmup", "2", "--no-cpu-baseline", "--full-record", full_path], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0].encode()) < 4096          # the contract line: the ONLY stdout line, short (round-5 verdict)
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "debug_share_device" in d
     assert d["config"]["global_batch"] == 200_000 and d["roofline"]["frac"] > 0
-    mp_ = {k: v for k, v in d["member_parallel"].items() if k != "what"}
+    assert all(not isinstance(v, (dict, list)) for v in d["roofline"].values())
+    full = json.load(open(full_path))                                 # the verbose blocks: full record (file + stderr)
+    assert full["value"] == pytest.approx(d["value"], rel=1e-5)
+    mp_ = {k: v for k, v in full["member_parallel"].items() if k != "what"}
     assert all(v["checked"] and v["members_per_rank"] == 4 for v in mp_.values())
+    assert any(k.startswith("mp_") and k.endswith("_speedup") for k in d["roofline"])
 
 
 @pytest.mark.skipif(_devices() < 2, reason="needs two visible GPUs")
 def test_bench_two_gpus_prints_one_line():
     import json
 
+    import tempfile
+
+    full_path = os.path.join(tempfile.mkdtemp(), "bench_full.json")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--no-cpu-baseline", "--full-record", full_path], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0].encode()) < 4096
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert all(v["checked"] for k, v in d["member_parallel"].items() if k != "what")
-    assert all(v["members_per_rank"] == 4 and v["speedup_vs_1gpu"] > 0 for k, v in d["member_parallel"].items() if k != "what")
+    mp_ = {k: v for k, v in json.load(open(full_path))["member_parallel"].items() if k != "what"}
+    assert all(v["checked"] for v in mp_.values())
+    assert all(v["members_per_rank"] == 4 and v["speedup_vs_1gpu"] > 0 for v in mp_.values())

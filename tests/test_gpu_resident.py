@@ -81,7 +81,7 @@ def test_resident_tiny_requests_of_very_short_sequences(eng, kind, L, M):
     """Sequences of 1-3 symbols: 48 bytes are more than one tile's 16 sequences (such requests take the byte area: only tile 0's
     workgroup reads the request line) and a tile's byte rows (16 x L bytes) are shorter than the 48-byte line (the workgroup writes
     only the dwords that hold the request's N x L bytes).  Resident answers against the launched call's bits, serve_tiny on and off
-    (`tools/runs/r4_tiny_edge.py`, `profiles/r4_tiny_edge.log`)."""
+    (`tools/archive/runs/r4_tiny_edge.py`, `profiles/r4_tiny_edge.log`)."""
     alpha = "UGCA"
     mk = {"mlp": lambda s: bm.MLP(L, 100, alpha, seed=s), "ge": lambda s: bm.GlobalEpistasisModel(L, 100, alpha, seed=s)}[kind]
     members = [mk(70 + s) for s in range(M)]
