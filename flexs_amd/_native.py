@@ -31,80 +31,7 @@ _i64p = C.POINTER(C.c_int64)
 _vp = C.c_void_p
 
 # name -> (restype, argtypes); the CPU test-suite checks that every one is exported
-SIGNATURES = {
-    "fx_version": (C.c_int, []),
-    "fx_status_name": (C.c_char_p, [C.c_int]),
-    "fx_device_count": (C.c_int, []),
-    "fx_engine_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
-    "fx_engine_destroy": (C.c_int, [_vp]),
-    "fx_engine_set_stream": (C.c_int, [_vp, _vp]),
-    "fx_engine_sync": (C.c_int, [_vp]),
-    "fx_engine_error_word_dev": (C.c_int, [_vp, _vp]),
-    "fx_last_error": (C.c_char_p, [_vp]),
-    "fx_engine_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
-    "fx_engine_get_option": (C.c_int, [_vp, C.c_char_p, _i64p]),
-    "fx_timer_start": (C.c_int, [_vp]),
-    "fx_engine_counters": (C.c_int, [_vp, _i64p, C.c_int]),
-    "fx_timer_stop": (C.c_int, [_vp, _f32p]),
-    "fx_model_create": (C.c_int, [_vp] + [C.c_int] * 6 + [C.POINTER(_vp)]),
-    "fx_model_destroy": (C.c_int, [_vp]),
-    "fx_model_num_params": (C.c_int64, [_vp]),
-    "fx_model_set_weights": (C.c_int, [_vp, _f32p, C.c_int64]),
-    "fx_model_get_weights": (C.c_int, [_vp, _f32p, C.c_int64]),
-    "fx_score": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _vp, C.c_int64, C.c_int, _u8p, _vp, _vp]),
-    "fx_plan_host_call": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
-    "fx_score_planes_dev": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _vp, C.c_int64, C.c_int, _u8p, _vp, C.c_int64]),
-    "fx_ensemble_mean_planes_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64, _vp]),
-    "fx_staging_input": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp)]),
-    "fx_train_orders": (C.c_int, [C.c_uint64, C.c_int64, C.c_int, _vp]),
-    "fx_score_stream_begin": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int64, C.c_int, _u8p, C.POINTER(_vp)]),
-    "fx_score_stream_rows": (C.c_int, [_vp, C.c_int64]),
-    "fx_score_stream_end": (C.c_int, [_vp, C.c_int, _vp, _vp]),
-    "fx_score_begin_staged": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int64, C.c_int, _u8p, C.c_int, C.c_int, C.c_int,
-                                        C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_uint), C.POINTER(C.c_int), C.POINTER(C.c_int), _vp, C.c_int64]),
-    "fx_score_abandon": (C.c_int, [_vp]),
-    "fx_result_alloc": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp)]),
-    "fx_result_free": (C.c_int, [_vp, _vp]),
-    "fx_score_begin": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.c_int64, C.c_int, _u8p, C.c_int, C.c_int, C.POINTER(_vp)]),
-    "fx_score_submit": (C.c_int, [_vp, C.c_int64, C.c_int64]),
-    "fx_score_finish": (C.c_int, [_vp, _vp, _vp]),
-    "fx_score_dev": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _vp, C.c_int64, C.c_int, _u8p, _vp, _vp]),
-    "fx_encode_onehot": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _u8p, C.c_int, _vp]),
-    "fx_encode_onehot_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _u8p, C.c_int, _vp]),
-    "fx_ensemble_reduce": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp]),
-    "fx_ensemble_reduce_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp]),
-    "fx_argmax_decode": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, _vp, _vp]),
-    "fx_decode_score": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _vp, C.c_int64, C.c_int, C.c_int, _vp, _u8p, _vp, _vp,
-                                  _vp]),
-    "fx_min_dist": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, _vp, C.c_int64, C.c_int, _vp, _vp]),
-    "fx_cache_create": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
-    "fx_cache_destroy": (C.c_int, [_vp]),
-    "fx_cache_size": (C.c_int64, [_vp]),
-    "fx_cache_append": (C.c_int, [_vp, _vp, C.c_int64]),
-    "fx_cache_min_dist": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, _vp, _vp]),
-    "fx_cache_nam_query": (C.c_int, [_vp, _vp, C.c_int, _u8p, C.c_int, _vp, C.c_int64, _vp, C.c_int64, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
-    "fx_cache_distances": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, _vp]),
-    "fx_cache_density": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, C.c_int, _vp, _vp, _vp]),
-    "fx_table_create": (C.c_int, [_vp, _vp, C.c_int64, C.POINTER(_vp)]),
-    "fx_table_destroy": (C.c_int, [_vp]),
-    "fx_table_lookup": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _u8p, C.c_int, _vp]),
-    "fx_table_additive": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _u8p, C.c_int, _vp]),
-    "fx_nam_combine": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, _vp]),
-    "fx_debug_packed_size": (C.c_int64, [C.c_int] * 6),
-    "fx_debug_pack_layout": (C.c_int, [C.c_int] * 6 + [_i64p]),
-    "fx_debug_mfma_per_tile": (C.c_int64, [C.c_int] * 6),
-    "fx_debug_trace_read": (C.c_int, [_vp, _vp, C.c_int64]),
-    "fx_debug_time_score": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _vp, C.c_int64, C.c_int, _u8p, _vp, C.c_int64, C.c_int, _f32p]),
-    "fx_debug_time_min_dist": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, C.c_int, _f32p]),
-    "fx_debug_pack_weights": (C.c_int, [C.c_int] * 6 + [_f32p, C.c_int64, _f32p, C.c_int64]),
-    "fx_debug_myers": (C.c_int, [_vp, C.c_int, _vp, C.c_int]),
-    "fx_debug_bounded_distance": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int]),
-    "fx_debug_myers_strips": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int]),
-    "fx_debug_train_trace": (C.c_int, [_vp, _vp]),
-    "fx_train_fit": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64, C.c_int, _u8p, _vp]),
-    "fx_debug_train_step_host": (C.c_int, [C.c_int] * 6 + [_vp, _vp, _vp, _vp, _vp, C.c_int, _u8p, _vp, _vp, C.c_int, _vp]),
-    "fx_debug_mfma_probe": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
-}
+from flexs_amd._abi import SIGNATURES  # noqa: E402  (the ctypes signature table, one entry per function of include/flexs_amd.h)
 
 _lib = None
 

@@ -210,6 +210,7 @@ struct fx_engine {
     int64_t cnn_seg_multi = 1;  // 1 = the position-segmented 4-letter form may spread a tile over several (4- or 8-wave) workgroups
     int64_t cnn_pair_seg4 = 1;  // 1 = the segmented protein form may use 4-wave workgroups (one wave per SIMD) when twice as many still fit in one wave of the grid
     int64_t cnn_pair_seg = -1;  // pair kernel, small batches: -1 = segment a tile's positions automatically, 0 = never, n > 0 = force SB = n workgroups per tile
+    int64_t dense_slab_coop = 3; // slab form: up to this many leftover tiles (tiles mod 8) of a workgroup are walked by its 8 waves together instead of a whole lockstep round; 0 = off
     int64_t dense_slab = 1;     // MLP / GE with H > 128: HxH blocks staged through LDS slabs by the workgroup (0 = every wave streams them from L2)
     int64_t ge_bytetab = 1;     // 1 = GlobalEpistasis layer 1 gathers from the byte-indexed per-position table (0 = LUT + code-indexed table: A/B)
     int64_t dense_waves = 0;    // MLP / GE canonical hidden width: 0 = auto (8 waves per workgroup for mid-size launches, else 16), 8 / 16 = force

@@ -312,6 +312,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "cnn_pair_seg")) return &e->cnn_pair_seg;
     if (!std::strcmp(key, "cnn_seg")) return &e->cnn_seg;
     if (!std::strcmp(key, "dense_slab")) return &e->dense_slab;
+    if (!std::strcmp(key, "dense_slab_coop")) return &e->dense_slab_coop;
     if (!std::strcmp(key, "cnn_big_units")) return &e->cnn_big_units;
     if (!std::strcmp(key, "poison_outputs")) return &e->poison_outputs;
     if (!std::strcmp(key, "trace")) return &e->trace;

@@ -672,6 +672,10 @@ int fx_score_finish(fx_engine* e, float* out_NM, float* out_mean) {
             e->launch_first_redone += 1;
             if (!c.packed_ok) return FX_OK;                // (the caller raises its own packing error)
             bool waits = false;
+            // a relay's flags of the FIRST attempt stand (its copiers gave up waiting and passed the rows on as they lay): the second
+            // attempt needs a value of its own, or its readers would take those tiles for delivered (found by the stopped-process
+            // test of round 6: "substring not found" for a batch of valid strings)
+            if (c.relay && (rc = relay_prepare(e, (c.N + 15) / 16))) return rc;
             if ((rc = staged_enqueue(e, &waits))) return rc == FX_EUNSUPPORTED ? fx_fail(e, FX_ESTATE, "launched-first call: the second attempt found no kernel") : rc;
             if ((rc = wait_for_results(e))) return rc;
             if (c.relay && (fx_err_read(e->h_err) & FX_ERR_STARVED)) {

@@ -65,6 +65,10 @@ __device__ __forceinline__ unsigned fx_xcd_block() {
 // were two straddling workgroups; 194 -> ~180 us on the 3 x 1e5 bench launch).
 // spread = true (relay launches, FxRelay): plain block order instead -- member 0's workgroups, the only ones that pull rows over
 // PCIe, then sit on all eight XCDs instead of one.
+// Round 6, measured and NOT kept: cutting a workgroup's share in whole rounds of four tiles (72 or 76 instead of 73 / 74, so that a 19th
+// tile always finds four waves on its SIMD).  The in-kernel timeline (profiles/r6_trace_probe.json) shows workgroups of 72 tiles leaving at
+// 175 us and those with a 19-tile SIMD at 192 us, but the 76-tile workgroups leave at 192 us as well: +0.4 % on the headline launch, within
+// +-1 % on seven other shapes (profiles/r6_unit_quant_ab.log).
 __device__ __forceinline__ void fx_unit_range(int64_t TG, int M, int64_t& u_lo, int64_t& u_hi, bool spread = false) {
     const int64_t G = gridDim.x, bid = spread ? (int64_t)blockIdx.x : (int64_t)fx_xcd_block();
     const int64_t U = (int64_t)M * TG;

@@ -618,3 +618,47 @@ def test_shared_last_tiles_of_the_dense_kernel_give_the_same_bits(eng, kind, L, 
     finally:
         eng.set_option("dense_coop", 1)
         eng.set_option("dense_small", 1)
+
+
+@pytest.mark.parametrize("kind,L,alpha,H,M,n", [
+    ("mlp", 14, "UGCA", 200, 1, 100_000), ("mlp", 14, "UGCA", 200, 1, 100_016), ("mlp", 14, "UGCA", 200, 1, 104_096),
+    ("mlp", 14, "UGCA", 200, 1, 108_192), ("mlp", 14, "UGCA", 200, 3, 33_333), ("mlp", 8, "TGCA", 256, 2, 50_001),
+    ("mlp", 14, "UGCA", 130, 1, 41_000), ("mlp", 14, "UGCA", 200, 1, 37), ("mlp", 14, "UGCA", 200, 1, 4_113),
+    ("ge", 90, s_utils.AAS, 200, 1, 100_000), ("ge", 90, s_utils.AAS, 200, 1, 104_096), ("ge", 90, s_utils.AAS, 200, 8, 50_000),
+    ("ge", 14, "UGCA", 256, 3, 33_333), ("ge", 237, s_utils.AAS, 200, 2, 20_481),
+])
+def test_leftover_tiles_of_the_slab_form_give_the_same_bits(eng, kind, L, alpha, H, M, n):
+    """Round 6: hidden sizes above 128 (dyna_ppo.py:54's MLP(seq_len, 200, alphabet)) run in lockstep rounds of 8 tiles per workgroup,
+    the H x H blocks streamed through LDS slabs once per round; a last round with one live tile cost as much as a full one (1e5
+    sequences: 24.4 tiles per workgroup -> a fourth round for one tile in 106 of 256 workgroups).  Up to `dense_slab_coop` (3)
+    leftover tiles are now walked by the workgroup's 8 waves together (score_dense_tile.h, blocks straight from L2).  Same arithmetic
+    per output element, so the SAME BITS as the lockstep rounds (`dense_slab_coop` = 0) and as any other limit; both agree with the
+    oracle; a bad character in a leftover tile is still reported."""
+    A = len(alpha)
+    natives, ws = zip(*[make_native(eng, kind, L, A, H, seed=600 + m) for m in range(M)])
+    lut = _native.make_lut(alpha)
+    b, seqs = rand_seqs(n, L, alpha, seed=L + H + M + 2)
+    eng.set_option("dense_small", 0)
+    try:
+        outs = {}
+        for coop in (0, 1, 3, 7):
+            eng.set_option("dense_slab_coop", coop)
+            outs[coop], _ = eng.score(list(natives), b, lut)
+        for coop in (1, 3, 7):
+            assert np.array_equal(outs[coop].view(np.uint32), outs[0].view(np.uint32)), coop
+        eng.set_option("dense_slab_coop", 3)
+        k = min(n, 300)
+        for m in range(M):
+            assert_scores(outs[3][:k, m], c_oracle.forward(kind, lut[b[:k]], A, ws[m]), f"{kind} L={L} H={H} member {m} slab")
+            assert_scores(outs[3][n - k:, m], c_oracle.forward(kind, lut[b[n - k:]], A, ws[m]), f"{kind} L={L} H={H} member {m} slab tail")
+        ncu = eng.get_option("num_cus")
+        tiles = (n + 15) // 16
+        for where in (n - 1, 16 * (tiles // ncu) - 1, n // 2):      # the leftover tiles are the last ones of each workgroup's range
+            bad = b.copy(); bad[min(max(where, 0), n - 1), L - 1] = ord("!")
+            with pytest.raises(ValueError):
+                eng.score(list(natives), bad, lut)
+        again, _ = eng.score(list(natives), b, lut)
+        assert np.array_equal(again, outs[3])
+    finally:
+        eng.set_option("dense_slab_coop", 3)
+        eng.set_option("dense_small", 1)

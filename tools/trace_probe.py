@@ -128,6 +128,18 @@ if __name__ == "__main__":
         rows.append(trace_case("[phases] cnn L=14 M=3 N=20", "cnn", 14, "UGCA", 3, 20, F=32, K=5))
         json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "trace_probe_phases.json"), "w"), indent=1)
         sys.exit(0)
+    if os.environ.get("FX_SET") == "r6":
+        # round 6: where the launches furthest below the roofline spend their time
+        rows.append(trace_case("mlp L=14 H=100 M=1 N=100000 (C3)", "mlp", 14, "UGCA", 1, 100_000))
+        rows.append(trace_case("mlp L=14 H=100 M=1 N=1000000", "mlp", 14, "UGCA", 1, 1_000_000))
+        rows.append(trace_case("mlp L=14 H=200 M=1 N=100000", "mlp", 14, "UGCA", 1, 100_000, H=200))
+        rows.append(trace_case("cnn L=8 H=200 M=1 N=100000", "cnn", 8, "TGCA", 1, 100_000, H=200, F=32, K=5))
+        rows.append(trace_case("ge L=90 M=1 N=100000", "ge", 90, AAS, 1, 100_000))
+        rows.append(trace_case("ge L=90 M=8 N=100000 (C4)", "ge", 90, AAS, 8, 100_000))
+        rows.append(trace_case("cnn L=8 M=1 N=10000 (C1)", "cnn", 8, "TGCA", 1, 10_000, F=32, K=5))
+        rows.append(trace_case("cnn L=8 M=3 N=100000 (C2 headline)", "cnn", 8, "TGCA", 3, 100_000, F=32, K=5))
+        json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "trace_probe_r6.json"), "w"), indent=1)
+        sys.exit(0)
     if os.environ.get("FX_SET") == "seg":
         # small launches of long sequences: position-segmented forms
         for kind, L, alpha, M, N, kw in (("cnn", 100, "UGCA", 3, 20, dict(F=32, K=5)), ("cnn", 50, "UGCA", 3, 20, dict(F=32, K=5)),
