@@ -527,8 +527,24 @@ int fx_score_begin_staged(fx_engine* e, fx_model* const* models, int M, int64_t 
 int fx_result_alloc(fx_engine* e, int64_t bytes, void** host) {
     if (!e || bytes < 1 || !host) return FX_EINVAL;
     FX_HIP(e, hipSetDevice(e->device));
-    const size_t len = ((size_t)bytes + 4095) & ~(size_t)4095;
-    void* p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    // whole 2 MiB pages where the kernel grants them (transparent huge pages): the device then translates one page per 2 MiB of scores
+    // instead of 512 -- results of 1e5 sequences x 3 members are 1.6 MB
+    constexpr size_t HUGE = (size_t)2 << 20;
+    const size_t len = (size_t)bytes >= HUGE / 2 ? (((size_t)bytes + HUGE - 1) & ~(HUGE - 1)) : (((size_t)bytes + 4095) & ~(size_t)4095);
+    void* p = MAP_FAILED;
+    if (len >= HUGE) {
+        // an aligned range out of a larger reservation (mmap gives no alignment), the slack returned at once
+        char* raw = (char*)mmap(nullptr, len + HUGE, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (raw != MAP_FAILED) {
+            char* al = (char*)(((uintptr_t)raw + HUGE - 1) & ~(uintptr_t)(HUGE - 1));
+            if (al > raw) munmap(raw, (size_t)(al - raw));
+            if (al + len < raw + len + HUGE) munmap(al + len, (size_t)(raw + len + HUGE - (al + len)));
+            p = al;
+            (void)madvise(p, len, MADV_HUGEPAGE);
+        }
+    } else {
+        p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    }
     if (p == MAP_FAILED) return fx_fail(e, FX_ENOMEM, "mmap of a result buffer failed");
     std::memset(p, 0, len);                                // (touch every page before it is pinned)
     void* dev = nullptr;
