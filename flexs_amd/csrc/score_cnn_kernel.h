@@ -18,6 +18,7 @@
 #pragma once
 #include "fx_common.h"
 #include "mfma_common.h"
+#include "score_cnn_quad_round.h"
 
 namespace {
 
@@ -30,6 +31,7 @@ struct CnnArgs {
     unsigned long long* trace;  // in-kernel timeline (null = off), see fx_stamp
     int wave_prio;              // 1 = fx_stagger_priority
     int stage_fill;             // 1 = small launches load the conv part first, idle waves bring the head's weights
+    int quad_tail;              // QT: 1 = the last (tiles mod 4) tiles of a workgroup are walked by wave quads (fx_cnn_quad_round)
     int64_t N;
     int64_t TG;                 // tile groups per member = ceil(N / (16*NT))
     int M, Mtot, m_off;
@@ -59,9 +61,16 @@ struct CnnArgs {
 // HEAD = false: the conv part only -- the global max-pooled features of every tile go to `pool_out` in accumulator
 // (= B-operand) layout and a separate head kernel (score_cnn_split.hip) finishes the sequence.  Used for the CNN
 // shapes whose (kernel size, hidden width) pair has no fused instantiation.
+// QT (round 6; the unrolled seq_len = 8 form in 16-wave workgroups): 18.31 tiles per SIMD on the 3 x 1e5 headline launch mean that a SIMD
+// with a 19th tile sets the launch (in-kernel timeline profiles/r6_trace_probe.json: workgroups of 72 tiles leave at 175 us, those of 73 / 74
+// at 192 us).  The (tiles mod 4) last tiles of a workgroup are left out of the per-SIMD shares and walked by wave QUADS -- one wave per SIMD,
+// a quarter of the tile's MFMAs on each pipe -- in one round after the main loop (fx_cnn_quad_round: same bits).
 template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1, int L1S = 0, bool PRIO = false,
-          bool SEG = false, bool HEAD = true, bool STG = false>
+          bool SEG = false, bool HEAD = true, bool STG = false, bool QT = false>
 __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
+    static_assert(!QT || (A == 4 && FT == 2 && HT == 7 && NT == 1 && DENSE_LDS && WAVES == 16 && G1 && L1S > 0 && L1S <= 4 && !SEG && HEAD && !STG),
+                  "QT is a form of the canonical unrolled kernel (exchange buffers of 8 KiB: four conv positions)");
+    constexpr int QXT = 8;                                  // QT: 16-channel tiles per exchange buffer (>= FT * L1S, >= HT + 1)
     static_assert(!STG || (!SEG && NT == 1), "STG copies ONE whole tile's bytes into the wave's LDS scratch");
     static_assert(HEAD || (NT == 1 && !DENSE_LDS), "the conv-only form is one tile per wave, conv weights in LDS");
     static_assert(!SEG || (NT == 1 && L1S == 0 && K * (A - 1) <= 16), "SEG is the ring-window, one-tile form");
@@ -142,8 +151,14 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
 
         // the workgroup's tiles in shares per SIMD (proportional to the waves it hosts); the waves of a SIMD pull from
         // their share's counter
-        const int64_t s_lo = t_lo + (t_hi - t_lo) * share.before / share.total;
-        const int64_t s_hi = t_lo + (t_hi - t_lo) * (share.before + share.mine) / share.total;
+        // QT: the tiles that do not divide by four wait for the quad round behind the main loop (not when the rows still arrive)
+        int nq = 0;
+        if constexpr (QT) {
+            if (p.quad_tail && t_hi - t_lo >= 8 && !p.ready.words) nq = (int)((t_hi - t_lo) & 3);
+        }
+        const int64_t t_main = t_hi - nq;
+        const int64_t s_lo = t_lo + (t_main - t_lo) * share.before / share.total;
+        const int64_t s_hi = t_lo + (t_main - t_lo) * (share.before + share.mine) / share.total;
         // launched-first call: the host packs the tiles of stage 0 first, then stage 1, ... (FxRowsReady): the share is walked from
         // its first tile of stage 0 on (and around), so the stages it asks for come in the order they are packed
         const bool rows_arrive = !SEG && NT == 1 && p.ready.words != nullptr;
@@ -513,6 +528,21 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
             }
             FX_TILE_DONE();
         }
+        if constexpr (QT) {
+            if (nq) {                                             // (workgroup-uniform)
+                // quad j = waves 4j .. 4j + 3 (hardware places consecutive waves on consecutive SIMDs; nothing depends on it), roles
+                // rotated from quad to quad as in score_cnn_quad.hip; the exchange buffers lie behind the LUT and the counters
+                const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), quad = wv >> 2, q = ((wv & 3) + quad) & 3;
+                const bool qlive = quad < nq;
+                f4* xq = reinterpret_cast<f4*>(smem + lds_floats + 64 + 12) + (qlive ? quad : 0) * (2 * QXT * 64);
+                const int64_t qtg = t_main + (qlive ? quad : 0);
+                const int64_t qn = qtg * 16 + sq;
+                const uint8_t* qrow = p.ascii + (qn < p.N ? qn : 0) * L;
+                float yq = 0.f;
+                fx_cnn_quad_round<FT, HT, K, L1S, QXT>(qlive, q, lane, qrow, lut_s, w1p, cb, w_c2, w_c3, w_d1, w_d2, db, p.rlh, xq, xq + QXT * 64, bad, yq);
+                if (qlive && q == 0 && g == 0 && qn < p.N) p.out[qn * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(yq);
+            }
+        }
         if (CAN_STAGE && staged && !got_tile) {
             // this wave has no tile: bring the dense head's weights, 8 KiB per chunk
             const f4* src = reinterpret_cast<const f4*>(p.w[m]) + p.conv_floats / 4;
@@ -545,10 +575,11 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
 }
 
 template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1, int L1S = 0, bool PRIO = false,
-          bool SEG = false, bool HEAD = true, bool STG = false>
+          bool SEG = false, bool HEAD = true, bool STG = false, bool QT = false>
 int launch_g(fx_engine* e, const CnnArgs& a_in, size_t lds_bytes) {
     constexpr int waves = WAVES;
-    auto kern = k_score_cnn_mfma<A, K, FT, HT, NT, DENSE_LDS, WAVES, G1, L1S, PRIO, SEG, HEAD, STG>;
+    auto kern = k_score_cnn_mfma<A, K, FT, HT, NT, DENSE_LDS, WAVES, G1, L1S, PRIO, SEG, HEAD, STG, QT>;
+    if (QT) lds_bytes += (size_t)3 * 2 * 8 * 1024;               // three quads' exchange buffers (2 x 8 KiB each)
     if (SEG) lds_bytes += (size_t)WAVES * FT * 64 * 16;          // segment-maxima slots
     const bool ahead = STG && e->cnn_stage_host >= 2 && lds_bytes + 2 * (size_t)WAVES * ((16 * (size_t)a_in.L + 15) / 16 * 16) <= (size_t)e->max_lds;
     if (STG) lds_bytes += (size_t)WAVES * ((16 * (size_t)a_in.L + 15) / 16 * 16) * (ahead ? 2 : 1);   // a tile's bytes per wave (two scratches with the look-ahead)

@@ -57,6 +57,11 @@ int dispatch_a4(fx_engine* e, const CnnArgs& a0, int variant, bool big, size_t f
                     return launch_g<4, 5, 2, 7, 1, true, 16, true, 10, true>(e, a, lds);
                 case 7:                                  // unrolled L = 8 specialisation with s_setprio (the default)
                     if (a.L != 8) return fx_fail(e, FX_EINVAL, "cnn_variant 7 is a seq_len = 8 specialisation");
+                    // ... with the (tiles mod 4) last tiles of a workgroup walked by wave quads (round 6; cnn_quad_tail = 0: A/B)
+                    if (e->cnn_quad_tail && !e->rows_req.on && lds + (size_t)3 * 2 * 8 * 1024 <= (size_t)e->max_lds) {
+                        a.quad_tail = 1;
+                        return launch_g<4, 5, 2, 7, 1, true, 16, true, 4, true, false, true, false, true>(e, a, lds);
+                    }
                     return launch_g<4, 5, 2, 7, 1, true, 16, true, 4, true>(e, a, lds);
                 case 11:                                 // unrolled L = 8 form in 8-wave workgroups (256-register budget): small launches
                     if (a.L != 8) return fx_fail(e, FX_EINVAL, "cnn_variant 11 is a seq_len = 8 specialisation");

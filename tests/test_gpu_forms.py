@@ -662,3 +662,40 @@ def test_leftover_tiles_of_the_slab_form_give_the_same_bits(eng, kind, L, alpha,
     finally:
         eng.set_option("dense_slab_coop", 3)
         eng.set_option("dense_small", 1)
+
+
+@pytest.mark.parametrize("M,n", [(3, 100_000), (1, 100_000), (3, 99_985), (1, 300_001), (3, 50_000), (8, 100_000), (2, 70_016), (1, 65_552), (3, 1_000_003)])
+def test_quad_tail_of_the_persistent_cnn_kernel_gives_the_same_bits(eng, M, n):
+    """Round 6: the unrolled seq_len = 8 kernel (BASELINE configs[0] / [1]) leaves the (tiles mod 4) last tiles of a workgroup out of its
+    per-SIMD shares and walks them with wave quads in one round behind the main loop (`cnn_quad_tail`, score_cnn_quad_round.h) -- the
+    3 x 1e5 headline launch has 18.31 tiles per SIMD and the SIMDs with a 19th tile set its duration.  Same MFMA / add sequence per
+    output element: the SAME BITS as one wave per tile throughout (`cnn_quad_tail` = 0); both agree with the oracle at the head and the
+    tail of the batch; a bad character in a tail tile is still reported."""
+    L, alpha = 8, "TGCA"
+    natives, ws = zip(*[make_native(eng, "cnn", L, 4, 100, 32, 5, seed=300 + m) for m in range(M)])
+    lut = _native.make_lut(alpha)
+    b, seqs = rand_seqs(n, L, alpha, seed=n % 89 + M)
+    try:
+        outs = {}
+        for qt in (0, 1):
+            eng.set_option("cnn_quad_tail", qt)
+            outs[qt], mean = eng.score(list(natives), b, lut, want_matrix=True, want_mean=True)
+            assert np.array_equal(mean, np.mean(outs[qt], axis=1))
+        assert np.array_equal(outs[1].view(np.uint32), outs[0].view(np.uint32))
+        k = min(n, 400)
+        for m in range(M):
+            assert_scores(outs[1][:k, m], c_oracle.forward("cnn", lut[b[:k]], 4, ws[m], F=32, K=5) if False else
+                          ref_np.keras_fitness(seqs[:k], alpha, "cnn", ws[m], exact=True), f"cnn L=8 quad tail member {m}")
+            assert_scores(outs[1][n - k:, m], ref_np.keras_fitness(seqs[n - k:], alpha, "cnn", ws[m], exact=True), f"cnn L=8 quad tail member {m} tail")
+        # a character outside the alphabet in the tiles that end a workgroup's range (the quad round's) and elsewhere
+        ncu = eng.get_option("num_cus")
+        tiles = (n + 15) // 16
+        per_member_wg = max(ncu // M, 1)
+        for where in (n - 1, 16 * (tiles // per_member_wg) - 1, 16 * (tiles // per_member_wg) - 17, n // 2):
+            bad = b.copy(); bad[min(max(where, 0), n - 1), L - 1] = ord("!")
+            with pytest.raises(ValueError):
+                eng.score(list(natives), bad, lut)
+        again, _ = eng.score(list(natives), b, lut)
+        assert np.array_equal(again, outs[1])
+    finally:
+        eng.set_option("cnn_quad_tail", 1)
