@@ -65,6 +65,9 @@ struct CnnArgs {
 // with a 19th tile sets the launch (in-kernel timeline profiles/r6_trace_probe.json: workgroups of 72 tiles leave at 175 us, those of 73 / 74
 // at 192 us).  The (tiles mod 4) last tiles of a workgroup are left out of the per-SIMD shares and walked by wave QUADS -- one wave per SIMD,
 // a quarter of the tile's MFMAs on each pipe -- in one round after the main loop (fx_cnn_quad_round: same bits).
+// Measured with it and NOT kept: a staged start (image by direct global -> LDS copies in two parts, every wave's first row asked for ahead of
+// the copies, first tiles start when the 35 KiB conv part has landed, the head part awaited through an LDS count) -- 1.5 % SLOWER on the
+// headline launch and on a one-member launch (profiles/r6_dma_start_ab.log; tools/archive/runs/r6_dma_start_ab.py).
 template <int A, int K, int FT, int HT, int NT, bool DENSE_LDS, int WAVES, bool G1, int L1S = 0, bool PRIO = false,
           bool SEG = false, bool HEAD = true, bool STG = false, bool QT = false>
 __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
@@ -222,9 +225,18 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                 }
                 srow = (fx_lds_u8p)(stw + (n[0] < p.N ? sq : 0) * L);
             }
-            // a byte of this lane's sequence
+            // a byte of this lane's sequence.  ROW8 (seq_len = 8, rows in device memory; round 6): the whole row is ONE 8-byte load per tile
+            // (any alignment: gfx950 compute runs with unaligned access enabled) and the positions are shifts, instead of eight byte loads:
+            // -1 % on the headline launch
+            constexpr bool ROW8 = !STG && L1S == 4 && K == 5;
+            [[maybe_unused]] unsigned long long rowq[NT];
+            if constexpr (ROW8) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) __builtin_memcpy(&rowq[nt], row[nt], 8);
+            }
             auto seq_byte = [&](int nt, int at) -> int {
                 if constexpr (STG) return (int)srow[at];
+                else if constexpr (ROW8) return (int)((rowq[nt] >> (8 * at)) & 0xFFull);
                 else return (int)row[nt][at];
             };
             // Sliding windows.  RING: positions live in slot (position mod window), and the position loop is
