@@ -87,6 +87,10 @@ def main():
         th.start()
         time.sleep(0.2)
 
+    if mode == "stopped" and _native._strpack is not None:
+        # ONE packing thread: packing is then about half of a call, so that a stop at a random moment lands where it matters -- kernels
+        # launched, rows not all packed -- often enough for the test to insist on a redone launch (with the pool it is ~15 % of a call)
+        _native._strpack.set_threads(1)
     print("READY", flush=True)                                   # (the parent of mode `stopped` starts its SIGSTOPs now)
     calls = mismatches = 0
     errors, times = [], []

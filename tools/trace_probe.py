@@ -128,6 +128,14 @@ if __name__ == "__main__":
         rows.append(trace_case("[phases] cnn L=14 M=3 N=20", "cnn", 14, "UGCA", 3, 20, F=32, K=5))
         json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "trace_probe_phases.json"), "w"), indent=1)
         sys.exit(0)
+    if os.environ.get("FX_SET") == "r6p":
+        # round 6, phase build (make trace-phases): where a lockstep round of the slab form goes -- first layer / H x H layer 2 / layer 3
+        rows.append(trace_case("[phases] mlp L=14 H=200 M=1 N=100000", "mlp", 14, "UGCA", 1, 100_000, H=200))
+        rows.append(trace_case("[phases] mlp L=14 H=200 M=1 N=32768 (one full round)", "mlp", 14, "UGCA", 1, 32_768, H=200))
+        rows.append(trace_case("[phases] ge L=90 H=200 M=1 N=100000", "ge", 90, AAS, 1, 100_000, H=200))
+        rows.append(trace_case("[phases] mlp L=14 H=100 M=1 N=100000", "mlp", 14, "UGCA", 1, 100_000))
+        json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "trace_probe_r6p.json"), "w"), indent=1)
+        sys.exit(0)
     if os.environ.get("FX_SET") == "r6":
         # round 6: where the launches furthest below the roofline spend their time
         rows.append(trace_case("mlp L=14 H=100 M=1 N=100000 (C3)", "mlp", 14, "UGCA", 1, 100_000))
