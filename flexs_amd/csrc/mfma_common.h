@@ -376,42 +376,49 @@ __device__ __forceinline__ void mma_layer(WPtr wblk, const f4 (&in)[TI][NT], f4 
     }
 }
 
-// mma_layer for weight matrices that do not fit LDS (hidden sizes 129..256: TI*TO KiB per layer): instead of every
-// wave streaming all blocks from L2 for every tile (which makes the kernel L2-bandwidth-bound), the WORKGROUP
-// streams them once per round of WAVES tiles through a double-buffered LDS slab of KG input tiles (KG*TO KiB).
-// While the waves run the MFMAs of slab s out of one buffer, every thread has the 16-byte pieces of slab s+1 in
-// flight in registers and parks them in the other buffer afterwards: one barrier per slab.  All waves of the
-// workgroup must call this in lockstep (same number of times).
-template <int TI, int TO, int KG, int THREADS>
-__device__ __forceinline__ void mma_layer_slab(const f4* __restrict__ wglob, f4* slab, const f4 (&in)[TI][1],
-                                               f4 (&acc)[TO][1], int lane, int rl_last) {
+// Weight matrices that do not fit LDS (hidden sizes 129..256: TI*TO KiB per layer): instead of every wave streaming all blocks from L2
+// for every tile (which makes the kernel L2-bandwidth-bound), the WORKGROUP streams them once per round of WAVES tiles through a
+// double-buffered LDS slab of KG input tiles (KG*TO KiB): one barrier per slab, all waves of the workgroup in lockstep.
+// Rounds 1-5 carried the next slab through registers (16-byte pieces in flight during a slab's MFMAs, parked in the other buffer
+// afterwards).  Round 6: the slabs are copied global -> LDS DIRECTLY (fx_dma16: no registers, no ds_write behind a slab's MFMAs) and the
+// stream of slabs runs on ACROSS layers and rounds: while a layer's last slab is being multiplied, the first slab of the NEXT layer
+// (`wnext`: the round's other H x H layer, or the next round's first one; nullptr = nothing follows) is already on its way into the free
+// buffer, so only the first layer of a member's first round waits for a trip to L2.  `st` carries the buffer the layer starts in and
+// whether its first slab has been asked for.  Same MFMA sequence per accumulator as before (and as mma_layer): the same bits;
+// MLP H=200 1e5 / 1e6: 171.2 -> 167.6 / 1568 -> 1530 us (profiles/r6_slab_dma_ab.log).
+struct FxSlabStream { int par; bool primed; };
+template <int TI, int TO, int KG, int WAVES>
+__device__ __forceinline__ void fx_slab_issue(const f4* __restrict__ wglob, int sl, f4* buf, int wave, int lane) {
+    constexpr int SLAB = KG * TO * 64;
+    const int tiles = TI - sl * KG < KG ? TI - sl * KG : KG;   // input tiles of this slab
+    const int chunks = tiles * TO;                              // 1 KiB (one wave-wide 16-byte copy) each
+    const unsigned base = __builtin_amdgcn_readfirstlane(fx_lds_addr(buf));
+    const f4* src = wglob + (size_t)sl * SLAB + lane;
+    for (int c = wave; c < chunks; c += WAVES) fx_dma16(src + c * 64, base + (unsigned)c * 1024u);
+}
+template <int TI, int TO, int KG, int WAVES>
+__device__ __forceinline__ void mma_layer_slab_dma(const f4* __restrict__ wglob, const f4* __restrict__ wnext, f4* slab, const f4 (&in)[TI][1],
+                                                   f4 (&acc)[TO][1], int lane, int rl_last, FxSlabStream& st) {
     constexpr int SLAB = KG * TO * 64;                         // f4 per (full) slab
     constexpr int NS = (TI + KG - 1) / KG;
-    constexpr int PER = (SLAB + THREADS - 1) / THREADS;
-    const int tid = threadIdx.x;
-    f4 pre[PER];
-#pragma unroll
-    for (int k = 0; k < PER; ++k)
-        if (tid + k * THREADS < SLAB) pre[k] = wglob[tid + k * THREADS];
-    __syncthreads();                                            // every wave is done with both buffers (previous layer)
-#pragma unroll
-    for (int k = 0; k < PER; ++k)
-        if (tid + k * THREADS < SLAB) slab[tid + k * THREADS] = pre[k];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (!st.primed) {
+        __syncthreads();                                        // every wave is done with both buffers
+        fx_slab_issue<TI, TO, KG, WAVES>(wglob, 0, slab + st.par * SLAB, wave, lane);
+    }
 #pragma unroll
     for (int sl = 0; sl < NS; ++sl) {
-        __syncthreads();                                        // slab sl is in LDS; buffer (sl+1)&1 is free
-        const int next_f4 = (sl + 1 < NS) ? ((TI - (sl + 1) * KG < KG ? TI - (sl + 1) * KG : KG) * TO * 64) : 0;
-#pragma unroll
-        for (int k = 0; k < PER; ++k)
-            if (tid + k * THREADS < next_f4) pre[k] = wglob[(sl + 1) * SLAB + tid + k * THREADS];
-        const f4* buf = slab + (sl & 1) * SLAB;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of slab sl have landed ...
+        __syncthreads();                                        // ... everybody's have; and the other buffer is free (slab sl - 1 is done)
+        f4* nbuf = slab + (st.par ^ 1) * SLAB;
+        if (sl + 1 < NS) fx_slab_issue<TI, TO, KG, WAVES>(wglob, sl + 1, nbuf, wave, lane);
+        else if (wnext) fx_slab_issue<TI, TO, KG, WAVES>(wnext, 0, nbuf, wave, lane);
+        const f4* buf = slab + st.par * SLAB;
 #pragma unroll
         for (int j = 0; j < KG; ++j) {
             const int mi = sl * KG + j;
             if (mi < TI) {
-                // four output tiles at a time: 16 registers of A fragments in flight instead of 4*TO (the wide layers
-                // already hold 2*TO accumulator quads), still >= 4 independent MFMAs between dependent ones
-                constexpr int MC = 4;
+                constexpr int MC = 4;                           // (as in mma_layer_slab)
 #pragma unroll
                 for (int m0 = 0; m0 < TO; m0 += MC) {
                     f4 a[MC];
@@ -428,11 +435,9 @@ __device__ __forceinline__ void mma_layer_slab(const f4* __restrict__ wglob, f4*
                 }
             }
         }
-        f4* nbuf = slab + ((sl + 1) & 1) * SLAB;
-#pragma unroll
-        for (int k = 0; k < PER; ++k)
-            if (tid + k * THREADS < next_f4) nbuf[tid + k * THREADS] = pre[k];
+        st.par ^= 1;
     }
+    st.primed = wnext != nullptr;
 }
 
 // acc[mo][nt] = bias[16*mo + 4*g .. +3] broadcast over the lane's sequence

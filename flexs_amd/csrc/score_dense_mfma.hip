@@ -19,6 +19,8 @@
 
 namespace {
 
+// SLAB: input tiles per slab (3 and 4 measured no faster once the slabs go global -> LDS directly: profiles/r6_slab_dma_ab.log)
+#define FX_SLAB_KG 2
 struct DenseArgs {
     const uint8_t* ascii;
     const uint8_t* lut;
@@ -62,6 +64,8 @@ __global__ void k_ge_bytetab(const float* __restrict__ w1, const uint8_t* __rest
     out[idx] = (l < L && c < A) ? w1[l * A + c] : 0.f;
 }
 
+// SLAB: one H x H layer of a lockstep round; WNEXT = the layer whose first slab is asked for during this one's last (nullptr: none follows)
+#define FX_SLAB_LAYER(W, WNEXT, IN, OUT) mma_layer_slab_dma<HT, HT, KG, WAVES>(W, WNEXT, slab, IN, OUT, lane, p.rlh, slab_st)
 // SLAB (with DG): the HxH blocks are streamed through LDS once per round of WAVES tiles (mma_layer_slab) instead
 // of once per tile per wave; the waves of a workgroup then walk the tiles in lockstep.
 // PF (rows in HOST memory, the PAIR / BT forms that copy a tile's bytes into LDS): a wave claims its NEXT tile before it scores the
@@ -73,7 +77,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
     static_assert(!PAIR || (KIND == FX_MLP && G1 && !W1G && !DG && NT == 1), "PAIR is the MLP gather form on a 4-letter alphabet");
     static_assert(!SLAB || (DG && NT == 1), "SLAB streams the L2-resident blocks of the one-tile form");
     static_assert(!BT || (KIND == FX_GE && NT == 1 && !DG && !SLAB), "BT is the GlobalEpistasis byte-table form");
-    constexpr int KG = 2;                                       // input tiles per slab
+    constexpr int KG = FX_SLAB_KG;                              // input tiles per slab
     // the last (tiles mod 4) tiles of a workgroup shared by wave groups instead of making one SIMD run an extra tile
     constexpr bool COOP_OK = NT == 1 && !SLAB && !DG && !W1G && WAVES == 16 && (PAIR || BT);
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -197,6 +201,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
         };
         [[maybe_unused]] int64_t pf_next = -2;              // PF: the tile claimed ahead (-2: none claimed, -1: the share is exhausted)
         [[maybe_unused]] bool pf_issued = false;            // PF: ... and its bytes are on their way into stw_alt
+        [[maybe_unused]] FxSlabStream slab_st{0, false};    // SLAB: the stream of slabs across layers and rounds (mma_layer_slab_dma)
         for (int64_t round = 0;; ++round) {
             // SLAB: lockstep rounds of WAVES tiles; waves without a tile in the last round run along on tile 0
             int64_t tg_want = t_lo + round * WAVES + (tid >> 6);
@@ -207,6 +212,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                 if (rows_arrive && (!p.relay.flags || m + p.m_off == 0)) fx_rows_wait(p.ready, (int)(tg_want % p.ready.Q), rows_known, p.err);
             }
             if (SLAB && t_lo + round * WAVES >= t_end) break;
+            [[maybe_unused]] const bool slab_more = SLAB && t_lo + (round + 1) * WAVES < t_end;   // another lockstep round follows
             const bool live = !SLAB || tg_want < t_end;
             const int64_t tg = live ? tg_want : t_lo;
             if (tiles_done == 0) fx_stamp(p.trace, 2);
@@ -365,13 +371,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                 // ---- layers 2, 3
                 f4 h2[HT][NT];
                 init_bias<HT, NT>(db + 16 * HT, h2, g);
-                if constexpr (SLAB) mma_layer_slab<HT, HT, KG, WAVES * 64>(w_d2, slab, h, h2, lane, p.rlh);
+                if constexpr (SLAB) FX_SLAB_LAYER(w_d2, w_d3, h, h2);
                 else mma_layer<HT, HT, NT>(w_d2, h, h2, lane, p.rlh);
                 relu_tiles<HT, NT>(h2);
                 FX_PHASE_STAMP(9);
                 asm volatile("" ::: "memory");
                 init_bias<HT, NT>(db + 32 * HT, h, g);
-                if constexpr (SLAB) mma_layer_slab<HT, HT, KG, WAVES * 64>(w_d3, slab, h2, h, lane, p.rlh);
+                if constexpr (SLAB) FX_SLAB_LAYER(w_d3, slab_more ? w_d2 : nullptr, h2, h);
                 else mma_layer<HT, HT, NT>(w_d3, h2, h, lane, p.rlh);
                 relu_tiles<HT, NT>(h);
                 FX_PHASE_STAMP(10);
@@ -502,7 +508,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                 FX_PHASE_STAMP(8);
                 // ---- layer 3 (HxH MFMA), layer 4 (dot)
                 init_bias<HT, NT>(db + 4 + 32 * HT, h, g);
-                if constexpr (SLAB) mma_layer_slab<HT, HT, KG, WAVES * 64>(w_d3, slab, h2, h, lane, p.rlh);
+                if constexpr (SLAB) FX_SLAB_LAYER(w_d3, slab_more ? w_d3 : nullptr, h2, h);
                 else mma_layer<HT, HT, NT>(w_d3, h2, h, lane, p.rlh);
                 relu_tiles<HT, NT>(h);
                 final_dot<HT, NT>(db + 4 + 48 * HT, db[4 + 64 * HT], h, y, g);
@@ -566,7 +572,7 @@ template <int KIND, int A, int HT, int NT, int WAVES, bool G1, bool W1G = false,
           bool PAIR = false, bool PF = false>
 int launch_inst(fx_engine* e, const DenseArgs& a_in, size_t lds_bytes) {
     auto kern = k_score_dense_mfma<KIND, A, HT, NT, WAVES, G1, W1G, DG, SLAB, BT, PAIR, PF>;
-    if (SLAB) lds_bytes += (size_t)2 * 2 * HT * 1024;           // two slabs of KG = 2 input tiles
+    if (SLAB) lds_bytes += (size_t)2 * FX_SLAB_KG * HT * 1024;  // two slabs of KG input tiles
     static bool attr_set[64] = {};
     if (!attr_set[e->device & 63]) {
         FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -686,7 +692,7 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
     if constexpr (DGc) {
         // hidden sizes 129..256: stream the HxH blocks through LDS slabs, one pass per round of 8 tiles (A/B: dense_slab = 0)
         // (not when the first-layer rows stream from L2 as well: measured 3 % slower there, profiles/archive/r1_run46)
-        const bool slab = e->dense_slab != 0 && !e->mlp_l1_mfma && !w1_global && lds + (size_t)4 * HT_ * 1024 <= (size_t)e->max_lds;
+        const bool slab = e->dense_slab != 0 && !e->mlp_l1_mfma && !w1_global && lds + (size_t)2 * FX_SLAB_KG * HT_ * 1024 <= (size_t)e->max_lds;
         if (slab) {
             a.slab_coop = e->dense_slab_coop > 0 ? (int)(e->dense_slab_coop < 7 ? e->dense_slab_coop : 7) : 0;
             if (s.kind == FX_MLP) return launch_inst<FX_MLP, 4, HT_, 1, W, true, false, true, true>(e, a, lds);
