@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 faulthandler.enable()
 
 from tools.bench_common import (AAS, ALPHABET, BATCH, F, H, K, KINDS, L, M, MFMA_FLOP, MIN_TIMED_S, PEAK_TF, _sig,  # noqa: E402,F401
-                                build_members, roofline_block, run_pipelined, time_launches)
+                                build_members, events_every, roofline_block, run_pipelined, time_launches)
 
 MAX_LINE_BYTES = 4096            # the driver's parser lost a 24.8 KB line in round 5 (parsed 14.9 KB in round 4)
 
@@ -276,6 +276,8 @@ def contract_line(full, full_path=None):
             "frac": _sig(r["frac"]), "frac_algorithmic": _sig(r["frac_algorithmic"]), "kernel_ms": _sig(r["kernel_ms"]),
             "traffic": (int(round(r["traffic"])) if r.get("traffic") else None), "algorithmic_bytes": r.get("algorithmic_bytes_per_launch"),
             "mfma_util_pmc": _sig(r.get("mfma_util_pmc")), "pmc_source": r.get("pmc_source")}
+    if r.get("kernel_ms_b2b"):
+        roof["kernel_ms_b2b"], roof["frac_b2b"] = _sig(r["kernel_ms_b2b"]), _sig(r.get("frac_b2b"))
     line["roofline"] = roof
     cb = full.get("cpu_baseline")
     if isinstance(cb, dict):
@@ -502,13 +504,13 @@ def main():
         # sequence mode: the global batch (world x N rows); rank r reads rows [r N, (r+1) N) of it
         d_seq = torch.from_numpy(synth.random_sequence_bytes(glob_n, L, ALPHABET, seed=0)).cuda()
     ens.stream.synchronize()
-    elapsed, host_issue_s, kern_ms = run_pipelined(ens, d_seq, glob_n, args.steps, args.warmup, torch, dist, use_dist)
+    elapsed, host_issue_s, kern_ms = run_pipelined(ens, d_seq, glob_n, args.steps, args.warmup, torch, dist, use_dist, events_every(args.steps))
     settled = None
     if elapsed < MIN_TIMED_S and not args.no_settled:
         # the driver's K steps are reported as asked; a K this short ends before the clocks settle, so a second,
         # longer bracket (>= 0.5 s of GPU time, same code path) is reported beside it
         s_steps = int(max(args.steps, np.ceil(1.2 * MIN_TIMED_S / (elapsed / max(args.steps, 1)))))
-        s_el, _, s_kern = run_pipelined(ens, d_seq, glob_n, s_steps, 0, torch, dist, use_dist)
+        s_el, _, s_kern = run_pipelined(ens, d_seq, glob_n, s_steps, 0, torch, dist, use_dist, events_every(s_steps))
         settled = (s_steps, s_el, s_kern)
 
     # ---- untimed completeness + correctness check of the last step
@@ -546,7 +548,7 @@ def main():
             confs = bb.configs_block(eng, local_rank, torch)
             cold = {"ms_per_step": elapsed / args.steps * 1e3, "kernel_ms": kern_ms, "value": world * N * args.steps / elapsed,
                     "what": "the same W warm-ups + K timed steps as the first GPU work of the process (device clocks still ramping)"}
-            elapsed, host_issue_s, kern_ms = run_pipelined(ens, d_seq, glob_n, args.steps, args.warmup, torch, dist, use_dist)
+            elapsed, host_issue_s, kern_ms = run_pipelined(ens, d_seq, glob_n, args.steps, args.warmup, torch, dist, use_dist, events_every(args.steps))
         out = make_report(world, N, args.steps, args.warmup, elapsed, host_issue_s, kern_ms, use_dist, args.mode,
                           head_members)
         if world == 1 and not args.no_live_pmc and not args.no_extras:
@@ -556,6 +558,19 @@ def main():
                 out["roofline"].update(traffic=pmc["hbm_bytes_per_launch"], mfma_util_pmc=pmc["mfma_util"], pmc_source=pmc["source"])
             else:
                 out["roofline"]["pmc_source"] = f"replayed (live passes failed): {out['roofline'].get('pmc_source')}"
+        out["roofline"]["kernel_ms_events"] = (f"HIP event pairs on the launch stream around every {events_every(args.steps)}th K1 launch of the K timed steps "
+                                               "(a pair around every launch cost the loop 7.8 us per step: profiles/r6_bench_loop_events.log)")
+        if world == 1 and args.mode == "sequence":
+            # the same launch back to back: ONE event pair around >= 40 ms of launches issued from C (no event latency inside the
+            # bracket) -- the figure rocprofv3's per-dispatch mean agrees with
+            try:
+                stride = (N + 63) // 64 * 64
+                b2b_planes = torch.zeros((head_members, stride), dtype=torch.float32, device="cuda")
+                b2b_ms, _ = time_launches(eng, members, d_seq.data_ptr(), N, L, members[0]._lut, b2b_planes, stride, min_ms=40.0)
+                out["roofline"]["kernel_ms_b2b"] = b2b_ms
+                out["roofline"]["frac_b2b"] = out["roofline"]["frac"] * out["roofline"]["kernel_ms"] / b2b_ms
+            except Exception as ex:  # noqa: BLE001
+                out.setdefault("block_errors", {})["kernel_ms_b2b"] = f"{type(ex).__name__}: {ex}"[:300]
         if cold:
             cold["frac_issued"] = out["roofline"]["frac_issued"] * out["roofline"]["kernel_ms"] / cold["kernel_ms"]
             out["cold_start"] = cold

@@ -547,6 +547,14 @@ class Engine:
     def ensemble_mean_planes_dev(self, d_planes: int, N: int, M: int, stride: int, d_out32: int):
         self.check(self._lib.fx_ensemble_mean_planes_dev(self.handle, _vp(d_planes), N, M, stride, _vp(d_out32)))
 
+    def score_mean_planes_dev(self, models: Sequence["NativeModel"], d_ascii: int, N: int, L: int, lut: np.ndarray,
+                              d_planes: int, stride: int, d_out32: int):
+        """score_planes_dev + ensemble_mean_planes_dev as one call: the scoring kernel takes the mean itself where it can."""
+        M = len(models)
+        arr = (_vp * M)(*[m.handle for m in models])
+        self.check(self._lib.fx_score_mean_planes_dev(self.handle, arr, M, _vp(d_ascii), N, L, _lut_ptr(lut),
+                                                      _vp(d_planes), stride, _vp(d_out32)))
+
     def encode_onehot(self, seq_bytes: np.ndarray, lut: np.ndarray, A: int) -> np.ndarray:
         N, L = seq_bytes.shape
         out = np.empty((N, L, A), np.float32)

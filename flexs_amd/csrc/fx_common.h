@@ -279,7 +279,8 @@ struct fx_engine {
     int64_t planar_stride = 0;
     // fused ensemble mean: set by the host / device entry points around score_dispatch when only the mean is wanted; a launcher
     // that averages in-kernel (small launches of the canonical CNN: score_cnn_quad.hip) sets fused_mean_done
-    float* fuse_mean_out = nullptr;
+    float* fuse_mean_out = nullptr;     // (explorer-size form: option fuse_mean)
+    float* fuse_mean_batch_out = nullptr;   // (batch form: option fuse_mean_batch)
     bool fused_mean_done = false;
     // resident small-call form (score_cnn_quad.hip / score_dense_small.hip, SERVER): one workgroup per (member, tile slot) stays
     // on the device between explorer-size calls and answers them through the mailboxes above
@@ -329,6 +330,8 @@ struct fx_engine {
     int64_t serve_fence = 0;    // 1 = a system fence after every tile's answers (round 3: ~0.5 us each, and the fences of one XCD serialise -- 24 us for the 378 tiles of a 2001-sequence request, profiles/r4_mailbox_probe3.log); 0 = none: the answers are system-scope stores, which write through by themselves (profiles/r4_mailbox_probe4.log)
     int64_t serve_poll_sleep = 8;     // s_sleep units (64 clocks each) between polls of the slots beyond FX_SERVE_FAST (0 = every slot spins)
     int64_t serve_small = 1;    // 1 = explorer-size calls of canonical CNN ensembles are answered by resident workgroups (0 = a launch per call: A/B)
+    int64_t fuse_mean_batch = 0; // A/B build: 1 = batch launches of the 4-letter CNN (rows resident in device memory, mean-only calls) let the LAST member to finish a tile average it in the
+                                // scoring kernel (written-through scores, one relaxed device-scope ticket per tile, no fences) instead of launching the mean kernel.  Bit-identical, SLOWER: 183.5 -> 185.1 us per headline step (profiles/r6_fused_mean_ab.log)
     int64_t fuse_mean = 0;      // 1 = explorer-size CNN ensemble calls average in the scoring kernel (last member to finish a tile, tickets + device-scope fences) instead of launching the mean kernel.  Bit-identical, but the two fences cost what the 3 us launch saves: 32.1 vs 32.2 us per call (profiles/r3_fused_mean_ab.log): off, kept as the A/B
     // launched-first host call (fx_score_begin_staged): what the launchers that can wait for rows copy into their arguments, and
     // whether the launch just enqueued did (a launcher that cannot returns FX_EUNSUPPORTED before it enqueues anything)

@@ -321,6 +321,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "cnn_quad_tail")) return &e->cnn_quad_tail;
     if (!std::strcmp(key, "dense_pipe")) return &e->dense_pipe;
     if (!std::strcmp(key, "fuse_mean")) return &e->fuse_mean;
+    if (!std::strcmp(key, "fuse_mean_batch")) return &e->fuse_mean_batch;
     if (!std::strcmp(key, "dense_coop")) return &e->dense_coop;
     if (!std::strcmp(key, "quad_rotate")) return &e->quad_rotate;
     if (!std::strcmp(key, "serve_small")) return &e->serve_small;
@@ -364,7 +365,7 @@ static bool ab_only_value(const fx_engine* e, const int64_t* s, int64_t value) {
     (void)e; (void)s; (void)value;
     return false;
 #else
-    if (s == &e->dense_pipe || s == &e->fuse_mean || s == &e->chunk_overlap || s == &e->cnn_conv1_mfma || s == &e->mlp_l1_mfma ||
+    if (s == &e->dense_pipe || s == &e->fuse_mean || s == &e->fuse_mean_batch || s == &e->chunk_overlap || s == &e->cnn_conv1_mfma || s == &e->mlp_l1_mfma ||
         s == &e->dense_few_waves_below || s == &e->train_split)
         return value != 0;
     if (s == &e->dense_waves) return value == 8;

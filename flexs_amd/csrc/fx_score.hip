@@ -81,9 +81,11 @@ int score_dispatch(fx_engine* e, fx_model* const* models, int M, const uint8_t* 
 static int score_then_mean(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N, int L,
                            float* d_planes, int64_t stride, float* mean_dst) {
     e->fuse_mean_out = (e->fuse_mean && stride && M > 1 && M <= 16) ? mean_dst : nullptr;
+    e->fuse_mean_batch_out = (e->fuse_mean_batch && stride && M > 1 && M <= 16) ? mean_dst : nullptr;
     e->fused_mean_done = false;
     const int rc = score_dispatch(e, models, M, d_ascii, N, L, d_planes, stride);
     e->fuse_mean_out = nullptr;
+    e->fuse_mean_batch_out = nullptr;
     if (rc) return rc;
     if (e->fused_mean_done) return FX_OK;
     return fx_launch_ensemble_mean_planar(e, d_planes, N, M, stride, mean_dst);
@@ -152,6 +154,22 @@ int fx_ensemble_mean_planes_dev(fx_engine* e, const float* d_planes, int64_t N, 
     FX_HIP(e, hipSetDevice(e->device));
     lp_disarm(e);                                          // (a pre-launched scoring instance holds most CUs until its idle limit: this call's kernels are queued behind it)
     return fx_launch_ensemble_mean_planar(e, d_planes, N, M, stride, d_out_mean);
+}
+
+// ... and both halves as one call: the scoring kernel takes the mean itself where a launcher offers it (round 6: the batch form of the
+// 4-letter CNN), otherwise the mean kernel follows.  The planes hold the members' scores afterwards either way.
+int fx_score_mean_planes_dev(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N, int L,
+                             const uint8_t lut[256], float* d_planes, int64_t stride, float* d_out_mean) {
+    int rc = validate_models(e, models, M, L, lut);
+    if (rc) return rc;
+    if (M > 16) return fx_fail(e, FX_EINVAL, "fx_score_mean_planes_dev: at most 16 members");
+    if (N < 0 || stride < N || (stride & 3)) return fx_fail(e, FX_EINVAL, "fx_score_mean_planes_dev: stride must be >= N and a multiple of 4");
+    if (N == 0) return FX_OK;
+    if (!d_ascii || !d_planes || !d_out_mean || (reinterpret_cast<uintptr_t>(d_planes) & 15)) return fx_fail(e, FX_EINVAL, "null or unaligned buffer");
+    FX_HIP(e, hipSetDevice(e->device));
+    if ((rc = fx_upload_lut(e, lut))) return rc;
+    e->counters.device_calls += 1; e->counters.sequences += N; e->counters.forwards += N * M;
+    return score_then_mean(e, models, M, d_ascii, N, L, d_planes, stride, d_out_mean);
 }
 
 int fx_staging_input(fx_engine* e, int64_t bytes, void** host) {

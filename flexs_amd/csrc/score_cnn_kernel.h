@@ -19,6 +19,7 @@
 #include "fx_common.h"
 #include "mfma_common.h"
 #include "score_cnn_quad_round.h"
+#include "np_sum.h"
 
 namespace {
 
@@ -50,7 +51,49 @@ struct CnnArgs {
     int stw_stride;             // STG: bytes of LDS scratch per wave (16 L rounded up to 16)
     int stw_ahead;              // STG: 1 = two scratches per wave, the next tile's bytes are asked for a tile ahead (fx_stage_tile_dma)
     FxRowsReady ready;          // launched-first host call: the rows arrive while the kernel runs (words == nullptr: they are all there)
+#if defined(FX_AB)
+    // fused ensemble mean (A/B build; fm_mean == nullptr: off): `out` is M member-major planes `out_sm` floats apart, all members in this launch
+    float* fm_mean;             // np.mean over the members, N floats
+    unsigned* fm_cnt;           // one ticket counter per tile, all zeros between launches (fx_zero_pool)
+#endif
 };
+
+#if defined(FX_AB)
+// Fused ensemble mean (ensemble.py:54-59 with the default np.mean; replaces the k_ensemble_mean_planar launch behind a batch launch).
+// MEASURED AND LOST (round 6, profiles/r6_fused_mean_ab.log: the headline step 183.5 -> 185.1 us; a wave waits ~2 us per tile for its
+// written-through scores and its ticket, which costs the launch more than the 3.6 us mean kernel behind it): A/B build only.
+// The wave that finishes member m of a tile writes its 16 scores THROUGH to memory (sc1 stores), waits for them, and takes a ticket
+// from the tile's counter (relaxed, device scope); the wave that draws the LAST ticket reads the other members' scores with device-scope
+// loads -- written through and waited for before their tickets were drawn -- and stores the NumPy-order mean (np_sum_row's order for fewer than eight
+// members, fx_np_div: the mean kernel's arithmetic, so the same bits), then puts the counter back to zero for the next launch.  No fences: a release /
+// acquire pair at device scope writes back and invalidates the XCD's whole L2 (round 1, run 42: 0.195 -> 0.499 ms per step).
+__device__ __forceinline__ void fx_fused_mean_tile(float* planes, int64_t stride, int M, int m, int64_t tile, int64_t n, int64_t N,
+                                                   float y, bool holder, float* mean, unsigned* cnt, int lane) {
+    unsigned* pl = reinterpret_cast<unsigned*>(planes);
+    if (holder && n < N) __hip_atomic_store(&pl[(int64_t)m * stride + n], __float_as_uint(y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the wave's scores are in memory before its ticket is drawn
+    unsigned ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(&cnt[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket != (unsigned)M - 1u) return;
+    if (lane == 0) __hip_atomic_store(&cnt[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (holder && n < N) {
+        // M < 8: NumPy sums a row of fewer than eight floats front to back from 0 (np_sum_row; seven values in flight, no array)
+        float x[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+            x[k] = k < M ? (k == m ? y : __uint_as_float(__hip_atomic_load(&pl[(int64_t)k * stride + n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) : 0.f;
+        float r = 0.f;
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+            if (k < M) r += x[k];
+        mean[n] = fx_np_div(r, (float)M);
+    }
+}
+#define FX_FM_ON(p) ((p).fm_mean != nullptr)
+#else
+#define FX_FM_ON(p) false
+#endif
 
 // L1S > 0: number of conv positions known at compile time (L1S = seq_len - K + 1): the position loop is fully
 // unrolled, so the sliding windows become register renames instead of v_mov chains and the padding tests fold.
@@ -533,6 +576,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
             relu_tiles<HT, NT>(h2);
             float y[NT];
             final_dot<HT, NT>(db + 32 * HT, db[48 * HT], h2, y, g);
+#if defined(FX_AB)
+            if (NT == 1 && !SEG && FX_FM_ON(p)) fx_fused_mean_tile(p.out, p.out_sm, p.M, m, tg, n[0], p.N, fx_nan_to_num(y[0]), g == 0, p.fm_mean, p.fm_cnt, lane);
+            else
+#endif
             if (g == 0) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
@@ -552,6 +599,11 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                 const uint8_t* qrow = p.ascii + (qn < p.N ? qn : 0) * L;
                 float yq = 0.f;
                 fx_cnn_quad_round<FT, HT, K, L1S, QXT>(qlive, q, lane, qrow, lut_s, w1p, cb, w_c2, w_c3, w_d1, w_d2, db, p.rlh, xq, xq + QXT * 64, bad, yq);
+#if defined(FX_AB)
+                if (FX_FM_ON(p)) {
+                    if (qlive && q == 0) fx_fused_mean_tile(p.out, p.out_sm, p.M, m, qtg, qn, p.N, fx_nan_to_num(yq), g == 0, p.fm_mean, p.fm_cnt, lane);
+                } else
+#endif
                 if (qlive && q == 0 && g == 0 && qn < p.N) p.out[qn * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(yq);
             }
         }
@@ -602,6 +654,9 @@ int launch_g(fx_engine* e, const CnnArgs& a_in, size_t lds_bytes) {
         attr_set[e->device & 63] = true;
     }
     CnnArgs a = a_in;
+#if defined(FX_AB)
+    if (SEG || !HEAD || NT != 1) a.fm_mean = nullptr;            // (forms that share a tile among waves / leave the head to another kernel: the mean kernel follows)
+#endif
     a.stw_stride = STG ? (int)((16 * (size_t)a.L + 15) / 16 * 16) : 0;
     a.stw_ahead = ahead ? 1 : 0;
     if (e->rows_req.on) {
@@ -620,6 +675,9 @@ int launch_g(fx_engine* e, const CnnArgs& a_in, size_t lds_bytes) {
     if (SEG && HEAD && a.seg_sb > 1) blocks = U * a.seg_sb;       // multi-workgroup segment form: exactly units x seg_sb
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(waves * 64), lds_bytes, e->stream, a);
     FX_HIP(e, hipGetLastError());
+#if defined(FX_AB)
+    if (a.fm_mean) e->fused_mean_done = true;
+#endif
     return FX_OK;
 }
 

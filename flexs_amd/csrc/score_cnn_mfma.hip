@@ -154,6 +154,17 @@ int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const
     a.off_cb = (int)lay.off_cb; a.off_w1p = (int)lay.off_w1p; a.conv_floats = (int)lay.conv_floats; a.off_d1 = (int)lay.off_d1;
     a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
 
+#if defined(FX_AB)
+    // mean-only call with the rows resident in device memory and every member in this launch: the last member to finish a tile averages
+    // it (fx_fused_mean_tile) -- no mean kernel behind the launch.  (Rows that arrive while the kernel runs keep the mean kernel: a
+    // starved launch is redone, and its tickets would be left half drawn.)
+    if (e->fuse_mean_batch_out && e->planar_stride && m_off == 0 && M == Mtot && M > 1 && M < 8 && !e->rows_req.on) {
+        void* ws = nullptr;
+        if (int rc = fx_zero_pool(e, (size_t)((N + 15) / 16) * sizeof(unsigned), &ws)) return rc;
+        a.fm_mean = e->fuse_mean_batch_out;
+        a.fm_cnt = (unsigned*)ws;
+    }
+#endif
     const size_t full = (size_t)lay.total_floats * 4 + 256 + 48, conv_only = (size_t)lay.conv_floats * 4 + 256 + 48;
     if (s.A == 2) {
         // binary alphabet (`BA = "01"`, sequence_utils.py:16): conv3 has ONE tap (kernel_size = len(alphabet) - 1);

@@ -328,12 +328,20 @@ class DistributedEnsemble(flexs_amd.Model):
                     natives = [self.models[i].native() for i in mine]
                     if timing:
                         timing[0].record(st)
-                    self._engine().score_planes_dev(natives, seq.data_ptr() + row0 * m0.model.L, hi - lo, m0.model.L,
-                                                    m0._lut, s.planes.data_ptr(), stride)
-                    if timing:
-                        timing[1].record(st)
-                    if local_reduce:
-                        self._reduce_planes(s.planes, hi - lo, M, stride, s.local)
+                    if local_reduce and M <= 16:
+                        # scores + their NumPy-order mean in one call: the scoring kernel averages a tile itself where it can
+                        # (the last member to finish it), otherwise the mean kernel follows inside the call
+                        self._engine().score_mean_planes_dev(natives, seq.data_ptr() + row0 * m0.model.L, hi - lo, m0.model.L,
+                                                             m0._lut, s.planes.data_ptr(), stride, s.local.data_ptr())
+                        if timing:
+                            timing[1].record(st)
+                    else:
+                        self._engine().score_planes_dev(natives, seq.data_ptr() + row0 * m0.model.L, hi - lo, m0.model.L,
+                                                        m0._lut, s.planes.data_ptr(), stride)
+                        if timing:
+                            timing[1].record(st)
+                        if local_reduce:
+                            self._reduce_planes(s.planes, hi - lo, M, stride, s.local)
                 if s.exchange:
                     # the error word travels WITH the scores: a character outside the alphabet fails the call on every rank
                     # (sequence_utils.py:46 raises for the whole batch) without a second collective or a host sync

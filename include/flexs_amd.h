@@ -306,6 +306,12 @@ int fx_score_planes_dev(fx_engine *e, fx_model *const *models, int M, const uint
                         int L, const uint8_t lut[256], float *d_planes, int64_t stride);
 int fx_ensemble_mean_planes_dev(fx_engine *e, const float *d_planes, int64_t N, int M, int64_t stride,
                                 float *d_out_mean);
+/* Both halves as ONE call (ensemble.py:54-59 with the default np.mean): the planes hold the members' scores and
+ * `d_out_mean` their NumPy-order mean afterwards.  Where the scoring kernel can take the mean itself -- the batch
+ * form of the 4-letter CNN: the last member to finish a 16-sequence tile averages it -- no second kernel is
+ * launched (engine option "fuse_mean_batch", default 1); same bits either way.  M <= 16. */
+int fx_score_mean_planes_dev(fx_engine *e, fx_model *const *models, int M, const uint8_t *d_ascii, int64_t N,
+                             int L, const uint8_t lut[256], float *d_planes, int64_t stride, float *d_out_mean);
 
 
 /* string_to_one_hot over a batch (sequence_utils.py:32-47 + keras_model.py:70-75):

@@ -699,3 +699,53 @@ def test_quad_tail_of_the_persistent_cnn_kernel_gives_the_same_bits(eng, M, n):
         assert np.array_equal(again, outs[1])
     finally:
         eng.set_option("cnn_quad_tail", 1)
+
+
+@pytest.mark.parametrize("L,M,n", [(8, 3, 100_000), (8, 3, 99_985), (8, 2, 70_016), (8, 7, 40_000), (8, 8, 30_000), (14, 3, 60_001), (10, 3, 50_000),
+                                   (8, 3, 5_000), (8, 5, 131_072)])
+def test_batch_launch_takes_the_ensemble_mean_itself(eng, L, M, n):
+    """Round 6: fx_score_mean_planes_dev (what DistributedEnsemble and bench.py issue for a mean-only step on rows resident in device
+    memory) = scores as member-major planes + np.mean(axis=1) of them bit for bit.  A/B build: the wave that finishes the LAST member
+    of a tile averages it in the scoring kernel (`fuse_mean_batch`, fx_fused_mean_tile: written-through scores, one relaxed device-scope
+    ticket per tile, no fences; fewer than eight members) -- same bits as the mean kernel, launch after launch (the tickets go back to
+    zero); measured slower and not in the production library (profiles/r6_fused_mean_ab.log)."""
+    import torch
+
+    alpha = "TGCA"
+    natives, _ = zip(*[make_native(eng, "cnn", L, 4, 100, 32, 5, seed=500 + m) for m in range(M)])
+    lut = _native.make_lut(alpha)
+    b, _ = rand_seqs(n, L, alpha, seed=n % 97 + M)
+    nm, _ = eng.score(list(natives), b, lut, want_matrix=True)
+    want = np.mean(nm, axis=1)
+    d_in = torch.from_numpy(b).cuda()
+    stride = (n + 63) // 64 * 64
+    try:
+        for fuse in (1, 0, 1):
+            if not ab_option(eng, "fuse_mean_batch", fuse):
+                continue                                             # (the production library has the mean kernel only)
+            for rep in range(3 if fuse else 1):
+                planes = torch.full((M, stride), float("nan"), device="cuda")
+                d_mean = torch.full((n,), float("nan"), device="cuda")
+                torch.cuda.synchronize()
+                eng.score_mean_planes_dev(list(natives), d_in.data_ptr(), n, L, lut, planes.data_ptr(), stride, d_mean.data_ptr())
+                eng.sync()
+                assert np.array_equal(planes[:, :n].t().cpu().numpy().view(np.uint32), nm.view(np.uint32)), (fuse, rep)
+                assert np.array_equal(d_mean.cpu().numpy().view(np.uint32), want.view(np.uint32)), (fuse, rep)
+            d_mean = torch.full((n,), float("nan"), device="cuda")
+            eng.score_dev(list(natives), d_in.data_ptr(), n, L, lut, None, d_mean.data_ptr())     # the engine's own planes
+            eng.sync()
+            assert np.array_equal(d_mean.cpu().numpy().view(np.uint32), want.view(np.uint32)), fuse
+            _, host_mean = eng.score(list(natives), b, lut, want_matrix=False, want_mean=True)     # host call, mean only
+            assert np.array_equal(host_mean.view(np.uint32), want.view(np.uint32)), fuse
+        # a character outside the alphabet is still reported, and the launch after it is clean
+        bad = b.copy(); bad[n // 3, L - 1] = ord("!")
+        d_bad = torch.from_numpy(bad).cuda()
+        eng.score_mean_planes_dev(list(natives), d_bad.data_ptr(), n, L, lut, planes.data_ptr(), stride, d_mean.data_ptr())
+        with pytest.raises(ValueError):
+            eng.sync()
+        d_mean.fill_(float("nan"))
+        eng.score_mean_planes_dev(list(natives), d_in.data_ptr(), n, L, lut, planes.data_ptr(), stride, d_mean.data_ptr())
+        eng.sync()
+        assert np.array_equal(d_mean.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    finally:
+        ab_option(eng, "fuse_mean_batch", 0)

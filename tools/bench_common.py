@@ -66,6 +66,14 @@ def build_members(kind, Lx, alphabet, members, device, Hx=H, Fx=F, Kx=K):
     return out
 
 
+def events_every(steps):
+    """Which launches of a timed loop get a HIP event pair: every 4th for short loops, 16 samples for long ones.  A pair around EVERY
+    launch cost the loop 7.8 us per step (192.7 vs 184.9 us, profiles/r6_bench_loop_events.log) -- the instrument was 4 % of the
+    measurement -- and a pair around every 4th 1.6 us; the bracketed launches still read ~5 us long (event latency), which is why the
+    report carries a back-to-back figure (one pair around many launches) beside them."""
+    return max(4, steps // 16)
+
+
 def run_pipelined(ens, d_seq, n, steps, warmup, torch, dist, use_dist, want_events=True):
     """W untimed + K timed steps of ens.launch / ens.finish, double-buffered: the gather of step k (communication
     stream) overlaps the scoring of step k + 1; barrier + synchronize on both sides of the timed region.
@@ -85,8 +93,10 @@ def run_pipelined(ens, d_seq, n, steps, warmup, torch, dist, use_dist, want_even
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] \
-        if want_events else None
+    # want_events: True / 1 = an event pair around every launch, k > 1 = around every k-th (events_every), 0 = none
+    every = int(want_events) if want_events else 0
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if i % every == 0 else None
+              for i in range(steps)] if every else None
     t0 = time.perf_counter()
     go(steps, events)
     host_issue = time.perf_counter() - t0                # host time to ENQUEUE the K steps (GPU still running)
@@ -101,7 +111,7 @@ def run_pipelined(ens, d_seq, n, steps, warmup, torch, dist, use_dist, want_even
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)         # MAX over ranks
         elapsed = float(t.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else None
+    kern_ms = float(np.mean([ev[0].elapsed_time(ev[1]) for ev in events if ev])) if events else None
     return elapsed, host_issue, kern_ms
 
 
