@@ -74,7 +74,7 @@ __global__ void k_ge_bytetab(const float* __restrict__ w1, const uint8_t* __rest
 template <int KIND, int A, int HT, int NT, int WAVES, bool G1, bool W1G, bool DG, bool SLAB = false, bool BT = false, bool PAIR = false, bool PF = false>
 __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
     static_assert(!PF || ((PAIR || BT) && NT == 1 && !SLAB), "PF is a form of the staged-tile first layers");
-    static_assert(!PAIR || (KIND == FX_MLP && G1 && !W1G && !DG && NT == 1), "PAIR is the MLP gather form on a 4-letter alphabet");
+    static_assert(!PAIR || (KIND == FX_MLP && G1 && !W1G && (!DG || SLAB) && NT == 1), "PAIR is the MLP gather form on a 4-letter alphabet (H x H blocks in LDS, or streamed through slabs)");
     static_assert(!SLAB || (DG && NT == 1), "SLAB streams the L2-resident blocks of the one-tile form");
     static_assert(!BT || (KIND == FX_GE && NT == 1 && !DG && !SLAB), "BT is the GlobalEpistasis byte-table form");
     constexpr int KG = FX_SLAB_KG;                              // input tiles per slab
@@ -530,8 +530,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                     const int64_t nn = tg * 16 + sq;
                     const uint8_t* crow = p.ascii + (nn < p.N ? nn : 0) * L;
                     float yc = 0.f;
-                    fx_dense_tile8<KIND, HT, false>(true, wv, lane, crow, L, p.A, p.rlh, 0, w_first, w1p, nullptr, w_d2, w_d3, db, lut_s, hx,
-                                                    nullptr, bad, yc);
+                    fx_dense_tile8<KIND, HT, false>(true, wv, lane, crow, L, p.A, p.rlh, PAIR ? 1 : 0, w_first, w1p, PAIR ? wpair : nullptr, w_d2, w_d3, db,
+                                                    lut_s, hx, nullptr, bad, yc);
                     if (wv == 0 && g == 0 && nn < p.N) p.out[nn * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(yc);
                     if (i + 1 < nslab) __syncthreads();              // the next tile reuses the exchange buffers
                 }
@@ -695,6 +695,15 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
         const bool slab = e->dense_slab != 0 && !e->mlp_l1_mfma && !w1_global && lds + (size_t)2 * FX_SLAB_KG * HT_ * 1024 <= (size_t)e->max_lds;
         if (slab) {
             a.slab_coop = e->dense_slab_coop > 0 ? (int)(e->dense_slab_coop < 7 ? e->dense_slab_coop : 7) : 0;
+            if (s.kind == FX_MLP && fx_mlp_first_layer_form(e, s, lay) == 1) {
+                // 4-letter alphabet, the pair rows fit beside the slabs (seq_len <= 15 at H = 200): a round's first layer is an LDS-bandwidth
+                // gather (8 waves x seq_len rows x HT KiB), and one pre-summed row per PAIR of positions halves it
+                a.lds_from = (int)tail;
+                a.lds_floats = 0;
+                a.off_w1pair = (int)lay.off_w1pair;
+                a.pair_floats = (int)lay.pair_floats;
+                return launch_inst<FX_MLP, 4, HT_, 1, W, true, false, true, true, false, true>(e, a, (size_t)lay.pair_floats * 4 + 256 + 32);
+            }
             if (s.kind == FX_MLP) return launch_inst<FX_MLP, 4, HT_, 1, W, true, false, true, true>(e, a, lds);
             return launch_inst<FX_GE, 4, HT_, 1, W, false, false, true, true>(e, a, lds);
         }
@@ -756,7 +765,14 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
 // 0 = one kernel row per position, 1 = one pre-summed row per PAIR of positions (the PAIR form), 2 = MFMA form (A/B option).
 int fx_mlp_first_layer_form(fx_engine* e, const FxShape& s, const FxPackLayout& lay) {
     if (e->mlp_l1_mfma) return 2;
-    if (lay.HT > 8 || !e->mlp_pair || lay.off_w1pair < 0) return 0;
+    if (!e->mlp_pair || lay.off_w1pair < 0) return 0;
+    if (lay.HT > 8) {
+        // H > 128 (round 6): the slab form with the pair rows in LDS -- nothing else of the image is (the vectors are read from L2) -- beside
+        // its two slabs; mlp_pair = 2 keeps the plain rows there (A/B)
+        if (!e->dense_slab || e->mlp_pair == 2) return 0;
+        const size_t need_slab = (size_t)lay.pair_floats * 4 + 256 + 32 + (size_t)2 * FX_SLAB_KG * lay.HT * 1024;
+        return need_slab <= (size_t)e->max_lds ? 1 : 0;
+    }
     const size_t need = (size_t)(lay.total_floats - lay.off_d2 + lay.pair_floats) * 4 + 256 + 32;
     return need <= (size_t)e->max_lds ? 1 : 0;
 }
