@@ -67,10 +67,9 @@ class FxError(RuntimeError):
 
 
 def _raise(code: int, eng_handle=None):
-    msg = lib().fx_last_error(eng_handle).decode() if eng_handle is not None else lib().fx_last_error(None).decode()
-    # Python-side exception types follow the reference: unknown character ->
-    # ValueError (str.index, sequence_utils.py:46); shape problems -> ValueError
-    # (Keras raises ValueError on incompatible input shapes).
+    msg = lib().fx_last_error(eng_handle).decode()
+    # exception types follow the reference: unknown character -> ValueError (str.index, sequence_utils.py:46); shape problems ->
+    # ValueError (Keras raises ValueError on incompatible input shapes)
     if code in (FX_EBADCHAR, FX_ESHAPE):
         raise ValueError(msg or status_name(code))
     raise FxError(code, msg)
@@ -547,13 +546,10 @@ class Engine:
     def ensemble_mean_planes_dev(self, d_planes: int, N: int, M: int, stride: int, d_out32: int):
         self.check(self._lib.fx_ensemble_mean_planes_dev(self.handle, _vp(d_planes), N, M, stride, _vp(d_out32)))
 
-    def score_mean_planes_dev(self, models: Sequence["NativeModel"], d_ascii: int, N: int, L: int, lut: np.ndarray,
-                              d_planes: int, stride: int, d_out32: int):
-        """score_planes_dev + ensemble_mean_planes_dev as one call: the scoring kernel takes the mean itself where it can."""
-        M = len(models)
-        arr = (_vp * M)(*[m.handle for m in models])
-        self.check(self._lib.fx_score_mean_planes_dev(self.handle, arr, M, _vp(d_ascii), N, L, _lut_ptr(lut),
-                                                      _vp(d_planes), stride, _vp(d_out32)))
+    def score_mean_planes_dev(self, models, d_ascii: int, N: int, L: int, lut: np.ndarray, d_planes: int, stride: int, d_out32: int):
+        """score_planes_dev + ensemble_mean_planes_dev as one call."""
+        arr = (_vp * len(models))(*[m.handle for m in models])
+        self.check(self._lib.fx_score_mean_planes_dev(self.handle, arr, len(models), _vp(d_ascii), N, L, _lut_ptr(lut), _vp(d_planes), stride, _vp(d_out32)))
 
     def encode_onehot(self, seq_bytes: np.ndarray, lut: np.ndarray, A: int) -> np.ndarray:
         N, L = seq_bytes.shape

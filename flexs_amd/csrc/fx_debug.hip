@@ -1,4 +1,4 @@
-// C ABI of libflexs_amd.so, part 5 of 5 (fx_internal.h): test and profiling hooks (fx_debug_*).
+// C ABI of libflexs_amd.so, part 6 of 6 (fx_internal.h): test and profiling hooks (fx_debug_*).
 #include <algorithm>
 #include <cstdio>
 #include <cstring>

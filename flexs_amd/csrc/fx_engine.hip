@@ -1,4 +1,4 @@
-// C ABI of libflexs_amd.so, part 1 of 5 (fx_internal.h): library, engine, options, device / pinned buffers, timers, models.
+// C ABI of libflexs_amd.so, part 1 of 6 (fx_internal.h): library, engine, options, device / pinned buffers, timers, models.
 // include/flexs_amd.h has the contract and the reference file:line each entry point replaces.
 #include <algorithm>
 #include <cstdio>

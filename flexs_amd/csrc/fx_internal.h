@@ -1,6 +1,7 @@
 // Internal to libflexs_amd.so: what the translation units of the C ABI share (round 5: fx_api.hip, 2 200 lines, became
 //   fx_engine.hip    library, engine, options, buffers, timers, models
-//   fx_score.hip     scoring entry points (fx_score*, encode / reduce / decode) and the launch planner
+//   fx_score.hip     scoring entry points (fx_score*) and the launch planner
+//   fx_codec.hip     one-hot encode, ensemble reduction, argmax decode (+ score)   [round 6]
 //   fx_resident.hip  resident small-call server, pre-launched layer-parallel instance, streamed calls, completion waits
 //   fx_nam.hip       NoisyAbstractModel: distances, device cache, table landscapes, blend
 //   fx_debug.hip     test / profiling hooks

@@ -1,4 +1,4 @@
-// C ABI of libflexs_amd.so, part 4 of 5 (fx_internal.h): NoisyAbstractModel -- neighbour search, device-resident cache,
+// C ABI of libflexs_amd.so, part 5 of 6 (fx_internal.h): NoisyAbstractModel -- neighbour search, device-resident cache,
 // distances / densities, table landscapes, the blend.
 #include <algorithm>
 #include <cstdio>

@@ -1,4 +1,4 @@
-// C ABI of libflexs_amd.so, part 3 of 5 (fx_internal.h): the resident small-call server (host side of the mailboxes), the
+// C ABI of libflexs_amd.so, part 4 of 6 (fx_internal.h): the resident small-call server (host side of the mailboxes), the
 // pre-launched instance of the layer-parallel protein form, streamed calls, and the ways a call waits for its results.
 #include <algorithm>
 #include <cstdio>
