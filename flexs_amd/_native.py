@@ -300,12 +300,10 @@ class _ResultPool:
 
 def _raise_pack_status(status: int):
     """What the reference raises for a batch `_strpack` could not pack (string_to_one_hot's np.array / str.index failures)."""
-    if status == 1:
-        raise ValueError("ragged sequence batch: all sequences must have the same length")
-    if status == 2:
-        raise ValueError("substring not found")
-    if status == 3:
-        raise TypeError("sequences must be str")
+    errors = {1: ValueError("ragged sequence batch: all sequences must have the same length"), 2: ValueError("substring not found"),
+              3: TypeError("sequences must be str")}
+    if status in errors:
+        raise errors[status]
 
 
 def wants_chunked(sequences, L: int) -> bool:
@@ -881,8 +879,7 @@ def train_fit(engine: Engine, jobs: List[dict], seq_bytes: np.ndarray, lut: np.n
         s.step, s.order, s.epochs, s.batch = int(j["step"]), order.ctypes.data, j["epochs"], j["batch"]
         s.keep, s.seed, s.step_loss = (keep.ctypes.data if keep is not None else None), int(j.get("seed", 0)), loss.ctypes.data
         keepalive.append((order, keep, loss))
-    engine.check(engine._lib.fx_train_fit(engine.handle, C.byref(arr), len(jobs), _ptr(seq_bytes), n, L, _lut_ptr(lut),
-                                          _ptr(labels)))
+    engine.check(engine._lib.fx_train_fit(engine.handle, C.byref(arr), len(jobs), _ptr(seq_bytes), n, L, _lut_ptr(lut), _ptr(labels)))
     return [(int(s.step), k[2]) for s, k in zip(arr, keepalive)]
 
 
@@ -895,9 +892,8 @@ def debug_train_step_host(kind: int, L: int, A: int, F: int, H: int, K: int, wei
     labels = np.ascontiguousarray(labels, np.float32)
     st, loss = C.c_int64(step), C.c_float(0.0)
     keep = None if keep is None else np.ascontiguousarray(keep, np.uint8)
-    rc = lib().fx_debug_train_step_host(kind, L, A, F, H, K, weights.ctypes.data, adam_m.ctypes.data, adam_v.ctypes.data,
-                                        C.addressof(st), _ptr(seq_bytes), seq_bytes.shape[0], _lut_ptr(lut), _ptr(labels),
-                                        _ptr(keep), R, C.addressof(loss))
+    rc = lib().fx_debug_train_step_host(kind, L, A, F, H, K, weights.ctypes.data, adam_m.ctypes.data, adam_v.ctypes.data, C.addressof(st),
+                                        _ptr(seq_bytes), seq_bytes.shape[0], _lut_ptr(lut), _ptr(labels), _ptr(keep), R, C.addressof(loss))
     if rc:
         raise FxError(rc, f"fx_debug_train_step_host failed: {status_name(rc)}")
     return int(st.value), float(loss.value)
