@@ -215,6 +215,8 @@ struct fx_engine {
     int64_t ge_bytetab = 1;     // 1 = GlobalEpistasis layer 1 gathers from the byte-indexed per-position table (0 = LUT + code-indexed table: A/B)
     int64_t dense_waves = 0;    // MLP / GE canonical hidden width: 0 = auto (8 waves per workgroup for mid-size launches, else 16), 8 / 16 = force
     int64_t dense_few_waves_below = 0;    // auto: tiles per SIMD below which the 8-wave form is used (0 = never: measured no gain, profiles/archive/r2_dense_waves_ab.log)
+    int64_t cnn_head_slab = 1;  // 4-letter CNN with more than 128 hidden units, batch launches (>= 16 tiles per workgroup): conv-only kernel + a head kernel that streams the H x H layer through LDS slabs
+                                // once per lockstep round of 8 tiles (k_cnn_head_slab) instead of the fused kernel, whose waves stream it from L2 per tile; 0 = the fused kernel (rounds 1-5)
     int64_t cnn_quad_tail = 1;  // K1, unrolled seq_len = 8 form: the (tiles mod 4) last tiles of a workgroup are walked by wave quads in one round behind the main loop; 0 = one wave per tile throughout (rounds 1-5)
     int64_t wave_prio = 1;      // 1 = static, distinct issue priorities for the waves of a SIMD (fx_stagger_priority); 0 = A/B baseline
     int64_t trace = 0;          // 1 = the MFMA scoring kernels stamp an in-kernel timeline into d_trace (fx_debug_trace_read)

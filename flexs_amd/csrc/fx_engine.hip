@@ -319,6 +319,7 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "ge_bytetab")) return &e->ge_bytetab;
     if (!std::strcmp(key, "wave_prio")) return &e->wave_prio;
     if (!std::strcmp(key, "cnn_quad_tail")) return &e->cnn_quad_tail;
+    if (!std::strcmp(key, "cnn_head_slab")) return &e->cnn_head_slab;
     if (!std::strcmp(key, "dense_pipe")) return &e->dense_pipe;
     if (!std::strcmp(key, "fuse_mean")) return &e->fuse_mean;
     if (!std::strcmp(key, "fuse_mean_batch")) return &e->fuse_mean_batch;

@@ -205,6 +205,8 @@ int fx_launch_score_cnn_mfma(fx_engine* e, fx_model* const* models, int M, const
         return launch_g<4, 7, 2, 7, 1, true, 8, true>(e, a, full);     // 7-tap window: shifting form, 256-register budget
     }
     if (s.A == 4) {
+        // more than 128 hidden units at batch size: the two-kernel path, whose head streams the H x H layer through LDS slabs (score_cnn_split.hip)
+        if (lay.HT >= 13 && e->cnn_head_slab && !e->rows_req.on && ((N + 15) / 16) * M >= (int64_t)e->num_cus * 16) return FX_EUNSUPPORTED;
         const bool big = ((N + 15) / 16) * M >= (int64_t)e->num_cus * e->cnn_big_units;   // units per CU from which 16-wave workgroups pay
         const int variant = (int)e->cnn_variant;
         switch (lay.HT) {

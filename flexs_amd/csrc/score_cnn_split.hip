@@ -65,9 +65,85 @@ __global__ void __launch_bounds__(WAVES * 64) k_cnn_head(HeadArgs p) {
     }
 }
 
+// Hidden sizes above 128 at batch size (round 6): the head's H x H layer (169 KiB at H = 200) streamed from L2 per tile and wave made the
+// fused kernel L2-latency-bound (0.61 of the pipe at 1e5 sequences).  Here the WORKGROUP streams it once per lockstep round of WAVES tiles
+// through two LDS slabs (mma_layer_slab_dma, the dense kernel's slab form), the first dense layer's blocks and the vectors are LDS-resident.
+// A last round of at most three live tiles is walked without slabs (blocks straight from L2, no barriers) instead of costing a whole
+// round.  Same MFMA sequence per output element as k_cnn_head and the fused kernel: the same bits.
+template <int FT, int HT, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_cnn_head_slab(HeadArgs p) {
+    constexpr int KG = 2, LONE = 3;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, sq = lane & 15;
+    const int vec_floats = p.head_floats - (p.off_db - p.off_d1);
+    float* vec_s = smem + FT * HT * 256;                                 // behind the first layer's blocks
+    f4* slab = reinterpret_cast<f4*>(vec_s + ((vec_floats + 3) & ~3));
+    int64_t u_lo, u_hi;
+    fx_unit_range(p.TG, p.M, u_lo, u_hi);
+    if (u_lo >= u_hi) return;
+    const int m_first = (int)(u_lo / p.TG), m_last = (int)((u_hi - 1) / p.TG);
+    for (int m = m_first; m <= m_last; ++m) {
+        __syncthreads();                                                 // the previous member's readers are done
+        fill_lds(reinterpret_cast<f4*>(smem), reinterpret_cast<const f4*>(p.w[m] + p.off_d1), FT * HT * 64);
+        for (int i = tid; i < vec_floats; i += WAVES * 64) vec_s[i] = p.w[m][p.off_db + i];
+        __syncthreads();
+        const f4* w_d1 = reinterpret_cast<const f4*>(smem);
+        const f4* w_d2 = reinterpret_cast<const f4*>(p.w[m] + p.off_d2);
+        const float* db = vec_s;
+        const int64_t t_lo = (u_lo > (int64_t)m * p.TG ? u_lo : (int64_t)m * p.TG) - (int64_t)m * p.TG;
+        const int64_t t_hi = (u_hi < (int64_t)(m + 1) * p.TG ? u_hi : (int64_t)(m + 1) * p.TG) - (int64_t)m * p.TG;
+        FxSlabStream st{0, false};
+        for (int64_t r0 = t_lo; r0 < t_hi; r0 += WAVES) {
+            const int64_t want = r0 + wave;
+            const bool live = want < t_hi;
+            const int64_t tile = live ? want : t_lo;                     // (a wave without a tile runs along on the first one)
+            const bool lone = r0 > t_lo && t_hi - r0 <= LONE;            // a last round of few tiles: no slabs
+            const int64_t left = t_hi - (r0 + WAVES);                    // tiles behind this round
+            const bool more = left > LONE;                               // ... and whether the next round streams slabs again
+            asm volatile("" ::: "memory");
+            asm volatile("" : "+v"(w_d2));
+            if (lone && !live) continue;
+            f4 pooled[FT][1];
+            const f4* src = p.pool + (((int64_t)m * p.TG + tile) * FT) * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < FT; ++t) pooled[t][0] = src[t * 64];
+            f4 h1[HT][1], h2[HT][1];
+            init_bias<HT, 1>(db, h1, g);
+            mma_layer<FT, HT, 1>(w_d1, pooled, h1, lane);
+            relu_tiles<HT, 1>(h1);
+            init_bias<HT, 1>(db + 16 * HT, h2, g);
+            if (lone) mma_layer<HT, HT, 1>(w_d2, h1, h2, lane, p.rlh);
+            else mma_layer_slab_dma<HT, HT, KG, WAVES>(w_d2, more ? w_d2 : nullptr, slab, h1, h2, lane, p.rlh, st);
+            relu_tiles<HT, 1>(h2);
+            float y[1];
+            final_dot<HT, 1>(db + 32 * HT, db[48 * HT], h2, y, g);
+            const int64_t n = tile * 16 + sq;
+            if (live && g == 0 && n < p.N) p.out[n * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(y[0]);
+        }
+    }
+}
+
 template <int FT, int HT>
 int launch_head(fx_engine* e, const HeadArgs& a) {
     constexpr int WAVES = 8;
+    if constexpr (HT >= 13) {
+        // at least two lockstep rounds per workgroup: the slab form
+        const int64_t U = (int64_t)a.M * a.TG;
+        const size_t lds = (size_t)FT * HT * 1024 + (size_t)((a.head_floats - (a.off_db - a.off_d1) + 3) & ~3) * 4 + (size_t)2 * 2 * HT * 1024;
+        if (e->cnn_head_slab && U >= (int64_t)e->num_cus * 2 * WAVES && lds <= (size_t)e->max_lds && a.off_d1 % 4 == 0) {
+            auto kern = k_cnn_head_slab<FT, HT, WAVES>;
+            static bool attr_set_s[64] = {};
+            if (!attr_set_s[e->device & 63]) {
+                FX_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_set_s[e->device & 63] = true;
+            }
+            const int64_t blocks = e->grid_blocks > 0 ? e->grid_blocks : e->num_cus;
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), lds, e->stream, a);
+            FX_HIP(e, hipGetLastError());
+            return FX_OK;
+        }
+    }
     const size_t lds = (size_t)a.head_floats * 4 + 16;
     const bool wlds = lds <= (size_t)e->max_lds && HT <= 8;
     const int64_t U = (int64_t)a.M * a.TG;
@@ -113,6 +189,13 @@ int launch_conv(fx_engine* e, const CnnArgs& a, size_t lds) {
         const bool seg = e->cnn_seg != 0 && (int64_t)a.M * a.TG <= e->num_cus && (e->cnn_seg > 0 || L1 >= 24) &&
                          lds + (size_t)8 * FT * 64 * 16 <= (size_t)e->max_lds;
         if (seg) return launch_g<4, K, FT, 1, 1, false, 8, true, 0, false, true, false>(e, a, lds);
+    }
+    if constexpr (K == 5 && FT == 2) {
+        // batch launches (the wide-head path, round 6): four waves per SIMD, and the unrolled walk of the canonical short landscape
+        if ((int64_t)a.M * a.TG >= (int64_t)e->num_cus * 16 && !e->rows_req.on) {
+            if (a.L == 8) return launch_g<4, 5, 2, 1, 1, false, 16, true, 4, true, false, false>(e, a, lds);
+            return launch_g<4, 5, 2, 1, 1, false, 16, true, 0, false, false, false>(e, a, lds);
+        }
     }
     return launch_g<4, K, FT, 1, 1, false, 8, true, 0, false, false, false>(e, a, lds);
 }

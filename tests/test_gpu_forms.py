@@ -752,3 +752,35 @@ def test_batch_launch_takes_the_ensemble_mean_itself(eng, L, M, n):
         assert np.array_equal(d_mean.cpu().numpy().view(np.uint32), want.view(np.uint32))
     finally:
         ab_option(eng, "fuse_mean_batch", 0)
+
+
+@pytest.mark.parametrize("L,H,M,n", [(8, 200, 1, 100_000), (8, 200, 1, 65_536 + 16 * 3), (8, 256, 2, 70_001), (14, 200, 3, 30_000), (8, 130, 1, 66_000),
+                                     (8, 200, 1, 4_000)])
+def test_wide_cnn_head_through_lds_slabs_gives_the_same_bits(eng, L, H, M, n):
+    """Round 6: a 4-letter CNN with more than 128 hidden units at batch size runs as the conv-only kernel + a head kernel that streams the
+    H x H layer through LDS slabs once per lockstep round of 8 tiles (`cnn_head_slab`, k_cnn_head_slab) instead of the fused kernel, whose
+    waves stream it from L2 per tile.  Same MFMA sequence per output element: the SAME BITS as the fused kernel (`cnn_head_slab` = 0);
+    both agree with the oracle at the head and the tail of the batch (ragged last tile, a last round of one to three tiles walked
+    without slabs); small batches keep the fused kernel."""
+    alpha = "TGCA" if L == 8 else "UGCA"
+    natives, ws = zip(*[make_native(eng, "cnn", L, 4, H, 32, 5, seed=700 + m) for m in range(M)])
+    lut = _native.make_lut(alpha)
+    b, seqs = rand_seqs(n, L, alpha, seed=n % 83 + H)
+    try:
+        outs = {}
+        for slab in (0, 1):
+            eng.set_option("cnn_head_slab", slab)
+            outs[slab], mean = eng.score(list(natives), b, lut, want_matrix=True, want_mean=True)
+            assert np.array_equal(mean, np.mean(outs[slab], axis=1))
+        assert np.array_equal(outs[1].view(np.uint32), outs[0].view(np.uint32))
+        k = min(n, 300)
+        for m in range(M):
+            assert_scores(outs[1][:k, m], ref_np.keras_fitness(seqs[:k], alpha, "cnn", ws[m], exact=True), f"cnn L={L} H={H} slab head member {m}")
+            assert_scores(outs[1][n - k:, m], ref_np.keras_fitness(seqs[n - k:], alpha, "cnn", ws[m], exact=True), f"cnn L={L} H={H} slab head member {m} tail")
+        bad = b.copy(); bad[n - 2, L - 1] = ord("!")
+        with pytest.raises(ValueError):
+            eng.score(list(natives), bad, lut)
+        again, _ = eng.score(list(natives), b, lut)
+        assert np.array_equal(again, outs[1])
+    finally:
+        eng.set_option("cnn_head_slab", 1)
