@@ -784,3 +784,23 @@ def test_wide_cnn_head_through_lds_slabs_gives_the_same_bits(eng, L, H, M, n):
         assert np.array_equal(again, outs[1])
     finally:
         eng.set_option("cnn_head_slab", 1)
+
+
+@pytest.mark.parametrize("L,H,K,n", [(20, 200, 5, 70_000), (12, 256, 3, 66_001)])
+def test_wide_protein_cnn_head_through_lds_slabs(eng, L, H, K, n):
+    """The 20-letter CNN with more than 128 hidden units always runs conv kernel + head kernel; at batch size the head is the slab form too
+    (k_cnn_head_slab): same bits as the head that streams from L2 (`cnn_head_slab` = 0), both held to the oracle."""
+    nm, w = make_native(eng, "cnn", L, 20, H, 32, K, seed=990)
+    lut = _native.make_lut(s_utils.AAS)
+    b, _ = rand_seqs(n, L, s_utils.AAS, seed=L + H)
+    try:
+        outs = {}
+        for slab in (0, 1):
+            eng.set_option("cnn_head_slab", slab)
+            outs[slab], _ = eng.score([nm], b, lut)
+        assert np.array_equal(outs[1].view(np.uint32), outs[0].view(np.uint32))
+        k = 200
+        assert_scores(outs[1][:k, 0], c_oracle.forward("cnn", lut[b[:k]], 20, w), f"protein cnn L={L} H={H} slab head")
+        assert_scores(outs[1][n - k:, 0], c_oracle.forward("cnn", lut[b[n - k:]], 20, w), f"protein cnn L={L} H={H} slab head tail")
+    finally:
+        eng.set_option("cnn_head_slab", 1)
