@@ -299,6 +299,8 @@ static int64_t* option_slot(fx_engine* e, const char* key) {
     if (!std::strcmp(key, "cnn_conv1_mfma")) return &e->cnn_conv1_mfma;
     if (!std::strcmp(key, "mlp_l1_mfma")) return &e->mlp_l1_mfma;
     if (!std::strcmp(key, "mlp_pair")) return &e->mlp_pair;
+    if (!std::strcmp(key, "mlp_l1_pos")) return &e->mlp_l1_pos;
+    if (!std::strcmp(key, "mlp_l1_pos_tiles")) return &e->mlp_l1_pos_tiles;
     if (!std::strcmp(key, "stage_bytes")) return &e->stage_bytes;
     if (!std::strcmp(key, "stage_fill")) return &e->stage_fill;
     if (!std::strcmp(key, "dma_fill")) return &e->dma_fill;

@@ -16,6 +16,7 @@
 #include "fx_common.h"
 #include "mfma_common.h"
 #include "score_dense_tile.h"
+#include "score_dense_l1.h"
 
 namespace {
 
@@ -48,6 +49,7 @@ struct DenseArgs {
     // SLAB: the last (tiles mod 8) tiles of a workgroup, up to this many, are walked one at a time by the workgroup's 8 waves together
     // (fx_dense_tile8, the H x H blocks straight from L2) instead of costing a whole lockstep round; 0 = off
     int slab_coop;
+    const f4* h1;               // W1G: the relu'd first-layer sums, [(member * TG + tile) * HT + mo][64 lanes], computed by k_mlp_l1_pos (score_dense_l1.h); nullptr = gather here
     FxRowsReady ready;          // launched-first host call: the rows arrive while the kernel runs (words == nullptr: they are all there)
     FxRelay relay;              // ... and member 0's workgroups pass them on to the other members through device memory (flags == nullptr: no)
 };
@@ -278,8 +280,19 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
             if (KIND == FX_MLP) {
                 static_assert(KIND != FX_MLP || A % 4 == 0, "one-hot k-steps must not straddle a position");
                 // ---- layer 1: relu(b1 + onehot @ W1), contraction index k = l*A + a
-                init_bias<HT, NT>(db, h, g);
-                if constexpr (PAIR) {
+                [[maybe_unused]] bool have_h1 = false;
+                if constexpr (W1G && NT == 1) {
+                    if (p.h1) {
+                        // the first layer was taken position-major by k_mlp_l1_pos (relu'd already; the relu below is idempotent)
+                        const f4* src = p.h1 + (((int64_t)m * p.TG + tg) * HT) * 64 + lane;
+#pragma unroll
+                        for (int mo = 0; mo < HT; ++mo) h[mo][0] = src[mo * 64];
+                        have_h1 = true;
+                    }
+                }
+                if (!have_h1) init_bias<HT, NT>(db, h, g);
+                if (have_h1) {
+                } else if constexpr (PAIR) {
                     // 4-letter alphabet: one pre-summed row per PAIR of positions (16 letter pairs), i.e. half the LDS
                     // traffic, half the adds and half the address arithmetic of the row-per-position gather below --
                     // the first layer is what a tile waits for while the matrix pipe idles (profiles/archive/r2_trace_probe)
@@ -530,8 +543,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_dense_mfma(DenseArgs p) {
                     const int64_t nn = tg * 16 + sq;
                     const uint8_t* crow = p.ascii + (nn < p.N ? nn : 0) * L;
                     float yc = 0.f;
-                    fx_dense_tile8<KIND, HT, false>(true, wv, lane, crow, L, p.A, p.rlh, PAIR ? 1 : 0, w_first, w1p, PAIR ? wpair : nullptr, w_d2, w_d3, db,
-                                                    lut_s, hx, nullptr, bad, yc);
+                    const float* l1 = PAIR ? wpair : nullptr;
+                    int l1_form = PAIR ? 1 : 0;
+                    if constexpr (W1G) {
+                        if (p.h1) { l1 = reinterpret_cast<const float*>(p.h1 + (((int64_t)m * p.TG + tg) * HT) * 64); l1_form = 2; }
+                    }
+                    fx_dense_tile8<KIND, HT, false>(true, wv, lane, crow, L, p.A, p.rlh, l1_form, w_first, w1p, l1, w_d2, w_d3, db, lut_s, hx, nullptr, bad, yc);
                     if (wv == 0 && g == 0 && nn < p.N) p.out[nn * p.out_sn + (p.m_off + m) * p.out_sm] = fx_nan_to_num(yc);
                     if (i + 1 < nslab) __syncthreads();              // the next tile reuses the exchange buffers
                 }
@@ -689,6 +706,30 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
     }
     a.lds_from = (int)lds_from;
     a.lds_floats = (int)(tail - lds_from);
+    if (w1_global && e->mlp_l1_pos && !e->mlp_l1_mfma && !e->rows_req.on && (int64_t)a.M * a.TG >= (int64_t)e->num_cus * e->mlp_l1_pos_tiles) {
+        // batch launch of an MLP whose first-layer rows do not fit LDS (protein alphabets): the first layer position-major into a scratch
+        // (k_mlp_l1_pos: the rows cross L2 -> LDS once per 16-32 tiles instead of once per sequence), then this kernel from there
+        L1Args l1{};
+        l1.ascii = a.ascii; l1.lut = a.lut; l1.err = a.err; l1.N = a.N; l1.TG = a.TG; l1.M = a.M; l1.L = a.L; l1.A = a.A;
+        l1.off_w1p = a.off_w1p; l1.off_db = a.off_db;
+        for (int m = 0; m < a.M; ++m) l1.w[m] = a.w[m];
+        void* h1 = nullptr;
+        if (int rc = fx_scratch(e, 2, (size_t)a.M * (size_t)a.TG * HT_ * 64 * sizeof(f4), &h1)) return rc;
+        l1.h1 = (f4*)h1;
+        const int rc1 = fx_launch_mlp_l1_pos(e, l1, HT_);
+        if (rc1 != FX_OK && rc1 != FX_EUNSUPPORTED) return rc1;
+        if (rc1 == FX_OK) {
+            a.h1 = (const f4*)h1;
+            if constexpr (DGc) {
+                // ... and the H x H layers through LDS slabs (the image in LDS is empty: vectors and leftover tiles read L2)
+                if (e->dense_slab && lds + (size_t)2 * FX_SLAB_KG * HT_ * 1024 <= (size_t)e->max_lds) {
+                    a.slab_coop = e->dense_slab_coop > 0 ? (int)(e->dense_slab_coop < 7 ? e->dense_slab_coop : 7) : 0;
+                    return launch_inst<FX_MLP, 4, HT_, 1, W, true, true, true, true>(e, a, lds);
+                }
+            }
+            return launch_inst<FX_MLP, 4, HT_, 1, W, true, true, DGc>(e, a, lds);
+        }
+    }
     if constexpr (DGc) {
         // hidden sizes 129..256: stream the HxH blocks through LDS slabs, one pass per round of 8 tiles (A/B: dense_slab = 0)
         // (not when the first-layer rows stream from L2 as well: measured 3 % slower there, profiles/archive/r1_run46)

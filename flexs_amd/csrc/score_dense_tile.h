@@ -88,7 +88,14 @@ __device__ __forceinline__ void fx_dense_tile8(bool live, int w8, int lane, cons
                 h[t] = mo < HT ? *reinterpret_cast<const f4*>(&db[16 * mo + 4 * g]) : splat4(0.f);
             }
             unsigned seen = 0;
-            if (pair) {
+            if (pair == 2) {
+                // the tile's first layer was taken by k_mlp_l1_pos (score_dense_l1.h): `w1pair` is its [mo][64 lanes] block (relu'd; the relu below is idempotent)
+#pragma unroll
+                for (int t = 0; t < OT; ++t) {
+                    const int mo = w8 + SW * t;
+                    if (mo < HT) h[t] = reinterpret_cast<const f4*>(w1pair)[mo * 64 + lane];
+                }
+            } else if (pair) {
                 const float* wp = w1pair + 4 * g;
                 constexpr int RS = 16 * HT + FX_PAIR_PAD;
                 const int np2 = L >> 1, nterm = np2 + (L & 1);    // pair rows, then the odd last position's own row

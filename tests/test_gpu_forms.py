@@ -804,3 +804,38 @@ def test_wide_protein_cnn_head_through_lds_slabs(eng, L, H, K, n):
         assert_scores(outs[1][n - k:, 0], c_oracle.forward("cnn", lut[b[n - k:]], 20, w), f"protein cnn L={L} H={H} slab head tail")
     finally:
         eng.set_option("cnn_head_slab", 1)
+
+
+@pytest.mark.parametrize("L,alpha,H,M,n", [(90, s_utils.AAS, 200, 1, 100_000), (90, s_utils.AAS, 100, 2, 40_003), (33, s_utils.AAS, 200, 1, 70_000),
+                                           (237, s_utils.AAS, 100, 1, 20_000), (400, "UGCA", 100, 1, 30_000), (31, s_utils.AAS, 256, 1, 66_000),
+                                           (90, s_utils.AAS, 64, 3, 25_000), (90, s_utils.AAS, 200, 1, 2_000)])
+def test_mlp_first_layer_position_major_gives_the_same_bits(eng, L, alpha, H, M, n):
+    """Round 6: an MLP whose first-layer rows do not fit LDS (protein alphabets: dyna_ppo.py:54's MLP(seq_len, 200, alphabet) on AAV is
+    90 x 20 rows of 200 floats) gathered seq_len rows PER SEQUENCE from L2 -- 0.03-0.27 of the MFMA rate.  At batch size the first layer is
+    now taken position-major by its own kernel (`mlp_l1_pos`, k_mlp_l1_pos: a position's rows cross L2 -> LDS once per 16-32 tiles) and the
+    dense kernel starts from its scratch.  Bias + rows in position order either way: the SAME BITS as the gather form (`mlp_l1_pos` = 0),
+    both held to the oracle at the head and the tail of the batch (ragged last tile, odd lengths, several members); a character outside
+    the alphabet is still reported; small batches keep the gather form."""
+    A = len(alpha)
+    natives, ws = zip(*[make_native(eng, "mlp", L, A, H, seed=800 + m) for m in range(M)])
+    lut = _native.make_lut(alpha)
+    b, _ = rand_seqs(n, L, alpha, seed=L + H + n % 7)
+    try:
+        outs = {}
+        for pos in (0, 1):
+            eng.set_option("mlp_l1_pos", pos)
+            outs[pos], mean = eng.score(list(natives), b, lut, want_matrix=True, want_mean=True)
+            assert np.array_equal(mean, np.mean(outs[pos], axis=1))
+        assert np.array_equal(outs[1].view(np.uint32), outs[0].view(np.uint32))
+        k = min(n, 200)
+        for m in range(M):
+            assert_scores(outs[1][:k, m], c_oracle.forward("mlp", lut[b[:k]], A, ws[m]), f"mlp L={L} A={A} H={H} position-major member {m}")
+            assert_scores(outs[1][n - k:, m], c_oracle.forward("mlp", lut[b[n - k:]], A, ws[m]), f"mlp L={L} A={A} H={H} position-major member {m} tail")
+        for where, col in ((n - 1, L - 1), (n // 2, 0), (17, L // 2)):
+            bad = b.copy(); bad[where, col] = ord("!")
+            with pytest.raises(ValueError):
+                eng.score(list(natives), bad, lut)
+        again, _ = eng.score(list(natives), b, lut)
+        assert np.array_equal(again, outs[1])
+    finally:
+        eng.set_option("mlp_l1_pos", 1)
