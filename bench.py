@@ -195,7 +195,8 @@ def make_report(world, N, steps, warmup, elapsed, host_issue_s, kern_ms, use_dis
 # cN = BASELINE.json configs[N-1] at the sizes the per-config block measures; tag -> key of the full record's `configs`
 CONFIG_TAGS = {"c1": "C1 cnn L=8 A=4 M=1 N=1e4", "c2_1e4": "C2 cnn L=8 A=4 M=3 N=1e4", "c3": "C3 mlp L=14 A=4 H=100 M=1 N=1e5",
                "c4": "C4 ge L=90 A=20 H=100 M=8 N=1e5", "c5": "C5 cnn L=237 A=20 M=3 N=62500 (one GPU's share of 5e5)",
-               "mlp_h200": "survey mlp H200 L14 N1e5", "cnn_h200": "survey cnn H200 L8 N1e5", "ge_m1": "survey ge M1 L90 N1e5"}
+               "mlp_h200": "survey mlp H200 L14 N1e5", "cnn_h200": "survey cnn H200 L8 N1e5", "ge_m1": "survey ge M1 L90 N1e5",
+               "mlp_aav_h200": "survey mlp H200 L90 A20 N1e5"}
 
 
 def contract_scalars(full):

@@ -263,7 +263,7 @@ struct fx_engine {
     int64_t stage_bytes = 1;    // 1 = MLP (pair rows) / GE (byte table) tiles copy their 16 x L sequence bytes into per-wave LDS scratch with 16-byte loads (0 = byte loads from global memory: A/B)
     int64_t mlp_l1_pos = 1;     // MLP whose first-layer rows do not fit LDS (protein alphabets), batch launches: 1 = the first layer position-major by its own kernel (k_mlp_l1_pos, score_dense_l1.h: the rows
                                 // cross L2 -> LDS once per 16-32 tiles) + the dense kernel from a scratch; 0 = every sequence gathers its seq_len rows from L2 (rounds 1-5)
-    int64_t mlp_l1_pos_tiles = 4; // ... from this many tiles per CU on
+    int64_t mlp_l1_pos_tiles = 3; // ... from more than this many tiles per CU on (below: the small-launch form, score_dense_small.hip)
     int64_t mlp_pair = 1;       // 1 = MLP layer 1 on a 4-letter alphabet gathers one pre-summed row per PAIR of positions (0 = one row per position: A/B; 2 = pairs for H <= 128 only, the slab form of wider layers keeps the plain rows: A/B)
     int64_t mlp_l1_mfma = 0;    // 1 = one-hot MLP layer 1 on MFMA instead of the LDS gather (A/B knob)
     int64_t dense_pipe = 0;     // MLP (pair rows) / GE (byte table): 1 / 2 = the software-pipelined form (tile t + 1's first layer inside tile t's MFMA layers, 8 waves, two-part direct LDS fill; 2 = A operands double-buffered by hand).  Bit-identical but measured 11-13 % SLOWER than the 16-wave form at every size (profiles/r3_dense_pipe_ab.log): off; kept as the A/B

@@ -34,9 +34,9 @@ struct L1Args {
 // (c mod 4) of the 256-byte bank row -- four random letters on four windows: ~2 cycles.  The sums are stored to the scratch at the MFMA
 // layout's lane index, so the permutation costs nothing.
 template <int HT> struct FxL1Row { static constexpr int R = (16 * HT) % 64, PAD = (R == 16 || R == 48) ? 0 : (16 - R + 64) % 64, RS = 16 * HT + PAD; };
-template <int HT, int TW, int KP>
-__global__ void __launch_bounds__(512) k_mlp_l1_pos(L1Args p) {
-    constexpr int WAVES = 8, RS = FxL1Row<HT>::RS;
+template <int HT, int TW, int KP, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_mlp_l1_pos(L1Args p) {
+    constexpr int RS = FxL1Row<HT>::RS;
     static_assert(KP == 2 || KP == 4, "a slab's bytes are one 2- or 4-byte load per sequence");
     static_assert(RS % 64 == 16 || RS % 64 == 48, "rows of consecutive letters start in consecutive 64-byte windows");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -116,16 +116,25 @@ __global__ void __launch_bounds__(512) k_mlp_l1_pos(L1Args p) {
                     load_bytes(s + 1, nxt);
                 }
                 const float* buf = rows + (s & 1) * slab_floats + 4 * g;
+                // the slab's letters first (KP x TW byte look-ups in flight together), then the gathers: a row's address no longer waits
+                // for its own look-up in front of every gather (two waves per SIMD hide little)
+                int off[KP][TW];
+#pragma unroll
+                for (int pp = 0; pp < KP; ++pp)
+#pragma unroll
+                    for (int k = 0; k < TW; ++k) {
+                        const unsigned c = lut_s[(cur[k] >> (8 * pp)) & 0xFFu];
+                        if (live[k] && s * KP + pp < L) seen |= c;      // a code is < A <= 127, or 0xFF: tested once per pass
+                        const unsigned ci = c < amax ? c : amax;
+                        off[pp][k] = (pp * A + (int)ci) * RS;
+                    }
 #pragma unroll
                 for (int pp = 0; pp < KP; ++pp) {
                     if (s * KP + pp < L) {
 #pragma unroll
                         for (int k = 0; k < TW; ++k) {
                             if (live[k]) {
-                                const unsigned c = lut_s[(cur[k] >> (8 * pp)) & 0xFFu];
-                                seen |= c;                      // a code is < A <= 127, or 0xFF: tested once per pass
-                                const unsigned ci = c < amax ? c : amax;
-                                const float* rowp = buf + (pp * A + (int)ci) * RS;
+                                const float* rowp = buf + off[pp][k];
 #pragma unroll
                                 for (int mo = 0; mo < HT; ++mo) acc[k][mo] += *reinterpret_cast<const f4*>(rowp + 16 * mo);
                             }
@@ -149,9 +158,9 @@ __global__ void __launch_bounds__(512) k_mlp_l1_pos(L1Args p) {
     if (bad) fx_raise(p.err, FX_ERR_BADCHAR);
 }
 
-template <int HT, int TW, int KP>
+template <int HT, int TW, int KP, int WAVES = 8>
 int launch_l1_pos(fx_engine* e, const L1Args& a) {
-    auto kern = k_mlp_l1_pos<HT, TW, KP>;
+    auto kern = k_mlp_l1_pos<HT, TW, KP, WAVES>;
     const size_t lds = 256 + (size_t)2 * KP * a.A * FxL1Row<HT>::RS * 4;
     if (lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
     static bool attr_set[64] = {};
@@ -162,7 +171,7 @@ int launch_l1_pos(fx_engine* e, const L1Args& a) {
     int64_t blocks = e->grid_blocks > 0 ? e->grid_blocks : e->num_cus;
     const int64_t U = (int64_t)a.M * a.TG;
     if (blocks > U) blocks = U;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, e->stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), lds, e->stream, a);
     FX_HIP(e, hipGetLastError());
     return FX_OK;
 }
@@ -173,9 +182,13 @@ inline int fx_launch_mlp_l1_pos(fx_engine* e, const L1Args& a, int HT) {
         case 1: return launch_l1_pos<1, 4, 4>(e, a);
         case 2: return launch_l1_pos<2, 4, 4>(e, a);
         case 4: return launch_l1_pos<4, 4, 4>(e, a);
-        case 7: return launch_l1_pos<7, 4, 4>(e, a);
+        case 7: return launch_l1_pos<7, 2, 4, 16>(e, a);         // (four waves per SIMD, two tiles each: -7 % against 8 waves x 4 tiles)
         case 8: return launch_l1_pos<8, 4, 4>(e, a);
-        case 13: { const int rc = launch_l1_pos<13, 3, 4>(e, a); return rc != FX_EUNSUPPORTED ? rc : launch_l1_pos<13, 3, 2>(e, a); }   // (four positions per barrier where two slabs of them fit: A <= 23)
+        case 13: {
+            // three waves per SIMD, two tiles each, four positions per barrier where two slabs of them fit (A <= 23); else two per barrier
+            const int rc = launch_l1_pos<13, 2, 4, 12>(e, a);
+            return rc != FX_EUNSUPPORTED ? rc : launch_l1_pos<13, 3, 2>(e, a);
+        }   // (four positions per barrier where two slabs of them fit: A <= 23)
         case 16: return launch_l1_pos<16, 2, 2>(e, a);
         default: return FX_EUNSUPPORTED;
     }

@@ -706,7 +706,7 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
     }
     a.lds_from = (int)lds_from;
     a.lds_floats = (int)(tail - lds_from);
-    if (w1_global && e->mlp_l1_pos && !e->mlp_l1_mfma && !e->rows_req.on && (int64_t)a.M * a.TG >= (int64_t)e->num_cus * e->mlp_l1_pos_tiles) {
+    if (w1_global && e->mlp_l1_pos && !e->mlp_l1_mfma && !e->rows_req.on && (int64_t)a.M * a.TG > (int64_t)e->num_cus * e->mlp_l1_pos_tiles) {
         // batch launch of an MLP whose first-layer rows do not fit LDS (protein alphabets): the first layer position-major into a scratch
         // (k_mlp_l1_pos: the rows cross L2 -> LDS once per 16-32 tiles instead of once per sequence), then this kernel from there
         L1Args l1{};

@@ -29,6 +29,8 @@ def configs_block(eng, device, torch):
         ("survey mlp H200 L14 N1e5", "mlp", 14, "UGCA", 1, 100_000, "k_score_dense_mfma<MLP>", 200),
         ("survey cnn H200 L8 N1e5", "cnn", 8, "TGCA", 1, 100_000, "k_score_cnn_mfma", 200),
         ("survey ge M1 L90 N1e5", "ge", 90, AAS, 1, 100_000, "k_score_dense_mfma<GE>", 100),
+        # the same member on a protein landscape (AAV: 90 residues x 20 letters): first-layer rows do not fit LDS (position-major first layer, round 6)
+        ("survey mlp H200 L90 A20 N1e5", "mlp", 90, AAS, 1, 100_000, "k_mlp_l1_pos + k_score_dense_mfma<MLP>", 200),
     ]
     out = {}
     for spec in specs:

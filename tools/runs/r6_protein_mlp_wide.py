@@ -23,7 +23,7 @@ for name, L, H, M, n in CASES:
     mods = build_members("mlp", L, AAS, M, 0, Hx=H)
     d_in = torch.from_numpy(synth.random_sequence_bytes(n, L, AAS, 0)).cuda()
     stride = (n + 63) // 64 * 64
-    opts = (0, 1)
+    opts = (0, 1, 2) if os.environ.get('FX_L1_EXP') else (0, 1)
     planes = {q: torch.zeros((M, stride), dtype=torch.float32, device="cuda") for q in opts}
     res = {q: [] for q in opts}
     for rep in range(3):
