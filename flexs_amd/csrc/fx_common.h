@@ -609,6 +609,8 @@ int fx_launch_score_cnn_pair(fx_engine* e, fx_model* const* models, int M, const
 int fx_launch_score_mlp_small(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N,
                               float* d_out_NM, int Mtot, int m_off);
 int fx_mlp_first_layer_form(fx_engine* e, const FxShape& s, const FxPackLayout& lay);
+// MLP whose first-layer rows do not fit LDS beside the rest of the image and that takes its first layer position-major at batch size (option mlp_l1_pos, score_dense_l1.h)
+bool fx_mlp_l1_pos_applies(const fx_engine* e, const FxShape& s, const FxPackLayout& lay);
 int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii,
                                int64_t N, float* d_out_NM, int Mtot, int m_off);
 int fx_launch_mfma_probe(fx_engine* e, const float* d_a, const float* d_b, const float* d_c, float* d_d);

@@ -199,6 +199,10 @@ static void plan_host_call(const fx_engine* e, fx_model* const* models, int M, i
     const double t_zc = std::max(t_k, (double)M * bytes / 45e9);
     const double t_copy = bytes / 35e9 + t_k + 25e-6;
     bool zc = mfma && t_zc < t_copy;
+    // an MLP that takes its first layer position-major at batch size wants its bytes in device memory (score_dense_l1.h reads two to four
+    // bytes per sequence and barrier); the gather form it would run over host rows is 2-3 x slower than the copy + that path
+    for (int m = 0; zc && m < M; ++m)
+        if (fx_mlp_l1_pos_applies(e, models[m]->shape, models[m]->layout) && (int64_t)M * ((N + 15) / 16) > (int64_t)e->num_cus * e->mlp_l1_pos_tiles) zc = false;
     if (e->zero_copy_mode == 0) zc = false;
     if (e->zero_copy_mode == 1) zc = true;
     // Pieces only pay when the host's marshalling (~20 GB/s with the packing threads + ~1 ns per string) is a visible

@@ -706,7 +706,13 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
     }
     a.lds_from = (int)lds_from;
     a.lds_floats = (int)(tail - lds_from);
-    if (w1_global && e->mlp_l1_pos && !e->mlp_l1_mfma && !e->rows_req.on && (int64_t)a.M * a.TG > (int64_t)e->num_cus * e->mlp_l1_pos_tiles) {
+    if (w1_global && fx_mlp_l1_pos_applies(e, s, lay) && (int64_t)a.M * a.TG > (int64_t)e->num_cus * e->mlp_l1_pos_tiles) {
+        // (rows that arrive while the kernel runs: the caller packs first instead -- nothing has been enqueued; rows in host memory: the
+        //  position-major kernel reads two to four bytes per sequence and barrier, which is no pattern for PCIe -- the planner sends such
+        //  calls down the copy path, fx_score.hip, and this is the net under it)
+        if (e->rows_req.on) return FX_EUNSUPPORTED;
+    }
+    if (w1_global && fx_mlp_l1_pos_applies(e, s, lay) && !e->ascii_host && (int64_t)a.M * a.TG > (int64_t)e->num_cus * e->mlp_l1_pos_tiles) {
         // batch launch of an MLP whose first-layer rows do not fit LDS (protein alphabets): the first layer position-major into a scratch
         // (k_mlp_l1_pos: the rows cross L2 -> LDS once per 16-32 tiles instead of once per sequence), then this kernel from there
         L1Args l1{};
@@ -816,6 +822,11 @@ int fx_mlp_first_layer_form(fx_engine* e, const FxShape& s, const FxPackLayout& 
     }
     const size_t need = (size_t)(lay.total_floats - lay.off_d2 + lay.pair_floats) * 4 + 256 + 32;
     return need <= (size_t)e->max_lds ? 1 : 0;
+}
+
+bool fx_mlp_l1_pos_applies(const fx_engine* e, const FxShape& s, const FxPackLayout& lay) {
+    if (s.kind != FX_MLP || !e->mlp_l1_pos || e->mlp_l1_mfma || s.A > 127) return false;
+    return (size_t)((lay.HT > 8 ? lay.off_d2 : lay.total_floats) - lay.off_w1p) * 4 + 256 + 32 > (size_t)e->max_lds;
 }
 
 int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N,

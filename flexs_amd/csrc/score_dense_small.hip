@@ -181,9 +181,7 @@ int fx_launch_score_mlp_small(fx_engine* e, fx_model* const* models, int M, cons
     int64_t per_cu = (lay.HT > 8 || (s.kind == FX_MLP && (int64_t)s.L * s.A >= 160)) ? 4 : 1;
     // (an MLP whose first-layer rows do not fit LDS -- protein alphabets -- has the position-major first layer from 2 tiles per CU on, round 6:
     //  16 384 sequences of L = 90, H = 200 take this form 105 us, 30 000 take that one 106, profiles/r6_protein_mlp_wide.log)
-    if (s.kind == FX_MLP && e->mlp_l1_pos && !e->mlp_l1_mfma && !e->rows_req.on &&
-        (size_t)((lay.HT > 8 ? lay.off_d2 : lay.total_floats) - lay.off_w1p) * 4 + 256 + 32 > (size_t)e->max_lds)
-        per_cu = e->mlp_l1_pos_tiles < per_cu ? e->mlp_l1_pos_tiles : per_cu;
+    if (fx_mlp_l1_pos_applies(e, s, lay) && !e->rows_req.on && !e->ascii_host) per_cu = e->mlp_l1_pos_tiles < per_cu ? e->mlp_l1_pos_tiles : per_cu;
     if (e->dense_small < 2 && U > per_cu * e->num_cus) return FX_EUNSUPPORTED;
     const int form = s.kind == FX_MLP ? fx_mlp_first_layer_form(e, s, lay) : 0;
     if (form > 1) return FX_EUNSUPPORTED;
