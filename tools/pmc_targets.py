@@ -54,6 +54,7 @@ run("mlp", 14, "UGCA", 1, 100_000, H=200, blocks=254)         # ... and as whole
 eng.set_option("dense_slab_coop", 3)
 run("cnn", 8, "TGCA", 1, 100_000, 32, 5, H=200)               # CNN with a 200-unit head
 run("ge", 90, AAS, 1, 100_000, H=200, blocks=250)
+run("mlp", 90, AAS, 1, 100_000, H=200, blocks=248)          # protein MLP (dyna_ppo.py:54 on AAV): k_mlp_l1_pos + the dense kernel from its scratch (round 6)
 eng.set_option("grid_blocks", 0)
 # K4: NoisyAbstractModel neighbour search, Levenshtein, RNA L = 14 and protein L = 90
 rng = np.random.default_rng(0)
