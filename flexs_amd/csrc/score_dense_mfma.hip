@@ -715,26 +715,40 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
     if (w1_global && fx_mlp_l1_pos_applies(e, s, lay) && !e->ascii_host && (int64_t)a.M * a.TG > (int64_t)e->num_cus * e->mlp_l1_pos_tiles) {
         // batch launch of an MLP whose first-layer rows do not fit LDS (protein alphabets): the first layer position-major into a scratch
         // (k_mlp_l1_pos: the rows cross L2 -> LDS once per 16-32 tiles instead of once per sequence), then this kernel from there
-        L1Args l1{};
-        l1.ascii = a.ascii; l1.lut = a.lut; l1.err = a.err; l1.N = a.N; l1.TG = a.TG; l1.M = a.M; l1.L = a.L; l1.A = a.A;
-        l1.off_w1p = a.off_w1p; l1.off_db = a.off_db;
-        for (int m = 0; m < a.M; ++m) l1.w[m] = a.w[m];
+        // in slices of at most ~512 MB of scratch (a slice of 1e5 sequences x 200 hidden units is 83 MB; the rows of a batch are independent)
+        const int64_t slice_tiles = std::max<int64_t>((int64_t)e->num_cus * 16, ((int64_t)512 << 20) / ((int64_t)a.M * HT_ * 1024));
+        const int64_t TG_all = a.TG, N_all = a.N;
+        const uint8_t* ascii_all = a.ascii;
+        float* out_all = a.out;
         void* h1 = nullptr;
-        if (int rc = fx_scratch(e, 2, (size_t)a.M * (size_t)a.TG * HT_ * 64 * sizeof(f4), &h1)) return rc;
-        l1.h1 = (f4*)h1;
-        const int rc1 = fx_launch_mlp_l1_pos(e, l1, HT_);
-        if (rc1 != FX_OK && rc1 != FX_EUNSUPPORTED) return rc1;
-        if (rc1 == FX_OK) {
+        if (int rc = fx_scratch(e, 2, (size_t)a.M * (size_t)std::min(TG_all, slice_tiles) * HT_ * 64 * sizeof(f4), &h1)) return rc;
+        bool first = true;
+        for (int64_t t0 = 0; t0 < TG_all; t0 += slice_tiles) {
+            const int64_t tiles = std::min(slice_tiles, TG_all - t0);
+            a.ascii = ascii_all + t0 * 16 * a.L;
+            a.out = out_all + t0 * 16 * a.out_sn;
+            a.N = std::min<int64_t>(tiles * 16, N_all - t0 * 16);
+            a.TG = tiles;
+            L1Args l1{};
+            l1.ascii = a.ascii; l1.lut = a.lut; l1.err = a.err; l1.N = a.N; l1.TG = a.TG; l1.M = a.M; l1.L = a.L; l1.A = a.A;
+            l1.off_w1p = a.off_w1p; l1.off_db = a.off_db;
+            for (int m = 0; m < a.M; ++m) l1.w[m] = a.w[m];
+            l1.h1 = (f4*)h1;
+            const int rc1 = fx_launch_mlp_l1_pos(e, l1, HT_);
+            if (rc1 == FX_EUNSUPPORTED && first) break;             // (no instantiation / the slabs do not fit: the gather form below, on the whole batch)
+            if (rc1 != FX_OK) return rc1;
+            first = false;
             a.h1 = (const f4*)h1;
-            if constexpr (DGc) {
-                // ... and the H x H layers through LDS slabs (the image in LDS is empty: vectors and leftover tiles read L2)
-                if (e->dense_slab && lds + (size_t)2 * FX_SLAB_KG * HT_ * 1024 <= (size_t)e->max_lds) {
-                    a.slab_coop = e->dense_slab_coop > 0 ? (int)(e->dense_slab_coop < 7 ? e->dense_slab_coop : 7) : 0;
-                    return launch_inst<FX_MLP, 4, HT_, 1, W, true, true, true, true>(e, a, lds);
-                }
-            }
-            return launch_inst<FX_MLP, 4, HT_, 1, W, true, true, DGc>(e, a, lds);
+            int rc2;
+            // ... and the H x H layers through LDS slabs where they do not fit (the image in LDS is empty: vectors and leftover tiles read L2)
+            if (DGc && e->dense_slab && lds + (size_t)2 * FX_SLAB_KG * HT_ * 1024 <= (size_t)e->max_lds) {
+                a.slab_coop = e->dense_slab_coop > 0 ? (int)(e->dense_slab_coop < 7 ? e->dense_slab_coop : 7) : 0;
+                rc2 = launch_inst<FX_MLP, 4, HT_, 1, W, true, true, DGc, DGc>(e, a, lds);
+            } else rc2 = launch_inst<FX_MLP, 4, HT_, 1, W, true, true, DGc>(e, a, lds);
+            if (rc2 != FX_OK) return rc2;
         }
+        a.ascii = ascii_all; a.out = out_all; a.N = N_all; a.TG = TG_all; a.h1 = nullptr;
+        if (!first) return FX_OK;
     }
     if constexpr (DGc) {
         // hidden sizes 129..256: stream the HxH blocks through LDS slabs, one pass per round of 8 tiles (A/B: dense_slab = 0)

@@ -808,14 +808,14 @@ def test_wide_protein_cnn_head_through_lds_slabs(eng, L, H, K, n):
 
 @pytest.mark.parametrize("L,alpha,H,M,n", [(90, s_utils.AAS, 200, 1, 100_000), (90, s_utils.AAS, 100, 2, 40_003), (33, s_utils.AAS, 200, 1, 70_000),
                                            (237, s_utils.AAS, 100, 1, 20_000), (400, "UGCA", 100, 1, 30_000), (31, s_utils.AAS, 256, 1, 66_000),
-                                           (90, s_utils.AAS, 64, 3, 25_000), (90, s_utils.AAS, 200, 1, 2_000)])
+                                           (90, s_utils.AAS, 64, 3, 25_000), (90, s_utils.AAS, 200, 1, 2_000), (30, s_utils.AAS, 200, 1, 700_001)])
 def test_mlp_first_layer_position_major_gives_the_same_bits(eng, L, alpha, H, M, n):
     """Round 6: an MLP whose first-layer rows do not fit LDS (protein alphabets: dyna_ppo.py:54's MLP(seq_len, 200, alphabet) on AAV is
     90 x 20 rows of 200 floats) gathered seq_len rows PER SEQUENCE from L2 -- 0.03-0.27 of the MFMA rate.  At batch size the first layer is
     now taken position-major by its own kernel (`mlp_l1_pos`, k_mlp_l1_pos: a position's rows cross L2 -> LDS once per 16-32 tiles) and the
     dense kernel starts from its scratch.  Bias + rows in position order either way: the SAME BITS as the gather form (`mlp_l1_pos` = 0),
     both held to the oracle at the head and the tail of the batch (ragged last tile, odd lengths, several members); a character outside
-    the alphabet is still reported; small batches keep the gather form."""
+    the alphabet is still reported; small batches keep the gather form; a batch whose scratch would pass 512 MB goes in slices (the 7e5 case)."""
     A = len(alpha)
     natives, ws = zip(*[make_native(eng, "mlp", L, A, H, seed=800 + m) for m in range(M)])
     lut = _native.make_lut(alpha)
