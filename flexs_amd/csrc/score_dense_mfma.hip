@@ -15,13 +15,13 @@
 
 #include "fx_common.h"
 #include "mfma_common.h"
+// SLAB: input tiles per slab (3 and 4 measured no faster once the slabs go global -> LDS directly: profiles/r6_slab_dma_ab.log)
+#define FX_SLAB_KG 2
 #include "score_dense_tile.h"
 #include "score_dense_l1.h"
 
 namespace {
 
-// SLAB: input tiles per slab (3 and 4 measured no faster once the slabs go global -> LDS directly: profiles/r6_slab_dma_ab.log)
-#define FX_SLAB_KG 2
 struct DenseArgs {
     const uint8_t* ascii;
     const uint8_t* lut;
@@ -821,27 +821,6 @@ int dispatch_dense(fx_engine* e, const FxShape& s, const FxPackLayout& lay, Dens
 }
 
 }  // namespace
-
-// Which terms the persistent kernel's MLP first layer adds (the small-launch kernel must add the same ones):
-// 0 = one kernel row per position, 1 = one pre-summed row per PAIR of positions (the PAIR form), 2 = MFMA form (A/B option).
-int fx_mlp_first_layer_form(fx_engine* e, const FxShape& s, const FxPackLayout& lay) {
-    if (e->mlp_l1_mfma) return 2;
-    if (!e->mlp_pair || lay.off_w1pair < 0) return 0;
-    if (lay.HT > 8) {
-        // H > 128 (round 6): the slab form with the pair rows in LDS -- nothing else of the image is (the vectors are read from L2) -- beside
-        // its two slabs; mlp_pair = 2 keeps the plain rows there (A/B)
-        if (!e->dense_slab || e->mlp_pair == 2) return 0;
-        const size_t need_slab = (size_t)lay.pair_floats * 4 + 256 + 32 + (size_t)2 * FX_SLAB_KG * lay.HT * 1024;
-        return need_slab <= (size_t)e->max_lds ? 1 : 0;
-    }
-    const size_t need = (size_t)(lay.total_floats - lay.off_d2 + lay.pair_floats) * 4 + 256 + 32;
-    return need <= (size_t)e->max_lds ? 1 : 0;
-}
-
-bool fx_mlp_l1_pos_applies(const fx_engine* e, const FxShape& s, const FxPackLayout& lay) {
-    if (s.kind != FX_MLP || !e->mlp_l1_pos || e->mlp_l1_mfma || s.A > 127) return false;
-    return (size_t)((lay.HT > 8 ? lay.off_d2 : lay.total_floats) - lay.off_w1p) * 4 + 256 + 32 > (size_t)e->max_lds;
-}
 
 int fx_launch_score_dense_mfma(fx_engine* e, fx_model* const* models, int M, const uint8_t* d_ascii, int64_t N,
                                float* d_out_NM, int Mtot, int m_off) {
