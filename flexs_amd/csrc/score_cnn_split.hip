@@ -238,11 +238,12 @@ int fx_launch_score_cnn_split(fx_engine* e, fx_model* const* models, int M, cons
         const FxShape& t = models[m]->shape;
         if (t.kind != FX_CNN || t.L != s.L || t.A != s.A || t.F != s.F || t.H != s.H || t.K != s.K) return FX_EUNSUPPORTED;
     }
-    if ((s.A != 4 && s.A != 20) || lay.FT < 1 || lay.FT > 4 || s.K < 2 || s.K > 7 || s.H > 256 || M > FX_MAX_M ||
-        e->cnn_conv1_mfma || (s.A == 20 && (lay.FT != 2 || !e->cnn_pair)))
+    // (binary alphabet, sequence_utils.py:16's BA: the canonical conv shape only -- its fused kernel covers 97..112 hidden units, this path the rest)
+    if ((s.A != 4 && s.A != 20 && s.A != 2) || lay.FT < 1 || lay.FT > 4 || s.K < 2 || s.K > 7 || s.H > 256 || M > FX_MAX_M ||
+        e->cnn_conv1_mfma || (s.A == 20 && (lay.FT != 2 || !e->cnn_pair)) || (s.A == 2 && (lay.FT != 2 || s.K != 5)))
         return FX_EUNSUPPORTED;
     const size_t conv_lds = (size_t)lay.conv_floats * 4 + 256 + 48;
-    if (s.A == 4 && conv_lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
+    if (s.A != 20 && conv_lds > (size_t)e->max_lds) return FX_EUNSUPPORTED;
     const int64_t TG = (N + 15) / 16;
     void* pool = nullptr;
     int rc = fx_scratch(e, 2, (size_t)M * (size_t)TG * lay.FT * 64 * sizeof(f4), &pool);
@@ -269,8 +270,9 @@ int fx_launch_score_cnn_split(fx_engine* e, fx_model* const* models, int M, cons
     a.off_cb = (int)lay.off_cb; a.off_w1p = (int)lay.off_w1p; a.conv_floats = (int)lay.conv_floats; a.off_d1 = (int)lay.off_d1;
     a.off_d2 = (int)lay.off_d2; a.off_db = (int)lay.off_db; a.total_floats = (int)lay.total_floats;
     a.pool_out = (f4*)pool;
-    rc = by_channel_tiles<CnnArgs>(lay.FT, [&] { return dispatch_conv<1>(e, a, conv_lds, s.K); }, [&] { return dispatch_conv<2>(e, a, conv_lds, s.K); },
-                                   [&] { return dispatch_conv<3>(e, a, conv_lds, s.K); }, [&] { return dispatch_conv<4>(e, a, conv_lds, s.K); });
+    if (s.A == 2) rc = launch_g<2, 5, 2, 1, 1, false, 8, true, 0, false, false, false>(e, a, conv_lds);
+    else rc = by_channel_tiles<CnnArgs>(lay.FT, [&] { return dispatch_conv<1>(e, a, conv_lds, s.K); }, [&] { return dispatch_conv<2>(e, a, conv_lds, s.K); },
+                                        [&] { return dispatch_conv<3>(e, a, conv_lds, s.K); }, [&] { return dispatch_conv<4>(e, a, conv_lds, s.K); });
     if (rc) return rc;
 
     HeadArgs h{};
