@@ -77,6 +77,10 @@ struct FxShape {
 //       kin = 16*sg + 4*r + (lane >> 4)        (k-step s = 4*sg + r covers rows 4s .. 4s+3)
 #define FX_PAIR_PAD 4          // floats between the MLP's pair rows (LDS bank spread, pack.cpp)
 
+// Rows of the conv1 gather table are 16 FT + 4 floats apart (round 6): sixteen lanes gather sixteen rows at once, and with rows 32 floats = 128 bytes
+// apart every row starts in one of TWO 16-byte slots of the 256-byte bank row (4- to 8-way conflicts on every gather of the protein CNN: 35 % of its
+// LDS cycles, profiles/r6_pmc_targets.md); 36 floats apart the rows of a tap walk all sixteen slots.  MLP rows (16 HT floats) are a different table.
+#define FX_C1_ROW(FT) (16 * (FT) + 4)
 struct FxPackLayout {
     int FT, HT;                 // output tiles of 16: filters, hidden units (HT rounded up to an instantiated size)
     int HTR;                    // hidden tiles that hold real units = ceil(H / 16) <= HT; the rest is zero padding
@@ -85,7 +89,7 @@ struct FxPackLayout {
     int64_t off_first;          // SG1 x (FT|HT) blocks
     int64_t off_c2, off_c3;     // K x FT x FT, K3 x FT x FT blocks           (CNN)
     int64_t off_cb;             // b1[16FT] b2[16FT] b3[16FT]                 (CNN)
-    int64_t off_w1p;            // conv1 kernel, plain [K*A][16FT] rows (gather form of the one-hot conv)
+    int64_t off_w1p;            // conv1 kernel, plain [K*A] rows of 16 FT floats, FX_C1_ROW(FT) floats apart (gather form of the one-hot conv)
     int64_t conv_floats;        // everything above (the part that must sit in LDS)
     int64_t off_d1, off_d2, off_d3;  // dense blocks: CNN d1 FTxHT, d2 HTxHT; MLP d2, d3 HTxHT; GE d3 HTxHT
     int64_t off_db;             // bias / vector area (layout per kind, see pack.cpp)

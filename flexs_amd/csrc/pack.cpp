@@ -52,7 +52,7 @@ FxPackLayout fx_pack_layout(const FxShape& s) {
         p.off_c2 = off;    off += (int64_t)s.K * p.FT * p.FT * BLK;
         p.off_c3 = off;    off += (int64_t)s.K3() * p.FT * p.FT * BLK;
         p.off_cb = off;    off += 3 * 16 * p.FT;
-        p.off_w1p = off;   off += (int64_t)s.K * s.A * 16 * p.FT;
+        p.off_w1p = off;   off += (int64_t)s.K * s.A * FX_C1_ROW(p.FT);
         p.conv_floats = off = rup(off, 4);
         p.off_d1 = off;    off += (int64_t)p.FT * p.HT * BLK;
         p.off_d2 = off;    off += (int64_t)p.HT * p.HT * BLK;
@@ -191,7 +191,7 @@ void fx_pack_weights(const FxShape& s, const float* blob, float* packed) {
         pack_vec(b1, fil, 16 * FT, packed + p.off_cb);
         pack_vec(b2, fil, 16 * FT, packed + p.off_cb + 16 * FT);
         pack_vec(b3, fil, 16 * FT, packed + p.off_cb + 32 * FT);
-        for (int k = 0; k < K * A; ++k) pack_vec(w1 + (int64_t)k * F, fil, 16 * FT, packed + p.off_w1p + (int64_t)k * 16 * FT);
+        for (int k = 0; k < K * A; ++k) pack_vec(w1 + (int64_t)k * F, fil, 16 * FT, packed + p.off_w1p + (int64_t)k * FX_C1_ROW(FT));
         for (int mi = 0; mi < FT; ++mi)
             for (int mo = 0; mo < HT; ++mo)
                 pack_dense_block(d1, H, fil, hid, mi, mo, packed + p.off_d1 + ((int64_t)mi * HT + mo) * 256);

@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_mfma(CnnArgs p) {
                         for (int j = 0; j < K; ++j)
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt) {
-                                const float* rowp = w1p + (j * A + cw[FX_CW(j)][nt]) * (16 * FT) + 4 * g;
+                                const float* rowp = w1p + (j * A + cw[FX_CW(j)][nt]) * FX_C1_ROW(FT) + 4 * g;
 #pragma unroll
                                 for (int mo = 0; mo < FT; ++mo) {
                                     const f4 w = *reinterpret_cast<const f4*>(rowp + 16 * mo);

@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_score_cnn_pair(PairArgs p) {
                     for (int t = 0; t < FT; ++t) o1[t] = *reinterpret_cast<const f4*>(&cb[16 * t + 4 * g]);
 #pragma unroll
                     for (int j = 0; j < K; ++j) {
-                        const float* rowp = w1p + (j * A + cw[j]) * (16 * FT) + 4 * g;
+                        const float* rowp = w1p + (j * A + cw[j]) * FX_C1_ROW(FT) + 4 * g;
 #pragma unroll
                         for (int t = 0; t < FT; ++t) o1[t] += *reinterpret_cast<const f4*>(rowp + 16 * t);
                     }

@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(QUADS * 256) k_score_cnn_quad(QuadArgs p) {
                     init_bias<FT, 1>(cb, o1, g);
 #pragma unroll
                     for (int j = 0; j < K; ++j) {
-                        const float* rowp = w1p + (j * A + c[j]) * (16 * FT) + 4 * g;
+                        const float* rowp = w1p + (j * A + c[j]) * FX_C1_ROW(FT) + 4 * g;
 #pragma unroll
                         for (int t = 0; t < FT; ++t) o1[t][0] += *reinterpret_cast<const f4*>(rowp + 16 * t);
                     }

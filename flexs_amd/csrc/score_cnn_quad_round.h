@@ -31,7 +31,7 @@ __device__ __forceinline__ void fx_cnn_quad_round(bool live, int q, int lane, co
             init_bias<FT, 1>(cb, o1, g);
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-                const float* rowp = w1p + (j * A + c[j]) * (16 * FT) + 4 * g;
+                const float* rowp = w1p + (j * A + c[j]) * FX_C1_ROW(FT) + 4 * g;
 #pragma unroll
                 for (int t = 0; t < FT; ++t) o1[t][0] += *reinterpret_cast<const f4*>(rowp + 16 * t);
             }

@@ -93,7 +93,7 @@ def cnn_tile(packed, lay, codes16, A, K, F, H, conv1_gather=True):
             o1 = init_bias(packed, lay["off_cb"], FT)
             if conv1_gather:
                 for j in range(K):
-                    rowp = lay["off_w1p"] + (j * A + code[:, s + j]) * (16 * FT) + 4 * G
+                    rowp = lay["off_w1p"] + (j * A + code[:, s + j]) * (16 * FT + 4) + 4 * G     # (rows FX_C1_ROW(FT) floats apart)
                     for mo in range(FT):
                         o1[mo] = o1[mo] + np.stack([packed[rowp + 16 * mo + r] for r in range(4)], axis=1)
             else:
@@ -218,7 +218,7 @@ def cnn_pair_tile(packed, lay, codes16, A, K, F, H):
             if s < L1:
                 o1 = [bias_tile(cb, t) for t in range(FT)]
                 for j in range(K):
-                    rowp = lay["off_w1p"] + (j * A + code[:, s + j]) * (16 * FT) + 4 * G
+                    rowp = lay["off_w1p"] + (j * A + code[:, s + j]) * (16 * FT + 4) + 4 * G     # (rows FX_C1_ROW(FT) floats apart)
                     for t in range(FT):
                         o1[t] = o1[t] + np.stack([packed[rowp + 16 * t + r] for r in range(4)], axis=1)
                 win1[mo][K - 1] = [np.maximum(x, 0) for x in o1]

@@ -68,7 +68,7 @@ def test_mlp_ge_dataflow_matches_oracle(L, A, alpha, H):
 
 def test_packed_sizes():
     # CNN(32,100,K5) on a 4-letter alphabet: 25 780 floats = 100.7 KiB -> fits the 160 KiB LDS
-    assert _native.lib().fx_debug_packed_size(_native.FX_CNN, 8, 4, 32, 100, 5) == 26420            # (+640 floats of plain conv1 rows for the gather form)
+    assert _native.lib().fx_debug_packed_size(_native.FX_CNN, 8, 4, 32, 100, 5) == 26500            # (+20 rows of 36 floats: the plain conv1 rows of the gather form, FX_C1_ROW)
     lay = _native.debug_pack_layout(_native.FX_CNN, 237, 20, 32, 100, 5)
     assert lay["conv_floats"] * 4 < 160 * 1024            # conv part alone fits for the protein alphabet
     with pytest.raises(ValueError):
