@@ -351,13 +351,26 @@ int launch_pair(fx_engine* e, PairArgs a, size_t lds_bytes) {
     }
     const int64_t U = (int64_t)a.M * a.TG;
     const int L1 = a.L - K + 1;
+    if (e->cnn_pair_seg < 0 && !e->rows_req.on && U > e->num_cus && U <= 2 * (int64_t)e->num_cus && a.TG >= 2 && a.out) {
+        // Between one and two units per CU (round 6) the whole-sequence form below is ONE serial walk per wave pair with half the pairs idle
+        // (1.47 ms at 237 residues whatever the count); two launches of the segmented form, half the tiles each, are two walks of a third
+        // of the length (3 x 2000 GFP sequences: 1466 -> 960 us)
+        PairArgs lo = a, hi = a;
+        const int64_t t_half = (a.TG + 1) / 2;
+        lo.TG = t_half; lo.N = a.N < t_half * 16 ? a.N : t_half * 16;
+        hi.TG = a.TG - t_half; hi.N = a.N - t_half * 16; hi.ascii = a.ascii + t_half * 16 * a.L; hi.out = a.out + t_half * 16 * a.out_sn;
+        if (int rc = launch_pair<A, K, HT, WAVES>(e, lo, lds_bytes)) return rc;
+        return launch_pair<A, K, HT, WAVES>(e, hi, lds_bytes);
+    }
     // Small batch (a CMA-ES / DyNA-PPO population, a single sequence): fewer units than half the CUs.  Cut every
     // tile into segments over SB workgroups so that the call's latency is ~L1/S + halo steps.  The halo (PL3 + PL2 +
     // PR2 + PR3 = 22 positions at A = 20) is recomputed by every segment, but the machine is otherwise empty: as many
     // workgroups per tile as fit in ONE wave of the grid (U x SB <= CUs), down to segments of two positions
     // (tools/archive/runs/r2_pair_seg_sweep.py: a 1-16 sequence call at L = 237 250 -> 181 us, at L = 90 269 -> 169 us).
     int64_t sb = fx_pair_seg_count(L1, WAVES / 2, U, e->num_cus);
-    if (e->cnn_pair_seg == 0 || 2 * U > e->num_cus) sb = 0;
+    // (round 6: up to ONE unit per CU -- between half and all of the CUs a workgroup's four wave pairs still split its tile's positions, SB = 1:
+    //  3 x 1000 GFP sequences were 189 lone 1.4 ms walks by one pair per workgroup)
+    if (e->cnn_pair_seg == 0 || U > e->num_cus) sb = 0;
     if (e->cnn_pair_seg > 0) sb = e->cnn_pair_seg;                       // test knob: force SB
     if (sb >= 1) {
         if constexpr (A == 20 && K == 5 && HT == 7 && WAVES == 8) {
@@ -420,7 +433,7 @@ int launch_pair_conv(fx_engine* e, PairArgs a, size_t lds_bytes) {
     // small batch: position-segmented over SB workgroups per tile, as launch_pair does for the fused form
     const int L1 = a.L - K + 1;
     int64_t sb = fx_pair_seg_count(L1, WAVES / 2, U, e->num_cus);
-    if (e->cnn_pair_seg == 0 || 2 * U > e->num_cus) sb = 0;
+    if (e->cnn_pair_seg == 0 || U > e->num_cus) sb = 0;
     if (e->cnn_pair_seg > 0) sb = e->cnn_pair_seg;
     if (sb >= 1) {
         FX_HIP(e, hipMemsetAsync(a.pool, 0, (size_t)U * 2 * 64 * 4 * sizeof(unsigned), e->stream));   // maxima of relu outputs: >= +0

@@ -839,3 +839,34 @@ def test_mlp_first_layer_position_major_gives_the_same_bits(eng, L, alpha, H, M,
         assert np.array_equal(again, outs[1])
     finally:
         eng.set_option("mlp_l1_pos", 1)
+
+
+@pytest.mark.parametrize("L,M,n", [(40, 3, 1000), (40, 3, 2000), (33, 1, 3000), (40, 8, 500), (90, 3, 1990), (40, 3, 1370), (25, 2, 4001)])
+def test_protein_cnn_mid_size_calls_are_segmented(eng, L, M, n):
+    """Round 6: the protein CNN between half a unit and two units per CU.  A unit (member, 16-sequence tile) is a serial walk over the
+    positions by one wave pair -- 1.47 ms at 237 residues -- and up to one unit per CU the four pairs of a workgroup now split its tile's
+    positions (`cnn_pair_seg` < 0, SB = 1: 3 x 1000 GFP sequences 1.5 ms -> 0.47 ms); between one and two units per CU the call is two
+    such launches of half the tiles.  Every conv3 output sees the same MFMA sequence as in the whole-sequence walk: the SAME BITS as
+    `cnn_pair_seg` = 0, both held to the oracle; ragged last tiles, a bad character in either half."""
+    natives, ws = zip(*[make_native(eng, "cnn", L, 20, 100, 32, 5, seed=900 + m) for m in range(M)])
+    lut = _native.make_lut(s_utils.AAS)
+    b, _ = rand_seqs(n, L, s_utils.AAS, seed=L + M + n)
+    try:
+        outs = {}
+        for seg in (0, -1):
+            eng.set_option("cnn_pair_seg", seg)
+            outs[seg], mean = eng.score(list(natives), b, lut, want_matrix=True, want_mean=True)
+            assert np.array_equal(mean, np.mean(outs[seg], axis=1))
+        assert np.array_equal(outs[-1].view(np.uint32), outs[0].view(np.uint32))
+        k = min(n, 150)
+        for m in range(M):
+            assert_scores(outs[-1][:k, m], c_oracle.forward("cnn", lut[b[:k]], 20, ws[m]), f"protein cnn mid L={L} member {m}")
+            assert_scores(outs[-1][n - k:, m], c_oracle.forward("cnn", lut[b[n - k:]], 20, ws[m]), f"protein cnn mid L={L} member {m} tail")
+        for where in (3, n - 1, n // 2 + 17):
+            bad = b.copy(); bad[where, L // 2] = ord("B")
+            with pytest.raises(ValueError):
+                eng.score(list(natives), bad, lut)
+        again, _ = eng.score(list(natives), b, lut)
+        assert np.array_equal(again, outs[-1])
+    finally:
+        eng.set_option("cnn_pair_seg", -1)
