@@ -299,6 +299,8 @@ FXT_HD int fxt_wave(const FxtWg& wg) {
     return wg.tid >> 6;
 #endif
 }
+// first dense layer on a one-hot input, weight gradient: from this many input rows (L x A + 1) on, one thread per element instead of MFMA tiles of two k-steps (train_step.h)
+#define FXT_ONEHOT_WGRAD_DIRECT 256
 #define FXT_FOR(i, count, wg) for (int i = (wg).tid; i < (count); i += (wg).nthr)
 FXT_HD void fxt_sync() {
 #if FXT_DEVICE

@@ -278,6 +278,51 @@ FXT_HD void fxt_forward_backward(const FxtJob& j, const FxtWg& wg, int step, int
         if (li == 0 && n.onehot_in) {
             // (one thread per output element -- 8 FMAs each, no per-tile bookkeeping -- was measured SLOWER than the 49
             // two-k-step MFMA tiles here: 7.4 vs 6.1 us for the 100 x 100 layer, profiles/r3_train_trace.log)
+#if FXT_DEVICE
+            if (Kd + 1 > FXT_ONEHOT_WGRAD_DIRECT && R <= 16) {
+                // Round 6, long one-hot inputs (a protein MLP: 1 801 x 200 elements per slice): as an MFMA product this is 1 469 tiles of TWO
+                // k-steps each -- ~2.5 us of per-tile bookkeeping for 2 MFMAs, 230 of the step's 257 us (profiles/r6_train_protein_survey.log).
+                // Directly instead: a thread owns an output column and a run of positions, keeps the column's R gradient values in registers
+                // and, per position, adds to each letter's element the values of the rows that carry the letter, in row order -- the terms
+                // the product adds (its other terms are exact zeros; the host build's chain of fmaf over the rows gives the same bits).
+                // (Four columns per thread and 16-byte stores measured the same 205 us per step -- the phase is bound by its 1.44 MB of partial
+                //  stores per slice -- and that instantiation made CNN cases of the device step fail although no CNN path reads this code:
+                //  csrc/OPTIONS.md; one column per thread it is.)
+                auto direct = [&](auto rows) {
+                    constexpr int RR = decltype(rows)::value;              // 8 (the default slice) or 16 rows, unrolled
+                    const int chunks = wg.nthr / Nd > 0 ? wg.nthr / Nd : 1;
+                    const int lpc = (L + chunks - 1) / chunks;
+                    FXT_FOR(t, chunks * Nd, wg) {
+                        const int ch = t / Nd, o = t - ch * Nd;
+                        const int l_hi = (ch + 1) * lpc < L ? (ch + 1) * lpc : L;
+                        float d[RR];
+#pragma unroll
+                        for (int r = 0; r < RR; ++r) d[r] = r < R ? du[r * Nd + o] : 0.f;
+                        for (int l = ch * lpc; l < l_hi; ++l) {
+                            int cr[RR];
+#pragma unroll
+                            for (int r = 0; r < RR; ++r) cr[r] = r < R ? codes[r * L + l] : -1;
+                            for (int c = 0; c < A; ++c) {
+                                float v = 0.f;
+#pragma unroll
+                                for (int r = 0; r < RR; ++r)
+                                    if (cr[r] == c) v += d[r];
+                                putw.put(l * A + c, o, v);
+                            }
+                        }
+                        if (ch == 0) {
+                            float v = 0.f;
+#pragma unroll
+                            for (int r = 0; r < RR; ++r)
+                                if (r < R) v += d[r];
+                            putw.put(Kd, o, v);
+                        }
+                    }
+                };
+                if (R <= 8) direct(std::integral_constant<int, 8>{});
+                else direct(std::integral_constant<int, 16>{});
+            } else
+#endif
             fxt_gemm(wg, Kd + 1, Nd, 1, R, FxtOneHotWGradA<WsCI>{codes, L, A, Kd, 0, dA}, FxtRowMajorB<WsCF>{du, Nd}, putw);
         } else {
             WsCF in = li == 0 ? feat : ws + w.act[li - 1];
